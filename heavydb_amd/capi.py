@@ -1,0 +1,247 @@
+"""ctypes binding of include/mi355q.h (the C-ABI drop-in boundary).
+
+Every structure here mirrors the header field-for-field; tests assert the sizes agree
+with the library's own `mi355q_abi_sizeof_*` probes.  The library is built in-tree by
+`heavydb_amd/_build.py` (hipcc, gfx950) and loading it FAILS LOUDLY if it is missing —
+there is no CPU fallback for the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+MAX_COLS = 16
+MAX_QUALS = 4
+MAX_TARGETS = 8
+MAX_SLOTS = 16
+MAX_GROUP_COLS = 4
+ABI_VERSION = 1
+
+# mi355q_type
+INT8, INT16, INT32, INT64, DOUBLE = 1, 2, 3, 4, 5
+# mi355q_op (SQLOps values)
+EQ, NE, LT, GT, LE, GE = 0, 2, 3, 4, 5, 6
+# mi355q_agg (SQLAgg values)
+AVG, MIN, MAX, SUM, COUNT, PROJECT_KEY = 0, 1, 2, 3, 4, 100
+# mi355q_desc_type
+GROUP_BY_PERFECT_HASH, GROUP_BY_BASELINE_HASH, NON_GROUPED_AGGREGATE = 0, 1, 4
+# generator kinds
+GEN_I32_UNIFORM31, GEN_I32_MOD, GEN_I64_MOD, GEN_I64_MOD_MUL, GEN_F64_UNIT = 1, 2, 3, 4, 5
+
+OK = 0
+ERR_OUT_OF_SLOTS = 3
+ERR_INVALID_PLAN = 100
+ERR_UNSUPPORTED = 101
+ERR_HIP = 102
+ERR_JOIN_NOT_ONE_TO_ONE = 103
+ERR_JOIN_TABLE_FULL = 104
+
+TYPE_WIDTH = {INT8: 1, INT16: 2, INT32: 4, INT64: 8, DOUBLE: 8}
+
+
+class ColDesc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("nullable", C.c_int32)]
+
+
+class Qual(C.Structure):
+    _fields_ = [("col", C.c_int32), ("op", C.c_int32), ("ival", C.c_int64), ("fval", C.c_double)]
+
+
+class Target(C.Structure):
+    _fields_ = [("agg", C.c_int32), ("col", C.c_int32), ("table", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class Range(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("has_nulls", C.c_int32), ("min", C.c_int64),
+                ("max", C.c_int64), ("fp_min", C.c_double), ("fp_max", C.c_double)]
+
+
+class Plan(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("n_cols", C.c_int32),
+        ("cols", ColDesc * MAX_COLS),
+        ("col_ranges", Range * MAX_COLS),
+        ("n_inner_cols", C.c_int32),
+        ("inner_cols", ColDesc * MAX_COLS),
+        ("inner_col_ranges", Range * MAX_COLS),
+        ("n_quals", C.c_int32),
+        ("quals", Qual * MAX_QUALS),
+        ("n_group_cols", C.c_int32),
+        ("group_cols", C.c_int32 * MAX_GROUP_COLS),
+        ("n_targets", C.c_int32),
+        ("targets", Target * MAX_TARGETS),
+        ("join_outer_col", C.c_int32),
+        ("join_table", C.c_void_p),
+        ("max_groups_buffer_entry_guess", C.c_int64),
+        ("bigint_count", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class QMD(C.Structure):
+    _fields_ = [
+        ("desc_type", C.c_int32),
+        ("keyless", C.c_int32),
+        ("idx_target_as_key", C.c_int32),
+        ("key_width", C.c_int32),
+        ("group_col_count", C.c_int32),
+        ("slot_count", C.c_int32),
+        ("entry_count", C.c_int64),
+        ("min_val", C.c_int64),
+        ("max_val", C.c_int64),
+        ("bucket", C.c_int64),
+        ("has_nulls", C.c_int32),
+        ("row_size", C.c_int32),
+        ("key_bytes", C.c_int32),
+        ("n_targets", C.c_int32),
+        ("target_slot", C.c_int32 * MAX_TARGETS),
+        ("target_skip_null", C.c_int32 * MAX_TARGETS),
+        ("target_is_fp", C.c_int32 * MAX_TARGETS),
+        ("target_agg", C.c_int32 * MAX_TARGETS),
+        ("target_arg_is_fp", C.c_int32 * MAX_TARGETS),
+        ("target_null", C.c_int64 * MAX_TARGETS),
+        ("init_vals", C.c_int64 * MAX_SLOTS),
+    ]
+
+    def as_dict(self):
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+
+class Inputs(C.Structure):
+    _fields_ = [
+        ("device_id", C.c_int32),
+        ("n_frags", C.c_int32),
+        ("col_buffers", C.POINTER(C.c_void_p)),
+        ("num_rows", C.POINTER(C.c_int64)),
+        ("inner_col_buffers", C.POINTER(C.c_void_p)),
+        ("inner_num_rows", C.c_int64),
+    ]
+
+
+class ExecOptions(C.Structure):
+    _fields_ = [
+        ("stream", C.c_void_p),
+        ("out_buffer", C.c_void_p),
+        ("force_generic", C.c_int32),
+        ("kernel_variant", C.c_int32),
+        ("scratch_bytes", C.c_int64),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class ExecReport(C.Structure):
+    _fields_ = [
+        ("kernel_name", C.c_char * 64),
+        ("kernel_ms", C.c_float),
+        ("total_ms", C.c_float),
+        ("n_launches", C.c_int32),
+        ("variant", C.c_int32),
+        ("rows_scanned", C.c_int64),
+        ("algorithmic_bytes", C.c_int64),
+        ("spilled_rows", C.c_int64),
+    ]
+
+
+class JoinSpec(C.Structure):
+    _fields_ = [
+        ("device_id", C.c_int32),
+        ("key_type", C.c_int32),
+        ("key_nullable", C.c_int32),
+        ("prefer_baseline", C.c_int32),
+        ("key_buffer", C.c_void_p),
+        ("num_rows", C.c_int64),
+        ("key_range", Range),
+        ("max_perfect_entries", C.c_int64),
+    ]
+
+
+# every symbol include/mi355q.h declares: (name, restype, argtypes)
+_P = C.POINTER
+SYMBOLS = [
+    ("mi355q_abi_version", C.c_int32, []),
+    ("mi355q_error_string", C.c_char_p, [C.c_int32]),
+    ("mi355q_device_count", C.c_int32, []),
+    ("mi355q_device_info", C.c_int32,
+     [C.c_int32, C.c_char_p, _P(C.c_int32), _P(C.c_int64), _P(C.c_int64), _P(C.c_int32),
+      _P(C.c_int32)]),
+    ("mi355q_qmd_init", C.c_int32, [_P(Plan), _P(QMD)]),
+    ("mi355q_qmd_buffer_bytes", C.c_int64, [_P(QMD)]),
+    ("mi355q_execute", C.c_int32,
+     [_P(Plan), _P(Inputs), _P(ExecOptions), _P(C.c_void_p), _P(ExecReport)]),
+    ("mi355q_result_create", C.c_int32, [_P(QMD), C.c_int32, C.c_void_p, _P(C.c_void_p)]),
+    ("mi355q_result_free", None, [C.c_void_p]),
+    ("mi355q_result_qmd", C.c_int32, [C.c_void_p, _P(QMD)]),
+    ("mi355q_result_device_ptr", C.c_void_p, [C.c_void_p]),
+    ("mi355q_result_bytes", C.c_int64, [C.c_void_p]),
+    ("mi355q_result_copy_to_host", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
+    ("mi355q_result_reduce", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mi355q_result_row_count", C.c_int64, [C.c_void_p]),
+    ("mi355q_result_fetch_rows", C.c_int32,
+     [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
+    ("mi355q_join_build", C.c_int32, [_P(JoinSpec), C.c_void_p, _P(C.c_void_p)]),
+    ("mi355q_join_free", None, [C.c_void_p]),
+    ("mi355q_join_info", C.c_int32,
+     [C.c_void_p, _P(C.c_int32), _P(C.c_int64), _P(C.c_int64), _P(C.c_int64), _P(C.c_void_p),
+      _P(C.c_int64), _P(C.c_float)]),
+    ("mi355q_shard_partition", C.c_int32,
+     [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("mi355q_shard_merge_rows", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    ("mi355q_generate_column", C.c_int32,
+     [C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_uint64, C.c_int64, C.c_int64,
+      C.c_int64, C.c_double, C.c_int32, C.c_void_p]),
+]
+
+LIB_NAME = "libmi355q.so"
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", LIB_NAME)
+
+
+_lib = None
+
+
+def load_library(path: str | None = None) -> C.CDLL:
+    """dlopen libmi355q.so and bind every declared symbol.  Raises if absent: the product
+    path has no fallback (the CPU oracle is test infrastructure only)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or lib_path()
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()'). "
+            "heavydb_amd has no CPU fallback.")
+    lib = C.CDLL(p)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mi355q_abi_version() != ABI_VERSION:
+        raise RuntimeError("mi355q ABI version mismatch")
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class Mi355qError(RuntimeError):
+    def __init__(self, code: int, where: str = ""):
+        self.code = code
+        msg = None
+        try:
+            msg = load_library().mi355q_error_string(code).decode()
+        except Exception:  # pragma: no cover
+            pass
+        super().__init__(f"mi355q error {code} ({msg}) {where}")
+
+
+def check(code: int, where: str = "") -> None:
+    if code != 0:
+        raise Mi355qError(code, where)

@@ -1,0 +1,341 @@
+"""Host-side mirror of the reference's operator interface for ONE query step.
+
+Names follow the reference so the parity tests read like Tests/GroupByTest.cpp:73-151:
+build a `RelAlgExecutionUnit` by hand, call `Executor.executeWorkUnit`, iterate the
+`ResultSet` with `getNextRow` / `rowCount`.
+
+  RelAlgExecutionUnit   QueryEngine/RelAlgExecutionUnit.h:167-218 (the used subset)
+  FetchResult           QueryEngine/ColumnFetcher.h:46-49 (raw column pointers per fragment)
+  Executor              QueryEngine/Execute.h:417; executeWorkUnit Execute.h:719
+  ResultSet             QueryEngine/ResultSet.h:263 (getNextRow), :327 (rowCount)
+  HashJoin              QueryEngine/JoinHashTable/HashJoin.h (getInstance -> perfect/baseline)
+
+Everything here is plumbing over the C-ABI in include/mi355q.h; the compute is the HIP
+library.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import capi
+from .capi import (AVG, COUNT, DOUBLE, INT8, INT16, INT32, INT64, MAX, MIN, PROJECT_KEY, SUM,
+                   check)
+
+
+@dataclass
+class ExpressionRange:
+    """ExpressionRange (QueryEngine/ExpressionRange.h): what fragment metadata tells the
+    planner about a column."""
+    valid: bool = False
+    min: int = 0
+    max: int = 0
+    has_nulls: bool = False
+    fp_min: float = 0.0
+    fp_max: float = 0.0
+
+    def to_c(self) -> capi.Range:
+        return capi.Range(int(self.valid), int(self.has_nulls), int(self.min), int(self.max),
+                          float(self.fp_min), float(self.fp_max))
+
+
+@dataclass
+class InputColDescriptor:
+    """InputColDescriptor + SQLTypeInfo of a fixed-width column."""
+    type: int
+    nullable: bool = False
+    range: ExpressionRange = field(default_factory=ExpressionRange)
+
+
+@dataclass
+class Qual:
+    """simple_quals entry: `col <op> literal`."""
+    col: int
+    op: int
+    literal: float | int
+
+
+@dataclass
+class TargetExpr:
+    """target_exprs entry: aggregate kind + argument column (-1 = COUNT(*)); table 1 reads
+    an inner-table column through the join's row id."""
+    agg: int
+    col: int = -1
+    table: int = 0
+
+
+@dataclass
+class RelAlgExecutionUnit:
+    input_col_descs: List[InputColDescriptor]
+    target_exprs: List[TargetExpr]
+    simple_quals: List[Qual] = field(default_factory=list)
+    groupby_exprs: List[int] = field(default_factory=list)
+    inner_col_descs: List[InputColDescriptor] = field(default_factory=list)
+    join_outer_col: int = -1
+    join_table: Optional["HashJoin"] = None
+    # ExecutionOptions / globals shaping the layout
+    max_groups_buffer_entry_guess: int = 16384  # Execute.cpp:111
+    bigint_count: bool = False
+
+    def to_plan(self) -> capi.Plan:
+        p = capi.Plan()
+        p.abi_version = capi.ABI_VERSION
+        if len(self.input_col_descs) > capi.MAX_COLS or len(self.inner_col_descs) > capi.MAX_COLS:
+            raise ValueError("too many columns")
+        p.n_cols = len(self.input_col_descs)
+        for i, c in enumerate(self.input_col_descs):
+            p.cols[i] = capi.ColDesc(c.type, int(c.nullable))
+            p.col_ranges[i] = c.range.to_c()
+        p.n_inner_cols = len(self.inner_col_descs)
+        for i, c in enumerate(self.inner_col_descs):
+            p.inner_cols[i] = capi.ColDesc(c.type, int(c.nullable))
+            p.inner_col_ranges[i] = c.range.to_c()
+        if len(self.simple_quals) > capi.MAX_QUALS:
+            raise ValueError("too many quals")
+        p.n_quals = len(self.simple_quals)
+        for i, q in enumerate(self.simple_quals):
+            is_fp = self.input_col_descs[q.col].type == DOUBLE
+            p.quals[i] = capi.Qual(q.col, q.op, 0 if is_fp else int(q.literal),
+                                   float(q.literal) if is_fp else 0.0)
+        p.n_group_cols = len(self.groupby_exprs)
+        for i, g in enumerate(self.groupby_exprs[:capi.MAX_GROUP_COLS]):
+            p.group_cols[i] = g
+        if len(self.target_exprs) > capi.MAX_TARGETS:
+            raise ValueError("too many targets")
+        p.n_targets = len(self.target_exprs)
+        for i, t in enumerate(self.target_exprs):
+            p.targets[i] = capi.Target(t.agg, t.col, t.table, 0)
+        p.join_outer_col = self.join_outer_col
+        p.join_table = self.join_table.handle if self.join_table is not None else None
+        p.max_groups_buffer_entry_guess = self.max_groups_buffer_entry_guess
+        p.bigint_count = int(self.bigint_count)
+        return p
+
+
+@dataclass
+class FetchResult:
+    """Raw device column pointers per (fragment, column) + rows per fragment."""
+    col_buffers: List[List[int]]      # [frag][col] -> device address
+    num_rows: List[int]               # [frag]
+    inner_col_buffers: List[int] = field(default_factory=list)
+    inner_num_rows: int = 0
+    device_id: int = 0
+    keepalive: list = field(default_factory=list)  # owners of the memory (e.g. tensors)
+
+    @staticmethod
+    def from_tensors(frag_cols: Sequence[Sequence["object"]], inner_cols: Sequence["object"] = (),
+                     device_id: int = 0) -> "FetchResult":
+        """Convenience: torch tensors (already on the device) -> FetchResult."""
+        bufs, rows, keep = [], [], []
+        for cols in frag_cols:
+            bufs.append([int(t.data_ptr()) for t in cols])
+            rows.append(int(cols[0].numel()))
+            keep.extend(cols)
+        inner = [int(t.data_ptr()) for t in inner_cols]
+        keep.extend(inner_cols)
+        return FetchResult(bufs, rows, inner, int(inner_cols[0].numel()) if inner_cols else 0,
+                           device_id, keep)
+
+    def to_c(self, n_cols: int) -> Tuple[capi.Inputs, list]:
+        n_frags = len(self.col_buffers)
+        flat = (C.c_void_p * max(1, n_frags * n_cols))()
+        for f, cols in enumerate(self.col_buffers):
+            if len(cols) != n_cols:
+                raise ValueError("fragment column count mismatch")
+            for c, ptr in enumerate(cols):
+                flat[f * n_cols + c] = ptr
+        rows = (C.c_int64 * max(1, n_frags))(*self.num_rows)
+        inner = (C.c_void_p * max(1, len(self.inner_col_buffers)))(*self.inner_col_buffers)
+        inp = capi.Inputs()
+        inp.device_id = self.device_id
+        inp.n_frags = n_frags
+        inp.col_buffers = C.cast(flat, C.POINTER(C.c_void_p))
+        inp.num_rows = C.cast(rows, C.POINTER(C.c_int64))
+        inp.inner_col_buffers = C.cast(inner, C.POINTER(C.c_void_p))
+        inp.inner_num_rows = self.inner_num_rows
+        return inp, [flat, rows, inner]
+
+
+class HashJoin:
+    """Join hash table handle (HashJoin::getInstance, HashJoin.cpp:286): perfect one-to-one
+    when the key range allows, keyed (baseline) otherwise."""
+
+    def __init__(self, handle: int):
+        self.handle = handle
+        self._lib = capi.load_library()
+
+    @staticmethod
+    def getInstance(key_buffer: int, num_rows: int, key_type: int, key_range: ExpressionRange,
+                    key_nullable: bool = False, device_id: int = 0, prefer_baseline: bool = False,
+                    max_perfect_entries: int = 0, stream: int | None = None) -> "HashJoin":
+        lib = capi.load_library()
+        spec = capi.JoinSpec(device_id, key_type, int(key_nullable), int(prefer_baseline),
+                             key_buffer, num_rows, key_range.to_c(), max_perfect_entries)
+        out = C.c_void_p()
+        check(lib.mi355q_join_build(C.byref(spec), stream, C.byref(out)), "join_build")
+        return HashJoin(out.value)
+
+    def info(self) -> dict:
+        ht, ec, mn, mx = C.c_int32(), C.c_int64(), C.c_int64(), C.c_int64()
+        ptr, nbytes, ms = C.c_void_p(), C.c_int64(), C.c_float()
+        check(self._lib.mi355q_join_info(self.handle, C.byref(ht), C.byref(ec), C.byref(mn),
+                                         C.byref(mx), C.byref(ptr), C.byref(nbytes),
+                                         C.byref(ms)))
+        return dict(hash_type=ht.value, entry_count=ec.value, min_key=mn.value, max_key=mx.value,
+                    device_ptr=ptr.value, bytes=nbytes.value, build_ms=ms.value)
+
+    def free(self):
+        if self.handle:
+            self._lib.mi355q_join_free(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class ResultSet:
+    """Owner of one ResultSetStorage buffer in HeavyDB row-wise layout, on the device."""
+
+    def __init__(self, handle: int, report: Optional[capi.ExecReport] = None):
+        self.handle = handle
+        self.report = report
+        self._lib = capi.load_library()
+        self._rows = None
+        self._cursor = 0
+
+    # -- descriptor / storage
+    def getQueryMemDesc(self) -> capi.QMD:
+        q = capi.QMD()
+        check(self._lib.mi355q_result_qmd(self.handle, C.byref(q)))
+        return q
+
+    def entryCount(self) -> int:
+        return self.getQueryMemDesc().entry_count
+
+    def device_ptr(self) -> int:
+        return self._lib.mi355q_result_device_ptr(self.handle)
+
+    def nbytes(self) -> int:
+        return self._lib.mi355q_result_bytes(self.handle)
+
+    def getStorage(self) -> np.ndarray:
+        """The raw buffer (ResultSetStorage::buff_) copied to the host, as int64 quads
+        shaped [entry_count, row_size/8]."""
+        q = self.getQueryMemDesc()
+        buf = np.empty(self.nbytes() // 8, dtype=np.int64)
+        check(self._lib.mi355q_result_copy_to_host(self.handle, buf.ctypes.data, buf.nbytes))
+        return buf.reshape(q.entry_count, q.row_size // 8)
+
+    # -- iteration
+    def rowCount(self) -> int:
+        return self._lib.mi355q_result_row_count(self.handle)
+
+    def fetch(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """All rows in entry order: (ival[n,t], dval[n,t], is_null[n,t])."""
+        q = self.getQueryMemDesc()
+        n = self.rowCount()
+        nt = q.n_targets
+        ival = np.zeros((max(n, 1), nt), dtype=np.int64)
+        dval = np.zeros((max(n, 1), nt), dtype=np.float64)
+        nul = np.zeros((max(n, 1), nt), dtype=np.int8)
+        got = C.c_int64()
+        check(self._lib.mi355q_result_fetch_rows(self.handle, n, ival.ctypes.data,
+                                                 dval.ctypes.data, nul.ctypes.data,
+                                                 C.byref(got)))
+        k = got.value
+        return ival[:k], dval[:k], nul[:k]
+
+    def getNextRow(self) -> list:
+        """One row of target values (None = SQL NULL); [] when exhausted."""
+        if self._rows is None:
+            q = self.getQueryMemDesc()
+            ival, dval, nul = self.fetch()
+            fp = [bool(q.target_is_fp[t]) for t in range(q.n_targets)]
+            self._rows = [
+                [None if nul[r, t] else (float(dval[r, t]) if fp[t] else int(ival[r, t]))
+                 for t in range(q.n_targets)] for r in range(ival.shape[0])]
+        if self._cursor >= len(self._rows):
+            return []
+        row = self._rows[self._cursor]
+        self._cursor += 1
+        return row
+
+    def reduce(self, that: "ResultSet", stream: int | None = None) -> None:
+        check(self._lib.mi355q_result_reduce(self.handle, that.handle, stream), "reduce")
+        self._rows = None
+
+    def free(self):
+        if self.handle:
+            self._lib.mi355q_result_free(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Executor:
+    """One per device.  executeWorkUnit = compile-free plan -> kernel family selection ->
+    launch -> ResultSet on the device."""
+
+    def __init__(self, device_id: int = 0):
+        self.device_id = device_id
+        self._lib = capi.load_library()
+
+    def initQueryMemoryDescriptor(self, ra_exe_unit: RelAlgExecutionUnit) -> capi.QMD:
+        q = capi.QMD()
+        plan = ra_exe_unit.to_plan()
+        check(self._lib.mi355q_qmd_init(C.byref(plan), C.byref(q)), "qmd_init")
+        return q
+
+    def executeWorkUnit(self, ra_exe_unit: RelAlgExecutionUnit, fetch_result: FetchResult,
+                        stream: int | None = None, out_buffer: int | None = None,
+                        force_generic: bool = False, kernel_variant: int = 0,
+                        scratch_bytes: int = 0, allow_retry: bool = True) -> ResultSet:
+        """Runs the step.  A negative code (ran out of group slots) doubles the baseline
+        table and retries, as RelAlgExecutor::executeWorkUnit does after its cardinality
+        estimation (RelAlgExecutor.cpp:4143-4145, :4194-4231)."""
+        guess = ra_exe_unit.max_groups_buffer_entry_guess
+        try:
+            for _ in range(24):
+                plan = ra_exe_unit.to_plan()
+                inp, keep = fetch_result.to_c(plan.n_cols)
+                opts = capi.ExecOptions()
+                opts.stream = stream
+                opts.out_buffer = out_buffer
+                opts.force_generic = int(force_generic)
+                opts.kernel_variant = kernel_variant
+                opts.scratch_bytes = scratch_bytes
+                out = C.c_void_p()
+                rep = capi.ExecReport()
+                code = self._lib.mi355q_execute(C.byref(plan), C.byref(inp), C.byref(opts),
+                                                C.byref(out), C.byref(rep))
+                del keep
+                if code == 0:
+                    return ResultSet(out.value, rep)
+                if (code < 0 or code == capi.ERR_OUT_OF_SLOTS) and allow_retry \
+                        and out_buffer is None and ra_exe_unit.groupby_exprs:
+                    ra_exe_unit.max_groups_buffer_entry_guess *= 2
+                    continue
+                raise capi.Mi355qError(code, "execute")
+            raise capi.Mi355qError(capi.ERR_OUT_OF_SLOTS, "execute (retries exhausted)")
+        finally:
+            if not allow_retry:
+                ra_exe_unit.max_groups_buffer_entry_guess = guess
+
+
+def generate_column(dst_ptr: int, n_rows: int, kind: int, seed: int, a: int = 0, b: int = 0,
+                    c: int = 0, a_f: float = 0.0, null_every: int = 0, row_offset: int = 0,
+                    device_id: int = 0, stream: int | None = None) -> None:
+    """Device-side synthetic column (same splitmix64 stream as the oracle's generator)."""
+    lib = capi.load_library()
+    check(lib.mi355q_generate_column(device_id, dst_ptr, n_rows, row_offset, kind, seed, a, b, c,
+                                     a_f, null_every, stream), "generate_column")

@@ -1,0 +1,339 @@
+/*
+ * mi355q.h — C-ABI of the MI355X-native query-step executor.
+ *
+ * This is the drop-in boundary for ONE HeavyDB query step (scan/filter ->
+ * hash group-by + aggregate -> hash-join probe).  Every entry point takes
+ * plain pointers and sizes (no C++ / torch types) and returns a HeavyDB
+ * error code (QueryEngine/enums.h:30-51): 0 = ok, >0 = persistent error,
+ * <0 = ran out of group slots (caller resizes the table and retries, as
+ * RelAlgExecutor.cpp:4143-4145, :4194-4231 does).
+ *
+ * Reference interfaces each entry point replaces (paths relative to the
+ * heavyai/heavydb tree):
+ *
+ *   mi355q_qmd_init        GroupByAndAggregate::initQueryMemoryDescriptor
+ *                          (QueryEngine/GroupByAndAggregate.cpp:859) =
+ *                          getColRangeInfo (:232-365) + get_keyless_info (:489-648)
+ *                          + QueryMemoryDescriptor::init
+ *                          (Descriptors/QueryMemoryDescriptor.cpp:240-446)
+ *   mi355q_execute         Executor::executeWorkUnit (QueryEngine/Execute.h:719,
+ *                          Execute.cpp:2144) at the point ExecutionKernel::runImpl
+ *                          has fetched chunks (ExecutionKernel.cpp:270-292, the seam
+ *                          run_query_external uses, ExternalExecutor.h:66-69):
+ *                          raw column pointers in, ResultSetStorage buffer out.
+ *   mi355q_result_reduce   ResultSetStorage::reduce (ResultSetReduction.cpp:203)
+ *   mi355q_result_*        ResultSet accessors (ResultSet.h:263 getNextRow,
+ *                          :327 rowCount; ResultSetIteration.cpp:2457 isEmptyEntry;
+ *                          ResultSetBufferAccessors.h:197 pair_to_double)
+ *   mi355q_join_build      HashJoin::getInstance (JoinHashTable/HashJoin.cpp:286):
+ *                          PerfectJoinHashTable (PerfectJoinHashTable.cpp:168) then
+ *                          BaselineJoinHashTable (BaselineJoinHashTable.cpp:484)
+ *   mi355q_shard_*         the multi-device merge of
+ *                          Executor::reduceMultiDeviceResultSets (Execute.cpp:1772)
+ *                          done on-device, for one-process-per-GPU operation.
+ */
+#ifndef MI355Q_H
+#define MI355Q_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355Q_ABI_VERSION 1
+
+#define MI355Q_MAX_COLS 16
+#define MI355Q_MAX_QUALS 4
+#define MI355Q_MAX_TARGETS 8
+#define MI355Q_MAX_SLOTS 16
+#define MI355Q_MAX_GROUP_COLS 4
+
+/* ---- error codes: numeric values of heavyai::ErrorCode (enums.h:30-51) ---- */
+#define MI355Q_OK 0
+#define MI355Q_ERR_DIV_BY_ZERO 1
+#define MI355Q_ERR_OUT_OF_GPU_MEM 2
+#define MI355Q_ERR_OUT_OF_SLOTS 3
+#define MI355Q_ERR_OUT_OF_CPU_MEM 6
+#define MI355Q_ERR_OVERFLOW_OR_UNDERFLOW 7
+#define MI355Q_ERR_OUT_OF_TIME 8
+#define MI355Q_ERR_INTERRUPTED 9
+/* library-level codes (outside the reference's range) */
+#define MI355Q_ERR_INVALID_PLAN 100
+#define MI355Q_ERR_UNSUPPORTED 101
+#define MI355Q_ERR_HIP 102
+#define MI355Q_ERR_JOIN_NOT_ONE_TO_ONE 103 /* reference: fill returns -1 -> 1:N rebuild */
+#define MI355Q_ERR_JOIN_TABLE_FULL 104     /* reference: write_baseline_hash_slot -2 */
+
+/* ---- column types (fixed-width, as ColumnFetcher hands them over) ---- */
+typedef enum mi355q_type {
+  MI355Q_INT8 = 1,
+  MI355Q_INT16 = 2,
+  MI355Q_INT32 = 3,
+  MI355Q_INT64 = 4,
+  MI355Q_DOUBLE = 5
+} mi355q_type;
+
+/* comparison operators: numeric values of SQLOps (Shared/sqldefs.h:31-38) */
+typedef enum mi355q_op {
+  MI355Q_EQ = 0,
+  MI355Q_NE = 2,
+  MI355Q_LT = 3,
+  MI355Q_GT = 4,
+  MI355Q_LE = 5,
+  MI355Q_GE = 6
+} mi355q_op;
+
+/* aggregates: numeric values of SQLAgg (Shared/sqldefs.h:76-90); PROJECT is a
+ * non-aggregate target that projects the group key (TargetInfo.is_agg == false,
+ * written with agg_id, TargetExprBuilder.cpp:58-72). */
+typedef enum mi355q_agg {
+  MI355Q_AVG = 0,
+  MI355Q_MIN = 1,
+  MI355Q_MAX = 2,
+  MI355Q_SUM = 3,
+  MI355Q_COUNT = 4,
+  MI355Q_PROJECT_KEY = 100
+} mi355q_agg;
+
+/* QueryDescriptionType (enums.h:53-59) */
+typedef enum mi355q_desc_type {
+  MI355Q_GROUP_BY_PERFECT_HASH = 0,
+  MI355Q_GROUP_BY_BASELINE_HASH = 1,
+  MI355Q_NON_GROUPED_AGGREGATE = 4
+} mi355q_desc_type;
+
+typedef struct mi355q_col_desc {
+  int32_t type;     /* mi355q_type */
+  int32_t nullable; /* 0 = NOT NULL; else NULL is the inline sentinel
+                       (Shared/InlineNullValues.h:29-35) */
+} mi355q_col_desc;
+
+/* simple_quals entry: `col <op> literal` (RelAlgExecutionUnit.h:170) */
+typedef struct mi355q_qual {
+  int32_t col; /* outer-table column index */
+  int32_t op;  /* mi355q_op */
+  int64_t ival; /* literal for integer columns */
+  double fval;  /* literal for double columns */
+} mi355q_qual;
+
+/* target_exprs entry (RelAlgExecutionUnit.h:173; Shared/TargetInfo.h:48-56) */
+typedef struct mi355q_target {
+  int32_t agg;   /* mi355q_agg */
+  int32_t col;   /* argument column, -1 for COUNT(*) */
+  int32_t table; /* 0 = outer (fact) column; 1 = inner (dim) column reached through
+                    the join's row id */
+  int32_t reserved;
+} mi355q_target;
+
+/* ExpressionRange of a column (what getExpressionRange returns from chunk
+ * metadata; ColRangeInfo GroupByAndAggregate.h / ExpressionRange.h). */
+typedef struct mi355q_range {
+  int32_t valid;     /* 0 = ExpressionRangeType::Invalid */
+  int32_t has_nulls;
+  int64_t min;
+  int64_t max;
+  double fp_min; /* used for double columns (keyless decisions only) */
+  double fp_max;
+} mi355q_range;
+
+typedef struct mi355q_join_table mi355q_join_table; /* opaque */
+
+/* The subset of RelAlgExecutionUnit (RelAlgExecutionUnit.h:167-218) + the
+ * expression ranges the planner derives from fragment metadata. */
+typedef struct mi355q_plan {
+  int32_t abi_version; /* MI355Q_ABI_VERSION */
+  int32_t n_cols;      /* outer-table input columns (input_col_descs) */
+  mi355q_col_desc cols[MI355Q_MAX_COLS];
+  mi355q_range col_ranges[MI355Q_MAX_COLS];
+  int32_t n_inner_cols; /* inner (dim) table columns reachable via the join */
+  mi355q_col_desc inner_cols[MI355Q_MAX_COLS];
+  mi355q_range inner_col_ranges[MI355Q_MAX_COLS];
+
+  int32_t n_quals; /* conjunction */
+  mi355q_qual quals[MI355Q_MAX_QUALS];
+
+  int32_t n_group_cols; /* 0 = non-grouped aggregate; 1 = single-column group by */
+  int32_t group_cols[MI355Q_MAX_GROUP_COLS];
+
+  int32_t n_targets;
+  mi355q_target targets[MI355Q_MAX_TARGETS];
+
+  /* join_quals: one equi-join level  outer.col = inner.key  (INNER join) */
+  int32_t join_outer_col;              /* -1 = no join */
+  const mi355q_join_table* join_table; /* built by mi355q_join_build */
+
+  /* ExecutionOptions / globals that shape the layout */
+  int64_t max_groups_buffer_entry_guess; /* baseline entry_count (Execute.cpp:111
+                                            g_default_max_groups_buffer_entry_guess
+                                            = 16384, or 2 x NDV estimate,
+                                            RelAlgExecutor.cpp:4213-4218) */
+  int32_t bigint_count;                  /* g_bigint_count (affects COUNT result type
+                                            only; slots are 8 bytes either way) */
+  int32_t reserved;
+} mi355q_plan;
+
+/* QueryMemoryDescriptor mirror (Descriptors/QueryMemoryDescriptor.h).  Row-wise
+ * layout, 8-byte padded slots (crt_min_byte_width = 8, Execute.cpp:2237). */
+typedef struct mi355q_qmd {
+  int32_t desc_type; /* mi355q_desc_type */
+  int32_t keyless;   /* keyless_hash_ */
+  int32_t idx_target_as_key; /* slot index whose value != init marks a live entry */
+  int32_t key_width; /* getEffectiveKeyWidth(): 8, or 4 for int32-range baseline keys */
+  int32_t group_col_count;
+  int32_t slot_count;
+  int64_t entry_count;
+  int64_t min_val; /* perfect hash: col_range_info.min */
+  int64_t max_val; /* perfect hash: col_range_info.max (NULL key maps to max+1) */
+  int64_t bucket;
+  int32_t has_nulls;
+  int32_t row_size;      /* bytes, getRowSize() (QueryMemoryDescriptor.cpp:848) */
+  int32_t key_bytes;     /* align_to_int64(group_col_count * key_width), 0 if keyless */
+  int32_t n_targets;
+  int32_t target_slot[MI355Q_MAX_TARGETS];      /* first slot of each target; -1 if the
+                                                   target is read from the key columns
+                                                   (target_groupby_indices) */
+  int32_t target_skip_null[MI355Q_MAX_TARGETS]; /* TargetInfo.skip_null_val */
+  int32_t target_is_fp[MI355Q_MAX_TARGETS];     /* result is double */
+  int32_t target_agg[MI355Q_MAX_TARGETS];       /* mi355q_agg */
+  int32_t target_arg_is_fp[MI355Q_MAX_TARGETS]; /* slot holds double bits (SUM/MIN/MAX/AVG
+                                                   of a double column) */
+  int64_t target_null[MI355Q_MAX_TARGETS];      /* bit pattern of the result type's NULL
+                                                   (null_val_bit_pattern,
+                                                   ResultSetBufferAccessors.h:229) */
+  int64_t init_vals[MI355Q_MAX_SLOTS];          /* init_agg_val_vec
+                                                   (OutputBufferInitialization.cpp:24) */
+} mi355q_qmd;
+
+/* FetchResult mirror (ColumnFetcher.h:46-49): borrowed device pointers. */
+typedef struct mi355q_inputs {
+  int32_t device_id;
+  int32_t n_frags;
+  /* col_buffers[frag * n_cols + col] -> device pointer to a dense fixed-width chunk */
+  const void* const* col_buffers;
+  const int64_t* num_rows; /* per fragment (host array) */
+  /* inner table, linearized into one chunk per column (reference fetches inner
+   * tables as one "all fragments" buffer, ColumnFetcher::getAllTableColumnFragments) */
+  const void* const* inner_col_buffers; /* [n_inner_cols] */
+  int64_t inner_num_rows;
+} mi355q_inputs;
+
+typedef struct mi355q_result mi355q_result; /* opaque: QueryMemoryDescriptor + buff_ */
+
+/* ExecutionOptions-like knobs for this library. */
+typedef struct mi355q_exec_options {
+  void* stream;      /* hipStream_t to launch on; NULL = library-owned stream */
+  void* out_buffer;  /* optional caller-owned device buffer for the result storage
+                        (>= mi355q_qmd_buffer_bytes); NULL = library allocates */
+  int32_t force_generic; /* 1 = always use the generic row kernel (testing) */
+  int32_t kernel_variant; /* 0 = plan-time choice; >0 selects a specific variant of
+                             the chosen family (testing / tuning) */
+  int64_t scratch_bytes;  /* cap for partition scratch (0 = default) */
+  int32_t reserved[4];
+} mi355q_exec_options;
+
+/* per-call timing/selection report (what launchGpuCode logs,
+ * QueryExecutionContext.cpp:334,364,579) */
+typedef struct mi355q_exec_report {
+  char kernel_name[64]; /* dominant kernel chosen at plan time */
+  float kernel_ms;      /* HIP-event time of the dominant kernel(s) on the launch stream */
+  float total_ms;       /* HIP-event time of the whole call on the launch stream */
+  int32_t n_launches;
+  int32_t variant;
+  int64_t rows_scanned;
+  int64_t algorithmic_bytes; /* column bytes the plan must read */
+  int64_t spilled_rows;      /* rows that took the direct-atomic spill path */
+} mi355q_exec_report;
+
+/* ---- library ---- */
+int32_t mi355q_abi_version(void);
+const char* mi355q_error_string(int32_t code);
+int32_t mi355q_device_count(void);
+/* fills name (<=256 bytes) and basic properties of a device */
+int32_t mi355q_device_info(int32_t device_id, char* name, int32_t* cu_count,
+                           int64_t* total_mem, int64_t* free_mem, int32_t* mem_clock_khz,
+                           int32_t* mem_bus_width);
+
+/* ---- plan -> layout ---- */
+int32_t mi355q_qmd_init(const mi355q_plan* plan, mi355q_qmd* out);
+int64_t mi355q_qmd_buffer_bytes(const mi355q_qmd* qmd);
+
+/* ---- execute one query step on one device ---- */
+int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* inputs,
+                       const mi355q_exec_options* opts, mi355q_result** out,
+                       mi355q_exec_report* report);
+
+/* ---- result set ---- */
+int32_t mi355q_result_create(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
+                             mi355q_result** out); /* wraps/allocates + initialises */
+void mi355q_result_free(mi355q_result* r);
+int32_t mi355q_result_qmd(const mi355q_result* r, mi355q_qmd* out);
+void* mi355q_result_device_ptr(const mi355q_result* r);
+int64_t mi355q_result_bytes(const mi355q_result* r);
+int32_t mi355q_result_copy_to_host(const mi355q_result* r, void* dst, int64_t dst_bytes);
+/* this += that, slot-wise with the targets' aggregate functions; baseline layouts
+ * re-hash every live entry of `that` into `this` (ResultSetReduction.cpp:203-383,
+ * :783-826).  Both on the same device. */
+int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_rs,
+                             void* stream);
+/* number of non-empty entries (ResultSet::rowCount, ResultSet.h:327) */
+int64_t mi355q_result_row_count(const mi355q_result* r);
+/* Materialise rows the way ResultSet::getNextRow does, in entry order: for every
+ * non-empty entry one row of n_targets values.  Integer-typed targets land in ival,
+ * double-typed in dval (AVG = sum/count, NULL if count == 0); is_null flags SQL NULL.
+ * Arrays are [max_rows * n_targets].  Returns rows written in *n_rows. */
+int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival,
+                                 double* dval, int8_t* is_null, int64_t* n_rows);
+
+/* ---- join hash tables ---- */
+typedef struct mi355q_join_spec {
+  int32_t device_id;
+  int32_t key_type;     /* mi355q_type of the inner key column */
+  int32_t key_nullable;
+  int32_t prefer_baseline; /* 1 = skip the perfect attempt (testing keyed tables) */
+  const void* key_buffer; /* device pointer, inner key column, linearized */
+  int64_t num_rows;
+  mi355q_range key_range; /* inner key ExpressionRange */
+  int64_t max_perfect_entries; /* 0 = default (PerfectJoinHashTable.cpp:219-224) */
+} mi355q_join_spec;
+
+/* HashType: 0 OneToOne perfect (int32 slot[max-min+1], -1 empty,
+ * HashJoinRuntime.cpp:71-86), 1 OneToOne baseline/keyed ({int64 key, int64 row id}
+ * [2 x NDV], empty key INT64_MAX, :346-373). */
+int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream,
+                          mi355q_join_table** out);
+void mi355q_join_free(mi355q_join_table* t);
+int32_t mi355q_join_info(const mi355q_join_table* t, int32_t* hash_type, int64_t* entry_count,
+                         int64_t* min_key, int64_t* max_key, void** device_ptr,
+                         int64_t* bytes, float* build_ms);
+
+/* ---- multi-device merge helpers (one process per GPU; the collective itself is
+ * issued by the host with RCCL between these calls) ---- */
+/* Baseline layouts: compact the live entries of `r` into `n_parts` contiguous runs of
+ * whole rows (row_size bytes each), run p holding the keys with
+ * MurmurHash3(key) / entry-hash % n_parts == p.  out_rows must hold entry_count rows;
+ * part_counts (device, int64[n_parts]) receives the run lengths. */
+int32_t mi355q_shard_partition(const mi355q_result* r, int32_t n_parts, void* out_rows,
+                               int64_t* part_counts_dev, void* stream);
+/* Insert `n_rows` whole rows (same layout as r) into r with the reduce semantics. */
+int32_t mi355q_shard_merge_rows(mi355q_result* r, const void* rows, int64_t n_rows,
+                                void* stream);
+
+/* ---- synthetic column generators (same splitmix64 stream as
+ * oracle/oracle.cpp) — device-side so 10 B-row tables never touch the host ---- */
+typedef enum mi355q_gen_kind {
+  MI355Q_GEN_I32_UNIFORM31 = 1, /* (int32)(u >> 33) in [0, 2^31) */
+  MI355Q_GEN_I32_MOD = 2,       /* (int32)(u % a) + b */
+  MI355Q_GEN_I64_MOD = 3,       /* (int64)(u % a) + b */
+  MI355Q_GEN_I64_MOD_MUL = 4,   /* (int64)(u % a) * b + c */
+  MI355Q_GEN_F64_UNIT = 5       /* (double)(u >> 11) * 2^-53 * a_f */
+} mi355q_gen_kind;
+int32_t mi355q_generate_column(int32_t device_id, void* dst, int64_t n_rows, int64_t row_offset,
+                               int32_t kind, uint64_t seed, int64_t a, int64_t b, int64_t c,
+                               double a_f, int32_t null_every, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355Q_H */

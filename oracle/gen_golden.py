@@ -1,0 +1,159 @@
+"""Generate tests/golden/ref_vectors.json from the REFERENCE'S OWN runtime functions
+(oracle/_ref/libref_runtime.so, compiled in place from /root/reference by oracle/Makefile).
+
+Run in the build container only (needs /root/reference):  python oracle/gen_golden.py
+The committed JSON is what travels; tests/test_oracle_golden.py pins oracle/oracle.cpp to it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc  # noqa: E402
+
+EMPTY64 = 2**63 - 1
+EMPTY32 = 2**31 - 1
+
+
+def main():
+    orc.build()
+    ref = orc.ref_lib()
+    assert ref is not None, "oracle/_ref not built (no /root/reference?)"
+    rng = np.random.default_rng(20260922)
+    out = {"source": "heavyai/heavydb reference sources compiled in place (oracle/ref_shim.cpp)"}
+
+    # ---- Murmur vectors
+    hashes = []
+    ints64 = [0, 1, 7, 42, 1000, 1000010, 9999999 * 1000003 + 7, -1, 2**40, -(2**63), 2**63 - 1]
+    ints64 += [int(x) for x in rng.integers(-2**62, 2**62, 24)]
+    for v in ints64:
+        b = struct.pack("<q", v)
+        hashes.append({"hex": b.hex(), "m3": ref.MurmurHash3(b, 8, 0), "m1": ref.MurmurHash1(b, 8, 0)})
+    for v in [0, 1, 7, 999, -1, 2**31 - 1, -(2**31)] + [int(x) for x in rng.integers(-2**31, 2**31, 16)]:
+        b = struct.pack("<i", v)
+        hashes.append({"hex": b.hex(), "m3": ref.MurmurHash3(b, 4, 0), "m1": ref.MurmurHash1(b, 4, 0)})
+    b = struct.pack("<qq", 3, 5)
+    hashes.append({"hex": b.hex(), "m3": ref.MurmurHash3(b, 16, 0), "m1": ref.MurmurHash1(b, 16, 0)})
+    for n in range(1, 20):  # tails of every length, non-zero seeds
+        b = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        seed = int(rng.integers(0, 2**32))
+        hashes.append({"hex": b.hex(), "seed": seed, "m3": ref.MurmurHash3(b, n, seed),
+                       "m1": ref.MurmurHash1(b, n, seed)})
+    out["hashes"] = hashes
+
+    # ---- baseline group-by traces: get_group_value (GroupByRuntime.cpp:25-48)
+    def baseline_trace(entry_count, key_width, keys, row_quad=2):
+        buf = np.zeros(entry_count * row_quad, dtype=np.int64)
+        for e in range(entry_count):
+            if key_width == 8:
+                buf[e * row_quad] = EMPTY64
+            else:
+                buf[e * row_quad:e * row_quad + 1].view(np.int32)[0] = EMPTY32
+        landed = []
+        for k in keys:
+            if key_width == 8:
+                kb = np.array([k], dtype=np.int64)
+            else:
+                kb = np.array([k, 0], dtype=np.int32)
+            p = ref.get_group_value(buf.ctypes.data, entry_count, kb.ctypes.data, 1, key_width,
+                                    row_quad)
+            if not p:
+                landed.append(-1)
+                continue
+            quad = (p - buf.ctypes.data) // 8
+            landed.append(int(quad))          # quad index of the first agg slot
+            buf[quad] += 1                    # COUNT
+        return {"entry_count": entry_count, "key_width": key_width, "row_quad": row_quad,
+                "keys": [int(k) for k in keys], "slot_quads": landed,
+                "final": [int(x) for x in buf]}
+
+    traces = [baseline_trace(8, 8, [10, 20, 30, 10, 40, 50, 20, 60])]
+    traces.append(baseline_trace(8, 8, [1, 2, 3, 4, 5, 6, 7, 8, 9]))  # overflow -> NULL
+    keys = [int(x) * 1000003 + 7 for x in rng.integers(0, 40, 200)]
+    traces.append(baseline_trace(97, 8, keys, row_quad=4))
+    keys32 = [int(x) for x in rng.integers(-1000, 1000, 300)]
+    traces.append(baseline_trace(1024, 4, keys32, row_quad=3))
+    out["baseline_traces"] = traces
+
+    # ---- perfect group-by trace: get_group_value_fast (GroupByRuntime.cpp:208-223)
+    def perfect_trace(min_key, n, keys, row_quad=2):
+        buf = np.zeros(n * row_quad, dtype=np.int64)
+        buf[0::row_quad] = EMPTY64
+        for k in keys:
+            p = ref.get_group_value_fast(buf.ctypes.data, k, min_key, 0, row_quad)
+            quad = (p - buf.ctypes.data) // 8
+            buf[quad] += k  # SUM(key)
+        return {"min_key": min_key, "entries": n, "row_quad": row_quad,
+                "keys": [int(k) for k in keys], "final": [int(x) for x in buf]}
+
+    out["perfect_traces"] = [perfect_trace(100, 5, [102, 100, 104, 102]),
+                             perfect_trace(-7, 32, [int(x) for x in rng.integers(-7, 25, 100)], 3)]
+
+    # ---- perfect join probe: hash_join_idx (GroupByRuntime.cpp:287-297)
+    table = np.full(5, -1, dtype=np.int32)
+    for row_id, k in enumerate([3, 1, 4]):
+        table[k - 1] = row_id
+    probes = [1, 2, 3, 4, 5, 0, 9, -5]
+    out["perfect_join"] = {
+        "min": 1, "max": 5, "table": [int(x) for x in table], "probes": probes,
+        "idx": [int(ref.hash_join_idx(table.ctypes.data, k, 1, 5)) for k in probes]}
+
+    # ---- keyed join probe: baseline_hash_join_idx_64 (JoinHashTableQueryRuntime.cpp:56-94)
+    def keyed_join(entry_count, dim_keys, probes):
+        tab = np.zeros((entry_count, 2), dtype=np.int64)
+        tab[:, 0] = EMPTY64
+        tab[:, 1] = -1
+        slots = []
+        for row_id, k in enumerate(dim_keys):
+            kb = struct.pack("<q", k)
+            h = ref.MurmurHash1(kb, 8, 0) % entry_count
+            while tab[h, 0] != EMPTY64:
+                h = (h + 1) % entry_count
+            tab[h] = (k, row_id)
+            slots.append(int(h))
+        res = []
+        for k in probes:
+            kb = np.array([k], dtype=np.int64)
+            res.append(int(ref.baseline_hash_join_idx_64(tab.ctypes.data, kb.ctypes.data, 8,
+                                                         entry_count)))
+        return {"entry_count": entry_count, "dim_keys": [int(k) for k in dim_keys],
+                "slots": slots, "table": [int(x) for x in tab.reshape(-1)],
+                "probes": [int(k) for k in probes], "idx": res}
+
+    kj = [keyed_join(8, [1000010, 2000013, 3000016, 7], [1000010, 7, 3000016, 8, 2000013, 0])]
+    dk = [int(x) * 1000003 for x in rng.permutation(500)[:200]]
+    pr = dk[:50] + [int(x) for x in rng.integers(0, 10**9, 50)]
+    kj.append(keyed_join(400, dk, pr))
+    kj.append(keyed_join(4, [5, 6, 7, 9], [5, 9, 11]))  # full table: -1 (kNoMatch) on miss
+    out["keyed_join"] = kj
+
+    # ---- decoders: fixed_width_int_decode / fixed_width_double_decode (DecodersImpl.h:27-55,121)
+    dec = []
+    for width, dt in [(1, np.int8), (2, np.int16), (4, np.int32), (8, np.int64)]:
+        info = np.iinfo(dt)
+        vals = np.array([0, 1, -1, info.min, info.max, 37, -99], dtype=dt)
+        dec.append({"width": width, "hex": vals.tobytes().hex(),
+                    "decoded": [int(ref.fixed_width_int_decode(vals.ctypes.data, width, i))
+                                for i in range(len(vals))]})
+    out["int_decode"] = dec
+    dv = np.array([0.0, -1.5, 2.2250738585072014e-308, 1e300, 999.999], dtype=np.float64)
+    out["double_decode"] = {"hex": dv.tobytes().hex(),
+                            "decoded": [float(ref.fixed_width_double_decode(dv.ctypes.data, i))
+                                        for i in range(len(dv))]}
+
+    dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests",
+                       "golden", "ref_vectors.json")
+    os.makedirs(os.path.dirname(dst), exist_ok=True)
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", dst, os.path.getsize(dst), "bytes")
+
+
+if __name__ == "__main__":
+    main()

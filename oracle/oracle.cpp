@@ -1,0 +1,1175 @@
+/*
+ * oracle.cpp — CPU restatement of HeavyDB's CPU executor semantics for ONE query
+ * step (scan/filter -> group-by + aggregate -> join probe).
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product library (libmi355q.so)
+ * never links, loads or calls anything in this directory.
+ *
+ * Parity status: PINNED — every function below is a restatement of the cited
+ * reference lines and is checked (tests/test_oracle_golden.py) against
+ *   (1) the known-answer vectors in tests/golden/ref_vectors.json, generated from the
+ *       reference's own sources compiled in place (oracle/_ref, oracle/Makefile,
+ *       oracle/gen_golden.py), and
+ *   (2) the ResultSetTest-style fill/reduce/iterate cases of Tests/ResultSetTest.cpp.
+ *
+ * All citations are relative to the heavyai/heavydb tree.
+ */
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <thread>
+#include <vector>
+
+#include "../include/mi355q.h"
+
+#define ORC_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr int64_t kEmptyKey64 = INT64_MAX;  // GpuRtConstants.h:27 EMPTY_KEY_64
+constexpr int32_t kEmptyKey32 = INT32_MAX;  // GpuRtConstants.h:28 EMPTY_KEY_32
+constexpr size_t kMaxBufferSize = size_t(1) << 30;  // GroupByAndAggregate.cpp:57
+
+// ---------------------------------------------------------------- hashing
+inline uint32_t rotl32(uint32_t x, int8_t r) {
+  return (x << r) | (x >> (32 - r));
+}
+
+// MurmurHash3Inl.h:11-72 (MurmurHash3_x86_32)
+uint32_t murmur3(const void* key, int len, uint32_t seed) {
+  const uint8_t* data = static_cast<const uint8_t*>(key);
+  const int nblocks = len / 4;
+  uint32_t h1 = seed;
+  const uint32_t c1 = 0xcc9e2d51, c2 = 0x1b873593;
+  for (int i = 0; i < nblocks; ++i) {
+    uint32_t k1;
+    memcpy(&k1, data + 4 * i, 4);
+    k1 *= c1;
+    k1 = rotl32(k1, 15);
+    k1 *= c2;
+    h1 ^= k1;
+    h1 = rotl32(h1, 13);
+    h1 = h1 * 5 + 0xe6546b64;
+  }
+  const uint8_t* tail = data + nblocks * 4;
+  uint32_t k1 = 0;
+  switch (len & 3) {
+    case 3:
+      k1 ^= tail[2] << 16;
+      [[fallthrough]];
+    case 2:
+      k1 ^= tail[1] << 8;
+      [[fallthrough]];
+    case 1:
+      k1 ^= tail[0];
+      k1 *= c1;
+      k1 = rotl32(k1, 15);
+      k1 *= c2;
+      h1 ^= k1;
+  }
+  h1 ^= len;
+  h1 ^= h1 >> 16;
+  h1 *= 0x85ebca6b;
+  h1 ^= h1 >> 13;
+  h1 *= 0xc2b2ae35;
+  h1 ^= h1 >> 16;
+  return h1;
+}
+
+// MurmurHash1Inl.h:22-62
+uint32_t murmur1(const void* key, int len, uint32_t seed) {
+  const unsigned int m = 0xc6a4a793;
+  unsigned int h = seed ^ (len * m);
+  const unsigned char* data = static_cast<const unsigned char*>(key);
+  while (len >= 4) {
+    unsigned int k;
+    memcpy(&k, data, 4);
+    h += k;
+    h *= m;
+    h ^= h >> 16;
+    data += 4;
+    len -= 4;
+  }
+  switch (len) {
+    case 3:
+      h += data[2] << 16;
+      [[fallthrough]];
+    case 2:
+      h += data[1] << 8;
+      [[fallthrough]];
+    case 1:
+      h += data[0];
+      h *= m;
+      h ^= h >> 16;
+  }
+  h *= m;
+  h ^= h >> 10;
+  h *= m;
+  h ^= h >> 17;
+  return h;
+}
+
+// ---------------------------------------------------------------- types / nulls
+inline int type_width(int t) {
+  switch (t) {
+    case MI355Q_INT8: return 1;
+    case MI355Q_INT16: return 2;
+    case MI355Q_INT32: return 4;
+    case MI355Q_INT64: return 8;
+    case MI355Q_DOUBLE: return 8;
+  }
+  return 0;
+}
+inline bool type_is_fp(int t) { return t == MI355Q_DOUBLE; }
+
+// Shared/InlineNullValues.h:29-35
+inline int64_t int_null_of(int t) {
+  switch (t) {
+    case MI355Q_INT8: return INT8_MIN;
+    case MI355Q_INT16: return INT16_MIN;
+    case MI355Q_INT32: return INT32_MIN;
+    default: return INT64_MIN;
+  }
+}
+inline int64_t dbl_bits(double d) {
+  int64_t r;
+  memcpy(&r, &d, 8);
+  return r;
+}
+inline double bits_dbl(int64_t b) {
+  double r;
+  memcpy(&r, &b, 8);
+  return r;
+}
+constexpr double kNullDouble = DBL_MIN;  // NULL_DOUBLE
+
+// DecodersImpl.h:27-55 fixed_width_int_decode (sign-extending load), :121-128 double
+inline int64_t decode_int(const int8_t* col, int t, int64_t pos) {
+  switch (t) {
+    case MI355Q_INT8: return *reinterpret_cast<const int8_t*>(col + pos);
+    case MI355Q_INT16: return *reinterpret_cast<const int16_t*>(col + pos * 2);
+    case MI355Q_INT32: return *reinterpret_cast<const int32_t*>(col + pos * 4);
+    default: return *reinterpret_cast<const int64_t*>(col + pos * 8);
+  }
+}
+inline double decode_dbl(const int8_t* col, int64_t pos) {
+  return *reinterpret_cast<const double*>(col + pos * 8);
+}
+
+// ---------------------------------------------------------------- aggregates (CPU)
+// RuntimeFunctions.cpp:362
+inline void agg_count(int64_t* agg) { ++*reinterpret_cast<uint64_t*>(agg); }
+// :1151
+inline void agg_sum(int64_t* agg, int64_t val) { *agg += val; }
+// :1163-1169
+inline void agg_max(int64_t* agg, int64_t val) { *agg = std::max(*agg, val); }
+inline void agg_min(int64_t* agg, int64_t val) { *agg = std::min(*agg, val); }
+// :1313-1325
+inline void agg_sum_skip_val(int64_t* agg, int64_t val, int64_t skip_val) {
+  const auto old = *agg;
+  if (val != skip_val) {
+    if (old != skip_val) {
+      agg_sum(agg, val);
+    } else {
+      *agg = val;
+    }
+  }
+}
+// :1401-1431 DEF_SKIP_AGG(agg_max / agg_min)
+inline void agg_max_skip_val(int64_t* agg, int64_t val, int64_t skip_val) {
+  if (val != skip_val) {
+    const int64_t old = *agg;
+    if (old != skip_val) {
+      agg_max(agg, val);
+    } else {
+      *agg = val;
+    }
+  }
+}
+inline void agg_min_skip_val(int64_t* agg, int64_t val, int64_t skip_val) {
+  if (val != skip_val) {
+    const int64_t old = *agg;
+    if (old != skip_val) {
+      agg_min(agg, val);
+    } else {
+      *agg = val;
+    }
+  }
+}
+// :1444-1470
+inline void agg_sum_double(int64_t* agg, double val) {
+  *agg = dbl_bits(bits_dbl(*agg) + val);
+}
+inline void agg_max_double(int64_t* agg, double val) {
+  *agg = dbl_bits(std::max(bits_dbl(*agg), val));
+}
+inline void agg_min_double(int64_t* agg, double val) {
+  *agg = dbl_bits(std::min(bits_dbl(*agg), val));
+}
+// :1558-1584 DEF_SKIP_AGG for double
+inline void agg_sum_double_skip_val(int64_t* agg, double val, double skip_val) {
+  if (val != skip_val) {
+    const int64_t old = *agg;
+    if (old != dbl_bits(skip_val)) {
+      agg_sum_double(agg, val);
+    } else {
+      *agg = dbl_bits(val);
+    }
+  }
+}
+inline void agg_max_double_skip_val(int64_t* agg, double val, double skip_val) {
+  if (val != skip_val) {
+    const int64_t old = *agg;
+    if (old != dbl_bits(skip_val)) {
+      agg_max_double(agg, val);
+    } else {
+      *agg = dbl_bits(val);
+    }
+  }
+}
+inline void agg_min_double_skip_val(int64_t* agg, double val, double skip_val) {
+  if (val != skip_val) {
+    const int64_t old = *agg;
+    if (old != dbl_bits(skip_val)) {
+      agg_min_double(agg, val);
+    } else {
+      *agg = dbl_bits(val);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- layout decisions
+struct TargetDesc {
+  int agg;
+  int col;
+  int table;
+  int arg_type;      // 0 for COUNT(*)
+  bool arg_nullable;
+  bool arg_fp;
+  bool skip_null;    // TargetInfo.skip_null_val after TargetExprBuilder.cpp:684-690
+  int slot;          // first slot, -1 if read from key columns
+  int n_slots;
+};
+
+const mi355q_col_desc& col_desc_of(const mi355q_plan& p, int table, int col) {
+  return table ? p.inner_cols[col] : p.cols[col];
+}
+const mi355q_range& col_range_of(const mi355q_plan& p, int table, int col) {
+  return table ? p.inner_col_ranges[col] : p.col_ranges[col];
+}
+
+// get_agg_initial_val (OutputBufferInitialization.cpp:132-289) for 8-byte slots.
+// `notnull` is the init type's notnull flag (forced false for non-grouped, :79-81).
+int64_t agg_initial_val(int agg, int arg_type, bool notnull) {
+  const bool fp = type_is_fp(arg_type);
+  switch (agg) {
+    case MI355Q_SUM:
+      if (!notnull) {
+        // SUM(int) has result type BIGINT -> NULL_BIGINT; SUM(double) -> NULL_DOUBLE bits
+        return fp ? dbl_bits(kNullDouble) : INT64_MIN;
+      }
+      return fp ? dbl_bits(0.0) : 0;
+    case MI355Q_AVG:
+    case MI355Q_COUNT:
+      return 0;
+    case MI355Q_MIN:
+      if (fp) {
+        return notnull ? dbl_bits(DBL_MAX) : dbl_bits(kNullDouble);
+      }
+      return notnull ? INT64_MAX : int_null_of(arg_type);
+    case MI355Q_MAX:
+      if (fp) {
+        return notnull ? dbl_bits(-DBL_MAX) : dbl_bits(kNullDouble);
+      }
+      return notnull ? INT64_MIN : int_null_of(arg_type);
+    default:
+      return 0;  // non-agg targets: 0 (init_agg_val_vec :35-47)
+  }
+}
+
+int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc>& out) {
+  out.clear();
+  for (int i = 0; i < p.n_targets; ++i) {
+    const auto& t = p.targets[i];
+    TargetDesc d{};
+    d.agg = t.agg;
+    d.col = t.col;
+    d.table = t.table;
+    if (t.agg == MI355Q_PROJECT_KEY) {
+      if (!is_group_by) return MI355Q_ERR_INVALID_PLAN;
+      d.col = p.group_cols[0];
+      d.table = 0;
+    }
+    if (d.col >= 0) {
+      const auto& cd = col_desc_of(p, d.table, d.col);
+      d.arg_type = cd.type;
+      d.arg_nullable = cd.nullable != 0;
+      d.arg_fp = type_is_fp(cd.type);
+    } else if (t.agg != MI355Q_COUNT) {
+      return MI355Q_ERR_INVALID_PLAN;
+    }
+    // TargetInfo.cpp:64-81: skip_null_val = !arg.notnull ; TargetExprBuilder.cpp:684-690:
+    // non-grouped aggregates with an argument force skip_null_val = true.
+    d.skip_null = (d.col >= 0 && t.agg != MI355Q_PROJECT_KEY) &&
+                  (d.arg_nullable || !is_group_by);
+    d.n_slots = (t.agg == MI355Q_AVG) ? 2 : 1;
+    out.push_back(d);
+  }
+  return 0;
+}
+
+// getExpressionRange-driven part of get_keyless_info (GroupByAndAggregate.cpp:489-648).
+// Returns {keyless, slot index of the target acting as key}.
+std::pair<bool, int> keyless_info(const mi355q_plan& p, const std::vector<TargetDesc>& ts) {
+  bool keyless = true, found = false;
+  int index = 0;
+  for (const auto& t : ts) {
+    const bool is_agg = t.agg != MI355Q_PROJECT_KEY;
+    if (!found && is_agg) {
+      const mi355q_range* r = t.col >= 0 ? &col_range_of(p, t.table, t.col) : nullptr;
+      switch (t.agg) {
+        case MI355Q_AVG:
+          ++index;
+          if (t.col >= 0 && t.arg_nullable) {
+            if (!r->valid || r->has_nulls) break;
+          }
+          found = true;
+          break;
+        case MI355Q_COUNT:
+          if (t.col >= 0 && t.arg_nullable) {
+            if (!r->valid || r->has_nulls) break;
+          }
+          found = true;
+          break;
+        case MI355Q_SUM:
+          if (t.arg_nullable) {
+            if (r->valid && !r->has_nulls) found = true;
+          } else if (r->valid) {
+            if (t.arg_fp) {
+              if (r->fp_max < 0 || r->fp_min > 0) found = true;
+            } else {
+              if (r->max < 0 || r->min > 0) found = true;
+            }
+          }
+          break;
+        case MI355Q_MIN: {
+          if (!r->valid) break;
+          const int64_t init_max = agg_initial_val(MI355Q_MIN, t.arg_type, !t.arg_nullable);
+          if (t.arg_fp) {
+            if (r->fp_max < bits_dbl(init_max)) found = true;
+          } else {
+            if (r->max < init_max) found = true;
+          }
+          break;
+        }
+        case MI355Q_MAX: {
+          if (!r->valid || r->has_nulls) break;
+          const int64_t init_min = agg_initial_val(MI355Q_MAX, t.arg_type, !t.arg_nullable);
+          if (t.arg_fp) {
+            if (r->fp_min > bits_dbl(init_min)) found = true;
+          } else {
+            if (r->min > init_min) found = true;
+          }
+          break;
+        }
+        default:
+          keyless = false;
+      }
+    }
+    if (!keyless) break;
+    if (!found) ++index;
+  }
+  return {keyless && found, index};
+}
+
+int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
+  memset(&q, 0, sizeof(q));
+  if (p.n_targets < 1 || p.n_targets > MI355Q_MAX_TARGETS) return MI355Q_ERR_INVALID_PLAN;
+  if (p.n_group_cols < 0 || p.n_group_cols > 1) return MI355Q_ERR_UNSUPPORTED;
+  const bool is_group_by = p.n_group_cols > 0;
+  std::vector<TargetDesc> ts;
+  if (int e = build_targets(p, is_group_by, ts)) return e;
+
+  q.n_targets = p.n_targets;
+  q.group_col_count = p.n_group_cols;
+  q.idx_target_as_key = -1;
+  if (!is_group_by) {
+    q.desc_type = MI355Q_NON_GROUPED_AGGREGATE;  // QueryMemoryDescriptor.cpp:271-300
+    q.entry_count = 1;
+    q.key_width = 8;
+  } else {
+    const int gc = p.group_cols[0];
+    const auto& gcd = p.cols[gc];
+    if (type_is_fp(gcd.type)) return MI355Q_ERR_UNSUPPORTED;
+    const auto& r = p.col_ranges[gc];
+    // getColRangeInfo, single-column case (GroupByAndAggregate.cpp:295-349)
+    bool baseline = false;
+    if (!r.valid || r.min > r.max) {
+      baseline = true;
+    } else {
+      const int64_t col_count = p.n_group_cols + p.n_targets;
+      const int64_t max_entry_count = kMaxBufferSize / (col_count * sizeof(int64_t));
+      // is_column_range_too_big_for_perfect_hash (:130-139), overflow -> too big
+      __int128 span = (__int128)r.max - (__int128)r.min;
+      if (span > INT64_MAX || (int64_t)span >= max_entry_count) baseline = true;
+    }
+    if (!baseline) {
+      q.desc_type = MI355Q_GROUP_BY_PERFECT_HASH;
+      q.min_val = r.min;
+      q.max_val = r.max;
+      q.bucket = 0;
+      q.has_nulls = r.has_nulls;
+      // getBucketedCardinality (:367-375)
+      q.entry_count = std::max<int64_t>(r.max - r.min + 1 + (r.has_nulls ? 1 : 0), 1);
+      auto ki = keyless_info(p, ts);
+      q.keyless = ki.first;
+      q.idx_target_as_key = ki.second;
+      q.key_width = 8;
+    } else {
+      q.desc_type = MI355Q_GROUP_BY_BASELINE_HASH;
+      q.entry_count = p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess
+                                                          : 16384;
+      // pick_baseline_key_width (QueryMemoryDescriptor.cpp:113-146)
+      int kw = 8;
+      if (r.valid) {
+        if (type_width(gcd.type) == 8 && r.has_nulls) {
+          kw = 8;
+        } else {
+          kw = (r.min > INT32_MIN && r.max < kEmptyKey32 - 1) ? 4 : 8;
+        }
+      }
+      q.key_width = kw;
+    }
+  }
+  // slots: ColSlotContext (ColSlotContext.cpp:35-100), all padded to 8 bytes
+  int slot = 0;
+  for (int i = 0; i < p.n_targets; ++i) {
+    auto& t = ts[i];
+    q.target_agg[i] = t.agg;
+    q.target_skip_null[i] = t.skip_null;
+    q.target_arg_is_fp[i] = t.arg_fp && t.agg != MI355Q_COUNT;
+    q.target_is_fp[i] = (t.agg == MI355Q_AVG) || (t.arg_fp && t.agg != MI355Q_COUNT);
+    if (t.agg == MI355Q_PROJECT_KEY && q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
+      // target_groupby_indices >= 0 -> zero-width slot (ColSlotContext.cpp:45-49)
+      q.target_slot[i] = -1;
+      t.slot = -1;
+    } else {
+      if (slot + t.n_slots > MI355Q_MAX_SLOTS) return MI355Q_ERR_INVALID_PLAN;
+      q.target_slot[i] = slot;
+      t.slot = slot;
+      // init_agg_val_vec (OutputBufferInitialization.cpp:24-84)
+      const bool init_notnull = is_group_by ? !t.arg_nullable : false;
+      q.init_vals[slot] = agg_initial_val(t.agg, t.arg_type, init_notnull);
+      if (t.agg == MI355Q_AVG) q.init_vals[slot + 1] = 0;
+      slot += t.n_slots;
+    }
+    // null_val_bit_pattern (ResultSetBufferAccessors.h:229-245) of the result type
+    switch (t.agg) {
+      case MI355Q_AVG: q.target_null[i] = dbl_bits(kNullDouble); break;
+      case MI355Q_SUM: q.target_null[i] = t.arg_fp ? dbl_bits(kNullDouble) : INT64_MIN; break;
+      case MI355Q_COUNT: q.target_null[i] = p.bigint_count ? INT64_MIN : INT32_MIN; break;
+      default:
+        q.target_null[i] = t.arg_fp ? dbl_bits(kNullDouble) : int_null_of(t.arg_type);
+    }
+  }
+  q.slot_count = slot;
+  // getRowSize (QueryMemoryDescriptor.cpp:848-860)
+  q.key_bytes = 0;
+  if (is_group_by && !q.keyless) {
+    q.key_bytes = (q.group_col_count * q.key_width + 7) & ~7;
+  }
+  q.row_size = q.key_bytes + 8 * q.slot_count;
+  if (q.row_size == 0) return MI355Q_ERR_INVALID_PLAN;
+  return 0;
+}
+
+// ---------------------------------------------------------------- buffer init
+// QueryMemoryInitializer::initRowGroups (QueryMemoryInitializer.cpp:617-698)
+void init_buffer(const mi355q_qmd& q, int64_t* buf) {
+  const int rq = q.row_size / 8;
+  const int kq = q.key_bytes / 8;
+  for (int64_t e = 0; e < q.entry_count; ++e) {
+    int64_t* row = buf + e * rq;
+    if (kq) {
+      if (q.key_width == 4) {
+        int32_t* k32 = reinterpret_cast<int32_t*>(row);
+        k32[0] = kEmptyKey32;
+        k32[1] = 0;  // padding
+      } else {
+        row[0] = kEmptyKey64;
+      }
+    }
+    for (int s = 0; s < q.slot_count; ++s) row[kq + s] = q.init_vals[s];
+  }
+}
+
+// ---------------------------------------------------------------- group slot lookup
+// RuntimeFunctions.cpp:1953-1992 get_matching_group_value<T>, single key column
+template <typename T>
+int64_t* get_matching_group_value_t(int64_t* groups_buffer, uint32_t h, T key,
+                                    uint32_t row_size_quad, T empty) {
+  int64_t* row = groups_buffer + (size_t)h * row_size_quad;
+  T* row_ptr = reinterpret_cast<T*>(row);
+  if (*row_ptr == empty) {
+    *row_ptr = key;
+    return row + 1;  // align_to_int64(row_ptr + 1)
+  }
+  if (*row_ptr == key) return row + 1;
+  return nullptr;
+}
+
+// GroupByRuntime.cpp:25-48 get_group_value (+ key_hash :20-23)
+int64_t* get_group_value(int64_t* groups_buffer, uint32_t entry_count, int64_t key,
+                         uint32_t key_width, uint32_t row_size_quad) {
+  uint32_t h;
+  if (key_width == 4) {
+    int32_t k32 = (int32_t)key;
+    h = murmur3(&k32, 4, 0) % entry_count;
+    auto m = get_matching_group_value_t<int32_t>(groups_buffer, h, k32, row_size_quad,
+                                                 kEmptyKey32);
+    if (m) return m;
+    uint32_t hp = (h + 1) % entry_count;
+    while (hp != h) {
+      m = get_matching_group_value_t<int32_t>(groups_buffer, hp, k32, row_size_quad,
+                                              kEmptyKey32);
+      if (m) return m;
+      hp = (hp + 1) % entry_count;
+    }
+    return nullptr;
+  }
+  h = murmur3(&key, 8, 0) % entry_count;
+  auto m = get_matching_group_value_t<int64_t>(groups_buffer, h, key, row_size_quad,
+                                               kEmptyKey64);
+  if (m) return m;
+  uint32_t hp = (h + 1) % entry_count;
+  while (hp != h) {
+    m = get_matching_group_value_t<int64_t>(groups_buffer, hp, key, row_size_quad,
+                                            kEmptyKey64);
+    if (m) return m;
+    hp = (hp + 1) % entry_count;
+  }
+  return nullptr;
+}
+
+// GroupByRuntime.cpp:208-223 get_group_value_fast (+ _with_original_key :225-241)
+inline int64_t* get_group_value_fast(int64_t* buf, int64_t key, int64_t orig_key,
+                                     int64_t min_key, uint32_t row_size_quad) {
+  int64_t off = (key - min_key) * row_size_quad;
+  if (buf[off] == kEmptyKey64) buf[off] = orig_key;
+  return buf + off + 1;
+}
+// RuntimeFunctions.cpp:2126-2133 get_group_value_fast_keyless
+inline int64_t* get_group_value_fast_keyless(int64_t* buf, int64_t key, int64_t min_key,
+                                             uint32_t row_size_quad) {
+  return buf + row_size_quad * (key - min_key);
+}
+
+// ---------------------------------------------------------------- join tables
+struct OrcJoin {
+  int hash_type = 0;  // 0 perfect one-to-one, 1 keyed one-to-one
+  int64_t min_key = 0, max_key = 0;
+  int64_t entry_count = 0;
+  int key_type = MI355Q_INT64;
+  bool key_nullable = false;
+  std::vector<int32_t> perfect;   // int32 slot[max-min+1], -1 empty
+  std::vector<int64_t> keyed;     // {key, payload} pairs
+};
+
+// GroupByRuntime.cpp:287-297 hash_join_idx, :311-318 _nullable
+inline int64_t hash_join_idx(const int32_t* buff, int64_t key, int64_t min_key,
+                             int64_t max_key) {
+  if (key >= min_key && key <= max_key) return buff[key - min_key];
+  return -1;
+}
+// JoinHashTableQueryRuntime.cpp:40-94 baseline_hash_join_idx_64
+inline int64_t baseline_hash_join_idx_64(const int64_t* buff, int64_t key,
+                                         size_t entry_count) {
+  if (!entry_count) return -1;
+  const uint32_t h = murmur1(&key, 8, 0) % entry_count;
+  auto slot = [&](uint32_t hh) -> int64_t {
+    const int64_t* e = buff + (size_t)hh * 2;
+    if (e[0] == key) return e[1];
+    if (e[0] == kEmptyKey64) return -2;  // kNotPresent
+    return -1;                           // kNoMatch
+  };
+  int64_t m = slot(h);
+  if (m != -1) return m;
+  uint32_t hp = (h + 1) % entry_count;
+  while (hp != h) {
+    m = slot(hp);
+    if (m != -1) return m;
+    hp = (hp + 1) % entry_count;
+  }
+  return -1;
+}
+
+// ---------------------------------------------------------------- row function
+struct ExecCtx {
+  const mi355q_plan* plan;
+  mi355q_qmd qmd;
+  std::vector<TargetDesc> ts;
+  const OrcJoin* join;
+  const int8_t* const* inner_cols;
+  int64_t inner_rows;
+};
+
+// DEF_CMP_NULLABLE (RuntimeFunctions.cpp:73-83) + toBool (>0): NULL operand -> false
+inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q, const int8_t* const* cols,
+                      int64_t pos) {
+  const auto& cd = p.cols[q.col];
+  if (type_is_fp(cd.type)) {
+    const double v = decode_dbl(cols[q.col], pos);
+    if (cd.nullable && v == kNullDouble) return false;
+    switch (q.op) {
+      case MI355Q_EQ: return v == q.fval;
+      case MI355Q_NE: return v != q.fval;
+      case MI355Q_LT: return v < q.fval;
+      case MI355Q_GT: return v > q.fval;
+      case MI355Q_LE: return v <= q.fval;
+      case MI355Q_GE: return v >= q.fval;
+    }
+    return false;
+  }
+  const int64_t v = decode_int(cols[q.col], cd.type, pos);
+  if (cd.nullable && v == int_null_of(cd.type)) return false;
+  switch (q.op) {
+    case MI355Q_EQ: return v == q.ival;
+    case MI355Q_NE: return v != q.ival;
+    case MI355Q_LT: return v < q.ival;
+    case MI355Q_GT: return v > q.ival;
+    case MI355Q_LE: return v <= q.ival;
+    case MI355Q_GE: return v >= q.ival;
+  }
+  return false;
+}
+
+// One target update into its slot(s): the agg_* call TargetExprCodegen::codegenAggregate
+// (TargetExprBuilder.cpp:470-590) would emit for 8-byte slots.
+inline void apply_target(const TargetDesc& t, int64_t* slots, const int8_t* const* cols,
+                         int64_t pos, const int8_t* const* inner_cols, int64_t inner_pos,
+                         int64_t key_val) {
+  int64_t* s = slots + t.slot;
+  if (t.agg == MI355Q_PROJECT_KEY) {
+    if (t.slot >= 0) *s = key_val;  // agg_id (RuntimeFunctions.cpp:1171)
+    return;
+  }
+  if (t.col < 0) {  // COUNT(*)
+    agg_count(s);
+    return;
+  }
+  const int8_t* col = t.table ? inner_cols[t.col] : cols[t.col];
+  const int64_t p = t.table ? inner_pos : pos;
+  if (t.arg_fp) {
+    const double v = decode_dbl(col, p);
+    switch (t.agg) {
+      case MI355Q_COUNT:
+        if (t.skip_null) {
+          if (v != kNullDouble) agg_count(s);  // agg_count_double_skip_val :1542
+        } else {
+          agg_count(s);
+        }
+        break;
+      case MI355Q_SUM:
+        if (t.skip_null) agg_sum_double_skip_val(s, v, kNullDouble);
+        else agg_sum_double(s, v);
+        break;
+      case MI355Q_AVG:
+        if (t.skip_null) {
+          agg_sum_double_skip_val(s, v, kNullDouble);
+          if (v != kNullDouble) agg_count(s + 1);
+        } else {
+          agg_sum_double(s, v);
+          agg_count(s + 1);
+        }
+        break;
+      case MI355Q_MIN:
+        if (t.skip_null) agg_min_double_skip_val(s, v, kNullDouble);
+        else agg_min_double(s, v);
+        break;
+      case MI355Q_MAX:
+        if (t.skip_null) agg_max_double_skip_val(s, v, kNullDouble);
+        else agg_max_double(s, v);
+        break;
+    }
+    return;
+  }
+  const int64_t raw = decode_int(col, t.arg_type, p);
+  const int64_t null_t = int_null_of(t.arg_type);
+  switch (t.agg) {
+    case MI355Q_COUNT:
+      if (t.skip_null) {
+        if (raw != null_t) agg_count(s);  // agg_count_skip_val :1361
+      } else {
+        agg_count(s);
+      }
+      break;
+    case MI355Q_SUM:
+    case MI355Q_AVG: {
+      if (t.skip_null) {
+        // convertNullIfAny: arg NULL -> NULL of the BIGINT sum type
+        const int64_t v = (raw == null_t) ? INT64_MIN : raw;
+        agg_sum_skip_val(s, v, INT64_MIN);
+        if (t.agg == MI355Q_AVG && v != INT64_MIN) agg_count(s + 1);
+      } else {
+        agg_sum(s, raw);
+        if (t.agg == MI355Q_AVG) agg_count(s + 1);
+      }
+      break;
+    }
+    case MI355Q_MIN:
+      // is_agg_domain_range_equivalent: skip value is the ARG type's null, sign-extended
+      if (t.skip_null) agg_min_skip_val(s, raw, null_t);
+      else agg_min(s, raw);
+      break;
+    case MI355Q_MAX:
+      if (t.skip_null) agg_max_skip_val(s, raw, null_t);
+      else agg_max(s, raw);
+      break;
+  }
+}
+
+// row_func + the loop of query_template / query_group_by_template
+// (QueryTemplateGenerator.cpp:265-549, :553-814) with pos_start = 0, pos_step = 1
+// (RuntimeFunctions.cpp:1835-1846).  Returns 0 or a HeavyDB error code.
+int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_rows,
+                     int64_t* buf) {
+  const auto& p = *c.plan;
+  const auto& q = c.qmd;
+  const int rq = q.row_size / 8;
+  const int kq = q.key_bytes / 8;
+  const bool grouped = q.desc_type != MI355Q_NON_GROUPED_AGGREGATE;
+  const int gc = grouped ? p.group_cols[0] : -1;
+  const int gtype = grouped ? p.cols[gc].type : 0;
+  const bool gnullable = grouped ? p.cols[gc].nullable != 0 : false;
+  for (int64_t pos = 0; pos < num_rows; ++pos) {
+    bool pass = true;
+    for (int i = 0; i < p.n_quals && pass; ++i) pass = eval_qual(p, p.quals[i], cols, pos);
+    if (!pass) continue;
+    int64_t inner_pos = -1;
+    if (p.join_outer_col >= 0) {
+      const auto& jc = p.cols[p.join_outer_col];
+      const int64_t k = decode_int(cols[p.join_outer_col], jc.type, pos);
+      if (jc.nullable && k == int_null_of(jc.type)) continue;  // hash_join_idx_nullable
+      if (c.join->hash_type == 0) {
+        inner_pos = hash_join_idx(c.join->perfect.data(), k, c.join->min_key, c.join->max_key);
+      } else {
+        inner_pos = baseline_hash_join_idx_64(c.join->keyed.data(), k, c.join->entry_count);
+      }
+      if (inner_pos < 0) continue;  // INNER join: no match drops the row
+    }
+    int64_t* slots;
+    int64_t key_val = 0;
+    if (!grouped) {
+      slots = buf;
+    } else {
+      const int64_t raw_key = decode_int(cols[gc], gtype, pos);
+      key_val = raw_key;
+      if (q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
+        int64_t k = raw_key;
+        // NULL key -> max + 1 (GroupByAndAggregate.cpp:1339-1345)
+        if (gnullable && raw_key == int_null_of(gtype)) k = q.max_val + 1;
+        if (k < q.min_val || k - q.min_val >= q.entry_count) {
+          return MI355Q_ERR_OUT_OF_SLOTS;  // out-of-range key: reference UB; we flag it
+        }
+        slots = q.keyless ? get_group_value_fast_keyless(buf, k, q.min_val, rq)
+                          : get_group_value_fast(buf, k, raw_key, q.min_val, rq);
+      } else {
+        slots = get_group_value(buf, (uint32_t)q.entry_count, raw_key, q.key_width, rq);
+        if (!slots) {
+          // row_func returns -pos -> "ran out of slots" (GroupByAndAggregate.cpp:1151-1156)
+          int64_t code = -(pos + 1);
+          return (int32_t)std::max<int64_t>(code, INT32_MIN);
+        }
+      }
+      (void)kq;
+    }
+    for (const auto& t : c.ts) {
+      apply_target(t, slots, cols, pos, c.inner_cols, inner_pos, key_val);
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------- reduce
+// ResultSetStorage::reduceOneSlot (ResultSetReduction.cpp:1496-1640): the same aggregate
+// applied to the other buffer's slot, init value as skip value.
+inline void reduce_one_target(const mi355q_qmd& q, int ti, int64_t* this_slots,
+                              const int64_t* that_slots) {
+  const int s = q.target_slot[ti];
+  if (s < 0) return;
+  int64_t* a = this_slots + s;
+  const int64_t* b = that_slots + s;
+  const int64_t init = q.init_vals[s];
+  const bool fp = q.target_arg_is_fp[ti];
+  const bool skip = q.target_skip_null[ti];
+  switch (q.target_agg[ti]) {
+    case MI355Q_COUNT:
+      agg_sum(a, *b);  // AGGREGATE_ONE_COUNT
+      break;
+    case MI355Q_AVG:
+      agg_sum(a + 1, b[1]);
+      [[fallthrough]];
+    case MI355Q_SUM:
+      if (skip) {
+        if (fp) agg_sum_double_skip_val(a, bits_dbl(*b), bits_dbl(init));
+        else agg_sum_skip_val(a, *b, init);
+      } else {
+        if (fp) agg_sum_double(a, bits_dbl(*b));
+        else agg_sum(a, *b);
+      }
+      break;
+    case MI355Q_MIN:
+      if (skip) {
+        if (fp) agg_min_double_skip_val(a, bits_dbl(*b), bits_dbl(init));
+        else agg_min_skip_val(a, *b, init);
+      } else {
+        if (fp) agg_min_double(a, bits_dbl(*b));
+        else agg_min(a, *b);
+      }
+      break;
+    case MI355Q_MAX:
+      if (skip) {
+        if (fp) agg_max_double_skip_val(a, bits_dbl(*b), bits_dbl(init));
+        else agg_max_skip_val(a, *b, init);
+      } else {
+        if (fp) agg_max_double(a, bits_dbl(*b));
+        else agg_max(a, *b);
+      }
+      break;
+    default:  // non-agg projection (:1584-1632, 8-byte case)
+      if (*b != init) *a = *b;
+  }
+}
+
+// ResultSetStorage::isEmptyEntry (ResultSetIteration.cpp:2457-2492)
+inline bool is_empty_entry(const mi355q_qmd& q, const int64_t* buf, int64_t e) {
+  if (q.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return false;
+  const int64_t* row = buf + e * (q.row_size / 8);
+  if (q.keyless) {
+    return row[q.idx_target_as_key] == q.init_vals[q.idx_target_as_key];
+  }
+  if (q.key_width == 4) return *reinterpret_cast<const int32_t*>(row) == kEmptyKey32;
+  return row[0] == kEmptyKey64;
+}
+
+// ResultSetStorage::reduce (ResultSetReduction.cpp:203-383); baseline entries re-hash
+// into `this` (get_group_value_reduction, :783-826).
+int32_t reduce_buffers(const mi355q_qmd& q, int64_t* this_buf, const int64_t* that_buf) {
+  const int rq = q.row_size / 8;
+  const int kq = q.key_bytes / 8;
+  if (q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
+    for (int64_t e = 0; e < q.entry_count; ++e) {
+      if (is_empty_entry(q, that_buf, e)) continue;
+      const int64_t* that_row = that_buf + e * rq;
+      int64_t key = q.key_width == 4 ? (int64_t) * reinterpret_cast<const int32_t*>(that_row)
+                                     : that_row[0];
+      int64_t* slots = get_group_value(this_buf, (uint32_t)q.entry_count, key, q.key_width, rq);
+      if (!slots) return MI355Q_ERR_OUT_OF_SLOTS;
+      for (int t = 0; t < q.n_targets; ++t) reduce_one_target(q, t, slots, that_row + kq);
+    }
+    return 0;
+  }
+  for (int64_t e = 0; e < q.entry_count; ++e) {
+    if (is_empty_entry(q, that_buf, e)) continue;
+    int64_t* this_row = this_buf + e * rq;
+    const int64_t* that_row = that_buf + e * rq;
+    if (kq) this_row[0] = that_row[0];  // key memcpy from rhs (ResultSetReductionJIT.cpp:705-711)
+    for (int t = 0; t < q.n_targets; ++t) reduce_one_target(q, t, this_row + kq, that_row + kq);
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ================================================================ exported C API
+ORC_EXPORT uint32_t orc_murmur3(const void* key, int len, uint32_t seed) {
+  return murmur3(key, len, seed);
+}
+ORC_EXPORT uint32_t orc_murmur1(const void* key, int len, uint32_t seed) {
+  return murmur1(key, len, seed);
+}
+
+ORC_EXPORT int32_t orc_qmd_init(const mi355q_plan* plan, mi355q_qmd* out) {
+  return qmd_init(*plan, *out);
+}
+
+ORC_EXPORT void orc_init_buffer(const mi355q_qmd* q, int64_t* buf) { init_buffer(*q, buf); }
+
+// raw slot-lookup entry points for the golden traces
+ORC_EXPORT int64_t orc_get_group_value_slot(int64_t* buf, uint32_t entry_count, int64_t key,
+                                            uint32_t key_width, uint32_t row_size_quad) {
+  int64_t* p = get_group_value(buf, entry_count, key, key_width, row_size_quad);
+  return p ? (p - buf) : -1;
+}
+ORC_EXPORT int64_t orc_get_group_value_fast_slot(int64_t* buf, int64_t key, int64_t min_key,
+                                                 uint32_t row_size_quad) {
+  return get_group_value_fast(buf, key, key, min_key, row_size_quad) - buf;
+}
+
+// ---- join build (restating HashJoinRuntime.cpp:71-86,203-216 and :346-373,505-538,575-640)
+ORC_EXPORT void* orc_join_build(const void* key_col, int key_type, int key_nullable,
+                                int64_t num_rows, int64_t min_key, int64_t max_key,
+                                int prefer_baseline, int64_t max_perfect_entries,
+                                int32_t* err) {
+  auto* j = new OrcJoin();
+  j->key_type = key_type;
+  j->key_nullable = key_nullable;
+  *err = 0;
+  const int8_t* col = static_cast<const int8_t*>(key_col);
+  const int64_t null_t = int_null_of(key_type);
+  if (max_perfect_entries <= 0) max_perfect_entries = INT32_MAX;  // PerfectJoinHashTable.cpp:219
+  __int128 span = (__int128)max_key - (__int128)min_key;
+  const bool perfect_ok = !prefer_baseline && max_key >= min_key && span < max_perfect_entries;
+  if (perfect_ok) {
+    j->hash_type = 0;
+    j->min_key = min_key;
+    j->max_key = max_key;
+    j->entry_count = max_key - min_key + 1;
+    j->perfect.assign(j->entry_count, -1);  // init_hash_join_buff
+    for (int64_t i = 0; i < num_rows; ++i) {
+      const int64_t k = decode_int(col, key_type, i);
+      if (key_nullable && k == null_t) continue;  // fill_hash_join_buff_impl skips NULL
+      if (k < min_key || k > max_key) {
+        *err = MI355Q_ERR_INVALID_PLAN;
+        delete j;
+        return nullptr;
+      }
+      int32_t& slot = j->perfect[k - min_key];
+      if (slot != -1) {  // fill_one_to_one_hashtable CAS failure -> -1
+        *err = MI355Q_ERR_JOIN_NOT_ONE_TO_ONE;
+        delete j;
+        return nullptr;
+      }
+      slot = (int32_t)i;
+    }
+    return j;
+  }
+  // keyed: entry_count = 2 x max(NDV,1) (BaselineJoinHashTable.cpp:484-486); NDV == rows
+  // for a unique key column.
+  j->hash_type = 1;
+  j->entry_count = 2 * std::max<int64_t>(num_rows, 1);
+  j->keyed.resize(j->entry_count * 2);
+  for (int64_t e = 0; e < j->entry_count; ++e) {  // init_baseline_hash_join_buff
+    j->keyed[2 * e] = kEmptyKey64;
+    j->keyed[2 * e + 1] = -1;
+  }
+  for (int64_t i = 0; i < num_rows; ++i) {
+    const int64_t k = decode_int(col, key_type, i);
+    if (key_nullable && k == null_t) continue;  // GenericKeyHandler should_skip_entries
+    uint32_t h = murmur1(&k, 8, 0) % j->entry_count;  // write_baseline_hash_slot
+    uint32_t start = h;
+    bool placed = false;
+    do {
+      int64_t* e = &j->keyed[(size_t)h * 2];
+      if (e[0] == kEmptyKey64) {
+        e[0] = k;
+        e[1] = i;
+        placed = true;
+        break;
+      }
+      if (e[0] == k) {
+        if (e[1] != -1) {
+          *err = MI355Q_ERR_JOIN_NOT_ONE_TO_ONE;
+          delete j;
+          return nullptr;
+        }
+        e[1] = i;
+        placed = true;
+        break;
+      }
+      h = (h + 1) % j->entry_count;
+    } while (h != start);
+    if (!placed) {
+      *err = MI355Q_ERR_JOIN_TABLE_FULL;
+      delete j;
+      return nullptr;
+    }
+  }
+  return j;
+}
+ORC_EXPORT void orc_join_free(void* j) { delete static_cast<OrcJoin*>(j); }
+ORC_EXPORT int64_t orc_join_probe(const void* jp, int64_t key) {
+  const auto* j = static_cast<const OrcJoin*>(jp);
+  if (j->hash_type == 0) return hash_join_idx(j->perfect.data(), key, j->min_key, j->max_key);
+  return baseline_hash_join_idx_64(j->keyed.data(), key, j->entry_count);
+}
+ORC_EXPORT int32_t orc_join_info(const void* jp, int32_t* hash_type, int64_t* entry_count) {
+  const auto* j = static_cast<const OrcJoin*>(jp);
+  *hash_type = j->hash_type;
+  *entry_count = j->entry_count;
+  return 0;
+}
+ORC_EXPORT const void* orc_join_buffer(const void* jp) {
+  const auto* j = static_cast<const OrcJoin*>(jp);
+  return j->hash_type == 0 ? (const void*)j->perfect.data() : (const void*)j->keyed.data();
+}
+
+// ---- execute: kernel per fragment on `n_threads` host threads, each with a private
+// output buffer (Execute.cpp:3121-3153, one ExecutionKernel per fragment on CPU), then the
+// buffers are reduced into the first one in order (Execute.cpp:1772-1792).  Input
+// pointers are HOST pointers.  out_buf must hold qmd.entry_count * qmd.row_size bytes.
+ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
+                               const void* join, int32_t n_threads, int64_t* out_buf,
+                               mi355q_qmd* out_qmd) {
+  ExecCtx c;
+  c.plan = plan;
+  if (int e = qmd_init(*plan, c.qmd)) return e;
+  if (int e = build_targets(*plan, plan->n_group_cols > 0, c.ts)) return e;
+  for (int i = 0; i < plan->n_targets; ++i) c.ts[i].slot = c.qmd.target_slot[i];
+  c.join = static_cast<const OrcJoin*>(join);
+  c.inner_cols = reinterpret_cast<const int8_t* const*>(in->inner_col_buffers);
+  c.inner_rows = in->inner_num_rows;
+  if (plan->join_outer_col >= 0 && !c.join) return MI355Q_ERR_INVALID_PLAN;
+  if (out_qmd) *out_qmd = c.qmd;
+  const size_t quads = (size_t)c.qmd.entry_count * (c.qmd.row_size / 8);
+  n_threads = std::max(1, std::min(n_threads, std::max(1, in->n_frags)));
+
+  std::vector<std::vector<int64_t>> bufs(n_threads);
+  std::vector<int32_t> errs(n_threads, 0);
+  std::atomic<int> next_frag{0};
+  auto worker = [&](int tid) {
+    int64_t* buf = tid == 0 ? out_buf : (bufs[tid].resize(quads), bufs[tid].data());
+    init_buffer(c.qmd, buf);
+    for (;;) {
+      const int f = next_frag.fetch_add(1);
+      if (f >= in->n_frags) break;
+      const int8_t* const* cols =
+          reinterpret_cast<const int8_t* const*>(in->col_buffers + (size_t)f * plan->n_cols);
+      const int32_t e = run_fragment(c, cols, in->num_rows[f], buf);
+      if (e) {
+        errs[tid] = e;
+        break;
+      }
+    }
+  };
+  if (n_threads == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t);
+    for (auto& t : th) t.join();
+  }
+  for (int t = 0; t < n_threads; ++t)
+    if (errs[t]) return errs[t];
+  for (int t = 1; t < n_threads; ++t) {
+    if (int e = reduce_buffers(c.qmd, out_buf, bufs[t].data())) return e;
+    std::vector<int64_t>().swap(bufs[t]);
+  }
+  return 0;
+}
+
+ORC_EXPORT int32_t orc_reduce(const mi355q_qmd* q, int64_t* this_buf, const int64_t* that_buf) {
+  return reduce_buffers(*q, this_buf, that_buf);
+}
+
+ORC_EXPORT int64_t orc_row_count(const mi355q_qmd* q, const int64_t* buf) {
+  int64_t n = 0;
+  for (int64_t e = 0; e < q->entry_count; ++e) n += !is_empty_entry(*q, buf, e);
+  return n;
+}
+
+// ResultSet::getNextRow over all entries (ResultSetIteration.cpp:125-230): per non-empty
+// entry, one value per target.  AVG via pair_to_double (ResultSetBufferAccessors.h:197-227).
+ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64_t max_rows,
+                                  int64_t* ival, double* dval, int8_t* is_null,
+                                  int64_t* n_rows) {
+  const int rq = q->row_size / 8;
+  const int kq = q->key_bytes / 8;
+  int64_t n = 0;
+  for (int64_t e = 0; e < q->entry_count && n < max_rows; ++e) {
+    if (is_empty_entry(*q, buf, e)) continue;
+    const int64_t* row = buf + e * rq;
+    for (int t = 0; t < q->n_targets; ++t) {
+      const size_t o = (size_t)n * q->n_targets + t;
+      ival[o] = 0;
+      dval[o] = 0;
+      is_null[o] = 0;
+      const int s = q->target_slot[t];
+      if (q->target_agg[t] == MI355Q_PROJECT_KEY && s < 0) {
+        ival[o] = q->key_width == 4 ? (int64_t) * reinterpret_cast<const int32_t*>(row) : row[0];
+        is_null[o] = ival[o] == q->target_null[t];
+        continue;
+      }
+      const int64_t v = row[kq + s];
+      switch (q->target_agg[t]) {
+        case MI355Q_AVG: {
+          const int64_t cnt = row[kq + s + 1];
+          if (cnt == 0) {
+            dval[o] = kNullDouble;
+            is_null[o] = 1;
+          } else {
+            const double dividend = q->target_arg_is_fp[t] ? bits_dbl(v) : (double)v;
+            dval[o] = dividend / (double)cnt;
+          }
+          break;
+        }
+        case MI355Q_COUNT:
+          ival[o] = v;
+          break;
+        default:
+          if (q->target_is_fp[t]) {
+            dval[o] = bits_dbl(v);
+            is_null[o] = q->target_skip_null[t] && v == q->target_null[t];
+          } else {
+            ival[o] = v;
+            // ResultSet::isNull: nullable type && value == null bit pattern
+            const bool nullable =
+                q->target_skip_null[t] || q->target_agg[t] == MI355Q_PROJECT_KEY;
+            is_null[o] = nullable && v == q->target_null[t];
+          }
+      }
+    }
+    ++n;
+  }
+  *n_rows = n;
+  return 0;
+}
+
+// ---- synthetic generator: u = splitmix64(seed ^ row * golden)
+static inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+ORC_EXPORT uint64_t orc_splitmix64(uint64_t x) { return splitmix64(x); }
+
+ORC_EXPORT int32_t orc_generate_column(void* dst, int64_t n_rows, int64_t row_offset,
+                                       int32_t kind, uint64_t seed, int64_t a, int64_t b,
+                                       int64_t c, double a_f, int32_t null_every) {
+  for (int64_t i = 0; i < n_rows; ++i) {
+    const uint64_t row = (uint64_t)(row_offset + i);
+    const uint64_t u = splitmix64(seed ^ (row * 0x9E3779B97F4A7C15ull));
+    const bool is_null = null_every > 0 && (u >> 40) % (uint64_t)null_every == 0;
+    switch (kind) {
+      case MI355Q_GEN_I32_UNIFORM31:
+        static_cast<int32_t*>(dst)[i] = is_null ? INT32_MIN : (int32_t)(u >> 33);
+        break;
+      case MI355Q_GEN_I32_MOD:
+        static_cast<int32_t*>(dst)[i] =
+            is_null ? INT32_MIN : (int32_t)((int64_t)(u % (uint64_t)a) + b);
+        break;
+      case MI355Q_GEN_I64_MOD:
+        static_cast<int64_t*>(dst)[i] = is_null ? INT64_MIN : (int64_t)(u % (uint64_t)a) + b;
+        break;
+      case MI355Q_GEN_I64_MOD_MUL:
+        static_cast<int64_t*>(dst)[i] =
+            is_null ? INT64_MIN : (int64_t)(u % (uint64_t)a) * b + c;
+        break;
+      case MI355Q_GEN_F64_UNIT:
+        static_cast<double*>(dst)[i] =
+            is_null ? kNullDouble : (double)(u >> 11) * 0x1.0p-53 * a_f;
+        break;
+      default:
+        return MI355Q_ERR_INVALID_PLAN;
+    }
+  }
+  return 0;
+}

@@ -1,0 +1,246 @@
+"""ctypes wrapper of oracle/liboracle.so (and oracle/_ref/libref_runtime.so when built).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (heavydb_amd) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from heavydb_amd import capi  # struct definitions only (include/mi355q.h mirror)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+REF_LIB = os.path.join(HERE, "_ref", "libref_runtime.so")
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and, when /root/reference is present, oracle/_ref)."""
+    targets = ["all"]
+    if os.path.isdir("/root/reference/QueryEngine"):
+        targets.append("ref")
+    if force:
+        subprocess.run(["make", "-C", HERE, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", HERE] + targets, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        src = os.path.join(HERE, "oracle.cpp")
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(src):
+            build()
+        l = C.CDLL(LIB)
+        P = C.POINTER
+        l.orc_murmur3.restype = C.c_uint32
+        l.orc_murmur3.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        l.orc_murmur1.restype = C.c_uint32
+        l.orc_murmur1.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+        l.orc_qmd_init.restype = C.c_int32
+        l.orc_qmd_init.argtypes = [P(capi.Plan), P(capi.QMD)]
+        l.orc_init_buffer.restype = None
+        l.orc_init_buffer.argtypes = [P(capi.QMD), C.c_void_p]
+        l.orc_get_group_value_slot.restype = C.c_int64
+        l.orc_get_group_value_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_int64, C.c_uint32,
+                                               C.c_uint32]
+        l.orc_get_group_value_fast_slot.restype = C.c_int64
+        l.orc_get_group_value_fast_slot.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32]
+        l.orc_join_build.restype = C.c_void_p
+        l.orc_join_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
+                                     C.c_int64, C.c_int, C.c_int64, P(C.c_int32)]
+        l.orc_join_free.restype = None
+        l.orc_join_free.argtypes = [C.c_void_p]
+        l.orc_join_probe.restype = C.c_int64
+        l.orc_join_probe.argtypes = [C.c_void_p, C.c_int64]
+        l.orc_join_info.restype = C.c_int32
+        l.orc_join_info.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_int64)]
+        l.orc_join_buffer.restype = C.c_void_p
+        l.orc_join_buffer.argtypes = [C.c_void_p]
+        l.orc_execute.restype = C.c_int32
+        l.orc_execute.argtypes = [P(capi.Plan), P(capi.Inputs), C.c_void_p, C.c_int32,
+                                  C.c_void_p, P(capi.QMD)]
+        l.orc_reduce.restype = C.c_int32
+        l.orc_reduce.argtypes = [P(capi.QMD), C.c_void_p, C.c_void_p]
+        l.orc_row_count.restype = C.c_int64
+        l.orc_row_count.argtypes = [P(capi.QMD), C.c_void_p]
+        l.orc_fetch_rows.restype = C.c_int32
+        l.orc_fetch_rows.argtypes = [P(capi.QMD), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, P(C.c_int64)]
+        l.orc_splitmix64.restype = C.c_uint64
+        l.orc_splitmix64.argtypes = [C.c_uint64]
+        l.orc_generate_column.restype = C.c_int32
+        l.orc_generate_column.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                          C.c_uint64, C.c_int64, C.c_int64, C.c_int64,
+                                          C.c_double, C.c_int32]
+        _lib = l
+    return _lib
+
+
+def ref_lib() -> Optional[C.CDLL]:
+    """The reference's own runtime functions, when oracle/_ref has been built."""
+    if not os.path.exists(REF_LIB):
+        return None
+    r = C.CDLL(REF_LIB)
+    r.MurmurHash3.restype = C.c_uint32
+    r.MurmurHash3.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    r.MurmurHash1.restype = C.c_uint32
+    r.MurmurHash1.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    r.get_group_value.restype = C.c_void_p
+    r.get_group_value.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
+                                  C.c_uint32]
+    r.get_group_value_fast.restype = C.c_void_p
+    r.get_group_value_fast.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_uint32]
+    r.hash_join_idx.restype = C.c_int64
+    r.hash_join_idx.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64]
+    r.baseline_hash_join_idx_64.restype = C.c_int64
+    r.baseline_hash_join_idx_64.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+    r.fixed_width_int_decode.restype = C.c_int64
+    r.fixed_width_int_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+    r.fixed_width_double_decode.restype = C.c_double
+    r.fixed_width_double_decode.argtypes = [C.c_void_p, C.c_int64]
+    return r
+
+
+NP_DTYPE = {capi.INT8: np.int8, capi.INT16: np.int16, capi.INT32: np.int32,
+            capi.INT64: np.int64, capi.DOUBLE: np.float64}
+
+
+def murmur3(data: bytes, seed: int = 0) -> int:
+    return lib().orc_murmur3(data, len(data), seed)
+
+
+def murmur1(data: bytes, seed: int = 0) -> int:
+    return lib().orc_murmur1(data, len(data), seed)
+
+
+def qmd_init(plan: capi.Plan) -> capi.QMD:
+    q = capi.QMD()
+    code = lib().orc_qmd_init(C.byref(plan), C.byref(q))
+    if code:
+        raise capi.Mi355qError(code, "oracle qmd_init")
+    return q
+
+
+class OracleJoin:
+    def __init__(self, keys: np.ndarray, key_type: int, min_key: int, max_key: int,
+                 nullable: bool = False, prefer_baseline: bool = False,
+                 max_perfect_entries: int = 0):
+        self.keys = np.ascontiguousarray(keys, dtype=NP_DTYPE[key_type])
+        err = C.c_int32()
+        self.handle = lib().orc_join_build(self.keys.ctypes.data, key_type, int(nullable),
+                                           len(self.keys), min_key, max_key,
+                                           int(prefer_baseline), max_perfect_entries,
+                                           C.byref(err))
+        self.err = err.value
+        if not self.handle:
+            raise capi.Mi355qError(self.err, "oracle join build")
+
+    def probe(self, key: int) -> int:
+        return lib().orc_join_probe(self.handle, key)
+
+    def info(self):
+        ht, ec = C.c_int32(), C.c_int64()
+        lib().orc_join_info(self.handle, C.byref(ht), C.byref(ec))
+        return dict(hash_type=ht.value, entry_count=ec.value)
+
+    def buffer(self) -> np.ndarray:
+        i = self.info()
+        ptr = lib().orc_join_buffer(self.handle)
+        if i["hash_type"] == 0:
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)),
+                                         shape=(i["entry_count"],)).copy()
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)),
+                                     shape=(i["entry_count"], 2)).copy()
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib().orc_join_free(self.handle)
+        except Exception:
+            pass
+
+
+def execute(plan: capi.Plan, frag_cols: Sequence[Sequence[np.ndarray]],
+            inner_cols: Sequence[np.ndarray] = (), join: Optional[OracleJoin] = None,
+            n_threads: int = 1) -> Tuple[capi.QMD, np.ndarray, int]:
+    """Run the step on host numpy columns.  Returns (qmd, buffer[entry_count,row_quads],
+    code)."""
+    q = qmd_init(plan)
+    n_frags = len(frag_cols)
+    n_cols = plan.n_cols
+    flat = (C.c_void_p * max(1, n_frags * n_cols))()
+    keep = []
+    rows = (C.c_int64 * max(1, n_frags))()
+    for f, cols in enumerate(frag_cols):
+        assert len(cols) == n_cols
+        for c, a in enumerate(cols):
+            a = np.ascontiguousarray(a, dtype=NP_DTYPE[plan.cols[c].type])
+            keep.append(a)
+            flat[f * n_cols + c] = a.ctypes.data
+        rows[f] = len(cols[0]) if cols else 0
+    inner = (C.c_void_p * max(1, len(inner_cols)))()
+    for c, a in enumerate(inner_cols):
+        a = np.ascontiguousarray(a, dtype=NP_DTYPE[plan.inner_cols[c].type])
+        keep.append(a)
+        inner[c] = a.ctypes.data
+    inp = capi.Inputs()
+    inp.device_id = -1
+    inp.n_frags = n_frags
+    inp.col_buffers = C.cast(flat, C.POINTER(C.c_void_p))
+    inp.num_rows = C.cast(rows, C.POINTER(C.c_int64))
+    inp.inner_col_buffers = C.cast(inner, C.POINTER(C.c_void_p))
+    inp.inner_num_rows = len(inner_cols[0]) if len(inner_cols) else 0
+    buf = np.empty((q.entry_count, q.row_size // 8), dtype=np.int64)
+    out_q = capi.QMD()
+    code = lib().orc_execute(C.byref(plan), C.byref(inp), join.handle if join else None,
+                             n_threads, buf.ctypes.data, C.byref(out_q))
+    return out_q, buf, code
+
+
+def init_buffer(q: capi.QMD) -> np.ndarray:
+    buf = np.empty((q.entry_count, q.row_size // 8), dtype=np.int64)
+    lib().orc_init_buffer(C.byref(q), buf.ctypes.data)
+    return buf
+
+
+def reduce(q: capi.QMD, this_buf: np.ndarray, that_buf: np.ndarray) -> int:
+    assert this_buf.flags.c_contiguous and that_buf.flags.c_contiguous
+    return lib().orc_reduce(C.byref(q), this_buf.ctypes.data, that_buf.ctypes.data)
+
+
+def row_count(q: capi.QMD, buf: np.ndarray) -> int:
+    return lib().orc_row_count(C.byref(q), buf.ctypes.data)
+
+
+def fetch_rows(q: capi.QMD, buf: np.ndarray):
+    n = row_count(q, buf)
+    nt = q.n_targets
+    ival = np.zeros((max(n, 1), nt), dtype=np.int64)
+    dval = np.zeros((max(n, 1), nt), dtype=np.float64)
+    nul = np.zeros((max(n, 1), nt), dtype=np.int8)
+    got = C.c_int64()
+    lib().orc_fetch_rows(C.byref(q), buf.ctypes.data, n, ival.ctypes.data, dval.ctypes.data,
+                         nul.ctypes.data, C.byref(got))
+    return ival[:got.value], dval[:got.value], nul[:got.value]
+
+
+def generate_column(n_rows: int, kind: int, seed: int, a: int = 0, b: int = 0, c: int = 0,
+                    a_f: float = 0.0, null_every: int = 0, row_offset: int = 0) -> np.ndarray:
+    dt = {capi.GEN_I32_UNIFORM31: np.int32, capi.GEN_I32_MOD: np.int32,
+          capi.GEN_I64_MOD: np.int64, capi.GEN_I64_MOD_MUL: np.int64,
+          capi.GEN_F64_UNIT: np.float64}[kind]
+    out = np.empty(n_rows, dtype=dt)
+    code = lib().orc_generate_column(out.ctypes.data, n_rows, row_offset, kind, seed, a, b, c,
+                                     a_f, null_every)
+    assert code == 0
+    return out

@@ -1,0 +1,145 @@
+"""Pin oracle/oracle.cpp to the reference: golden vectors generated from the reference's own
+sources (tests/golden/ref_vectors.json, oracle/gen_golden.py), the SURVEY (c') literals, and
+— when oracle/_ref is present — the reference functions themselves, live."""
+import ctypes as C
+import struct
+
+import numpy as np
+import pytest
+
+EMPTY64 = 2**63 - 1
+EMPTY32 = 2**31 - 1
+
+
+def test_murmur_golden(oracle, golden):
+    for h in golden["hashes"]:
+        b = bytes.fromhex(h["hex"])
+        seed = h.get("seed", 0)
+        assert oracle.murmur3(b, seed) == h["m3"], h
+        assert oracle.murmur1(b, seed) == h["m1"], h
+
+
+def test_murmur_survey_literals(oracle):
+    # SURVEY.md section 8(c'): values produced from the reference sources
+    lit = {0: (1669671676, 533107803), 1: (1392991556, 2619614180), 7: (4157363267, 3494347355),
+           42: (1871679806, 575224328), 1000: (2827443468, 3092276255),
+           1000010: (3537811470, 3303879907), 10000029000004: (4167831984, 3923777440),
+           -1: (1651860712, 1905253887), 2**40: (2851483426, 2855848196)}
+    for k, (m3, m1) in lit.items():
+        b = struct.pack("<q", k)
+        assert oracle.murmur3(b) == m3 and oracle.murmur1(b) == m1
+    assert oracle.murmur3(struct.pack("<i", 0)) == 593689054  # canonical MurmurHash3_x86_32
+    assert oracle.murmur3(struct.pack("<qq", 3, 5)) == 2388078947
+    assert oracle.murmur1(struct.pack("<qq", 3, 5)) == 2049968836
+
+
+def _baseline_run(oracle, tr):
+    n, kw, rq = tr["entry_count"], tr["key_width"], tr["row_quad"]
+    buf = np.zeros(n * rq, dtype=np.int64)
+    for e in range(n):
+        if kw == 8:
+            buf[e * rq] = EMPTY64
+        else:
+            buf[e * rq:e * rq + 1].view(np.int32)[0] = EMPTY32
+    landed = []
+    for k in tr["keys"]:
+        s = oracle.lib().orc_get_group_value_slot(buf.ctypes.data, n, k, kw, rq)
+        landed.append(int(s))
+        if s >= 0:
+            buf[s] += 1
+    return landed, [int(x) for x in buf]
+
+
+def test_baseline_groupby_traces(oracle, golden):
+    for tr in golden["baseline_traces"]:
+        landed, final = _baseline_run(oracle, tr)
+        assert landed == tr["slot_quads"]
+        assert final == tr["final"]
+    # SURVEY (c') literal: keys 10,20,30,10,40,50,20,60 in 8 entries
+    tr = golden["baseline_traces"][0]
+    assert [q // 2 for q in tr["slot_quads"]] == [4, 3, 5, 4, 6, 0, 3, 7]
+
+
+def test_perfect_groupby_traces(oracle, golden):
+    for tr in golden["perfect_traces"]:
+        rq = tr["row_quad"]
+        buf = np.zeros(tr["entries"] * rq, dtype=np.int64)
+        buf[0::rq] = EMPTY64
+        for k in tr["keys"]:
+            s = oracle.lib().orc_get_group_value_fast_slot(buf.ctypes.data, k, tr["min_key"], rq)
+            buf[s] += k
+        assert [int(x) for x in buf] == tr["final"]
+
+
+def test_perfect_join_probe(oracle, golden):
+    pj = golden["perfect_join"]
+    j = oracle.OracleJoin(np.array([3, 1, 4], dtype=np.int64), 4, pj["min"], pj["max"])
+    assert j.info()["hash_type"] == 0
+    assert [int(x) for x in j.buffer()] == pj["table"]
+    assert [j.probe(k) for k in pj["probes"]] == pj["idx"]
+
+
+def test_keyed_join_build_and_probe(oracle, golden):
+    for kj in golden["keyed_join"][:2]:
+        keys = np.array(kj["dim_keys"], dtype=np.int64)
+        # the oracle sizes keyed tables at 2 x rows like the reference (2 x NDV)
+        j = oracle.OracleJoin(keys, 4, 0, -1, prefer_baseline=True)
+        assert j.info() == {"hash_type": 1, "entry_count": kj["entry_count"]}
+        tab = j.buffer()
+        assert [int(x) for x in tab.reshape(-1)] == kj["table"]  # serial insert order == ref
+        assert [j.probe(k) for k in kj["probes"]] == kj["idx"]
+    # the two distinct "no match" values of the reference: -2 at an empty slot
+    assert golden["keyed_join"][0]["idx"][3] == -2
+
+
+def test_decoders(oracle, golden):
+    # decode through a non-grouped MIN/MAX/SUM over each width == reference decode
+    from heavydb_amd import capi
+    from heavydb_amd.executor import InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    tmap = {1: capi.INT8, 2: capi.INT16, 4: capi.INT32, 8: capi.INT64}
+    for d in golden["int_decode"]:
+        t = tmap[d["width"]]
+        vals = np.frombuffer(bytes.fromhex(d["hex"]), dtype=oracle.NP_DTYPE[t])
+        for i, want in enumerate(d["decoded"]):
+            ra = RelAlgExecutionUnit([InputColDescriptor(t)],
+                                     [TargetExpr(capi.MAX, 0)])
+            q, buf, code = oracle.execute(ra.to_plan(), [[vals[i:i + 1]]])
+            assert code == 0
+            if want == oracle.NP_DTYPE[t](np.iinfo(oracle.NP_DTYPE[t]).min):
+                continue  # equals the NULL sentinel: skipped by the non-grouped skip_val rule
+            assert int(buf[0, 0]) == want
+
+
+@pytest.mark.skipif(__import__("oracle.oracle", fromlist=["x"]).ref_lib() is None,
+                    reason="oracle/_ref not built")
+def test_live_against_reference_functions(oracle):
+    """Fuzz the restatement against the reference's own compiled functions."""
+    ref = oracle.ref_lib()
+    rng = np.random.default_rng(7)
+    for _ in range(300):
+        n = int(rng.integers(1, 33))
+        b = bytes(rng.integers(0, 256, n, dtype=np.uint8))
+        seed = int(rng.integers(0, 2**32))
+        assert oracle.murmur3(b, seed) == ref.MurmurHash3(b, n, seed)
+        assert oracle.murmur1(b, seed) == ref.MurmurHash1(b, n, seed)
+    for kw, rq, n in [(8, 4, 61), (4, 2, 128), (8, 2, 7)]:
+        ref_buf = np.zeros(n * rq, dtype=np.int64)
+        for e in range(n):
+            if kw == 8:
+                ref_buf[e * rq] = EMPTY64
+            else:
+                ref_buf[e * rq:e * rq + 1].view(np.int32)[0] = EMPTY32
+        my_buf = ref_buf.copy()
+        for k in rng.integers(-50, 50, 400):
+            k = int(k)
+            kb = np.array([k], dtype=np.int64) if kw == 8 else np.array([k, 0], dtype=np.int32)
+            p = ref.get_group_value(ref_buf.ctypes.data, n, kb.ctypes.data, 1, kw, rq)
+            s = oracle.lib().orc_get_group_value_slot(my_buf.ctypes.data, n, k, kw, rq)
+            if not p:
+                assert s == -1
+                continue
+            quad = (p - ref_buf.ctypes.data) // 8
+            assert quad == s
+            ref_buf[quad] += 1
+            my_buf[s] += 1
+        assert (ref_buf == my_buf).all()
