@@ -165,6 +165,7 @@ class JoinSpec(C.Structure):
 _P = C.POINTER
 SYMBOLS = [
     ("mi355q_abi_version", C.c_int32, []),
+    ("mi355q_abi_sizeof", C.c_int64, [C.c_int32]),
     ("mi355q_error_string", C.c_char_p, [C.c_int32]),
     ("mi355q_device_count", C.c_int32, []),
     ("mi355q_device_info", C.c_int32,
@@ -175,6 +176,7 @@ SYMBOLS = [
     ("mi355q_execute", C.c_int32,
      [_P(Plan), _P(Inputs), _P(ExecOptions), _P(C.c_void_p), _P(ExecReport)]),
     ("mi355q_result_create", C.c_int32, [_P(QMD), C.c_int32, C.c_void_p, _P(C.c_void_p)]),
+    ("mi355q_result_wrap", C.c_int32, [_P(QMD), C.c_int32, C.c_void_p, _P(C.c_void_p)]),
     ("mi355q_result_free", None, [C.c_void_p]),
     ("mi355q_result_qmd", C.c_int32, [C.c_void_p, _P(QMD)]),
     ("mi355q_result_device_ptr", C.c_void_p, [C.c_void_p]),
@@ -226,6 +228,10 @@ def load_library(path: str | None = None) -> C.CDLL:
         fn.argtypes = args
     if lib.mi355q_abi_version() != ABI_VERSION:
         raise RuntimeError("mi355q ABI version mismatch")
+    for which, st in ((1, Plan), (2, QMD), (3, Inputs), (4, ExecOptions), (5, ExecReport),
+                      (6, JoinSpec)):
+        if lib.mi355q_abi_sizeof(which) != C.sizeof(st):
+            raise RuntimeError(f"ctypes mirror of struct #{which} disagrees with the library")
     if path is None:
         _lib = lib
     return lib

@@ -1,0 +1,754 @@
+// api.cpp — the C-ABI of libmi355q (include/mi355q.h): host C++ that turns a plan into a
+// launch sequence over the HIP kernel family.  No torch, no JIT, no CUDA-compat layer.
+//
+// Shape of one call, against the reference's step executor (heavyai/heavydb):
+//   mi355q_execute ~ Executor::executeWorkUnit (Execute.cpp:2144) after fetchChunks:
+//     plan -> QueryMemoryDescriptor mirror (plan.cpp) -> output buffer init (K6/K7 analogue,
+//     QueryMemoryInitializer.cpp:1144) -> kernel family member chosen at plan time ->
+//     error code folded from one device word (QueryExecutionContext.cpp:366 copies one int32
+//     per thread; we keep a single word).
+// The result stays in HBM; nothing is copied to the host unless the caller asks.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "kernels.h"
+#include "plan.h"
+
+using namespace mq;
+
+struct mi355q_join_table {
+  int device_id = 0;
+  int hash_type = 0;  // 0 perfect one-to-one, 1 keyed one-to-one
+  int key_type = MI355Q_INT64;
+  int64_t entry_count = 0;
+  int64_t min_key = 0, max_key = 0;
+  void* buf = nullptr;
+  int64_t bytes = 0;
+  float build_ms = 0.f;
+};
+
+struct mi355q_result {
+  mi355q_qmd qmd{};
+  DevPlan dplan{};  // layout + targets for reduce / iteration kernels
+  int device_id = 0;
+  int64_t* buf = nullptr;
+  int64_t bytes = 0;
+  bool owns_buf = false;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                     \
+  do {                                                    \
+    hipError_t _e = (expr);                               \
+    if (_e != hipSuccess) {                               \
+      last_hip_error = _e;                                \
+      return _e == hipErrorOutOfMemory ? MI355Q_ERR_OUT_OF_GPU_MEM : MI355Q_ERR_HIP; \
+    }                                                     \
+  } while (0)
+
+thread_local hipError_t last_hip_error = hipSuccess;
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int cu_count_of(int dev) {
+  static std::mutex mu;
+  static int cache[64];
+  std::lock_guard<std::mutex> lk(mu);
+  if (dev < 0 || dev >= 64) return 256;
+  if (!cache[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0)
+      v = 256;
+    cache[dev] = v;
+  }
+  return cache[dev];
+}
+
+// Small pinned-free device scratch for the error word / counters, one per call.
+struct DevWord {
+  void* p = nullptr;
+  ~DevWord() {
+    if (p) (void)hipFree(p);
+  }
+};
+
+RowInit make_row_init(const mi355q_qmd& q) {
+  RowInit r{};
+  r.row_quad = q.row_size / 8;
+  const int kq = q.key_bytes / 8;
+  for (int i = 0; i < kq; ++i) {
+    // key_width 4: low word EMPTY_KEY_32, high word (padding) 0
+    r.quad[i] = q.key_width == 4 ? (int64_t)(uint32_t)kEmptyKey32 : kEmptyKey64;
+  }
+  for (int s = 0; s < q.slot_count; ++s) r.quad[kq + s] = q.init_vals[s];
+  return r;
+}
+
+int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
+  if (p.join_outer_col < 0) return MI355Q_OK;
+  if (!p.join_table || p.join_outer_col >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
+  const mi355q_col_desc& jc = p.cols[p.join_outer_col];
+  if (type_is_fp(jc.type)) return MI355Q_ERR_UNSUPPORTED;
+  const mi355q_join_table* jt = p.join_table;
+  d->join_col = p.join_outer_col;
+  d->join_type = jc.type;
+  d->join_nullable = jc.nullable != 0;
+  d->join_hash_type = jt->hash_type;
+  d->join_buf = jt->buf;
+  d->join_min = jt->min_key;
+  d->join_max = jt->max_key;
+  d->join_entries = jt->entry_count;
+  for (int i = 0; i < p.n_inner_cols; ++i) {
+    d->inner_cols[i] = in && in->inner_col_buffers ? (const int8_t*)in->inner_col_buffers[i] : nullptr;
+  }
+  for (int i = 0; i < p.n_targets; ++i) {
+    if (d->targets[i].table == 1 && d->targets[i].col >= 0 && !d->inner_cols[d->targets[i].col])
+      return MI355Q_ERR_INVALID_PLAN;
+  }
+  return MI355Q_OK;
+}
+
+int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
+  // every distinct outer column the plan touches is read once per row
+  bool used[MI355Q_MAX_COLS] = {false};
+  for (int i = 0; i < p.n_quals; ++i) used[p.quals[i].col] = true;
+  if (p.n_group_cols) used[p.group_cols[0]] = true;
+  if (p.join_outer_col >= 0) used[p.join_outer_col] = true;
+  for (int i = 0; i < p.n_targets; ++i) {
+    if (p.targets[i].table == 0 && p.targets[i].col >= 0 && p.targets[i].agg != MI355Q_PROJECT_KEY)
+      used[p.targets[i].col] = true;
+  }
+  int64_t per_row = 0;
+  for (int c = 0; c < p.n_cols; ++c) {
+    if (used[c]) per_row += type_width(p.cols[c].type);
+  }
+  int64_t rows = 0;
+  for (int f = 0; f < in.n_frags; ++f) rows += in.num_rows[f];
+  return per_row * rows;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mi355q_abi_version(void) { return MI355Q_ABI_VERSION; }
+
+int64_t mi355q_abi_sizeof(int32_t which) {
+  switch (which) {
+    case 1: return sizeof(mi355q_plan);
+    case 2: return sizeof(mi355q_qmd);
+    case 3: return sizeof(mi355q_inputs);
+    case 4: return sizeof(mi355q_exec_options);
+    case 5: return sizeof(mi355q_exec_report);
+    case 6: return sizeof(mi355q_join_spec);
+    default: return -1;
+  }
+}
+
+const char* mi355q_error_string(int32_t code) {
+  if (code < 0) return "ran out of group slots (negative row position): resize and retry";
+  switch (code) {
+    case MI355Q_OK: return "No Error";
+    case MI355Q_ERR_DIV_BY_ZERO: return "Division by zero";
+    case MI355Q_ERR_OUT_OF_GPU_MEM: return "Out of GPU memory";
+    case MI355Q_ERR_OUT_OF_SLOTS: return "Out of Slots";
+    case MI355Q_ERR_OUT_OF_CPU_MEM: return "Not enough host memory to execute the query";
+    case MI355Q_ERR_OVERFLOW_OR_UNDERFLOW: return "Overflow or underflow";
+    case MI355Q_ERR_OUT_OF_TIME: return "Query execution has exceeded the time limit";
+    case MI355Q_ERR_INTERRUPTED: return "Query execution has been interrupted";
+    case MI355Q_ERR_INVALID_PLAN: return "Invalid plan";
+    case MI355Q_ERR_UNSUPPORTED: return "Plan shape not supported by this kernel family";
+    case MI355Q_ERR_HIP: return hipGetErrorString(last_hip_error);
+    case MI355Q_ERR_JOIN_NOT_ONE_TO_ONE: return "Join key column is not unique (one-to-many)";
+    case MI355Q_ERR_JOIN_TABLE_FULL: return "Keyed join hash table is full";
+    default: return "Unknown error";
+  }
+}
+
+int32_t mi355q_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int32_t mi355q_device_info(int32_t device_id, char* name, int32_t* cu_count, int64_t* total_mem,
+                           int64_t* free_mem, int32_t* mem_clock_khz, int32_t* mem_bus_width) {
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  if (name) {
+    std::snprintf(name, 256, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (mem_clock_khz) *mem_clock_khz = prop.memoryClockRate;
+  if (mem_bus_width) *mem_bus_width = prop.memoryBusWidth;
+  DeviceGuard g(device_id);
+  size_t fr = 0, tot = 0;
+  HIP_TRY(hipMemGetInfo(&fr, &tot));
+  if (total_mem) *total_mem = (int64_t)tot;
+  if (free_mem) *free_mem = (int64_t)fr;
+  return MI355Q_OK;
+}
+
+int32_t mi355q_qmd_init(const mi355q_plan* plan, mi355q_qmd* out) {
+  if (!plan || !out) return MI355Q_ERR_INVALID_PLAN;
+  return qmd_init(*plan, out);
+}
+
+int64_t mi355q_qmd_buffer_bytes(const mi355q_qmd* qmd) {
+  return qmd ? qmd->entry_count * (int64_t)qmd->row_size : 0;
+}
+
+static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
+                                  mi355q_result** out);
+
+int32_t mi355q_result_create(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
+                             mi355q_result** out) {
+  if (int32_t e = result_create_impl(qmd, device_id, device_buffer, out)) return e;
+  DeviceGuard g(device_id);
+  hipError_t he = launch_init_buffer((*out)->buf, qmd->entry_count, make_row_init(*qmd), nullptr);
+  if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+  if (he != hipSuccess) {
+    last_hip_error = he;
+    mi355q_result_free(*out);
+    *out = nullptr;
+    return MI355Q_ERR_HIP;
+  }
+  return MI355Q_OK;
+}
+
+int32_t mi355q_result_wrap(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
+                           mi355q_result** out) {
+  if (!device_buffer) return MI355Q_ERR_INVALID_PLAN;
+  return result_create_impl(qmd, device_id, device_buffer, out);
+}
+
+static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
+                                  mi355q_result** out) {
+  if (!qmd || !out || qmd->row_size <= 0 || qmd->entry_count <= 0) return MI355Q_ERR_INVALID_PLAN;
+  DeviceGuard g(device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  auto* r = new (std::nothrow) mi355q_result();
+  if (!r) return MI355Q_ERR_OUT_OF_CPU_MEM;
+  r->qmd = *qmd;
+  r->device_id = device_id;
+  r->bytes = qmd->entry_count * (int64_t)qmd->row_size;
+  // layout-only device plan (targets for reduce/iteration)
+  DevPlan& d = r->dplan;
+  std::memset(&d, 0, sizeof(d));
+  d.n_targets = qmd->n_targets;
+  for (int i = 0; i < qmd->n_targets; ++i) {
+    DevTarget& t = d.targets[i];
+    t.agg = qmd->target_agg[i];
+    t.col = -1;
+    t.skip_null = qmd->target_skip_null[i];
+    t.slot = qmd->target_slot[i];
+    t.arg_fp = qmd->target_arg_is_fp[i];
+  }
+  d.slot_count = qmd->slot_count;
+  d.desc_type = qmd->desc_type;
+  d.keyless = qmd->keyless;
+  d.key_width = qmd->key_width;
+  d.row_quad = qmd->row_size / 8;
+  d.key_quad = qmd->key_bytes / 8;
+  d.entry_count = qmd->entry_count;
+  d.min_val = qmd->min_val;
+  d.max_val = qmd->max_val;
+  d.join_col = -1;
+  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) d.init_vals[i] = qmd->init_vals[i];
+  if (device_buffer) {
+    r->buf = (int64_t*)device_buffer;
+  } else {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)r->bytes);
+    if (e != hipSuccess) {
+      last_hip_error = e;
+      delete r;
+      return MI355Q_ERR_OUT_OF_GPU_MEM;
+    }
+    r->buf = (int64_t*)p;
+    r->owns_buf = true;
+  }
+  *out = r;
+  return MI355Q_OK;
+}
+
+void mi355q_result_free(mi355q_result* r) {
+  if (!r) return;
+  if (r->owns_buf && r->buf) {
+    DeviceGuard g(r->device_id);
+    (void)hipFree(r->buf);
+  }
+  delete r;
+}
+
+int32_t mi355q_result_qmd(const mi355q_result* r, mi355q_qmd* out) {
+  if (!r || !out) return MI355Q_ERR_INVALID_PLAN;
+  *out = r->qmd;
+  return MI355Q_OK;
+}
+void* mi355q_result_device_ptr(const mi355q_result* r) { return r ? r->buf : nullptr; }
+int64_t mi355q_result_bytes(const mi355q_result* r) { return r ? r->bytes : 0; }
+
+int32_t mi355q_result_copy_to_host(const mi355q_result* r, void* dst, int64_t dst_bytes) {
+  if (!r || !dst || dst_bytes < r->bytes) return MI355Q_ERR_INVALID_PLAN;
+  DeviceGuard g(r->device_id);
+  HIP_TRY(hipMemcpy(dst, r->buf, (size_t)r->bytes, hipMemcpyDeviceToHost));
+  return MI355Q_OK;
+}
+
+static int32_t run_reduce(mi355q_result* dst, const int64_t* rows, int64_t n_rows, void* stream) {
+  DeviceGuard g(dst->device_id);
+  DevWord err;
+  HIP_TRY(hipMalloc(&err.p, sizeof(int32_t)));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(err.p, 0, sizeof(int32_t), s));
+  HIP_TRY(launch_reduce(dst->dplan, dst->qmd.idx_target_as_key, dst->buf, rows, n_rows,
+                        (int32_t*)err.p, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return h_err;
+}
+
+int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_rs, void* stream) {
+  if (!this_rs || !that_rs) return MI355Q_ERR_INVALID_PLAN;
+  const mi355q_qmd& a = this_rs->qmd;
+  const mi355q_qmd& b = that_rs->qmd;
+  if (a.desc_type != b.desc_type || a.row_size != b.row_size || a.slot_count != b.slot_count ||
+      a.keyless != b.keyless || a.key_width != b.key_width ||
+      this_rs->device_id != that_rs->device_id) {
+    return MI355Q_ERR_INVALID_PLAN;
+  }
+  if (a.desc_type != MI355Q_GROUP_BY_BASELINE_HASH && a.entry_count != b.entry_count)
+    return MI355Q_ERR_INVALID_PLAN;
+  return run_reduce(this_rs, that_rs->buf, b.entry_count, stream);
+}
+
+int64_t mi355q_result_row_count(const mi355q_result* r) {
+  if (!r) return -1;
+  if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return 1;
+  DeviceGuard g(r->device_id);
+  DevWord cnt;
+  if (hipMalloc(&cnt.p, sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (launch_count_nonempty(r->dplan, r->qmd.idx_target_as_key, r->buf,
+                            (unsigned long long*)cnt.p, nullptr) != hipSuccess)
+    return -1;
+  unsigned long long h = 0;
+  if (hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)h;
+}
+
+// Host-side iteration over the copied-back buffer, like ResultSet::getNextRow
+// (ResultSetIteration.cpp:125-230, getTargetValueFromBufferRowwise) for 8-byte slots.
+int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival,
+                                 double* dval, int8_t* is_null, int64_t* n_rows) {
+  if (!r || !ival || !dval || !is_null || !n_rows) return MI355Q_ERR_INVALID_PLAN;
+  const mi355q_qmd& q = r->qmd;
+  std::vector<int64_t> host;
+  try {
+    host.resize((size_t)(r->bytes / 8));
+  } catch (...) {
+    return MI355Q_ERR_OUT_OF_CPU_MEM;
+  }
+  if (int32_t e = mi355q_result_copy_to_host(r, host.data(), r->bytes)) return e;
+  const int rq = q.row_size / 8, kq = q.key_bytes / 8, nt = q.n_targets;
+  int64_t n = 0;
+  for (int64_t e = 0; e < q.entry_count && n < max_rows; ++e) {
+    const int64_t* row = host.data() + e * rq;
+    bool empty = false;
+    if (q.desc_type != MI355Q_NON_GROUPED_AGGREGATE) {
+      if (q.keyless) {
+        empty = row[q.idx_target_as_key] == q.init_vals[q.idx_target_as_key];
+      } else if (q.key_width == 4) {
+        empty = *(const int32_t*)row == kEmptyKey32;
+      } else {
+        empty = row[0] == kEmptyKey64;
+      }
+    }
+    if (empty) continue;
+    for (int t = 0; t < nt; ++t) {
+      const size_t o = (size_t)n * nt + t;
+      ival[o] = 0;
+      dval[o] = 0.0;
+      is_null[o] = 0;
+      const int s = q.target_slot[t];
+      const int agg = q.target_agg[t];
+      if (agg == MI355Q_PROJECT_KEY && s < 0) {
+        ival[o] = q.key_width == 4 ? (int64_t) * (const int32_t*)row : row[0];
+        is_null[o] = ival[o] == q.target_null[t];
+        continue;
+      }
+      const int64_t v = row[kq + s];
+      if (agg == MI355Q_AVG) {
+        const int64_t cnt = row[kq + s + 1];
+        if (cnt == 0) {  // pair_to_double: count 0 -> NULL_DOUBLE
+          dval[o] = kNullDouble;
+          is_null[o] = 1;
+        } else {
+          dval[o] = (q.target_arg_is_fp[t] ? bits_dbl(v) : (double)v) / (double)cnt;
+        }
+      } else if (agg == MI355Q_COUNT) {
+        ival[o] = v;
+      } else if (q.target_is_fp[t]) {
+        dval[o] = bits_dbl(v);
+        is_null[o] = q.target_skip_null[t] && v == q.target_null[t];
+      } else {
+        ival[o] = v;
+        const bool nullable = q.target_skip_null[t] || agg == MI355Q_PROJECT_KEY;
+        is_null[o] = nullable && v == q.target_null[t];
+      }
+    }
+    ++n;
+  }
+  *n_rows = n;
+  return MI355Q_OK;
+}
+
+// ------------------------------------------------------------------------------- execute
+int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
+                       const mi355q_exec_options* opts, mi355q_result** out,
+                       mi355q_exec_report* report) {
+  if (!plan || !in || !out) return MI355Q_ERR_INVALID_PLAN;
+  if (in->n_frags < 0 || (in->n_frags > 0 && (!in->col_buffers || !in->num_rows)))
+    return MI355Q_ERR_INVALID_PLAN;
+  *out = nullptr;
+  mi355q_exec_options o{};
+  if (opts) o = *opts;
+
+  mi355q_qmd q;
+  if (int32_t e = qmd_init(*plan, &q)) return e;
+  DevPlan d;
+  if (int32_t e = build_dev_plan(*plan, q, &d)) return e;
+  if (int32_t e = attach_join(*plan, in, &d)) return e;
+
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  const int n_cus = cu_count_of(in->device_id);
+
+  // stream: caller's, or a library-owned one for this call
+  hipStream_t s = (hipStream_t)o.stream;
+  bool own_stream = false;
+  if (!s) {
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    own_stream = true;
+  }
+  struct StreamGuard {
+    hipStream_t s;
+    bool own;
+    ~StreamGuard() {
+      if (own) (void)hipStreamDestroy(s);
+    }
+  } sg{s, own_stream};
+
+  mi355q_result* res = nullptr;
+  if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;
+  struct ResGuard {
+    mi355q_result* r;
+    ~ResGuard() { mi355q_result_free(r); }
+  } rg{res};
+
+  // device copies of the fragment tables + error word, one allocation
+  const int nf = in->n_frags, nc = plan->n_cols;
+  int64_t total_rows = 0, max_frag_rows = 0;
+  for (int f = 0; f < nf; ++f) {
+    if (in->num_rows[f] < 0) return MI355Q_ERR_INVALID_PLAN;
+    total_rows += in->num_rows[f];
+    max_frag_rows = std::max(max_frag_rows, in->num_rows[f]);
+  }
+  const size_t ptr_bytes = sizeof(void*) * (size_t)std::max(1, nf * nc);
+  const size_t rows_bytes = sizeof(int64_t) * (size_t)std::max(1, nf);
+  const size_t meta_bytes = ptr_bytes + rows_bytes + 64;
+  DevWord meta;
+  HIP_TRY(hipMalloc(&meta.p, meta_bytes));
+  char* mp = (char*)meta.p;
+  const int8_t* const* d_cols = (const int8_t* const*)mp;
+  const int64_t* d_rows = (const int64_t*)(mp + ptr_bytes);
+  int32_t* d_err = (int32_t*)(mp + ptr_bytes + rows_bytes);
+  HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
+  if (nf > 0) {
+    HIP_TRY(hipMemcpyAsync(mp, in->col_buffers, sizeof(void*) * (size_t)(nf * nc),
+                           hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(mp + ptr_bytes, in->num_rows, sizeof(int64_t) * (size_t)nf,
+                           hipMemcpyHostToDevice, s));
+  }
+
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  LaunchStats st;
+  constexpr int kEvPool = 128;
+  std::vector<hipEvent_t> ev_pool;
+  struct PoolGuard {
+    std::vector<hipEvent_t>& v;
+    ~PoolGuard() {
+      for (hipEvent_t e : v) (void)hipEventDestroy(e);
+    }
+  } pg{ev_pool};
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev_start));
+    HIP_TRY(hipEventCreate(&ev_stop));
+    HIP_TRY(hipEventCreate(&st.k_start));
+    HIP_TRY(hipEventCreate(&st.k_stop));
+    for (int i = 0; i < kEvPool; ++i) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      ev_pool.push_back(e);
+    }
+    st.ev_pool = ev_pool.data();
+    st.n_ev = kEvPool;
+  }
+  struct EvGuard {
+    hipEvent_t a, b, c, d;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+      if (c) (void)hipEventDestroy(c);
+      if (d) (void)hipEventDestroy(d);
+    }
+  } eg{ev_start, ev_stop, st.k_start, st.k_stop};
+
+  FragView fv{d_cols, d_rows, in->col_buffers, in->num_rows, nf, nc, total_rows, max_frag_rows};
+
+  // ---- plan-time kernel selection (a fixed family; no JIT)
+  enum { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM } kind = K_GENERIC;
+  if (!o.force_generic && nf > 0) {
+    if (scan_count_eligible(d, fv)) kind = K_SCAN_COUNT;
+    else if (perfect_lds_eligible(d, fv)) kind = K_PERFECT_LDS;
+    else if (baseline_fast_eligible(d, fv)) kind = K_BASELINE_FAST;
+    else if (join_sum_eligible(d, fv)) kind = K_JOIN_SUM;
+  }
+
+  DevWord scratch;
+  int64_t scratch_bytes = 0;
+  if (kind == K_BASELINE_FAST) {
+    scratch_bytes = baseline_fast_scratch_bytes(d, fv, o.kernel_variant, o.scratch_bytes, n_cus);
+    if (scratch_bytes > 0) {
+      hipError_t e = hipMalloc(&scratch.p, (size_t)scratch_bytes);
+      if (e != hipSuccess) {
+        last_hip_error = e;
+        return MI355Q_ERR_OUT_OF_GPU_MEM;
+      }
+    }
+  }
+
+  if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
+  HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+
+  if (nf > 0) {
+    switch (kind) {
+      case K_SCAN_COUNT:
+        HIP_TRY(launch_scan_count(d, fv, res->buf, n_cus, s, &st));
+        break;
+      case K_PERFECT_LDS:
+        HIP_TRY(launch_perfect_lds(d, fv, res->buf, d_err, n_cus, s, &st));
+        break;
+      case K_BASELINE_FAST:
+        HIP_TRY(launch_baseline_fast(d, fv, res->buf, d_err, scratch.p, scratch_bytes,
+                                     o.scratch_bytes, o.kernel_variant, n_cus, s, &st));
+        break;
+      case K_JOIN_SUM:
+        HIP_TRY(launch_join_sum(d, fv, res->buf, n_cus, s, &st));
+        break;
+      default:
+        st.kernel_name = "k_generic";
+        st.n_launches = 1;
+        if (st.k_start) HIP_TRY(hipEventRecord(st.k_start, s));
+        HIP_TRY(launch_generic(d, d_cols, d_rows, nf, max_frag_rows, res->buf, d_err, n_cus, s));
+        if (st.k_stop) HIP_TRY(hipEventRecord(st.k_stop, s));
+    }
+  }
+  if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
+
+  int32_t h_err[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  unsigned long long h_spills = 0;
+  if (st.spill_counter) {
+    HIP_TRY(hipMemcpyAsync(&h_spills, st.spill_counter, sizeof(h_spills), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  st.spilled_rows = (int64_t)h_spills;
+
+  if (report) {
+    std::memset(report, 0, sizeof(*report));
+    std::snprintf(report->kernel_name, sizeof(report->kernel_name), "%s",
+                  st.kernel_name ? st.kernel_name : "");
+    (void)hipEventElapsedTime(&report->total_ms, ev_start, ev_stop);
+    if (st.n_events_used > 0) {
+      float acc = 0.f;
+      for (int i = 0; i + 1 < st.n_events_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) acc += ms;
+      }
+      report->kernel_ms = acc;
+    } else if (st.n_launches > 0 && nf > 0) {
+      if (hipEventElapsedTime(&report->kernel_ms, st.k_start, st.k_stop) != hipSuccess)
+        report->kernel_ms = 0.f;
+    }
+    report->n_launches = st.n_launches;
+    report->variant = st.variant;
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+    report->spilled_rows = st.spilled_rows;
+  }
+  if (h_err[0]) return h_err[0];
+  rg.r = nullptr;
+  *out = res;
+  return MI355Q_OK;
+}
+
+// ------------------------------------------------------------------------------- joins
+int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream, mi355q_join_table** out) {
+  if (!spec || !out || spec->num_rows < 0) return MI355Q_ERR_INVALID_PLAN;
+  if (spec->key_type < MI355Q_INT8 || spec->key_type > MI355Q_INT64) return MI355Q_ERR_UNSUPPORTED;
+  if (spec->num_rows > (int64_t)INT32_MAX) return MI355Q_ERR_UNSUPPORTED;  // int32 row ids
+  *out = nullptr;
+  DeviceGuard g(spec->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  hipStream_t s = (hipStream_t)stream;
+  auto* jt = new (std::nothrow) mi355q_join_table();
+  if (!jt) return MI355Q_ERR_OUT_OF_CPU_MEM;
+  struct JG {
+    mi355q_join_table* j;
+    ~JG() { mi355q_join_free(j); }
+  } jg{jt};
+  jt->device_id = spec->device_id;
+  jt->key_type = spec->key_type;
+  const mi355q_range& r = spec->key_range;
+  // PerfectJoinHashTable::getInstance (PerfectJoinHashTable.cpp:168-246): perfect when the
+  // inner key range is known and max-min+1 entries fit; else keyed (HashJoin.cpp:340-372).
+  int64_t max_entries = spec->max_perfect_entries > 0 ? spec->max_perfect_entries : (int64_t)INT32_MAX;
+  bool perfect = !spec->prefer_baseline && r.valid && r.max >= r.min &&
+                 ((__int128)r.max - (__int128)r.min) < (__int128)max_entries;
+  DevWord err;
+  HIP_TRY(hipMalloc(&err.p, sizeof(int32_t)));
+  HIP_TRY(hipMemsetAsync(err.p, 0, sizeof(int32_t), s));
+  hipEvent_t e0, e1;
+  HIP_TRY(hipEventCreate(&e0));
+  HIP_TRY(hipEventCreate(&e1));
+  struct EG {
+    hipEvent_t a, b;
+    ~EG() {
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+    }
+  } eg{e0, e1};
+  HIP_TRY(hipEventRecord(e0, s));
+  if (perfect) {
+    jt->hash_type = 0;
+    jt->min_key = r.min;
+    jt->max_key = r.max;
+    jt->entry_count = r.max - r.min + 1;
+    jt->bytes = jt->entry_count * (int64_t)sizeof(int32_t);
+    hipError_t e = hipMalloc(&jt->buf, (size_t)jt->bytes);
+    if (e != hipSuccess) {
+      last_hip_error = e;
+      return MI355Q_ERR_OUT_OF_GPU_MEM;
+    }
+    HIP_TRY(hipMemsetAsync(jt->buf, 0xFF, (size_t)jt->bytes, s));  // init_hash_join_buff: -1
+    HIP_TRY(launch_join_fill_perfect((const int8_t*)spec->key_buffer, spec->key_type,
+                                     spec->key_nullable, spec->num_rows, r.min, r.max,
+                                     (int32_t*)jt->buf, (int32_t*)err.p, s));
+  } else {
+    jt->hash_type = 1;
+    jt->entry_count = 2 * std::max<int64_t>(spec->num_rows, 1);  // BaselineJoinHashTable.cpp:484
+    if (jt->entry_count > (int64_t)UINT32_MAX) return MI355Q_ERR_UNSUPPORTED;
+    jt->bytes = jt->entry_count * 16;
+    hipError_t e = hipMalloc(&jt->buf, (size_t)jt->bytes);
+    if (e != hipSuccess) {
+      last_hip_error = e;
+      return MI355Q_ERR_OUT_OF_GPU_MEM;
+    }
+    HIP_TRY(launch_join_init_baseline((int64_t*)jt->buf, jt->entry_count, s));
+    HIP_TRY(launch_join_fill_baseline((const int8_t*)spec->key_buffer, spec->key_type,
+                                      spec->key_nullable, spec->num_rows, (int64_t*)jt->buf,
+                                      jt->entry_count, (int32_t*)err.p, s));
+  }
+  HIP_TRY(hipEventRecord(e1, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  (void)hipEventElapsedTime(&jt->build_ms, e0, e1);
+  if (h_err) return h_err;
+  jg.j = nullptr;
+  *out = jt;
+  return MI355Q_OK;
+}
+
+void mi355q_join_free(mi355q_join_table* t) {
+  if (!t) return;
+  if (t->buf) {
+    DeviceGuard g(t->device_id);
+    (void)hipFree(t->buf);
+  }
+  delete t;
+}
+
+int32_t mi355q_join_info(const mi355q_join_table* t, int32_t* hash_type, int64_t* entry_count,
+                         int64_t* min_key, int64_t* max_key, void** device_ptr, int64_t* bytes,
+                         float* build_ms) {
+  if (!t) return MI355Q_ERR_INVALID_PLAN;
+  if (hash_type) *hash_type = t->hash_type;
+  if (entry_count) *entry_count = t->entry_count;
+  if (min_key) *min_key = t->min_key;
+  if (max_key) *max_key = t->max_key;
+  if (device_ptr) *device_ptr = t->buf;
+  if (bytes) *bytes = t->bytes;
+  if (build_ms) *build_ms = t->build_ms;
+  return MI355Q_OK;
+}
+
+// ------------------------------------------------------------------------------- shards
+int32_t mi355q_shard_partition(const mi355q_result* r, int32_t n_parts, void* out_rows,
+                               int64_t* part_counts_dev, void* stream) {
+  if (!r || !out_rows || !part_counts_dev || n_parts < 1 || n_parts > 256)
+    return MI355Q_ERR_INVALID_PLAN;
+  if (r->qmd.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return MI355Q_ERR_UNSUPPORTED;
+  DeviceGuard g(r->device_id);
+  DevWord cur;
+  HIP_TRY(hipMalloc(&cur.p, sizeof(int64_t) * 256));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(launch_shard_partition(r->dplan, r->qmd.idx_target_as_key, r->buf, n_parts,
+                                 (int64_t*)out_rows, part_counts_dev, (int64_t*)cur.p, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return MI355Q_OK;
+}
+
+int32_t mi355q_shard_merge_rows(mi355q_result* r, const void* rows, int64_t n_rows, void* stream) {
+  if (!r || (!rows && n_rows > 0) || n_rows < 0) return MI355Q_ERR_INVALID_PLAN;
+  if (n_rows == 0) return MI355Q_OK;
+  if (r->qmd.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return MI355Q_ERR_UNSUPPORTED;
+  return run_reduce(r, (const int64_t*)rows, n_rows, stream);
+}
+
+// ------------------------------------------------------------------------------- synth
+int32_t mi355q_generate_column(int32_t device_id, void* dst, int64_t n_rows, int64_t row_offset,
+                               int32_t kind, uint64_t seed, int64_t a, int64_t b, int64_t c,
+                               double a_f, int32_t null_every, void* stream) {
+  if (!dst || n_rows < 0 || kind < MI355Q_GEN_I32_UNIFORM31 || kind > MI355Q_GEN_F64_UNIT)
+    return MI355Q_ERR_INVALID_PLAN;
+  if ((kind == MI355Q_GEN_I32_MOD || kind == MI355Q_GEN_I64_MOD || kind == MI355Q_GEN_I64_MOD_MUL) &&
+      a <= 0)
+    return MI355Q_ERR_INVALID_PLAN;
+  DeviceGuard g(device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  HIP_TRY(launch_generate(dst, n_rows, row_offset, kind, seed, a, b, c, a_f, null_every,
+                          (hipStream_t)stream));
+  return MI355Q_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+// fast_common.h — pieces shared by the specialised kernel families (kernels_fast.hip,
+// kernels_part.hip): the 16-byte-per-lane streaming skeleton, the normalised range filter, the
+// slot programme, and the plan-time shape test.  gfx950 wave64 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "rowfunc.h"
+
+namespace mq {
+namespace fast {
+
+constexpr int kBlock = 256;
+
+struct none_t {};
+
+template <typename T>
+struct is_none { static constexpr bool value = false; };
+template <>
+struct is_none<none_t> { static constexpr bool value = true; };
+
+// ---- 4-row vector loads -------------------------------------------------------------
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef long long v2i64 __attribute__((ext_vector_type(2)));
+
+template <typename T>
+struct Quad {
+  T v[4];
+};
+template <>
+struct Quad<none_t> {};
+
+template <typename T>
+MQ_D void load_quad(const int8_t* base, int64_t quad, Quad<T>& q);
+template <>
+MQ_D void load_quad<int32_t>(const int8_t* base, int64_t quad, Quad<int32_t>& q) {
+  const v4i32 x = __builtin_nontemporal_load((const v4i32*)base + quad);
+  q.v[0] = x.x; q.v[1] = x.y; q.v[2] = x.z; q.v[3] = x.w;
+}
+template <>
+MQ_D void load_quad<int64_t>(const int8_t* base, int64_t quad, Quad<int64_t>& q) {
+  const v2i64 a = __builtin_nontemporal_load((const v2i64*)base + quad * 2);
+  const v2i64 b = __builtin_nontemporal_load((const v2i64*)base + quad * 2 + 1);
+  q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y;
+}
+template <>
+MQ_D void load_quad<double>(const int8_t* base, int64_t quad, Quad<double>& q) {
+  const v2i64 a = __builtin_nontemporal_load((const v2i64*)base + quad * 2);
+  const v2i64 b = __builtin_nontemporal_load((const v2i64*)base + quad * 2 + 1);
+  q.v[0] = bits_dbl(a.x); q.v[1] = bits_dbl(a.y);
+  q.v[2] = bits_dbl(b.x); q.v[3] = bits_dbl(b.y);
+}
+template <>
+MQ_D void load_quad<none_t>(const int8_t*, int64_t, Quad<none_t>&) {}
+
+template <typename T>
+MQ_D T load_one(const int8_t* base, int64_t pos) { return ((const T*)base)[pos]; }
+template <>
+MQ_D none_t load_one<none_t>(const int8_t*, int64_t) { return none_t{}; }
+
+template <typename T>
+MQ_D T quad_get(const Quad<T>& q, int i) { return q.v[i]; }
+template <>
+MQ_D none_t quad_get<none_t>(const Quad<none_t>&, int) { return none_t{}; }
+
+// Filter normalised at plan time to  lo <= v <= hi  (optionally negated for <>), plus the
+// NULL exclusion of DEF_CMP_NULLABLE (RuntimeFunctions.cpp:73-83).
+struct RangeFilter {
+  int64_t lo, hi;
+  int32_t negate, nullable;
+  int64_t null_val;
+  int32_t col;
+};
+template <typename T>
+MQ_D bool filter_pass(const RangeFilter& f, T v) {
+  const int64_t x = (int64_t)v;
+  bool in = x >= f.lo && x <= f.hi;
+  if (f.negate) in = !in;
+  if (f.nullable && x == f.null_val) in = false;
+  return in;
+}
+template <>
+MQ_D bool filter_pass<none_t>(const RangeFilter&, none_t) { return true; }
+
+// Streaming skeleton.  fn(frag, pos, filter_value, key, val) is called for every row; the
+// caller applies the filter (so it can count before touching other columns).
+template <typename FT, typename KT, typename VT, typename Fn>
+MQ_D void scan_fragments(const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows,
+                         int n_frags, int n_cols, int fcol, int kcol, int vcol, Fn&& fn) {
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * blockDim.x;
+  for (int f = 0; f < n_frags; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * n_cols;
+    const int8_t* fb = is_none<FT>::value ? nullptr : fc[fcol];
+    const int8_t* kb = is_none<KT>::value ? nullptr : fc[kcol];
+    const int8_t* vb = is_none<VT>::value ? nullptr : fc[vcol];
+    const int64_t n = num_rows[f];
+    const int64_t nq = n >> 2;
+    int64_t q = gtid;
+    // two quads in flight per lane for memory-level parallelism
+    for (; q + gsize < nq; q += 2 * gsize) {
+      Quad<FT> f0, f1;
+      Quad<KT> k0, k1;
+      Quad<VT> v0, v1;
+      load_quad<FT>(fb, q, f0);
+      load_quad<FT>(fb, q + gsize, f1);
+      load_quad<KT>(kb, q, k0);
+      load_quad<KT>(kb, q + gsize, k1);
+      load_quad<VT>(vb, q, v0);
+      load_quad<VT>(vb, q + gsize, v1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fn(quad_get(f0, i), quad_get(k0, i), quad_get(v0, i));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fn(quad_get(f1, i), quad_get(k1, i), quad_get(v1, i));
+    }
+    for (; q < nq; q += gsize) {
+      Quad<FT> f0;
+      Quad<KT> k0;
+      Quad<VT> v0;
+      load_quad<FT>(fb, q, f0);
+      load_quad<KT>(kb, q, k0);
+      load_quad<VT>(vb, q, v0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fn(quad_get(f0, i), quad_get(k0, i), quad_get(v0, i));
+    }
+    const int64_t tail = (nq << 2) + gtid;  // < 4 leftover rows
+    if (tail < n) {
+      fn(load_one<FT>(fb, tail), load_one<KT>(kb, tail), load_one<VT>(vb, tail));
+    }
+  }
+}
+
+MQ_D unsigned long long wave_sum_u64(unsigned long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+MQ_D long long wave_sum_i64(long long v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Slot programme shared by the LDS and baseline families: which op each 8-byte slot takes.
+enum SlotOp : int32_t { SO_COUNT = 0, SO_SUM_I = 1, SO_SUM_F = 2, SO_MIN_I = 3, SO_MAX_I = 4,
+                        SO_MIN_F = 5, SO_MAX_F = 6, SO_KEY = 7 };
+struct SlotProg {
+  int32_t n;                         // slots
+  int32_t op[MI355Q_MAX_SLOTS];
+};
+
+MQ_D void apply_slots_global(const SlotProg& sp, int64_t* slots, double fval, int64_t ival) {
+  for (int j = 0; j < sp.n; ++j) {
+    int64_t* s = slots + j;
+    switch (sp.op[j]) {
+      case SO_COUNT: atomicAdd((unsigned long long*)s, 1ull); break;
+      case SO_SUM_I: atomicAdd((unsigned long long*)s, (unsigned long long)ival); break;
+      case SO_SUM_F: atomicAdd((double*)s, fval); break;
+      case SO_MIN_I: atomicMin((long long*)s, (long long)ival); break;
+      case SO_MAX_I: atomicMax((long long*)s, (long long)ival); break;
+      case SO_MIN_F: a_minmax_f64<true, false, false>(s, fval, 0.0); break;
+      case SO_MAX_F: a_minmax_f64<true, true, false>(s, fval, 0.0); break;
+      default: break;
+    }
+  }
+}
+
+template <typename VT>
+MQ_D double as_f64(VT v) { return (double)v; }
+template <>
+MQ_D double as_f64<none_t>(none_t) { return 0.0; }
+template <typename VT>
+MQ_D int64_t as_i64(VT v) { return (int64_t)v; }
+template <>
+MQ_D int64_t as_i64<none_t>(none_t) { return 0; }
+
+// ---------------------------------------------------------------------------- host side
+inline bool all_aligned16(const FragView& fv, int col) {
+  for (int f = 0; f < fv.n_frags; ++f) {
+    if (((uintptr_t)fv.h_cols[(size_t)f * fv.n_cols + col]) & 15) return false;
+  }
+  return true;
+}
+
+// Turn `col <op> literal` on an integer column into an inclusive range (+ negate for <>).
+inline bool make_range_filter(const DevQual& q, RangeFilter* f) {
+  if (q.type != MI355Q_INT32 && q.type != MI355Q_INT64) return false;
+  f->col = q.col;
+  f->negate = 0;
+  f->nullable = q.nullable;
+  f->null_val = int_null_of(q.type);
+  const int64_t tmin = q.type == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN;
+  const int64_t tmax = q.type == MI355Q_INT32 ? (int64_t)INT32_MAX : INT64_MAX;
+  const int64_t x = q.ival;
+  switch (q.op) {
+    case MI355Q_EQ: f->lo = x; f->hi = x; break;
+    case MI355Q_NE: f->lo = x; f->hi = x; f->negate = 1; break;
+    case MI355Q_LT:
+      if (x == INT64_MIN) { f->lo = 1; f->hi = 0; } else { f->lo = tmin; f->hi = x - 1; }
+      break;
+    case MI355Q_LE: f->lo = tmin; f->hi = x; break;
+    case MI355Q_GT:
+      if (x == INT64_MAX) { f->lo = 1; f->hi = 0; } else { f->lo = x + 1; f->hi = tmax; }
+      break;
+    case MI355Q_GE: f->lo = x; f->hi = tmax; break;
+    default: return false;
+  }
+  return true;
+}
+
+inline RangeFilter no_filter() {
+  RangeFilter f{};
+  f.lo = INT64_MIN;
+  f.hi = INT64_MAX;
+  f.col = 0;
+  return f;
+}
+
+// Common shape test for the grouped fast families: at most one integer qual, every value
+// aggregate on ONE NOT NULL column of type int64/double, COUNT(*) and key projections free.
+struct FastShape {
+  int fil_type = 0;   // 0 none / MI355Q_INT32 / MI355Q_INT64
+  RangeFilter flt;
+  int vcol = -1, vtype = 0;
+  SlotProg sp;
+};
+
+inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* s) {
+  if (p.join_col >= 0 || p.n_quals > 1 || p.group_nullable) return false;
+  s->flt = no_filter();
+  if (p.n_quals == 1) {
+    if (!make_range_filter(p.quals[0], &s->flt)) return false;
+    s->fil_type = p.quals[0].type;
+    if (!all_aligned16(fv, p.quals[0].col)) return false;
+  }
+  s->sp.n = p.slot_count;
+  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) s->sp.op[i] = SO_COUNT;
+  for (int i = 0; i < p.n_targets; ++i) {
+    const DevTarget& t = p.targets[i];
+    if (t.table != 0) return false;
+    if (t.agg == MI355Q_PROJECT_KEY) {
+      if (t.slot >= 0) s->sp.op[t.slot] = SO_KEY;
+      continue;
+    }
+    if (t.agg == MI355Q_COUNT) {
+      if (t.skip_null) return false;  // COUNT(nullable col): generic path
+      s->sp.op[t.slot] = SO_COUNT;
+      continue;
+    }
+    if (t.skip_null || t.col < 0) return false;
+    if (t.arg_type != MI355Q_INT64 && t.arg_type != MI355Q_DOUBLE) return false;
+    if (s->vcol >= 0 && s->vcol != t.col) return false;
+    s->vcol = t.col;
+    s->vtype = t.arg_type;
+    const bool fp = t.arg_fp;
+    switch (t.agg) {
+      case MI355Q_SUM: s->sp.op[t.slot] = fp ? SO_SUM_F : SO_SUM_I; break;
+      case MI355Q_AVG:
+        s->sp.op[t.slot] = fp ? SO_SUM_F : SO_SUM_I;
+        s->sp.op[t.slot + 1] = SO_COUNT;
+        break;
+      case MI355Q_MIN: s->sp.op[t.slot] = fp ? SO_MIN_F : SO_MIN_I; break;
+      case MI355Q_MAX: s->sp.op[t.slot] = fp ? SO_MAX_F : SO_MAX_I; break;
+      default: return false;
+    }
+  }
+  if (s->vcol >= 0 && !all_aligned16(fv, s->vcol)) return false;
+  if (!all_aligned16(fv, p.group_col)) return false;
+  return true;
+}
+
+
+inline void rec(hipEvent_t e, hipStream_t s) {
+  if (e) (void)hipEventRecord(e, s);
+}
+
+}  // namespace fast
+}  // namespace mq

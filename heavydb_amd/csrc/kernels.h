@@ -1,0 +1,99 @@
+// kernels.h — host-callable launchers of the HIP kernel family (internal to libmi355q).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include "dev_common.h"
+
+namespace mq {
+
+struct RowInit {           // one output row image: key quads then slot init values
+  int64_t quad[1 + MI355Q_MAX_SLOTS];
+  int32_t row_quad;
+};
+
+struct LaunchStats {
+  const char* kernel_name = "";
+  int n_launches = 0;
+  int variant = 0;
+  int64_t spilled_rows = 0;
+  // events bracketing the dominant kernel(s) only (subset of the whole call)
+  hipEvent_t k_start = nullptr, k_stop = nullptr;
+  // multi-launch families: pairs (start, stop) taken from this pool, one per dominant launch
+  hipEvent_t* ev_pool = nullptr;
+  int n_ev = 0;
+  int n_events_used = 0;
+  unsigned long long* spill_counter = nullptr;  // device word (read back by the caller)
+};
+
+// ---- generic family (kernels_generic.hip)
+hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,
+                              hipStream_t s);
+hipError_t launch_generic(const DevPlan& p, const int8_t* const* d_cols,
+                          const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows,
+                          int64_t* out, int32_t* d_err, int n_cus, hipStream_t s);
+hipError_t launch_reduce(const DevPlan& p, int idx_target_as_key, int64_t* this_buf,
+                         const int64_t* that_rows, int64_t that_entries, int32_t* d_err,
+                         hipStream_t s);
+hipError_t launch_count_nonempty(const DevPlan& p, int idx_target_as_key, const int64_t* buf,
+                                 unsigned long long* d_count, hipStream_t s);
+hipError_t launch_shard_partition(const DevPlan& p, int idx_target_as_key, const int64_t* buf,
+                                  int n_parts, int64_t* out_rows, int64_t* d_part_counts,
+                                  int64_t* d_cursors /* n_parts scratch */, hipStream_t s);
+hipError_t launch_join_fill_perfect(const int8_t* keys, int type, int nullable, int64_t n,
+                                    int64_t min_key, int64_t max_key, int32_t* buf,
+                                    int32_t* d_err, hipStream_t s);
+hipError_t launch_join_init_baseline(int64_t* tab, int64_t entries, hipStream_t s);
+hipError_t launch_join_fill_baseline(const int8_t* keys, int type, int nullable, int64_t n,
+                                     int64_t* tab, int64_t entries, int32_t* d_err,
+                                     hipStream_t s);
+hipError_t launch_generate(void* dst, int64_t n_rows, int64_t row_offset, int kind,
+                           uint64_t seed, int64_t a, int64_t b, int64_t c, double a_f,
+                           int null_every, hipStream_t s);
+
+// ---- fast families (kernels_fast.hip); each returns hipErrorNotSupported-free bool
+// eligibility via the *_eligible functions, decided at plan time.
+struct FragView {
+  const int8_t* const* d_cols;  // device array [n_frags * n_cols]
+  const int64_t* d_num_rows;    // device array [n_frags]
+  const void* const* h_cols;    // host copy of the pointer table (alignment checks)
+  const int64_t* h_num_rows;
+  int n_frags;
+  int n_cols;
+  int64_t total_rows;
+  int64_t max_frag_rows;
+};
+
+bool scan_count_eligible(const DevPlan& p, const FragView& fv);
+hipError_t launch_scan_count(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus,
+                             hipStream_t s, LaunchStats* st);
+
+bool perfect_lds_eligible(const DevPlan& p, const FragView& fv);
+hipError_t launch_perfect_lds(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err,
+                              int n_cus, hipStream_t s, LaunchStats* st);
+
+bool baseline_fast_eligible(const DevPlan& p, const FragView& fv);
+// scratch: device workspace of scratch_bytes; variant selects direct-atomic (1) or
+// partitioned (2); 0 = plan-time choice.
+hipError_t launch_baseline_fast(const DevPlan& p, const FragView& fv, int64_t* out,
+                                int32_t* d_err, void* scratch, int64_t scratch_bytes,
+                                int64_t cap_bytes, int variant, int n_cus, hipStream_t s,
+                                LaunchStats* st);
+int64_t baseline_fast_scratch_bytes(const DevPlan& p, const FragView& fv, int variant,
+                                    int64_t cap_bytes, int n_cus);
+// variant resolution: 1 direct atomics, 2 partitioned, 3 partitioned + LDS write combining
+int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested);
+
+// kernels_part.hip
+int64_t part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes,
+                           bool staged);
+hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int64_t* out,
+                                       int32_t* d_err, void* scratch, int64_t scratch_bytes,
+                                       int64_t cap_bytes, bool staged, int n_cus, hipStream_t s,
+                                       LaunchStats* st);
+
+bool join_sum_eligible(const DevPlan& p, const FragView& fv);
+hipError_t launch_join_sum(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus,
+                           hipStream_t s, LaunchStats* st);
+
+}  // namespace mq

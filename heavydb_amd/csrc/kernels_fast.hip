@@ -1,0 +1,512 @@
+// kernels_fast.hip — the specialised members of the kernel family, selected at plan time.
+//
+// All of them share one streaming skeleton written for gfx950: every lane reads FOUR
+// consecutive rows of each column it needs with 16-byte loads (int32 -> one dwordx4, 8-byte
+// types -> two), a wave covers 256 consecutive rows per step, and the grid strides over
+// 4-row "quads" of each fragment (the fragment loop of multifrag_query_hoisted_literals,
+// RuntimeFunctions.cpp:2434-2471, lives inside the kernel).  Work is integer/hash/reduction:
+// HBM-bound, no MFMA.
+//
+//   scan_count     COUNT(*) WHERE col <op> k         (SURVEY cfg1)  per-lane popcount ->
+//                  wave shuffle reduce -> one atomic per block
+//   perfect_lds    GROUP BY small-range int key      (SURVEY cfg2)  per-block LDS table
+//                  (ds atomics), flushed once per block with global atomics — the reference's
+//                  shared-memory group-by idea (GpuSharedMemoryUtils.cpp) without the JIT
+//   baseline       GROUP BY high-cardinality int64   (SURVEY cfg3)  direct: global CAS insert
+//                  + atomics; partitioned: hash-partition rows into LDS-sized key ranges,
+//                  then aggregate each range in LDS and emit each group once
+//   join_sum       fact JOIN dim ... SUM/COUNT       (SURVEY cfg4)  probe fused into the scan
+#include "fast_common.h"
+
+namespace mq {
+
+using namespace fast;
+
+namespace {
+
+// =========================================================================== scan_count
+template <typename FT>
+__global__ __launch_bounds__(kBlock) void k_scan_count(const int8_t* const* __restrict__ cols,
+                                                        const int64_t* __restrict__ num_rows,
+                                                        int n_frags, int n_cols, RangeFilter flt,
+                                                        int64_t* __restrict__ out) {
+  unsigned long long cnt = 0;
+  scan_fragments<FT, none_t, none_t>(cols, num_rows, n_frags, n_cols, flt.col, 0, 0,
+                                     [&](FT fv, none_t, none_t) { cnt += filter_pass<FT>(flt, fv); });
+  cnt = wave_sum_u64(cnt);
+  __shared__ unsigned long long s_part[kBlock / 64];
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < kBlock / 64; ++i) t += s_part[i];
+    if (t) atomicAdd((unsigned long long*)out, t);
+  }
+}
+
+// =========================================================================== perfect_lds
+template <typename VT>
+MQ_D void slot_apply_lds(int op, int64_t* s, int64_t key, VT val);
+
+MQ_D void lds_minmax_f64(int64_t* s, double v, bool is_max) {
+  int64_t old = *(volatile int64_t*)s;
+  for (;;) {
+    const double o = bits_dbl(old);
+    const double r = is_max ? (o < v ? v : o) : (v < o ? v : o);
+    const int64_t nv = dbl_bits(r);
+    if (nv == old) return;
+    const int64_t seen = (int64_t)atomicCAS((unsigned long long*)s, (unsigned long long)old,
+                                            (unsigned long long)nv);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+
+template <typename VT>
+MQ_D void apply_slots(const SlotProg& sp, int64_t* slots, int64_t key, VT val) {
+  for (int j = 0; j < sp.n; ++j) {
+    int64_t* s = slots + j;
+    switch (sp.op[j]) {
+      case SO_COUNT: atomicAdd((unsigned long long*)s, 1ull); break;
+      case SO_KEY: *(volatile int64_t*)s = key; break;
+      default:
+        if constexpr (!is_none<VT>::value) {
+          switch (sp.op[j]) {
+            case SO_SUM_I: atomicAdd((unsigned long long*)s, (unsigned long long)(int64_t)val); break;
+            case SO_SUM_F: atomicAdd((double*)s, (double)val); break;
+            case SO_MIN_I: atomicMin((long long*)s, (long long)val); break;
+            case SO_MAX_I: atomicMax((long long*)s, (long long)val); break;
+            case SO_MIN_F: lds_minmax_f64(s, (double)val, false); break;
+            case SO_MAX_F: lds_minmax_f64(s, (double)val, true); break;
+          }
+        }
+    }
+  }
+}
+
+// Merge one partial slot value into a global slot (NOT NULL semantics: init is the identity).
+MQ_D void flush_slot(int op, int64_t* g, int64_t v, int64_t init) {
+  if (v == init) return;
+  switch (op) {
+    case SO_COUNT:
+    case SO_SUM_I: atomicAdd((unsigned long long*)g, (unsigned long long)v); break;
+    case SO_SUM_F: atomicAdd((double*)g, bits_dbl(v)); break;
+    case SO_MIN_I: atomicMin((long long*)g, (long long)v); break;
+    case SO_MAX_I: atomicMax((long long*)g, (long long)v); break;
+    case SO_MIN_F: a_minmax_f64<true, false, false>(g, bits_dbl(v), 0.0); break;
+    case SO_MAX_F: a_minmax_f64<true, true, false>(g, bits_dbl(v), 0.0); break;
+    default: MQ_STORE64(g, v);
+  }
+}
+
+struct PerfectArgs {
+  int64_t min_val, entry_count;
+  int32_t row_quad, key_quad;
+  int32_t kcol, vcol;
+  SlotProg sp;
+  int64_t init[MI355Q_MAX_SLOTS];
+};
+
+template <typename FT, typename KT, typename VT>
+__global__ __launch_bounds__(kBlock) void k_perfect_lds(const int8_t* const* __restrict__ cols,
+                                                         const int64_t* __restrict__ num_rows,
+                                                         int n_frags, int n_cols, RangeFilter flt,
+                                                         PerfectArgs a, int64_t* __restrict__ out,
+                                                         int32_t* __restrict__ d_err) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int64_t* tab = (int64_t*)smem_raw;
+  const int rq = a.row_quad, kq = a.key_quad;
+  const int64_t quads = a.entry_count * rq;
+  for (int64_t i = threadIdx.x; i < quads; i += kBlock) {
+    const int j = (int)(i % rq);
+    tab[i] = j < kq ? kEmptyKey64 : a.init[j - kq];
+  }
+  __syncthreads();
+  bool bad = false;
+  scan_fragments<FT, KT, VT>(cols, num_rows, n_frags, n_cols, flt.col, a.kcol, a.vcol,
+                             [&](FT fv, KT key, VT val) {
+    if (!filter_pass<FT>(flt, fv)) return;
+    const int64_t idx = (int64_t)key - a.min_val;
+    if (idx < 0 || idx >= a.entry_count) {
+      bad = true;
+      return;
+    }
+    int64_t* row = tab + idx * rq;
+    if (kq) {
+      if (*(volatile int64_t*)row == kEmptyKey64) *(volatile int64_t*)row = (int64_t)key;
+    }
+    apply_slots<VT>(a.sp, row + kq, (int64_t)key, val);
+  });
+  if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+  __syncthreads();
+  // flush: one pass over the block's table, only touched slots reach HBM
+  for (int64_t i = threadIdx.x; i < quads; i += kBlock) {
+    const int j = (int)(i % rq);
+    const int64_t v = tab[i];
+    if (j < kq) {
+      if (v != kEmptyKey64) MQ_STORE64(out + i, v);
+    } else {
+      flush_slot(a.sp.op[j - kq], out + i, v, a.init[j - kq]);
+    }
+  }
+}
+
+// =========================================================================== baseline direct
+struct BaselineArgs {
+  int64_t entry_count;
+  int32_t row_quad;
+  int32_t kcol, vcol;
+  SlotProg sp;  // slots after the key quad
+};
+
+template <typename FT, typename VT>
+__global__ __launch_bounds__(kBlock) void k_baseline_direct(const int8_t* const* __restrict__ cols,
+                                                             const int64_t* __restrict__ num_rows,
+                                                             int n_frags, int n_cols,
+                                                             RangeFilter flt, BaselineArgs a,
+                                                             int64_t* __restrict__ out,
+                                                             int32_t* __restrict__ d_err) {
+  const uint32_t ne = (uint32_t)a.entry_count;
+  bool full = false;
+  scan_fragments<FT, int64_t, VT>(cols, num_rows, n_frags, n_cols, flt.col, a.kcol, a.vcol,
+                                  [&](FT fv, int64_t key, VT val) {
+    if (!filter_pass<FT>(flt, fv)) return;
+    int64_t* slots = baseline_find_or_insert(out, ne, a.row_quad, 8, key);
+    if (!slots) {
+      full = true;
+      return;
+    }
+    apply_slots_global(a.sp, slots, as_f64<VT>(val), as_i64<VT>(val));
+  });
+  if (full) atomicCAS(d_err, 0, -1);
+}
+
+// =========================================================================== join + sum
+struct JoinSumArgs {
+  int32_t kcol, vcol;        // outer key column, outer value column (or -1)
+  int32_t n_slots;
+  int32_t op[4];             // 0 COUNT(*), 1 SUM(outer v), 2 SUM(inner w)
+  int32_t hash_type;
+  const void* table;
+  int64_t min_key, max_key, entries;
+  const int64_t* inner_w;    // inner int64 payload column (or null)
+  int64_t null_sum;          // NULL_BIGINT: the non-grouped SUM starts NULL
+};
+
+template <typename VT>
+__global__ __launch_bounds__(kBlock) void k_join_sum(const int8_t* const* __restrict__ cols,
+                                                      const int64_t* __restrict__ num_rows,
+                                                      int n_frags, int n_cols, JoinSumArgs a,
+                                                      int64_t* __restrict__ out) {
+  long long acc[4] = {0, 0, 0, 0};
+  unsigned long long contrib[4] = {0, 0, 0, 0};  // non-NULL contributions per slot
+  scan_fragments<none_t, int64_t, VT>(cols, num_rows, n_frags, n_cols, 0, a.kcol, a.vcol,
+                                      [&](none_t, int64_t key, VT val) {
+    int64_t idx;
+    if (a.hash_type == 0) {
+      idx = (key >= a.min_key && key <= a.max_key) ? ((const int32_t*)a.table)[key - a.min_key] : -1;
+    } else {
+      const int64_t* tab = (const int64_t*)a.table;
+      const uint32_t n = (uint32_t)a.entries;
+      idx = -1;
+      const uint32_t h = murmur1_u64((uint64_t)key) % n;
+      uint32_t hp = h;
+      do {
+        const int64_t k = tab[(size_t)hp * 2];
+        if (k == key) {
+          idx = tab[(size_t)hp * 2 + 1];
+          break;
+        }
+        if (k == kEmptyKey64) break;
+        hp = hp + 1 == n ? 0 : hp + 1;
+      } while (hp != h);
+    }
+    if (idx < 0) return;
+    for (int j = 0; j < a.n_slots; ++j) {
+      if (a.op[j] == 0) {
+        ++contrib[j];
+      } else {
+        // non-grouped SUM skips the NULL sentinel even on NOT NULL columns
+        // (skip_null_val forced, TargetExprBuilder.cpp:684-690)
+        const int64_t v = a.op[j] == 1 ? as_i64<VT>(val) : a.inner_w[idx];
+        if (v != a.null_sum) {
+          acc[j] += v;
+          ++contrib[j];
+        }
+      }
+    }
+  });
+  __shared__ long long s_acc[kBlock / 64][8];
+  for (int j = 0; j < 4; ++j) {
+    acc[j] = wave_sum_i64(acc[j]);
+    contrib[j] = wave_sum_u64(contrib[j]);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    for (int j = 0; j < 4; ++j) {
+      s_acc[threadIdx.x >> 6][j] = acc[j];
+      s_acc[threadIdx.x >> 6][4 + j] = (long long)contrib[j];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < kBlock / 64; ++w)
+      for (int j = 0; j < 8; ++j) t[j] += s_acc[w][j];
+    for (int j = 0; j < a.n_slots; ++j) {
+      if (!t[4 + j]) continue;
+      if (a.op[j] == 0) {
+        atomicAdd((unsigned long long*)(out + j), (unsigned long long)t[4 + j]);
+      } else {
+        // slot is NULL until the first non-NULL contribution; a partial sum that happens to
+        // equal the sentinel bit pattern must still be added, so CAS explicitly
+        int64_t old = MQ_LOAD64(out + j);
+        for (;;) {
+          const int64_t nv = old == a.null_sum ? t[j] : old + t[j];
+          const int64_t seen = (int64_t)MQ_CAS64(out + j, old, nv);
+          if (seen == old) break;
+          old = seen;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------- host side
+inline int stream_grid(int n_cus, int blocks_per_cu, int64_t total_rows) {
+  int64_t want = (total_rows / 4 + kBlock - 1) / kBlock;
+  int64_t cap = (int64_t)n_cus * blocks_per_cu;
+  if (want < 1) want = 1;
+  return (int)(want < cap ? want : cap);
+}
+
+constexpr int64_t kPerfectLdsMaxBytes = 64 * 1024;
+
+}  // namespace
+
+// ------------------------------------------------------------------------ scan_count
+bool scan_count_eligible(const DevPlan& p, const FragView& fv) {
+  if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col >= 0) return false;
+  if (p.n_targets != 1 || p.targets[0].agg != MI355Q_COUNT || p.targets[0].col >= 0) return false;
+  if (p.n_quals != 1) return false;
+  RangeFilter f;
+  if (!make_range_filter(p.quals[0], &f)) return false;
+  return all_aligned16(fv, p.quals[0].col);
+}
+
+hipError_t launch_scan_count(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus,
+                             hipStream_t s, LaunchStats* st) {
+  RangeFilter f;
+  make_range_filter(p.quals[0], &f);
+  const int grid = stream_grid(n_cus, 8, fv.total_rows);
+  st->kernel_name = "k_scan_count";
+  st->n_launches = 1;
+  rec(st->k_start, s);
+  if (p.quals[0].type == MI355Q_INT32) {
+    hipLaunchKernelGGL(k_scan_count<int32_t>, dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, f, out);
+  } else {
+    hipLaunchKernelGGL(k_scan_count<int64_t>, dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, f, out);
+  }
+  rec(st->k_stop, s);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------ perfect_lds
+bool perfect_lds_eligible(const DevPlan& p, const FragView& fv) {
+  if (p.desc_type != MI355Q_GROUP_BY_PERFECT_HASH) return false;
+  if (p.group_type != MI355Q_INT32 && p.group_type != MI355Q_INT64) return false;
+  if (p.entry_count * p.row_quad * 8 > kPerfectLdsMaxBytes) return false;
+  FastShape s;
+  return grouped_fast_shape(p, fv, &s);
+}
+
+template <typename FT, typename KT>
+static hipError_t launch_perfect_lds_v(const FastShape& fs, const PerfectArgs& a, const FragView& fv,
+                                       int64_t* out, int32_t* d_err, int grid, size_t lds,
+                                       hipStream_t s) {
+  if (fs.vcol < 0) {
+    hipLaunchKernelGGL((k_perfect_lds<FT, KT, none_t>), dim3(grid), dim3(kBlock), lds, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
+  } else if (fs.vtype == MI355Q_INT64) {
+    hipLaunchKernelGGL((k_perfect_lds<FT, KT, int64_t>), dim3(grid), dim3(kBlock), lds, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
+  } else {
+    hipLaunchKernelGGL((k_perfect_lds<FT, KT, double>), dim3(grid), dim3(kBlock), lds, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_perfect_lds(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err,
+                              int n_cus, hipStream_t s, LaunchStats* st) {
+  FastShape fs;
+  grouped_fast_shape(p, fv, &fs);
+  PerfectArgs a{};
+  a.min_val = p.min_val;
+  a.entry_count = p.entry_count;
+  a.row_quad = p.row_quad;
+  a.key_quad = p.key_quad;
+  a.kcol = p.group_col;
+  a.vcol = fs.vcol < 0 ? 0 : fs.vcol;
+  a.sp = fs.sp;
+  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) a.init[i] = p.init_vals[i];
+  const size_t lds = (size_t)(p.entry_count * p.row_quad * 8);
+  int bpc = (int)((160 * 1024) / (lds + 512));
+  if (bpc > 8) bpc = 8;
+  if (bpc < 1) bpc = 1;
+  const int grid = stream_grid(n_cus, bpc, fv.total_rows);
+  st->kernel_name = "k_perfect_lds";
+  st->n_launches = 1;
+  rec(st->k_start, s);
+  hipError_t e;
+  const bool k32 = p.group_type == MI355Q_INT32;
+  if (fs.fil_type == 0) {
+    e = k32 ? launch_perfect_lds_v<none_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s)
+            : launch_perfect_lds_v<none_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s);
+  } else if (fs.fil_type == MI355Q_INT32) {
+    e = k32 ? launch_perfect_lds_v<int32_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s)
+            : launch_perfect_lds_v<int32_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s);
+  } else {
+    e = k32 ? launch_perfect_lds_v<int64_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s)
+            : launch_perfect_lds_v<int64_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s);
+  }
+  rec(st->k_stop, s);
+  return e;
+}
+
+// ------------------------------------------------------------------------ baseline
+bool baseline_fast_eligible(const DevPlan& p, const FragView& fv) {
+  if (p.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || p.key_width != 8) return false;
+  if (p.group_type != MI355Q_INT64) return false;
+  FastShape s;
+  return grouped_fast_shape(p, fv, &s);
+}
+
+// Plan-time choice inside the baseline family: tiny inputs or tiny tables are fastest with
+// direct atomics; everything else partitions.
+int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested) {
+  if (requested >= 1 && requested <= 3) return requested;
+  if (fv.total_rows < (int64_t)8 << 20 || p.entry_count < 65536) return 1;
+  return 2;
+}
+
+int64_t baseline_fast_scratch_bytes(const DevPlan& p, const FragView& fv, int variant,
+                                    int64_t cap_bytes, int n_cus) {
+  const int v = baseline_fast_variant(p, fv, variant);
+  if (v == 1) return 0;
+  return part_scratch_bytes(p, fv, n_cus, cap_bytes, v == 3);
+}
+
+template <typename FT>
+static hipError_t launch_baseline_direct_v(const FastShape& fs, const BaselineArgs& a,
+                                           const FragView& fv, int64_t* out, int32_t* d_err,
+                                           int grid, hipStream_t s) {
+  if (fs.vcol < 0) {
+    hipLaunchKernelGGL((k_baseline_direct<FT, none_t>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
+  } else if (fs.vtype == MI355Q_INT64) {
+    hipLaunchKernelGGL((k_baseline_direct<FT, int64_t>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
+  } else {
+    hipLaunchKernelGGL((k_baseline_direct<FT, double>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_baseline_fast(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err,
+                                void* scratch, int64_t scratch_bytes, int64_t cap_bytes,
+                                int variant, int n_cus, hipStream_t s, LaunchStats* st) {
+  const int v = baseline_fast_variant(p, fv, variant);
+  if (v != 1) {
+    return launch_baseline_partitioned(p, fv, out, d_err, scratch, scratch_bytes, cap_bytes, v == 3,
+                                       n_cus, s, st);
+  }
+  FastShape fs;
+  grouped_fast_shape(p, fv, &fs);
+  BaselineArgs a{};
+  a.entry_count = p.entry_count;
+  a.row_quad = p.row_quad;
+  a.kcol = p.group_col;
+  a.vcol = fs.vcol < 0 ? 0 : fs.vcol;
+  a.sp = fs.sp;
+  const int grid = stream_grid(n_cus, 8, fv.total_rows);
+  st->kernel_name = "k_baseline_direct";
+  st->n_launches = 1;
+  st->variant = 1;
+  rec(st->k_start, s);
+  hipError_t e;
+  if (fs.fil_type == 0) e = launch_baseline_direct_v<none_t>(fs, a, fv, out, d_err, grid, s);
+  else if (fs.fil_type == MI355Q_INT32) e = launch_baseline_direct_v<int32_t>(fs, a, fv, out, d_err, grid, s);
+  else e = launch_baseline_direct_v<int64_t>(fs, a, fv, out, d_err, grid, s);
+  rec(st->k_stop, s);
+  return e;
+}
+
+// ------------------------------------------------------------------------ join_sum
+static bool join_sum_shape(const DevPlan& p, const FragView& fv, JoinSumArgs* a) {
+  if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col < 0 || p.n_quals != 0) return false;
+  if (p.join_type != MI355Q_INT64 || p.join_nullable) return false;
+  if (p.n_targets > 4) return false;
+  a->kcol = p.join_col;
+  a->vcol = -1;
+  a->inner_w = nullptr;
+  a->n_slots = p.n_targets;
+  for (int i = 0; i < p.n_targets; ++i) {
+    const DevTarget& t = p.targets[i];
+    if (t.slot != i) return false;
+    if (t.agg == MI355Q_COUNT && t.col < 0) {
+      a->op[i] = 0;
+    } else if (t.agg == MI355Q_SUM && t.arg_type == MI355Q_INT64 && !t.arg_nullable) {
+      if (t.table == 0) {
+        if (a->vcol >= 0 && a->vcol != t.col) return false;
+        a->vcol = t.col;
+        a->op[i] = 1;
+      } else {
+        const int64_t* w = (const int64_t*)p.inner_cols[t.col];
+        if (a->inner_w && a->inner_w != w) return false;
+        a->inner_w = w;
+        a->op[i] = 2;
+      }
+    } else {
+      return false;
+    }
+  }
+  if (!all_aligned16(fv, p.join_col)) return false;
+  if (a->vcol >= 0 && !all_aligned16(fv, a->vcol)) return false;
+  a->hash_type = p.join_hash_type;
+  a->table = p.join_buf;
+  a->min_key = p.join_min;
+  a->max_key = p.join_max;
+  a->entries = p.join_entries;
+  a->null_sum = INT64_MIN;
+  return true;
+}
+
+bool join_sum_eligible(const DevPlan& p, const FragView& fv) {
+  JoinSumArgs a;
+  return join_sum_shape(p, fv, &a);
+}
+
+hipError_t launch_join_sum(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus,
+                           hipStream_t s, LaunchStats* st) {
+  JoinSumArgs a;
+  join_sum_shape(p, fv, &a);
+  const int grid = stream_grid(n_cus, 8, fv.total_rows);
+  st->kernel_name = "k_join_sum";
+  st->n_launches = 1;
+  rec(st->k_start, s);
+  if (a.vcol < 0) {
+    a.vcol = 0;
+    hipLaunchKernelGGL(k_join_sum<none_t>, dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, a, out);
+  } else {
+    hipLaunchKernelGGL(k_join_sum<int64_t>, dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, a, out);
+  }
+  rec(st->k_stop, s);
+  return hipGetLastError();
+}
+
+}  // namespace mq

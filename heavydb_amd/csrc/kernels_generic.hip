@@ -1,0 +1,365 @@
+// kernels_generic.hip — the generic members of the kernel family: any plan the C-ABI accepts
+// runs here (row interpreter with atomic slot updates); the fast families in
+// kernels_fast.hip take over at plan time for the shapes they cover.
+//
+// gfx950 only: 256-thread workgroups (4 waves, one per SIMD), grid-stride over each
+// fragment like the reference's multi-fragment kernel loop
+// (multifrag_query_hoisted_literals, RuntimeFunctions.cpp:2434-2471).
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "rowfunc.h"
+
+namespace mq {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void k_init_buffer(int64_t* __restrict__ buf,
+                                                         int64_t total_quads, RowInit init) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total_quads; i += stride) {
+    buf[i] = init.quad[i % init.row_quad];
+  }
+}
+
+// Generic row kernel.  Grouped plans update the output table with device atomics; the
+// non-grouped plan keeps per-thread partial rows in LDS, folds them per block and issues one
+// atomic merge per target per block (the reference folds per-thread partials on the host,
+// Executor::reduceResults Execute.cpp:1444).
+__global__ __launch_bounds__(kBlock) void k_generic(DevPlan p, const int8_t* const* __restrict__ cols,
+                                                     const int64_t* __restrict__ num_rows,
+                                                     int n_frags, int64_t* __restrict__ out,
+                                                     int32_t* __restrict__ d_err) {
+  constexpr int kLocStride = MI355Q_MAX_SLOTS + 1;
+  __shared__ int64_t s_loc[kBlock * kLocStride];
+  const bool ng = p.desc_type == MI355Q_NON_GROUPED_AGGREGATE;
+  int64_t* my_loc = s_loc + threadIdx.x * kLocStride;
+  if (ng) {
+    for (int i = 0; i < p.slot_count; ++i) my_loc[i] = p.init_vals[i];
+  }
+  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kBlock;
+  int32_t err = 0;
+  for (int f = 0; f < n_frags && !err; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * p.n_cols;
+    const int64_t n = num_rows[f];
+    for (int64_t pos = gtid; pos < n; pos += gsize) {
+      const int32_t e = ng ? process_row<false>(p, fc, pos, out, my_loc)
+                           : process_row<true>(p, fc, pos, out, nullptr);
+      if (e) {
+        err = e;
+        break;
+      }
+    }
+  }
+  if (err) atomicCAS(d_err, 0, err);
+  if (ng) {
+    __syncthreads();
+    if (threadIdx.x < p.n_targets) {
+      const DevTarget& t = p.targets[threadIdx.x];
+      int64_t acc[2] = {p.init_vals[t.slot], t.agg == MI355Q_AVG ? p.init_vals[t.slot + 1] : 0};
+      // fold the block's 256 partial rows for this target, serially, with plain ops
+      DevTarget lt = t;
+      lt.slot = 0;
+      int64_t lin[2] = {p.init_vals[t.slot], 0};
+      for (int th = 0; th < kBlock; ++th) {
+        const int64_t* src = s_loc + th * kLocStride + t.slot;
+        reduce_target<false>(lt, lin, acc, src);
+      }
+      // one atomic merge per target per block
+      DevTarget gt = t;
+      int64_t that[MI355Q_MAX_SLOTS];
+      that[0] = acc[0];
+      that[1] = acc[1];
+      gt.slot = 0;
+      reduce_target<true>(gt, lin, out + t.slot, that);
+    }
+  }
+}
+
+// this (op)= that, entry-wise.  `that` holds that_entries rows of the same layout; baseline
+// rows are re-hashed into `this` (get_group_value_reduction, ResultSetReduction.cpp:783-826),
+// perfect/non-grouped rows are index aligned.
+__global__ __launch_bounds__(kBlock) void k_reduce(DevPlan p, int idx_target_as_key,
+                                                    int64_t* __restrict__ this_buf,
+                                                    const int64_t* __restrict__ that_rows,
+                                                    int64_t that_entries,
+                                                    int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < that_entries; e += stride) {
+    const int64_t* src = that_rows + e * p.row_quad;
+    if (is_empty_row(p, src, idx_target_as_key)) continue;
+    int64_t* slots;
+    if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
+      const int64_t key = p.key_width == 4 ? (int64_t) * (const int32_t*)src : src[0];
+      slots = baseline_find_or_insert(this_buf, (uint32_t)p.entry_count, p.row_quad, p.key_width,
+                                      key);
+      if (!slots) {
+        atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+        continue;
+      }
+    } else {
+      int64_t* row = this_buf + e * p.row_quad;
+      if (p.key_quad) MQ_STORE64(row, src[0]);
+      slots = row + p.key_quad;
+    }
+    const int64_t* that_slots = src + p.key_quad;
+    for (int i = 0; i < p.n_targets; ++i) {
+      reduce_target<true>(p.targets[i], p.init_vals, slots, that_slots);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_count_nonempty(DevPlan p, int idx_target_as_key,
+                                                            const int64_t* __restrict__ buf,
+                                                            unsigned long long* __restrict__ cnt) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  unsigned long long local = 0;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < p.entry_count; e += stride) {
+    local += !is_empty_row(p, buf + e * p.row_quad, idx_target_as_key);
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0 && local) atomicAdd(cnt, local);
+}
+
+MQ_D uint32_t shard_of(const DevPlan& p, const int64_t* row, int n_parts) {
+  if (p.key_width == 4) return murmur3_u32((uint32_t) * (const int32_t*)row) % (uint32_t)n_parts;
+  // upper hash bits, so a shard's keys still spread over the whole local table
+  return (uint32_t)(((uint64_t)murmur3_u64((uint64_t)row[0]) * (uint64_t)n_parts) >> 32);
+}
+
+__global__ __launch_bounds__(kBlock) void k_shard_count(DevPlan p, int idx_target_as_key,
+                                                         const int64_t* __restrict__ buf,
+                                                         int n_parts,
+                                                         int64_t* __restrict__ part_counts) {
+  __shared__ unsigned long long s_cnt[256];
+  for (int i = threadIdx.x; i < n_parts; i += kBlock) s_cnt[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < p.entry_count; e += stride) {
+    const int64_t* row = buf + e * p.row_quad;
+    if (is_empty_row(p, row, idx_target_as_key)) continue;
+    atomicAdd(&s_cnt[shard_of(p, row, n_parts)], 1ull);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n_parts; i += kBlock) {
+    if (s_cnt[i]) atomicAdd((unsigned long long*)&part_counts[i], s_cnt[i]);
+  }
+}
+
+__global__ void k_shard_offsets(const int64_t* __restrict__ part_counts, int n_parts,
+                                int64_t* __restrict__ cursors) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    int64_t acc = 0;
+    for (int i = 0; i < n_parts; ++i) {
+      cursors[i] = acc;
+      acc += part_counts[i];
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_shard_scatter(DevPlan p, int idx_target_as_key,
+                                                           const int64_t* __restrict__ buf,
+                                                           int n_parts,
+                                                           int64_t* __restrict__ out_rows,
+                                                           int64_t* __restrict__ cursors) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < p.entry_count; e += stride) {
+    const int64_t* row = buf + e * p.row_quad;
+    if (is_empty_row(p, row, idx_target_as_key)) continue;
+    const uint32_t part = shard_of(p, row, n_parts);
+    const int64_t dst = (int64_t)atomicAdd((unsigned long long*)&cursors[part], 1ull);
+    int64_t* o = out_rows + dst * p.row_quad;
+    for (int j = 0; j < p.row_quad; ++j) o[j] = row[j];
+  }
+}
+
+// ---- join hash table builds -------------------------------------------------------------
+// OneToOne perfect: slot[key - min] = row id under CAS(-1 -> id)
+// (fill_one_to_one_hashtable JoinHashImpl.h:43-52; fill_hash_join_buff HashJoinRuntime.cpp:203).
+__global__ __launch_bounds__(kBlock) void k_join_fill_perfect(const int8_t* __restrict__ keys,
+                                                               int type, int nullable, int64_t n,
+                                                               int64_t min_key, int64_t max_key,
+                                                               int32_t* __restrict__ buf,
+                                                               int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t null_t = int_null_of(type);
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t k = decode_int(keys, type, i);
+    if (nullable && k == null_t) continue;
+    if (k < min_key || k > max_key) {
+      atomicCAS(d_err, 0, MI355Q_ERR_INVALID_PLAN);
+      continue;
+    }
+    if (atomicCAS((int*)&buf[k - min_key], -1, (int)i) != -1) {
+      atomicCAS(d_err, 0, MI355Q_ERR_JOIN_NOT_ONE_TO_ONE);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_join_init_baseline(int64_t* __restrict__ tab,
+                                                                int64_t entries) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < entries * 2; i += stride) {
+    tab[i] = (i & 1) ? -1 : kEmptyKey64;
+  }
+}
+
+// Keyed OneToOne: {key, row id} entries, MurmurHash1 % entry_count + linear probing
+// (write_baseline_hash_slot HashJoinRuntime.cpp:505-538).
+__global__ __launch_bounds__(kBlock) void k_join_fill_baseline(const int8_t* __restrict__ keys,
+                                                                int type, int nullable, int64_t n,
+                                                                int64_t* __restrict__ tab,
+                                                                int64_t entries,
+                                                                int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t null_t = int_null_of(type);
+  const uint32_t ne = (uint32_t)entries;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t k = decode_int(keys, type, i);
+    if (nullable && k == null_t) continue;
+    const uint32_t h = murmur1_u64((uint64_t)k) % ne;
+    uint32_t hp = h;
+    bool placed = false;
+    do {
+      int64_t* e = tab + (size_t)hp * 2;
+      const int64_t old = (int64_t)atomicCAS((unsigned long long*)e,
+                                             (unsigned long long)kEmptyKey64,
+                                             (unsigned long long)k);
+      if (old == kEmptyKey64 || old == k) {
+        if (atomicCAS((unsigned long long*)(e + 1), (unsigned long long)-1ll,
+                      (unsigned long long)i) != (unsigned long long)-1ll) {
+          atomicCAS(d_err, 0, MI355Q_ERR_JOIN_NOT_ONE_TO_ONE);
+        }
+        placed = true;
+        break;
+      }
+      hp = hp + 1 == ne ? 0 : hp + 1;
+    } while (hp != h);
+    if (!placed) atomicCAS(d_err, 0, MI355Q_ERR_JOIN_TABLE_FULL);
+  }
+}
+
+// ---- synthetic columns ------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_generate(void* __restrict__ dst, int64_t n_rows,
+                                                      int64_t row_offset, int kind, uint64_t seed,
+                                                      int64_t a, int64_t b, int64_t c, double a_f,
+                                                      int null_every) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n_rows; i += stride) {
+    const uint64_t row = (uint64_t)(row_offset + i);
+    const uint64_t u = splitmix64(seed ^ (row * 0x9E3779B97F4A7C15ull));
+    const bool is_null = null_every > 0 && (u >> 40) % (uint64_t)null_every == 0;
+    switch (kind) {
+      case MI355Q_GEN_I32_UNIFORM31:
+        ((int32_t*)dst)[i] = is_null ? INT32_MIN : (int32_t)(u >> 33);
+        break;
+      case MI355Q_GEN_I32_MOD:
+        ((int32_t*)dst)[i] = is_null ? INT32_MIN : (int32_t)((int64_t)(u % (uint64_t)a) + b);
+        break;
+      case MI355Q_GEN_I64_MOD:
+        ((int64_t*)dst)[i] = is_null ? INT64_MIN : (int64_t)(u % (uint64_t)a) + b;
+        break;
+      case MI355Q_GEN_I64_MOD_MUL:
+        ((int64_t*)dst)[i] = is_null ? INT64_MIN : (int64_t)(u % (uint64_t)a) * b + c;
+        break;
+      default:
+        ((double*)dst)[i] = is_null ? kNullDouble : (double)(u >> 11) * 0x1.0p-53 * a_f;
+    }
+  }
+}
+
+inline int grid_for(int64_t work_items, int max_blocks = 2048) {
+  int64_t b = (work_items + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+}  // namespace
+
+hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,
+                              hipStream_t s) {
+  const int64_t quads = entry_count * init.row_quad;
+  hipLaunchKernelGGL(k_init_buffer, dim3(grid_for(quads)), dim3(kBlock), 0, s, buf, quads, init);
+  return hipGetLastError();
+}
+
+hipError_t launch_generic(const DevPlan& p, const int8_t* const* d_cols,
+                          const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows,
+                          int64_t* out, int32_t* d_err, int n_cus, hipStream_t s) {
+  const int grid = grid_for(max_frag_rows, n_cus * 8);
+  hipLaunchKernelGGL(k_generic, dim3(grid), dim3(kBlock), 0, s, p, d_cols, d_num_rows, n_frags,
+                     out, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce(const DevPlan& p, int idx_target_as_key, int64_t* this_buf,
+                         const int64_t* that_rows, int64_t that_entries, int32_t* d_err,
+                         hipStream_t s) {
+  if (that_entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_reduce, dim3(grid_for(that_entries)), dim3(kBlock), 0, s, p,
+                     idx_target_as_key, this_buf, that_rows, that_entries, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_count_nonempty(const DevPlan& p, int idx_target_as_key, const int64_t* buf,
+                                 unsigned long long* d_count, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_count_nonempty, dim3(grid_for(p.entry_count)), dim3(kBlock), 0, s, p,
+                     idx_target_as_key, buf, d_count);
+  return hipGetLastError();
+}
+
+hipError_t launch_shard_partition(const DevPlan& p, int idx_target_as_key, const int64_t* buf,
+                                  int n_parts, int64_t* out_rows, int64_t* d_part_counts,
+                                  int64_t* d_cursors, hipStream_t s) {
+  if (n_parts < 1 || n_parts > 256) return hipErrorInvalidValue;
+  hipError_t e = hipMemsetAsync(d_part_counts, 0, sizeof(int64_t) * n_parts, s);
+  if (e != hipSuccess) return e;
+  const int grid = grid_for(p.entry_count);
+  hipLaunchKernelGGL(k_shard_count, dim3(grid), dim3(kBlock), 0, s, p, idx_target_as_key, buf,
+                     n_parts, d_part_counts);
+  hipLaunchKernelGGL(k_shard_offsets, dim3(1), dim3(64), 0, s, d_part_counts, n_parts, d_cursors);
+  hipLaunchKernelGGL(k_shard_scatter, dim3(grid), dim3(kBlock), 0, s, p, idx_target_as_key, buf,
+                     n_parts, out_rows, d_cursors);
+  return hipGetLastError();
+}
+
+hipError_t launch_join_fill_perfect(const int8_t* keys, int type, int nullable, int64_t n,
+                                    int64_t min_key, int64_t max_key, int32_t* buf,
+                                    int32_t* d_err, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_join_fill_perfect, dim3(grid_for(n)), dim3(kBlock), 0, s, keys, type,
+                     nullable, n, min_key, max_key, buf, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_join_init_baseline(int64_t* tab, int64_t entries, hipStream_t s) {
+  hipLaunchKernelGGL(k_join_init_baseline, dim3(grid_for(entries * 2)), dim3(kBlock), 0, s, tab,
+                     entries);
+  return hipGetLastError();
+}
+
+hipError_t launch_join_fill_baseline(const int8_t* keys, int type, int nullable, int64_t n,
+                                     int64_t* tab, int64_t entries, int32_t* d_err,
+                                     hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_join_fill_baseline, dim3(grid_for(n)), dim3(kBlock), 0, s, keys, type,
+                     nullable, n, tab, entries, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_generate(void* dst, int64_t n_rows, int64_t row_offset, int kind, uint64_t seed,
+                           int64_t a, int64_t b, int64_t c, double a_f, int null_every,
+                           hipStream_t s) {
+  if (n_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_generate, dim3(grid_for(n_rows, 8192)), dim3(kBlock), 0, s, dst, n_rows,
+                     row_offset, kind, seed, a, b, c, a_f, null_every);
+  return hipGetLastError();
+}
+
+}  // namespace mq

@@ -1,0 +1,20 @@
+// plan.h — internal host-side declarations of libmi355q (not part of the C-ABI).
+#pragma once
+
+#include "dev_common.h"
+
+namespace mq {
+
+struct ResolvedTarget {
+  int agg = 0, col = -1, table = 0;
+  int arg_type = 0;
+  bool arg_nullable = false, arg_fp = false, skip_null = false;
+  int n_slots = 1;
+  const mi355q_range* range = nullptr;
+};
+
+int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out);
+int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q);
+int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d);
+
+}  // namespace mq

@@ -1,0 +1,437 @@
+// rowfunc.h — the per-row logic of the generic kernel family: filter -> join probe -> group
+// slot -> aggregate updates, written once and used with atomic slot updates on the device.
+//
+// When compiled with -DMQ_EMU (tests/emu only, plain g++) the atomics degrade to plain
+// single-threaded operations so the row logic can be unit-tested without a GPU.  That build
+// is test infrastructure; the product library always uses the device atomics.
+//
+// Reference semantics restated (heavyai/heavydb):
+//   filters      DEF_CMP_NULLABLE RuntimeFunctions.cpp:73-83, toBool LogicalIR.cpp:344-352
+//   aggregates   agg_* RuntimeFunctions.cpp:362,1151-1169,1313-1431,1444-1470,1558-1584
+//   perfect slot get_group_value_fast GroupByRuntime.cpp:208-241, keyless
+//                RuntimeFunctions.cpp:2126-2133
+//   baseline     get_group_value GroupByRuntime.cpp:25-48 (+ key_hash :20-23); insertion is
+//                insert-or-find under CAS like any concurrent build, so slot POSITIONS are
+//                order dependent and compared as sets (docs hash_joins.rst)
+//   join probe   hash_join_idx GroupByRuntime.cpp:287-318; baseline_hash_join_idx_64
+//                JoinHashTableQueryRuntime.cpp:40-94
+#pragma once
+
+#include "dev_common.h"
+
+namespace mq {
+
+#if defined(MQ_EMU)
+// ---------------------------------------------------------------- emulation atomics
+template <typename T>
+inline T emu_cas(T* p, T expect, T desired) {
+  T old = *p;
+  if (old == expect) *p = desired;
+  return old;
+}
+#define MQ_CAS64(p, e, d) mq::emu_cas<unsigned long long>((unsigned long long*)(p), (unsigned long long)(e), (unsigned long long)(d))
+#define MQ_CAS32(p, e, d) mq::emu_cas<unsigned int>((unsigned int*)(p), (unsigned int)(e), (unsigned int)(d))
+#define MQ_ADD64(p, v) (*(unsigned long long*)(p) += (unsigned long long)(v))
+#define MQ_ADDF64(p, v) (*(double*)(p) += (v))
+#define MQ_MIN64(p, v) (*(long long*)(p) = (*(long long*)(p) < (long long)(v) ? *(long long*)(p) : (long long)(v)))
+#define MQ_MAX64(p, v) (*(long long*)(p) = (*(long long*)(p) > (long long)(v) ? *(long long*)(p) : (long long)(v)))
+#define MQ_LOAD64(p) (*(volatile int64_t*)(p))
+#define MQ_STORE64(p, v) (*(volatile int64_t*)(p) = (v))
+#define MQ_FN inline
+#else
+#define MQ_CAS64(p, e, d) atomicCAS((unsigned long long*)(p), (unsigned long long)(e), (unsigned long long)(d))
+#define MQ_CAS32(p, e, d) atomicCAS((unsigned int*)(p), (unsigned int)(e), (unsigned int)(d))
+#define MQ_ADD64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(v))
+#define MQ_ADDF64(p, v) atomicAdd((double*)(p), (double)(v))
+#define MQ_MIN64(p, v) atomicMin((long long*)(p), (long long)(v))
+#define MQ_MAX64(p, v) atomicMax((long long*)(p), (long long)(v))
+#define MQ_LOAD64(p) __hip_atomic_load((int64_t*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MQ_STORE64(p, v) __hip_atomic_store((int64_t*)(p), (int64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MQ_FN __device__ __forceinline__
+#endif
+
+// ---------------------------------------------------------------- slot update primitives
+// All take the slot as int64_t* (8-byte padded slots).  *_skip variants implement the
+// reference's "_skip_val" semantics: the slot starts at the NULL sentinel (== skip) and the
+// first non-NULL value overwrites it.
+template <bool A>
+MQ_FN void a_count(int64_t* s) {
+  if (A) MQ_ADD64(s, 1ull);
+  else *s += 1;
+}
+template <bool A>
+MQ_FN void a_sum_i64(int64_t* s, int64_t v) {
+  if (A) MQ_ADD64(s, v);
+  else *s += v;
+}
+template <bool A>
+MQ_FN void a_sum_i64_skip(int64_t* s, int64_t v, int64_t skip) {
+  if (v == skip) return;
+  if (!A) {
+    *s = (*s == skip) ? v : *s + v;
+    return;
+  }
+  int64_t old = MQ_LOAD64(s);
+  for (;;) {
+    const int64_t nv = (old == skip) ? v : old + v;
+    const int64_t seen = (int64_t)MQ_CAS64(s, old, nv);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+template <bool A>
+MQ_FN void a_min_i64(int64_t* s, int64_t v) {
+  if (A) MQ_MIN64(s, v);
+  else *s = *s < v ? *s : v;
+}
+template <bool A>
+MQ_FN void a_max_i64(int64_t* s, int64_t v) {
+  if (A) MQ_MAX64(s, v);
+  else *s = *s > v ? *s : v;
+}
+template <bool A>
+MQ_FN void a_min_i64_skip(int64_t* s, int64_t v, int64_t skip) {
+  if (v == skip) return;
+  if (!A) {
+    *s = (*s == skip) ? v : (*s < v ? *s : v);
+    return;
+  }
+  int64_t old = MQ_LOAD64(s);
+  for (;;) {
+    const int64_t nv = (old == skip) ? v : (old < v ? old : v);
+    if (nv == old) return;
+    const int64_t seen = (int64_t)MQ_CAS64(s, old, nv);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+template <bool A>
+MQ_FN void a_max_i64_skip(int64_t* s, int64_t v, int64_t skip) {
+  if (v == skip) return;
+  if (!A) {
+    *s = (*s == skip) ? v : (*s > v ? *s : v);
+    return;
+  }
+  int64_t old = MQ_LOAD64(s);
+  for (;;) {
+    const int64_t nv = (old == skip) ? v : (old > v ? old : v);
+    if (nv == old) return;
+    const int64_t seen = (int64_t)MQ_CAS64(s, old, nv);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+template <bool A>
+MQ_FN void a_sum_f64(int64_t* s, double v) {
+  if (A) MQ_ADDF64(s, v);
+  else *s = dbl_bits(bits_dbl(*s) + v);
+}
+template <bool A>
+MQ_FN void a_sum_f64_skip(int64_t* s, double v, double skip) {
+  if (v == skip) return;
+  const int64_t skip_bits = dbl_bits(skip);
+  if (!A) {
+    *s = (*s == skip_bits) ? dbl_bits(v) : dbl_bits(bits_dbl(*s) + v);
+    return;
+  }
+  int64_t old = MQ_LOAD64(s);
+  for (;;) {
+    const int64_t nv = (old == skip_bits) ? dbl_bits(v) : dbl_bits(bits_dbl(old) + v);
+    const int64_t seen = (int64_t)MQ_CAS64(s, old, nv);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+// MIN/MAX on doubles: CAS loops (std::min/max semantics of agg_min_double/agg_max_double)
+template <bool A, bool IS_MAX, bool SKIP>
+MQ_FN void a_minmax_f64(int64_t* s, double v, double skip) {
+  if (SKIP && v == skip) return;
+  const int64_t skip_bits = dbl_bits(skip);
+  int64_t old = A ? MQ_LOAD64(s) : *s;
+  for (;;) {
+    int64_t nv;
+    if (SKIP && old == skip_bits) {
+      nv = dbl_bits(v);
+    } else {
+      const double o = bits_dbl(old);
+      const double r = IS_MAX ? (o < v ? v : o) : (v < o ? v : o);
+      nv = dbl_bits(r);
+    }
+    if (nv == old) return;
+    if (!A) {
+      *s = nv;
+      return;
+    }
+    const int64_t seen = (int64_t)MQ_CAS64(s, old, nv);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+
+// ---------------------------------------------------------------- filter
+MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
+  if (q.type == MI355Q_DOUBLE) {
+    const double v = decode_dbl(col, pos);
+    if (q.nullable && v == kNullDouble) return false;
+    switch (q.op) {
+      case MI355Q_EQ: return v == q.fval;
+      case MI355Q_NE: return v != q.fval;
+      case MI355Q_LT: return v < q.fval;
+      case MI355Q_GT: return v > q.fval;
+      case MI355Q_LE: return v <= q.fval;
+      default: return v >= q.fval;
+    }
+  }
+  const int64_t v = decode_int(col, q.type, pos);
+  if (q.nullable && v == int_null_of(q.type)) return false;
+  switch (q.op) {
+    case MI355Q_EQ: return v == q.ival;
+    case MI355Q_NE: return v != q.ival;
+    case MI355Q_LT: return v < q.ival;
+    case MI355Q_GT: return v > q.ival;
+    case MI355Q_LE: return v <= q.ival;
+    default: return v >= q.ival;
+  }
+}
+
+// ---------------------------------------------------------------- join probe
+// Returns inner row id or < 0 (no match).
+MQ_FN int64_t join_probe(const DevPlan& p, int64_t key) {
+  if (p.join_hash_type == 0) {
+    if (key >= p.join_min && key <= p.join_max) {
+      return ((const int32_t*)p.join_buf)[key - p.join_min];
+    }
+    return -1;
+  }
+  const int64_t* tab = (const int64_t*)p.join_buf;
+  const uint32_t n = (uint32_t)p.join_entries;
+  if (!n) return -1;
+  const uint32_t h = murmur1_u64((uint64_t)key) % n;
+  uint32_t hp = h;
+  do {
+    const int64_t k = tab[(size_t)hp * 2];
+    if (k == key) return tab[(size_t)hp * 2 + 1];
+    if (k == kEmptyKey64) return -2;  // kNotPresent
+    hp = hp + 1 == n ? 0 : hp + 1;
+  } while (hp != h);
+  return -1;  // kNoMatch
+}
+
+// ---------------------------------------------------------------- group slot
+// Returns pointer to the first aggregate slot of the row's group, or nullptr when the
+// baseline table is full (caller raises the out-of-slots error).
+MQ_FN int64_t* baseline_find_or_insert(int64_t* buf, uint32_t entry_count, int row_quad,
+                                       int key_width, int64_t key) {
+  if (key_width == 4) {
+    const int32_t k32 = (int32_t)key;
+    const uint32_t h = murmur3_u32((uint32_t)k32) % entry_count;
+    uint32_t hp = h;
+    do {
+      int64_t* row = buf + (size_t)hp * row_quad;
+      const uint32_t old = MQ_CAS32(row, (uint32_t)kEmptyKey32, (uint32_t)k32);
+      if (old == (uint32_t)kEmptyKey32 || old == (uint32_t)k32) return row + 1;
+      hp = hp + 1 == entry_count ? 0 : hp + 1;
+    } while (hp != h);
+    return nullptr;
+  }
+  const uint32_t h = murmur3_u64((uint64_t)key) % entry_count;
+  uint32_t hp = h;
+  do {
+    int64_t* row = buf + (size_t)hp * row_quad;
+    const int64_t old = (int64_t)MQ_CAS64(row, kEmptyKey64, key);
+    if (old == kEmptyKey64 || old == key) return row + 1;
+    hp = hp + 1 == entry_count ? 0 : hp + 1;
+  } while (hp != h);
+  return nullptr;
+}
+
+// ---------------------------------------------------------------- one target, one row
+template <bool A>
+MQ_FN void apply_target(const DevTarget& t, int64_t* slots, const int8_t* const* cols,
+                        int64_t pos, const int8_t* const* inner_cols, int64_t inner_pos,
+                        int64_t key_val) {
+  if (t.agg == MI355Q_PROJECT_KEY) {
+    if (t.slot >= 0) {  // agg_id
+      if (A) MQ_STORE64(slots + t.slot, key_val);
+      else slots[t.slot] = key_val;
+    }
+    return;
+  }
+  int64_t* s = slots + t.slot;
+  if (t.col < 0) {
+    a_count<A>(s);
+    return;
+  }
+  const int8_t* col = t.table ? inner_cols[t.col] : cols[t.col];
+  const int64_t p = t.table ? inner_pos : pos;
+  if (t.arg_fp) {
+    const double v = decode_dbl(col, p);
+    switch (t.agg) {
+      case MI355Q_COUNT:
+        if (!t.skip_null || v != kNullDouble) a_count<A>(s);
+        break;
+      case MI355Q_SUM:
+        if (t.skip_null) a_sum_f64_skip<A>(s, v, kNullDouble);
+        else a_sum_f64<A>(s, v);
+        break;
+      case MI355Q_AVG:
+        if (t.skip_null) {
+          if (v != kNullDouble) {
+            a_sum_f64_skip<A>(s, v, kNullDouble);
+            a_count<A>(s + 1);
+          }
+        } else {
+          a_sum_f64<A>(s, v);
+          a_count<A>(s + 1);
+        }
+        break;
+      case MI355Q_MIN:
+        if (t.skip_null) a_minmax_f64<A, false, true>(s, v, kNullDouble);
+        else a_minmax_f64<A, false, false>(s, v, 0.0);
+        break;
+      default:
+        if (t.skip_null) a_minmax_f64<A, true, true>(s, v, kNullDouble);
+        else a_minmax_f64<A, true, false>(s, v, 0.0);
+    }
+    return;
+  }
+  const int64_t raw = decode_int(col, t.arg_type, p);
+  const int64_t null_t = int_null_of(t.arg_type);
+  switch (t.agg) {
+    case MI355Q_COUNT:
+      if (!t.skip_null || raw != null_t) a_count<A>(s);
+      break;
+    case MI355Q_SUM:
+    case MI355Q_AVG:
+      if (t.skip_null) {
+        if (raw != null_t) {
+          // slot starts at NULL_BIGINT for SUM (skip value) and at 0 for AVG.sum
+          a_sum_i64_skip<A>(s, raw, INT64_MIN);
+          if (t.agg == MI355Q_AVG) a_count<A>(s + 1);
+        }
+      } else {
+        a_sum_i64<A>(s, raw);
+        if (t.agg == MI355Q_AVG) a_count<A>(s + 1);
+      }
+      break;
+    case MI355Q_MIN:
+      if (t.skip_null) a_min_i64_skip<A>(s, raw, null_t);
+      else a_min_i64<A>(s, raw);
+      break;
+    default:
+      if (t.skip_null) a_max_i64_skip<A>(s, raw, null_t);
+      else a_max_i64<A>(s, raw);
+  }
+}
+
+// ---------------------------------------------------------------- reduce one target
+// this_slots (op)= that_slots with the target's aggregate, init value as the skip value
+// (ResultSetStorage::reduceOneSlot, ResultSetReduction.cpp:1496-1640).
+template <bool A>
+MQ_FN void reduce_target(const DevTarget& t, const int64_t* init_vals, int64_t* this_slots,
+                         const int64_t* that_slots) {
+  if (t.slot < 0) return;
+  int64_t* a = this_slots + t.slot;
+  const int64_t b = that_slots[t.slot];
+  const int64_t init = init_vals[t.slot];
+  const bool fp = t.arg_fp && t.agg != MI355Q_COUNT;
+  switch (t.agg) {
+    case MI355Q_COUNT:
+      a_sum_i64<A>(a, b);
+      break;
+    case MI355Q_AVG:
+      a_sum_i64<A>(a + 1, that_slots[t.slot + 1]);
+      // fallthrough
+    case MI355Q_SUM:
+      if (t.skip_null) {
+        if (fp) a_sum_f64_skip<A>(a, bits_dbl(b), bits_dbl(init));
+        else a_sum_i64_skip<A>(a, b, init);
+      } else {
+        if (fp) a_sum_f64<A>(a, bits_dbl(b));
+        else a_sum_i64<A>(a, b);
+      }
+      break;
+    case MI355Q_MIN:
+      if (fp) {
+        if (t.skip_null) a_minmax_f64<A, false, true>(a, bits_dbl(b), bits_dbl(init));
+        else a_minmax_f64<A, false, false>(a, bits_dbl(b), 0.0);
+      } else {
+        if (t.skip_null) a_min_i64_skip<A>(a, b, init);
+        else a_min_i64<A>(a, b);
+      }
+      break;
+    case MI355Q_MAX:
+      if (fp) {
+        if (t.skip_null) a_minmax_f64<A, true, true>(a, bits_dbl(b), bits_dbl(init));
+        else a_minmax_f64<A, true, false>(a, bits_dbl(b), 0.0);
+      } else {
+        if (t.skip_null) a_max_i64_skip<A>(a, b, init);
+        else a_max_i64<A>(a, b);
+      }
+      break;
+    default:
+      if (b != init) {
+        if (A) MQ_STORE64(a, b);
+        else *a = b;
+      }
+  }
+}
+
+// isEmptyEntry (ResultSetIteration.cpp:2457-2492)
+MQ_FN bool is_empty_row(const DevPlan& p, const int64_t* row, int idx_target_as_key) {
+  if (p.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return false;
+  if (p.keyless) return row[idx_target_as_key] == p.init_vals[idx_target_as_key];
+  if (p.key_width == 4) return *(const int32_t*)row == kEmptyKey32;
+  return row[0] == kEmptyKey64;
+}
+
+// ---------------------------------------------------------------- the row function
+// Returns 0, or a HeavyDB-style error: < 0 when the baseline table is full.
+template <bool A>
+MQ_FN int32_t process_row(const DevPlan& p, const int8_t* const* cols, int64_t pos,
+                          int64_t* out_buf, int64_t* nongrouped_slots) {
+  for (int i = 0; i < p.n_quals; ++i) {
+    if (!eval_qual(p.quals[i], cols[p.quals[i].col], pos)) return 0;
+  }
+  int64_t inner_pos = -1;
+  if (p.join_col >= 0) {
+    const int64_t k = decode_int(cols[p.join_col], p.join_type, pos);
+    if (p.join_nullable && k == int_null_of(p.join_type)) return 0;
+    inner_pos = join_probe(p, k);
+    if (inner_pos < 0) return 0;
+  }
+  int64_t* slots;
+  int64_t key_val = 0;
+  if (p.desc_type == MI355Q_NON_GROUPED_AGGREGATE) {
+    slots = nongrouped_slots;
+  } else {
+    const int64_t raw_key = decode_int(cols[p.group_col], p.group_type, pos);
+    key_val = raw_key;
+    if (p.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
+      int64_t k = raw_key;
+      if (p.group_nullable && raw_key == int_null_of(p.group_type)) k = p.max_val + 1;
+      const int64_t idx = k - p.min_val;
+      if (idx < 0 || idx >= p.entry_count) return MI355Q_ERR_OUT_OF_SLOTS;
+      int64_t* row = out_buf + idx * p.row_quad;
+      if (!p.keyless) {
+        if (MQ_LOAD64(row) == kEmptyKey64) MQ_STORE64(row, raw_key);
+        slots = row + 1;
+      } else {
+        slots = row;
+      }
+    } else {
+      slots = baseline_find_or_insert(out_buf, (uint32_t)p.entry_count, p.row_quad, p.key_width,
+                                      raw_key);
+      if (!slots) {
+        const int64_t code = -(pos + 1);
+        return code < INT32_MIN ? INT32_MIN : (int32_t)code;
+      }
+    }
+  }
+  for (int i = 0; i < p.n_targets; ++i) {
+    apply_target<A>(p.targets[i], slots, cols, pos, p.inner_cols, inner_pos, key_val);
+  }
+  return 0;
+}
+
+}  // namespace mq

@@ -237,9 +237,10 @@ typedef struct mi355q_exec_options {
  * QueryExecutionContext.cpp:334,364,579) */
 typedef struct mi355q_exec_report {
   char kernel_name[64]; /* dominant kernel chosen at plan time */
-  float kernel_ms;      /* HIP-event time of the dominant kernel(s) on the launch stream */
+  float kernel_ms;      /* HIP-event time summed over the launches of the dominant kernel,
+                           measured on the launch stream; avg = kernel_ms / n_launches */
   float total_ms;       /* HIP-event time of the whole call on the launch stream */
-  int32_t n_launches;
+  int32_t n_launches;   /* launches of the dominant kernel */
   int32_t variant;
   int64_t rows_scanned;
   int64_t algorithmic_bytes; /* column bytes the plan must read */
@@ -248,6 +249,9 @@ typedef struct mi355q_exec_report {
 
 /* ---- library ---- */
 int32_t mi355q_abi_version(void);
+/* sizeof() of the ABI structs as compiled into the library, for binding self-checks:
+ * 1 plan, 2 qmd, 3 inputs, 4 exec_options, 5 exec_report, 6 join_spec */
+int64_t mi355q_abi_sizeof(int32_t which);
 const char* mi355q_error_string(int32_t code);
 int32_t mi355q_device_count(void);
 /* fills name (<=256 bytes) and basic properties of a device */
@@ -267,6 +271,10 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* inputs,
 /* ---- result set ---- */
 int32_t mi355q_result_create(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
                              mi355q_result** out); /* wraps/allocates + initialises */
+/* wraps an existing, already populated device buffer of this layout (no initialisation;
+ * the caller keeps ownership) — e.g. a partial buffer received from another GPU */
+int32_t mi355q_result_wrap(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
+                           mi355q_result** out);
 void mi355q_result_free(mi355q_result* r);
 int32_t mi355q_result_qmd(const mi355q_result* r, mi355q_qmd* out);
 void* mi355q_result_device_ptr(const mi355q_result* r);

@@ -1,0 +1,235 @@
+"""Query-shape matrix shared by the CPU (oracle vs host-emulated row logic) and GPU (HIP vs
+oracle) parity tests.  Shapes follow the reference's hot-path suites in Tests/ExecuteTest.cpp:
+Select.FilterAndSimpleAggregation (:1885), GroupBy (:2587), FilterAndGroupBy (:2815),
+GroupByBoundariesAndNull (:2874), GroupByKeylessAndNotKeyless (:3158), GroupByPerfectHash
+(:11414), GroupByBaselineHash (:11487), Joins_InnerJoin_TwoTables (:12852),
+Joins_DifferentIntegerTypes (:12710) — restated as hand-built execution units the way
+Tests/GroupByTest.cpp:73-151 does.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from heavydb_amd import capi
+from heavydb_amd.capi import (AVG, COUNT, DOUBLE, EQ, GE, GT, INT8, INT16, INT32, INT64, LE, LT,
+                              MAX, MIN, NE, PROJECT_KEY, SUM)
+from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
+                                  TargetExpr)
+
+NP = {INT8: np.int8, INT16: np.int16, INT32: np.int32, INT64: np.int64, DOUBLE: np.float64}
+NULLS = {INT8: -2**7, INT16: -2**15, INT32: -2**31, INT64: -2**63, DOUBLE: 2.2250738585072014e-308}
+
+
+@dataclass
+class Case:
+    name: str
+    ra: RelAlgExecutionUnit
+    frags: List[List[np.ndarray]]                 # [frag][col]
+    inner: List[np.ndarray] = field(default_factory=list)
+    join_keys: Optional[np.ndarray] = None        # inner key column (when joining)
+    join_key_type: int = INT64
+    join_range: Optional[ExpressionRange] = None
+    join_prefer_baseline: bool = False
+    expect_error: Optional[int] = None
+    fp_rtol: float = 1e-9                         # fp64 SUM/AVG rel <= 1e-9
+
+
+def col_range(arrs: List[np.ndarray], t: int, nullable: bool) -> ExpressionRange:
+    """What getExpressionRange derives from chunk metadata: min/max over non-NULL values."""
+    a = np.concatenate(arrs) if arrs else np.zeros(0, NP[t])
+    if nullable:
+        mask = a != NP[t](NULLS[t])
+        has_nulls = bool((~mask).any())
+        a = a[mask]
+    else:
+        has_nulls = False
+    if a.size == 0:
+        return ExpressionRange(True, 0, -1, has_nulls)  # empty range: min > max
+    if t == DOUBLE:
+        return ExpressionRange(True, 0, 0, has_nulls, float(a.min()), float(a.max()))
+    return ExpressionRange(True, int(a.min()), int(a.max()), has_nulls)
+
+
+def split(arr: np.ndarray, sizes: List[int]) -> List[np.ndarray]:
+    out, o = [], 0
+    for s in sizes:
+        out.append(np.ascontiguousarray(arr[o:o + s]))
+        o += s
+    assert o == len(arr)
+    return out
+
+
+def with_nulls(rng, a: np.ndarray, t: int, frac: float) -> np.ndarray:
+    a = a.copy()
+    a[rng.random(len(a)) < frac] = NP[t](NULLS[t])
+    return a
+
+
+def make_table(rng, n: int, frag_sizes: List[int], spec: List[tuple]):
+    """spec: [(type, nullable, generator(rng, n) -> array)].  Returns (descs, frags)."""
+    cols = []
+    for t, nullable, gen in spec:
+        a = np.asarray(gen(rng, n)).astype(NP[t])
+        if nullable:
+            a = with_nulls(rng, a, t, 0.07)
+        cols.append(a)
+    descs = [InputColDescriptor(t, nullable, col_range([c], t, nullable))
+             for (t, nullable, _), c in zip(spec, cols)]
+    per_col = [split(c, frag_sizes) for c in cols]
+    frags = [[per_col[c][f] for c in range(len(cols))] for f in range(len(frag_sizes))]
+    return descs, frags
+
+
+def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
+    rng = np.random.default_rng(seed)
+    cases: List[Case] = []
+    n = 20000 * scale
+    fs = [n // 4 + 3, n // 4 - 3, n // 2 - 5, 5]  # ragged fragments incl. a tiny one
+    assert sum(fs) == n
+
+    # columns: 0 i32 uniform, 1 i64 small-range key, 2 i64 value, 3 f64 value,
+    #          4 i64 sparse key, 5 i8, 6 i16 nullable, 7 i32 nullable, 8 i64 nullable,
+    #          9 f64 nullable, 10 i32 small key nullable
+    spec = [
+        (INT32, False, lambda r, m: r.integers(0, 2**31 - 1, m)),
+        (INT64, False, lambda r, m: r.integers(0, 100, m)),
+        (INT64, False, lambda r, m: r.integers(-500000, 500001, m)),
+        (DOUBLE, False, lambda r, m: r.random(m) * 1000.0),
+        (INT64, False, lambda r, m: r.integers(0, 3000, m) * 1000003 + 7),
+        (INT8, False, lambda r, m: r.integers(-100, 100, m)),
+        (INT16, True, lambda r, m: r.integers(-3000, 3000, m)),
+        (INT32, True, lambda r, m: r.integers(-10**6, 10**6, m)),
+        (INT64, True, lambda r, m: r.integers(-10**12, 10**12, m)),
+        (DOUBLE, True, lambda r, m: r.normal(0, 100, m)),
+        (INT32, True, lambda r, m: r.integers(5, 40, m)),
+    ]
+    descs, frags = make_table(rng, n, fs, spec)
+
+    def ra(targets, quals=(), group=(), guess=16384):
+        return RelAlgExecutionUnit(list(descs), list(targets), list(quals), list(group),
+                                   max_groups_buffer_entry_guess=guess)
+
+    # ---- Select.FilterAndSimpleAggregation
+    cases.append(Case("count_star_filter_i32_lt", ra([TargetExpr(COUNT)], [Qual(0, LT, 2**30)]), frags))
+    for op, lit in [(LE, 10**9), (GT, 10**9), (GE, 2**30), (EQ, int(frags[0][0][5])), (NE, int(frags[0][0][5]))]:
+        cases.append(Case(f"count_star_filter_i32_op{op}", ra([TargetExpr(COUNT)], [Qual(0, op, lit)]), frags))
+    cases.append(Case("count_star_filter_i64", ra([TargetExpr(COUNT)], [Qual(2, GT, 0)]), frags))
+    cases.append(Case("count_star_nofilter", ra([TargetExpr(COUNT)]), frags))
+    cases.append(Case("simple_aggs_all", ra([TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(MIN, 2),
+                                             TargetExpr(MAX, 2), TargetExpr(AVG, 2), TargetExpr(SUM, 3),
+                                             TargetExpr(AVG, 3)]), frags))
+    cases.append(Case("simple_aggs_minmax_f64", ra([TargetExpr(MIN, 3), TargetExpr(MAX, 3),
+                                                    TargetExpr(MIN, 5), TargetExpr(MAX, 5)],
+                                                   [Qual(3, LT, 500.0)]), frags))
+    cases.append(Case("simple_aggs_nullable", ra([TargetExpr(COUNT, 7), TargetExpr(SUM, 7), TargetExpr(AVG, 8),
+                                                  TargetExpr(MIN, 6), TargetExpr(MAX, 9), TargetExpr(SUM, 9),
+                                                  TargetExpr(COUNT, 9), TargetExpr(AVG, 9)],
+                                                 [Qual(7, GT, -500000), Qual(0, LT, 2**30)]), frags))
+    cases.append(Case("simple_aggs_empty_result", ra([TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(MIN, 3),
+                                                      TargetExpr(AVG, 2), TargetExpr(MAX, 7)],
+                                                     [Qual(0, LT, -5)]), frags))  # all NULL but COUNT
+    cases.append(Case("filter_on_nullable_eq", ra([TargetExpr(COUNT), TargetExpr(SUM, 8)],
+                                                  [Qual(10, NE, 17)]), frags))   # NULL <> 17 is not true
+
+    # ---- GroupBy / GroupByPerfectHash / keyless vs keyed
+    cases.append(Case("perfect_key_sum_projectkey", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 2)], group=[1]), frags))
+    cases.append(Case("perfect_sum_only_keyed", ra([TargetExpr(SUM, 2)], group=[1]), frags))       # range spans 0 -> keyed
+    cases.append(Case("perfect_count_keyless", ra([TargetExpr(COUNT), TargetExpr(SUM, 2)], group=[1]), frags))
+    cases.append(Case("perfect_avg_keyless_idx1", ra([TargetExpr(AVG, 3), TargetExpr(MIN, 2)], group=[1]), frags))
+    cases.append(Case("perfect_minmax_f64_i64", ra([TargetExpr(MIN, 3), TargetExpr(MAX, 3), TargetExpr(MIN, 2),
+                                                    TargetExpr(MAX, 2), TargetExpr(COUNT)], group=[1]), frags))
+    cases.append(Case("perfect_filtered", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 3)],
+                                             [Qual(0, LT, 2**30)], [1]), frags))
+    cases.append(Case("perfect_int8_key", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 5)],
+                                             group=[5]), frags))
+    # ---- GroupByBoundariesAndNull: nullable key (NULL group = max+1), nullable args
+    cases.append(Case("perfect_nullable_key", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 2)],
+                                                 group=[10]), frags))
+    cases.append(Case("perfect_nullable_args", ra([TargetExpr(COUNT, 7), TargetExpr(SUM, 7), TargetExpr(AVG, 9),
+                                                   TargetExpr(MIN, 8), TargetExpr(MAX, 6), TargetExpr(SUM, 9)],
+                                                  group=[1]), frags))
+    cases.append(Case("perfect_nullable_key_and_args", ra([TargetExpr(MIN, 9), TargetExpr(MAX, 7), TargetExpr(AVG, 6)],
+                                                          [Qual(2, GE, -400000)], [10]), frags))
+
+    # ---- GroupByBaselineHash
+    cases.append(Case("baseline_count_avg", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 3)],
+                                              group=[4], guess=8192), frags))
+    cases.append(Case("baseline_filtered_count_avg", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 3)],
+                                                        [Qual(0, LT, 2**30)], [4], guess=8192), frags))
+    cases.append(Case("baseline_sum_min_max_i64", ra([TargetExpr(SUM, 2), TargetExpr(MIN, 2), TargetExpr(MAX, 2),
+                                                      TargetExpr(COUNT)], group=[4], guess=6001), frags))
+    cases.append(Case("baseline_nullable_args", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 8), TargetExpr(AVG, 7),
+                                                    TargetExpr(MIN, 9), TargetExpr(COUNT, 6)], group=[4], guess=7000),
+                      frags))
+    cases.append(Case("baseline_nullable_i64_key", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], group=[8],
+                                                      guess=3 * n), frags))
+    cases.append(Case("baseline_exact_fit", ra([TargetExpr(COUNT)], group=[4], guess=3000), frags))  # 100 % fill
+    cases.append(Case("baseline_out_of_slots", ra([TargetExpr(COUNT)], group=[4], guess=1000), frags,
+                      expect_error=-1))
+
+    # baseline with a 4-byte compact key: wide-ranged int32 values (fits int32, too wide for perfect)
+    descs32, frags32 = make_table(rng, n, fs, [
+        (INT32, False, lambda r, m: r.integers(0, 2000, m) * 1000003 % (2**31 - 3)),
+        (INT64, False, lambda r, m: r.integers(1, 10**6, m)),
+        (DOUBLE, False, lambda r, m: r.random(m)),
+    ])
+    cases.append(Case("baseline_key32_compact",
+                      RelAlgExecutionUnit(descs32, [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(AVG, 2)],
+                                          groupby_exprs=[0], max_groups_buffer_entry_guess=5000), frags32))
+
+    # ---- empty and tiny inputs
+    empty = [[np.zeros(0, NP[t]) for t, _, _ in spec]]
+    cases.append(Case("empty_input_nongrouped", ra([TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(AVG, 3)]), empty))
+    cases.append(Case("empty_input_perfect", ra([TargetExpr(COUNT), TargetExpr(SUM, 2)], group=[1]), empty))
+    cases.append(Case("no_fragments", ra([TargetExpr(COUNT), TargetExpr(MIN, 2)]), []))
+    one = [[c[:1] for c in frags[0]]]
+    cases.append(Case("single_row", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 3)], group=[1]), one))
+
+    # ---- Joins_InnerJoin_TwoTables / Joins_DifferentIntegerTypes
+    m = 700
+    dim_dense = rng.permutation(m).astype(np.int64)            # dense unique keys 0..m-1
+    dim_w = rng.integers(-1000, 1000, m).astype(np.int64)
+    dim_f = rng.random(m)
+    inner_descs = [InputColDescriptor(INT64, False, col_range([dim_dense], INT64, False)),
+                   InputColDescriptor(INT64, False, col_range([dim_w], INT64, False)),
+                   InputColDescriptor(DOUBLE, False, col_range([dim_f], DOUBLE, False))]
+    fdescs, ffrags = make_table(rng, n, fs, [
+        (INT64, False, lambda r, mm: r.integers(-50, m + 50, mm)),      # some keys miss
+        (INT64, False, lambda r, mm: r.integers(-10**6, 10**6, mm)),
+        (INT32, True, lambda r, mm: r.integers(0, m, mm)),              # int32 nullable join key
+        (INT64, False, lambda r, mm: r.integers(0, 30, mm)),            # group key
+    ])
+
+    def jra(targets, outer_col=0, quals=(), group=(), guess=16384):
+        return RelAlgExecutionUnit(list(fdescs), list(targets), list(quals), list(group),
+                                   inner_col_descs=list(inner_descs), join_outer_col=outer_col,
+                                   max_groups_buffer_entry_guess=guess)
+
+    dense_rng = col_range([dim_dense], INT64, False)
+    for pb, tag in [(False, "perfect"), (True, "keyed")]:
+        cases.append(Case(f"join_{tag}_sum_fact", jra([TargetExpr(SUM, 1)]), ffrags, [dim_dense, dim_w, dim_f],
+                          dim_dense, INT64, dense_rng, pb))
+        cases.append(Case(f"join_{tag}_sum_dim_count", jra([TargetExpr(SUM, 1, 1), TargetExpr(COUNT), TargetExpr(SUM, 1)]),
+                          ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, pb))
+        cases.append(Case(f"join_{tag}_int32_nullable_key", jra([TargetExpr(COUNT), TargetExpr(AVG, 2, 1),
+                                                                 TargetExpr(MIN, 1, 1)], outer_col=2),
+                          ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, pb))
+        cases.append(Case(f"join_{tag}_groupby", jra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 1, 1),
+                                                      TargetExpr(AVG, 2, 1)], group=[3], quals=[Qual(1, GT, 0)]),
+                          ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, pb))
+    cases.append(Case("join_no_match_at_all", jra([TargetExpr(SUM, 1), TargetExpr(COUNT)], quals=[Qual(0, LT, -10)]),
+                      ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, False))
+    sparse = (rng.permutation(5 * m)[:m].astype(np.int64)) * 1000003
+    sdescs = [InputColDescriptor(INT64, False, col_range([sparse], INT64, False))] + inner_descs[1:]
+    sfd, sff = make_table(rng, n, fs, [
+        (INT64, False, lambda r, mm: sparse[r.integers(0, m, mm)] + (r.random(mm) < 0.1)),
+        (INT64, False, lambda r, mm: r.integers(1, 1000, mm)),
+    ])
+    cases.append(Case("join_sparse_keyed_sum",
+                      RelAlgExecutionUnit(sfd, [TargetExpr(SUM, 1), TargetExpr(SUM, 1, 1), TargetExpr(COUNT)],
+                                          inner_col_descs=sdescs, join_outer_col=0),
+                      sff, [sparse, dim_w, dim_f], sparse, INT64, col_range([sparse], INT64, False), False))
+    return cases

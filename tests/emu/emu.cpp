@@ -1,0 +1,119 @@
+// emu.cpp — TEST-ONLY host emulation of the generic kernel's row logic.
+//
+// Compiles heavydb_amd/csrc/rowfunc.h + plan.cpp with plain g++ and -DMQ_EMU (device atomics
+// become single-threaded plain ops) so the plan-time layout decisions and the per-row
+// semantics of the product can be checked against the oracle on a machine without a GPU.
+// It is never part of libmi355q.so and never reachable from the product API.
+#include <cstring>
+#include <vector>
+
+#include "../../heavydb_amd/csrc/plan.h"
+#include "../../heavydb_amd/csrc/rowfunc.h"
+
+using namespace mq;
+
+extern "C" int32_t emu_qmd_init(const mi355q_plan* p, mi355q_qmd* q) { return qmd_init(*p, q); }
+
+extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
+                               int join_hash_type, const void* join_buf, int64_t join_min,
+                               int64_t join_max, int64_t join_entries, int64_t* out,
+                               mi355q_qmd* out_qmd) {
+  mi355q_qmd q;
+  if (int32_t e = qmd_init(*plan, &q)) return e;
+  DevPlan d;
+  if (int32_t e = build_dev_plan(*plan, q, &d)) return e;
+  if (plan->join_outer_col >= 0) {
+    d.join_col = plan->join_outer_col;
+    d.join_type = plan->cols[plan->join_outer_col].type;
+    d.join_nullable = plan->cols[plan->join_outer_col].nullable != 0;
+    d.join_hash_type = join_hash_type;
+    d.join_buf = join_buf;
+    d.join_min = join_min;
+    d.join_max = join_max;
+    d.join_entries = join_entries;
+    for (int i = 0; i < plan->n_inner_cols; ++i) d.inner_cols[i] = (const int8_t*)in->inner_col_buffers[i];
+  }
+  if (out_qmd) *out_qmd = q;
+  const int rq = q.row_size / 8, kq = q.key_bytes / 8;
+  for (int64_t e = 0; e < q.entry_count; ++e) {
+    for (int j = 0; j < rq; ++j) {
+      out[e * rq + j] = j < kq ? (q.key_width == 4 ? (int64_t)(uint32_t)kEmptyKey32 : kEmptyKey64)
+                               : q.init_vals[j - kq];
+    }
+  }
+  const bool ng = q.desc_type == MI355Q_NON_GROUPED_AGGREGATE;
+  // emulate several "threads" for the non-grouped fold: rows are dealt round-robin to 7
+  // partial rows which are then folded exactly like the kernel's block fold + global merge
+  constexpr int kThreads = 7;
+  std::vector<int64_t> loc(kThreads * (MI355Q_MAX_SLOTS + 1));
+  for (int t = 0; t < kThreads; ++t)
+    for (int s = 0; s < d.slot_count; ++s) loc[t * (MI355Q_MAX_SLOTS + 1) + s] = d.init_vals[s];
+  for (int f = 0; f < in->n_frags; ++f) {
+    const int8_t* const* cols = (const int8_t* const*)(in->col_buffers + (size_t)f * plan->n_cols);
+    for (int64_t pos = 0; pos < in->num_rows[f]; ++pos) {
+      int32_t e;
+      if (ng) {
+        e = process_row<false>(d, cols, pos, out, loc.data() + (pos % kThreads) * (MI355Q_MAX_SLOTS + 1));
+      } else {
+        e = process_row<true>(d, cols, pos, out, nullptr);
+      }
+      if (e) return e;
+    }
+  }
+  if (ng) {
+    for (int ti = 0; ti < d.n_targets; ++ti) {
+      const DevTarget& t = d.targets[ti];
+      int64_t acc[2] = {d.init_vals[t.slot], t.agg == MI355Q_AVG ? d.init_vals[t.slot + 1] : 0};
+      DevTarget lt = t;
+      lt.slot = 0;
+      int64_t lin[2] = {d.init_vals[t.slot], 0};
+      for (int th = 0; th < kThreads; ++th) {
+        reduce_target<false>(lt, lin, acc, loc.data() + th * (MI355Q_MAX_SLOTS + 1) + t.slot);
+      }
+      int64_t that[2] = {acc[0], acc[1]};
+      reduce_target<true>(lt, lin, out + t.slot, that);
+    }
+  }
+  return 0;
+}
+
+// this += that through the same code the k_reduce kernel runs per entry
+extern "C" int32_t emu_reduce(const mi355q_qmd* q, int64_t* this_buf, const int64_t* that_rows,
+                              int64_t that_entries) {
+  DevPlan d;
+  std::memset(&d, 0, sizeof(d));
+  d.n_targets = q->n_targets;
+  for (int i = 0; i < q->n_targets; ++i) {
+    d.targets[i].agg = q->target_agg[i];
+    d.targets[i].col = -1;
+    d.targets[i].skip_null = q->target_skip_null[i];
+    d.targets[i].slot = q->target_slot[i];
+    d.targets[i].arg_fp = q->target_arg_is_fp[i];
+  }
+  d.slot_count = q->slot_count;
+  d.desc_type = q->desc_type;
+  d.keyless = q->keyless;
+  d.key_width = q->key_width;
+  d.row_quad = q->row_size / 8;
+  d.key_quad = q->key_bytes / 8;
+  d.entry_count = q->entry_count;
+  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) d.init_vals[i] = q->init_vals[i];
+  for (int64_t e = 0; e < that_entries; ++e) {
+    const int64_t* src = that_rows + e * d.row_quad;
+    if (is_empty_row(d, src, q->idx_target_as_key)) continue;
+    int64_t* slots;
+    if (d.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
+      const int64_t key = d.key_width == 4 ? (int64_t) * (const int32_t*)src : src[0];
+      slots = baseline_find_or_insert(this_buf, (uint32_t)d.entry_count, d.row_quad, d.key_width, key);
+      if (!slots) return MI355Q_ERR_OUT_OF_SLOTS;
+    } else {
+      int64_t* row = this_buf + e * d.row_quad;
+      if (d.key_quad) row[0] = src[0];
+      slots = row + d.key_quad;
+    }
+    for (int i = 0; i < d.n_targets; ++i) {
+      reduce_target<true>(d.targets[i], d.init_vals, slots, src + d.key_quad);
+    }
+  }
+  return 0;
+}

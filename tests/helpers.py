@@ -1,0 +1,128 @@
+"""Comparison helpers for ResultSetStorage buffers (oracle vs product)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from heavydb_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMPTY64 = 2**63 - 1
+EMPTY32 = 2**31 - 1
+
+
+def qmd_equal(a: capi.QMD, b: capi.QMD):
+    da, db = a.as_dict(), b.as_dict()
+    assert da == db, {k: (da[k], db[k]) for k in da if da[k] != db[k]}
+
+
+def fp_slots(q: capi.QMD):
+    """Slot indices holding double bits."""
+    s = set()
+    for t in range(q.n_targets):
+        if q.target_arg_is_fp[t] and q.target_slot[t] >= 0:
+            s.add(q.target_slot[t])
+    return s
+
+
+def _close(a: int, b: int, rtol: float) -> bool:
+    if a == b:
+        return True
+    fa = np.array([a], dtype=np.int64).view(np.float64)[0]
+    fb = np.array([b], dtype=np.int64).view(np.float64)[0]
+    return bool(np.isfinite(fa) and np.isfinite(fb) and abs(fa - fb) <= rtol * max(abs(fa), abs(fb), 1e-300))
+
+
+def compare_buffers(q: capi.QMD, want: np.ndarray, got: np.ndarray, rtol: float = 1e-9):
+    """Perfect-hash / non-grouped: index-aligned, bit-exact for integer quads, rtol on fp64
+    slots.  Baseline: compared as key -> slots maps (slot positions are insertion-order
+    dependent even in the reference; docs hash_joins.rst)."""
+    rq, kq = q.row_size // 8, q.key_bytes // 8
+    want = want.reshape(-1, rq)
+    got = got.reshape(-1, rq)
+    assert want.shape == got.shape
+    fps = fp_slots(q)
+    if q.desc_type == capi.GROUP_BY_BASELINE_HASH:
+        def to_map(buf):
+            m = {}
+            if q.key_width == 4:
+                keys = buf[:, 0].copy().view(np.int32)[::2]
+                live = keys != EMPTY32
+            else:
+                keys = buf[:, 0]
+                live = keys != EMPTY64
+            for i in np.nonzero(live)[0]:
+                k = int(keys[i])
+                assert k not in m, f"duplicate key {k} in table"
+                m[k] = buf[i, kq:]
+            return m
+        mw, mg = to_map(want), to_map(got)
+        assert mw.keys() == mg.keys(), (len(mw), len(mg))
+        for k, w in mw.items():
+            g = mg[k]
+            for s in range(q.slot_count):
+                if s in fps:
+                    assert _close(int(w[s]), int(g[s]), rtol), (k, s, w, g)
+                else:
+                    assert int(w[s]) == int(g[s]), (k, s, w, g)
+        return
+    int_cols = [c for c in range(rq) if not (c >= kq and (c - kq) in fps)]
+    bad = np.nonzero((want[:, int_cols] != got[:, int_cols]).any(axis=1))[0]
+    assert bad.size == 0, (bad[:5], want[bad[:5]], got[bad[:5]])
+    for s in fps:
+        w = want[:, kq + s]
+        g = got[:, kq + s]
+        diff = np.nonzero(w != g)[0]
+        for i in diff:
+            assert _close(int(w[i]), int(g[i]), rtol), (i, s, w[i], g[i])
+
+
+def compare_rows(q: capi.QMD, want, got, rtol: float = 1e-9):
+    """fetch_rows outputs (ival, dval, is_null): exact for ints/nulls, rtol for doubles;
+    baseline rows are matched as multisets via sorting on the integer columns."""
+    wi, wd, wn = want
+    gi, gd, gn = got
+    assert wi.shape == gi.shape, (wi.shape, gi.shape)
+    if q.desc_type == capi.GROUP_BY_BASELINE_HASH and wi.shape[0] > 1:
+        def order(i, d):
+            return np.lexsort(tuple(i[:, c] for c in range(i.shape[1])[::-1]))
+        ow, og = order(wi, wd), order(gi, gd)
+        wi, wd, wn = wi[ow], wd[ow], wn[ow]
+        gi, gd, gn = gi[og], gd[og], gn[og]
+    assert (wi == gi).all()
+    assert (wn == gn).all()
+    ok = np.isclose(wd, gd, rtol=rtol, atol=0.0) | (wd == gd)
+    assert ok.all(), (wd[~ok][:5], gd[~ok][:5])
+
+
+_emu = None
+
+
+def emu_lib() -> C.CDLL:
+    """Host emulation of the product's row logic (tests/emu/emu.cpp, -DMQ_EMU)."""
+    global _emu
+    if _emu is None:
+        out = os.path.join(ROOT, "tests", "_emu", "libemu.so")
+        srcs = [os.path.join(ROOT, "tests", "emu", "emu.cpp"),
+                os.path.join(ROOT, "heavydb_amd", "csrc", "plan.cpp")]
+        deps = srcs + [os.path.join(ROOT, "heavydb_amd", "csrc", h)
+                       for h in ("rowfunc.h", "dev_common.h", "plan.h")] + \
+            [os.path.join(ROOT, "include", "mi355q.h")]
+        if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DMQ_EMU", "-Wall",
+                            "-Wno-unused-function"] + srcs + ["-o", out], check=True)
+        l = C.CDLL(out)
+        P = C.POINTER
+        l.emu_qmd_init.restype = C.c_int32
+        l.emu_qmd_init.argtypes = [P(capi.Plan), P(capi.QMD)]
+        l.emu_execute.restype = C.c_int32
+        l.emu_execute.argtypes = [P(capi.Plan), P(capi.Inputs), C.c_int, C.c_void_p, C.c_int64,
+                                  C.c_int64, C.c_int64, C.c_void_p, P(capi.QMD)]
+        l.emu_reduce.restype = C.c_int32
+        l.emu_reduce.argtypes = [P(capi.QMD), C.c_void_p, C.c_void_p, C.c_int64]
+        _emu = l
+    return _emu
