@@ -431,6 +431,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   *out = nullptr;
   mi355q_exec_options o{};
   if (opts) o = *opts;
+  set_debug_knobs(o.reserved[0], o.reserved[1]);
 
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;

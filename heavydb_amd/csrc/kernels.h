@@ -26,6 +26,11 @@ struct LaunchStats {
   unsigned long long* spill_counter = nullptr;  // device word (read back by the caller)
 };
 
+// tuning knobs for experiments (exec_options.reserved[0..1]); 0 = built-in choice
+int debug_blocks_per_cu();
+int debug_part_p();
+void set_debug_knobs(int blocks_per_cu, int part_p);
+
 // ---- generic family (kernels_generic.hip)
 hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,
                               hipStream_t s);

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_count(const int8_t* const* __re
                                                         int n_frags, int n_cols, RangeFilter flt,
                                                         int64_t* __restrict__ out) {
   unsigned long long cnt = 0;
-  scan_fragments<FT, none_t, none_t>(cols, num_rows, n_frags, n_cols, flt.col, 0, 0,
+  scan_fragments<FT, none_t, none_t, 8>(cols, num_rows, n_frags, n_cols, flt.col, 0, 0,
                                      [&](FT fv, none_t, none_t) { cnt += filter_pass<FT>(flt, fv); });
   cnt = wave_sum_u64(cnt);
   __shared__ unsigned long long s_part[kBlock / 64];
@@ -273,6 +273,8 @@ __global__ __launch_bounds__(kBlock) void k_join_sum(const int8_t* const* __rest
 
 // ---------------------------------------------------------------------------- host side
 inline int stream_grid(int n_cus, int blocks_per_cu, int64_t total_rows) {
+  const int dbg = debug_blocks_per_cu();
+  if (dbg > 0) blocks_per_cu = dbg;
   int64_t want = (total_rows / 4 + kBlock - 1) / kBlock;
   int64_t cap = (int64_t)n_cus * blocks_per_cu;
   if (want < 1) want = 1;
@@ -297,7 +299,7 @@ hipError_t launch_scan_count(const DevPlan& p, const FragView& fv, int64_t* out,
                              hipStream_t s, LaunchStats* st) {
   RangeFilter f;
   make_range_filter(p.quals[0], &f);
-  const int grid = stream_grid(n_cus, 8, fv.total_rows);
+  const int grid = stream_grid(n_cus, 2, fv.total_rows);
   st->kernel_name = "k_scan_count";
   st->n_launches = 1;
   rec(st->k_start, s);
@@ -353,7 +355,7 @@ hipError_t launch_perfect_lds(const DevPlan& p, const FragView& fv, int64_t* out
   for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) a.init[i] = p.init_vals[i];
   const size_t lds = (size_t)(p.entry_count * p.row_quad * 8);
   int bpc = (int)((160 * 1024) / (lds + 512));
-  if (bpc > 8) bpc = 8;
+  if (bpc > 4) bpc = 4;
   if (bpc < 1) bpc = 1;
   const int grid = stream_grid(n_cus, bpc, fv.total_rows);
   st->kernel_name = "k_perfect_lds";
@@ -493,7 +495,7 @@ hipError_t launch_join_sum(const DevPlan& p, const FragView& fv, int64_t* out, i
                            hipStream_t s, LaunchStats* st) {
   JoinSumArgs a;
   join_sum_shape(p, fv, &a);
-  const int grid = stream_grid(n_cus, 8, fv.total_rows);
+  const int grid = stream_grid(n_cus, 4, fv.total_rows);
   st->kernel_name = "k_join_sum";
   st->n_launches = 1;
   rec(st->k_start, s);

@@ -280,6 +280,14 @@ inline int grid_for(int64_t work_items, int max_blocks = 2048) {
 
 }  // namespace
 
+static thread_local int g_dbg_bpc = 0, g_dbg_p = 0;
+int debug_blocks_per_cu() { return g_dbg_bpc; }
+int debug_part_p() { return g_dbg_p; }
+void set_debug_knobs(int blocks_per_cu, int part_p) {
+  g_dbg_bpc = blocks_per_cu;
+  g_dbg_p = part_p;
+}
+
 hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,
                               hipStream_t s) {
   const int64_t quads = entry_count * init.row_quad;

@@ -373,6 +373,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   uint32_t P = next_pow2((groups + (uint64_t)(0.55 * e_max) - 1) / (uint64_t)(0.55 * e_max));
   const uint32_t p_max = staged ? 2048u : 8192u;
   if (P > p_max) P = p_max;
+  if (debug_part_p() > 0) P = next_pow2((uint64_t)debug_part_p()) > p_max ? p_max : next_pow2((uint64_t)debug_part_p());
   h.g.P = (int32_t)P;
   h.g.lgP = 0;
   while ((1u << h.g.lgP) < P) ++h.g.lgP;
