@@ -11,7 +11,9 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,6 +66,18 @@ struct DeviceGuard {
   }
   ~DeviceGuard() {
     if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+// MI355Q_TRACE=1: host-side wall-clock marks of one execute call on stderr
+struct Trace {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  Trace() : on(std::getenv("MI355Q_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(stderr, "[mi355q] %8.3f ms  %s\n", ms, what);
   }
 };
 
@@ -433,6 +447,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   if (opts) o = *opts;
   set_debug_knobs(o.reserved[0], o.reserved[1]);
 
+  Trace tr;
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;
   DevPlan d;
@@ -534,6 +549,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     else if (join_sum_eligible(d, fv)) kind = K_JOIN_SUM;
   }
 
+  tr.mark("setup done");
   DevWord scratch;
   int64_t scratch_bytes = 0;
   if (kind == K_BASELINE_FAST) {
@@ -547,6 +563,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     }
   }
 
+  tr.mark("scratch allocated");
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
   HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
 
@@ -574,15 +591,26 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     }
   }
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
+  tr.mark("launched");
 
   int32_t h_err[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
-  unsigned long long h_spills = 0;
-  if (st.spill_counter) {
-    HIP_TRY(hipMemcpyAsync(&h_spills, st.spill_counter, sizeof(h_spills), hipMemcpyDeviceToHost, s));
+  uint32_t h_spills = 0;
+  if (st.spill_counter32) {
+    HIP_TRY(hipMemcpyAsync(&h_spills, st.spill_counter32, sizeof(h_spills), hipMemcpyDeviceToHost, s));
   }
   HIP_TRY(hipStreamSynchronize(s));
+  tr.mark("synchronized");
   st.spilled_rows = (int64_t)h_spills;
+  if (h_err[1] && kind == K_BASELINE_FAST) {
+    // the partitioned family ran out of spill space (extreme skew): redo the step with the
+    // direct-atomic member of the same family
+    HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
+    HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+    HIP_TRY(launch_baseline_fast(d, fv, res->buf, d_err, nullptr, 0, 0, 1, n_cus, s, &st));
+    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
 
   if (report) {
     std::memset(report, 0, sizeof(*report));

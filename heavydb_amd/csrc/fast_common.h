@@ -63,6 +63,10 @@ template <typename T>
 MQ_D T quad_get(const Quad<T>& q, int i) { return q.v[i]; }
 template <>
 MQ_D none_t quad_get<none_t>(const Quad<none_t>&, int) { return none_t{}; }
+template <typename T>
+MQ_D void quad_set(Quad<T>& q, int i, T v) { q.v[i] = v; }
+template <>
+MQ_D void quad_set<none_t>(Quad<none_t>&, int, none_t) {}
 
 // Filter normalised at plan time to  lo <= v <= hi  (optionally negated for <>), plus the
 // NULL exclusion of DEF_CMP_NULLABLE (RuntimeFunctions.cpp:73-83).

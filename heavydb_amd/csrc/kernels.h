@@ -23,7 +23,7 @@ struct LaunchStats {
   hipEvent_t* ev_pool = nullptr;
   int n_ev = 0;
   int n_events_used = 0;
-  unsigned long long* spill_counter = nullptr;  // device word (read back by the caller)
+  uint32_t* spill_counter32 = nullptr;  // device word (read back by the caller)
 };
 
 // tuning knobs for experiments (exec_options.reserved[0..1]); 0 = built-in choice
@@ -86,15 +86,17 @@ hipError_t launch_baseline_fast(const DevPlan& p, const FragView& fv, int64_t* o
                                 LaunchStats* st);
 int64_t baseline_fast_scratch_bytes(const DevPlan& p, const FragView& fv, int variant,
                                     int64_t cap_bytes, int n_cus);
-// variant resolution: 1 direct atomics, 2 partitioned, 3 partitioned + LDS write combining
-int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested);
+// variant resolution: 1 direct atomics, 2 partition-then-aggregate
+int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested, int n_cus);
 
 // kernels_part.hip
-int64_t part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes,
-                           bool staged);
+bool part_supported(const DevPlan& p, const FragView& fv, int n_cus);
+int64_t part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes);
+// d_err[0]: reference error code; d_err[1]: set when the spill list overflowed (the caller
+// re-runs the step with the direct kernel)
 hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int64_t* out,
                                        int32_t* d_err, void* scratch, int64_t scratch_bytes,
-                                       int64_t cap_bytes, bool staged, int n_cus, hipStream_t s,
+                                       int64_t cap_bytes, int n_cus, hipStream_t s,
                                        LaunchStats* st);
 
 bool join_sum_eligible(const DevPlan& p, const FragView& fv);

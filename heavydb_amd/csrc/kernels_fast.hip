@@ -387,17 +387,19 @@ bool baseline_fast_eligible(const DevPlan& p, const FragView& fv) {
 
 // Plan-time choice inside the baseline family: tiny inputs or tiny tables are fastest with
 // direct atomics; everything else partitions.
-int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested) {
-  if (requested >= 1 && requested <= 3) return requested;
-  if (fv.total_rows < (int64_t)8 << 20 || p.entry_count < 65536) return 1;
+int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested, int n_cus) {
+  if (requested == 1) return 1;
+  const bool can_part = part_supported(p, fv, n_cus);
+  if (requested == 2) return can_part ? 2 : 1;
+  if (!can_part || fv.total_rows < (int64_t)8 << 20 || p.entry_count < 65536) return 1;
   return 2;
 }
 
 int64_t baseline_fast_scratch_bytes(const DevPlan& p, const FragView& fv, int variant,
                                     int64_t cap_bytes, int n_cus) {
-  const int v = baseline_fast_variant(p, fv, variant);
+  const int v = baseline_fast_variant(p, fv, variant, n_cus);
   if (v == 1) return 0;
-  return part_scratch_bytes(p, fv, n_cus, cap_bytes, v == 3);
+  return part_scratch_bytes(p, fv, n_cus, cap_bytes);
 }
 
 template <typename FT>
@@ -420,10 +422,10 @@ static hipError_t launch_baseline_direct_v(const FastShape& fs, const BaselineAr
 hipError_t launch_baseline_fast(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err,
                                 void* scratch, int64_t scratch_bytes, int64_t cap_bytes,
                                 int variant, int n_cus, hipStream_t s, LaunchStats* st) {
-  const int v = baseline_fast_variant(p, fv, variant);
+  const int v = baseline_fast_variant(p, fv, variant, n_cus);
   if (v != 1) {
-    return launch_baseline_partitioned(p, fv, out, d_err, scratch, scratch_bytes, cap_bytes, v == 3,
-                                       n_cus, s, st);
+    return launch_baseline_partitioned(p, fv, out, d_err, scratch, scratch_bytes, cap_bytes, n_cus, s,
+                                       st);
   }
   FastShape fs;
   grouped_fast_shape(p, fv, &fs);

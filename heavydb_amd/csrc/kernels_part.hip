@@ -4,24 +4,37 @@
 // Why: with 10 M groups the output table (20 M x 32 B = 640 MB) is larger than every on-chip
 // memory, so updating it row by row (the reference's GPU path: one CAS + atomics per row,
 // cuda_mapd_rt.cu:180-246,436-545) turns every row into random HBM read-modify-writes.
-// Instead the scan hash-partitions the surviving rows into P key ranges sized so that one
-// range's groups fit a per-CU LDS hash table, and a second kernel aggregates each range
-// entirely in LDS and emits each group ONCE into the HeavyDB-layout table:
+// Here the scan range-partitions the surviving rows by the HOME SLOT the reference would
+// probe first,  home = MurmurHash3(key) % entry_count  (GroupByRuntime.cpp:20-48), a second
+// kernel aggregates each home-slot range in a per-CU LDS table, places the groups with the
+// reference's own linear probing rule and writes the range of the output table with plain
+// coalesced stores.  No global atomic is issued per row, and the finished buffer is a valid
+// linear-probing image of get_group_value: every key sits at or after its home slot with no
+// empty slot in between.
 //
-//   phase 1  k_part_scatter    stream the columns (16 B/lane loads), filter, hash, append the
-//                              16-byte record {key, value bits} to this block's private run
-//                              of partition p.  Runs are block-private, so the cursors are LDS
-//                              atomics and no global atomic is issued per row.  STAGED = true
-//                              write-combines four records per partition in LDS and emits
-//                              whole 64-byte lines.
-//   phase 2  k_part_aggregate  one workgroup per partition: LDS open-addressing table
-//                              {key, partial slots}, ds atomics per record, then one
-//                              insert-or-find + atomics per GROUP into the output table.
-//
-// Robustness: a run that overflows its capacity, or an LDS table that fills up, sends the row
-// straight to the output table with the same CAS + atomics the direct kernel uses, so skewed
-// inputs degrade in speed, never in correctness.  Rows are processed in chunks of fragments
-// so the scratch stays bounded.
+//   phase 1  k_part_scatter    stream the columns (16 B/lane non-temporal loads, next tile
+//                              prefetched into registers), filter, hash, append the 16-byte
+//                              record {key, value bits} to this workgroup's private run of
+//                              partition p.  Records are write-combined in LDS: a partition
+//                              owns one line of L = 8192 / P records (128 B at P = 1024, the
+//                              smallest write MI355X's HBM absorbs at streaming efficiency —
+//                              tools/microbench/scatter.hip) and a full line leaves as one
+//                              coalesced store.  Two workgroup barriers per 4096-row tile.
+//   phase 2  k_part_aggregate  one workgroup per (partition, sub-range): LDS open-addressing
+//                              table {key, partial slots} fed with ds atomics; sub-ranges
+//                              (R > 1) re-read the partition's runs and keep their own home
+//                              range, so an LDS table only ever holds entry_count / (2 P R)
+//                              groups.  Emission claims canonical slots in an LDS bitmap and
+//                              stores rows + empty rows; a later chunk first re-loads the
+//                              range (merge).
+//   phase 3  k_spill_merge     the few groups that probe past the end of their range, and
+//                              every record that met a full run / full LDS table, are kept
+//                              as partial rows in a spill list and merged last with the
+//                              reference's CAS insert-or-find, so skew costs speed, never
+//                              correctness.
+#include <cstdio>
+#include <cstdlib>
+
 #include "fast_common.h"
 
 namespace mq {
@@ -31,23 +44,58 @@ using namespace fast;
 namespace {
 
 constexpr int kPartBlock = 1024;
+constexpr int kStageRecs = 8192;       // staged records per workgroup (128 KB of LDS)
+constexpr int kSegRecs = 8;            // records per 128-byte segment (one owner lane each)
+constexpr int kMaxInt = 8;             // internal (LDS) partial slots per group
+constexpr int kMaxSub = 4;             // sub-ranges per partition
+constexpr uint32_t kSpillCap = 1u << 20;
 
 struct alignas(16) Rec {
   int64_t key;
   int64_t val;
 };
 
+struct SpillEntry {
+  int64_t key;
+  int64_t part[kMaxInt];
+};
+
+// home slot arithmetic with plan-time magic numbers (exact for 32-bit operands:
+// Lemire, "Faster remainder by direct computation", 2019)
+struct HomeMap {
+  uint32_t d;        // entry_count
+  uint32_t S1;       // home slots per partition
+  uint32_t S2;       // home slots per sub-range
+  uint32_t R;        // sub-ranges per partition
+  uint64_t d_magic;  // 2^64 / d + 1
+  uint64_t s1_magic; // 2^64 / S1 + 1
+};
+
+MQ_D uint32_t home_of(const HomeMap& m, int64_t key) {
+  const uint32_t h = murmur3_u64((uint64_t)key);
+  const uint64_t low = m.d_magic * (uint64_t)h;
+  return (uint32_t)__umul64hi(low, (uint64_t)m.d);
+}
+MQ_D uint32_t part_of(const HomeMap& m, uint32_t home) {
+  return (uint32_t)__umul64hi(m.s1_magic, (uint64_t)home);
+}
+
 struct PartGeom {
-  int32_t P, lgP, B;
-  uint32_t cap;      // records per (block, partition) run
-  uint32_t E;        // LDS table entries in phase 2
-  int32_t ns_int;    // distinct partial slots kept per group in LDS
+  int32_t P, lgL, B;   // partitions, log2(records per staged line), scatter workgroups
+  uint32_t L;          // records per line = kStageRecs / P
+  uint32_t cap;        // records per (workgroup, partition) run, multiple of L
+  uint32_t E;          // LDS table entries in phase 2
+  uint32_t b_mult;     // floor((E / 4) * 2^32 / S2): monotone map home-offset -> LDS bucket
+  int32_t ns_int;      // distinct partial slots kept per group in LDS
+  uint32_t lds_table_bytes;  // keys + slot arrays of the LDS table (16-byte multiple)
+  uint32_t slot_off[kMaxInt];  // byte offset of each internal slot array in LDS
+  HomeMap hm;
 };
 
 struct PartSlots {
-  int32_t int_op[8];                 // op of each internal slot
-  int32_t out_map[MI355Q_MAX_SLOTS]; // output slot -> internal slot
-  int64_t int_init[8];               // identity of each internal slot
+  int32_t int_op[kMaxInt];            // op of each internal slot
+  int32_t out_map[MI355Q_MAX_SLOTS];  // output slot -> internal slot (-1: key / none)
+  int64_t int_init[kMaxInt];          // identity of each internal slot
 };
 
 struct TableArgs {
@@ -55,17 +103,33 @@ struct TableArgs {
   uint32_t entry_count;
   int32_t row_quad;
   SlotProg sp;
+  int64_t init[MI355Q_MAX_SLOTS];
 };
 
-MQ_D void spill_direct(const TableArgs& t, int64_t key, int64_t val_bits, int32_t* d_err,
-                       unsigned long long* spills) {
-  int64_t* slots = baseline_find_or_insert(t.out, t.entry_count, t.row_quad, 8, key);
-  if (!slots) {
-    atomicCAS(d_err, 0, -1);
+struct SpillList {
+  uint32_t* count;     // device word
+  SpillEntry* entries;
+  int32_t* d_err;      // [0] reference error code, [1] spill list overflow
+};
+
+// LDS-only barrier: waits for this wave's LDS traffic, NOT for its outstanding global loads,
+// so the next tile's column loads stay in flight across the two barriers of a round.
+MQ_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+MQ_D void spill_append(const SpillList& sl, int64_t key, const int64_t* part, int n) {
+  const uint32_t i = atomicAdd(sl.count, 1u);
+  if (i >= kSpillCap) {
+    atomicExch(sl.d_err + 1, 1);
     return;
   }
-  apply_slots_global(t.sp, slots, bits_dbl(val_bits), val_bits);
-  atomicAdd(spills, 1ull);
+  SpillEntry& e = sl.entries[i];
+  e.key = key;
+  for (int j = 0; j < n; ++j) e.part[j] = part[j];
+}
+MQ_D void spill_record(const SpillList& sl, const PartSlots& ps, int ns, int64_t key, int64_t vb) {
+  int64_t part[kMaxInt];
+  for (int j = 0; j < kMaxInt; ++j) part[j] = ps.int_op[j] == SO_COUNT ? 1 : vb;
+  spill_append(sl, key, part, ns);
 }
 
 template <typename VT>
@@ -77,161 +141,254 @@ MQ_D int64_t val_bits_of<double>(double v) { return dbl_bits(v); }
 template <>
 MQ_D int64_t val_bits_of<none_t>(none_t) { return 0; }
 
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+
 // ------------------------------------------------------------------------- phase 1
-template <typename FT, typename VT, bool STAGED>
-__global__ __launch_bounds__(kPartBlock) void k_part_scatter(
-    const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows, int n_frags,
-    int n_cols, RangeFilter flt, int kcol, int vcol, PartGeom g, Rec* __restrict__ scratch,
-    uint32_t* __restrict__ cnt, TableArgs tab, int32_t* __restrict__ d_err,
-    unsigned long long* __restrict__ spills) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  uint32_t* cursor = (uint32_t*)smem_raw;  // [P] records appended so far
-  const int b = blockIdx.x;
-  for (int i = threadIdx.x; i < g.P; i += kPartBlock) cursor[i] = 0;
-  __syncthreads();
-  const int sh = 32 - g.lgP;
-  if (!STAGED) {
-    scan_fragments<FT, int64_t, VT>(cols, num_rows, n_frags, n_cols, flt.col, kcol, vcol,
-                                    [&](FT fv, int64_t key, VT val) {
-      if (!filter_pass<FT>(flt, fv)) return;
-      const uint32_t h = murmur3_u64((uint64_t)key);
-      const uint32_t pid = g.lgP ? (h >> sh) : 0u;
-      const uint32_t slot = atomicAdd(&cursor[pid], 1u);
-      const int64_t vb = val_bits_of<VT>(val);
-      if (slot < g.cap) {
-        Rec r{key, vb};
-        scratch[((size_t)pid * g.B + b) * g.cap + slot] = r;
-      } else {
-        spill_direct(tab, key, vb, d_err, spills);
-      }
-    });
+template <typename FT, typename VT>
+struct Tile {
+  Quad<FT> f;
+  Quad<int64_t> k;
+  Quad<VT> v;
+  int valid;  // rows of this lane's quad that exist (0..4)
+};
+
+template <typename FT, typename VT>
+MQ_D void load_tile(const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows,
+                    int n_cols, int fcol, int kcol, int vcol, int f, int64_t tile_in_frag,
+                    Tile<FT, VT>& t) {
+  const int8_t* const* fc = cols + (size_t)f * n_cols;
+  const int64_t n = num_rows[f];
+  const int64_t q = tile_in_frag * kPartBlock + threadIdx.x;
+  const int64_t r0 = q << 2;
+  t.valid = 0;
+  if (r0 >= n) return;
+  const int8_t* fb = is_none<FT>::value ? nullptr : fc[fcol];
+  const int8_t* kb = fc[kcol];
+  const int8_t* vb = is_none<VT>::value ? nullptr : fc[vcol];
+  if (r0 + 4 <= n) {
+    load_quad<FT>(fb, q, t.f);
+    load_quad<int64_t>(kb, q, t.k);
+    load_quad<VT>(vb, q, t.v);
+    t.valid = 4;
   } else {
-    // LDS write-combining: 4-record (64-byte) staging line per partition.  A record with
-    // stream position `slot` may enter the line only while generation slot>>2 is the one
-    // being filled; the lane that lands on position 3 queues the line for a cooperative
-    // 64-byte flush after the barrier.
-    Rec* stage = (Rec*)(smem_raw + (((size_t)g.P * 4 + 15) & ~(size_t)15));  // [P][4]
-    uint32_t* flushed = (uint32_t*)(stage + (size_t)g.P * 4);                // [P] gens flushed
-    uint32_t* full_list = flushed + g.P;                                     // [P]: <= 1 line per stream per round
-    __shared__ uint32_t s_nfull;
-    __shared__ uint32_t s_pending;
-    for (int i = threadIdx.x; i < g.P; i += kPartBlock) flushed[i] = 0;
-    if (threadIdx.x == 0) {
-      s_nfull = 0;
-      s_pending = 0;
-    }
-    __syncthreads();
-    const int64_t gtid = (int64_t)blockIdx.x * kPartBlock + threadIdx.x;
-    const int64_t gsize = (int64_t)gridDim.x * kPartBlock;
-    for (int f = 0; f < n_frags; ++f) {
-      const int8_t* const* fc = cols + (size_t)f * n_cols;
-      const int8_t* fb = is_none<FT>::value ? nullptr : fc[flt.col];
-      const int8_t* kb = fc[kcol];
-      const int8_t* vb = is_none<VT>::value ? nullptr : fc[vcol];
-      const int64_t n = num_rows[f];
-      const int64_t nq = (n + 3) >> 2;
-      // every lane walks the same number of tiles so the barriers stay uniform
-      const int64_t tiles = (nq + gsize - 1) / gsize;
-      for (int64_t t = 0; t < tiles; ++t) {
-        const int64_t q = gtid + t * gsize;
-        int64_t keys[4], vals[4];
-        uint32_t pid[4], slot[4];
-        uint32_t pend = 0;
-        if (q < nq) {
-          const int64_t r0 = q << 2;
-          if (r0 + 4 <= n) {
-            Quad<FT> f0;
-            Quad<int64_t> k0;
-            Quad<VT> v0;
-            load_quad<FT>(fb, q, f0);
-            load_quad<int64_t>(kb, q, k0);
-            load_quad<VT>(vb, q, v0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if (filter_pass<FT>(flt, quad_get(f0, i))) pend |= 1u << i;
-              keys[i] = k0.v[i];
-              vals[i] = val_bits_of<VT>(quad_get(v0, i));
-            }
-          } else {
-            for (int i = 0; i < 4 && r0 + i < n; ++i) {
-              if (filter_pass<FT>(flt, load_one<FT>(fb, r0 + i))) pend |= 1u << i;
-              keys[i] = load_one<int64_t>(kb, r0 + i);
-              vals[i] = val_bits_of<VT>(load_one<VT>(vb, r0 + i));
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (pend & (1u << i)) {
-            const uint32_t h = murmur3_u64((uint64_t)keys[i]);
-            pid[i] = g.lgP ? (h >> sh) : 0u;
-            slot[i] = atomicAdd(&cursor[pid[i]], 1u);
-            if (slot[i] >= g.cap) {  // run full: straight to the output table
-              spill_direct(tab, keys[i], vals[i], d_err, spills);
-              pend &= ~(1u << i);
-            }
-          }
-        }
-        for (;;) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            if ((pend & (1u << i)) && (slot[i] >> 2) == *(volatile uint32_t*)&flushed[pid[i]]) {
-              Rec r{keys[i], vals[i]};
-              stage[(size_t)pid[i] * 4 + (slot[i] & 3)] = r;
-              pend &= ~(1u << i);
-              if ((slot[i] & 3) == 3) full_list[atomicAdd(&s_nfull, 1u)] = pid[i];
-            }
-          }
-          if (pend) atomicOr(&s_pending, 1u);
-          __syncthreads();
-          const uint32_t nfull = s_nfull;
-          const uint32_t more = s_pending;
-          for (uint32_t j = threadIdx.x; j < nfull * 4; j += kPartBlock) {
-            const uint32_t p = full_list[j >> 2];
-            const uint32_t gen = flushed[p];
-            scratch[((size_t)p * g.B + b) * g.cap + (size_t)gen * 4 + (j & 3)] = stage[(size_t)p * 4 + (j & 3)];
-          }
-          __syncthreads();
-          for (uint32_t j = threadIdx.x; j < nfull; j += kPartBlock) flushed[full_list[j]] += 1;
-          if (threadIdx.x == 0) {
-            s_nfull = 0;
-            s_pending = 0;
-          }
-          __syncthreads();
-          if (!more) break;
-        }
-      }
-    }
-    // drain the partially filled lines
-    for (int p = threadIdx.x; p < g.P; p += kPartBlock) {
-      const uint32_t total = cursor[p] < g.cap ? cursor[p] : g.cap;
-      const uint32_t done = flushed[p] * 4;
-      for (uint32_t s = done; s < total; ++s) {
-        scratch[((size_t)p * g.B + b) * g.cap + s] = stage[(size_t)p * 4 + (s & 3)];
+    t.valid = (int)(n - r0);
+    for (int i = 0; i < 4; ++i) {
+      if (i < t.valid) {
+        quad_set(t.f, i, load_one<FT>(fb, r0 + i));
+        t.k.v[i] = load_one<int64_t>(kb, r0 + i);
+        quad_set(t.v, i, load_one<VT>(vb, r0 + i));
       }
     }
   }
+}
+
+// Cooperative flush of 128-byte segments: `need` marks the lanes whose own segment (index
+// seg_base + lane) must leave; 8 lanes write one segment, 8 segments per wave instruction.
+// dst_rec = record index in `scratch` of the segment's first record (valid where need).
+MQ_D void flush_segments(bool need, uint64_t dst_rec, const Rec* __restrict__ stage, int seg_base,
+                         Rec* __restrict__ scratch) {
+  const uint64_t mask = __ballot(need);
+  if (!mask) return;
+  const int lane = threadIdx.x & 63;
+  const int n_need = __popcll(mask);
+  const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+  const int rank_need = __popcll(mask & lt);
+  const int rank_not = lane - rank_need;
+  // forward permute: lane j < n_need receives the lane id of the j-th needed segment
+  const int dest = need ? rank_need : n_need + rank_not;
+  const int owner_of_rank = __builtin_amdgcn_ds_permute(dest << 2, lane);
+  const uint32_t dlo = (uint32_t)dst_rec, dhi = (uint32_t)(dst_rec >> 32);
+  for (int it = 0; it * 8 < n_need; ++it) {
+    const int j = it * 8 + (lane >> 3);
+    const int owner = __shfl(owner_of_rank, j & 63, 64);
+    const uint32_t olo = (uint32_t)__shfl((int)dlo, owner, 64);
+    const uint32_t ohi = (uint32_t)__shfl((int)dhi, owner, 64);
+    if (j < n_need) {
+      const uint64_t o = ((uint64_t)ohi << 32) | olo;
+      const Rec r = stage[(size_t)(seg_base + owner) * kSegRecs + (lane & 7)];
+      scratch[o + (lane & 7)] = r;
+    }
+  }
+}
+
+template <typename FT, typename VT>
+__global__ __launch_bounds__(kPartBlock) void k_part_scatter(
+    const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows, int n_frags,
+    int n_cols, RangeFilter flt, int kcol, int vcol, PartGeom g, PartSlots ps,
+    Rec* __restrict__ scratch, uint32_t* __restrict__ cnt, SpillList sl) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  Rec* stage = (Rec*)smem_raw;                                   // [P][L] = kStageRecs records
+  uint32_t* cursor = (uint32_t*)(smem_raw + kStageRecs * sizeof(Rec));  // [P] records appended
+  uint32_t* flushed = cursor + g.P;                              // [P] lines already flushed
+  const int t = threadIdx.x, b = blockIdx.x, G = gridDim.x;
+  const int lgL = g.lgL;
+  const uint32_t Lm1 = g.L - 1;
+  for (int i = t; i < g.P; i += kPartBlock) {
+    cursor[i] = 0;
+    flushed[i] = 0;
+  }
+  // this lane's flush duty: segment t of the staging area = segment (t & (spl-1)) of the
+  // open line of partition t >> lgSpl
+  const int lgSpl = lgL - 3;  // log2(segments per line)
+  const int own_p = t >> lgSpl;
+  const uint32_t own_seg = (uint32_t)t & ((1u << lgSpl) - 1);
+  const uint64_t own_run = ((uint64_t)own_p * g.B + b) * g.cap;
+
+  // carried records: slot taken in an earlier round, line not open yet
+  int64_t c_key[4], c_val[4];
+  uint32_t c_pid[4], c_slot[4];
+  uint32_t c_mask = 0;
+
+  // flattened tile walk over the fragments: tile numbers are global, workgroup b owns the
+  // tiles == b (mod G)
+  int f = 0;
+  int64_t base = 0;          // global number of fragment f's first tile
+  int64_t nt_f = n_frags > 0 ? ((num_rows[0] + 3) / 4 + kPartBlock - 1) / kPartBlock : 0;
+  int64_t gt = b;
+  auto seek = [&]() {
+    while (f < n_frags && gt >= base + nt_f) {
+      base += nt_f;
+      ++f;
+      nt_f = f < n_frags ? ((num_rows[f] + 3) / 4 + kPartBlock - 1) / kPartBlock : 0;
+    }
+  };
+  seek();
+  Tile<FT, VT> cur;
+  cur.valid = 0;
+  bool have = f < n_frags;
+  if (have) load_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, gt - base, cur);
   __syncthreads();
-  for (int p = threadIdx.x; p < g.P; p += kPartBlock) {
-    const uint32_t c = cursor[p];
-    cnt[(size_t)p * g.B + b] = c < g.cap ? c : g.cap;
+
+  while (have) {
+    // prefetch the next tile before touching LDS
+    gt += G;
+    seek();
+    const bool have_next = f < n_frags;
+    Tile<FT, VT> nxt;
+    nxt.valid = 0;
+    if (have_next) load_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, gt - base, nxt);
+
+    // (A) take stream positions for the surviving rows
+    uint32_t n_mask = 0;
+    uint32_t pid[4], slot[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (i < cur.valid && filter_pass<FT>(flt, quad_get(cur.f, i))) {
+        const uint32_t home = home_of(g.hm, cur.k.v[i]);
+        pid[i] = part_of(g.hm, home);
+        slot[i] = atomicAdd(&cursor[pid[i]], 1u);
+        n_mask |= 1u << i;
+      }
+    }
+    lds_barrier();  // cursors of this round are final; last round's flush is complete
+
+    // (B) place: open line -> LDS, whole future lines -> straight to the run, last
+    // (partial) line -> carry to the next round
+    const uint32_t own_cur = cursor[own_p], own_fl = flushed[own_p];
+    auto place = [&](int64_t key, int64_t vb, uint32_t p, uint32_t s) -> bool {
+      if (s >= g.cap) {  // run full
+        spill_record(sl, ps, g.ns_int, key, vb);
+        return true;
+      }
+      const uint32_t line = s >> lgL;
+      const uint32_t fl = flushed[p];
+      if (line == fl) {
+        stage[((size_t)p << lgL) + (s & Lm1)] = Rec{key, vb};
+        return true;
+      }
+      if (line < (cursor[p] >> lgL)) {
+        scratch[((uint64_t)p * g.B + b) * g.cap + s] = Rec{key, vb};
+        return true;
+      }
+      return false;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (c_mask & (1u << i)) {
+        if (place(c_key[i], c_val[i], c_pid[i], c_slot[i])) c_mask &= ~(1u << i);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (n_mask & (1u << i)) {
+        const int64_t vb = val_bits_of<VT>(quad_get(cur.v, i));
+        if (!place(cur.k.v[i], vb, pid[i], slot[i])) {
+          // carried slot i is free: everything carried from the last round was placed above
+          c_key[i] = cur.k.v[i];
+          c_val[i] = vb;
+          c_pid[i] = pid[i];
+          c_slot[i] = slot[i];
+          c_mask |= 1u << i;
+        }
+      }
+    }
+    lds_barrier();  // the open lines are complete
+
+    // (F) flush every line whose last slot was taken this round
+    {
+      const uint32_t new_fl = own_cur >> lgL;
+      const bool need = t < (g.P << lgSpl) && new_fl > own_fl && (uint64_t)own_fl * g.L < g.cap;
+      flush_segments(need, own_run + ((uint64_t)own_fl << lgL) + own_seg * kSegRecs, stage,
+                     t & ~63, scratch);
+      if (t < (g.P << lgSpl) && own_seg == 0 && new_fl > own_fl) flushed[own_p] = new_fl;
+    }
+    cur = nxt;
+    have = have_next;
+  }
+  lds_barrier();
+  // records still carried belong to the open (last, partial) line
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (c_mask & (1u << i)) {
+      const uint32_t s = c_slot[i], p = c_pid[i];
+      if (s >= g.cap) spill_record(sl, ps, g.ns_int, c_key[i], c_val[i]);
+      else stage[((size_t)p << lgL) + (s & Lm1)] = Rec{c_key[i], c_val[i]};
+    }
+  }
+  lds_barrier();
+  // drain the partially filled lines (whole segments; the run length says what is valid)
+  {
+    const bool owner = t < (g.P << lgSpl);
+    const uint32_t c = owner ? cursor[own_p] : 0u;
+    const uint32_t fl = owner ? flushed[own_p] : 0u;
+    const uint32_t rem = c - (fl << lgL);  // < L
+    const bool need = owner && own_seg * kSegRecs < rem && ((uint64_t)fl << lgL) + own_seg * kSegRecs < g.cap;
+    flush_segments(need, own_run + ((uint64_t)fl << lgL) + own_seg * kSegRecs, stage, t & ~63, scratch);
+    if (owner && own_seg == 0) cnt[(size_t)own_p * g.B + b] = c < g.cap ? c : g.cap;
   }
 }
 
 // ------------------------------------------------------------------------- phase 2
-MQ_D void lds_apply(int op, int64_t* s, int64_t vb) {
+// LDS table of one unit: int64 keys[E] in buckets of four (32 B, two ds_read_b128 per probe),
+// then one array per internal slot — COUNT slots are uint32 (a unit never sees 2^32 records
+// in one chunk; an older partial that could overflow is routed to the spill list instead),
+// every other op keeps the full 8 bytes.  Internal slots are ordered by op id, so a
+// compile-time op set (MASK) fixes every array offset; MASK = 0 is the runtime-generic member.
+typedef long long v2i64_t __attribute__((ext_vector_type(2)));
+
+MQ_D void lds_apply(int op, char* base, uint32_t e, int64_t vb) {
   switch (op) {
-    case SO_COUNT: atomicAdd((unsigned long long*)s, 1ull); break;
-    case SO_SUM_I: atomicAdd((unsigned long long*)s, (unsigned long long)vb); break;
-    case SO_SUM_F: atomicAdd((double*)s, bits_dbl(vb)); break;
-    case SO_MIN_I: atomicMin((long long*)s, (long long)vb); break;
-    case SO_MAX_I: atomicMax((long long*)s, (long long)vb); break;
-    case SO_MIN_F: a_minmax_f64<true, false, false>(s, bits_dbl(vb), 0.0); break;
-    case SO_MAX_F: a_minmax_f64<true, true, false>(s, bits_dbl(vb), 0.0); break;
+    case SO_COUNT: atomicAdd((uint32_t*)base + e, 1u); break;
+    case SO_SUM_I: atomicAdd((unsigned long long*)base + e, (unsigned long long)vb); break;
+    case SO_SUM_F: atomicAdd((double*)base + e, bits_dbl(vb)); break;
+    case SO_MIN_I: atomicMin((long long*)base + e, (long long)vb); break;
+    case SO_MAX_I: atomicMax((long long*)base + e, (long long)vb); break;
+    case SO_MIN_F: a_minmax_f64<true, false, false>((int64_t*)base + e, bits_dbl(vb), 0.0); break;
+    case SO_MAX_F: a_minmax_f64<true, true, false>((int64_t*)base + e, bits_dbl(vb), 0.0); break;
     default: break;
   }
 }
-
+// merge a PARTIAL (count / sum / min / max of several rows) into an LDS slot
+MQ_D void lds_merge(int op, char* base, uint32_t e, int64_t partial) {
+  switch (op) {
+    case SO_COUNT: atomicAdd((uint32_t*)base + e, (uint32_t)partial); break;
+    case SO_SUM_I: atomicAdd((unsigned long long*)base + e, (unsigned long long)partial); break;
+    default: lds_apply(op, base, e, partial);
+  }
+}
+MQ_D int64_t lds_slot_value(int op, const char* base, uint32_t e) {
+  return op == SO_COUNT ? (int64_t)((const uint32_t*)base)[e] : ((const int64_t*)base)[e];
+}
 MQ_D void global_merge(int op, int64_t* gslot, int64_t partial) {
   switch (op) {
     case SO_COUNT:
@@ -245,83 +402,239 @@ MQ_D void global_merge(int op, int64_t* gslot, int64_t partial) {
   }
 }
 
-__global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const Rec* __restrict__ scratch,
-                                                                const uint32_t* __restrict__ cnt,
-                                                                PartSlots ps, TableArgs tab,
-                                                                int32_t* __restrict__ d_err,
-                                                                unsigned long long* __restrict__ spills) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  int64_t* lkeys = (int64_t*)smem_raw;   // [E]
-  int64_t* lslots = lkeys + g.E;         // [ns_int][E]  (slot-major: conflict-free strides)
-  uint32_t* lcnt = (uint32_t*)(lslots + (size_t)g.ns_int * g.E);  // [B]
-  const int ns = g.ns_int;
-  auto insert_rec = [&](const Rec& r) {
-    const uint32_t h = murmur3_u64((uint64_t)r.key);
-    // the partition used the top lgP bits; the LDS slot uses the bits below them
-    const uint32_t low = g.lgP ? (h << g.lgP) : h;
-    uint32_t e = (uint32_t)(((uint64_t)low * g.E) >> 32);
-    for (uint32_t probes = 0; probes < g.E; ++probes) {
-      const int64_t old = (int64_t)atomicCAS((unsigned long long*)&lkeys[e],
-                                             (unsigned long long)kEmptyKey64,
-                                             (unsigned long long)r.key);
-      if (old == kEmptyKey64 || old == r.key) {
-        for (int j = 0; j < ns; ++j) lds_apply(ps.int_op[j], &lslots[(size_t)j * g.E + e], r.val);
-        return;
-      }
-      e = e + 1 == g.E ? 0 : e + 1;
+constexpr uint32_t kNoEntry = 0xffffffffu;
+
+// one row's update of entry e, every op of the set
+template <int MASK>
+MQ_D void apply_row(char* smem, const PartGeom& g, const PartSlots& ps, uint32_t e, int64_t vb) {
+  if (MASK == 0) {
+    for (int m = 0; m < g.ns_int; ++m) lds_apply(ps.int_op[m], smem + g.slot_off[m], e, vb);
+    return;
+  }
+  int m = 0;
+#pragma unroll
+  for (int op = SO_COUNT; op <= SO_MAX_F; ++op) {
+    if (MASK & (1 << op)) {
+      lds_apply(op, smem + g.slot_off[m], e, vb);
+      ++m;
     }
-    spill_direct(tab, r.key, r.val, d_err, spills);  // LDS table full
-  };
-  for (int p = blockIdx.x; p < g.P; p += gridDim.x) {
-    for (uint32_t e = threadIdx.x; e < g.E; e += kPartBlock) {
-      lkeys[e] = kEmptyKey64;
-      for (int j = 0; j < ns; ++j) lslots[(size_t)j * g.E + e] = ps.int_init[j];
-    }
-    __syncthreads();
-    // run lengths of this partition -> LDS (one coalesced read), then one wave per run with
-    // four 16-byte record loads in flight per lane
-    for (int b = threadIdx.x; b < g.B; b += kPartBlock) lcnt[b] = cnt[(size_t)p * g.B + b];
-    __syncthreads();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int b = wave; b < g.B; b += kPartBlock / 64) {
-      const uint32_t n = lcnt[b];
-      const Rec* run = scratch + ((size_t)p * g.B + b) * g.cap;
-      uint32_t i = lane;
-      for (; i + 192 < n; i += 256) {
-        const Rec r0 = run[i], r1 = run[i + 64], r2 = run[i + 128], r3 = run[i + 192];
-        insert_rec(r0);
-        insert_rec(r1);
-        insert_rec(r2);
-        insert_rec(r3);
-      }
-      for (; i < n; i += 64) insert_rec(run[i]);
-    }
-    __syncthreads();
-    // emit: one insert-or-find per group, partial slots merged with atomics (a key may
-    // already be there from an earlier chunk or from a spilled row)
-    for (uint32_t e = threadIdx.x; e < g.E; e += kPartBlock) {
-      const int64_t key = lkeys[e];
-      if (key == kEmptyKey64) continue;
-      int64_t* slots = baseline_find_or_insert(tab.out, tab.entry_count, tab.row_quad, 8, key);
-      if (!slots) {
-        atomicCAS(d_err, 0, -1);
-        continue;
-      }
-      for (int j = 0; j < tab.sp.n; ++j) {
-        const int m = ps.out_map[j];
-        if (m >= 0) global_merge(tab.sp.op[j], slots + j, lslots[(size_t)m * g.E + e]);
-      }
-    }
-    __syncthreads();
   }
 }
 
-uint32_t next_pow2(uint64_t v) {
-  uint64_t p = 1;
-  while (p < v) p <<= 1;
-  return (uint32_t)p;
+// insert-or-find `key` starting at bucket b (linear probing over 4-key buckets): returns the
+// entry, or kNoEntry when the table is full.  A bucket with a free slot has never been full,
+// so a key that is not in it is not in the table: claim the first free slot.
+MQ_D uint32_t lds_locate(int64_t* lkeys, uint32_t n_buckets, uint32_t b, int64_t key) {
+  for (uint32_t trips = 0; trips < n_buckets;) {
+    int64_t* bk = lkeys + (size_t)b * 4;
+    const v2i64_t a = *(const v2i64_t*)bk, c = *((const v2i64_t*)bk + 1);
+    const int j = a.x == key ? 0 : a.y == key ? 1 : c.x == key ? 2 : c.y == key ? 3 : -1;
+    if (j >= 0) return b * 4 + (uint32_t)j;
+    const int fe = a.x == kEmptyKey64 ? 0 : a.y == kEmptyKey64 ? 1 : c.x == kEmptyKey64 ? 2
+                   : c.y == kEmptyKey64 ? 3 : -1;
+    if (fe >= 0) {
+      const int64_t old = (int64_t)atomicCAS((unsigned long long*)(bk + fe), (unsigned long long)kEmptyKey64,
+                                             (unsigned long long)key);
+      if (old == kEmptyKey64 || old == key) return b * 4 + (uint32_t)fe;
+      continue;  // another key took that slot: look at this bucket again
+    }
+    b = b + 1 == n_buckets ? 0 : b + 1;
+    ++trips;
+  }
+  return kNoEntry;
 }
 
+template <int MASK>
+__global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const Rec* __restrict__ scratch,
+                                                                const uint32_t* __restrict__ cnt,
+                                                                PartSlots ps, TableArgs tab, SpillList sl,
+                                                                int merge, uint32_t chunk_records_max,
+                                                                unsigned long long* __restrict__ dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int64_t* const lkeys = (int64_t*)smem_raw;
+  uint32_t* bitmap = (uint32_t*)(smem_raw + g.lds_table_bytes);  // [(S2 + 31) / 32]
+  const uint32_t bm_words = (g.hm.S2 + 31) / 32;
+  uint32_t* lcnt = bitmap + bm_words;                            // [B]
+  const int ns = g.ns_int;
+  const int t = threadIdx.x;
+  const int G = gridDim.x;
+  const int R = (int)g.hm.R;
+  const uint32_t n_buckets = g.E >> 2;
+  // sub-ranges of one partition run on workgroups of the same XCD (block id mod 8) at the same
+  // time, so the second reader of a run is served by that XCD's L2
+  const bool paired = R > 1 && G % (8 * R) == 0;
+
+  uint32_t lo = 0, n_slots = 0;  // this unit's home range [lo, lo + n_slots)
+  // MI355Q_TRACE: lane 0 of every workgroup accumulates the cycles of each phase
+  long long t_mark = dbg ? clock64() : 0;
+  unsigned long long t_acc[5] = {0, 0, 0, 0, 0};
+  auto mark = [&](int ph) {
+    if (dbg) {
+      const long long now = clock64();
+      t_acc[ph] += (unsigned long long)(now - t_mark);
+      t_mark = now;
+    }
+  };
+  auto bucket_of = [&](uint32_t x) -> uint32_t { return (uint32_t)(((uint64_t)x * g.b_mult) >> 32); };
+  auto insert_rec = [&](const Rec& r, bool valid) {
+    const uint32_t x = home_of(g.hm, r.key) - lo;
+    if (!valid || x >= n_slots) return;  // past the run's end / another sub-range's record
+    const uint32_t e = lds_locate(lkeys, n_buckets, bucket_of(x), r.key);
+    if (e != kNoEntry) apply_row<MASK>(smem_raw, g, ps, e, r.val);
+    else spill_record(sl, ps, ns, r.key, r.val);
+  };
+
+  for (int it = 0;; ++it) {
+    int p, r;
+    if (paired) {
+      const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+      r = j % R;
+      p = (j / R) * 8 + xcd + (G / R) * it;
+    } else {
+      const int v = blockIdx.x + G * it;
+      p = v / R;
+      r = v % R;
+    }
+    if (p >= g.P) break;
+    {
+      const uint64_t p_lo = (uint64_t)p * g.hm.S1;
+      const uint64_t p_hi = p_lo + g.hm.S1 < g.hm.d ? p_lo + g.hm.S1 : g.hm.d;
+      uint64_t a = p_lo + (uint64_t)r * g.hm.S2, z = a + g.hm.S2;
+      if (z > p_hi) z = p_hi;
+      if (a > z) a = z;
+      lo = (uint32_t)a;
+      n_slots = (uint32_t)(z - a);
+    }
+    for (uint32_t e = t; e < g.E; e += kPartBlock) {
+      lkeys[e] = kEmptyKey64;
+      for (int m = 0; m < ns; ++m) {
+        if (ps.int_op[m] == SO_COUNT) ((uint32_t*)(smem_raw + g.slot_off[m]))[e] = 0;
+        else ((int64_t*)(smem_raw + g.slot_off[m]))[e] = ps.int_init[m];
+      }
+    }
+    for (uint32_t w = t; w < bm_words; w += kPartBlock) bitmap[w] = 0;
+    for (int b = t; b < g.B; b += kPartBlock) lcnt[b] = cnt[(size_t)p * g.B + b];
+    __syncthreads();
+    mark(0);
+    if (n_slots) {
+      if (merge) {
+        // groups of earlier chunks: re-load this range of the table as partial rows
+        for (uint32_t s = t; s < n_slots; s += kPartBlock) {
+          const int64_t* row = tab.out + (size_t)(lo + s) * tab.row_quad;
+          const int64_t key = row[0];
+          if (key == kEmptyKey64) continue;
+          int64_t part[kMaxInt];
+          for (int m = 0; m < kMaxInt; ++m) part[m] = 0;
+          bool big = false;  // a 32-bit LDS counter could wrap
+          for (int j = tab.sp.n - 1; j >= 0; --j) {
+            const int m = ps.out_map[j];
+            if (m >= 0) {
+              part[m] = row[1 + j];
+              if (ps.int_op[m] == SO_COUNT &&
+                  (uint64_t)part[m] + chunk_records_max >= 0xffffffffull) big = true;
+            }
+          }
+          const uint32_t x = home_of(g.hm, key) - lo;
+          const uint32_t e = (x < n_slots && !big) ? lds_locate(lkeys, n_buckets, bucket_of(x), key) : kNoEntry;
+          if (e == kNoEntry) {  // probed in from another range / no room / huge count: merged last
+            spill_append(sl, key, part, ns);
+            continue;
+          }
+          for (int m = 0; m < ns; ++m) lds_merge(ps.int_op[m], smem_raw + g.slot_off[m], e, part[m]);
+        }
+      }
+      mark(1);
+      // one wave per run; four 16-byte record loads per lane, the next four already in flight
+      const int wave = t >> 6, lane = t & 63;
+      for (int b = wave; b < g.B; b += kPartBlock / 64) {
+        const uint32_t n = lcnt[b];
+        if (!n) continue;
+        const Rec* run = scratch + ((size_t)p * g.B + b) * g.cap;
+        const uint32_t last = n - 1;
+        auto at = [&](uint32_t i) -> uint32_t { return i < last ? i : last; };  // clamped: always loadable
+        Rec c0 = run[at(lane)], c1 = run[at(lane + 64)], c2 = run[at(lane + 128)], c3 = run[at(lane + 192)];
+        for (uint32_t base = 0; base < n; base += 256) {
+          const uint32_t i = base + lane, nx = i + 256;
+          const Rec n0 = run[at(nx)], n1 = run[at(nx + 64)], n2 = run[at(nx + 128)], n3 = run[at(nx + 192)];
+          insert_rec(c0, i < n);
+          insert_rec(c1, i + 64 < n);
+          insert_rec(c2, i + 128 < n);
+          insert_rec(c3, i + 192 < n);
+          c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+      }
+    }
+    __syncthreads();
+    mark(2);
+    // emit: claim the first free slot at or after the home slot (the reference's probing
+    // rule, GroupByRuntime.cpp:25-48) in the LDS bitmap, then store the finished row
+    for (uint32_t e = t; e < g.E && n_slots; e += kPartBlock) {
+      const int64_t key = lkeys[e];
+      if (key == kEmptyKey64) continue;
+      uint32_t s = home_of(g.hm, key) - lo;
+      bool placed = false;
+      while (s < n_slots) {
+        const uint32_t bit = 1u << (s & 31);
+        const uint32_t old = atomicOr(&bitmap[s >> 5], bit);
+        if (!(old & bit)) {
+          placed = true;
+          break;
+        }
+        // skip the occupied run inside this word
+        const uint32_t free_above = ~(old | bit) & ~((bit << 1) - 1u);
+        s = free_above ? (s & ~31u) + (uint32_t)__builtin_ctz(free_above) : (s | 31u) + 1u;
+      }
+      if (!placed) {  // probes past the end of the range: merged last, canonically
+        int64_t part[kMaxInt];
+        for (int m = 0; m < kMaxInt; ++m)
+          part[m] = m < ns ? lds_slot_value(ps.int_op[m], smem_raw + g.slot_off[m], e) : 0;
+        spill_append(sl, key, part, ns);
+        continue;
+      }
+      int64_t* row = tab.out + (size_t)(lo + s) * tab.row_quad;
+      row[0] = key;
+      for (int j = 0; j < tab.sp.n; ++j) {
+        const int m = ps.out_map[j];
+        row[1 + j] = m >= 0 ? lds_slot_value(ps.int_op[m], smem_raw + g.slot_off[m], e)
+                            : (tab.sp.op[j] == SO_KEY ? key : tab.init[j]);
+      }
+    }
+    __syncthreads();
+    mark(3);
+    for (uint32_t s = t; s < n_slots; s += kPartBlock) {
+      if (bitmap[s >> 5] & (1u << (s & 31))) continue;
+      int64_t* row = tab.out + (size_t)(lo + s) * tab.row_quad;
+      row[0] = kEmptyKey64;
+      for (int j = 0; j < tab.sp.n; ++j) row[1 + j] = tab.init[j];
+    }
+    __syncthreads();
+    mark(4);
+  }
+  if (dbg && t == 0) {
+    for (int i = 0; i < 5; ++i) atomicAdd(dbg + i, t_acc[i]);
+  }
+}
+
+// ------------------------------------------------------------------------- phase 3
+__global__ __launch_bounds__(256) void k_spill_merge(PartSlots ps, TableArgs tab, SpillList sl, int ns) {
+  uint32_t n = *sl.count;
+  if (n > kSpillCap) n = kSpillCap;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const SpillEntry& e = sl.entries[i];
+    int64_t* slots = baseline_find_or_insert(tab.out, tab.entry_count, tab.row_quad, 8, e.key);
+    if (!slots) {
+      atomicCAS(sl.d_err, 0, -1);  // out of group slots: the caller resizes and retries
+      continue;
+    }
+    for (int j = 0; j < tab.sp.n; ++j) {
+      const int m = ps.out_map[j];
+      if (m >= 0) global_merge(tab.sp.op[j], slots + j, e.part[m]);
+      else if (tab.sp.op[j] == SO_KEY) MQ_STORE64(slots + j, e.key);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- host side
 int64_t op_identity(int op) {
   switch (op) {
     case SO_MIN_I: return INT64_MAX;
@@ -335,21 +648,28 @@ int64_t op_identity(int op) {
 struct PartPlanHost {
   PartGeom g;
   PartSlots ps;
-  int64_t chunk_rows;       // max rows per chunk
-  int64_t scratch_bytes;    // records + counts
+  int64_t chunk_rows;     // max rows per chunk
+  int64_t rec_bytes;      // runs
+  int64_t cnt_bytes;      // run lengths
+  int64_t scratch_bytes;  // runs + lengths + spill list
   size_t lds1, lds2;
-  bool staged;
+  int op_mask;            // set of internal ops (bit per SlotOp)
 };
 
-constexpr size_t kLdsBudget = 140 * 1024;
+constexpr size_t kLdsTableBudget = 150 * 1024;
 
 bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, int n_cus,
-                    int64_t scratch_cap, bool staged, PartPlanHost* out) {
+                    int64_t scratch_cap, PartPlanHost* out) {
   PartPlanHost& h = *out;
-  h.staged = staged;
+  if (p.entry_count < 64 || p.entry_count >= ((int64_t)1 << 32)) return false;
+  if (fv.max_frag_rows > 0xfff00000ll) return false;  // 32-bit LDS counters per chunk
   // internal slots: distinct ops only (COUNT(*) and AVG's count share one LDS counter)
   int n_int = 0;
   for (int j = 0; j < MI355Q_MAX_SLOTS; ++j) h.ps.out_map[j] = -1;
+  for (int j = 0; j < kMaxInt; ++j) {
+    h.ps.int_op[j] = -1;
+    h.ps.int_init[j] = 0;
+  }
   for (int j = 0; j < fs.sp.n; ++j) {
     const int op = fs.sp.op[j];
     if (op == SO_KEY) continue;
@@ -357,7 +677,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     for (int k = 0; k < n_int; ++k)
       if (h.ps.int_op[k] == op) m = k;
     if (m < 0) {
-      if (n_int >= 8) return false;
+      if (n_int >= kMaxInt) return false;
       m = n_int++;
       h.ps.int_op[m] = op;
       h.ps.int_init[m] = op_identity(op);
@@ -365,121 +685,178 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     h.ps.out_map[j] = m;
   }
   if (n_int == 0) return false;
+  // internal slots in ascending op order (the compile-time op sets of phase 2 rely on it)
+  for (int a = 0; a < n_int; ++a)
+    for (int b = a + 1; b < n_int; ++b)
+      if (h.ps.int_op[b] < h.ps.int_op[a]) {
+        const int oa = h.ps.int_op[a], ob = h.ps.int_op[b];
+        h.ps.int_op[a] = ob;
+        h.ps.int_op[b] = oa;
+        h.ps.int_init[a] = op_identity(ob);
+        h.ps.int_init[b] = op_identity(oa);
+        for (int j = 0; j < MI355Q_MAX_SLOTS; ++j) {
+          if (h.ps.out_map[j] == a) h.ps.out_map[j] = b;
+          else if (h.ps.out_map[j] == b) h.ps.out_map[j] = a;
+        }
+      }
+  h.op_mask = 0;
+  for (int m = 0; m < n_int; ++m) h.op_mask |= 1 << h.ps.int_op[m];
   h.g.ns_int = n_int;
-  const size_t entry_bytes = 8 * (size_t)(1 + n_int);
-  const uint32_t e_max = (uint32_t)(kLdsBudget / entry_bytes);
+  size_t entry_bytes = 8;
+  for (int m = 0; m < n_int; ++m) entry_bytes += h.ps.int_op[m] == SO_COUNT ? 4 : 8;
+  const uint32_t e_max = (uint32_t)(kLdsTableBudget / entry_bytes) & ~3u;
   // expected groups: the caller sizes the table at ~2 x NDV (50 % fill, docs results.rst)
-  const uint64_t groups = (uint64_t)(p.entry_count / 2 > 0 ? p.entry_count / 2 : 1);
-  uint32_t P = next_pow2((groups + (uint64_t)(0.55 * e_max) - 1) / (uint64_t)(0.55 * e_max));
-  const uint32_t p_max = staged ? 2048u : 8192u;
-  if (P > p_max) P = p_max;
-  if (debug_part_p() > 0) P = next_pow2((uint64_t)debug_part_p()) > p_max ? p_max : next_pow2((uint64_t)debug_part_p());
+  const uint64_t d = (uint64_t)p.entry_count;
+  const uint64_t groups = d / 2 > 0 ? d / 2 : 1;
+  const uint64_t per_unit = (uint64_t)(0.8 * e_max);
+  const uint64_t units = (groups + per_unit - 1) / per_unit;
+  uint32_t P = 8;
+  while (P < 1024 && P < units) P <<= 1;
+  const uint32_t R = (uint32_t)((units + P - 1) / P);
+  if (R > (uint32_t)kMaxSub) return false;
   h.g.P = (int32_t)P;
-  h.g.lgP = 0;
-  while ((1u << h.g.lgP) < P) ++h.g.lgP;
-  uint64_t e_want = (groups / P) * 2 + 64;  // ~50 % fill
+  h.g.L = kStageRecs / P;
+  h.g.lgL = 0;
+  while ((1u << h.g.lgL) < h.g.L) ++h.g.lgL;
+  HomeMap& hm = h.g.hm;
+  hm.d = (uint32_t)d;
+  hm.S1 = (uint32_t)((d + P - 1) / P);
+  hm.R = R < 1 ? 1 : R;
+  hm.S2 = (hm.S1 + hm.R - 1) / hm.R;
+  hm.d_magic = ~0ull / hm.d + 1;
+  hm.s1_magic = ~0ull / hm.S1 + 1;
+  uint64_t e_want = hm.S2;  // an LDS entry per home slot when it fits (50 % fill)
   if (e_want > e_max) e_want = e_max;
-  if (e_want < 256) e_want = 256;
-  h.g.E = (uint32_t)e_want;
+  if (e_want < 64) e_want = 64;
+  h.g.E = ((uint32_t)e_want + 3) & ~3u;  // keeps every slot array 16-byte aligned
+  h.g.lds_table_bytes = (uint32_t)((size_t)h.g.E * entry_bytes);
+  {
+    uint32_t off = h.g.E * 8;  // 8-byte slot arrays first, then the 4-byte counters
+    for (int m = 0; m < kMaxInt; ++m) h.g.slot_off[m] = 0;
+    for (int m = 0; m < n_int; ++m)
+      if (h.ps.int_op[m] != SO_COUNT) { h.g.slot_off[m] = off; off += h.g.E * 8; }
+    for (int m = 0; m < n_int; ++m)
+      if (h.ps.int_op[m] == SO_COUNT) { h.g.slot_off[m] = off; off += h.g.E * 4; }
+  }
+  {
+    const uint64_t m = ((uint64_t)(h.g.E / 4) << 32) / hm.S2;
+    h.g.b_mult = (uint32_t)(m > 0xffffffffull ? 0xffffffffull : m);
+  }
   h.g.B = n_cus;  // one 1024-lane workgroup per CU
   // chunking: worst case every row survives the filter; shrink the chunk until the runs
-  // (1.2 x mean + 6 sigma + slack per run) fit the scratch cap, never below one fragment
-  int64_t chunk_rows = fv.total_rows;
+  // (1.2 x mean + 6 sigma + a line of slack per run) fit the scratch cap, never below one
+  // fragment
+  const int64_t spill_bytes = 64 + (int64_t)kSpillCap * (int64_t)sizeof(SpillEntry);
+  int64_t chunk_rows = fv.total_rows > 0 ? fv.total_rows : 1;
+  if (chunk_rows > 0xfff00000ll) chunk_rows = 0xfff00000ll;  // 32-bit LDS counters per chunk
   for (;;) {
     const double per_run = (double)chunk_rows / ((double)P * h.g.B);
-    uint64_t cap = (uint64_t)(per_run * 1.2 + 6.0 * __builtin_sqrt(per_run + 1.0)) + 36;
-    cap = (cap + 3) & ~3ull;  // whole 64-byte lines
+    uint64_t cap = (uint64_t)(per_run * 1.2 + 6.0 * __builtin_sqrt(per_run + 1.0)) + h.g.L;
+    cap = (cap + h.g.L - 1) / h.g.L * h.g.L;  // whole lines
     if (cap > 0x7fffffffull) return false;
     h.g.cap = (uint32_t)cap;
-    h.scratch_bytes = (int64_t)P * h.g.B * (int64_t)cap * (int64_t)sizeof(Rec) + (int64_t)P * h.g.B * 4 + 256;
+    h.rec_bytes = (int64_t)P * h.g.B * (int64_t)cap * (int64_t)sizeof(Rec);
+    h.cnt_bytes = ((int64_t)P * h.g.B * 4 + 255) & ~255ll;
+    h.scratch_bytes = h.rec_bytes + h.cnt_bytes + spill_bytes;
     if (h.scratch_bytes <= scratch_cap || chunk_rows <= fv.max_frag_rows) break;
     chunk_rows = (int64_t)(chunk_rows * 0.9);
     if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
   }
   h.chunk_rows = chunk_rows;
-  h.lds1 = (size_t)P * 4;
-  if (staged) {
-    h.lds1 = (((size_t)P * 4 + 15) & ~(size_t)15) + (size_t)P * 4 * sizeof(Rec) + (size_t)P * 4 +
-             (size_t)P * 4;
-    if (h.lds1 > 158 * 1024) return false;
-  }
-  h.lds2 = (size_t)h.g.E * entry_bytes + (size_t)h.g.B * 4;
-  return true;
+  h.lds1 = kStageRecs * sizeof(Rec) + (size_t)P * 8;
+  h.lds2 = (size_t)h.g.E * entry_bytes + (size_t)((hm.S2 + 31) / 32) * 4 + (size_t)h.g.B * 4;
+  return h.lds2 <= 160 * 1024;
 }
 
 template <typename FT, typename VT>
-hipError_t launch_scatter_t(bool staged, int grid, size_t lds, hipStream_t s, const FragView& fv,
-                            int f0, int nf, const RangeFilter& flt, int kcol, int vcol,
-                            const PartGeom& g, Rec* scratch, uint32_t* cnt, const TableArgs& tab,
-                            int32_t* d_err, unsigned long long* spills) {
+hipError_t launch_scatter_t(int grid, size_t lds, hipStream_t s, const FragView& fv, int f0, int nf,
+                            const RangeFilter& flt, int kcol, int vcol, const PartGeom& g,
+                            const PartSlots& ps, Rec* scratch, uint32_t* cnt, const SpillList& sl) {
   const int8_t* const* cols = fv.d_cols + (size_t)f0 * fv.n_cols;
   const int64_t* rows = fv.d_num_rows + f0;
   // opt in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
-  if (staged)
-    (void)hipFuncSetAttribute((const void*)k_part_scatter<FT, VT, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (staged) {
-    hipLaunchKernelGGL((k_part_scatter<FT, VT, true>), dim3(grid), dim3(kPartBlock), lds, s, cols, rows,
-                       nf, fv.n_cols, flt, kcol, vcol, g, scratch, cnt, tab, d_err, spills);
-  } else {
-    hipLaunchKernelGGL((k_part_scatter<FT, VT, false>), dim3(grid), dim3(kPartBlock), lds, s, cols, rows,
-                       nf, fv.n_cols, flt, kcol, vcol, g, scratch, cnt, tab, d_err, spills);
-  }
+  (void)hipFuncSetAttribute((const void*)k_part_scatter<FT, VT>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL((k_part_scatter<FT, VT>), dim3(grid), dim3(kPartBlock), lds, s, cols, rows, nf,
+                     fv.n_cols, flt, kcol, vcol, g, ps, scratch, cnt, sl);
   return hipGetLastError();
 }
 
 template <typename FT>
-hipError_t launch_scatter_v(const FastShape& fs, bool staged, int grid, size_t lds, hipStream_t s,
+hipError_t launch_scatter_v(const FastShape& fs, int grid, size_t lds, hipStream_t s,
                             const FragView& fv, int f0, int nf, int kcol, const PartGeom& g,
-                            Rec* scratch, uint32_t* cnt, const TableArgs& tab, int32_t* d_err,
-                            unsigned long long* spills) {
+                            const PartSlots& ps, Rec* scratch, uint32_t* cnt, const SpillList& sl) {
   const int vcol = fs.vcol < 0 ? 0 : fs.vcol;
   if (fs.vcol < 0)
-    return launch_scatter_t<FT, none_t>(staged, grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, scratch, cnt, tab, d_err, spills);
+    return launch_scatter_t<FT, none_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl);
   if (fs.vtype == MI355Q_INT64)
-    return launch_scatter_t<FT, int64_t>(staged, grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, scratch, cnt, tab, d_err, spills);
-  return launch_scatter_t<FT, double>(staged, grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, scratch, cnt, tab, d_err, spills);
+    return launch_scatter_t<FT, int64_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl);
+  return launch_scatter_t<FT, double>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl);
 }
 
 }  // namespace
 
-int64_t part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes,
-                           bool staged) {
+bool part_supported(const DevPlan& p, const FragView& fv, int n_cus) {
+  FastShape fs;
+  if (!grouped_fast_shape(p, fv, &fs)) return false;
+  PartPlanHost h;
+  return make_part_plan(p, fs, fv, n_cus, (int64_t)32 << 30, &h);
+}
+
+int64_t part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes) {
   FastShape fs;
   if (!grouped_fast_shape(p, fv, &fs)) return 0;
   if (cap_bytes <= 0) cap_bytes = (int64_t)32 << 30;
   PartPlanHost h;
-  if (!make_part_plan(p, fs, fv, n_cus, cap_bytes, staged, &h)) return 0;
+  if (!make_part_plan(p, fs, fv, n_cus, cap_bytes, &h)) return 0;
   return h.scratch_bytes + 64;
 }
 
 hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int64_t* out,
                                        int32_t* d_err, void* scratch, int64_t scratch_bytes,
-                                       int64_t cap_bytes, bool staged, int n_cus, hipStream_t s,
+                                       int64_t cap_bytes, int n_cus, hipStream_t s,
                                        LaunchStats* st) {
   FastShape fs;
   if (!grouped_fast_shape(p, fv, &fs)) return hipErrorInvalidValue;
   if (cap_bytes <= 0) cap_bytes = (int64_t)32 << 30;
   PartPlanHost h;
   // same inputs as part_scratch_bytes -> the same plan
-  if (!make_part_plan(p, fs, fv, n_cus, cap_bytes, staged, &h)) return hipErrorInvalidValue;
+  if (!make_part_plan(p, fs, fv, n_cus, cap_bytes, &h)) return hipErrorInvalidValue;
   if (h.scratch_bytes + 64 > scratch_bytes) return hipErrorInvalidValue;
   hipEvent_t* ev_pool = st->ev_pool;
   const int n_ev = st->n_ev;
   Rec* recs = (Rec*)scratch;
-  const size_t rec_bytes = (size_t)h.g.P * h.g.B * h.g.cap * sizeof(Rec);
-  uint32_t* cnt = (uint32_t*)((char*)scratch + rec_bytes);
-  unsigned long long* spills = (unsigned long long*)((char*)scratch + ((h.scratch_bytes + 7) & ~7ll));
-  hipError_t e = hipMemsetAsync(spills, 0, sizeof(unsigned long long), s);
+  uint32_t* cnt = (uint32_t*)((char*)scratch + h.rec_bytes);
+  char* spill_base = (char*)scratch + h.rec_bytes + h.cnt_bytes;
+  SpillList sl{(uint32_t*)spill_base, (SpillEntry*)(spill_base + 64), d_err};
+  hipError_t e = hipMemsetAsync(spill_base, 0, 64, s);
   if (e != hipSuccess) return e;
-  TableArgs tab{out, (uint32_t)p.entry_count, p.row_quad, fs.sp};
-  st->kernel_name = staged ? "k_part_scatter_staged" : "k_part_scatter";
-  st->variant = staged ? 3 : 2;
+  TableArgs tab{};
+  tab.out = out;
+  tab.entry_count = (uint32_t)p.entry_count;
+  tab.row_quad = p.row_quad;
+  tab.sp = fs.sp;
+  for (int j = 0; j < MI355Q_MAX_SLOTS; ++j) tab.init[j] = p.init_vals[j];
+  st->kernel_name = "k_part_scatter";
+  st->variant = 2;
   st->n_launches = 0;
-  (void)hipFuncSetAttribute((const void*)k_part_aggregate, hipFuncAttributeMaxDynamicSharedMemorySize,
+  // phase-2 member: the common op sets are compiled in, everything else runs the generic one
+  auto agg_kernel = k_part_aggregate<0>;
+  switch (h.op_mask) {
+    case 1 << SO_COUNT: agg_kernel = k_part_aggregate<(1 << SO_COUNT)>; break;
+    case (1 << SO_COUNT) | (1 << SO_SUM_F): agg_kernel = k_part_aggregate<((1 << SO_COUNT) | (1 << SO_SUM_F))>; break;
+    case (1 << SO_COUNT) | (1 << SO_SUM_I): agg_kernel = k_part_aggregate<((1 << SO_COUNT) | (1 << SO_SUM_I))>; break;
+    case 1 << SO_SUM_F: agg_kernel = k_part_aggregate<(1 << SO_SUM_F)>; break;
+    case 1 << SO_SUM_I: agg_kernel = k_part_aggregate<(1 << SO_SUM_I)>; break;
+    default: break;
+  }
+  (void)hipFuncSetAttribute((const void*)agg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h.lds2);
+  // MI355Q_TRACE: per-phase cycle counters of phase 2 live in the spill header's tail
+  unsigned long long* dbg = std::getenv("MI355Q_TRACE") ? (unsigned long long*)(spill_base + 8) : nullptr;
   int f = 0;
   int ev_i = 0;
+  int chunk = 0;
   while (f < fv.n_frags) {
     int64_t rows = 0;
     int f1 = f;
@@ -489,26 +866,46 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     }
     if (ev_pool && ev_i + 1 < n_ev) (void)hipEventRecord(ev_pool[ev_i], s);
     if (fs.fil_type == 0)
-      e = launch_scatter_v<none_t>(fs, staged, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, recs, cnt, tab, d_err, spills);
+      e = launch_scatter_v<none_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl);
     else if (fs.fil_type == MI355Q_INT32)
-      e = launch_scatter_v<int32_t>(fs, staged, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, recs, cnt, tab, d_err, spills);
+      e = launch_scatter_v<int32_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl);
     else
-      e = launch_scatter_v<int64_t>(fs, staged, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, recs, cnt, tab, d_err, spills);
+      e = launch_scatter_v<int64_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl);
     if (e != hipSuccess) return e;
     if (ev_pool && ev_i + 1 < n_ev) {
       (void)hipEventRecord(ev_pool[ev_i + 1], s);
       ev_i += 2;
     }
     st->n_launches += 1;
-    const int grid2 = h.g.P < n_cus ? h.g.P : n_cus;
-    hipLaunchKernelGGL(k_part_aggregate, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, recs, cnt,
-                       h.ps, tab, d_err, spills);
+    const int units = h.g.P * (int)h.g.hm.R;
+    const int grid2 = units < n_cus ? units : n_cus;
+    hipLaunchKernelGGL(agg_kernel, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, recs, cnt, h.ps,
+                       tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_spill_merge, dim3(256), dim3(256), 0, s, h.ps, tab, sl, h.g.ns_int);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // spilled_rows reports the last chunk's list; the word is re-armed for the next chunk
+    if (f1 < fv.n_frags) {
+      e = hipMemsetAsync(spill_base, 0, 4, s);
+      if (e != hipSuccess) return e;
+    }
     f = f1;
+    ++chunk;
   }
-  st->spill_counter = spills;
+  st->spill_counter32 = (uint32_t*)spill_base;
   st->n_events_used = ev_i;
+  if (dbg) {
+    unsigned long long h_dbg[5] = {0, 0, 0, 0, 0};
+    uint32_t h_sp = 0;
+    (void)hipMemcpy(&h_sp, spill_base, 4, hipMemcpyDeviceToHost);
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(h_dbg, dbg, sizeof(h_dbg), hipMemcpyDeviceToHost);
+    const double wg = (double)(h.g.P * (int)h.g.hm.R < n_cus ? h.g.P * (int)h.g.hm.R : n_cus);
+    std::fprintf(stderr, "[mi355q] phase 2 Mcycles per workgroup: init %.3f  merge-load %.3f  records %.3f  emit %.3f  empties %.3f | spills %u\n",
+                 h_dbg[0] / wg / 1e6, h_dbg[1] / wg / 1e6, h_dbg[2] / wg / 1e6, h_dbg[3] / wg / 1e6, h_dbg[4] / wg / 1e6, h_sp);
+  }
   return hipSuccess;
 }
 

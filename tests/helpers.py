@@ -46,28 +46,32 @@ def compare_buffers(q: capi.QMD, want: np.ndarray, got: np.ndarray, rtol: float 
     assert want.shape == got.shape
     fps = fp_slots(q)
     if q.desc_type == capi.GROUP_BY_BASELINE_HASH:
-        def to_map(buf):
-            m = {}
+        def live_sorted(buf):
             if q.key_width == 4:
-                keys = buf[:, 0].copy().view(np.int32)[::2]
+                keys = buf[:, 0].copy().view(np.int32)[::2].astype(np.int64)
                 live = keys != EMPTY32
             else:
                 keys = buf[:, 0]
                 live = keys != EMPTY64
-            for i in np.nonzero(live)[0]:
-                k = int(keys[i])
-                assert k not in m, f"duplicate key {k} in table"
-                m[k] = buf[i, kq:]
-            return m
-        mw, mg = to_map(want), to_map(got)
-        assert mw.keys() == mg.keys(), (len(mw), len(mg))
-        for k, w in mw.items():
-            g = mg[k]
-            for s in range(q.slot_count):
-                if s in fps:
-                    assert _close(int(w[s]), int(g[s]), rtol), (k, s, w, g)
-                else:
-                    assert int(w[s]) == int(g[s]), (k, s, w, g)
+            idx = np.nonzero(live)[0]
+            order = np.argsort(keys[idx], kind="stable")
+            k = keys[idx][order]
+            dup = np.nonzero(k[1:] == k[:-1])[0]
+            assert dup.size == 0, f"duplicate key {int(k[dup[0]])} in table"
+            return k, buf[idx][order][:, kq:]
+        kw, sw = live_sorted(want)
+        kg, sg = live_sorted(got)
+        assert kw.shape == kg.shape and (kw == kg).all(), (kw.shape, kg.shape)
+        for s in range(q.slot_count):
+            w, g = sw[:, s], sg[:, s]
+            diff = np.nonzero(w != g)[0]
+            if s in fps:
+                fw, fg = w[diff].view(np.float64), g[diff].view(np.float64)
+                ok = np.isfinite(fw) & np.isfinite(fg) & \
+                    (np.abs(fw - fg) <= rtol * np.maximum(np.maximum(np.abs(fw), np.abs(fg)), 1e-300))
+                assert ok.all(), (s, kw[diff[~ok]][:5], fw[~ok][:5], fg[~ok][:5])
+            else:
+                assert diff.size == 0, (s, kw[diff[:5]], w[diff[:5]], g[diff[:5]])
         return
     int_cols = [c for c in range(rq) if not (c >= kq and (c - kq) in fps)]
     bad = np.nonzero((want[:, int_cols] != got[:, int_cols]).any(axis=1))[0]
@@ -96,6 +100,59 @@ def compare_rows(q: capi.QMD, want, got, rtol: float = 1e-9):
     assert (wn == gn).all()
     ok = np.isclose(wd, gd, rtol=rtol, atol=0.0) | (wd == gd)
     assert ok.all(), (wd[~ok][:5], gd[~ok][:5])
+
+
+def murmur3_u64(keys: np.ndarray) -> np.ndarray:
+    """MurmurHash3_x86_32 of little-endian int64 keys, seed 0 (key_hash of one 8-byte key,
+    GroupByRuntime.cpp:20-23 + MurmurHash3Inl.h) — numpy restatement, pinned against the
+    reference-generated vectors in tests/golden (test_oracle_golden.py)."""
+    k = keys.astype(np.int64).view(np.uint64)
+    M = np.uint64(0xFFFFFFFF)
+
+    def mul(a, b):
+        return (a * np.uint64(b)) & M
+
+    def rotl(x, r):
+        return ((x << np.uint64(r)) | (x >> np.uint64(32 - r))) & M
+
+    h = np.zeros(k.shape, dtype=np.uint64)
+    for blk in (k & M, k >> np.uint64(32)):
+        k1 = mul(blk, 0xcc9e2d51)
+        k1 = mul(rotl(k1, 15), 0x1b873593)
+        h ^= k1
+        h = (mul(rotl(h, 13), 5) + np.uint64(0xe6546b64)) & M
+    h ^= np.uint64(8)
+    h ^= h >> np.uint64(16)
+    h = mul(h, 0x85ebca6b)
+    h ^= h >> np.uint64(13)
+    h = mul(h, 0xc2b2ae35)
+    h ^= h >> np.uint64(16)
+    return h
+
+
+def check_probe_invariant(q: capi.QMD, buf: np.ndarray):
+    """A baseline buffer must be a valid image of get_group_value's linear probing
+    (GroupByRuntime.cpp:25-48): every key sits at or after its home slot
+    MurmurHash3(key) % entry_count (cyclically) with no empty slot in between — i.e. the
+    reference's own probe sequence finds it."""
+    if q.desc_type != capi.GROUP_BY_BASELINE_HASH or q.key_width != 8 or q.key_bytes != 8:
+        return
+    rq = q.row_size // 8
+    rows = buf.reshape(-1, rq)
+    n = rows.shape[0]
+    keys = rows[:, 0]
+    live = keys != EMPTY64
+    pos = np.nonzero(live)[0]
+    if pos.size == 0:
+        return
+    home = (murmur3_u64(keys[pos]) % np.uint64(n)).astype(np.int64)
+    # number of empty slots in the cyclic interval [home, pos) must be zero
+    empties = np.concatenate([[0], np.cumsum(~live)]).astype(np.int64)  # empties[i] = # empty in [0, i)
+    total_empty = int(empties[n])
+    fwd = pos >= home
+    gap = np.where(fwd, empties[pos] - empties[home], total_empty - empties[home] + empties[pos])
+    bad = np.nonzero(gap != 0)[0]
+    assert bad.size == 0, (bad.size, pos[bad[:5]], home[bad[:5]], keys[pos[bad[:5]]])
 
 
 _emu = None

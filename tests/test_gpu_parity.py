@@ -9,7 +9,7 @@ import pytest
 
 from heavydb_amd import capi
 from tests import cases as cases_mod
-from tests.helpers import compare_buffers, compare_rows, qmd_equal
+from tests.helpers import check_probe_invariant, compare_buffers, compare_rows, qmd_equal
 
 pytestmark = pytest.mark.gpu
 
@@ -197,7 +197,7 @@ def test_device_generator_matches_oracle(torch_cuda, oracle):
 
 
 # ------------------------------------------------------------------------------------------
-# The baseline (high-cardinality) family has three members; force each one, with a scratch
+# The baseline (high-cardinality) family has two members; force each one, with a scratch
 # budget small enough to split the input into several chunks.
 def _baseline_table(rng, n, n_keys, skew=0.0):
     from heavydb_amd.executor import ExpressionRange, InputColDescriptor
@@ -215,7 +215,7 @@ def _baseline_table(rng, n, n_keys, skew=0.0):
     return descs, [key, val, ival, fil]
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3], ids=["direct", "partitioned", "partitioned_staged"])
+@pytest.mark.parametrize("variant", [1, 2], ids=["direct", "partitioned"])
 @pytest.mark.parametrize("shape", ["count_avg_f64_filtered", "sum_min_max_i64", "count_only", "skewed"])
 def test_baseline_family_members(torch_cuda, oracle, variant, shape):
     from heavydb_amd.executor import (Executor, FetchResult, Qual, RelAlgExecutionUnit, TargetExpr)
@@ -251,10 +251,13 @@ def test_baseline_family_members(torch_cuda, oracle, variant, shape):
                                      allow_retry=False)
     assert rs.report.variant == variant
     compare_buffers(q, want, rs.getStorage(), 1e-9)
+    check_probe_invariant(q, rs.getStorage())
     compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
 
 
-def test_large_property_checks(torch_cuda):
+@pytest.mark.parametrize("n_keys,total", [(1_000_000, 256_000_000), (10_000_000, 320_000_000)],
+                         ids=["1Mkeys", "10Mkeys_two_subranges"])
+def test_large_property_checks(torch_cuda, n_keys, total):
     """Size-independent properties at a size the oracle does not visit (256 M rows, device
     generated): SUM(COUNT) == rows passing the filter (counted by the independent scan
     kernel), every key is a legal generator output, group count == key cardinality, and the
@@ -262,8 +265,6 @@ def test_large_property_checks(torch_cuda):
     from heavydb_amd import synth
     from heavydb_amd.executor import Executor, Qual, RelAlgExecutionUnit, TargetExpr
     torch = torch_cuda
-    total = 256_000_000
-    n_keys = 1_000_000
     ra, fr, info = synth.cfg3(torch, total, filtered=True, n_keys=n_keys)
     ex = Executor(0)
     rs = ex.executeWorkUnit(ra, fr, allow_retry=False)
@@ -279,5 +280,7 @@ def test_large_property_checks(torch_cuda):
     assert abs(passing / total - 0.5) < 1e-3
     assert (nul == 0).all() and (dval[:, 2] > 0).all() and (dval[:, 2] < 1000).all()
     # another family member must produce the same table
+    assert rs.report.variant == 2
+    check_probe_invariant(rs.getQueryMemDesc(), rs.getStorage())
     rs1 = ex.executeWorkUnit(ra, fr, kernel_variant=1, allow_retry=False)
     compare_buffers(rs.getQueryMemDesc(), rs1.getStorage(), rs.getStorage(), 1e-9)
