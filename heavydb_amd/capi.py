@@ -168,6 +168,7 @@ SYMBOLS = [
     ("mi355q_abi_sizeof", C.c_int64, [C.c_int32]),
     ("mi355q_error_string", C.c_char_p, [C.c_int32]),
     ("mi355q_device_count", C.c_int32, []),
+    ("mi355q_release_workspace", C.c_int32, [C.c_int32]),
     ("mi355q_device_info", C.c_int32,
      [C.c_int32, C.c_char_p, _P(C.c_int32), _P(C.c_int64), _P(C.c_int64), _P(C.c_int32),
       _P(C.c_int32)]),

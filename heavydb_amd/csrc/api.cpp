@@ -95,6 +95,23 @@ int cu_count_of(int dev) {
   return cache[dev];
 }
 
+// Per-device workspace kept between calls: the partition scratch (tens of GB for the headline
+// workload — hipMalloc/hipFree of that size costs up to a second per call), the fragment
+// pointer tables and the timing events.  Calls on one device are serialised by `mu`, like
+// the reference's per-device gpu_exec_mutex_ (ExecutionKernel.cpp:216-220).
+struct DeviceCtx {
+  std::mutex mu;
+  void* scratch = nullptr;
+  int64_t scratch_bytes = 0;
+  void* meta = nullptr;
+  size_t meta_bytes = 0;
+  std::vector<hipEvent_t> events;
+};
+DeviceCtx& ctx_of(int dev) {
+  static DeviceCtx ctxs[64];
+  return ctxs[dev < 0 ? 0 : dev % 64];
+}
+
 // Small pinned-free device scratch for the error word / counters, one per call.
 struct DevWord {
   void* p = nullptr;
@@ -217,6 +234,21 @@ int32_t mi355q_device_info(int32_t device_id, char* name, int32_t* cu_count, int
   HIP_TRY(hipMemGetInfo(&fr, &tot));
   if (total_mem) *total_mem = (int64_t)tot;
   if (free_mem) *free_mem = (int64_t)fr;
+  return MI355Q_OK;
+}
+
+int32_t mi355q_release_workspace(int32_t device_id) {
+  DeviceCtx& ctx = ctx_of(device_id);
+  std::lock_guard<std::mutex> lk(ctx.mu);
+  DeviceGuard g(device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  if (ctx.scratch) (void)hipFree(ctx.scratch);
+  if (ctx.meta) (void)hipFree(ctx.meta);
+  for (hipEvent_t e : ctx.events) (void)hipEventDestroy(e);
+  ctx.scratch = ctx.meta = nullptr;
+  ctx.scratch_bytes = 0;
+  ctx.meta_bytes = 0;
+  ctx.events.clear();
   return MI355Q_OK;
 }
 
@@ -491,9 +523,16 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   const size_t ptr_bytes = sizeof(void*) * (size_t)std::max(1, nf * nc);
   const size_t rows_bytes = sizeof(int64_t) * (size_t)std::max(1, nf);
   const size_t meta_bytes = ptr_bytes + rows_bytes + 64;
-  DevWord meta;
-  HIP_TRY(hipMalloc(&meta.p, meta_bytes));
-  char* mp = (char*)meta.p;
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::mutex> ctx_lock(ctx.mu);
+  if (ctx.meta_bytes < meta_bytes) {
+    if (ctx.meta) (void)hipFree(ctx.meta);
+    ctx.meta = nullptr;
+    ctx.meta_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx.meta, meta_bytes * 2));
+    ctx.meta_bytes = meta_bytes * 2;
+  }
+  char* mp = (char*)ctx.meta;
   const int8_t* const* d_cols = (const int8_t* const*)mp;
   const int64_t* d_rows = (const int64_t*)(mp + ptr_bytes);
   int32_t* d_err = (int32_t*)(mp + ptr_bytes + rows_bytes);
@@ -508,35 +547,21 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   LaunchStats st;
   constexpr int kEvPool = 128;
-  std::vector<hipEvent_t> ev_pool;
-  struct PoolGuard {
-    std::vector<hipEvent_t>& v;
-    ~PoolGuard() {
-      for (hipEvent_t e : v) (void)hipEventDestroy(e);
-    }
-  } pg{ev_pool};
+  hipEvent_t* ev_pool = nullptr;
   if (report) {
-    HIP_TRY(hipEventCreate(&ev_start));
-    HIP_TRY(hipEventCreate(&ev_stop));
-    HIP_TRY(hipEventCreate(&st.k_start));
-    HIP_TRY(hipEventCreate(&st.k_stop));
-    for (int i = 0; i < kEvPool; ++i) {
+    while ((int)ctx.events.size() < kEvPool + 4) {
       hipEvent_t e;
       HIP_TRY(hipEventCreate(&e));
-      ev_pool.push_back(e);
+      ctx.events.push_back(e);
     }
-    st.ev_pool = ev_pool.data();
+    ev_start = ctx.events[0];
+    ev_stop = ctx.events[1];
+    st.k_start = ctx.events[2];
+    st.k_stop = ctx.events[3];
+    ev_pool = ctx.events.data() + 4;
+    st.ev_pool = ev_pool;
     st.n_ev = kEvPool;
   }
-  struct EvGuard {
-    hipEvent_t a, b, c, d;
-    ~EvGuard() {
-      if (a) (void)hipEventDestroy(a);
-      if (b) (void)hipEventDestroy(b);
-      if (c) (void)hipEventDestroy(c);
-      if (d) (void)hipEventDestroy(d);
-    }
-  } eg{ev_start, ev_stop, st.k_start, st.k_stop};
 
   FragView fv{d_cols, d_rows, in->col_buffers, in->num_rows, nf, nc, total_rows, max_frag_rows};
 
@@ -550,16 +575,29 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   }
 
   tr.mark("setup done");
-  DevWord scratch;
   int64_t scratch_bytes = 0;
+  int64_t scratch_cap = o.scratch_bytes;
   if (kind == K_BASELINE_FAST) {
-    scratch_bytes = baseline_fast_scratch_bytes(d, fv, o.kernel_variant, o.scratch_bytes, n_cus);
-    if (scratch_bytes > 0) {
-      hipError_t e = hipMalloc(&scratch.p, (size_t)scratch_bytes);
-      if (e != hipSuccess) {
+    // default cap: 32 GB, halved while the device cannot provide it (the planner then cuts
+    // the input into more chunks)
+    for (;;) {
+      scratch_bytes = baseline_fast_scratch_bytes(d, fv, o.kernel_variant, scratch_cap, n_cus);
+      if (scratch_bytes <= ctx.scratch_bytes) break;
+      if (ctx.scratch) (void)hipFree(ctx.scratch);
+      ctx.scratch = nullptr;
+      ctx.scratch_bytes = 0;
+      hipError_t e = hipMalloc(&ctx.scratch, (size_t)scratch_bytes);
+      if (e == hipSuccess) {
+        ctx.scratch_bytes = scratch_bytes;
+        break;
+      }
+      (void)hipGetLastError();
+      const int64_t cur_cap = scratch_cap > 0 ? scratch_cap : ((int64_t)32 << 30);
+      if (cur_cap <= ((int64_t)1 << 30)) {
         last_hip_error = e;
         return MI355Q_ERR_OUT_OF_GPU_MEM;
       }
+      scratch_cap = cur_cap / 2;
     }
   }
 
@@ -576,8 +614,8 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         HIP_TRY(launch_perfect_lds(d, fv, res->buf, d_err, n_cus, s, &st));
         break;
       case K_BASELINE_FAST:
-        HIP_TRY(launch_baseline_fast(d, fv, res->buf, d_err, scratch.p, scratch_bytes,
-                                     o.scratch_bytes, o.kernel_variant, n_cus, s, &st));
+        HIP_TRY(launch_baseline_fast(d, fv, res->buf, d_err, ctx.scratch, ctx.scratch_bytes,
+                                     scratch_cap, o.kernel_variant, n_cus, s, &st));
         break;
       case K_JOIN_SUM:
         HIP_TRY(launch_join_sum(d, fv, res->buf, n_cus, s, &st));

@@ -215,7 +215,8 @@ template <typename FT, typename VT>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows, int n_frags,
     int n_cols, RangeFilter flt, int kcol, int vcol, PartGeom g, PartSlots ps,
-    Rec* __restrict__ scratch, uint32_t* __restrict__ cnt, SpillList sl) {
+    Rec* __restrict__ scratch, uint32_t* __restrict__ cnt, SpillList sl,
+    unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Rec* stage = (Rec*)smem_raw;                                   // [P][L] = kStageRecs records
   uint32_t* cursor = (uint32_t*)(smem_raw + kStageRecs * sizeof(Rec));  // [P] records appended
@@ -234,6 +235,16 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
   const uint32_t own_seg = (uint32_t)t & ((1u << lgSpl) - 1);
   const uint64_t own_run = ((uint64_t)own_p * g.B + b) * g.cap;
 
+  // MI355Q_TRACE: thread 0 of every workgroup accumulates the cycles of each phase
+  long long t_mark = dbg ? clock64() : 0;
+  unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
+  auto mark = [&](int ph) {
+    if (dbg) {
+      const long long now = clock64();
+      t_acc[ph] += (unsigned long long)(now - t_mark);
+      t_mark = now;
+    }
+  };
   // carried records: slot taken in an earlier round, line not open yet
   int64_t c_key[4], c_val[4];
   uint32_t c_pid[4], c_slot[4];
@@ -267,6 +278,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     Tile<FT, VT> nxt;
     nxt.valid = 0;
     if (have_next) load_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, gt - base, nxt);
+    mark(0);
 
     // (A) take stream positions for the surviving rows
     uint32_t n_mask = 0;
@@ -280,7 +292,9 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
         n_mask |= 1u << i;
       }
     }
+    mark(1);
     lds_barrier();  // cursors of this round are final; last round's flush is complete
+    mark(2);
 
     // (B) place: open line -> LDS, whole future lines -> straight to the run, last
     // (partial) line -> carry to the next round
@@ -322,7 +336,9 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
         }
       }
     }
+    mark(3);
     lds_barrier();  // the open lines are complete
+    mark(4);
 
     // (F) flush every line whose last slot was taken this round
     {
@@ -334,6 +350,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     }
     cur = nxt;
     have = have_next;
+    mark(5);
+  }
+  if (dbg && t == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(dbg + 8 + i, t_acc[i]);
   }
   lds_barrier();
   // records still carried belong to the open (last, partial) line
@@ -746,7 +766,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   // chunking: worst case every row survives the filter; shrink the chunk until the runs
   // (1.2 x mean + 6 sigma + a line of slack per run) fit the scratch cap, never below one
   // fragment
-  const int64_t spill_bytes = 64 + (int64_t)kSpillCap * (int64_t)sizeof(SpillEntry);
+  const int64_t spill_bytes = 256 + (int64_t)kSpillCap * (int64_t)sizeof(SpillEntry);
   int64_t chunk_rows = fv.total_rows > 0 ? fv.total_rows : 1;
   if (chunk_rows > 0xfff00000ll) chunk_rows = 0xfff00000ll;  // 32-bit LDS counters per chunk
   for (;;) {
@@ -771,27 +791,29 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
 template <typename FT, typename VT>
 hipError_t launch_scatter_t(int grid, size_t lds, hipStream_t s, const FragView& fv, int f0, int nf,
                             const RangeFilter& flt, int kcol, int vcol, const PartGeom& g,
-                            const PartSlots& ps, Rec* scratch, uint32_t* cnt, const SpillList& sl) {
+                            const PartSlots& ps, Rec* scratch, uint32_t* cnt, const SpillList& sl,
+                            unsigned long long* dbg) {
   const int8_t* const* cols = fv.d_cols + (size_t)f0 * fv.n_cols;
   const int64_t* rows = fv.d_num_rows + f0;
   // opt in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
   (void)hipFuncSetAttribute((const void*)k_part_scatter<FT, VT>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((k_part_scatter<FT, VT>), dim3(grid), dim3(kPartBlock), lds, s, cols, rows, nf,
-                     fv.n_cols, flt, kcol, vcol, g, ps, scratch, cnt, sl);
+                     fv.n_cols, flt, kcol, vcol, g, ps, scratch, cnt, sl, dbg);
   return hipGetLastError();
 }
 
 template <typename FT>
 hipError_t launch_scatter_v(const FastShape& fs, int grid, size_t lds, hipStream_t s,
                             const FragView& fv, int f0, int nf, int kcol, const PartGeom& g,
-                            const PartSlots& ps, Rec* scratch, uint32_t* cnt, const SpillList& sl) {
+                            const PartSlots& ps, Rec* scratch, uint32_t* cnt, const SpillList& sl,
+                            unsigned long long* dbg) {
   const int vcol = fs.vcol < 0 ? 0 : fs.vcol;
   if (fs.vcol < 0)
-    return launch_scatter_t<FT, none_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl);
+    return launch_scatter_t<FT, none_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl, dbg);
   if (fs.vtype == MI355Q_INT64)
-    return launch_scatter_t<FT, int64_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl);
-  return launch_scatter_t<FT, double>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl);
+    return launch_scatter_t<FT, int64_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl, dbg);
+  return launch_scatter_t<FT, double>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl, dbg);
 }
 
 }  // namespace
@@ -828,8 +850,8 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   Rec* recs = (Rec*)scratch;
   uint32_t* cnt = (uint32_t*)((char*)scratch + h.rec_bytes);
   char* spill_base = (char*)scratch + h.rec_bytes + h.cnt_bytes;
-  SpillList sl{(uint32_t*)spill_base, (SpillEntry*)(spill_base + 64), d_err};
-  hipError_t e = hipMemsetAsync(spill_base, 0, 64, s);
+  SpillList sl{(uint32_t*)spill_base, (SpillEntry*)(spill_base + 256), d_err};
+  hipError_t e = hipMemsetAsync(spill_base, 0, 256, s);
   if (e != hipSuccess) return e;
   TableArgs tab{};
   tab.out = out;
@@ -853,7 +875,7 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   (void)hipFuncSetAttribute((const void*)agg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h.lds2);
   // MI355Q_TRACE: per-phase cycle counters of phase 2 live in the spill header's tail
-  unsigned long long* dbg = std::getenv("MI355Q_TRACE") ? (unsigned long long*)(spill_base + 8) : nullptr;
+  unsigned long long* dbg = std::getenv("MI355Q_TRACE") ? (unsigned long long*)(spill_base + 64) : nullptr;
   int f = 0;
   int ev_i = 0;
   int chunk = 0;
@@ -866,11 +888,11 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     }
     if (ev_pool && ev_i + 1 < n_ev) (void)hipEventRecord(ev_pool[ev_i], s);
     if (fs.fil_type == 0)
-      e = launch_scatter_v<none_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl);
+      e = launch_scatter_v<none_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl, dbg);
     else if (fs.fil_type == MI355Q_INT32)
-      e = launch_scatter_v<int32_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl);
+      e = launch_scatter_v<int32_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl, dbg);
     else
-      e = launch_scatter_v<int64_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl);
+      e = launch_scatter_v<int64_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl, dbg);
     if (e != hipSuccess) return e;
     if (ev_pool && ev_i + 1 < n_ev) {
       (void)hipEventRecord(ev_pool[ev_i + 1], s);
@@ -897,7 +919,7 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   st->spill_counter32 = (uint32_t*)spill_base;
   st->n_events_used = ev_i;
   if (dbg) {
-    unsigned long long h_dbg[5] = {0, 0, 0, 0, 0};
+    unsigned long long h_dbg[16] = {0};
     uint32_t h_sp = 0;
     (void)hipMemcpy(&h_sp, spill_base, 4, hipMemcpyDeviceToHost);
     (void)hipStreamSynchronize(s);
@@ -905,6 +927,9 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     const double wg = (double)(h.g.P * (int)h.g.hm.R < n_cus ? h.g.P * (int)h.g.hm.R : n_cus);
     std::fprintf(stderr, "[mi355q] phase 2 Mcycles per workgroup: init %.3f  merge-load %.3f  records %.3f  emit %.3f  empties %.3f | spills %u\n",
                  h_dbg[0] / wg / 1e6, h_dbg[1] / wg / 1e6, h_dbg[2] / wg / 1e6, h_dbg[3] / wg / 1e6, h_dbg[4] / wg / 1e6, h_sp);
+    std::fprintf(stderr, "[mi355q] phase 1 Mcycles per workgroup: prefetch-issue %.3f  hash+cursor %.3f  barrier1 %.3f  place %.3f  barrier2 %.3f  flush %.3f\n",
+                 h_dbg[8] / (double)h.g.B / 1e6, h_dbg[9] / (double)h.g.B / 1e6, h_dbg[10] / (double)h.g.B / 1e6,
+                 h_dbg[11] / (double)h.g.B / 1e6, h_dbg[12] / (double)h.g.B / 1e6, h_dbg[13] / (double)h.g.B / 1e6);
   }
   return hipSuccess;
 }

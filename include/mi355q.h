@@ -254,6 +254,10 @@ int32_t mi355q_abi_version(void);
 int64_t mi355q_abi_sizeof(int32_t which);
 const char* mi355q_error_string(int32_t code);
 int32_t mi355q_device_count(void);
+/* The library keeps a per-device workspace between calls (partition scratch, fragment
+ * tables, timing events) the way the reference keeps its per-device allocator arenas
+ * (CudaAllocator, DataMgr/Allocators/CudaAllocator.cpp); this frees it. */
+int32_t mi355q_release_workspace(int32_t device_id);
 /* fills name (<=256 bytes) and basic properties of a device */
 int32_t mi355q_device_info(int32_t device_id, char* name, int32_t* cu_count,
                            int64_t* total_mem, int64_t* free_mem, int32_t* mem_clock_khz,
