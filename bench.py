@@ -114,15 +114,27 @@ def cpu_baseline(cfg: str, info: dict, target_s: float) -> dict:
         assert code == 0, code
         return dt
 
-    # calibrate on a small sample, then size the timed sample for ~target_s
-    cal_rows = 1_000_000
-    dt = run(sample(cal_rows, threads))
-    rate = cal_rows * threads / max(dt, 1e-6)
-    rows_per_frag = int(min(max(rate * target_s / threads, cal_rows), 48_000_000))
+    # Sample shape: the reference dispatches one CPU kernel per fragment, each with a private
+    # output buffer (Execute.cpp:3121-3153), then reduces the buffers pairwise.  For the
+    # big-table configs a kernel's buffer is the whole 640 MB baseline table, so the sample
+    # bounds the number of concurrent kernels (16 threads = 10 GB of tables) and the rows per
+    # kernel so that the whole leg stays within ~20-30 s of CPU work.
+    if cfg in ("cfg3", "cfg3f"):
+        threads = max(1, min(threads, 16))
+        # ~1 us per row per thread (cache- and TLB-missing probes of a 640 MB table) plus a
+        # sequential pairwise reduce of the per-kernel tables: 4 M rows per kernel ~ 20 s
+        rows_per_frag = int(4_000_000 * min(max(target_s, 1.0), 12.0) / 12.0)
+    else:
+        # calibrate on a small sample, then size the timed sample for ~target_s
+        cal_rows = 1_000_000
+        dt = run(sample(cal_rows, threads))
+        rate = cal_rows * threads / max(dt, 1e-6)
+        rows_per_frag = int(min(max(rate * target_s / threads, cal_rows), 48_000_000))
     frags = sample(rows_per_frag, threads)
     dt = run(frags)
     total = rows_per_frag * threads
     return {"value": total / dt, "unit": "rows/s", "cores": threads, "kind": "port",
+            "host_cores": os.cpu_count(),
             "sample": f"{total} rows of {cfg} ({threads} fragments x {rows_per_frag} rows, one "
                       f"kernel per fragment per host thread + pairwise reduce), {dt:.2f} s"}
 
@@ -211,10 +223,15 @@ def main():
     alg_bytes_launch = sum(r.algorithmic_bytes for r in reports) / max(k_n, 1)
     achieved = alg_bytes_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     kname = reports[-1].kernel_name.decode() if reports else ""
+    # HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/traffic.json:
+    # FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE, per input row of that kernel)
     traffic = None
     try:
         with open(args.traffic_json) as f:
-            traffic = json.load(f).get(kname)
+            tj = json.load(f).get(kname)
+        if tj and k_n:
+            rows_per_launch = sum(r.rows_scanned for r in reports) / k_n
+            traffic = tj["hbm_bytes_per_row"] * rows_per_launch
     except Exception:
         pass
 

@@ -143,3 +143,37 @@ def test_live_against_reference_functions(oracle):
             ref_buf[quad] += 1
             my_buf[s] += 1
         assert (ref_buf == my_buf).all()
+
+
+def test_probe_invariant_checker(oracle):
+    """tests.helpers.check_probe_invariant (used by the GPU parity tests to prove a product
+    buffer is a valid image of the reference's linear probing) accepts the oracle's own
+    get_group_value table and rejects a table with a displaced key; its numpy MurmurHash3
+    agrees with the oracle's (reference-pinned) one."""
+    from heavydb_amd import capi
+    from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, RelAlgExecutionUnit,
+                                      TargetExpr)
+    from tests.helpers import check_probe_invariant, murmur3_u64
+    rng = np.random.default_rng(5)
+    keys = (rng.integers(0, 3000, 20000) * 1000003 + 7).astype(np.int64)
+    for k in keys[:64]:
+        assert int(murmur3_u64(np.array([k]))[0]) == oracle.murmur3(struct.pack("<q", int(k)))
+    ra = RelAlgExecutionUnit(
+        [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, 2999 * 1000003 + 7))],
+        [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT)], [], [0],
+        max_groups_buffer_entry_guess=4200)  # ~71 % fill: long probe chains
+    q, buf, code = oracle.execute(ra.to_plan(), [[keys]], n_threads=1)
+    assert code == 0
+    check_probe_invariant(q, buf)
+    rq = q.row_size // 8
+    rows = buf.reshape(-1, rq).copy()
+    live = np.nonzero(rows[:, 0] != EMPTY64)[0]
+    empty = np.nonzero(rows[:, 0] == EMPTY64)[0]
+    # move one key far away from its probe chain: the reference's probe would not find it
+    src = live[len(live) // 2]
+    home = int(murmur3_u64(rows[src:src + 1, 0])[0] % rows.shape[0])
+    dst = next(int(e) for e in empty if (int(e) - home) % rows.shape[0] > (int(empty[np.searchsorted(empty, home) % len(empty)]) - home) % rows.shape[0])
+    rows[dst] = rows[src]
+    rows[src, 0] = EMPTY64
+    with pytest.raises(AssertionError):
+        check_probe_invariant(q, rows.reshape(-1))
