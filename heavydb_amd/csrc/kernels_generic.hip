@@ -7,6 +7,7 @@
 // (multifrag_query_hoisted_literals, RuntimeFunctions.cpp:2434-2471).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include "kernels.h"
 #include "rowfunc.h"
 
@@ -282,7 +283,11 @@ inline int grid_for(int64_t work_items, int max_blocks = 2048) {
 
 static thread_local int g_dbg_bpc = 0, g_dbg_p = 0;
 int debug_blocks_per_cu() { return g_dbg_bpc; }
-int debug_part_p() { return g_dbg_p; }
+int debug_part_p() {
+  if (g_dbg_p) return g_dbg_p;
+  const char* e = std::getenv("MI355Q_DBG_MODE");  // timing experiments only
+  return e ? std::atoi(e) : 0;
+}
 void set_debug_knobs(int blocks_per_cu, int part_p) {
   g_dbg_bpc = blocks_per_cu;
   g_dbg_p = part_p;

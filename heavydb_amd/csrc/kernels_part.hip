@@ -60,24 +60,28 @@ struct SpillEntry {
   int64_t part[kMaxInt];
 };
 
-// home slot arithmetic with plan-time magic numbers (exact for 32-bit operands:
-// Lemire, "Faster remainder by direct computation", 2019)
+// home slot arithmetic with plan-time reciprocals: q' = mulhi(x, floor(2^32 / d)) is
+// floor(x / d) or one less (x / d - x * floor(2^32 / d) / 2^32 < x / 2^32 < 1), so one
+// conditional subtraction makes the remainder exact — 2 multiplies instead of a 64-bit
+// division
 struct HomeMap {
   uint32_t d;        // entry_count
   uint32_t S1;       // home slots per partition
   uint32_t S2;       // home slots per sub-range
   uint32_t R;        // sub-ranges per partition
-  uint64_t d_magic;  // 2^64 / d + 1
-  uint64_t s1_magic; // 2^64 / S1 + 1
+  uint32_t d_rcp;    // floor(2^32 / d)   (d >= 2)
+  uint32_t s1_rcp;   // floor(2^32 / S1)  (S1 >= 2)
 };
 
 MQ_D uint32_t home_of(const HomeMap& m, int64_t key) {
   const uint32_t h = murmur3_u64((uint64_t)key);
-  const uint64_t low = m.d_magic * (uint64_t)h;
-  return (uint32_t)__umul64hi(low, (uint64_t)m.d);
+  uint32_t r = h - __umulhi(h, m.d_rcp) * m.d;
+  if (r >= m.d) r -= m.d;
+  return r;
 }
 MQ_D uint32_t part_of(const HomeMap& m, uint32_t home) {
-  return (uint32_t)__umul64hi(m.s1_magic, (uint64_t)home);
+  const uint32_t q = __umulhi(home, m.s1_rcp);
+  return q + (home - q * m.S1 >= m.S1 ? 1u : 0u);
 }
 
 struct PartGeom {
@@ -89,6 +93,7 @@ struct PartGeom {
   int32_t ns_int;      // distinct partial slots kept per group in LDS
   uint32_t lds_table_bytes;  // keys + slot arrays of the LDS table (16-byte multiple)
   uint32_t slot_off[kMaxInt];  // byte offset of each internal slot array in LDS
+  int32_t dbg_mode;            // timing experiments only; 0 in production
   HomeMap hm;
 };
 
@@ -141,9 +146,18 @@ MQ_D int64_t val_bits_of<double>(double v) { return dbl_bits(v); }
 template <>
 MQ_D int64_t val_bits_of<none_t>(none_t) { return 0; }
 
-typedef int v4i32_t __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------------- phase 1
+// What phase 1 needs of the plan, kept small so it stays in SGPRs.
+struct ScatterArgs {
+  int32_t P, lgL, B;
+  uint32_t L, cap;
+  HomeMap hm;
+  int32_t ns_int;
+  uint32_t count_mask;  // internal slots that are COUNT (a spilled record contributes 1 there)
+  int32_t dbg_mode;     // timing experiments only (exec_options.reserved[1]); 0 in production
+};
+
 template <typename FT, typename VT>
 struct Tile {
   Quad<FT> f;
@@ -182,72 +196,83 @@ MQ_D void load_tile(const int8_t* const* __restrict__ cols, const int64_t* __res
   }
 }
 
+// range filter on the column's own width (an int32 column is compared with 32-bit bounds;
+// make_range_filter clamps lo/hi to the column type)
+template <typename T>
+MQ_D bool filter_pass_narrow(const RangeFilter& f, T v) { return filter_pass<T>(f, v); }
+template <>
+MQ_D bool filter_pass_narrow<int32_t>(const RangeFilter& f, int32_t v) {
+  bool in = v >= (int32_t)f.lo && v <= (int32_t)f.hi;
+  if (f.negate) in = !in;
+  if (f.nullable && v == (int32_t)f.null_val) in = false;
+  return in;
+}
+
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+MQ_D void store_rec_nt(Rec* dst, const Rec& r) {
+  v4i32_t x;
+  x.x = (int)(uint32_t)r.key;
+  x.y = (int)(uint32_t)((uint64_t)r.key >> 32);
+  x.z = (int)(uint32_t)r.val;
+  x.w = (int)(uint32_t)((uint64_t)r.val >> 32);
+  __builtin_nontemporal_store(x, (v4i32_t*)dst);
+}
+
 // Cooperative flush of 128-byte segments: `need` marks the lanes whose own segment (index
 // seg_base + lane) must leave; 8 lanes write one segment, 8 segments per wave instruction.
 // dst_rec = record index in `scratch` of the segment's first record (valid where need).
-MQ_D void flush_segments(bool need, uint64_t dst_rec, const Rec* __restrict__ stage, int seg_base,
+MQ_D void flush_segments(bool need, uint32_t dst_rec, const Rec* __restrict__ stage, int seg_base,
                          Rec* __restrict__ scratch) {
   const uint64_t mask = __ballot(need);
   if (!mask) return;
   const int lane = threadIdx.x & 63;
   const int n_need = __popcll(mask);
-  const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;
-  const int rank_need = __popcll(mask & lt);
-  const int rank_not = lane - rank_need;
+  const int rank_need = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
   // forward permute: lane j < n_need receives the lane id of the j-th needed segment
-  const int dest = need ? rank_need : n_need + rank_not;
+  const int dest = need ? rank_need : n_need + (lane - rank_need);
   const int owner_of_rank = __builtin_amdgcn_ds_permute(dest << 2, lane);
-  const uint32_t dlo = (uint32_t)dst_rec, dhi = (uint32_t)(dst_rec >> 32);
   for (int it = 0; it * 8 < n_need; ++it) {
     const int j = it * 8 + (lane >> 3);
     const int owner = __shfl(owner_of_rank, j & 63, 64);
-    const uint32_t olo = (uint32_t)__shfl((int)dlo, owner, 64);
-    const uint32_t ohi = (uint32_t)__shfl((int)dhi, owner, 64);
+    const uint32_t o = (uint32_t)__shfl((int)dst_rec, owner, 64);
     if (j < n_need) {
-      const uint64_t o = ((uint64_t)ohi << 32) | olo;
       const Rec r = stage[(size_t)(seg_base + owner) * kSegRecs + (lane & 7)];
-      scratch[o + (lane & 7)] = r;
+      store_rec_nt(scratch + (size_t)o + (lane & 7), r);
     }
   }
+}
+
+MQ_D void spill_raw(const SpillList& sl, const ScatterArgs& g, int64_t key, int64_t vb) {
+  int64_t part[kMaxInt];
+  for (int j = 0; j < kMaxInt; ++j) part[j] = (g.count_mask >> j) & 1u ? 1 : vb;
+  spill_append(sl, key, part, g.ns_int);
 }
 
 template <typename FT, typename VT>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows, int n_frags,
-    int n_cols, RangeFilter flt, int kcol, int vcol, PartGeom g, PartSlots ps,
-    Rec* __restrict__ scratch, uint32_t* __restrict__ cnt, SpillList sl,
-    unsigned long long* __restrict__ dbg) {
+    int n_cols, RangeFilter flt, int kcol, int vcol, ScatterArgs g, Rec* __restrict__ scratch,
+    uint32_t* __restrict__ cnt, SpillList sl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Rec* stage = (Rec*)smem_raw;                                   // [P][L] = kStageRecs records
-  uint32_t* cursor = (uint32_t*)(smem_raw + kStageRecs * sizeof(Rec));  // [P] records appended
-  uint32_t* flushed = cursor + g.P;                              // [P] lines already flushed
+  Rec* stage = (Rec*)smem_raw;                                 // [P][L] = kStageRecs records
+  // per partition {records appended, lines flushed}: one ds_read_b64 fetches both
+  uint2* state = (uint2*)(smem_raw + kStageRecs * sizeof(Rec));  // [P]
   const int t = threadIdx.x, b = blockIdx.x, G = gridDim.x;
   const int lgL = g.lgL;
   const uint32_t Lm1 = g.L - 1;
-  for (int i = t; i < g.P; i += kPartBlock) {
-    cursor[i] = 0;
-    flushed[i] = 0;
-  }
+  for (int i = t; i < g.P; i += kPartBlock) state[i] = make_uint2(0u, 0u);
   // this lane's flush duty: segment t of the staging area = segment (t & (spl-1)) of the
-  // open line of partition t >> lgSpl
+  // open line of partition t >> lgSpl  (P * L == kStageRecs: every lane owns one segment)
   const int lgSpl = lgL - 3;  // log2(segments per line)
   const int own_p = t >> lgSpl;
   const uint32_t own_seg = (uint32_t)t & ((1u << lgSpl) - 1);
-  const uint64_t own_run = ((uint64_t)own_p * g.B + b) * g.cap;
+  const uint32_t own_run = ((uint32_t)own_p * g.B + b) * g.cap;  // record index (< 2^32 by plan)
 
-  // MI355Q_TRACE: thread 0 of every workgroup accumulates the cycles of each phase
-  long long t_mark = dbg ? clock64() : 0;
-  unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0};
-  auto mark = [&](int ph) {
-    if (dbg) {
-      const long long now = clock64();
-      t_acc[ph] += (unsigned long long)(now - t_mark);
-      t_mark = now;
-    }
-  };
-  // carried records: slot taken in an earlier round, line not open yet
+  // carried records: stream position taken in the previous round, line not open then; by
+  // construction their line IS open in this round, so only the staging index is kept
   int64_t c_key[4], c_val[4];
-  uint32_t c_pid[4], c_slot[4];
+  uint32_t c_sidx[4];
   uint32_t c_mask = 0;
 
   // flattened tile walk over the fragments: tile numbers are global, workgroup b owns the
@@ -278,103 +303,88 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     Tile<FT, VT> nxt;
     nxt.valid = 0;
     if (have_next) load_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, gt - base, nxt);
-    mark(0);
 
     // (A) take stream positions for the surviving rows
     uint32_t n_mask = 0;
     uint32_t pid[4], slot[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (i < cur.valid && filter_pass<FT>(flt, quad_get(cur.f, i))) {
-        const uint32_t home = home_of(g.hm, cur.k.v[i]);
-        pid[i] = part_of(g.hm, home);
-        slot[i] = atomicAdd(&cursor[pid[i]], 1u);
+      if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i))) {
+        pid[i] = (g.dbg_mode & 1) ? ((uint32_t)cur.k.v[i] * 2654435761u) >> (32 - 10)
+                                  : part_of(g.hm, home_of(g.hm, cur.k.v[i]));
+        slot[i] = atomicAdd(&state[pid[i]].x, 1u);
         n_mask |= 1u << i;
       }
     }
-    mark(1);
-    lds_barrier();  // cursors of this round are final; last round's flush is complete
-    mark(2);
+    if (!(g.dbg_mode & 4)) lds_barrier();  // cursors of this round are final; last round's flush is complete
 
-    // (B) place: open line -> LDS, whole future lines -> straight to the run, last
-    // (partial) line -> carry to the next round
-    const uint32_t own_cur = cursor[own_p], own_fl = flushed[own_p];
-    auto place = [&](int64_t key, int64_t vb, uint32_t p, uint32_t s) -> bool {
-      if (s >= g.cap) {  // run full
-        spill_record(sl, ps, g.ns_int, key, vb);
-        return true;
-      }
-      const uint32_t line = s >> lgL;
-      const uint32_t fl = flushed[p];
-      if (line == fl) {
-        stage[((size_t)p << lgL) + (s & Lm1)] = Rec{key, vb};
-        return true;
-      }
-      if (line < (cursor[p] >> lgL)) {
-        scratch[((uint64_t)p * g.B + b) * g.cap + s] = Rec{key, vb};
-        return true;
-      }
-      return false;
-    };
+    // (B) place.  Carried records first (their line is open now), then the new ones: open line
+    // -> LDS; last, still partial line -> carry; anything else (run full, or a whole line
+    // taken within this round) is rare and handled behind one wave-level branch.
+    const uint2 own = state[own_p];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (c_mask & (1u << i)) {
-        if (place(c_key[i], c_val[i], c_pid[i], c_slot[i])) c_mask &= ~(1u << i);
-      }
+      if (c_mask & (1u << i)) stage[c_sidx[i]] = Rec{c_key[i], c_val[i]};
     }
+    c_mask = 0;
+    uint32_t rare = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (n_mask & (1u << i)) {
+        const uint2 st = state[pid[i]];
+        const uint32_t line = slot[i] >> lgL;
+        const uint32_t sidx = (pid[i] << lgL) + (slot[i] & Lm1);
         const int64_t vb = val_bits_of<VT>(quad_get(cur.v, i));
-        if (!place(cur.k.v[i], vb, pid[i], slot[i])) {
-          // carried slot i is free: everything carried from the last round was placed above
+        if (slot[i] < g.cap && line == st.y) {
+          stage[sidx] = Rec{cur.k.v[i], vb};
+        } else if (slot[i] < g.cap && line == (st.x >> lgL)) {
           c_key[i] = cur.k.v[i];
           c_val[i] = vb;
-          c_pid[i] = pid[i];
-          c_slot[i] = slot[i];
+          c_sidx[i] = sidx;
           c_mask |= 1u << i;
+        } else {
+          rare |= 1u << i;
         }
       }
     }
-    mark(3);
-    lds_barrier();  // the open lines are complete
-    mark(4);
+    if (__ballot(rare != 0)) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (rare & (1u << i)) {
+          const int64_t vb = val_bits_of<VT>(quad_get(cur.v, i));
+          if (slot[i] >= g.cap) spill_raw(sl, g, cur.k.v[i], vb);  // run full
+          else scratch[(size_t)(((uint32_t)pid[i] * g.B + b) * g.cap + slot[i])] = Rec{cur.k.v[i], vb};
+        }
+      }
+    }
+    if (!(g.dbg_mode & 8)) lds_barrier();  // the open lines are complete
 
-    // (F) flush every line whose last slot was taken this round
+    // (F) flush every line whose last slot was taken this round; lines in between went
+    // straight to the run above
     {
-      const uint32_t new_fl = own_cur >> lgL;
-      const bool need = t < (g.P << lgSpl) && new_fl > own_fl && (uint64_t)own_fl * g.L < g.cap;
-      flush_segments(need, own_run + ((uint64_t)own_fl << lgL) + own_seg * kSegRecs, stage,
-                     t & ~63, scratch);
-      if (t < (g.P << lgSpl) && own_seg == 0 && new_fl > own_fl) flushed[own_p] = new_fl;
+      const uint32_t new_fl = own.x >> lgL;
+      const bool adv = new_fl > own.y;
+      const bool need = adv && (own.y << lgL) < g.cap;
+      flush_segments(need && !(g.dbg_mode & 2), own_run + (own.y << lgL) + own_seg * kSegRecs, stage, t & ~63, scratch);
+      if (adv && own_seg == 0) state[own_p].y = new_fl;
     }
     cur = nxt;
     have = have_next;
-    mark(5);
-  }
-  if (dbg && t == 0) {
-    for (int i = 0; i < 6; ++i) atomicAdd(dbg + 8 + i, t_acc[i]);
   }
   lds_barrier();
   // records still carried belong to the open (last, partial) line
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    if (c_mask & (1u << i)) {
-      const uint32_t s = c_slot[i], p = c_pid[i];
-      if (s >= g.cap) spill_record(sl, ps, g.ns_int, c_key[i], c_val[i]);
-      else stage[((size_t)p << lgL) + (s & Lm1)] = Rec{c_key[i], c_val[i]};
-    }
+    if (c_mask & (1u << i)) stage[c_sidx[i]] = Rec{c_key[i], c_val[i]};
   }
   lds_barrier();
   // drain the partially filled lines (whole segments; the run length says what is valid)
   {
-    const bool owner = t < (g.P << lgSpl);
-    const uint32_t c = owner ? cursor[own_p] : 0u;
-    const uint32_t fl = owner ? flushed[own_p] : 0u;
-    const uint32_t rem = c - (fl << lgL);  // < L
-    const bool need = owner && own_seg * kSegRecs < rem && ((uint64_t)fl << lgL) + own_seg * kSegRecs < g.cap;
-    flush_segments(need, own_run + ((uint64_t)fl << lgL) + own_seg * kSegRecs, stage, t & ~63, scratch);
-    if (owner && own_seg == 0) cnt[(size_t)own_p * g.B + b] = c < g.cap ? c : g.cap;
+    const uint2 st = state[own_p];
+    const uint32_t rem = st.x - (st.y << lgL);  // < L
+    const bool need = own_seg * kSegRecs < rem && (st.y << lgL) + own_seg * kSegRecs < g.cap;
+    flush_segments(need, own_run + (st.y << lgL) + own_seg * kSegRecs, stage, t & ~63, scratch);
+    if (own_seg == 0) cnt[(size_t)own_p * g.B + b] = st.x < g.cap ? st.x : g.cap;
   }
 }
 
@@ -496,12 +506,57 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     }
   };
   auto bucket_of = [&](uint32_t x) -> uint32_t { return (uint32_t)(((uint64_t)x * g.b_mult) >> 32); };
-  auto insert_rec = [&](const Rec& r, bool valid) {
-    const uint32_t x = home_of(g.hm, r.key) - lo;
-    if (!valid || x >= n_slots) return;  // past the run's end / another sub-range's record
-    const uint32_t e = lds_locate(lkeys, n_buckets, bucket_of(x), r.key);
-    if (e != kNoEntry) apply_row<MASK>(smem_raw, g, ps, e, r.val);
-    else spill_record(sl, ps, ns, r.key, r.val);
+  // Four records per lane per step: all four bucket reads are issued before any is consumed
+  // (LDS latency overlaps 4x), hits — the common case once a unit's table is warm — update
+  // their slots straight away, misses fall back to the insert-or-find loop afterwards.
+  auto insert4 = [&](const Rec& r0, const Rec& r1, const Rec& r2, const Rec& r3, uint32_t n_valid) {
+    const Rec* rr[4] = {&r0, &r1, &r2, &r3};
+    uint32_t bk[4];
+    uint32_t in_mask = 0;
+    if (g.dbg_mode & 32) {  // timing experiment: memory only
+      if (r0.key + r1.key + r2.key + r3.key == 0x1234567) atomicAdd(sl.count, 1u);
+      return;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t x = home_of(g.hm, rr[j]->key) - lo;
+      const bool in = (uint32_t)j < n_valid && x < n_slots;  // else: past the run's end / another sub-range
+      bk[j] = in ? bucket_of(x) : 0u;
+      in_mask |= (in ? 1u : 0u) << j;
+    }
+    if (g.dbg_mode & 16) {  // timing experiment: hash + range test only
+      if (in_mask == 0x77) atomicAdd(sl.count, 1u);
+      return;
+    }
+    v2i64_t ka[4], kc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t* bp = lkeys + (size_t)bk[j] * 4;
+      ka[j] = *(const v2i64_t*)bp;
+      kc[j] = *((const v2i64_t*)bp + 1);
+    }
+    uint32_t miss = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t key = rr[j]->key;
+      const int hit = ka[j].x == key ? 0 : ka[j].y == key ? 1 : kc[j].x == key ? 2 : kc[j].y == key ? 3 : -1;
+      if (in_mask & (1u << j)) {
+        if (hit >= 0) apply_row<MASK>(smem_raw, g, ps, bk[j] * 4 + (uint32_t)hit, rr[j]->val);
+        else miss |= 1u << j;
+      }
+    }
+    // misses (first touch of a group, or a group displaced from a full bucket): ONE loop per
+    // lane over its missing records, so a wave pays the longest per-lane chain once
+    while (miss) {
+      const int j = __builtin_ctz(miss);
+      miss &= miss - 1;
+      const int64_t key = j == 0 ? r0.key : j == 1 ? r1.key : j == 2 ? r2.key : r3.key;
+      const int64_t val = j == 0 ? r0.val : j == 1 ? r1.val : j == 2 ? r2.val : r3.val;
+      const uint32_t b0 = j == 0 ? bk[0] : j == 1 ? bk[1] : j == 2 ? bk[2] : bk[3];
+      const uint32_t e = lds_locate(lkeys, n_buckets, b0, key);
+      if (e != kNoEntry) apply_row<MASK>(smem_raw, g, ps, e, val);
+      else spill_record(sl, ps, ns, key, val);
+    }
   };
 
   for (int it = 0;; ++it) {
@@ -576,10 +631,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
         for (uint32_t base = 0; base < n; base += 256) {
           const uint32_t i = base + lane, nx = i + 256;
           const Rec n0 = run[at(nx)], n1 = run[at(nx + 64)], n2 = run[at(nx + 128)], n3 = run[at(nx + 192)];
-          insert_rec(c0, i < n);
-          insert_rec(c1, i + 64 < n);
-          insert_rec(c2, i + 128 < n);
-          insert_rec(c3, i + 192 < n);
+          insert4(c0, c1, c2, c3, i < n ? (n - i + 63) / 64 : 0u);
           c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
       }
@@ -743,8 +795,9 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   hm.S1 = (uint32_t)((d + P - 1) / P);
   hm.R = R < 1 ? 1 : R;
   hm.S2 = (hm.S1 + hm.R - 1) / hm.R;
-  hm.d_magic = ~0ull / hm.d + 1;
-  hm.s1_magic = ~0ull / hm.S1 + 1;
+  hm.d_rcp = (uint32_t)(((uint64_t)1 << 32) / hm.d);
+  hm.s1_rcp = hm.S1 >= 2 ? (uint32_t)(((uint64_t)1 << 32) / hm.S1) : 0u;
+  if (hm.S1 < 2) return false;
   uint64_t e_want = hm.S2;  // an LDS entry per home slot when it fits (50 % fill)
   if (e_want > e_max) e_want = e_max;
   if (e_want < 64) e_want = 64;
@@ -762,6 +815,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     const uint64_t m = ((uint64_t)(h.g.E / 4) << 32) / hm.S2;
     h.g.b_mult = (uint32_t)(m > 0xffffffffull ? 0xffffffffull : m);
   }
+  h.g.dbg_mode = debug_part_p();
   h.g.B = n_cus;  // one 1024-lane workgroup per CU
   // chunking: worst case every row survives the filter; shrink the chunk until the runs
   // (1.2 x mean + 6 sigma + a line of slack per run) fit the scratch cap, never below one
@@ -774,6 +828,12 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     uint64_t cap = (uint64_t)(per_run * 1.2 + 6.0 * __builtin_sqrt(per_run + 1.0)) + h.g.L;
     cap = (cap + h.g.L - 1) / h.g.L * h.g.L;  // whole lines
     if (cap > 0x7fffffffull) return false;
+    if ((uint64_t)P * h.g.B * cap >= ((uint64_t)1 << 32)) {  // 32-bit record indices in phase 1
+      if (chunk_rows <= fv.max_frag_rows) return false;
+      chunk_rows = (int64_t)(chunk_rows * 0.9);
+      if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
+      continue;
+    }
     h.g.cap = (uint32_t)cap;
     h.rec_bytes = (int64_t)P * h.g.B * (int64_t)cap * (int64_t)sizeof(Rec);
     h.cnt_bytes = ((int64_t)P * h.g.B * 4 + 255) & ~255ll;
@@ -790,30 +850,28 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
 
 template <typename FT, typename VT>
 hipError_t launch_scatter_t(int grid, size_t lds, hipStream_t s, const FragView& fv, int f0, int nf,
-                            const RangeFilter& flt, int kcol, int vcol, const PartGeom& g,
-                            const PartSlots& ps, Rec* scratch, uint32_t* cnt, const SpillList& sl,
-                            unsigned long long* dbg) {
+                            const RangeFilter& flt, int kcol, int vcol, const ScatterArgs& g,
+                            Rec* scratch, uint32_t* cnt, const SpillList& sl) {
   const int8_t* const* cols = fv.d_cols + (size_t)f0 * fv.n_cols;
   const int64_t* rows = fv.d_num_rows + f0;
   // opt in to > 64 KB of dynamic LDS (gfx950: 160 KB per workgroup)
   (void)hipFuncSetAttribute((const void*)k_part_scatter<FT, VT>,
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL((k_part_scatter<FT, VT>), dim3(grid), dim3(kPartBlock), lds, s, cols, rows, nf,
-                     fv.n_cols, flt, kcol, vcol, g, ps, scratch, cnt, sl, dbg);
+                     fv.n_cols, flt, kcol, vcol, g, scratch, cnt, sl);
   return hipGetLastError();
 }
 
 template <typename FT>
 hipError_t launch_scatter_v(const FastShape& fs, int grid, size_t lds, hipStream_t s,
-                            const FragView& fv, int f0, int nf, int kcol, const PartGeom& g,
-                            const PartSlots& ps, Rec* scratch, uint32_t* cnt, const SpillList& sl,
-                            unsigned long long* dbg) {
+                            const FragView& fv, int f0, int nf, int kcol, const ScatterArgs& g,
+                            Rec* scratch, uint32_t* cnt, const SpillList& sl) {
   const int vcol = fs.vcol < 0 ? 0 : fs.vcol;
   if (fs.vcol < 0)
-    return launch_scatter_t<FT, none_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl, dbg);
+    return launch_scatter_t<FT, none_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, scratch, cnt, sl);
   if (fs.vtype == MI355Q_INT64)
-    return launch_scatter_t<FT, int64_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl, dbg);
-  return launch_scatter_t<FT, double>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, ps, scratch, cnt, sl, dbg);
+    return launch_scatter_t<FT, int64_t>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, scratch, cnt, sl);
+  return launch_scatter_t<FT, double>(grid, lds, s, fv, f0, nf, fs.flt, kcol, vcol, g, scratch, cnt, sl);
 }
 
 }  // namespace
@@ -876,6 +934,18 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                             (int)h.lds2);
   // MI355Q_TRACE: per-phase cycle counters of phase 2 live in the spill header's tail
   unsigned long long* dbg = std::getenv("MI355Q_TRACE") ? (unsigned long long*)(spill_base + 64) : nullptr;
+  ScatterArgs sa{};
+  sa.P = h.g.P;
+  sa.lgL = h.g.lgL;
+  sa.B = h.g.B;
+  sa.L = h.g.L;
+  sa.cap = h.g.cap;
+  sa.hm = h.g.hm;
+  sa.ns_int = h.g.ns_int;
+  sa.count_mask = 0;
+  sa.dbg_mode = debug_part_p();
+  for (int m = 0; m < h.g.ns_int; ++m)
+    if (h.ps.int_op[m] == SO_COUNT) sa.count_mask |= 1u << m;
   int f = 0;
   int ev_i = 0;
   int chunk = 0;
@@ -888,11 +958,11 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     }
     if (ev_pool && ev_i + 1 < n_ev) (void)hipEventRecord(ev_pool[ev_i], s);
     if (fs.fil_type == 0)
-      e = launch_scatter_v<none_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl, dbg);
+      e = launch_scatter_v<none_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, sa, recs, cnt, sl);
     else if (fs.fil_type == MI355Q_INT32)
-      e = launch_scatter_v<int32_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl, dbg);
+      e = launch_scatter_v<int32_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, sa, recs, cnt, sl);
     else
-      e = launch_scatter_v<int64_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, h.g, h.ps, recs, cnt, sl, dbg);
+      e = launch_scatter_v<int64_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, sa, recs, cnt, sl);
     if (e != hipSuccess) return e;
     if (ev_pool && ev_i + 1 < n_ev) {
       (void)hipEventRecord(ev_pool[ev_i + 1], s);
@@ -927,9 +997,6 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     const double wg = (double)(h.g.P * (int)h.g.hm.R < n_cus ? h.g.P * (int)h.g.hm.R : n_cus);
     std::fprintf(stderr, "[mi355q] phase 2 Mcycles per workgroup: init %.3f  merge-load %.3f  records %.3f  emit %.3f  empties %.3f | spills %u\n",
                  h_dbg[0] / wg / 1e6, h_dbg[1] / wg / 1e6, h_dbg[2] / wg / 1e6, h_dbg[3] / wg / 1e6, h_dbg[4] / wg / 1e6, h_sp);
-    std::fprintf(stderr, "[mi355q] phase 1 Mcycles per workgroup: prefetch-issue %.3f  hash+cursor %.3f  barrier1 %.3f  place %.3f  barrier2 %.3f  flush %.3f\n",
-                 h_dbg[8] / (double)h.g.B / 1e6, h_dbg[9] / (double)h.g.B / 1e6, h_dbg[10] / (double)h.g.B / 1e6,
-                 h_dbg[11] / (double)h.g.B / 1e6, h_dbg[12] / (double)h.g.B / 1e6, h_dbg[13] / (double)h.g.B / 1e6);
   }
   return hipSuccess;
 }
