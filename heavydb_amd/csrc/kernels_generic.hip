@@ -161,19 +161,52 @@ __global__ void k_shard_offsets(const int64_t* __restrict__ part_counts, int n_p
   }
 }
 
+// Rows are appended run by run with ONE global atomic per (workgroup chunk, part): the chunk's
+// rows are counted per part in LDS, the workgroup reserves a contiguous range of every run,
+// and each row then takes its position from an LDS cursor.  (A global atomic per row on
+// n_parts <= 8 words would serialise: ~12 ns per same-address atomic.)
+constexpr int kShardChunk = 16;  // entries per lane per chunk
 __global__ __launch_bounds__(kBlock) void k_shard_scatter(DevPlan p, int idx_target_as_key,
                                                            const int64_t* __restrict__ buf,
                                                            int n_parts,
                                                            int64_t* __restrict__ out_rows,
                                                            int64_t* __restrict__ cursors) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < p.entry_count; e += stride) {
-    const int64_t* row = buf + e * p.row_quad;
-    if (is_empty_row(p, row, idx_target_as_key)) continue;
-    const uint32_t part = shard_of(p, row, n_parts);
-    const int64_t dst = (int64_t)atomicAdd((unsigned long long*)&cursors[part], 1ull);
-    int64_t* o = out_rows + dst * p.row_quad;
-    for (int j = 0; j < p.row_quad; ++j) o[j] = row[j];
+  __shared__ unsigned int s_cnt[256];
+  __shared__ unsigned long long s_base[256];
+  const int64_t chunk = (int64_t)kBlock * kShardChunk;
+  for (int64_t c0 = (int64_t)blockIdx.x * chunk; c0 < p.entry_count; c0 += (int64_t)gridDim.x * chunk) {
+    for (int i = threadIdx.x; i < n_parts; i += kBlock) s_cnt[i] = 0;
+    __syncthreads();
+    uint32_t part[kShardChunk];
+#pragma unroll
+    for (int k = 0; k < kShardChunk; ++k) {
+      const int64_t e = c0 + (int64_t)k * kBlock + threadIdx.x;
+      part[k] = 0xffffffffu;
+      if (e < p.entry_count) {
+        const int64_t* row = buf + e * p.row_quad;
+        if (!is_empty_row(p, row, idx_target_as_key)) {
+          part[k] = shard_of(p, row, n_parts);
+          atomicAdd(&s_cnt[part[k]], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_parts; i += kBlock) {
+      const unsigned int c = s_cnt[i];
+      s_base[i] = c ? atomicAdd((unsigned long long*)&cursors[i], (unsigned long long)c) : 0ull;
+      s_cnt[i] = 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < kShardChunk; ++k) {
+      if (part[k] == 0xffffffffu) continue;
+      const int64_t e = c0 + (int64_t)k * kBlock + threadIdx.x;
+      const int64_t* row = buf + e * p.row_quad;
+      const int64_t dst = (int64_t)(s_base[part[k]] + atomicAdd(&s_cnt[part[k]], 1u));
+      int64_t* o = out_rows + dst * p.row_quad;
+      for (int j = 0; j < p.row_quad; ++j) o[j] = row[j];
+    }
+    __syncthreads();
   }
 }
 

@@ -284,3 +284,56 @@ def test_large_property_checks(torch_cuda, n_keys, total):
     check_probe_invariant(rs.getQueryMemDesc(), rs.getStorage())
     rs1 = ex.executeWorkUnit(ra, fr, kernel_variant=1, allow_retry=False)
     compare_buffers(rs.getQueryMemDesc(), rs1.getStorage(), rs.getStorage(), 1e-9)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_partition_and_merge_on_one_device(torch_cuda, oracle, world):
+    """The keyed multi-GPU merge (multi_gpu.merge_keyed) with all `world` shards living on one
+    GPU: every shard's table is compacted into `world` runs by key hash
+    (mi355q_shard_partition), the runs are regrouped by destination (what the RCCL all-to-all
+    does) and folded into fresh tables (mi355q_shard_merge_rows).  The union of the
+    destination tables must equal the oracle's result over all fragments, and destination d
+    must only hold keys of shard d.  (The collective choreography itself is covered by
+    tests/test_multi_gpu_gloo.py.)"""
+    from heavydb_amd.executor import Executor, FetchResult, Qual, RelAlgExecutionUnit, TargetExpr
+    from heavydb_amd.multi_gpu import HipShard
+    from tests.helpers import murmur3_u64
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    n, n_keys = 400_000, 60_000
+    descs, cols = _baseline_table(rng, n, n_keys)
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1),
+                                     TargetExpr(capi.MIN, 2)], [Qual(3, capi.LT, 2**30)], [0],
+                             max_groups_buffer_entry_guess=2 * n_keys)
+    n_frags = 2 * world + 1
+    cuts = (np.linspace(0, n, n_frags + 1).astype(int) // 4) * 4
+    cuts[-1] = n
+    frags = [[c[cuts[i]:cuts[i + 1]] for c in cols] for i in range(n_frags)]
+    q, want, code = oracle.execute(ra.to_plan(), frags, n_threads=2)
+    assert code == 0
+    dev = [torch.from_numpy(c).cuda() for c in cols]
+    ex = Executor(0)
+    shards = []
+    for r in range(world):
+        bufs = [[int(t.data_ptr()) + int(cuts[i]) * t.element_size() for t in dev]
+                for i in range(n_frags) if i % world == r]
+        rows = [int(cuts[i + 1] - cuts[i]) for i in range(n_frags) if i % world == r]
+        shards.append(HipShard.execute(torch, ex, ra, FetchResult(bufs, rows, keepalive=dev)))
+    parts = [s.partition_rows(world) for s in shards]  # (rows sorted by destination, counts)
+    merged = np.zeros((0, q.row_size // 8), dtype=np.int64)
+    for d in range(world):
+        out = shards[0].fresh_like()
+        for rows, counts in parts:
+            lo = sum(counts[:d])
+            out.merge_rows(rows[lo:lo + counts[d]].contiguous())
+        torch.cuda.synchronize()
+        tab = out.buffer().cpu().numpy()
+        live = tab[tab[:, 0] != 2**63 - 1]
+        owner = ((murmur3_u64(live[:, 0]) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+        assert (owner == d).all()
+        merged = np.concatenate([merged, live])
+    # the union, laid out as one table for the comparison helper (positions are irrelevant)
+    assert merged.shape[0] <= q.entry_count
+    full = oracle.init_buffer(q).reshape(q.entry_count, -1)
+    full[:merged.shape[0]] = merged
+    compare_buffers(q, want, full.reshape(-1), 1e-9)

@@ -1,0 +1,180 @@
+"""world_size-2 (and 3) CPU runs of the multi-GPU merge choreography (heavydb_amd/multi_gpu.py)
+over the `gloo` backend.  The collectives, the split/exchange/fold order and the ownership
+rules are exactly the ones the GPU path runs over RCCL; only the ShardOps backend differs: here
+it is numpy + the oracle (test infrastructure), on the GPU it is HipShard (C-ABI kernels).
+
+Each rank executes the oracle on its fragments (fragment f -> rank f % world, the reference's
+rule), merges, and rank 0 compares with the oracle run over ALL fragments."""
+from __future__ import annotations
+
+import os
+import socket
+import sys
+import traceback
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+EMPTY64 = 2**63 - 1
+
+
+class NumpyShard:
+    """ShardOps over numpy buffers + the oracle's reduce/init (CPU stand-in for HipShard)."""
+
+    def __init__(self, torch, orc, q, buf=None):
+        self._torch, self._orc, self._q = torch, orc, q
+        self._np = buf if buf is not None else orc.init_buffer(q)
+        self._np = np.ascontiguousarray(self._np).reshape(q.entry_count, q.row_size // 8)
+
+    def qmd(self):
+        return self._q
+
+    def buffer(self):
+        return self._torch.from_numpy(self._np)  # shares memory: all_reduce results land in place
+
+    def partition_rows(self, n_parts):
+        from tests.helpers import murmur3_u64
+        assert self._q.key_width == 8
+        live = self._np[self._np[:, 0] != EMPTY64]
+        # same shard function as mi355q_shard_partition: upper hash bits
+        part = ((murmur3_u64(live[:, 0]) * np.uint64(n_parts)) >> np.uint64(32)).astype(np.int64)
+        order = np.argsort(part, kind="stable")
+        counts = np.bincount(part, minlength=n_parts).tolist()
+        return self._torch.from_numpy(np.ascontiguousarray(live[order])), [int(c) for c in counts]
+
+    def fresh_like(self):
+        return NumpyShard(self._torch, self._orc, self._q)
+
+    def merge_rows(self, rows):
+        rows = rows.numpy()
+        n = rows.shape[0]
+        if not n:
+            return
+        assert n <= self._q.entry_count
+        that = self._orc.init_buffer(self._q).reshape(self._q.entry_count, -1)
+        that[:n] = rows
+        assert self._orc.reduce(self._q, self._np, that) == 0
+
+    def reduce_from(self, other_buffer):
+        other = np.ascontiguousarray(other_buffer.numpy()).reshape(self._np.shape)
+        assert self._orc.reduce(self._q, self._np, other) == 0
+
+
+def _table(shape, seed=7):
+    from heavydb_amd import capi
+    from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
+                                      TargetExpr)
+    rng = np.random.default_rng(seed)
+    n = 60_000
+    if shape == "keyed":
+        n_keys = 9_000
+        key = (rng.integers(0, n_keys, n) * 1000003 + 7).astype(np.int64)
+        val = (rng.random(n) * 1000.0).astype(np.float64)
+        fil = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+        descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7)),
+                 InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0)),
+                 InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1)],
+                                 [Qual(2, capi.LT, 2**30)], [0], max_groups_buffer_entry_guess=2 * n_keys)
+        cols = [key, val, fil]
+    elif shape == "perfect":
+        key = rng.integers(0, 1000, n).astype(np.int32)
+        val = rng.integers(-500_000, 500_001, n).astype(np.int64)
+        descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 999)),
+                 InputColDescriptor(capi.INT64, False, ExpressionRange(True, -500_000, 500_000))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 1),
+                                         TargetExpr(capi.MAX, 1)], groupby_exprs=[0])
+        cols = [key, val]
+    elif shape == "perfect_nullable":  # NULL-aware slots: exercises the all_gather + reduce branch
+        key = rng.integers(0, 50, n).astype(np.int32)
+        val = rng.integers(-1000, 1000, n).astype(np.int64)
+        val[rng.random(n) < 0.3] = -(2**63)
+        descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 49)),
+                 InputColDescriptor(capi.INT64, True, ExpressionRange(True, -1000, 999, True))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 1), TargetExpr(capi.COUNT, 1),
+                                         TargetExpr(capi.AVG, 1)], groupby_exprs=[0])
+        cols = [key, val]
+    else:  # non-grouped COUNT(*) WHERE
+        fil = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+        descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT)], [Qual(0, capi.LT, 2**30)])
+        cols = [fil]
+    n_frags = 7
+    cuts = np.linspace(0, n, n_frags + 1).astype(int)
+    frags = [[c[cuts[i]:cuts[i + 1]] for c in cols] for i in range(n_frags)]
+    return ra, frags
+
+
+def _worker(rank, world, port, shape, errq):
+    try:
+        import torch
+        import torch.distributed as dist
+        from heavydb_amd import capi
+        from heavydb_amd.multi_gpu import merge
+        from oracle import oracle as orc
+        from tests.helpers import compare_buffers, compare_rows
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        ra, frags = _table(shape)
+        plan = ra.to_plan()
+        mine = [f for i, f in enumerate(frags) if i % world == rank]
+        q, buf, code = orc.execute(plan, mine, n_threads=1)
+        assert code == 0
+        shard = NumpyShard(torch, orc, q, buf)
+        out = merge(shard, dist, torch, gather_to_rank0=True)
+        q_all, want, code = orc.execute(plan, frags, n_threads=2)
+        assert code == 0
+        got = out.buffer().numpy()
+        if q.desc_type == capi.GROUP_BY_BASELINE_HASH:
+            # every rank owns exactly the keys of its shard after the all-to-all ...
+            from tests.helpers import murmur3_u64
+            live = got[got[:, 0] != EMPTY64]
+            owner = ((murmur3_u64(live[:, 0]) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+            if rank != 0:
+                assert (owner == rank).all()
+            else:  # ... and rank 0 additionally gathered everything
+                compare_buffers(q_all, want, got.reshape(-1), 1e-9)
+                compare_rows(q_all, orc.fetch_rows(q_all, want), orc.fetch_rows(q_all, got.reshape(-1)), 1e-9)
+        else:
+            compare_buffers(q_all, want, got.reshape(-1), 1e-9)  # dense: every rank holds the full result
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # surface the traceback in the parent
+        errq.put((rank, traceback.format_exc()))
+        raise
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("shape", ["keyed", "perfect", "perfect_nullable", "non_grouped"])
+def test_merge_over_gloo(shape, world):
+    import torch.multiprocessing as mp
+    from oracle import oracle as orc
+    orc.lib()  # build once in the parent
+    ctx = mp.get_context("spawn")
+    errq = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, errq)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    errs = []
+    while not errq.empty():
+        errs.append(errq.get())
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+            errs.append((-1, "timeout"))
+    assert not errs, "\n".join(f"rank {r}:\n{t}" for r, t in errs)
+    assert all(p.exitcode == 0 for p in procs)
