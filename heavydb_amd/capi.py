@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 MAX_COLS = 16
 MAX_QUALS = 4
@@ -222,6 +223,16 @@ def load_library(path: str | None = None) -> C.CDLL:
             f"{p} not found: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()'). "
             "heavydb_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64, and device pointers
+    # / streams only interoperate when both sides resolve to the same copy.  If torch is going
+    # to be used in this process it must be the first to load the runtime, so import it (when
+    # installed) before dlopen-ing the library; loading the library first and torch afterwards
+    # makes the first launch fail with a HIP error.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is optional for the C-ABI itself
+            pass
     lib = C.CDLL(p)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)  # AttributeError if the export is missing

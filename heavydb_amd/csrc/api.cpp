@@ -63,6 +63,9 @@ struct DeviceGuard {
   explicit DeviceGuard(int dev) {
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
     ok = hipSetDevice(dev) == hipSuccess;
+    // hipGetLastError() is per thread and sticky: another runtime user in this process (torch)
+    // may have left an unrelated error behind, which the launch checks would then report
+    (void)hipGetLastError();
   }
   ~DeviceGuard() {
     if (prev >= 0) (void)hipSetDevice(prev);

@@ -315,7 +315,11 @@ inline int grid_for(int64_t work_items, int max_blocks = 2048) {
 }  // namespace
 
 static thread_local int g_dbg_bpc = 0, g_dbg_p = 0;
-int debug_blocks_per_cu() { return g_dbg_bpc; }
+int debug_blocks_per_cu() {
+  if (g_dbg_bpc) return g_dbg_bpc;
+  const char* e = std::getenv("MI355Q_DBG_BPC");  // tuning experiments only
+  return e ? std::atoi(e) : 0;
+}
 int debug_part_p() {
   if (g_dbg_p) return g_dbg_p;
   const char* e = std::getenv("MI355Q_DBG_MODE");  // timing experiments only

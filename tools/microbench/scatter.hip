@@ -48,6 +48,17 @@ __global__ __launch_bounds__(kT) void k_scatter_sim(const v4i32* __restrict__ fc
       st16<NTS>(dst + kT + t, r1);
       continue;
     }
+    if (mode == 3) {
+      // lane-owned lines: lanes 0..255 each write one whole 128-byte line (8 x 16-byte stores)
+      if (t < 256) {
+        const long long g = round * 256 + t;
+        const unsigned pid = ((unsigned)g * 0x9E3779B1u) & (unsigned)(P - 1);
+        const long long addr = ((long long)pid * B + b) * run_vec + (g / P) * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) st16<NTS>(scratch + addr + k, (k & 1) ? r1 : r0);
+      }
+      continue;
+    }
     // scattered: the workgroup-round emits 2048/LINE_LANES lines; line g -> partition perm(g % P)
     const int lines_per_round = 2 * kT / LINE_LANES;
 #pragma unroll
@@ -150,6 +161,11 @@ int main(int argc, char** argv) {
   run(k_scatter_sim<1, false, 0>, "read-only", 1, 0);
   run(k_scatter_sim<1, false, 0>, "read+contig write", 1, 1);
   run(k_scatter_sim<1, true, 0>, "read+contig write nt", 1, 1);
+  run(k_scatter_sim<8, false, 0>, "lane-owned 128 B line plain", 1024, 3);
+  run(k_scatter_sim<8, true, 0>, "lane-owned 128 B line nt", 1024, 3);
+  run(k_scatter_sim<8, false, 0>, "L=128 [p][b] plain (8 lanes)", 1024, 2);
+  run(k_scatter_sim<8, true, 0>, "L=128 [p][b] nt (8 lanes)", 1024, 2);
+  if (argc > 2) return 0;
   const int Ps[] = {512, 2048, 4096};
   for (int P : Ps) {
     run(k_scatter_sim<1, false, 0>, "L=16  [p][b] plain", P, 2);
