@@ -643,6 +643,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   HIP_TRY(hipStreamSynchronize(s));
   tr.mark("synchronized");
   st.spilled_rows = (int64_t)h_spills;
+  if (h_err[1] && tr.on) std::fprintf(stderr, "[mi355q] partitioned family gave up (code %d, spills %u): re-running with the direct kernel\n", h_err[1], h_spills);
   if (h_err[1] && kind == K_BASELINE_FAST) {
     // the partitioned family ran out of spill space (extreme skew): redo the step with the
     // direct-atomic member of the same family

@@ -249,142 +249,232 @@ MQ_D void spill_raw(const SpillList& sl, const ScatterArgs& g, int64_t key, int6
   spill_append(sl, key, part, g.ns_int);
 }
 
+// Role split inside the 16-wave workgroup: waves 0..11 PRODUCE (load, filter, hash, take a
+// stream position, write the record into the partition's open staging line), waves 12..15
+// FLUSH (poll the per-partition counters, send complete lines to the runs, open the next
+// line).  The two sides only meet through three LDS words per partition — there is no
+// workgroup barrier in the steady state, so one wave's LDS / HBM latency never stalls another
+// (the barrier version of this kernel spent ~17 % of its time parked in s_barrier).
+//   cursor[p]   stream positions handed out               (producers: atomicAdd)
+//   written[p]  records that have reached the staging area (producers: atomicAdd after the write)
+//   flushed[p]  lines already sent to the run = index of the open line (flushers: store after
+//               the line has been read)
+// A record may only be staged while its line is the open one; otherwise the lane keeps it
+// pending (<= 4 per lane) and retries on its next tile.  LDS executes one wave's instructions
+// in order, so "written counts it" implies "the record is there", and "flushed moved on"
+// implies "the old line has been read".
+constexpr int kProdWaves = 12;
+constexpr int kFlushWaves = kPartBlock / 64 - kProdWaves;
+constexpr int kSegPerFlusher = (kStageRecs / kSegRecs) / (kFlushWaves * 64);  // 4
+constexpr uint32_t kMaxSpins = 1u << 20;  // ~1 s of s_sleep: only a broken protocol gets there
+
+MQ_D uint32_t lds_peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+MQ_D void lds_poke(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+template <typename FT, typename VT>
+MQ_D void load_wave_tile(const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows,
+                         int n_cols, int fcol, int kcol, int vcol, int f, int64_t quad, Tile<FT, VT>& t) {
+  const int8_t* const* fc = cols + (size_t)f * n_cols;
+  const int64_t n = num_rows[f];
+  const int64_t r0 = quad << 2;
+  t.valid = 0;
+  if (r0 >= n) return;
+  const int8_t* fb = is_none<FT>::value ? nullptr : fc[fcol];
+  const int8_t* kb = fc[kcol];
+  const int8_t* vb = is_none<VT>::value ? nullptr : fc[vcol];
+  if (r0 + 4 <= n) {
+    load_quad<FT>(fb, quad, t.f);
+    load_quad<int64_t>(kb, quad, t.k);
+    load_quad<VT>(vb, quad, t.v);
+    t.valid = 4;
+  } else {
+    t.valid = (int)(n - r0);
+    for (int i = 0; i < 4; ++i) {
+      if (i < t.valid) {
+        quad_set(t.f, i, load_one<FT>(fb, r0 + i));
+        t.k.v[i] = load_one<int64_t>(kb, r0 + i);
+        quad_set(t.v, i, load_one<VT>(vb, r0 + i));
+      }
+    }
+  }
+}
+
 template <typename FT, typename VT>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows, int n_frags,
     int n_cols, RangeFilter flt, int kcol, int vcol, ScatterArgs g, Rec* __restrict__ scratch,
     uint32_t* __restrict__ cnt, SpillList sl) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  Rec* stage = (Rec*)smem_raw;                                 // [P][L] = kStageRecs records
-  // per partition {records appended, lines flushed}: one ds_read_b64 fetches both
-  uint2* state = (uint2*)(smem_raw + kStageRecs * sizeof(Rec));  // [P]
+  Rec* stage = (Rec*)smem_raw;                                      // [P][L] = kStageRecs records
+  uint32_t* cursor = (uint32_t*)(smem_raw + kStageRecs * sizeof(Rec));  // [P]
+  uint32_t* written = cursor + g.P;                                 // [P]
+  uint32_t* flushed = written + g.P;                                // [P]
+  uint32_t* done = flushed + g.P;                                   // producer waves finished
   const int t = threadIdx.x, b = blockIdx.x, G = gridDim.x;
+  const int wave = t >> 6, lane = t & 63;
   const int lgL = g.lgL;
   const uint32_t Lm1 = g.L - 1;
-  for (int i = t; i < g.P; i += kPartBlock) state[i] = make_uint2(0u, 0u);
-  // this lane's flush duty: segment t of the staging area = segment (t & (spl-1)) of the
-  // open line of partition t >> lgSpl  (P * L == kStageRecs: every lane owns one segment)
-  const int lgSpl = lgL - 3;  // log2(segments per line)
-  const int own_p = t >> lgSpl;
-  const uint32_t own_seg = (uint32_t)t & ((1u << lgSpl) - 1);
-  const uint32_t own_run = ((uint32_t)own_p * g.B + b) * g.cap;  // record index (< 2^32 by plan)
-
-  // carried records: stream position taken in the previous round, line not open then; by
-  // construction their line IS open in this round, so only the staging index is kept
-  int64_t c_key[4], c_val[4];
-  uint32_t c_sidx[4];
-  uint32_t c_mask = 0;
-
-  // flattened tile walk over the fragments: tile numbers are global, workgroup b owns the
-  // tiles == b (mod G)
-  int f = 0;
-  int64_t base = 0;          // global number of fragment f's first tile
-  int64_t nt_f = n_frags > 0 ? ((num_rows[0] + 3) / 4 + kPartBlock - 1) / kPartBlock : 0;
-  int64_t gt = b;
-  auto seek = [&]() {
-    while (f < n_frags && gt >= base + nt_f) {
-      base += nt_f;
-      ++f;
-      nt_f = f < n_frags ? ((num_rows[f] + 3) / 4 + kPartBlock - 1) / kPartBlock : 0;
-    }
-  };
-  seek();
-  Tile<FT, VT> cur;
-  cur.valid = 0;
-  bool have = f < n_frags;
-  if (have) load_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, gt - base, cur);
+  for (int i = t; i < 3 * g.P + 1; i += kPartBlock) cursor[i] = 0;
   __syncthreads();
 
-  while (have) {
-    // prefetch the next tile before touching LDS
-    gt += G;
-    seek();
-    const bool have_next = f < n_frags;
-    Tile<FT, VT> nxt;
-    nxt.valid = 0;
-    if (have_next) load_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, gt - base, nxt);
-
-    // (A) take stream positions for the surviving rows
-    uint32_t n_mask = 0;
-    uint32_t pid[4], slot[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i))) {
-        pid[i] = (g.dbg_mode & 1) ? ((uint32_t)cur.k.v[i] * 2654435761u) >> (32 - 10)
-                                  : part_of(g.hm, home_of(g.hm, cur.k.v[i]));
-        slot[i] = atomicAdd(&state[pid[i]].x, 1u);
-        n_mask |= 1u << i;
+  if (wave < kProdWaves) {
+    // ------------------------------------------------------------------ producers
+    constexpr int64_t kSuperQuads = (int64_t)kProdWaves * 64;  // quads per workgroup step
+    int64_t c_key[4], c_val[4];
+    uint32_t c_pid[4], c_slot[4];
+    uint32_t c_mask = 0;
+    // flattened walk over the fragments in super-tiles of 12 wave-tiles; workgroup b owns the
+    // super-tiles == b (mod G), wave w the w-th wave-tile of each
+    int f = 0;
+    int64_t base = 0;
+    int64_t nt_f = n_frags > 0 ? ((num_rows[0] + 3) / 4 + kSuperQuads - 1) / kSuperQuads : 0;
+    int64_t gt = b;
+    auto seek = [&]() {
+      while (f < n_frags && gt >= base + nt_f) {
+        base += nt_f;
+        ++f;
+        nt_f = f < n_frags ? ((num_rows[f] + 3) / 4 + kSuperQuads - 1) / kSuperQuads : 0;
       }
-    }
-    if (!(g.dbg_mode & 4)) lds_barrier();  // cursors of this round are final; last round's flush is complete
-
-    // (B) place.  Carried records first (their line is open now), then the new ones: open line
-    // -> LDS; last, still partial line -> carry; anything else (run full, or a whole line
-    // taken within this round) is rare and handled behind one wave-level branch.
-    const uint2 own = state[own_p];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (c_mask & (1u << i)) stage[c_sidx[i]] = Rec{c_key[i], c_val[i]};
-    }
-    c_mask = 0;
-    uint32_t rare = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (n_mask & (1u << i)) {
-        const uint2 st = state[pid[i]];
-        const uint32_t line = slot[i] >> lgL;
-        const uint32_t sidx = (pid[i] << lgL) + (slot[i] & Lm1);
-        const int64_t vb = val_bits_of<VT>(quad_get(cur.v, i));
-        if (slot[i] < g.cap && line == st.y) {
-          stage[sidx] = Rec{cur.k.v[i], vb};
-        } else if (slot[i] < g.cap && line == (st.x >> lgL)) {
-          c_key[i] = cur.k.v[i];
-          c_val[i] = vb;
-          c_sidx[i] = sidx;
-          c_mask |= 1u << i;
-        } else {
-          rare |= 1u << i;
-        }
-      }
-    }
-    if (__ballot(rare != 0)) {
+    };
+    auto quad_of = [&]() -> int64_t { return (gt - base) * kSuperQuads + wave * 64 + lane; };
+    // stage one record if its line is open; true = the record has left this lane
+    auto try_stage = [&](int64_t key, int64_t vb, uint32_t p, uint32_t s) -> bool {
+      if (lds_peek(&flushed[p]) != (s >> lgL)) return false;
+      asm volatile("" ::: "memory");  // compiler order only: the LDS itself runs a wave in order
+      stage[((size_t)p << lgL) + (s & Lm1)] = Rec{key, vb};
+      asm volatile("" ::: "memory");
+      atomicAdd(&written[p], 1u);
+      return true;
+    };
+    auto retry_pending = [&]() {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (rare & (1u << i)) {
-          const int64_t vb = val_bits_of<VT>(quad_get(cur.v, i));
-          if (slot[i] >= g.cap) spill_raw(sl, g, cur.k.v[i], vb);  // run full
-          else scratch[(size_t)(((uint32_t)pid[i] * g.B + b) * g.cap + slot[i])] = Rec{cur.k.v[i], vb};
+        if ((c_mask & (1u << i)) && try_stage(c_key[i], c_val[i], c_pid[i], c_slot[i])) c_mask &= ~(1u << i);
+      }
+    };
+    seek();
+    Tile<FT, VT> cur;
+    cur.valid = 0;
+    bool have = f < n_frags;
+    if (have) load_wave_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, quad_of(), cur);
+    while (have) {
+      gt += G;
+      seek();
+      const bool have_next = f < n_frags;
+      Tile<FT, VT> nxt;
+      nxt.valid = 0;
+      if (have_next) load_wave_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, quad_of(), nxt);
+
+      retry_pending();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        bool park = false;
+        uint32_t p = 0, s = 0;
+        int64_t vb = 0;
+        if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i))) {
+          p = (g.dbg_mode & 1) ? ((uint32_t)cur.k.v[i] * 2654435761u) >> (32 - 10)
+                               : part_of(g.hm, home_of(g.hm, cur.k.v[i]));
+          s = atomicAdd(&cursor[p], 1u);
+          vb = val_bits_of<VT>(quad_get(cur.v, i));
+          if (s >= g.cap) spill_raw(sl, g, cur.k.v[i], vb);  // run full
+          else park = !try_stage(cur.k.v[i], vb, p, s);
+        }
+        // Line not open yet: park the record in pending slot i.  If an older record still
+        // waits there, the WHOLE wave waits for the flushers and keeps retrying every
+        // pending record of every lane (never spin inside divergent code: the idle lanes of
+        // this wave may hold exactly the records another line is waiting for).
+        uint32_t spins = 0;
+        while (__any(park && (c_mask & (1u << i)))) {
+          retry_pending();
+          // the record in hand is retried too: its line may have opened meanwhile, and another
+          // wave may be waiting for exactly that line to fill
+          if (park && try_stage(cur.k.v[i], vb, p, s)) park = false;
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > kMaxSpins) {  // cannot happen unless the protocol is broken: bail out
+            atomicExch(sl.d_err + 1, 2);
+            c_mask = 0;
+            break;
+          }
+        }
+        if (park) {
+          c_key[i] = cur.k.v[i];
+          c_val[i] = vb;
+          c_pid[i] = p;
+          c_slot[i] = s;
+          c_mask |= 1u << i;
         }
       }
+      cur = nxt;
+      have = have_next;
     }
-    if (!(g.dbg_mode & 8)) lds_barrier();  // the open lines are complete
+    // drain this lane's pending records, then report the wave finished
+    for (uint32_t spins = 0; __any(c_mask != 0); ++spins) {
+      retry_pending();
+      __builtin_amdgcn_s_sleep(2);
+      if (spins > kMaxSpins) {
+        atomicExch(sl.d_err + 1, 3);
+        break;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) atomicAdd(done, 1u);
+    return;
+  }
 
-    // (F) flush every line whose last slot was taken this round; lines in between went
-    // straight to the run above
-    {
-      const uint32_t new_fl = own.x >> lgL;
-      const bool adv = new_fl > own.y;
-      const bool need = adv && (own.y << lgL) < g.cap;
-      flush_segments(need && !(g.dbg_mode & 2), own_run + (own.y << lgL) + own_seg * kSegRecs, stage, t & ~63, scratch);
-      if (adv && own_seg == 0) state[own_p].y = new_fl;
-    }
-    cur = nxt;
-    have = have_next;
-  }
-  lds_barrier();
-  // records still carried belong to the open (last, partial) line
+  // -------------------------------------------------------------------- flushers
+  // Flusher lane `fid` owns segments fid + 256 k (k = 0..3); in pass k a wave covers 64
+  // consecutive segments, so the segments of one line (<= 64) always share a pass and a wave.
+  const int fid = (wave - kProdWaves) * 64 + lane;
+  const int lgSpl = lgL - 3;
+  uint32_t my_fl[kSegPerFlusher];
+  for (int k = 0; k < kSegPerFlusher; ++k) my_fl[k] = 0;
+  uint32_t idle = 0;
+  for (;;) {
+    const bool all_done = lds_peek(done) == (uint32_t)kProdWaves;  // read BEFORE the scan
+    bool any_work = false;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (c_mask & (1u << i)) stage[c_sidx[i]] = Rec{c_key[i], c_val[i]};
+    for (int k = 0; k < kSegPerFlusher; ++k) {
+      const int seg = k * (kFlushWaves * 64) + fid;
+      const int p = seg >> lgSpl;
+      const uint32_t sidx = (uint32_t)seg & ((1u << lgSpl) - 1);
+      const uint32_t w = lds_peek(&written[p]);
+      const bool need = (w >> lgL) > my_fl[k] && (my_fl[k] << lgL) < g.cap;
+      asm volatile("" ::: "memory");
+      flush_segments(need, ((uint32_t)p * g.B + b) * g.cap + (my_fl[k] << lgL) + sidx * kSegRecs, stage,
+                     seg - lane, scratch);
+      asm volatile("" ::: "memory");
+      if (need) {
+        my_fl[k] += 1;
+        if (sidx == 0) lds_poke(&flushed[p], my_fl[k]);  // after this wave's reads of the line
+      }
+      any_work |= need;
+    }
+    if (!__any(any_work)) {
+      if (all_done) break;
+      __builtin_amdgcn_s_sleep(4);
+      if (++idle > kMaxSpins) {  // producers stuck: give up rather than hang the device
+        atomicExch(sl.d_err + 1, 4 + (int)lds_peek(done) * 16);
+        break;
+      }
+    } else {
+      idle = 0;
+    }
   }
-  lds_barrier();
-  // drain the partially filled lines (whole segments; the run length says what is valid)
-  {
-    const uint2 st = state[own_p];
-    const uint32_t rem = st.x - (st.y << lgL);  // < L
-    const bool need = own_seg * kSegRecs < rem && (st.y << lgL) + own_seg * kSegRecs < g.cap;
-    flush_segments(need, own_run + (st.y << lgL) + own_seg * kSegRecs, stage, t & ~63, scratch);
-    if (own_seg == 0) cnt[(size_t)own_p * g.B + b] = st.x < g.cap ? st.x : g.cap;
+  // every producer is done and every complete line is out: drain the partial open lines
+#pragma unroll
+  for (int k = 0; k < kSegPerFlusher; ++k) {
+    const int seg = k * (kFlushWaves * 64) + fid;
+    const int p = seg >> lgSpl;
+    const uint32_t sidx = (uint32_t)seg & ((1u << lgSpl) - 1);
+    const uint32_t w = lds_peek(&written[p]);
+    const uint32_t rem = w - (my_fl[k] << lgL);  // < L
+    const bool need = sidx * kSegRecs < rem && (my_fl[k] << lgL) + sidx * kSegRecs < g.cap;
+    flush_segments(need, ((uint32_t)p * g.B + b) * g.cap + (my_fl[k] << lgL) + sidx * kSegRecs, stage,
+                   seg - lane, scratch);
+    if (sidx == 0) {
+      const uint32_t c = lds_peek(&cursor[p]);
+      cnt[(size_t)p * g.B + b] = c < g.cap ? c : g.cap;
+    }
   }
 }
 
@@ -782,7 +872,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   const uint64_t groups = d / 2 > 0 ? d / 2 : 1;
   const uint64_t per_unit = (uint64_t)(0.8 * e_max);
   const uint64_t units = (groups + per_unit - 1) / per_unit;
-  uint32_t P = 8;
+  uint32_t P = 16;  // a line's segments (<= 64) must fit one flusher wave pass
   while (P < 1024 && P < units) P <<= 1;
   const uint32_t R = (uint32_t)((units + P - 1) / P);
   if (R > (uint32_t)kMaxSub) return false;
@@ -843,7 +933,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
   }
   h.chunk_rows = chunk_rows;
-  h.lds1 = kStageRecs * sizeof(Rec) + (size_t)P * 8;
+  h.lds1 = kStageRecs * sizeof(Rec) + (size_t)P * 12 + 16;  // staging lines + cursor / written / flushed + done
   h.lds2 = (size_t)h.g.E * entry_bytes + (size_t)((hm.S2 + 31) / 32) * 4 + (size_t)h.g.B * 4;
   return h.lds2 <= 160 * 1024;
 }
