@@ -73,11 +73,13 @@ struct HomeMap {
   uint32_t s1_rcp;   // floor(2^32 / S1)  (S1 >= 2)
 };
 
-MQ_D uint32_t home_of(const HomeMap& m, int64_t key) {
-  const uint32_t h = murmur3_u64((uint64_t)key);
+MQ_D uint32_t home_from_hash(const HomeMap& m, uint32_t h) {
   uint32_t r = h - __umulhi(h, m.d_rcp) * m.d;
   if (r >= m.d) r -= m.d;
   return r;
+}
+MQ_D uint32_t home_of(const HomeMap& m, int64_t key) {
+  return home_from_hash(m, murmur3_u64((uint64_t)key));
 }
 MQ_D uint32_t part_of(const HomeMap& m, uint32_t home) {
   const uint32_t q = __umulhi(home, m.s1_rcp);
@@ -541,22 +543,68 @@ MQ_D void apply_row(char* smem, const PartGeom& g, const PartSlots& ps, uint32_t
   }
 }
 
-// insert-or-find `key` starting at bucket b (linear probing over 4-key buckets): returns the
-// entry, or kNoEntry when the table is full.  A bucket with a free slot has never been full,
-// so a key that is not in it is not in the table: claim the first free slot.
-MQ_D uint32_t lds_locate(int64_t* lkeys, uint32_t n_buckets, uint32_t b, int64_t key) {
+// LDS table addressing: TWO candidate buckets per key (A from the home slot, B from other
+// hash bits), a new key goes to the less loaded one.  With 4-slot buckets at ~64 % fill a
+// single-choice table leaves 8 % of the groups outside their home bucket, and since a wave
+// walks the probe rounds of its slowest lane, EVERY 256-record step paid 4-5 dependent LDS
+// round trips; with two choices 99.9 % of the groups sit in A or B, which the hot loop reads
+// up front.  Two lanes that insert the same new key at the same moment may pick different
+// buckets; such twins are folded together before emission (fold_twins below).
+struct Bucket {
+  v2i64_t a, c;
+};
+MQ_D Bucket read_bucket(const int64_t* lkeys, uint32_t b) {
+  const int64_t* bk = lkeys + (size_t)b * 4;
+  Bucket r;
+  r.a = *(const v2i64_t*)bk;
+  r.c = *((const v2i64_t*)bk + 1);
+  return r;
+}
+MQ_D int find_in(const Bucket& k, int64_t key) {
+  return k.a.x == key ? 0 : k.a.y == key ? 1 : k.c.x == key ? 2 : k.c.y == key ? 3 : -1;
+}
+MQ_D int load_of(const Bucket& k) {
+  return (k.a.x != kEmptyKey64) + (k.a.y != kEmptyKey64) + (k.c.x != kEmptyKey64) + (k.c.y != kEmptyKey64);
+}
+MQ_D int first_empty(const Bucket& k) {
+  return k.a.x == kEmptyKey64 ? 0 : k.a.y == kEmptyKey64 ? 1 : k.c.x == kEmptyKey64 ? 2
+         : k.c.y == kEmptyKey64 ? 3 : -1;
+}
+MQ_D uint32_t bucket_b_of(uint32_t h, uint32_t n_buckets) {
+  return (uint32_t)(((uint64_t)(h * 2654435761u) * n_buckets) >> 32);
+}
+
+// insert-or-find: candidate buckets ba / bb, then (both full) linear probing from bb + 1.
+// Returns the entry or kNoEntry when the table is full.
+MQ_D uint32_t lds_locate(int64_t* lkeys, uint32_t n_buckets, uint32_t ba, uint32_t bb, int64_t key) {
+  for (;;) {
+    const Bucket A = read_bucket(lkeys, ba), B = read_bucket(lkeys, bb);
+    int j = find_in(A, key);
+    if (j >= 0) return ba * 4 + (uint32_t)j;
+    j = find_in(B, key);
+    if (j >= 0) return bb * 4 + (uint32_t)j;
+    const int la = load_of(A), lb = load_of(B);
+    if (la == 4 && lb == 4) break;
+    const bool use_a = la <= lb;
+    const uint32_t bt = use_a ? ba : bb;
+    const int fe = first_empty(use_a ? A : B);
+    const int64_t old = (int64_t)atomicCAS((unsigned long long*)(lkeys + (size_t)bt * 4 + fe),
+                                           (unsigned long long)kEmptyKey64, (unsigned long long)key);
+    if (old == kEmptyKey64 || old == key) return bt * 4 + (uint32_t)fe;
+    // another key took that slot: look again
+  }
+  // both candidates full (they stay full): first fit over the following buckets
+  uint32_t b = bb + 1 == n_buckets ? 0 : bb + 1;
   for (uint32_t trips = 0; trips < n_buckets;) {
-    int64_t* bk = lkeys + (size_t)b * 4;
-    const v2i64_t a = *(const v2i64_t*)bk, c = *((const v2i64_t*)bk + 1);
-    const int j = a.x == key ? 0 : a.y == key ? 1 : c.x == key ? 2 : c.y == key ? 3 : -1;
+    const Bucket K = read_bucket(lkeys, b);
+    const int j = find_in(K, key);
     if (j >= 0) return b * 4 + (uint32_t)j;
-    const int fe = a.x == kEmptyKey64 ? 0 : a.y == kEmptyKey64 ? 1 : c.x == kEmptyKey64 ? 2
-                   : c.y == kEmptyKey64 ? 3 : -1;
+    const int fe = first_empty(K);
     if (fe >= 0) {
-      const int64_t old = (int64_t)atomicCAS((unsigned long long*)(bk + fe), (unsigned long long)kEmptyKey64,
-                                             (unsigned long long)key);
+      const int64_t old = (int64_t)atomicCAS((unsigned long long*)(lkeys + (size_t)b * 4 + fe),
+                                             (unsigned long long)kEmptyKey64, (unsigned long long)key);
       if (old == kEmptyKey64 || old == key) return b * 4 + (uint32_t)fe;
-      continue;  // another key took that slot: look at this bucket again
+      continue;
     }
     b = b + 1 == n_buckets ? 0 : b + 1;
     ++trips;
@@ -601,7 +649,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
   // their slots straight away, misses fall back to the insert-or-find loop afterwards.
   auto insert4 = [&](const Rec& r0, const Rec& r1, const Rec& r2, const Rec& r3, uint32_t n_valid) {
     const Rec* rr[4] = {&r0, &r1, &r2, &r3};
-    uint32_t bk[4];
+    uint32_t ba[4], bb[4];
     uint32_t in_mask = 0;
     if (g.dbg_mode & 32) {  // timing experiment: memory only
       if (r0.key + r1.key + r2.key + r3.key == 0x1234567) atomicAdd(sl.count, 1u);
@@ -609,41 +657,42 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t x = home_of(g.hm, rr[j]->key) - lo;
+      const uint32_t h = murmur3_u64((uint64_t)rr[j]->key);
+      const uint32_t x = home_from_hash(g.hm, h) - lo;
       const bool in = (uint32_t)j < n_valid && x < n_slots;  // else: past the run's end / another sub-range
-      bk[j] = in ? bucket_of(x) : 0u;
+      ba[j] = in ? bucket_of(x) : 0u;
+      bb[j] = in ? bucket_b_of(h, n_buckets) : 0u;
       in_mask |= (in ? 1u : 0u) << j;
     }
-    if (g.dbg_mode & 16) {  // timing experiment: hash + range test only
-      if (in_mask == 0x77) atomicAdd(sl.count, 1u);
-      return;
-    }
-    v2i64_t ka[4], kc[4];
+    Bucket ka[4], kb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int64_t* bp = lkeys + (size_t)bk[j] * 4;
-      ka[j] = *(const v2i64_t*)bp;
-      kc[j] = *((const v2i64_t*)bp + 1);
+      ka[j] = read_bucket(lkeys, ba[j]);
+      kb[j] = read_bucket(lkeys, bb[j]);
     }
     uint32_t miss = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int64_t key = rr[j]->key;
-      const int hit = ka[j].x == key ? 0 : ka[j].y == key ? 1 : kc[j].x == key ? 2 : kc[j].y == key ? 3 : -1;
+      const int ha = find_in(ka[j], key), hb = find_in(kb[j], key);
       if (in_mask & (1u << j)) {
-        if (hit >= 0) apply_row<MASK>(smem_raw, g, ps, bk[j] * 4 + (uint32_t)hit, rr[j]->val);
-        else miss |= 1u << j;
+        if (ha >= 0 || hb >= 0) {
+          const uint32_t e = ha >= 0 ? ba[j] * 4 + (uint32_t)ha : bb[j] * 4 + (uint32_t)hb;
+          apply_row<MASK>(smem_raw, g, ps, e, rr[j]->val);
+        } else {
+          miss |= 1u << j;
+        }
       }
     }
-    // misses (first touch of a group, or a group displaced from a full bucket): ONE loop per
-    // lane over its missing records, so a wave pays the longest per-lane chain once
+    // misses (first touch of a group, or both candidate buckets full): one loop per lane
     while (miss) {
       const int j = __builtin_ctz(miss);
       miss &= miss - 1;
       const int64_t key = j == 0 ? r0.key : j == 1 ? r1.key : j == 2 ? r2.key : r3.key;
       const int64_t val = j == 0 ? r0.val : j == 1 ? r1.val : j == 2 ? r2.val : r3.val;
-      const uint32_t b0 = j == 0 ? bk[0] : j == 1 ? bk[1] : j == 2 ? bk[2] : bk[3];
-      const uint32_t e = lds_locate(lkeys, n_buckets, b0, key);
+      const uint32_t a0 = j == 0 ? ba[0] : j == 1 ? ba[1] : j == 2 ? ba[2] : ba[3];
+      const uint32_t b0 = j == 0 ? bb[0] : j == 1 ? bb[1] : j == 2 ? bb[2] : bb[3];
+      const uint32_t e = lds_locate(lkeys, n_buckets, a0, b0, key);
       if (e != kNoEntry) apply_row<MASK>(smem_raw, g, ps, e, val);
       else spill_record(sl, ps, ns, key, val);
     }
@@ -699,8 +748,11 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
                   (uint64_t)part[m] + chunk_records_max >= 0xffffffffull) big = true;
             }
           }
-          const uint32_t x = home_of(g.hm, key) - lo;
-          const uint32_t e = (x < n_slots && !big) ? lds_locate(lkeys, n_buckets, bucket_of(x), key) : kNoEntry;
+          const uint32_t h = murmur3_u64((uint64_t)key);
+          const uint32_t x = home_from_hash(g.hm, h) - lo;
+          const uint32_t e = (x < n_slots && !big)
+                                 ? lds_locate(lkeys, n_buckets, bucket_of(x), bucket_b_of(h, n_buckets), key)
+                                 : kNoEntry;
           if (e == kNoEntry) {  // probed in from another range / no room / huge count: merged last
             spill_append(sl, key, part, ns);
             continue;
@@ -728,6 +780,37 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     }
     __syncthreads();
     mark(2);
+    // fold twins: an entry that is not in its key's bucket A may have a twin earlier in the
+    // key's probe sequence (A, then B, then the buckets after B) — created when two lanes
+    // inserted the same new key at the same moment.  The later copy is added to the earlier
+    // one and cleared.
+    for (uint32_t e = t; e < g.E && n_slots; e += kPartBlock) {
+      const int64_t key = lkeys[e];
+      if (key == kEmptyKey64) continue;
+      const uint32_t h = murmur3_u64((uint64_t)key);
+      const uint32_t ba = bucket_of(home_from_hash(g.hm, h) - lo), bb = bucket_b_of(h, n_buckets);
+      const uint32_t be = e >> 2;
+      if (be == ba) continue;
+      uint32_t twin = kNoEntry;
+      int j = find_in(read_bucket(lkeys, ba), key);
+      if (j >= 0) {
+        twin = ba * 4 + (uint32_t)j;
+      } else if (be != bb) {
+        // overflow entry: B, then the buckets between B and its own
+        for (uint32_t b = bb; b != be; b = b + 1 == n_buckets ? 0 : b + 1) {
+          j = find_in(read_bucket(lkeys, b), key);
+          if (j >= 0) {
+            twin = b * 4 + (uint32_t)j;
+            break;
+          }
+        }
+      }
+      if (twin == kNoEntry) continue;
+      for (int m = 0; m < ns; ++m)
+        lds_merge(ps.int_op[m], smem_raw + g.slot_off[m], twin, lds_slot_value(ps.int_op[m], smem_raw + g.slot_off[m], e));
+      lkeys[e] = kEmptyKey64;
+    }
+    __syncthreads();
     // emit: claim the first free slot at or after the home slot (the reference's probing
     // rule, GroupByRuntime.cpp:25-48) in the LDS bitmap, then store the finished row
     for (uint32_t e = t; e < g.E && n_slots; e += kPartBlock) {
