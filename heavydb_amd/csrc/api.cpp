@@ -109,6 +109,7 @@ struct DeviceCtx {
   void* meta = nullptr;
   size_t meta_bytes = 0;
   std::vector<hipEvent_t> events;
+  hipStream_t stream = nullptr;  // library-owned launch stream (when the caller passes none)
 };
 DeviceCtx& ctx_of(int dev) {
   static DeviceCtx ctxs[64];
@@ -247,6 +248,8 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   if (!g.ok) return MI355Q_ERR_HIP;
   if (ctx.scratch) (void)hipFree(ctx.scratch);
   if (ctx.meta) (void)hipFree(ctx.meta);
+  if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
+  ctx.stream = nullptr;
   for (hipEvent_t e : ctx.events) (void)hipEventDestroy(e);
   ctx.scratch = ctx.meta = nullptr;
   ctx.scratch_bytes = 0;
@@ -493,20 +496,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   if (!g.ok) return MI355Q_ERR_HIP;
   const int n_cus = cu_count_of(in->device_id);
 
-  // stream: caller's, or a library-owned one for this call
-  hipStream_t s = (hipStream_t)o.stream;
-  bool own_stream = false;
-  if (!s) {
-    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-    own_stream = true;
-  }
-  struct StreamGuard {
-    hipStream_t s;
-    bool own;
-    ~StreamGuard() {
-      if (own) (void)hipStreamDestroy(s);
-    }
-  } sg{s, own_stream};
+  hipStream_t s = (hipStream_t)o.stream;  // caller's, or the device context's own (below)
 
   mi355q_result* res = nullptr;
   if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;
@@ -534,6 +524,10 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     ctx.meta_bytes = 0;
     HIP_TRY(hipMalloc(&ctx.meta, meta_bytes * 2));
     ctx.meta_bytes = meta_bytes * 2;
+  }
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
   }
   char* mp = (char*)ctx.meta;
   const int8_t* const* d_cols = (const int8_t* const*)mp;
@@ -606,7 +600,10 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
 
   tr.mark("scratch allocated");
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
-  HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+  // the partitioned member writes every row of the table itself (empty rows included)
+  const bool self_init = kind == K_BASELINE_FAST && nf > 0 &&
+                         baseline_fast_variant(d, fv, o.kernel_variant, n_cus) == 2;
+  if (!self_init) HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
 
   if (nf > 0) {
     switch (kind) {
