@@ -12,20 +12,21 @@
 // linear-probing image of get_group_value: every key sits at or after its home slot with no
 // empty slot in between.
 //
-//   phase 1  k_part_scatter    stream the columns (16 B/lane non-temporal loads, next tile
-//                              prefetched into registers), filter, hash, append the 16-byte
-//                              record {key, value bits} to this workgroup's private run of
-//                              partition p.  Records are write-combined in LDS: a partition
-//                              owns one line of L = 8192 / P records (128 B at P = 1024, the
-//                              smallest write MI355X's HBM absorbs at streaming efficiency —
-//                              tools/microbench/scatter.hip) and a full line leaves as one
-//                              coalesced store.  Two workgroup barriers per 4096-row tile.
-//   phase 2  k_part_aggregate  one workgroup per (partition, sub-range): LDS open-addressing
-//                              table {key, partial slots} fed with ds atomics; sub-ranges
+//   phase 1  k_part_scatter    12 producer waves per workgroup stream the columns (16 B/lane
+//                              non-temporal loads, next tile prefetched into registers), filter,
+//                              hash, and append the 16-byte record {key, value bits} to this
+//                              workgroup's private run of partition p through an LDS staging
+//                              line of L = 8192 / P records (128 B at P = 1024, the smallest
+//                              write MI355X's HBM absorbs at streaming efficiency —
+//                              tools/microbench/scatter.hip); 4 flusher waves send full lines
+//                              to the runs as coalesced stores.  Producers and flushers meet
+//                              only through three LDS words per partition: no barriers.
+//   phase 2  k_part_aggregate  one workgroup per (partition, sub-range): two-choice bucketized
+//                              LDS table {key, partial slots} fed with ds atomics; sub-ranges
 //                              (R > 1) re-read the partition's runs and keep their own home
 //                              range, so an LDS table only ever holds entry_count / (2 P R)
 //                              groups.  Emission claims canonical slots in an LDS bitmap and
-//                              stores rows + empty rows; a later chunk first re-loads the
+//                              stores rows + empty rows; a later chunk first re-loads its
 //                              range (merge).
 //   phase 3  k_spill_merge     the few groups that probe past the end of their range, and
 //                              every record that met a full run / full LDS table, are kept
