@@ -337,3 +337,74 @@ def test_shard_partition_and_merge_on_one_device(torch_cuda, oracle, world):
     full = oracle.init_buffer(q).reshape(q.entry_count, -1)
     full[:merged.shape[0]] = merged
     compare_buffers(q, want, full.reshape(-1), 1e-9)
+
+
+@pytest.mark.parametrize("variant", [1, 2], ids=["direct", "partitioned"])
+@pytest.mark.parametrize("edge", ["no_survivors", "ragged_tiny_fragments", "negative_and_extreme_keys",
+                                  "few_groups", "table_too_small"])
+def test_baseline_family_edge_cases(torch_cuda, oracle, variant, edge):
+    """Edge cases of the reference's tests for this path, through both members of the baseline
+    family: an empty result, fragments of a few rows, keys at the ends of the int64 range,
+    three groups, and a table that is too small (negative error code -> the caller doubles
+    the table and retries, RelAlgExecutor.cpp:4143-4231)."""
+    from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, InputColDescriptor, Qual,
+                                      RelAlgExecutionUnit, TargetExpr)
+    torch = torch_cuda
+    rng = np.random.default_rng(17)
+    n = 200_000
+    n_keys = 40_000
+    guess = 2 * n_keys
+    ids = rng.integers(0, n_keys, n)
+    key = (ids * 1000003 + 7).astype(np.int64)
+    fil = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+    k_lit = 2**30
+    sizes = [n // 2, n - n // 2]
+    if edge == "no_survivors":
+        k_lit = 0  # i32 < 0 never holds
+    elif edge == "ragged_tiny_fragments":
+        sizes = [4, 8, 12, n - 24 - 4 * 1000, 4 * 1000 - 4, 4]
+    elif edge == "negative_and_extreme_keys":
+        key = rng.integers(-2**63, 2**63 - 2, n_keys, dtype=np.int64)[ids]
+        key[:4] = [-2**63, 2**63 - 2, 0, -1]  # EMPTY_KEY_64 (2^63 - 1) itself is reserved
+    elif edge == "few_groups":
+        key = (rng.integers(0, 3, n) * 5 - 5).astype(np.int64)
+        guess = 200_000  # a big, almost empty table keeps the partitioned member eligible
+    elif edge == "table_too_small":
+        guess = n_keys // 2  # fewer entries than groups
+    val = (rng.random(n) * 1000.0).astype(np.float64)
+    kmin, kmax = int(key.min()), int(key.max())
+    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, kmin, kmax)),
+             InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0)),
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1),
+                                     TargetExpr(capi.MAX, 1)], [Qual(2, capi.LT, k_lit)], [0],
+                             max_groups_buffer_entry_guess=guess)
+    cols = [key, val, fil]
+    frags, o = [], 0
+    for s in sizes:
+        frags.append([c[o:o + s] for c in cols])
+        o += s
+    assert o == n
+    dev = [torch.from_numpy(c).cuda() for c in cols]
+    bufs, o = [], 0
+    for s in sizes:
+        bufs.append([int(t.data_ptr()) + o * t.element_size() for t in dev])
+        o += s
+    fr = FetchResult(bufs, sizes, keepalive=dev)
+    ex = Executor(0)
+    if edge == "table_too_small":
+        with pytest.raises(capi.Mi355qError) as ei:
+            ex.executeWorkUnit(ra, fr, kernel_variant=variant, allow_retry=False)
+        assert ei.value.code < 0 or ei.value.code == capi.ERR_OUT_OF_SLOTS
+        rs = ex.executeWorkUnit(ra, fr, kernel_variant=variant)  # retry ladder doubles the table
+        assert ra.max_groups_buffer_entry_guess >= n_keys
+    else:
+        rs = ex.executeWorkUnit(ra, fr, kernel_variant=variant, allow_retry=False)
+    assert rs.report.variant == variant  # the forced family member really ran
+    q, want, code = oracle.execute(ra.to_plan(), frags, n_threads=2)
+    assert code == 0
+    compare_buffers(q, want, rs.getStorage(), 1e-9)
+    check_probe_invariant(q, rs.getStorage())
+    compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
+    if edge == "no_survivors":
+        assert rs.rowCount() == 0
