@@ -32,6 +32,8 @@ struct mi355q_join_table {
   int64_t min_key = 0, max_key = 0;
   void* buf = nullptr;
   int64_t bytes = 0;
+  void* bitmap = nullptr;  // perfect tables: presence bitmap (1 bit per slot), for probes that
+                           // only need to know WHETHER a key matches (no inner column read)
   float build_ms = 0.f;
 };
 
@@ -147,6 +149,7 @@ int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
   d->join_nullable = jc.nullable != 0;
   d->join_hash_type = jt->hash_type;
   d->join_buf = jt->buf;
+  d->join_bitmap = (const uint32_t*)jt->bitmap;
   d->join_min = jt->min_key;
   d->join_max = jt->max_key;
   d->join_entries = jt->entry_count;
@@ -731,6 +734,15 @@ int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream, mi355q_joi
     HIP_TRY(launch_join_fill_perfect((const int8_t*)spec->key_buffer, spec->key_type,
                                      spec->key_nullable, spec->num_rows, r.min, r.max,
                                      (int32_t*)jt->buf, (int32_t*)err.p, s));
+    {
+      const size_t bm_bytes = (size_t)((jt->entry_count + 31) / 32) * 4;
+      hipError_t be = hipMalloc(&jt->bitmap, bm_bytes);
+      if (be != hipSuccess) {
+        last_hip_error = be;
+        return MI355Q_ERR_OUT_OF_GPU_MEM;
+      }
+      HIP_TRY(launch_join_presence_bitmap((const int32_t*)jt->buf, jt->entry_count, (uint32_t*)jt->bitmap, s));
+    }
   } else {
     jt->hash_type = 1;
     jt->entry_count = 2 * std::max<int64_t>(spec->num_rows, 1);  // BaselineJoinHashTable.cpp:484
@@ -759,9 +771,10 @@ int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream, mi355q_joi
 
 void mi355q_join_free(mi355q_join_table* t) {
   if (!t) return;
-  if (t->buf) {
+  if (t->buf || t->bitmap) {
     DeviceGuard g(t->device_id);
-    (void)hipFree(t->buf);
+    if (t->buf) (void)hipFree(t->buf);
+    if (t->bitmap) (void)hipFree(t->bitmap);
   }
   delete t;
 }

@@ -144,6 +144,7 @@ struct DevPlan {
   // join
   int32_t join_col, join_type, join_nullable, join_hash_type;
   const void* join_buf;
+  const uint32_t* join_bitmap;  // perfect tables: 1 bit per slot = "slot holds a row id" (or null)
   int64_t join_min, join_max, join_entries;
   const int8_t* inner_cols[MI355Q_MAX_COLS];
 };

@@ -48,6 +48,9 @@ hipError_t launch_shard_partition(const DevPlan& p, int idx_target_as_key, const
 hipError_t launch_join_fill_perfect(const int8_t* keys, int type, int nullable, int64_t n,
                                     int64_t min_key, int64_t max_key, int32_t* buf,
                                     int32_t* d_err, hipStream_t s);
+// bit i = (table[i] >= 0): the semi-join view of a perfect table, 32x smaller than the table
+hipError_t launch_join_presence_bitmap(const int32_t* table, int64_t entries, uint32_t* bitmap,
+                                       hipStream_t s);
 hipError_t launch_join_init_baseline(int64_t* tab, int64_t entries, hipStream_t s);
 hipError_t launch_join_fill_baseline(const int8_t* keys, int type, int nullable, int64_t n,
                                      int64_t* tab, int64_t entries, int32_t* d_err,

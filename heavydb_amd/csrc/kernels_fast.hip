@@ -190,6 +190,7 @@ struct JoinSumArgs {
   const void* table;
   int64_t min_key, max_key, entries;
   const int64_t* inner_w;    // inner int64 payload column (or null)
+  const uint32_t* bitmap;    // perfect table's presence bitmap when no slot reads the inner table
   int64_t null_sum;          // NULL_BIGINT: the non-grouped SUM starts NULL
 };
 
@@ -203,7 +204,12 @@ __global__ __launch_bounds__(kBlock) void k_join_sum(const int8_t* const* __rest
   scan_fragments<none_t, int64_t, VT>(cols, num_rows, n_frags, n_cols, 0, a.kcol, a.vcol,
                                       [&](none_t, int64_t key, VT val) {
     int64_t idx;
-    if (a.hash_type == 0) {
+    if (a.bitmap) {
+      // semi-join: only WHETHER the key matches is needed, so probe the 1-bit-per-slot view of
+      // the perfect table (32x smaller: 12.5 MB for 100 M dim rows, L2 / Infinity-Cache resident)
+      const uint64_t off = (uint64_t)key - (uint64_t)a.min_key;
+      idx = (key >= a.min_key && key <= a.max_key && ((a.bitmap[off >> 5] >> (off & 31)) & 1u)) ? 0 : -1;
+    } else if (a.hash_type == 0) {
       idx = (key >= a.min_key && key <= a.max_key) ? ((const int32_t*)a.table)[key - a.min_key] : -1;
     } else {
       const int64_t* tab = (const int64_t*)a.table;
@@ -480,6 +486,7 @@ static bool join_sum_shape(const DevPlan& p, const FragView& fv, JoinSumArgs* a)
   if (!all_aligned16(fv, p.join_col)) return false;
   if (a->vcol >= 0 && !all_aligned16(fv, a->vcol)) return false;
   a->hash_type = p.join_hash_type;
+  a->bitmap = (p.join_hash_type == 0 && !a->inner_w) ? p.join_bitmap : nullptr;
   a->table = p.join_buf;
   a->min_key = p.join_min;
   a->max_key = p.join_max;

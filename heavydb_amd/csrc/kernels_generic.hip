@@ -379,6 +379,30 @@ hipError_t launch_shard_partition(const DevPlan& p, int idx_target_as_key, const
   return hipGetLastError();
 }
 
+__global__ __launch_bounds__(kBlock) void k_join_presence_bitmap(const int32_t* __restrict__ table,
+                                                                  int64_t entries,
+                                                                  uint32_t* __restrict__ bitmap) {
+  // one lane per slot, one 64-bit ballot per wave = two bitmap words
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  const int64_t padded = (entries + 63) & ~(int64_t)63;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < padded; i += stride) {
+    const bool live = i < entries && table[i] >= 0;
+    const unsigned long long m = __ballot(live);
+    if ((threadIdx.x & 63) == 0) {
+      bitmap[i >> 5] = (uint32_t)m;
+      if (i + 32 < entries) bitmap[(i >> 5) + 1] = (uint32_t)(m >> 32);
+    }
+  }
+}
+
+hipError_t launch_join_presence_bitmap(const int32_t* table, int64_t entries, uint32_t* bitmap,
+                                       hipStream_t s) {
+  if (entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_join_presence_bitmap, dim3(grid_for(entries)), dim3(kBlock), 0, s, table, entries,
+                     bitmap);
+  return hipGetLastError();
+}
+
 hipError_t launch_join_fill_perfect(const int8_t* keys, int type, int nullable, int64_t n,
                                     int64_t min_key, int64_t max_key, int32_t* buf,
                                     int32_t* d_err, hipStream_t s) {
