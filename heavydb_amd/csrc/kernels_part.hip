@@ -554,11 +554,19 @@ MQ_D void apply_row(char* smem, const PartGeom& g, const PartSlots& ps, uint32_t
 struct Bucket {
   v2i64_t a, c;
 };
-MQ_D Bucket read_bucket(const int64_t* lkeys, uint32_t b) {
-  const int64_t* bk = lkeys + (size_t)b * 4;
+// Keys live in two half-bucket arrays — slots {0,1} of every bucket, then slots {2,3} — so a
+// 16-byte half-bucket read can start on any of the 16 bank groups of the LDS (a 32-byte
+// bucket stride would only ever use 8 of them and double the conflicts of random probes).
+MQ_D int64_t* key_slot(int64_t* lkeys, uint32_t n_buckets, uint32_t b, int j) {
+  return lkeys + (j < 2 ? (size_t)b * 2 + j : (size_t)n_buckets * 2 + (size_t)b * 2 + (j - 2));
+}
+MQ_D int64_t* key_of_entry(int64_t* lkeys, uint32_t n_buckets, uint32_t e) {
+  return key_slot(lkeys, n_buckets, e >> 2, (int)(e & 3));
+}
+MQ_D Bucket read_bucket(const int64_t* lkeys, uint32_t n_buckets, uint32_t b) {
   Bucket r;
-  r.a = *(const v2i64_t*)bk;
-  r.c = *((const v2i64_t*)bk + 1);
+  r.a = *((const v2i64_t*)lkeys + b);
+  r.c = *((const v2i64_t*)lkeys + n_buckets + b);
   return r;
 }
 MQ_D int find_in(const Bucket& k, int64_t key) {
@@ -579,7 +587,7 @@ MQ_D uint32_t bucket_b_of(uint32_t h, uint32_t n_buckets) {
 // Returns the entry or kNoEntry when the table is full.
 MQ_D uint32_t lds_locate(int64_t* lkeys, uint32_t n_buckets, uint32_t ba, uint32_t bb, int64_t key) {
   for (;;) {
-    const Bucket A = read_bucket(lkeys, ba), B = read_bucket(lkeys, bb);
+    const Bucket A = read_bucket(lkeys, n_buckets, ba), B = read_bucket(lkeys, n_buckets, bb);
     int j = find_in(A, key);
     if (j >= 0) return ba * 4 + (uint32_t)j;
     j = find_in(B, key);
@@ -589,7 +597,7 @@ MQ_D uint32_t lds_locate(int64_t* lkeys, uint32_t n_buckets, uint32_t ba, uint32
     const bool use_a = la <= lb;
     const uint32_t bt = use_a ? ba : bb;
     const int fe = first_empty(use_a ? A : B);
-    const int64_t old = (int64_t)atomicCAS((unsigned long long*)(lkeys + (size_t)bt * 4 + fe),
+    const int64_t old = (int64_t)atomicCAS((unsigned long long*)key_slot(lkeys, n_buckets, bt, fe),
                                            (unsigned long long)kEmptyKey64, (unsigned long long)key);
     if (old == kEmptyKey64 || old == key) return bt * 4 + (uint32_t)fe;
     // another key took that slot: look again
@@ -597,12 +605,12 @@ MQ_D uint32_t lds_locate(int64_t* lkeys, uint32_t n_buckets, uint32_t ba, uint32
   // both candidates full (they stay full): first fit over the following buckets
   uint32_t b = bb + 1 == n_buckets ? 0 : bb + 1;
   for (uint32_t trips = 0; trips < n_buckets;) {
-    const Bucket K = read_bucket(lkeys, b);
+    const Bucket K = read_bucket(lkeys, n_buckets, b);
     const int j = find_in(K, key);
     if (j >= 0) return b * 4 + (uint32_t)j;
     const int fe = first_empty(K);
     if (fe >= 0) {
-      const int64_t old = (int64_t)atomicCAS((unsigned long long*)(lkeys + (size_t)b * 4 + fe),
+      const int64_t old = (int64_t)atomicCAS((unsigned long long*)key_slot(lkeys, n_buckets, b, fe),
                                              (unsigned long long)kEmptyKey64, (unsigned long long)key);
       if (old == kEmptyKey64 || old == key) return b * 4 + (uint32_t)fe;
       continue;
@@ -668,8 +676,8 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     Bucket ka[4], kb[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      ka[j] = read_bucket(lkeys, ba[j]);
-      kb[j] = read_bucket(lkeys, bb[j]);
+      ka[j] = read_bucket(lkeys, n_buckets, ba[j]);
+      kb[j] = read_bucket(lkeys, n_buckets, bb[j]);
     }
     uint32_t miss = 0;
 #pragma unroll
@@ -721,7 +729,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       n_slots = (uint32_t)(z - a);
     }
     for (uint32_t e = t; e < g.E; e += kPartBlock) {
-      lkeys[e] = kEmptyKey64;
+      lkeys[e] = kEmptyKey64;  // (initialisation: the key layout does not matter here)
       for (int m = 0; m < ns; ++m) {
         if (ps.int_op[m] == SO_COUNT) ((uint32_t*)(smem_raw + g.slot_off[m]))[e] = 0;
         else ((int64_t*)(smem_raw + g.slot_off[m]))[e] = ps.int_init[m];
@@ -786,20 +794,20 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     // inserted the same new key at the same moment.  The later copy is added to the earlier
     // one and cleared.
     for (uint32_t e = t; e < g.E && n_slots; e += kPartBlock) {
-      const int64_t key = lkeys[e];
+      const int64_t key = *key_of_entry(lkeys, n_buckets, e);
       if (key == kEmptyKey64) continue;
       const uint32_t h = murmur3_u64((uint64_t)key);
       const uint32_t ba = bucket_of(home_from_hash(g.hm, h) - lo), bb = bucket_b_of(h, n_buckets);
       const uint32_t be = e >> 2;
       if (be == ba) continue;
       uint32_t twin = kNoEntry;
-      int j = find_in(read_bucket(lkeys, ba), key);
+      int j = find_in(read_bucket(lkeys, n_buckets, ba), key);
       if (j >= 0) {
         twin = ba * 4 + (uint32_t)j;
       } else if (be != bb) {
         // overflow entry: B, then the buckets between B and its own
         for (uint32_t b = bb; b != be; b = b + 1 == n_buckets ? 0 : b + 1) {
-          j = find_in(read_bucket(lkeys, b), key);
+          j = find_in(read_bucket(lkeys, n_buckets, b), key);
           if (j >= 0) {
             twin = b * 4 + (uint32_t)j;
             break;
@@ -809,13 +817,13 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       if (twin == kNoEntry) continue;
       for (int m = 0; m < ns; ++m)
         lds_merge(ps.int_op[m], smem_raw + g.slot_off[m], twin, lds_slot_value(ps.int_op[m], smem_raw + g.slot_off[m], e));
-      lkeys[e] = kEmptyKey64;
+      *key_of_entry(lkeys, n_buckets, e) = kEmptyKey64;
     }
     __syncthreads();
     // emit: claim the first free slot at or after the home slot (the reference's probing
     // rule, GroupByRuntime.cpp:25-48) in the LDS bitmap, then store the finished row
     for (uint32_t e = t; e < g.E && n_slots; e += kPartBlock) {
-      const int64_t key = lkeys[e];
+      const int64_t key = *key_of_entry(lkeys, n_buckets, e);
       if (key == kEmptyKey64) continue;
       uint32_t s = home_of(g.hm, key) - lo;
       bool placed = false;
