@@ -191,15 +191,15 @@ class HipShard:
 
     def partition_rows(self, n_parts: int):
         torch = self._torch
-        n_live = self._lib.mi355q_result_row_count(self.handle)
         rq = self._qmd.row_size // 8
-        rows = torch.empty((max(n_live, 1), rq), dtype=torch.int64, device=self._buf.device)
+        # worst case every entry is live; the run lengths (read back anyway for the exchange)
+        # say how many rows were written — no separate row-count pass
+        rows = torch.empty((max(self._qmd.entry_count, 1), rq), dtype=torch.int64, device=self._buf.device)
         counts = torch.zeros(n_parts, dtype=torch.int64, device=self._buf.device)
         check(self._lib.mi355q_shard_partition(self.handle, n_parts, int(rows.data_ptr()),
                                                int(counts.data_ptr()), None), "shard_partition")
         c = [int(x) for x in counts.cpu().tolist()]
-        assert sum(c) == n_live
-        return rows[:n_live], c
+        return rows[:sum(c)], c
 
     def fresh_like(self) -> "HipShard":
         return HipShard(self._torch, self._qmd, self.device_id)
