@@ -627,7 +627,8 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         st.kernel_name = "k_generic";
         st.n_launches = 1;
         if (st.k_start) HIP_TRY(hipEventRecord(st.k_start, s));
-        HIP_TRY(launch_generic(d, d_cols, d_rows, nf, max_frag_rows, res->buf, d_err, n_cus, s));
+        HIP_TRY(launch_generic(d, q.idx_target_as_key, make_row_init(q), d_cols, d_rows, nf, max_frag_rows,
+                               res->buf, d_err, n_cus, s));
         if (st.k_stop) HIP_TRY(hipEventRecord(st.k_stop, s));
     }
   }

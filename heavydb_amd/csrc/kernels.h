@@ -34,9 +34,12 @@ void set_debug_knobs(int blocks_per_cu, int part_p);
 // ---- generic family (kernels_generic.hip)
 hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,
                               hipStream_t s);
-hipError_t launch_generic(const DevPlan& p, const int8_t* const* d_cols,
-                          const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows,
-                          int64_t* out, int32_t* d_err, int n_cus, hipStream_t s);
+// perfect-hash tables that fit LDS are aggregated in a per-workgroup LDS copy and folded into
+// `out` with the reduce rule; everything else updates `out` directly
+hipError_t launch_generic(const DevPlan& p, int idx_target_as_key, const RowInit& init,
+                          const int8_t* const* d_cols, const int64_t* d_num_rows, int n_frags,
+                          int64_t max_frag_rows, int64_t* out, int32_t* d_err, int n_cus,
+                          hipStream_t s);
 hipError_t launch_reduce(const DevPlan& p, int idx_target_as_key, int64_t* this_buf,
                          const int64_t* that_rows, int64_t that_entries, int32_t* d_err,
                          hipStream_t s);

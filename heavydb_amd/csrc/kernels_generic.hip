@@ -80,6 +80,48 @@ __global__ __launch_bounds__(kBlock) void k_generic(DevPlan p, const int8_t* con
   }
 }
 
+// Generic row kernel for perfect-hash tables that fit LDS: every workgroup aggregates into a
+// private LDS copy of the table (same row function, same atomics — they act on LDS instead of
+// on one contended set of global rows), then folds its copy into the output with the
+// ResultSetStorage::reduce rule per target (index aligned).  With 1 K groups the plain generic
+// kernel serialises a billion rows on 1 K global addresses; this one touches them once per
+// workgroup.
+__global__ __launch_bounds__(kBlock) void k_generic_lds(DevPlan p, int idx_target_as_key, RowInit init,
+                                                         const int8_t* const* __restrict__ cols,
+                                                         const int64_t* __restrict__ num_rows, int n_frags,
+                                                         int64_t* __restrict__ out,
+                                                         int32_t* __restrict__ d_err) {
+  extern __shared__ __attribute__((aligned(16))) int64_t s_tab[];
+  const int64_t quads = p.entry_count * p.row_quad;
+  for (int64_t i = threadIdx.x; i < quads; i += kBlock) s_tab[i] = init.quad[i % init.row_quad];
+  __syncthreads();
+  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kBlock;
+  int32_t err = 0;
+  for (int f = 0; f < n_frags && !err; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * p.n_cols;
+    const int64_t n = num_rows[f];
+    for (int64_t pos = gtid; pos < n; pos += gsize) {
+      const int32_t e = process_row<true>(p, fc, pos, s_tab, nullptr);
+      if (e) {
+        err = e;
+        break;
+      }
+    }
+  }
+  if (err) atomicCAS(d_err, 0, err);
+  __syncthreads();
+  for (int64_t e = threadIdx.x; e < p.entry_count; e += kBlock) {
+    const int64_t* src = s_tab + e * p.row_quad;
+    if (is_empty_row(p, src, idx_target_as_key)) continue;
+    int64_t* row = out + e * p.row_quad;
+    if (p.key_quad) MQ_STORE64(row, src[0]);
+    for (int i = 0; i < p.n_targets; ++i) {
+      reduce_target<true>(p.targets[i], p.init_vals, row + p.key_quad, src + p.key_quad);
+    }
+  }
+}
+
 // this (op)= that, entry-wise.  `that` holds that_entries rows of the same layout; baseline
 // rows are re-hashed into `this` (get_group_value_reduction, ResultSetReduction.cpp:783-826),
 // perfect/non-grouped rows are index aligned.
@@ -337,9 +379,20 @@ hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& 
   return hipGetLastError();
 }
 
-hipError_t launch_generic(const DevPlan& p, const int8_t* const* d_cols,
-                          const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows,
-                          int64_t* out, int32_t* d_err, int n_cus, hipStream_t s) {
+hipError_t launch_generic(const DevPlan& p, int idx_target_as_key, const RowInit& init,
+                          const int8_t* const* d_cols, const int64_t* d_num_rows, int n_frags,
+                          int64_t max_frag_rows, int64_t* out, int32_t* d_err, int n_cus,
+                          hipStream_t s) {
+  const int64_t tab_bytes = p.entry_count * p.row_quad * 8;
+  if (p.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && tab_bytes > 0 && tab_bytes <= 64 * 1024) {
+    // two workgroups per CU keep their private tables in LDS
+    const int grid = grid_for(max_frag_rows, n_cus * 2);
+    (void)hipFuncSetAttribute((const void*)k_generic_lds, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)tab_bytes);
+    hipLaunchKernelGGL(k_generic_lds, dim3(grid), dim3(kBlock), (size_t)tab_bytes, s, p, idx_target_as_key,
+                       init, d_cols, d_num_rows, n_frags, out, d_err);
+    return hipGetLastError();
+  }
   const int grid = grid_for(max_frag_rows, n_cus * 8);
   hipLaunchKernelGGL(k_generic, dim3(grid), dim3(kBlock), 0, s, p, d_cols, d_num_rows, n_frags,
                      out, d_err);
