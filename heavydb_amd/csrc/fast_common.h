@@ -155,17 +155,45 @@ MQ_D long long wave_sum_i64(long long v) {
 
 // Slot programme shared by the LDS and baseline families: which op each 8-byte slot takes.
 enum SlotOp : int32_t { SO_COUNT = 0, SO_SUM_I = 1, SO_SUM_F = 2, SO_MIN_I = 3, SO_MAX_I = 4,
-                        SO_MIN_F = 5, SO_MAX_F = 6, SO_KEY = 7 };
+                        SO_MIN_F = 5, SO_MAX_F = 6, SO_KEY = 7,
+                        SO_COUNT_NN = 8 };  // rows whose value is not NULL (COUNT(col), AVG's count)
 struct SlotProg {
   int32_t n;                         // slots
   int32_t op[MI355Q_MAX_SLOTS];
+  // nullable value column (the reference's *_skip_val aggregates, RuntimeFunctions.cpp:1313-1431,
+  // :1558-1584): NULL inputs are skipped by every value op; slots flagged null_init start at
+  // the NULL sentinel, the first non-NULL value overwrites it (SUM / MIN / MAX; AVG's sum
+  // starts at 0, OutputBufferInitialization.cpp:132-289)
+  int32_t val_nullable;
+  int32_t null_init[MI355Q_MAX_SLOTS];
+  int64_t null_bits;                 // bit pattern of the value column's NULL
 };
 
-MQ_D void apply_slots_global(const SlotProg& sp, int64_t* slots, double fval, int64_t ival) {
+// one row's update of a group's slots in the output table.  fval / ival: the value as double /
+// int64; vbits: its bit pattern (NULL test)
+MQ_D void apply_slots_global(const SlotProg& sp, int64_t* slots, double fval, int64_t ival, int64_t vbits) {
+  const bool is_null = sp.val_nullable && vbits == sp.null_bits;
   for (int j = 0; j < sp.n; ++j) {
     int64_t* s = slots + j;
+    if (sp.op[j] == SO_COUNT) {
+      atomicAdd((unsigned long long*)s, 1ull);
+      continue;
+    }
+    if (is_null) continue;  // every other op reads the value
+    if (sp.null_init[j]) {
+      switch (sp.op[j]) {
+        case SO_SUM_I: a_sum_i64_skip<true>(s, ival, sp.null_bits); break;
+        case SO_SUM_F: a_sum_f64_skip<true>(s, fval, bits_dbl(sp.null_bits)); break;
+        case SO_MIN_I: a_min_i64_skip<true>(s, ival, sp.null_bits); break;
+        case SO_MAX_I: a_max_i64_skip<true>(s, ival, sp.null_bits); break;
+        case SO_MIN_F: a_minmax_f64<true, false, true>(s, fval, bits_dbl(sp.null_bits)); break;
+        case SO_MAX_F: a_minmax_f64<true, true, true>(s, fval, bits_dbl(sp.null_bits)); break;
+        default: break;
+      }
+      continue;
+    }
     switch (sp.op[j]) {
-      case SO_COUNT: atomicAdd((unsigned long long*)s, 1ull); break;
+      case SO_COUNT_NN: atomicAdd((unsigned long long*)s, 1ull); break;
       case SO_SUM_I: atomicAdd((unsigned long long*)s, (unsigned long long)ival); break;
       case SO_SUM_F: atomicAdd((double*)s, fval); break;
       case SO_MIN_I: atomicMin((long long*)s, (long long)ival); break;
@@ -177,6 +205,12 @@ MQ_D void apply_slots_global(const SlotProg& sp, int64_t* slots, double fval, in
   }
 }
 
+template <typename VT>
+MQ_D int64_t as_bits(VT v) { return (int64_t)v; }
+template <>
+MQ_D int64_t as_bits<double>(double v) { return dbl_bits(v); }
+template <>
+MQ_D int64_t as_bits<none_t>(none_t) { return 0; }
 template <typename VT>
 MQ_D double as_f64(VT v) { return (double)v; }
 template <>
@@ -238,7 +272,10 @@ struct FastShape {
 };
 
 inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* s) {
-  if (p.join_col >= 0 || p.n_quals > 1 || p.group_nullable) return false;
+  if (p.join_col >= 0 || p.n_quals > 1) return false;
+  // a NULL group key: the baseline layout keeps the sentinel as an ordinary key; the perfect
+  // layout translates it (max + 1) and is left to the generic family
+  if (p.group_nullable && p.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return false;
   s->flt = no_filter();
   if (p.n_quals == 1) {
     if (!make_range_filter(p.quals[0], &s->flt)) return false;
@@ -246,7 +283,12 @@ inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* 
     if (!all_aligned16(fv, p.quals[0].col)) return false;
   }
   s->sp.n = p.slot_count;
-  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) s->sp.op[i] = SO_COUNT;
+  s->sp.val_nullable = 0;
+  s->sp.null_bits = 0;
+  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) {
+    s->sp.op[i] = SO_COUNT;
+    s->sp.null_init[i] = 0;
+  }
   for (int i = 0; i < p.n_targets; ++i) {
     const DevTarget& t = p.targets[i];
     if (t.table != 0) return false;
@@ -254,26 +296,47 @@ inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* 
       if (t.slot >= 0) s->sp.op[t.slot] = SO_KEY;
       continue;
     }
-    if (t.agg == MI355Q_COUNT) {
-      if (t.skip_null) return false;  // COUNT(nullable col): generic path
-      s->sp.op[t.slot] = SO_COUNT;
+    if (t.agg == MI355Q_COUNT && (t.col < 0 || !t.skip_null)) {
+      s->sp.op[t.slot] = SO_COUNT;  // COUNT(*) / COUNT(NOT NULL col)
       continue;
     }
-    if (t.skip_null || t.col < 0) return false;
+    if (t.col < 0) return false;
+    // every value aggregate (and COUNT(nullable col)) reads ONE int64 / double column
     if (t.arg_type != MI355Q_INT64 && t.arg_type != MI355Q_DOUBLE) return false;
     if (s->vcol >= 0 && s->vcol != t.col) return false;
     s->vcol = t.col;
     s->vtype = t.arg_type;
+    if (t.skip_null) {
+      s->sp.val_nullable = 1;
+      s->sp.null_bits = t.arg_type == MI355Q_DOUBLE ? kNullDoubleBits : INT64_MIN;
+    }
     const bool fp = t.arg_fp;
     switch (t.agg) {
-      case MI355Q_SUM: s->sp.op[t.slot] = fp ? SO_SUM_F : SO_SUM_I; break;
+      case MI355Q_COUNT: s->sp.op[t.slot] = SO_COUNT_NN; break;
+      case MI355Q_SUM:
+        s->sp.op[t.slot] = fp ? SO_SUM_F : SO_SUM_I;
+        s->sp.null_init[t.slot] = t.skip_null;
+        break;
       case MI355Q_AVG:
         s->sp.op[t.slot] = fp ? SO_SUM_F : SO_SUM_I;
-        s->sp.op[t.slot + 1] = SO_COUNT;
+        s->sp.op[t.slot + 1] = t.skip_null ? SO_COUNT_NN : SO_COUNT;
         break;
-      case MI355Q_MIN: s->sp.op[t.slot] = fp ? SO_MIN_F : SO_MIN_I; break;
-      case MI355Q_MAX: s->sp.op[t.slot] = fp ? SO_MAX_F : SO_MAX_I; break;
+      case MI355Q_MIN:
+        s->sp.op[t.slot] = fp ? SO_MIN_F : SO_MIN_I;
+        s->sp.null_init[t.slot] = t.skip_null;
+        break;
+      case MI355Q_MAX:
+        s->sp.op[t.slot] = fp ? SO_MAX_F : SO_MAX_I;
+        s->sp.null_init[t.slot] = t.skip_null;
+        break;
       default: return false;
+    }
+  }
+  // one column cannot be nullable for one target and NOT NULL for another
+  if (s->sp.val_nullable) {
+    for (int i = 0; i < p.n_targets; ++i) {
+      const DevTarget& t = p.targets[i];
+      if (t.table == 0 && t.col == s->vcol && t.agg != MI355Q_PROJECT_KEY && !t.skip_null) return false;
     }
   }
   if (s->vcol >= 0 && !all_aligned16(fv, s->vcol)) return false;

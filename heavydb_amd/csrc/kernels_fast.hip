@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_baseline_direct(const int8_t* const*
       full = true;
       return;
     }
-    apply_slots_global(a.sp, slots, as_f64<VT>(val), as_i64<VT>(val));
+    apply_slots_global(a.sp, slots, as_f64<VT>(val), as_i64<VT>(val), as_bits<VT>(val));
   });
   if (full) atomicCAS(d_err, 0, -1);
 }
@@ -326,7 +326,7 @@ bool perfect_lds_eligible(const DevPlan& p, const FragView& fv) {
   if (p.group_type != MI355Q_INT32 && p.group_type != MI355Q_INT64) return false;
   if (p.entry_count * p.row_quad * 8 > kPerfectLdsMaxBytes) return false;
   FastShape s;
-  return grouped_fast_shape(p, fv, &s);
+  return grouped_fast_shape(p, fv, &s) && !s.sp.val_nullable;
 }
 
 template <typename FT, typename KT>

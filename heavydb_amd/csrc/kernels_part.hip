@@ -104,7 +104,31 @@ struct PartSlots {
   int32_t int_op[kMaxInt];            // op of each internal slot
   int32_t out_map[MI355Q_MAX_SLOTS];  // output slot -> internal slot (-1: key / none)
   int64_t int_init[kMaxInt];          // identity of each internal slot
+  // nullable value column: NULL inputs only count for COUNT(*); nn_slot is the internal
+  // COUNT_NN slot (non-NULL values), through which "no value seen" turns the output slots
+  // flagged SlotProg::null_init back into the NULL sentinel on emission
+  int32_t val_nullable;
+  int32_t nn_slot;
+  int32_t nn_hidden;                  // nn_slot is not mapped by any output slot
+  int32_t pad_;
+  int64_t null_bits;
 };
+
+MQ_D int64_t op_identity_dev(int op) {
+  switch (op) {
+    case SO_MIN_I: return INT64_MAX;
+    case SO_MAX_I: return INT64_MIN;
+    case SO_MIN_F: return 0x7fefffffffffffffll;            // DBL_MAX
+    case SO_MAX_F: return (int64_t)0xffefffffffffffffull;  // -DBL_MAX
+    default: return 0;
+  }
+}
+// partial row of ONE raw record for internal slot `op`
+MQ_D int64_t raw_partial(int op, int64_t vb, bool is_null) {
+  if (op == SO_COUNT) return 1;
+  if (op == SO_COUNT_NN) return is_null ? 0 : 1;
+  return is_null ? op_identity_dev(op) : vb;
+}
 
 struct TableArgs {
   int64_t* out;
@@ -136,7 +160,8 @@ MQ_D void spill_append(const SpillList& sl, int64_t key, const int64_t* part, in
 }
 MQ_D void spill_record(const SpillList& sl, const PartSlots& ps, int ns, int64_t key, int64_t vb) {
   int64_t part[kMaxInt];
-  for (int j = 0; j < kMaxInt; ++j) part[j] = ps.int_op[j] == SO_COUNT ? 1 : vb;
+  const bool is_null = ps.val_nullable && vb == ps.null_bits;
+  for (int j = 0; j < kMaxInt; ++j) part[j] = raw_partial(ps.int_op[j], vb, is_null);
   spill_append(sl, key, part, ns);
 }
 
@@ -157,7 +182,9 @@ struct ScatterArgs {
   uint32_t L, cap;
   HomeMap hm;
   int32_t ns_int;
-  uint32_t count_mask;  // internal slots that are COUNT (a spilled record contributes 1 there)
+  uint32_t ops_packed;  // internal slot ops, 4 bits each (for the partial row of a spilled record)
+  int32_t val_nullable;
+  int64_t null_bits;
   int32_t dbg_mode;     // timing experiments only (exec_options.reserved[1]); 0 in production
 };
 
@@ -248,7 +275,8 @@ MQ_D void flush_segments(bool need, uint32_t dst_rec, const Rec* __restrict__ st
 
 MQ_D void spill_raw(const SpillList& sl, const ScatterArgs& g, int64_t key, int64_t vb) {
   int64_t part[kMaxInt];
-  for (int j = 0; j < kMaxInt; ++j) part[j] = (g.count_mask >> j) & 1u ? 1 : vb;
+  const bool is_null = g.val_nullable && vb == g.null_bits;
+  for (int j = 0; j < kMaxInt; ++j) part[j] = raw_partial((int)((g.ops_packed >> (4 * j)) & 15u), vb, is_null);
   spill_append(sl, key, part, g.ns_int);
 }
 
@@ -491,7 +519,8 @@ typedef long long v2i64_t __attribute__((ext_vector_type(2)));
 
 MQ_D void lds_apply(int op, char* base, uint32_t e, int64_t vb) {
   switch (op) {
-    case SO_COUNT: atomicAdd((uint32_t*)base + e, 1u); break;
+    case SO_COUNT:
+    case SO_COUNT_NN: atomicAdd((uint32_t*)base + e, 1u); break;
     case SO_SUM_I: atomicAdd((unsigned long long*)base + e, (unsigned long long)vb); break;
     case SO_SUM_F: atomicAdd((double*)base + e, bits_dbl(vb)); break;
     case SO_MIN_I: atomicMin((long long*)base + e, (long long)vb); break;
@@ -504,17 +533,20 @@ MQ_D void lds_apply(int op, char* base, uint32_t e, int64_t vb) {
 // merge a PARTIAL (count / sum / min / max of several rows) into an LDS slot
 MQ_D void lds_merge(int op, char* base, uint32_t e, int64_t partial) {
   switch (op) {
-    case SO_COUNT: atomicAdd((uint32_t*)base + e, (uint32_t)partial); break;
+    case SO_COUNT:
+    case SO_COUNT_NN: atomicAdd((uint32_t*)base + e, (uint32_t)partial); break;
     case SO_SUM_I: atomicAdd((unsigned long long*)base + e, (unsigned long long)partial); break;
     default: lds_apply(op, base, e, partial);
   }
 }
+MQ_D bool is_count_op(int op) { return op == SO_COUNT || op == SO_COUNT_NN; }
 MQ_D int64_t lds_slot_value(int op, const char* base, uint32_t e) {
-  return op == SO_COUNT ? (int64_t)((const uint32_t*)base)[e] : ((const int64_t*)base)[e];
+  return is_count_op(op) ? (int64_t)((const uint32_t*)base)[e] : ((const int64_t*)base)[e];
 }
 MQ_D void global_merge(int op, int64_t* gslot, int64_t partial) {
   switch (op) {
     case SO_COUNT:
+    case SO_COUNT_NN:
     case SO_SUM_I: atomicAdd((unsigned long long*)gslot, (unsigned long long)partial); break;
     case SO_SUM_F: atomicAdd((double*)gslot, bits_dbl(partial)); break;
     case SO_MIN_I: atomicMin((long long*)gslot, (long long)partial); break;
@@ -530,15 +562,18 @@ constexpr uint32_t kNoEntry = 0xffffffffu;
 // one row's update of entry e, every op of the set
 template <int MASK>
 MQ_D void apply_row(char* smem, const PartGeom& g, const PartSlots& ps, uint32_t e, int64_t vb) {
+  const bool is_null = ps.val_nullable && vb == ps.null_bits;  // only COUNT(*) sees a NULL value
   if (MASK == 0) {
-    for (int m = 0; m < g.ns_int; ++m) lds_apply(ps.int_op[m], smem + g.slot_off[m], e, vb);
+    for (int m = 0; m < g.ns_int; ++m)
+      if (!is_null || ps.int_op[m] == SO_COUNT) lds_apply(ps.int_op[m], smem + g.slot_off[m], e, vb);
     return;
   }
   int m = 0;
 #pragma unroll
-  for (int op = SO_COUNT; op <= SO_MAX_F; ++op) {
+  for (int op = SO_COUNT; op <= SO_COUNT_NN; ++op) {
+    if (op == SO_KEY) continue;
     if (MASK & (1 << op)) {
-      lds_apply(op, smem + g.slot_off[m], e, vb);
+      if (!is_null || op == SO_COUNT) lds_apply(op, smem + g.slot_off[m], e, vb);
       ++m;
     }
   }
@@ -731,7 +766,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     for (uint32_t e = t; e < g.E; e += kPartBlock) {
       lkeys[e] = kEmptyKey64;  // (initialisation: the key layout does not matter here)
       for (int m = 0; m < ns; ++m) {
-        if (ps.int_op[m] == SO_COUNT) ((uint32_t*)(smem_raw + g.slot_off[m]))[e] = 0;
+        if (is_count_op(ps.int_op[m])) ((uint32_t*)(smem_raw + g.slot_off[m]))[e] = 0;
         else ((int64_t*)(smem_raw + g.slot_off[m]))[e] = ps.int_init[m];
       }
     }
@@ -749,14 +784,23 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
           int64_t part[kMaxInt];
           for (int m = 0; m < kMaxInt; ++m) part[m] = 0;
           bool big = false;  // a 32-bit LDS counter could wrap
+          bool any_value = false;  // some nullable value slot already holds a value
           for (int j = tab.sp.n - 1; j >= 0; --j) {
             const int m = ps.out_map[j];
             if (m >= 0) {
-              part[m] = row[1 + j];
-              if (ps.int_op[m] == SO_COUNT &&
+              int64_t v = row[1 + j];
+              if (tab.sp.null_init[j]) {
+                if (v == ps.null_bits) v = ps.int_init[m];  // NULL so far: contributes nothing
+                else any_value = true;
+              }
+              part[m] = v;
+              if (is_count_op(ps.int_op[m]) &&
                   (uint64_t)part[m] + chunk_records_max >= 0xffffffffull) big = true;
             }
           }
+          // the hidden non-NULL counter (no COUNT(col) / AVG in the output): only zero / non-zero
+          // matters
+          if (ps.nn_slot >= 0 && ps.nn_hidden) part[ps.nn_slot] = any_value ? 1 : 0;
           const uint32_t h = murmur3_u64((uint64_t)key);
           const uint32_t x = home_from_hash(g.hm, h) - lo;
           const uint32_t e = (x < n_slots && !big)
@@ -847,10 +891,14 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       }
       int64_t* row = tab.out + (size_t)(lo + s) * tab.row_quad;
       row[0] = key;
+      const bool no_value = ps.nn_slot >= 0 &&
+                            lds_slot_value(SO_COUNT_NN, smem_raw + g.slot_off[ps.nn_slot], e) == 0;
       for (int j = 0; j < tab.sp.n; ++j) {
         const int m = ps.out_map[j];
-        row[1 + j] = m >= 0 ? lds_slot_value(ps.int_op[m], smem_raw + g.slot_off[m], e)
-                            : (tab.sp.op[j] == SO_KEY ? key : tab.init[j]);
+        int64_t v = m >= 0 ? lds_slot_value(ps.int_op[m], smem_raw + g.slot_off[m], e)
+                           : (tab.sp.op[j] == SO_KEY ? key : tab.init[j]);
+        if (tab.sp.null_init[j] && no_value) v = ps.null_bits;  // SUM / MIN / MAX of no value: NULL
+        row[1 + j] = v;
       }
     }
     __syncthreads();
@@ -880,10 +928,28 @@ __global__ __launch_bounds__(256) void k_spill_merge(PartSlots ps, TableArgs tab
       atomicCAS(sl.d_err, 0, -1);  // out of group slots: the caller resizes and retries
       continue;
     }
+    const bool no_value = ps.nn_slot >= 0 && e.part[ps.nn_slot] == 0;
     for (int j = 0; j < tab.sp.n; ++j) {
       const int m = ps.out_map[j];
-      if (m >= 0) global_merge(tab.sp.op[j], slots + j, e.part[m]);
-      else if (tab.sp.op[j] == SO_KEY) MQ_STORE64(slots + j, e.key);
+      if (m < 0) {
+        if (tab.sp.op[j] == SO_KEY) MQ_STORE64(slots + j, e.key);
+        continue;
+      }
+      if (!tab.sp.null_init[j]) {
+        global_merge(tab.sp.op[j], slots + j, e.part[m]);
+        continue;
+      }
+      if (no_value) continue;  // the partial holds no value: the slot keeps what it has (NULL or not)
+      const int64_t v = e.part[m];
+      switch (tab.sp.op[j]) {  // slot starts at the NULL sentinel: first value overwrites it
+        case SO_SUM_I: a_sum_i64_skip<true>(slots + j, v, ps.null_bits); break;
+        case SO_SUM_F: a_sum_f64_skip<true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
+        case SO_MIN_I: a_min_i64_skip<true>(slots + j, v, ps.null_bits); break;
+        case SO_MAX_I: a_max_i64_skip<true>(slots + j, v, ps.null_bits); break;
+        case SO_MIN_F: a_minmax_f64<true, false, true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
+        case SO_MAX_F: a_minmax_f64<true, true, true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
+        default: break;
+      }
     }
   }
 }
@@ -939,6 +1005,26 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     h.ps.out_map[j] = m;
   }
   if (n_int == 0) return false;
+  // nullable value column with a SUM / MIN / MAX: a hidden counter of non-NULL values tells
+  // emission whether the slot holds a value or is still NULL (COUNT(col) / AVG already keep one)
+  h.ps.val_nullable = fs.sp.val_nullable;
+  h.ps.null_bits = fs.sp.null_bits;
+  h.ps.nn_slot = -1;
+  h.ps.nn_hidden = 0;
+  h.ps.pad_ = 0;
+  bool any_null_init = false;
+  for (int j = 0; j < fs.sp.n; ++j) any_null_init |= fs.sp.null_init[j] != 0;
+  if (fs.sp.val_nullable && any_null_init) {
+    bool have = false;
+    for (int k = 0; k < n_int; ++k) have |= h.ps.int_op[k] == SO_COUNT_NN;
+    if (!have) {
+      if (n_int >= kMaxInt) return false;
+      h.ps.int_op[n_int] = SO_COUNT_NN;
+      h.ps.int_init[n_int] = 0;
+      ++n_int;
+      h.ps.nn_hidden = 1;
+    }
+  }
   // internal slots in ascending op order (the compile-time op sets of phase 2 rely on it)
   for (int a = 0; a < n_int; ++a)
     for (int b = a + 1; b < n_int; ++b)
@@ -954,10 +1040,14 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
         }
       }
   h.op_mask = 0;
-  for (int m = 0; m < n_int; ++m) h.op_mask |= 1 << h.ps.int_op[m];
+  for (int m = 0; m < n_int; ++m) {
+    h.op_mask |= 1 << h.ps.int_op[m];
+    if (h.ps.int_op[m] == SO_COUNT_NN && any_null_init) h.ps.nn_slot = m;
+  }
   h.g.ns_int = n_int;
   size_t entry_bytes = 8;
-  for (int m = 0; m < n_int; ++m) entry_bytes += h.ps.int_op[m] == SO_COUNT ? 4 : 8;
+  for (int m = 0; m < n_int; ++m)
+    entry_bytes += (h.ps.int_op[m] == SO_COUNT || h.ps.int_op[m] == SO_COUNT_NN) ? 4 : 8;
   const uint32_t e_max = (uint32_t)(kLdsTableBudget / entry_bytes) & ~3u;
   // expected groups: the caller sizes the table at ~2 x NDV (50 % fill, docs results.rst)
   const uint64_t d = (uint64_t)p.entry_count;
@@ -988,10 +1078,11 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   {
     uint32_t off = h.g.E * 8;  // 8-byte slot arrays first, then the 4-byte counters
     for (int m = 0; m < kMaxInt; ++m) h.g.slot_off[m] = 0;
+    auto is_cnt = [&](int m) { return h.ps.int_op[m] == SO_COUNT || h.ps.int_op[m] == SO_COUNT_NN; };
     for (int m = 0; m < n_int; ++m)
-      if (h.ps.int_op[m] != SO_COUNT) { h.g.slot_off[m] = off; off += h.g.E * 8; }
+      if (!is_cnt(m)) { h.g.slot_off[m] = off; off += h.g.E * 8; }
     for (int m = 0; m < n_int; ++m)
-      if (h.ps.int_op[m] == SO_COUNT) { h.g.slot_off[m] = off; off += h.g.E * 4; }
+      if (is_cnt(m)) { h.g.slot_off[m] = off; off += h.g.E * 4; }
   }
   {
     const uint64_t m = ((uint64_t)(h.g.E / 4) << 32) / hm.S2;
@@ -1110,6 +1201,13 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     case (1 << SO_COUNT) | (1 << SO_SUM_I): agg_kernel = k_part_aggregate<((1 << SO_COUNT) | (1 << SO_SUM_I))>; break;
     case 1 << SO_SUM_F: agg_kernel = k_part_aggregate<(1 << SO_SUM_F)>; break;
     case 1 << SO_SUM_I: agg_kernel = k_part_aggregate<(1 << SO_SUM_I)>; break;
+    // nullable value column: COUNT(*), AVG(col) [, COUNT(col)]
+    case (1 << SO_COUNT) | (1 << SO_SUM_F) | (1 << SO_COUNT_NN):
+      agg_kernel = k_part_aggregate<((1 << SO_COUNT) | (1 << SO_SUM_F) | (1 << SO_COUNT_NN))>;
+      break;
+    case (1 << SO_COUNT) | (1 << SO_SUM_I) | (1 << SO_COUNT_NN):
+      agg_kernel = k_part_aggregate<((1 << SO_COUNT) | (1 << SO_SUM_I) | (1 << SO_COUNT_NN))>;
+      break;
     default: break;
   }
   (void)hipFuncSetAttribute((const void*)agg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1124,10 +1222,11 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   sa.cap = h.g.cap;
   sa.hm = h.g.hm;
   sa.ns_int = h.g.ns_int;
-  sa.count_mask = 0;
+  sa.ops_packed = 0;
   sa.dbg_mode = debug_part_p();
-  for (int m = 0; m < h.g.ns_int; ++m)
-    if (h.ps.int_op[m] == SO_COUNT) sa.count_mask |= 1u << m;
+  for (int m = 0; m < h.g.ns_int; ++m) sa.ops_packed |= (uint32_t)(h.ps.int_op[m] & 15) << (4 * m);
+  sa.val_nullable = h.ps.val_nullable;
+  sa.null_bits = h.ps.null_bits;
   int f = 0;
   int ev_i = 0;
   int chunk = 0;

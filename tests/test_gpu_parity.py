@@ -216,14 +216,40 @@ def _baseline_table(rng, n, n_keys, skew=0.0):
 
 
 @pytest.mark.parametrize("variant", [1, 2], ids=["direct", "partitioned"])
-@pytest.mark.parametrize("shape", ["count_avg_f64_filtered", "sum_min_max_i64", "count_only", "skewed"])
+@pytest.mark.parametrize("shape", ["count_avg_f64_filtered", "sum_min_max_i64", "count_only", "skewed",
+                                   "nullable_avg_count_f64", "nullable_sum_min_max_i64", "nullable_key_and_sum"])
 def test_baseline_family_members(torch_cuda, oracle, variant, shape):
     from heavydb_amd.executor import (Executor, FetchResult, Qual, RelAlgExecutionUnit, TargetExpr)
     torch = torch_cuda
     rng = np.random.default_rng(99)
     n, n_keys = 600_000, 150_000
     descs, cols = _baseline_table(rng, n, n_keys, skew=0.6 if shape == "skewed" else 0.0)
-    if shape in ("count_avg_f64_filtered", "skewed"):
+    if shape.startswith("nullable"):
+        # NULL sentinels (Shared/InlineNullValues.h): 30 % of the values, and every value of the
+        # groups with key id < 2000, so some groups end with SUM / MIN / MAX / AVG = NULL
+        from heavydb_amd.executor import ExpressionRange, InputColDescriptor
+        ids = (cols[0] - 7) // 1000003
+        nulls = (rng.random(n) < 0.3) | (ids < 2000)
+        cols[1] = cols[1].copy()
+        cols[2] = cols[2].copy()
+        cols[1][nulls] = np.float64(2.2250738585072014e-308)  # NULL_DOUBLE = DBL_MIN
+        cols[2][nulls] = -2**63
+        descs[1] = InputColDescriptor(capi.DOUBLE, True, ExpressionRange(True, 0, 0, True, 0.0, 1000.0))
+        descs[2] = InputColDescriptor(capi.INT64, True, ExpressionRange(True, -10**6, 10**6, True))
+        if shape == "nullable_key_and_sum":
+            cols[0] = cols[0].copy()
+            cols[0][rng.random(n) < 0.01] = -2**63  # NULL group key: a group of its own
+            descs[0] = InputColDescriptor(capi.INT64, True, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7, True))
+    if shape == "nullable_avg_count_f64":
+        targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.COUNT, 1), TargetExpr(capi.AVG, 1)]
+        quals = [Qual(3, capi.LT, 2**30)]
+    elif shape == "nullable_sum_min_max_i64":
+        targets = [TargetExpr(capi.SUM, 2), TargetExpr(capi.MIN, 2), TargetExpr(capi.MAX, 2), TargetExpr(capi.COUNT)]
+        quals = []
+    elif shape == "nullable_key_and_sum":
+        targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 1), TargetExpr(capi.COUNT)]
+        quals = [Qual(3, capi.GE, 2**28)]
+    elif shape in ("count_avg_f64_filtered", "skewed"):
         targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1)]
         quals = [Qual(3, capi.LT, 2**30)]
     elif shape == "sum_min_max_i64":
