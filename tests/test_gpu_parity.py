@@ -434,3 +434,39 @@ def test_baseline_family_edge_cases(torch_cuda, oracle, variant, edge):
     compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
     if edge == "no_survivors":
         assert rs.rowCount() == 0
+
+
+def test_full_size_property_checks(torch_cuda):
+    """BASELINE.json's headline size — 10 B rows, 10 M int64 keys, filtered — through
+    size-independent properties (the oracle cannot visit this size): group count == key
+    cardinality, every key a legal generator output and distinct, SUM(COUNT) == rows passing
+    the filter as counted by the independent non-grouped scan kernel, and the checksum of
+    checksums SUM_g(COUNT_g x AVG_g) == SUM(f64) over the passing rows computed by the
+    non-grouped generic kernel (relative 1e-9); the buffer is a valid probing image."""
+    from heavydb_amd import synth
+    from heavydb_amd.executor import Executor, Qual, RelAlgExecutionUnit, TargetExpr
+    torch = torch_cuda
+    free, _ = torch.cuda.mem_get_info(0)
+    total = 10_000_000_000
+    if free < total * 20 + (40 << 30):
+        pytest.skip("needs ~240 GB of free HBM")
+    n_keys = 10_000_000
+    ra, fr, info = synth.cfg3(torch, total, filtered=True, n_keys=n_keys)
+    ex = Executor(0)
+    rs = ex.executeWorkUnit(ra, fr, allow_retry=False)
+    assert rs.report.variant == 2 and rs.report.kernel_name.decode() == "k_part_scatter"
+    ival, dval, nul = rs.fetch()
+    assert ival.shape[0] == n_keys
+    keys = ival[:, 0]
+    assert ((keys - 7) % 1000003 == 0).all() and keys.min() == 7 and keys.max() == (n_keys - 1) * 1000003 + 7
+    assert len(np.unique(keys)) == n_keys
+    cnt_ra = RelAlgExecutionUnit(ra.input_col_descs, [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1)],
+                                 [Qual(2, capi.LT, 2**30)])
+    row = ex.executeWorkUnit(cnt_ra, fr).getNextRow()
+    passing, total_sum = int(row[0]), float(row[1])
+    assert int(ival[:, 1].sum()) == passing
+    assert abs(passing / total - 0.5) < 1e-4
+    assert (nul == 0).all() and (dval[:, 2] > 0).all() and (dval[:, 2] < 1000).all()
+    checksum = float((ival[:, 1].astype(np.float64) * dval[:, 2]).sum())
+    assert abs(checksum - total_sum) <= 1e-9 * abs(total_sum), (checksum, total_sum)
+    check_probe_invariant(rs.getQueryMemDesc(), rs.getStorage())
