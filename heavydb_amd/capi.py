@@ -180,6 +180,8 @@ SYMBOLS = [
     ("mi355q_result_create", C.c_int32, [_P(QMD), C.c_int32, C.c_void_p, _P(C.c_void_p)]),
     ("mi355q_result_wrap", C.c_int32, [_P(QMD), C.c_int32, C.c_void_p, _P(C.c_void_p)]),
     ("mi355q_result_free", None, [C.c_void_p]),
+    ("mi355q_result_topk", C.c_int32,
+     [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, _P(C.c_int64), C.c_void_p]),
     ("mi355q_result_qmd", C.c_int32, [C.c_void_p, _P(QMD)]),
     ("mi355q_result_device_ptr", C.c_void_p, [C.c_void_p]),
     ("mi355q_result_bytes", C.c_int64, [C.c_void_p]),

@@ -410,6 +410,29 @@ int64_t mi355q_result_row_count(const mi355q_result* r) {
   return (int64_t)h;
 }
 
+int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t descending,
+                           int32_t nulls_first, int64_t k, void* out_rows_dev, int64_t* n_rows,
+                           void* stream) {
+  if (!r || !out_rows_dev || !n_rows || target_idx < 0 || target_idx >= r->qmd.n_targets || k < 1)
+    return MI355Q_ERR_INVALID_PLAN;
+  if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return MI355Q_ERR_UNSUPPORTED;
+  if (k > topk_max_k()) return MI355Q_ERR_UNSUPPORTED;
+  if (k > r->qmd.entry_count) k = r->qmd.entry_count;
+  DeviceGuard g(r->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  hipStream_t s = (hipStream_t)stream;
+  DevWord scratch;
+  HIP_TRY(hipMalloc(&scratch.p, (size_t)topk_scratch_bytes(r->qmd.entry_count) + 64));
+  int64_t* d_n = (int64_t*)((char*)scratch.p + topk_scratch_bytes(r->qmd.entry_count));
+  const mi355q_qmd& q = r->qmd;
+  HIP_TRY(launch_topk(r->dplan, q.idx_target_as_key, target_idx, q.target_null[target_idx],
+                      q.target_is_fp[target_idx] != 0, descending != 0, nulls_first != 0, r->buf, k,
+                      scratch.p, (int64_t*)out_rows_dev, d_n, s));
+  HIP_TRY(hipMemcpyAsync(n_rows, d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return MI355Q_OK;
+}
+
 // Host-side iteration over the copied-back buffer, like ResultSet::getNextRow
 // (ResultSetIteration.cpp:125-230, getTargetValueFromBufferRowwise) for 8-byte slots.
 int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival,

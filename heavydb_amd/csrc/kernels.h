@@ -105,6 +105,13 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                                        int64_t cap_bytes, int n_cus, hipStream_t s,
                                        LaunchStats* st);
 
+// ---- ORDER BY one target LIMIT k on the device (kernels_sort.hip)
+int64_t topk_scratch_bytes(int64_t entry_count);
+int topk_max_k();
+hipError_t launch_topk(const DevPlan& p, int idx_target_as_key, int target, int64_t null_pattern,
+                       bool fp_result, bool desc, bool nulls_first, const int64_t* buf, int64_t k,
+                       void* scratch, int64_t* out_rows, int64_t* d_n_out, hipStream_t s);
+
 bool join_sum_eligible(const DevPlan& p, const FragView& fv);
 hipError_t launch_join_sum(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus,
                            hipStream_t s, LaunchStats* st);

@@ -1,0 +1,250 @@
+// kernels_sort.hip — ORDER BY <one target> [ASC | DESC] [NULLS FIRST | LAST] LIMIT k over a grouped
+// result, on the device, so a dashboard-style "top n groups" never copies the 640 MB table to
+// the host.
+//
+// Reference: ResultSet::sort (ResultSet.cpp:801-851) -> baselineSort -> baseline_sort
+// (ResultSetSortImpl.cu: order-entry column, thrust::sort_by_key of entry indices) and
+// TopKSort.cu (partition NULLs, radix sort, take the first n).  Here the k best entries are
+// SELECTED instead of sorting everything:
+//   1. k_topk_keys      one order-preserving uint64 per entry (empty entries sort last, NULLs
+//                       first or last, DESC by complementing)
+//   2. k_topk_hist x 6  MSB-first 11-bit radix histograms of the entries that still match the
+//      k_topk_pick x 6  prefix found so far; each pick fixes 11 more bits of the k-th key
+//   3. k_topk_collect   entries below the k-th key, plus as many equal to it as are still needed
+//   4. k_topk_finish    one workgroup: bitonic sort of the <= 4096 candidates in LDS, then the
+//                       rows are gathered in order
+// Ties at the k-th position are broken arbitrarily, as in the reference.
+#include <hip/hip_runtime.h>
+
+#include "kernels.h"
+#include "rowfunc.h"
+
+namespace mq {
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kRadixBits = 11;
+constexpr int kBins = 1 << kRadixBits;
+constexpr int kPasses = 6;  // 6 x 11 = 66 >= 64 bits
+constexpr uint64_t kEmptySortKey = ~0ull;
+constexpr uint64_t kNullLastKey = ~0ull - 1;
+
+struct TopkState {  // device words shared by the passes
+  unsigned long long prefix;      // bits of the k-th key fixed so far (left aligned)
+  unsigned long long remaining;   // how many keys with this prefix are still wanted
+  unsigned long long n_below;     // candidates written by collect
+  unsigned long long n_ties;      // ties taken
+  unsigned int hist[kBins];
+};
+
+MQ_D uint64_t order_key_of(const DevPlan& p, const DevTarget& t, const int64_t* row, int idx_target_as_key,
+                           int64_t null_pattern, bool fp_result, bool desc, bool nulls_first) {
+  if (is_empty_row(p, row, idx_target_as_key)) return kEmptySortKey;
+  uint64_t u;
+  bool is_null = false;
+  if (t.agg == MI355Q_PROJECT_KEY && t.slot < 0) {
+    const int64_t v = p.key_width == 4 ? (int64_t) * (const int32_t*)row : row[0];
+    is_null = v == null_pattern;
+    u = (uint64_t)v ^ 0x8000000000000000ull;
+  } else {
+    const int64_t* s = row + p.key_quad + t.slot;
+    if (t.agg == MI355Q_AVG) {
+      const int64_t cnt = s[1];
+      is_null = cnt == 0;  // pair_to_double: count 0 -> NULL
+      const double d = is_null ? 0.0 : (t.arg_fp ? bits_dbl(s[0]) : (double)s[0]) / (double)cnt;
+      const uint64_t b = (uint64_t)dbl_bits(d);
+      u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    } else if (fp_result) {
+      is_null = (t.skip_null) && s[0] == null_pattern;
+      const uint64_t b = (uint64_t)s[0];
+      u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    } else {
+      is_null = (t.skip_null || t.agg == MI355Q_PROJECT_KEY) && s[0] == null_pattern;
+      u = (uint64_t)s[0] ^ 0x8000000000000000ull;
+    }
+  }
+  if (is_null) return nulls_first ? 0ull : kNullLastKey;
+  if (desc) u = ~u;
+  // keep the reserved patterns free: 0 (NULLS FIRST), ~0 - 1 (NULLS LAST), ~0 (empty)
+  if (u == 0ull) u = 1ull;
+  if (u >= kNullLastKey) u = kNullLastKey - 1;
+  return u;
+}
+
+__global__ __launch_bounds__(kBlock) void k_topk_keys(DevPlan p, int idx_target_as_key, int target,
+                                                       int64_t null_pattern, int fp_result, int desc,
+                                                       int nulls_first, const int64_t* __restrict__ buf,
+                                                       uint64_t* __restrict__ keys, TopkState* st,
+                                                       unsigned long long k) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < p.entry_count; e += stride) {
+    keys[e] = order_key_of(p, p.targets[target], buf + e * p.row_quad, idx_target_as_key, null_pattern,
+                           fp_result != 0, desc != 0, nulls_first != 0);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st->prefix = 0;
+    st->remaining = k;
+    st->n_below = 0;
+    st->n_ties = 0;
+  }
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < kBins; i += kBlock) st->hist[i] = 0;
+}
+
+// histogram of digit `pass` (MSB first) over the keys whose higher digits equal the prefix
+__global__ __launch_bounds__(kBlock) void k_topk_hist(const uint64_t* __restrict__ keys, int64_t n, int pass,
+                                                       TopkState* st) {
+  __shared__ unsigned int s_hist[kBins];
+  for (int i = threadIdx.x; i < kBins; i += kBlock) s_hist[i] = 0;
+  __syncthreads();
+  const int hi_bits = pass * kRadixBits;                 // bits already fixed
+  const int shift = 64 - hi_bits - kRadixBits;           // may be negative in the last pass
+  const uint64_t prefix = st->prefix;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+    const uint64_t u = keys[e];
+    if (hi_bits && (u >> (64 - hi_bits)) != (prefix >> (64 - hi_bits))) continue;
+    const unsigned int d = shift >= 0 ? (unsigned int)(u >> shift) & (kBins - 1)
+                                      : (unsigned int)(u << -shift) & (kBins - 1);
+    atomicAdd(&s_hist[d], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBins; i += kBlock)
+    if (s_hist[i]) atomicAdd(&st->hist[i], s_hist[i]);
+}
+
+// one workgroup: find the digit where the running count reaches `remaining`
+__global__ __launch_bounds__(kBlock) void k_topk_pick(int pass, TopkState* st) {
+  __shared__ unsigned long long s_part[kBlock];
+  const int per = kBins / kBlock;  // 8 consecutive bins per lane
+  unsigned long long local = 0;
+  for (int i = 0; i < per; ++i) local += st->hist[threadIdx.x * per + i];
+  s_part[threadIdx.x] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long want = st->remaining;
+    unsigned long long acc = 0;
+    int lane = 0;
+    while (lane < kBlock - 1 && acc + s_part[lane] < want) acc += s_part[lane++];
+    int bin = lane * per;
+    while (bin < kBins - 1 && acc + st->hist[bin] < want) acc += st->hist[bin++];
+    const int hi_bits = pass * kRadixBits;
+    const int shift = 64 - hi_bits - kRadixBits;
+    const unsigned long long digit = (unsigned long long)bin;
+    st->prefix |= shift >= 0 ? digit << shift : digit >> -shift;
+    st->remaining = want - acc;  // still wanted among the keys of this digit
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < kBins; i += kBlock) st->hist[i] = 0;
+}
+
+struct Cand {
+  uint64_t key;
+  uint64_t entry;
+};
+
+__global__ __launch_bounds__(kBlock) void k_topk_collect(const uint64_t* __restrict__ keys, int64_t n,
+                                                          TopkState* st, Cand* __restrict__ cands,
+                                                          unsigned long long k) {
+  const uint64_t kth = st->prefix;            // all 64 bits are fixed now
+  const unsigned long long ties_wanted = st->remaining;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) {
+    const uint64_t u = keys[e];
+    if (u == kEmptySortKey) continue;
+    if (u < kth) {
+      const unsigned long long i = atomicAdd(&st->n_below, 1ull);
+      if (i < k) cands[i] = Cand{u, (uint64_t)e};
+    } else if (u == kth) {
+      const unsigned long long i = atomicAdd(&st->n_ties, 1ull);
+      if (i < ties_wanted) cands[k - 1 - i] = Cand{u, (uint64_t)e};  // ties fill from the back
+    }
+  }
+}
+
+constexpr int kMaxTopk = 4096;
+
+// one workgroup of 1024 lanes: bitonic sort of the candidates, then gather the rows
+__global__ __launch_bounds__(1024) void k_topk_finish(DevPlan p, const int64_t* __restrict__ buf,
+                                                       TopkState* st, const Cand* __restrict__ cands,
+                                                       unsigned long long k, int64_t* __restrict__ out_rows,
+                                                       int64_t* __restrict__ n_out) {
+  __shared__ uint64_t s_key[kMaxTopk];
+  __shared__ uint32_t s_ent[kMaxTopk];
+  // number of real candidates: all below the k-th key + the ties taken (bounded by what exists)
+  unsigned long long below = st->n_below;
+  if (below > k) below = k;
+  unsigned long long ties = st->n_ties < st->remaining ? st->n_ties : st->remaining;
+  if (below + ties > k) ties = k - below;
+  const unsigned int n = (unsigned int)(below + ties);
+  for (unsigned int i = threadIdx.x; i < kMaxTopk; i += 1024) {
+    Cand c{kEmptySortKey, 0};
+    if (i < below) c = cands[i];
+    else if (i < n) c = cands[k - 1 - (i - below)];
+    s_key[i] = c.key;
+    s_ent[i] = (uint32_t)c.entry;
+  }
+  __syncthreads();
+  for (unsigned int size = 2; size <= kMaxTopk; size <<= 1) {
+    for (unsigned int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (unsigned int i = threadIdx.x; i < kMaxTopk / 2; i += 1024) {
+        const unsigned int lo = 2 * i - (i & (stride - 1));
+        const unsigned int hi = lo + stride;
+        const bool up = (lo & size) == 0;
+        const uint64_t a = s_key[lo], b = s_key[hi];
+        const uint32_t ea = s_ent[lo], eb = s_ent[hi];
+        // total order on (key, entry) so the result is deterministic for equal keys
+        const bool gt = a > b || (a == b && ea > eb);
+        if (gt == up) {
+          s_key[lo] = b; s_key[hi] = a;
+          s_ent[lo] = eb; s_ent[hi] = ea;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (unsigned int i = threadIdx.x; i < n * (unsigned int)p.row_quad; i += 1024) {
+    const unsigned int r = i / p.row_quad, j = i % p.row_quad;
+    out_rows[(size_t)r * p.row_quad + j] = buf[(size_t)s_ent[r] * p.row_quad + j];
+  }
+  if (threadIdx.x == 0) *n_out = (int64_t)n;
+}
+
+inline int grid_for(int64_t work_items, int max_blocks = 2048) {
+  int64_t b = (work_items + kBlock - 1) / kBlock;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}
+
+}  // namespace
+
+int64_t topk_scratch_bytes(int64_t entry_count) {
+  return entry_count * 8 + (int64_t)sizeof(TopkState) + (int64_t)kMaxTopk * (int64_t)sizeof(Cand) + 512;
+}
+int topk_max_k() { return kMaxTopk; }
+
+hipError_t launch_topk(const DevPlan& p, int idx_target_as_key, int target, int64_t null_pattern,
+                       bool fp_result, bool desc, bool nulls_first, const int64_t* buf, int64_t k,
+                       void* scratch, int64_t* out_rows, int64_t* d_n_out, hipStream_t s) {
+  if (k < 1 || k > kMaxTopk) return hipErrorInvalidValue;
+  uint64_t* keys = (uint64_t*)scratch;
+  char* tail = (char*)scratch + (((size_t)p.entry_count * 8 + 255) & ~(size_t)255);
+  TopkState* st = (TopkState*)tail;
+  Cand* cands = (Cand*)(tail + ((sizeof(TopkState) + 255) & ~(size_t)255));
+  const int grid = grid_for(p.entry_count);
+  hipLaunchKernelGGL(k_topk_keys, dim3(grid), dim3(kBlock), 0, s, p, idx_target_as_key, target, null_pattern,
+                     (int)fp_result, (int)desc, (int)nulls_first, buf, keys, st, (unsigned long long)k);
+  for (int pass = 0; pass < kPasses; ++pass) {
+    hipLaunchKernelGGL(k_topk_hist, dim3(grid), dim3(kBlock), 0, s, keys, p.entry_count, pass, st);
+    hipLaunchKernelGGL(k_topk_pick, dim3(1), dim3(kBlock), 0, s, pass, st);
+  }
+  hipLaunchKernelGGL(k_topk_collect, dim3(grid), dim3(kBlock), 0, s, keys, p.entry_count, st, cands,
+                     (unsigned long long)k);
+  hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, s, p, buf, st, cands, (unsigned long long)k,
+                     out_rows, d_n_out);
+  return hipGetLastError();
+}
+
+}  // namespace mq

@@ -233,6 +233,16 @@ class ResultSet:
         return buf.reshape(q.entry_count, q.row_size // 8)
 
     # -- iteration
+    def sort(self, target_idx: int, top_n: int, out_rows_dev: int, desc: bool = True,
+             nulls_first: bool = False) -> int:
+        """ORDER BY target [DESC] LIMIT top_n on the device (ResultSet::sort with one order
+        entry, ResultSet.h:278): the best rows land, in order, in the caller's device buffer
+        (top_n rows of this layout); returns how many were written."""
+        n = C.c_int64()
+        check(self._lib.mi355q_result_topk(self.handle, target_idx, int(desc), int(nulls_first), top_n,
+                                           out_rows_dev, C.byref(n), None), "result_topk")
+        return n.value
+
     def rowCount(self) -> int:
         return self._lib.mi355q_result_row_count(self.handle)
 

@@ -298,6 +298,16 @@ int64_t mi355q_result_row_count(const mi355q_result* r);
 int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival,
                                  double* dval, int8_t* is_null, int64_t* n_rows);
 
+/* ORDER BY <target> [ASC | DESC] [NULLS FIRST | LAST] LIMIT k over a grouped (or projected)
+ * result, on the device: the k best non-empty entries are written to out_rows_dev as whole rows
+ * of r's layout, in order; *n_rows = min(k, live entries).  k <= 4096.  Replaces
+ * ResultSet::sort -> baselineSort (ResultSet.cpp:801-851) -> baseline_sort
+ * (ResultSetSortImpl.cu) / TopKSort.cu for one order entry; ties at the k-th position are
+ * broken arbitrarily, as in the reference.  AVG targets are ordered by sum / count. */
+int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t descending,
+                           int32_t nulls_first, int64_t k, void* out_rows_dev, int64_t* n_rows,
+                           void* stream);
+
 /* ---- join hash tables ---- */
 typedef struct mi355q_join_spec {
   int32_t device_id;

@@ -470,3 +470,61 @@ def test_full_size_property_checks(torch_cuda):
     checksum = float((ival[:, 1].astype(np.float64) * dval[:, 2]).sum())
     assert abs(checksum - total_sum) <= 1e-9 * abs(total_sum), (checksum, total_sum)
     check_probe_invariant(rs.getQueryMemDesc(), rs.getStorage())
+
+
+@pytest.mark.parametrize("order", ["count_desc", "avg_asc", "key_desc", "max_nullable_desc_nulls_first",
+                                   "max_nullable_asc_nulls_last"])
+def test_topk_on_device(torch_cuda, oracle, order):
+    """ORDER BY one target LIMIT k on the device against the oracle's table sorted on the host
+    (ResultSet::sort semantics; ties at the k-th position may be broken either way, so the
+    ordered VALUES must agree and every returned row must be a row of the table)."""
+    from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, InputColDescriptor,
+                                      RelAlgExecutionUnit, TargetExpr)
+    torch = torch_cuda
+    rng = np.random.default_rng(23)
+    n, n_keys = 300_000, 20_000
+    key = (rng.integers(0, n_keys, n) * 1000003 + 7).astype(np.int64)
+    val = (rng.random(n) * 1000.0).astype(np.float64)
+    ival = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    ival[(key % 11 == 0) | (rng.random(n) < 0.2)] = -2**63  # some groups have no value at all
+    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7)),
+             InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0)),
+             InputColDescriptor(capi.INT64, True, ExpressionRange(True, -10**6, 10**6, True))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1),
+                                     TargetExpr(capi.MAX, 2)], [], [0], max_groups_buffer_entry_guess=2 * n_keys)
+    cols = [key, val, ival]
+    dev = [torch.from_numpy(c).cuda() for c in cols]
+    fr = FetchResult([[int(t.data_ptr()) for t in dev]], [n], keepalive=dev)
+    rs = Executor(0).executeWorkUnit(ra, fr, allow_retry=False)
+    q = rs.getQueryMemDesc()
+    rq = q.row_size // 8
+    target, desc, nulls_first = {"count_desc": (1, True, False), "avg_asc": (2, False, False),
+                                 "key_desc": (0, True, False),
+                                 "max_nullable_desc_nulls_first": (3, True, True),
+                                 "max_nullable_asc_nulls_last": (3, False, False)}[order]
+    table = rs.getStorage().reshape(-1, rq)
+    live = table[table[:, 0] != 2**63 - 1]
+
+    def value_of(rows):
+        if target == 0:
+            return rows[:, 0].astype(np.float64), np.zeros(len(rows), bool)
+        s = 1 + q.target_slot[target]
+        if target == 2:
+            return rows[:, s].view(np.float64) / rows[:, s + 1], rows[:, s + 1] == 0
+        return rows[:, s].astype(np.float64), rows[:, s] == -2**63
+
+    for k in (1, 10, 1000, 4096):
+        out = torch.empty((k, rq), dtype=torch.int64, device="cuda")
+        got_n = rs.sort(target, k, int(out.data_ptr()), desc=desc, nulls_first=nulls_first)
+        got = out.cpu().numpy()[:got_n]
+        v, isnull = value_of(live)
+        sort_v = np.where(isnull, -np.inf if nulls_first else np.inf, -v if desc else v)
+        want_v = np.sort(sort_v, kind="stable")[:k]
+        assert got_n == min(k, live.shape[0])
+        gv, gnull = value_of(got)
+        got_v = np.where(gnull, -np.inf if nulls_first else np.inf, -gv if desc else gv)
+        assert np.array_equal(got_v, want_v), (order, k, got_v[:5], want_v[:5])
+        # every returned row is a row of the table (whole-row equality through the key)
+        by_key = {int(r[0]): r for r in live}
+        assert all((by_key[int(r[0])] == r).all() for r in got)
+        assert len({int(r[0]) for r in got}) == got_n
