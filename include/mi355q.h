@@ -25,6 +25,8 @@
  *   mi355q_result_*        ResultSet accessors (ResultSet.h:263 getNextRow,
  *                          :327 rowCount; ResultSetIteration.cpp:2457 isEmptyEntry;
  *                          ResultSetBufferAccessors.h:197 pair_to_double)
+ *   mi355q_result_topk     ResultSet::sort (ResultSet.h:278) -> baselineSort /
+ *                          TopKSort.cu for one order entry with a row limit
  *   mi355q_join_build      HashJoin::getInstance (JoinHashTable/HashJoin.cpp:286):
  *                          PerfectJoinHashTable (PerfectJoinHashTable.cpp:168) then
  *                          BaselineJoinHashTable (BaselineJoinHashTable.cpp:484)
