@@ -96,7 +96,6 @@ struct PartGeom {
   int32_t ns_int;      // distinct partial slots kept per group in LDS
   uint32_t lds_table_bytes;  // keys + slot arrays of the LDS table (16-byte multiple)
   uint32_t slot_off[kMaxInt];  // byte offset of each internal slot array in LDS
-  int32_t dbg_mode;            // timing experiments only; 0 in production
   HomeMap hm;
 };
 
@@ -185,7 +184,6 @@ struct ScatterArgs {
   uint32_t ops_packed;  // internal slot ops, 4 bits each (for the partial row of a spilled record)
   int32_t val_nullable;
   int64_t null_bits;
-  int32_t dbg_mode;     // timing experiments only (exec_options.reserved[1]); 0 in production
 };
 
 template <typename FT, typename VT>
@@ -403,8 +401,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
         uint32_t p = 0, s = 0;
         int64_t vb = 0;
         if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i))) {
-          p = (g.dbg_mode & 1) ? ((uint32_t)cur.k.v[i] * 2654435761u) >> (32 - 10)
-                               : part_of(g.hm, home_of(g.hm, cur.k.v[i]));
+          p = part_of(g.hm, home_of(g.hm, cur.k.v[i]));
           s = atomicAdd(&cursor[p], 1u);
           vb = val_bits_of<VT>(quad_get(cur.v, i));
           if (s >= g.cap) spill_raw(sl, g, cur.k.v[i], vb);  // run full
@@ -695,10 +692,6 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     const Rec* rr[4] = {&r0, &r1, &r2, &r3};
     uint32_t ba[4], bb[4];
     uint32_t in_mask = 0;
-    if (g.dbg_mode & 32) {  // timing experiment: memory only
-      if (r0.key + r1.key + r2.key + r3.key == 0x1234567) atomicAdd(sl.count, 1u);
-      return;
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const uint32_t h = murmur3_u64((uint64_t)rr[j]->key);
@@ -1088,7 +1081,6 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     const uint64_t m = ((uint64_t)(h.g.E / 4) << 32) / hm.S2;
     h.g.b_mult = (uint32_t)(m > 0xffffffffull ? 0xffffffffull : m);
   }
-  h.g.dbg_mode = debug_part_p();
   h.g.B = n_cus;  // one 1024-lane workgroup per CU
   // chunking: worst case every row survives the filter; shrink the chunk until the runs
   // (1.2 x mean + 6 sigma + a line of slack per run) fit the scratch cap, never below one
@@ -1223,7 +1215,6 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   sa.hm = h.g.hm;
   sa.ns_int = h.g.ns_int;
   sa.ops_packed = 0;
-  sa.dbg_mode = debug_part_p();
   for (int m = 0; m < h.g.ns_int; ++m) sa.ops_packed |= (uint32_t)(h.ps.int_op[m] & 15) << (4 * m);
   sa.val_nullable = h.ps.val_nullable;
   sa.null_bits = h.ps.null_bits;
