@@ -34,6 +34,7 @@
 //                              reference's CAS insert-or-find, so skew costs speed, never
 //                              correctness.
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 #include "fast_common.h"
@@ -49,7 +50,7 @@ constexpr int kStageRecs = 8192;       // staged records per workgroup (128 KB o
 constexpr int kSegRecs = 8;            // records per 128-byte segment (one owner lane each)
 constexpr int kMaxInt = 8;             // internal (LDS) partial slots per group
 constexpr int kMaxSub = 4;             // sub-ranges per partition
-constexpr uint32_t kSpillCap = 1u << 20;
+constexpr uint32_t kSpillCap = 1u << 22;  // 4 M partial rows (288 MB of the scratch)
 
 struct alignas(16) Rec {
   int64_t key;
@@ -295,6 +296,9 @@ MQ_D void spill_raw(const SpillList& sl, const ScatterArgs& g, int64_t key, int6
 constexpr int kProdWaves = 12;
 constexpr int kFlushWaves = kPartBlock / 64 - kProdWaves;
 constexpr int kSegPerFlusher = (kStageRecs / kSegRecs) / (kFlushWaves * 64);  // 4
+constexpr int kHotSlots = 256;          // per-workgroup heavy-hitter table (keys with >~0.4 % of the rows)
+constexpr uint32_t kHotPromote = 16;    // net sampled sightings (Misra-Gries) before a key is declared hot
+constexpr int kHotSampleLg = 4;         // 1 record in 16 votes
 constexpr uint32_t kMaxSpins = 1u << 20;  // ~1 s of s_sleep: only a broken protocol gets there
 
 MQ_D uint32_t lds_peek(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -328,6 +332,25 @@ MQ_D void load_wave_tile(const int8_t* const* __restrict__ cols, const int64_t* 
   }
 }
 
+// one raw record folded into a heavy hitter's partial row (8-byte LDS slots, internal op order)
+MQ_D void hot_apply(int op, int64_t* s, int64_t vb, bool is_null) {
+  if (op == SO_COUNT) {
+    atomicAdd((unsigned long long*)s, 1ull);
+    return;
+  }
+  if (is_null) return;
+  switch (op) {
+    case SO_COUNT_NN: atomicAdd((unsigned long long*)s, 1ull); break;
+    case SO_SUM_I: atomicAdd((unsigned long long*)s, (unsigned long long)vb); break;
+    case SO_SUM_F: atomicAdd((double*)s, bits_dbl(vb)); break;
+    case SO_MIN_I: atomicMin((long long*)s, (long long)vb); break;
+    case SO_MAX_I: atomicMax((long long*)s, (long long)vb); break;
+    case SO_MIN_F: a_minmax_f64<true, false, false>(s, bits_dbl(vb), 0.0); break;
+    case SO_MAX_F: a_minmax_f64<true, true, false>(s, bits_dbl(vb), 0.0); break;
+    default: break;
+  }
+}
+
 template <typename FT, typename VT>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows, int n_frags,
@@ -339,11 +362,30 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
   uint32_t* written = cursor + g.P;                                 // [P]
   uint32_t* flushed = written + g.P;                                // [P]
   uint32_t* done = flushed + g.P;                                   // producer waves finished
+  uint32_t* n_hot = done + 1;                                       // keys promoted so far
+  // Heavy hitters.  A key that owns a sizeable share of the rows would overflow its partition's
+  // runs and throttle everybody on one staging line, so each workgroup keeps a small table of
+  // such keys and folds their records into partial rows right here (spilled once, at the end).
+  // Detection is a per-slot Misra-Gries counter fed by 1 record in 16: a key is promoted after
+  // kHotPromote net sampled sightings in its slot — uniform keys never get there.  Until the
+  // first promotion the per-record cost is zero (one LDS word read per wave tile).  Promotion
+  // only changes where LATER records of the key go, so exactness does not depend on the heuristic.
+  int64_t* hot_key = (int64_t*)(smem_raw + ((kStageRecs * sizeof(Rec) + (size_t)g.P * 12 + 8 + 15) & ~(size_t)15));
+  int64_t* cand_key = hot_key + kHotSlots;
+  int64_t* hot_slot = cand_key + kHotSlots;                         // [ns_int][kHotSlots]
+  uint32_t* cand_cnt = (uint32_t*)(hot_slot + (size_t)g.ns_int * kHotSlots);
   const int t = threadIdx.x, b = blockIdx.x, G = gridDim.x;
   const int wave = t >> 6, lane = t & 63;
   const int lgL = g.lgL;
   const uint32_t Lm1 = g.L - 1;
-  for (int i = t; i < 3 * g.P + 1; i += kPartBlock) cursor[i] = 0;
+  for (int i = t; i < 3 * g.P + 2; i += kPartBlock) cursor[i] = 0;
+  for (int i = t; i < kHotSlots; i += kPartBlock) {
+    hot_key[i] = kEmptyKey64;
+    cand_key[i] = kEmptyKey64;
+    cand_cnt[i] = 0;
+    for (int m = 0; m < g.ns_int; ++m)
+      hot_slot[m * kHotSlots + i] = op_identity_dev((int)((g.ops_packed >> (4 * m)) & 15u));
+  }
   __syncthreads();
 
   if (wave < kProdWaves) {
@@ -352,6 +394,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     int64_t c_key[4], c_val[4];
     uint32_t c_pid[4], c_slot[4];
     uint32_t c_mask = 0;
+    uint32_t tile_no = 0;
     // flattened walk over the fragments in super-tiles of 12 wave-tiles; workgroup b owns the
     // super-tiles == b (mod G), wave w the w-th wave-tile of each
     int f = 0;
@@ -395,17 +438,54 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
       if (have_next) load_wave_tile<FT, VT>(cols, num_rows, n_cols, flt.col, kcol, vcol, f, quad_of(), nxt);
 
       retry_pending();
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      // Heavy-hitter work is wave-uniform: a tile looks at the hot table only once a key has been
+      // promoted, and only every 16th tile of a wave votes — all other tiles run the plain path
+      // with no per-record cost.
+      ++tile_no;
+      const bool any_hot = lds_peek(n_hot) != 0;
+      const bool voting = (tile_no & ((1u << kHotSampleLg) - 1)) == 1;  // tiles 1, 17, 33, ...: a wave's first tile votes
+      auto one_row = [&](int i, auto hot_aware) {
         bool park = false;
         uint32_t p = 0, s = 0;
         int64_t vb = 0;
         if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i))) {
-          p = part_of(g.hm, home_of(g.hm, cur.k.v[i]));
-          s = atomicAdd(&cursor[p], 1u);
+          const int64_t key = cur.k.v[i];
+          const uint32_t h = murmur3_u64((uint64_t)key);
           vb = val_bits_of<VT>(quad_get(cur.v, i));
-          if (s >= g.cap) spill_raw(sl, g, cur.k.v[i], vb);  // run full
-          else park = !try_stage(cur.k.v[i], vb, p, s);
+          bool folded = false;
+          if (decltype(hot_aware)::value) {
+            const uint32_t hs = (h >> 9) & (kHotSlots - 1);
+            const int64_t hk = *(volatile int64_t*)&hot_key[hs];
+            if (hk == key) {  // heavy hitter: fold the record into its partial row
+              const bool is_null = g.val_nullable && vb == g.null_bits;
+              for (int m = 0; m < g.ns_int; ++m)
+                hot_apply((int)((g.ops_packed >> (4 * m)) & 15u), &hot_slot[m * kHotSlots + hs], vb, is_null);
+              folded = true;
+            } else if (voting && hk == kEmptyKey64) {  // slot still free: Misra-Gries vote
+              const int64_t ck = *(volatile int64_t*)&cand_key[hs];
+              if (ck == key) {
+                const uint32_t votes = atomicAdd(&cand_cnt[hs], 1u) + 1;
+                if (votes >= kHotPromote && votes < 0x80000000u &&
+                    atomicCAS((unsigned long long*)&hot_key[hs], (unsigned long long)kEmptyKey64,
+                              (unsigned long long)key) == (unsigned long long)kEmptyKey64)
+                  atomicAdd(n_hot, 1u);
+              } else {
+                const uint32_t c = *(volatile uint32_t*)&cand_cnt[hs];
+                if (c <= 1 || c > 0x7fffffffu) {  // the old candidate ran out of votes
+                  *(volatile int64_t*)&cand_key[hs] = key;
+                  *(volatile uint32_t*)&cand_cnt[hs] = 1;
+                } else {
+                  atomicSub(&cand_cnt[hs], 1u);
+                }
+              }
+            }
+          }
+          if (!folded) {
+            p = part_of(g.hm, home_from_hash(g.hm, h));
+            s = atomicAdd(&cursor[p], 1u);
+            if (s >= g.cap) spill_raw(sl, g, key, vb);  // run full
+            else park = !try_stage(key, vb, p, s);
+          }
         }
         // Line not open yet: park the record in pending slot i.  If an older record still
         // waits there, the WHOLE wave waits for the flushers and keeps retrying every
@@ -431,6 +511,13 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
           c_slot[i] = s;
           c_mask |= 1u << i;
         }
+      };
+      if (any_hot || voting) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) one_row(i, std::true_type{});
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) one_row(i, std::false_type{});
       }
       cur = nxt;
       have = have_next;
@@ -503,6 +590,14 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
       const uint32_t c = lds_peek(&cursor[p]);
       cnt[(size_t)p * g.B + b] = c < g.cap ? c : g.cap;
     }
+  }
+  // the heavy hitters' partial rows go to the spill list (merged by k_spill_merge)
+  for (int i = fid; i < kHotSlots; i += kFlushWaves * 64) {
+    const int64_t key = hot_key[i];
+    if (key == kEmptyKey64) continue;
+    int64_t part[kMaxInt];
+    for (int m = 0; m < kMaxInt; ++m) part[m] = m < g.ns_int ? hot_slot[m * kHotSlots + i] : 0;
+    spill_append(sl, key, part, g.ns_int);
   }
 }
 
@@ -911,39 +1006,95 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
 }
 
 // ------------------------------------------------------------------------- phase 3
-__global__ __launch_bounds__(256) void k_spill_merge(PartSlots ps, TableArgs tab, SpillList sl, int ns) {
-  uint32_t n = *sl.count;
-  if (n > kSpillCap) n = kSpillCap;
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const SpillEntry& e = sl.entries[i];
-    int64_t* slots = baseline_find_or_insert(tab.out, tab.entry_count, tab.row_quad, 8, e.key);
-    if (!slots) {
-      atomicCAS(sl.d_err, 0, -1);  // out of group slots: the caller resizes and retries
+// merge one partial row (internal slots) into the output table with the reference's insert-or-find
+MQ_D void merge_partial_global(const PartSlots& ps, const TableArgs& tab, const SpillList& sl, int64_t key,
+                               const int64_t* part) {
+  int64_t* slots = baseline_find_or_insert(tab.out, tab.entry_count, tab.row_quad, 8, key);
+  if (!slots) {
+    atomicCAS(sl.d_err, 0, -1);  // out of group slots: the caller resizes and retries
+    return;
+  }
+  const bool no_value = ps.nn_slot >= 0 && part[ps.nn_slot] == 0;
+  for (int j = 0; j < tab.sp.n; ++j) {
+    const int m = ps.out_map[j];
+    if (m < 0) {
+      if (tab.sp.op[j] == SO_KEY) MQ_STORE64(slots + j, key);
       continue;
     }
-    const bool no_value = ps.nn_slot >= 0 && e.part[ps.nn_slot] == 0;
-    for (int j = 0; j < tab.sp.n; ++j) {
-      const int m = ps.out_map[j];
-      if (m < 0) {
-        if (tab.sp.op[j] == SO_KEY) MQ_STORE64(slots + j, e.key);
-        continue;
-      }
-      if (!tab.sp.null_init[j]) {
-        global_merge(tab.sp.op[j], slots + j, e.part[m]);
-        continue;
-      }
-      if (no_value) continue;  // the partial holds no value: the slot keeps what it has (NULL or not)
-      const int64_t v = e.part[m];
-      switch (tab.sp.op[j]) {  // slot starts at the NULL sentinel: first value overwrites it
-        case SO_SUM_I: a_sum_i64_skip<true>(slots + j, v, ps.null_bits); break;
-        case SO_SUM_F: a_sum_f64_skip<true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
-        case SO_MIN_I: a_min_i64_skip<true>(slots + j, v, ps.null_bits); break;
-        case SO_MAX_I: a_max_i64_skip<true>(slots + j, v, ps.null_bits); break;
-        case SO_MIN_F: a_minmax_f64<true, false, true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
-        case SO_MAX_F: a_minmax_f64<true, true, true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
-        default: break;
-      }
+    if (!tab.sp.null_init[j]) {
+      global_merge(tab.sp.op[j], slots + j, part[m]);
+      continue;
     }
+    if (no_value) continue;  // the partial holds no value: the slot keeps what it has (NULL or not)
+    const int64_t v = part[m];
+    switch (tab.sp.op[j]) {  // slot starts at the NULL sentinel: first value overwrites it
+      case SO_SUM_I: a_sum_i64_skip<true>(slots + j, v, ps.null_bits); break;
+      case SO_SUM_F: a_sum_f64_skip<true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
+      case SO_MIN_I: a_min_i64_skip<true>(slots + j, v, ps.null_bits); break;
+      case SO_MAX_I: a_max_i64_skip<true>(slots + j, v, ps.null_bits); break;
+      case SO_MIN_F: a_minmax_f64<true, false, true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
+      case SO_MAX_F: a_minmax_f64<true, true, true>(slots + j, bits_dbl(v), bits_dbl(ps.null_bits)); break;
+      default: break;
+    }
+  }
+}
+
+// partial (op) partial in LDS, 8-byte slots
+MQ_D void lds_fold_partial(int op, int64_t* s, int64_t v) {
+  switch (op) {
+    case SO_COUNT:
+    case SO_COUNT_NN:
+    case SO_SUM_I: atomicAdd((unsigned long long*)s, (unsigned long long)v); break;
+    case SO_SUM_F: atomicAdd((double*)s, bits_dbl(v)); break;
+    case SO_MIN_I: atomicMin((long long*)s, (long long)v); break;
+    case SO_MAX_I: atomicMax((long long*)s, (long long)v); break;
+    case SO_MIN_F: a_minmax_f64<true, false, false>(s, bits_dbl(v), 0.0); break;
+    case SO_MAX_F: a_minmax_f64<true, true, false>(s, bits_dbl(v), 0.0); break;
+    default: break;
+  }
+}
+
+// The spill list is dominated by repeats of a few keys when it is long (a moderately hot key
+// that overflowed its runs): every workgroup first folds its 1024-entry slice in a small LDS
+// table, so the output table sees one insert-or-find per distinct key and slice instead of one
+// contended atomic chain per entry.
+constexpr int kSpillSlice = 1024;
+constexpr int kSpillLds = 2048;  // LDS table entries (50 % fill at worst)
+__global__ __launch_bounds__(256) void k_spill_merge(PartSlots ps, TableArgs tab, SpillList sl, int ns) {
+  __shared__ int64_t s_key[kSpillLds];
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [ns][kSpillLds] partial slots
+  int64_t* s_part = (int64_t*)smem_raw;
+  uint32_t n = *sl.count;
+  if (n > kSpillCap) n = kSpillCap;
+  for (uint32_t base = blockIdx.x * kSpillSlice; base < n; base += gridDim.x * kSpillSlice) {
+    for (int i = threadIdx.x; i < kSpillLds; i += 256) {
+      s_key[i] = kEmptyKey64;
+      for (int m = 0; m < ns; ++m) s_part[m * kSpillLds + i] = ps.int_init[m];
+    }
+    __syncthreads();
+    const uint32_t end = base + kSpillSlice < n ? base + kSpillSlice : n;
+    for (uint32_t i = base + threadIdx.x; i < end; i += 256) {
+      const SpillEntry& e = sl.entries[i];
+      uint32_t h = murmur3_u64((uint64_t)e.key) & (kSpillLds - 1);
+      for (;;) {  // at most kSpillSlice distinct keys in kSpillLds slots: always terminates
+        int64_t k = *(volatile int64_t*)&s_key[h];
+        if (k == kEmptyKey64)
+          k = (int64_t)atomicCAS((unsigned long long*)&s_key[h], (unsigned long long)kEmptyKey64,
+                                 (unsigned long long)e.key);
+        if (k == kEmptyKey64 || k == e.key) break;
+        h = (h + 1) & (kSpillLds - 1);
+      }
+      for (int m = 0; m < ns; ++m) lds_fold_partial(ps.int_op[m], &s_part[m * kSpillLds + h], e.part[m]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSpillLds; i += 256) {
+      const int64_t key = s_key[i];
+      if (key == kEmptyKey64) continue;
+      int64_t part[kMaxInt];
+      for (int m = 0; m < kMaxInt; ++m) part[m] = m < ns ? s_part[m * kSpillLds + i] : 0;
+      merge_partial_global(ps, tab, sl, key, part);
+    }
+    __syncthreads();
   }
 }
 
@@ -1108,7 +1259,9 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
   }
   h.chunk_rows = chunk_rows;
-  h.lds1 = kStageRecs * sizeof(Rec) + (size_t)P * 12 + 16;  // staging lines + cursor / written / flushed + done
+  // staging lines + cursor / written / flushed + done + heavy-hitter table
+  h.lds1 = kStageRecs * sizeof(Rec) + (size_t)P * 12 + 48 + (size_t)kHotSlots * (8 + 8 + 8 * (size_t)n_int + 4);
+  if (h.lds1 > 160 * 1024) return false;
   h.lds2 = (size_t)h.g.E * entry_bytes + (size_t)((hm.S2 + 31) / 32) * 4 + (size_t)h.g.B * 4;
   return h.lds2 <= 160 * 1024;
 }
@@ -1247,7 +1400,10 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                        tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_spill_merge, dim3(256), dim3(256), 0, s, h.ps, tab, sl, h.g.ns_int);
+    (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              h.g.ns_int * kSpillLds * 8);
+    hipLaunchKernelGGL(k_spill_merge, dim3(512), dim3(256), (size_t)h.g.ns_int * kSpillLds * 8, s, h.ps, tab, sl,
+                       h.g.ns_int);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     // spilled_rows reports the last chunk's list; the word is re-armed for the next chunk

@@ -528,3 +528,33 @@ def test_topk_on_device(torch_cuda, oracle, order):
         by_key = {int(r[0]): r for r in live}
         assert all((by_key[int(r[0])] == r).all() for r in got)
         assert len({int(r[0]) for r in got}) == got_n
+
+
+def test_heavy_hitters_at_scale(torch_cuda):
+    """Skewed keys at a size the oracle does not visit (128 M rows): one key owns 25 % of the
+    rows (promoted to the scatter kernel's heavy-hitter table), one owns 0.3 % (stays below the
+    promotion threshold, overflows its runs and goes through the spill list), the rest is
+    uniform over 1 M keys.  The partitioned member must agree with the direct-atomic member
+    (integer quads bit-exact, fp64 sums to 1e-9) and stay on its own path."""
+    from heavydb_amd import synth
+    from heavydb_amd.executor import Executor
+    torch = torch_cuda
+    total, n_keys = 128_000_000, 1_000_000
+    ra, fr, info = synth.cfg3(torch, total, filtered=True, n_keys=n_keys)
+    key = fr.keepalive[0]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    u = torch.rand(key.numel(), device="cuda", generator=g)
+    key[u < 0.25] = 7 + 1000003 * 4242
+    key[(u >= 0.25) & (u < 0.253)] = 7 + 1000003 * 777
+    del u
+    torch.cuda.synchronize()
+    ex = Executor(0)
+    rs = ex.executeWorkUnit(ra, fr, allow_retry=False)
+    assert rs.report.variant == 2 and rs.report.kernel_name.decode() == "k_part_scatter"
+    rs1 = ex.executeWorkUnit(ra, fr, kernel_variant=1, allow_retry=False)
+    compare_buffers(rs.getQueryMemDesc(), rs1.getStorage(), rs.getStorage(), 1e-9)
+    check_probe_invariant(rs.getQueryMemDesc(), rs.getStorage())
+    ival, dval, nul = rs.fetch()
+    hot = ival[ival[:, 0] == 7 + 1000003 * 4242]
+    assert hot.shape[0] == 1 and abs(hot[0, 1] / (total * 0.5 * 0.25) - 1) < 0.01
