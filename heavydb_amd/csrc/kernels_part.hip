@@ -50,17 +50,14 @@ constexpr int kStageRecs = 8192;       // staged records per workgroup (128 KB o
 constexpr int kSegRecs = 8;            // records per 128-byte segment (one owner lane each)
 constexpr int kMaxInt = 8;             // internal (LDS) partial slots per group
 constexpr int kMaxSub = 4;             // sub-ranges per partition
-constexpr uint32_t kSpillCap = 1u << 22;  // 4 M partial rows (288 MB of the scratch)
+constexpr uint32_t kSpillMin = 1u << 22;  // spill list: at least 4 M partial rows, else 1/16 of a chunk's rows
 
 struct alignas(16) Rec {
   int64_t key;
   int64_t val;
 };
 
-struct SpillEntry {
-  int64_t key;
-  int64_t part[kMaxInt];
-};
+// spill list entry: {key, ns_int partial slots} = (1 + ns_int) x 8 bytes, packed
 
 // home slot arithmetic with plan-time reciprocals: q' = mulhi(x, floor(2^32 / d)) is
 // floor(x / d) or one less (x / d - x * floor(2^32 / d) / 2^32 < x / 2^32 < 1), so one
@@ -140,8 +137,10 @@ struct TableArgs {
 
 struct SpillList {
   uint32_t* count;     // device word
-  SpillEntry* entries;
+  int64_t* entries;    // [cap][1 + ns_int]
   int32_t* d_err;      // [0] reference error code, [1] spill list overflow
+  uint32_t cap;
+  int32_t stride;      // quads per entry = 1 + ns_int
 };
 
 // LDS-only barrier: waits for this wave's LDS traffic, NOT for its outstanding global loads,
@@ -150,13 +149,13 @@ MQ_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "
 
 MQ_D void spill_append(const SpillList& sl, int64_t key, const int64_t* part, int n) {
   const uint32_t i = atomicAdd(sl.count, 1u);
-  if (i >= kSpillCap) {
+  if (i >= sl.cap) {
     atomicExch(sl.d_err + 1, 1);
     return;
   }
-  SpillEntry& e = sl.entries[i];
-  e.key = key;
-  for (int j = 0; j < n; ++j) e.part[j] = part[j];
+  int64_t* e = sl.entries + (size_t)i * sl.stride;
+  e[0] = key;
+  for (int j = 0; j < n; ++j) e[1 + j] = part[j];
 }
 MQ_D void spill_record(const SpillList& sl, const PartSlots& ps, int ns, int64_t key, int64_t vb) {
   int64_t part[kMaxInt];
@@ -183,6 +182,7 @@ struct ScatterArgs {
   HomeMap hm;
   int32_t ns_int;
   uint32_t ops_packed;  // internal slot ops, 4 bits each (for the partial row of a spilled record)
+  int32_t n_cand;       // heavy-hitter candidate slots (power of two)
   int32_t val_nullable;
   int64_t null_bits;
 };
@@ -272,11 +272,39 @@ MQ_D void flush_segments(bool need, uint32_t dst_rec, const Rec* __restrict__ st
   }
 }
 
-MQ_D void spill_raw(const SpillList& sl, const ScatterArgs& g, int64_t key, int64_t vb) {
-  int64_t part[kMaxInt];
+// Spill list positions for phase 1 are handed out from workgroup-private blocks of
+// kSpillBlock entries: one global atomic per block instead of one per record (a skewed input
+// spills millions of records; one shared counter would serialise them at ~12 ns each).
+// blk = {next, end} packed in one LDS word; ~0 = a lane is fetching the next block.
+constexpr uint32_t kSpillBlock = 256;
+constexpr unsigned long long kSpillBusy = ~0ull;
+MQ_D uint32_t spill_slot_from_block(const SpillList& sl, unsigned long long* blk) {
+  for (;;) {
+    const unsigned long long w = __hip_atomic_load(blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (w == kSpillBusy) continue;
+    const uint32_t next = (uint32_t)w, end = (uint32_t)(w >> 32);
+    if (next < end) {
+      if (atomicCAS(blk, w, ((unsigned long long)end << 32) | (next + 1)) == w) return next;
+    } else if (atomicCAS(blk, w, kSpillBusy) == w) {
+      // this lane fetches the next block and publishes it before leaving the loop (the other
+      // lanes of the wave spin in this very loop)
+      const uint32_t base = atomicAdd(sl.count, kSpillBlock);
+      __hip_atomic_store(blk, ((unsigned long long)(base + kSpillBlock) << 32) | (base + 1), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_WORKGROUP);
+      return base;
+    }
+  }
+}
+MQ_D void spill_raw(const SpillList& sl, const ScatterArgs& g, unsigned long long* blk, int64_t key, int64_t vb) {
+  const uint32_t i = spill_slot_from_block(sl, blk);
+  if (i >= sl.cap) {
+    atomicExch(sl.d_err + 1, 1);
+    return;
+  }
   const bool is_null = g.val_nullable && vb == g.null_bits;
-  for (int j = 0; j < kMaxInt; ++j) part[j] = raw_partial((int)((g.ops_packed >> (4 * j)) & 15u), vb, is_null);
-  spill_append(sl, key, part, g.ns_int);
+  int64_t* e = sl.entries + (size_t)i * sl.stride;
+  e[0] = key;
+  for (int j = 0; j < g.ns_int; ++j) e[1 + j] = raw_partial((int)((g.ops_packed >> (4 * j)) & 15u), vb, is_null);
 }
 
 // Role split inside the 16-wave workgroup: waves 0..11 PRODUCE (load, filter, hash, take a
@@ -363,6 +391,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
   uint32_t* flushed = written + g.P;                                // [P]
   uint32_t* done = flushed + g.P;                                   // producer waves finished
   uint32_t* n_hot = done + 1;                                       // keys promoted so far
+  unsigned long long* sp_blk = (unsigned long long*)(((uintptr_t)(n_hot + 1) + 7) & ~(uintptr_t)7);  // spill block {next, end}
   // Heavy hitters.  A key that owns a sizeable share of the rows would overflow its partition's
   // runs and throttle everybody on one staging line, so each workgroup keeps a small table of
   // such keys and folds their records into partial rows right here (spilled once, at the end).
@@ -371,18 +400,19 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
   // first promotion the per-record cost is zero (one LDS word read per wave tile).  Promotion
   // only changes where LATER records of the key go, so exactness does not depend on the heuristic.
   int64_t* hot_key = (int64_t*)(smem_raw + ((kStageRecs * sizeof(Rec) + (size_t)g.P * 12 + 8 + 15) & ~(size_t)15));
-  int64_t* cand_key = hot_key + kHotSlots;
-  int64_t* hot_slot = cand_key + kHotSlots;                         // [ns_int][kHotSlots]
-  uint32_t* cand_cnt = (uint32_t*)(hot_slot + (size_t)g.ns_int * kHotSlots);
+  int64_t* hot_slot = hot_key + kHotSlots;                          // [ns_int][kHotSlots]
+  // candidates: {16-bit key fingerprint, 16-bit vote count} per slot, many more slots than
+  // the hot table so that a key with ~0.05 % of the rows still out-votes its slot's noise
+  uint32_t* cand = (uint32_t*)(hot_slot + (size_t)g.ns_int * kHotSlots);  // [g.n_cand]
   const int t = threadIdx.x, b = blockIdx.x, G = gridDim.x;
   const int wave = t >> 6, lane = t & 63;
   const int lgL = g.lgL;
   const uint32_t Lm1 = g.L - 1;
   for (int i = t; i < 3 * g.P + 2; i += kPartBlock) cursor[i] = 0;
+  for (int i = t; i < g.n_cand; i += kPartBlock) cand[i] = 0;
+  if (t == 0) *sp_blk = 0;  // next == end: the first spill fetches a block
   for (int i = t; i < kHotSlots; i += kPartBlock) {
     hot_key[i] = kEmptyKey64;
-    cand_key[i] = kEmptyKey64;
-    cand_cnt[i] = 0;
     for (int m = 0; m < g.ns_int; ++m)
       hot_slot[m * kHotSlots + i] = op_identity_dev((int)((g.ops_packed >> (4 * m)) & 15u));
   }
@@ -461,29 +491,27 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
               for (int m = 0; m < g.ns_int; ++m)
                 hot_apply((int)((g.ops_packed >> (4 * m)) & 15u), &hot_slot[m * kHotSlots + hs], vb, is_null);
               folded = true;
-            } else if (voting && hk == kEmptyKey64) {  // slot still free: Misra-Gries vote
-              const int64_t ck = *(volatile int64_t*)&cand_key[hs];
-              if (ck == key) {
-                const uint32_t votes = atomicAdd(&cand_cnt[hs], 1u) + 1;
-                if (votes >= kHotPromote && votes < 0x80000000u &&
+            } else if (voting && hk == kEmptyKey64) {  // hot slot still free: Misra-Gries vote
+              const uint32_t cs = h & (uint32_t)(g.n_cand - 1);
+              const uint32_t fp = (h >> 16) << 16;
+              const uint32_t c = *(volatile uint32_t*)&cand[cs];
+              if ((c & 0xffff0000u) == fp && (c & 0xffffu)) {
+                const uint32_t votes = (atomicAdd(&cand[cs], 1u) + 1) & 0xffffu;
+                if (votes >= kHotPromote && votes < 0x8000u &&
                     atomicCAS((unsigned long long*)&hot_key[hs], (unsigned long long)kEmptyKey64,
                               (unsigned long long)key) == (unsigned long long)kEmptyKey64)
                   atomicAdd(n_hot, 1u);
+              } else if ((c & 0xffffu) <= 1 || (c & 0xffffu) >= 0x8000u) {
+                *(volatile uint32_t*)&cand[cs] = fp | 1u;  // the old candidate ran out of votes
               } else {
-                const uint32_t c = *(volatile uint32_t*)&cand_cnt[hs];
-                if (c <= 1 || c > 0x7fffffffu) {  // the old candidate ran out of votes
-                  *(volatile int64_t*)&cand_key[hs] = key;
-                  *(volatile uint32_t*)&cand_cnt[hs] = 1;
-                } else {
-                  atomicSub(&cand_cnt[hs], 1u);
-                }
+                atomicSub(&cand[cs], 1u);
               }
             }
           }
           if (!folded) {
             p = part_of(g.hm, home_from_hash(g.hm, h));
             s = atomicAdd(&cursor[p], 1u);
-            if (s >= g.cap) spill_raw(sl, g, key, vb);  // run full
+            if (s >= g.cap) spill_raw(sl, g, sp_blk, key, vb);  // run full
             else park = !try_stage(key, vb, p, s);
           }
         }
@@ -590,6 +618,12 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
       const uint32_t c = lds_peek(&cursor[p]);
       cnt[(size_t)p * g.B + b] = c < g.cap ? c : g.cap;
     }
+  }
+  // the unused tail of this workgroup's last spill block must read as "no entry"
+  {
+    const unsigned long long w = *sp_blk;
+    const uint32_t next = (uint32_t)w, end = (uint32_t)(w >> 32);
+    for (uint32_t i = next + fid; i < end && i < sl.cap; i += kFlushWaves * 64) sl.entries[(size_t)i * sl.stride] = kEmptyKey64;
   }
   // the heavy hitters' partial rows go to the spill list (merged by k_spill_merge)
   for (int i = fid; i < kHotSlots; i += kFlushWaves * 64) {
@@ -1065,7 +1099,7 @@ __global__ __launch_bounds__(256) void k_spill_merge(PartSlots ps, TableArgs tab
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];  // [ns][kSpillLds] partial slots
   int64_t* s_part = (int64_t*)smem_raw;
   uint32_t n = *sl.count;
-  if (n > kSpillCap) n = kSpillCap;
+  if (n > sl.cap) n = sl.cap;
   for (uint32_t base = blockIdx.x * kSpillSlice; base < n; base += gridDim.x * kSpillSlice) {
     for (int i = threadIdx.x; i < kSpillLds; i += 256) {
       s_key[i] = kEmptyKey64;
@@ -1074,17 +1108,19 @@ __global__ __launch_bounds__(256) void k_spill_merge(PartSlots ps, TableArgs tab
     __syncthreads();
     const uint32_t end = base + kSpillSlice < n ? base + kSpillSlice : n;
     for (uint32_t i = base + threadIdx.x; i < end; i += 256) {
-      const SpillEntry& e = sl.entries[i];
-      uint32_t h = murmur3_u64((uint64_t)e.key) & (kSpillLds - 1);
+      const int64_t* e = sl.entries + (size_t)i * sl.stride;
+      const int64_t ekey = e[0];
+      if (ekey == kEmptyKey64) continue;  // padding of a partly used spill block
+      uint32_t h = murmur3_u64((uint64_t)ekey) & (kSpillLds - 1);
       for (;;) {  // at most kSpillSlice distinct keys in kSpillLds slots: always terminates
         int64_t k = *(volatile int64_t*)&s_key[h];
         if (k == kEmptyKey64)
           k = (int64_t)atomicCAS((unsigned long long*)&s_key[h], (unsigned long long)kEmptyKey64,
-                                 (unsigned long long)e.key);
-        if (k == kEmptyKey64 || k == e.key) break;
+                                 (unsigned long long)ekey);
+        if (k == kEmptyKey64 || k == ekey) break;
         h = (h + 1) & (kSpillLds - 1);
       }
-      for (int m = 0; m < ns; ++m) lds_fold_partial(ps.int_op[m], &s_part[m * kSpillLds + h], e.part[m]);
+      for (int m = 0; m < ns; ++m) lds_fold_partial(ps.int_op[m], &s_part[m * kSpillLds + h], e[1 + m]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < kSpillLds; i += 256) {
@@ -1117,6 +1153,8 @@ struct PartPlanHost {
   int64_t cnt_bytes;      // run lengths
   int64_t scratch_bytes;  // runs + lengths + spill list
   size_t lds1, lds2;
+  uint32_t spill_cap;     // spill list entries
+  int n_cand;             // heavy-hitter candidate slots in phase 1
   int op_mask;            // set of internal ops (bit per SlotOp)
 };
 
@@ -1236,7 +1274,6 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   // chunking: worst case every row survives the filter; shrink the chunk until the runs
   // (1.2 x mean + 6 sigma + a line of slack per run) fit the scratch cap, never below one
   // fragment
-  const int64_t spill_bytes = 256 + (int64_t)kSpillCap * (int64_t)sizeof(SpillEntry);
   int64_t chunk_rows = fv.total_rows > 0 ? fv.total_rows : 1;
   if (chunk_rows > 0xfff00000ll) chunk_rows = 0xfff00000ll;  // 32-bit LDS counters per chunk
   for (;;) {
@@ -1253,6 +1290,13 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     h.g.cap = (uint32_t)cap;
     h.rec_bytes = (int64_t)P * h.g.B * (int64_t)cap * (int64_t)sizeof(Rec);
     h.cnt_bytes = ((int64_t)P * h.g.B * 4 + 255) & ~255ll;
+    // spill list: room for 1/16 of the chunk's rows (skewed keys overflow their runs by a few
+    // per cent of the records), at least kSpillMin entries
+    int64_t spill_cap = chunk_rows / 16;
+    if (spill_cap < (int64_t)kSpillMin) spill_cap = kSpillMin;
+    if (spill_cap > 0x7fffffffll) spill_cap = 0x7fffffffll;
+    h.spill_cap = (uint32_t)spill_cap;
+    const int64_t spill_bytes = 256 + spill_cap * 8 * (int64_t)(1 + n_int);
     h.scratch_bytes = h.rec_bytes + h.cnt_bytes + spill_bytes;
     if (h.scratch_bytes <= scratch_cap || chunk_rows <= fv.max_frag_rows) break;
     chunk_rows = (int64_t)(chunk_rows * 0.9);
@@ -1260,8 +1304,13 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   }
   h.chunk_rows = chunk_rows;
   // staging lines + cursor / written / flushed + done + heavy-hitter table
-  h.lds1 = kStageRecs * sizeof(Rec) + (size_t)P * 12 + 48 + (size_t)kHotSlots * (8 + 8 + 8 * (size_t)n_int + 4);
-  if (h.lds1 > 160 * 1024) return false;
+  {
+    const size_t fixed = kStageRecs * sizeof(Rec) + (size_t)P * 12 + 48 + (size_t)kHotSlots * (8 + 8 * (size_t)n_int);
+    h.n_cand = 2048;
+    while (h.n_cand > 64 && fixed + (size_t)h.n_cand * 4 > 160 * 1024) h.n_cand >>= 1;
+    h.lds1 = fixed + (size_t)h.n_cand * 4;
+    if (h.lds1 > 160 * 1024) return false;
+  }
   h.lds2 = (size_t)h.g.E * entry_bytes + (size_t)((hm.S2 + 31) / 32) * 4 + (size_t)h.g.B * 4;
   return h.lds2 <= 160 * 1024;
 }
@@ -1326,7 +1375,7 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   Rec* recs = (Rec*)scratch;
   uint32_t* cnt = (uint32_t*)((char*)scratch + h.rec_bytes);
   char* spill_base = (char*)scratch + h.rec_bytes + h.cnt_bytes;
-  SpillList sl{(uint32_t*)spill_base, (SpillEntry*)(spill_base + 256), d_err};
+  SpillList sl{(uint32_t*)spill_base, (int64_t*)(spill_base + 256), d_err, h.spill_cap, 1 + h.g.ns_int};
   hipError_t e = hipMemsetAsync(spill_base, 0, 256, s);
   if (e != hipSuccess) return e;
   TableArgs tab{};
@@ -1368,6 +1417,7 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   sa.hm = h.g.hm;
   sa.ns_int = h.g.ns_int;
   sa.ops_packed = 0;
+  sa.n_cand = h.n_cand;
   for (int m = 0; m < h.g.ns_int; ++m) sa.ops_packed |= (uint32_t)(h.ps.int_op[m] & 15) << (4 * m);
   sa.val_nullable = h.ps.val_nullable;
   sa.null_bits = h.ps.null_bits;

@@ -12,7 +12,14 @@ rows = int(float(sys.argv[2])) if len(sys.argv) > 2 else 1_000_000_000
 for hot in [float(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ["0", "0.001", "0.01", "0.1", "0.3"])]:
     ra, fr, info = synth.cfg3(torch, rows, filtered=True)
     key = fr.keepalive[0]
-    if hot > 0:
+    if hot < 0:  # Zipf(s = 1) ranks: rank = n_keys ** u, u uniform -> P(rank) ~ 1 / rank
+        g = torch.Generator(device="cuda"); g.manual_seed(1)
+        step = 1 << 26
+        for lo in range(0, key.numel(), step):
+            u = torch.rand(min(step, key.numel() - lo), device="cuda", generator=g, dtype=torch.float64)
+            rank = torch.exp(u * 16.118095650958319).to(torch.int64).clamp_(0, 9_999_999)  # ln(1e7)
+            key[lo:lo + step] = rank * 1000003 + 7
+    elif hot > 0:
         g = torch.Generator(device="cuda"); g.manual_seed(1)
         step = 1 << 26
         for lo in range(0, key.numel(), step):
