@@ -16,10 +16,12 @@ MAX_QUALS = 4
 MAX_TARGETS = 8
 MAX_SLOTS = 16
 MAX_GROUP_COLS = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # mi355q_type
 INT8, INT16, INT32, INT64, DOUBLE = 1, 2, 3, 4, 5
+# mi355q_encoding
+ENC_NONE, ENC_FIXED, ENC_DICT, ENC_DATE_IN_DAYS = 0, 1, 2, 3
 # mi355q_op (SQLOps values)
 EQ, NE, LT, GT, LE, GE = 0, 2, 3, 4, 5, 6
 # mi355q_agg (SQLAgg values)
@@ -41,7 +43,8 @@ TYPE_WIDTH = {INT8: 1, INT16: 2, INT32: 4, INT64: 8, DOUBLE: 8}
 
 
 class ColDesc(C.Structure):
-    _fields_ = [("type", C.c_int32), ("nullable", C.c_int32)]
+    _fields_ = [("type", C.c_int32), ("nullable", C.c_int32), ("encoding", C.c_int32),
+                ("logical_type", C.c_int32)]
 
 
 class Qual(C.Structure):
@@ -55,7 +58,8 @@ class Target(C.Structure):
 
 class Range(C.Structure):
     _fields_ = [("valid", C.c_int32), ("has_nulls", C.c_int32), ("min", C.c_int64),
-                ("max", C.c_int64), ("fp_min", C.c_double), ("fp_max", C.c_double)]
+                ("max", C.c_int64), ("fp_min", C.c_double), ("fp_max", C.c_double),
+                ("bucket", C.c_int64)]
 
 
 class Plan(C.Structure):
@@ -93,11 +97,17 @@ class QMD(C.Structure):
         ("min_val", C.c_int64),
         ("max_val", C.c_int64),
         ("bucket", C.c_int64),
+        ("group_min", C.c_int64 * MAX_GROUP_COLS),
+        ("group_card", C.c_int64 * MAX_GROUP_COLS),
+        ("group_null_key", C.c_int64 * MAX_GROUP_COLS),
+        ("group_bucket", C.c_int64 * MAX_GROUP_COLS),
+        ("group_has_nulls", C.c_int32 * MAX_GROUP_COLS),
         ("has_nulls", C.c_int32),
         ("row_size", C.c_int32),
         ("key_bytes", C.c_int32),
         ("n_targets", C.c_int32),
         ("target_slot", C.c_int32 * MAX_TARGETS),
+        ("target_key_idx", C.c_int32 * MAX_TARGETS),
         ("target_skip_null", C.c_int32 * MAX_TARGETS),
         ("target_is_fp", C.c_int32 * MAX_TARGETS),
         ("target_agg", C.c_int32 * MAX_TARGETS),

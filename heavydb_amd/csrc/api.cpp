@@ -129,12 +129,7 @@ struct DevWord {
 RowInit make_row_init(const mi355q_qmd& q) {
   RowInit r{};
   r.row_quad = q.row_size / 8;
-  const int kq = q.key_bytes / 8;
-  for (int i = 0; i < kq; ++i) {
-    // key_width 4: low word EMPTY_KEY_32, high word (padding) 0
-    r.quad[i] = q.key_width == 4 ? (int64_t)(uint32_t)kEmptyKey32 : kEmptyKey64;
-  }
-  for (int s = 0; s < q.slot_count; ++s) r.quad[kq + s] = q.init_vals[s];
+  row_init_image(q, r.quad);
   return r;
 }
 
@@ -145,7 +140,7 @@ int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
   if (type_is_fp(jc.type)) return MI355Q_ERR_UNSUPPORTED;
   const mi355q_join_table* jt = p.join_table;
   d->join_col = p.join_outer_col;
-  d->join_type = jc.type;
+  d->join_type = col_type_code(jc);
   d->join_nullable = jc.nullable != 0;
   d->join_hash_type = jt->hash_type;
   d->join_buf = jt->buf;
@@ -167,7 +162,7 @@ int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
   // every distinct outer column the plan touches is read once per row
   bool used[MI355Q_MAX_COLS] = {false};
   for (int i = 0; i < p.n_quals; ++i) used[p.quals[i].col] = true;
-  if (p.n_group_cols) used[p.group_cols[0]] = true;
+  for (int g = 0; g < p.n_group_cols; ++g) used[p.group_cols[g]] = true;
   if (p.join_outer_col >= 0) used[p.join_outer_col] = true;
   for (int i = 0; i < p.n_targets; ++i) {
     if (p.targets[i].table == 0 && p.targets[i].col >= 0 && p.targets[i].agg != MI355Q_PROJECT_KEY)
@@ -307,26 +302,8 @@ static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void
   // layout-only device plan (targets for reduce/iteration)
   DevPlan& d = r->dplan;
   std::memset(&d, 0, sizeof(d));
-  d.n_targets = qmd->n_targets;
-  for (int i = 0; i < qmd->n_targets; ++i) {
-    DevTarget& t = d.targets[i];
-    t.agg = qmd->target_agg[i];
-    t.col = -1;
-    t.skip_null = qmd->target_skip_null[i];
-    t.slot = qmd->target_slot[i];
-    t.arg_fp = qmd->target_arg_is_fp[i];
-  }
-  d.slot_count = qmd->slot_count;
-  d.desc_type = qmd->desc_type;
-  d.keyless = qmd->keyless;
-  d.key_width = qmd->key_width;
-  d.row_quad = qmd->row_size / 8;
-  d.key_quad = qmd->key_bytes / 8;
-  d.entry_count = qmd->entry_count;
-  d.min_val = qmd->min_val;
-  d.max_val = qmd->max_val;
-  d.join_col = -1;
-  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) d.init_vals[i] = qmd->init_vals[i];
+  layout_from_qmd(*qmd, &d);
+  for (int i = 0; i < qmd->n_targets; ++i) d.targets[i].col = -1;
   if (device_buffer) {
     r->buf = (int64_t*)device_buffer;
   } else {
@@ -469,7 +446,8 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
       const int s = q.target_slot[t];
       const int agg = q.target_agg[t];
       if (agg == MI355Q_PROJECT_KEY && s < 0) {
-        ival[o] = q.key_width == 4 ? (int64_t) * (const int32_t*)row : row[0];
+        const int ki = q.target_key_idx[t];
+        ival[o] = q.key_width == 4 ? (int64_t)((const int32_t*)row)[ki] : row[ki];
         is_null[o] = ival[o] == q.target_null[t];
         continue;
       }

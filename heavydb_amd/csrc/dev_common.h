@@ -25,17 +25,34 @@ constexpr int32_t kEmptyKey32 = INT32_MAX;  // GpuRtConstants.h:28
 constexpr double kNullDouble = 2.2250738585072014e-308;  // NULL_DOUBLE = DBL_MIN
 constexpr int64_t kNullDoubleBits = 0x0010000000000000ll;
 
-MQ_HD int type_width(int t) {
+// A column "type code" packs what the decoders need into one int: the storage type, the
+// encoding, the SQL type after decoding and (for encoded columns) the nullable flag:
+//   code = storage | encoding << 4 | logical << 8 | nullable << 12
+// A plain (unencoded) column's code is just its mi355q_type, so `code == MI355Q_INT64` style
+// tests keep selecting plain columns only — encoded columns never match the fast families.
+MQ_HD int tc_storage(int c) { return c & 15; }
+MQ_HD int tc_enc(int c) { return (c >> 4) & 15; }
+MQ_HD int tc_logical(int c) { return ((c >> 8) & 15) ? ((c >> 8) & 15) : (c & 15); }
+MQ_HD int tc_nullable(int c) { return (c >> 12) & 1; }
+MQ_HD int tc_make(int storage, int enc, int logical, int nullable) {
+  return storage | (enc << 4) | (logical << 8) | ((nullable ? 1 : 0) << 12);
+}
+
+MQ_HD int plain_width(int t) {
   return t == MI355Q_INT8 ? 1 : t == MI355Q_INT16 ? 2 : t == MI355Q_INT32 ? 4 : 8;
 }
-MQ_HD bool type_is_fp(int t) { return t == MI355Q_DOUBLE; }
+// bytes per element of the chunk as stored
+MQ_HD int type_width(int code) { return plain_width(tc_storage(code)); }
+MQ_HD bool type_is_fp(int code) { return tc_storage(code) == MI355Q_DOUBLE; }
 // Shared/InlineNullValues.h:29-35
-MQ_HD int64_t int_null_of(int t) {
+MQ_HD int64_t plain_int_null(int t) {
   return t == MI355Q_INT8    ? (int64_t)INT8_MIN
          : t == MI355Q_INT16 ? (int64_t)INT16_MIN
          : t == MI355Q_INT32 ? (int64_t)INT32_MIN
                              : INT64_MIN;
 }
+// NULL sentinel of the column's values AFTER decoding (the logical type's)
+MQ_HD int64_t int_null_of(int code) { return plain_int_null(tc_logical(code)); }
 
 MQ_HD uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 
@@ -74,6 +91,24 @@ MQ_HD uint32_t murmur3_u64(uint64_t key) {
   h1 ^= h1 >> 16;
   return h1;
 }
+// ... n 4-byte blocks (a multi-column key of n_words * 4 bytes), seed 0:
+// key_hash(key, key_count, key_byte_width) (GroupByRuntime.cpp:20-23)
+MQ_HD uint32_t murmur3_words(const uint32_t* w, int n_words) {
+  uint32_t h1 = 0;
+  for (int i = 0; i < n_words; ++i) {
+    uint32_t k1 = w[i] * 0xcc9e2d51u;
+    k1 = rotl32(k1, 15) * 0x1b873593u;
+    h1 ^= k1;
+    h1 = rotl32(h1, 13) * 5u + 0xe6546b64u;
+  }
+  h1 ^= (uint32_t)(n_words * 4);
+  h1 ^= h1 >> 16;
+  h1 *= 0x85ebca6bu;
+  h1 ^= h1 >> 13;
+  h1 *= 0xc2b2ae35u;
+  h1 ^= h1 >> 16;
+  return h1;
+}
 // MurmurHash1 (MurmurHash1Inl.h:22-62) of an int64 key, seed 0 — the keyed join hash
 // (JoinHashTableQueryRuntime.cpp:63, HashJoinRuntime.cpp:514).
 MQ_HD uint32_t murmur1_u64(uint64_t key) {
@@ -101,12 +136,47 @@ MQ_HD uint64_t splitmix64(uint64_t x) {
 }
 
 // fixed_width_int_decode (DecodersImpl.h:27-55): sign-extending fixed-width load.
-MQ_HD int64_t decode_int(const int8_t* col, int type, int64_t pos) {
-  switch (type) {
+MQ_HD int64_t load_int(const int8_t* col, int t, int64_t pos) {
+  switch (t) {
     case MI355Q_INT8: return *(const int8_t*)(col + pos);
     case MI355Q_INT16: return *(const int16_t*)(col + pos * 2);
     case MI355Q_INT32: return *(const int32_t*)(col + pos * 4);
     default: return *(const int64_t*)(col + pos * 8);
+  }
+}
+constexpr int64_t kSecsPerDay = 86400;
+// Column element fetch for a type code: the plain load, or the encoded variants
+//   ENC_FIXED         fixed_width_int_decode + codgenAdjustFixedEncNull (ColumnIR.cpp:456-495):
+//                     the storage sentinel becomes the logical type's sentinel
+//   ENC_DICT          fixed_width_unsigned_decode (DecodersImpl.h:57-85) for 1/2-byte ids,
+//                     NULL = 255 / 65535 -> NULL_INT
+//   ENC_DATE_IN_DAYS  fixed_width_small_date_decode (DecodersImpl.h:130-139): days -> seconds,
+//                     storage NULL -> NULL_BIGINT
+MQ_HD int64_t decode_int(const int8_t* col, int code, int64_t pos) {
+  if (code < 16) return load_int(col, code, pos);
+  const int st = tc_storage(code);
+  switch (tc_enc(code)) {
+    case MI355Q_ENC_FIXED: {
+      const int64_t v = load_int(col, st, pos);
+      return (tc_nullable(code) && v == plain_int_null(st)) ? plain_int_null(tc_logical(code)) : v;
+    }
+    case MI355Q_ENC_DICT: {
+      if (st == MI355Q_INT8) {
+        const int64_t v = *(const uint8_t*)(col + pos);
+        return (tc_nullable(code) && v == 255) ? (int64_t)INT32_MIN : v;
+      }
+      if (st == MI355Q_INT16) {
+        const int64_t v = *(const uint16_t*)(col + pos * 2);
+        return (tc_nullable(code) && v == 65535) ? (int64_t)INT32_MIN : v;
+      }
+      return load_int(col, st, pos);
+    }
+    case MI355Q_ENC_DATE_IN_DAYS: {
+      const int64_t v = load_int(col, st, pos);
+      return v == plain_int_null(st) ? INT64_MIN : v * kSecsPerDay;
+    }
+    default:
+      return load_int(col, st, pos);
   }
 }
 // fixed_width_double_decode (DecodersImpl.h:121-128)
@@ -125,21 +195,29 @@ MQ_HD double bits_dbl(int64_t i) {
 
 // ------------------------------------------------------------------ device-side plan
 struct DevQual {
-  int32_t col, op, type, nullable;
+  int32_t col, op, type, nullable;  // type: type code of the column
   int64_t ival;
   double fval;
 };
 struct DevTarget {
-  int32_t agg, col, table, arg_type;
+  int32_t agg, col, table, arg_type;  // arg_type: type code of the argument column
   int32_t arg_nullable, skip_null, slot, arg_fp;
+  int32_t key_idx, pad_;  // PROJECT_KEY: which group column
 };
 struct DevPlan {
   int32_t n_cols, n_quals, n_targets, slot_count;
   DevQual quals[MI355Q_MAX_QUALS];
   DevTarget targets[MI355Q_MAX_TARGETS];
   int32_t desc_type, keyless, key_width, row_quad;
-  int32_t key_quad, group_col, group_type, group_nullable;
+  int32_t key_quad, group_col, group_type, group_nullable;  // first (or only) group column
   int64_t entry_count, min_val, max_val;
+  // all group columns (n_group == 1 repeats the fields above)
+  int32_t n_group, group_pad_;
+  int32_t group_cols[MI355Q_MAX_GROUP_COLS], group_types[MI355Q_MAX_GROUP_COLS];
+  int32_t group_translate[MI355Q_MAX_GROUP_COLS];  // perfect hash: NULL key -> group_null_key
+  int64_t group_min[MI355Q_MAX_GROUP_COLS], group_card[MI355Q_MAX_GROUP_COLS];
+  int64_t group_mul[MI355Q_MAX_GROUP_COLS], group_null_key[MI355Q_MAX_GROUP_COLS];
+  int64_t group_bucket[MI355Q_MAX_GROUP_COLS];  // 0 = not bucketed
   int64_t init_vals[MI355Q_MAX_SLOTS];
   // join
   int32_t join_col, join_type, join_nullable, join_hash_type;

@@ -8,7 +8,7 @@
 namespace mq {
 
 struct RowInit {           // one output row image: key quads then slot init values
-  int64_t quad[1 + MI355Q_MAX_SLOTS];
+  int64_t quad[MI355Q_MAX_GROUP_COLS + MI355Q_MAX_SLOTS];
   int32_t row_quad;
 };
 

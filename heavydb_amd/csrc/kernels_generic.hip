@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kBlock) void k_generic_lds(DevPlan p, int idx_targe
     const int64_t* src = s_tab + e * p.row_quad;
     if (is_empty_row(p, src, idx_target_as_key)) continue;
     int64_t* row = out + e * p.row_quad;
-    if (p.key_quad) MQ_STORE64(row, src[0]);
+    for (int k = p.key_quad - 1; k >= 0; --k) MQ_STORE64(row + k, src[k]);
     for (int i = 0; i < p.n_targets; ++i) {
       reduce_target<true>(p.targets[i], p.init_vals, row + p.key_quad, src + p.key_quad);
     }
@@ -132,26 +132,8 @@ __global__ __launch_bounds__(kBlock) void k_reduce(DevPlan p, int idx_target_as_
                                                     int32_t* __restrict__ d_err) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < that_entries; e += stride) {
-    const int64_t* src = that_rows + e * p.row_quad;
-    if (is_empty_row(p, src, idx_target_as_key)) continue;
-    int64_t* slots;
-    if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
-      const int64_t key = p.key_width == 4 ? (int64_t) * (const int32_t*)src : src[0];
-      slots = baseline_find_or_insert(this_buf, (uint32_t)p.entry_count, p.row_quad, p.key_width,
-                                      key);
-      if (!slots) {
-        atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
-        continue;
-      }
-    } else {
-      int64_t* row = this_buf + e * p.row_quad;
-      if (p.key_quad) MQ_STORE64(row, src[0]);
-      slots = row + p.key_quad;
-    }
-    const int64_t* that_slots = src + p.key_quad;
-    for (int i = 0; i < p.n_targets; ++i) {
-      reduce_target<true>(p.targets[i], p.init_vals, slots, that_slots);
-    }
+    const int32_t err = reduce_entry<true>(p, idx_target_as_key, this_buf, that_rows + e * p.row_quad, e);
+    if (err) atomicCAS(d_err, 0, err);
   }
 }
 
@@ -168,6 +150,10 @@ __global__ __launch_bounds__(kBlock) void k_count_nonempty(DevPlan p, int idx_ta
 }
 
 MQ_D uint32_t shard_of(const DevPlan& p, const int64_t* row, int n_parts) {
+  if (p.n_group > 1) {  // the whole key's hash, upper bits
+    const int n_words = p.n_group * (p.key_width / 4);
+    return (uint32_t)(((uint64_t)murmur3_words((const uint32_t*)row, n_words) * (uint64_t)n_parts) >> 32);
+  }
   if (p.key_width == 4) return murmur3_u32((uint32_t) * (const int32_t*)row) % (uint32_t)n_parts;
   // upper hash bits, so a shard's keys still spread over the whole local table
   return (uint32_t)(((uint64_t)murmur3_u64((uint64_t)row[0]) * (uint64_t)n_parts) >> 32);

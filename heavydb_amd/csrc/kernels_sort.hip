@@ -44,7 +44,7 @@ MQ_D uint64_t order_key_of(const DevPlan& p, const DevTarget& t, const int64_t* 
   uint64_t u;
   bool is_null = false;
   if (t.agg == MI355Q_PROJECT_KEY && t.slot < 0) {
-    const int64_t v = p.key_width == 4 ? (int64_t) * (const int32_t*)row : row[0];
+    const int64_t v = row_key_component(row, p.key_width, t.key_idx);
     is_null = v == null_pattern;
     u = (uint64_t)v ^ 0x8000000000000000ull;
   } else {

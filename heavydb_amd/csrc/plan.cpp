@@ -8,6 +8,8 @@
 //   get_keyless_info                                GroupByAndAggregate.cpp:489-648
 //   QueryMemoryDescriptor::init                     Descriptors/QueryMemoryDescriptor.cpp:240-446
 //   pick_baseline_key_width                         Descriptors/QueryMemoryDescriptor.cpp:113-146
+//   multi-column getColRangeInfo / perfect key hash GroupByAndAggregate.cpp:241-283,1546-1598
+//   get_col_decoder (encodings -> type codes)       ColumnIR.cpp (get_col_decoder), DecodersImpl.h
 //   ColSlotContext (slots per target)               Descriptors/ColSlotContext.cpp:35-100
 //   getRowSize                                      Descriptors/QueryMemoryDescriptor.cpp:848-860
 //   init_agg_val_vec / get_agg_initial_val          OutputBufferInitialization.cpp:24-84,132-289
@@ -33,6 +35,16 @@ struct ArgInfo {
 };
 
 bool valid_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_DOUBLE; }
+bool int_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_INT64; }
+
+constexpr int64_t kBaselineGroupbyThreshold = 1000000;  // g_baseline_groupby_threshold, Execute.cpp:113
+
+// getBucketedCardinality (GroupByAndAggregate.cpp:367-375)
+int64_t bucketed_cardinality(const mi355q_range& r) {
+  int64_t c = r.max - r.min;
+  if (r.bucket > 0) c /= r.bucket;
+  return c + 1 + (r.has_nulls ? 1 : 0);
+}
 
 // Initial slot value for an aggregate whose init type has `notnull`.
 int64_t initial_val(int agg, const ArgInfo& a, bool notnull) {
@@ -53,6 +65,27 @@ int64_t initial_val(int agg, const ArgInfo& a, bool notnull) {
 
 }  // namespace
 
+// mi355q_col_desc -> type code (dev_common.h); < 0 = invalid combination
+int col_type_code(const mi355q_col_desc& c) {
+  if (!valid_type(c.type)) return -1;
+  switch (c.encoding) {
+    case MI355Q_ENC_NONE:
+      return c.type;
+    case MI355Q_ENC_FIXED:
+      if (!int_type(c.type) || !int_type(c.logical_type) || c.logical_type <= c.type) return -1;
+      return tc_make(c.type, MI355Q_ENC_FIXED, c.logical_type, c.nullable);
+    case MI355Q_ENC_DICT:
+      if (c.type == MI355Q_INT32) return MI355Q_INT32;  // 4-byte ids: plain signed int32
+      if (c.type != MI355Q_INT8 && c.type != MI355Q_INT16) return -1;
+      return tc_make(c.type, MI355Q_ENC_DICT, MI355Q_INT32, c.nullable);
+    case MI355Q_ENC_DATE_IN_DAYS:
+      if (c.type != MI355Q_INT16 && c.type != MI355Q_INT32) return -1;
+      return tc_make(c.type, MI355Q_ENC_DATE_IN_DAYS, MI355Q_INT64, 1);
+    default:
+      return -1;
+  }
+}
+
 int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out) {
   for (int i = 0; i < p.n_targets; ++i) {
     const mi355q_target& t = p.targets[i];
@@ -72,7 +105,9 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
         break;
       case MI355Q_PROJECT_KEY:
         if (!grouped) return MI355Q_ERR_INVALID_PLAN;
-        r.col = p.group_cols[0];
+        r.key_idx = t.col < 0 ? 0 : t.col;
+        if (r.key_idx >= p.n_group_cols) return MI355Q_ERR_INVALID_PLAN;
+        r.col = p.group_cols[r.key_idx];
         r.table = 0;
         break;
       default:
@@ -82,8 +117,8 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
       const int ncols = r.table ? p.n_inner_cols : p.n_cols;
       if (r.col >= ncols || (r.table && p.join_outer_col < 0)) return MI355Q_ERR_INVALID_PLAN;
       const mi355q_col_desc& cd = r.table ? p.inner_cols[r.col] : p.cols[r.col];
-      if (!valid_type(cd.type)) return MI355Q_ERR_INVALID_PLAN;
-      r.arg_type = cd.type;
+      r.arg_type = col_type_code(cd);
+      if (r.arg_type < 0) return MI355Q_ERR_INVALID_PLAN;
       r.arg_nullable = cd.nullable != 0;
       r.arg_fp = type_is_fp(cd.type);
       r.range = r.table ? &p.inner_col_ranges[r.col] : &p.col_ranges[r.col];
@@ -156,17 +191,20 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   if (p.abi_version != MI355Q_ABI_VERSION) return MI355Q_ERR_INVALID_PLAN;
   if (p.n_cols < 0 || p.n_cols > MI355Q_MAX_COLS || p.n_inner_cols < 0 ||
       p.n_inner_cols > MI355Q_MAX_COLS || p.n_quals < 0 || p.n_quals > MI355Q_MAX_QUALS ||
-      p.n_targets < 1 || p.n_targets > MI355Q_MAX_TARGETS || p.n_group_cols < 0) {
+      p.n_targets < 1 || p.n_targets > MI355Q_MAX_TARGETS || p.n_group_cols < 0 ||
+      p.n_group_cols > MI355Q_MAX_GROUP_COLS) {
     return MI355Q_ERR_INVALID_PLAN;
   }
-  if (p.n_group_cols > 1) return MI355Q_ERR_UNSUPPORTED;  // multi-column keys: SURVEY f1
   for (int i = 0; i < p.n_cols; ++i) {
-    if (!valid_type(p.cols[i].type)) return MI355Q_ERR_INVALID_PLAN;
+    if (col_type_code(p.cols[i]) < 0) return MI355Q_ERR_INVALID_PLAN;
+  }
+  for (int i = 0; i < p.n_inner_cols; ++i) {
+    if (col_type_code(p.inner_cols[i]) < 0) return MI355Q_ERR_INVALID_PLAN;
   }
   for (int i = 0; i < p.n_quals; ++i) {
     if (p.quals[i].col < 0 || p.quals[i].col >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
   }
-  const bool grouped = p.n_group_cols == 1;
+  const bool grouped = p.n_group_cols >= 1;
   ResolvedTarget ts[MI355Q_MAX_TARGETS];
   if (int32_t e = resolve_targets(p, grouped, ts)) return e;
 
@@ -177,40 +215,107 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   q->entry_count = 1;
   q->desc_type = MI355Q_NON_GROUPED_AGGREGATE;
 
-  if (grouped) {
-    const int gc = p.group_cols[0];
+  for (int g = 0; g < p.n_group_cols; ++g) {
+    const int gc = p.group_cols[g];
     if (gc < 0 || gc >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
     if (type_is_fp(p.cols[gc].type)) return MI355Q_ERR_UNSUPPORTED;  // fp keys
+  }
+  const int64_t baseline_entries =
+      p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess : 16384;
+
+  if (p.n_group_cols == 1) {
+    const int gc = p.group_cols[0];
     const mi355q_range& r = p.col_ranges[gc];
     bool use_baseline = !r.valid || r.min > r.max;
     if (!use_baseline) {
       const int64_t col_count = p.n_group_cols + p.n_targets;
       const int64_t max_entries = kMaxBufferSize / (col_count * (int64_t)sizeof(int64_t));
       const __int128 span = (__int128)r.max - (__int128)r.min;
-      use_baseline = span >= (__int128)max_entries;
+      // a bucketed range stays on the perfect hash (":344 is_baseline_candidate && !bucket")
+      use_baseline = span >= (__int128)max_entries && !r.bucket;
+      if (!use_baseline && span / (r.bucket > 0 ? r.bucket : 1) >= (__int128)INT32_MAX)
+        return MI355Q_ERR_UNSUPPORTED;
     }
     if (use_baseline) {
       q->desc_type = MI355Q_GROUP_BY_BASELINE_HASH;
-      q->entry_count =
-          p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess : 16384;
-      if (q->entry_count > (int64_t)UINT32_MAX) return MI355Q_ERR_UNSUPPORTED;  // h is uint32
-      if (r.valid && !(type_width(p.cols[gc].type) == 8 && r.has_nulls) &&
-          r.min > (int64_t)INT32_MIN && r.max < (int64_t)kEmptyKey32 - 1) {
-        q->key_width = 4;
-      }
     } else {
       q->desc_type = MI355Q_GROUP_BY_PERFECT_HASH;
       q->min_val = r.min;
       q->max_val = r.max;
+      q->bucket = r.bucket > 0 ? r.bucket : 0;
       q->has_nulls = r.has_nulls != 0;
-      const int64_t card = r.max - r.min + 1 + (r.has_nulls ? 1 : 0);
+      const int64_t card = bucketed_cardinality(r);
       q->entry_count = card > 1 ? card : 1;
-      bool keyless = false;
-      int key_slot = 0;
-      keyless_decision(p, ts, &keyless, &key_slot);
-      q->keyless = keyless;
-      q->idx_target_as_key = key_slot;
+      q->group_min[0] = r.min;
+      q->group_card[0] = card;
+      q->group_bucket[0] = q->bucket;
+      q->group_null_key[0] = r.max + (q->bucket ? q->bucket : 1);
+      q->group_has_nulls[0] = r.has_nulls != 0;
     }
+  } else if (p.n_group_cols > 1) {
+    // getColRangeInfo, groupby_exprs.size() != 1: perfect hash iff every column has an
+    // integer range and the product of the bucketed cardinalities is within
+    // g_baseline_groupby_threshold; zero / overflow -> baseline
+    bool perfect = true;
+    __int128 card = 1;
+    for (int g = 0; g < p.n_group_cols && perfect; ++g) {
+      const mi355q_range& r = p.col_ranges[p.group_cols[g]];
+      if (!r.valid || r.min > r.max) {
+        perfect = false;
+        break;
+      }
+      const __int128 c = ((__int128)r.max - (__int128)r.min) / (r.bucket > 0 ? r.bucket : 1) + 1 +
+                         (r.has_nulls ? 1 : 0);
+      if (c > (__int128)INT64_MAX) {
+        perfect = false;
+        break;
+      }
+      card *= c;
+      if (card > (__int128)INT64_MAX) perfect = false;
+    }
+    if (perfect && (card == 0 || card > (__int128)kBaselineGroupbyThreshold)) perfect = false;
+    if (perfect) {
+      q->desc_type = MI355Q_GROUP_BY_PERFECT_HASH;
+      q->entry_count = (int64_t)card;
+      q->min_val = 0;
+      q->max_val = (int64_t)card;  // "col range info max contains the expected cardinality"
+      for (int g = 0; g < p.n_group_cols; ++g) {
+        const mi355q_range& r = p.col_ranges[p.group_cols[g]];
+        q->group_min[g] = r.min;
+        q->group_card[g] = bucketed_cardinality(r);
+        q->group_bucket[g] = r.bucket > 0 ? r.bucket : 0;
+        q->group_null_key[g] = r.max + (r.bucket > 0 ? r.bucket : 1);
+        q->group_has_nulls[g] = r.has_nulls != 0;
+        if (r.has_nulls) q->has_nulls = 1;
+      }
+    } else {
+      q->desc_type = MI355Q_GROUP_BY_BASELINE_HASH;
+    }
+  }
+  if (q->desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
+    bool keyless = false;
+    int key_slot = 0;
+    keyless_decision(p, ts, &keyless, &key_slot);
+    if (p.n_group_cols == 1 && q->bucket) keyless = false;  // "!col_range_info.bucket"
+    q->keyless = keyless;
+    q->idx_target_as_key = key_slot;
+  } else if (q->desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
+    q->entry_count = baseline_entries;
+    if (q->entry_count > (int64_t)UINT32_MAX) return MI355Q_ERR_UNSUPPORTED;  // h is uint32
+    // pick_baseline_key_width: 4 only if every component's range is a valid int32 range
+    int kw = 4;
+    for (int g = 0; g < p.n_group_cols; ++g) {
+      const int gc = p.group_cols[g];
+      const mi355q_range& r = p.col_ranges[gc];
+      const int logical_w = plain_width(tc_logical(col_type_code(p.cols[gc])));
+      int w = 8;
+      if (r.valid && !(logical_w == 8 && r.has_nulls) && r.min > (int64_t)INT32_MIN &&
+          r.max < (int64_t)kEmptyKey32 - 1) {
+        w = 4;
+      }
+      if (w > kw) kw = w;
+    }
+    q->key_width = kw;
   }
 
   int slot = 0;
@@ -219,6 +324,7 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
     ArgInfo a{t.arg_type, t.arg_nullable, t.arg_fp, t.range};
     q->target_agg[i] = t.agg;
     q->target_skip_null[i] = t.skip_null;
+    q->target_key_idx[i] = t.key_idx;
     q->target_arg_is_fp[i] = t.arg_fp && t.agg != MI355Q_COUNT;
     q->target_is_fp[i] = t.agg == MI355Q_AVG || (t.arg_fp && t.agg != MI355Q_COUNT);
     const bool key_in_row =
@@ -254,11 +360,58 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   return MI355Q_OK;
 }
 
+// fill_empty_key (ResultSet.cpp) + initColumnsPerRow (QueryMemoryInitializer.cpp:617-698):
+// every key component EMPTY — with 4-byte components an odd count leaves a zero padding word —
+// then the slots' init values.
+void row_init_image(const mi355q_qmd& q, int64_t* quad) {
+  const int kq = q.key_bytes / 8;
+  for (int i = 0; i < kq; ++i) quad[i] = kEmptyKey64;
+  if (q.key_width == 4) {
+    int32_t* k32 = (int32_t*)quad;
+    for (int i = 0; i < 2 * kq; ++i) k32[i] = i < q.group_col_count ? kEmptyKey32 : 0;
+  }
+  for (int s = 0; s < q.slot_count; ++s) quad[kq + s] = q.init_vals[s];
+}
+
+void layout_from_qmd(const mi355q_qmd& q, DevPlan* d) {
+  d->n_targets = q.n_targets;
+  for (int i = 0; i < q.n_targets; ++i) {
+    DevTarget& t = d->targets[i];
+    t.agg = q.target_agg[i];
+    t.skip_null = q.target_skip_null[i];
+    t.slot = q.target_slot[i];
+    t.arg_fp = q.target_arg_is_fp[i];
+    t.key_idx = q.target_key_idx[i];
+  }
+  d->slot_count = q.slot_count;
+  d->desc_type = q.desc_type;
+  d->keyless = q.keyless;
+  d->key_width = q.key_width;
+  d->row_quad = q.row_size / 8;
+  d->key_quad = q.key_bytes / 8;
+  d->entry_count = q.entry_count;
+  d->min_val = q.min_val;
+  d->max_val = q.max_val;
+  d->n_group = q.group_col_count;
+  int64_t mul = 1;
+  for (int g = 0; g < q.group_col_count && g < MI355Q_MAX_GROUP_COLS; ++g) {
+    d->group_min[g] = q.group_min[g];
+    d->group_card[g] = q.group_card[g];
+    d->group_null_key[g] = q.group_null_key[g];
+    d->group_bucket[g] = q.group_bucket[g];
+    d->group_mul[g] = mul;
+    mul *= q.group_card[g] > 0 ? q.group_card[g] : 1;
+  }
+  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) d->init_vals[i] = q.init_vals[i];
+  d->join_col = -1;
+}
+
 int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
   std::memset(d, 0, sizeof(*d));
-  const bool grouped = p.n_group_cols == 1;
+  const bool grouped = p.n_group_cols >= 1;
   ResolvedTarget ts[MI355Q_MAX_TARGETS];
   if (int32_t e = resolve_targets(p, grouped, ts)) return e;
+  layout_from_qmd(q, d);
   d->n_cols = p.n_cols;
   d->n_quals = p.n_quals;
   for (int i = 0; i < p.n_quals; ++i) {
@@ -266,7 +419,7 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
     DevQual& o = d->quals[i];
     o.col = s.col;
     o.op = s.op;
-    o.type = p.cols[s.col].type;
+    o.type = col_type_code(p.cols[s.col]);
     o.nullable = p.cols[s.col].nullable != 0;
     o.ival = s.ival;
     o.fval = s.fval;
@@ -278,32 +431,26 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
         return MI355Q_ERR_UNSUPPORTED;
     }
   }
-  d->n_targets = p.n_targets;
   for (int i = 0; i < p.n_targets; ++i) {
     DevTarget& o = d->targets[i];
-    o.agg = ts[i].agg;
     o.col = ts[i].col;
     o.table = ts[i].table;
     o.arg_type = ts[i].arg_type;
     o.arg_nullable = ts[i].arg_nullable;
-    o.skip_null = ts[i].skip_null;
-    o.slot = q.target_slot[i];
-    o.arg_fp = ts[i].arg_fp;
+    o.arg_fp = ts[i].arg_fp;  // COUNT(double col) still decodes a double
   }
-  d->slot_count = q.slot_count;
-  d->desc_type = q.desc_type;
-  d->keyless = q.keyless;
-  d->key_width = q.key_width;
-  d->row_quad = q.row_size / 8;
-  d->key_quad = q.key_bytes / 8;
-  d->group_col = grouped ? p.group_cols[0] : -1;
-  d->group_type = grouped ? p.cols[p.group_cols[0]].type : 0;
+  for (int g = 0; g < p.n_group_cols; ++g) {
+    const mi355q_col_desc& cd = p.cols[p.group_cols[g]];
+    d->group_cols[g] = p.group_cols[g];
+    d->group_types[g] = col_type_code(cd);
+    // NULL keys are translated to max + 1 where the range says the column has them
+    // (groupByColumnCodegen translate_null_val, IRCodegen.cpp:1413-1512)
+    d->group_translate[g] = q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && cd.nullable &&
+                            (p.n_group_cols == 1 || q.group_has_nulls[g]);
+  }
+  d->group_col = grouped ? d->group_cols[0] : -1;
+  d->group_type = grouped ? d->group_types[0] : 0;
   d->group_nullable = grouped ? p.cols[p.group_cols[0]].nullable != 0 : 0;
-  d->entry_count = q.entry_count;
-  d->min_val = q.min_val;
-  d->max_val = q.max_val;
-  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) d->init_vals[i] = q.init_vals[i];
-  d->join_col = -1;
   return MI355Q_OK;
 }
 

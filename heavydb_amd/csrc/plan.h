@@ -7,14 +7,20 @@ namespace mq {
 
 struct ResolvedTarget {
   int agg = 0, col = -1, table = 0;
-  int arg_type = 0;
+  int arg_type = 0;  // type code (dev_common.h)
+  int key_idx = 0;   // PROJECT_KEY: index into group_cols
   bool arg_nullable = false, arg_fp = false, skip_null = false;
   int n_slots = 1;
   const mi355q_range* range = nullptr;
 };
 
+int col_type_code(const mi355q_col_desc& c);  // < 0 = invalid
 int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out);
 int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q);
 int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d);
+// the layout part of a DevPlan (what reduce / iteration / sort need) from a descriptor alone
+void layout_from_qmd(const mi355q_qmd& q, DevPlan* d);
+// one initialised row (key quads then slot init values); quad holds row_size / 8 entries
+void row_init_image(const mi355q_qmd& q, int64_t* quad);
 
 }  // namespace mq

@@ -37,6 +37,9 @@ inline T emu_cas(T* p, T expect, T desired) {
 #define MQ_MAX64(p, v) (*(long long*)(p) = (*(long long*)(p) > (long long)(v) ? *(long long*)(p) : (long long)(v)))
 #define MQ_LOAD64(p) (*(volatile int64_t*)(p))
 #define MQ_STORE64(p, v) (*(volatile int64_t*)(p) = (v))
+#define MQ_FENCE() ((void)0)
+#define MQ_LOAD32(p) (*(volatile int32_t*)(p))
+#define MQ_STORE32(p, v) (*(volatile int32_t*)(p) = (v))
 #define MQ_FN inline
 #else
 #define MQ_CAS64(p, e, d) atomicCAS((unsigned long long*)(p), (unsigned long long)(e), (unsigned long long)(d))
@@ -47,6 +50,9 @@ inline T emu_cas(T* p, T expect, T desired) {
 #define MQ_MAX64(p, v) atomicMax((long long*)(p), (long long)(v))
 #define MQ_LOAD64(p) __hip_atomic_load((int64_t*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MQ_STORE64(p, v) __hip_atomic_store((int64_t*)(p), (int64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MQ_FENCE() __threadfence()
+#define MQ_LOAD32(p) __hip_atomic_load((int32_t*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define MQ_STORE32(p, v) __hip_atomic_store((int32_t*)(p), (int32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MQ_FN __device__ __forceinline__
 #endif
 
@@ -245,15 +251,122 @@ MQ_FN int64_t* baseline_find_or_insert(int64_t* buf, uint32_t entry_count, int r
   return nullptr;
 }
 
+// Multi-column keys (key_count components of key_width bytes each, packed at the row start).
+// The reference's GPU build claims the first component with a CAS and lets late arrivals spin
+// until the last component is written (cuda_mapd_rt.cu get_matching_group_value); here the
+// first component doubles as a write lock: EMPTY -> LOCKED (EMPTY - 1, a value the reference
+// also keeps out of int32 key ranges: is_valid_int32_range) -> the real value, published with
+// a release fence after the other components are in place.  One loop, no early return: the
+// winner publishes inside the iteration it won in, so lanes of its own wave that lost the CAS
+// see the key on their next trip (no intra-wave deadlock).  Returns the first slot, nullptr
+// when the table is full, and sets *bad when the key itself is unrepresentable.
+constexpr int64_t kLockedKey64 = INT64_MAX - 1;
+constexpr int32_t kLockedKey32 = INT32_MAX - 1;
+constexpr int kMaxLockSpins = 1 << 24;
+
+MQ_FN int64_t* baseline_find_or_insert_multi(int64_t* buf, uint32_t entry_count, int row_quad,
+                                             int key_width, int key_count, const int64_t* keys,
+                                             bool* bad) {
+  const int key_quad = (key_count * key_width + 7) >> 3;
+  uint32_t words[2 * MI355Q_MAX_GROUP_COLS];
+  int n_words;
+  if (key_width == 4) {
+    for (int i = 0; i < key_count; ++i) words[i] = (uint32_t)(int32_t)keys[i];
+    n_words = key_count;
+    if ((int32_t)keys[0] == kLockedKey32 || (int32_t)keys[0] == kEmptyKey32) *bad = true;
+  } else {
+    for (int i = 0; i < key_count; ++i) {
+      words[2 * i] = (uint32_t)(uint64_t)keys[i];
+      words[2 * i + 1] = (uint32_t)((uint64_t)keys[i] >> 32);
+    }
+    n_words = 2 * key_count;
+    if (keys[0] == kLockedKey64 || keys[0] == kEmptyKey64) *bad = true;
+  }
+  if (*bad) return nullptr;
+  const uint32_t h = murmur3_words(words, n_words) % entry_count;
+  uint32_t hp = h;
+  int64_t* found = nullptr;
+  bool done = false;
+  int spins = 0;
+  while (!done) {
+    int64_t* row = buf + (size_t)hp * row_quad;
+    bool advance = false;
+    if (key_width == 4) {
+      int32_t* r32 = (int32_t*)row;
+      const int32_t old = (int32_t)MQ_CAS32(r32, (uint32_t)kEmptyKey32, (uint32_t)kLockedKey32);
+      if (old == kEmptyKey32) {
+        for (int i = 1; i < key_count; ++i) MQ_STORE32(r32 + i, (int32_t)keys[i]);
+        MQ_FENCE();
+        MQ_STORE32(r32, (int32_t)keys[0]);
+        found = row + key_quad;
+        done = true;
+      } else if (old == kLockedKey32) {
+        if (++spins > kMaxLockSpins) {
+          *bad = true;
+          done = true;
+        }
+      } else if (old == (int32_t)keys[0]) {
+        MQ_FENCE();
+        bool same = true;
+        for (int i = 1; i < key_count; ++i) same = same && MQ_LOAD32(r32 + i) == (int32_t)keys[i];
+        if (same) {
+          found = row + key_quad;
+          done = true;
+        } else {
+          advance = true;
+        }
+      } else {
+        advance = true;
+      }
+    } else {
+      const int64_t old = (int64_t)MQ_CAS64(row, kEmptyKey64, kLockedKey64);
+      if (old == kEmptyKey64) {
+        for (int i = 1; i < key_count; ++i) MQ_STORE64(row + i, keys[i]);
+        MQ_FENCE();
+        MQ_STORE64(row, keys[0]);
+        found = row + key_quad;
+        done = true;
+      } else if (old == kLockedKey64) {
+        if (++spins > kMaxLockSpins) {
+          *bad = true;
+          done = true;
+        }
+      } else if (old == keys[0]) {
+        MQ_FENCE();
+        bool same = true;
+        for (int i = 1; i < key_count; ++i) same = same && MQ_LOAD64(row + i) == keys[i];
+        if (same) {
+          found = row + key_quad;
+          done = true;
+        } else {
+          advance = true;
+        }
+      } else {
+        advance = true;
+      }
+    }
+    if (advance) {
+      hp = hp + 1 == entry_count ? 0 : hp + 1;
+      if (hp == h) done = true;  // wrapped: table full
+    }
+  }
+  return found;
+}
+
+// component i of the key stored at the start of `row`
+MQ_FN int64_t row_key_component(const int64_t* row, int key_width, int i) {
+  return key_width == 4 ? (int64_t)((const int32_t*)row)[i] : row[i];
+}
+
 // ---------------------------------------------------------------- one target, one row
 template <bool A>
 MQ_FN void apply_target(const DevTarget& t, int64_t* slots, const int8_t* const* cols,
                         int64_t pos, const int8_t* const* inner_cols, int64_t inner_pos,
-                        int64_t key_val) {
+                        const int64_t* key_vals) {
   if (t.agg == MI355Q_PROJECT_KEY) {
     if (t.slot >= 0) {  // agg_id
-      if (A) MQ_STORE64(slots + t.slot, key_val);
-      else slots[t.slot] = key_val;
+      if (A) MQ_STORE64(slots + t.slot, key_vals[t.key_idx]);
+      else slots[t.slot] = key_vals[t.key_idx];
     }
     return;
   }
@@ -385,6 +498,43 @@ MQ_FN bool is_empty_row(const DevPlan& p, const int64_t* row, int idx_target_as_
   return row[0] == kEmptyKey64;
 }
 
+// ---------------------------------------------------------------- reduce one entry
+// Entry `e` of another buffer of the same layout folded into this_buf: baseline rows are
+// re-hashed (get_group_value_reduction, ResultSetReduction.cpp:783-826), perfect / non-grouped
+// rows are index aligned with the key columns copied from the right-hand side
+// (ResultSetReductionJIT.cpp:705-711).  Returns 0 or MI355Q_ERR_OUT_OF_SLOTS.
+template <bool A>
+MQ_FN int32_t reduce_entry(const DevPlan& p, int idx_target_as_key, int64_t* this_buf,
+                           const int64_t* src, int64_t e) {
+  if (is_empty_row(p, src, idx_target_as_key)) return 0;
+  int64_t* slots;
+  if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
+    if (p.n_group <= 1) {
+      slots = baseline_find_or_insert(this_buf, (uint32_t)p.entry_count, p.row_quad, p.key_width,
+                                      row_key_component(src, p.key_width, 0));
+    } else {
+      int64_t keys[MI355Q_MAX_GROUP_COLS];
+      for (int g = 0; g < p.n_group; ++g) keys[g] = row_key_component(src, p.key_width, g);
+      bool bad = false;
+      slots = baseline_find_or_insert_multi(this_buf, (uint32_t)p.entry_count, p.row_quad,
+                                            p.key_width, p.n_group, keys, &bad);
+    }
+    if (!slots) return MI355Q_ERR_OUT_OF_SLOTS;
+  } else {
+    int64_t* row = this_buf + e * p.row_quad;
+    for (int k = p.key_quad - 1; k >= 0; --k) {
+      if (A) MQ_STORE64(row + k, src[k]);
+      else row[k] = src[k];
+    }
+    slots = row + p.key_quad;
+  }
+  const int64_t* that_slots = src + p.key_quad;
+  for (int i = 0; i < p.n_targets; ++i) {
+    reduce_target<A>(p.targets[i], p.init_vals, slots, that_slots);
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------- the row function
 // Returns 0, or a HeavyDB-style error: < 0 when the baseline table is full.
 template <bool A>
@@ -401,27 +551,50 @@ MQ_FN int32_t process_row(const DevPlan& p, const int8_t* const* cols, int64_t p
     if (inner_pos < 0) return 0;
   }
   int64_t* slots;
-  int64_t key_val = 0;
+  int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};  // the group columns' values as decoded
   if (p.desc_type == MI355Q_NON_GROUPED_AGGREGATE) {
     slots = nongrouped_slots;
   } else {
-    const int64_t raw_key = decode_int(cols[p.group_col], p.group_type, pos);
-    key_val = raw_key;
+    for (int g = 0; g < p.n_group; ++g) {
+      keys[g] = decode_int(cols[p.group_cols[g]], p.group_types[g], pos);
+    }
     if (p.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
-      int64_t k = raw_key;
-      if (p.group_nullable && raw_key == int_null_of(p.group_type)) k = p.max_val + 1;
-      const int64_t idx = k - p.min_val;
+      // entry index: single column key - min (get_group_value_fast, GroupByRuntime.cpp:208-223);
+      // several columns sum_i (key_i - min_i) * prod_{j<i} card_j (perfect_key_hash,
+      // GroupByAndAggregate.cpp:1546-1598).  The key columns of the row hold the TRANSLATED
+      // keys (NULL -> max + 1), as both get_group_value_fast and
+      // get_matching_group_value_perfect_hash (RuntimeFunctions.cpp:2077-2091) store them.
+      int64_t tk[MI355Q_MAX_GROUP_COLS];
+      int64_t idx = 0;
+      for (int g = 0; g < p.n_group; ++g) {
+        int64_t k = keys[g];
+        if (p.group_translate[g] && k == int_null_of(p.group_types[g])) k = p.group_null_key[g];
+        tk[g] = k;
+        int64_t d = k - p.group_min[g];
+        if (p.group_bucket[g]) d /= p.group_bucket[g];
+        if (d < 0 || d >= p.group_card[g]) return MI355Q_ERR_OUT_OF_SLOTS;
+        idx += d * p.group_mul[g];
+      }
       if (idx < 0 || idx >= p.entry_count) return MI355Q_ERR_OUT_OF_SLOTS;
       int64_t* row = out_buf + idx * p.row_quad;
       if (!p.keyless) {
-        if (MQ_LOAD64(row) == kEmptyKey64) MQ_STORE64(row, raw_key);
-        slots = row + 1;
+        if (MQ_LOAD64(row) == kEmptyKey64) {
+          for (int g = p.n_group - 1; g >= 0; --g) MQ_STORE64(row + g, tk[g]);
+        }
+        slots = row + p.n_group;
       } else {
         slots = row;
       }
     } else {
-      slots = baseline_find_or_insert(out_buf, (uint32_t)p.entry_count, p.row_quad, p.key_width,
-                                      raw_key);
+      if (p.n_group == 1) {
+        slots = baseline_find_or_insert(out_buf, (uint32_t)p.entry_count, p.row_quad, p.key_width,
+                                        keys[0]);
+      } else {
+        bool bad = false;
+        slots = baseline_find_or_insert_multi(out_buf, (uint32_t)p.entry_count, p.row_quad,
+                                              p.key_width, p.n_group, keys, &bad);
+        if (bad) return MI355Q_ERR_INVALID_PLAN;
+      }
       if (!slots) {
         const int64_t code = -(pos + 1);
         return code < INT32_MIN ? INT32_MIN : (int32_t)code;
@@ -429,7 +602,7 @@ MQ_FN int32_t process_row(const DevPlan& p, const int8_t* const* cols, int64_t p
     }
   }
   for (int i = 0; i < p.n_targets; ++i) {
-    apply_target<A>(p.targets[i], slots, cols, pos, p.inner_cols, inner_pos, key_val);
+    apply_target<A>(p.targets[i], slots, cols, pos, p.inner_cols, inner_pos, keys);
   }
   return 0;
 }

@@ -36,18 +36,26 @@ class ExpressionRange:
     has_nulls: bool = False
     fp_min: float = 0.0
     fp_max: float = 0.0
+    bucket: int = 0
 
     def to_c(self) -> capi.Range:
         return capi.Range(int(self.valid), int(self.has_nulls), int(self.min), int(self.max),
-                          float(self.fp_min), float(self.fp_max))
+                          float(self.fp_min), float(self.fp_max), int(self.bucket))
 
 
 @dataclass
 class InputColDescriptor:
-    """InputColDescriptor + SQLTypeInfo of a fixed-width column."""
+    """InputColDescriptor + SQLTypeInfo of a fixed-width column: `type` is the chunk's storage
+    type; `encoding` / `logical_type` describe kENCODING_FIXED / _DICT / _DATE_IN_DAYS columns
+    (decoded on load, DecodersImpl.h); the range is in decoded values."""
     type: int
     nullable: bool = False
     range: ExpressionRange = field(default_factory=ExpressionRange)
+    encoding: int = 0
+    logical_type: int = 0
+
+    def to_c(self) -> capi.ColDesc:
+        return capi.ColDesc(self.type, int(self.nullable), self.encoding, self.logical_type)
 
 
 @dataclass
@@ -61,7 +69,8 @@ class Qual:
 @dataclass
 class TargetExpr:
     """target_exprs entry: aggregate kind + argument column (-1 = COUNT(*)); table 1 reads
-    an inner-table column through the join's row id."""
+    an inner-table column through the join's row id.  PROJECT_KEY: `col` is the index of the
+    projected key within groupby_exprs (default: the first)."""
     agg: int
     col: int = -1
     table: int = 0
@@ -87,11 +96,11 @@ class RelAlgExecutionUnit:
             raise ValueError("too many columns")
         p.n_cols = len(self.input_col_descs)
         for i, c in enumerate(self.input_col_descs):
-            p.cols[i] = capi.ColDesc(c.type, int(c.nullable))
+            p.cols[i] = c.to_c()
             p.col_ranges[i] = c.range.to_c()
         p.n_inner_cols = len(self.inner_col_descs)
         for i, c in enumerate(self.inner_col_descs):
-            p.inner_cols[i] = capi.ColDesc(c.type, int(c.nullable))
+            p.inner_cols[i] = c.to_c()
             p.inner_col_ranges[i] = c.range.to_c()
         if len(self.simple_quals) > capi.MAX_QUALS:
             raise ValueError("too many quals")
@@ -100,8 +109,10 @@ class RelAlgExecutionUnit:
             is_fp = self.input_col_descs[q.col].type == DOUBLE
             p.quals[i] = capi.Qual(q.col, q.op, 0 if is_fp else int(q.literal),
                                    float(q.literal) if is_fp else 0.0)
+        if len(self.groupby_exprs) > capi.MAX_GROUP_COLS:
+            raise ValueError("too many group-by columns")
         p.n_group_cols = len(self.groupby_exprs)
-        for i, g in enumerate(self.groupby_exprs[:capi.MAX_GROUP_COLS]):
+        for i, g in enumerate(self.groupby_exprs):
             p.group_cols[i] = g
         if len(self.target_exprs) > capi.MAX_TARGETS:
             raise ValueError("too many targets")

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 1
+#define MI355Q_ABI_VERSION 2
 
 #define MI355Q_MAX_COLS 16
 #define MI355Q_MAX_QUALS 4
@@ -77,6 +77,23 @@ typedef enum mi355q_type {
   MI355Q_DOUBLE = 5
 } mi355q_type;
 
+/* Column encodings ColumnFetcher hands over undecoded (EncodingType, Shared/sqltypes.h; the
+ * decoders are chosen by get_col_decoder, QueryEngine/ColumnIR.cpp, and live in
+ * DecodersImpl.h).  `type` of the column is always the STORAGE type of the chunk. */
+typedef enum mi355q_encoding {
+  MI355Q_ENC_NONE = 0,
+  MI355Q_ENC_FIXED = 1, /* kENCODING_FIXED: integer stored narrower than its SQL type
+                           (`logical_type`); NULL is the storage type's sentinel and is widened
+                           to the logical sentinel on load (codgenAdjustFixedEncNull,
+                           ColumnIR.cpp; fixed_width_int_decode DecodersImpl.h:27-55) */
+  MI355Q_ENC_DICT = 2,  /* kENCODING_DICT string ids: 1/2-byte chunks are UNSIGNED
+                           (fixed_width_unsigned_decode DecodersImpl.h:57-85), NULL = 255 / 65535,
+                           widened to the INT32 sentinel; 4-byte chunks are plain int32 */
+  MI355Q_ENC_DATE_IN_DAYS = 3 /* kENCODING_DATE_IN_DAYS: int16/int32 days since epoch ->
+                                 int64 seconds (x 86400), NULL -> NULL_BIGINT
+                                 (fixed_width_small_date_decode DecodersImpl.h:130-139) */
+} mi355q_encoding;
+
 /* comparison operators: numeric values of SQLOps (Shared/sqldefs.h:31-38) */
 typedef enum mi355q_op {
   MI355Q_EQ = 0,
@@ -107,9 +124,12 @@ typedef enum mi355q_desc_type {
 } mi355q_desc_type;
 
 typedef struct mi355q_col_desc {
-  int32_t type;     /* mi355q_type */
+  int32_t type;     /* mi355q_type of the chunk as stored */
   int32_t nullable; /* 0 = NOT NULL; else NULL is the inline sentinel
                        (Shared/InlineNullValues.h:29-35) */
+  int32_t encoding; /* mi355q_encoding */
+  int32_t logical_type; /* SQL type after decoding (ENC_FIXED); 0 = same as `type`
+                           (ENC_DICT implies INT32, ENC_DATE_IN_DAYS implies INT64) */
 } mi355q_col_desc;
 
 /* simple_quals entry: `col <op> literal` (RelAlgExecutionUnit.h:170) */
@@ -123,7 +143,8 @@ typedef struct mi355q_qual {
 /* target_exprs entry (RelAlgExecutionUnit.h:173; Shared/TargetInfo.h:48-56) */
 typedef struct mi355q_target {
   int32_t agg;   /* mi355q_agg */
-  int32_t col;   /* argument column, -1 for COUNT(*) */
+  int32_t col;   /* argument column, -1 for COUNT(*); for PROJECT_KEY the index into
+                    group_cols of the projected key (< 0 = the first) */
   int32_t table; /* 0 = outer (fact) column; 1 = inner (dim) column reached through
                     the join's row id */
   int32_t reserved;
@@ -138,6 +159,10 @@ typedef struct mi355q_range {
   int64_t max;
   double fp_min; /* used for double columns (keyless decisions only) */
   double fp_max;
+  int64_t bucket; /* ExpressionRange::getBucket(): 0, or the stride of the values (86400 for
+                     DATE columns, ExpressionRange.cpp:622-624); bucketed keys index the perfect
+                     hash by (key - min) / bucket and never use the baseline or keyless
+                     layouts (GroupByAndAggregate.cpp:344-349, QueryMemoryDescriptor.cpp:322-327) */
 } mi355q_range;
 
 typedef struct mi355q_join_table mi355q_join_table; /* opaque */
@@ -156,7 +181,8 @@ typedef struct mi355q_plan {
   int32_t n_quals; /* conjunction */
   mi355q_qual quals[MI355Q_MAX_QUALS];
 
-  int32_t n_group_cols; /* 0 = non-grouped aggregate; 1 = single-column group by */
+  int32_t n_group_cols; /* 0 = non-grouped aggregate; 1..MI355Q_MAX_GROUP_COLS group-by
+                           columns (integer typed, any mix of widths) */
   int32_t group_cols[MI355Q_MAX_GROUP_COLS];
 
   int32_t n_targets;
@@ -182,13 +208,25 @@ typedef struct mi355q_qmd {
   int32_t desc_type; /* mi355q_desc_type */
   int32_t keyless;   /* keyless_hash_ */
   int32_t idx_target_as_key; /* slot index whose value != init marks a live entry */
-  int32_t key_width; /* getEffectiveKeyWidth(): 8, or 4 for int32-range baseline keys */
+  int32_t key_width; /* getEffectiveKeyWidth(): 8, or 4 when every baseline key component
+                        fits int32 (pick_baseline_key_width, QueryMemoryDescriptor.cpp:135-146) */
   int32_t group_col_count;
   int32_t slot_count;
   int64_t entry_count;
-  int64_t min_val; /* perfect hash: col_range_info.min */
-  int64_t max_val; /* perfect hash: col_range_info.max (NULL key maps to max+1) */
+  int64_t min_val; /* single-column perfect hash: col_range_info.min */
+  int64_t max_val; /* single-column perfect hash: col_range_info.max (NULL key maps to max+1);
+                      multi-column perfect hash: the cardinality product (= entry_count), as
+                      getColRangeInfo returns it (GroupByAndAggregate.cpp:268-273) */
   int64_t bucket;
+  /* per group column (perfect hash): range minimum, getBucketedCardinality, and the value a
+   * NULL key is translated to (max + max(bucket, 1); GroupByAndAggregate.cpp:1339-1345).  The entry
+   * index of a multi-column key is sum_i (key_i - min_i) / bucket_i * prod_{j<i} card_j
+   * (codegenPerfectHashFunction, GroupByAndAggregate.cpp:1546-1598). */
+  int64_t group_min[MI355Q_MAX_GROUP_COLS];
+  int64_t group_card[MI355Q_MAX_GROUP_COLS];
+  int64_t group_null_key[MI355Q_MAX_GROUP_COLS];
+  int64_t group_bucket[MI355Q_MAX_GROUP_COLS];
+  int32_t group_has_nulls[MI355Q_MAX_GROUP_COLS];
   int32_t has_nulls;
   int32_t row_size;      /* bytes, getRowSize() (QueryMemoryDescriptor.cpp:848) */
   int32_t key_bytes;     /* align_to_int64(group_col_count * key_width), 0 if keyless */
@@ -196,6 +234,7 @@ typedef struct mi355q_qmd {
   int32_t target_slot[MI355Q_MAX_TARGETS];      /* first slot of each target; -1 if the
                                                    target is read from the key columns
                                                    (target_groupby_indices) */
+  int32_t target_key_idx[MI355Q_MAX_TARGETS];   /* PROJECT_KEY: which group column */
   int32_t target_skip_null[MI355Q_MAX_TARGETS]; /* TargetInfo.skip_null_val */
   int32_t target_is_fp[MI355Q_MAX_TARGETS];     /* result is double */
   int32_t target_agg[MI355Q_MAX_TARGETS];       /* mi355q_agg */

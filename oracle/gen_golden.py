@@ -95,6 +95,70 @@ def main():
     out["perfect_traces"] = [perfect_trace(100, 5, [102, 100, 104, 102]),
                              perfect_trace(-7, 32, [int(x) for x in rng.integers(-7, 25, 100)], 3)]
 
+    # ---- bucketed perfect trace (DATE keys, bucket 86400): get_group_value_fast with a bucket
+    def perfect_bucket_trace(min_key, bucket, n, keys, row_quad=2):
+        buf = np.zeros(n * row_quad, dtype=np.int64)
+        buf[0::row_quad] = EMPTY64
+        for k in keys:
+            p = ref.get_group_value_fast(buf.ctypes.data, k, min_key, bucket, row_quad)
+            buf[(p - buf.ctypes.data) // 8] += 1
+        return {"min_key": min_key, "bucket": bucket, "entries": n, "row_quad": row_quad,
+                "keys": [int(k) for k in keys], "final": [int(x) for x in buf]}
+
+    days = [int(x) for x in rng.integers(18000, 18020, 60)]
+    out["perfect_bucket_traces"] = [perfect_bucket_trace(18000 * 86400, 86400, 20, [d * 86400 for d in days])]
+
+    # ---- multi-column baseline traces: get_group_value with key_count components
+    def multi_trace(entry_count, key_width, key_count, keys, row_quad):
+        dt = np.int64 if key_width == 8 else np.int32
+        buf = np.zeros(entry_count * row_quad, dtype=np.int64)
+        kq = (key_count * key_width + 7) // 8
+        for e in range(entry_count):
+            kv = buf[e * row_quad:e * row_quad + kq].view(dt)
+            kv[:key_count] = EMPTY64 if key_width == 8 else EMPTY32
+        landed = []
+        for k in keys:
+            kb = np.zeros(kq * (8 // key_width), dtype=dt)
+            kb[:key_count] = k
+            p = ref.get_group_value(buf.ctypes.data, entry_count, kb.ctypes.data, key_count, key_width,
+                                    row_quad)
+            if not p:
+                landed.append(-1)
+                continue
+            quad = (p - buf.ctypes.data) // 8
+            landed.append(int(quad))
+            buf[quad] += 1
+        return {"entry_count": entry_count, "key_width": key_width, "key_count": key_count,
+                "row_quad": row_quad, "keys": [[int(x) for x in k] for k in keys],
+                "slot_quads": landed, "final": [int(x) for x in buf]}
+
+    mt = []
+    k2 = [[int(a) * 1000003 + 7, int(b)] for a, b in zip(rng.integers(0, 12, 150), rng.integers(-3, 3, 150))]
+    mt.append(multi_trace(131, 8, 2, k2, 4))
+    k3 = [[int(a), int(b), int(c)] for a, b, c in zip(rng.integers(-40, 40, 200), rng.integers(0, 3, 200),
+                                                       rng.integers(1000, 1004, 200))]
+    mt.append(multi_trace(257, 4, 3, k3, 3))       # 12 key bytes + 4 padding
+    mt.append(multi_trace(16, 4, 2, [[i, -i] for i in range(20)], 2))  # overflow -> NULL
+    out["multi_baseline_traces"] = mt
+
+    # ---- encoded-column decoders (DecodersImpl.h:57-85 unsigned, :130-139 small date)
+    u8 = np.array([0, 1, 127, 128, 200, 254, 255], dtype=np.uint8)
+    u16 = np.array([0, 1, 32767, 32768, 65534, 65535], dtype=np.uint16)
+    out["unsigned_decode"] = [
+        {"width": 1, "hex": u8.tobytes().hex(),
+         "decoded": [int(ref.fixed_width_unsigned_decode(u8.ctypes.data, 1, i)) for i in range(len(u8))]},
+        {"width": 2, "hex": u16.tobytes().hex(),
+         "decoded": [int(ref.fixed_width_unsigned_decode(u16.ctypes.data, 2, i)) for i in range(len(u16))]}]
+    d32 = np.array([0, 1, -1, 18000, -(2**31), 2**31 - 1], dtype=np.int32)
+    d16 = np.array([0, 1, -1, 18000, -(2**15), 2**15 - 1], dtype=np.int16)
+    out["small_date_decode"] = [
+        {"width": 4, "hex": d32.tobytes().hex(),
+         "decoded": [int(ref.fixed_width_small_date_decode(d32.ctypes.data, 4, -(2**31), -(2**63), i))
+                     for i in range(len(d32))]},
+        {"width": 2, "hex": d16.tobytes().hex(),
+         "decoded": [int(ref.fixed_width_small_date_decode(d16.ctypes.data, 2, -(2**15), -(2**63), i))
+                     for i in range(len(d16))]}]
+
     # ---- perfect join probe: hash_join_idx (GroupByRuntime.cpp:287-297)
     table = np.full(5, -1, dtype=np.int32)
     for row_id, k in enumerate([3, 1, 4]):

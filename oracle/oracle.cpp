@@ -159,6 +159,52 @@ inline int64_t decode_int(const int8_t* col, int t, int64_t pos) {
     default: return *reinterpret_cast<const int64_t*>(col + pos * 8);
   }
 }
+// DecodersImpl.h:57-85 fixed_width_unsigned_decode
+inline int64_t decode_unsigned(const int8_t* col, int t, int64_t pos) {
+  switch (t) {
+    case MI355Q_INT8: return *reinterpret_cast<const uint8_t*>(col + pos);
+    case MI355Q_INT16: return *reinterpret_cast<const uint16_t*>(col + pos * 2);
+    case MI355Q_INT32: return *reinterpret_cast<const uint32_t*>(col + pos * 4);
+    default: return (int64_t) * reinterpret_cast<const uint64_t*>(col + pos * 8);
+  }
+}
+// The SQL type a column's values have once decoded (get_col_bit_width / the column's
+// SQLTypeInfo): ENC_FIXED carries it, dictionary ids are INT, dates-in-days are 64-bit.
+inline int logical_type_of(const mi355q_col_desc& cd) {
+  switch (cd.encoding) {
+    case MI355Q_ENC_FIXED: return cd.logical_type;
+    case MI355Q_ENC_DICT: return MI355Q_INT32;
+    case MI355Q_ENC_DATE_IN_DAYS: return MI355Q_INT64;
+    default: return cd.type;
+  }
+}
+// Column fetch as the row function sees it (CodeGenerator::codegenFixedLengthColVar,
+// ColumnIR.cpp:258-306): decoder chosen by get_col_decoder, then for nullable FIXED / small
+// DICT columns the storage NULL is widened to the logical NULL (codgenAdjustFixedEncNull
+// :456-495 -> cast_<from>_to_<to>_nullable); FixedWidthSmallDate
+// (fixed_width_small_date_decode, DecodersImpl.h:130-139) maps NULL and scales days to seconds.
+inline int64_t decode_col(const mi355q_col_desc& cd, const int8_t* col, int64_t pos) {
+  switch (cd.encoding) {
+    case MI355Q_ENC_FIXED: {
+      const int64_t v = decode_int(col, cd.type, pos);
+      if (cd.nullable && v == int_null_of(cd.type)) return int_null_of(cd.logical_type);
+      return v;
+    }
+    case MI355Q_ENC_DICT: {
+      if (type_width(cd.type) >= 4) return decode_int(col, cd.type, pos);
+      const int64_t v = decode_unsigned(col, cd.type, pos);
+      const int64_t enc_null = cd.type == MI355Q_INT8 ? 255 : 65535;  // inline_fixed_encoding_null_val
+      if (cd.nullable && v == enc_null) return INT32_MIN;
+      return v;
+    }
+    case MI355Q_ENC_DATE_IN_DAYS: {
+      const int64_t v = decode_int(col, cd.type, pos);
+      return v == int_null_of(cd.type) ? INT64_MIN : v * 86400;
+    }
+    default:
+      return decode_int(col, cd.type, pos);
+  }
+}
 inline double decode_dbl(const int8_t* col, int64_t pos) {
   return *reinterpret_cast<const double*>(col + pos * 8);
 }
@@ -256,6 +302,8 @@ struct TargetDesc {
   bool skip_null;    // TargetInfo.skip_null_val after TargetExprBuilder.cpp:684-690
   int slot;          // first slot, -1 if read from key columns
   int n_slots;
+  int key_idx;       // PROJECT_KEY: which group column
+  const mi355q_col_desc* cd;  // argument column (nullptr for COUNT(*))
 };
 
 const mi355q_col_desc& col_desc_of(const mi355q_plan& p, int table, int col) {
@@ -304,12 +352,15 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
     d.table = t.table;
     if (t.agg == MI355Q_PROJECT_KEY) {
       if (!is_group_by) return MI355Q_ERR_INVALID_PLAN;
-      d.col = p.group_cols[0];
+      d.key_idx = t.col < 0 ? 0 : t.col;
+      if (d.key_idx >= p.n_group_cols) return MI355Q_ERR_INVALID_PLAN;
+      d.col = p.group_cols[d.key_idx];
       d.table = 0;
     }
     if (d.col >= 0) {
       const auto& cd = col_desc_of(p, d.table, d.col);
-      d.arg_type = cd.type;
+      d.cd = &cd;
+      d.arg_type = logical_type_of(cd);
       d.arg_nullable = cd.nullable != 0;
       d.arg_fp = type_is_fp(cd.type);
     } else if (t.agg != MI355Q_COUNT) {
@@ -389,10 +440,17 @@ std::pair<bool, int> keyless_info(const mi355q_plan& p, const std::vector<Target
   return {keyless && found, index};
 }
 
+// getBucketedCardinality (GroupByAndAggregate.cpp:367-375)
+int64_t bucketed_cardinality(const mi355q_range& r) {
+  int64_t c = r.max - r.min;
+  if (r.bucket > 0) c /= r.bucket;
+  return c + 1 + (r.has_nulls ? 1 : 0);
+}
+
 int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   memset(&q, 0, sizeof(q));
   if (p.n_targets < 1 || p.n_targets > MI355Q_MAX_TARGETS) return MI355Q_ERR_INVALID_PLAN;
-  if (p.n_group_cols < 0 || p.n_group_cols > 1) return MI355Q_ERR_UNSUPPORTED;
+  if (p.n_group_cols < 0 || p.n_group_cols > MI355Q_MAX_GROUP_COLS) return MI355Q_ERR_INVALID_PLAN;
   const bool is_group_by = p.n_group_cols > 0;
   std::vector<TargetDesc> ts;
   if (int e = build_targets(p, is_group_by, ts)) return e;
@@ -400,17 +458,17 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   q.n_targets = p.n_targets;
   q.group_col_count = p.n_group_cols;
   q.idx_target_as_key = -1;
+  q.key_width = 8;
+  for (int g = 0; g < p.n_group_cols; ++g) {
+    if (type_is_fp(p.cols[p.group_cols[g]].type)) return MI355Q_ERR_UNSUPPORTED;
+  }
+  bool baseline = false;
   if (!is_group_by) {
     q.desc_type = MI355Q_NON_GROUPED_AGGREGATE;  // QueryMemoryDescriptor.cpp:271-300
     q.entry_count = 1;
-    q.key_width = 8;
-  } else {
-    const int gc = p.group_cols[0];
-    const auto& gcd = p.cols[gc];
-    if (type_is_fp(gcd.type)) return MI355Q_ERR_UNSUPPORTED;
-    const auto& r = p.col_ranges[gc];
+  } else if (p.n_group_cols == 1) {
+    const auto& r = p.col_ranges[p.group_cols[0]];
     // getColRangeInfo, single-column case (GroupByAndAggregate.cpp:295-349)
-    bool baseline = false;
     if (!r.valid || r.min > r.max) {
       baseline = true;
     } else {
@@ -418,35 +476,84 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
       const int64_t max_entry_count = kMaxBufferSize / (col_count * sizeof(int64_t));
       // is_column_range_too_big_for_perfect_hash (:130-139), overflow -> too big
       __int128 span = (__int128)r.max - (__int128)r.min;
-      if (span > INT64_MAX || (int64_t)span >= max_entry_count) baseline = true;
+      const bool is_baseline_candidate = span > INT64_MAX || (int64_t)span >= max_entry_count;
+      // ":344  else if (is_baseline_candidate && !col_range_info.bucket)"
+      if (is_baseline_candidate && !(r.bucket > 0)) baseline = true;
+      if (!baseline && span / (r.bucket > 0 ? r.bucket : 1) >= INT32_MAX) return MI355Q_ERR_UNSUPPORTED;
     }
     if (!baseline) {
       q.desc_type = MI355Q_GROUP_BY_PERFECT_HASH;
       q.min_val = r.min;
       q.max_val = r.max;
-      q.bucket = 0;
+      q.bucket = r.bucket > 0 ? r.bucket : 0;
       q.has_nulls = r.has_nulls;
-      // getBucketedCardinality (:367-375)
-      q.entry_count = std::max<int64_t>(r.max - r.min + 1 + (r.has_nulls ? 1 : 0), 1);
-      auto ki = keyless_info(p, ts);
-      q.keyless = ki.first;
-      q.idx_target_as_key = ki.second;
-      q.key_width = 8;
-    } else {
-      q.desc_type = MI355Q_GROUP_BY_BASELINE_HASH;
-      q.entry_count = p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess
-                                                          : 16384;
-      // pick_baseline_key_width (QueryMemoryDescriptor.cpp:113-146)
-      int kw = 8;
+      q.entry_count = std::max<int64_t>(bucketed_cardinality(r), 1);
+      q.group_min[0] = r.min;
+      q.group_card[0] = bucketed_cardinality(r);
+      q.group_bucket[0] = q.bucket;
+      q.group_null_key[0] = r.max + (q.bucket ? q.bucket : 1);  // translated_null_value
+      q.group_has_nulls[0] = r.has_nulls;
+    }
+  } else {
+    // getColRangeInfo, several group columns (GroupByAndAggregate.cpp:241-283): the product of
+    // the per-column bucketed cardinalities decides; zero, > g_baseline_groupby_threshold
+    // (1 000 000, Execute.cpp:113) or a checked_int64_t overflow -> baseline
+    __int128 cardinality = 1;
+    bool has_nulls = false;
+    for (int g = 0; g < p.n_group_cols && !baseline; ++g) {
+      const auto& r = p.col_ranges[p.group_cols[g]];
+      if (!r.valid || r.min > r.max) {  // get_expr_range_info: not a perfect-hash candidate
+        baseline = true;
+        break;
+      }
+      const __int128 crt = ((__int128)r.max - (__int128)r.min) / (r.bucket > 0 ? r.bucket : 1) + 1 +
+                           (r.has_nulls ? 1 : 0);
+      cardinality *= crt;
+      if (crt > INT64_MAX || cardinality > INT64_MAX) baseline = true;
+      has_nulls = has_nulls || r.has_nulls;
+    }
+    if (!baseline && (cardinality == 0 || cardinality > 1000000)) baseline = true;
+    if (!baseline) {
+      q.desc_type = MI355Q_GROUP_BY_PERFECT_HASH;
+      q.min_val = 0;
+      q.max_val = (int64_t)cardinality;
+      q.has_nulls = has_nulls;
+      q.entry_count = (int64_t)cardinality;  // QueryMemoryDescriptor.cpp:336-339
+      for (int g = 0; g < p.n_group_cols; ++g) {
+        const auto& r = p.col_ranges[p.group_cols[g]];
+        q.group_min[g] = r.min;
+        q.group_card[g] = bucketed_cardinality(r);
+        q.group_bucket[g] = r.bucket > 0 ? r.bucket : 0;
+        q.group_null_key[g] = r.max + (r.bucket > 0 ? r.bucket : 1);
+        q.group_has_nulls[g] = r.has_nulls;
+      }
+    }
+  }
+  if (is_group_by && !baseline) {
+    auto ki = keyless_info(p, ts);
+    // QueryMemoryDescriptor.cpp:322-327: "... && !col_range_info.bucket && keyless_info.keyless"
+    q.keyless = ki.first && !q.bucket;
+    q.idx_target_as_key = ki.second;
+  } else if (baseline) {
+    q.desc_type = MI355Q_GROUP_BY_BASELINE_HASH;
+    q.entry_count = p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess
+                                                        : 16384;
+    // pick_baseline_key_width (QueryMemoryDescriptor.cpp:113-146): the widest component
+    int kw = 4;
+    for (int g = 0; g < p.n_group_cols; ++g) {
+      const auto& gcd = p.cols[p.group_cols[g]];
+      const auto& r = p.col_ranges[p.group_cols[g]];
+      int w = 8;
       if (r.valid) {
-        if (type_width(gcd.type) == 8 && r.has_nulls) {
-          kw = 8;
+        if (type_width(logical_type_of(gcd)) == 8 && r.has_nulls) {
+          w = 8;
         } else {
-          kw = (r.min > INT32_MIN && r.max < kEmptyKey32 - 1) ? 4 : 8;
+          w = (r.min > INT32_MIN && r.max < kEmptyKey32 - 1) ? 4 : 8;  // is_valid_int32_range
         }
       }
-      q.key_width = kw;
+      kw = std::max(kw, w);
     }
+    q.key_width = kw;
   }
   // slots: ColSlotContext (ColSlotContext.cpp:35-100), all padded to 8 bytes
   int slot = 0;
@@ -454,6 +561,7 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
     auto& t = ts[i];
     q.target_agg[i] = t.agg;
     q.target_skip_null[i] = t.skip_null;
+    q.target_key_idx[i] = t.key_idx;
     q.target_arg_is_fp[i] = t.arg_fp && t.agg != MI355Q_COUNT;
     q.target_is_fp[i] = (t.agg == MI355Q_AVG) || (t.arg_fp && t.agg != MI355Q_COUNT);
     if (t.agg == MI355Q_PROJECT_KEY && q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
@@ -497,13 +605,12 @@ void init_buffer(const mi355q_qmd& q, int64_t* buf) {
   const int kq = q.key_bytes / 8;
   for (int64_t e = 0; e < q.entry_count; ++e) {
     int64_t* row = buf + e * rq;
-    if (kq) {
+    if (kq) {  // result_set::fill_empty_key: every component EMPTY, padding zero
       if (q.key_width == 4) {
         int32_t* k32 = reinterpret_cast<int32_t*>(row);
-        k32[0] = kEmptyKey32;
-        k32[1] = 0;  // padding
+        for (int i = 0; i < 2 * kq; ++i) k32[i] = i < q.group_col_count ? kEmptyKey32 : 0;
       } else {
-        row[0] = kEmptyKey64;
+        for (int i = 0; i < kq; ++i) row[i] = kEmptyKey64;
       }
     }
     for (int s = 0; s < q.slot_count; ++s) row[kq + s] = q.init_vals[s];
@@ -558,11 +665,67 @@ int64_t* get_group_value(int64_t* groups_buffer, uint32_t entry_count, int64_t k
   return nullptr;
 }
 
-// GroupByRuntime.cpp:208-223 get_group_value_fast (+ _with_original_key :225-241)
-inline int64_t* get_group_value_fast(int64_t* buf, int64_t key, int64_t orig_key,
-                                     int64_t min_key, uint32_t row_size_quad) {
-  int64_t off = (key - min_key) * row_size_quad;
-  if (buf[off] == kEmptyKey64) buf[off] = orig_key;
+// RuntimeFunctions.cpp:1953-1992 get_matching_group_value<T>, key_count components:
+// an empty first component claims the row (memcpy of the whole key), otherwise memcmp.
+template <typename T>
+int64_t* get_matching_group_value_n(int64_t* groups_buffer, uint32_t h, const T* key,
+                                    uint32_t key_count, uint32_t row_size_quad, T empty) {
+  int64_t* row = groups_buffer + (size_t)h * row_size_quad;
+  T* row_ptr = reinterpret_cast<T*>(row);
+  const size_t key_bytes = key_count * sizeof(T);
+  int64_t* slots = row + (key_bytes + 7) / 8;  // align_to_int64(row_ptr + key_count)
+  if (*row_ptr == empty) {
+    memcpy(row_ptr, key, key_bytes);
+    return slots;
+  }
+  if (memcmp(row_ptr, key, key_bytes) == 0) return slots;
+  return nullptr;
+}
+
+// GroupByRuntime.cpp:25-48 get_group_value over a key of key_count components of key_width
+// bytes: h = MurmurHash3(key, key_count * key_width, 0) % entry_count, linear probing.
+// `key` points at the packed components (int32[] or int64[]).
+int64_t* get_group_value_n(int64_t* groups_buffer, uint32_t entry_count, const void* key,
+                           uint32_t key_count, uint32_t key_width, uint32_t row_size_quad) {
+  const uint32_t h = murmur3(key, key_count * key_width, 0) % entry_count;
+  auto match = [&](uint32_t hh) -> int64_t* {
+    if (key_width == 4) {
+      return get_matching_group_value_n<int32_t>(groups_buffer, hh, static_cast<const int32_t*>(key),
+                                                 key_count, row_size_quad, kEmptyKey32);
+    }
+    return get_matching_group_value_n<int64_t>(groups_buffer, hh, static_cast<const int64_t*>(key),
+                                               key_count, row_size_quad, kEmptyKey64);
+  };
+  if (int64_t* m = match(h)) return m;
+  uint32_t hp = (h + 1) % entry_count;
+  while (hp != h) {
+    if (int64_t* m = match(hp)) return m;
+    hp = (hp + 1) % entry_count;
+  }
+  return nullptr;
+}
+
+// RuntimeFunctions.cpp:2077-2091 get_matching_group_value_perfect_hash: 64-bit key columns
+// prepended to the row, written when the first one is still empty.
+inline int64_t* get_matching_group_value_perfect_hash(int64_t* groups_buffer, uint32_t hashed_index,
+                                                      const int64_t* key, uint32_t key_count,
+                                                      uint32_t row_size_quad) {
+  const size_t off = (size_t)hashed_index * row_size_quad;
+  if (groups_buffer[off] == kEmptyKey64) {
+    for (uint32_t i = 0; i < key_count; ++i) groups_buffer[off + i] = key[i];
+  }
+  return groups_buffer + off + key_count;
+}
+
+// GroupByRuntime.cpp:208-223 get_group_value_fast: the row's key column receives the key it
+// was called with — the TRANSLATED key (NULL -> max + 1, GroupByAndAggregate.cpp:1339-1345).
+// (:225-241 _with_original_key is only emitted under must_use_baseline_sort.)
+inline int64_t* get_group_value_fast(int64_t* buf, int64_t key, int64_t min_key, int64_t bucket,
+                                     uint32_t row_size_quad) {
+  int64_t key_diff = key - min_key;
+  if (bucket) key_diff /= bucket;
+  int64_t off = key_diff * row_size_quad;
+  if (buf[off] == kEmptyKey64) buf[off] = key;
   return buf + off + 1;
 }
 // RuntimeFunctions.cpp:2126-2133 get_group_value_fast_keyless
@@ -637,8 +800,8 @@ inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q, const int8_t* 
     }
     return false;
   }
-  const int64_t v = decode_int(cols[q.col], cd.type, pos);
-  if (cd.nullable && v == int_null_of(cd.type)) return false;
+  const int64_t v = decode_col(cd, cols[q.col], pos);
+  if (cd.nullable && v == int_null_of(logical_type_of(cd))) return false;
   switch (q.op) {
     case MI355Q_EQ: return v == q.ival;
     case MI355Q_NE: return v != q.ival;
@@ -654,10 +817,10 @@ inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q, const int8_t* 
 // (TargetExprBuilder.cpp:470-590) would emit for 8-byte slots.
 inline void apply_target(const TargetDesc& t, int64_t* slots, const int8_t* const* cols,
                          int64_t pos, const int8_t* const* inner_cols, int64_t inner_pos,
-                         int64_t key_val) {
+                         const int64_t* key_vals) {
   int64_t* s = slots + t.slot;
   if (t.agg == MI355Q_PROJECT_KEY) {
-    if (t.slot >= 0) *s = key_val;  // agg_id (RuntimeFunctions.cpp:1171)
+    if (t.slot >= 0) *s = key_vals[t.key_idx];  // agg_id (RuntimeFunctions.cpp:1171)
     return;
   }
   if (t.col < 0) {  // COUNT(*)
@@ -700,7 +863,7 @@ inline void apply_target(const TargetDesc& t, int64_t* slots, const int8_t* cons
     }
     return;
   }
-  const int64_t raw = decode_int(col, t.arg_type, p);
+  const int64_t raw = decode_col(*t.cd, col, p);
   const int64_t null_t = int_null_of(t.arg_type);
   switch (t.agg) {
     case MI355Q_COUNT:
@@ -745,9 +908,7 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
   const int rq = q.row_size / 8;
   const int kq = q.key_bytes / 8;
   const bool grouped = q.desc_type != MI355Q_NON_GROUPED_AGGREGATE;
-  const int gc = grouped ? p.group_cols[0] : -1;
-  const int gtype = grouped ? p.cols[gc].type : 0;
-  const bool gnullable = grouped ? p.cols[gc].nullable != 0 : false;
+  const int ng = q.group_col_count;
   for (int64_t pos = 0; pos < num_rows; ++pos) {
     bool pass = true;
     for (int i = 0; i < p.n_quals && pass; ++i) pass = eval_qual(p, p.quals[i], cols, pos);
@@ -755,8 +916,8 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
     int64_t inner_pos = -1;
     if (p.join_outer_col >= 0) {
       const auto& jc = p.cols[p.join_outer_col];
-      const int64_t k = decode_int(cols[p.join_outer_col], jc.type, pos);
-      if (jc.nullable && k == int_null_of(jc.type)) continue;  // hash_join_idx_nullable
+      const int64_t k = decode_col(jc, cols[p.join_outer_col], pos);
+      if (jc.nullable && k == int_null_of(logical_type_of(jc))) continue;  // hash_join_idx_nullable
       if (c.join->hash_type == 0) {
         inner_pos = hash_join_idx(c.join->perfect.data(), k, c.join->min_key, c.join->max_key);
       } else {
@@ -765,33 +926,64 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
       if (inner_pos < 0) continue;  // INNER join: no match drops the row
     }
     int64_t* slots;
-    int64_t key_val = 0;
+    int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};  // group_by_expr_cache_: values as decoded
     if (!grouped) {
       slots = buf;
     } else {
-      const int64_t raw_key = decode_int(cols[gc], gtype, pos);
-      key_val = raw_key;
+      for (int g = 0; g < ng; ++g) {
+        keys[g] = decode_col(p.cols[p.group_cols[g]], cols[p.group_cols[g]], pos);
+      }
       if (q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
-        int64_t k = raw_key;
-        // NULL key -> max + 1 (GroupByAndAggregate.cpp:1339-1345)
-        if (gnullable && raw_key == int_null_of(gtype)) k = q.max_val + 1;
-        if (k < q.min_val || k - q.min_val >= q.entry_count) {
-          return MI355Q_ERR_OUT_OF_SLOTS;  // out-of-range key: reference UB; we flag it
+        // groupByColumnCodegen (IRCodegen.cpp:1413-1512): where the column's range has nulls,
+        // a NULL key is translated to max + 1 before hashing / storing
+        int64_t tk[MI355Q_MAX_GROUP_COLS];
+        for (int g = 0; g < ng; ++g) {
+          const auto& gcd = p.cols[p.group_cols[g]];
+          const bool translate = gcd.nullable && (ng == 1 || q.group_has_nulls[g]);
+          tk[g] = (translate && keys[g] == int_null_of(logical_type_of(gcd))) ? q.group_null_key[g]
+                                                                              : keys[g];
+          // out-of-range key: undefined behaviour in the reference; flagged here
+          const int64_t b = q.group_bucket[g] ? q.group_bucket[g] : 1;
+          if (tk[g] < q.group_min[g] || (tk[g] - q.group_min[g]) / b >= q.group_card[g]) {
+            return MI355Q_ERR_OUT_OF_SLOTS;
+          }
         }
-        slots = q.keyless ? get_group_value_fast_keyless(buf, k, q.min_val, rq)
-                          : get_group_value_fast(buf, k, raw_key, q.min_val, rq);
+        if (ng == 1) {
+          slots = q.keyless ? get_group_value_fast_keyless(buf, tk[0], q.min_val, rq)
+                            : get_group_value_fast(buf, tk[0], q.min_val, q.bucket, rq);
+        } else {
+          // perfect_key_hash (codegenPerfectHashFunction, GroupByAndAggregate.cpp:1546-1598)
+          int64_t hash = 0;
+          for (int g = 0; g < ng; ++g) {
+            int64_t term = tk[g] - q.group_min[g];
+            if (q.group_bucket[g]) term /= q.group_bucket[g];  // CreateSDiv
+            for (int prev = 0; prev < g; ++prev) term *= q.group_card[prev];
+            hash += term;
+          }
+          const uint32_t h32 = (uint32_t)hash;  // CreateTrunc to i32
+          slots = q.keyless ? buf + (size_t)rq * h32  // ..._perfect_hash_keyless :2098-2103
+                            : get_matching_group_value_perfect_hash(buf, h32, tk, ng, rq);
+        }
+      } else if (ng == 1) {
+        slots = get_group_value(buf, (uint32_t)q.entry_count, keys[0], q.key_width, rq);
       } else {
-        slots = get_group_value(buf, (uint32_t)q.entry_count, raw_key, q.key_width, rq);
-        if (!slots) {
-          // row_func returns -pos -> "ran out of slots" (GroupByAndAggregate.cpp:1151-1156)
-          int64_t code = -(pos + 1);
-          return (int32_t)std::max<int64_t>(code, INT32_MIN);
-        }
+        // the sub-keys are stored into an i32 or i64 array of key_count elements
+        // (codegenGroupBy, GroupByAndAggregate.cpp:1316-1372)
+        int32_t k32[MI355Q_MAX_GROUP_COLS];
+        for (int g = 0; g < ng; ++g) k32[g] = (int32_t)keys[g];
+        slots = get_group_value_n(buf, (uint32_t)q.entry_count,
+                                  q.key_width == 4 ? (const void*)k32 : (const void*)keys, ng,
+                                  q.key_width, rq);
+      }
+      if (!slots) {
+        // row_func returns -pos -> "ran out of slots" (GroupByAndAggregate.cpp:1151-1156)
+        int64_t code = -(pos + 1);
+        return (int32_t)std::max<int64_t>(code, INT32_MIN);
       }
       (void)kq;
     }
     for (const auto& t : c.ts) {
-      apply_target(t, slots, cols, pos, c.inner_cols, inner_pos, key_val);
+      apply_target(t, slots, cols, pos, c.inner_cols, inner_pos, keys);
     }
   }
   return 0;
@@ -868,9 +1060,15 @@ int32_t reduce_buffers(const mi355q_qmd& q, int64_t* this_buf, const int64_t* th
     for (int64_t e = 0; e < q.entry_count; ++e) {
       if (is_empty_entry(q, that_buf, e)) continue;
       const int64_t* that_row = that_buf + e * rq;
-      int64_t key = q.key_width == 4 ? (int64_t) * reinterpret_cast<const int32_t*>(that_row)
-                                     : that_row[0];
-      int64_t* slots = get_group_value(this_buf, (uint32_t)q.entry_count, key, q.key_width, rq);
+      int64_t* slots;
+      if (q.group_col_count <= 1) {
+        int64_t key = q.key_width == 4 ? (int64_t) * reinterpret_cast<const int32_t*>(that_row)
+                                       : that_row[0];
+        slots = get_group_value(this_buf, (uint32_t)q.entry_count, key, q.key_width, rq);
+      } else {  // the row's key bytes are the key (get_group_value_reduction)
+        slots = get_group_value_n(this_buf, (uint32_t)q.entry_count, that_row, q.group_col_count,
+                                  q.key_width, rq);
+      }
       if (!slots) return MI355Q_ERR_OUT_OF_SLOTS;
       for (int t = 0; t < q.n_targets; ++t) reduce_one_target(q, t, slots, that_row + kq);
     }
@@ -880,7 +1078,7 @@ int32_t reduce_buffers(const mi355q_qmd& q, int64_t* this_buf, const int64_t* th
     if (is_empty_entry(q, that_buf, e)) continue;
     int64_t* this_row = this_buf + e * rq;
     const int64_t* that_row = that_buf + e * rq;
-    if (kq) this_row[0] = that_row[0];  // key memcpy from rhs (ResultSetReductionJIT.cpp:705-711)
+    for (int k = 0; k < kq; ++k) this_row[k] = that_row[k];  // key memcpy from rhs (ResultSetReductionJIT.cpp:705-711)
     for (int t = 0; t < q.n_targets; ++t) reduce_one_target(q, t, this_row + kq, that_row + kq);
   }
   return 0;
@@ -910,7 +1108,26 @@ ORC_EXPORT int64_t orc_get_group_value_slot(int64_t* buf, uint32_t entry_count, 
 }
 ORC_EXPORT int64_t orc_get_group_value_fast_slot(int64_t* buf, int64_t key, int64_t min_key,
                                                  uint32_t row_size_quad) {
-  return get_group_value_fast(buf, key, key, min_key, row_size_quad) - buf;
+  return get_group_value_fast(buf, key, min_key, 0, row_size_quad) - buf;
+}
+ORC_EXPORT int64_t orc_get_group_value_fast_bucket_slot(int64_t* buf, int64_t key, int64_t min_key,
+                                                        int64_t bucket, uint32_t row_size_quad) {
+  return get_group_value_fast(buf, key, min_key, bucket, row_size_quad) - buf;
+}
+// multi-component keys: `key` = key_count packed int32 / int64 components
+ORC_EXPORT int64_t orc_get_group_value_n_slot(int64_t* buf, uint32_t entry_count, const void* key,
+                                              uint32_t key_count, uint32_t key_width,
+                                              uint32_t row_size_quad) {
+  int64_t* p = get_group_value_n(buf, entry_count, key, key_count, key_width, row_size_quad);
+  return p ? (p - buf) : -1;
+}
+ORC_EXPORT int64_t orc_perfect_hash_slot(int64_t* buf, uint32_t hashed_index, const int64_t* key,
+                                         uint32_t key_count, uint32_t row_size_quad) {
+  return get_matching_group_value_perfect_hash(buf, hashed_index, key, key_count, row_size_quad) - buf;
+}
+// the column fetch of the row function for an encoded column
+ORC_EXPORT int64_t orc_decode_col(const mi355q_col_desc* cd, const void* col, int64_t pos) {
+  return decode_col(*cd, static_cast<const int8_t*>(col), pos);
 }
 
 // ---- join build (restating HashJoinRuntime.cpp:71-86,203-216 and :346-373,505-538,575-640)
@@ -1093,7 +1310,8 @@ ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64
       is_null[o] = 0;
       const int s = q->target_slot[t];
       if (q->target_agg[t] == MI355Q_PROJECT_KEY && s < 0) {
-        ival[o] = q->key_width == 4 ? (int64_t) * reinterpret_cast<const int32_t*>(row) : row[0];
+        const int ki = q->target_key_idx[t];
+        ival[o] = q->key_width == 4 ? (int64_t) reinterpret_cast<const int32_t*>(row)[ki] : row[ki];
         is_null[o] = ival[o] == q->target_null[t];
         continue;
       }

@@ -55,6 +55,16 @@ def lib() -> C.CDLL:
                                                C.c_uint32]
         l.orc_get_group_value_fast_slot.restype = C.c_int64
         l.orc_get_group_value_fast_slot.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint32]
+        l.orc_get_group_value_fast_bucket_slot.restype = C.c_int64
+        l.orc_get_group_value_fast_bucket_slot.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64,
+                                                           C.c_uint32]
+        l.orc_get_group_value_n_slot.restype = C.c_int64
+        l.orc_get_group_value_n_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
+                                                 C.c_uint32, C.c_uint32]
+        l.orc_perfect_hash_slot.restype = C.c_int64
+        l.orc_perfect_hash_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+        l.orc_decode_col.restype = C.c_int64
+        l.orc_decode_col.argtypes = [P(capi.ColDesc), C.c_void_p, C.c_int64]
         l.orc_join_build.restype = C.c_void_p
         l.orc_join_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                      C.c_int64, C.c_int, C.c_int64, P(C.c_int32)]
@@ -108,6 +118,10 @@ def ref_lib() -> Optional[C.CDLL]:
     r.fixed_width_int_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     r.fixed_width_double_decode.restype = C.c_double
     r.fixed_width_double_decode.argtypes = [C.c_void_p, C.c_int64]
+    r.fixed_width_unsigned_decode.restype = C.c_int64
+    r.fixed_width_unsigned_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
+    r.fixed_width_small_date_decode.restype = C.c_int64
+    r.fixed_width_small_date_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
     return r
 
 

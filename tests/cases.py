@@ -180,6 +180,113 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       RelAlgExecutionUnit(descs32, [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(AVG, 2)],
                                           groupby_exprs=[0], max_groups_buffer_entry_guess=5000), frags32))
 
+    # ---- multi-column group by (GroupBy tests with several keys, ExecuteTest.cpp:2587-2873;
+    # multi-column perfect hash :11414-11486, baseline :11487-11530)
+    K0, K1 = TargetExpr(PROJECT_KEY, 0), TargetExpr(PROJECT_KEY, 1)
+    cases.append(Case("multi_perfect_2col_keyed", ra([K0, K1, TargetExpr(SUM, 2)], group=[1, 5]),
+                      frags))                                   # 100 x 200 entries, SUM spans 0 -> keyed
+    cases.append(Case("multi_perfect_2col_keyless", ra([TargetExpr(COUNT), TargetExpr(AVG, 3)], group=[1, 5]), frags))
+    cases.append(Case("multi_perfect_nullable_translate", ra([K0, K1, TargetExpr(SUM, 2), TargetExpr(COUNT, 7)],
+                                                             [Qual(0, LT, 2**30)], group=[10, 1]), frags))
+    cases.append(Case("multi_perfect_keyless_nullable", ra([TargetExpr(COUNT), TargetExpr(MAX, 9)], group=[1, 10]),
+                      frags))
+    cases.append(Case("multi_perfect_3col", ra([TargetExpr(PROJECT_KEY, 2), K0, K1, TargetExpr(COUNT),
+                                                TargetExpr(SUM, 2)], group=[5, 10, 1]), frags))  # 200 x 36 x 100
+    cases.append(Case("multi_baseline_i64_2col", ra([K0, K1, TargetExpr(COUNT), TargetExpr(AVG, 3)], group=[4, 1],
+                                                    guess=3 * n), frags))
+    cases.append(Case("multi_baseline_nullable_i64", ra([K1, K0, TargetExpr(SUM, 2), TargetExpr(MIN, 9)],
+                                                        [Qual(0, GE, 2**29)], group=[8, 10], guess=3 * n), frags))
+    cases.append(Case("multi_baseline_4col", ra([K0, K1, TargetExpr(PROJECT_KEY, 2), TargetExpr(PROJECT_KEY, 3),
+                                                 TargetExpr(COUNT), TargetExpr(MAX, 2)], group=[4, 6, 5, 1],
+                                                guess=4 * n), frags))
+    cases.append(Case("multi_baseline_out_of_slots", ra([TargetExpr(COUNT)], group=[4, 1], guess=2000), frags,
+                      expect_error=-1))
+    # 4-byte components: every key range is a valid int32 range (pick_baseline_key_width)
+    d4, f4 = make_table(rng, n, fs, [
+        (INT32, False, lambda r, m: r.integers(0, 300, m) * 1000003 % (2**31 - 3)),
+        (INT16, True, lambda r, m: r.integers(-20, 20, m)),
+        (INT64, False, lambda r, m: r.integers(10**6, 10**6 + 5, m)),   # int64 column, int32-sized range
+        (DOUBLE, False, lambda r, m: r.random(m)),
+        (INT64, True, lambda r, m: r.integers(-1000, 1000, m)),
+    ])
+    cases.append(Case("multi_baseline_key32_2col",
+                      RelAlgExecutionUnit(d4, [K0, K1, TargetExpr(COUNT), TargetExpr(AVG, 3)],
+                                          groupby_exprs=[0, 1], max_groups_buffer_entry_guess=3 * n), f4))
+    cases.append(Case("multi_baseline_key32_3col_padded",
+                      RelAlgExecutionUnit(d4, [TargetExpr(PROJECT_KEY, 2), K1, K0, TargetExpr(SUM, 4),
+                                               TargetExpr(MIN, 3)],
+                                          groupby_exprs=[0, 1, 2], max_groups_buffer_entry_guess=4 * n), f4))
+
+    # ---- encoded columns (kENCODING_FIXED / _DICT / _DATE_IN_DAYS): decoders + NULL widening
+    def enc_table():
+        m = n
+        fixed16 = rng.integers(-3000, 3000, m).astype(np.int16)             # BIGINT stored in 16 bits
+        fixed16[rng.random(m) < 0.07] = np.int16(-2**15)
+        fixed32 = (rng.integers(0, 500, m) * 4000003 - 10**9).astype(np.int32)  # BIGINT in 32 bits, NOT NULL
+        dict8 = rng.integers(0, 200, m).astype(np.uint8)                    # string ids, 1 byte, nullable
+        dict8[rng.random(m) < 0.05] = np.uint8(255)
+        dict16 = rng.integers(0, 40000, m).astype(np.uint16)                # 2-byte ids, NOT NULL (ids > 32767!)
+        date32 = rng.integers(18000, 18012, m).astype(np.int32)             # DATE in days, nullable
+        date32[rng.random(m) < 0.05] = np.int32(-2**31)
+        date16 = rng.integers(-50, 50, m).astype(np.int16)                  # DATE in 16-bit days
+        val = rng.integers(-10**6, 10**6, m).astype(np.int64)
+        raw = [fixed16, fixed32, dict8, dict16, date32, date16, val]
+
+        def decoded(i):
+            a = raw[i].astype(np.int64)
+            if i == 0:
+                return np.where(raw[0] == np.int16(-2**15), -2**63, a)
+            if i == 2:
+                return np.where(raw[2] == 255, -2**31, a)
+            if i == 4:
+                return np.where(raw[4] == np.int32(-2**31), -2**63, a * 86400)
+            if i == 5:
+                return np.where(raw[5] == np.int16(-2**15), -2**63, a * 86400)
+            return a
+
+        def rng_of(i, null_val, nullable, bucket=0):
+            d = decoded(i)
+            live = d[d != null_val] if nullable else d
+            return ExpressionRange(True, int(live.min()), int(live.max()), bool(nullable and (d == null_val).any()),
+                                   bucket=bucket)
+        descs_e = [
+            InputColDescriptor(INT16, True, rng_of(0, -2**63, True), capi.ENC_FIXED, INT64),
+            InputColDescriptor(INT32, False, rng_of(1, 0, False), capi.ENC_FIXED, INT64),
+            InputColDescriptor(INT8, True, rng_of(2, -2**31, True), capi.ENC_DICT),
+            InputColDescriptor(INT16, False, rng_of(3, 0, False), capi.ENC_DICT),
+            InputColDescriptor(INT32, True, rng_of(4, -2**63, True, 86400), capi.ENC_DATE_IN_DAYS),
+            InputColDescriptor(INT16, True, rng_of(5, -2**63, True, 86400), capi.ENC_DATE_IN_DAYS),
+            InputColDescriptor(INT64, False, col_range([val], INT64, False)),
+        ]
+        # chunks travel as signed arrays of the storage width (the bytes are what matter)
+        stored = [raw[0], raw[1], raw[2].view(np.int8), raw[3].view(np.int16), raw[4], raw[5], raw[6]]
+        per_col = [split(c, fs) for c in stored]
+        return descs_e, [[per_col[c][f] for c in range(len(stored))] for f in range(len(fs))]
+
+    de, fe = enc_table()
+
+    def era(targets, quals=(), group=(), guess=16384):
+        return RelAlgExecutionUnit(list(de), list(targets), list(quals), list(group),
+                                   max_groups_buffer_entry_guess=guess)
+
+    cases.append(Case("enc_nongrouped_fixed_nulls", era([TargetExpr(COUNT, 0), TargetExpr(SUM, 0), TargetExpr(MIN, 0),
+                                                         TargetExpr(MAX, 0), TargetExpr(AVG, 0), TargetExpr(SUM, 1)]),
+                      fe))
+    cases.append(Case("enc_filter_date_and_fixed", era([TargetExpr(COUNT), TargetExpr(MIN, 4), TargetExpr(MAX, 4),
+                                                        TargetExpr(MAX, 5)],
+                                                       [Qual(4, GE, 18005 * 86400), Qual(0, GT, -1000)]), fe))
+    cases.append(Case("enc_group_dict8_nullable", era([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 0),
+                                                       TargetExpr(MIN, 0)], group=[2]), fe))
+    cases.append(Case("enc_group_dict16_unsigned", era([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 6)],
+                                                       group=[3]), fe))
+    cases.append(Case("enc_group_date_bucketed", era([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 0)],
+                                                     group=[4]), fe))           # (key - min) / 86400
+    cases.append(Case("enc_group_date16_dict8_multi", era([TargetExpr(PROJECT_KEY, 0), TargetExpr(PROJECT_KEY, 1),
+                                                           TargetExpr(COUNT), TargetExpr(MAX, 1)], group=[5, 2]), fe))
+    cases.append(Case("enc_group_fixed32_baseline", era([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 0)],
+                                                        group=[1], guess=4000), fe))
+    cases.append(Case("enc_group_fixed16_nullable_key", era([TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], group=[0]), fe))
+
     # ---- empty and tiny inputs
     empty = [[np.zeros(0, NP[t]) for t, _, _ in spec]]
     cases.append(Case("empty_input_nongrouped", ra([TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(AVG, 3)]), empty))

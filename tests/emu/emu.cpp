@@ -24,7 +24,7 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   if (int32_t e = build_dev_plan(*plan, q, &d)) return e;
   if (plan->join_outer_col >= 0) {
     d.join_col = plan->join_outer_col;
-    d.join_type = plan->cols[plan->join_outer_col].type;
+    d.join_type = col_type_code(plan->cols[plan->join_outer_col]);
     d.join_nullable = plan->cols[plan->join_outer_col].nullable != 0;
     d.join_hash_type = join_hash_type;
     d.join_buf = join_buf;
@@ -34,13 +34,8 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     for (int i = 0; i < plan->n_inner_cols; ++i) d.inner_cols[i] = (const int8_t*)in->inner_col_buffers[i];
   }
   if (out_qmd) *out_qmd = q;
-  const int rq = q.row_size / 8, kq = q.key_bytes / 8;
-  for (int64_t e = 0; e < q.entry_count; ++e) {
-    for (int j = 0; j < rq; ++j) {
-      out[e * rq + j] = j < kq ? (q.key_width == 4 ? (int64_t)(uint32_t)kEmptyKey32 : kEmptyKey64)
-                               : q.init_vals[j - kq];
-    }
-  }
+  const int rq = q.row_size / 8;
+  for (int64_t e = 0; e < q.entry_count; ++e) row_init_image(q, out + e * rq);
   const bool ng = q.desc_type == MI355Q_NON_GROUPED_AGGREGATE;
   // emulate several "threads" for the non-grouped fold: rows are dealt round-robin to 7
   // partial rows which are then folded exactly like the kernel's block fold + global merge
@@ -82,38 +77,9 @@ extern "C" int32_t emu_reduce(const mi355q_qmd* q, int64_t* this_buf, const int6
                               int64_t that_entries) {
   DevPlan d;
   std::memset(&d, 0, sizeof(d));
-  d.n_targets = q->n_targets;
-  for (int i = 0; i < q->n_targets; ++i) {
-    d.targets[i].agg = q->target_agg[i];
-    d.targets[i].col = -1;
-    d.targets[i].skip_null = q->target_skip_null[i];
-    d.targets[i].slot = q->target_slot[i];
-    d.targets[i].arg_fp = q->target_arg_is_fp[i];
-  }
-  d.slot_count = q->slot_count;
-  d.desc_type = q->desc_type;
-  d.keyless = q->keyless;
-  d.key_width = q->key_width;
-  d.row_quad = q->row_size / 8;
-  d.key_quad = q->key_bytes / 8;
-  d.entry_count = q->entry_count;
-  for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) d.init_vals[i] = q->init_vals[i];
+  layout_from_qmd(*q, &d);
   for (int64_t e = 0; e < that_entries; ++e) {
-    const int64_t* src = that_rows + e * d.row_quad;
-    if (is_empty_row(d, src, q->idx_target_as_key)) continue;
-    int64_t* slots;
-    if (d.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
-      const int64_t key = d.key_width == 4 ? (int64_t) * (const int32_t*)src : src[0];
-      slots = baseline_find_or_insert(this_buf, (uint32_t)d.entry_count, d.row_quad, d.key_width, key);
-      if (!slots) return MI355Q_ERR_OUT_OF_SLOTS;
-    } else {
-      int64_t* row = this_buf + e * d.row_quad;
-      if (d.key_quad) row[0] = src[0];
-      slots = row + d.key_quad;
-    }
-    for (int i = 0; i < d.n_targets; ++i) {
-      reduce_target<true>(d.targets[i], d.init_vals, slots, src + d.key_quad);
-    }
+    if (int32_t err = reduce_entry<true>(d, q->idx_target_as_key, this_buf, that_rows + e * d.row_quad, e)) return err;
   }
   return 0;
 }

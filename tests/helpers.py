@@ -36,6 +36,16 @@ def _close(a: int, b: int, rtol: float) -> bool:
     return bool(np.isfinite(fa) and np.isfinite(fb) and abs(fa - fb) <= rtol * max(abs(fa), abs(fb), 1e-300))
 
 
+def key_matrix(q: capi.QMD, buf: np.ndarray) -> np.ndarray:
+    """[entries, group_col_count] int64 matrix of the key components stored at the row starts."""
+    kq = q.key_bytes // 8
+    ng = max(q.group_col_count, 1)
+    if q.key_width == 4:
+        k32 = np.ascontiguousarray(buf[:, :kq]).view(np.int32).reshape(buf.shape[0], 2 * kq)
+        return k32[:, :ng].astype(np.int64)
+    return np.ascontiguousarray(buf[:, :ng])
+
+
 def compare_buffers(q: capi.QMD, want: np.ndarray, got: np.ndarray, rtol: float = 1e-9):
     """Perfect-hash / non-grouped: index-aligned, bit-exact for integer quads, rtol on fp64
     slots.  Baseline: compared as key -> slots maps (slot positions are insertion-order
@@ -47,21 +57,19 @@ def compare_buffers(q: capi.QMD, want: np.ndarray, got: np.ndarray, rtol: float 
     fps = fp_slots(q)
     if q.desc_type == capi.GROUP_BY_BASELINE_HASH:
         def live_sorted(buf):
-            if q.key_width == 4:
-                keys = buf[:, 0].copy().view(np.int32)[::2].astype(np.int64)
-                live = keys != EMPTY32
-            else:
-                keys = buf[:, 0]
-                live = keys != EMPTY64
+            keys = key_matrix(q, buf)
+            live = keys[:, 0] != (EMPTY32 if q.key_width == 4 else EMPTY64)
             idx = np.nonzero(live)[0]
-            order = np.argsort(keys[idx], kind="stable")
-            k = keys[idx][order]
-            dup = np.nonzero(k[1:] == k[:-1])[0]
-            assert dup.size == 0, f"duplicate key {int(k[dup[0]])} in table"
+            k = keys[idx]
+            order = np.lexsort(tuple(k[:, c] for c in range(k.shape[1])[::-1]))
+            k = k[order]
+            dup = np.nonzero((k[1:] == k[:-1]).all(axis=1))[0]
+            assert dup.size == 0, f"duplicate key {k[dup[0]].tolist()} in table"
             return k, buf[idx][order][:, kq:]
         kw, sw = live_sorted(want)
         kg, sg = live_sorted(got)
         assert kw.shape == kg.shape and (kw == kg).all(), (kw.shape, kg.shape)
+        kw = kw[:, 0] if kw.shape[1] == 1 else kw
         for s in range(q.slot_count):
             w, g = sw[:, s], sg[:, s]
             diff = np.nonzero(w != g)[0]
@@ -130,29 +138,57 @@ def murmur3_u64(keys: np.ndarray) -> np.ndarray:
     return h
 
 
+def murmur3_words(words: np.ndarray) -> np.ndarray:
+    """MurmurHash3_x86_32, seed 0, of rows of little-endian 4-byte blocks ([n, n_words] uint32):
+    key_hash(key, key_count, key_width) for any key shape (GroupByRuntime.cpp:20-23)."""
+    M = np.uint64(0xFFFFFFFF)
+    w = words.astype(np.uint64)
+
+    def mul(a, b):
+        return (a * np.uint64(b)) & M
+
+    def rotl(x, r):
+        return ((x << np.uint64(r)) | (x >> np.uint64(32 - r))) & M
+
+    h = np.zeros(w.shape[0], dtype=np.uint64)
+    for i in range(w.shape[1]):
+        k1 = mul(w[:, i], 0xcc9e2d51)
+        k1 = mul(rotl(k1, 15), 0x1b873593)
+        h ^= k1
+        h = (mul(rotl(h, 13), 5) + np.uint64(0xe6546b64)) & M
+    h ^= np.uint64(4 * w.shape[1])
+    h ^= h >> np.uint64(16)
+    h = mul(h, 0x85ebca6b)
+    h ^= h >> np.uint64(13)
+    h = mul(h, 0xc2b2ae35)
+    h ^= h >> np.uint64(16)
+    return h
+
+
 def check_probe_invariant(q: capi.QMD, buf: np.ndarray):
     """A baseline buffer must be a valid image of get_group_value's linear probing
     (GroupByRuntime.cpp:25-48): every key sits at or after its home slot
-    MurmurHash3(key) % entry_count (cyclically) with no empty slot in between — i.e. the
-    reference's own probe sequence finds it."""
-    if q.desc_type != capi.GROUP_BY_BASELINE_HASH or q.key_width != 8 or q.key_bytes != 8:
+    MurmurHash3(key bytes) % entry_count (cyclically) with no empty slot in between — i.e. the
+    reference's own probe sequence finds it.  Any key shape (1..4 components, 4 or 8 bytes)."""
+    if q.desc_type != capi.GROUP_BY_BASELINE_HASH:
         return
-    rq = q.row_size // 8
+    rq, kq = q.row_size // 8, q.key_bytes // 8
     rows = buf.reshape(-1, rq)
     n = rows.shape[0]
-    keys = rows[:, 0]
-    live = keys != EMPTY64
+    n_words = max(q.group_col_count, 1) * (q.key_width // 4)
+    words = np.ascontiguousarray(rows[:, :kq]).view(np.uint32).reshape(n, 2 * kq)[:, :n_words]
+    live = key_matrix(q, rows)[:, 0] != (EMPTY32 if q.key_width == 4 else EMPTY64)
     pos = np.nonzero(live)[0]
     if pos.size == 0:
         return
-    home = (murmur3_u64(keys[pos]) % np.uint64(n)).astype(np.int64)
+    home = (murmur3_words(words[pos]) % np.uint64(n)).astype(np.int64)
     # number of empty slots in the cyclic interval [home, pos) must be zero
     empties = np.concatenate([[0], np.cumsum(~live)]).astype(np.int64)  # empties[i] = # empty in [0, i)
     total_empty = int(empties[n])
     fwd = pos >= home
     gap = np.where(fwd, empties[pos] - empties[home], total_empty - empties[home] + empties[pos])
     bad = np.nonzero(gap != 0)[0]
-    assert bad.size == 0, (bad.size, pos[bad[:5]], home[bad[:5]], keys[pos[bad[:5]]])
+    assert bad.size == 0, (bad.size, pos[bad[:5]], home[bad[:5]], rows[pos[bad[:5]], :kq])
 
 
 _emu = None

@@ -114,7 +114,10 @@ def test_out_of_slots_retry_ladder(torch_cuda, oracle):
 
 @pytest.mark.parametrize("name", ["simple_aggs_all", "simple_aggs_nullable", "perfect_key_sum_projectkey",
                                   "perfect_nullable_args", "perfect_nullable_key", "baseline_count_avg",
-                                  "baseline_nullable_args", "baseline_key32_compact"])
+                                  "baseline_nullable_args", "baseline_key32_compact",
+                                  "multi_perfect_nullable_translate", "multi_perfect_2col_keyless",
+                                  "multi_baseline_i64_2col", "multi_baseline_key32_3col_padded",
+                                  "enc_group_date_bucketed"])
 def test_device_reduce_matches_oracle(torch_cuda, oracle, name):
     """mi355q_result_reduce (device) == ResultSetStorage::reduce restated (oracle), and the
     reduced halves equal the single pass — what Tests/GpuSharedMemoryTest.cpp checks for
@@ -558,3 +561,107 @@ def test_heavy_hitters_at_scale(torch_cuda):
     ival, dval, nul = rs.fetch()
     hot = ival[ival[:, 0] == 7 + 1000003 * 4242]
     assert hot.shape[0] == 1 and abs(hot[0, 1] / (total * 0.5 * 0.25) - 1) < 0.01
+
+
+@pytest.mark.parametrize("shape", ["i64_pairs", "i32_triples", "hot_pairs"])
+def test_multi_column_keys_at_scale(torch_cuda, oracle, shape):
+    """Multi-column baseline keys under real contention: a few million rows racing for the rows
+    of one table (the first key component is the write lock while a row's key is being laid
+    down), ten hot groups taking every row of a wave, 8- and 4-byte components incl. the padded
+    12-byte key.  Table == oracle (as key -> slots maps), valid probing image, device reduce of
+    two halves, the keyed multi-GPU merge pieces (partition by whole-key hash + merge) and a
+    device top-k ordered by the SECOND key column."""
+    from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, InputColDescriptor, Qual,
+                                      RelAlgExecutionUnit, TargetExpr)
+    from heavydb_amd.multi_gpu import HipShard
+    from tests.helpers import key_matrix
+    torch = torch_cuda
+    rng = np.random.default_rng(41)
+    n = 3_000_000
+    if shape == "i64_pairs":
+        a = (rng.integers(0, 2000, n) * 1000003 + 7).astype(np.int64)
+        b = rng.integers(-50, 50, n).astype(np.int64)
+        b[rng.random(n) < 0.05] = -2**63
+        keys = [(a, capi.INT64, False), (b, capi.INT64, True)]
+        guess = 500_000
+    elif shape == "i32_triples":
+        a = (rng.integers(0, 700, n) * 1000003 % (2**31 - 3)).astype(np.int32)
+        b = rng.integers(-20, 20, n).astype(np.int16)
+        b[rng.random(n) < 0.05] = -2**15
+        c = rng.integers(10**6, 10**6 + 6, n).astype(np.int64)
+        keys = [(a, capi.INT32, False), (b, capi.INT16, True), (c, capi.INT64, False)]
+        guess = 400_000
+    else:
+        a = (rng.integers(0, 5, n) * 10**12).astype(np.int64)
+        b = rng.integers(0, 2, n).astype(np.int64)
+        keys = [(a, capi.INT64, False), (b, capi.INT64, False)]
+        guess = 16384
+    val = (rng.random(n) * 1000.0).astype(np.float64)
+    fil = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+    nk = len(keys)
+    descs = []
+    for arr, t, nullable in keys:
+        live = arr[arr != np.iinfo(arr.dtype).min] if nullable else arr
+        descs.append(InputColDescriptor(t, nullable, ExpressionRange(True, int(live.min()), int(live.max()),
+                                                                     bool(nullable and (len(live) < len(arr))))))
+    descs += [InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0)),
+              InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+    targets = [TargetExpr(capi.PROJECT_KEY, i) for i in range(nk)] + \
+        [TargetExpr(capi.COUNT), TargetExpr(capi.AVG, nk), TargetExpr(capi.MAX, nk)]
+    ra = RelAlgExecutionUnit(descs, targets, [Qual(nk + 1, capi.LT, 2**30)], list(range(nk)),
+                             max_groups_buffer_entry_guess=guess)
+    cols = [k[0] for k in keys] + [val, fil]
+    cuts = [0, n // 3, n // 3 + 7, n]
+    frags = [[c[cuts[i]:cuts[i + 1]] for c in cols] for i in range(3)]
+    q, want, code = oracle.execute(ra.to_plan(), frags, n_threads=3)
+    assert code == 0 and q.desc_type == capi.GROUP_BY_BASELINE_HASH and q.group_col_count == nk
+    assert q.key_width == (4 if shape == "i32_triples" else 8)
+    dev = [torch.from_numpy(c).cuda() for c in cols]
+
+    def fetch(lo, hi):
+        return FetchResult([[int(t.data_ptr()) + cuts[i] * t.element_size() for t in dev] for i in range(lo, hi)],
+                           [cuts[i + 1] - cuts[i] for i in range(lo, hi)], keepalive=dev)
+    ex = Executor(0)
+    rs = ex.executeWorkUnit(ra, fetch(0, 3), allow_retry=False)
+    qmd_equal(q, rs.getQueryMemDesc())
+    got = rs.getStorage()
+    compare_buffers(q, want, got, 1e-9)
+    check_probe_invariant(q, got)
+    compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
+    # device reduce of two halves == the single pass
+    r1 = ex.executeWorkUnit(ra, fetch(0, 1), allow_retry=False)
+    r2 = ex.executeWorkUnit(ra, fetch(1, 3), allow_retry=False)
+    r1.reduce(r2)
+    compare_buffers(q, want, r1.getStorage(), 1e-9)
+    check_probe_invariant(q, r1.getStorage())
+    # keyed multi-GPU merge pieces: 3 destinations, whole-key hash
+    sh = HipShard.execute(torch, ex, ra, fetch(0, 3))
+    rows, counts = sh.partition_rows(3)
+    rq = q.row_size // 8
+    merged = []
+    for d in range(3):
+        out = sh.fresh_like()
+        lo = sum(counts[:d])
+        out.merge_rows(rows[lo:lo + counts[d]].contiguous())
+        torch.cuda.synchronize()
+        tab = out.buffer().cpu().numpy()
+        check_probe_invariant(q, tab.reshape(-1))
+        km = key_matrix(q, tab)
+        merged.append(tab[km[:, 0] != (2**31 - 1 if q.key_width == 4 else 2**63 - 1)])
+    assert sum(len(m) for m in merged) == oracle.row_count(q, want) and all(len(m) for m in merged[:2])
+    full = oracle.init_buffer(q).reshape(q.entry_count, -1)
+    allrows = np.concatenate(merged)
+    full[:allrows.shape[0]] = allrows
+    compare_buffers(q, want, full.reshape(-1), 1e-9)
+    # top-k ordered by the second key column, descending, NULLs last
+    k = 50
+    out = torch.empty((k, rq), dtype=torch.int64, device="cuda")
+    got_n = rs.sort(1, k, int(out.data_ptr()), desc=True, nulls_first=False)
+    top = key_matrix(q, out.cpu().numpy()[:got_n])[:, 1]
+    livek = key_matrix(q, got.reshape(-1, rq))
+    livek = livek[livek[:, 0] != (2**31 - 1 if q.key_width == 4 else 2**63 - 1)][:, 1]
+    null2 = {capi.INT64: -2**63, capi.INT16: -2**15}.get(keys[1][1]) if keys[1][2] else None
+    order = np.sort(np.where(livek == null2, -np.inf, livek.astype(np.float64)) if null2 is not None
+                    else livek.astype(np.float64))[::-1][:k]
+    got_order = np.where(top == null2, -np.inf, top.astype(np.float64)) if null2 is not None else top.astype(np.float64)
+    assert got_n == min(k, len(livek)) and np.array_equal(got_order, order)

@@ -37,11 +37,8 @@ class NumpyShard:
         return self._torch.from_numpy(self._np)  # shares memory: all_reduce results land in place
 
     def partition_rows(self, n_parts):
-        from tests.helpers import murmur3_u64
-        assert self._q.key_width == 8
         live = self._np[self._np[:, 0] != EMPTY64]
-        # same shard function as mi355q_shard_partition: upper hash bits
-        part = ((murmur3_u64(live[:, 0]) * np.uint64(n_parts)) >> np.uint64(32)).astype(np.int64)
+        part = _owner(self._q, live, n_parts)
         order = np.argsort(part, kind="stable")
         counts = np.bincount(part, minlength=n_parts).tolist()
         return self._torch.from_numpy(np.ascontiguousarray(live[order])), [int(c) for c in counts]
@@ -64,6 +61,20 @@ class NumpyShard:
         assert self._orc.reduce(self._q, self._np, other) == 0
 
 
+def _owner(q, live, n_parts):
+    """The shard function of mi355q_shard_partition: upper bits of the key hash — of the single
+    int64 key, or of all the key bytes for a multi-column key."""
+    from tests.helpers import murmur3_u64, murmur3_words
+    assert q.key_width == 8
+    if q.group_col_count > 1:
+        kq = q.key_bytes // 8
+        words = np.ascontiguousarray(live[:, :kq]).view(np.uint32).reshape(live.shape[0], 2 * kq)
+        h = murmur3_words(words[:, :2 * q.group_col_count])
+    else:
+        h = murmur3_u64(live[:, 0])
+    return ((h * np.uint64(n_parts)) >> np.uint64(32)).astype(np.int64)
+
+
 def _table(shape, seed=7):
     from heavydb_amd import capi
     from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
@@ -81,6 +92,18 @@ def _table(shape, seed=7):
         ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1)],
                                  [Qual(2, capi.LT, 2**30)], [0], max_groups_buffer_entry_guess=2 * n_keys)
         cols = [key, val, fil]
+    elif shape == "keyed_two_columns":  # multi-column baseline key: sharded by the whole key's hash
+        k0 = (rng.integers(0, 900, n) * 1000003 + 7).astype(np.int64)
+        k1 = rng.integers(-5, 5, n).astype(np.int64)
+        k1[rng.random(n) < 0.1] = -(2**63)
+        val = (rng.random(n) * 1000.0).astype(np.float64)
+        descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, 899 * 1000003 + 7)),
+                 InputColDescriptor(capi.INT64, True, ExpressionRange(True, -5, 4, True)),
+                 InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY, 0), TargetExpr(capi.PROJECT_KEY, 1),
+                                         TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 2)],
+                                 groupby_exprs=[0, 1], max_groups_buffer_entry_guess=30_000)
+        cols = [k0, k1, val]
     elif shape == "perfect":
         key = rng.integers(0, 1000, n).astype(np.int32)
         val = rng.integers(-500_000, 500_001, n).astype(np.int64)
@@ -132,9 +155,8 @@ def _worker(rank, world, port, shape, errq):
         got = out.buffer().numpy()
         if q.desc_type == capi.GROUP_BY_BASELINE_HASH:
             # every rank owns exactly the keys of its shard after the all-to-all ...
-            from tests.helpers import murmur3_u64
             live = got[got[:, 0] != EMPTY64]
-            owner = ((murmur3_u64(live[:, 0]) * np.uint64(world)) >> np.uint64(32)).astype(np.int64)
+            owner = _owner(q, live, world)
             if rank != 0:
                 assert (owner == rank).all()
             else:  # ... and rank 0 additionally gathered everything
@@ -156,7 +178,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("shape", ["keyed", "perfect", "perfect_nullable", "non_grouped"])
+@pytest.mark.parametrize("shape", ["keyed", "keyed_two_columns", "perfect", "perfect_nullable", "non_grouped"])
 def test_merge_over_gloo(shape, world):
     import torch.multiprocessing as mp
     from oracle import oracle as orc

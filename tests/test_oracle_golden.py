@@ -71,6 +71,72 @@ def test_perfect_groupby_traces(oracle, golden):
         assert [int(x) for x in buf] == tr["final"]
 
 
+def test_perfect_bucketed_traces(oracle, golden):
+    """get_group_value_fast with a bucket (DATE keys): reference-generated trace."""
+    for tr in golden["perfect_bucket_traces"]:
+        rq = tr["row_quad"]
+        buf = np.zeros(tr["entries"] * rq, dtype=np.int64)
+        buf[0::rq] = EMPTY64
+        for k in tr["keys"]:
+            s = oracle.lib().orc_get_group_value_fast_bucket_slot(buf.ctypes.data, k, tr["min_key"],
+                                                                  tr["bucket"], rq)
+            buf[s] += 1
+        assert [int(x) for x in buf] == tr["final"]
+
+
+def test_multi_column_baseline_traces(oracle, golden):
+    """get_group_value over 2- and 3-component keys of 8 and 4 bytes (incl. the padded 12-byte
+    key and a full table), slot by slot against the reference's own function."""
+    for tr in golden["multi_baseline_traces"]:
+        n, kw, kc, rq = tr["entry_count"], tr["key_width"], tr["key_count"], tr["row_quad"]
+        dt = np.int64 if kw == 8 else np.int32
+        kq = (kc * kw + 7) // 8
+        buf = np.zeros(n * rq, dtype=np.int64)
+        for e in range(n):
+            buf[e * rq:e * rq + kq].view(dt)[:kc] = EMPTY64 if kw == 8 else EMPTY32
+        landed = []
+        for k in tr["keys"]:
+            kb = np.array(k, dtype=dt)
+            s = oracle.lib().orc_get_group_value_n_slot(buf.ctypes.data, n, kb.ctypes.data, kc, kw, rq)
+            landed.append(int(s))
+            if s >= 0:
+                buf[s] += 1
+        assert landed == tr["slot_quads"]
+        assert [int(x) for x in buf] == tr["final"]
+
+
+def test_encoded_decoders(oracle, golden):
+    """fixed_width_unsigned_decode / fixed_width_small_date_decode vectors from the reference
+    == the oracle's column fetch for ENC_DICT (NOT NULL: no sentinel widening) and
+    ENC_DATE_IN_DAYS columns."""
+    import ctypes as C
+    from heavydb_amd import capi
+    tmap = {1: capi.INT8, 2: capi.INT16, 4: capi.INT32}
+    for d in golden["unsigned_decode"]:
+        raw = np.frombuffer(bytes.fromhex(d["hex"]), dtype=np.uint8).copy()
+        cd = capi.ColDesc(tmap[d["width"]], 0, capi.ENC_DICT, 0)
+        got = [int(oracle.lib().orc_decode_col(C.byref(cd), raw.ctypes.data, i)) for i in range(len(d["decoded"]))]
+        assert got == d["decoded"]
+        # nullable: the all-ones id is NULL and widens to NULL_INT
+        cdn = capi.ColDesc(tmap[d["width"]], 1, capi.ENC_DICT, 0)
+        gotn = [int(oracle.lib().orc_decode_col(C.byref(cdn), raw.ctypes.data, i)) for i in range(len(d["decoded"]))]
+        top = 255 if d["width"] == 1 else 65535
+        assert gotn == [(-2**31 if v == top else v) for v in d["decoded"]]
+    for d in golden["small_date_decode"]:
+        raw = np.frombuffer(bytes.fromhex(d["hex"]), dtype=np.uint8).copy()
+        cd = capi.ColDesc(tmap[d["width"]], 1, capi.ENC_DATE_IN_DAYS, 0)
+        got = [int(oracle.lib().orc_decode_col(C.byref(cd), raw.ctypes.data, i)) for i in range(len(d["decoded"]))]
+        assert got == d["decoded"]
+    # ENC_FIXED: sign-extending load (pinned by int_decode above) + NULL widening
+    v = np.array([5, -7, -(2**15), 2**15 - 1], dtype=np.int16)
+    cd = capi.ColDesc(capi.INT16, 1, capi.ENC_FIXED, capi.INT64)
+    assert [int(oracle.lib().orc_decode_col(C.byref(cd), v.ctypes.data, i)) for i in range(4)] == \
+        [5, -7, -(2**63), 2**15 - 1]
+    cd = capi.ColDesc(capi.INT16, 0, capi.ENC_FIXED, capi.INT32)
+    assert [int(oracle.lib().orc_decode_col(C.byref(cd), v.ctypes.data, i)) for i in range(4)] == \
+        [5, -7, -(2**15), 2**15 - 1]
+
+
 def test_perfect_join_probe(oracle, golden):
     pj = golden["perfect_join"]
     j = oracle.OracleJoin(np.array([3, 1, 4], dtype=np.int64), 4, pj["min"], pj["max"])
