@@ -26,6 +26,8 @@ ENC_NONE, ENC_FIXED, ENC_DICT, ENC_DATE_IN_DAYS = 0, 1, 2, 3
 EQ, NE, LT, GT, LE, GE = 0, 2, 3, 4, 5, 6
 # mi355q_agg (SQLAgg values)
 AVG, MIN, MAX, SUM, COUNT, PROJECT_KEY = 0, 1, 2, 3, 4, 100
+# mi355q_join_kind
+JOIN_INNER, JOIN_LEFT = 0, 1
 # mi355q_desc_type
 GROUP_BY_PERFECT_HASH, GROUP_BY_BASELINE_HASH, NON_GROUPED_AGGREGATE = 0, 1, 4
 # generator kinds
@@ -79,6 +81,10 @@ class Plan(C.Structure):
         ("targets", Target * MAX_TARGETS),
         ("join_outer_col", C.c_int32),
         ("join_table", C.c_void_p),
+        ("n_join_cols", C.c_int32),
+        ("join_outer_cols", C.c_int32 * MAX_GROUP_COLS),
+        ("join_kind", C.c_int32),
+        ("reserved2", C.c_int32),
         ("max_groups_buffer_entry_guess", C.c_int64),
         ("bigint_count", C.c_int32),
         ("reserved", C.c_int32),
@@ -169,6 +175,12 @@ class JoinSpec(C.Structure):
         ("num_rows", C.c_int64),
         ("key_range", Range),
         ("max_perfect_entries", C.c_int64),
+        ("n_keys", C.c_int32),
+        ("one_to_many", C.c_int32),
+        ("more_key_types", C.c_int32 * (MAX_GROUP_COLS - 1)),
+        ("more_key_nullables", C.c_int32 * (MAX_GROUP_COLS - 1)),
+        ("more_key_buffers", C.c_void_p * (MAX_GROUP_COLS - 1)),
+        ("keyed_entry_count", C.c_int64),
     ]
 
 
@@ -202,6 +214,7 @@ SYMBOLS = [
      [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
     ("mi355q_join_build", C.c_int32, [_P(JoinSpec), C.c_void_p, _P(C.c_void_p)]),
     ("mi355q_join_free", None, [C.c_void_p]),
+    ("mi355q_join_key_shape", C.c_int32, [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),
     ("mi355q_join_info", C.c_int32,
      [C.c_void_p, _P(C.c_int32), _P(C.c_int64), _P(C.c_int64), _P(C.c_int64), _P(C.c_void_p),
       _P(C.c_int64), _P(C.c_float)]),

@@ -26,8 +26,9 @@ using namespace mq;
 
 struct mi355q_join_table {
   int device_id = 0;
-  int hash_type = 0;  // 0 perfect one-to-one, 1 keyed one-to-one
+  int hash_type = 0;  // 0 perfect 1:1, 1 keyed 1:1, 2 perfect 1:N, 3 keyed 1:N (mi355q.h)
   int key_type = MI355Q_INT64;
+  int n_keys = 1, width = 8;  // key components / component width of keyed tables
   int64_t entry_count = 0;
   int64_t min_key = 0, max_key = 0;
   void* buf = nullptr;
@@ -135,13 +136,26 @@ RowInit make_row_init(const mi355q_qmd& q) {
 
 int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
   if (p.join_outer_col < 0) return MI355Q_OK;
-  if (!p.join_table || p.join_outer_col >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
-  const mi355q_col_desc& jc = p.cols[p.join_outer_col];
-  if (type_is_fp(jc.type)) return MI355Q_ERR_UNSUPPORTED;
+  if (!p.join_table) return MI355Q_ERR_INVALID_PLAN;
   const mi355q_join_table* jt = p.join_table;
-  d->join_col = p.join_outer_col;
-  d->join_type = col_type_code(jc);
-  d->join_nullable = jc.nullable != 0;
+  const int n_keys = p.n_join_cols > 1 ? p.n_join_cols : 1;
+  if (n_keys > MI355Q_MAX_GROUP_COLS || n_keys != jt->n_keys) return MI355Q_ERR_INVALID_PLAN;
+  if (p.join_kind != MI355Q_JOIN_INNER && p.join_kind != MI355Q_JOIN_LEFT) return MI355Q_ERR_UNSUPPORTED;
+  for (int i = 0; i < n_keys; ++i) {
+    const int c = (i == 0 && p.n_join_cols <= 1) ? p.join_outer_col : p.join_outer_cols[i];
+    if (c < 0 || c >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
+    const mi355q_col_desc& jc = p.cols[c];
+    if (type_is_fp(jc.type)) return MI355Q_ERR_UNSUPPORTED;
+    d->join_cols[i] = c;
+    d->join_types[i] = col_type_code(jc);
+    d->join_nullables[i] = jc.nullable != 0;
+  }
+  d->join_col = d->join_cols[0];
+  d->join_type = d->join_types[0];
+  d->join_nullable = d->join_nullables[0];
+  d->join_n_keys = n_keys;
+  d->join_width = jt->width;
+  d->join_kind = p.join_kind;
   d->join_hash_type = jt->hash_type;
   d->join_buf = jt->buf;
   d->join_bitmap = (const uint32_t*)jt->bitmap;
@@ -163,7 +177,10 @@ int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
   bool used[MI355Q_MAX_COLS] = {false};
   for (int i = 0; i < p.n_quals; ++i) used[p.quals[i].col] = true;
   for (int g = 0; g < p.n_group_cols; ++g) used[p.group_cols[g]] = true;
-  if (p.join_outer_col >= 0) used[p.join_outer_col] = true;
+  if (p.join_outer_col >= 0) {
+    used[p.join_outer_col] = true;
+    for (int i = 1; i < p.n_join_cols && i < MI355Q_MAX_GROUP_COLS; ++i) used[p.join_outer_cols[i]] = true;
+  }
   for (int i = 0; i < p.n_targets; ++i) {
     if (p.targets[i].table == 0 && p.targets[i].col >= 0 && p.targets[i].agg != MI355Q_PROJECT_KEY)
       used[p.targets[i].col] = true;
@@ -685,10 +702,98 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
 }
 
 // ------------------------------------------------------------------------------- joins
+namespace {
+
+// One attempt at one layout.  `one_to_many` selects hash types 2/3 instead of 0/1.
+int32_t join_build_layout(const mi355q_join_spec* spec, bool perfect, bool one_to_many,
+                          const JoinKeyCols& kc, hipStream_t s, mi355q_join_table* jt, int32_t* d_err) {
+  const mi355q_range& r = spec->key_range;
+  const int64_t n = spec->num_rows;
+  if (jt->buf) (void)hipFree(jt->buf);
+  if (jt->bitmap) (void)hipFree(jt->bitmap);
+  jt->buf = jt->bitmap = nullptr;
+  HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int32_t), s));
+  jt->n_keys = kc.n;
+  jt->width = perfect ? 8 : kc.width;
+  auto alloc = [&](int64_t bytes) -> int32_t {
+    jt->bytes = bytes;
+    hipError_t e = hipMalloc(&jt->buf, (size_t)(bytes > 0 ? bytes : 4));
+    if (e != hipSuccess) {
+      last_hip_error = e;
+      return MI355Q_ERR_OUT_OF_GPU_MEM;
+    }
+    return MI355Q_OK;
+  };
+  if (perfect) {
+    jt->min_key = r.min;
+    jt->max_key = r.max;
+    jt->entry_count = r.max - r.min + 1;
+  } else {
+    jt->min_key = jt->max_key = 0;
+    jt->entry_count = spec->keyed_entry_count > 0 ? spec->keyed_entry_count
+                                                  : 2 * std::max<int64_t>(n, 1);  // BaselineJoinHashTable.cpp:484
+    if (jt->entry_count > (int64_t)UINT32_MAX) return MI355Q_ERR_UNSUPPORTED;
+  }
+  const int64_t entries = jt->entry_count;
+  if (!one_to_many) {
+    if (perfect) {
+      jt->hash_type = 0;
+      if (int32_t e = alloc(entries * (int64_t)sizeof(int32_t))) return e;
+      HIP_TRY(hipMemsetAsync(jt->buf, 0xFF, (size_t)jt->bytes, s));  // init_hash_join_buff: -1
+      HIP_TRY(launch_join_fill_perfect(kc.col[0], kc.type[0], kc.nullable[0], n, r.min, r.max,
+                                       (int32_t*)jt->buf, d_err, s));
+      const size_t bm_bytes = (size_t)((entries + 31) / 32) * 4;
+      hipError_t be = hipMalloc(&jt->bitmap, bm_bytes);
+      if (be != hipSuccess) {
+        last_hip_error = be;
+        return MI355Q_ERR_OUT_OF_GPU_MEM;
+      }
+      HIP_TRY(launch_join_presence_bitmap((const int32_t*)jt->buf, entries, (uint32_t*)jt->bitmap, s));
+    } else {
+      jt->hash_type = 1;
+      const int stride = kc.n + 1;
+      if (int32_t e = alloc(entries * stride * kc.width)) return e;
+      HIP_TRY(launch_join_init_keyed(jt->buf, entries, kc.n, stride, kc.width, s));
+      HIP_TRY(launch_join_fill_keyed(kc, n, jt->buf, entries, stride, true, d_err, s));
+    }
+    return MI355Q_OK;
+  }
+  // one-to-many: [keys |] offsets | counts | payloads
+  jt->hash_type = perfect ? 2 : 3;
+  const int64_t key_bytes = perfect ? 0 : entries * kc.n * kc.width;
+  if (int32_t e = alloc(key_bytes + (2 * entries + std::max<int64_t>(n, 1)) * (int64_t)sizeof(int32_t))) return e;
+  if (!perfect) {
+    HIP_TRY(launch_join_init_keyed(jt->buf, entries, kc.n, kc.n, kc.width, s));
+    HIP_TRY(launch_join_fill_keyed(kc, n, jt->buf, entries, kc.n, false, d_err, s));
+  }
+  int32_t* offsets = (int32_t*)((int8_t*)jt->buf + key_bytes);
+  DevWord tiles;
+  HIP_TRY(hipMalloc(&tiles.p, sizeof(int64_t) * (size_t)(entries / 2048 + 2)));
+  HIP_TRY(launch_join_one_to_many(kc, n, jt->hash_type, jt->buf, entries, jt->min_key, jt->max_key, offsets,
+                                  offsets + entries, offsets + 2 * entries, (int64_t*)tiles.p, d_err, s));
+  HIP_TRY(hipStreamSynchronize(s));  // tiles is freed on return
+  return MI355Q_OK;
+}
+
+}  // namespace
+
 int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream, mi355q_join_table** out) {
   if (!spec || !out || spec->num_rows < 0) return MI355Q_ERR_INVALID_PLAN;
-  if (spec->key_type < MI355Q_INT8 || spec->key_type > MI355Q_INT64) return MI355Q_ERR_UNSUPPORTED;
   if (spec->num_rows > (int64_t)INT32_MAX) return MI355Q_ERR_UNSUPPORTED;  // int32 row ids
+  const int n_keys = spec->n_keys > 1 ? spec->n_keys : 1;
+  if (n_keys > MI355Q_MAX_GROUP_COLS) return MI355Q_ERR_INVALID_PLAN;
+  JoinKeyCols kc{};
+  kc.n = n_keys;
+  kc.width = 4;
+  for (int i = 0; i < n_keys; ++i) {
+    kc.col[i] = (const int8_t*)(i == 0 ? spec->key_buffer : spec->more_key_buffers[i - 1]);
+    kc.type[i] = i == 0 ? spec->key_type : spec->more_key_types[i - 1];
+    kc.nullable[i] = i == 0 ? spec->key_nullable : spec->more_key_nullables[i - 1];
+    if (kc.type[i] < MI355Q_INT8 || kc.type[i] > MI355Q_INT64) return MI355Q_ERR_UNSUPPORTED;
+    if (spec->num_rows > 0 && !kc.col[i]) return MI355Q_ERR_INVALID_PLAN;
+    // BaselineJoinHashTable::getKeyComponentWidth: 8 iff an inner key column is wider than 4 bytes
+    if (type_width(kc.type[i]) > 4) kc.width = 8;
+  }
   *out = nullptr;
   DeviceGuard g(spec->device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
@@ -702,14 +807,14 @@ int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream, mi355q_joi
   jt->device_id = spec->device_id;
   jt->key_type = spec->key_type;
   const mi355q_range& r = spec->key_range;
-  // PerfectJoinHashTable::getInstance (PerfectJoinHashTable.cpp:168-246): perfect when the
-  // inner key range is known and max-min+1 entries fit; else keyed (HashJoin.cpp:340-372).
+  // PerfectJoinHashTable::getInstance (PerfectJoinHashTable.cpp:168-246): perfect when there is
+  // ONE key column whose range is known and max-min+1 entries fit; else keyed
+  // (HashJoin.cpp:340-372).
   int64_t max_entries = spec->max_perfect_entries > 0 ? spec->max_perfect_entries : (int64_t)INT32_MAX;
-  bool perfect = !spec->prefer_baseline && r.valid && r.max >= r.min &&
-                 ((__int128)r.max - (__int128)r.min) < (__int128)max_entries;
+  const bool perfect = n_keys == 1 && !spec->prefer_baseline && r.valid && r.max >= r.min &&
+                       ((__int128)r.max - (__int128)r.min) < (__int128)max_entries;
   DevWord err;
   HIP_TRY(hipMalloc(&err.p, sizeof(int32_t)));
-  HIP_TRY(hipMemsetAsync(err.p, 0, sizeof(int32_t), s));
   hipEvent_t e0, e1;
   HIP_TRY(hipEventCreate(&e0));
   HIP_TRY(hipEventCreate(&e1));
@@ -721,53 +826,28 @@ int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream, mi355q_joi
     }
   } eg{e0, e1};
   HIP_TRY(hipEventRecord(e0, s));
-  if (perfect) {
-    jt->hash_type = 0;
-    jt->min_key = r.min;
-    jt->max_key = r.max;
-    jt->entry_count = r.max - r.min + 1;
-    jt->bytes = jt->entry_count * (int64_t)sizeof(int32_t);
-    hipError_t e = hipMalloc(&jt->buf, (size_t)jt->bytes);
-    if (e != hipSuccess) {
-      last_hip_error = e;
-      return MI355Q_ERR_OUT_OF_GPU_MEM;
-    }
-    HIP_TRY(hipMemsetAsync(jt->buf, 0xFF, (size_t)jt->bytes, s));  // init_hash_join_buff: -1
-    HIP_TRY(launch_join_fill_perfect((const int8_t*)spec->key_buffer, spec->key_type,
-                                     spec->key_nullable, spec->num_rows, r.min, r.max,
-                                     (int32_t*)jt->buf, (int32_t*)err.p, s));
-    {
-      const size_t bm_bytes = (size_t)((jt->entry_count + 31) / 32) * 4;
-      hipError_t be = hipMalloc(&jt->bitmap, bm_bytes);
-      if (be != hipSuccess) {
-        last_hip_error = be;
-        return MI355Q_ERR_OUT_OF_GPU_MEM;
-      }
-      HIP_TRY(launch_join_presence_bitmap((const int32_t*)jt->buf, jt->entry_count, (uint32_t*)jt->bitmap, s));
-    }
-  } else {
-    jt->hash_type = 1;
-    jt->entry_count = 2 * std::max<int64_t>(spec->num_rows, 1);  // BaselineJoinHashTable.cpp:484
-    if (jt->entry_count > (int64_t)UINT32_MAX) return MI355Q_ERR_UNSUPPORTED;
-    jt->bytes = jt->entry_count * 16;
-    hipError_t e = hipMalloc(&jt->buf, (size_t)jt->bytes);
-    if (e != hipSuccess) {
-      last_hip_error = e;
-      return MI355Q_ERR_OUT_OF_GPU_MEM;
-    }
-    HIP_TRY(launch_join_init_baseline((int64_t*)jt->buf, jt->entry_count, s));
-    HIP_TRY(launch_join_fill_baseline((const int8_t*)spec->key_buffer, spec->key_type,
-                                      spec->key_nullable, spec->num_rows, (int64_t*)jt->buf,
-                                      jt->entry_count, (int32_t*)err.p, s));
+  int32_t h_err = 0;
+  // the reference tries OneToOne first and rebuilds as OneToMany when the fill reports a
+  // duplicate key (PerfectJoinHashTable::reify / BaselineJoinHashTable::reify)
+  for (int attempt = spec->one_to_many == 2 ? 1 : 0; attempt < 2; ++attempt) {
+    if (int32_t e = join_build_layout(spec, perfect, attempt == 1, kc, s, jt, (int32_t*)err.p)) return e;
+    HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h_err != MI355Q_ERR_JOIN_NOT_ONE_TO_ONE || spec->one_to_many == 0) break;
   }
   HIP_TRY(hipEventRecord(e1, s));
-  int32_t h_err = 0;
-  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipEventElapsedTime(&jt->build_ms, e0, e1);
   if (h_err) return h_err;
   jg.j = nullptr;
   *out = jt;
+  return MI355Q_OK;
+}
+
+int32_t mi355q_join_key_shape(const mi355q_join_table* t, int32_t* key_components, int32_t* component_width) {
+  if (!t) return MI355Q_ERR_INVALID_PLAN;
+  if (key_components) *key_components = t->n_keys;
+  if (component_width) *component_width = t->width;
   return MI355Q_OK;
 }
 

@@ -127,6 +127,38 @@ MQ_HD uint32_t murmur1_u64(uint64_t key) {
   return h;
 }
 
+// MurmurHash1 over n 4-byte words, seed 0: the hash of a (composite) keyed-join key of
+// n_words * 4 bytes (get_composite_key_index_impl / baseline_hash_join_idx_impl,
+// JoinHashTableQueryRuntime.cpp:35-94,140-163)
+MQ_HD uint32_t murmur1_words(const uint32_t* w, int n_words) {
+  const uint32_t m = 0xc6a4a793u;
+  uint32_t h = 0u ^ ((uint32_t)(n_words * 4) * m);
+  for (int i = 0; i < n_words; ++i) {
+    h += w[i];
+    h *= m;
+    h ^= h >> 16;
+  }
+  h *= m;
+  h ^= h >> 10;
+  h *= m;
+  h ^= h >> 17;
+  return h;
+}
+
+// Pack the components of a join key the way the table stores them (int32[] or int64[]);
+// returns the number of 4-byte words.
+MQ_HD int pack_join_key(const int64_t* keys, int n_keys, int width, uint32_t* words) {
+  if (width == 4) {
+    for (int i = 0; i < n_keys; ++i) words[i] = (uint32_t)(int32_t)keys[i];
+    return n_keys;
+  }
+  for (int i = 0; i < n_keys; ++i) {
+    words[2 * i] = (uint32_t)(uint64_t)keys[i];
+    words[2 * i + 1] = (uint32_t)((uint64_t)keys[i] >> 32);
+  }
+  return 2 * n_keys;
+}
+
 // BASELINE.md section 3 generator: u = splitmix64(seed ^ row * golden)
 MQ_HD uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -224,6 +256,12 @@ struct DevPlan {
   const void* join_buf;
   const uint32_t* join_bitmap;  // perfect tables: 1 bit per slot = "slot holds a row id" (or null)
   int64_t join_min, join_max, join_entries;
+  // composite keys / one-to-many / LEFT (join_hash_type: 0 perfect 1:1, 1 keyed 1:1,
+  // 2 perfect 1:N, 3 keyed 1:N — layouts in include/mi355q.h)
+  int32_t join_n_keys, join_width;  // key components and their width in bytes (keyed tables)
+  int32_t join_cols[MI355Q_MAX_GROUP_COLS], join_types[MI355Q_MAX_GROUP_COLS];
+  int32_t join_nullables[MI355Q_MAX_GROUP_COLS];
+  int32_t join_kind, join_pad_;
   const int8_t* inner_cols[MI355Q_MAX_COLS];
 };
 

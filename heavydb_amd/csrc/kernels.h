@@ -58,6 +58,20 @@ hipError_t launch_join_init_baseline(int64_t* tab, int64_t entries, hipStream_t 
 hipError_t launch_join_fill_baseline(const int8_t* keys, int type, int nullable, int64_t n,
                                      int64_t* tab, int64_t entries, int32_t* d_err,
                                      hipStream_t s);
+// inner key columns of a join table build
+struct JoinKeyCols {
+  const int8_t* col[MI355Q_MAX_GROUP_COLS];
+  int32_t type[MI355Q_MAX_GROUP_COLS], nullable[MI355Q_MAX_GROUP_COLS];
+  int32_t n, width;  // components and their width in the table (4 / 8)
+};
+hipError_t launch_join_init_keyed(void* tab, int64_t entries, int n_keys, int stride, int width,
+                                  hipStream_t s);
+hipError_t launch_join_fill_keyed(const JoinKeyCols& kc, int64_t n, void* tab, int64_t entries, int stride,
+                                  bool with_payload, int32_t* d_err, hipStream_t s);
+hipError_t launch_join_one_to_many(const JoinKeyCols& kc, int64_t n, int hash_type, const void* tab,
+                                   int64_t entries, int64_t min_key, int64_t max_key, int32_t* offsets,
+                                   int32_t* counts, int32_t* payloads, int64_t* tile_scratch,
+                                   int32_t* d_err, hipStream_t s);
 hipError_t launch_generate(void* dst, int64_t n_rows, int64_t row_offset, int kind,
                            uint64_t seed, int64_t a, int64_t b, int64_t c, double a_f,
                            int null_every, hipStream_t s);

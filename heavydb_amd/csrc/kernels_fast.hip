@@ -458,6 +458,8 @@ hipError_t launch_baseline_fast(const DevPlan& p, const FragView& fv, int64_t* o
 static bool join_sum_shape(const DevPlan& p, const FragView& fv, JoinSumArgs* a) {
   if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col < 0 || p.n_quals != 0) return false;
   if (p.join_type != MI355Q_INT64 || p.join_nullable) return false;
+  // one-to-one tables with one 8-byte key component, INNER joins
+  if (p.join_hash_type > 1 || p.join_n_keys != 1 || p.join_width != 8 || p.join_kind != MI355Q_JOIN_INNER) return false;
   if (p.n_targets > 4) return false;
   a->kcol = p.join_col;
   a->vcol = -1;

@@ -304,6 +304,245 @@ __global__ __launch_bounds__(kBlock) void k_join_fill_baseline(const int8_t* __r
   }
 }
 
+// ---- composite / one-to-many join tables -------------------------------------------------
+MQ_D bool load_join_key(const JoinKeyCols& kc, int64_t i, int64_t* keys) {
+  bool ok = true;
+  for (int k = 0; k < kc.n; ++k) {
+    keys[k] = decode_int(kc.col[k], kc.type[k], i);
+    // rows with a NULL key component are not inserted (GenericKeyHandler skips them,
+    // fill_hash_join_buff_impl :203-216)
+    ok = ok && !(kc.nullable[k] && keys[k] == int_null_of(kc.type[k]));
+  }
+  return ok;
+}
+
+// Insert-or-find of a key of n_keys components of type T in a keyed table (slot stride in
+// components).  One component: the reference's CAS EMPTY -> key (write_baseline_hash_slot,
+// HashJoinRuntime.cpp:505-538).  Several: the first component is the write lock (EMPTY ->
+// EMPTY - 1 -> value) so a reader never sees half a key; see baseline_find_or_insert_multi.
+template <typename T, typename U>
+MQ_D int64_t keyed_insert(T* tab, uint32_t entries, int n_keys, int stride, const int64_t* keys,
+                          T empty, int32_t* bad) {
+  uint32_t words[2 * MI355Q_MAX_GROUP_COLS];
+  const int n_words = pack_join_key(keys, n_keys, (int)sizeof(T), words);
+  const T locked = empty - 1;
+  if ((T)keys[0] == empty || (n_keys > 1 && (T)keys[0] == locked)) {
+    *bad = 1;
+    return -1;
+  }
+  const uint32_t h = murmur1_words(words, n_words) % entries;
+  uint32_t hp = h;
+  int64_t found = -1;
+  bool done = false;
+  int spins = 0;
+  while (!done) {
+    T* e = tab + (size_t)hp * stride;
+    bool advance = false;
+    const T old = (T)atomicCAS((U*)e, (U)empty, (U)(n_keys > 1 ? locked : (T)keys[0]));
+    if (old == empty) {
+      if (n_keys > 1) {
+        for (int i = 1; i < n_keys; ++i) __hip_atomic_store(e + i, (T)keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        __hip_atomic_store(e, (T)keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      found = hp;
+      done = true;
+    } else if (n_keys > 1 && old == locked) {
+      if (++spins > kMaxLockSpins) {
+        *bad = 1;
+        done = true;
+      }
+    } else if (old == (T)keys[0]) {
+      bool same = true;
+      if (n_keys > 1) {
+        __threadfence();
+        for (int i = 1; i < n_keys; ++i)
+          same = same && __hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (T)keys[i];
+      }
+      if (same) {
+        found = hp;
+        done = true;
+      } else {
+        advance = true;
+      }
+    } else {
+      advance = true;
+    }
+    if (advance) {
+      hp = hp + 1 == entries ? 0 : hp + 1;
+      if (hp == h) done = true;
+    }
+  }
+  return found;
+}
+
+// keys EMPTY, payload component (one-to-one) -1 (init_baseline_hash_join_buff,
+// HashJoinRuntime.cpp:346-373)
+__global__ __launch_bounds__(kBlock) void k_join_init_keyed(void* __restrict__ tab, int64_t entries,
+                                                             int n_keys, int stride, int width) {
+  const int64_t total = entries * stride;
+  const int64_t step = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < total; i += step) {
+    const bool is_key = (int)(i % stride) < n_keys;
+    if (width == 4) ((int32_t*)tab)[i] = is_key ? kEmptyKey32 : -1;
+    else ((int64_t*)tab)[i] = is_key ? kEmptyKey64 : -1;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_join_fill_keyed(JoinKeyCols kc, int64_t n, void* __restrict__ tab,
+                                                             int64_t entries, int stride, int with_payload,
+                                                             int32_t* __restrict__ d_err) {
+  const int64_t step = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    int64_t keys[MI355Q_MAX_GROUP_COLS];
+    if (!load_join_key(kc, i, keys)) continue;
+    int32_t bad = 0;
+    int64_t slot;
+    if (kc.width == 4) {
+      slot = keyed_insert<int32_t, unsigned int>((int32_t*)tab, (uint32_t)entries, kc.n, stride, keys, kEmptyKey32, &bad);
+    } else {
+      slot = keyed_insert<int64_t, unsigned long long>((int64_t*)tab, (uint32_t)entries, kc.n, stride, keys,
+                                                       kEmptyKey64, &bad);
+    }
+    if (slot < 0) {
+      atomicCAS(d_err, 0, bad ? MI355Q_ERR_INVALID_PLAN : MI355Q_ERR_JOIN_TABLE_FULL);
+      continue;
+    }
+    if (with_payload) {
+      bool dup;
+      if (kc.width == 4) {
+        dup = atomicCAS((int*)tab + slot * stride + kc.n, -1, (int)i) != -1;
+      } else {
+        dup = atomicCAS((unsigned long long*)tab + slot * stride + kc.n, (unsigned long long)-1ll,
+                        (unsigned long long)i) != (unsigned long long)-1ll;
+      }
+      if (dup) atomicCAS(d_err, 0, MI355Q_ERR_JOIN_NOT_ONE_TO_ONE);
+    }
+  }
+}
+
+// slot of an inner row's key in a built one-to-many table: perfect = key - min, keyed = the
+// key's entry (read-only probe), -1 = not there
+MQ_D int64_t one_to_many_slot(const JoinKeyCols& kc, int hash_type, const void* tab, int64_t entries,
+                              int64_t min_key, int64_t max_key, const int64_t* keys) {
+  if (hash_type == 2) return (keys[0] >= min_key && keys[0] <= max_key) ? keys[0] - min_key : -1;
+  return keyed_slot_of(tab, (uint32_t)entries, kc.n, kc.width, kc.n, keys);
+}
+
+// count_matches (HashJoinRuntime.cpp:652-700)
+__global__ __launch_bounds__(kBlock) void k_join_count(JoinKeyCols kc, int64_t n, int hash_type,
+                                                        const void* __restrict__ tab, int64_t entries,
+                                                        int64_t min_key, int64_t max_key,
+                                                        int32_t* __restrict__ counts,
+                                                        int32_t* __restrict__ d_err) {
+  const int64_t step = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    int64_t keys[MI355Q_MAX_GROUP_COLS];
+    if (!load_join_key(kc, i, keys)) continue;
+    const int64_t slot = one_to_many_slot(kc, hash_type, tab, entries, min_key, max_key, keys);
+    if (slot < 0) {
+      atomicCAS(d_err, 0, MI355Q_ERR_INVALID_PLAN);  // key outside the declared range
+      continue;
+    }
+    atomicAdd(&counts[slot], 1);
+  }
+}
+
+// fill_row_ids (HashJoinRuntime.cpp:895-945): payloads[offsets[slot] + running count] = row id
+__global__ __launch_bounds__(kBlock) void k_join_fill_ids(JoinKeyCols kc, int64_t n, int hash_type,
+                                                           const void* __restrict__ tab, int64_t entries,
+                                                           int64_t min_key, int64_t max_key,
+                                                           const int32_t* __restrict__ offsets,
+                                                           int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ payloads) {
+  const int64_t step = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    int64_t keys[MI355Q_MAX_GROUP_COLS];
+    if (!load_join_key(kc, i, keys)) continue;
+    const int64_t slot = one_to_many_slot(kc, hash_type, tab, entries, min_key, max_key, keys);
+    if (slot < 0) continue;
+    payloads[offsets[slot] + atomicAdd(&counts[slot], 1)] = (int32_t)i;
+  }
+}
+
+// Exclusive scan of the per-slot counts into offsets, -1 where the count is zero (the
+// reference: inclusive_scan of the counts shifted by one, then pos[i] = scan[i] only where
+// count[i] != 0, HashJoinRuntime.cpp:1525-1548).  Three passes: tile sums, scan of the tile
+// sums by one workgroup, tile-local scan + write.
+constexpr int kScanTile = kBlock * 8;
+__global__ __launch_bounds__(kBlock) void k_scan_tile_sums(const int32_t* __restrict__ counts, int64_t n,
+                                                            int64_t* __restrict__ tile_sums) {
+  __shared__ int64_t s_part[kBlock / 64];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile;
+  int64_t local = 0;
+  for (int k = 0; k < 8; ++k) {
+    const int64_t i = base + (int64_t)k * kBlock + threadIdx.x;
+    if (i < n) local += counts[i];
+  }
+  for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = local;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t t = 0;
+    for (int w = 0; w < kBlock / 64; ++w) t += s_part[w];
+    tile_sums[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_scan_tile_offsets(int64_t* __restrict__ tile_sums, int64_t n_tiles) {
+  // one workgroup: each thread owns a contiguous chunk of the tile sums
+  __shared__ int64_t s_chunk[kBlock];
+  const int64_t per = (n_tiles + kBlock - 1) / kBlock;
+  const int64_t lo = (int64_t)threadIdx.x * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  int64_t sum = 0;
+  for (int64_t i = lo; i < hi; ++i) sum += tile_sums[i];
+  s_chunk[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t acc = 0;
+    for (int t = 0; t < kBlock; ++t) {
+      const int64_t v = s_chunk[t];
+      s_chunk[t] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  int64_t acc = s_chunk[threadIdx.x];
+  for (int64_t i = lo; i < hi; ++i) {
+    const int64_t v = tile_sums[i];
+    tile_sums[i] = acc;
+    acc += v;
+  }
+}
+__global__ __launch_bounds__(kBlock) void k_scan_write_offsets(const int32_t* __restrict__ counts, int64_t n,
+                                                                const int64_t* __restrict__ tile_offsets,
+                                                                int32_t* __restrict__ offsets) {
+  // thread t owns 8 consecutive slots of the tile
+  __shared__ int64_t s_thread[kBlock];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * 8;
+  int32_t c[8];
+  int64_t sum = 0;
+  for (int k = 0; k < 8; ++k) {
+    c[k] = base + k < n ? counts[base + k] : 0;
+    sum += c[k];
+  }
+  s_thread[threadIdx.x] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t acc = tile_offsets[blockIdx.x];
+    for (int t = 0; t < kBlock; ++t) {
+      const int64_t v = s_thread[t];
+      s_thread[t] = acc;
+      acc += v;
+    }
+  }
+  __syncthreads();
+  int64_t acc = s_thread[threadIdx.x];
+  for (int k = 0; k < 8; ++k) {
+    if (base + k < n) offsets[base + k] = c[k] ? (int32_t)acc : -1;
+    acc += c[k];
+  }
+}
+
 // ---- synthetic columns ------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(void* __restrict__ dst, int64_t n_rows,
                                                       int64_t row_offset, int kind, uint64_t seed,
@@ -463,6 +702,47 @@ hipError_t launch_join_fill_baseline(const int8_t* keys, int type, int nullable,
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_join_fill_baseline, dim3(grid_for(n)), dim3(kBlock), 0, s, keys, type,
                      nullable, n, tab, entries, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_join_init_keyed(void* tab, int64_t entries, int n_keys, int stride, int width,
+                                  hipStream_t s) {
+  hipLaunchKernelGGL(k_join_init_keyed, dim3(grid_for(entries * stride)), dim3(kBlock), 0, s, tab, entries,
+                     n_keys, stride, width);
+  return hipGetLastError();
+}
+
+hipError_t launch_join_fill_keyed(const JoinKeyCols& kc, int64_t n, void* tab, int64_t entries, int stride,
+                                  bool with_payload, int32_t* d_err, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_join_fill_keyed, dim3(grid_for(n)), dim3(kBlock), 0, s, kc, n, tab, entries, stride,
+                     with_payload ? 1 : 0, d_err);
+  return hipGetLastError();
+}
+
+// offsets / counts / payloads of a one-to-many table whose key section (keyed tables) is
+// already filled; tile_scratch holds (entries / 2048 + 1) int64
+hipError_t launch_join_one_to_many(const JoinKeyCols& kc, int64_t n, int hash_type, const void* tab,
+                                   int64_t entries, int64_t min_key, int64_t max_key, int32_t* offsets,
+                                   int32_t* counts, int32_t* payloads, int64_t* tile_scratch,
+                                   int32_t* d_err, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)entries, s);
+  if (e != hipSuccess) return e;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_join_count, dim3(grid_for(n)), dim3(kBlock), 0, s, kc, n, hash_type, tab, entries,
+                       min_key, max_key, counts, d_err);
+  }
+  const int64_t n_tiles = (entries + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, counts, entries, tile_scratch);
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kBlock), 0, s, tile_scratch, n_tiles);
+  hipLaunchKernelGGL(k_scan_write_offsets, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, counts, entries,
+                     tile_scratch, offsets);
+  e = hipMemsetAsync(counts, 0, sizeof(int32_t) * (size_t)entries, s);
+  if (e != hipSuccess) return e;
+  if (n > 0) {
+    hipLaunchKernelGGL(k_join_fill_ids, dim3(grid_for(n)), dim3(kBlock), 0, s, kc, n, hash_type, tab, entries,
+                       min_key, max_key, offsets, counts, payloads);
+  }
   return hipGetLastError();
 }
 

@@ -119,7 +119,8 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
       const mi355q_col_desc& cd = r.table ? p.inner_cols[r.col] : p.cols[r.col];
       r.arg_type = col_type_code(cd);
       if (r.arg_type < 0) return MI355Q_ERR_INVALID_PLAN;
-      r.arg_nullable = cd.nullable != 0;
+      // inner columns of an outer join are nullable whatever their declaration
+      r.arg_nullable = cd.nullable != 0 || (r.table && p.join_kind == MI355Q_JOIN_LEFT);
       r.arg_fp = type_is_fp(cd.type);
       r.range = r.table ? &p.inner_col_ranges[r.col] : &p.col_ranges[r.col];
     }

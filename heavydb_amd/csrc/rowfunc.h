@@ -201,26 +201,90 @@ MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
 }
 
 // ---------------------------------------------------------------- join probe
-// Returns inner row id or < 0 (no match).
-MQ_FN int64_t join_probe(const DevPlan& p, int64_t key) {
-  if (p.join_hash_type == 0) {
-    if (key >= p.join_min && key <= p.join_max) {
-      return ((const int32_t*)p.join_buf)[key - p.join_min];
-    }
-    return -1;
-  }
-  const int64_t* tab = (const int64_t*)p.join_buf;
-  const uint32_t n = (uint32_t)p.join_entries;
-  if (!n) return -1;
-  const uint32_t h = murmur1_u64((uint64_t)key) % n;
+// Keyed tables: components of `width` bytes; one-to-one slots are (key..., payload), one-to-many
+// slots are the key alone.  Returns the slot index, -2 when probing stops at an empty slot
+// (kNotPresent), -1 when the table wrapped (kNoMatch)
+// (baseline_hash_join_idx_impl / get_composite_key_index_impl,
+// JoinHashTableQueryRuntime.cpp:35-94,140-163).
+MQ_FN int64_t keyed_slot_of(const void* tab, uint32_t entries, int n_keys, int width, int stride,
+                            const int64_t* keys) {
+  if (!entries) return -1;
+  uint32_t words[2 * MI355Q_MAX_GROUP_COLS];
+  const int n_words = pack_join_key(keys, n_keys, width, words);
+  const uint32_t h = murmur1_words(words, n_words) % entries;
   uint32_t hp = h;
   do {
-    const int64_t k = tab[(size_t)hp * 2];
-    if (k == key) return tab[(size_t)hp * 2 + 1];
-    if (k == kEmptyKey64) return -2;  // kNotPresent
-    hp = hp + 1 == n ? 0 : hp + 1;
+    bool same = true, empty;
+    if (width == 4) {
+      const int32_t* e = (const int32_t*)tab + (size_t)hp * stride;
+      for (int i = 0; i < n_keys; ++i) same = same && e[i] == (int32_t)keys[i];
+      empty = e[0] == kEmptyKey32;
+    } else {
+      const int64_t* e = (const int64_t*)tab + (size_t)hp * stride;
+      for (int i = 0; i < n_keys; ++i) same = same && e[i] == keys[i];
+      empty = e[0] == kEmptyKey64;
+    }
+    if (same) return hp;
+    if (empty) return -2;
+    hp = hp + 1 == entries ? 0 : hp + 1;
   } while (hp != h);
-  return -1;  // kNoMatch
+  return -1;
+}
+
+// The set of inner rows matching one outer row: `count` row ids at `ids`, or (one-to-one
+// tables) the single row id `single`.  count == 0: no match.
+struct JoinMatch {
+  const int32_t* ids;
+  int64_t single;
+  int32_t count;
+};
+
+MQ_FN JoinMatch join_lookup(const DevPlan& p, const int64_t* keys) {
+  JoinMatch m{nullptr, -1, 0};
+  const int64_t n = p.join_entries;
+  switch (p.join_hash_type) {
+    case 0: {  // hash_join_idx (GroupByRuntime.cpp:287-297)
+      if (keys[0] >= p.join_min && keys[0] <= p.join_max) {
+        m.single = ((const int32_t*)p.join_buf)[keys[0] - p.join_min];
+        m.count = m.single >= 0;
+      }
+      break;
+    }
+    case 1: {
+      const int stride = p.join_n_keys + 1;
+      const int64_t slot = keyed_slot_of(p.join_buf, (uint32_t)n, p.join_n_keys, p.join_width, stride, keys);
+      if (slot >= 0) {
+        m.single = p.join_width == 4 ? (int64_t)((const int32_t*)p.join_buf)[slot * stride + p.join_n_keys]
+                                     : ((const int64_t*)p.join_buf)[slot * stride + p.join_n_keys];
+        m.count = m.single >= 0;
+      }
+      break;
+    }
+    case 2: {  // HashJoin::codegenMatchingSet: offsets | counts | payloads, all int32
+      if (keys[0] >= p.join_min && keys[0] <= p.join_max) {
+        const int32_t* offsets = (const int32_t*)p.join_buf;
+        const int32_t off = offsets[keys[0] - p.join_min];
+        if (off >= 0) {
+          m.count = offsets[n + (keys[0] - p.join_min)];
+          m.ids = offsets + 2 * n + off;
+        }
+      }
+      break;
+    }
+    default: {  // keys | offsets | counts | payloads
+      const int64_t slot = keyed_slot_of(p.join_buf, (uint32_t)n, p.join_n_keys, p.join_width, p.join_n_keys, keys);
+      if (slot >= 0) {
+        const int32_t* offsets =
+            (const int32_t*)((const int8_t*)p.join_buf + (size_t)n * p.join_n_keys * p.join_width);
+        const int32_t off = offsets[slot];
+        if (off >= 0) {
+          m.count = offsets[n + slot];
+          m.ids = offsets + 2 * n + off;
+        }
+      }
+    }
+  }
+  return m;
 }
 
 // ---------------------------------------------------------------- group slot
@@ -375,6 +439,10 @@ MQ_FN void apply_target(const DevTarget& t, int64_t* slots, const int8_t* const*
     a_count<A>(s);
     return;
   }
+  // LEFT join, no match: every inner column is NULL (codegenOuterJoinNullPlaceholder,
+  // ColumnIR.cpp) and inner columns are nullable under an outer join, so each aggregate's
+  // _skip_val form leaves its slot alone
+  if (t.table && inner_pos < 0) return;
   const int8_t* col = t.table ? inner_cols[t.col] : cols[t.col];
   const int64_t p = t.table ? inner_pos : pos;
   if (t.arg_fp) {
@@ -543,12 +611,22 @@ MQ_FN int32_t process_row(const DevPlan& p, const int8_t* const* cols, int64_t p
   for (int i = 0; i < p.n_quals; ++i) {
     if (!eval_qual(p.quals[i], cols[p.quals[i].col], pos)) return 0;
   }
-  int64_t inner_pos = -1;
+  JoinMatch jm{nullptr, -1, 1};  // no join: one pass with no inner row
   if (p.join_col >= 0) {
-    const int64_t k = decode_int(cols[p.join_col], p.join_type, pos);
-    if (p.join_nullable && k == int_null_of(p.join_type)) return 0;
-    inner_pos = join_probe(p, k);
-    if (inner_pos < 0) return 0;
+    int64_t jk[MI355Q_MAX_GROUP_COLS];
+    bool null_key = false;
+    for (int i = 0; i < p.join_n_keys; ++i) {
+      jk[i] = decode_int(cols[p.join_cols[i]], p.join_types[i], pos);
+      null_key = null_key || (p.join_nullables[i] && jk[i] == int_null_of(p.join_types[i]));
+    }
+    jm.count = 0;
+    if (!null_key) jm = join_lookup(p, jk);  // a NULL key matches nothing (hash_join_idx_nullable)
+    if (jm.count <= 0) {
+      if (p.join_kind != MI355Q_JOIN_LEFT) return 0;  // INNER: the row is dropped
+      jm.ids = nullptr;  // LEFT: kept once, inner side NULL
+      jm.single = -1;
+      jm.count = 1;
+    }
   }
   int64_t* slots;
   int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};  // the group columns' values as decoded
@@ -601,8 +679,13 @@ MQ_FN int32_t process_row(const DevPlan& p, const int8_t* const* cols, int64_t p
       }
     }
   }
-  for (int i = 0; i < p.n_targets; ++i) {
-    apply_target<A>(p.targets[i], slots, cols, pos, p.inner_cols, inner_pos, keys);
+  // one joined row per matching inner row (JoinLoop over the matching set); the group keys
+  // are outer columns, so the group slot is the same for all of them
+  for (int m = 0; m < jm.count; ++m) {
+    const int64_t inner_pos = jm.ids ? (int64_t)jm.ids[m] : jm.single;
+    for (int i = 0; i < p.n_targets; ++i) {
+      apply_target<A>(p.targets[i], slots, cols, pos, p.inner_cols, inner_pos, keys);
+    }
   }
   return 0;
 }

@@ -83,8 +83,9 @@ class RelAlgExecutionUnit:
     simple_quals: List[Qual] = field(default_factory=list)
     groupby_exprs: List[int] = field(default_factory=list)
     inner_col_descs: List[InputColDescriptor] = field(default_factory=list)
-    join_outer_col: int = -1
+    join_outer_col: int | Sequence[int] = -1   # one column, or a list for a composite key
     join_table: Optional["HashJoin"] = None
+    join_kind: int = 0                          # capi.JOIN_INNER / JOIN_LEFT
     # ExecutionOptions / globals shaping the layout
     max_groups_buffer_entry_guess: int = 16384  # Execute.cpp:111
     bigint_count: bool = False
@@ -119,7 +120,14 @@ class RelAlgExecutionUnit:
         p.n_targets = len(self.target_exprs)
         for i, t in enumerate(self.target_exprs):
             p.targets[i] = capi.Target(t.agg, t.col, t.table, 0)
-        p.join_outer_col = self.join_outer_col
+        jcols = list(self.join_outer_col) if isinstance(self.join_outer_col, (list, tuple)) else [self.join_outer_col]
+        if len(jcols) > capi.MAX_GROUP_COLS:
+            raise ValueError("too many join key columns")
+        p.join_outer_col = jcols[0]
+        p.n_join_cols = len(jcols) if len(jcols) > 1 else 0
+        for i, c in enumerate(jcols):
+            p.join_outer_cols[i] = c
+        p.join_kind = self.join_kind
         p.join_table = self.join_table.handle if self.join_table is not None else None
         p.max_groups_buffer_entry_guess = self.max_groups_buffer_entry_guess
         p.bigint_count = int(self.bigint_count)
@@ -171,20 +179,36 @@ class FetchResult:
 
 
 class HashJoin:
-    """Join hash table handle (HashJoin::getInstance, HashJoin.cpp:286): perfect one-to-one
-    when the key range allows, keyed (baseline) otherwise."""
+    """Join hash table handle (HashJoin::getInstance, HashJoin.cpp:286): perfect when there is
+    one key column and its range allows, keyed (baseline) otherwise; OneToOne first, rebuilt
+    as OneToMany when a key repeats (one_to_many=1) — or OneToOne only (0, a duplicate is an
+    error) / OneToMany straight away (2)."""
 
     def __init__(self, handle: int):
         self.handle = handle
         self._lib = capi.load_library()
 
     @staticmethod
-    def getInstance(key_buffer: int, num_rows: int, key_type: int, key_range: ExpressionRange,
-                    key_nullable: bool = False, device_id: int = 0, prefer_baseline: bool = False,
-                    max_perfect_entries: int = 0, stream: int | None = None) -> "HashJoin":
+    def getInstance(key_buffer, num_rows: int, key_type, key_range: ExpressionRange,
+                    key_nullable=False, device_id: int = 0, prefer_baseline: bool = False,
+                    max_perfect_entries: int = 0, stream: int | None = None,
+                    one_to_many: int = 0, keyed_entry_count: int = 0) -> "HashJoin":
+        """key_buffer / key_type / key_nullable: scalars for one key column, equal-length lists
+        for a composite key."""
         lib = capi.load_library()
-        spec = capi.JoinSpec(device_id, key_type, int(key_nullable), int(prefer_baseline),
-                             key_buffer, num_rows, key_range.to_c(), max_perfect_entries)
+        bufs = list(key_buffer) if isinstance(key_buffer, (list, tuple)) else [key_buffer]
+        types = list(key_type) if isinstance(key_type, (list, tuple)) else [key_type]
+        nulls = list(key_nullable) if isinstance(key_nullable, (list, tuple)) else [key_nullable] * len(bufs)
+        assert len(bufs) == len(types) == len(nulls) <= capi.MAX_GROUP_COLS
+        spec = capi.JoinSpec(device_id, types[0], int(nulls[0]), int(prefer_baseline),
+                             bufs[0], num_rows, key_range.to_c(), max_perfect_entries)
+        spec.n_keys = len(bufs)
+        spec.one_to_many = one_to_many
+        spec.keyed_entry_count = keyed_entry_count
+        for i in range(1, len(bufs)):
+            spec.more_key_types[i - 1] = types[i]
+            spec.more_key_nullables[i - 1] = int(nulls[i])
+            spec.more_key_buffers[i - 1] = bufs[i]
         out = C.c_void_p()
         check(lib.mi355q_join_build(C.byref(spec), stream, C.byref(out)), "join_build")
         return HashJoin(out.value)
@@ -195,8 +219,11 @@ class HashJoin:
         check(self._lib.mi355q_join_info(self.handle, C.byref(ht), C.byref(ec), C.byref(mn),
                                          C.byref(mx), C.byref(ptr), C.byref(nbytes),
                                          C.byref(ms)))
+        kc, kw = C.c_int32(), C.c_int32()
+        check(self._lib.mi355q_join_key_shape(self.handle, C.byref(kc), C.byref(kw)))
         return dict(hash_type=ht.value, entry_count=ec.value, min_key=mn.value, max_key=mx.value,
-                    device_ptr=ptr.value, bytes=nbytes.value, build_ms=ms.value)
+                    device_ptr=ptr.value, bytes=nbytes.value, build_ms=ms.value,
+                    key_components=kc.value, component_width=kw.value)
 
     def free(self):
         if self.handle:

@@ -116,6 +116,11 @@ typedef enum mi355q_agg {
   MI355Q_PROJECT_KEY = 100
 } mi355q_agg;
 
+/* join kinds: INNER drops outer rows without a match; LEFT keeps them once with every inner
+ * column NULL (JoinType::LEFT; Executor::buildJoinLoops, IRCodegen.cpp, JoinLoop kinds
+ * UpperBound/Set/Singleton with an outer-join "found" flag) */
+typedef enum mi355q_join_kind { MI355Q_JOIN_INNER = 0, MI355Q_JOIN_LEFT = 1 } mi355q_join_kind;
+
 /* QueryDescriptionType (enums.h:53-59) */
 typedef enum mi355q_desc_type {
   MI355Q_GROUP_BY_PERFECT_HASH = 0,
@@ -188,9 +193,15 @@ typedef struct mi355q_plan {
   int32_t n_targets;
   mi355q_target targets[MI355Q_MAX_TARGETS];
 
-  /* join_quals: one equi-join level  outer.col = inner.key  (INNER join) */
-  int32_t join_outer_col;              /* -1 = no join */
+  /* join_quals: one equi-join level  outer.col = inner.key [AND outer.col2 = inner.key2 ...] */
+  int32_t join_outer_col;              /* first (or only) outer key column; -1 = no join */
   const mi355q_join_table* join_table; /* built by mi355q_join_build */
+  int32_t n_join_cols;                 /* 0 or 1 = single-column key; 2..MI355Q_MAX_GROUP_COLS =
+                                          composite key: join_outer_cols[i] pairs with the i-th
+                                          inner key column the table was built from */
+  int32_t join_outer_cols[MI355Q_MAX_GROUP_COLS];
+  int32_t join_kind;                   /* mi355q_join_kind (JoinType, Shared/sqldefs.h) */
+  int32_t reserved2;
 
   /* ExecutionOptions / globals that shape the layout */
   int64_t max_groups_buffer_entry_guess; /* baseline entry_count (Execute.cpp:111
@@ -352,24 +363,55 @@ int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t d
 /* ---- join hash tables ---- */
 typedef struct mi355q_join_spec {
   int32_t device_id;
-  int32_t key_type;     /* mi355q_type of the inner key column */
+  int32_t key_type;     /* mi355q_type of the (first) inner key column */
   int32_t key_nullable;
   int32_t prefer_baseline; /* 1 = skip the perfect attempt (testing keyed tables) */
   const void* key_buffer; /* device pointer, inner key column, linearized */
   int64_t num_rows;
-  mi355q_range key_range; /* inner key ExpressionRange */
+  mi355q_range key_range; /* inner key ExpressionRange (single-column keys) */
   int64_t max_perfect_entries; /* 0 = default (PerfectJoinHashTable.cpp:219-224) */
+  /* composite keys (inner_outer_pairs_.size() > 1 -> BaselineJoinHashTable): further inner
+   * key columns after the first; n_keys 0 or 1 = single column */
+  int32_t n_keys;
+  int32_t one_to_many; /* 0 = OneToOne only: a duplicate key fails with
+                          MI355Q_ERR_JOIN_NOT_ONE_TO_ONE; 1 = rebuild as OneToMany like
+                          HashJoin::getInstance does when the OneToOne fill reports a
+                          duplicate (PerfectJoinHashTable.cpp:255-290 reify ->
+                          NeedsOneToManyHash); 2 = build OneToMany straight away */
+  int32_t more_key_types[MI355Q_MAX_GROUP_COLS - 1];
+  int32_t more_key_nullables[MI355Q_MAX_GROUP_COLS - 1];
+  const void* more_key_buffers[MI355Q_MAX_GROUP_COLS - 1];
+  int64_t keyed_entry_count; /* 0 = 2 x num_rows; the reference sizes keyed tables at 2 x its
+                                (HyperLogLog) estimate of the distinct keys,
+                                BaselineJoinHashTable.cpp:484-486 — a binding that has that
+                                estimate passes 2 x NDV here */
 } mi355q_join_spec;
 
-/* HashType: 0 OneToOne perfect (int32 slot[max-min+1], -1 empty,
- * HashJoinRuntime.cpp:71-86), 1 OneToOne baseline/keyed ({int64 key, int64 row id}
- * [2 x NDV], empty key INT64_MAX, :346-373). */
+/* HashType / layout of the buffer (docs/source/execution/hash_joins.rst "Hash Join Buffers"):
+ *   0 OneToOne perfect   int32 slot[max-min+1], -1 empty (HashJoinRuntime.cpp:71-86)
+ *   1 OneToOne keyed     entry_count x (key components..., payload) of 4- or 8-byte integers,
+ *                        first component EMPTY (INT32_MAX / INT64_MAX) when free, payload = row
+ *                        id (HashJoinRuntime.cpp:346-373, :505-538); component width 8 iff an
+ *                        inner key column is wider than 4 bytes
+ *                        (BaselineJoinHashTable::getKeyComponentWidth), entry_count = 2 x rows
+ *   2 OneToMany perfect  int32 offsets[entries] | int32 counts[entries] | int32 payloads[rows]:
+ *                        offsets -1 where no row has the key, else the start of the key's row
+ *                        ids in payloads (fill_one_to_many_hash_table,
+ *                        HashJoinRuntime.cpp:1503-1560: count_matches -> inclusive_scan ->
+ *                        fill_row_ids)
+ *   3 OneToMany keyed    keys[entries x components] | offsets | counts | payloads
+ *                        (fill_one_to_many_baseline_hash_table, HashJoinRuntime.cpp:1975-2100)
+ * The order of the row ids inside one key's payload run is build-order dependent in the
+ * reference as well (hash_joins.rst "comparing buffers"). */
 int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream,
                           mi355q_join_table** out);
 void mi355q_join_free(mi355q_join_table* t);
 int32_t mi355q_join_info(const mi355q_join_table* t, int32_t* hash_type, int64_t* entry_count,
                          int64_t* min_key, int64_t* max_key, void** device_ptr,
                          int64_t* bytes, float* build_ms);
+/* key component count and width (bytes) of a keyed table (1 / 8 for perfect tables) */
+int32_t mi355q_join_key_shape(const mi355q_join_table* t, int32_t* key_components,
+                              int32_t* component_width);
 
 /* ---- multi-device merge helpers (one process per GPU; the collective itself is
  * issued by the host with RCCL between these calls) ---- */

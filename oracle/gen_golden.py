@@ -197,6 +197,54 @@ def main():
     kj.append(keyed_join(4, [5, 6, 7, 9], [5, 9, 11]))  # full table: -1 (kNoMatch) on miss
     out["keyed_join"] = kj
 
+    # ---- composite keyed tables: baseline_hash_join_idx_{32,64} with several key components
+    # and get_composite_key_index_{32,64} (JoinHashTableQueryRuntime.cpp:35-94,140-163).  The
+    # tables are laid down here with the reference's MurmurHash1 + linear probing in row order.
+    def composite(entry_count, width, dim_rows, probes, with_payload):
+        dt = np.int32 if width == 4 else np.int64
+        empty = EMPTY32 if width == 4 else EMPTY64
+        kc = len(dim_rows[0])
+        stride = kc + (1 if with_payload else 0)
+        tab = np.zeros((entry_count, stride), dtype=dt)
+        tab[:, :kc] = empty
+        if with_payload:
+            tab[:, kc] = -1
+        for row_id, k in enumerate(dim_rows):
+            kb = np.array(k, dtype=dt)
+            h = ref.MurmurHash1(kb.ctypes.data, kc * width, 0) % entry_count
+            while tab[h, 0] != empty and not (tab[h, :kc] == kb).all():
+                h = (h + 1) % entry_count
+            tab[h, :kc] = kb
+            if with_payload:
+                tab[h, kc] = row_id
+        res = []
+        for k in probes:
+            kb = np.array(k, dtype=dt)
+            if with_payload:
+                f = ref.baseline_hash_join_idx_32 if width == 4 else ref.baseline_hash_join_idx_64
+                res.append(int(f(tab.ctypes.data, kb.ctypes.data, kc * width, entry_count)))
+            else:
+                f = ref.get_composite_key_index_32 if width == 4 else ref.get_composite_key_index_64
+                res.append(int(f(kb.ctypes.data, kc, tab.ctypes.data, entry_count)))
+        return {"entry_count": entry_count, "width": width, "key_count": kc, "with_payload": with_payload,
+                "dim_rows": [[int(x) for x in k] for k in dim_rows], "table": [int(x) for x in tab.reshape(-1)],
+                "probes": [[int(x) for x in k] for k in probes], "idx": res}
+
+    ck = []
+    rows2 = [[int(a), int(b)] for a, b in zip(rng.permutation(300)[:120], rng.integers(-5, 5, 120))]
+    pr2 = rows2[:40] + [[int(a), int(b)] for a, b in zip(rng.integers(0, 300, 40), rng.integers(-5, 5, 40))]
+    ck.append(composite(240, 4, rows2, pr2, True))
+    rows3 = [[int(a) * 1000003, int(b), int(c)] for a, b, c in zip(rng.permutation(200)[:90], rng.integers(0, 3, 90),
+                                                                    rng.integers(-2**40, 2**40, 90))]
+    pr3 = rows3[:30] + [[r[0], r[1], r[2] + 1] for r in rows3[:20]]
+    ck.append(composite(180, 8, rows3, pr3, True))
+    dup = [[int(a), int(b)] for a, b in zip(rng.integers(0, 30, 150), rng.integers(0, 3, 150))]  # repeats
+    ck.append(composite(300, 4, dup, dup[:40] + [[99, 99], [0, 7]], False))
+    ck.append(composite(300, 8, [[d[0] * 10**10, d[1]] for d in dup], [[d[0] * 10**10, d[1]] for d in dup[:40]] +
+                        [[5, 5]], False))
+    ck.append(composite(6, 4, [[1, 1], [3, 3], [0, 0]], [[1, 1], [3, 3], [0, 0], [2, 2]], True))  # hash_joins.rst
+    out["composite_keyed"] = ck
+
     # ---- decoders: fixed_width_int_decode / fixed_width_double_decode (DecodersImpl.h:27-55,121)
     dec = []
     for width, dt in [(1, np.int8), (2, np.int16), (4, np.int32), (8, np.int64)]:

@@ -361,7 +361,7 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
       const auto& cd = col_desc_of(p, d.table, d.col);
       d.cd = &cd;
       d.arg_type = logical_type_of(cd);
-      d.arg_nullable = cd.nullable != 0;
+      d.arg_nullable = cd.nullable != 0 || (d.table && p.join_kind == MI355Q_JOIN_LEFT);
       d.arg_fp = type_is_fp(cd.type);
     } else if (t.agg != MI355Q_COUNT) {
       return MI355Q_ERR_INVALID_PLAN;
@@ -735,14 +735,18 @@ inline int64_t* get_group_value_fast_keyless(int64_t* buf, int64_t key, int64_t 
 }
 
 // ---------------------------------------------------------------- join tables
+// Layouts (docs/source/execution/hash_joins.rst "Hash Join Buffers"):
+//   0 OneToOne perfect  int32 slot[max-min+1]
+//   1 OneToOne keyed    entry_count x (key components..., payload), 4- or 8-byte integers
+//   2 OneToMany perfect offsets | counts | payloads (int32 each)
+//   3 OneToMany keyed   keys | offsets | counts | payloads
 struct OrcJoin {
-  int hash_type = 0;  // 0 perfect one-to-one, 1 keyed one-to-one
+  int hash_type = 0;
   int64_t min_key = 0, max_key = 0;
   int64_t entry_count = 0;
-  int key_type = MI355Q_INT64;
-  bool key_nullable = false;
-  std::vector<int32_t> perfect;   // int32 slot[max-min+1], -1 empty
-  std::vector<int64_t> keyed;     // {key, payload} pairs
+  int n_keys = 1, width = 8;
+  std::vector<int8_t> buf;  // the whole hash join buffer, byte for byte
+  const int32_t* perfect() const { return reinterpret_cast<const int32_t*>(buf.data()); }
 };
 
 // GroupByRuntime.cpp:287-297 hash_join_idx, :311-318 _nullable
@@ -751,16 +755,18 @@ inline int64_t hash_join_idx(const int32_t* buff, int64_t key, int64_t min_key,
   if (key >= min_key && key <= max_key) return buff[key - min_key];
   return -1;
 }
-// JoinHashTableQueryRuntime.cpp:40-94 baseline_hash_join_idx_64
-inline int64_t baseline_hash_join_idx_64(const int64_t* buff, int64_t key,
-                                         size_t entry_count) {
+// JoinHashTableQueryRuntime.cpp:35-94 baseline_hash_join_idx_impl<T>: slots of
+// (key components..., payload); -2 (kNotPresent) at an empty slot, -1 (kNoMatch) on wrap
+template <typename T>
+int64_t baseline_hash_join_idx(const T* buff, const T* key, int key_count, size_t entry_count,
+                               T empty) {
   if (!entry_count) return -1;
-  const uint32_t h = murmur1(&key, 8, 0) % entry_count;
+  const uint32_t h = murmur1(key, key_count * sizeof(T), 0) % entry_count;
   auto slot = [&](uint32_t hh) -> int64_t {
-    const int64_t* e = buff + (size_t)hh * 2;
-    if (e[0] == key) return e[1];
-    if (e[0] == kEmptyKey64) return -2;  // kNotPresent
-    return -1;                           // kNoMatch
+    const T* e = buff + (size_t)hh * (key_count + 1);
+    if (memcmp(e, key, key_count * sizeof(T)) == 0) return e[key_count];
+    if (e[0] == empty) return -2;
+    return -1;
   };
   int64_t m = slot(h);
   if (m != -1) return m;
@@ -771,6 +777,81 @@ inline int64_t baseline_hash_join_idx_64(const int64_t* buff, int64_t key,
     hp = (hp + 1) % entry_count;
   }
   return -1;
+}
+inline int64_t baseline_hash_join_idx_64(const int64_t* buff, int64_t key, size_t entry_count) {
+  return baseline_hash_join_idx<int64_t>(buff, &key, 1, entry_count, kEmptyKey64);
+}
+// JoinHashTableQueryRuntime.cpp:140-163 get_composite_key_index_impl<T>: index of the key in
+// the key dictionary of a one-to-many keyed table, -1 if absent
+template <typename T>
+int64_t get_composite_key_index(const T* key, size_t key_count, const T* dict, size_t entry_count,
+                                T empty) {
+  const uint32_t h = murmur1(key, key_count * sizeof(T), 0) % entry_count;
+  uint32_t off = h * key_count;
+  if (memcmp(&dict[off], key, key_count * sizeof(T)) == 0) return h;
+  uint32_t hp = (h + 1) % entry_count;
+  while (hp != h) {
+    off = hp * key_count;
+    if (memcmp(&dict[off], key, key_count * sizeof(T)) == 0) return hp;
+    if (dict[off] == empty) return -1;
+    hp = (hp + 1) % entry_count;
+  }
+  return -1;
+}
+
+// The matching set of one outer key (HashJoin::codegenMatchingSet, HashJoin.cpp; one-to-one
+// tables: codegenSlot): `count` inner row ids at `ids`, or the single id.
+struct Matches {
+  const int32_t* ids = nullptr;
+  int64_t single = -1;
+  int32_t count = 0;
+};
+Matches join_lookup(const OrcJoin& j, const int64_t* keys) {
+  Matches m;
+  const int64_t n = j.entry_count;
+  int32_t k32[MI355Q_MAX_GROUP_COLS];
+  for (int i = 0; i < j.n_keys; ++i) k32[i] = (int32_t)keys[i];
+  switch (j.hash_type) {
+    case 0:
+      m.single = hash_join_idx(j.perfect(), keys[0], j.min_key, j.max_key);
+      m.count = m.single >= 0;
+      break;
+    case 1:
+      m.single = j.width == 4
+                     ? baseline_hash_join_idx<int32_t>(reinterpret_cast<const int32_t*>(j.buf.data()), k32,
+                                                       j.n_keys, n, kEmptyKey32)
+                     : baseline_hash_join_idx<int64_t>(reinterpret_cast<const int64_t*>(j.buf.data()), keys,
+                                                       j.n_keys, n, kEmptyKey64);
+      m.count = m.single >= 0;
+      break;
+    case 2: {
+      const int32_t* offsets = j.perfect();
+      const int64_t off = hash_join_idx(offsets, keys[0], j.min_key, j.max_key);
+      if (off >= 0) {
+        m.count = (int32_t)hash_join_idx(offsets + n, keys[0], j.min_key, j.max_key);
+        m.ids = offsets + 2 * n + off;
+      }
+      break;
+    }
+    default: {
+      const int64_t idx =
+          j.width == 4 ? get_composite_key_index<int32_t>(k32, j.n_keys,
+                                                          reinterpret_cast<const int32_t*>(j.buf.data()), n,
+                                                          kEmptyKey32)
+                       : get_composite_key_index<int64_t>(keys, j.n_keys,
+                                                          reinterpret_cast<const int64_t*>(j.buf.data()), n,
+                                                          kEmptyKey64);
+      if (idx >= 0) {
+        const int32_t* offsets =
+            reinterpret_cast<const int32_t*>(j.buf.data() + (size_t)n * j.n_keys * j.width);
+        if (offsets[idx] >= 0) {
+          m.count = offsets[n + idx];
+          m.ids = offsets + 2 * n + offsets[idx];
+        }
+      }
+    }
+  }
+  return m;
 }
 
 // ---------------------------------------------------------------- row function
@@ -827,6 +908,10 @@ inline void apply_target(const TargetDesc& t, int64_t* slots, const int8_t* cons
     agg_count(s);
     return;
   }
+  // outer join without a match: the inner column value is the NULL placeholder
+  // (codegenOuterJoinNullPlaceholder); inner columns are nullable under an outer join, so the
+  // _skip_val aggregate leaves the slot untouched
+  if (t.table && inner_pos < 0) return;
   const int8_t* col = t.table ? inner_cols[t.col] : cols[t.col];
   const int64_t p = t.table ? inner_pos : pos;
   if (t.arg_fp) {
@@ -913,17 +998,25 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
     bool pass = true;
     for (int i = 0; i < p.n_quals && pass; ++i) pass = eval_qual(p, p.quals[i], cols, pos);
     if (!pass) continue;
-    int64_t inner_pos = -1;
+    Matches jm;
+    jm.count = 1;  // no join: one pass without an inner row
     if (p.join_outer_col >= 0) {
-      const auto& jc = p.cols[p.join_outer_col];
-      const int64_t k = decode_col(jc, cols[p.join_outer_col], pos);
-      if (jc.nullable && k == int_null_of(logical_type_of(jc))) continue;  // hash_join_idx_nullable
-      if (c.join->hash_type == 0) {
-        inner_pos = hash_join_idx(c.join->perfect.data(), k, c.join->min_key, c.join->max_key);
-      } else {
-        inner_pos = baseline_hash_join_idx_64(c.join->keyed.data(), k, c.join->entry_count);
+      const int nk = p.n_join_cols > 1 ? p.n_join_cols : 1;
+      int64_t jk[MI355Q_MAX_GROUP_COLS];
+      bool null_key = false;
+      for (int i = 0; i < nk; ++i) {
+        const int jc_idx = (i == 0 && p.n_join_cols <= 1) ? p.join_outer_col : p.join_outer_cols[i];
+        const auto& jc = p.cols[jc_idx];
+        jk[i] = decode_col(jc, cols[jc_idx], pos);
+        // hash_join_idx_nullable / NULL never equals anything
+        null_key = null_key || (jc.nullable && jk[i] == int_null_of(logical_type_of(jc)));
       }
-      if (inner_pos < 0) continue;  // INNER join: no match drops the row
+      jm = null_key ? Matches{} : join_lookup(*c.join, jk);
+      if (jm.count <= 0) {
+        if (p.join_kind != MI355Q_JOIN_LEFT) continue;  // INNER join: no match drops the row
+        jm = Matches{};   // LEFT join: the row survives once with a NULL inner side
+        jm.count = 1;
+      }
     }
     int64_t* slots;
     int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};  // group_by_expr_cache_: values as decoded
@@ -982,8 +1075,12 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
       }
       (void)kq;
     }
-    for (const auto& t : c.ts) {
-      apply_target(t, slots, cols, pos, c.inner_cols, inner_pos, keys);
+    // one joined row per matching inner row (JoinLoop, Set / Singleton kinds)
+    for (int m = 0; m < jm.count; ++m) {
+      const int64_t inner_pos = jm.ids ? (int64_t)jm.ids[m] : jm.single;
+      for (const auto& t : c.ts) {
+        apply_target(t, slots, cols, pos, c.inner_cols, inner_pos, keys);
+      }
     }
   }
   return 0;
@@ -1130,92 +1227,200 @@ ORC_EXPORT int64_t orc_decode_col(const mi355q_col_desc* cd, const void* col, in
   return decode_col(*cd, static_cast<const int8_t*>(col), pos);
 }
 
-// ---- join build (restating HashJoinRuntime.cpp:71-86,203-216 and :346-373,505-538,575-640)
+// ---- join build (restating HashJoinRuntime.cpp:71-86,203-216 one-to-one perfect;
+// :346-373,505-538,575-640 keyed; :652-700,895-945,1503-1560 one-to-many perfect;
+// :1975-2100 one-to-many keyed).  Serial, so payload runs are in row order.
+namespace {
+
+struct KeyCols {
+  const int8_t* col[MI355Q_MAX_GROUP_COLS];
+  int type[MI355Q_MAX_GROUP_COLS];
+  bool nullable[MI355Q_MAX_GROUP_COLS];
+  int n;
+};
+// false: a NULL component -> the row is not inserted (GenericKeyHandler / fill_hash_join_buff_impl)
+bool load_key(const KeyCols& kc, int64_t i, int64_t* keys) {
+  for (int k = 0; k < kc.n; ++k) {
+    keys[k] = decode_int(kc.col[k], kc.type[k], i);
+    if (kc.nullable[k] && keys[k] == int_null_of(kc.type[k])) return false;
+  }
+  return true;
+}
+
+// write_baseline_hash_slot / get_matching_baseline_hash_slot_at (HashJoinRuntime.cpp:465-538):
+// claim or find the key's slot; stride in components
+template <typename T>
+int64_t keyed_slot_insert(T* tab, int64_t entry_count, int n_keys, int stride, const int64_t* keys,
+                          T empty) {
+  T k[MI355Q_MAX_GROUP_COLS];
+  for (int i = 0; i < n_keys; ++i) k[i] = (T)keys[i];
+  uint32_t h = murmur1(k, n_keys * sizeof(T), 0) % entry_count;
+  const uint32_t start = h;
+  do {
+    T* e = tab + (size_t)h * stride;
+    if (e[0] == empty) {
+      memcpy(e, k, n_keys * sizeof(T));
+      return h;
+    }
+    if (memcmp(e, k, n_keys * sizeof(T)) == 0) return h;
+    h = (h + 1) % entry_count;
+  } while (h != start);
+  return -1;
+}
+
+int32_t build_join(OrcJoin& j, const KeyCols& kc, int64_t num_rows, bool perfect, bool one_to_many,
+                   int64_t min_key, int64_t max_key, int64_t keyed_entries) {
+  int width = 4;  // BaselineJoinHashTable::getKeyComponentWidth
+  for (int i = 0; i < kc.n; ++i)
+    if (type_width(kc.type[i]) > 4) width = 8;
+  j.n_keys = kc.n;
+  j.width = perfect ? 8 : width;
+  j.min_key = perfect ? min_key : 0;
+  j.max_key = perfect ? max_key : 0;
+  // keyed: entry_count = 2 x max(tuples, 1) (BaselineJoinHashTable.cpp:484-486)
+  j.entry_count = perfect ? max_key - min_key + 1
+                          : (keyed_entries > 0 ? keyed_entries : 2 * std::max<int64_t>(num_rows, 1));
+  const int64_t n = j.entry_count;
+  int64_t keys[MI355Q_MAX_GROUP_COLS];
+  auto keyed_init = [&](int stride) {
+    for (int64_t e = 0; e < n; ++e) {
+      for (int c = 0; c < stride; ++c) {
+        if (width == 4) reinterpret_cast<int32_t*>(j.buf.data())[e * stride + c] = c < kc.n ? kEmptyKey32 : -1;
+        else reinterpret_cast<int64_t*>(j.buf.data())[e * stride + c] = c < kc.n ? kEmptyKey64 : -1;
+      }
+    }
+  };
+  auto keyed_insert = [&](int stride) -> int64_t {
+    return width == 4 ? keyed_slot_insert<int32_t>(reinterpret_cast<int32_t*>(j.buf.data()), n, kc.n, stride,
+                                                   keys, kEmptyKey32)
+                      : keyed_slot_insert<int64_t>(reinterpret_cast<int64_t*>(j.buf.data()), n, kc.n, stride,
+                                                   keys, kEmptyKey64);
+  };
+  if (!one_to_many) {
+    if (perfect) {
+      j.hash_type = 0;
+      j.buf.assign((size_t)n * 4, (int8_t)0xFF);  // init_hash_join_buff: -1
+      int32_t* slots = reinterpret_cast<int32_t*>(j.buf.data());
+      for (int64_t i = 0; i < num_rows; ++i) {
+        if (!load_key(kc, i, keys)) continue;
+        if (keys[0] < min_key || keys[0] > max_key) return MI355Q_ERR_INVALID_PLAN;
+        int32_t& slot = slots[keys[0] - min_key];
+        if (slot != -1) return MI355Q_ERR_JOIN_NOT_ONE_TO_ONE;  // fill_one_to_one_hashtable CAS failure
+        slot = (int32_t)i;
+      }
+      return 0;
+    }
+    j.hash_type = 1;
+    const int stride = kc.n + 1;
+    j.buf.assign((size_t)n * stride * width, 0);
+    keyed_init(stride);
+    for (int64_t i = 0; i < num_rows; ++i) {
+      if (!load_key(kc, i, keys)) continue;
+      const int64_t slot = keyed_insert(stride);
+      if (slot < 0) return MI355Q_ERR_JOIN_TABLE_FULL;
+      if (width == 4) {
+        int32_t& pay = reinterpret_cast<int32_t*>(j.buf.data())[slot * stride + kc.n];
+        if (pay != -1) return MI355Q_ERR_JOIN_NOT_ONE_TO_ONE;
+        pay = (int32_t)i;
+      } else {
+        int64_t& pay = reinterpret_cast<int64_t*>(j.buf.data())[slot * stride + kc.n];
+        if (pay != -1) return MI355Q_ERR_JOIN_NOT_ONE_TO_ONE;
+        pay = i;
+      }
+    }
+    return 0;
+  }
+  // one-to-many
+  j.hash_type = perfect ? 2 : 3;
+  const size_t key_bytes = perfect ? 0 : (size_t)n * kc.n * width;
+  j.buf.assign(key_bytes + (size_t)(2 * n + std::max<int64_t>(num_rows, 1)) * 4, 0);
+  if (!perfect) keyed_init(kc.n);
+  int32_t* offsets = reinterpret_cast<int32_t*>(j.buf.data() + key_bytes);
+  int32_t* counts = offsets + n;
+  int32_t* payloads = counts + n;
+  std::vector<int64_t> slot_of(num_rows, -1);
+  for (int64_t i = 0; i < num_rows; ++i) {  // keys, then count_matches
+    if (!load_key(kc, i, keys)) continue;
+    int64_t slot;
+    if (perfect) {
+      if (keys[0] < min_key || keys[0] > max_key) return MI355Q_ERR_INVALID_PLAN;
+      slot = keys[0] - min_key;
+    } else {
+      slot = keyed_insert(kc.n);
+      if (slot < 0) return MI355Q_ERR_JOIN_TABLE_FULL;
+    }
+    slot_of[i] = slot;
+    ++counts[slot];
+  }
+  // inclusive_scan of the shifted counts; pos only where count != 0, -1 elsewhere (:1525-1548)
+  int32_t acc = 0;
+  for (int64_t e = 0; e < n; ++e) {
+    offsets[e] = counts[e] ? acc : -1;
+    acc += counts[e];
+  }
+  std::fill(counts, counts + n, 0);
+  for (int64_t i = 0; i < num_rows; ++i) {  // fill_row_ids
+    if (slot_of[i] < 0) continue;
+    payloads[offsets[slot_of[i]] + counts[slot_of[i]]++] = (int32_t)i;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// key_cols / key_types / key_nullables: n_keys inner key columns.  one_to_many: 0 = OneToOne
+// only, 1 = rebuild as OneToMany on a duplicate (HashJoin::getInstance retry), 2 = OneToMany.
+ORC_EXPORT void* orc_join_build_n(const void* const* key_cols, const int32_t* key_types,
+                                  const int32_t* key_nullables, int32_t n_keys, int64_t num_rows,
+                                  int64_t min_key, int64_t max_key, int prefer_baseline,
+                                  int64_t max_perfect_entries, int32_t one_to_many,
+                                  int64_t keyed_entries, int32_t* err) {
+  KeyCols kc{};
+  kc.n = n_keys;
+  for (int i = 0; i < n_keys; ++i) {
+    kc.col[i] = static_cast<const int8_t*>(key_cols[i]);
+    kc.type[i] = key_types[i];
+    kc.nullable[i] = key_nullables[i] != 0;
+  }
+  *err = 0;
+  if (max_perfect_entries <= 0) max_perfect_entries = INT32_MAX;  // PerfectJoinHashTable.cpp:219
+  __int128 span = (__int128)max_key - (__int128)min_key;
+  const bool perfect = n_keys == 1 && !prefer_baseline && max_key >= min_key && span < max_perfect_entries;
+  auto* j = new OrcJoin();
+  for (int attempt = one_to_many == 2 ? 1 : 0; attempt < 2; ++attempt) {
+    *err = build_join(*j, kc, num_rows, perfect, attempt == 1, min_key, max_key, keyed_entries);
+    if (*err != MI355Q_ERR_JOIN_NOT_ONE_TO_ONE || one_to_many == 0) break;
+  }
+  if (*err) {
+    delete j;
+    return nullptr;
+  }
+  return j;
+}
 ORC_EXPORT void* orc_join_build(const void* key_col, int key_type, int key_nullable,
                                 int64_t num_rows, int64_t min_key, int64_t max_key,
                                 int prefer_baseline, int64_t max_perfect_entries,
                                 int32_t* err) {
-  auto* j = new OrcJoin();
-  j->key_type = key_type;
-  j->key_nullable = key_nullable;
-  *err = 0;
-  const int8_t* col = static_cast<const int8_t*>(key_col);
-  const int64_t null_t = int_null_of(key_type);
-  if (max_perfect_entries <= 0) max_perfect_entries = INT32_MAX;  // PerfectJoinHashTable.cpp:219
-  __int128 span = (__int128)max_key - (__int128)min_key;
-  const bool perfect_ok = !prefer_baseline && max_key >= min_key && span < max_perfect_entries;
-  if (perfect_ok) {
-    j->hash_type = 0;
-    j->min_key = min_key;
-    j->max_key = max_key;
-    j->entry_count = max_key - min_key + 1;
-    j->perfect.assign(j->entry_count, -1);  // init_hash_join_buff
-    for (int64_t i = 0; i < num_rows; ++i) {
-      const int64_t k = decode_int(col, key_type, i);
-      if (key_nullable && k == null_t) continue;  // fill_hash_join_buff_impl skips NULL
-      if (k < min_key || k > max_key) {
-        *err = MI355Q_ERR_INVALID_PLAN;
-        delete j;
-        return nullptr;
-      }
-      int32_t& slot = j->perfect[k - min_key];
-      if (slot != -1) {  // fill_one_to_one_hashtable CAS failure -> -1
-        *err = MI355Q_ERR_JOIN_NOT_ONE_TO_ONE;
-        delete j;
-        return nullptr;
-      }
-      slot = (int32_t)i;
-    }
-    return j;
-  }
-  // keyed: entry_count = 2 x max(NDV,1) (BaselineJoinHashTable.cpp:484-486); NDV == rows
-  // for a unique key column.
-  j->hash_type = 1;
-  j->entry_count = 2 * std::max<int64_t>(num_rows, 1);
-  j->keyed.resize(j->entry_count * 2);
-  for (int64_t e = 0; e < j->entry_count; ++e) {  // init_baseline_hash_join_buff
-    j->keyed[2 * e] = kEmptyKey64;
-    j->keyed[2 * e + 1] = -1;
-  }
-  for (int64_t i = 0; i < num_rows; ++i) {
-    const int64_t k = decode_int(col, key_type, i);
-    if (key_nullable && k == null_t) continue;  // GenericKeyHandler should_skip_entries
-    uint32_t h = murmur1(&k, 8, 0) % j->entry_count;  // write_baseline_hash_slot
-    uint32_t start = h;
-    bool placed = false;
-    do {
-      int64_t* e = &j->keyed[(size_t)h * 2];
-      if (e[0] == kEmptyKey64) {
-        e[0] = k;
-        e[1] = i;
-        placed = true;
-        break;
-      }
-      if (e[0] == k) {
-        if (e[1] != -1) {
-          *err = MI355Q_ERR_JOIN_NOT_ONE_TO_ONE;
-          delete j;
-          return nullptr;
-        }
-        e[1] = i;
-        placed = true;
-        break;
-      }
-      h = (h + 1) % j->entry_count;
-    } while (h != start);
-    if (!placed) {
-      *err = MI355Q_ERR_JOIN_TABLE_FULL;
-      delete j;
-      return nullptr;
-    }
-  }
-  return j;
+  const void* cols[1] = {key_col};
+  const int32_t types[1] = {key_type}, nulls[1] = {key_nullable};
+  return orc_join_build_n(cols, types, nulls, 1, num_rows, min_key, max_key, prefer_baseline,
+                          max_perfect_entries, 0, 0, err);
 }
 ORC_EXPORT void orc_join_free(void* j) { delete static_cast<OrcJoin*>(j); }
 ORC_EXPORT int64_t orc_join_probe(const void* jp, int64_t key) {
   const auto* j = static_cast<const OrcJoin*>(jp);
-  if (j->hash_type == 0) return hash_join_idx(j->perfect.data(), key, j->min_key, j->max_key);
-  return baseline_hash_join_idx_64(j->keyed.data(), key, j->entry_count);
+  const Matches m = join_lookup(*j, &key);
+  if (j->hash_type == 0) return hash_join_idx(j->perfect(), key, j->min_key, j->max_key);
+  if (j->hash_type == 1 && j->n_keys == 1 && j->width == 8)
+    return baseline_hash_join_idx_64(reinterpret_cast<const int64_t*>(j->buf.data()), key, j->entry_count);
+  return m.count ? (m.ids ? m.ids[0] : m.single) : -1;
+}
+// the matching set of a (composite) key: writes up to max_ids row ids, returns the count
+ORC_EXPORT int32_t orc_join_matches(const void* jp, const int64_t* keys, int32_t* ids, int32_t max_ids) {
+  const auto* j = static_cast<const OrcJoin*>(jp);
+  const Matches m = join_lookup(*j, keys);
+  for (int i = 0; i < m.count && i < max_ids; ++i) ids[i] = m.ids ? m.ids[i] : (int32_t)m.single;
+  return m.count;
 }
 ORC_EXPORT int32_t orc_join_info(const void* jp, int32_t* hash_type, int64_t* entry_count) {
   const auto* j = static_cast<const OrcJoin*>(jp);
@@ -1223,9 +1428,15 @@ ORC_EXPORT int32_t orc_join_info(const void* jp, int32_t* hash_type, int64_t* en
   *entry_count = j->entry_count;
   return 0;
 }
-ORC_EXPORT const void* orc_join_buffer(const void* jp) {
+ORC_EXPORT int32_t orc_join_shape(const void* jp, int32_t* n_keys, int32_t* width, int64_t* bytes) {
   const auto* j = static_cast<const OrcJoin*>(jp);
-  return j->hash_type == 0 ? (const void*)j->perfect.data() : (const void*)j->keyed.data();
+  *n_keys = j->n_keys;
+  *width = j->width;
+  *bytes = (int64_t)j->buf.size();
+  return 0;
+}
+ORC_EXPORT const void* orc_join_buffer(const void* jp) {
+  return static_cast<const OrcJoin*>(jp)->buf.data();
 }
 
 // ---- execute: kernel per fragment on `n_threads` host threads, each with a private

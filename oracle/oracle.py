@@ -68,6 +68,13 @@ def lib() -> C.CDLL:
         l.orc_join_build.restype = C.c_void_p
         l.orc_join_build.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_int64,
                                      C.c_int64, C.c_int, C.c_int64, P(C.c_int32)]
+        l.orc_join_build_n.restype = C.c_void_p
+        l.orc_join_build_n.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64,
+                                       C.c_int64, C.c_int, C.c_int64, C.c_int32, C.c_int64, P(C.c_int32)]
+        l.orc_join_matches.restype = C.c_int32
+        l.orc_join_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        l.orc_join_shape.restype = C.c_int32
+        l.orc_join_shape.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_int32), P(C.c_int64)]
         l.orc_join_free.restype = None
         l.orc_join_free.argtypes = [C.c_void_p]
         l.orc_join_probe.restype = C.c_int64
@@ -118,6 +125,12 @@ def ref_lib() -> Optional[C.CDLL]:
     r.fixed_width_int_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     r.fixed_width_double_decode.restype = C.c_double
     r.fixed_width_double_decode.argtypes = [C.c_void_p, C.c_int64]
+    r.get_composite_key_index_64.restype = C.c_int64
+    r.get_composite_key_index_64.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    r.get_composite_key_index_32.restype = C.c_int64
+    r.get_composite_key_index_32.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+    r.baseline_hash_join_idx_32.restype = C.c_int64
+    r.baseline_hash_join_idx_32.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
     r.fixed_width_unsigned_decode.restype = C.c_int64
     r.fixed_width_unsigned_decode.argtypes = [C.c_void_p, C.c_int32, C.c_int64]
     r.fixed_width_small_date_decode.restype = C.c_int64
@@ -146,15 +159,22 @@ def qmd_init(plan: capi.Plan) -> capi.QMD:
 
 
 class OracleJoin:
-    def __init__(self, keys: np.ndarray, key_type: int, min_key: int, max_key: int,
-                 nullable: bool = False, prefer_baseline: bool = False,
-                 max_perfect_entries: int = 0):
-        self.keys = np.ascontiguousarray(keys, dtype=NP_DTYPE[key_type])
+    """keys / key_type / nullable: one inner key column, or equal-length lists for a composite
+    key.  one_to_many: 0 OneToOne only, 1 rebuild as OneToMany on a duplicate, 2 OneToMany."""
+
+    def __init__(self, keys, key_type, min_key: int, max_key: int,
+                 nullable=False, prefer_baseline: bool = False,
+                 max_perfect_entries: int = 0, one_to_many: int = 0, keyed_entry_count: int = 0):
+        cols = list(keys) if isinstance(keys, (list, tuple)) else [keys]
+        types = list(key_type) if isinstance(key_type, (list, tuple)) else [key_type]
+        nulls = list(nullable) if isinstance(nullable, (list, tuple)) else [nullable] * len(cols)
+        self.keys = [np.ascontiguousarray(k, dtype=NP_DTYPE[t]) for k, t in zip(cols, types)]
+        n = len(self.keys)
+        ptrs = (C.c_void_p * n)(*[k.ctypes.data for k in self.keys])
         err = C.c_int32()
-        self.handle = lib().orc_join_build(self.keys.ctypes.data, key_type, int(nullable),
-                                           len(self.keys), min_key, max_key,
-                                           int(prefer_baseline), max_perfect_entries,
-                                           C.byref(err))
+        self.handle = lib().orc_join_build_n(ptrs, (C.c_int32 * n)(*types), (C.c_int32 * n)(*[int(x) for x in nulls]),
+                                             n, len(self.keys[0]), min_key, max_key, int(prefer_baseline),
+                                             max_perfect_entries, one_to_many, keyed_entry_count, C.byref(err))
         self.err = err.value
         if not self.handle:
             raise capi.Mi355qError(self.err, "oracle join build")
@@ -162,19 +182,41 @@ class OracleJoin:
     def probe(self, key: int) -> int:
         return lib().orc_join_probe(self.handle, key)
 
+    def matches(self, key) -> list:
+        """Row ids of the matching set of a (composite) key."""
+        k = np.atleast_1d(np.asarray(key, dtype=np.int64))
+        ids = np.zeros(1 << 16, dtype=np.int32)
+        n = lib().orc_join_matches(self.handle, k.ctypes.data, ids.ctypes.data, len(ids))
+        return [int(x) for x in ids[:n]]
+
     def info(self):
         ht, ec = C.c_int32(), C.c_int64()
         lib().orc_join_info(self.handle, C.byref(ht), C.byref(ec))
+        nk, w, nb = C.c_int32(), C.c_int32(), C.c_int64()
+        lib().orc_join_shape(self.handle, C.byref(nk), C.byref(w), C.byref(nb))
+        self._shape = (nk.value, w.value, nb.value)
         return dict(hash_type=ht.value, entry_count=ec.value)
 
-    def buffer(self) -> np.ndarray:
-        i = self.info()
+    def shape(self):
+        self.info()
+        return dict(key_components=self._shape[0], component_width=self._shape[1], bytes=self._shape[2])
+
+    def raw(self) -> np.ndarray:
+        """The whole hash join buffer as bytes."""
+        nb = self.shape()["bytes"]
         ptr = lib().orc_join_buffer(self.handle)
+        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint8)), shape=(nb,)).copy()
+
+    def buffer(self) -> np.ndarray:
+        """OneToOne tables as arrays: int32[entries] (perfect) or [entries, components + 1]."""
+        i = self.info()
+        sh = self.shape()
+        raw = self.raw()
         if i["hash_type"] == 0:
-            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int32)),
-                                         shape=(i["entry_count"],)).copy()
-        return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_int64)),
-                                     shape=(i["entry_count"], 2)).copy()
+            return raw.view(np.int32).copy()
+        dt = np.int32 if sh["component_width"] == 4 else np.int64
+        stride = sh["key_components"] + (1 if i["hash_type"] == 1 else 0)
+        return raw[:i["entry_count"] * stride * sh["component_width"]].view(dt).reshape(i["entry_count"], stride).copy()
 
     def __del__(self):
         try:

@@ -29,10 +29,12 @@ class Case:
     ra: RelAlgExecutionUnit
     frags: List[List[np.ndarray]]                 # [frag][col]
     inner: List[np.ndarray] = field(default_factory=list)
-    join_keys: Optional[np.ndarray] = None        # inner key column (when joining)
-    join_key_type: int = INT64
+    join_keys: object = None                      # inner key column (or a list of them: composite key)
+    join_key_type: object = INT64
     join_range: Optional[ExpressionRange] = None
     join_prefer_baseline: bool = False
+    join_one_to_many: int = 0                     # 0 OneToOne only, 1 rebuild on duplicates, 2 OneToMany
+    join_key_nullable: object = False             # bool, or a list for composite keys
     expect_error: Optional[int] = None
     fp_rtol: float = 1e-9                         # fp64 SUM/AVG rel <= 1e-9
 
@@ -339,4 +341,90 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       RelAlgExecutionUnit(sfd, [TargetExpr(SUM, 1), TargetExpr(SUM, 1, 1), TargetExpr(COUNT)],
                                           inner_col_descs=sdescs, join_outer_col=0),
                       sff, [sparse, dim_w, dim_f], sparse, INT64, col_range([sparse], INT64, False), False))
+
+    # ---- one-to-many tables, LEFT joins, composite keys (JoinHashTableTest.cpp:286-378,539-597;
+    # ExecuteTest Joins_LeftOuterJoin / Joins_OneToMany shapes)
+    reps = rng.integers(0, 4, m)                                  # each key 0..3 times
+    dim_dup = np.repeat(np.arange(m, dtype=np.int64), reps)
+    rng.shuffle(dim_dup)
+    md = len(dim_dup)
+    dup_w = rng.integers(-1000, 1000, md).astype(np.int64)
+    dup_f = rng.random(md)
+    dup_descs = [InputColDescriptor(INT64, False, col_range([dim_dup], INT64, False)),
+                 InputColDescriptor(INT64, False, col_range([dup_w], INT64, False)),
+                 InputColDescriptor(DOUBLE, False, col_range([dup_f], DOUBLE, False))]
+    dup_rng = ExpressionRange(True, 0, m - 1)
+
+    def dra(targets, outer_col=0, quals=(), group=(), kind=capi.JOIN_INNER, inner=dup_descs):
+        return RelAlgExecutionUnit(list(fdescs), list(targets), list(quals), list(group),
+                                   inner_col_descs=list(inner), join_outer_col=outer_col, join_kind=kind)
+
+    for pb, tag in [(False, "perfect"), (True, "keyed")]:
+        cases.append(Case(f"join_1n_{tag}_sums", dra([TargetExpr(SUM, 1), TargetExpr(COUNT), TargetExpr(SUM, 1, 1),
+                                                      TargetExpr(AVG, 2, 1)]),
+                          ffrags, [dim_dup, dup_w, dup_f], dim_dup, INT64, dup_rng, pb, join_one_to_many=1))
+        cases.append(Case(f"join_1n_{tag}_groupby_int32_key", dra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT),
+                                                                   TargetExpr(MAX, 1, 1), TargetExpr(AVG, 2, 1)],
+                                                                  outer_col=2, group=[3]),
+                          ffrags, [dim_dup, dup_w, dup_f], dim_dup, INT64, dup_rng, pb, join_one_to_many=2))
+        cases.append(Case(f"join_left_{tag}_1to1", jra([TargetExpr(COUNT), TargetExpr(COUNT, 1, 1), TargetExpr(SUM, 1, 1),
+                                                        TargetExpr(SUM, 1), TargetExpr(MIN, 2, 1), TargetExpr(AVG, 2, 1)]),
+                          ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, pb))
+        cases[-1].ra.join_kind = capi.JOIN_LEFT
+        cases.append(Case(f"join_left_{tag}_1n_groupby", dra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT),
+                                                              TargetExpr(COUNT, 1, 1), TargetExpr(SUM, 1, 1),
+                                                              TargetExpr(MAX, 2, 1)], outer_col=2, group=[3],
+                                                             kind=capi.JOIN_LEFT),
+                          ffrags, [dim_dup, dup_w, dup_f], dim_dup, INT64, dup_rng, pb, join_one_to_many=1))
+    cases.append(Case("join_left_no_match_at_all", dra([TargetExpr(COUNT), TargetExpr(SUM, 1, 1), TargetExpr(COUNT, 2, 1)],
+                                                       quals=[Qual(0, LT, -10)], kind=capi.JOIN_LEFT),
+                      ffrags, [dim_dup, dup_w, dup_f], dim_dup, INT64, dup_rng, False, join_one_to_many=1))
+    # int32 inner key column, keyed: 4-byte components (getKeyComponentWidth), some inner NULLs
+    dim32 = rng.permutation(3 * m)[:m].astype(np.int32)
+    dim32[rng.random(m) < 0.05] = np.int32(-2**31)
+    d32_descs = [InputColDescriptor(INT32, True, col_range([dim32], INT32, True))] + inner_descs[1:]
+    c32 = Case("join_keyed_int32_inner_width4",
+               RelAlgExecutionUnit(list(fdescs), [TargetExpr(COUNT), TargetExpr(SUM, 1, 1)],
+                                   inner_col_descs=d32_descs, join_outer_col=2),
+               ffrags, [dim32, dim_w, dim_f], dim32, INT32, col_range([dim32], INT32, True), True,
+               join_key_nullable=True)
+    cases.append(c32)
+    # composite keys: (int32, int16) -> 4-byte components one-to-one; (int64, int32) with
+    # duplicates -> 8-byte components one-to-many
+    ca = rng.integers(0, 60, m).astype(np.int32)
+    cb = (np.arange(m) // 60).astype(np.int16)                      # (ca, cb) not unique in general ...
+    pair = np.unique(np.stack([ca.astype(np.int64), cb.astype(np.int64)], 1), axis=0)
+    ca, cb = pair[:, 0].astype(np.int32), pair[:, 1].astype(np.int16)  # ... so keep the distinct pairs
+    mc = len(ca)
+    cw = rng.integers(-1000, 1000, mc).astype(np.int64)
+    comp_descs = [InputColDescriptor(INT32, False, col_range([ca], INT32, False)),
+                  InputColDescriptor(INT16, False, col_range([cb], INT16, False)),
+                  InputColDescriptor(INT64, False, col_range([cw], INT64, False))]
+    cfd, cff = make_table(rng, n, fs, [
+        (INT64, False, lambda r, mm: r.integers(-3, 63, mm)),           # pairs with ca (int64 outer, int32 inner)
+        (INT32, True, lambda r, mm: r.integers(0, 13, mm)),             # pairs with cb, nullable
+        (INT64, False, lambda r, mm: r.integers(1, 1000, mm)),
+        (INT64, False, lambda r, mm: r.integers(0, 9, mm)),             # group key
+    ])
+    for kind, tag in [(capi.JOIN_INNER, "inner"), (capi.JOIN_LEFT, "left")]:
+        cases.append(Case(f"join_composite_key32_1to1_{tag}",
+                          RelAlgExecutionUnit(cfd, [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 2, 1),
+                                                    TargetExpr(SUM, 2), TargetExpr(COUNT, 2, 1)], groupby_exprs=[3],
+                                              inner_col_descs=comp_descs, join_outer_col=[0, 1], join_kind=kind),
+                          cff, [ca, cb, cw], [ca, cb], [INT32, INT16], ExpressionRange(), False))
+    ka = (rng.integers(0, 40, 3 * m) * 10**10).astype(np.int64)
+    kb = rng.integers(0, 5, 3 * m).astype(np.int32)
+    kw_ = rng.integers(-1000, 1000, 3 * m).astype(np.int64)
+    k_descs = [InputColDescriptor(INT64, False, col_range([ka], INT64, False)),
+               InputColDescriptor(INT32, False, col_range([kb], INT32, False)),
+               InputColDescriptor(INT64, False, col_range([kw_], INT64, False))]
+    kfd, kff = make_table(rng, n, fs, [
+        (INT64, False, lambda r, mm: r.integers(0, 45, mm) * 10**10),
+        (INT8, False, lambda r, mm: r.integers(0, 6, mm)),
+        (DOUBLE, False, lambda r, mm: r.random(mm)),
+    ])
+    cases.append(Case("join_composite_key64_1n",
+                      RelAlgExecutionUnit(kfd, [TargetExpr(COUNT), TargetExpr(SUM, 2, 1), TargetExpr(SUM, 2), TargetExpr(MIN, 2, 1)],
+                                          inner_col_descs=k_descs, join_outer_col=[0, 1]),
+                      kff, [ka, kb, kw_], [ka, kb], [INT64, INT32], ExpressionRange(), False, join_one_to_many=1))
     return cases

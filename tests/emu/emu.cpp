@@ -16,16 +16,26 @@ extern "C" int32_t emu_qmd_init(const mi355q_plan* p, mi355q_qmd* q) { return qm
 
 extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                                int join_hash_type, const void* join_buf, int64_t join_min,
-                               int64_t join_max, int64_t join_entries, int64_t* out,
-                               mi355q_qmd* out_qmd) {
+                               int64_t join_max, int64_t join_entries, int join_n_keys,
+                               int join_width, int64_t* out, mi355q_qmd* out_qmd) {
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;
   DevPlan d;
   if (int32_t e = build_dev_plan(*plan, q, &d)) return e;
   if (plan->join_outer_col >= 0) {
-    d.join_col = plan->join_outer_col;
-    d.join_type = col_type_code(plan->cols[plan->join_outer_col]);
-    d.join_nullable = plan->cols[plan->join_outer_col].nullable != 0;
+    const int nk = plan->n_join_cols > 1 ? plan->n_join_cols : 1;
+    for (int i = 0; i < nk; ++i) {
+      const int c = (i == 0 && plan->n_join_cols <= 1) ? plan->join_outer_col : plan->join_outer_cols[i];
+      d.join_cols[i] = c;
+      d.join_types[i] = col_type_code(plan->cols[c]);
+      d.join_nullables[i] = plan->cols[c].nullable != 0;
+    }
+    d.join_col = d.join_cols[0];
+    d.join_type = d.join_types[0];
+    d.join_nullable = d.join_nullables[0];
+    d.join_n_keys = join_n_keys;
+    d.join_width = join_width;
+    d.join_kind = plan->join_kind;
     d.join_hash_type = join_hash_type;
     d.join_buf = join_buf;
     d.join_min = join_min;

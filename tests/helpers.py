@@ -214,7 +214,7 @@ def emu_lib() -> C.CDLL:
         l.emu_qmd_init.argtypes = [P(capi.Plan), P(capi.QMD)]
         l.emu_execute.restype = C.c_int32
         l.emu_execute.argtypes = [P(capi.Plan), P(capi.Inputs), C.c_int, C.c_void_p, C.c_int64,
-                                  C.c_int64, C.c_int64, C.c_void_p, P(capi.QMD)]
+                                  C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, P(capi.QMD)]
         l.emu_reduce.restype = C.c_int32
         l.emu_reduce.argtypes = [P(capi.QMD), C.c_void_p, C.c_void_p, C.c_int64]
         _emu = l

@@ -45,9 +45,13 @@ def _build_join(torch, case):
     from heavydb_amd.executor import HashJoin
     if case.join_keys is None:
         return None, None
-    kt = torch.from_numpy(np.ascontiguousarray(case.join_keys)).cuda()
-    hj = HashJoin.getInstance(int(kt.data_ptr()), int(kt.numel()), case.join_key_type,
-                              case.join_range, prefer_baseline=case.join_prefer_baseline)
+    cols = case.join_keys if isinstance(case.join_keys, (list, tuple)) else [case.join_keys]
+    kt = [torch.from_numpy(np.ascontiguousarray(k)).cuda() for k in cols]
+    multi = isinstance(case.join_keys, (list, tuple))
+    hj = HashJoin.getInstance([int(t.data_ptr()) for t in kt] if multi else int(kt[0].data_ptr()),
+                              int(kt[0].numel()), case.join_key_type, case.join_range,
+                              key_nullable=case.join_key_nullable, prefer_baseline=case.join_prefer_baseline,
+                              one_to_many=case.join_one_to_many)
     return hj, kt
 
 
@@ -56,7 +60,8 @@ def _oracle_join(oracle, case):
         return None
     r = case.join_range
     return oracle.OracleJoin(case.join_keys, case.join_key_type, r.min, r.max,
-                             prefer_baseline=case.join_prefer_baseline)
+                             nullable=case.join_key_nullable, prefer_baseline=case.join_prefer_baseline,
+                             one_to_many=case.join_one_to_many)
 
 
 @pytest.mark.parametrize("force_generic", [True, False], ids=["generic", "planned"])
@@ -665,3 +670,89 @@ def test_multi_column_keys_at_scale(torch_cuda, oracle, shape):
                     else livek.astype(np.float64))[::-1][:k]
     got_order = np.where(top == null2, -np.inf, top.astype(np.float64)) if null2 is not None else top.astype(np.float64)
     assert got_n == min(k, len(livek)) and np.array_equal(got_order, order)
+
+
+def _decode_join_table(raw: np.ndarray, hash_type: int, entries: int, kc: int, w: int, min_key: int = 0):
+    """{key tuple: sorted row ids} of a hash join buffer — HashTable::toSet() of the reference's
+    JoinHashTableTest (slot positions and the order inside a payload run depend on the build
+    order, so tables are compared decoded)."""
+    out = {}
+    if hash_type == 0:
+        slots = raw.view(np.int32)[:entries]
+        return {(int(min_key + i),): [int(v)] for i, v in enumerate(slots) if v >= 0}
+    dt = np.int32 if w == 4 else np.int64
+    empty = 2**31 - 1 if w == 4 else 2**63 - 1
+    if hash_type == 1:
+        tab = raw[:entries * (kc + 1) * w].view(dt).reshape(entries, kc + 1)
+        return {tuple(int(x) for x in r[:kc]): [int(r[kc])] for r in tab if r[0] != empty}
+    key_bytes = 0 if hash_type == 2 else entries * kc * w
+    i32 = raw[key_bytes:].view(np.int32)
+    offsets, counts, payloads = i32[:entries], i32[entries:2 * entries], i32[2 * entries:]
+    keys = None if hash_type == 2 else raw[:key_bytes].view(dt).reshape(entries, kc)
+    for e in range(entries):
+        if offsets[e] < 0:
+            assert counts[e] == 0
+            continue
+        k = (int(min_key + e),) if hash_type == 2 else tuple(int(x) for x in keys[e])
+        out[k] = sorted(int(x) for x in payloads[offsets[e]:offsets[e] + counts[e]])
+    return out
+
+
+@pytest.mark.parametrize("shape", ["perfect_1n", "keyed_1n_i64", "composite_1to1_w4", "composite_1n_w8",
+                                   "keyed_1to1_int32"])
+def test_join_tables_built_on_device_at_scale(torch_cuda, oracle, shape):
+    """One-to-many (count -> scan -> fill), composite-key and 4-byte keyed join tables built by
+    the device kernels from a few hundred thousand inner rows, decoded and compared with the
+    oracle's serial build (itself pinned to the reference's probe functions and to the layouts
+    of hash_joins.rst); the scan is checked through offsets == exclusive prefix of counts."""
+    import ctypes
+    from heavydb_amd.executor import ExpressionRange, HashJoin
+    torch = torch_cuda
+    rng = np.random.default_rng(99)
+    m = 300_000
+    nullable = False
+    rngk = ExpressionRange()
+    pb, otm = False, 1
+    if shape == "perfect_1n":
+        cols, types = [rng.integers(0, 50_000, m).astype(np.int64)], [capi.INT64]
+        rngk = ExpressionRange(True, 0, 49_999)
+    elif shape == "keyed_1n_i64":
+        k = (rng.integers(0, 50_000, m) * 1000003).astype(np.int64)
+        k[rng.random(m) < 0.02] = -2**63
+        cols, types, nullable, pb = [k], [capi.INT64], True, True
+    elif shape == "composite_1to1_w4":
+        pair = np.unique(np.stack([rng.integers(0, 3000, m), rng.integers(-50, 50, m)], 1), axis=0)
+        rng.shuffle(pair)
+        cols, types, otm = [pair[:, 0].astype(np.int32), pair[:, 1].astype(np.int16)], [capi.INT32, capi.INT16], 0
+    elif shape == "composite_1n_w8":
+        cols = [(rng.integers(0, 2000, m) * 10**10).astype(np.int64), rng.integers(0, 8, m).astype(np.int32),
+                rng.integers(0, 2, m).astype(np.int8)]
+        types = [capi.INT64, capi.INT32, capi.INT8]
+    else:
+        cols, types, pb, otm = [rng.permutation(4 * m)[:m].astype(np.int32)], [capi.INT32], True, 0
+    n_rows = len(cols[0])
+    dev = [torch.from_numpy(c).cuda() for c in cols]
+    multi = len(cols) > 1
+    hj = HashJoin.getInstance([int(t.data_ptr()) for t in dev] if multi else int(dev[0].data_ptr()), n_rows,
+                              types if multi else types[0], rngk, key_nullable=nullable, prefer_baseline=pb,
+                              one_to_many=otm)
+    oj = oracle.OracleJoin(cols if multi else cols[0], types if multi else types[0], rngk.min, rngk.max if rngk.valid else -1,
+                           nullable=nullable, prefer_baseline=pb, one_to_many=otm)
+    info, oinfo, osh = hj.info(), oj.info(), oj.shape()
+    assert (info["hash_type"], info["entry_count"], info["key_components"], info["component_width"]) == \
+        (oinfo["hash_type"], oinfo["entry_count"], osh["key_components"], osh["component_width"] if oinfo["hash_type"] % 2 else 8)
+    assert info["bytes"] == osh["bytes"]
+    raw = np.empty(info["bytes"], dtype=np.uint8)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpy(ctypes.c_void_p(raw.ctypes.data), ctypes.c_void_p(info["device_ptr"]), ctypes.c_size_t(raw.nbytes), 2)
+    kc, w, ent = info["key_components"], info["component_width"], info["entry_count"]
+    got = _decode_join_table(raw, info["hash_type"], ent, kc, w, info["min_key"])
+    want = _decode_join_table(oj.raw(), oinfo["hash_type"], ent, kc, w, info["min_key"])
+    assert got == want
+    if info["hash_type"] >= 2:
+        key_bytes = 0 if info["hash_type"] == 2 else ent * kc * w
+        i32 = raw[key_bytes:].view(np.int32)
+        offsets, counts = i32[:ent].astype(np.int64), i32[ent:2 * ent].astype(np.int64)
+        excl = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        assert ((offsets == excl) | ((counts == 0) & (offsets == -1))).all()
+        assert int(counts.sum()) == sum(len(v) for v in want.values())

@@ -151,11 +151,66 @@ def test_keyed_join_build_and_probe(oracle, golden):
         # the oracle sizes keyed tables at 2 x rows like the reference (2 x NDV)
         j = oracle.OracleJoin(keys, 4, 0, -1, prefer_baseline=True)
         assert j.info() == {"hash_type": 1, "entry_count": kj["entry_count"]}
+        assert j.shape()["component_width"] == 8
         tab = j.buffer()
         assert [int(x) for x in tab.reshape(-1)] == kj["table"]  # serial insert order == ref
         assert [j.probe(k) for k in kj["probes"]] == kj["idx"]
     # the two distinct "no match" values of the reference: -2 at an empty slot
     assert golden["keyed_join"][0]["idx"][3] == -2
+
+
+def test_composite_keyed_tables(oracle, golden):
+    """Keyed join tables with several key components, 4- and 8-byte: the oracle's build lays the
+    keys (and one-to-one payloads) down exactly where the reference's MurmurHash1 probing puts
+    them, baseline_hash_join_idx_{32,64} / get_composite_key_index_{32,64} agree on every probe,
+    and a one-to-many table returns each key's rows.  Includes the 6-entry table of
+    docs/source/execution/hash_joins.rst."""
+    from heavydb_amd import capi
+    for ck in golden["composite_keyed"]:
+        kc, w, n = ck["key_count"], ck["width"], ck["entry_count"]
+        rows = np.array(ck["dim_rows"], dtype=np.int64)
+        t = capi.INT32 if w == 4 else capi.INT64
+        j = oracle.OracleJoin([rows[:, i] for i in range(kc)], [t] * kc, 0, -1, prefer_baseline=True,
+                              one_to_many=0 if ck["with_payload"] else 2, keyed_entry_count=n)
+        assert j.info() == {"hash_type": 1 if ck["with_payload"] else 3, "entry_count": n}
+        assert j.shape()["key_components"] == kc and j.shape()["component_width"] == w
+        stride = kc + (1 if ck["with_payload"] else 0)
+        dt = np.int32 if w == 4 else np.int64
+        tab = j.raw()[:n * stride * w].view(dt)
+        assert [int(x) for x in tab] == ck["table"]
+        for probe, idx in zip(ck["probes"], ck["idx"]):
+            m = j.matches(probe)
+            want_rows = [i for i, r in enumerate(ck["dim_rows"]) if r == probe]
+            if ck["with_payload"]:
+                assert m == ([idx] if idx >= 0 else []) and m == want_rows
+            else:
+                assert (idx >= 0) == bool(m) and m == want_rows  # serial build: row order
+    # the literal of hash_joins.rst: keys land in slots 1, 2, 3 of 6
+    doc = golden["composite_keyed"][-1]
+    assert doc["table"][3:12] == [1, 1, 0, 3, 3, 1, 0, 0, 2]
+
+
+def test_one_to_many_perfect_doc_example(oracle):
+    """hash_joins.rst 'One-To-Many JoinHashTable Example': table2 = (0, 1, 3, 3) ->
+    | offsets 0 1 * 2 | counts 1 1 * 2 | payloads 0 1 2 3 |; and the keyed variant
+    | keys * (1,1) (3,3) (0,0) * * | offsets * 0 1 3 * * | counts * 1 2 1 * * | payloads 1 2 3 0 |."""
+    from heavydb_amd import capi
+    b = np.array([0, 1, 3, 3], dtype=np.int32)
+    j = oracle.OracleJoin(b, capi.INT32, 0, 3, one_to_many=1)  # OneToOne fails on the duplicate -> rebuilt
+    assert j.info() == {"hash_type": 2, "entry_count": 4}
+    assert [int(x) for x in j.raw().view(np.int32)] == [0, 1, -1, 2, 1, 1, 0, 2, 0, 1, 2, 3]
+    assert j.matches(3) == [2, 3] and j.matches(2) == [] and j.matches(7) == []
+    with pytest.raises(capi.Mi355qError) as ei:
+        oracle.OracleJoin(b, capi.INT32, 0, 3, one_to_many=0)
+    assert ei.value.code == capi.ERR_JOIN_NOT_ONE_TO_ONE
+    j = oracle.OracleJoin([b, b], [capi.INT32, capi.INT32], 0, -1, one_to_many=1, keyed_entry_count=6)
+    assert j.info() == {"hash_type": 3, "entry_count": 6}
+    raw = j.raw().view(np.int32)
+    E = EMPTY32
+    assert [int(x) for x in raw[:12]] == [E, E, 1, 1, 3, 3, 0, 0, E, E, E, E]
+    assert [int(x) for x in raw[12:18]] == [-1, 0, 1, 3, -1, -1]
+    assert [int(x) for x in raw[18:24]] == [0, 1, 2, 1, 0, 0]
+    assert [int(x) for x in raw[24:28]] == [1, 2, 3, 0]
 
 
 def test_decoders(oracle, golden):

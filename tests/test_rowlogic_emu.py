@@ -18,7 +18,8 @@ def _oracle_join(oracle, case):
         return None
     r = case.join_range
     return oracle.OracleJoin(case.join_keys, case.join_key_type, r.min, r.max,
-                             prefer_baseline=case.join_prefer_baseline)
+                             nullable=case.join_key_nullable, prefer_baseline=case.join_prefer_baseline,
+                             one_to_many=case.join_one_to_many)
 
 
 def _emu_execute(case, plan, oj):
@@ -42,17 +43,19 @@ def _emu_execute(case, plan, oj):
     q = capi.QMD()
     assert lib.emu_qmd_init(C.byref(plan), C.byref(q)) == 0
     buf = np.empty((q.entry_count, q.row_size // 8), dtype=np.int64)
-    jt, jbuf, jmin, jmax, jn = 0, None, 0, 0, 0
+    jt, jbuf, jmin, jmax, jn, jk, jw = 0, None, 0, 0, 0, 1, 8
     if oj is not None:
         info = oj.info()
+        sh = oj.shape()
         jt = info["hash_type"]
-        jb = oj.buffer()
+        jb = oj.raw()
         jbuf = jb.ctypes.data
         jn = info["entry_count"]
+        jk, jw = sh["key_components"], sh["component_width"]
         jmin, jmax = case.join_range.min, case.join_range.max
         keep = jb  # noqa: F841
     out_q = capi.QMD()
-    code = lib.emu_execute(C.byref(plan), C.byref(inp), jt, jbuf, jmin, jmax, jn, buf.ctypes.data,
+    code = lib.emu_execute(C.byref(plan), C.byref(inp), jt, jbuf, jmin, jmax, jn, jk, jw, buf.ctypes.data,
                            C.byref(out_q))
     return out_q, buf, code
 
