@@ -106,7 +106,9 @@ int cu_count_of(int dev) {
 // pointer tables and the timing events.  Calls on one device are serialised by `mu`, like
 // the reference's per-device gpu_exec_mutex_ (ExecutionKernel.cpp:216-220).
 struct DeviceCtx {
-  std::mutex mu;
+  std::recursive_mutex mu;  // the packed multi-column path re-enters mi355q_execute
+  void* aux = nullptr;      // packed key column + temporary tables of that path
+  int64_t aux_bytes = 0;
   void* scratch = nullptr;
   int64_t scratch_bytes = 0;
   void* meta = nullptr;
@@ -258,11 +260,14 @@ int32_t mi355q_device_info(int32_t device_id, char* name, int32_t* cu_count, int
 
 int32_t mi355q_release_workspace(int32_t device_id) {
   DeviceCtx& ctx = ctx_of(device_id);
-  std::lock_guard<std::mutex> lk(ctx.mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx.mu);
   DeviceGuard g(device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
   if (ctx.scratch) (void)hipFree(ctx.scratch);
   if (ctx.meta) (void)hipFree(ctx.meta);
+  if (ctx.aux) (void)hipFree(ctx.aux);
+  ctx.aux = nullptr;
+  ctx.aux_bytes = 0;
   if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
   ctx.stream = nullptr;
   for (hipEvent_t e : ctx.events) (void)hipEventDestroy(e);
@@ -494,6 +499,216 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
   return MI355Q_OK;
 }
 
+// ------------------------------------------------------------------------------- packed keys
+// Baseline-hash GROUP BY over several columns whose ranges together fit 62 bits: pack the key
+// columns of every row into one int64 column (one streaming pass), run the step on that column
+// with the single-key fast family (partition-then-aggregate), and re-emit the finished table
+// with the real key components — MurmurHash3 over the key bytes, the reference's layout.  The
+// slots of a row are the same in both tables (key projections take no slot in the baseline
+// layout), so the re-emission copies them.  Anything this cannot take (no ranges, too many
+// bits, joins, small inputs) stays with the row kernel.
+namespace {
+
+constexpr int32_t kNotTaken = INT32_MIN + 7;  // internal: "use the ordinary path"
+
+bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, PackSpec* ps) {
+  if (q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || p.n_group_cols < 2 || p.join_outer_col >= 0) return false;
+  if (p.n_cols >= MI355Q_MAX_COLS) return false;  // the packed column is appended to the inputs
+  std::memset(ps, 0, sizeof(*ps));
+  ps->n = p.n_group_cols;
+  int shift = 0;
+  for (int g = 0; g < p.n_group_cols; ++g) {
+    const int c = p.group_cols[g];
+    const mi355q_range& r = p.col_ranges[c];
+    if (!r.valid || r.min > r.max) return false;
+    const __int128 span = (__int128)r.max - (__int128)r.min + 1 + (p.cols[c].nullable ? 1 : 0);
+    if (span > ((__int128)1 << 61)) return false;
+    int bits = 1;
+    while (((__int128)1 << bits) < span) ++bits;
+    if (shift + bits > 62) return false;  // the packed key must stay below EMPTY_KEY_64
+    ps->cols[g] = c;
+    ps->types[g] = d.group_types[g];
+    ps->nullable[g] = p.cols[c].nullable != 0;
+    ps->shift[g] = shift;
+    ps->min[g] = r.min;
+    ps->card[g] = (uint64_t)span;
+    ps->mask[g] = (((uint64_t)1) << bits) - 1;
+    shift += bits;
+  }
+  return true;
+}
+
+int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
+                             const mi355q_qmd& q, const DevPlan& d, int n_cus, mi355q_result** out,
+                             mi355q_exec_report* report) {
+  PackSpec ps;
+  if (!pack_spec_of(*plan, q, d, &ps)) return kNotTaken;
+  const int nf = in->n_frags, nc = plan->n_cols;
+  int64_t total_rows = 0, max_frag_rows = 0;
+  for (int f = 0; f < nf; ++f) {
+    if (in->num_rows[f] < 0) return MI355Q_ERR_INVALID_PLAN;
+    total_rows += in->num_rows[f];
+    max_frag_rows = std::max(max_frag_rows, in->num_rows[f]);
+  }
+  // small inputs: the row kernel is as fast (kernel_variant 2 asks for this path regardless, 1 for
+  // the row kernel)
+  if (o.kernel_variant == 1 || (o.kernel_variant != 2 && total_rows < ((int64_t)8 << 20))) return kNotTaken;
+
+  // derived plan: the packed column (appended, range unknown -> baseline, 8-byte key) is the
+  // only group column; key projections are dropped (they own no slot)
+  mi355q_plan p2 = *plan;
+  p2.n_cols = nc + 1;
+  p2.cols[nc] = mi355q_col_desc{MI355Q_INT64, 0, MI355Q_ENC_NONE, 0};
+  p2.col_ranges[nc] = mi355q_range{};
+  p2.n_group_cols = 1;
+  p2.group_cols[0] = nc;
+  p2.n_targets = 0;
+  for (int t = 0; t < plan->n_targets; ++t) {
+    if (plan->targets[t].agg != MI355Q_PROJECT_KEY) p2.targets[p2.n_targets++] = plan->targets[t];
+  }
+  if (p2.n_targets == 0) return kNotTaken;
+  mi355q_qmd q2;
+  if (qmd_init(p2, &q2) != MI355Q_OK) return kNotTaken;
+  if (q2.slot_count != q.slot_count || q2.entry_count != q.entry_count) return kNotTaken;
+  for (int i = 0; i < q.slot_count; ++i)
+    if (q2.init_vals[i] != q.init_vals[i]) return kNotTaken;
+
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  // memory: two temporary tables + the packed column of one pass (a group of fragments)
+  const int64_t tmp_bytes = (q2.entry_count * (int64_t)q2.row_size + 255) & ~255ll;
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  int64_t pack_budget = std::min<int64_t>((int64_t)16 << 30, ((int64_t)free_b + ctx.aux_bytes) / 3);
+  int64_t pass_rows = pack_budget / 8;
+  if (const char* e = std::getenv("MI355Q_PACK_PASS_ROWS")) {  // tests: force several passes
+    const int64_t v = std::atoll(e);
+    if (v > 0 && v < pass_rows) pass_rows = std::max<int64_t>(v, max_frag_rows);
+  }
+  if (pass_rows < max_frag_rows + 2 * (int64_t)nf) return kNotTaken;
+  if (pass_rows > total_rows) pass_rows = total_rows;
+  const int64_t pack_bytes = ((pass_rows + 2 * (int64_t)nf) * 8 + 255) & ~255ll;
+  const int64_t tab_bytes = sizeof(void*) * (size_t)nf;
+  const int64_t need = pack_bytes + 2 * tmp_bytes + ((tab_bytes + 255) & ~255ll) + 256;
+  if (ctx.aux_bytes < need) {
+    if (ctx.aux) (void)hipFree(ctx.aux);
+    ctx.aux = nullptr;
+    ctx.aux_bytes = 0;
+    if (hipMalloc(&ctx.aux, (size_t)need) != hipSuccess) {
+      (void)hipGetLastError();
+      return kNotTaken;
+    }
+    ctx.aux_bytes = need;
+  }
+  char* aux = (char*)ctx.aux;
+  int64_t* packed = (int64_t*)aux;
+  int64_t* tmp_a = (int64_t*)(aux + pack_bytes);
+  int64_t* tmp_b = (int64_t*)(aux + pack_bytes + tmp_bytes);
+  int64_t** d_packed_tab = (int64_t**)(aux + pack_bytes + 2 * tmp_bytes);
+  int32_t* d_err = (int32_t*)(aux + pack_bytes + 2 * tmp_bytes + ((tab_bytes + 255) & ~255ll));
+
+  mi355q_result* res = nullptr;
+  if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;
+  struct ResGuard {
+    mi355q_result* r;
+    ~ResGuard() { mi355q_result_free(r); }
+  } rg{res};
+  // device copy of the caller's column table (the pack kernel reads the key columns from it)
+  DevWord d_tab, d_rows;
+  HIP_TRY(hipMalloc(&d_tab.p, sizeof(void*) * (size_t)std::max(1, nf * nc)));
+  HIP_TRY(hipMalloc(&d_rows.p, sizeof(int64_t) * (size_t)std::max(1, nf)));
+  HIP_TRY(hipMemcpyAsync(d_tab.p, in->col_buffers, sizeof(void*) * (size_t)(nf * nc), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemcpyAsync(d_rows.p, in->num_rows, sizeof(int64_t) * (size_t)nf, hipMemcpyHostToDevice, s));
+  HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+
+  std::vector<const void*> cols2((size_t)nf * (nc + 1));
+  std::vector<int64_t*> h_packed((size_t)nf);
+  mi355q_exec_report acc{};
+  int pass = 0;
+  int f = 0;
+  while (f < nf) {
+    int f1 = f;
+    int64_t rows = 0, off = 0;
+    while (f1 < nf && (f1 == f || rows + in->num_rows[f1] <= pass_rows)) {
+      h_packed[f1] = packed + off;
+      off += (in->num_rows[f1] + 1) & ~(int64_t)1;  // 16-byte aligned fragment chunks
+      rows += in->num_rows[f1];
+      ++f1;
+    }
+    const int pnf = f1 - f;
+    HIP_TRY(hipMemcpyAsync(d_packed_tab, h_packed.data() + f, sizeof(void*) * (size_t)pnf, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_pack_keys(ps, (const int8_t* const*)d_tab.p + (size_t)f * nc, (const int64_t*)d_rows.p + f, pnf,
+                             nc, max_frag_rows, d_packed_tab, d_err, n_cus, s));
+    for (int i = 0; i < pnf; ++i) {
+      for (int c = 0; c < nc; ++c) cols2[(size_t)i * (nc + 1) + c] = in->col_buffers[(size_t)(f + i) * nc + c];
+      cols2[(size_t)i * (nc + 1) + nc] = h_packed[f + i];
+    }
+    mi355q_inputs in2 = *in;
+    in2.n_frags = pnf;
+    in2.col_buffers = cols2.data();
+    in2.num_rows = in->num_rows + f;
+    mi355q_exec_options o2 = o;
+    o2.stream = s;
+    o2.out_buffer = pass == 0 ? tmp_a : tmp_b;
+    mi355q_result* r2 = nullptr;
+    mi355q_exec_report rep2{};
+    const int32_t e2 = mi355q_execute(&p2, &in2, &o2, &r2, &rep2);
+    if (e2 == MI355Q_ERR_OUT_OF_GPU_MEM || e2 == MI355Q_ERR_UNSUPPORTED) return kNotTaken;
+    if (e2) return e2;  // incl. < 0: out of slots -> the caller grows the table
+    if (pass > 0) {
+      HIP_TRY(launch_reduce(r2->dplan, q2.idx_target_as_key, tmp_a, tmp_b, q2.entry_count, d_err, s));
+    }
+    if (pass == 0) {  // the report names the member the first (a full-sized) pass ran
+      std::snprintf(acc.kernel_name, sizeof(acc.kernel_name), "%s", rep2.kernel_name);
+      acc.variant = rep2.variant;
+    }
+    acc.kernel_ms += rep2.kernel_ms;
+    acc.n_launches += rep2.n_launches;
+    acc.spilled_rows += rep2.spilled_rows;
+    mi355q_result_free(r2);
+    f = f1;
+    ++pass;
+  }
+  HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+  if (nf > 0) HIP_TRY(launch_unpack_emit(ps, d, tmp_a, q2.entry_count, res->buf, d_err, s));
+  if (ev1) HIP_TRY(hipEventRecord(ev1, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_err == MI355Q_ERR_UNSUPPORTED) return kNotTaken;  // a key outside its declared range
+  if (h_err) return h_err;
+  if (report) {
+    *report = acc;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  rg.r = nullptr;
+  *out = res;
+  return MI355Q_OK;
+}
+
+}  // namespace
+
 // ------------------------------------------------------------------------------- execute
 int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                        const mi355q_exec_options* opts, mi355q_result** out,
@@ -517,6 +732,12 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   if (!g.ok) return MI355Q_ERR_HIP;
   const int n_cus = cu_count_of(in->device_id);
 
+  if (!o.force_generic && in->n_frags > 0) {
+    const int32_t e = execute_packed_multi(plan, in, o, q, d, n_cus, out, report);
+    if (e != kNotTaken) return e;
+    *out = nullptr;
+  }
+
   hipStream_t s = (hipStream_t)o.stream;  // caller's, or the device context's own (below)
 
   mi355q_result* res = nullptr;
@@ -538,7 +759,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   const size_t rows_bytes = sizeof(int64_t) * (size_t)std::max(1, nf);
   const size_t meta_bytes = ptr_bytes + rows_bytes + 64;
   DeviceCtx& ctx = ctx_of(in->device_id);
-  std::lock_guard<std::mutex> ctx_lock(ctx.mu);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
   if (ctx.meta_bytes < meta_bytes) {
     if (ctx.meta) (void)hipFree(ctx.meta);
     ctx.meta = nullptr;

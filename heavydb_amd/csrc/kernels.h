@@ -58,6 +58,27 @@ hipError_t launch_join_init_baseline(int64_t* tab, int64_t entries, hipStream_t 
 hipError_t launch_join_fill_baseline(const int8_t* keys, int type, int nullable, int64_t n,
                                      int64_t* tab, int64_t entries, int32_t* d_err,
                                      hipStream_t s);
+// ---- multi-column keys through the single-key fast families: the group columns of a row are
+// packed into one int64 (per column: (key - min), or the last code for NULL, at its bit offset),
+// the step runs on the packed column, and the finished table is re-emitted with the real key
+// components (kernels_generic.hip: k_pack_keys / k_unpack_emit)
+struct PackSpec {
+  int32_t n;
+  int32_t cols[MI355Q_MAX_GROUP_COLS], types[MI355Q_MAX_GROUP_COLS];  // column index, type code
+  int32_t nullable[MI355Q_MAX_GROUP_COLS], shift[MI355Q_MAX_GROUP_COLS];
+  int64_t min[MI355Q_MAX_GROUP_COLS];
+  uint64_t card[MI355Q_MAX_GROUP_COLS];  // codes 0 .. card-1 (card-1 = NULL for nullable columns)
+  uint64_t mask[MI355Q_MAX_GROUP_COLS];
+};
+// packed_cols: device array [n_frags] of output pointers
+hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, const int64_t* d_num_rows,
+                            int n_frags, int n_cols, int64_t max_frag_rows, int64_t* const* packed_cols,
+                            int32_t* d_err, int n_cus, hipStream_t s);
+// tmp: table of the packed single-key step (rows = packed key + slot_count slots); out: the
+// initialised final table described by p
+hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,
+                              int64_t* out, int32_t* d_err, hipStream_t s);
+
 // inner key columns of a join table build
 struct JoinKeyCols {
   const int8_t* col[MI355Q_MAX_GROUP_COLS];

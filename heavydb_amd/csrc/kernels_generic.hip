@@ -249,6 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_join_fill_perfect(const int8_t* __re
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   const int64_t null_t = int_null_of(type);
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    if (*(volatile int32_t*)d_err) break;  // the attempt has already failed (e.g. a duplicate key)
     const int64_t k = decode_int(keys, type, i);
     if (nullable && k == null_t) continue;
     if (k < min_key || k > max_key) {
@@ -256,7 +257,8 @@ __global__ __launch_bounds__(kBlock) void k_join_fill_perfect(const int8_t* __re
       continue;
     }
     if (atomicCAS((int*)&buf[k - min_key], -1, (int)i) != -1) {
-      atomicCAS(d_err, 0, MI355Q_ERR_JOIN_NOT_ONE_TO_ONE);
+      // one report is enough: ten million same-address atomics would take 100 ms
+      if (*(volatile int32_t*)d_err == 0) atomicCAS(d_err, 0, MI355Q_ERR_JOIN_NOT_ONE_TO_ONE);
     }
   }
 }
@@ -342,7 +344,7 @@ MQ_D int64_t keyed_insert(T* tab, uint32_t entries, int n_keys, int stride, cons
     if (old == empty) {
       if (n_keys > 1) {
         for (int i = 1; i < n_keys; ++i) __hip_atomic_store(e + i, (T)keys[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
+        MQ_PUBLISH_ORDER();
         __hip_atomic_store(e, (T)keys[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       found = hp;
@@ -355,7 +357,6 @@ MQ_D int64_t keyed_insert(T* tab, uint32_t entries, int n_keys, int stride, cons
     } else if (old == (T)keys[0]) {
       bool same = true;
       if (n_keys > 1) {
-        __threadfence();
         for (int i = 1; i < n_keys; ++i)
           same = same && __hip_atomic_load(e + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (T)keys[i];
       }
@@ -394,6 +395,7 @@ __global__ __launch_bounds__(kBlock) void k_join_fill_keyed(JoinKeyCols kc, int6
                                                              int32_t* __restrict__ d_err) {
   const int64_t step = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += step) {
+    if (*(volatile int32_t*)d_err) break;  // the attempt has already failed
     int64_t keys[MI355Q_MAX_GROUP_COLS];
     if (!load_join_key(kc, i, keys)) continue;
     int32_t bad = 0;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_join_fill_keyed(JoinKeyCols kc, int6
         dup = atomicCAS((unsigned long long*)tab + slot * stride + kc.n, (unsigned long long)-1ll,
                         (unsigned long long)i) != (unsigned long long)-1ll;
       }
-      if (dup) atomicCAS(d_err, 0, MI355Q_ERR_JOIN_NOT_ONE_TO_ONE);
+      if (dup && *(volatile int32_t*)d_err == 0) atomicCAS(d_err, 0, MI355Q_ERR_JOIN_NOT_ONE_TO_ONE);
     }
   }
 }
@@ -540,6 +542,65 @@ __global__ __launch_bounds__(kBlock) void k_scan_write_offsets(const int32_t* __
   for (int k = 0; k < 8; ++k) {
     if (base + k < n) offsets[base + k] = c[k] ? (int32_t)acc : -1;
     acc += c[k];
+  }
+}
+
+// ---- packed multi-column keys --------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_pack_keys(PackSpec ps, const int8_t* const* __restrict__ cols,
+                                                       const int64_t* __restrict__ num_rows, int n_frags,
+                                                       int n_cols, int64_t* const* __restrict__ packed,
+                                                       int32_t* __restrict__ d_err) {
+  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kBlock;
+  bool bad = false;
+  for (int f = 0; f < n_frags; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * n_cols;
+    int64_t* dst = packed[f];
+    const int64_t n = num_rows[f];
+    for (int64_t pos = gtid; pos < n; pos += gsize) {
+      uint64_t code = 0;
+      for (int g = 0; g < ps.n; ++g) {
+        const int64_t k = decode_int(fc[ps.cols[g]], ps.types[g], pos);
+        uint64_t c;
+        if (ps.nullable[g] && k == int_null_of(ps.types[g])) {
+          c = ps.card[g] - 1;
+        } else {
+          c = (uint64_t)k - (uint64_t)ps.min[g];
+          // a value outside the declared range cannot be packed: the caller re-runs the step
+          // with the row kernel (which hashes any key)
+          bad = bad || k < ps.min[g] || c >= ps.card[g] - (ps.nullable[g] ? 1 : 0);
+        }
+        code |= c << ps.shift[g];
+      }
+      __builtin_nontemporal_store((int64_t)code, dst + pos);
+    }
+  }
+  if (bad) atomicCAS(d_err, 0, MI355Q_ERR_UNSUPPORTED);
+}
+
+__global__ __launch_bounds__(kBlock) void k_unpack_emit(PackSpec ps, DevPlan p, const int64_t* __restrict__ tmp,
+                                                         int64_t tmp_entries, int64_t* __restrict__ out,
+                                                         int32_t* __restrict__ d_err) {
+  const int tmp_quad = 1 + p.slot_count;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < tmp_entries; e += stride) {
+    const int64_t* src = tmp + e * tmp_quad;
+    if (src[0] == kEmptyKey64) continue;
+    const uint64_t code = (uint64_t)src[0];
+    int64_t keys[MI355Q_MAX_GROUP_COLS];
+    for (int g = 0; g < ps.n; ++g) {
+      const uint64_t c = (code >> ps.shift[g]) & ps.mask[g];
+      keys[g] = (ps.nullable[g] && c == ps.card[g] - 1) ? int_null_of(ps.types[g]) : (int64_t)(c + (uint64_t)ps.min[g]);
+    }
+    // the packed keys are pairwise distinct and `out` is fresh: claim a row, never search
+    int64_t* slots = baseline_insert_distinct_multi(out, (uint32_t)p.entry_count, p.row_quad, p.key_width, ps.n,
+                                                    keys);
+    if (!slots) {
+      atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+      continue;
+    }
+    // every packed key is distinct, so this lane is the only writer of the row's slots
+    for (int j = 0; j < p.slot_count; ++j) slots[j] = src[1 + j];
   }
 }
 
@@ -743,6 +804,23 @@ hipError_t launch_join_one_to_many(const JoinKeyCols& kc, int64_t n, int hash_ty
     hipLaunchKernelGGL(k_join_fill_ids, dim3(grid_for(n)), dim3(kBlock), 0, s, kc, n, hash_type, tab, entries,
                        min_key, max_key, offsets, counts, payloads);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, const int64_t* d_num_rows,
+                            int n_frags, int n_cols, int64_t max_frag_rows, int64_t* const* packed_cols,
+                            int32_t* d_err, int n_cus, hipStream_t s) {
+  if (n_frags <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_pack_keys, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, ps, d_cols,
+                     d_num_rows, n_frags, n_cols, packed_cols, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,
+                              int64_t* out, int32_t* d_err, hipStream_t s) {
+  if (tmp_entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_unpack_emit, dim3(grid_for(tmp_entries)), dim3(kBlock), 0, s, ps, p, tmp, tmp_entries, out,
+                     d_err);
   return hipGetLastError();
 }
 

@@ -38,6 +38,7 @@ inline T emu_cas(T* p, T expect, T desired) {
 #define MQ_LOAD64(p) (*(volatile int64_t*)(p))
 #define MQ_STORE64(p, v) (*(volatile int64_t*)(p) = (v))
 #define MQ_FENCE() ((void)0)
+#define MQ_PUBLISH_ORDER() ((void)0)
 #define MQ_LOAD32(p) (*(volatile int32_t*)(p))
 #define MQ_STORE32(p, v) (*(volatile int32_t*)(p) = (v))
 #define MQ_FN inline
@@ -51,6 +52,11 @@ inline T emu_cas(T* p, T expect, T desired) {
 #define MQ_LOAD64(p) __hip_atomic_load((int64_t*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MQ_STORE64(p, v) __hip_atomic_store((int64_t*)(p), (int64_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MQ_FENCE() __threadfence()
+// Order the agent-scope atomic (write-through) stores of a key's tail before the store that
+// publishes its first component: wait until they are acknowledged.  A full release fence would
+// also write back the L2 (buffer_wbl2) for plain stores this protocol never issues — that costs
+// microseconds per inserted key.
+#define MQ_PUBLISH_ORDER() __builtin_amdgcn_s_waitcnt(0)
 #define MQ_LOAD32(p) __hip_atomic_load((int32_t*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MQ_STORE32(p, v) __hip_atomic_store((int32_t*)(p), (int32_t)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define MQ_FN __device__ __forceinline__
@@ -360,7 +366,7 @@ MQ_FN int64_t* baseline_find_or_insert_multi(int64_t* buf, uint32_t entry_count,
       const int32_t old = (int32_t)MQ_CAS32(r32, (uint32_t)kEmptyKey32, (uint32_t)kLockedKey32);
       if (old == kEmptyKey32) {
         for (int i = 1; i < key_count; ++i) MQ_STORE32(r32 + i, (int32_t)keys[i]);
-        MQ_FENCE();
+        MQ_PUBLISH_ORDER();
         MQ_STORE32(r32, (int32_t)keys[0]);
         found = row + key_quad;
         done = true;
@@ -370,7 +376,8 @@ MQ_FN int64_t* baseline_find_or_insert_multi(int64_t* buf, uint32_t entry_count,
           done = true;
         }
       } else if (old == (int32_t)keys[0]) {
-        MQ_FENCE();
+        // the loads below depend on the CAS result and are agent-scope atomic loads, so they
+        // observe what the winner published before it released the first component
         bool same = true;
         for (int i = 1; i < key_count; ++i) same = same && MQ_LOAD32(r32 + i) == (int32_t)keys[i];
         if (same) {
@@ -386,7 +393,7 @@ MQ_FN int64_t* baseline_find_or_insert_multi(int64_t* buf, uint32_t entry_count,
       const int64_t old = (int64_t)MQ_CAS64(row, kEmptyKey64, kLockedKey64);
       if (old == kEmptyKey64) {
         for (int i = 1; i < key_count; ++i) MQ_STORE64(row + i, keys[i]);
-        MQ_FENCE();
+        MQ_PUBLISH_ORDER();
         MQ_STORE64(row, keys[0]);
         found = row + key_quad;
         done = true;
@@ -396,7 +403,6 @@ MQ_FN int64_t* baseline_find_or_insert_multi(int64_t* buf, uint32_t entry_count,
           done = true;
         }
       } else if (old == keys[0]) {
-        MQ_FENCE();
         bool same = true;
         for (int i = 1; i < key_count; ++i) same = same && MQ_LOAD64(row + i) == keys[i];
         if (same) {
@@ -415,6 +421,35 @@ MQ_FN int64_t* baseline_find_or_insert_multi(int64_t* buf, uint32_t entry_count,
     }
   }
   return found;
+}
+
+// Bulk insertion of keys that are known to be pairwise DISTINCT and absent from the table (a
+// finished table being re-emitted): a row is claimed by CAS on its first component and never
+// searched for, so there is nothing to publish — an occupied row is simply skipped.
+MQ_FN int64_t* baseline_insert_distinct_multi(int64_t* buf, uint32_t entry_count, int row_quad,
+                                              int key_width, int key_count, const int64_t* keys) {
+  const int key_quad = (key_count * key_width + 7) >> 3;
+  uint32_t words[2 * MI355Q_MAX_GROUP_COLS];
+  const int n_words = pack_join_key(keys, key_count, key_width, words);
+  const uint32_t h = murmur3_words(words, n_words) % entry_count;
+  uint32_t hp = h;
+  do {
+    int64_t* row = buf + (size_t)hp * row_quad;
+    if (key_width == 4) {
+      int32_t* r32 = (int32_t*)row;
+      if ((int32_t)MQ_CAS32(r32, (uint32_t)kEmptyKey32, (uint32_t)(int32_t)keys[0]) == kEmptyKey32) {
+        for (int i = 1; i < key_count; ++i) r32[i] = (int32_t)keys[i];
+        return row + key_quad;
+      }
+    } else {
+      if ((int64_t)MQ_CAS64(row, kEmptyKey64, keys[0]) == kEmptyKey64) {
+        for (int i = 1; i < key_count; ++i) row[i] = keys[i];
+        return row + key_quad;
+      }
+    }
+    hp = hp + 1 == entry_count ? 0 : hp + 1;
+  } while (hp != h);
+  return nullptr;
 }
 
 // component i of the key stored at the start of `row`

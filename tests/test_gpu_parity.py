@@ -616,7 +616,7 @@ def test_multi_column_keys_at_scale(torch_cuda, oracle, shape):
     ra = RelAlgExecutionUnit(descs, targets, [Qual(nk + 1, capi.LT, 2**30)], list(range(nk)),
                              max_groups_buffer_entry_guess=guess)
     cols = [k[0] for k in keys] + [val, fil]
-    cuts = [0, n // 3, n // 3 + 7, n]
+    cuts = [0, n // 3, n // 3 + 8, n]  # an 8-row fragment; every chunk stays 16-byte aligned
     frags = [[c[cuts[i]:cuts[i + 1]] for c in cols] for i in range(3)]
     q, want, code = oracle.execute(ra.to_plan(), frags, n_threads=3)
     assert code == 0 and q.desc_type == capi.GROUP_BY_BASELINE_HASH and q.group_col_count == nk
@@ -627,12 +627,20 @@ def test_multi_column_keys_at_scale(torch_cuda, oracle, shape):
         return FetchResult([[int(t.data_ptr()) + cuts[i] * t.element_size() for t in dev] for i in range(lo, hi)],
                            [cuts[i + 1] - cuts[i] for i in range(lo, hi)], keepalive=dev)
     ex = Executor(0)
-    rs = ex.executeWorkUnit(ra, fetch(0, 3), allow_retry=False)
+    rs = ex.executeWorkUnit(ra, fetch(0, 3), allow_retry=False, kernel_variant=1)
+    assert rs.report.kernel_name.decode() == "k_generic"
     qmd_equal(q, rs.getQueryMemDesc())
     got = rs.getStorage()
     compare_buffers(q, want, got, 1e-9)
     check_probe_invariant(q, got)
     compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
+    # the packed-key route (key columns packed into one int64, single-key fast family, table
+    # re-emitted with the real components) must produce the same table
+    rp = ex.executeWorkUnit(ra, fetch(0, 3), allow_retry=False, kernel_variant=2)
+    assert rp.report.kernel_name.decode() in ("k_part_scatter", "k_baseline_direct")
+    qmd_equal(q, rp.getQueryMemDesc())
+    compare_buffers(q, want, rp.getStorage(), 1e-9)
+    check_probe_invariant(q, rp.getStorage())
     # device reduce of two halves == the single pass
     r1 = ex.executeWorkUnit(ra, fetch(0, 1), allow_retry=False)
     r2 = ex.executeWorkUnit(ra, fetch(1, 3), allow_retry=False)
@@ -756,3 +764,66 @@ def test_join_tables_built_on_device_at_scale(torch_cuda, oracle, shape):
         excl = np.concatenate([[0], np.cumsum(counts)[:-1]])
         assert ((offsets == excl) | ((counts == 0) & (offsets == -1))).all()
         assert int(counts.sum()) == sum(len(v) for v in want.values())
+
+
+@pytest.mark.parametrize("passes", ["one_pass", "several_passes"])
+def test_packed_multi_column_route_at_scale(torch_cuda, oracle, passes, monkeypatch):
+    """200 M rows, GROUP BY (sparse int64, nullable int32): the plan-time choice is the packed-key
+    route (pack -> partition-then-aggregate -> re-emit with the real key components).  Checked
+    through size-independent properties — COUNT sums to the rows that pass the filter, the
+    groups are exactly the expected pairs, the table is a valid image of the reference's
+    probing over the 16 key bytes — and against the row kernel's table on a 16 M-row prefix.
+    With MI355Q_PACK_PASS_ROWS the input is cut into passes whose tables are reduced."""
+    from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, InputColDescriptor, Qual,
+                                      RelAlgExecutionUnit, TargetExpr, generate_column)
+    from tests.helpers import key_matrix
+    torch = torch_cuda
+    if passes == "several_passes":
+        monkeypatch.setenv("MI355Q_PACK_PASS_ROWS", str(70_000_000))
+    n, frag = 200_000_000, 32_000_000
+    n_a, n_b = 200_000, 5
+    a = torch.empty(n, dtype=torch.int64, device="cuda")
+    b = torch.empty(n, dtype=torch.int32, device="cuda")
+    v = torch.empty(n, dtype=torch.float64, device="cuda")
+    fil = torch.empty(n, dtype=torch.int32, device="cuda")
+    generate_column(int(a.data_ptr()), n, capi.GEN_I64_MOD_MUL, 1, n_a, 1000003, 7)
+    generate_column(int(b.data_ptr()), n, capi.GEN_I32_MOD, 2, n_b, -2, null_every=10)
+    generate_column(int(v.data_ptr()), n, capi.GEN_F64_UNIT, 3, a_f=1000.0)
+    generate_column(int(fil.data_ptr()), n, capi.GEN_I32_UNIFORM31, 4)
+    torch.cuda.synchronize()
+    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, (n_a - 1) * 1000003 + 7)),
+             InputColDescriptor(capi.INT32, True, ExpressionRange(True, -2, n_b - 3, True)),
+             InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0)),
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY, 0), TargetExpr(capi.PROJECT_KEY, 1),
+                                     TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 2)], [Qual(3, capi.LT, 2**30)],
+                             [0, 1], max_groups_buffer_entry_guess=2 * n_a * (n_b + 1))
+    cols = [a, b, v, fil]
+
+    def fetch(rows):
+        bufs, nr, o = [], [], 0
+        while o < rows:
+            m = min(frag, rows - o)
+            bufs.append([int(t.data_ptr()) + o * t.element_size() for t in cols])
+            nr.append(m)
+            o += m
+        return FetchResult(bufs, nr, keepalive=cols)
+    ex = Executor(0)
+    rs = ex.executeWorkUnit(ra, fetch(n), allow_retry=False)
+    assert rs.report.kernel_name.decode() == "k_part_scatter"
+    q = rs.getQueryMemDesc()
+    assert q.desc_type == capi.GROUP_BY_BASELINE_HASH and q.group_col_count == 2 and q.key_width == 8
+    table = rs.getStorage()
+    check_probe_invariant(q, table)
+    ival, dval, nul = rs.fetch()
+    cnt_ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT)], [Qual(3, capi.LT, 2**30)])
+    assert int(ival[:, 2].sum()) == ex.executeWorkUnit(cnt_ra, fetch(n)).getNextRow()[0]
+    assert ival.shape[0] == n_a * (n_b + 1)  # every (a, b-or-NULL) pair occurs
+    assert ((ival[:, 0] - 7) % 1000003 == 0).all() and set(np.unique(ival[:, 1])) == {-2**31, -2, -1, 0, 1, 2}
+    assert (nul[:, 1] == (ival[:, 1] == -2**31)).all() and (dval[:, 3] > 0).all() and (dval[:, 3] < 1000).all()
+    # prefix: packed route == row kernel, as key -> slots maps
+    m = 16_000_000
+    r_pack = ex.executeWorkUnit(ra, fetch(m), allow_retry=False, kernel_variant=2)
+    r_row = ex.executeWorkUnit(ra, fetch(m), allow_retry=False, kernel_variant=1)
+    assert r_pack.report.kernel_name.decode() == "k_part_scatter" and r_row.report.kernel_name.decode() == "k_generic"
+    compare_buffers(q, r_row.getStorage(), r_pack.getStorage(), 1e-9)
