@@ -512,10 +512,28 @@ namespace {
 constexpr int32_t kNotTaken = INT32_MIN + 7;  // internal: "use the ordinary path"
 
 bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, PackSpec* ps) {
-  if (q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || p.n_group_cols < 2 || p.join_outer_col >= 0) return false;
+  if (p.join_outer_col >= 0 || p.n_group_cols < 1) return false;
   if (p.n_cols >= MI355Q_MAX_COLS) return false;  // the packed column is appended to the inputs
   std::memset(ps, 0, sizeof(*ps));
   ps->n = p.n_group_cols;
+  if (q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
+    // tables that fit LDS belong to the LDS kernels; bucketed keys cannot be restored from
+    // their index
+    if (q.entry_count * (int64_t)q.row_size <= 64 * 1024 || q.entry_count >= ((int64_t)1 << 31)) return false;
+    ps->mode = 1;
+    for (int g = 0; g < p.n_group_cols; ++g) {
+      if (q.group_bucket[g]) return false;
+      ps->cols[g] = p.group_cols[g];
+      ps->types[g] = d.group_types[g];
+      ps->translate[g] = d.group_translate[g];
+      ps->min[g] = q.group_min[g];
+      ps->card[g] = (uint64_t)q.group_card[g];
+      ps->mul[g] = d.group_mul[g];
+      ps->null_key[g] = q.group_null_key[g];
+    }
+    return true;
+  }
+  if (q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || p.n_group_cols < 2) return false;
   int shift = 0;
   for (int g = 0; g < p.n_group_cols; ++g) {
     const int c = p.group_cols[g];
@@ -542,6 +560,8 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
                              const mi355q_qmd& q, const DevPlan& d, int n_cus, mi355q_result** out,
                              mi355q_exec_report* report) {
   PackSpec ps;
+  // kernel_variant 1 = "the row kernel / direct members", as everywhere else
+  if (o.kernel_variant == 1) return kNotTaken;
   if (!pack_spec_of(*plan, q, d, &ps)) return kNotTaken;
   const int nf = in->n_frags, nc = plan->n_cols;
   int64_t total_rows = 0, max_frag_rows = 0;
@@ -567,11 +587,34 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     if (plan->targets[t].agg != MI355Q_PROJECT_KEY) p2.targets[p2.n_targets++] = plan->targets[t];
   }
   if (p2.n_targets == 0) return kNotTaken;
+  if (ps.mode == 1) {  // a baseline table at 50 % fill for the groups of the perfect layout
+    const int64_t guess = 2 * q.entry_count;
+    if (guess > (int64_t)UINT32_MAX) return kNotTaken;
+    p2.max_groups_buffer_entry_guess = guess;
+  }
   mi355q_qmd q2;
   if (qmd_init(p2, &q2) != MI355Q_OK) return kNotTaken;
-  if (q2.slot_count != q.slot_count || q2.entry_count != q.entry_count) return kNotTaken;
-  for (int i = 0; i < q.slot_count; ++i)
-    if (q2.init_vals[i] != q.init_vals[i]) return kNotTaken;
+  if (q2.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return kNotTaken;
+  if (ps.mode == 0 && (q2.slot_count != q.slot_count || q2.entry_count != q.entry_count)) return kNotTaken;
+  // where every slot of the final row comes from: a slot of the packed step's row, or (perfect
+  // layouts: projected keys own a slot) the original value of a key component
+  {
+    int t2 = 0;
+    for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) ps.slot_src[i] = 0;
+    for (int t = 0; t < plan->n_targets; ++t) {
+      const int sf = q.target_slot[t];
+      if (plan->targets[t].agg == MI355Q_PROJECT_KEY) {
+        if (sf >= 0) ps.slot_src[sf] = -(1 + q.target_key_idx[t]);
+        continue;
+      }
+      const int st = q2.target_slot[t2++];
+      const int ns = plan->targets[t].agg == MI355Q_AVG ? 2 : 1;
+      for (int j = 0; j < ns; ++j) {
+        if (sf < 0 || st < 0 || q2.init_vals[st + j] != q.init_vals[sf + j]) return kNotTaken;
+        ps.slot_src[sf + j] = st + j;
+      }
+    }
+  }
 
   DeviceCtx& ctx = ctx_of(in->device_id);
   std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
@@ -689,7 +732,7 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     ++pass;
   }
   HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
-  if (nf > 0) HIP_TRY(launch_unpack_emit(ps, d, tmp_a, q2.entry_count, res->buf, d_err, s));
+  if (nf > 0) HIP_TRY(launch_unpack_emit(ps, d, tmp_a, q2.entry_count, q2.row_size / 8, res->buf, d_err, s));
   if (ev1) HIP_TRY(hipEventRecord(ev1, s));
   int32_t h_err = 0;
   HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));

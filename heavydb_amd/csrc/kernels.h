@@ -69,6 +69,13 @@ struct PackSpec {
   int64_t min[MI355Q_MAX_GROUP_COLS];
   uint64_t card[MI355Q_MAX_GROUP_COLS];  // codes 0 .. card-1 (card-1 = NULL for nullable columns)
   uint64_t mask[MI355Q_MAX_GROUP_COLS];
+  // perfect-hash layouts (mode 1): the code is the ENTRY INDEX sum_i (key_i - min_i) * mul_i with
+  // NULL keys translated to null_key first, exactly as the row function computes it
+  int32_t mode, pad_;
+  int32_t translate[MI355Q_MAX_GROUP_COLS];
+  int64_t mul[MI355Q_MAX_GROUP_COLS], null_key[MI355Q_MAX_GROUP_COLS];
+  // final slot <- temp slot (>= 0) or <- original value of key component -(1 + k)
+  int32_t slot_src[MI355Q_MAX_SLOTS];
 };
 // packed_cols: device array [n_frags] of output pointers
 hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, const int64_t* d_num_rows,
@@ -77,7 +84,7 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 // tmp: table of the packed single-key step (rows = packed key + slot_count slots); out: the
 // initialised final table described by p
 hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,
-                              int64_t* out, int32_t* d_err, hipStream_t s);
+                              int tmp_quad, int64_t* out, int32_t* d_err, hipStream_t s);
 
 // inner key columns of a join table build
 struct JoinKeyCols {

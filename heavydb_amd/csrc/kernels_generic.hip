@@ -560,8 +560,15 @@ __global__ __launch_bounds__(kBlock) void k_pack_keys(PackSpec ps, const int8_t*
     for (int64_t pos = gtid; pos < n; pos += gsize) {
       uint64_t code = 0;
       for (int g = 0; g < ps.n; ++g) {
-        const int64_t k = decode_int(fc[ps.cols[g]], ps.types[g], pos);
+        int64_t k = decode_int(fc[ps.cols[g]], ps.types[g], pos);
         uint64_t c;
+        if (ps.mode == 1) {  // perfect hash: the entry index
+          if (ps.translate[g] && k == int_null_of(ps.types[g])) k = ps.null_key[g];
+          c = (uint64_t)k - (uint64_t)ps.min[g];
+          bad = bad || k < ps.min[g] || c >= ps.card[g];
+          code += c * (uint64_t)ps.mul[g];
+          continue;
+        }
         if (ps.nullable[g] && k == int_null_of(ps.types[g])) {
           c = ps.card[g] - 1;
         } else {
@@ -601,6 +608,36 @@ __global__ __launch_bounds__(kBlock) void k_unpack_emit(PackSpec ps, DevPlan p, 
     }
     // every packed key is distinct, so this lane is the only writer of the row's slots
     for (int j = 0; j < p.slot_count; ++j) slots[j] = src[1 + j];
+  }
+}
+
+// perfect-hash layouts: the packed key IS the entry index, so the row is addressed directly; key
+// quads receive the translated keys, projected-key slots the original values (NULL restored)
+__global__ __launch_bounds__(kBlock) void k_unpack_perfect(PackSpec ps, DevPlan p, const int64_t* __restrict__ tmp,
+                                                            int64_t tmp_entries, int tmp_quad,
+                                                            int64_t* __restrict__ out, int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < tmp_entries; e += stride) {
+    const int64_t* src = tmp + e * tmp_quad;
+    if (src[0] == kEmptyKey64) continue;
+    const int64_t idx = src[0];
+    if (idx < 0 || idx >= p.entry_count) {
+      atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+      continue;
+    }
+    int64_t tk[MI355Q_MAX_GROUP_COLS], orig[MI355Q_MAX_GROUP_COLS];
+    for (int g = 0; g < ps.n; ++g) {
+      const int64_t d = (idx / ps.mul[g]) % (int64_t)ps.card[g];
+      tk[g] = d + ps.min[g];
+      orig[g] = (ps.translate[g] && tk[g] == ps.null_key[g]) ? int_null_of(ps.types[g]) : tk[g];
+    }
+    int64_t* row = out + idx * p.row_quad;
+    for (int g = 0; g < p.key_quad; ++g) row[g] = tk[g];
+    int64_t* slots = row + p.key_quad;
+    for (int j = 0; j < p.slot_count; ++j) {
+      const int sj = ps.slot_src[j];
+      slots[j] = sj >= 0 ? src[1 + sj] : orig[-(sj + 1)];
+    }
   }
 }
 
@@ -817,8 +854,13 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 }
 
 hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,
-                              int64_t* out, int32_t* d_err, hipStream_t s) {
+                              int tmp_quad, int64_t* out, int32_t* d_err, hipStream_t s) {
   if (tmp_entries <= 0) return hipSuccess;
+  if (ps.mode == 1) {
+    hipLaunchKernelGGL(k_unpack_perfect, dim3(grid_for(tmp_entries)), dim3(kBlock), 0, s, ps, p, tmp, tmp_entries,
+                       tmp_quad, out, d_err);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(k_unpack_emit, dim3(grid_for(tmp_entries)), dim3(kBlock), 0, s, ps, p, tmp, tmp_entries, out,
                      d_err);
   return hipGetLastError();

@@ -1238,6 +1238,9 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   const uint64_t units = (groups + per_unit - 1) / per_unit;
   uint32_t P = 16;  // a line's segments (<= 64) must fit one flusher wave pass
   while (P < 1024 && P < units) P <<= 1;
+  // phase 2 runs one workgroup per (partition, sub-range): with few groups the LDS table would
+  // allow a handful of partitions, which leaves most CUs idle while the records are read back
+  while (P < 1024 && P < (uint32_t)n_cus && (uint64_t)P * 4 <= d) P <<= 1;
   const uint32_t R = (uint32_t)((units + P - 1) / P);
   if (R > (uint32_t)kMaxSub) return false;
   h.g.P = (int32_t)P;
