@@ -54,10 +54,6 @@ hipError_t launch_join_fill_perfect(const int8_t* keys, int type, int nullable, 
 // bit i = (table[i] >= 0): the semi-join view of a perfect table, 32x smaller than the table
 hipError_t launch_join_presence_bitmap(const int32_t* table, int64_t entries, uint32_t* bitmap,
                                        hipStream_t s);
-hipError_t launch_join_init_baseline(int64_t* tab, int64_t entries, hipStream_t s);
-hipError_t launch_join_fill_baseline(const int8_t* keys, int type, int nullable, int64_t n,
-                                     int64_t* tab, int64_t entries, int32_t* d_err,
-                                     hipStream_t s);
 // ---- multi-column keys through the single-key fast families: the group columns of a row are
 // packed into one int64 (per column: (key - min), or the last code for NULL, at its bit offset),
 // the step runs on the packed column, and the finished table is re-emitted with the real key

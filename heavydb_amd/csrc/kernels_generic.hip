@@ -263,49 +263,6 @@ __global__ __launch_bounds__(kBlock) void k_join_fill_perfect(const int8_t* __re
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_join_init_baseline(int64_t* __restrict__ tab,
-                                                                int64_t entries) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < entries * 2; i += stride) {
-    tab[i] = (i & 1) ? -1 : kEmptyKey64;
-  }
-}
-
-// Keyed OneToOne: {key, row id} entries, MurmurHash1 % entry_count + linear probing
-// (write_baseline_hash_slot HashJoinRuntime.cpp:505-538).
-__global__ __launch_bounds__(kBlock) void k_join_fill_baseline(const int8_t* __restrict__ keys,
-                                                                int type, int nullable, int64_t n,
-                                                                int64_t* __restrict__ tab,
-                                                                int64_t entries,
-                                                                int32_t* __restrict__ d_err) {
-  const int64_t stride = (int64_t)gridDim.x * kBlock;
-  const int64_t null_t = int_null_of(type);
-  const uint32_t ne = (uint32_t)entries;
-  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-    const int64_t k = decode_int(keys, type, i);
-    if (nullable && k == null_t) continue;
-    const uint32_t h = murmur1_u64((uint64_t)k) % ne;
-    uint32_t hp = h;
-    bool placed = false;
-    do {
-      int64_t* e = tab + (size_t)hp * 2;
-      const int64_t old = (int64_t)atomicCAS((unsigned long long*)e,
-                                             (unsigned long long)kEmptyKey64,
-                                             (unsigned long long)k);
-      if (old == kEmptyKey64 || old == k) {
-        if (atomicCAS((unsigned long long*)(e + 1), (unsigned long long)-1ll,
-                      (unsigned long long)i) != (unsigned long long)-1ll) {
-          atomicCAS(d_err, 0, MI355Q_ERR_JOIN_NOT_ONE_TO_ONE);
-        }
-        placed = true;
-        break;
-      }
-      hp = hp + 1 == ne ? 0 : hp + 1;
-    } while (hp != h);
-    if (!placed) atomicCAS(d_err, 0, MI355Q_ERR_JOIN_TABLE_FULL);
-  }
-}
-
 // ---- composite / one-to-many join tables -------------------------------------------------
 MQ_D bool load_join_key(const JoinKeyCols& kc, int64_t i, int64_t* keys) {
   bool ok = true;
@@ -785,21 +742,6 @@ hipError_t launch_join_fill_perfect(const int8_t* keys, int type, int nullable, 
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_join_fill_perfect, dim3(grid_for(n)), dim3(kBlock), 0, s, keys, type,
                      nullable, n, min_key, max_key, buf, d_err);
-  return hipGetLastError();
-}
-
-hipError_t launch_join_init_baseline(int64_t* tab, int64_t entries, hipStream_t s) {
-  hipLaunchKernelGGL(k_join_init_baseline, dim3(grid_for(entries * 2)), dim3(kBlock), 0, s, tab,
-                     entries);
-  return hipGetLastError();
-}
-
-hipError_t launch_join_fill_baseline(const int8_t* keys, int type, int nullable, int64_t n,
-                                     int64_t* tab, int64_t entries, int32_t* d_err,
-                                     hipStream_t s) {
-  if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_join_fill_baseline, dim3(grid_for(n)), dim3(kBlock), 0, s, keys, type,
-                     nullable, n, tab, entries, d_err);
   return hipGetLastError();
 }
 

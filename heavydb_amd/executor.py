@@ -237,6 +237,20 @@ class HashJoin:
             pass
 
 
+def rows_to_arrow(q: capi.QMD, ival: np.ndarray, dval: np.ndarray, is_null: np.ndarray,
+                  names: Optional[Sequence[str]] = None):
+    """fetch_rows output -> pyarrow.Table (host-side; columns int64 / float64 with null masks)."""
+    import pyarrow as pa
+    cols, fields = [], []
+    for t in range(q.n_targets):
+        fp = bool(q.target_is_fp[t])
+        vals = dval[:, t] if fp else ival[:, t]
+        mask = is_null[:, t].astype(bool)
+        cols.append(pa.array(vals, type=pa.float64() if fp else pa.int64(), mask=mask if mask.any() else None))
+        fields.append(names[t] if names else f"target_{t}")
+    return pa.table(cols, names=fields)
+
+
 class ResultSet:
     """Owner of one ResultSetStorage buffer in HeavyDB row-wise layout, on the device."""
 
@@ -298,6 +312,12 @@ class ResultSet:
                                                  C.byref(got)))
         k = got.value
         return ival[:k], dval[:k], nul[:k]
+
+    def to_arrow(self, names: Optional[Sequence[str]] = None):
+        """The rows as a pyarrow.Table — what ArrowResultSetConverter::convertToArrow
+        (QueryEngine/ArrowResultSetConverter.cpp) produces from a ResultSet: one column per
+        target, BIGINT -> int64, DOUBLE -> float64, SQL NULLs as validity bits."""
+        return rows_to_arrow(self.getQueryMemDesc(), *self.fetch(), names=names)
 
     def getNextRow(self) -> list:
         """One row of target values (None = SQL NULL); [] when exhausted."""

@@ -298,3 +298,22 @@ def test_probe_invariant_checker(oracle):
     rows[src, 0] = EMPTY64
     with pytest.raises(AssertionError):
         check_probe_invariant(q, rows.reshape(-1))
+
+
+def test_rows_to_arrow(oracle):
+    """The Arrow export of the host mirror (ArrowResultSetConverter analogue): values and NULLs of
+    every target survive the conversion (fed here with the oracle's rows of a nullable case)."""
+    from heavydb_amd.executor import rows_to_arrow
+    from tests import cases as cases_mod
+    case = next(c for c in cases_mod.build_cases() if c.name == "baseline_nullable_args")
+    q, buf, code = oracle.execute(case.ra.to_plan(), case.frags)
+    assert code == 0
+    ival, dval, nul = oracle.fetch_rows(q, buf)
+    tab = rows_to_arrow(q, ival, dval, nul, names=["key", "sum", "avg", "min", "cnt"])
+    assert tab.num_rows == ival.shape[0] and tab.column_names == ["key", "sum", "avg", "min", "cnt"]
+    for t, name in enumerate(tab.column_names):
+        col = tab.column(name).to_pylist()
+        for r in (0, 1, len(col) // 2, len(col) - 1):
+            want = None if nul[r, t] else (float(dval[r, t]) if q.target_is_fp[t] else int(ival[r, t]))
+            assert col[r] == want
+    assert tab.column("sum").null_count == int(nul[:, 1].sum())
