@@ -26,6 +26,7 @@ ENC_NONE, ENC_FIXED, ENC_DICT, ENC_DATE_IN_DAYS = 0, 1, 2, 3
 EQ, NE, LT, GT, LE, GE = 0, 2, 3, 4, 5, 6
 # mi355q_agg (SQLAgg values)
 AVG, MIN, MAX, SUM, COUNT, PROJECT_KEY = 0, 1, 2, 3, 4, 100
+COUNT_IF, SUM_IF = 10, 11
 # mi355q_join_kind
 JOIN_INNER, JOIN_LEFT = 0, 1
 # mi355q_desc_type
@@ -55,7 +56,7 @@ class Qual(C.Structure):
 
 class Target(C.Structure):
     _fields_ = [("agg", C.c_int32), ("col", C.c_int32), ("table", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("cond", Qual)]
 
 
 class Range(C.Structure):

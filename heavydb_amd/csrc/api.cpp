@@ -186,6 +186,7 @@ int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
   for (int i = 0; i < p.n_targets; ++i) {
     if (p.targets[i].table == 0 && p.targets[i].col >= 0 && p.targets[i].agg != MI355Q_PROJECT_KEY)
       used[p.targets[i].col] = true;
+    if (p.targets[i].agg == MI355Q_COUNT_IF || p.targets[i].agg == MI355Q_SUM_IF) used[p.targets[i].cond.col] = true;
   }
   int64_t per_row = 0;
   for (int c = 0; c < p.n_cols; ++c) {
@@ -482,7 +483,7 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
         } else {
           dval[o] = (q.target_arg_is_fp[t] ? bits_dbl(v) : (double)v) / (double)cnt;
         }
-      } else if (agg == MI355Q_COUNT) {
+      } else if (agg == MI355Q_COUNT || agg == MI355Q_COUNT_IF) {
         ival[o] = v;
       } else if (q.target_is_fp[t]) {
         dval[o] = bits_dbl(v);

@@ -235,6 +235,7 @@ struct DevTarget {
   int32_t agg, col, table, arg_type;  // arg_type: type code of the argument column
   int32_t arg_nullable, skip_null, slot, arg_fp;
   int32_t key_idx, pad_;  // PROJECT_KEY: which group column
+  DevQual cond;           // COUNT_IF / SUM_IF
 };
 struct DevPlan {
   int32_t n_cols, n_quals, n_targets, slot_count;

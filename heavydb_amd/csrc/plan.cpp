@@ -50,6 +50,7 @@ int64_t bucketed_cardinality(const mi355q_range& r) {
 int64_t initial_val(int agg, const ArgInfo& a, bool notnull) {
   switch (agg) {
     case MI355Q_SUM:
+    case MI355Q_SUM_IF:
       if (notnull) return a.fp ? dbl_bits(0.0) : 0;
       return a.fp ? kNullDoubleBits : INT64_MIN;  // NULL of DOUBLE / of the BIGINT sum
     case MI355Q_MIN:
@@ -103,6 +104,14 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
         break;
       case MI355Q_COUNT:
         break;
+      case MI355Q_SUM_IF:
+        if (t.col < 0) return MI355Q_ERR_INVALID_PLAN;
+        [[fallthrough]];
+      case MI355Q_COUNT_IF:
+        if (t.cond.col < 0 || t.cond.col >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
+        if (t.agg == MI355Q_COUNT_IF) r.col = -1;  // the condition is the argument
+        r.cond_nullable = p.cols[t.cond.col].nullable != 0;
+        break;
       case MI355Q_PROJECT_KEY:
         if (!grouped) return MI355Q_ERR_INVALID_PLAN;
         r.key_idx = t.col < 0 ? 0 : t.col;
@@ -126,6 +135,8 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
     }
     const bool is_agg = t.agg != MI355Q_PROJECT_KEY;
     r.skip_null = is_agg && r.col >= 0 && (r.arg_nullable || !grouped);
+    // COUNT_IF's argument is the condition itself (TargetInfo.cpp:60-82)
+    if (t.agg == MI355Q_COUNT_IF) r.skip_null = r.cond_nullable || !grouped;
     r.n_slots = t.agg == MI355Q_AVG ? 2 : 1;
   }
   return MI355Q_OK;
@@ -345,9 +356,11 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
         q->target_null[i] = kNullDoubleBits;
         break;
       case MI355Q_SUM:
+      case MI355Q_SUM_IF:
         q->target_null[i] = t.arg_fp ? kNullDoubleBits : INT64_MIN;
         break;
       case MI355Q_COUNT:
+      case MI355Q_COUNT_IF:
         q->target_null[i] = p.bigint_count ? INT64_MIN : (int64_t)INT32_MIN;
         break;
       default:
@@ -439,6 +452,21 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
     o.arg_type = ts[i].arg_type;
     o.arg_nullable = ts[i].arg_nullable;
     o.arg_fp = ts[i].arg_fp;  // COUNT(double col) still decodes a double
+    if (ts[i].agg == MI355Q_COUNT_IF || ts[i].agg == MI355Q_SUM_IF) {
+      const mi355q_qual& c = p.targets[i].cond;
+      o.cond.col = c.col;
+      o.cond.op = c.op;
+      o.cond.type = col_type_code(p.cols[c.col]);
+      o.cond.nullable = p.cols[c.col].nullable != 0;
+      o.cond.ival = c.ival;
+      o.cond.fval = c.fval;
+      switch (c.op) {
+        case MI355Q_EQ: case MI355Q_NE: case MI355Q_LT: case MI355Q_GT: case MI355Q_LE: case MI355Q_GE:
+          break;
+        default:
+          return MI355Q_ERR_UNSUPPORTED;
+      }
+    }
   }
   for (int g = 0; g < p.n_group_cols; ++g) {
     const mi355q_col_desc& cd = p.cols[p.group_cols[g]];

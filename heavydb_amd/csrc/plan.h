@@ -9,6 +9,7 @@ struct ResolvedTarget {
   int agg = 0, col = -1, table = 0;
   int arg_type = 0;  // type code (dev_common.h)
   int key_idx = 0;   // PROJECT_KEY: index into group_cols
+  bool cond_nullable = false;  // COUNT_IF / SUM_IF: the condition column is nullable
   bool arg_nullable = false, arg_fp = false, skip_null = false;
   int n_slots = 1;
   const mi355q_range* range = nullptr;

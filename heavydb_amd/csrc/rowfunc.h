@@ -470,6 +470,17 @@ MQ_FN void apply_target(const DevTarget& t, int64_t* slots, const int8_t* const*
     return;
   }
   int64_t* s = slots + t.slot;
+  int agg = t.agg;
+  if (agg == MI355Q_COUNT_IF || agg == MI355Q_SUM_IF) {
+    // the condition is TRUE only when it evaluates to 1: a NULL operand is not TRUE
+    // (agg_count_if_skip_val, codegenConditionalAggregateCondValSelector)
+    if (!eval_qual(t.cond, cols[t.cond.col], pos)) return;
+    if (agg == MI355Q_COUNT_IF) {
+      a_count<A>(s);
+      return;
+    }
+    agg = MI355Q_SUM;
+  }
   if (t.col < 0) {
     a_count<A>(s);
     return;
@@ -482,7 +493,7 @@ MQ_FN void apply_target(const DevTarget& t, int64_t* slots, const int8_t* const*
   const int64_t p = t.table ? inner_pos : pos;
   if (t.arg_fp) {
     const double v = decode_dbl(col, p);
-    switch (t.agg) {
+    switch (agg) {
       case MI355Q_COUNT:
         if (!t.skip_null || v != kNullDouble) a_count<A>(s);
         break;
@@ -513,7 +524,7 @@ MQ_FN void apply_target(const DevTarget& t, int64_t* slots, const int8_t* const*
   }
   const int64_t raw = decode_int(col, t.arg_type, p);
   const int64_t null_t = int_null_of(t.arg_type);
-  switch (t.agg) {
+  switch (agg) {
     case MI355Q_COUNT:
       if (!t.skip_null || raw != null_t) a_count<A>(s);
       break;
@@ -523,11 +534,11 @@ MQ_FN void apply_target(const DevTarget& t, int64_t* slots, const int8_t* const*
         if (raw != null_t) {
           // slot starts at NULL_BIGINT for SUM (skip value) and at 0 for AVG.sum
           a_sum_i64_skip<A>(s, raw, INT64_MIN);
-          if (t.agg == MI355Q_AVG) a_count<A>(s + 1);
+          if (agg == MI355Q_AVG) a_count<A>(s + 1);
         }
       } else {
         a_sum_i64<A>(s, raw);
-        if (t.agg == MI355Q_AVG) a_count<A>(s + 1);
+        if (agg == MI355Q_AVG) a_count<A>(s + 1);
       }
       break;
     case MI355Q_MIN:
@@ -551,7 +562,8 @@ MQ_FN void reduce_target(const DevTarget& t, const int64_t* init_vals, int64_t* 
   const int64_t b = that_slots[t.slot];
   const int64_t init = init_vals[t.slot];
   const bool fp = t.arg_fp && t.agg != MI355Q_COUNT;
-  switch (t.agg) {
+  const int agg = t.agg == MI355Q_COUNT_IF ? MI355Q_COUNT : t.agg == MI355Q_SUM_IF ? MI355Q_SUM : t.agg;
+  switch (agg) {
     case MI355Q_COUNT:
       a_sum_i64<A>(a, b);
       break;

@@ -74,6 +74,7 @@ class TargetExpr:
     agg: int
     col: int = -1
     table: int = 0
+    cond: Optional["Qual"] = None   # COUNT_IF / SUM_IF: the condition `col <op> literal`
 
 
 @dataclass
@@ -119,7 +120,12 @@ class RelAlgExecutionUnit:
             raise ValueError("too many targets")
         p.n_targets = len(self.target_exprs)
         for i, t in enumerate(self.target_exprs):
-            p.targets[i] = capi.Target(t.agg, t.col, t.table, 0)
+            ct = capi.Target(t.agg, t.col, t.table, 0)
+            if t.cond is not None:
+                is_fp = self.input_col_descs[t.cond.col].type == DOUBLE
+                ct.cond = capi.Qual(t.cond.col, t.cond.op, 0 if is_fp else int(t.cond.literal),
+                                    float(t.cond.literal) if is_fp else 0.0)
+            p.targets[i] = ct
         jcols = list(self.join_outer_col) if isinstance(self.join_outer_col, (list, tuple)) else [self.join_outer_col]
         if len(jcols) > capi.MAX_GROUP_COLS:
             raise ValueError("too many join key columns")

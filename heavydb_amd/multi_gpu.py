@@ -54,9 +54,9 @@ def _dense_slot_ops(q: capi.QMD) -> Optional[List[Tuple[int, str, bool]]]:
         if q.target_skip_null[t] or agg == capi.PROJECT_KEY:
             return None
         fp = bool(q.target_arg_is_fp[t])
-        if agg == capi.COUNT:
+        if agg in (capi.COUNT, capi.COUNT_IF):
             ops.append((kq + s, "sum", False))
-        elif agg == capi.SUM:
+        elif agg in (capi.SUM, capi.SUM_IF):
             ops.append((kq + s, "sum", fp))
         elif agg == capi.AVG:
             ops.append((kq + s, "sum", fp))

@@ -113,6 +113,12 @@ typedef enum mi355q_agg {
   MI355Q_MAX = 2,
   MI355Q_SUM = 3,
   MI355Q_COUNT = 4,
+  MI355Q_COUNT_IF = 10, /* COUNT_IF(cond): rows whose condition is TRUE (agg_count_if[_skip_val],
+                           RuntimeFunctions.cpp:1356-1375) */
+  MI355Q_SUM_IF = 11,   /* SUM_IF(col, cond): SUM over the rows whose condition is TRUE
+                           (agg_sum_if*, RuntimeFunctions.cpp:1157-1161,1341-1346,1450-1456;
+                           codegenConditionalAggregateCondValSelector: TRUE means == 1, a NULL
+                           condition is not TRUE) */
   MI355Q_PROJECT_KEY = 100
 } mi355q_agg;
 
@@ -153,6 +159,7 @@ typedef struct mi355q_target {
   int32_t table; /* 0 = outer (fact) column; 1 = inner (dim) column reached through
                     the join's row id */
   int32_t reserved;
+  mi355q_qual cond; /* COUNT_IF / SUM_IF: the condition `outer col <op> literal` */
 } mi355q_target;
 
 /* ExpressionRange of a column (what getExpressionRange returns from chunk

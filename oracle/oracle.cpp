@@ -304,6 +304,7 @@ struct TargetDesc {
   int n_slots;
   int key_idx;       // PROJECT_KEY: which group column
   const mi355q_col_desc* cd;  // argument column (nullptr for COUNT(*))
+  const mi355q_qual* cond;    // COUNT_IF / SUM_IF
 };
 
 const mi355q_col_desc& col_desc_of(const mi355q_plan& p, int table, int col) {
@@ -319,6 +320,7 @@ int64_t agg_initial_val(int agg, int arg_type, bool notnull) {
   const bool fp = type_is_fp(arg_type);
   switch (agg) {
     case MI355Q_SUM:
+    case MI355Q_SUM_IF:  // OutputBufferInitialization.cpp:139-176: kSUM and kSUM_IF share the case
       if (!notnull) {
         // SUM(int) has result type BIGINT -> NULL_BIGINT; SUM(double) -> NULL_DOUBLE bits
         return fp ? dbl_bits(kNullDouble) : INT64_MIN;
@@ -326,6 +328,7 @@ int64_t agg_initial_val(int agg, int arg_type, bool notnull) {
       return fp ? dbl_bits(0.0) : 0;
     case MI355Q_AVG:
     case MI355Q_COUNT:
+    case MI355Q_COUNT_IF:
       return 0;
     case MI355Q_MIN:
       if (fp) {
@@ -363,13 +366,26 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
       d.arg_type = logical_type_of(cd);
       d.arg_nullable = cd.nullable != 0 || (d.table && p.join_kind == MI355Q_JOIN_LEFT);
       d.arg_fp = type_is_fp(cd.type);
-    } else if (t.agg != MI355Q_COUNT) {
+    } else if (t.agg != MI355Q_COUNT && t.agg != MI355Q_COUNT_IF) {
       return MI355Q_ERR_INVALID_PLAN;
+    }
+    if (t.agg == MI355Q_COUNT_IF || t.agg == MI355Q_SUM_IF) {
+      if (t.cond.col < 0 || t.cond.col >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
+      d.cond = &t.cond;
+      if (t.agg == MI355Q_COUNT_IF) {  // the condition is the argument
+        d.col = -1;
+        d.cd = nullptr;
+        d.arg_type = 0;
+        d.arg_fp = false;
+        d.arg_nullable = false;
+      }
     }
     // TargetInfo.cpp:64-81: skip_null_val = !arg.notnull ; TargetExprBuilder.cpp:684-690:
     // non-grouped aggregates with an argument force skip_null_val = true.
     d.skip_null = (d.col >= 0 && t.agg != MI355Q_PROJECT_KEY) &&
                   (d.arg_nullable || !is_group_by);
+    // COUNT_IF: skip_null_val follows the nullability of the condition (its argument)
+    if (t.agg == MI355Q_COUNT_IF) d.skip_null = p.cols[t.cond.col].nullable != 0 || !is_group_by;
     d.n_slots = (t.agg == MI355Q_AVG) ? 2 : 1;
     out.push_back(d);
   }
@@ -581,8 +597,10 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
     // null_val_bit_pattern (ResultSetBufferAccessors.h:229-245) of the result type
     switch (t.agg) {
       case MI355Q_AVG: q.target_null[i] = dbl_bits(kNullDouble); break;
-      case MI355Q_SUM: q.target_null[i] = t.arg_fp ? dbl_bits(kNullDouble) : INT64_MIN; break;
-      case MI355Q_COUNT: q.target_null[i] = p.bigint_count ? INT64_MIN : INT32_MIN; break;
+      case MI355Q_SUM:
+      case MI355Q_SUM_IF: q.target_null[i] = t.arg_fp ? dbl_bits(kNullDouble) : INT64_MIN; break;
+      case MI355Q_COUNT:
+      case MI355Q_COUNT_IF: q.target_null[i] = p.bigint_count ? INT64_MIN : INT32_MIN; break;
       default:
         q.target_null[i] = t.arg_fp ? dbl_bits(kNullDouble) : int_null_of(t.arg_type);
     }
@@ -896,13 +914,23 @@ inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q, const int8_t* 
 
 // One target update into its slot(s): the agg_* call TargetExprCodegen::codegenAggregate
 // (TargetExprBuilder.cpp:470-590) would emit for 8-byte slots.
-inline void apply_target(const TargetDesc& t, int64_t* slots, const int8_t* const* cols,
-                         int64_t pos, const int8_t* const* inner_cols, int64_t inner_pos,
-                         const int64_t* key_vals) {
+inline void apply_target(const mi355q_plan& p_, const TargetDesc& t, int64_t* slots,
+                         const int8_t* const* cols, int64_t pos, const int8_t* const* inner_cols,
+                         int64_t inner_pos, const int64_t* key_vals) {
   int64_t* s = slots + t.slot;
   if (t.agg == MI355Q_PROJECT_KEY) {
     if (t.slot >= 0) *s = key_vals[t.key_idx];  // agg_id (RuntimeFunctions.cpp:1171)
     return;
+  }
+  if (t.agg == MI355Q_COUNT_IF || t.agg == MI355Q_SUM_IF) {
+    // agg_count_if[_skip_val] (RuntimeFunctions.cpp:1356-1375): counted when the condition is
+    // neither NULL nor 0; agg_sum_if* (:1157-1161,1341-1346,1450-1456) with the i8 condition of
+    // codegenConditionalAggregateCondValSelector (WindowFunctionIR.cpp:1610-1640): == 1
+    if (!eval_qual(p_, *t.cond, cols, pos)) return;
+    if (t.agg == MI355Q_COUNT_IF) {
+      agg_count(s);
+      return;
+    }
   }
   if (t.col < 0) {  // COUNT(*)
     agg_count(s);
@@ -925,6 +953,7 @@ inline void apply_target(const TargetDesc& t, int64_t* slots, const int8_t* cons
         }
         break;
       case MI355Q_SUM:
+      case MI355Q_SUM_IF:
         if (t.skip_null) agg_sum_double_skip_val(s, v, kNullDouble);
         else agg_sum_double(s, v);
         break;
@@ -959,6 +988,7 @@ inline void apply_target(const TargetDesc& t, int64_t* slots, const int8_t* cons
       }
       break;
     case MI355Q_SUM:
+    case MI355Q_SUM_IF:
     case MI355Q_AVG: {
       if (t.skip_null) {
         // convertNullIfAny: arg NULL -> NULL of the BIGINT sum type
@@ -1079,7 +1109,7 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
     for (int m = 0; m < jm.count; ++m) {
       const int64_t inner_pos = jm.ids ? (int64_t)jm.ids[m] : jm.single;
       for (const auto& t : c.ts) {
-        apply_target(t, slots, cols, pos, c.inner_cols, inner_pos, keys);
+        apply_target(p, t, slots, cols, pos, c.inner_cols, inner_pos, keys);
       }
     }
   }
@@ -1100,12 +1130,14 @@ inline void reduce_one_target(const mi355q_qmd& q, int ti, int64_t* this_slots,
   const bool skip = q.target_skip_null[ti];
   switch (q.target_agg[ti]) {
     case MI355Q_COUNT:
+    case MI355Q_COUNT_IF:  // ResultSetReduction.cpp:1524-1535
       agg_sum(a, *b);  // AGGREGATE_ONE_COUNT
       break;
     case MI355Q_AVG:
       agg_sum(a + 1, b[1]);
       [[fallthrough]];
     case MI355Q_SUM:
+    case MI355Q_SUM_IF:  // :1543-1548
       if (skip) {
         if (fp) agg_sum_double_skip_val(a, bits_dbl(*b), bits_dbl(init));
         else agg_sum_skip_val(a, *b, init);
@@ -1540,6 +1572,7 @@ ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64
           break;
         }
         case MI355Q_COUNT:
+        case MI355Q_COUNT_IF:
           ival[o] = v;
           break;
         default:

@@ -14,7 +14,7 @@ from typing import Callable, List, Optional
 import numpy as np
 
 from heavydb_amd import capi
-from heavydb_amd.capi import (AVG, COUNT, DOUBLE, EQ, GE, GT, INT8, INT16, INT32, INT64, LE, LT,
+from heavydb_amd.capi import (COUNT_IF, SUM_IF, AVG, COUNT, DOUBLE, EQ, GE, GT, INT8, INT16, INT32, INT64, LE, LT,
                               MAX, MIN, NE, PROJECT_KEY, SUM)
 from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
                                   TargetExpr)
@@ -181,6 +181,21 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("baseline_key32_compact",
                       RelAlgExecutionUnit(descs32, [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(AVG, 2)],
                                           groupby_exprs=[0], max_groups_buffer_entry_guess=5000), frags32))
+
+    # ---- conditional aggregates (COUNT_IF / SUM_IF, ExecuteTest.cpp Select.ConditionalAggregate shapes)
+    CI = lambda c, op, lit: TargetExpr(COUNT_IF, cond=Qual(c, op, lit))            # noqa: E731
+    SI = lambda v, c, op, lit: TargetExpr(SUM_IF, v, cond=Qual(c, op, lit))        # noqa: E731
+    cases.append(Case("cond_aggs_nongrouped", ra([TargetExpr(COUNT), CI(0, LT, 2**30), CI(7, GT, 0), CI(9, LE, 0.0),
+                                                  SI(2, 0, GE, 2**30), SI(3, 7, LT, 0), SI(8, 10, EQ, 17),
+                                                  SI(9, 3, GT, 500.0)]), frags))       # nullable cond / value columns
+    cases.append(Case("cond_aggs_perfect_keyed", ra([CI(0, LT, 2**30), TargetExpr(SUM, 2), SI(3, 7, GE, 0)],
+                                                    group=[1]), frags))               # COUNT_IF first -> not keyless
+    cases.append(Case("cond_aggs_perfect_keyless", ra([TargetExpr(COUNT), CI(7, NE, 5), SI(8, 0, LT, 10**9)],
+                                                      [Qual(2, GT, -400000)], group=[10]), frags))
+    cases.append(Case("cond_aggs_baseline", ra([TargetExpr(PROJECT_KEY), CI(6, GT, 0), SI(2, 5, LT, 0),
+                                                SI(9, 9, GT, 0.0), TargetExpr(COUNT)], group=[4], guess=8192), frags))
+    cases.append(Case("cond_aggs_multi_col", ra([TargetExpr(PROJECT_KEY, 1), CI(0, LT, 2**29), SI(3, 0, GE, 2**29)],
+                                                group=[4, 1], guess=3 * n), frags))
 
     # ---- multi-column group by (GroupBy tests with several keys, ExecuteTest.cpp:2587-2873;
     # multi-column perfect hash :11414-11486, baseline :11487-11530)
