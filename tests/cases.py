@@ -194,7 +194,7 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                                                       [Qual(2, GT, -400000)], group=[10]), frags))
     cases.append(Case("cond_aggs_baseline", ra([TargetExpr(PROJECT_KEY), CI(6, GT, 0), SI(2, 5, LT, 0),
                                                 SI(9, 9, GT, 0.0), TargetExpr(COUNT)], group=[4], guess=8192), frags))
-    cases.append(Case("cond_aggs_multi_col", ra([TargetExpr(PROJECT_KEY, 1), CI(0, LT, 2**29), SI(3, 0, GE, 2**29)],
+    cases.append(Case("cond_aggs_multi_col", ra([TargetExpr(PROJECT_KEY, 1), TargetExpr(PROJECT_KEY, 0), CI(0, LT, 2**29), SI(3, 0, GE, 2**29)],
                                                 group=[4, 1], guess=3 * n), frags))
 
     # ---- multi-column group by (GroupBy tests with several keys, ExecuteTest.cpp:2587-2873;

@@ -100,7 +100,12 @@ def compare_rows(q: capi.QMD, want, got, rtol: float = 1e-9):
     assert wi.shape == gi.shape, (wi.shape, gi.shape)
     if q.desc_type == capi.GROUP_BY_BASELINE_HASH and wi.shape[0] > 1:
         def order(i, d):
-            return np.lexsort(tuple(i[:, c] for c in range(i.shape[1])[::-1]))
+            # integer columns first; rows that tie on them (no unique key projected) by the doubles
+            # rounded well above the fp tolerance
+            dr = np.where(np.isfinite(d), np.round(d / np.maximum(np.abs(d), 1e-300) * 1e6) *
+                          10.0 ** np.floor(np.log10(np.maximum(np.abs(d), 1e-300))), 0.0)
+            keys = [dr[:, c] for c in range(d.shape[1])[::-1]] + [i[:, c] for c in range(i.shape[1])[::-1]]
+            return np.lexsort(tuple(keys))
         ow, og = order(wi, wd), order(gi, gd)
         wi, wd, wn = wi[ow], wd[ow], wn[ow]
         gi, gd, gn = gi[og], gd[og], gn[og]
