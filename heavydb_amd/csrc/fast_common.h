@@ -166,7 +166,8 @@ struct SlotProg {
   // starts at 0, OutputBufferInitialization.cpp:132-289)
   int32_t val_nullable;
   int32_t null_init[MI355Q_MAX_SLOTS];
-  int64_t null_bits;                 // bit pattern of the value column's NULL
+  int64_t null_bits;                 // bit pattern of the value column's NULL as loaded
+  int64_t slot_null;                 // the sentinel the null_init slots start at (their init value)
 };
 
 // one row's update of a group's slots in the output table.  fval / ival: the value as double /
@@ -182,12 +183,12 @@ MQ_D void apply_slots_global(const SlotProg& sp, int64_t* slots, double fval, in
     if (is_null) continue;  // every other op reads the value
     if (sp.null_init[j]) {
       switch (sp.op[j]) {
-        case SO_SUM_I: a_sum_i64_skip<true>(s, ival, sp.null_bits); break;
-        case SO_SUM_F: a_sum_f64_skip<true>(s, fval, bits_dbl(sp.null_bits)); break;
-        case SO_MIN_I: a_min_i64_skip<true>(s, ival, sp.null_bits); break;
-        case SO_MAX_I: a_max_i64_skip<true>(s, ival, sp.null_bits); break;
-        case SO_MIN_F: a_minmax_f64<true, false, true>(s, fval, bits_dbl(sp.null_bits)); break;
-        case SO_MAX_F: a_minmax_f64<true, true, true>(s, fval, bits_dbl(sp.null_bits)); break;
+        case SO_SUM_I: a_sum_i64_skip<true>(s, ival, sp.slot_null); break;
+        case SO_SUM_F: a_sum_f64_skip<true>(s, fval, bits_dbl(sp.slot_null)); break;
+        case SO_MIN_I: a_min_i64_skip<true>(s, ival, sp.slot_null); break;
+        case SO_MAX_I: a_max_i64_skip<true>(s, ival, sp.slot_null); break;
+        case SO_MIN_F: a_minmax_f64<true, false, true>(s, fval, bits_dbl(sp.slot_null)); break;
+        case SO_MAX_F: a_minmax_f64<true, true, true>(s, fval, bits_dbl(sp.slot_null)); break;
         default: break;
       }
       continue;
@@ -271,6 +272,15 @@ struct FastShape {
   SlotProg sp;
 };
 
+// Value columns the fast families load natively: plain int64 / double / int32 chunks, and
+// kENCODING_FIXED(32) columns — the decoder of those is the same sign-extending 4-byte load, and
+// their NULL (the storage sentinel) is recognised before widening.
+inline int fast_value_type(int code) {
+  if (code == MI355Q_INT64 || code == MI355Q_DOUBLE || code == MI355Q_INT32) return code;
+  if (tc_enc(code) == MI355Q_ENC_FIXED && tc_storage(code) == MI355Q_INT32) return MI355Q_INT32;
+  return 0;
+}
+
 inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* s) {
   if (p.join_col >= 0 || p.n_quals > 1 || p.n_group > 1) return false;
   // a NULL group key: the baseline layout keeps the sentinel as an ordinary key; the perfect
@@ -285,6 +295,7 @@ inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* 
   s->sp.n = p.slot_count;
   s->sp.val_nullable = 0;
   s->sp.null_bits = 0;
+  s->sp.slot_null = 0;
   for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) {
     s->sp.op[i] = SO_COUNT;
     s->sp.null_init[i] = 0;
@@ -301,14 +312,17 @@ inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* 
       continue;
     }
     if (t.col < 0) return false;
-    // every value aggregate (and COUNT(nullable col)) reads ONE int64 / double column
-    if (t.arg_type != MI355Q_INT64 && t.arg_type != MI355Q_DOUBLE) return false;
+    // every value aggregate (and COUNT(nullable col)) reads ONE int64 / int32 / double column
+    const int vt = fast_value_type(t.arg_type);
+    if (!vt) return false;
     if (s->vcol >= 0 && s->vcol != t.col) return false;
     s->vcol = t.col;
-    s->vtype = t.arg_type;
+    s->vtype = vt;
     if (t.skip_null) {
       s->sp.val_nullable = 1;
-      s->sp.null_bits = t.arg_type == MI355Q_DOUBLE ? kNullDoubleBits : INT64_MIN;
+      // the sentinel as the kernel loads it: the STORAGE type's (an int32 chunk is widened by
+      // sign extension, so NULL_INT arrives as (int64)INT32_MIN)
+      s->sp.null_bits = vt == MI355Q_DOUBLE ? kNullDoubleBits : vt == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN;
     }
     const bool fp = t.arg_fp;
     switch (t.agg) {
@@ -331,6 +345,19 @@ inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* 
         break;
       default: return false;
     }
+  }
+  // the slots that start at a NULL sentinel must share it (SUM(int) starts at NULL_BIGINT, MIN /
+  // MAX at the argument type's NULL: equal for int64 / double / FIXED-encoded BIGINT columns,
+  // different for a plain nullable INT column aggregated both ways — left to the row kernel)
+  {
+    bool have = false;
+    for (int j = 0; j < p.slot_count; ++j) {
+      if (!s->sp.null_init[j]) continue;
+      if (have && p.init_vals[j] != s->sp.slot_null) return false;
+      s->sp.slot_null = p.init_vals[j];
+      have = true;
+    }
+    if (!have) s->sp.slot_null = s->sp.null_bits;
   }
   // one column cannot be nullable for one target and NOT NULL for another
   if (s->sp.val_nullable) {

@@ -321,9 +321,17 @@ hipError_t launch_scan_count(const DevPlan& p, const FragView& fv, int64_t* out,
 }
 
 // ------------------------------------------------------------------------ perfect_lds
+static int perfect_key_storage(const DevPlan& p) {
+  if (p.group_type == MI355Q_INT32 || p.group_type == MI355Q_INT64) return p.group_type;
+  if (tc_enc(p.group_type) == MI355Q_ENC_FIXED && tc_storage(p.group_type) == MI355Q_INT32 && !p.group_nullable)
+    return MI355Q_INT32;
+  return 0;
+}
+
 bool perfect_lds_eligible(const DevPlan& p, const FragView& fv) {
   if (p.desc_type != MI355Q_GROUP_BY_PERFECT_HASH) return false;
-  if (p.group_type != MI355Q_INT32 && p.group_type != MI355Q_INT64) return false;
+  // plain INT / BIGINT keys, or a NOT NULL kENCODING_FIXED(32) key (the same 4-byte load)
+  if (perfect_key_storage(p) == 0) return false;
   if (p.entry_count * p.row_quad * 8 > kPerfectLdsMaxBytes) return false;
   FastShape s;
   return grouped_fast_shape(p, fv, &s) && !s.sp.val_nullable;
@@ -338,6 +346,9 @@ static hipError_t launch_perfect_lds_v(const FastShape& fs, const PerfectArgs& a
                        fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
   } else if (fs.vtype == MI355Q_INT64) {
     hipLaunchKernelGGL((k_perfect_lds<FT, KT, int64_t>), dim3(grid), dim3(kBlock), lds, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
+  } else if (fs.vtype == MI355Q_INT32) {
+    hipLaunchKernelGGL((k_perfect_lds<FT, KT, int32_t>), dim3(grid), dim3(kBlock), lds, s, fv.d_cols,
                        fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
   } else {
     hipLaunchKernelGGL((k_perfect_lds<FT, KT, double>), dim3(grid), dim3(kBlock), lds, s, fv.d_cols,
@@ -368,7 +379,7 @@ hipError_t launch_perfect_lds(const DevPlan& p, const FragView& fv, int64_t* out
   st->n_launches = 1;
   rec(st->k_start, s);
   hipError_t e;
-  const bool k32 = p.group_type == MI355Q_INT32;
+  const bool k32 = perfect_key_storage(p) == MI355Q_INT32;
   if (fs.fil_type == 0) {
     e = k32 ? launch_perfect_lds_v<none_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s)
             : launch_perfect_lds_v<none_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s);
@@ -417,6 +428,9 @@ static hipError_t launch_baseline_direct_v(const FastShape& fs, const BaselineAr
                        fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
   } else if (fs.vtype == MI355Q_INT64) {
     hipLaunchKernelGGL((k_baseline_direct<FT, int64_t>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+                       fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
+  } else if (fs.vtype == MI355Q_INT32) {
+    hipLaunchKernelGGL((k_baseline_direct<FT, int32_t>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
                        fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
   } else {
     hipLaunchKernelGGL((k_baseline_direct<FT, double>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols,

@@ -182,6 +182,13 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       RelAlgExecutionUnit(descs32, [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(AVG, 2)],
                                           groupby_exprs=[0], max_groups_buffer_entry_guess=5000), frags32))
 
+    # ---- 4-byte value columns (plain INT / nullable INT) through the perfect and baseline layouts
+    cases.append(Case("perfect_int32_values", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 0), TargetExpr(MAX, 0),
+                                                  TargetExpr(AVG, 0)], group=[1]), frags))
+    cases.append(Case("baseline_int32_nullable_values", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 7), TargetExpr(COUNT, 7),
+                                                            TargetExpr(MIN, 7), TargetExpr(AVG, 7)], group=[4], guess=8192),
+                      frags))
+
     # ---- conditional aggregates (COUNT_IF / SUM_IF, ExecuteTest.cpp Select.ConditionalAggregate shapes)
     CI = lambda c, op, lit: TargetExpr(COUNT_IF, cond=Qual(c, op, lit))            # noqa: E731
     SI = lambda v, c, op, lit: TargetExpr(SUM_IF, v, cond=Qual(c, op, lit))        # noqa: E731
@@ -303,6 +310,17 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("enc_group_fixed32_baseline", era([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 0)],
                                                         group=[1], guess=4000), fe))
     cases.append(Case("enc_group_fixed16_nullable_key", era([TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], group=[0]), fe))
+
+    # kENCODING_FIXED(32) BIGINT key and value, NOT NULL: the plan-time choice is the LDS perfect-hash
+    # kernel reading both as 4-byte chunks
+    k32 = rng.integers(0, 500, n).astype(np.int32)
+    v32 = rng.integers(-10**6, 10**6, n).astype(np.int32)
+    fx_descs = [InputColDescriptor(INT32, False, col_range([k32], INT32, False), capi.ENC_FIXED, INT64),
+                InputColDescriptor(INT32, False, col_range([v32], INT32, False), capi.ENC_FIXED, INT64)]
+    fx_frags = [[a, b] for a, b in zip(split(k32, fs), split(v32, fs))]
+    cases.append(Case("enc_fixed32_key_and_value_perfect",
+                      RelAlgExecutionUnit(fx_descs, [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(COUNT),
+                                                     TargetExpr(MIN, 1), TargetExpr(AVG, 1)], groupby_exprs=[0]), fx_frags))
 
     # ---- empty and tiny inputs
     empty = [[np.zeros(0, NP[t]) for t, _, _ in spec]]

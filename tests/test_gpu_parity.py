@@ -225,7 +225,9 @@ def _baseline_table(rng, n, n_keys, skew=0.0):
 
 @pytest.mark.parametrize("variant", [1, 2], ids=["direct", "partitioned"])
 @pytest.mark.parametrize("shape", ["count_avg_f64_filtered", "sum_min_max_i64", "count_only", "skewed",
-                                   "nullable_avg_count_f64", "nullable_sum_min_max_i64", "nullable_key_and_sum"])
+                                   "nullable_avg_count_f64", "nullable_sum_min_max_i64", "nullable_key_and_sum",
+                                   "int32_sum_avg_min_max", "int32_nullable", "int32_nullable_minmax",
+                                   "fixed32_bigint_nullable"])
 def test_baseline_family_members(torch_cuda, oracle, variant, shape):
     from heavydb_amd.executor import (Executor, FetchResult, Qual, RelAlgExecutionUnit, TargetExpr)
     torch = torch_cuda
@@ -248,7 +250,29 @@ def test_baseline_family_members(torch_cuda, oracle, variant, shape):
             cols[0] = cols[0].copy()
             cols[0][rng.random(n) < 0.01] = -2**63  # NULL group key: a group of its own
             descs[0] = InputColDescriptor(capi.INT64, True, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7, True))
-    if shape == "nullable_avg_count_f64":
+    if shape in ("int32_sum_avg_min_max", "int32_nullable", "int32_nullable_minmax", "fixed32_bigint_nullable"):
+        # 4-byte value chunks: plain INT, nullable INT, and a BIGINT column stored with
+        # kENCODING_FIXED(32) (its NULL is the storage sentinel, widened to NULL_BIGINT)
+        from heavydb_amd.executor import ExpressionRange, InputColDescriptor
+        v32 = rng.integers(-10**6, 10**6, n).astype(np.int32)
+        nullable = shape != "int32_sum_avg_min_max"
+        if nullable:
+            ids = (cols[0] - 7) // 1000003
+            v32[(rng.random(n) < 0.3) | (ids < 2000)] = np.int32(-2**31)
+        cols[2] = v32
+        descs[2] = InputColDescriptor(capi.INT32, nullable, ExpressionRange(True, -10**6, 10**6, nullable),
+                                      capi.ENC_FIXED if shape == "fixed32_bigint_nullable" else 0,
+                                      capi.INT64 if shape == "fixed32_bigint_nullable" else 0)
+        targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 2), TargetExpr(capi.AVG, 2), TargetExpr(capi.MIN, 2),
+                   TargetExpr(capi.MAX, 2), TargetExpr(capi.COUNT, 2), TargetExpr(capi.COUNT)]
+        # a plain nullable INT column starts SUM at NULL_BIGINT but MIN / MAX at NULL_INT: the fast
+        # families take one sentinel per step, so the two kinds are exercised separately
+        if shape == "int32_nullable":
+            targets = [t for t in targets if t.agg not in (capi.MIN, capi.MAX)]
+        if shape == "int32_nullable_minmax":
+            targets = [t for t in targets if t.agg not in (capi.SUM,)]
+        quals = [Qual(3, capi.LT, 2**30)]
+    elif shape == "nullable_avg_count_f64":
         targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.COUNT, 1), TargetExpr(capi.AVG, 1)]
         quals = [Qual(3, capi.LT, 2**30)]
     elif shape == "nullable_sum_min_max_i64":
