@@ -89,6 +89,7 @@ class Plan(C.Structure):
         ("max_groups_buffer_entry_guess", C.c_int64),
         ("bigint_count", C.c_int32),
         ("reserved", C.c_int32),
+        ("num_tuples", C.c_int64),
     ]
 
 
@@ -111,6 +112,8 @@ class QMD(C.Structure):
         ("group_has_nulls", C.c_int32 * MAX_GROUP_COLS),
         ("has_nulls", C.c_int32),
         ("row_size", C.c_int32),
+        ("slot_width", C.c_int32),
+        ("pad_", C.c_int32),
         ("key_bytes", C.c_int32),
         ("n_targets", C.c_int32),
         ("target_slot", C.c_int32 * MAX_TARGETS),

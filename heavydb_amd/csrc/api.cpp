@@ -109,6 +109,8 @@ struct DeviceCtx {
   std::recursive_mutex mu;  // the packed multi-column path re-enters mi355q_execute
   void* aux = nullptr;      // packed key column + temporary tables of that path
   int64_t aux_bytes = 0;
+  void* wide = nullptr;     // 8-byte-slot table of a step whose result layout has 4-byte slots
+  int64_t wide_bytes = 0;
   void* scratch = nullptr;
   int64_t scratch_bytes = 0;
   void* meta = nullptr;
@@ -269,6 +271,9 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   if (ctx.aux) (void)hipFree(ctx.aux);
   ctx.aux = nullptr;
   ctx.aux_bytes = 0;
+  if (ctx.wide) (void)hipFree(ctx.wide);
+  ctx.wide = nullptr;
+  ctx.wide_bytes = 0;
   if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
   ctx.stream = nullptr;
   for (hipEvent_t e : ctx.events) (void)hipEventDestroy(e);
@@ -452,7 +457,9 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
     const int64_t* row = host.data() + e * rq;
     bool empty = false;
     if (q.desc_type != MI355Q_NON_GROUPED_AGGREGATE) {
-      if (q.keyless) {
+      if (q.keyless && q.slot_width == 4) {
+        empty = ((const int32_t*)row)[q.idx_target_as_key] == (int32_t)q.init_vals[q.idx_target_as_key];
+      } else if (q.keyless) {
         empty = row[q.idx_target_as_key] == q.init_vals[q.idx_target_as_key];
       } else if (q.key_width == 4) {
         empty = *(const int32_t*)row == kEmptyKey32;
@@ -474,7 +481,8 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
         is_null[o] = ival[o] == q.target_null[t];
         continue;
       }
-      const int64_t v = row[kq + s];
+      // compact layouts hold 32-bit slots (read_int_from_buff with the slot's width)
+      const int64_t v = q.slot_width == 4 ? (int64_t)((const int32_t*)(row + kq))[s] : row[kq + s];
       if (agg == MI355Q_AVG) {
         const int64_t cnt = row[kq + s + 1];
         if (cnt == 0) {  // pair_to_double: count 0 -> NULL_DOUBLE
@@ -775,6 +783,58 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   DeviceGuard g(in->device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
   const int n_cus = cu_count_of(in->device_id);
+
+  if (q.slot_width == 4) {
+    // Compact layout (4-byte slots): the step runs on the 8-byte layout of the same plan — same
+    // entry count, same key bytes, same hash — and the finished table is narrowed row by row.
+    int64_t rows = 0;
+    for (int f = 0; f < in->n_frags; ++f) rows += in->num_rows[f];
+    if (rows > (int64_t)UINT32_MAX) return MI355Q_ERR_INVALID_PLAN;  // a 32-bit COUNT would wrap
+    mi355q_plan p8 = *plan;
+    p8.bigint_count = 1;  // pick_target_compact_width: g_bigint_count -> 8-byte slots
+    mi355q_qmd q8;
+    if (int32_t e = qmd_init(p8, &q8)) return e;
+    if (q8.slot_width != 8 || q8.entry_count != q.entry_count || q8.key_bytes != q.key_bytes ||
+        q8.slot_count != q.slot_count)
+      return MI355Q_ERR_UNSUPPORTED;
+    DeviceCtx& ctx = ctx_of(in->device_id);
+    std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+    const int64_t need = q8.entry_count * (int64_t)q8.row_size;
+    if (ctx.wide_bytes < need) {
+      if (ctx.wide) (void)hipFree(ctx.wide);
+      ctx.wide = nullptr;
+      ctx.wide_bytes = 0;
+      hipError_t he = hipMalloc(&ctx.wide, (size_t)need);
+      if (he != hipSuccess) {
+        last_hip_error = he;
+        return MI355Q_ERR_OUT_OF_GPU_MEM;
+      }
+      ctx.wide_bytes = need;
+    }
+    hipStream_t s4 = (hipStream_t)o.stream;
+    if (!s4) {
+      if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+      s4 = ctx.stream;
+    }
+    mi355q_exec_options o8 = o;
+    o8.stream = s4;
+    o8.out_buffer = ctx.wide;
+    mi355q_result* r8 = nullptr;
+    if (int32_t e = mi355q_execute(&p8, in, &o8, &r8, report)) return e;
+    mi355q_result_free(r8);
+    mi355q_result* res4 = nullptr;
+    if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res4)) return e;
+    hipError_t he = launch_narrow_slots((const int64_t*)ctx.wide, q8.row_size / 8, q.key_bytes / 8, q.slot_count,
+                                        q.row_size / 8, q.entry_count, res4->buf, s4);
+    if (he == hipSuccess) he = hipStreamSynchronize(s4);
+    if (he != hipSuccess) {
+      last_hip_error = he;
+      mi355q_result_free(res4);
+      return MI355Q_ERR_HIP;
+    }
+    *out = res4;
+    return MI355Q_OK;
+  }
 
   if (!o.force_generic && in->n_frags > 0) {
     const int32_t e = execute_packed_multi(plan, in, o, q, d, n_cus, out, report);

@@ -245,7 +245,7 @@ struct DevPlan {
   int32_t key_quad, group_col, group_type, group_nullable;  // first (or only) group column
   int64_t entry_count, min_val, max_val;
   // all group columns (n_group == 1 repeats the fields above)
-  int32_t n_group, group_pad_;
+  int32_t n_group, slot_width;  // slot_width: 8, or 4 for the compact COUNT(*)-only layouts
   int32_t group_cols[MI355Q_MAX_GROUP_COLS], group_types[MI355Q_MAX_GROUP_COLS];
   int32_t group_translate[MI355Q_MAX_GROUP_COLS];  // perfect hash: NULL key -> group_null_key
   int64_t group_min[MI355Q_MAX_GROUP_COLS], group_card[MI355Q_MAX_GROUP_COLS];

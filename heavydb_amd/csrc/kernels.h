@@ -82,6 +82,10 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,
                               int tmp_quad, int64_t* out, int32_t* d_err, hipStream_t s);
 
+// compact COUNT(*)-only layouts: the finished 8-byte-slot table -> its 4-byte-slot image
+hipError_t launch_narrow_slots(const int64_t* wide, int wide_quad, int key_quad, int slot_count,
+                               int narrow_quad, int64_t entries, int64_t* out, hipStream_t s);
+
 // inner key columns of a join table build
 struct JoinKeyCols {
   const int8_t* col[MI355Q_MAX_GROUP_COLS];

@@ -502,6 +502,16 @@ __global__ __launch_bounds__(kBlock) void k_scan_write_offsets(const int32_t* __
   }
 }
 
+// ---- 8-byte -> 4-byte slots (compact COUNT(*)-only layouts) --------------------------------
+__global__ __launch_bounds__(kBlock) void k_narrow_slots(const int64_t* __restrict__ wide, int wide_quad,
+                                                          int key_quad, int slot_count, int narrow_quad,
+                                                          int64_t entries, int64_t* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < entries; e += stride) {
+    narrow_row(wide + e * wide_quad, key_quad, slot_count, narrow_quad, out + e * narrow_quad);
+  }
+}
+
 // ---- packed multi-column keys --------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_pack_keys(PackSpec ps, const int8_t* const* __restrict__ cols,
                                                        const int64_t* __restrict__ num_rows, int n_frags,
@@ -783,6 +793,14 @@ hipError_t launch_join_one_to_many(const JoinKeyCols& kc, int64_t n, int hash_ty
     hipLaunchKernelGGL(k_join_fill_ids, dim3(grid_for(n)), dim3(kBlock), 0, s, kc, n, hash_type, tab, entries,
                        min_key, max_key, offsets, counts, payloads);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_narrow_slots(const int64_t* wide, int wide_quad, int key_quad, int slot_count,
+                               int narrow_quad, int64_t entries, int64_t* out, hipStream_t s) {
+  if (entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_narrow_slots, dim3(grid_for(entries)), dim3(kBlock), 0, s, wide, wide_quad, key_quad,
+                     slot_count, narrow_quad, entries, out);
   return hipGetLastError();
 }
 

@@ -47,6 +47,10 @@ MQ_D uint64_t order_key_of(const DevPlan& p, const DevTarget& t, const int64_t* 
     const int64_t v = row_key_component(row, p.key_width, t.key_idx);
     is_null = v == null_pattern;
     u = (uint64_t)v ^ 0x8000000000000000ull;
+  } else if (p.slot_width == 4) {  // compact layouts: COUNT(*) or a projected key, 32-bit
+    const int64_t v = ((const int32_t*)(row + p.key_quad))[t.slot];
+    is_null = t.agg == MI355Q_PROJECT_KEY && v == null_pattern;
+    u = (uint64_t)v ^ 0x8000000000000000ull;
   } else {
     const int64_t* s = row + p.key_quad + t.slot;
     if (t.agg == MI355Q_AVG) {

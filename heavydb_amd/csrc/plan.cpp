@@ -369,7 +369,18 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   }
   q->slot_count = slot;
   q->key_bytes = (grouped && !q->keyless) ? ((q->group_col_count * q->key_width + 7) & ~7) : 0;
-  q->row_size = q->key_bytes + 8 * q->slot_count;
+  // pick_target_compact_width (QueryMemoryDescriptor.cpp:748-840): one group column, only
+  // COUNT(*) and projections of keys of at most 4 bytes, <= UINT32_MAX input rows -> 4-byte slots
+  bool compact = !p.bigint_count && p.n_group_cols == 1 &&
+                 (uint64_t)(p.num_tuples < 0 ? 0 : p.num_tuples) <= (uint64_t)UINT32_MAX;
+  for (int i = 0; i < p.n_targets && compact; ++i) {
+    const ResolvedTarget& t = ts[i];
+    if (t.agg == MI355Q_COUNT && t.col < 0) continue;
+    if (t.agg == MI355Q_PROJECT_KEY && plain_width(tc_logical(t.arg_type)) <= 4) continue;
+    compact = false;
+  }
+  q->slot_width = compact ? 4 : 8;
+  q->row_size = q->key_bytes + ((q->slot_width * q->slot_count + 7) & ~7);
   if (q->row_size <= 0) return MI355Q_ERR_INVALID_PLAN;
   return MI355Q_OK;
 }
@@ -383,6 +394,12 @@ void row_init_image(const mi355q_qmd& q, int64_t* quad) {
   if (q.key_width == 4) {
     int32_t* k32 = (int32_t*)quad;
     for (int i = 0; i < 2 * kq; ++i) k32[i] = i < q.group_col_count ? kEmptyKey32 : 0;
+  }
+  if (q.slot_width == 4) {
+    int32_t* s32 = (int32_t*)(quad + kq);
+    const int n32 = (q.row_size - q.key_bytes) / 4;
+    for (int s = 0; s < n32; ++s) s32[s] = s < q.slot_count ? (int32_t)q.init_vals[s] : 0;
+    return;
   }
   for (int s = 0; s < q.slot_count; ++s) quad[kq + s] = q.init_vals[s];
 }
@@ -407,6 +424,7 @@ void layout_from_qmd(const mi355q_qmd& q, DevPlan* d) {
   d->min_val = q.min_val;
   d->max_val = q.max_val;
   d->n_group = q.group_col_count;
+  d->slot_width = q.slot_width ? q.slot_width : 8;
   int64_t mul = 1;
   for (int g = 0; g < q.group_col_count && g < MI355Q_MAX_GROUP_COLS; ++g) {
     d->group_min[g] = q.group_min[g];

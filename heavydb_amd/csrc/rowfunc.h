@@ -608,9 +608,43 @@ MQ_FN void reduce_target(const DevTarget& t, const int64_t* init_vals, int64_t* 
 // isEmptyEntry (ResultSetIteration.cpp:2457-2492)
 MQ_FN bool is_empty_row(const DevPlan& p, const int64_t* row, int idx_target_as_key) {
   if (p.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return false;
+  if (p.keyless && p.slot_width == 4)
+    return ((const int32_t*)row)[idx_target_as_key] == (int32_t)p.init_vals[idx_target_as_key];
   if (p.keyless) return row[idx_target_as_key] == p.init_vals[idx_target_as_key];
   if (p.key_width == 4) return *(const int32_t*)row == kEmptyKey32;
   return row[0] == kEmptyKey64;
+}
+
+// ---------------------------------------------------------------- 4-byte slots
+// The compact layouts (slot_width 4) only ever hold COUNT(*) and projections of keys of at most
+// 4 bytes (pick_target_compact_width).  The step itself runs on the 8-byte layout of the same
+// plan; narrow_row turns a finished row into its compact image (same entry, same key bytes).
+MQ_FN void narrow_row(const int64_t* wide, int key_quad, int slot_count, int narrow_row_quad, int64_t* dst) {
+  for (int k = 0; k < key_quad; ++k) dst[k] = wide[k];
+  int32_t* s32 = (int32_t*)(dst + key_quad);
+  const int n32 = (narrow_row_quad - key_quad) * 2;
+  for (int s = 0; s < n32; ++s) s32[s] = s < slot_count ? (int32_t)wide[key_quad + s] : 0;
+}
+// this (op)= that for one target of a compact row: agg_sum on the 32-bit COUNT
+// (AGGREGATE_ONE_COUNT with chosen_bytes 4), projections copied when set
+template <bool A>
+MQ_FN void reduce_target_compact(const DevTarget& t, const int64_t* init_vals, int32_t* this_slots,
+                                 const int32_t* that_slots) {
+  if (t.slot < 0) return;
+  const int32_t b = that_slots[t.slot];
+  if (t.agg == MI355Q_PROJECT_KEY) {
+    if (b != (int32_t)init_vals[t.slot]) {
+      if (A) MQ_STORE32(this_slots + t.slot, b);
+      else this_slots[t.slot] = b;
+    }
+    return;
+  }
+#if defined(MQ_EMU)
+  this_slots[t.slot] = (int32_t)((uint32_t)this_slots[t.slot] + (uint32_t)b);
+#else
+  if (A) atomicAdd((unsigned int*)(this_slots + t.slot), (unsigned int)b);
+  else this_slots[t.slot] = (int32_t)((uint32_t)this_slots[t.slot] + (uint32_t)b);
+#endif
 }
 
 // ---------------------------------------------------------------- reduce one entry
@@ -644,6 +678,12 @@ MQ_FN int32_t reduce_entry(const DevPlan& p, int idx_target_as_key, int64_t* thi
     slots = row + p.key_quad;
   }
   const int64_t* that_slots = src + p.key_quad;
+  if (p.slot_width == 4) {
+    for (int i = 0; i < p.n_targets; ++i) {
+      reduce_target_compact<A>(p.targets[i], p.init_vals, (int32_t*)slots, (const int32_t*)that_slots);
+    }
+    return 0;
+  }
   for (int i = 0; i < p.n_targets; ++i) {
     reduce_target<A>(p.targets[i], p.init_vals, slots, that_slots);
   }

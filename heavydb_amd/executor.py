@@ -90,6 +90,8 @@ class RelAlgExecutionUnit:
     # ExecutionOptions / globals shaping the layout
     max_groups_buffer_entry_guess: int = 16384  # Execute.cpp:111
     bigint_count: bool = False
+    num_tuples: int = 0   # rows of the input tables (0 = unknown / small): COUNT(*)-only group-bys
+                          # get 4-byte slots while this is <= UINT32_MAX (pick_target_compact_width)
 
     def to_plan(self) -> capi.Plan:
         p = capi.Plan()
@@ -137,6 +139,7 @@ class RelAlgExecutionUnit:
         p.join_table = self.join_table.handle if self.join_table is not None else None
         p.max_groups_buffer_entry_guess = self.max_groups_buffer_entry_guess
         p.bigint_count = int(self.bigint_count)
+        p.num_tuples = int(self.num_tuples)
         return p
 
 

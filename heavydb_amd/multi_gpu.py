@@ -42,6 +42,8 @@ class ShardOps(Protocol):
 def _dense_slot_ops(q: capi.QMD) -> Optional[List[Tuple[int, str, bool]]]:
     """[(quad column, 'sum'|'min'|'max', is_fp)] when every quad of the row can be merged by
     a plain all_reduce; None when NULL-aware or projected slots need the reduce kernel."""
+    if q.slot_width != 8:  # 4-byte slots: two per quad -> the reduce kernel
+        return None
     kq = q.key_bytes // 8
     ops: List[Tuple[int, str, bool]] = []
     if kq:

@@ -215,13 +215,21 @@ typedef struct mi355q_plan {
                                             g_default_max_groups_buffer_entry_guess
                                             = 16384, or 2 x NDV estimate,
                                             RelAlgExecutor.cpp:4213-4218) */
-  int32_t bigint_count;                  /* g_bigint_count (affects COUNT result type
-                                            only; slots are 8 bytes either way) */
+  int32_t bigint_count;                  /* g_bigint_count: COUNT is BIGINT and slots are always
+                                            8 bytes wide */
   int32_t reserved;
+  int64_t num_tuples;                    /* rows of the input tables (query_infos getNumTuples);
+                                            0 = unknown / small.  A single-column GROUP BY whose
+                                            targets are only COUNT(*) and projections of a key of
+                                            at most 4 bytes gets 4-BYTE slots while this stays
+                                            <= UINT32_MAX and bigint_count is off
+                                            (pick_target_compact_width,
+                                            QueryMemoryDescriptor.cpp:748-840) */
 } mi355q_plan;
 
-/* QueryMemoryDescriptor mirror (Descriptors/QueryMemoryDescriptor.h).  Row-wise
- * layout, 8-byte padded slots (crt_min_byte_width = 8, Execute.cpp:2237). */
+/* QueryMemoryDescriptor mirror (Descriptors/QueryMemoryDescriptor.h).  Row-wise layout; slots
+ * are 8 bytes wide (crt_min_byte_width = 8, Execute.cpp:2237) except for the COUNT(*)-only
+ * shapes that pick_target_compact_width narrows to 4 (slot_width). */
 typedef struct mi355q_qmd {
   int32_t desc_type; /* mi355q_desc_type */
   int32_t keyless;   /* keyless_hash_ */
@@ -246,7 +254,10 @@ typedef struct mi355q_qmd {
   int64_t group_bucket[MI355Q_MAX_GROUP_COLS];
   int32_t group_has_nulls[MI355Q_MAX_GROUP_COLS];
   int32_t has_nulls;
-  int32_t row_size;      /* bytes, getRowSize() (QueryMemoryDescriptor.cpp:848) */
+  int32_t row_size;      /* bytes, getRowSize() (QueryMemoryDescriptor.cpp:848):
+                            align8(key bytes) + align8(slot_count * slot_width) */
+  int32_t slot_width;    /* 8, or 4 (ColSlotContext::setAllSlotsPaddedSize(min_slot_size)) */
+  int32_t pad_;
   int32_t key_bytes;     /* align_to_int64(group_col_count * key_width), 0 if keyless */
   int32_t n_targets;
   int32_t target_slot[MI355Q_MAX_TARGETS];      /* first slot of each target; -1 if the

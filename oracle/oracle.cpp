@@ -606,12 +606,25 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
     }
   }
   q.slot_count = slot;
-  // getRowSize (QueryMemoryDescriptor.cpp:848-860)
+  // pick_target_compact_width (QueryMemoryDescriptor.cpp:748-840) -> setAllSlotsPaddedSize (:265):
+  // 8 unless !g_bigint_count, exactly one group-by expression, every target either COUNT(*) or a
+  // non-aggregate integer of at most 4 bytes (here: the projected key), and the input tables hold
+  // at most UINT32_MAX tuples — then 4
+  bool compact = !p.bigint_count && p.n_group_cols == 1 &&
+                 (uint64_t)std::max<int64_t>(p.num_tuples, 0) <= (uint64_t)UINT32_MAX;
+  for (const auto& t : ts) {
+    if (t.agg == MI355Q_COUNT && t.col < 0) continue;
+    if (t.agg == MI355Q_PROJECT_KEY && type_width(t.arg_type) <= 4) continue;
+    compact = false;
+  }
+  q.slot_width = compact ? 4 : 8;
+  // getRowSize (QueryMemoryDescriptor.cpp:848-860); slots packed back to back
+  // (ColSlotContext::getAlignedPaddedSizeForRange, ColSlotContext.cpp:152-166)
   q.key_bytes = 0;
   if (is_group_by && !q.keyless) {
     q.key_bytes = (q.group_col_count * q.key_width + 7) & ~7;
   }
-  q.row_size = q.key_bytes + 8 * q.slot_count;
+  q.row_size = q.key_bytes + ((q.slot_width * q.slot_count + 7) & ~7);
   if (q.row_size == 0) return MI355Q_ERR_INVALID_PLAN;
   return 0;
 }
@@ -631,7 +644,12 @@ void init_buffer(const mi355q_qmd& q, int64_t* buf) {
         for (int i = 0; i < kq; ++i) row[i] = kEmptyKey64;
       }
     }
-    for (int s = 0; s < q.slot_count; ++s) row[kq + s] = q.init_vals[s];
+    if (q.slot_width == 4) {
+      int32_t* s32 = reinterpret_cast<int32_t*>(row + kq);
+      for (int s = 0; s < (rq - kq) * 2; ++s) s32[s] = s < q.slot_count ? (int32_t)q.init_vals[s] : 0;
+    } else {
+      for (int s = 0; s < q.slot_count; ++s) row[kq + s] = q.init_vals[s];
+    }
   }
 }
 
@@ -1105,6 +1123,20 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
       }
       (void)kq;
     }
+    if (q.slot_width == 4) {
+      // 4-byte slots: agg_count_int32 (RuntimeFunctions.cpp:1222-1225) / agg_id_int32 (:1259-1261)
+      int32_t* s32 = reinterpret_cast<int32_t*>(slots);
+      for (int m = 0; m < jm.count; ++m) {
+        for (const auto& t : c.ts) {
+          if (t.agg == MI355Q_PROJECT_KEY) {
+            if (t.slot >= 0) s32[t.slot] = (int32_t)keys[t.key_idx];
+          } else {
+            ++*reinterpret_cast<uint32_t*>(s32 + t.slot);
+          }
+        }
+      }
+      continue;
+    }
     // one joined row per matching inner row (JoinLoop, Set / Singleton kinds)
     for (int m = 0; m < jm.count; ++m) {
       const int64_t inner_pos = jm.ids ? (int64_t)jm.ids[m] : jm.single;
@@ -1173,11 +1205,34 @@ inline void reduce_one_target(const mi355q_qmd& q, int ti, int64_t* this_slots,
 inline bool is_empty_entry(const mi355q_qmd& q, const int64_t* buf, int64_t e) {
   if (q.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return false;
   const int64_t* row = buf + e * (q.row_size / 8);
+  if (q.keyless && q.slot_width == 4) {
+    return reinterpret_cast<const int32_t*>(row)[q.idx_target_as_key] == (int32_t)q.init_vals[q.idx_target_as_key];
+  }
   if (q.keyless) {
     return row[q.idx_target_as_key] == q.init_vals[q.idx_target_as_key];
   }
   if (q.key_width == 4) return *reinterpret_cast<const int32_t*>(row) == kEmptyKey32;
   return row[0] == kEmptyKey64;
+}
+
+// reduceOneSlot with 4-byte slots: AGGREGATE_ONE_COUNT on 32 bits, projections copied when set
+inline void reduce_one_target_compact(const mi355q_qmd& q, int ti, int64_t* this_slots,
+                                      const int64_t* that_slots) {
+  const int s = q.target_slot[ti];
+  if (s < 0) return;
+  int32_t* a = reinterpret_cast<int32_t*>(this_slots) + s;
+  const int32_t b = reinterpret_cast<const int32_t*>(that_slots)[s];
+  if (q.target_agg[ti] == MI355Q_PROJECT_KEY) {
+    if (b != (int32_t)q.init_vals[s]) *a = b;
+  } else {
+    *a = (int32_t)((uint32_t)*a + (uint32_t)b);
+  }
+}
+inline void reduce_targets(const mi355q_qmd& q, int64_t* this_slots, const int64_t* that_slots) {
+  for (int t = 0; t < q.n_targets; ++t) {
+    if (q.slot_width == 4) reduce_one_target_compact(q, t, this_slots, that_slots);
+    else reduce_one_target(q, t, this_slots, that_slots);
+  }
 }
 
 // ResultSetStorage::reduce (ResultSetReduction.cpp:203-383); baseline entries re-hash
@@ -1199,7 +1254,7 @@ int32_t reduce_buffers(const mi355q_qmd& q, int64_t* this_buf, const int64_t* th
                                   q.key_width, rq);
       }
       if (!slots) return MI355Q_ERR_OUT_OF_SLOTS;
-      for (int t = 0; t < q.n_targets; ++t) reduce_one_target(q, t, slots, that_row + kq);
+      reduce_targets(q, slots, that_row + kq);
     }
     return 0;
   }
@@ -1208,7 +1263,7 @@ int32_t reduce_buffers(const mi355q_qmd& q, int64_t* this_buf, const int64_t* th
     int64_t* this_row = this_buf + e * rq;
     const int64_t* that_row = that_buf + e * rq;
     for (int k = 0; k < kq; ++k) this_row[k] = that_row[k];  // key memcpy from rhs (ResultSetReductionJIT.cpp:705-711)
-    for (int t = 0; t < q.n_targets; ++t) reduce_one_target(q, t, this_row + kq, that_row + kq);
+    reduce_targets(q, this_row + kq, that_row + kq);
   }
   return 0;
 }
@@ -1558,7 +1613,7 @@ ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64
         is_null[o] = ival[o] == q->target_null[t];
         continue;
       }
-      const int64_t v = row[kq + s];
+      const int64_t v = q->slot_width == 4 ? (int64_t) reinterpret_cast<const int32_t*>(row + kq)[s] : row[kq + s];
       switch (q->target_agg[t]) {
         case MI355Q_AVG: {
           const int64_t cnt = row[kq + s + 1];

@@ -182,6 +182,23 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       RelAlgExecutionUnit(descs32, [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(AVG, 2)],
                                           groupby_exprs=[0], max_groups_buffer_entry_guess=5000), frags32))
 
+    # ---- 4-byte slots (pick_target_compact_width): one group column, COUNT(*) and projections of
+    # keys of at most 4 bytes only, <= UINT32_MAX input tuples, g_bigint_count off
+    cases.append(Case("compact_perfect_nullable_int32_key", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], group=[10]),
+                      frags))                                          # keyless: [key i32][count u32]
+    cases.append(Case("compact_perfect_int8_key_filtered", ra([TargetExpr(COUNT), TargetExpr(PROJECT_KEY)],
+                                                              [Qual(0, LT, 2**30)], group=[5]), frags))
+    cases.append(Case("compact_perfect_count_only_int64_key", ra([TargetExpr(COUNT)], group=[1]), frags))
+    cases.append(Case("compact_baseline_count_only", ra([TargetExpr(COUNT)], [Qual(2, GT, 0)], group=[4], guess=8192),
+                      frags))                                          # key 8 B + count 4 B + pad
+    c8 = Case("compact_off_bigint_count", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], group=[10]), frags)
+    c8.ra.bigint_count = True
+    cases.append(c8)
+    c9 = Case("compact_off_many_tuples", ra([TargetExpr(COUNT)], group=[4], guess=8192), frags)
+    c9.ra.num_tuples = 2**32
+    cases.append(c9)
+    cases.append(Case("compact_off_int64_projection", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], group=[1]), frags))
+
     # ---- 4-byte value columns (plain INT / nullable INT) through the perfect and baseline layouts
     cases.append(Case("perfect_int32_values", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 0), TargetExpr(MAX, 0),
                                                   TargetExpr(AVG, 0)], group=[1]), frags))
@@ -322,6 +339,10 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       RelAlgExecutionUnit(fx_descs, [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(COUNT),
                                                      TargetExpr(MIN, 1), TargetExpr(AVG, 1)], groupby_exprs=[0]), fx_frags))
 
+    cases.append(Case("compact_baseline_key32",
+                      RelAlgExecutionUnit(descs32, [TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], groupby_exprs=[0],
+                                          max_groups_buffer_entry_guess=5000), frags32))  # 4-byte key, 4-byte count
+
     # ---- empty and tiny inputs
     empty = [[np.zeros(0, NP[t]) for t, _, _ in spec]]
     cases.append(Case("empty_input_nongrouped", ra([TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(AVG, 3)]), empty))
@@ -460,4 +481,6 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       RelAlgExecutionUnit(kfd, [TargetExpr(COUNT), TargetExpr(SUM, 2, 1), TargetExpr(SUM, 2), TargetExpr(MIN, 2, 1)],
                                           inner_col_descs=k_descs, join_outer_col=[0, 1]),
                       kff, [ka, kb, kw_], [ka, kb], [INT64, INT32], ExpressionRange(), False, join_one_to_many=1))
+    cases.append(Case("compact_join_1n_count", dra([TargetExpr(COUNT)], outer_col=2, group=[3], kind=capi.JOIN_LEFT),
+                      ffrags, [dim_dup, dup_w, dup_f], dim_dup, INT64, dup_rng, False, join_one_to_many=1))
     return cases

@@ -20,6 +20,24 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                                int join_width, int64_t* out, mi355q_qmd* out_qmd) {
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;
+  if (q.slot_width == 4) {
+    // like mi355q_execute: the step runs on the 8-byte layout of the same plan, then every row is
+    // narrowed (rowfunc.h narrow_row)
+    mi355q_plan p8 = *plan;
+    p8.bigint_count = 1;
+    mi355q_qmd q8;
+    if (int32_t e = qmd_init(p8, &q8)) return e;
+    std::vector<int64_t> wide((size_t)q8.entry_count * (q8.row_size / 8));
+    if (int32_t e = emu_execute(&p8, in, join_hash_type, join_buf, join_min, join_max, join_entries, join_n_keys,
+                                join_width, wide.data(), nullptr))
+      return e;
+    for (int64_t e = 0; e < q.entry_count; ++e) {
+      narrow_row(wide.data() + e * (q8.row_size / 8), q.key_bytes / 8, q.slot_count, q.row_size / 8,
+                 out + e * (q.row_size / 8));
+    }
+    if (out_qmd) *out_qmd = q;
+    return 0;
+  }
   DevPlan d;
   if (int32_t e = build_dev_plan(*plan, q, &d)) return e;
   if (plan->join_outer_col >= 0) {

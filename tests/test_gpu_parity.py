@@ -122,7 +122,8 @@ def test_out_of_slots_retry_ladder(torch_cuda, oracle):
                                   "baseline_nullable_args", "baseline_key32_compact",
                                   "multi_perfect_nullable_translate", "multi_perfect_2col_keyless",
                                   "multi_baseline_i64_2col", "multi_baseline_key32_3col_padded",
-                                  "enc_group_date_bucketed"])
+                                  "enc_group_date_bucketed", "compact_perfect_nullable_int32_key",
+                                  "compact_baseline_count_only", "compact_baseline_key32"])
 def test_device_reduce_matches_oracle(torch_cuda, oracle, name):
     """mi355q_result_reduce (device) == ResultSetStorage::reduce restated (oracle), and the
     reduced halves equal the single pass — what Tests/GpuSharedMemoryTest.cpp checks for
@@ -872,3 +873,40 @@ def test_packed_route_on_perfect_layouts(torch_cuda, oracle, name):
     qmd_equal(q, rs.getQueryMemDesc())
     compare_buffers(q, want, rs.getStorage(), case.fp_rtol)
     compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), case.fp_rtol)
+
+
+def test_compact_slots_topk_and_shards(torch_cuda, oracle):
+    """4-byte-slot layout (SELECT key, COUNT(*) ... GROUP BY key over < 2^32 rows): top-k ordered by
+    the 32-bit COUNT, and the keyed multi-GPU merge pieces (partition + merge of whole compact
+    rows), against the oracle."""
+    from heavydb_amd.executor import Executor
+    from heavydb_amd.multi_gpu import HipShard
+    case = next(c for c in CASES if c.name == "compact_baseline_count_only")
+    q, want, code = oracle.execute(case.ra.to_plan(), case.frags, n_threads=2)
+    assert code == 0 and q.slot_width == 4 and q.row_size == 16
+    frag_t, inner_t = _upload(torch_cuda, case)
+    ex = Executor(0)
+    fr = _fetch_result(case, frag_t, inner_t)
+    rs = ex.executeWorkUnit(case.ra, fr, allow_retry=False)
+    qmd_equal(q, rs.getQueryMemDesc())
+    compare_buffers(q, want, rs.getStorage())
+    iv, _, _ = oracle.fetch_rows(q, want)
+    k = 25
+    out = torch_cuda.empty((k, 2), dtype=torch_cuda.int64, device="cuda")
+    n = rs.sort(0, k, int(out.data_ptr()), desc=True)
+    got_counts = out.cpu().numpy()[:n, 1].copy().view(np.int32)[::2]
+    assert n == k and np.array_equal(got_counts, np.sort(iv[:, 0])[::-1][:k])
+    sh = HipShard.execute(torch_cuda, ex, case.ra, fr)
+    rows, counts = sh.partition_rows(2)
+    merged = []
+    for d in range(2):
+        o = sh.fresh_like()
+        lo = sum(counts[:d])
+        o.merge_rows(rows[lo:lo + counts[d]].contiguous())
+        torch_cuda.cuda.synchronize()
+        tab = o.buffer().cpu().numpy()
+        merged.append(tab[tab[:, 0] != 2**63 - 1])
+    full = oracle.init_buffer(q).reshape(q.entry_count, -1)
+    allrows = np.concatenate(merged)
+    full[:allrows.shape[0]] = allrows
+    compare_buffers(q, want, full.reshape(-1))
