@@ -19,7 +19,7 @@ MAX_GROUP_COLS = 4
 ABI_VERSION = 2
 
 # mi355q_type
-INT8, INT16, INT32, INT64, DOUBLE = 1, 2, 3, 4, 5
+INT8, INT16, INT32, INT64, DOUBLE, FLOAT = 1, 2, 3, 4, 5, 6
 # mi355q_encoding
 ENC_NONE, ENC_FIXED, ENC_DICT, ENC_DATE_IN_DAYS = 0, 1, 2, 3
 # mi355q_op (SQLOps values)
@@ -42,7 +42,7 @@ ERR_HIP = 102
 ERR_JOIN_NOT_ONE_TO_ONE = 103
 ERR_JOIN_TABLE_FULL = 104
 
-TYPE_WIDTH = {INT8: 1, INT16: 2, INT32: 4, INT64: 8, DOUBLE: 8}
+TYPE_WIDTH = {INT8: 1, INT16: 2, INT32: 4, INT64: 8, DOUBLE: 8, FLOAT: 4}
 
 
 class ColDesc(C.Structure):
@@ -122,6 +122,7 @@ class QMD(C.Structure):
         ("target_is_fp", C.c_int32 * MAX_TARGETS),
         ("target_agg", C.c_int32 * MAX_TARGETS),
         ("target_arg_is_fp", C.c_int32 * MAX_TARGETS),
+        ("target_arg_is_f32", C.c_int32 * MAX_TARGETS),
         ("target_null", C.c_int64 * MAX_TARGETS),
         ("init_vals", C.c_int64 * MAX_SLOTS),
     ]

@@ -149,7 +149,7 @@ int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
     const int c = (i == 0 && p.n_join_cols <= 1) ? p.join_outer_col : p.join_outer_cols[i];
     if (c < 0 || c >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
     const mi355q_col_desc& jc = p.cols[c];
-    if (type_is_fp(jc.type)) return MI355Q_ERR_UNSUPPORTED;
+    if (type_is_fp(jc.type) || type_is_f32(jc.type)) return MI355Q_ERR_UNSUPPORTED;
     d->join_cols[i] = c;
     d->join_types[i] = col_type_code(jc);
     d->join_nullables[i] = jc.nullable != 0;
@@ -489,8 +489,13 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
           dval[o] = kNullDouble;
           is_null[o] = 1;
         } else {
-          dval[o] = (q.target_arg_is_fp[t] ? bits_dbl(v) : (double)v) / (double)cnt;
+          const double sum = q.target_arg_is_f32[t] ? (double)bits_flt((int32_t)v)
+                                                    : q.target_arg_is_fp[t] ? bits_dbl(v) : (double)v;
+          dval[o] = sum / (double)cnt;
         }
+      } else if (q.target_arg_is_f32[t]) {  // float result in the low 4 bytes of the slot
+        dval[o] = (double)bits_flt((int32_t)v);
+        is_null[o] = q.target_skip_null[t] && (int32_t)v == (int32_t)q.target_null[t];
       } else if (agg == MI355Q_COUNT || agg == MI355Q_COUNT_IF) {
         ival[o] = v;
       } else if (q.target_is_fp[t]) {

@@ -24,6 +24,8 @@ constexpr int64_t kEmptyKey64 = INT64_MAX;  // GpuRtConstants.h:27
 constexpr int32_t kEmptyKey32 = INT32_MAX;  // GpuRtConstants.h:28
 constexpr double kNullDouble = 2.2250738585072014e-308;  // NULL_DOUBLE = DBL_MIN
 constexpr int64_t kNullDoubleBits = 0x0010000000000000ll;
+constexpr float kNullFloat = 1.17549435e-38f;            // NULL_FLOAT = FLT_MIN
+constexpr int32_t kNullFloatBits = 0x00800000;
 
 // A column "type code" packs what the decoders need into one int: the storage type, the
 // encoding, the SQL type after decoding and (for encoded columns) the nullable flag:
@@ -39,11 +41,12 @@ MQ_HD int tc_make(int storage, int enc, int logical, int nullable) {
 }
 
 MQ_HD int plain_width(int t) {
-  return t == MI355Q_INT8 ? 1 : t == MI355Q_INT16 ? 2 : t == MI355Q_INT32 ? 4 : 8;
+  return t == MI355Q_INT8 ? 1 : t == MI355Q_INT16 ? 2 : (t == MI355Q_INT32 || t == MI355Q_FLOAT) ? 4 : 8;
 }
 // bytes per element of the chunk as stored
 MQ_HD int type_width(int code) { return plain_width(tc_storage(code)); }
 MQ_HD bool type_is_fp(int code) { return tc_storage(code) == MI355Q_DOUBLE; }
+MQ_HD bool type_is_f32(int code) { return tc_storage(code) == MI355Q_FLOAT; }
 // Shared/InlineNullValues.h:29-35
 MQ_HD int64_t plain_int_null(int t) {
   return t == MI355Q_INT8    ? (int64_t)INT8_MIN
@@ -219,6 +222,20 @@ MQ_HD int64_t dbl_bits(double d) {
   u.d = d;
   return u.i;
 }
+// float bits in the low half of an 8-byte slot; the value an initialised slot holds is the
+// int32 pattern sign-extended (get_agg_initial_val returns int64, OutputBufferInitialization.cpp)
+MQ_HD int32_t flt_bits(float f) {
+  union { float f; int32_t i; } u;
+  u.f = f;
+  return u.i;
+}
+MQ_HD float bits_flt(int32_t i) {
+  union { float f; int32_t i; } u;
+  u.i = i;
+  return u.f;
+}
+// fixed_width_float_decode (DecodersImpl.h:109-119)
+MQ_HD float decode_flt(const int8_t* col, int64_t pos) { return *(const float*)(col + pos * 4); }
 MQ_HD double bits_dbl(int64_t i) {
   union { double d; int64_t i; } u;
   u.i = i;
@@ -234,7 +251,7 @@ struct DevQual {
 struct DevTarget {
   int32_t agg, col, table, arg_type;  // arg_type: type code of the argument column
   int32_t arg_nullable, skip_null, slot, arg_fp;
-  int32_t key_idx, pad_;  // PROJECT_KEY: which group column
+  int32_t key_idx, arg_f32;  // PROJECT_KEY: which group column; FLOAT argument (slot = float bits)
   DevQual cond;           // COUNT_IF / SUM_IF
 };
 struct DevPlan {

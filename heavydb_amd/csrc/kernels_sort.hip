@@ -53,10 +53,15 @@ MQ_D uint64_t order_key_of(const DevPlan& p, const DevTarget& t, const int64_t* 
     u = (uint64_t)v ^ 0x8000000000000000ull;
   } else {
     const int64_t* s = row + p.key_quad + t.slot;
-    if (t.agg == MI355Q_AVG) {
+    if (t.arg_f32 && t.agg != MI355Q_AVG && t.agg != MI355Q_COUNT) {  // float bits in the low half
+      is_null = t.skip_null && (int32_t)s[0] == (int32_t)null_pattern;
+      const uint64_t b = (uint64_t)dbl_bits((double)bits_flt((int32_t)s[0]));
+      u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    } else if (t.agg == MI355Q_AVG) {
       const int64_t cnt = s[1];
       is_null = cnt == 0;  // pair_to_double: count 0 -> NULL
-      const double d = is_null ? 0.0 : (t.arg_fp ? bits_dbl(s[0]) : (double)s[0]) / (double)cnt;
+      const double sum = t.arg_f32 ? (double)bits_flt((int32_t)s[0]) : t.arg_fp ? bits_dbl(s[0]) : (double)s[0];
+      const double d = is_null ? 0.0 : sum / (double)cnt;
       const uint64_t b = (uint64_t)dbl_bits(d);
       u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
     } else if (fp_result) {

@@ -30,11 +30,12 @@ constexpr int64_t kMaxBufferSize = int64_t(1) << 30;  // GroupByAndAggregate.cpp
 struct ArgInfo {
   int type = 0;
   bool nullable = false;
-  bool fp = false;
+  bool fp = false;   // DOUBLE or FLOAT
   const mi355q_range* range = nullptr;
+  bool f32 = false;  // FLOAT: 4-byte init patterns, sign-extended (byte_width 4 cases)
 };
 
-bool valid_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_DOUBLE; }
+bool valid_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_FLOAT; }
 bool int_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_INT64; }
 
 constexpr int64_t kBaselineGroupbyThreshold = 1000000;  // g_baseline_groupby_threshold, Execute.cpp:113
@@ -48,6 +49,19 @@ int64_t bucketed_cardinality(const mi355q_range& r) {
 
 // Initial slot value for an aggregate whose init type has `notnull`.
 int64_t initial_val(int agg, const ArgInfo& a, bool notnull) {
+  if (a.f32) {  // get_agg_initial_val with byte_width 4 (OutputBufferInitialization.cpp:139-236)
+    switch (agg) {
+      case MI355Q_SUM:
+      case MI355Q_SUM_IF:
+        return notnull ? (int64_t)flt_bits(0.0f) : (int64_t)kNullFloatBits;
+      case MI355Q_MIN:
+        return notnull ? (int64_t)flt_bits(FLT_MAX) : (int64_t)kNullFloatBits;
+      case MI355Q_MAX:
+        return notnull ? (int64_t)flt_bits(-FLT_MAX) : (int64_t)kNullFloatBits;
+      default:
+        return 0;
+    }
+  }
   switch (agg) {
     case MI355Q_SUM:
     case MI355Q_SUM_IF:
@@ -131,6 +145,7 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
       // inner columns of an outer join are nullable whatever their declaration
       r.arg_nullable = cd.nullable != 0 || (r.table && p.join_kind == MI355Q_JOIN_LEFT);
       r.arg_fp = type_is_fp(cd.type);
+      r.arg_f32 = type_is_f32(cd.type);
       r.range = r.table ? &p.inner_col_ranges[r.col] : &p.col_ranges[r.col];
     }
     const bool is_agg = t.agg != MI355Q_PROJECT_KEY;
@@ -153,7 +168,7 @@ void keyless_decision(const mi355q_plan& p, const ResolvedTarget* ts, bool* keyl
   for (int i = 0; i < p.n_targets; ++i) {
     const ResolvedTarget& t = ts[i];
     if (!found && t.agg != MI355Q_PROJECT_KEY) {
-      ArgInfo a{t.arg_type, t.arg_nullable, t.arg_fp, t.range};
+      ArgInfo a{t.arg_type, t.arg_nullable, t.arg_fp || t.arg_f32, t.range, t.arg_f32};
       const bool rng_ok = a.range && a.range->valid;
       switch (t.agg) {
         case MI355Q_AVG:
@@ -230,7 +245,7 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   for (int g = 0; g < p.n_group_cols; ++g) {
     const int gc = p.group_cols[g];
     if (gc < 0 || gc >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
-    if (type_is_fp(p.cols[gc].type)) return MI355Q_ERR_UNSUPPORTED;  // fp keys
+    if (type_is_fp(p.cols[gc].type) || type_is_f32(p.cols[gc].type)) return MI355Q_ERR_UNSUPPORTED;  // fp keys
   }
   const int64_t baseline_entries =
       p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess : 16384;
@@ -333,12 +348,13 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   int slot = 0;
   for (int i = 0; i < p.n_targets; ++i) {
     const ResolvedTarget& t = ts[i];
-    ArgInfo a{t.arg_type, t.arg_nullable, t.arg_fp, t.range};
+    ArgInfo a{t.arg_type, t.arg_nullable, t.arg_fp || t.arg_f32, t.range, t.arg_f32};
     q->target_agg[i] = t.agg;
     q->target_skip_null[i] = t.skip_null;
     q->target_key_idx[i] = t.key_idx;
     q->target_arg_is_fp[i] = t.arg_fp && t.agg != MI355Q_COUNT;
-    q->target_is_fp[i] = t.agg == MI355Q_AVG || (t.arg_fp && t.agg != MI355Q_COUNT);
+    q->target_arg_is_f32[i] = t.arg_f32 && t.agg != MI355Q_COUNT;
+    q->target_is_fp[i] = t.agg == MI355Q_AVG || ((t.arg_fp || t.arg_f32) && t.agg != MI355Q_COUNT);
     const bool key_in_row =
         t.agg == MI355Q_PROJECT_KEY && q->desc_type == MI355Q_GROUP_BY_BASELINE_HASH;
     if (key_in_row) {
@@ -357,14 +373,15 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
         break;
       case MI355Q_SUM:
       case MI355Q_SUM_IF:
-        q->target_null[i] = t.arg_fp ? kNullDoubleBits : INT64_MIN;
+        q->target_null[i] = t.arg_f32 ? (int64_t)kNullFloatBits : t.arg_fp ? kNullDoubleBits : INT64_MIN;
         break;
       case MI355Q_COUNT:
       case MI355Q_COUNT_IF:
         q->target_null[i] = p.bigint_count ? INT64_MIN : (int64_t)INT32_MIN;
         break;
       default:
-        q->target_null[i] = t.arg_fp ? kNullDoubleBits : int_null_of(t.arg_type);
+        q->target_null[i] = t.arg_f32 ? (int64_t)kNullFloatBits
+                                      : t.arg_fp ? kNullDoubleBits : int_null_of(t.arg_type);
     }
   }
   q->slot_count = slot;
@@ -412,6 +429,7 @@ void layout_from_qmd(const mi355q_qmd& q, DevPlan* d) {
     t.skip_null = q.target_skip_null[i];
     t.slot = q.target_slot[i];
     t.arg_fp = q.target_arg_is_fp[i];
+    t.arg_f32 = q.target_arg_is_f32[i];
     t.key_idx = q.target_key_idx[i];
   }
   d->slot_count = q.slot_count;
@@ -470,6 +488,7 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
     o.arg_type = ts[i].arg_type;
     o.arg_nullable = ts[i].arg_nullable;
     o.arg_fp = ts[i].arg_fp;  // COUNT(double col) still decodes a double
+    o.arg_f32 = ts[i].arg_f32;
     if (ts[i].agg == MI355Q_COUNT_IF || ts[i].agg == MI355Q_SUM_IF) {
       const mi355q_qual& c = p.targets[i].cond;
       o.cond.col = c.col;

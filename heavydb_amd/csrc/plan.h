@@ -11,6 +11,7 @@ struct ResolvedTarget {
   int key_idx = 0;   // PROJECT_KEY: index into group_cols
   bool cond_nullable = false;  // COUNT_IF / SUM_IF: the condition column is nullable
   bool arg_nullable = false, arg_fp = false, skip_null = false;
+  bool arg_f32 = false;  // FLOAT argument: single-precision slot arithmetic
   int n_slots = 1;
   const mi355q_range* range = nullptr;
 };

@@ -33,6 +33,7 @@ inline T emu_cas(T* p, T expect, T desired) {
 #define MQ_CAS32(p, e, d) mq::emu_cas<unsigned int>((unsigned int*)(p), (unsigned int)(e), (unsigned int)(d))
 #define MQ_ADD64(p, v) (*(unsigned long long*)(p) += (unsigned long long)(v))
 #define MQ_ADDF64(p, v) (*(double*)(p) += (v))
+#define MQ_ADDF32(p, v) (*(float*)(p) += (v))
 #define MQ_MIN64(p, v) (*(long long*)(p) = (*(long long*)(p) < (long long)(v) ? *(long long*)(p) : (long long)(v)))
 #define MQ_MAX64(p, v) (*(long long*)(p) = (*(long long*)(p) > (long long)(v) ? *(long long*)(p) : (long long)(v)))
 #define MQ_LOAD64(p) (*(volatile int64_t*)(p))
@@ -47,6 +48,7 @@ inline T emu_cas(T* p, T expect, T desired) {
 #define MQ_CAS32(p, e, d) atomicCAS((unsigned int*)(p), (unsigned int)(e), (unsigned int)(d))
 #define MQ_ADD64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(v))
 #define MQ_ADDF64(p, v) atomicAdd((double*)(p), (double)(v))
+#define MQ_ADDF32(p, v) atomicAdd((float*)(p), (float)(v))
 #define MQ_MIN64(p, v) atomicMin((long long*)(p), (long long)(v))
 #define MQ_MAX64(p, v) atomicMax((long long*)(p), (long long)(v))
 #define MQ_LOAD64(p) __hip_atomic_load((int64_t*)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -180,8 +182,69 @@ MQ_FN void a_minmax_f64(int64_t* s, double v, double skip) {
   }
 }
 
+// FLOAT arguments: single precision on the low 4 bytes of the 8-byte slot (agg_sum_float,
+// agg_min_float, agg_max_float and their _skip_val forms, RuntimeFunctions.cpp:1496-1520,
+// :1586-1594); the upper 4 bytes keep what the row initialisation put there.
+template <bool A>
+MQ_FN void a_sum_f32(int64_t* s, float v) {
+  if (A) MQ_ADDF32(s, v);
+  else *(float*)s += v;
+}
+template <bool A>
+MQ_FN void a_sum_f32_skip(int64_t* s, float v, int32_t skip_bits) {
+  if (v == bits_flt(skip_bits)) return;
+  int32_t* s32 = (int32_t*)s;
+  if (!A) {
+    *s32 = (*s32 == skip_bits) ? flt_bits(v) : flt_bits(bits_flt(*s32) + v);
+    return;
+  }
+  int32_t old = MQ_LOAD32(s32);
+  for (;;) {
+    const int32_t nv = (old == skip_bits) ? flt_bits(v) : flt_bits(bits_flt(old) + v);
+    const int32_t seen = (int32_t)MQ_CAS32(s32, old, nv);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+template <bool A, bool IS_MAX, bool SKIP>
+MQ_FN void a_minmax_f32(int64_t* s, float v, int32_t skip_bits) {
+  if (SKIP && v == bits_flt(skip_bits)) return;
+  int32_t* s32 = (int32_t*)s;
+  int32_t old = A ? MQ_LOAD32(s32) : *s32;
+  for (;;) {
+    int32_t nv;
+    if (SKIP && old == skip_bits) {
+      nv = flt_bits(v);
+    } else {
+      const float o = bits_flt(old);
+      nv = flt_bits(IS_MAX ? (o < v ? v : o) : (v < o ? v : o));
+    }
+    if (nv == old) return;
+    if (!A) {
+      *s32 = nv;
+      return;
+    }
+    const int32_t seen = (int32_t)MQ_CAS32(s32, old, nv);
+    if (seen == old) return;
+    old = seen;
+  }
+}
+
 // ---------------------------------------------------------------- filter
 MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
+  if (q.type == MI355Q_FLOAT) {  // the literal is folded to the column's type: compared in float
+    const float v = decode_flt(col, pos);
+    const float lit = (float)q.fval;
+    if (q.nullable && v == kNullFloat) return false;
+    switch (q.op) {
+      case MI355Q_EQ: return v == lit;
+      case MI355Q_NE: return v != lit;
+      case MI355Q_LT: return v < lit;
+      case MI355Q_GT: return v > lit;
+      case MI355Q_LE: return v <= lit;
+      default: return v >= lit;
+    }
+  }
   if (q.type == MI355Q_DOUBLE) {
     const double v = decode_dbl(col, pos);
     if (q.nullable && v == kNullDouble) return false;
@@ -491,6 +554,37 @@ MQ_FN void apply_target(const DevTarget& t, int64_t* slots, const int8_t* const*
   if (t.table && inner_pos < 0) return;
   const int8_t* col = t.table ? inner_cols[t.col] : cols[t.col];
   const int64_t p = t.table ? inner_pos : pos;
+  if (t.arg_f32) {
+    const float v = decode_flt(col, p);
+    switch (agg) {
+      case MI355Q_COUNT:
+        if (!t.skip_null || v != kNullFloat) a_count<A>(s);
+        break;
+      case MI355Q_SUM:
+        if (t.skip_null) a_sum_f32_skip<A>(s, v, kNullFloatBits);
+        else a_sum_f32<A>(s, v);
+        break;
+      case MI355Q_AVG:
+        if (t.skip_null) {
+          if (v != kNullFloat) {
+            a_sum_f32_skip<A>(s, v, kNullFloatBits);
+            a_count<A>(s + 1);
+          }
+        } else {
+          a_sum_f32<A>(s, v);
+          a_count<A>(s + 1);
+        }
+        break;
+      case MI355Q_MIN:
+        if (t.skip_null) a_minmax_f32<A, false, true>(s, v, kNullFloatBits);
+        else a_minmax_f32<A, false, false>(s, v, 0);
+        break;
+      default:
+        if (t.skip_null) a_minmax_f32<A, true, true>(s, v, kNullFloatBits);
+        else a_minmax_f32<A, true, false>(s, v, 0);
+    }
+    return;
+  }
   if (t.arg_fp) {
     const double v = decode_dbl(col, p);
     switch (agg) {
@@ -563,6 +657,27 @@ MQ_FN void reduce_target(const DevTarget& t, const int64_t* init_vals, int64_t* 
   const int64_t init = init_vals[t.slot];
   const bool fp = t.arg_fp && t.agg != MI355Q_COUNT;
   const int agg = t.agg == MI355Q_COUNT_IF ? MI355Q_COUNT : t.agg == MI355Q_SUM_IF ? MI355Q_SUM : t.agg;
+  if (t.arg_f32 && agg != MI355Q_COUNT) {  // reduceOneSlot with chosen_bytes = sizeof(float)
+    const float bf = bits_flt((int32_t)b);
+    const int32_t init32 = (int32_t)init;
+    switch (agg) {
+      case MI355Q_AVG:
+        a_sum_i64<A>(a + 1, that_slots[t.slot + 1]);
+        // fallthrough
+      case MI355Q_SUM:
+        if (t.skip_null) a_sum_f32_skip<A>(a, bf, init32);
+        else a_sum_f32<A>(a, bf);
+        break;
+      case MI355Q_MIN:
+        if (t.skip_null) a_minmax_f32<A, false, true>(a, bf, init32);
+        else a_minmax_f32<A, false, false>(a, bf, 0);
+        break;
+      default:
+        if (t.skip_null) a_minmax_f32<A, true, true>(a, bf, init32);
+        else a_minmax_f32<A, true, false>(a, bf, 0);
+    }
+    return;
+  }
   switch (agg) {
     case MI355Q_COUNT:
       a_sum_i64<A>(a, b);

@@ -110,7 +110,7 @@ class RelAlgExecutionUnit:
             raise ValueError("too many quals")
         p.n_quals = len(self.simple_quals)
         for i, q in enumerate(self.simple_quals):
-            is_fp = self.input_col_descs[q.col].type == DOUBLE
+            is_fp = self.input_col_descs[q.col].type in (DOUBLE, capi.FLOAT)
             p.quals[i] = capi.Qual(q.col, q.op, 0 if is_fp else int(q.literal),
                                    float(q.literal) if is_fp else 0.0)
         if len(self.groupby_exprs) > capi.MAX_GROUP_COLS:
@@ -124,7 +124,7 @@ class RelAlgExecutionUnit:
         for i, t in enumerate(self.target_exprs):
             ct = capi.Target(t.agg, t.col, t.table, 0)
             if t.cond is not None:
-                is_fp = self.input_col_descs[t.cond.col].type == DOUBLE
+                is_fp = self.input_col_descs[t.cond.col].type in (DOUBLE, capi.FLOAT)
                 ct.cond = capi.Qual(t.cond.col, t.cond.op, 0 if is_fp else int(t.cond.literal),
                                     float(t.cond.literal) if is_fp else 0.0)
             p.targets[i] = ct

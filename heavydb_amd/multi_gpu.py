@@ -53,7 +53,7 @@ def _dense_slot_ops(q: capi.QMD) -> Optional[List[Tuple[int, str, bool]]]:
         agg = q.target_agg[t]
         if s < 0:
             continue
-        if q.target_skip_null[t] or agg == capi.PROJECT_KEY:
+        if q.target_skip_null[t] or agg == capi.PROJECT_KEY or q.target_arg_is_f32[t]:
             return None
         fp = bool(q.target_arg_is_fp[t])
         if agg in (capi.COUNT, capi.COUNT_IF):

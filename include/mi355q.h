@@ -74,7 +74,12 @@ typedef enum mi355q_type {
   MI355Q_INT16 = 2,
   MI355Q_INT32 = 3,
   MI355Q_INT64 = 4,
-  MI355Q_DOUBLE = 5
+  MI355Q_DOUBLE = 5,
+  MI355Q_FLOAT = 6 /* kFLOAT, 4-byte chunks (fixed_width_float_decode, DecodersImpl.h:109-119).
+                      Aggregates with a FLOAT argument work in single precision on the LOW 4
+                      bytes of their 8-byte slot (takes_float_argument, Shared/TargetInfo.h:106;
+                      agg_sum_float / agg_min_float / agg_max_float, RuntimeFunctions.cpp:1496-
+                      1520); filter and aggregate argument only — not a group or join key */
 } mi355q_type;
 
 /* Column encodings ColumnFetcher hands over undecoded (EncodingType, Shared/sqltypes.h; the
@@ -269,6 +274,8 @@ typedef struct mi355q_qmd {
   int32_t target_agg[MI355Q_MAX_TARGETS];       /* mi355q_agg */
   int32_t target_arg_is_fp[MI355Q_MAX_TARGETS]; /* slot holds double bits (SUM/MIN/MAX/AVG
                                                    of a double column) */
+  int32_t target_arg_is_f32[MI355Q_MAX_TARGETS]; /* slot holds FLOAT bits in its low 4 bytes
+                                                    (SUM/MIN/MAX/AVG of a float column) */
   int64_t target_null[MI355Q_MAX_TARGETS];      /* bit pattern of the result type's NULL
                                                    (null_val_bit_pattern,
                                                    ResultSetBufferAccessors.h:229) */

@@ -124,10 +124,12 @@ inline int type_width(int t) {
     case MI355Q_INT32: return 4;
     case MI355Q_INT64: return 8;
     case MI355Q_DOUBLE: return 8;
+    case MI355Q_FLOAT: return 4;
   }
   return 0;
 }
 inline bool type_is_fp(int t) { return t == MI355Q_DOUBLE; }
+inline bool type_is_f32(int t) { return t == MI355Q_FLOAT; }
 
 // Shared/InlineNullValues.h:29-35
 inline int64_t int_null_of(int t) {
@@ -149,6 +151,17 @@ inline double bits_dbl(int64_t b) {
   return r;
 }
 constexpr double kNullDouble = DBL_MIN;  // NULL_DOUBLE
+constexpr float kNullFloat = FLT_MIN;    // NULL_FLOAT
+inline int32_t flt_bits(float f) {
+  int32_t r;
+  memcpy(&r, &f, 4);
+  return r;
+}
+inline float bits_flt(int32_t b) {
+  float r;
+  memcpy(&r, &b, 4);
+  return r;
+}
 
 // DecodersImpl.h:27-55 fixed_width_int_decode (sign-extending load), :121-128 double
 inline int64_t decode_int(const int8_t* col, int t, int64_t pos) {
@@ -207,6 +220,10 @@ inline int64_t decode_col(const mi355q_col_desc& cd, const int8_t* col, int64_t 
 }
 inline double decode_dbl(const int8_t* col, int64_t pos) {
   return *reinterpret_cast<const double*>(col + pos * 8);
+}
+// DecodersImpl.h:109-119 fixed_width_float_decode
+inline float decode_flt(const int8_t* col, int64_t pos) {
+  return *reinterpret_cast<const float*>(col + pos * 4);
 }
 
 // ---------------------------------------------------------------- aggregates (CPU)
@@ -291,6 +308,26 @@ inline void agg_min_double_skip_val(int64_t* agg, double val, double skip_val) {
   }
 }
 
+// RuntimeFunctions.cpp:1496-1520 agg_sum_float / agg_max_float / agg_min_float: single precision
+// on the low 4 bytes of the slot; :1586-1594 DEF_SKIP_AGG for float
+inline void agg_sum_float(int32_t* agg, float val) { *agg = flt_bits(bits_flt(*agg) + val); }
+inline void agg_max_float(int32_t* agg, float val) { *agg = flt_bits(std::max(bits_flt(*agg), val)); }
+inline void agg_min_float(int32_t* agg, float val) { *agg = flt_bits(std::min(bits_flt(*agg), val)); }
+#define ORC_SKIP_AGG_F32(name)                                                   \
+  inline void name##_skip_val(int32_t* agg, float val, float skip_val) {         \
+    if (val != skip_val) {                                                       \
+      const int32_t old = *agg;                                                  \
+      if (old != flt_bits(skip_val)) {                                           \
+        name(agg, val);                                                          \
+      } else {                                                                   \
+        *agg = flt_bits(val);                                                    \
+      }                                                                          \
+    }                                                                            \
+  }
+ORC_SKIP_AGG_F32(agg_sum_float)
+ORC_SKIP_AGG_F32(agg_max_float)
+ORC_SKIP_AGG_F32(agg_min_float)
+
 // ---------------------------------------------------------------- layout decisions
 struct TargetDesc {
   int agg;
@@ -299,6 +336,7 @@ struct TargetDesc {
   int arg_type;      // 0 for COUNT(*)
   bool arg_nullable;
   bool arg_fp;
+  bool arg_f32;      // FLOAT argument (takes_float_argument): 4-byte slot arithmetic
   bool skip_null;    // TargetInfo.skip_null_val after TargetExprBuilder.cpp:684-690
   int slot;          // first slot, -1 if read from key columns
   int n_slots;
@@ -318,6 +356,16 @@ const mi355q_range& col_range_of(const mi355q_plan& p, int table, int col) {
 // `notnull` is the init type's notnull flag (forced false for non-grouped, :79-81).
 int64_t agg_initial_val(int agg, int arg_type, bool notnull) {
   const bool fp = type_is_fp(arg_type);
+  if (type_is_f32(arg_type)) {
+    // byte_width 4 cases (:139-236): the int32 bit pattern of the float, returned as int64
+    switch (agg) {
+      case MI355Q_SUM:
+      case MI355Q_SUM_IF: return notnull ? flt_bits(0.0f) : flt_bits(kNullFloat);
+      case MI355Q_MIN: return notnull ? flt_bits(FLT_MAX) : flt_bits(kNullFloat);
+      case MI355Q_MAX: return notnull ? flt_bits(-FLT_MAX) : flt_bits(kNullFloat);
+      default: return 0;
+    }
+  }
   switch (agg) {
     case MI355Q_SUM:
     case MI355Q_SUM_IF:  // OutputBufferInitialization.cpp:139-176: kSUM and kSUM_IF share the case
@@ -366,6 +414,7 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
       d.arg_type = logical_type_of(cd);
       d.arg_nullable = cd.nullable != 0 || (d.table && p.join_kind == MI355Q_JOIN_LEFT);
       d.arg_fp = type_is_fp(cd.type);
+      d.arg_f32 = type_is_f32(cd.type);
     } else if (t.agg != MI355Q_COUNT && t.agg != MI355Q_COUNT_IF) {
       return MI355Q_ERR_INVALID_PLAN;
     }
@@ -377,6 +426,7 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
         d.cd = nullptr;
         d.arg_type = 0;
         d.arg_fp = false;
+        d.arg_f32 = false;
         d.arg_nullable = false;
       }
     }
@@ -419,7 +469,7 @@ std::pair<bool, int> keyless_info(const mi355q_plan& p, const std::vector<Target
           if (t.arg_nullable) {
             if (r->valid && !r->has_nulls) found = true;
           } else if (r->valid) {
-            if (t.arg_fp) {
+            if ((t.arg_fp || t.arg_f32)) {
               if (r->fp_max < 0 || r->fp_min > 0) found = true;
             } else {
               if (r->max < 0 || r->min > 0) found = true;
@@ -429,7 +479,7 @@ std::pair<bool, int> keyless_info(const mi355q_plan& p, const std::vector<Target
         case MI355Q_MIN: {
           if (!r->valid) break;
           const int64_t init_max = agg_initial_val(MI355Q_MIN, t.arg_type, !t.arg_nullable);
-          if (t.arg_fp) {
+          if ((t.arg_fp || t.arg_f32)) {
             if (r->fp_max < bits_dbl(init_max)) found = true;
           } else {
             if (r->max < init_max) found = true;
@@ -439,7 +489,7 @@ std::pair<bool, int> keyless_info(const mi355q_plan& p, const std::vector<Target
         case MI355Q_MAX: {
           if (!r->valid || r->has_nulls) break;
           const int64_t init_min = agg_initial_val(MI355Q_MAX, t.arg_type, !t.arg_nullable);
-          if (t.arg_fp) {
+          if ((t.arg_fp || t.arg_f32)) {
             if (r->fp_min > bits_dbl(init_min)) found = true;
           } else {
             if (r->min > init_min) found = true;
@@ -476,7 +526,8 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   q.idx_target_as_key = -1;
   q.key_width = 8;
   for (int g = 0; g < p.n_group_cols; ++g) {
-    if (type_is_fp(p.cols[p.group_cols[g]].type)) return MI355Q_ERR_UNSUPPORTED;
+    if (type_is_fp(p.cols[p.group_cols[g]].type) || type_is_f32(p.cols[p.group_cols[g]].type))
+      return MI355Q_ERR_UNSUPPORTED;
   }
   bool baseline = false;
   if (!is_group_by) {
@@ -579,7 +630,8 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
     q.target_skip_null[i] = t.skip_null;
     q.target_key_idx[i] = t.key_idx;
     q.target_arg_is_fp[i] = t.arg_fp && t.agg != MI355Q_COUNT;
-    q.target_is_fp[i] = (t.agg == MI355Q_AVG) || (t.arg_fp && t.agg != MI355Q_COUNT);
+    q.target_arg_is_f32[i] = t.arg_f32 && t.agg != MI355Q_COUNT;
+    q.target_is_fp[i] = (t.agg == MI355Q_AVG) || ((t.arg_fp || t.arg_f32) && t.agg != MI355Q_COUNT);
     if (t.agg == MI355Q_PROJECT_KEY && q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
       // target_groupby_indices >= 0 -> zero-width slot (ColSlotContext.cpp:45-49)
       q.target_slot[i] = -1;
@@ -598,11 +650,14 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
     switch (t.agg) {
       case MI355Q_AVG: q.target_null[i] = dbl_bits(kNullDouble); break;
       case MI355Q_SUM:
-      case MI355Q_SUM_IF: q.target_null[i] = t.arg_fp ? dbl_bits(kNullDouble) : INT64_MIN; break;
+      case MI355Q_SUM_IF:
+        q.target_null[i] = t.arg_f32 ? flt_bits(kNullFloat) : t.arg_fp ? dbl_bits(kNullDouble) : INT64_MIN;
+        break;
       case MI355Q_COUNT:
       case MI355Q_COUNT_IF: q.target_null[i] = p.bigint_count ? INT64_MIN : INT32_MIN; break;
       default:
-        q.target_null[i] = t.arg_fp ? dbl_bits(kNullDouble) : int_null_of(t.arg_type);
+        q.target_null[i] = t.arg_f32 ? flt_bits(kNullFloat)
+                                     : t.arg_fp ? dbl_bits(kNullDouble) : int_null_of(t.arg_type);
     }
   }
   q.slot_count = slot;
@@ -904,6 +959,20 @@ struct ExecCtx {
 inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q, const int8_t* const* cols,
                       int64_t pos) {
   const auto& cd = p.cols[q.col];
+  if (type_is_f32(cd.type)) {  // lt_float_nullable etc. (DEF_CMP_NULLABLE for float): single precision
+    const float v = decode_flt(cols[q.col], pos);
+    const float lit = (float)q.fval;
+    if (cd.nullable && v == kNullFloat) return false;
+    switch (q.op) {
+      case MI355Q_EQ: return v == lit;
+      case MI355Q_NE: return v != lit;
+      case MI355Q_LT: return v < lit;
+      case MI355Q_GT: return v > lit;
+      case MI355Q_LE: return v <= lit;
+      case MI355Q_GE: return v >= lit;
+    }
+    return false;
+  }
   if (type_is_fp(cd.type)) {
     const double v = decode_dbl(cols[q.col], pos);
     if (cd.nullable && v == kNullDouble) return false;
@@ -960,6 +1029,40 @@ inline void apply_target(const mi355q_plan& p_, const TargetDesc& t, int64_t* sl
   if (t.table && inner_pos < 0) return;
   const int8_t* col = t.table ? inner_cols[t.col] : cols[t.col];
   const int64_t p = t.table ? inner_pos : pos;
+  if (t.arg_f32) {
+    // takes_float_argument: agg_chosen_bytes = sizeof(float) (TargetExprBuilder.cpp:477-481);
+    // the COUNT component of AVG and COUNT(col) itself stay 8 bytes wide
+    const float v = decode_flt(col, p);
+    int32_t* s32 = reinterpret_cast<int32_t*>(s);
+    switch (t.agg) {
+      case MI355Q_COUNT:
+        if (!t.skip_null || v != kNullFloat) agg_count(s);
+        break;
+      case MI355Q_SUM:
+      case MI355Q_SUM_IF:
+        if (t.skip_null) agg_sum_float_skip_val(s32, v, kNullFloat);
+        else agg_sum_float(s32, v);
+        break;
+      case MI355Q_AVG:
+        if (t.skip_null) {
+          agg_sum_float_skip_val(s32, v, kNullFloat);
+          if (v != kNullFloat) agg_count(s + 1);
+        } else {
+          agg_sum_float(s32, v);
+          agg_count(s + 1);
+        }
+        break;
+      case MI355Q_MIN:
+        if (t.skip_null) agg_min_float_skip_val(s32, v, kNullFloat);
+        else agg_min_float(s32, v);
+        break;
+      case MI355Q_MAX:
+        if (t.skip_null) agg_max_float_skip_val(s32, v, kNullFloat);
+        else agg_max_float(s32, v);
+        break;
+    }
+    return;
+  }
   if (t.arg_fp) {
     const double v = decode_dbl(col, p);
     switch (t.agg) {
@@ -1160,6 +1263,30 @@ inline void reduce_one_target(const mi355q_qmd& q, int ti, int64_t* this_slots,
   const int64_t init = q.init_vals[s];
   const bool fp = q.target_arg_is_fp[ti];
   const bool skip = q.target_skip_null[ti];
+  if (q.target_arg_is_f32[ti]) {  // chosen_bytes = sizeof(float) (ResultSetReduction.cpp:1514-1520)
+    int32_t* a32 = reinterpret_cast<int32_t*>(a);
+    const float bf = bits_flt((int32_t)*b);
+    const float initf = bits_flt((int32_t)init);
+    switch (q.target_agg[ti]) {
+      case MI355Q_AVG:
+        agg_sum(a + 1, b[1]);
+        [[fallthrough]];
+      case MI355Q_SUM:
+      case MI355Q_SUM_IF:
+        if (skip) agg_sum_float_skip_val(a32, bf, initf);
+        else agg_sum_float(a32, bf);
+        break;
+      case MI355Q_MIN:
+        if (skip) agg_min_float_skip_val(a32, bf, initf);
+        else agg_min_float(a32, bf);
+        break;
+      case MI355Q_MAX:
+        if (skip) agg_max_float_skip_val(a32, bf, initf);
+        else agg_max_float(a32, bf);
+        break;
+    }
+    return;
+  }
   switch (q.target_agg[ti]) {
     case MI355Q_COUNT:
     case MI355Q_COUNT_IF:  // ResultSetReduction.cpp:1524-1535
@@ -1621,7 +1748,9 @@ ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64
             dval[o] = kNullDouble;
             is_null[o] = 1;
           } else {
-            const double dividend = q->target_arg_is_fp[t] ? bits_dbl(v) : (double)v;
+            // pair_to_double (ResultSetBufferAccessors.h:197-227): float_argument_input reads a float
+            const double dividend = q->target_arg_is_f32[t] ? (double)bits_flt((int32_t)v)
+                                    : q->target_arg_is_fp[t] ? bits_dbl(v) : (double)v;
             dval[o] = dividend / (double)cnt;
           }
           break;
@@ -1631,7 +1760,10 @@ ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64
           ival[o] = v;
           break;
         default:
-          if (q->target_is_fp[t]) {
+          if (q->target_arg_is_f32[t]) {  // float slot: 4 bytes (getTargetValueFromBufferRowwise)
+            dval[o] = (double)bits_flt((int32_t)v);
+            is_null[o] = q->target_skip_null[t] && (int32_t)v == (int32_t)q->target_null[t];
+          } else if (q->target_is_fp[t]) {
             dval[o] = bits_dbl(v);
             is_null[o] = q->target_skip_null[t] && v == q->target_null[t];
           } else {

@@ -139,7 +139,7 @@ def ref_lib() -> Optional[C.CDLL]:
 
 
 NP_DTYPE = {capi.INT8: np.int8, capi.INT16: np.int16, capi.INT32: np.int32,
-            capi.INT64: np.int64, capi.DOUBLE: np.float64}
+            capi.INT64: np.int64, capi.DOUBLE: np.float64, capi.FLOAT: np.float32}
 
 
 def murmur3(data: bytes, seed: int = 0) -> int:

@@ -19,8 +19,9 @@ from heavydb_amd.capi import (COUNT_IF, SUM_IF, AVG, COUNT, DOUBLE, EQ, GE, GT, 
 from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
                                   TargetExpr)
 
-NP = {INT8: np.int8, INT16: np.int16, INT32: np.int32, INT64: np.int64, DOUBLE: np.float64}
-NULLS = {INT8: -2**7, INT16: -2**15, INT32: -2**31, INT64: -2**63, DOUBLE: 2.2250738585072014e-308}
+NP = {INT8: np.int8, INT16: np.int16, INT32: np.int32, INT64: np.int64, DOUBLE: np.float64, capi.FLOAT: np.float32}
+NULLS = {INT8: -2**7, INT16: -2**15, INT32: -2**31, INT64: -2**63, DOUBLE: 2.2250738585072014e-308,
+         capi.FLOAT: float(np.finfo(np.float32).tiny)}
 
 
 @dataclass
@@ -50,7 +51,7 @@ def col_range(arrs: List[np.ndarray], t: int, nullable: bool) -> ExpressionRange
         has_nulls = False
     if a.size == 0:
         return ExpressionRange(True, 0, -1, has_nulls)  # empty range: min > max
-    if t == DOUBLE:
+    if t in (DOUBLE, capi.FLOAT):
         return ExpressionRange(True, 0, 0, has_nulls, float(a.min()), float(a.max()))
     return ExpressionRange(True, int(a.min()), int(a.max()), has_nulls)
 
@@ -181,6 +182,34 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("baseline_key32_compact",
                       RelAlgExecutionUnit(descs32, [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(AVG, 2)],
                                           groupby_exprs=[0], max_groups_buffer_entry_guess=5000), frags32))
+
+    # ---- FLOAT arguments: single-precision slot arithmetic on the low 4 bytes (takes_float_argument)
+    FL = capi.FLOAT
+    dfl, ffl = make_table(rng, n, fs, [
+        (INT64, False, lambda r, m: r.integers(0, 60, m)),                      # perfect key
+        (FL, False, lambda r, m: r.random(m) * 100.0 + 1.0),                    # positive floats
+        (FL, True, lambda r, m: r.random(m) * 50.0 - 10.0),                     # nullable, spans 0
+        (INT64, False, lambda r, m: r.integers(0, 2500, m) * 1000003 + 7),      # baseline key
+        (INT32, False, lambda r, m: r.integers(0, 2**31 - 1, m)),
+    ])
+
+    def fra(targets, quals=(), group=(), guess=16384):
+        return RelAlgExecutionUnit(list(dfl), list(targets), list(quals), list(group),
+                                   max_groups_buffer_entry_guess=guess)
+    cases.append(Case("float_nongrouped_aggs", fra([TargetExpr(SUM, 1), TargetExpr(MIN, 1), TargetExpr(MAX, 1),
+                                                    TargetExpr(AVG, 1), TargetExpr(COUNT, 2), TargetExpr(SUM, 2),
+                                                    TargetExpr(MIN, 2), TargetExpr(AVG, 2)],
+                                                   [Qual(1, LT, 80.5)]), ffl))
+    cases.append(Case("float_nongrouped_all_null", fra([TargetExpr(SUM, 2), TargetExpr(MAX, 1), TargetExpr(AVG, 2),
+                                                        TargetExpr(COUNT)], [Qual(4, LT, -1)]), ffl))
+    cases.append(Case("float_perfect_keyed", fra([TargetExpr(SUM, 2), TargetExpr(MAX, 2), TargetExpr(MIN, 1)], group=[0]),
+                      ffl))                    # SUM(nullable) / MAX(has nulls) / MIN(float quirk): keyed
+    cases.append(Case("float_perfect_keyless_sum", fra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1), TargetExpr(AVG, 2),
+                                                        TargetExpr(MAX, 1)], group=[0]), ffl))  # SUM > 0 -> keyless
+    cases.append(Case("float_baseline", fra([TargetExpr(PROJECT_KEY), TargetExpr(AVG, 1), TargetExpr(MIN, 2),
+                                             TargetExpr(SUM, 2), TargetExpr(COUNT, 2), TargetExpr(MAX, 1),
+                                             TargetExpr(SUM_IF, 1, cond=Qual(2, GT, 0.0))],
+                                            [Qual(4, LT, 2**30)], group=[3], guess=8192), ffl))
 
     # ---- 4-byte slots (pick_target_compact_width): one group column, COUNT(*) and projections of
     # keys of at most 4 bytes only, <= UINT32_MAX input tuples, g_bigint_count off
