@@ -170,7 +170,9 @@ int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
     d->inner_cols[i] = in && in->inner_col_buffers ? (const int8_t*)in->inner_col_buffers[i] : nullptr;
   }
   for (int i = 0; i < p.n_targets; ++i) {
-    if (d->targets[i].table == 1 && d->targets[i].col >= 0 && !d->inner_cols[d->targets[i].col])
+    // (an empty inner table has no chunks: nothing can match, the pointers are never followed)
+    if (d->targets[i].table == 1 && d->targets[i].col >= 0 && !d->inner_cols[d->targets[i].col] &&
+        in && in->inner_num_rows > 0)
       return MI355Q_ERR_INVALID_PLAN;
   }
   return MI355Q_OK;

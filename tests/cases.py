@@ -510,6 +510,27 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       RelAlgExecutionUnit(kfd, [TargetExpr(COUNT), TargetExpr(SUM, 2, 1), TargetExpr(SUM, 2), TargetExpr(MIN, 2, 1)],
                                           inner_col_descs=k_descs, join_outer_col=[0, 1]),
                       kff, [ka, kb, kw_], [ka, kb], [INT64, INT32], ExpressionRange(), False, join_one_to_many=1))
+    # ---- edge cases of the wider shapes: empty inputs, empty / all-NULL inner tables
+    cases.append(Case("multi_col_empty_input", ra([K0, K1, TargetExpr(COUNT), TargetExpr(SUM, 2)], group=[4, 1],
+                                                  guess=4096), empty))
+    cases.append(Case("multi_col_no_fragments", ra([TargetExpr(COUNT), TargetExpr(AVG, 3)], group=[1, 5]), []))
+    e_key = np.zeros(0, np.int64)
+    e_descs = [InputColDescriptor(INT64, False, ExpressionRange(True, 0, -1)),
+               InputColDescriptor(INT64, False, ExpressionRange(True, 0, -1)),
+               InputColDescriptor(DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 0.0))]
+    for kind, tag in [(capi.JOIN_INNER, "inner"), (capi.JOIN_LEFT, "left")]:
+        cases.append(Case(f"join_empty_inner_table_{tag}",
+                          dra([TargetExpr(COUNT), TargetExpr(SUM, 1), TargetExpr(SUM, 1, 1), TargetExpr(COUNT, 2, 1)],
+                              kind=kind, inner=e_descs),
+                          ffrags, [e_key, e_key, np.zeros(0, np.float64)], e_key, INT64, ExpressionRange(True, 0, -1),
+                          False, join_one_to_many=1))
+    all_null = np.full(50, -2**63, dtype=np.int64)
+    n_descs = [InputColDescriptor(INT64, True, ExpressionRange(True, 0, -1, True))] + dup_descs[1:]
+    cases.append(Case("join_all_null_inner_keys_left",
+                      dra([TargetExpr(COUNT), TargetExpr(COUNT, 1, 1), TargetExpr(MIN, 2, 1)], kind=capi.JOIN_LEFT,
+                          inner=n_descs),
+                      ffrags, [all_null, dup_w[:50], dup_f[:50]], all_null, INT64, ExpressionRange(True, 0, -1, True),
+                      False, join_one_to_many=2, join_key_nullable=True))
     cases.append(Case("compact_join_1n_count", dra([TargetExpr(COUNT)], outer_col=2, group=[3], kind=capi.JOIN_LEFT),
                       ffrags, [dim_dup, dup_w, dup_f], dim_dup, INT64, dup_rng, False, join_one_to_many=1))
     return cases
