@@ -533,10 +533,11 @@ bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, P
   std::memset(ps, 0, sizeof(*ps));
   ps->n = p.n_group_cols;
   if (q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
-    // tables that fit LDS belong to the LDS kernels; bucketed keys cannot be restored from
-    // their index
-    if (q.entry_count * (int64_t)q.row_size <= 64 * 1024 || q.entry_count >= ((int64_t)1 << 31)) return false;
-    ps->mode = 1;
+    // single-column tables that fit LDS already have their kernel; multi-column ones reach it
+    // through the packed index (mode 2); bucketed keys cannot be restored from their index
+    const bool small = q.entry_count * (int64_t)q.row_size <= 64 * 1024;
+    if ((small && p.n_group_cols < 2) || q.entry_count >= ((int64_t)1 << 31)) return false;
+    ps->mode = small ? 2 : 1;
     for (int g = 0; g < p.n_group_cols; ++g) {
       if (q.group_bucket[g]) return false;
       ps->cols[g] = p.group_cols[g];
@@ -608,9 +609,20 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     if (guess > (int64_t)UINT32_MAX) return kNotTaken;
     p2.max_groups_buffer_entry_guess = guess;
   }
+  if (ps.mode == 2) {  // the index is a perfect-hash key itself: range [0, entries)
+    p2.col_ranges[nc].valid = 1;
+    p2.col_ranges[nc].min = 0;
+    p2.col_ranges[nc].max = q.entry_count - 1;
+  }
   mi355q_qmd q2;
   if (qmd_init(p2, &q2) != MI355Q_OK) return kNotTaken;
-  if (q2.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return kNotTaken;
+  if (ps.mode == 2) {
+    if (q2.desc_type != MI355Q_GROUP_BY_PERFECT_HASH || q2.entry_count != q.entry_count) return kNotTaken;
+    ps.tmp_idx_target = q2.idx_target_as_key;
+    ps.tmp_init = q2.keyless ? q2.init_vals[q2.idx_target_as_key] : 0;
+  } else if (q2.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) {
+    return kNotTaken;
+  }
   if (ps.mode == 0 && (q2.slot_count != q.slot_count || q2.entry_count != q.entry_count)) return kNotTaken;
   // where every slot of the final row comes from: a slot of the packed step's row, or (perfect
   // layouts: projected keys own a slot) the original value of a key component
@@ -748,7 +760,8 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     ++pass;
   }
   HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
-  if (nf > 0) HIP_TRY(launch_unpack_emit(ps, d, tmp_a, q2.entry_count, q2.row_size / 8, res->buf, d_err, s));
+  if (nf > 0)
+    HIP_TRY(launch_unpack_emit(ps, d, tmp_a, q2.entry_count, q2.row_size / 8, q2.key_bytes / 8, res->buf, d_err, s));
   if (ev1) HIP_TRY(hipEventRecord(ev1, s));
   int32_t h_err = 0;
   HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));

@@ -67,7 +67,10 @@ struct PackSpec {
   uint64_t mask[MI355Q_MAX_GROUP_COLS];
   // perfect-hash layouts (mode 1): the code is the ENTRY INDEX sum_i (key_i - min_i) * mul_i with
   // NULL keys translated to null_key first, exactly as the row function computes it
-  int32_t mode, pad_;
+  int32_t mode;  // 0 bit-packed (baseline), 1 entry index into a baseline temp table, 2 entry index
+                 // into an index-aligned (perfect) temp table
+  int32_t tmp_idx_target;  // mode 2: emptiness of a keyless temp row = slot tmp_idx_target == tmp_init
+  int64_t tmp_init;
   int32_t translate[MI355Q_MAX_GROUP_COLS];
   int64_t mul[MI355Q_MAX_GROUP_COLS], null_key[MI355Q_MAX_GROUP_COLS];
   // final slot <- temp slot (>= 0) or <- original value of key component -(1 + k)
@@ -80,7 +83,7 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 // tmp: table of the packed single-key step (rows = packed key + slot_count slots); out: the
 // initialised final table described by p
 hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,
-                              int tmp_quad, int64_t* out, int32_t* d_err, hipStream_t s);
+                              int tmp_quad, int tmp_key_quad, int64_t* out, int32_t* d_err, hipStream_t s);
 
 // compact COUNT(*)-only layouts: the finished 8-byte-slot table -> its 4-byte-slot image
 hipError_t launch_narrow_slots(const int64_t* wide, int wide_quad, int key_quad, int slot_count,

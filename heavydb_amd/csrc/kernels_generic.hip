@@ -529,7 +529,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_keys(PackSpec ps, const int8_t*
       for (int g = 0; g < ps.n; ++g) {
         int64_t k = decode_int(fc[ps.cols[g]], ps.types[g], pos);
         uint64_t c;
-        if (ps.mode == 1) {  // perfect hash: the entry index
+        if (ps.mode >= 1) {  // perfect hash: the entry index
           if (ps.translate[g] && k == int_null_of(ps.types[g])) k = ps.null_key[g];
           c = (uint64_t)k - (uint64_t)ps.min[g];
           bad = bad || k < ps.min[g] || c >= ps.card[g];
@@ -579,15 +579,24 @@ __global__ __launch_bounds__(kBlock) void k_unpack_emit(PackSpec ps, DevPlan p, 
 }
 
 // perfect-hash layouts: the packed key IS the entry index, so the row is addressed directly; key
-// quads receive the translated keys, projected-key slots the original values (NULL restored)
+// quads receive the translated keys, projected-key slots the original values (NULL restored).
+// The temp table is either a baseline table keyed by the index (mode 1) or itself index-aligned
+// (mode 2: small tables aggregated by the LDS perfect-hash kernel).
 __global__ __launch_bounds__(kBlock) void k_unpack_perfect(PackSpec ps, DevPlan p, const int64_t* __restrict__ tmp,
-                                                            int64_t tmp_entries, int tmp_quad,
+                                                            int64_t tmp_entries, int tmp_quad, int tmp_key_quad,
                                                             int64_t* __restrict__ out, int32_t* __restrict__ d_err) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < tmp_entries; e += stride) {
     const int64_t* src = tmp + e * tmp_quad;
-    if (src[0] == kEmptyKey64) continue;
-    const int64_t idx = src[0];
+    int64_t idx;
+    if (ps.mode == 2) {
+      const bool empty = tmp_key_quad ? src[0] == kEmptyKey64 : src[ps.tmp_idx_target] == ps.tmp_init;
+      if (empty) continue;
+      idx = e;
+    } else {
+      if (src[0] == kEmptyKey64) continue;
+      idx = src[0];
+    }
     if (idx < 0 || idx >= p.entry_count) {
       atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
       continue;
@@ -603,7 +612,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_perfect(PackSpec ps, DevPlan 
     int64_t* slots = row + p.key_quad;
     for (int j = 0; j < p.slot_count; ++j) {
       const int sj = ps.slot_src[j];
-      slots[j] = sj >= 0 ? src[1 + sj] : orig[-(sj + 1)];
+      slots[j] = sj >= 0 ? src[tmp_key_quad + sj] : orig[-(sj + 1)];
     }
   }
 }
@@ -814,11 +823,11 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 }
 
 hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,
-                              int tmp_quad, int64_t* out, int32_t* d_err, hipStream_t s) {
+                              int tmp_quad, int tmp_key_quad, int64_t* out, int32_t* d_err, hipStream_t s) {
   if (tmp_entries <= 0) return hipSuccess;
-  if (ps.mode == 1) {
+  if (ps.mode >= 1) {
     hipLaunchKernelGGL(k_unpack_perfect, dim3(grid_for(tmp_entries)), dim3(kBlock), 0, s, ps, p, tmp, tmp_entries,
-                       tmp_quad, out, d_err);
+                       tmp_quad, tmp_key_quad, out, d_err);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(k_unpack_emit, dim3(grid_for(tmp_entries)), dim3(kBlock), 0, s, ps, p, tmp, tmp_entries, out,

@@ -855,21 +855,24 @@ def test_packed_multi_column_route_at_scale(torch_cuda, oracle, passes, monkeypa
 
 
 @pytest.mark.parametrize("name", ["multi_perfect_2col_keyed", "multi_perfect_2col_keyless", "multi_perfect_3col",
-                                  "multi_perfect_nullable_translate",
+                                  "multi_perfect_nullable_translate", "multi_perfect_keyless_nullable",
+                                  "enc_group_date16_dict8_multi",
                                   "enc_group_dict16_unsigned", "enc_group_fixed16_nullable_key"])
 def test_packed_route_on_perfect_layouts(torch_cuda, oracle, name):
-    """Perfect-hash tables that do not fit LDS (single- or multi-column keys) through the
-    partitioned family: the entry index is the packed key, the finished groups are written to
-    their index-aligned rows with the translated key columns and the projected-key slots
-    restored.  Index-aligned, bit-exact against the oracle (fp64 sums within 1e-9)."""
+    """Perfect-hash tables through the packed-index route: tables beyond LDS size (single- or
+    multi-column keys) via the partitioned family, small multi-column tables via the LDS
+    perfect-hash kernel on the index; the finished groups are written to their index-aligned rows
+    with the translated key columns and the projected-key slots restored.  Index-aligned,
+    bit-exact against the oracle (fp64 sums within 1e-9)."""
     from heavydb_amd.executor import Executor
     case = next(c for c in CASES if c.name == name)
     q, want, code = oracle.execute(case.ra.to_plan(), case.frags, case.inner, None, n_threads=2)
-    assert code == 0 and q.desc_type == capi.GROUP_BY_PERFECT_HASH and q.entry_count * q.row_size > 64 * 1024
+    assert code == 0 and q.desc_type == capi.GROUP_BY_PERFECT_HASH
+    assert q.entry_count * q.row_size > 64 * 1024 or q.group_col_count > 1
     frag_t, inner_t = _upload(torch_cuda, case)
     rs = Executor(0).executeWorkUnit(case.ra, _fetch_result(case, frag_t, inner_t), allow_retry=False,
                                      kernel_variant=2)
-    assert rs.report.kernel_name.decode() in ("k_part_scatter", "k_baseline_direct", "k_generic")
+    assert rs.report.kernel_name.decode() in ("k_part_scatter", "k_baseline_direct", "k_generic", "k_perfect_lds")
     qmd_equal(q, rs.getQueryMemDesc())
     compare_buffers(q, want, rs.getStorage(), case.fp_rtol)
     compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), case.fp_rtol)
