@@ -229,7 +229,8 @@ def main():
     try:
         with open(args.traffic_json) as f:
             tj = json.load(f).get(kname)
-        if tj and k_n:
+        # the committed PMC passes were taken on the default workload (cfg3f) only
+        if tj and k_n and cfg == "cfg3f":
             rows_per_launch = sum(r.rows_scanned for r in reports) / k_n
             traffic = tj["hbm_bytes_per_row"] * rows_per_launch
     except Exception:
@@ -242,6 +243,8 @@ def main():
         verify = {"groups": int(ival.shape[0])}
         if cfg in ("cfg3", "cfg3f"):
             verify["sum_count"] = int(ival[:, 1].sum())
+        if cfg == "cfg4":
+            verify["slots"] = [int(x) for x in ival[0]]
 
     out = {
         "metric": "rows/sec, filtered GROUP BY (key, COUNT(*), AVG(f64)) on 10 B int64-key rows",

@@ -929,22 +929,32 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   FragView fv{d_cols, d_rows, in->col_buffers, in->num_rows, nf, nc, total_rows, max_frag_rows};
 
   // ---- plan-time kernel selection (a fixed family; no JIT)
-  enum { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM } kind = K_GENERIC;
+  enum { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART } kind = K_GENERIC;
   if (!o.force_generic && nf > 0) {
     if (scan_count_eligible(d, fv)) kind = K_SCAN_COUNT;
     else if (perfect_lds_eligible(d, fv)) kind = K_PERFECT_LDS;
     else if (baseline_fast_eligible(d, fv)) kind = K_BASELINE_FAST;
     else if (join_sum_eligible(d, fv)) kind = K_JOIN_SUM;
+    // semi-join + aggregate over a large fact table: radix-partitioned probe (bitmap slices in
+    // LDS) instead of one random bitmap read per row; kernel_variant 1 / 2 force either member
+    if (kind == K_JOIN_SUM && o.kernel_variant != 1 && join_part_supported(d, fv, n_cus) &&
+        (o.kernel_variant == 2 || total_rows >= ((int64_t)64 << 20)))
+      kind = K_JOIN_PART;
   }
 
   tr.mark("setup done");
   int64_t scratch_bytes = 0;
   int64_t scratch_cap = o.scratch_bytes;
-  if (kind == K_BASELINE_FAST) {
+  if (kind == K_BASELINE_FAST || kind == K_JOIN_PART) {
     // default cap: 32 GB, halved while the device cannot provide it (the planner then cuts
     // the input into more chunks)
     for (;;) {
-      scratch_bytes = baseline_fast_scratch_bytes(d, fv, o.kernel_variant, scratch_cap, n_cus);
+      scratch_bytes = kind == K_JOIN_PART ? join_part_scratch_bytes(d, fv, n_cus, scratch_cap)
+                                          : baseline_fast_scratch_bytes(d, fv, o.kernel_variant, scratch_cap, n_cus);
+      if (kind == K_JOIN_PART && scratch_bytes == 0) {  // no plan within this cap: direct probe
+        kind = K_JOIN_SUM;
+        break;
+      }
       if (scratch_bytes <= ctx.scratch_bytes) break;
       if (ctx.scratch) (void)hipFree(ctx.scratch);
       ctx.scratch = nullptr;
@@ -986,6 +996,10 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
       case K_JOIN_SUM:
         HIP_TRY(launch_join_sum(d, fv, res->buf, n_cus, s, &st));
         break;
+      case K_JOIN_PART:
+        HIP_TRY(launch_join_partitioned(d, fv, res->buf, d_err, ctx.scratch, ctx.scratch_bytes, scratch_cap, n_cus,
+                                        s, &st));
+        break;
       default:
         st.kernel_name = "k_generic";
         st.n_launches = 1;
@@ -1008,6 +1022,14 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   tr.mark("synchronized");
   st.spilled_rows = (int64_t)h_spills;
   if (h_err[1] && tr.on) std::fprintf(stderr, "[mi355q] partitioned family gave up (code %d, spills %u): re-running with the direct kernel\n", h_err[1], h_spills);
+  if (h_err[1] && kind == K_JOIN_PART) {
+    // the partitioned probe ran out of spill space (extreme skew): redo with the direct probe
+    HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
+    HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+    HIP_TRY(launch_join_sum(d, fv, res->buf, n_cus, s, &st));
+    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
   if (h_err[1] && kind == K_BASELINE_FAST) {
     // the partitioned family ran out of spill space (extreme skew): redo the step with the
     // direct-atomic member of the same family

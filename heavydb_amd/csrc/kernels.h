@@ -150,6 +150,14 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                                        int64_t cap_bytes, int n_cus, hipStream_t s,
                                        LaunchStats* st);
 
+// radix join probe (kernels_part.hip): non-grouped INNER semi-join + COUNT(*) / SUM(fact col) with
+// the fact rows partitioned by key range so that every partition probes a bitmap slice in LDS
+bool join_part_supported(const DevPlan& p, const FragView& fv, int n_cus);
+int64_t join_part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes);
+hipError_t launch_join_partitioned(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err,
+                                   void* scratch, int64_t scratch_bytes, int64_t cap_bytes, int n_cus,
+                                   hipStream_t s, LaunchStats* st);
+
 // ---- ORDER BY one target LIMIT k on the device (kernels_sort.hip)
 int64_t topk_scratch_bytes(int64_t entry_count);
 int topk_max_k();

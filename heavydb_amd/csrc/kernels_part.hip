@@ -188,6 +188,7 @@ struct ScatterArgs {
   int32_t n_cand;       // heavy-hitter candidate slots (power of two)
   int32_t val_nullable;
   int64_t null_bits;
+  int64_t kmin;         // DIRECT partitioning (join probes): partition = (key - kmin) / S1
 };
 
 template <typename FT, typename VT>
@@ -248,6 +249,14 @@ MQ_D void store_rec_nt(Rec* dst, const Rec& r) {
   x.z = (int)(uint32_t)r.val;
   x.w = (int)(uint32_t)((uint64_t)r.val >> 32);
   __builtin_nontemporal_store(x, (v4i32_t*)dst);
+}
+
+MQ_D Rec load_rec_nt(const Rec* src) {
+  const v4i32_t x = __builtin_nontemporal_load((const v4i32_t*)src);
+  Rec r;
+  r.key = (int64_t)(((uint64_t)(uint32_t)x.y << 32) | (uint64_t)(uint32_t)x.x);
+  r.val = (int64_t)(((uint64_t)(uint32_t)x.w << 32) | (uint64_t)(uint32_t)x.z);
+  return r;
 }
 
 // Cooperative flush of 128-byte segments: `need` marks the lanes whose own segment (index
@@ -382,7 +391,10 @@ MQ_D void hot_apply(int op, int64_t* s, int64_t vb, bool is_null) {
   }
 }
 
-template <typename FT, typename VT>
+// DIRECT = false: records are partitioned by their home slot in the group-by table (hash);
+// DIRECT = true: by key range, `(key - kmin) / S1`, keys outside [kmin, kmin + hm.d) are dropped —
+// the partitions of a radix join probe (k_part_join), whose bitmap slices then fit LDS.
+template <typename FT, typename VT, bool DIRECT = false>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows, int n_frags,
     int n_cols, RangeFilter flt, int kcol, int vcol, ScatterArgs g, Rec* __restrict__ scratch,
@@ -481,7 +493,8 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
         bool park = false;
         uint32_t p = 0, s = 0;
         int64_t vb = 0;
-        if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i))) {
+        if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i)) &&
+            (!DIRECT || (uint64_t)cur.k.v[i] - (uint64_t)g.kmin < (uint64_t)g.hm.d)) {
           const int64_t key = cur.k.v[i];
           const uint32_t h = murmur3_u64((uint64_t)key);
           vb = val_bits_of<VT>(quad_get(cur.v, i));
@@ -512,7 +525,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
             }
           }
           if (!folded) {
-            p = part_of(g.hm, home_from_hash(g.hm, h));
+            p = part_of(g.hm, DIRECT ? (uint32_t)((uint64_t)key - (uint64_t)g.kmin) : home_from_hash(g.hm, h));
             s = atomicAdd(&cursor[p], 1u);
             if (s >= g.cap) spill_raw(sl, g, sp_blk, key, vb);  // run full
             else park = !try_stage(key, vb, p, s);
@@ -1148,6 +1161,129 @@ int64_t op_identity(int op) {
   }
 }
 
+// ------------------------------------------------------------------------- radix join probe
+// Semi-join + aggregate (`SELECT SUM(fact.v), COUNT(*) FROM fact JOIN dim ON fact.k = dim.k`, the
+// inner side reduced to the presence bitmap of its perfect table): a direct probe of a 12.5 MB
+// bitmap is bound by ~7 x 10^10 random reads/s (cfg4).  Partitioning the fact rows by key range
+// first makes every partition's bitmap slice fit LDS, so the probes never leave the CU:
+//   phase 1  k_part_scatter<.., DIRECT>   16 B read + 16 B written per row
+//   phase 2  k_part_join                  16 B read per row, LDS bit test, register accumulators
+struct JoinPartArgs {
+  int32_t P, B;
+  uint32_t cap, S1;        // run capacity; keys per partition (multiple of 32)
+  int64_t kmin;
+  uint64_t range;          // max - min + 1
+  const uint32_t* bitmap;  // 1 bit per key of [kmin, kmin + range)
+  int64_t bm_words;
+  int32_t n_slots;
+  int32_t op[4];           // per output slot: 0 COUNT(*), 1 SUM(fact value)
+  int64_t null_sum;        // NULL_BIGINT: skipped by the (non-grouped) SUM, and its slot's sentinel
+};
+
+// block-wide sums of the three accumulators, then one merge per output slot per workgroup
+MQ_D void join_part_epilogue(const JoinPartArgs& a, long long sum, unsigned long long n_match,
+                             unsigned long long n_nn, int64_t* __restrict__ out, long long* s_red) {
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off, 64);
+    n_match += __shfl_down(n_match, off, 64);
+    n_nn += __shfl_down(n_nn, off, 64);
+  }
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_red[wave * 3 + 0] = sum;
+    s_red[wave * 3 + 1] = (long long)n_match;
+    s_red[wave * 3 + 2] = (long long)n_nn;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long t_sum = 0, t_match = 0, t_nn = 0;
+    for (int w = 0; w < n_waves; ++w) {
+      t_sum += s_red[w * 3];
+      t_match += s_red[w * 3 + 1];
+      t_nn += s_red[w * 3 + 2];
+    }
+    for (int j = 0; j < a.n_slots; ++j) {
+      if (a.op[j] == 0) {
+        if (t_match) atomicAdd((unsigned long long*)(out + j), (unsigned long long)t_match);
+      } else if (t_nn) {
+        // the slot is NULL until the first non-NULL contribution (non-grouped SUM, skip_val)
+        int64_t old = MQ_LOAD64(out + j);
+        for (;;) {
+          const int64_t nv = old == a.null_sum ? t_sum : old + t_sum;
+          const int64_t seen = (int64_t)MQ_CAS64(out + j, old, nv);
+          if (seen == old) break;
+          old = seen;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(kPartBlock) void k_part_join(JoinPartArgs a, const Rec* __restrict__ scratch,
+                                                           const uint32_t* __restrict__ cnt,
+                                                           int64_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  uint32_t* s_bm = (uint32_t*)smem_raw;                     // [S1 / 32]
+  long long* s_red = (long long*)(smem_raw + (a.S1 >> 3));  // [16 waves x 3]
+  const int t = threadIdx.x;
+  const uint32_t nw = a.S1 >> 5;
+  long long sum = 0;
+  unsigned long long n_match = 0, n_nn = 0;
+  for (int p = blockIdx.x; p < a.P; p += gridDim.x) {
+    const int64_t w0 = ((int64_t)p * a.S1) >> 5;
+    for (uint32_t i = t; i < nw; i += kPartBlock) s_bm[i] = w0 + i < a.bm_words ? a.bitmap[w0 + i] : 0u;
+    __syncthreads();
+    const int64_t base = a.kmin + (int64_t)p * a.S1;
+    for (int b = 0; b < a.B; ++b) {
+      const uint32_t n = cnt[(size_t)p * a.B + b];
+      const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
+      for (uint32_t i0 = 0; i0 < n; i0 += 4 * kPartBlock) {
+        Rec r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // four independent 16-byte loads in flight per lane
+          const uint32_t i = i0 + u * kPartBlock + t;
+          r[u] = i < n ? load_rec_nt(run + i) : Rec{base - 1, 0};
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint32_t x = (uint32_t)(r[u].key - base);
+          if (x < a.S1 && ((s_bm[x >> 5] >> (x & 31)) & 1u)) {
+            ++n_match;
+            if (r[u].val != a.null_sum) {
+              sum += r[u].val;
+              ++n_nn;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  join_part_epilogue(a, sum, n_match, n_nn, out, s_red);
+}
+
+// records that overflowed their runs and the partial rows of heavy-hitter keys: probe the global
+// bitmap (entries: key, SUM partial, COUNT partial, COUNT_NN partial)
+__global__ __launch_bounds__(256) void k_join_spill(JoinPartArgs a, SpillList sl, int64_t* __restrict__ out) {
+  __shared__ long long s_red[4 * 3];
+  uint32_t n = *sl.count;
+  if (n > sl.cap) n = sl.cap;
+  long long sum = 0;
+  unsigned long long n_match = 0, n_nn = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int64_t* e = sl.entries + (size_t)i * sl.stride;
+    const int64_t key = e[0];
+    if (key == kEmptyKey64) continue;
+    const uint64_t off = (uint64_t)key - (uint64_t)a.kmin;
+    if (off < a.range && ((a.bitmap[off >> 5] >> (off & 31)) & 1u)) {
+      sum += e[1];
+      n_match += (unsigned long long)e[2];
+      n_nn += (unsigned long long)e[3];
+    }
+  }
+  join_part_epilogue(a, sum, n_match, n_nn, out, s_red);
+}
+
 struct PartPlanHost {
   PartGeom g;
   PartSlots ps;
@@ -1485,6 +1621,190 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     std::fprintf(stderr, "[mi355q] phase 2 Mcycles per workgroup: init %.3f  merge-load %.3f  records %.3f  emit %.3f  empties %.3f | spills %u\n",
                  h_dbg[0] / wg / 1e6, h_dbg[1] / wg / 1e6, h_dbg[2] / wg / 1e6, h_dbg[3] / wg / 1e6, h_dbg[4] / wg / 1e6, h_sp);
   }
+  return hipSuccess;
+}
+
+// ---------------------------------------------------------------- radix join probe: host side
+namespace {
+
+struct JoinPartHost {
+  ScatterArgs sa;
+  JoinPartArgs ja;
+  int64_t chunk_rows, rec_bytes, cnt_bytes, scratch_bytes;
+  size_t lds1, lds2;
+  uint32_t spill_cap;
+  int vcol;  // fact value column or -1
+};
+
+// the plan shapes this family takes: non-grouped, INNER one-to-one perfect join on a NOT NULL
+// int64 key with the presence bitmap available, targets COUNT(*) / SUM(fact int64 NOT NULL col)
+bool make_join_part_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scratch_cap, JoinPartHost* out) {
+  JoinPartHost& h = *out;
+  if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col < 0 || p.n_quals != 0) return false;
+  if (p.join_hash_type != 0 || !p.join_bitmap || p.join_n_keys != 1 || p.join_kind != MI355Q_JOIN_INNER) return false;
+  if (p.join_type != MI355Q_INT64 || p.join_nullable || p.n_targets > 4) return false;
+  if (fv.max_frag_rows > 0xfff00000ll) return false;
+  h.vcol = -1;
+  h.ja = JoinPartArgs{};
+  h.ja.n_slots = p.n_targets;
+  for (int i = 0; i < p.n_targets; ++i) {
+    const DevTarget& t = p.targets[i];
+    if (t.slot != i) return false;
+    if (t.agg == MI355Q_COUNT && t.col < 0) {
+      h.ja.op[i] = 0;
+    } else if (t.agg == MI355Q_SUM && t.table == 0 && t.arg_type == MI355Q_INT64 && !t.arg_nullable) {
+      if (h.vcol >= 0 && h.vcol != t.col) return false;
+      h.vcol = t.col;
+      h.ja.op[i] = 1;
+    } else {
+      return false;
+    }
+  }
+  if (!all_aligned16(fv, p.join_col) || (h.vcol >= 0 && !all_aligned16(fv, h.vcol))) return false;
+  const __int128 range128 = (__int128)p.join_max - (__int128)p.join_min + 1;
+  if (range128 < 64 || range128 >= ((__int128)1 << 32)) return false;
+  const uint64_t range = (uint64_t)range128;
+  // partitions: at least one per CU, bitmap slice within ~120 KB of LDS
+  uint32_t P = 16;
+  auto s1_of = [&](uint32_t parts) { return (uint32_t)((((range + parts - 1) / parts) + 31) & ~(uint64_t)31); };
+  while (P < 1024 && (P < (uint32_t)n_cus || s1_of(P) / 8 > 120 * 1024)) P <<= 1;
+  const uint32_t S1 = s1_of(P);
+  if (S1 / 8 > 150 * 1024 || S1 < 32) return false;
+  ScatterArgs& sa = h.sa;
+  sa = ScatterArgs{};
+  sa.P = (int32_t)P;
+  sa.L = kStageRecs / P;
+  sa.lgL = 0;
+  while ((1u << sa.lgL) < sa.L) ++sa.lgL;
+  sa.B = n_cus;
+  sa.hm.d = (uint32_t)range;
+  sa.hm.S1 = S1;
+  sa.hm.S2 = S1;
+  sa.hm.R = 1;
+  sa.hm.d_rcp = (uint32_t)(((uint64_t)1 << 32) / sa.hm.d);
+  sa.hm.s1_rcp = (uint32_t)(((uint64_t)1 << 32) / S1);
+  sa.kmin = p.join_min;
+  // partial rows of spilled / heavy-hitter records: SUM, COUNT, COUNT of non-NULL values
+  sa.ns_int = 3;
+  sa.ops_packed = (uint32_t)SO_SUM_I | ((uint32_t)SO_COUNT << 4) | ((uint32_t)SO_COUNT_NN << 8);
+  sa.val_nullable = 1;  // the non-grouped SUM skips NULL_BIGINT even on a NOT NULL column
+  sa.null_bits = INT64_MIN;
+  int64_t chunk_rows = fv.total_rows > 0 ? fv.total_rows : 1;
+  if (chunk_rows > 0xfff00000ll) chunk_rows = 0xfff00000ll;
+  if (scratch_cap <= 0) scratch_cap = (int64_t)32 << 30;
+  for (;;) {
+    const double per_run = (double)chunk_rows / ((double)P * sa.B);
+    uint64_t cap = (uint64_t)(per_run * 1.2 + 6.0 * __builtin_sqrt(per_run + 1.0)) + sa.L;
+    cap = (cap + sa.L - 1) / sa.L * sa.L;
+    const bool too_many = cap > 0x7fffffffull || (uint64_t)P * sa.B * cap >= ((uint64_t)1 << 32);
+    int64_t spill_cap = chunk_rows / 16;
+    if (spill_cap < (int64_t)kSpillMin) spill_cap = kSpillMin;
+    if (spill_cap > 0x7fffffffll) spill_cap = 0x7fffffffll;
+    h.rec_bytes = (int64_t)P * sa.B * (int64_t)cap * (int64_t)sizeof(Rec);
+    h.cnt_bytes = ((int64_t)P * sa.B * 4 + 255) & ~255ll;
+    const int64_t spill_bytes = 256 + spill_cap * 8 * (int64_t)(1 + sa.ns_int);
+    h.scratch_bytes = h.rec_bytes + h.cnt_bytes + spill_bytes;
+    if (!too_many && (h.scratch_bytes <= scratch_cap || chunk_rows <= fv.max_frag_rows)) {
+      sa.cap = (uint32_t)cap;
+      h.spill_cap = (uint32_t)spill_cap;
+      break;
+    }
+    if (chunk_rows <= fv.max_frag_rows) return false;
+    chunk_rows = (int64_t)(chunk_rows * 0.9);
+    if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
+  }
+  h.chunk_rows = chunk_rows;
+  {
+    const size_t fixed = kStageRecs * sizeof(Rec) + (size_t)P * 12 + 48 + (size_t)kHotSlots * (8 + 8 * (size_t)sa.ns_int);
+    sa.n_cand = 2048;
+    while (sa.n_cand > 64 && fixed + (size_t)sa.n_cand * 4 > 160 * 1024) sa.n_cand >>= 1;
+    h.lds1 = fixed + (size_t)sa.n_cand * 4;
+    if (h.lds1 > 160 * 1024) return false;
+  }
+  h.lds2 = (size_t)(S1 / 8) + 16 * 3 * 8;
+  JoinPartArgs& ja = h.ja;
+  ja.P = (int32_t)P;
+  ja.B = sa.B;
+  ja.cap = sa.cap;
+  ja.S1 = S1;
+  ja.kmin = p.join_min;
+  ja.range = range;
+  ja.bitmap = p.join_bitmap;
+  ja.bm_words = (int64_t)((range + 31) / 32);
+  ja.null_sum = INT64_MIN;
+  return true;
+}
+
+}  // namespace
+
+bool join_part_supported(const DevPlan& p, const FragView& fv, int n_cus) {
+  JoinPartHost h;
+  return make_join_part_plan(p, fv, n_cus, (int64_t)32 << 30, &h);
+}
+
+int64_t join_part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes) {
+  JoinPartHost h;
+  if (!make_join_part_plan(p, fv, n_cus, cap_bytes, &h)) return 0;
+  return h.scratch_bytes + 64;
+}
+
+hipError_t launch_join_partitioned(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err,
+                                   void* scratch, int64_t scratch_bytes, int64_t cap_bytes, int n_cus,
+                                   hipStream_t s, LaunchStats* st) {
+  JoinPartHost h;
+  if (!make_join_part_plan(p, fv, n_cus, cap_bytes, &h)) return hipErrorInvalidValue;
+  if (h.scratch_bytes + 64 > scratch_bytes) return hipErrorInvalidValue;
+  Rec* recs = (Rec*)scratch;
+  uint32_t* cnt = (uint32_t*)((char*)scratch + h.rec_bytes);
+  char* spill_base = (char*)scratch + h.rec_bytes + h.cnt_bytes;
+  SpillList sl{(uint32_t*)spill_base, (int64_t*)(spill_base + 256), d_err, h.spill_cap, 1 + h.sa.ns_int};
+  st->kernel_name = "k_part_scatter";
+  st->variant = 2;
+  st->n_launches = 0;
+  (void)hipFuncSetAttribute((const void*)k_part_join, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds2);
+  RangeFilter flt = no_filter();
+  const int vcol = h.vcol < 0 ? 0 : h.vcol;
+  int ev_i = 0;
+  int f = 0;
+  while (f < fv.n_frags) {
+    int64_t rows = 0;
+    int f1 = f;
+    while (f1 < fv.n_frags && (f1 == f || rows + fv.h_num_rows[f1] <= h.chunk_rows)) {
+      rows += fv.h_num_rows[f1];
+      ++f1;
+    }
+    hipError_t e = hipMemsetAsync(spill_base, 0, 256, s);
+    if (e != hipSuccess) return e;
+    if (st->ev_pool && ev_i + 1 < st->n_ev) (void)hipEventRecord(st->ev_pool[ev_i], s);
+    const int8_t* const* cols = fv.d_cols + (size_t)f * fv.n_cols;
+    const int64_t* nrows = fv.d_num_rows + f;
+    if (h.vcol >= 0) {
+      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, int64_t, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
+      hipLaunchKernelGGL((k_part_scatter<none_t, int64_t, true>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
+                         nrows, f1 - f, fv.n_cols, flt, p.join_col, vcol, h.sa, recs, cnt, sl);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, none_t, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
+      hipLaunchKernelGGL((k_part_scatter<none_t, none_t, true>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
+                         nrows, f1 - f, fv.n_cols, flt, p.join_col, vcol, h.sa, recs, cnt, sl);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (st->ev_pool && ev_i + 1 < st->n_ev) {
+      (void)hipEventRecord(st->ev_pool[ev_i + 1], s);
+      ev_i += 2;
+    }
+    st->n_launches += 1;
+    const int grid2 = h.ja.P < n_cus ? h.ja.P : n_cus;
+    hipLaunchKernelGGL(k_part_join, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.ja, recs, cnt, out);
+    hipLaunchKernelGGL(k_join_spill, dim3(256), dim3(256), 0, s, h.ja, sl, out);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    f = f1;
+  }
+  st->spill_counter32 = (uint32_t*)spill_base;
+  st->n_events_used = ev_i;
   return hipSuccess;
 }
 

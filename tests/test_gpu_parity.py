@@ -913,3 +913,64 @@ def test_compact_slots_topk_and_shards(torch_cuda, oracle):
     allrows = np.concatenate(merged)
     full[:allrows.shape[0]] = allrows
     compare_buffers(q, want, full.reshape(-1))
+
+
+@pytest.mark.parametrize("shape", ["uniform", "hot_key", "count_only"])
+def test_radix_join_probe(torch_cuda, oracle, shape):
+    """Semi-join + SUM / COUNT with the fact rows partitioned by key range (k_part_scatter in
+    DIRECT mode -> k_part_join probing bitmap slices in LDS): equal to the oracle on 2 M rows,
+    and bit-identical to the direct-probe member (k_join_sum) on 40 M rows — including a key
+    that owns a third of the rows (heavy-hitter table / spill list -> k_join_spill), keys outside
+    the inner range on both sides, NULL_BIGINT values (skipped by the non-grouped SUM) and inner
+    keys that are absent (holes in the bitmap)."""
+    from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, HashJoin, InputColDescriptor,
+                                      RelAlgExecutionUnit, TargetExpr)
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    m = 3_000_000
+    dim = np.sort(rng.choice(np.arange(1000, 1000 + 2 * m, dtype=np.int64), m, replace=False))  # half the range absent
+    dmin, dmax = int(dim.min()), int(dim.max())
+    dk = torch.from_numpy(dim).cuda()
+    hj = HashJoin.getInstance(int(dk.data_ptr()), m, capi.INT64, ExpressionRange(True, dmin, dmax))
+    assert hj.info()["hash_type"] == 0
+
+    def table(n):
+        k = rng.integers(dmin - 5000, dmax + 5000, n).astype(np.int64)
+        if shape == "hot_key":
+            k[rng.random(n) < 0.33] = dim[12345]
+        v = rng.integers(-10**9, 10**9, n).astype(np.int64)
+        v[rng.random(n) < 0.01] = -2**63
+        return k, v
+    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, dmin - 5000, dmax + 5000)),
+             InputColDescriptor(capi.INT64, False, ExpressionRange(True, -10**9, 10**9))]
+    inner = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, dmin, dmax))]
+    targets = [TargetExpr(capi.COUNT)] if shape == "count_only" else \
+        [TargetExpr(capi.SUM, 1), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1)]
+    ra = RelAlgExecutionUnit(descs, targets, inner_col_descs=inner, join_outer_col=0, join_table=hj)
+    ex = Executor(0)
+
+    def run(k, v, variant):
+        n = len(k)
+        cuts = [0, n // 2 + 4, n]
+        dev = [torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()]
+        fr = FetchResult([[int(t.data_ptr()) + cuts[i] * 8 for t in dev] for i in range(2)],
+                         [cuts[i + 1] - cuts[i] for i in range(2)], [int(dk.data_ptr())], m, keepalive=dev + [dk])
+        rs = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=variant)
+        return rs, cuts
+    k, v = table(2_000_000)
+    rs, cuts = run(k, v, 2)
+    assert rs.report.kernel_name.decode() == "k_part_scatter"
+    oj = oracle.OracleJoin(dim, capi.INT64, dmin, dmax)
+    ra.join_table = None
+    q, want, code = oracle.execute(ra.to_plan(), [[k[cuts[i]:cuts[i + 1]], v[cuts[i]:cuts[i + 1]]] for i in range(2)],
+                                   [dim], oj, n_threads=2)
+    ra.join_table = hj
+    assert code == 0
+    compare_buffers(q, want, rs.getStorage())
+    k, v = table(40_000_000)
+    part, _ = run(k, v, 2)
+    direct, _ = run(k, v, 1)
+    assert part.report.kernel_name.decode() == "k_part_scatter" and direct.report.kernel_name.decode() == "k_join_sum"
+    assert np.array_equal(part.getStorage(), direct.getStorage())
+    matched = np.isin(k, dim)
+    assert int(part.getStorage().reshape(-1)[0 if shape == "count_only" else 1]) == int(matched.sum())
