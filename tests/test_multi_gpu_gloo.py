@@ -104,6 +104,19 @@ def _table(shape, seed=7):
                                          TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 2)],
                                  groupby_exprs=[0, 1], max_groups_buffer_entry_guess=30_000)
         cols = [k0, k1, val]
+    elif shape == "keyed_compact":  # COUNT(*)-only: 4-byte slots, 16-byte rows travel whole
+        key = (rng.integers(0, 9000, n) * 1000003 + 7).astype(np.int64)
+        descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, 8999 * 1000003 + 7))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT)], groupby_exprs=[0], max_groups_buffer_entry_guess=18_000)
+        cols = [key]
+    elif shape == "perfect_float":  # float slots: merged by the reduce rule, not by all_reduce
+        key = rng.integers(0, 300, n).astype(np.int32)
+        val = (rng.random(n) * 10.0).astype(np.float32)
+        descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 299)),
+                 InputColDescriptor(capi.FLOAT, False, ExpressionRange(True, 0, 0, False, 0.0, 10.0))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 1), TargetExpr(capi.MAX, 1),
+                                         TargetExpr(capi.COUNT)], groupby_exprs=[0])
+        cols = [key, val]
     elif shape == "perfect":
         key = rng.integers(0, 1000, n).astype(np.int32)
         val = rng.integers(-500_000, 500_001, n).astype(np.int64)
@@ -178,7 +191,8 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world", [2, 3])
-@pytest.mark.parametrize("shape", ["keyed", "keyed_two_columns", "perfect", "perfect_nullable", "non_grouped"])
+@pytest.mark.parametrize("shape", ["keyed", "keyed_two_columns", "keyed_compact", "perfect", "perfect_nullable",
+                                   "perfect_float", "non_grouped"])
 def test_merge_over_gloo(shape, world):
     import torch.multiprocessing as mp
     from oracle import oracle as orc
