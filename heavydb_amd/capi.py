@@ -217,6 +217,7 @@ SYMBOLS = [
     ("mi355q_result_row_count", C.c_int64, [C.c_void_p]),
     ("mi355q_result_fetch_rows", C.c_int32,
      [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
+    ("mi355q_result_to_columns", C.c_int32, [C.c_void_p, _P(C.c_void_p), C.c_int32, _P(C.c_int64), C.c_void_p]),
     ("mi355q_join_build", C.c_int32, [_P(JoinSpec), C.c_void_p, _P(C.c_void_p)]),
     ("mi355q_join_free", None, [C.c_void_p]),
     ("mi355q_join_key_shape", C.c_int32, [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),

@@ -417,6 +417,40 @@ int64_t mi355q_result_row_count(const mi355q_result* r) {
   return (int64_t)h;
 }
 
+int32_t mi355q_result_to_columns(const mi355q_result* r, void* const* cols_dev, int32_t n_cols, int64_t* n_rows,
+                                 void* stream) {
+  if (!r || !cols_dev || !n_rows || n_cols != r->qmd.n_targets) return MI355Q_ERR_INVALID_PLAN;
+  if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return MI355Q_ERR_UNSUPPORTED;  // one row: fetch_rows
+  const mi355q_qmd& q = r->qmd;
+  if (q.entry_count >= ((int64_t)1 << 31)) return MI355Q_ERR_UNSUPPORTED;
+  for (int t = 0; t < n_cols; ++t)
+    if (!cols_dev[t]) return MI355Q_ERR_INVALID_PLAN;
+  DeviceGuard g(r->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t rows = mi355q_result_row_count(r);
+  if (rows < 0) return MI355Q_ERR_HIP;
+  *n_rows = rows;
+  if (rows == 0) return MI355Q_OK;
+  ColumnarSpec cs{};
+  for (int t = 0; t < q.n_targets; ++t) {
+    cs.null_pat[t] = q.target_null[t];
+    cs.is_fp[t] = q.target_is_fp[t];
+  }
+  DevWord scratch;
+  const size_t flag_bytes = ((size_t)q.entry_count * 4 + 255) & ~(size_t)255;
+  const size_t tile_bytes = ((size_t)(q.entry_count / 2048 + 2) * 8 + 255) & ~(size_t)255;
+  const size_t tab_bytes = sizeof(void*) * (size_t)q.n_targets;
+  HIP_TRY(hipMalloc(&scratch.p, 2 * flag_bytes + tile_bytes + tab_bytes));
+  char* base = (char*)scratch.p;
+  int64_t** d_cols = (int64_t**)(base + 2 * flag_bytes + tile_bytes);
+  HIP_TRY(hipMemcpyAsync(d_cols, cols_dev, tab_bytes, hipMemcpyHostToDevice, s));
+  HIP_TRY(launch_to_columns(r->dplan, q.idx_target_as_key, cs, r->buf, (int32_t*)base, (int32_t*)(base + flag_bytes),
+                            (int64_t*)(base + 2 * flag_bytes), d_cols, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return MI355Q_OK;
+}
+
 int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t descending,
                            int32_t nulls_first, int64_t k, void* out_rows_dev, int64_t* n_rows,
                            void* stream) {

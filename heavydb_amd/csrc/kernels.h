@@ -85,6 +85,16 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,
                               int tmp_quad, int tmp_key_quad, int64_t* out, int32_t* d_err, hipStream_t s);
 
+// dense columns of the non-empty entries (ColumnarResults): flags/offsets are int32[entries] scratch,
+// tile_scratch holds (entries / 2048 + 2) int64; cols = device array of n_targets column pointers
+struct ColumnarSpec {
+  int64_t null_pat[MI355Q_MAX_TARGETS];
+  int32_t is_fp[MI355Q_MAX_TARGETS];
+};
+hipError_t launch_to_columns(const DevPlan& p, int idx_target_as_key, const ColumnarSpec& cs, const int64_t* buf,
+                             int32_t* flags, int32_t* offsets, int64_t* tile_scratch, int64_t* const* cols,
+                             hipStream_t s);
+
 // compact COUNT(*)-only layouts: the finished 8-byte-slot table -> its 4-byte-slot image
 hipError_t launch_narrow_slots(const int64_t* wide, int wide_quad, int key_quad, int slot_count,
                                int narrow_quad, int64_t entries, int64_t* out, hipStream_t s);

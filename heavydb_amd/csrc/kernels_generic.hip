@@ -502,6 +502,47 @@ __global__ __launch_bounds__(kBlock) void k_scan_write_offsets(const int32_t* __
   }
 }
 
+// ---- ColumnarResults: dense per-target columns of the non-empty entries ------------------------
+__global__ __launch_bounds__(kBlock) void k_mark_live(DevPlan p, int idx_target_as_key, const int64_t* __restrict__ buf,
+                                                       int32_t* __restrict__ flags) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < p.entry_count; e += stride) {
+    flags[e] = is_empty_row(p, buf + e * p.row_quad, idx_target_as_key) ? 0 : 1;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_columns_write(DevPlan p, ColumnarSpec cs, const int64_t* __restrict__ buf,
+                                                           const int32_t* __restrict__ offsets,
+                                                           int64_t* const* __restrict__ cols) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < p.entry_count; e += stride) {
+    const int32_t dst = offsets[e];
+    if (dst < 0) continue;
+    const int64_t* row = buf + e * p.row_quad;
+    for (int t = 0; t < p.n_targets; ++t) {
+      const DevTarget& tg = p.targets[t];
+      int64_t v;
+      if (tg.agg == MI355Q_PROJECT_KEY && tg.slot < 0) {
+        v = row_key_component(row, p.key_width, tg.key_idx);
+      } else {
+        const int64_t* s = row + p.key_quad;
+        const int64_t raw = p.slot_width == 4 ? (int64_t)((const int32_t*)s)[tg.slot] : s[tg.slot];
+        if (tg.agg == MI355Q_AVG) {  // pair_to_double
+          const int64_t cnt = s[tg.slot + 1];
+          const double sum = tg.arg_f32 ? (double)bits_flt((int32_t)raw) : tg.arg_fp ? bits_dbl(raw) : (double)raw;
+          v = cnt == 0 ? kNullDoubleBits : dbl_bits(sum / (double)cnt);
+        } else if (tg.arg_f32 && tg.agg != MI355Q_COUNT) {  // float result, widened
+          const bool is_null = tg.skip_null && (int32_t)raw == (int32_t)cs.null_pat[t];
+          v = is_null ? kNullDoubleBits : dbl_bits((double)bits_flt((int32_t)raw));
+        } else {
+          v = raw;  // integers and doubles already carry their inline NULL sentinel
+        }
+      }
+      cols[t][dst] = v;
+    }
+  }
+}
+
 // ---- 8-byte -> 4-byte slots (compact COUNT(*)-only layouts) --------------------------------
 __global__ __launch_bounds__(kBlock) void k_narrow_slots(const int64_t* __restrict__ wide, int wide_quad,
                                                           int key_quad, int slot_count, int narrow_quad,
@@ -802,6 +843,21 @@ hipError_t launch_join_one_to_many(const JoinKeyCols& kc, int64_t n, int hash_ty
     hipLaunchKernelGGL(k_join_fill_ids, dim3(grid_for(n)), dim3(kBlock), 0, s, kc, n, hash_type, tab, entries,
                        min_key, max_key, offsets, counts, payloads);
   }
+  return hipGetLastError();
+}
+
+hipError_t launch_to_columns(const DevPlan& p, int idx_target_as_key, const ColumnarSpec& cs, const int64_t* buf,
+                             int32_t* flags, int32_t* offsets, int64_t* tile_scratch, int64_t* const* cols,
+                             hipStream_t s) {
+  const int64_t n = p.entry_count;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_mark_live, dim3(grid_for(n)), dim3(kBlock), 0, s, p, idx_target_as_key, buf, flags);
+  const int64_t n_tiles = (n + kScanTile - 1) / kScanTile;
+  hipLaunchKernelGGL(k_scan_tile_sums, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, flags, n, tile_scratch);
+  hipLaunchKernelGGL(k_scan_tile_offsets, dim3(1), dim3(kBlock), 0, s, tile_scratch, n_tiles);
+  hipLaunchKernelGGL(k_scan_write_offsets, dim3((unsigned)n_tiles), dim3(kBlock), 0, s, flags, n, tile_scratch,
+                     offsets);
+  hipLaunchKernelGGL(k_columns_write, dim3(grid_for(n)), dim3(kBlock), 0, s, p, cs, buf, offsets, cols);
   return hipGetLastError();
 }
 

@@ -322,6 +322,19 @@ class ResultSet:
         k = got.value
         return ival[:k], dval[:k], nul[:k]
 
+    def to_columns(self, torch):
+        """ColumnarResults on the device (ColumnarResults.cpp materializeAllColumnsGroupBy): one
+        dense int64 tensor per target holding the non-empty entries in entry order; floating-point
+        targets carry double bits (`.view(torch.float64)`), SQL NULL is the inline sentinel."""
+        q = self.getQueryMemDesc()
+        n = self.rowCount()
+        cols = [torch.empty(max(n, 1), dtype=torch.int64, device="cuda") for _ in range(q.n_targets)]
+        ptrs = (C.c_void_p * q.n_targets)(*[int(c.data_ptr()) for c in cols])
+        got = C.c_int64()
+        check(self._lib.mi355q_result_to_columns(self.handle, ptrs, q.n_targets, C.byref(got), None),
+              "result_to_columns")
+        return [c[:got.value] for c in cols], got.value
+
     def to_arrow(self, names: Optional[Sequence[str]] = None):
         """The rows as a pyarrow.Table — what ArrowResultSetConverter::convertToArrow
         (QueryEngine/ArrowResultSetConverter.cpp) produces from a ResultSet: one column per

@@ -385,6 +385,16 @@ int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t d
                            int32_t nulls_first, int64_t k, void* out_rows_dev, int64_t* n_rows,
                            void* stream);
 
+/* ColumnarResults for a grouped result, on the device (QueryEngine/ColumnarResults.cpp:1374-1600
+ * materializeAllColumnsGroupBy: locateAndCountEntries -> partial sums -> compactAndCopyEntries):
+ * the non-empty entries, in entry order, as one dense 8-byte column per target.  Integer targets
+ * are written as int64, floating-point ones as double (AVG = sum / count; FLOAT results widened),
+ * SQL NULL as the inline sentinel (mi355q_qmd.target_null for integers, NULL_DOUBLE for
+ * floating point).  cols_dev[t] must hold mi355q_result_row_count(r) values; *n_rows receives the
+ * row count.  The rows come out in the order mi355q_result_fetch_rows iterates them. */
+int32_t mi355q_result_to_columns(const mi355q_result* r, void* const* cols_dev, int32_t n_cols,
+                                 int64_t* n_rows, void* stream);
+
 /* ---- join hash tables ---- */
 typedef struct mi355q_join_spec {
   int32_t device_id;

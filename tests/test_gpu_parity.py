@@ -974,3 +974,31 @@ def test_radix_join_probe(torch_cuda, oracle, shape):
     assert np.array_equal(part.getStorage(), direct.getStorage())
     matched = np.isin(k, dim)
     assert int(part.getStorage().reshape(-1)[0 if shape == "count_only" else 1]) == int(matched.sum())
+
+
+@pytest.mark.parametrize("name", ["perfect_avg_keyless_idx1", "perfect_nullable_key_and_args", "baseline_nullable_args",
+                                  "multi_baseline_key32_3col_padded", "compact_perfect_nullable_int32_key",
+                                  "compact_baseline_key32", "float_baseline", "cond_aggs_perfect_keyless"])
+def test_columnar_results_on_device(torch_cuda, oracle, name):
+    """mi355q_result_to_columns (ColumnarResults: locate + count, prefix sums, compact + copy, on
+    the device) == the rows mi355q_result_fetch_rows materialises on the host, in the same order:
+    integers bit-exact, doubles bit-exact (same arithmetic), NULLs as inline sentinels."""
+    from heavydb_amd.executor import Executor
+    case = next(c for c in CASES if c.name == name)
+    frag_t, inner_t = _upload(torch_cuda, case)
+    rs = Executor(0).executeWorkUnit(case.ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+    q = rs.getQueryMemDesc()
+    cols, n = rs.to_columns(torch_cuda)
+    iv, dv, nu = rs.fetch()
+    assert n == rs.rowCount() == iv.shape[0] and n > 0
+    null_double = np.float64(2.2250738585072014e-308)
+    for t in range(q.n_targets):
+        c = cols[t].cpu().numpy()
+        isnull = nu[:, t].astype(bool)
+        if q.target_is_fp[t]:
+            d = c.view(np.float64)
+            assert np.array_equal(d[~isnull], dv[~isnull, t])
+            assert (d[isnull] == null_double).all()
+        else:
+            assert np.array_equal(c[~isnull], iv[~isnull, t])
+            assert (c[isnull] == q.target_null[t]).all()
