@@ -132,9 +132,9 @@ def compare_rows(q: capi.QMD, want, got, rtol: float = 1e-9):
     if q.desc_type == capi.GROUP_BY_BASELINE_HASH and wi.shape[0] > 1:
         def order(i, d):
             # integer columns first; rows that tie on them (no unique key projected) by the doubles
-            # rounded well above the fp tolerance
-            dr = np.where(np.isfinite(d), np.round(d / np.maximum(np.abs(d), 1e-300) * 1e6) *
-                          10.0 ** np.floor(np.log10(np.maximum(np.abs(d), 1e-300))), 0.0)
+            # rounded to single precision, i.e. well above the fp64 tolerance
+            with np.errstate(over="ignore"):
+                dr = np.where(np.isfinite(d), d, 0.0).astype(np.float32)
             keys = [dr[:, c] for c in range(d.shape[1])[::-1]] + [i[:, c] for c in range(i.shape[1])[::-1]]
             return np.lexsort(tuple(keys))
         ow, og = order(wi, wd), order(gi, gd)

@@ -1002,3 +1002,60 @@ def test_columnar_results_on_device(torch_cuda, oracle, name):
         else:
             assert np.array_equal(c[~isnull], iv[~isnull, t])
             assert (c[isnull] == q.target_null[t]).all()
+
+
+def test_hip_matches_oracle_on_random_plans(torch_cuda, oracle):
+    """The generator of tests/test_plan_fuzz.py (random tables x random plans: 0-3 group columns of
+    mixed widths / encodings, every aggregate kind, conditional aggregates, floats, with and
+    without ranges) through the HIP library with a random member choice (plan-time, direct /
+    row kernel, partitioned / packed routes) against the oracle."""
+    from heavydb_amd.executor import Executor, FetchResult, Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.test_plan_fuzz import INT_TYPES, _fuzz_table  # noqa: F401
+    torch = torch_cuda
+    rng = np.random.default_rng(4242)
+    ex = Executor(0)
+    ran = 0
+    for i in range(160):
+        n_rows = int(rng.integers(8, 3000))
+        descs, cols = _fuzz_table(rng, n_rows)
+        int_cols = [j for j, d in enumerate(descs) if d.type not in (capi.DOUBLE, capi.FLOAT)]
+        n_group = int(rng.integers(0, 4))
+        group = [int(x) for x in rng.choice(int_cols, size=min(n_group, len(int_cols)), replace=False)] if int_cols else []
+        targets = []
+        for _ in range(int(rng.integers(1, 5))):
+            k = int(rng.integers(0, 9))
+            col = int(rng.integers(0, len(descs)))
+            cond = Qual(int(rng.integers(0, len(descs))), [capi.LT, capi.GE, capi.NE][int(rng.integers(0, 3))], 0)
+            if k == 0 and group:
+                targets.append(TargetExpr(capi.PROJECT_KEY, int(rng.integers(0, len(group)))))
+            elif k <= 1:
+                targets.append(TargetExpr(capi.COUNT))
+            elif k == 2:
+                targets.append(TargetExpr(capi.COUNT, col))
+            elif k == 3:
+                targets.append(TargetExpr(capi.COUNT_IF, cond=cond))
+            elif k == 4:
+                targets.append(TargetExpr(capi.SUM_IF, col, cond=cond))
+            else:
+                targets.append(TargetExpr([capi.SUM, capi.AVG, capi.MIN, capi.MAX][k - 5], col))
+        quals = [Qual(int(rng.integers(0, len(descs))), capi.GE, -5)] if rng.integers(0, 2) else []
+        ra = RelAlgExecutionUnit(descs, targets, quals, group, max_groups_buffer_entry_guess=8192,
+                                 bigint_count=bool(rng.integers(0, 4) == 0))
+        cut = (n_rows // 2) & ~3
+        frags = [[c[:cut] for c in cols], [c[cut:] for c in cols]]
+        try:
+            q, want, code = oracle.execute(ra.to_plan(), frags, n_threads=2)
+        except capi.Mi355qError:
+            continue
+        if code != 0:
+            continue
+        dev = [[torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in f] for f in frags]
+        fr = FetchResult([[int(t.data_ptr()) for t in f] for f in dev], [len(f[0]) for f in frags], keepalive=dev)
+        variant = int(rng.integers(0, 3))
+        rs = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=variant,
+                                force_generic=bool(rng.integers(0, 5) == 0))
+        qmd_equal(q, rs.getQueryMemDesc())
+        compare_buffers(q, want, rs.getStorage(), 1e-9)
+        compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
+        ran += 1
+    assert ran > 100, ran

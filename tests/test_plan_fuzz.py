@@ -1,0 +1,193 @@
+"""Randomised cross-check of the two independent restatements of the layout decisions
+(GroupByAndAggregate::getColRangeInfo / get_keyless_info / QueryMemoryDescriptor::init /
+pick_target_compact_width / init_agg_val_vec): heavydb_amd/csrc/plan.cpp (product, through the
+host emulation library) against oracle/oracle.cpp, over a few thousand random plans — group columns
+1..4 of mixed widths and encodings, valid / invalid / bucketed ranges, every aggregate kind,
+g_bigint_count, tuple counts either side of UINT32_MAX."""
+import ctypes as C
+
+import numpy as np
+
+from heavydb_amd import capi
+from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
+                                  TargetExpr)
+from tests.helpers import emu_lib
+
+INT_TYPES = [capi.INT8, capi.INT16, capi.INT32, capi.INT64]
+WIDTH = {capi.INT8: 8, capi.INT16: 16, capi.INT32: 32, capi.INT64: 64}
+
+
+def _random_col(rng):
+    kind = rng.integers(0, 10)
+    nullable = bool(rng.integers(0, 2))
+    if kind == 0:
+        lo, hi = sorted(rng.uniform(-1e3, 1e3, 2))
+        return InputColDescriptor(capi.DOUBLE, nullable, ExpressionRange(True, 0, 0, bool(rng.integers(0, 2)) and nullable,
+                                                                         float(lo), float(hi)))
+    if kind == 1:
+        lo, hi = sorted(rng.uniform(-1e3, 1e3, 2))
+        return InputColDescriptor(capi.FLOAT, nullable, ExpressionRange(True, 0, 0, bool(rng.integers(0, 2)) and nullable,
+                                                                        float(lo), float(hi)))
+    t = INT_TYPES[rng.integers(0, 4)]
+    enc, logical = 0, 0
+    if kind == 2 and t != capi.INT64:
+        enc, logical = capi.ENC_FIXED, INT_TYPES[rng.integers(INT_TYPES.index(t) + 1, 4)]
+    elif kind == 3 and t in (capi.INT8, capi.INT16, capi.INT32):
+        enc = capi.ENC_DICT
+    elif kind == 4 and t in (capi.INT16, capi.INT32):
+        enc = capi.ENC_DATE_IN_DAYS
+    bits = WIDTH[logical or (capi.INT32 if enc == capi.ENC_DICT else capi.INT64 if enc == capi.ENC_DATE_IN_DAYS else t)]
+    span_kind = rng.integers(0, 6)
+    if span_kind == 0:
+        rngx = ExpressionRange(False)
+    else:
+        top = min(2 ** (bits - 1) - 2, [50, 5000, 10 ** 6, 2 ** 31 - 3, 2 ** 40, 2 ** 62][span_kind])
+        lo = int(rng.integers(-min(top, 2 ** 62), 1)) if rng.integers(0, 2) else 0
+        hi = lo + int(rng.integers(0, max(top // (1 if span_kind > 2 else 1), 1)))
+        hi = min(hi, 2 ** (bits - 1) - 2)
+        bucket = 86400 if enc == capi.ENC_DATE_IN_DAYS and rng.integers(0, 2) else 0
+        rngx = ExpressionRange(True, lo, max(hi, lo), bool(rng.integers(0, 2)) and nullable, bucket=bucket)
+    return InputColDescriptor(t, nullable, rngx, enc, logical)
+
+
+def _random_plan(rng):
+    n_cols = int(rng.integers(2, 9))
+    descs = [_random_col(rng) for _ in range(n_cols)]
+    int_cols = [i for i, d in enumerate(descs) if d.type not in (capi.DOUBLE, capi.FLOAT)]
+    n_group = int(rng.integers(0, 5))
+    group = [int(x) for x in rng.choice(int_cols, size=min(n_group, len(int_cols)), replace=False)] if int_cols else []
+    targets = []
+    for _ in range(int(rng.integers(1, 6))):
+        k = rng.integers(0, 9)
+        col = int(rng.integers(0, n_cols))
+        cond = Qual(int(rng.integers(0, n_cols)), capi.LT, 5)
+        if k == 0 and group:
+            targets.append(TargetExpr(capi.PROJECT_KEY, int(rng.integers(0, len(group)))))
+        elif k == 1:
+            targets.append(TargetExpr(capi.COUNT))
+        elif k == 2:
+            targets.append(TargetExpr(capi.COUNT, col))
+        elif k == 3:
+            targets.append(TargetExpr(capi.COUNT_IF, cond=cond))
+        elif k == 4:
+            targets.append(TargetExpr(capi.SUM_IF, col, cond=cond))
+        else:
+            targets.append(TargetExpr([capi.SUM, capi.AVG, capi.MIN, capi.MAX][(k - 5) % 4], col))
+    ra = RelAlgExecutionUnit(descs, targets, [], group,
+                             max_groups_buffer_entry_guess=int(rng.choice([0, 1000, 16384, 10 ** 6])),
+                             bigint_count=bool(rng.integers(0, 4) == 0),
+                             num_tuples=int(rng.choice([0, 10 ** 6, 2 ** 32 - 1, 2 ** 32, 10 ** 10])))
+    return ra
+
+
+def test_layout_decisions_agree(oracle):
+    rng = np.random.default_rng(2026)
+    emu = emu_lib()
+    kinds = {}
+    for i in range(3000):
+        ra = _random_plan(rng)
+        plan = ra.to_plan()
+        qe, qo = capi.QMD(), capi.QMD()
+        ce = emu.emu_qmd_init(C.byref(plan), C.byref(qe))
+        co = oracle.lib().orc_qmd_init(C.byref(plan), C.byref(qo))
+        assert (ce == 0) == (co == 0), (i, ce, co, [(d.type, d.encoding) for d in ra.input_col_descs], ra.groupby_exprs)
+        if ce:
+            continue
+        de, do = qe.as_dict(), qo.as_dict()
+        assert de == do, (i, {k: (de[k], do[k]) for k in de if de[k] != do[k]})
+        kinds[(qe.desc_type, qe.keyless, qe.slot_width, qe.key_width, min(qe.group_col_count, 2))] = 1
+    # the generator must actually reach the interesting corners
+    assert len(kinds) >= 12, sorted(kinds)
+
+
+def _fuzz_table(rng, n_rows):
+    """Columns whose contents honour their descriptors: plain and kENCODING_FIXED integers, doubles,
+    floats; nullable ones really contain the sentinel when the range says so."""
+    descs, cols = [], []
+    n_cols = int(rng.integers(3, 8))
+    for _ in range(n_cols):
+        kind = int(rng.integers(0, 8))
+        nullable = bool(rng.integers(0, 2))
+        has_nulls = nullable and bool(rng.integers(0, 3))
+        if kind <= 1:
+            t, dt = (capi.DOUBLE, np.float64) if kind == 0 else (capi.FLOAT, np.float32)
+            lo, hi = sorted(rng.uniform(-100, 100, 2))
+            a = rng.uniform(lo, hi, n_rows).astype(dt)
+            if has_nulls:
+                a[rng.random(n_rows) < 0.2] = np.finfo(dt).tiny
+            descs.append(InputColDescriptor(t, nullable, ExpressionRange(True, 0, 0, has_nulls, float(lo), float(hi))))
+            cols.append(a)
+            continue
+        t = INT_TYPES[int(rng.integers(0, 4))]
+        dt = {capi.INT8: np.int8, capi.INT16: np.int16, capi.INT32: np.int32, capi.INT64: np.int64}[t]
+        enc, logical = 0, 0
+        if kind == 2 and t != capi.INT64:
+            enc, logical = capi.ENC_FIXED, INT_TYPES[int(rng.integers(INT_TYPES.index(t) + 1, 4))]
+        info = np.iinfo(dt)
+        span = int(rng.choice([3, 40, 3000, 10 ** 7]))
+        lo = int(rng.integers(max(info.min + 1, -span), 1))
+        hi = int(min(info.max - 2, lo + span))
+        a = rng.integers(lo, hi + 1, n_rows).astype(dt)
+        if has_nulls:
+            a[rng.random(n_rows) < 0.2] = info.min
+        valid = bool(rng.integers(0, 8))  # sometimes no range at all -> baseline hash
+        descs.append(InputColDescriptor(t, nullable, ExpressionRange(valid, lo, hi, has_nulls), enc, logical))
+        cols.append(a)
+    return descs, cols
+
+
+def test_row_logic_agrees_on_random_plans(oracle):
+    """Random tables x random plans through the product's row function (host emulation) and the
+    oracle: same layout, same table (baseline as key -> slots maps, fp64 within 1e-9, fp32 2e-4)."""
+    from tests.helpers import compare_buffers, qmd_equal
+    rng = np.random.default_rng(77)
+    emu = emu_lib()
+    ran = errors = 0
+    for i in range(400):
+        n_rows = int(rng.integers(1, 400))
+        descs, cols = _fuzz_table(rng, n_rows)
+        int_cols = [j for j, d in enumerate(descs) if d.type not in (capi.DOUBLE, capi.FLOAT)]
+        n_group = int(rng.integers(0, 4))
+        group = [int(x) for x in rng.choice(int_cols, size=min(n_group, len(int_cols)), replace=False)] if int_cols else []
+        targets = []
+        for _ in range(int(rng.integers(1, 5))):
+            k = int(rng.integers(0, 9))
+            col = int(rng.integers(0, len(descs)))
+            cc = int(rng.integers(0, len(descs)))
+            cond = Qual(cc, [capi.LT, capi.GE, capi.NE][int(rng.integers(0, 3))], 0)
+            if k == 0 and group:
+                targets.append(TargetExpr(capi.PROJECT_KEY, int(rng.integers(0, len(group)))))
+            elif k == 1 or (k == 0 and not group):
+                targets.append(TargetExpr(capi.COUNT))
+            elif k == 2:
+                targets.append(TargetExpr(capi.COUNT, col))
+            elif k == 3:
+                targets.append(TargetExpr(capi.COUNT_IF, cond=cond))
+            elif k == 4:
+                targets.append(TargetExpr(capi.SUM_IF, col, cond=cond))
+            else:
+                targets.append(TargetExpr([capi.SUM, capi.AVG, capi.MIN, capi.MAX][k - 5], col))
+        quals = [Qual(int(rng.integers(0, len(descs))), capi.GE, -5)] if rng.integers(0, 2) else []
+        ra = RelAlgExecutionUnit(descs, targets, quals, group, max_groups_buffer_entry_guess=2048,
+                                 bigint_count=bool(rng.integers(0, 4) == 0))
+        cut = n_rows // 2
+        frags = [[c[:cut] for c in cols], [c[cut:] for c in cols]]
+        plan = ra.to_plan()
+        try:
+            q, want, code = oracle.execute(plan, frags, n_threads=2)
+        except capi.Mi355qError:
+            qe = capi.QMD()
+            assert emu.emu_qmd_init(C.byref(plan), C.byref(qe)) != 0  # both reject the plan
+            errors += 1
+            continue
+        from tests.test_rowlogic_emu import _emu_execute
+        from tests.cases import Case
+        eq, got, ecode = _emu_execute(Case(f"fuzz{i}", ra, frags), plan, None)
+        if code != 0 or ecode != 0:
+            assert code != 0 and ecode != 0, (i, code, ecode)
+            errors += 1
+            continue
+        qmd_equal(q, eq)
+        compare_buffers(q, want, got, 1e-9)
+        ran += 1
+    assert ran > 250, (ran, errors)
