@@ -169,6 +169,14 @@ void keyless_decision(const mi355q_plan& p, const ResolvedTarget* ts, bool* keyl
     const ResolvedTarget& t = ts[i];
     if (!found && t.agg != MI355Q_PROJECT_KEY) {
       ArgInfo a{t.arg_type, t.arg_nullable, t.arg_fp || t.arg_f32, t.range, t.arg_f32};
+      // a column from the inner side of an outer join can be NULL whatever its metadata says
+      // (getExpressionRange sets hasNulls for outer-join projections, ExpressionRange.cpp)
+      mi355q_range outer_rng;
+      if (t.table && p.join_kind == MI355Q_JOIN_LEFT && a.range) {
+        outer_rng = *a.range;
+        outer_rng.has_nulls = 1;
+        a.range = &outer_rng;
+      }
       const bool rng_ok = a.range && a.range->valid;
       switch (t.agg) {
         case MI355Q_AVG:

@@ -451,6 +451,14 @@ std::pair<bool, int> keyless_info(const mi355q_plan& p, const std::vector<Target
     const bool is_agg = t.agg != MI355Q_PROJECT_KEY;
     if (!found && is_agg) {
       const mi355q_range* r = t.col >= 0 ? &col_range_of(p, t.table, t.col) : nullptr;
+      // getExpressionRange marks a column projected from the inner side of an outer join as
+      // having nulls (ExpressionRange.cpp, is_outer_join_proj -> setHasNulls)
+      mi355q_range outer_r;
+      if (r && t.table && p.join_kind == MI355Q_JOIN_LEFT) {
+        outer_r = *r;
+        outer_r.has_nulls = 1;
+        r = &outer_r;
+      }
       switch (t.agg) {
         case MI355Q_AVG:
           ++index;

@@ -1059,3 +1059,34 @@ def test_hip_matches_oracle_on_random_plans(torch_cuda, oracle):
         compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
         ran += 1
     assert ran > 100, ran
+
+
+def test_hip_joins_match_oracle_on_random_plans(torch_cuda, oracle):
+    """Random joins (tests/test_plan_fuzz._fuzz_join: perfect / keyed, one-to-one / one-to-many,
+    1-3 key components, NULL keys, INNER / LEFT, grouped or not): tables built and probed by the
+    HIP library against the oracle."""
+    from heavydb_amd.executor import Executor
+    from tests.test_plan_fuzz import _fuzz_join
+    rng = np.random.default_rng(1234)
+    ex = Executor(0)
+    layouts = set()
+    for i in range(120):
+        case = _fuzz_join(rng)
+        oj = _oracle_join(oracle, case)
+        q, want, code = oracle.execute(case.ra.to_plan(), case.frags, case.inner, oj, n_threads=2)
+        assert code == 0
+        frag_t, inner_t = _upload(torch_cuda, case)
+        hj, keep = _build_join(torch_cuda, case)
+        info = hj.info()
+        assert (info["hash_type"], info["entry_count"]) == (oj.info()["hash_type"], oj.info()["entry_count"])
+        layouts.add((info["hash_type"], info["key_components"], info["component_width"]))
+        case.ra.join_table = hj
+        try:
+            rs = ex.executeWorkUnit(case.ra, _fetch_result(case, frag_t, inner_t), allow_retry=False,
+                                    force_generic=bool(rng.integers(0, 3) == 0))
+            qmd_equal(q, rs.getQueryMemDesc())
+            compare_buffers(q, want, rs.getStorage(), 1e-9)
+        finally:
+            case.ra.join_table = None
+            hj.free()
+    assert len(layouts) >= 6, sorted(layouts)

@@ -191,3 +191,87 @@ def test_row_logic_agrees_on_random_plans(oracle):
         compare_buffers(q, want, got, 1e-9)
         ran += 1
     assert ran > 250, (ran, errors)
+
+
+def _fuzz_join(rng):
+    """A random dim table (1-3 integer key columns, duplicates and NULL keys now and then) and a
+    fact table probing it; returns (Case-like pieces)."""
+    from tests.cases import Case
+    n, m = int(rng.integers(1, 500)), int(rng.integers(0, 120))
+    n_keys = int(rng.integers(1, 4))
+    span = [int(rng.choice([5, 30, 200])) for _ in range(n_keys)]
+    ktypes = [[capi.INT16, capi.INT32, capi.INT64][int(rng.integers(0, 3))] for _ in range(n_keys)]
+    kdt = {capi.INT16: np.int16, capi.INT32: np.int32, capi.INT64: np.int64}
+    knull = [bool(rng.integers(0, 3) == 0) for _ in range(n_keys)]
+    dim_keys = []
+    for k in range(n_keys):
+        a = rng.integers(0, span[k], m).astype(kdt[ktypes[k]])
+        if knull[k] and m:
+            a[rng.random(m) < 0.15] = np.iinfo(kdt[ktypes[k]]).min
+        dim_keys.append(a)
+    if rng.integers(0, 2) and m:  # make the key unique (first occurrence of every tuple)
+        _, first = np.unique(np.stack([a.astype(np.int64) for a in dim_keys], 1), axis=0, return_index=True)
+        first.sort()
+        dim_keys = [a[first] for a in dim_keys]
+        m = len(first)
+    dim_w = rng.integers(-50, 50, m).astype(np.int64)
+    dim_f = rng.uniform(-5, 5, m)
+    inner_descs = [InputColDescriptor(ktypes[k], knull[k], ExpressionRange(True, 0, span[k] - 1, knull[k]))
+                   for k in range(n_keys)] + \
+        [InputColDescriptor(capi.INT64, False, ExpressionRange(True, -50, 49)),
+         InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, -5.0, 5.0))]
+    inner_cols = dim_keys + [dim_w, dim_f]
+    # fact: outer key columns (a little wider than the dim's range, sometimes NULL), a value, a group key
+    otypes = [[capi.INT32, capi.INT64][int(rng.integers(0, 2))] for _ in range(n_keys)]
+    odt = {capi.INT32: np.int32, capi.INT64: np.int64}
+    onull = [bool(rng.integers(0, 3) == 0) for _ in range(n_keys)]
+    fact, fdescs = [], []
+    for k in range(n_keys):
+        a = rng.integers(-2, span[k] + 2, n).astype(odt[otypes[k]])
+        if onull[k]:
+            a[rng.random(n) < 0.1] = np.iinfo(odt[otypes[k]]).min
+        fact.append(a)
+        fdescs.append(InputColDescriptor(otypes[k], onull[k], ExpressionRange(True, -2, span[k] + 1, onull[k])))
+    fact.append(rng.integers(-100, 100, n).astype(np.int64))
+    fdescs.append(InputColDescriptor(capi.INT64, False, ExpressionRange(True, -100, 99)))
+    fact.append(rng.integers(0, 6, n).astype(np.int32))
+    fdescs.append(InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 5)))
+    v, g = n_keys, n_keys + 1
+    pool = [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, v), TargetExpr(capi.SUM, n_keys, 1), TargetExpr(capi.AVG, n_keys + 1, 1),
+            TargetExpr(capi.MIN, n_keys + 1, 1), TargetExpr(capi.COUNT, n_keys, 1), TargetExpr(capi.MAX, v)]
+    targets = [pool[int(j)] for j in rng.choice(len(pool), size=int(rng.integers(1, 5)), replace=False)]
+    grouped = bool(rng.integers(0, 2))
+    if grouped:
+        targets = [TargetExpr(capi.PROJECT_KEY)] + targets
+    ra = RelAlgExecutionUnit(fdescs, targets, [], [g] if grouped else [], inner_col_descs=inner_descs,
+                             join_outer_col=list(range(n_keys)) if n_keys > 1 else 0,
+                             join_kind=int(rng.integers(0, 2)))
+    cut = n // 2
+    frags = [[c[:cut] for c in fact], [c[cut:] for c in fact]]
+    single = n_keys == 1
+    case = Case("fuzz_join", ra, frags, inner_cols, dim_keys[0] if single else dim_keys, ktypes[0] if single else ktypes,
+                ExpressionRange(True, 0, span[0] - 1) if single else ExpressionRange(),
+                bool(rng.integers(0, 2)) if single else False, join_one_to_many=1,
+                join_key_nullable=knull[0] if single else knull)
+    return case
+
+
+def test_join_row_logic_agrees_on_random_plans(oracle):
+    """Random joins — perfect / keyed tables, one-to-one (unique keys) or rebuilt one-to-many,
+    1-3 key components of mixed widths, NULL keys on both sides, INNER / LEFT, grouped or not —
+    through the product's row function (host emulation) against the oracle."""
+    from tests.helpers import compare_buffers, qmd_equal
+    from tests.test_rowlogic_emu import _emu_execute, _oracle_join
+    rng = np.random.default_rng(99)
+    layouts = set()
+    for i in range(300):
+        case = _fuzz_join(rng)
+        plan = case.ra.to_plan()
+        oj = _oracle_join(oracle, case)
+        layouts.add((oj.info()["hash_type"], oj.shape()["key_components"], oj.shape()["component_width"]))
+        q, want, code = oracle.execute(plan, case.frags, case.inner, oj, n_threads=2)
+        eq, got, ecode = _emu_execute(case, plan, oj)
+        assert code == 0 and ecode == 0, (i, code, ecode)
+        qmd_equal(q, eq)
+        compare_buffers(q, want, got, 1e-9)
+    assert len(layouts) >= 8, sorted(layouts)
