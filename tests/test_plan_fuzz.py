@@ -118,13 +118,35 @@ def _fuzz_table(rng, n_rows):
             descs.append(InputColDescriptor(t, nullable, ExpressionRange(True, 0, 0, has_nulls, float(lo), float(hi))))
             cols.append(a)
             continue
+        if kind == 3:  # dictionary ids: 1/2-byte chunks are unsigned, NULL = 255 / 65535
+            t, udt, top = [(capi.INT8, np.uint8, 254), (capi.INT16, np.uint16, 65534)][int(rng.integers(0, 2))]
+            hi = int(rng.integers(1, top + 1))
+            a = rng.integers(0, hi + 1, n_rows).astype(udt)
+            if has_nulls:
+                a[rng.random(n_rows) < 0.2] = top + 1
+            descs.append(InputColDescriptor(t, nullable, ExpressionRange(True, 0, hi, has_nulls), capi.ENC_DICT))
+            cols.append(a.view(np.int8 if t == capi.INT8 else np.int16))
+            continue
+        if kind == 4:  # DATE in days: decoded to seconds, bucketed range
+            t, sdt = [(capi.INT16, np.int16), (capi.INT32, np.int32)][int(rng.integers(0, 2))]
+            lo = int(rng.integers(-300, 300))
+            hi = lo + int(rng.integers(0, 200))
+            a = rng.integers(lo, hi + 1, n_rows).astype(sdt)
+            if has_nulls:
+                a[rng.random(n_rows) < 0.2] = np.iinfo(sdt).min
+            bucket = 86400 if rng.integers(0, 2) else 0
+            descs.append(InputColDescriptor(t, nullable or has_nulls, ExpressionRange(True, lo * 86400, hi * 86400,
+                                                                                     has_nulls, bucket=bucket),
+                                            capi.ENC_DATE_IN_DAYS))
+            cols.append(a)
+            continue
         t = INT_TYPES[int(rng.integers(0, 4))]
         dt = {capi.INT8: np.int8, capi.INT16: np.int16, capi.INT32: np.int32, capi.INT64: np.int64}[t]
         enc, logical = 0, 0
         if kind == 2 and t != capi.INT64:
             enc, logical = capi.ENC_FIXED, INT_TYPES[int(rng.integers(INT_TYPES.index(t) + 1, 4))]
         info = np.iinfo(dt)
-        span = int(rng.choice([3, 40, 3000, 10 ** 7]))
+        span = int(rng.choice([3, 40, 3000, 2 * 10 ** 5]))
         lo = int(rng.integers(max(info.min + 1, -span), 1))
         hi = int(min(info.max - 2, lo + span))
         a = rng.integers(lo, hi + 1, n_rows).astype(dt)
@@ -275,3 +297,47 @@ def test_join_row_logic_agrees_on_random_plans(oracle):
         qmd_equal(q, eq)
         compare_buffers(q, want, got, 1e-9)
     assert len(layouts) >= 8, sorted(layouts)
+
+
+def test_reduce_agrees_on_random_plans(oracle):
+    """ResultSetStorage::reduce on random layouts: (a) the oracle's reduce of two halves equals its
+    single pass, (b) the product's reduce_entry (host emulation of k_reduce) applied to the same two
+    buffers equals the oracle's reduce."""
+    from tests.helpers import compare_buffers
+    rng = np.random.default_rng(31)
+    emu = emu_lib()
+    ran = 0
+    for i in range(250):
+        n_rows = int(rng.integers(2, 300))
+        descs, cols = _fuzz_table(rng, n_rows)
+        int_cols = [j for j, d in enumerate(descs) if d.type not in (capi.DOUBLE, capi.FLOAT)]
+        group = [int(x) for x in rng.choice(int_cols, size=min(int(rng.integers(0, 4)), len(int_cols)), replace=False)] \
+            if int_cols else []
+        targets = [TargetExpr(capi.PROJECT_KEY, 0)] if group and rng.integers(0, 2) else []
+        for _ in range(int(rng.integers(1, 4))):
+            k = int(rng.integers(0, 6))
+            col = int(rng.integers(0, len(descs)))
+            targets.append(TargetExpr(capi.COUNT) if k == 0 else TargetExpr(capi.COUNT, col) if k == 1 else
+                           TargetExpr([capi.SUM, capi.AVG, capi.MIN, capi.MAX][k - 2], col))
+        ra = RelAlgExecutionUnit(descs, targets, [], group, max_groups_buffer_entry_guess=2048)
+        plan = ra.to_plan()
+        cut = n_rows // 2
+        a_frag, b_frag = [[c[:cut] for c in cols]], [[c[cut:] for c in cols]]
+        try:
+            q, full, code = oracle.execute(plan, a_frag + b_frag)
+        except capi.Mi355qError:
+            continue
+        if code != 0:
+            continue
+        _, a, ca = oracle.execute(plan, a_frag)
+        _, b, cb = oracle.execute(plan, b_frag)
+        assert ca == 0 and cb == 0
+        red = a.copy()
+        assert oracle.reduce(q, red, b) == 0
+        compare_buffers(q, full, red, 1e-9)
+        mine = np.ascontiguousarray(a.copy())
+        bb = np.ascontiguousarray(b)
+        assert emu.emu_reduce(C.byref(q), mine.ctypes.data, bb.ctypes.data, q.entry_count) == 0
+        compare_buffers(q, red, mine, 1e-12)
+        ran += 1
+    assert ran > 150, ran
