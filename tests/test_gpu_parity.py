@@ -1058,6 +1058,38 @@ def test_hip_matches_oracle_on_random_plans(torch_cuda, oracle):
         compare_buffers(q, want, rs.getStorage(), 1e-9)
         compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
         ran += 1
+        n = rs.rowCount()
+        if not group or n == 0:
+            continue
+        # ColumnarResults on the device == host iteration, row for row
+        iv, dv, nu = rs.fetch()
+        cols_d, n_c = rs.to_columns(torch)
+        assert n_c == n
+        for t in range(q.n_targets):
+            c = cols_d[t].cpu().numpy()
+            isnull = nu[:, t].astype(bool)
+            if q.target_is_fp[t]:
+                assert np.array_equal(c.view(np.float64)[~isnull], dv[~isnull, t])
+                assert (c.view(np.float64)[isnull] == np.float64(2.2250738585072014e-308)).all()
+            else:
+                assert np.array_equal(c[~isnull], iv[~isnull, t]) and (c[isnull] == q.target_null[t]).all()
+        # ORDER BY a random target LIMIT k on the device: the ordered values
+        t = int(rng.integers(0, q.n_targets))
+        k = int(min(n, rng.integers(1, 9)))
+        desc, nulls_first = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        rq = q.row_size // 8
+        out = torch.empty((k, rq), dtype=torch.int64, device="cuda")
+        got_n = rs.sort(t, k, int(out.data_ptr()), desc=desc, nulls_first=nulls_first)
+        assert got_n == k
+        top = oracle.init_buffer(q).reshape(q.entry_count, rq)
+        top[:k] = out.cpu().numpy()
+        ti, td, tn = oracle.fetch_rows(q, top.reshape(-1))
+        vals = (dv if q.target_is_fp[t] else iv.astype(np.float64))[:, t]
+        key = np.where(nu[:, t].astype(bool), -np.inf if nulls_first else np.inf, -vals if desc else vals)
+        want_key = np.sort(key, kind="stable")[:k]
+        gvals = (td if q.target_is_fp[t] else ti.astype(np.float64))[:, t]
+        got_key = np.where(tn[:, t].astype(bool), -np.inf if nulls_first else np.inf, -gvals if desc else gvals)
+        assert np.array_equal(got_key, want_key), (i, t, desc, nulls_first, got_key, want_key)
     assert ran > 100, ran
 
 
