@@ -1667,7 +1667,10 @@ bool make_join_part_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_
   // partitions: at least one per CU, bitmap slice within ~120 KB of LDS
   uint32_t P = 16;
   auto s1_of = [&](uint32_t parts) { return (uint32_t)((((range + parts - 1) / parts) + 31) & ~(uint64_t)31); };
-  while (P < 1024 && (P < (uint32_t)n_cus || s1_of(P) / 8 > 120 * 1024)) P <<= 1;
+  // as many partitions as the scatter supports: with 256 the 12 producer waves of a workgroup
+  // contend on 256 LDS cursors and stage 512-byte lines (9.1 ms per 1.43 B rows); 1024
+  // partitions = the geometry the scatter was tuned on
+  while (P < 1024 && (P < 4 * (uint32_t)n_cus || s1_of(P) / 8 > 120 * 1024) && s1_of(P * 2) >= 64) P <<= 1;
   const uint32_t S1 = s1_of(P);
   if (S1 / 8 > 150 * 1024 || S1 < 32) return false;
   ScatterArgs& sa = h.sa;
