@@ -203,6 +203,13 @@ def test_one_to_many_perfect_doc_example(oracle):
     with pytest.raises(capi.Mi355qError) as ei:
         oracle.OracleJoin(b, capi.INT32, 0, 3, one_to_many=0)
     assert ei.value.code == capi.ERR_JOIN_NOT_ONE_TO_ONE
+    # 'One-To-One BaselineJoinHashTable Example': table2 = (0, 1, 3), key (b, b) ->
+    # | keys * (1,1,1) (3,3,2) (0,0,0) * * |   (payload = row id interleaved with the key)
+    b3 = np.array([0, 1, 3], dtype=np.int32)
+    j = oracle.OracleJoin([b3, b3], [capi.INT32, capi.INT32], 0, -1, one_to_many=0, keyed_entry_count=6)
+    assert j.info() == {"hash_type": 1, "entry_count": 6}
+    E = EMPTY32
+    assert [int(x) for x in j.raw().view(np.int32)] == [E, E, -1, 1, 1, 1, 3, 3, 2, 0, 0, 0, E, E, -1, E, E, -1]
     j = oracle.OracleJoin([b, b], [capi.INT32, capi.INT32], 0, -1, one_to_many=1, keyed_entry_count=6)
     assert j.info() == {"hash_type": 3, "entry_count": 6}
     raw = j.raw().view(np.int32)
