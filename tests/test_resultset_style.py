@@ -1,0 +1,126 @@
+"""Ports of the reference's own ResultSet fill / reduce / iterate tests (Tests/ResultSetTest.cpp
+Reduce.PerfectHashOneCol :1591, Reduce.PerfectHashOneColKeyless :1660, Reduce.BaselineHashOneCol,
+Iterate.* :1398-1584) with its fillers restated (Tests/ResultSetTestUtils.cpp:104-160 fill_one_entry_no_
+collisions, :322-351 fill_storage_buffer_perfect_hash_rowwise, :395-430 ..._baseline_rowwise,
+EvenNumberGenerator ResultSetTestUtils.h:39-52): every second entry holds the value v = 0, 2, 4, ...
+in every target (AVG as the pair (v, 1)); two such buffers are reduced and iterated; the
+expectations are the reference test's own formulas (test_reduce :1026-1100: SUM / COUNT = step *
+entry, everything else = entry).  Run against the oracle's reduce / iteration AND the product's
+reduce logic (host emulation of k_reduce)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from heavydb_amd import capi
+from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+from tests.helpers import emu_lib
+
+EMPTY64 = 2**63 - 1
+DEADBEEF = 0xdeadbeef
+
+
+def _qmd(oracle, baseline: bool, keyless: bool):
+    """key int64; targets: projected key (the reference's non-aggregate column), AVG(int), SUM(int) —
+    generate_test_target_infos (:938-955) without the string column."""
+    key_range = ExpressionRange(False) if baseline else ExpressionRange(True, 0, 99)
+    descs = [InputColDescriptor(capi.INT64, False, key_range), InputColDescriptor(capi.INT32, True, ExpressionRange(False))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.AVG, 1), TargetExpr(capi.SUM, 1)],
+                             groupby_exprs=[0], max_groups_buffer_entry_guess=200)
+    q = oracle.qmd_init(ra.to_plan())
+    if baseline:
+        assert q.desc_type == capi.GROUP_BY_BASELINE_HASH and q.entry_count == 200 and q.key_bytes == 8
+    else:
+        assert q.desc_type == capi.GROUP_BY_PERFECT_HASH and q.entry_count == 100 and not q.keyless
+        if keyless:  # setHasKeylessHash(true); setTargetIdxForKey(2): AVG's count slot marks live entries
+            q.keyless, q.idx_target_as_key, q.key_bytes = 1, 2, 0
+            q.row_size = 8 * q.slot_count
+    return q
+
+
+def _fill_perfect(q, step=2):
+    """fill_storage_buffer_perfect_hash_rowwise + fill_one_entry_no_collisions"""
+    rq, kq = q.row_size // 8, q.key_bytes // 8
+    buf = np.zeros((q.entry_count, rq), dtype=np.int64)
+    v = 0
+    for i in range(q.entry_count):
+        if i % step == 0:
+            if kq:
+                buf[i, 0] = v
+            buf[i, kq:] = [v, v, 1, v]  # projected column, AVG (sum, count), SUM
+            v += 2
+        else:
+            if kq:
+                buf[i, 0] = EMPTY64
+            buf[i, kq:] = [0, 0, 0, 0] if q.keyless else [DEADBEEF, DEADBEEF, 0, DEADBEEF]
+    return buf
+
+
+def _check_reduced(q, buf, fetch, step=2):
+    iv, dv, nu = fetch(q, buf)
+    assert iv.shape[0] == (q.entry_count + step - 1) // step if q.desc_type != capi.GROUP_BY_BASELINE_HASH else True
+    for r in range(iv.shape[0]):
+        entry = int(iv[r, 0])  # the projected column is the entry's own value
+        assert entry % 2 == 0
+        assert not nu[r].any()
+        assert dv[r, 1] == float(entry)          # AVG = (v + v) / (1 + 1)
+        assert iv[r, 2] == step * entry          # SUM = step * entry (two buffers, step 2)
+    return iv[:, 0]
+
+
+@pytest.mark.parametrize("keyless", [False, True], ids=["PerfectHashOneCol", "PerfectHashOneColKeyless"])
+@pytest.mark.parametrize("impl", ["oracle", "product_reduce"])
+def test_reduce_perfect_hash_one_col(oracle, keyless, impl):
+    q = _qmd(oracle, False, keyless)
+    a, b = _fill_perfect(q), _fill_perfect(q)
+    if impl == "oracle":
+        assert oracle.reduce(q, a, b) == 0
+    else:
+        assert emu_lib().emu_reduce(C.byref(q), a.ctypes.data, b.ctypes.data, q.entry_count) == 0
+    keys = _check_reduced(q, a, oracle.fetch_rows)
+    assert list(keys) == list(range(0, 100, 2))          # entry order, Iterate.* expectations
+    assert oracle.row_count(q, a) == 50
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product_reduce"])
+def test_reduce_baseline_hash_one_col(oracle, impl):
+    """Reduce.BaselineHashOneCol: the filler places v = 0, 2, 4, ... with get_group_value
+    (fill_storage_buffer_baseline_rowwise), the reduction re-hashes them."""
+    q = _qmd(oracle, True, False)
+    rq = q.row_size // 8
+
+    def fill():
+        buf = np.zeros((q.entry_count, rq), dtype=np.int64)
+        buf[:, 0] = EMPTY64
+        # the baseline layout projects the key from the key column itself: slots are AVG (sum, count), SUM
+        buf[:, 1:] = [DEADBEEF, 0, DEADBEEF]  # "kCOUNT ? 0 : 0xdeadbeef" — AVG's count starts at 0
+        flat = buf.reshape(-1)
+        for v in range(0, 2 * (q.entry_count // 2), 2):
+            s = oracle.lib().orc_get_group_value_slot(flat.ctypes.data, q.entry_count, v, 8, rq)
+            assert s >= 0
+            flat[s:s + 3] = [v, 1, v]
+        return buf
+    a, b = fill(), fill()
+    if impl == "oracle":
+        assert oracle.reduce(q, a, b) == 0
+    else:
+        assert emu_lib().emu_reduce(C.byref(q), a.ctypes.data, b.ctypes.data, q.entry_count) == 0
+    keys = _check_reduced(q, a, oracle.fetch_rows)
+    assert sorted(keys) == list(range(0, 200, 2))
+    # the slots agree with the key column, and the table is still a valid probing image
+    live = a[a[:, 0] != EMPTY64]
+    assert (live[:, 3] == 2 * live[:, 0]).all() and (live[:, 2] == 2).all()
+    from tests.helpers import check_probe_invariant
+    check_probe_invariant(q, a.reshape(-1))
+
+
+def test_iterate_perfect_hash_one_col(oracle):
+    """Iterate.PerfectHashOneCol (:1398): rows come out in entry order with ref_val += 2."""
+    q = _qmd(oracle, False, False)
+    buf = _fill_perfect(q)
+    iv, dv, nu = oracle.fetch_rows(q, buf)
+    ref = 0
+    for r in range(iv.shape[0]):
+        assert iv[r, 0] == ref and dv[r, 1] == float(ref) and iv[r, 2] == ref and not nu[r].any()
+        ref += 2
+    assert ref == 100
