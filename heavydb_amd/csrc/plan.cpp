@@ -40,7 +40,10 @@ bool int_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_INT64; }
 
 constexpr int64_t kBaselineGroupbyThreshold = 1000000;  // g_baseline_groupby_threshold, Execute.cpp:113
 
-// getBucketedCardinality (GroupByAndAggregate.cpp:367-375)
+// two's-complement add: a caller-supplied range may end at INT64_MAX
+int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+
+// getBucketedCardinality (GroupByAndAggregate.cpp:367-375); callers have bounded max - min
 int64_t bucketed_cardinality(const mi355q_range& r) {
   int64_t c = r.max - r.min;
   if (r.bucket > 0) c /= r.bucket;
@@ -284,7 +287,7 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
       q->group_min[0] = r.min;
       q->group_card[0] = card;
       q->group_bucket[0] = q->bucket;
-      q->group_null_key[0] = r.max + (q->bucket ? q->bucket : 1);
+      q->group_null_key[0] = wrap_add(r.max, q->bucket ? q->bucket : 1);
       q->group_has_nulls[0] = r.has_nulls != 0;
     }
   } else if (p.n_group_cols > 1) {
@@ -319,7 +322,7 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
         q->group_min[g] = r.min;
         q->group_card[g] = bucketed_cardinality(r);
         q->group_bucket[g] = r.bucket > 0 ? r.bucket : 0;
-        q->group_null_key[g] = r.max + (r.bucket > 0 ? r.bucket : 1);
+        q->group_null_key[g] = wrap_add(r.max, r.bucket > 0 ? r.bucket : 1);
         q->group_has_nulls[g] = r.has_nulls != 0;
         if (r.has_nulls) q->has_nulls = 1;
       }
