@@ -31,6 +31,7 @@ COUNT_IF, SUM_IF = 10, 11
 JOIN_INNER, JOIN_LEFT = 0, 1
 # mi355q_desc_type
 GROUP_BY_PERFECT_HASH, GROUP_BY_BASELINE_HASH, NON_GROUPED_AGGREGATE = 0, 1, 4
+OUTPUT_ROWWISE, OUTPUT_COLUMNAR, OUTPUT_ROWWISE_COLUMNAR_DECISIONS = 0, 1, 2  # mi355q_columnar_hint
 # generator kinds
 GEN_I32_UNIFORM31, GEN_I32_MOD, GEN_I64_MOD, GEN_I64_MOD_MUL, GEN_F64_UNIT = 1, 2, 3, 4, 5
 
@@ -88,7 +89,7 @@ class Plan(C.Structure):
         ("reserved2", C.c_int32),
         ("max_groups_buffer_entry_guess", C.c_int64),
         ("bigint_count", C.c_int32),
-        ("reserved", C.c_int32),
+        ("output_columnar_hint", C.c_int32),
         ("num_tuples", C.c_int64),
     ]
 
@@ -113,7 +114,7 @@ class QMD(C.Structure):
         ("has_nulls", C.c_int32),
         ("row_size", C.c_int32),
         ("slot_width", C.c_int32),
-        ("pad_", C.c_int32),
+        ("output_columnar", C.c_int32),
         ("key_bytes", C.c_int32),
         ("n_targets", C.c_int32),
         ("target_slot", C.c_int32 * MAX_TARGETS),
@@ -202,6 +203,8 @@ SYMBOLS = [
       _P(C.c_int32)]),
     ("mi355q_qmd_init", C.c_int32, [_P(Plan), _P(QMD)]),
     ("mi355q_qmd_buffer_bytes", C.c_int64, [_P(QMD)]),
+    ("mi355q_qmd_group_col_offset", C.c_int64, [_P(QMD), C.c_int32]),
+    ("mi355q_qmd_slot_col_offset", C.c_int64, [_P(QMD), C.c_int32]),
     ("mi355q_execute", C.c_int32,
      [_P(Plan), _P(Inputs), _P(ExecOptions), _P(C.c_void_p), _P(ExecReport)]),
     ("mi355q_result_create", C.c_int32, [_P(QMD), C.c_int32, C.c_void_p, _P(C.c_void_p)]),

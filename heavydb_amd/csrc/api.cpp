@@ -291,18 +291,59 @@ int32_t mi355q_qmd_init(const mi355q_plan* plan, mi355q_qmd* out) {
   return qmd_init(*plan, out);
 }
 
-int64_t mi355q_qmd_buffer_bytes(const mi355q_qmd* qmd) {
-  return qmd ? qmd->entry_count * (int64_t)qmd->row_size : 0;
+int64_t mi355q_qmd_buffer_bytes(const mi355q_qmd* qmd) { return qmd ? qmd_buffer_bytes(*qmd) : 0; }
+int64_t mi355q_qmd_group_col_offset(const mi355q_qmd* qmd, int32_t g) { return qmd ? qmd_group_col_offset(*qmd, g) : -1; }
+int64_t mi355q_qmd_slot_col_offset(const mi355q_qmd* qmd, int32_t s) {
+  return qmd && s < qmd->slot_count ? qmd_slot_col_offset(*qmd, s) : -1;
 }
 
+// ---- columnar results (output_columnar_): the device operations that walk rows run on a
+// row-wise twin of the buffer (same entries, same values; rowfunc.h entry_to_columns)
+static ColLayout col_layout_of(const mi355q_qmd& q) {
+  ColLayout L{};
+  L.entry_count = q.entry_count;
+  L.slot_col_bytes = ((int64_t)q.slot_width * q.entry_count + 7) & ~(int64_t)7;
+  L.key_quads = q.key_bytes / 8;
+  L.slot_count = q.slot_count;
+  L.slot_width = q.slot_width;
+  L.row_quad = q.row_size / 8;
+  return L;
+}
 static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
                                   mi355q_result** out);
+namespace {
+struct RowTwin {
+  mi355q_result* tw = nullptr;
+  ~RowTwin() {
+    if (tw) mi355q_result_free(tw);
+  }
+};
+int32_t make_row_twin(const mi355q_result* r, hipStream_t s, RowTwin* out) {
+  mi355q_qmd rq = r->qmd;
+  rq.output_columnar = 0;
+  if (int32_t e = result_create_impl(&rq, r->device_id, nullptr, &out->tw)) return e;
+  DeviceGuard g(r->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  HIP_TRY(launch_columns_to_rows(col_layout_of(r->qmd), r->buf, out->tw->buf, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return MI355Q_OK;
+}
+int32_t store_row_twin(const RowTwin& t, mi355q_result* r, hipStream_t s) {
+  DeviceGuard g(r->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  HIP_TRY(launch_rows_to_columns(col_layout_of(r->qmd), t.tw->buf, r->buf, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return MI355Q_OK;
+}
+}  // namespace
 
 int32_t mi355q_result_create(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
                              mi355q_result** out) {
   if (int32_t e = result_create_impl(qmd, device_id, device_buffer, out)) return e;
   DeviceGuard g(device_id);
-  hipError_t he = launch_init_buffer((*out)->buf, qmd->entry_count, make_row_init(*qmd), nullptr);
+  hipError_t he = qmd->output_columnar
+                      ? launch_init_columns(col_layout_of(*qmd), make_row_init(*qmd), (*out)->buf, nullptr)
+                      : launch_init_buffer((*out)->buf, qmd->entry_count, make_row_init(*qmd), nullptr);
   if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
   if (he != hipSuccess) {
     last_hip_error = he;
@@ -328,7 +369,11 @@ static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void
   if (!r) return MI355Q_ERR_OUT_OF_CPU_MEM;
   r->qmd = *qmd;
   r->device_id = device_id;
-  r->bytes = qmd->entry_count * (int64_t)qmd->row_size;
+  r->bytes = qmd_buffer_bytes(*qmd);
+  if (r->bytes <= 0) {
+    delete r;
+    return MI355Q_ERR_INVALID_PLAN;
+  }
   // layout-only device plan (targets for reduce/iteration)
   DevPlan& d = r->dplan;
   std::memset(&d, 0, sizeof(d));
@@ -394,18 +439,30 @@ int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_r
   const mi355q_qmd& a = this_rs->qmd;
   const mi355q_qmd& b = that_rs->qmd;
   if (a.desc_type != b.desc_type || a.row_size != b.row_size || a.slot_count != b.slot_count ||
-      a.keyless != b.keyless || a.key_width != b.key_width ||
+      a.keyless != b.keyless || a.key_width != b.key_width || a.output_columnar != b.output_columnar ||
       this_rs->device_id != that_rs->device_id) {
     return MI355Q_ERR_INVALID_PLAN;
   }
   if (a.desc_type != MI355Q_GROUP_BY_BASELINE_HASH && a.entry_count != b.entry_count)
     return MI355Q_ERR_INVALID_PLAN;
+  if (a.output_columnar) {
+    RowTwin ta, tb;
+    if (int32_t e = make_row_twin(this_rs, (hipStream_t)stream, &ta)) return e;
+    if (int32_t e = make_row_twin(that_rs, (hipStream_t)stream, &tb)) return e;
+    if (int32_t e = mi355q_result_reduce(ta.tw, tb.tw, stream)) return e;
+    return store_row_twin(ta, this_rs, (hipStream_t)stream);
+  }
   return run_reduce(this_rs, that_rs->buf, b.entry_count, stream);
 }
 
 int64_t mi355q_result_row_count(const mi355q_result* r) {
   if (!r) return -1;
   if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return 1;
+  if (r->qmd.output_columnar) {
+    RowTwin t;
+    if (make_row_twin(r, nullptr, &t)) return -1;
+    return mi355q_result_row_count(t.tw);
+  }
   DeviceGuard g(r->device_id);
   DevWord cnt;
   if (hipMalloc(&cnt.p, sizeof(unsigned long long)) != hipSuccess) return -1;
@@ -421,6 +478,11 @@ int32_t mi355q_result_to_columns(const mi355q_result* r, void* const* cols_dev, 
                                  void* stream) {
   if (!r || !cols_dev || !n_rows || n_cols != r->qmd.n_targets) return MI355Q_ERR_INVALID_PLAN;
   if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return MI355Q_ERR_UNSUPPORTED;  // one row: fetch_rows
+  if (r->qmd.output_columnar) {
+    RowTwin t;
+    if (int32_t e = make_row_twin(r, (hipStream_t)stream, &t)) return e;
+    return mi355q_result_to_columns(t.tw, cols_dev, n_cols, n_rows, stream);
+  }
   const mi355q_qmd& q = r->qmd;
   if (q.entry_count >= ((int64_t)1 << 31)) return MI355Q_ERR_UNSUPPORTED;
   for (int t = 0; t < n_cols; ++t)
@@ -458,6 +520,11 @@ int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t d
     return MI355Q_ERR_INVALID_PLAN;
   if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return MI355Q_ERR_UNSUPPORTED;
   if (k > topk_max_k()) return MI355Q_ERR_UNSUPPORTED;
+  if (r->qmd.output_columnar) {  // the rows come out row-wise (row_size bytes each)
+    RowTwin t;
+    if (int32_t e = make_row_twin(r, (hipStream_t)stream, &t)) return e;
+    return mi355q_result_topk(t.tw, target_idx, descending, nulls_first, k, out_rows_dev, n_rows, stream);
+  }
   if (k > r->qmd.entry_count) k = r->qmd.entry_count;
   DeviceGuard g(r->device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
@@ -479,6 +546,11 @@ int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t d
 int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival,
                                  double* dval, int8_t* is_null, int64_t* n_rows) {
   if (!r || !ival || !dval || !is_null || !n_rows) return MI355Q_ERR_INVALID_PLAN;
+  if (r->qmd.output_columnar) {
+    RowTwin t;
+    if (int32_t e = make_row_twin(r, nullptr, &t)) return e;
+    return mi355q_result_fetch_rows(t.tw, max_rows, ival, dval, is_null, n_rows);
+  }
   const mi355q_qmd& q = r->qmd;
   std::vector<int64_t> host;
   try {
@@ -837,6 +909,30 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   DeviceGuard g(in->device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
   const int n_cus = cu_count_of(in->device_id);
+
+  if (q.output_columnar) {
+    // Columnar output: the step runs on the row-wise form of the same decisions (same entry
+    // count, 8-byte key components, same hash, same slots) into a library-owned table, and the
+    // finished table is moved column by column into the caller-visible buffer.
+    mi355q_plan pr = *plan;
+    pr.output_columnar_hint = MI355Q_OUTPUT_ROWWISE_COLUMNAR_DECISIONS;
+    mi355q_exec_options orw = o;
+    orw.out_buffer = nullptr;
+    RowTwin t;
+    if (int32_t e = mi355q_execute(&pr, in, &orw, &t.tw, report)) return e;
+    const mi355q_qmd& qr = t.tw->qmd;
+    if (qr.entry_count != q.entry_count || qr.row_size != q.row_size || qr.key_bytes != q.key_bytes ||
+        qr.slot_count != q.slot_count || qr.slot_width != q.slot_width || qr.output_columnar)
+      return MI355Q_ERR_UNSUPPORTED;
+    mi355q_result* rc = nullptr;
+    if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &rc)) return e;
+    if (int32_t e = store_row_twin(t, rc, (hipStream_t)o.stream)) {
+      mi355q_result_free(rc);
+      return e;
+    }
+    *out = rc;
+    return MI355Q_OK;
+  }
 
   if (q.slot_width == 4) {
     // Compact layout (4-byte slots): the step runs on the 8-byte layout of the same plan — same
@@ -1282,6 +1378,11 @@ int32_t mi355q_shard_partition(const mi355q_result* r, int32_t n_parts, void* ou
   if (!r || !out_rows || !part_counts_dev || n_parts < 1 || n_parts > 256)
     return MI355Q_ERR_INVALID_PLAN;
   if (r->qmd.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return MI355Q_ERR_UNSUPPORTED;
+  if (r->qmd.output_columnar) {  // the exchanged rows are row-wise whatever the table's layout
+    RowTwin t;
+    if (int32_t e = make_row_twin(r, (hipStream_t)stream, &t)) return e;
+    return mi355q_shard_partition(t.tw, n_parts, out_rows, part_counts_dev, stream);
+  }
   DeviceGuard g(r->device_id);
   DevWord cur;
   HIP_TRY(hipMalloc(&cur.p, sizeof(int64_t) * 256));
@@ -1296,6 +1397,12 @@ int32_t mi355q_shard_merge_rows(mi355q_result* r, const void* rows, int64_t n_ro
   if (!r || (!rows && n_rows > 0) || n_rows < 0) return MI355Q_ERR_INVALID_PLAN;
   if (n_rows == 0) return MI355Q_OK;
   if (r->qmd.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return MI355Q_ERR_UNSUPPORTED;
+  if (r->qmd.output_columnar) {
+    RowTwin t;
+    if (int32_t e = make_row_twin(r, (hipStream_t)stream, &t)) return e;
+    if (int32_t e = mi355q_shard_merge_rows(t.tw, rows, n_rows, stream)) return e;
+    return store_row_twin(t, r, (hipStream_t)stream);
+  }
   return run_reduce(r, (const int64_t*)rows, n_rows, stream);
 }
 

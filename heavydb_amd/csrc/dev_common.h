@@ -283,4 +283,12 @@ struct DevPlan {
   const int8_t* inner_cols[MI355Q_MAX_COLS];
 };
 
+// geometry of a columnar result buffer (output_columnar_; rowfunc.h entry_to_columns)
+struct ColLayout {
+  int64_t entry_count;
+  int64_t slot_col_bytes;  // align_to_int64(slot_width * entry_count)
+  int32_t key_quads;       // group columns stored (0 when keyless)
+  int32_t slot_count, slot_width, row_quad;
+};
+
 }  // namespace mq

@@ -99,6 +99,11 @@ hipError_t launch_to_columns(const DevPlan& p, int idx_target_as_key, const Colu
 hipError_t launch_narrow_slots(const int64_t* wide, int wide_quad, int key_quad, int slot_count,
                                int narrow_quad, int64_t entries, int64_t* out, hipStream_t s);
 
+// row-wise <-> columnar result buffers (ColLayout: dev_common.h); init = initColumnarGroups
+hipError_t launch_rows_to_columns(const ColLayout& L, const int64_t* rows, void* cols, hipStream_t s);
+hipError_t launch_columns_to_rows(const ColLayout& L, const void* cols, int64_t* rows, hipStream_t s);
+hipError_t launch_init_columns(const ColLayout& L, const RowInit& init, void* cols, hipStream_t s);
+
 // inner key columns of a join table build
 struct JoinKeyCols {
   const int8_t* col[MI355Q_MAX_GROUP_COLS];

@@ -553,6 +553,28 @@ __global__ __launch_bounds__(kBlock) void k_narrow_slots(const int64_t* __restri
   }
 }
 
+// ---- row-wise <-> columnar result buffers (output_columnar_) ---------------------------------
+// one lane per entry: the column side is coalesced (consecutive entries), the row side walks
+// whole rows (every fetched line is used by the loop over the row's quads)
+__global__ __launch_bounds__(kBlock) void k_rows_to_columns(ColLayout L, const int64_t* __restrict__ rows,
+                                                             int8_t* __restrict__ cols) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < L.entry_count; e += stride)
+    entry_to_columns(L, rows + e * L.row_quad, cols, e);
+}
+__global__ __launch_bounds__(kBlock) void k_columns_to_rows(ColLayout L, const int8_t* __restrict__ cols,
+                                                             int64_t* __restrict__ rows) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < L.entry_count; e += stride)
+    entry_from_columns(L, cols, e, rows + e * L.row_quad);
+}
+// initColumnarGroups (QueryMemoryInitializer.cpp:713-780): every column filled with its init value
+__global__ __launch_bounds__(kBlock) void k_init_columns(ColLayout L, RowInit init, int8_t* __restrict__ cols) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < L.entry_count; e += stride)
+    entry_to_columns(L, init.quad, cols, e);
+}
+
 // ---- packed multi-column keys --------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_pack_keys(PackSpec ps, const int8_t* const* __restrict__ cols,
                                                        const int64_t* __restrict__ num_rows, int n_frags,
@@ -866,6 +888,23 @@ hipError_t launch_narrow_slots(const int64_t* wide, int wide_quad, int key_quad,
   if (entries <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_narrow_slots, dim3(grid_for(entries)), dim3(kBlock), 0, s, wide, wide_quad, key_quad,
                      slot_count, narrow_quad, entries, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_rows_to_columns(const ColLayout& L, const int64_t* rows, void* cols, hipStream_t s) {
+  if (L.entry_count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rows_to_columns, dim3(grid_for(L.entry_count)), dim3(kBlock), 0, s, L, rows, (int8_t*)cols);
+  return hipGetLastError();
+}
+hipError_t launch_columns_to_rows(const ColLayout& L, const void* cols, int64_t* rows, hipStream_t s) {
+  if (L.entry_count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_columns_to_rows, dim3(grid_for(L.entry_count)), dim3(kBlock), 0, s, L, (const int8_t*)cols,
+                     rows);
+  return hipGetLastError();
+}
+hipError_t launch_init_columns(const ColLayout& L, const RowInit& init, void* cols, hipStream_t s) {
+  if (L.entry_count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_init_columns, dim3(grid_for(L.entry_count)), dim3(kBlock), 0, s, L, init, (int8_t*)cols);
   return hipGetLastError();
 }
 

@@ -230,7 +230,8 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   if (p.n_cols < 0 || p.n_cols > MI355Q_MAX_COLS || p.n_inner_cols < 0 ||
       p.n_inner_cols > MI355Q_MAX_COLS || p.n_quals < 0 || p.n_quals > MI355Q_MAX_QUALS ||
       p.n_targets < 1 || p.n_targets > MI355Q_MAX_TARGETS || p.n_group_cols < 0 ||
-      p.n_group_cols > MI355Q_MAX_GROUP_COLS) {
+      p.n_group_cols > MI355Q_MAX_GROUP_COLS || p.output_columnar_hint < MI355Q_OUTPUT_ROWWISE ||
+      p.output_columnar_hint > MI355Q_OUTPUT_ROWWISE_COLUMNAR_DECISIONS) {
     return MI355Q_ERR_INVALID_PLAN;
   }
   for (int i = 0; i < p.n_cols; ++i) {
@@ -340,9 +341,10 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   } else if (q->desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
     q->entry_count = baseline_entries;
     if (q->entry_count > (int64_t)UINT32_MAX) return MI355Q_ERR_UNSUPPORTED;  // h is uint32
-    // pick_baseline_key_width: 4 only if every component's range is a valid int32 range
-    int kw = 4;
-    for (int g = 0; g < p.n_group_cols; ++g) {
+    // pick_baseline_key_width: 4 only if every component's range is a valid int32 range;
+    // "output_columnar ? 8 : pick_baseline_key_width(...)" (QueryMemoryDescriptor.cpp:386-388)
+    int kw = p.output_columnar_hint ? 8 : 4;
+    for (int g = 0; g < p.n_group_cols && !p.output_columnar_hint; ++g) {
       const int gc = p.group_cols[g];
       const mi355q_range& r = p.col_ranges[gc];
       const int logical_w = plain_width(tc_logical(col_type_code(p.cols[gc])));
@@ -410,7 +412,35 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   q->slot_width = compact ? 4 : 8;
   q->row_size = q->key_bytes + ((q->slot_width * q->slot_count + 7) & ~7);
   if (q->row_size <= 0) return MI355Q_ERR_INVALID_PLAN;
+  q->output_columnar = p.output_columnar_hint == MI355Q_OUTPUT_COLUMNAR;
+  // Not restated: with a columnar keyless single-column perfect hash the reference still calls
+  // get_columnar_group_bin_offset (GroupByAndAggregate.cpp:1425-1430, GroupByRuntime.cpp:228-239),
+  // which reads the FIRST SLOT's column as if it were the key column and overwrites an entry equal
+  // to EMPTY_KEY_64 with the key.  A first slot that starts at that value (MIN over int64) is refused.
+  if (q->output_columnar && q->keyless && p.n_group_cols == 1 && q->slot_width == 8 && q->slot_count > 0 &&
+      q->init_vals[0] == kEmptyKey64)
+    return MI355Q_ERR_UNSUPPORTED;
   return MI355Q_OK;
+}
+
+// getBufferSizeBytes (QueryMemoryDescriptor.cpp:1084-1111); columnar: 8 bytes per group column and
+// entry + getTotalBytesOfColumnarBuffers (every slot column align_to_int64(width * entry_count))
+int64_t qmd_buffer_bytes(const mi355q_qmd& q) {
+  if (!q.output_columnar) return q.entry_count * (int64_t)q.row_size;
+  return qmd_slot_col_offset(q, q.slot_count);
+}
+
+int64_t qmd_group_col_offset(const mi355q_qmd& q, int g) {
+  if (!q.output_columnar || q.keyless || g < 0 || g >= q.group_col_count) return -1;
+  return (int64_t)g * 8 * q.entry_count;
+}
+
+// s == slot_count gives the end of the last column (= the buffer size)
+int64_t qmd_slot_col_offset(const mi355q_qmd& q, int s) {
+  if (!q.output_columnar || s < 0 || s > q.slot_count) return -1;
+  const int64_t keys = q.keyless ? 0 : (int64_t)q.group_col_count * 8 * q.entry_count;
+  const int64_t col = ((int64_t)q.slot_width * q.entry_count + 7) & ~(int64_t)7;
+  return keys + (int64_t)s * col;
 }
 
 // fill_empty_key (ResultSet.cpp) + initColumnsPerRow (QueryMemoryInitializer.cpp:617-698):

@@ -19,6 +19,9 @@ struct ResolvedTarget {
 int col_type_code(const mi355q_col_desc& c);  // < 0 = invalid
 int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out);
 int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q);
+int64_t qmd_buffer_bytes(const mi355q_qmd& q);
+int64_t qmd_group_col_offset(const mi355q_qmd& q, int g);  // columnar descriptors; -1 otherwise
+int64_t qmd_slot_col_offset(const mi355q_qmd& q, int s);
 int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d);
 // the layout part of a DevPlan (what reduce / iteration / sort need) from a descriptor alone
 void layout_from_qmd(const mi355q_qmd& q, DevPlan* d);

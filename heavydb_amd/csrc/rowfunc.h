@@ -740,6 +740,35 @@ MQ_FN void narrow_row(const int64_t* wide, int key_quad, int slot_count, int nar
   const int n32 = (narrow_row_quad - key_quad) * 2;
   for (int s = 0; s < n32; ++s) s32[s] = s < slot_count ? (int32_t)wide[key_quad + s] : 0;
 }
+// ---------------------------------------------------------------- columnar output
+// A columnar descriptor (output_columnar_) stores entry e of group column g at
+// g * 8 * entry_count + e * 8 (getPrependedGroupColOffInBytes, QueryMemoryDescriptor.cpp:962-975;
+// no group columns when keyless) and of slot s at keys + s * align8(slot_width * entry_count) +
+// e * slot_width (getColOffInBytes :906-929).  The step runs on the row-wise form of the same
+// decisions; these move one finished entry between the two forms (same entry index, same values).
+MQ_FN void entry_to_columns(const ColLayout& L, const int64_t* row, int8_t* cols, int64_t e) {
+  for (int k = 0; k < L.key_quads; ++k) ((int64_t*)(cols + (int64_t)k * 8 * L.entry_count))[e] = row[k];
+  int8_t* sc = cols + (int64_t)L.key_quads * 8 * L.entry_count;
+  if (L.slot_width == 8) {
+    for (int s = 0; s < L.slot_count; ++s) ((int64_t*)(sc + (int64_t)s * L.slot_col_bytes))[e] = row[L.key_quads + s];
+  } else {
+    const int32_t* s32 = (const int32_t*)(row + L.key_quads);
+    for (int s = 0; s < L.slot_count; ++s) ((int32_t*)(sc + (int64_t)s * L.slot_col_bytes))[e] = s32[s];
+  }
+}
+MQ_FN void entry_from_columns(const ColLayout& L, const int8_t* cols, int64_t e, int64_t* row) {
+  for (int k = 0; k < L.key_quads; ++k) row[k] = ((const int64_t*)(cols + (int64_t)k * 8 * L.entry_count))[e];
+  const int8_t* sc = cols + (int64_t)L.key_quads * 8 * L.entry_count;
+  if (L.slot_width == 8) {
+    for (int s = 0; s < L.slot_count; ++s) row[L.key_quads + s] = ((const int64_t*)(sc + (int64_t)s * L.slot_col_bytes))[e];
+  } else {
+    int32_t* s32 = (int32_t*)(row + L.key_quads);
+    const int n32 = (L.row_quad - L.key_quads) * 2;  // an odd slot count leaves one zero padding word
+    for (int s = 0; s < n32; ++s)
+      s32[s] = s < L.slot_count ? ((const int32_t*)(sc + (int64_t)s * L.slot_col_bytes))[e] : 0;
+  }
+}
+
 // this (op)= that for one target of a compact row: agg_sum on the 32-bit COUNT
 // (AGGREGATE_ONE_COUNT with chosen_bytes 4), projections copied when set
 template <bool A>

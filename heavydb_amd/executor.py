@@ -90,6 +90,7 @@ class RelAlgExecutionUnit:
     # ExecutionOptions / globals shaping the layout
     max_groups_buffer_entry_guess: int = 16384  # Execute.cpp:111
     bigint_count: bool = False
+    output_columnar_hint: int = 0  # capi.OUTPUT_COLUMNAR: columnar result buffer (g_enable_columnar_output)
     num_tuples: int = 0   # rows of the input tables (0 = unknown / small): COUNT(*)-only group-bys
                           # get 4-byte slots while this is <= UINT32_MAX (pick_target_compact_width)
 
@@ -139,6 +140,7 @@ class RelAlgExecutionUnit:
         p.join_table = self.join_table.handle if self.join_table is not None else None
         p.max_groups_buffer_entry_guess = self.max_groups_buffer_entry_guess
         p.bigint_count = int(self.bigint_count)
+        p.output_columnar_hint = int(self.output_columnar_hint)
         p.num_tuples = int(self.num_tuples)
         return p
 
@@ -287,11 +289,27 @@ class ResultSet:
 
     def getStorage(self) -> np.ndarray:
         """The raw buffer (ResultSetStorage::buff_) copied to the host, as int64 quads
-        shaped [entry_count, row_size/8]."""
+        shaped [entry_count, row_size/8] — or flat for a columnar descriptor (`columns()` splits it)."""
         q = self.getQueryMemDesc()
         buf = np.empty(self.nbytes() // 8, dtype=np.int64)
         check(self._lib.mi355q_result_copy_to_host(self.handle, buf.ctypes.data, buf.nbytes))
-        return buf.reshape(q.entry_count, q.row_size // 8)
+        return buf if q.output_columnar else buf.reshape(q.entry_count, q.row_size // 8)
+
+    def columns(self) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+        """A columnar buffer (output_columnar_) split into its (group columns, slot columns), each of
+        entry_count elements: int64 keys, int64 or int32 slots."""
+        q = self.getQueryMemDesc()
+        if not q.output_columnar:
+            raise ValueError("row-wise result: use getStorage()")
+        raw = self.getStorage().view(np.int8)
+        n = q.entry_count
+        keys = [] if q.keyless else [
+            raw[(o := self._lib.mi355q_qmd_group_col_offset(C.byref(q), g)):o + 8 * n].view(np.int64)
+            for g in range(q.group_col_count)]
+        dt = np.int32 if q.slot_width == 4 else np.int64
+        slots = [raw[(o := self._lib.mi355q_qmd_slot_col_offset(C.byref(q), s)):o + q.slot_width * n].view(dt)
+                 for s in range(q.slot_count)]
+        return keys, slots
 
     # -- iteration
     def sort(self, target_idx: int, top_n: int, out_rows_dev: int, desc: bool = True,

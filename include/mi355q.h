@@ -222,7 +222,14 @@ typedef struct mi355q_plan {
                                             RelAlgExecutor.cpp:4213-4218) */
   int32_t bigint_count;                  /* g_bigint_count: COUNT is BIGINT and slots are always
                                             8 bytes wide */
-  int32_t reserved;
+  int32_t output_columnar_hint;          /* mi355q_columnar_hint: 1 = the step's output buffer is
+                                            COLUMNAR (output_columnar_hint of
+                                            QueryMemoryDescriptor::init, g_enable_columnar_output;
+                                            QueryMemoryDescriptor.cpp:311,387,515-531): one
+                                            8-byte column per group column, then one column per
+                                            slot, each align_to_int64(width * entry_count) bytes
+                                            (getColOffInBytes :906-947).  Baseline key components
+                                            are then 8 bytes wide (:387). */
   int64_t num_tuples;                    /* rows of the input tables (query_infos getNumTuples);
                                             0 = unknown / small.  A single-column GROUP BY whose
                                             targets are only COUNT(*) and projections of a key of
@@ -232,7 +239,17 @@ typedef struct mi355q_plan {
                                             QueryMemoryDescriptor.cpp:748-840) */
 } mi355q_plan;
 
-/* QueryMemoryDescriptor mirror (Descriptors/QueryMemoryDescriptor.h).  Row-wise layout; slots
+/* plan.output_columnar_hint */
+typedef enum mi355q_columnar_hint {
+  MI355Q_OUTPUT_ROWWISE = 0,
+  MI355Q_OUTPUT_COLUMNAR = 1,
+  /* the layout DECISIONS of a columnar descriptor (8-byte baseline key components) stored
+   * row-wise: the library's own intermediate form of a columnar step, also accepted from callers */
+  MI355Q_OUTPUT_ROWWISE_COLUMNAR_DECISIONS = 2
+} mi355q_columnar_hint;
+
+/* QueryMemoryDescriptor mirror (Descriptors/QueryMemoryDescriptor.h).  Row-wise layout unless
+ * output_columnar is set; slots
  * are 8 bytes wide (crt_min_byte_width = 8, Execute.cpp:2237) except for the COUNT(*)-only
  * shapes that pick_target_compact_width narrows to 4 (slot_width). */
 typedef struct mi355q_qmd {
@@ -260,9 +277,16 @@ typedef struct mi355q_qmd {
   int32_t group_has_nulls[MI355Q_MAX_GROUP_COLS];
   int32_t has_nulls;
   int32_t row_size;      /* bytes, getRowSize() (QueryMemoryDescriptor.cpp:848):
-                            align8(key bytes) + align8(slot_count * slot_width) */
+                            align8(key bytes) + align8(slot_count * slot_width).  For a
+                            columnar descriptor: the size of one entry in the row-wise form of
+                            the same decisions (the buffer itself is sized by
+                            mi355q_qmd_buffer_bytes) */
   int32_t slot_width;    /* 8, or 4 (ColSlotContext::setAllSlotsPaddedSize(min_slot_size)) */
-  int32_t pad_;
+  int32_t output_columnar; /* output_columnar_: the buffer is
+                              [group col 0 | ... | slot 0 | slot 1 | ...], every column
+                              align_to_int64(width * entry_count) bytes, group columns 8 bytes
+                              wide (getPrependedGroupColOffInBytes :962-975), none when
+                              keyless; see mi355q_qmd_group_col_offset / _slot_col_offset */
   int32_t key_bytes;     /* align_to_int64(group_col_count * key_width), 0 if keyless */
   int32_t n_targets;
   int32_t target_slot[MI355Q_MAX_TARGETS];      /* first slot of each target; -1 if the
@@ -343,6 +367,12 @@ int32_t mi355q_device_info(int32_t device_id, char* name, int32_t* cu_count,
 /* ---- plan -> layout ---- */
 int32_t mi355q_qmd_init(const mi355q_plan* plan, mi355q_qmd* out);
 int64_t mi355q_qmd_buffer_bytes(const mi355q_qmd* qmd);
+/* Columnar descriptors: byte offset of group column g (getPrependedGroupColOffInBytes,
+ * QueryMemoryDescriptor.cpp:962-975) and of slot column s (getColOffInBytes :906-929) in the
+ * buffer; -1 if the descriptor is row-wise or the index is out of range (a keyless descriptor
+ * has no group columns). */
+int64_t mi355q_qmd_group_col_offset(const mi355q_qmd* qmd, int32_t g);
+int64_t mi355q_qmd_slot_col_offset(const mi355q_qmd* qmd, int32_t s);
 
 /* ---- execute one query step on one device ---- */
 int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* inputs,

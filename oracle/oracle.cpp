@@ -613,9 +613,10 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
     q.desc_type = MI355Q_GROUP_BY_BASELINE_HASH;
     q.entry_count = p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess
                                                         : 16384;
-    // pick_baseline_key_width (QueryMemoryDescriptor.cpp:113-146): the widest component
-    int kw = 4;
-    for (int g = 0; g < p.n_group_cols; ++g) {
+    // pick_baseline_key_width (QueryMemoryDescriptor.cpp:113-146): the widest component;
+    // "group_col_compact_width = output_columnar ? 8 : pick_baseline_key_width" (:386-388)
+    int kw = p.output_columnar_hint ? 8 : 4;
+    for (int g = 0; g < p.n_group_cols && !p.output_columnar_hint; ++g) {
       const auto& gcd = p.cols[p.group_cols[g]];
       const auto& r = p.col_ranges[p.group_cols[g]];
       int w = 8;
@@ -689,7 +690,127 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   }
   q.row_size = q.key_bytes + ((q.slot_width * q.slot_count + 7) & ~7);
   if (q.row_size == 0) return MI355Q_ERR_INVALID_PLAN;
+  // output_columnar_ = output_columnar_hint for GroupByPerfectHash / GroupByBaselineHash /
+  // NonGroupedAggregate without distinct / quantile / mode targets (QueryMemoryDescriptor.cpp:515-531)
+  if (p.output_columnar_hint < 0 || p.output_columnar_hint > 2) return MI355Q_ERR_INVALID_PLAN;
+  q.output_columnar = p.output_columnar_hint == MI355Q_OUTPUT_COLUMNAR;
+  // the library refuses the one columnar shape whose reference behaviour it does not restate
+  // (see columnar_bin_single below): keyless single-column perfect hash whose first slot starts at
+  // EMPTY_KEY_64
+  if (q.output_columnar && q.keyless && p.n_group_cols == 1 && q.slot_width == 8 && q.slot_count > 0 &&
+      q.init_vals[0] == kEmptyKey64)
+    return MI355Q_ERR_UNSUPPORTED;
   return 0;
+}
+
+// ---------------------------------------------------------------- columnar layout
+inline int64_t align_to_int64(int64_t v) { return (v + 7) & ~(int64_t)7; }
+// getPrependedGroupColOffInBytes (QueryMemoryDescriptor.cpp:962-975): max(groupColWidth, 8) per key
+int64_t col_group_off(const mi355q_qmd& q, int group_idx) {
+  int64_t offset = 0;
+  for (int col_idx = 0; col_idx < group_idx; ++col_idx)
+    offset += align_to_int64(std::max<int64_t>(q.key_width, 8) * q.entry_count);
+  return offset;
+}
+// getColOffInBytes, output_columnar_ branch (:906-929)
+int64_t col_slot_off(const mi355q_qmd& q, int col_idx) {
+  int64_t offset = 0;
+  if (!q.keyless) offset += col_group_off(q, q.group_col_count);  // getPrependedGroupBufferSizeInBytes
+  for (int index = 0; index < col_idx; ++index) offset += align_to_int64((int64_t)q.slot_width * q.entry_count);
+  return offset;
+}
+// getBufferSizeBytes (:1084-1111): 8 * group columns * entries + getTotalBytesOfColumnarBuffers
+int64_t buffer_bytes(const mi355q_qmd& q) {
+  if (!q.output_columnar) return q.entry_count * (int64_t)q.row_size;
+  int64_t total = q.keyless ? 0 : (int64_t)sizeof(int64_t) * q.group_col_count * q.entry_count;
+  for (int s = 0; s < q.slot_count; ++s) total += align_to_int64((int64_t)q.slot_width * q.entry_count);
+  return total;
+}
+// one entry of a columnar buffer <-> the row image the row-wise code works on (key quads, slots)
+void col_gather(const mi355q_qmd& q, const int64_t* buf, int64_t e, int64_t* row) {
+  const int8_t* b = reinterpret_cast<const int8_t*>(buf);
+  const int kq = q.key_bytes / 8;
+  for (int k = 0; k < kq; ++k) row[k] = reinterpret_cast<const int64_t*>(b + col_group_off(q, k))[e];
+  for (int w = kq; w < q.row_size / 8; ++w) row[w] = 0;
+  for (int sl = 0; sl < q.slot_count; ++sl) {
+    const int8_t* c = b + col_slot_off(q, sl);
+    if (q.slot_width == 8) row[kq + sl] = reinterpret_cast<const int64_t*>(c)[e];
+    else reinterpret_cast<int32_t*>(row + kq)[sl] = reinterpret_cast<const int32_t*>(c)[e];
+  }
+}
+void col_scatter_slots(const mi355q_qmd& q, const int64_t* slots, int64_t* buf, int64_t e) {
+  int8_t* b = reinterpret_cast<int8_t*>(buf);
+  for (int sl = 0; sl < q.slot_count; ++sl) {
+    int8_t* c = b + col_slot_off(q, sl);
+    if (q.slot_width == 8) reinterpret_cast<int64_t*>(c)[e] = slots[sl];
+    else reinterpret_cast<int32_t*>(c)[e] = reinterpret_cast<const int32_t*>(slots)[sl];
+  }
+}
+void col_scatter(const mi355q_qmd& q, const int64_t* row, int64_t* buf, int64_t e) {
+  int8_t* b = reinterpret_cast<int8_t*>(buf);
+  const int kq = q.key_bytes / 8;
+  for (int k = 0; k < kq; ++k) reinterpret_cast<int64_t*>(b + col_group_off(q, k))[e] = row[k];
+  col_scatter_slots(q, row + kq, buf, e);
+}
+// the row-wise descriptor of the same decisions
+mi355q_qmd rowwise_of(const mi355q_qmd& q) {
+  mi355q_qmd r = q;
+  r.output_columnar = 0;
+  return r;
+}
+std::vector<int64_t> col_to_rows(const mi355q_qmd& q, const int64_t* buf) {
+  const int rq = q.row_size / 8;
+  std::vector<int64_t> rows((size_t)q.entry_count * rq);
+  for (int64_t e = 0; e < q.entry_count; ++e) col_gather(q, buf, e, rows.data() + e * rq);
+  return rows;
+}
+// get_columnar_group_bin_offset (GroupByRuntime.cpp:227-239).  The reference emits it for the
+// keyless layout as well (GroupByAndAggregate.cpp:1425-1430), where key_base_ptr is the FIRST SLOT's
+// column: an entry equal to EMPTY_KEY_64 there is overwritten with the key.
+inline uint32_t get_columnar_group_bin_offset(int64_t* key_base_ptr, int64_t key, int64_t min_key, int64_t bucket) {
+  int64_t off = key - min_key;
+  if (bucket) off /= bucket;
+  if (key_base_ptr[off] == kEmptyKey64) key_base_ptr[off] = key;
+  return (uint32_t)off;
+}
+// set_matching_group_value_perfect_hash_columnar (RuntimeFunctions.cpp:2109-2120)
+inline void set_matching_group_value_perfect_hash_columnar(int64_t* groups_buffer, uint32_t hashed_index,
+                                                           const int64_t* key, uint32_t key_count,
+                                                           uint32_t entry_count) {
+  if (groups_buffer[hashed_index] == kEmptyKey64) {
+    for (uint32_t i = 0; i < key_count; i++) groups_buffer[(size_t)i * entry_count + hashed_index] = key[i];
+  }
+}
+// get_matching_group_value_columnar_slot<int64_t> (RuntimeFunctions.cpp:1994-2017)
+inline int32_t get_matching_group_value_columnar_slot(int64_t* groups_buffer, uint32_t entry_count, uint32_t h,
+                                                      const int64_t* key, uint32_t key_count) {
+  size_t off = h;
+  if (groups_buffer[off] == kEmptyKey64) {
+    for (size_t i = 0; i < key_count; ++i) {
+      groups_buffer[off] = key[i];
+      off += entry_count;
+    }
+    return (int32_t)h;
+  }
+  off = h;
+  for (size_t i = 0; i < key_count; ++i) {
+    if (groups_buffer[off] != key[i]) return -1;
+    off += entry_count;
+  }
+  return (int32_t)h;
+}
+// get_group_value_columnar_slot (GroupByRuntime.cpp:84-105), key_width 8
+inline int32_t get_group_value_columnar_slot(int64_t* groups_buffer, uint32_t entry_count, const int64_t* key,
+                                             uint32_t key_count) {
+  const uint32_t h = murmur3(key, (int)(key_count * sizeof(int64_t)), 0) % entry_count;
+  if (get_matching_group_value_columnar_slot(groups_buffer, entry_count, h, key, key_count) != -1) return (int32_t)h;
+  uint32_t h_probe = (h + 1) % entry_count;
+  while (h_probe != h) {
+    if (get_matching_group_value_columnar_slot(groups_buffer, entry_count, h_probe, key, key_count) != -1)
+      return (int32_t)h_probe;
+    h_probe = (h_probe + 1) % entry_count;
+  }
+  return -1;
 }
 
 // ---------------------------------------------------------------- buffer init
@@ -697,6 +818,30 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
 void init_buffer(const mi355q_qmd& q, int64_t* buf) {
   const int rq = q.row_size / 8;
   const int kq = q.key_bytes / 8;
+  if (q.output_columnar) {
+    // initColumnarGroups (QueryMemoryInitializer.cpp:713-780): each key column EMPTY_KEY_64, each
+    // slot column its init value at the slot's width, the pointer re-aligned after every column
+    int8_t* buffer_ptr = reinterpret_cast<int8_t*>(buf);
+    if (!q.keyless) {
+      for (int i = 0; i < q.group_col_count; ++i) {
+        int64_t* c = reinterpret_cast<int64_t*>(buffer_ptr);
+        for (int64_t e = 0; e < q.entry_count; ++e) c[e] = kEmptyKey64;
+        buffer_ptr += 8 * q.entry_count;
+      }
+    }
+    for (int i = 0; i < q.slot_count; ++i) {
+      if (q.slot_width == 4) {
+        int32_t* c = reinterpret_cast<int32_t*>(buffer_ptr);
+        for (int64_t e = 0; e < q.entry_count; ++e) c[e] = (int32_t)q.init_vals[i];
+        if (q.entry_count & 1) c[q.entry_count] = 0;  // the padding word (uninitialised in the reference)
+      } else {
+        int64_t* c = reinterpret_cast<int64_t*>(buffer_ptr);
+        for (int64_t e = 0; e < q.entry_count; ++e) c[e] = q.init_vals[i];
+      }
+      buffer_ptr += align_to_int64((int64_t)q.slot_width * q.entry_count);
+    }
+    return;
+  }
   for (int64_t e = 0; e < q.entry_count; ++e) {
     int64_t* row = buf + e * rq;
     if (kq) {  // result_set::fill_empty_key: every component EMPTY, padding zero
@@ -1179,8 +1324,14 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
     }
     int64_t* slots;
     int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};  // group_by_expr_cache_: values as decoded
+    // columnar output: the entry ("bin") comes from the *_columnar runtime functions and the
+    // aggregate calls address column + bin * width; here the entry's slots are gathered into a
+    // row image, updated by the same agg_* calls, and written back
+    int64_t col_bin = -1;
+    int64_t col_tmp[MI355Q_MAX_SLOTS + 1];
+    const bool columnar = q.output_columnar && grouped;
     if (!grouped) {
-      slots = buf;
+      slots = buf;  // one entry: every 8-byte slot column holds one value, same bytes as a row
     } else {
       for (int g = 0; g < ng; ++g) {
         keys[g] = decode_col(p.cols[p.group_cols[g]], cols[p.group_cols[g]], pos);
@@ -1200,7 +1351,25 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
             return MI355Q_ERR_OUT_OF_SLOTS;
           }
         }
-        if (ng == 1) {
+        if (columnar && ng == 1) {
+          // codegenSingleColumnPerfectHash: get_columnar_group_bin_offset on groups_buffer (the key
+          // column — or, keyless, the first slot's column) with the TRANSLATED key
+          col_bin = get_columnar_group_bin_offset(buf, tk[0], q.min_val, q.bucket);
+          slots = nullptr;
+        } else if (columnar) {
+          int64_t hash = 0;
+          for (int g = 0; g < ng; ++g) {
+            int64_t term = tk[g] - q.group_min[g];
+            if (q.group_bucket[g]) term /= q.group_bucket[g];
+            for (int prev = 0; prev < g; ++prev) term *= q.group_card[prev];
+            hash += term;
+          }
+          const uint32_t h32 = (uint32_t)hash;
+          // codegenMultiColumnPerfectHash, columnar: keys are set unless keyless
+          if (!q.keyless) set_matching_group_value_perfect_hash_columnar(buf, h32, tk, ng, (uint32_t)q.entry_count);
+          col_bin = h32;
+          slots = nullptr;
+        } else if (ng == 1) {
           slots = q.keyless ? get_group_value_fast_keyless(buf, tk[0], q.min_val, rq)
                             : get_group_value_fast(buf, tk[0], q.min_val, q.bucket, rq);
         } else {
@@ -1216,6 +1385,11 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
           slots = q.keyless ? buf + (size_t)rq * h32  // ..._perfect_hash_keyless :2098-2103
                             : get_matching_group_value_perfect_hash(buf, h32, tk, ng, rq);
         }
+      } else if (columnar) {
+        // codegenMultiColumnBaselineHash: get_group_value_columnar_slot, 8-byte components
+        const int32_t b = get_group_value_columnar_slot(buf, (uint32_t)q.entry_count, keys, ng);
+        col_bin = b;
+        slots = b < 0 ? nullptr : col_tmp;
       } else if (ng == 1) {
         slots = get_group_value(buf, (uint32_t)q.entry_count, keys[0], q.key_width, rq);
       } else {
@@ -1226,6 +1400,14 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
         slots = get_group_value_n(buf, (uint32_t)q.entry_count,
                                   q.key_width == 4 ? (const void*)k32 : (const void*)keys, ng,
                                   q.key_width, rq);
+      }
+      if (columnar && col_bin >= 0) {
+        for (int sl = 0; sl < q.slot_count; ++sl) {
+          const int8_t* c = reinterpret_cast<const int8_t*>(buf) + col_slot_off(q, sl);
+          if (q.slot_width == 8) col_tmp[sl] = reinterpret_cast<const int64_t*>(c)[col_bin];
+          else reinterpret_cast<int32_t*>(col_tmp)[sl] = reinterpret_cast<const int32_t*>(c)[col_bin];
+        }
+        slots = col_tmp;
       }
       if (!slots) {
         // row_func returns -pos -> "ran out of slots" (GroupByAndAggregate.cpp:1151-1156)
@@ -1246,6 +1428,7 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
           }
         }
       }
+      if (col_bin >= 0) col_scatter_slots(q, col_tmp, buf, col_bin);
       continue;
     }
     // one joined row per matching inner row (JoinLoop, Set / Singleton kinds)
@@ -1255,6 +1438,7 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
         apply_target(p, t, slots, cols, pos, c.inner_cols, inner_pos, keys);
       }
     }
+    if (col_bin >= 0) col_scatter_slots(q, col_tmp, buf, col_bin);
   }
   return 0;
 }
@@ -1339,6 +1523,15 @@ inline void reduce_one_target(const mi355q_qmd& q, int ti, int64_t* this_slots,
 // ResultSetStorage::isEmptyEntry (ResultSetIteration.cpp:2457-2492)
 inline bool is_empty_entry(const mi355q_qmd& q, const int64_t* buf, int64_t e) {
   if (q.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return false;
+  if (q.output_columnar) {  // isEmptyEntryColumnar (ResultSet.cpp): first key column / the keyless key slot's column
+    const int8_t* b = reinterpret_cast<const int8_t*>(buf);
+    if (q.keyless) {
+      const int8_t* c = b + col_slot_off(q, q.idx_target_as_key);
+      return q.slot_width == 4 ? reinterpret_cast<const int32_t*>(c)[e] == (int32_t)q.init_vals[q.idx_target_as_key]
+                               : reinterpret_cast<const int64_t*>(c)[e] == q.init_vals[q.idx_target_as_key];
+    }
+    return reinterpret_cast<const int64_t*>(b)[e] == kEmptyKey64;
+  }
   const int64_t* row = buf + e * (q.row_size / 8);
   if (q.keyless && q.slot_width == 4) {
     return reinterpret_cast<const int32_t*>(row)[q.idx_target_as_key] == (int32_t)q.init_vals[q.idx_target_as_key];
@@ -1375,6 +1568,16 @@ inline void reduce_targets(const mi355q_qmd& q, int64_t* this_slots, const int64
 int32_t reduce_buffers(const mi355q_qmd& q, int64_t* this_buf, const int64_t* that_buf) {
   const int rq = q.row_size / 8;
   const int kq = q.key_bytes / 8;
+  if (q.output_columnar) {
+    // ResultSetStorage::reduce on columnar buffers applies the same per-entry rules through
+    // column offsets (reduceOneEntryNoCollisions / reduceOneEntryBaseline with
+    // getColOffInBytes): reduced here on the row images of both sides
+    const mi355q_qmd qr = rowwise_of(q);
+    std::vector<int64_t> a = col_to_rows(q, this_buf), b = col_to_rows(q, that_buf);
+    if (int32_t e = reduce_buffers(qr, a.data(), b.data())) return e;
+    for (int64_t e = 0; e < q.entry_count; ++e) col_scatter(q, a.data() + e * rq, this_buf, e);
+    return 0;
+  }
   if (q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
     for (int64_t e = 0; e < q.entry_count; ++e) {
       if (is_empty_entry(q, that_buf, e)) continue;
@@ -1678,7 +1881,7 @@ ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   c.inner_rows = in->inner_num_rows;
   if (plan->join_outer_col >= 0 && !c.join) return MI355Q_ERR_INVALID_PLAN;
   if (out_qmd) *out_qmd = c.qmd;
-  const size_t quads = (size_t)c.qmd.entry_count * (c.qmd.row_size / 8);
+  const size_t quads = (size_t)(buffer_bytes(c.qmd) / 8);
   n_threads = std::max(1, std::min(n_threads, std::max(1, in->n_frags)));
 
   std::vector<std::vector<int64_t>> bufs(n_threads);
@@ -1715,6 +1918,10 @@ ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   return 0;
 }
 
+ORC_EXPORT int64_t orc_buffer_bytes(const mi355q_qmd* q) { return buffer_bytes(*q); }
+ORC_EXPORT int64_t orc_col_group_off(const mi355q_qmd* q, int32_t g) { return col_group_off(*q, g); }
+ORC_EXPORT int64_t orc_col_slot_off(const mi355q_qmd* q, int32_t s) { return col_slot_off(*q, s); }
+
 ORC_EXPORT int32_t orc_reduce(const mi355q_qmd* q, int64_t* this_buf, const int64_t* that_buf) {
   return reduce_buffers(*q, this_buf, that_buf);
 }
@@ -1730,6 +1937,11 @@ ORC_EXPORT int64_t orc_row_count(const mi355q_qmd* q, const int64_t* buf) {
 ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64_t max_rows,
                                   int64_t* ival, double* dval, int8_t* is_null,
                                   int64_t* n_rows) {
+  if (q->output_columnar) {  // getTargetValueFromBufferColwise reads the same values through column offsets
+    const mi355q_qmd qr = rowwise_of(*q);
+    const std::vector<int64_t> rows = col_to_rows(*q, buf);
+    return orc_fetch_rows(&qr, rows.data(), max_rows, ival, dval, is_null, n_rows);
+  }
   const int rq = q->row_size / 8;
   const int kq = q->key_bytes / 8;
   int64_t n = 0;

@@ -86,6 +86,11 @@ def lib() -> C.CDLL:
         l.orc_execute.restype = C.c_int32
         l.orc_execute.argtypes = [P(capi.Plan), P(capi.Inputs), C.c_void_p, C.c_int32,
                                   C.c_void_p, P(capi.QMD)]
+        for fn in ("orc_buffer_bytes", "orc_col_group_off", "orc_col_slot_off"):
+            getattr(l, fn).restype = C.c_int64
+        l.orc_buffer_bytes.argtypes = [P(capi.QMD)]
+        l.orc_col_group_off.argtypes = [P(capi.QMD), C.c_int32]
+        l.orc_col_slot_off.argtypes = [P(capi.QMD), C.c_int32]
         l.orc_reduce.restype = C.c_int32
         l.orc_reduce.argtypes = [P(capi.QMD), C.c_void_p, C.c_void_p]
         l.orc_row_count.restype = C.c_int64
@@ -256,15 +261,34 @@ def execute(plan: capi.Plan, frag_cols: Sequence[Sequence[np.ndarray]],
     inp.num_rows = C.cast(rows, C.POINTER(C.c_int64))
     inp.inner_col_buffers = C.cast(inner, C.POINTER(C.c_void_p))
     inp.inner_num_rows = len(inner_cols[0]) if len(inner_cols) else 0
-    buf = np.empty((q.entry_count, q.row_size // 8), dtype=np.int64)
+    buf = _alloc(q)
     out_q = capi.QMD()
     code = lib().orc_execute(C.byref(plan), C.byref(inp), join.handle if join else None,
                              n_threads, buf.ctypes.data, C.byref(out_q))
     return out_q, buf, code
 
 
+def buffer_bytes(q: capi.QMD) -> int:
+    return lib().orc_buffer_bytes(C.byref(q))
+
+
+def col_group_off(q: capi.QMD, g: int) -> int:
+    return lib().orc_col_group_off(C.byref(q), g)
+
+
+def col_slot_off(q: capi.QMD, s: int) -> int:
+    return lib().orc_col_slot_off(C.byref(q), s)
+
+
+def _alloc(q: capi.QMD) -> np.ndarray:
+    """[entry_count, row quads] for a row-wise descriptor, flat int64 for a columnar one."""
+    if q.output_columnar:
+        return np.zeros(buffer_bytes(q) // 8, dtype=np.int64)
+    return np.empty((q.entry_count, q.row_size // 8), dtype=np.int64)
+
+
 def init_buffer(q: capi.QMD) -> np.ndarray:
-    buf = np.empty((q.entry_count, q.row_size // 8), dtype=np.int64)
+    buf = _alloc(q)
     lib().orc_init_buffer(C.byref(q), buf.ctypes.data)
     return buf
 

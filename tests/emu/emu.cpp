@@ -14,12 +14,59 @@ using namespace mq;
 
 extern "C" int32_t emu_qmd_init(const mi355q_plan* p, mi355q_qmd* q) { return qmd_init(*p, q); }
 
+// api.cpp col_layout_of
+static ColLayout emu_col_layout(const mi355q_qmd& q) {
+  ColLayout L{};
+  L.entry_count = q.entry_count;
+  L.slot_col_bytes = ((int64_t)q.slot_width * q.entry_count + 7) & ~(int64_t)7;
+  L.key_quads = q.key_bytes / 8;
+  L.slot_count = q.slot_count;
+  L.slot_width = q.slot_width;
+  L.row_quad = q.row_size / 8;
+  return L;
+}
+
+extern "C" int64_t emu_buffer_bytes(const mi355q_qmd* q) { return qmd_buffer_bytes(*q); }
+extern "C" int64_t emu_group_col_offset(const mi355q_qmd* q, int g) { return qmd_group_col_offset(*q, g); }
+extern "C" int64_t emu_slot_col_offset(const mi355q_qmd* q, int s) { return qmd_slot_col_offset(*q, s); }
+
+// initColumnarGroups through the product's code (k_init_columns: entry_to_columns of the init row)
+extern "C" void emu_init_buffer(const mi355q_qmd* q, int64_t* buf) {
+  int64_t img[MI355Q_MAX_GROUP_COLS + MI355Q_MAX_SLOTS];
+  row_init_image(*q, img);
+  if (q->output_columnar) {
+    const ColLayout L = emu_col_layout(*q);
+    for (int64_t e = 0; e < q->entry_count; ++e) entry_to_columns(L, img, (int8_t*)buf, e);
+  } else {
+    for (int64_t e = 0; e < q->entry_count; ++e) std::memcpy(buf + e * (q->row_size / 8), img, q->row_size);
+  }
+}
+
 extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                                int join_hash_type, const void* join_buf, int64_t join_min,
                                int64_t join_max, int64_t join_entries, int join_n_keys,
                                int join_width, int64_t* out, mi355q_qmd* out_qmd) {
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;
+  if (q.output_columnar) {
+    // like mi355q_execute: the step runs on the row-wise form of the same decisions, then every
+    // entry is moved into the columns (rowfunc.h entry_to_columns)
+    mi355q_plan pr = *plan;
+    pr.output_columnar_hint = MI355Q_OUTPUT_ROWWISE_COLUMNAR_DECISIONS;
+    mi355q_qmd qr;
+    if (int32_t e = qmd_init(pr, &qr)) return e;
+    if (qr.entry_count != q.entry_count || qr.row_size != q.row_size || qr.key_bytes != q.key_bytes ||
+        qr.slot_count != q.slot_count || qr.slot_width != q.slot_width)
+      return MI355Q_ERR_UNSUPPORTED;
+    std::vector<int64_t> rows((size_t)qr.entry_count * (qr.row_size / 8));
+    if (int32_t e = emu_execute(&pr, in, join_hash_type, join_buf, join_min, join_max, join_entries, join_n_keys,
+                                join_width, rows.data(), nullptr))
+      return e;
+    const ColLayout L = emu_col_layout(q);
+    for (int64_t e = 0; e < q.entry_count; ++e) entry_to_columns(L, rows.data() + e * L.row_quad, (int8_t*)out, e);
+    if (out_qmd) *out_qmd = q;
+    return 0;
+  }
   if (q.slot_width == 4) {
     // like mi355q_execute: the step runs on the 8-byte layout of the same plan, then every row is
     // narrowed (rowfunc.h narrow_row)
@@ -103,6 +150,21 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
 // this += that through the same code the k_reduce kernel runs per entry
 extern "C" int32_t emu_reduce(const mi355q_qmd* q, int64_t* this_buf, const int64_t* that_rows,
                               int64_t that_entries) {
+  if (q->output_columnar) {
+    // mi355q_result_reduce on columnar handles: row-wise twins, the reduce kernel's code, store back
+    mi355q_qmd qr = *q;
+    qr.output_columnar = 0;
+    const ColLayout L = emu_col_layout(*q);
+    std::vector<int64_t> a((size_t)q->entry_count * L.row_quad), b((size_t)that_entries * L.row_quad);
+    ColLayout Lb = L;
+    Lb.entry_count = that_entries;
+    Lb.slot_col_bytes = ((int64_t)q->slot_width * that_entries + 7) & ~(int64_t)7;
+    for (int64_t e = 0; e < q->entry_count; ++e) entry_from_columns(L, (const int8_t*)this_buf, e, a.data() + e * L.row_quad);
+    for (int64_t e = 0; e < that_entries; ++e) entry_from_columns(Lb, (const int8_t*)that_rows, e, b.data() + e * L.row_quad);
+    if (int32_t err = emu_reduce(&qr, a.data(), b.data(), that_entries)) return err;
+    for (int64_t e = 0; e < q->entry_count; ++e) entry_to_columns(L, a.data() + e * L.row_quad, (int8_t*)this_buf, e);
+    return 0;
+  }
   DevPlan d;
   std::memset(&d, 0, sizeof(d));
   layout_from_qmd(*q, &d);

@@ -154,6 +154,39 @@ def compare_rows(q: capi.QMD, want, got, rtol: float = 1e-9):
     assert ok.all(), (wd[~ok][:5], gd[~ok][:5])
 
 
+def rowwise_qmd(q: capi.QMD) -> capi.QMD:
+    r = capi.QMD.from_buffer_copy(q)
+    r.output_columnar = 0
+    return r
+
+
+def columnar_to_rows(q: capi.QMD, flat: np.ndarray) -> np.ndarray:
+    """The row images [entry_count, row_size / 8] of a columnar buffer — the layout written out
+    from the reference's formulas a third time (numpy): group column g at g * 8 * E
+    (getPrependedGroupColOffInBytes, none when keyless), then slot column s at
+    s * align8(slot_width * E) (getColOffInBytes); total = getBufferSizeBytes."""
+    assert q.output_columnar
+    E = q.entry_count
+    raw = np.ascontiguousarray(flat).view(np.int8).reshape(-1)
+    kq = 0 if q.keyless else q.group_col_count
+    assert kq == q.key_bytes // 8
+    rows = np.zeros((E, q.row_size // 8), dtype=np.int64)
+    off = 0
+    for k in range(kq):
+        rows[:, k] = raw[off:off + 8 * E].view(np.int64)
+        off += 8 * E
+    col_bytes = (q.slot_width * E + 7) // 8 * 8
+    s32 = rows[:, kq:].view(np.int32) if q.slot_width == 4 else None
+    for s in range(q.slot_count):
+        if q.slot_width == 8:
+            rows[:, kq + s] = raw[off:off + 8 * E].view(np.int64)
+        else:
+            s32[:, s] = raw[off:off + 4 * E].view(np.int32)
+        off += col_bytes
+    assert off == raw.nbytes, (off, raw.nbytes)
+    return rows
+
+
 def murmur3_u64(keys: np.ndarray) -> np.ndarray:
     """MurmurHash3_x86_32 of little-endian int64 keys, seed 0 (key_hash of one 8-byte key,
     GroupByRuntime.cpp:20-23 + MurmurHash3Inl.h) — numpy restatement, pinned against the
@@ -259,6 +292,13 @@ def emu_lib() -> C.CDLL:
         l.emu_execute.restype = C.c_int32
         l.emu_execute.argtypes = [P(capi.Plan), P(capi.Inputs), C.c_int, C.c_void_p, C.c_int64,
                                   C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_void_p, P(capi.QMD)]
+        for fn in ("emu_buffer_bytes", "emu_group_col_offset", "emu_slot_col_offset"):
+            getattr(l, fn).restype = C.c_int64
+        l.emu_buffer_bytes.argtypes = [P(capi.QMD)]
+        l.emu_group_col_offset.argtypes = [P(capi.QMD), C.c_int]
+        l.emu_slot_col_offset.argtypes = [P(capi.QMD), C.c_int]
+        l.emu_init_buffer.restype = None
+        l.emu_init_buffer.argtypes = [P(capi.QMD), C.c_void_p]
         l.emu_reduce.restype = C.c_int32
         l.emu_reduce.argtypes = [P(capi.QMD), C.c_void_p, C.c_void_p, C.c_int64]
         _emu = l

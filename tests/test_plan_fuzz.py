@@ -158,6 +158,35 @@ def _fuzz_table(rng, n_rows):
     return descs, cols
 
 
+def _fuzz_row_plan(rng, descs):
+    """A random step over the columns of _fuzz_table: 0-3 group columns, 1-4 targets of every kind, maybe a qual."""
+    int_cols = [j for j, d in enumerate(descs) if d.type not in (capi.DOUBLE, capi.FLOAT)]
+    n_group = int(rng.integers(0, 4))
+    group = [int(x) for x in rng.choice(int_cols, size=min(n_group, len(int_cols)), replace=False)] if int_cols else []
+    targets = []
+    for _ in range(int(rng.integers(1, 5))):
+        k = int(rng.integers(0, 9))
+        col = int(rng.integers(0, len(descs)))
+        cc = int(rng.integers(0, len(descs)))
+        cond = Qual(cc, [capi.LT, capi.GE, capi.NE][int(rng.integers(0, 3))], 0)
+        if k == 0 and group:
+            targets.append(TargetExpr(capi.PROJECT_KEY, int(rng.integers(0, len(group)))))
+        elif k == 1 or (k == 0 and not group):
+            targets.append(TargetExpr(capi.COUNT))
+        elif k == 2:
+            targets.append(TargetExpr(capi.COUNT, col))
+        elif k == 3:
+            targets.append(TargetExpr(capi.COUNT_IF, cond=cond))
+        elif k == 4:
+            targets.append(TargetExpr(capi.SUM_IF, col, cond=cond))
+        else:
+            targets.append(TargetExpr([capi.SUM, capi.AVG, capi.MIN, capi.MAX][k - 5], col))
+    quals = [Qual(int(rng.integers(0, len(descs))), capi.GE, -5)] if rng.integers(0, 2) else []
+    ra = RelAlgExecutionUnit(descs, targets, quals, group, max_groups_buffer_entry_guess=2048,
+                             bigint_count=bool(rng.integers(0, 4) == 0))
+    return ra
+
+
 def test_row_logic_agrees_on_random_plans(oracle):
     """Random tables x random plans through the product's row function (host emulation) and the
     oracle: same layout, same table (baseline as key -> slots maps, fp64 within 1e-9, fp32 2e-4)."""
@@ -168,30 +197,7 @@ def test_row_logic_agrees_on_random_plans(oracle):
     for i in range(400):
         n_rows = int(rng.integers(1, 400))
         descs, cols = _fuzz_table(rng, n_rows)
-        int_cols = [j for j, d in enumerate(descs) if d.type not in (capi.DOUBLE, capi.FLOAT)]
-        n_group = int(rng.integers(0, 4))
-        group = [int(x) for x in rng.choice(int_cols, size=min(n_group, len(int_cols)), replace=False)] if int_cols else []
-        targets = []
-        for _ in range(int(rng.integers(1, 5))):
-            k = int(rng.integers(0, 9))
-            col = int(rng.integers(0, len(descs)))
-            cc = int(rng.integers(0, len(descs)))
-            cond = Qual(cc, [capi.LT, capi.GE, capi.NE][int(rng.integers(0, 3))], 0)
-            if k == 0 and group:
-                targets.append(TargetExpr(capi.PROJECT_KEY, int(rng.integers(0, len(group)))))
-            elif k == 1 or (k == 0 and not group):
-                targets.append(TargetExpr(capi.COUNT))
-            elif k == 2:
-                targets.append(TargetExpr(capi.COUNT, col))
-            elif k == 3:
-                targets.append(TargetExpr(capi.COUNT_IF, cond=cond))
-            elif k == 4:
-                targets.append(TargetExpr(capi.SUM_IF, col, cond=cond))
-            else:
-                targets.append(TargetExpr([capi.SUM, capi.AVG, capi.MIN, capi.MAX][k - 5], col))
-        quals = [Qual(int(rng.integers(0, len(descs))), capi.GE, -5)] if rng.integers(0, 2) else []
-        ra = RelAlgExecutionUnit(descs, targets, quals, group, max_groups_buffer_entry_guess=2048,
-                                 bigint_count=bool(rng.integers(0, 4) == 0))
+        ra = _fuzz_row_plan(rng, descs)
         cut = n_rows // 2
         frags = [[c[:cut] for c in cols], [c[cut:] for c in cols]]
         plan = ra.to_plan()

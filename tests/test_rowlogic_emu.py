@@ -42,7 +42,8 @@ def _emu_execute(case, plan, oj):
     inp.inner_num_rows = len(case.inner[0]) if case.inner else 0
     q = capi.QMD()
     assert lib.emu_qmd_init(C.byref(plan), C.byref(q)) == 0
-    buf = np.empty((q.entry_count, q.row_size // 8), dtype=np.int64)
+    buf = (np.zeros(lib.emu_buffer_bytes(C.byref(q)) // 8, dtype=np.int64) if q.output_columnar
+           else np.empty((q.entry_count, q.row_size // 8), dtype=np.int64))
     jt, jbuf, jmin, jmax, jn, jk, jw = 0, None, 0, 0, 0, 1, 8
     if oj is not None:
         info = oj.info()
