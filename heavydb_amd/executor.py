@@ -303,12 +303,13 @@ class ResultSet:
             raise ValueError("row-wise result: use getStorage()")
         raw = self.getStorage().view(np.int8)
         n = q.entry_count
-        keys = [] if q.keyless else [
-            raw[(o := self._lib.mi355q_qmd_group_col_offset(C.byref(q), g)):o + 8 * n].view(np.int64)
-            for g in range(q.group_col_count)]
-        dt = np.int32 if q.slot_width == 4 else np.int64
-        slots = [raw[(o := self._lib.mi355q_qmd_slot_col_offset(C.byref(q), s)):o + q.slot_width * n].view(dt)
-                 for s in range(q.slot_count)]
+        keys, slots = [], []
+        for g in range(0 if q.keyless else q.group_col_count):
+            o = self._lib.mi355q_qmd_group_col_offset(C.byref(q), g)
+            keys.append(raw[o:o + 8 * n].view(np.int64))
+        for s in range(q.slot_count):
+            o = self._lib.mi355q_qmd_slot_col_offset(C.byref(q), s)
+            slots.append(raw[o:o + q.slot_width * n].view(np.int32 if q.slot_width == 4 else np.int64))
         return keys, slots
 
     # -- iteration

@@ -169,6 +169,11 @@ class HipShard:
     def execute(torch, executor, ra_exe_unit, fetch_result, **kw) -> "HipShard":
         """Run the step with the result storage owned by a torch tensor."""
         q = executor.initQueryMemoryDescriptor(ra_exe_unit)
+        if q.output_columnar:
+            # the exchange moves whole rows: run the distributed step row-wise
+            # (capi.OUTPUT_ROWWISE_COLUMNAR_DECISIONS keeps the columnar layout decisions) and
+            # convert the merged table at the end
+            raise ValueError("multi-GPU merge works on row-wise results; use OUTPUT_ROWWISE_COLUMNAR_DECISIONS")
         buf = torch.empty((q.entry_count, q.row_size // 8), dtype=torch.int64,
                           device=f"cuda:{executor.device_id}")
         rs = executor.executeWorkUnit(ra_exe_unit, fetch_result, out_buffer=int(buf.data_ptr()),
