@@ -26,7 +26,7 @@ CHILD = textwrap.dedent("""
     def h64():
         return int(HOSTILE64[rng.integers(0, len(HOSTILE64))])
     def mutate(p):
-        k = int(rng.integers(0, 16))
+        k = int(rng.integers(0, 17))
         i = int(rng.integers(0, capi.MAX_COLS))
         t = int(rng.integers(0, capi.MAX_TARGETS))
         g = int(rng.integers(0, capi.MAX_GROUP_COLS))
@@ -45,6 +45,7 @@ CHILD = textwrap.dedent("""
         elif k == 12: p.col_ranges[i].bucket = h64()
         elif k == 13: p.max_groups_buffer_entry_guess = h64()
         elif k == 14: p.num_tuples = h64()
+        elif k == 16: p.output_columnar_hint = int(rng.integers(-2, 5))
         else:
             p.join_outer_col = h32(); p.n_join_cols = h32(); p.n_inner_cols = h32(); p.join_kind = h32()
     ok = bad = 0
@@ -61,7 +62,11 @@ CHILD = textwrap.dedent("""
             assert q.slot_width in (4, 8) and q.key_bytes %% 8 == 0 and q.key_bytes <= 8 * capi.MAX_GROUP_COLS
             for j in range(q.n_targets):
                 assert -1 <= q.target_slot[j] < q.slot_count
-            assert lib.mi355q_qmd_buffer_bytes(C.byref(q)) == q.entry_count * q.row_size
+            if not q.output_columnar:
+                assert lib.mi355q_qmd_buffer_bytes(C.byref(q)) == q.entry_count * q.row_size
+            else:
+                assert lib.mi355q_qmd_buffer_bytes(C.byref(q)) >= q.entry_count * q.slot_width * q.slot_count
+                assert lib.mi355q_qmd_slot_col_offset(C.byref(q), q.slot_count) == -1
         else:
             bad += 1
             assert rc in (capi.ERR_INVALID_PLAN, capi.ERR_UNSUPPORTED), rc
