@@ -1354,7 +1354,16 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
         if (columnar && ng == 1) {
           // codegenSingleColumnPerfectHash: get_columnar_group_bin_offset on groups_buffer (the key
           // column — or, keyless, the first slot's column) with the TRANSLATED key
-          col_bin = get_columnar_group_bin_offset(buf, tk[0], q.min_val, q.bucket);
+          if (q.keyless && q.slot_width == 4) {
+            // NOT restated: here the reference's call reads (and could overwrite) 8 bytes at
+            // key_base_ptr[bin] of a column of 4-byte slots, i.e. other entries' slots or memory past
+            // the buffer (AddressSanitizer flags the literal restatement); only the bin is taken
+            int64_t off = tk[0] - q.min_val;
+            if (q.bucket) off /= q.bucket;
+            col_bin = off;
+          } else {
+            col_bin = get_columnar_group_bin_offset(buf, tk[0], q.min_val, q.bucket);
+          }
           slots = nullptr;
         } else if (columnar) {
           int64_t hash = 0;

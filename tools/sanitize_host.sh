@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/.."
 ASAN=$(gcc -print-file-name=libasan.so)
 EMU_SRCS="tests/emu/emu.cpp heavydb_amd/csrc/plan.cpp"
-EMU_TESTS="tests/test_rowlogic_emu.py tests/test_plan_fuzz.py tests/test_resultset_style.py"
+EMU_TESTS="tests/test_rowlogic_emu.py tests/test_plan_fuzz.py tests/test_resultset_style.py tests/test_columnar.py"
 mkdir -p tests/_emu
 for san in undefined address; do
   extra=""; [ $san = undefined ] && extra="-fno-sanitize-recover=undefined"
@@ -18,6 +18,7 @@ done
 rm -f tests/_emu/libemu.so   # rebuilt on demand by tests/helpers.py
 g++ -O1 -g -std=c++17 -fPIC -pthread -fsanitize=address,undefined -Wall -Wno-unused-function -shared \
     oracle/oracle.cpp -o oracle/liboracle.so
-LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider || rc=$?
+LD_PRELOAD=$ASAN ASAN_OPTIONS=detect_leaks=0 python -m pytest tests -x -q -s -m "not gpu" -p no:cacheprovider 2>&1 | tail -40; rc=${PIPESTATUS[0]}
+echo "sanitized-oracle suite exit code: $rc"
 make -B -C oracle liboracle.so
 exit ${rc:-0}
