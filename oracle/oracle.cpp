@@ -1578,13 +1578,34 @@ int32_t reduce_buffers(const mi355q_qmd& q, int64_t* this_buf, const int64_t* th
   const int rq = q.row_size / 8;
   const int kq = q.key_bytes / 8;
   if (q.output_columnar) {
-    // ResultSetStorage::reduce on columnar buffers applies the same per-entry rules through
-    // column offsets (reduceOneEntryNoCollisions / reduceOneEntryBaseline with
-    // getColOffInBytes): reduced here on the row images of both sides
+    // ResultSetStorage::reduce on columnar buffers: the same per-entry rules through column offsets
+    // (reduceOneEntryNoCollisions; baseline: reduceOneEntryBaseline with
+    // get_group_value_columnar_reduction, ResultSetReduction.cpp:621-676).  The slots of the two
+    // entries are gathered into row images for reduceOneSlot and written back.
     const mi355q_qmd qr = rowwise_of(q);
-    std::vector<int64_t> a = col_to_rows(q, this_buf), b = col_to_rows(q, that_buf);
-    if (int32_t e = reduce_buffers(qr, a.data(), b.data())) return e;
-    for (int64_t e = 0; e < q.entry_count; ++e) col_scatter(q, a.data() + e * rq, this_buf, e);
+    std::vector<int64_t> a(rq), b(rq);
+    for (int64_t e = 0; e < q.entry_count; ++e) {
+      if (is_empty_entry(q, that_buf, e)) continue;
+      col_gather(q, that_buf, e, b.data());
+      int64_t bin = e;
+      if (q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
+        // get_group_value_columnar_reduction: claim an empty bin with the key or find the key
+        const uint32_t ec = (uint32_t)q.entry_count;
+        const uint32_t h = murmur3(b.data(), (int)(kq * sizeof(int64_t)), 0) % ec;
+        bin = -1;
+        for (uint32_t i = 0, hp = h; i < ec; ++i, hp = (hp + 1) % ec) {
+          if (get_matching_group_value_columnar_slot(this_buf, ec, hp, b.data(), (uint32_t)kq) != -1) {
+            bin = hp;
+            break;
+          }
+        }
+        if (bin < 0) return MI355Q_ERR_OUT_OF_SLOTS;
+      }
+      col_gather(q, this_buf, bin, a.data());
+      for (int k = 0; k < kq; ++k) a[k] = b[k];  // perfect hash: the key copy from the right-hand side
+      reduce_targets(qr, a.data() + kq, b.data() + kq);
+      col_scatter(q, a.data(), this_buf, bin);
+    }
     return 0;
   }
   if (q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
@@ -1927,6 +1948,11 @@ ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   return 0;
 }
 
+// get_group_value_columnar_slot on a columnar buffer's key columns: the bin, or -1 when full
+ORC_EXPORT int32_t orc_get_group_value_columnar_slot(int64_t* buf, uint32_t entry_count, const int64_t* key,
+                                                     uint32_t key_count) {
+  return get_group_value_columnar_slot(buf, entry_count, key, key_count);
+}
 ORC_EXPORT int64_t orc_buffer_bytes(const mi355q_qmd* q) { return buffer_bytes(*q); }
 ORC_EXPORT int64_t orc_col_group_off(const mi355q_qmd* q, int32_t g) { return col_group_off(*q, g); }
 ORC_EXPORT int64_t orc_col_slot_off(const mi355q_qmd* q, int32_t s) { return col_slot_off(*q, s); }

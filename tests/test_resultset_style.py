@@ -124,3 +124,115 @@ def test_iterate_perfect_hash_one_col(oracle):
         assert iv[r, 0] == ref and dv[r, 1] == float(ref) and iv[r, 2] == ref and not nu[r].any()
         ref += 2
     assert ref == 100
+
+
+# ---------------------------------------------------------------------------------------------
+# Two key columns and COLUMNAR buffers: Reduce.PerfectHashTwoCol{,Keyless,Columnar,ColumnarKeyless}
+# (:1735-1808), Reduce.PerfectHashOneColColumnar{,Keyless} (:1607, :1677), Reduce.BaselineHash{,Columnar}
+# (:1811-1827) with the colwise fillers restated (fill_storage_buffer_perfect_hash_colwise
+# ResultSetTestUtils.cpp:250-320, fill_storage_buffer_baseline_colwise :352-393: every column
+# advance_to_next_columnar_*_buff = align_to_int64(width * entry_count) after the previous one).
+def _qmd2(oracle, n_keys: int, baseline: bool, keyless: bool, columnar: bool, entries: int = 36):
+    side = 6 if n_keys == 2 else entries
+    kr = ExpressionRange(False) if baseline else ExpressionRange(True, 0, side - 1)
+    descs = [InputColDescriptor(capi.INT64, False, kr) for _ in range(n_keys)] + \
+        [InputColDescriptor(capi.INT32, True, ExpressionRange(False))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY, 0), TargetExpr(capi.AVG, n_keys), TargetExpr(capi.SUM, n_keys)],
+                             groupby_exprs=list(range(n_keys)), max_groups_buffer_entry_guess=entries,
+                             output_columnar_hint=capi.OUTPUT_COLUMNAR if columnar else capi.OUTPUT_ROWWISE)
+    q = oracle.qmd_init(ra.to_plan())
+    assert q.entry_count == entries and q.output_columnar == int(columnar) and not q.keyless
+    assert q.desc_type == (capi.GROUP_BY_BASELINE_HASH if baseline else capi.GROUP_BY_PERFECT_HASH)
+    if keyless:  # setHasKeylessHash(true); setTargetIdxForKey(2)
+        q.keyless, q.idx_target_as_key, q.key_bytes = 1, 2, 0
+        q.row_size = 8 * q.slot_count
+    return q
+
+
+def _assemble(q, key_cols, slot_cols):
+    """row-wise: [entry, quads]; columnar: the columns laid end to end, each align8(8 * entries)"""
+    if q.output_columnar:
+        return np.concatenate([np.asarray(c, dtype=np.int64) for c in key_cols + slot_cols])
+    return np.stack([np.asarray(c, dtype=np.int64) for c in key_cols + slot_cols], axis=1).copy()
+
+
+def _fill_perfect2(q, n_keys, step=2):
+    E = q.entry_count
+    live = np.arange(E) % step == 0
+    v = np.where(live, 2 * (np.arange(E) // step), 0)
+    keys = [] if q.keyless else [np.where(live, v, EMPTY64) for _ in range(n_keys)]
+    dead = 0 if q.keyless else DEADBEEF
+    slots = [np.where(live, v, dead) for _ in range(q.slot_count)]
+    if q.target_slot[0] < 0:  # the baseline layout projects the key from the key column
+        base = 0
+    else:
+        base = 1
+    slots[base + 1] = np.where(live, 1, 0)  # AVG's count
+    return _assemble(q, keys, slots)
+
+
+def _reduce_both(oracle, q, a, b):
+    a_o, a_e = a.copy(), a.copy()
+    assert oracle.reduce(q, a_o, b) == 0
+    assert emu_lib().emu_reduce(C.byref(q), a_e.ctypes.data, b.ctypes.data, q.entry_count) == 0
+    return a_o, a_e
+
+
+@pytest.mark.parametrize("n_keys", [1, 2])
+@pytest.mark.parametrize("keyless", [False, True], ids=["keyed", "keyless"])
+@pytest.mark.parametrize("columnar", [False, True], ids=["rowwise", "columnar"])
+def test_reduce_perfect_hash_layouts(oracle, n_keys, keyless, columnar):
+    q = _qmd2(oracle, n_keys, False, keyless, columnar)
+    a, b = _fill_perfect2(q, n_keys), _fill_perfect2(q, n_keys)
+    for red in _reduce_both(oracle, q, a, b):
+        iv, dv, nu = oracle.fetch_rows(q, red)
+        assert iv.shape[0] == 18 and oracle.row_count(q, red) == 18
+        for r in range(18):
+            entry = 2 * r  # EvenNumberGenerator, step 2: entry i holds v = i
+            assert iv[r, 0] == entry and dv[r, 1] == float(entry) and iv[r, 2] == 2 * entry and not nu[r].any()
+    if columnar:  # the columns are where getColOffInBytes says
+        raw = a.view(np.int64)
+        nk = 0 if keyless else n_keys
+        assert raw.size == (nk + q.slot_count) * 36
+        for k in range(nk):
+            assert oracle.col_group_off(q, k) == 8 * 36 * k
+        for s in range(q.slot_count):
+            assert oracle.col_slot_off(q, s) == 8 * 36 * (nk + s)
+
+
+@pytest.mark.parametrize("columnar", [False, True], ids=["rowwise", "columnar"])
+def test_reduce_baseline_hash_two_col(oracle, columnar):
+    """Reduce.BaselineHash / BaselineHashColumnar: EvenNumberGenerator against ReverseOddOrEven, step 1,
+    keys (v, v) placed by get_group_value / get_group_value_columnar; every key appears once, so after
+    the reduction and the sort on the first target row r holds r everywhere."""
+    n, E = 16, 64
+    q = _qmd2(oracle, 2, True, False, columnar, entries=E)
+    assert q.key_width == 8 and q.key_bytes == 16 and q.target_slot[0] == -1
+
+    def fill(values):
+        buf = oracle.init_buffer(q)
+        rows = np.zeros((E, q.row_size // 8), dtype=np.int64)
+        for v in values:
+            key = np.array([v, v], dtype=np.int64)
+            if columnar:
+                b = oracle.lib().orc_get_group_value_columnar_slot(buf.ctypes.data, E, key.ctypes.data, 2)
+                assert b >= 0
+                flat = buf.view(np.int64)
+                for s, x in enumerate([v, 1, v]):  # AVG (sum, count), SUM
+                    flat[oracle.col_slot_off(q, s) // 8 + b] = x
+            else:
+                flat = buf.reshape(-1)
+                s0 = oracle.lib().orc_get_group_value_n_slot(flat.ctypes.data, E, key.ctypes.data, 2, 8, q.row_size // 8)
+                assert s0 >= 0
+                flat[s0:s0 + 3] = [v, 1, v]
+        del rows
+        return buf
+    a = fill(range(0, 2 * n, 2))                 # EvenNumberGenerator
+    b = fill(range(2 * n - 1, 0, -2))            # ReverseOddOrEvenNumberGenerator(2 * n - 1)
+    for red in _reduce_both(oracle, q, a, b):
+        iv, dv, nu = oracle.fetch_rows(q, red)
+        order = np.argsort(iv[:, 0])
+        iv, dv = iv[order], dv[order]
+        assert iv.shape[0] == 2 * n
+        for r in range(2 * n):
+            assert iv[r, 0] == r and dv[r, 1] == float(r) and iv[r, 2] == r  # step 1: SUM = 1 * row_idx
