@@ -11,7 +11,9 @@
  *   (1) the known-answer vectors in tests/golden/ref_vectors.json, generated from the
  *       reference's own sources compiled in place (oracle/_ref, oracle/Makefile,
  *       oracle/gen_golden.py), and
- *   (2) the ResultSetTest-style fill/reduce/iterate cases of Tests/ResultSetTest.cpp.
+ *   (2) ports of the reference's own ResultSet fill / reduce / iterate tests
+ *       (Tests/ResultSetTest.cpp Reduce.* / Iterate.*, row-wise and columnar, one and two key
+ *       columns, keyed and keyless, baseline) in tests/test_resultset_style.py.
  *
  * All citations are relative to the heavyai/heavydb tree.
  */
