@@ -32,8 +32,8 @@ from .capi import check
 
 class ShardOps(Protocol):
     def qmd(self) -> capi.QMD: ...
-    def buffer(self): ...                       # torch int64 tensor [entry_count, row_quad]
-    def partition_rows(self, n_parts: int): ...  # -> (rows tensor [live, row_quad], counts list)
+    def buffer(self): ...                       # torch int64 tensor [entry_count, row_quad]; flat when columnar
+    def partition_rows(self, n_parts: int): ...  # -> (ROW-WISE rows tensor [live, row_quad], counts list)
     def fresh_like(self) -> "ShardOps": ...
     def merge_rows(self, rows) -> None: ...
     def reduce_from(self, other_buffer) -> None: ...
@@ -46,8 +46,8 @@ def _dense_slot_ops(q: capi.QMD) -> Optional[List[Tuple[int, str, bool]]]:
         return None
     kq = q.key_bytes // 8
     ops: List[Tuple[int, str, bool]] = []
-    if kq:
-        ops.append((0, "min", False))  # key quad: EMPTY_KEY_64 = INT64_MAX, so MIN keeps the key
+    for k in range(kq):  # every key quad (a multi-column perfect hash stores one per group column)
+        ops.append((k, "min", False))  # EMPTY_KEY_64 = INT64_MAX, so MIN keeps the key
     for t in range(q.n_targets):
         s = q.target_slot[t]
         agg = q.target_agg[t]
@@ -79,8 +79,18 @@ def merge_dense(shard: ShardOps, dist, torch, group=None) -> ShardOps:
         return shard
     buf = shard.buffer()
     ops = _dense_slot_ops(q)
+    red = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}
+    if ops is not None and q.output_columnar:
+        # columnar buffer: quad column c of the row image IS a contiguous column of entry_count
+        # 8-byte values at c * entry_count quads (group columns first, then the slots; 8-byte
+        # slots, or _dense_slot_ops would have said no) -> reduced in place, no staging copy
+        flat = buf.view(-1)
+        n = q.entry_count
+        for col, op, fp in ops:
+            view = flat[col * n:(col + 1) * n]
+            dist.all_reduce(view.view(torch.float64) if fp else view, op=red[op], group=group)
+        return shard
     if ops is not None:
-        red = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}
         groups = {}
         for col, op, fp in ops:
             groups.setdefault((op, fp), []).append(col)
@@ -155,9 +165,7 @@ class HipShard:
         self._lib = capi.load_library()
         self._qmd = qmd
         self.device_id = device_id
-        rq = qmd.row_size // 8
-        self._buf = buf if buf is not None else torch.empty((qmd.entry_count, rq), dtype=torch.int64,
-                                                            device=f"cuda:{device_id}")
+        self._buf = buf if buf is not None else HipShard._alloc(torch, self._lib, qmd, device_id)
         if handle is None:
             h = C.c_void_p()
             check(self._lib.mi355q_result_create(C.byref(qmd), device_id, int(self._buf.data_ptr()),
@@ -166,16 +174,18 @@ class HipShard:
         self.handle = handle
 
     @staticmethod
+    def _alloc(torch, lib, q: capi.QMD, device_id: int):
+        """[entry_count, row quads] for a row-wise descriptor, flat quads for a columnar one."""
+        if q.output_columnar:
+            return torch.empty(lib.mi355q_qmd_buffer_bytes(C.byref(q)) // 8, dtype=torch.int64,
+                               device=f"cuda:{device_id}")
+        return torch.empty((q.entry_count, q.row_size // 8), dtype=torch.int64, device=f"cuda:{device_id}")
+
+    @staticmethod
     def execute(torch, executor, ra_exe_unit, fetch_result, **kw) -> "HipShard":
         """Run the step with the result storage owned by a torch tensor."""
         q = executor.initQueryMemoryDescriptor(ra_exe_unit)
-        if q.output_columnar:
-            # the exchange moves whole rows: run the distributed step row-wise
-            # (capi.OUTPUT_ROWWISE_COLUMNAR_DECISIONS keeps the columnar layout decisions) and
-            # convert the merged table at the end
-            raise ValueError("multi-GPU merge works on row-wise results; use OUTPUT_ROWWISE_COLUMNAR_DECISIONS")
-        buf = torch.empty((q.entry_count, q.row_size // 8), dtype=torch.int64,
-                          device=f"cuda:{executor.device_id}")
+        buf = HipShard._alloc(torch, capi.load_library(), q, executor.device_id)
         rs = executor.executeWorkUnit(ra_exe_unit, fetch_result, out_buffer=int(buf.data_ptr()),
                                       allow_retry=False, **kw)
         sh = HipShard(torch, q, executor.device_id, buf, rs.handle)

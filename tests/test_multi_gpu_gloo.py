@@ -28,7 +28,13 @@ class NumpyShard:
     def __init__(self, torch, orc, q, buf=None):
         self._torch, self._orc, self._q = torch, orc, q
         self._np = buf if buf is not None else orc.init_buffer(q)
-        self._np = np.ascontiguousarray(self._np).reshape(q.entry_count, q.row_size // 8)
+        self._np = np.ascontiguousarray(self._np)
+        if not q.output_columnar:  # a columnar buffer stays flat (columns end to end)
+            self._np = self._np.reshape(q.entry_count, q.row_size // 8)
+
+    def _rows(self):
+        from tests.helpers import columnar_to_rows
+        return columnar_to_rows(self._q, self._np) if self._q.output_columnar else self._np
 
     def qmd(self):
         return self._q
@@ -37,7 +43,8 @@ class NumpyShard:
         return self._torch.from_numpy(self._np)  # shares memory: all_reduce results land in place
 
     def partition_rows(self, n_parts):
-        live = self._np[self._np[:, 0] != EMPTY64]
+        rows = self._rows()
+        live = rows[rows[:, 0] != EMPTY64]
         part = _owner(self._q, live, n_parts)
         order = np.argsort(part, kind="stable")
         counts = np.bincount(part, minlength=n_parts).tolist()
@@ -52,8 +59,14 @@ class NumpyShard:
         if not n:
             return
         assert n <= self._q.entry_count
-        that = self._orc.init_buffer(self._q).reshape(self._q.entry_count, -1)
-        that[:n] = rows
+        that = self._orc.init_buffer(self._q)
+        if self._q.output_columnar:  # lay the received rows into the first n entries, column by column
+            flat, e = that.view(np.int64), self._q.entry_count
+            for c in range(rows.shape[1]):
+                flat[c * e:c * e + n] = rows[:, c]
+        else:
+            that = that.reshape(self._q.entry_count, -1)
+            that[:n] = rows
         assert self._orc.reduce(self._q, self._np, that) == 0
 
     def reduce_from(self, other_buffer):
@@ -77,6 +90,10 @@ def _owner(q, live, n_parts):
 
 def _table(shape, seed=7):
     from heavydb_amd import capi
+    if shape.endswith("_columnar"):  # the same step with a columnar result buffer
+        ra, frags = _table(shape[:-len("_columnar")], seed)
+        ra.output_columnar_hint = capi.OUTPUT_COLUMNAR
+        return ra, frags
     from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
                                       TargetExpr)
     rng = np.random.default_rng(seed)
@@ -125,6 +142,16 @@ def _table(shape, seed=7):
         ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 1),
                                          TargetExpr(capi.MAX, 1)], groupby_exprs=[0])
         cols = [key, val]
+    elif shape == "perfect_two_columns_unprojected":  # every key quad has to be merged, projected or not
+        # sorted first key: every fragment (hence every rank) sees only a slice of the groups
+        k0 = (np.arange(n) * 40 // n).astype(np.int32)
+        k1 = rng.integers(-3, 4, n).astype(np.int64)
+        val = rng.integers(1, 1000, n).astype(np.int64)
+        descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 39)),
+                 InputColDescriptor(capi.INT64, False, ExpressionRange(True, -3, 3)),
+                 InputColDescriptor(capi.INT64, False, ExpressionRange(False))]  # NOT NULL: the all_reduce branch
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.MAX, 2), TargetExpr(capi.MIN, 2)], groupby_exprs=[0, 1])
+        cols = [k0, k1, val]
     elif shape == "perfect_nullable":  # NULL-aware slots: exercises the all_gather + reduce branch
         key = rng.integers(0, 50, n).astype(np.int32)
         val = rng.integers(-1000, 1000, n).astype(np.int64)
@@ -166,6 +193,11 @@ def _worker(rank, world, port, shape, errq):
         q_all, want, code = orc.execute(plan, frags, n_threads=2)
         assert code == 0
         got = out.buffer().numpy()
+        if q.output_columnar:  # compared as row images (tests/helpers.columnar_to_rows)
+            from tests.helpers import columnar_to_rows, rowwise_qmd
+            assert got.ndim == 1 and got.nbytes == orc.buffer_bytes(q)
+            got, want = columnar_to_rows(q, got), columnar_to_rows(q_all, want)
+            q_all = rowwise_qmd(q_all)
         if q.desc_type == capi.GROUP_BY_BASELINE_HASH:
             # every rank owns exactly the keys of its shard after the all-to-all ...
             live = got[got[:, 0] != EMPTY64]
@@ -192,7 +224,9 @@ def _free_port():
 
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("shape", ["keyed", "keyed_two_columns", "keyed_compact", "perfect", "perfect_nullable",
-                                   "perfect_float", "non_grouped"])
+                                   "perfect_float", "non_grouped", "perfect_two_columns_unprojected",
+                                   "perfect_columnar", "perfect_nullable_columnar", "keyed_columnar",
+                                   "keyed_two_columns_columnar", "perfect_two_columns_unprojected_columnar"])
 def test_merge_over_gloo(shape, world):
     import torch.multiprocessing as mp
     from oracle import oracle as orc
