@@ -303,3 +303,29 @@ def emu_lib() -> C.CDLL:
         l.emu_reduce.argtypes = [P(capi.QMD), C.c_void_p, C.c_void_p, C.c_int64]
         _emu = l
     return _emu
+
+
+def decode_join_table(raw: np.ndarray, hash_type: int, entries: int, kc: int, w: int, min_key: int = 0):
+    """{key tuple: sorted row ids} of a hash join buffer — HashTable::toSet() of the reference's
+    JoinHashTableTest (slot positions and the order inside a payload run depend on the build
+    order, so tables are compared decoded)."""
+    out = {}
+    if hash_type == 0:
+        slots = raw.view(np.int32)[:entries]
+        return {(int(min_key + i),): [int(v)] for i, v in enumerate(slots) if v >= 0}
+    dt = np.int32 if w == 4 else np.int64
+    empty = 2**31 - 1 if w == 4 else 2**63 - 1
+    if hash_type == 1:
+        tab = raw[:entries * (kc + 1) * w].view(dt).reshape(entries, kc + 1)
+        return {tuple(int(x) for x in r[:kc]): [int(r[kc])] for r in tab if r[0] != empty}
+    key_bytes = 0 if hash_type == 2 else entries * kc * w
+    i32 = raw[key_bytes:].view(np.int32)
+    offsets, counts, payloads = i32[:entries], i32[entries:2 * entries], i32[2 * entries:]
+    keys = None if hash_type == 2 else raw[:key_bytes].view(dt).reshape(entries, kc)
+    for e in range(entries):
+        if offsets[e] < 0:
+            assert counts[e] == 0
+            continue
+        k = (int(min_key + e),) if hash_type == 2 else tuple(int(x) for x in keys[e])
+        out[k] = sorted(int(x) for x in payloads[offsets[e]:offsets[e] + counts[e]])
+    return out

@@ -705,30 +705,7 @@ def test_multi_column_keys_at_scale(torch_cuda, oracle, shape):
     assert got_n == min(k, len(livek)) and np.array_equal(got_order, order)
 
 
-def _decode_join_table(raw: np.ndarray, hash_type: int, entries: int, kc: int, w: int, min_key: int = 0):
-    """{key tuple: sorted row ids} of a hash join buffer — HashTable::toSet() of the reference's
-    JoinHashTableTest (slot positions and the order inside a payload run depend on the build
-    order, so tables are compared decoded)."""
-    out = {}
-    if hash_type == 0:
-        slots = raw.view(np.int32)[:entries]
-        return {(int(min_key + i),): [int(v)] for i, v in enumerate(slots) if v >= 0}
-    dt = np.int32 if w == 4 else np.int64
-    empty = 2**31 - 1 if w == 4 else 2**63 - 1
-    if hash_type == 1:
-        tab = raw[:entries * (kc + 1) * w].view(dt).reshape(entries, kc + 1)
-        return {tuple(int(x) for x in r[:kc]): [int(r[kc])] for r in tab if r[0] != empty}
-    key_bytes = 0 if hash_type == 2 else entries * kc * w
-    i32 = raw[key_bytes:].view(np.int32)
-    offsets, counts, payloads = i32[:entries], i32[entries:2 * entries], i32[2 * entries:]
-    keys = None if hash_type == 2 else raw[:key_bytes].view(dt).reshape(entries, kc)
-    for e in range(entries):
-        if offsets[e] < 0:
-            assert counts[e] == 0
-            continue
-        k = (int(min_key + e),) if hash_type == 2 else tuple(int(x) for x in keys[e])
-        out[k] = sorted(int(x) for x in payloads[offsets[e]:offsets[e] + counts[e]])
-    return out
+from tests.helpers import decode_join_table as _decode_join_table  # noqa: E402
 
 
 @pytest.mark.parametrize("shape", ["perfect_1n", "keyed_1n_i64", "composite_1to1_w4", "composite_1n_w8",
