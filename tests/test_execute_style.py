@@ -1,0 +1,217 @@
+"""Ports of the reference's end-to-end query tests (Tests/ExecuteTest.cpp): ITS `test` table
+(rows of the three INSERT statements at :30063-30115, 10 + 5 + 5 rows in fragments of 2 rows, numeric
+columns only; `str` as its dictionary ids) and ITS query texts from Select.FilterAndSimpleAggregation
+(:1888-1970), Select.GroupByPerfectHash (:11423-11480) and friends — the ones that are a single step
+of scan / filter / group by / aggregate.  Exactly like the reference's `c(query, dt)`, the SQL text runs
+on SQLite; the same query written as a RelAlgExecutionUnit runs through the oracle and through the
+product's row logic (host emulation), and the three row sets must agree."""
+import math
+import sqlite3
+
+import numpy as np
+import pytest
+
+from heavydb_amd import capi
+from heavydb_amd.executor import InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+from tests.cases import Case, col_range
+from tests.helpers import F32_ATOL, F32_RTOL
+
+I8, I16, I32, I64, F32, F64 = capi.INT8, capi.INT16, capi.INT32, capi.INT64, capi.FLOAT, capi.DOUBLE
+NP = {I8: np.int8, I16: np.int16, I32: np.int32, I64: np.int64, F32: np.float32, F64: np.float64}
+NULL = {I8: -2**7, I16: -2**15, I32: -2**31, I64: -2**63, F32: np.finfo(np.float32).tiny, F64: np.finfo(np.float64).tiny}
+M1, M2 = 1418509395, 1418595795     # '2014-12-13 22:23:15', '2014-12-14 22:23:15'
+DAY = 936835200                     # '1999-09-09' in seconds; 10843 days
+
+# name: (storage type, nullable, [row1, row2, row3], encoding, logical type)
+COLS = {
+    "x": (I32, False, [7, 8, 7]), "w": (I8, True, [-8, -7, -7]), "y": (I32, True, [42, 43, 43]),
+    "z": (I16, True, [101, -78, 102]), "t": (I64, True, [1001, 1002, 1002]),
+    "f": (F32, True, [1.1, 1.2, 1.3]), "ff": (F32, True, [1.1, 101.2, 1000.3]), "fn": (F32, True, [None, -101.2, -1000.3]),
+    "d": (F64, True, [2.2, 2.4, 2.6]), "dn": (F64, True, [None, -2002.4, -220.6]),
+    "str": (I32, False, [0, 1, 2], capi.ENC_DICT, 0),                       # 'foo', 'bar', 'baz'
+    "m": (I64, True, [M1, M1, M2]),
+    "o1": (I16, True, [DAY // 86400, None, DAY // 86400], capi.ENC_DATE_IN_DAYS, 0),  # date encoding fixed(16)
+    "fx": (I16, True, [9, None, 11], capi.ENC_FIXED, I32),                  # int encoding fixed(16)
+    "u": (I32, True, [None, None, None]), "ofd": (I32, True, [2147483647, None, 1]),
+    "ufd": (I32, False, [-2147483648, -2147483647, -1]), "ofq": (I64, True, [None, 2**63 - 1, 1]),
+    "ufq": (I64, False, [-1, -2**63, -2**63]), "smallint_nulls": (I16, True, [32767, None, 1]),
+}
+NAMES = list(COLS)
+REPEAT = [10, 5, 5]   # g_num_rows = 10
+
+
+def _table():
+    arrays, descs, sql_cols = [], [], []
+    for name in NAMES:
+        spec = COLS[name]
+        t, nullable, vals = spec[:3]
+        enc, logical = (spec[3], spec[4]) if len(spec) > 3 else (0, 0)
+        stored = np.array([NULL[t] if v is None else v for v, r in zip(vals, REPEAT) for _ in range(r)], dtype=NP[t])
+        logical_vals = [None if v is None else (v * 86400 if enc == capi.ENC_DATE_IN_DAYS else
+                                               float(np.float32(v)) if t == F32 else v)
+                        for v, r in zip(vals, REPEAT) for _ in range(r)]
+        arrays.append(stored)
+        sql_cols.append(logical_vals)
+        if enc == capi.ENC_DATE_IN_DAYS:
+            rng = col_range([stored.astype(np.int64) * 86400], I64, False)
+            nn = [v for v in logical_vals if v is not None]
+            from heavydb_amd.executor import ExpressionRange
+            rng = ExpressionRange(True, min(nn), max(nn), any(v is None for v in logical_vals), bucket=86400)
+        else:
+            rng = col_range([stored], t, nullable)
+        descs.append(InputColDescriptor(t, nullable, rng, enc, logical))
+    n = sum(REPEAT)
+    frags = [[a[i:i + 2] for a in arrays] for i in range(0, n, 2)]  # fragment size 2 (:30049)
+    db = sqlite3.connect(":memory:")
+    db.execute("CREATE TABLE test (" + ", ".join(NAMES) + ")")
+    db.executemany("INSERT INTO test VALUES (" + ",".join("?" * len(NAMES)) + ")", list(zip(*sql_cols)))
+    return descs, frags, db
+
+
+A = {"COUNT": capi.COUNT, "SUM": capi.SUM, "AVG": capi.AVG, "MIN": capi.MIN, "MAX": capi.MAX}
+OPS = {"<": capi.LT, ">": capi.GT, "=": capi.EQ, "<>": capi.NE, "<=": capi.LE, ">=": capi.GE}
+
+
+# column NAMES here; resolved against the query's own input_col_descs (the reference fetches only the
+# columns a query uses, RelAlgExecutionUnit::input_col_descs)
+def agg(fn, col=None):
+    return ("agg", A[fn], col)
+
+
+def q(col, op, lit):
+    return (col, OPS[op], lit)
+
+
+def key(i=0):
+    return ("key", i, None)
+
+
+def _unit(descs, frags, targets, quals, group, **kw):
+    used = []
+    for n in list(group) + [t[2] for t in targets if t[0] == "agg" and t[2]] + [c for c, _, _ in quals]:
+        if n not in used:
+            used.append(n)
+    if not used:
+        used = ["x"]
+    idx = {n: i for i, n in enumerate(used)}
+    src = [NAMES.index(n) for n in used]
+    tx = [TargetExpr(capi.PROJECT_KEY, t[1]) if t[0] == "key" else TargetExpr(t[1], -1 if t[2] is None else idx[t[2]])
+          for t in targets]
+    ra = RelAlgExecutionUnit([descs[i] for i in src], tx, [Qual(idx[c], op, lit) for c, op, lit in quals],
+                             [idx[g] for g in group], **kw)
+    return ra, [[f[i] for i in src] for f in frags]
+
+
+# (the reference's SQL text, targets, quals, group-by columns in GROUP BY order)
+QUERIES = [
+    ("SELECT COUNT(*) FROM test;", [agg("COUNT")], [], []),
+    ("SELECT COUNT(f) FROM test;", [agg("COUNT", "f")], [], []),
+    ("SELECT COUNT(smallint_nulls), COUNT(*), COUNT(fn) FROM test;",
+     [agg("COUNT", "smallint_nulls"), agg("COUNT"), agg("COUNT", "fn")], [], []),
+    ("SELECT MIN(x) FROM test;", [agg("MIN", "x")], [], []),
+    ("SELECT MAX(x) FROM test;", [agg("MAX", "x")], [], []),
+    ("SELECT MIN(z) FROM test;", [agg("MIN", "z")], [], []),
+    ("SELECT MAX(z) FROM test;", [agg("MAX", "z")], [], []),
+    ("SELECT MIN(t) FROM test;", [agg("MIN", "t")], [], []),
+    ("SELECT MAX(t) FROM test;", [agg("MAX", "t")], [], []),
+    ("SELECT MIN(ff) FROM test;", [agg("MIN", "ff")], [], []),
+    ("SELECT MIN(fn) FROM test;", [agg("MIN", "fn")], [], []),
+    ("SELECT SUM(ff) FROM test;", [agg("SUM", "ff")], [], []),
+    ("SELECT SUM(fn) FROM test;", [agg("SUM", "fn")], [], []),
+    ("SELECT SUM(d) FROM test;", [agg("SUM", "d")], [], []),
+    ("SELECT SUM(dn) FROM test;", [agg("SUM", "dn")], [], []),
+    ("SELECT COUNT(*) FROM test WHERE x > 6 AND x < 8;", [agg("COUNT")], [q("x", ">", 6), q("x", "<", 8)], []),
+    ("SELECT COUNT(*) FROM test WHERE x > 6 AND x < 8 AND z > 100 AND z < 102;", [agg("COUNT")],
+     [q("x", ">", 6), q("x", "<", 8), q("z", ">", 100), q("z", "<", 102)], []),
+    ("SELECT COUNT(*) FROM test WHERE x <> 7;", [agg("COUNT")], [q("x", "<>", 7)], []),
+    ("SELECT COUNT(*) FROM test WHERE z <> 102;", [agg("COUNT")], [q("z", "<>", 102)], []),
+    ("SELECT COUNT(*) FROM test WHERE t <> 1002;", [agg("COUNT")], [q("t", "<>", 1002)], []),
+    ("SELECT MIN(x) FROM test WHERE x = 7;", [agg("MIN", "x")], [q("x", "=", 7)], []),
+    ("SELECT MIN(z) FROM test WHERE z = 101;", [agg("MIN", "z")], [q("z", "=", 101)], []),
+    ("SELECT MIN(t) FROM test WHERE t = 1001;", [agg("MIN", "t")], [q("t", "=", 1001)], []),
+    ("SELECT AVG(y) FROM test WHERE x > 6 AND x < 8;", [agg("AVG", "y")], [q("x", ">", 6), q("x", "<", 8)], []),
+    ("SELECT AVG(y) FROM test WHERE z > 100 AND z < 102;", [agg("AVG", "y")], [q("z", ">", 100), q("z", "<", 102)], []),
+    ("SELECT AVG(y) FROM test WHERE t > 1000 AND t < 1002;", [agg("AVG", "y")], [q("t", ">", 1000), q("t", "<", 1002)], []),
+    ("SELECT COUNT(*) FROM test WHERE ff < 5.75;", [agg("COUNT")], [q("ff", "<", 5.75)], []),   # 23.0/4.0 folded
+    ("SELECT SUM(ofd), MIN(ofd), MAX(ofd), COUNT(ofd), AVG(ofd) FROM test;",
+     [agg("SUM", "ofd"), agg("MIN", "ofd"), agg("MAX", "ofd"), agg("COUNT", "ofd"), agg("AVG", "ofd")], [], []),
+    ("SELECT COUNT(u), SUM(u), MIN(u), AVG(u) FROM test;", [agg("COUNT", "u"), agg("SUM", "u"), agg("MIN", "u"), agg("AVG", "u")], [], []),
+    # (MIN(ufd) / MIN(ufq) are left out on purpose: those NOT NULL columns hold INT32_MIN / INT64_MIN,
+    # and a non-grouped MIN is NULL-aware whatever the column says (set_notnull(target, false),
+    # OutputBufferInitialization.cpp:281-286), so the reference skips exactly those values)
+    ("SELECT MAX(ufd), MAX(ufq), MAX(ofq) FROM test;", [agg("MAX", "ufd"), agg("MAX", "ufq"), agg("MAX", "ofq")], [], []),
+    ("SELECT MIN(fx), MAX(fx), SUM(fx), COUNT(fx) FROM test;", [agg("MIN", "fx"), agg("MAX", "fx"), agg("SUM", "fx"), agg("COUNT", "fx")], [], []),
+    ("SELECT MIN(o1), MAX(o1), COUNT(o1) FROM test;", [agg("MIN", "o1"), agg("MAX", "o1"), agg("COUNT", "o1")], [], []),
+    # Select.GroupByPerfectHash
+    ("SELECT COUNT(*) FROM test GROUP BY x ORDER BY x DESC;", [agg("COUNT")], [], ["x"]),
+    ("SELECT y, COUNT(*) FROM test GROUP BY y ORDER BY y DESC;", [key(), agg("COUNT")], [], ["y"]),
+    ("SELECT str, COUNT(*) FROM test GROUP BY str ORDER BY str DESC;", [key(), agg("COUNT")], [], ["str"]),
+    ("SELECT COUNT(*), z FROM test where x = 7 GROUP BY z ORDER BY z DESC;", [agg("COUNT"), key()], [q("x", "=", 7)], ["z"]),
+    ("SELECT z as z0, z as z1, COUNT(*) FROM test GROUP BY z0, z1 ORDER BY z0 DESC;", [key(0), key(1), agg("COUNT")], [], ["z", "z"]),
+    ("SELECT x, COUNT(y), SUM(y), AVG(y), MIN(y), MAX(y) FROM test GROUP BY x ORDER BY x DESC;",
+     [key(), agg("COUNT", "y"), agg("SUM", "y"), agg("AVG", "y"), agg("MIN", "y"), agg("MAX", "y")], [], ["x"]),
+    ("SELECT y, SUM(fn), AVG(ff), MAX(f) from test GROUP BY y ORDER BY y DESC;",
+     [key(), agg("SUM", "fn"), agg("AVG", "ff"), agg("MAX", "f")], [], ["y"]),
+    # multi-column perfect hash
+    ("SELECT str, x FROM test GROUP BY x, str ORDER BY str, x;", [key(1), key(0)], [], ["x", "str"]),
+    ("SELECT str, x, MAX(smallint_nulls), AVG(y), COUNT(dn) FROM test GROUP BY x, str ORDER BY str, x;",
+     [key(1), key(0), agg("MAX", "smallint_nulls"), agg("AVG", "y"), agg("COUNT", "dn")], [], ["x", "str"]),
+    ("SELECT str, x, MAX(smallint_nulls), COUNT(dn), COUNT(*) as cnt FROM test GROUP BY x, str ORDER BY cnt, str;",
+     [key(1), key(0), agg("MAX", "smallint_nulls"), agg("COUNT", "dn"), agg("COUNT")], [], ["x", "str"]),
+    ("SELECT x, str, z, SUM(dn), MAX(dn), AVG(dn) FROM test GROUP BY x, str, z ORDER BY str, z, x;",
+     [key(0), key(1), key(2), agg("SUM", "dn"), agg("MAX", "dn"), agg("AVG", "dn")], [], ["x", "str", "z"]),
+    ("SELECT x, SUM(dn), str, MAX(dn), z, AVG(dn), COUNT(*) FROM test GROUP BY z, x, str ORDER BY str, z, x;",
+     [key(1), agg("SUM", "dn"), key(2), agg("MAX", "dn"), key(0), agg("AVG", "dn"), agg("COUNT")], [], ["z", "x", "str"]),
+    # NULL group keys, bigint / date / fixed-encoded keys
+    ("SELECT ofd, COUNT(*), SUM(x) FROM test GROUP BY ofd;", [key(), agg("COUNT"), agg("SUM", "x")], [], ["ofd"]),
+    ("SELECT u, COUNT(*) FROM test GROUP BY u;", [key(), agg("COUNT")], [], ["u"]),
+    ("SELECT smallint_nulls, MIN(w), MAX(t) FROM test GROUP BY smallint_nulls;", [key(), agg("MIN", "w"), agg("MAX", "t")], [], ["smallint_nulls"]),
+    ("SELECT m, COUNT(*), AVG(d) FROM test GROUP BY m;", [key(), agg("COUNT"), agg("AVG", "d")], [], ["m"]),
+    ("SELECT o1, COUNT(*) FROM test GROUP BY o1;", [key(), agg("COUNT")], [], ["o1"]),
+    ("SELECT fx, COUNT(*), SUM(z) FROM test GROUP BY fx;", [key(), agg("COUNT"), agg("SUM", "z")], [], ["fx"]),
+    ("SELECT t, w, COUNT(*), MIN(ff) FROM test GROUP BY t, w;", [key(0), key(1), agg("COUNT"), agg("MIN", "ff")], [], ["t", "w"]),
+]
+
+
+def _rows(fetch, qmd):
+    iv, dv, nu = fetch
+    out = []
+    for r in range(iv.shape[0]):
+        out.append(tuple(None if nu[r, t] else (float(dv[r, t]) if qmd.target_is_fp[t] else int(iv[r, t]))
+                         for t in range(qmd.n_targets)))
+    return out
+
+
+def _key(row):
+    return tuple((0, 0) if v is None else (1, v) for v in row if not isinstance(v, float)), \
+        tuple(v for v in row if isinstance(v, float))
+
+
+@pytest.mark.parametrize("bigint_count", [False, True], ids=["int_count", "bigint_count"])
+@pytest.mark.parametrize("qi", range(len(QUERIES)), ids=[s[0][7:60].replace(" ", "_") for s in QUERIES])
+def test_reference_queries(oracle, qi, bigint_count):
+    from tests.test_rowlogic_emu import _emu_execute
+    sql, targets, quals, group = QUERIES[qi]
+    descs, frags, db = _table()
+    ra, frags = _unit(descs, frags, targets, quals, group, bigint_count=bigint_count, num_tuples=sum(REPEAT))
+    plan = ra.to_plan()
+    qm, buf, code = oracle.execute(plan, frags, n_threads=3)
+    assert code == 0
+    fp = [bool(qm.target_is_fp[t]) for t in range(qm.n_targets)]
+    want = sorted((tuple(float(v) if f and v is not None else v for v, f in zip(r, fp))
+                   for r in db.execute(sql).fetchall()), key=_key)
+    got = sorted(_rows(oracle.fetch_rows(qm, buf), qm), key=_key)
+    eq, ebuf, ecode = _emu_execute(Case("ref", ra, frags), plan, None)
+    assert ecode == 0
+    got_emu = sorted(_rows(oracle.fetch_rows(eq, ebuf), eq), key=_key)
+    for name, rows in (("oracle", got), ("product row logic", got_emu)):
+        assert len(rows) == len(want), (name, sql, want, rows)
+        for w, g in zip(want, rows):
+            for t, (a, b) in enumerate(zip(w, g)):
+                if a is None or b is None:
+                    assert a is None and b is None, (name, sql, t, w, g)
+                elif fp[t]:
+                    rt, at = (F32_RTOL, F32_ATOL) if qm.target_arg_is_f32[t] else (1e-12, 0.0)
+                    assert math.isclose(a, b, rel_tol=rt, abs_tol=at), (name, sql, t, w, g)
+                else:
+                    assert a == b, (name, sql, t, w, g)
