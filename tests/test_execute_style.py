@@ -215,3 +215,99 @@ def test_reference_queries(oracle, qi, bigint_count):
                     assert math.isclose(a, b, rel_tol=rt, abs_tol=at), (name, sql, t, w, g)
                 else:
                     assert a == b, (name, sql, t, w, g)
+
+
+# ---- joins against the reference's `test_inner` (ExecuteTest.cpp:29719-29738: two rows)
+INNER = {"x": (I32, False, [7, -9]), "y": (I32, True, [43, 72]), "xx": (I16, True, [7, -9])}
+INNER_NAMES = list(INNER)
+
+# (SQL text, targets [("agg", kind, column, table)], quals on test, group-by (test columns),
+#  join: (outer columns, inner columns, LEFT?))
+JOIN_QUERIES = [
+    ("SELECT COUNT(*) FROM test JOIN test_inner ON test.x = test_inner.x;",                      # :12857
+     [("agg", capi.COUNT, None, 0)], [], [], (["x"], ["x"], False)),
+    ("SELECT COUNT(*) FROM test LEFT JOIN test_inner ON test.x = test_inner.x WHERE test.y > 42;",  # :13371
+     [("agg", capi.COUNT, None, 0)], [q("y", ">", 42)], [], (["x"], ["x"], True)),
+    ("SELECT a.x, count(*) FROM test a LEFT JOIN test_inner b ON a.x = b.y WHERE a.x = 7 GROUP BY 1 ORDER BY 2;",  # :13681
+     [("key", 0, None, 0), ("agg", capi.COUNT, None, 0)], [q("x", "=", 7)], ["x"], (["x"], ["y"], True)),
+    ("SELECT a.x, COUNT(b.y) FROM test a LEFT JOIN test_inner b ON b.x = a.x GROUP BY a.x ORDER BY a.x;",  # :13513 without the LIKE
+     [("key", 0, None, 0), ("agg", capi.COUNT, "y", 1)], [], ["x"], (["x"], ["x"], True)),
+    ("SELECT a.x, SUM(b.y), MIN(b.xx), AVG(a.d) FROM test a JOIN test_inner b ON b.x = a.x GROUP BY a.x;",
+     [("key", 0, None, 0), ("agg", capi.SUM, "y", 1), ("agg", capi.MIN, "xx", 1), ("agg", capi.AVG, "d", 0)], [], ["x"],
+     (["x"], ["x"], False)),
+    ("SELECT COUNT(*), SUM(a.t) FROM test a JOIN test_inner b ON a.x = b.x AND a.y = b.y;",       # composite key (:13385 shape)
+     [("agg", capi.COUNT, None, 0), ("agg", capi.SUM, "t", 0)], [], [], (["x", "y"], ["x", "y"], False)),
+    ("SELECT a.y, COUNT(b.x), MAX(b.xx) FROM test a LEFT JOIN test_inner b ON a.x = b.x AND a.y = b.y GROUP BY a.y;",
+     [("key", 0, None, 0), ("agg", capi.COUNT, "x", 1), ("agg", capi.MAX, "xx", 1)], [], ["y"], (["x", "y"], ["x", "y"], True)),
+]
+
+
+def _join_case(descs, frags, db, spec):
+    sql, targets, quals, group, (outer, inner, left) = spec
+    used = []
+    for n in list(group) + list(outer) + [t[2] for t in targets if t[0] == "agg" and t[2] and t[3] == 0] + [c for c, _, _ in quals]:
+        if n not in used:
+            used.append(n)
+    idx = {n: i for i, n in enumerate(used)}
+    src = [NAMES.index(n) for n in used]
+    inner_arrays = {n: np.array(INNER[n][2], dtype=NP[INNER[n][0]]) for n in INNER_NAMES}
+    inner_descs = [InputColDescriptor(INNER[n][0], INNER[n][1], col_range([inner_arrays[n]], INNER[n][0], INNER[n][1]))
+                   for n in INNER_NAMES]
+    tx = []
+    for t in targets:
+        if t[0] == "key":
+            tx.append(TargetExpr(capi.PROJECT_KEY, t[1]))
+        elif t[3]:
+            tx.append(TargetExpr(t[1], INNER_NAMES.index(t[2]), 1))
+        else:
+            tx.append(TargetExpr(t[1], -1 if t[2] is None else idx[t[2]]))
+    ra = RelAlgExecutionUnit([descs[i] for i in src], tx, [Qual(idx[c], op, lit) for c, op, lit in quals],
+                             [idx[g] for g in group], inner_col_descs=inner_descs,
+                             join_outer_col=[idx[o] for o in outer] if len(outer) > 1 else idx[outer[0]],
+                             join_kind=capi.JOIN_LEFT if left else capi.JOIN_INNER)
+    keys = [inner_arrays[n] for n in inner]
+    ktypes = [INNER[n][0] for n in inner]
+    knull = [INNER[n][1] for n in inner]
+    single = len(inner) == 1
+    kr = col_range([keys[0]], ktypes[0], knull[0]) if single else None
+    from heavydb_amd.executor import ExpressionRange
+    case = Case("ref_join", ra, [[f[i] for i in src] for f in frags], [inner_arrays[n] for n in INNER_NAMES],
+                keys[0] if single else keys, ktypes[0] if single else ktypes, kr if single else ExpressionRange(),
+                False, join_one_to_many=1, join_key_nullable=knull[0] if single else knull)
+    if "test_inner" not in [r[0] for r in db.execute("SELECT name FROM sqlite_master")]:
+        db.execute("CREATE TABLE test_inner (" + ", ".join(INNER_NAMES) + ")")
+        db.executemany("INSERT INTO test_inner VALUES (?,?,?)", list(zip(*[INNER[n][2] for n in INNER_NAMES])))
+    return case, sql
+
+
+def _compare(sql, db, qm, rows_by_engine):
+    fp = [bool(qm.target_is_fp[t]) for t in range(qm.n_targets)]
+    want = sorted((tuple(float(v) if f and v is not None else v for v, f in zip(r, fp))
+                   for r in db.execute(sql).fetchall()), key=_key)
+    for name, rows in rows_by_engine:
+        rows = sorted(rows, key=_key)
+        assert len(rows) == len(want), (name, sql, want, rows)
+        for w, g in zip(want, rows):
+            for t, (a, b) in enumerate(zip(w, g)):
+                if a is None or b is None:
+                    assert a is None and b is None, (name, sql, t, w, g)
+                elif fp[t]:
+                    rt, at = (F32_RTOL, F32_ATOL) if qm.target_arg_is_f32[t] else (1e-12, 0.0)
+                    assert math.isclose(a, b, rel_tol=rt, abs_tol=at), (name, sql, t, w, g)
+                else:
+                    assert a == b, (name, sql, t, w, g)
+
+
+@pytest.mark.parametrize("ji", range(len(JOIN_QUERIES)), ids=[s[0][7:70].replace(" ", "_") for s in JOIN_QUERIES])
+def test_reference_join_queries(oracle, ji):
+    from tests.test_rowlogic_emu import _emu_execute, _oracle_join
+    descs, frags, db = _table()
+    case, sql = _join_case(descs, frags, db, JOIN_QUERIES[ji])
+    plan = case.ra.to_plan()
+    oj = _oracle_join(oracle, case)
+    qm, buf, code = oracle.execute(plan, case.frags, case.inner, oj, n_threads=3)
+    assert code == 0
+    eq, ebuf, ecode = _emu_execute(case, plan, oj)
+    assert ecode == 0
+    _compare(sql, db, qm, [("oracle", _rows(oracle.fetch_rows(qm, buf), qm)),
+                           ("product row logic", _rows(oracle.fetch_rows(eq, ebuf), eq))])

@@ -37,3 +37,19 @@ def test_reference_queries_on_gpu(torch_cuda, oracle, qi):
                 assert math.isclose(a, b, rel_tol=rt, abs_tol=at), (sql, t, w, g)
             else:
                 assert a == b, (sql, t, w, g)
+
+
+@pytest.mark.parametrize("ji", range(7))
+def test_reference_join_queries_on_gpu(torch_cuda, oracle, ji):
+    from heavydb_amd.executor import Executor
+    from tests.test_execute_style import JOIN_QUERIES, _compare, _join_case
+    from tests.test_gpu_parity import _build_join
+    assert len(JOIN_QUERIES) == 7
+    descs, frags, db = _table()
+    case, sql = _join_case(descs, frags, db, JOIN_QUERIES[ji])
+    frag_t, inner_t = _upload(torch_cuda, case)
+    hj, keep = _build_join(torch_cuda, case)
+    case.ra.join_table = hj
+    rs = Executor(0).executeWorkUnit(case.ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+    qm = rs.getQueryMemDesc()
+    _compare(sql, db, qm, [("HIP library", _rows(rs.fetch(), qm))])
