@@ -5,6 +5,8 @@ import ctypes as C
 import os
 import re
 
+import pytest
+
 from heavydb_amd import capi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -66,3 +68,38 @@ def test_invalid_plans_are_rejected():
     ra = RelAlgExecutionUnit([InputColDescriptor(capi.DOUBLE)], [TargetExpr(capi.COUNT)], groupby_exprs=[0])
     assert lib.mi355q_qmd_init(C.byref(ra.to_plan()), C.byref(q)) == capi.ERR_UNSUPPORTED
     assert lib.mi355q_error_string(3) == b"Out of Slots"
+
+
+def test_product_path_fails_loudly_without_the_library(tmp_path):
+    """No CPU fallback: a missing HIP library is an error at load time, and nothing under heavydb_amd/
+    imports the oracle (test infrastructure)."""
+    import re
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        capi.load_library(str(tmp_path / "libmi355q.so"))
+    pkg = os.path.join(ROOT, "heavydb_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
+                assert "liboracle" not in src and "oracle/" not in src.replace("oracle/oracle.cpp)", ""), f
+
+
+def test_execute_without_a_device_reports_an_error_code():
+    """On a box without a GPU the entry points return a HIP error code (never a result)."""
+    import ctypes as C
+    lib = capi.load_library()
+    if lib.mi355q_device_count() > 0:
+        pytest.skip("a GPU is present")
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    ra = RelAlgExecutionUnit([InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 9))], [TargetExpr(capi.COUNT)])
+    plan = ra.to_plan()
+    inp = capi.Inputs()
+    out = C.c_void_p()
+    rc = lib.mi355q_execute(C.byref(plan), C.byref(inp), None, C.byref(out), None)
+    assert rc == capi.ERR_HIP and not out.value
+    q = capi.QMD()
+    assert lib.mi355q_qmd_init(C.byref(plan), C.byref(q)) == 0
+    h = C.c_void_p()
+    assert lib.mi355q_result_create(C.byref(q), 0, None, C.byref(h)) in (capi.ERR_HIP, 2)  # 2 = ERR_OUT_OF_GPU_MEM
+    assert not h.value
