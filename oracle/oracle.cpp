@@ -1955,6 +1955,10 @@ ORC_EXPORT int32_t orc_get_group_value_columnar_slot(int64_t* buf, uint32_t entr
                                                      uint32_t key_count) {
   return get_group_value_columnar_slot(buf, entry_count, key, key_count);
 }
+// get_columnar_group_bin_offset on a key column (golden vectors)
+ORC_EXPORT uint32_t orc_get_columnar_group_bin_offset(int64_t* key_col, int64_t key, int64_t min_key, int64_t bucket) {
+  return get_columnar_group_bin_offset(key_col, key, min_key, bucket);
+}
 ORC_EXPORT int64_t orc_buffer_bytes(const mi355q_qmd* q) { return buffer_bytes(*q); }
 ORC_EXPORT int64_t orc_col_group_off(const mi355q_qmd* q, int32_t g) { return col_group_off(*q, g); }
 ORC_EXPORT int64_t orc_col_slot_off(const mi355q_qmd* q, int32_t s) { return col_slot_off(*q, s); }

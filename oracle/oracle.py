@@ -89,6 +89,8 @@ def lib() -> C.CDLL:
         for fn in ("orc_buffer_bytes", "orc_col_group_off", "orc_col_slot_off"):
             getattr(l, fn).restype = C.c_int64
         l.orc_buffer_bytes.argtypes = [P(capi.QMD)]
+        l.orc_get_columnar_group_bin_offset.restype = C.c_uint32
+        l.orc_get_columnar_group_bin_offset.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
         l.orc_get_group_value_columnar_slot.restype = C.c_int32
         l.orc_get_group_value_columnar_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         l.orc_col_group_off.argtypes = [P(capi.QMD), C.c_int32]

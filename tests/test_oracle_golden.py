@@ -324,3 +324,52 @@ def test_rows_to_arrow(oracle):
             want = None if nul[r, t] else (float(dval[r, t]) if q.target_is_fp[t] else int(ival[r, t]))
             assert col[r] == want
     assert tab.column("sum").null_count == int(nul[:, 1].sum())
+
+
+def test_columnar_runtime_functions_match_reference_vectors(oracle):
+    """get_group_value_columnar_slot / get_columnar_group_bin_offset restated in oracle.cpp against
+    traces produced by the reference's own functions (oracle/gen_golden_columnar.py ->
+    tests/golden/ref_columnar_vectors.json), and against the reference live when oracle/_ref is here."""
+    import ctypes as C
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_columnar_vectors.json")
+    g = json.load(open(path))
+    EMPTY = 2**63 - 1
+    ref = oracle.ref_lib()
+    if ref is not None:
+        ref.get_group_value_columnar_slot.restype = C.c_int32
+        ref.get_group_value_columnar_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+        ref.get_columnar_group_bin_offset.restype = C.c_uint32
+        ref.get_columnar_group_bin_offset.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]
+    lib = oracle.lib()
+    assert len(g["columnar_baseline_traces"]) >= 4
+    for tr in g["columnar_baseline_traces"]:
+        ec, kc = tr["entry_count"], tr["key_count"]
+        buf = np.full(ec * kc, EMPTY, dtype=np.int64)
+        live = np.full(ec * kc, EMPTY, dtype=np.int64)
+        for k, want in zip(tr["keys"], tr["bins"]):
+            kb = np.array(k, dtype=np.int64)
+            assert lib.orc_get_group_value_columnar_slot(buf.ctypes.data, ec, kb.ctypes.data, kc) == want
+            if ref is not None:
+                assert ref.get_group_value_columnar_slot(live.ctypes.data, ec, kb.ctypes.data, kc, 8) == want
+        assert buf.tolist() == tr["final_key_columns"]
+    for tr in g["columnar_perfect_traces"]:
+        col = np.full(tr["entries"], EMPTY, dtype=np.int64)
+        for k, want in zip(tr["keys"], tr["bins"]):
+            assert lib.orc_get_columnar_group_bin_offset(col.ctypes.data, k, tr["min_key"], tr["bucket"]) == want
+        assert col.tolist() == tr["final_key_column"]
+    # the same bins through a whole columnar step: a baseline GROUP BY over the first trace's keys
+    from heavydb_amd import capi
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    tr = g["columnar_baseline_traces"][0]
+    keys = np.array([k[0] for k in tr["keys"]], dtype=np.int64)
+    ra = RelAlgExecutionUnit([InputColDescriptor(capi.INT64, False, ExpressionRange(False))], [TargetExpr(capi.COUNT)],
+                             groupby_exprs=[0], max_groups_buffer_entry_guess=tr["entry_count"],
+                             output_columnar_hint=capi.OUTPUT_COLUMNAR, bigint_count=True)
+    q, buf, code = oracle.execute(ra.to_plan(), [[keys]])
+    assert code == 0 and q.output_columnar and q.entry_count == 8
+    assert buf[:8].tolist() == tr["final_key_columns"]
+    counts = buf[8:16]
+    for k, b in zip(tr["keys"], tr["bins"]):
+        assert counts[b] == sum(1 for kk in tr["keys"] if kk == k)
