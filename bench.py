@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline time")
     ap.add_argument("--verify", action="store_true", help="size-independent property checks")
+    ap.add_argument("--prepartitioned", action="store_true",
+                    help="cfg3/cfg3f, N > 1: the table arrives hash-partitioned by key (every key on one "
+                         "rank), so the final merge is skipped (SURVEY 8e's second mode)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-kernel HBM bytes/launch from a rocprofv3 --pmc pass (optional)")
     return ap.parse_args()
@@ -177,7 +180,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         total_rows = int(t.item())
 
-    ra, fr, info = synth.CONFIGS[cfg](torch, total_rows, rank, world, local_rank)
+    prepart = bool(args.prepartitioned and cfg in ("cfg3", "cfg3f") and world > 1)
+    extra = {"prepartitioned": True} if prepart else {}
+    ra, fr, info = synth.CONFIGS[cfg](torch, total_rows, rank, world, local_rank, **extra)
     info["ra"] = ra
     if cfg == "cfg4":
         info["dim_rows"] = fr.inner_num_rows
@@ -189,7 +194,7 @@ def main():
                               force_generic=args.force_generic)
         rep = sh.report
         if world > 1:
-            sh = merge(sh, dist, torch)
+            sh = merge(sh, dist, torch, prepartitioned=prepart)
         return sh, rep
 
     def sync():
@@ -261,7 +266,7 @@ def main():
         "data": "synthetic (device-generated splitmix64 columns, 32 M-row fragments)",
         "config": {"workload": f"{cfg}: {total_rows} rows" + ("" if total_rows == want else f" (largest that fits; asked {want})"),
                    "bytes_per_row": bpr, "fragments_per_rank": len(fr.num_rows), "rows_per_rank": local_rows,
-                   "kernel": kname, "variant": int(reports[-1].variant) if reports else 0,
+                   "prepartitioned_by_key": prepart, "kernel": kname, "variant": int(reports[-1].variant) if reports else 0,
                    "device": name.value.decode(), "cus": cus.value,
                    "hbm_reported_gbs": round(2 * clk.value * 1e3 * bus.value / 8 / 1e9, 1)},
         "achieved_gbs_whole_step": total_rows * bpr * args.steps / elapsed / 1e9,

@@ -110,12 +110,18 @@ def merge_dense(shard: ShardOps, dist, torch, group=None) -> ShardOps:
     return out
 
 
-def merge_keyed(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool = False) -> ShardOps:
+def merge_keyed(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool = False,
+                prepartitioned: bool = False) -> ShardOps:
+    """prepartitioned: the input ROWS were already dealt to the ranks by key (every key lives on one
+    rank), so the per-rank tables are disjoint and there is nothing to exchange ("no final
+    collective, just gather"); only the optional gather to rank 0 runs."""
     q = shard.qmd()
     world = dist.get_world_size(group)
     if world == 1:
         return shard
     rq = q.row_size // 8
+    if prepartitioned:
+        return _gather_to_rank0(shard, shard, dist, torch, group, rq) if gather_to_rank0 else shard
     rows, counts = shard.partition_rows(world)
     send_counts = torch.tensor(counts, dtype=torch.int64, device=rows.device)
     recv_counts = torch.empty_like(send_counts)
@@ -127,31 +133,36 @@ def merge_keyed(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool 
                            input_split_sizes=[c * rq for c in counts], group=group)
     out = shard.fresh_like()
     out.merge_rows(recv_rows)
-    if gather_to_rank0:
-        mine, _ = out.partition_rows(1)
-        n_mine = torch.tensor([mine.shape[0]], dtype=torch.int64, device=rows.device)
-        sizes = [torch.empty_like(n_mine) for _ in range(world)]
-        dist.all_gather(sizes, n_mine, group=group)
-        sizes = [int(s.item()) for s in sizes]
-        rank = dist.get_rank(group)
-        if rank == 0:
-            bufs = [torch.empty((s, rq), dtype=torch.int64, device=rows.device) for s in sizes]
-            bufs[0].copy_(mine)
-            reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(1, world) if sizes[r]]
-            for r_ in reqs:
-                r_.wait()
-            for r in range(1, world):
-                if sizes[r]:
-                    out.merge_rows(bufs[r])
-        elif mine.shape[0]:
-            dist.send(mine.contiguous(), dst=0, group=group)
+    return _gather_to_rank0(out, shard, dist, torch, group, rq) if gather_to_rank0 else out
+
+
+def _gather_to_rank0(out: ShardOps, shard: ShardOps, dist, torch, group, rq: int) -> ShardOps:
+    """Rank 0 additionally folds every other rank's (disjoint) rows into its table."""
+    world = dist.get_world_size(group)
+    mine, _ = out.partition_rows(1)
+    n_mine = torch.tensor([mine.shape[0]], dtype=torch.int64, device=mine.device)
+    sizes = [torch.empty_like(n_mine) for _ in range(world)]
+    dist.all_gather(sizes, n_mine, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    rank = dist.get_rank(group)
+    if rank == 0:
+        bufs = [torch.empty((s, rq), dtype=torch.int64, device=mine.device) for s in sizes]
+        reqs = [dist.irecv(bufs[r], src=r, group=group) for r in range(1, world) if sizes[r]]
+        for r_ in reqs:
+            r_.wait()
+        for r in range(1, world):
+            if sizes[r]:
+                out.merge_rows(bufs[r])
+    elif mine.shape[0]:
+        dist.send(mine.contiguous(), dst=0, group=group)
     return out
 
 
-def merge(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool = False) -> ShardOps:
+def merge(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool = False,
+          prepartitioned: bool = False) -> ShardOps:
     """The final-aggregate merge of one step across the ranks of `group`."""
     if shard.qmd().desc_type == capi.GROUP_BY_BASELINE_HASH:
-        return merge_keyed(shard, dist, torch, group, gather_to_rank0)
+        return merge_keyed(shard, dist, torch, group, gather_to_rank0, prepartitioned)
     return merge_dense(shard, dist, torch, group)
 
 

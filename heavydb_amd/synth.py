@@ -99,10 +99,16 @@ def cfg2(torch, total_rows=1_000_000_000, rank=0, world=1, device_id=0, keyless=
 
 # ---- cfg3: SELECT key, COUNT(*), AVG(f64) FROM t [WHERE i32 < k] GROUP BY key
 def cfg3(torch, total_rows=10_000_000_000, rank=0, world=1, device_id=0, filtered=True,
-         n_keys=10_000_000, k=2**30):
+         n_keys=10_000_000, k=2**30, prepartitioned=False):
     stride = 1_000_003
-    specs = [ColSpec(INT64, GEN_I64_MOD_MUL, a=n_keys, b=stride, c=7,
-                     range=ExpressionRange(True, 7, (n_keys - 1) * stride + 7)),
+    # prepartitioned: the table arrives hash-partitioned by key — rank r only holds the keys
+    # ((i * world + r) * stride + 7), so the per-rank results are disjoint and need no merge
+    key_spec = (ColSpec(INT64, GEN_I64_MOD_MUL, a=max(n_keys // world, 1), b=stride * world, c=7 + stride * rank,
+                        range=ExpressionRange(True, 7, (n_keys - 1) * stride + 7))
+                if prepartitioned and world > 1 else
+                ColSpec(INT64, GEN_I64_MOD_MUL, a=n_keys, b=stride, c=7,
+                        range=ExpressionRange(True, 7, (n_keys - 1) * stride + 7)))
+    specs = [key_spec,
              ColSpec(DOUBLE, GEN_F64_UNIT, a_f=1000.0, range=ExpressionRange(True, 0, 0, False, 0.0, 1000.0))]
     quals = []
     if filtered:

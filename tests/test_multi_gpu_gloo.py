@@ -183,13 +183,23 @@ def _worker(rank, world, port, shape, errq):
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
         dist.init_process_group("gloo", rank=rank, world_size=world)
-        ra, frags = _table(shape)
+        prepart = shape == "keyed_prepartitioned"
+        ra, frags = _table("keyed" if prepart else shape)
         plan = ra.to_plan()
-        mine = [f for i, f in enumerate(frags) if i % world == rank]
+        if prepart:
+            # rows dealt to the ranks BY KEY (every key on exactly one rank): no exchange, gather only
+            cols = [np.concatenate([f[c] for f in frags]) for c in range(len(frags[0]))]
+            sel = ((cols[0] - 7) // 1000003) % world == rank
+            mine = [[c[sel] for c in cols]]
+        else:
+            mine = [f for i, f in enumerate(frags) if i % world == rank]
         q, buf, code = orc.execute(plan, mine, n_threads=1)
         assert code == 0
         shard = NumpyShard(torch, orc, q, buf)
-        out = merge(shard, dist, torch, gather_to_rank0=True)
+        before = shard.buffer().numpy().copy()
+        out = merge(shard, dist, torch, gather_to_rank0=True, prepartitioned=prepart)
+        if prepart and rank != 0:
+            assert out is shard and np.array_equal(before, out.buffer().numpy())  # nothing moved
         q_all, want, code = orc.execute(plan, frags, n_threads=2)
         assert code == 0
         got = out.buffer().numpy()
@@ -203,7 +213,7 @@ def _worker(rank, world, port, shape, errq):
             live = got[got[:, 0] != EMPTY64]
             owner = _owner(q, live, world)
             if rank != 0:
-                assert (owner == rank).all()
+                assert prepart or (owner == rank).all()
             else:  # ... and rank 0 additionally gathered everything
                 compare_buffers(q_all, want, got.reshape(-1), 1e-9)
                 compare_rows(q_all, orc.fetch_rows(q_all, want), orc.fetch_rows(q_all, got.reshape(-1)), 1e-9)
@@ -226,7 +236,7 @@ def _free_port():
 @pytest.mark.parametrize("shape", ["keyed", "keyed_two_columns", "keyed_compact", "perfect", "perfect_nullable",
                                    "perfect_float", "non_grouped", "perfect_two_columns_unprojected",
                                    "perfect_columnar", "perfect_nullable_columnar", "keyed_columnar",
-                                   "keyed_two_columns_columnar", "perfect_two_columns_unprojected_columnar"])
+                                   "keyed_two_columns_columnar", "perfect_two_columns_unprojected_columnar", "keyed_prepartitioned"])
 def test_merge_over_gloo(shape, world):
     import torch.multiprocessing as mp
     from oracle import oracle as orc
@@ -248,3 +258,19 @@ def test_merge_over_gloo(shape, world):
             errs.append((-1, "timeout"))
     assert not errs, "\n".join(f"rank {r}:\n{t}" for r, t in errs)
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_prepartitioned_key_streams_are_disjoint(oracle):
+    """bench.py --prepartitioned: the per-rank key generators of heavydb_amd/synth.cfg3 (same
+    splitmix64 stream as the device generator) produce disjoint slices of the original key set."""
+    from heavydb_amd import capi
+    n_keys, stride, world, n = 1000, 1_000_003, 4, 20_000
+    full = set(oracle.generate_column(n, capi.GEN_I64_MOD_MUL, 0xC0FFEE00, n_keys, stride, 7).tolist())
+    seen = set()
+    for rank in range(world):
+        k = set(oracle.generate_column(n, capi.GEN_I64_MOD_MUL, 0xC0FFEE00, n_keys // world, stride * world,
+                                       7 + stride * rank).tolist())
+        assert len(k) == n_keys // world and not (k & seen) and k <= full
+        assert all(((x - 7) // stride) % world == rank for x in k)
+        seen |= k
+    assert seen == full
