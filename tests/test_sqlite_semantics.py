@@ -201,3 +201,12 @@ def test_random_joins_agree_with_sqlite(oracle):
         r = _check_case(oracle, _fuzz_join(rng))
         tally[r] = tally.get(r, 0) + 1
     assert tally.get("ok", 0) > 120, tally
+
+
+def test_benchmark_shapes_at_a_million_rows_agree_with_sqlite(oracle):
+    """The shapes BASELINE.json benchmarks (filtered baseline GROUP BY, perfect-hash GROUP BY, filtered
+    scan, join probe + SUM, one-to-many LEFT join) at 1 M rows: oracle == SQLite.  The GPU leg
+    (tests/test_zz_gpu_sqlite_scale.py) runs the same cases through the kernel families."""
+    from tests.test_zz_gpu_sqlite_scale import SHAPES
+    for name, _, case in SHAPES:
+        assert _check_case(oracle, case) == "ok", name
