@@ -232,7 +232,9 @@ inline float decode_flt(const int8_t* col, int64_t pos) {
 // RuntimeFunctions.cpp:362
 inline void agg_count(int64_t* agg) { ++*reinterpret_cast<uint64_t*>(agg); }
 // :1151
-inline void agg_sum(int64_t* agg, int64_t val) { *agg += val; }
+// (the reference's `*agg += val` wraps on x86; written with unsigned arithmetic so that the wrap is
+// defined behaviour here too)
+inline void agg_sum(int64_t* agg, int64_t val) { *agg = (int64_t)((uint64_t)*agg + (uint64_t)val); }
 // :1163-1169
 inline void agg_max(int64_t* agg, int64_t val) { *agg = std::max(*agg, val); }
 inline void agg_min(int64_t* agg, int64_t val) { *agg = std::min(*agg, val); }

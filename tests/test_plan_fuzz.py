@@ -355,3 +355,16 @@ def test_reduce_agrees_on_random_plans(oracle):
         compare_buffers(q, red, mine, 1e-12)
         ran += 1
     assert ran > 150, ran
+
+
+def test_boundary_values_agree(oracle):
+    """tools/boundary_fuzz.py: columns of type extremes / NULL sentinels through the product's row logic
+    and the oracle."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        "boundary_fuzz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "boundary_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ok = sum(mod.run(seed, 150).get("ok", 0) for seed in (101, 102))
+    assert ok > 250, ok
