@@ -368,3 +368,8 @@ def test_boundary_values_agree(oracle):
     spec.loader.exec_module(mod)
     ok = sum(mod.run(seed, 150).get("ok", 0) for seed in (101, 102))
     assert ok > 250, ok
+    keys = {}
+    for seed in (201, 202):
+        for k, v in mod.run_keys(seed, 150).items():
+            keys[k] = keys.get(k, 0) + v
+    assert keys.get("ok_0_w8", 0) > 20 and keys.get("ok_1_w8", 0) > 100 and keys.get("ok_1_w4", 0) > 3, keys

@@ -68,5 +68,53 @@ def run(seed, iters):
     return tally
 
 
+def run_keys(seed, iters):
+    """group keys at the extremes of their types (EMPTY_KEY_32/64 neighbours, the int32 boundary for
+    8-byte keys), 1-3 group columns, perfect and baseline layouts"""
+    from tests.helpers import columnar_to_rows, rowwise_qmd
+    rng = np.random.default_rng(seed); tally = {}
+    for it in range(iters):
+        n = int(rng.integers(1, 120))
+        ng = int(rng.integers(1, 4))
+        cols, descs = [], []
+        for g in range(ng):
+            t = [capi.INT8, capi.INT16, capi.INT32, capi.INT64][int(rng.integers(0, 4))]
+            info = np.iinfo(NP[t])
+            nullable = bool(rng.integers(0, 2))
+            hi = [info.max - 3, info.max - 2] + ([info.max - 1, info.max] if t != capi.INT64 else [])  # INT64_MAX - 1: the product's lock value (DESIGN)
+            lo = ([info.min] if nullable or t != capi.INT64 else []) + [info.min + 1, info.min + 2]
+            near32 = [2**31 - 3, 2**31 - 2, 2**31 - 1, 2**31, -2**31, -2**31 + 1, -2**31 - 1] if t == capi.INT64 else []
+            pool = np.array(lo + [-1, 0, 1] + hi + near32, dtype=np.int64)
+            pick = pool[rng.integers(0, len(pool), int(rng.integers(1, 5)))]       # few distinct values
+            a = pick[rng.integers(0, len(pick), n)].astype(NP[t])
+            rk = int(rng.integers(0, 3))
+            r = V(False) if rk == 0 else col_range([a], t, nullable)
+            cols.append(a); descs.append(InputColDescriptor(t, nullable, r))
+        val = rng.integers(-100, 100, n).astype(np.int64)
+        cols.append(val); descs.append(InputColDescriptor(capi.INT64, False, V(True, -100, 99)))
+        targets = [TargetExpr(capi.PROJECT_KEY, g) for g in range(ng) if rng.integers(0, 2)] + [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, ng)]
+        ra = RelAlgExecutionUnit(descs, targets, [], list(range(ng)), max_groups_buffer_entry_guess=int(rng.choice([16, 64, 2048])),
+                                 output_columnar_hint=int(rng.integers(0, 2)), num_tuples=n)
+        cut = n // 2
+        case = Case("k", ra, [[c[:cut] for c in cols], [c[cut:] for c in cols]])
+        plan = ra.to_plan()
+        try:
+            q, want, code = oracle.execute(plan, case.frags, n_threads=2)
+        except capi.Mi355qError as e:
+            from tests.helpers import emu_lib
+            import ctypes as C
+            assert emu_lib().emu_qmd_init(C.byref(plan), C.byref(capi.QMD())) != 0
+            tally["rejected"] = tally.get("rejected", 0) + 1; continue
+        eq, got, ecode = _emu_execute(case, plan, None)
+        assert (code == 0) == (ecode == 0), (seed, it, code, ecode)
+        if code: tally["err"] = tally.get("err", 0) + 1; continue
+        qmd_equal(q, eq)
+        if q.output_columnar: compare_buffers(rowwise_qmd(q), columnar_to_rows(q, want), columnar_to_rows(q, got), 1e-9)
+        else: compare_buffers(q, want, got, 1e-9)
+        k = "ok_%d_w%d" % (q.desc_type, q.key_width)
+        tally[k] = tally.get(k, 0) + 1
+    return tally
+
+
 if __name__ == "__main__":
-    print(sys.argv[1], run(int(sys.argv[1]), int(sys.argv[2])))
+    print(sys.argv[1], run(int(sys.argv[1]), int(sys.argv[2])), run_keys(int(sys.argv[1]), int(sys.argv[2])))
