@@ -116,5 +116,59 @@ def run_keys(seed, iters):
     return tally
 
 
+def run_joins(seed, iters):
+    """join keys at the extremes of their types on both sides, NULL keys, duplicates, empty inner
+    tables, all four table layouts, INNER / LEFT: product row logic vs oracle vs SQLite"""
+    from tests.test_rowlogic_emu import _oracle_join
+    from tests.test_sqlite_semantics import _check_case
+    NPJ = {capi.INT16: np.int16, capi.INT32: np.int32, capi.INT64: np.int64}
+    rng = np.random.default_rng(seed); tally = {}
+    for it in range(iters):
+        t = [capi.INT16, capi.INT32, capi.INT64][int(rng.integers(0, 3))]
+        info = np.iinfo(NPJ[t])
+        wide = bool(rng.integers(0, 2))
+        if wide:   # extremes of the type: only a keyed table can hold them
+            pool = np.array([info.min + 1, info.min + 2, -1, 0, 1, info.max - 3, info.max - 2], dtype=np.int64)
+        else:
+            base = int(rng.choice([0, -5, info.max - 40, info.min + 2]))
+            pool = base + np.arange(0, 12, dtype=np.int64)
+        m = int(rng.integers(0, 10))
+        dim = pool[rng.integers(0, len(pool), m)] if rng.integers(0, 2) else rng.permutation(pool)[:m]
+        dnull = bool(rng.integers(0, 2))
+        dim = dim.astype(NPJ[t])
+        m = len(dim)
+        if dnull and m: dim[rng.random(m) < 0.2] = info.min
+        n = int(rng.integers(1, 80))
+        fact = np.concatenate([pool, [info.min, info.max if t != capi.INT64 else info.max - 2]])[rng.integers(0, len(pool) + 2, n)].astype(NPJ[t])
+        fnull = bool(rng.integers(0, 2))
+        if not fnull: fact[fact == info.min] = pool[0]
+        v = rng.integers(-50, 50, n).astype(np.int64)
+        g = rng.integers(0, 3, n).astype(np.int32)
+        w = rng.integers(-9, 9, m).astype(np.int64)
+        fd = [InputColDescriptor(t, fnull, col_range([fact], t, fnull)), InputColDescriptor(capi.INT64, False, V(True, -50, 49)),
+              InputColDescriptor(capi.INT32, False, V(True, 0, 2))]
+        idesc = [InputColDescriptor(t, dnull, col_range([dim], t, dnull)), InputColDescriptor(capi.INT64, False, V(True, -9, 8))]
+        grouped = bool(rng.integers(0, 2))
+        targets = ([TargetExpr(capi.PROJECT_KEY)] if grouped else []) + [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1), TargetExpr(capi.SUM, 1, 1), TargetExpr(capi.COUNT, 0, 1)]
+        ra = RelAlgExecutionUnit(fd, targets, [], [2] if grouped else [], inner_col_descs=idesc, join_outer_col=0, join_kind=int(rng.integers(0, 2)))
+        dr = col_range([dim], t, dnull)
+        if dr.min > dr.max: dr = V(True, 0, 0)
+        case = Case("bj", ra, [[fact, v, g]], [dim, w], dim, t, dr, bool(rng.integers(0, 2)) or wide, join_one_to_many=1, join_key_nullable=dnull)
+        plan = ra.to_plan()
+        try:
+            oj = _oracle_join(oracle, case)
+        except capi.Mi355qError as e:
+            tally["build_" + str(e.code)] = tally.get("build_" + str(e.code), 0) + 1; continue
+        q, want, code = oracle.execute(plan, case.frags, case.inner, oj)
+        eq, got, ecode = _emu_execute(case, plan, oj)
+        assert code == 0 and ecode == 0, (seed, it, code, ecode)
+        qmd_equal(q, eq); compare_buffers(q, want, got, 1e-9)
+        r = _check_case(oracle, case)
+        k = f"{r}_ht{oj.info()['hash_type']}"
+        tally[k] = tally.get(k, 0) + 1
+    return tally
+
+
 if __name__ == "__main__":
-    print(sys.argv[1], run(int(sys.argv[1]), int(sys.argv[2])), run_keys(int(sys.argv[1]), int(sys.argv[2])))
+    print(sys.argv[1], run(int(sys.argv[1]), int(sys.argv[2])), run_keys(int(sys.argv[1]), int(sys.argv[2])),
+          run_joins(int(sys.argv[1]), int(sys.argv[2])))
