@@ -16,7 +16,8 @@ from tests.test_rowlogic_emu import _emu_execute
 NP = {capi.INT8: np.int8, capi.INT16: np.int16, capi.INT32: np.int32, capi.INT64: np.int64}
 
 
-def run(seed, iters):
+def run(seed, iters, engine=None):
+    engine = engine or _emu_execute
     rng = np.random.default_rng(seed)
     tally = {}
     for it in range(iters):
@@ -55,7 +56,7 @@ def run(seed, iters):
             q, want, code = oracle.execute(plan, case.frags, n_threads=2)
         except capi.Mi355qError:
             tally["rejected"] = tally.get("rejected", 0) + 1; continue
-        eq, got, ecode = _emu_execute(case, plan, None)
+        eq, got, ecode = engine(case, plan, None)
         assert (code == 0) == (ecode == 0), (seed, it, code, ecode)
         if code: tally["err"] = tally.get("err", 0) + 1; continue
         qmd_equal(q, eq)
@@ -68,7 +69,8 @@ def run(seed, iters):
     return tally
 
 
-def run_keys(seed, iters):
+def run_keys(seed, iters, engine=None):
+    engine = engine or _emu_execute
     """group keys at the extremes of their types (EMPTY_KEY_32/64 neighbours, the int32 boundary for
     8-byte keys), 1-3 group columns, perfect and baseline layouts"""
     from tests.helpers import columnar_to_rows, rowwise_qmd
@@ -105,7 +107,7 @@ def run_keys(seed, iters):
             import ctypes as C
             assert emu_lib().emu_qmd_init(C.byref(plan), C.byref(capi.QMD())) != 0
             tally["rejected"] = tally.get("rejected", 0) + 1; continue
-        eq, got, ecode = _emu_execute(case, plan, None)
+        eq, got, ecode = engine(case, plan, None)
         assert (code == 0) == (ecode == 0), (seed, it, code, ecode)
         if code: tally["err"] = tally.get("err", 0) + 1; continue
         qmd_equal(q, eq)
@@ -116,7 +118,8 @@ def run_keys(seed, iters):
     return tally
 
 
-def run_joins(seed, iters):
+def run_joins(seed, iters, engine=None):
+    engine = engine or _emu_execute
     """join keys at the extremes of their types on both sides, NULL keys, duplicates, empty inner
     tables, all four table layouts, INNER / LEFT: product row logic vs oracle vs SQLite"""
     from tests.test_rowlogic_emu import _oracle_join
@@ -160,7 +163,7 @@ def run_joins(seed, iters):
         except capi.Mi355qError as e:
             tally["build_" + str(e.code)] = tally.get("build_" + str(e.code), 0) + 1; continue
         q, want, code = oracle.execute(plan, case.frags, case.inner, oj)
-        eq, got, ecode = _emu_execute(case, plan, oj)
+        eq, got, ecode = engine(case, plan, oj)
         assert code == 0 and ecode == 0, (seed, it, code, ecode)
         qmd_equal(q, eq); compare_buffers(q, want, got, 1e-9)
         r = _check_case(oracle, case)
