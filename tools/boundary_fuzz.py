@@ -66,6 +66,23 @@ def run(seed, iters, engine=None):
         else:
             compare_buffers(q, want, got, 1e-9)
         tally["ok"] = tally.get("ok", 0) + 1
+        if engine is _emu_execute:
+            # ResultSetStorage::reduce of the two per-fragment buffers: oracle vs the product's reduce code
+            import ctypes as C
+            from tests.helpers import columnar_to_rows, emu_lib, rowwise_qmd
+            _, a, ca = oracle.execute(plan, case.frags[:1])
+            _, b, cb = oracle.execute(plan, case.frags[1:])
+            if ca == 0 and cb == 0:
+                r_o, r_e = a.copy(), a.copy()
+                co = oracle.reduce(q, r_o, b)
+                ce = emu_lib().emu_reduce(C.byref(q), r_e.ctypes.data, b.ctypes.data, q.entry_count)
+                assert (co == 0) == (ce == 0), (seed, it, co, ce)
+                if co == 0:
+                    if q.output_columnar:
+                        compare_buffers(rowwise_qmd(q), columnar_to_rows(q, r_o), columnar_to_rows(q, r_e), 1e-9)
+                    else:
+                        compare_buffers(q, r_o, r_e, 1e-9)
+                    tally["reduce_ok"] = tally.get("reduce_ok", 0) + 1
     return tally
 
 
