@@ -189,6 +189,36 @@ def run_joins(seed, iters, engine=None):
     return tally
 
 
+def run_fp(seed, iters, with_nan=False):
+    """MIN / MAX / COUNT over FLOAT and DOUBLE columns of +-inf, +-0.0, the NULL sentinels (FLT_MIN / DBL_MIN),
+    +-MAX and eps, bit for bit.  NaN is left out by default: the reference's MIN / MAX are comparison based,
+    so their result with NaN inputs depends on the order of the rows (in the reference as well)."""
+    rng = np.random.default_rng(seed); tally = {}
+    for it in range(iters):
+        n = int(rng.integers(1, 60))
+        key = rng.integers(0, 4, n).astype(np.int32)
+        f64 = bool(rng.integers(0, 2))
+        dt = np.float64 if f64 else np.float32
+        fi = np.finfo(dt)
+        pool = [np.inf, -np.inf, -0.0, 0.0, fi.tiny, fi.max, -fi.max, 1.5, -2.25, fi.eps] + ([np.nan] if with_nan else [])
+        a = np.array(pool, dtype=dt)[rng.integers(0, len(pool), n)]
+        nullable = bool(rng.integers(0, 2))
+        d = [InputColDescriptor(capi.INT32, False, V(True, 0, 3)), InputColDescriptor(capi.DOUBLE if f64 else capi.FLOAT, nullable, V(False))]
+        grouped = bool(rng.integers(0, 2))
+        tg = [TargetExpr([capi.MIN, capi.MAX, capi.COUNT][int(rng.integers(0, 3))], 1) for _ in range(int(rng.integers(1, 4)))]
+        ra = RelAlgExecutionUnit(d, tg, [], [0] if grouped else [])
+        case = Case("fp", ra, [[key, a]])
+        plan = ra.to_plan()
+        q, want, code = oracle.execute(plan, case.frags)
+        eq, got, ecode = _emu_execute(case, plan, None)
+        assert code == 0 and ecode == 0
+        qmd_equal(q, eq)
+        if not np.array_equal(want, got):
+            tally["bad"] = tally.get("bad", 0) + 1
+        else: tally["ok"] = tally.get("ok", 0) + 1
+    return tally
+
+
 if __name__ == "__main__":
     print(sys.argv[1], run(int(sys.argv[1]), int(sys.argv[2])), run_keys(int(sys.argv[1]), int(sys.argv[2])),
-          run_joins(int(sys.argv[1]), int(sys.argv[2])))
+          run_joins(int(sys.argv[1]), int(sys.argv[2])), run_fp(int(sys.argv[1]), int(sys.argv[2])))
