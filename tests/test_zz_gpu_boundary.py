@@ -54,3 +54,9 @@ def test_boundary_joins_on_gpu(torch_cuda, oracle):
     mod = _tool()
     t = mod.run_joins(7003, 120, _hip_engine(torch_cuda))
     assert sum(v for k, v in t.items() if k.startswith("ok_")) > 100, t
+
+
+def test_boundary_floats_on_gpu(torch_cuda, oracle):
+    mod = _tool()
+    t = mod.run_fp(7004, 150, False, _hip_engine(torch_cuda))
+    assert t == {"ok": 150}, t
