@@ -373,6 +373,8 @@ def test_boundary_values_agree(oracle):
         for k, v in mod.run_keys(seed, 150).items():
             keys[k] = keys.get(k, 0) + v
     assert mod.run_fp(401, 300) == {"ok": 300}
+    enc = mod.run_enc(501, 200)
+    assert enc.get("ok", 0) > 170 and set(enc) <= {"ok", "rejected", "keyless-null-aware"}, enc
     joins = mod.run_joins(301, 200)
     assert all(joins.get(f"ok_ht{h}", 0) > 5 for h in range(4)) and sum(joins.values()) == 200, joins
     assert keys.get("ok_0_w8", 0) > 20 and keys.get("ok_1_w8", 0) > 100 and keys.get("ok_1_w4", 0) > 3, keys

@@ -224,6 +224,66 @@ def run_fp(seed, iters, with_nan=False, engine=None):
     return tally
 
 
+def _enc_col(rng, n):
+    from tests.test_sqlite_semantics import _decoded_values
+    kind = int(rng.integers(0, 3))
+    if kind == 0:      # kENCODING_FIXED: storage narrower than the logical type
+        st = [capi.INT8, capi.INT16, capi.INT32][int(rng.integers(0, 3))]
+        lg = [t for t in (capi.INT16, capi.INT32, capi.INT64) if t > st][int(rng.integers(0, 3 - [capi.INT8, capi.INT16, capi.INT32].index(st)))]
+        enc = capi.ENC_FIXED
+    elif kind == 1:    # dictionary ids: unsigned 1 / 2 bytes, signed 4 bytes
+        st, lg, enc = [capi.INT8, capi.INT16, capi.INT32][int(rng.integers(0, 3))], 0, capi.ENC_DICT
+    else:              # DATE in days, 2 or 4 bytes
+        st, lg, enc = [capi.INT16, capi.INT32][int(rng.integers(0, 2))], 0, capi.ENC_DATE_IN_DAYS
+    info = np.iinfo(NP[st])
+    nullable = bool(rng.integers(0, 2))
+    pool = [info.min + 1, info.min + 2, -2, -1, 0, 1, 2, info.max - 2, info.max - 1]
+    if enc == capi.ENC_DATE_IN_DAYS and st == capi.INT32:
+        pool = [-30000, -1, 0, 1, 18000, 18001, 40000]
+    if not (enc == capi.ENC_DICT and st != capi.INT32): pool.append(info.max)   # unsigned ids: -1 is the NULL id (255 / 65535)
+    if enc == capi.ENC_DICT and st != capi.INT32 and not nullable: pool = [p for p in pool if p != -1]
+    if nullable: pool.append(info.min if not (enc == capi.ENC_DICT and st != capi.INT32) else -1)
+    if enc == capi.ENC_DICT and st != capi.INT32 and not nullable: pass
+    a = np.array(pool, dtype=np.int64)[rng.integers(0, len(pool), n)].astype(NP[st])
+    d = InputColDescriptor(st, nullable, V(False), enc, lg)
+    vals = [v for v in _decoded_values(d, a) if v is not None]
+    has_null = any(v is None for v in _decoded_values(d, a))
+    if vals and rng.integers(0, 2):
+        d.range = V(True, min(vals), max(vals), has_null, bucket=86400 if enc == capi.ENC_DATE_IN_DAYS and rng.integers(0, 2) else 0)
+    return d, a
+def run_enc(seed, iters):
+    """kENCODING_FIXED / dictionary-id / DATE-in-days columns at their storage extremes (and NULL
+    patterns), as group keys and aggregate arguments: product row logic vs oracle vs SQLite (decoded with
+    numpy)"""
+    from tests.test_sqlite_semantics import _check_case
+    rng = np.random.default_rng(seed); tally = {}
+    for it in range(iters):
+        n = int(rng.integers(1, 100))
+        descs, cols = [], []
+        for _ in range(int(rng.integers(1, 4))):
+            d, a = _enc_col(rng, n); descs.append(d); cols.append(a)
+        grouped = bool(rng.integers(0, 2))
+        group = [int(rng.integers(0, len(cols)))] if grouped else []
+        tg = ([TargetExpr(capi.PROJECT_KEY)] if grouped else []) + [TargetExpr(capi.COUNT)]
+        for _ in range(int(rng.integers(1, 4))):
+            tg.append(TargetExpr([capi.MIN, capi.MAX, capi.SUM, capi.COUNT, capi.AVG][int(rng.integers(0, 5))], int(rng.integers(0, len(cols)))))
+        ra = RelAlgExecutionUnit(descs, tg, [], group, max_groups_buffer_entry_guess=64)
+        case = Case("enc", ra, [[c[:n // 2] for c in cols], [c[n // 2:] for c in cols]])
+        plan = ra.to_plan()
+        try:
+            q, want, code = oracle.execute(plan, case.frags, n_threads=2)
+        except capi.Mi355qError:
+            tally["rejected"] = tally.get("rejected", 0) + 1; continue
+        eq, got, ecode = _emu_execute(case, plan, None)
+        assert (code == 0) == (ecode == 0), (seed, it, code, ecode)
+        if code: tally["err"] = tally.get("err", 0) + 1; continue
+        qmd_equal(q, eq); compare_buffers(q, want, got, 1e-9)
+        r = _check_case(oracle, case)
+        tally[r] = tally.get(r, 0) + 1
+    return tally
+
+
 if __name__ == "__main__":
     print(sys.argv[1], run(int(sys.argv[1]), int(sys.argv[2])), run_keys(int(sys.argv[1]), int(sys.argv[2])),
-          run_joins(int(sys.argv[1]), int(sys.argv[2])), run_fp(int(sys.argv[1]), int(sys.argv[2])))
+          run_joins(int(sys.argv[1]), int(sys.argv[2])), run_fp(int(sys.argv[1]), int(sys.argv[2])),
+          run_enc(int(sys.argv[1]), int(sys.argv[2])))
