@@ -60,3 +60,9 @@ def test_boundary_floats_on_gpu(torch_cuda, oracle):
     mod = _tool()
     t = mod.run_fp(7004, 150, False, _hip_engine(torch_cuda))
     assert t == {"ok": 150}, t
+
+
+def test_boundary_encoded_columns_on_gpu(torch_cuda, oracle):
+    mod = _tool()
+    t = mod.run_enc(7005, 120, _hip_engine(torch_cuda))
+    assert t.get("ok", 0) > 90 and set(t) <= {"ok", "rejected", "keyless-null-aware"}, t

@@ -251,7 +251,7 @@ def _enc_col(rng, n):
     if vals and rng.integers(0, 2):
         d.range = V(True, min(vals), max(vals), has_null, bucket=86400 if enc == capi.ENC_DATE_IN_DAYS and rng.integers(0, 2) else 0)
     return d, a
-def run_enc(seed, iters):
+def run_enc(seed, iters, engine=None):
     """kENCODING_FIXED / dictionary-id / DATE-in-days columns at their storage extremes (and NULL
     patterns), as group keys and aggregate arguments: product row logic vs oracle vs SQLite (decoded with
     numpy)"""
@@ -274,7 +274,7 @@ def run_enc(seed, iters):
             q, want, code = oracle.execute(plan, case.frags, n_threads=2)
         except capi.Mi355qError:
             tally["rejected"] = tally.get("rejected", 0) + 1; continue
-        eq, got, ecode = _emu_execute(case, plan, None)
+        eq, got, ecode = (engine or _emu_execute)(case, plan, None)
         assert (code == 0) == (ecode == 0), (seed, it, code, ecode)
         if code: tally["err"] = tally.get("err", 0) + 1; continue
         qmd_equal(q, eq); compare_buffers(q, want, got, 1e-9)
