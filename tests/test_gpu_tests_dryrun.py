@@ -172,3 +172,12 @@ def test_dryrun_boundary(monkeypatch, oracle):
     assert sum(v for k, v in mod.run_joins(7003, 30, eng).items() if k.startswith("ok_")) > 20
     assert mod.run_fp(7004, 30, False, eng) == {"ok": 30}
     assert mod.run_enc(7005, 30, eng).get("ok", 0) > 20
+
+
+def test_dryrun_parity_matrix(monkeypatch, oracle):
+    _install(monkeypatch, oracle)
+    import tests.test_gpu_parity as m
+    for case in m.CASES[::4]:
+        m.test_hip_matches_oracle(torch, oracle, case, False)
+    for name in ("simple_aggs_nullable", "baseline_count_avg", "multi_baseline_i64_2col", "compact_baseline_key32"):
+        m.test_device_reduce_matches_oracle(torch, oracle, name)
