@@ -396,6 +396,10 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
         q->target_null[i] = t.arg_f32 ? (int64_t)kNullFloatBits
                                       : t.arg_fp ? kNullDoubleBits : int_null_of(t.arg_type);
     }
+    // ResultSet::isNull looks at the TYPE first: a projected key of a NOT NULL column is never NULL,
+    // even when it holds the inline NULL pattern (ExecuteTest.cpp:4911 expects -2147483648 back from
+    // an `int not null` column).  EMPTY_KEY_64 can never be a key, so it stands for "no NULL pattern".
+    if (t.agg == MI355Q_PROJECT_KEY && !t.arg_nullable) q->target_null[i] = kEmptyKey64;
   }
   q->slot_count = slot;
   q->key_bytes = (grouped && !q->keyless) ? ((q->group_col_count * q->key_width + 7) & ~7) : 0;

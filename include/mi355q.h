@@ -302,7 +302,10 @@ typedef struct mi355q_qmd {
                                                     (SUM/MIN/MAX/AVG of a float column) */
   int64_t target_null[MI355Q_MAX_TARGETS];      /* bit pattern of the result type's NULL
                                                    (null_val_bit_pattern,
-                                                   ResultSetBufferAccessors.h:229) */
+                                                   ResultSetBufferAccessors.h:229); EMPTY_KEY_64
+                                                   (never a key) for the projection of a NOT
+                                                   NULL key column, which is never NULL
+                                                   (ResultSet::isNull tests the type first) */
   int64_t init_vals[MI355Q_MAX_SLOTS];          /* init_agg_val_vec
                                                    (OutputBufferInitialization.cpp:24) */
 } mi355q_qmd;

@@ -672,6 +672,9 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
         q.target_null[i] = t.arg_f32 ? flt_bits(kNullFloat)
                                      : t.arg_fp ? dbl_bits(kNullDouble) : int_null_of(t.arg_type);
     }
+    // ResultSet::isNull (ResultSetIteration.cpp) checks ti.get_notnull() first: the projection of a
+    // NOT NULL key column is never NULL whatever bits it holds; EMPTY_KEY_64 (never a key) = no pattern
+    if (t.agg == MI355Q_PROJECT_KEY && !t.arg_nullable) q.target_null[i] = kEmptyKey64;
   }
   q.slot_count = slot;
   // pick_target_compact_width (QueryMemoryDescriptor.cpp:748-840) -> setAllSlotsPaddedSize (:265):

@@ -162,6 +162,10 @@ QUERIES = [
      [key(0), key(1), key(2), agg("SUM", "dn"), agg("MAX", "dn"), agg("AVG", "dn")], [], ["x", "str", "z"]),
     ("SELECT x, SUM(dn), str, MAX(dn), z, AVG(dn), COUNT(*) FROM test GROUP BY z, x, str ORDER BY str, z, x;",
      [key(1), agg("SUM", "dn"), key(2), agg("MAX", "dn"), key(0), agg("AVG", "dn"), agg("COUNT")], [], ["z", "x", "str"]),
+    # a NOT NULL key column holding INT32_MIN (the inline NULL pattern) next to other keys (:2019, :2028, :5107)
+    ("SELECT x, COUNT(*) AS n FROM test GROUP BY x, ufd ORDER BY x, n;", [key(0), agg("COUNT")], [], ["x", "ufd"]),
+    ("SELECT COUNT(*) as val FROM test GROUP BY x, y, ufd ORDER BY val;", [agg("COUNT")], [], ["x", "y", "ufd"]),
+    ("SELECT ufd, COUNT(*) n FROM test GROUP BY ufd, str ORDER BY ufd, n;", [key(0), agg("COUNT")], [], ["ufd", "str"]),
     # NULL group keys, bigint / date / fixed-encoded keys
     ("SELECT ofd, COUNT(*), SUM(x) FROM test GROUP BY ofd;", [key(), agg("COUNT"), agg("SUM", "x")], [], ["ofd"]),
     ("SELECT u, COUNT(*) FROM test GROUP BY u;", [key(), agg("COUNT")], [], ["u"]),
