@@ -162,6 +162,27 @@ QUERIES = [
      [key(0), key(1), key(2), agg("SUM", "dn"), agg("MAX", "dn"), agg("AVG", "dn")], [], ["x", "str", "z"]),
     ("SELECT x, SUM(dn), str, MAX(dn), z, AVG(dn), COUNT(*) FROM test GROUP BY z, x, str ORDER BY str, z, x;",
      [key(1), agg("SUM", "dn"), key(2), agg("MAX", "dn"), key(0), agg("AVG", "dn"), agg("COUNT")], [], ["z", "x", "str"]),
+    ("SELECT x, AVG(ff) AS val FROM test GROUP BY x ORDER BY val;", [key(), agg("AVG", "ff")], [], ["x"]),          # :2022
+    ("SELECT COUNT(*) FROM test WHERE d = 2.2", [agg("COUNT")], [q("d", "=", 2.2)], []),                                # :2034
+    # :2041-2044 with the DATE literal '1999-09-08' written in seconds (SQLite holds the decoded seconds here)
+    ("SELECT COUNT(*) FROM test WHERE o1 > 936748800;", [agg("COUNT")], [q("o1", ">", 936748800)], []),
+    ("SELECT COUNT(*) FROM test WHERE o1 <= 936748800;", [agg("COUNT")], [q("o1", "<=", 936748800)], []),
+    ("SELECT COUNT(*) FROM test WHERE o1 = 936748800;", [agg("COUNT")], [q("o1", "=", 936748800)], []),
+    ("SELECT COUNT(*) FROM test WHERE o1 <> 936748800;", [agg("COUNT")], [q("o1", "<>", 936748800)], []),
+    # Select.FilterAndMultipleAggregation (:2577, :2581), Select.FilterAndGroupBy (:2822, :2843-2847, :2862),
+    # Select.GroupByPushDownFilterIntoExprRange (:5310-5319)
+    ("SELECT AVG(x), AVG(y) FROM test;", [agg("AVG", "x"), agg("AVG", "y")], [], []),
+    ("SELECT str, AVG(x), COUNT(*) as xx, COUNT(*) as countval FROM test GROUP BY str ORDER BY str;",
+     [key(), agg("AVG", "x"), agg("COUNT"), agg("COUNT")], [], ["str"]),
+    ("SELECT x, y, COUNT(*) FROM test GROUP BY x, y;", [key(0), key(1), agg("COUNT")], [], ["x", "y"]),
+    ("SELECT x, AVG(u), COUNT(*) AS n FROM test GROUP BY x ORDER BY n DESC;", [key(), agg("AVG", "u"), agg("COUNT")], [], ["x"]),
+    ("SELECT fx, COUNT(*) n FROM test GROUP BY fx ORDER BY n DESC, fx IS NULL DESC;", [key(), agg("COUNT")], [], ["fx"]),
+    ("SELECT x, COUNT(*) AS n FROM test WHERE x > 7 GROUP BY x ORDER BY x", [key(), agg("COUNT")], [q("x", ">", 7)], ["x"]),
+    ("SELECT y, COUNT(*) AS n FROM test WHERE y < 43 GROUP BY y ORDER BY n DESC", [key(), agg("COUNT")], [q("y", "<", 43)], ["y"]),
+    ("SELECT z, COUNT(*) AS n FROM test WHERE z <= 43 AND y > 10 GROUP BY z ORDER BY n DESC", [key(), agg("COUNT")],
+     [q("z", "<=", 43), q("y", ">", 10)], ["z"]),
+    ("SELECT t, SUM(y) AS sum_y FROM test WHERE t < 2000 GROUP BY t ORDER BY t DESC", [key(), agg("SUM", "y")], [q("t", "<", 2000)], ["t"]),
+    ("SELECT MAX(y) AS n FROM test WHERE x = 7 GROUP BY z ORDER BY n;", [agg("MAX", "y")], [q("x", "=", 7)], ["z"]),   # :3177 without HAVING MAX(x) > 5 (always true)
     # a NOT NULL key column holding INT32_MIN (the inline NULL pattern) next to other keys (:2019, :2028, :5107)
     ("SELECT x, COUNT(*) AS n FROM test GROUP BY x, ufd ORDER BY x, n;", [key(0), agg("COUNT")], [], ["x", "ufd"]),
     ("SELECT COUNT(*) as val FROM test GROUP BY x, y, ufd ORDER BY val;", [agg("COUNT")], [], ["x", "y", "ufd"]),
