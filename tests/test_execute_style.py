@@ -251,6 +251,10 @@ def test_reference_queries(oracle, qi, bigint_count):
 # ---- joins against the reference's `test_inner` (ExecuteTest.cpp:29719-29738: two rows)
 INNER = {"x": (I32, False, [7, -9]), "y": (I32, True, [43, 72]), "xx": (I16, True, [7, -9])}
 INNER_NAMES = list(INNER)
+# join_test (:9785-9799): str / dup_str as the dictionary ids of 'foo', 'bar', 'baz'; dup_str repeats 'foo'
+JOIN_TEST = {"x": (I32, False, [7, 8, 9]), "y": (I32, True, [43, None, None]), "str": (I32, False, [0, 1, 2]),
+             "dup_str": (I32, False, [0, 0, 1])}
+INNER_TABLES = {"test_inner": INNER, "join_test": JOIN_TEST}
 
 # (SQL text, targets [("agg", kind, column, table)], quals on test, group-by (test columns),
 #  join: (outer columns, inner columns, LEFT?))
@@ -270,18 +274,31 @@ JOIN_QUERIES = [
      [("agg", capi.COUNT, None, 0), ("agg", capi.SUM, "t", 0)], [], [], (["x", "y"], ["x", "y"], False)),
     ("SELECT a.y, COUNT(b.x), MAX(b.xx) FROM test a LEFT JOIN test_inner b ON a.x = b.x AND a.y = b.y GROUP BY a.y;",
      [("key", 0, None, 0), ("agg", capi.COUNT, "x", 1), ("agg", capi.MAX, "xx", 1)], [], ["y"], (["x", "y"], ["x", "y"], True)),
+    # one-to-many: join_test.dup_str holds 'foo' twice (:12859, :12867, :13482)
+    ("SELECT COUNT(*) FROM test a JOIN join_test b ON a.str = b.dup_str;",
+     [("agg", capi.COUNT, None, 0)], [], [], (["str"], ["dup_str"], False), "join_test"),
+    ("SELECT a.x FROM test a JOIN join_test b ON a.str = b.dup_str GROUP BY a.x ORDER BY a.x;",
+     [("key", 0, None, 0)], [], ["x"], (["str"], ["dup_str"], False), "join_test"),
+    ("SELECT COUNT(*) FROM test a LEFT JOIN join_test b ON a.str = b.dup_str;",
+     [("agg", capi.COUNT, None, 0)], [], [], (["str"], ["dup_str"], True), "join_test"),
+    ("SELECT a.str, COUNT(*), SUM(b.x), COUNT(b.y) FROM test a LEFT JOIN join_test b ON a.str = b.dup_str GROUP BY a.str;",
+     [("key", 0, None, 0), ("agg", capi.COUNT, None, 0), ("agg", capi.SUM, "x", 1), ("agg", capi.COUNT, "y", 1)], [], ["str"],
+     (["str"], ["dup_str"], True), "join_test"),
 ]
 
 
 def _join_case(descs, frags, db, spec):
-    sql, targets, quals, group, (outer, inner, left) = spec
+    sql, targets, quals, group, (outer, inner, left) = spec[:5]
+    tname = spec[5] if len(spec) > 5 else "test_inner"
+    INNER, INNER_NAMES = INNER_TABLES[tname], list(INNER_TABLES[tname])
     used = []
     for n in list(group) + list(outer) + [t[2] for t in targets if t[0] == "agg" and t[2] and t[3] == 0] + [c for c, _, _ in quals]:
         if n not in used:
             used.append(n)
     idx = {n: i for i, n in enumerate(used)}
     src = [NAMES.index(n) for n in used]
-    inner_arrays = {n: np.array(INNER[n][2], dtype=NP[INNER[n][0]]) for n in INNER_NAMES}
+    inner_arrays = {n: np.array([NULL[INNER[n][0]] if v is None else v for v in INNER[n][2]], dtype=NP[INNER[n][0]])
+                    for n in INNER_NAMES}
     inner_descs = [InputColDescriptor(INNER[n][0], INNER[n][1], col_range([inner_arrays[n]], INNER[n][0], INNER[n][1]))
                    for n in INNER_NAMES]
     tx = []
@@ -305,9 +322,10 @@ def _join_case(descs, frags, db, spec):
     case = Case("ref_join", ra, [[f[i] for i in src] for f in frags], [inner_arrays[n] for n in INNER_NAMES],
                 keys[0] if single else keys, ktypes[0] if single else ktypes, kr if single else ExpressionRange(),
                 False, join_one_to_many=1, join_key_nullable=knull[0] if single else knull)
-    if "test_inner" not in [r[0] for r in db.execute("SELECT name FROM sqlite_master")]:
-        db.execute("CREATE TABLE test_inner (" + ", ".join(INNER_NAMES) + ")")
-        db.executemany("INSERT INTO test_inner VALUES (?,?,?)", list(zip(*[INNER[n][2] for n in INNER_NAMES])))
+    if tname not in [r[0] for r in db.execute("SELECT name FROM sqlite_master")]:
+        db.execute(f"CREATE TABLE {tname} (" + ", ".join(INNER_NAMES) + ")")
+        db.executemany(f"INSERT INTO {tname} VALUES (" + ",".join("?" * len(INNER_NAMES)) + ")",
+                       list(zip(*[INNER[n][2] for n in INNER_NAMES])))
     return case, sql
 
 

@@ -39,12 +39,12 @@ def test_reference_queries_on_gpu(torch_cuda, oracle, qi):
                 assert a == b, (sql, t, w, g)
 
 
-@pytest.mark.parametrize("ji", range(7))
+@pytest.mark.parametrize("ji", range(11))
 def test_reference_join_queries_on_gpu(torch_cuda, oracle, ji):
     from heavydb_amd.executor import Executor
     from tests.test_execute_style import JOIN_QUERIES, _compare, _join_case
     from tests.test_gpu_parity import _build_join
-    assert len(JOIN_QUERIES) == 7
+    assert len(JOIN_QUERIES) == 11
     descs, frags, db = _table()
     case, sql = _join_case(descs, frags, db, JOIN_QUERIES[ji])
     frag_t, inner_t = _upload(torch_cuda, case)
