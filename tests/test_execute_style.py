@@ -169,6 +169,30 @@ QUERIES = [
     ("SELECT COUNT(*) FROM test WHERE o1 <= 936748800;", [agg("COUNT")], [q("o1", "<=", 936748800)], []),
     ("SELECT COUNT(*) FROM test WHERE o1 = 936748800;", [agg("COUNT")], [q("o1", "=", 936748800)], []),
     ("SELECT COUNT(*) FROM test WHERE o1 <> 936748800;", [agg("COUNT")], [q("o1", "<>", 936748800)], []),
+    # more of Select.FilterAndSimpleAggregation and friends (found by scanning ExecuteTest.cpp for single-step texts)
+    ("SELECT AVG(d) FROM test;", [agg("AVG", "d")], [], []),
+    ("SELECT AVG(f) FROM test;", [agg("AVG", "f")], [], []),
+    ("SELECT MIN(d) FROM test;", [agg("MIN", "d")], [], []),
+    ("SELECT MAX(d) FROM test;", [agg("MAX", "d")], [], []),
+    ("SELECT MIN(f) FROM test;", [agg("MIN", "f")], [], []),
+    ("SELECT MAX(f) FROM test;", [agg("MAX", "f")], [], []),
+    ("SELECT SUM(f) FROM test;", [agg("SUM", "f")], [], []),
+    ("SELECT SUM(x), AVG(y) FROM test;", [agg("SUM", "x"), agg("AVG", "y")], [], []),
+    ("SELECT COUNT(*) FROM test WHERE x > 8;", [agg("COUNT")], [q("x", ">", 8)], []),
+    ("SELECT SUM(x) FROM test WHERE x > 8;", [agg("SUM", "x")], [q("x", ">", 8)], []),          # no row qualifies: NULL
+    ("SELECT SUM(d) FROM test WHERE x > 8;", [agg("SUM", "d")], [q("x", ">", 8)], []),
+    ("SELECT SUM(f) FROM test WHERE x > 8;", [agg("SUM", "f")], [q("x", ">", 8)], []),
+    ("SELECT MIN(x) FROM test WHERE x <> 7 AND x <> 8;", [agg("MIN", "x")], [q("x", "<>", 7), q("x", "<>", 8)], []),
+    ("SELECT MIN(x) FROM test WHERE z <> 101 AND z <> 102;", [agg("MIN", "x")], [q("z", "<>", 101), q("z", "<>", 102)], []),
+    ("SELECT MIN(x) FROM test WHERE t <> 1001 AND t <> 1002;", [agg("MIN", "x")], [q("t", "<>", 1001), q("t", "<>", 1002)], []),
+    ("SELECT COUNT(*) FROM test WHERE f > 1.0 AND f < 1.2;", [agg("COUNT")], [q("f", ">", 1.0), q("f", "<", 1.2)], []),
+    ("SELECT COUNT(*) FROM test WHERE f > 1.101 AND f < 1.299;", [agg("COUNT")], [q("f", ">", 1.101), q("f", "<", 1.299)], []),
+    ("SELECT COUNT(*) FROM test WHERE f > 1.201 AND f < 1.4;", [agg("COUNT")], [q("f", ">", 1.201), q("f", "<", 1.4)], []),
+    ("SELECT COUNT(*) FROM test WHERE f > 1.0 AND f < 1.2 AND d > 2.0 AND d < 2.4;", [agg("COUNT")],
+     [q("f", ">", 1.0), q("f", "<", 1.2), q("d", ">", 2.0), q("d", "<", 2.4)], []),
+    ("SELECT x, COUNT(x) FROM test GROUP BY x;", [key(), agg("COUNT", "x")], [], ["x"]),
+    ("SELECT x, y, COUNT(x) FROM test GROUP BY x,y;", [key(0), key(1), agg("COUNT", "x")], [], ["x", "y"]),
+    ("SELECT X, COUNT(*) AS N FROM test GROUP BY teSt.x ORDER BY n DESC;", [key(), agg("COUNT")], [], ["x"]),
     # Select.FilterAndMultipleAggregation (:2577, :2581), Select.FilterAndGroupBy (:2822, :2843-2847, :2862),
     # Select.GroupByPushDownFilterIntoExprRange (:5310-5319)
     ("SELECT AVG(x), AVG(y) FROM test;", [agg("AVG", "x"), agg("AVG", "y")], [], []),
