@@ -520,6 +520,9 @@ int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t d
     return MI355Q_ERR_INVALID_PLAN;
   if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return MI355Q_ERR_UNSUPPORTED;
   if (k > topk_max_k()) return MI355Q_ERR_UNSUPPORTED;
+  // ordering by a floating-point KEY projection (read from the key column) is not built
+  if (r->qmd.target_agg[target_idx] == MI355Q_PROJECT_KEY && r->qmd.target_is_fp[target_idx])
+    return MI355Q_ERR_UNSUPPORTED;
   if (r->qmd.output_columnar) {  // the rows come out row-wise (row_size bytes each)
     RowTwin t;
     if (int32_t e = make_row_twin(r, (hipStream_t)stream, &t)) return e;
@@ -587,6 +590,10 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
         const int ki = q.target_key_idx[t];
         ival[o] = q.key_width == 4 ? (int64_t)((const int32_t*)row)[ki] : row[ki];
         is_null[o] = ival[o] == q.target_null[t];
+        if (q.target_is_fp[t]) {  // floating-point key: the quad holds double bits (FLOAT widened)
+          dval[o] = bits_dbl(ival[o]);
+          ival[o] = 0;
+        }
         continue;
       }
       // compact layouts hold 32-bit slots (read_int_from_buff with the slot's width)
@@ -635,6 +642,8 @@ constexpr int32_t kNotTaken = INT32_MIN + 7;  // internal: "use the ordinary pat
 
 bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, PackSpec* ps) {
   if (p.join_outer_col >= 0 || p.n_group_cols < 1) return false;
+  for (int g = 0; g < p.n_group_cols; ++g)  // floating-point keys have no integer range to pack
+    if (type_is_fp(p.cols[p.group_cols[g]].type) || type_is_f32(p.cols[p.group_cols[g]].type)) return false;
   if (p.n_cols >= MI355Q_MAX_COLS) return false;  // the packed column is appended to the inputs
   std::memset(ps, 0, sizeof(*ps));
   ps->n = p.n_group_cols;

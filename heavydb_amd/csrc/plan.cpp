@@ -257,15 +257,21 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   for (int g = 0; g < p.n_group_cols; ++g) {
     const int gc = p.group_cols[g];
     if (gc < 0 || gc >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
-    if (type_is_fp(p.cols[gc].type) || type_is_f32(p.cols[gc].type)) return MI355Q_ERR_UNSUPPORTED;  // fp keys
   }
+  // floating-point group keys: always the baseline layout (getColRangeInfo's Float / Double cases,
+  // GroupByAndAggregate.cpp:199-207), 8-byte components (pick_baseline_key_component_width: "no
+  // compaction for floating point yet"); the key is the bit pattern of the value cast to double
+  // (groupByColumnCodegen: castToTypeIn(group_key, 64) + bitcast, IRCodegen.cpp:1505-1507)
+  bool fp_key = false;
+  for (int g = 0; g < p.n_group_cols; ++g)
+    fp_key = fp_key || type_is_fp(p.cols[p.group_cols[g]].type) || type_is_f32(p.cols[p.group_cols[g]].type);
   const int64_t baseline_entries =
       p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess : 16384;
 
   if (p.n_group_cols == 1) {
     const int gc = p.group_cols[0];
     const mi355q_range& r = p.col_ranges[gc];
-    bool use_baseline = !r.valid || r.min > r.max;
+    bool use_baseline = fp_key || !r.valid || r.min > r.max;
     if (!use_baseline) {
       const int64_t col_count = p.n_group_cols + p.n_targets;
       const int64_t max_entries = kMaxBufferSize / (col_count * (int64_t)sizeof(int64_t));
@@ -295,7 +301,7 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
     // getColRangeInfo, groupby_exprs.size() != 1: perfect hash iff every column has an
     // integer range and the product of the bucketed cardinalities is within
     // g_baseline_groupby_threshold; zero / overflow -> baseline
-    bool perfect = true;
+    bool perfect = !fp_key;
     __int128 card = 1;
     for (int g = 0; g < p.n_group_cols && perfect; ++g) {
       const mi355q_range& r = p.col_ranges[p.group_cols[g]];
@@ -343,8 +349,8 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
     if (q->entry_count > (int64_t)UINT32_MAX) return MI355Q_ERR_UNSUPPORTED;  // h is uint32
     // pick_baseline_key_width: 4 only if every component's range is a valid int32 range;
     // "output_columnar ? 8 : pick_baseline_key_width(...)" (QueryMemoryDescriptor.cpp:386-388)
-    int kw = p.output_columnar_hint ? 8 : 4;
-    for (int g = 0; g < p.n_group_cols && !p.output_columnar_hint; ++g) {
+    int kw = (p.output_columnar_hint || fp_key) ? 8 : 4;
+    for (int g = 0; g < p.n_group_cols && kw == 4; ++g) {
       const int gc = p.group_cols[g];
       const mi355q_range& r = p.col_ranges[gc];
       const int logical_w = plain_width(tc_logical(col_type_code(p.cols[gc])));
@@ -399,6 +405,8 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
     // ResultSet::isNull looks at the TYPE first: a projected key of a NOT NULL column is never NULL,
     // even when it holds the inline NULL pattern (ExecuteTest.cpp:4911 expects -2147483648 back from
     // an `int not null` column).  EMPTY_KEY_64 can never be a key, so it stands for "no NULL pattern".
+    // a FLOAT key sits in its key column as the double it was widened to: so does its NULL (FLT_MIN)
+    if (t.agg == MI355Q_PROJECT_KEY && t.arg_f32) q->target_null[i] = dbl_bits((double)bits_flt((int32_t)kNullFloatBits));
     if (t.agg == MI355Q_PROJECT_KEY && !t.arg_nullable) q->target_null[i] = kEmptyKey64;
   }
   q->slot_count = slot;
@@ -410,7 +418,7 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   for (int i = 0; i < p.n_targets && compact; ++i) {
     const ResolvedTarget& t = ts[i];
     if (t.agg == MI355Q_COUNT && t.col < 0) continue;
-    if (t.agg == MI355Q_PROJECT_KEY && plain_width(tc_logical(t.arg_type)) <= 4) continue;
+    if (t.agg == MI355Q_PROJECT_KEY && plain_width(tc_logical(t.arg_type)) <= 4 && !t.arg_f32) continue;
     compact = false;
   }
   q->slot_width = compact ? 4 : 8;

@@ -865,7 +865,11 @@ MQ_FN int32_t process_row(const DevPlan& p, const int8_t* const* cols, int64_t p
     slots = nongrouped_slots;
   } else {
     for (int g = 0; g < p.n_group; ++g) {
-      keys[g] = decode_int(cols[p.group_cols[g]], p.group_types[g], pos);
+      // DOUBLE keys: decode_int's 8-byte load IS the bit pattern; FLOAT keys are widened to double
+      // first (castToTypeIn(group_key, 64) then bitcast, IRCodegen.cpp:1505-1507)
+      keys[g] = type_is_f32(p.group_types[g])
+                    ? dbl_bits((double)*(const float*)(cols[p.group_cols[g]] + pos * 4))
+                    : decode_int(cols[p.group_cols[g]], p.group_types[g], pos);
     }
     if (p.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
       // entry index: single column key - min (get_group_value_fast, GroupByRuntime.cpp:208-223);

@@ -537,18 +537,19 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   q.group_col_count = p.n_group_cols;
   q.idx_target_as_key = -1;
   q.key_width = 8;
-  for (int g = 0; g < p.n_group_cols; ++g) {
-    if (type_is_fp(p.cols[p.group_cols[g]].type) || type_is_f32(p.cols[p.group_cols[g]].type))
-      return MI355Q_ERR_UNSUPPORTED;
-  }
-  bool baseline = false;
+  // getColRangeInfo, ExpressionRangeType::Float / Double (GroupByAndAggregate.cpp:199-207): a
+  // floating-point group key always takes the baseline layout
+  bool fp_key = false;
+  for (int g = 0; g < p.n_group_cols; ++g)
+    fp_key = fp_key || type_is_fp(p.cols[p.group_cols[g]].type) || type_is_f32(p.cols[p.group_cols[g]].type);
+  bool baseline = fp_key;
   if (!is_group_by) {
     q.desc_type = MI355Q_NON_GROUPED_AGGREGATE;  // QueryMemoryDescriptor.cpp:271-300
     q.entry_count = 1;
   } else if (p.n_group_cols == 1) {
     const auto& r = p.col_ranges[p.group_cols[0]];
     // getColRangeInfo, single-column case (GroupByAndAggregate.cpp:295-349)
-    if (!r.valid || r.min > r.max) {
+    if (fp_key || !r.valid || r.min > r.max) {
       baseline = true;
     } else {
       const int64_t col_count = p.n_group_cols + p.n_targets;
@@ -624,7 +625,8 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
       const auto& gcd = p.cols[p.group_cols[g]];
       const auto& r = p.col_ranges[p.group_cols[g]];
       int w = 8;
-      if (r.valid) {
+      // pick_baseline_key_component_width: "No compaction for floating point yet" -> 8
+      if (r.valid && !type_is_fp(gcd.type) && !type_is_f32(gcd.type)) {
         if (type_width(logical_type_of(gcd)) == 8 && r.has_nulls) {
           w = 8;
         } else {
@@ -674,6 +676,9 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
     }
     // ResultSet::isNull (ResultSetIteration.cpp) checks ti.get_notnull() first: the projection of a
     // NOT NULL key column is never NULL whatever bits it holds; EMPTY_KEY_64 (never a key) = no pattern
+    // the key column holds a FLOAT key as the double it was cast to (castToTypeIn(group_key, 64)), its
+    // NULL (FLT_MIN) included
+    if (t.agg == MI355Q_PROJECT_KEY && t.arg_f32) q.target_null[i] = dbl_bits((double)kNullFloat);
     if (t.agg == MI355Q_PROJECT_KEY && !t.arg_nullable) q.target_null[i] = kEmptyKey64;
   }
   q.slot_count = slot;
@@ -685,7 +690,7 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
                  (uint64_t)std::max<int64_t>(p.num_tuples, 0) <= (uint64_t)UINT32_MAX;
   for (const auto& t : ts) {
     if (t.agg == MI355Q_COUNT && t.col < 0) continue;
-    if (t.agg == MI355Q_PROJECT_KEY && type_width(t.arg_type) <= 4) continue;
+    if (t.agg == MI355Q_PROJECT_KEY && type_width(t.arg_type) <= 4 && !t.arg_f32) continue;  // is_int_and_no_bigger_than
     compact = false;
   }
   q.slot_width = compact ? 4 : 8;
@@ -1341,7 +1346,11 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
       slots = buf;  // one entry: every 8-byte slot column holds one value, same bytes as a row
     } else {
       for (int g = 0; g < ng; ++g) {
-        keys[g] = decode_col(p.cols[p.group_cols[g]], cols[p.group_cols[g]], pos);
+        const auto& gcd0 = p.cols[p.group_cols[g]];
+        // groupByColumnCodegen: a floating-point key is cast to double and bit-cast to i64
+        keys[g] = type_is_f32(gcd0.type) ? dbl_bits((double)decode_flt(cols[p.group_cols[g]], pos))
+                  : type_is_fp(gcd0.type) ? dbl_bits(decode_dbl(cols[p.group_cols[g]], pos))
+                                          : decode_col(gcd0, cols[p.group_cols[g]], pos);
       }
       if (q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
         // groupByColumnCodegen (IRCodegen.cpp:1413-1512): where the column's range has nulls,
@@ -2004,6 +2013,10 @@ ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64
         const int ki = q->target_key_idx[t];
         ival[o] = q->key_width == 4 ? (int64_t) reinterpret_cast<const int32_t*>(row)[ki] : row[ki];
         is_null[o] = ival[o] == q->target_null[t];
+        if (q->target_is_fp[t]) {  // getTargetValueFromBufferRowwise on an 8-byte fp key: a double
+          dval[o] = bits_dbl(ival[o]);
+          ival[o] = 0;
+        }
         continue;
       }
       const int64_t v = q->slot_width == 4 ? (int64_t) reinterpret_cast<const int32_t*>(row + kq)[s] : row[kq + s];

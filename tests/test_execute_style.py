@@ -193,6 +193,14 @@ QUERIES = [
     ("SELECT x, COUNT(x) FROM test GROUP BY x;", [key(), agg("COUNT", "x")], [], ["x"]),
     ("SELECT x, y, COUNT(x) FROM test GROUP BY x,y;", [key(0), key(1), agg("COUNT", "x")], [], ["x", "y"]),
     ("SELECT X, COUNT(*) AS N FROM test GROUP BY teSt.x ORDER BY n DESC;", [key(), agg("COUNT")], [], ["x"]),
+    # floating-point group keys (always the baseline layout; the key is the bit pattern of the value as a double)
+    ("SELECT COUNT(*) AS n FROM test GROUP BY d ORDER BY n;", [agg("COUNT")], [], ["d"]),
+    ("SELECT COUNT(*) AS n FROM test GROUP BY f ORDER BY n;", [agg("COUNT")], [], ["f"]),
+    ("SELECT d, COUNT(*), SUM(x) FROM test GROUP BY d;", [key(), agg("COUNT"), agg("SUM", "x")], [], ["d"]),
+    ("SELECT f, COUNT(*), MIN(z) FROM test GROUP BY f;", [key(), agg("COUNT"), agg("MIN", "z")], [], ["f"]),
+    ("SELECT fn, COUNT(*) FROM test GROUP BY fn;", [key(), agg("COUNT")], [], ["fn"]),                 # NULL FLOAT key
+    ("SELECT dn, AVG(y), COUNT(*) FROM test GROUP BY dn;", [key(), agg("AVG", "y"), agg("COUNT")], [], ["dn"]),   # NULL DOUBLE key
+    ("SELECT x, dn, f, COUNT(*) FROM test GROUP BY x, dn, f;", [key(0), key(1), key(2), agg("COUNT")], [], ["x", "dn", "f"]),
     # Select.FilterAndMultipleAggregation (:2577, :2581), Select.FilterAndGroupBy (:2822, :2843-2847, :2862),
     # Select.GroupByPushDownFilterIntoExprRange (:5310-5319)
     ("SELECT AVG(x), AVG(y) FROM test;", [agg("AVG", "x"), agg("AVG", "y")], [], []),

@@ -172,6 +172,7 @@ def test_dryrun_boundary(monkeypatch, oracle):
     assert sum(v for k, v in mod.run_joins(7003, 30, eng).items() if k.startswith("ok_")) > 20
     assert mod.run_fp(7004, 30, False, eng) == {"ok": 30}
     assert mod.run_enc(7005, 30, eng).get("ok", 0) > 20
+    assert mod.run_fpkeys(7006, 30, eng).get("ok_1", 0) > 15
 
 
 def test_dryrun_parity_matrix(monkeypatch, oracle):

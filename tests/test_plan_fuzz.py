@@ -373,6 +373,8 @@ def test_boundary_values_agree(oracle):
         for k, v in mod.run_keys(seed, 150).items():
             keys[k] = keys.get(k, 0) + v
     assert mod.run_fp(401, 300) == {"ok": 300}
+    fpk = mod.run_fpkeys(601, 200)
+    assert fpk.get("ok_1", 0) > 120 and set(fpk) <= {"ok_0", "ok_1", "err", "keyless-null-aware_0"}, fpk
     enc = mod.run_enc(501, 200)
     assert enc.get("ok", 0) > 170 and set(enc) <= {"ok", "rejected", "keyless-null-aware"}, enc
     joins = mod.run_joins(301, 200)

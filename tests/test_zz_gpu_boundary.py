@@ -66,3 +66,9 @@ def test_boundary_encoded_columns_on_gpu(torch_cuda, oracle):
     mod = _tool()
     t = mod.run_enc(7005, 120, _hip_engine(torch_cuda))
     assert t.get("ok", 0) > 90 and set(t) <= {"ok", "rejected", "keyless-null-aware"}, t
+
+
+def test_floating_point_group_keys_on_gpu(torch_cuda, oracle):
+    mod = _tool()
+    t = mod.run_fpkeys(7006, 120, _hip_engine(torch_cuda))
+    assert t.get("ok_1", 0) > 70 and set(t) <= {"ok_0", "ok_1", "err", "keyless-null-aware_0"}, t

@@ -293,7 +293,56 @@ def run_enc(seed, iters, engine=None):
     return tally
 
 
+def run_fpkeys(seed, iters, engine=None):
+    """floating-point group keys (DOUBLE / FLOAT, nullable or not, alone or next to integer keys): always
+    the baseline layout with the value's double bit pattern as the key; product vs oracle vs SQLite.
+    (No signed-zero pairs and no NaN: bit patterns differ where SQL values compare equal.)"""
+    from tests.test_sqlite_semantics import _check_case
+    rng = np.random.default_rng(seed); tally = {}
+    for it in range(iters):
+        n = int(rng.integers(1, 150))
+        cols, descs, group = [], [], []
+        for g in range(int(rng.integers(1, 4))):
+            kind = int(rng.integers(0, 3))
+            nullable = bool(rng.integers(0, 2))
+            if kind == 2:
+                a = rng.integers(-3, 4, n).astype(np.int32)
+                if nullable: a[rng.random(n) < 0.2] = -2**31
+                d = InputColDescriptor(capi.INT32, nullable, col_range([a], capi.INT32, nullable))
+            else:
+                dt = np.float64 if kind == 0 else np.float32
+                fi = np.finfo(dt)
+                pool = np.array([np.inf, -np.inf, 0.0, 1.5, -2.25, fi.max, -fi.max, fi.eps, 2 * fi.tiny, 1e10, -1e-10], dtype=dt)
+                pick = pool[rng.integers(0, len(pool), int(rng.integers(1, 6)))]
+                a = pick[rng.integers(0, len(pick), n)].astype(dt)
+                if nullable: a[rng.random(n) < 0.2] = fi.tiny
+                d = InputColDescriptor(capi.DOUBLE if kind == 0 else capi.FLOAT, nullable, V(False))
+            cols.append(a); descs.append(d); group.append(g)
+        val = rng.integers(-100, 100, n).astype(np.int64)
+        cols.append(val); descs.append(InputColDescriptor(capi.INT64, False, V(True, -100, 99)))
+        targets = [TargetExpr(capi.PROJECT_KEY, g) for g in group if rng.integers(0, 3)] + [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, len(group))]
+        ra = RelAlgExecutionUnit(descs, targets, [], group, max_groups_buffer_entry_guess=int(rng.choice([64, 1024])),
+                                 output_columnar_hint=int(rng.integers(0, 2)), num_tuples=n)
+        case = Case("fpk", ra, [[c[:n // 2] for c in cols], [c[n // 2:] for c in cols]])
+        plan = ra.to_plan()
+        q, want, code = oracle.execute(plan, case.frags, n_threads=2)
+        eq, got, ecode = (engine or _emu_execute)(case, plan, None)
+        assert (code == 0) == (ecode == 0), (seed, it, code, ecode)
+        if code: tally["err"] = tally.get("err", 0) + 1; continue
+        qmd_equal(q, eq)
+        if q.output_columnar:
+            from tests.helpers import columnar_to_rows, rowwise_qmd
+            compare_buffers(rowwise_qmd(q), columnar_to_rows(q, want), columnar_to_rows(q, got), 1e-9)
+        else:
+            compare_buffers(q, want, got, 1e-9)
+        case.ra.output_columnar_hint = 0
+        r = _check_case(oracle, case)
+        k = f"{r}_{q.desc_type}"
+        tally[k] = tally.get(k, 0) + 1
+    return tally
+
+
 if __name__ == "__main__":
     print(sys.argv[1], run(int(sys.argv[1]), int(sys.argv[2])), run_keys(int(sys.argv[1]), int(sys.argv[2])),
           run_joins(int(sys.argv[1]), int(sys.argv[2])), run_fp(int(sys.argv[1]), int(sys.argv[2])),
-          run_enc(int(sys.argv[1]), int(sys.argv[2])))
+          run_enc(int(sys.argv[1]), int(sys.argv[2])), run_fpkeys(int(sys.argv[1]), int(sys.argv[2])))
