@@ -66,7 +66,11 @@ def test_invalid_plans_are_rejected():
     ra = RelAlgExecutionUnit([InputColDescriptor(capi.INT32)], [TargetExpr(capi.PROJECT_KEY)])
     assert lib.mi355q_qmd_init(C.byref(ra.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN
     ra = RelAlgExecutionUnit([InputColDescriptor(capi.DOUBLE)], [TargetExpr(capi.COUNT)], groupby_exprs=[0])
-    assert lib.mi355q_qmd_init(C.byref(ra.to_plan()), C.byref(q)) == capi.ERR_UNSUPPORTED
+    # a floating-point group key is the baseline layout with an 8-byte key, whatever the range says
+    assert lib.mi355q_qmd_init(C.byref(ra.to_plan()), C.byref(q)) == 0
+    assert (q.desc_type, q.key_width) == (capi.GROUP_BY_BASELINE_HASH, 8)
+    ra = RelAlgExecutionUnit([InputColDescriptor(capi.INT32)], [TargetExpr(capi.COUNT)], groupby_exprs=[0], output_columnar_hint=9)
+    assert lib.mi355q_qmd_init(C.byref(ra.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN
     assert lib.mi355q_error_string(3) == b"Out of Slots"
 
 
