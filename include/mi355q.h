@@ -199,7 +199,9 @@ typedef struct mi355q_plan {
   mi355q_qual quals[MI355Q_MAX_QUALS];
 
   int32_t n_group_cols; /* 0 = non-grouped aggregate; 1..MI355Q_MAX_GROUP_COLS group-by
-                           columns (integer typed, any mix of widths) */
+                           columns: integers of any mix of widths, or DOUBLE / FLOAT
+                           (floating-point keys always take the baseline layout; the key is the
+                           bit pattern of the value widened to double) */
   int32_t group_cols[MI355Q_MAX_GROUP_COLS];
 
   int32_t n_targets;
