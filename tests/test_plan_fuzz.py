@@ -7,6 +7,7 @@ g_bigint_count, tuple counts either side of UINT32_MAX."""
 import ctypes as C
 
 import numpy as np
+import pytest
 
 from heavydb_amd import capi
 from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
@@ -380,3 +381,30 @@ def test_boundary_values_agree(oracle):
     joins = mod.run_joins(301, 200)
     assert all(joins.get(f"ok_ht{h}", 0) > 5 for h in range(4)) and sum(joins.values()) == 200, joins
     assert keys.get("ok_0_w8", 0) > 20 and keys.get("ok_1_w8", 0) > 100 and keys.get("ok_1_w4", 0) > 3, keys
+
+
+def test_compact_baseline_rows_with_several_slots(oracle):
+    """SELECT COUNT(*), COUNT(*) ... GROUP BY key: two 4-byte slots share one quad of a baseline row
+    (found by tools/soak_fuzz.py as a limitation of compare_buffers, not of the product)."""
+    from tests.cases import Case
+    from tests.helpers import compare_buffers, qmd_equal
+    from tests.test_rowlogic_emu import _emu_execute
+    rng = np.random.default_rng(3)
+    key = (rng.integers(0, 300, 5000) * 1000003).astype(np.int64)
+    ra = RelAlgExecutionUnit([InputColDescriptor(capi.INT64, False, ExpressionRange(False))],
+                             [TargetExpr(capi.COUNT), TargetExpr(capi.COUNT), TargetExpr(capi.COUNT)], [], [0],
+                             max_groups_buffer_entry_guess=1024, num_tuples=5000)
+    case = Case("c", ra, [[key[:2500]], [key[2500:]]])
+    plan = ra.to_plan()
+    q, want, code = oracle.execute(plan, case.frags, n_threads=2)
+    eq, got, ecode = _emu_execute(case, plan, None)
+    assert code == 0 and ecode == 0 and q.slot_width == 4 and q.slot_count == 3 and q.row_size == 24
+    qmd_equal(q, eq)
+    compare_buffers(q, want, got)
+    iv, _, _ = oracle.fetch_rows(q, got)
+    assert iv.shape == (300, 3) and (iv[:, 0] == iv[:, 1]).all() and iv[:, 0].sum() == 5000
+    bad = got.copy()
+    live = np.nonzero(bad[:, 0] != 2**63 - 1)[0]
+    bad[live[0], 2] += 1                      # the third COUNT, alone in its quad's low half
+    with pytest.raises(AssertionError):
+        compare_buffers(q, want, bad)
