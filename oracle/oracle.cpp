@@ -1932,13 +1932,13 @@ ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
 
   std::vector<std::vector<int64_t>> bufs(n_threads);
   std::vector<int32_t> errs(n_threads, 0);
-  std::atomic<int> next_frag{0};
   auto worker = [&](int tid) {
     int64_t* buf = tid == 0 ? out_buf : (bufs[tid].resize(quads), bufs[tid].data());
     init_buffer(c.qmd, buf);
-    for (;;) {
-      const int f = next_frag.fetch_add(1);
-      if (f >= in->n_frags) break;
+    // fragments are dealt to the kernels statically (f = tid, tid + n_threads, ...): which partial
+    // buffer a row lands in — and with it every order-dependent corner of the reference's reduce,
+    // e.g. a keyless all-NULL group that looks empty — is the same on every run
+    for (int f = tid; f < in->n_frags; f += n_threads) {
       const int8_t* const* cols =
           reinterpret_cast<const int8_t* const*>(in->col_buffers + (size_t)f * plan->n_cols);
       const int32_t e = run_fragment(c, cols, in->num_rows[f], buf);

@@ -235,12 +235,29 @@ class OracleJoin:
             pass
 
 
+def keyless_key_is_null_aware(q: capi.QMD) -> bool:
+    """get_keyless_info only guards MAX against NULL-aware key targets (GroupByAndAggregate.cpp:489-648)."""
+    if not q.keyless:
+        return False
+    for t in range(q.n_targets):
+        if q.target_slot[t] in (q.idx_target_as_key, q.idx_target_as_key - 1) and q.target_skip_null[t]:
+            if q.target_slot[t] == q.idx_target_as_key or q.target_agg[t] == capi.AVG:
+                return True
+    return False
+
+
 def execute(plan: capi.Plan, frag_cols: Sequence[Sequence[np.ndarray]],
             inner_cols: Sequence[np.ndarray] = (), join: Optional[OracleJoin] = None,
             n_threads: int = 1) -> Tuple[capi.QMD, np.ndarray, int]:
     """Run the step on host numpy columns.  Returns (qmd, buffer[entry_count,row_quads],
     code)."""
     q = qmd_init(plan)
+    if n_threads > 1 and keyless_key_is_null_aware(q):
+        # a keyless layout whose "key" slot is a NULL-aware aggregate: an all-NULL group of a partial
+        # buffer looks empty and ResultSetStorage::reduce drops its other slots (reference behaviour,
+        # DESIGN section 2) — the merged result depends on how rows were dealt to kernels.  One kernel is
+        # the reading that does not.
+        n_threads = 1
     n_frags = len(frag_cols)
     n_cols = plan.n_cols
     flat = (C.c_void_p * max(1, n_frags * n_cols))()
