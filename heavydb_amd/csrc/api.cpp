@@ -445,6 +445,19 @@ int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_r
   }
   if (a.desc_type != MI355Q_GROUP_BY_BASELINE_HASH && a.entry_count != b.entry_count)
     return MI355Q_ERR_INVALID_PLAN;
+  // same geometry is not enough: the slots are merged with THIS result's aggregate ops, so the
+  // two descriptors must agree on what every slot holds (ResultSetStorage::reduce CHECKs the
+  // descriptors' compatibility the same way, ResultSetReduction.cpp:203-215)
+  if (a.n_targets != b.n_targets || a.slot_width != b.slot_width || a.idx_target_as_key != b.idx_target_as_key)
+    return MI355Q_ERR_INVALID_PLAN;
+  for (int t = 0; t < a.n_targets && t < MI355Q_MAX_TARGETS; ++t) {
+    if (a.target_agg[t] != b.target_agg[t] || a.target_slot[t] != b.target_slot[t] ||
+        a.target_skip_null[t] != b.target_skip_null[t] || a.target_arg_is_fp[t] != b.target_arg_is_fp[t] ||
+        a.target_arg_is_f32[t] != b.target_arg_is_f32[t])
+      return MI355Q_ERR_INVALID_PLAN;
+  }
+  for (int j = 0; j < a.slot_count && j < MI355Q_MAX_SLOTS; ++j)
+    if (a.init_vals[j] != b.init_vals[j]) return MI355Q_ERR_INVALID_PLAN;
   if (a.output_columnar) {
     RowTwin ta, tb;
     if (int32_t e = make_row_twin(this_rs, (hipStream_t)stream, &ta)) return e;
@@ -729,8 +742,13 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     p2.col_ranges[nc].min = 0;
     p2.col_ranges[nc].max = q.entry_count - 1;
   }
+  // the temporary table always has 8-byte slots: k_unpack_emit / k_unpack_perfect read it quad by
+  // quad, and a multi-pass run reduces it with 64-bit adds (pick_target_compact_width would narrow a
+  // COUNT(*)-only derived plan to 4-byte slots)
+  p2.bigint_count = 1;
   mi355q_qmd q2;
   if (qmd_init(p2, &q2) != MI355Q_OK) return kNotTaken;
+  if (q2.slot_width != 8 || q2.row_size % 8 != 0) return kNotTaken;
   if (ps.mode == 2) {
     if (q2.desc_type != MI355Q_GROUP_BY_PERFECT_HASH || q2.entry_count != q.entry_count) return kNotTaken;
     ps.tmp_idx_target = q2.idx_target_as_key;
@@ -860,6 +878,10 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     const int32_t e2 = mi355q_execute(&p2, &in2, &o2, &r2, &rep2);
     if (e2 == MI355Q_ERR_OUT_OF_GPU_MEM || e2 == MI355Q_ERR_UNSUPPORTED) return kNotTaken;
     if (e2) return e2;  // incl. < 0: out of slots -> the caller grows the table
+    struct R2Guard {
+      mi355q_result* r;
+      ~R2Guard() { if (r) mi355q_result_free(r); }
+    } r2g{r2};
     if (pass > 0) {
       HIP_TRY(launch_reduce(r2->dplan, q2.idx_target_as_key, tmp_a, tmp_b, q2.entry_count, d_err, s));
     }
@@ -870,7 +892,6 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     acc.kernel_ms += rep2.kernel_ms;
     acc.n_launches += rep2.n_launches;
     acc.spilled_rows += rep2.spilled_rows;
-    mi355q_result_free(r2);
     f = f1;
     ++pass;
   }

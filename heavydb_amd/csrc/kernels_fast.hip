@@ -332,6 +332,9 @@ bool perfect_lds_eligible(const DevPlan& p, const FragView& fv) {
   if (p.desc_type != MI355Q_GROUP_BY_PERFECT_HASH) return false;
   // plain INT / BIGINT keys, or a NOT NULL kENCODING_FIXED(32) key (the same 4-byte load)
   if (perfect_key_storage(p) == 0) return false;
+  // a bucketed range indexes by (key - min) / bucket (get_group_value_fast); this kernel's index
+  // is key - min, so bucketed keys stay with the row kernel
+  if (p.group_bucket[0] != 0) return false;
   if (p.entry_count * p.row_quad * 8 > kPerfectLdsMaxBytes) return false;
   FastShape s;
   return grouped_fast_shape(p, fv, &s) && !s.sp.val_nullable;

@@ -803,7 +803,8 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
                                                                 const uint32_t* __restrict__ cnt,
                                                                 PartSlots ps, TableArgs tab, SpillList sl,
                                                                 int merge, uint32_t chunk_records_max,
-                                                                unsigned long long* __restrict__ dbg) {
+                                                                unsigned long long* __restrict__ dbg,
+                                                                uint32_t* __restrict__ prog, int pair_window) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int64_t* const lkeys = (int64_t*)smem_raw;
   uint32_t* bitmap = (uint32_t*)(smem_raw + g.lds_table_bytes);  // [(S2 + 31) / 32]
@@ -817,6 +818,15 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
   // sub-ranges of one partition run on workgroups of the same XCD (block id mod 8) at the same
   // time, so the second reader of a run is served by that XCD's L2
   const bool paired = R > 1 && G % (8 * R) == 0;
+  // Pair pacing (a speed hint, never a correctness condition): the two sub-range units of a
+  // partition read the SAME runs, so whichever reads second can be served by the XCD's L2 / the
+  // Infinity Cache instead of HBM — if it is not too far behind.  Every wave counts the runs it has
+  // finished in prog[workgroup]; before a wave starts a round of runs it waits (bounded) until its
+  // partner workgroup is within `pair_window` rounds.  A partner that never shows up only costs
+  // the bounded wait once: the wave stops pacing.
+  const bool pacing = paired && R == 2 && pair_window > 0 && prog != nullptr;
+  const uint32_t partner = blockIdx.x ^ 8u;
+  bool pace_off = false;
 
   uint32_t lo = 0, n_slots = 0;  // this unit's home range [lo, lo + n_slots)
   // MI355Q_TRACE: lane 0 of every workgroup accumulates the cycles of each phase
@@ -954,9 +964,29 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       mark(1);
       // one wave per run; four 16-byte record loads per lane, the next four already in flight
       const int wave = t >> 6, lane = t & 63;
-      for (int b = wave; b < g.B; b += kPartBlock / 64) {
+      constexpr int kWaves = kPartBlock / 64;
+      const uint32_t rounds_per_unit = (uint32_t)(g.B + kWaves - 1) / kWaves;
+      for (int b = wave; b < g.B; b += kWaves) {
+        if (pacing && !pace_off) {
+          const uint32_t round = (uint32_t)it * rounds_per_unit + (uint32_t)(b / kWaves);
+          if (round >= (uint32_t)pair_window) {
+            // runs the partner must have finished: one of round (round - window) at least
+            const uint32_t need = (round - (uint32_t)pair_window) * kWaves + 1;
+            uint32_t spins = 0;
+            while (__hip_atomic_load(prog + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+              __builtin_amdgcn_s_sleep(8);
+              if (++spins > 4096) {  // ~1 ms: the partner is not running beside us
+                pace_off = true;
+                break;
+              }
+            }
+          }
+        }
         const uint32_t n = lcnt[b];
-        if (!n) continue;
+        if (!n) {
+          if (pacing && lane == 0) atomicAdd(prog + blockIdx.x, 1u);
+          continue;
+        }
         const Rec* run = scratch + ((size_t)p * g.B + b) * g.cap;
         const uint32_t last = n - 1;
         auto at = [&](uint32_t i) -> uint32_t { return i < last ? i : last; };  // clamped: always loadable
@@ -967,7 +997,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
           insert4(c0, c1, c2, c3, i < n ? (n - i + 63) / 64 : 0u);
           c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
+        if (pacing && lane == 0) atomicAdd(prog + blockIdx.x, 1u);
       }
+    } else if (pacing && t == 0) {
+      atomicAdd(prog + blockIdx.x, (uint32_t)g.B);  // an empty unit still counts its rounds
     }
     __syncthreads();
     mark(2);
@@ -1298,6 +1331,8 @@ struct PartPlanHost {
 };
 
 constexpr size_t kLdsTableBudget = 150 * 1024;
+constexpr int kPairWindowDefault = 1;
+constexpr int64_t kProgBytes = 4096;  // phase-2 pacing counters, one word per workgroup (<= 1024 CUs)
 
 bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, int n_cus,
                     int64_t scratch_cap, PartPlanHost* out) {
@@ -1432,7 +1467,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     }
     h.g.cap = (uint32_t)cap;
     h.rec_bytes = (int64_t)P * h.g.B * (int64_t)cap * (int64_t)sizeof(Rec);
-    h.cnt_bytes = ((int64_t)P * h.g.B * 4 + 255) & ~255ll;
+    h.cnt_bytes = (((int64_t)P * h.g.B * 4 + 255) & ~255ll) + kProgBytes;  // run lengths + pacing counters
     // spill list: room for 1/16 of the chunk's rows (skewed keys overflow their runs by a few
     // per cent of the records), at least kSpillMin entries
     int64_t spill_cap = chunk_rows / 16;
@@ -1553,6 +1588,11 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                             (int)h.lds2);
   // MI355Q_TRACE: per-phase cycle counters of phase 2 live in the spill header's tail
   unsigned long long* dbg = std::getenv("MI355Q_TRACE") ? (unsigned long long*)(spill_base + 64) : nullptr;
+  // pacing counters of phase 2 (tail of the run-length area); MI355Q_PAIR_WINDOW=0 switches pacing off
+  uint32_t* prog = (uint32_t*)((char*)scratch + h.rec_bytes + h.cnt_bytes - kProgBytes);
+  int pair_window = kPairWindowDefault;
+  if (const char* e = std::getenv("MI355Q_PAIR_WINDOW")) pair_window = std::atoi(e);
+  if (n_cus * 4 > kProgBytes) pair_window = 0;
   ScatterArgs sa{};
   sa.P = h.g.P;
   sa.lgL = h.g.lgL;
@@ -1591,8 +1631,13 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     st->n_launches += 1;
     const int units = h.g.P * (int)h.g.hm.R;
     const int grid2 = units < n_cus ? units : n_cus;
+    if (pair_window > 0) {
+      e = hipMemsetAsync(prog, 0, kProgBytes, s);
+      if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(agg_kernel, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, recs, cnt, h.ps,
-                       tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg);
+                       tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg,
+                       prog, pair_window);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,

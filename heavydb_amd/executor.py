@@ -430,8 +430,12 @@ class Executor:
                 del keep
                 if code == 0:
                     return ResultSet(out.value, rep)
-                if (code < 0 or code == capi.ERR_OUT_OF_SLOTS) and allow_retry \
-                        and out_buffer is None and ra_exe_unit.groupby_exprs:
+                # only a baseline-hash table grows with the guess; on a perfect-hash layout code 3
+                # means a key outside its declared range and a retry would repeat the same step
+                grows = code < 0 or (code == capi.ERR_OUT_OF_SLOTS and
+                                     self.initQueryMemoryDescriptor(ra_exe_unit).desc_type
+                                     == capi.GROUP_BY_BASELINE_HASH)
+                if grows and allow_retry and out_buffer is None and ra_exe_unit.groupby_exprs:
                     ra_exe_unit.max_groups_buffer_entry_guess *= 2
                     continue
                 raise capi.Mi355qError(code, "execute")

@@ -75,13 +75,18 @@ def _descs(specs):
     return [InputColDescriptor(s.type, False, s.range) for s in specs]
 
 
+def gen_tuples(specs: List[ColSpec]):
+    """(kind, seed, a, b, c, a_f) per column: what a host-side generator needs to reproduce the table."""
+    return [(s.kind, SEED0 + ci, s.a, s.b, s.c, s.a_f) for ci, s in enumerate(specs)]
+
+
 # ---- cfg1: SELECT COUNT(*) FROM t WHERE i32 < k
 def cfg1(torch, total_rows=100_000_000, rank=0, world=1, device_id=0, k=2**30):
     specs = [ColSpec(INT32, GEN_I32_UNIFORM31, range=ExpressionRange(True, 0, 2**31 - 1))]
     frags = my_fragments(total_rows, rank, world)
     cols, bufs, rows = generate_table(torch, specs, frags, device_id)
     ra = RelAlgExecutionUnit(_descs(specs), [TargetExpr(COUNT)], [Qual(0, LT, k)])
-    return ra, FetchResult(bufs, rows, device_id=device_id, keepalive=cols), dict(bytes_per_row=4)
+    return ra, FetchResult(bufs, rows, device_id=device_id, keepalive=cols), dict(bytes_per_row=4, gens=gen_tuples(specs))
 
 
 # ---- cfg2: SELECT key, SUM(val) FROM t GROUP BY key   (1 K int32 keys -> perfect hash)
@@ -94,7 +99,7 @@ def cfg2(torch, total_rows=1_000_000_000, rank=0, world=1, device_id=0, keyless=
     frags = my_fragments(total_rows, rank, world)
     cols, bufs, rows = generate_table(torch, specs, frags, device_id)
     ra = RelAlgExecutionUnit(_descs(specs), [TargetExpr(PROJECT_KEY), TargetExpr(SUM, 1)], groupby_exprs=[0])
-    return ra, FetchResult(bufs, rows, device_id=device_id, keepalive=cols), dict(bytes_per_row=12)
+    return ra, FetchResult(bufs, rows, device_id=device_id, keepalive=cols), dict(bytes_per_row=12, gens=gen_tuples(specs))
 
 
 # ---- cfg3: SELECT key, COUNT(*), AVG(f64) FROM t [WHERE i32 < k] GROUP BY key
@@ -119,7 +124,7 @@ def cfg3(torch, total_rows=10_000_000_000, rank=0, world=1, device_id=0, filtere
     ra = RelAlgExecutionUnit(_descs(specs), [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 1)],
                              quals, [0], max_groups_buffer_entry_guess=2 * n_keys)  # 50 % fill
     return ra, FetchResult(bufs, rows, device_id=device_id, keepalive=cols), \
-        dict(bytes_per_row=20 if filtered else 16, n_keys=n_keys)
+        dict(bytes_per_row=20 if filtered else 16, n_keys=n_keys, gens=gen_tuples(specs))
 
 
 # ---- cfg4: fact JOIN dim ON fact.k = dim.k ; SUM(fact.v) [, SUM(dim.w)]
@@ -144,7 +149,8 @@ def cfg4(torch, total_rows=10_000_000_000, rank=0, world=1, device_id=0, dim_row
                              join_outer_col=0, join_table=hj)
     fr = FetchResult(bufs, rows, [int(dim_k.data_ptr()), int(dim_w.data_ptr())], dim_rows, device_id,
                      keepalive=cols + [dim_k, dim_w, hj])
-    return ra, fr, dict(bytes_per_row=16, join=hj.info())
+    return ra, fr, dict(bytes_per_row=16, join=hj.info(), gens=gen_tuples(specs), dim_mul=mul,
+                        dim_w_gen=(GEN_I64_MOD, SEED0 + 100, 2001, -1000, 0, 0.0))
 
 
 CONFIGS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": lambda *a, **k: cfg3(*a, filtered=False, **k),

@@ -25,6 +25,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <thread>
 #include <vector>
@@ -2098,6 +2099,181 @@ ORC_EXPORT int32_t orc_generate_column(void* dst, int64_t n_rows, int64_t row_of
       default:
         return MI355Q_ERR_INVALID_PLAN;
     }
+  }
+  return 0;
+}
+
+// ================================================================ BASELINE-size runs
+// The configurations of BASELINE.json are too large to be handed over as host arrays (1 B rows of
+// cfg3-filtered = 20 GB), so this entry point generates every fragment inside the kernel thread that
+// scans it, block by block, with the same counter-based generator as orc_generate_column, and
+// otherwise runs the step exactly like orc_execute: one kernel per fragment with a private output
+// buffer per host thread (Execute.cpp:3121-3153), then ResultSetStorage::reduce of the buffers in
+// order (Execute.cpp:1772-1792).
+
+namespace {
+
+// ResultSetStorage::reduce on a row-wise baseline table with one 8-byte key is multi-threaded in the
+// reference once `that` has more than 100000 entries (use_multithreaded_reduction,
+// ResultSetReduction.cpp:43-45, :236-272): cpu_threads() workers over ranges of `that`'s entries,
+// insertion into `this` by compare-and-swap of the key word with a write-pending sentinel
+// (get_matching_group_value_reduction :697-737; fill_slots copies `that`'s slots into a claimed row).
+// Every key occurs once in `that`, so a row of `this` is reduced by one thread only.
+int32_t reduce_baseline_mt(const mi355q_qmd& q, int64_t* this_buf, const int64_t* that_buf, int n_threads) {
+  const int rq = q.row_size / 8;
+  const uint32_t ec = (uint32_t)q.entry_count;
+  std::atomic<int32_t> err{0};
+  auto worker = [&](int64_t lo, int64_t hi) {
+    for (int64_t e = lo; e < hi; ++e) {
+      const int64_t* that_row = that_buf + e * rq;
+      const int64_t key = that_row[0];
+      if (key == kEmptyKey64) continue;
+      const uint32_t h = murmur3(&key, 8, 0) % ec;
+      uint32_t hp = h;
+      bool done = false;
+      do {
+        int64_t* row = this_buf + (size_t)hp * rq;
+        int64_t expected = kEmptyKey64;
+        if (__atomic_compare_exchange_n(row, &expected, kEmptyKey64 - 1, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {
+          for (int j = 1; j < rq; ++j) row[j] = that_row[j];  // fill_slots
+          __atomic_store_n(row, key, __ATOMIC_SEQ_CST);
+          done = true;
+          break;
+        }
+        while (__atomic_load_n(row, __ATOMIC_SEQ_CST) == kEmptyKey64 - 1) {
+        }
+        if (__atomic_load_n(row, __ATOMIC_SEQ_CST) == key) {
+          reduce_targets(q, row + 1, that_row + 1);
+          done = true;
+          break;
+        }
+        hp = (hp + 1) % ec;
+      } while (hp != h);
+      if (!done) {
+        err.store(MI355Q_ERR_OUT_OF_SLOTS);
+        return;
+      }
+    }
+  };
+  std::vector<std::thread> th;
+  const int64_t per = (q.entry_count + n_threads - 1) / n_threads;
+  for (int t = 0; t < n_threads; ++t) {
+    const int64_t lo = t * per, hi = std::min<int64_t>(lo + per, q.entry_count);
+    if (lo < hi) th.emplace_back(worker, lo, hi);
+  }
+  for (auto& t : th) t.join();
+  return err.load();
+}
+
+inline double now_s() {
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+}  // namespace
+
+struct orc_gen_spec {
+  int32_t kind;        // MI355Q_GEN_*
+  int32_t null_every;
+  uint64_t seed;
+  int64_t a, b, c;
+  double a_f;
+};
+
+// timing[0] buffer initialisation (max over kernels), [1] row loops incl. generation (wall of the
+// kernel phase minus [0]), [2] generation alone (max over threads of the time spent in the
+// generator), [3] reduce of the per-kernel buffers.  reduce_threads: workers inside one reduce
+// (the reference uses cpu_threads()); the buffers themselves are reduced in order.
+ORC_EXPORT int32_t orc_execute_streamed(const mi355q_plan* plan, const orc_gen_spec* gens, int64_t total_rows,
+                                        int64_t row_offset, int64_t frag_rows, int64_t block_rows,
+                                        const void* const* inner_cols, int64_t inner_rows, const void* join,
+                                        int32_t n_threads, int32_t reduce_threads, int64_t* out_buf,
+                                        mi355q_qmd* out_qmd, double* timing) {
+  ExecCtx c;
+  c.plan = plan;
+  if (int e = qmd_init(*plan, c.qmd)) return e;
+  if (int e = build_targets(*plan, plan->n_group_cols > 0, c.ts)) return e;
+  for (int i = 0; i < plan->n_targets; ++i) c.ts[i].slot = c.qmd.target_slot[i];
+  c.join = static_cast<const OrcJoin*>(join);
+  c.inner_cols = reinterpret_cast<const int8_t* const*>(inner_cols);
+  c.inner_rows = inner_rows;
+  if (plan->join_outer_col >= 0 && !c.join) return MI355Q_ERR_INVALID_PLAN;
+  if (out_qmd) *out_qmd = c.qmd;
+  if (frag_rows <= 0 || block_rows <= 0 || total_rows < 0) return MI355Q_ERR_INVALID_PLAN;
+  const size_t quads = (size_t)(buffer_bytes(c.qmd) / 8);
+  const int64_t n_frags = (total_rows + frag_rows - 1) / frag_rows;
+  n_threads = (int32_t)std::max<int64_t>(1, std::min<int64_t>(n_threads, std::max<int64_t>(1, n_frags)));
+  const int nc = plan->n_cols;
+  auto width_of = [&](int col) -> size_t {
+    switch (gens[col].kind) {
+      case MI355Q_GEN_I32_UNIFORM31:
+      case MI355Q_GEN_I32_MOD: return 4;
+      default: return 8;
+    }
+  };
+
+  std::vector<std::vector<int64_t>> bufs(n_threads);
+  std::vector<int32_t> errs(n_threads, 0);
+  std::vector<double> t_init(n_threads, 0.0), t_gen(n_threads, 0.0);
+  const double t0 = now_s();
+  auto worker = [&](int tid) {
+    const double a0 = now_s();
+    int64_t* buf = tid == 0 ? out_buf : (bufs[tid].resize(quads), bufs[tid].data());
+    init_buffer(c.qmd, buf);
+    t_init[tid] = now_s() - a0;
+    std::vector<std::vector<int64_t>> block(nc);  // int64 storage keeps every column 8-byte aligned
+    std::vector<const int8_t*> cols(nc);
+    for (int col = 0; col < nc; ++col) {
+      block[col].resize((size_t)((block_rows * (int64_t)width_of(col) + 7) / 8));
+      cols[col] = reinterpret_cast<const int8_t*>(block[col].data());
+    }
+    for (int64_t f = tid; f < n_frags; f += n_threads) {
+      const int64_t f_lo = f * frag_rows, f_hi = std::min(total_rows, f_lo + frag_rows);
+      for (int64_t lo = f_lo; lo < f_hi; lo += block_rows) {
+        const int64_t n = std::min(block_rows, f_hi - lo);
+        const double g0 = now_s();
+        for (int col = 0; col < nc; ++col) {
+          const orc_gen_spec& g = gens[col];
+          if (int e = orc_generate_column(block[col].data(), n, row_offset + lo, g.kind, g.seed, g.a, g.b, g.c, g.a_f,
+                                          g.null_every)) {
+            errs[tid] = e;
+            return;
+          }
+        }
+        t_gen[tid] += now_s() - g0;
+        if (int32_t e = run_fragment(c, cols.data(), n, buf)) {
+          errs[tid] = e;
+          return;
+        }
+      }
+    }
+  };
+  if (n_threads == 1) {
+    worker(0);
+  } else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) th.emplace_back(worker, t);
+    for (auto& t : th) t.join();
+  }
+  const double t1 = now_s();
+  for (int t = 0; t < n_threads; ++t)
+    if (errs[t]) return errs[t];
+  const bool mt_reduce = reduce_threads > 1 && c.qmd.desc_type == MI355Q_GROUP_BY_BASELINE_HASH &&
+                         !c.qmd.output_columnar && c.qmd.group_col_count == 1 && c.qmd.key_width == 8 &&
+                         c.qmd.slot_width == 8 && c.qmd.entry_count > 100000;
+  for (int t = 1; t < n_threads; ++t) {
+    const int32_t e = mt_reduce ? reduce_baseline_mt(c.qmd, out_buf, bufs[t].data(), reduce_threads)
+                                : reduce_buffers(c.qmd, out_buf, bufs[t].data());
+    if (e) return e;
+    std::vector<int64_t>().swap(bufs[t]);
+  }
+  const double t2 = now_s();
+  if (timing) {
+    timing[0] = *std::max_element(t_init.begin(), t_init.end());
+    timing[1] = (t1 - t0) - timing[0];
+    timing[2] = *std::max_element(t_gen.begin(), t_gen.end());
+    timing[3] = t2 - t1;
   }
   return 0;
 }

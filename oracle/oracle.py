@@ -345,3 +345,58 @@ def generate_column(n_rows: int, kind: int, seed: int, a: int = 0, b: int = 0, c
                                      a_f, null_every)
     assert code == 0
     return out
+
+
+class GenSpec(C.Structure):
+    """One synthetic column of a streamed run (orc_gen_spec)."""
+    _fields_ = [("kind", C.c_int32), ("null_every", C.c_int32), ("seed", C.c_uint64),
+                ("a", C.c_int64), ("b", C.c_int64), ("c", C.c_int64), ("a_f", C.c_double)]
+
+
+def host_threads_for_tables(table_bytes: int, want: Optional[int] = None, reserve: float = 0.5) -> int:
+    """How many kernels (one private output buffer each) this host can run at once: the core count,
+    bounded by `reserve` of MemAvailable divided by one buffer."""
+    n = want or os.cpu_count() or 1
+    try:
+        with open("/proc/meminfo") as f:
+            avail_kb = next(int(l.split()[1]) for l in f if l.startswith("MemAvailable"))
+        n = min(n, max(1, int(avail_kb * 1024 * reserve) // max(table_bytes, 1)))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def execute_streamed(plan: capi.Plan, gens: Sequence[tuple], total_rows: int, frag_rows: int = 32_000_000,
+                     block_rows: int = 1 << 20, inner_cols: Sequence[np.ndarray] = (),
+                     join: Optional[OracleJoin] = None, n_threads: int = 1, reduce_threads: int = 1,
+                     row_offset: int = 0):
+    """The step over a GENERATED table (BASELINE-size runs): every fragment is produced inside the
+    kernel thread that scans it with the generator of generate_column.  gens: per column
+    (kind, seed, a, b, c, a_f[, null_every]).  Returns (qmd, buffer, code, timing) with timing =
+    dict(init_s, kernels_s, generate_s, reduce_s)."""
+    l = lib()
+    l.orc_execute_streamed.restype = C.c_int32
+    l.orc_execute_streamed.argtypes = [C.POINTER(capi.Plan), C.POINTER(GenSpec), C.c_int64, C.c_int64, C.c_int64,
+                                       C.c_int64, C.POINTER(C.c_void_p), C.c_int64, C.c_void_p, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.POINTER(capi.QMD), C.POINTER(C.c_double)]
+    assert len(gens) == plan.n_cols
+    g = (GenSpec * len(gens))()
+    for i, spec in enumerate(gens):
+        kind, seed, a, b, c, a_f = spec[:6]
+        g[i].kind, g[i].seed, g[i].a, g[i].b, g[i].c, g[i].a_f = kind, seed, a, b, c, a_f
+        g[i].null_every = spec[6] if len(spec) > 6 else 0
+    q = qmd_init(plan)
+    keep = []
+    inner = (C.c_void_p * max(1, len(inner_cols)))()
+    for c_, a_ in enumerate(inner_cols):
+        a_ = np.ascontiguousarray(a_, dtype=NP_DTYPE[plan.inner_cols[c_].type])
+        keep.append(a_)
+        inner[c_] = a_.ctypes.data
+    buf = _alloc(q)
+    out_q = capi.QMD()
+    timing = (C.c_double * 4)()
+    code = l.orc_execute_streamed(C.byref(plan), g, total_rows, row_offset, frag_rows, block_rows,
+                                  C.cast(inner, C.POINTER(C.c_void_p)), len(inner_cols[0]) if len(inner_cols) else 0,
+                                  join.handle if join else None, n_threads, reduce_threads, buf.ctypes.data,
+                                  C.byref(out_q), timing)
+    return out_q, buf, code, dict(init_s=timing[0], kernels_s=timing[1], generate_s=timing[2], reduce_s=timing[3])

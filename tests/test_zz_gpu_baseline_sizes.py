@@ -1,0 +1,141 @@
+"""BASELINE.json's configurations at (or, for the 10 B-row ones, at a tenth of) their full size on the
+device, against the ORACLE — not against other product kernels:
+
+  cfg1   COUNT(*) WHERE i32 < k                       100 M rows   (full size)
+  cfg2   key, SUM(val) GROUP BY key, 1 K keys         1 B rows     (full size)
+  cfg3f  key, COUNT(*), AVG(f64) WHERE .. GROUP BY    1 B rows, 10 M keys, 20 M-entry baseline table
+  cfg4   fact JOIN dim (100 M rows) SUM(fact.v) [, SUM(dim.w)]   1 B fact rows, perfect and keyed table
+
+The oracle generates every fragment inside the host thread that scans it (orc_execute_streamed: same
+counter-based generator as the device's mi355q_generate_column; one kernel per fragment with a private
+output buffer, then ResultSetStorage::reduce in order — Execute.cpp:3121-3153, :1772-1792,
+ResultSetReduction.cpp:203-383), so nothing of BASELINE size crosses the PCIe bus or sits in host
+memory except the per-kernel output buffers.  What is compared: ResultSetStorage buffers — index-aligned
+for the dense layouts, as key -> slots maps for the baseline table (slot positions are insertion-order
+dependent in the reference too); COUNT / SUM(int) / keys bit-exact, AVG.sum to 1e-9 relative
+(ResultSetBufferAccessors.h:197-227 for what the slots mean).  With 1 B rows the partitioned family
+runs several chunks of REAL size (the scratch cap of the call is lowered so that the chunk loop,
+table re-load and merge between chunks all execute), which the small-size matrix only reaches with
+an artificial 16 MB cap.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import pytest
+
+from heavydb_amd import capi
+from tests.helpers import check_probe_invariant, compare_buffers, compare_rows
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    capi.load_library()
+    return torch
+
+
+def _threads(orc, table_bytes: int) -> int:
+    # one private output buffer per kernel thread; leave half of the host memory alone
+    return orc.host_threads_for_tables(max(table_bytes, 1), want=min(os.cpu_count() or 1, 64))
+
+
+def _free_gb(torch) -> float:
+    free, _ = torch.cuda.mem_get_info(0)
+    return free / 2**30
+
+
+def test_cfg1_full_size_vs_oracle(torch_cuda, oracle):
+    from heavydb_amd import synth
+    from heavydb_amd.executor import Executor
+    torch = torch_cuda
+    n = 100_000_000
+    ra, fr, info = synth.cfg1(torch, n)
+    rs = Executor(0).executeWorkUnit(ra, fr)
+    q, want, code, _ = oracle.execute_streamed(ra.to_plan(), info["gens"], n, n_threads=_threads(oracle, 8))
+    assert code == 0
+    compare_buffers(q, want, rs.getStorage())
+    assert rs.report.kernel_name.decode() == "k_scan_count"
+    assert abs(int(rs.getNextRow()[0]) / n - 0.5) < 1e-3
+
+
+@pytest.mark.parametrize("keyless", [False, True])
+def test_cfg2_full_size_vs_oracle(torch_cuda, oracle, keyless):
+    from heavydb_amd import synth
+    from heavydb_amd.executor import Executor
+    torch = torch_cuda
+    n = 1_000_000_000
+    if _free_gb(torch) < 16:
+        pytest.skip("needs 12 GB of columns in HBM")
+    ra, fr, info = synth.cfg2(torch, n, keyless=keyless)
+    rs = Executor(0).executeWorkUnit(ra, fr)
+    q, want, code, _ = oracle.execute_streamed(ra.to_plan(), info["gens"], n, n_threads=_threads(oracle, 16384))
+    assert code == 0
+    assert bool(q.keyless) == keyless
+    compare_buffers(q, want, rs.getStorage())
+    assert rs.report.kernel_name.decode() == "k_perfect_lds"
+    compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
+
+
+@pytest.mark.parametrize("filtered", [True, False])
+def test_cfg3_one_billion_rows_vs_oracle(torch_cuda, oracle, filtered):
+    from heavydb_amd import synth
+    from heavydb_amd.executor import Executor
+    torch = torch_cuda
+    n, n_keys = 1_000_000_000, 10_000_000
+    if _free_gb(torch) < 40:
+        pytest.skip("needs 20 GB of columns + table + scratch in HBM")
+    ra, fr, info = synth.cfg3(torch, n, filtered=filtered, n_keys=n_keys)
+    # 6 GB of partition scratch: the 1 B rows are cut into >= 4 chunks of real size (table re-load and
+    # merge between chunks), like the 7 chunks of the 10 B-row headline run
+    rs = Executor(0).executeWorkUnit(ra, fr, allow_retry=False, scratch_bytes=6 << 30)
+    assert rs.report.variant == 2 and rs.report.kernel_name.decode() == "k_part_scatter"
+    assert rs.report.n_launches >= 4, rs.report.n_launches
+    got = rs.getStorage()
+    qg = rs.getQueryMemDesc()
+    table_bytes = qg.entry_count * qg.row_size
+    t0 = time.time()
+    q, want, code, timing = oracle.execute_streamed(ra.to_plan(), info["gens"], n,
+                                                    n_threads=_threads(oracle, table_bytes),
+                                                    reduce_threads=min(os.cpu_count() or 1, 64))
+    assert code == 0, code
+    print(f"oracle cfg3 filtered={filtered}: {time.time() - t0:.1f} s {timing}")
+    assert q.entry_count == qg.entry_count == 2 * n_keys and q.row_size == qg.row_size == 32
+    compare_buffers(q, want, got, 1e-9)           # key -> {COUNT, AVG.sum, AVG.count}: exact / 1e-9
+    check_probe_invariant(qg, got)                # a valid image of get_group_value's probing
+    assert rs.rowCount() == n_keys
+
+
+@pytest.mark.parametrize("sparse,sum_dim", [(False, False), (False, True), (True, False), (True, True)])
+def test_cfg4_one_billion_rows_vs_oracle(torch_cuda, oracle, sparse, sum_dim):
+    """Query A (SUM(fact.v)) and Query B (+ SUM(dim.w)) of SURVEY 8(d), perfect int32[] table
+    (dense dim keys) and keyed {key, row id} table (sparse dim keys, 3.2 GB)."""
+    from heavydb_amd import synth
+    from heavydb_amd.executor import Executor
+    torch = torch_cuda
+    n, m = 1_000_000_000, 100_000_000
+    if _free_gb(torch) < 40:
+        pytest.skip("needs 16 GB of fact columns + dim + join table in HBM")
+    ra, fr, info = synth.cfg4(torch, n, dim_rows=m, sparse=sparse, sum_dim=sum_dim)
+    assert info["join"]["hash_type"] == (1 if sparse else 0)
+    rs = Executor(0).executeWorkUnit(ra, fr)
+    mul = info["dim_mul"]
+    dim_k = np.arange(m, dtype=np.int64) * mul
+    g = info["dim_w_gen"]
+    dim_w = oracle.generate_column(m, g[0], g[1], g[2], g[3], g[4], g[5])
+    join = oracle.OracleJoin(dim_k, capi.INT64, 0, (m - 1) * mul)
+    assert join.info()["hash_type"] == info["join"]["hash_type"]
+    assert join.info()["entry_count"] == info["join"]["entry_count"]
+    plan = ra.to_plan()
+    plan.join_table = None
+    q, want, code, _ = oracle.execute_streamed(plan, info["gens"], n, inner_cols=[dim_k, dim_w], join=join,
+                                               n_threads=_threads(oracle, 64))
+    assert code == 0, code
+    compare_buffers(q, want, rs.getStorage())     # SUM over int64: bit-exact
+    compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 0.0)
