@@ -24,6 +24,7 @@ INT8, INT16, INT32, INT64, DOUBLE, FLOAT = 1, 2, 3, 4, 5, 6
 ENC_NONE, ENC_FIXED, ENC_DICT, ENC_DATE_IN_DAYS = 0, 1, 2, 3
 # mi355q_op (SQLOps values)
 EQ, NE, LT, GT, LE, GE = 0, 2, 3, 4, 5, 6
+IS_NULL, IS_NOT_NULL = 16, 17  # unary quals (kISNULL, kISNOTNULL): no literal
 # mi355q_agg (SQLAgg values)
 AVG, MIN, MAX, SUM, COUNT, PROJECT_KEY = 0, 1, 2, 3, 4, 100
 COUNT_IF, SUM_IF = 10, 11

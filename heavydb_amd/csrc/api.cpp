@@ -1106,8 +1106,16 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   int64_t scratch_bytes = 0;
   int64_t scratch_cap = o.scratch_bytes;
   if (kind == K_BASELINE_FAST || kind == K_JOIN_PART) {
-    // default cap: 32 GB, halved while the device cannot provide it (the planner then cuts
-    // the input into more chunks)
+    // default cap: kDefaultScratchCap, but never more than 70 % of what the device has free right now
+    // (counting the scratch this context already holds), halved while the device cannot provide it
+    // (the planner then cuts the input into more chunks)
+    if (scratch_cap <= 0) {
+      size_t free_b = 0, total_b = 0;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        const int64_t spare = (int64_t)((double)((int64_t)free_b + ctx.scratch_bytes) * 0.7);
+        scratch_cap = std::max<int64_t>(std::min<int64_t>(kDefaultScratchCap, spare), (int64_t)1 << 30);
+      }
+    }
     for (;;) {
       scratch_bytes = kind == K_JOIN_PART ? join_part_scratch_bytes(d, fv, n_cus, scratch_cap)
                                           : baseline_fast_scratch_bytes(d, fv, o.kernel_variant, scratch_cap, n_cus);
@@ -1125,7 +1133,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         break;
       }
       (void)hipGetLastError();
-      const int64_t cur_cap = scratch_cap > 0 ? scratch_cap : ((int64_t)32 << 30);
+      const int64_t cur_cap = scratch_cap > 0 ? scratch_cap : kDefaultScratchCap;
       if (cur_cap <= ((int64_t)1 << 30)) {
         last_hip_error = e;
         return MI355Q_ERR_OUT_OF_GPU_MEM;

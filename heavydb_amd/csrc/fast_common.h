@@ -31,23 +31,29 @@ struct Quad {
 template <>
 struct Quad<none_t> {};
 
+// Column chunks are reached through a pointer table in memory, so the compiler only knows them as
+// generic pointers and would emit FLAT loads: those count against lgkmcnt as well as vmcnt, i.e.
+// every wait for an LDS result (the scatter's staging protocol, the LDS tables) also waits for the
+// prefetched tile.  The chunks are device (global) memory by contract: say so, and the loads become
+// global_load_dwordx4 ... nt with a scalar base.
+#define MQ_GLOBAL __attribute__((address_space(1)))
 template <typename T>
 MQ_D void load_quad(const int8_t* base, int64_t quad, Quad<T>& q);
 template <>
 MQ_D void load_quad<int32_t>(const int8_t* base, int64_t quad, Quad<int32_t>& q) {
-  const v4i32 x = __builtin_nontemporal_load((const v4i32*)base + quad);
+  const v4i32 x = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad);
   q.v[0] = x.x; q.v[1] = x.y; q.v[2] = x.z; q.v[3] = x.w;
 }
 template <>
 MQ_D void load_quad<int64_t>(const int8_t* base, int64_t quad, Quad<int64_t>& q) {
-  const v2i64 a = __builtin_nontemporal_load((const v2i64*)base + quad * 2);
-  const v2i64 b = __builtin_nontemporal_load((const v2i64*)base + quad * 2 + 1);
+  const v2i64 a = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + quad * 2);
+  const v2i64 b = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + quad * 2 + 1);
   q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y;
 }
 template <>
 MQ_D void load_quad<double>(const int8_t* base, int64_t quad, Quad<double>& q) {
-  const v2i64 a = __builtin_nontemporal_load((const v2i64*)base + quad * 2);
-  const v2i64 b = __builtin_nontemporal_load((const v2i64*)base + quad * 2 + 1);
+  const v2i64 a = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + quad * 2);
+  const v2i64 b = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + quad * 2 + 1);
   q.v[0] = bits_dbl(a.x); q.v[1] = bits_dbl(a.y);
   q.v[2] = bits_dbl(b.x); q.v[3] = bits_dbl(b.y);
 }
@@ -55,7 +61,7 @@ template <>
 MQ_D void load_quad<none_t>(const int8_t*, int64_t, Quad<none_t>&) {}
 
 template <typename T>
-MQ_D T load_one(const int8_t* base, int64_t pos) { return ((const T*)base)[pos]; }
+MQ_D T load_one(const int8_t* base, int64_t pos) { return ((const MQ_GLOBAL T*)base)[pos]; }
 template <>
 MQ_D none_t load_one<none_t>(const int8_t*, int64_t) { return none_t{}; }
 
@@ -250,6 +256,13 @@ inline bool make_range_filter(const DevQual& q, RangeFilter* f) {
       if (x == INT64_MAX) { f->lo = 1; f->hi = 0; } else { f->lo = x + 1; f->hi = tmax; }
       break;
     case MI355Q_GE: f->lo = x; f->hi = tmax; break;
+    // x IS NOT NULL: every value but the sentinel (all of them on a NOT NULL column);
+    // x IS NULL: the sentinel alone — and nothing on a NOT NULL column (codegenIsNull)
+    case MI355Q_IS_NOT_NULL: f->lo = tmin; f->hi = tmax; break;
+    case MI355Q_IS_NULL:
+      if (q.nullable) { f->lo = f->null_val; f->hi = f->null_val; f->nullable = 0; }
+      else { f->lo = 1; f->hi = 0; }
+      break;
     default: return false;
   }
   return true;

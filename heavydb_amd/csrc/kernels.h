@@ -7,6 +7,12 @@
 
 namespace mq {
 
+// Partition scratch of the partitioned families when the caller sets no cap: large enough for the
+// record-index limit of one chunk (2^32 records x 16 B) plus its spill list, so that 10 B rows are
+// three chunks; mi355q_execute lowers it to what the device can actually spare (api.cpp).
+constexpr int64_t kDefaultScratchCap = (int64_t)76 << 30;
+
+
 struct RowInit {           // one output row image: key quads then slot init values
   int64_t quad[MI355Q_MAX_GROUP_COLS + MI355Q_MAX_SLOTS];
   int32_t row_quad;

@@ -85,6 +85,37 @@ MQ_D uint32_t part_of(const HomeMap& m, uint32_t home) {
   return q + (home - q * m.S1 >= m.S1 ? 1u : 0u);
 }
 
+// Record identity.  Phase 1 has just computed h = MurmurHash3(key) (it names the partition); phase 2
+// needs h again for the home slot and the LDS buckets, and was spending a third of its vector
+// instructions recomputing it for every record it visits (twice per record with two sub-ranges).
+// MurmurHash3_x86_32 over the two words of an int64 key is, for a FIXED low word, a bijection of the
+// high word (every step — multiply by an odd constant, rotate, xor, x*5+c, fmix32 — is invertible),
+// so the pair (low word, h) identifies the key exactly: records and the LDS tables carry that
+// 64-bit "kid" = h << 32 | low word, phase 2 reads h out of it, and the key is rebuilt where a row
+// leaves for the output table or the spill list (once per group, not once per record).
+MQ_D int64_t kid_of(int64_t key, uint32_t h) { return (int64_t)(((uint64_t)h << 32) | (uint64_t)(uint32_t)key); }
+MQ_D uint32_t kid_hash(int64_t kid) { return (uint32_t)((uint64_t)kid >> 32); }
+MQ_D int64_t key_of_kid(int64_t kid) {
+  const uint32_t lo = (uint32_t)kid;
+  uint32_t h = kid_hash(kid);
+  // undo fmix32 (x ^= x >> 16 is its own inverse; x ^= x >> 13 needs the 26-bit term as well)
+  h ^= h >> 16;
+  h *= 0x7ed1b41du;  // 0xc2b2ae35^-1 mod 2^32
+  h ^= (h >> 13) ^ (h >> 26);
+  h *= 0xa5cb9243u;  // 0x85ebca6b^-1
+  h ^= h >> 16;
+  h ^= 8u;           // the length
+  // h = rotl(h1 ^ k2', 13) * 5 + 0xe6546b64 with h1 = the state after the low word's block
+  h = (h - 0xe6546b64u) * 0xcccccccdu;  // 5^-1
+  h = (h >> 13) | (h << 19);
+  uint32_t k1 = lo * 0xcc9e2d51u;
+  k1 = rotl32(k1, 15) * 0x1b873593u;
+  const uint32_t h1 = rotl32(k1, 13) * 5u + 0xe6546b64u;
+  uint32_t k2 = (h ^ h1) * 0x56ed309bu;  // 0x1b873593^-1
+  k2 = ((k2 >> 15) | (k2 << 17)) * 0xdee13bb1u;  // 0xcc9e2d51^-1
+  return (int64_t)(((uint64_t)k2 << 32) | lo);
+}
+
 struct PartGeom {
   int32_t P, lgL, B;   // partitions, log2(records per staged line), scatter workgroups
   uint32_t L;          // records per line = kStageRecs / P
@@ -492,7 +523,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
       auto one_row = [&](int i, auto hot_aware) {
         bool park = false;
         uint32_t p = 0, s = 0;
-        int64_t vb = 0;
+        int64_t vb = 0, rk = 0;  // rk: what the record carries — the key (DIRECT) or its kid
         if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i)) &&
             (!DIRECT || (uint64_t)cur.k.v[i] - (uint64_t)g.kmin < (uint64_t)g.hm.d)) {
           const int64_t key = cur.k.v[i];
@@ -526,9 +557,12 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
           }
           if (!folded) {
             p = part_of(g.hm, DIRECT ? (uint32_t)((uint64_t)key - (uint64_t)g.kmin) : home_from_hash(g.hm, h));
-            s = atomicAdd(&cursor[p], 1u);
-            if (s >= g.cap) spill_raw(sl, g, sp_blk, key, vb);  // run full
-            else park = !try_stage(key, vb, p, s);
+            rk = DIRECT ? key : kid_of(key, h);
+            // (the one key whose kid is the LDS tables' empty mark takes the spill list, like a record
+            // that meets a full run)
+            s = (!DIRECT && rk == kEmptyKey64) ? g.cap : atomicAdd(&cursor[p], 1u);
+            if (s >= g.cap) spill_raw(sl, g, sp_blk, key, vb);
+            else park = !try_stage(rk, vb, p, s);
           }
         }
         // Line not open yet: park the record in pending slot i.  If an older record still
@@ -540,7 +574,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
           retry_pending();
           // the record in hand is retried too: its line may have opened meanwhile, and another
           // wave may be waiting for exactly that line to fill
-          if (park && try_stage(cur.k.v[i], vb, p, s)) park = false;
+          if (park && try_stage(rk, vb, p, s)) park = false;
           __builtin_amdgcn_s_sleep(2);
           if (++spins > kMaxSpins) {  // cannot happen unless the protocol is broken: bail out
             atomicExch(sl.d_err + 1, 2);
@@ -549,7 +583,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
           }
         }
         if (park) {
-          c_key[i] = cur.k.v[i];
+          c_key[i] = rk;
           c_val[i] = vb;
           c_pid[i] = p;
           c_slot[i] = s;
@@ -756,9 +790,7 @@ MQ_D int first_empty(const Bucket& k) {
   return k.a.x == kEmptyKey64 ? 0 : k.a.y == kEmptyKey64 ? 1 : k.c.x == kEmptyKey64 ? 2
          : k.c.y == kEmptyKey64 ? 3 : -1;
 }
-MQ_D uint32_t bucket_b_of(uint32_t h, uint32_t n_buckets) {
-  return (uint32_t)(((uint64_t)(h * 2654435761u) * n_buckets) >> 32);
-}
+MQ_D uint32_t bucket_b_of(uint32_t h, uint32_t n_buckets) { return __umulhi(h * 2654435761u, n_buckets); }
 
 // insert-or-find: candidate buckets ba / bb, then (both full) linear probing from bb + 1.
 // Returns the entry or kNoEntry when the table is full.
@@ -803,8 +835,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
                                                                 const uint32_t* __restrict__ cnt,
                                                                 PartSlots ps, TableArgs tab, SpillList sl,
                                                                 int merge, uint32_t chunk_records_max,
-                                                                unsigned long long* __restrict__ dbg,
-                                                                uint32_t* __restrict__ prog, int pair_window) {
+                                                                unsigned long long* __restrict__ dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int64_t* const lkeys = (int64_t*)smem_raw;
   uint32_t* bitmap = (uint32_t*)(smem_raw + g.lds_table_bytes);  // [(S2 + 31) / 32]
@@ -818,15 +849,6 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
   // sub-ranges of one partition run on workgroups of the same XCD (block id mod 8) at the same
   // time, so the second reader of a run is served by that XCD's L2
   const bool paired = R > 1 && G % (8 * R) == 0;
-  // Pair pacing (a speed hint, never a correctness condition): the two sub-range units of a
-  // partition read the SAME runs, so whichever reads second can be served by the XCD's L2 / the
-  // Infinity Cache instead of HBM — if it is not too far behind.  Every wave counts the runs it has
-  // finished in prog[workgroup]; before a wave starts a round of runs it waits (bounded) until its
-  // partner workgroup is within `pair_window` rounds.  A partner that never shows up only costs
-  // the bounded wait once: the wave stops pacing.
-  const bool pacing = paired && R == 2 && pair_window > 0 && prog != nullptr;
-  const uint32_t partner = blockIdx.x ^ 8u;
-  bool pace_off = false;
 
   uint32_t lo = 0, n_slots = 0;  // this unit's home range [lo, lo + n_slots)
   // MI355Q_TRACE: lane 0 of every workgroup accumulates the cycles of each phase
@@ -839,7 +861,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       t_mark = now;
     }
   };
-  auto bucket_of = [&](uint32_t x) -> uint32_t { return (uint32_t)(((uint64_t)x * g.b_mult) >> 32); };
+  auto bucket_of = [&](uint32_t x) -> uint32_t { return __umulhi(x, g.b_mult); };
   // Four records per lane per step: all four bucket reads are issued before any is consumed
   // (LDS latency overlaps 4x), hits — the common case once a unit's table is warm — update
   // their slots straight away, misses fall back to the insert-or-find loop afterwards.
@@ -849,7 +871,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     uint32_t in_mask = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t h = murmur3_u64((uint64_t)rr[j]->key);
+      const uint32_t h = kid_hash(rr[j]->key);  // the records carry kids (kid_of), not keys
       const uint32_t x = home_from_hash(g.hm, h) - lo;
       const bool in = (uint32_t)j < n_valid && x < n_slots;  // else: past the run's end / another sub-range
       ba[j] = in ? bucket_of(x) : 0u;
@@ -886,7 +908,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       const uint32_t b0 = j == 0 ? bb[0] : j == 1 ? bb[1] : j == 2 ? bb[2] : bb[3];
       const uint32_t e = lds_locate(lkeys, n_buckets, a0, b0, key);
       if (e != kNoEntry) apply_row<MASK>(smem_raw, g, ps, e, val);
-      else spill_record(sl, ps, ns, key, val);
+      else spill_record(sl, ps, ns, key_of_kid(key), val);
     }
   };
 
@@ -951,8 +973,9 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
           if (ps.nn_slot >= 0 && ps.nn_hidden) part[ps.nn_slot] = any_value ? 1 : 0;
           const uint32_t h = murmur3_u64((uint64_t)key);
           const uint32_t x = home_from_hash(g.hm, h) - lo;
-          const uint32_t e = (x < n_slots && !big)
-                                 ? lds_locate(lkeys, n_buckets, bucket_of(x), bucket_b_of(h, n_buckets), key)
+          const int64_t kid = kid_of(key, h);
+          const uint32_t e = (x < n_slots && !big && kid != kEmptyKey64)
+                                 ? lds_locate(lkeys, n_buckets, bucket_of(x), bucket_b_of(h, n_buckets), kid)
                                  : kNoEntry;
           if (e == kNoEntry) {  // probed in from another range / no room / huge count: merged last
             spill_append(sl, key, part, ns);
@@ -964,29 +987,9 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       mark(1);
       // one wave per run; four 16-byte record loads per lane, the next four already in flight
       const int wave = t >> 6, lane = t & 63;
-      constexpr int kWaves = kPartBlock / 64;
-      const uint32_t rounds_per_unit = (uint32_t)(g.B + kWaves - 1) / kWaves;
-      for (int b = wave; b < g.B; b += kWaves) {
-        if (pacing && !pace_off) {
-          const uint32_t round = (uint32_t)it * rounds_per_unit + (uint32_t)(b / kWaves);
-          if (round >= (uint32_t)pair_window) {
-            // runs the partner must have finished: one of round (round - window) at least
-            const uint32_t need = (round - (uint32_t)pair_window) * kWaves + 1;
-            uint32_t spins = 0;
-            while (__hip_atomic_load(prog + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-              __builtin_amdgcn_s_sleep(8);
-              if (++spins > 4096) {  // ~1 ms: the partner is not running beside us
-                pace_off = true;
-                break;
-              }
-            }
-          }
-        }
+      for (int b = wave; b < g.B; b += kPartBlock / 64) {
         const uint32_t n = lcnt[b];
-        if (!n) {
-          if (pacing && lane == 0) atomicAdd(prog + blockIdx.x, 1u);
-          continue;
-        }
+        if (!n) continue;
         const Rec* run = scratch + ((size_t)p * g.B + b) * g.cap;
         const uint32_t last = n - 1;
         auto at = [&](uint32_t i) -> uint32_t { return i < last ? i : last; };  // clamped: always loadable
@@ -997,10 +1000,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
           insert4(c0, c1, c2, c3, i < n ? (n - i + 63) / 64 : 0u);
           c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         }
-        if (pacing && lane == 0) atomicAdd(prog + blockIdx.x, 1u);
       }
-    } else if (pacing && t == 0) {
-      atomicAdd(prog + blockIdx.x, (uint32_t)g.B);  // an empty unit still counts its rounds
     }
     __syncthreads();
     mark(2);
@@ -1009,9 +1009,9 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     // inserted the same new key at the same moment.  The later copy is added to the earlier
     // one and cleared.
     for (uint32_t e = t; e < g.E && n_slots; e += kPartBlock) {
-      const int64_t key = *key_of_entry(lkeys, n_buckets, e);
+      const int64_t key = *key_of_entry(lkeys, n_buckets, e);  // a kid
       if (key == kEmptyKey64) continue;
-      const uint32_t h = murmur3_u64((uint64_t)key);
+      const uint32_t h = kid_hash(key);
       const uint32_t ba = bucket_of(home_from_hash(g.hm, h) - lo), bb = bucket_b_of(h, n_buckets);
       const uint32_t be = e >> 2;
       if (be == ba) continue;
@@ -1038,9 +1038,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     // emit: claim the first free slot at or after the home slot (the reference's probing
     // rule, GroupByRuntime.cpp:25-48) in the LDS bitmap, then store the finished row
     for (uint32_t e = t; e < g.E && n_slots; e += kPartBlock) {
-      const int64_t key = *key_of_entry(lkeys, n_buckets, e);
-      if (key == kEmptyKey64) continue;
-      uint32_t s = home_of(g.hm, key) - lo;
+      const int64_t kid = *key_of_entry(lkeys, n_buckets, e);
+      if (kid == kEmptyKey64) continue;
+      const int64_t key = key_of_kid(kid);
+      uint32_t s = home_from_hash(g.hm, kid_hash(kid)) - lo;
       bool placed = false;
       while (s < n_slots) {
         const uint32_t bit = 1u << (s & 31);
@@ -1331,8 +1332,6 @@ struct PartPlanHost {
 };
 
 constexpr size_t kLdsTableBudget = 150 * 1024;
-constexpr int kPairWindowDefault = 1;
-constexpr int64_t kProgBytes = 4096;  // phase-2 pacing counters, one word per workgroup (<= 1024 CUs)
 
 bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, int n_cus,
                     int64_t scratch_cap, PartPlanHost* out) {
@@ -1467,7 +1466,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     }
     h.g.cap = (uint32_t)cap;
     h.rec_bytes = (int64_t)P * h.g.B * (int64_t)cap * (int64_t)sizeof(Rec);
-    h.cnt_bytes = (((int64_t)P * h.g.B * 4 + 255) & ~255ll) + kProgBytes;  // run lengths + pacing counters
+    h.cnt_bytes = ((int64_t)P * h.g.B * 4 + 255) & ~255ll;
     // spill list: room for 1/16 of the chunk's rows (skewed keys overflow their runs by a few
     // per cent of the records), at least kSpillMin entries
     int64_t spill_cap = chunk_rows / 16;
@@ -1479,6 +1478,13 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     if (h.scratch_bytes <= scratch_cap || chunk_rows <= fv.max_frag_rows) break;
     chunk_rows = (int64_t)(chunk_rows * 0.9);
     if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
+  }
+  // equal-sized chunks: 10 B rows under a 3.4 B-row limit are three chunks of 3.3 B, not two full
+  // ones and a sliver (every chunk pays the table re-load, the emission and the launch tails)
+  if (fv.total_rows > chunk_rows) {
+    const int64_t n_chunks = (fv.total_rows + chunk_rows - 1) / chunk_rows;
+    const int64_t even = (fv.total_rows + n_chunks - 1) / n_chunks + fv.max_frag_rows;  // fragments are not split
+    if (even < chunk_rows) chunk_rows = even;
   }
   h.chunk_rows = chunk_rows;
   // staging lines + cursor / written / flushed + done + heavy-hitter table
@@ -1527,13 +1533,13 @@ bool part_supported(const DevPlan& p, const FragView& fv, int n_cus) {
   FastShape fs;
   if (!grouped_fast_shape(p, fv, &fs)) return false;
   PartPlanHost h;
-  return make_part_plan(p, fs, fv, n_cus, (int64_t)32 << 30, &h);
+  return make_part_plan(p, fs, fv, n_cus, kDefaultScratchCap, &h);
 }
 
 int64_t part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes) {
   FastShape fs;
   if (!grouped_fast_shape(p, fv, &fs)) return 0;
-  if (cap_bytes <= 0) cap_bytes = (int64_t)32 << 30;
+  if (cap_bytes <= 0) cap_bytes = kDefaultScratchCap;
   PartPlanHost h;
   if (!make_part_plan(p, fs, fv, n_cus, cap_bytes, &h)) return 0;
   return h.scratch_bytes + 64;
@@ -1545,7 +1551,7 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                                        LaunchStats* st) {
   FastShape fs;
   if (!grouped_fast_shape(p, fv, &fs)) return hipErrorInvalidValue;
-  if (cap_bytes <= 0) cap_bytes = (int64_t)32 << 30;
+  if (cap_bytes <= 0) cap_bytes = kDefaultScratchCap;
   PartPlanHost h;
   // same inputs as part_scratch_bytes -> the same plan
   if (!make_part_plan(p, fs, fv, n_cus, cap_bytes, &h)) return hipErrorInvalidValue;
@@ -1588,11 +1594,6 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                             (int)h.lds2);
   // MI355Q_TRACE: per-phase cycle counters of phase 2 live in the spill header's tail
   unsigned long long* dbg = std::getenv("MI355Q_TRACE") ? (unsigned long long*)(spill_base + 64) : nullptr;
-  // pacing counters of phase 2 (tail of the run-length area); MI355Q_PAIR_WINDOW=0 switches pacing off
-  uint32_t* prog = (uint32_t*)((char*)scratch + h.rec_bytes + h.cnt_bytes - kProgBytes);
-  int pair_window = kPairWindowDefault;
-  if (const char* e = std::getenv("MI355Q_PAIR_WINDOW")) pair_window = std::atoi(e);
-  if (n_cus * 4 > kProgBytes) pair_window = 0;
   ScatterArgs sa{};
   sa.P = h.g.P;
   sa.lgL = h.g.lgL;
@@ -1631,13 +1632,8 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     st->n_launches += 1;
     const int units = h.g.P * (int)h.g.hm.R;
     const int grid2 = units < n_cus ? units : n_cus;
-    if (pair_window > 0) {
-      e = hipMemsetAsync(prog, 0, kProgBytes, s);
-      if (e != hipSuccess) return e;
-    }
     hipLaunchKernelGGL(agg_kernel, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, recs, cnt, h.ps,
-                       tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg,
-                       prog, pair_window);
+                       tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1739,7 +1735,7 @@ bool make_join_part_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_
   sa.null_bits = INT64_MIN;
   int64_t chunk_rows = fv.total_rows > 0 ? fv.total_rows : 1;
   if (chunk_rows > 0xfff00000ll) chunk_rows = 0xfff00000ll;
-  if (scratch_cap <= 0) scratch_cap = (int64_t)32 << 30;
+  if (scratch_cap <= 0) scratch_cap = kDefaultScratchCap;
   for (;;) {
     const double per_run = (double)chunk_rows / ((double)P * sa.B);
     uint64_t cap = (uint64_t)(per_run * 1.2 + 6.0 * __builtin_sqrt(per_run + 1.0)) + sa.L;
@@ -1787,7 +1783,7 @@ bool make_join_part_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_
 
 bool join_part_supported(const DevPlan& p, const FragView& fv, int n_cus) {
   JoinPartHost h;
-  return make_join_part_plan(p, fv, n_cus, (int64_t)32 << 30, &h);
+  return make_join_part_plan(p, fv, n_cus, kDefaultScratchCap, &h);
 }
 
 int64_t join_part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes) {

@@ -152,7 +152,13 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
       r.range = r.table ? &p.inner_col_ranges[r.col] : &p.col_ranges[r.col];
     }
     const bool is_agg = t.agg != MI355Q_PROJECT_KEY;
-    r.skip_null = is_agg && r.col >= 0 && (r.arg_nullable || !grouped);
+    // constrained_not_null (OutputBufferInitialization.cpp:301-324): `arg IS NOT NULL` among the quals
+    r.constrained = false;
+    if (is_agg && r.col >= 0 && r.table == 0) {
+      for (int k = 0; k < p.n_quals; ++k)
+        if (p.quals[k].op == MI355Q_IS_NOT_NULL && p.quals[k].col == r.col) r.constrained = true;
+    }
+    r.skip_null = is_agg && r.col >= 0 && ((r.arg_nullable && !r.constrained) || !grouped);
     // COUNT_IF's argument is the condition itself (TargetInfo.cpp:60-82)
     if (t.agg == MI355Q_COUNT_IF) r.skip_null = r.cond_nullable || !grouped;
     r.n_slots = t.agg == MI355Q_AVG ? 2 : 1;
@@ -192,7 +198,7 @@ void keyless_decision(const mi355q_plan& p, const ResolvedTarget* ts, bool* keyl
           found = true;
           break;
         case MI355Q_SUM:
-          if (t.arg_nullable) {
+          if (t.arg_nullable && !t.constrained) {  // GroupByAndAggregate.cpp:531
             found = rng_ok && !a.range->has_nulls;
           } else if (rng_ok) {
             found = a.fp ? (a.range->fp_max < 0 || a.range->fp_min > 0)
@@ -381,7 +387,7 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
     } else {
       if (slot + t.n_slots > MI355Q_MAX_SLOTS) return MI355Q_ERR_INVALID_PLAN;
       q->target_slot[i] = slot;
-      const bool init_notnull = grouped ? !t.arg_nullable : false;
+      const bool init_notnull = grouped ? (!t.arg_nullable || t.constrained) : false;
       q->init_vals[slot] = initial_val(t.agg, a, init_notnull);
       if (t.agg == MI355Q_AVG) q->init_vals[slot + 1] = 0;
       slot += t.n_slots;
@@ -528,7 +534,7 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
     o.fval = s.fval;
     switch (s.op) {
       case MI355Q_EQ: case MI355Q_NE: case MI355Q_LT: case MI355Q_GT: case MI355Q_LE:
-      case MI355Q_GE:
+      case MI355Q_GE: case MI355Q_IS_NULL: case MI355Q_IS_NOT_NULL:
         break;
       default:
         return MI355Q_ERR_UNSUPPORTED;

@@ -12,6 +12,7 @@ struct ResolvedTarget {
   bool cond_nullable = false;  // COUNT_IF / SUM_IF: the condition column is nullable
   bool arg_nullable = false, arg_fp = false, skip_null = false;
   bool arg_f32 = false;  // FLOAT argument: single-precision slot arithmetic
+  bool constrained = false;  // constrained_not_null: a qual `arg IS NOT NULL`
   int n_slots = 1;
   const mi355q_range* range = nullptr;
 };

@@ -232,6 +232,16 @@ MQ_FN void a_minmax_f32(int64_t* s, float v, int32_t skip_bits) {
 
 // ---------------------------------------------------------------- filter
 MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
+  if (q.op == MI355Q_IS_NULL || q.op == MI355Q_IS_NOT_NULL) {
+    // codegenIsNull (LogicalIR.cpp:381-432): false on a NOT NULL type, else value == inline NULL
+    bool is_null = false;
+    if (q.nullable) {
+      if (q.type == MI355Q_FLOAT) is_null = decode_flt(col, pos) == kNullFloat;
+      else if (q.type == MI355Q_DOUBLE) is_null = decode_dbl(col, pos) == kNullDouble;
+      else is_null = decode_int(col, q.type, pos) == int_null_of(q.type);
+    }
+    return q.op == MI355Q_IS_NULL ? is_null : !is_null;
+  }
   if (q.type == MI355Q_FLOAT) {  // the literal is folded to the column's type: compared in float
     const float v = decode_flt(col, pos);
     const float lit = (float)q.fval;

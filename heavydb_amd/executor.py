@@ -63,7 +63,7 @@ class Qual:
     """simple_quals entry: `col <op> literal`."""
     col: int
     op: int
-    literal: float | int
+    literal: float | int = 0  # unused by IS_NULL / IS_NOT_NULL
 
 
 @dataclass

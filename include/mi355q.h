@@ -106,7 +106,16 @@ typedef enum mi355q_op {
   MI355Q_LT = 3,
   MI355Q_GT = 4,
   MI355Q_LE = 5,
-  MI355Q_GE = 6
+  MI355Q_GE = 6,
+  /* unary quals on a column, no literal (kISNULL = 16, kISNOTNULL = 17).  `x IS NULL` is FALSE on a
+   * NOT NULL column and `value == the type's inline NULL` otherwise (CodeGenerator::codegenIsNull,
+   * LogicalIR.cpp:381-432; doubles compare with FCMP_OEQ against NULL_DOUBLE); `x IS NOT NULL` is its
+   * negation (RelAlgTranslator.cpp:640-643 builds NOT(ISNULL(x))).  A qual `x IS NOT NULL` also makes
+   * the GROUPED aggregates over x NOT NULL for this step (constrained_not_null,
+   * OutputBufferInitialization.cpp:287,301-324 — init values; TargetExprBuilder.cpp:690 — plain
+   * instead of _skip_val aggregates; GroupByAndAggregate.cpp:531 — the keyless rule of SUM). */
+  MI355Q_IS_NULL = 16,
+  MI355Q_IS_NOT_NULL = 17
 } mi355q_op;
 
 /* aggregates: numeric values of SQLAgg (Shared/sqldefs.h:76-90); PROJECT is a

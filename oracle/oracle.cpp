@@ -343,6 +343,7 @@ struct TargetDesc {
   bool arg_fp;
   bool arg_f32;      // FLOAT argument (takes_float_argument): 4-byte slot arithmetic
   bool skip_null;    // TargetInfo.skip_null_val after TargetExprBuilder.cpp:684-690
+  bool constrained;  // constrained_not_null(arg, quals)
   int slot;          // first slot, -1 if read from key columns
   int n_slots;
   int key_idx;       // PROJECT_KEY: which group column
@@ -435,10 +436,18 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
         d.arg_nullable = false;
       }
     }
+    // constrained_not_null (OutputBufferInitialization.cpp:301-324): a qual `arg IS NOT NULL` (or
+    // NOT(arg IS NULL), the same thing here) on the aggregate's own argument expression
+    d.constrained = false;
+    if (d.col >= 0 && d.table == 0 && t.agg != MI355Q_PROJECT_KEY) {
+      for (int k = 0; k < p.n_quals; ++k)
+        if (p.quals[k].op == MI355Q_IS_NOT_NULL && p.quals[k].col == d.col) d.constrained = true;
+    }
     // TargetInfo.cpp:64-81: skip_null_val = !arg.notnull ; TargetExprBuilder.cpp:684-690:
-    // non-grouped aggregates with an argument force skip_null_val = true.
+    // non-grouped aggregates with an argument force skip_null_val = true; otherwise a constrained
+    // argument turns it off.
     d.skip_null = (d.col >= 0 && t.agg != MI355Q_PROJECT_KEY) &&
-                  (d.arg_nullable || !is_group_by);
+                  ((d.arg_nullable && !d.constrained) || !is_group_by);
     // COUNT_IF: skip_null_val follows the nullability of the condition (its argument)
     if (t.agg == MI355Q_COUNT_IF) d.skip_null = p.cols[t.cond.col].nullable != 0 || !is_group_by;
     d.n_slots = (t.agg == MI355Q_AVG) ? 2 : 1;
@@ -479,7 +488,8 @@ std::pair<bool, int> keyless_info(const mi355q_plan& p, const std::vector<Target
           found = true;
           break;
         case MI355Q_SUM:
-          if (t.arg_nullable) {
+          // "if (constrained_not_null(arg_expr, quals)) arg_ti.set_notnull(true)" (:531) — SUM only
+          if (t.arg_nullable && !t.constrained) {
             if (r->valid && !r->has_nulls) found = true;
           } else if (r->valid) {
             if ((t.arg_fp || t.arg_f32)) {
@@ -657,7 +667,9 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
       q.target_slot[i] = slot;
       t.slot = slot;
       // init_agg_val_vec (OutputBufferInitialization.cpp:24-84)
-      const bool init_notnull = is_group_by ? !t.arg_nullable : false;
+      // init_agg_val_vec(targets, quals, qmd) :280-290: constrained -> set_notnull(true); non-grouped
+      // aggregates are forced nullable afterwards (:79-81)
+      const bool init_notnull = is_group_by ? (!t.arg_nullable || t.constrained) : false;
       q.init_vals[slot] = agg_initial_val(t.agg, t.arg_type, init_notnull);
       if (t.agg == MI355Q_AVG) q.init_vals[slot + 1] = 0;
       slot += t.n_slots;
@@ -1125,6 +1137,17 @@ struct ExecCtx {
 inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q, const int8_t* const* cols,
                       int64_t pos) {
   const auto& cd = p.cols[q.col];
+  if (q.op == MI355Q_IS_NULL || q.op == MI355Q_IS_NOT_NULL) {
+    // codegenIsNull (LogicalIR.cpp:381-432): constant false on a NOT NULL type, otherwise the value
+    // equals the type's inline NULL (FCMP_OEQ for floating point); IS NOT NULL = NOT(IS NULL)
+    bool is_null = false;
+    if (cd.nullable) {
+      if (type_is_f32(cd.type)) is_null = decode_flt(cols[q.col], pos) == kNullFloat;
+      else if (type_is_fp(cd.type)) is_null = decode_dbl(cols[q.col], pos) == kNullDouble;
+      else is_null = decode_col(cd, cols[q.col], pos) == int_null_of(logical_type_of(cd));
+    }
+    return q.op == MI355Q_IS_NULL ? is_null : !is_null;
+  }
   if (type_is_f32(cd.type)) {  // lt_float_nullable etc. (DEF_CMP_NULLABLE for float): single precision
     const float v = decode_flt(cols[q.col], pos);
     const float lit = (float)q.fval;

@@ -137,6 +137,36 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("filter_on_nullable_eq", ra([TargetExpr(COUNT), TargetExpr(SUM, 8)],
                                                   [Qual(10, NE, 17)]), frags))   # NULL <> 17 is not true
 
+    # ---- IS [NOT] NULL quals and constrained_not_null (OutputBufferInitialization.cpp:287,301-324;
+    # ExecuteTest FilterAndGroupBy: `... WHERE x IS NOT NULL GROUP BY ...`): a grouped aggregate whose
+    # argument is constrained starts from the NOT NULL init value and uses the plain agg functions
+    IS_NULL, IS_NOT_NULL = capi.IS_NULL, capi.IS_NOT_NULL
+    cases.append(Case("isnotnull_count_nongrouped", ra([TargetExpr(COUNT), TargetExpr(COUNT, 8), TargetExpr(SUM, 8)],
+                                                       [Qual(8, IS_NOT_NULL)]), frags))
+    cases.append(Case("isnull_count_nongrouped", ra([TargetExpr(COUNT), TargetExpr(COUNT, 8), TargetExpr(MIN, 7)],
+                                                    [Qual(8, IS_NULL)]), frags))
+    cases.append(Case("isnull_on_notnull_col_is_false", ra([TargetExpr(COUNT), TargetExpr(SUM, 2)],
+                                                           [Qual(2, IS_NULL)]), frags))
+    cases.append(Case("isnotnull_on_notnull_col_is_true", ra([TargetExpr(COUNT), TargetExpr(SUM, 2)],
+                                                             [Qual(2, IS_NOT_NULL)]), frags))
+    cases.append(Case("isnotnull_f64_nongrouped", ra([TargetExpr(COUNT), TargetExpr(AVG, 9), TargetExpr(MAX, 9)],
+                                                     [Qual(9, IS_NOT_NULL)]), frags))
+    cases.append(Case("constrained_perfect_sum_min_max", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 8), TargetExpr(MIN, 8),
+                                                            TargetExpr(MAX, 8), TargetExpr(COUNT, 8), TargetExpr(AVG, 8)],
+                                                           [Qual(8, IS_NOT_NULL)], [1]), frags))
+    cases.append(Case("constrained_perfect_sum_keyless_rule", ra([TargetExpr(SUM, 7), TargetExpr(COUNT)],
+                                                                 [Qual(7, IS_NOT_NULL)], [1]), frags))
+    cases.append(Case("constrained_other_column_unaffected", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 7), TargetExpr(MIN, 8)],
+                                                                [Qual(8, IS_NOT_NULL)], [1]), frags))
+    cases.append(Case("constrained_f64_perfect", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 9), TargetExpr(MIN, 9), TargetExpr(AVG, 9)],
+                                                    [Qual(9, IS_NOT_NULL), Qual(0, LT, 2**30)], [1]), frags))
+    cases.append(Case("constrained_baseline_avg_min", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 8),
+                                                          TargetExpr(MIN, 8)], [Qual(8, IS_NOT_NULL)], [4], guess=8192), frags))
+    cases.append(Case("isnull_grouped_baseline", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 8), TargetExpr(MAX, 2)],
+                                                    [Qual(8, IS_NULL)], [4], guess=8192), frags))
+    cases.append(Case("isnotnull_nullable_group_key", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 2)],
+                                                         [Qual(10, IS_NOT_NULL)], [10]), frags))
+
     # ---- GroupBy / GroupByPerfectHash / keyless vs keyed
     cases.append(Case("perfect_key_sum_projectkey", ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 2)], group=[1]), frags))
     cases.append(Case("perfect_sum_only_keyed", ra([TargetExpr(SUM, 2)], group=[1]), frags))       # range spans 0 -> keyed

@@ -74,7 +74,14 @@ def _random_plan(rng):
             targets.append(TargetExpr(capi.SUM_IF, col, cond=cond))
         else:
             targets.append(TargetExpr([capi.SUM, capi.AVG, capi.MIN, capi.MAX][(k - 5) % 4], col))
-    ra = RelAlgExecutionUnit(descs, targets, [], group,
+    # constrained_not_null: `arg IS NOT NULL` on (often) an aggregate's own argument changes init
+    # values, the skip_val choice and SUM's keyless rule
+    quals = []
+    if rng.integers(0, 3) == 0:
+        arg_cols = [t.col for t in targets if t.agg != capi.PROJECT_KEY and t.col >= 0]
+        qc = int(rng.choice(arg_cols)) if arg_cols and rng.integers(0, 4) else int(rng.integers(0, n_cols))
+        quals = [Qual(qc, capi.IS_NOT_NULL if rng.integers(0, 4) else capi.IS_NULL)]
+    ra = RelAlgExecutionUnit(descs, targets, quals, group,
                              max_groups_buffer_entry_guess=int(rng.choice([0, 1000, 16384, 10 ** 6])),
                              bigint_count=bool(rng.integers(0, 4) == 0),
                              num_tuples=int(rng.choice([0, 10 ** 6, 2 ** 32 - 1, 2 ** 32, 10 ** 10])))
@@ -183,6 +190,10 @@ def _fuzz_row_plan(rng, descs):
         else:
             targets.append(TargetExpr([capi.SUM, capi.AVG, capi.MIN, capi.MAX][k - 5], col))
     quals = [Qual(int(rng.integers(0, len(descs))), capi.GE, -5)] if rng.integers(0, 2) else []
+    if rng.integers(0, 3) == 0:
+        arg_cols = [t.col for t in targets if t.agg != capi.PROJECT_KEY and t.col >= 0]
+        qc = int(rng.choice(arg_cols)) if arg_cols else int(rng.integers(0, len(descs)))
+        quals.append(Qual(qc, capi.IS_NOT_NULL if rng.integers(0, 3) else capi.IS_NULL))
     ra = RelAlgExecutionUnit(descs, targets, quals, group, max_groups_buffer_entry_guess=2048,
                              bigint_count=bool(rng.integers(0, 4) == 0))
     return ra

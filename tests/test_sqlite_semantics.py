@@ -56,6 +56,8 @@ def _sql_for(case):
         return f"d.i{t.col}" if t.table else f"f.c{t.col}"
 
     def cond(q):
+        if q.op in (capi.IS_NULL, capi.IS_NOT_NULL):
+            return f"f.c{q.col} IS {'NOT ' if q.op == capi.IS_NOT_NULL else ''}NULL"
         return f"f.c{q.col} {OPS[q.op]} {_lit(descs[q.col], q)}"
     sel = []
     for t in ra.target_exprs:
@@ -73,7 +75,10 @@ def _sql_for(case):
             # group without a qualifying row reads 0 where SQL says NULL
             arg_d = ra.inner_col_descs[t.col] if t.table else descs[t.col]
             left_inner = t.table and ra.join_kind == capi.JOIN_LEFT
-            if ra.groupby_exprs and not arg_d.nullable and not left_inner:
+            # ... and so does an argument constrained by a qual `arg IS NOT NULL` (constrained_not_null
+            # -> set_notnull(target, true), OutputBufferInitialization.cpp:287)
+            constrained = (not t.table) and any(q.op == capi.IS_NOT_NULL and q.col == t.col for q in ra.simple_quals)
+            if ra.groupby_exprs and (not arg_d.nullable or constrained) and not left_inner:
                 e = f"COALESCE({e}, 0)"
             sel.append(e)
         else:
