@@ -36,6 +36,16 @@ struct mi355q_join_table {
   void* bitmap = nullptr;  // perfect tables: presence bitmap (1 bit per slot), for probes that
                            // only need to know WHETHER a key matches (no inner column read)
   float build_ms = 0.f;
+  // perfect tables: per-key aggregated payload for the payload probe (kernels_part.hip), built on
+  // first use for one inner column and kept with the table (the inner table does not change under
+  // a join table): rows per key, sum of the inner column over them, non-NULL values among them
+  std::mutex pay_mu;
+  uint32_t* pay_cnt = nullptr;
+  int64_t* pay_wsum = nullptr;
+  uint32_t* pay_wnn = nullptr;
+  const void* pay_col = nullptr;
+  int pay_has_nulls = 0;
+  float pay_build_ms = 0.f;
 };
 
 struct mi355q_result {
@@ -1089,7 +1099,8 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   FragView fv{d_cols, d_rows, in->col_buffers, in->num_rows, nf, nc, total_rows, max_frag_rows};
 
   // ---- plan-time kernel selection (a fixed family; no JIT)
-  enum { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART } kind = K_GENERIC;
+  enum { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART, K_JOIN_PROBE } kind = K_GENERIC;
+  JoinPayloadView pay{};
   if (!o.force_generic && nf > 0) {
     if (scan_count_eligible(d, fv)) kind = K_SCAN_COUNT;
     else if (perfect_lds_eligible(d, fv)) kind = K_PERFECT_LDS;
@@ -1102,10 +1113,63 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
       kind = K_JOIN_PART;
   }
 
+  // joins that read the inner side / one-to-many tables / LEFT joins over a large outer table: the
+  // payload probe (per-key aggregated payload of the perfect table in LDS).  The semi-join shapes
+  // keep their 1-bit-per-key member above.
+  if (!o.force_generic && nf > 0 && kind != K_JOIN_PART && o.kernel_variant != 1 && plan->join_table &&
+      d.join_col >= 0 && (o.kernel_variant == 3 || total_rows >= ((int64_t)16 << 20))) {
+    int wcol = -1;
+    if (join_probe_wants(d, fv, &wcol)) {
+      mi355q_join_table* jt = const_cast<mi355q_join_table*>(plan->join_table);
+      const void* inner = wcol >= 0 ? (const void*)d.inner_cols[wcol] : nullptr;
+      std::lock_guard<std::mutex> pl(jt->pay_mu);
+      const int64_t entries = jt->entry_count;
+      bool ok = true;
+      if (!jt->pay_cnt || (inner && jt->pay_col != inner)) {
+        // (re)build: counts always, sums for this inner column
+        hipEvent_t b0 = nullptr, b1 = nullptr;
+        (void)hipEventCreate(&b0);
+        (void)hipEventCreate(&b1);
+        DevWord flags;
+        ok = hipMalloc(&flags.p, 64) == hipSuccess;
+        if (ok && !jt->pay_cnt) ok = hipMalloc((void**)&jt->pay_cnt, (size_t)entries * 4) == hipSuccess;
+        if (ok && inner && !jt->pay_wsum) ok = hipMalloc((void**)&jt->pay_wsum, (size_t)entries * 8) == hipSuccess;
+        if (ok && inner && !jt->pay_wnn) ok = hipMalloc((void**)&jt->pay_wnn, (size_t)entries * 4) == hipSuccess;
+        if (ok) {
+          (void)hipMemsetAsync(flags.p, 0, 64, s);
+          if (b0) (void)hipEventRecord(b0, s);
+          ok = launch_join_payload_build(jt->buf, jt->hash_type, entries, inner, jt->pay_cnt, jt->pay_wsum, jt->pay_wnn,
+                                         (int32_t*)flags.p, n_cus, s) == hipSuccess;
+          if (b1) (void)hipEventRecord(b1, s);
+          int32_t h_flags = 0;
+          ok = ok && hipMemcpyAsync(&h_flags, flags.p, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
+               hipStreamSynchronize(s) == hipSuccess;
+          if (ok) {
+            jt->pay_col = inner;
+            jt->pay_has_nulls = h_flags & 1;
+            if (b0 && b1) (void)hipEventElapsedTime(&jt->pay_build_ms, b0, b1);
+          }
+        }
+        if (b0) (void)hipEventDestroy(b0);
+        if (b1) (void)hipEventDestroy(b1);
+        if (!ok) (void)hipGetLastError();
+      }
+      if (ok) {
+        pay.cnt_k = jt->pay_cnt;
+        pay.wsum_k = inner ? jt->pay_wsum : nullptr;
+        pay.wnn_k = inner ? jt->pay_wnn : nullptr;
+        pay.inner_col = inner;
+        pay.entries = entries;
+        pay.has_nulls = jt->pay_has_nulls;
+        if (join_probe_supported(d, fv, pay, n_cus)) kind = K_JOIN_PROBE;
+      }
+    }
+  }
+
   tr.mark("setup done");
   int64_t scratch_bytes = 0;
   int64_t scratch_cap = o.scratch_bytes;
-  if (kind == K_BASELINE_FAST || kind == K_JOIN_PART) {
+  if (kind == K_BASELINE_FAST || kind == K_JOIN_PART || kind == K_JOIN_PROBE) {
     // default cap: kDefaultScratchCap, but never more than 70 % of what the device has free right now
     // (counting the scratch this context already holds), halved while the device cannot provide it
     // (the planner then cuts the input into more chunks)
@@ -1117,8 +1181,13 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
       }
     }
     for (;;) {
-      scratch_bytes = kind == K_JOIN_PART ? join_part_scratch_bytes(d, fv, n_cus, scratch_cap)
-                                          : baseline_fast_scratch_bytes(d, fv, o.kernel_variant, scratch_cap, n_cus);
+      scratch_bytes = kind == K_JOIN_PART    ? join_part_scratch_bytes(d, fv, n_cus, scratch_cap)
+                      : kind == K_JOIN_PROBE ? join_probe_scratch_bytes(d, fv, pay, n_cus, scratch_cap)
+                                             : baseline_fast_scratch_bytes(d, fv, o.kernel_variant, scratch_cap, n_cus);
+      if (kind == K_JOIN_PROBE && scratch_bytes == 0) {  // no plan within this cap: the row kernel
+        kind = join_sum_eligible(d, fv) ? K_JOIN_SUM : K_GENERIC;
+        break;
+      }
       if (kind == K_JOIN_PART && scratch_bytes == 0) {  // no plan within this cap: direct probe
         kind = K_JOIN_SUM;
         break;
@@ -1168,6 +1237,10 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         HIP_TRY(launch_join_partitioned(d, fv, res->buf, d_err, ctx.scratch, ctx.scratch_bytes, scratch_cap, n_cus,
                                         s, &st));
         break;
+      case K_JOIN_PROBE:
+        HIP_TRY(launch_join_probe(d, fv, pay, res->buf, d_err, ctx.scratch, ctx.scratch_bytes, scratch_cap, n_cus, s,
+                                  &st));
+        break;
       default:
         st.kernel_name = "k_generic";
         st.n_launches = 1;
@@ -1195,6 +1268,16 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
     HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
     HIP_TRY(launch_join_sum(d, fv, res->buf, n_cus, s, &st));
+    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (h_err[1] && kind == K_JOIN_PROBE) {
+    // the payload probe ran out of spill space (extreme skew): redo the step with the row kernel
+    HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
+    HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+    HIP_TRY(launch_generic(d, q.idx_target_as_key, make_row_init(q), d_cols, d_rows, nf, max_frag_rows, res->buf, d_err,
+                           n_cus, s));
+    st.kernel_name = "k_generic";
     HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
@@ -1388,10 +1471,13 @@ int32_t mi355q_join_key_shape(const mi355q_join_table* t, int32_t* key_component
 
 void mi355q_join_free(mi355q_join_table* t) {
   if (!t) return;
-  if (t->buf || t->bitmap) {
+  if (t->buf || t->bitmap || t->pay_cnt) {
     DeviceGuard g(t->device_id);
     if (t->buf) (void)hipFree(t->buf);
     if (t->bitmap) (void)hipFree(t->bitmap);
+    if (t->pay_cnt) (void)hipFree(t->pay_cnt);
+    if (t->pay_wsum) (void)hipFree(t->pay_wsum);
+    if (t->pay_wnn) (void)hipFree(t->pay_wnn);
   }
   delete t;
 }

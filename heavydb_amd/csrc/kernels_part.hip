@@ -1318,6 +1318,257 @@ __global__ __launch_bounds__(256) void k_join_spill(JoinPartArgs a, SpillList sl
   join_part_epilogue(a, sum, n_match, n_nn, out, s_red);
 }
 
+// ------------------------------------------------------------------------- payload probe
+// Joins whose targets READ the inner side — SUM / COUNT of an inner column, one-to-many tables
+// (one joined row per match), LEFT joins — through the same radix route as the semi-join above.
+// What makes it possible is an aggregate pushed into the join table: the non-grouped targets only
+// need, per key k of a perfect-hash table,
+//     cnt[k]   rows of the inner table with that key           (0 / 1 for a one-to-one table)
+//     wsum[k]  the sum of the inner column over those rows, NULLs skipped
+//     wnn[k]   how many of them are not NULL
+// because  COUNT(*) = sum_rows cnt[key],  SUM(fact.v) = sum_rows v * cnt[key],
+// SUM(dim.w) = sum_rows wsum[key],  COUNT(dim.w) = sum_rows wnn[key]  — exactly what one joined row
+// per match (hash_join_idx / the one-to-many loop, JoinHashTableQueryRuntime.cpp:56-163,
+// HashJoinRuntime.cpp:654-1110) adds up to, integer arithmetic, any order.  The arrays are built once
+// per (join table, inner column) from the reference-layout table (k_join_payload) and cached on the
+// join handle; phase 2 keeps a partition's slice of them in LDS (4-16 bytes per key), so a probe costs
+// LDS reads instead of 2-5 dependent random HBM reads (offsets, counts, payload run, inner column).
+// LEFT joins add the unmatched outer rows afterwards from totals over the whole outer table:
+//     COUNT(*) = J + (N - M),  SUM(fact.v) = SVc + (SV_all - SVm)   (J joined rows, M matched outer rows).
+struct ProbeArgs {
+  int32_t P, B, R;
+  uint32_t cap, S1, S2;    // run capacity; keys per partition; keys per sub-range (multiple of 32)
+  int64_t kmin;
+  uint64_t range;          // max - min + 1
+  const uint32_t* cnt_k;   // [range]
+  const int64_t* wsum_k;   // [range] or null
+  const uint32_t* wnn_k;   // [range] or null (inner column NOT NULL: wnn = cnt)
+  int64_t null_sum;        // NULL_BIGINT: skipped by the non-grouped SUM over the outer value
+};
+// accumulators (device words, wrapping 64-bit adds)
+enum ProbeAcc { PA_J = 0, PA_M, PA_SVC, PA_SVM, PA_NNVC, PA_NNVM, PA_SW, PA_NNW, PA_N };
+
+MQ_D void probe_reduce_store(unsigned long long* acc, const unsigned long long* v, unsigned long long* s_red) {
+  const int wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6, lane = threadIdx.x & 63;
+  for (int k = 0; k < PA_N; ++k) {
+    unsigned long long x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    if (lane == 0) s_red[wave * PA_N + k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < PA_N) {
+    unsigned long long tot = 0;
+    for (int w = 0; w < n_waves; ++w) tot += s_red[w * PA_N + threadIdx.x];
+    if (tot) atomicAdd(acc + threadIdx.x, tot);
+  }
+}
+
+__global__ __launch_bounds__(kPartBlock) void k_part_probe(ProbeArgs a, const Rec* __restrict__ scratch,
+                                                            const uint32_t* __restrict__ cnt,
+                                                            unsigned long long* __restrict__ acc) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  // LDS slice of one unit: wsum[S2] (8 B) | cnt[S2] | wnn[S2] | reduction scratch
+  int64_t* s_ws = (int64_t*)smem_raw;
+  uint32_t* s_cnt = (uint32_t*)(smem_raw + (a.wsum_k ? (size_t)a.S2 * 8 : 0));
+  uint32_t* s_nn = s_cnt + a.S2;
+  unsigned long long* s_red = (unsigned long long*)(s_nn + (a.wnn_k ? a.S2 : 0));
+  const int t = threadIdx.x;
+  unsigned long long v[PA_N];
+  for (int k = 0; k < PA_N; ++k) v[k] = 0;
+  const int units = a.P * a.R;
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int p = u / a.R, r = u % a.R;
+    const uint64_t off0 = (uint64_t)p * a.S1 + (uint64_t)r * a.S2;  // first key offset of the unit
+    uint32_t nk = a.S2;                                             // keys of this unit
+    if ((uint64_t)r * a.S2 + nk > a.S1) nk = a.S1 > (uint64_t)r * a.S2 ? (uint32_t)(a.S1 - (uint64_t)r * a.S2) : 0u;
+    for (uint32_t i = t; i < a.S2; i += kPartBlock) {
+      const bool live = i < nk && off0 + i < a.range;
+      s_cnt[i] = live ? a.cnt_k[off0 + i] : 0u;
+      if (a.wsum_k) s_ws[i] = live ? a.wsum_k[off0 + i] : 0;
+      if (a.wnn_k) s_nn[i] = live ? a.wnn_k[off0 + i] : 0u;
+    }
+    __syncthreads();
+    const int64_t base = a.kmin + (int64_t)off0;
+    for (int b = 0; b < a.B; ++b) {
+      const uint32_t n = cnt[(size_t)p * a.B + b];
+      const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
+      for (uint32_t i0 = 0; i0 < n; i0 += 4 * kPartBlock) {
+        Rec rec[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // four independent 16-byte loads in flight per lane
+          const uint32_t i = i0 + q * kPartBlock + t;
+          rec[q] = i < n ? load_rec_nt(run + i) : Rec{base - 1, 0};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t x = (uint32_t)(rec[q].key - base);
+          if (x < nk) {
+            const unsigned long long c = s_cnt[x];
+            if (c) {
+              const bool nn = rec[q].val != a.null_sum;
+              v[PA_J] += c;
+              v[PA_M] += 1;
+              if (nn) {
+                v[PA_SVC] += (unsigned long long)rec[q].val * c;
+                v[PA_SVM] += (unsigned long long)rec[q].val;
+                v[PA_NNVC] += c;
+                v[PA_NNVM] += 1;
+              }
+              if (a.wsum_k) v[PA_SW] += (unsigned long long)s_ws[x];
+              v[PA_NNW] += a.wnn_k ? (unsigned long long)s_nn[x] : c;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  probe_reduce_store(acc, v, s_red);
+}
+
+// run overflows and heavy-hitter partial rows {key, SUM(v) partial, COUNT partial, COUNT_NN partial}
+// against the global arrays
+__global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long s_red[4 * PA_N];
+  uint32_t n = *sl.count;
+  if (n > sl.cap) n = sl.cap;
+  unsigned long long v[PA_N];
+  for (int k = 0; k < PA_N; ++k) v[k] = 0;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int64_t* e = sl.entries + (size_t)i * sl.stride;
+    const int64_t key = e[0];
+    if (key == kEmptyKey64) continue;
+    const uint64_t off = (uint64_t)key - (uint64_t)a.kmin;
+    if (off >= a.range) continue;
+    const unsigned long long c = a.cnt_k[off];
+    if (!c) continue;
+    const unsigned long long rows = (unsigned long long)e[2], rows_nn = (unsigned long long)e[3];
+    v[PA_J] += rows * c;
+    v[PA_M] += rows;
+    v[PA_SVC] += (unsigned long long)e[1] * c;
+    v[PA_SVM] += (unsigned long long)e[1];
+    v[PA_NNVC] += rows_nn * c;
+    v[PA_NNVM] += rows_nn;
+    if (a.wsum_k) v[PA_SW] += rows * (unsigned long long)a.wsum_k[off];
+    v[PA_NNW] += rows * (a.wnn_k ? (unsigned long long)a.wnn_k[off] : c);
+  }
+  probe_reduce_store(acc, v, s_red);
+}
+
+// totals over the whole outer value column (LEFT joins): acc2 = {sum of non-NULL values, their count}
+template <typename VT>
+__global__ __launch_bounds__(256) void k_outer_totals(const int8_t* const* __restrict__ cols,
+                                                      const int64_t* __restrict__ num_rows, int n_frags, int n_cols,
+                                                      int vcol, int64_t null_sum, unsigned long long* __restrict__ acc2) {
+  __shared__ unsigned long long s_red[4 * 2];
+  unsigned long long sum = 0, nn = 0;
+  scan_fragments<none_t, none_t, VT>(cols, num_rows, n_frags, n_cols, 0, 0, vcol, [&](none_t, none_t, VT val) {
+    const int64_t x = (int64_t)val;
+    if (x != null_sum) {
+      sum += (unsigned long long)x;
+      ++nn;
+    }
+  });
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off, 64);
+    nn += __shfl_down(nn, off, 64);
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    s_red[wave * 2] = sum;
+    s_red[wave * 2 + 1] = nn;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned long long tot = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) tot += s_red[w * 2 + threadIdx.x];
+    if (tot) atomicAdd(acc2 + threadIdx.x, tot);
+  }
+}
+
+// the output slots from the accumulators (one thread).  op: 0 COUNT(*), 1 SUM(outer v), 2 SUM(inner w),
+// 3 COUNT(outer v), 4 COUNT(inner w).  A non-grouped SUM that saw no value stays NULL (skip_val
+// aggregates start at the sentinel, OutputBufferInitialization.cpp:79-81).
+struct ProbeFinish {
+  int32_t n_slots, left;
+  int32_t op[4];
+  int64_t n_outer_rows;    // N
+  int64_t null_sum;
+};
+__global__ void k_probe_finish(ProbeFinish f, const unsigned long long* __restrict__ acc,
+                               const unsigned long long* __restrict__ acc2, int64_t* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  const unsigned long long J = acc[PA_J], M = acc[PA_M];
+  unsigned long long sv = acc[PA_SVC], nnv = acc[PA_NNVC];
+  unsigned long long rows = J;
+  if (f.left) {  // every unmatched outer row appears once, inner columns NULL
+    rows = J + ((unsigned long long)f.n_outer_rows - M);
+    sv = acc[PA_SVC] + (acc2[0] - acc[PA_SVM]);
+    nnv = acc[PA_NNVC] + (acc2[1] - acc[PA_NNVM]);
+  }
+  for (int j = 0; j < f.n_slots; ++j) {
+    switch (f.op[j]) {
+      case 0: out[j] = (int64_t)rows; break;
+      case 1: out[j] = nnv ? (int64_t)sv : f.null_sum; break;
+      case 2: out[j] = acc[PA_NNW] ? (int64_t)acc[PA_SW] : f.null_sum; break;
+      case 3: out[j] = (int64_t)nnv; break;
+      default: out[j] = (int64_t)acc[PA_NNW]; break;
+    }
+  }
+}
+
+// cnt / wsum / wnn of every key slot of a perfect-hash join table (layouts: include/mi355q.h):
+// one-to-one `int32 slot[entries]` (-1 empty), one-to-many `offsets | counts | payloads`.
+// flags[0] is set when some matching inner value is NULL (then wnn differs from cnt and has to be
+// carried along).  w == nullptr: only the counts are wanted.
+__global__ __launch_bounds__(256) void k_join_payload(const int32_t* __restrict__ table, int hash_type,
+                                                      int64_t entries, const int64_t* __restrict__ w,
+                                                      uint32_t* __restrict__ cnt_k, int64_t* __restrict__ wsum_k,
+                                                      uint32_t* __restrict__ wnn_k, int32_t* __restrict__ flags) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool any_null = false;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < entries; x += stride) {
+    uint32_t c = 0, nn = 0;
+    unsigned long long sum = 0;
+    if (hash_type == 0) {
+      const int32_t id = table[x];
+      if (id >= 0) {
+        c = 1;
+        if (w) {
+          const int64_t v = w[id];
+          if (v != INT64_MIN) {
+            sum = (unsigned long long)v;
+            nn = 1;
+          }
+        }
+      }
+    } else {
+      const int32_t off = table[x];
+      const int32_t n = table[entries + x];
+      if (off >= 0 && n > 0) {
+        c = (uint32_t)n;
+        if (w) {
+          const int32_t* ids = table + 2 * entries + off;
+          for (int32_t i = 0; i < n; ++i) {
+            const int64_t v = w[ids[i]];
+            if (v != INT64_MIN) {
+              sum += (unsigned long long)v;
+              ++nn;
+            }
+          }
+        }
+      }
+    }
+    cnt_k[x] = c;
+    if (w) {
+      wsum_k[x] = (int64_t)sum;
+      wnn_k[x] = nn;
+      any_null |= nn != c;
+    }
+  }
+  if (__any(any_null) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+}
+
 struct PartPlanHost {
   PartGeom g;
   PartSlots ps;
@@ -1460,7 +1711,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     if (cap > 0x7fffffffull) return false;
     if ((uint64_t)P * h.g.B * cap >= ((uint64_t)1 << 32)) {  // 32-bit record indices in phase 1
       if (chunk_rows <= fv.max_frag_rows) return false;
-      chunk_rows = (int64_t)(chunk_rows * 0.9);
+      chunk_rows = (int64_t)(chunk_rows * 0.97);
       if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
       continue;
     }
@@ -1476,7 +1727,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     const int64_t spill_bytes = 256 + spill_cap * 8 * (int64_t)(1 + n_int);
     h.scratch_bytes = h.rec_bytes + h.cnt_bytes + spill_bytes;
     if (h.scratch_bytes <= scratch_cap || chunk_rows <= fv.max_frag_rows) break;
-    chunk_rows = (int64_t)(chunk_rows * 0.9);
+    chunk_rows = (int64_t)(chunk_rows * 0.97);
     if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
   }
   // equal-sized chunks: 10 B rows under a 3.4 B-row limit are three chunks of 3.3 B, not two full
@@ -1754,7 +2005,7 @@ bool make_join_part_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_
       break;
     }
     if (chunk_rows <= fv.max_frag_rows) return false;
-    chunk_rows = (int64_t)(chunk_rows * 0.9);
+    chunk_rows = (int64_t)(chunk_rows * 0.97);
     if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
   }
   h.chunk_rows = chunk_rows;
@@ -1847,6 +2098,271 @@ hipError_t launch_join_partitioned(const DevPlan& p, const FragView& fv, int64_t
     if (e != hipSuccess) return e;
     f = f1;
   }
+  st->spill_counter32 = (uint32_t*)spill_base;
+  st->n_events_used = ev_i;
+  return hipSuccess;
+}
+
+// ---------------------------------------------------------------- payload probe: host side
+hipError_t launch_join_payload_build(const void* table, int hash_type, int64_t entries, const void* inner_col,
+                                     uint32_t* cnt_k, int64_t* wsum_k, uint32_t* wnn_k, int32_t* d_flags,
+                                     int n_cus, hipStream_t s) {
+  int64_t blocks = (entries + 255) / 256;
+  if (blocks > (int64_t)n_cus * 16) blocks = (int64_t)n_cus * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_join_payload, dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t*)table, hash_type, entries,
+                     (const int64_t*)inner_col, cnt_k, wsum_k, wnn_k, d_flags);
+  return hipGetLastError();
+}
+
+namespace {
+
+struct ProbePartHost {
+  ScatterArgs sa;
+  ProbeArgs pa;
+  ProbeFinish fin;
+  int64_t chunk_rows, rec_bytes, cnt_bytes, scratch_bytes;
+  size_t lds1, lds2;
+  uint32_t spill_cap;
+  int vcol;    // outer value column or -1
+  int wcol;    // inner column or -1
+};
+
+constexpr size_t kProbeLdsBudget = 144 * 1024;
+
+// plan shapes: non-grouped, no quals, perfect-hash table (one-to-one or one-to-many), one NOT NULL
+// int64 key, INNER or LEFT; targets COUNT(*), SUM / COUNT of ONE plain int64 outer column and of ONE
+// plain int64 inner column
+bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus, int64_t scratch_cap,
+                     ProbePartHost* out) {
+  ProbePartHost& h = *out;
+  if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col < 0 || p.n_quals != 0) return false;
+  if ((p.join_hash_type != 0 && p.join_hash_type != 2) || p.join_n_keys != 1) return false;
+  if (p.join_kind != MI355Q_JOIN_INNER && p.join_kind != MI355Q_JOIN_LEFT) return false;
+  if (p.join_type != MI355Q_INT64 || p.join_nullable || p.n_targets > 4) return false;
+  if (fv.max_frag_rows > 0xfff00000ll) return false;
+  h.vcol = h.wcol = -1;
+  h.fin = ProbeFinish{};
+  h.fin.n_slots = p.n_targets;
+  h.fin.left = p.join_kind == MI355Q_JOIN_LEFT;
+  h.fin.n_outer_rows = fv.total_rows;
+  h.fin.null_sum = INT64_MIN;
+  for (int i = 0; i < p.n_targets; ++i) {
+    const DevTarget& t = p.targets[i];
+    if (t.slot != i) return false;
+    if (t.agg == MI355Q_COUNT && t.col < 0) {
+      h.fin.op[i] = 0;
+      continue;
+    }
+    if ((t.agg != MI355Q_SUM && t.agg != MI355Q_COUNT) || t.arg_type != MI355Q_INT64) return false;
+    if (t.table == 0) {
+      if (h.vcol >= 0 && h.vcol != t.col) return false;
+      h.vcol = t.col;
+      h.fin.op[i] = t.agg == MI355Q_SUM ? 1 : 3;
+    } else {
+      if (h.wcol >= 0 && h.wcol != t.col) return false;
+      h.wcol = t.col;
+      h.fin.op[i] = t.agg == MI355Q_SUM ? 2 : 4;
+    }
+  }
+  if (!all_aligned16(fv, p.join_col) || (h.vcol >= 0 && !all_aligned16(fv, h.vcol))) return false;
+  const __int128 range128 = (__int128)p.join_max - (__int128)p.join_min + 1;
+  if (range128 < 64 || range128 >= ((__int128)1 << 32)) return false;
+  const uint64_t range = (uint64_t)range128;
+  // the payload arrays must be there for exactly this inner column (api.cpp builds them first)
+  if (!pay.cnt_k || pay.entries != (int64_t)range) return false;
+  if (h.wcol >= 0 && (!pay.wsum_k || pay.inner_col != (const void*)p.inner_cols[h.wcol])) return false;
+  const bool need_nn = h.wcol >= 0 && pay.has_nulls;
+  const size_t entry_bytes = 4 + (h.wcol >= 0 ? 8 : 0) + (need_nn ? 4 : 0);
+  uint32_t P = 16;
+  auto s1_of = [&](uint32_t parts) { return (uint32_t)((((range + parts - 1) / parts) + 31) & ~(uint64_t)31); };
+  while (P < 1024 && (P < 4 * (uint32_t)n_cus || (size_t)s1_of(P) * entry_bytes > kProbeLdsBudget) && s1_of(P * 2) >= 64) P <<= 1;
+  const uint32_t S1 = s1_of(P);
+  if (S1 < 32) return false;
+  uint32_t R = (uint32_t)(((size_t)S1 * entry_bytes + kProbeLdsBudget - 1) / kProbeLdsBudget);
+  if (R < 1) R = 1;
+  if (R > 3) return false;  // every sub-range re-reads the partition's records: beyond 3 the direct probe wins
+  const uint32_t S2 = (uint32_t)((((uint64_t)S1 + R - 1) / R + 31) & ~(uint64_t)31);
+  ScatterArgs& sa = h.sa;
+  sa = ScatterArgs{};
+  sa.P = (int32_t)P;
+  sa.L = kStageRecs / P;
+  sa.lgL = 0;
+  while ((1u << sa.lgL) < sa.L) ++sa.lgL;
+  sa.B = n_cus;
+  sa.hm.d = (uint32_t)range;
+  sa.hm.S1 = S1;
+  sa.hm.S2 = S1;
+  sa.hm.R = 1;
+  sa.hm.d_rcp = (uint32_t)(((uint64_t)1 << 32) / sa.hm.d);
+  sa.hm.s1_rcp = (uint32_t)(((uint64_t)1 << 32) / S1);
+  sa.kmin = p.join_min;
+  sa.ns_int = 3;  // spilled / heavy-hitter partial rows: SUM, COUNT, COUNT of non-NULL values
+  sa.ops_packed = (uint32_t)SO_SUM_I | ((uint32_t)SO_COUNT << 4) | ((uint32_t)SO_COUNT_NN << 8);
+  sa.val_nullable = 1;
+  sa.null_bits = INT64_MIN;
+  int64_t chunk_rows = fv.total_rows > 0 ? fv.total_rows : 1;
+  if (chunk_rows > 0xfff00000ll) chunk_rows = 0xfff00000ll;
+  if (scratch_cap <= 0) scratch_cap = kDefaultScratchCap;
+  for (;;) {
+    const double per_run = (double)chunk_rows / ((double)P * sa.B);
+    uint64_t cap = (uint64_t)(per_run * 1.2 + 6.0 * __builtin_sqrt(per_run + 1.0)) + sa.L;
+    cap = (cap + sa.L - 1) / sa.L * sa.L;
+    const bool too_many = cap > 0x7fffffffull || (uint64_t)P * sa.B * cap >= ((uint64_t)1 << 32);
+    int64_t spill_cap = chunk_rows / 16;
+    if (spill_cap < (int64_t)kSpillMin) spill_cap = kSpillMin;
+    if (spill_cap > 0x7fffffffll) spill_cap = 0x7fffffffll;
+    h.rec_bytes = (int64_t)P * sa.B * (int64_t)cap * (int64_t)sizeof(Rec);
+    h.cnt_bytes = ((int64_t)P * sa.B * 4 + 255) & ~255ll;
+    const int64_t spill_bytes = 256 + spill_cap * 8 * (int64_t)(1 + sa.ns_int);
+    h.scratch_bytes = h.rec_bytes + h.cnt_bytes + spill_bytes;
+    if (!too_many && (h.scratch_bytes <= scratch_cap || chunk_rows <= fv.max_frag_rows)) {
+      sa.cap = (uint32_t)cap;
+      h.spill_cap = (uint32_t)spill_cap;
+      break;
+    }
+    if (chunk_rows <= fv.max_frag_rows) return false;
+    chunk_rows = (int64_t)(chunk_rows * 0.97);
+    if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
+  }
+  if (fv.total_rows > chunk_rows) {
+    const int64_t n_chunks = (fv.total_rows + chunk_rows - 1) / chunk_rows;
+    const int64_t even = (fv.total_rows + n_chunks - 1) / n_chunks + fv.max_frag_rows;
+    if (even < chunk_rows) chunk_rows = even;
+  }
+  h.chunk_rows = chunk_rows;
+  {
+    const size_t fixed = kStageRecs * sizeof(Rec) + (size_t)P * 12 + 48 + (size_t)kHotSlots * (8 + 8 * (size_t)sa.ns_int);
+    sa.n_cand = 2048;
+    while (sa.n_cand > 64 && fixed + (size_t)sa.n_cand * 4 > 160 * 1024) sa.n_cand >>= 1;
+    h.lds1 = fixed + (size_t)sa.n_cand * 4;
+    if (h.lds1 > 160 * 1024) return false;
+  }
+  h.lds2 = (size_t)S2 * entry_bytes + (size_t)16 * PA_N * 8 + 64;
+  if (h.lds2 > 160 * 1024) return false;
+  ProbeArgs& pa = h.pa;
+  pa = ProbeArgs{};
+  pa.P = (int32_t)P;
+  pa.B = sa.B;
+  pa.R = (int32_t)R;
+  pa.cap = sa.cap;
+  pa.S1 = S1;
+  pa.S2 = S2;
+  pa.kmin = p.join_min;
+  pa.range = range;
+  pa.cnt_k = pay.cnt_k;
+  pa.wsum_k = h.wcol >= 0 ? pay.wsum_k : nullptr;
+  pa.wnn_k = need_nn ? pay.wnn_k : nullptr;
+  pa.null_sum = INT64_MIN;
+  return true;
+}
+
+}  // namespace
+
+bool join_probe_supported(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus) {
+  ProbePartHost h;
+  return make_probe_plan(p, fv, pay, n_cus, kDefaultScratchCap, &h);
+}
+
+// which inner column (if any) the payload of this plan has to be built for; false = shape not taken
+bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col) {
+  JoinPayloadView fake{};
+  const __int128 range128 = (__int128)p.join_max - (__int128)p.join_min + 1;
+  if (range128 < 64 || range128 >= ((__int128)1 << 32)) return false;
+  fake.entries = (int64_t)range128;
+  fake.cnt_k = (const uint32_t*)16;  // shape test only: the pointers are not followed
+  fake.wsum_k = (const int64_t*)16;
+  fake.wnn_k = (const uint32_t*)16;
+  fake.has_nulls = 1;
+  int wcol = -1;
+  for (int i = 0; i < p.n_targets; ++i)
+    if (p.targets[i].table == 1 && p.targets[i].col >= 0) wcol = p.targets[i].col;
+  fake.inner_col = wcol >= 0 ? (const void*)p.inner_cols[wcol] : nullptr;
+  ProbePartHost h;
+  if (!make_probe_plan(p, fv, fake, 256, kDefaultScratchCap, &h)) return false;
+  *inner_col = h.wcol;
+  return true;
+}
+
+int64_t join_probe_scratch_bytes(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus,
+                                 int64_t cap_bytes) {
+  ProbePartHost h;
+  if (!make_probe_plan(p, fv, pay, n_cus, cap_bytes, &h)) return 0;
+  return h.scratch_bytes + 64 + 256;
+}
+
+hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int64_t* out,
+                             int32_t* d_err, void* scratch, int64_t scratch_bytes, int64_t cap_bytes, int n_cus,
+                             hipStream_t s, LaunchStats* st) {
+  ProbePartHost h;
+  if (!make_probe_plan(p, fv, pay, n_cus, cap_bytes, &h)) return hipErrorInvalidValue;
+  if (h.scratch_bytes + 64 + 256 > scratch_bytes) return hipErrorInvalidValue;
+  Rec* recs = (Rec*)scratch;
+  uint32_t* cnt = (uint32_t*)((char*)scratch + h.rec_bytes);
+  char* spill_base = (char*)scratch + h.rec_bytes + h.cnt_bytes;
+  SpillList sl{(uint32_t*)spill_base, (int64_t*)(spill_base + 256), d_err, h.spill_cap, 1 + h.sa.ns_int};
+  // accumulators live behind the spill list
+  unsigned long long* acc = (unsigned long long*)((char*)scratch + h.scratch_bytes + 64 - 64);
+  acc = (unsigned long long*)(((uintptr_t)acc + 63) & ~(uintptr_t)63);
+  unsigned long long* acc2 = acc + PA_N;
+  hipError_t e = hipMemsetAsync(acc, 0, (PA_N + 2) * 8, s);
+  if (e != hipSuccess) return e;
+  st->kernel_name = "k_part_scatter";
+  st->variant = 3;
+  st->n_launches = 0;
+  (void)hipFuncSetAttribute((const void*)k_part_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds2);
+  RangeFilter flt = no_filter();
+  const int vcol = h.vcol < 0 ? 0 : h.vcol;
+  int ev_i = 0;
+  int f = 0;
+  while (f < fv.n_frags) {
+    int64_t rows = 0;
+    int f1 = f;
+    while (f1 < fv.n_frags && (f1 == f || rows + fv.h_num_rows[f1] <= h.chunk_rows)) {
+      rows += fv.h_num_rows[f1];
+      ++f1;
+    }
+    e = hipMemsetAsync(spill_base, 0, 256, s);
+    if (e != hipSuccess) return e;
+    if (st->ev_pool && ev_i + 1 < st->n_ev) (void)hipEventRecord(st->ev_pool[ev_i], s);
+    const int8_t* const* cols = fv.d_cols + (size_t)f * fv.n_cols;
+    const int64_t* nrows = fv.d_num_rows + f;
+    if (h.vcol >= 0) {
+      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, int64_t, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
+      hipLaunchKernelGGL((k_part_scatter<none_t, int64_t, true>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
+                         nrows, f1 - f, fv.n_cols, flt, p.join_col, vcol, h.sa, recs, cnt, sl);
+    } else {
+      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, none_t, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
+      hipLaunchKernelGGL((k_part_scatter<none_t, none_t, true>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
+                         nrows, f1 - f, fv.n_cols, flt, p.join_col, vcol, h.sa, recs, cnt, sl);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (st->ev_pool && ev_i + 1 < st->n_ev) {
+      (void)hipEventRecord(st->ev_pool[ev_i + 1], s);
+      ev_i += 2;
+    }
+    st->n_launches += 1;
+    const int units = h.pa.P * h.pa.R;
+    const int grid2 = units < n_cus ? units : n_cus;
+    hipLaunchKernelGGL(k_part_probe, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.pa, recs, cnt, acc);
+    hipLaunchKernelGGL(k_probe_spill, dim3(256), dim3(256), 0, s, h.pa, sl, acc);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    f = f1;
+  }
+  if (h.fin.left && h.vcol >= 0) {
+    int64_t want = (fv.total_rows / 4 + kBlock - 1) / kBlock;
+    if (want < 1) want = 1;
+    const int grid = (int)(want < (int64_t)n_cus * 2 ? want : (int64_t)n_cus * 2);
+    hipLaunchKernelGGL(k_outer_totals<int64_t>, dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags,
+                       fv.n_cols, h.vcol, (int64_t)INT64_MIN, acc2);
+  }
+  hipLaunchKernelGGL(k_probe_finish, dim3(1), dim3(64), 0, s, h.fin, acc, acc2, out);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
   st->spill_counter32 = (uint32_t*)spill_base;
   st->n_events_used = ev_i;
   return hipSuccess;

@@ -47,6 +47,10 @@ def _threads(orc, table_bytes: int) -> int:
 
 
 def _free_gb(torch) -> float:
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()  # earlier tests of the session may have left hundreds of GB in torch's cache
+    capi.load_library().mi355q_release_workspace(0)  # ... and tens of GB of partition scratch in the library
     free, _ = torch.cuda.mem_get_info(0)
     return free / 2**30
 
