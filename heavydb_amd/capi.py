@@ -25,6 +25,12 @@ ENC_NONE, ENC_FIXED, ENC_DICT, ENC_DATE_IN_DAYS = 0, 1, 2, 3
 # mi355q_op (SQLOps values)
 EQ, NE, LT, GT, LE, GE = 0, 2, 3, 4, 5, 6
 IS_NULL, IS_NOT_NULL = 16, 17  # unary quals (kISNULL, kISNOTNULL): no literal
+
+
+class OrderEntry(C.Structure):
+    """mi355q_order_entry (Analyzer::OrderEntry: tle_no - 1, is_desc, nulls_first)."""
+    _fields_ = [("target_idx", C.c_int32), ("descending", C.c_int32), ("nulls_first", C.c_int32),
+                ("reserved", C.c_int32)]
 # mi355q_agg (SQLAgg values)
 AVG, MIN, MAX, SUM, COUNT, PROJECT_KEY = 0, 1, 2, 3, 4, 100
 COUNT_IF, SUM_IF = 10, 11
@@ -213,6 +219,8 @@ SYMBOLS = [
     ("mi355q_result_free", None, [C.c_void_p]),
     ("mi355q_result_topk", C.c_int32,
      [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, _P(C.c_int64), C.c_void_p]),
+    ("mi355q_result_sort", C.c_int32,
+     [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, _P(C.c_int64), C.c_void_p]),
     ("mi355q_result_qmd", C.c_int32, [C.c_void_p, _P(QMD)]),
     ("mi355q_result_device_ptr", C.c_void_p, [C.c_void_p]),
     ("mi355q_result_bytes", C.c_int64, [C.c_void_p]),

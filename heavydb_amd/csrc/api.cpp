@@ -43,6 +43,10 @@ struct mi355q_join_table {
   uint32_t* pay_cnt = nullptr;
   int64_t* pay_wsum = nullptr;
   uint32_t* pay_wnn = nullptr;
+  void* pay16 = nullptr;         // the same as 16-byte entries (L2 mode of the probe)
+  const void* pay16_col = nullptr;
+  bool pay16_built = false;
+  int pay16_has_nulls = 0;
   const void* pay_col = nullptr;
   int pay_has_nulls = 0;
   float pay_build_ms = 0.f;
@@ -562,6 +566,41 @@ int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t d
   HIP_TRY(launch_topk(r->dplan, q.idx_target_as_key, target_idx, q.target_null[target_idx],
                       q.target_is_fp[target_idx] != 0, descending != 0, nulls_first != 0, r->buf, k,
                       scratch.p, (int64_t*)out_rows_dev, d_n, s));
+  HIP_TRY(hipMemcpyAsync(n_rows, d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return MI355Q_OK;
+}
+
+int32_t mi355q_result_sort(const mi355q_result* r, const mi355q_order_entry* order, int32_t n_order,
+                           int64_t limit, int64_t offset, void* out_rows_dev, int64_t* n_rows, void* stream) {
+  if (!r || !order || !out_rows_dev || !n_rows || n_order < 1 || n_order > MI355Q_MAX_TARGETS || limit < 0 ||
+      offset < 0)
+    return MI355Q_ERR_INVALID_PLAN;
+  if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return MI355Q_ERR_UNSUPPORTED;
+  SortOrderEntry oe[MI355Q_MAX_TARGETS];
+  for (int i = 0; i < n_order; ++i) {
+    const int t = order[i].target_idx;
+    if (t < 0 || t >= r->qmd.n_targets) return MI355Q_ERR_INVALID_PLAN;
+    // ordering by a floating-point KEY projection (read from the key column) is not built
+    if (r->qmd.target_agg[t] == MI355Q_PROJECT_KEY && r->qmd.target_is_fp[t]) return MI355Q_ERR_UNSUPPORTED;
+    oe[i] = SortOrderEntry{t, order[i].descending != 0, order[i].nulls_first != 0, r->qmd.target_is_fp[t] != 0,
+                           r->qmd.target_null[t]};
+  }
+  if (r->qmd.output_columnar) {  // the rows come out row-wise (row_size bytes each)
+    RowTwin t;
+    if (int32_t e = make_row_twin(r, (hipStream_t)stream, &t)) return e;
+    return mi355q_result_sort(t.tw, order, n_order, limit, offset, out_rows_dev, n_rows, stream);
+  }
+  if (r->qmd.entry_count >= ((int64_t)1 << 32)) return MI355Q_ERR_UNSUPPORTED;
+  DeviceGuard g(r->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  hipStream_t s = (hipStream_t)stream;
+  DevWord scratch;
+  const int64_t sb = sort_scratch_bytes(r->qmd.entry_count);
+  HIP_TRY(hipMalloc(&scratch.p, (size_t)sb + 64));
+  int64_t* d_n = (int64_t*)((char*)scratch.p + sb);
+  HIP_TRY(launch_sort(r->dplan, r->qmd.idx_target_as_key, oe, n_order, r->buf, offset, limit, scratch.p,
+                      (int64_t*)out_rows_dev, d_n, s));
   HIP_TRY(hipMemcpyAsync(n_rows, d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
   HIP_TRY(hipStreamSynchronize(s));
   return MI355Q_OK;
@@ -1118,35 +1157,47 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   // keep their 1-bit-per-key member above.
   if (!o.force_generic && nf > 0 && kind != K_JOIN_PART && o.kernel_variant != 1 && plan->join_table &&
       d.join_col >= 0 && (o.kernel_variant == 3 || total_rows >= ((int64_t)16 << 20))) {
-    int wcol = -1;
-    if (join_probe_wants(d, fv, &wcol)) {
+    int wcol = -1, l2 = 0;
+    if (join_probe_wants(d, fv, &wcol, &l2)) {
       mi355q_join_table* jt = const_cast<mi355q_join_table*>(plan->join_table);
       const void* inner = wcol >= 0 ? (const void*)d.inner_cols[wcol] : nullptr;
       std::lock_guard<std::mutex> pl(jt->pay_mu);
       const int64_t entries = jt->entry_count;
       bool ok = true;
-      if (!jt->pay_cnt || (inner && jt->pay_col != inner)) {
-        // (re)build: counts always, sums for this inner column
+      const bool have = l2 ? (jt->pay16_built && (!inner || jt->pay16_col == inner))
+                           : (jt->pay_cnt && (!inner || jt->pay_col == inner));
+      if (!have) {
+        // (re)build for this inner column, in the layout the chosen mode reads
         hipEvent_t b0 = nullptr, b1 = nullptr;
         (void)hipEventCreate(&b0);
         (void)hipEventCreate(&b1);
         DevWord flags;
         ok = hipMalloc(&flags.p, 64) == hipSuccess;
-        if (ok && !jt->pay_cnt) ok = hipMalloc((void**)&jt->pay_cnt, (size_t)entries * 4) == hipSuccess;
-        if (ok && inner && !jt->pay_wsum) ok = hipMalloc((void**)&jt->pay_wsum, (size_t)entries * 8) == hipSuccess;
-        if (ok && inner && !jt->pay_wnn) ok = hipMalloc((void**)&jt->pay_wnn, (size_t)entries * 4) == hipSuccess;
+        if (l2) {
+          if (ok && !jt->pay16) ok = hipMalloc(&jt->pay16, (size_t)entries * 16) == hipSuccess;
+        } else {
+          if (ok && !jt->pay_cnt) ok = hipMalloc((void**)&jt->pay_cnt, (size_t)entries * 4) == hipSuccess;
+          if (ok && inner && !jt->pay_wsum) ok = hipMalloc((void**)&jt->pay_wsum, (size_t)entries * 8) == hipSuccess;
+          if (ok && inner && !jt->pay_wnn) ok = hipMalloc((void**)&jt->pay_wnn, (size_t)entries * 4) == hipSuccess;
+        }
         if (ok) {
           (void)hipMemsetAsync(flags.p, 0, 64, s);
           if (b0) (void)hipEventRecord(b0, s);
           ok = launch_join_payload_build(jt->buf, jt->hash_type, entries, inner, jt->pay_cnt, jt->pay_wsum, jt->pay_wnn,
-                                         (int32_t*)flags.p, n_cus, s) == hipSuccess;
+                                         l2 ? jt->pay16 : nullptr, (int32_t*)flags.p, n_cus, s) == hipSuccess;
           if (b1) (void)hipEventRecord(b1, s);
           int32_t h_flags = 0;
           ok = ok && hipMemcpyAsync(&h_flags, flags.p, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
                hipStreamSynchronize(s) == hipSuccess;
           if (ok) {
-            jt->pay_col = inner;
-            jt->pay_has_nulls = h_flags & 1;
+            if (l2) {
+              jt->pay16_built = true;
+              jt->pay16_col = inner;
+              jt->pay16_has_nulls = h_flags & 1;
+            } else {
+              jt->pay_col = inner;
+              jt->pay_has_nulls = h_flags & 1;
+            }
             if (b0 && b1) (void)hipEventElapsedTime(&jt->pay_build_ms, b0, b1);
           }
         }
@@ -1155,12 +1206,13 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         if (!ok) (void)hipGetLastError();
       }
       if (ok) {
-        pay.cnt_k = jt->pay_cnt;
-        pay.wsum_k = inner ? jt->pay_wsum : nullptr;
-        pay.wnn_k = inner ? jt->pay_wnn : nullptr;
+        pay.cnt_k = l2 ? nullptr : jt->pay_cnt;
+        pay.wsum_k = (!l2 && inner) ? jt->pay_wsum : nullptr;
+        pay.wnn_k = (!l2 && inner) ? jt->pay_wnn : nullptr;
+        pay.pay16 = l2 ? jt->pay16 : nullptr;
         pay.inner_col = inner;
         pay.entries = entries;
-        pay.has_nulls = jt->pay_has_nulls;
+        pay.has_nulls = l2 ? jt->pay16_has_nulls : jt->pay_has_nulls;
         if (join_probe_supported(d, fv, pay, n_cus)) kind = K_JOIN_PROBE;
       }
     }
@@ -1471,13 +1523,14 @@ int32_t mi355q_join_key_shape(const mi355q_join_table* t, int32_t* key_component
 
 void mi355q_join_free(mi355q_join_table* t) {
   if (!t) return;
-  if (t->buf || t->bitmap || t->pay_cnt) {
+  if (t->buf || t->bitmap || t->pay_cnt || t->pay16) {
     DeviceGuard g(t->device_id);
     if (t->buf) (void)hipFree(t->buf);
     if (t->bitmap) (void)hipFree(t->bitmap);
     if (t->pay_cnt) (void)hipFree(t->pay_cnt);
     if (t->pay_wsum) (void)hipFree(t->pay_wsum);
     if (t->pay_wnn) (void)hipFree(t->pay_wnn);
+    if (t->pay16) (void)hipFree(t->pay16);
   }
   delete t;
 }

@@ -186,20 +186,32 @@ hipError_t launch_topk(const DevPlan& p, int idx_target_as_key, int target, int6
                        bool fp_result, bool desc, bool nulls_first, const int64_t* buf, int64_t k,
                        void* scratch, int64_t* out_rows, int64_t* d_n_out, hipStream_t s);
 
+// full ORDER BY (kernels_sort.hip): one entry per order column, most significant first
+struct SortOrderEntry {
+  int32_t target;
+  int32_t desc, nulls_first, fp_result;
+  int64_t null_pattern;
+};
+int64_t sort_scratch_bytes(int64_t entry_count);
+hipError_t launch_sort(const DevPlan& p, int idx_target_as_key, const SortOrderEntry* order, int n_order,
+                       const int64_t* buf, int64_t offset, int64_t limit, void* scratch, int64_t* out_rows,
+                       int64_t* d_n_out, hipStream_t s);
+
 // payload probe (kernels_part.hip): joins whose non-grouped targets read the inner side / one-to-many
 // tables / LEFT joins, through per-key aggregated payload arrays of a perfect-hash table kept in LDS
 struct JoinPayloadView {
   const uint32_t* cnt_k;   // [entries] rows per key
   const int64_t* wsum_k;   // [entries] sum of the inner column over the key's rows (NULLs skipped)
   const uint32_t* wnn_k;   // [entries] non-NULL values among them
+  const void* pay16;       // [entries] {wsum, cnt, wnn} as one 16-byte entry per key (L2 mode), or null
   const void* inner_col;   // the inner column wsum / wnn were built for (nullptr: counts only)
   int64_t entries;
   int32_t has_nulls;       // some matching inner value is NULL: wnn != cnt somewhere
 };
 hipError_t launch_join_payload_build(const void* table, int hash_type, int64_t entries, const void* inner_col,
-                                     uint32_t* cnt_k, int64_t* wsum_k, uint32_t* wnn_k, int32_t* d_flags,
+                                     uint32_t* cnt_k, int64_t* wsum_k, uint32_t* wnn_k, void* pay16, int32_t* d_flags,
                                      int n_cus, hipStream_t s);
-bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col);
+bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int* l2_mode);
 bool join_probe_supported(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus);
 int64_t join_probe_scratch_bytes(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus,
                                  int64_t cap_bytes);

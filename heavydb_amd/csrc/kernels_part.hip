@@ -1335,6 +1335,15 @@ __global__ __launch_bounds__(256) void k_join_spill(JoinPartArgs a, SpillList sl
 // LDS reads instead of 2-5 dependent random HBM reads (offsets, counts, payload run, inner column).
 // LEFT joins add the unmatched outer rows afterwards from totals over the whole outer table:
 //     COUNT(*) = J + (N - M),  SUM(fact.v) = SVc + (SV_all - SVm)   (J joined rows, M matched outer rows).
+// Key ranges too wide for LDS slices (cfg4: 100 M inner keys = 98 K keys per partition) keep the
+// slice in the XCD's L2 instead: one 16-byte entry per key, and all workgroups of an XCD walk the
+// SAME partition at the same time (k_part_probe_l2), so its 1.5 MB slice is fetched from HBM once and
+// every probe after that is an L2 hit — 265 G random reads/s against 54 G/s from HBM
+// (tools/microbench/gather.hip, profiles/r02_microbench_gather.txt).
+struct Pay16 {
+  int64_t wsum;
+  uint32_t cnt, wnn;
+};
 struct ProbeArgs {
   int32_t P, B, R;
   uint32_t cap, S1, S2;    // run capacity; keys per partition; keys per sub-range (multiple of 32)
@@ -1343,6 +1352,7 @@ struct ProbeArgs {
   const uint32_t* cnt_k;   // [range]
   const int64_t* wsum_k;   // [range] or null
   const uint32_t* wnn_k;   // [range] or null (inner column NOT NULL: wnn = cnt)
+  const Pay16* pay16;      // [range] the same three as one 16-byte entry per key (L2 mode), or null
   int64_t null_sum;        // NULL_BIGINT: skipped by the non-grouped SUM over the outer value
 };
 // accumulators (device words, wrapping 64-bit adds)
@@ -1426,6 +1436,57 @@ __global__ __launch_bounds__(kPartBlock) void k_part_probe(ProbeArgs a, const Re
   probe_reduce_store(acc, v, s_red);
 }
 
+// L2 mode: workgroup (xcd, g) of the grid's 8 x G takes the runs g, g + G, ... of the partitions
+// xcd, xcd + 8, ...  (block b runs on XCD b % 8 — observed, not promised: a different placement only
+// costs the L2 hits, never correctness)
+__global__ __launch_bounds__(256) void k_part_probe_l2(ProbeArgs a, const Rec* __restrict__ scratch,
+                                                        const uint32_t* __restrict__ cnt,
+                                                        unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long s_red[4 * PA_N];
+  const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
+  const int t = threadIdx.x;
+  unsigned long long v[PA_N];
+  for (int k = 0; k < PA_N; ++k) v[k] = 0;
+  for (int p = xcd; p < a.P; p += 8) {
+    for (int b = g; b < a.B; b += G) {
+      const uint32_t n = cnt[(size_t)p * a.B + b];
+      const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
+      for (uint32_t i0 = 0; i0 < n; i0 += 4 * 256) {
+        Rec rec[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t i = i0 + q * 256 + t;
+          rec[q] = i < n ? load_rec_nt(run + i) : Rec{a.kmin - 1, 0};
+        }
+        Pay16 pe[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {  // four independent gathers in flight
+          const uint64_t off = (uint64_t)rec[q].key - (uint64_t)a.kmin;
+          pe[q] = off < a.range ? a.pay16[off] : Pay16{0, 0u, 0u};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned long long c = pe[q].cnt;
+          if (c) {
+            const bool nn = rec[q].val != a.null_sum;
+            v[PA_J] += c;
+            v[PA_M] += 1;
+            if (nn) {
+              v[PA_SVC] += (unsigned long long)rec[q].val * c;
+              v[PA_SVM] += (unsigned long long)rec[q].val;
+              v[PA_NNVC] += c;
+              v[PA_NNVM] += 1;
+            }
+            v[PA_SW] += (unsigned long long)pe[q].wsum;
+            v[PA_NNW] += pe[q].wnn;
+          }
+        }
+      }
+    }
+  }
+  probe_reduce_store(acc, v, s_red);
+}
+
 // run overflows and heavy-hitter partial rows {key, SUM(v) partial, COUNT partial, COUNT_NN partial}
 // against the global arrays
 __global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, unsigned long long* __restrict__ acc) {
@@ -1440,7 +1501,17 @@ __global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, 
     if (key == kEmptyKey64) continue;
     const uint64_t off = (uint64_t)key - (uint64_t)a.kmin;
     if (off >= a.range) continue;
-    const unsigned long long c = a.cnt_k[off];
+    unsigned long long c, ws, wn;
+    if (a.pay16) {
+      const Pay16 pe = a.pay16[off];
+      c = pe.cnt;
+      ws = (unsigned long long)pe.wsum;
+      wn = pe.wnn;
+    } else {
+      c = a.cnt_k[off];
+      ws = a.wsum_k ? (unsigned long long)a.wsum_k[off] : 0ull;
+      wn = a.wnn_k ? (unsigned long long)a.wnn_k[off] : c;
+    }
     if (!c) continue;
     const unsigned long long rows = (unsigned long long)e[2], rows_nn = (unsigned long long)e[3];
     v[PA_J] += rows * c;
@@ -1449,8 +1520,8 @@ __global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, 
     v[PA_SVM] += (unsigned long long)e[1];
     v[PA_NNVC] += rows_nn * c;
     v[PA_NNVM] += rows_nn;
-    if (a.wsum_k) v[PA_SW] += rows * (unsigned long long)a.wsum_k[off];
-    v[PA_NNW] += rows * (a.wnn_k ? (unsigned long long)a.wnn_k[off] : c);
+    v[PA_SW] += rows * ws;
+    v[PA_NNW] += rows * wn;
   }
   probe_reduce_store(acc, v, s_red);
 }
@@ -1524,7 +1595,8 @@ __global__ void k_probe_finish(ProbeFinish f, const unsigned long long* __restri
 __global__ __launch_bounds__(256) void k_join_payload(const int32_t* __restrict__ table, int hash_type,
                                                       int64_t entries, const int64_t* __restrict__ w,
                                                       uint32_t* __restrict__ cnt_k, int64_t* __restrict__ wsum_k,
-                                                      uint32_t* __restrict__ wnn_k, int32_t* __restrict__ flags) {
+                                                      uint32_t* __restrict__ wnn_k, Pay16* __restrict__ pay16,
+                                                      int32_t* __restrict__ flags) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   bool any_null = false;
   for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < entries; x += stride) {
@@ -1559,12 +1631,17 @@ __global__ __launch_bounds__(256) void k_join_payload(const int32_t* __restrict_
         }
       }
     }
-    cnt_k[x] = c;
-    if (w) {
-      wsum_k[x] = (int64_t)sum;
-      wnn_k[x] = nn;
-      any_null |= nn != c;
+    if (!w) nn = c;  // no inner column: nothing can be NULL
+    if (pay16) {
+      pay16[x] = Pay16{(int64_t)sum, c, nn};
+    } else {
+      cnt_k[x] = c;
+      if (w) {
+        wsum_k[x] = (int64_t)sum;
+        wnn_k[x] = nn;
+      }
     }
+    any_null |= nn != c;
   }
   if (__any(any_null) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
 }
@@ -2105,13 +2182,13 @@ hipError_t launch_join_partitioned(const DevPlan& p, const FragView& fv, int64_t
 
 // ---------------------------------------------------------------- payload probe: host side
 hipError_t launch_join_payload_build(const void* table, int hash_type, int64_t entries, const void* inner_col,
-                                     uint32_t* cnt_k, int64_t* wsum_k, uint32_t* wnn_k, int32_t* d_flags,
+                                     uint32_t* cnt_k, int64_t* wsum_k, uint32_t* wnn_k, void* pay16, int32_t* d_flags,
                                      int n_cus, hipStream_t s) {
   int64_t blocks = (entries + 255) / 256;
   if (blocks > (int64_t)n_cus * 16) blocks = (int64_t)n_cus * 16;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_join_payload, dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t*)table, hash_type, entries,
-                     (const int64_t*)inner_col, cnt_k, wsum_k, wnn_k, d_flags);
+                     (const int64_t*)inner_col, cnt_k, wsum_k, wnn_k, (Pay16*)pay16, d_flags);
   return hipGetLastError();
 }
 
@@ -2126,6 +2203,7 @@ struct ProbePartHost {
   uint32_t spill_cap;
   int vcol;    // outer value column or -1
   int wcol;    // inner column or -1
+  bool l2_mode;  // slices in L2 (k_part_probe_l2) instead of LDS (k_part_probe)
 };
 
 constexpr size_t kProbeLdsBudget = 144 * 1024;
@@ -2170,18 +2248,30 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   if (range128 < 64 || range128 >= ((__int128)1 << 32)) return false;
   const uint64_t range = (uint64_t)range128;
   // the payload arrays must be there for exactly this inner column (api.cpp builds them first)
-  if (!pay.cnt_k || pay.entries != (int64_t)range) return false;
-  if (h.wcol >= 0 && (!pay.wsum_k || pay.inner_col != (const void*)p.inner_cols[h.wcol])) return false;
+  if (pay.entries != (int64_t)range) return false;
+  if (h.wcol >= 0 && pay.inner_col != (const void*)p.inner_cols[h.wcol]) return false;
   const bool need_nn = h.wcol >= 0 && pay.has_nulls;
   const size_t entry_bytes = 4 + (h.wcol >= 0 ? 8 : 0) + (need_nn ? 4 : 0);
   uint32_t P = 16;
   auto s1_of = [&](uint32_t parts) { return (uint32_t)((((range + parts - 1) / parts) + 31) & ~(uint64_t)31); };
-  while (P < 1024 && (P < 4 * (uint32_t)n_cus || (size_t)s1_of(P) * entry_bytes > kProbeLdsBudget) && s1_of(P * 2) >= 64) P <<= 1;
+  // geometry and mode are decided on the widest entry this plan could need (so they do not depend on
+  // whether the inner column turned out to hold NULLs); the LDS slices then use the actual width
+  const size_t worst_bytes = 4 + (h.wcol >= 0 ? 12 : 0);
+  while (P < 1024 && (P < 4 * (uint32_t)n_cus || (size_t)s1_of(P) * worst_bytes > kProbeLdsBudget) && s1_of(P * 2) >= 64) P <<= 1;
   const uint32_t S1 = s1_of(P);
   if (S1 < 32) return false;
   uint32_t R = (uint32_t)(((size_t)S1 * entry_bytes + kProbeLdsBudget - 1) / kProbeLdsBudget);
   if (R < 1) R = 1;
-  if (R > 3) return false;  // every sub-range re-reads the partition's records: beyond 3 the direct probe wins
+  // every LDS sub-range re-reads the partition's records: beyond 3 the slice stays in L2 instead
+  // (16-byte entries, at most 2 MB per partition so two or three live slices fit the XCD's 4 MB)
+  h.l2_mode = ((size_t)S1 * worst_bytes + kProbeLdsBudget - 1) / kProbeLdsBudget > 3;
+  if (h.l2_mode) {
+    if ((size_t)S1 * sizeof(Pay16) > ((size_t)2 << 20)) return false;
+    if (!pay.pay16) return false;
+    R = 1;
+  } else if (!pay.cnt_k || (h.wcol >= 0 && !pay.wsum_k)) {
+    return false;
+  }
   const uint32_t S2 = (uint32_t)((((uint64_t)S1 + R - 1) / R + 31) & ~(uint64_t)31);
   ScatterArgs& sa = h.sa;
   sa = ScatterArgs{};
@@ -2238,7 +2328,7 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
     h.lds1 = fixed + (size_t)sa.n_cand * 4;
     if (h.lds1 > 160 * 1024) return false;
   }
-  h.lds2 = (size_t)S2 * entry_bytes + (size_t)16 * PA_N * 8 + 64;
+  h.lds2 = h.l2_mode ? 0 : (size_t)S2 * entry_bytes + (size_t)16 * PA_N * 8 + 64;
   if (h.lds2 > 160 * 1024) return false;
   ProbeArgs& pa = h.pa;
   pa = ProbeArgs{};
@@ -2250,9 +2340,10 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   pa.S2 = S2;
   pa.kmin = p.join_min;
   pa.range = range;
-  pa.cnt_k = pay.cnt_k;
-  pa.wsum_k = h.wcol >= 0 ? pay.wsum_k : nullptr;
-  pa.wnn_k = need_nn ? pay.wnn_k : nullptr;
+  pa.cnt_k = h.l2_mode ? nullptr : pay.cnt_k;
+  pa.wsum_k = (!h.l2_mode && h.wcol >= 0) ? pay.wsum_k : nullptr;
+  pa.wnn_k = (!h.l2_mode && need_nn) ? pay.wnn_k : nullptr;
+  pa.pay16 = h.l2_mode ? (const Pay16*)pay.pay16 : nullptr;
   pa.null_sum = INT64_MIN;
   return true;
 }
@@ -2265,7 +2356,7 @@ bool join_probe_supported(const DevPlan& p, const FragView& fv, const JoinPayloa
 }
 
 // which inner column (if any) the payload of this plan has to be built for; false = shape not taken
-bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col) {
+bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int* l2_mode) {
   JoinPayloadView fake{};
   const __int128 range128 = (__int128)p.join_max - (__int128)p.join_min + 1;
   if (range128 < 64 || range128 >= ((__int128)1 << 32)) return false;
@@ -2273,6 +2364,7 @@ bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col) {
   fake.cnt_k = (const uint32_t*)16;  // shape test only: the pointers are not followed
   fake.wsum_k = (const int64_t*)16;
   fake.wnn_k = (const uint32_t*)16;
+  fake.pay16 = (const void*)16;
   fake.has_nulls = 1;
   int wcol = -1;
   for (int i = 0; i < p.n_targets; ++i)
@@ -2281,6 +2373,7 @@ bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col) {
   ProbePartHost h;
   if (!make_probe_plan(p, fv, fake, 256, kDefaultScratchCap, &h)) return false;
   *inner_col = h.wcol;
+  *l2_mode = h.l2_mode ? 1 : 0;
   return true;
 }
 
@@ -2345,9 +2438,13 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
       ev_i += 2;
     }
     st->n_launches += 1;
-    const int units = h.pa.P * h.pa.R;
-    const int grid2 = units < n_cus ? units : n_cus;
-    hipLaunchKernelGGL(k_part_probe, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.pa, recs, cnt, acc);
+    if (h.l2_mode) {
+      hipLaunchKernelGGL(k_part_probe_l2, dim3(n_cus * 8), dim3(256), 0, s, h.pa, recs, cnt, acc);
+    } else {
+      const int units = h.pa.P * h.pa.R;
+      const int grid2 = units < n_cus ? units : n_cus;
+      hipLaunchKernelGGL(k_part_probe, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.pa, recs, cnt, acc);
+    }
     hipLaunchKernelGGL(k_probe_spill, dim3(256), dim3(256), 0, s, h.pa, sl, acc);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

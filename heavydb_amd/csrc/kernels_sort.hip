@@ -15,6 +15,9 @@
 //                       rows are gathered in order
 // Ties at the k-th position are broken arbitrarily, as in the reference.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>  // device radix sort of (order key, entry) pairs — the reference uses
+                                // thrust::sort_by_key at the same spot (ResultSetSortImpl.cu)
 
 #include "kernels.h"
 #include "rowfunc.h"
@@ -220,6 +223,49 @@ __global__ __launch_bounds__(1024) void k_topk_finish(DevPlan p, const int64_t* 
   if (threadIdx.x == 0) *n_out = (int64_t)n;
 }
 
+// ---- full sort: ORDER BY several targets, any LIMIT / OFFSET (ResultSet::sort -> baselineSort /
+// radixSortOnGpu / parallelTop, ResultSet.cpp:781-851; comparator semantics ResultSetComparator
+// ::operator(), ResultSet.cpp:1310-1470: order entries compared in sequence, NULLs first or last per
+// entry whatever the direction, DESC flips non-NULL values only, AVG compared as sum / count).
+// A stable least-significant-key-first radix sort of the permutation of entries: for the LAST order
+// entry first, the 64-bit order-preserving key of every entry in its current position is computed
+// (k_sort_keys, the same key function as the top-k selection) and the (key, entry) pairs are sorted;
+// after the first order entry's pass the permutation is ordered by all of them.  Empty entries carry
+// the largest key in every pass and stay behind the live ones.
+__global__ __launch_bounds__(kBlock) void k_sort_iota(uint32_t* __restrict__ perm, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) perm[e] = (uint32_t)e;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sort_keys(DevPlan p, int idx_target_as_key, int target,
+                                                       int64_t null_pattern, int fp_result, int desc,
+                                                       int nulls_first, const int64_t* __restrict__ buf,
+                                                       const uint32_t* __restrict__ perm,
+                                                       uint64_t* __restrict__ keys) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.entry_count; i += stride) {
+    keys[i] = order_key_of(p, p.targets[target], buf + (int64_t)perm[i] * p.row_quad, idx_target_as_key, null_pattern,
+                           fp_result != 0, desc != 0, nulls_first != 0);
+  }
+}
+
+// rows [offset, offset + n_out) of the sorted permutation, as whole rows; n_live = non-empty entries
+__global__ __launch_bounds__(kBlock) void k_sort_gather(DevPlan p, const int64_t* __restrict__ buf,
+                                                         const uint32_t* __restrict__ perm, int64_t offset,
+                                                         int64_t limit, const int64_t* __restrict__ n_live,
+                                                         int64_t* __restrict__ out_rows, int64_t* __restrict__ n_out) {
+  int64_t n = *n_live - offset;
+  if (n < 0) n = 0;
+  if (limit > 0 && n > limit) n = limit;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = n;
+  const int64_t quads = n * p.row_quad;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < quads; i += stride) {
+    const int64_t r = i / p.row_quad, j = i % p.row_quad;
+    out_rows[i] = buf[(int64_t)perm[offset + r] * p.row_quad + j];
+  }
+}
+
 inline int grid_for(int64_t work_items, int max_blocks = 2048) {
   int64_t b = (work_items + kBlock - 1) / kBlock;
   if (b < 1) b = 1;
@@ -253,6 +299,52 @@ hipError_t launch_topk(const DevPlan& p, int idx_target_as_key, int target, int6
                      (unsigned long long)k);
   hipLaunchKernelGGL(k_topk_finish, dim3(1), dim3(1024), 0, s, p, buf, st, cands, (unsigned long long)k,
                      out_rows, d_n_out);
+  return hipGetLastError();
+}
+
+// scratch layout of the full sort: keys[2][E] | perm[2][E] | n_live, n_out | rocprim temporary storage
+static size_t sort_tmp_bytes(int64_t entry_count) {
+  size_t tmp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                  (uint32_t*)nullptr, (size_t)entry_count, 0, 64, (hipStream_t) nullptr);
+  return (tmp + 255) & ~(size_t)255;
+}
+int64_t sort_scratch_bytes(int64_t entry_count) {
+  const size_t e = (size_t)(entry_count > 0 ? entry_count : 1);
+  return (int64_t)(2 * ((e * 8 + 255) & ~(size_t)255) + 2 * ((e * 4 + 255) & ~(size_t)255) + 256 + sort_tmp_bytes(entry_count));
+}
+
+hipError_t launch_sort(const DevPlan& p, int idx_target_as_key, const SortOrderEntry* order, int n_order,
+                       const int64_t* buf, int64_t offset, int64_t limit, void* scratch, int64_t* out_rows,
+                       int64_t* d_n_out, hipStream_t s) {
+  if (n_order < 1 || offset < 0 || limit < 0 || p.entry_count >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
+  const size_t e = (size_t)(p.entry_count > 0 ? p.entry_count : 1);
+  const size_t kb = (e * 8 + 255) & ~(size_t)255, pb = (e * 4 + 255) & ~(size_t)255;
+  char* base = (char*)scratch;
+  uint64_t* keys[2] = {(uint64_t*)base, (uint64_t*)(base + kb)};
+  uint32_t* perm[2] = {(uint32_t*)(base + 2 * kb), (uint32_t*)(base + 2 * kb + pb)};
+  int64_t* d_live = (int64_t*)(base + 2 * kb + 2 * pb);
+  void* tmp = base + 2 * kb + 2 * pb + 256;
+  size_t tmp_bytes = sort_tmp_bytes(p.entry_count);
+  const int grid = grid_for(p.entry_count);
+  hipLaunchKernelGGL(k_sort_iota, dim3(grid), dim3(kBlock), 0, s, perm[0], p.entry_count);
+  int cur = 0;
+  for (int o = n_order - 1; o >= 0; --o) {
+    const SortOrderEntry& oe = order[o];
+    hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(kBlock), 0, s, p, idx_target_as_key, oe.target, oe.null_pattern,
+                       (int)oe.fp_result, (int)oe.desc, (int)oe.nulls_first, buf, perm[cur], keys[0]);
+    hipError_t e2 = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys[0], keys[1], perm[cur], perm[1 - cur],
+                                              (size_t)p.entry_count, 0, 64, s);
+    if (e2 != hipSuccess) return e2;
+    cur = 1 - cur;
+  }
+  hipError_t e3 = hipMemsetAsync(d_live, 0, 16, s);
+  if (e3 != hipSuccess) return e3;
+  e3 = launch_count_nonempty(p, idx_target_as_key, buf, (unsigned long long*)d_live, s);
+  if (e3 != hipSuccess) return e3;
+  int64_t want = limit > 0 ? limit : p.entry_count;
+  hipLaunchKernelGGL(k_sort_gather, dim3(grid_for(want * p.row_quad)), dim3(kBlock), 0, s, p, buf, perm[cur], offset, limit,
+                     d_live, out_rows, d_n_out);
   return hipGetLastError();
 }
 

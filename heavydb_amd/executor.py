@@ -323,6 +323,19 @@ class ResultSet:
                                            out_rows_dev, C.byref(n), None), "result_topk")
         return n.value
 
+    def sort_by(self, order_entries, out_rows_dev: int, limit: int = 0, offset: int = 0) -> int:
+        """ORDER BY several targets [LIMIT limit OFFSET offset] on the device (ResultSet::sort with a
+        list of Analyzer::OrderEntry).  order_entries: [(target_idx, desc, nulls_first), ...], most
+        significant first; limit 0 = every live row.  The rows land, in order, in the caller's device
+        buffer (whole rows of this layout); returns how many were written."""
+        oe = (capi.OrderEntry * len(order_entries))()
+        for i, (t, desc, nf) in enumerate(order_entries):
+            oe[i].target_idx, oe[i].descending, oe[i].nulls_first = int(t), int(bool(desc)), int(bool(nf))
+        n = C.c_int64()
+        check(self._lib.mi355q_result_sort(self.handle, oe, len(order_entries), int(limit), int(offset),
+                                           out_rows_dev, C.byref(n), None), "result_sort")
+        return n.value
+
     def rowCount(self) -> int:
         return self._lib.mi355q_result_row_count(self.handle)
 

@@ -429,6 +429,25 @@ int32_t mi355q_result_topk(const mi355q_result* r, int32_t target_idx, int32_t d
                            int32_t nulls_first, int64_t k, void* out_rows_dev, int64_t* n_rows,
                            void* stream);
 
+/* ORDER BY <target> [ASC | DESC] [NULLS FIRST | LAST], ... LIMIT limit OFFSET offset over a grouped
+ * result, on the device, any number of order entries and any limit (0 = every live row): a stable
+ * least-significant-first radix sort of the entry permutation by each order entry's 64-bit
+ * order-preserving key.  Replaces ResultSet::sort (ResultSet.cpp:781-851: baselineSort /
+ * radixSortOnGpu / parallelTop; comparator ResultSetComparator::operator(), :1310-1470) and
+ * ResultSetSortImpl.cu / TopKSort.cu / StreamingTopN for sorts the top-k selection above does not
+ * take.  out_rows_dev receives whole rows of r's row-wise layout in order (min(limit, live - offset)
+ * rows, the count in *n_rows; it must have room for `limit` rows, or for mi355q_result_row_count(r)
+ * rows when limit is 0).  Rows that tie on every order entry come out in an unspecified order, as
+ * in the reference. */
+typedef struct mi355q_order_entry {
+  int32_t target_idx;  /* tle_no - 1 */
+  int32_t descending;  /* is_desc */
+  int32_t nulls_first;
+  int32_t reserved;
+} mi355q_order_entry;
+int32_t mi355q_result_sort(const mi355q_result* r, const mi355q_order_entry* order, int32_t n_order,
+                           int64_t limit, int64_t offset, void* out_rows_dev, int64_t* n_rows, void* stream);
+
 /* ColumnarResults for a grouped result, on the device (QueryEngine/ColumnarResults.cpp:1374-1600
  * materializeAllColumnsGroupBy: locateAndCountEntries -> partial sums -> compactAndCopyEntries):
  * the non-empty entries, in entry order, as one dense 8-byte column per target.  Integer targets

@@ -2300,3 +2300,94 @@ ORC_EXPORT int32_t orc_execute_streamed(const mi355q_plan* plan, const orc_gen_s
   }
   return 0;
 }
+
+// ================================================================ ORDER BY
+// ResultSet::sort (ResultSet.cpp:781-851) with ResultSetComparator::operator() (:1310-1470): the
+// permutation of the non-empty entries ordered by the order entries in sequence — both NULL: next
+// entry; one NULL: it goes first iff nulls_first (whatever the direction); integers and doubles by
+// value, AVG as pair_to_double, `(lhs < rhs) != is_desc`; then top_n / offset.  out_perm receives
+// entry indices; returns how many.  std::stable_sort: ties keep entry order (the reference's
+// std::sort leaves them unspecified).
+struct orc_order_entry {
+  int32_t target_idx, descending, nulls_first, reserved;
+};
+
+ORC_EXPORT int64_t orc_sort(const mi355q_qmd* q, const int64_t* buf, const orc_order_entry* order, int32_t n_order,
+                            int64_t limit, int64_t offset, int64_t* out_perm) {
+  if (q->output_columnar) {
+    const mi355q_qmd qr = rowwise_of(*q);
+    const std::vector<int64_t> rows = col_to_rows(*q, buf);
+    return orc_sort(&qr, rows.data(), order, n_order, limit, offset, out_perm);
+  }
+  const int rq = q->row_size / 8, kq = q->key_bytes / 8;
+  struct Val {
+    bool is_null, is_fp;
+    int64_t i;
+    double d;
+  };
+  auto value_of = [&](int64_t e, int t) -> Val {
+    const int64_t* row = buf + e * rq;
+    const int s = q->target_slot[t];
+    Val v{false, false, 0, 0.0};
+    if (q->target_agg[t] == MI355Q_PROJECT_KEY && s < 0) {
+      const int ki = q->target_key_idx[t];
+      v.i = q->key_width == 4 ? (int64_t) reinterpret_cast<const int32_t*>(row)[ki] : row[ki];
+      v.is_null = v.i == q->target_null[t];
+      return v;
+    }
+    const int64_t raw = q->slot_width == 4 ? (int64_t) reinterpret_cast<const int32_t*>(row + kq)[s] : row[kq + s];
+    switch (q->target_agg[t]) {
+      case MI355Q_AVG: {
+        const int64_t cnt = row[kq + s + 1];
+        v.is_fp = true;
+        v.is_null = cnt == 0;  // isNull(pair): !i2
+        if (!v.is_null)
+          v.d = (q->target_arg_is_f32[t] ? (double)bits_flt((int32_t)raw) : q->target_arg_is_fp[t] ? bits_dbl(raw) : (double)raw) /
+                (double)cnt;
+        return v;
+      }
+      case MI355Q_COUNT:
+      case MI355Q_COUNT_IF:
+        v.i = raw;
+        return v;
+      default:
+        if (q->target_arg_is_f32[t]) {
+          v.is_fp = true;
+          v.d = (double)bits_flt((int32_t)raw);
+          v.is_null = q->target_skip_null[t] && (int32_t)raw == (int32_t)q->target_null[t];
+        } else if (q->target_is_fp[t]) {
+          v.is_fp = true;
+          v.d = bits_dbl(raw);
+          v.is_null = q->target_skip_null[t] && raw == q->target_null[t];
+        } else {
+          v.i = raw;
+          v.is_null = (q->target_skip_null[t] || q->target_agg[t] == MI355Q_PROJECT_KEY) && raw == q->target_null[t];
+        }
+        return v;
+    }
+  };
+  std::vector<int64_t> perm;
+  for (int64_t e = 0; e < q->entry_count; ++e)
+    if (!is_empty_entry(*q, buf, e)) perm.push_back(e);
+  std::stable_sort(perm.begin(), perm.end(), [&](int64_t lhs, int64_t rhs) {
+    for (int o = 0; o < n_order; ++o) {
+      const orc_order_entry& oe = order[o];
+      const Val a = value_of(lhs, oe.target_idx), b = value_of(rhs, oe.target_idx);
+      if (a.is_null && b.is_null) continue;
+      if (a.is_null) return oe.nulls_first != 0;
+      if (b.is_null) return oe.nulls_first == 0;
+      if (a.is_fp) {
+        if (a.d == b.d) continue;
+        return (a.d < b.d) != (oe.descending != 0);
+      }
+      if (a.i == b.i) continue;
+      return (a.i < b.i) != (oe.descending != 0);
+    }
+    return false;
+  });
+  int64_t n = (int64_t)perm.size() - offset;
+  if (n < 0) n = 0;
+  if (limit > 0 && n > limit) n = limit;
+  for (int64_t i = 0; i < n; ++i) out_perm[i] = perm[(size_t)(offset + i)];
+  return n;
+}

@@ -400,3 +400,17 @@ def execute_streamed(plan: capi.Plan, gens: Sequence[tuple], total_rows: int, fr
                                   join.handle if join else None, n_threads, reduce_threads, buf.ctypes.data,
                                   C.byref(out_q), timing)
     return out_q, buf, code, dict(init_s=timing[0], kernels_s=timing[1], generate_s=timing[2], reduce_s=timing[3])
+
+
+def sort(q: capi.QMD, buf: np.ndarray, order_entries, limit: int = 0, offset: int = 0) -> np.ndarray:
+    """ResultSet::sort: entry indices of the live rows ordered by [(target_idx, desc, nulls_first), ...]."""
+    l = lib()
+    l.orc_sort.restype = C.c_int64
+    l.orc_sort.argtypes = [C.POINTER(capi.QMD), C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p]
+    oe = (capi.OrderEntry * len(order_entries))()
+    for i, (t, desc, nf) in enumerate(order_entries):
+        oe[i].target_idx, oe[i].descending, oe[i].nulls_first = int(t), int(bool(desc)), int(bool(nf))
+    buf = np.ascontiguousarray(buf)
+    out = np.zeros(max(int(q.entry_count), 1), dtype=np.int64)
+    n = l.orc_sort(C.byref(q), buf.ctypes.data, oe, len(order_entries), limit, offset, out.ctypes.data)
+    return out[:n]

@@ -127,3 +127,42 @@ def test_payload_probe_sub_ranges_and_column_switch(torch_cuda, oracle):
         q, want, code = oracle.execute(ra.to_plan(), [[k, v]], [dim, w1, w2], oj, n_threads=2)
         assert code == 0
         compare_buffers(q, want, rs.getStorage())
+
+
+@pytest.mark.parametrize("left", [False, True])
+def test_payload_probe_l2_mode(torch_cuda, oracle, left):
+    """A key range too wide for LDS slices (32 M inner keys: 31 K keys per partition): the 16-byte-per-key
+    payload slice of a partition stays in the XCD's L2 (k_part_probe_l2), inner column with NULLs."""
+    from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, HashJoin, InputColDescriptor,
+                                      RelAlgExecutionUnit, TargetExpr)
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    m = 32_000_000
+    dim = np.arange(m, dtype=np.int64)
+    dim[:1000] = rng.permutation(dim[:1000])
+    w = rng.integers(-1000, 1000, m).astype(np.int64)
+    w[::17] = -2**63
+    dk, dw = torch.from_numpy(dim).cuda(), torch.from_numpy(w).cuda()
+    hj = HashJoin.getInstance(int(dk.data_ptr()), m, capi.INT64, ExpressionRange(True, 0, m - 1))
+    n = 6_000_000
+    k = rng.integers(-1000, m + 1000, n).astype(np.int64)
+    k[rng.random(n) < 0.2] = 12345                      # a hot key (heavy-hitter path -> spill kernel)
+    v = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, -1000, m + 999)),
+             InputColDescriptor(capi.INT64, False, ExpressionRange(True, -10**6, 10**6))]
+    inner = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 0, m - 1)),
+             InputColDescriptor(capi.INT64, True, ExpressionRange(True, -1000, 1000, True))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.SUM, 1), TargetExpr(capi.SUM, 1, 1), TargetExpr(capi.COUNT),
+                                     TargetExpr(capi.COUNT, 1, 1)],
+                             inner_col_descs=inner, join_outer_col=0, join_table=hj,
+                             join_kind=capi.JOIN_LEFT if left else capi.JOIN_INNER)
+    dev = [torch.from_numpy(k).cuda(), torch.from_numpy(v).cuda()]
+    fr = FetchResult([[int(t.data_ptr()) for t in dev]], [n], [int(dk.data_ptr()), int(dw.data_ptr())], m,
+                     keepalive=dev + [dk, dw])
+    rs = Executor(0).executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=3)
+    assert rs.report.variant == 3
+    oj = oracle.OracleJoin(dim, capi.INT64, 0, m - 1)
+    ra.join_table = None
+    q, want, code = oracle.execute(ra.to_plan(), [[k, v]], [dim, w], oj, n_threads=4)
+    assert code == 0
+    compare_buffers(q, want, rs.getStorage())
