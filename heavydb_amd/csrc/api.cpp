@@ -1583,6 +1583,42 @@ int32_t mi355q_shard_merge_rows(mi355q_result* r, const void* rows, int64_t n_ro
   return run_reduce(r, (const int64_t*)rows, n_rows, stream);
 }
 
+static bool slice_exchange_shape(const mi355q_qmd& q) {
+  return q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && !q.output_columnar && q.group_col_count == 1 &&
+         q.key_width == 8 && q.slot_width == 8 && q.entry_count < ((int64_t)1 << 32);
+}
+
+int32_t mi355q_shard_pads(const mi355q_result* r, int32_t world, int32_t pad_rows, void* out_pads_dev,
+                          int32_t* ok_dev, void* stream) {
+  if (!r || !out_pads_dev || !ok_dev || world < 1 || world > 1024 || pad_rows < 1 || pad_rows > r->qmd.entry_count)
+    return MI355Q_ERR_INVALID_PLAN;
+  if (!slice_exchange_shape(r->qmd)) return MI355Q_ERR_UNSUPPORTED;
+  DeviceGuard g(r->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  HIP_TRY(launch_shard_pads(r->dplan, r->buf, world, pad_rows, (int64_t*)out_pads_dev, ok_dev, (hipStream_t)stream));
+  return MI355Q_OK;
+}
+
+int32_t mi355q_shard_merge_range(mi355q_result* r, const void* rows, int64_t n_rows, int64_t home_lo,
+                                 int64_t home_hi, void* stream) {
+  if (!r || (!rows && n_rows > 0) || n_rows < 0 || home_lo < 0 || home_hi < home_lo || home_hi > r->qmd.entry_count)
+    return MI355Q_ERR_INVALID_PLAN;
+  if (!slice_exchange_shape(r->qmd)) return MI355Q_ERR_UNSUPPORTED;
+  if (n_rows == 0) return MI355Q_OK;
+  DeviceGuard g(r->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  DevWord err;
+  HIP_TRY(hipMalloc(&err.p, sizeof(int32_t)));
+  hipStream_t s = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(err.p, 0, sizeof(int32_t), s));
+  HIP_TRY(launch_reduce_range(r->dplan, r->qmd.idx_target_as_key, r->buf, (const int64_t*)rows, n_rows, home_lo, home_hi,
+                              (int32_t*)err.p, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return h_err;
+}
+
 // ------------------------------------------------------------------------------- synth
 int32_t mi355q_generate_column(int32_t device_id, void* dst, int64_t n_rows, int64_t row_offset,
                                int32_t kind, uint64_t seed, int64_t a, int64_t b, int64_t c,

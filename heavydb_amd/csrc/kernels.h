@@ -51,6 +51,11 @@ hipError_t launch_reduce(const DevPlan& p, int idx_target_as_key, int64_t* this_
                          hipStream_t s);
 hipError_t launch_count_nonempty(const DevPlan& p, int idx_target_as_key, const int64_t* buf,
                                  unsigned long long* d_count, hipStream_t s);
+// multi-device merge by home-slot slices (kernels_generic.hip)
+hipError_t launch_shard_pads(const DevPlan& p, const int64_t* buf, int world, int pad_rows, int64_t* out_pads,
+                             int32_t* d_ok, hipStream_t s);
+hipError_t launch_reduce_range(const DevPlan& p, int idx_target_as_key, int64_t* this_buf, const int64_t* that_rows,
+                               int64_t that_entries, int64_t home_lo, int64_t home_hi, int32_t* d_err, hipStream_t s);
 hipError_t launch_shard_partition(const DevPlan& p, int idx_target_as_key, const int64_t* buf,
                                   int n_parts, int64_t* out_rows, int64_t* d_part_counts,
                                   int64_t* d_cursors /* n_parts scratch */, hipStream_t s);

@@ -132,9 +132,9 @@ __global__ __launch_bounds__(kBlock) void k_perfect_lds(const int8_t* const* __r
       return;
     }
     int64_t* row = tab + idx * rq;
-    if (kq) {
-      if (*(volatile int64_t*)row == kEmptyKey64) *(volatile int64_t*)row = (int64_t)key;
-    }
+    // every row of a group stores the same key: a plain store, nothing to read back or wait for
+    // (the read-compare-store this replaces stalled the wave on an LDS round trip per row)
+    if (kq) *(volatile int64_t*)row = (int64_t)key;
     apply_slots<VT>(a.sp, row + kq, (int64_t)key, val);
   });
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);

@@ -770,6 +770,71 @@ hipError_t launch_reduce(const DevPlan& p, int idx_target_as_key, int64_t* this_
   return hipGetLastError();
 }
 
+// ---- multi-device merge by home-slot slices (baseline tables with one int64 key).
+// Rank r of `world` owns the keys whose HOME slot (MurmurHash3(key) % entry_count, GroupByRuntime.cpp:20-48)
+// lies in [bound(r), bound(r + 1)), bound(r) = r * entry_count / world.  Because linear probing keeps a
+// key at or shortly after its home slot, the rows rank r needs from any other rank are that rank's
+// table rows [bound(r), bound(r + 1)) — a contiguous slice, sent as it is — plus the few rows of the
+// probe cluster that runs past the slice's end (the `pad`: the next pad_rows rows, wrapping at the
+// table's end).  No partition pass, no counts to exchange: every split size is known up front.
+//   k_shard_pads    copies the pad after each slice and checks that it contains an empty slot (then no
+//                   cluster that starts inside the slice can reach beyond it)
+//   k_reduce_range  folds received rows into this rank's table, keeping only keys whose home slot is in
+//                   the rank's range (a slice also holds strays of the PREVIOUS range's clusters, a pad
+//                   holds rows of the NEXT range: both belong to somebody else)
+__global__ __launch_bounds__(kBlock) void k_shard_pads(DevPlan p, const int64_t* __restrict__ buf, int world,
+                                                        int pad_rows, int64_t* __restrict__ out_pads,
+                                                        int32_t* __restrict__ ok) {
+  const int r = blockIdx.x;  // one workgroup per boundary
+  __shared__ int s_found;
+  if (threadIdx.x == 0) s_found = 0;
+  __syncthreads();
+  const int64_t hi = (int64_t)(((__int128)(r + 1) * p.entry_count) / world);
+  int found = 0;
+  for (int i = threadIdx.x; i < pad_rows; i += kBlock) {
+    int64_t e = hi + i;
+    if (e >= p.entry_count) e -= p.entry_count;
+    if (e >= p.entry_count) e %= p.entry_count;
+    const int64_t* row = buf + e * p.row_quad;
+    int64_t* dst = out_pads + ((int64_t)r * pad_rows + i) * p.row_quad;
+    for (int j = 0; j < p.row_quad; ++j) dst[j] = row[j];
+    found |= row[0] == kEmptyKey64;
+  }
+  if (found) atomicOr(&s_found, 1);
+  __syncthreads();
+  if (threadIdx.x == 0) ok[r] = s_found;
+}
+
+__global__ __launch_bounds__(kBlock) void k_reduce_range(DevPlan p, int idx_target_as_key, int64_t* __restrict__ this_buf,
+                                                          const int64_t* __restrict__ that_rows, int64_t that_entries,
+                                                          uint32_t home_lo, uint32_t home_hi, int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < that_entries; e += stride) {
+    const int64_t* row = that_rows + e * p.row_quad;
+    const int64_t key = row[0];
+    if (key == kEmptyKey64) continue;
+    const uint32_t home = murmur3_u64((uint64_t)key) % (uint32_t)p.entry_count;
+    if (home < home_lo || home >= home_hi) continue;
+    const int32_t err = reduce_entry<true>(p, idx_target_as_key, this_buf, row, e);
+    if (err) atomicCAS(d_err, 0, err);
+  }
+}
+
+hipError_t launch_shard_pads(const DevPlan& p, const int64_t* buf, int world, int pad_rows, int64_t* out_pads,
+                             int32_t* d_ok, hipStream_t s) {
+  if (world < 1 || pad_rows < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_shard_pads, dim3(world), dim3(kBlock), 0, s, p, buf, world, pad_rows, out_pads, d_ok);
+  return hipGetLastError();
+}
+
+hipError_t launch_reduce_range(const DevPlan& p, int idx_target_as_key, int64_t* this_buf, const int64_t* that_rows,
+                               int64_t that_entries, int64_t home_lo, int64_t home_hi, int32_t* d_err, hipStream_t s) {
+  if (that_entries <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_reduce_range, dim3(grid_for(that_entries)), dim3(kBlock), 0, s, p, idx_target_as_key, this_buf,
+                     that_rows, that_entries, (uint32_t)home_lo, (uint32_t)home_hi, d_err);
+  return hipGetLastError();
+}
+
 hipError_t launch_count_nonempty(const DevPlan& p, int idx_target_as_key, const int64_t* buf,
                                  unsigned long long* d_count, hipStream_t s) {
   hipError_t e = hipMemsetAsync(d_count, 0, sizeof(unsigned long long), s);

@@ -1273,15 +1273,20 @@ __global__ __launch_bounds__(kPartBlock) void k_part_join(JoinPartArgs a, const 
       const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
       for (uint32_t i0 = 0; i0 < n; i0 += 4 * kPartBlock) {
         Rec r[4];
+        // four independent 16-byte loads in flight per lane: UNCONDITIONAL loads of a clamped index (a
+        // load under `if (i < n)` sits in its own exec-masked block and the compiler waits for it
+        // before issuing the next one), the out-of-range lanes are discarded afterwards
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {  // four independent 16-byte loads in flight per lane
+        for (int u = 0; u < 4; ++u) {
           const uint32_t i = i0 + u * kPartBlock + t;
-          r[u] = i < n ? load_rec_nt(run + i) : Rec{base - 1, 0};
+          r[u] = load_rec_nt(run + (i < n ? i : n - 1));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const uint32_t x = (uint32_t)(r[u].key - base);
-          if (x < a.S1 && ((s_bm[x >> 5] >> (x & 31)) & 1u)) {
+          const bool live = i0 + u * kPartBlock + t < n;  // (the loaded values are never patched: a write to
+                                                          //  r[u] right after its load makes the compiler wait there)
+          if (live && x < a.S1 && ((s_bm[x >> 5] >> (x & 31)) & 1u)) {
             ++n_match;
             if (r[u].val != a.null_sum) {
               sum += r[u].val;
@@ -1405,14 +1410,14 @@ __global__ __launch_bounds__(kPartBlock) void k_part_probe(ProbeArgs a, const Re
       for (uint32_t i0 = 0; i0 < n; i0 += 4 * kPartBlock) {
         Rec rec[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // four independent 16-byte loads in flight per lane
+        for (int q = 0; q < 4; ++q) {  // four independent 16-byte loads in flight per lane (clamped, unconditional)
           const uint32_t i = i0 + q * kPartBlock + t;
-          rec[q] = i < n ? load_rec_nt(run + i) : Rec{base - 1, 0};
+          rec[q] = load_rec_nt(run + (i < n ? i : n - 1));
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const uint32_t x = (uint32_t)(rec[q].key - base);
-          if (x < nk) {
+          if (i0 + q * kPartBlock + t < n && x < nk) {
             const unsigned long long c = s_cnt[x];
             if (c) {
               const bool nn = rec[q].val != a.null_sum;
@@ -1439,34 +1444,66 @@ __global__ __launch_bounds__(kPartBlock) void k_part_probe(ProbeArgs a, const Re
 // L2 mode: workgroup (xcd, g) of the grid's 8 x G takes the runs g, g + G, ... of the partitions
 // xcd, xcd + 8, ...  (block b runs on XCD b % 8 — observed, not promised: a different placement only
 // costs the L2 hits, never correctness)
+// Pacing (speed only): the workgroups of an XCD group stay within two consecutive partitions, so at
+// most two slices (2 x 1.5 MB) compete for the XCD's 4 MB of L2 — without it the group spreads over
+// many partitions and the probes fall back to Infinity-Cache speed (measured: 73 G probes/s instead of
+// the 265 G/s of L2 hits).  `pace[xcd]` counts finished (workgroup, partition) pairs; a workgroup starts
+// its iteration i once everybody has finished iteration i - 2.  Bounded wait: a group that is not
+// fully resident only loses the pacing.
 __global__ __launch_bounds__(256) void k_part_probe_l2(ProbeArgs a, const Rec* __restrict__ scratch,
                                                         const uint32_t* __restrict__ cnt,
-                                                        unsigned long long* __restrict__ acc) {
+                                                        unsigned long long* __restrict__ acc,
+                                                        unsigned int* __restrict__ pace) {
   __shared__ unsigned long long s_red[4 * PA_N];
   const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
   const int t = threadIdx.x;
   unsigned long long v[PA_N];
   for (int k = 0; k < PA_N; ++k) v[k] = 0;
-  for (int p = xcd; p < a.P; p += 8) {
+  bool pacing = pace != nullptr;
+  int it = 0;
+  for (int p = xcd; p < a.P; p += 8, ++it) {
+    if (pacing && it >= 2) {
+      if (t == 0) {
+        const unsigned int need = (unsigned int)(it - 1) * (unsigned int)G;
+        unsigned int spins = 0;
+        while (__hip_atomic_load(pace + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1u << 14)) break;  // ~10 ms: the group is not running together
+        }
+      }
+      __syncthreads();
+    }
     for (int b = g; b < a.B; b += G) {
       const uint32_t n = cnt[(size_t)p * a.B + b];
       const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
+      if (!n) continue;
+      // records of the NEXT step are already in flight while this step's gathers run; every load is an
+      // unconditional load of a clamped index (a load under `if (i < n)` gets its own exec-masked block
+      // and a wait right behind it)
+      Rec rec[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t i = q * 256 + t;
+        rec[q] = load_rec_nt(run + (i < n ? i : n - 1));
+      }
       for (uint32_t i0 = 0; i0 < n; i0 += 4 * 256) {
-        Rec rec[4];
+        Rec nxt[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const uint32_t i = i0 + q * 256 + t;
-          rec[q] = i < n ? load_rec_nt(run + i) : Rec{a.kmin - 1, 0};
+          const uint32_t i = i0 + 4 * 256 + q * 256 + t;
+          nxt[q] = load_rec_nt(run + (i < n ? i : n - 1));
         }
         Pay16 pe[4];
+        bool hit[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // four independent gathers in flight
+        for (int q = 0; q < 4; ++q) {  // four independent gathers in flight (index 0 for keys outside the range)
           const uint64_t off = (uint64_t)rec[q].key - (uint64_t)a.kmin;
-          pe[q] = off < a.range ? a.pay16[off] : Pay16{0, 0u, 0u};
+          hit[q] = i0 + q * 256 + t < n && off < a.range;
+          pe[q] = a.pay16[hit[q] ? off : 0ull];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const unsigned long long c = pe[q].cnt;
+          const unsigned long long c = hit[q] ? pe[q].cnt : 0u;
           if (c) {
             const bool nn = rec[q].val != a.null_sum;
             v[PA_J] += c;
@@ -1481,7 +1518,13 @@ __global__ __launch_bounds__(256) void k_part_probe_l2(ProbeArgs a, const Rec* _
             v[PA_NNW] += pe[q].wnn;
           }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rec[q] = nxt[q];
       }
+    }
+    if (pacing) {
+      __syncthreads();
+      if (t == 0) atomicAdd(pace + xcd, 1u);
     }
   }
   probe_reduce_store(acc, v, s_red);
@@ -2381,7 +2424,7 @@ int64_t join_probe_scratch_bytes(const DevPlan& p, const FragView& fv, const Joi
                                  int64_t cap_bytes) {
   ProbePartHost h;
   if (!make_probe_plan(p, fv, pay, n_cus, cap_bytes, &h)) return 0;
-  return h.scratch_bytes + 64 + 256;
+  return h.scratch_bytes + 64 + 512;
 }
 
 hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int64_t* out,
@@ -2389,7 +2432,7 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
                              hipStream_t s, LaunchStats* st) {
   ProbePartHost h;
   if (!make_probe_plan(p, fv, pay, n_cus, cap_bytes, &h)) return hipErrorInvalidValue;
-  if (h.scratch_bytes + 64 + 256 > scratch_bytes) return hipErrorInvalidValue;
+  if (h.scratch_bytes + 64 + 512 > scratch_bytes) return hipErrorInvalidValue;
   Rec* recs = (Rec*)scratch;
   uint32_t* cnt = (uint32_t*)((char*)scratch + h.rec_bytes);
   char* spill_base = (char*)scratch + h.rec_bytes + h.cnt_bytes;
@@ -2398,7 +2441,7 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
   unsigned long long* acc = (unsigned long long*)((char*)scratch + h.scratch_bytes + 64 - 64);
   acc = (unsigned long long*)(((uintptr_t)acc + 63) & ~(uintptr_t)63);
   unsigned long long* acc2 = acc + PA_N;
-  hipError_t e = hipMemsetAsync(acc, 0, (PA_N + 2) * 8, s);
+  hipError_t e = hipMemsetAsync(acc, 0, (PA_N + 2) * 8 + 64, s);
   if (e != hipSuccess) return e;
   st->kernel_name = "k_part_scatter";
   st->variant = 3;
@@ -2439,7 +2482,12 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
     }
     st->n_launches += 1;
     if (h.l2_mode) {
-      hipLaunchKernelGGL(k_part_probe_l2, dim3(n_cus * 8), dim3(256), 0, s, h.pa, recs, cnt, acc);
+      unsigned int* pace = std::getenv("MI355Q_PROBE_NO_PACING") ? nullptr : (unsigned int*)(acc2 + 2);
+      if (pace) {
+        e = hipMemsetAsync(pace, 0, 64, s);
+        if (e != hipSuccess) return e;
+      }
+      hipLaunchKernelGGL(k_part_probe_l2, dim3(n_cus * 8), dim3(256), 0, s, h.pa, recs, cnt, acc, pace);
     } else {
       const int units = h.pa.P * h.pa.R;
       const int grid2 = units < n_cus ? units : n_cus;

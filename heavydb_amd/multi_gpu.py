@@ -37,6 +37,8 @@ class ShardOps(Protocol):
     def fresh_like(self) -> "ShardOps": ...
     def merge_rows(self, rows) -> None: ...
     def reduce_from(self, other_buffer) -> None: ...
+    # optional (slice exchange): boundary_pads(world, pad_rows) -> (pads [world, pad_rows, rq], ok int32[world]);
+    #                            merge_range(rows, home_lo, home_hi)
 
 
 def _dense_slot_ops(q: capi.QMD) -> Optional[List[Tuple[int, str, bool]]]:
@@ -122,6 +124,13 @@ def merge_keyed(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool 
     rq = q.row_size // 8
     if prepartitioned:
         return _gather_to_rank0(shard, shard, dist, torch, group, rq) if gather_to_rank0 else shard
+    global LAST_KEYED_PATH
+    LAST_KEYED_PATH = "partition"
+    if slice_exchange_ok(q, world) and hasattr(shard, "boundary_pads"):
+        out = _merge_keyed_by_slices(shard, dist, torch, group)
+        if out is not None:
+            LAST_KEYED_PATH = "slices"
+            return _gather_to_rank0(out, shard, dist, torch, group, rq) if gather_to_rank0 else out
     rows, counts = shard.partition_rows(world)
     send_counts = torch.tensor(counts, dtype=torch.int64, device=rows.device)
     recv_counts = torch.empty_like(send_counts)
@@ -134,6 +143,55 @@ def merge_keyed(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool 
     out = shard.fresh_like()
     out.merge_rows(recv_rows)
     return _gather_to_rank0(out, shard, dist, torch, group, rq) if gather_to_rank0 else out
+
+
+LAST_KEYED_PATH = ""   # which keyed merge ran last in this process ("slices" / "partition"): for tests and bench.py
+SLICE_PAD_ROWS = 1024  # rows after a slice's end that travel with it (the tail of a boundary-crossing cluster)
+
+
+def slice_bounds(entry_count: int, world: int) -> List[int]:
+    """bound(r) = r * entry_count // world: rank r owns the home slots [bound(r), bound(r + 1))."""
+    return [r * entry_count // world for r in range(world + 1)]
+
+
+def slice_exchange_ok(q: capi.QMD, world: int) -> bool:
+    """The shapes the slice exchange takes: row-wise baseline table, one 8-byte key, 8-byte slots, and
+    slices comfortably longer than the pad."""
+    return (q.desc_type == capi.GROUP_BY_BASELINE_HASH and not q.output_columnar and q.group_col_count == 1
+            and q.key_width == 8 and q.slot_width == 8 and q.entry_count // world >= 4 * SLICE_PAD_ROWS)
+
+
+def _merge_keyed_by_slices(shard: ShardOps, dist, torch, group) -> Optional[ShardOps]:
+    """Keyed merge without a partition pass and without exchanging counts: rank r
+    owns the keys whose home slot is in slice r of the table; linear probing keeps a key at or just after
+    its home slot, so every rank sends slice r of ITS table to rank r in place — the split sizes are the
+    slice lengths, known to everybody — followed by a second, tiny all_to_all with the SLICE_PAD_ROWS
+    rows after each slice (clusters that cross a boundary).  The receiver folds the `world` slices and
+    pads of its range into a fresh table, keeping only keys whose home slot is in its range.  One
+    device->host read at the very end (the all-reduced "every pad ended in an empty slot" flag); when
+    it says no, None is returned and the caller runs the general partition + exchange path."""
+    q = shard.qmd()
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    rq = q.row_size // 8
+    b = slice_bounds(q.entry_count, world)
+    table = shard.buffer()
+    pads, ok = shard.boundary_pads(world, SLICE_PAD_ROWS)        # [world, pad, rq] rows, int32[world]
+    my_len = b[rank + 1] - b[rank]
+    recv_main = torch.empty((world * my_len, rq), dtype=torch.int64, device=table.device)
+    dist.all_to_all_single(recv_main.view(-1), table.contiguous().view(-1),
+                           output_split_sizes=[my_len * rq] * world,
+                           input_split_sizes=[(b[r + 1] - b[r]) * rq for r in range(world)], group=group)
+    recv_pads = torch.empty_like(pads)
+    dist.all_to_all_single(recv_pads.view(-1), pads.contiguous().view(-1), group=group)
+    flag = ok.min().to(torch.int64).reshape(1)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    out = shard.fresh_like()
+    out.merge_range(recv_main, b[rank], b[rank + 1])
+    out.merge_range(recv_pads.view(-1, rq), b[rank], b[rank + 1])
+    if int(flag.item()) == 0:   # a cluster longer than the pad somewhere: the general path
+        return None
+    return out
 
 
 def _gather_to_rank0(out: ShardOps, shard: ShardOps, dist, torch, group, rq: int) -> ShardOps:
@@ -231,6 +289,24 @@ class HipShard:
 
     def fresh_like(self) -> "HipShard":
         return HipShard(self._torch, self._qmd, self.device_id)
+
+    def boundary_pads(self, world: int, pad_rows: int):
+        torch = self._torch
+        rq = self._qmd.row_size // 8
+        pads = torch.empty((world, pad_rows, rq), dtype=torch.int64, device=self._buf.device)
+        ok = torch.zeros(world, dtype=torch.int32, device=self._buf.device)
+        torch.cuda.current_stream().synchronize()
+        check(self._lib.mi355q_shard_pads(self.handle, world, pad_rows, int(pads.data_ptr()), int(ok.data_ptr()), None),
+              "shard_pads")
+        torch.cuda.synchronize(self._buf.device)
+        return pads, ok
+
+    def merge_range(self, rows, home_lo: int, home_hi: int) -> None:
+        n = int(rows.shape[0])
+        if n:
+            self._torch.cuda.current_stream().synchronize()
+            check(self._lib.mi355q_shard_merge_range(self.handle, int(rows.data_ptr()), n, home_lo, home_hi, None),
+                  "shard_merge_range")
 
     def merge_rows(self, rows) -> None:
         n = int(rows.shape[0])

@@ -519,6 +519,22 @@ int32_t mi355q_join_key_shape(const mi355q_join_table* t, int32_t* key_component
  * part_counts (device, int64[n_parts]) receives the run lengths. */
 int32_t mi355q_shard_partition(const mi355q_result* r, int32_t n_parts, void* out_rows,
                                int64_t* part_counts_dev, void* stream);
+/* Slice exchange (row-wise baseline tables with one 8-byte key and 8-byte slots): rank r of `world`
+ * owns the keys whose home slot MurmurHash3(key) % entry_count (GroupByRuntime.cpp:20-48) lies in
+ * [r * entry_count / world, (r + 1) * entry_count / world).  Linear probing keeps a key at or just
+ * after its home slot, so what rank r needs from a peer is that peer's table rows of the same range —
+ * sent in place, every split size known without a count exchange — plus the `pad_rows` rows after the
+ * range's end (the tail of a probe cluster that crosses the boundary; wraps at the table's end).
+ * mi355q_shard_pads copies the pad after each of the `world` ranges into out_pads_dev
+ * ([world][pad_rows] whole rows) and sets ok_dev[r] = 1 when pad r contains an empty slot, i.e. no
+ * cluster starting in range r reaches beyond its pad (otherwise fall back to mi355q_shard_partition).
+ * mi355q_shard_merge_range folds `n_rows` received rows into r, keeping only the keys whose home slot
+ * is in [home_lo, home_hi) (a slice also contains strays of the previous range's clusters, a pad
+ * contains rows of the next range). */
+int32_t mi355q_shard_pads(const mi355q_result* r, int32_t world, int32_t pad_rows, void* out_pads_dev,
+                          int32_t* ok_dev, void* stream);
+int32_t mi355q_shard_merge_range(mi355q_result* r, const void* rows, int64_t n_rows, int64_t home_lo,
+                                 int64_t home_hi, void* stream);
 /* Insert `n_rows` whole rows (same layout as r) into r with the reduce semantics. */
 int32_t mi355q_shard_merge_rows(mi355q_result* r, const void* rows, int64_t n_rows,
                                 void* stream);

@@ -69,6 +69,29 @@ class NumpyShard:
             that[:n] = rows
         assert self._orc.reduce(self._q, self._np, that) == 0
 
+    # ---- slice exchange (multi_gpu._merge_keyed_by_slices): the numpy twins of mi355q_shard_pads /
+    # mi355q_shard_merge_range
+    def boundary_pads(self, world, pad_rows):
+        from heavydb_amd.multi_gpu import slice_bounds
+        rows, e = self._rows(), self._q.entry_count
+        b = slice_bounds(e, world)
+        pads = np.zeros((world, pad_rows, rows.shape[1]), dtype=np.int64)
+        ok = np.zeros(world, dtype=np.int32)
+        for r in range(world):
+            idx = (b[r + 1] + np.arange(pad_rows)) % e
+            pads[r] = rows[idx]
+            ok[r] = int((rows[idx, 0] == EMPTY64).any())
+        return self._torch.from_numpy(pads), self._torch.from_numpy(ok)
+
+    def merge_range(self, rows, home_lo, home_hi):
+        from tests.helpers import murmur3_u64
+        rows = rows.numpy().reshape(-1, self._np.shape[1])
+        live = rows[rows[:, 0] != EMPTY64]
+        home = (murmur3_u64(live[:, 0]) % np.uint64(self._q.entry_count)).astype(np.int64)
+        mine = live[(home >= home_lo) & (home < home_hi)]
+        for o in range(0, len(mine), self._q.entry_count):  # merge_rows lays at most entry_count rows into a buffer
+            self.merge_rows(self._torch.from_numpy(np.ascontiguousarray(mine[o:o + self._q.entry_count])))
+
     def reduce_from(self, other_buffer):
         other = np.ascontiguousarray(other_buffer.numpy()).reshape(self._np.shape)
         assert self._orc.reduce(self._q, self._np, other) == 0
@@ -109,6 +132,22 @@ def _table(shape, seed=7):
         ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1)],
                                  [Qual(2, capi.LT, 2**30)], [0], max_groups_buffer_entry_guess=2 * n_keys)
         cols = [key, val, fil]
+    elif shape in ("keyed_sliced", "keyed_sliced_dense"):
+        # a table long enough for the slice exchange (entry_count / world >= 4 pads); the dense variant
+        # fills it to ~85 % so that probe clusters cross the slice boundaries (strays + pads matter)
+        n_keys = 40_000 if shape == "keyed_sliced" else 68_000
+        n = 200_000
+        key = (rng.integers(0, n_keys, n) * 1000003 + 7).astype(np.int64)
+        val = (rng.random(n) * 1000.0).astype(np.float64)
+        ival = rng.integers(-10**6, 10**6, n).astype(np.int64)
+        ival[rng.random(n) < 0.1] = -(2**63)
+        descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7)),
+                 InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0)),
+                 InputColDescriptor(capi.INT64, True, ExpressionRange(True, -10**6, 10**6, True))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1),
+                                         TargetExpr(capi.MIN, 2), TargetExpr(capi.SUM, 2)],
+                                 [], [0], max_groups_buffer_entry_guess=80_000)
+        cols = [key, val, ival]
     elif shape == "keyed_two_columns":  # multi-column baseline key: sharded by the whole key's hash
         k0 = (rng.integers(0, 900, n) * 1000003 + 7).astype(np.int64)
         k1 = rng.integers(-5, 5, n).astype(np.int64)
@@ -200,6 +239,9 @@ def _worker(rank, world, port, shape, errq):
         out = merge(shard, dist, torch, gather_to_rank0=True, prepartitioned=prepart)
         if prepart and rank != 0:
             assert out is shard and np.array_equal(before, out.buffer().numpy())  # nothing moved
+        if shape.startswith("keyed_sliced") or shape == "keyed":
+            from heavydb_amd import multi_gpu
+            assert multi_gpu.LAST_KEYED_PATH == "slices", multi_gpu.LAST_KEYED_PATH
         q_all, want, code = orc.execute(plan, frags, n_threads=2)
         assert code == 0
         got = out.buffer().numpy()
@@ -211,7 +253,13 @@ def _worker(rank, world, port, shape, errq):
         if q.desc_type == capi.GROUP_BY_BASELINE_HASH:
             # every rank owns exactly the keys of its shard after the all-to-all ...
             live = got[got[:, 0] != EMPTY64]
-            owner = _owner(q, live, world)
+            from heavydb_amd.multi_gpu import slice_bounds, slice_exchange_ok
+            if slice_exchange_ok(q, world) and not prepart:  # ownership by home-slot range
+                from tests.helpers import murmur3_u64
+                home = (murmur3_u64(live[:, 0]) % np.uint64(q.entry_count)).astype(np.int64)
+                owner = np.searchsorted(np.array(slice_bounds(q.entry_count, world)[1:]), home, side="right")
+            else:
+                owner = _owner(q, live, world)
             if rank != 0:
                 assert prepart or (owner == rank).all()
             else:  # ... and rank 0 additionally gathered everything
@@ -230,6 +278,14 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,shape", [(2, "keyed_sliced"), (3, "keyed_sliced_dense"), (5, "keyed_sliced_dense"),
+                                         (8, "keyed_sliced")])
+def test_slice_exchange_over_gloo(world, shape):
+    """The keyed merge by home-slot slices (no partition pass, no count exchange) at world 2 / 3 / 5 / 8:
+    uneven slice lengths, probe clusters crossing the boundaries, the wrap-around pad of the last slice."""
+    test_merge_over_gloo(shape, world)
 
 
 @pytest.mark.parametrize("world", [2, 3])
