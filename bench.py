@@ -168,6 +168,11 @@ def measure_ceiling(torch, device_id: int) -> dict:
     return out
 
 
+def _keyed_merge_path():
+    from heavydb_amd import multi_gpu
+    return multi_gpu.LAST_KEYED_PATH or None
+
+
 def main():
     args = parse_args()
     import torch
@@ -307,7 +312,8 @@ def main():
         "data": "synthetic (device-generated splitmix64 columns, 32 M-row fragments)",
         "config": {"workload": f"{cfg}: {total_rows} rows" + ("" if total_rows == want else f" (largest that fits; asked {want})"),
                    "bytes_per_row": bpr, "fragments_per_rank": len(fr.num_rows), "rows_per_rank": local_rows,
-                   "prepartitioned_by_key": prepart, "kernel": kname, "variant": int(reports[-1].variant) if reports else 0,
+                   "prepartitioned_by_key": prepart, "keyed_merge": _keyed_merge_path() if world > 1 else None,
+                   "kernel": kname, "variant": int(reports[-1].variant) if reports else 0,
                    "device": name.value.decode(), "cus": cus.value,
                    "hbm_reported_gbs": round(2 * clk.value * 1e3 * bus.value / 8 / 1e9, 1)},
         "achieved_gbs_whole_step": total_rows * bpr * args.steps / elapsed / 1e9,

@@ -1450,11 +1450,12 @@ __global__ __launch_bounds__(kPartBlock) void k_part_probe(ProbeArgs a, const Re
 // the 265 G/s of L2 hits).  `pace[xcd]` counts finished (workgroup, partition) pairs; a workgroup starts
 // its iteration i once everybody has finished iteration i - 2.  Bounded wait: a group that is not
 // fully resident only loses the pacing.
-__global__ __launch_bounds__(256) void k_part_probe_l2(ProbeArgs a, const Rec* __restrict__ scratch,
+template <int BLOCK, bool GATHER, int UQ>
+__global__ __launch_bounds__(BLOCK) void k_part_probe_l2(ProbeArgs a, const Rec* __restrict__ scratch,
                                                         const uint32_t* __restrict__ cnt,
                                                         unsigned long long* __restrict__ acc,
                                                         unsigned int* __restrict__ pace) {
-  __shared__ unsigned long long s_red[4 * PA_N];
+  __shared__ unsigned long long s_red[(BLOCK / 64) * PA_N];
   const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
   const int t = threadIdx.x;
   unsigned long long v[PA_N];
@@ -1480,29 +1481,29 @@ __global__ __launch_bounds__(256) void k_part_probe_l2(ProbeArgs a, const Rec* _
       // records of the NEXT step are already in flight while this step's gathers run; every load is an
       // unconditional load of a clamped index (a load under `if (i < n)` gets its own exec-masked block
       // and a wait right behind it)
-      Rec rec[4];
+      Rec rec[UQ];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t i = q * 256 + t;
+      for (int q = 0; q < UQ; ++q) {
+        const uint32_t i = q * BLOCK + t;
         rec[q] = load_rec_nt(run + (i < n ? i : n - 1));
       }
-      for (uint32_t i0 = 0; i0 < n; i0 += 4 * 256) {
-        Rec nxt[4];
+      for (uint32_t i0 = 0; i0 < n; i0 += UQ * BLOCK) {
+        Rec nxt[UQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const uint32_t i = i0 + 4 * 256 + q * 256 + t;
+        for (int q = 0; q < UQ; ++q) {
+          const uint32_t i = i0 + UQ * BLOCK + q * BLOCK + t;
           nxt[q] = load_rec_nt(run + (i < n ? i : n - 1));
         }
-        Pay16 pe[4];
-        bool hit[4];
+        Pay16 pe[UQ];
+        bool hit[UQ];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {  // four independent gathers in flight (index 0 for keys outside the range)
+        for (int q = 0; q < UQ; ++q) {  // four independent gathers in flight (index 0 for keys outside the range)
           const uint64_t off = (uint64_t)rec[q].key - (uint64_t)a.kmin;
-          hit[q] = i0 + q * 256 + t < n && off < a.range;
-          pe[q] = a.pay16[hit[q] ? off : 0ull];
+          hit[q] = i0 + q * BLOCK + t < n && off < a.range;
+          pe[q] = GATHER ? a.pay16[hit[q] ? off : 0ull] : Pay16{(int64_t)off, 1u, 1u};
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < UQ; ++q) {
           const unsigned long long c = hit[q] ? pe[q].cnt : 0u;
           if (c) {
             const bool nn = rec[q].val != a.null_sum;
@@ -1519,7 +1520,7 @@ __global__ __launch_bounds__(256) void k_part_probe_l2(ProbeArgs a, const Rec* _
           }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rec[q] = nxt[q];
+        for (int q = 0; q < UQ; ++q) rec[q] = nxt[q];
       }
     }
     if (pacing) {
@@ -2487,7 +2488,13 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
         e = hipMemsetAsync(pace, 0, 64, s);
         if (e != hipSuccess) return e;
       }
-      hipLaunchKernelGGL(k_part_probe_l2, dim3(n_cus * 8), dim3(256), 0, s, h.pa, recs, cnt, acc, pace);
+      // one 1024-lane workgroup per CU (measured, 3.2 B rows: 2048 workgroups of 256 lanes stream the
+      // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms)
+      const char* var = std::getenv("MI355Q_PROBE_L2_VARIANT");  // experiments: 4 = four records per lane per step
+      if (var && var[0] == '4')
+        hipLaunchKernelGGL((k_part_probe_l2<1024, true, 4>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      else
+        hipLaunchKernelGGL((k_part_probe_l2<1024, true, 8>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
     } else {
       const int units = h.pa.P * h.pa.R;
       const int grid2 = units < n_cus ? units : n_cus;

@@ -69,7 +69,8 @@ def _table():
 
 
 A = {"COUNT": capi.COUNT, "SUM": capi.SUM, "AVG": capi.AVG, "MIN": capi.MIN, "MAX": capi.MAX}
-OPS = {"<": capi.LT, ">": capi.GT, "=": capi.EQ, "<>": capi.NE, "<=": capi.LE, ">=": capi.GE}
+OPS = {"<": capi.LT, ">": capi.GT, "=": capi.EQ, "<>": capi.NE, "<=": capi.LE, ">=": capi.GE,
+       "IS NULL": capi.IS_NULL, "IS NOT NULL": capi.IS_NOT_NULL}
 
 
 # column NAMES here; resolved against the query's own input_col_descs (the reference fetches only the
@@ -233,7 +234,60 @@ QUERIES = [
     ("SELECT o1, COUNT(*) FROM test GROUP BY o1;", [key(), agg("COUNT")], [], ["o1"]),
     ("SELECT fx, COUNT(*), SUM(z) FROM test GROUP BY fx;", [key(), agg("COUNT"), agg("SUM", "z")], [], ["fx"]),
     ("SELECT t, w, COUNT(*), MIN(ff) FROM test GROUP BY t, w;", [key(0), key(1), agg("COUNT"), agg("MIN", "ff")], [], ["t", "w"]),
+    # IS [NOT] NULL quals and constrained_not_null (a qual `arg IS NOT NULL` makes the grouped aggregate over
+    # arg NOT NULL for the step: OutputBufferInitialization.cpp:287,301-324) — ExecuteTest.cpp:1955, :1989,
+    # :2023-2026, :2830-2832 (without the always-true HAVING), :2868, :5183-5198, :5770-5771
+    ("SELECT SUM(z) FROM test WHERE z IS NOT NULL;", [agg("SUM", "z")], [q("z", "IS NOT NULL", 0)], []),
+    ("SELECT COUNT(*) FROM test WHERE u IS NOT NULL;", [agg("COUNT")], [q("u", "IS NOT NULL", 0)], []),
+    ("SELECT x, MAX(fn) as val FROM test WHERE fn IS NOT NULL GROUP BY x ORDER BY val;",
+     [key(), agg("MAX", "fn")], [q("fn", "IS NOT NULL", 0)], ["x"]),
+    ("SELECT MAX(dn) FROM test WHERE dn IS NOT NULL;", [agg("MAX", "dn")], [q("dn", "IS NOT NULL", 0)], []),
+    ("SELECT x, MAX(dn) as val FROM test WHERE dn IS NOT NULL GROUP BY x ORDER BY val;",
+     [key(), agg("MAX", "dn")], [q("dn", "IS NOT NULL", 0)], ["x"]),
+    ("SELECT str, MIN(y) FROM test WHERE y IS NOT NULL GROUP BY str ORDER BY str DESC;",
+     [key(), agg("MIN", "y")], [q("y", "IS NOT NULL", 0)], ["str"]),
+    ("SELECT x, MAX(z) FROM test WHERE z IS NOT NULL GROUP BY x;", [key(), agg("MAX", "z")], [q("z", "IS NOT NULL", 0)], ["x"]),
+    ("SELECT x, SUM(z) FROM test WHERE z IS NOT NULL GROUP BY x ORDER BY x;", [key(), agg("SUM", "z")],
+     [q("z", "IS NOT NULL", 0)], ["x"]),
+    ("SELECT d, MAX(f) FROM test WHERE f IS NOT NULL GROUP BY d;", [key(), agg("MAX", "f")], [q("f", "IS NOT NULL", 0)], ["d"]),
+    ("SELECT d, AVG(f) FROM test WHERE f IS NOT NULL GROUP BY d;", [key(), agg("AVG", "f")], [q("f", "IS NOT NULL", 0)], ["d"]),
+    ("SELECT d, SUM(f) FROM test WHERE f IS NOT NULL GROUP BY d;", [key(), agg("SUM", "f")], [q("f", "IS NOT NULL", 0)], ["d"]),
+    ("SELECT x, y, SUM(f) FROM test WHERE f IS NOT NULL GROUP BY x, y;", [key(0), key(1), agg("SUM", "f")],
+     [q("f", "IS NOT NULL", 0)], ["x", "y"]),
+    ("SELECT COUNT(*) FROM test WHERE str IS NULL;", [agg("COUNT")], [q("str", "IS NULL", 0)], []),
+    ("SELECT COUNT(*) FROM test WHERE str IS NOT NULL;", [agg("COUNT")], [q("str", "IS NOT NULL", 0)], []),
+    ("SELECT str, COUNT(*) FROM test where str IS NOT NULL GROUP BY str ORDER BY str;", [key(), agg("COUNT")],
+     [q("str", "IS NOT NULL", 0)], ["str"]),
+    ("SELECT x, SUM(fn), COUNT(fn), MIN(dn) FROM test WHERE fn IS NOT NULL GROUP BY x;",
+     [key(), agg("SUM", "fn"), agg("COUNT", "fn"), agg("MIN", "dn")], [q("fn", "IS NOT NULL", 0)], ["x"]),
+    ("SELECT x, COUNT(*) FROM test WHERE dn IS NULL GROUP BY x;", [key(), agg("COUNT")], [q("dn", "IS NULL", 0)], ["x"]),
 ]
+
+# The layout the reference's own comments name for a query ("single-column perfect hash", "all these key
+# columns are small ranged to force perfect hash", "multi-column perfect hash": ExecuteTest.cpp:11414-11470;
+# floating-point keys always take the baseline layout, GroupByAndAggregate.cpp:199-207): reference-held
+# intent the layout decisions (plan.cpp / oracle qmd_init) are checked against.
+INTENDED_LAYOUT = {sql: capi.GROUP_BY_PERFECT_HASH for sql in [
+    "SELECT COUNT(*) FROM test GROUP BY x ORDER BY x DESC;",
+    "SELECT y, COUNT(*) FROM test GROUP BY y ORDER BY y DESC;",
+    "SELECT str, COUNT(*) FROM test GROUP BY str ORDER BY str DESC;",
+    "SELECT COUNT(*), z FROM test where x = 7 GROUP BY z ORDER BY z DESC;",
+    "SELECT z as z0, z as z1, COUNT(*) FROM test GROUP BY z0, z1 ORDER BY z0 DESC;",
+    "SELECT x, COUNT(y), SUM(y), AVG(y), MIN(y), MAX(y) FROM test GROUP BY x ORDER BY x DESC;",
+    "SELECT y, SUM(fn), AVG(ff), MAX(f) from test GROUP BY y ORDER BY y DESC;",
+    "SELECT str, x FROM test GROUP BY x, str ORDER BY str, x;",
+    "SELECT str, x, MAX(smallint_nulls), AVG(y), COUNT(dn) FROM test GROUP BY x, str ORDER BY str, x;",
+    "SELECT str, x, MAX(smallint_nulls), COUNT(dn), COUNT(*) as cnt FROM test GROUP BY x, str ORDER BY cnt, str;",
+    "SELECT x, str, z, SUM(dn), MAX(dn), AVG(dn) FROM test GROUP BY x, str, z ORDER BY str, z, x;",
+    "SELECT x, SUM(dn), str, MAX(dn), z, AVG(dn), COUNT(*) FROM test GROUP BY z, x, str ORDER BY str, z, x;",
+]}
+INTENDED_LAYOUT.update({sql: capi.GROUP_BY_BASELINE_HASH for sql in [
+    "SELECT COUNT(*) AS n FROM test GROUP BY d ORDER BY n;",
+    "SELECT COUNT(*) AS n FROM test GROUP BY f ORDER BY n;",
+    "SELECT d, COUNT(*), SUM(x) FROM test GROUP BY d;",
+    "SELECT f, COUNT(*), MIN(z) FROM test GROUP BY f;",
+    "SELECT d, MAX(f) FROM test WHERE f IS NOT NULL GROUP BY d;",
+]})
 
 
 def _rows(fetch, qmd):
@@ -260,6 +314,8 @@ def test_reference_queries(oracle, qi, bigint_count):
     plan = ra.to_plan()
     qm, buf, code = oracle.execute(plan, frags, n_threads=3)
     assert code == 0
+    if sql in INTENDED_LAYOUT:
+        assert qm.desc_type == INTENDED_LAYOUT[sql], (sql, qm.desc_type)
     fp = [bool(qm.target_is_fp[t]) for t in range(qm.n_targets)]
     want = sorted((tuple(float(v) if f and v is not None else v for v, f in zip(r, fp))
                    for r in db.execute(sql).fetchall()), key=_key)

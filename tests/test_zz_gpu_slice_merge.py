@@ -54,7 +54,7 @@ def test_slice_merge_with_simulated_ranks(torch_cuda, oracle, world, fill):
     shards = []
     for r in range(world):
         mine = [f for f in range(n_frags) if f % world == r]
-        fr = FetchResult([[int(t.data_ptr()) + cuts[f] * 8 for t in dev] for f in mine],
+        fr = FetchResult([[int(t.data_ptr()) + int(cuts[f]) * 8 for t in dev] for f in mine],
                          [int(cuts[f + 1] - cuts[f]) for f in mine], keepalive=dev)
         shards.append(HipShard.execute(torch, ex, ra, fr))
     q = shards[0].qmd()
