@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <new>
 #include <vector>
 
@@ -44,6 +45,7 @@ struct mi355q_join_table {
   int64_t* pay_wsum = nullptr;
   uint32_t* pay_wnn = nullptr;
   void* pay16 = nullptr;         // the same as 16-byte entries (L2 mode of the probe)
+  int64_t* pay8 = nullptr;       // one-to-one tables, L2 mode: the inner value per key slot, INT64_MIN = absent
   const void* pay16_col = nullptr;
   bool pay16_built = false;
   int pay16_has_nulls = 0;
@@ -537,6 +539,157 @@ int32_t mi355q_result_to_columns(const mi355q_result* r, void* const* cols_dev, 
   HIP_TRY(launch_to_columns(r->dplan, q.idx_target_as_key, cs, r->buf, (int32_t*)base, (int32_t*)(base + flag_bytes),
                             (int64_t*)(base + 2 * flag_bytes), d_cols, s));
   HIP_TRY(hipStreamSynchronize(s));
+  return MI355Q_OK;
+}
+
+// ---- Arrow C Data Interface export
+namespace {
+
+struct ArrowColumnOwner {          // private_data of one child array: its two host buffers
+  std::vector<uint8_t> validity;   // empty when the column has no NULL
+  std::vector<int64_t> values;
+  const void* buffers[2];
+};
+struct ArrowBatchOwner {           // private_data of the struct array
+  std::vector<ArrowArray> child_storage;
+  std::vector<ArrowArray*> child_ptrs;
+  const void* buffers[1];
+};
+struct ArrowSchemaOwner {
+  std::vector<std::string> names;
+  std::vector<ArrowSchema> child_storage;
+  std::vector<ArrowSchema*> child_ptrs;
+};
+
+void release_child_array(ArrowArray* a) {
+  if (!a || !a->release) return;
+  delete static_cast<ArrowColumnOwner*>(a->private_data);
+  a->release = nullptr;
+}
+void release_batch_array(ArrowArray* a) {
+  if (!a || !a->release) return;
+  ArrowBatchOwner* o = static_cast<ArrowBatchOwner*>(a->private_data);
+  for (ArrowArray* c : o->child_ptrs)
+    if (c->release) c->release(c);
+  delete o;
+  a->release = nullptr;
+}
+void release_child_schema(ArrowSchema* s) {
+  if (s) s->release = nullptr;     // storage belongs to the parent
+}
+void release_batch_schema(ArrowSchema* s) {
+  if (!s || !s->release) return;
+  ArrowSchemaOwner* o = static_cast<ArrowSchemaOwner*>(s->private_data);
+  for (ArrowSchema* c : o->child_ptrs)
+    if (c->release) c->release(c);
+  delete o;
+  s->release = nullptr;
+}
+
+}  // namespace
+
+int32_t mi355q_result_export_arrow(const mi355q_result* r, const char* const* names, struct ArrowSchema* out_schema,
+                                   struct ArrowArray* out_array, void* stream) {
+  if (!r || !out_schema || !out_array) return MI355Q_ERR_INVALID_PLAN;
+  const mi355q_qmd& q = r->qmd;
+  const int nt = q.n_targets;
+  int64_t n_rows = 0;
+  std::vector<std::vector<int64_t>> cols((size_t)nt);
+  std::vector<std::vector<uint8_t>> nulls((size_t)nt);  // one flag per row (converted to bitmaps below)
+  if (q.desc_type == MI355Q_NON_GROUPED_AGGREGATE) {
+    std::vector<int64_t> iv((size_t)nt);
+    std::vector<double> dv((size_t)nt);
+    std::vector<int8_t> nu((size_t)nt);
+    if (int32_t e = mi355q_result_fetch_rows(r, 1, iv.data(), dv.data(), nu.data(), &n_rows)) return e;
+    for (int t = 0; t < nt; ++t) {
+      int64_t bits = iv[t];
+      if (q.target_is_fp[t]) std::memcpy(&bits, &dv[t], 8);
+      cols[t].assign((size_t)n_rows, bits);
+      nulls[t].assign((size_t)n_rows, (uint8_t)(nu[t] != 0));
+    }
+  } else {
+    n_rows = mi355q_result_row_count(r);
+    if (n_rows < 0) return MI355Q_ERR_HIP;
+    DeviceGuard g(r->device_id);
+    if (!g.ok) return MI355Q_ERR_HIP;
+    DevWord dev;
+    const size_t col_bytes = ((size_t)std::max<int64_t>(n_rows, 1) * 8 + 255) & ~(size_t)255;
+    HIP_TRY(hipMalloc(&dev.p, col_bytes * (size_t)nt));
+    std::vector<void*> ptrs((size_t)nt);
+    for (int t = 0; t < nt; ++t) ptrs[t] = (char*)dev.p + col_bytes * (size_t)t;
+    int64_t got = 0;
+    if (int32_t e = mi355q_result_to_columns(r, ptrs.data(), nt, &got, stream)) return e;
+    n_rows = got;
+    for (int t = 0; t < nt; ++t) {
+      cols[t].resize((size_t)n_rows);
+      if (n_rows) HIP_TRY(hipMemcpy(cols[t].data(), ptrs[t], (size_t)n_rows * 8, hipMemcpyDeviceToHost));
+      // NULL = the inline sentinel mi355q_result_to_columns wrote (target_null / NULL_DOUBLE)
+      const int64_t null_bits = q.target_is_fp[t] ? kNullDoubleBits : q.target_null[t];
+      const bool can_be_null = q.target_is_fp[t] ? (q.target_skip_null[t] || q.target_agg[t] == MI355Q_AVG ||
+                                                    q.target_agg[t] == MI355Q_PROJECT_KEY)
+                                                 : (q.target_skip_null[t] || q.target_agg[t] == MI355Q_PROJECT_KEY);
+      nulls[t].assign((size_t)n_rows, 0);
+      if (can_be_null)
+        for (int64_t i = 0; i < n_rows; ++i) nulls[t][(size_t)i] = cols[t][(size_t)i] == null_bits;
+    }
+  }
+  // ---- schema: struct<target_0: int64 | float64, ...>
+  ArrowSchemaOwner* so = new ArrowSchemaOwner();
+  so->names.resize((size_t)nt);
+  so->child_storage.resize((size_t)nt);
+  so->child_ptrs.resize((size_t)nt);
+  for (int t = 0; t < nt; ++t) {
+    so->names[t] = names && names[t] ? std::string(names[t]) : "target_" + std::to_string(t);
+    ArrowSchema& c = so->child_storage[t];
+    c = ArrowSchema{};
+    c.format = q.target_is_fp[t] ? "g" : "l";
+    c.name = so->names[t].c_str();
+    c.flags = 2;  // ARROW_FLAG_NULLABLE
+    c.release = release_child_schema;
+    so->child_ptrs[t] = &c;
+  }
+  *out_schema = ArrowSchema{};
+  out_schema->format = "+s";
+  out_schema->name = "";
+  out_schema->n_children = nt;
+  out_schema->children = so->child_ptrs.data();
+  out_schema->release = release_batch_schema;
+  out_schema->private_data = so;
+  // ---- array
+  ArrowBatchOwner* bo = new ArrowBatchOwner();
+  bo->child_storage.resize((size_t)nt);
+  bo->child_ptrs.resize((size_t)nt);
+  for (int t = 0; t < nt; ++t) {
+    ArrowColumnOwner* co = new ArrowColumnOwner();
+    int64_t null_count = 0;
+    for (uint8_t f : nulls[t]) null_count += f;
+    if (null_count) {
+      co->validity.assign((size_t)((n_rows + 7) / 8), 0);
+      for (int64_t i = 0; i < n_rows; ++i)
+        if (!nulls[t][(size_t)i]) co->validity[(size_t)(i >> 3)] |= (uint8_t)(1u << (i & 7));
+    }
+    co->values = std::move(cols[t]);
+    co->buffers[0] = null_count ? (const void*)co->validity.data() : nullptr;
+    co->buffers[1] = co->values.data();
+    ArrowArray& a = bo->child_storage[t];
+    a = ArrowArray{};
+    a.length = n_rows;
+    a.null_count = null_count;
+    a.n_buffers = 2;
+    a.buffers = co->buffers;
+    a.release = release_child_array;
+    a.private_data = co;
+    bo->child_ptrs[t] = &a;
+  }
+  bo->buffers[0] = nullptr;
+  *out_array = ArrowArray{};
+  out_array->length = n_rows;
+  out_array->n_buffers = 1;
+  out_array->buffers = bo->buffers;
+  out_array->n_children = nt;
+  out_array->children = bo->child_ptrs.data();
+  out_array->release = release_batch_array;
+  out_array->private_data = bo;
   return MI355Q_OK;
 }
 
@@ -1175,6 +1328,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         ok = hipMalloc(&flags.p, 64) == hipSuccess;
         if (l2) {
           if (ok && !jt->pay16) ok = hipMalloc(&jt->pay16, (size_t)entries * 16) == hipSuccess;
+          if (ok && jt->hash_type == 0 && !jt->pay8) ok = hipMalloc((void**)&jt->pay8, (size_t)entries * 8) == hipSuccess;
         } else {
           if (ok && !jt->pay_cnt) ok = hipMalloc((void**)&jt->pay_cnt, (size_t)entries * 4) == hipSuccess;
           if (ok && inner && !jt->pay_wsum) ok = hipMalloc((void**)&jt->pay_wsum, (size_t)entries * 8) == hipSuccess;
@@ -1184,7 +1338,8 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
           (void)hipMemsetAsync(flags.p, 0, 64, s);
           if (b0) (void)hipEventRecord(b0, s);
           ok = launch_join_payload_build(jt->buf, jt->hash_type, entries, inner, jt->pay_cnt, jt->pay_wsum, jt->pay_wnn,
-                                         l2 ? jt->pay16 : nullptr, (int32_t*)flags.p, n_cus, s) == hipSuccess;
+                                         l2 ? jt->pay16 : nullptr, l2 ? jt->pay8 : nullptr, (int32_t*)flags.p, n_cus,
+                                         s) == hipSuccess;
           if (b1) (void)hipEventRecord(b1, s);
           int32_t h_flags = 0;
           ok = ok && hipMemcpyAsync(&h_flags, flags.p, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -1210,6 +1365,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         pay.wsum_k = (!l2 && inner) ? jt->pay_wsum : nullptr;
         pay.wnn_k = (!l2 && inner) ? jt->pay_wnn : nullptr;
         pay.pay16 = l2 ? jt->pay16 : nullptr;
+        pay.pay8 = l2 ? jt->pay8 : nullptr;
         pay.inner_col = inner;
         pay.entries = entries;
         pay.has_nulls = l2 ? jt->pay16_has_nulls : jt->pay_has_nulls;
@@ -1531,6 +1687,7 @@ void mi355q_join_free(mi355q_join_table* t) {
     if (t->pay_wsum) (void)hipFree(t->pay_wsum);
     if (t->pay_wnn) (void)hipFree(t->pay_wnn);
     if (t->pay16) (void)hipFree(t->pay16);
+    if (t->pay8) (void)hipFree(t->pay8);
   }
   delete t;
 }

@@ -63,25 +63,26 @@ MQ_D void lds_minmax_f64(int64_t* s, double v, bool is_max) {
 }
 
 template <typename VT>
-MQ_D void apply_slots(const SlotProg& sp, int64_t* slots, int64_t key, VT val) {
-  for (int j = 0; j < sp.n; ++j) {
-    int64_t* s = slots + j;
-    switch (sp.op[j]) {
-      case SO_COUNT: atomicAdd((unsigned long long*)s, 1ull); break;
-      case SO_KEY: *(volatile int64_t*)s = key; break;
-      default:
-        if constexpr (!is_none<VT>::value) {
-          switch (sp.op[j]) {
-            case SO_SUM_I: atomicAdd((unsigned long long*)s, (unsigned long long)(int64_t)val); break;
-            case SO_SUM_F: atomicAdd((double*)s, (double)val); break;
-            case SO_MIN_I: atomicMin((long long*)s, (long long)val); break;
-            case SO_MAX_I: atomicMax((long long*)s, (long long)val); break;
-            case SO_MIN_F: lds_minmax_f64(s, (double)val, false); break;
-            case SO_MAX_F: lds_minmax_f64(s, (double)val, true); break;
-          }
+MQ_D void apply_slot(int op, int64_t* s, int64_t key, VT val) {
+  switch (op) {
+    case SO_COUNT: atomicAdd((unsigned long long*)s, 1ull); break;
+    case SO_KEY: *(volatile int64_t*)s = key; break;
+    default:
+      if constexpr (!is_none<VT>::value) {
+        switch (op) {
+          case SO_SUM_I: atomicAdd((unsigned long long*)s, (unsigned long long)(int64_t)val); break;
+          case SO_SUM_F: atomicAdd((double*)s, (double)val); break;
+          case SO_MIN_I: atomicMin((long long*)s, (long long)val); break;
+          case SO_MAX_I: atomicMax((long long*)s, (long long)val); break;
+          case SO_MIN_F: lds_minmax_f64(s, (double)val, false); break;
+          case SO_MAX_F: lds_minmax_f64(s, (double)val, true); break;
         }
-    }
+      }
   }
+}
+template <typename VT>
+MQ_D void apply_slots(const SlotProg& sp, int64_t* slots, int64_t key, VT val) {
+  for (int j = 0; j < sp.n; ++j) apply_slot<VT>(sp.op[j], slots + j, key, val);
 }
 
 // Merge one partial slot value into a global slot (NOT NULL semantics: init is the identity).
@@ -116,33 +117,38 @@ __global__ __launch_bounds__(kBlock) void k_perfect_lds(const int8_t* const* __r
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int64_t* tab = (int64_t*)smem_raw;
   const int rq = a.row_quad, kq = a.key_quad;
-  const int64_t quads = a.entry_count * rq;
+  const int64_t ne = a.entry_count;
+  const int64_t quads = ne * rq;
+  // The LDS copy is COLUMN-major: quad j of entry e at tab[j * ne + e].  In the row-major image a
+  // 16-byte row puts every SUM slot on an odd bank pair, i.e. the 64-bit ds_add of a wave only ever
+  // uses half of the LDS banks; one contiguous array per quad spreads random entries over all of them.
   for (int64_t i = threadIdx.x; i < quads; i += kBlock) {
-    const int j = (int)(i % rq);
+    const int j = (int)(i / ne);
     tab[i] = j < kq ? kEmptyKey64 : a.init[j - kq];
   }
   __syncthreads();
   bool bad = false;
+  const SlotProg& sp = a.sp;
   scan_fragments<FT, KT, VT>(cols, num_rows, n_frags, n_cols, flt.col, a.kcol, a.vcol,
                              [&](FT fv, KT key, VT val) {
     if (!filter_pass<FT>(flt, fv)) return;
     const int64_t idx = (int64_t)key - a.min_val;
-    if (idx < 0 || idx >= a.entry_count) {
+    if (idx < 0 || idx >= ne) {
       bad = true;
       return;
     }
-    int64_t* row = tab + idx * rq;
     // every row of a group stores the same key: a plain store, nothing to read back or wait for
     // (the read-compare-store this replaces stalled the wave on an LDS round trip per row)
-    if (kq) *(volatile int64_t*)row = (int64_t)key;
-    apply_slots<VT>(a.sp, row + kq, (int64_t)key, val);
+    if (kq) *(volatile int64_t*)(tab + idx) = (int64_t)key;
+    for (int j = 0; j < sp.n; ++j) apply_slot<VT>(sp.op[j], tab + (int64_t)(kq + j) * ne + idx, (int64_t)key, val);
   });
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
   __syncthreads();
-  // flush: one pass over the block's table, only touched slots reach HBM
+  // flush: one pass over the block's table (output rows stay row-major), only touched slots reach HBM
   for (int64_t i = threadIdx.x; i < quads; i += kBlock) {
+    const int64_t e = i / rq;
     const int j = (int)(i % rq);
-    const int64_t v = tab[i];
+    const int64_t v = tab[(int64_t)j * ne + e];
     if (j < kq) {
       if (v != kEmptyKey64) MQ_STORE64(out + i, v);
     } else {

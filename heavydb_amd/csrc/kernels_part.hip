@@ -1358,6 +1358,9 @@ struct ProbeArgs {
   const int64_t* wsum_k;   // [range] or null
   const uint32_t* wnn_k;   // [range] or null (inner column NOT NULL: wnn = cnt)
   const Pay16* pay16;      // [range] the same three as one 16-byte entry per key (L2 mode), or null
+  const int64_t* pay8;     // [range] L2 mode, one-to-one table without NULLs among the matching inner values:
+                           // the inner value itself, INT64_MIN where no row has the key (divergent 16-byte
+                           // loads run at half the rate of 8-byte ones: 133 vs 265 G probes/s)
   int64_t null_sum;        // NULL_BIGINT: skipped by the non-grouped SUM over the outer value
 };
 // accumulators (device words, wrapping 64-bit adds)
@@ -1450,7 +1453,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_probe(ProbeArgs a, const Re
 // the 265 G/s of L2 hits).  `pace[xcd]` counts finished (workgroup, partition) pairs; a workgroup starts
 // its iteration i once everybody has finished iteration i - 2.  Bounded wait: a group that is not
 // fully resident only loses the pacing.
-template <int BLOCK, bool GATHER, int UQ>
+template <int BLOCK, bool PAY8, int UQ>
 __global__ __launch_bounds__(BLOCK) void k_part_probe_l2(ProbeArgs a, const Rec* __restrict__ scratch,
                                                         const uint32_t* __restrict__ cnt,
                                                         unsigned long long* __restrict__ acc,
@@ -1500,7 +1503,13 @@ __global__ __launch_bounds__(BLOCK) void k_part_probe_l2(ProbeArgs a, const Rec*
         for (int q = 0; q < UQ; ++q) {  // four independent gathers in flight (index 0 for keys outside the range)
           const uint64_t off = (uint64_t)rec[q].key - (uint64_t)a.kmin;
           hit[q] = i0 + q * BLOCK + t < n && off < a.range;
-          pe[q] = GATHER ? a.pay16[hit[q] ? off : 0ull] : Pay16{(int64_t)off, 1u, 1u};
+          if (PAY8) {
+            const int64_t w = a.pay8[hit[q] ? off : 0ull];
+            const uint32_t present = w != INT64_MIN;
+            pe[q] = Pay16{present ? w : 0, present, present};
+          } else {
+            pe[q] = a.pay16[hit[q] ? off : 0ull];
+          }
         }
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
@@ -1546,7 +1555,12 @@ __global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, 
     const uint64_t off = (uint64_t)key - (uint64_t)a.kmin;
     if (off >= a.range) continue;
     unsigned long long c, ws, wn;
-    if (a.pay16) {
+    if (a.pay8) {
+      const int64_t w = a.pay8[off];
+      c = w != INT64_MIN;
+      ws = c ? (unsigned long long)w : 0ull;
+      wn = c;
+    } else if (a.pay16) {
       const Pay16 pe = a.pay16[off];
       c = pe.cnt;
       ws = (unsigned long long)pe.wsum;
@@ -1640,7 +1654,7 @@ __global__ __launch_bounds__(256) void k_join_payload(const int32_t* __restrict_
                                                       int64_t entries, const int64_t* __restrict__ w,
                                                       uint32_t* __restrict__ cnt_k, int64_t* __restrict__ wsum_k,
                                                       uint32_t* __restrict__ wnn_k, Pay16* __restrict__ pay16,
-                                                      int32_t* __restrict__ flags) {
+                                                      int64_t* __restrict__ pay8, int32_t* __restrict__ flags) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   bool any_null = false;
   for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < entries; x += stride) {
@@ -1676,9 +1690,10 @@ __global__ __launch_bounds__(256) void k_join_payload(const int32_t* __restrict_
       }
     }
     if (!w) nn = c;  // no inner column: nothing can be NULL
+    if (pay8) pay8[x] = c ? (int64_t)sum : INT64_MIN;  // (only read when the table is one-to-one and nn == c everywhere)
     if (pay16) {
       pay16[x] = Pay16{(int64_t)sum, c, nn};
-    } else {
+    } else if (!pay8) {
       cnt_k[x] = c;
       if (w) {
         wsum_k[x] = (int64_t)sum;
@@ -2226,13 +2241,13 @@ hipError_t launch_join_partitioned(const DevPlan& p, const FragView& fv, int64_t
 
 // ---------------------------------------------------------------- payload probe: host side
 hipError_t launch_join_payload_build(const void* table, int hash_type, int64_t entries, const void* inner_col,
-                                     uint32_t* cnt_k, int64_t* wsum_k, uint32_t* wnn_k, void* pay16, int32_t* d_flags,
-                                     int n_cus, hipStream_t s) {
+                                     uint32_t* cnt_k, int64_t* wsum_k, uint32_t* wnn_k, void* pay16, int64_t* pay8,
+                                     int32_t* d_flags, int n_cus, hipStream_t s) {
   int64_t blocks = (entries + 255) / 256;
   if (blocks > (int64_t)n_cus * 16) blocks = (int64_t)n_cus * 16;
   if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(k_join_payload, dim3((unsigned)blocks), dim3(256), 0, s, (const int32_t*)table, hash_type, entries,
-                     (const int64_t*)inner_col, cnt_k, wsum_k, wnn_k, (Pay16*)pay16, d_flags);
+                     (const int64_t*)inner_col, cnt_k, wsum_k, wnn_k, (Pay16*)pay16, pay8, d_flags);
   return hipGetLastError();
 }
 
@@ -2311,7 +2326,7 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   h.l2_mode = ((size_t)S1 * worst_bytes + kProbeLdsBudget - 1) / kProbeLdsBudget > 3;
   if (h.l2_mode) {
     if ((size_t)S1 * sizeof(Pay16) > ((size_t)2 << 20)) return false;
-    if (!pay.pay16) return false;
+    if (!pay.pay16 && !pay.pay8) return false;
     R = 1;
   } else if (!pay.cnt_k || (h.wcol >= 0 && !pay.wsum_k)) {
     return false;
@@ -2387,7 +2402,9 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   pa.cnt_k = h.l2_mode ? nullptr : pay.cnt_k;
   pa.wsum_k = (!h.l2_mode && h.wcol >= 0) ? pay.wsum_k : nullptr;
   pa.wnn_k = (!h.l2_mode && need_nn) ? pay.wnn_k : nullptr;
-  pa.pay16 = h.l2_mode ? (const Pay16*)pay.pay16 : nullptr;
+  pa.pay8 = (h.l2_mode && pay.pay8 && p.join_hash_type == 0 && !pay.has_nulls) ? pay.pay8 : nullptr;
+  pa.pay16 = (h.l2_mode && !pa.pay8) ? (const Pay16*)pay.pay16 : nullptr;
+  if (h.l2_mode && !pa.pay8 && !pa.pay16) return false;
   pa.null_sum = INT64_MIN;
   return true;
 }
@@ -2409,6 +2426,7 @@ bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int*
   fake.wsum_k = (const int64_t*)16;
   fake.wnn_k = (const uint32_t*)16;
   fake.pay16 = (const void*)16;
+  fake.pay8 = nullptr;
   fake.has_nulls = 1;
   int wcol = -1;
   for (int i = 0; i < p.n_targets; ++i)
@@ -2489,12 +2507,12 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
         if (e != hipSuccess) return e;
       }
       // one 1024-lane workgroup per CU (measured, 3.2 B rows: 2048 workgroups of 256 lanes stream the
-      // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms)
-      const char* var = std::getenv("MI355Q_PROBE_L2_VARIANT");  // experiments: 4 = four records per lane per step
-      if (var && var[0] == '4')
+      // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms;
+      // four or eight records per lane per step: no difference)
+      if (h.pa.pay8)
         hipLaunchKernelGGL((k_part_probe_l2<1024, true, 4>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
       else
-        hipLaunchKernelGGL((k_part_probe_l2<1024, true, 8>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+        hipLaunchKernelGGL((k_part_probe_l2<1024, false, 4>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
     } else {
       const int units = h.pa.P * h.pa.R;
       const int grid2 = units < n_cus ? units : n_cus;

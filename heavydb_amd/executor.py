@@ -373,6 +373,22 @@ class ResultSet:
         target, BIGINT -> int64, DOUBLE -> float64, SQL NULLs as validity bits."""
         return rows_to_arrow(self.getQueryMemDesc(), *self.fetch(), names=names)
 
+    def to_arrow_native(self, names: Optional[Sequence[str]] = None):
+        """The same table through the library's own Arrow C Data Interface export
+        (mi355q_result_export_arrow: device-side ColumnarResults -> host buffers -> ArrowArray /
+        ArrowSchema structs), imported zero-copy by pyarrow."""
+        import pyarrow as pa
+        c_schema = C.create_string_buffer(72)   # struct ArrowSchema: 9 words (Arrow C Data Interface)
+        c_array = C.create_string_buffer(80)    # struct ArrowArray: 10 words
+        ps, pa_ = C.addressof(c_schema), C.addressof(c_array)
+        arr = None
+        if names is not None:
+            keep = [n.encode() for n in names]
+            arr = (C.c_char_p * len(keep))(*keep)
+        check(self._lib.mi355q_result_export_arrow(self.handle, arr, ps, pa_, None), "result_export_arrow")
+        batch = pa.RecordBatch._import_from_c(pa_, ps)
+        return pa.Table.from_batches([batch])
+
     def getNextRow(self) -> list:
         """One row of target values (None = SQL NULL); [] when exhausted."""
         if self._rows is None:

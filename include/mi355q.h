@@ -511,6 +511,45 @@ int32_t mi355q_join_info(const mi355q_join_table* t, int32_t* hash_type, int64_t
 int32_t mi355q_join_key_shape(const mi355q_join_table* t, int32_t* key_components,
                               int32_t* component_width);
 
+/* ---- Arrow export (ArrowResultSetConverter::convertToArrow, QueryEngine/ArrowResultSetConverter.cpp):
+ * the rows of a result as ONE struct-typed ArrowArray (a record batch) + its ArrowSchema through the
+ * Arrow C Data Interface — plain C structs defined by the Arrow specification, no Arrow library on
+ * either side of the ABI.  One child per target: BIGINT / COUNT / projected integer keys -> int64 ("l"),
+ * DOUBLE / AVG / floating-point targets -> float64 ("g"), SQL NULL -> validity bitmap.  The columns are
+ * produced dense on the device (mi355q_result_to_columns), copied to the host once, and owned by the
+ * exported array until its release callback runs.  Non-grouped results export their single row.
+ * The struct definitions below are the specification's (arrow/c/abi.h); they are guarded so a
+ * translation unit that already includes Arrow's header can include this one too. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+  const char* format;
+  const char* name;
+  const char* metadata;
+  int64_t flags;
+  int64_t n_children;
+  struct ArrowSchema** children;
+  struct ArrowSchema* dictionary;
+  void (*release)(struct ArrowSchema*);
+  void* private_data;
+};
+struct ArrowArray {
+  int64_t length;
+  int64_t null_count;
+  int64_t offset;
+  int64_t n_buffers;
+  int64_t n_children;
+  const void** buffers;
+  struct ArrowArray** children;
+  struct ArrowArray* dictionary;
+  void (*release)(struct ArrowArray*);
+  void* private_data;
+};
+#endif
+/* names: n_targets column names, or NULL for "target_<i>". */
+int32_t mi355q_result_export_arrow(const mi355q_result* r, const char* const* names, struct ArrowSchema* out_schema,
+                                   struct ArrowArray* out_array, void* stream);
+
 /* ---- multi-device merge helpers (one process per GPU; the collective itself is
  * issued by the host with RCCL between these calls) ---- */
 /* Baseline layouts: compact the live entries of `r` into `n_parts` contiguous runs of

@@ -129,8 +129,9 @@ def test_payload_probe_sub_ranges_and_column_switch(torch_cuda, oracle):
         compare_buffers(q, want, rs.getStorage())
 
 
+@pytest.mark.parametrize("inner_nulls", [True, False])
 @pytest.mark.parametrize("left", [False, True])
-def test_payload_probe_l2_mode(torch_cuda, oracle, left):
+def test_payload_probe_l2_mode(torch_cuda, oracle, left, inner_nulls):
     """A key range too wide for LDS slices (32 M inner keys: 31 K keys per partition): the 16-byte-per-key
     payload slice of a partition stays in the XCD's L2 (k_part_probe_l2), inner column with NULLs."""
     from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, HashJoin, InputColDescriptor,
@@ -141,7 +142,8 @@ def test_payload_probe_l2_mode(torch_cuda, oracle, left):
     dim = np.arange(m, dtype=np.int64)
     dim[:1000] = rng.permutation(dim[:1000])
     w = rng.integers(-1000, 1000, m).astype(np.int64)
-    w[::17] = -2**63
+    if inner_nulls:        # 16-byte {sum, rows, non-NULL} entries; without NULLs the 8-byte value-or-absent entries
+        w[::17] = -2**63
     dk, dw = torch.from_numpy(dim).cuda(), torch.from_numpy(w).cuda()
     hj = HashJoin.getInstance(int(dk.data_ptr()), m, capi.INT64, ExpressionRange(True, 0, m - 1))
     n = 6_000_000
