@@ -46,6 +46,7 @@ struct mi355q_join_table {
   uint32_t* pay_wnn = nullptr;
   void* pay16 = nullptr;         // the same as 16-byte entries (L2 mode of the probe)
   int64_t* pay8 = nullptr;       // one-to-one tables, L2 mode: the inner value per key slot, INT64_MIN = absent
+  int64_t* pay_kkeys = nullptr;  // keyed tables: the key of every slot (pay16 / pay8 are then per slot)
   const void* pay16_col = nullptr;
   bool pay16_built = false;
   int pay16_has_nulls = 0;
@@ -1328,7 +1329,9 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         ok = hipMalloc(&flags.p, 64) == hipSuccess;
         if (l2) {
           if (ok && !jt->pay16) ok = hipMalloc(&jt->pay16, (size_t)entries * 16) == hipSuccess;
-          if (ok && jt->hash_type == 0 && !jt->pay8) ok = hipMalloc((void**)&jt->pay8, (size_t)entries * 8) == hipSuccess;
+          if (ok && (jt->hash_type == 0 || jt->hash_type == 1) && !jt->pay8)
+            ok = hipMalloc((void**)&jt->pay8, (size_t)entries * 8) == hipSuccess;
+          if (ok && l2 == 2 && !jt->pay_kkeys) ok = hipMalloc((void**)&jt->pay_kkeys, (size_t)entries * 8) == hipSuccess;
         } else {
           if (ok && !jt->pay_cnt) ok = hipMalloc((void**)&jt->pay_cnt, (size_t)entries * 4) == hipSuccess;
           if (ok && inner && !jt->pay_wsum) ok = hipMalloc((void**)&jt->pay_wsum, (size_t)entries * 8) == hipSuccess;
@@ -1337,9 +1340,11 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         if (ok) {
           (void)hipMemsetAsync(flags.p, 0, 64, s);
           if (b0) (void)hipEventRecord(b0, s);
-          ok = launch_join_payload_build(jt->buf, jt->hash_type, entries, inner, jt->pay_cnt, jt->pay_wsum, jt->pay_wnn,
-                                         l2 ? jt->pay16 : nullptr, l2 ? jt->pay8 : nullptr, (int32_t*)flags.p, n_cus,
-                                         s) == hipSuccess;
+          ok = (l2 == 2 ? launch_join_payload_keyed_build(jt->buf, jt->hash_type, entries, inner, jt->pay_kkeys, jt->pay16,
+                                                          jt->pay8, (int32_t*)flags.p, n_cus, s)
+                        : launch_join_payload_build(jt->buf, jt->hash_type, entries, inner, jt->pay_cnt, jt->pay_wsum,
+                                                    jt->pay_wnn, l2 ? jt->pay16 : nullptr, l2 ? jt->pay8 : nullptr,
+                                                    (int32_t*)flags.p, n_cus, s)) == hipSuccess;
           if (b1) (void)hipEventRecord(b1, s);
           int32_t h_flags = 0;
           ok = ok && hipMemcpyAsync(&h_flags, flags.p, 4, hipMemcpyDeviceToHost, s) == hipSuccess &&
@@ -1366,6 +1371,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         pay.wnn_k = (!l2 && inner) ? jt->pay_wnn : nullptr;
         pay.pay16 = l2 ? jt->pay16 : nullptr;
         pay.pay8 = l2 ? jt->pay8 : nullptr;
+        pay.kkeys = l2 == 2 ? jt->pay_kkeys : nullptr;
         pay.inner_col = inner;
         pay.entries = entries;
         pay.has_nulls = l2 ? jt->pay16_has_nulls : jt->pay_has_nulls;
@@ -1688,6 +1694,7 @@ void mi355q_join_free(mi355q_join_table* t) {
     if (t->pay_wnn) (void)hipFree(t->pay_wnn);
     if (t->pay16) (void)hipFree(t->pay16);
     if (t->pay8) (void)hipFree(t->pay8);
+    if (t->pay_kkeys) (void)hipFree(t->pay_kkeys);
   }
   delete t;
 }

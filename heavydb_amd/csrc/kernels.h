@@ -210,6 +210,8 @@ struct JoinPayloadView {
   const uint32_t* wnn_k;   // [entries] non-NULL values among them
   const void* pay16;       // [entries] {wsum, cnt, wnn} as one 16-byte entry per key (L2 mode), or null
   const int64_t* pay8;     // [entries] one-to-one tables: the inner value, INT64_MIN where absent (L2 mode), or null
+  const int64_t* kkeys;    // keyed tables: [entries] the key of every slot (EMPTY_KEY_64 where free); pay16 / pay8
+                           // are then indexed by slot
   const void* inner_col;   // the inner column wsum / wnn were built for (nullptr: counts only)
   int64_t entries;
   int32_t has_nulls;       // some matching inner value is NULL: wnn != cnt somewhere
@@ -217,6 +219,10 @@ struct JoinPayloadView {
 hipError_t launch_join_payload_build(const void* table, int hash_type, int64_t entries, const void* inner_col,
                                      uint32_t* cnt_k, int64_t* wsum_k, uint32_t* wnn_k, void* pay16, int64_t* pay8,
                                      int32_t* d_flags, int n_cus, hipStream_t s);
+hipError_t launch_join_payload_keyed_build(const void* table, int hash_type, int64_t entries, const void* inner_col,
+                                           int64_t* kkeys, void* pay16, int64_t* pay8, int32_t* d_flags, int n_cus,
+                                           hipStream_t s);
+// l2_mode: 0 = LDS slices of a perfect table, 1 = L2 slices of a perfect table, 2 = keyed table (L2 slices by slot)
 bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int* l2_mode);
 bool join_probe_supported(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus);
 int64_t join_probe_scratch_bytes(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus,

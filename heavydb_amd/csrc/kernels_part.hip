@@ -422,14 +422,17 @@ MQ_D void hot_apply(int op, int64_t* s, int64_t vb, bool is_null) {
   }
 }
 
-// DIRECT = false: records are partitioned by their home slot in the group-by table (hash);
-// DIRECT = true: by key range, `(key - kmin) / S1`, keys outside [kmin, kmin + hm.d) are dropped —
-// the partitions of a radix join probe (k_part_join), whose bitmap slices then fit LDS.
-template <typename FT, typename VT, bool DIRECT = false>
+// MODE 0: records are partitioned by their home slot in the group-by table (MurmurHash3) and carry kids;
+// MODE 1 (DIRECT): by key range, `(key - kmin) / S1`, keys outside [kmin, kmin + hm.d) are dropped —
+// the partitions of a radix join probe (k_part_join / k_part_probe), whose slices then fit LDS / L2;
+// MODE 2: by the home slot of a KEYED join table, MurmurHash1(key) % entries (baseline_hash_join_idx,
+// JoinHashTableQueryRuntime.cpp:56-94), records carry the key (k_part_probe_keyed).
+template <typename FT, typename VT, int MODE = 0>
 __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
     const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows, int n_frags,
     int n_cols, RangeFilter flt, int kcol, int vcol, ScatterArgs g, Rec* __restrict__ scratch,
     uint32_t* __restrict__ cnt, SpillList sl) {
+  constexpr bool DIRECT = MODE == 1;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   Rec* stage = (Rec*)smem_raw;                                      // [P][L] = kStageRecs records
   uint32_t* cursor = (uint32_t*)(smem_raw + kStageRecs * sizeof(Rec));  // [P]
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
         if (i < cur.valid && filter_pass_narrow<FT>(flt, quad_get(cur.f, i)) &&
             (!DIRECT || (uint64_t)cur.k.v[i] - (uint64_t)g.kmin < (uint64_t)g.hm.d)) {
           const int64_t key = cur.k.v[i];
-          const uint32_t h = murmur3_u64((uint64_t)key);
+          const uint32_t h = MODE == 2 ? murmur1_u64((uint64_t)key) : murmur3_u64((uint64_t)key);
           vb = val_bits_of<VT>(quad_get(cur.v, i));
           bool folded = false;
           if (decltype(hot_aware)::value) {
@@ -557,10 +560,10 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
           }
           if (!folded) {
             p = part_of(g.hm, DIRECT ? (uint32_t)((uint64_t)key - (uint64_t)g.kmin) : home_from_hash(g.hm, h));
-            rk = DIRECT ? key : kid_of(key, h);
+            rk = MODE != 0 ? key : kid_of(key, h);
             // (the one key whose kid is the LDS tables' empty mark takes the spill list, like a record
             // that meets a full run)
-            s = (!DIRECT && rk == kEmptyKey64) ? g.cap : atomicAdd(&cursor[p], 1u);
+            s = (MODE == 0 && rk == kEmptyKey64) ? g.cap : atomicAdd(&cursor[p], 1u);
             if (s >= g.cap) spill_raw(sl, g, sp_blk, key, vb);
             else park = !try_stage(rk, vb, p, s);
           }
@@ -1361,6 +1364,8 @@ struct ProbeArgs {
   const int64_t* pay8;     // [range] L2 mode, one-to-one table without NULLs among the matching inner values:
                            // the inner value itself, INT64_MIN where no row has the key (divergent 16-byte
                            // loads run at half the rate of 8-byte ones: 133 vs 265 G probes/s)
+  const int64_t* kkeys;    // keyed tables (MODE 2): the key of every table slot, EMPTY_KEY_64 where free;
+                           // pay16 / pay8 are then indexed by SLOT, `range` is the table's entry count
   int64_t null_sum;        // NULL_BIGINT: skipped by the non-grouped SUM over the outer value
 };
 // accumulators (device words, wrapping 64-bit adds)
@@ -1540,6 +1545,156 @@ __global__ __launch_bounds__(BLOCK) void k_part_probe_l2(ProbeArgs a, const Rec*
   probe_reduce_store(acc, v, s_red);
 }
 
+// Keyed (baseline) join tables — sparse keys — through the same route: the outer rows are partitioned by
+// the HOME SLOT of their key in the join table (scatter MODE 2), so a partition only ever probes one
+// contiguous slice of the table: its keys (8 B per slot, `kkeys`) and the per-slot payload stay in the
+// XCD's L2 while all workgroups of the XCD walk that partition.  Probing is the reference's linear probe
+// (get_matching_slot, JoinHashTableQueryRuntime.cpp:40-54): stop at the key or at an empty slot.
+template <bool PAY8>
+__global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Rec* __restrict__ scratch,
+                                                            const uint32_t* __restrict__ cnt,
+                                                            unsigned long long* __restrict__ acc) {
+  __shared__ unsigned long long s_red[16 * PA_N];
+  constexpr int BLOCK = 1024, UQ = 4;
+  const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
+  const int t = threadIdx.x;
+  const uint32_t entries = (uint32_t)a.range;
+  unsigned long long v[PA_N];
+  for (int k = 0; k < PA_N; ++k) v[k] = 0;
+  for (int p = xcd; p < a.P; p += 8) {
+    for (int b = g; b < a.B; b += G) {
+      const uint32_t n = cnt[(size_t)p * a.B + b];
+      const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
+      if (!n) continue;
+      Rec rec[UQ];
+#pragma unroll
+      for (int q = 0; q < UQ; ++q) {
+        const uint32_t i = q * BLOCK + t;
+        rec[q] = load_rec_nt(run + (i < n ? i : n - 1));
+      }
+      for (uint32_t i0 = 0; i0 < n; i0 += UQ * BLOCK) {
+        Rec nxt[UQ];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const uint32_t i = i0 + UQ * BLOCK + q * BLOCK + t;
+          nxt[q] = load_rec_nt(run + (i < n ? i : n - 1));
+        }
+        uint32_t hp[UQ];
+        int64_t k0[UQ];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {  // the first probe of all four, unconditionally, in flight together
+          hp[q] = murmur1_u64((uint64_t)rec[q].key) % entries;
+          k0[q] = a.kkeys[hp[q]];
+        }
+        int64_t slot[UQ];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const bool live = i0 + q * BLOCK + t < n;
+          slot[q] = -1;
+          if (live) {
+            int64_t k = k0[q];
+            uint32_t h = hp[q];
+            for (uint32_t trips = 0; trips < entries; ++trips) {  // collisions: the rest of the linear probe
+              if (k == rec[q].key) {
+                slot[q] = h;
+                break;
+              }
+              if (k == kEmptyKey64) break;
+              h = h + 1 == entries ? 0 : h + 1;
+              k = a.kkeys[h];
+            }
+          }
+        }
+        Pay16 pe[UQ];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const uint64_t idx = slot[q] >= 0 ? (uint64_t)slot[q] : 0ull;
+          if (PAY8) {
+            const int64_t w = a.pay8[idx];
+            const uint32_t present = w != INT64_MIN;
+            pe[q] = Pay16{present ? w : 0, present, present};
+          } else {
+            pe[q] = a.pay16[idx];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const unsigned long long c = slot[q] >= 0 ? pe[q].cnt : 0u;
+          if (c) {
+            const bool nn = rec[q].val != a.null_sum;
+            v[PA_J] += c;
+            v[PA_M] += 1;
+            if (nn) {
+              v[PA_SVC] += (unsigned long long)rec[q].val * c;
+              v[PA_SVM] += (unsigned long long)rec[q].val;
+              v[PA_NNVC] += c;
+              v[PA_NNVM] += 1;
+            }
+            v[PA_SW] += (unsigned long long)pe[q].wsum;
+            v[PA_NNW] += pe[q].wnn;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) rec[q] = nxt[q];
+      }
+    }
+  }
+  probe_reduce_store(acc, v, s_red);
+}
+
+// keys + per-slot payload of a keyed join table with ONE 8-byte key component: one-to-one
+// `{key, row id}[entries]`, one-to-many `keys[entries] | offsets | counts | payloads` (include/mi355q.h)
+__global__ __launch_bounds__(256) void k_join_payload_keyed(const int64_t* __restrict__ table, int hash_type,
+                                                            int64_t entries, const int64_t* __restrict__ w,
+                                                            int64_t* __restrict__ kkeys, Pay16* __restrict__ pay16,
+                                                            int64_t* __restrict__ pay8, int32_t* __restrict__ flags) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  bool any_null = false;
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < entries; x += stride) {
+    uint32_t c = 0, nn = 0;
+    unsigned long long sum = 0;
+    int64_t key;
+    if (hash_type == 1) {
+      key = table[2 * x];
+      const int64_t id = table[2 * x + 1];
+      if (key != kEmptyKey64 && id >= 0) {
+        c = 1;
+        if (w) {
+          const int64_t val = w[id];
+          if (val != INT64_MIN) {
+            sum = (unsigned long long)val;
+            nn = 1;
+          }
+        }
+      }
+    } else {
+      key = table[x];
+      const int32_t* offsets = (const int32_t*)(table + entries);
+      const int32_t off = offsets[x];
+      const int32_t n = offsets[entries + x];
+      if (key != kEmptyKey64 && off >= 0 && n > 0) {
+        c = (uint32_t)n;
+        if (w) {
+          const int32_t* ids = offsets + 2 * entries + off;
+          for (int32_t i = 0; i < n; ++i) {
+            const int64_t val = w[ids[i]];
+            if (val != INT64_MIN) {
+              sum += (unsigned long long)val;
+              ++nn;
+            }
+          }
+        }
+      }
+    }
+    if (!w) nn = c;
+    kkeys[x] = key;
+    if (pay8) pay8[x] = c ? (int64_t)sum : INT64_MIN;
+    pay16[x] = Pay16{(int64_t)sum, c, nn};
+    any_null |= nn != c;
+  }
+  if (__any(any_null) && (threadIdx.x & 63) == 0) atomicOr(flags, 1);
+}
+
 // run overflows and heavy-hitter partial rows {key, SUM(v) partial, COUNT partial, COUNT_NN partial}
 // against the global arrays
 __global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, unsigned long long* __restrict__ acc) {
@@ -1552,8 +1707,26 @@ __global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, 
     const int64_t* e = sl.entries + (size_t)i * sl.stride;
     const int64_t key = e[0];
     if (key == kEmptyKey64) continue;
-    const uint64_t off = (uint64_t)key - (uint64_t)a.kmin;
-    if (off >= a.range) continue;
+    uint64_t off;
+    if (a.kkeys) {  // keyed table: linear probe for the slot
+      const uint32_t entries = (uint32_t)a.range;
+      uint32_t h = murmur1_u64((uint64_t)key) % entries;
+      bool found = false;
+      for (uint32_t trips = 0; trips < entries; ++trips) {
+        const int64_t k = a.kkeys[h];
+        if (k == key) {
+          found = true;
+          break;
+        }
+        if (k == kEmptyKey64) break;
+        h = h + 1 == entries ? 0 : h + 1;
+      }
+      if (!found) continue;
+      off = h;
+    } else {
+      off = (uint64_t)key - (uint64_t)a.kmin;
+      if (off >= a.range) continue;
+    }
     unsigned long long c, ws, wn;
     if (a.pay8) {
       const int64_t w = a.pay8[off];
@@ -2210,14 +2383,14 @@ hipError_t launch_join_partitioned(const DevPlan& p, const FragView& fv, int64_t
     const int8_t* const* cols = fv.d_cols + (size_t)f * fv.n_cols;
     const int64_t* nrows = fv.d_num_rows + f;
     if (h.vcol >= 0) {
-      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, int64_t, true>,
+      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, int64_t, 1>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
-      hipLaunchKernelGGL((k_part_scatter<none_t, int64_t, true>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
+      hipLaunchKernelGGL((k_part_scatter<none_t, int64_t, 1>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
                          nrows, f1 - f, fv.n_cols, flt, p.join_col, vcol, h.sa, recs, cnt, sl);
     } else {
-      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, none_t, true>,
+      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, none_t, 1>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
-      hipLaunchKernelGGL((k_part_scatter<none_t, none_t, true>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
+      hipLaunchKernelGGL((k_part_scatter<none_t, none_t, 1>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
                          nrows, f1 - f, fv.n_cols, flt, p.join_col, vcol, h.sa, recs, cnt, sl);
     }
     e = hipGetLastError();
@@ -2251,6 +2424,17 @@ hipError_t launch_join_payload_build(const void* table, int hash_type, int64_t e
   return hipGetLastError();
 }
 
+hipError_t launch_join_payload_keyed_build(const void* table, int hash_type, int64_t entries, const void* inner_col,
+                                           int64_t* kkeys, void* pay16, int64_t* pay8, int32_t* d_flags, int n_cus,
+                                           hipStream_t s) {
+  int64_t blocks = (entries + 255) / 256;
+  if (blocks > (int64_t)n_cus * 16) blocks = (int64_t)n_cus * 16;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_join_payload_keyed, dim3((unsigned)blocks), dim3(256), 0, s, (const int64_t*)table, hash_type,
+                     entries, (const int64_t*)inner_col, kkeys, (Pay16*)pay16, pay8, d_flags);
+  return hipGetLastError();
+}
+
 namespace {
 
 struct ProbePartHost {
@@ -2263,6 +2447,7 @@ struct ProbePartHost {
   int vcol;    // outer value column or -1
   int wcol;    // inner column or -1
   bool l2_mode;  // slices in L2 (k_part_probe_l2) instead of LDS (k_part_probe)
+  bool keyed;    // keyed join table: partitioned by hash slot, probed in L2 (k_part_probe_keyed)
 };
 
 constexpr size_t kProbeLdsBudget = 144 * 1024;
@@ -2274,7 +2459,9 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
                      ProbePartHost* out) {
   ProbePartHost& h = *out;
   if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col < 0 || p.n_quals != 0) return false;
-  if ((p.join_hash_type != 0 && p.join_hash_type != 2) || p.join_n_keys != 1) return false;
+  if (p.join_hash_type < 0 || p.join_hash_type > 3 || p.join_n_keys != 1) return false;
+  h.keyed = p.join_hash_type == 1 || p.join_hash_type == 3;
+  if (h.keyed && p.join_width != 8) return false;
   if (p.join_kind != MI355Q_JOIN_INNER && p.join_kind != MI355Q_JOIN_LEFT) return false;
   if (p.join_type != MI355Q_INT64 || p.join_nullable || p.n_targets > 4) return false;
   if (fv.max_frag_rows > 0xfff00000ll) return false;
@@ -2303,7 +2490,8 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
     }
   }
   if (!all_aligned16(fv, p.join_col) || (h.vcol >= 0 && !all_aligned16(fv, h.vcol))) return false;
-  const __int128 range128 = (__int128)p.join_max - (__int128)p.join_min + 1;
+  // perfect tables: the partitions are key ranges; keyed tables: ranges of table slots
+  const __int128 range128 = h.keyed ? (__int128)p.join_entries : (__int128)p.join_max - (__int128)p.join_min + 1;
   if (range128 < 64 || range128 >= ((__int128)1 << 32)) return false;
   const uint64_t range = (uint64_t)range128;
   // the payload arrays must be there for exactly this inner column (api.cpp builds them first)
@@ -2323,8 +2511,13 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   if (R < 1) R = 1;
   // every LDS sub-range re-reads the partition's records: beyond 3 the slice stays in L2 instead
   // (16-byte entries, at most 2 MB per partition so two or three live slices fit the XCD's 4 MB)
-  h.l2_mode = ((size_t)S1 * worst_bytes + kProbeLdsBudget - 1) / kProbeLdsBudget > 3;
-  if (h.l2_mode) {
+  h.l2_mode = h.keyed || ((size_t)S1 * worst_bytes + kProbeLdsBudget - 1) / kProbeLdsBudget > 3;
+  if (h.keyed) {
+    // slice = keys (8 B per slot) + payload (8 or 16 B per slot); beyond ~3.5 MB the L2 no longer holds it
+    if ((size_t)S1 * 16 > ((size_t)7 << 19)) return false;
+    if (!pay.kkeys || (!pay.pay16 && !pay.pay8)) return false;
+    R = 1;
+  } else if (h.l2_mode) {
     if ((size_t)S1 * sizeof(Pay16) > ((size_t)2 << 20)) return false;
     if (!pay.pay16 && !pay.pay8) return false;
     R = 1;
@@ -2345,7 +2538,7 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   sa.hm.R = 1;
   sa.hm.d_rcp = (uint32_t)(((uint64_t)1 << 32) / sa.hm.d);
   sa.hm.s1_rcp = (uint32_t)(((uint64_t)1 << 32) / S1);
-  sa.kmin = p.join_min;
+  sa.kmin = h.keyed ? 0 : p.join_min;
   sa.ns_int = 3;  // spilled / heavy-hitter partial rows: SUM, COUNT, COUNT of non-NULL values
   sa.ops_packed = (uint32_t)SO_SUM_I | ((uint32_t)SO_COUNT << 4) | ((uint32_t)SO_COUNT_NN << 8);
   sa.val_nullable = 1;
@@ -2397,12 +2590,14 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   pa.cap = sa.cap;
   pa.S1 = S1;
   pa.S2 = S2;
-  pa.kmin = p.join_min;
+  pa.kmin = h.keyed ? 0 : p.join_min;
   pa.range = range;
   pa.cnt_k = h.l2_mode ? nullptr : pay.cnt_k;
   pa.wsum_k = (!h.l2_mode && h.wcol >= 0) ? pay.wsum_k : nullptr;
   pa.wnn_k = (!h.l2_mode && need_nn) ? pay.wnn_k : nullptr;
-  pa.pay8 = (h.l2_mode && pay.pay8 && p.join_hash_type == 0 && !pay.has_nulls) ? pay.pay8 : nullptr;
+  pa.kkeys = h.keyed ? pay.kkeys : nullptr;
+  pa.pay8 = (h.l2_mode && pay.pay8 && (p.join_hash_type == 0 || p.join_hash_type == 1) && !pay.has_nulls) ? pay.pay8
+                                                                                                            : nullptr;
   pa.pay16 = (h.l2_mode && !pa.pay8) ? (const Pay16*)pay.pay16 : nullptr;
   if (h.l2_mode && !pa.pay8 && !pa.pay16) return false;
   pa.null_sum = INT64_MIN;
@@ -2419,7 +2614,8 @@ bool join_probe_supported(const DevPlan& p, const FragView& fv, const JoinPayloa
 // which inner column (if any) the payload of this plan has to be built for; false = shape not taken
 bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int* l2_mode) {
   JoinPayloadView fake{};
-  const __int128 range128 = (__int128)p.join_max - (__int128)p.join_min + 1;
+  const bool keyed = p.join_hash_type == 1 || p.join_hash_type == 3;
+  const __int128 range128 = keyed ? (__int128)p.join_entries : (__int128)p.join_max - (__int128)p.join_min + 1;
   if (range128 < 64 || range128 >= ((__int128)1 << 32)) return false;
   fake.entries = (int64_t)range128;
   fake.cnt_k = (const uint32_t*)16;  // shape test only: the pointers are not followed
@@ -2427,6 +2623,7 @@ bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int*
   fake.wnn_k = (const uint32_t*)16;
   fake.pay16 = (const void*)16;
   fake.pay8 = nullptr;
+  fake.kkeys = (const int64_t*)16;
   fake.has_nulls = 1;
   int wcol = -1;
   for (int i = 0; i < p.n_targets; ++i)
@@ -2435,7 +2632,7 @@ bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int*
   ProbePartHost h;
   if (!make_probe_plan(p, fv, fake, 256, kDefaultScratchCap, &h)) return false;
   *inner_col = h.wcol;
-  *l2_mode = h.l2_mode ? 1 : 0;
+  *l2_mode = h.keyed ? 2 : h.l2_mode ? 1 : 0;
   return true;
 }
 
@@ -2482,16 +2679,17 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
     if (st->ev_pool && ev_i + 1 < st->n_ev) (void)hipEventRecord(st->ev_pool[ev_i], s);
     const int8_t* const* cols = fv.d_cols + (size_t)f * fv.n_cols;
     const int64_t* nrows = fv.d_num_rows + f;
-    if (h.vcol >= 0) {
-      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, int64_t, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
-      hipLaunchKernelGGL((k_part_scatter<none_t, int64_t, true>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
-                         nrows, f1 - f, fv.n_cols, flt, p.join_col, vcol, h.sa, recs, cnt, sl);
+    auto scatter = [&](auto kern) {
+      (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
+      hipLaunchKernelGGL(kern, dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols, nrows, f1 - f, fv.n_cols, flt, p.join_col,
+                         vcol, h.sa, recs, cnt, sl);
+    };
+    if (h.keyed) {
+      if (h.vcol >= 0) scatter(k_part_scatter<none_t, int64_t, 2>);
+      else scatter(k_part_scatter<none_t, none_t, 2>);
     } else {
-      (void)hipFuncSetAttribute((const void*)k_part_scatter<none_t, none_t, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
-      hipLaunchKernelGGL((k_part_scatter<none_t, none_t, true>), dim3(h.sa.B), dim3(kPartBlock), h.lds1, s, cols,
-                         nrows, f1 - f, fv.n_cols, flt, p.join_col, vcol, h.sa, recs, cnt, sl);
+      if (h.vcol >= 0) scatter(k_part_scatter<none_t, int64_t, 1>);
+      else scatter(k_part_scatter<none_t, none_t, 1>);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -2500,7 +2698,10 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
       ev_i += 2;
     }
     st->n_launches += 1;
-    if (h.l2_mode) {
+    if (h.keyed) {
+      if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed<true>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc);
+      else hipLaunchKernelGGL((k_part_probe_keyed<false>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc);
+    } else if (h.l2_mode) {
       unsigned int* pace = std::getenv("MI355Q_PROBE_NO_PACING") ? nullptr : (unsigned int*)(acc2 + 2);
       if (pace) {
         e = hipMemsetAsync(pace, 0, 64, s);

@@ -24,16 +24,19 @@ def torch_cuda():
     return torch
 
 
+@pytest.mark.parametrize("sparse", [False, True], ids=["perfect", "keyed"])
 @pytest.mark.parametrize("one_to_many", [False, True])
 @pytest.mark.parametrize("left", [False, True])
 @pytest.mark.parametrize("shape", ["all_targets", "inner_only", "hot_key", "inner_nulls", "no_inner_col"])
-def test_payload_probe_matches_oracle(torch_cuda, oracle, one_to_many, left, shape):
+def test_payload_probe_matches_oracle(torch_cuda, oracle, one_to_many, left, shape, sparse):
     from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, HashJoin, InputColDescriptor,
                                       RelAlgExecutionUnit, TargetExpr)
     torch = torch_cuda
     rng = np.random.default_rng(11 + 2 * int(one_to_many) + int(left))
     n_keys = 400_000
     keys = np.sort(rng.choice(np.arange(5000, 5000 + 2 * n_keys, dtype=np.int64), n_keys, replace=False))
+    mul = 1000003 if sparse else 1   # sparse keys: the range is too wide for a perfect table -> keyed (baseline) table
+    keys = keys * mul
     if one_to_many:   # 1-4 inner rows per key, shuffled
         dim = rng.permutation(np.repeat(keys, rng.integers(1, 5, n_keys)))
     else:
@@ -47,14 +50,14 @@ def test_payload_probe_matches_oracle(torch_cuda, oracle, one_to_many, left, sha
     dk, dw = torch.from_numpy(dim).cuda(), torch.from_numpy(w).cuda()
     hj = HashJoin.getInstance(int(dk.data_ptr()), m, capi.INT64, ExpressionRange(True, dmin, dmax),
                               one_to_many=1 if one_to_many else 0)
-    assert hj.info()["hash_type"] == (2 if one_to_many else 0)
+    assert hj.info()["hash_type"] == (2 if one_to_many else 0) + (1 if sparse else 0)
     n = 3_000_000
-    k = rng.integers(dmin - 20000, dmax + 20000, n).astype(np.int64)
+    k = rng.integers(dmin // mul - 20000, dmax // mul + 20000, n).astype(np.int64) * mul   # about half of them match
     if shape == "hot_key":
         k[rng.random(n) < 0.4] = keys[777]
     v = rng.integers(-10**9, 10**9, n).astype(np.int64)
     v[rng.random(n) < 0.02] = -2**63   # skipped by the non-grouped SUM / COUNT(v)
-    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, dmin - 20000, dmax + 20000)),
+    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, dmin - 20000 * mul, dmax + 20000 * mul)),
              InputColDescriptor(capi.INT64, False, ExpressionRange(True, -10**9, 10**9))]
     inner = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, dmin, dmax)),
              InputColDescriptor(capi.INT64, w_nullable, ExpressionRange(True, -10**6, 10**6, w_nullable))]
