@@ -867,10 +867,26 @@ bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, P
     // single-column tables that fit LDS already have their kernel; multi-column ones reach it
     // through the packed index (mode 2); bucketed keys cannot be restored from their index
     const bool small = q.entry_count * (int64_t)q.row_size <= 64 * 1024;
-    if ((small && p.n_group_cols < 2) || q.entry_count >= ((int64_t)1 << 31)) return false;
+    // one plain NOT NULL INT / BIGINT (or FIXED(32)) key: k_perfect_lds reads it natively.  Every other
+    // single key — dictionary ids, FIXED(8/16), DATE in days, nullable (translated) keys — reaches the
+    // same kernel through the index column the pack kernel decodes it into.
+    if (small && p.n_group_cols < 2) {
+      const mi355q_col_desc& kc = p.cols[p.group_cols[0]];
+      const int tc = d.group_types[0];
+      const bool native = !kc.nullable && !q.group_bucket[0] &&
+                          (tc == MI355Q_INT32 || tc == MI355Q_INT64 ||
+                           (tc_enc(tc) == MI355Q_ENC_FIXED && tc_storage(tc) == MI355Q_INT32));
+      if (native) return false;
+    }
+    if (q.entry_count >= ((int64_t)1 << 31)) return false;
     ps->mode = small ? 2 : 1;
     for (int g = 0; g < p.n_group_cols; ++g) {
-      if (q.group_bucket[g]) return false;
+      // a bucketed range maps (key - min) / bucket to the index: the key can only be restored from the
+      // index when every value is a multiple of the bucket above min — DATE in days decoded to seconds
+      if (q.group_bucket[g] &&
+          !(tc_enc(d.group_types[g]) == MI355Q_ENC_DATE_IN_DAYS && q.group_bucket[g] == 86400 && q.group_min[g] % 86400 == 0))
+        return false;
+      ps->bucket[g] = q.group_bucket[g];
       ps->cols[g] = p.group_cols[g];
       ps->types[g] = d.group_types[g];
       ps->translate[g] = d.group_translate[g];

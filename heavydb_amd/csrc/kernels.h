@@ -84,6 +84,7 @@ struct PackSpec {
   int64_t tmp_init;
   int32_t translate[MI355Q_MAX_GROUP_COLS];
   int64_t mul[MI355Q_MAX_GROUP_COLS], null_key[MI355Q_MAX_GROUP_COLS];
+  int64_t bucket[MI355Q_MAX_GROUP_COLS];  // perfect-hash modes: 0, or the bucket the index divides by (DATE in days)
   // final slot <- temp slot (>= 0) or <- original value of key component -(1 + k)
   int32_t slot_src[MI355Q_MAX_SLOTS];
 };

@@ -595,6 +595,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_keys(PackSpec ps, const int8_t*
         if (ps.mode >= 1) {  // perfect hash: the entry index
           if (ps.translate[g] && k == int_null_of(ps.types[g])) k = ps.null_key[g];
           c = (uint64_t)k - (uint64_t)ps.min[g];
+          if (ps.bucket[g]) c /= (uint64_t)ps.bucket[g];  // get_group_value_fast's (key - min) / bucket
           bad = bad || k < ps.min[g] || c >= ps.card[g];
           code += c * (uint64_t)ps.mul[g];
           continue;
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_perfect(PackSpec ps, DevPlan 
     int64_t tk[MI355Q_MAX_GROUP_COLS], orig[MI355Q_MAX_GROUP_COLS];
     for (int g = 0; g < ps.n; ++g) {
       const int64_t d = (idx / ps.mul[g]) % (int64_t)ps.card[g];
-      tk[g] = d + ps.min[g];
+      tk[g] = d * (ps.bucket[g] ? ps.bucket[g] : 1) + ps.min[g];
       orig[g] = (ps.translate[g] && tk[g] == ps.null_key[g]) ? int_null_of(ps.types[g]) : tk[g];
     }
     int64_t* row = out + idx * p.row_quad;

@@ -1553,7 +1553,8 @@ __global__ __launch_bounds__(BLOCK) void k_part_probe_l2(ProbeArgs a, const Rec*
 template <bool PAY8>
 __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Rec* __restrict__ scratch,
                                                             const uint32_t* __restrict__ cnt,
-                                                            unsigned long long* __restrict__ acc) {
+                                                            unsigned long long* __restrict__ acc,
+                                                            unsigned int* __restrict__ pace) {
   __shared__ unsigned long long s_red[16 * PA_N];
   constexpr int BLOCK = 1024, UQ = 4;
   const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
@@ -1561,7 +1562,25 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
   const uint32_t entries = (uint32_t)a.range;
   unsigned long long v[PA_N];
   for (int k = 0; k < PA_N; ++k) v[k] = 0;
+  // a.R > 1: the partition's slot range is walked in R passes (each re-reads the partition's records and
+  // keeps the keys whose home slot is in the pass's sub-range), so that the slice being probed — 16 B per
+  // slot — stays within what an XCD's L2 holds next to the record stream
+  int it = 0;
   for (int p = xcd; p < a.P; p += 8) {
+   for (int r = 0; r < a.R; ++r, ++it) {
+    // pacing as in k_part_probe_l2: the XCD's workgroups stay within two consecutive (partition, pass) units
+    if (pace && it >= 2) {
+      if (t == 0) {
+        const unsigned int need = (unsigned int)(it - 1) * (unsigned int)G;
+        unsigned int spins = 0;
+        while (__hip_atomic_load(pace + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1u << 14)) break;
+        }
+      }
+      __syncthreads();
+    }
+    const uint32_t sub_lo = (uint32_t)p * a.S1 + (uint32_t)r * a.S2, sub_hi = sub_lo + a.S2;
     for (int b = g; b < a.B; b += G) {
       const uint32_t n = cnt[(size_t)p * a.B + b];
       const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
@@ -1581,15 +1600,17 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
         }
         uint32_t hp[UQ];
         int64_t k0[UQ];
+        bool mine[UQ];
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {  // the first probe of all four, unconditionally, in flight together
           hp[q] = murmur1_u64((uint64_t)rec[q].key) % entries;
-          k0[q] = a.kkeys[hp[q]];
+          mine[q] = a.R == 1 || (hp[q] >= sub_lo && hp[q] < sub_hi);
+          k0[q] = a.kkeys[mine[q] ? hp[q] : sub_lo];
         }
         int64_t slot[UQ];
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
-          const bool live = i0 + q * BLOCK + t < n;
+          const bool live = i0 + q * BLOCK + t < n && mine[q];
           slot[q] = -1;
           if (live) {
             int64_t k = k0[q];
@@ -1638,6 +1659,11 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
         for (int q = 0; q < UQ; ++q) rec[q] = nxt[q];
       }
     }
+    if (pace) {
+      __syncthreads();
+      if (t == 0) atomicAdd(pace + xcd, 1u);
+    }
+   }
   }
   probe_reduce_store(acc, v, s_red);
 }
@@ -2513,10 +2539,18 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   // (16-byte entries, at most 2 MB per partition so two or three live slices fit the XCD's 4 MB)
   h.l2_mode = h.keyed || ((size_t)S1 * worst_bytes + kProbeLdsBudget - 1) / kProbeLdsBudget > 3;
   if (h.keyed) {
-    // slice = keys (8 B per slot) + payload (8 or 16 B per slot); beyond ~3.5 MB the L2 no longer holds it
-    if ((size_t)S1 * 16 > ((size_t)7 << 19)) return false;
+    // slice = keys (8 B per slot) + payload (8 or 16 B per slot): passes of at most 3.5 MB of it.  Measured on
+    // cfg4's sparse 200 M-slot table (3.1 MB per partition, 3.2 B rows, profiles/r02_keyed_probe_passes.jsonl):
+    // one pass 89 ms, two passes of 1.6 MB 114 ms (the second read of the records costs more than the smaller
+    // slice gives), direct probe 140 ms; without pacing the XCD group 113 / 129 ms
     if (!pay.kkeys || (!pay.pay16 && !pay.pay8)) return false;
-    R = 1;
+    R = (uint32_t)(((size_t)S1 * 16 + ((size_t)7 << 19) - 1) / ((size_t)7 << 19));
+    if (R < 1) R = 1;
+    if (const char* e = std::getenv("MI355Q_PROBE_KEYED_R")) {  // tests: several passes on a small table
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 4) R = (uint32_t)v;
+    }
+    if (R > 4) return false;
   } else if (h.l2_mode) {
     if ((size_t)S1 * sizeof(Pay16) > ((size_t)2 << 20)) return false;
     if (!pay.pay16 && !pay.pay8) return false;
@@ -2698,15 +2732,15 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
       ev_i += 2;
     }
     st->n_launches += 1;
+    unsigned int* pace = (h.l2_mode && !std::getenv("MI355Q_PROBE_NO_PACING")) ? (unsigned int*)(acc2 + 2) : nullptr;
+    if (pace) {
+      e = hipMemsetAsync(pace, 0, 64, s);
+      if (e != hipSuccess) return e;
+    }
     if (h.keyed) {
-      if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed<true>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc);
-      else hipLaunchKernelGGL((k_part_probe_keyed<false>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc);
+      if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed<true>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      else hipLaunchKernelGGL((k_part_probe_keyed<false>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
     } else if (h.l2_mode) {
-      unsigned int* pace = std::getenv("MI355Q_PROBE_NO_PACING") ? nullptr : (unsigned int*)(acc2 + 2);
-      if (pace) {
-        e = hipMemsetAsync(pace, 0, 64, s);
-        if (e != hipSuccess) return e;
-      }
       // one 1024-lane workgroup per CU (measured, 3.2 B rows: 2048 workgroups of 256 lanes stream the
       // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms;
       // four or eight records per lane per step: no difference)

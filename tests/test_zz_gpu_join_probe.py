@@ -171,3 +171,11 @@ def test_payload_probe_l2_mode(torch_cuda, oracle, left, inner_nulls):
     q, want, code = oracle.execute(ra.to_plan(), [[k, v]], [dim, w], oj, n_threads=4)
     assert code == 0
     compare_buffers(q, want, rs.getStorage())
+
+
+def test_keyed_probe_in_several_passes(torch_cuda, oracle, monkeypatch):
+    """The keyed probe with its slot range walked in 3 passes per partition (what a table too large for one
+    L2-resident slice per partition gets), forced on a small table."""
+    monkeypatch.setenv("MI355Q_PROBE_KEYED_R", "3")
+    test_payload_probe_matches_oracle(torch_cuda, oracle, True, True, "all_targets", True)
+    test_payload_probe_matches_oracle(torch_cuda, oracle, False, False, "hot_key", True)
