@@ -838,7 +838,8 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
                                                                 const uint32_t* __restrict__ cnt,
                                                                 PartSlots ps, TableArgs tab, SpillList sl,
                                                                 int merge, uint32_t chunk_records_max,
-                                                                unsigned long long* __restrict__ dbg) {
+                                                                unsigned long long* __restrict__ dbg,
+                                                                unsigned int* __restrict__ pair_ctr) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int64_t* const lkeys = (int64_t*)smem_raw;
   uint32_t* bitmap = (uint32_t*)(smem_raw + g.lds_table_bytes);  // [(S2 + 31) / 32]
@@ -947,6 +948,23 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     for (int b = t; b < g.B; b += kPartBlock) lcnt[b] = cnt[(size_t)p * g.B + b];
     __syncthreads();
     mark(0);
+    // Pair rendezvous (speed only): the two sub-range workgroups of a partition — same XCD, blocks b and
+    // b ^ 8 — read the SAME runs in the same order; started together, the second reader of a line finds
+    // it in the XCD's L2 instead of fetching it from HBM again.  One counter per pair, bumped by both at
+    // this point of every unit; bounded wait, a partner that never shows up only costs the pacing.
+    if (pair_ctr && paired && R == 2) {
+      if (t == 0) {
+        unsigned int* c = pair_ctr + (blockIdx.x & ~8u);
+        atomicAdd(c, 1u);
+        const unsigned int need = 2u * (unsigned int)(it + 1);
+        unsigned int spins = 0;
+        while (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1u << 14)) break;
+        }
+      }
+      __syncthreads();
+    }
     if (n_slots) {
       if (merge) {
         // groups of earlier chunks: re-load this range of the table as partial rows
@@ -2052,7 +2070,7 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     }
     h.g.cap = (uint32_t)cap;
     h.rec_bytes = (int64_t)P * h.g.B * (int64_t)cap * (int64_t)sizeof(Rec);
-    h.cnt_bytes = ((int64_t)P * h.g.B * 4 + 255) & ~255ll;
+    h.cnt_bytes = (((int64_t)P * h.g.B * 4 + 255) & ~255ll) + 4096;  // run lengths + the pair counters of phase 2
     // spill list: room for 1/16 of the chunk's rows (skewed keys overflow their runs by a few
     // per cent of the records), at least kSpillMin entries
     int64_t spill_cap = chunk_rows / 16;
@@ -2180,6 +2198,8 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                             (int)h.lds2);
   // MI355Q_TRACE: per-phase cycle counters of phase 2 live in the spill header's tail
   unsigned long long* dbg = std::getenv("MI355Q_TRACE") ? (unsigned long long*)(spill_base + 64) : nullptr;
+  unsigned int* pair_ctr = (n_cus * 4 <= 4096 && !std::getenv("MI355Q_NO_PAIR_RENDEZVOUS"))
+                               ? (unsigned int*)((char*)scratch + h.rec_bytes + h.cnt_bytes - 4096) : nullptr;
   ScatterArgs sa{};
   sa.P = h.g.P;
   sa.lgL = h.g.lgL;
@@ -2218,8 +2238,13 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     st->n_launches += 1;
     const int units = h.g.P * (int)h.g.hm.R;
     const int grid2 = units < n_cus ? units : n_cus;
+    if (pair_ctr) {
+      e = hipMemsetAsync(pair_ctr, 0, 4096, s);
+      if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(agg_kernel, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, recs, cnt, h.ps,
-                       tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg);
+                       tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg,
+                       pair_ctr);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
