@@ -1799,6 +1799,41 @@ int32_t mi355q_shard_merge_range(mi355q_result* r, const void* rows, int64_t n_r
   return h_err;
 }
 
+int32_t mi355q_shard_merge_slices(mi355q_result* r, const void* const* slices, const void* const* pads, int32_t n_src,
+                                  int32_t pad_rows, int64_t home_lo, int64_t home_hi, void* stream) {
+  if (!r || !slices || n_src < 1 || pad_rows < 0 || home_lo < 0 || home_hi <= home_lo || home_hi > r->qmd.entry_count)
+    return MI355Q_ERR_INVALID_PLAN;
+  if (!slice_exchange_shape(r->qmd) || n_src > 16) return MI355Q_ERR_UNSUPPORTED;
+  for (int i = 0; i < n_src; ++i)
+    if (!slices[i] || (pads && pad_rows > 0 && !pads[i])) return MI355Q_ERR_INVALID_PLAN;
+  DeviceCtx& ctx = ctx_of(r->device_id);
+  std::lock_guard<std::recursive_mutex> lk(ctx.mu);
+  DeviceGuard g(r->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  const int n_cus = cu_count_of(r->device_id);
+  const int64_t need = slice_merge_scratch_bytes(r->dplan, home_lo, home_hi, n_cus);
+  if (need == 0) return MI355Q_ERR_UNSUPPORTED;  // the caller folds with mi355q_shard_merge_range
+  if (need + 64 > ctx.scratch_bytes) {
+    if (ctx.scratch) (void)hipFree(ctx.scratch);
+    ctx.scratch = nullptr;
+    ctx.scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx.scratch, (size_t)need + 64));
+    ctx.scratch_bytes = need + 64;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // the error word: the last 64 bytes of the workspace
+  int32_t* d_err = (int32_t*)((char*)ctx.scratch + ((need + 7) & ~(int64_t)7));
+  HIP_TRY(hipMemsetAsync(d_err, 0, 2 * sizeof(int32_t), s));
+  HIP_TRY(launch_slice_merge(r->dplan, r->buf, (const int64_t* const*)slices, pads && pad_rows > 0 ? (const int64_t* const*)pads : nullptr,
+                             n_src, pad_rows, home_lo, home_hi, d_err, ctx.scratch, need, n_cus, s));
+  int32_t h_err[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  // word 0: the table ran out of group slots; word 1: the stray list overflowed.  Either way rows
+  // [home_lo, home_hi) of r are incomplete: re-initialise r and fold with mi355q_shard_merge_range.
+  return (h_err[0] || h_err[1]) ? MI355Q_ERR_OUT_OF_SLOTS : MI355Q_OK;
+}
+
 // ------------------------------------------------------------------------------- synth
 int32_t mi355q_generate_column(int32_t device_id, void* dst, int64_t n_rows, int64_t row_offset,
                                int32_t kind, uint64_t seed, int64_t a, int64_t b, int64_t c,

@@ -56,6 +56,13 @@ hipError_t launch_shard_pads(const DevPlan& p, const int64_t* buf, int world, in
                              int32_t* d_ok, hipStream_t s);
 hipError_t launch_reduce_range(const DevPlan& p, int idx_target_as_key, int64_t* this_buf, const int64_t* that_rows,
                                int64_t that_entries, int64_t home_lo, int64_t home_hi, int32_t* d_err, hipStream_t s);
+// LDS fold of the slice exchange (kernels_part.hip): rows [lo, hi) of n_src tables + their pads into rows
+// [lo, hi) of `out`; 0 scratch bytes = the layout is not one the partitioned family takes
+int64_t slice_merge_scratch_bytes(const DevPlan& p, int64_t lo, int64_t hi, int n_cus);
+hipError_t launch_slice_merge(const DevPlan& p, int64_t* out, const int64_t* const* src, const int64_t* const* pads,
+                              int n_src, int pad_rows, int64_t lo, int64_t hi, int32_t* d_err, void* scratch,
+                              int64_t scratch_bytes, int n_cus, hipStream_t s);
+
 hipError_t launch_shard_partition(const DevPlan& p, int idx_target_as_key, const int64_t* buf,
                                   int n_parts, int64_t* out_rows, int64_t* d_part_counts,
                                   int64_t* d_cursors /* n_parts scratch */, hipStream_t s);

@@ -167,6 +167,20 @@ struct TableArgs {
   int64_t init[MI355Q_MAX_SLOTS];
 };
 
+// Slice-merge mode of phase 2 (multi-device merge): no records; every unit of this rank's
+// home range folds the rows of the same table range out of `n_src` tables — the slices the peers sent —
+// into its LDS table, plus (the last unit) the pad rows that followed each slice.  Rows are partial rows
+// like the ones a later chunk re-loads, so the merge-load code is the same; a row whose home slot is in
+// the range but not in the unit goes to the spill list (merged by k_spill_merge), a row whose home slot
+// is outside [lo, hi) belongs to another rank and is dropped.
+constexpr int kMaxMergeSrc = 16;
+struct SliceMerge {
+  const int64_t* src[kMaxMergeSrc];   // src[i] + (slot - lo) * row_quad = row `slot` of table i, slot in [lo, hi)
+  const int64_t* pads[kMaxMergeSrc];  // pad_rows rows that followed slice i (slots hi, hi + 1, ... wrapping)
+  int32_t n_src, pad_rows;
+  uint32_t lo, hi;
+};
+
 struct SpillList {
   uint32_t* count;     // device word
   int64_t* entries;    // [cap][1 + ns_int]
@@ -839,7 +853,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
                                                                 PartSlots ps, TableArgs tab, SpillList sl,
                                                                 int merge, uint32_t chunk_records_max,
                                                                 unsigned long long* __restrict__ dbg,
-                                                                unsigned int* __restrict__ pair_ctr) {
+                                                                unsigned int* __restrict__ pair_ctr, SliceMerge ms) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int64_t* const lkeys = (int64_t*)smem_raw;
   uint32_t* bitmap = (uint32_t*)(smem_raw + g.lds_table_bytes);  // [(S2 + 31) / 32]
@@ -934,9 +948,15 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       uint64_t a = p_lo + (uint64_t)r * g.hm.S2, z = a + g.hm.S2;
       if (z > p_hi) z = p_hi;
       if (a > z) a = z;
+      if (ms.n_src > 0) {  // slice merge: only the part of the unit inside this rank's home range
+        if (a < ms.lo) a = ms.lo;
+        if (z > ms.hi) z = ms.hi;
+        if (a > z) a = z;
+      }
       lo = (uint32_t)a;
       n_slots = (uint32_t)(z - a);
     }
+    if (ms.n_src > 0 && n_slots == 0) continue;  // a unit of another rank's range (uniform per workgroup)
     for (uint32_t e = t; e < g.E; e += kPartBlock) {
       lkeys[e] = kEmptyKey64;  // (initialisation: the key layout does not matter here)
       for (int m = 0; m < ns; ++m) {
@@ -945,7 +965,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       }
     }
     for (uint32_t w = t; w < bm_words; w += kPartBlock) bitmap[w] = 0;
-    for (int b = t; b < g.B; b += kPartBlock) lcnt[b] = cnt[(size_t)p * g.B + b];
+    for (int b = t; b < g.B; b += kPartBlock) lcnt[b] = cnt ? cnt[(size_t)p * g.B + b] : 0u;
     __syncthreads();
     mark(0);
     // Pair rendezvous (speed only): the two sub-range workgroups of a partition — same XCD, blocks b and
@@ -966,12 +986,11 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       __syncthreads();
     }
     if (n_slots) {
-      if (merge) {
-        // groups of earlier chunks: re-load this range of the table as partial rows
-        for (uint32_t s = t; s < n_slots; s += kPartBlock) {
-          const int64_t* row = tab.out + (size_t)(lo + s) * tab.row_quad;
+      // one partial row (a table row of an earlier chunk, or of a peer's slice) into the LDS table
+      auto merge_row = [&](const int64_t* row, bool foreign_possible) {
+        {
           const int64_t key = row[0];
-          if (key == kEmptyKey64) continue;
+          if (key == kEmptyKey64) return;
           int64_t part[kMaxInt];
           for (int m = 0; m < kMaxInt; ++m) part[m] = 0;
           bool big = false;  // a 32-bit LDS counter could wrap
@@ -993,17 +1012,29 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
           // matters
           if (ps.nn_slot >= 0 && ps.nn_hidden) part[ps.nn_slot] = any_value ? 1 : 0;
           const uint32_t h = murmur3_u64((uint64_t)key);
-          const uint32_t x = home_from_hash(g.hm, h) - lo;
+          const uint32_t home = home_from_hash(g.hm, h);
+          if (foreign_possible && (home < ms.lo || home >= ms.hi)) return;  // another rank's key
+          const uint32_t x = home - lo;
           const int64_t kid = kid_of(key, h);
           const uint32_t e = (x < n_slots && !big && kid != kEmptyKey64)
                                  ? lds_locate(lkeys, n_buckets, bucket_of(x), bucket_b_of(h, n_buckets), kid)
                                  : kNoEntry;
           if (e == kNoEntry) {  // probed in from another range / no room / huge count: merged last
             spill_append(sl, key, part, ns);
-            continue;
+            return;
           }
           for (int m = 0; m < ns; ++m) lds_merge(ps.int_op[m], smem_raw + g.slot_off[m], e, part[m]);
         }
+      };
+      if (merge) {
+        // groups of earlier chunks: re-load this range of the table as partial rows
+        for (uint32_t s = t; s < n_slots; s += kPartBlock) merge_row(tab.out + (size_t)(lo + s) * tab.row_quad, false);
+      }
+      for (int i = 0; i < ms.n_src; ++i) {
+        for (uint32_t s = t; s < n_slots; s += kPartBlock)
+          merge_row(ms.src[i] + (size_t)(lo + s - ms.lo) * tab.row_quad, true);
+        if (lo + n_slots == ms.hi)  // the unit that ends the range also takes the pads
+          for (uint32_t s = t; s < (uint32_t)ms.pad_rows; s += kPartBlock) merge_row(ms.pads[i] + (size_t)s * tab.row_quad, true);
       }
       mark(1);
       // one wave per run; four 16-byte record loads per lane, the next four already in flight
@@ -2244,7 +2275,7 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     }
     hipLaunchKernelGGL(agg_kernel, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, recs, cnt, h.ps,
                        tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg,
-                       pair_ctr);
+                       pair_ctr, SliceMerge{});
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2274,6 +2305,101 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
                  h_dbg[0] / wg / 1e6, h_dbg[1] / wg / 1e6, h_dbg[2] / wg / 1e6, h_dbg[3] / wg / 1e6, h_dbg[4] / wg / 1e6, h_sp);
   }
   return hipSuccess;
+}
+
+// ---------------------------------------------------------------- slice merge (multi-device): host side
+namespace {
+
+// The slot program of a table known only by its layout (mi355q_result_create: no input columns): the
+// merge of partial rows does not care which column a slot was fed from.
+bool slice_merge_plan(const DevPlan& p, int n_cus, FastShape* fs, PartPlanHost* h) {
+  if (p.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || p.n_group != 1 || p.key_width != 8 || p.slot_width != 8 ||
+      p.key_quad != 1)
+    return false;
+  DevPlan q = p;
+  q.join_col = -1;
+  q.n_quals = 0;
+  for (int i = 0; i < q.n_targets; ++i) {
+    DevTarget& t = q.targets[i];
+    t.table = 0;
+    if (t.arg_f32) return false;
+    if (t.agg == MI355Q_PROJECT_KEY || (t.agg == MI355Q_COUNT && !t.skip_null)) continue;
+    t.col = 0;
+    t.arg_type = t.arg_fp ? MI355Q_DOUBLE : MI355Q_INT64;
+  }
+  FragView fv{};
+  fv.total_rows = 1;
+  fv.max_frag_rows = 1;
+  if (!grouped_fast_shape(q, fv, fs)) return false;
+  return make_part_plan(q, *fs, fv, n_cus, kDefaultScratchCap, h);
+}
+
+uint32_t slice_merge_spill_cap(int64_t lo, int64_t hi) {
+  // strays of clusters that cross a unit boundary, partial counts too large for a 32-bit LDS counter, rows
+  // the two-choice table had no room for: a small fraction of the range (an overflow is reported through
+  // d_err, the caller then folds with mi355q_shard_merge_range)
+  const int64_t c = (hi - lo) / 4 + 65536;
+  return (uint32_t)(c > 0x7fffffffll ? 0x7fffffffll : c);
+}
+
+}  // namespace
+
+int64_t slice_merge_scratch_bytes(const DevPlan& p, int64_t lo, int64_t hi, int n_cus) {
+  FastShape fs;
+  PartPlanHost h;
+  if (!slice_merge_plan(p, n_cus, &fs, &h)) return 0;
+  return 256 + (int64_t)slice_merge_spill_cap(lo, hi) * 8 * (1 + h.g.ns_int) + 64;
+}
+
+// Folds rows [lo, hi) of `n_src` tables (src[i] = the address of row `lo` of table i) and the pad_rows
+// rows that followed each into rows [lo, hi) of `out`, keeping only keys whose home slot is in [lo, hi).
+// Rows [lo, hi) of `out` are overwritten (canonical emission per unit); strays are CAS-merged afterwards
+// and may land anywhere from their home slot on, like any late insert.
+hipError_t launch_slice_merge(const DevPlan& p, int64_t* out, const int64_t* const* src, const int64_t* const* pads,
+                              int n_src, int pad_rows, int64_t lo, int64_t hi, int32_t* d_err, void* scratch,
+                              int64_t scratch_bytes, int n_cus, hipStream_t s) {
+  if (n_src < 1 || n_src > kMaxMergeSrc || lo < 0 || hi <= lo || hi > p.entry_count) return hipErrorInvalidValue;
+  FastShape fs;
+  PartPlanHost h;
+  if (!slice_merge_plan(p, n_cus, &fs, &h)) return hipErrorInvalidValue;
+  const uint32_t spill_cap = slice_merge_spill_cap(lo, hi);
+  if (256 + (int64_t)spill_cap * 8 * (1 + h.g.ns_int) > scratch_bytes) return hipErrorInvalidValue;
+  char* spill_base = (char*)scratch;
+  SpillList sl{(uint32_t*)spill_base, (int64_t*)(spill_base + 256), d_err, spill_cap, 1 + h.g.ns_int};
+  hipError_t e = hipMemsetAsync(spill_base, 0, 256, s);
+  if (e != hipSuccess) return e;
+  TableArgs tab{};
+  tab.out = out;
+  tab.entry_count = (uint32_t)p.entry_count;
+  tab.row_quad = p.row_quad;
+  tab.sp = fs.sp;
+  for (int j = 0; j < MI355Q_MAX_SLOTS; ++j) tab.init[j] = p.init_vals[j];
+  SliceMerge ms{};
+  for (int i = 0; i < n_src; ++i) {
+    ms.src[i] = src[i];
+    ms.pads[i] = pads ? pads[i] : nullptr;
+  }
+  ms.n_src = n_src;
+  ms.pad_rows = pads ? pad_rows : 0;
+  ms.lo = (uint32_t)lo;
+  ms.hi = (uint32_t)hi;
+  auto agg_kernel = k_part_aggregate<0>;  // no records in this mode: the op-set members gain nothing
+  (void)hipFuncSetAttribute((const void*)agg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds2);
+  const int units = h.g.P * (int)h.g.hm.R;
+  const int grid2 = units < n_cus ? units : n_cus;
+  // 32-bit LDS counters: n_src partial counts are added up per group; a partial that could make the sum
+  // wrap goes through the 64-bit spill merge instead
+  const uint32_t big_from = 0xffffffffu - 0xffffffffu / (uint32_t)(n_src + 1);
+  hipLaunchKernelGGL(agg_kernel, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, (const Rec*)nullptr,
+                     (const uint32_t*)nullptr, h.ps, tab, sl, 0, big_from, (unsigned long long*)nullptr,
+                     (unsigned int*)nullptr, ms);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            h.g.ns_int * kSpillLds * 8);
+  hipLaunchKernelGGL(k_spill_merge, dim3(512), dim3(256), (size_t)h.g.ns_int * kSpillLds * 8, s, h.ps, tab, sl,
+                     h.g.ns_int);
+  return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- radix join probe: host side

@@ -146,6 +146,7 @@ def merge_keyed(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool 
 
 
 LAST_KEYED_PATH = ""   # which keyed merge ran last in this process ("slices" / "partition"): for tests and bench.py
+LAST_SLICE_FOLD = ""   # how the received slices were folded last ("lds": mi355q_shard_merge_slices / "rows")
 SLICE_PAD_ROWS = 1024  # rows after a slice's end that travel with it (the tail of a boundary-crossing cluster)
 
 
@@ -187,8 +188,15 @@ def _merge_keyed_by_slices(shard: ShardOps, dist, torch, group) -> Optional[Shar
     flag = ok.min().to(torch.int64).reshape(1)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     out = shard.fresh_like()
-    out.merge_range(recv_main, b[rank], b[rank + 1])
-    out.merge_range(recv_pads.view(-1, rq), b[rank], b[rank + 1])
+    # one LDS fold of all slices and pads when the backend has it and takes the layout ...
+    folded = out.merge_slices(recv_main, recv_pads, world, b[rank], b[rank + 1]) if hasattr(out, "merge_slices") else False
+    if folded is None:      # ... overflowed half way: start from a fresh table
+        out = shard.fresh_like()
+    if not folded:          # ... else row by row with the reduce kernel
+        out.merge_range(recv_main, b[rank], b[rank + 1])
+        out.merge_range(recv_pads.view(-1, rq), b[rank], b[rank + 1])
+    global LAST_SLICE_FOLD
+    LAST_SLICE_FOLD = "lds" if folded else "rows"
     if int(flag.item()) == 0:   # a cluster longer than the pad somewhere: the general path
         return None
     return out
@@ -307,6 +315,25 @@ class HipShard:
             self._torch.cuda.current_stream().synchronize()
             check(self._lib.mi355q_shard_merge_range(self.handle, int(rows.data_ptr()), n, home_lo, home_hi, None),
                   "shard_merge_range")
+
+    def merge_slices(self, recv_main, recv_pads, n_src: int, home_lo: int, home_hi: int):
+        """All received slices ([n_src * (home_hi - home_lo), rq]) and pads ([n_src, pad, rq]) in one LDS fold.
+        True = done; False = layout not taken (self untouched); None = overflow (self incomplete)."""
+        if n_src > 16:
+            return False
+        rq = self._qmd.row_size // 8
+        step = (home_hi - home_lo) * rq * 8
+        pad_rows = int(recv_pads.shape[1])
+        slices = (C.c_void_p * n_src)(*[int(recv_main.data_ptr()) + i * step for i in range(n_src)])
+        pads = (C.c_void_p * n_src)(*[int(recv_pads.data_ptr()) + i * pad_rows * rq * 8 for i in range(n_src)])
+        self._torch.cuda.current_stream().synchronize()
+        code = self._lib.mi355q_shard_merge_slices(self.handle, slices, pads, n_src, pad_rows, home_lo, home_hi, None)
+        if code == capi.ERR_UNSUPPORTED:
+            return False
+        if code == capi.ERR_OUT_OF_SLOTS:
+            return None
+        check(code, "shard_merge_slices")
+        return True
 
     def merge_rows(self, rows) -> None:
         n = int(rows.shape[0])

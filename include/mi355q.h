@@ -574,6 +574,16 @@ int32_t mi355q_shard_pads(const mi355q_result* r, int32_t world, int32_t pad_row
                           int32_t* ok_dev, void* stream);
 int32_t mi355q_shard_merge_range(mi355q_result* r, const void* rows, int64_t n_rows, int64_t home_lo,
                                  int64_t home_hi, void* stream);
+/* The same fold in one launch and in LDS (phase 2 of the partitioned GROUP BY without records): rows
+ * [home_lo, home_hi) of `n_src` tables of r's layout — slices[i] is the device address of row home_lo of
+ * table i, i.e. what peer i sent — plus the pad_rows rows that followed each (pads[i]; pads may be NULL)
+ * are merged into rows [home_lo, home_hi) of r, which are OVERWRITTEN (r is a fresh table in the slice
+ * exchange).  n_src <= 16.  MI355Q_ERR_UNSUPPORTED: a slot program the partitioned family does not take
+ * (r untouched: use mi355q_shard_merge_range); MI355Q_ERR_OUT_OF_SLOTS: the table or the stray list
+ * overflowed (r incomplete: re-create it and use mi355q_shard_merge_range). */
+int32_t mi355q_shard_merge_slices(mi355q_result* r, const void* const* slices, const void* const* pads,
+                                  int32_t n_src, int32_t pad_rows, int64_t home_lo, int64_t home_hi,
+                                  void* stream);
 /* Insert `n_rows` whole rows (same layout as r) into r with the reduce semantics. */
 int32_t mi355q_shard_merge_rows(mi355q_result* r, const void* rows, int64_t n_rows,
                                 void* stream);

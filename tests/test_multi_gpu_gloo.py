@@ -92,6 +92,15 @@ class NumpyShard:
         for o in range(0, len(mine), self._q.entry_count):  # merge_rows lays at most entry_count rows into a buffer
             self.merge_rows(self._torch.from_numpy(np.ascontiguousarray(mine[o:o + self._q.entry_count])))
 
+    def merge_slices(self, recv_main, recv_pads, n_src, home_lo, home_hi):
+        # twin of mi355q_shard_merge_slices: the same fold in one call (16 sources at most, like the library)
+        if n_src > 16:
+            return False
+        assert recv_main.shape[0] == n_src * (home_hi - home_lo) and recv_pads.shape[0] == n_src
+        self.merge_range(recv_main, home_lo, home_hi)
+        self.merge_range(recv_pads.reshape(-1, recv_pads.shape[-1]), home_lo, home_hi)
+        return True
+
     def reduce_from(self, other_buffer):
         other = np.ascontiguousarray(other_buffer.numpy()).reshape(self._np.shape)
         assert self._orc.reduce(self._q, self._np, other) == 0

@@ -26,8 +26,12 @@ def torch_cuda():
     return torch
 
 
-@pytest.mark.parametrize("world,fill", [(2, 0.5), (8, 0.5), (5, 0.85)])
-def test_slice_merge_with_simulated_ranks(torch_cuda, oracle, world, fill):
+# slot programs: "mixed" aggregates two value columns (only the row-by-row fold takes it); "f64" and
+# "nullable_i64" are programs of the partitioned family, which the LDS fold (mi355q_shard_merge_slices) takes
+@pytest.mark.parametrize("fold", ["rows", "lds"])
+@pytest.mark.parametrize("world,fill,prog", [(2, 0.5, "mixed"), (8, 0.5, "f64"), (5, 0.85, "nullable_i64"),
+                                             (16, 0.5, "nullable_i64"), (3, 0.7, "f64")])
+def test_slice_merge_with_simulated_ranks(torch_cuda, oracle, world, fill, prog, fold):
     from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, InputColDescriptor, RelAlgExecutionUnit,
                                       TargetExpr)
     from heavydb_amd.multi_gpu import SLICE_PAD_ROWS, HipShard, slice_bounds, slice_exchange_ok
@@ -43,9 +47,13 @@ def test_slice_merge_with_simulated_ranks(torch_cuda, oracle, world, fill):
     descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7)),
              InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0)),
              InputColDescriptor(capi.INT64, True, ExpressionRange(True, -10**6, 10**6, True))]
-    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1),
-                                     TargetExpr(capi.MIN, 2), TargetExpr(capi.SUM, 2)], [], [0],
-                             max_groups_buffer_entry_guess=entries)
+    targets = {"mixed": [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1),
+                         TargetExpr(capi.MIN, 2), TargetExpr(capi.SUM, 2)],
+               "f64": [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1),
+                       TargetExpr(capi.MIN, 1), TargetExpr(capi.MAX, 1)],
+               "nullable_i64": [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 2), TargetExpr(capi.PROJECT_KEY),
+                                TargetExpr(capi.MIN, 2), TargetExpr(capi.COUNT, 2)]}[prog]
+    ra = RelAlgExecutionUnit(descs, targets, [], [0], max_groups_buffer_entry_guess=entries)
     cuts = np.linspace(0, n, n_frags + 1).astype(int) // 4 * 4
     cuts[-1] = n
     cols = [key, val, ival]
@@ -69,14 +77,22 @@ def test_slice_merge_with_simulated_ranks(torch_cuda, oracle, world, fill):
         recv_main = torch.cat([s.buffer()[b[r]:b[r + 1]] for s in shards]).contiguous()
         recv_pads = torch.cat([p[r] for p in pads]).contiguous()
         out = shards[r].fresh_like()
-        out.merge_range(recv_main, b[r], b[r + 1])
-        out.merge_range(recv_pads.view(-1, rq), b[r], b[r + 1])
+        if fold == "lds":
+            took = out.merge_slices(recv_main, recv_pads.view(world, SLICE_PAD_ROWS, rq), world, b[r], b[r + 1])
+            assert took is (prog != "mixed")
+            if not took:
+                continue
+        else:
+            out.merge_range(recv_main, b[r], b[r + 1])
+            out.merge_range(recv_pads.view(-1, rq), b[r], b[r + 1])
         torch.cuda.synchronize()
         rows = out.buffer().cpu().numpy()
         live = rows[rows[:, 0] != EMPTY64]
         home = (murmur3_u64(live[:, 0]) % np.uint64(entries)).astype(np.int64)
         assert ((home >= b[r]) & (home < b[r + 1])).all()
         merged.append(live)
+    if not merged:
+        return   # the LDS fold declined the layout on every rank (asserted above)
     allrows = np.concatenate(merged)
     assert len(np.unique(allrows[:, 0])) == len(allrows)      # every key on exactly one rank
     got = np.full((entries, rq), 0, dtype=np.int64)

@@ -61,6 +61,16 @@ def main():
     fold_ms, out = timed(fold)
     live = int((out.buffer()[:, 0] != 2**63 - 1).sum().item())
 
+    took = []
+
+    def fold_lds():
+        o = shards[0].fresh_like()
+        took.append(o.merge_slices(recv_main, recv_pads.view(world, SLICE_PAD_ROWS, rq), world, b[0], b[1]))
+        return o
+    lds_ms, out_lds = timed(fold_lds)
+    live_lds = int((out_lds.buffer()[:, 0] != 2**63 - 1).sum().item())
+    fresh_ms, _ = timed(lambda: shards[0].fresh_like())
+
     def general():
         rows, counts = shards[0].partition_rows(world)
         o = shards[0].fresh_like()
@@ -69,6 +79,8 @@ def main():
     gen_ms, _ = timed(general)
     print(json.dumps({"world": world, "rows_per_rank": total // world, "step_ms_per_rank": round(sum(step_ms) / world, 2),
                       "slice_path_ms": {"pads": round(pads_ms, 3), "fold_slices_and_pads_incl_fresh_table": round(fold_ms, 3),
+                                        "lds_fold_incl_fresh_table": round(lds_ms, 3), "lds_fold_took": bool(took and took[-1]),
+                                        "groups_after_lds_fold": live_lds, "fresh_table_alone": round(fresh_ms, 3),
                                         "exchange_bytes_per_pair": int((b[1] - b[0]) * q.row_size)},
                       "general_path_ms": {"partition_plus_merge_rows_incl_fresh_table": round(gen_ms, 3)},
                       "groups_owned_by_rank0": live, "pads_ok": int(ok0.min().item())}))
