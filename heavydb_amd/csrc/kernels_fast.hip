@@ -157,6 +157,71 @@ __global__ __launch_bounds__(kBlock) void k_perfect_lds(const int8_t* const* __r
   }
 }
 
+// The same kernel with the slot program known at compile time (PROG: one nibble per slot, op + 1) and
+// 1024-lane workgroups.  The generic member above spends ~100 instructions per row walking the op switch
+// of every slot (scalar branches, a waitcnt per LDS op): at 12 bytes per row that, not HBM, is what bounds
+// it (cfg2: 0.62 of the roofline where the bare read pattern with one ds_add per row reaches 0.79 - 0.83,
+// tools/microbench/groupby_small.hip).  Here a row is the index arithmetic in 32 bits, one key store and
+// one LDS atomic per slot; one workgroup per CU keeps 16 waves streaming (measured: 1024 lanes per CU in one
+// workgroup stream 4 - 5 % faster than in four, 2048 lanes per CU are slower).
+constexpr int kPerfectWide = 1024;
+template <uint32_t PROG, int J>
+constexpr int prog_op() { return (int)((PROG >> (4 * J)) & 15u) - 1; }
+template <uint32_t PROG>
+constexpr int prog_n() { return PROG >= 0x1000u ? 4 : PROG >= 0x100u ? 3 : PROG >= 0x10u ? 2 : 1; }
+
+template <typename FT, typename KT, typename VT, uint32_t PROG>
+__global__ __launch_bounds__(kPerfectWide) void k_perfect_lds_prog(const int8_t* const* __restrict__ cols,
+                                                                    const int64_t* __restrict__ num_rows,
+                                                                    int n_frags, int n_cols, RangeFilter flt,
+                                                                    PerfectArgs a, int64_t* __restrict__ out,
+                                                                    int32_t* __restrict__ d_err) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int64_t* tab = (int64_t*)smem_raw;
+  constexpr int NS = prog_n<PROG>();
+  const int kq = a.key_quad, rq = a.row_quad;
+  const uint32_t ne = (uint32_t)a.entry_count;
+  const uint32_t quads = ne * (uint32_t)rq;
+  // column-major LDS copy as in k_perfect_lds: quad j of entry e at tab[j * ne + e]
+  for (uint32_t i = threadIdx.x; i < quads; i += kPerfectWide) {
+    const int j = (int)(i / ne);
+    tab[i] = j < kq ? kEmptyKey64 : a.init[j - kq];
+  }
+  __syncthreads();
+  bool bad = false;
+  int64_t* const slots = tab + (kq ? ne : 0u);
+  scan_fragments<FT, KT, VT>(cols, num_rows, n_frags, n_cols, flt.col, a.kcol, a.vcol,
+                             [&](FT fv, KT key, VT val) {
+    if (!filter_pass<FT>(flt, fv)) return;
+    const uint64_t d = (uint64_t)((int64_t)key - a.min_val);
+    if (d >= (uint64_t)ne) {
+      bad = true;
+      return;
+    }
+    const uint32_t idx = (uint32_t)d;
+    // a keyed row stores the key once, in the key quad; a projected-key slot (SO_KEY, always slot 0 in
+    // the compiled programs) is filled from it at the flush
+    if (kq) *(volatile int64_t*)(tab + idx) = (int64_t)key;
+    if (prog_op<PROG, 0>() != SO_KEY || !kq) apply_slot<VT>(prog_op<PROG, 0>(), slots + idx, (int64_t)key, val);
+    if constexpr (NS > 1) apply_slot<VT>(prog_op<PROG, 1>(), slots + ne + idx, (int64_t)key, val);
+    if constexpr (NS > 2) apply_slot<VT>(prog_op<PROG, 2>(), slots + 2 * ne + idx, (int64_t)key, val);
+    if constexpr (NS > 3) apply_slot<VT>(prog_op<PROG, 3>(), slots + 3 * ne + idx, (int64_t)key, val);
+  });
+  if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < quads; i += kPerfectWide) {
+    const uint32_t e = i / (uint32_t)rq;
+    const int j = (int)(i % (uint32_t)rq);
+    const bool key_slot = kq && j == kq && prog_op<PROG, 0>() == SO_KEY;
+    const int64_t v = tab[(key_slot ? 0u : (uint32_t)j * ne) + e];
+    if (j < kq || key_slot) {
+      if (v != kEmptyKey64) MQ_STORE64(out + i, v);
+    } else {
+      flush_slot(a.sp.op[j - kq], out + i, v, a.init[j - kq]);
+    }
+  }
+}
+
 // =========================================================================== baseline direct
 struct BaselineArgs {
   int64_t entry_count;
@@ -346,10 +411,60 @@ bool perfect_lds_eligible(const DevPlan& p, const FragView& fv) {
   return grouped_fast_shape(p, fv, &s) && !s.sp.val_nullable;
 }
 
+// The compile-time slot programs (nibble = SlotOp + 1, slot 0 in the lowest nibble) and the value type
+// each is instantiated for; anything else runs the generic member.
+constexpr uint32_t prog_of(int o0, int o1 = -1, int o2 = -1, int o3 = -1) {
+  return (uint32_t)(o0 + 1) | (uint32_t)(o1 + 1) << 4 | (uint32_t)(o2 + 1) << 8 | (uint32_t)(o3 + 1) << 12;
+}
+template <typename FT, typename KT>
+static bool launch_perfect_prog_v(const FastShape& fs, const PerfectArgs& a, const FragView& fv, int64_t* out,
+                                  int32_t* d_err, int grid, size_t lds, hipStream_t s) {
+  if (a.key_quad > 1 || fs.sp.n < 1 || fs.sp.n > 4 || a.row_quad != a.key_quad + fs.sp.n) return false;
+  const uint32_t prog = prog_of(fs.sp.op[0], fs.sp.n > 1 ? fs.sp.op[1] : -1, fs.sp.n > 2 ? fs.sp.op[2] : -1,
+                                fs.sp.n > 3 ? fs.sp.op[3] : -1);
+  const int vt = fs.vcol < 0 ? 0 : fs.vtype;
+#define MQ_PROG(VT_CODE, VT, ...)                                                                              \
+  if (vt == (VT_CODE) && prog == prog_of(__VA_ARGS__)) {                                                       \
+    auto k = k_perfect_lds_prog<FT, KT, VT, prog_of(__VA_ARGS__)>;                                             \
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kPerfectWide), lds, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, \
+                       fs.flt, a, out, d_err);                                                                 \
+    return true;                                                                                               \
+  }
+  // (a keyed table projects the key into slot 0 as well: SO_KEY)
+  MQ_PROG(0, none_t, SO_COUNT)
+  MQ_PROG(0, none_t, SO_KEY, SO_COUNT)
+  MQ_PROG(MI355Q_INT64, int64_t, SO_SUM_I)
+  MQ_PROG(MI355Q_INT64, int64_t, SO_KEY, SO_SUM_I)
+  MQ_PROG(MI355Q_INT64, int64_t, SO_COUNT, SO_SUM_I)
+  MQ_PROG(MI355Q_INT64, int64_t, SO_SUM_I, SO_COUNT)
+  MQ_PROG(MI355Q_INT64, int64_t, SO_KEY, SO_COUNT, SO_SUM_I)
+  MQ_PROG(MI355Q_INT64, int64_t, SO_KEY, SO_SUM_I, SO_COUNT)
+  MQ_PROG(MI355Q_INT64, int64_t, SO_KEY, SO_COUNT, SO_SUM_I, SO_COUNT)
+  MQ_PROG(MI355Q_INT32, int32_t, SO_SUM_I)
+  MQ_PROG(MI355Q_INT32, int32_t, SO_KEY, SO_SUM_I)
+  MQ_PROG(MI355Q_INT32, int32_t, SO_KEY, SO_SUM_I, SO_COUNT)
+  MQ_PROG(MI355Q_DOUBLE, double, SO_SUM_F)
+  MQ_PROG(MI355Q_DOUBLE, double, SO_KEY, SO_SUM_F)
+  MQ_PROG(MI355Q_DOUBLE, double, SO_COUNT, SO_SUM_F)
+  MQ_PROG(MI355Q_DOUBLE, double, SO_SUM_F, SO_COUNT)
+  MQ_PROG(MI355Q_DOUBLE, double, SO_KEY, SO_COUNT, SO_SUM_F)
+  MQ_PROG(MI355Q_DOUBLE, double, SO_KEY, SO_SUM_F, SO_COUNT)
+  MQ_PROG(MI355Q_DOUBLE, double, SO_KEY, SO_COUNT, SO_SUM_F, SO_COUNT)
+#undef MQ_PROG
+  return false;
+}
+
 template <typename FT, typename KT>
 static hipError_t launch_perfect_lds_v(const FastShape& fs, const PerfectArgs& a, const FragView& fv,
                                        int64_t* out, int32_t* d_err, int grid, size_t lds,
-                                       hipStream_t s) {
+                                       hipStream_t s, int n_cus) {
+  {  // compile-time slot program, one 1024-lane workgroup per CU
+    int64_t want = (fv.total_rows / 4 + kPerfectWide - 1) / kPerfectWide;
+    if (want < 1) want = 1;
+    const int grid_w = (int)(want < n_cus ? want : n_cus);
+    if (launch_perfect_prog_v<FT, KT>(fs, a, fv, out, d_err, grid_w, lds, s)) return hipGetLastError();
+  }
   if (fs.vcol < 0) {
     hipLaunchKernelGGL((k_perfect_lds<FT, KT, none_t>), dim3(grid), dim3(kBlock), lds, s, fv.d_cols,
                        fv.d_num_rows, fv.n_frags, fv.n_cols, fs.flt, a, out, d_err);
@@ -390,14 +505,14 @@ hipError_t launch_perfect_lds(const DevPlan& p, const FragView& fv, int64_t* out
   hipError_t e;
   const bool k32 = perfect_key_storage(p) == MI355Q_INT32;
   if (fs.fil_type == 0) {
-    e = k32 ? launch_perfect_lds_v<none_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s)
-            : launch_perfect_lds_v<none_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s);
+    e = k32 ? launch_perfect_lds_v<none_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus)
+            : launch_perfect_lds_v<none_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus);
   } else if (fs.fil_type == MI355Q_INT32) {
-    e = k32 ? launch_perfect_lds_v<int32_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s)
-            : launch_perfect_lds_v<int32_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s);
+    e = k32 ? launch_perfect_lds_v<int32_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus)
+            : launch_perfect_lds_v<int32_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus);
   } else {
-    e = k32 ? launch_perfect_lds_v<int64_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s)
-            : launch_perfect_lds_v<int64_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s);
+    e = k32 ? launch_perfect_lds_v<int64_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus)
+            : launch_perfect_lds_v<int64_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus);
   }
   rec(st->k_stop, s);
   return e;
