@@ -1345,8 +1345,9 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         ok = hipMalloc(&flags.p, 64) == hipSuccess;
         if (l2) {
           if (ok && !jt->pay16) ok = hipMalloc(&jt->pay16, (size_t)entries * 16) == hipSuccess;
+          // one-to-one tables: the 8-byte payload — interleaved with the slot's key for a keyed table
           if (ok && (jt->hash_type == 0 || jt->hash_type == 1) && !jt->pay8)
-            ok = hipMalloc((void**)&jt->pay8, (size_t)entries * 8) == hipSuccess;
+            ok = hipMalloc((void**)&jt->pay8, (size_t)entries * (l2 == 2 ? 16 : 8)) == hipSuccess;
           if (ok && l2 == 2 && !jt->pay_kkeys) ok = hipMalloc((void**)&jt->pay_kkeys, (size_t)entries * 8) == hipSuccess;
         } else {
           if (ok && !jt->pay_cnt) ok = hipMalloc((void**)&jt->pay_cnt, (size_t)entries * 4) == hipSuccess;

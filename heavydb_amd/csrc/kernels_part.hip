@@ -1449,9 +1449,19 @@ struct ProbeArgs {
                            // the inner value itself, INT64_MIN where no row has the key (divergent 16-byte
                            // loads run at half the rate of 8-byte ones: 133 vs 265 G probes/s)
   const int64_t* kkeys;    // keyed tables (MODE 2): the key of every table slot, EMPTY_KEY_64 where free;
-                           // pay16 / pay8 are then indexed by SLOT, `range` is the table's entry count
+                           // pay16 is then indexed by SLOT, `range` is the table's entry count, and pay8 is
+                           // INTERLEAVED with the keys — {key, inner value or INT64_MIN}[entries], 16 B per
+                           // slot: one gather finds the key and its payload (two arrays cost two cache lines
+                           // per probe, and a 3 MB slice next to the record stream does not stay in a 4 MB L2)
   int64_t null_sum;        // NULL_BIGINT: skipped by the non-grouped SUM over the outer value
+  uint32_t range_rcp;      // floor(2^32 / range) (keyed: slot = hash % range without a division)
 };
+MQ_D uint32_t probe_slot_of(const ProbeArgs& a, uint32_t h) {
+  const uint32_t n = (uint32_t)a.range;
+  uint32_t r = h - __umulhi(h, a.range_rcp) * n;
+  if (r >= n) r -= n;
+  return r;
+}
 // accumulators (device words, wrapping 64-bit adds)
 enum ProbeAcc { PA_J = 0, PA_M, PA_SVC, PA_SVM, PA_NNVC, PA_NNVM, PA_SW, PA_NNW, PA_N };
 
@@ -1683,13 +1693,21 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
           nxt[q] = load_rec_nt(run + (i < n ? i : n - 1));
         }
         uint32_t hp[UQ];
-        int64_t k0[UQ];
+        int64_t k0[UQ], w0[UQ];
         bool mine[UQ];
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {  // the first probe of all four, unconditionally, in flight together
-          hp[q] = murmur1_u64((uint64_t)rec[q].key) % entries;
+          hp[q] = probe_slot_of(a, murmur1_u64((uint64_t)rec[q].key));
           mine[q] = a.R == 1 || (hp[q] >= sub_lo && hp[q] < sub_hi);
-          k0[q] = a.kkeys[mine[q] ? hp[q] : sub_lo];
+          const uint32_t at = mine[q] ? hp[q] : sub_lo;
+          if (PAY8) {
+            const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
+            k0[q] = kp.x;
+            w0[q] = kp.y;
+          } else {
+            k0[q] = a.kkeys[at];
+            w0[q] = 0;
+          }
         }
         int64_t slot[UQ];
 #pragma unroll
@@ -1706,20 +1724,24 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
               }
               if (k == kEmptyKey64) break;
               h = h + 1 == entries ? 0 : h + 1;
-              k = a.kkeys[h];
+              if (PAY8) {
+                const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[h];
+                k = kp.x;
+                w0[q] = kp.y;
+              } else {
+                k = a.kkeys[h];
+              }
             }
           }
         }
         Pay16 pe[UQ];
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
-          const uint64_t idx = slot[q] >= 0 ? (uint64_t)slot[q] : 0ull;
-          if (PAY8) {
-            const int64_t w = a.pay8[idx];
-            const uint32_t present = w != INT64_MIN;
-            pe[q] = Pay16{present ? w : 0, present, present};
+          if (PAY8) {  // the payload came with the key
+            const uint32_t present = slot[q] >= 0 && w0[q] != INT64_MIN;
+            pe[q] = Pay16{present ? w0[q] : 0, present, present};
           } else {
-            pe[q] = a.pay16[idx];
+            pe[q] = a.pay16[slot[q] >= 0 ? (uint64_t)slot[q] : 0ull];
           }
         }
 #pragma unroll
@@ -1798,7 +1820,10 @@ __global__ __launch_bounds__(256) void k_join_payload_keyed(const int64_t* __res
     }
     if (!w) nn = c;
     kkeys[x] = key;
-    if (pay8) pay8[x] = c ? (int64_t)sum : INT64_MIN;
+    if (pay8) {  // interleaved {key, value}: see ProbeArgs::kkeys
+      pay8[2 * x] = key;
+      pay8[2 * x + 1] = c ? (int64_t)sum : INT64_MIN;
+    }
     pay16[x] = Pay16{(int64_t)sum, c, nn};
     any_null |= nn != c;
   }
@@ -1820,7 +1845,7 @@ __global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, 
     uint64_t off;
     if (a.kkeys) {  // keyed table: linear probe for the slot
       const uint32_t entries = (uint32_t)a.range;
-      uint32_t h = murmur1_u64((uint64_t)key) % entries;
+      uint32_t h = probe_slot_of(a, murmur1_u64((uint64_t)key));
       bool found = false;
       for (uint32_t trips = 0; trips < entries; ++trips) {
         const int64_t k = a.kkeys[h];
@@ -1839,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_probe_spill(ProbeArgs a, SpillList sl, 
     }
     unsigned long long c, ws, wn;
     if (a.pay8) {
-      const int64_t w = a.pay8[off];
+      const int64_t w = a.kkeys ? a.pay8[2 * off + 1] : a.pay8[off];
       c = w != INT64_MIN;
       ws = c ? (unsigned long long)w : 0ull;
       wn = c;
@@ -2824,6 +2849,7 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   pa.pay16 = (h.l2_mode && !pa.pay8) ? (const Pay16*)pay.pay16 : nullptr;
   if (h.l2_mode && !pa.pay8 && !pa.pay16) return false;
   pa.null_sum = INT64_MIN;
+  pa.range_rcp = (range >= 2 && range < ((uint64_t)1 << 32)) ? (uint32_t)(((uint64_t)1 << 32) / range) : 0u;
   return true;
 }
 
