@@ -263,18 +263,48 @@ struct JoinSumArgs {
   const int64_t* inner_w;    // inner int64 payload column (or null)
   const uint32_t* bitmap;    // perfect table's presence bitmap when no slot reads the inner table
   int64_t null_sum;          // NULL_BIGINT: the non-grouped SUM starts NULL
+  int32_t k2col;             // second component of a composite (int64, int64) key, or -1
+  uint32_t entries_rcp;      // floor(2^32 / entries): hash % entries without a division
 };
 
-template <typename VT>
+// K2T = int64_t: composite (int64, int64) key on a keyed one-to-one table, slots (k0, k1, row id) — the hash
+// is MurmurHash1 over the 16 key bytes, a slot is free when its first component is EMPTY_KEY_64
+// (get_composite_key_index_impl, JoinHashTableQueryRuntime.cpp:140-163)
+template <typename K2T, typename VT>
 __global__ __launch_bounds__(kBlock) void k_join_sum(const int8_t* const* __restrict__ cols,
                                                       const int64_t* __restrict__ num_rows,
                                                       int n_frags, int n_cols, JoinSumArgs a,
                                                       int64_t* __restrict__ out) {
   long long acc[4] = {0, 0, 0, 0};
   unsigned long long contrib[4] = {0, 0, 0, 0};  // non-NULL contributions per slot
-  scan_fragments<none_t, int64_t, VT>(cols, num_rows, n_frags, n_cols, 0, a.kcol, a.vcol,
-                                      [&](none_t, int64_t key, VT val) {
+  auto slot_of = [&](uint32_t h) -> uint32_t {
+    const uint32_t n = (uint32_t)a.entries;
+    uint32_t r = h - __umulhi(h, a.entries_rcp) * n;
+    if (r >= n) r -= n;
+    return r;
+  };
+  scan_fragments<K2T, int64_t, VT>(cols, num_rows, n_frags, n_cols, a.k2col < 0 ? 0 : a.k2col, a.kcol, a.vcol,
+                                   [&](K2T key2, int64_t key, VT val) {
     int64_t idx;
+    if constexpr (!is_none<K2T>::value) {
+      const int64_t* tab = (const int64_t*)a.table;
+      const uint32_t n = (uint32_t)a.entries;
+      const uint32_t w[4] = {(uint32_t)(uint64_t)key, (uint32_t)((uint64_t)key >> 32), (uint32_t)(uint64_t)key2,
+                             (uint32_t)((uint64_t)key2 >> 32)};
+      const uint32_t h = slot_of(murmur1_words(w, 4));
+      idx = -1;
+      uint32_t hp = h;
+      do {
+        const int64_t* e = tab + (size_t)hp * 3;
+        const int64_t e0 = e[0], e1 = e[1];
+        if (e0 == key && e1 == (int64_t)key2) {
+          idx = e[2];
+          break;
+        }
+        if (e0 == kEmptyKey64) break;
+        hp = hp + 1 == n ? 0 : hp + 1;
+      } while (hp != h);
+    } else
     if (a.bitmap) {
       // semi-join: only WHETHER the key matches is needed, so probe the 1-bit-per-slot view of
       // the perfect table (32x smaller: 12.5 MB for 100 M dim rows, L2 / Infinity-Cache resident)
@@ -286,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_join_sum(const int8_t* const* __rest
       const int64_t* tab = (const int64_t*)a.table;
       const uint32_t n = (uint32_t)a.entries;
       idx = -1;
-      const uint32_t h = murmur1_u64((uint64_t)key) % n;
+      const uint32_t h = slot_of(murmur1_u64((uint64_t)key));
       uint32_t hp = h;
       do {
         const int64_t k = tab[(size_t)hp * 2];
@@ -596,8 +626,16 @@ hipError_t launch_baseline_fast(const DevPlan& p, const FragView& fv, int64_t* o
 static bool join_sum_shape(const DevPlan& p, const FragView& fv, JoinSumArgs* a) {
   if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col < 0 || p.n_quals != 0) return false;
   if (p.join_type != MI355Q_INT64 || p.join_nullable) return false;
-  // one-to-one tables with one 8-byte key component, INNER joins
-  if (p.join_hash_type > 1 || p.join_n_keys != 1 || p.join_width != 8 || p.join_kind != MI355Q_JOIN_INNER) return false;
+  // one-to-one tables with one 8-byte key component — or, keyed, two of them — INNER joins
+  if (p.join_hash_type > 1 || p.join_width != 8 || p.join_kind != MI355Q_JOIN_INNER) return false;
+  a->k2col = -1;
+  if (p.join_n_keys == 2) {
+    if (p.join_hash_type != 1 || p.join_types[1] != MI355Q_INT64 || p.join_nullables[1]) return false;
+    a->k2col = p.join_cols[1];
+    if (!all_aligned16(fv, a->k2col)) return false;
+  } else if (p.join_n_keys != 1) {
+    return false;
+  }
   if (p.n_targets > 4) return false;
   a->kcol = p.join_col;
   a->vcol = -1;
@@ -631,6 +669,11 @@ static bool join_sum_shape(const DevPlan& p, const FragView& fv, JoinSumArgs* a)
   a->min_key = p.join_min;
   a->max_key = p.join_max;
   a->entries = p.join_entries;
+  a->entries_rcp = 0;
+  if (p.join_hash_type == 1) {
+    if (p.join_entries < 2 || p.join_entries >= ((int64_t)1 << 32)) return false;
+    a->entries_rcp = (uint32_t)(((uint64_t)1 << 32) / (uint64_t)p.join_entries);
+  }
   a->null_sum = INT64_MIN;
   return true;
 }
@@ -648,12 +691,20 @@ hipError_t launch_join_sum(const DevPlan& p, const FragView& fv, int64_t* out, i
   st->kernel_name = "k_join_sum";
   st->n_launches = 1;
   rec(st->k_start, s);
-  if (a.vcol < 0) {
-    a.vcol = 0;
-    hipLaunchKernelGGL(k_join_sum<none_t>, dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+  const bool no_val = a.vcol < 0;
+  if (no_val) a.vcol = 0;
+  if (a.k2col >= 0) {
+    if (no_val)
+      hipLaunchKernelGGL((k_join_sum<int64_t, none_t>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows,
+                         fv.n_frags, fv.n_cols, a, out);
+    else
+      hipLaunchKernelGGL((k_join_sum<int64_t, int64_t>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows,
+                         fv.n_frags, fv.n_cols, a, out);
+  } else if (no_val) {
+    hipLaunchKernelGGL((k_join_sum<none_t, none_t>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
                        fv.d_num_rows, fv.n_frags, fv.n_cols, a, out);
   } else {
-    hipLaunchKernelGGL(k_join_sum<int64_t>, dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
+    hipLaunchKernelGGL((k_join_sum<none_t, int64_t>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
                        fv.d_num_rows, fv.n_frags, fv.n_cols, a, out);
   }
   rec(st->k_stop, s);

@@ -540,6 +540,29 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       RelAlgExecutionUnit(kfd, [TargetExpr(COUNT), TargetExpr(SUM, 2, 1), TargetExpr(SUM, 2), TargetExpr(MIN, 2, 1)],
                                           inner_col_descs=k_descs, join_outer_col=[0, 1]),
                       kff, [ka, kb, kw_], [ka, kb], [INT64, INT32], ExpressionRange(), False, join_one_to_many=1))
+    # (int64, int64) one-to-one composite key, non-grouped COUNT / SUM(outer) / SUM(inner): the shape the
+    # streaming probe kernel takes (k_join_sum with a second key component); sparse components, ~60 % matches,
+    # inner pairs that share a first component (so the probe must compare both), ragged fragments
+    qa = (rng.integers(0, 400, 4 * m) * 10**9 + 5).astype(np.int64)
+    qb = rng.integers(-3, 4, 4 * m).astype(np.int64) * 2**33
+    qpair = np.unique(np.stack([qa, qb], 1), axis=0)
+    qa, qb = np.ascontiguousarray(qpair[:, 0]), np.ascontiguousarray(qpair[:, 1])
+    qw = rng.integers(-1000, 1000, len(qa)).astype(np.int64)
+    q_descs = [InputColDescriptor(INT64, False, col_range([qa], INT64, False)),
+               InputColDescriptor(INT64, False, col_range([qb], INT64, False)),
+               InputColDescriptor(INT64, False, col_range([qw], INT64, False))]
+    qfd, qff = make_table(rng, n, fs, [
+        (INT64, False, lambda r, mm: r.integers(0, 500, mm) * 10**9 + 5),
+        (INT64, False, lambda r, mm: r.integers(-3, 4, mm) * 2**33),
+        (INT64, False, lambda r, mm: r.integers(-50, 1000, mm)),
+    ])
+    cases.append(Case("join_composite_key64_1to1_sum",
+                      RelAlgExecutionUnit(qfd, [TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(SUM, 2, 1)],
+                                          inner_col_descs=q_descs, join_outer_col=[0, 1]),
+                      qff, [qa, qb, qw], [qa, qb], [INT64, INT64], ExpressionRange(), False))
+    cases.append(Case("join_composite_key64_1to1_count",
+                      RelAlgExecutionUnit(qfd, [TargetExpr(COUNT)], inner_col_descs=q_descs, join_outer_col=[0, 1]),
+                      qff, [qa, qb, qw], [qa, qb], [INT64, INT64], ExpressionRange(), False))
     # ---- edge cases of the wider shapes: empty inputs, empty / all-NULL inner tables
     cases.append(Case("multi_col_empty_input", ra([K0, K1, TargetExpr(COUNT), TargetExpr(SUM, 2)], group=[4, 1],
                                                   guess=4096), empty))
