@@ -282,8 +282,13 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
       const int64_t col_count = p.n_group_cols + p.n_targets;
       const int64_t max_entries = kMaxBufferSize / (col_count * (int64_t)sizeof(int64_t));
       const __int128 span = (__int128)r.max - (__int128)r.min;
-      // a bucketed range stays on the perfect hash (":344 is_baseline_candidate && !bucket")
-      use_baseline = span >= (__int128)max_entries && !r.bucket;
+      // a bucketed range stays on the perfect hash (":344 is_baseline_candidate && !bucket"); so does a
+      // dictionary-encoded string key when the step has no filters (:312-343: "we are better off attempting
+      // perfect hash ... and failing later due to excessive memory use"; with filters and no cardinality
+      // estimate — none reaches this seam — the range that is too big takes the baseline layout)
+      const bool too_big = span >= (__int128)max_entries;
+      const bool dict_key = p.cols[gc].encoding == MI355Q_ENC_DICT && !(r.bucket > 0);
+      use_baseline = dict_key ? (too_big && p.n_quals > 0) : (too_big && !(r.bucket > 0));
       if (!use_baseline && span / (r.bucket > 0 ? r.bucket : 1) >= (__int128)INT32_MAX)
         return MI355Q_ERR_UNSUPPORTED;
     }

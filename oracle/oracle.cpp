@@ -568,8 +568,17 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
       // is_column_range_too_big_for_perfect_hash (:130-139), overflow -> too big
       __int128 span = (__int128)r.max - (__int128)r.min;
       const bool is_baseline_candidate = span > INT64_MAX || (int64_t)span >= max_entry_count;
-      // ":344  else if (is_baseline_candidate && !col_range_info.bucket)"
-      if (is_baseline_candidate && !(r.bucket > 0)) baseline = true;
+      // :312-343 a dictionary-encoded string key without a bucket: too big a range only means baseline when
+      // the step has filters (no cardinality estimate reaches this seam: ":337 !group_cardinality_estimation_");
+      // without filters the perfect hash is kept ("we are better off attempting perfect hash ... and failing
+      // later due to excessive memory use") — Tests/GroupByTest.cpp BaselineFallbackTest / BaselineNoFilters
+      const bool dict_key = p.cols[p.group_cols[0]].encoding == MI355Q_ENC_DICT && !(r.bucket > 0);
+      if (dict_key) {
+        if (p.n_quals > 0 && is_baseline_candidate) baseline = true;
+      } else if (is_baseline_candidate && !(r.bucket > 0)) {
+        // ":344  else if (is_baseline_candidate && !col_range_info.bucket)"
+        baseline = true;
+      }
       if (!baseline && span / (r.bucket > 0 ? r.bucket : 1) >= INT32_MAX) return MI355Q_ERR_UNSUPPORTED;
     }
     if (!baseline) {

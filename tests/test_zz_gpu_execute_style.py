@@ -53,3 +53,22 @@ def test_reference_join_queries_on_gpu(torch_cuda, oracle, ji):
     rs = Executor(0).executeWorkUnit(case.ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
     qm = rs.getQueryMemDesc()
     _compare(sql, db, qm, [("HIP library", _rows(rs.fetch(), qm))])
+
+
+def test_group_by_test_baseline_no_filters_on_gpu(torch_cuda):
+    """Tests/GroupByTest.cpp BaselineNoFilters (:264-338): a dictionary-encoded string key whose cached range is
+    [0, 134217728], no filter, max_groups_buffer_entry_guess = 1 — the perfect hash is kept (134 217 729 entries,
+    2 GB) and the two groups come back with COUNT = 1 each."""
+    import numpy as np
+    from heavydb_amd import capi
+    from heavydb_amd.executor import Executor
+    from tests.test_groupby_test_style import STR, TOO_BIG, X, _unit
+    ra = _unit(TOO_BIG, False, 1)
+    case = Case("BaselineNoFilters", ra, [[STR, X]])
+    frag_t, inner_t = _upload(torch_cuda, case)
+    rs = Executor(0).executeWorkUnit(ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+    qm = rs.getQueryMemDesc()
+    assert qm.desc_type == capi.GROUP_BY_PERFECT_HASH and qm.entry_count == TOO_BIG + 1
+    assert rs.rowCount() == 2
+    iv, dv, nu = rs.fetch()
+    assert sorted(int(v) for v in np.asarray(iv)[:, 0]) == [1, 1]
