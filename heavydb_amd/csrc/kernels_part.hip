@@ -1699,7 +1699,7 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
         for (int q = 0; q < UQ; ++q) {  // the first probe of all four, unconditionally, in flight together
           hp[q] = probe_slot_of(a, murmur1_u64((uint64_t)rec[q].key));
           mine[q] = a.R == 1 || (hp[q] >= sub_lo && hp[q] < sub_hi);
-          const uint32_t at = mine[q] ? hp[q] : sub_lo;
+          const uint32_t at = mine[q] ? hp[q] : (sub_lo < entries ? sub_lo : 0u);  // (the last partition's later passes may start past the table)
           if (PAY8) {
             const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
             k0[q] = kp.x;
