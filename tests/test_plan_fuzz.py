@@ -357,8 +357,9 @@ def test_reduce_agrees_on_random_plans(oracle):
         # (only MAX is guarded there) although an all-NULL group then looks empty, so a partial
         # buffer can hide rows that the single pass still counts — the reference's own rule,
         # restated as is by both implementations (checked against each other below)
-        key_t = [t for t in range(q.n_targets) if q.keyless and q.target_slot[t] in
-                 (q.idx_target_as_key, q.idx_target_as_key - 1)]
+        key_t = [t for t in range(q.n_targets) if q.keyless and
+                 (q.target_slot[t] == q.idx_target_as_key or
+                  (q.target_agg[t] == capi.AVG and q.target_slot[t] == q.idx_target_as_key - 1))]
         if not (key_t and q.target_skip_null[key_t[0]]):
             compare_rows(q, oracle.fetch_rows(q, full), oracle.fetch_rows(q, red), 1e-9)
         mine = np.ascontiguousarray(a.copy())

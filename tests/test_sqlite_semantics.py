@@ -149,8 +149,10 @@ def _check_case(oracle, case):
         return "rejected"
     if code != 0:
         return "error"
-    key_t = [t for t in range(q.n_targets) if q.keyless and q.target_slot[t] in
-             (q.idx_target_as_key, q.idx_target_as_key - 1)]
+    # the target whose slot tells an empty entry from a group (AVG: its COUNT slot, one after the slot it is listed at)
+    key_t = [t for t in range(q.n_targets) if q.keyless and
+             (q.target_slot[t] == q.idx_target_as_key or
+              (q.target_agg[t] == capi.AVG and q.target_slot[t] == q.idx_target_as_key - 1))]
     if key_t and q.target_skip_null[key_t[0]]:
         return "keyless-null-aware"
     got = sorted(_oracle_rows(oracle, case, q, buf), key=_key)

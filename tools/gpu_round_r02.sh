@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 2 profile set: kernel trace + PMC passes of the default bench, bench lines of every config
+# Round 2 profile set (profiles/r02_*): gpu_round_profiles.sh + the plain bench line, cfg4 Query B and sparse variants, Query B kernel table
 export TMPDIR=/tmp
 bash tools/gpu_round_profiles.sh r02
 out=gpurun_out/round_r02
