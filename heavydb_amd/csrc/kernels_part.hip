@@ -124,8 +124,7 @@ struct PartGeom {
   uint32_t L;          // records per line = kStageRecs / P
   uint32_t cap;        // records per (workgroup, partition) run, multiple of L
   uint32_t E;          // LDS table entries in phase 2
-  uint32_t b_mult;     // bucket A of home offset x = (x * b_mult) >> b_shift, b_mult = floor((E / 4) * 2^b_shift / S2):
-  uint32_t b_shift;    // a 24-bit multiply (full rate; v_mul_hi_u32 is quarter rate), monotone in x
+  uint32_t b_mult;     // floor((E / 4) * 2^32 / S2): monotone map home-offset -> LDS bucket
   int32_t ns_int;      // distinct partial slots kept per group in LDS
   uint32_t lds_table_bytes;  // keys + slot arrays of the LDS table (16-byte multiple)
   uint32_t slot_off[kMaxInt];  // byte offset of each internal slot array in LDS
@@ -811,13 +810,7 @@ MQ_D int first_empty(const Bucket& k) {
   return k.a.x == kEmptyKey64 ? 0 : k.a.y == kEmptyKey64 ? 1 : k.c.x == kEmptyKey64 ? 2
          : k.c.y == kEmptyKey64 ? 3 : -1;
 }
-// bucket B: other bits of the hash, spread with full-rate 24-bit multiplies (the two 32-bit multiplies this
-// replaces cost 8 issue slots per record visit in a loop that is bound by vector-ALU issue):
-// the low 24 bits of h times an odd constant, bits 12..31 of that as a 20-bit fraction of n_buckets (< 4096)
-MQ_D uint32_t bucket_b_of(uint32_t h, uint32_t n_buckets) {
-  const uint32_t t = __umul24(h & 0xffffffu, 0x9e3779u);
-  return __umul24(t >> 12, n_buckets) >> 20;
-}
+MQ_D uint32_t bucket_b_of(uint32_t h, uint32_t n_buckets) { return __umulhi(h * 2654435761u, n_buckets); }
 
 // insert-or-find: candidate buckets ba / bb, then (both full) linear probing from bb + 1.
 // Returns the entry or kNoEntry when the table is full.
@@ -890,7 +883,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
       t_mark = now;
     }
   };
-  auto bucket_of = [&](uint32_t x) -> uint32_t { return __umul24(x, g.b_mult) >> g.b_shift; };
+  auto bucket_of = [&](uint32_t x) -> uint32_t { return __umulhi(x, g.b_mult); };
   // Four records per lane per step: all four bucket reads are issued before any is consumed
   // (LDS latency overlaps 4x), hits — the common case once a unit's table is warm — update
   // their slots straight away, misses fall back to the insert-or-find loop afterwards.
@@ -2146,17 +2139,8 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
       if (is_cnt(m)) { h.g.slot_off[m] = off; off += h.g.E * 4; }
   }
   {
-    // the largest shift (<= 20) whose multiplier fits 24 bits and whose products fit 32
-    if (hm.S2 >= (1u << 24) || h.g.E / 4 >= 4096) return false;
-    uint32_t sh = 20;
-    uint64_t m = 0;
-    for (;; --sh) {
-      m = ((uint64_t)(h.g.E / 4) << sh) / hm.S2;
-      if ((m < (1u << 24) && (uint64_t)(hm.S2 - 1) * m < ((uint64_t)1 << 32)) || sh == 0) break;
-    }
-    if (m >= (1u << 24) || (uint64_t)(hm.S2 - 1) * m >= ((uint64_t)1 << 32)) return false;
-    h.g.b_mult = (uint32_t)m;
-    h.g.b_shift = sh;
+    const uint64_t m = ((uint64_t)(h.g.E / 4) << 32) / hm.S2;
+    h.g.b_mult = (uint32_t)(m > 0xffffffffull ? 0xffffffffull : m);
   }
   h.g.B = n_cus;  // one 1024-lane workgroup per CU
   // chunking: worst case every row survives the filter; shrink the chunk until the runs
