@@ -133,14 +133,16 @@ def compare_rows(q: capi.QMD, want, got, rtol: float = 1e-9):
     gi, gd, gn = got
     assert wi.shape == gi.shape, (wi.shape, gi.shape)
     if q.desc_type == capi.GROUP_BY_BASELINE_HASH and wi.shape[0] > 1:
-        def order(i, d):
-            # integer columns first; rows that tie on them (no unique key projected) by the doubles
-            # rounded to single precision, i.e. well above the fp64 tolerance
+        def order(i, d, nl):
+            # integer columns first, then the NULL flags (a NULL reads as 0 in the value arrays: rows that tie
+            # on every value may still differ in which of them is NULL); rows that tie on all of those (no
+            # unique key projected) by the doubles rounded to single precision, i.e. well above the fp64 tolerance
             with np.errstate(over="ignore"):
                 dr = np.where(np.isfinite(d), d, 0.0).astype(np.float32)
-            keys = [dr[:, c] for c in range(d.shape[1])[::-1]] + [i[:, c] for c in range(i.shape[1])[::-1]]
+            keys = ([dr[:, c] for c in range(d.shape[1])[::-1]] + [nl[:, c] for c in range(nl.shape[1])[::-1]] +
+                    [i[:, c] for c in range(i.shape[1])[::-1]])
             return np.lexsort(tuple(keys))
-        ow, og = order(wi, wd), order(gi, gd)
+        ow, og = order(wi, wd, wn), order(gi, gd, gn)
         wi, wd, wn = wi[ow], wd[ow], wn[ow]
         gi, gd, gn = gi[og], gd[og], gn[og]
     assert (wi == gi).all()
