@@ -139,8 +139,11 @@ def compare_rows(q: capi.QMD, want, got, rtol: float = 1e-9):
             # unique key projected) by the doubles rounded to single precision, i.e. well above the fp64 tolerance
             with np.errstate(over="ignore"):
                 dr = np.where(np.isfinite(d), d, 0.0).astype(np.float32)
-            keys = ([dr[:, c] for c in range(d.shape[1])[::-1]] + [nl[:, c] for c in range(nl.shape[1])[::-1]] +
-                    [i[:, c] for c in range(i.shape[1])[::-1]])
+            # (last resort: the exact doubles — two rows closer than single precision but further apart than
+            # the tolerance must not swap places between the two sides)
+            dx = np.where(np.isfinite(d), d, 0.0)
+            keys = ([dx[:, c] for c in range(d.shape[1])[::-1]] + [dr[:, c] for c in range(d.shape[1])[::-1]] +
+                    [nl[:, c] for c in range(nl.shape[1])[::-1]] + [i[:, c] for c in range(i.shape[1])[::-1]])
             return np.lexsort(tuple(keys))
         ow, og = order(wi, wd, wn), order(gi, gd, gn)
         wi, wd, wn = wi[ow], wd[ow], wn[ow]
