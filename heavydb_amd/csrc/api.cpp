@@ -857,7 +857,7 @@ namespace {
 constexpr int32_t kNotTaken = INT32_MIN + 7;  // internal: "use the ordinary path"
 
 bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, PackSpec* ps) {
-  if (p.join_outer_col >= 0 || p.n_group_cols < 1) return false;
+  if (p.join_outer_col >= 0 || p.n_group_cols < 1 || d.col0_key_quirk) return false;
   for (int g = 0; g < p.n_group_cols; ++g)  // floating-point keys have no integer range to pack
     if (type_is_fp(p.cols[p.group_cols[g]].type) || type_is_f32(p.cols[p.group_cols[g]].type)) return false;
   if (p.n_cols >= MI355Q_MAX_COLS) return false;  // the packed column is appended to the inputs

@@ -279,7 +279,12 @@ struct DevPlan {
   int32_t join_n_keys, join_width;  // key components and their width in bytes (keyed tables)
   int32_t join_cols[MI355Q_MAX_GROUP_COLS], join_types[MI355Q_MAX_GROUP_COLS];
   int32_t join_nullables[MI355Q_MAX_GROUP_COLS];
-  int32_t join_kind, join_pad_;
+  int32_t join_kind;
+  // columnar keyless single-column perfect hash whose first slot starts at EMPTY_KEY_64 (MIN over a NOT NULL
+  // 8-byte integer): get_columnar_group_bin_offset (GroupByRuntime.cpp:228-239) takes the first slot's column for
+  // the key column and writes the (translated) key into a slot that still holds the init value before the
+  // aggregate runs — per kernel and in row order that is MIN(key, values); applied here as one more MIN
+  int32_t col0_key_quirk;
   const int8_t* inner_cols[MI355Q_MAX_COLS];
 };
 

@@ -295,7 +295,7 @@ inline int fast_value_type(int code) {
 }
 
 inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* s) {
-  if (p.join_col >= 0 || p.n_quals > 1 || p.n_group > 1) return false;
+  if (p.join_col >= 0 || p.n_quals > 1 || p.n_group > 1 || p.col0_key_quirk) return false;
   // a NULL group key: the baseline layout keeps the sentinel as an ordinary key; the perfect
   // layout translates it (max + 1) and is left to the generic family
   if (p.group_nullable && p.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return false;

@@ -436,13 +436,21 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   q->row_size = q->key_bytes + ((q->slot_width * q->slot_count + 7) & ~7);
   if (q->row_size <= 0) return MI355Q_ERR_INVALID_PLAN;
   q->output_columnar = p.output_columnar_hint == MI355Q_OUTPUT_COLUMNAR;
-  // Not restated: with a columnar keyless single-column perfect hash the reference still calls
+  // With a columnar keyless single-column perfect hash the reference still calls
   // get_columnar_group_bin_offset (GroupByAndAggregate.cpp:1425-1430, GroupByRuntime.cpp:228-239),
   // which reads the FIRST SLOT's column as if it were the key column and overwrites an entry equal
   // to EMPTY_KEY_64 with the key.  A first slot that starts at that value (MIN over int64) is refused.
   if (q->output_columnar && q->keyless && p.n_group_cols == 1 && q->slot_width == 8 && q->slot_count > 0 &&
-      q->init_vals[0] == kEmptyKey64)
-    return MI355Q_ERR_UNSUPPORTED;
+      q->init_vals[0] == kEmptyKey64) {
+    // ... restated for the deterministic case: an unbucketed key (every row of a group writes the same key) and a
+    // plain MIN in that slot, where "key first, then the aggregate" is MIN(key, values) however the rows are dealt
+    // to kernels (DevPlan::col0_key_quirk).  A bucketed key would leave the first row's key there: refused.
+    bool min_first = false;
+    for (int i = 0; i < p.n_targets; ++i)
+      if (q->target_slot[i] == 0 && q->target_agg[i] == MI355Q_MIN && !q->target_skip_null[i] && !q->target_arg_is_fp[i])
+        min_first = true;
+    if (q->bucket > 0 || !min_first) return MI355Q_ERR_UNSUPPORTED;
+  }
   return MI355Q_OK;
 }
 
@@ -526,6 +534,9 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
   ResolvedTarget ts[MI355Q_MAX_TARGETS];
   if (int32_t e = resolve_targets(p, grouped, ts)) return e;
   layout_from_qmd(q, d);
+  // (the step itself runs on the row-wise form of the columnar decisions: either hint)
+  d->col0_key_quirk = p.output_columnar_hint != 0 && q.keyless && p.n_group_cols == 1 && q.slot_width == 8 &&
+                      q.slot_count > 0 && q.init_vals[0] == kEmptyKey64;
   d->n_cols = p.n_cols;
   d->n_quals = p.n_quals;
   for (int i = 0; i < p.n_quals; ++i) {

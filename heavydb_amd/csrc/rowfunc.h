@@ -907,6 +907,7 @@ MQ_FN int32_t process_row(const DevPlan& p, const int8_t* const* cols, int64_t p
         slots = row + p.n_group;
       } else {
         slots = row;
+        if (p.col0_key_quirk) a_min_i64<A>(slots, tk[0]);
       }
     } else {
       if (p.n_group == 1) {

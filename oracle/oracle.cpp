@@ -731,9 +731,17 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   // the library refuses the one columnar shape whose reference behaviour it does not restate
   // (see columnar_bin_single below): keyless single-column perfect hash whose first slot starts at
   // EMPTY_KEY_64
+  //   ... restated (the literal get_columnar_group_bin_offset call of the row function) where it is deterministic:
+  // an unbucketed key and a plain MIN over a NOT NULL integer in that slot — "key first, then the aggregate" is
+  // MIN(key, values) however the rows are dealt to kernels; a bucketed key would leave the FIRST row's key there
   if (q.output_columnar && q.keyless && p.n_group_cols == 1 && q.slot_width == 8 && q.slot_count > 0 &&
-      q.init_vals[0] == kEmptyKey64)
-    return MI355Q_ERR_UNSUPPORTED;
+      q.init_vals[0] == kEmptyKey64) {
+    bool min_first = false;
+    for (int i = 0; i < p.n_targets; ++i)
+      if (q.target_slot[i] == 0 && q.target_agg[i] == MI355Q_MIN && !q.target_skip_null[i] && !q.target_arg_is_fp[i])
+        min_first = true;
+    if (q.bucket > 0 || !min_first) return MI355Q_ERR_UNSUPPORTED;
+  }
   return 0;
 }
 

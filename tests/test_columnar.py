@@ -94,12 +94,19 @@ def test_layout_literals(oracle):
     q = oracle.qmd_init(ra.to_plan())
     prod, orc = _offsets(q, oracle)
     assert prod == orc == ([], [0, 8], 16)
-    # the refused corner: keyless single-column perfect hash whose first slot starts at EMPTY_KEY_64
+    # keyless single-column perfect hash whose first slot starts at EMPTY_KEY_64 (MIN over a NOT NULL BIGINT):
+    # get_columnar_group_bin_offset takes that slot's column for the key column (GroupByRuntime.cpp:228-239).
+    # The outcome does not depend on the row order: every row of a group writes the same key
     ra = _ra([0], [TargetExpr(capi.MIN, 1), TargetExpr(capi.COUNT)], [V(True, 0, 6), V(True, 1, 9)])
     p = ra.to_plan()
     qe, qo = capi.QMD(), capi.QMD()
-    assert emu_lib().emu_qmd_init(C.byref(p), C.byref(qe)) == capi.ERR_UNSUPPORTED
-    assert oracle.lib().orc_qmd_init(C.byref(p), C.byref(qo)) == capi.ERR_UNSUPPORTED
+    assert emu_lib().emu_qmd_init(C.byref(p), C.byref(qe)) == 0 and qe.keyless and qe.init_vals[0] == 2**63 - 1
+    assert oracle.lib().orc_qmd_init(C.byref(p), C.byref(qo)) == 0
+    rab = _ra([0], [TargetExpr(capi.MIN, 1), TargetExpr(capi.COUNT)], [V(True, 0, 600, bucket=100), V(True, 1, 9)])
+    pb = rab.to_plan()
+    # (a bucketed key never gets the keyless layout, so the order-dependent variant cannot arise)
+    assert emu_lib().emu_qmd_init(C.byref(pb), C.byref(qe)) == 0 and not qe.keyless
+    assert oracle.lib().orc_qmd_init(C.byref(pb), C.byref(qo)) == 0 and not qo.keyless
     p.output_columnar_hint = 7
     assert emu_lib().emu_qmd_init(C.byref(p), C.byref(qe)) == capi.ERR_INVALID_PLAN
     assert oracle.lib().orc_qmd_init(C.byref(p), C.byref(qo)) == capi.ERR_INVALID_PLAN
@@ -125,6 +132,36 @@ def test_init_images_agree(oracle):
         qr = rowwise_qmd(q)
         assert np.array_equal(rows, oracle.init_buffer(qr))
         assert oracle.row_count(q, want) == 0
+
+
+def test_first_slot_taken_for_the_key_column(oracle):
+    """The reference's columnar keyless quirk, literally: SELECT MIN(v), COUNT(*) GROUP BY k with k in [0, 6] and
+    v in [3, 9] — in a columnar buffer slot 0 of group k comes out as MIN(k, MIN(v)), not MIN(v), because
+    get_columnar_group_bin_offset writes the key into a first-slot entry that still equals EMPTY_KEY_64.  The
+    row-wise step of the same query is unaffected."""
+    from tests.cases import Case
+    V = ExpressionRange
+    rng = np.random.default_rng(3)
+    k = rng.integers(0, 7, 500).astype(np.int64)
+    v = rng.integers(3, 10, 500).astype(np.int64)
+    frags = [[k[:250], v[:250]], [k[250:], v[250:]]]
+    ra = _ra([0], [TargetExpr(capi.MIN, 1), TargetExpr(capi.COUNT)], [V(True, 0, 6), V(True, 3, 9)])
+    plan = ra.to_plan()
+    q, want, code = oracle.execute(plan, frags, n_threads=2)
+    assert code == 0 and q.output_columnar == 1 and q.keyless == 1
+    rows = columnar_to_rows(q, want).reshape(q.entry_count, -1)
+    for key in range(7):
+        assert rows[key, 0] == min(key, int(v[k == key].min())) and rows[key, 1] == int((k == key).sum())
+    eq, got, ecode = _emu_execute(Case("quirk", ra, frags), plan, None)
+    assert ecode == 0
+    qmd_equal(q, eq)
+    assert np.array_equal(np.asarray(want).view(np.int64), np.asarray(got).view(np.int64))
+    row = copy.copy(ra)
+    row.output_columnar_hint = 0
+    qr, wr, code = oracle.execute(row.to_plan(), frags, n_threads=2)
+    rr = np.asarray(wr).view(np.int64).reshape(qr.entry_count, -1)
+    for key in range(7):
+        assert rr[key, -2] == int(v[k == key].min())
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
