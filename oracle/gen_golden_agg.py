@@ -1,0 +1,160 @@
+"""Generate tests/golden/ref_agg_vectors.json from the REFERENCE'S OWN aggregate and comparison runtime functions
+(QueryEngine/RuntimeFunctions.cpp compiled unmodified into oracle/_ref/libref_runtime.so, oracle/Makefile).
+
+Run in the build container only (needs /root/reference):  python oracle/gen_golden_agg.py
+The committed JSON is what travels.  tests/test_oracle_golden.py::test_aggregates_match_reference_functions pins
+oracle/oracle.cpp's row function to it on the CPU, tests/test_gpu_parity.py::test_hip_aggregates_match_reference_functions
+pins the HIP library to it on the device.
+
+Each "agg" case is one grouped step  SELECT AGG(v) FROM t GROUP BY k  with a single group (k = 0 everywhere) over a
+short column v: the expected slot value is what the reference's own agg_* function — the one TargetExprBuilder's
+codegenAggregate names for that target (TargetExprBuilder.cpp:600-760: base name, _double for floating-point
+arguments, _skip_val with the argument type's inline NULL when the target skips NULLs) — leaves in a slot that started
+at the descriptor's init value after being called once per row, in row order.
+Each "cmp" case is  SELECT COUNT(*) FROM t WHERE v <op> literal : the expected count is the number of rows for which
+the reference's <op>_<type>_nullable_lhs / plain comparison (DEF_CMP_NULLABLE_LHS, RuntimeFunctions.cpp:85-96) is > 0
+(toBool).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import struct
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from heavydb_amd import capi  # noqa: E402
+from heavydb_amd.executor import ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+
+NP = {capi.INT8: np.int8, capi.INT16: np.int16, capi.INT32: np.int32, capi.INT64: np.int64, capi.DOUBLE: np.float64}
+TNAME = {capi.INT8: "int8_t", capi.INT16: "int16_t", capi.INT32: "int32_t", capi.INT64: "int64_t", capi.DOUBLE: "double"}
+INT_NULL = {capi.INT8: -2**7, capi.INT16: -2**15, capi.INT32: -2**31, capi.INT64: -2**63}
+NULL_DOUBLE = float(np.finfo(np.float64).tiny)
+AGG_NAME = {capi.COUNT: "count", capi.SUM: "sum", capi.MIN: "min", capi.MAX: "max"}
+
+
+def dbl_bits(x: float) -> int:
+    return struct.unpack("<q", struct.pack("<d", x))[0]
+
+
+def step_unit(t, nullable, vals, agg):
+    """GROUP BY k (always 0) -> perfect hash with one entry; the target under test owns the last slot."""
+    nn = [v for v in vals if not (v == (NULL_DOUBLE if t == capi.DOUBLE else INT_NULL[t]) and nullable)]
+    if t == capi.DOUBLE:
+        rng_v = ExpressionRange(True, 0, 0, nullable, min(nn) if nn else 0.0, max(nn) if nn else 0.0)
+    else:
+        rng_v = ExpressionRange(True, int(min(nn)) if nn else 0, int(max(nn)) if nn else 0, nullable)
+    descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 0)), InputColDescriptor(t, nullable, rng_v)]
+    return RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT), TargetExpr(agg, 1)], [], [0], bigint_count=True)
+
+
+def main():
+    orc.build()
+    ref = C.CDLL(orc.REF_LIB)
+    rng = np.random.default_rng(2026)
+    out = {"source": "QueryEngine/RuntimeFunctions.cpp of the reference, compiled unmodified (oracle/ref_shim.cpp)", "agg": [], "cmp": []}
+
+    # ---- aggregates
+    def ref_fold(agg, t, skip, init, vals):
+        slot = C.c_int64(init)
+        p = C.byref(slot)
+        fp = t == capi.DOUBLE
+        name = "agg_" + AGG_NAME[agg] + ("_double" if fp else "") + ("_skip_val" if skip else "")
+        fn = getattr(ref, name)
+        fn.restype = C.c_uint64 if agg == capi.COUNT else (C.c_int64 if agg == capi.SUM and not fp else None)
+        # the argument as the call site passes it (TargetExprBuilder.cpp:486-495, 553-569): sign-extended to the
+        # slot's 64 bits; for SUM / COUNT (not "domain range equivalent") convertNullIfAny first turns the argument
+        # type's NULL into the NULL of the aggregate's own type (BIGINT here) and that is the skip value, while
+        # MIN / MAX keep the argument type's NULL
+        arg_null = NULL_DOUBLE if fp else INT_NULL[t]
+        widen = skip and not fp and agg in (capi.SUM, capi.COUNT)
+        null = NULL_DOUBLE if fp else (INT_NULL[capi.INT64] if widen else INT_NULL[t])
+        for v in vals:
+            if fp:
+                fn.argtypes = [C.c_void_p, C.c_double] + ([C.c_double] if skip else [])
+                fn(p, C.c_double(v), *([C.c_double(null)] if skip else []))
+            else:
+                arg = null if (widen and int(v) == arg_null) else int(v)
+                fn.argtypes = [C.c_void_p, C.c_int64] + ([C.c_int64] if skip else [])
+                fn(p, C.c_int64(arg), *([C.c_int64(null)] if skip else []))
+        return name, slot.value
+
+    for t in (capi.INT64, capi.INT32, capi.INT16, capi.INT8, capi.DOUBLE):
+        for nullable in (False, True):
+            for agg in (capi.COUNT, capi.SUM, capi.MIN, capi.MAX):
+                for variant in range(4):
+                    n = [1, 7, 40, 40][variant]
+                    if t == capi.DOUBLE:
+                        vals = [float(x) for x in (rng.random(n) - 0.5) * [1.0, 1e3, 1e-3, 1e12][variant]]
+                        if variant == 3:
+                            vals[3], vals[9] = -0.0, 0.0
+                    else:
+                        lo, hi = np.iinfo(NP[t]).min + 1, np.iinfo(NP[t]).max
+                        span = [(lo, hi), (-50, 50), (lo // 4, hi // 4), (hi - 60, hi)][variant]
+                        if t == capi.INT64:  # keep SUM inside int64
+                            span = [(-2**40, 2**40), (-50, 50), (-2**60, 2**60), (2**62 - 60, 2**62)][variant]
+                        vals = [int(x) for x in rng.integers(span[0], span[1], n, dtype=np.int64)]
+                    if nullable:
+                        null = NULL_DOUBLE if t == capi.DOUBLE else INT_NULL[t]
+                        for i in range(0, n, 3):
+                            vals[i] = null
+                        if variant == 1:
+                            vals = [null] * n   # a group whose argument is NULL in every row
+                    ra = step_unit(t, nullable, vals, agg)
+                    plan = ra.to_plan()
+                    q = orc.qmd_init(plan)
+                    slot = q.target_slot[1]
+                    skip = bool(q.target_skip_null[1])
+                    init = int(q.init_vals[slot])
+                    name, want = ref_fold(agg, t, skip, init, vals)
+                    out["agg"].append({"agg": AGG_NAME[agg], "type": TNAME[t], "nullable": nullable, "ref_function": name,
+                                       "values": [dbl_bits(v) for v in vals] if t == capi.DOUBLE else vals,
+                                       "values_are_double_bits": t == capi.DOUBLE, "slot": slot, "init": init, "want": want})
+
+    # ---- comparisons: DEF_CMP_NULLABLE_LHS (a nullable column against a literal) / the plain operator
+    OPS = {"eq": capi.EQ, "ne": capi.NE, "lt": capi.LT, "gt": capi.GT, "le": capi.LE, "ge": capi.GE}
+    for t in (capi.INT64, capi.INT32, capi.INT16, capi.INT8, capi.DOUBLE):
+        for nullable in (False, True):
+            for opn, opc in OPS.items():
+                n = 64
+                if t == capi.DOUBLE:
+                    vals = [float(x) for x in np.round((rng.random(n) - 0.5) * 20.0)]
+                    lit = 3.0
+                    null = NULL_DOUBLE
+                else:
+                    vals = [int(x) for x in rng.integers(-10, 11, n)]
+                    lit = 3
+                    null = INT_NULL[t]
+                if nullable:
+                    for i in range(0, n, 5):
+                        vals[i] = null
+                passed = 0
+                if nullable:
+                    fn = getattr(ref, f"{opn}_{TNAME[t]}_nullable_lhs")
+                    fn.restype = C.c_int8
+                    ct = C.c_double if t == capi.DOUBLE else {capi.INT8: C.c_int8, capi.INT16: C.c_int16, capi.INT32: C.c_int32, capi.INT64: C.c_int64}[t]
+                    nt = C.c_double if t == capi.DOUBLE else C.c_int64
+                    fn.argtypes = [ct, ct, nt, C.c_int8]
+                    for v in vals:
+                        passed += int(fn(ct(v), ct(lit), nt(null), C.c_int8(-128)) > 0)
+                    fname = f"{opn}_{TNAME[t]}_nullable_lhs"
+                else:
+                    import operator
+                    f = {"eq": operator.eq, "ne": operator.ne, "lt": operator.lt, "gt": operator.gt, "le": operator.le, "ge": operator.ge}[opn]
+                    passed = sum(int(f(v, lit)) for v in vals)
+                    fname = "plain C++ operator (NOT NULL operands: codegenCmp emits icmp / fcmp)"
+                out["cmp"].append({"op": opn, "op_code": opc, "type": TNAME[t], "nullable": nullable, "ref_function": fname,
+                                   "values": [dbl_bits(v) for v in vals] if t == capi.DOUBLE else vals,
+                                   "values_are_double_bits": t == capi.DOUBLE, "literal": lit, "want_count": passed})
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_agg_vectors.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out["agg"]), "aggregate cases,", len(out["cmp"]), "comparison cases")
+
+
+if __name__ == "__main__":
+    main()

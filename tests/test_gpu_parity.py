@@ -1070,6 +1070,41 @@ def test_hip_matches_oracle_on_random_plans(torch_cuda, oracle):
     assert ran > 100, ran
 
 
+@pytest.mark.parametrize("force_generic", [False, True], ids=["planned", "generic"])
+def test_hip_aggregates_and_comparisons_match_reference_functions(torch_cuda, force_generic):
+    """tests/golden/ref_agg_vectors.json — slots left by the reference's own agg_* functions and row counts passed by
+    its own *_nullable_lhs comparisons (QueryEngine/RuntimeFunctions.cpp compiled unmodified, oracle/gen_golden_agg.py)
+    — against the HIP library directly, no oracle in between.  Integer slots bit-exact; SUM(double) to 1e-12 relative
+    (the device adds in a different order), MIN / MAX / COUNT over doubles bit-exact."""
+    import struct
+    from heavydb_amd.executor import Executor, FetchResult
+    from tests.test_oracle_golden import _agg_vectors, agg_case_unit, cmp_case_unit
+    torch = torch_cuda
+    vec = _agg_vectors()
+    ex = Executor(0)
+
+    def run(ra, frags):
+        dev = [[torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in f] for f in frags]
+        fr = FetchResult([[int(t.data_ptr()) for t in f] for f in dev], [len(f[0]) for f in frags], keepalive=dev)
+        rs = ex.executeWorkUnit(ra, fr, allow_retry=False, force_generic=force_generic)
+        return rs.getQueryMemDesc(), np.asarray(rs.getStorage()).view(np.int64)
+
+    for case in vec["agg"]:
+        ra, frags = agg_case_unit(case)
+        q, buf = run(ra, frags)
+        assert q.target_slot[1] == case["slot"] and int(q.init_vals[case["slot"]]) == case["init"]
+        got = int(buf.reshape(q.entry_count, -1)[0, q.key_bytes // 8 + case["slot"]])
+        if case["type"] == "double" and case["agg"] == "sum" and got != case["want"]:
+            g, w = (struct.unpack("<d", struct.pack("<q", x))[0] for x in (got, case["want"]))
+            assert abs(g - w) <= 1e-12 * max(abs(g), abs(w)), (case["ref_function"], g, w)
+        else:
+            assert got == case["want"], (case["ref_function"], case["type"], case["nullable"], got, case["want"])
+    for case in vec["cmp"]:
+        ra, frags = cmp_case_unit(case)
+        q, buf = run(ra, frags)
+        assert int(buf.reshape(-1)[0]) == case["want_count"], (case["ref_function"], case["want_count"])
+
+
 @pytest.mark.parametrize("targets", ["key_count_count_key", "count_only"])
 def test_partitioned_family_on_a_sparse_index_with_a_tiny_input(torch_cuda, oracle, targets):
     """A DATE-in-days key grouped by its (unbucketed) seconds: a perfect-hash layout of 5 M entries of which 61

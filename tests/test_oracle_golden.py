@@ -373,3 +373,78 @@ def test_columnar_runtime_functions_match_reference_vectors(oracle):
     counts = buf[8:16]
     for k, b in zip(tr["keys"], tr["bins"]):
         assert counts[b] == sum(1 for kk in tr["keys"] if kk == k)
+
+
+# ---- aggregates and comparisons against vectors produced by the reference's own RuntimeFunctions.cpp
+# (tests/golden/ref_agg_vectors.json, oracle/gen_golden_agg.py)
+_TYPE = {"int8_t": ("INT8", np.int8), "int16_t": ("INT16", np.int16), "int32_t": ("INT32", np.int32),
+         "int64_t": ("INT64", np.int64), "double": ("DOUBLE", np.float64)}
+
+
+def _agg_vectors():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_agg_vectors.json")) as f:
+        return json.load(f)
+
+
+def agg_case_unit(case):
+    """The step of one "agg" vector: SELECT COUNT(*), AGG(v) FROM t GROUP BY k with k = 0 in every row."""
+    from heavydb_amd import capi
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    tname, npt = _TYPE[case["type"]]
+    t = getattr(capi, tname)
+    if case["values_are_double_bits"]:
+        v = np.array(case["values"], dtype=np.int64).view(np.float64)
+    else:
+        v = np.array(case["values"], dtype=npt)
+    null = np.finfo(np.float64).tiny if t == capi.DOUBLE else np.iinfo(npt).min
+    nn = v[v != null] if case["nullable"] else v
+    if t == capi.DOUBLE:
+        rng_v = ExpressionRange(True, 0, 0, case["nullable"], float(nn.min()) if nn.size else 0.0, float(nn.max()) if nn.size else 0.0)
+    else:
+        rng_v = ExpressionRange(True, int(nn.min()) if nn.size else 0, int(nn.max()) if nn.size else 0, case["nullable"])
+    descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 0)), InputColDescriptor(t, case["nullable"], rng_v)]
+    agg = {"count": capi.COUNT, "sum": capi.SUM, "min": capi.MIN, "max": capi.MAX}[case["agg"]]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT), TargetExpr(agg, 1)], [], [0], bigint_count=True)
+    return ra, [[np.zeros(len(v), dtype=np.int32), v]]
+
+
+def cmp_case_unit(case):
+    from heavydb_amd import capi
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    tname, npt = _TYPE[case["type"]]
+    t = getattr(capi, tname)
+    v = (np.array(case["values"], dtype=np.int64).view(np.float64) if case["values_are_double_bits"]
+         else np.array(case["values"], dtype=npt))
+    rng_v = (ExpressionRange(True, 0, 0, case["nullable"], -10.0, 10.0) if t == capi.DOUBLE
+             else ExpressionRange(True, -10, 10, case["nullable"]))
+    ra = RelAlgExecutionUnit([InputColDescriptor(t, case["nullable"], rng_v)], [TargetExpr(capi.COUNT)],
+                             [Qual(0, case["op_code"], case["literal"])], [])
+    return ra, [[v]]
+
+
+def test_aggregates_match_reference_functions(oracle):
+    """Every aggregate x argument type x nullability: the slot the oracle's row function leaves equals what the
+    reference's own agg_* function leaves (bit for bit, doubles included: same operations in the same order)."""
+    vec = _agg_vectors()
+    assert len(vec["agg"]) == 160
+    for case in vec["agg"]:
+        ra, frags = agg_case_unit(case)
+        q, buf, code = oracle.execute(ra.to_plan(), frags, n_threads=1)
+        assert code == 0
+        assert q.target_slot[1] == case["slot"] and int(q.init_vals[case["slot"]]) == case["init"], case["ref_function"]
+        rows = np.asarray(buf).view(np.int64).reshape(q.entry_count, -1)
+        kq = q.key_bytes // 8
+        assert int(rows[0, kq + case["slot"]]) == case["want"], (case["ref_function"], case["type"], case["nullable"],
+                                                                  case["values"][:6], int(rows[0, kq + case["slot"]]), case["want"])
+
+
+def test_comparisons_match_reference_functions(oracle):
+    vec = _agg_vectors()
+    assert len(vec["cmp"]) == 60
+    for case in vec["cmp"]:
+        ra, frags = cmp_case_unit(case)
+        q, buf, code = oracle.execute(ra.to_plan(), frags, n_threads=1)
+        assert code == 0
+        assert int(np.asarray(buf).view(np.int64).reshape(-1)[0]) == case["want_count"], (case["ref_function"], case["want_count"])
