@@ -115,6 +115,117 @@ def main():
                                        "values": [dbl_bits(v) for v in vals] if t == capi.DOUBLE else vals,
                                        "values_are_double_bits": t == capi.DOUBLE, "slot": slot, "init": init, "want": want})
 
+    # ---- FLOAT arguments: SUM / MIN / MAX run agg_*_float on the LOW FOUR BYTES of the 8-byte slot
+    # (takes_float_argument -> agg_chosen_bytes = sizeof(float), TargetExprBuilder.cpp:477-483, 519-522); COUNT(float)
+    # widens the value to double and counts with agg_count_double[_skip_val] ((double)NULL_FLOAT as the skip value)
+    NULL_FLOAT = float(np.finfo(np.float32).tiny)
+    for nullable in (False, True):
+        for agg in (capi.COUNT, capi.SUM, capi.MIN, capi.MAX):
+            for variant in range(3):
+                n = [1, 9, 40][variant]
+                vals = [float(np.float32(x)) for x in (rng.random(n) - 0.5) * [1.0, 1e3, 1e-3][variant]]
+                if nullable:
+                    for i in range(0, n, 3):
+                        vals[i] = NULL_FLOAT
+                    if variant == 1:
+                        vals = [NULL_FLOAT] * n
+                nn = [v for v in vals if not (nullable and v == NULL_FLOAT)]
+                descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 0)),
+                         InputColDescriptor(capi.FLOAT, nullable, ExpressionRange(True, 0, 0, nullable, min(nn) if nn else 0.0, max(nn) if nn else 0.0))]
+                ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT), TargetExpr(agg, 1)], [], [0], bigint_count=True)
+                q = orc.qmd_init(ra.to_plan())
+                slot, skip, init = q.target_slot[1], bool(q.target_skip_null[1]), int(q.init_vals[q.target_slot[1]])
+                cell = C.c_int64(init)
+                if agg == capi.COUNT:
+                    name = "agg_count_double" + ("_skip_val" if skip else "")
+                    fn = getattr(ref, name)
+                    fn.restype = C.c_uint64
+                    fn.argtypes = [C.c_void_p, C.c_double] + ([C.c_double] if skip else [])
+                    for v in vals:
+                        fn(C.byref(cell), C.c_double(float(np.float32(v))), *([C.c_double(float(np.float32(NULL_FLOAT)))] if skip else []))
+                else:
+                    name = "agg_" + AGG_NAME[agg] + "_float" + ("_skip_val" if skip else "")
+                    fn = getattr(ref, name)
+                    fn.restype = None
+                    fn.argtypes = [C.c_void_p, C.c_float] + ([C.c_float] if skip else [])
+                    for v in vals:
+                        fn(C.byref(cell), C.c_float(v), *([C.c_float(NULL_FLOAT)] if skip else []))
+                out["agg"].append({"agg": AGG_NAME[agg], "type": "float", "nullable": nullable, "ref_function": name,
+                                   "values": [int(np.float32(v).view(np.int32)) for v in vals], "values_are_float_bits": True,
+                                   "values_are_double_bits": False, "slot": slot, "init": init, "want": cell.value})
+
+    # ---- conditional aggregates: COUNT_IF(c < 3) and SUM_IF(v, c < 3) over a nullable condition column c.
+    # cond = lt_int64_t_nullable_lhs(c, 3, NULL_BIGINT, -128) in {1, 0, -128}.  COUNT_IF: the (nullable BOOLEAN)
+    # argument goes through convertNullIfAny -> NULL_BIGINT and agg_count_if_skip_val; SUM_IF: the condition becomes
+    # (cond == 1) (codegenConditionalAggregateCondValSelector, WindowFunctionIR.cpp:1610-1637) and the value goes to
+    # agg_sum_if[_skip_val] / agg_sum_if_double[_skip_val]
+    lt = ref.lt_int64_t_nullable_lhs
+    lt.restype = C.c_int8
+    lt.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int8]
+    NULL_BIG = INT_NULL[capi.INT64]
+    out["cond"] = []
+    for vt in (capi.INT64, capi.DOUBLE):
+        for v_nullable in (False, True):
+            for c_nullable in (False, True):
+                n = 48
+                cvals = [int(x) for x in rng.integers(-5, 9, n)]
+                if c_nullable:
+                    for i in range(1, n, 4):
+                        cvals[i] = NULL_BIG
+                if vt == capi.DOUBLE:
+                    vvals = [float(x) for x in (rng.random(n) - 0.5) * 100.0]
+                    vnull = NULL_DOUBLE
+                else:
+                    vvals = [int(x) for x in rng.integers(-1000, 1000, n)]
+                    vnull = NULL_BIG
+                if v_nullable:
+                    for i in range(0, n, 5):
+                        vvals[i] = vnull
+                conds = [int(lt(c, 3, NULL_BIG, -128)) if c_nullable else int(c < 3) for c in cvals]
+                nnv = [v for v in vvals if not (v_nullable and v == vnull)]
+                nnc = [c for c in cvals if not (c_nullable and c == NULL_BIG)]
+                descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 0)),
+                         InputColDescriptor(vt, v_nullable, ExpressionRange(True, 0, 0, v_nullable, min(nnv), max(nnv)) if vt == capi.DOUBLE
+                                            else ExpressionRange(True, int(min(nnv)), int(max(nnv)), v_nullable)),
+                         InputColDescriptor(capi.INT64, c_nullable, ExpressionRange(True, min(nnc), max(nnc), c_nullable))]
+                ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT_IF, cond=Qual(2, capi.LT, 3)),
+                                                 TargetExpr(capi.SUM_IF, 1, cond=Qual(2, capi.LT, 3))], [], [0], bigint_count=True)
+                q = orc.qmd_init(ra.to_plan())
+                # COUNT_IF
+                cell = C.c_int64(int(q.init_vals[q.target_slot[0]]))
+                if c_nullable:
+                    f = ref.agg_count_if_skip_val
+                    f.restype = C.c_uint64
+                    f.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+                    for c in conds:
+                        f(C.byref(cell), NULL_BIG if c == -128 else c, NULL_BIG)
+                    cname = "agg_count_if_skip_val"
+                else:
+                    f = ref.agg_count_if
+                    f.restype = C.c_uint64
+                    f.argtypes = [C.c_void_p, C.c_int64]
+                    for c in conds:
+                        f(C.byref(cell), c)
+                    cname = "agg_count_if"
+                want_count = cell.value
+                # SUM_IF
+                cell = C.c_int64(int(q.init_vals[q.target_slot[1]]))
+                skip = bool(q.target_skip_null[1])
+                sname = "agg_sum_if" + ("_double" if vt == capi.DOUBLE else "") + ("_skip_val" if skip else "")
+                f = getattr(ref, sname)
+                f.restype = None if vt == capi.DOUBLE else C.c_int64
+                vt_c = C.c_double if vt == capi.DOUBLE else C.c_int64
+                f.argtypes = [C.c_void_p, vt_c] + ([vt_c] if skip else []) + [C.c_int8]
+                for v, c in zip(vvals, conds):
+                    f(C.byref(cell), vt_c(v), *([vt_c(vnull)] if skip else []), C.c_int8(1 if c == 1 else 0))
+                out["cond"].append({"value_type": TNAME[vt], "value_nullable": v_nullable, "cond_nullable": c_nullable,
+                                    "ref_functions": [cname, sname],
+                                    "values": [dbl_bits(v) for v in vvals] if vt == capi.DOUBLE else vvals,
+                                    "values_are_double_bits": vt == capi.DOUBLE, "cond_values": cvals,
+                                    "slots": [q.target_slot[0], q.target_slot[1]],
+                                    "init": [int(q.init_vals[q.target_slot[0]]), int(q.init_vals[q.target_slot[1]])],
+                                    "want": [want_count, cell.value]})
+
     # ---- comparisons: DEF_CMP_NULLABLE_LHS (a nullable column against a literal) / the plain operator
     OPS = {"eq": capi.EQ, "ne": capi.NE, "lt": capi.LT, "gt": capi.GT, "le": capi.LE, "ge": capi.GE}
     for t in (capi.INT64, capi.INT32, capi.INT16, capi.INT8, capi.DOUBLE):
@@ -153,7 +264,7 @@ def main():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "ref_agg_vectors.json")
     with open(path, "w") as f:
         json.dump(out, f)
-    print("wrote", path, os.path.getsize(path), "bytes;", len(out["agg"]), "aggregate cases,", len(out["cmp"]), "comparison cases")
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out["agg"]), "aggregate cases,", len(out["cond"]), "conditional cases,", len(out["cmp"]), "comparison cases")
 
 
 if __name__ == "__main__":

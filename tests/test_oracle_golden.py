@@ -378,7 +378,7 @@ def test_columnar_runtime_functions_match_reference_vectors(oracle):
 # ---- aggregates and comparisons against vectors produced by the reference's own RuntimeFunctions.cpp
 # (tests/golden/ref_agg_vectors.json, oracle/gen_golden_agg.py)
 _TYPE = {"int8_t": ("INT8", np.int8), "int16_t": ("INT16", np.int16), "int32_t": ("INT32", np.int32),
-         "int64_t": ("INT64", np.int64), "double": ("DOUBLE", np.float64)}
+         "int64_t": ("INT64", np.int64), "double": ("DOUBLE", np.float64), "float": ("FLOAT", np.float32)}
 
 
 def _agg_vectors():
@@ -396,11 +396,13 @@ def agg_case_unit(case):
     t = getattr(capi, tname)
     if case["values_are_double_bits"]:
         v = np.array(case["values"], dtype=np.int64).view(np.float64)
+    elif case.get("values_are_float_bits"):
+        v = np.array(case["values"], dtype=np.int32).view(np.float32)
     else:
         v = np.array(case["values"], dtype=npt)
-    null = np.finfo(np.float64).tiny if t == capi.DOUBLE else np.iinfo(npt).min
+    null = np.finfo(npt).tiny if t in (capi.DOUBLE, capi.FLOAT) else np.iinfo(npt).min
     nn = v[v != null] if case["nullable"] else v
-    if t == capi.DOUBLE:
+    if t in (capi.DOUBLE, capi.FLOAT):
         rng_v = ExpressionRange(True, 0, 0, case["nullable"], float(nn.min()) if nn.size else 0.0, float(nn.max()) if nn.size else 0.0)
     else:
         rng_v = ExpressionRange(True, int(nn.min()) if nn.size else 0, int(nn.max()) if nn.size else 0, case["nullable"])
@@ -408,6 +410,27 @@ def agg_case_unit(case):
     agg = {"count": capi.COUNT, "sum": capi.SUM, "min": capi.MIN, "max": capi.MAX}[case["agg"]]
     ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT), TargetExpr(agg, 1)], [], [0], bigint_count=True)
     return ra, [[np.zeros(len(v), dtype=np.int32), v]]
+
+
+def cond_case_unit(case):
+    """SELECT COUNT_IF(c < 3), SUM_IF(v, c < 3) FROM t GROUP BY k (k = 0 in every row)."""
+    from heavydb_amd import capi
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    dbl = case["values_are_double_bits"]
+    v = np.array(case["values"], dtype=np.int64)
+    v = v.view(np.float64) if dbl else v
+    c = np.array(case["cond_values"], dtype=np.int64)
+    vnull = np.finfo(np.float64).tiny if dbl else -2**63
+    nnv = v[v != vnull] if case["value_nullable"] else v
+    nnc = c[c != -2**63] if case["cond_nullable"] else c
+    rv = (ExpressionRange(True, 0, 0, case["value_nullable"], float(nnv.min()), float(nnv.max())) if dbl
+          else ExpressionRange(True, int(nnv.min()), int(nnv.max()), case["value_nullable"]))
+    descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 0)),
+             InputColDescriptor(capi.DOUBLE if dbl else capi.INT64, case["value_nullable"], rv),
+             InputColDescriptor(capi.INT64, case["cond_nullable"], ExpressionRange(True, int(nnc.min()), int(nnc.max()), case["cond_nullable"]))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT_IF, cond=Qual(2, capi.LT, 3)),
+                                     TargetExpr(capi.SUM_IF, 1, cond=Qual(2, capi.LT, 3))], [], [0], bigint_count=True)
+    return ra, [[np.zeros(len(v), dtype=np.int32), v, c]]
 
 
 def cmp_case_unit(case):
@@ -428,7 +451,16 @@ def test_aggregates_match_reference_functions(oracle):
     """Every aggregate x argument type x nullability: the slot the oracle's row function leaves equals what the
     reference's own agg_* function leaves (bit for bit, doubles included: same operations in the same order)."""
     vec = _agg_vectors()
-    assert len(vec["agg"]) == 160
+    assert len(vec["agg"]) == 184 and len(vec["cond"]) == 8
+    for case in vec["cond"]:   # COUNT_IF / SUM_IF: agg_count_if[_skip_val], agg_sum_if[_double][_skip_val]
+        ra, frags = cond_case_unit(case)
+        q, buf, code = oracle.execute(ra.to_plan(), frags, n_threads=1)
+        assert code == 0
+        rows = np.asarray(buf).view(np.int64).reshape(q.entry_count, -1)
+        kq = q.key_bytes // 8
+        for j in range(2):
+            assert q.target_slot[j] == case["slots"][j] and int(q.init_vals[case["slots"][j]]) == case["init"][j]
+            assert int(rows[0, kq + case["slots"][j]]) == case["want"][j], (case["ref_functions"][j], case)
     for case in vec["agg"]:
         ra, frags = agg_case_unit(case)
         q, buf, code = oracle.execute(ra.to_plan(), frags, n_threads=1)
