@@ -226,6 +226,25 @@ def main():
                                     "init": [int(q.init_vals[q.target_slot[0]]), int(q.init_vals[q.target_slot[1]])],
                                     "want": [want_count, cell.value]})
 
+    # ---- multi-column perfect hash: get_matching_group_value_perfect_hash (RuntimeFunctions.cpp:2077-2091) writes the
+    # key columns of entry `hashed_index` on first touch and returns the slots behind them
+    gm = ref.get_matching_group_value_perfect_hash
+    gm.restype = C.c_void_p
+    gm.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+    out["perfect_multi"] = []
+    for key_count, rq, entries in ((2, 4, 12), (3, 5, 20), (4, 6, 9)):
+        buf = np.full(entries * rq, 2**63 - 1, dtype=np.int64)
+        for e in range(entries):
+            buf[e * rq + key_count:(e + 1) * rq] = 0
+        calls = []
+        for _ in range(3 * entries):
+            h = int(rng.integers(0, entries))
+            key = np.array([h * 7 + g for g in range(key_count)], dtype=np.int64)   # one key tuple per entry
+            p = gm(buf.ctypes.data, h, key.ctypes.data, key_count, rq)
+            calls.append({"hashed_index": h, "key": key.tolist(), "returned_quad_offset": (p - buf.ctypes.data) // 8})
+        out["perfect_multi"].append({"key_count": key_count, "row_size_quad": rq, "entry_count": entries, "calls": calls,
+                                     "final_buffer": buf.tolist()})
+
     # ---- comparisons: DEF_CMP_NULLABLE_LHS (a nullable column against a literal) / the plain operator
     OPS = {"eq": capi.EQ, "ne": capi.NE, "lt": capi.LT, "gt": capi.GT, "le": capi.LE, "ge": capi.GE}
     for t in (capi.INT64, capi.INT32, capi.INT16, capi.INT8, capi.DOUBLE):

@@ -480,3 +480,20 @@ def test_comparisons_match_reference_functions(oracle):
         q, buf, code = oracle.execute(ra.to_plan(), frags, n_threads=1)
         assert code == 0
         assert int(np.asarray(buf).view(np.int64).reshape(-1)[0]) == case["want_count"], (case["ref_function"], case["want_count"])
+
+
+def test_multi_column_perfect_hash_matches_reference_function(oracle):
+    """get_matching_group_value_perfect_hash of the reference (vectors in ref_agg_vectors.json) vs the oracle's."""
+    vec = _agg_vectors()
+    assert len(vec["perfect_multi"]) == 3
+    lib = oracle.lib()
+    for tr in vec["perfect_multi"]:
+        kc, rq, n = tr["key_count"], tr["row_size_quad"], tr["entry_count"]
+        buf = np.full(n * rq, 2**63 - 1, dtype=np.int64)
+        for e in range(n):
+            buf[e * rq + kc:(e + 1) * rq] = 0
+        for call in tr["calls"]:
+            key = np.array(call["key"], dtype=np.int64)
+            off = lib.orc_perfect_hash_slot(buf.ctypes.data, call["hashed_index"], key.ctypes.data, kc, rq)
+            assert off == call["returned_quad_offset"], call
+        assert buf.tolist() == tr["final_buffer"]
