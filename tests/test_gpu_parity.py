@@ -1128,8 +1128,9 @@ def test_partitioned_family_on_a_sparse_index_with_a_tiny_input(torch_cuda, orac
     are ever touched, 2 425 rows.  kernel_variant 2 sends it through the packed-index route into the partitioned
     family with 1 024 partitions, 16-record runs and a few hundred spilled records — the geometry of the
     headline run with nothing in it.  (Found by a soak run of the fuzzer while an experimental pair of LDS
-    bucket hashes was in the tree: spilled records were lost and stray groups appeared; the committed hashes
-    are checked here on the shape that showed it.)"""
+    bucket hashes was in the tree — `__umul24(...) >> 20` shifts arithmetically because HIP's __umul24 returns
+    int, a product >= 2^31 gave a negative bucket: records were lost and stray groups appeared.  The committed
+    hashes are checked here on the shape that showed it.)"""
     from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, InputColDescriptor, RelAlgExecutionUnit,
                                       TargetExpr)
     torch = torch_cuda
