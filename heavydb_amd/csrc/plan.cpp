@@ -127,7 +127,8 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
       case MI355Q_COUNT_IF:
         if (t.cond.col < 0 || t.cond.col >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
         if (t.agg == MI355Q_COUNT_IF) r.col = -1;  // the condition is the argument
-        r.cond_nullable = p.cols[t.cond.col].nullable != 0;
+        // `x IS [NOT] NULL` is itself never NULL (a NOT NULL BOOLEAN, Analyzer UOper kISNULL)
+        r.cond_nullable = p.cols[t.cond.col].nullable != 0 && t.cond.op != MI355Q_IS_NULL && t.cond.op != MI355Q_IS_NOT_NULL;
         break;
       case MI355Q_PROJECT_KEY:
         if (!grouped) return MI355Q_ERR_INVALID_PLAN;
@@ -574,6 +575,7 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
       o.cond.fval = c.fval;
       switch (c.op) {
         case MI355Q_EQ: case MI355Q_NE: case MI355Q_LT: case MI355Q_GT: case MI355Q_LE: case MI355Q_GE:
+        case MI355Q_IS_NULL: case MI355Q_IS_NOT_NULL:   // Select.CountIf / SumIf: COUNT_IF(x IS NULL), SUM_IF(v, x IS NOT NULL)
           break;
         default:
           return MI355Q_ERR_UNSUPPORTED;

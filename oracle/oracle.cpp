@@ -449,7 +449,10 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
     d.skip_null = (d.col >= 0 && t.agg != MI355Q_PROJECT_KEY) &&
                   ((d.arg_nullable && !d.constrained) || !is_group_by);
     // COUNT_IF: skip_null_val follows the nullability of the condition (its argument)
-    if (t.agg == MI355Q_COUNT_IF) d.skip_null = p.cols[t.cond.col].nullable != 0 || !is_group_by;
+    // (`x IS [NOT] NULL` is itself a NOT NULL BOOLEAN)
+    if (t.agg == MI355Q_COUNT_IF)
+      d.skip_null = (p.cols[t.cond.col].nullable != 0 && t.cond.op != MI355Q_IS_NULL && t.cond.op != MI355Q_IS_NOT_NULL) ||
+                    !is_group_by;
     d.n_slots = (t.agg == MI355Q_AVG) ? 2 : 1;
     out.push_back(d);
   }

@@ -465,3 +465,150 @@ def test_non_grouped_aggregates_are_null_aware(oracle):
     assert code == 0 and ecode == 0
     for rows in (_rows(oracle.fetch_rows(qm, buf), qm), _rows(oracle.fetch_rows(eq, ebuf), eq)):
         assert rows == [(10, -2147483647, 10, -1, 20)]
+
+
+# ---- Select.CountIf / Select.SumIf (ExecuteTest.cpp:4020-4198): the reference's own fixture table
+# `data_types_basic5` (numeric columns; tests/golden/ref_data_types_basic5_numeric.json, generated from
+# Tests/Import/datafiles/data_types_basic5.csv.gz by tests/golden/gen_data_types_basic5.py) and its query
+# generators.  The reference checks COUNT_IF(cond) against COUNT(1) WHERE cond and SUM_IF(v, cond) against
+# SUM(CASE WHEN cond THEN v END) on its own engine; here the first form runs through the oracle and the product's
+# row logic and the second form runs on SQLite.
+_B5_TYPES = {"int8_t": I8, "int16_t": I16, "int32_t": I32, "int64_t": I64, "float": F32, "double": F64}
+_B5_CONDS = {" IS NULL": (capi.IS_NULL, 0), " IS NOT NULL": (capi.IS_NOT_NULL, 0), " > 0": (capi.GT, 0)}
+
+
+def basic5_table():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "ref_data_types_basic5_numeric.json")) as f:
+        d = json.load(f)
+    names = list(d["columns"])
+    arrays, descs = {}, {}
+    for n in names:
+        t = _B5_TYPES[d["types"][n]]
+        vals = d["columns"][n]
+        a = np.array([NULL[t] if v is None else v for v in vals], dtype=NP[t])
+        arrays[n] = a
+        descs[n] = InputColDescriptor(t, True, col_range([a], t, True))
+    db = sqlite3.connect(":memory:")
+    db.execute("CREATE TABLE data_types_basic5 (" + ", ".join(names) + ")")
+    py = [[None if v is None else (float(np.float32(v)) if d["types"][n] == "float" else v) for v in d["columns"][n]] for n in names]
+    db.executemany("INSERT INTO data_types_basic5 VALUES (" + ",".join("?" * len(names)) + ")", list(zip(*py)))
+    return names, arrays, descs, db
+
+
+def basic5_unit(arrays, descs, cols, targets, quals=(), group=()):
+    """cols: the table columns the step fetches; targets / quals / group index into that list."""
+    idx = {n: i for i, n in enumerate(cols)}
+    tx = []
+    for t in targets:
+        if t[0] == "key":
+            tx.append(TargetExpr(capi.PROJECT_KEY, 0))
+        else:
+            _, kind, col, cond = t
+            c = None if cond is None else Qual(idx[cond[0]], *_B5_CONDS[cond[1]])
+            tx.append(TargetExpr(kind, -1 if col is None else idx[col], cond=c))
+    ra = RelAlgExecutionUnit([descs[n] for n in cols], tx, [Qual(idx[c], *_B5_CONDS[op]) for c, op in quals],
+                             [idx[g] for g in group], num_tuples=len(arrays[cols[0]]))
+    n = len(arrays[cols[0]])
+    frags = [[arrays[c][i:i + 32] for c in cols] for i in range(0, n, 32)]
+    return ra, frags
+
+
+def _both_engines(oracle, ra, frags):
+    from tests.test_rowlogic_emu import _emu_execute
+    plan = ra.to_plan()
+    qm, buf, code = oracle.execute(plan, frags, n_threads=3)
+    assert code == 0
+    eq, ebuf, ecode = _emu_execute(Case("ref", ra, frags), plan, None)
+    assert ecode == 0
+    return qm, [("oracle", _rows(oracle.fetch_rows(qm, buf), qm)), ("product row logic", _rows(oracle.fetch_rows(eq, ebuf), eq))]
+
+
+def count_if_queries():
+    """(SQL as the reference writes it, the COUNT(1) form it is checked against, step description)"""
+    names, arrays, descs, db = basic5_table()
+    out = []
+    for col in names:                                            # 1. non-group by (:4058-4074)
+        for cond in [" IS NULL", " > 0"]:
+            out.append((f"SELECT COUNT_IF({col}{cond}) FROM data_types_basic5",
+                        f"SELECT COUNT(1) FROM data_types_basic5 WHERE {col}{cond}",
+                        ([col], [("agg", capi.COUNT_IF, None, (col, cond))], (), ())))
+    for col in names:                                            # 2. group-by (:4076-4088)
+        out.append((f"SELECT CNT FROM (SELECT {col}, COUNT_IF({col} IS NULL) CNT FROM data_types_basic5 WHERE {col} IS NULL GROUP BY {col}) T",
+                    f"SELECT COUNT(1) FROM data_types_basic5 WHERE {col} IS NULL",
+                    ([col], [("key",), ("agg", capi.COUNT_IF, None, (col, " IS NULL"))], ((col, " IS NULL"),), (col,))))
+    return (names, arrays, descs, db), out
+
+
+def sum_if_queries():
+    names, arrays, descs, db = basic5_table()
+    out = []
+    for col in names:                                            # 1. non-group by (:4135-4158)
+        for op in _B5_CONDS:
+            out.append((f"SELECT SUM_IF({col}, {col}{op}) FROM data_types_basic5",
+                        f"SELECT SUM(CASE WHEN {col}{op} THEN {col} END) FROM data_types_basic5",
+                        ([col], [("agg", capi.SUM_IF, col, (col, op))], (), ()), col))
+    for col in names[1:]:                                        # 3. agg col and cond col are different (:4180-4196)
+        for op in _B5_CONDS:
+            out.append((f"SELECT SUM_IF(Tiny_int, {col}{op}) FROM data_types_basic5",
+                        f"SELECT SUM(CASE WHEN {col}{op} THEN Tiny_int END) FROM data_types_basic5",
+                        (["Tiny_int", col], [("agg", capi.SUM_IF, "Tiny_int", (col, op))], (), ()), "Tiny_int"))
+    return (names, arrays, descs, db), out
+
+
+def _expected_sum(db, arrays, alt_sql, value_col):
+    """SQLite runs the alternative query; BIGINT sums are taken modulo 2^64 like the reference's agg_sum (SQLite
+    raises on overflow), selected with the same CASE as a 0 / 1 flag."""
+    if value_col == "Big_int":
+        flags = [r[0] for r in db.execute(alt_sql.replace(f"SUM(CASE WHEN", "SELECT_FLAG(").replace("SELECT SELECT_FLAG(", "SELECT (CASE WHEN")
+                                          .replace(f" THEN {value_col} END)", " THEN 1 ELSE 0 END)")).fetchall()]
+        sel = arrays[value_col][np.array(flags, dtype=bool)]
+        sel = sel[sel != NULL[I64]]
+        return None if sel.size == 0 else int(np.sum(sel.astype(np.uint64), dtype=np.uint64).astype(np.int64))
+    return db.execute(alt_sql).fetchone()[0]
+
+
+def test_select_count_if(oracle):
+    (names, arrays, descs, db), queries = count_if_queries()
+    assert len(queries) == 18
+    for sql, alt, (cols, targets, quals, group) in queries:
+        want = db.execute(alt).fetchone()[0]
+        ra, frags = basic5_unit(arrays, descs, cols, targets, quals, group)
+        qm, engines = _both_engines(oracle, ra, frags)
+        for name, rows in engines:
+            if group:   # one group (the NULL key) when the column has NULLs, none otherwise; CNT is the last target
+                assert [r[-1] for r in rows] == ([want] if want else []), (name, sql, rows, want)
+            else:
+                assert rows == [(want,)], (name, sql, rows, want)
+
+
+def test_select_sum_if(oracle):
+    (names, arrays, descs, db), queries = sum_if_queries()
+    assert len(queries) == 33
+    for sql, alt, (cols, targets, quals, group), value_col in queries:
+        want = _expected_sum(db, arrays, alt, value_col)
+        ra, frags = basic5_unit(arrays, descs, cols, targets, quals, group)
+        qm, engines = _both_engines(oracle, ra, frags)
+        for name, rows in engines:
+            got = rows[0][0]
+            if want is None or got is None:
+                assert want is None and got is None, (name, sql, got, want)
+            elif isinstance(got, float):
+                rt, at = (F32_RTOL, F32_ATOL) if value_col == "Float_" else (1e-12, 0.0)
+                assert math.isclose(got, want, rel_tol=rt, abs_tol=at), (name, sql, got, want)
+            else:
+                assert got == want, (name, sql, got, want)
+
+
+def test_select_sum_if_grouped(oracle):
+    """:4160-4178 — SELECT col, SUM_IF(col, col <cond>) FROM test GROUP BY 1 on the `test` table."""
+    descs, frags, db = _table()
+    for col in ["fn", "dn", "u", "ofd", "smallint_nulls"]:
+        for op, (opc, lit) in _B5_CONDS.items():
+            alt = f"SELECT {col}, SUM(CASE WHEN {col}{op} THEN {col} END) FROM test GROUP BY 1"
+            i = NAMES.index(col)
+            ra = RelAlgExecutionUnit([descs[i]], [TargetExpr(capi.PROJECT_KEY, 0), TargetExpr(capi.SUM_IF, 0, cond=Qual(0, opc, lit))],
+                                     [], [0], num_tuples=sum(REPEAT))
+            qm, engines = _both_engines(oracle, ra, [[f[i]] for f in frags])
+            _compare(alt, db, qm, engines)

@@ -72,3 +72,54 @@ def test_group_by_test_baseline_no_filters_on_gpu(torch_cuda):
     assert rs.rowCount() == 2
     iv, dv, nu = rs.fetch()
     assert sorted(int(v) for v in np.asarray(iv)[:, 0]) == [1, 1]
+
+
+def _gpu_rows(torch_cuda, ra, frags):
+    from heavydb_amd.executor import Executor
+    case = Case("ref", ra, frags)
+    frag_t, inner_t = _upload(torch_cuda, case)
+    rs = Executor(0).executeWorkUnit(ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+    qm = rs.getQueryMemDesc()
+    return qm, _rows(rs.fetch(), qm)
+
+
+def test_select_count_if_and_sum_if_on_gpu(torch_cuda):
+    """Select.CountIf / Select.SumIf (ExecuteTest.cpp:4020-4198) with dt = GPU: COUNT_IF(cond) against COUNT(1) WHERE cond
+    and SUM_IF(v, cond) against SUM(CASE WHEN cond THEN v END) (SQLite) on the reference's data_types_basic5 fixture,
+    conditions `x IS NULL`, `x IS NOT NULL`, `x > 0`; then the grouped SUM_IF queries on the `test` table."""
+    import numpy as np
+    from heavydb_amd import capi
+    from heavydb_amd.executor import Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.test_execute_style import (_B5_CONDS, NAMES, _compare, _expected_sum, basic5_unit, count_if_queries,
+                                          sum_if_queries)
+    (names, arrays, descs, db), queries = count_if_queries()
+    for sql, alt, (cols, targets, quals, group) in queries:
+        want = db.execute(alt).fetchone()[0]
+        ra, frags = basic5_unit(arrays, descs, cols, targets, quals, group)
+        qm, rows = _gpu_rows(torch_cuda, ra, frags)
+        if group:
+            assert [r[-1] for r in rows] == ([want] if want else []), (sql, rows, want)
+        else:
+            assert rows == [(want,)], (sql, rows, want)
+    (names, arrays, descs, db), queries = sum_if_queries()
+    for sql, alt, (cols, targets, quals, group), value_col in queries:
+        want = _expected_sum(db, arrays, alt, value_col)
+        ra, frags = basic5_unit(arrays, descs, cols, targets, quals, group)
+        qm, rows = _gpu_rows(torch_cuda, ra, frags)
+        got = rows[0][0]
+        if want is None or got is None:
+            assert want is None and got is None, (sql, got, want)
+        elif isinstance(got, float):
+            rt, at = (F32_RTOL, F32_ATOL) if value_col == "Float_" else (1e-12, 0.0)
+            assert math.isclose(got, want, rel_tol=rt, abs_tol=at), (sql, got, want)
+        else:
+            assert got == want, (sql, got, want)
+    descs_t, frags_t, db_t = _table()
+    for col in ["fn", "dn", "u", "ofd", "smallint_nulls"]:
+        for op, (opc, lit) in _B5_CONDS.items():
+            alt = f"SELECT {col}, SUM(CASE WHEN {col}{op} THEN {col} END) FROM test GROUP BY 1"
+            i = NAMES.index(col)
+            ra = RelAlgExecutionUnit([descs_t[i]], [TargetExpr(capi.PROJECT_KEY, 0), TargetExpr(capi.SUM_IF, 0, cond=Qual(0, opc, lit))],
+                                     [], [0], num_tuples=sum(REPEAT))
+            qm, rows = _gpu_rows(torch_cuda, ra, [[f[i]] for f in frags_t])
+            _compare(alt, db_t, qm, [("HIP library", rows)])
