@@ -176,7 +176,8 @@ def _fuzz_row_plan(rng, descs):
         k = int(rng.integers(0, 9))
         col = int(rng.integers(0, len(descs)))
         cc = int(rng.integers(0, len(descs)))
-        cond = Qual(cc, [capi.LT, capi.GE, capi.NE][int(rng.integers(0, 3))], 0)
+        # (the reference's Select.CountIf / SumIf also condition on `x IS NULL` / `x IS NOT NULL`)
+        cond = Qual(cc, [capi.LT, capi.GE, capi.NE, capi.IS_NULL, capi.IS_NOT_NULL][int(rng.integers(0, 5))], 0)
         if k == 0 and group:
             targets.append(TargetExpr(capi.PROJECT_KEY, int(rng.integers(0, len(group)))))
         elif k == 1 or (k == 0 and not group):
