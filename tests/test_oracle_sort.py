@@ -46,3 +46,58 @@ def test_oracle_sort_agrees_with_sqlite(oracle, case):
                     assert a is None and b is None, (ob, w, g)
                 else:
                     assert abs(float(a) - float(b)) <= 1e-9 * max(1.0, abs(float(a))), (ob, w, g)
+
+
+# ---- Select.GpuSort / Select.SpeculativeTopNSort (ExecuteTest.cpp:11338-11378) on the reference's gpu_sort_test
+# table (import_gpu_sort_test, :9583-9603: four rows (2, 2, 2, 2), six rows (16000, 16000, 16000, 127),
+# fragment_size = 2)
+GPU_SORT_COLS = {"x": capi.INT64, "y": capi.INT32, "z": capi.INT16, "t": capi.INT8}
+GPU_SORT_ROWS = [(2, 2, 2, 2)] * 4 + [(16000, 16000, 16000, 127)] * 6
+# (the reference's SQL, group column, targets after the key, ORDER BY target index, DESC?, LIMIT, projected columns)
+GPU_SORT_QUERIES = [
+    ("SELECT x, COUNT(*) AS val FROM gpu_sort_test GROUP BY x ORDER BY val DESC;", "x", 1, 1, True, 0, None),
+    ("SELECT y, COUNT(*) AS val FROM gpu_sort_test GROUP BY y ORDER BY val DESC;", "y", 1, 1, True, 0, None),
+    ("SELECT y, COUNT(*), COUNT(*) AS val FROM gpu_sort_test GROUP BY y ORDER BY val DESC;", "y", 2, 2, True, 0, None),
+    ("SELECT z, COUNT(*) AS val FROM gpu_sort_test GROUP BY z ORDER BY val DESC;", "z", 1, 1, True, 0, None),
+    ("SELECT t, COUNT(*) AS val FROM gpu_sort_test GROUP BY t ORDER BY val DESC;", "t", 1, 1, True, 0, None),
+    ("SELECT x, COUNT(*) AS val FROM gpu_sort_test GROUP BY x ORDER BY val DESC LIMIT 2;", "x", 1, 1, True, 2, None),
+    ("SELECT x from (SELECT COUNT(*) AS val, x FROM gpu_sort_test GROUP BY x ORDER BY val ASC LIMIT 3);", "x", 1, 1, False, 3, [0]),
+    ("SELECT val from (SELECT y, COUNT(*) AS val FROM gpu_sort_test GROUP BY y ORDER BY val DESC LIMIT 3);", "y", 1, 1, True, 3, [1]),
+]
+
+
+def gpu_sort_unit(col, n_counts):
+    from heavydb_amd.executor import InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    from tests.cases import col_range
+    t = GPU_SORT_COLS[col]
+    i = list(GPU_SORT_COLS).index(col)
+    npt = {capi.INT64: np.int64, capi.INT32: np.int32, capi.INT16: np.int16, capi.INT8: np.int8}[t]
+    a = np.array([r[i] for r in GPU_SORT_ROWS], dtype=npt)
+    ra = RelAlgExecutionUnit([InputColDescriptor(t, True, col_range([a], t, True))],
+                             [TargetExpr(capi.PROJECT_KEY, 0)] + [TargetExpr(capi.COUNT)] * n_counts, [], [0],
+                             num_tuples=len(a))
+    return ra, [[a[j:j + 2]] for j in range(0, len(a), 2)]
+
+
+def gpu_sort_db():
+    db = sqlite3.connect(":memory:")
+    db.execute("CREATE TABLE gpu_sort_test (x bigint, y int, z smallint, t tinyint)")
+    db.executemany("INSERT INTO gpu_sort_test VALUES (?, ?, ?, ?)", GPU_SORT_ROWS)
+    return db
+
+
+@pytest.mark.parametrize("qi", range(len(GPU_SORT_QUERIES)))
+def test_select_gpu_sort_and_speculative_top_n(oracle, qi):
+    sql, col, n_counts, order_t, desc, limit, project = GPU_SORT_QUERIES[qi]
+    ra, frags = gpu_sort_unit(col, n_counts)
+    q, buf, code = oracle.execute(ra.to_plan(), frags, n_threads=2)
+    assert code == 0
+    iv, dv, nu = oracle.fetch_rows(q, buf)
+    all_live = np.sort(oracle.sort(q, buf, [(0, False, False)], limit=0))
+    pos = {int(e): i for i, e in enumerate(all_live)}
+    perm = oracle.sort(q, buf, [(order_t, desc, False)], limit=limit)
+    got = [tuple(int(v) for v in iv[pos[int(e)]]) for e in perm]
+    if project is not None:
+        got = [tuple(r[c] for c in project) for r in got]
+    want = [tuple(r) for r in gpu_sort_db().execute(sql).fetchall()]
+    assert got == want, (sql, got, want)   # no ties in this table: the order is total

@@ -115,3 +115,33 @@ def test_sort_on_device_matches_oracle(torch_cuda, oracle, name, layout):
             if lookup is not None:
                 for r in got:
                     assert np.array_equal(lookup[int(r[0])], r)
+
+
+@pytest.mark.parametrize("qi", range(8))
+def test_select_gpu_sort_and_speculative_top_n_on_gpu(torch_cuda, oracle, qi):
+    """Select.GpuSort / Select.SpeculativeTopNSort (ExecuteTest.cpp:11338-11378) with dt = GPU: the reference's
+    gpu_sort_test table and query texts, GROUP BY + ORDER BY val [LIMIT n] through mi355q_execute +
+    mi355q_result_sort, against SQLite running the text."""
+    from heavydb_amd.executor import Executor, FetchResult
+    from tests.test_oracle_sort import GPU_SORT_QUERIES, gpu_sort_db, gpu_sort_unit
+    torch = torch_cuda
+    assert len(GPU_SORT_QUERIES) == 8
+    sql, col, n_counts, order_t, desc, limit, project = GPU_SORT_QUERIES[qi]
+    ra, frags = gpu_sort_unit(col, n_counts)
+    dev = [[torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in f] for f in frags]
+    fr = FetchResult([[int(t.data_ptr()) for t in f] for f in dev], [len(f[0]) for f in frags], keepalive=dev)
+    rs = Executor(0).executeWorkUnit(ra, fr, allow_retry=False)
+    q = rs.getQueryMemDesc()
+    rq = q.row_size // 8
+    n_live = rs.rowCount()
+    out = torch.empty((max(n_live, 1), rq), dtype=torch.int64, device="cuda")
+    n = rs.sort_by([(order_t, desc, False)], int(out.data_ptr()), limit=limit)
+    assert n == (min(limit, n_live) if limit else n_live)
+    top = oracle.init_buffer(q).reshape(q.entry_count, rq)
+    top[:n] = out[:n].cpu().numpy()
+    iv, dv, nu = oracle.fetch_rows(q, top.reshape(-1))      # iteration of the sorted rows, in order
+    got = [tuple(int(v) for v in iv[i]) for i in range(n)]
+    if project is not None:
+        got = [tuple(r[c] for c in project) for r in got]
+    want = [tuple(r) for r in gpu_sort_db().execute(sql).fetchall()]
+    assert got == want, (sql, got, want)
