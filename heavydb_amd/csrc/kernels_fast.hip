@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kPerfectWide) void k_perfect_lds_prog(const int8_t*
   __syncthreads();
   bool bad = false;
   int64_t* const slots = tab + (kq ? ne : 0u);
-  scan_fragments<FT, KT, VT>(cols, num_rows, n_frags, n_cols, flt.col, a.kcol, a.vcol,
+  scan_fragments<FT, KT, VT, 4>(cols, num_rows, n_frags, n_cols, flt.col, a.kcol, a.vcol,
                              [&](FT fv, KT key, VT val) {
     if (!filter_pass<FT>(flt, fv)) return;
     const uint64_t d = (uint64_t)((int64_t)key - a.min_val);
