@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from heavydb_amd import capi
-from heavydb_amd.executor import InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+from heavydb_amd.executor import ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
 from tests.cases import Case, col_range
 from tests.helpers import F32_ATOL, F32_RTOL
 
@@ -612,3 +612,60 @@ def test_select_sum_if_grouped(oracle):
                                      [], [0], num_tuples=sum(REPEAT))
             qm, engines = _both_engines(oracle, ra, [[f[i]] for f in frags])
             _compare(alt, db, qm, engines)
+
+
+# ---- Select.AggregateOnEmptyTable (ExecuteTest.cpp:2298-2331) and Select.NullGroupBy (:1870-1883)
+# empty_test_table (id int, x bigint, y int, z smallint, t tinyint, f float, d double, b boolean), no rows (:10354)
+EMPTY_COLS = {"id": I32, "x": I64, "y": I32, "z": I16, "t": I8, "f": F32, "d": F64, "b": I8}
+EMPTY_TABLE_QUERIES = []
+for _where in ("", " WHERE id > 5"):
+    for _fn, _cols in (("AVG", "xyztfd"), ("MIN", "xyztfdb"), ("MAX", "xyztfdb"), ("SUM", "xyztfd"), ("COUNT", "xyztfdb")):
+        EMPTY_TABLE_QUERIES.append(("SELECT " + ", ".join(f"{_fn}({c})" for c in _cols) + " FROM empty_test_table" + _where + ";",
+                                    _fn, list(_cols), bool(_where)))
+
+
+def empty_table_unit(fn, cols, with_where, n_frags):
+    """n_frags = 0: the table has no fragments; 1: one fragment of zero rows (both occur in the reference: an empty
+    table, and "skipped fragment" — ExecuteTest.cpp:2310)."""
+    names = ["id"] + cols
+    descs = [InputColDescriptor(EMPTY_COLS[n], True, ExpressionRange(False, 0, 0)) for n in names]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(A[fn], 1 + i) for i in range(len(cols))],
+                             [Qual(0, capi.GT, 5)] if with_where else [], [], num_tuples=0)
+    frags = [[np.zeros(0, dtype=NP[EMPTY_COLS[n]]) for n in names]] * n_frags
+    return ra, frags
+
+
+@pytest.mark.parametrize("n_frags", [0, 1])
+@pytest.mark.parametrize("qi", range(10))
+def test_select_aggregate_on_empty_table(oracle, qi, n_frags):
+    sql, fn, cols, with_where = EMPTY_TABLE_QUERIES[qi]
+    db = sqlite3.connect(":memory:")
+    db.execute("CREATE TABLE empty_test_table (" + ", ".join(EMPTY_COLS) + ")")
+    want = db.execute(sql).fetchall()
+    assert want == [tuple([0 if fn == "COUNT" else None] * len(cols))]
+    ra, frags = empty_table_unit(fn, cols, with_where, n_frags)
+    qm, engines = _both_engines(oracle, ra, frags)
+    for name, rows in engines:
+        assert rows == want, (name, sql, rows)
+
+
+def null_group_by_unit(t):
+    """CREATE TABLE table_null_group_by (val TEXT | DOUBLE); INSERT NULL; SELECT val FROM ... GROUP BY val"""
+    if t == "TEXT":     # a dictionary-encoded string column holding one NULL id
+        desc = InputColDescriptor(I32, True, ExpressionRange(True, 0, -1, True), capi.ENC_DICT, 0)
+        col = np.array([NULL[I32]], dtype=np.int32)
+    else:
+        desc = InputColDescriptor(F64, True, ExpressionRange(True, 0, 0, True, 0.0, -1.0))
+        col = np.array([NULL[F64]], dtype=np.float64)
+    return RelAlgExecutionUnit([desc], [TargetExpr(capi.PROJECT_KEY, 0)], [], [0], num_tuples=1), [[col]]
+
+
+@pytest.mark.parametrize("t", ["TEXT", "DOUBLE"])
+def test_select_null_group_by(oracle, t):
+    ra, frags = null_group_by_unit(t)
+    try:
+        qm, engines = _both_engines(oracle, ra, frags)
+    except capi.Mi355qError as e:
+        pytest.fail(f"GROUP BY a column that only holds NULL was rejected: {e}")
+    for name, rows in engines:
+        assert rows == [(None,)], (name, rows)    # one group, its key NULL (the reference only checks that it runs)

@@ -123,3 +123,18 @@ def test_select_count_if_and_sum_if_on_gpu(torch_cuda):
                                      [], [0], num_tuples=sum(REPEAT))
             qm, rows = _gpu_rows(torch_cuda, ra, [[f[i]] for f in frags_t])
             _compare(alt, db_t, qm, [("HIP library", rows)])
+
+
+@pytest.mark.parametrize("n_frags", [0, 1])
+def test_select_aggregate_on_empty_table_and_null_group_by_on_gpu(torch_cuda, n_frags):
+    """Select.AggregateOnEmptyTable (ExecuteTest.cpp:2298-2331: no fragments / one empty fragment, with and without a
+    qual) and Select.NullGroupBy (:1870-1883) with dt = GPU."""
+    from tests.test_execute_style import EMPTY_TABLE_QUERIES, empty_table_unit, null_group_by_unit
+    for sql, fn, cols, with_where in EMPTY_TABLE_QUERIES:
+        ra, frags = empty_table_unit(fn, cols, with_where, n_frags)
+        qm, rows = _gpu_rows(torch_cuda, ra, frags)
+        assert rows == [tuple([0 if fn == "COUNT" else None] * len(cols))], (sql, rows)
+    for t in ("TEXT", "DOUBLE"):
+        ra, frags = null_group_by_unit(t)
+        qm, rows = _gpu_rows(torch_cuda, ra, frags)
+        assert rows == [(None,)], (t, rows)
