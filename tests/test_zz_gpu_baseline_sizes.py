@@ -147,3 +147,79 @@ def test_cfg4_one_billion_rows_vs_oracle(torch_cuda, oracle, sparse, sum_dim):
     assert code == 0, code
     compare_buffers(q, want, rs.getStorage())     # SUM over int64: bit-exact
     compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 0.0)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE.json's 10 B-row configurations at their REAL size against the oracle.
+# The step runs exactly as bench.py runs it: default scratch -> the 3-chunk geometry of the headline run
+# (3.33 B rows per chunk, the run capacity, spill list and 32-bit LDS counters of that size), not the 4 x 250 M-row
+# chunks of the 1 B-row tests above.  The oracle streams the same 10 B generated rows through its scalar row
+# function on the host (one kernel thread per fragment, private 640 MB tables, pairwise reduce), ~1 - 2 minutes.
+def _oracle_threads_big(orc, table_bytes: int) -> int:
+    return orc.host_threads_for_tables(max(table_bytes, 1), want=min(os.cpu_count() or 1, 128))
+
+
+def test_cfg3f_full_size_vs_oracle(torch_cuda, oracle):
+    """The headline: key, COUNT(*), AVG(f64) WHERE i32 < 2^30 GROUP BY key — 10 B rows, 10 M int64 keys, the 640 MB
+    table compared as a key -> {COUNT, AVG.sum, AVG.count} map with the oracle's (ResultSetReduction.cpp:203-383
+    decides what a merged slot holds, ResultSetBufferAccessors.h:197-227 what the pair means): COUNT exact,
+    AVG.sum 1e-9 relative."""
+    from heavydb_amd import synth
+    from heavydb_amd.executor import Executor
+    torch = torch_cuda
+    total, n_keys = 10_000_000_000, 10_000_000
+    if _free_gb(torch) < (total * 20 + (40 << 30)) / 2**30:
+        pytest.skip("needs ~240 GB of free HBM")
+    ra, fr, info = synth.cfg3(torch, total, filtered=True, n_keys=n_keys)
+    rs = Executor(0).executeWorkUnit(ra, fr, allow_retry=False)   # default scratch: the bench's own chunking
+    assert rs.report.variant == 2 and rs.report.kernel_name.decode() == "k_part_scatter"
+    assert 2 <= rs.report.n_launches <= 4, rs.report.n_launches
+    got = rs.getStorage()
+    qg = rs.getQueryMemDesc()
+    n_rows_out = rs.rowCount()
+    del rs, fr   # the 200 GB of columns are not needed while the host scans
+    _free_gb(torch)
+    table_bytes = qg.entry_count * qg.row_size
+    t0 = time.time()
+    q, want, code, timing = oracle.execute_streamed(ra.to_plan(), info["gens"], total,
+                                                    n_threads=_oracle_threads_big(oracle, table_bytes),
+                                                    reduce_threads=min(os.cpu_count() or 1, 64))
+    assert code == 0, code
+    print(f"oracle cfg3f 10 B rows: {time.time() - t0:.1f} s {timing}")
+    assert q.entry_count == qg.entry_count == 2 * n_keys and q.row_size == qg.row_size == 32
+    compare_buffers(q, want, got, 1e-9)
+    check_probe_invariant(qg, got)
+    assert n_rows_out == n_keys
+
+
+@pytest.mark.parametrize("sum_dim", [False, True], ids=["query_a", "query_b"])
+def test_cfg4_full_size_vs_oracle(torch_cuda, oracle, sum_dim):
+    """cfg4 at 10 B fact rows x 100 M dim rows (dense keys, perfect int32[] table): SUM(fact.v) [, SUM(dim.w)]
+    bit-exact against the oracle's probe of its own table (hash_join_idx, GroupByRuntime.cpp:287-297)."""
+    from heavydb_amd import synth
+    from heavydb_amd.executor import Executor
+    torch = torch_cuda
+    n, m = 10_000_000_000, 100_000_000
+    if _free_gb(torch) < (n * 16 + (60 << 30)) / 2**30:
+        pytest.skip("needs ~220 GB of free HBM")
+    ra, fr, info = synth.cfg4(torch, n, dim_rows=m, sparse=False, sum_dim=sum_dim)
+    rs = Executor(0).executeWorkUnit(ra, fr)
+    got = rs.getStorage()
+    got_rows = rs.fetch()
+    kernel = rs.report.kernel_name.decode()
+    plan = ra.to_plan()
+    plan.join_table = None    # the oracle probes ITS OWN table, built below from the same dim keys
+    ra.join_table = None
+    del rs, fr                # 160 GB of fact columns are not needed while the host scans
+    _free_gb(torch)
+    dim_k = np.arange(m, dtype=np.int64)
+    g = info["dim_w_gen"]
+    dim_w = oracle.generate_column(m, g[0], g[1], g[2], g[3], g[4], g[5])
+    join = oracle.OracleJoin(dim_k, capi.INT64, 0, m - 1)
+    t0 = time.time()
+    q, want, code, timing = oracle.execute_streamed(plan, info["gens"], n, inner_cols=[dim_k, dim_w], join=join,
+                                                    n_threads=os.cpu_count() or 1)
+    assert code == 0, code
+    print(f"oracle cfg4 sum_dim={sum_dim} 10 B rows ({kernel}): {time.time() - t0:.1f} s {timing}")
+    compare_buffers(q, want, got)
+    compare_rows(q, oracle.fetch_rows(q, want), got_rows, 0.0)
