@@ -16,7 +16,9 @@ MAX_QUALS = 4
 MAX_TARGETS = 8
 MAX_SLOTS = 16
 MAX_GROUP_COLS = 4
-ABI_VERSION = 2
+MAX_EXPRS = 4
+MAX_EXPR_NODES = 8
+ABI_VERSION = 3
 
 # mi355q_type
 INT8, INT16, INT32, INT64, DOUBLE, FLOAT = 1, 2, 3, 4, 5, 6
@@ -42,8 +44,12 @@ OUTPUT_ROWWISE, OUTPUT_COLUMNAR, OUTPUT_ROWWISE_COLUMNAR_DECISIONS = 0, 1, 2  # 
 # generator kinds
 GEN_I32_UNIFORM31, GEN_I32_MOD, GEN_I64_MOD, GEN_I64_MOD_MUL, GEN_F64_UNIT = 1, 2, 3, 4, 5
 
+# mi355q_expr_op (projected expressions)
+EX_COL, EX_LIT, EX_CAST, EX_ADD, EX_SUB, EX_MUL = 1, 2, 3, 4, 5, 6
+
 OK = 0
 ERR_OUT_OF_SLOTS = 3
+ERR_OVERFLOW_OR_UNDERFLOW = 7
 ERR_INVALID_PLAN = 100
 ERR_UNSUPPORTED = 101
 ERR_HIP = 102
@@ -73,6 +79,16 @@ class Range(C.Structure):
                 ("bucket", C.c_int64)]
 
 
+class ExprNode(C.Structure):
+    _fields_ = [("op", C.c_int32), ("type", C.c_int32), ("arg", C.c_int32), ("reserved", C.c_int32),
+                ("ilit", C.c_int64), ("flit", C.c_double)]
+
+
+class Expr(C.Structure):
+    _fields_ = [("n_nodes", C.c_int32), ("reserved", C.c_int32), ("nodes", ExprNode * MAX_EXPR_NODES),
+                ("range", Range)]
+
+
 class Plan(C.Structure):
     _fields_ = [
         ("abi_version", C.c_int32),
@@ -98,6 +114,9 @@ class Plan(C.Structure):
         ("bigint_count", C.c_int32),
         ("output_columnar_hint", C.c_int32),
         ("num_tuples", C.c_int64),
+        ("n_exprs", C.c_int32),
+        ("reserved3", C.c_int32),
+        ("exprs", Expr * MAX_EXPRS),
     ]
 
 

@@ -128,6 +128,8 @@ struct DeviceCtx {
   int64_t aux_bytes = 0;
   void* wide = nullptr;     // 8-byte-slot table of a step whose result layout has 4-byte slots
   int64_t wide_bytes = 0;
+  void* proj = nullptr;     // dense temporary columns of projected expressions (one pass of fragments)
+  int64_t proj_bytes = 0;
   void* scratch = nullptr;
   int64_t scratch_bytes = 0;
   void* meta = nullptr;
@@ -198,6 +200,10 @@ int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
 int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
   // every distinct outer column the plan touches is read once per row
   bool used[MI355Q_MAX_COLS] = {false};
+  for (int k = 0; k < p.n_exprs && k < MI355Q_MAX_EXPRS; ++k)  // an expression reads its operand columns
+    for (int i = 0; i < p.exprs[k].n_nodes && i < MI355Q_MAX_EXPR_NODES; ++i)
+      if (p.exprs[k].nodes[i].op == MI355Q_EX_COL && p.exprs[k].nodes[i].arg >= 0 && p.exprs[k].nodes[i].arg < p.n_cols)
+        used[p.exprs[k].nodes[i].arg] = true;
   for (int i = 0; i < p.n_quals; ++i) used[p.quals[i].col] = true;
   for (int g = 0; g < p.n_group_cols; ++g) used[p.group_cols[g]] = true;
   if (p.join_outer_col >= 0) {
@@ -210,7 +216,7 @@ int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
     if (p.targets[i].agg == MI355Q_COUNT_IF || p.targets[i].agg == MI355Q_SUM_IF) used[p.targets[i].cond.col] = true;
   }
   int64_t per_row = 0;
-  for (int c = 0; c < p.n_cols; ++c) {
+  for (int c = 0; c < p.n_cols; ++c) {  // physical columns only (indices >= n_cols are expressions)
     if (used[c]) per_row += type_width(p.cols[c].type);
   }
   int64_t rows = 0;
@@ -293,6 +299,9 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   if (ctx.wide) (void)hipFree(ctx.wide);
   ctx.wide = nullptr;
   ctx.wide_bytes = 0;
+  if (ctx.proj) (void)hipFree(ctx.proj);
+  ctx.proj = nullptr;
+  ctx.proj_bytes = 0;
   if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
   ctx.stream = nullptr;
   for (hipEvent_t e : ctx.events) (void)hipEventDestroy(e);
@@ -1134,6 +1143,159 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
   return MI355Q_OK;
 }
 
+// Plans with projected expressions (mi355q_expr): scan / filter / PROJECT.  The expressions of a pass of
+// fragments are evaluated into dense temporary columns (k_project), the step runs on the lowered plan — where
+// those columns are ordinary inputs, so every kernel family applies — and the passes' results are folded with
+// the reduce rule (ResultSetStorage::reduce, as for the reference's per-fragment kernels).  One pass when the
+// temporary columns fit a third of the free memory (<= 16 GB).
+int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
+                          mi355q_result** out, mi355q_exec_report* report) {
+  mi355q_plan lp;
+  DevExprSet xs;
+  if (int32_t e = lower_exprs(*plan, &lp, &xs)) return e;
+  mi355q_qmd q;
+  if (int32_t e = qmd_init(*plan, &q)) return e;
+  DevPlan d;
+  if (int32_t e = build_dev_plan(lp, q, &d)) return e;
+  if (int32_t e = attach_join(lp, in, &d)) return e;
+  const int nf = in->n_frags, nc = plan->n_cols, nx = plan->n_exprs, nc2 = nc + nx;
+  if (nf == 0) return mi355q_execute(&lp, in, &o, out, report);
+  uint32_t qual_expr_mask = 0;
+  for (int i = 0; i < plan->n_quals; ++i)
+    if (plan->quals[i].col >= nc) qual_expr_mask |= 1u << (plan->quals[i].col - nc);
+  int64_t total_rows = 0, max_frag_rows = 0;
+  for (int f = 0; f < nf; ++f) {
+    if (in->num_rows[f] < 0) return MI355Q_ERR_INVALID_PLAN;
+    total_rows += in->num_rows[f];
+    max_frag_rows = std::max(max_frag_rows, in->num_rows[f]);
+  }
+  int64_t row_bytes = 0;
+  for (int k = 0; k < nx; ++k) row_bytes += plain_width(xs.e[k].type);
+
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  const int n_cus = cu_count_of(in->device_id);
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const int64_t budget = std::min<int64_t>((int64_t)16 << 30, ((int64_t)free_b + ctx.proj_bytes) / 3);
+  // every (fragment, expression) chunk starts on a 16-byte boundary: the fast families want aligned columns
+  const int64_t pad = 16 * (int64_t)nx;
+  int64_t pass_rows = std::max<int64_t>(budget / std::max<int64_t>(row_bytes, 1), max_frag_rows);
+  if (o.reserved[2] > 0) pass_rows = std::max<int64_t>(o.reserved[2], max_frag_rows);  // tests: several passes
+  if (pass_rows > total_rows) pass_rows = total_rows;
+  const int64_t tab_bytes = ((int64_t)sizeof(void*) * nf * nc2 + 255) & ~255ll;
+  const int64_t rows_bytes = ((int64_t)sizeof(int64_t) * nf + 255) & ~255ll;
+  // (worst case: every fragment of a pass pads every expression chunk once)
+  const int64_t col_region = ((pass_rows * row_bytes + pad * nf) + 255) & ~255ll;
+  const int64_t need = col_region + tab_bytes + rows_bytes + 256;
+  if (ctx.proj_bytes < need) {
+    if (ctx.proj) (void)hipFree(ctx.proj);
+    ctx.proj = nullptr;
+    ctx.proj_bytes = 0;
+    hipError_t he = hipMalloc(&ctx.proj, (size_t)need);
+    if (he != hipSuccess) {
+      last_hip_error = he;
+      (void)hipGetLastError();
+      return MI355Q_ERR_OUT_OF_GPU_MEM;
+    }
+    ctx.proj_bytes = need;
+  }
+  char* base = (char*)ctx.proj;
+  const int8_t** d_tab = (const int8_t**)(base + col_region);
+  int64_t* d_rows = (int64_t*)(base + col_region + tab_bytes);
+  int32_t* d_err = (int32_t*)(base + col_region + tab_bytes + rows_bytes);
+  HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
+  HIP_TRY(hipMemcpyAsync(d_rows, in->num_rows, sizeof(int64_t) * (size_t)nf, hipMemcpyHostToDevice, s));
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+
+  std::vector<const void*> cols2((size_t)nf * nc2);
+  mi355q_result* res = nullptr;
+  struct ResGuard {
+    mi355q_result*& r;
+    ~ResGuard() { if (r) mi355q_result_free(r); }
+  } rg{res};
+  mi355q_exec_report acc{};
+  int pass = 0, f = 0;
+  while (f < nf) {
+    int f1 = f;
+    int64_t rows = 0, off = 0;
+    while (f1 < nf && (f1 == f || rows + in->num_rows[f1] <= pass_rows)) {
+      for (int c = 0; c < nc; ++c) cols2[(size_t)(f1 - f) * nc2 + c] = in->col_buffers[(size_t)f1 * nc + c];
+      for (int k = 0; k < nx; ++k) {
+        cols2[(size_t)(f1 - f) * nc2 + nc + k] = base + off;
+        off += (in->num_rows[f1] * plain_width(xs.e[k].type) + 15) & ~15ll;
+      }
+      rows += in->num_rows[f1];
+      ++f1;
+    }
+    if (off > col_region) return MI355Q_ERR_OUT_OF_GPU_MEM;  // (cannot happen: the region is sized for it)
+    const int pnf = f1 - f;
+    HIP_TRY(hipMemcpyAsync(d_tab, cols2.data(), sizeof(void*) * (size_t)pnf * nc2, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_project(xs, d, qual_expr_mask, d_tab, d_rows + f, pnf, max_frag_rows, d_err, n_cus, s));
+    int32_t h_err = 0;
+    HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (cols2 is re-used by the next pass; the step below synchronises anyway)
+    if (h_err) return h_err;
+    mi355q_inputs in2 = *in;
+    in2.n_frags = pnf;
+    in2.col_buffers = cols2.data();
+    in2.num_rows = in->num_rows + f;
+    mi355q_exec_options o2 = o;
+    o2.stream = s;
+    o2.out_buffer = pass == 0 ? o.out_buffer : nullptr;
+    mi355q_result* r2 = nullptr;
+    mi355q_exec_report rep2{};
+    if (int32_t e2 = mi355q_execute(&lp, &in2, &o2, &r2, &rep2)) return e2;
+    if (pass == 0) {
+      res = r2;
+      std::snprintf(acc.kernel_name, sizeof(acc.kernel_name), "%s", rep2.kernel_name);
+      acc.variant = rep2.variant;
+    } else {
+      const int32_t er = mi355q_result_reduce(res, r2, s);
+      mi355q_result_free(r2);
+      if (er) return er;
+    }
+    acc.kernel_ms += rep2.kernel_ms;
+    acc.n_launches += rep2.n_launches;
+    acc.spilled_rows += rep2.spilled_rows;
+    f = f1;
+    ++pass;
+  }
+  if (ev1) {
+    HIP_TRY(hipEventRecord(ev1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (report) {
+    *report = acc;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  *out = res;
+  res = nullptr;
+  return MI355Q_OK;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------- execute
@@ -1147,6 +1309,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   mi355q_exec_options o{};
   if (opts) o = *opts;
   set_debug_knobs(o.reserved[0], o.reserved[1]);
+  if (plan->n_exprs != 0) return execute_projected(plan, in, o, out, report);
 
   Trace tr;
   mi355q_qmd q;

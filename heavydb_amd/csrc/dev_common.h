@@ -288,6 +288,26 @@ struct DevPlan {
   const int8_t* inner_cols[MI355Q_MAX_COLS];
 };
 
+// ------------------------------------------------------------------ projected expressions
+// mi355q_expr lowered by plan.cpp (lower_exprs): every node knows the type and nullability of what it
+// pops, so the evaluator (expr.h) is a flat loop without type inference.
+enum : int32_t { EXF_NULLABLE = 1, EXF_LHS_NULLABLE = 2, EXF_RHS_NULLABLE = 4 };
+struct DevExprNode {
+  int32_t op, type;  // mi355q_expr_op; plain mi355q_type of the result
+  int32_t arg;       // EX_COL: column index; EX_CAST: the operand's type
+  int32_t flags;     // EXF_*: result / lhs (or cast operand) / rhs nullable
+  int64_t ilit;      // EX_LIT (integers); EX_COL: the column's type code
+  double flit;       // EX_LIT (DOUBLE / FLOAT)
+};
+struct DevExpr {
+  int32_t n_nodes, type, nullable, pad_;
+  DevExprNode nodes[MI355Q_MAX_EXPR_NODES];
+};
+struct DevExprSet {
+  int32_t n, n_cols;  // expressions; physical columns (expression k is written as column n_cols + k)
+  DevExpr e[MI355Q_MAX_EXPRS];
+};
+
 // geometry of a columnar result buffer (output_columnar_; rowfunc.h entry_to_columns)
 struct ColLayout {
   int64_t entry_count;

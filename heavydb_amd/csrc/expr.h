@@ -1,0 +1,134 @@
+// expr.h — evaluator of the projected-expression micro-ops (mi355q_expr lowered to DevExpr by plan.cpp).
+//
+// One function, used by the projection kernel (kernels_generic.hip k_project) on the device and by the
+// host emulation of tests/emu.  Values travel as 64-bit patterns: integers sign-extended (SQL NULL = the
+// inline sentinel of the node's type, Shared/InlineNullValues.h), DOUBLE as its bits, FLOAT as its bits in
+// the low word.  Reference semantics restated (heavyai/heavydb):
+//   casts        CastIR.cpp:424-495 codegenCastBetweenIntTypes (+ :497-553 the narrowing check: error when
+//                v > max(to) or v <= min(to), NULL exempt), :555-594 codegenCastToFp, :596-653
+//                codegenCastFromFp; cast_<a>_to_<b>_nullable and DEF_ROUND_NULLABLE,
+//                RuntimeFunctions.cpp:262-330
+//   + - *        ArithmeticIR.cpp:39-75 codegenArith; integers: :861-909 codegenBinOpWithOverflowForCPU
+//                (sadd/ssub/smul.with.overflow at the operand type's width, NULL operands skip the check and
+//                give NULL: codegenSkipOverflowCheckForNull); floating point: add_/sub_/mul_<type>_nullable,
+//                RuntimeFunctions.cpp:46-53
+//   error        ErrorCode::OVERFLOW_OR_UNDERFLOW = 7 (QueryEngine/enums.h:30-51)
+#pragma once
+
+#include "dev_common.h"
+
+namespace mq {
+
+MQ_HD bool ex_is_int(int t) { return t >= MI355Q_INT8 && t <= MI355Q_INT64; }
+MQ_HD int64_t ex_int_max(int t) {
+  return t == MI355Q_INT8 ? (int64_t)INT8_MAX : t == MI355Q_INT16 ? (int64_t)INT16_MAX
+         : t == MI355Q_INT32 ? (int64_t)INT32_MAX : INT64_MAX;
+}
+MQ_HD int64_t ex_int_min(int t) { return plain_int_null(t); }  // the type's minimum IS its NULL sentinel
+MQ_HD int64_t ex_flt_pattern(float f) { return (int64_t)(uint32_t)flt_bits(f); }
+MQ_HD float ex_flt_of(int64_t v) { return bits_flt((int32_t)(uint32_t)v); }
+
+// *err receives MI355Q_ERR_OVERFLOW_OR_UNDERFLOW when a check fires (the value returned is then unspecified)
+MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos, int32_t* err) {
+  int64_t st[4] = {0, 0, 0, 0};
+  int sp = 0;
+  for (int i = 0; i < e.n_nodes; ++i) {
+    const DevExprNode& n = e.nodes[i];
+    switch (n.op) {
+      case MI355Q_EX_COL: {
+        const int8_t* c = cols[n.arg];
+        if (n.type == MI355Q_DOUBLE) st[sp++] = *(const int64_t*)(c + pos * 8);
+        else if (n.type == MI355Q_FLOAT) st[sp++] = (int64_t)*(const uint32_t*)(c + pos * 4);
+        else st[sp++] = decode_int(c, (int)n.ilit, pos);
+        break;
+      }
+      case MI355Q_EX_LIT:
+        st[sp++] = n.type == MI355Q_DOUBLE ? dbl_bits(n.flit)
+                   : n.type == MI355Q_FLOAT ? ex_flt_pattern((float)n.flit) : n.ilit;
+        break;
+      case MI355Q_EX_CAST: {
+        const int from = n.arg, to = n.type;
+        const bool nullable = (n.flags & EXF_LHS_NULLABLE) != 0;
+        const int64_t v = st[sp - 1];
+        int64_t r = v;
+        if (ex_is_int(from)) {
+          const bool is_null = nullable && v == plain_int_null(from);
+          if (ex_is_int(to)) {
+            if (is_null) {
+              r = plain_int_null(to);
+            } else if (plain_width(to) < plain_width(from) && (v > ex_int_max(to) || v <= ex_int_min(to))) {
+              *err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+            }
+          } else if (to == MI355Q_DOUBLE) {
+            r = is_null ? kNullDoubleBits : dbl_bits((double)v);
+          } else {
+            r = is_null ? (int64_t)(uint32_t)kNullFloatBits : ex_flt_pattern((float)v);
+          }
+        } else if (from == MI355Q_DOUBLE) {
+          const double d = bits_dbl(v);
+          const bool is_null = nullable && d == kNullDouble;
+          if (to == MI355Q_FLOAT) r = is_null ? (int64_t)(uint32_t)kNullFloatBits : ex_flt_pattern((float)d);
+          else if (ex_is_int(to)) r = is_null ? plain_int_null(to) : (int64_t)(d + (d < 0.0 ? -0.5 : 0.5));
+        } else {  // FLOAT
+          const float f = ex_flt_of(v);
+          const bool is_null = nullable && f == kNullFloat;
+          if (to == MI355Q_DOUBLE) r = is_null ? kNullDoubleBits : dbl_bits((double)f);
+          else if (ex_is_int(to)) r = is_null ? plain_int_null(to) : (int64_t)(f + (f < 0.0f ? -0.5f : 0.5f));
+        }
+        st[sp - 1] = r;
+        break;
+      }
+      default: {  // MI355Q_EX_ADD / _SUB / _MUL
+        const int64_t b = st[--sp];
+        const int64_t a = st[sp - 1];
+        const int t = n.type;
+        int64_t r;
+        if (ex_is_int(t)) {
+          const int64_t nul = plain_int_null(t);
+          if (((n.flags & EXF_LHS_NULLABLE) && a == nul) || ((n.flags & EXF_RHS_NULLABLE) && b == nul)) {
+            r = nul;
+          } else {
+            bool ovf;
+            long long w;
+            if (n.op == MI355Q_EX_ADD) ovf = __builtin_add_overflow((long long)a, (long long)b, &w);
+            else if (n.op == MI355Q_EX_SUB) ovf = __builtin_sub_overflow((long long)a, (long long)b, &w);
+            else ovf = __builtin_mul_overflow((long long)a, (long long)b, &w);
+            r = (int64_t)w;
+            if (t != MI355Q_INT64) {  // narrower operands cannot wrap 64 bits (|a|, |b| <= 2^31)
+              ovf = r > ex_int_max(t) || r < ex_int_min(t);
+              r = t == MI355Q_INT8 ? (int64_t)(int8_t)r : t == MI355Q_INT16 ? (int64_t)(int16_t)r : (int64_t)(int32_t)r;
+            }
+            if (ovf) *err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+          }
+        } else if (t == MI355Q_DOUBLE) {
+          const double x = bits_dbl(a), y = bits_dbl(b);
+          if (((n.flags & EXF_LHS_NULLABLE) && x == kNullDouble) || ((n.flags & EXF_RHS_NULLABLE) && y == kNullDouble))
+            r = kNullDoubleBits;
+          else
+            r = dbl_bits(n.op == MI355Q_EX_ADD ? x + y : n.op == MI355Q_EX_SUB ? x - y : x * y);
+        } else {
+          const float x = ex_flt_of(a), y = ex_flt_of(b);
+          if (((n.flags & EXF_LHS_NULLABLE) && x == kNullFloat) || ((n.flags & EXF_RHS_NULLABLE) && y == kNullFloat))
+            r = (int64_t)(uint32_t)kNullFloatBits;
+          else
+            r = ex_flt_pattern(n.op == MI355Q_EX_ADD ? x + y : n.op == MI355Q_EX_SUB ? x - y : x * y);
+        }
+        st[sp - 1] = r;
+      }
+    }
+  }
+  return st[0];
+}
+
+// the value as the dense temporary column stores it (a plain column of the expression's type)
+MQ_HD void store_expr_value(int8_t* col, int type, int64_t pos, int64_t v) {
+  switch (type) {
+    case MI355Q_INT8: *(int8_t*)(col + pos) = (int8_t)v; break;
+    case MI355Q_INT16: *(int16_t*)(col + pos * 2) = (int16_t)v; break;
+    case MI355Q_INT32:
+    case MI355Q_FLOAT: *(int32_t*)(col + pos * 4) = (int32_t)(uint32_t)v; break;
+    default: *(int64_t*)(col + pos * 8) = v;
+  }
+}
+
+}  // namespace mq

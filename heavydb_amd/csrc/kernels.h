@@ -99,6 +99,12 @@ struct PackSpec {
 hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, const int64_t* d_num_rows,
                             int n_frags, int n_cols, int64_t max_frag_rows, int64_t* const* packed_cols,
                             int32_t* d_err, int n_cus, hipStream_t s);
+// projected expressions: d_cols is the pass's extended fragment table [frag][xs.n_cols + xs.n]; the last xs.n
+// pointers of every fragment are the output columns (dense, of each expression's result type).  p = the
+// device plan of the LOWERED plan (quals, join): it decides whether a row's overflow counts.
+hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_expr_mask, const int8_t* const* d_cols,
+                          const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_err, int n_cus,
+                          hipStream_t s);
 // tmp: table of the packed single-key step (rows = packed key + slot_count slots); out: the
 // initialised final table described by p
 hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include "kernels.h"
 #include "rowfunc.h"
+#include "expr.h"
 
 namespace mq {
 
@@ -681,6 +682,53 @@ __global__ __launch_bounds__(kBlock) void k_unpack_perfect(PackSpec ps, DevPlan 
   }
 }
 
+// ---- projected expressions (scan / filter / PROJECT) --------------------------------------
+// Every expression of the plan is evaluated once per row into a dense temporary column of its result type;
+// the step then runs on the lowered plan (plan.cpp lower_exprs), in which those columns are ordinary inputs, so
+// every kernel family applies to group keys / aggregate arguments / quals that are expressions.  `cols` is the
+// EXTENDED fragment table of the pass: [frag][n_cols physical + n expressions], the expression columns being
+// the outputs.  The reference's row function evaluates target and group-by expressions only for rows that
+// passed the quals (and found a match under an INNER join), so an overflow only counts there; an expression
+// used by a qual is evaluated for every row (Executor::compileBody: filters first, then the body).
+__global__ __launch_bounds__(kBlock) void k_project(DevExprSet xs, DevPlan p, uint32_t qual_expr_mask,
+                                                     const int8_t* const* __restrict__ cols,
+                                                     const int64_t* __restrict__ num_rows, int n_frags,
+                                                     int32_t* __restrict__ d_err) {
+  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kBlock;
+  const int nc = xs.n_cols + xs.n;
+  for (int f = 0; f < n_frags; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * nc;
+    const int64_t n = num_rows[f];
+    for (int64_t pos = gtid; pos < n; pos += gsize) {
+      uint32_t err_mask = 0;
+      for (int k = 0; k < xs.n; ++k) {
+        int32_t err = 0;
+        const int64_t v = eval_expr(xs.e[k], fc, pos, &err);
+        store_expr_value(const_cast<int8_t*>(fc[xs.n_cols + k]), xs.e[k].type, pos, v);
+        if (err) err_mask |= 1u << k;
+      }
+      if (err_mask) {  // rare: does the row count?
+        bool counts = (err_mask & qual_expr_mask) != 0;
+        if (!counts) {
+          counts = true;
+          for (int i = 0; i < p.n_quals && counts; ++i) counts = eval_qual(p.quals[i], fc[p.quals[i].col], pos);
+          if (counts && p.join_col >= 0 && p.join_kind != MI355Q_JOIN_LEFT) {
+            int64_t jk[MI355Q_MAX_GROUP_COLS];
+            bool null_key = false;
+            for (int i = 0; i < p.join_n_keys; ++i) {
+              jk[i] = decode_int(fc[p.join_cols[i]], p.join_types[i], pos);
+              null_key = null_key || (p.join_nullables[i] && jk[i] == int_null_of(p.join_types[i]));
+            }
+            counts = !null_key && join_lookup(p, jk).count > 0;
+          }
+        }
+        if (counts) atomicCAS(d_err, 0, MI355Q_ERR_OVERFLOW_OR_UNDERFLOW);
+      }
+    }
+  }
+}
+
 // ---- synthetic columns ------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(void* __restrict__ dst, int64_t n_rows,
                                                       int64_t row_offset, int kind, uint64_t seed,
@@ -980,6 +1028,15 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
   if (n_frags <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_pack_keys, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, ps, d_cols,
                      d_num_rows, n_frags, n_cols, packed_cols, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_expr_mask, const int8_t* const* d_cols,
+                          const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_err, int n_cus,
+                          hipStream_t s) {
+  if (n_frags <= 0 || xs.n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_project, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, xs, p, qual_expr_mask,
+                     d_cols, d_num_rows, n_frags, d_err);
   return hipGetLastError();
 }
 

@@ -104,6 +104,98 @@ int col_type_code(const mi355q_col_desc& c) {
   }
 }
 
+// ---------------------------------------------------------------- projected expressions
+// Type rules of the micro-op programs (what Analyzer::BinOper::normalize_simple_predicate / the analyzer's
+// common-type casts leave for the code generator): both operands of + - * already have the node's type,
+// casts go between any two numeric types, a column node takes the column's logical type.
+int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev) {
+  if (p.n_exprs < 0 || p.n_exprs > MI355Q_MAX_EXPRS || p.n_cols < 0 || p.n_cols + p.n_exprs > MI355Q_MAX_COLS)
+    return MI355Q_ERR_INVALID_PLAN;
+  if (lowered != &p) *lowered = p;
+  DevExprSet local;
+  DevExprSet& ds = dev ? *dev : local;
+  std::memset(&ds, 0, sizeof(ds));
+  ds.n = p.n_exprs;
+  ds.n_cols = p.n_cols;
+  for (int k = 0; k < p.n_exprs; ++k) {
+    const mi355q_expr& x = p.exprs[k];
+    if (x.n_nodes < 1 || x.n_nodes > MI355Q_MAX_EXPR_NODES) return MI355Q_ERR_INVALID_PLAN;
+    DevExpr& d = ds.e[k];
+    d.n_nodes = x.n_nodes;
+    int st_type[4];
+    bool st_null[4];
+    int sp = 0;
+    for (int i = 0; i < x.n_nodes; ++i) {
+      const mi355q_expr_node& n = x.nodes[i];
+      DevExprNode& o = d.nodes[i];
+      o.op = n.op;
+      o.ilit = n.ilit;
+      o.flit = n.flit;
+      switch (n.op) {
+        case MI355Q_EX_COL: {
+          if (n.arg < 0 || n.arg >= p.n_cols || sp >= 4) return MI355Q_ERR_INVALID_PLAN;
+          const int code = col_type_code(p.cols[n.arg]);
+          if (code < 0) return MI355Q_ERR_INVALID_PLAN;
+          o.arg = n.arg;
+          o.type = tc_logical(code);
+          o.ilit = code;
+          o.flags = p.cols[n.arg].nullable ? EXF_NULLABLE : 0;
+          st_type[sp] = o.type;
+          st_null[sp] = p.cols[n.arg].nullable != 0;
+          ++sp;
+          break;
+        }
+        case MI355Q_EX_LIT: {
+          if (!valid_type(n.type) || sp >= 4) return MI355Q_ERR_INVALID_PLAN;
+          if (int_type(n.type) &&
+              (n.ilit > (n.type == MI355Q_INT8 ? INT8_MAX : n.type == MI355Q_INT16 ? INT16_MAX
+                         : n.type == MI355Q_INT32 ? (int64_t)INT32_MAX : INT64_MAX) ||
+               n.ilit < plain_int_null(n.type)))
+            return MI355Q_ERR_INVALID_PLAN;
+          o.type = n.type;
+          o.flags = 0;
+          st_type[sp] = n.type;
+          st_null[sp] = false;
+          ++sp;
+          break;
+        }
+        case MI355Q_EX_CAST: {
+          if (!valid_type(n.type) || sp < 1) return MI355Q_ERR_INVALID_PLAN;
+          o.type = n.type;
+          o.arg = st_type[sp - 1];
+          o.flags = st_null[sp - 1] ? (EXF_NULLABLE | EXF_LHS_NULLABLE) : 0;
+          st_type[sp - 1] = n.type;
+          break;
+        }
+        case MI355Q_EX_ADD:
+        case MI355Q_EX_SUB:
+        case MI355Q_EX_MUL: {
+          if (!valid_type(n.type) || sp < 2) return MI355Q_ERR_INVALID_PLAN;
+          if (st_type[sp - 1] != n.type || st_type[sp - 2] != n.type) return MI355Q_ERR_INVALID_PLAN;
+          o.type = n.type;
+          o.flags = (st_null[sp - 2] ? EXF_LHS_NULLABLE : 0) | (st_null[sp - 1] ? EXF_RHS_NULLABLE : 0);
+          const bool nul = st_null[sp - 2] || st_null[sp - 1];
+          if (nul) o.flags |= EXF_NULLABLE;
+          --sp;
+          st_null[sp - 1] = nul;
+          break;
+        }
+        default:
+          return MI355Q_ERR_UNSUPPORTED;
+      }
+    }
+    if (sp != 1) return MI355Q_ERR_INVALID_PLAN;
+    d.type = st_type[0];
+    d.nullable = st_null[0] ? 1 : 0;
+    const int c = p.n_cols + k;
+    lowered->cols[c] = mi355q_col_desc{d.type, d.nullable, MI355Q_ENC_NONE, 0};
+    lowered->col_ranges[c] = x.range;
+  }
+  lowered->n_cols = p.n_cols + p.n_exprs;
+  lowered->n_exprs = 0;
+  return MI355Q_OK;
+}
+
 int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out) {
   for (int i = 0; i < p.n_targets; ++i) {
     const mi355q_target& t = p.targets[i];
@@ -234,6 +326,14 @@ void keyless_decision(const mi355q_plan& p, const ResolvedTarget* ts, bool* keyl
 int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   std::memset(q, 0, sizeof(*q));
   if (p.abi_version != MI355Q_ABI_VERSION) return MI355Q_ERR_INVALID_PLAN;
+  if (p.n_exprs != 0) {  // the layout of a plan with expressions is the layout of its lowered form
+    mi355q_plan lp;
+    if (int32_t e = lower_exprs(p, &lp, nullptr)) return e;
+    if (lp.join_outer_col >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;  // expressions are not join keys
+    for (int i = 1; i < lp.n_join_cols && i < MI355Q_MAX_GROUP_COLS; ++i)
+      if (lp.join_outer_cols[i] >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
+    return qmd_init(lp, q);
+  }
   if (p.n_cols < 0 || p.n_cols > MI355Q_MAX_COLS || p.n_inner_cols < 0 ||
       p.n_inner_cols > MI355Q_MAX_COLS || p.n_quals < 0 || p.n_quals > MI355Q_MAX_QUALS ||
       p.n_targets < 1 || p.n_targets > MI355Q_MAX_TARGETS || p.n_group_cols < 0 ||
@@ -530,6 +630,11 @@ void layout_from_qmd(const mi355q_qmd& q, DevPlan* d) {
 }
 
 int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
+  if (p.n_exprs != 0) {
+    mi355q_plan lp;
+    if (int32_t e = lower_exprs(p, &lp, nullptr)) return e;
+    return build_dev_plan(lp, q, d);
+  }
   std::memset(d, 0, sizeof(*d));
   const bool grouped = p.n_group_cols >= 1;
   ResolvedTarget ts[MI355Q_MAX_TARGETS];

@@ -26,6 +26,12 @@ int64_t qmd_slot_col_offset(const mi355q_qmd& q, int s);
 int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d);
 // the layout part of a DevPlan (what reduce / iteration / sort need) from a descriptor alone
 void layout_from_qmd(const mi355q_qmd& q, DevPlan* d);
+// Projected expressions (mi355q_expr): validates every program and returns the plan in which expression k
+// is an ordinary described column n_cols + k (its result type / nullability, the caller's range) and
+// n_exprs == 0 — the plan every kernel family and the layout code see after the projection pass
+// (kernels_generic.hip k_project) has written the expression's values into a dense temporary column.
+// `dev` (optional) receives the lowered programs.
+int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev);
 // one initialised row (key quads then slot init values); quad holds row_size / 8 entries
 void row_init_image(const mi355q_qmd& q, int64_t* quad);
 

@@ -78,6 +78,82 @@ class TargetExpr:
 
 
 @dataclass
+class ExprNode:
+    """One micro-op of a projected expression (mi355q_expr_node; postfix order)."""
+    op: int
+    type: int = 0
+    arg: int = 0
+    ilit: int = 0
+    flit: float = 0.0
+
+
+@dataclass
+class Expr:
+    """A projected expression = a virtual outer column (Analyzer::UOper kCAST / BinOper kPLUS, kMINUS,
+    kMULTIPLY over ColumnVar and Constant, as CodeGenerator::codegenCast / codegenArith compile them).
+    Build with the helpers: Expr.col(c), Expr.lit(type, v), e.cast(type), e.add(other) / .sub / .mul."""
+    nodes: List[ExprNode]
+    range: ExpressionRange = field(default_factory=ExpressionRange)
+
+    @staticmethod
+    def col(c: int) -> "Expr":
+        return Expr([ExprNode(capi.EX_COL, 0, c)])
+
+    @staticmethod
+    def lit(type: int, v) -> "Expr":
+        fp = type in (DOUBLE, capi.FLOAT)
+        return Expr([ExprNode(capi.EX_LIT, type, 0, 0 if fp else int(v), float(v) if fp else 0.0)])
+
+    def cast(self, type: int) -> "Expr":
+        return Expr(self.nodes + [ExprNode(capi.EX_CAST, type)])
+
+    def _bin(self, op: int, other: "Expr", type: int) -> "Expr":
+        return Expr(self.nodes + other.nodes + [ExprNode(op, type)])
+
+    def add(self, other: "Expr", type: int) -> "Expr":
+        return self._bin(capi.EX_ADD, other, type)
+
+    def sub(self, other: "Expr", type: int) -> "Expr":
+        return self._bin(capi.EX_SUB, other, type)
+
+    def mul(self, other: "Expr", type: int) -> "Expr":
+        return self._bin(capi.EX_MUL, other, type)
+
+    def with_range(self, r: ExpressionRange) -> "Expr":
+        return Expr(self.nodes, r)
+
+    def result(self, descs: Sequence[InputColDescriptor]) -> Tuple[int, bool]:
+        """(type, nullable) of the value: the typing rules of plan.cpp lower_exprs."""
+        st: List[Tuple[int, bool]] = []
+        for n in self.nodes:
+            if n.op == capi.EX_COL:
+                d = descs[n.arg]
+                lt = d.logical_type or (INT32 if d.encoding == capi.ENC_DICT else
+                                        INT64 if d.encoding == capi.ENC_DATE_IN_DAYS else d.type)
+                st.append((lt, bool(d.nullable)))
+            elif n.op == capi.EX_LIT:
+                st.append((n.type, False))
+            elif n.op == capi.EX_CAST:
+                st[-1] = (n.type, st[-1][1])
+            else:
+                b = st.pop()
+                a = st.pop()
+                st.append((n.type, a[1] or b[1]))
+        assert len(st) == 1
+        return st[0]
+
+    def to_c(self) -> capi.Expr:
+        e = capi.Expr()
+        if len(self.nodes) > capi.MAX_EXPR_NODES:
+            raise ValueError("expression too long")
+        e.n_nodes = len(self.nodes)
+        for i, n in enumerate(self.nodes):
+            e.nodes[i] = capi.ExprNode(n.op, n.type, n.arg, 0, int(n.ilit), float(n.flit))
+        e.range = self.range.to_c()
+        return e
+
+
+@dataclass
 class RelAlgExecutionUnit:
     input_col_descs: List[InputColDescriptor]
     target_exprs: List[TargetExpr]
@@ -93,6 +169,13 @@ class RelAlgExecutionUnit:
     output_columnar_hint: int = 0  # capi.OUTPUT_COLUMNAR: columnar result buffer (g_enable_columnar_output)
     num_tuples: int = 0   # rows of the input tables (0 = unknown / small): COUNT(*)-only group-bys
                           # get 4-byte slots while this is <= UINT32_MAX (pick_target_compact_width)
+    # projected expressions: expression k is the virtual outer column len(input_col_descs) + k
+    exprs: List[Expr] = field(default_factory=list)
+
+    def col_type(self, c: int) -> int:
+        """storage type of outer column c; for a virtual column the expression's result type"""
+        n = len(self.input_col_descs)
+        return self.input_col_descs[c].type if c < n else self.exprs[c - n].result(self.input_col_descs)[0]
 
     def to_plan(self) -> capi.Plan:
         p = capi.Plan()
@@ -111,7 +194,7 @@ class RelAlgExecutionUnit:
             raise ValueError("too many quals")
         p.n_quals = len(self.simple_quals)
         for i, q in enumerate(self.simple_quals):
-            is_fp = self.input_col_descs[q.col].type in (DOUBLE, capi.FLOAT)
+            is_fp = self.col_type(q.col) in (DOUBLE, capi.FLOAT)
             p.quals[i] = capi.Qual(q.col, q.op, 0 if is_fp else int(q.literal),
                                    float(q.literal) if is_fp else 0.0)
         if len(self.groupby_exprs) > capi.MAX_GROUP_COLS:
@@ -125,7 +208,7 @@ class RelAlgExecutionUnit:
         for i, t in enumerate(self.target_exprs):
             ct = capi.Target(t.agg, t.col, t.table, 0)
             if t.cond is not None:
-                is_fp = self.input_col_descs[t.cond.col].type in (DOUBLE, capi.FLOAT)
+                is_fp = self.col_type(t.cond.col) in (DOUBLE, capi.FLOAT)
                 ct.cond = capi.Qual(t.cond.col, t.cond.op, 0 if is_fp else int(t.cond.literal),
                                     float(t.cond.literal) if is_fp else 0.0)
             p.targets[i] = ct
@@ -142,6 +225,11 @@ class RelAlgExecutionUnit:
         p.bigint_count = int(self.bigint_count)
         p.output_columnar_hint = int(self.output_columnar_hint)
         p.num_tuples = int(self.num_tuples)
+        if len(self.exprs) > capi.MAX_EXPRS or len(self.exprs) + len(self.input_col_descs) > capi.MAX_COLS:
+            raise ValueError("too many expressions")
+        p.n_exprs = len(self.exprs)
+        for i, e in enumerate(self.exprs):
+            p.exprs[i] = e.to_c()
         return p
 
 

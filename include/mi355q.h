@@ -44,13 +44,15 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 2
+#define MI355Q_ABI_VERSION 3
 
 #define MI355Q_MAX_COLS 16
 #define MI355Q_MAX_QUALS 4
 #define MI355Q_MAX_TARGETS 8
 #define MI355Q_MAX_SLOTS 16
 #define MI355Q_MAX_GROUP_COLS 4
+#define MI355Q_MAX_EXPRS 4
+#define MI355Q_MAX_EXPR_NODES 8
 
 /* ---- error codes: numeric values of heavyai::ErrorCode (enums.h:30-51) ---- */
 #define MI355Q_OK 0
@@ -193,6 +195,54 @@ typedef struct mi355q_range {
 
 typedef struct mi355q_join_table mi355q_join_table; /* opaque */
 
+/* ---- projected expressions ("scan/filter/PROJECT"): a fixed parametric micro-op set, no JIT ----
+ * What the reference compiles per query with CodeGenerator::codegen(expr) — casts (CastIR.cpp:21-57
+ * codegenCast, :424-495 codegenCastBetweenIntTypes, :555-594 codegenCastToFp, :596-653 codegenCastFromFp),
+ * + - * (ArithmeticIR.cpp:39 codegenArith, :187-262 codegenAdd, :264-340 codegenSub, :359-429 codegenMul,
+ * :861-909 codegenBinOpWithOverflowForCPU) over columns and literals — is described here as a short POSTFIX
+ * program per expression.  An expression is a VIRTUAL outer column: expression k is column index
+ * n_cols + k wherever the plan takes an outer column (group_cols, targets[].col with table 0, quals[].col,
+ * targets[].cond.col); n_cols + n_exprs <= MI355Q_MAX_COLS.  Expressions cannot be join keys.
+ * Values carry SQL NULL in band, as the reference's do: the inline sentinel of the node's type
+ * (Shared/InlineNullValues.h).  Integer + - * and narrowing casts are overflow-checked at the width of
+ * the node's type; a row that passes every qual (and finds a match under an INNER join) and overflows
+ * ends the step with MI355Q_ERR_OVERFLOW_OR_UNDERFLOW (ErrorCode 7), as the reference's row function
+ * does; an expression inside a qual is evaluated for every row. */
+typedef enum mi355q_expr_op {
+  MI355Q_EX_COL = 1,   /* push outer column `arg` (decoded): type = the column's logical type,
+                          nullable = the column's */
+  MI355Q_EX_LIT = 2,   /* push a literal of `type`: ilit (integers) / flit (DOUBLE, FLOAT); never NULL */
+  MI355Q_EX_CAST = 3,  /* cast the top of the stack to `type`.  integer -> wider integer: NULL to NULL
+                          (cast_<from>_to_<to>_nullable, RuntimeFunctions.cpp:262-300); -> narrower
+                          integer: error 7 when v > max(to) or v <= min(to)
+                          (codegenCastBetweenIntTypesOverflowChecks, CastIR.cpp:497-553; NULL passes);
+                          integer -> DOUBLE / FLOAT: sitofp; DOUBLE <-> FLOAT: fpext / fptrunc;
+                          DOUBLE / FLOAT -> integer: round half away from zero, then truncate
+                          (DEF_ROUND_NULLABLE, RuntimeFunctions.cpp:283-293) */
+  MI355Q_EX_ADD = 4,   /* pop rhs, pop lhs, push lhs + rhs; both operands have the node's `type`
+                          (the analyzer has normalised them); NULL if either operand is NULL */
+  MI355Q_EX_SUB = 5,
+  MI355Q_EX_MUL = 6
+} mi355q_expr_op;
+
+typedef struct mi355q_expr_node {
+  int32_t op;   /* mi355q_expr_op */
+  int32_t type; /* mi355q_type of the node's result (ignored for MI355Q_EX_COL) */
+  int32_t arg;  /* MI355Q_EX_COL: outer column index (a physical column, < n_cols) */
+  int32_t reserved;
+  int64_t ilit;
+  double flit;
+} mi355q_expr_node;
+
+typedef struct mi355q_expr {
+  int32_t n_nodes; /* 1..MI355Q_MAX_EXPR_NODES, postfix; the stack never exceeds 4 values and ends at 1 */
+  int32_t reserved;
+  mi355q_expr_node nodes[MI355Q_MAX_EXPR_NODES];
+  mi355q_range range; /* getExpressionRange of the whole expression (ExpressionRange.cpp: casts keep the
+                         operand's range, + - * combine the operands' bounds): drives the perfect-hash /
+                         keyless decisions exactly like a column's range */
+} mi355q_expr;
+
 /* The subset of RelAlgExecutionUnit (RelAlgExecutionUnit.h:167-218) + the
  * expression ranges the planner derives from fragment metadata. */
 typedef struct mi355q_plan {
@@ -248,6 +298,10 @@ typedef struct mi355q_plan {
                                             <= UINT32_MAX and bigint_count is off
                                             (pick_target_compact_width,
                                             QueryMemoryDescriptor.cpp:748-840) */
+  /* projected expressions: virtual outer columns n_cols .. n_cols + n_exprs - 1 (see mi355q_expr) */
+  int32_t n_exprs;
+  int32_t reserved3;
+  mi355q_expr exprs[MI355Q_MAX_EXPRS];
 } mi355q_plan;
 
 /* plan.output_columnar_hint */

@@ -1144,8 +1144,193 @@ Matches join_lookup(const OrcJoin& j, const int64_t* keys) {
 }
 
 // ---------------------------------------------------------------- row function
+
+// ================================================================ projected expressions
+// A CPU restatement of what the reference's code generator emits for the expression shapes of the plan ABI
+// (mi355q_expr: casts and + - * over columns and literals); the product evaluates them in a projection pass
+// (heavydb_amd/csrc/expr.h), this file per row inside the row function, as the reference does.
+//   typing       the analyzer has already given both operands of a BinOper one type (ArithmeticIR.cpp:61
+//                CHECK_EQ(lhs_type.get_type(), rhs_type.get_type())); a ColumnVar has the column's SQL type
+//   casts        CodeGenerator::codegenCast (CastIR.cpp:71-135): integer operands go to
+//                codegenCastBetweenIntTypes (:424-495) or codegenCastToFp (:555-594), floating-point ones to
+//                codegenCastFromFp (:596-653); nullable operands call cast_<from>_to_<to>_nullable
+//                (RuntimeFunctions.cpp:262-268), fp -> integer the rounding form (:283-293); a NARROWING
+//                integer cast is preceded by codegenCastBetweenIntTypesOverflowChecks (:497-553):
+//                over = v > max(to), under = v <= min(to) (sic), a NULL operand is exempt
+//   + - *        CodeGenerator::codegenArith (ArithmeticIR.cpp:39-75).  Integers, CPU device:
+//                codegenBinOpWithOverflowForCPU (:861-909) = llvm.s{add,sub,mul}.with.overflow at the operand
+//                type's width, error ErrorCode::OVERFLOW_OR_UNDERFLOW (enums.h) on overflow; with a nullable
+//                operand codegenSkipOverflowCheckForNull jumps past the check and the result is the type's
+//                NULL.  Floating point: plain fadd / fsub / fmul, or add_/sub_/mul_<type>_nullable[_lhs|_rhs]
+//                (RuntimeFunctions.cpp:46-71) — NULL if a nullable operand equals the NULL value.
+//   where        target and group-by expressions are emitted inside the filter's true branch (after the join
+//                loop found a match); an expression inside a qual runs for every row.
+struct OrcVal {
+  int type;      // mi355q_type
+  bool nullable; // get_notnull() == false
+  int64_t i;     // integers (sign-extended)
+  double d;      // DOUBLE
+  float f;       // FLOAT
+};
+
+inline int64_t int_max_of_type(int t) {
+  switch (t) {
+    case MI355Q_INT8: return INT8_MAX;
+    case MI355Q_INT16: return INT16_MAX;
+    case MI355Q_INT32: return INT32_MAX;
+    default: return INT64_MAX;
+  }
+}
+inline bool is_int_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_INT64; }
+inline int int_bytes(int t) { return t == MI355Q_INT8 ? 1 : t == MI355Q_INT16 ? 2 : t == MI355Q_INT32 ? 4 : 8; }
+inline bool val_is_null(const OrcVal& v) {
+  if (!v.nullable) return false;
+  if (v.type == MI355Q_DOUBLE) return v.d == kNullDouble;
+  if (v.type == MI355Q_FLOAT) return v.f == kNullFloat;
+  return v.i == int_null_of(v.type);
+}
+inline OrcVal null_of(int type) {
+  OrcVal r{type, true, 0, 0.0, 0.0f};
+  if (type == MI355Q_DOUBLE) r.d = kNullDouble;
+  else if (type == MI355Q_FLOAT) r.f = kNullFloat;
+  else r.i = int_null_of(type);
+  return r;
+}
+
+// codegenCast for one value; returns 0 or ErrorCode 7
+inline int32_t cast_value(const OrcVal& v, int to, OrcVal* out) {
+  OrcVal r{to, v.nullable, 0, 0.0, 0.0f};
+  if (is_int_type(v.type)) {
+    if (is_int_type(to)) {
+      if (int_bytes(to) < int_bytes(v.type) && !val_is_null(v)) {  // narrowing: the overflow checks
+        if (v.i > int_max_of_type(to) || v.i <= int_null_of(to)) return MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+      }
+      r.i = val_is_null(v) ? int_null_of(to) : v.i;  // cast_<from>_to_<to>_nullable / sext / trunc
+    } else if (to == MI355Q_DOUBLE) {
+      r.d = val_is_null(v) ? kNullDouble : (double)v.i;  // sitofp
+    } else {
+      r.f = val_is_null(v) ? kNullFloat : (float)v.i;
+    }
+  } else if (v.type == MI355Q_DOUBLE) {
+    if (to == MI355Q_DOUBLE) r.d = v.d;
+    else if (to == MI355Q_FLOAT) r.f = val_is_null(v) ? kNullFloat : (float)v.d;  // fptrunc
+    else r.i = val_is_null(v) ? int_null_of(to) : (int64_t)(v.d + (v.d < 0.0 ? -0.5 : 0.5));
+  } else {
+    if (to == MI355Q_FLOAT) r.f = v.f;
+    else if (to == MI355Q_DOUBLE) r.d = val_is_null(v) ? kNullDouble : (double)v.f;  // fpext
+    else r.i = val_is_null(v) ? int_null_of(to) : (int64_t)(v.f + (v.f < 0.0f ? -0.5f : 0.5f));
+  }
+  *out = r;
+  return 0;
+}
+
+// codegenArith for one pair of values of type `t`
+inline int32_t arith_value(int op, int t, const OrcVal& a, const OrcVal& b, OrcVal* out) {
+  OrcVal r{t, a.nullable || b.nullable, 0, 0.0, 0.0f};
+  if (val_is_null(a) || val_is_null(b)) {
+    *out = null_of(t);
+    out->nullable = r.nullable;
+    return 0;
+  }
+  if (is_int_type(t)) {
+    __int128 w = op == MI355Q_EX_ADD ? (__int128)a.i + b.i : op == MI355Q_EX_SUB ? (__int128)a.i - b.i : (__int128)a.i * b.i;
+    if (w > (__int128)int_max_of_type(t) || w < (__int128)int_null_of(t)) return MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+    r.i = (int64_t)w;
+  } else if (t == MI355Q_DOUBLE) {
+    r.d = op == MI355Q_EX_ADD ? a.d + b.d : op == MI355Q_EX_SUB ? a.d - b.d : a.d * b.d;
+  } else {
+    r.f = op == MI355Q_EX_ADD ? a.f + b.f : op == MI355Q_EX_SUB ? a.f - b.f : a.f * b.f;
+  }
+  *out = r;
+  return 0;
+}
+
+// one expression on one row; `p` is the plan as the caller stated it (physical columns only)
+inline int32_t eval_expression(const mi355q_plan& p, const mi355q_expr& x, const int8_t* const* cols, int64_t pos,
+                               OrcVal* out) {
+  OrcVal st[MI355Q_MAX_EXPR_NODES];
+  int sp = 0;
+  for (int i = 0; i < x.n_nodes; ++i) {
+    const mi355q_expr_node& n = x.nodes[i];
+    switch (n.op) {
+      case MI355Q_EX_COL: {
+        const mi355q_col_desc& cd = p.cols[n.arg];
+        OrcVal v{logical_type_of(cd), cd.nullable != 0, 0, 0.0, 0.0f};
+        if (type_is_f32(cd.type)) v.f = decode_flt(cols[n.arg], pos);
+        else if (type_is_fp(cd.type)) v.d = decode_dbl(cols[n.arg], pos);
+        else v.i = decode_col(cd, cols[n.arg], pos);
+        st[sp++] = v;
+        break;
+      }
+      case MI355Q_EX_LIT: {
+        OrcVal v{n.type, false, 0, 0.0, 0.0f};
+        if (n.type == MI355Q_DOUBLE) v.d = n.flit;
+        else if (n.type == MI355Q_FLOAT) v.f = (float)n.flit;
+        else v.i = n.ilit;
+        st[sp++] = v;
+        break;
+      }
+      case MI355Q_EX_CAST:
+        if (int32_t e = cast_value(st[sp - 1], n.type, &st[sp - 1])) return e;
+        break;
+      default: {
+        const OrcVal b = st[--sp];
+        if (int32_t e = arith_value(n.op, n.type, st[sp - 1], b, &st[sp - 1])) return e;
+      }
+    }
+  }
+  *out = st[0];
+  return 0;
+}
+
+// The plan with every expression described as the column n_cols + k (type / nullability from the rules
+// above, range as stated by the caller), which is what the layout decisions and the row function read.
+inline int lower_plan(const mi355q_plan& p, mi355q_plan* out) {
+  *out = p;
+  if (p.n_exprs == 0) return 0;
+  if (p.n_exprs < 0 || p.n_exprs > MI355Q_MAX_EXPRS || p.n_cols + p.n_exprs > MI355Q_MAX_COLS) return MI355Q_ERR_INVALID_PLAN;
+  for (int k = 0; k < p.n_exprs; ++k) {
+    const mi355q_expr& x = p.exprs[k];
+    if (x.n_nodes < 1 || x.n_nodes > MI355Q_MAX_EXPR_NODES) return MI355Q_ERR_INVALID_PLAN;
+    int ty[MI355Q_MAX_EXPR_NODES];
+    bool nu[MI355Q_MAX_EXPR_NODES];
+    int sp = 0;
+    for (int i = 0; i < x.n_nodes; ++i) {
+      const mi355q_expr_node& n = x.nodes[i];
+      if (n.op == MI355Q_EX_COL) {
+        if (n.arg < 0 || n.arg >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
+        ty[sp] = logical_type_of(p.cols[n.arg]);
+        nu[sp] = p.cols[n.arg].nullable != 0;
+        ++sp;
+      } else if (n.op == MI355Q_EX_LIT) {
+        ty[sp] = n.type;
+        nu[sp] = false;
+        ++sp;
+      } else if (n.op == MI355Q_EX_CAST) {
+        if (sp < 1) return MI355Q_ERR_INVALID_PLAN;
+        ty[sp - 1] = n.type;
+      } else if (n.op == MI355Q_EX_ADD || n.op == MI355Q_EX_SUB || n.op == MI355Q_EX_MUL) {
+        if (sp < 2 || ty[sp - 1] != n.type || ty[sp - 2] != n.type) return MI355Q_ERR_INVALID_PLAN;
+        nu[sp - 2] = nu[sp - 2] || nu[sp - 1];
+        --sp;
+      } else {
+        return MI355Q_ERR_UNSUPPORTED;
+      }
+      if (sp > 4) return MI355Q_ERR_INVALID_PLAN;
+    }
+    if (sp != 1) return MI355Q_ERR_INVALID_PLAN;
+    out->cols[p.n_cols + k] = mi355q_col_desc{ty[0], nu[0] ? 1 : 0, MI355Q_ENC_NONE, 0};
+    out->col_ranges[p.n_cols + k] = x.range;
+  }
+  out->n_cols = p.n_cols + p.n_exprs;
+  out->n_exprs = 0;
+  return 0;
+}
+
 struct ExecCtx {
-  const mi355q_plan* plan;
+  const mi355q_plan* plan;   // the LOWERED plan when the caller's has expressions (storage: `lowered`)
+  const mi355q_plan* stated = nullptr;  // the caller's plan (expression programs, physical columns)
+  mi355q_plan lowered;
   mi355q_qmd qmd;
   std::vector<TargetDesc> ts;
   const OrcJoin* join;
@@ -1354,7 +1539,33 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
   const int kq = q.key_bytes / 8;
   const bool grouped = q.desc_type != MI355Q_NON_GROUPED_AGGREGATE;
   const int ng = q.group_col_count;
+  // projected expressions: each row's values live in one 8-byte cell per expression, and the column table
+  // the rest of the row function reads is extended by pointers biased so that "column[pos]" is that cell
+  const mi355q_plan& sp = *c.stated;
+  const int nx = sp.n_exprs, np = sp.n_cols;
+  const int8_t* cx[MI355Q_MAX_COLS];
+  int64_t vcell[MI355Q_MAX_EXPRS] = {0, 0, 0, 0};
+  uint32_t qual_exprs = 0;
+  if (nx) {
+    for (int i = 0; i < np; ++i) cx[i] = cols[i];
+    cols = cx;
+    for (int i = 0; i < p.n_quals; ++i)
+      if (p.quals[i].col >= np) qual_exprs |= 1u << (p.quals[i].col - np);
+  }
+  auto eval_into_cell = [&](int k, int64_t pos) -> int32_t {
+    OrcVal v;
+    if (int32_t e = eval_expression(sp, sp.exprs[k], cx, pos, &v)) return e;
+    const int w = type_width(v.type);
+    if (v.type == MI355Q_DOUBLE) vcell[k] = dbl_bits(v.d);
+    else if (v.type == MI355Q_FLOAT) vcell[k] = (int64_t)(uint32_t)flt_bits(v.f);
+    else vcell[k] = v.i;
+    cx[np + k] = reinterpret_cast<const int8_t*>(reinterpret_cast<uintptr_t>(&vcell[k]) - (uintptr_t)pos * (uintptr_t)w);
+    return 0;
+  };
   for (int64_t pos = 0; pos < num_rows; ++pos) {
+    for (int k = 0; k < nx; ++k)  // expressions inside quals: every row
+      if (qual_exprs & (1u << k))
+        if (int32_t e = eval_into_cell(k, pos)) return e;
     bool pass = true;
     for (int i = 0; i < p.n_quals && pass; ++i) pass = eval_qual(p, p.quals[i], cols, pos);
     if (!pass) continue;
@@ -1378,6 +1589,9 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
         jm.count = 1;
       }
     }
+    for (int k = 0; k < nx; ++k)  // group-by and target expressions: rows that reach the body
+      if (!(qual_exprs & (1u << k)))
+        if (int32_t e = eval_into_cell(k, pos)) return e;
     int64_t* slots;
     int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};  // group_by_expr_cache_: values as decoded
     // columnar output: the entry ("bin") comes from the *_columnar runtime functions and the
@@ -1707,7 +1921,25 @@ ORC_EXPORT uint32_t orc_murmur1(const void* key, int len, uint32_t seed) {
 }
 
 ORC_EXPORT int32_t orc_qmd_init(const mi355q_plan* plan, mi355q_qmd* out) {
-  return qmd_init(*plan, *out);
+  mi355q_plan lp;
+  if (int e = lower_plan(*plan, &lp)) return e;
+  return qmd_init(lp, *out);
+}
+
+// one projected expression on one row (golden vectors of the cast / arithmetic semantics): the value as a
+// 64-bit pattern (integers sign-extended, DOUBLE bits, FLOAT bits in the low word), its type and NULL flag;
+// returns 0 or ErrorCode 7
+ORC_EXPORT int32_t orc_eval_expr(const mi355q_plan* plan, int32_t k, const void* const* cols, int64_t pos,
+                                 int64_t* out_bits, int32_t* out_type, int32_t* out_is_null) {
+  if (k < 0 || k >= plan->n_exprs) return MI355Q_ERR_INVALID_PLAN;
+  mi355q_plan lp;
+  if (int e = lower_plan(*plan, &lp)) return e;
+  OrcVal v;
+  if (int32_t e = eval_expression(*plan, plan->exprs[k], reinterpret_cast<const int8_t* const*>(cols), pos, &v)) return e;
+  *out_bits = v.type == MI355Q_DOUBLE ? dbl_bits(v.d) : v.type == MI355Q_FLOAT ? (int64_t)(uint32_t)flt_bits(v.f) : v.i;
+  *out_type = v.type;
+  *out_is_null = val_is_null(v) ? 1 : 0;
+  return 0;
 }
 
 ORC_EXPORT void orc_init_buffer(const mi355q_qmd* q, int64_t* buf) { init_buffer(*q, buf); }
@@ -1962,9 +2194,11 @@ ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                                const void* join, int32_t n_threads, int64_t* out_buf,
                                mi355q_qmd* out_qmd) {
   ExecCtx c;
-  c.plan = plan;
-  if (int e = qmd_init(*plan, c.qmd)) return e;
-  if (int e = build_targets(*plan, plan->n_group_cols > 0, c.ts)) return e;
+  c.stated = plan;
+  if (int e = lower_plan(*plan, &c.lowered)) return e;
+  c.plan = &c.lowered;
+  if (int e = qmd_init(c.lowered, c.qmd)) return e;
+  if (int e = build_targets(c.lowered, plan->n_group_cols > 0, c.ts)) return e;
   for (int i = 0; i < plan->n_targets; ++i) c.ts[i].slot = c.qmd.target_slot[i];
   c.join = static_cast<const OrcJoin*>(join);
   c.inner_cols = reinterpret_cast<const int8_t* const*>(in->inner_col_buffers);
@@ -2234,9 +2468,11 @@ ORC_EXPORT int32_t orc_execute_streamed(const mi355q_plan* plan, const orc_gen_s
                                         int32_t n_threads, int32_t reduce_threads, int64_t* out_buf,
                                         mi355q_qmd* out_qmd, double* timing) {
   ExecCtx c;
-  c.plan = plan;
-  if (int e = qmd_init(*plan, c.qmd)) return e;
-  if (int e = build_targets(*plan, plan->n_group_cols > 0, c.ts)) return e;
+  c.stated = plan;
+  if (int e = lower_plan(*plan, &c.lowered)) return e;
+  c.plan = &c.lowered;
+  if (int e = qmd_init(c.lowered, c.qmd)) return e;
+  if (int e = build_targets(c.lowered, plan->n_group_cols > 0, c.ts)) return e;
   for (int i = 0; i < plan->n_targets; ++i) c.ts[i].slot = c.qmd.target_slot[i];
   c.join = static_cast<const OrcJoin*>(join);
   c.inner_cols = reinterpret_cast<const int8_t* const*>(inner_cols);

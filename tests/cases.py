@@ -16,7 +16,7 @@ import numpy as np
 from heavydb_amd import capi
 from heavydb_amd.capi import (COUNT_IF, SUM_IF, AVG, COUNT, DOUBLE, EQ, GE, GT, INT8, INT16, INT32, INT64, LE, LT,
                               MAX, MIN, NE, PROJECT_KEY, SUM)
-from heavydb_amd.executor import (ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
+from heavydb_amd.executor import (Expr, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit,
                                   TargetExpr)
 
 NP = {INT8: np.int8, INT16: np.int16, INT32: np.int32, INT64: np.int64, DOUBLE: np.float64, capi.FLOAT: np.float32}
@@ -54,6 +54,58 @@ def col_range(arrs: List[np.ndarray], t: int, nullable: bool) -> ExpressionRange
     if t in (DOUBLE, capi.FLOAT):
         return ExpressionRange(True, 0, 0, has_nulls, float(a.min()), float(a.max()))
     return ExpressionRange(True, int(a.min()), int(a.max()), has_nulls)
+
+
+def expr_values(e: Expr, descs, cols):
+    """The expression over whole columns with numpy (test infrastructure: ranges of the virtual columns, the
+    way getExpressionRange would bound them, and SQLite's input): returns (values, null mask, type).  Integer
+    arithmetic is done in Python ints so that an overflow of the node's type is visible (-> None entries)."""
+    st = []
+    for nd in e.nodes:
+        if nd.op == capi.EX_COL:
+            d = descs[nd.arg]
+            a = np.asarray(cols[nd.arg])
+            if d.type in (DOUBLE, capi.FLOAT):
+                null = (a == NP[d.type](NULLS[d.type])) if d.nullable else np.zeros(len(a), bool)
+                st.append((a.astype(np.float64) if d.type == DOUBLE else a.astype(np.float32), null, d.type))
+            else:
+                null = (a == NULLS[d.type]) if d.nullable else np.zeros(len(a), bool)
+                st.append((a.astype(object), null, d.type))
+        elif nd.op == capi.EX_LIT:
+            n = len(st[0][0]) if st else 1
+            v = nd.flit if nd.type in (DOUBLE, capi.FLOAT) else nd.ilit
+            arr = np.full(n, v, dtype=np.float64 if nd.type == DOUBLE else np.float32 if nd.type == capi.FLOAT else object)
+            st.append((arr, np.zeros(n, bool), nd.type))
+        elif nd.op == capi.EX_CAST:
+            v, null, t = st.pop()
+            if nd.type in (DOUBLE, capi.FLOAT):
+                r = np.array([float(x) for x in v], dtype=np.float64 if nd.type == DOUBLE else np.float32)
+            elif t in (DOUBLE, capi.FLOAT):
+                r = np.array([int(x + (-0.5 if x < 0 else 0.5)) if np.isfinite(x) else 0 for x in v], dtype=object)
+            else:
+                r = v
+            st.append((r, null, nd.type))
+        else:
+            (b, bn, _), (a, an, _) = st.pop(), st.pop()
+            r = a + b if nd.op == capi.EX_ADD else a - b if nd.op == capi.EX_SUB else a * b
+            st.append((r, an | bn, nd.type))
+    return st[0]
+
+
+def expr_range(e: Expr, descs, frags) -> ExpressionRange:
+    cols = [np.concatenate([f[c] for f in frags]) for c in range(len(descs))] if frags else []
+    if not frags or len(cols[0]) == 0:
+        return ExpressionRange(True, 0, -1)
+    v, null, t = expr_values(e, descs, cols)
+    ok = v[~null]
+    if len(ok) == 0:
+        return ExpressionRange(True, 0, -1, bool(null.any()))
+    if t in (DOUBLE, capi.FLOAT):
+        return ExpressionRange(True, 0, 0, bool(null.any()), float(ok.min()), float(ok.max()))
+    lo, hi = int(min(ok)), int(max(ok))
+    # an expression whose exact range leaves its type overflows at run time; the declared range stays inside
+    tmin, tmax = NULLS[t], -NULLS[t] - 1
+    return ExpressionRange(True, max(lo, tmin), min(hi, tmax), bool(null.any()))
 
 
 def split(arr: np.ndarray, sizes: List[int]) -> List[np.ndarray]:
@@ -563,6 +615,78 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("join_composite_key64_1to1_count",
                       RelAlgExecutionUnit(qfd, [TargetExpr(COUNT)], inner_col_descs=q_descs, join_outer_col=[0, 1]),
                       qff, [qa, qb, qw], [qa, qb], [INT64, INT64], ExpressionRange(), False))
+    # ---- projected expressions (SURVEY north_star "scan/filter/PROJECT"): the shapes of the
+    # reference's own synthetic benchmark — GROUP BY cast(x as double) (Benchmarks/synthetic_benchmark/queries/
+    # BaselineHash/BH001.sql), max(x10 + 1) / sum(x10 + 1) next to plain columns (MultiStep/MSBS001.sql, grouped by
+    # cast(x1k as float)) — and casts / + - * in aggregate arguments and quals, incl. the overflow error
+    def xra(exprs, targets, quals=(), group=(), guess=16384, src=(descs, frags)):
+        d, fr = src
+        xs = [e.with_range(expr_range(e, d, fr)) for e in exprs]
+        return RelAlgExecutionUnit(list(d), list(targets), list(quals), list(group), max_groups_buffer_entry_guess=guess,
+                                   exprs=xs)
+    NC = len(descs)
+    C = Expr.col
+    cases.append(Case("expr_group_cast_i32_double",     # BH001: group by cast(x as double) -> baseline layout
+                      xra([C(10).cast(DOUBLE)], [TargetExpr(PROJECT_KEY), TargetExpr(COUNT, 7), TargetExpr(SUM, 7),
+                                                 TargetExpr(MAX, 7), TargetExpr(MIN, 7), TargetExpr(AVG, 7)],
+                          group=[NC], guess=256), frags))
+    cases.append(Case("expr_group_cast_float_multistep",  # MSBS001, first step
+                      xra([C(10).cast(capi.FLOAT), C(7).add(Expr.lit(INT32, 1), INT32)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(MAX, 7), TargetExpr(MAX, 5),
+                           TargetExpr(MAX, NC + 1), TargetExpr(SUM, 7), TargetExpr(SUM, NC + 1)], group=[NC], guess=256),
+                      frags))
+    cases.append(Case("expr_arg_cast_mul_perfect",
+                      xra([C(5).cast(INT64).mul(C(2), INT64)], [TargetExpr(PROJECT_KEY), TargetExpr(SUM, NC),
+                                                               TargetExpr(MIN, NC), TargetExpr(COUNT)], group=[1]), frags))
+    cases.append(Case("expr_qual_on_nullable_sum",
+                      xra([C(7).add(C(10), INT32)], [TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(COUNT, NC)],
+                          [Qual(NC, LT, 100000)]), frags))
+    cases.append(Case("expr_double_arith_nongrouped",
+                      xra([C(3).mul(Expr.lit(DOUBLE, 2.5), DOUBLE).sub(C(9), DOUBLE)],
+                          [TargetExpr(SUM, NC), TargetExpr(MIN, NC), TargetExpr(COUNT, NC), TargetExpr(AVG, NC)],
+                          [Qual(0, LT, 2**30)]), frags))
+    cases.append(Case("expr_group_cast_double_to_int",   # rounding cast as a perfect-hash key
+                      xra([C(3).cast(INT32)], [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(MAX, 3)],
+                          group=[NC]), frags))
+    cases.append(Case("expr_baseline_key_plus_literal",
+                      xra([C(4).add(Expr.lit(INT64, 5), INT64)], [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 3)],
+                          group=[NC], guess=8192), frags))
+    cases.append(Case("expr_narrowing_cast_and_widening",
+                      xra([C(1).cast(INT8), C(6).cast(INT64).mul(Expr.lit(INT64, 1000), INT64)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(SUM, NC + 1), TargetExpr(COUNT, NC + 1)], group=[NC]), frags))
+    cases.append(Case("expr_overflow_is_an_error",       # int32 + 2^30 overflows for half of the rows
+                      xra([C(0).add(Expr.lit(INT32, 2**30), INT32)], [TargetExpr(MAX, NC), TargetExpr(COUNT)]), frags,
+                      expect_error=capi.ERR_OVERFLOW_OR_UNDERFLOW))
+    cases.append(Case("expr_overflow_only_in_filtered_rows",  # ... but not among the rows that pass the qual
+                      xra([C(0).add(Expr.lit(INT32, 2**30), INT32)], [TargetExpr(MAX, NC), TargetExpr(COUNT)],
+                          [Qual(0, LT, 2**30)]), frags))
+    cases.append(Case("expr_overflow_in_a_qual_counts_for_every_row",
+                      xra([C(0).add(Expr.lit(INT32, 2**30), INT32)], [TargetExpr(COUNT)],
+                          [Qual(0, LT, 2**30), Qual(NC, GT, 0)]), frags, expect_error=capi.ERR_OVERFLOW_OR_UNDERFLOW))
+    jx = [Expr.col(1).add(Expr.lit(INT64, 2**63 - 10**6), INT64)]   # overflows for positive values of column 1
+    jxr = [e.with_range(expr_range(e, fdescs, ffrags)) for e in jx]
+    cases.append(Case("expr_join_overflow_only_in_filtered_rows",  # rows with col1 > 0 are dropped by the qual
+                      RelAlgExecutionUnit(list(fdescs), [TargetExpr(MAX, len(fdescs)), TargetExpr(COUNT), TargetExpr(SUM, 1, 1)],
+                                          [Qual(1, LE, 0)], [], inner_col_descs=list(inner_descs), join_outer_col=0, exprs=jxr),
+                      ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, False))
+    # key + (INT64_MAX - (m - 1)) overflows exactly for the keys >= m, which find no inner row: an INNER join drops
+    # those rows before the target is evaluated (no error); under a LEFT join they survive and the step fails
+    jx3 = [Expr.col(0).add(Expr.lit(INT64, 2**63 - 1 - (m - 1)), INT64)]
+    jx3r = [e.with_range(expr_range(e, fdescs, ffrags)) for e in jx3]
+    for kind, tag, err in [(capi.JOIN_INNER, "inner", None), (capi.JOIN_LEFT, "left", capi.ERR_OVERFLOW_OR_UNDERFLOW)]:
+        cases.append(Case(f"expr_join_overflow_only_in_unmatched_rows_{tag}",
+                          RelAlgExecutionUnit(list(fdescs), [TargetExpr(MAX, len(fdescs)), TargetExpr(COUNT), TargetExpr(SUM, 1, 1)],
+                                              [], [], inner_col_descs=list(inner_descs), join_outer_col=0, join_kind=kind,
+                                              exprs=jx3r),
+                          ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, False, expect_error=err))
+    jx2 = [Expr.col(1).mul(Expr.lit(INT64, 3), INT64).sub(Expr.col(3), INT64)]
+    jx2r = [e.with_range(expr_range(e, fdescs, ffrags)) for e in jx2]
+    cases.append(Case("expr_join_groupby_expression_target",
+                      RelAlgExecutionUnit(list(fdescs), [TargetExpr(PROJECT_KEY), TargetExpr(SUM, len(fdescs)), TargetExpr(SUM, 1, 1),
+                                                         TargetExpr(COUNT)], [], [3], inner_col_descs=list(inner_descs),
+                                          join_outer_col=0, exprs=jx2r),
+                      ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, False))
+
     # ---- edge cases of the wider shapes: empty inputs, empty / all-NULL inner tables
     cases.append(Case("multi_col_empty_input", ra([K0, K1, TargetExpr(COUNT), TargetExpr(SUM, 2)], group=[4, 1],
                                                   guess=4096), empty))

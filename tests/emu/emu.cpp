@@ -9,6 +9,7 @@
 
 #include "../../heavydb_amd/csrc/plan.h"
 #include "../../heavydb_amd/csrc/rowfunc.h"
+#include "../../heavydb_amd/csrc/expr.h"
 
 using namespace mq;
 
@@ -42,10 +43,105 @@ extern "C" void emu_init_buffer(const mi355q_qmd* q, int64_t* buf) {
   }
 }
 
+// the product's evaluator (heavydb_amd/csrc/expr.h) on one row: value pattern, result type; 0 or ErrorCode 7
+extern "C" int32_t emu_eval_expr(const mi355q_plan* plan, int32_t k, const void* const* cols, int64_t pos,
+                                 int64_t* out_bits, int32_t* out_type) {
+  mi355q_plan lp;
+  DevExprSet xs;
+  if (int32_t e = lower_exprs(*plan, &lp, &xs)) return e;
+  if (k < 0 || k >= xs.n) return MI355Q_ERR_INVALID_PLAN;
+  int32_t err = 0;
+  *out_bits = eval_expr(xs.e[k], (const int8_t* const*)cols, pos, &err);
+  *out_type = xs.e[k].type;
+  return err;
+}
+
+static void emu_attach_join(const mi355q_plan* plan, const mi355q_inputs* in, int join_hash_type, const void* join_buf,
+                            int64_t join_min, int64_t join_max, int64_t join_entries, int join_n_keys, int join_width,
+                            DevPlan* dp) {
+  DevPlan& d = *dp;
+  if (plan->join_outer_col < 0) return;
+  const int nk = plan->n_join_cols > 1 ? plan->n_join_cols : 1;
+  for (int i = 0; i < nk; ++i) {
+    const int c = (i == 0 && plan->n_join_cols <= 1) ? plan->join_outer_col : plan->join_outer_cols[i];
+    d.join_cols[i] = c;
+    d.join_types[i] = col_type_code(plan->cols[c]);
+    d.join_nullables[i] = plan->cols[c].nullable != 0;
+  }
+  d.join_col = d.join_cols[0];
+  d.join_type = d.join_types[0];
+  d.join_nullable = d.join_nullables[0];
+  d.join_n_keys = join_n_keys;
+  d.join_width = join_width;
+  d.join_kind = plan->join_kind;
+  d.join_hash_type = join_hash_type;
+  d.join_buf = join_buf;
+  d.join_min = join_min;
+  d.join_max = join_max;
+  d.join_entries = join_entries;
+  for (int i = 0; i < plan->n_inner_cols; ++i) d.inner_cols[i] = (const int8_t*)in->inner_col_buffers[i];
+}
+
 extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                                int join_hash_type, const void* join_buf, int64_t join_min,
                                int64_t join_max, int64_t join_entries, int join_n_keys,
                                int join_width, int64_t* out, mi355q_qmd* out_qmd) {
+  if (plan->n_exprs != 0) {
+    // like mi355q_execute (api.cpp execute_projected + kernels_generic.hip k_project): the expressions are
+    // evaluated into dense temporary columns and the step runs on the lowered plan
+    mi355q_plan lp;
+    DevExprSet xs;
+    if (int32_t e = lower_exprs(*plan, &lp, &xs)) return e;
+    mi355q_qmd ql;
+    if (int32_t e = qmd_init(*plan, &ql)) return e;
+    DevPlan dl;
+    if (int32_t e = build_dev_plan(lp, ql, &dl)) return e;
+    emu_attach_join(&lp, in, join_hash_type, join_buf, join_min, join_max, join_entries, join_n_keys, join_width, &dl);
+    const int nc = plan->n_cols, nx = plan->n_exprs, nc2 = nc + nx;
+    uint32_t qual_expr_mask = 0;
+    for (int i = 0; i < plan->n_quals; ++i)
+      if (plan->quals[i].col >= nc) qual_expr_mask |= 1u << (plan->quals[i].col - nc);
+    std::vector<std::vector<int64_t>> store((size_t)in->n_frags * nx);
+    std::vector<const void*> cols2((size_t)in->n_frags * nc2);
+    for (int f = 0; f < in->n_frags; ++f) {
+      const int64_t n = in->num_rows[f];
+      for (int c = 0; c < nc; ++c) cols2[(size_t)f * nc2 + c] = in->col_buffers[(size_t)f * nc + c];
+      for (int k = 0; k < nx; ++k) {
+        store[(size_t)f * nx + k].assign((size_t)n + 2, 0);
+        cols2[(size_t)f * nc2 + nc + k] = store[(size_t)f * nx + k].data();
+      }
+      const int8_t* const* fc = (const int8_t* const*)(cols2.data() + (size_t)f * nc2);
+      for (int64_t pos = 0; pos < n; ++pos) {
+        uint32_t err_mask = 0;
+        for (int k = 0; k < nx; ++k) {
+          int32_t err = 0;
+          const int64_t v = eval_expr(xs.e[k], fc, pos, &err);
+          store_expr_value((int8_t*)fc[nc + k], xs.e[k].type, pos, v);
+          if (err) err_mask |= 1u << k;
+        }
+        if (!err_mask) continue;
+        bool counts = (err_mask & qual_expr_mask) != 0;
+        if (!counts) {
+          counts = true;
+          for (int i = 0; i < dl.n_quals && counts; ++i) counts = eval_qual(dl.quals[i], fc[dl.quals[i].col], pos);
+          if (counts && dl.join_col >= 0 && dl.join_kind != MI355Q_JOIN_LEFT) {
+            int64_t jk[MI355Q_MAX_GROUP_COLS];
+            bool null_key = false;
+            for (int i = 0; i < dl.join_n_keys; ++i) {
+              jk[i] = decode_int(fc[dl.join_cols[i]], dl.join_types[i], pos);
+              null_key = null_key || (dl.join_nullables[i] && jk[i] == int_null_of(dl.join_types[i]));
+            }
+            counts = !null_key && join_lookup(dl, jk).count > 0;
+          }
+        }
+        if (counts) return MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+      }
+    }
+    mi355q_inputs in2 = *in;
+    in2.col_buffers = cols2.data();
+    return emu_execute(&lp, &in2, join_hash_type, join_buf, join_min, join_max, join_entries, join_n_keys, join_width,
+                       out, out_qmd);
+  }
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;
   if (q.output_columnar) {
@@ -87,27 +183,7 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   }
   DevPlan d;
   if (int32_t e = build_dev_plan(*plan, q, &d)) return e;
-  if (plan->join_outer_col >= 0) {
-    const int nk = plan->n_join_cols > 1 ? plan->n_join_cols : 1;
-    for (int i = 0; i < nk; ++i) {
-      const int c = (i == 0 && plan->n_join_cols <= 1) ? plan->join_outer_col : plan->join_outer_cols[i];
-      d.join_cols[i] = c;
-      d.join_types[i] = col_type_code(plan->cols[c]);
-      d.join_nullables[i] = plan->cols[c].nullable != 0;
-    }
-    d.join_col = d.join_cols[0];
-    d.join_type = d.join_types[0];
-    d.join_nullable = d.join_nullables[0];
-    d.join_n_keys = join_n_keys;
-    d.join_width = join_width;
-    d.join_kind = plan->join_kind;
-    d.join_hash_type = join_hash_type;
-    d.join_buf = join_buf;
-    d.join_min = join_min;
-    d.join_max = join_max;
-    d.join_entries = join_entries;
-    for (int i = 0; i < plan->n_inner_cols; ++i) d.inner_cols[i] = (const int8_t*)in->inner_col_buffers[i];
-  }
+  emu_attach_join(plan, in, join_hash_type, join_buf, join_min, join_max, join_entries, join_n_keys, join_width, &d);
   if (out_qmd) *out_qmd = q;
   const int rq = q.row_size / 8;
   for (int64_t e = 0; e < q.entry_count; ++e) row_init_image(q, out + e * rq);

@@ -1,0 +1,183 @@
+"""Projected expressions (mi355q_expr): the cast / + - * micro-ops against the REFERENCE'S OWN runtime functions.
+
+tests/golden/ref_expr_vectors.json was produced by oracle/gen_golden_expr.py from
+cast_<from>_to_<to>_nullable and {add,sub,mul}_<type>_nullable[_lhs|_rhs] of QueryEngine/RuntimeFunctions.cpp
+(compiled unmodified into oracle/_ref).  Both evaluators must reproduce every vector bit for bit:
+  * the oracle's      oracle/oracle.cpp eval_expression      (orc_eval_expr)
+  * the product's     heavydb_amd/csrc/expr.h eval_expr      (through the host emulation here; the device leg is
+                      tests/test_gpu_parity.py::test_hip_expressions_match_reference_functions)
+The overflow rule is not a runtime function in the reference (llvm.s{add,sub,mul}.with.overflow,
+ArithmeticIR.cpp:840-909; codegenCastBetweenIntTypesOverflowChecks, CastIR.cpp:497-553) and is held against
+exact integer arithmetic.  Whole steps with expressions are part of the case matrix (tests/cases.py expr_*):
+oracle vs product row logic, vs SQLite, and vs the HIP library on the device."""
+import ctypes as C
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from heavydb_amd import capi
+from heavydb_amd.executor import Expr, ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+from tests.helpers import emu_lib
+
+NP = {capi.INT8: np.int8, capi.INT16: np.int16, capi.INT32: np.int32, capi.INT64: np.int64,
+      capi.DOUBLE: np.float64, capi.FLOAT: np.float32}
+INTS = [capi.INT8, capi.INT16, capi.INT32, capi.INT64]
+INT_NULL = {capi.INT8: -2**7, capi.INT16: -2**15, capi.INT32: -2**31, capi.INT64: -2**63}
+INT_MAX = {t: -v - 1 for t, v in INT_NULL.items()}
+
+
+def _vectors():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_expr_vectors.json")
+    with open(path) as f:
+        return json.load(f)
+
+
+def _col_of(t, pattern):
+    """a one-row column of type t holding the 64-bit pattern (integers sign-extended, fp as bits)"""
+    if t == capi.DOUBLE:
+        return np.array([struct.unpack("<d", struct.pack("<q", pattern))[0]], dtype=np.float64)
+    if t == capi.FLOAT:
+        return np.array([struct.unpack("<f", struct.pack("<I", pattern & 0xffffffff))[0]], dtype=np.float32)
+    return np.array([pattern], dtype=NP[t])
+
+
+def _plan(descs, expr):
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT)], exprs=[expr.with_range(ExpressionRange())])
+    return ra.to_plan()
+
+
+def _eval_both(oracle, plan, cols):
+    """(oracle pattern, product pattern, oracle code, product code) of expression 0 on row 0"""
+    ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+    ol = oracle.lib()
+    ol.orc_eval_expr.restype = C.c_int32
+    ol.orc_eval_expr.argtypes = [C.POINTER(capi.Plan), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    ob, ot, on = C.c_int64(), C.c_int32(), C.c_int32()
+    oc = ol.orc_eval_expr(C.byref(plan), 0, ptrs, 0, C.byref(ob), C.byref(ot), C.byref(on))
+    el = emu_lib()
+    el.emu_eval_expr.restype = C.c_int32
+    el.emu_eval_expr.argtypes = [C.POINTER(capi.Plan), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int32)]
+    eb, et = C.c_int64(), C.c_int32()
+    ec = el.emu_eval_expr(C.byref(plan), 0, ptrs, 0, C.byref(eb), C.byref(et))
+    return ob.value, eb.value, oc, ec
+
+
+def _same_pattern(t, a, b):
+    if t == capi.FLOAT:
+        return (a & 0xffffffff) == (b & 0xffffffff)
+    return a == b
+
+
+def test_casts_match_the_reference_runtime_functions(oracle):
+    for v in _vectors()["cast"]:
+        f, t = v["from"], v["to"]
+        plan = _plan([InputColDescriptor(f, True)], Expr.col(0).cast(t))
+        ob, eb, oc, ec = _eval_both(oracle, plan, [_col_of(f, v["in"])])
+        assert oc == 0 and ec == 0, v
+        assert _same_pattern(t, ob, v["out"]), ("oracle", v, ob)
+        assert _same_pattern(t, eb, v["out"]), ("product", v, eb)
+
+
+def test_arithmetic_matches_the_reference_runtime_functions(oracle):
+    for v in _vectors()["arith"]:
+        t, sfx = v["type"], v["suffix"]
+        descs = [InputColDescriptor(t, sfx in ("_nullable", "_nullable_lhs")),
+                 InputColDescriptor(t, sfx in ("_nullable", "_nullable_rhs"))]
+        e = Expr.col(0)._bin(v["op"], Expr.col(1), t)
+        ob, eb, oc, ec = _eval_both(oracle, _plan(descs, e), [_col_of(t, v["a"]), _col_of(t, v["b"])])
+        assert oc == 0 and ec == 0, v
+        assert _same_pattern(t, ob, v["out"]), ("oracle", v, ob)
+        assert _same_pattern(t, eb, v["out"]), ("product", v, eb)
+
+
+def test_vectors_still_match_the_reference_live(oracle):
+    """When oracle/_ref is present (build container), a sample of the vectors is re-derived from the reference's
+    functions themselves: the committed file has not drifted."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built here")
+    ref = C.CDLL(oracle.REF_LIB)
+    ref.cast_int32_t_to_double_nullable.restype = C.c_double
+    ref.cast_int32_t_to_double_nullable.argtypes = [C.c_int32, C.c_int32, C.c_double]
+    n = 0
+    for v in _vectors()["cast"]:
+        if v["from"] == capi.INT32 and v["to"] == capi.DOUBLE:
+            r = ref.cast_int32_t_to_double_nullable(v["in"], -2**31, float(np.finfo(np.float64).tiny))
+            assert struct.unpack("<q", struct.pack("<d", r))[0] == v["out"]
+            n += 1
+    assert n > 5
+    ref.mul_int64_t_nullable_lhs.restype = C.c_int64
+    ref.mul_int64_t_nullable_lhs.argtypes = [C.c_int64, C.c_int64, C.c_int64]
+    for v in _vectors()["arith"]:
+        if v["type"] == capi.INT64 and v["op"] == capi.EX_MUL and v["suffix"] == "_nullable_lhs":
+            assert ref.mul_int64_t_nullable_lhs(v["a"], v["b"], -2**63) == v["out"]
+
+
+def test_integer_overflow_rule_against_exact_arithmetic(oracle):
+    """s{add,sub,mul}.with.overflow at the operand type's width: error 7 exactly when the exact result leaves the
+    type (a NULL operand skips the check); otherwise the exact result."""
+    rng = np.random.default_rng(77)
+    for t in INTS:
+        lo, hi = INT_NULL[t], INT_MAX[t]
+        edge = [lo, lo + 1, -1, 0, 1, 2, hi - 1, hi, hi // 2 + 1, lo // 2 - 1]
+        vals = edge + [int(x) for x in rng.integers(lo, hi, 12, endpoint=True)]
+        for op, f in ((capi.EX_ADD, lambda a, b: a + b), (capi.EX_SUB, lambda a, b: a - b), (capi.EX_MUL, lambda a, b: a * b)):
+            for nullable in (False, True):
+                descs = [InputColDescriptor(t, nullable), InputColDescriptor(t, nullable)]
+                plan = _plan(descs, Expr.col(0)._bin(op, Expr.col(1), t))
+                for a in vals:
+                    for b in vals[::2]:
+                        ob, eb, oc, ec = _eval_both(oracle, plan, [_col_of(t, a), _col_of(t, b)])
+                        if nullable and (a == lo or b == lo):
+                            assert oc == 0 and ec == 0 and ob == lo and eb == lo, (t, op, a, b)
+                            continue
+                        exact = f(a, b)
+                        if lo <= exact <= hi:
+                            assert oc == 0 and ec == 0 and ob == exact and eb == exact, (t, op, a, b, ob, eb)
+                        else:
+                            assert oc == 7 and ec == 7, (t, op, a, b, oc, ec)
+
+
+def test_narrowing_cast_rule(oracle):
+    """codegenCastBetweenIntTypesOverflowChecks (CastIR.cpp:497-553): error when v > max(to) or v <= min(to) —
+    the target's minimum (its NULL sentinel) is refused too; a NULL operand passes and becomes the target's NULL."""
+    for f in INTS:
+        for t in INTS:
+            if INT_MAX[t] >= INT_MAX[f]:
+                continue
+            for nullable in (False, True):
+                plan = _plan([InputColDescriptor(f, nullable)], Expr.col(0).cast(t))
+                for v in (INT_MAX[t], INT_MAX[t] + 1, INT_NULL[t], INT_NULL[t] + 1, INT_NULL[t] - 1, 0, -5, INT_NULL[f]):
+                    ob, eb, oc, ec = _eval_both(oracle, plan, [_col_of(f, v)])
+                    if nullable and v == INT_NULL[f]:
+                        assert oc == 0 and ec == 0 and ob == INT_NULL[t] and eb == INT_NULL[t]
+                    elif v > INT_MAX[t] or v <= INT_NULL[t]:
+                        assert oc == 7 and ec == 7, (f, t, v, oc, ec)
+                    else:
+                        assert oc == 0 and ec == 0 and ob == v and eb == v
+
+
+def test_invalid_programs_are_refused(oracle):
+    """plan-time validation (plan.cpp lower_exprs and the oracle's lower_plan): operand types that differ from
+    the node's, an unbalanced stack, a column out of range, an expression used as a join key."""
+    descs = [InputColDescriptor(capi.INT32, False), InputColDescriptor(capi.INT64, False)]
+    bad = [Expr.col(0).add(Expr.col(1), capi.INT64),      # int32 + int64 without the analyzer's cast
+           Expr.col(0).add(Expr.lit(capi.INT32, 1), capi.INT64),
+           Expr(Expr.col(0).nodes + Expr.col(1).nodes),    # two values left on the stack
+           Expr(Expr.col(0).cast(capi.INT64).nodes[1:]),   # cast of nothing
+           Expr.col(5)]
+    el = emu_lib()
+    for e in bad:
+        plan = _plan(descs, e)
+        q = capi.QMD()
+        assert el.emu_qmd_init(C.byref(plan), C.byref(q)) == capi.ERR_INVALID_PLAN
+        with pytest.raises(Exception):
+            oracle.qmd_init(plan)
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT)], exprs=[Expr.col(1).add(Expr.lit(capi.INT64, 1), capi.INT64)],
+                             inner_col_descs=[InputColDescriptor(capi.INT64, False)], join_outer_col=2)
+    q = capi.QMD()
+    assert el.emu_qmd_init(C.byref(ra.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN

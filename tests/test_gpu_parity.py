@@ -104,10 +104,13 @@ def test_hip_matches_oracle(torch_cuda, oracle, case, force_generic):
         ex = Executor(0)
         fr = _fetch_result(case, frag_t, inner_t)
         if case.expect_error is not None:
-            assert code < 0
             with pytest.raises(capi.Mi355qError) as ei:
                 ex.executeWorkUnit(case.ra, fr, force_generic=force_generic, allow_retry=False)
-            assert ei.value.code < 0 or ei.value.code == capi.ERR_OUT_OF_SLOTS
+            if case.expect_error > 0:   # a persistent error code, e.g. 7 = OVERFLOW_OR_UNDERFLOW
+                assert code == case.expect_error and ei.value.code == case.expect_error, (code, ei.value.code)
+            else:
+                assert code < 0
+                assert ei.value.code < 0 or ei.value.code == capi.ERR_OUT_OF_SLOTS
             return
         assert code == 0
         rs = ex.executeWorkUnit(case.ra, fr, force_generic=force_generic, allow_retry=False)
@@ -1145,6 +1148,58 @@ def test_hip_aggregates_and_comparisons_match_reference_functions(torch_cuda, fo
             assert abs(g - w) <= 1e-12 * max(abs(g), abs(w)), (case["ref_functions"][1], g, w)
         else:
             assert got == want, (case["ref_functions"][1], got, want)
+
+
+def test_hip_expressions_match_reference_functions(torch_cuda):
+    """tests/golden/ref_expr_vectors.json — cast_<a>_to_<b>_nullable and {add,sub,mul}_<type>_nullable[_lhs|_rhs] of
+    the reference's RuntimeFunctions.cpp (oracle/gen_golden_expr.py) — against the HIP library directly (the
+    projection kernel k_project), no oracle in between: every vector of one (op, types, nullability) family is a row
+    of one step  SELECT id, MIN(<expr>) GROUP BY id  whose group holds exactly that row, so the MIN slot is the
+    expression's value (the untouched NULL sentinel when it is NULL).  Bit-exact."""
+    from tests.test_expr import INTS, INT_NULL, _col_of, _vectors
+    from heavydb_amd.executor import Executor, Expr, ExpressionRange, FetchResult, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    torch = torch_cuda
+    ex = Executor(0)
+    vec = _vectors()
+    fams = {}
+    for v in vec["cast"]:
+        fams.setdefault(("cast", v["from"], v["to"], ""), []).append(v)
+    for v in vec["arith"]:
+        fams.setdefault(("arith", v["type"], v["op"], v["suffix"]), []).append(v)
+    checked = 0
+    for (kind, a, b, sfx), vs in fams.items():
+        n = len(vs)
+        ids = np.arange(n, dtype=np.int32)
+        if kind == "cast":
+            cols = [np.concatenate([_col_of(a, v["in"]) for v in vs])]
+            descs = [InputColDescriptor(a, True)]
+            e, rt = Expr.col(1).cast(b), b
+        else:
+            cols = [np.concatenate([_col_of(a, v["a"]) for v in vs]), np.concatenate([_col_of(a, v["b"]) for v in vs])]
+            descs = [InputColDescriptor(a, sfx in ("_nullable", "_nullable_lhs")),
+                     InputColDescriptor(a, sfx in ("_nullable", "_nullable_rhs"))]
+            e, rt = Expr.col(1)._bin(b, Expr.col(2), a), a
+        descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, n - 1))] + descs
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.MIN, len(descs))], [], [0],
+                                 exprs=[e.with_range(ExpressionRange())])
+        dev = [torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in [ids] + cols]
+        fr = FetchResult([[int(t.data_ptr()) for t in dev]], [n], keepalive=dev)
+        rs = ex.executeWorkUnit(ra, fr, allow_retry=False)
+        q = rs.getQueryMemDesc()
+        rows = np.asarray(rs.getStorage()).view(np.int64).reshape(q.entry_count, -1)
+        slot = q.key_bytes // 8 + q.target_slot[1]
+        assert q.entry_count == n
+        for i, v in enumerate(vs):
+            got, want = int(rows[i, slot]), v["out"]
+            if rt == capi.FLOAT:      # FLOAT slots: the low four bytes
+                assert got & 0xffffffff == want & 0xffffffff, (kind, a, b, sfx, v, hex(got))
+            elif rt in INTS and want == INT_NULL[rt]:
+                # a NULL result leaves the slot at MIN's init value: the argument type's NULL sentinel
+                assert got == INT_NULL[rt], (kind, a, b, sfx, v, got)
+            else:
+                assert got == want, (kind, a, b, sfx, v, got)
+            checked += 1
+    assert checked == len(vec["cast"]) + len(vec["arith"])
 
 
 @pytest.mark.parametrize("targets", ["key_count_count_key", "count_only"])

@@ -182,3 +182,9 @@ def test_dryrun_parity_matrix(monkeypatch, oracle):
         m.test_hip_matches_oracle(torch, oracle, case, False)
     for name in ("simple_aggs_nullable", "baseline_count_avg", "multi_baseline_i64_2col", "compact_baseline_key32"):
         m.test_device_reduce_matches_oracle(torch, oracle, name)
+
+
+def test_dryrun_expression_vectors(monkeypatch, oracle):
+    _install(monkeypatch, oracle)
+    import tests.test_gpu_parity as m
+    m.test_hip_expressions_match_reference_functions(torch)

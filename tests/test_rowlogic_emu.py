@@ -68,7 +68,10 @@ def test_emulated_rowlogic_matches_oracle(oracle, case):
     q, want, code = oracle.execute(plan, case.frags, case.inner, oj, n_threads=3)
     eq, got, ecode = _emu_execute(case, plan, oj)
     if case.expect_error is not None:
-        assert code < 0 and ecode < 0
+        if case.expect_error > 0:   # a persistent error code (enums.h:30-51), e.g. 7 = OVERFLOW_OR_UNDERFLOW
+            assert code == ecode == case.expect_error, (code, ecode)
+        else:                       # < 0: ran out of group slots
+            assert code < 0 and ecode < 0
         return
     assert code == 0 and ecode == 0, (code, ecode)
     qmd_equal(q, eq)

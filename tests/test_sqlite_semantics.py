@@ -42,8 +42,35 @@ def _decoded_values(d, a):
     return [None if n else int(x) for x, n in zip(v, null)]
 
 
-def _lit(d, q):
-    return repr(float(q.literal)) if d.type in (capi.DOUBLE, capi.FLOAT) else str(int(q.literal))
+def _lit(col_type, q):
+    return repr(float(q.literal)) if col_type in (capi.DOUBLE, capi.FLOAT) else str(int(q.literal))
+
+
+def _expr_sql(e, descs):
+    """A projected expression (postfix micro-ops) as SQLite text over the base table's columns: integer
+    arithmetic is 64-bit in SQLite (the cases keep clear of overflow), CAST(.. AS REAL) for the casts to
+    DOUBLE / FLOAT (the FLOAT cases use values single precision holds exactly), ROUND() — half away from
+    zero, like DEF_ROUND_NULLABLE — for floating point -> integer."""
+    st = []
+    for n in e.nodes:
+        if n.op == capi.EX_COL:
+            st.append((f"c{n.arg}", descs[n.arg].type in (capi.DOUBLE, capi.FLOAT)))
+        elif n.op == capi.EX_LIT:
+            fp = n.type in (capi.DOUBLE, capi.FLOAT)
+            st.append((repr(float(n.flit)) if fp else str(int(n.ilit)), fp))
+        elif n.op == capi.EX_CAST:
+            x, fp = st.pop()
+            to_fp = n.type in (capi.DOUBLE, capi.FLOAT)
+            if to_fp:
+                st.append((f"CAST({x} AS REAL)", True))
+            elif fp:
+                st.append((f"CAST(ROUND({x}) AS INTEGER)", False))
+            else:
+                st.append((x, False))
+        else:
+            (b, _), (a, fp) = st.pop(), st.pop()
+            st.append((f"({a} {'+' if n.op == capi.EX_ADD else '-' if n.op == capi.EX_SUB else '*'} {b})", fp))
+    return st[0][0]
 
 
 def _sql_for(case):
@@ -58,7 +85,7 @@ def _sql_for(case):
     def cond(q):
         if q.op in (capi.IS_NULL, capi.IS_NOT_NULL):
             return f"f.c{q.col} IS {'NOT ' if q.op == capi.IS_NOT_NULL else ''}NULL"
-        return f"f.c{q.col} {OPS[q.op]} {_lit(descs[q.col], q)}"
+        return f"f.c{q.col} {OPS[q.op]} {_lit(ra.col_type(q.col), q)}"
     sel = []
     for t in ra.target_exprs:
         if t.agg == capi.PROJECT_KEY:
@@ -99,10 +126,16 @@ def _load(case):
     db = sqlite3.connect(":memory:")
     ra = case.ra
     n_cols = len(ra.input_col_descs)
-    db.execute("CREATE TABLE f (" + ", ".join(f"c{i}" for i in range(n_cols)) + ")")
+    # expressions: f is a view that adds one computed column per expression (c<n_cols + k>) to the base table
+    base = "fb" if ra.exprs else "f"
+    db.execute(f"CREATE TABLE {base} (" + ", ".join(f"c{i}" for i in range(n_cols)) + ")")
     for cols in case.frags:
         vals = [_decoded_values(d, a) for d, a in zip(ra.input_col_descs, cols)]
-        db.executemany("INSERT INTO f VALUES (" + ",".join("?" * n_cols) + ")", list(zip(*vals)))
+        db.executemany(f"INSERT INTO {base} VALUES (" + ",".join("?" * n_cols) + ")", list(zip(*vals)))
+    if ra.exprs:
+        db.execute("CREATE VIEW f AS SELECT " + ", ".join(f"c{i}" for i in range(n_cols)) + ", " +
+                   ", ".join(f"{_expr_sql(e, ra.input_col_descs)} AS c{n_cols + k}" for k, e in enumerate(ra.exprs)) +
+                   " FROM fb")
     if case.join_keys is not None:
         keys = case.join_keys if isinstance(case.join_keys, (list, tuple)) else [case.join_keys]
         ktypes = case.join_key_type if isinstance(case.join_key_type, (list, tuple)) else [case.join_key_type]

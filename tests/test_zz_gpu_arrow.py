@@ -16,12 +16,13 @@ CASES = [c for c in cases_mod.build_cases() if c.name in NAMES]
 
 
 def _sorted_rows(cols, n_rows):
-    # None sorts first; a float column may differ in the last bits between the two sides, so the sort key of a
-    # float is rounded (the comparison below uses the real values)
+    # None sorts first; a float column may differ in the last bits between the two sides (FLOAT arguments are
+    # summed in single precision, in another order on the device), so the sort key of a float is rounded well
+    # above that (the comparison below uses the real values)
     def k(v):
         if v is None:
             return (0, 0.0)
-        return (1, float(f"{v:.9e}") if isinstance(v, float) else v)
+        return (1, float(f"{v:.3e}") if isinstance(v, float) else v)
     order = sorted(range(n_rows), key=lambda r: tuple(k(c[r]) for c in cols))
     return [tuple(c[r] for c in cols) for r in order]
 
@@ -54,8 +55,13 @@ def test_native_arrow_export_matches_oracle(case, oracle):
         want_cols.append([None if nul[r, t] else (float(dval[r, t]) if is_fp else int(ival[r, t]))
                           for r in range(n_rows)])
         got_cols.append(g.to_pylist())
+    from tests.helpers import F32_ATOL, F32_RTOL
+    # the parity bar of DESIGN section 2: doubles 1e-9 relative; targets over a FLOAT argument 2e-4 (+ absolute)
+    rtol = [max(1e-9, F32_RTOL) if q.target_arg_is_f32[t] else 1e-9 for t in range(len(names))]
+    atol = [F32_ATOL if q.target_arg_is_f32[t] else 0.0 for t in range(len(names))]
     for a_row, b_row in zip(_sorted_rows(want_cols, n_rows), _sorted_rows(got_cols, n_rows)):
-        for a, b in zip(a_row, b_row):
+        for t, (a, b) in enumerate(zip(a_row, b_row)):
             assert (a is None) == (b is None), (a_row, b_row)
             if a is not None:
-                assert a == b or (isinstance(a, float) and abs(a - b) <= 1e-9 * max(1.0, abs(a))), (a_row, b_row)
+                assert a == b or (isinstance(a, float) and
+                                  abs(a - b) <= rtol[t] * max(abs(a), abs(b)) + atol[t]), (t, a_row, b_row)
