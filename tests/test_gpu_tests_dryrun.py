@@ -188,3 +188,10 @@ def test_dryrun_expression_vectors(monkeypatch, oracle):
     _install(monkeypatch, oracle)
     import tests.test_gpu_parity as m
     m.test_hip_expressions_match_reference_functions(torch)
+
+
+def test_dryrun_refbench(monkeypatch, oracle):
+    _install(monkeypatch, oracle)
+    import tests.test_zz_gpu_refbench as m
+    for name in ("NGA01", "PHS002", "BH001", "MSBS001", "MSPHM006"):
+        m._run(torch, oracle, name, 30_000, 3_000, 0)

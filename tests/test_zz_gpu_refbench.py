@@ -1,0 +1,60 @@
+"""The reference's synthetic benchmark queries (tools/refbench.py: Benchmarks/synthetic_benchmark/queries/*/*.sql on
+create_table.py's schema) through the HIP library against the oracle: at the CPU tests' small size with the
+plan-time kernel choice and with the large-input family members forced (kernel_variant 2), and at 16 M rows — large
+enough for the planner to pick the partitioned / packed / projected routes itself — for one query per family."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from heavydb_amd import capi
+from tests.helpers import compare_buffers, compare_rows
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import refbench  # noqa: E402
+
+QUERIES = refbench.queries()
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    capi.load_library()
+    return torch
+
+
+def _run(torch, oracle, name, n_rows, card_cap, variant):
+    from heavydb_amd.executor import Executor, FetchResult
+    names, descs, gens = refbench.schema(card_cap)
+    cols = [oracle.generate_column(n_rows, g[0], g[1], g[2], g[3], g[4], g[5]) for g in gens]
+    cut = (n_rows // 3) // 4 * 4
+    frags = [[c[:cut] for c in cols], [c[cut:] for c in cols]]
+    ra, _ = refbench.build_unit(QUERIES[name], names, descs, n_rows)
+    q, want, code = oracle.execute(ra.to_plan(), frags, n_threads=min(os.cpu_count() or 1, 16))
+    assert code == 0
+    dev = [torch.from_numpy(np.ascontiguousarray(c)).cuda() for c in cols]
+    es = [t.element_size() for t in dev]
+    fr = FetchResult([[int(t.data_ptr()) for t in dev], [int(t.data_ptr()) + cut * e for t, e in zip(dev, es)]],
+                     [cut, n_rows - cut], keepalive=dev)
+    rs = Executor(0).executeWorkUnit(ra, fr, kernel_variant=variant)
+    compare_buffers(q, want, rs.getStorage(), 1e-9)
+    compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
+    return rs.report.kernel_name.decode()
+
+
+@pytest.mark.parametrize("variant", [0, 2], ids=["planned", "large_input_members"])
+@pytest.mark.parametrize("name", list(QUERIES), ids=list(QUERIES))
+def test_refbench_queries_small(torch_cuda, oracle, name, variant):
+    _run(torch_cuda, oracle, name, 30_000, 3_000, variant)
+
+
+@pytest.mark.parametrize("name", ["NGA02", "NGA05", "PHS003", "PHS006", "PHM004", "BH002", "BH006", "BH008", "BH010",
+                                  "MSBS003", "MSPHS002", "MSPHM006", "S002"])
+def test_refbench_queries_16m_rows(torch_cuda, oracle, name):
+    kernel = _run(torch_cuda, oracle, name, 16_000_000, 0, 0)
+    print(name, kernel)
