@@ -170,6 +170,7 @@ class Inputs(C.Structure):
         ("num_rows", C.POINTER(C.c_int64)),
         ("inner_col_buffers", C.POINTER(C.c_void_p)),
         ("inner_num_rows", C.c_int64),
+        ("inner_version", C.c_int64),
     ]
 
 
@@ -180,8 +181,15 @@ class ExecOptions(C.Structure):
         ("force_generic", C.c_int32),
         ("kernel_variant", C.c_int32),
         ("scratch_bytes", C.c_int64),
-        ("reserved", C.c_int32 * 4),
+        ("tune_blocks_per_cu", C.c_int32),
+        ("probe_keyed_passes", C.c_int32),
+        ("pass_rows", C.c_int64),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_int32),
     ]
+
+
+OPT_TRACE, OPT_NO_PAIR_RENDEZVOUS, OPT_PROBE_NO_PACING = 1, 2, 4
 
 
 class ExecReport(C.Structure):
@@ -233,6 +241,10 @@ SYMBOLS = [
     ("mi355q_qmd_slot_col_offset", C.c_int64, [_P(QMD), C.c_int32]),
     ("mi355q_execute", C.c_int32,
      [_P(Plan), _P(Inputs), _P(ExecOptions), _P(C.c_void_p), _P(ExecReport)]),
+    ("mi355q_execute_async", C.c_int32,
+     [_P(Plan), _P(Inputs), _P(ExecOptions), _P(C.c_void_p), _P(C.c_void_p)]),
+    ("mi355q_wait", C.c_int32, [C.c_void_p, _P(ExecReport)]),
+    ("mi355q_reserve_workspace", C.c_int32, [_P(Plan), _P(Inputs), _P(ExecOptions), _P(C.c_int64)]),
     ("mi355q_result_create", C.c_int32, [_P(QMD), C.c_int32, C.c_void_p, _P(C.c_void_p)]),
     ("mi355q_result_wrap", C.c_int32, [_P(QMD), C.c_int32, C.c_void_p, _P(C.c_void_p)]),
     ("mi355q_result_free", None, [C.c_void_p]),
@@ -257,6 +269,8 @@ SYMBOLS = [
     ("mi355q_join_build", C.c_int32, [_P(JoinSpec), C.c_void_p, _P(C.c_void_p)]),
     ("mi355q_join_free", None, [C.c_void_p]),
     ("mi355q_join_key_shape", C.c_int32, [C.c_void_p, _P(C.c_int32), _P(C.c_int32)]),
+    ("mi355q_join_invalidate_payload", C.c_int32, [C.c_void_p]),
+    ("mi355q_join_payload_info", C.c_int32, [C.c_void_p, _P(C.c_int64), _P(C.c_float), _P(C.c_int64)]),
     ("mi355q_join_info", C.c_int32,
      [C.c_void_p, _P(C.c_int32), _P(C.c_int64), _P(C.c_int64), _P(C.c_int64), _P(C.c_void_p),
       _P(C.c_int64), _P(C.c_float)]),

@@ -48,11 +48,12 @@ struct mi355q_join_table {
   int64_t* pay8 = nullptr;       // one-to-one tables, L2 mode: the inner value per key slot, INT64_MIN = absent
   int64_t* pay_kkeys = nullptr;  // keyed tables: the key of every slot (pay16 / pay8 are then per slot)
   const void* pay16_col = nullptr;
-  bool pay16_built = false;
+  bool pay16_built = false, pay_col_built = false;
   int pay16_has_nulls = 0;
   const void* pay_col = nullptr;
   int pay_has_nulls = 0;
   float pay_build_ms = 0.f;
+  int64_t pay_version = 0, pay16_version = 0;  // mi355q_inputs.inner_version the payloads were built for
 };
 
 struct mi355q_result {
@@ -92,11 +93,11 @@ struct DeviceGuard {
   }
 };
 
-// MI355Q_TRACE=1: host-side wall-clock marks of one execute call on stderr
+// MI355Q_OPT_TRACE: host-side wall-clock marks of one execute call on stderr
 struct Trace {
   bool on;
   std::chrono::steady_clock::time_point t0;
-  Trace() : on(std::getenv("MI355Q_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  explicit Trace(bool enabled) : on(enabled), t0(std::chrono::steady_clock::now()) {}
   void mark(const char* what) {
     if (!on) return;
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -136,6 +137,7 @@ struct DeviceCtx {
   size_t meta_bytes = 0;
   std::vector<hipEvent_t> events;
   hipStream_t stream = nullptr;  // library-owned launch stream (when the caller passes none)
+  struct mi355q_pending* inflight = nullptr;  // a step enqueued by mi355q_execute_async and not yet waited for
 };
 DeviceCtx& ctx_of(int dev) {
   static DeviceCtx ctxs[64];
@@ -1018,10 +1020,8 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
   (void)hipMemGetInfo(&free_b, &total_b);
   int64_t pack_budget = std::min<int64_t>((int64_t)16 << 30, ((int64_t)free_b + ctx.aux_bytes) / 3);
   int64_t pass_rows = pack_budget / 8;
-  if (const char* e = std::getenv("MI355Q_PACK_PASS_ROWS")) {  // tests: force several passes
-    const int64_t v = std::atoll(e);
-    if (v > 0 && v < pass_rows) pass_rows = std::max<int64_t>(v, max_frag_rows);
-  }
+  if (o.pass_rows > 0 && o.pass_rows < pass_rows)  // tests: force several passes
+    pass_rows = std::max<int64_t>(o.pass_rows, max_frag_rows);
   if (pass_rows < max_frag_rows + 2 * (int64_t)nf) return kNotTaken;
   if (pass_rows > total_rows) pass_rows = total_rows;
   const int64_t pack_bytes = ((pass_rows + 2 * (int64_t)nf) * 8 + 255) & ~255ll;
@@ -1143,6 +1143,127 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
   return MI355Q_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// The part of a step that needs the host to look at the device: error words, the spill counter, the
+// re-run with the direct member when the partitioned family gave up, the report.  mi355q_execute runs it
+// right after the launches; mi355q_execute_async parks it in a mi355q_pending until mi355q_wait (or the
+// next call on the device) runs it.  Everything it touches is owned here: the caller's host arrays may be
+// gone by then.
+enum StepKind { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART, K_JOIN_PROBE, K_SCAN_AGG };
+struct TailState {
+  mi355q_qmd q;
+  DevPlan d;
+  StepKind kind;
+  LaunchStats st;
+  mi355q_result* res;
+  int32_t* d_err;
+  const int8_t* const* d_cols;
+  const int64_t* d_rows;
+  std::vector<const void*> h_cols;
+  std::vector<int64_t> h_rows;
+  int nf, nc, n_cus;
+  int64_t total_rows, max_frag_rows, alg_bytes;
+  hipStream_t s;
+  hipEvent_t ev_start, ev_stop;
+  hipEvent_t* ev_pool;
+  bool trace;
+};
+
+int32_t finish_step(TailState& t, mi355q_exec_report* report) {
+  hipStream_t s = t.s;
+  LaunchStats& st = t.st;
+  const mi355q_qmd& q = t.q;
+  const DevPlan& d = t.d;
+  FragView fv{t.d_cols, t.d_rows, t.h_cols.data(), t.h_rows.data(), t.nf, t.nc, t.total_rows, t.max_frag_rows};
+  int32_t h_err[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h_err, t.d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  uint32_t h_spills = 0;
+  if (st.spill_counter32) {
+    HIP_TRY(hipMemcpyAsync(&h_spills, st.spill_counter32, sizeof(h_spills), hipMemcpyDeviceToHost, s));
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  st.spilled_rows = (int64_t)h_spills;
+  if (h_err[1] && t.trace) std::fprintf(stderr, "[mi355q] partitioned family gave up (code %d, spills %u): re-running with the direct kernel\n", h_err[1], h_spills);
+  if (h_err[1] && t.kind == K_JOIN_PART) {
+    // the partitioned probe ran out of spill space (extreme skew): redo with the direct probe
+    HIP_TRY(hipMemsetAsync(t.d_err, 0, 64, s));
+    HIP_TRY(launch_init_buffer(t.res->buf, q.entry_count, make_row_init(q), s));
+    HIP_TRY(launch_join_sum(d, fv, t.res->buf, t.n_cus, s, &st));
+    HIP_TRY(hipMemcpyAsync(h_err, t.d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (h_err[1] && t.kind == K_JOIN_PROBE) {
+    // the payload probe ran out of spill space (extreme skew): redo the step with the row kernel
+    HIP_TRY(hipMemsetAsync(t.d_err, 0, 64, s));
+    HIP_TRY(launch_init_buffer(t.res->buf, q.entry_count, make_row_init(q), s));
+    HIP_TRY(launch_generic(d, q.idx_target_as_key, make_row_init(q), t.d_cols, t.d_rows, t.nf, t.max_frag_rows, t.res->buf,
+                           t.d_err, t.n_cus, s));
+    st.kernel_name = "k_generic";
+    HIP_TRY(hipMemcpyAsync(h_err, t.d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (h_err[1] && t.kind == K_BASELINE_FAST) {
+    // the partitioned family ran out of spill space (extreme skew): redo the step with the
+    // direct-atomic member of the same family
+    HIP_TRY(hipMemsetAsync(t.d_err, 0, 64, s));
+    HIP_TRY(launch_init_buffer(t.res->buf, q.entry_count, make_row_init(q), s));
+    HIP_TRY(launch_baseline_fast(d, fv, t.res->buf, t.d_err, nullptr, 0, 0, 1, t.n_cus, s, &st));
+    HIP_TRY(hipMemcpyAsync(h_err, t.d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (report) {
+    std::memset(report, 0, sizeof(*report));
+    std::snprintf(report->kernel_name, sizeof(report->kernel_name), "%s", st.kernel_name ? st.kernel_name : "");
+    (void)hipEventElapsedTime(&report->total_ms, t.ev_start, t.ev_stop);
+    if (st.n_events_used > 0) {
+      float acc = 0.f;
+      for (int i = 0; i + 1 < st.n_events_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.ev_pool[i], t.ev_pool[i + 1]) == hipSuccess) acc += ms;
+      }
+      report->kernel_ms = acc;
+    } else if (st.n_launches > 0 && t.nf > 0) {
+      if (hipEventElapsedTime(&report->kernel_ms, st.k_start, st.k_stop) != hipSuccess) report->kernel_ms = 0.f;
+    }
+    report->n_launches = st.n_launches;
+    report->variant = st.variant;
+    report->rows_scanned = t.total_rows;
+    report->algorithmic_bytes = t.alg_bytes;
+    report->spilled_rows = st.spilled_rows;
+  }
+  return h_err[0];
+}
+
+}  // namespace
+
+struct mi355q_pending {
+  TailState* tail = nullptr;  // null once the step has been finished
+  int device_id = 0;
+  int32_t code = MI355Q_OK;
+  mi355q_exec_report rep{};
+};
+
+namespace {
+
+// finishes the step a previous mi355q_execute_async left in flight on this device (ctx.mu held)
+void drain_inflight(DeviceCtx& ctx) {
+  mi355q_pending* p = ctx.inflight;
+  if (!p) return;
+  ctx.inflight = nullptr;
+  if (p->tail) {
+    p->code = finish_step(*p->tail, &p->rep);
+    delete p->tail;
+    p->tail = nullptr;
+  }
+}
+
+// reserved != nullptr: RESERVE mode — plan the step, size and allocate the per-device workspace it would use,
+// launch nothing (mi355q_reserve_workspace); the column pointers are not looked at
+int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options* opts,
+                     mi355q_result** out, mi355q_exec_report* report, mi355q_pending** pend,
+                     int64_t* reserved = nullptr);
+
 // Plans with projected expressions (mi355q_expr): scan / filter / PROJECT.  The expressions of a pass of
 // fragments are evaluated into dense temporary columns (k_project), the step runs on the lowered plan — where
 // those columns are ordinary inputs, so every kernel family applies — and the passes' results are folded with
@@ -1188,7 +1309,7 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
   // every (fragment, expression) chunk starts on a 16-byte boundary: the fast families want aligned columns
   const int64_t pad = 16 * (int64_t)nx;
   int64_t pass_rows = std::max<int64_t>(budget / std::max<int64_t>(row_bytes, 1), max_frag_rows);
-  if (o.reserved[2] > 0) pass_rows = std::max<int64_t>(o.reserved[2], max_frag_rows);  // tests: several passes
+  if (o.pass_rows > 0) pass_rows = std::max<int64_t>(o.pass_rows, max_frag_rows);  // tests: several passes
   if (pass_rows > total_rows) pass_rows = total_rows;
   const int64_t tab_bytes = ((int64_t)sizeof(void*) * nf * nc2 + 255) & ~255ll;
   const int64_t rows_bytes = ((int64_t)sizeof(int64_t) * nf + 255) & ~255ll;
@@ -1302,16 +1423,102 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
 int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                        const mi355q_exec_options* opts, mi355q_result** out,
                        mi355q_exec_report* report) {
+  return execute_impl(plan, in, opts, out, report, nullptr);
+}
+
+int32_t mi355q_reserve_workspace(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options* opts,
+                                 int64_t* reserved_bytes) {
+  if (!plan || !in) return MI355Q_ERR_INVALID_PLAN;
+  int64_t bytes = 0;
+  // the planner looks at the pointer table for alignment only: a table of NULLs stands in for it
+  std::vector<const void*> none((size_t)std::max(1, in->n_frags * std::max(plan->n_cols + plan->n_exprs, 1)), nullptr);
+  mi355q_inputs in2 = *in;
+  in2.col_buffers = none.data();
+  mi355q_result* r = nullptr;
+  const int32_t e = execute_impl(plan, &in2, opts, &r, nullptr, nullptr, &bytes);
+  if (r) mi355q_result_free(r);
+  if (reserved_bytes) *reserved_bytes = bytes;
+  return e;
+}
+
+// Stream-ordered form of mi355q_execute: every kernel of the step is enqueued on the stream and the call
+// returns without waiting for the device.  *out is valid at once for STREAM-ORDERED use on the same stream
+// (mi355q_shard_pads, a collective enqueued behind it, ...); whether the step succeeded — error code, the
+// retry with the direct member after a spill overflow, the report — is only known after mi355q_wait.  One step
+// per device may be in flight: the next call on the device finishes it first.  Routes that need the host in
+// the middle of the step (projected expressions, packed multi-column keys, columnar / 4-byte-slot results,
+// the first build of a join payload) run to completion inside this call; mi355q_wait then returns at once.
+int32_t mi355q_execute_async(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options* opts,
+                             mi355q_result** out, mi355q_pending** pending) {
+  if (!pending) return MI355Q_ERR_INVALID_PLAN;
+  *pending = nullptr;
+  mi355q_pending* p = nullptr;
+  mi355q_exec_report rep{};
+  const int32_t e = execute_impl(plan, in, opts, out, &rep, &p);
+  if (!p) {  // completed (or failed) synchronously
+    p = new (std::nothrow) mi355q_pending();
+    if (!p) return e ? e : MI355Q_ERR_OUT_OF_CPU_MEM;
+    p->device_id = in ? in->device_id : 0;
+    p->code = e;
+    p->rep = rep;
+  }
+  *pending = p;
+  return p->tail ? MI355Q_OK : e;
+}
+
+int32_t mi355q_wait(mi355q_pending* p, mi355q_exec_report* report) {
+  if (!p) return MI355Q_ERR_INVALID_PLAN;
+  {
+    DeviceCtx& ctx = ctx_of(p->device_id);
+    std::lock_guard<std::recursive_mutex> lk(ctx.mu);
+    if (ctx.inflight == p) {
+      DeviceGuard g(p->device_id);
+      drain_inflight(ctx);
+    }
+  }
+  if (report) *report = p->rep;
+  const int32_t code = p->code;
+  delete p->tail;
+  delete p;
+  return code;
+}
+
+namespace {
+int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
+                     const mi355q_exec_options* opts, mi355q_result** out,
+                     mi355q_exec_report* report, mi355q_pending** pend, int64_t* reserved) {
   if (!plan || !in || !out) return MI355Q_ERR_INVALID_PLAN;
   if (in->n_frags < 0 || (in->n_frags > 0 && (!in->col_buffers || !in->num_rows)))
     return MI355Q_ERR_INVALID_PLAN;
   *out = nullptr;
+  {  // a step left in flight by mi355q_execute_async owns the device workspace: finish it first
+    DeviceCtx& c0 = ctx_of(in->device_id);
+    std::lock_guard<std::recursive_mutex> lk0(c0.mu);
+    if (c0.inflight) {
+      DeviceGuard g0(in->device_id);
+      drain_inflight(c0);
+    }
+  }
   mi355q_exec_options o{};
   if (opts) o = *opts;
-  set_debug_knobs(o.reserved[0], o.reserved[1]);
-  if (plan->n_exprs != 0) return execute_projected(plan, in, o, out, report);
+  {
+    TuneKnobs k;
+    k.blocks_per_cu = o.tune_blocks_per_cu;
+    k.probe_keyed_passes = o.probe_keyed_passes;
+    k.pass_rows = o.pass_rows;
+    k.flags = o.flags;
+    set_tune_knobs(k);
+  }
+  if (plan->n_exprs != 0) {
+    if (reserved) {  // the step proper runs on the lowered plan: reserve for that
+      mi355q_plan lp;
+      if (int32_t e = lower_exprs(*plan, &lp, nullptr)) return e;
+      return execute_impl(&lp, in, &o, out, report, nullptr, reserved);
+    }
+    return execute_projected(plan, in, o, out, report);
+  }
 
-  Trace tr;
+  Trace tr((o.flags & MI355Q_OPT_TRACE) != 0);
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;
   DevPlan d;
@@ -1330,6 +1537,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     pr.output_columnar_hint = MI355Q_OUTPUT_ROWWISE_COLUMNAR_DECISIONS;
     mi355q_exec_options orw = o;
     orw.out_buffer = nullptr;
+    if (reserved) return execute_impl(&pr, in, &orw, out, report, nullptr, reserved);
     RowTwin t;
     if (int32_t e = mi355q_execute(&pr, in, &orw, &t.tw, report)) return e;
     const mi355q_qmd& qr = t.tw->qmd;
@@ -1359,6 +1567,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     if (q8.slot_width != 8 || q8.entry_count != q.entry_count || q8.key_bytes != q.key_bytes ||
         q8.slot_count != q.slot_count)
       return MI355Q_ERR_UNSUPPORTED;
+    if (reserved) return execute_impl(&p8, in, &o, out, report, nullptr, reserved);
     DeviceCtx& ctx = ctx_of(in->device_id);
     std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
     const int64_t need = q8.entry_count * (int64_t)q8.row_size;
@@ -1398,7 +1607,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     return MI355Q_OK;
   }
 
-  if (!o.force_generic && in->n_frags > 0) {
+  if (!o.force_generic && in->n_frags > 0 && !reserved) {
     const int32_t e = execute_packed_multi(plan, in, o, q, d, n_cus, out, report);
     if (e != kNotTaken) return e;
     *out = nullptr;
@@ -1471,7 +1680,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   FragView fv{d_cols, d_rows, in->col_buffers, in->num_rows, nf, nc, total_rows, max_frag_rows};
 
   // ---- plan-time kernel selection (a fixed family; no JIT)
-  enum { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART, K_JOIN_PROBE } kind = K_GENERIC;
+  StepKind kind = K_GENERIC;
   JoinPayloadView pay{};
   if (!o.force_generic && nf > 0) {
     if (scan_count_eligible(d, fv)) kind = K_SCAN_COUNT;
@@ -1488,7 +1697,7 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   // joins that read the inner side / one-to-many tables / LEFT joins over a large outer table: the
   // payload probe (per-key aggregated payload of the perfect table in LDS).  The semi-join shapes
   // keep their 1-bit-per-key member above.
-  if (!o.force_generic && nf > 0 && kind != K_JOIN_PART && o.kernel_variant != 1 && plan->join_table &&
+  if (!o.force_generic && nf > 0 && kind != K_JOIN_PART && o.kernel_variant != 1 && plan->join_table && !reserved &&
       d.join_col >= 0 && (o.kernel_variant == 3 || total_rows >= ((int64_t)16 << 20))) {
     int wcol = -1, l2 = 0;
     if (join_probe_wants(d, fv, &wcol, &l2)) {
@@ -1497,8 +1706,9 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
       std::lock_guard<std::mutex> pl(jt->pay_mu);
       const int64_t entries = jt->entry_count;
       bool ok = true;
-      const bool have = l2 ? (jt->pay16_built && (!inner || jt->pay16_col == inner))
-                           : (jt->pay_cnt && (!inner || jt->pay_col == inner));
+      // a cached payload is only as good as the column it was derived from: same address AND same generation
+      const bool have = l2 ? (jt->pay16_built && (!inner || (jt->pay16_col == inner && jt->pay16_version == in->inner_version)))
+                           : (jt->pay_col_built && (!inner || (jt->pay_col == inner && jt->pay_version == in->inner_version)));
       if (!have) {
         // (re)build for this inner column, in the layout the chosen mode reads
         hipEvent_t b0 = nullptr, b1 = nullptr;
@@ -1533,9 +1743,12 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
             if (l2) {
               jt->pay16_built = true;
               jt->pay16_col = inner;
+              jt->pay16_version = in->inner_version;
               jt->pay16_has_nulls = h_flags & 1;
             } else {
+              jt->pay_col_built = true;
               jt->pay_col = inner;
+              jt->pay_version = in->inner_version;
               jt->pay_has_nulls = h_flags & 1;
             }
             if (b0 && b1) (void)hipEventElapsedTime(&jt->pay_build_ms, b0, b1);
@@ -1606,6 +1819,10 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   }
 
   tr.mark("scratch allocated");
+  if (reserved) {  // mi355q_reserve_workspace: nothing is launched
+    *reserved = ctx.scratch_bytes;
+    return MI355Q_OK;
+  }
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
   // the partitioned member writes every row of the table itself (empty rows included)
   const bool self_init = kind == K_BASELINE_FAST && nf > 0 &&
@@ -1647,71 +1864,52 @@ int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   tr.mark("launched");
 
-  int32_t h_err[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
-  uint32_t h_spills = 0;
-  if (st.spill_counter32) {
-    HIP_TRY(hipMemcpyAsync(&h_spills, st.spill_counter32, sizeof(h_spills), hipMemcpyDeviceToHost, s));
-  }
-  HIP_TRY(hipStreamSynchronize(s));
-  tr.mark("synchronized");
-  st.spilled_rows = (int64_t)h_spills;
-  if (h_err[1] && tr.on) std::fprintf(stderr, "[mi355q] partitioned family gave up (code %d, spills %u): re-running with the direct kernel\n", h_err[1], h_spills);
-  if (h_err[1] && kind == K_JOIN_PART) {
-    // the partitioned probe ran out of spill space (extreme skew): redo with the direct probe
-    HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
-    HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
-    HIP_TRY(launch_join_sum(d, fv, res->buf, n_cus, s, &st));
-    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
-  if (h_err[1] && kind == K_JOIN_PROBE) {
-    // the payload probe ran out of spill space (extreme skew): redo the step with the row kernel
-    HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
-    HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
-    HIP_TRY(launch_generic(d, q.idx_target_as_key, make_row_init(q), d_cols, d_rows, nf, max_frag_rows, res->buf, d_err,
-                           n_cus, s));
-    st.kernel_name = "k_generic";
-    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
-  if (h_err[1] && kind == K_BASELINE_FAST) {
-    // the partitioned family ran out of spill space (extreme skew): redo the step with the
-    // direct-atomic member of the same family
-    HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
-    HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
-    HIP_TRY(launch_baseline_fast(d, fv, res->buf, d_err, nullptr, 0, 0, 1, n_cus, s, &st));
-    HIP_TRY(hipMemcpyAsync(h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
-
-  if (report) {
-    std::memset(report, 0, sizeof(*report));
-    std::snprintf(report->kernel_name, sizeof(report->kernel_name), "%s",
-                  st.kernel_name ? st.kernel_name : "");
-    (void)hipEventElapsedTime(&report->total_ms, ev_start, ev_stop);
-    if (st.n_events_used > 0) {
-      float acc = 0.f;
-      for (int i = 0; i + 1 < st.n_events_used; i += 2) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, ev_pool[i], ev_pool[i + 1]) == hipSuccess) acc += ms;
-      }
-      report->kernel_ms = acc;
-    } else if (st.n_launches > 0 && nf > 0) {
-      if (hipEventElapsedTime(&report->kernel_ms, st.k_start, st.k_stop) != hipSuccess)
-        report->kernel_ms = 0.f;
+  TailState* tail = new (std::nothrow) TailState();
+  if (!tail) return MI355Q_ERR_OUT_OF_CPU_MEM;
+  tail->q = q;
+  tail->d = d;
+  tail->kind = kind;
+  tail->st = st;
+  tail->res = res;
+  tail->d_err = d_err;
+  tail->d_cols = d_cols;
+  tail->d_rows = d_rows;
+  tail->h_cols.assign(in->col_buffers, in->col_buffers + (size_t)nf * nc);
+  tail->h_rows.assign(in->num_rows, in->num_rows + nf);
+  tail->nf = nf;
+  tail->nc = nc;
+  tail->n_cus = n_cus;
+  tail->total_rows = total_rows;
+  tail->max_frag_rows = max_frag_rows;
+  tail->alg_bytes = algorithmic_bytes(*plan, *in);
+  tail->s = s;
+  tail->ev_start = ev_start;
+  tail->ev_stop = ev_stop;
+  tail->ev_pool = ev_pool;
+  tail->trace = tr.on;
+  if (pend) {  // mi355q_execute_async: the rest runs in mi355q_wait (or before the next call on this device)
+    mi355q_pending* p = new (std::nothrow) mi355q_pending();
+    if (!p) {
+      delete tail;
+      return MI355Q_ERR_OUT_OF_CPU_MEM;
     }
-    report->n_launches = st.n_launches;
-    report->variant = st.variant;
-    report->rows_scanned = total_rows;
-    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
-    report->spilled_rows = st.spilled_rows;
+    p->tail = tail;
+    p->device_id = in->device_id;
+    ctx.inflight = p;
+    *pend = p;
+    rg.r = nullptr;
+    *out = res;
+    return MI355Q_OK;
   }
-  if (h_err[0]) return h_err[0];
+  const int32_t code = finish_step(*tail, report);
+  delete tail;
+  tr.mark("synchronized");
+  if (code) return code;
   rg.r = nullptr;
   *out = res;
   return MI355Q_OK;
 }
+}  // namespace
 
 // ------------------------------------------------------------------------------- joins
 namespace {
@@ -1853,6 +2051,35 @@ int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream, mi355q_joi
   if (h_err) return h_err;
   jg.j = nullptr;
   *out = jt;
+  return MI355Q_OK;
+}
+
+int32_t mi355q_join_invalidate_payload(mi355q_join_table* t) {
+  if (!t) return MI355Q_ERR_INVALID_PLAN;
+  std::lock_guard<std::mutex> pl(t->pay_mu);
+  // the buffers are kept (the next build reuses them); only their validity goes
+  t->pay16_built = false;
+  t->pay_col_built = false;
+  t->pay16_col = nullptr;
+  t->pay_col = nullptr;
+  return MI355Q_OK;
+}
+
+int32_t mi355q_join_payload_info(const mi355q_join_table* t, int64_t* bytes, float* build_ms, int64_t* inner_version) {
+  if (!t) return MI355Q_ERR_INVALID_PLAN;
+  mi355q_join_table* jt = const_cast<mi355q_join_table*>(t);
+  std::lock_guard<std::mutex> pl(jt->pay_mu);
+  int64_t b = 0;
+  const int64_t n = t->entry_count;
+  if (t->pay_cnt) b += n * 4;
+  if (t->pay_wsum) b += n * 8;
+  if (t->pay_wnn) b += n * 4;
+  if (t->pay16) b += n * 16;
+  if (t->pay8) b += n * (t->pay_kkeys ? 16 : 8);
+  if (t->pay_kkeys) b += n * 8;
+  if (bytes) *bytes = b;
+  if (build_ms) *build_ms = t->pay_build_ms;
+  if (inner_version) *inner_version = t->pay16_built ? t->pay16_version : t->pay_version;
   return MI355Q_OK;
 }
 

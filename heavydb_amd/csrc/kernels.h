@@ -32,10 +32,16 @@ struct LaunchStats {
   uint32_t* spill_counter32 = nullptr;  // device word (read back by the caller)
 };
 
-// tuning knobs for experiments (exec_options.reserved[0..1]); 0 = built-in choice
-int debug_blocks_per_cu();
-int debug_part_p();
-void set_debug_knobs(int blocks_per_cu, int part_p);
+// testing / tuning knobs of one mi355q_execute call (mi355q_exec_options; thread-local while the call runs —
+// derived plans re-enter mi355q_execute with the same options).  Nothing reads the environment.
+struct TuneKnobs {
+  int blocks_per_cu = 0;
+  int probe_keyed_passes = 0;
+  int64_t pass_rows = 0;
+  uint32_t flags = 0;  // MI355Q_OPT_*
+};
+const TuneKnobs& tune_knobs();
+void set_tune_knobs(const TuneKnobs& k);
 
 // ---- generic family (kernels_generic.hip)
 hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,

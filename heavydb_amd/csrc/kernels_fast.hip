@@ -380,7 +380,7 @@ __global__ __launch_bounds__(kBlock) void k_join_sum(const int8_t* const* __rest
 
 // ---------------------------------------------------------------------------- host side
 inline int stream_grid(int n_cus, int blocks_per_cu, int64_t total_rows) {
-  const int dbg = debug_blocks_per_cu();
+  const int dbg = tune_knobs().blocks_per_cu;
   if (dbg > 0) blocks_per_cu = dbg;
   int64_t want = (total_rows / 4 + kBlock - 1) / kBlock;
   int64_t cap = (int64_t)n_cus * blocks_per_cu;

@@ -767,21 +767,9 @@ inline int grid_for(int64_t work_items, int max_blocks = 2048) {
 
 }  // namespace
 
-static thread_local int g_dbg_bpc = 0, g_dbg_p = 0;
-int debug_blocks_per_cu() {
-  if (g_dbg_bpc) return g_dbg_bpc;
-  const char* e = std::getenv("MI355Q_DBG_BPC");  // tuning experiments only
-  return e ? std::atoi(e) : 0;
-}
-int debug_part_p() {
-  if (g_dbg_p) return g_dbg_p;
-  const char* e = std::getenv("MI355Q_DBG_MODE");  // timing experiments only
-  return e ? std::atoi(e) : 0;
-}
-void set_debug_knobs(int blocks_per_cu, int part_p) {
-  g_dbg_bpc = blocks_per_cu;
-  g_dbg_p = part_p;
-}
+static thread_local TuneKnobs g_knobs;
+const TuneKnobs& tune_knobs() { return g_knobs; }
+void set_tune_knobs(const TuneKnobs& k) { g_knobs = k; }
 
 hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,
                               hipStream_t s) {

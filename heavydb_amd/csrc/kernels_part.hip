@@ -52,7 +52,6 @@ constexpr int kMaxInt = 8;             // internal (LDS) partial slots per group
 constexpr int kMaxSub = 4;             // sub-ranges per partition
 // phase 2 pair counters: 4 KB of rendezvous words (one per workgroup), then one progress word per wave
 constexpr int kPairCtrBytes = 4096 + 256 * 16 * 4;
-constexpr int kPairPaceDefault = 0;
 constexpr uint32_t kSpillMin = 1u << 22;  // spill list: at least 4 M partial rows, else 1/16 of a chunk's rows
 
 struct alignas(16) Rec {
@@ -856,8 +855,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
                                                                 PartSlots ps, TableArgs tab, SpillList sl,
                                                                 int merge, uint32_t chunk_records_max,
                                                                 unsigned long long* __restrict__ dbg,
-                                                                unsigned int* __restrict__ pair_ctr, SliceMerge ms,
-                                                                int pace_w) {
+                                                                unsigned int* __restrict__ pair_ctr, SliceMerge ms) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   int64_t* const lkeys = (int64_t*)smem_raw;
   uint32_t* bitmap = (uint32_t*)(smem_raw + g.lds_table_bytes);  // [(S2 + 31) / 32]
@@ -934,11 +932,6 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
     }
   };
 
-  // per-wave progress words of the pair (see the record loop)
-  bool pacing = pace_w > 0 && pair_ctr && paired && R == 2 && cnt != nullptr;
-  unsigned int my_step = 1, twin = 0xffffff00u;  // (first check passes: nothing loaded yet)
-  unsigned int* const my_prog = pair_ctr ? pair_ctr + 1024 + (size_t)blockIdx.x * 16 + (t >> 6) : nullptr;
-  unsigned int* const twin_prog = pair_ctr ? pair_ctr + 1024 + (size_t)(blockIdx.x ^ 8u) * 16 + (t >> 6) : nullptr;
   for (int it = 0;; ++it) {
     int p, r;
     if (paired) {
@@ -1057,32 +1050,6 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
         Rec c0 = run[at(lane)], c1 = run[at(lane + 64)], c2 = run[at(lane + 128)], c3 = run[at(lane + 192)];
         for (uint32_t base = 0; base < n; base += 256) {
           const uint32_t i = base + lane, nx = i + 256;
-          // Pair pacing (speed only): wave w of both sub-range workgroups of a partition reads the SAME
-          // records in the same order.  Each publishes the number of steps it has done and stays at most
-          // pace_w steps ahead of its twin, so the later of the two finds the lines in the XCD's L2.
-          // The twin's word is loaded one step before it is looked at (its latency hides behind a whole
-          // step and the check needs no wait the record loads do not need anyway); the spin loop is the
-          // rare path.
-          if (pacing) {
-            if (twin + (unsigned int)pace_w < my_step) {
-              unsigned int spins = 0;
-              do {
-                __builtin_amdgcn_s_sleep(2);
-                twin = __builtin_nontemporal_load((const MQ_GLOBAL unsigned int*)twin_prog);
-                if (++spins > (1u << 12)) {  // the twin is not there (not co-resident / far behind): stop pacing
-                  pacing = false;
-                  break;
-                }
-              } while (twin + (unsigned int)pace_w < my_step);
-            }
-            // plain accesses on purpose: both workgroups sit behind the same L2, a store writes through the
-            // CU's L1 and the streaming records evict the polled line from the reader's L1 within a step; an
-            // agent-scope load would go to memory and — loads return in order — hold back the record loads
-            // issued after it (measured: records phase 2 x slower).  A stale value only costs pacing.
-            if (lane == 0) __builtin_nontemporal_store(my_step, (MQ_GLOBAL unsigned int*)my_prog);  // (volatile would wait vmcnt(0))
-            twin = __builtin_nontemporal_load((const MQ_GLOBAL unsigned int*)twin_prog);
-            ++my_step;
-          }
           const Rec n0 = run[at(nx)], n1 = run[at(nx + 64)], n2 = run[at(nx + 128)], n3 = run[at(nx + 192)];
           insert4(c0, c1, c2, c3, i < n ? (n - i + 63) / 64 : 0u);
           c0 = n0; c1 = n1; c2 = n2; c3 = n3;
@@ -2287,13 +2254,11 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   }
   (void)hipFuncSetAttribute((const void*)agg_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)h.lds2);
-  // MI355Q_TRACE: per-phase cycle counters of phase 2 live in the spill header's tail
-  unsigned long long* dbg = std::getenv("MI355Q_TRACE") ? (unsigned long long*)(spill_base + 64) : nullptr;
-  unsigned int* pair_ctr = (n_cus <= 256 && !std::getenv("MI355Q_NO_PAIR_RENDEZVOUS"))
+  // MI355Q_OPT_TRACE: per-phase cycle counters of phase 2 live in the spill header's tail
+  const uint32_t opt_flags = tune_knobs().flags;
+  unsigned long long* dbg = (opt_flags & MI355Q_OPT_TRACE) ? (unsigned long long*)(spill_base + 64) : nullptr;
+  unsigned int* pair_ctr = (n_cus <= 256 && !(opt_flags & MI355Q_OPT_NO_PAIR_RENDEZVOUS))
                                ? (unsigned int*)((char*)scratch + h.rec_bytes + h.cnt_bytes - kPairCtrBytes) : nullptr;
-  // pacing window of the pair (steps of 256 records per wave a workgroup may run ahead of its partner)
-  int pace_w = kPairPaceDefault;
-  if (const char* e = std::getenv("MI355Q_PAIR_WINDOW")) pace_w = std::atoi(e);
   ScatterArgs sa{};
   sa.P = h.g.P;
   sa.lgL = h.g.lgL;
@@ -2338,7 +2303,7 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     }
     hipLaunchKernelGGL(agg_kernel, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, recs, cnt, h.ps,
                        tab, sl, chunk > 0 ? 1 : 0, (uint32_t)(rows > 0xfff00000ll ? 0xfff00000ll : rows), dbg,
-                       pair_ctr, SliceMerge{}, pace_w);
+                       pair_ctr, SliceMerge{});
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2455,7 +2420,7 @@ hipError_t launch_slice_merge(const DevPlan& p, int64_t* out, const int64_t* con
   const uint32_t big_from = 0xffffffffu - 0xffffffffu / (uint32_t)(n_src + 1);
   hipLaunchKernelGGL(agg_kernel, dim3(grid2), dim3(kPartBlock), h.lds2, s, h.g, (const Rec*)nullptr,
                      (const uint32_t*)nullptr, h.ps, tab, sl, 0, big_from, (unsigned long long*)nullptr,
-                     (unsigned int*)nullptr, ms, 0);
+                     (unsigned int*)nullptr, ms);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
   (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2760,8 +2725,8 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
     if (!pay.kkeys || (!pay.pay16 && !pay.pay8)) return false;
     R = (uint32_t)(((size_t)S1 * 16 + ((size_t)7 << 19) - 1) / ((size_t)7 << 19));
     if (R < 1) R = 1;
-    if (const char* e = std::getenv("MI355Q_PROBE_KEYED_R")) {  // tests: several passes on a small table
-      const int v = std::atoi(e);
+    {  // tests: several passes on a small table
+      const int v = tune_knobs().probe_keyed_passes;
       if (v >= 1 && v <= 4) R = (uint32_t)v;
     }
     if (R > 4) return false;
@@ -2947,7 +2912,7 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
       ev_i += 2;
     }
     st->n_launches += 1;
-    unsigned int* pace = (h.l2_mode && !std::getenv("MI355Q_PROBE_NO_PACING")) ? (unsigned int*)(acc2 + 2) : nullptr;
+    unsigned int* pace = (h.l2_mode && !(tune_knobs().flags & MI355Q_OPT_PROBE_NO_PACING)) ? (unsigned int*)(acc2 + 2) : nullptr;
     if (pace) {
       e = hipMemsetAsync(pace, 0, 64, s);
       if (e != hipSuccess) return e;

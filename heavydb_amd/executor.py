@@ -242,6 +242,8 @@ class FetchResult:
     inner_num_rows: int = 0
     device_id: int = 0
     keepalive: list = field(default_factory=list)  # owners of the memory (e.g. tensors)
+    inner_version: int = 0   # generation of the inner columns' content (mi355q_inputs.inner_version): bump it when
+                             # an inner column is rewritten in place, or its memory is reused for another column
 
     @staticmethod
     def from_tensors(frag_cols: Sequence[Sequence["object"]], inner_cols: Sequence["object"] = (),
@@ -274,6 +276,7 @@ class FetchResult:
         inp.num_rows = C.cast(rows, C.POINTER(C.c_int64))
         inp.inner_col_buffers = C.cast(inner, C.POINTER(C.c_void_p))
         inp.inner_num_rows = self.inner_num_rows
+        inp.inner_version = int(self.inner_version)
         return inp, [flat, rows, inner]
 
 
@@ -286,6 +289,15 @@ class HashJoin:
     def __init__(self, handle: int):
         self.handle = handle
         self._lib = capi.load_library()
+
+    def invalidate_payload(self) -> None:
+        """Drop the per-inner-column payloads the table caches (see FetchResult.inner_version)."""
+        check(self._lib.mi355q_join_invalidate_payload(self.handle), "join_invalidate_payload")
+
+    def payload_info(self) -> dict:
+        b, ms, ver = C.c_int64(), C.c_float(), C.c_int64()
+        check(self._lib.mi355q_join_payload_info(self.handle, C.byref(b), C.byref(ms), C.byref(ver)), "join_payload_info")
+        return dict(bytes=b.value, build_ms=ms.value, inner_version=ver.value)
 
     @staticmethod
     def getInstance(key_buffer, num_rows: int, key_type, key_range: ExpressionRange,
@@ -525,7 +537,8 @@ class Executor:
     def executeWorkUnit(self, ra_exe_unit: RelAlgExecutionUnit, fetch_result: FetchResult,
                         stream: int | None = None, out_buffer: int | None = None,
                         force_generic: bool = False, kernel_variant: int = 0,
-                        scratch_bytes: int = 0, allow_retry: bool = True) -> ResultSet:
+                        scratch_bytes: int = 0, allow_retry: bool = True, pass_rows: int = 0,
+                        probe_keyed_passes: int = 0, flags: int = 0, tune_blocks_per_cu: int = 0) -> ResultSet:
         """Runs the step.  A negative code (ran out of group slots) doubles the baseline
         table and retries, as RelAlgExecutor::executeWorkUnit does after its cardinality
         estimation (RelAlgExecutor.cpp:4143-4145, :4194-4231)."""
@@ -540,6 +553,10 @@ class Executor:
                 opts.force_generic = int(force_generic)
                 opts.kernel_variant = kernel_variant
                 opts.scratch_bytes = scratch_bytes
+                opts.pass_rows = pass_rows
+                opts.probe_keyed_passes = probe_keyed_passes
+                opts.flags = flags
+                opts.tune_blocks_per_cu = tune_blocks_per_cu
                 out = C.c_void_p()
                 rep = capi.ExecReport()
                 code = self._lib.mi355q_execute(C.byref(plan), C.byref(inp), C.byref(opts),
@@ -560,6 +577,71 @@ class Executor:
         finally:
             if not allow_retry:
                 ra_exe_unit.max_groups_buffer_entry_guess = guess
+
+
+    def _opts(self, stream, out_buffer, force_generic, kernel_variant, scratch_bytes, pass_rows=0,
+              probe_keyed_passes=0, flags=0, tune_blocks_per_cu=0) -> capi.ExecOptions:
+        opts = capi.ExecOptions()
+        opts.stream = stream
+        opts.out_buffer = out_buffer
+        opts.force_generic = int(force_generic)
+        opts.kernel_variant = kernel_variant
+        opts.scratch_bytes = scratch_bytes
+        opts.pass_rows = pass_rows
+        opts.probe_keyed_passes = probe_keyed_passes
+        opts.flags = flags
+        opts.tune_blocks_per_cu = tune_blocks_per_cu
+        return opts
+
+    def executeWorkUnitAsync(self, ra_exe_unit: RelAlgExecutionUnit, fetch_result: FetchResult,
+                             stream: int | None = None, out_buffer: int | None = None, force_generic: bool = False,
+                             kernel_variant: int = 0, scratch_bytes: int = 0, flags: int = 0):
+        """mi355q_execute_async: the step is enqueued and the call returns; the ResultSet may be handed to
+        stream-ordered consumers on the same stream at once, `wait()` on the returned PendingStep gives the
+        error code (raised) and the report.  No retry ladder: an out-of-slots table is the caller's to grow."""
+        plan = ra_exe_unit.to_plan()
+        inp, keep = fetch_result.to_c(plan.n_cols)
+        opts = self._opts(stream, out_buffer, force_generic, kernel_variant, scratch_bytes, flags=flags)
+        out, pend = C.c_void_p(), C.c_void_p()
+        code = self._lib.mi355q_execute_async(C.byref(plan), C.byref(inp), C.byref(opts), C.byref(out), C.byref(pend))
+        del keep
+        if code and not pend.value:
+            raise capi.Mi355qError(code, "execute_async")
+        rs = ResultSet(out.value, capi.ExecReport()) if out.value else None
+        return rs, PendingStep(self._lib, pend.value, rs)
+
+    def reserveWorkspace(self, ra_exe_unit: RelAlgExecutionUnit, fetch_result: FetchResult, scratch_bytes: int = 0,
+                         kernel_variant: int = 0) -> int:
+        """mi355q_reserve_workspace: allocate what the step will need from the per-device workspace now (the
+        cold first call of a 10 B-row GROUP BY otherwise spends 1 - 2 s in hipMalloc).  Returns the bytes held."""
+        plan = ra_exe_unit.to_plan()
+        inp, keep = fetch_result.to_c(plan.n_cols)
+        opts = self._opts(None, None, False, kernel_variant, scratch_bytes)
+        got = C.c_int64()
+        check(self._lib.mi355q_reserve_workspace(C.byref(plan), C.byref(inp), C.byref(opts), C.byref(got)),
+              "reserve_workspace")
+        del keep
+        return got.value
+
+
+class PendingStep:
+    """A step enqueued by Executor.executeWorkUnitAsync (mi355q_pending)."""
+
+    def __init__(self, lib, handle, result_set):
+        self._lib, self.handle, self.result_set = lib, handle, result_set
+
+    def wait(self):
+        """Blocks until the step has finished; raises on an error code; returns the ResultSet (with its report)."""
+        if self.handle is None:
+            return self.result_set
+        rep = capi.ExecReport()
+        code = self._lib.mi355q_wait(self.handle, C.byref(rep))
+        self.handle = None
+        if code:
+            raise capi.Mi355qError(code, "wait")
+        if self.result_set is not None:
+            self.result_set.report = rep
+        return self.result_set
 
 
 def generate_column(dst_ptr: int, n_rows: int, kind: int, seed: int, a: int = 0, b: int = 0,

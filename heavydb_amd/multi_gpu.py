@@ -126,7 +126,20 @@ def merge_keyed(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool 
         return _gather_to_rank0(shard, shard, dist, torch, group, rq) if gather_to_rank0 else shard
     global LAST_KEYED_PATH
     LAST_KEYED_PATH = "partition"
-    if slice_exchange_ok(q, world) and hasattr(shard, "boundary_pads"):
+    # The slice exchange sends table rows IN PLACE with split sizes every rank computes from ITS OWN entry count:
+    # every rank must hold a table of the same geometry.  Executor.executeWorkUnit doubles the entry guess per rank
+    # when a shard runs out of slots, so skewed shards can end up with different table sizes — ranks would then take
+    # different collective sequences or pass mismatched split sizes (a hang, or a silently wrong merge).  One tiny
+    # all-reduce settles it: the slices path only runs when (entry_count, row_size, slice-path-capable) agree on
+    # every rank; the partition path below re-hashes rows and tolerates any mix of table sizes.
+    mine = slice_exchange_ok(q, world) and hasattr(shard, "boundary_pads")
+    dev = shard.buffer().device   # the collective's tensors live where the table lives (RCCL: HBM; gloo: host)
+    geom = torch.tensor([q.entry_count, -q.entry_count, q.row_size, -q.row_size, 1 if mine else 0], dtype=torch.int64,
+                        device=dev)
+    dist.all_reduce(geom, op=dist.ReduceOp.MIN, group=group)
+    g = [int(x) for x in geom.cpu().tolist()]
+    agree = g[0] == -g[1] and g[2] == -g[3] and g[4] == 1
+    if agree:
         out = _merge_keyed_by_slices(shard, dist, torch, group)
         if out is not None:
             LAST_KEYED_PATH = "slices"

@@ -386,6 +386,12 @@ typedef struct mi355q_inputs {
    * tables as one "all fragments" buffer, ColumnFetcher::getAllTableColumnFragments) */
   const void* const* inner_col_buffers; /* [n_inner_cols] */
   int64_t inner_num_rows;
+  /* Generation of the inner columns' CONTENT.  A join table keeps, per inner column, payloads derived from the
+   * column's values (per-key counts / sums for the payload probes of large outer tables).  They are reused
+   * while (device pointer, inner_version) are unchanged: a caller that rewrites an inner column in place — or
+   * frees it and lets a new column land on the same address — must pass a different inner_version (or call
+   * mi355q_join_invalidate_payload); 0 is a valid version like any other. */
+  int64_t inner_version;
 } mi355q_inputs;
 
 typedef struct mi355q_result mi355q_result; /* opaque: QueryMemoryDescriptor + buff_ */
@@ -399,8 +405,19 @@ typedef struct mi355q_exec_options {
   int32_t kernel_variant; /* 0 = plan-time choice; >0 selects a specific variant of
                              the chosen family (testing / tuning) */
   int64_t scratch_bytes;  /* cap for partition scratch (0 = default) */
-  int32_t reserved[4];
+  /* testing / tuning knobs: explicit fields of the ABI (nothing in the library reads the environment);
+   * 0 = the built-in choice */
+  int32_t tune_blocks_per_cu;   /* workgroups per CU of the streaming kernels (experiments) */
+  int32_t probe_keyed_passes;   /* keyed payload probe: passes per partition, 1..4 (tests: several passes
+                                   on a small table) */
+  int64_t pass_rows;            /* packed-key and projected-expression routes: rows per pass (tests force
+                                   several passes; the fragments are never split) */
+  uint32_t flags;               /* MI355Q_OPT_* */
+  int32_t reserved;
 } mi355q_exec_options;
+#define MI355Q_OPT_TRACE 1u              /* host-side wall-clock marks and phase-2 cycle counters on stderr */
+#define MI355Q_OPT_NO_PAIR_RENDEZVOUS 2u /* partitioned GROUP BY phase 2: no rendezvous of the sub-range pair */
+#define MI355Q_OPT_PROBE_NO_PACING 4u    /* L2 payload probe: no per-XCD partition pacing */
 
 /* per-call timing/selection report (what launchGpuCode logs,
  * QueryExecutionContext.cpp:334,364,579) */
@@ -446,6 +463,29 @@ int64_t mi355q_qmd_slot_col_offset(const mi355q_qmd* qmd, int32_t s);
 int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* inputs,
                        const mi355q_exec_options* opts, mi355q_result** out,
                        mi355q_exec_report* report);
+
+/* Stream-ordered execute (the reference's launch is synchronous, DeviceKernel.cpp:84; one process per GPU with
+ * collectives behind the step wants the opposite): every kernel of the step is enqueued on opts->stream (or the
+ * library's stream) and the call returns without waiting for the device.  *out may be handed at once to
+ * stream-ordered consumers ON THE SAME STREAM (mi355q_shard_pads, mi355q_shard_merge_*, a collective enqueued
+ * behind them); everything that needs the host — the error code, the re-run with the direct member after a
+ * spill overflow, the report — happens in mi355q_wait, which must be called exactly once per pending handle
+ * (it frees it).  On an error from mi355q_wait the result handle is still the caller's to free.  One step per
+ * device can be in flight; any other mi355q_execute[_async] on the device finishes it first.  Routes that need
+ * the host mid-step (projected expressions, packed multi-column keys, columnar / 4-byte-slot results, the
+ * first build of a join payload) complete inside the call. */
+typedef struct mi355q_pending mi355q_pending;
+int32_t mi355q_execute_async(const mi355q_plan* plan, const mi355q_inputs* inputs,
+                             const mi355q_exec_options* opts, mi355q_result** out,
+                             mi355q_pending** pending);
+int32_t mi355q_wait(mi355q_pending* pending, mi355q_exec_report* report);
+
+/* Allocates (and keeps, until mi355q_release_workspace) what a step of this plan over inputs of this shape needs
+ * from the per-device workspace — the partition scratch above all: tens of GB for a 10 B-row GROUP BY, a
+ * hipMalloc of that size takes 1 - 2 s — so that the first mi355q_execute does not pay for it.  `inputs` only
+ * has to carry device_id, n_frags, num_rows (and the join's inner_num_rows); the column pointers may be NULL. */
+int32_t mi355q_reserve_workspace(const mi355q_plan* plan, const mi355q_inputs* inputs,
+                                 const mi355q_exec_options* opts, int64_t* reserved_bytes);
 
 /* ---- result set ---- */
 int32_t mi355q_result_create(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
@@ -561,6 +601,12 @@ void mi355q_join_free(mi355q_join_table* t);
 int32_t mi355q_join_info(const mi355q_join_table* t, int32_t* hash_type, int64_t* entry_count,
                          int64_t* min_key, int64_t* max_key, void** device_ptr,
                          int64_t* bytes, float* build_ms);
+/* Drops every payload the table caches about inner columns (see mi355q_inputs.inner_version); the next step
+ * that wants one rebuilds it. */
+int32_t mi355q_join_invalidate_payload(mi355q_join_table* t);
+/* What the payload cache holds: device bytes, the time the last build took (a first-run cost of the payload
+ * probes that is NOT inside any step's kernel_ms), and the inner_version it was built for. */
+int32_t mi355q_join_payload_info(const mi355q_join_table* t, int64_t* bytes, float* build_ms, int64_t* inner_version);
 /* key component count and width (bytes) of a keyed table (1 / 8 for perfect tables) */
 int32_t mi355q_join_key_shape(const mi355q_join_table* t, int32_t* key_components,
                               int32_t* component_width);

@@ -803,13 +803,12 @@ def test_packed_multi_column_route_at_scale(torch_cuda, oracle, passes, monkeypa
     through size-independent properties — COUNT sums to the rows that pass the filter, the
     groups are exactly the expected pairs, the table is a valid image of the reference's
     probing over the 16 key bytes — and against the row kernel's table on a 16 M-row prefix.
-    With MI355Q_PACK_PASS_ROWS the input is cut into passes whose tables are reduced."""
+    With exec_options.pass_rows the input is cut into passes whose tables are reduced."""
     from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, InputColDescriptor, Qual,
                                       RelAlgExecutionUnit, TargetExpr, generate_column)
     from tests.helpers import key_matrix
     torch = torch_cuda
-    if passes == "several_passes":
-        monkeypatch.setenv("MI355Q_PACK_PASS_ROWS", str(70_000_000))
+    pass_rows = 70_000_000 if passes == "several_passes" else 0
     n, frag = 200_000_000, 32_000_000
     n_a, n_b = 200_000, 5
     a = torch.empty(n, dtype=torch.int64, device="cuda")
@@ -839,7 +838,7 @@ def test_packed_multi_column_route_at_scale(torch_cuda, oracle, passes, monkeypa
             o += m
         return FetchResult(bufs, nr, keepalive=cols)
     ex = Executor(0)
-    rs = ex.executeWorkUnit(ra, fetch(n), allow_retry=False)
+    rs = ex.executeWorkUnit(ra, fetch(n), allow_retry=False, pass_rows=pass_rows)
     assert rs.report.kernel_name.decode() == "k_part_scatter"
     q = rs.getQueryMemDesc()
     assert q.desc_type == capi.GROUP_BY_BASELINE_HASH and q.group_col_count == 2 and q.key_width == 8

@@ -87,13 +87,9 @@ def test_cfg2_full_size_vs_oracle(torch_cuda, oracle, keyless):
     compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
 
 
-# pace: MI355Q_PAIR_WINDOW, the experimental pacing of phase 2's workgroup pairs (default 0 = off):
-# it must never change a result
-@pytest.mark.parametrize("filtered,pace", [(True, 0), (False, 0), (True, 2)])
-def test_cfg3_one_billion_rows_vs_oracle(torch_cuda, oracle, monkeypatch, filtered, pace):
+@pytest.mark.parametrize("filtered", [True, False])
+def test_cfg3_one_billion_rows_vs_oracle(torch_cuda, oracle, filtered):
     from heavydb_amd import synth
-    if pace:
-        monkeypatch.setenv("MI355Q_PAIR_WINDOW", str(pace))
     from heavydb_amd.executor import Executor
     torch = torch_cuda
     n, n_keys = 1_000_000_000, 10_000_000

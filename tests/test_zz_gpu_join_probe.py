@@ -28,7 +28,7 @@ def torch_cuda():
 @pytest.mark.parametrize("one_to_many", [False, True])
 @pytest.mark.parametrize("left", [False, True])
 @pytest.mark.parametrize("shape", ["all_targets", "inner_only", "hot_key", "inner_nulls", "no_inner_col"])
-def test_payload_probe_matches_oracle(torch_cuda, oracle, one_to_many, left, shape, sparse):
+def test_payload_probe_matches_oracle(torch_cuda, oracle, one_to_many, left, shape, sparse, keyed_passes=0):
     from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, HashJoin, InputColDescriptor,
                                       RelAlgExecutionUnit, TargetExpr)
     torch = torch_cuda
@@ -76,7 +76,7 @@ def test_payload_probe_matches_oracle(torch_cuda, oracle, one_to_many, left, sha
                      [cuts[i + 1] - cuts[i] for i in range(2)], [int(dk.data_ptr()), int(dw.data_ptr())], m,
                      keepalive=dev + [dk, dw])
     ex = Executor(0)
-    rs = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=3)
+    rs = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=3, probe_keyed_passes=keyed_passes)
     assert rs.report.variant == 3 and rs.report.kernel_name.decode() == "k_part_scatter", \
         (rs.report.variant, rs.report.kernel_name)
     row = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=1)      # the row kernel / direct probe
@@ -89,8 +89,30 @@ def test_payload_probe_matches_oracle(torch_cuda, oracle, one_to_many, left, sha
     compare_buffers(q, want, rs.getStorage())
     assert np.array_equal(rs.getStorage(), row.getStorage())
     # a second call reuses the cached payload (and must not be confused by it)
-    again = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=3)
+    again = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=3, probe_keyed_passes=keyed_passes)
     assert np.array_equal(again.getStorage(), rs.getStorage())
+    if shape == "all_targets" and not keyed_passes:
+        # the inner column rewritten IN PLACE (same device pointer, new content): with a new inner_version the
+        # cached per-key payload is rebuilt; mi355q_join_invalidate_payload does the same for callers that cannot
+        # version their columns (a stale payload gave SUM(dim.w) of the old values)
+        w2 = (w * 3 + 1).astype(np.int64)
+        dw.copy_(torch.from_numpy(w2).cuda())
+        torch.cuda.synchronize()
+        ra.join_table = None
+        q2, want2, code2 = oracle.execute(ra.to_plan(), [[k[cuts[i]:cuts[i + 1]], v[cuts[i]:cuts[i + 1]]] for i in range(2)],
+                                          [dim, w2], oj, n_threads=2)
+        ra.join_table = hj
+        assert code2 == 0 and not np.array_equal(want2, want)
+        fr.inner_version = 1
+        fresh = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=3)
+        compare_buffers(q2, want2, fresh.getStorage())
+        info = hj.payload_info()
+        assert info["bytes"] > 0 and info["inner_version"] == 1
+        dw.copy_(torch.from_numpy(w).cuda())       # back to the first content under the SAME version ...
+        torch.cuda.synchronize()
+        hj.invalidate_payload()                    # ... so the cache has to be dropped explicitly
+        back = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=3)
+        compare_buffers(q, want, back.getStorage())
 
 
 def test_payload_probe_sub_ranges_and_column_switch(torch_cuda, oracle):
@@ -176,6 +198,5 @@ def test_payload_probe_l2_mode(torch_cuda, oracle, left, inner_nulls):
 def test_keyed_probe_in_several_passes(torch_cuda, oracle, monkeypatch):
     """The keyed probe with its slot range walked in 3 passes per partition (what a table too large for one
     L2-resident slice per partition gets), forced on a small table."""
-    monkeypatch.setenv("MI355Q_PROBE_KEYED_R", "3")
-    test_payload_probe_matches_oracle(torch_cuda, oracle, True, True, "all_targets", True)
-    test_payload_probe_matches_oracle(torch_cuda, oracle, False, False, "hot_key", True)
+    test_payload_probe_matches_oracle(torch_cuda, oracle, True, True, "all_targets", True, keyed_passes=3)
+    test_payload_probe_matches_oracle(torch_cuda, oracle, False, False, "hot_key", True, keyed_passes=3)
