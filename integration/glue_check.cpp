@@ -1,0 +1,433 @@
+// glue_check.cpp — native driver of the HeavyDB binding (integration/Mi355qExecutor.cpp): no Python.
+//
+// For each query an execution unit is built the way RelAlgExecutor would hand it over — Analyzer::ColumnVar /
+// Constant / UOper(kCAST) / BinOper / AggExpr objects in a RelAlgExecutionUnit, GPU_LEVEL chunk pointers in a
+// FetchResult, a QueryMemoryDescriptor for the layout self-check — run_query_mi355q runs the step through the
+// C-ABI and copies the table into ResultSet::allocateStorage()'s buffer with mi355q_result_copy_to_host, and that
+// ResultSetStorage-layout buffer is compared with what the ORACLE (oracle/liboracle.so, the CPU restatement of the
+// reference's executor) produces from a HAND-WRITTEN mi355q_plan of the same query over the same rows.  The plan
+// the binding derives is also compared with the hand-written one field by field, so a mistranslation cannot hide
+// behind both sides sharing it.  Exit code 0 = every query agreed.
+//
+//   integration/build.sh && integration/glue_check
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "Mi355qExecutor.h"
+
+extern "C" {
+int32_t orc_qmd_init(const mi355q_plan* plan, mi355q_qmd* out);
+int64_t orc_buffer_bytes(const mi355q_qmd* q);
+int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in, const void* join, int32_t n_threads,
+                    int64_t* out_buf, mi355q_qmd* out_qmd);
+void* orc_join_build(const void* key_col, int key_type, int key_nullable, int64_t num_rows, int64_t min_key,
+                     int64_t max_key, int prefer_baseline, int64_t max_perfect_entries, int32_t* err);
+void orc_join_free(void* j);
+}
+
+#define HIPCK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); std::exit(2); } } while (0)
+#define MQCK(x) do { int32_t c_ = (x); if (c_) { std::printf("mi355q error %d at line %d\n", c_, __LINE__); std::exit(2); } } while (0)
+
+namespace {
+
+constexpr int kTable = 1, kDim = 2, kDb = 1;
+int g_failures = 0;
+void expect(bool ok, const char* what) {
+  if (!ok) {
+    std::printf("  FAILED: %s\n", what);
+    ++g_failures;
+  }
+}
+
+struct Column {
+  SQLTypeInfo ti;
+  int gen_kind;
+  uint64_t seed;
+  int64_t a, b, c;
+  double a_f;
+  void* dev = nullptr;
+  std::vector<int8_t> host;
+};
+
+// a fact table generated on the device (mi355q_generate_column), mirrored to the host for the oracle
+struct Table {
+  int64_t n_rows = 0;
+  std::vector<Column> cols;
+  void generate() {
+    for (Column& c : cols) {
+      const size_t bytes = (size_t)n_rows * c.ti.get_size();
+      HIPCK(hipMalloc(&c.dev, bytes));
+      MQCK(mi355q_generate_column(0, c.dev, n_rows, 0, c.gen_kind, c.seed, c.a, c.b, c.c, c.a_f, 0, nullptr));
+      HIPCK(hipDeviceSynchronize());
+      c.host.resize(bytes);
+      HIPCK(hipMemcpy(c.host.data(), c.dev, bytes, hipMemcpyDeviceToHost));
+    }
+  }
+};
+
+std::shared_ptr<Analyzer::ColumnVar> colvar(const Table& t, int table_id, int col, int rte = 0) {
+  return std::make_shared<Analyzer::ColumnVar>(t.cols[col].ti, shared::ColumnKey{kDb, table_id, col}, rte);
+}
+std::shared_ptr<Analyzer::Constant> int_lit(SQLTypes t, int64_t v) {
+  Datum d{};
+  if (t == kINT) d.intval = (int32_t)v; else d.bigintval = v;
+  return std::make_shared<Analyzer::Constant>(SQLTypeInfo(t, true), false, d);
+}
+
+// two fragments per column (16-byte aligned split), as fetchChunks would hand them over
+FetchResult fetch(const Table& t, const std::vector<int>& cols, std::vector<int64_t>* frag_rows) {
+  const int64_t cut = (t.n_rows / 3) / 4 * 4;
+  FetchResult fr;
+  for (int f = 0; f < 2; ++f) {
+    std::vector<const int8_t*> ptrs;
+    for (int c : cols) ptrs.push_back((const int8_t*)t.cols[c].dev + (f ? cut * t.cols[c].ti.get_size() : 0));
+    fr.col_buffers.push_back(ptrs);
+    fr.fragment_info.num_rows.push_back({f ? t.n_rows - cut : cut});
+    frag_rows->push_back(f ? t.n_rows - cut : cut);
+  }
+  return fr;
+}
+
+// the oracle's table of a plan over the host mirror of the same columns
+std::vector<int64_t> oracle_table(const mi355q_plan& plan, const Table& t, const std::vector<int>& cols,
+                                  const std::vector<int64_t>& frag_rows, const void* join, const std::vector<const void*>& inner,
+                                  int64_t inner_rows, mi355q_qmd* q) {
+  MQCK(orc_qmd_init(&plan, q));
+  std::vector<int64_t> buf((size_t)orc_buffer_bytes(q) / 8);
+  std::vector<const void*> ptrs;
+  int64_t off = 0;
+  for (size_t f = 0; f < frag_rows.size(); ++f) {
+    for (int c : cols) ptrs.push_back(t.cols[c].host.data() + off * t.cols[c].ti.get_size());
+    off += frag_rows[f];
+  }
+  mi355q_inputs in{};
+  in.device_id = -1;
+  in.n_frags = (int32_t)frag_rows.size();
+  in.col_buffers = ptrs.data();
+  in.num_rows = frag_rows.data();
+  in.inner_col_buffers = inner.data();
+  in.inner_num_rows = inner_rows;
+  mi355q_qmd oq;
+  MQCK(orc_execute(&plan, &in, join, 8, buf.data(), &oq));
+  return buf;
+}
+
+QueryMemoryDescriptor qmd_of(const mi355q_qmd& q) {  // what HeavyDB's own initQueryMemoryDescriptor would say
+  QueryMemoryDescriptor d;
+  d.entry_count = (size_t)q.entry_count;
+  d.row_size = (size_t)q.row_size;
+  d.compact_byte_width = (int8_t)q.slot_width;
+  d.keyless = q.keyless != 0;
+  d.columnar = q.output_columnar != 0;
+  d.buffer_bytes = (size_t)orc_buffer_bytes(&q);
+  return d;
+}
+
+// rows of a (row-wise, 8-byte slot) table as key -> slots, baseline tables place keys in insertion order
+void compare_tables(const mi355q_qmd& q, const int64_t* want, const int64_t* got, const std::vector<bool>& slot_is_fp) {
+  const int rq = q.row_size / 8, kq = q.key_bytes / 8;
+  if (q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) {  // index-aligned layouts: quad by quad
+    for (int64_t e = 0; e < q.entry_count; ++e)
+      for (int j = 0; j < rq; ++j) {
+        const int64_t a = want[e * rq + j], b = got[e * rq + j];
+        if (a == b) continue;
+        double x, y;
+        std::memcpy(&x, &a, 8);
+        std::memcpy(&y, &b, 8);
+        const bool fp = j >= kq && slot_is_fp[j - kq];
+        if (!fp || !(std::fabs(x - y) <= 1e-9 * std::max(std::fabs(x), std::fabs(y)))) {
+          expect(false, "dense table differs");
+          return;
+        }
+      }
+    return;
+  }
+  std::map<std::vector<int64_t>, const int64_t*> w, g;
+  for (int64_t e = 0; e < q.entry_count; ++e) {
+    if (want[e * rq] != INT64_MAX) w[std::vector<int64_t>(want + e * rq, want + e * rq + kq)] = want + e * rq + kq;
+    if (got[e * rq] != INT64_MAX) g[std::vector<int64_t>(got + e * rq, got + e * rq + kq)] = got + e * rq + kq;
+  }
+  expect(w.size() == g.size(), "group count differs");
+  for (const auto& kv : w) {
+    auto it = g.find(kv.first);
+    if (it == g.end()) {
+      expect(false, "a group is missing");
+      return;
+    }
+    for (int j = 0; j < rq - kq; ++j) {
+      const int64_t a = kv.second[j], b = it->second[j];
+      if (a == b) continue;
+      double x, y;
+      std::memcpy(&x, &a, 8);
+      std::memcpy(&y, &b, 8);
+      if (!slot_is_fp[j] || !(std::fabs(x - y) <= 1e-9 * std::max(std::fabs(x), std::fabs(y)))) {
+        expect(false, "a group's slots differ");
+        return;
+      }
+    }
+  }
+}
+
+// the parts of a plan a translation has to get right
+void compare_plans(const mi355q_plan& a, const mi355q_plan& b) {
+  expect(a.n_cols == b.n_cols && a.n_inner_cols == b.n_inner_cols && a.n_quals == b.n_quals &&
+             a.n_group_cols == b.n_group_cols && a.n_targets == b.n_targets && a.n_exprs == b.n_exprs, "plan: counts");
+  expect(!std::memcmp(a.cols, b.cols, sizeof(mi355q_col_desc) * a.n_cols), "plan: column descriptors");
+  for (int i = 0; i < a.n_cols; ++i)
+    expect(a.col_ranges[i].valid == b.col_ranges[i].valid && a.col_ranges[i].min == b.col_ranges[i].min &&
+               a.col_ranges[i].max == b.col_ranges[i].max && a.col_ranges[i].has_nulls == b.col_ranges[i].has_nulls &&
+               a.col_ranges[i].fp_min == b.col_ranges[i].fp_min && a.col_ranges[i].fp_max == b.col_ranges[i].fp_max, "plan: column range");
+  for (int i = 0; i < a.n_quals; ++i)
+    expect(a.quals[i].col == b.quals[i].col && a.quals[i].op == b.quals[i].op && a.quals[i].ival == b.quals[i].ival, "plan: qual");
+  for (int i = 0; i < a.n_group_cols; ++i) expect(a.group_cols[i] == b.group_cols[i], "plan: group column");
+  for (int i = 0; i < a.n_targets; ++i)
+    expect(a.targets[i].agg == b.targets[i].agg && a.targets[i].col == b.targets[i].col && a.targets[i].table == b.targets[i].table, "plan: target");
+  for (int k = 0; k < a.n_exprs; ++k) {
+    expect(a.exprs[k].n_nodes == b.exprs[k].n_nodes, "plan: expression length");
+    for (int i = 0; i < a.exprs[k].n_nodes; ++i) {
+      const auto &x = a.exprs[k].nodes[i], &y = b.exprs[k].nodes[i];
+      expect(x.op == y.op && x.arg == y.arg && x.ilit == y.ilit && x.flit == y.flit && (x.op == MI355Q_EX_COL || x.type == y.type), "plan: expression node");
+    }
+    expect(a.exprs[k].range.min == b.exprs[k].range.min && a.exprs[k].range.max == b.exprs[k].range.max &&
+               a.exprs[k].range.fp_min == b.exprs[k].range.fp_min && a.exprs[k].range.fp_max == b.exprs[k].range.fp_max, "plan: expression range");
+  }
+  expect(a.join_outer_col == b.join_outer_col && a.join_kind == b.join_kind && a.n_join_cols == b.n_join_cols, "plan: join");
+  expect(a.max_groups_buffer_entry_guess == b.max_groups_buffer_entry_guess && a.num_tuples == b.num_tuples, "plan: options");
+}
+
+}  // namespace
+
+int main() {
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev < 1) {
+    std::printf("glue_check: no GPU\n");
+    return 77;
+  }
+  Executor executor;
+  const int64_t N = 6000000;
+  const int64_t n_keys = 90000;
+  // fact table: 0 key BIGINT NOT NULL (sparse), 1 f64 DOUBLE NOT NULL, 2 i32 INT NOT NULL, 3 x INT nullable-typed in [1, 40],
+  //             4 fk BIGINT NOT NULL in [-50, M + 50)
+  const int64_t M = 200000;
+  Table t;
+  t.n_rows = N;
+  t.cols = {{SQLTypeInfo(kBIGINT, true), MI355Q_GEN_I64_MOD_MUL, 0xC0FFEE00, n_keys, 1000003, 7, 0.0},
+            {SQLTypeInfo(kDOUBLE, true), MI355Q_GEN_F64_UNIT, 0xC0FFEE01, 0, 0, 0, 1000.0},
+            {SQLTypeInfo(kINT, true), MI355Q_GEN_I32_UNIFORM31, 0xC0FFEE02, 0, 0, 0, 0.0},
+            {SQLTypeInfo(kINT, false), MI355Q_GEN_I32_MOD, 0xC0FFEE03, 40, 1, 0, 0.0},
+            {SQLTypeInfo(kBIGINT, true), MI355Q_GEN_I64_MOD, 0xC0FFEE04, M + 100, -50, 0, 0.0}};
+  t.generate();
+  const int64_t key_max = (n_keys - 1) * 1000003 + 7;
+  executor.column_ranges[{kTable, 0}] = ExpressionRange::makeIntRange(7, key_max, 0, false);
+  executor.column_ranges[{kTable, 1}] = ExpressionRange::makeDoubleRange(0.0, 1000.0, false);
+  executor.column_ranges[{kTable, 2}] = ExpressionRange::makeIntRange(0, INT32_MAX, 0, false);
+  executor.column_ranges[{kTable, 3}] = ExpressionRange::makeIntRange(1, 40, 0, false);
+  executor.column_ranges[{kTable, 4}] = ExpressionRange::makeIntRange(-50, M + 49, 0, false);
+  for (int c = 0; c < 5; ++c) executor.column_types[{kTable, c}] = t.cols[c].ti;
+  const std::vector<InputTableInfo> query_infos = {{shared::TableKey{kDb, kTable}, N}};
+
+  // ---------------------------------------------------------------- query 1: the headline shape
+  //   SELECT key, COUNT(*), AVG(f64) FROM t WHERE i32 < 2^30 GROUP BY key
+  {
+    std::printf("query 1: SELECT key, COUNT(*), AVG(f64) FROM t WHERE i32 < 1073741824 GROUP BY key\n");
+    RelAlgExecutionUnit ra;
+    for (int c : {0, 1, 2}) ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(c, kTable, kDb, 0));
+    auto key = colvar(t, kTable, 0), f64 = colvar(t, kTable, 1), i32 = colvar(t, kTable, 2);
+    ra.simple_quals.push_back(std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kBOOLEAN, true), kLT, i32, int_lit(kINT, 1 << 30)));
+    ra.groupby_exprs.push_back(key);
+    Analyzer::AggExpr cnt(SQLTypeInfo(kBIGINT, true), kCOUNT, nullptr), avg(SQLTypeInfo(kDOUBLE, true), kAVG, f64);
+    ra.target_exprs = {key.get(), &cnt, &avg};
+    // the plan written by hand
+    mi355q_plan hp{};
+    hp.abi_version = MI355Q_ABI_VERSION;
+    hp.n_cols = 3;
+    hp.cols[0] = {MI355Q_INT64, 0, 0, 0};
+    hp.cols[1] = {MI355Q_DOUBLE, 0, 0, 0};
+    hp.cols[2] = {MI355Q_INT32, 0, 0, 0};
+    hp.col_ranges[0] = {1, 0, 7, key_max, 0, 0, 0};
+    hp.col_ranges[1] = {1, 0, 0, 0, 0.0, 1000.0, 0};
+    hp.col_ranges[2] = {1, 0, 0, INT32_MAX, 0, 0, 0};
+    hp.n_quals = 1;
+    hp.quals[0] = {2, MI355Q_LT, 1 << 30, 0.0};
+    hp.n_group_cols = 1;
+    hp.group_cols[0] = 0;
+    hp.n_targets = 3;
+    hp.targets[0] = {MI355Q_PROJECT_KEY, 0, 0, 0, {}};
+    hp.targets[1] = {MI355Q_COUNT, -1, 0, 0, {}};
+    hp.targets[2] = {MI355Q_AVG, 1, 0, 0, {}};
+    hp.join_outer_col = -1;
+    hp.max_groups_buffer_entry_guess = 2 * n_keys;
+    hp.num_tuples = N;
+    compare_plans(hp, mi355q_glue::to_plan(ra, query_infos, &executor, nullptr, 2 * n_keys, false));
+    std::vector<int64_t> frag_rows;
+    const FetchResult fr = fetch(t, {0, 1, 2}, &frag_rows);
+    mi355q_qmd q;
+    const std::vector<int64_t> want = oracle_table(hp, t, {0, 1, 2}, frag_rows, nullptr, {}, 0, &q);
+    const ResultSetPtr rs = mi355q_glue::run_query_mi355q(ra, fr, query_infos, qmd_of(q), &executor, 0, 2 * n_keys, nullptr, {}, 0);
+    expect(q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && q.entry_count == 2 * n_keys && q.row_size == 32, "layout");
+    compare_tables(q, want.data(), (const int64_t*)const_cast<ResultSetStorage*>(rs->getStorage())->getUnderlyingBuffer(), {false, true, false});
+  }
+
+  // ---------------------------------------------------------------- query 2: projected expressions (BH001 / MSBS001 shapes)
+  //   SELECT cast(x AS DOUBLE), COUNT(*), MAX(x + 1), SUM(x + 1) FROM t GROUP BY cast(x AS DOUBLE)
+  {
+    std::printf("query 2: SELECT cast(x AS DOUBLE) k, COUNT(*), MAX(x + 1), SUM(x + 1) FROM t GROUP BY k\n");
+    RelAlgExecutionUnit ra;
+    ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(3, kTable, kDb, 0));
+    auto x = colvar(t, kTable, 3);
+    auto k = std::make_shared<Analyzer::UOper>(SQLTypeInfo(kDOUBLE, false), kCAST, x);
+    auto x1 = std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kINT, false), kPLUS, x, int_lit(kINT, 1));
+    ra.groupby_exprs.push_back(k);
+    Analyzer::AggExpr cnt(SQLTypeInfo(kBIGINT, true), kCOUNT, nullptr), mx(SQLTypeInfo(kINT, false), kMAX, x1), sm(SQLTypeInfo(kBIGINT, false), kSUM, x1);
+    ra.target_exprs = {k.get(), &cnt, &mx, &sm};
+    mi355q_plan hp{};
+    hp.abi_version = MI355Q_ABI_VERSION;
+    hp.n_cols = 1;
+    hp.cols[0] = {MI355Q_INT32, 1, 0, 0};
+    hp.col_ranges[0] = {1, 0, 1, 40, 0, 0, 0};
+    hp.n_exprs = 2;
+    hp.exprs[0].n_nodes = 2;
+    hp.exprs[0].nodes[0] = {MI355Q_EX_COL, 0, 0, 0, 0, 0.0};
+    hp.exprs[0].nodes[1] = {MI355Q_EX_CAST, MI355Q_DOUBLE, 0, 0, 0, 0.0};
+    hp.exprs[0].range = {1, 0, 0, 0, 1.0, 40.0, 0};
+    hp.exprs[1].n_nodes = 3;
+    hp.exprs[1].nodes[0] = {MI355Q_EX_COL, 0, 0, 0, 0, 0.0};
+    hp.exprs[1].nodes[1] = {MI355Q_EX_LIT, MI355Q_INT32, 0, 0, 1, 0.0};
+    hp.exprs[1].nodes[2] = {MI355Q_EX_ADD, MI355Q_INT32, 0, 0, 0, 0.0};
+    hp.exprs[1].range = {1, 0, 2, 41, 0, 0, 0};
+    hp.n_group_cols = 1;
+    hp.group_cols[0] = 1;   // expression 0 = virtual column n_cols + 0
+    hp.n_targets = 4;
+    hp.targets[0] = {MI355Q_PROJECT_KEY, 0, 0, 0, {}};
+    hp.targets[1] = {MI355Q_COUNT, -1, 0, 0, {}};
+    hp.targets[2] = {MI355Q_MAX, 2, 0, 0, {}};
+    hp.targets[3] = {MI355Q_SUM, 2, 0, 0, {}};
+    hp.join_outer_col = -1;
+    hp.max_groups_buffer_entry_guess = 16384;
+    hp.num_tuples = N;
+    compare_plans(hp, mi355q_glue::to_plan(ra, query_infos, &executor, nullptr, 16384, false));
+    std::vector<int64_t> frag_rows;
+    const FetchResult fr = fetch(t, {3}, &frag_rows);
+    mi355q_qmd q;
+    const std::vector<int64_t> want = oracle_table(hp, t, {3}, frag_rows, nullptr, {}, 0, &q);
+    const ResultSetPtr rs = mi355q_glue::run_query_mi355q(ra, fr, query_infos, qmd_of(q), &executor, 0, 16384, nullptr, {}, 0);
+    expect(q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH, "a floating-point key takes the baseline layout");
+    compare_tables(q, want.data(), (const int64_t*)const_cast<ResultSetStorage*>(rs->getStorage())->getUnderlyingBuffer(), {false, false, false, false});
+  }
+
+  // ---------------------------------------------------------------- query 3: hash-join probe + SUM
+  //   SELECT SUM(t.i32w), SUM(d.w), COUNT(*) FROM t JOIN d ON t.fk = d.k
+  {
+    std::printf("query 3: SELECT SUM(t.key), SUM(d.w), COUNT(*) FROM t JOIN d ON t.fk = d.k\n");
+    Table d;
+    d.n_rows = M;
+    d.cols = {{SQLTypeInfo(kBIGINT, true), MI355Q_GEN_I64_MOD, 0, 0, 0, 0, 0.0}, {SQLTypeInfo(kBIGINT, true), MI355Q_GEN_I64_MOD, 0xD1, 2001, -1000, 0, 0.0}};
+    // keys 0 .. M-1 (dense, unique): written on the host, then uploaded
+    d.cols[0].host.resize((size_t)M * 8);
+    for (int64_t i = 0; i < M; ++i) ((int64_t*)d.cols[0].host.data())[i] = (i * 7919) % M;
+    HIPCK(hipMalloc(&d.cols[0].dev, (size_t)M * 8));
+    HIPCK(hipMemcpy(d.cols[0].dev, d.cols[0].host.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+    {
+      Column& w = d.cols[1];
+      HIPCK(hipMalloc(&w.dev, (size_t)M * 8));
+      MQCK(mi355q_generate_column(0, w.dev, M, 0, w.gen_kind, w.seed, w.a, w.b, w.c, w.a_f, 0, nullptr));
+      HIPCK(hipDeviceSynchronize());
+      w.host.resize((size_t)M * 8);
+      HIPCK(hipMemcpy(w.host.data(), w.dev, (size_t)M * 8, hipMemcpyDeviceToHost));
+    }
+    executor.column_types[{kDim, 0}] = d.cols[0].ti;
+    executor.column_types[{kDim, 1}] = d.cols[1].ti;
+    executor.column_ranges[{kDim, 0}] = ExpressionRange::makeIntRange(0, M - 1, 0, false);
+    executor.column_ranges[{kDim, 1}] = ExpressionRange::makeIntRange(-1000, 1000, 0, false);
+    mi355q_join_spec js{};
+    js.device_id = 0;
+    js.key_type = MI355Q_INT64;
+    js.key_buffer = d.cols[0].dev;
+    js.num_rows = M;
+    js.key_range = {1, 0, 0, M - 1, 0, 0, 0};
+    mi355q_join_table* jt = nullptr;
+    MQCK(mi355q_join_build(&js, nullptr, &jt));
+    int32_t oerr = 0;
+    void* oj = orc_join_build(d.cols[0].host.data(), MI355Q_INT64, 0, M, 0, M - 1, 0, 0, &oerr);
+    expect(oj != nullptr && oerr == 0, "oracle join build");
+    RelAlgExecutionUnit ra;
+    ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(4, kTable, kDb, 0));
+    ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(0, kTable, kDb, 0));
+    ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(0, kDim, kDb, 1));
+    ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(1, kDim, kDb, 1));
+    auto fk = colvar(t, kTable, 4), v = colvar(t, kTable, 0), dk = colvar(d, kDim, 0, 1), dw = colvar(d, kDim, 1, 1);
+    JoinCondition jc;
+    jc.type = JoinType::INNER;
+    jc.quals.push_back(std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kBOOLEAN, true), kEQ, fk, dk));
+    ra.join_quals.push_back(jc);
+    ra.groupby_exprs.push_back(nullptr);
+    Analyzer::AggExpr s1(SQLTypeInfo(kBIGINT, false), kSUM, v), s2(SQLTypeInfo(kBIGINT, false), kSUM, dw), cnt(SQLTypeInfo(kBIGINT, true), kCOUNT, nullptr);
+    ra.target_exprs = {&s1, &s2, &cnt};
+    mi355q_plan hp{};
+    hp.abi_version = MI355Q_ABI_VERSION;
+    hp.n_cols = 2;
+    hp.cols[0] = {MI355Q_INT64, 0, 0, 0};
+    hp.cols[1] = {MI355Q_INT64, 0, 0, 0};
+    hp.col_ranges[0] = {1, 0, -50, M + 49, 0, 0, 0};
+    hp.col_ranges[1] = {1, 0, 7, key_max, 0, 0, 0};
+    hp.n_inner_cols = 2;
+    hp.inner_cols[0] = {MI355Q_INT64, 0, 0, 0};
+    hp.inner_cols[1] = {MI355Q_INT64, 0, 0, 0};
+    hp.inner_col_ranges[0] = {1, 0, 0, M - 1, 0, 0, 0};
+    hp.inner_col_ranges[1] = {1, 0, -1000, 1000, 0, 0, 0};
+    hp.n_targets = 3;
+    hp.targets[0] = {MI355Q_SUM, 1, 0, 0, {}};
+    hp.targets[1] = {MI355Q_SUM, 1, 1, 0, {}};
+    hp.targets[2] = {MI355Q_COUNT, -1, 0, 0, {}};
+    hp.join_outer_col = 0;
+    hp.join_outer_cols[0] = 0;
+    hp.join_kind = MI355Q_JOIN_INNER;
+    hp.max_groups_buffer_entry_guess = 16384;
+    hp.num_tuples = N + M;
+    const std::vector<InputTableInfo> qi2 = {{shared::TableKey{kDb, kTable}, N}, {shared::TableKey{kDb, kDim}, M}};
+    compare_plans(hp, mi355q_glue::to_plan(ra, qi2, &executor, jt, 16384, false));
+    std::vector<int64_t> frag_rows;
+    const FetchResult fr = fetch(t, {4, 0}, &frag_rows);
+    mi355q_qmd q;
+    const std::vector<int64_t> want = oracle_table(hp, t, {4, 0}, frag_rows, oj, {d.cols[0].host.data(), d.cols[1].host.data()}, M, &q);
+    const ResultSetPtr rs = mi355q_glue::run_query_mi355q(ra, fr, qi2, qmd_of(q), &executor, 0, 16384, jt,
+                                                          {(const int8_t*)d.cols[0].dev, (const int8_t*)d.cols[1].dev}, M);
+    expect(q.desc_type == MI355Q_NON_GROUPED_AGGREGATE, "layout");
+    compare_tables(q, want.data(), (const int64_t*)const_cast<ResultSetStorage*>(rs->getStorage())->getUnderlyingBuffer(), {false, false, false});
+    std::printf("  SUM(t.key) = %lld, SUM(d.w) = %lld, COUNT(*) = %lld\n", (long long)want[0], (long long)want[1], (long long)want[2]);
+    mi355q_join_free(jt);
+    orc_join_free(oj);
+  }
+
+  // ---------------------------------------------------------------- an error crosses the seam as QueryExecutionError
+  {
+    std::printf("query 4: the table of query 1 with room for a tenth of its groups -> QueryExecutionError\n");
+    RelAlgExecutionUnit ra;
+    for (int c : {0, 1}) ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(c, kTable, kDb, 0));
+    auto key = colvar(t, kTable, 0), f64 = colvar(t, kTable, 1);
+    ra.groupby_exprs.push_back(key);
+    Analyzer::AggExpr cnt(SQLTypeInfo(kBIGINT, true), kCOUNT, nullptr), avg(SQLTypeInfo(kDOUBLE, true), kAVG, f64);
+    ra.target_exprs = {key.get(), &cnt, &avg};
+    std::vector<int64_t> frag_rows;
+    const FetchResult fr = fetch(t, {0, 1}, &frag_rows);
+    const mi355q_plan p = mi355q_glue::to_plan(ra, query_infos, &executor, nullptr, n_keys / 10, false);
+    mi355q_qmd q;
+    MQCK(orc_qmd_init(&p, &q));
+    bool thrown = false;
+    try {
+      mi355q_glue::run_query_mi355q(ra, fr, query_infos, qmd_of(q), &executor, 0, n_keys / 10, nullptr, {}, 0);
+    } catch (const QueryExecutionError& e) {
+      thrown = e.getErrorCode() < 0 || e.getErrorCode() == MI355Q_ERR_OUT_OF_SLOTS;
+    }
+    expect(thrown, "out of slots must surface as QueryExecutionError (negative code or 3)");
+  }
+  std::printf(g_failures ? "glue_check: %d FAILURE(S)\n" : "glue_check: all queries agree with the oracle\n", g_failures);
+  return g_failures ? 1 : 0;
+}
