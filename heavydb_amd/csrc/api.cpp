@@ -1150,7 +1150,7 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
 // right after the launches; mi355q_execute_async parks it in a mi355q_pending until mi355q_wait (or the
 // next call on the device) runs it.  Everything it touches is owned here: the caller's host arrays may be
 // gone by then.
-enum StepKind { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART, K_JOIN_PROBE, K_SCAN_AGG };
+enum StepKind { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART, K_JOIN_PROBE, K_SCAN_AGG, K_LDS_GROUPBY };
 struct TailState {
   mi355q_qmd q;
   DevPlan d;
@@ -1200,6 +1200,21 @@ int32_t finish_step(TailState& t, mi355q_exec_report* report) {
     HIP_TRY(launch_generic(d, q.idx_target_as_key, make_row_init(q), t.d_cols, t.d_rows, t.nf, t.max_frag_rows, t.res->buf,
                            t.d_err, t.n_cus, s));
     st.kernel_name = "k_generic";
+    HIP_TRY(hipMemcpyAsync(h_err, t.d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (h_err[1] && t.kind == K_LDS_GROUPBY) {
+    // more groups than an LDS replica holds (a baseline table: the group count is only known now): redo the step
+    // with the partitioned / direct family, or the row kernel
+    HIP_TRY(hipMemsetAsync(t.d_err, 0, 64, s));
+    HIP_TRY(launch_init_buffer(t.res->buf, q.entry_count, make_row_init(q), s));
+    if (baseline_fast_eligible(d, fv)) {
+      HIP_TRY(launch_baseline_fast(d, fv, t.res->buf, t.d_err, nullptr, 0, 0, 1, t.n_cus, s, &st));
+    } else {
+      HIP_TRY(launch_generic(d, q.idx_target_as_key, make_row_init(q), t.d_cols, t.d_rows, t.nf, t.max_frag_rows, t.res->buf,
+                             t.d_err, t.n_cus, s));
+      st.kernel_name = "k_generic";
+    }
     HIP_TRY(hipMemcpyAsync(h_err, t.d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
@@ -1607,7 +1622,19 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     return MI355Q_OK;
   }
 
-  if (!o.force_generic && in->n_frags > 0 && !reserved) {
+  // (small multi-column perfect-hash tables: the LDS group-by computes the entry index from the key columns itself,
+  // no packed index column needed)
+  bool lds_direct = false;
+  if (!o.force_generic && in->n_frags > 0 && o.kernel_variant == 0 && d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
+    int64_t tr = 0, mr = 0;
+    for (int f = 0; f < in->n_frags; ++f) {
+      tr += in->num_rows[f];
+      mr = std::max(mr, in->num_rows[f]);
+    }
+    FragView fvh{nullptr, nullptr, in->col_buffers, in->num_rows, in->n_frags, plan->n_cols, tr, mr};
+    lds_direct = lds_groupby_eligible(d, fvh);
+  }
+  if (!o.force_generic && in->n_frags > 0 && !reserved && !lds_direct) {
     const int32_t e = execute_packed_multi(plan, in, o, q, d, n_cus, out, report);
     if (e != kNotTaken) return e;
     *out = nullptr;
@@ -1684,7 +1711,13 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   JoinPayloadView pay{};
   if (!o.force_generic && nf > 0) {
     if (scan_count_eligible(d, fv)) kind = K_SCAN_COUNT;
+    else if (o.kernel_variant != 1 && scan_agg_eligible(d, fv)) kind = K_SCAN_AGG;
     else if (perfect_lds_eligible(d, fv)) kind = K_PERFECT_LDS;
+    // few groups: the table replicated in every workgroup's LDS (perfect-hash layouts up to 64 K entries that fit;
+    // baseline layouts whose entry guess says "small" — if the groups turn out to be too many the step is re-run)
+    else if (o.kernel_variant == 0 && lds_groupby_eligible(d, fv) &&
+             (d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH || d.entry_count <= 65536))
+      kind = K_LDS_GROUPBY;
     else if (baseline_fast_eligible(d, fv)) kind = K_BASELINE_FAST;
     else if (join_sum_eligible(d, fv)) kind = K_JOIN_SUM;
     // semi-join + aggregate over a large fact table: radix-partitioned probe (bitmap slices in
@@ -1834,8 +1867,14 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
       case K_SCAN_COUNT:
         HIP_TRY(launch_scan_count(d, fv, res->buf, n_cus, s, &st));
         break;
+      case K_SCAN_AGG:
+        HIP_TRY(launch_scan_agg(d, fv, res->buf, n_cus, s, &st));
+        break;
       case K_PERFECT_LDS:
         HIP_TRY(launch_perfect_lds(d, fv, res->buf, d_err, n_cus, s, &st));
+        break;
+      case K_LDS_GROUPBY:
+        HIP_TRY(launch_lds_groupby(d, fv, res->buf, d_err, n_cus, s, &st));
         break;
       case K_BASELINE_FAST:
         HIP_TRY(launch_baseline_fast(d, fv, res->buf, d_err, ctx.scratch, ctx.scratch_bytes,

@@ -173,7 +173,10 @@ struct SlotProg {
   int32_t val_nullable;
   int32_t null_init[MI355Q_MAX_SLOTS];
   int64_t null_bits;                 // bit pattern of the value column's NULL as loaded
-  int64_t slot_null;                 // the sentinel the null_init slots start at (their init value)
+  // the sentinel each null_init slot starts at (its init value): SUM(int) starts at NULL_BIGINT, MIN / MAX at the
+  // ARGUMENT type's NULL — different values for a nullable INT column aggregated both ways (the reference's own
+  // benchmark: count / sum / max / min / avg of one nullable INT column, PerfectHashSingleCol/PHS001.sql)
+  int64_t slot_null[MI355Q_MAX_SLOTS];
 };
 
 // one row's update of a group's slots in the output table.  fval / ival: the value as double /
@@ -189,12 +192,12 @@ MQ_D void apply_slots_global(const SlotProg& sp, int64_t* slots, double fval, in
     if (is_null) continue;  // every other op reads the value
     if (sp.null_init[j]) {
       switch (sp.op[j]) {
-        case SO_SUM_I: a_sum_i64_skip<true>(s, ival, sp.slot_null); break;
-        case SO_SUM_F: a_sum_f64_skip<true>(s, fval, bits_dbl(sp.slot_null)); break;
-        case SO_MIN_I: a_min_i64_skip<true>(s, ival, sp.slot_null); break;
-        case SO_MAX_I: a_max_i64_skip<true>(s, ival, sp.slot_null); break;
-        case SO_MIN_F: a_minmax_f64<true, false, true>(s, fval, bits_dbl(sp.slot_null)); break;
-        case SO_MAX_F: a_minmax_f64<true, true, true>(s, fval, bits_dbl(sp.slot_null)); break;
+        case SO_SUM_I: a_sum_i64_skip<true>(s, ival, sp.slot_null[j]); break;
+        case SO_SUM_F: a_sum_f64_skip<true>(s, fval, bits_dbl(sp.slot_null[j])); break;
+        case SO_MIN_I: a_min_i64_skip<true>(s, ival, sp.slot_null[j]); break;
+        case SO_MAX_I: a_max_i64_skip<true>(s, ival, sp.slot_null[j]); break;
+        case SO_MIN_F: a_minmax_f64<true, false, true>(s, fval, bits_dbl(sp.slot_null[j])); break;
+        case SO_MAX_F: a_minmax_f64<true, true, true>(s, fval, bits_dbl(sp.slot_null[j])); break;
         default: break;
       }
       continue;
@@ -308,10 +311,10 @@ inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* 
   s->sp.n = p.slot_count;
   s->sp.val_nullable = 0;
   s->sp.null_bits = 0;
-  s->sp.slot_null = 0;
   for (int i = 0; i < MI355Q_MAX_SLOTS; ++i) {
     s->sp.op[i] = SO_COUNT;
     s->sp.null_init[i] = 0;
+    s->sp.slot_null[i] = 0;
   }
   for (int i = 0; i < p.n_targets; ++i) {
     const DevTarget& t = p.targets[i];
@@ -359,19 +362,10 @@ inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* 
       default: return false;
     }
   }
-  // the slots that start at a NULL sentinel must share it (SUM(int) starts at NULL_BIGINT, MIN /
-  // MAX at the argument type's NULL: equal for int64 / double / FIXED-encoded BIGINT columns,
-  // different for a plain nullable INT column aggregated both ways — left to the row kernel)
-  {
-    bool have = false;
-    for (int j = 0; j < p.slot_count; ++j) {
-      if (!s->sp.null_init[j]) continue;
-      if (have && p.init_vals[j] != s->sp.slot_null) return false;
-      s->sp.slot_null = p.init_vals[j];
-      have = true;
-    }
-    if (!have) s->sp.slot_null = s->sp.null_bits;
-  }
+  // every slot that starts at a NULL sentinel carries its own (SUM(int): NULL_BIGINT; MIN / MAX: the argument
+  // type's NULL)
+  for (int j = 0; j < p.slot_count; ++j)
+    s->sp.slot_null[j] = s->sp.null_init[j] ? p.init_vals[j] : s->sp.null_bits;
   // one column cannot be nullable for one target and NOT NULL for another
   if (s->sp.val_nullable) {
     for (int i = 0; i < p.n_targets; ++i) {

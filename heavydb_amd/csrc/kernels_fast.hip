@@ -16,6 +16,9 @@
 //                  + atomics; partitioned: hash-partition rows into LDS-sized key ranges,
 //                  then aggregate each range in LDS and emit each group once
 //   join_sum       fact JOIN dim ... SUM/COUNT       (SURVEY cfg4)  probe fused into the scan
+#include <cstring>
+#include <type_traits>
+
 #include "fast_common.h"
 
 namespace mq {
@@ -42,6 +45,292 @@ __global__ __launch_bounds__(kBlock) void k_scan_count(const int8_t* const* __re
     for (int i = 0; i < kBlock / 64; ++i) t += s_part[i];
     if (t) atomicAdd((unsigned long long*)out, t);
   }
+}
+
+
+// =========================================================================== scan_agg
+// Non-grouped aggregates over SEVERAL columns with up to four range quals — the shape of the reference's own
+// NonGroupedAgg benchmark (Benchmarks/synthetic_benchmark/queries/NonGroupedAgg/NGA01-05.sql: six columns, one
+// aggregate kind each; query_template's register accumulators, QueryTemplateGenerator.cpp:265-549).  Same
+// streaming skeleton as k_scan_count (a workgroup walks contiguous tiles, every lane keeps UQ independent
+// 16-byte loads per column in flight), one set of typed register accumulators per COLUMN — rows with a value,
+// sum, min, max — whatever the targets over that column need; a wave shuffle reduce, one LDS fold per
+// workgroup, and the workgroup's partial row is merged into the output with the reduce rule (reduce_target: the
+// _skip_val forms non-grouped aggregates always take, TargetExprBuilder.cpp:684-690).
+constexpr int kScanAggCols = 8;
+struct ScanAggArgs {
+  int32_t n_used, n_flt;
+  int32_t col[kScanAggCols], type[kScanAggCols], nullable[kScanAggCols];  // type: MI355Q_INT32 / _INT64 / _DOUBLE (plain)
+  RangeFilter flt[MI355Q_MAX_QUALS];
+  int32_t flt_type[MI355Q_MAX_QUALS];
+  int32_t target_cslot[MI355Q_MAX_TARGETS];  // index into col[] of each target's argument, -1 = COUNT(*)
+};
+
+struct ColAcc {
+  unsigned long long cnt;  // rows whose value is not NULL (and passed the quals)
+  int64_t sum_i, min_i, max_i;
+  double sum_f, min_f, max_f;
+};
+
+// a quad of any column as loaded: 16 bytes (4-byte types) or 32 bytes (8-byte types); the loads of a step are
+// all issued before the first value is looked at (wave-uniform branches do not wait for memory)
+struct RawQuad {
+  v4i32 lo, hi;
+};
+MQ_D void load_raw(const int8_t* base, int64_t quad, bool w8, RawQuad& r) {
+  if (w8) {
+    r.lo = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2);
+    r.hi = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2 + 1);
+  } else {
+    r.lo = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad);
+  }
+}
+MQ_D int64_t raw_i64(const RawQuad& r, int i) {
+  const v4i32& h = i < 2 ? r.lo : r.hi;
+  const int j = (i & 1) * 2;
+  return (int64_t)(((uint64_t)(uint32_t)(j ? h.w : h.y) << 32) | (uint64_t)(uint32_t)(j ? h.z : h.x));
+}
+MQ_D int32_t raw_i32(const RawQuad& r, int i) { return i == 0 ? r.lo.x : i == 1 ? r.lo.y : i == 2 ? r.lo.z : r.lo.w; }
+
+MQ_D void scan_agg_apply(ColAcc& a, const RawQuad& r, int type, uint32_t pass, bool nullable) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bool ok = (pass >> i) & 1u;
+    if (type == MI355Q_DOUBLE) {
+      const double v = bits_dbl(raw_i64(r, i));
+      ok = ok && !(nullable && v == kNullDouble);
+      if (ok) {
+        a.cnt += 1;
+        a.sum_f += v;
+        a.min_f = v < a.min_f ? v : a.min_f;
+        a.max_f = a.max_f < v ? v : a.max_f;
+      }
+    } else {
+      const int64_t x = type == MI355Q_INT32 ? (int64_t)raw_i32(r, i) : raw_i64(r, i);
+      ok = ok && !(nullable && x == (type == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN));
+      if (ok) {
+        a.cnt += 1;
+        a.sum_i += x;
+        a.min_i = x < a.min_i ? x : a.min_i;
+        a.max_i = a.max_i < x ? x : a.max_i;
+      }
+    }
+  }
+}
+MQ_D uint32_t scan_agg_filter(const RangeFilter& f, int type, const RawQuad& r) {
+  uint32_t m = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bool p = type == MI355Q_INT32 ? filter_pass<int32_t>(f, raw_i32(r, i)) : filter_pass<int64_t>(f, raw_i64(r, i));
+    m |= (p ? 1u : 0u) << i;
+  }
+  return m;
+}
+
+template <typename T>
+MQ_D void scan_agg_one(ColAcc& a, const int8_t* base, int64_t pos, bool nullable) {
+  const T v = load_one<T>(base, pos);
+  if constexpr (std::is_same<T, double>::value) {
+    if (nullable && v == kNullDouble) return;
+    a.cnt += 1;
+    a.sum_f += v;
+    a.min_f = v < a.min_f ? v : a.min_f;
+    a.max_f = a.max_f < v ? v : a.max_f;
+  } else {
+    const int64_t x = (int64_t)v;
+    if (nullable && x == (std::is_same<T, int32_t>::value ? (int64_t)INT32_MIN : INT64_MIN)) return;
+    a.cnt += 1;
+    a.sum_i += x;
+    a.min_i = x < a.min_i ? x : a.min_i;
+    a.max_i = a.max_i < x ? x : a.max_i;
+  }
+}
+
+MQ_D double wave_sum_f64(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+MQ_D long long wave_min_i64(long long v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_down(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+MQ_D long long wave_max_i64(long long v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const long long o = __shfl_down(v, off, 64);
+    v = v < o ? o : v;
+  }
+  return v;
+}
+MQ_D double wave_min_f64(double v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+MQ_D double wave_max_f64(double v) {
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_down(v, off, 64);
+    v = v < o ? o : v;
+  }
+  return v;
+}
+
+// NC / NF: columns / quals this member holds registers for (the step's register footprint is UQ x (NC + NF) raw quads)
+template <int UQ, int NC, int NF>
+__global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __restrict__ cols,
+                                                      const int64_t* __restrict__ num_rows, int n_frags, int n_cols,
+                                                      ScanAggArgs a, DevPlan p, int64_t* __restrict__ out) {
+  ColAcc acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    acc[c].cnt = 0;
+    acc[c].sum_i = 0;
+    acc[c].min_i = INT64_MAX;
+    acc[c].max_i = INT64_MIN;
+    acc[c].sum_f = 0.0;
+    acc[c].min_f = 1.7976931348623157e308;
+    acc[c].max_f = -1.7976931348623157e308;
+  }
+  unsigned long long rows_passing = 0;
+  const int64_t tile_q = (int64_t)kBlock * UQ;
+  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kBlock;
+  for (int f = 0; f < n_frags; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * n_cols;
+    const int64_t n = num_rows[f];
+    const int64_t nq = n >> 2;
+    const int64_t n_tiles = nq / tile_q;
+    // the fragment's chunk of every stream, fetched once
+    const int8_t *fbase[NF], *cbase[NC];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) fbase[k] = k < a.n_flt ? fc[a.flt[k].col] : nullptr;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cbase[c] = c < a.n_used ? fc[a.col[c]] : nullptr;
+    // one step = UQ quads of every column: phase 1 issues every load, phase 2 filters and accumulates
+    auto do_step = [&](int64_t q0, int n_quads, int64_t stride) {
+      RawQuad fr[NF][UQ];
+      RawQuad cr[NC][UQ];
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        if (u >= n_quads) break;
+        const int64_t quad = q0 + (int64_t)u * stride;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          if (k >= a.n_flt) break;
+          load_raw(fbase[k], quad, a.flt_type[k] != MI355Q_INT32, fr[k][u]);
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (c >= a.n_used) break;
+          load_raw(cbase[c], quad, a.type[c] != MI355Q_INT32, cr[c][u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        if (u >= n_quads) break;
+        uint32_t pass = 15u;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          if (k >= a.n_flt) break;
+          pass &= scan_agg_filter(a.flt[k], a.flt_type[k], fr[k][u]);
+        }
+        rows_passing += __popc(pass);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (c >= a.n_used) break;
+          scan_agg_apply(acc[c], cr[c][u], a.type[c], pass, a.nullable[c] != 0);
+        }
+      }
+    };
+    for (int64_t t = (blockIdx.x + (int64_t)f * 7) % gridDim.x; t < n_tiles; t += gridDim.x)
+      do_step(t * tile_q + threadIdx.x, UQ, kBlock);
+    for (int64_t q = n_tiles * tile_q + gtid; q < nq; q += gsize) do_step(q, 1, 0);
+    const int64_t tail = (nq << 2) + gtid;
+    if (tail < n) {
+      bool pass = true;
+      for (int k = 0; k < a.n_flt; ++k) {
+        pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], load_one<int32_t>(fc[a.flt[k].col], tail))
+                                                      : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fc[a.flt[k].col], tail)));
+      }
+      if (pass) {
+        rows_passing += 1;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (c >= a.n_used) break;
+          const int8_t* base = fc[a.col[c]];
+          if (a.type[c] == MI355Q_INT32) scan_agg_one<int32_t>(acc[c], base, tail, a.nullable[c] != 0);
+          else if (a.type[c] == MI355Q_INT64) scan_agg_one<int64_t>(acc[c], base, tail, a.nullable[c] != 0);
+          else scan_agg_one<double>(acc[c], base, tail, a.nullable[c] != 0);
+        }
+      }
+    }
+  }
+  // wave reduce, then one fold per workgroup in LDS
+  __shared__ unsigned long long s_rows[kBlock / 64];
+  __shared__ ColAcc s_acc[kBlock / 64][kScanAggCols];
+  rows_passing = wave_sum_u64(rows_passing);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (c >= a.n_used) break;
+    ColAcc r;
+    r.cnt = wave_sum_u64(acc[c].cnt);
+    r.sum_i = wave_sum_i64(acc[c].sum_i);
+    r.min_i = wave_min_i64(acc[c].min_i);
+    r.max_i = wave_max_i64(acc[c].max_i);
+    r.sum_f = wave_sum_f64(acc[c].sum_f);
+    r.min_f = wave_min_f64(acc[c].min_f);
+    r.max_f = wave_max_f64(acc[c].max_f);
+    if (lane == 0) s_acc[wave][c] = r;
+  }
+  if (lane == 0) s_rows[wave] = rows_passing;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  unsigned long long rows = 0;
+  for (int w = 0; w < kBlock / 64; ++w) rows += s_rows[w];
+  if (!rows) return;  // nothing passed in this workgroup: the slots keep what they have
+  // the workgroup's partial row, as the row function would have left it in a private buffer
+  int64_t part[MI355Q_MAX_SLOTS];
+  for (int j = 0; j < p.slot_count; ++j) part[j] = p.init_vals[j];
+  for (int i = 0; i < p.n_targets; ++i) {
+    const DevTarget& t = p.targets[i];
+    const int cs = a.target_cslot[i];
+    if (cs < 0) {
+      part[t.slot] = (int64_t)rows;
+      continue;
+    }
+    ColAcc r = s_acc[0][cs];
+    for (int w = 1; w < kBlock / 64; ++w) {
+      const ColAcc& o = s_acc[w][cs];
+      r.cnt += o.cnt;
+      r.sum_i += o.sum_i;
+      r.min_i = o.min_i < r.min_i ? o.min_i : r.min_i;
+      r.max_i = r.max_i < o.max_i ? o.max_i : r.max_i;
+      r.sum_f += o.sum_f;
+      r.min_f = o.min_f < r.min_f ? o.min_f : r.min_f;
+      r.max_f = r.max_f < o.max_f ? o.max_f : r.max_f;
+    }
+    const bool fp = a.type[cs] == MI355Q_DOUBLE;
+    switch (t.agg) {
+      case MI355Q_COUNT: part[t.slot] = (int64_t)r.cnt; break;
+      case MI355Q_AVG:
+        part[t.slot + 1] = (int64_t)r.cnt;
+        [[fallthrough]];
+      case MI355Q_SUM:
+        if (r.cnt) part[t.slot] = fp ? dbl_bits(r.sum_f) : r.sum_i;
+        break;
+      case MI355Q_MIN:
+        if (r.cnt) part[t.slot] = fp ? dbl_bits(r.min_f) : r.min_i;
+        break;
+      default:
+        if (r.cnt) part[t.slot] = fp ? dbl_bits(r.max_f) : r.max_i;
+    }
+  }
+  for (int i = 0; i < p.n_targets; ++i) reduce_target<true>(p.targets[i], p.init_vals, out, part);
 }
 
 // =========================================================================== perfect_lds
@@ -417,6 +706,69 @@ hipError_t launch_scan_count(const DevPlan& p, const FragView& fv, int64_t* out,
     hipLaunchKernelGGL(k_scan_count<int64_t>, dim3(grid), dim3(kBlock), 0, s, fv.d_cols,
                        fv.d_num_rows, fv.n_frags, fv.n_cols, f, out);
   }
+  rec(st->k_stop, s);
+  return hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------------ scan_agg
+static bool scan_agg_args(const DevPlan& p, const FragView& fv, ScanAggArgs* a) {
+  if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col >= 0 || p.n_quals > MI355Q_MAX_QUALS) return false;
+  std::memset(a, 0, sizeof(*a));
+  for (int i = 0; i < p.n_quals; ++i) {
+    if (!make_range_filter(p.quals[i], &a->flt[i])) return false;
+    a->flt_type[i] = p.quals[i].type;
+    if (!all_aligned16(fv, p.quals[i].col)) return false;
+  }
+  a->n_flt = p.n_quals;
+  for (int i = 0; i < p.n_targets; ++i) {
+    const DevTarget& t = p.targets[i];
+    a->target_cslot[i] = -1;
+    if (t.table != 0 || t.arg_f32) return false;
+    if (t.agg == MI355Q_COUNT && t.col < 0) continue;
+    if (t.agg != MI355Q_COUNT && t.agg != MI355Q_SUM && t.agg != MI355Q_MIN && t.agg != MI355Q_MAX && t.agg != MI355Q_AVG)
+      return false;
+    if (t.col < 0) return false;
+    if (t.arg_type != MI355Q_INT32 && t.arg_type != MI355Q_INT64 && t.arg_type != MI355Q_DOUBLE) return false;
+    // SUM / AVG of an integer column accumulate 64-bit; an AVG over integers keeps an integer sum slot
+    int cs = -1;
+    for (int c = 0; c < a->n_used; ++c)
+      if (a->col[c] == t.col) cs = c;
+    if (cs < 0) {
+      if (a->n_used >= kScanAggCols) return false;
+      cs = a->n_used++;
+      a->col[cs] = t.col;
+      a->type[cs] = t.arg_type;
+      a->nullable[cs] = t.skip_null;
+      if (!all_aligned16(fv, t.col)) return false;
+    } else if (a->nullable[cs] != t.skip_null) {
+      return false;  // one column, two NULL conventions: the row kernel
+    }
+    a->target_cslot[i] = cs;
+  }
+  return true;
+}
+
+bool scan_agg_eligible(const DevPlan& p, const FragView& fv) {
+  ScanAggArgs a;
+  return scan_agg_args(p, fv, &a);
+}
+
+hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus, hipStream_t s, LaunchStats* st) {
+  ScanAggArgs a;
+  if (!scan_agg_args(p, fv, &a)) return hipErrorInvalidValue;
+  const int grid = stream_grid(n_cus, 2, fv.total_rows);
+  st->kernel_name = "k_scan_agg";
+  st->n_launches = 1;
+  rec(st->k_start, s);
+  // every lane keeps about eight 16-byte loads in flight: quads per column per step by the number of columns
+  const int streams = a.n_used + a.n_flt;
+  if (streams <= 2)
+    hipLaunchKernelGGL((k_scan_agg<4, 2, 2>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out);
+  else if (streams <= 4)
+    hipLaunchKernelGGL((k_scan_agg<2, 4, 4>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out);
+  else
+    hipLaunchKernelGGL((k_scan_agg<1, kScanAggCols, MI355Q_MAX_QUALS>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out);
   rec(st->k_stop, s);
   return hipGetLastError();
 }

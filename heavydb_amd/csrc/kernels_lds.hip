@@ -1,0 +1,542 @@
+// kernels_lds.hip — GROUP BY with FEW groups: the whole table lives in every workgroup's LDS.
+//
+// The shapes of the reference's own synthetic benchmark that have up to a few thousand groups
+// (Benchmarks/synthetic_benchmark/queries: PerfectHashSingleCol/PHS001-003, PerfectHashMultiCol/PHM001-002,
+// BaselineHash/BH001-003 — GROUP BY cast(x AS DOUBLE) — and the MultiStep queries over x1k / x100 x y10): one to
+// three key columns, one to three VALUE columns, every aggregate kind over columns declared nullable.  Before this
+// kernel they ran in the row kernel: one global atomic per row and slot on a handful of addresses (0.2 - 2 % of the
+// roofline, and a baseline table with ten groups serialised the whole device on ten cache lines).
+//
+//   layout   per workgroup (1024 lanes, one per CU) K REPLICAS of the table in LDS; lane l updates replica l % K,
+//            so a table with 10 groups does not serialise 64 lanes on one LDS word (K = as many as fit, <= 64).
+//            One replica = one array per accumulator: rows (u32) per entry; per value column, as needed by the
+//            targets over it: non-NULL count (u32), sum (i64 / f64), min, max.  Perfect-hash layouts index the
+//            arrays by the entry index  sum_i (key_i - min_i) * mul_i  (NULL keys translated; get_group_value_fast,
+//            GroupByRuntime.cpp:208-223; perfect_key_hash, GroupByAndAggregate.cpp:1546-1598); baseline layouts
+//            keep an open-addressing key array per replica and use the LDS slot as the index.
+//   stream   the scan of k_scan_agg: every load of a step is issued before the first value is looked at.
+//   flush    replicas are folded into replica 0 inside the workgroup, then every live entry is merged into the
+//            output table with the reduce rule (reduce_target: the same code the reduce kernel runs, so NULL-aware
+//            slots, AVG pairs and projected keys behave exactly as in ResultSetStorage::reduce); baseline entries
+//            go through the reference's insert-or-find (get_group_value, GroupByRuntime.cpp:25-48).
+//   give up  a baseline table with more groups than a replica holds sets a flag; the caller re-runs the step with
+//            the partitioned family.
+#include <cstring>
+#include <type_traits>
+
+#include "fast_common.h"
+
+namespace mq {
+
+using namespace fast;
+
+namespace {
+
+constexpr int kLdsBlock = 1024;
+constexpr int kLdsVals = 3;              // value columns
+constexpr int kLdsKeys = 3;              // key columns (perfect hash)
+constexpr size_t kLdsBudget = 152 * 1024;
+constexpr uint32_t kLdsHashMax = 4096;   // slots of one baseline replica
+
+struct LdsVal {
+  int32_t col, type, nullable;           // type: MI355Q_INT32 / _INT64 / _DOUBLE (plain)
+  int32_t off_cnt, off_sum, off_min, off_max;  // byte offsets of the arrays inside a replica, -1 = not kept
+};
+struct LdsArgs {
+  int32_t n_vals, n_flt, n_keys;
+  int32_t baseline;                      // 0: perfect-hash index; 1: open addressing on one 8-byte key
+  uint32_t entries;                      // arrays' length: perfect entry count, or the hash slots (power of two)
+  int32_t copies_lg;                     // log2(K)
+  uint32_t copy_bytes;                   // bytes of one replica (16-byte multiple)
+  int32_t off_rows, off_keys;            // rows[entries] (u32); keys[entries] (int64, baseline)
+  LdsVal v[kLdsVals];
+  RangeFilter flt[MI355Q_MAX_QUALS];
+  int32_t flt_type[MI355Q_MAX_QUALS];
+  int32_t key_col[kLdsKeys], key_type[kLdsKeys], key_translate[kLdsKeys];
+  int64_t key_min[kLdsKeys], key_card[kLdsKeys], key_mul[kLdsKeys], key_null_key[kLdsKeys];
+  int32_t target_v[MI355Q_MAX_TARGETS];  // index into v[] of each target's argument, -1 = none
+};
+
+struct RawQ {
+  v4i32 lo, hi;
+};
+MQ_D void load_rawq(const int8_t* base, int64_t quad, bool w8, RawQ& r) {
+  if (w8) {
+    r.lo = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2);
+    r.hi = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2 + 1);
+  } else {
+    r.lo = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad);
+  }
+}
+MQ_D int64_t rawq_i64(const RawQ& r, int i) {
+  const v4i32& h = i < 2 ? r.lo : r.hi;
+  const int j = (i & 1) * 2;
+  return (int64_t)(((uint64_t)(uint32_t)(j ? h.w : h.y) << 32) | (uint64_t)(uint32_t)(j ? h.z : h.x));
+}
+MQ_D int32_t rawq_i32(const RawQ& r, int i) { return i == 0 ? r.lo.x : i == 1 ? r.lo.y : i == 2 ? r.lo.z : r.lo.w; }
+MQ_D int64_t rawq_int(const RawQ& r, int type, int i) { return type == MI355Q_INT32 ? (int64_t)rawq_i32(r, i) : rawq_i64(r, i); }
+
+MQ_D void lds_min_f64(int64_t* s, double v) {
+  int64_t old = *(volatile int64_t*)s;
+  for (;;) {
+    const double o = bits_dbl(old);
+    if (!(v < o)) return;
+    const int64_t seen = (int64_t)atomicCAS((unsigned long long*)s, (unsigned long long)old, (unsigned long long)dbl_bits(v));
+    if (seen == old) return;
+    old = seen;
+  }
+}
+MQ_D void lds_max_f64(int64_t* s, double v) {
+  int64_t old = *(volatile int64_t*)s;
+  for (;;) {
+    const double o = bits_dbl(old);
+    if (!(o < v)) return;
+    const int64_t seen = (int64_t)atomicCAS((unsigned long long*)s, (unsigned long long)old, (unsigned long long)dbl_bits(v));
+    if (seen == old) return;
+    old = seen;
+  }
+}
+
+// one value of value column c folded into entry e of replica `rep`
+MQ_D void lds_update(char* rep, const LdsVal& v, uint32_t e, int64_t bits) {
+  if (v.type == MI355Q_DOUBLE) {
+    const double x = bits_dbl(bits);
+    if (v.nullable && x == kNullDouble) return;
+    if (v.off_cnt >= 0) atomicAdd((uint32_t*)(rep + v.off_cnt) + e, 1u);
+    if (v.off_sum >= 0) atomicAdd((double*)(rep + v.off_sum) + e, x);
+    if (v.off_min >= 0) lds_min_f64((int64_t*)(rep + v.off_min) + e, x);
+    if (v.off_max >= 0) lds_max_f64((int64_t*)(rep + v.off_max) + e, x);
+  } else {
+    if (v.nullable && bits == (v.type == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN)) return;
+    if (v.off_cnt >= 0) atomicAdd((uint32_t*)(rep + v.off_cnt) + e, 1u);
+    if (v.off_sum >= 0) atomicAdd((unsigned long long*)(rep + v.off_sum) + e, (unsigned long long)bits);
+    if (v.off_min >= 0) atomicMin((long long*)(rep + v.off_min) + e, (long long)bits);
+    if (v.off_max >= 0) atomicMax((long long*)(rep + v.off_max) + e, (long long)bits);
+  }
+}
+
+// find-or-insert in one replica's key array (linear probing from a multiplicative hash); kNoSlot when full
+constexpr uint32_t kNoSlot = 0xffffffffu;
+MQ_D uint32_t lds_key_slot(int64_t* keys, uint32_t H, int64_t key) {
+  uint32_t s = (uint32_t)((uint64_t)key * 0x9E3779B97F4A7C15ull >> 40) & (H - 1);
+  for (uint32_t trips = 0; trips < H; ++trips) {
+    const int64_t k = *(volatile int64_t*)&keys[s];
+    if (k == key) return s;
+    if (k == kEmptyKey64) {
+      const int64_t old = (int64_t)atomicCAS((unsigned long long*)&keys[s], (unsigned long long)kEmptyKey64, (unsigned long long)key);
+      if (old == kEmptyKey64 || old == key) return s;
+      continue;  // another key took it: look at the slot again
+    }
+    s = (s + 1) & (H - 1);
+  }
+  return kNoSlot;
+}
+
+// NF / NK / NV: quals, key columns and value columns this member holds registers for; UQ quads per column per step.
+// Every index into the kernel-argument structs is a compile-time constant after unrolling: a dynamically indexed
+// by-value kernel argument is lowered to a private-memory (scratch) copy, and every access to it would then be a
+// scratch load in front of the column loads it feeds.
+template <int NF, int NK, int NV, int UQ>
+__global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* __restrict__ cols,
+                                                            const int64_t* __restrict__ num_rows, int n_frags, int n_cols,
+                                                            LdsArgs a, DevPlan p, int64_t* __restrict__ out,
+                                                            int32_t* __restrict__ d_err) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const uint32_t K = 1u << a.copies_lg;
+  const uint32_t ne = a.entries;
+  // ---- initialise every replica: counters 0, sums 0, min / max identities, keys empty
+  for (uint32_t r = 0; r < K; ++r) {
+    char* rep = smem + (size_t)r * a.copy_bytes;
+    for (uint32_t e = t; e < ne; e += kLdsBlock) {
+      ((uint32_t*)(rep + a.off_rows))[e] = 0;
+      if (a.baseline) ((int64_t*)(rep + a.off_keys))[e] = kEmptyKey64;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        if (c >= a.n_vals) break;
+        const LdsVal& v = a.v[c];
+        const bool fp = v.type == MI355Q_DOUBLE;
+        if (v.off_cnt >= 0) ((uint32_t*)(rep + v.off_cnt))[e] = 0;
+        if (v.off_sum >= 0) ((int64_t*)(rep + v.off_sum))[e] = 0;  // 0 and +0.0 share the pattern
+        if (v.off_min >= 0) ((int64_t*)(rep + v.off_min))[e] = fp ? 0x7fefffffffffffffll : INT64_MAX;
+        if (v.off_max >= 0) ((int64_t*)(rep + v.off_max))[e] = fp ? (int64_t)0xffefffffffffffffull : INT64_MIN;
+      }
+    }
+  }
+  __syncthreads();
+  char* const my_rep = smem + (size_t)((uint32_t)t & (K - 1)) * a.copy_bytes;
+  bool bad = false, full = false;
+
+  // one row whose quals passed: kv = the key columns' values (DOUBLE keys as their bit pattern), vv = the value columns'
+  auto one_row = [&](const int64_t (&kv)[NK], const int64_t (&vv)[NV]) {
+    uint32_t e;
+    if (a.baseline) {
+      e = lds_key_slot((int64_t*)(my_rep + a.off_keys), ne, kv[0]);
+      if (e == kNoSlot) {
+        full = true;
+        return;
+      }
+    } else {
+      int64_t idx = 0;
+      bool in_range = true;
+#pragma unroll
+      for (int g = 0; g < NK; ++g) {
+        if (g >= a.n_keys) break;
+        int64_t k = kv[g];
+        if (a.key_translate[g] && k == (a.key_type[g] == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN)) k = a.key_null_key[g];
+        const int64_t d = k - a.key_min[g];
+        in_range = in_range && d >= 0 && d < a.key_card[g];
+        idx += d * a.key_mul[g];
+      }
+      if (!in_range || (uint64_t)idx >= (uint64_t)ne) {
+        bad = true;
+        return;
+      }
+      e = (uint32_t)idx;
+    }
+    atomicAdd((uint32_t*)(my_rep + a.off_rows) + e, 1u);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      if (c >= a.n_vals) break;
+      lds_update(my_rep, a.v[c], e, vv[c]);
+    }
+  };
+
+  const int64_t tile_q = (int64_t)kLdsBlock * UQ;
+  const int64_t gtid = (int64_t)blockIdx.x * kLdsBlock + t;
+  const int64_t gsize = (int64_t)gridDim.x * kLdsBlock;
+  for (int f = 0; f < n_frags; ++f) {
+    if (*(volatile int32_t*)(d_err + 1)) break;  // some workgroup's replica overflowed: the step is re-run anyway
+    const int8_t* const* fc = cols + (size_t)f * n_cols;
+    const int64_t n = num_rows[f];
+    const int64_t nq = n >> 2;
+    const int64_t n_tiles = nq / tile_q;
+    // the fragment's chunk of every stream, fetched once
+    const int8_t *fb[NF > 0 ? NF : 1], *kb[NK], *vb[NV];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) fb[k] = k < a.n_flt ? fc[a.flt[k].col] : nullptr;
+#pragma unroll
+    for (int g = 0; g < NK; ++g) kb[g] = g < a.n_keys ? fc[a.key_col[g]] : nullptr;
+#pragma unroll
+    for (int c = 0; c < NV; ++c) vb[c] = c < a.n_vals ? fc[a.v[c].col] : nullptr;
+    auto do_step = [&](int64_t q0, int n_quads, int64_t stride) {
+      RawQ fr[NF > 0 ? NF : 1][UQ], kr[NK][UQ], vr[NV][UQ];
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        if (u >= n_quads) break;
+        const int64_t quad = q0 + (int64_t)u * stride;
+#pragma unroll
+        for (int k = 0; k < NF; ++k)
+          if (k < a.n_flt) load_rawq(fb[k], quad, a.flt_type[k] != MI355Q_INT32, fr[k][u]);
+#pragma unroll
+        for (int g = 0; g < NK; ++g)
+          if (g < a.n_keys) load_rawq(kb[g], quad, a.key_type[g] != MI355Q_INT32, kr[g][u]);
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          if (c < a.n_vals) load_rawq(vb[c], quad, a.v[c].type != MI355Q_INT32, vr[c][u]);
+      }
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        if (u >= n_quads) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bool pass = true;
+#pragma unroll
+          for (int k = 0; k < NF; ++k) {
+            if (k >= a.n_flt) break;
+            pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], rawq_i32(fr[k][u], i))
+                                                          : filter_pass<int64_t>(a.flt[k], rawq_i64(fr[k][u], i)));
+          }
+          if (!pass) continue;
+          int64_t kv[NK], vv[NV];
+#pragma unroll
+          for (int g = 0; g < NK; ++g) kv[g] = g < a.n_keys ? rawq_int(kr[g][u], a.key_type[g] == MI355Q_INT32 ? MI355Q_INT32 : MI355Q_INT64, i) : 0;
+#pragma unroll
+          for (int c = 0; c < NV; ++c) vv[c] = c < a.n_vals ? rawq_int(vr[c][u], a.v[c].type == MI355Q_INT32 ? MI355Q_INT32 : MI355Q_INT64, i) : 0;
+          one_row(kv, vv);
+        }
+      }
+    };
+    for (int64_t tl = (blockIdx.x + (int64_t)f * 7) % gridDim.x; tl < n_tiles; tl += gridDim.x)
+      do_step(tl * tile_q + t, UQ, kLdsBlock);
+    for (int64_t q = n_tiles * tile_q + gtid; q < nq; q += gsize) do_step(q, 1, 0);
+    const int64_t tail = (nq << 2) + gtid;
+    if (tail < n) {
+      bool pass = true;
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        if (k >= a.n_flt) break;
+        pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], load_one<int32_t>(fb[k], tail))
+                                                      : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fb[k], tail)));
+      }
+      if (pass) {
+        int64_t kv[NK], vv[NV];
+#pragma unroll
+        for (int g = 0; g < NK; ++g)
+          kv[g] = g >= a.n_keys ? 0 : a.key_type[g] == MI355Q_INT32 ? (int64_t)load_one<int32_t>(kb[g], tail) : load_one<int64_t>(kb[g], tail);
+#pragma unroll
+        for (int c = 0; c < NV; ++c)
+          vv[c] = c >= a.n_vals ? 0 : a.v[c].type == MI355Q_INT32 ? (int64_t)load_one<int32_t>(vb[c], tail) : load_one<int64_t>(vb[c], tail);
+        one_row(kv, vv);
+      }
+    }
+  }
+  if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+  if (full) atomicExch(d_err + 1, 1);  // more groups than a replica holds: the caller takes another family
+  __syncthreads();
+
+  // ---- fold replicas 1 .. K-1 into replica 0
+  char* const rep0 = smem;
+  for (uint32_t r = 1; r < K; ++r) {
+    char* rep = smem + (size_t)r * a.copy_bytes;
+    for (uint32_t e = t; e < ne; e += kLdsBlock) {
+      const uint32_t rows = ((uint32_t*)(rep + a.off_rows))[e];
+      if (!rows) continue;
+      uint32_t e0 = e;
+      if (a.baseline) {
+        e0 = lds_key_slot((int64_t*)(rep0 + a.off_keys), ne, ((int64_t*)(rep + a.off_keys))[e]);
+        if (e0 == kNoSlot) {
+          atomicExch(d_err + 1, 1);
+          continue;
+        }
+      }
+      atomicAdd((uint32_t*)(rep0 + a.off_rows) + e0, rows);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        if (c >= a.n_vals) break;
+        const LdsVal& v = a.v[c];
+        const bool fp = v.type == MI355Q_DOUBLE;
+        if (v.off_cnt >= 0) atomicAdd((uint32_t*)(rep0 + v.off_cnt) + e0, ((uint32_t*)(rep + v.off_cnt))[e]);
+        if (v.off_sum >= 0) {
+          if (fp) atomicAdd((double*)(rep0 + v.off_sum) + e0, ((double*)(rep + v.off_sum))[e]);
+          else atomicAdd((unsigned long long*)(rep0 + v.off_sum) + e0, ((unsigned long long*)(rep + v.off_sum))[e]);
+        }
+        if (v.off_min >= 0) {
+          if (fp) lds_min_f64((int64_t*)(rep0 + v.off_min) + e0, ((double*)(rep + v.off_min))[e]);
+          else atomicMin((long long*)(rep0 + v.off_min) + e0, ((long long*)(rep + v.off_min))[e]);
+        }
+        if (v.off_max >= 0) {
+          if (fp) lds_max_f64((int64_t*)(rep0 + v.off_max) + e0, ((double*)(rep + v.off_max))[e]);
+          else atomicMax((long long*)(rep0 + v.off_max) + e0, ((long long*)(rep + v.off_max))[e]);
+        }
+      }
+    }
+    __syncthreads();  // (baseline: inserts into replica 0 of one round must be visible to the next)
+  }
+
+  // ---- merge every live entry of replica 0 into the output table with the reduce rule
+  for (uint32_t e = t; e < ne; e += kLdsBlock) {
+    const uint32_t rows = ((const uint32_t*)(rep0 + a.off_rows))[e];
+    if (!rows) continue;
+    int64_t key0 = 0, key1 = 0, key2 = 0;  // the group columns' values as decoded (what a projection shows)
+    int64_t* slots;
+    if (a.baseline) {
+      key0 = ((const int64_t*)(rep0 + a.off_keys))[e];
+      slots = baseline_find_or_insert(out, (uint32_t)p.entry_count, p.row_quad, p.key_width, key0);
+      if (!slots) {
+        atomicCAS(d_err, 0, -1);  // out of group slots: the caller grows the table and retries
+        continue;
+      }
+    } else {
+      int64_t tk0 = 0, tk1 = 0, tk2 = 0;
+      uint32_t rem = e;
+#pragma unroll
+      for (int g = NK - 1; g >= 0; --g) {  // entry index -> key components (mul_g ascending with g)
+        if (g >= a.n_keys) continue;
+        const int64_t d = (int64_t)(rem / (uint32_t)a.key_mul[g]);
+        rem -= (uint32_t)(d * a.key_mul[g]);
+        const int64_t tk = d + a.key_min[g];
+        const int64_t orig = (a.key_translate[g] && tk == a.key_null_key[g])
+                                 ? (a.key_type[g] == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN) : tk;
+        if (g == 0) { tk0 = tk; key0 = orig; } else if (g == 1) { tk1 = tk; key1 = orig; } else { tk2 = tk; key2 = orig; }
+      }
+      int64_t* row = out + (size_t)e * p.row_quad;
+      if (!p.keyless) {
+        if (MQ_LOAD64(row) == kEmptyKey64) {
+          if (a.n_keys > 2) MQ_STORE64(row + 2, tk2);
+          if (a.n_keys > 1) MQ_STORE64(row + 1, tk1);
+          MQ_STORE64(row, tk0);
+        }
+        slots = row + a.n_keys;
+      } else {
+        slots = row;
+      }
+    }
+    // the entry's partial row, slot by slot (static slot indices: no private-memory array), merged with the reduce rule
+#pragma unroll
+    for (int i = 0; i < MI355Q_MAX_TARGETS; ++i) {
+      if (i >= p.n_targets) break;
+      const DevTarget& tg = p.targets[i];
+      if (tg.slot < 0) continue;
+      int64_t v0 = p.init_vals[tg.slot], v1 = tg.agg == MI355Q_AVG ? p.init_vals[tg.slot + 1] : 0;
+      if (tg.agg == MI355Q_PROJECT_KEY) {
+        v0 = tg.key_idx == 0 ? key0 : tg.key_idx == 1 ? key1 : key2;
+      } else {
+        const int c = a.target_v[i];
+        if (c < 0) {
+          v0 = (int64_t)rows;
+        } else {
+          const LdsVal v = c == 0 ? a.v[0] : (NV > 1 && c == 1) ? a.v[NV > 1 ? 1 : 0] : a.v[NV > 2 ? 2 : 0];
+          // rows with a value: the non-NULL counter where one is kept (nullable column), else every row
+          const uint32_t cnt = v.off_cnt >= 0 ? ((const uint32_t*)(rep0 + v.off_cnt))[e] : rows;
+          switch (tg.agg) {
+            case MI355Q_COUNT: v0 = (int64_t)cnt; break;
+            case MI355Q_AVG:
+              v1 = (int64_t)cnt;
+              [[fallthrough]];
+            case MI355Q_SUM:
+              if (cnt) v0 = ((const int64_t*)(rep0 + v.off_sum))[e];
+              break;
+            case MI355Q_MIN:
+              if (cnt) v0 = ((const int64_t*)(rep0 + v.off_min))[e];
+              break;
+            default:
+              if (cnt) v0 = ((const int64_t*)(rep0 + v.off_max))[e];
+          }
+        }
+      }
+      // reduce_target reads that_slots[t.slot (+ 1)]: hand it a two-quad window positioned at the target's slot
+      int64_t win[2] = {v0, v1};
+      DevTarget lt = tg;
+      lt.slot = 0;
+      reduce_target<true>(lt, p.init_vals + tg.slot, slots + tg.slot, win);
+    }
+  }
+}
+
+bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
+  LdsArgs& a = *out;
+  std::memset(&a, 0, sizeof(a));
+  if (p.desc_type == MI355Q_NON_GROUPED_AGGREGATE || p.join_col >= 0 || p.col0_key_quirk || p.slot_width != 8) return false;
+  if (p.n_quals > MI355Q_MAX_QUALS) return false;
+  for (int i = 0; i < p.n_quals; ++i) {
+    if (!make_range_filter(p.quals[i], &a.flt[i])) return false;
+    a.flt_type[i] = p.quals[i].type;
+    if (!all_aligned16(fv, p.quals[i].col)) return false;
+  }
+  a.n_flt = p.n_quals;
+  // keys
+  if (p.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
+    if (p.n_group < 1 || p.n_group > kLdsKeys || p.entry_count < 1 || p.entry_count > 65536) return false;
+    for (int g = 0; g < p.n_group; ++g) {
+      if (p.group_types[g] != MI355Q_INT32 && p.group_types[g] != MI355Q_INT64) return false;
+      if (p.group_bucket[g] != 0 || !all_aligned16(fv, p.group_cols[g])) return false;
+      a.key_col[g] = p.group_cols[g];
+      a.key_type[g] = p.group_types[g];
+      a.key_translate[g] = p.group_translate[g];
+      a.key_min[g] = p.group_min[g];
+      a.key_card[g] = p.group_card[g];
+      a.key_mul[g] = p.group_mul[g];
+      a.key_null_key[g] = p.group_null_key[g];
+      if (g > 0 && p.group_mul[g] < p.group_mul[g - 1]) return false;  // (the flush divides in descending order)
+    }
+    a.n_keys = p.n_group;
+    a.entries = (uint32_t)p.entry_count;
+  } else if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
+    // one 8-byte-wide key column (BIGINT, or DOUBLE as its bit pattern); 4-byte keys take the value sign-extended
+    if (p.n_group != 1) return false;
+    const int kt = p.group_types[0];
+    if (kt != MI355Q_INT64 && kt != MI355Q_DOUBLE && kt != MI355Q_INT32) return false;
+    if (!all_aligned16(fv, p.group_cols[0])) return false;
+    a.key_col[0] = p.group_cols[0];
+    a.key_type[0] = kt;
+    a.n_keys = 1;
+    a.baseline = 1;
+    a.entries = kLdsHashMax;
+  } else {
+    return false;
+  }
+  // targets -> value columns and the accumulators each needs
+  for (int c = 0; c < kLdsVals; ++c) a.v[c].off_cnt = a.v[c].off_sum = a.v[c].off_min = a.v[c].off_max = -1;
+  bool need[kLdsVals][4] = {};
+  for (int i = 0; i < p.n_targets; ++i) {
+    const DevTarget& t = p.targets[i];
+    a.target_v[i] = -1;
+    if (t.agg == MI355Q_PROJECT_KEY) continue;
+    if (t.table != 0 || t.arg_f32) return false;
+    if (t.agg == MI355Q_COUNT && t.col < 0) continue;
+    if (t.agg != MI355Q_COUNT && t.agg != MI355Q_SUM && t.agg != MI355Q_MIN && t.agg != MI355Q_MAX && t.agg != MI355Q_AVG) return false;
+    if (t.col < 0) return false;
+    if (t.arg_type != MI355Q_INT32 && t.arg_type != MI355Q_INT64 && t.arg_type != MI355Q_DOUBLE) return false;
+    int c = -1;
+    for (int k = 0; k < a.n_vals; ++k)
+      if (a.v[k].col == t.col) c = k;
+    if (c < 0) {
+      if (a.n_vals >= kLdsVals || !all_aligned16(fv, t.col)) return false;
+      c = a.n_vals++;
+      a.v[c].col = t.col;
+      a.v[c].type = t.arg_type;
+      a.v[c].nullable = t.skip_null;
+    } else if (a.v[c].nullable != t.skip_null) {
+      return false;
+    }
+    a.target_v[i] = c;
+    if (t.skip_null) need[c][0] = true;  // (a NOT NULL column's count is the entry's `rows`)
+    if (t.agg == MI355Q_SUM || t.agg == MI355Q_AVG) need[c][1] = true;
+    if (t.agg == MI355Q_MIN) need[c][2] = true;
+    if (t.agg == MI355Q_MAX) need[c][3] = true;
+  }
+  // one replica: 8-byte arrays first, then the 4-byte counters
+  uint32_t off = 0;
+  if (a.baseline) {
+    a.off_keys = (int32_t)off;
+    off += a.entries * 8;
+  }
+  for (int c = 0; c < a.n_vals; ++c)
+    for (int k = 1; k < 4; ++k)
+      if (need[c][k]) {
+        (k == 1 ? a.v[c].off_sum : k == 2 ? a.v[c].off_min : a.v[c].off_max) = (int32_t)off;
+        off += a.entries * 8;
+      }
+  a.off_rows = (int32_t)off;
+  off += a.entries * 4;
+  for (int c = 0; c < a.n_vals; ++c)
+    if (need[c][0]) {
+      a.v[c].off_cnt = (int32_t)off;
+      off += a.entries * 4;
+    }
+  a.copy_bytes = (off + 15u) & ~15u;
+  if (a.copy_bytes > kLdsBudget) return false;
+  a.copies_lg = 0;
+  while (a.copies_lg < 6 && ((size_t)a.copy_bytes << (a.copies_lg + 1)) <= kLdsBudget) ++a.copies_lg;
+  return a.n_flt + a.n_keys + a.n_vals <= 8;
+}
+
+}  // namespace
+
+bool lds_groupby_eligible(const DevPlan& p, const FragView& fv) {
+  LdsArgs a;
+  return make_lds_args(p, fv, &a);
+}
+
+hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int n_cus,
+                              hipStream_t s, LaunchStats* st) {
+  LdsArgs a;
+  if (!make_lds_args(p, fv, &a)) return hipErrorInvalidValue;
+  const size_t lds = (size_t)a.copy_bytes << a.copies_lg;
+  int64_t want = (fv.total_rows / 4 + kLdsBlock - 1) / kLdsBlock;
+  if (want < 1) want = 1;
+  const int grid = (int)(want < n_cus ? want : n_cus);
+  st->kernel_name = "k_groupby_lds";
+  st->n_launches = 1;
+  st->variant = 4;
+  rec(st->k_start, s);
+  const int streams = a.n_flt + a.n_keys + a.n_vals;
+#define MQ_LDS_LAUNCH(NF, NK, NV, UQ)                                                                                \
+  do {                                                                                                               \
+    auto k = k_groupby_lds<NF, NK, NV, UQ>;                                                                          \
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kLdsBlock), lds, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, \
+                       out, d_err);                                                                                  \
+  } while (0)
+  (void)streams;
+  if (a.n_flt <= 1 && a.n_keys == 1 && a.n_vals <= 1) MQ_LDS_LAUNCH(1, 1, 1, 2);       // PHS / BH shapes
+  else if (a.n_flt <= 1 && a.n_vals <= 1) MQ_LDS_LAUNCH(1, 3, 1, 1);                     // PHM shapes
+  else if (a.n_flt <= 1 && a.n_keys == 1) MQ_LDS_LAUNCH(1, 1, 3, 1);                     // MultiStep, one key
+  else MQ_LDS_LAUNCH(4, 3, 3, 1);
+#undef MQ_LDS_LAUNCH
+  rec(st->k_stop, s);
+  return hipGetLastError();
+}
+
+}  // namespace mq

@@ -142,7 +142,6 @@ struct PartSlots {
   int32_t nn_hidden;                  // nn_slot is not mapped by any output slot
   int32_t pad_;
   int64_t null_bits;                  // the value column's NULL as loaded
-  int64_t slot_null;                  // sentinel of the null_init output slots
 };
 
 MQ_D int64_t op_identity_dev(int op) {
@@ -1002,7 +1001,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
             if (m >= 0) {
               int64_t v = row[1 + j];
               if (tab.sp.null_init[j]) {
-                if (v == ps.slot_null) v = ps.int_init[m];  // NULL so far: contributes nothing
+                if (v == tab.init[j]) v = ps.int_init[m];  // NULL so far (the slot's own sentinel): contributes nothing
                 else any_value = true;
               }
               part[m] = v;
@@ -1123,7 +1122,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_aggregate(PartGeom g, const
         const int m = ps.out_map[j];
         int64_t v = m >= 0 ? lds_slot_value(ps.int_op[m], smem_raw + g.slot_off[m], e)
                            : (tab.sp.op[j] == SO_KEY ? key : tab.init[j]);
-        if (tab.sp.null_init[j] && no_value) v = ps.slot_null;  // SUM / MIN / MAX of no value: NULL
+        if (tab.sp.null_init[j] && no_value) v = tab.init[j];  // SUM / MIN / MAX of no value: the slot's NULL
         row[1 + j] = v;
       }
     }
@@ -1166,12 +1165,12 @@ MQ_D void merge_partial_global(const PartSlots& ps, const TableArgs& tab, const 
     if (no_value) continue;  // the partial holds no value: the slot keeps what it has (NULL or not)
     const int64_t v = part[m];
     switch (tab.sp.op[j]) {  // slot starts at the NULL sentinel: first value overwrites it
-      case SO_SUM_I: a_sum_i64_skip<true>(slots + j, v, ps.slot_null); break;
-      case SO_SUM_F: a_sum_f64_skip<true>(slots + j, bits_dbl(v), bits_dbl(ps.slot_null)); break;
-      case SO_MIN_I: a_min_i64_skip<true>(slots + j, v, ps.slot_null); break;
-      case SO_MAX_I: a_max_i64_skip<true>(slots + j, v, ps.slot_null); break;
-      case SO_MIN_F: a_minmax_f64<true, false, true>(slots + j, bits_dbl(v), bits_dbl(ps.slot_null)); break;
-      case SO_MAX_F: a_minmax_f64<true, true, true>(slots + j, bits_dbl(v), bits_dbl(ps.slot_null)); break;
+      case SO_SUM_I: a_sum_i64_skip<true>(slots + j, v, tab.init[j]); break;
+      case SO_SUM_F: a_sum_f64_skip<true>(slots + j, bits_dbl(v), bits_dbl(tab.init[j])); break;
+      case SO_MIN_I: a_min_i64_skip<true>(slots + j, v, tab.init[j]); break;
+      case SO_MAX_I: a_max_i64_skip<true>(slots + j, v, tab.init[j]); break;
+      case SO_MIN_F: a_minmax_f64<true, false, true>(slots + j, bits_dbl(v), bits_dbl(tab.init[j])); break;
+      case SO_MAX_F: a_minmax_f64<true, true, true>(slots + j, bits_dbl(v), bits_dbl(tab.init[j])); break;
       default: break;
     }
   }
@@ -2026,7 +2025,6 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   // emission whether the slot holds a value or is still NULL (COUNT(col) / AVG already keep one)
   h.ps.val_nullable = fs.sp.val_nullable;
   h.ps.null_bits = fs.sp.null_bits;
-  h.ps.slot_null = fs.sp.slot_null;
   h.ps.nn_slot = -1;
   h.ps.nn_hidden = 0;
   h.ps.pad_ = 0;

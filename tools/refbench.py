@@ -156,6 +156,10 @@ def main():
     ap.add_argument("--verify-rows", type=float, default=0, help="also check every query against the oracle on a table "
                     "of this many rows (test infrastructure; 0 = skip)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--budget-ms", type=float, default=1500.0, help="a query whose step on the first fragment "
+                    "extrapolates beyond this at the full size is not run at the full size (the extrapolation is "
+                    "reported instead): a shape that still takes the row kernel with a handful of groups serialises "
+                    "the device on a few cache lines for minutes")
     args = ap.parse_args()
     import torch
     from heavydb_amd import capi
@@ -190,6 +194,21 @@ def main():
         bpr = sum(4 if dict(INT_COLS).get(c) else 8 for c in used)
         line = {"query": name, "rows": n_rows, "bytes_per_row": bpr}
         try:
+            # probe on the first fragment: kernel choice and a rate
+            fr1 = FetchResult(bufs[:1], rows[:1], keepalive=cols)
+            ex.executeWorkUnit(ra, fr1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rs1 = ex.executeWorkUnit(ra, fr1)
+            torch.cuda.synchronize()
+            probe_ms = (time.perf_counter() - t0) * 1e3
+            est = probe_ms * n_rows / rows[0]
+            if est > args.budget_ms:
+                line.update(kernel=rs1.report.kernel_name.decode(), skipped=True, probe_rows=rows[0], probe_ms=round(probe_ms, 3),
+                            extrapolated_ms=round(est, 1), whole_step_frac=round(n_rows * bpr / (est * 1e-3) / 8e12, 5))
+                print(json.dumps(line), flush=True)
+                out_lines.append(line)
+                continue
             rs = ex.executeWorkUnit(ra, fr)      # warm-up (workspace, retry ladder of the entry guess)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
