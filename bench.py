@@ -265,6 +265,30 @@ def main():
     ms_per_step = elapsed * 1e3 / max(args.steps, 1)
     rows_per_s = total_rows * args.steps / elapsed
 
+    # N > 1: one more, UNTIMED step taken apart on every rank — the rank's own step, then the merge — so that the line
+    # shows where a rank's time goes (the timed loop above has no sync between the two)
+    per_rank = None
+    if world > 1:
+        from heavydb_amd import multi_gpu
+        sync()
+        t1 = time.perf_counter()
+        sh1 = HipShard.execute(torch, ex, ra, fr, kernel_variant=args.variant, force_generic=args.force_generic,
+                               scratch_bytes=int(args.scratch_gb * 2**30))
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        merge(sh1, dist, torch, prepartitioned=prepart)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        r1 = sh1.report
+        mine = {"rank": rank, "rows": local_rows, "step_ms": round((t2 - t1) * 1e3, 3), "merge_ms": round((t3 - t2) * 1e3, 3),
+                "kernel": r1.kernel_name.decode(), "kernel_ms_per_launch": round(float(r1.kernel_ms) / max(int(r1.n_launches), 1), 3),
+                "launches": int(r1.n_launches),
+                "roofline_frac": round(float(r1.algorithmic_bytes) / max(float(r1.kernel_ms), 1e-9) / 1e6 / HBM_PEAK_GBS, 4),
+                "merge_bytes_sent": int(multi_gpu.LAST_MERGE_BYTES_SENT), "keyed_merge": multi_gpu.LAST_KEYED_PATH or None}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
+
     # dominant kernel roofline (rank 0's launches; HIP events on the launch stream)
     k_ms = sum(r.kernel_ms for r in reports)
     k_n = sum(max(r.n_launches, 1) for r in reports)
@@ -277,15 +301,37 @@ def main():
     traffic = None
     traffic_source = None
     try:
+        import hashlib
         with open(args.traffic_json) as f:
-            tj = json.load(f).get(kname)
-        # the committed PMC passes were taken on the default workload (cfg3f) only
+            tall = json.load(f)
+        tj = tall.get(kname)
+        # the counters belong to ONE build of the kernel: the file records the hash of the kernel source it was
+        # measured on (tools/make_traffic_json.py), and a build whose source differs reports no traffic rather than
+        # a number that can no longer notice a regression.  The PMC passes are taken on the default workload only.
+        src = os.path.join(ROOT, "heavydb_amd", "csrc", "kernels_part.hip")
+        sha = hashlib.sha256(open(src, "rb").read()).hexdigest()[:16]
         if tj and k_n and cfg == "cfg3f":
-            rows_per_launch = sum(r.rows_scanned for r in reports) / k_n
-            traffic = tj["hbm_bytes_per_row"] * rows_per_launch
-            traffic_source = "static: " + tj.get("source", "profiles/traffic.json (rocprofv3 --pmc pass of this workload)")
+            if tall.get("kernel_source_sha16") == sha:
+                rows_per_launch = sum(r.rows_scanned for r in reports) / k_n
+                traffic = tj["hbm_bytes_per_row"] * rows_per_launch
+                traffic_source = "rocprofv3 --pmc passes of this build (kernels_part.hip " + sha + "): " + tj.get("from", "")[:160]
+            else:
+                traffic_source = "none: profiles/traffic.json was measured on another build of kernels_part.hip"
     except Exception:
         pass
+
+    # what the partition-then-aggregate scheme can reach at best on THIS box: per input row 20 B read,
+    # s x 16 B of records written, R x s x 16 B of records read back, each at the rate the box measures for that
+    # kind of traffic (reads: the scan kernel; writes: derived from the copy rate, a copy being one read + one write)
+    scheme_ceiling = None
+    if cfg == "cfg3f" and ceiling and ceiling.get("read_gbs") and ceiling.get("copy_gbs"):
+        rd = ceiling["read_gbs"]
+        wr = 1.0 / max(2.0 / ceiling["copy_gbs"] - 1.0 / rd, 1e-9)
+        sel, R = 0.5, 2
+        ns_per_row = 20.0 / rd + sel * 16.0 / wr + R * sel * 16.0 / (0.93 * rd)
+        scheme_ceiling = {"frac": 20.0 / ns_per_row / HBM_PEAK_GBS, "read_gbs": rd, "write_gbs": round(wr, 1),
+                          "selectivity": sel, "sub_ranges": R,
+                          "formula": "20 B / (20/read + s*16/write + R*s*16/(0.93*read)) / 8 TB/s"}
 
     verify = None
     if args.verify and rank == 0:
@@ -331,8 +377,13 @@ def main():
                      "kernel": kname, "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": alg_bytes_launch,
                      "whole_step_achieved": total_rows * bpr * args.steps / elapsed / 1e9,
                      "whole_step_frac": total_rows * bpr * args.steps / elapsed / 1e9 / HBM_PEAK_GBS,
+                     "scheme_ceiling_frac": scheme_ceiling["frac"] if scheme_ceiling else None,
+                     "scheme_ceiling": scheme_ceiling,
                      "measured_ceiling": ceiling},
     }
+    if per_rank:
+        out["per_rank"] = per_rank
+        out["ranks_reported_by_rccl"] = world if dist is None else dist.get_world_size()
     if verify:
         out["verify"] = verify
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -185,11 +185,11 @@ class ExecOptions(C.Structure):
         ("probe_keyed_passes", C.c_int32),
         ("pass_rows", C.c_int64),
         ("flags", C.c_uint32),
-        ("reserved", C.c_int32),
+        ("tune_cus", C.c_int32),
     ]
 
 
-OPT_TRACE, OPT_NO_PAIR_RENDEZVOUS, OPT_PROBE_NO_PACING = 1, 2, 4
+OPT_TRACE, OPT_NO_PAIR_RENDEZVOUS, OPT_PROBE_NO_PACING, OPT_NO_LDS_BASELINE, OPT_LDS_BASELINE_LARGE = 1, 2, 4, 8, 16
 
 
 class ExecReport(C.Structure):

@@ -866,6 +866,7 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
 namespace {
 
 constexpr int32_t kNotTaken = INT32_MIN + 7;  // internal: "use the ordinary path"
+constexpr int32_t kRetryNoLds = INT32_MIN + 8;  // internal: the LDS group-by ran out of replica room, plan again without it
 
 bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, PackSpec* ps) {
   if (p.join_outer_col >= 0 || p.n_group_cols < 1 || d.col0_key_quirk) return false;
@@ -908,7 +909,12 @@ bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, P
     }
     return true;
   }
-  if (q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || p.n_group_cols < 2) return false;
+  // baseline layouts: several key columns, or ONE key column whose table has 4-byte key components
+  // (pick_baseline_key_width: every key fits int32 — the reference benchmark's x10k_s10k / x100k_s10k BIGINT keys):
+  // the partitioned family emits 8-byte keys, so the step runs on the packed (key - min) column into a temporary
+  // 8-byte-key table and k_unpack_emit lays the finished groups out with the real 4-byte components
+  if (q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return false;
+  if (p.n_group_cols < 2 && q.key_width != 4) return false;
   int shift = 0;
   for (int g = 0; g < p.n_group_cols; ++g) {
     const int c = p.group_cols[g];
@@ -1203,21 +1209,9 @@ int32_t finish_step(TailState& t, mi355q_exec_report* report) {
     HIP_TRY(hipMemcpyAsync(h_err, t.d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
-  if (h_err[1] && t.kind == K_LDS_GROUPBY) {
-    // more groups than an LDS replica holds (a baseline table: the group count is only known now): redo the step
-    // with the partitioned / direct family, or the row kernel
-    HIP_TRY(hipMemsetAsync(t.d_err, 0, 64, s));
-    HIP_TRY(launch_init_buffer(t.res->buf, q.entry_count, make_row_init(q), s));
-    if (baseline_fast_eligible(d, fv)) {
-      HIP_TRY(launch_baseline_fast(d, fv, t.res->buf, t.d_err, nullptr, 0, 0, 1, t.n_cus, s, &st));
-    } else {
-      HIP_TRY(launch_generic(d, q.idx_target_as_key, make_row_init(q), t.d_cols, t.d_rows, t.nf, t.max_frag_rows, t.res->buf,
-                             t.d_err, t.n_cus, s));
-      st.kernel_name = "k_generic";
-    }
-    HIP_TRY(hipMemcpyAsync(h_err, t.d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-  }
+  // more groups than an LDS replica holds (a baseline table: the group count is only known now): the caller plans
+  // the step again without that member (packed route / partitioned family / row kernel, whatever applies)
+  if (h_err[1] && t.kind == K_LDS_GROUPBY) return kRetryNoLds;
   if (h_err[1] && t.kind == K_BASELINE_FAST) {
     // the partitioned family ran out of spill space (extreme skew): redo the step with the
     // direct-atomic member of the same family
@@ -1278,6 +1272,128 @@ void drain_inflight(DeviceCtx& ctx) {
 int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options* opts,
                      mi355q_result** out, mi355q_exec_report* report, mi355q_pending** pend,
                      int64_t* reserved = nullptr);
+
+// Grouped steps whose aggregates read SEVERAL value columns, over inputs large enough for the partitioned / packed
+// routes: one run per value column through the single-value families, zipped into the final layout
+// (kernels_generic.hip k_zip_targets).  kNotTaken when the shape does not call for it.
+int32_t execute_multi_value(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
+                            const mi355q_qmd& q, const DevPlan& d, mi355q_result** out, mi355q_exec_report* report) {
+  if (plan->n_group_cols < 1 || plan->join_outer_col >= 0 || q.slot_width != 8 || q.output_columnar || d.col0_key_quirk)
+    return kNotTaken;
+  // the value columns, in order of first use
+  int vcols[MI355Q_MAX_TARGETS], n_v = 0;
+  for (int t = 0; t < plan->n_targets; ++t) {
+    const mi355q_target& tg = plan->targets[t];
+    if (tg.agg == MI355Q_PROJECT_KEY || tg.col < 0) continue;
+    if (tg.table != 0 || tg.agg == MI355Q_COUNT_IF || tg.agg == MI355Q_SUM_IF) return kNotTaken;
+    bool seen = false;
+    for (int k = 0; k < n_v; ++k) seen = seen || vcols[k] == tg.col;
+    if (!seen) vcols[n_v++] = tg.col;
+  }
+  if (n_v < 2 || n_v > 4) return kNotTaken;
+  int64_t total_rows = 0;
+  for (int f = 0; f < in->n_frags; ++f) total_rows += in->num_rows[f];
+  if (total_rows < ((int64_t)8 << 20)) return kNotTaken;   // small inputs: one pass of the row kernel is as good
+
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  mi355q_result* res = nullptr;
+  if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;   // initialised
+  struct ResGuard {
+    mi355q_result* r;
+    ~ResGuard() { if (r) mi355q_result_free(r); }
+  } rg{res};
+  DevWord err;
+  HIP_TRY(hipMalloc(&err.p, 64));
+  HIP_TRY(hipMemsetAsync(err.p, 0, 64, s));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+  mi355q_exec_report acc{};
+  for (int k = 0; k < n_v; ++k) {
+    // run k: the targets over value column k; run 0 also carries COUNT(*) and the key projections
+    mi355q_plan sp = *plan;
+    sp.n_targets = 0;
+    int orig_of[MI355Q_MAX_TARGETS];
+    for (int t = 0; t < plan->n_targets; ++t) {
+      const mi355q_target& tg = plan->targets[t];
+      const bool valueless = tg.agg == MI355Q_PROJECT_KEY || tg.col < 0;
+      if (valueless ? k == 0 : tg.col == vcols[k]) {
+        orig_of[sp.n_targets] = t;
+        sp.targets[sp.n_targets++] = tg;
+      }
+    }
+    mi355q_exec_options o2 = o;
+    o2.stream = s;
+    o2.out_buffer = nullptr;
+    mi355q_result* r2 = nullptr;
+    mi355q_exec_report rep2{};
+    if (int32_t e2 = mi355q_execute(&sp, in, &o2, &r2, &rep2)) return e2;
+    struct R2Guard {
+      mi355q_result* r;
+      ~R2Guard() { if (r) mi355q_result_free(r); }
+    } r2g{r2};
+    const mi355q_qmd& q2 = r2->qmd;
+    if (q2.desc_type != q.desc_type || q2.entry_count != q.entry_count || q2.slot_width != 8 || q2.output_columnar ||
+        (q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && q2.key_width != q.key_width))
+      return MI355Q_ERR_UNSUPPORTED;
+    int32_t src[MI355Q_MAX_SLOTS], dst[MI355Q_MAX_SLOTS];
+    int n = 0;
+    for (int t2 = 0; t2 < sp.n_targets; ++t2) {
+      const int t = orig_of[t2];
+      const int ss = q2.target_slot[t2], sf = q.target_slot[t];
+      if ((ss < 0) != (sf < 0)) return MI355Q_ERR_UNSUPPORTED;   // (a projection read from the key columns on both sides)
+      if (ss < 0) continue;
+      const int ns = plan->targets[t].agg == MI355Q_AVG ? 2 : 1;
+      for (int j = 0; j < ns; ++j) {
+        if (q2.init_vals[ss + j] != q.init_vals[sf + j]) return MI355Q_ERR_UNSUPPORTED;
+        src[n] = ss + j;
+        dst[n] = sf + j;
+        ++n;
+      }
+    }
+    HIP_TRY(launch_zip_targets(res->dplan, r2->dplan, q2.idx_target_as_key, r2->buf, res->buf, src, dst, n, (int32_t*)err.p, s));
+    HIP_TRY(hipStreamSynchronize(s));   // r2 is freed at the end of this iteration
+    if (k == 0) {
+      std::snprintf(acc.kernel_name, sizeof(acc.kernel_name), "%s", rep2.kernel_name);
+      acc.variant = rep2.variant;
+    }
+    acc.kernel_ms += rep2.kernel_ms;
+    acc.n_launches += rep2.n_launches;
+    acc.spilled_rows += rep2.spilled_rows;
+  }
+  if (ev1) HIP_TRY(hipEventRecord(ev1, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_err) return h_err;
+  if (report) {
+    *report = acc;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  rg.r = nullptr;
+  *out = res;
+  return MI355Q_OK;
+}
 
 // Plans with projected expressions (mi355q_expr): scan / filter / PROJECT.  The expressions of a pass of
 // fragments are evaluated into dense temporary columns (k_project), the step runs on the lowered plan — where
@@ -1542,7 +1658,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
 
   DeviceGuard g(in->device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
-  const int n_cus = cu_count_of(in->device_id);
+  const int n_cus = o.tune_cus > 0 ? std::min(o.tune_cus, cu_count_of(in->device_id)) : cu_count_of(in->device_id);
 
   if (q.output_columnar) {
     // Columnar output: the step runs on the row-wise form of the same decisions (same entry
@@ -1625,7 +1741,9 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   // (small multi-column perfect-hash tables: the LDS group-by computes the entry index from the key columns itself,
   // no packed index column needed)
   bool lds_direct = false;
-  if (!o.force_generic && in->n_frags > 0 && o.kernel_variant == 0 && d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
+  if (!o.force_generic && in->n_frags > 0 && o.kernel_variant == 0 &&
+      (d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH ||
+       (d.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && d.entry_count <= 65536 && !(o.flags & MI355Q_OPT_NO_LDS_BASELINE) && !pend))) {
     int64_t tr = 0, mr = 0;
     for (int f = 0; f < in->n_frags; ++f) {
       tr += in->num_rows[f];
@@ -1638,6 +1756,21 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     const int32_t e = execute_packed_multi(plan, in, o, q, d, n_cus, out, report);
     if (e != kNotTaken) return e;
     *out = nullptr;
+  }
+
+  if (!o.force_generic && in->n_frags > 0 && !reserved && !lds_direct && o.kernel_variant != 1 && d.n_group >= 1) {
+    // several value columns over a large input (and no LDS-sized table): one run per value column, zipped
+    int64_t tr = 0, mr = 0;
+    for (int f = 0; f < in->n_frags; ++f) {
+      tr += in->num_rows[f];
+      mr = std::max(mr, in->num_rows[f]);
+    }
+    FragView fvh{nullptr, nullptr, in->col_buffers, in->num_rows, in->n_frags, plan->n_cols, tr, mr};
+    if (!lds_groupby_eligible(d, fvh) || (d.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && d.entry_count > 65536)) {
+      const int32_t e = execute_multi_value(plan, in, o, q, d, out, report);
+      if (e != kNotTaken && e != MI355Q_ERR_UNSUPPORTED) return e;
+      *out = nullptr;
+    }
   }
 
   hipStream_t s = (hipStream_t)o.stream;  // caller's, or the device context's own (below)
@@ -1716,7 +1849,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     // few groups: the table replicated in every workgroup's LDS (perfect-hash layouts up to 64 K entries that fit;
     // baseline layouts whose entry guess says "small" — if the groups turn out to be too many the step is re-run)
     else if (o.kernel_variant == 0 && lds_groupby_eligible(d, fv) &&
-             (d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH || d.entry_count <= 65536))
+             (d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH ||
+              (d.entry_count <= 65536 && !(o.flags & MI355Q_OPT_NO_LDS_BASELINE) && !pend)))
       kind = K_LDS_GROUPBY;
     else if (baseline_fast_eligible(d, fv)) kind = K_BASELINE_FAST;
     else if (join_sum_eligible(d, fv)) kind = K_JOIN_SUM;
@@ -1943,6 +2077,14 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   const int32_t code = finish_step(*tail, report);
   delete tail;
   tr.mark("synchronized");
+  if (code == kRetryNoLds) {
+    mi355q_result_free(res);
+    rg.r = nullptr;
+    mi355q_exec_options o2 = o;
+    // small replicas did not hold the groups: the largest replica next, then another family
+    o2.flags |= (o.flags & MI355Q_OPT_LDS_BASELINE_LARGE) ? MI355Q_OPT_NO_LDS_BASELINE : MI355Q_OPT_LDS_BASELINE_LARGE;
+    return execute_impl(plan, in, &o2, out, report, nullptr, nullptr);
+  }
   if (code) return code;
   rg.r = nullptr;
   *out = res;

@@ -105,6 +105,10 @@ struct PackSpec {
 hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, const int64_t* d_num_rows,
                             int n_frags, int n_cols, int64_t max_frag_rows, int64_t* const* packed_cols,
                             int32_t* d_err, int n_cus, hipStream_t s);
+// copies slots src[i] of every live row of `sub` (layout ps) to slots dst[i] of the same group's row in `fin`
+// (layout pf, same group columns): see k_zip_targets
+hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_s, const int64_t* sub, int64_t* fin,
+                              const int32_t* src, const int32_t* dst, int n, int32_t* d_err, hipStream_t s);
 // projected expressions: d_cols is the pass's extended fragment table [frag][xs.n_cols + xs.n]; the last xs.n
 // pointers of every fragment are the output columns (dense, of each expression's result type).  p = the
 // device plan of the LOWERED plan (quals, join): it decides whether a row's overflow counts.

@@ -729,6 +729,69 @@ __global__ __launch_bounds__(kBlock) void k_project(DevExprSet xs, DevPlan p, ui
   }
 }
 
+// ---- several value columns through the single-value families --------------------------------
+// A grouped step whose aggregates read two or three different columns (the reference's MultiStep benchmark:
+// max(x100), max(x10), max(x10 + 1), sum(x100), sum(x10 + 1) per group) is run once per VALUE column through the
+// single-value kernel families — same keys, same quals, so every run finds the same groups — and the runs' tables
+// are zipped into the final layout: one lane per entry of a run's table locates the group's row in the final
+// table (same entry index for perfect-hash layouts; the reference's insert-or-find for baseline ones) and copies
+// the run's slots to where the final layout keeps them.
+struct ZipMap {
+  int32_t n;                          // slot copies
+  int32_t src[MI355Q_MAX_SLOTS], dst[MI355Q_MAX_SLOTS];  // slot index in the run's row -> slot index in the final row
+};
+__global__ __launch_bounds__(kBlock) void k_zip_targets(DevPlan pf, DevPlan ps, int idx_key_s, const int64_t* __restrict__ sub,
+                                                         int64_t* __restrict__ fin, ZipMap zm, int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < ps.entry_count; e += stride) {
+    const int64_t* row_s = sub + e * ps.row_quad;
+    if (is_empty_row(ps, row_s, idx_key_s)) continue;
+    const int64_t* slots_s = row_s + ps.key_quad;
+    int64_t* slots_f;
+    if (pf.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
+      int64_t* row_f = fin + e * pf.row_quad;   // same key columns and ranges: the same entry index
+      if (!pf.keyless) {
+        if (MQ_LOAD64(row_f) == kEmptyKey64) {
+          // the translated keys of the entry: from the run's key quads when it kept them, else from the index
+          int64_t rem = e;
+          for (int g = pf.n_group - 1; g >= 0; --g) {
+            int64_t tk;
+            if (!ps.keyless) {
+              tk = row_s[g];
+            } else {
+              const int64_t d = rem / pf.group_mul[g];
+              rem -= d * pf.group_mul[g];
+              tk = d * (pf.group_bucket[g] ? pf.group_bucket[g] : 1) + pf.group_min[g];
+            }
+            MQ_STORE64(row_f + g, tk);
+          }
+        }
+        slots_f = row_f + pf.n_group;
+      } else {
+        slots_f = row_f;
+      }
+    } else {
+      int64_t keys[MI355Q_MAX_GROUP_COLS];
+      for (int g = 0; g < pf.n_group; ++g) keys[g] = row_key_component(row_s, ps.key_width, g);
+      if (pf.n_group == 1) {
+        slots_f = baseline_find_or_insert(fin, (uint32_t)pf.entry_count, pf.row_quad, pf.key_width, keys[0]);
+      } else {
+        bool bad = false;
+        slots_f = baseline_find_or_insert_multi(fin, (uint32_t)pf.entry_count, pf.row_quad, pf.key_width, pf.n_group, keys, &bad);
+        if (bad) {
+          atomicCAS(d_err, 0, MI355Q_ERR_INVALID_PLAN);
+          continue;
+        }
+      }
+      if (!slots_f) {
+        atomicCAS(d_err, 0, -1);
+        continue;
+      }
+    }
+    for (int j = 0; j < zm.n; ++j) MQ_STORE64(slots_f + zm.dst[j], slots_s[zm.src[j]]);
+  }
+}
+
 // ---- synthetic columns ------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_generate(void* __restrict__ dst, int64_t n_rows,
                                                       int64_t row_offset, int kind, uint64_t seed,
@@ -1016,6 +1079,19 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
   if (n_frags <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_pack_keys, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, ps, d_cols,
                      d_num_rows, n_frags, n_cols, packed_cols, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_s, const int64_t* sub, int64_t* fin,
+                              const int32_t* src, const int32_t* dst, int n, int32_t* d_err, hipStream_t s) {
+  ZipMap zm{};
+  zm.n = n;
+  for (int i = 0; i < n; ++i) {
+    zm.src[i] = src[i];
+    zm.dst[i] = dst[i];
+  }
+  if (ps.entry_count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_zip_targets, dim3(grid_for(ps.entry_count)), dim3(kBlock), 0, s, pf, ps, idx_key_s, sub, fin, zm, d_err);
   return hipGetLastError();
 }
 

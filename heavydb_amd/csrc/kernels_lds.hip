@@ -36,7 +36,8 @@ constexpr int kLdsBlock = 1024;
 constexpr int kLdsVals = 3;              // value columns
 constexpr int kLdsKeys = 3;              // key columns (perfect hash)
 constexpr size_t kLdsBudget = 152 * 1024;
-constexpr uint32_t kLdsHashMax = 4096;   // slots of one baseline replica
+constexpr uint32_t kLdsHashSmall = 256;  // slots of one baseline replica, first attempt (many replicas)
+constexpr uint32_t kLdsHashMax = 4096;   // ... at most, second attempt
 
 struct LdsVal {
   int32_t col, type, nullable;           // type: MI355Q_INT32 / _INT64 / _DOUBLE (plain)
@@ -257,8 +258,12 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
         }
       }
     };
-    for (int64_t tl = (blockIdx.x + (int64_t)f * 7) % gridDim.x; tl < n_tiles; tl += gridDim.x)
+    uint32_t tiles_done = 0;
+    for (int64_t tl = (blockIdx.x + (int64_t)f * 7) % gridDim.x; tl < n_tiles; tl += gridDim.x) {
+      // (a baseline attempt that cannot hold the groups is abandoned by everybody soon after the first overflow)
+      if (a.baseline && (tiles_done++ & 31u) == 31u && *(volatile int32_t*)(d_err + 1)) break;
       do_step(tl * tile_q + t, UQ, kLdsBlock);
+    }
     for (int64_t q = n_tiles * tile_q + gtid; q < nq; q += gsize) do_step(q, 1, 0);
     const int64_t tail = (nq << 2) + gtid;
     if (tail < n) {
@@ -442,7 +447,9 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
     a.key_type[0] = kt;
     a.n_keys = 1;
     a.baseline = 1;
-    a.entries = kLdsHashMax;
+    // the group count of a baseline table is only known afterwards: first 256-slot replicas (a table with a handful
+    // of groups gets one replica per few lanes), then the largest replica that fits, then another family
+    a.entries = (tune_knobs().flags & MI355Q_OPT_LDS_BASELINE_LARGE) ? kLdsHashMax : kLdsHashSmall;
   } else {
     return false;
   }
@@ -477,25 +484,37 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
     if (t.agg == MI355Q_MAX) need[c][3] = true;
   }
   // one replica: 8-byte arrays first, then the 4-byte counters
-  uint32_t off = 0;
-  if (a.baseline) {
-    a.off_keys = (int32_t)off;
-    off += a.entries * 8;
-  }
-  for (int c = 0; c < a.n_vals; ++c)
-    for (int k = 1; k < 4; ++k)
-      if (need[c][k]) {
-        (k == 1 ? a.v[c].off_sum : k == 2 ? a.v[c].off_min : a.v[c].off_max) = (int32_t)off;
-        off += a.entries * 8;
-      }
-  a.off_rows = (int32_t)off;
-  off += a.entries * 4;
-  for (int c = 0; c < a.n_vals; ++c)
-    if (need[c][0]) {
-      a.v[c].off_cnt = (int32_t)off;
-      off += a.entries * 4;
+  auto lay_out = [&](uint32_t entries) -> uint32_t {
+    uint32_t off = 0;
+    a.entries = entries;
+    a.off_keys = -1;
+    if (a.baseline) {
+      a.off_keys = (int32_t)off;
+      off += entries * 8;
     }
-  a.copy_bytes = (off + 15u) & ~15u;
+    for (int c = 0; c < a.n_vals; ++c)
+      for (int k = 1; k < 4; ++k) {
+        int32_t& o = k == 1 ? a.v[c].off_sum : k == 2 ? a.v[c].off_min : a.v[c].off_max;
+        o = -1;
+        if (need[c][k]) {
+          o = (int32_t)off;
+          off += entries * 8;
+        }
+      }
+    a.off_rows = (int32_t)off;
+    off += entries * 4;
+    for (int c = 0; c < a.n_vals; ++c) {
+      a.v[c].off_cnt = -1;
+      if (need[c][0]) {
+        a.v[c].off_cnt = (int32_t)off;
+        off += entries * 4;
+      }
+    }
+    return (off + 15u) & ~15u;
+  };
+  a.copy_bytes = lay_out(a.entries);
+  // (second baseline attempt: the largest power-of-two replica the accumulators leave room for)
+  while (a.baseline && a.copy_bytes > kLdsBudget && a.entries > kLdsHashSmall) a.copy_bytes = lay_out(a.entries / 2);
   if (a.copy_bytes > kLdsBudget) return false;
   a.copies_lg = 0;
   while (a.copies_lg < 6 && ((size_t)a.copy_bytes << (a.copies_lg + 1)) <= kLdsBudget) ++a.copies_lg;

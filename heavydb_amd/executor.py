@@ -538,7 +538,8 @@ class Executor:
                         stream: int | None = None, out_buffer: int | None = None,
                         force_generic: bool = False, kernel_variant: int = 0,
                         scratch_bytes: int = 0, allow_retry: bool = True, pass_rows: int = 0,
-                        probe_keyed_passes: int = 0, flags: int = 0, tune_blocks_per_cu: int = 0) -> ResultSet:
+                        probe_keyed_passes: int = 0, flags: int = 0, tune_blocks_per_cu: int = 0,
+                        tune_cus: int = 0) -> ResultSet:
         """Runs the step.  A negative code (ran out of group slots) doubles the baseline
         table and retries, as RelAlgExecutor::executeWorkUnit does after its cardinality
         estimation (RelAlgExecutor.cpp:4143-4145, :4194-4231)."""
@@ -557,6 +558,7 @@ class Executor:
                 opts.probe_keyed_passes = probe_keyed_passes
                 opts.flags = flags
                 opts.tune_blocks_per_cu = tune_blocks_per_cu
+                opts.tune_cus = tune_cus
                 out = C.c_void_p()
                 rep = capi.ExecReport()
                 code = self._lib.mi355q_execute(C.byref(plan), C.byref(inp), C.byref(opts),

@@ -153,12 +153,15 @@ def merge_keyed(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool 
     dist.all_to_all_single(recv_rows.view(-1), rows.contiguous().view(-1),
                            output_split_sizes=[c * rq for c in recv],
                            input_split_sizes=[c * rq for c in counts], group=group)
+    global LAST_MERGE_BYTES_SENT
+    LAST_MERGE_BYTES_SENT = int((sum(counts) - counts[dist.get_rank(group)]) * q.row_size)
     out = shard.fresh_like()
     out.merge_rows(recv_rows)
     return _gather_to_rank0(out, shard, dist, torch, group, rq) if gather_to_rank0 else out
 
 
 LAST_KEYED_PATH = ""   # which keyed merge ran last in this process ("slices" / "partition"): for tests and bench.py
+LAST_MERGE_BYTES_SENT = 0  # bytes this rank handed to the collectives of the last merge (bench.py reports it)
 LAST_SLICE_FOLD = ""   # how the received slices were folded last ("lds": mi355q_shard_merge_slices / "rows")
 SLICE_PAD_ROWS = 1024  # rows after a slice's end that travel with it (the tail of a boundary-crossing cluster)
 
@@ -198,6 +201,8 @@ def _merge_keyed_by_slices(shard: ShardOps, dist, torch, group) -> Optional[Shar
                            input_split_sizes=[(b[r + 1] - b[r]) * rq for r in range(world)], group=group)
     recv_pads = torch.empty_like(pads)
     dist.all_to_all_single(recv_pads.view(-1), pads.contiguous().view(-1), group=group)
+    global LAST_MERGE_BYTES_SENT
+    LAST_MERGE_BYTES_SENT = int((q.entry_count - my_len) * q.row_size + (world - 1) * SLICE_PAD_ROWS * q.row_size)
     flag = ok.min().to(torch.int64).reshape(1)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
     out = shard.fresh_like()

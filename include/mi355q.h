@@ -413,11 +413,16 @@ typedef struct mi355q_exec_options {
   int64_t pass_rows;            /* packed-key and projected-expression routes: rows per pass (tests force
                                    several passes; the fragments are never split) */
   uint32_t flags;               /* MI355Q_OPT_* */
-  int32_t reserved;
+  int32_t tune_cus;             /* plan and launch as if the device had this many CUs (experiments: how a family
+                                   scales with the CU count, whether two families could share the device) */
 } mi355q_exec_options;
 #define MI355Q_OPT_TRACE 1u              /* host-side wall-clock marks and phase-2 cycle counters on stderr */
 #define MI355Q_OPT_NO_PAIR_RENDEZVOUS 2u /* partitioned GROUP BY phase 2: no rendezvous of the sub-range pair */
 #define MI355Q_OPT_PROBE_NO_PACING 4u    /* L2 payload probe: no per-XCD partition pacing */
+#define MI355Q_OPT_NO_LDS_BASELINE 8u    /* baseline layouts: do not try the few-groups LDS member (the library sets
+                                            this itself when it re-runs a step whose groups did not fit a replica) */
+#define MI355Q_OPT_LDS_BASELINE_LARGE 16u /* ... try it with the largest replica LDS holds (second attempt: the first
+                                            uses 256-slot replicas, many of them, for tables with a handful of groups) */
 
 /* per-call timing/selection report (what launchGpuCode logs,
  * QueryExecutionContext.cpp:334,364,579) */

@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--settings", default="0:0,2:0,0:48,0:32,0:8", help="flags:scratch_gb, ... (flags 2 = no pair rendezvous)")
     ap.add_argument("--trace", default="0:0")
+    ap.add_argument("--cus", default="", help="comma-separated CU counts to plan / launch with (tune_cus): how phase 1 "
+                    "and phase 2 scale, i.e. whether they could run side by side on disjoint CU sets")
     args = ap.parse_args()
     import torch
     from heavydb_amd import capi, synth
@@ -37,19 +39,19 @@ def main():
     ra, fr, info = synth.cfg3(torch, rows, filtered=True)
     ex = Executor(0)
 
-    def run(flags: int, scratch_gb: float, steps: int):
+    def run(flags: int, scratch_gb: float, steps: int, cus: int = 0):
         sb = int(scratch_gb * 2**30)
-        sh = HipShard.execute(torch, ex, ra, fr, scratch_bytes=sb, flags=flags)  # warm (allocates the scratch)
+        sh = HipShard.execute(torch, ex, ra, fr, scratch_bytes=sb, flags=flags, tune_cus=cus)  # warm (allocates the scratch)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         reps = []
         for _ in range(steps):
-            sh = HipShard.execute(torch, ex, ra, fr, scratch_bytes=sb, flags=flags)
+            sh = HipShard.execute(torch, ex, ra, fr, scratch_bytes=sb, flags=flags, tune_cus=cus)
             reps.append(sh.report)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 1e3 / steps
         r = reps[-1]
-        return {"flags": flags, "scratch_gb": scratch_gb, "ms_per_step": round(ms, 3),
+        return {"flags": flags, "cus": cus, "scratch_gb": scratch_gb, "ms_per_step": round(ms, 3),
                 "total_ms_events": round(float(r.total_ms), 3), "chunks": int(r.n_launches),
                 "scatter_ms_per_launch": round(float(r.kernel_ms) / max(int(r.n_launches), 1), 3),
                 "whole_step_frac": round(rows * 20 / (ms * 1e-3) / 8e12, 4), "spilled": int(r.spilled_rows)}
@@ -60,6 +62,8 @@ def main():
             print(json.dumps(run(int(w), float(g), args.steps)), flush=True)
         except Exception as e:
             print(json.dumps({"flags": w, "scratch_gb": g, "error": repr(e)}), flush=True)
+    for c in [int(x) for x in args.cus.split(",") if x]:
+        print(json.dumps(run(capi.OPT_TRACE, 0.0, 2, c)), flush=True)
     if args.trace:
         w, g = args.trace.split(":")
         print(json.dumps(run(int(w) | capi.OPT_TRACE, float(g), 1)), flush=True)

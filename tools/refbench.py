@@ -216,7 +216,7 @@ def main():
                 rs = ex.executeWorkUnit(ra, fr)
                 if spec.get("sort"):
                     outbuf = torch.empty(100 * rs.getQueryMemDesc().row_size // 8, dtype=torch.int64, device="cuda:0")
-                    rs.sort(len(spec["targets"]) - 1, 100, outbuf, desc=False)
+                    rs.sort(len(spec["targets"]) - 1, 100, int(outbuf.data_ptr()), desc=False)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) * 1e3 / args.steps
             line.update(kernel=rs.report.kernel_name.decode(), variant=int(rs.report.variant), ms=round(ms, 3),
