@@ -524,8 +524,12 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   q->slot_count = slot;
   q->key_bytes = (grouped && !q->keyless) ? ((q->group_col_count * q->key_width + 7) & ~7) : 0;
   // pick_target_compact_width (QueryMemoryDescriptor.cpp:748-840): one group column, only
-  // COUNT(*) and projections of keys of at most 4 bytes, <= UINT32_MAX input rows -> 4-byte slots
-  bool compact = !p.bigint_count && p.n_group_cols == 1 &&
+  // COUNT(*) and projections of keys of at most 4 bytes, <= UINT32_MAX input rows -> 4-byte slots.
+  // A baseline-hash step rebuilds its slot context from the target list (:382-384) after that width was
+  // applied (:263-269), so its slots come out unset and the constructor pads them to 8 (:507): the
+  // narrowing survives only for perfect hash (ColSlotContext run on the reference's own code,
+  // tests/golden/ref_layout_vectors.json).
+  bool compact = !p.bigint_count && p.n_group_cols == 1 && q->desc_type != MI355Q_GROUP_BY_BASELINE_HASH &&
                  (uint64_t)(p.num_tuples < 0 ? 0 : p.num_tuples) <= (uint64_t)UINT32_MAX;
   for (int i = 0; i < p.n_targets && compact; ++i) {
     const ResolvedTarget& t = ts[i];

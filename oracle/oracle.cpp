@@ -710,8 +710,9 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   // pick_target_compact_width (QueryMemoryDescriptor.cpp:748-840) -> setAllSlotsPaddedSize (:265):
   // 8 unless !g_bigint_count, exactly one group-by expression, every target either COUNT(*) or a
   // non-aggregate integer of at most 4 bytes (here: the projected key), and the input tables hold
-  // at most UINT32_MAX tuples — then 4
-  bool compact = !p.bigint_count && p.n_group_cols == 1 &&
+  // at most UINT32_MAX tuples — then 4.  Baseline hash rebuilds the slot context afterwards (:382-384): its
+  // slots are left unset and the constructor pads them to 8 (:507), so it never keeps the narrow width.
+  bool compact = !p.bigint_count && p.n_group_cols == 1 && q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH &&
                  (uint64_t)std::max<int64_t>(p.num_tuples, 0) <= (uint64_t)UINT32_MAX;
   for (const auto& t : ts) {
     if (t.agg == MI355Q_COUNT && t.col < 0) continue;

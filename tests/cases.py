@@ -301,7 +301,7 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                                                               [Qual(0, LT, 2**30)], group=[5]), frags))
     cases.append(Case("compact_perfect_count_only_int64_key", ra([TargetExpr(COUNT)], group=[1]), frags))
     cases.append(Case("compact_baseline_count_only", ra([TargetExpr(COUNT)], [Qual(2, GT, 0)], group=[4], guess=8192),
-                      frags))                                          # key 8 B + count 4 B + pad
+                      frags))                                          # baseline never narrows: key 8 B + count 8 B
     c8 = Case("compact_off_bigint_count", ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], group=[10]), frags)
     c8.ra.bigint_count = True
     cases.append(c8)
@@ -452,7 +452,7 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
 
     cases.append(Case("compact_baseline_key32",
                       RelAlgExecutionUnit(descs32, [TargetExpr(PROJECT_KEY), TargetExpr(COUNT)], groupby_exprs=[0],
-                                          max_groups_buffer_entry_guess=5000), frags32))  # 4-byte key, 4-byte count
+                                          max_groups_buffer_entry_guess=5000), frags32))  # 4-byte key (padded to 8), 8-byte count
 
     # ---- empty and tiny inputs
     empty = [[np.zeros(0, NP[t]) for t, _, _ in spec]]

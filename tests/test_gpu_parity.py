@@ -883,14 +883,14 @@ def test_packed_route_on_perfect_layouts(torch_cuda, oracle, name):
 
 
 def test_compact_slots_topk_and_shards(torch_cuda, oracle):
-    """4-byte-slot layout (SELECT key, COUNT(*) ... GROUP BY key over < 2^32 rows): top-k ordered by
-    the 32-bit COUNT, and the keyed multi-GPU merge pieces (partition + merge of whole compact
-    rows), against the oracle."""
+    """SELECT key, COUNT(*) ... GROUP BY key over < 2^32 rows on a baseline-hash step (8-byte slots holding a 32-bit
+    COUNT: baseline hash never keeps pick_target_compact_width's narrowing, tests/test_ref_layout.py): top-k ordered
+    by the COUNT, and the keyed multi-GPU merge pieces (partition + merge of whole rows), against the oracle."""
     from heavydb_amd.executor import Executor
     from heavydb_amd.multi_gpu import HipShard
     case = next(c for c in CASES if c.name == "compact_baseline_count_only")
     q, want, code = oracle.execute(case.ra.to_plan(), case.frags, n_threads=2)
-    assert code == 0 and q.slot_width == 4 and q.row_size == 16
+    assert code == 0 and q.slot_width == 8 and q.row_size == 16
     frag_t, inner_t = _upload(torch_cuda, case)
     ex = Executor(0)
     fr = _fetch_result(case, frag_t, inner_t)

@@ -105,7 +105,9 @@ def test_layout_decisions_agree(oracle):
         assert de == do, (i, {k: (de[k], do[k]) for k in de if de[k] != do[k]})
         kinds[(qe.desc_type, qe.keyless, qe.slot_width, qe.key_width, min(qe.group_col_count, 2))] = 1
     # the generator must actually reach the interesting corners
-    assert len(kinds) >= 12, sorted(kinds)
+    # (baseline hash never keeps 4-byte slots: tests/test_ref_layout.py)
+    assert len(kinds) >= 11, sorted(kinds)
+    assert not any(k[0] == capi.GROUP_BY_BASELINE_HASH and k[2] == 4 for k in kinds), sorted(kinds)
 
 
 def _fuzz_table(rng, n_rows):
@@ -396,9 +398,11 @@ def test_boundary_values_agree(oracle):
     assert keys.get("ok_0_w8", 0) > 20 and keys.get("ok_1_w8", 0) > 100 and keys.get("ok_1_w4", 0) > 3, keys
 
 
-def test_compact_baseline_rows_with_several_slots(oracle):
-    """SELECT COUNT(*), COUNT(*) ... GROUP BY key: two 4-byte slots share one quad of a baseline row
-    (found by tools/soak_fuzz.py as a limitation of compare_buffers, not of the product)."""
+def test_baseline_rows_with_several_count_slots(oracle):
+    """SELECT COUNT(*), COUNT(*), COUNT(*) ... GROUP BY key on a baseline-hash step: the slots stay 8 bytes wide
+    (the reference rebuilds the slot context for baseline hash, QueryMemoryDescriptor.cpp:382-384 — the 4-byte
+    narrowing survives only for perfect hash, tests/test_ref_layout.py), and compare_buffers notices a change in
+    any one of them."""
     from tests.cases import Case
     from tests.helpers import compare_buffers, qmd_equal
     from tests.test_rowlogic_emu import _emu_execute
@@ -411,13 +415,13 @@ def test_compact_baseline_rows_with_several_slots(oracle):
     plan = ra.to_plan()
     q, want, code = oracle.execute(plan, case.frags, n_threads=2)
     eq, got, ecode = _emu_execute(case, plan, None)
-    assert code == 0 and ecode == 0 and q.slot_width == 4 and q.slot_count == 3 and q.row_size == 24
+    assert code == 0 and ecode == 0 and q.slot_width == 8 and q.slot_count == 3 and q.row_size == 32
     qmd_equal(q, eq)
     compare_buffers(q, want, got)
     iv, _, _ = oracle.fetch_rows(q, got)
     assert iv.shape == (300, 3) and (iv[:, 0] == iv[:, 1]).all() and iv[:, 0].sum() == 5000
     bad = got.copy()
     live = np.nonzero(bad[:, 0] != 2**63 - 1)[0]
-    bad[live[0], 2] += 1                      # the third COUNT, alone in its quad's low half
+    bad[live[0], 3] += 1                      # the third COUNT
     with pytest.raises(AssertionError):
         compare_buffers(q, want, bad)
