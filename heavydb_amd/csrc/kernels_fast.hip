@@ -917,10 +917,12 @@ int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested, i
   if (requested == 1) return 1;
   const bool can_part = part_supported(p, fv, n_cus);
   if (requested == 2) return can_part ? 2 : 1;
-  // direct atomics only for small INPUTS: on a large input a small table means many rows per group, i.e. every row
-  // contends for a few cache lines (10 K groups: 580 ms per 1 B rows against ~10 ms partitioned); tables with at most
-  // a few thousand groups never get here (the LDS group-by takes them)
-  if (!can_part || fv.total_rows < (int64_t)8 << 20) return 1;
+  // direct atomics for small inputs and for small TABLES: measured on 1 B rows with 10 K groups (refbench PHS004 /
+  // PHM003 / BH004), the partitioned family takes 2.2 s — ten keys per partition, each a tenth of its rows, all
+  // through the heavy-hitter path — against 0.58 s of contended direct atomics (profiles/r03_refbench_*.jsonl); from
+  // 100 K groups on it wins (18 ms).  Tables of at most a few thousand groups never get here (the LDS group-by
+  // takes them); the band in between is the open cliff of DESIGN section 9.
+  if (!can_part || fv.total_rows < (int64_t)8 << 20 || p.entry_count < 65536) return 1;
   return 2;
 }
 

@@ -571,7 +571,11 @@ class Executor:
                 grows = code < 0 or (code == capi.ERR_OUT_OF_SLOTS and
                                      self.initQueryMemoryDescriptor(ra_exe_unit).desc_type
                                      == capi.GROUP_BY_BASELINE_HASH)
-                if grows and allow_retry and out_buffer is None and ra_exe_unit.groupby_exprs:
+                # (a table never needs more entries than twice the rows it is fed: past that, growing cannot help and
+                # the code is reported instead of being retried with ever larger tables)
+                fed = 2 * max(sum(fetch_result.num_rows), 8192)
+                if (grows and allow_retry and out_buffer is None and ra_exe_unit.groupby_exprs
+                        and ra_exe_unit.max_groups_buffer_entry_guess < fed):
                     ra_exe_unit.max_groups_buffer_entry_guess *= 2
                     continue
                 raise capi.Mi355qError(code, "execute")

@@ -335,3 +335,63 @@ def decode_join_table(raw: np.ndarray, hash_type: int, entries: int, kc: int, w:
         k = (int(min_key + e),) if hash_type == 2 else tuple(int(x) for x in keys[e])
         out[k] = sorted(int(x) for x in payloads[offsets[e]:offsets[e] + counts[e]])
     return out
+
+
+_hostsim = None
+
+
+def hostsim_lib() -> str:
+    """tests/hostsim: the library's host code (api.cpp, plan.cpp) and kernels_generic.hip compiled for the CPU against
+    a stand-in HIP runtime (memory = host memory poisoned with 0xA5, launches on a pool of host threads), the fast
+    kernel families replaced by row-function stand-ins (tests/hostsim/kernels_host.cpp).  Returns the path of the
+    built library (same C ABI as libmi355q.so)."""
+    global _hostsim
+    if _hostsim is not None:
+        return _hostsim
+    src_dir = os.path.join(ROOT, "tests", "hostsim")
+    csrc = os.path.join(ROOT, "heavydb_amd", "csrc")
+    out_dir = os.path.join(ROOT, "tests", "_hostsim")
+    out = os.path.join(out_dir, "libmi355q_hostsim.so")
+    cxx = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(cxx):
+        cxx = "g++"
+    deps = [os.path.join(src_dir, f) for f in ("hip_host.cpp", "kernels_host.cpp", "shim/hip/hip_runtime.h",
+                                               "shim/hip/hip_runtime_api.h")] + \
+        [os.path.join(csrc, f) for f in ("api.cpp", "plan.cpp", "kernels_generic.hip", "kernels.h", "rowfunc.h",
+                                         "dev_common.h", "plan.h", "expr.h")] + [os.path.join(ROOT, "include", "mi355q.h")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        os.makedirs(out_dir, exist_ok=True)
+        # the one construct the stand-in cannot express: dynamic LDS declared `extern __shared__`
+        with open(os.path.join(csrc, "kernels_generic.hip")) as f:
+            kg = f.read()
+        decl = "extern __shared__ __attribute__((aligned(16))) int64_t s_tab[];"
+        assert kg.count(decl) == 1
+        kg_cpp = os.path.join(out_dir, "kernels_generic_host.cpp")
+        with open(kg_cpp, "w") as f:
+            f.write(kg.replace(decl, "int64_t* const s_tab = (int64_t*)hipsim::dynamic_shared();"))
+        # kernels whose body holds a barrier, a wave shuffle / ballot or LDS run as fibers; the rest as plain loops
+        import re
+        names = []
+        for m in re.finditer(r"__global__[^{;]*?void\s+(k_\w+)\s*\(", kg):
+            depth, i = 0, kg.index("{", m.end())
+            start = i
+            while True:
+                depth += {"{": 1, "}": -1}.get(kg[i], 0)
+                i += 1
+                if depth == 0:
+                    break
+            if re.search(r"__syncthreads|__shfl|__ballot|__shared__", kg[start:i]):
+                names.append(m.group(1))
+        with open(os.path.join(out_dir, "barrier_kernels.inc"), "w") as f:
+            f.write("".join(f'    "{n}",\n' for n in names))
+        flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-w", "-I" + os.path.join(src_dir, "shim"), "-I" + csrc,
+                 "-I" + os.path.join(ROOT, "include"), "-I" + out_dir]
+        objs = []
+        for src in (os.path.join(csrc, "api.cpp"), os.path.join(csrc, "plan.cpp"), kg_cpp,
+                    os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")):
+            obj = os.path.join(out_dir, os.path.basename(src) + ".o")
+            subprocess.run([cxx] + flags + ["-c", src, "-o", obj], check=True)
+            objs.append(obj)
+        subprocess.run([cxx, "-shared", "-pthread", "-Wl,-Bsymbolic", "-o", out] + objs, check=True)
+    _hostsim = out
+    return out
