@@ -118,8 +118,21 @@ MQ_D void lds_update(char* rep, const LdsVal& v, uint32_t e, int64_t bits) {
 
 // find-or-insert in one replica's key array (linear probing from a multiplicative hash); kNoSlot when full
 constexpr uint32_t kNoSlot = 0xffffffffu;
+// (the TOP bits of the product, and the key's high half folded into its low half first: a DOUBLE key that holds a small
+// integer has 40 - 50 trailing zero bits, so bits 40 .. 51 of `key * odd` are all zero — the version that took those
+// bits sent every group of cast(x AS DOUBLE) to slot 0 and probed linearly from there: BH002 / BH003 ran 16 - 50 x
+// slower than the same shape on an integer key, profiles/r03_refbench_1b_call4.jsonl)
+MQ_D uint32_t lds_key_home(uint32_t H, int64_t key) {
+  uint64_t x = (uint64_t)key;
+  x ^= x >> 32;
+  x *= 0x9E3779B97F4A7C15ull;
+  x ^= x >> 29;
+  x *= 0xBF58476D1CE4E5B9ull;
+  const int lg = 31 - __builtin_clz(H | 1u);
+  return lg ? (uint32_t)(x >> (64 - lg)) & (H - 1) : 0u;
+}
 MQ_D uint32_t lds_key_slot(int64_t* keys, uint32_t H, int64_t key) {
-  uint32_t s = (uint32_t)((uint64_t)key * 0x9E3779B97F4A7C15ull >> 40) & (H - 1);
+  uint32_t s = lds_key_home(H, key);
   for (uint32_t trips = 0; trips < H; ++trips) {
     const int64_t k = *(volatile int64_t*)&keys[s];
     if (k == key) return s;
