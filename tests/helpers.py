@@ -337,30 +337,38 @@ def decode_join_table(raw: np.ndarray, hash_type: int, entries: int, kc: int, w:
     return out
 
 
-_hostsim = None
+_hostsim = {}
 
 
-def hostsim_lib() -> str:
+def hostsim_lib(real_fast: bool = False) -> str:
     """tests/hostsim: the library's host code (api.cpp, plan.cpp) and kernels_generic.hip compiled for the CPU against
     a stand-in HIP runtime (memory = host memory poisoned with 0xA5, launches on a pool of host threads), the fast
     kernel families replaced by row-function stand-ins (tests/hostsim/kernels_host.cpp).  Returns the path of the
-    built library (same C ABI as libmi355q.so)."""
-    global _hostsim
-    if _hostsim is not None:
-        return _hostsim
+    built library (same C ABI as libmi355q.so).
+
+    real_fast=True: a second library in which kernels_fast.hip and kernels_lds.hip are the REAL device sources, compiled
+    for the host (their blocks run as 1024 cooperative fibers): k_scan_count, k_scan_agg, k_perfect_lds(_prog),
+    k_baseline_direct, k_join_sum and k_groupby_lds execute their own code on the CPU.  Only the partitioned family
+    (kernels_part.hip: workgroups that wait for each other) and the sort keep their stand-ins."""
+    key = bool(real_fast)
+    if _hostsim.get(key) is not None:
+        return _hostsim[key]
     src_dir = os.path.join(ROOT, "tests", "hostsim")
     csrc = os.path.join(ROOT, "heavydb_amd", "csrc")
-    out_dir = os.path.join(ROOT, "tests", "_hostsim")
-    out = os.path.join(out_dir, "libmi355q_hostsim.so")
+    out_dir = os.path.join(ROOT, "tests", "_hostsim_real" if real_fast else "_hostsim")
+    out = os.path.join(out_dir, "libmi355q_hostsim_real.so" if real_fast else "libmi355q_hostsim.so")
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = "g++"
+    real_srcs = ["kernels_fast.hip", "kernels_lds.hip", "fast_common.h"] if real_fast else []
     deps = [os.path.join(src_dir, f) for f in ("hip_host.cpp", "kernels_host.cpp", "shim/hip/hip_runtime.h",
                                                "shim/hip/hip_runtime_api.h")] + \
-        [os.path.join(csrc, f) for f in ("api.cpp", "plan.cpp", "kernels_generic.hip", "kernels.h", "rowfunc.h",
-                                         "dev_common.h", "plan.h", "expr.h")] + [os.path.join(ROOT, "include", "mi355q.h")]
+        [os.path.join(csrc, f) for f in ["api.cpp", "plan.cpp", "kernels_generic.hip", "kernels.h", "rowfunc.h",
+                                         "dev_common.h", "plan.h", "expr.h"] + real_srcs] + \
+        [os.path.join(ROOT, "include", "mi355q.h")]
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(out_dir, exist_ok=True)
+        import re
         # the one construct the stand-in cannot express: dynamic LDS declared `extern __shared__`
         with open(os.path.join(csrc, "kernels_generic.hip")) as f:
             kg = f.read()
@@ -370,8 +378,7 @@ def hostsim_lib() -> str:
         with open(kg_cpp, "w") as f:
             f.write(kg.replace(decl, "int64_t* const s_tab = (int64_t*)hipsim::dynamic_shared();"))
         # kernels whose body holds a barrier, a wave shuffle / ballot or LDS run as fibers; the rest as plain loops
-        import re
-        names = []
+        names, plain = [], []
         for m in re.finditer(r"__global__[^{;]*?void\s+(k_\w+)\s*\(", kg):
             depth, i = 0, kg.index("{", m.end())
             start = i
@@ -380,18 +387,32 @@ def hostsim_lib() -> str:
                 i += 1
                 if depth == 0:
                     break
-            if re.search(r"__syncthreads|__shfl|__ballot|__shared__", kg[start:i]):
-                names.append(m.group(1))
+            (names if re.search(r"__syncthreads|__shfl|__ballot|__shared__", kg[start:i]) else plain).append(m.group(1))
         with open(os.path.join(out_dir, "barrier_kernels.inc"), "w") as f:
             f.write("".join(f'    "{n}",\n' for n in names))
+        with open(os.path.join(out_dir, "plain_kernels.inc"), "w") as f:
+            f.write("".join(f'    "{n}",\n' for n in plain))
         flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-w", "-I" + os.path.join(src_dir, "shim"), "-I" + csrc,
                  "-I" + os.path.join(ROOT, "include"), "-I" + out_dir]
+        srcs = [os.path.join(csrc, "api.cpp"), os.path.join(csrc, "plan.cpp"), kg_cpp,
+                os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
+        if real_fast:
+            flags.append("-DHOSTSIM_REAL_FAST")
+            for name in ("kernels_fast.hip", "kernels_lds.hip"):
+                with open(os.path.join(csrc, name)) as f:
+                    src = f.read()
+                src, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char (\w+)\[\];",
+                                 r"char* const \1 = (char*)hipsim::dynamic_shared();", src)
+                assert n >= 1 and "extern __shared__" not in src, name
+                cpp = os.path.join(out_dir, name.replace(".hip", "_host.cpp"))
+                with open(cpp, "w") as f:
+                    f.write(src)
+                srcs.append(cpp)
         objs = []
-        for src in (os.path.join(csrc, "api.cpp"), os.path.join(csrc, "plan.cpp"), kg_cpp,
-                    os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")):
+        for src in srcs:
             obj = os.path.join(out_dir, os.path.basename(src) + ".o")
             subprocess.run([cxx] + flags + ["-c", src, "-o", obj], check=True)
             objs.append(obj)
         subprocess.run([cxx, "-shared", "-pthread", "-Wl,-Bsymbolic", "-o", out] + objs, check=True)
-    _hostsim = out
+    _hostsim[key] = out
     return out

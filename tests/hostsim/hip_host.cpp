@@ -33,16 +33,26 @@ const char* const kBarrierKernels[] = {
 #include "barrier_kernels.inc"
     nullptr};
 
-bool needs_fibers(const char* name) {
-  for (int i = 0; kBarrierKernels[i]; ++i)
-    if (std::strstr(name, kBarrierKernels[i])) {
+bool names_one_of(const char* name, const char* const* list) {
+  for (int i = 0; list[i]; ++i)
+    if (std::strstr(name, list[i])) {
       // (whole identifier: k_generic must not match k_generic_lds and vice versa)
-      const char* at = std::strstr(name, kBarrierKernels[i]);
-      const char c = at[std::strlen(kBarrierKernels[i])];
+      const char* at = std::strstr(name, list[i]);
+      const char c = at[std::strlen(list[i])];
       if (!(std::isalnum((unsigned char)c) || c == '_')) return true;
     }
   return false;
 }
+#ifdef HOSTSIM_REAL_FAST
+// the real kernels_fast.hip / kernels_lds.hip are compiled in (templates launched through local names): every kernel
+// that is not a known barrier-free kernel of kernels_generic.hip runs as fibers
+const char* const kPlainKernels[] = {
+#include "plain_kernels.inc"
+    nullptr};
+bool needs_fibers(const char* name) { return !names_one_of(name, kPlainKernels); }
+#else
+bool needs_fibers(const char* name) { return names_one_of(name, kBarrierKernels); }
+#endif
 
 constexpr int kMaxThreads = 1024;
 constexpr int kWave = 64;

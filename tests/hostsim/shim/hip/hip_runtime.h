@@ -59,6 +59,8 @@ inline T __shfl_down(T v, unsigned delta, int width = 64) {
 }
 inline unsigned long long __ballot(int pred) { return hipsim::wave_ballot(pred != 0); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 
 // atomics: the threads of a block really run concurrently
 template <typename T>

@@ -1,0 +1,55 @@
+"""The REAL fast kernels on the CPU: kernels_fast.hip (k_scan_count, k_scan_agg, k_perfect_lds, k_perfect_lds_prog,
+k_baseline_direct, k_join_sum) and kernels_lds.hip (k_groupby_lds) compiled for the host against the stand-in HIP runtime
+of tests/hostsim — a workgroup runs as 1024 cooperative fibers with working barriers, shuffles, LDS and atomics — behind
+the real api.cpp / plan.cpp.  Results are held against the oracle exactly as the gpu tests do.  This is a functional check
+of the device code itself (index arithmetic, tails, NULL handling, replica folds, flush rules) on a machine without a GPU; it says
+nothing about timing or about races (fibers of a block run one after the other between barriers).  Only the partitioned
+family (kernels_part.hip) and the sort keep their stand-ins here."""
+import ctypes as C
+
+import pytest
+
+from heavydb_amd import capi
+from tests import cases as cases_mod
+from tests.helpers import hostsim_lib
+from tests import test_hostsim_flow as flow
+
+CASES = cases_mod.build_cases()
+REAL_FAMILIES = {"k_scan_count", "k_scan_agg", "k_perfect_lds", "k_perfect_lds_prog", "k_baseline_direct", "k_join_sum",
+                 "k_groupby_lds"}
+
+
+@pytest.fixture(scope="module")
+def sim():
+    lib = capi.load_library(hostsim_lib(real_fast=True))
+    lib.hostsim_configure.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_int32]
+    lib.hostsim_configure.restype = None
+    lib.hostsim_live_allocations.restype = C.c_int
+    saved = capi._lib
+    capi._lib = lib
+    lib.hostsim_configure(flow.ALL_ROUTES, 0, 0, 0)
+    yield lib
+    capi._lib = saved
+
+
+SEEN = set()
+
+
+@pytest.mark.parametrize("variant", [0, 1], ids=["planned", "direct_members"])
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_case_matrix_through_the_real_fast_kernels(sim, oracle, case, variant):
+    rs = flow._check(oracle, case, kernel_variant=variant)
+    if rs is not None:
+        SEEN.add(rs.report.kernel_name.decode())
+
+
+@pytest.mark.parametrize("name", list(flow.QUERIES), ids=list(flow.QUERIES))
+def test_refbench_queries_through_the_real_fast_kernels(sim, oracle, name):
+    rs = flow._check(oracle, flow._refbench_case(oracle, name, 6000, 600), kernel_variant=0)
+    assert rs is not None
+    SEEN.add(rs.report.kernel_name.decode())
+
+
+def test_zz_every_real_family_ran():
+    missing = REAL_FAMILIES - SEEN - {"k_perfect_lds_prog"}
+    assert not missing, (missing, SEEN)
