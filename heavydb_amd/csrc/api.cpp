@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <new>
@@ -54,6 +55,10 @@ struct mi355q_join_table {
   int pay_has_nulls = 0;
   float pay_build_ms = 0.f;
   int64_t pay_version = 0, pay16_version = 0;  // mi355q_inputs.inner_version the payloads were built for
+  // a payload the probe plan then refused (built, dropped): not built again for the same column and step shape
+  bool pay_refused = false;
+  const void* pay_refused_col = nullptr;
+  int64_t pay_refused_rows = 0;
 };
 
 struct mi355q_result {
@@ -567,8 +572,7 @@ struct ArrowBatchOwner {           // private_data of the struct array
   std::vector<ArrowArray*> child_ptrs;
   const void* buffers[1];
 };
-struct ArrowSchemaOwner {
-  std::vector<std::string> names;
+struct ArrowSchemaOwner {          // private_data of the struct schema: the child structs (not their names)
   std::vector<ArrowSchema> child_storage;
   std::vector<ArrowSchema*> child_ptrs;
 };
@@ -586,8 +590,14 @@ void release_batch_array(ArrowArray* a) {
   delete o;
   a->release = nullptr;
 }
+// a child schema owns its name: a consumer may move a child out of the parent (copy the struct, mark the source
+// released) and release the parent first — the moved child's name must outlive the parent (Arrow C Data Interface,
+// "moving child arrays")
 void release_child_schema(ArrowSchema* s) {
-  if (s) s->release = nullptr;     // storage belongs to the parent
+  if (!s || !s->release) return;
+  delete static_cast<std::string*>(s->private_data);
+  s->private_data = nullptr;
+  s->release = nullptr;
 }
 void release_batch_schema(ArrowSchema* s) {
   if (!s || !s->release) return;
@@ -600,9 +610,29 @@ void release_batch_schema(ArrowSchema* s) {
 
 }  // namespace
 
+static int32_t export_arrow_impl(const mi355q_result* r, const char* const* names, struct ArrowSchema* out_schema,
+                                 struct ArrowArray* out_array, void* stream);
+
 int32_t mi355q_result_export_arrow(const mi355q_result* r, const char* const* names, struct ArrowSchema* out_schema,
                                    struct ArrowArray* out_array, void* stream) {
   if (!r || !out_schema || !out_array) return MI355Q_ERR_INVALID_PLAN;
+  *out_schema = ArrowSchema{};
+  *out_array = ArrowArray{};
+  // no C++ exception crosses the C boundary: an allocation failure is an error code, and what was built is released
+  try {
+    return export_arrow_impl(r, names, out_schema, out_array, stream);
+  } catch (const std::bad_alloc&) {
+  } catch (...) {
+  }
+  if (out_schema->release) out_schema->release(out_schema);
+  if (out_array->release) out_array->release(out_array);
+  *out_schema = ArrowSchema{};
+  *out_array = ArrowArray{};
+  return MI355Q_ERR_OUT_OF_CPU_MEM;
+}
+
+static int32_t export_arrow_impl(const mi355q_result* r, const char* const* names, struct ArrowSchema* out_schema,
+                                 struct ArrowArray* out_array, void* stream) {
   const mi355q_qmd& q = r->qmd;
   const int nt = q.n_targets;
   int64_t n_rows = 0;
@@ -646,33 +676,45 @@ int32_t mi355q_result_export_arrow(const mi355q_result* r, const char* const* na
     }
   }
   // ---- schema: struct<target_0: int64 | float64, ...>
+  // (the parent is handed to the caller's struct FIRST, children are attached one by one: whatever exists when an
+  // allocation fails is reachable from out_schema / out_array and released by the wrapper)
   ArrowSchemaOwner* so = new ArrowSchemaOwner();
-  so->names.resize((size_t)nt);
-  so->child_storage.resize((size_t)nt);
-  so->child_ptrs.resize((size_t)nt);
-  for (int t = 0; t < nt; ++t) {
-    so->names[t] = names && names[t] ? std::string(names[t]) : "target_" + std::to_string(t);
-    ArrowSchema& c = so->child_storage[t];
-    c = ArrowSchema{};
-    c.format = q.target_is_fp[t] ? "g" : "l";
-    c.name = so->names[t].c_str();
-    c.flags = 2;  // ARROW_FLAG_NULLABLE
-    c.release = release_child_schema;
-    so->child_ptrs[t] = &c;
-  }
   *out_schema = ArrowSchema{};
   out_schema->format = "+s";
   out_schema->name = "";
-  out_schema->n_children = nt;
-  out_schema->children = so->child_ptrs.data();
+  out_schema->n_children = 0;
   out_schema->release = release_batch_schema;
   out_schema->private_data = so;
+  so->child_storage.resize((size_t)nt);
+  so->child_ptrs.resize((size_t)nt);
+  for (int t = 0; t < nt; ++t) {
+    so->child_storage[t] = ArrowSchema{};
+    so->child_ptrs[t] = &so->child_storage[t];
+  }
+  out_schema->children = so->child_ptrs.data();
+  out_schema->n_children = nt;
+  for (int t = 0; t < nt; ++t) {
+    std::string* nm = new std::string(names && names[t] ? std::string(names[t]) : "target_" + std::to_string(t));
+    ArrowSchema& c = so->child_storage[t];
+    c.format = q.target_is_fp[t] ? "g" : "l";
+    c.name = nm->c_str();
+    c.flags = 2;  // ARROW_FLAG_NULLABLE
+    c.private_data = nm;
+    c.release = release_child_schema;
+  }
   // ---- array
   ArrowBatchOwner* bo = new ArrowBatchOwner();
+  *out_array = ArrowArray{};
+  out_array->release = release_batch_array;
+  out_array->private_data = bo;
   bo->child_storage.resize((size_t)nt);
   bo->child_ptrs.resize((size_t)nt);
   for (int t = 0; t < nt; ++t) {
-    ArrowColumnOwner* co = new ArrowColumnOwner();
+    bo->child_storage[t] = ArrowArray{};
+    bo->child_ptrs[t] = &bo->child_storage[t];
+  }
+  for (int t = 0; t < nt; ++t) {
+    std::unique_ptr<ArrowColumnOwner> co(new ArrowColumnOwner());
     int64_t null_count = 0;
     for (uint8_t f : nulls[t]) null_count += f;
     if (null_count) {
@@ -684,24 +726,19 @@ int32_t mi355q_result_export_arrow(const mi355q_result* r, const char* const* na
     co->buffers[0] = null_count ? (const void*)co->validity.data() : nullptr;
     co->buffers[1] = co->values.data();
     ArrowArray& a = bo->child_storage[t];
-    a = ArrowArray{};
     a.length = n_rows;
     a.null_count = null_count;
     a.n_buffers = 2;
     a.buffers = co->buffers;
     a.release = release_child_array;
-    a.private_data = co;
-    bo->child_ptrs[t] = &a;
+    a.private_data = co.release();
   }
   bo->buffers[0] = nullptr;
-  *out_array = ArrowArray{};
   out_array->length = n_rows;
   out_array->n_buffers = 1;
   out_array->buffers = bo->buffers;
   out_array->n_children = nt;
   out_array->children = bo->child_ptrs.data();
-  out_array->release = release_batch_array;
-  out_array->private_data = bo;
   return MI355Q_OK;
 }
 
@@ -1763,18 +1800,11 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   }
 
   if (!o.force_generic && in->n_frags > 0 && !reserved && !lds_direct && o.kernel_variant != 1 && d.n_group >= 1) {
-    // several value columns over a large input (and no LDS-sized table): one run per value column, zipped
-    int64_t tr = 0, mr = 0;
-    for (int f = 0; f < in->n_frags; ++f) {
-      tr += in->num_rows[f];
-      mr = std::max(mr, in->num_rows[f]);
-    }
-    FragView fvh{nullptr, nullptr, in->col_buffers, in->num_rows, in->n_frags, plan->n_cols, tr, mr};
-    if (!lds_groupby_eligible(d, fvh) || (d.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && d.entry_count > 65536)) {
-      const int32_t e = execute_multi_value(plan, in, o, q, d, out, report);
-      if (e != kNotTaken && e != MI355Q_ERR_UNSUPPORTED) return e;
-      *out = nullptr;
-    }
+    // several value columns over a large input, and the LDS group-by is not going to take the step (table too large,
+    // a forced variant, or its attempts already failed): one run per value column, zipped
+    const int32_t e = execute_multi_value(plan, in, o, q, d, out, report);
+    if (e != kNotTaken && e != MI355Q_ERR_UNSUPPORTED) return e;
+    *out = nullptr;
   }
 
   hipStream_t s = (hipStream_t)o.stream;  // caller's, or the device context's own (below)
@@ -1871,16 +1901,16 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   if (!o.force_generic && nf > 0 && kind != K_JOIN_PART && o.kernel_variant != 1 && plan->join_table && !reserved &&
       d.join_col >= 0 && (o.kernel_variant == 3 || total_rows >= ((int64_t)16 << 20))) {
     int wcol = -1, l2 = 0;
-    if (join_probe_wants(d, fv, &wcol, &l2)) {
+    if (join_probe_wants(d, fv, n_cus, &wcol, &l2)) {
       mi355q_join_table* jt = const_cast<mi355q_join_table*>(plan->join_table);
       const void* inner = wcol >= 0 ? (const void*)d.inner_cols[wcol] : nullptr;
       std::lock_guard<std::mutex> pl(jt->pay_mu);
       const int64_t entries = jt->entry_count;
-      bool ok = true;
+      bool ok = !(jt->pay_refused && jt->pay_refused_col == inner && jt->pay_refused_rows == total_rows);
       // a cached payload is only as good as the column it was derived from: same address AND same generation
       const bool have = l2 ? (jt->pay16_built && (!inner || (jt->pay16_col == inner && jt->pay16_version == in->inner_version)))
                            : (jt->pay_col_built && (!inner || (jt->pay_col == inner && jt->pay_version == in->inner_version)));
-      if (!have) {
+      if (ok && !have) {
         // (re)build for this inner column, in the layout the chosen mode reads
         hipEvent_t b0 = nullptr, b1 = nullptr;
         (void)hipEventCreate(&b0);
@@ -1939,7 +1969,33 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
         pay.inner_col = inner;
         pay.entries = entries;
         pay.has_nulls = l2 ? jt->pay16_has_nulls : jt->pay_has_nulls;
-        if (join_probe_supported(d, fv, pay, n_cus)) kind = K_JOIN_PROBE;
+        if (join_probe_supported(d, fv, pay, n_cus)) {
+          kind = K_JOIN_PROBE;
+        } else {
+          // the probe plan does not take this payload after all: entries x 16 B of device memory are not kept for a
+          // member that will not run (the step falls back to k_join_sum / the row kernel below)
+          auto drop = [](auto*& ptr) {
+            if (ptr) (void)hipFree((void*)ptr);
+            ptr = nullptr;
+          };
+          if (l2) {
+            drop(jt->pay16);
+            drop(jt->pay8);
+            drop(jt->pay_kkeys);
+            jt->pay16_built = false;
+            jt->pay16_col = nullptr;
+          } else {
+            drop(jt->pay_cnt);
+            drop(jt->pay_wsum);
+            drop(jt->pay_wnn);
+            jt->pay_col_built = false;
+            jt->pay_col = nullptr;
+          }
+          pay = JoinPayloadView{};
+          jt->pay_refused = true;
+          jt->pay_refused_col = inner;
+          jt->pay_refused_rows = total_rows;
+        }
       }
     }
   }
@@ -2085,8 +2141,10 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     mi355q_result_free(res);
     rg.r = nullptr;
     mi355q_exec_options o2 = o;
-    // small replicas did not hold the groups: the largest replica next, then another family
-    o2.flags |= (o.flags & MI355Q_OPT_LDS_BASELINE_LARGE) ? MI355Q_OPT_NO_LDS_BASELINE : MI355Q_OPT_LDS_BASELINE_LARGE;
+    // small replicas did not hold the groups: the largest replica next, then eight windows of it, then another family
+    o2.flags |= !(o.flags & MI355Q_OPT_LDS_BASELINE_LARGE)     ? MI355Q_OPT_LDS_BASELINE_LARGE
+                : !(o.flags & MI355Q_OPT_LDS_BASELINE_WINDOWS) ? MI355Q_OPT_LDS_BASELINE_WINDOWS
+                                                               : MI355Q_OPT_NO_LDS_BASELINE;
     return execute_impl(plan, in, &o2, out, report, nullptr, nullptr);
   }
   if (code) return code;
@@ -2247,6 +2305,7 @@ int32_t mi355q_join_invalidate_payload(mi355q_join_table* t) {
   t->pay_col_built = false;
   t->pay16_col = nullptr;
   t->pay_col = nullptr;
+  t->pay_refused = false;
   return MI355Q_OK;
 }
 

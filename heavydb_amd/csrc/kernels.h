@@ -258,7 +258,7 @@ hipError_t launch_join_payload_keyed_build(const void* table, int hash_type, int
                                            int64_t* kkeys, void* pay16, int64_t* pay8, int32_t* d_flags, int n_cus,
                                            hipStream_t s);
 // l2_mode: 0 = LDS slices of a perfect table, 1 = L2 slices of a perfect table, 2 = keyed table (L2 slices by slot)
-bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int* l2_mode);
+bool join_probe_wants(const DevPlan& p, const FragView& fv, int n_cus, int* inner_col, int* l2_mode);
 bool join_probe_supported(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus);
 int64_t join_probe_scratch_bytes(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int n_cus,
                                  int64_t cap_bytes);

@@ -21,6 +21,13 @@
 //            go through the reference's insert-or-find (get_group_value, GroupByRuntime.cpp:25-48).
 //   give up  a baseline table with more groups than a replica holds sets a flag; the caller re-runs the step with
 //            the partitioned family.
+//   windows  a table that does not fit one LDS is cut into T <= 8 WINDOWS (perfect hash: T ranges of the entry index;
+//            baseline: T classes of a key hash): workgroup b owns window b % T and row stripe b / T, reads every row of
+//            its stripe and keeps the rows of its window.  The columns are read T times (by workgroups that run side by
+//            side, so mostly out of the Infinity Cache) instead of once — against the partitioned family's exchange of
+//            16 B written + 16 B read per row, and against one global atomic per row and slot on a few thousand
+//            addresses: the reference benchmark's 10 K-group shapes (PHS004, PHM003, BH004, BH007) took 1.8 - 3.3 ns per
+//            row that way (profiles/r03_refbench_128m_call4.jsonl).
 #include <cstring>
 #include <type_traits>
 
@@ -38,6 +45,7 @@ constexpr int kLdsKeys = 3;              // key columns (perfect hash)
 constexpr size_t kLdsBudget = 152 * 1024;
 constexpr uint32_t kLdsHashSmall = 256;  // slots of one baseline replica, first attempt (many replicas)
 constexpr uint32_t kLdsHashMax = 4096;   // ... at most, second attempt
+constexpr uint32_t kLdsMaxWindows = 8;   // windows of a table that does not fit one LDS (the columns are read once per window)
 
 struct LdsVal {
   int32_t col, type, nullable;           // type: MI355Q_INT32 / _INT64 / _DOUBLE (plain)
@@ -46,7 +54,8 @@ struct LdsVal {
 struct LdsArgs {
   int32_t n_vals, n_flt, n_keys;
   int32_t baseline;                      // 0: perfect-hash index; 1: open addressing on one 8-byte key
-  uint32_t entries;                      // arrays' length: perfect entry count, or the hash slots (power of two)
+  uint32_t entries;                      // arrays' length: entries of ONE window (perfect), or the hash slots (power of two)
+  uint32_t windows;                      // T >= 1: workgroup b keeps the rows of window b % T
   int32_t copies_lg;                     // log2(K)
   uint32_t copy_bytes;                   // bytes of one replica (16-byte multiple)
   int32_t off_rows, off_keys;            // rows[entries] (u32); keys[entries] (int64, baseline)
@@ -131,6 +140,14 @@ MQ_D uint32_t lds_key_home(uint32_t H, int64_t key) {
   const int lg = 31 - __builtin_clz(H | 1u);
   return lg ? (uint32_t)(x >> (64 - lg)) & (H - 1) : 0u;
 }
+// the window of a baseline key: other bits of the same kind of mix (independent of the slot a key takes inside its window)
+MQ_D uint32_t lds_key_window(uint32_t T, int64_t key) {
+  uint64_t x = (uint64_t)key;
+  x ^= x >> 31;
+  x *= 0xD6E8FEB86659FD93ull;
+  x ^= x >> 32;
+  return (uint32_t)(((x & 0xffffffffull) * T) >> 32);
+}
 MQ_D uint32_t lds_key_slot(int64_t* keys, uint32_t H, int64_t key) {
   uint32_t s = lds_key_home(H, key);
   for (uint32_t trips = 0; trips < H; ++trips) {
@@ -159,6 +176,12 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
   const int t = threadIdx.x;
   const uint32_t K = 1u << a.copies_lg;
   const uint32_t ne = a.entries;
+  // windows: this workgroup's window, its row stripe and the number of stripes (T = 1: the whole table, every workgroup a stripe)
+  const uint32_t T = a.windows;
+  const uint32_t win = T > 1 ? blockIdx.x % T : 0u;
+  const uint32_t stripe = T > 1 ? blockIdx.x / T : blockIdx.x;
+  const uint32_t n_stripes = T > 1 ? gridDim.x / T : gridDim.x;
+  const uint32_t e_lo = a.baseline ? 0u : win * ne;  // perfect hash: first entry index of the window
   // ---- initialise every replica: counters 0, sums 0, min / max identities, keys empty
   for (uint32_t r = 0; r < K; ++r) {
     char* rep = smem + (size_t)r * a.copy_bytes;
@@ -185,8 +208,16 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
   auto one_row = [&](const int64_t (&kv)[NK], const int64_t (&vv)[NV]) {
     uint32_t e;
     if (a.baseline) {
-      e = lds_key_slot((int64_t*)(my_rep + a.off_keys), ne, kv[0]);
+      // a FLOAT key is the bit pattern of the double it widens to (castToTypeIn(group_key, 64), IRCodegen.cpp:1505-1507)
+      const int64_t key = a.key_type[0] == MI355Q_FLOAT ? dbl_bits((double)bits_flt((int32_t)kv[0])) : kv[0];
+      if (T > 1 && lds_key_window(T, key) != win) return;
+      if (full) return;  // (this lane already knows the attempt is lost)
+      e = lds_key_slot((int64_t*)(my_rep + a.off_keys), ne, key);
       if (e == kNoSlot) {
+        // published at once: a full replica costs every later row of its keys a walk over the whole key array, and
+        // the other workgroups only stop when they see the flag (the version that raised it after the scan made a
+        // lost attempt slower than a successful one: BH003, profiles/r03_refbench_cliffs_call5_kernel_stats.csv)
+        atomicExch(d_err + 1, 1);
         full = true;
         return;
       }
@@ -202,11 +233,12 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
         in_range = in_range && d >= 0 && d < a.key_card[g];
         idx += d * a.key_mul[g];
       }
-      if (!in_range || (uint64_t)idx >= (uint64_t)ne) {
+      if (!in_range || (uint64_t)idx >= (uint64_t)p.entry_count) {
         bad = true;
         return;
       }
-      e = (uint32_t)idx;
+      e = (uint32_t)idx - e_lo;
+      if (e >= ne) return;  // another window's row
     }
     atomicAdd((uint32_t*)(my_rep + a.off_rows) + e, 1u);
 #pragma unroll
@@ -217,8 +249,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
   };
 
   const int64_t tile_q = (int64_t)kLdsBlock * UQ;
-  const int64_t gtid = (int64_t)blockIdx.x * kLdsBlock + t;
-  const int64_t gsize = (int64_t)gridDim.x * kLdsBlock;
+  const int64_t gtid = (int64_t)stripe * kLdsBlock + t;
+  const int64_t gsize = (int64_t)n_stripes * kLdsBlock;
   for (int f = 0; f < n_frags; ++f) {
     if (*(volatile int32_t*)(d_err + 1)) break;  // some workgroup's replica overflowed: the step is re-run anyway
     const int8_t* const* fc = cols + (size_t)f * n_cols;
@@ -244,7 +276,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
           if (k < a.n_flt) load_rawq(fb[k], quad, a.flt_type[k] != MI355Q_INT32, fr[k][u]);
 #pragma unroll
         for (int g = 0; g < NK; ++g)
-          if (g < a.n_keys) load_rawq(kb[g], quad, a.key_type[g] != MI355Q_INT32, kr[g][u]);
+          if (g < a.n_keys) load_rawq(kb[g], quad, a.key_type[g] != MI355Q_INT32 && a.key_type[g] != MI355Q_FLOAT, kr[g][u]);
 #pragma unroll
         for (int c = 0; c < NV; ++c)
           if (c < a.n_vals) load_rawq(vb[c], quad, a.v[c].type != MI355Q_INT32, vr[c][u]);
@@ -264,7 +296,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
           if (!pass) continue;
           int64_t kv[NK], vv[NV];
 #pragma unroll
-          for (int g = 0; g < NK; ++g) kv[g] = g < a.n_keys ? rawq_int(kr[g][u], a.key_type[g] == MI355Q_INT32 ? MI355Q_INT32 : MI355Q_INT64, i) : 0;
+          for (int g = 0; g < NK; ++g)
+            kv[g] = g < a.n_keys ? rawq_int(kr[g][u], (a.key_type[g] == MI355Q_INT32 || a.key_type[g] == MI355Q_FLOAT) ? MI355Q_INT32 : MI355Q_INT64, i) : 0;
 #pragma unroll
           for (int c = 0; c < NV; ++c) vv[c] = c < a.n_vals ? rawq_int(vr[c][u], a.v[c].type == MI355Q_INT32 ? MI355Q_INT32 : MI355Q_INT64, i) : 0;
           one_row(kv, vv);
@@ -272,9 +305,9 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
       }
     };
     uint32_t tiles_done = 0;
-    for (int64_t tl = (blockIdx.x + (int64_t)f * 7) % gridDim.x; tl < n_tiles; tl += gridDim.x) {
+    for (int64_t tl = (stripe + (int64_t)f * 7) % n_stripes; tl < n_tiles; tl += n_stripes) {
       // (a baseline attempt that cannot hold the groups is abandoned by everybody soon after the first overflow)
-      if (a.baseline && (tiles_done++ & 31u) == 31u && *(volatile int32_t*)(d_err + 1)) break;
+      if (a.baseline && (full || ((tiles_done++ & 3u) == 3u && *(volatile int32_t*)(d_err + 1)))) break;
       do_step(tl * tile_q + t, UQ, kLdsBlock);
     }
     for (int64_t q = n_tiles * tile_q + gtid; q < nq; q += gsize) do_step(q, 1, 0);
@@ -291,7 +324,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
         int64_t kv[NK], vv[NV];
 #pragma unroll
         for (int g = 0; g < NK; ++g)
-          kv[g] = g >= a.n_keys ? 0 : a.key_type[g] == MI355Q_INT32 ? (int64_t)load_one<int32_t>(kb[g], tail) : load_one<int64_t>(kb[g], tail);
+          kv[g] = g >= a.n_keys ? 0 : (a.key_type[g] == MI355Q_INT32 || a.key_type[g] == MI355Q_FLOAT) ? (int64_t)load_one<int32_t>(kb[g], tail) : load_one<int64_t>(kb[g], tail);
 #pragma unroll
         for (int c = 0; c < NV; ++c)
           vv[c] = c >= a.n_vals ? 0 : a.v[c].type == MI355Q_INT32 ? (int64_t)load_one<int32_t>(vb[c], tail) : load_one<int64_t>(vb[c], tail);
@@ -357,7 +390,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
       }
     } else {
       int64_t tk0 = 0, tk1 = 0, tk2 = 0;
-      uint32_t rem = e;
+      if ((uint64_t)e_lo + e >= (uint64_t)p.entry_count) continue;  // (padding of the last window)
+      uint32_t rem = e_lo + e;
 #pragma unroll
       for (int g = NK - 1; g >= 0; --g) {  // entry index -> key components (mul_g ascending with g)
         if (g >= a.n_keys) continue;
@@ -368,7 +402,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
                                  ? (a.key_type[g] == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN) : tk;
         if (g == 0) { tk0 = tk; key0 = orig; } else if (g == 1) { tk1 = tk; key1 = orig; } else { tk2 = tk; key2 = orig; }
       }
-      int64_t* row = out + (size_t)e * p.row_quad;
+      int64_t* row = out + (size_t)(e_lo + e) * p.row_quad;
       if (!p.keyless) {
         if (MQ_LOAD64(row) == kEmptyKey64) {
           if (a.n_keys > 2) MQ_STORE64(row + 2, tk2);
@@ -425,6 +459,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
 bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
   LdsArgs& a = *out;
   std::memset(&a, 0, sizeof(a));
+  a.windows = 1;
   if (p.desc_type == MI355Q_NON_GROUPED_AGGREGATE || p.join_col >= 0 || p.col0_key_quirk || p.slot_width != 8) return false;
   if (p.n_quals > MI355Q_MAX_QUALS) return false;
   for (int i = 0; i < p.n_quals; ++i) {
@@ -451,10 +486,11 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
     a.n_keys = p.n_group;
     a.entries = (uint32_t)p.entry_count;
   } else if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
-    // one 8-byte-wide key column (BIGINT, or DOUBLE as its bit pattern); 4-byte keys take the value sign-extended
+    // one 8-byte-wide key column (BIGINT, or DOUBLE as its bit pattern); 4-byte integer keys take the value
+    // sign-extended, FLOAT keys the bit pattern of the double they widen to
     if (p.n_group != 1) return false;
     const int kt = p.group_types[0];
-    if (kt != MI355Q_INT64 && kt != MI355Q_DOUBLE && kt != MI355Q_INT32) return false;
+    if (kt != MI355Q_INT64 && kt != MI355Q_DOUBLE && kt != MI355Q_INT32 && kt != MI355Q_FLOAT) return false;
     if (!all_aligned16(fv, p.group_cols[0])) return false;
     a.key_col[0] = p.group_cols[0];
     a.key_type[0] = kt;
@@ -462,7 +498,10 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
     a.baseline = 1;
     // the group count of a baseline table is only known afterwards: first 256-slot replicas (a table with a handful
     // of groups gets one replica per few lanes), then the largest replica that fits, then another family
-    a.entries = (tune_knobs().flags & MI355Q_OPT_LDS_BASELINE_LARGE) ? kLdsHashMax : kLdsHashSmall;
+    // third attempt: kLdsMaxWindows windows (classes of a key hash) of the largest replica
+    const uint32_t fl = tune_knobs().flags;
+    a.entries = (fl & (MI355Q_OPT_LDS_BASELINE_LARGE | MI355Q_OPT_LDS_BASELINE_WINDOWS)) ? kLdsHashMax : kLdsHashSmall;
+    if (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) a.windows = kLdsMaxWindows;
   } else {
     return false;
   }
@@ -528,6 +567,19 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
   a.copy_bytes = lay_out(a.entries);
   // (second baseline attempt: the largest power-of-two replica the accumulators leave room for)
   while (a.baseline && a.copy_bytes > kLdsBudget && a.entries > kLdsHashSmall) a.copy_bytes = lay_out(a.entries / 2);
+  // a perfect-hash table larger than the LDS: the fewest windows whose share fits (one replica each)
+  if (!a.baseline && a.copy_bytes > kLdsBudget) {
+    const uint32_t total = (uint32_t)p.entry_count;
+    for (uint32_t T = 2; T <= kLdsMaxWindows; ++T) {
+      const uint32_t share = (total + T - 1) / T;
+      if (lay_out(share) <= kLdsBudget) {
+        a.windows = T;
+        a.copy_bytes = lay_out(share);
+        break;
+      }
+    }
+    if (a.windows == 1) a.copy_bytes = lay_out(total);  // (does not fit: refused below)
+  }
   if (a.copy_bytes > kLdsBudget) return false;
   a.copies_lg = 0;
   while (a.copies_lg < 6 && ((size_t)a.copy_bytes << (a.copies_lg + 1)) <= kLdsBudget) ++a.copies_lg;
@@ -548,7 +600,12 @@ hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out
   const size_t lds = (size_t)a.copy_bytes << a.copies_lg;
   int64_t want = (fv.total_rows / 4 + kLdsBlock - 1) / kLdsBlock;
   if (want < 1) want = 1;
-  const int grid = (int)(want < n_cus ? want : n_cus);
+  // windows: T workgroups (one per window) share a row stripe
+  const int T = (int)a.windows;
+  int64_t stripes = n_cus / T;
+  if (stripes > want) stripes = want;
+  if (stripes < 1) stripes = 1;
+  const int grid = (int)stripes * T;
   st->kernel_name = "k_groupby_lds";
   st->n_launches = 1;
   st->variant = 4;

@@ -2824,7 +2824,7 @@ bool join_probe_supported(const DevPlan& p, const FragView& fv, const JoinPayloa
 }
 
 // which inner column (if any) the payload of this plan has to be built for; false = shape not taken
-bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int* l2_mode) {
+bool join_probe_wants(const DevPlan& p, const FragView& fv, int n_cus, int* inner_col, int* l2_mode) {
   JoinPayloadView fake{};
   const bool keyed = p.join_hash_type == 1 || p.join_hash_type == 3;
   const __int128 range128 = keyed ? (__int128)p.join_entries : (__int128)p.join_max - (__int128)p.join_min + 1;
@@ -2842,7 +2842,8 @@ bool join_probe_wants(const DevPlan& p, const FragView& fv, int* inner_col, int*
     if (p.targets[i].table == 1 && p.targets[i].col >= 0) wcol = p.targets[i].col;
   fake.inner_col = wcol >= 0 ? (const void*)p.inner_cols[wcol] : nullptr;
   ProbePartHost h;
-  if (!make_probe_plan(p, fv, fake, 256, kDefaultScratchCap, &h)) return false;
+  // (the geometry — partitions, slice sizes, L2 mode — depends on the CU count: the device's own, not a nominal 256)
+  if (!make_probe_plan(p, fv, fake, n_cus, kDefaultScratchCap, &h)) return false;
   *inner_col = h.wcol;
   *l2_mode = h.keyed ? 2 : h.l2_mode ? 1 : 0;
   return true;

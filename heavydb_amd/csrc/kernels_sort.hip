@@ -41,6 +41,13 @@ struct TopkState {  // device words shared by the passes
   unsigned int hist[kBins];
 };
 
+// order-preserving pattern of a double; -0.0 and +0.0 are ONE value (ResultSetComparator compares doubles numerically:
+// with distinct patterns a multi-key ORDER BY would stop at the first key where the reference goes on to the next)
+MQ_D uint64_t ordered_f64(double d) {
+  const uint64_t b = d == 0.0 ? 0ull : (uint64_t)dbl_bits(d);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
 MQ_D uint64_t order_key_of(const DevPlan& p, const DevTarget& t, const int64_t* row, int idx_target_as_key,
                            int64_t null_pattern, bool fp_result, bool desc, bool nulls_first) {
   if (is_empty_row(p, row, idx_target_as_key)) return kEmptySortKey;
@@ -58,19 +65,16 @@ MQ_D uint64_t order_key_of(const DevPlan& p, const DevTarget& t, const int64_t* 
     const int64_t* s = row + p.key_quad + t.slot;
     if (t.arg_f32 && t.agg != MI355Q_AVG && t.agg != MI355Q_COUNT) {  // float bits in the low half
       is_null = t.skip_null && (int32_t)s[0] == (int32_t)null_pattern;
-      const uint64_t b = (uint64_t)dbl_bits((double)bits_flt((int32_t)s[0]));
-      u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+      u = ordered_f64((double)bits_flt((int32_t)s[0]));
     } else if (t.agg == MI355Q_AVG) {
       const int64_t cnt = s[1];
       is_null = cnt == 0;  // pair_to_double: count 0 -> NULL
       const double sum = t.arg_f32 ? (double)bits_flt((int32_t)s[0]) : t.arg_fp ? bits_dbl(s[0]) : (double)s[0];
       const double d = is_null ? 0.0 : sum / (double)cnt;
-      const uint64_t b = (uint64_t)dbl_bits(d);
-      u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+      u = ordered_f64(d);
     } else if (fp_result) {
       is_null = (t.skip_null) && s[0] == null_pattern;
-      const uint64_t b = (uint64_t)s[0];
-      u = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+      u = ordered_f64(bits_dbl(s[0]));
     } else {
       is_null = (t.skip_null || t.agg == MI355Q_PROJECT_KEY) && s[0] == null_pattern;
       u = (uint64_t)s[0] ^ 0x8000000000000000ull;
@@ -78,7 +82,10 @@ MQ_D uint64_t order_key_of(const DevPlan& p, const DevTarget& t, const int64_t* 
   }
   if (is_null) return nulls_first ? 0ull : kNullLastKey;
   if (desc) u = ~u;
-  // keep the reserved patterns free: 0 (NULLS FIRST), ~0 - 1 (NULLS LAST), ~0 (empty)
+  // keep the reserved patterns free: 0 (NULLS FIRST), ~0 - 1 (NULLS LAST), ~0 (empty).  Known deviation: the two
+  // smallest and the three largest patterns of the value range fold onto their neighbour (INT64_MIN / INT64_MIN + 1 and
+  // INT64_MAX - 2 .. INT64_MAX for an integer target), i.e. they tie where the reference orders them; a nullable
+  // integer target never holds INT64_MIN (it is the NULL sentinel) and no finite double reaches the fp patterns.
   if (u == 0ull) u = 1ull;
   if (u >= kNullLastKey) u = kNullLastKey - 1;
   return u;

@@ -423,6 +423,8 @@ typedef struct mi355q_exec_options {
                                             this itself when it re-runs a step whose groups did not fit a replica) */
 #define MI355Q_OPT_LDS_BASELINE_LARGE 16u /* ... try it with the largest replica LDS holds (second attempt: the first
                                             uses 256-slot replicas, many of them, for tables with a handful of groups) */
+#define MI355Q_OPT_LDS_BASELINE_WINDOWS 32u /* ... third attempt: the groups spread over 8 windows (classes of a key hash),
+                                            one workgroup per window and row stripe, the largest replica each */
 
 /* per-call timing/selection report (what launchGpuCode logs,
  * QueryExecutionContext.cpp:334,364,579) */

@@ -32,15 +32,16 @@ def golden():
 # kernels themselves, and tests that need device-only members (ORDER BY, payload probes, slice merges) or sizes a CPU
 # cannot visit fail or time out here by design.  Usage:
 #   MI355Q_HOSTSIM=1 python -m pytest tests -m gpu -p no:cacheprovider --timeout 120 -q
+# MI355Q_HOSTSIM=real: the same with the REAL kernels_fast.hip / kernels_lds.hip compiled for the host (hostsim_lib(real_fast=True)).
 # Never set on a GPU box: the driver's gpu run loads the real libmi355q.so.
-if os.environ.get("MI355Q_HOSTSIM") == "1":
+if os.environ.get("MI355Q_HOSTSIM") in ("1", "real"):
     @pytest.fixture(scope="session", autouse=True)
     def _hostsim_session():
         import torch
         from heavydb_amd import capi
         from tests.helpers import hostsim_lib
         assert not torch.cuda.is_available(), "MI355Q_HOSTSIM is for machines without a GPU"
-        lib = capi.load_library(hostsim_lib())
+        lib = capi.load_library(hostsim_lib(real_fast=os.environ.get("MI355Q_HOSTSIM") == "real"))
         capi._lib = lib
         real_zeros, real_empty, real_full, real_arange = torch.zeros, torch.empty, torch.full, torch.arange
         strip = lambda f: (lambda *a, **k: f(*a, **{x: y for x, y in k.items() if x != "device"}))  # noqa: E731

@@ -164,13 +164,13 @@ bool lds_groupby_eligible(const DevPlan& p, const FragView&) {
   for (int i = 0; i < p.n_quals; ++i)
     if (p.quals[i].type != MI355Q_INT32 && p.quals[i].type != MI355Q_INT64) return false;
   if (p.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
-    if (p.n_group < 1 || p.n_group > 3 || p.entry_count > 4096) return false;   // "fits a replica"
+    if (p.n_group < 1 || p.n_group > 3 || p.entry_count > 8 * 4096) return false;   // "fits eight windows of a replica"
     for (int g = 0; g < p.n_group; ++g)
       if ((p.group_types[g] != MI355Q_INT32 && p.group_types[g] != MI355Q_INT64) || p.group_bucket[g]) return false;
   } else if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
     if (p.n_group != 1) return false;
     const int kt = p.group_types[0];
-    if (kt != MI355Q_INT64 && kt != MI355Q_DOUBLE && kt != MI355Q_INT32) return false;
+    if (kt != MI355Q_INT64 && kt != MI355Q_DOUBLE && kt != MI355Q_INT32 && kt != MI355Q_FLOAT) return false;
   } else {
     return false;
   }
@@ -180,7 +180,9 @@ hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out
                               LaunchStats* st) {
   finish(p, fv, out, d_err, st, "k_groupby_lds", 4, F_LDS_GROUPBY);
   if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
-    const int64_t cap = (tune_knobs().flags & MI355Q_OPT_LDS_BASELINE_LARGE) ? g_cfg.lds_large_groups : g_cfg.lds_small_groups;
+    const uint32_t fl = tune_knobs().flags;
+    const int64_t cap = (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) ? 8 * (int64_t)g_cfg.lds_large_groups
+                        : (fl & MI355Q_OPT_LDS_BASELINE_LARGE) ? g_cfg.lds_large_groups : g_cfg.lds_small_groups;
     if (live_entries(p, out) > cap) {
       // a replica ran out of room: what the table holds now is not a result
       for (int64_t i = 0; i < p.entry_count * p.row_quad; ++i) out[i] = 0x6b6b6b6b6b6b6b6bll;
@@ -257,7 +259,7 @@ bool join_part_supported(const DevPlan&, const FragView&, int) { return false; }
 int64_t join_part_scratch_bytes(const DevPlan&, const FragView&, int, int64_t) { return 0; }
 hipError_t launch_join_partitioned(const DevPlan&, const FragView&, int64_t*, int32_t*, void*, int64_t, int64_t, int,
                                    hipStream_t, LaunchStats*) { return hipErrorNotSupported; }
-bool join_probe_wants(const DevPlan&, const FragView&, int*, int*) { return false; }
+bool join_probe_wants(const DevPlan&, const FragView&, int, int*, int*) { return false; }
 bool join_probe_supported(const DevPlan&, const FragView&, const JoinPayloadView&, int) { return false; }
 int64_t join_probe_scratch_bytes(const DevPlan&, const FragView&, const JoinPayloadView&, int, int64_t) { return 0; }
 hipError_t launch_join_probe(const DevPlan&, const FragView&, const JoinPayloadView&, int64_t*, int32_t*, void*, int64_t,

@@ -177,11 +177,12 @@ def _baseline_case(oracle, n_groups, n_rows=5000, seed=3):
     return cases_mod.Case("b", ra, [[key[:n_rows // 2], val[:n_rows // 2]], [key[n_rows // 2:], val[n_rows // 2:]]])
 
 
-@pytest.mark.parametrize("groups,attempts,final", [(20, 1, "k_groupby_lds"), (200, 2, "k_groupby_lds"),
-                                                   (1500, 2, "k_baseline_direct")])
+@pytest.mark.parametrize("groups,attempts,final", [(20, 1, "k_groupby_lds"), (120, 2, "k_groupby_lds"),
+                                                   (1000, 3, "k_groupby_lds"), (1500, 3, "k_baseline_direct")])
 def test_lds_replica_overflow_retry_chain(sim, oracle, groups, attempts, final):
-    """a baseline table's group count is only known afterwards: small replicas, then the largest, then another family"""
-    sim.hostsim_configure(ALL_ROUTES, 64, 512, 0)
+    """a baseline table's group count is only known afterwards: small replicas, then the largest, then eight windows of
+    the largest, then another family"""
+    sim.hostsim_configure(ALL_ROUTES, 64, 150, 0)
     rs = _check(oracle, _baseline_case(oracle, groups))
     assert sim.hostsim_launches(F_LDS_GROUPBY) == attempts
     assert rs.report.kernel_name.decode() == final
@@ -237,3 +238,80 @@ def test_out_of_device_memory_is_an_error_code(sim, oracle):
     gc.collect()
     assert sim.hostsim_live_allocations() <= before
     _check(oracle, case)
+
+
+# ---- Arrow C Data Interface export (mi355q_result_export_arrow) on the host runtime
+def _arrow_case():
+    return next(c for c in CASES if c.name == "baseline_nullable_args")
+
+
+def test_arrow_export_matches_oracle_rows(sim, oracle):
+    import pyarrow as pa
+    from heavydb_amd.executor import Executor
+    sim.hostsim_configure(ALL_ROUTES, 0, 0, 0)
+    case = _arrow_case()
+    rs = Executor(0).executeWorkUnit(case.ra, _fetch_result(case), allow_retry=False)
+    q, buf, code = oracle.execute(case.ra.to_plan(), case.frags, case.inner, None, n_threads=2)
+    assert code == 0
+    ival, dval, nul = oracle.fetch_rows(q, buf)
+    names = [f"c{i}" for i in range(q.n_targets)]
+    got = rs.to_arrow_native(names)
+    assert got.schema.names == names and got.num_rows == ival.shape[0]
+    key = lambda row: tuple((0, 0) if v is None else (1, v) for v in row)  # noqa: E731
+    want_rows = sorted((tuple(None if nul[r, t] else (float(dval[r, t]) if q.target_is_fp[t] else int(ival[r, t]))
+                              for t in range(q.n_targets)) for r in range(ival.shape[0])), key=key)
+    got_rows = sorted(zip(*[got.column(n).to_pylist() for n in names]), key=key)
+    for a, b in zip(want_rows, got_rows):
+        for x, y in zip(a, b):
+            assert (x is None) == (y is None) and (x is None or x == y or abs(x - y) <= 1e-9 * max(abs(x), abs(y))), (a, b)
+    for t, n in enumerate(names):
+        assert got.column(n).type == (pa.float64() if q.target_is_fp[t] else pa.int64())
+
+
+def test_arrow_child_moved_out_survives_its_parent(sim, oracle):
+    """Arrow C Data Interface, "moving child arrays": a consumer copies a child struct out of the parent, marks the
+    source released and releases the parent FIRST; the moved child (its name, its buffers) must stay valid until its own
+    release runs (the names used to live in the parent's private data)."""
+    from heavydb_amd.executor import Executor
+    sim.hostsim_configure(ALL_ROUTES, 0, 0, 0)
+    case = _arrow_case()
+    rs = Executor(0).executeWorkUnit(case.ra, _fetch_result(case), allow_retry=False)
+
+    class Schema(C.Structure):
+        pass
+    Schema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_void_p), ("flags", C.c_int64),
+                       ("n_children", C.c_int64), ("children", C.POINTER(C.POINTER(Schema))), ("dictionary", C.c_void_p),
+                       ("release", C.CFUNCTYPE(None, C.POINTER(Schema))), ("private_data", C.c_void_p)]
+
+    class Array(C.Structure):
+        pass
+    Array._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64), ("n_buffers", C.c_int64),
+                      ("n_children", C.c_int64), ("buffers", C.POINTER(C.c_void_p)), ("children", C.POINTER(C.POINTER(Array))),
+                      ("dictionary", C.c_void_p), ("release", C.CFUNCTYPE(None, C.POINTER(Array))), ("private_data", C.c_void_p)]
+    assert C.sizeof(Schema) == 72 and C.sizeof(Array) == 80
+    sch, arr = Schema(), Array()
+    names = [b"alpha", b"beta", b"gamma", b"delta", b"epsilon", b"zeta", b"eta", b"theta"][:rs.getQueryMemDesc().n_targets]
+    c_names = (C.c_char_p * len(names))(*names)
+    rc = sim.mi355q_result_export_arrow(rs.handle, c_names, C.addressof(sch), C.addressof(arr), None)
+    assert rc == 0 and sch.n_children == len(names) and arr.n_children == len(names)
+    # move child 1 of both out: copy the struct, mark the source released
+    moved_s, moved_a = Schema(), Array()
+    C.memmove(C.addressof(moved_s), C.addressof(sch.children[1].contents), 72)
+    C.memmove(C.addressof(moved_a), C.addressof(arr.children[1].contents), 80)
+    C.memset(C.addressof(sch.children[1].contents) + Schema.release.offset, 0, 8)
+    C.memset(C.addressof(arr.children[1].contents) + Array.release.offset, 0, 8)
+    n_rows = arr.length
+    sch.release(C.byref(sch))
+    arr.release(C.byref(arr))
+    assert not sch.release and not arr.release
+    import gc
+    gc.collect()
+    junk = [bytes(200) for _ in range(2000)]   # (give a dangling name every chance to be overwritten)
+    assert moved_s.name == b"beta" and moved_s.format in (b"l", b"g")
+    assert moved_a.length == n_rows and moved_a.n_buffers == 2
+    vals = (C.c_int64 * max(int(n_rows), 1)).from_address(moved_a.buffers[1])
+    assert n_rows == 0 or isinstance(vals[int(n_rows) - 1], int)
+    moved_s.release(C.byref(moved_s))
+    moved_a.release(C.byref(moved_a))
+    assert not moved_s.release and not moved_a.release
+    del junk

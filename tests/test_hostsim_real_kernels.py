@@ -53,3 +53,26 @@ def test_refbench_queries_through_the_real_fast_kernels(sim, oracle, name):
 def test_zz_every_real_family_ran():
     missing = REAL_FAMILIES - SEEN - {"k_perfect_lds_prog"}
     assert not missing, (missing, SEEN)
+
+
+# ---- tables that do not fit one LDS: windows (perfect hash: ranges of the entry index; baseline: classes of a key hash)
+@pytest.mark.parametrize("name", ["PHS004", "PHM003", "BH004", "BH007", "MSPHS002", "MSPHM002", "MSBS002"])
+def test_windowed_lds_groupby_on_ten_thousand_groups(sim, oracle, name):
+    """the reference benchmark's 10 K-group shapes at their real cardinality: 3 - 8 windows per table"""
+    case = flow._refbench_case(oracle, name, 40000, 10000)
+    rs = flow._check(oracle, case, kernel_variant=0)
+    assert rs is not None
+    assert rs.report.kernel_name.decode() == "k_groupby_lds", rs.report.kernel_name
+    assert rs.rowCount() > 4096
+
+
+def test_windowed_baseline_gives_up_beyond_eight_windows(sim, oracle):
+    """more groups than eight windows hold: the chain ends in another family, the result is still the oracle's"""
+    case = flow._baseline_case(oracle, 60000, n_rows=90000)
+    case.ra.max_groups_buffer_entry_guess = 65536 * 2
+    rs = flow._check(oracle, case)
+    assert rs.report.kernel_name.decode() != "k_groupby_lds"
+    # close to what eight windows hold (28 K groups in 32 K slots): whichever family ends up with it, the oracle's result
+    case = flow._baseline_case(oracle, 30000, n_rows=90000)
+    case.ra.max_groups_buffer_entry_guess = 65536
+    flow._check(oracle, case)

@@ -53,8 +53,16 @@ def test_refbench_queries_small(torch_cuda, oracle, name, variant):
     _run(torch_cuda, oracle, name, 30_000, 3_000, variant)
 
 
-@pytest.mark.parametrize("name", ["NGA02", "NGA05", "PHS003", "PHS006", "PHM004", "BH002", "BH006", "BH008", "BH010",
-                                  "MSBS003", "MSPHS002", "MSPHM006", "S002"])
+@pytest.mark.parametrize("name", ["PHS004", "PHM003", "BH004", "BH007", "MSPHS002", "MSPHM002", "MSBS002"])
+def test_refbench_windowed_lds_groupby(torch_cuda, oracle, name):
+    """the 10 K-group shapes at their real cardinality: tables that do not fit one LDS run as 3 - 8 windows of
+    k_groupby_lds (perfect hash: ranges of the entry index; baseline, FLOAT / DOUBLE / BIGINT key: classes of a key hash)"""
+    kernel = _run(torch_cuda, oracle, name, 400_000, 10_000, 0)
+    assert kernel == "k_groupby_lds", kernel
+
+
+@pytest.mark.parametrize("name", ["NGA02", "NGA05", "PHS003", "PHS004", "PHS006", "PHM004", "BH002", "BH004", "BH006",
+                                  "BH007", "BH008", "BH010", "MSBS001", "MSBS003", "MSPHS002", "MSPHM006", "S002"])
 def test_refbench_queries_16m_rows(torch_cuda, oracle, name):
     kernel = _run(torch_cuda, oracle, name, 16_000_000, 0, 0)
     print(name, kernel)
