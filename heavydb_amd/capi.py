@@ -255,6 +255,7 @@ SYMBOLS = [
     ("mi355q_shard_merge_range", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p]),
     ("mi355q_shard_merge_slices", C.c_int32, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int32,
                                               C.c_int32, C.c_int64, C.c_int64, C.c_void_p]),
+    ("mi355q_explain", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]),
     ("mi355q_result_export_arrow", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355q_result_sort", C.c_int32,
      [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_int64, C.c_void_p, _P(C.c_int64), C.c_void_p]),

@@ -72,6 +72,17 @@ struct mi355q_result {
 
 namespace {
 
+// mi355q_explain: the route of a step, written down while execute_impl plans it in RESERVE mode (nothing is launched,
+// nothing is allocated: t_plan_only).  Every derived route (projection, row-wise / 8-byte twins, packed keys, one run
+// per value column) notes itself and plans its derived step the same way.
+thread_local std::string* t_route = nullptr;
+thread_local bool t_plan_only = false;
+void route_note(const char* what) {
+  if (!t_route) return;
+  if (!t_route->empty()) *t_route += " > ";
+  *t_route += what;
+}
+
 #define HIP_TRY(expr)                                     \
   do {                                                    \
     hipError_t _e = (expr);                               \
@@ -907,11 +918,20 @@ constexpr int32_t kRetryNoLds = INT32_MIN + 8;  // internal: the LDS group-by ra
 
 bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, PackSpec* ps) {
   if (p.join_outer_col >= 0 || p.n_group_cols < 1 || d.col0_key_quirk) return false;
-  for (int g = 0; g < p.n_group_cols; ++g)  // floating-point keys have no integer range to pack
-    if (type_is_fp(p.cols[p.group_cols[g]].type) || type_is_f32(p.cols[p.group_cols[g]].type)) return false;
-  if (p.n_cols >= MI355Q_MAX_COLS) return false;  // the packed column is appended to the inputs
   std::memset(ps, 0, sizeof(*ps));
   ps->n = p.n_group_cols;
+  // ONE plain FLOAT key on a baseline table: the table stores the double it widens to, so the "packed" column is that
+  // double's bit pattern and the single-key families (which read 8-byte keys) take the step — the reference
+  // benchmark's GROUP BY cast(x AS FLOAT) (MultiStep/MSBS001-005)
+  if (p.n_group_cols == 1 && q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && p.cols[p.group_cols[0]].type == MI355Q_FLOAT &&
+      p.cols[p.group_cols[0]].encoding == MI355Q_ENC_NONE && q.key_width == 8) {
+    ps->raw_f32 = 1;
+    ps->cols[0] = p.group_cols[0];
+    ps->types[0] = d.group_types[0];
+    return true;
+  }
+  for (int g = 0; g < p.n_group_cols; ++g)  // other floating-point keys have no integer range to pack
+    if (type_is_fp(p.cols[p.group_cols[g]].type) || type_is_f32(p.cols[p.group_cols[g]].type)) return false;
   if (q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
     // single-column tables that fit LDS already have their kernel; multi-column ones reach it
     // through the packed index (mode 2); bucketed keys cannot be restored from their index
@@ -974,9 +994,12 @@ bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, P
   return true;
 }
 
+int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options* opts, mi355q_result** out,
+                     mi355q_exec_report* report, mi355q_pending** pend, int64_t* reserved);
+
 int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
                              const mi355q_qmd& q, const DevPlan& d, int n_cus, mi355q_result** out,
-                             mi355q_exec_report* report) {
+                             mi355q_exec_report* report, int64_t* reserved) {
   PackSpec ps;
   // kernel_variant 1 = "the row kernel / direct members", as everywhere else
   if (o.kernel_variant == 1) return kNotTaken;
@@ -995,11 +1018,32 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
   // derived plan: the packed column (appended, range unknown -> baseline, 8-byte key) is the
   // only group column; key projections are dropped (they own no slot)
   mi355q_plan p2 = *plan;
-  p2.n_cols = nc + 1;
-  p2.cols[nc] = mi355q_col_desc{MI355Q_INT64, 0, MI355Q_ENC_NONE, 0};
-  p2.col_ranges[nc] = mi355q_range{};
+  // where the packed column sits in the derived step's column table: appended — or, when the table is full
+  // (MI355Q_MAX_COLS), in the place of a key column nothing else reads (its only reader, the grouping, is what the packed
+  // column replaces; key projections own no slot in the derived plan)
+  int pk = nc;
+  if (nc >= MI355Q_MAX_COLS) {
+    pk = -1;
+    for (int g = 0; g < plan->n_group_cols && pk < 0; ++g) {
+      const int c = plan->group_cols[g];
+      bool used = false;
+      for (int t = 0; t < plan->n_targets; ++t) {
+        const mi355q_target& tg = plan->targets[t];
+        if (tg.agg == MI355Q_PROJECT_KEY) continue;
+        used = used || (tg.table == 0 && tg.col == c) ||
+               ((tg.agg == MI355Q_COUNT_IF || tg.agg == MI355Q_SUM_IF) && tg.cond.col == c);
+      }
+      for (int k = 0; k < plan->n_quals; ++k) used = used || plan->quals[k].col == c;
+      if (!used) pk = c;
+    }
+    if (pk < 0) return kNotTaken;
+  }
+  const int nc2 = pk == nc ? nc + 1 : nc;
+  p2.n_cols = nc2;
+  p2.cols[pk] = mi355q_col_desc{MI355Q_INT64, 0, MI355Q_ENC_NONE, 0};
+  p2.col_ranges[pk] = mi355q_range{};
   p2.n_group_cols = 1;
-  p2.group_cols[0] = nc;
+  p2.group_cols[0] = pk;
   p2.n_targets = 0;
   for (int t = 0; t < plan->n_targets; ++t) {
     if (plan->targets[t].agg != MI355Q_PROJECT_KEY) p2.targets[p2.n_targets++] = plan->targets[t];
@@ -1011,9 +1055,9 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     p2.max_groups_buffer_entry_guess = guess;
   }
   if (ps.mode == 2) {  // the index is a perfect-hash key itself: range [0, entries)
-    p2.col_ranges[nc].valid = 1;
-    p2.col_ranges[nc].min = 0;
-    p2.col_ranges[nc].max = q.entry_count - 1;
+    p2.col_ranges[pk].valid = 1;
+    p2.col_ranges[pk].min = 0;
+    p2.col_ranges[pk].max = q.entry_count - 1;
   }
   // the temporary table always has 8-byte slots: k_unpack_emit / k_unpack_perfect read it quad by
   // quad, and a multi-pass run reduces it with 64-bit adds (pick_target_compact_width would narrow a
@@ -1050,6 +1094,21 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     }
   }
 
+  if (reserved) {  // RESERVE / explain: the derived single-key step over all fragments (one pass), nothing launched
+    route_note(ps.raw_f32 ? "k_pack_keys (FLOAT key widened)" : ps.mode == 0 ? "k_pack_keys (bit-packed key)" : ps.mode == 1 ? "k_pack_keys (entry index, baseline temp)"
+                                                                             : "k_pack_keys (entry index, perfect temp)");
+    std::vector<const void*> cols2((size_t)nf * nc2, nullptr);
+    for (int i = 0; i < nf; ++i)
+      for (int c = 0; c < nc; ++c)
+        if (c != pk) cols2[(size_t)i * nc2 + c] = in->col_buffers[(size_t)i * nc + c];
+    mi355q_inputs in2 = *in;
+    in2.col_buffers = cols2.data();
+    mi355q_exec_options o2 = o;
+    o2.out_buffer = nullptr;
+    const int32_t e2 = execute_impl(&p2, &in2, &o2, out, report, nullptr, reserved);
+    if (e2 == MI355Q_OK) route_note(ps.mode == 2 ? "k_unpack_perfect" : "k_unpack_emit");
+    return e2;
+  }
   DeviceCtx& ctx = ctx_of(in->device_id);
   std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
   hipStream_t s = (hipStream_t)o.stream;
@@ -1115,7 +1174,7 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     }
   } evg{ev0, ev1};
 
-  std::vector<const void*> cols2((size_t)nf * (nc + 1));
+  std::vector<const void*> cols2((size_t)nf * nc2);
   std::vector<int64_t*> h_packed((size_t)nf);
   mi355q_exec_report acc{};
   int pass = 0;
@@ -1134,8 +1193,8 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
     HIP_TRY(launch_pack_keys(ps, (const int8_t* const*)d_tab.p + (size_t)f * nc, (const int64_t*)d_rows.p + f, pnf,
                              nc, max_frag_rows, d_packed_tab, d_err, n_cus, s));
     for (int i = 0; i < pnf; ++i) {
-      for (int c = 0; c < nc; ++c) cols2[(size_t)i * (nc + 1) + c] = in->col_buffers[(size_t)(f + i) * nc + c];
-      cols2[(size_t)i * (nc + 1) + nc] = h_packed[f + i];
+      for (int c = 0; c < nc; ++c) cols2[(size_t)i * nc2 + c] = in->col_buffers[(size_t)(f + i) * nc + c];
+      cols2[(size_t)i * nc2 + pk] = h_packed[f + i];
     }
     mi355q_inputs in2 = *in;
     in2.n_frags = pnf;
@@ -1314,7 +1373,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in, const mi3
 // routes: one run per value column through the single-value families, zipped into the final layout
 // (kernels_generic.hip k_zip_targets).  kNotTaken when the shape does not call for it.
 int32_t execute_multi_value(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
-                            const mi355q_qmd& q, const DevPlan& d, mi355q_result** out, mi355q_exec_report* report) {
+                            const mi355q_qmd& q, const DevPlan& d, mi355q_result** out, mi355q_exec_report* report,
+                            int64_t* reserved) {
   if (plan->n_group_cols < 1 || plan->join_outer_col >= 0 || q.slot_width != 8 || q.output_columnar || d.col0_key_quirk)
     return kNotTaken;
   // the value columns, in order of first use
@@ -1334,6 +1394,20 @@ int32_t execute_multi_value(const mi355q_plan* plan, const mi355q_inputs* in, co
   // packed route: how the tests reach this route with small tables)
   if (o.kernel_variant != 2 && total_rows < ((int64_t)8 << 20)) return kNotTaken;
 
+  if (reserved) {  // RESERVE / explain: the run over the first value column (every run has the same shape)
+    char note[64];
+    std::snprintf(note, sizeof(note), "%d runs (one per value column) + k_zip_targets, each", n_v);
+    route_note(note);
+    mi355q_plan sp = *plan;
+    sp.n_targets = 0;
+    for (int t = 0; t < plan->n_targets; ++t) {
+      const mi355q_target& tg = plan->targets[t];
+      if (tg.agg == MI355Q_PROJECT_KEY || tg.col < 0 || tg.col == vcols[0]) sp.targets[sp.n_targets++] = tg;
+    }
+    mi355q_exec_options o2 = o;
+    o2.out_buffer = nullptr;
+    return execute_impl(&sp, in, &o2, out, report, nullptr, reserved);
+  }
   DeviceGuard g(in->device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
   DeviceCtx& ctx = ctx_of(in->device_id);
@@ -1613,6 +1687,38 @@ int32_t mi355q_reserve_workspace(const mi355q_plan* plan, const mi355q_inputs* i
   return e;
 }
 
+// EXPLAIN for one step: the route mi355q_execute would take for this plan over inputs of this shape (fragment row
+// counts; the pointer table is not looked at: 16-byte aligned chunks are assumed), as a " > "-separated chain of
+// the derived-plan stages and the kernel family that runs the step, e.g.
+//   "k_project > k_pack_keys (entry index, baseline temp) > k_part_scatter + k_part_aggregate > k_unpack_emit".
+// Nothing is launched and no workspace is allocated; *scratch_bytes = the partition scratch the step would ask for.
+int32_t mi355q_explain(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options* opts, char* route,
+                       int64_t route_len, int64_t* scratch_bytes) {
+  if (!plan || !in || (route_len > 0 && !route)) return MI355Q_ERR_INVALID_PLAN;
+  int64_t bytes = 0;
+  std::string text;
+  int32_t e;
+  try {
+    std::vector<const void*> none((size_t)std::max(1, in->n_frags * std::max(plan->n_cols + plan->n_exprs, 1)), nullptr);
+    mi355q_inputs in2 = *in;
+    in2.col_buffers = none.data();  // (16-byte aligned chunks assumed, as mi355q_reserve_workspace does)
+    mi355q_result* r = nullptr;
+    t_route = &text;
+    t_plan_only = true;
+    e = execute_impl(plan, &in2, opts, &r, nullptr, nullptr, &bytes);
+    t_route = nullptr;
+    t_plan_only = false;
+    if (r) mi355q_result_free(r);
+  } catch (...) {
+    t_route = nullptr;
+    t_plan_only = false;
+    return MI355Q_ERR_OUT_OF_CPU_MEM;
+  }
+  if (route && route_len > 0) std::snprintf(route, (size_t)route_len, "%s", text.c_str());
+  if (scratch_bytes) *scratch_bytes = bytes;
+  return e;
+}
+
 // Stream-ordered form of mi355q_execute: every kernel of the step is enqueued on the stream and the call
 // returns without waiting for the device.  *out is valid at once for STREAM-ORDERED use on the same stream
 // (mi355q_shard_pads, a collective enqueued behind it, ...); whether the step succeeded — error code, the
@@ -1683,6 +1789,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   }
   if (plan->n_exprs != 0) {
     if (reserved) {  // the step proper runs on the lowered plan: reserve for that
+      route_note("k_project");
       mi355q_plan lp;
       if (int32_t e = lower_exprs(*plan, &lp, nullptr)) return e;
       return execute_impl(&lp, in, &o, out, report, nullptr, reserved);
@@ -1709,7 +1816,10 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     pr.output_columnar_hint = MI355Q_OUTPUT_ROWWISE_COLUMNAR_DECISIONS;
     mi355q_exec_options orw = o;
     orw.out_buffer = nullptr;
-    if (reserved) return execute_impl(&pr, in, &orw, out, report, nullptr, reserved);
+    if (reserved) {
+      route_note("row-wise twin + k_rows_to_columns");
+      return execute_impl(&pr, in, &orw, out, report, nullptr, reserved);
+    }
     RowTwin t;
     if (int32_t e = mi355q_execute(&pr, in, &orw, &t.tw, report)) return e;
     const mi355q_qmd& qr = t.tw->qmd;
@@ -1739,7 +1849,10 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     if (q8.slot_width != 8 || q8.entry_count != q.entry_count || q8.key_bytes != q.key_bytes ||
         q8.slot_count != q.slot_count)
       return MI355Q_ERR_UNSUPPORTED;
-    if (reserved) return execute_impl(&p8, in, &o, out, report, nullptr, reserved);
+    if (reserved) {
+      route_note("8-byte-slot twin + k_narrow_slots");
+      return execute_impl(&p8, in, &o, out, report, nullptr, reserved);
+    }
     DeviceCtx& ctx = ctx_of(in->device_id);
     std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
     const int64_t need = q8.entry_count * (int64_t)q8.row_size;
@@ -1793,17 +1906,21 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     FragView fvh{nullptr, nullptr, in->col_buffers, in->num_rows, in->n_frags, plan->n_cols, tr, mr};
     lds_direct = lds_groupby_eligible(d, fvh);
   }
-  if (!o.force_generic && in->n_frags > 0 && !reserved && !lds_direct) {
-    const int32_t e = execute_packed_multi(plan, in, o, q, d, n_cus, out, report);
+  if (!o.force_generic && in->n_frags > 0 && !lds_direct) {
+    const size_t mark = t_route ? t_route->size() : 0;
+    const int32_t e = execute_packed_multi(plan, in, o, q, d, n_cus, out, report, reserved);
     if (e != kNotTaken) return e;
+    if (t_route) t_route->resize(mark);
     *out = nullptr;
   }
 
-  if (!o.force_generic && in->n_frags > 0 && !reserved && !lds_direct && o.kernel_variant != 1 && d.n_group >= 1) {
+  if (!o.force_generic && in->n_frags > 0 && !lds_direct && o.kernel_variant != 1 && d.n_group >= 1) {
     // several value columns over a large input, and the LDS group-by is not going to take the step (table too large,
     // a forced variant, or its attempts already failed): one run per value column, zipped
-    const int32_t e = execute_multi_value(plan, in, o, q, d, out, report);
+    const size_t mark = t_route ? t_route->size() : 0;
+    const int32_t e = execute_multi_value(plan, in, o, q, d, out, report, reserved);
     if (e != kNotTaken && e != MI355Q_ERR_UNSUPPORTED) return e;
+    if (t_route) t_route->resize(mark);
     *out = nullptr;
   }
 
@@ -2026,7 +2143,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
         kind = K_JOIN_SUM;
         break;
       }
-      if (scratch_bytes <= ctx.scratch_bytes) break;
+      if (scratch_bytes <= ctx.scratch_bytes || t_plan_only) break;
       if (ctx.scratch) (void)hipFree(ctx.scratch);
       ctx.scratch = nullptr;
       ctx.scratch_bytes = 0;
@@ -2046,8 +2163,21 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   }
 
   tr.mark("scratch allocated");
-  if (reserved) {  // mi355q_reserve_workspace: nothing is launched
-    *reserved = ctx.scratch_bytes;
+  if (reserved) {  // mi355q_reserve_workspace / mi355q_explain: nothing is launched
+    if (t_route) {
+      char note[96];
+      const char* name = kind == K_SCAN_COUNT ? "k_scan_count" : kind == K_SCAN_AGG ? "k_scan_agg"
+                         : kind == K_PERFECT_LDS ? "k_perfect_lds" : kind == K_LDS_GROUPBY ? "k_groupby_lds"
+                         : kind == K_JOIN_SUM ? "k_join_sum" : kind == K_JOIN_PART ? "k_part_scatter + k_part_join"
+                         : kind == K_JOIN_PROBE ? "k_part_scatter + k_part_probe"
+                         : kind == K_BASELINE_FAST
+                             ? (nf > 0 && baseline_fast_variant(d, fv, o.kernel_variant, n_cus) == 2 ? "k_part_scatter + k_part_aggregate"
+                                                                                                      : "k_baseline_direct")
+                             : "k_generic";
+      std::snprintf(note, sizeof(note), "%s", name);
+      route_note(note);
+    }
+    *reserved = t_plan_only ? scratch_bytes : ctx.scratch_bytes;
     return MI355Q_OK;
   }
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));

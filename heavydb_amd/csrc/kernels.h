@@ -93,6 +93,9 @@ struct PackSpec {
   // NULL keys translated to null_key first, exactly as the row function computes it
   int32_t mode;  // 0 bit-packed (baseline), 1 entry index into a baseline temp table, 2 entry index
                  // into an index-aligned (perfect) temp table
+  int32_t raw_f32;  // mode 0, ONE FLOAT key: the "packed" key is the bit pattern of the double the key widens to — what
+                    // the table stores for a FLOAT key anyway (castToTypeIn(group_key, 64), IRCodegen.cpp:1505-1507) —
+                    // so the partitioned family, which reads 8-byte keys, takes the step
   int32_t tmp_idx_target;  // mode 2: emptiness of a keyless temp row = slot tmp_idx_target == tmp_init
   int64_t tmp_init;
   int32_t translate[MI355Q_MAX_GROUP_COLS];

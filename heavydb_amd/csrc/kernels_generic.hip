@@ -589,6 +589,10 @@ __global__ __launch_bounds__(kBlock) void k_pack_keys(PackSpec ps, const int8_t*
     int64_t* dst = packed[f];
     const int64_t n = num_rows[f];
     for (int64_t pos = gtid; pos < n; pos += gsize) {
+      if (ps.raw_f32) {  // one FLOAT key: widened, as the table stores it (NULL = FLT_MIN widens like any value)
+        __builtin_nontemporal_store(dbl_bits((double)*(const float*)(fc[ps.cols[0]] + pos * 4)), dst + pos);
+        continue;
+      }
       uint64_t code = 0;
       for (int g = 0; g < ps.n; ++g) {
         int64_t k = decode_int(fc[ps.cols[g]], ps.types[g], pos);
@@ -627,7 +631,8 @@ __global__ __launch_bounds__(kBlock) void k_unpack_emit(PackSpec ps, DevPlan p, 
     if (src[0] == kEmptyKey64) continue;
     const uint64_t code = (uint64_t)src[0];
     int64_t keys[MI355Q_MAX_GROUP_COLS];
-    for (int g = 0; g < ps.n; ++g) {
+    if (ps.raw_f32) keys[0] = (int64_t)code;
+    for (int g = 0; g < ps.n && !ps.raw_f32; ++g) {
       const uint64_t c = (code >> ps.shift[g]) & ps.mask[g];
       keys[g] = (ps.nullable[g] && c == ps.card[g] - 1) ? int_null_of(ps.types[g]) : (int64_t)(c + (uint64_t)ps.min[g]);
     }

@@ -76,3 +76,34 @@ def test_windowed_baseline_gives_up_beyond_eight_windows(sim, oracle):
     case = flow._baseline_case(oracle, 30000, n_rows=90000)
     case.ra.max_groups_buffer_entry_guess = 65536
     flow._check(oracle, case)
+
+
+# ---- mi355q_explain: the route of every reference benchmark query at the benchmark's own sizes, without a GPU
+def _explain(name, n_rows):
+    from heavydb_amd.executor import Executor
+    names, descs, _ = flow.refbench.schema()
+    ra, _ = flow.refbench.build_unit(flow.QUERIES[name], names, descs, n_rows)
+    frag = flow.refbench.FRAGMENT_ROWS
+    rows = [frag] * (n_rows // frag) + ([n_rows % frag] if n_rows % frag else [])
+    return Executor(0).explain(ra, rows)
+
+
+@pytest.mark.parametrize("n_rows", [4 * 32_000_000, 1_000_000_000], ids=["128M", "1B"])
+@pytest.mark.parametrize("name", list(flow.QUERIES), ids=list(flow.QUERIES))
+def test_no_reference_benchmark_query_takes_the_row_kernel(sim, name, n_rows):
+    """none of the reference's 57 synthetic-benchmark steps may end up in k_generic at the sizes the
+    benchmark runs (4 x 32 M rows, and 1 B).  The planner is the product's own (api.cpp, plan.cpp, the eligibility rules
+    of kernels_fast.hip / kernels_lds.hip compiled for the host); only the partitioned family's rule is a stand-in."""
+    route = _explain(name, n_rows)
+    assert route and "k_generic" not in route, (name, route)
+
+
+def test_explain_names_the_stages_of_a_derived_route(sim):
+    r = _explain("BH005", 1_000_000_000)      # GROUP BY cast(x100k AS DOUBLE): projected key, 100 K groups
+    assert r.startswith("k_project") and "k_part_scatter" in r, r
+    r = _explain("PHS004", 1_000_000_000)     # 10 K-entry perfect hash, five aggregates: windows of the LDS group-by
+    assert r == "k_groupby_lds", r
+    r = _explain("NGA03", 1_000_000_000)
+    assert r == "k_scan_agg", r
+    r = _explain("MSPHS009", 1_000_000_000)   # x10m, two value columns: packed index, one run per value column
+    assert "k_zip_targets" in r and "k_part_scatter" in r, r
