@@ -425,6 +425,8 @@ static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void
   for (int i = 0; i < qmd->n_targets; ++i) d.targets[i].col = -1;
   if (device_buffer) {
     r->buf = (int64_t*)device_buffer;
+  } else if (t_plan_only) {
+    r->buf = (int64_t*)(uintptr_t)4096;  // mi355q_explain: nothing is launched, the table is never touched
   } else {
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, (size_t)r->bytes);

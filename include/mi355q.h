@@ -499,7 +499,7 @@ int32_t mi355q_reserve_workspace(const mi355q_plan* plan, const mi355q_inputs* i
  * ExecutionOptions::just_explain).  The route mi355q_execute would take for this plan over inputs of this shape, as a
  * " > "-separated chain of derived-plan stages and the kernel family that runs the step, e.g.
  *   "k_project > k_pack_keys (entry index, baseline temp) > k_part_scatter + k_part_aggregate > k_unpack_emit".
- * Nothing is launched, no workspace is allocated (the result table of the step is, briefly); `inputs` as for
+ * Nothing is launched and nothing is allocated; `inputs` as for
  * mi355q_reserve_workspace.  *scratch_bytes = the partition scratch the step would ask for.  The answer depends on the
  * input size (small inputs take the row kernel, large ones the partitioned / packed members) and on the device's CUs. */
 int32_t mi355q_explain(const mi355q_plan* plan, const mi355q_inputs* inputs, const mi355q_exec_options* opts,
