@@ -127,29 +127,27 @@ MQ_D void lds_update(char* rep, const LdsVal& v, uint32_t e, int64_t bits) {
 
 // find-or-insert in one replica's key array (linear probing from a multiplicative hash); kNoSlot when full
 constexpr uint32_t kNoSlot = 0xffffffffu;
-// (the TOP bits of the product, and the key's high half folded into its low half first: a DOUBLE key that holds a small
-// integer has 40 - 50 trailing zero bits, so bits 40 .. 51 of `key * odd` are all zero — the version that took those
-// bits sent every group of cast(x AS DOUBLE) to slot 0 and probed linearly from there: BH002 / BH003 ran 16 - 50 x
-// slower than the same shape on an integer key, profiles/r03_refbench_1b_call4.jsonl)
-MQ_D uint32_t lds_key_home(uint32_t H, int64_t key) {
-  uint64_t x = (uint64_t)key;
-  x ^= x >> 32;
-  x *= 0x9E3779B97F4A7C15ull;
-  x ^= x >> 29;
-  x *= 0xBF58476D1CE4E5B9ull;
-  const int lg = 31 - __builtin_clz(H | 1u);
-  return lg ? (uint32_t)(x >> (64 - lg)) & (H - 1) : 0u;
+// One 32-bit mix of the 8 key bytes serves both decisions: its TOP bits pick the window (mul-hi by T), its LOW bits the home
+// slot inside the window's key array.  Both halves of the key feed it (a DOUBLE key that holds a small integer has its
+// entropy in the HIGH word and 40 - 50 trailing zero bits: the first version hashed `key * odd >> 40` and sent every group
+// of cast(x AS DOUBLE) to slot 0 — BH002 / BH003 ran 16 - 50 x slower than the same shape on an integer key,
+// profiles/r03_refbench_1b_call4.jsonl; strided BIGINT keys have it in the low word), four 32-bit multiplies in all: the
+// 64-bit multiplies of the second version cost 12 quarter-rate instructions per row VISIT, and a row is visited once
+// per window (BH004, 8 windows: 12.8 ms per 128 M rows against 2.0 ms for the perfect-hash twin,
+// profiles/r03_lds_retry_chain_kernel_trace_call7.csv).
+MQ_D uint32_t lds_key_mix(int64_t key) {
+  const uint32_t lo = (uint32_t)(uint64_t)key, hi = (uint32_t)((uint64_t)key >> 32);
+  uint32_t h = (lo * 0x9E3779B1u) ^ (hi * 0x85EBCA77u);
+  h ^= h >> 15;
+  h *= 0x2C1B3C6Du;
+  h ^= h >> 12;
+  h *= 0x297A2D39u;
+  h ^= h >> 15;
+  return h;
 }
-// the window of a baseline key: other bits of the same kind of mix (independent of the slot a key takes inside its window)
-MQ_D uint32_t lds_key_window(uint32_t T, int64_t key) {
-  uint64_t x = (uint64_t)key;
-  x ^= x >> 31;
-  x *= 0xD6E8FEB86659FD93ull;
-  x ^= x >> 32;
-  return (uint32_t)(((x & 0xffffffffull) * T) >> 32);
-}
-MQ_D uint32_t lds_key_slot(int64_t* keys, uint32_t H, int64_t key) {
-  uint32_t s = lds_key_home(H, key);
+MQ_D uint32_t lds_mix_window(uint32_t T, uint32_t h) { return __umulhi(h, T); }
+MQ_D uint32_t lds_key_slot(int64_t* keys, uint32_t H, int64_t key, uint32_t h) {
+  uint32_t s = h & (H - 1);  // H is a power of two
   for (uint32_t trips = 0; trips < H; ++trips) {
     const int64_t k = *(volatile int64_t*)&keys[s];
     if (k == key) return s;
@@ -200,8 +198,10 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
       }
     }
   }
+  if (t == 0) *(uint32_t*)(smem + ((size_t)a.copy_bytes << a.copies_lg)) = 0u;
   __syncthreads();
   char* const my_rep = smem + (size_t)((uint32_t)t & (K - 1)) * a.copy_bytes;
+  volatile uint32_t* const s_full = (volatile uint32_t*)(smem + ((size_t)a.copy_bytes << a.copies_lg));  // behind the replicas
   bool bad = false, full = false;
 
   // one row whose quals passed: kv = the key columns' values (DOUBLE keys as their bit pattern), vv = the value columns'
@@ -210,10 +210,18 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
     if (a.baseline) {
       // a FLOAT key is the bit pattern of the double it widens to (castToTypeIn(group_key, 64), IRCodegen.cpp:1505-1507)
       const int64_t key = a.key_type[0] == MI355Q_FLOAT ? dbl_bits((double)bits_flt((int32_t)kv[0])) : kv[0];
-      if (T > 1 && lds_key_window(T, key) != win) return;
-      if (full) return;  // (this lane already knows the attempt is lost)
-      e = lds_key_slot((int64_t*)(my_rep + a.off_keys), ne, key);
+      const uint32_t h = lds_key_mix(key);
+      if (T > 1 && lds_mix_window(T, h) != win) return;
+      // the attempt is lost as soon as ONE lane of the workgroup finds a replica full: everybody else learns it from an
+      // LDS word instead of walking a full key array itself (one walk per lane and divergence group made a lost
+      // attempt cost 10 - 12 ms whatever the input size, profiles/r03_lds_retry_chain_kernel_trace_call7.csv)
+      if (full || *s_full) {
+        full = true;
+        return;
+      }
+      e = lds_key_slot((int64_t*)(my_rep + a.off_keys), ne, key, h);
       if (e == kNoSlot) {
+        *s_full = 1u;
         // published at once: a full replica costs every later row of its keys a walk over the whole key array, and
         // the other workgroups only stop when they see the flag (the version that raised it after the scan made a
         // lost attempt slower than a successful one: BH003, profiles/r03_refbench_cliffs_call5_kernel_stats.csv)
@@ -345,7 +353,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
       if (!rows) continue;
       uint32_t e0 = e;
       if (a.baseline) {
-        e0 = lds_key_slot((int64_t*)(rep0 + a.off_keys), ne, ((int64_t*)(rep + a.off_keys))[e]);
+        const int64_t fk = ((int64_t*)(rep + a.off_keys))[e];
+        e0 = lds_key_slot((int64_t*)(rep0 + a.off_keys), ne, fk, lds_key_mix(fk));
         if (e0 == kNoSlot) {
           atomicExch(d_err + 1, 1);
           continue;
@@ -597,7 +606,7 @@ hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out
                               hipStream_t s, LaunchStats* st) {
   LdsArgs a;
   if (!make_lds_args(p, fv, &a)) return hipErrorInvalidValue;
-  const size_t lds = (size_t)a.copy_bytes << a.copies_lg;
+  const size_t lds = ((size_t)a.copy_bytes << a.copies_lg) + 16;  // + the workgroup's "a replica is full" word
   int64_t want = (fv.total_rows / 4 + kLdsBlock - 1) / kLdsBlock;
   if (want < 1) want = 1;
   // windows: T workgroups (one per window) share a row stripe
