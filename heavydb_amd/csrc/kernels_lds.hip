@@ -221,11 +221,10 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
       }
       e = lds_key_slot((int64_t*)(my_rep + a.off_keys), ne, key, h);
       if (e == kNoSlot) {
-        *s_full = 1u;
-        // published at once: a full replica costs every later row of its keys a walk over the whole key array, and
-        // the other workgroups only stop when they see the flag (the version that raised it after the scan made a
-        // lost attempt slower than a successful one: BH003, profiles/r03_refbench_cliffs_call5_kernel_stats.csv)
-        atomicExch(d_err + 1, 1);
+        // published at once (the other workgroups stop when they see the flag), and ONCE per workgroup: 1 024 lanes x 256
+        // workgroups exchanging the same global word are 262 K serialised atomics, ~ 10 ns each — most of what a lost
+        // attempt used to cost (profiles/r03_lds_retry_chain_kernel_trace_call8.csv)
+        if (atomicExch((uint32_t*)s_full, 1u) == 0u) atomicExch(d_err + 1, 1);
         full = true;
         return;
       }
@@ -341,8 +340,11 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
     }
   }
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
-  if (full) atomicExch(d_err + 1, 1);  // more groups than a replica holds: the caller takes another family
+  // a lost attempt (this workgroup's, or another's) is neither folded nor flushed: the caller takes another member and
+  // initialises the table again
+  if (t == 0 && a.baseline && *(volatile int32_t*)(d_err + 1)) *s_full = 1u;
   __syncthreads();
+  if (*s_full) return;
 
   // ---- fold replicas 1 .. K-1 into replica 0
   char* const rep0 = smem;
@@ -355,8 +357,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
       if (a.baseline) {
         const int64_t fk = ((int64_t*)(rep + a.off_keys))[e];
         e0 = lds_key_slot((int64_t*)(rep0 + a.off_keys), ne, fk, lds_key_mix(fk));
-        if (e0 == kNoSlot) {
-          atomicExch(d_err + 1, 1);
+        if (e0 == kNoSlot) {  // the replicas together hold more groups than one does
+          if (atomicExch((uint32_t*)s_full, 1u) == 0u) atomicExch(d_err + 1, 1);
           continue;
         }
       }
@@ -382,6 +384,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
       }
     }
     __syncthreads();  // (baseline: inserts into replica 0 of one round must be visible to the next)
+    if (*s_full) return;
   }
 
   // ---- merge every live entry of replica 0 into the output table with the reduce rule

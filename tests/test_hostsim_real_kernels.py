@@ -107,3 +107,15 @@ def test_explain_names_the_stages_of_a_derived_route(sim):
     assert r == "k_scan_agg", r
     r = _explain("MSPHS009", 1_000_000_000)   # x10m, two value columns: packed index, one run per value column
     assert "k_zip_targets" in r and "k_part_scatter" in r, r
+
+
+@pytest.mark.parametrize("groups,n_rows", [(20, 5000), (200, 5000), (300, 2000), (1000, 20000), (3000, 20000), (20000, 60000)])
+def test_baseline_lds_chain_with_the_real_kernel(sim, oracle, groups, n_rows):
+    """small replicas -> the largest replica -> eight windows -> another family, each lost attempt abandoned without a fold or a
+    flush; (300 groups, 2 000 rows): every replica holds its share but their union does not fit replica 0 — the fold gives up"""
+    case = flow._baseline_case(oracle, groups, n_rows=n_rows)
+    case.ra.max_groups_buffer_entry_guess = max(4096, 4 * groups)
+    rs = flow._check(oracle, case)
+    assert rs is not None
+    if groups <= 3000:
+        assert rs.report.kernel_name.decode() == "k_groupby_lds", rs.report.kernel_name
