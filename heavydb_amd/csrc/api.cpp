@@ -2017,10 +2017,15 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   // joins that read the inner side / one-to-many tables / LEFT joins over a large outer table: the
   // payload probe (per-key aggregated payload of the perfect table in LDS).  The semi-join shapes
   // keep their 1-bit-per-key member above.
+  // The L2 members of that probe map workgroup b to XCD b % 8 and group b / 8 and walk the runs with stride
+  // gridDim / 8: they are planned and launched with a multiple of 8 workgroups, or not at all (found by the host
+  // simulation, which first ran them on "4 CUs": gridDim / 8 = 0 never advances — on the device a `tune_cus` below 8
+  // would have hung the GPU, and one that is not a multiple of 8 would have read some runs twice).
+  const int n_cus_probe = n_cus >= 8 ? (n_cus & ~7) : 0;
   if (!o.force_generic && nf > 0 && kind != K_JOIN_PART && o.kernel_variant != 1 && plan->join_table && !reserved &&
       d.join_col >= 0 && (o.kernel_variant == 3 || total_rows >= ((int64_t)16 << 20))) {
     int wcol = -1, l2 = 0;
-    if (join_probe_wants(d, fv, n_cus, &wcol, &l2)) {
+    if (n_cus_probe && join_probe_wants(d, fv, n_cus_probe, &wcol, &l2)) {
       mi355q_join_table* jt = const_cast<mi355q_join_table*>(plan->join_table);
       const void* inner = wcol >= 0 ? (const void*)d.inner_cols[wcol] : nullptr;
       std::lock_guard<std::mutex> pl(jt->pay_mu);
@@ -2088,7 +2093,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
         pay.inner_col = inner;
         pay.entries = entries;
         pay.has_nulls = l2 ? jt->pay16_has_nulls : jt->pay_has_nulls;
-        if (join_probe_supported(d, fv, pay, n_cus)) {
+        if (join_probe_supported(d, fv, pay, n_cus_probe)) {
           kind = K_JOIN_PROBE;
         } else {
           // the probe plan does not take this payload after all: entries x 16 B of device memory are not kept for a
@@ -2135,7 +2140,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     }
     for (;;) {
       scratch_bytes = kind == K_JOIN_PART    ? join_part_scratch_bytes(d, fv, n_cus, scratch_cap)
-                      : kind == K_JOIN_PROBE ? join_probe_scratch_bytes(d, fv, pay, n_cus, scratch_cap)
+                      : kind == K_JOIN_PROBE ? join_probe_scratch_bytes(d, fv, pay, n_cus_probe, scratch_cap)
                                              : baseline_fast_scratch_bytes(d, fv, o.kernel_variant, scratch_cap, n_cus);
       if (kind == K_JOIN_PROBE && scratch_bytes == 0) {  // no plan within this cap: the row kernel
         kind = join_sum_eligible(d, fv) ? K_JOIN_SUM : K_GENERIC;
@@ -2214,7 +2219,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
                                         s, &st));
         break;
       case K_JOIN_PROBE:
-        HIP_TRY(launch_join_probe(d, fv, pay, res->buf, d_err, ctx.scratch, ctx.scratch_bytes, scratch_cap, n_cus, s,
+        HIP_TRY(launch_join_probe(d, fv, pay, res->buf, d_err, ctx.scratch, ctx.scratch_bytes, scratch_cap, n_cus_probe, s,
                                   &st));
         break;
       default:

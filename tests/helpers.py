@@ -346,10 +346,11 @@ def hostsim_lib(real_fast: bool = False) -> str:
     kernel families replaced by row-function stand-ins (tests/hostsim/kernels_host.cpp).  Returns the path of the
     built library (same C ABI as libmi355q.so).
 
-    real_fast=True: a second library in which kernels_fast.hip and kernels_lds.hip are the REAL device sources, compiled
-    for the host (their blocks run as 1024 cooperative fibers): k_scan_count, k_scan_agg, k_perfect_lds(_prog),
-    k_baseline_direct, k_join_sum and k_groupby_lds execute their own code on the CPU.  Only the partitioned family
-    (kernels_part.hip: workgroups that wait for each other) and the sort keep their stand-ins."""
+    real_fast=True: a second library in which EVERY kernel file is the real device source compiled for the host (blocks
+    run as 1024 cooperative fibers): kernels_fast.hip, kernels_lds.hip, kernels_part.hip (the producer / flusher pipeline
+    of the scatter works because every polling loop of the device code sleeps, and s_sleep is a fiber yield here; waits
+    for OTHER workgroups are bounded on the device and simply expire here, blocks run one after the other) and
+    kernels_sort.hip (rocPRIM's radix sort replaced by a std::stable_sort stand-in, shim/rocprim)."""
     key = bool(real_fast)
     if _hostsim.get(key) is not None:
         return _hostsim[key]
@@ -360,12 +361,12 @@ def hostsim_lib(real_fast: bool = False) -> str:
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = "g++"
-    real_srcs = ["kernels_fast.hip", "kernels_lds.hip", "fast_common.h"] if real_fast else []
+    real_srcs = ["kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "fast_common.h"] if real_fast else []
     deps = [os.path.join(src_dir, f) for f in ("hip_host.cpp", "kernels_host.cpp", "shim/hip/hip_runtime.h",
                                                "shim/hip/hip_runtime_api.h")] + \
         [os.path.join(csrc, f) for f in ["api.cpp", "plan.cpp", "kernels_generic.hip", "kernels.h", "rowfunc.h",
                                          "dev_common.h", "plan.h", "expr.h"] + real_srcs] + \
-        [os.path.join(ROOT, "include", "mi355q.h")]
+        [os.path.join(ROOT, "include", "mi355q.h"), os.path.abspath(__file__)]   # (the build recipe patches the sources)
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(out_dir, exist_ok=True)
         import re
@@ -398,12 +399,31 @@ def hostsim_lib(real_fast: bool = False) -> str:
                 os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
         if real_fast:
             flags.append("-DHOSTSIM_REAL_FAST")
-            for name in ("kernels_fast.hip", "kernels_lds.hip"):
+            for name in ("kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip"):
                 with open(os.path.join(csrc, name)) as f:
                     src = f.read()
                 src, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char (\w+)\[\];",
                                  r"char* const \1 = (char*)hipsim::dynamic_shared();", src)
-                assert n >= 1 and "extern __shared__" not in src, name
+                assert "extern __shared__" not in src, name
+                if name == "kernels_part.hip":
+                    # the LDS-only barrier is an inline-asm s_barrier
+                    pat = 'asm volatile("s_waitcnt lgkmcnt(0)\\n\\ts_barrier" ::: "memory");'
+                    assert src.count(pat) == 1
+                    src = src.replace(pat, "__syncthreads();")
+                    # a wave runs in lockstep on the device; the fibers of a flusher wave meet before the line they
+                    # have just read is declared free
+                    pat = '      asm volatile("" ::: "memory");\n      if (need) {\n        my_fl[k] += 1;'
+                    assert src.count(pat) == 1
+                    src = src.replace(pat, "      hipsim::wave_sync();\n      if (need) {\n        my_fl[k] += 1;")
+                    # values every lane of a wave reads from LDS "at the same instant" are wave-uniform on the device; here
+                    # the fibers read at different times, so lane 0's reading is broadcast where control flow depends on it
+                    pat = "const bool all_done = lds_peek(done) == (uint32_t)kProdWaves;"
+                    assert src.count(pat) == 1
+                    src = src.replace(pat, "const bool all_done = __shfl((int)(lds_peek(done) == (uint32_t)kProdWaves), 0) != 0;")
+                    # lanes of one wave wait for the lane that fetches the next spill block: that lane must get to run
+                    pat = "if (w == kSpillBusy) continue;"
+                    assert src.count(pat) == 1
+                    src = src.replace(pat, "if (w == kSpillBusy) { hipsim::fiber_yield(); continue; }")
                 cpp = os.path.join(out_dir, name.replace(".hip", "_host.cpp"))
                 with open(cpp, "w") as f:
                     f.write(src)

@@ -8,6 +8,9 @@
 //            cooperative fibers (ucontext) that yield at a barrier — deterministic, no data races, atomics trivially
 //            atomic; per-wave (64 lanes) exchange buffers for shuffles / ballots, a dynamic LDS area
 #include <ucontext.h>
+#include <unistd.h>
+
+#include <csignal>
 
 #include <cctype>
 #include <chrono>
@@ -84,7 +87,9 @@ struct Sched {
   const std::function<void()>* body = nullptr;
   Idx block, grid_dim, block_dim;
   Barrier block_barrier, wave_barrier[kMaxThreads / kWave];
-  uint64_t xchg[kMaxThreads];
+  uint64_t xchg[kMaxThreads], recv[kMaxThreads];
+  unsigned char state[kMaxThreads];   // HOSTSIM_WATCHDOG: where each fiber waits (0 runs, 1 block barrier, 2 wave barrier, 3 yield, 4 done)
+  const char* kernel_name = "";
   unsigned long long ballot[kMaxThreads / kWave];
   std::vector<char> dyn;
   bool in_fibers = false;
@@ -126,8 +131,34 @@ void wait_at(Barrier& b) {
     ++b.gen;
     return;
   }
+  Sched& s = sched();
+  const int id = s.cur;
+  s.state[id] = &b == &s.block_barrier ? 1 : 2;
   const uint64_t g = b.gen;
   while (b.gen == g) yield();
+  s.state[id] = 0;
+}
+
+// HOSTSIM_WATCHDOG=<seconds>: a launch that is still running then reports where its fibers wait, wave by wave, and aborts
+void watchdog(int) {
+  Sched& s = sched();
+  char buf[256];
+  int n = std::snprintf(buf, sizeof(buf), "[hipsim] watchdog: %s block %u, %d threads, current fiber %d\n", s.kernel_name, s.block.x, s.n, s.cur);
+  (void)!write(2, buf, (size_t)n);
+  for (int w = 0; w * kWave < s.n; ++w) {
+    int c[5] = {0, 0, 0, 0, 0};
+    for (int l = 0; l < kWave && w * kWave + l < s.n; ++l) ++c[s.state[w * kWave + l] > 4 ? 0 : s.state[w * kWave + l]];
+    n = std::snprintf(buf, sizeof(buf), "  wave %2d: running %d, block barrier %d, wave barrier %d (arrived %d of %d), yielding %d, done %d\n", w,
+                      c[0], c[1], c[2], s.wave_barrier[w].arrived, s.wave_barrier[w].expected, c[3], c[4]);
+    (void)!write(2, buf, (size_t)n);
+    if (c[4] && c[4] < kWave) {   // which lanes have left
+      unsigned long long m = 0;
+      for (int l = 0; l < kWave && w * kWave + l < s.n; ++l) m |= (unsigned long long)(s.state[w * kWave + l] == 4) << l;
+      n = std::snprintf(buf, sizeof(buf), "           lanes done: %016llx\n", m);
+      (void)!write(2, buf, (size_t)n);
+    }
+  }
+  _exit(97);
 }
 
 void run_block_fibers(Sched& s, int n_threads) {
@@ -141,7 +172,9 @@ void run_block_fibers(Sched& s, int n_threads) {
     s.ctx[t].uc_link = &s.main_ctx;
     makecontext(&s.ctx[t], trampoline, 0);
     s.finished[t] = false;
+    s.state[t] = 0;
   }
+  s.n = n_threads;
   std::vector<char> gone((size_t)n_threads, 0);
   int alive = n_threads;
   s.in_fibers = true;
@@ -152,6 +185,7 @@ void run_block_fibers(Sched& s, int n_threads) {
       set_ids(s, t);
       swapcontext(&s.main_ctx, &s.ctx[t]);
       if (s.finished[t]) {
+        s.state[t] = 4;
         gone[t] = 1;
         --alive;
         s.block_barrier.drop();
@@ -179,6 +213,14 @@ void launch(const char* name, dim3 grid, dim3 block, size_t shmem, const std::fu
   s.grid_dim = Idx{grid.x, grid.y, grid.z};
   if (s.dyn.size() < shmem + 64) s.dyn.resize(shmem + 64);
   const bool fibers = needs_fibers(name);
+  static const bool trace = std::getenv("HOSTSIM_TRACE") != nullptr;   // (test infrastructure: which launch is running)
+  s.kernel_name = name;
+  static const int wd = std::getenv("HOSTSIM_WATCHDOG") ? std::atoi(std::getenv("HOSTSIM_WATCHDOG")) : 0;
+  if (wd > 0) {
+    std::signal(SIGALRM, watchdog);
+    alarm((unsigned)wd);
+  }
+  if (trace) std::fprintf(stderr, "[hipsim] %s grid %u block %u lds %zu %s\n", name, grid.x, block.x, shmem, fibers ? "fibers" : "plain");
   for (unsigned z = 0; z < grid.z; ++z)
     for (unsigned y = 0; y < grid.y; ++y)
       for (unsigned x = 0; x < grid.x; ++x) {
@@ -193,6 +235,7 @@ void launch(const char* name, dim3 grid, dim3 block, size_t shmem, const std::fu
           }
         }
       }
+  if (wd > 0) alarm(0);
 }
 
 static void not_in_fibers(const char* what) {
@@ -231,6 +274,51 @@ unsigned long long wave_ballot(bool pred) {
   wait_at(s.wave_barrier[wave]);
   return r;
 }
+
+uint64_t wave_exchange_abs(uint64_t v, int src_lane) {
+  Sched& s = sched();
+  if (!s.in_fibers) not_in_fibers("a wave shuffle");
+  const int tid = flat_tid(), wave = tid / kWave;
+  const int n = (int)(s.block_dim.x * s.block_dim.y * s.block_dim.z);
+  const int wave_size = std::min(kWave, n - wave * kWave);
+  s.xchg[tid] = v;
+  wait_at(s.wave_barrier[wave]);
+  const uint64_t r = (src_lane >= 0 && src_lane < wave_size) ? s.xchg[wave * kWave + src_lane] : v;
+  wait_at(s.wave_barrier[wave]);
+  return r;
+}
+
+uint64_t wave_permute_push(int dst_lane, uint64_t v) {
+  Sched& s = sched();
+  if (!s.in_fibers) not_in_fibers("ds_permute");
+  const int tid = flat_tid(), wave = tid / kWave;
+  const int n = (int)(s.block_dim.x * s.block_dim.y * s.block_dim.z);
+  const int wave_size = std::min(kWave, n - wave * kWave);
+  s.recv[tid] = 0;
+  wait_at(s.wave_barrier[wave]);
+  if (dst_lane >= 0 && dst_lane < wave_size) s.recv[wave * kWave + dst_lane] = v;
+  wait_at(s.wave_barrier[wave]);
+  const uint64_t r = s.recv[tid];
+  wait_at(s.wave_barrier[wave]);
+  return r;
+}
+
+void wave_sync() {
+  Sched& s = sched();
+  if (!s.in_fibers) return;
+  wait_at(s.wave_barrier[flat_tid() / kWave]);
+}
+
+void fiber_yield() {
+  Sched& s = sched();
+  if (!s.in_fibers) return;
+  const int id = s.cur;
+  s.state[id] = 3;
+  yield();
+  s.state[id] = 0;
+}
+
+int lane_id() { return flat_tid() % kWave; }
 
 void* dynamic_shared() {
   Sched& s = sched();
@@ -352,7 +440,7 @@ hipError_t hipSetDevice(int d) {
   return hipSuccess;
 }
 hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) {
-  *v = 4;  // "compute units": keeps the grids of the simulated launches small
+  *v = 8;  // "compute units": keeps the grids of the simulated launches small (8: the L2 probes spread over 8 XCDs)
   return hipSuccess;
 }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
@@ -360,7 +448,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
   std::snprintf(p->name, sizeof(p->name), "hostsim");
   std::snprintf(p->gcnArchName, sizeof(p->gcnArchName), "x86-64");
   p->totalGlobalMem = kTotal;
-  p->multiProcessorCount = 4;
+  p->multiProcessorCount = 8;
   p->warpSize = 64;
   return hipSuccess;
 }

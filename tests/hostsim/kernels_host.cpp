@@ -42,6 +42,7 @@ void hostsim_configure(uint32_t routes, int32_t lds_small_groups, int32_t lds_la
 int32_t hostsim_launches(int32_t family) { return family >= 0 && family < 16 ? g_cfg.launches[family] : -1; }
 }
 
+#ifndef HOSTSIM_REAL_FAST   // (HOSTSIM_REAL_FAST: the real kernels_fast / _lds / _part / _sort .hip are compiled in instead)
 namespace mq {
 
 namespace {
@@ -127,7 +128,6 @@ int64_t live_entries(const DevPlan& p, const int64_t* out) {
 
 }  // namespace
 
-#ifndef HOSTSIM_REAL_FAST   // (HOSTSIM_REAL_FAST: the real kernels_fast.hip / kernels_lds.hip are compiled in)
 // ---- non-grouped scans
 bool scan_count_eligible(const DevPlan& p, const FragView&) {
   return on(F_SCAN_COUNT) && p.desc_type == MI355Q_NON_GROUPED_AGGREGATE && p.join_col < 0 && p.n_targets == 1 &&
@@ -199,13 +199,11 @@ bool baseline_fast_eligible(const DevPlan& p, const FragView&) {
   if (p.group_type != MI355Q_INT64 && p.group_type != MI355Q_DOUBLE) return false;
   return one_value_shape(p);
 }
-#endif
 bool part_supported(const DevPlan& p, const FragView& fv, int) { return on(F_BASELINE_PART) && baseline_fast_eligible(p, fv); }
 int64_t part_scratch_bytes(const DevPlan&, const FragView& fv, int, int64_t cap_bytes) {
   const int64_t want = fv.total_rows * 16 + 4096;
   return cap_bytes > 0 ? std::min(want, cap_bytes) : want;
 }
-#ifndef HOSTSIM_REAL_FAST
 int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested, int n_cus) {
   if (requested == 1) return 1;
   const bool can_part = part_supported(p, fv, n_cus);
@@ -216,7 +214,6 @@ int baseline_fast_variant(const DevPlan& p, const FragView& fv, int requested, i
 int64_t baseline_fast_scratch_bytes(const DevPlan& p, const FragView& fv, int variant, int64_t cap_bytes, int n_cus) {
   return baseline_fast_variant(p, fv, variant, n_cus) == 1 ? 0 : part_scratch_bytes(p, fv, n_cus, cap_bytes);
 }
-#endif
 hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, void* scratch,
                                        int64_t scratch_bytes, int64_t, int, hipStream_t, LaunchStats* st) {
   if (!scratch || scratch_bytes < 4096) return hipErrorInvalidValue;   // the caller sized and passed the workspace
@@ -234,7 +231,6 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   }
   return hipSuccess;
 }
-#ifndef HOSTSIM_REAL_FAST
 hipError_t launch_baseline_fast(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, void* scratch,
                                 int64_t scratch_bytes, int64_t cap_bytes, int variant, int n_cus, hipStream_t s,
                                 LaunchStats* st) {
@@ -254,7 +250,6 @@ hipError_t launch_join_sum(const DevPlan& p, const FragView& fv, int64_t* out, i
   finish(p, fv, out, nullptr, st, "k_join_sum", 0, F_JOIN_SUM);
   return hipSuccess;
 }
-#endif
 bool join_part_supported(const DevPlan&, const FragView&, int) { return false; }
 int64_t join_part_scratch_bytes(const DevPlan&, const FragView&, int, int64_t) { return 0; }
 hipError_t launch_join_partitioned(const DevPlan&, const FragView&, int64_t*, int32_t*, void*, int64_t, int64_t, int,
@@ -282,3 +277,4 @@ hipError_t launch_sort(const DevPlan&, int, const SortOrderEntry*, int, const in
                        int64_t*, hipStream_t) { return hipErrorNotSupported; }
 
 }  // namespace mq
+#endif  // HOSTSIM_REAL_FAST

@@ -30,6 +30,11 @@ void launch(const char* kernel_name, dim3 grid, dim3 block, size_t shmem, const 
 void sync_threads();
 uint64_t wave_exchange(uint64_t v, int src_lane_delta);   // value of lane (lane + delta), own value past the end
 unsigned long long wave_ballot(bool pred);
+uint64_t wave_exchange_abs(uint64_t v, int src_lane);     // value of lane src_lane (own value when out of range)
+uint64_t wave_permute_push(int dst_lane, uint64_t v);     // ds_permute: lane dst_lane receives v; 0 where nobody wrote
+void wave_sync();                                         // all live lanes of the wave (lockstep points of the device code)
+void fiber_yield();                                       // lets the other fibers of the block run (s_sleep in a polling loop)
+int lane_id();
 void* dynamic_shared();
 }  // namespace hipsim
 
@@ -58,6 +63,34 @@ inline T __shfl_down(T v, unsigned delta, int width = 64) {
   return out;
 }
 inline unsigned long long __ballot(int pred) { return hipsim::wave_ballot(pred != 0); }
+inline int __any(int pred) { return hipsim::wave_ballot(pred != 0) != 0ull; }
+template <typename T>
+inline T __shfl(T v, int src_lane, int width = 64) {
+  (void)width;
+  uint64_t bits = 0;
+  static_assert(sizeof(T) <= 8, "shuffle of at most 8 bytes");
+  std::memcpy(&bits, &v, sizeof(T));
+  bits = hipsim::wave_exchange_abs(bits, src_lane);
+  T out;
+  std::memcpy(&out, &bits, sizeof(T));
+  return out;
+}
+// polling loops of the device code sleep between two looks: here the other fibers of the block get to run
+inline void __builtin_amdgcn_s_sleep(int) { hipsim::fiber_yield(); }
+// a wave runs in lockstep on the device; where the code relies on it, the fibers of a wave meet
+inline void __builtin_amdgcn_wave_barrier() { hipsim::wave_sync(); }
+inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned v) {
+  const int l = hipsim::lane_id();
+  return v + (unsigned)__builtin_popcount(mask & (l >= 32 ? 0xffffffffu : ((1u << l) - 1u)));
+}
+inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned v) {
+  const int l = hipsim::lane_id();
+  return v + (l > 32 ? (unsigned)__builtin_popcount(mask & ((1u << (l - 32)) - 1u)) : 0u);
+}
+inline int __builtin_amdgcn_ds_permute(int addr, int val) {
+  return (int)(uint32_t)hipsim::wave_permute_push((addr >> 2) & 63, (uint64_t)(uint32_t)val);
+}
+inline long long clock64() { return (long long)__builtin_ia32_rdtsc(); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
@@ -85,6 +118,8 @@ inline unsigned atomicAdd(unsigned* p, unsigned v) { return hipsim_fetch_add(p, 
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return hipsim_fetch_add(p, v); }
 inline float atomicAdd(float* p, float v) { return hipsim_fetch_add(p, v); }
 inline double atomicAdd(double* p, double v) { return hipsim_fetch_add(p, v); }
+inline unsigned atomicSub(unsigned* p, unsigned v) { return __atomic_fetch_sub(p, v, __ATOMIC_SEQ_CST); }
+inline int atomicSub(int* p, int v) { return __atomic_fetch_sub(p, v, __ATOMIC_SEQ_CST); }
 template <typename T>
 inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 template <typename T>

@@ -1,10 +1,13 @@
-"""The REAL fast kernels on the CPU: kernels_fast.hip (k_scan_count, k_scan_agg, k_perfect_lds, k_perfect_lds_prog,
-k_baseline_direct, k_join_sum) and kernels_lds.hip (k_groupby_lds) compiled for the host against the stand-in HIP runtime
-of tests/hostsim — a workgroup runs as 1024 cooperative fibers with working barriers, shuffles, LDS and atomics — behind
-the real api.cpp / plan.cpp.  Results are held against the oracle exactly as the gpu tests do.  This is a functional check
+"""The REAL kernels on the CPU: kernels_fast.hip (k_scan_count, k_scan_agg, k_perfect_lds, k_perfect_lds_prog,
+k_baseline_direct, k_join_sum), kernels_lds.hip (k_groupby_lds), kernels_part.hip (k_part_scatter / k_part_aggregate /
+k_spill_merge, the radix and payload join probes, the slice merge) and kernels_sort.hip (top-k selection; the full sort
+with a stand-in for rocPRIM's radix sort) compiled for the host against the stand-in HIP runtime of tests/hostsim — a
+workgroup runs as 1024 cooperative fibers with working barriers, shuffles, ballots, ds_permute, LDS and atomics; the
+polling loops of the scatter's producer / flusher pipeline sleep on the device, and s_sleep is a fiber yield here —
+behind the real api.cpp / plan.cpp.  Results are held against the oracle exactly as the gpu tests do.  This is a functional check
 of the device code itself (index arithmetic, tails, NULL handling, replica folds, flush rules) on a machine without a GPU; it says
-nothing about timing or about races (fibers of a block run one after the other between barriers).  Only the partitioned
-family (kernels_part.hip) and the sort keep their stand-ins here."""
+nothing about timing or about races (fibers of a block run one after the other between barriers, blocks one after the
+other: waits for another workgroup — pair rendezvous, probe pacing — are bounded on the device and expire here)."""
 import ctypes as C
 
 import pytest
@@ -16,7 +19,7 @@ from tests import test_hostsim_flow as flow
 
 CASES = cases_mod.build_cases()
 REAL_FAMILIES = {"k_scan_count", "k_scan_agg", "k_perfect_lds", "k_perfect_lds_prog", "k_baseline_direct", "k_join_sum",
-                 "k_groupby_lds"}
+                 "k_groupby_lds", "k_part_scatter"}
 
 
 @pytest.fixture(scope="module")
@@ -35,7 +38,7 @@ def sim():
 SEEN = set()
 
 
-@pytest.mark.parametrize("variant", [0, 1], ids=["planned", "direct_members"])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3], ids=["planned", "direct_members", "partitioned_members", "payload_probe"])
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
 def test_case_matrix_through_the_real_fast_kernels(sim, oracle, case, variant):
     rs = flow._check(oracle, case, kernel_variant=variant)
