@@ -263,7 +263,7 @@ def test_columnar_row_logic_fuzz(oracle):
     rng = np.random.default_rng(7117)
     emu = emu_lib()
     ran = refused = errors = 0
-    for i in range(300):
+    for i in range(100):   # (tools/soak_fuzz.py runs thousands with fresh seeds; the suite keeps a sample)
         n_rows = int(rng.integers(1, 400))
         descs, cols = _fuzz_table(rng, n_rows)
         ra = _fuzz_row_plan(rng, descs)
@@ -288,7 +288,7 @@ def test_columnar_row_logic_fuzz(oracle):
         qr = rowwise_qmd(q)
         compare_buffers(qr, columnar_to_rows(q, want), columnar_to_rows(q, got), 1e-9)
         ran += 1
-    assert ran > 180, (ran, refused, errors)
+    assert ran > 55, (ran, refused, errors)
 
 
 def test_columnar_join_fuzz(oracle):

@@ -209,7 +209,7 @@ def test_row_logic_agrees_on_random_plans(oracle):
     rng = np.random.default_rng(77)
     emu = emu_lib()
     ran = errors = 0
-    for i in range(400):
+    for i in range(200):   # (tools/soak_fuzz.py runs thousands with fresh seeds; the suite keeps a sample)
         n_rows = int(rng.integers(1, 400))
         descs, cols = _fuzz_table(rng, n_rows)
         ra = _fuzz_row_plan(rng, descs)
@@ -233,7 +233,7 @@ def test_row_logic_agrees_on_random_plans(oracle):
         qmd_equal(q, eq)
         compare_buffers(q, want, got, 1e-9)
         ran += 1
-    assert ran > 250, (ran, errors)
+    assert ran > 120, (ran, errors)
 
 
 def _fuzz_join(rng):
@@ -328,7 +328,7 @@ def test_reduce_agrees_on_random_plans(oracle):
     rng = np.random.default_rng(31)
     emu = emu_lib()
     ran = 0
-    for i in range(250):
+    for i in range(120):
         n_rows = int(rng.integers(2, 300))
         descs, cols = _fuzz_table(rng, n_rows)
         int_cols = [j for j, d in enumerate(descs) if d.type not in (capi.DOUBLE, capi.FLOAT)]
@@ -370,7 +370,7 @@ def test_reduce_agrees_on_random_plans(oracle):
         assert emu.emu_reduce(C.byref(q), mine.ctypes.data, bb.ctypes.data, q.entry_count) == 0
         compare_buffers(q, red, mine, 1e-12)
         ran += 1
-    assert ran > 150, ran
+    assert ran > 70, ran
 
 
 def test_boundary_values_agree(oracle):

@@ -48,10 +48,12 @@ def schema(card_cap: int = 0):
         descs.append(InputColDescriptor(capi.INT32, True, ExpressionRange(True, 1, n, False)))
         gens.append((capi.GEN_I32_MOD, 0xBE9C0000 + i, n, 1, 0, 0.0))
     for i, (nm, n) in enumerate(BIG_COLS):
-        n = cap(n)
         names.append(nm)
+        # a capped table draws fewer distinct values but keeps the column's declared range (chunk metadata min / max of the
+        # real table): the stride-10 000 columns must stay baseline-hash keys, as in the benchmark — a capped RANGE of
+        # 6 - 30 M would turn them into perfect-hash tables of that many entries
         descs.append(InputColDescriptor(capi.INT64, True, ExpressionRange(True, STEP, n * STEP, False)))
-        gens.append((capi.GEN_I64_MOD_MUL, 0xBE9C0100 + i, n, STEP, STEP, 0.0))
+        gens.append((capi.GEN_I64_MOD_MUL, 0xBE9C0100 + i, cap(n), STEP, STEP, 0.0))
     return names, descs, gens
 
 
