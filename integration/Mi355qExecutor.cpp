@@ -272,6 +272,31 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
   return p;
 }
 
+std::string explain_query_mi355q(const RelAlgExecutionUnit& ra, const std::vector<InputTableInfo>& query_infos,
+                                 const Executor* executor, int device_id, size_t max_groups_buffer_entry_guess,
+                                 const mi355q_join_table* join_table, int64_t inner_num_rows, bool output_columnar_hint) {
+  const mi355q_plan plan = to_plan(ra, query_infos, executor, join_table, max_groups_buffer_entry_guess, output_columnar_hint);
+  // only the SHAPE of the input decides the route: one entry per fragment of the outer table, no chunk pointers
+  std::vector<int64_t> rows;
+  if (!query_infos.empty()) {
+#ifdef MI355Q_GLUE_MOCK_HEADERS
+    rows = query_infos.front().fragment_rows;
+    if (rows.empty()) rows.push_back(query_infos.front().num_tuples);
+#else
+    for (const auto& frag : query_infos.front().info.fragments) rows.push_back((int64_t)frag.getNumTuples());
+#endif
+  }
+  mi355q_inputs in{};
+  in.device_id = device_id;
+  in.n_frags = (int32_t)rows.size();
+  in.num_rows = rows.data();
+  in.inner_num_rows = inner_num_rows;
+  char route[512] = {0};
+  int64_t scratch = 0;
+  check(mi355q_explain(&plan, &in, nullptr, route, (int64_t)sizeof(route), &scratch));
+  return std::string("mi355q route: ") + route + " (partition scratch " + std::to_string(scratch >> 20) + " MiB)";
+}
+
 ResultSetPtr run_query_mi355q(const RelAlgExecutionUnit& ra, const FetchResult& fetch_result,
                               const std::vector<InputTableInfo>& query_infos,
                               const QueryMemoryDescriptor& query_mem_desc, Executor* executor, int device_id,

@@ -1,6 +1,8 @@
 // Mi355qExecutor.h — the HeavyDB-side binding of libmi355q.so (what would live in QueryEngine/).
 #pragma once
 
+#include <string>
+
 #include "mi355q.h"
 
 #ifdef MI355Q_GLUE_MOCK_HEADERS
@@ -31,5 +33,13 @@ ResultSetPtr run_query_mi355q(const RelAlgExecutionUnit& ra, const FetchResult& 
                               const QueryMemoryDescriptor& query_mem_desc, Executor* executor, int device_id,
                               size_t max_groups_buffer_entry_guess, const mi355q_join_table* join_table,
                               const std::vector<const int8_t*>& inner_col_buffers, int64_t inner_num_rows);
+
+// ExecutionOptions::just_explain (Execute.cpp: executeWorkUnit returns the generated IR as an "explanation" ResultSet,
+// RelAlgExecutor.cpp:executeRelAlgQuery): a fixed family has no IR to show, so the explanation of a step is the ROUTE —
+// the derived-plan stages and the kernel family mi355q_execute would take for this plan over fragments of these sizes
+// (mi355q_explain: nothing is launched, nothing allocated).
+std::string explain_query_mi355q(const RelAlgExecutionUnit& ra, const std::vector<InputTableInfo>& query_infos,
+                                 const Executor* executor, int device_id, size_t max_groups_buffer_entry_guess,
+                                 const mi355q_join_table* join_table, int64_t inner_num_rows, bool output_columnar_hint);
 
 }  // namespace mi355q_glue

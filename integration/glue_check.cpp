@@ -270,6 +270,10 @@ int main() {
     const FetchResult fr = fetch(t, {0, 1, 2}, &frag_rows);
     mi355q_qmd q;
     const std::vector<int64_t> want = oracle_table(hp, t, {0, 1, 2}, frag_rows, nullptr, {}, 0, &q);
+    // what just_explain would show for this step
+    const std::string route = mi355q_glue::explain_query_mi355q(ra, query_infos, &executor, 0, 2 * n_keys, nullptr, 0, false);
+    std::printf("  %s\n", route.c_str());
+    expect(route.find("k_generic") == std::string::npos || N < (8 << 20), "the headline shape does not plan the row kernel");
     const ResultSetPtr rs = mi355q_glue::run_query_mi355q(ra, fr, query_infos, qmd_of(q), &executor, 0, 2 * n_keys, nullptr, {}, 0);
     expect(q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && q.entry_count == 2 * n_keys && q.row_size == 32, "layout");
     compare_tables(q, want.data(), (const int64_t*)const_cast<ResultSetStorage*>(rs->getStorage())->getUnderlyingBuffer(), {false, true, false});

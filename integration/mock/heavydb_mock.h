@@ -231,6 +231,7 @@ class ExpressionRange {
 struct InputTableInfo {
   shared::TableKey table_key;
   int64_t num_tuples;  // info.getNumTuples()
+  std::vector<int64_t> fragment_rows;  // info.fragments[i].getNumTuples() (Fragmenter_Namespace::TableInfo); may be empty here
 };
 
 class Executor;
