@@ -220,7 +220,35 @@ def _table(shape, seed=7):
     return ra, frags
 
 
-def _worker(rank, world, port, shape, errq):
+def _bind_host_simulation(torch):
+    """This process's `device` is the host simulation of the library (tests/hostsim, every kernel file compiled for the
+    CPU): HipShard — the ShardOps the GPU path uses — then runs the product's own mi355q_execute / mi355q_shard_* /
+    slice-merge kernels on tensors that are plain CPU tensors, and gloo moves them."""
+    from heavydb_amd import capi
+    from tests.helpers import hostsim_lib
+    capi._lib = capi.load_library(hostsim_lib(real_fast=True))
+    real = {n: getattr(torch, n) for n in ("zeros", "empty", "full", "arange")}
+    strip = lambda f: (lambda *a, **k: f(*a, **{x: y for x, y in k.items() if x != "device" or not str(y).startswith("cuda")}))  # noqa: E731
+    for n, f in real.items():
+        setattr(torch, n, strip(f))
+
+    class _Stream:
+        def synchronize(self):
+            pass
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.synchronize = lambda *a, **k: None
+
+
+def _aligned_copy(a):
+    a = np.ascontiguousarray(a)
+    raw = np.empty(a.nbytes + 64, np.uint8)
+    off = (-raw.ctypes.data) % 64
+    out = raw[off:off + a.nbytes].view(a.dtype)
+    out[...] = a
+    return out
+
+
+def _worker(rank, world, port, shape, errq, real_library=False):
     try:
         import torch
         import torch.distributed as dist
@@ -230,6 +258,8 @@ def _worker(rank, world, port, shape, errq):
         from tests.helpers import compare_buffers, compare_rows
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
+        if real_library:
+            _bind_host_simulation(torch)
         dist.init_process_group("gloo", rank=rank, world_size=world)
         prepart = shape == "keyed_prepartitioned"
         mismatched = shape == "keyed_sliced_mismatched"
@@ -246,9 +276,18 @@ def _worker(rank, world, port, shape, errq):
             mine = [[c[sel] for c in cols]]
         else:
             mine = [f for i, f in enumerate(frags) if i % world == rank]
-        q, buf, code = orc.execute(plan, mine, n_threads=1)
-        assert code == 0
-        shard = NumpyShard(torch, orc, q, buf)
+        if real_library:
+            # the rank's step through the product's own executor and kernels, result storage owned by a tensor (HipShard)
+            from heavydb_amd.executor import Executor, FetchResult
+            from heavydb_amd.multi_gpu import HipShard
+            keep = [[_aligned_copy(c) for c in f] for f in mine]
+            fr = FetchResult([[c.ctypes.data for c in f] for f in keep], [len(f[0]) for f in keep], keepalive=keep)
+            shard = HipShard.execute(torch, Executor(0), ra, fr)
+            q = shard.qmd()
+        else:
+            q, buf, code = orc.execute(plan, mine, n_threads=1)
+            assert code == 0
+            shard = NumpyShard(torch, orc, q, buf)
         before = shard.buffer().numpy().copy()
         out = merge(shard, dist, torch, gather_to_rank0=True, prepartitioned=prepart)
         if prepart and rank != 0:
@@ -310,14 +349,17 @@ def test_slice_exchange_over_gloo(world, shape):
                                    "perfect_float", "non_grouped", "perfect_two_columns_unprojected",
                                    "perfect_columnar", "perfect_nullable_columnar", "keyed_columnar",
                                    "keyed_two_columns_columnar", "perfect_two_columns_unprojected_columnar", "keyed_prepartitioned"])
-def test_merge_over_gloo(shape, world):
+def test_merge_over_gloo(shape, world, real_library=False):
     import torch.multiprocessing as mp
     from oracle import oracle as orc
     orc.lib()  # build once in the parent
+    if real_library:
+        from tests.helpers import hostsim_lib
+        hostsim_lib(real_fast=True)
     ctx = mp.get_context("spawn")
     errq = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, errq)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, errq, real_library)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -331,6 +373,19 @@ def test_merge_over_gloo(shape, world):
             errs.append((-1, "timeout"))
     assert not errs, "\n".join(f"rank {r}:\n{t}" for r, t in errs)
     assert all(p.exitcode == 0 for p in procs)
+
+
+@pytest.mark.parametrize("world,shape", [(2, "keyed_sliced"), (3, "keyed_sliced_dense"), (2, "keyed"), (2, "keyed_two_columns"),
+                                         (3, "keyed_compact"), (2, "perfect"), (3, "perfect_nullable"), (2, "perfect_float"),
+                                         (2, "non_grouped"), (2, "keyed_columnar"), (2, "perfect_columnar"),
+                                         (2, "keyed_prepartitioned"), (3, "keyed_sliced_mismatched")])
+def test_merge_over_gloo_with_the_librarys_own_code(world, shape):
+    """The same choreography with the PRODUCT on every rank instead of the numpy twin: each rank's step runs through
+    mi355q_execute, its shard is a HipShard (mi355q_shard_pads / _merge_slices with the LDS slice fold / _partition /
+    _merge_rows / _reduce, the calls the GPU path makes), on the host simulation of the library (tests/hostsim: every
+    kernel file compiled for the CPU); gloo carries the tensors RCCL would.  Rank 0 compares with the oracle over all
+    fragments.  What this cannot show is RCCL itself and timing — the ABI sequence and its device code, it can."""
+    test_merge_over_gloo(shape, world, real_library=True)
 
 
 def test_prepartitioned_key_streams_are_disjoint(oracle):
