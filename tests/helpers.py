@@ -420,6 +420,12 @@ def hostsim_lib(real_fast: bool = False) -> str:
                     pat = "const bool all_done = lds_peek(done) == (uint32_t)kProdWaves;"
                     assert src.count(pat) == 1
                     src = src.replace(pat, "const bool all_done = __shfl((int)(lds_peek(done) == (uint32_t)kProdWaves), 0) != 0;")
+                    # ... and the lanes that flush the segments of ONE staging line must agree on how far that line has
+                    # been written (one LDS read in lockstep on the device): the reading of the line's first lane counts
+                    pat = "const uint32_t w = lds_peek(&written[p]);"
+                    assert src.count(pat) == 2
+                    src = src.replace(pat, "const uint32_t w = (uint32_t)__shfl((int)lds_peek(&written[p]), "
+                                           "(int)((threadIdx.x & 63) - (sidx & 63)));")
                     # lanes of one wave wait for the lane that fetches the next spill block: that lane must get to run
                     pat = "if (w == kSpillBusy) continue;"
                     assert src.count(pat) == 1

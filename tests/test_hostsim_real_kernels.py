@@ -10,6 +10,8 @@ nothing about timing or about races (fibers of a block run one after the other b
 other: waits for another workgroup — pair rendezvous, probe pacing — are bounded on the device and expire here)."""
 import ctypes as C
 
+import numpy as np
+
 import pytest
 
 from heavydb_amd import capi
@@ -122,3 +124,30 @@ def test_baseline_lds_chain_with_the_real_kernel(sim, oracle, groups, n_rows):
     assert rs is not None
     if groups <= 3000:
         assert rs.report.kernel_name.decode() == "k_groupby_lds", rs.report.kernel_name
+
+
+@pytest.mark.parametrize("shape", ["count_only_filtered", "sum_min_max_i64"])
+def test_partitioned_family_keeps_every_record_with_long_staging_lines(sim, oracle, shape):
+    """150 K groups over 16 partitions: 512-record staging lines whose 64 segments are flushed by the 64 lanes of one wave.
+    On the device those lanes read `written[p]` in lockstep; the simulation has to hand them ONE reading (tests/helpers.py
+    patches it in), otherwise a lane that read earlier flushes its segment of the line a generation late — records of the
+    next generation in place of its own.  (Found by running tests/test_gpu_parity.py on the simulation: groups went missing
+    while the total count stayed right.)"""
+    from heavydb_amd.executor import Executor, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(99)
+    n, n_keys = 300_000, 150_000
+    key = (rng.integers(0, n_keys, n) * 1000003 + 7).astype(np.int64)
+    val = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    fil = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7)),
+             InputColDescriptor(capi.INT64, False, ExpressionRange(True, -10**6, 10**6)),
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+    if shape == "count_only_filtered":
+        targets, quals = [TargetExpr(capi.COUNT)], [Qual(2, capi.GE, 2**29)]
+    else:
+        targets, quals = [TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 1), TargetExpr(capi.MAX, 1), TargetExpr(capi.COUNT)], []
+    ra = RelAlgExecutionUnit(descs, targets, quals, [0], max_groups_buffer_entry_guess=2 * n_keys)
+    cut = (n // 3) & ~3
+    case = cases_mod.Case(shape, ra, [[key[:cut], val[:cut], fil[:cut]], [key[cut:], val[cut:], fil[cut:]]])
+    rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=16 << 20)
+    assert rs.report.kernel_name.decode() == "k_part_scatter" and rs.report.variant == 2
