@@ -26,3 +26,17 @@ find $out/trace2 -name "*kernel_trace.csv" -exec cp {} $out/lds_retry_chain_kern
 [ -x tools/microbench/groupby_lds_typed ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/microbench/groupby_lds_typed tools/microbench/groupby_lds_typed.hip
 timeout 60 ./tools/microbench/groupby_lds_typed 1e9 > $out/microbench_groupby_lds_typed.txt 2>&1; cat $out/microbench_groupby_lds_typed.txt
 timeout 60 ./integration/glue_check > $out/glue_check.log 2>&1; echo "glue_check exit $?"
+python - <<'PY' > $out/explain_routes.txt 2>&1
+import sys
+sys.path.insert(0, "tools")
+import refbench
+from heavydb_amd import capi
+from heavydb_amd.executor import Executor
+capi.load_library()
+names, descs, _ = refbench.schema()
+ex = Executor(0)
+for q in refbench.queries():
+    ra, _ = refbench.build_unit(refbench.queries()[q], names, descs, 10**9)
+    print(q, "->", ex.explain(ra, [32_000_000] * 31 + [8_000_000]))
+PY
+head -8 $out/explain_routes.txt
