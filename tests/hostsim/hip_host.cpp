@@ -89,6 +89,8 @@ struct Sched {
   Barrier block_barrier, wave_barrier[kMaxThreads / kWave];
   uint64_t xchg[kMaxThreads], recv[kMaxThreads];
   unsigned char state[kMaxThreads];   // HOSTSIM_WATCHDOG: where each fiber waits (0 runs, 1 block barrier, 2 wave barrier, 3 yield, 4 done)
+  const Barrier* wait_b[kMaxThreads];  // the barrier a fiber is parked at (null: runnable) and the generation it waits to pass:
+  uint64_t wait_gen[kMaxThreads];      // the scheduler does not switch to a fiber whose barrier has not moved
   const char* kernel_name = "";
   unsigned long long ballot[kMaxThreads / kWave];
   std::vector<char> dyn;
@@ -135,7 +137,10 @@ void wait_at(Barrier& b) {
   const int id = s.cur;
   s.state[id] = &b == &s.block_barrier ? 1 : 2;
   const uint64_t g = b.gen;
+  s.wait_b[id] = &b;
+  s.wait_gen[id] = g;
   while (b.gen == g) yield();
+  s.wait_b[id] = nullptr;
   s.state[id] = 0;
 }
 
@@ -173,14 +178,18 @@ void run_block_fibers(Sched& s, int n_threads) {
     makecontext(&s.ctx[t], trampoline, 0);
     s.finished[t] = false;
     s.state[t] = 0;
+    s.wait_b[t] = nullptr;
   }
   s.n = n_threads;
   std::vector<char> gone((size_t)n_threads, 0);
   int alive = n_threads;
   s.in_fibers = true;
   while (alive > 0) {
+    int resumed = 0;
     for (int t = 0; t < n_threads; ++t) {
       if (gone[t]) continue;
+      if (s.wait_b[t] && s.wait_b[t]->gen == s.wait_gen[t]) continue;  // still parked: resuming it would only yield again
+      ++resumed;
       s.cur = t;
       set_ids(s, t);
       swapcontext(&s.main_ctx, &s.ctx[t]);
@@ -191,6 +200,10 @@ void run_block_fibers(Sched& s, int n_threads) {
         s.block_barrier.drop();
         s.wave_barrier[t / kWave].drop();
       }
+    }
+    if (!resumed) {  // every live fiber is parked at a barrier nobody will complete: the kernel deadlocked
+      std::fprintf(stderr, "[hipsim] deadlock: all %d live fibers are parked at barriers\n", alive);
+      watchdog(0);
     }
   }
   s.in_fibers = false;
