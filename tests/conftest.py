@@ -46,7 +46,7 @@ if os.environ.get("MI355Q_HOSTSIM") in ("1", "real"):
         real_zeros, real_empty, real_full, real_arange = torch.zeros, torch.empty, torch.full, torch.arange
         strip = lambda f: (lambda *a, **k: f(*a, **{x: y for x, y in k.items() if x != "device"}))  # noqa: E731
         torch.zeros, torch.empty, torch.full, torch.arange = strip(real_zeros), strip(real_empty), strip(real_full), strip(real_arange)
-        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.Tensor.cuda = lambda self, *a, **k: self.clone()   # a "device" copy: it must not alias the host array it came from
         torch.cuda.is_available = lambda: True
         torch.cuda.synchronize = lambda *a, **k: None
         torch.cuda.device_count = lambda: 1
