@@ -196,6 +196,10 @@ def main():
         bpr = sum(4 if dict(INT_COLS).get(c) else 8 for c in used)
         line = {"query": name, "rows": n_rows, "bytes_per_row": bpr}
         try:
+            line["route"] = ex.explain(ra, rows)     # mi355q_explain: derived-plan stages + kernel family at this size
+        except Exception as e:                       # (never in the way of the measurement)
+            line["route"] = "explain failed: " + str(e)
+        try:
             # probe on the first fragment: kernel choice and a rate
             fr1 = FetchResult(bufs[:1], rows[:1], keepalive=cols)
             ex.executeWorkUnit(ra, fr1)
