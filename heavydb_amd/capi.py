@@ -18,7 +18,7 @@ MAX_SLOTS = 16
 MAX_GROUP_COLS = 4
 MAX_EXPRS = 4
 MAX_EXPR_NODES = 8
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # mi355q_type
 INT8, INT16, INT32, INT64, DOUBLE, FLOAT = 1, 2, 3, 4, 5, 6
@@ -55,6 +55,7 @@ ERR_UNSUPPORTED = 101
 ERR_HIP = 102
 ERR_JOIN_NOT_ONE_TO_ONE = 103
 ERR_JOIN_TABLE_FULL = 104
+STEP_RECOMPUTED = 110  # mi355q_wait: result complete, but re-run after the async call returned
 
 TYPE_WIDTH = {INT8: 1, INT16: 2, INT32: 4, INT64: 8, DOUBLE: 8, FLOAT: 4}
 
@@ -186,6 +187,8 @@ class ExecOptions(C.Structure):
         ("pass_rows", C.c_int64),
         ("flags", C.c_uint32),
         ("tune_cus", C.c_int32),
+        ("tune_overlap_cus", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

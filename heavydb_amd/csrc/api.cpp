@@ -160,6 +160,8 @@ DeviceCtx& ctx_of(int dev) {
   return ctxs[dev < 0 ? 0 : dev % 64];
 }
 
+void drain_inflight(DeviceCtx& ctx);  // finishes the step mi355q_execute_async left in flight (defined with finish_step)
+
 // Small pinned-free device scratch for the error word / counters, one per call.
 struct DevWord {
   void* p = nullptr;
@@ -276,6 +278,7 @@ const char* mi355q_error_string(int32_t code) {
     case MI355Q_ERR_HIP: return hipGetErrorString(last_hip_error);
     case MI355Q_ERR_JOIN_NOT_ONE_TO_ONE: return "Join key column is not unique (one-to-many)";
     case MI355Q_ERR_JOIN_TABLE_FULL: return "Keyed join hash table is full";
+    case MI355Q_STEP_RECOMPUTED: return "Step re-run inside mi355q_wait: redo what was enqueued behind it";
     default: return "Unknown error";
   }
 }
@@ -309,6 +312,9 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   std::lock_guard<std::recursive_mutex> lk(ctx.mu);
   DeviceGuard g(device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
+  // a step left in flight by mi355q_execute_async still points into the workspace (error words, column table,
+  // events, the launch stream): finish it before anything is freed
+  drain_inflight(ctx);
   if (ctx.scratch) (void)hipFree(ctx.scratch);
   if (ctx.meta) (void)hipFree(ctx.meta);
   if (ctx.aux) (void)hipFree(ctx.aux);
@@ -1272,9 +1278,19 @@ struct TailState {
   hipEvent_t ev_start, ev_stop;
   hipEvent_t* ev_pool;
   bool trace;
+  TuneKnobs knobs;          // the knobs the step was planned with: a re-run in mi355q_wait (another thread, another
+                            // call's knobs in between) must plan with the same ones
+  bool recomputed = false;  // finish_step re-ran the step into res->buf after the first launches had completed
+};
+
+struct KnobScope {  // the thread's knobs for the duration of finish_step
+  TuneKnobs saved;
+  explicit KnobScope(const TuneKnobs& k) : saved(tune_knobs()) { set_tune_knobs(k); }
+  ~KnobScope() { set_tune_knobs(saved); }
 };
 
 int32_t finish_step(TailState& t, mi355q_exec_report* report) {
+  KnobScope knob_scope(t.knobs);
   hipStream_t s = t.s;
   LaunchStats& st = t.st;
   const mi355q_qmd& q = t.q;
@@ -1288,6 +1304,7 @@ int32_t finish_step(TailState& t, mi355q_exec_report* report) {
   }
   HIP_TRY(hipStreamSynchronize(s));
   st.spilled_rows = (int64_t)h_spills;
+  if (h_err[1] && (t.kind == K_JOIN_PART || t.kind == K_JOIN_PROBE || t.kind == K_BASELINE_FAST)) t.recomputed = true;
   if (h_err[1] && t.trace) std::fprintf(stderr, "[mi355q] partitioned family gave up (code %d, spills %u): re-running with the direct kernel\n", h_err[1], h_spills);
   if (h_err[1] && t.kind == K_JOIN_PART) {
     // the partitioned probe ran out of spill space (extreme skew): redo with the direct probe
@@ -1360,6 +1377,9 @@ void drain_inflight(DeviceCtx& ctx) {
   ctx.inflight = nullptr;
   if (p->tail) {
     p->code = finish_step(*p->tail, &p->rep);
+    // the step was re-run after the call had returned: a consumer enqueued behind the first launches (pads, slices,
+    // a collective) worked on the table the abandoned attempt left — tell the caller to redo it
+    if (p->code == MI355Q_OK && p->tail->recomputed) p->code = MI355Q_STEP_RECOMPUTED;
     delete p->tail;
     p->tail = nullptr;
   }
@@ -1736,6 +1756,7 @@ int32_t mi355q_execute_async(const mi355q_plan* plan, const mi355q_inputs* in, c
   mi355q_exec_report rep{};
   const int32_t e = execute_impl(plan, in, opts, out, &rep, &p);
   if (!p) {  // completed (or failed) synchronously
+    if (e) return e;  // a failed call leaves no handle behind (*pending stays NULL)
     p = new (std::nothrow) mi355q_pending();
     if (!p) return e ? e : MI355Q_ERR_OUT_OF_CPU_MEM;
     p->device_id = in ? in->device_id : 0;
@@ -1787,6 +1808,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     k.probe_keyed_passes = o.probe_keyed_passes;
     k.pass_rows = o.pass_rows;
     k.flags = o.flags;
+    k.overlap_cus = o.tune_overlap_cus;
     set_tune_knobs(k);
   }
   if (plan->n_exprs != 0) {
@@ -2231,6 +2253,12 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
         if (st.k_stop) HIP_TRY(hipEventRecord(st.k_stop, s));
     }
   }
+  if (st.spill_counter32) {
+    // the counter lives in the partition scratch, which mi355q_shard_merge_slices (or the next call) may reuse or
+    // reallocate before mi355q_wait looks at it: keep a copy next to the error words
+    HIP_TRY(hipMemcpyAsync(d_err + 4, st.spill_counter32, 4, hipMemcpyDeviceToDevice, s));
+    st.spill_counter32 = (uint32_t*)(d_err + 4);
+  }
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   tr.mark("launched");
 
@@ -2257,6 +2285,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   tail->ev_stop = ev_stop;
   tail->ev_pool = ev_pool;
   tail->trace = tr.on;
+  tail->knobs = tune_knobs();
   if (pend) {  // mi355q_execute_async: the rest runs in mi355q_wait (or before the next call on this device)
     mi355q_pending* p = new (std::nothrow) mi355q_pending();
     if (!p) {

@@ -39,6 +39,7 @@ struct TuneKnobs {
   int probe_keyed_passes = 0;
   int64_t pass_rows = 0;
   uint32_t flags = 0;  // MI355Q_OPT_*
+  int overlap_cus = 0;  // partitioned GROUP BY: CUs of phase 1 while phase 2 of the previous chunk runs on the rest
 };
 const TuneKnobs& tune_knobs();
 void set_tune_knobs(const TuneKnobs& k);

@@ -36,6 +36,8 @@
 #include <cstdio>
 #include <type_traits>
 #include <cstdlib>
+#include <mutex>
+#include <vector>
 
 #include "fast_common.h"
 
@@ -1990,9 +1992,19 @@ struct PartPlanHost {
   uint32_t spill_cap;     // spill list entries
   int n_cand;             // heavy-hitter candidate slots in phase 1
   int op_mask;            // set of internal ops (bit per SlotOp)
+  // phase 1 of chunk i + 1 next to phase 2 of chunk i: two buffers of `buf_bytes` (runs + lengths +
+  // spill list) in the scratch, g.B scatter workgroups and grid2 aggregate workgroups share the device
+  int overlap;            // 0 = one phase after the other on the whole device
+  int grid2;              // workgroups of phase 2
+  int64_t buf_bytes;      // one buffer set (256-byte multiple)
 };
 
 constexpr size_t kLdsTableBudget = 150 * 1024;
+// phase 1 of the next chunk on this many CUs while phase 2 runs on the rest (0 = off); an input is cut into at
+// least kOverlapMinChunks chunks then, so that all but the first scatter and the last aggregate have company
+constexpr int kDefaultOverlapCus = 0;
+constexpr int kOverlapMinChunks = 6;
+constexpr int64_t kOverlapMinRows = 256ll << 20;
 
 bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, int n_cus,
                     int64_t scratch_cap, PartPlanHost* out) {
@@ -2108,10 +2120,30 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     h.g.b_mult = (uint32_t)(m > 0xffffffffull ? 0xffffffffull : m);
   }
   h.g.B = n_cus;  // one 1024-lane workgroup per CU
+  h.grid2 = n_cus;
+  h.overlap = 0;
+  {
+    int ov = tune_knobs().overlap_cus;
+    if (ov == 0) ov = kDefaultOverlapCus;
+    // (the 16-workgroup granularity keeps phase 2's sub-range pairs on one XCD; small devices — the host
+    // simulation's 8 "CUs" — take any split)
+    if (ov > 0 && ov < n_cus && fv.total_rows >= (tune_knobs().overlap_cus > 0 ? 2 * fv.max_frag_rows : kOverlapMinRows) &&
+        fv.n_frags >= 2) {
+      h.overlap = 1;
+      h.g.B = ov;
+      h.grid2 = n_cus - ov;
+      scratch_cap /= 2;
+    }
+  }
   // chunking: worst case every row survives the filter; shrink the chunk until the runs
   // (1.2 x mean + 6 sigma + a line of slack per run) fit the scratch cap, never below one
   // fragment
   int64_t chunk_rows = fv.total_rows > 0 ? fv.total_rows : 1;
+  if (h.overlap) {
+    const int64_t want = (fv.total_rows + kOverlapMinChunks - 1) / kOverlapMinChunks + fv.max_frag_rows;
+    if (want < chunk_rows) chunk_rows = want;
+    if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
+  }
   if (chunk_rows > 0xfff00000ll) chunk_rows = 0xfff00000ll;  // 32-bit LDS counters per chunk
   for (;;) {
     const double per_run = (double)chunk_rows / ((double)P * h.g.B);
@@ -2134,8 +2166,9 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
     if (spill_cap > 0x7fffffffll) spill_cap = 0x7fffffffll;
     h.spill_cap = (uint32_t)spill_cap;
     const int64_t spill_bytes = 256 + spill_cap * 8 * (int64_t)(1 + n_int);
-    h.scratch_bytes = h.rec_bytes + h.cnt_bytes + spill_bytes;
-    if (h.scratch_bytes <= scratch_cap || chunk_rows <= fv.max_frag_rows) break;
+    h.buf_bytes = (h.rec_bytes + h.cnt_bytes + spill_bytes + 255) & ~255ll;
+    h.scratch_bytes = h.overlap ? 2 * h.buf_bytes : h.rec_bytes + h.cnt_bytes + spill_bytes;
+    if (h.buf_bytes <= scratch_cap || chunk_rows <= fv.max_frag_rows) break;
     chunk_rows = (int64_t)(chunk_rows * 0.97);
     if (chunk_rows < fv.max_frag_rows) chunk_rows = fv.max_frag_rows;
   }
@@ -2157,6 +2190,29 @@ bool make_part_plan(const DevPlan& p, const FastShape& fs, const FragView& fv, i
   }
   h.lds2 = (size_t)h.g.E * entry_bytes + (size_t)((hm.S2 + 31) / 32) * 4 + (size_t)h.g.B * 4;
   return h.lds2 <= 160 * 1024;
+}
+
+// second stream and the four ordering events of the overlapped pipeline, one set per device, created on first use and
+// kept (like the per-device workspace)
+struct OverlapRes {
+  hipStream_t s2 = nullptr;
+  hipEvent_t ev_scat[2] = {nullptr, nullptr}, ev_agg[2] = {nullptr, nullptr};
+};
+OverlapRes* overlap_resources() {
+  static OverlapRes res[64];
+  static std::mutex mu;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  OverlapRes& r = res[dev < 0 ? 0 : dev % 64];
+  if (!r.s2) {
+    if (hipStreamCreateWithFlags(&r.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    for (int i = 0; i < 2; ++i)
+      if (hipEventCreateWithFlags(&r.ev_scat[i], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&r.ev_agg[i], hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+  }
+  return &r;
 }
 
 template <typename FT, typename VT>
@@ -2273,6 +2329,89 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
   int f = 0;
   int ev_i = 0;
   int chunk = 0;
+  if (h.overlap) {
+    // ---- phase 1 of chunk i + 1 on g.B CUs next to phase 2 of chunk i on the other grid2 ----
+    // stream s: scatter(0), scatter(1), ...  (scatter(i) waits until aggregate(i - 2) has let go of its buffer)
+    // stream s2: aggregate(0) + spill merge(0), aggregate(1) + ...   (aggregate(i) waits for scatter(i); one after
+    // the other, because chunk i + 1 re-loads the table rows chunk i wrote)
+    // Enqueued in an order that is also a valid sequential schedule (the host simulation runs a launch when it is
+    // enqueued): scatter(0); then scatter(i + 1), aggregate(i) for every i.
+    OverlapRes* ov = overlap_resources();
+    if (!ov) return hipErrorInvalidValue;
+    struct Chunk { int f0, nf; int64_t rows; };
+    std::vector<Chunk> chunks;
+    while (f < fv.n_frags) {
+      int64_t rows = 0;
+      int f1 = f;
+      while (f1 < fv.n_frags && (f1 == f || rows + fv.h_num_rows[f1] <= h.chunk_rows)) {
+        rows += fv.h_num_rows[f1];
+        ++f1;
+      }
+      chunks.push_back({f, f1 - f, rows});
+      f = f1;
+    }
+    const int n = (int)chunks.size();
+    auto buf_recs = [&](int b) { return (Rec*)((char*)scratch + (int64_t)b * h.buf_bytes); };
+    auto buf_cnt = [&](int b) { return (uint32_t*)((char*)scratch + (int64_t)b * h.buf_bytes + h.rec_bytes); };
+    auto buf_spill = [&](int b) { return (char*)scratch + (int64_t)b * h.buf_bytes + h.rec_bytes + h.cnt_bytes; };
+    auto buf_sl = [&](int b) {
+      char* sb = buf_spill(b);
+      return SpillList{(uint32_t*)sb, (int64_t*)(sb + 256), d_err, h.spill_cap, 1 + h.g.ns_int};
+    };
+    auto scatter = [&](int i) -> hipError_t {
+      const int b = i & 1;
+      hipError_t e2;
+      if (i >= 2 && (e2 = hipStreamWaitEvent(s, ov->ev_agg[b], 0)) != hipSuccess) return e2;
+      if ((e2 = hipMemsetAsync(buf_spill(b), 0, 256, s)) != hipSuccess) return e2;
+      if (ev_pool && ev_i + 1 < n_ev) (void)hipEventRecord(ev_pool[ev_i], s);
+      const Chunk& c = chunks[i];
+      if (fs.fil_type == 0)
+        e2 = launch_scatter_v<none_t>(fs, h.g.B, h.lds1, s, fv, c.f0, c.nf, p.group_col, sa, buf_recs(b), buf_cnt(b), buf_sl(b));
+      else if (fs.fil_type == MI355Q_INT32)
+        e2 = launch_scatter_v<int32_t>(fs, h.g.B, h.lds1, s, fv, c.f0, c.nf, p.group_col, sa, buf_recs(b), buf_cnt(b), buf_sl(b));
+      else
+        e2 = launch_scatter_v<int64_t>(fs, h.g.B, h.lds1, s, fv, c.f0, c.nf, p.group_col, sa, buf_recs(b), buf_cnt(b), buf_sl(b));
+      if (e2 != hipSuccess) return e2;
+      if (ev_pool && ev_i + 1 < n_ev) {
+        (void)hipEventRecord(ev_pool[ev_i + 1], s);
+        ev_i += 2;
+      }
+      st->n_launches += 1;
+      return hipEventRecord(ov->ev_scat[b], s);
+    };
+    auto aggregate = [&](int i) -> hipError_t {
+      const int b = i & 1;
+      const Chunk& c = chunks[i];
+      hipError_t e2;
+      if ((e2 = hipStreamWaitEvent(ov->s2, ov->ev_scat[b], 0)) != hipSuccess) return e2;
+      unsigned int* pc = (h.grid2 <= 256 && !(opt_flags & MI355Q_OPT_NO_PAIR_RENDEZVOUS))
+                             ? (unsigned int*)((char*)buf_cnt(b) + h.cnt_bytes - kPairCtrBytes) : nullptr;
+      if (pc && (e2 = hipMemsetAsync(pc, 0, kPairCtrBytes, ov->s2)) != hipSuccess) return e2;
+      const int units = h.g.P * (int)h.g.hm.R;
+      const int g2 = units < h.grid2 ? units : h.grid2;
+      hipLaunchKernelGGL(agg_kernel, dim3(g2), dim3(kPartBlock), h.lds2, ov->s2, h.g, buf_recs(b), buf_cnt(b), h.ps,
+                         tab, buf_sl(b), i > 0 ? 1 : 0, (uint32_t)(c.rows > 0xfff00000ll ? 0xfff00000ll : c.rows),
+                         (unsigned long long*)nullptr, pc, SliceMerge{});
+      if ((e2 = hipGetLastError()) != hipSuccess) return e2;
+      (void)hipFuncSetAttribute((const void*)k_spill_merge, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                h.g.ns_int * kSpillLds * 8);
+      hipLaunchKernelGGL(k_spill_merge, dim3(512), dim3(256), (size_t)h.g.ns_int * kSpillLds * 8, ov->s2, h.ps, tab,
+                         buf_sl(b), h.g.ns_int);
+      if ((e2 = hipGetLastError()) != hipSuccess) return e2;
+      return hipEventRecord(ov->ev_agg[b], ov->s2);
+    };
+    // everything enqueued on s so far (table init by the caller, the memsets above) precedes the first aggregate
+    // through ev_scat[0]
+    if ((e = scatter(0)) != hipSuccess) return e;
+    for (int i = 0; i < n; ++i) {
+      if (i + 1 < n && (e = scatter(i + 1)) != hipSuccess) return e;
+      if ((e = aggregate(i)) != hipSuccess) return e;
+    }
+    if ((e = hipStreamWaitEvent(s, ov->ev_agg[(n - 1) & 1], 0)) != hipSuccess) return e;
+    st->spill_counter32 = (uint32_t*)buf_spill((n - 1) & 1);
+    st->n_events_used = ev_i;
+    return hipSuccess;
+  }
   while (f < fv.n_frags) {
     int64_t rows = 0;
     int f1 = f;
@@ -2294,7 +2433,7 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
     }
     st->n_launches += 1;
     const int units = h.g.P * (int)h.g.hm.R;
-    const int grid2 = units < n_cus ? units : n_cus;
+    const int grid2 = units < h.grid2 ? units : h.grid2;
     if (pair_ctr) {
       e = hipMemsetAsync(pair_ctr, 0, kPairCtrBytes, s);
       if (e != hipSuccess) return e;

@@ -539,7 +539,7 @@ class Executor:
                         force_generic: bool = False, kernel_variant: int = 0,
                         scratch_bytes: int = 0, allow_retry: bool = True, pass_rows: int = 0,
                         probe_keyed_passes: int = 0, flags: int = 0, tune_blocks_per_cu: int = 0,
-                        tune_cus: int = 0) -> ResultSet:
+                        tune_cus: int = 0, tune_overlap_cus: int = 0) -> ResultSet:
         """Runs the step.  A negative code (ran out of group slots) doubles the baseline
         table and retries, as RelAlgExecutor::executeWorkUnit does after its cardinality
         estimation (RelAlgExecutor.cpp:4143-4145, :4194-4231)."""
@@ -559,6 +559,7 @@ class Executor:
                 opts.flags = flags
                 opts.tune_blocks_per_cu = tune_blocks_per_cu
                 opts.tune_cus = tune_cus
+                opts.tune_overlap_cus = tune_overlap_cus
                 out = C.c_void_p()
                 rep = capi.ExecReport()
                 code = self._lib.mi355q_execute(C.byref(plan), C.byref(inp), C.byref(opts),
@@ -651,13 +652,20 @@ class PendingStep:
     def __init__(self, lib, handle, result_set):
         self._lib, self.handle, self.result_set = lib, handle, result_set
 
+    recomputed = False  # mi355q_wait answered MI355Q_STEP_RECOMPUTED: stream-ordered consumers must be redone
+
     def wait(self):
-        """Blocks until the step has finished; raises on an error code; returns the ResultSet (with its report)."""
+        """Blocks until the step has finished; raises on an error code; returns the ResultSet (with its report).
+        `self.recomputed` tells whether the step was re-run inside the wait (MI355Q_STEP_RECOMPUTED): whatever was
+        enqueued behind the first launches read the table of the abandoned attempt."""
         if self.handle is None:
             return self.result_set
         rep = capi.ExecReport()
         code = self._lib.mi355q_wait(self.handle, C.byref(rep))
         self.handle = None
+        if code == capi.STEP_RECOMPUTED:
+            self.recomputed = True
+            code = 0
         if code:
             raise capi.Mi355qError(code, "wait")
         if self.result_set is not None:

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 3
+#define MI355Q_ABI_VERSION 4
 
 #define MI355Q_MAX_COLS 16
 #define MI355Q_MAX_QUALS 4
@@ -69,6 +69,12 @@ extern "C" {
 #define MI355Q_ERR_HIP 102
 #define MI355Q_ERR_JOIN_NOT_ONE_TO_ONE 103 /* reference: fill returns -1 -> 1:N rebuild */
 #define MI355Q_ERR_JOIN_TABLE_FULL 104     /* reference: write_baseline_hash_slot -2 */
+/* mi355q_wait only, and not an error: the result is complete and correct, but the step had to be RE-RUN inside
+ * mi355q_wait (the partitioned family ran out of spill space and the direct member took over), i.e. after
+ * mi355q_execute_async had returned.  Whatever the caller enqueued behind the first launches on the same stream
+ * (mi355q_shard_pads, slices handed to a collective, a merge) read the table of the abandoned attempt and has to
+ * be redone from the result as it is now. */
+#define MI355Q_STEP_RECOMPUTED 110
 
 /* ---- column types (fixed-width, as ColumnFetcher hands them over) ---- */
 typedef enum mi355q_type {
@@ -415,6 +421,11 @@ typedef struct mi355q_exec_options {
   uint32_t flags;               /* MI355Q_OPT_* */
   int32_t tune_cus;             /* plan and launch as if the device had this many CUs (experiments: how a family
                                    scales with the CU count, whether two families could share the device) */
+  int32_t tune_overlap_cus;     /* partitioned GROUP BY: > 0 = phase 1 (k_part_scatter) of chunk i + 1 runs on this many
+                                   CUs WHILE phase 2 (k_part_aggregate) of chunk i runs on the others (second stream,
+                                   two record buffers of half the scratch each); 0 = the built-in choice, -1 = phases
+                                   one after the other on the whole device */
+  int32_t reserved0;            /* 0 */
 } mi355q_exec_options;
 #define MI355Q_OPT_TRACE 1u              /* host-side wall-clock marks and phase-2 cycle counters on stderr */
 #define MI355Q_OPT_NO_PAIR_RENDEZVOUS 2u /* partitioned GROUP BY phase 2: no rendezvous of the sub-range pair */

@@ -424,6 +424,9 @@ hipError_t hipEventCreate(hipEvent_t* e) {
   *e = new ihipEvent_t{0.0};
   return hipSuccess;
 }
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+// a launch runs when it is enqueued, so whatever an event stands for has already happened
+hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) { return e ? hipSuccess : hipErrorInvalidValue; }
 hipError_t hipEventDestroy(hipEvent_t e) {
   delete e;
   return hipSuccess;

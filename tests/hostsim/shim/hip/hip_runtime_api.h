@@ -18,6 +18,7 @@ typedef struct ihipStream_t* hipStream_t;
 typedef struct ihipEvent_t* hipEvent_t;
 
 enum { hipStreamNonBlocking = 1 };
+enum { hipEventDisableTiming = 2 };
 typedef enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2,
                              hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 } hipMemcpyKind;
 typedef enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 63 } hipDeviceAttribute_t;
@@ -55,6 +56,8 @@ hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize(void);
 hipError_t hipEventCreate(hipEvent_t* e);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s);
 hipError_t hipEventSynchronize(hipEvent_t e);

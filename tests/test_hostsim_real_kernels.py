@@ -151,3 +151,37 @@ def test_partitioned_family_keeps_every_record_with_long_staging_lines(sim, orac
     case = cases_mod.Case(shape, ra, [[key[:cut], val[:cut], fil[:cut]], [key[cut:], val[cut:], fil[cut:]]])
     rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=16 << 20)
     assert rs.report.kernel_name.decode() == "k_part_scatter" and rs.report.variant == 2
+
+
+@pytest.mark.parametrize("overlap_cus", [2, 4, 6])
+@pytest.mark.parametrize("shape", ["count_avg_filtered", "sum_min_max_i64"])
+def test_partitioned_family_with_phase_1_next_to_phase_2(sim, oracle, shape, overlap_cus):
+    """`tune_overlap_cus`: k_part_scatter of chunk i + 1 on some of the CUs while k_part_aggregate of chunk i runs on the
+    others (second stream, two record buffers, two spill lists).  Seven fragments under a small scratch cap =
+    seven chunks, so both buffers are reused several times and every later chunk re-loads the table rows its predecessor
+    wrote.  The simulation runs a launch when it is enqueued, i.e. it checks the enqueue order, the buffer arithmetic and
+    the geometry with fewer scatter workgroups than CUs — not the overlap itself."""
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(1234 + overlap_cus)
+    n, n_keys = 280_000, 90_000
+    key = (rng.integers(0, n_keys, n) * 1000003 + 7).astype(np.int64)
+    fil = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+    if shape == "count_avg_filtered":
+        val = rng.random(n) * 1000.0
+        descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7)),
+                 InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 1000.0)),
+                 InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+        targets, quals = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 1)], [Qual(2, capi.LT, 2**30)]
+    else:
+        val = rng.integers(-10**6, 10**6, n).astype(np.int64)
+        descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, (n_keys - 1) * 1000003 + 7)),
+                 InputColDescriptor(capi.INT64, False, ExpressionRange(True, -10**6, 10**6)),
+                 InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+        targets, quals = [TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 1), TargetExpr(capi.MAX, 1), TargetExpr(capi.COUNT)], []
+    ra = RelAlgExecutionUnit(descs, targets, quals, [0], max_groups_buffer_entry_guess=2 * n_keys)
+    cuts = [0] + [(n * k // 7) & ~3 for k in range(1, 7)] + [n]
+    frags = [[key[a:b], val[a:b], fil[a:b]] for a, b in zip(cuts[:-1], cuts[1:])]
+    case = cases_mod.Case(shape, ra, frags)
+    rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=8 << 20, tune_overlap_cus=overlap_cus)
+    assert rs.report.kernel_name.decode() == "k_part_scatter" and rs.report.variant == 2
+    assert rs.report.n_launches >= 4, rs.report.n_launches

@@ -155,7 +155,7 @@ void rank_main(int rank, int world, int64_t total_rows, int64_t n_keys, ncclUniq
     mi355q_pending* pend = nullptr;
     MQCK(mi355q_execute_async(&plan, &in, &opts, &res, &pend));
     mi355q_result* fresh = nullptr;
-    if (world > 1) {
+    auto exchange = [&]() {
       MQCK(mi355q_shard_pads(res, world, kPadRows, pads, ok, s));
       NCCK(ncclGroupStart());
       for (int r = 0; r < world; ++r) {
@@ -184,9 +184,28 @@ void rank_main(int rank, int world, int64_t total_rows, int64_t n_keys, ncclUniq
       } else {
         MQCK(e);
       }
-    }
+    };
+    if (world > 1) exchange();
     mi355q_exec_report rep{};
-    MQCK(mi355q_wait(pend, &rep));
+    int32_t wc = mi355q_wait(pend, &rep);
+    // MI355Q_STEP_RECOMPUTED: the step was re-run inside the wait (spill overflow), so the pads and slices enqueued
+    // behind the first launches came from the abandoned table.  The exchange is a collective: every rank redoes it
+    // when any rank has to (flag agreed on with one small all-reduce).
+    int32_t* redo = ok + world;
+    int32_t h_redo = wc == MI355Q_STEP_RECOMPUTED ? 1 : 0;
+    if (wc == MI355Q_STEP_RECOMPUTED) wc = MI355Q_OK;
+    MQCK(wc);
+    if (world > 1) {
+      HIPCK(hipMemcpyAsync(redo, &h_redo, sizeof(int32_t), hipMemcpyHostToDevice, s));
+      NCCK(ncclAllReduce(redo, redo, 1, ncclInt32, ncclMax, comm, s));
+      HIPCK(hipMemcpyAsync(&h_redo, redo, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+      HIPCK(hipStreamSynchronize(s));
+      if (h_redo) {
+        mi355q_result_free(fresh);
+        fresh = nullptr;
+        exchange();
+      }
+    }
     HIPCK(hipStreamSynchronize(s));
     step_ms[rank] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (iter == 2) {
