@@ -1928,7 +1928,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
       mr = std::max(mr, in->num_rows[f]);
     }
     FragView fvh{nullptr, nullptr, in->col_buffers, in->num_rows, in->n_frags, plan->n_cols, tr, mr};
-    lds_direct = lds_groupby_eligible(d, fvh);
+    lds_direct = lds_groupby_eligible(d, fvh, n_cus);
   }
   if (!o.force_generic && in->n_frags > 0 && !lds_direct) {
     const size_t mark = t_route ? t_route->size() : 0;
@@ -2023,7 +2023,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     else if (perfect_lds_eligible(d, fv)) kind = K_PERFECT_LDS;
     // few groups: the table replicated in every workgroup's LDS (perfect-hash layouts up to 64 K entries that fit;
     // baseline layouts whose entry guess says "small" — if the groups turn out to be too many the step is re-run)
-    else if (o.kernel_variant == 0 && lds_groupby_eligible(d, fv) &&
+    else if (o.kernel_variant == 0 && lds_groupby_eligible(d, fv, n_cus) &&
              (d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH ||
               (d.entry_count <= 65536 && !(o.flags & MI355Q_OPT_NO_LDS_BASELINE) && !pend)))
       kind = K_LDS_GROUPBY;

@@ -182,7 +182,7 @@ hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, i
 // of 1-3 integer key columns with <= 65536 entries, or a baseline layout over one 8-byte / int32 key with at most a
 // few thousand groups (more: d_err[1] is set and the caller re-runs the step with another family); 1-3 value
 // columns, any aggregate kinds, NULL-aware or not, up to 4 integer range quals
-bool lds_groupby_eligible(const DevPlan& p, const FragView& fv);
+bool lds_groupby_eligible(const DevPlan& p, const FragView& fv, int n_cus);
 hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int n_cus,
                               hipStream_t s, LaunchStats* st);
 bool scan_count_eligible(const DevPlan& p, const FragView& fv);

@@ -65,6 +65,10 @@ struct LdsArgs {
   int32_t key_col[kLdsKeys], key_type[kLdsKeys], key_translate[kLdsKeys];
   int64_t key_min[kLdsKeys], key_card[kLdsKeys], key_mul[kLdsKeys], key_null_key[kLdsKeys];
   int32_t target_v[MI355Q_MAX_TARGETS];  // index into v[] of each target's argument, -1 = none
+  // typed members (k_groupby_lds_typed): every value column a plain INT32, no quals; one replica =
+  //   keys[E] i64 (baseline) | sum[NV][E] i64 | rows[E] u32 | cnt[NV][E] u32 | min[NV][E] i32 | max[NV][E] i32 (mm only)
+  int32_t typed, mm;
+  uint32_t t_off_keys, t_off_sum, t_off_rows, t_off_cnt, t_off_min, t_off_max;
 };
 
 struct RawQ {
@@ -149,13 +153,14 @@ MQ_D uint32_t lds_mix_window(uint32_t T, uint32_t h) { return __umulhi(h, T); }
 MQ_D uint32_t lds_key_slot(int64_t* keys, uint32_t H, int64_t key, uint32_t h) {
   uint32_t s = h & (H - 1);  // H is a power of two
   for (uint32_t trips = 0; trips < H; ++trips) {
-    const int64_t k = *(volatile int64_t*)&keys[s];
-    if (k == key) return s;
+    int64_t k = *(volatile int64_t*)&keys[s];
     if (k == kEmptyKey64) {
-      const int64_t old = (int64_t)atomicCAS((unsigned long long*)&keys[s], (unsigned long long)kEmptyKey64, (unsigned long long)key);
-      if (old == kEmptyKey64 || old == key) return s;
-      continue;  // another key took it: look at the slot again
+      // (a lost exchange hands back the key that took the slot: it is compared below and the walk moves on — the
+      // re-look used to count as a trip without advancing, so a contended replica could report "full" early)
+      k = (int64_t)atomicCAS((unsigned long long*)&keys[s], (unsigned long long)kEmptyKey64, (unsigned long long)key);
+      if (k == kEmptyKey64) return s;
     }
+    if (k == key) return s;
     s = (s + 1) & (H - 1);
   }
   return kNoSlot;
@@ -468,7 +473,347 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
   }
 }
 
-bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
+// ---------------------------------------------------------------------------------------------------------------------
+// TYPED members (round 4).  k_groupby_lds above decides every role at run time — key / value types, which accumulators a
+// column keeps, perfect hash or baseline — and its row loop is 5 941 static instructions per 8 rows, 3 899 of them uniform
+// branches (profiles/r03_isa_k_groupby_lds_static.txt): ~130 dynamic instructions per row visit, 0.10 - 0.26 of the
+// roofline on the reference benchmark's PerfectHashSingleCol / MultiCol / BaselineHash / MultiStep shapes.  Those shapes
+// (Benchmarks/synthetic_benchmark/create_table.py:116-137: every column INT, the strided ones BIGINT; keys cast to DOUBLE
+// or FLOAT for the baseline groups) are what the reference's shared-memory group-by serves (NativeCodegen.cpp:2750-2845),
+// so they get members with the roles compiled in:
+//   KK   0 = perfect hash over NK INT32 key columns (32-bit index arithmetic: the entry index fits 16 bits per component)
+//        1 = baseline, one 8-byte key (BIGINT, or DOUBLE as its bit pattern)
+//        2 = baseline, FLOAT key (the bit pattern of the double it widens to, IRCodegen.cpp:1505-1507)
+//        3 = baseline, INT32 key (sign-extended)
+//   NV   INT32 value columns (nullable or not: one uniform flag per column); per column a non-NULL count (u32), a sum
+//        (i64) and — MM — min / max kept as INT32 (`ds_min_i32` instead of a 64-bit LDS atomic, 8 instead of 16 bytes)
+//   UQ   quads per lane, column and step; the NEXT tile's loads are issued before this tile's rows are looked at
+// A row of another window is rejected on its key alone, before any value is touched.  No quals (the benchmark's grouped
+// queries have none); anything else — quals, wider values, DOUBLE arguments — stays with the generic member.
+MQ_D int32_t v4_get(const v4i32& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+template <int KK, int NK, int NV, bool MM, int UQ>
+__global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* const* __restrict__ cols,
+                                                                  const int64_t* __restrict__ num_rows, int n_frags, int n_cols,
+                                                                  LdsArgs a, DevPlan p, int64_t* __restrict__ out,
+                                                                  int32_t* __restrict__ d_err) {
+  static_assert(KK == 0 || NK == 1, "baseline members take one key column");
+  constexpr bool kBase = KK != 0;
+  constexpr int KW = KK == 1 ? 2 : 1;  // 16-byte loads per key quad
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int t = threadIdx.x;
+  const uint32_t K = 1u << a.copies_lg;
+  const uint32_t E = a.entries;
+  const uint32_t T = a.windows;
+  const uint32_t win = T > 1 ? blockIdx.x % T : 0u;
+  const uint32_t stripe = T > 1 ? blockIdx.x / T : blockIdx.x;
+  const uint32_t n_stripes = T > 1 ? gridDim.x / T : gridDim.x;
+  const uint32_t e_lo = kBase ? 0u : win * E;
+  // ---- initialise every replica
+  for (uint32_t r = 0; r < K; ++r) {
+    char* rep = smem + (size_t)r * a.copy_bytes;
+    for (uint32_t e = t; e < E; e += kLdsBlock) {
+      if (kBase) ((int64_t*)(rep + a.t_off_keys))[e] = kEmptyKey64;
+      ((uint32_t*)(rep + a.t_off_rows))[e] = 0;
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        ((int64_t*)(rep + a.t_off_sum))[c * E + e] = 0;
+        ((uint32_t*)(rep + a.t_off_cnt))[c * E + e] = 0;
+        if (MM) {
+          ((int32_t*)(rep + a.t_off_min))[c * E + e] = INT32_MAX;
+          ((int32_t*)(rep + a.t_off_max))[c * E + e] = INT32_MIN;
+        }
+      }
+    }
+  }
+  volatile uint32_t* const s_full = (volatile uint32_t*)(smem + ((size_t)a.copy_bytes << a.copies_lg));  // behind the replicas
+  if (t == 0) *s_full = 0u;
+  __syncthreads();
+  char* const my_rep = smem + (size_t)((uint32_t)t & (K - 1)) * a.copy_bytes;
+  int64_t* const my_keys = (int64_t*)(my_rep + a.t_off_keys);
+  unsigned long long* const my_sum = (unsigned long long*)(my_rep + a.t_off_sum);
+  uint32_t* const my_rows = (uint32_t*)(my_rep + a.t_off_rows);
+  uint32_t* const my_cnt = (uint32_t*)(my_rep + a.t_off_cnt);
+  int32_t* const my_min = (int32_t*)(my_rep + a.t_off_min);
+  int32_t* const my_max = (int32_t*)(my_rep + a.t_off_max);
+  bool bad = false, full = false;
+  // uniform per-column constants (static indices after unrolling: scalar registers, never a scratch copy of `a`)
+  uint32_t kmin[NK], kcard[NK], kmul[NK], knull[NK];
+  bool ktr[NK], vnull[NV];
+#pragma unroll
+  for (int g = 0; g < NK; ++g) {
+    kmin[g] = (uint32_t)(int32_t)a.key_min[g];
+    kcard[g] = (uint32_t)a.key_card[g];
+    kmul[g] = (uint32_t)a.key_mul[g];
+    knull[g] = (uint32_t)a.key_null_key[g];
+    ktr[g] = a.key_translate[g] != 0;
+  }
+#pragma unroll
+  for (int c = 0; c < NV; ++c) vnull[c] = a.v[c].nullable != 0;
+  const uint32_t n_entries = (uint32_t)p.entry_count;
+
+  // one row: klo = the low (or only) 32 bits of each key column's value, khi = the high word of an 8-byte key
+  auto one_row = [&](const int32_t (&klo)[NK], int32_t khi, const int32_t (&vv)[NV]) {
+    uint32_t e;
+    if constexpr (kBase) {
+      int64_t key;
+      if constexpr (KK == 1) key = (int64_t)(((uint64_t)(uint32_t)khi << 32) | (uint64_t)(uint32_t)klo[0]);
+      else if constexpr (KK == 2) key = dbl_bits((double)bits_flt(klo[0]));
+      else key = (int64_t)klo[0];
+      const uint32_t h = lds_key_mix(key);
+      if (T > 1 && lds_mix_window(T, h) != win) return;  // another window's row: nothing else of it is looked at
+      if (full || *s_full) {  // (see k_groupby_lds: a lost attempt is abandoned by everybody at the first overflow)
+        full = true;
+        return;
+      }
+      e = lds_key_slot(my_keys, E, key, h);
+      if (e == kNoSlot) {
+        if (atomicExch((uint32_t*)s_full, 1u) == 0u) atomicExch(d_err + 1, 1);
+        full = true;
+        return;
+      }
+    } else {
+      // 32-bit throughout: make_lds_args admits |key_min| < 2^30 and cardinalities <= 65 536, so `k - min` taken modulo
+      // 2^32 is either the true difference or >= 2^30 (out of range), and the entry index stays below 2^32
+      uint32_t idx = 0;
+      bool in_range = true;
+#pragma unroll
+      for (int g = 0; g < NK; ++g) {
+        uint32_t ku = (uint32_t)klo[g];
+        if (ktr[g] && klo[g] == INT32_MIN) ku = knull[g];
+        const uint32_t d = ku - kmin[g];
+        in_range = in_range && d < kcard[g];
+        idx += d * kmul[g];
+      }
+      if (!in_range || idx >= n_entries) {
+        bad = true;
+        return;
+      }
+      e = idx - e_lo;
+      if (e >= E) return;  // another window's row
+    }
+    atomicAdd(my_rows + e, 1u);
+#pragma unroll
+    for (int c = 0; c < NV; ++c) {
+      const int32_t v = vv[c];
+      if (vnull[c] && v == INT32_MIN) continue;
+      atomicAdd(my_cnt + c * E + e, 1u);
+      atomicAdd(my_sum + c * E + e, (unsigned long long)(int64_t)v);
+      if (MM) {
+        atomicMin(my_min + c * E + e, v);
+        atomicMax(my_max + c * E + e, v);
+      }
+    }
+  };
+
+  struct Tile {
+    v4i32 k[NK][UQ][KW];
+    v4i32 v[NV][UQ];
+  };
+  const int64_t tile_q = (int64_t)kLdsBlock * UQ;
+  const int64_t gtid = (int64_t)stripe * kLdsBlock + t;
+  const int64_t gsize = (int64_t)n_stripes * kLdsBlock;
+  for (int f = 0; f < n_frags; ++f) {
+    if (kBase && *(volatile int32_t*)(d_err + 1)) break;  // some workgroup's replica overflowed: the step is re-run anyway
+    const int8_t* const* fc = cols + (size_t)f * n_cols;
+    const int64_t n = num_rows[f];
+    const int64_t nq = n >> 2;
+    const int64_t n_tiles = nq / tile_q;
+    const int8_t *kb[NK], *vb[NV];
+#pragma unroll
+    for (int g = 0; g < NK; ++g) kb[g] = fc[a.key_col[g]];
+#pragma unroll
+    for (int c = 0; c < NV; ++c) vb[c] = fc[a.v[c].col];
+    auto load_tile = [&](Tile& tl, int64_t q0, int64_t stride) {
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        const int64_t quad = q0 + (int64_t)u * stride;
+#pragma unroll
+        for (int g = 0; g < NK; ++g) {
+#pragma unroll
+          for (int w = 0; w < KW; ++w) tl.k[g][u][w] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)kb[g] + quad * KW + w);
+        }
+#pragma unroll
+        for (int c = 0; c < NV; ++c) tl.v[c][u] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)vb[c] + quad);
+      }
+    };
+    auto do_tile = [&](const Tile& tl, int n_quads) {
+#pragma unroll
+      for (int u = 0; u < UQ; ++u) {
+        if (u >= n_quads) break;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          int32_t klo[NK], vv[NV];
+          int32_t khi = 0;
+#pragma unroll
+          for (int g = 0; g < NK; ++g) {
+            if constexpr (KK == 1) {  // four int64 in two 16-byte words: row i = words (2i, 2i + 1)
+              klo[g] = v4_get(tl.k[g][u][i >> 1], (i & 1) * 2);
+              khi = v4_get(tl.k[g][u][i >> 1], (i & 1) * 2 + 1);
+            } else {
+              klo[g] = v4_get(tl.k[g][u][0], i);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < NV; ++c) vv[c] = v4_get(tl.v[c][u], i);
+          one_row(klo, khi, vv);
+        }
+      }
+    };
+    Tile cur, nxt;
+    uint32_t tiles_done = 0;
+    int64_t tl = (stripe + (int64_t)f * 7) % n_stripes;
+    if (tl < n_tiles) load_tile(nxt, tl * tile_q + t, kLdsBlock);
+    for (; tl < n_tiles; tl += n_stripes) {
+      cur = nxt;
+      const int64_t nx = tl + n_stripes;
+      if (nx < n_tiles) load_tile(nxt, nx * tile_q + t, kLdsBlock);
+      if (kBase && (full || ((tiles_done++ & 3u) == 3u && *(volatile int32_t*)(d_err + 1)))) break;
+      do_tile(cur, UQ);
+    }
+    for (int64_t q = n_tiles * tile_q + gtid; q < nq; q += gsize) {
+      load_tile(cur, q, 0);  // (UQ copies of one quad; only the first is used)
+      do_tile(cur, 1);
+    }
+    const int64_t tail = (nq << 2) + gtid;
+    if (tail < n) {
+      int32_t klo[NK], vv[NV];
+      int32_t khi = 0;
+#pragma unroll
+      for (int g = 0; g < NK; ++g) {
+        if constexpr (KK == 1) {
+          const int64_t k8 = load_one<int64_t>(kb[g], tail);
+          klo[g] = (int32_t)(uint32_t)(uint64_t)k8;
+          khi = (int32_t)(uint32_t)((uint64_t)k8 >> 32);
+        } else {
+          klo[g] = load_one<int32_t>(kb[g], tail);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NV; ++c) vv[c] = load_one<int32_t>(vb[c], tail);
+      one_row(klo, khi, vv);
+    }
+  }
+  if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+  if (t == 0 && kBase && *(volatile int32_t*)(d_err + 1)) *s_full = 1u;
+  __syncthreads();
+  if (*s_full) return;  // a lost attempt is neither folded nor flushed
+
+  // ---- fold replicas 1 .. K-1 into replica 0
+  char* const rep0 = smem;
+  int64_t* const keys0 = (int64_t*)(rep0 + a.t_off_keys);
+  unsigned long long* const sum0 = (unsigned long long*)(rep0 + a.t_off_sum);
+  uint32_t* const rows0 = (uint32_t*)(rep0 + a.t_off_rows);
+  uint32_t* const cnt0 = (uint32_t*)(rep0 + a.t_off_cnt);
+  int32_t* const min0 = (int32_t*)(rep0 + a.t_off_min);
+  int32_t* const max0 = (int32_t*)(rep0 + a.t_off_max);
+  for (uint32_t r = 1; r < K; ++r) {
+    const char* rep = smem + (size_t)r * a.copy_bytes;
+    for (uint32_t e = t; e < E; e += kLdsBlock) {
+      const uint32_t rows = ((const uint32_t*)(rep + a.t_off_rows))[e];
+      if (!rows) continue;
+      uint32_t e0 = e;
+      if (kBase) {
+        const int64_t fk = ((const int64_t*)(rep + a.t_off_keys))[e];
+        e0 = lds_key_slot(keys0, E, fk, lds_key_mix(fk));
+        if (e0 == kNoSlot) {  // the replicas together hold more groups than one does
+          if (atomicExch((uint32_t*)s_full, 1u) == 0u) atomicExch(d_err + 1, 1);
+          continue;
+        }
+      }
+      atomicAdd(rows0 + e0, rows);
+#pragma unroll
+      for (int c = 0; c < NV; ++c) {
+        const uint32_t cn = ((const uint32_t*)(rep + a.t_off_cnt))[c * E + e];
+        if (!cn) continue;
+        atomicAdd(cnt0 + c * E + e0, cn);
+        atomicAdd(sum0 + c * E + e0, ((const unsigned long long*)(rep + a.t_off_sum))[c * E + e]);
+        if (MM) {
+          atomicMin(min0 + c * E + e0, ((const int32_t*)(rep + a.t_off_min))[c * E + e]);
+          atomicMax(max0 + c * E + e0, ((const int32_t*)(rep + a.t_off_max))[c * E + e]);
+        }
+      }
+    }
+    __syncthreads();  // (baseline: inserts into replica 0 of one round must be visible to the next)
+    if (*s_full) return;
+  }
+
+  // ---- merge every live entry of replica 0 into the output table with the reduce rule (as k_groupby_lds does)
+  for (uint32_t e = t; e < E; e += kLdsBlock) {
+    const uint32_t rows = rows0[e];
+    if (!rows) continue;
+    int64_t key0 = 0, key1 = 0, key2 = 0;
+    int64_t* slots;
+    if (kBase) {
+      key0 = keys0[e];
+      slots = baseline_find_or_insert(out, n_entries, p.row_quad, p.key_width, key0);
+      if (!slots) {
+        atomicCAS(d_err, 0, -1);  // out of group slots: the caller grows the table and retries
+        continue;
+      }
+    } else {
+      int64_t tk0 = 0, tk1 = 0, tk2 = 0;
+      if (e_lo + e >= n_entries) continue;  // (padding of the last window)
+      uint32_t rem = e_lo + e;
+#pragma unroll
+      for (int g = NK - 1; g >= 0; --g) {  // entry index -> key components (mul_g ascending with g)
+        const uint32_t d = rem / kmul[g];
+        rem -= d * kmul[g];
+        const int64_t tk = (int64_t)d + a.key_min[g];
+        const int64_t orig = (ktr[g] && tk == a.key_null_key[g]) ? (int64_t)INT32_MIN : tk;
+        if (g == 0) { tk0 = tk; key0 = orig; } else if (g == 1) { tk1 = tk; key1 = orig; } else { tk2 = tk; key2 = orig; }
+      }
+      int64_t* row = out + (size_t)(e_lo + e) * p.row_quad;
+      if (!p.keyless) {
+        if (MQ_LOAD64(row) == kEmptyKey64) {
+          if (NK > 2) MQ_STORE64(row + 2, tk2);
+          if (NK > 1) MQ_STORE64(row + 1, tk1);
+          MQ_STORE64(row, tk0);
+        }
+        slots = row + NK;
+      } else {
+        slots = row;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MI355Q_MAX_TARGETS; ++i) {
+      if (i >= p.n_targets) break;
+      const DevTarget& tg = p.targets[i];
+      if (tg.slot < 0) continue;
+      int64_t v0 = p.init_vals[tg.slot], v1 = tg.agg == MI355Q_AVG ? p.init_vals[tg.slot + 1] : 0;
+      if (tg.agg == MI355Q_PROJECT_KEY) {
+        v0 = tg.key_idx == 0 ? key0 : tg.key_idx == 1 ? key1 : key2;
+      } else {
+        const int c = a.target_v[i];
+        if (c < 0) {
+          v0 = (int64_t)rows;
+        } else {
+          const uint32_t cnt = cnt0[(uint32_t)c * E + e];
+          switch (tg.agg) {
+            case MI355Q_COUNT: v0 = (int64_t)cnt; break;
+            case MI355Q_AVG:
+              v1 = (int64_t)cnt;
+              [[fallthrough]];
+            case MI355Q_SUM:
+              if (cnt) v0 = (int64_t)sum0[(uint32_t)c * E + e];
+              break;
+            case MI355Q_MIN:
+              if (cnt && MM) v0 = (int64_t)min0[(uint32_t)c * E + e];
+              break;
+            default:
+              if (cnt && MM) v0 = (int64_t)max0[(uint32_t)c * E + e];
+          }
+        }
+      }
+      int64_t win2[2] = {v0, v1};
+      DevTarget lt = tg;
+      lt.slot = 0;
+      reduce_target<true>(lt, p.init_vals + tg.slot, slots + tg.slot, win2);
+    }
+  }
+}
+
+bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out) {
   LdsArgs& a = *out;
   std::memset(&a, 0, sizeof(a));
   a.windows = 1;
@@ -576,39 +921,123 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, LdsArgs* out) {
     }
     return (off + 15u) & ~15u;
   };
-  a.copy_bytes = lay_out(a.entries);
+  // typed member (k_groupby_lds_typed): no quals, 1 - 3 plain INT32 value columns; perfect hash over INT32 keys whose
+  // ranges keep the index arithmetic in 32 bits, or a baseline table over one BIGINT / DOUBLE / FLOAT / INT key
+  a.typed = a.n_flt == 0 && a.n_vals >= 1 && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
+  a.mm = 0;
+  for (int c = 0; c < a.n_vals; ++c) {
+    a.typed = a.typed && a.v[c].type == MI355Q_INT32;
+    a.mm |= (need[c][2] || need[c][3]) ? 1 : 0;
+  }
+  if (!a.baseline)
+    for (int g = 0; g < a.n_keys; ++g)
+      a.typed = a.typed && a.key_type[g] == MI355Q_INT32 && a.key_min[g] > -(1ll << 30) && a.key_min[g] < (1ll << 30) &&
+                a.key_card[g] >= 1 && a.key_card[g] <= 65536 && a.key_mul[g] >= 1 && a.key_mul[g] <= 65536;
+  auto lay_out_typed = [&](uint32_t entries) -> uint32_t {
+    const uint32_t nv = (uint32_t)a.n_vals;
+    uint32_t off = 0;
+    a.entries = entries;
+    a.t_off_keys = 0;
+    if (a.baseline) off += entries * 8;
+    a.t_off_sum = off;
+    off += nv * entries * 8;
+    a.t_off_rows = off;
+    off += entries * 4;
+    a.t_off_cnt = off;
+    off += nv * entries * 4;
+    a.t_off_min = a.t_off_max = 0;
+    if (a.mm) {
+      a.t_off_min = off;
+      off += nv * entries * 4;
+      a.t_off_max = off;
+      off += nv * entries * 4;
+    }
+    return (off + 15u) & ~15u;
+  };
+  auto lay = [&](uint32_t entries) -> uint32_t { return a.typed ? lay_out_typed(entries) : lay_out(entries); };
+  a.copy_bytes = lay(a.entries);
   // (second baseline attempt: the largest power-of-two replica the accumulators leave room for)
-  while (a.baseline && a.copy_bytes > kLdsBudget && a.entries > kLdsHashSmall) a.copy_bytes = lay_out(a.entries / 2);
+  while (a.baseline && a.copy_bytes > kLdsBudget && a.entries > kLdsHashSmall) a.copy_bytes = lay(a.entries / 2);
   // a perfect-hash table larger than the LDS: the fewest windows whose share fits (one replica each)
   if (!a.baseline && a.copy_bytes > kLdsBudget) {
     const uint32_t total = (uint32_t)p.entry_count;
     for (uint32_t T = 2; T <= kLdsMaxWindows; ++T) {
       const uint32_t share = (total + T - 1) / T;
-      if (lay_out(share) <= kLdsBudget) {
+      if (lay(share) <= kLdsBudget) {
         a.windows = T;
-        a.copy_bytes = lay_out(share);
+        a.copy_bytes = lay(share);
         break;
       }
     }
-    if (a.windows == 1) a.copy_bytes = lay_out(total);  // (does not fit: refused below)
+    if (a.windows == 1) a.copy_bytes = lay(total);  // (does not fit: refused below)
   }
   if (a.copy_bytes > kLdsBudget) return false;
   a.copies_lg = 0;
   while (a.copies_lg < 6 && ((size_t)a.copy_bytes << (a.copies_lg + 1)) <= kLdsBudget) ++a.copies_lg;
+  // the per-entry row / non-NULL counters are 32 bits wide per workgroup: a stripe must stay below 2^32 rows (ADVICE r03;
+  // only reachable with a handful of workgroups — tune_cus, or eight windows on a small device — and > 4 G rows)
+  {
+    int64_t stripes = (n_cus > 0 ? n_cus : 1) / (int64_t)a.windows;
+    if (stripes < 1) stripes = 1;
+    if (fv.total_rows / stripes >= 0xfff00000ll) return false;
+  }
   return a.n_flt + a.n_keys + a.n_vals <= 8;
 }
 
 }  // namespace
 
-bool lds_groupby_eligible(const DevPlan& p, const FragView& fv) {
+bool lds_groupby_eligible(const DevPlan& p, const FragView& fv, int n_cus) {
   LdsArgs a;
-  return make_lds_args(p, fv, &a);
+  return make_lds_args(p, fv, n_cus, &a);
 }
+
+namespace {
+struct LdsLaunch {
+  const FragView& fv;
+  const LdsArgs& a;
+  const DevPlan& p;
+  int64_t* out;
+  int32_t* d_err;
+  int grid;
+  size_t lds;
+  hipStream_t s;
+};
+template <int KK, int NK, int NV, bool MM>
+void launch_typed_member(const LdsLaunch& l) {
+  // two quads per lane and column while the tile (this one and the next in flight) stays within ~64 registers
+  constexpr int UQ = (NK * (KK == 1 ? 2 : 1) + NV) <= 3 ? 2 : 1;
+  auto k = k_groupby_lds_typed<KK, NK, NV, MM, UQ>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds);
+  hipLaunchKernelGGL(k, dim3(l.grid), dim3(kLdsBlock), l.lds, l.s, l.fv.d_cols, l.fv.d_num_rows, l.fv.n_frags, l.fv.n_cols,
+                     l.a, l.p, l.out, l.d_err);
+}
+template <int KK, int NK>
+void launch_typed_nv(const LdsLaunch& l) {
+  const bool mm = l.a.mm != 0;
+  switch (l.a.n_vals) {
+    case 1: mm ? launch_typed_member<KK, NK, 1, true>(l) : launch_typed_member<KK, NK, 1, false>(l); break;
+    case 2: mm ? launch_typed_member<KK, NK, 2, true>(l) : launch_typed_member<KK, NK, 2, false>(l); break;
+    default: mm ? launch_typed_member<KK, NK, 3, true>(l) : launch_typed_member<KK, NK, 3, false>(l);
+  }
+}
+void launch_typed(const LdsLaunch& l) {
+  if (!l.a.baseline) {
+    if (l.a.n_keys == 1) launch_typed_nv<0, 1>(l);
+    else if (l.a.n_keys == 2) launch_typed_nv<0, 2>(l);
+    else launch_typed_nv<0, 3>(l);
+  } else {
+    const int kt = l.a.key_type[0];
+    if (kt == MI355Q_INT64 || kt == MI355Q_DOUBLE) launch_typed_nv<1, 1>(l);
+    else if (kt == MI355Q_FLOAT) launch_typed_nv<2, 1>(l);
+    else launch_typed_nv<3, 1>(l);
+  }
+}
+}  // namespace
 
 hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int n_cus,
                               hipStream_t s, LaunchStats* st) {
   LdsArgs a;
-  if (!make_lds_args(p, fv, &a)) return hipErrorInvalidValue;
+  if (!make_lds_args(p, fv, n_cus, &a)) return hipErrorInvalidValue;
   const size_t lds = ((size_t)a.copy_bytes << a.copies_lg) + 16;  // + the workgroup's "a replica is full" word
   int64_t want = (fv.total_rows / 4 + kLdsBlock - 1) / kLdsBlock;
   if (want < 1) want = 1;
@@ -620,7 +1049,7 @@ hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out
   const int grid = (int)stripes * T;
   st->kernel_name = "k_groupby_lds";
   st->n_launches = 1;
-  st->variant = 4;
+  st->variant = a.typed ? 5 : 4;  // 5: a typed member (k_groupby_lds_typed)
   rec(st->k_start, s);
   const int streams = a.n_flt + a.n_keys + a.n_vals;
 #define MQ_LDS_LAUNCH(NF, NK, NV, UQ)                                                                                \
@@ -631,7 +1060,8 @@ hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out
                        out, d_err);                                                                                  \
   } while (0)
   (void)streams;
-  if (a.n_flt <= 1 && a.n_keys == 1 && a.n_vals <= 1) MQ_LDS_LAUNCH(1, 1, 1, 2);       // PHS / BH shapes
+  if (a.typed) launch_typed(LdsLaunch{fv, a, p, out, d_err, grid, lds, s});
+  else if (a.n_flt <= 1 && a.n_keys == 1 && a.n_vals <= 1) MQ_LDS_LAUNCH(1, 1, 1, 2);       // PHS / BH shapes
   else if (a.n_flt <= 1 && a.n_vals <= 1) MQ_LDS_LAUNCH(1, 3, 1, 1);                     // PHM shapes
   else if (a.n_flt <= 1 && a.n_keys == 1) MQ_LDS_LAUNCH(1, 1, 3, 1);                     // MultiStep, one key
   else MQ_LDS_LAUNCH(4, 3, 3, 1);

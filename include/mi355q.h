@@ -436,6 +436,8 @@ typedef struct mi355q_exec_options {
                                             uses 256-slot replicas, many of them, for tables with a handful of groups) */
 #define MI355Q_OPT_LDS_BASELINE_WINDOWS 32u /* ... third attempt: the groups spread over 8 windows (classes of a key hash),
                                             one workgroup per window and row stripe, the largest replica each */
+#define MI355Q_OPT_LDS_GENERIC_MEMBER 64u /* few-groups LDS GROUP BY: the run-time-role member even where a typed member
+                                            (roles compiled in) applies (tests compare the two) */
 
 /* per-call timing/selection report (what launchGpuCode logs,
  * QueryExecutionContext.cpp:334,364,579) */

@@ -159,7 +159,7 @@ hipError_t launch_perfect_lds(const DevPlan& p, const FragView& fv, int64_t* out
   finish(p, fv, out, d_err, st, "k_perfect_lds", 0, F_PERFECT_LDS);
   return hipSuccess;
 }
-bool lds_groupby_eligible(const DevPlan& p, const FragView&) {
+bool lds_groupby_eligible(const DevPlan& p, const FragView&, int) {
   if (!on(F_LDS_GROUPBY) || p.join_col >= 0 || p.col0_key_quirk || p.slot_width != 8 || p.n_quals > MI355Q_MAX_QUALS) return false;
   for (int i = 0; i < p.n_quals; ++i)
     if (p.quals[i].type != MI355Q_INT32 && p.quals[i].type != MI355Q_INT64) return false;

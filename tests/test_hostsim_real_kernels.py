@@ -61,14 +61,32 @@ def test_zz_every_real_family_ran():
 
 
 # ---- tables that do not fit one LDS: windows (perfect hash: ranges of the entry index; baseline: classes of a key hash)
+@pytest.mark.parametrize("member", ["typed", "generic"])
 @pytest.mark.parametrize("name", ["PHS004", "PHM003", "BH004", "BH007", "MSPHS002", "MSPHM002", "MSBS002"])
-def test_windowed_lds_groupby_on_ten_thousand_groups(sim, oracle, name):
-    """the reference benchmark's 10 K-group shapes at their real cardinality: 3 - 8 windows per table"""
+def test_windowed_lds_groupby_on_ten_thousand_groups(sim, oracle, name, member):
+    """the reference benchmark's 10 K-group shapes at their real cardinality: 2 - 8 windows per table, through the typed
+    member (roles compiled in, report.variant 5) and the run-time-role member (MI355Q_OPT_LDS_GENERIC_MEMBER, variant 4)"""
     case = flow._refbench_case(oracle, name, 40000, 10000)
-    rs = flow._check(oracle, case, kernel_variant=0)
+    rs = flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_LDS_GENERIC_MEMBER if member == "generic" else 0)
     assert rs is not None
     assert rs.report.kernel_name.decode() == "k_groupby_lds", rs.report.kernel_name
+    assert rs.report.variant == (4 if member == "generic" else 5), rs.report.variant
     assert rs.rowCount() > 4096
+
+
+LDS_SHAPES = ["PHS001", "PHS003", "PHM001", "PHM002", "BH001", "BH003", "MSBS001", "MSPHS001", "MSPHM001"]
+
+
+@pytest.mark.parametrize("member", ["typed", "generic"])
+@pytest.mark.parametrize("name", LDS_SHAPES)
+def test_small_lds_groupby_both_members(sim, oracle, name, member):
+    """the few-groups shapes (replicated tables) through both members; odd row counts so that the quad remainder and the
+    tail rows of every fragment are visited"""
+    case = flow._refbench_case(oracle, name, 9001, 700)
+    rs = flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_LDS_GENERIC_MEMBER if member == "generic" else 0)
+    assert rs is not None
+    if rs.report.kernel_name.decode() == "k_groupby_lds":
+        assert rs.report.variant == (4 if member == "generic" else 5), rs.report.variant
 
 
 def test_windowed_baseline_gives_up_beyond_eight_windows(sim, oracle):

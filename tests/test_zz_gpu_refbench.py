@@ -28,7 +28,7 @@ def torch_cuda():
     return torch
 
 
-def _run(torch, oracle, name, n_rows, card_cap, variant):
+def _run(torch, oracle, name, n_rows, card_cap, variant, flags=0, report=None):
     from heavydb_amd.executor import Executor, FetchResult
     names, descs, gens = refbench.schema(card_cap)
     cols = [oracle.generate_column(n_rows, g[0], g[1], g[2], g[3], g[4], g[5]) for g in gens]
@@ -41,9 +41,11 @@ def _run(torch, oracle, name, n_rows, card_cap, variant):
     es = [t.element_size() for t in dev]
     fr = FetchResult([[int(t.data_ptr()) for t in dev], [int(t.data_ptr()) + cut * e for t, e in zip(dev, es)]],
                      [cut, n_rows - cut], keepalive=dev)
-    rs = Executor(0).executeWorkUnit(ra, fr, kernel_variant=variant)
+    rs = Executor(0).executeWorkUnit(ra, fr, kernel_variant=variant, flags=flags)
     compare_buffers(q, want, rs.getStorage(), 1e-9)
     compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
+    if report is not None:
+        report["variant"] = int(rs.report.variant)
     return rs.report.kernel_name.decode()
 
 
@@ -53,12 +55,30 @@ def test_refbench_queries_small(torch_cuda, oracle, name, variant):
     _run(torch_cuda, oracle, name, 30_000, 3_000, variant)
 
 
+@pytest.mark.parametrize("member", ["typed", "generic"])
 @pytest.mark.parametrize("name", ["PHS004", "PHM003", "BH004", "BH007", "MSPHS002", "MSPHM002", "MSBS002"])
-def test_refbench_windowed_lds_groupby(torch_cuda, oracle, name):
-    """the 10 K-group shapes at their real cardinality: tables that do not fit one LDS run as 3 - 8 windows of
-    k_groupby_lds (perfect hash: ranges of the entry index; baseline, FLOAT / DOUBLE / BIGINT key: classes of a key hash)"""
-    kernel = _run(torch_cuda, oracle, name, 400_000, 10_000, 0)
+def test_refbench_windowed_lds_groupby(torch_cuda, oracle, name, member):
+    """the 10 K-group shapes at their real cardinality: tables that do not fit one LDS run as 2 - 8 windows of
+    k_groupby_lds (perfect hash: ranges of the entry index; baseline, FLOAT / DOUBLE / BIGINT key: classes of a key hash),
+    through the typed member (roles compiled in, variant 5) and the run-time-role member (variant 4)"""
+    rep = {}
+    kernel = _run(torch_cuda, oracle, name, 400_000, 10_000, 0,
+                  flags=capi.OPT_LDS_GENERIC_MEMBER if member == "generic" else 0, report=rep)
     assert kernel == "k_groupby_lds", kernel
+    assert rep["variant"] == (4 if member == "generic" else 5), rep
+
+
+@pytest.mark.parametrize("member", ["typed", "generic"])
+@pytest.mark.parametrize("name", ["PHS001", "PHS002", "PHS003", "PHM001", "PHM002", "BH001", "BH002", "BH003", "MSBS001",
+                                  "MSPHS001", "MSPHM001"])
+def test_refbench_small_lds_groupby_both_members(torch_cuda, oracle, name, member):
+    """the few-groups shapes (table replicated K times per workgroup) at 3 M rows (odd count: quad remainder and tail rows),
+    every member of the typed family the benchmark reaches against the oracle"""
+    rep = {}
+    kernel = _run(torch_cuda, oracle, name, 3_000_003, 0, 0,
+                  flags=capi.OPT_LDS_GENERIC_MEMBER if member == "generic" else 0, report=rep)
+    if kernel == "k_groupby_lds":
+        assert rep["variant"] == (4 if member == "generic" else 5), rep
 
 
 @pytest.mark.parametrize("name", ["NGA02", "NGA05", "PHS003", "PHS004", "PHS006", "PHM004", "BH002", "BH004", "BH006",
