@@ -1640,10 +1640,21 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
     if (off > col_region) return MI355Q_ERR_OUT_OF_GPU_MEM;  // (cannot happen: the region is sized for it)
     const int pnf = f1 - f;
     HIP_TRY(hipMemcpyAsync(d_tab, cols2.data(), sizeof(void*) * (size_t)pnf * nc2, hipMemcpyHostToDevice, s));
-    HIP_TRY(launch_project(xs, d, qual_expr_mask, d_tab, d_rows + f, pnf, max_frag_rows, d_err, n_cus, s));
-    int32_t h_err = 0;
-    HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+    // one-operation expressions over aligned plain columns: the vectorised members (k_project_simple); an overflow there
+    // only raises word 2 and the interpreter (which knows whether the offending row counts) runs after all
+    bool simple = project_simple_shapes(xs) && !o.force_generic;
+    for (size_t i = 0; simple && i < (size_t)pnf * nc2; ++i) simple = ((uintptr_t)cols2[i] & 15) == 0;
+    HIP_TRY(launch_project(xs, d, qual_expr_mask, d_tab, d_rows + f, pnf, max_frag_rows, d_err, n_cus, s, simple));
+    int32_t h_err3[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h_err3, d_err, sizeof(h_err3), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));  // (cols2 is re-used by the next pass; the step below synchronises anyway)
+    if (simple && h_err3[2]) {
+      HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
+      HIP_TRY(launch_project(xs, d, qual_expr_mask, d_tab, d_rows + f, pnf, max_frag_rows, d_err, n_cus, s, false));
+      HIP_TRY(hipMemcpyAsync(h_err3, d_err, sizeof(h_err3), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+    }
+    const int32_t h_err = h_err3[0];
     if (h_err) return h_err;
     mi355q_inputs in2 = *in;
     in2.n_frags = pnf;

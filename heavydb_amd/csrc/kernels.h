@@ -118,7 +118,9 @@ hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_
 // device plan of the LOWERED plan (quals, join): it decides whether a row's overflow counts.
 hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_expr_mask, const int8_t* const* d_cols,
                           const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_err, int n_cus,
-                          hipStream_t s);
+                          hipStream_t s, bool simple = false);
+// every expression is CAST(plain INT / BIGINT column AS DOUBLE | FLOAT) or column + - * literal (k_project_simple)
+bool project_simple_shapes(const DevExprSet& xs);
 // tmp: table of the packed single-key step (rows = packed key + slot_count slots); out: the
 // initialised final table described by p
 hipError_t launch_unpack_emit(const PackSpec& ps, const DevPlan& p, const int64_t* tmp, int64_t tmp_entries,

@@ -552,46 +552,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   for (int c = 0; c < NV; ++c) vnull[c] = a.v[c].nullable != 0;
   const uint32_t n_entries = (uint32_t)p.entry_count;
 
-  // one row: klo = the low (or only) 32 bits of each key column's value, khi = the high word of an 8-byte key
-  auto one_row = [&](const int32_t (&klo)[NK], int32_t khi, const int32_t (&vv)[NV]) {
-    uint32_t e;
-    if constexpr (kBase) {
-      int64_t key;
-      if constexpr (KK == 1) key = (int64_t)(((uint64_t)(uint32_t)khi << 32) | (uint64_t)(uint32_t)klo[0]);
-      else if constexpr (KK == 2) key = dbl_bits((double)bits_flt(klo[0]));
-      else key = (int64_t)klo[0];
-      const uint32_t h = lds_key_mix(key);
-      if (T > 1 && lds_mix_window(T, h) != win) return;  // another window's row: nothing else of it is looked at
-      if (full || *s_full) {  // (see k_groupby_lds: a lost attempt is abandoned by everybody at the first overflow)
-        full = true;
-        return;
-      }
-      e = lds_key_slot(my_keys, E, key, h);
-      if (e == kNoSlot) {
-        if (atomicExch((uint32_t*)s_full, 1u) == 0u) atomicExch(d_err + 1, 1);
-        full = true;
-        return;
-      }
-    } else {
-      // 32-bit throughout: make_lds_args admits |key_min| < 2^30 and cardinalities <= 65 536, so `k - min` taken modulo
-      // 2^32 is either the true difference or >= 2^30 (out of range), and the entry index stays below 2^32
-      uint32_t idx = 0;
-      bool in_range = true;
-#pragma unroll
-      for (int g = 0; g < NK; ++g) {
-        uint32_t ku = (uint32_t)klo[g];
-        if (ktr[g] && klo[g] == INT32_MIN) ku = knull[g];
-        const uint32_t d = ku - kmin[g];
-        in_range = in_range && d < kcard[g];
-        idx += d * kmul[g];
-      }
-      if (!in_range || idx >= n_entries) {
-        bad = true;
-        return;
-      }
-      e = idx - e_lo;
-      if (e >= E) return;  // another window's row
-    }
+  // entry e takes one row's values
+  auto update = [&](uint32_t e, const int32_t (&vv)[NV]) {
     atomicAdd(my_rows + e, 1u);
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
@@ -604,6 +566,61 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
         atomicMax(my_max + c * E + e, v);
       }
     }
+  };
+  // baseline: the 8-byte key a row groups by, from the low (or only) word klo and the high word khi of the column value
+  auto key_of = [&](int32_t klo, int32_t khi) -> int64_t {
+    if constexpr (KK == 1) return (int64_t)(((uint64_t)(uint32_t)khi << 32) | (uint64_t)(uint32_t)klo);
+    else if constexpr (KK == 2) return dbl_bits((double)bits_flt(klo));
+    else return (int64_t)klo;
+  };
+  // baseline, the first probe missed (a new group, or a collision): insert-or-find.  kNoSlot = the attempt is lost — as
+  // soon as ONE lane of the workgroup finds a replica full everybody else learns it from an LDS word instead of walking
+  // a full key array itself, and the global flag is raised once per workgroup (see k_groupby_lds)
+  auto slow_locate = [&](int64_t key, uint32_t h) -> uint32_t {
+    if (full || *s_full) {
+      full = true;
+      return kNoSlot;
+    }
+    const uint32_t e = lds_key_slot(my_keys, E, key, h);
+    if (e == kNoSlot) {
+      if (atomicExch((uint32_t*)s_full, 1u) == 0u) atomicExch(d_err + 1, 1);
+      full = true;
+    }
+    return e;
+  };
+  // perfect hash: the entry of a row (32-bit throughout: make_lds_args admits |key_min| < 2^30 and cardinalities <= 65 536,
+  // so `k - min` taken modulo 2^32 is either the true difference or >= 2^30 (out of range), and the entry index stays
+  // below 2^32); kNoSlot = another window's row, or (bad) a key outside its declared range
+  auto perfect_entry = [&](const int32_t (&klo)[NK]) -> uint32_t {
+    uint32_t idx = 0;
+    bool in_range = true;
+#pragma unroll
+    for (int g = 0; g < NK; ++g) {
+      uint32_t ku = (uint32_t)klo[g];
+      if (ktr[g] && klo[g] == INT32_MIN) ku = knull[g];
+      const uint32_t d = ku - kmin[g];
+      in_range = in_range && d < kcard[g];
+      idx += d * kmul[g];
+    }
+    if (!in_range || idx >= n_entries) {
+      bad = true;
+      return kNoSlot;
+    }
+    const uint32_t e = idx - e_lo;
+    return e < E ? e : kNoSlot;
+  };
+  // one row on its own (quad remainders, tail rows)
+  auto one_row = [&](const int32_t (&klo)[NK], int32_t khi, const int32_t (&vv)[NV]) {
+    uint32_t e;
+    if constexpr (kBase) {
+      const int64_t key = key_of(klo[0], khi);
+      const uint32_t h = lds_key_mix(key);
+      if (T > 1 && lds_mix_window(T, h) != win) return;  // another window's row: nothing else of it is looked at
+      e = slow_locate(key, h);
+    } else {
+      e = perfect_entry(klo);
+    }
+    if (e != kNoSlot) update(e, vv);
   };
 
   struct Tile {
@@ -641,22 +658,47 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
         if (u >= n_quads) break;
+        if constexpr (kBase) {
+          // the four rows of a quad together: keys and hashes first, then the four first-probe reads of the key array
+          // in one go (one LDS round trip instead of four dependent ones — a wave's step is a chain of latencies, and
+          // with eight windows it is walked eight times per row), then the updates; a miss takes the insert-or-find walk
+          int64_t key[4], k0[4];
+          uint32_t hh[4];
+          bool acc[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          int32_t klo[NK], vv[NV];
-          int32_t khi = 0;
-#pragma unroll
-          for (int g = 0; g < NK; ++g) {
-            if constexpr (KK == 1) {  // four int64 in two 16-byte words: row i = words (2i, 2i + 1)
-              klo[g] = v4_get(tl.k[g][u][i >> 1], (i & 1) * 2);
-              khi = v4_get(tl.k[g][u][i >> 1], (i & 1) * 2 + 1);
-            } else {
-              klo[g] = v4_get(tl.k[g][u][0], i);
-            }
+          for (int i = 0; i < 4; ++i) {
+            if constexpr (KK == 1) key[i] = key_of(v4_get(tl.k[0][u][i >> 1], (i & 1) * 2), v4_get(tl.k[0][u][i >> 1], (i & 1) * 2 + 1));
+            else key[i] = key_of(v4_get(tl.k[0][u][0], i), 0);
+            hh[i] = lds_key_mix(key[i]);
+            acc[i] = !(T > 1 && lds_mix_window(T, hh[i]) != win);
           }
 #pragma unroll
-          for (int c = 0; c < NV; ++c) vv[c] = v4_get(tl.v[c][u], i);
-          one_row(klo, khi, vv);
+          for (int i = 0; i < 4; ++i) k0[i] = acc[i] ? *(volatile int64_t*)&my_keys[hh[i] & (E - 1)] : kEmptyKey64;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            if (!acc[i]) continue;
+            uint32_t e = hh[i] & (E - 1);
+            if (k0[i] != key[i]) {
+              e = slow_locate(key[i], hh[i]);
+              if (e == kNoSlot) continue;
+            }
+            int32_t vv[NV];
+#pragma unroll
+            for (int c = 0; c < NV; ++c) vv[c] = v4_get(tl.v[c][u], i);
+            update(e, vv);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int32_t klo[NK], vv[NV];
+#pragma unroll
+            for (int g = 0; g < NK; ++g) klo[g] = v4_get(tl.k[g][u][0], i);
+            const uint32_t e = perfect_entry(klo);
+            if (e == kNoSlot) continue;
+#pragma unroll
+            for (int c = 0; c < NV; ++c) vv[c] = v4_get(tl.v[c][u], i);
+            update(e, vv);
+          }
         }
       }
     };
