@@ -17,34 +17,12 @@ namespace mi355q_glue {
 
 namespace {
 
-[[noreturn]] void unsupported(const char* what) { throw std::runtime_error(std::string("mi355q: ") + what); }
-
 void check(int32_t code) {
   if (code) throw QueryExecutionError(code);  // heavyai::ErrorCode values; < 0 = out of group slots
 }
 
-// the chunk's STORAGE type (ColumnFetcher hands chunks over undecoded)
-int32_t storage_type(const SQLTypeInfo& ti) {
-  if (ti.get_type() == kDOUBLE) return MI355Q_DOUBLE;
-  if (ti.get_type() == kFLOAT) return MI355Q_FLOAT;
-  switch (ti.get_size()) {
-    case 1: return MI355Q_INT8;
-    case 2: return MI355Q_INT16;
-    case 4: return MI355Q_INT32;
-    case 8: return MI355Q_INT64;
-    default: unsupported("column width");
-  }
-}
-int32_t logical_type(const SQLTypeInfo& ti) {
-  if (ti.get_type() == kDOUBLE) return MI355Q_DOUBLE;
-  if (ti.get_type() == kFLOAT) return MI355Q_FLOAT;
-  switch (ti.get_logical_size()) {
-    case 1: return MI355Q_INT8;
-    case 2: return MI355Q_INT16;
-    case 4: return MI355Q_INT32;
-    default: return MI355Q_INT64;
-  }
-}
+// (storage_type / logical_type / agg_kind / emit_expr / translate_qual / translate_agg: Mi355qTranslate.h — the half of
+// this binding that compiles against the reference's own headers in this image)
 
 mi355q_range to_range(const ExpressionRange& r) {
   mi355q_range out{};
@@ -67,47 +45,17 @@ struct Translator {
   const Executor* executor;
   mi355q_plan& p;
   // (table_id, column_id) of every outer / inner input column, in input_col_descs order = FetchResult column order
-  std::vector<std::pair<int, int>> outer_cols, inner_cols;
+  std::vector<shared::ColumnKey> outer_cols, inner_cols;
   std::vector<const Analyzer::Expr*> expr_of;  // expression k of the plan (structural identity by pointer)
 
-  int find(const std::vector<std::pair<int, int>>& v, const shared::ColumnKey& k) const {
+  int find(const std::vector<shared::ColumnKey>& v, const shared::ColumnKey& k) const {
     for (size_t i = 0; i < v.size(); ++i)
-      if (v[i].first == k.table_id && v[i].second == k.column_id) return (int)i;
+      if (v[i].db_id == k.db_id && v[i].table_id == k.table_id && v[i].column_id == k.column_id) return (int)i;
     unsupported("column is not among input_col_descs");
   }
 
-  // postfix program of a value expression over OUTER columns (CodeGenerator::codegenCast / codegenArith shapes)
   void emit(const Analyzer::Expr* e, mi355q_expr& x) {
-    auto push = [&](int32_t op, int32_t type, int32_t arg, int64_t ilit, double flit) {
-      if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) unsupported("expression too long");
-      x.nodes[x.n_nodes++] = mi355q_expr_node{op, type, arg, 0, ilit, flit};
-    };
-    if (auto cv = dynamic_cast<const Analyzer::ColumnVar*>(e)) {
-      if (cv->get_rte_idx() != 0) unsupported("expression over an inner column");
-      push(MI355Q_EX_COL, 0, find(outer_cols, cv->getColumnKey()), 0, 0.0);
-    } else if (auto c = dynamic_cast<const Analyzer::Constant*>(e)) {
-      if (c->get_is_null()) unsupported("NULL literal");
-      const auto& ti = c->get_type_info();
-      const Datum d = c->get_constval();
-      const int32_t t = logical_type(ti);
-      if (t == MI355Q_DOUBLE) push(MI355Q_EX_LIT, t, 0, 0, d.doubleval);
-      else if (t == MI355Q_FLOAT) push(MI355Q_EX_LIT, t, 0, 0, d.floatval);
-      else push(MI355Q_EX_LIT, t, 0, t == MI355Q_INT8 ? d.tinyintval : t == MI355Q_INT16 ? d.smallintval
-                                     : t == MI355Q_INT32 ? d.intval : d.bigintval, 0.0);
-    } else if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
-      if (u->get_optype() != kCAST) unsupported("unary operator");
-      emit(u->get_operand(), x);
-      push(MI355Q_EX_CAST, logical_type(u->get_type_info()), 0, 0, 0.0);
-    } else if (auto b = dynamic_cast<const Analyzer::BinOper*>(e)) {
-      const int32_t op = b->get_optype() == kPLUS ? MI355Q_EX_ADD : b->get_optype() == kMINUS ? MI355Q_EX_SUB
-                         : b->get_optype() == kMULTIPLY ? MI355Q_EX_MUL : 0;
-      if (!op) unsupported("binary operator");
-      emit(b->get_left_operand(), x);
-      emit(b->get_right_operand(), x);
-      push(op, logical_type(b->get_type_info()), 0, 0, 0.0);
-    } else {
-      unsupported("expression kind");
-    }
+    emit_expr(e, x, [this](const Analyzer::ColumnVar* cv) { return find(outer_cols, cv->getColumnKey()); });
   }
 
   // outer column index of a value expression: a plain column, or the virtual column of a projected expression
@@ -129,38 +77,7 @@ struct Translator {
 
   // simple_quals / quals entry: <value> <cmp> <literal>, <value> IS NULL, NOT(<value> IS NULL)
   mi355q_qual qual(const Analyzer::Expr* e) {
-    mi355q_qual q{};
-    if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
-      if (u->get_optype() == kISNULL) {
-        q.col = value_col(u->get_operand());
-        q.op = MI355Q_IS_NULL;
-        return q;
-      }
-      if (u->get_optype() == kNOT) {  // RelAlgTranslator builds IS NOT NULL as NOT(ISNULL(x))
-        auto in = dynamic_cast<const Analyzer::UOper*>(u->get_operand());
-        if (in && in->get_optype() == kISNULL) {
-          q.col = value_col(in->get_operand());
-          q.op = MI355Q_IS_NOT_NULL;
-          return q;
-        }
-      }
-      unsupported("unary qual");
-    }
-    auto b = dynamic_cast<const Analyzer::BinOper*>(e);
-    auto lit = b ? dynamic_cast<const Analyzer::Constant*>(b->get_right_operand()) : nullptr;
-    if (!b || !lit || lit->get_is_null()) unsupported("qual shape");
-    switch (b->get_optype()) {  // SQLOps values are the ABI's (mi355q_op)
-      case kEQ: case kNE: case kLT: case kGT: case kLE: case kGE: q.op = (int32_t)b->get_optype(); break;
-      default: unsupported("comparison operator");
-    }
-    q.col = value_col(b->get_left_operand());
-    const auto& ti = lit->get_type_info();
-    const Datum d = lit->get_constval();
-    if (ti.get_type() == kDOUBLE) q.fval = d.doubleval;
-    else if (ti.get_type() == kFLOAT) q.fval = d.floatval;
-    else q.ival = ti.get_logical_size() == 1 ? d.tinyintval : ti.get_logical_size() == 2 ? d.smallintval
-                  : ti.get_logical_size() == 4 ? d.intval : d.bigintval;
-    return q;
+    return translate_qual(e, [this](const Analyzer::Expr* v) { return value_col(v); });
   }
 };
 
@@ -180,22 +97,15 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
     mi355q_col_desc cd{};
     cd.type = storage_type(ti);
     cd.nullable = !ti.get_notnull();
-    switch (ti.get_compression()) {
-      case kENCODING_FIXED:
-        cd.encoding = MI355Q_ENC_FIXED;
-        cd.logical_type = logical_type(ti);
-        break;
-      case kENCODING_DICT: cd.encoding = MI355Q_ENC_DICT; break;           // ids; 1/2-byte chunks are unsigned
-      case kENCODING_DATE_IN_DAYS: cd.encoding = MI355Q_ENC_DATE_IN_DAYS; break;
-      default: break;
-    }
+    cd.encoding = encoding_of(ti);
+    if (cd.encoding == MI355Q_ENC_FIXED) cd.logical_type = logical_type(ti);
     Analyzer::ColumnVar cv(ti, shared::ColumnKey{tk.db_id, tk.table_id, icd->getColId()}, inner ? 1 : 0);
     const mi355q_range r = to_range(getExpressionRange(&cv, query_infos, executor));
     int32_t& n = inner ? p.n_inner_cols : p.n_cols;
     if (n >= MI355Q_MAX_COLS) unsupported("too many input columns");
     (inner ? p.inner_cols : p.cols)[n] = cd;
     (inner ? p.inner_col_ranges : p.col_ranges)[n] = r;
-    (inner ? t.inner_cols : t.outer_cols).push_back({tk.table_id, icd->getColId()});
+    (inner ? t.inner_cols : t.outer_cols).push_back(shared::ColumnKey{tk.db_id, tk.table_id, icd->getColId()});
     ++n;
   }
   // groupby_exprs: {nullptr} = non-grouped; a ColumnVar or a projected expression each
@@ -218,17 +128,8 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
     mi355q_target tg{};
     tg.col = -1;
     if (auto agg = dynamic_cast<const Analyzer::AggExpr*>(te)) {
-      if (agg->get_is_distinct()) unsupported("DISTINCT aggregate");
-      tg.agg = (int32_t)agg->get_aggtype();  // SQLAgg values are the ABI's (mi355q_agg)
-      if (const auto* arg = agg->get_arg()) {
-        auto cv = dynamic_cast<const Analyzer::ColumnVar*>(arg);
-        if (cv && cv->get_rte_idx() != 0) {
-          tg.table = 1;
-          tg.col = t.find(t.inner_cols, cv->getColumnKey());
-        } else {
-          tg.col = t.value_col(arg);
-        }
-      }
+      tg = translate_agg(agg, [&t](const Analyzer::Expr* v) { return t.value_col(v); },
+                         [&t](const Analyzer::ColumnVar* cv) { return t.find(t.inner_cols, cv->getColumnKey()); });
     } else {
       tg.agg = MI355Q_PROJECT_KEY;
       int idx = -1;

@@ -17,6 +17,8 @@
 #include "QueryEngine/ResultSet.h"
 #endif
 
+#include "Mi355qTranslate.h"
+
 namespace mi355q_glue {
 
 // RelAlgExecutionUnit (RelAlgExecutionUnit.h:167-218) + chunk metadata -> mi355q_plan.  Throws

@@ -1,0 +1,218 @@
+// Mi355qTranslate.h — the type-mapping half of the HeavyDB binding: SQLTypeInfo -> mi355q_type, SQLAgg -> mi355q_agg,
+// Analyzer expressions -> mi355q_expr / mi355q_qual / mi355q_target.  Header-only, and written against NOTHING but
+//   Shared/sqltypes.h, Shared/sqldefs.h, Analyzer/Analyzer.h
+// so that it compiles against the REFERENCE'S OWN headers in this image (g++ -DNO_BOOST, the Boost-free mode
+// Logger/Logger.h provides; the way oracle/ref_layout_shim.cpp does): integration/real_headers_check.cpp builds real
+// Analyzer::ColumnVar / Constant / UOper / BinOper / AggExpr objects and runs every function below on them
+// (tests/test_integration_glue.py::test_translate_half_against_the_reference_headers).  The other half of the binding
+// (Mi355qExecutor.cpp: RelAlgExecutionUnit, InputTableInfo, getExpressionRange, ResultSet) needs headers that do NOT
+// compile here — QueryEngine/RelAlgExecutionUnit.h, InputMetadata.h, ResultSet.h, ColumnFetcher.h stop at
+// Shared/StringTransform.h:21 `#include <boost/config.hpp>` (reached through Fragmenter/../Catalog/), ExpressionRange.h
+// at :22 `#include <boost/multiprecision/cpp_int.hpp>`, JoinHashTable/HashJoin.h at :19 `#include <llvm/IR/Value.h>` —
+// and stays on integration/mock/heavydb_mock.h.
+#pragma once
+
+#include <functional>
+#include <stdexcept>
+#include <string>
+
+#include "mi355q.h"
+
+#ifndef MI355Q_GLUE_MOCK_HEADERS
+#include "Analyzer/Analyzer.h"
+#include "Shared/sqldefs.h"
+#include "Shared/sqltypes.h"
+#endif
+
+namespace mi355q_glue {
+
+[[noreturn]] inline void unsupported(const char* what) { throw std::runtime_error(std::string("mi355q: ") + what); }
+
+// Types the plan ABI cannot state are refused here instead of being read as integers of their byte width: DECIMAL /
+// NUMERIC (scale: casts, multiplication and AVG would need scale_decimal_up / _down), none-encoded strings, arrays,
+// geo, TIMESTAMP(3|6|9) and intervals.
+inline void check_supported_type(const SQLTypeInfo& ti) {
+  if (ti.is_decimal()) unsupported("DECIMAL / NUMERIC column or literal");
+  if (ti.is_array()) unsupported("array column");
+  if (ti.is_geometry()) unsupported("geo column");
+  if (ti.is_string() && ti.get_compression() != kENCODING_DICT) unsupported("none-encoded string column");
+  if (ti.is_high_precision_timestamp()) unsupported("TIMESTAMP with a dimension");
+  switch (ti.get_type()) {
+    case kBOOLEAN: case kTINYINT: case kSMALLINT: case kINT: case kBIGINT: case kFLOAT: case kDOUBLE:
+    case kDATE: case kTIME: case kTIMESTAMP: case kTEXT: case kVARCHAR: case kCHAR: break;
+    default: unsupported("column type");
+  }
+}
+
+// the chunk's STORAGE type (ColumnFetcher hands chunks over undecoded)
+inline int32_t storage_type(const SQLTypeInfo& ti) {
+  check_supported_type(ti);
+  if (ti.get_type() == kDOUBLE) return MI355Q_DOUBLE;
+  if (ti.get_type() == kFLOAT) return MI355Q_FLOAT;
+  switch (ti.get_size()) {
+    case 1: return MI355Q_INT8;
+    case 2: return MI355Q_INT16;
+    case 4: return MI355Q_INT32;
+    case 8: return MI355Q_INT64;
+    default: unsupported("column width");
+  }
+}
+inline int32_t logical_type(const SQLTypeInfo& ti) {
+  check_supported_type(ti);
+  if (ti.get_type() == kDOUBLE) return MI355Q_DOUBLE;
+  if (ti.get_type() == kFLOAT) return MI355Q_FLOAT;
+  switch (ti.get_logical_size()) {
+    case 1: return MI355Q_INT8;
+    case 2: return MI355Q_INT16;
+    case 4: return MI355Q_INT32;
+    default: return MI355Q_INT64;
+  }
+}
+inline int32_t encoding_of(const SQLTypeInfo& ti) {
+  switch (ti.get_compression()) {
+    case kENCODING_FIXED: return MI355Q_ENC_FIXED;
+    case kENCODING_DICT: return MI355Q_ENC_DICT;            // ids; 1/2-byte chunks are unsigned
+    case kENCODING_DATE_IN_DAYS: return MI355Q_ENC_DATE_IN_DAYS;
+    case kENCODING_NONE: return MI355Q_ENC_NONE;
+    default: unsupported("column encoding");
+  }
+}
+
+// SQLAgg (Shared/sqldefs.h:76-90) -> mi355q_agg.  kAVG .. kCOUNT and kCOUNT_IF / kSUM_IF carry the reference's numeric
+// values in the ABI; everything else (APPROX_*, SAMPLE, SINGLE_VALUE, MODE) is not an aggregate of this path.
+inline int32_t agg_kind(SQLAgg a) {
+  switch (a) {
+    case kAVG: return MI355Q_AVG;
+    case kMIN: return MI355Q_MIN;
+    case kMAX: return MI355Q_MAX;
+    case kSUM: return MI355Q_SUM;
+    case kCOUNT: return MI355Q_COUNT;
+    case kCOUNT_IF: return MI355Q_COUNT_IF;
+    case kSUM_IF: return MI355Q_SUM_IF;
+    default: unsupported("aggregate kind");
+  }
+}
+static_assert((int)kAVG == MI355Q_AVG && (int)kMIN == MI355Q_MIN && (int)kMAX == MI355Q_MAX && (int)kSUM == MI355Q_SUM &&
+                  (int)kCOUNT == MI355Q_COUNT && (int)kCOUNT_IF == MI355Q_COUNT_IF && (int)kSUM_IF == MI355Q_SUM_IF,
+              "mi355q_agg keeps the numeric values of SQLAgg");
+static_assert((int)kEQ == MI355Q_EQ && (int)kNE == MI355Q_NE && (int)kLT == MI355Q_LT && (int)kGT == MI355Q_GT &&
+                  (int)kLE == MI355Q_LE && (int)kGE == MI355Q_GE && (int)kISNULL == MI355Q_IS_NULL &&
+                  (int)kISNOTNULL == MI355Q_IS_NOT_NULL,
+              "mi355q_op keeps the numeric values of SQLOps");
+
+inline int64_t int_literal(const SQLTypeInfo& ti, const Datum& d) {
+  switch (ti.get_logical_size()) {
+    case 1: return d.tinyintval;
+    case 2: return d.smallintval;
+    case 4: return d.intval;
+    default: return d.bigintval;
+  }
+}
+
+// postfix program of a value expression over OUTER columns (CodeGenerator::codegenCast / codegenArith shapes).
+// `outer_col` resolves a ColumnVar of the outer table to its position among the input columns.
+inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
+                      const std::function<int(const Analyzer::ColumnVar*)>& outer_col) {
+  auto push = [&](int32_t op, int32_t type, int32_t arg, int64_t ilit, double flit) {
+    if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) unsupported("expression too long");
+    x.nodes[x.n_nodes++] = mi355q_expr_node{op, type, arg, 0, ilit, flit};
+  };
+  if (auto cv = dynamic_cast<const Analyzer::ColumnVar*>(e)) {
+    if (cv->get_rte_idx() != 0) unsupported("expression over an inner column");
+    check_supported_type(cv->get_type_info());
+    push(MI355Q_EX_COL, 0, outer_col(cv), 0, 0.0);
+  } else if (auto c = dynamic_cast<const Analyzer::Constant*>(e)) {
+    if (c->get_is_null()) unsupported("NULL literal");
+    const auto& ti = c->get_type_info();
+    const Datum d = c->get_constval();
+    const int32_t t = logical_type(ti);
+    if (t == MI355Q_DOUBLE) push(MI355Q_EX_LIT, t, 0, 0, d.doubleval);
+    else if (t == MI355Q_FLOAT) push(MI355Q_EX_LIT, t, 0, 0, d.floatval);
+    else push(MI355Q_EX_LIT, t, 0, int_literal(ti, d), 0.0);
+  } else if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
+    if (u->get_optype() != kCAST) unsupported("unary operator");
+    emit_expr(u->get_operand(), x, outer_col);
+    push(MI355Q_EX_CAST, logical_type(u->get_type_info()), 0, 0, 0.0);
+  } else if (auto b = dynamic_cast<const Analyzer::BinOper*>(e)) {
+    const int32_t op = b->get_optype() == kPLUS ? MI355Q_EX_ADD : b->get_optype() == kMINUS ? MI355Q_EX_SUB
+                       : b->get_optype() == kMULTIPLY ? MI355Q_EX_MUL : 0;
+    if (!op) unsupported("binary operator");
+    emit_expr(b->get_left_operand(), x, outer_col);
+    emit_expr(b->get_right_operand(), x, outer_col);
+    push(op, logical_type(b->get_type_info()), 0, 0, 0.0);
+  } else {
+    unsupported("expression kind");
+  }
+}
+
+// simple_quals / quals entry, or the condition of COUNT_IF / SUM_IF: <value> <cmp> <literal>, <value> IS NULL,
+// NOT(<value> IS NULL).  `value_col` gives the outer column (or virtual expression column) of a value expression.
+inline mi355q_qual translate_qual(const Analyzer::Expr* e, const std::function<int(const Analyzer::Expr*)>& value_col) {
+  mi355q_qual q{};
+  if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
+    if (u->get_optype() == kISNULL) {
+      q.col = value_col(u->get_operand());
+      q.op = MI355Q_IS_NULL;
+      return q;
+    }
+    if (u->get_optype() == kNOT) {  // RelAlgTranslator builds IS NOT NULL as NOT(ISNULL(x))
+      auto in = dynamic_cast<const Analyzer::UOper*>(u->get_operand());
+      if (in && in->get_optype() == kISNULL) {
+        q.col = value_col(in->get_operand());
+        q.op = MI355Q_IS_NOT_NULL;
+        return q;
+      }
+    }
+    unsupported("unary qual");
+  }
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  auto lit = b ? dynamic_cast<const Analyzer::Constant*>(b->get_right_operand()) : nullptr;
+  if (!b || !lit || lit->get_is_null()) unsupported("qual shape");
+  switch (b->get_optype()) {  // SQLOps values are the ABI's (mi355q_op)
+    case kEQ: case kNE: case kLT: case kGT: case kLE: case kGE: q.op = (int32_t)b->get_optype(); break;
+    default: unsupported("comparison operator");
+  }
+  q.col = value_col(b->get_left_operand());
+  const auto& ti = lit->get_type_info();
+  check_supported_type(ti);
+  const Datum d = lit->get_constval();
+  if (ti.get_type() == kDOUBLE) q.fval = d.doubleval;
+  else if (ti.get_type() == kFLOAT) q.fval = d.floatval;
+  else q.ival = int_literal(ti, d);
+  return q;
+}
+
+// an aggregate of target_exprs (get_target_info, Shared/TargetInfo.h:48-56).  `inner_col` resolves a ColumnVar of the
+// inner table; COUNT_IF(cond): the argument IS the condition; SUM_IF(value, cond): the condition is arg1
+// (RelAlgTranslator.cpp:348-360).
+inline mi355q_target translate_agg(const Analyzer::AggExpr* agg, const std::function<int(const Analyzer::Expr*)>& value_col,
+                                   const std::function<int(const Analyzer::ColumnVar*)>& inner_col) {
+  mi355q_target tg{};
+  tg.col = -1;
+  if (agg->get_is_distinct()) unsupported("DISTINCT aggregate");
+  tg.agg = agg_kind(agg->get_aggtype());
+  const Analyzer::Expr* arg = agg->get_arg();
+  if (tg.agg == MI355Q_COUNT_IF) {
+    if (!arg) unsupported("COUNT_IF without a condition");
+    tg.cond = translate_qual(arg, value_col);
+    return tg;
+  }
+  if (tg.agg == MI355Q_SUM_IF) {
+    const auto cond = agg->get_arg1();
+    if (!arg || !cond) unsupported("SUM_IF shape");
+    tg.cond = translate_qual(cond.get(), value_col);
+  }
+  if (arg) {
+    auto cv = dynamic_cast<const Analyzer::ColumnVar*>(arg);
+    if (cv && cv->get_rte_idx() != 0) {
+      check_supported_type(cv->get_type_info());
+      tg.table = 1;
+      tg.col = inner_col(cv);
+    } else {
+      tg.col = value_col(arg);
+    }
+  }
+  return tg;
+}
+
+}  // namespace mi355q_glue

@@ -28,23 +28,37 @@
 #include <string>
 #include <vector>
 
-// ---- Shared/sqltypes.h, Shared/sqldefs.h (numeric values as in the reference)
-enum SQLTypes { kNULLT = 0, kBOOLEAN = 1, kBIGINT = 9, kFLOAT = 10, kDOUBLE = 11, kINT = 6, kSMALLINT = 5, kTINYINT = 22, kTEXT = 13, kDATE = 15 };
-enum EncodingType { kENCODING_NONE = 0, kENCODING_FIXED = 1, kENCODING_DICT = 4, kENCODING_DATE_IN_DAYS = 10 };
+// ---- Shared/sqltypes.h:65-100, :261-273, Shared/sqldefs.h:31-58, :76-90: the enumerators this binding names, with the
+// reference's numeric values (tests/test_integration_glue.py::test_mock_enums_match_the_reference compiles a TU that
+// includes BOTH this file's values and the reference's headers and static_asserts every pair)
+enum SQLTypes {
+  kNULLT = 0, kBOOLEAN = 1, kCHAR = 2, kVARCHAR = 3, kNUMERIC = 4, kDECIMAL = 5, kINT = 6, kSMALLINT = 7, kFLOAT = 8,
+  kDOUBLE = 9, kTIME = 10, kTIMESTAMP = 11, kBIGINT = 12, kTEXT = 13, kDATE = 14, kARRAY = 15, kPOINT = 18, kTINYINT = 22
+};
+enum EncodingType { kENCODING_NONE = 0, kENCODING_FIXED = 1, kENCODING_RL = 2, kENCODING_DIFF = 3, kENCODING_DICT = 4,
+                    kENCODING_SPARSE = 5, kENCODING_GEOINT = 6, kENCODING_DATE_IN_DAYS = 7 };
 enum SQLOps { kEQ = 0, kBW_EQ, kNE, kLT, kGT, kLE, kGE, kAND, kOR, kNOT, kMINUS, kPLUS, kMULTIPLY, kDIVIDE, kMODULO, kUMINUS, kISNULL, kISNOTNULL, kEXISTS, kCAST };
-enum SQLAgg { kAVG = 0, kMIN, kMAX, kSUM, kCOUNT };
+enum SQLAgg { kAVG = 0, kMIN, kMAX, kSUM, kCOUNT, kAPPROX_COUNT_DISTINCT, kAPPROX_QUANTILE, kSAMPLE, kSINGLE_VALUE, kMODE,
+              kCOUNT_IF, kSUM_IF, kINVALID_AGG };
 enum class JoinType { INNER, LEFT };
 enum class ExecutorDeviceType { CPU, GPU };
 
 class SQLTypeInfo {
  public:
-  SQLTypeInfo(SQLTypes t = kNULLT, bool notnull = false, EncodingType c = kENCODING_NONE, int comp_param = 0)
-      : type_(t), notnull_(notnull), comp_(c), comp_param_(comp_param) {}
+  SQLTypeInfo(SQLTypes t = kNULLT, bool notnull = false, EncodingType c = kENCODING_NONE, int comp_param = 0, int dimension = 0)
+      : type_(t), notnull_(notnull), comp_(c), comp_param_(comp_param), dimension_(dimension) {}
   SQLTypes get_type() const { return type_; }
   bool get_notnull() const { return notnull_; }
   EncodingType get_compression() const { return comp_; }
   int get_comp_param() const { return comp_param_; }
   bool is_fp() const { return type_ == kFLOAT || type_ == kDOUBLE; }
+  // (sqltypes.h: IS_NUMBER / is_decimal / is_string / is_array / is_geometry / is_high_precision_timestamp)
+  bool is_decimal() const { return type_ == kDECIMAL || type_ == kNUMERIC; }
+  bool is_string() const { return type_ == kTEXT || type_ == kVARCHAR || type_ == kCHAR; }
+  bool is_array() const { return type_ == kARRAY; }
+  bool is_geometry() const { return type_ == kPOINT; }
+  int get_dimension() const { return dimension_; }
+  bool is_high_precision_timestamp() const { return type_ == kTIMESTAMP && dimension_ > 0; }
   bool is_integer() const { return type_ == kTINYINT || type_ == kSMALLINT || type_ == kINT || type_ == kBIGINT; }
   // bytes of the SQL type
   int get_logical_size() const {
@@ -66,6 +80,7 @@ class SQLTypeInfo {
   bool notnull_;
   EncodingType comp_;
   int comp_param_;
+  int dimension_;
 };
 
 union Datum {
@@ -136,16 +151,19 @@ class BinOper : public Expr {
 };
 class AggExpr : public Expr {
  public:
-  AggExpr(const SQLTypeInfo& ti, SQLAgg a, std::shared_ptr<Expr> arg, bool distinct = false)
-      : Expr(ti), agg_(a), arg_(std::move(arg)), distinct_(distinct) {}
+  AggExpr(const SQLTypeInfo& ti, SQLAgg a, std::shared_ptr<Expr> arg, bool distinct = false,
+          std::shared_ptr<Expr> arg1 = nullptr)
+      : Expr(ti), agg_(a), arg_(std::move(arg)), distinct_(distinct), arg1_(std::move(arg1)) {}
   SQLAgg get_aggtype() const { return agg_; }
-  const Expr* get_arg() const { return arg_.get(); }  // nullptr: COUNT(*)
+  Expr* get_arg() const { return arg_.get(); }  // nullptr: COUNT(*); COUNT_IF: the condition
   bool get_is_distinct() const { return distinct_; }
+  std::shared_ptr<Expr> get_arg1() const { return arg1_; }  // SUM_IF: the condition (Analyzer.h:1055)
 
  private:
   SQLAgg agg_;
   std::shared_ptr<Expr> arg_;
   bool distinct_;
+  std::shared_ptr<Expr> arg1_;
 };
 }  // namespace Analyzer
 

@@ -1,0 +1,147 @@
+// real_headers_check.cpp — the type-mapping half of the binding (integration/Mi355qTranslate.h) compiled against the
+// REFERENCE'S OWN Shared/sqltypes.h, Shared/sqldefs.h and Analyzer/Analyzer.h (not the mock), and run on real Analyzer
+// objects.  Built by tests/test_integration_glue.py where /root/reference exists:
+//   g++ -std=c++17 -DNO_BOOST -include oracle/_stubs/ref_layout_prelude.h -Ioracle/_stubs -I/root/reference
+//       -I/root/reference/QueryEngine -Iinclude -Iintegration real_headers_check.cpp analyzer_link_stubs.cpp
+// Also asserts that integration/mock/heavydb_mock.h states the reference's enum values (mock_enum_values.inc is
+// generated from the mock by the test).
+#include <cassert>
+#include <cstdio>
+#include <memory>
+
+#include "Mi355qTranslate.h"
+
+#ifdef MI355Q_CHECK_MOCK_ENUMS
+#include "mock_enum_values.inc"  // static_asserts: <mock value> == <reference enumerator>
+#endif
+
+using namespace mi355q_glue;
+
+#define REQ(c) do { if (!(c)) { std::printf("FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
+
+template <typename F>
+static bool refuses(F&& f) {
+  try {
+    f();
+  } catch (const std::runtime_error&) {
+    return true;
+  }
+  return false;
+}
+
+int main() {
+  using Analyzer::AggExpr;
+  using Analyzer::BinOper;
+  using Analyzer::ColumnVar;
+  using Analyzer::Constant;
+  using Analyzer::UOper;
+  // ---- column types: SQL type + encoding -> storage / logical type of the plan ABI
+  SQLTypeInfo t_int(kINT, false), t_big(kBIGINT, true), t_dbl(kDOUBLE, false), t_flt(kFLOAT, false);
+  SQLTypeInfo t_small_fixed(kINT, false);
+  t_small_fixed.set_compression(kENCODING_FIXED);
+  t_small_fixed.set_comp_param(16);
+  t_small_fixed.set_fixed_size();
+  SQLTypeInfo t_date_days(kDATE, false);
+  t_date_days.set_compression(kENCODING_DATE_IN_DAYS);
+  t_date_days.set_comp_param(32);
+  t_date_days.set_fixed_size();
+  SQLTypeInfo t_dict(kTEXT, false);
+  t_dict.set_compression(kENCODING_DICT);
+  t_dict.set_comp_param(8);
+  t_dict.set_size(1);  // what DDL does for TEXT ENCODING DICT(8) (Catalog/Catalog.cpp:3348, :4311: set_size(comp_param / 8));
+                       // set_fixed_size() -> get_storage_size() would say 4 for every dictionary width (sqltypes.h:1428-1431)
+  REQ(storage_type(t_int) == MI355Q_INT32 && logical_type(t_int) == MI355Q_INT32);
+  REQ(storage_type(t_big) == MI355Q_INT64 && storage_type(t_dbl) == MI355Q_DOUBLE && storage_type(t_flt) == MI355Q_FLOAT);
+  REQ(storage_type(t_small_fixed) == MI355Q_INT16 && logical_type(t_small_fixed) == MI355Q_INT32);
+  REQ(encoding_of(t_small_fixed) == MI355Q_ENC_FIXED && encoding_of(t_int) == MI355Q_ENC_NONE);
+  REQ(storage_type(t_date_days) == MI355Q_INT32 && logical_type(t_date_days) == MI355Q_INT64 &&
+      encoding_of(t_date_days) == MI355Q_ENC_DATE_IN_DAYS);
+  REQ(storage_type(t_dict) == MI355Q_INT8 && encoding_of(t_dict) == MI355Q_ENC_DICT);
+  // refused: DECIMAL, none-encoded strings, arrays, TIMESTAMP(6), geo
+  SQLTypeInfo t_dec(kDECIMAL, 10, 2, false);
+  SQLTypeInfo t_str(kTEXT, false);
+  SQLTypeInfo t_arr(kARRAY, false);
+  SQLTypeInfo t_ts6(kTIMESTAMP, 6, 0, false);
+  SQLTypeInfo t_pt(kPOINT, false);
+  REQ(refuses([&] { storage_type(t_dec); }) && refuses([&] { storage_type(t_str); }) && refuses([&] { logical_type(t_arr); }) &&
+      refuses([&] { storage_type(t_ts6); }) && refuses([&] { storage_type(t_pt); }));
+  // ---- aggregates
+  REQ(agg_kind(kAVG) == MI355Q_AVG && agg_kind(kCOUNT) == MI355Q_COUNT && agg_kind(kCOUNT_IF) == MI355Q_COUNT_IF &&
+      agg_kind(kSUM_IF) == MI355Q_SUM_IF);
+  REQ(refuses([] { agg_kind(kAPPROX_COUNT_DISTINCT); }) && refuses([] { agg_kind(kMODE); }));
+  // ---- expressions over real Analyzer objects: CAST(x AS DOUBLE), x + 1, y * 3 - x
+  const shared::ColumnKey kx{1, 7, 3}, ky{1, 7, 4}, kw{1, 9, 2};
+  auto x = std::make_shared<ColumnVar>(t_int, kx, 0);
+  auto y = std::make_shared<ColumnVar>(t_big, ky, 0);
+  auto w = std::make_shared<ColumnVar>(t_big, kw, 1);  // inner table
+  auto outer_col = [&](const ColumnVar* cv) { return cv->getColumnKey() == kx ? 0 : cv->getColumnKey() == ky ? 1 : -1; };
+  auto inner_col = [&](const ColumnVar* cv) { return cv->getColumnKey() == kw ? 0 : -1; };
+  auto value_col = [&](const Analyzer::Expr* e) {
+    auto cv = dynamic_cast<const ColumnVar*>(e);
+    return cv ? outer_col(cv) : 100;  // 100: "a projected expression" (the executor half allocates those)
+  };
+  {
+    auto cast = std::make_shared<UOper>(t_dbl, false, kCAST, x);
+    mi355q_expr e{};
+    emit_expr(cast.get(), e, outer_col);
+    REQ(e.n_nodes == 2 && e.nodes[0].op == MI355Q_EX_COL && e.nodes[0].arg == 0 && e.nodes[1].op == MI355Q_EX_CAST &&
+        e.nodes[1].type == MI355Q_DOUBLE);
+  }
+  {
+    Datum one;
+    one.intval = 1;
+    auto lit = std::make_shared<Constant>(t_int, false, one);
+    auto add = std::make_shared<BinOper>(t_int, false, kPLUS, kONE, x, lit);
+    mi355q_expr e{};
+    emit_expr(add.get(), e, outer_col);
+    REQ(e.n_nodes == 3 && e.nodes[1].op == MI355Q_EX_LIT && e.nodes[1].ilit == 1 && e.nodes[1].type == MI355Q_INT32 &&
+        e.nodes[2].op == MI355Q_EX_ADD && e.nodes[2].type == MI355Q_INT32);
+    Datum three;
+    three.bigintval = 3;
+    auto l3 = std::make_shared<Constant>(t_big, false, three);
+    auto mul = std::make_shared<BinOper>(t_big, false, kMULTIPLY, kONE, y, l3);
+    auto xb = std::make_shared<UOper>(t_big, false, kCAST, x);
+    auto sub = std::make_shared<BinOper>(t_big, false, kMINUS, kONE, mul, xb);
+    mi355q_expr e2{};
+    emit_expr(sub.get(), e2, outer_col);
+    REQ(e2.n_nodes == 6 && e2.nodes[5].op == MI355Q_EX_SUB && e2.nodes[2].op == MI355Q_EX_MUL && e2.nodes[4].op == MI355Q_EX_CAST &&
+        e2.nodes[4].type == MI355Q_INT64);
+    auto div = std::make_shared<BinOper>(t_big, false, kDIVIDE, kONE, y, l3);
+    mi355q_expr e3{};
+    REQ(refuses([&] { emit_expr(div.get(), e3, outer_col); }));
+    mi355q_expr e4{};
+    REQ(refuses([&] { emit_expr(w.get(), e4, outer_col); }));  // an inner column is not a projectable value
+    // ---- quals: x < 1, y IS NULL, NOT(y IS NULL)
+    auto lt = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kLT, kONE, x, lit);
+    mi355q_qual q = translate_qual(lt.get(), value_col);
+    REQ(q.op == MI355Q_LT && q.col == 0 && q.ival == 1);
+    auto isnull = std::make_shared<UOper>(SQLTypeInfo(kBOOLEAN, true), false, kISNULL, y);
+    q = translate_qual(isnull.get(), value_col);
+    REQ(q.op == MI355Q_IS_NULL && q.col == 1);
+    auto notnull = std::make_shared<UOper>(SQLTypeInfo(kBOOLEAN, true), false, kNOT, isnull);
+    q = translate_qual(notnull.get(), value_col);
+    REQ(q.op == MI355Q_IS_NOT_NULL && q.col == 1);
+    auto ge_cols = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kGE, kONE, x, y);
+    REQ(refuses([&] { translate_qual(ge_cols.get(), value_col); }));  // column-vs-column compare: not in the plan ABI
+    // ---- aggregates: SUM(y), COUNT(*), SUM(dim.w), COUNT_IF(x < 1), SUM_IF(y, x < 1), COUNT(DISTINCT x)
+    AggExpr sum_y(t_big, kSUM, y, false, nullptr);
+    mi355q_target tg = translate_agg(&sum_y, value_col, inner_col);
+    REQ(tg.agg == MI355Q_SUM && tg.col == 1 && tg.table == 0);
+    AggExpr count_star(SQLTypeInfo(kINT, true), kCOUNT, nullptr, false, nullptr);
+    tg = translate_agg(&count_star, value_col, inner_col);
+    REQ(tg.agg == MI355Q_COUNT && tg.col == -1);
+    AggExpr sum_w(t_big, kSUM, w, false, nullptr);
+    tg = translate_agg(&sum_w, value_col, inner_col);
+    REQ(tg.agg == MI355Q_SUM && tg.table == 1 && tg.col == 0);
+    AggExpr count_if(SQLTypeInfo(kINT, true), kCOUNT_IF, lt, false, nullptr);
+    tg = translate_agg(&count_if, value_col, inner_col);
+    REQ(tg.agg == MI355Q_COUNT_IF && tg.col == -1 && tg.cond.op == MI355Q_LT && tg.cond.col == 0 && tg.cond.ival == 1);
+    AggExpr sum_if(t_big, kSUM_IF, y, false, lt);
+    tg = translate_agg(&sum_if, value_col, inner_col);
+    REQ(tg.agg == MI355Q_SUM_IF && tg.col == 1 && tg.cond.op == MI355Q_LT && tg.cond.col == 0);
+    AggExpr count_distinct(SQLTypeInfo(kINT, true), kCOUNT, x, true, nullptr);
+    REQ(refuses([&] { translate_agg(&count_distinct, value_col, inner_col); }));
+  }
+  std::printf("real_headers_check ok\n");
+  return 0;
+}
