@@ -1,9 +1,8 @@
 // rowfunc.h — the per-row logic of the generic kernel family: filter -> join probe -> group
 // slot -> aggregate updates, written once and used with atomic slot updates on the device.
 //
-// When compiled with -DMQ_EMU (tests/emu only, plain g++) the atomics degrade to plain
-// single-threaded operations so the row logic can be unit-tested without a GPU.  That build
-// is test infrastructure; the product library always uses the device atomics.
+// tests/emu compiles this header for the host (plain g++) with its own single-threaded stand-ins for the
+// atomics, so the row logic can be unit-tested without a GPU; the product library always uses the device atomics.
 //
 // Reference semantics restated (heavyai/heavydb):
 //   filters      DEF_CMP_NULLABLE RuntimeFunctions.cpp:73-83, toBool LogicalIR.cpp:344-352
@@ -21,32 +20,15 @@
 
 namespace mq {
 
-#if defined(MQ_EMU)
-// ---------------------------------------------------------------- emulation atomics
-template <typename T>
-inline T emu_cas(T* p, T expect, T desired) {
-  T old = *p;
-  if (old == expect) *p = desired;
-  return old;
-}
-#define MQ_CAS64(p, e, d) mq::emu_cas<unsigned long long>((unsigned long long*)(p), (unsigned long long)(e), (unsigned long long)(d))
-#define MQ_CAS32(p, e, d) mq::emu_cas<unsigned int>((unsigned int*)(p), (unsigned int)(e), (unsigned int)(d))
-#define MQ_ADD64(p, v) (*(unsigned long long*)(p) += (unsigned long long)(v))
-#define MQ_ADDF64(p, v) (*(double*)(p) += (v))
-#define MQ_ADDF32(p, v) (*(float*)(p) += (v))
-#define MQ_MIN64(p, v) (*(long long*)(p) = (*(long long*)(p) < (long long)(v) ? *(long long*)(p) : (long long)(v)))
-#define MQ_MAX64(p, v) (*(long long*)(p) = (*(long long*)(p) > (long long)(v) ? *(long long*)(p) : (long long)(v)))
-#define MQ_LOAD64(p) (*(volatile int64_t*)(p))
-#define MQ_STORE64(p, v) (*(volatile int64_t*)(p) = (v))
-#define MQ_FENCE() ((void)0)
-#define MQ_PUBLISH_ORDER() ((void)0)
-#define MQ_LOAD32(p) (*(volatile int32_t*)(p))
-#define MQ_STORE32(p, v) (*(volatile int32_t*)(p) = (v))
-#define MQ_FN inline
-#else
+// The slot-update primitives below are written over this macro set (device atomics).  tests/emu compiles this header for
+// the host with single-threaded stand-ins it defines BEFORE including it (tests/emu/emu_atomics.h sets MQ_SLOT_ATOMICS);
+// nothing of that test double lives in the product sources.
+#ifndef MQ_SLOT_ATOMICS
+#define MQ_SLOT_ATOMICS 1
 #define MQ_CAS64(p, e, d) atomicCAS((unsigned long long*)(p), (unsigned long long)(e), (unsigned long long)(d))
 #define MQ_CAS32(p, e, d) atomicCAS((unsigned int*)(p), (unsigned int)(e), (unsigned int)(d))
 #define MQ_ADD64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(v))
+#define MQ_ADD32(p, v) atomicAdd((unsigned int*)(p), (unsigned int)(v))
 #define MQ_ADDF64(p, v) atomicAdd((double*)(p), (double)(v))
 #define MQ_ADDF32(p, v) atomicAdd((float*)(p), (float)(v))
 #define MQ_MIN64(p, v) atomicMin((long long*)(p), (long long)(v))
@@ -793,12 +775,8 @@ MQ_FN void reduce_target_compact(const DevTarget& t, const int64_t* init_vals, i
     }
     return;
   }
-#if defined(MQ_EMU)
-  this_slots[t.slot] = (int32_t)((uint32_t)this_slots[t.slot] + (uint32_t)b);
-#else
-  if (A) atomicAdd((unsigned int*)(this_slots + t.slot), (unsigned int)b);
+  if (A) MQ_ADD32(this_slots + t.slot, b);
   else this_slots[t.slot] = (int32_t)((uint32_t)this_slots[t.slot] + (uint32_t)b);
-#endif
 }
 
 // ---------------------------------------------------------------- reduce one entry

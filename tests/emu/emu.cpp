@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../heavydb_amd/csrc/plan.h"
+#include "emu_atomics.h"  // before rowfunc.h: the host stand-ins of its atomics
 #include "../../heavydb_amd/csrc/rowfunc.h"
 #include "../../heavydb_amd/csrc/expr.h"
 

@@ -284,7 +284,7 @@ def emu_lib() -> C.CDLL:
         out = os.path.join(ROOT, "tests", "_emu", "libemu.so")
         srcs = [os.path.join(ROOT, "tests", "emu", "emu.cpp"),
                 os.path.join(ROOT, "heavydb_amd", "csrc", "plan.cpp")]
-        deps = srcs + [os.path.join(ROOT, "heavydb_amd", "csrc", h)
+        deps = srcs + [os.path.join(ROOT, "tests", "emu", "emu_atomics.h")] + [os.path.join(ROOT, "heavydb_amd", "csrc", h)
                        for h in ("rowfunc.h", "dev_common.h", "plan.h", "expr.h")] + \
             [os.path.join(ROOT, "include", "mi355q.h")]
         if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
