@@ -195,6 +195,7 @@ class ExecOptions(C.Structure):
 OPT_TRACE, OPT_NO_PAIR_RENDEZVOUS, OPT_PROBE_NO_PACING, OPT_NO_LDS_BASELINE, OPT_LDS_BASELINE_LARGE = 1, 2, 4, 8, 16
 OPT_LDS_BASELINE_WINDOWS = 32
 OPT_LDS_GENERIC_MEMBER = 64
+OPT_NO_IDX_PART = 128
 
 
 class ExecReport(C.Structure):

@@ -922,6 +922,8 @@ int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64
 namespace {
 
 constexpr int32_t kNotTaken = INT32_MIN + 7;  // internal: "use the ordinary path"
+constexpr int64_t kIdxPartMinRows = (int64_t)8 << 20;  // below this the row kernel / LDS members are as good
+constexpr int32_t kRetryNoIdx = INT32_MIN + 9;  // internal: the index-partitioned family gave up (spill list), plan again without it
 constexpr int32_t kRetryNoLds = INT32_MIN + 8;  // internal: the LDS group-by ran out of replica room, plan again without it
 
 bool pack_spec_of(const mi355q_plan& p, const mi355q_qmd& q, const DevPlan& d, PackSpec* ps) {
@@ -1260,7 +1262,7 @@ int32_t execute_packed_multi(const mi355q_plan* plan, const mi355q_inputs* in, c
 // right after the launches; mi355q_execute_async parks it in a mi355q_pending until mi355q_wait (or the
 // next call on the device) runs it.  Everything it touches is owned here: the caller's host arrays may be
 // gone by then.
-enum StepKind { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART, K_JOIN_PROBE, K_SCAN_AGG, K_LDS_GROUPBY };
+enum StepKind { K_GENERIC, K_SCAN_COUNT, K_PERFECT_LDS, K_BASELINE_FAST, K_JOIN_SUM, K_JOIN_PART, K_JOIN_PROBE, K_SCAN_AGG, K_LDS_GROUPBY, K_IDX_PART };
 struct TailState {
   mi355q_qmd q;
   DevPlan d;
@@ -1327,6 +1329,7 @@ int32_t finish_step(TailState& t, mi355q_exec_report* report) {
   // more groups than an LDS replica holds (a baseline table: the group count is only known now): the caller plans
   // the step again without that member (packed route / partitioned family / row kernel, whatever applies)
   if (h_err[1] && t.kind == K_LDS_GROUPBY) return kRetryNoLds;
+  if (h_err[1] && t.kind == K_IDX_PART) return kRetryNoIdx;
   if (h_err[1] && t.kind == K_BASELINE_FAST) {
     // the partitioned family ran out of spill space (extreme skew): redo the step with the
     // direct-atomic member of the same family
@@ -1929,8 +1932,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
 
   // (small multi-column perfect-hash tables: the LDS group-by computes the entry index from the key columns itself,
   // no packed index column needed)
-  bool lds_direct = false;
-  if (!o.force_generic && in->n_frags > 0 && o.kernel_variant == 0 &&
+  bool lds_direct = false, idx_direct = false;
+  if (!o.force_generic && in->n_frags > 0 && (o.kernel_variant == 0 || o.kernel_variant == 2) &&
       (d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH ||
        (d.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && d.entry_count <= 65536 && !(o.flags & MI355Q_OPT_NO_LDS_BASELINE) && !pend))) {
     int64_t tr = 0, mr = 0;
@@ -1939,7 +1942,12 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
       mr = std::max(mr, in->num_rows[f]);
     }
     FragView fvh{nullptr, nullptr, in->col_buffers, in->num_rows, in->n_frags, plan->n_cols, tr, mr};
-    lds_direct = lds_groupby_eligible(d, fvh, n_cus);
+    if (o.kernel_variant == 0) lds_direct = lds_groupby_eligible(d, fvh, n_cus);
+    // perfect-hash tables too large for LDS over plain INT keys and values: partitioned by entry index with narrow
+    // records (kernels_idx.hip) instead of packed keys + one exchange per value column (kernel_variant 2 = "the
+    // large-input members" takes it whatever the input size: tests)
+    if (!lds_direct && !pend && d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && (tr >= kIdxPartMinRows || o.kernel_variant == 2))
+      lds_direct = idx_direct = idx_part_eligible(d, fvh, n_cus);
   }
   if (!o.force_generic && in->n_frags > 0 && !lds_direct) {
     const size_t mark = t_route ? t_route->size() : 0;
@@ -2038,6 +2046,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
              (d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH ||
               (d.entry_count <= 65536 && !(o.flags & MI355Q_OPT_NO_LDS_BASELINE) && !pend)))
       kind = K_LDS_GROUPBY;
+    else if (idx_direct && idx_part_eligible(d, fv, n_cus)) kind = K_IDX_PART;
     else if (baseline_fast_eligible(d, fv)) kind = K_BASELINE_FAST;
     else if (join_sum_eligible(d, fv)) kind = K_JOIN_SUM;
     // semi-join + aggregate over a large fact table: radix-partitioned probe (bitmap slices in
@@ -2160,7 +2169,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   tr.mark("setup done");
   int64_t scratch_bytes = 0;
   int64_t scratch_cap = o.scratch_bytes;
-  if (kind == K_BASELINE_FAST || kind == K_JOIN_PART || kind == K_JOIN_PROBE) {
+  if (kind == K_BASELINE_FAST || kind == K_JOIN_PART || kind == K_JOIN_PROBE || kind == K_IDX_PART) {
     // default cap: kDefaultScratchCap, but never more than 70 % of what the device has free right now
     // (counting the scratch this context already holds), halved while the device cannot provide it
     // (the planner then cuts the input into more chunks)
@@ -2173,12 +2182,14 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     }
     for (;;) {
       scratch_bytes = kind == K_JOIN_PART    ? join_part_scratch_bytes(d, fv, n_cus, scratch_cap)
+                      : kind == K_IDX_PART   ? idx_part_scratch_bytes(d, fv, n_cus, scratch_cap)
                       : kind == K_JOIN_PROBE ? join_probe_scratch_bytes(d, fv, pay, n_cus_probe, scratch_cap)
                                              : baseline_fast_scratch_bytes(d, fv, o.kernel_variant, scratch_cap, n_cus);
       if (kind == K_JOIN_PROBE && scratch_bytes == 0) {  // no plan within this cap: the row kernel
         kind = join_sum_eligible(d, fv) ? K_JOIN_SUM : K_GENERIC;
         break;
       }
+      if (kind == K_IDX_PART && scratch_bytes == 0) return MI355Q_ERR_OUT_OF_GPU_MEM;  // (eligible means it plans)
       if (kind == K_JOIN_PART && scratch_bytes == 0) {  // no plan within this cap: direct probe
         kind = K_JOIN_SUM;
         break;
@@ -2210,6 +2221,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
                          : kind == K_PERFECT_LDS ? "k_perfect_lds" : kind == K_LDS_GROUPBY ? "k_groupby_lds"
                          : kind == K_JOIN_SUM ? "k_join_sum" : kind == K_JOIN_PART ? "k_part_scatter + k_part_join"
                          : kind == K_JOIN_PROBE ? "k_part_scatter + k_part_probe"
+                         : kind == K_IDX_PART ? "k_idx_scatter + k_idx_aggregate"
                          : kind == K_BASELINE_FAST
                              ? (nf > 0 && baseline_fast_variant(d, fv, o.kernel_variant, n_cus) == 2 ? "k_part_scatter + k_part_aggregate"
                                                                                                       : "k_baseline_direct")
@@ -2243,6 +2255,9 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
       case K_BASELINE_FAST:
         HIP_TRY(launch_baseline_fast(d, fv, res->buf, d_err, ctx.scratch, ctx.scratch_bytes,
                                      scratch_cap, o.kernel_variant, n_cus, s, &st));
+        break;
+      case K_IDX_PART:
+        HIP_TRY(launch_idx_partitioned(d, fv, res->buf, d_err, ctx.scratch, ctx.scratch_bytes, scratch_cap, n_cus, s, &st));
         break;
       case K_JOIN_SUM:
         HIP_TRY(launch_join_sum(d, fv, res->buf, n_cus, s, &st));
@@ -2314,6 +2329,13 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   const int32_t code = finish_step(*tail, report);
   delete tail;
   tr.mark("synchronized");
+  if (code == kRetryNoIdx) {
+    mi355q_result_free(res);
+    rg.r = nullptr;
+    mi355q_exec_options o2 = o;
+    o2.flags |= MI355Q_OPT_NO_IDX_PART;
+    return execute_impl(plan, in, &o2, out, report, nullptr, nullptr);
+  }
   if (code == kRetryNoLds) {
     mi355q_result_free(res);
     rg.r = nullptr;

@@ -185,6 +185,11 @@ hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, i
 // few thousand groups (more: d_err[1] is set and the caller re-runs the step with another family); 1-3 value
 // columns, any aggregate kinds, NULL-aware or not, up to 4 integer range quals
 bool lds_groupby_eligible(const DevPlan& p, const FragView& fv, int n_cus);
+// ---- perfect-hash GROUP BY on a table too large for LDS: partition by entry index, narrow records (kernels_idx.hip)
+bool idx_part_eligible(const DevPlan& p, const FragView& fv, int n_cus);
+int64_t idx_part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes);
+hipError_t launch_idx_partitioned(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, void* scratch,
+                                  int64_t scratch_bytes, int64_t cap_bytes, int n_cus, hipStream_t s, LaunchStats* st);
 hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int n_cus,
                               hipStream_t s, LaunchStats* st);
 bool scan_count_eligible(const DevPlan& p, const FragView& fv);

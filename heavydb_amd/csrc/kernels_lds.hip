@@ -32,6 +32,7 @@
 #include <type_traits>
 
 #include "fast_common.h"
+#include "lds_args.h"
 
 namespace mq {
 
@@ -40,36 +41,7 @@ using namespace fast;
 namespace {
 
 constexpr int kLdsBlock = 1024;
-constexpr int kLdsVals = 3;              // value columns
-constexpr int kLdsKeys = 3;              // key columns (perfect hash)
 constexpr size_t kLdsBudget = 152 * 1024;
-constexpr uint32_t kLdsHashSmall = 256;  // slots of one baseline replica, first attempt (many replicas)
-constexpr uint32_t kLdsHashMax = 4096;   // ... at most, second attempt
-constexpr uint32_t kLdsMaxWindows = 8;   // windows of a table that does not fit one LDS (the columns are read once per window)
-
-struct LdsVal {
-  int32_t col, type, nullable;           // type: MI355Q_INT32 / _INT64 / _DOUBLE (plain)
-  int32_t off_cnt, off_sum, off_min, off_max;  // byte offsets of the arrays inside a replica, -1 = not kept
-};
-struct LdsArgs {
-  int32_t n_vals, n_flt, n_keys;
-  int32_t baseline;                      // 0: perfect-hash index; 1: open addressing on one 8-byte key
-  uint32_t entries;                      // arrays' length: entries of ONE window (perfect), or the hash slots (power of two)
-  uint32_t windows;                      // T >= 1: workgroup b keeps the rows of window b % T
-  int32_t copies_lg;                     // log2(K)
-  uint32_t copy_bytes;                   // bytes of one replica (16-byte multiple)
-  int32_t off_rows, off_keys;            // rows[entries] (u32); keys[entries] (int64, baseline)
-  LdsVal v[kLdsVals];
-  RangeFilter flt[MI355Q_MAX_QUALS];
-  int32_t flt_type[MI355Q_MAX_QUALS];
-  int32_t key_col[kLdsKeys], key_type[kLdsKeys], key_translate[kLdsKeys];
-  int64_t key_min[kLdsKeys], key_card[kLdsKeys], key_mul[kLdsKeys], key_null_key[kLdsKeys];
-  int32_t target_v[MI355Q_MAX_TARGETS];  // index into v[] of each target's argument, -1 = none
-  // typed members (k_groupby_lds_typed): every value column a plain INT32, no quals; one replica =
-  //   keys[E] i64 (baseline) | sum[NV][E] i64 | rows[E] u32 | cnt[NV][E] u32 | min[NV][E] i32 | max[NV][E] i32 (mm only)
-  int32_t typed, mm;
-  uint32_t t_off_keys, t_off_sum, t_off_rows, t_off_cnt, t_off_min, t_off_max;
-};
 
 struct RawQ {
   v4i32 lo, hi;
@@ -166,6 +138,35 @@ MQ_D uint32_t lds_key_slot(int64_t* keys, uint32_t H, int64_t key, uint32_t h) {
   return kNoSlot;
 }
 
+// Windows: which window and row stripe a workgroup takes.  The T workgroups that share a stripe read the same rows, so
+// they belong on ONE XCD (one L2): consecutive block ids are dealt to the 8 XCDs round-robin, so with `xcd_aware`
+// (grid = 8 x T x stripes-per-XCD) workgroup b sits on XCD b % 8 and is the (b / 8)-th there — stripe (b / 8) / T of that
+// XCD, window (b / 8) % T.  Without it (grids too small to fill eight XCDs: tune_cus, the host simulation) stripe-mates
+// are simply consecutive blocks.  Measured before: BH007 (8 windows, 12 B/row) 29.7 ms per 1 B rows = 3.2 TB/s of
+// reads that mostly missed the L2 (profiles/r04_refbench_1b_call3.jsonl).
+struct WinMap {
+  uint32_t win, stripe, n_stripes;
+};
+MQ_D WinMap lds_window_map(uint32_t T, uint32_t xcd_aware) {
+  WinMap m;
+  if (T <= 1) {
+    m.win = 0;
+    m.stripe = blockIdx.x;
+    m.n_stripes = gridDim.x;
+  } else if (xcd_aware) {
+    const uint32_t xcd = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t per_xcd = (gridDim.x >> 3) / T;  // stripes per XCD
+    m.win = j % T;
+    m.stripe = (j / T) * 8u + xcd;
+    m.n_stripes = per_xcd * 8u;
+  } else {
+    m.win = blockIdx.x % T;
+    m.stripe = blockIdx.x / T;
+    m.n_stripes = gridDim.x / T;
+  }
+  return m;
+}
+
 // NF / NK / NV: quals, key columns and value columns this member holds registers for; UQ quads per column per step.
 // Every index into the kernel-argument structs is a compile-time constant after unrolling: a dynamically indexed
 // by-value kernel argument is lowered to a private-memory (scratch) copy, and every access to it would then be a
@@ -181,9 +182,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
   const uint32_t ne = a.entries;
   // windows: this workgroup's window, its row stripe and the number of stripes (T = 1: the whole table, every workgroup a stripe)
   const uint32_t T = a.windows;
-  const uint32_t win = T > 1 ? blockIdx.x % T : 0u;
-  const uint32_t stripe = T > 1 ? blockIdx.x / T : blockIdx.x;
-  const uint32_t n_stripes = T > 1 ? gridDim.x / T : gridDim.x;
+  const WinMap wm = lds_window_map(T, a.xcd_aware);
+  const uint32_t win = wm.win, stripe = wm.stripe, n_stripes = wm.n_stripes;
   const uint32_t e_lo = a.baseline ? 0u : win * ne;  // perfect hash: first entry index of the window
   // ---- initialise every replica: counters 0, sums 0, min / max identities, keys empty
   for (uint32_t r = 0; r < K; ++r) {
@@ -505,9 +505,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   const uint32_t K = 1u << a.copies_lg;
   const uint32_t E = a.entries;
   const uint32_t T = a.windows;
-  const uint32_t win = T > 1 ? blockIdx.x % T : 0u;
-  const uint32_t stripe = T > 1 ? blockIdx.x / T : blockIdx.x;
-  const uint32_t n_stripes = T > 1 ? gridDim.x / T : gridDim.x;
+  const WinMap wm = lds_window_map(T, a.xcd_aware);
+  const uint32_t win = wm.win, stripe = wm.stripe, n_stripes = wm.n_stripes;
   const uint32_t e_lo = kBase ? 0u : win * E;
   // ---- initialise every replica
   for (uint32_t r = 0; r < K; ++r) {
@@ -857,83 +856,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
 
 bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out) {
   LdsArgs& a = *out;
-  std::memset(&a, 0, sizeof(a));
-  a.windows = 1;
-  if (p.desc_type == MI355Q_NON_GROUPED_AGGREGATE || p.join_col >= 0 || p.col0_key_quirk || p.slot_width != 8) return false;
-  if (p.n_quals > MI355Q_MAX_QUALS) return false;
-  for (int i = 0; i < p.n_quals; ++i) {
-    if (!make_range_filter(p.quals[i], &a.flt[i])) return false;
-    a.flt_type[i] = p.quals[i].type;
-    if (!all_aligned16(fv, p.quals[i].col)) return false;
-  }
-  a.n_flt = p.n_quals;
-  // keys
-  if (p.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
-    if (p.n_group < 1 || p.n_group > kLdsKeys || p.entry_count < 1 || p.entry_count > 65536) return false;
-    for (int g = 0; g < p.n_group; ++g) {
-      if (p.group_types[g] != MI355Q_INT32 && p.group_types[g] != MI355Q_INT64) return false;
-      if (p.group_bucket[g] != 0 || !all_aligned16(fv, p.group_cols[g])) return false;
-      a.key_col[g] = p.group_cols[g];
-      a.key_type[g] = p.group_types[g];
-      a.key_translate[g] = p.group_translate[g];
-      a.key_min[g] = p.group_min[g];
-      a.key_card[g] = p.group_card[g];
-      a.key_mul[g] = p.group_mul[g];
-      a.key_null_key[g] = p.group_null_key[g];
-      if (g > 0 && p.group_mul[g] < p.group_mul[g - 1]) return false;  // (the flush divides in descending order)
-    }
-    a.n_keys = p.n_group;
-    a.entries = (uint32_t)p.entry_count;
-  } else if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
-    // one 8-byte-wide key column (BIGINT, or DOUBLE as its bit pattern); 4-byte integer keys take the value
-    // sign-extended, FLOAT keys the bit pattern of the double they widen to
-    if (p.n_group != 1) return false;
-    const int kt = p.group_types[0];
-    if (kt != MI355Q_INT64 && kt != MI355Q_DOUBLE && kt != MI355Q_INT32 && kt != MI355Q_FLOAT) return false;
-    if (!all_aligned16(fv, p.group_cols[0])) return false;
-    a.key_col[0] = p.group_cols[0];
-    a.key_type[0] = kt;
-    a.n_keys = 1;
-    a.baseline = 1;
-    // the group count of a baseline table is only known afterwards: first 256-slot replicas (a table with a handful
-    // of groups gets one replica per few lanes), then the largest replica that fits, then another family
-    // third attempt: kLdsMaxWindows windows (classes of a key hash) of the largest replica
-    const uint32_t fl = tune_knobs().flags;
-    a.entries = (fl & (MI355Q_OPT_LDS_BASELINE_LARGE | MI355Q_OPT_LDS_BASELINE_WINDOWS)) ? kLdsHashMax : kLdsHashSmall;
-    if (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) a.windows = kLdsMaxWindows;
-  } else {
-    return false;
-  }
-  // targets -> value columns and the accumulators each needs
-  for (int c = 0; c < kLdsVals; ++c) a.v[c].off_cnt = a.v[c].off_sum = a.v[c].off_min = a.v[c].off_max = -1;
   bool need[kLdsVals][4] = {};
-  for (int i = 0; i < p.n_targets; ++i) {
-    const DevTarget& t = p.targets[i];
-    a.target_v[i] = -1;
-    if (t.agg == MI355Q_PROJECT_KEY) continue;
-    if (t.table != 0 || t.arg_f32) return false;
-    if (t.agg == MI355Q_COUNT && t.col < 0) continue;
-    if (t.agg != MI355Q_COUNT && t.agg != MI355Q_SUM && t.agg != MI355Q_MIN && t.agg != MI355Q_MAX && t.agg != MI355Q_AVG) return false;
-    if (t.col < 0) return false;
-    if (t.arg_type != MI355Q_INT32 && t.arg_type != MI355Q_INT64 && t.arg_type != MI355Q_DOUBLE) return false;
-    int c = -1;
-    for (int k = 0; k < a.n_vals; ++k)
-      if (a.v[k].col == t.col) c = k;
-    if (c < 0) {
-      if (a.n_vals >= kLdsVals || !all_aligned16(fv, t.col)) return false;
-      c = a.n_vals++;
-      a.v[c].col = t.col;
-      a.v[c].type = t.arg_type;
-      a.v[c].nullable = t.skip_null;
-    } else if (a.v[c].nullable != t.skip_null) {
-      return false;
-    }
-    a.target_v[i] = c;
-    if (t.skip_null) need[c][0] = true;  // (a NOT NULL column's count is the entry's `rows`)
-    if (t.agg == MI355Q_SUM || t.agg == MI355Q_AVG) need[c][1] = true;
-    if (t.agg == MI355Q_MIN) need[c][2] = true;
-    if (t.agg == MI355Q_MAX) need[c][3] = true;
-  }
+  if (!lds_describe(p, fv, 65536, tune_knobs().flags, &a, need)) return false;
   // one replica: 8-byte arrays first, then the 4-byte counters
   auto lay_out = [&](uint32_t entries) -> uint32_t {
     uint32_t off = 0;
@@ -1088,7 +1012,14 @@ hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out
   int64_t stripes = n_cus / T;
   if (stripes > want) stripes = want;
   if (stripes < 1) stripes = 1;
-  const int grid = (int)stripes * T;
+  int grid = (int)stripes * T;
+  // windows on a full device: the T workgroups of a stripe on one XCD, i.e. per XCD a whole number of stripes
+  a.xcd_aware = 0;
+  if (T > 1 && n_cus >= 64 && (n_cus / 8) / T >= 1 && stripes * T >= n_cus - T) {
+    const int per_xcd = (n_cus / 8) / T;
+    grid = 8 * T * per_xcd;
+    a.xcd_aware = 1;
+  }
   st->kernel_name = "k_groupby_lds";
   st->n_launches = 1;
   st->variant = a.typed ? 5 : 4;  // 5: a typed member (k_groupby_lds_typed)

@@ -438,6 +438,8 @@ typedef struct mi355q_exec_options {
                                             one workgroup per window and row stripe, the largest replica each */
 #define MI355Q_OPT_LDS_GENERIC_MEMBER 64u /* few-groups LDS GROUP BY: the run-time-role member even where a typed member
                                             (roles compiled in) applies (tests compare the two) */
+#define MI355Q_OPT_NO_IDX_PART 128u       /* large perfect-hash tables: not the index-partitioned family (the library sets this
+                                            itself when it re-runs a step whose spill list overflowed) */
 
 /* per-call timing/selection report (what launchGpuCode logs,
  * QueryExecutionContext.cpp:334,364,579) */

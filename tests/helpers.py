@@ -361,7 +361,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
         cxx = "g++"
-    real_srcs = ["kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "fast_common.h"] if real_fast else []
+    real_srcs = ["kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_idx.hip", "fast_common.h", "lds_args.h"] if real_fast else []
     deps = [os.path.join(src_dir, f) for f in ("hip_host.cpp", "kernels_host.cpp", "shim/hip/hip_runtime.h",
                                                "shim/hip/hip_runtime_api.h")] + \
         [os.path.join(csrc, f) for f in ["api.cpp", "plan.cpp", "kernels_generic.hip", "kernels.h", "rowfunc.h",
@@ -399,7 +399,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
                 os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
         if real_fast:
             flags.append("-DHOSTSIM_REAL_FAST")
-            for name in ("kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip"):
+            for name in ("kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_idx.hip"):
                 with open(os.path.join(csrc, name)) as f:
                     src = f.read()
                 src, n = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char (\w+)\[\];",
@@ -430,6 +430,21 @@ def hostsim_lib(real_fast: bool = False) -> str:
                     pat = "if (w == kSpillBusy) continue;"
                     assert src.count(pat) == 1
                     src = src.replace(pat, "if (w == kSpillBusy) { hipsim::fiber_yield(); continue; }")
+                if name == "kernels_idx.hip":
+                    # the same producer / flusher pipeline as k_part_scatter: the same four stand-ins for wave lockstep
+                    pat = '      asm volatile("" ::: "memory");\n      if (need) {\n        my_fl[k] += 1;'
+                    assert src.count(pat) == 1
+                    src = src.replace(pat, "      hipsim::wave_sync();\n      if (need) {\n        my_fl[k] += 1;")
+                    pat = "const bool all_done = idx_peek(done) == (uint32_t)kIdxProdWaves;"
+                    assert src.count(pat) == 1
+                    src = src.replace(pat, "const bool all_done = __shfl((int)(idx_peek(done) == (uint32_t)kIdxProdWaves), 0) != 0;")
+                    pat = "const uint32_t w = idx_peek(&written[p]);"
+                    assert src.count(pat) == 2
+                    src = src.replace(pat, "const uint32_t w = (uint32_t)__shfl((int)idx_peek(&written[p]), "
+                                           "(int)((threadIdx.x & 63) - (sidx & 63)));")
+                    pat = "if (w == kIdxSpillBusy) continue;"
+                    assert src.count(pat) == 1
+                    src = src.replace(pat, "if (w == kIdxSpillBusy) { hipsim::fiber_yield(); continue; }")
                 cpp = os.path.join(out_dir, name.replace(".hip", "_host.cpp"))
                 with open(cpp, "w") as f:
                     f.write(src)

@@ -276,5 +276,14 @@ int64_t sort_scratch_bytes(int64_t) { return 256; }
 hipError_t launch_sort(const DevPlan&, int, const SortOrderEntry*, int, const int64_t*, int64_t, int64_t, void*, int64_t*,
                        int64_t*, hipStream_t) { return hipErrorNotSupported; }
 
+// ---- perfect-hash GROUP BY partitioned by entry index (kernels_idx.hip): no stand-in — the family is simply absent from
+// this build (the packed route keeps those shapes); the real kernels run in the HOSTSIM_REAL_FAST build
+bool idx_part_eligible(const DevPlan&, const FragView&, int) { return false; }
+int64_t idx_part_scratch_bytes(const DevPlan&, const FragView&, int, int64_t) { return 0; }
+hipError_t launch_idx_partitioned(const DevPlan&, const FragView&, int64_t*, int32_t*, void*, int64_t, int64_t, int, hipStream_t,
+                                  LaunchStats*) {
+  return hipErrorInvalidValue;
+}
+
 }  // namespace mq
 #endif  // HOSTSIM_REAL_FAST

@@ -128,7 +128,9 @@ def test_explain_names_the_stages_of_a_derived_route(sim):
     assert r == "k_groupby_lds", r
     r = _explain("NGA03", 1_000_000_000)
     assert r == "k_scan_agg", r
-    r = _explain("MSPHS009", 1_000_000_000)   # x10m, two value columns: packed index, one run per value column
+    r = _explain("MSPHS009", 1_000_000_000)   # x10m, two value columns: one exchange of 16-byte {entry, v0, v1} records
+    assert r == "k_idx_scatter + k_idx_aggregate", r
+    r = _explain("MSBS006", 1_000_000_000)    # (BIGINT stride key, x100), two value columns: packed key, one run per value column
     assert "k_zip_targets" in r and "k_part_scatter" in r, r
 
 
@@ -203,3 +205,63 @@ def test_partitioned_family_with_phase_1_next_to_phase_2(sim, oracle, shape, ove
     rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=8 << 20, tune_overlap_cus=overlap_cus)
     assert rs.report.kernel_name.decode() == "k_part_scatter" and rs.report.variant == 2
     assert rs.report.n_launches >= 4, rs.report.n_launches
+
+
+# ---- perfect-hash tables too large for LDS: the index-partitioned family (kernels_idx.hip) -------------------------------
+IDX_SHAPES = ["PHS005", "PHS006", "PHM004", "PHM005", "MSPHS003", "MSPHS006", "MSPHS007", "MSPHS008", "MSPHS010", "MSPHM003",
+              "MSPHM006"]
+
+
+@pytest.mark.parametrize("name", IDX_SHAPES)
+def test_idx_partitioned_family_on_the_benchmark_shapes(sim, oracle, name):
+    """PerfectHashSingleCol / MultiCol / MultiStep shapes with 100 K+ entries: k_idx_scatter (8-byte records for one value
+    column, 16-byte records for two or three — ONE exchange, no packed key column, no zip) + k_idx_aggregate (LDS table
+    indexed by the entry, merged into the table with the reduce rule), kernel_variant 2 = the large-input members on a
+    small input.  Row counts that leave a quad remainder and a tail in every fragment."""
+    case = flow._refbench_case(oracle, name, 150_003, 120_000)
+    rs = flow._check(oracle, case, kernel_variant=2)
+    assert rs is not None
+    assert rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.variant == 6, (rs.report.kernel_name, rs.report.variant)
+
+
+def test_idx_partitioned_family_in_several_chunks_and_with_spills(sim, oracle):
+    """a scratch cap that cuts the input into chunks (every chunk merges into the table again), and a skewed key column
+    whose hot entries overflow their runs: the spill list is applied record by record afterwards"""
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(77)
+    n, card = 260_000, 90_000
+    key = rng.integers(1, card + 1, n).astype(np.int32)
+    key[rng.random(n) < 0.35] = 4242          # one entry owns a third of the rows: its run overflows
+    val = rng.integers(1, 11, n).astype(np.int32)
+    val[rng.random(n) < 0.05] = np.iinfo(np.int32).min   # NULLs
+    v2 = rng.integers(-1000, 1000, n).astype(np.int32)
+    descs = [InputColDescriptor(capi.INT32, True, ExpressionRange(True, 1, card, True)),
+             InputColDescriptor(capi.INT32, True, ExpressionRange(True, 1, 10, True)),
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, -1000, 1000))]
+    for targets in ([TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT, 1), TargetExpr(capi.SUM, 1), TargetExpr(capi.MAX, 1),
+                     TargetExpr(capi.MIN, 1), TargetExpr(capi.AVG, 1)],
+                    [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1), TargetExpr(capi.AVG, 2),
+                     TargetExpr(capi.MIN, 2)]):
+        ra = RelAlgExecutionUnit(descs, targets, [], [0], max_groups_buffer_entry_guess=2 * card)
+        cuts = [0] + [(n * k // 5) & ~3 for k in range(1, 5)] + [n]
+        frags = [[key[a:b], val[a:b], v2[a:b]] for a, b in zip(cuts[:-1], cuts[1:])]
+        case = cases_mod.Case("idx_skew", ra, frags)
+        rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=18 << 20)
+        assert rs.report.kernel_name.decode() == "k_idx_scatter", rs.report.kernel_name
+        assert rs.report.n_launches >= 2, rs.report.n_launches
+        assert rs.report.spilled_rows > 0
+
+
+def test_idx_partitioned_family_reports_a_key_outside_its_range(sim, oracle):
+    from heavydb_amd.executor import Executor, ExpressionRange, FetchResult, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    n, card = 100_000, 80_000
+    key = (np.arange(n) % card + 1).astype(np.int32)
+    key[777] = card + 5      # outside the declared range: the reference would write past the table; here error 3
+    val = np.ones(n, np.int32)
+    descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 1, card)),
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, 1, 1))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 1)], [], [0])
+    case = cases_mod.Case("idx_bad_key", ra, [[key, val]])
+    with pytest.raises(capi.Mi355qError) as ei:
+        Executor(0).executeWorkUnit(ra, flow._fetch_result(case), allow_retry=False, kernel_variant=2)
+    assert ei.value.code == capi.ERR_OUT_OF_SLOTS

@@ -86,3 +86,22 @@ def test_refbench_small_lds_groupby_both_members(torch_cuda, oracle, name, membe
 def test_refbench_queries_16m_rows(torch_cuda, oracle, name):
     kernel = _run(torch_cuda, oracle, name, 16_000_000, 0, 0)
     print(name, kernel)
+
+
+@pytest.mark.parametrize("name", ["PHS005", "PHS006", "PHM004", "PHM005", "MSPHS003", "MSPHS006", "MSPHS007", "MSPHS008",
+                                  "MSPHS010", "MSPHM003", "MSPHM006"])
+def test_refbench_idx_partitioned_family(torch_cuda, oracle, name):
+    """perfect-hash tables too large for LDS (100 K+ entries, 1 - 3 INT keys, 1 - 3 INT value columns): k_idx_scatter +
+    k_idx_aggregate (kernels_idx.hip; 8-byte records for one value column, 16-byte records for two or three, one exchange)
+    against the oracle; kernel_variant 2 takes the family on a 2 M-row input (odd count: quad remainders and tails)"""
+    rep = {}
+    kernel = _run(torch_cuda, oracle, name, 2_000_003, 150_000, 2, report=rep)
+    assert kernel == "k_idx_scatter" and rep["variant"] == 6, (kernel, rep)
+
+
+def test_refbench_idx_partitioned_family_planned_at_16m_rows(torch_cuda, oracle):
+    """at the benchmark's own cardinalities the planner picks the family itself from 8 M rows on"""
+    for name in ["PHS007", "MSPHS005", "MSPHS012"]:
+        rep = {}
+        kernel = _run(torch_cuda, oracle, name, 16_000_000, 0, 0, report=rep)
+        assert kernel == "k_idx_scatter", (name, kernel)
