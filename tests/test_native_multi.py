@@ -37,3 +37,17 @@ def test_multi_check_runs():
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "multi_check: ok" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks", [3, 8])
+def test_multi_check_runs_with_simulated_ranks(ranks):
+    """`multi_check --sim N`: N ranks on ONE device (own threads, streams, fragments f % N, tables), the grouped send / recv of
+    the slice and pad exchanges as device-to-device copies behind stream events: the N x N slices really move and every rank
+    folds N sources with mi355q_shard_merge_slices — what RCCL on a 1-GPU box degenerates to nothing (VERDICT r03 next #6)."""
+    if not os.path.exists(BIN):
+        _build()
+    r = subprocess.run([BIN, "--sim", str(ranks), "192e6", "1e6"], capture_output=True, text=True, timeout=600)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "multi_check: ok" in r.stdout and f"{ranks} rank(s) simulated" in r.stdout

@@ -19,12 +19,21 @@
 //   add up to the key cardinality; SUM over all tables of COUNT(*) == rows passing the filter (counted by a second,
 //   non-grouped step per rank and all-reduced).
 //
+// `multi_check --sim N [rows] [keys]`: N ranks SIMULATED ON ONE DEVICE — every rank its own host thread, stream, fragments
+//   (f % N), tables and receive buffers; the grouped ncclSend / ncclRecv of the slice and pad exchanges become device-to-device
+//   copies enqueued on the receiver's stream behind an event of the sender's stream (LoopComm below), the all-reduces go
+//   through the host.  So the N x N slices really move and every rank folds N sources — what a 1-GPU box degenerates to a
+//   no-op with RCCL.  The library keeps ONE workspace per device, so the ranks take turns for the calls that use it
+//   (the step, mi355q_shard_merge_slices); timing means nothing in this mode.
+//
 // Build (tools/native/build_multi_check.sh):  hipcc -O2 -std=c++17 multi_check.cpp -I../../include
 //        -L../../heavydb_amd/lib -lmi355q -lrccl -lpthread ;  run:  multi_check [n_gpus] [total_rows]
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -63,6 +72,85 @@ uint32_t murmur3_u64(uint64_t key) {  // MurmurHash3_x86_32 of the 8 key bytes, 
   return h1;
 }
 
+// ---- the loopback transport of --sim ------------------------------------------------------------------------------
+struct HostBarrier {
+  std::mutex mu;
+  std::condition_variable cv;
+  int n = 0, waiting = 0;
+  uint64_t gen = 0;
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    const uint64_t g = gen;
+    if (++waiting == n) {
+      waiting = 0;
+      ++gen;
+      cv.notify_all();
+    } else {
+      // (a rank that failed has left: the others must not wait for it for ever)
+      while (!cv.wait_for(lk, std::chrono::milliseconds(200), [&] { return gen != g; }))
+        if (failures.load()) break;
+    }
+  }
+};
+struct LoopComm {
+  int world = 0;
+  HostBarrier bar;
+  std::mutex device_turn;                      // one workspace per device in the library: ranks take turns
+  std::vector<const char*> send_ptr;           // [from][to]
+  std::vector<size_t> send_bytes;              // [from][to]
+  std::vector<hipEvent_t> ready, done;         // [rank]: "my sends may be read", "I have read what I receive"
+  std::vector<int32_t> flags;                  // [rank][n] for the host all-reduces
+  int flags_n = 0;
+};
+LoopComm* g_loop = nullptr;
+
+// rank `me` sends `bytes[r]` from send[r] to every r and receives recv_bytes into recv[r] from every r (one grouped
+// ncclSend / ncclRecv round); returns false on a HIP error
+bool loop_all_to_all(LoopComm& c, int me, const std::vector<const char*>& send, const std::vector<size_t>& bytes,
+                     const std::vector<char*>& recv, hipStream_t s) {
+  for (int r = 0; r < c.world; ++r) {
+    c.send_ptr[(size_t)me * c.world + r] = send[r];
+    c.send_bytes[(size_t)me * c.world + r] = bytes[r];
+  }
+  if (hipEventRecord(c.ready[me], s) != hipSuccess) return false;
+  c.bar.wait();
+  for (int r = 0; r < c.world; ++r) {
+    if (hipStreamWaitEvent(s, c.ready[r], 0) != hipSuccess) return false;
+    const size_t n = c.send_bytes[(size_t)r * c.world + me];
+    if (n && hipMemcpyAsync(recv[r], c.send_ptr[(size_t)r * c.world + me], n, hipMemcpyDeviceToDevice, s) != hipSuccess) return false;
+  }
+  if (hipEventRecord(c.done[me], s) != hipSuccess) return false;
+  c.bar.wait();
+  for (int r = 0; r < c.world; ++r)   // my send buffers are free again once every reader is done
+    if (hipStreamWaitEvent(s, c.done[r], 0) != hipSuccess) return false;
+  return true;
+}
+// element-wise MIN (or MAX) of n int32 over the ranks, through the host
+bool loop_all_reduce(LoopComm& c, int me, int32_t* d, int n, bool take_max, hipStream_t s) {
+  std::vector<int32_t> h((size_t)n);
+  if (hipMemcpyAsync(h.data(), d, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, s) != hipSuccess) return false;
+  if (hipStreamSynchronize(s) != hipSuccess) return false;
+  c.bar.wait();            // (the previous round's readers are done with `flags`)
+  if (me == 0) {
+    c.flags.assign((size_t)c.world * n, 0);
+    c.flags_n = n;
+  }
+  c.bar.wait();
+  for (int i = 0; i < n; ++i) c.flags[(size_t)me * n + i] = h[i];
+  c.bar.wait();
+  for (int i = 0; i < n; ++i) {
+    int32_t v = c.flags[i];
+    for (int r = 1; r < c.world; ++r) {
+      const int32_t x = c.flags[(size_t)r * n + i];
+      v = take_max ? std::max(v, x) : std::min(v, x);
+    }
+    h[i] = v;
+  }
+  if (hipMemcpyAsync(d, h.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, s) != hipSuccess) return false;
+  return hipStreamSynchronize(s) == hipSuccess;
+}
+#define LOOPCK(x) do { if (!(x)) { std::printf("[rank %d] loopback transport failed at line %d\n", rank, __LINE__); failures.fetch_add(1); return; } } while (0)
+
 mi355q_plan headline_plan(int64_t n_keys, bool grouped) {
   mi355q_plan p{};
   p.abi_version = MI355Q_ABI_VERSION;
@@ -93,9 +181,11 @@ mi355q_plan headline_plan(int64_t n_keys, bool grouped) {
 
 void rank_main(int rank, int world, int64_t total_rows, int64_t n_keys, ncclUniqueId id, int64_t* group_counts,
                double* step_ms) {
-  HIPCK(hipSetDevice(rank));
-  ncclComm_t comm;
-  NCCK(ncclCommInitRank(&comm, world, id, rank));
+  const bool sim = g_loop != nullptr;   // N ranks on device 0
+  const int dev = sim ? 0 : rank;
+  HIPCK(hipSetDevice(dev));
+  ncclComm_t comm = nullptr;
+  if (!sim) NCCK(ncclCommInitRank(&comm, world, id, rank));
   hipStream_t s;
   HIPCK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   // ---- this rank's fragments of the table
@@ -115,15 +205,15 @@ void rank_main(int rank, int world, int64_t total_rows, int64_t n_keys, ncclUniq
   int64_t lo_row = 0;
   for (size_t i = 0; i < frag_rows.size(); ++i) {
     char *k = (char*)d_key + lo_row * 8, *v = (char*)d_val + lo_row * 8, *fl = (char*)d_fil + lo_row * 4;
-    MQCK(mi355q_generate_column(rank, k, frag_rows[i], frag_off[i], MI355Q_GEN_I64_MOD_MUL, 0xC0FFEE00, n_keys, 1000003, 7, 0.0, 0, s));
-    MQCK(mi355q_generate_column(rank, v, frag_rows[i], frag_off[i], MI355Q_GEN_F64_UNIT, 0xC0FFEE01, 0, 0, 0, 1000.0, 0, s));
-    MQCK(mi355q_generate_column(rank, fl, frag_rows[i], frag_off[i], MI355Q_GEN_I32_UNIFORM31, 0xC0FFEE02, 0, 0, 0, 0.0, 0, s));
+    MQCK(mi355q_generate_column(dev, k, frag_rows[i], frag_off[i], MI355Q_GEN_I64_MOD_MUL, 0xC0FFEE00, n_keys, 1000003, 7, 0.0, 0, s));
+    MQCK(mi355q_generate_column(dev, v, frag_rows[i], frag_off[i], MI355Q_GEN_F64_UNIT, 0xC0FFEE01, 0, 0, 0, 1000.0, 0, s));
+    MQCK(mi355q_generate_column(dev, fl, frag_rows[i], frag_off[i], MI355Q_GEN_I32_UNIFORM31, 0xC0FFEE02, 0, 0, 0, 0.0, 0, s));
     cols.insert(cols.end(), {k, v, fl});
     lo_row += frag_rows[i];
   }
   HIPCK(hipStreamSynchronize(s));
   mi355q_inputs in{};
-  in.device_id = rank;
+  in.device_id = dev;
   in.n_frags = (int32_t)frag_rows.size();
   in.col_buffers = cols.data();
   in.num_rows = frag_rows.data();
@@ -147,14 +237,98 @@ void rank_main(int rank, int world, int64_t total_rows, int64_t n_keys, ncclUniq
   mi355q_exec_options opts{};
   opts.stream = s;
   opts.out_buffer = table;
+  // size-independent checks of this rank's share of the final table
+  auto check_table = [&](const mi355q_result* mine, const mi355q_exec_report& rep) {
+    std::vector<int64_t> h((size_t)(E * rq));
+    MQCK(mi355q_result_copy_to_host(mine, h.data(), E * row_bytes));
+    int64_t groups = 0, counted = 0;
+    bool owned = true;
+    for (int64_t e = 0; e < E; ++e) {
+      if (h[e * rq] == INT64_MAX) continue;
+      ++groups;
+      counted += h[e * rq + 1];
+      const int64_t home = murmur3_u64((uint64_t)h[e * rq]) % (uint64_t)E;
+      owned = owned && (world == 1 || (home >= my_lo && home < my_hi));
+    }
+    REQ(owned);
+    group_counts[rank] = groups;
+    group_counts[world + rank] = counted;
+    std::printf("[rank %d] %lld rows in %zu fragments: step + merge %.3f ms (kernel %s, %d launches, %.3f ms on the stream), %lld groups in my range\n",
+                rank, (long long)local, frag_rows.size(), step_ms[rank], rep.kernel_name, rep.n_launches, rep.total_ms, (long long)groups);
+  };
   for (int iter = 0; iter < 3; ++iter) {   // iteration 0 warms the workspace up; the last one is timed
-    NCCK(ncclAllReduce(ok, ok, 1, ncclInt32, ncclMin, comm, s));   // a barrier on the stream
+    if (sim) g_loop->bar.wait();
+    else NCCK(ncclAllReduce(ok, ok, 1, ncclInt32, ncclMin, comm, s));   // a barrier on the stream
     HIPCK(hipStreamSynchronize(s));
     const auto t0 = std::chrono::steady_clock::now();
     mi355q_result* res = nullptr;
     mi355q_pending* pend = nullptr;
-    MQCK(mi355q_execute_async(&plan, &in, &opts, &res, &pend));
     mi355q_result* fresh = nullptr;
+    // --sim: the same sequence with the loopback transport; the calls that use the library's per-device workspace are
+    // made in turns and completed (the N ranks share device 0)
+    auto exchange_sim = [&]() {
+      {
+        std::lock_guard<std::mutex> turn(g_loop->device_turn);
+        MQCK(mi355q_shard_pads(res, world, kPadRows, pads, ok, s));
+        HIPCK(hipStreamSynchronize(s));
+      }
+      std::vector<const char*> snd(world);
+      std::vector<size_t> nb(world);
+      std::vector<char*> rcv(world);
+      for (int r = 0; r < world; ++r) {
+        snd[r] = (const char*)table + bound[r] * row_bytes;
+        nb[r] = (size_t)((bound[r + 1] - bound[r]) * row_bytes);
+        rcv[r] = (char*)recv + (int64_t)r * my_len * row_bytes;
+      }
+      LOOPCK(loop_all_to_all(*g_loop, rank, snd, nb, rcv, s));
+      for (int r = 0; r < world; ++r) {
+        snd[r] = (const char*)pads + (int64_t)r * kPadRows * row_bytes;
+        nb[r] = (size_t)(kPadRows * row_bytes);
+        rcv[r] = (char*)recv_pads + (int64_t)r * kPadRows * row_bytes;
+      }
+      LOOPCK(loop_all_to_all(*g_loop, rank, snd, nb, rcv, s));
+      LOOPCK(loop_all_reduce(*g_loop, rank, ok, world, false, s));
+      std::lock_guard<std::mutex> turn(g_loop->device_turn);
+      MQCK(mi355q_result_create(&q, dev, fresh_buf, &fresh));
+      std::vector<const void*> slices(world), padv(world);
+      for (int r = 0; r < world; ++r) {
+        slices[r] = (const char*)recv + (int64_t)r * my_len * row_bytes;
+        padv[r] = (const char*)recv_pads + (int64_t)r * kPadRows * row_bytes;
+      }
+      int32_t e = mi355q_shard_merge_slices(fresh, slices.data(), padv.data(), world, kPadRows, my_lo, my_hi, s);
+      if (e == MI355Q_ERR_UNSUPPORTED) {
+        MQCK(mi355q_shard_merge_range(fresh, recv, (int64_t)world * my_len, my_lo, my_hi, s));
+        MQCK(mi355q_shard_merge_range(fresh, recv_pads, (int64_t)world * kPadRows, my_lo, my_hi, s));
+      } else {
+        MQCK(e);
+      }
+      HIPCK(hipStreamSynchronize(s));
+    };
+    if (sim) {
+      mi355q_exec_report rep{};
+      {
+        std::lock_guard<std::mutex> turn(g_loop->device_turn);
+        MQCK(mi355q_execute_async(&plan, &in, &opts, &res, &pend));
+        int32_t wc = mi355q_wait(pend, &rep);
+        if (wc == MI355Q_STEP_RECOMPUTED) wc = MI355Q_OK;   // nothing was enqueued behind the step yet
+        MQCK(wc);
+        HIPCK(hipStreamSynchronize(s));
+      }
+      if (world > 1) exchange_sim();
+      step_ms[rank] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (iter == 2) {
+        std::vector<int32_t> h_ok(world, 1);
+        if (world > 1) HIPCK(hipMemcpy(h_ok.data(), ok, sizeof(int32_t) * world, hipMemcpyDeviceToHost));
+        for (int r = 0; r < world; ++r) REQ(h_ok[r] == 1);
+        std::lock_guard<std::mutex> turn(g_loop->device_turn);
+        check_table(world > 1 ? fresh : res, rep);
+      }
+      g_loop->bar.wait();   // nobody re-runs its step into `table` while a peer may still be reading a slice of it
+      if (fresh) mi355q_result_free(fresh);
+      mi355q_result_free(res);
+      continue;
+    }
+    MQCK(mi355q_execute_async(&plan, &in, &opts, &res, &pend));
     auto exchange = [&]() {
       MQCK(mi355q_shard_pads(res, world, kPadRows, pads, ok, s));
       NCCK(ncclGroupStart());
@@ -171,7 +345,7 @@ void rank_main(int rank, int world, int64_t total_rows, int64_t n_keys, ncclUniq
       NCCK(ncclGroupEnd());
       // ok[r] = 1 when pad r of MY table ends in an empty slot; every rank needs min over ranks and pads
       NCCK(ncclAllReduce(ok, ok, world, ncclInt32, ncclMin, comm, s));
-      MQCK(mi355q_result_create(&q, rank, fresh_buf, &fresh));
+      MQCK(mi355q_result_create(&q, dev, fresh_buf, &fresh));
       std::vector<const void*> slices(world), padv(world);
       for (int r = 0; r < world; ++r) {
         slices[r] = (const char*)recv + (int64_t)r * my_len * row_bytes;
@@ -212,24 +386,7 @@ void rank_main(int rank, int world, int64_t total_rows, int64_t n_keys, ncclUniq
       std::vector<int32_t> h_ok(world, 1);
       if (world > 1) HIPCK(hipMemcpy(h_ok.data(), ok, sizeof(int32_t) * world, hipMemcpyDeviceToHost));
       for (int r = 0; r < world; ++r) REQ(h_ok[r] == 1);   // else: the general partition path (mi355q_shard_partition)
-      const mi355q_result* mine = world > 1 ? fresh : res;
-      // ---- checks
-      std::vector<int64_t> h((size_t)(E * rq));
-      MQCK(mi355q_result_copy_to_host(mine, h.data(), E * row_bytes));
-      int64_t groups = 0, counted = 0;
-      bool owned = true;
-      for (int64_t e = 0; e < E; ++e) {
-        if (h[e * rq] == INT64_MAX) continue;
-        ++groups;
-        counted += h[e * rq + 1];
-        const int64_t home = murmur3_u64((uint64_t)h[e * rq]) % (uint64_t)E;
-        owned = owned && (world == 1 || (home >= my_lo && home < my_hi));
-      }
-      REQ(owned);
-      group_counts[rank] = groups;
-      group_counts[world + rank] = counted;
-      std::printf("[rank %d] %lld rows in %zu fragments: step + merge %.3f ms (kernel %s, %d launches, %.3f ms on the stream), %lld groups in my range\n",
-                  rank, (long long)local, frag_rows.size(), step_ms[rank], rep.kernel_name, rep.n_launches, rep.total_ms, (long long)groups);
+      check_table(world > 1 ? fresh : res, rep);
     }
     if (fresh) mi355q_result_free(fresh);
     mi355q_result_free(res);
@@ -240,16 +397,19 @@ void rank_main(int rank, int world, int64_t total_rows, int64_t n_keys, ncclUniq
     mi355q_result* cr = nullptr;
     mi355q_exec_options co{};
     co.stream = s;
+    std::unique_lock<std::mutex> turn;
+    if (sim) turn = std::unique_lock<std::mutex>(g_loop->device_turn);
     MQCK(mi355q_execute(&cp, &in, &co, &cr, nullptr));
     int64_t c = 0;
     MQCK(mi355q_result_copy_to_host(cr, &c, 8));
     group_counts[2 * world + rank] = c;
     mi355q_result_free(cr);
   }
-  ncclCommDestroy(comm);
+  if (comm) ncclCommDestroy(comm);
   (void)hipFree(table); (void)hipFree(fresh_buf); (void)hipFree(recv); (void)hipFree(pads); (void)hipFree(recv_pads); (void)hipFree(ok);
   (void)hipFree(d_key); (void)hipFree(d_val); (void)hipFree(d_fil);
-  (void)mi355q_release_workspace(rank);
+  if (sim) g_loop->bar.wait();
+  if (!sim || rank == 0) (void)mi355q_release_workspace(dev);
 }
 
 }  // namespace
@@ -260,12 +420,35 @@ int main(int argc, char** argv) {
     std::printf("multi_check: no GPU\n");
     return 77;
   }
-  const int world = argc > 1 ? std::min(std::atoi(argv[1]), n_dev) : n_dev;
-  const int64_t total_rows = argc > 2 ? (int64_t)std::atof(argv[2]) : 256000000;
-  const int64_t n_keys = argc > 3 ? (int64_t)std::atof(argv[3]) : 2000000;
-  std::printf("multi_check: %d device(s), %lld rows, %lld keys\n", world, (long long)total_rows, (long long)n_keys);
-  ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) {
+  int arg0 = 1;
+  int sim_ranks = 0;
+  if (argc > 2 && std::strcmp(argv[1], "--sim") == 0) {
+    sim_ranks = std::max(1, std::atoi(argv[2]));
+    arg0 = 3;
+  }
+  const int world = sim_ranks ? sim_ranks : (argc > arg0 ? std::min(std::atoi(argv[arg0]), n_dev) : n_dev);
+  if (!sim_ranks && argc > arg0) ++arg0;
+  const int64_t total_rows = argc > arg0 ? (int64_t)std::atof(argv[arg0]) : 256000000;
+  const int64_t n_keys = argc > arg0 + 1 ? (int64_t)std::atof(argv[arg0 + 1]) : 2000000;
+  std::printf("multi_check: %d %s, %lld rows, %lld keys\n", world, sim_ranks ? "rank(s) simulated on device 0" : "device(s)",
+              (long long)total_rows, (long long)n_keys);
+  LoopComm loop;
+  if (sim_ranks) {
+    if (hipSetDevice(0) != hipSuccess) return 1;
+    loop.world = world;
+    loop.bar.n = world;
+    loop.send_ptr.assign((size_t)world * world, nullptr);
+    loop.send_bytes.assign((size_t)world * world, 0);
+    loop.ready.resize(world);
+    loop.done.resize(world);
+    for (int r = 0; r < world; ++r)
+      if (hipEventCreateWithFlags(&loop.ready[r], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&loop.done[r], hipEventDisableTiming) != hipSuccess)
+        return 1;
+    g_loop = &loop;
+  }
+  ncclUniqueId id{};
+  if (!sim_ranks && ncclGetUniqueId(&id) != ncclSuccess) {
     std::printf("multi_check: ncclGetUniqueId failed\n");
     return 1;
   }

@@ -17,3 +17,14 @@ for k in (10, 100, 4096):
         n = rs.sort(1, k, int(out.data_ptr()), desc=True)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"top-{k} by COUNT(*) DESC over {q.entry_count} entries ({rs.rowCount()} groups): {dt*1e3:.3f} ms; best counts {out[:3,1].tolist()}")
+
+# the FULL sort (mi355q_result_sort: one device radix sort of (key, entry) pairs per order entry — rocPRIM, where the
+# reference calls thrust::sort_by_key — then a row gather), every live row, one and two order entries
+n_live = rs.rowCount()
+out_all = torch.empty((n_live, rq), dtype=torch.int64, device="cuda")
+for order, tag in (([(1, True, False)], "COUNT(*) DESC"), ([(1, True, False), (0, False, False)], "COUNT(*) DESC, key ASC")):
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        n = rs.sort_by(order, int(out_all.data_ptr()))
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"full sort ORDER BY {tag} over {q.entry_count} entries ({n} rows out, {n * q.row_size / 1e6:.0f} MB gathered): {dt*1e3:.3f} ms")
