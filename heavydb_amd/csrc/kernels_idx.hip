@@ -600,7 +600,15 @@ bool make_idx_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scra
   bool need[kLdsVals][4];
   if (tune_knobs().flags & MI355Q_OPT_NO_IDX_PART) return false;
   if (!lds_describe(p, fv, ((int64_t)1 << 31) - 1, 0, &a, need)) return false;
-  if (a.baseline || a.n_flt != 0 || a.n_vals < 1 || a.n_keys < 1) return false;
+  if (a.baseline || a.n_flt != 0 || a.n_keys < 1) return false;
+  if (a.n_vals == 0) {
+    // only COUNT(*) / key projections (Sort/S001-003: SELECT key, COUNT(*) ... GROUP BY key): the 8-byte record's value
+    // half carries the first key column again and no target reads it
+    a.n_vals = 1;
+    a.v[0].col = a.key_col[0];
+    a.v[0].type = MI355Q_INT32;
+    a.v[0].nullable = 0;
+  }
   if (p.entry_count <= 65536 || fv.n_frags < 1 || n_cus < 1) return false;
   if (fv.max_frag_rows > 0xfff00000ll) return false;
   for (int v = 0; v < a.n_vals; ++v) {

@@ -424,6 +424,14 @@ hipError_t hipEventCreate(hipEvent_t* e) {
   *e = new ihipEvent_t{0.0};
   return hipSuccess;
 }
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
+  *p = std::malloc(bytes ? bytes : 1);
+  return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void* p) {
+  std::free(p);
+  return hipSuccess;
+}
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 // a launch runs when it is enqueued, so whatever an event stands for has already happened
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t e, unsigned) { return e ? hipSuccess : hipErrorInvalidValue; }
