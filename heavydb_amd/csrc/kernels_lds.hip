@@ -924,6 +924,14 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out
   a.copy_bytes = lay(a.entries);
   // (second baseline attempt: the largest power-of-two replica the accumulators leave room for)
   while (a.baseline && a.copy_bytes > kLdsBudget && a.entries > kLdsHashSmall) a.copy_bytes = lay(a.entries / 2);
+  // baseline, the large replica, windows not forced: as many windows as the NDV estimate needs at <= 80 % fill
+  if (a.baseline && a.windows == 1 && a.entries > kLdsHashSmall) {
+    const int64_t est = p.entry_count / 2;
+    int64_t T = (est * 5 / 4 + a.entries - 1) / a.entries;
+    if (T < 1) T = 1;
+    if (T > (int64_t)kLdsMaxWindows) T = kLdsMaxWindows;
+    a.windows = (uint32_t)T;
+  }
   // a perfect-hash table larger than the LDS: the fewest windows whose share fits (one replica each)
   if (!a.baseline && a.copy_bytes > kLdsBudget) {
     const uint32_t total = (uint32_t)p.entry_count;
