@@ -45,9 +45,10 @@ OUTPUT_ROWWISE, OUTPUT_COLUMNAR, OUTPUT_ROWWISE_COLUMNAR_DECISIONS = 0, 1, 2  # 
 GEN_I32_UNIFORM31, GEN_I32_MOD, GEN_I64_MOD, GEN_I64_MOD_MUL, GEN_F64_UNIT = 1, 2, 3, 4, 5
 
 # mi355q_expr_op (projected expressions)
-EX_COL, EX_LIT, EX_CAST, EX_ADD, EX_SUB, EX_MUL = 1, 2, 3, 4, 5, 6
+EX_COL, EX_LIT, EX_CAST, EX_ADD, EX_SUB, EX_MUL, EX_DIV, EX_MOD = 1, 2, 3, 4, 5, 6, 7, 8
 
 OK = 0
+ERR_DIV_BY_ZERO = 1
 ERR_OUT_OF_SLOTS = 3
 ERR_OVERFLOW_OR_UNDERFLOW = 7
 ERR_INVALID_PLAN = 100

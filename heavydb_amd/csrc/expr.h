@@ -12,7 +12,9 @@
 //                (sadd/ssub/smul.with.overflow at the operand type's width, NULL operands skip the check and
 //                give NULL: codegenSkipOverflowCheckForNull); floating point: add_/sub_/mul_<type>_nullable,
 //                RuntimeFunctions.cpp:46-53
-//   error        ErrorCode::OVERFLOW_OR_UNDERFLOW = 7 (QueryEngine/enums.h:30-51)
+//   / %          ArithmeticIR.cpp:431-560 codegenDiv (zero check skipped behind a NULL operand), :731-760 codegenMod (zero
+//                check first); div_/mod_<type>_nullable[_lhs|_rhs], RuntimeFunctions.cpp:46-71
+//   error        ErrorCode::OVERFLOW_OR_UNDERFLOW = 7, DIV_BY_ZERO = 1 (QueryEngine/enums.h:30-51)
 #pragma once
 
 #include "dev_common.h"
@@ -28,7 +30,8 @@ MQ_HD int64_t ex_int_min(int t) { return plain_int_null(t); }  // the type's min
 MQ_HD int64_t ex_flt_pattern(float f) { return (int64_t)(uint32_t)flt_bits(f); }
 MQ_HD float ex_flt_of(int64_t v) { return bits_flt((int32_t)(uint32_t)v); }
 
-// *err receives MI355Q_ERR_OVERFLOW_OR_UNDERFLOW when a check fires (the value returned is then unspecified)
+// *err receives MI355Q_ERR_OVERFLOW_OR_UNDERFLOW / MI355Q_ERR_DIV_BY_ZERO when a check fires (the value returned is then
+// unspecified); the FIRST check that fires along the program is the one reported
 MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos, int32_t* err) {
   int64_t st[4] = {0, 0, 0, 0};
   int sp = 0;
@@ -57,7 +60,7 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
             if (is_null) {
               r = plain_int_null(to);
             } else if (plain_width(to) < plain_width(from) && (v > ex_int_max(to) || v <= ex_int_min(to))) {
-              *err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+              { if (!*err) *err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW; }
             }
           } else if (to == MI355Q_DOUBLE) {
             r = is_null ? kNullDoubleBits : dbl_bits((double)v);
@@ -74,6 +77,44 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
           const bool is_null = nullable && f == kNullFloat;
           if (to == MI355Q_DOUBLE) r = is_null ? kNullDoubleBits : dbl_bits((double)f);
           else if (ex_is_int(to)) r = is_null ? plain_int_null(to) : (int64_t)(f + (f < 0.0f ? -0.5f : 0.5f));
+        }
+        st[sp - 1] = r;
+        break;
+      }
+      case MI355Q_EX_DIV:
+      case MI355Q_EX_MOD: {
+        const int64_t b = st[--sp];
+        const int64_t a = st[sp - 1];
+        const int t = n.type;
+        const bool ln = (n.flags & EXF_LHS_NULLABLE) != 0, rn = (n.flags & EXF_RHS_NULLABLE) != 0;
+        int64_t r;
+        if (ex_is_int(t)) {
+          const int64_t nul = plain_int_null(t);
+          // DIV: a NULL pattern in EITHER operand skips the zero check as soon as one of them may be NULL; MOD tests first
+          const bool skip = n.op == MI355Q_EX_DIV && (ln || rn) && (a == nul || b == nul);
+          if (!skip && b == 0) {
+            { if (!*err) *err = MI355Q_ERR_DIV_BY_ZERO; }
+            r = nul;
+          } else if ((ln && a == nul) || (rn && b == nul)) {
+            r = nul;
+          } else if (b == 0) {
+            r = nul;                        // (INT_MIN / 0 behind the skip: undefined in the reference, never trapped here)
+          } else if (b == -1) {
+            r = n.op == MI355Q_EX_DIV ? (int64_t)(0 - (uint64_t)a) : 0;  // INT_MIN / -1 wraps instead of trapping
+          } else {
+            r = n.op == MI355Q_EX_DIV ? a / b : a % b;
+          }
+          if (t != MI355Q_INT64) r = t == MI355Q_INT8 ? (int64_t)(int8_t)r : t == MI355Q_INT16 ? (int64_t)(int16_t)r : (int64_t)(int32_t)r;
+        } else if (t == MI355Q_DOUBLE) {
+          const double x = bits_dbl(a), y = bits_dbl(b);
+          const bool skip = (ln || rn) && (x == kNullDouble || y == kNullDouble);
+          if (!skip && !(y < 0.0 || y > 0.0)) { if (!*err) *err = MI355Q_ERR_DIV_BY_ZERO; }
+          r = ((ln && x == kNullDouble) || (rn && y == kNullDouble)) ? kNullDoubleBits : dbl_bits(x / y);
+        } else {
+          const float x = ex_flt_of(a), y = ex_flt_of(b);
+          const bool skip = (ln || rn) && (x == kNullFloat || y == kNullFloat);
+          if (!skip && !(y < 0.0f || y > 0.0f)) { if (!*err) *err = MI355Q_ERR_DIV_BY_ZERO; }
+          r = ((ln && x == kNullFloat) || (rn && y == kNullFloat)) ? (int64_t)(uint32_t)kNullFloatBits : ex_flt_pattern(x / y);
         }
         st[sp - 1] = r;
         break;
@@ -98,7 +139,7 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
               ovf = r > ex_int_max(t) || r < ex_int_min(t);
               r = t == MI355Q_INT8 ? (int64_t)(int8_t)r : t == MI355Q_INT16 ? (int64_t)(int16_t)r : (int64_t)(int32_t)r;
             }
-            if (ovf) *err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+            if (ovf) { if (!*err) *err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW; }
           }
         } else if (t == MI355Q_DOUBLE) {
           const double x = bits_dbl(a), y = bits_dbl(b);

@@ -707,11 +707,16 @@ __global__ __launch_bounds__(kBlock) void k_project(DevExprSet xs, DevPlan p, ui
     const int64_t n = num_rows[f];
     for (int64_t pos = gtid; pos < n; pos += gsize) {
       uint32_t err_mask = 0;
+      int32_t first_err = 0, first_qual_err = 0;  // the code of the first expression that failed (7 overflow, 1 division by zero)
       for (int k = 0; k < xs.n; ++k) {
         int32_t err = 0;
         const int64_t v = eval_expr(xs.e[k], fc, pos, &err);
         store_expr_value(const_cast<int8_t*>(fc[xs.n_cols + k]), xs.e[k].type, pos, v);
-        if (err) err_mask |= 1u << k;
+        if (err) {
+          err_mask |= 1u << k;
+          if (!first_err) first_err = err;
+          if (!first_qual_err && ((qual_expr_mask >> k) & 1u)) first_qual_err = err;
+        }
       }
       if (err_mask) {  // rare: does the row count?
         bool counts = (err_mask & qual_expr_mask) != 0;
@@ -728,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void k_project(DevExprSet xs, DevPlan p, ui
             counts = !null_key && join_lookup(p, jk).count > 0;
           }
         }
-        if (counts) atomicCAS(d_err, 0, MI355Q_ERR_OVERFLOW_OR_UNDERFLOW);
+        if (counts) atomicCAS(d_err, 0, first_qual_err ? first_qual_err : first_err);
       }
     }
   }

@@ -169,8 +169,11 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
         }
         case MI355Q_EX_ADD:
         case MI355Q_EX_SUB:
-        case MI355Q_EX_MUL: {
+        case MI355Q_EX_MUL:
+        case MI355Q_EX_DIV:
+        case MI355Q_EX_MOD: {
           if (!valid_type(n.type) || sp < 2) return MI355Q_ERR_INVALID_PLAN;
+          if (n.op == MI355Q_EX_MOD && !int_type(n.type)) return MI355Q_ERR_INVALID_PLAN;
           if (st_type[sp - 1] != n.type || st_type[sp - 2] != n.type) return MI355Q_ERR_INVALID_PLAN;
           o.type = n.type;
           o.flags = (st_null[sp - 2] ? EXF_LHS_NULLABLE : 0) | (st_null[sp - 1] ? EXF_RHS_NULLABLE : 0);

@@ -119,6 +119,12 @@ class Expr:
     def mul(self, other: "Expr", type: int) -> "Expr":
         return self._bin(capi.EX_MUL, other, type)
 
+    def div(self, other: "Expr", type: int) -> "Expr":
+        return self._bin(capi.EX_DIV, other, type)
+
+    def mod(self, other: "Expr", type: int) -> "Expr":
+        return self._bin(capi.EX_MOD, other, type)
+
     def with_range(self, r: ExpressionRange) -> "Expr":
         return Expr(self.nodes, r)
 

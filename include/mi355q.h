@@ -228,7 +228,15 @@ typedef enum mi355q_expr_op {
   MI355Q_EX_ADD = 4,   /* pop rhs, pop lhs, push lhs + rhs; both operands have the node's `type`
                           (the analyzer has normalised them); NULL if either operand is NULL */
   MI355Q_EX_SUB = 5,
-  MI355Q_EX_MUL = 6
+  MI355Q_EX_MUL = 6,
+  MI355Q_EX_DIV = 7,   /* lhs / rhs (integers truncate towards zero; DOUBLE / FLOAT divide).  codegenDiv, ArithmeticIR.cpp:431-560
+                          with g_null_div_by_zero off: when an operand may be NULL and one IS the type's NULL pattern the
+                          zero check is skipped (codegenSkipOverflowCheckForNull, :343-357) and the result is
+                          div_<type>_nullable[_lhs|_rhs] (RuntimeFunctions.cpp:46-71); otherwise a divisor equal to
+                          zero (floating point: not "ordered and != 0", so NaN too) ends the step with
+                          MI355Q_ERR_DIV_BY_ZERO (ErrorCode 1) for a row that counts, like an overflow */
+  MI355Q_EX_MOD = 8    /* lhs % rhs, integers only (codegenMod, :731-760): the divisor is tested against zero FIRST, whatever
+                          the operands' NULLs (error 1); then mod_<type>_nullable[_lhs|_rhs] */
 } mi355q_expr_op;
 
 typedef struct mi355q_expr_node {

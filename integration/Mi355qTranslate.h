@@ -135,7 +135,8 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
     push(MI355Q_EX_CAST, logical_type(u->get_type_info()), 0, 0, 0.0);
   } else if (auto b = dynamic_cast<const Analyzer::BinOper*>(e)) {
     const int32_t op = b->get_optype() == kPLUS ? MI355Q_EX_ADD : b->get_optype() == kMINUS ? MI355Q_EX_SUB
-                       : b->get_optype() == kMULTIPLY ? MI355Q_EX_MUL : 0;
+                       : b->get_optype() == kMULTIPLY ? MI355Q_EX_MUL : b->get_optype() == kDIVIDE ? MI355Q_EX_DIV
+                       : b->get_optype() == kMODULO ? MI355Q_EX_MOD : 0;
     if (!op) unsupported("binary operator");
     emit_expr(b->get_left_operand(), x, outer_col);
     emit_expr(b->get_right_operand(), x, outer_col);

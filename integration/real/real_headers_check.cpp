@@ -107,8 +107,13 @@ int main() {
     REQ(e2.n_nodes == 6 && e2.nodes[5].op == MI355Q_EX_SUB && e2.nodes[2].op == MI355Q_EX_MUL && e2.nodes[4].op == MI355Q_EX_CAST &&
         e2.nodes[4].type == MI355Q_INT64);
     auto div = std::make_shared<BinOper>(t_big, false, kDIVIDE, kONE, y, l3);
+    auto mod = std::make_shared<BinOper>(t_big, false, kMODULO, kONE, div, l3);
     mi355q_expr e3{};
-    REQ(refuses([&] { emit_expr(div.get(), e3, outer_col); }));
+    emit_expr(mod.get(), e3, outer_col);
+    REQ(e3.n_nodes == 5 && e3.nodes[2].op == MI355Q_EX_DIV && e3.nodes[4].op == MI355Q_EX_MOD && e3.nodes[4].type == MI355Q_INT64);
+    auto band = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kAND, kONE, y, l3);
+    mi355q_expr e5{};
+    REQ(refuses([&] { emit_expr(band.get(), e5, outer_col); }));
     mi355q_expr e4{};
     REQ(refuses([&] { emit_expr(w.get(), e4, outer_col); }));  // an inner column is not a projectable value
     // ---- quals: x < 1, y IS NULL, NOT(y IS NULL)

@@ -95,10 +95,12 @@ def main():
             r = fn(v, null_of(f), null_of(t))
             out["cast"].append({"from": f, "to": t, "in": bits(f, v), "out": bits(t, r)})
     # ---- arithmetic
-    ops = {"add": capi.EX_ADD, "sub": capi.EX_SUB, "mul": capi.EX_MUL}
+    ops = {"add": capi.EX_ADD, "sub": capi.EX_SUB, "mul": capi.EX_MUL, "div": capi.EX_DIV, "mod": capi.EX_MOD}
     for t in INTS + [capi.FLOAT, capi.DOUBLE]:
         vals = int_samples(t, rng) if t in INTS else fp_samples(t, rng)
         for name, op in ops.items():
+            if name == "mod" and t not in INTS:
+                continue
             for suffix in ("_nullable", "_nullable_lhs", "_nullable_rhs"):
                 fn = getattr(ref, f"{name}_{TNAME[t]}{suffix}")
                 fn.restype = CT[t]
@@ -110,7 +112,16 @@ def main():
                     for b in b_list:
                         a_null = suffix in ("_nullable", "_nullable_lhs") and a == null_of(t)
                         b_null = suffix in ("_nullable", "_nullable_rhs") and b == null_of(t)
-                        if t in INTS and not (a_null or b_null):
+                        if name in ("div", "mod"):
+                            # what the generated code lets reach the function: a non-zero divisor (the zero check sits in
+                            # front — skipped, for DIV, behind a NULL pattern, where the function returns NULL or would trap)
+                            if name == "mod" and b == 0:
+                                continue  # codegenMod tests the divisor first, whatever the NULLs
+                            if (b == 0 or b == 0.0) and not (a_null or b_null):
+                                continue
+                            if t in INTS and (b == 0 or (a == INT_NULL[t] and b == -1)) and not ((suffix != "_nullable_rhs" and a_null) or b_null):
+                                continue  # INT_MIN / 0 and INT_MIN / -1: SIGFPE in the reference
+                        elif t in INTS and not (a_null or b_null):
                             exact = a + b if name == "add" else a - b if name == "sub" else a * b
                             if not (INT_NULL[t] <= exact <= INT_MAX[t]):
                                 continue  # signed overflow: the check fires first

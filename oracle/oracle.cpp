@@ -1228,6 +1228,38 @@ inline int32_t cast_value(const OrcVal& v, int to, OrcVal* out) {
 // codegenArith for one pair of values of type `t`
 inline int32_t arith_value(int op, int t, const OrcVal& a, const OrcVal& b, OrcVal* out) {
   OrcVal r{t, a.nullable || b.nullable, 0, 0.0, 0.0f};
+  if (op == MI355Q_EX_DIV || op == MI355Q_EX_MOD) {
+    // codegenDiv (ArithmeticIR.cpp:431-560, g_null_div_by_zero off): with a nullable operand, a NULL PATTERN in either operand
+    // skips the zero check (codegenSkipOverflowCheckForNull :343-357 tests both against the type's NULL); codegenMod
+    // (:731-760) tests the divisor first, whatever the NULLs.  Then div_/mod_<type>_nullable[_lhs|_rhs]
+    // (RuntimeFunctions.cpp:46-71): NULL when a NULLABLE operand is NULL, else lhs op rhs.
+    const bool any_nullable = a.nullable || b.nullable;
+    auto pattern_null = [&](const OrcVal& v) {
+      return is_int_type(t) ? v.i == int_null_of(t) : t == MI355Q_DOUBLE ? v.d == kNullDouble : v.f == kNullFloat;
+    };
+    const bool skip = op == MI355Q_EX_DIV && any_nullable && (pattern_null(a) || pattern_null(b));
+    const bool zero = is_int_type(t) ? b.i == 0 : t == MI355Q_DOUBLE ? !(b.d < 0.0 || b.d > 0.0) : !(b.f < 0.0f || b.f > 0.0f);
+    if (op == MI355Q_EX_MOD && !is_int_type(t)) return MI355Q_ERR_INVALID_PLAN;
+    if (!skip && zero) return MI355Q_ERR_DIV_BY_ZERO;
+    if (val_is_null(a) || val_is_null(b)) {
+      *out = null_of(t);
+      out->nullable = r.nullable;
+      return 0;
+    }
+    if (is_int_type(t)) {
+      int64_t w;
+      if (b.i == 0) w = int_null_of(t);                        // (undefined in the reference: INT_MIN / 0 behind the skip)
+      else if (b.i == -1) w = op == MI355Q_EX_DIV ? (int64_t)(0 - (uint64_t)a.i) : 0;   // INT_MIN / -1: wraps here, traps there
+      else w = op == MI355Q_EX_DIV ? a.i / b.i : a.i % b.i;
+      r.i = t == MI355Q_INT8 ? (int64_t)(int8_t)w : t == MI355Q_INT16 ? (int64_t)(int16_t)w : t == MI355Q_INT32 ? (int64_t)(int32_t)w : w;
+    } else if (t == MI355Q_DOUBLE) {
+      r.d = a.d / b.d;
+    } else {
+      r.f = a.f / b.f;
+    }
+    *out = r;
+    return 0;
+  }
   if (val_is_null(a) || val_is_null(b)) {
     *out = null_of(t);
     out->nullable = r.nullable;
@@ -1310,8 +1342,10 @@ inline int lower_plan(const mi355q_plan& p, mi355q_plan* out) {
       } else if (n.op == MI355Q_EX_CAST) {
         if (sp < 1) return MI355Q_ERR_INVALID_PLAN;
         ty[sp - 1] = n.type;
-      } else if (n.op == MI355Q_EX_ADD || n.op == MI355Q_EX_SUB || n.op == MI355Q_EX_MUL) {
+      } else if (n.op == MI355Q_EX_ADD || n.op == MI355Q_EX_SUB || n.op == MI355Q_EX_MUL || n.op == MI355Q_EX_DIV ||
+                 n.op == MI355Q_EX_MOD) {
         if (sp < 2 || ty[sp - 1] != n.type || ty[sp - 2] != n.type) return MI355Q_ERR_INVALID_PLAN;
+        if (n.op == MI355Q_EX_MOD && !is_int_type(n.type)) return MI355Q_ERR_INVALID_PLAN;
         nu[sp - 2] = nu[sp - 2] || nu[sp - 1];
         --sp;
       } else {

@@ -87,7 +87,19 @@ def expr_values(e: Expr, descs, cols):
             st.append((r, null, nd.type))
         else:
             (b, bn, _), (a, an, _) = st.pop(), st.pop()
-            r = a + b if nd.op == capi.EX_ADD else a - b if nd.op == capi.EX_SUB else a * b
+            if nd.op in (capi.EX_DIV, capi.EX_MOD):
+                if nd.type in (DOUBLE, capi.FLOAT):
+                    with np.errstate(divide="ignore", invalid="ignore"):
+                        r = a / b
+                else:  # truncating quotient, remainder with the dividend's sign; a zero divisor errors at run time (0 here)
+                    def one(x, y):
+                        if y == 0:
+                            return 0
+                        q = abs(x) // abs(y) * (1 if (x < 0) == (y < 0) else -1)
+                        return q if nd.op == capi.EX_DIV else x - q * y
+                    r = np.array([one(int(x), int(y)) for x, y in zip(a, b)], dtype=object)
+            else:
+                r = a + b if nd.op == capi.EX_ADD else a - b if nd.op == capi.EX_SUB else a * b
             st.append((r, an | bn, nd.type))
     return st[0]
 
@@ -663,6 +675,17 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("expr_overflow_in_a_qual_counts_for_every_row",
                       xra([C(0).add(Expr.lit(INT32, 2**30), INT32)], [TargetExpr(COUNT)],
                           [Qual(0, LT, 2**30), Qual(NC, GT, 0)]), frags, expect_error=capi.ERR_OVERFLOW_OR_UNDERFLOW))
+    # / and % (ArithmeticIR.cpp:431-560, :731-760): column 5 (int32, small values around 0) as a divisor
+    cases.append(Case("expr_div_by_zero_is_error_1",
+                      xra([C(0).div(C(5).cast(INT32), INT32)], [TargetExpr(MAX, NC), TargetExpr(COUNT)]), frags,
+                      expect_error=capi.ERR_DIV_BY_ZERO))
+    cases.append(Case("expr_mod_and_div_by_a_literal_grouped",
+                      xra([C(0).mod(Expr.lit(INT32, 7), INT32), C(2).div(Expr.lit(INT64, -3), INT64)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, NC + 1), TargetExpr(MIN, NC + 1)],
+                          group=[NC], guess=64), frags))
+    cases.append(Case("expr_double_division_by_a_positive_column",
+                      xra([C(3).div(C(9).add(Expr.lit(DOUBLE, 1e9), DOUBLE), DOUBLE)],
+                          [TargetExpr(SUM, NC), TargetExpr(COUNT, NC)]), frags))
     jx = [Expr.col(1).add(Expr.lit(INT64, 2**63 - 10**6), INT64)]   # overflows for positive values of column 1
     jxr = [e.with_range(expr_range(e, fdescs, ffrags)) for e in jx]
     cases.append(Case("expr_join_overflow_only_in_filtered_rows",  # rows with col1 > 0 are dropped by the qual

@@ -114,11 +114,16 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
       const int8_t* const* fc = (const int8_t* const*)(cols2.data() + (size_t)f * nc2);
       for (int64_t pos = 0; pos < n; ++pos) {
         uint32_t err_mask = 0;
+        int32_t first_err = 0, first_qual_err = 0;  // as k_project: the first failing expression's code (7 / 1)
         for (int k = 0; k < nx; ++k) {
           int32_t err = 0;
           const int64_t v = eval_expr(xs.e[k], fc, pos, &err);
           store_expr_value((int8_t*)fc[nc + k], xs.e[k].type, pos, v);
-          if (err) err_mask |= 1u << k;
+          if (err) {
+            err_mask |= 1u << k;
+            if (!first_err) first_err = err;
+            if (!first_qual_err && ((qual_expr_mask >> k) & 1u)) first_qual_err = err;
+          }
         }
         if (!err_mask) continue;
         bool counts = (err_mask & qual_expr_mask) != 0;
@@ -135,7 +140,7 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
             counts = !null_key && join_lookup(dl, jk).count > 0;
           }
         }
-        if (counts) return MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+        if (counts) return first_qual_err ? first_qual_err : first_err;
       }
     }
     mi355q_inputs in2 = *in;

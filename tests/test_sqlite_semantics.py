@@ -69,7 +69,8 @@ def _expr_sql(e, descs):
                 st.append((x, False))
         else:
             (b, _), (a, fp) = st.pop(), st.pop()
-            st.append((f"({a} {'+' if n.op == capi.EX_ADD else '-' if n.op == capi.EX_SUB else '*'} {b})", fp))
+            sym = {capi.EX_ADD: "+", capi.EX_SUB: "-", capi.EX_MUL: "*", capi.EX_DIV: "/", capi.EX_MOD: "%"}[n.op]
+            st.append((f"({a} {sym} {b})", fp))
     return st[0][0]
 
 
