@@ -1831,6 +1831,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   }
   mi355q_exec_options o{};
   if (opts) o = *opts;
+  for (int i = 0; i < plan->n_quals && i < MI355Q_MAX_QUALS; ++i)
+    if (MI355Q_QUAL_OR_GROUP(plan->quals[i].op) != 0) o.force_generic = 1;  // a disjunction among the quals: the row kernel
   {
     TuneKnobs k;
     k.blocks_per_cu = o.tune_blocks_per_cu;

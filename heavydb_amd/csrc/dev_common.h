@@ -244,9 +244,10 @@ MQ_HD double bits_dbl(int64_t i) {
 
 // ------------------------------------------------------------------ device-side plan
 struct DevQual {
-  int32_t col, op, type, nullable;  // type: type code of the column
+  int32_t col, op, type, nullable;  // type: type code of the column; op: the comparison alone
   int64_t ival;
   double fval;
+  int32_t or_group, pad_;           // 0 = a conjunct of its own; 1..3 = member of that disjunction
 };
 struct DevTarget {
   int32_t agg, col, table, arg_type;  // arg_type: type code of the argument column

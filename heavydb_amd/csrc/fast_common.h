@@ -240,6 +240,7 @@ inline bool all_aligned16(const FragView& fv, int col) {
 
 // Turn `col <op> literal` on an integer column into an inclusive range (+ negate for <>).
 inline bool make_range_filter(const DevQual& q, RangeFilter* f) {
+  if (q.or_group != 0) return false;  // a member of a disjunction is not a conjunct (those plans take the row kernel)
   if (q.type != MI355Q_INT32 && q.type != MI355Q_INT64) return false;
   f->col = q.col;
   f->negate = 0;

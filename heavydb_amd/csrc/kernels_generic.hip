@@ -721,8 +721,7 @@ __global__ __launch_bounds__(kBlock) void k_project(DevExprSet xs, DevPlan p, ui
       if (err_mask) {  // rare: does the row count?
         bool counts = (err_mask & qual_expr_mask) != 0;
         if (!counts) {
-          counts = true;
-          for (int i = 0; i < p.n_quals && counts; ++i) counts = eval_qual(p.quals[i], fc[p.quals[i].col], pos);
+          counts = quals_pass(p, fc, pos);
           if (counts && p.join_col >= 0 && p.join_kind != MI355Q_JOIN_LEFT) {
             int64_t jk[MI355Q_MAX_GROUP_COLS];
             bool null_key = false;

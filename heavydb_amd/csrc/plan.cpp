@@ -252,7 +252,7 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
     r.constrained = false;
     if (is_agg && r.col >= 0 && r.table == 0) {
       for (int k = 0; k < p.n_quals; ++k)
-        if (p.quals[k].op == MI355Q_IS_NOT_NULL && p.quals[k].col == r.col) r.constrained = true;
+        if (p.quals[k].op == MI355Q_IS_NOT_NULL && p.quals[k].col == r.col) r.constrained = true;  // (a top-level conjunct: group 0)
     }
     r.skip_null = is_agg && r.col >= 0 && ((r.arg_nullable && !r.constrained) || !grouped);
     // COUNT_IF's argument is the condition itself (TargetInfo.cpp:60-82)
@@ -656,12 +656,15 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
     const mi355q_qual& s = p.quals[i];
     DevQual& o = d->quals[i];
     o.col = s.col;
-    o.op = s.op;
+    o.op = MI355Q_QUAL_OP(s.op);
+    o.or_group = MI355Q_QUAL_OR_GROUP(s.op);
+    o.pad_ = 0;
+    if (s.op < 0 || (s.op >> 16) != 0 || o.or_group > MI355Q_MAX_OR_GROUPS) return MI355Q_ERR_INVALID_PLAN;
     o.type = col_type_code(p.cols[s.col]);
     o.nullable = p.cols[s.col].nullable != 0;
     o.ival = s.ival;
     o.fval = s.fval;
-    switch (s.op) {
+    switch (o.op) {
       case MI355Q_EQ: case MI355Q_NE: case MI355Q_LT: case MI355Q_GT: case MI355Q_LE:
       case MI355Q_GE: case MI355Q_IS_NULL: case MI355Q_IS_NOT_NULL:
         break;
@@ -679,8 +682,11 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
     o.arg_f32 = ts[i].arg_f32;
     if (ts[i].agg == MI355Q_COUNT_IF || ts[i].agg == MI355Q_SUM_IF) {
       const mi355q_qual& c = p.targets[i].cond;
+      if (MI355Q_QUAL_OR_GROUP(c.op) != 0 || c.op < 0 || (c.op >> 16) != 0) return MI355Q_ERR_INVALID_PLAN;
       o.cond.col = c.col;
       o.cond.op = c.op;
+      o.cond.or_group = 0;
+      o.cond.pad_ = 0;
       o.cond.type = col_type_code(p.cols[c.col]);
       o.cond.nullable = p.cols[c.col].nullable != 0;
       o.cond.ival = c.ival;

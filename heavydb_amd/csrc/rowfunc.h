@@ -822,14 +822,30 @@ MQ_FN int32_t reduce_entry(const DevPlan& p, int idx_target_as_key, int64_t* thi
   return 0;
 }
 
+// The whole filter of a step: every plain qual TRUE and, of every disjunction (quals sharing an or_group), at least one
+// member TRUE — the reference's logical_and / logical_or over nullable booleans followed by toBool (LogicalIR.cpp:299-352:
+// a NULL condition is not TRUE).
+MQ_FN bool quals_pass(const DevPlan& p, const int8_t* const* cols, int64_t pos) {
+  uint32_t seen = 0, any = 0;
+  for (int i = 0; i < p.n_quals; ++i) {
+    const DevQual& q = p.quals[i];
+    const bool t = eval_qual(q, cols[q.col], pos);
+    if (q.or_group == 0) {
+      if (!t) return false;
+    } else {
+      seen |= 1u << q.or_group;
+      if (t) any |= 1u << q.or_group;
+    }
+  }
+  return seen == any;
+}
+
 // ---------------------------------------------------------------- the row function
 // Returns 0, or a HeavyDB-style error: < 0 when the baseline table is full.
 template <bool A>
 MQ_FN int32_t process_row(const DevPlan& p, const int8_t* const* cols, int64_t pos,
                           int64_t* out_buf, int64_t* nongrouped_slots) {
-  for (int i = 0; i < p.n_quals; ++i) {
-    if (!eval_qual(p.quals[i], cols[p.quals[i].col], pos)) return 0;
-  }
+  if (!quals_pass(p, cols, pos)) return 0;
   JoinMatch jm{nullptr, -1, 1};  // no join: one pass with no inner row
   if (p.join_col >= 0) {
     int64_t jk[MI355Q_MAX_GROUP_COLS];

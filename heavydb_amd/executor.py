@@ -64,6 +64,7 @@ class Qual:
     col: int
     op: int
     literal: float | int = 0  # unused by IS_NULL / IS_NOT_NULL
+    or_group: int = 0         # 1..3: member of that disjunction (quals sharing a group are OR-ed, everything else AND-ed)
 
 
 @dataclass
@@ -201,7 +202,7 @@ class RelAlgExecutionUnit:
         p.n_quals = len(self.simple_quals)
         for i, q in enumerate(self.simple_quals):
             is_fp = self.col_type(q.col) in (DOUBLE, capi.FLOAT)
-            p.quals[i] = capi.Qual(q.col, q.op, 0 if is_fp else int(q.literal),
+            p.quals[i] = capi.Qual(q.col, q.op | (q.or_group << 8), 0 if is_fp else int(q.literal),
                                    float(q.literal) if is_fp else 0.0)
         if len(self.groupby_exprs) > capi.MAX_GROUP_COLS:
             raise ValueError("too many group-by columns")

@@ -165,10 +165,22 @@ typedef struct mi355q_col_desc {
                            (ENC_DICT implies INT32, ENC_DATE_IN_DAYS implies INT64) */
 } mi355q_col_desc;
 
-/* simple_quals entry: `col <op> literal` (RelAlgExecutionUnit.h:170) */
+/* simple_quals / quals entry: `col <op> literal` (RelAlgExecutionUnit.h:170).  The quals of a plan are a CONJUNCTION of
+ * such comparisons and of DISJUNCTIONS of them: quals whose `op` carries the same non-zero group number
+ * (MI355Q_QUAL_IN_OR_GROUP(op, g), g = 1..3) are OR-ed together, the groups and the plain quals are AND-ed — `x < 5 AND
+ * (y = 1 OR y = 2 OR z IS NULL)`.  With the reference's three-valued logic (logical_and / logical_or over nullable booleans,
+ * LogicalIR.cpp:299-340) a row passes the filter when the whole condition is TRUE — `toBool`, :344-352: NULL counts as
+ * false — i.e. when every plain qual is TRUE and every group has a member that is TRUE; NOT over a comparison is folded
+ * into the operator by the binding (NULL stays "not TRUE" either way).  Plans with a disjunction run in the row kernel.
+ * A member of a group is never a `constrained_not_null` witness (OutputBufferInitialization.cpp:301-324 looks at top-level
+ * conjuncts only). */
+#define MI355Q_QUAL_OP(op) ((op) & 0xff)
+#define MI355Q_QUAL_OR_GROUP(op) (((op) >> 8) & 0xff)
+#define MI355Q_QUAL_IN_OR_GROUP(op, g) ((op) | ((g) << 8))
+#define MI355Q_MAX_OR_GROUPS 3
 typedef struct mi355q_qual {
   int32_t col; /* outer-table column index */
-  int32_t op;  /* mi355q_op */
+  int32_t op;  /* mi355q_op, + the disjunction it belongs to (MI355Q_QUAL_IN_OR_GROUP) */
   int64_t ival; /* literal for integer columns */
   double fval;  /* literal for double columns */
 } mi355q_qual;

@@ -117,11 +117,10 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
     p.group_cols[p.n_group_cols++] = t.value_col(g.get());
   }
   // simple_quals and quals: a conjunction
+  int32_t n_or_groups = 0;
   for (const auto* lst : {&ra.simple_quals, &ra.quals})
-    for (const auto& q : *lst) {
-      if (p.n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
-      p.quals[p.n_quals++] = t.qual(q.get());
-    }
+    for (const auto& q : *lst)
+      translate_conjunct(q.get(), [&t](const Analyzer::Expr* v) { return t.value_col(v); }, p.quals, &p.n_quals, &n_or_groups);
   // target_exprs (get_target_info, Shared/TargetInfo.h:48-56): aggregates, or projections of a group key
   for (const auto* te : ra.target_exprs) {
     if (p.n_targets >= MI355Q_MAX_TARGETS) unsupported("too many targets");

@@ -183,6 +183,48 @@ inline mi355q_qual translate_qual(const Analyzer::Expr* e, const std::function<i
   return q;
 }
 
+// One conjunct of simple_quals / quals -> one or more plan quals: a comparison, or a DISJUNCTION of comparisons (`a OR b OR
+// ...`, Analyzer::BinOper kOR nested any way round) whose members share a fresh group number; NOT over a comparison is
+// folded into the operator (NOT(x < 5) = x >= 5: NULL stays "not TRUE" either way, LogicalIR.cpp:299-352).
+inline void translate_conjunct(const Analyzer::Expr* e, const std::function<int(const Analyzer::Expr*)>& value_col,
+                               mi355q_qual* quals, int32_t* n_quals, int32_t* n_groups, int32_t group = 0) {
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  if (b && b->get_optype() == kOR) {
+    if (!group) {
+      if (*n_groups >= MI355Q_MAX_OR_GROUPS) unsupported("too many disjunctions");
+      group = ++*n_groups;
+    }
+    translate_conjunct(b->get_left_operand(), value_col, quals, n_quals, n_groups, group);
+    translate_conjunct(b->get_right_operand(), value_col, quals, n_quals, n_groups, group);
+    return;
+  }
+  if (b && b->get_optype() == kAND) {
+    if (group) unsupported("AND inside OR");
+    translate_conjunct(b->get_left_operand(), value_col, quals, n_quals, n_groups, 0);
+    translate_conjunct(b->get_right_operand(), value_col, quals, n_quals, n_groups, 0);
+    return;
+  }
+  mi355q_qual q{};
+  auto u = dynamic_cast<const Analyzer::UOper*>(e);
+  auto inner = u && u->get_optype() == kNOT ? dynamic_cast<const Analyzer::BinOper*>(u->get_operand()) : nullptr;
+  if (inner) {
+    q = translate_qual(inner, value_col);
+    switch (q.op) {
+      case MI355Q_EQ: q.op = MI355Q_NE; break;
+      case MI355Q_NE: q.op = MI355Q_EQ; break;
+      case MI355Q_LT: q.op = MI355Q_GE; break;
+      case MI355Q_GE: q.op = MI355Q_LT; break;
+      case MI355Q_GT: q.op = MI355Q_LE; break;
+      default: q.op = MI355Q_GT; break;  // NOT(<=)
+    }
+  } else {
+    q = translate_qual(e, value_col);
+  }
+  if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
+  q.op = MI355Q_QUAL_IN_OR_GROUP(q.op, group);
+  quals[(*n_quals)++] = q;
+}
+
 // an aggregate of target_exprs (get_target_info, Shared/TargetInfo.h:48-56).  `inner_col` resolves a ColumnVar of the
 // inner table; COUNT_IF(cond): the argument IS the condition; SUM_IF(value, cond): the condition is arg1
 // (RelAlgTranslator.cpp:348-360).

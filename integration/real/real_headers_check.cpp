@@ -126,6 +126,23 @@ int main() {
     auto notnull = std::make_shared<UOper>(SQLTypeInfo(kBOOLEAN, true), false, kNOT, isnull);
     q = translate_qual(notnull.get(), value_col);
     REQ(q.op == MI355Q_IS_NOT_NULL && q.col == 1);
+    // x < 1 OR y IS NULL OR NOT(x >= 1)  -> three quals of one group; AND of that with another comparison
+    auto ge = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kGE, kONE, x, lit);
+    auto not_ge = std::make_shared<UOper>(SQLTypeInfo(kBOOLEAN, false), false, kNOT, ge);
+    auto or1 = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, true), false, kOR, kONE, lt, isnull);
+    auto or2 = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, true), false, kOR, kONE, or1, not_ge);
+    auto both = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, true), false, kAND, kONE, or2, ge);
+    mi355q_qual qs[MI355Q_MAX_QUALS];
+    int32_t nq = 0, ng = 0;
+    translate_conjunct(both.get(), value_col, qs, &nq, &ng);
+    REQ(nq == 4 && ng == 1);
+    REQ(MI355Q_QUAL_OP(qs[0].op) == MI355Q_LT && MI355Q_QUAL_OR_GROUP(qs[0].op) == 1);
+    REQ(MI355Q_QUAL_OP(qs[1].op) == MI355Q_IS_NULL && MI355Q_QUAL_OR_GROUP(qs[1].op) == 1 && qs[1].col == 1);
+    REQ(MI355Q_QUAL_OP(qs[2].op) == MI355Q_LT && MI355Q_QUAL_OR_GROUP(qs[2].op) == 1);   // NOT(x >= 1) folded
+    REQ(qs[3].op == MI355Q_GE);
+    auto and_in_or = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, true), false, kOR, kONE, both, lt);
+    nq = ng = 0;
+    REQ(refuses([&] { translate_conjunct(and_in_or.get(), value_col, qs, &nq, &ng); }));
     auto ge_cols = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kGE, kONE, x, y);
     REQ(refuses([&] { translate_qual(ge_cols.get(), value_col); }));  // column-vs-column compare: not in the plan ABI
     // ---- aggregates: SUM(y), COUNT(*), SUM(dim.w), COUNT_IF(x < 1), SUM_IF(y, x < 1), COUNT(DISTINCT x)

@@ -1374,8 +1374,10 @@ struct ExecCtx {
 };
 
 // DEF_CMP_NULLABLE (RuntimeFunctions.cpp:73-83) + toBool (>0): NULL operand -> false
-inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q, const int8_t* const* cols,
+inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q_in, const int8_t* const* cols,
                       int64_t pos) {
+  mi355q_qual q = q_in;
+  q.op = MI355Q_QUAL_OP(q_in.op);  // (the disjunction a qual belongs to travels in the upper bits)
   const auto& cd = p.cols[q.col];
   if (q.op == MI355Q_IS_NULL || q.op == MI355Q_IS_NOT_NULL) {
     // codegenIsNull (LogicalIR.cpp:381-432): constant false on a NOT NULL type, otherwise the value
@@ -1601,9 +1603,20 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
     for (int k = 0; k < nx; ++k)  // expressions inside quals: every row
       if (qual_exprs & (1u << k))
         if (int32_t e = eval_into_cell(k, pos)) return e;
+    // codegenLogical (LogicalIR.cpp:299-340) + toBool (:344-352): the condition must be TRUE — every plain conjunct, and
+    // of every disjunction (quals sharing a group number) at least one member; NULL is not TRUE
     bool pass = true;
-    for (int i = 0; i < p.n_quals && pass; ++i) pass = eval_qual(p, p.quals[i], cols, pos);
-    if (!pass) continue;
+    uint32_t or_seen = 0, or_any = 0;
+    for (int i = 0; i < p.n_quals && pass; ++i) {
+      const int g = MI355Q_QUAL_OR_GROUP(p.quals[i].op);
+      const bool t = eval_qual(p, p.quals[i], cols, pos);
+      if (g == 0) pass = t;
+      else {
+        or_seen |= 1u << g;
+        if (t) or_any |= 1u << g;
+      }
+    }
+    if (!pass || or_seen != or_any) continue;
     Matches jm;
     jm.count = 1;  // no join: one pass without an inner row
     if (p.join_outer_col >= 0) {

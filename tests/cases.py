@@ -675,6 +675,21 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("expr_overflow_in_a_qual_counts_for_every_row",
                       xra([C(0).add(Expr.lit(INT32, 2**30), INT32)], [TargetExpr(COUNT)],
                           [Qual(0, LT, 2**30), Qual(NC, GT, 0)]), frags, expect_error=capi.ERR_OVERFLOW_OR_UNDERFLOW))
+    # OR among the quals (LogicalIR.cpp:299-340): disjunctions of comparisons AND-ed with plain conjuncts; a NULL member is not
+    # TRUE; an `x IS NOT NULL` inside a disjunction is not a constrained_not_null witness
+    cases.append(Case("qual_or_two_ranges_count",
+                      ra([TargetExpr(COUNT), TargetExpr(SUM, 2)], [Qual(0, LT, 2**28, 1), Qual(0, GT, 2**31 - 2**28, 1)]), frags))
+    cases.append(Case("qual_or_with_null_members_and_a_conjunct_grouped",
+                      ra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 7), TargetExpr(MIN, 8)],
+                         [Qual(2, GT, -400000), Qual(7, LT, 0, 1), Qual(8, GT, 0, 1), Qual(6, capi.IS_NULL, 0, 1)],
+                         group=[1]), frags))
+    cases.append(Case("qual_two_disjunctions_and_not_null_member",
+                      ra([TargetExpr(PROJECT_KEY), TargetExpr(SUM, 7), TargetExpr(AVG, 9), TargetExpr(COUNT, 7)],
+                         [Qual(7, capi.IS_NOT_NULL, 0, 1), Qual(3, LT, 100.0, 1), Qual(10, EQ, 7, 2), Qual(10, GE, 30, 2)],
+                         group=[10]), frags))
+    cases.append(Case("qual_or_on_an_expression",
+                      xra([C(0).mod(Expr.lit(INT32, 10), INT32)], [TargetExpr(COUNT), TargetExpr(MAX, NC)],
+                          [Qual(NC, EQ, 3, 1), Qual(NC, EQ, 7, 1), Qual(1, LT, 50)]), frags))
     # / and % (ArithmeticIR.cpp:431-560, :731-760): column 5 (int32, small values around 0) as a divisor
     cases.append(Case("expr_div_by_zero_is_error_1",
                       xra([C(0).div(C(5).cast(INT32), INT32)], [TargetExpr(MAX, NC), TargetExpr(COUNT)]), frags,

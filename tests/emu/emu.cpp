@@ -128,8 +128,7 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         if (!err_mask) continue;
         bool counts = (err_mask & qual_expr_mask) != 0;
         if (!counts) {
-          counts = true;
-          for (int i = 0; i < dl.n_quals && counts; ++i) counts = eval_qual(dl.quals[i], fc[dl.quals[i].col], pos);
+          counts = quals_pass(dl, fc, pos);
           if (counts && dl.join_col >= 0 && dl.join_kind != MI355Q_JOIN_LEFT) {
             int64_t jk[MI355Q_MAX_GROUP_COLS];
             bool null_key = false;

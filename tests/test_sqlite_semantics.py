@@ -105,7 +105,7 @@ def _sql_for(case):
             left_inner = t.table and ra.join_kind == capi.JOIN_LEFT
             # ... and so does an argument constrained by a qual `arg IS NOT NULL` (constrained_not_null
             # -> set_notnull(target, true), OutputBufferInitialization.cpp:287)
-            constrained = (not t.table) and any(q.op == capi.IS_NOT_NULL and q.col == t.col for q in ra.simple_quals)
+            constrained = (not t.table) and any(q.op == capi.IS_NOT_NULL and q.col == t.col and not q.or_group for q in ra.simple_quals)
             if ra.groupby_exprs and (not arg_d.nullable or constrained) and not left_inner:
                 e = f"COALESCE({e}, 0)"
             sel.append(e)
@@ -117,7 +117,10 @@ def _sql_for(case):
         on = " AND ".join(f"f.c{c} = d.k{i}" for i, c in enumerate(join_cols))
         sql += (" LEFT JOIN" if ra.join_kind == capi.JOIN_LEFT else " JOIN") + f" d ON {on}"
     if ra.simple_quals:
-        sql += " WHERE " + " AND ".join(cond(q) for q in ra.simple_quals)
+        parts = [cond(q) for q in ra.simple_quals if not q.or_group]
+        for g in sorted({q.or_group for q in ra.simple_quals if q.or_group}):
+            parts.append("(" + " OR ".join(cond(q) for q in ra.simple_quals if q.or_group == g) + ")")
+        sql += " WHERE " + " AND ".join(parts)
     if ra.groupby_exprs:
         sql += " GROUP BY " + ", ".join(f"f.c{g}" for g in ra.groupby_exprs)
     return sql
