@@ -52,6 +52,8 @@ def parse_args():
     ap.add_argument("--scratch-gb", type=float, default=0, help="partition scratch cap of the step (0 = library default)")
     ap.add_argument("--overlap-cus", type=int, default=0, help="partitioned GROUP BY: CUs of phase 1 while phase 2 of the previous "
                     "chunk runs on the rest (tune_overlap_cus; 0 = the library's choice, -1 = phases one after the other)")
+    ap.add_argument("--probe-passes", type=int, default=0, help="cfg4 --sparse: passes per partition of the keyed payload probe "
+                    "(probe_keyed_passes; 0 = the library's choice)")
     ap.add_argument("--sparse", action="store_true", help="cfg4: sparse dim keys -> keyed {key, row id} join table (3.2 GB)")
     ap.add_argument("--sum-dim", action="store_true", help="cfg4: Query B, also SUM(dim.w) (reads an inner column)")
     ap.add_argument("--verify", action="store_true", help="size-independent property checks")
@@ -229,7 +231,7 @@ def main():
     def step():
         sh = HipShard.execute(torch, ex, ra, fr, kernel_variant=args.variant,
                               force_generic=args.force_generic, scratch_bytes=int(args.scratch_gb * 2**30),
-                              tune_overlap_cus=args.overlap_cus)
+                              tune_overlap_cus=args.overlap_cus, probe_keyed_passes=args.probe_passes)
         rep = sh.report
         if world > 1:
             sh = merge(sh, dist, torch, prepartitioned=prepart)

@@ -1612,7 +1612,12 @@ __global__ __launch_bounds__(BLOCK) void k_part_probe_l2(ProbeArgs a, const Rec*
 // contiguous slice of the table: its keys (8 B per slot, `kkeys`) and the per-slot payload stay in the
 // XCD's L2 while all workgroups of the XCD walk that partition.  Probing is the reference's linear probe
 // (get_matching_slot, JoinHashTableQueryRuntime.cpp:40-54): stop at the key or at an empty slot.
-template <bool PAY8>
+// PM: 0 = keys (kkeys, 8 B per slot), then the slot's 16-byte payload entry; 1 = {key, inner value} interleaved (pay8);
+//     2 = KEYS ONLY — a one-to-one table none of whose inner columns is read (cfg4 Query A on sparse keys): a match
+//     counts one joined row and nothing else is fetched, so a partition's slice is 8 B per slot — 1.6 MB for cfg4's 200 M
+//     slots, which an XCD's 4 MB L2 does keep next to the record stream (the 16-byte slices, 3.1 MB, hit 73 %:
+//     profiles/r03_cfg4_join_pmc_before.txt)
+template <int PM>
 __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Rec* __restrict__ scratch,
                                                             const uint32_t* __restrict__ cnt,
                                                             unsigned long long* __restrict__ acc,
@@ -1668,7 +1673,7 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
           hp[q] = probe_slot_of(a, murmur1_u64((uint64_t)rec[q].key));
           mine[q] = a.R == 1 || (hp[q] >= sub_lo && hp[q] < sub_hi);
           const uint32_t at = mine[q] ? hp[q] : (sub_lo < entries ? sub_lo : 0u);  // (the last partition's later passes may start past the table)
-          if (PAY8) {
+          if (PM == 1) {
             const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
             k0[q] = kp.x;
             w0[q] = kp.y;
@@ -1692,7 +1697,7 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
               }
               if (k == kEmptyKey64) break;
               h = h + 1 == entries ? 0 : h + 1;
-              if (PAY8) {
+              if (PM == 1) {
                 const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[h];
                 k = kp.x;
                 w0[q] = kp.y;
@@ -1705,7 +1710,9 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
         Pay16 pe[UQ];
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
-          if (PAY8) {  // the payload came with the key
+          if (PM == 2) {
+            pe[q] = Pay16{0, slot[q] >= 0 ? 1u : 0u, 0u};
+          } else if (PM == 1) {  // the payload came with the key
             const uint32_t present = slot[q] >= 0 && w0[q] != INT64_MIN;
             pe[q] = Pay16{present ? w0[q] : 0, present, present};
           } else {
@@ -2790,6 +2797,7 @@ struct ProbePartHost {
   int wcol;    // inner column or -1
   bool l2_mode;  // slices in L2 (k_part_probe_l2) instead of LDS (k_part_probe)
   bool keyed;    // keyed join table: partitioned by hash slot, probed in L2 (k_part_probe_keyed)
+  bool keys_only;  // ... one-to-one and no inner column read: the probe fetches the slot keys alone (8 B per slot)
 };
 
 constexpr size_t kProbeLdsBudget = 144 * 1024;
@@ -2803,6 +2811,7 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
   if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col < 0 || p.n_quals != 0) return false;
   if (p.join_hash_type < 0 || p.join_hash_type > 3 || p.join_n_keys != 1) return false;
   h.keyed = p.join_hash_type == 1 || p.join_hash_type == 3;
+  h.keys_only = false;
   if (h.keyed && p.join_width != 8) return false;
   if (p.join_kind != MI355Q_JOIN_INNER && p.join_kind != MI355Q_JOIN_LEFT) return false;
   if (p.join_type != MI355Q_INT64 || p.join_nullable || p.n_targets > 4) return false;
@@ -2860,7 +2869,8 @@ bool make_probe_plan(const DevPlan& p, const FragView& fv, const JoinPayloadView
     // one pass 89 ms, two passes of 1.6 MB 114 ms (the second read of the records costs more than the smaller
     // slice gives), direct probe 140 ms; without pacing the XCD group 113 / 129 ms
     if (!pay.kkeys || (!pay.pay16 && !pay.pay8)) return false;
-    R = (uint32_t)(((size_t)S1 * 16 + ((size_t)7 << 19) - 1) / ((size_t)7 << 19));
+    h.keys_only = p.join_hash_type == 1 && h.wcol < 0;
+    R = (uint32_t)(((size_t)S1 * (h.keys_only ? 8 : 16) + ((size_t)7 << 19) - 1) / ((size_t)7 << 19));
     if (R < 1) R = 1;
     {  // tests: several passes on a small table
       const int v = tune_knobs().probe_keyed_passes;
@@ -3056,8 +3066,9 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
       if (e != hipSuccess) return e;
     }
     if (h.keyed) {
-      if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed<true>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
-      else hipLaunchKernelGGL((k_part_probe_keyed<false>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      if (h.keys_only) hipLaunchKernelGGL((k_part_probe_keyed<2>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      else if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed<1>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      else hipLaunchKernelGGL((k_part_probe_keyed<0>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
     } else if (h.l2_mode) {
       // one 1024-lane workgroup per CU (measured, 3.2 B rows: 2048 workgroups of 256 lanes stream the
       // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms;
