@@ -52,6 +52,7 @@ def parse_args():
     ap.add_argument("--scratch-gb", type=float, default=0, help="partition scratch cap of the step (0 = library default)")
     ap.add_argument("--overlap-cus", type=int, default=0, help="partitioned GROUP BY: CUs of phase 1 while phase 2 of the previous "
                     "chunk runs on the rest (tune_overlap_cus; 0 = the library's choice, -1 = phases one after the other)")
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="tune_blocks_per_cu (experiments)")
     ap.add_argument("--probe-passes", type=int, default=0, help="cfg4 --sparse: passes per partition of the keyed payload probe "
                     "(probe_keyed_passes; 0 = the library's choice)")
     ap.add_argument("--sparse", action="store_true", help="cfg4: sparse dim keys -> keyed {key, row id} join table (3.2 GB)")
@@ -228,10 +229,14 @@ def main():
     ex = Executor(local_rank)
     local_rows = sum(fr.num_rows)
 
+    # the plan / input structs of the C-ABI are built once (as the reference compiles a step once); a step = one
+    # mi355q_execute on them + the result storage it writes
+    prep = HipShard.prepare(ex, ra, fr, kernel_variant=args.variant, force_generic=args.force_generic,
+                            scratch_bytes=int(args.scratch_gb * 2**30), tune_overlap_cus=args.overlap_cus,
+                            probe_keyed_passes=args.probe_passes, tune_blocks_per_cu=args.blocks_per_cu)
+
     def step():
-        sh = HipShard.execute(torch, ex, ra, fr, kernel_variant=args.variant,
-                              force_generic=args.force_generic, scratch_bytes=int(args.scratch_gb * 2**30),
-                              tune_overlap_cus=args.overlap_cus, probe_keyed_passes=args.probe_passes)
+        sh = HipShard.execute_prepared(torch, prep)
         rep = sh.report
         if world > 1:
             sh = merge(sh, dist, torch, prepartitioned=prepart)

@@ -198,8 +198,10 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
         const bool fp = v.type == MI355Q_DOUBLE;
         if (v.off_cnt >= 0) ((uint32_t*)(rep + v.off_cnt))[e] = 0;
         if (v.off_sum >= 0) ((int64_t*)(rep + v.off_sum))[e] = 0;  // 0 and +0.0 share the pattern
-        if (v.off_min >= 0) ((int64_t*)(rep + v.off_min))[e] = fp ? 0x7fefffffffffffffll : INT64_MAX;
-        if (v.off_max >= 0) ((int64_t*)(rep + v.off_max))[e] = fp ? (int64_t)0xffefffffffffffffull : INT64_MIN;
+        // (doubles: +inf / -inf, not +-DBL_MAX — a group whose only values are infinite must come out infinite where the
+        // reference's _skip_val aggregate takes the first value as it is; found by the division vectors, x / DBL_MIN = inf)
+        if (v.off_min >= 0) ((int64_t*)(rep + v.off_min))[e] = fp ? 0x7ff0000000000000ll : INT64_MAX;
+        if (v.off_max >= 0) ((int64_t*)(rep + v.off_max))[e] = fp ? (int64_t)0xfff0000000000000ull : INT64_MIN;
       }
     }
   }
@@ -924,14 +926,7 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out
   a.copy_bytes = lay(a.entries);
   // (second baseline attempt: the largest power-of-two replica the accumulators leave room for)
   while (a.baseline && a.copy_bytes > kLdsBudget && a.entries > kLdsHashSmall) a.copy_bytes = lay(a.entries / 2);
-  // baseline, the large replica, windows not forced: as many windows as the NDV estimate needs at <= 80 % fill
-  if (a.baseline && a.windows == 1 && a.entries > kLdsHashSmall) {
-    const int64_t est = p.entry_count / 2;
-    int64_t T = (est * 5 / 4 + a.entries - 1) / a.entries;
-    if (T < 1) T = 1;
-    if (T > (int64_t)kLdsMaxWindows) T = kLdsMaxWindows;
-    a.windows = (uint32_t)T;
-  }
+
   // a perfect-hash table larger than the LDS: the fewest windows whose share fits (one replica each)
   if (!a.baseline && a.copy_bytes > kLdsBudget) {
     const uint32_t total = (uint32_t)p.entry_count;

@@ -3066,9 +3066,12 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
       if (e != hipSuccess) return e;
     }
     if (h.keyed) {
-      if (h.keys_only) hipLaunchKernelGGL((k_part_probe_keyed<2>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
-      else if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed<1>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
-      else hipLaunchKernelGGL((k_part_probe_keyed<0>), dim3(n_cus), dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      // (tune_blocks_per_cu: experiments with two workgroups per CU — twice the gathers in flight)
+      const int bpc = tune_knobs().blocks_per_cu >= 1 && tune_knobs().blocks_per_cu <= 2 ? tune_knobs().blocks_per_cu : 1;
+      const dim3 pg(n_cus * bpc);
+      if (h.keys_only) hipLaunchKernelGGL((k_part_probe_keyed<2>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      else if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed<1>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      else hipLaunchKernelGGL((k_part_probe_keyed<0>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
     } else if (h.l2_mode) {
       // one 1024-lane workgroup per CU (measured, 3.2 B rows: 2048 workgroups of 256 lanes stream the
       // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms;

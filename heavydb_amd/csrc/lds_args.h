@@ -87,17 +87,14 @@ inline bool lds_describe(const DevPlan& p, const FragView& fv, int64_t max_entri
     a.n_keys = 1;
     a.baseline = 1;
     // the group count of a baseline table is only known afterwards: first 256-slot replicas (a table with a handful
-    // of groups gets one replica per few lanes), then the largest replica that fits, then another family
-    // third attempt: kLdsMaxWindows windows (classes of a key hash) of the largest replica
-    // The caller sizes a baseline table at ~2 x its NDV estimate (docs results.rst "50 % fill"): an estimate beyond what
-    // 256-slot replicas hold skips the first attempt, and the number of windows of the second follows the estimate
-    // (make_lds_args, once the replica size is known) — BH007 (10 K groups) ran small -> large -> EIGHT windows, every row
-    // visited eight times (29.7 ms per 1 B rows, profiles/r04_refbench_1b_call4.jsonl), where four windows hold the groups.
+    // of groups gets one replica per few lanes), then the largest replica that fits, then kLdsMaxWindows windows (classes
+    // of a key hash) of it, then another family.  (Round 4 tried to size the second attempt from the table's entry count
+    // — the caller's NDV guess x 2 — and skip the first: the reference's default guess is 16 384 whatever the data holds
+    // (g_default_max_groups_buffer_entry_guess, Execute.cpp:111), so BH001's ten groups got three windows and ran 2.4 x
+    // slower, 5.5 -> 13.5 ms per 1 B rows, profiles/r04_refbench_sel_call5.jsonl; reverted.)
     const uint32_t fl = knob_flags;
-    const bool small_ok = p.entry_count / 2 <= 192;
-    const bool large = (fl & (MI355Q_OPT_LDS_BASELINE_LARGE | MI355Q_OPT_LDS_BASELINE_WINDOWS)) || !small_ok;
-    a.entries = large ? kLdsHashMax : kLdsHashSmall;
-    if ((fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) || ((fl & MI355Q_OPT_LDS_BASELINE_LARGE) && !small_ok)) a.windows = kLdsMaxWindows;
+    a.entries = (fl & (MI355Q_OPT_LDS_BASELINE_LARGE | MI355Q_OPT_LDS_BASELINE_WINDOWS)) ? kLdsHashMax : kLdsHashSmall;
+    if (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) a.windows = kLdsMaxWindows;
   } else {
     return false;
   }

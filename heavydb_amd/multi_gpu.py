@@ -288,6 +288,38 @@ class HipShard:
         rs.handle = None  # ownership moved
         return sh
 
+    @staticmethod
+    def prepare(executor, ra_exe_unit, fetch_result, scratch_bytes: int = 0, kernel_variant: int = 0, force_generic: bool = False,
+                flags: int = 0, tune_cus: int = 0, tune_overlap_cus: int = 0, probe_keyed_passes: int = 0,
+                tune_blocks_per_cu: int = 0):
+        """Everything of a step that does not change from one execution to the next, built once: the plan and input structs of
+        the C-ABI, the options, the layout descriptor (the reference compiles a step once and runs it many times too —
+        the code cache, NativeCodegen.cpp).  `execute_prepared` then only allocates the result storage and calls the library."""
+        lib = capi.load_library()
+        plan = ra_exe_unit.to_plan()
+        inp, keep = fetch_result.to_c(plan.n_cols)
+        opts = executor._opts(None, None, force_generic, kernel_variant, scratch_bytes, probe_keyed_passes=probe_keyed_passes,
+                              flags=flags, tune_blocks_per_cu=tune_blocks_per_cu)
+        opts.tune_cus = tune_cus
+        opts.tune_overlap_cus = tune_overlap_cus
+        return dict(lib=lib, plan=plan, inp=inp, keep=(keep, fetch_result), opts=opts, qmd=executor.initQueryMemoryDescriptor(ra_exe_unit),
+                    device_id=executor.device_id)
+
+    @staticmethod
+    def execute_prepared(torch, prep) -> "HipShard":
+        """One execution of a prepared step (mi355q_execute; no retry ladder), result storage owned by a torch tensor."""
+        lib, q = prep["lib"], prep["qmd"]
+        buf = HipShard._alloc(torch, lib, q, prep["device_id"])
+        prep["opts"].out_buffer = int(buf.data_ptr())
+        out = C.c_void_p()
+        rep = capi.ExecReport()
+        code = lib.mi355q_execute(C.byref(prep["plan"]), C.byref(prep["inp"]), C.byref(prep["opts"]), C.byref(out), C.byref(rep))
+        if code:
+            raise capi.Mi355qError(code, "execute")
+        sh = HipShard(torch, q, prep["device_id"], buf, out.value)
+        sh.report = rep
+        return sh
+
     def result_set(self):
         from .executor import ResultSet
         rs = ResultSet(self.handle)
