@@ -1665,45 +1665,65 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
           const uint32_t i = i0 + UQ * BLOCK + q * BLOCK + t;
           nxt[q] = load_rec_nt(run + (i < n ? i : n - 1));
         }
-        uint32_t hp[UQ];
-        int64_t k0[UQ], w0[UQ];
-        bool mine[UQ];
-#pragma unroll
-        for (int q = 0; q < UQ; ++q) {  // the first probe of all four, unconditionally, in flight together
-          hp[q] = probe_slot_of(a, murmur1_u64((uint64_t)rec[q].key));
-          mine[q] = a.R == 1 || (hp[q] >= sub_lo && hp[q] < sub_hi);
-          const uint32_t at = mine[q] ? hp[q] : (sub_lo < entries ? sub_lo : 0u);  // (the last partition's later passes may start past the table)
-          if (PM == 1) {
-            const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
-            k0[q] = kp.x;
-            w0[q] = kp.y;
-          } else {
-            k0[q] = a.kkeys[at];
-            w0[q] = 0;
-          }
-        }
-        int64_t slot[UQ];
+        // The linear probes of the lane's four records advance TOGETHER, a window of W consecutive slots per record and
+        // round: all windows of a round are in flight at once.  (Until round 4 each record walked its probe sequence on its
+        // own, one slot per dependent gather: a wave follows its slowest lane, so a step paid the SUM over its four
+        // records of the longest probe sequence among 64 lanes — ~10 dependent L2 round trips per wave-probe, 82 % of the
+        // kernel's wave cycles parked in s_waitcnt, profiles/r04_cfg4_keyed_probe_sq_counters_*_call6.txt.)
+        constexpr int W = PM == 1 ? 2 : 4;   // slots per window: 32 bytes of {key, value} pairs, or of keys
+        uint32_t cur[UQ];
+        int64_t slot[UQ], w0[UQ];
+        uint32_t pend = 0;
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
-          const bool live = i0 + q * BLOCK + t < n && mine[q];
+          cur[q] = probe_slot_of(a, murmur1_u64((uint64_t)rec[q].key));
+          const bool mine = a.R == 1 || (cur[q] >= sub_lo && cur[q] < sub_hi);
           slot[q] = -1;
-          if (live) {
-            int64_t k = k0[q];
-            uint32_t h = hp[q];
-            for (uint32_t trips = 0; trips < entries; ++trips) {  // collisions: the rest of the linear probe
-              if (k == rec[q].key) {
-                slot[q] = h;
-                break;
-              }
-              if (k == kEmptyKey64) break;
-              h = h + 1 == entries ? 0 : h + 1;
+          w0[q] = 0;
+          if (i0 + q * BLOCK + t < n && mine) pend |= 1u << q;
+        }
+        for (uint32_t rounds = 0; pend && rounds <= entries / W + 1; ++rounds) {
+          int64_t wk[UQ][W], wvv[UQ][W];
+          // (unconditional loads — a record that is done re-reads its last window out of the cache: loads under a
+          // lane-dependent `if` are serialised by the compiler, one s_waitcnt each; r02_l2_probe_variants.jsonl)
+#pragma unroll
+          for (int q = 0; q < UQ; ++q) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              uint32_t at = cur[q] + (uint32_t)j;
+              if (at >= entries) at -= entries;   // (the probe sequence wraps at the table's end)
               if (PM == 1) {
-                const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[h];
-                k = kp.x;
-                w0[q] = kp.y;
+                const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
+                wk[q][j] = kp.x;
+                wvv[q][j] = kp.y;
               } else {
-                k = a.kkeys[h];
+                wk[q][j] = a.kkeys[at];
+                wvv[q][j] = 0;
               }
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < UQ; ++q) {
+            if (!(pend & (1u << q))) continue;
+            bool done = false;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              if (done) continue;
+              if (wk[q][j] == rec[q].key) {
+                uint32_t at = cur[q] + (uint32_t)j;
+                if (at >= entries) at -= entries;
+                slot[q] = at;
+                w0[q] = wvv[q][j];
+                done = true;
+              } else if (wk[q][j] == kEmptyKey64) {
+                done = true;
+              }
+            }
+            if (done) {
+              pend &= ~(1u << q);
+            } else {
+              cur[q] += W;
+              if (cur[q] >= entries) cur[q] -= entries;
             }
           }
         }
