@@ -821,6 +821,49 @@ __global__ __launch_bounds__(kBlock) void k_project_simple(SimpleProj sp, const 
 // are zipped into the final layout: one lane per entry of a run's table locates the group's row in the final
 // table (same entry index for perfect-hash layouts; the reference's insert-or-find for baseline ones) and copies
 // the run's slots to where the final layout keeps them.
+// ---- GROUP BY CAST(<integer column> AS DOUBLE | FLOAT): the step ran on the integer column (a perfect-hash layout, `sub`);
+// every live entry is re-keyed with the cast value — the bit pattern of the double the key widens to (castToTypeIn(group_key,
+// 64), IRCodegen.cpp:1505-1507; NULL -> the NULL of the cast's type, cast_<int>_to_<fp>_nullable) — and merged into the
+// baseline-hash table of the stated plan with the reduce rule (two integers that cast to one FLOAT become one group).
+__global__ __launch_bounds__(kBlock) void k_cast_key_emit(DevPlan pf, DevPlan ps, int idx_key_s, int cast_to_float,
+                                                           const int64_t* __restrict__ sub, int64_t* __restrict__ fin,
+                                                           int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < ps.entry_count; e += stride) {
+    const int64_t* row_s = sub + e * ps.row_quad;
+    if (is_empty_row(ps, row_s, idx_key_s)) continue;
+    const int64_t* slots_s = row_s + ps.key_quad;
+    // the integer key of the entry: index -> translated key (single column: mul = 1); the translated NULL key is the NULL
+    const int64_t tk = e + ps.group_min[0];
+    const bool is_null = ps.group_translate[0] && tk == ps.group_null_key[0];
+    int64_t key;
+    if (cast_to_float) key = dbl_bits((double)(is_null ? kNullFloat : (float)tk));
+    else key = is_null ? kNullDoubleBits : dbl_bits((double)tk);
+    int64_t* slots_f = baseline_find_or_insert(fin, (uint32_t)pf.entry_count, pf.row_quad, pf.key_width, key);
+    if (!slots_f) {
+      atomicCAS(d_err, 0, -1);  // out of group slots: the caller grows the table and retries
+      continue;
+    }
+    for (int i = 0; i < pf.n_targets; ++i) {
+      const DevTarget& tf = pf.targets[i];
+      const DevTarget& ts = ps.targets[i];
+      if (tf.slot < 0) continue;
+      int64_t win[2];
+      if (tf.agg == MI355Q_PROJECT_KEY) {
+        win[0] = key;
+        win[1] = 0;
+      } else {
+        if (ts.slot < 0) continue;
+        win[0] = slots_s[ts.slot];
+        win[1] = tf.agg == MI355Q_AVG ? slots_s[ts.slot + 1] : 0;
+      }
+      DevTarget lt = tf;
+      lt.slot = 0;
+      reduce_target<true>(lt, pf.init_vals + tf.slot, slots_f + tf.slot, win);
+    }
+  }
+}
+
 struct ZipMap {
   int32_t n;                          // slot copies
   int32_t src[MI355Q_MAX_SLOTS], dst[MI355Q_MAX_SLOTS];  // slot index in the run's row -> slot index in the final row
@@ -1232,6 +1275,13 @@ bool project_simple_shapes(const DevExprSet& xs) {
 
 // `simple`: every expression is of the one-operation shape AND the caller found every source chunk 16-byte aligned —
 // one k_project_simple launch per expression; an overflow raises d_err[2] and the caller comes back with simple = false
+hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, const int64_t* sub,
+                                int64_t* fin, int32_t* d_err, hipStream_t s) {
+  if (ps.entry_count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_cast_key_emit, dim3(grid_for(ps.entry_count)), dim3(kBlock), 0, s, pf, ps, idx_key_s, cast_to_float, sub, fin, d_err);
+  return hipGetLastError();
+}
+
 hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_expr_mask, const int8_t* const* d_cols,
                           const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_err, int n_cus,
                           hipStream_t s, bool simple) {

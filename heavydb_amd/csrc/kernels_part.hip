@@ -1617,18 +1617,54 @@ __global__ __launch_bounds__(BLOCK) void k_part_probe_l2(ProbeArgs a, const Rec*
 //     counts one joined row and nothing else is fetched, so a partition's slice is 8 B per slot — 1.6 MB for cfg4's 200 M
 //     slots, which an XCD's 4 MB L2 does keep next to the record stream (the 16-byte slices, 3.1 MB, hit 73 %:
 //     profiles/r03_cfg4_join_pmc_before.txt)
+// Probe scheduling (round 4).  Every lane keeps K = 4 probe sequences in flight and each round fetches, for every sequence,
+// a WINDOW of W consecutive slots; a sequence that ends (key found, or an empty slot) is REPLACED in the same round by the
+// wave's next record, taken from a per-wave ring of records in LDS that the wave itself fills with coalesced chunks of its
+// run — nothing is shared between waves, so the inner loop has no workgroup barrier, and a long probe sequence (the
+// table is half full: 1.5 slots on average, but the longest of a few hundred sequences is ~10) delays only its own lane
+// slot.  History, cfg4 sparse, 3.33 B probes per launch: one slot per dependent gather, each record's sequence walked on
+// its own — a wave follows its slowest lane, ~10 dependent L2 round trips per wave-probe, 82 % of the wave cycles in
+// s_waitcnt (profiles/r04_cfg4_keyed_probe_sq_counters_*_call6.txt) — 50.9 ms; the four sequences of a lane advancing
+// together in windows, still finishing together: ~41 ms (profiles/r04_bench_cfg4_sparse*_call7.json).
+constexpr int kProbeRing = 512, kProbeChunk = 256;  // records per wave: the ring (two chunks), one coalesced chunk
+constexpr size_t kProbeKeyedLds = 16 * PA_N * sizeof(unsigned long long) + (size_t)16 * kProbeRing * sizeof(Rec);
+#define MQ_WAVE_LDS_SYNC()               \
+  do {                                   \
+    asm volatile("" ::: "memory");       \
+    __builtin_amdgcn_wave_barrier();     \
+    asm volatile("" ::: "memory");       \
+  } while (0)
+
 template <int PM>
 __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Rec* __restrict__ scratch,
                                                             const uint32_t* __restrict__ cnt,
                                                             unsigned long long* __restrict__ acc,
                                                             unsigned int* __restrict__ pace) {
-  __shared__ unsigned long long s_red[16 * PA_N];
-  constexpr int BLOCK = 1024, UQ = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int K = 4, CH = kProbeChunk, RING = kProbeRing;
+  constexpr int W = PM == 1 ? 2 : 4;  // slots per window: 32 bytes of {key, value} pairs, or of keys
+  unsigned long long* s_red = (unsigned long long*)smem_raw;  // [16 * PA_N]
   const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
-  const int t = threadIdx.x;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  v4i32_t* ring = (v4i32_t*)(smem_raw + 16 * PA_N * sizeof(unsigned long long)) + wave * RING;
   const uint32_t entries = (uint32_t)a.range;
+  const uint32_t max_steps = entries / W + 1;
   unsigned long long v[PA_N];
   for (int k = 0; k < PA_N; ++k) v[k] = 0;
+  auto tally = [&](unsigned long long c, int64_t wsum, uint32_t wnn, int64_t val) {
+    if (!c) return;
+    const bool nn = val != a.null_sum;
+    v[PA_J] += c;
+    v[PA_M] += 1;
+    if (nn) {
+      v[PA_SVC] += (unsigned long long)val * c;
+      v[PA_SVM] += (unsigned long long)val;
+      v[PA_NNVC] += c;
+      v[PA_NNVM] += 1;
+    }
+    v[PA_SW] += (unsigned long long)wsum;
+    v[PA_NNW] += wnn;
+  };
   // a.R > 1: the partition's slot range is walked in R passes (each re-reads the partition's records and
   // keeps the keys whose home slot is in the pass's sub-range), so that the slice being probed — 16 B per
   // slot — stays within what an XCD's L2 holds next to the record stream
@@ -1648,116 +1684,149 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
       __syncthreads();
     }
     const uint32_t sub_lo = (uint32_t)p * a.S1 + (uint32_t)r * a.S2, sub_hi = sub_lo + a.S2;
-    for (int b = g; b < a.B; b += G) {
-      const uint32_t n = cnt[(size_t)p * a.B + b];
-      const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
-      if (!n) continue;
-      Rec rec[UQ];
-#pragma unroll
-      for (int q = 0; q < UQ; ++q) {
-        const uint32_t i = q * BLOCK + t;
-        rec[q] = load_rec_nt(run + (i < n ? i : n - 1));
+    // the wave's share of the unit: chunk c of the runs b = g, g + G, ... with c = wave (mod 16)
+    int b = g;
+    uint32_t c = (uint32_t)wave;
+    uint32_t n_run = b < a.B ? cnt[(size_t)p * a.B + b] : 0u;
+    v4i32_t pre[4];          // the next chunk, on its way from HBM: records lane + 64 j
+    uint32_t pre_count = 0;  // > 0: `pre` holds a chunk that is not in the ring yet
+    bool more = true;
+    auto fetch = [&]() {
+      while (b < a.B && (uint64_t)c * CH >= n_run) {
+        b += G;
+        c = (uint32_t)wave;
+        n_run = b < a.B ? cnt[(size_t)p * a.B + b] : 0u;
       }
-      for (uint32_t i0 = 0; i0 < n; i0 += UQ * BLOCK) {
-        Rec nxt[UQ];
+      if (b >= a.B) {
+        more = false;
+        return;
+      }
+      const uint32_t count = n_run - c * CH < (uint32_t)CH ? n_run - c * CH : (uint32_t)CH;
+      const Rec* base = scratch + ((size_t)p * a.B + b) * a.cap + (size_t)c * CH;
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) {
-          const uint32_t i = i0 + UQ * BLOCK + q * BLOCK + t;
-          nxt[q] = load_rec_nt(run + (i < n ? i : n - 1));
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t i = (uint32_t)lane + 64u * j;
+        pre[j] = __builtin_nontemporal_load((const v4i32_t*)(base + (i < count ? i : count - 1)));
+      }
+      pre_count = count;
+      c += 16;
+    };
+    uint32_t avail = 0, taken = 0;  // records put into / taken out of the wave's ring (wave-uniform, running totals)
+    int64_t key[K], val[K];
+    uint32_t cur[K], steps[K], pslot[K];
+    uint32_t active = 0, paying = 0;
+#pragma unroll
+    for (int q = 0; q < K; ++q) {
+      key[q] = 0;
+      val[q] = 0;
+      cur[q] = 0;
+      steps[q] = 0;
+      pslot[q] = 0;
+    }
+    fetch();
+    for (;;) {
+      if (pre_count && avail - taken <= (uint32_t)(RING - CH)) {  // room for a chunk: move it into the ring
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t i = (uint32_t)lane + 64u * j;
+          if (i < pre_count) ring[(avail + i) & (RING - 1)] = pre[j];
         }
-        // The linear probes of the lane's four records advance TOGETHER, a window of W consecutive slots per record and
-        // round: all windows of a round are in flight at once.  (Until round 4 each record walked its probe sequence on its
-        // own, one slot per dependent gather: a wave follows its slowest lane, so a step paid the SUM over its four
-        // records of the longest probe sequence among 64 lanes — ~10 dependent L2 round trips per wave-probe, 82 % of the
-        // kernel's wave cycles parked in s_waitcnt, profiles/r04_cfg4_keyed_probe_sq_counters_*_call6.txt.)
-        constexpr int W = PM == 1 ? 2 : 4;   // slots per window: 32 bytes of {key, value} pairs, or of keys
-        uint32_t cur[UQ];
-        int64_t slot[UQ], w0[UQ];
-        uint32_t pend = 0;
+        avail += pre_count;
+        pre_count = 0;
+        MQ_WAVE_LDS_SYNC();
+      }
+      // free sequences take the next records of the ring, in lane order
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) {
-          cur[q] = probe_slot_of(a, murmur1_u64((uint64_t)rec[q].key));
-          const bool mine = a.R == 1 || (cur[q] >= sub_lo && cur[q] < sub_hi);
-          slot[q] = -1;
-          w0[q] = 0;
-          if (i0 + q * BLOCK + t < n && mine) pend |= 1u << q;
-        }
-        for (uint32_t rounds = 0; pend && rounds <= entries / W + 1; ++rounds) {
-          int64_t wk[UQ][W], wvv[UQ][W];
-          // (unconditional loads — a record that is done re-reads its last window out of the cache: loads under a
-          // lane-dependent `if` are serialised by the compiler, one s_waitcnt each; r02_l2_probe_variants.jsonl)
-#pragma unroll
-          for (int q = 0; q < UQ; ++q) {
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-              uint32_t at = cur[q] + (uint32_t)j;
-              if (at >= entries) at -= entries;   // (the probe sequence wraps at the table's end)
-              if (PM == 1) {
-                const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
-                wk[q][j] = kp.x;
-                wvv[q][j] = kp.y;
-              } else {
-                wk[q][j] = a.kkeys[at];
-                wvv[q][j] = 0;
-              }
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < UQ; ++q) {
-            if (!(pend & (1u << q))) continue;
-            bool done = false;
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-              if (done) continue;
-              if (wk[q][j] == rec[q].key) {
-                uint32_t at = cur[q] + (uint32_t)j;
-                if (at >= entries) at -= entries;
-                slot[q] = at;
-                w0[q] = wvv[q][j];
-                done = true;
-              } else if (wk[q][j] == kEmptyKey64) {
-                done = true;
-              }
-            }
-            if (done) {
-              pend &= ~(1u << q);
-            } else {
-              cur[q] += W;
-              if (cur[q] >= entries) cur[q] -= entries;
-            }
+      for (int q = 0; q < K; ++q) {
+        const bool want = !(active & (1u << q));
+        const unsigned long long m = __ballot(want);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t room = avail - taken, wanted = (uint32_t)__popcll(m);
+        const bool get = want && rank < room;
+        const v4i32_t x = ring[(get ? taken + rank : taken) & (RING - 1)];
+        if (get) {
+          key[q] = (int64_t)(((uint64_t)(uint32_t)x.y << 32) | (uint64_t)(uint32_t)x.x);
+          val[q] = (int64_t)(((uint64_t)(uint32_t)x.w << 32) | (uint64_t)(uint32_t)x.z);
+          const uint32_t home = probe_slot_of(a, murmur1_u64((uint64_t)key[q]));
+          if (a.R == 1 || (home >= sub_lo && home < sub_hi)) {  // (else: another pass's record)
+            cur[q] = home;
+            steps[q] = 0;
+            active |= 1u << q;
           }
         }
-        Pay16 pe[UQ];
+        taken += wanted < room ? wanted : room;
+      }
+      MQ_WAVE_LDS_SYNC();
+      if (!__any(active != 0)) {
+        if (taken != avail || pre_count) continue;
+        if (!more) break;
+        fetch();
+        continue;
+      }
+      // one window per sequence, all in flight together (unconditional loads — a free sequence re-reads its last window
+      // out of the cache: loads under a lane-dependent `if` are serialised by the compiler, one s_waitcnt each;
+      // r02_l2_probe_variants.jsonl)
+      int64_t wk[K][W], wvv[K][W];
+      Pay16 pe[K];
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) {
-          if (PM == 2) {
-            pe[q] = Pay16{0, slot[q] >= 0 ? 1u : 0u, 0u};
-          } else if (PM == 1) {  // the payload came with the key
-            const uint32_t present = slot[q] >= 0 && w0[q] != INT64_MIN;
-            pe[q] = Pay16{present ? w0[q] : 0, present, present};
+      for (int q = 0; q < K; ++q) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          uint32_t at = cur[q] + (uint32_t)j;
+          if (at >= entries) at -= entries;  // (the probe sequence wraps at the table's end)
+          if (PM == 1) {
+            const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
+            wk[q][j] = kp.x;
+            wvv[q][j] = kp.y;
           } else {
-            pe[q] = a.pay16[slot[q] >= 0 ? (uint64_t)slot[q] : 0ull];
+            wk[q][j] = a.kkeys[at];
+            wvv[q][j] = 0;
           }
         }
+        if (PM == 0) pe[q] = a.pay16[pslot[q]];  // the payload entry of a sequence that found its slot last round
+      }
+      if (!pre_count && more) fetch();  // (issued behind the windows: the round does not wait for it)
 #pragma unroll
-        for (int q = 0; q < UQ; ++q) {
-          const unsigned long long c = slot[q] >= 0 ? pe[q].cnt : 0u;
-          if (c) {
-            const bool nn = rec[q].val != a.null_sum;
-            v[PA_J] += c;
-            v[PA_M] += 1;
-            if (nn) {
-              v[PA_SVC] += (unsigned long long)rec[q].val * c;
-              v[PA_SVM] += (unsigned long long)rec[q].val;
-              v[PA_NNVC] += c;
-              v[PA_NNVM] += 1;
-            }
-            v[PA_SW] += (unsigned long long)pe[q].wsum;
-            v[PA_NNW] += pe[q].wnn;
+      for (int q = 0; q < K; ++q) {
+        const uint32_t bit = 1u << q;
+        if (!(active & bit)) continue;
+        if (PM == 0 && (paying & bit)) {
+          tally(pe[q].cnt, pe[q].wsum, pe[q].wnn, val[q]);
+          paying &= ~bit;
+          active &= ~bit;
+          pslot[q] = 0;
+          continue;
+        }
+        int state = 0;  // 1 found, 2 empty slot: no match
+        uint32_t at_hit = 0;
+        int64_t w0 = 0;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          if (state) continue;
+          if (wk[q][j] == key[q]) {
+            at_hit = cur[q] + (uint32_t)j;
+            if (at_hit >= entries) at_hit -= entries;
+            w0 = wvv[q][j];
+            state = 1;
+          } else if (wk[q][j] == kEmptyKey64) {
+            state = 2;
           }
         }
-#pragma unroll
-        for (int q = 0; q < UQ; ++q) rec[q] = nxt[q];
+        if (state == 1) {
+          if (PM == 0) {
+            pslot[q] = at_hit;
+            paying |= bit;
+          } else {
+            if (PM == 2) tally(1, 0, 0, val[q]);
+            else if (w0 != INT64_MIN) tally(1, w0, 1, val[q]);
+            active &= ~bit;
+          }
+        } else if (state == 2 || ++steps[q] > max_steps) {
+          active &= ~bit;
+        } else {
+          cur[q] += W;
+          if (cur[q] >= entries) cur[q] -= entries;
+        }
       }
     }
     if (pace) {
@@ -1766,6 +1835,7 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
     }
    }
   }
+  __syncthreads();
   probe_reduce_store(acc, v, s_red);
 }
 
@@ -3086,12 +3156,15 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
       if (e != hipSuccess) return e;
     }
     if (h.keyed) {
-      // (tune_blocks_per_cu: experiments with two workgroups per CU — twice the gathers in flight)
-      const int bpc = tune_knobs().blocks_per_cu >= 1 && tune_knobs().blocks_per_cu <= 2 ? tune_knobs().blocks_per_cu : 1;
-      const dim3 pg(n_cus * bpc);
-      if (h.keys_only) hipLaunchKernelGGL((k_part_probe_keyed<2>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
-      else if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed<1>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
-      else hipLaunchKernelGGL((k_part_probe_keyed<0>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      // one 1024-lane workgroup per CU: 16 waves, each with its own ring of records in LDS
+      const dim3 pg(n_cus);
+      auto probe = [&](auto kern) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kProbeKeyedLds);
+        hipLaunchKernelGGL(kern, pg, dim3(1024), kProbeKeyedLds, s, h.pa, recs, cnt, acc, pace);
+      };
+      if (h.keys_only) probe(k_part_probe_keyed<2>);
+      else if (h.pa.pay8) probe(k_part_probe_keyed<1>);
+      else probe(k_part_probe_keyed<0>);
     } else if (h.l2_mode) {
       // one 1024-lane workgroup per CU (measured, 3.2 B rows: 2048 workgroups of 256 lanes stream the
       // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms;
