@@ -1550,6 +1550,138 @@ int32_t execute_multi_value(const mi355q_plan* plan, const mi355q_inputs* in, co
   return MI355Q_OK;
 }
 
+// GROUP BY CAST(<plain integer column> AS DOUBLE | FLOAT) — the reference benchmark's BaselineHash and MultiStep
+// BaselineHash shapes (Benchmarks/synthetic_benchmark/queries/BaselineHash/BH001-006.sql, MultiStep/MSBS001-005.sql).  A
+// floating-point key always takes the baseline layout (GroupByAndAggregate.cpp:232-365: getExprRangeInfo is FloatingPoint),
+// but the groups ARE the integer column's values: the step runs on a derived plan that groups by the integer column
+// itself (perfect hash: the LDS / partitioned families, no key expression to project), and its entries are then re-keyed
+// with the cast value and merged into the baseline table of the stated plan (kernels_generic.hip k_cast_key_emit).
+// kNotTaken when the shape does not call for it.
+int32_t execute_cast_key(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
+                         mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
+  if (plan->n_group_cols != 1 || plan->join_outer_col >= 0 || plan->output_columnar_hint != 0 || o.kernel_variant == 1 ||
+      o.force_generic)
+    return kNotTaken;
+  const int nc = plan->n_cols, gc = plan->group_cols[0];
+  if (gc < nc || gc >= nc + plan->n_exprs) return kNotTaken;
+  const mi355q_expr& ex = plan->exprs[gc - nc];
+  if (ex.n_nodes != 2 || ex.nodes[0].op != MI355Q_EX_COL || ex.nodes[1].op != MI355Q_EX_CAST) return kNotTaken;
+  const int to = ex.nodes[1].type, c = ex.nodes[0].arg;
+  if ((to != MI355Q_DOUBLE && to != MI355Q_FLOAT) || c < 0 || c >= nc) return kNotTaken;
+  const mi355q_col_desc& cd = plan->cols[c];
+  const mi355q_range& cr = plan->col_ranges[c];
+  if ((cd.type != MI355Q_INT32 && cd.type != MI355Q_INT64) || cd.encoding != MI355Q_ENC_NONE ||
+      (cd.logical_type != 0 && cd.logical_type != cd.type) || !cr.valid || cr.bucket != 0 || (cr.has_nulls && !cd.nullable))
+    return kNotTaken;
+  int64_t total_rows = 0;
+  for (int f = 0; f < in->n_frags; ++f) total_rows += in->num_rows[f];
+  // (kernel_variant 2 = "the large-input members": how the tests reach this route with small tables)
+  if (o.kernel_variant != 2 && total_rows < ((int64_t)4 << 20)) return kNotTaken;
+  // the derived plan: the key expression leaves, the expressions behind it move down one column
+  mi355q_plan p2 = *plan;
+  p2.group_cols[0] = c;
+  for (int e = gc - nc; e + 1 < plan->n_exprs; ++e) p2.exprs[e] = plan->exprs[e + 1];
+  p2.n_exprs = plan->n_exprs - 1;
+  bool key_read = false;
+  auto move = [&](int32_t& col) {
+    key_read = key_read || col == gc;
+    if (col > gc) --col;
+  };
+  for (int t = 0; t < p2.n_targets; ++t) {
+    mi355q_target& tg = p2.targets[t];
+    if (tg.agg == MI355Q_PROJECT_KEY) continue;
+    if (tg.table == 0 && tg.col >= 0) move(tg.col);
+    if (tg.agg == MI355Q_COUNT_IF || tg.agg == MI355Q_SUM_IF) move(tg.cond.col);
+  }
+  for (int i = 0; i < p2.n_quals; ++i) move(p2.quals[i].col);
+  if (key_read) return kNotTaken;  // the cast value itself is aggregated or filtered on
+  mi355q_qmd q, q2;
+  if (qmd_init(*plan, &q) != MI355Q_OK || qmd_init(p2, &q2) != MI355Q_OK) return kNotTaken;
+  if (q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || q.slot_width != 8 || q.key_width != 8 || q.output_columnar ||
+      q2.desc_type != MI355Q_GROUP_BY_PERFECT_HASH || q2.slot_width != 8 || q2.output_columnar)
+    return kNotTaken;
+  for (int t = 0; t < plan->n_targets; ++t) {
+    const int sf = q.target_slot[t], ss = q2.target_slot[t];
+    if (plan->targets[t].agg == MI355Q_PROJECT_KEY) {
+      if (sf >= 0) return kNotTaken;  // (baseline: projections are read from the key column)
+      continue;
+    }
+    if (sf < 0 || ss < 0) return kNotTaken;
+    for (int j = 0; j < (plan->targets[t].agg == MI355Q_AVG ? 2 : 1); ++j)
+      if (q.init_vals[sf + j] != q2.init_vals[ss + j]) return kNotTaken;
+  }
+  mi355q_exec_options o2 = o;
+  o2.out_buffer = nullptr;
+  if (reserved) {
+    route_note("the step grouped by the integer column + k_cast_key_emit");
+    return execute_impl(&p2, in, &o2, out, report, nullptr, reserved);
+  }
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+  o2.stream = s;
+  mi355q_result* r2 = nullptr;
+  mi355q_exec_report rep2{};
+  if (int32_t e2 = mi355q_execute(&p2, in, &o2, &r2, &rep2)) {
+    if (e2 == MI355Q_ERR_UNSUPPORTED || e2 == MI355Q_ERR_OUT_OF_GPU_MEM || e2 < 0) return kNotTaken;
+    return e2;
+  }
+  struct R2Guard {
+    mi355q_result* r;
+    ~R2Guard() { if (r) mi355q_result_free(r); }
+  } r2g{r2};
+  if (r2->qmd.desc_type != MI355Q_GROUP_BY_PERFECT_HASH || r2->qmd.slot_width != 8 || r2->qmd.output_columnar ||
+      r2->qmd.entry_count != q2.entry_count || r2->qmd.group_min[0] != q2.group_min[0])
+    return kNotTaken;
+  mi355q_result* res = nullptr;
+  if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;
+  struct ResGuard {
+    mi355q_result* r;
+    ~ResGuard() { if (r) mi355q_result_free(r); }
+  } rg{res};
+  HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+  DevWord err;
+  HIP_TRY(hipMalloc(&err.p, 64));
+  HIP_TRY(hipMemsetAsync(err.p, 0, 64, s));
+  // (NULL keys of a nullable column sit at max + 1: groupByColumnCodegen translate_null_val, as plan.cpp build_dev_plan)
+  HIP_TRY(launch_cast_key_emit(res->dplan, r2->dplan, r2->qmd.idx_target_as_key, to == MI355Q_FLOAT ? 1 : 0, cd.nullable != 0,
+                               q2.group_min[0], q2.group_null_key[0], r2->buf, res->buf, (int32_t*)err.p, s));
+  if (ev1) HIP_TRY(hipEventRecord(ev1, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_err) return h_err;
+  if (report) {
+    *report = rep2;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->n_launches = rep2.n_launches + 1;
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  rg.r = nullptr;
+  *out = res;
+  return MI355Q_OK;
+}
+
 // Plans with projected expressions (mi355q_expr): scan / filter / PROJECT.  The expressions of a pass of
 // fragments are evaluated into dense temporary columns (k_project), the step runs on the lowered plan — where
 // those columns are ordinary inputs, so every kernel family applies — and the passes' results are folded with
@@ -1843,6 +1975,10 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     set_tune_knobs(k);
   }
   if (plan->n_exprs != 0) {
+    if (!pend) {
+      const int32_t e = execute_cast_key(plan, in, o, out, report, reserved);
+      if (e != kNotTaken) return e;
+    }
     if (reserved) {  // the step proper runs on the lowered plan: reserve for that
       route_note("k_project");
       mi355q_plan lp;

@@ -112,8 +112,9 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 // copies slots src[i] of every live row of `sub` (layout ps) to slots dst[i] of the same group's row in `fin`
 // (layout pf, same group columns): see k_zip_targets
 // GROUP BY CAST(int column AS DOUBLE | FLOAT): entries of the integer-keyed perfect table re-keyed and merged into the baseline table
-hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, const int64_t* sub,
-                                int64_t* fin, int32_t* d_err, hipStream_t s);
+hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, int translate,
+                                int64_t key_min, int64_t null_key, const int64_t* sub, int64_t* fin, int32_t* d_err,
+                                hipStream_t s);
 hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_s, const int64_t* sub, int64_t* fin,
                               const int32_t* src, const int32_t* dst, int n, int32_t* d_err, hipStream_t s);
 // projected expressions: d_cols is the pass's extended fragment table [frag][xs.n_cols + xs.n]; the last xs.n

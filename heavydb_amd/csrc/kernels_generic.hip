@@ -825,19 +825,26 @@ __global__ __launch_bounds__(kBlock) void k_project_simple(SimpleProj sp, const 
 // every live entry is re-keyed with the cast value — the bit pattern of the double the key widens to (castToTypeIn(group_key,
 // 64), IRCodegen.cpp:1505-1507; NULL -> the NULL of the cast's type, cast_<int>_to_<fp>_nullable) — and merged into the
 // baseline-hash table of the stated plan with the reduce rule (two integers that cast to one FLOAT become one group).
-__global__ __launch_bounds__(kBlock) void k_cast_key_emit(DevPlan pf, DevPlan ps, int idx_key_s, int cast_to_float,
+struct CastKeyArgs {
+  int32_t idx_key_s;      // keyless integer-keyed table: the target whose slot tells an empty entry
+  int32_t cast_to_float;  // the cast's type: FLOAT (else DOUBLE)
+  int32_t translate;      // the integer column is nullable: its NULL sits at `null_key` (max + 1)
+  int32_t reserved;
+  int64_t key_min, null_key;
+};
+__global__ __launch_bounds__(kBlock) void k_cast_key_emit(DevPlan pf, DevPlan ps, CastKeyArgs ck,
                                                            const int64_t* __restrict__ sub, int64_t* __restrict__ fin,
                                                            int32_t* __restrict__ d_err) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < ps.entry_count; e += stride) {
     const int64_t* row_s = sub + e * ps.row_quad;
-    if (is_empty_row(ps, row_s, idx_key_s)) continue;
+    if (is_empty_row(ps, row_s, ck.idx_key_s)) continue;
     const int64_t* slots_s = row_s + ps.key_quad;
     // the integer key of the entry: index -> translated key (single column: mul = 1); the translated NULL key is the NULL
-    const int64_t tk = e + ps.group_min[0];
-    const bool is_null = ps.group_translate[0] && tk == ps.group_null_key[0];
+    const int64_t tk = e + ck.key_min;
+    const bool is_null = ck.translate && tk == ck.null_key;
     int64_t key;
-    if (cast_to_float) key = dbl_bits((double)(is_null ? kNullFloat : (float)tk));
+    if (ck.cast_to_float) key = dbl_bits((double)(is_null ? kNullFloat : (float)tk));
     else key = is_null ? kNullDoubleBits : dbl_bits((double)tk);
     int64_t* slots_f = baseline_find_or_insert(fin, (uint32_t)pf.entry_count, pf.row_quad, pf.key_width, key);
     if (!slots_f) {
@@ -1275,10 +1282,12 @@ bool project_simple_shapes(const DevExprSet& xs) {
 
 // `simple`: every expression is of the one-operation shape AND the caller found every source chunk 16-byte aligned —
 // one k_project_simple launch per expression; an overflow raises d_err[2] and the caller comes back with simple = false
-hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, const int64_t* sub,
-                                int64_t* fin, int32_t* d_err, hipStream_t s) {
+hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, int translate,
+                                int64_t key_min, int64_t null_key, const int64_t* sub, int64_t* fin, int32_t* d_err,
+                                hipStream_t s) {
   if (ps.entry_count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(k_cast_key_emit, dim3(grid_for(ps.entry_count)), dim3(kBlock), 0, s, pf, ps, idx_key_s, cast_to_float, sub, fin, d_err);
+  const CastKeyArgs ck{idx_key_s, cast_to_float, translate, 0, key_min, null_key};
+  hipLaunchKernelGGL(k_cast_key_emit, dim3(grid_for(ps.entry_count)), dim3(kBlock), 0, s, pf, ps, ck, sub, fin, d_err);
   return hipGetLastError();
 }
 

@@ -1635,39 +1635,24 @@ constexpr size_t kProbeKeyedLds = 16 * PA_N * sizeof(unsigned long long) + (size
     asm volatile("" ::: "memory");       \
   } while (0)
 
-template <int PM>
+template <int PM, int K>
 __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Rec* __restrict__ scratch,
                                                             const uint32_t* __restrict__ cnt,
                                                             unsigned long long* __restrict__ acc,
                                                             unsigned int* __restrict__ pace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int K = 4, CH = kProbeChunk, RING = kProbeRing;
+  constexpr int CH = kProbeChunk, RING = kProbeRing;
   constexpr int W = PM == 1 ? 2 : 4;  // slots per window: 32 bytes of {key, value} pairs, or of keys
   unsigned long long* s_red = (unsigned long long*)smem_raw;  // [16 * PA_N]
   const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // (wave-uniform: the chunk bookkeeping stays in scalar registers)
   v4i32_t* ring = (v4i32_t*)(smem_raw + 16 * PA_N * sizeof(unsigned long long)) + wave * RING;
   const uint32_t entries = (uint32_t)a.range;
-  const uint32_t max_steps = entries / W + 1;
+  // PM 1 / 2: a match is exactly one joined row, so J = M, SVC = SVM, NNVC = NNVM — three of the eight sums are kept
+  // per lane: matches, SUM(outer value) and COUNT(outer value) over the matches, plus SUM(inner value) for PM 1
   unsigned long long v[PA_N];
   for (int k = 0; k < PA_N; ++k) v[k] = 0;
-  auto tally = [&](unsigned long long c, int64_t wsum, uint32_t wnn, int64_t val) {
-    if (!c) return;
-    const bool nn = val != a.null_sum;
-    v[PA_J] += c;
-    v[PA_M] += 1;
-    if (nn) {
-      v[PA_SVC] += (unsigned long long)val * c;
-      v[PA_SVM] += (unsigned long long)val;
-      v[PA_NNVC] += c;
-      v[PA_NNVM] += 1;
-    }
-    v[PA_SW] += (unsigned long long)wsum;
-    v[PA_NNW] += wnn;
-  };
-  // a.R > 1: the partition's slot range is walked in R passes (each re-reads the partition's records and
-  // keeps the keys whose home slot is in the pass's sub-range), so that the slice being probed — 16 B per
-  // slot — stays within what an XCD's L2 holds next to the record stream
   int it = 0;
   for (int p = xcd; p < a.P; p += 8) {
    for (int r = 0; r < a.R; ++r, ++it) {
@@ -1683,6 +1668,8 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
       }
       __syncthreads();
     }
+    // a.R > 1: the partition's slot range is walked in R passes (each re-reads the partition's records and keeps the keys
+    // whose home slot is in the pass's sub-range)
     const uint32_t sub_lo = (uint32_t)p * a.S1 + (uint32_t)r * a.S2, sub_hi = sub_lo + a.S2;
     // the wave's share of the unit: chunk c of the runs b = g, g + G, ... with c = wave (mod 16)
     int b = g;
@@ -1691,39 +1678,17 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
     v4i32_t pre[4];          // the next chunk, on its way from HBM: records lane + 64 j
     uint32_t pre_count = 0;  // > 0: `pre` holds a chunk that is not in the ring yet
     bool more = true;
-    auto fetch = [&]() {
-      while (b < a.B && (uint64_t)c * CH >= n_run) {
-        b += G;
-        c = (uint32_t)wave;
-        n_run = b < a.B ? cnt[(size_t)p * a.B + b] : 0u;
-      }
-      if (b >= a.B) {
-        more = false;
-        return;
-      }
-      const uint32_t count = n_run - c * CH < (uint32_t)CH ? n_run - c * CH : (uint32_t)CH;
-      const Rec* base = scratch + ((size_t)p * a.B + b) * a.cap + (size_t)c * CH;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t i = (uint32_t)lane + 64u * j;
-        pre[j] = __builtin_nontemporal_load((const v4i32_t*)(base + (i < count ? i : count - 1)));
-      }
-      pre_count = count;
-      c += 16;
-    };
     uint32_t avail = 0, taken = 0;  // records put into / taken out of the wave's ring (wave-uniform, running totals)
     int64_t key[K], val[K];
-    uint32_t cur[K], steps[K], pslot[K];
-    uint32_t active = 0, paying = 0;
+    uint32_t cur[K], pslot[K];
+    uint32_t active = 0, paying = 0, stale = 0;  // stale: rounds since one of the lane's sequences ended
 #pragma unroll
     for (int q = 0; q < K; ++q) {
       key[q] = 0;
       val[q] = 0;
       cur[q] = 0;
-      steps[q] = 0;
       pslot[q] = 0;
     }
-    fetch();
     for (;;) {
       if (pre_count && avail - taken <= (uint32_t)(RING - CH)) {  // room for a chunk: move it into the ring
 #pragma unroll
@@ -1750,51 +1715,83 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
           const uint32_t home = probe_slot_of(a, murmur1_u64((uint64_t)key[q]));
           if (a.R == 1 || (home >= sub_lo && home < sub_hi)) {  // (else: another pass's record)
             cur[q] = home;
-            steps[q] = 0;
             active |= 1u << q;
           }
         }
         taken += wanted < room ? wanted : room;
       }
       MQ_WAVE_LDS_SYNC();
-      if (!__any(active != 0)) {
-        if (taken != avail || pre_count) continue;
-        if (!more) break;
-        fetch();
-        continue;
-      }
+      const bool busy = __any(active != 0);
+      if (!busy && taken == avail && !pre_count && !more) break;
       // one window per sequence, all in flight together (unconditional loads — a free sequence re-reads its last window
       // out of the cache: loads under a lane-dependent `if` are serialised by the compiler, one s_waitcnt each;
       // r02_l2_probe_variants.jsonl)
       int64_t wk[K][W], wvv[K][W];
       Pay16 pe[K];
+      if (busy) {
 #pragma unroll
-      for (int q = 0; q < K; ++q) {
+        for (int q = 0; q < K; ++q) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) {
-          uint32_t at = cur[q] + (uint32_t)j;
-          if (at >= entries) at -= entries;  // (the probe sequence wraps at the table's end)
-          if (PM == 1) {
-            const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
-            wk[q][j] = kp.x;
-            wvv[q][j] = kp.y;
-          } else {
-            wk[q][j] = a.kkeys[at];
-            wvv[q][j] = 0;
+          for (int j = 0; j < W; ++j) {
+            uint32_t at = cur[q] + (uint32_t)j;
+            if (at >= entries) at -= entries;  // (the probe sequence wraps at the table's end)
+            if (PM == 1) {
+              const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
+              wk[q][j] = kp.x;
+              wvv[q][j] = kp.y;
+            } else {
+              wk[q][j] = a.kkeys[at];
+              wvv[q][j] = 0;
+            }
           }
+          if (PM == 0) pe[q] = a.pay16[pslot[q]];  // the payload entry of a sequence that found its slot last round
         }
-        if (PM == 0) pe[q] = a.pay16[pslot[q]];  // the payload entry of a sequence that found its slot last round
       }
-      if (!pre_count && more) fetch();  // (issued behind the windows: the round does not wait for it)
+      if (!pre_count && more) {  // the next chunk (issued behind the windows: the round does not wait for it)
+        while (b < a.B && (uint64_t)c * CH >= n_run) {
+          b += G;
+          c = (uint32_t)wave;
+          n_run = b < a.B ? cnt[(size_t)p * a.B + b] : 0u;
+        }
+        if (b >= a.B) {
+          more = false;
+        } else {
+          const uint32_t count = n_run - c * CH < (uint32_t)CH ? n_run - c * CH : (uint32_t)CH;
+          const Rec* base = scratch + ((size_t)p * a.B + b) * a.cap + (size_t)c * CH;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t i = (uint32_t)lane + 64u * j;
+            pre[j] = __builtin_nontemporal_load((const v4i32_t*)(base + (i < count ? i : count - 1)));
+          }
+          pre_count = count;
+          c += 16;
+        }
+      }
+      if (!busy) continue;
+      bool ended = false;
 #pragma unroll
       for (int q = 0; q < K; ++q) {
         const uint32_t bit = 1u << q;
         if (!(active & bit)) continue;
         if (PM == 0 && (paying & bit)) {
-          tally(pe[q].cnt, pe[q].wsum, pe[q].wnn, val[q]);
+          const unsigned long long cc = pe[q].cnt;
+          if (cc) {
+            const bool nn = val[q] != a.null_sum;
+            v[PA_J] += cc;
+            v[PA_M] += 1;
+            if (nn) {
+              v[PA_SVC] += (unsigned long long)val[q] * cc;
+              v[PA_SVM] += (unsigned long long)val[q];
+              v[PA_NNVC] += cc;
+              v[PA_NNVM] += 1;
+            }
+            v[PA_SW] += (unsigned long long)pe[q].wsum;
+            v[PA_NNW] += pe[q].wnn;
+          }
           paying &= ~bit;
           active &= ~bit;
           pslot[q] = 0;
+          ended = true;
           continue;
         }
         int state = 0;  // 1 found, 2 empty slot: no match
@@ -1805,28 +1802,38 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
           if (state) continue;
           if (wk[q][j] == key[q]) {
             at_hit = cur[q] + (uint32_t)j;
-            if (at_hit >= entries) at_hit -= entries;
             w0 = wvv[q][j];
             state = 1;
           } else if (wk[q][j] == kEmptyKey64) {
             state = 2;
           }
         }
-        if (state == 1) {
-          if (PM == 0) {
-            pslot[q] = at_hit;
-            paying |= bit;
-          } else {
-            if (PM == 2) tally(1, 0, 0, val[q]);
-            else if (w0 != INT64_MIN) tally(1, w0, 1, val[q]);
-            active &= ~bit;
+        if (state == 1 && PM == 0) {
+          if (at_hit >= entries) at_hit -= entries;
+          pslot[q] = at_hit;
+          paying |= bit;
+        } else if (state) {
+          if (state == 1 && (PM == 2 || w0 != INT64_MIN)) {
+            v[PA_M] += 1;
+            if (val[q] != a.null_sum) {
+              v[PA_SVM] += (unsigned long long)val[q];
+              v[PA_NNVM] += 1;
+            }
+            if (PM == 1) v[PA_SW] += (unsigned long long)w0;
           }
-        } else if (state == 2 || ++steps[q] > max_steps) {
           active &= ~bit;
+          ended = true;
         } else {
           cur[q] += W;
           if (cur[q] >= entries) cur[q] -= entries;
         }
+      }
+      // (a table without a free slot and a key that is not in it: no sequence of the lane has ended for a whole walk)
+      stale = ended ? 0u : stale + 1u;
+      if (stale > entries / W + 1) {
+        active = 0;
+        paying = 0;
+        stale = 0;
       }
     }
     if (pace) {
@@ -1835,7 +1842,165 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
     }
    }
   }
+  if (PM != 0) {  // one joined row per match
+    v[PA_J] = v[PA_M];
+    v[PA_SVC] = v[PA_SVM];
+    v[PA_NNVC] = v[PA_NNVM];
+    if (PM == 1) v[PA_NNW] = v[PA_M];
+  }
   __syncthreads();
+  probe_reduce_store(acc, v, s_red);
+}
+
+template <int PM>
+__global__ __launch_bounds__(1024) void k_part_probe_keyed_ls(ProbeArgs a, const Rec* __restrict__ scratch,
+                                                            const uint32_t* __restrict__ cnt,
+                                                            unsigned long long* __restrict__ acc,
+                                                            unsigned int* __restrict__ pace) {
+  __shared__ unsigned long long s_red[16 * PA_N];
+  constexpr int BLOCK = 1024, UQ = 4;
+  const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
+  const int t = threadIdx.x;
+  const uint32_t entries = (uint32_t)a.range;
+  unsigned long long v[PA_N];
+  for (int k = 0; k < PA_N; ++k) v[k] = 0;
+  // a.R > 1: the partition's slot range is walked in R passes (each re-reads the partition's records and
+  // keeps the keys whose home slot is in the pass's sub-range), so that the slice being probed — 16 B per
+  // slot — stays within what an XCD's L2 holds next to the record stream
+  int it = 0;
+  for (int p = xcd; p < a.P; p += 8) {
+   for (int r = 0; r < a.R; ++r, ++it) {
+    // pacing as in k_part_probe_l2: the XCD's workgroups stay within two consecutive (partition, pass) units
+    if (pace && it >= 2) {
+      if (t == 0) {
+        const unsigned int need = (unsigned int)(it - 1) * (unsigned int)G;
+        unsigned int spins = 0;
+        while (__hip_atomic_load(pace + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > (1u << 14)) break;
+        }
+      }
+      __syncthreads();
+    }
+    const uint32_t sub_lo = (uint32_t)p * a.S1 + (uint32_t)r * a.S2, sub_hi = sub_lo + a.S2;
+    for (int b = g; b < a.B; b += G) {
+      const uint32_t n = cnt[(size_t)p * a.B + b];
+      const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
+      if (!n) continue;
+      Rec rec[UQ];
+#pragma unroll
+      for (int q = 0; q < UQ; ++q) {
+        const uint32_t i = q * BLOCK + t;
+        rec[q] = load_rec_nt(run + (i < n ? i : n - 1));
+      }
+      for (uint32_t i0 = 0; i0 < n; i0 += UQ * BLOCK) {
+        Rec nxt[UQ];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const uint32_t i = i0 + UQ * BLOCK + q * BLOCK + t;
+          nxt[q] = load_rec_nt(run + (i < n ? i : n - 1));
+        }
+        // The linear probes of the lane's four records advance TOGETHER, a window of W consecutive slots per record and
+        // round: all windows of a round are in flight at once.  (Until round 4 each record walked its probe sequence on its
+        // own, one slot per dependent gather: a wave follows its slowest lane, so a step paid the SUM over its four
+        // records of the longest probe sequence among 64 lanes — ~10 dependent L2 round trips per wave-probe, 82 % of the
+        // kernel's wave cycles parked in s_waitcnt, profiles/r04_cfg4_keyed_probe_sq_counters_*_call6.txt.)
+        constexpr int W = PM == 1 ? 2 : 4;   // slots per window: 32 bytes of {key, value} pairs, or of keys
+        uint32_t cur[UQ];
+        int64_t slot[UQ], w0[UQ];
+        uint32_t pend = 0;
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          cur[q] = probe_slot_of(a, murmur1_u64((uint64_t)rec[q].key));
+          const bool mine = a.R == 1 || (cur[q] >= sub_lo && cur[q] < sub_hi);
+          slot[q] = -1;
+          w0[q] = 0;
+          if (i0 + q * BLOCK + t < n && mine) pend |= 1u << q;
+        }
+        for (uint32_t rounds = 0; pend && rounds <= entries / W + 1; ++rounds) {
+          int64_t wk[UQ][W], wvv[UQ][W];
+          // (unconditional loads — a record that is done re-reads its last window out of the cache: loads under a
+          // lane-dependent `if` are serialised by the compiler, one s_waitcnt each; r02_l2_probe_variants.jsonl)
+#pragma unroll
+          for (int q = 0; q < UQ; ++q) {
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              uint32_t at = cur[q] + (uint32_t)j;
+              if (at >= entries) at -= entries;   // (the probe sequence wraps at the table's end)
+              if (PM == 1) {
+                const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
+                wk[q][j] = kp.x;
+                wvv[q][j] = kp.y;
+              } else {
+                wk[q][j] = a.kkeys[at];
+                wvv[q][j] = 0;
+              }
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < UQ; ++q) {
+            if (!(pend & (1u << q))) continue;
+            bool done = false;
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+              if (done) continue;
+              if (wk[q][j] == rec[q].key) {
+                uint32_t at = cur[q] + (uint32_t)j;
+                if (at >= entries) at -= entries;
+                slot[q] = at;
+                w0[q] = wvv[q][j];
+                done = true;
+              } else if (wk[q][j] == kEmptyKey64) {
+                done = true;
+              }
+            }
+            if (done) {
+              pend &= ~(1u << q);
+            } else {
+              cur[q] += W;
+              if (cur[q] >= entries) cur[q] -= entries;
+            }
+          }
+        }
+        Pay16 pe[UQ];
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          if (PM == 2) {
+            pe[q] = Pay16{0, slot[q] >= 0 ? 1u : 0u, 0u};
+          } else if (PM == 1) {  // the payload came with the key
+            const uint32_t present = slot[q] >= 0 && w0[q] != INT64_MIN;
+            pe[q] = Pay16{present ? w0[q] : 0, present, present};
+          } else {
+            pe[q] = a.pay16[slot[q] >= 0 ? (uint64_t)slot[q] : 0ull];
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const unsigned long long c = slot[q] >= 0 ? pe[q].cnt : 0u;
+          if (c) {
+            const bool nn = rec[q].val != a.null_sum;
+            v[PA_J] += c;
+            v[PA_M] += 1;
+            if (nn) {
+              v[PA_SVC] += (unsigned long long)rec[q].val * c;
+              v[PA_SVM] += (unsigned long long)rec[q].val;
+              v[PA_NNVC] += c;
+              v[PA_NNVM] += 1;
+            }
+            v[PA_SW] += (unsigned long long)pe[q].wsum;
+            v[PA_NNW] += pe[q].wnn;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) rec[q] = nxt[q];
+      }
+    }
+    if (pace) {
+      __syncthreads();
+      if (t == 0) atomicAdd(pace + xcd, 1u);
+    }
+   }
+  }
   probe_reduce_store(acc, v, s_red);
 }
 
@@ -3162,9 +3327,24 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kProbeKeyedLds);
         hipLaunchKernelGGL(kern, pg, dim3(1024), kProbeKeyedLds, s, h.pa, recs, cnt, acc, pace);
       };
-      if (h.keys_only) probe(k_part_probe_keyed<2>);
-      else if (h.pa.pay8) probe(k_part_probe_keyed<1>);
-      else probe(k_part_probe_keyed<0>);
+      const int sel = tune_knobs().blocks_per_cu;  // (experiment selector)
+      if (sel == 4) {
+        if (h.keys_only) hipLaunchKernelGGL((k_part_probe_keyed_ls<2>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+        else if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed_ls<1>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+        else hipLaunchKernelGGL((k_part_probe_keyed_ls<0>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
+      } else if (sel == 3) {
+        if (h.keys_only) probe(k_part_probe_keyed<2, 4>);
+        else if (h.pa.pay8) probe(k_part_probe_keyed<1, 4>);
+        else probe(k_part_probe_keyed<0, 4>);
+      } else if (sel == 5) {
+        if (h.keys_only) probe(k_part_probe_keyed<2, 1>);
+        else if (h.pa.pay8) probe(k_part_probe_keyed<1, 1>);
+        else probe(k_part_probe_keyed<0, 1>);
+      } else {
+        if (h.keys_only) probe(k_part_probe_keyed<2, 2>);
+        else if (h.pa.pay8) probe(k_part_probe_keyed<1, 2>);
+        else probe(k_part_probe_keyed<0, 2>);
+      }
     } else if (h.l2_mode) {
       // one 1024-lane workgroup per CU (measured, 3.2 B rows: 2048 workgroups of 256 lanes stream the
       // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms;

@@ -79,6 +79,7 @@ inline T __shfl(T v, int src_lane, int width = 64) {
 inline void __builtin_amdgcn_s_sleep(int) { hipsim::fiber_yield(); }
 // a wave runs in lockstep on the device; where the code relies on it, the fibers of a wave meet
 inline void __builtin_amdgcn_wave_barrier() { hipsim::wave_sync(); }
+inline int __builtin_amdgcn_readfirstlane(int v) { return v; }  // (only ever applied to wave-uniform values)
 inline unsigned __builtin_amdgcn_mbcnt_lo(unsigned mask, unsigned v) {
   const int l = hipsim::lane_id();
   return v + (unsigned)__builtin_popcount(mask & (l >= 32 ? 0xffffffffu : ((1u << l) - 1u)));

