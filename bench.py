@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--overlap-cus", type=int, default=0, help="partitioned GROUP BY: CUs of phase 1 while phase 2 of the previous "
                     "chunk runs on the rest (tune_overlap_cus; 0 = the library's choice, -1 = phases one after the other)")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="tune_blocks_per_cu (experiments)")
+    ap.add_argument("--opt-flags", type=int, default=0, help="mi355q_exec_options.flags (MI355Q_OPT_*, experiments: 4 = payload probe without pacing)")
     ap.add_argument("--probe-passes", type=int, default=0, help="cfg4 --sparse: passes per partition of the keyed payload probe "
                     "(probe_keyed_passes; 0 = the library's choice)")
     ap.add_argument("--sparse", action="store_true", help="cfg4: sparse dim keys -> keyed {key, row id} join table (3.2 GB)")
@@ -233,7 +234,7 @@ def main():
     # mi355q_execute on them + the result storage it writes
     prep = HipShard.prepare(ex, ra, fr, kernel_variant=args.variant, force_generic=args.force_generic,
                             scratch_bytes=int(args.scratch_gb * 2**30), tune_overlap_cus=args.overlap_cus,
-                            probe_keyed_passes=args.probe_passes, tune_blocks_per_cu=args.blocks_per_cu)
+                            probe_keyed_passes=args.probe_passes, tune_blocks_per_cu=args.blocks_per_cu, flags=args.opt_flags)
 
     def step():
         sh = HipShard.execute_prepared(torch, prep)

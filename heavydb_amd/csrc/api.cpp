@@ -2249,7 +2249,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
           // one-to-one tables: the 8-byte payload — interleaved with the slot's key for a keyed table
           if (ok && (jt->hash_type == 0 || jt->hash_type == 1) && !jt->pay8)
             ok = hipMalloc((void**)&jt->pay8, (size_t)entries * (l2 == 2 ? 16 : 8)) == hipSuccess;
-          if (ok && l2 == 2 && !jt->pay_kkeys) ok = hipMalloc((void**)&jt->pay_kkeys, (size_t)entries * 8) == hipSuccess;
+          // (one spare key behind the end: the keyed probe reads the keys two at a time)
+          if (ok && l2 == 2 && !jt->pay_kkeys) ok = hipMalloc((void**)&jt->pay_kkeys, (size_t)entries * 8 + 16) == hipSuccess;
         } else {
           if (ok && !jt->pay_cnt) ok = hipMalloc((void**)&jt->pay_cnt, (size_t)entries * 4) == hipSuccess;
           if (ok && inner && !jt->pay_wsum) ok = hipMalloc((void**)&jt->pay_wsum, (size_t)entries * 8) == hipSuccess;

@@ -712,6 +712,7 @@ __global__ __launch_bounds__(kPartBlock) void k_part_scatter(
 // every other op keeps the full 8 bytes.  Internal slots are ordered by op id, so a
 // compile-time op set (MASK) fixes every array offset; MASK = 0 is the runtime-generic member.
 typedef long long v2i64_t __attribute__((ext_vector_type(2)));
+typedef long long v2i64_a8_t __attribute__((ext_vector_type(2), aligned(8)));  // (two consecutive 8-byte words, not 16-byte aligned)
 
 MQ_D void lds_apply(int op, char* base, uint32_t e, int64_t vb) {
   switch (op) {
@@ -1617,15 +1618,24 @@ __global__ __launch_bounds__(BLOCK) void k_part_probe_l2(ProbeArgs a, const Rec*
 //     counts one joined row and nothing else is fetched, so a partition's slice is 8 B per slot — 1.6 MB for cfg4's 200 M
 //     slots, which an XCD's 4 MB L2 does keep next to the record stream (the 16-byte slices, 3.1 MB, hit 73 %:
 //     profiles/r03_cfg4_join_pmc_before.txt)
-// Probe scheduling (round 4).  Every lane keeps K = 4 probe sequences in flight and each round fetches, for every sequence,
-// a WINDOW of W consecutive slots; a sequence that ends (key found, or an empty slot) is REPLACED in the same round by the
-// wave's next record, taken from a per-wave ring of records in LDS that the wave itself fills with coalesced chunks of its
-// run — nothing is shared between waves, so the inner loop has no workgroup barrier, and a long probe sequence (the
-// table is half full: 1.5 slots on average, but the longest of a few hundred sequences is ~10) delays only its own lane
-// slot.  History, cfg4 sparse, 3.33 B probes per launch: one slot per dependent gather, each record's sequence walked on
-// its own — a wave follows its slowest lane, ~10 dependent L2 round trips per wave-probe, 82 % of the wave cycles in
-// s_waitcnt (profiles/r04_cfg4_keyed_probe_sq_counters_*_call6.txt) — 50.9 ms; the four sequences of a lane advancing
-// together in windows, still finishing together: ~41 ms (profiles/r04_bench_cfg4_sparse*_call7.json).
+// Probe scheduling (round 4).  Every lane keeps K probe sequences in flight and each round fetches, for every sequence, W
+// consecutive slots; a sequence that ends (key found, or an empty slot) is REPLACED in the same round by the wave's next
+// record, taken from a per-wave ring of records in LDS that the wave itself fills with coalesced chunks of its run —
+// nothing is shared between waves, so the inner loop has no workgroup barrier, and a long probe sequence (the table is
+// half full: 1.5 slots on average, but the longest of a few hundred sequences is ~10) delays only its own lane slot.
+// Measured on cfg4's sparse variant, 3.33 B probes per launch (profiles/r04_cfg4_keyed_probe_variants_call*.jsonl, the
+// SQ / TCP counters next to them):
+//   one slot per dependent gather, every record's sequence walked on its own: a wave follows its slowest lane, ~10
+//     dependent L2 round trips per wave-probe, 82 % of the wave cycles in s_waitcnt                             50.9 ms
+//   the four sequences of a lane advancing together in windows of 32 bytes, still finishing together            ~41 ms
+//   rings, K = 1 / 2 / 4 with 32-byte windows (2 - 4 gathers per round): ~40 ms whatever K — no longer latency, the
+//     L2's request rate: every gather of a round is a request of its own, 2.7 per probe
+//   four LANES per sequence, one aligned 64-byte line per round (1.0 request per probe, TCP_TCC_READ_REQ): 38.7 ms,
+//     now bound by instruction issue (4.8 VALU + 3.5 SALU wave instructions per probe: sixteen probes per instruction)
+//   rings, ONE 16-byte gather per sequence and round — two keys (PM 0 / 2), K = 4:                              27 ms
+//   {key, value} slots (PM 1) gain nothing from narrower rounds (36 - 44 ms): their 3.1 MB slice does not stay in
+//     the XCD's L2 next to the record stream, the probes run at the Infinity Cache's gather rate; K = 2, W = 2 is the
+//     fastest of the measured members there.
 constexpr int kProbeRing = 512, kProbeChunk = 256;  // records per wave: the ring (two chunks), one coalesced chunk
 constexpr size_t kProbeKeyedLds = 16 * PA_N * sizeof(unsigned long long) + (size_t)16 * kProbeRing * sizeof(Rec);
 #define MQ_WAVE_LDS_SYNC()               \
@@ -1635,14 +1645,13 @@ constexpr size_t kProbeKeyedLds = 16 * PA_N * sizeof(unsigned long long) + (size
     asm volatile("" ::: "memory");       \
   } while (0)
 
-template <int PM, int K>
+template <int PM, int K, int W>
 __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Rec* __restrict__ scratch,
                                                             const uint32_t* __restrict__ cnt,
                                                             unsigned long long* __restrict__ acc,
                                                             unsigned int* __restrict__ pace) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int CH = kProbeChunk, RING = kProbeRing;
-  constexpr int W = PM == 1 ? 2 : 4;  // slots per window: 32 bytes of {key, value} pairs, or of keys
   unsigned long long* s_red = (unsigned long long*)smem_raw;  // [16 * PA_N]
   const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
   const int t = threadIdx.x, lane = t & 63;
@@ -1731,6 +1740,14 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
       if (busy) {
 #pragma unroll
         for (int q = 0; q < K; ++q) {
+          if (PM != 1 && W == 2) {  // two keys with one 16-byte load (the key array carries a spare key behind its end)
+            const v2i64_a8_t kk = *(const MQ_GLOBAL v2i64_a8_t*)(a.kkeys + cur[q]);
+            wk[q][0] = kk.x;
+            wk[q][1] = cur[q] + 1 < entries ? kk.y : a.kkeys[0];
+            wvv[q][0] = wvv[q][1] = 0;
+            if (PM == 0) pe[q] = a.pay16[pslot[q]];
+            continue;
+          }
 #pragma unroll
           for (int j = 0; j < W; ++j) {
             uint32_t at = cur[q] + (uint32_t)j;
@@ -1849,158 +1866,6 @@ __global__ __launch_bounds__(1024) void k_part_probe_keyed(ProbeArgs a, const Re
     if (PM == 1) v[PA_NNW] = v[PA_M];
   }
   __syncthreads();
-  probe_reduce_store(acc, v, s_red);
-}
-
-template <int PM>
-__global__ __launch_bounds__(1024) void k_part_probe_keyed_ls(ProbeArgs a, const Rec* __restrict__ scratch,
-                                                            const uint32_t* __restrict__ cnt,
-                                                            unsigned long long* __restrict__ acc,
-                                                            unsigned int* __restrict__ pace) {
-  __shared__ unsigned long long s_red[16 * PA_N];
-  constexpr int BLOCK = 1024, UQ = 4;
-  const int xcd = blockIdx.x & 7, g = blockIdx.x >> 3, G = gridDim.x >> 3;
-  const int t = threadIdx.x;
-  const uint32_t entries = (uint32_t)a.range;
-  unsigned long long v[PA_N];
-  for (int k = 0; k < PA_N; ++k) v[k] = 0;
-  // a.R > 1: the partition's slot range is walked in R passes (each re-reads the partition's records and
-  // keeps the keys whose home slot is in the pass's sub-range), so that the slice being probed — 16 B per
-  // slot — stays within what an XCD's L2 holds next to the record stream
-  int it = 0;
-  for (int p = xcd; p < a.P; p += 8) {
-   for (int r = 0; r < a.R; ++r, ++it) {
-    // pacing as in k_part_probe_l2: the XCD's workgroups stay within two consecutive (partition, pass) units
-    if (pace && it >= 2) {
-      if (t == 0) {
-        const unsigned int need = (unsigned int)(it - 1) * (unsigned int)G;
-        unsigned int spins = 0;
-        while (__hip_atomic_load(pace + xcd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-          __builtin_amdgcn_s_sleep(16);
-          if (++spins > (1u << 14)) break;
-        }
-      }
-      __syncthreads();
-    }
-    const uint32_t sub_lo = (uint32_t)p * a.S1 + (uint32_t)r * a.S2, sub_hi = sub_lo + a.S2;
-    for (int b = g; b < a.B; b += G) {
-      const uint32_t n = cnt[(size_t)p * a.B + b];
-      const Rec* run = scratch + ((size_t)p * a.B + b) * a.cap;
-      if (!n) continue;
-      Rec rec[UQ];
-#pragma unroll
-      for (int q = 0; q < UQ; ++q) {
-        const uint32_t i = q * BLOCK + t;
-        rec[q] = load_rec_nt(run + (i < n ? i : n - 1));
-      }
-      for (uint32_t i0 = 0; i0 < n; i0 += UQ * BLOCK) {
-        Rec nxt[UQ];
-#pragma unroll
-        for (int q = 0; q < UQ; ++q) {
-          const uint32_t i = i0 + UQ * BLOCK + q * BLOCK + t;
-          nxt[q] = load_rec_nt(run + (i < n ? i : n - 1));
-        }
-        // The linear probes of the lane's four records advance TOGETHER, a window of W consecutive slots per record and
-        // round: all windows of a round are in flight at once.  (Until round 4 each record walked its probe sequence on its
-        // own, one slot per dependent gather: a wave follows its slowest lane, so a step paid the SUM over its four
-        // records of the longest probe sequence among 64 lanes — ~10 dependent L2 round trips per wave-probe, 82 % of the
-        // kernel's wave cycles parked in s_waitcnt, profiles/r04_cfg4_keyed_probe_sq_counters_*_call6.txt.)
-        constexpr int W = PM == 1 ? 2 : 4;   // slots per window: 32 bytes of {key, value} pairs, or of keys
-        uint32_t cur[UQ];
-        int64_t slot[UQ], w0[UQ];
-        uint32_t pend = 0;
-#pragma unroll
-        for (int q = 0; q < UQ; ++q) {
-          cur[q] = probe_slot_of(a, murmur1_u64((uint64_t)rec[q].key));
-          const bool mine = a.R == 1 || (cur[q] >= sub_lo && cur[q] < sub_hi);
-          slot[q] = -1;
-          w0[q] = 0;
-          if (i0 + q * BLOCK + t < n && mine) pend |= 1u << q;
-        }
-        for (uint32_t rounds = 0; pend && rounds <= entries / W + 1; ++rounds) {
-          int64_t wk[UQ][W], wvv[UQ][W];
-          // (unconditional loads — a record that is done re-reads its last window out of the cache: loads under a
-          // lane-dependent `if` are serialised by the compiler, one s_waitcnt each; r02_l2_probe_variants.jsonl)
-#pragma unroll
-          for (int q = 0; q < UQ; ++q) {
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-              uint32_t at = cur[q] + (uint32_t)j;
-              if (at >= entries) at -= entries;   // (the probe sequence wraps at the table's end)
-              if (PM == 1) {
-                const v2i64_t kp = ((const MQ_GLOBAL v2i64_t*)a.pay8)[at];
-                wk[q][j] = kp.x;
-                wvv[q][j] = kp.y;
-              } else {
-                wk[q][j] = a.kkeys[at];
-                wvv[q][j] = 0;
-              }
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < UQ; ++q) {
-            if (!(pend & (1u << q))) continue;
-            bool done = false;
-#pragma unroll
-            for (int j = 0; j < W; ++j) {
-              if (done) continue;
-              if (wk[q][j] == rec[q].key) {
-                uint32_t at = cur[q] + (uint32_t)j;
-                if (at >= entries) at -= entries;
-                slot[q] = at;
-                w0[q] = wvv[q][j];
-                done = true;
-              } else if (wk[q][j] == kEmptyKey64) {
-                done = true;
-              }
-            }
-            if (done) {
-              pend &= ~(1u << q);
-            } else {
-              cur[q] += W;
-              if (cur[q] >= entries) cur[q] -= entries;
-            }
-          }
-        }
-        Pay16 pe[UQ];
-#pragma unroll
-        for (int q = 0; q < UQ; ++q) {
-          if (PM == 2) {
-            pe[q] = Pay16{0, slot[q] >= 0 ? 1u : 0u, 0u};
-          } else if (PM == 1) {  // the payload came with the key
-            const uint32_t present = slot[q] >= 0 && w0[q] != INT64_MIN;
-            pe[q] = Pay16{present ? w0[q] : 0, present, present};
-          } else {
-            pe[q] = a.pay16[slot[q] >= 0 ? (uint64_t)slot[q] : 0ull];
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < UQ; ++q) {
-          const unsigned long long c = slot[q] >= 0 ? pe[q].cnt : 0u;
-          if (c) {
-            const bool nn = rec[q].val != a.null_sum;
-            v[PA_J] += c;
-            v[PA_M] += 1;
-            if (nn) {
-              v[PA_SVC] += (unsigned long long)rec[q].val * c;
-              v[PA_SVM] += (unsigned long long)rec[q].val;
-              v[PA_NNVC] += c;
-              v[PA_NNVM] += 1;
-            }
-            v[PA_SW] += (unsigned long long)pe[q].wsum;
-            v[PA_NNW] += pe[q].wnn;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < UQ; ++q) rec[q] = nxt[q];
-      }
-    }
-    if (pace) {
-      __syncthreads();
-      if (t == 0) atomicAdd(pace + xcd, 1u);
-    }
-   }
-  }
   probe_reduce_store(acc, v, s_red);
 }
 
@@ -3327,24 +3192,10 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kProbeKeyedLds);
         hipLaunchKernelGGL(kern, pg, dim3(1024), kProbeKeyedLds, s, h.pa, recs, cnt, acc, pace);
       };
-      const int sel = tune_knobs().blocks_per_cu;  // (experiment selector)
-      if (sel == 4) {
-        if (h.keys_only) hipLaunchKernelGGL((k_part_probe_keyed_ls<2>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
-        else if (h.pa.pay8) hipLaunchKernelGGL((k_part_probe_keyed_ls<1>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
-        else hipLaunchKernelGGL((k_part_probe_keyed_ls<0>), pg, dim3(1024), 0, s, h.pa, recs, cnt, acc, pace);
-      } else if (sel == 3) {
-        if (h.keys_only) probe(k_part_probe_keyed<2, 4>);
-        else if (h.pa.pay8) probe(k_part_probe_keyed<1, 4>);
-        else probe(k_part_probe_keyed<0, 4>);
-      } else if (sel == 5) {
-        if (h.keys_only) probe(k_part_probe_keyed<2, 1>);
-        else if (h.pa.pay8) probe(k_part_probe_keyed<1, 1>);
-        else probe(k_part_probe_keyed<0, 1>);
-      } else {
-        if (h.keys_only) probe(k_part_probe_keyed<2, 2>);
-        else if (h.pa.pay8) probe(k_part_probe_keyed<1, 2>);
-        else probe(k_part_probe_keyed<0, 2>);
-      }
+      // (sequences per lane, slots per round: profiles/r04_cfg4_keyed_probe_variants_call*.jsonl)
+      if (h.keys_only) probe(k_part_probe_keyed<2, 4, 2>);
+      else if (h.pa.pay8) probe(k_part_probe_keyed<1, 2, 2>);
+      else probe(k_part_probe_keyed<0, 2, 2>);
     } else if (h.l2_mode) {
       // one 1024-lane workgroup per CU (measured, 3.2 B rows: 2048 workgroups of 256 lanes stream the
       // records at 2.1 TB/s and take 52.8 ms; 256 of 1024 lanes stream at 6.5 TB/s and take 25.7 ms;

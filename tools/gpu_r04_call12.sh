@@ -1,0 +1,13 @@
+#!/bin/bash
+# round 4, call 12: keyed probe, one lane per sequence and ONE 16-byte gather per round (K = 4, 6, 2) against four lanes per sequence
+out=${1:-gpurun_out/r04_call12}
+mkdir -p $out
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+python -c "import torch; x=torch.zeros(4).cuda(); print('device ok', x.sum().item())" || { echo "no GPU"; exit 3; }
+for sel in 3 5 6 0; do
+  for args in "--sparse" "--sparse --sum-dim"; do
+    tag=$(echo "$args" | tr -d ' -' )_sel$sel
+    timeout 300 python bench.py --config cfg4 $args --blocks-per-cu $sel --steps 2 --warmup 1 --no-cpu-baseline --verify > $out/bench_cfg4_$tag.json 2> $out/bench_cfg4_$tag.err
+    echo "sel=$sel cfg4 $args: exit $? $(python -c "import json,sys; d=json.load(open('$out/bench_cfg4_$tag.json')); print(d['ms_per_step'], d['verify'])" 2>&1)"
+  done
+done
