@@ -1550,6 +1550,134 @@ int32_t execute_multi_value(const mi355q_plan* plan, const mi355q_inputs* in, co
   return MI355Q_OK;
 }
 
+// Baseline steps over 2 - 3 plain INT key columns that all have ranges — the reference's PerfectHashMultiCol / MultiStep
+// shapes beyond g_baseline_groupby_threshold (PHM006, MSPHM005, MSPHM007: ~11 M combinations, Execute.cpp:113,
+// GroupByAndAggregate.cpp:232-365) — over a large input: the product of the ranges still indexes a table the
+// index-partitioned family (kernels_idx.hip) aggregates in one exchange, so the step runs on a library-owned PERFECT
+// twin of the layout and its live entries are re-keyed into the baseline table of the stated plan
+// (kernels_generic.hip k_perfect_twin_emit).  kNotTaken when the shape does not call for it.
+constexpr int64_t kTwinMaxEntries = (int64_t)32 << 20;
+int32_t execute_perfect_twin(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o, const mi355q_qmd& q,
+                             int n_cus, mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
+  if (q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || plan->n_group_cols < 2 || plan->n_group_cols > 3 ||
+      plan->join_outer_col >= 0 || plan->n_exprs != 0 || q.slot_width != 8 || q.output_columnar ||
+      plan->output_columnar_hint != 0 || o.kernel_variant == 1 || o.force_generic)
+    return kNotTaken;
+  __int128 card = 1;
+  int32_t translate[MI355Q_MAX_GROUP_COLS], key_type[MI355Q_MAX_GROUP_COLS];
+  for (int g = 0; g < plan->n_group_cols; ++g) {
+    const int c = plan->group_cols[g];
+    if (c < 0 || c >= plan->n_cols) return kNotTaken;
+    const mi355q_col_desc& cd = plan->cols[c];
+    const mi355q_range& r = plan->col_ranges[c];
+    if (cd.type != MI355Q_INT32 || cd.encoding != MI355Q_ENC_NONE || (cd.logical_type != 0 && cd.logical_type != cd.type) ||
+        !r.valid || r.bucket != 0 || r.min > r.max || (r.has_nulls && !cd.nullable))
+      return kNotTaken;
+    card *= (__int128)r.max - (__int128)r.min + 1 + (r.has_nulls ? 1 : 0);
+    if (card > (__int128)kTwinMaxEntries) return kNotTaken;
+    translate[g] = cd.nullable && r.has_nulls;  // (build_dev_plan's rule for several key columns)
+    key_type[g] = col_type_code(cd);
+  }
+  int64_t total_rows = 0, max_rows = 0;
+  for (int f = 0; f < in->n_frags; ++f) {
+    total_rows += in->num_rows[f];
+    max_rows = std::max(max_rows, in->num_rows[f]);
+  }
+  // (kernel_variant 2 = "the large-input members": how the tests reach this route with small tables)
+  if (o.kernel_variant != 2 && total_rows < kIdxPartMinRows) return kNotTaken;
+  PerfectTwinScope twin(kTwinMaxEntries);
+  mi355q_qmd q2;
+  if (qmd_init(*plan, &q2) != MI355Q_OK) return kNotTaken;
+  if (q2.desc_type != MI355Q_GROUP_BY_PERFECT_HASH || q2.slot_width != 8 || q2.output_columnar ||
+      q2.entry_count * (int64_t)q2.row_size > ((int64_t)4 << 30))
+    return kNotTaken;
+  DevPlan d2;
+  if (build_dev_plan(*plan, q2, &d2) != MI355Q_OK) return kNotTaken;
+  {
+    FragView fvh{nullptr, nullptr, in->col_buffers, in->num_rows, in->n_frags, plan->n_cols, total_rows, max_rows};
+    if (!idx_part_eligible(d2, fvh, n_cus)) return kNotTaken;
+  }
+  for (int t = 0; t < plan->n_targets; ++t) {
+    const int sf = q.target_slot[t], ss = q2.target_slot[t];
+    if (plan->targets[t].agg == MI355Q_PROJECT_KEY) {
+      if (sf >= 0) return kNotTaken;  // (baseline: projections are read from the key columns)
+      continue;
+    }
+    if (sf < 0 || ss < 0) return kNotTaken;
+    for (int j = 0; j < (plan->targets[t].agg == MI355Q_AVG ? 2 : 1); ++j)
+      if (q.init_vals[sf + j] != q2.init_vals[ss + j]) return kNotTaken;
+  }
+  mi355q_exec_options o2 = o;
+  o2.out_buffer = nullptr;
+  if (reserved) {
+    route_note("perfect-hash twin + k_perfect_twin_emit");
+    return execute_impl(plan, in, &o2, out, report, nullptr, reserved);
+  }
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+  o2.stream = s;
+  mi355q_result* r2 = nullptr;
+  mi355q_exec_report rep2{};
+  if (int32_t e2 = mi355q_execute(plan, in, &o2, &r2, &rep2)) {
+    if (e2 == MI355Q_ERR_UNSUPPORTED || e2 == MI355Q_ERR_OUT_OF_GPU_MEM || e2 < 0) return kNotTaken;
+    return e2;
+  }
+  struct R2Guard {
+    mi355q_result* r;
+    ~R2Guard() { if (r) mi355q_result_free(r); }
+  } r2g{r2};
+  if (r2->qmd.desc_type != MI355Q_GROUP_BY_PERFECT_HASH || r2->qmd.slot_width != 8 || r2->qmd.output_columnar ||
+      r2->qmd.entry_count != q2.entry_count)
+    return kNotTaken;
+  mi355q_result* res = nullptr;
+  if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;
+  struct ResGuard {
+    mi355q_result* r;
+    ~ResGuard() { if (r) mi355q_result_free(r); }
+  } rg{res};
+  HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+  DevWord err;
+  HIP_TRY(hipMalloc(&err.p, 64));
+  HIP_TRY(hipMemsetAsync(err.p, 0, 64, s));
+  HIP_TRY(launch_perfect_twin_emit(res->dplan, r2->dplan, r2->qmd.idx_target_as_key, plan->n_group_cols, translate, key_type,
+                                   q2.group_min, q2.group_card, q2.group_null_key, r2->buf, res->buf, (int32_t*)err.p, s));
+  if (ev1) HIP_TRY(hipEventRecord(ev1, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_err) return h_err;
+  if (report) {
+    *report = rep2;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->n_launches = rep2.n_launches + 1;
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  rg.r = nullptr;
+  *out = res;
+  return MI355Q_OK;
+}
+
 // GROUP BY CAST(<plain integer column> AS DOUBLE | FLOAT) — the reference benchmark's BaselineHash and MultiStep
 // BaselineHash shapes (Benchmarks/synthetic_benchmark/queries/BaselineHash/BH001-006.sql, MultiStep/MSBS001-005.sql).  A
 // floating-point key always takes the baseline layout (GroupByAndAggregate.cpp:232-365: getExprRangeInfo is FloatingPoint),
@@ -2102,6 +2230,13 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     if (!lds_direct && !pend && d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && (tr >= kIdxPartMinRows || o.kernel_variant == 2))
       lds_direct = idx_direct = idx_part_eligible(d, fvh, n_cus);
   }
+  if (!o.force_generic && in->n_frags > 0 && !lds_direct && !pend) {
+    const size_t mark = t_route ? t_route->size() : 0;
+    const int32_t e = execute_perfect_twin(plan, in, o, q, n_cus, out, report, reserved);
+    if (e != kNotTaken) return e;
+    if (t_route) t_route->resize(mark);
+    *out = nullptr;
+  }
   if (!o.force_generic && in->n_frags > 0 && !lds_direct) {
     const size_t mark = t_route ? t_route->size() : 0;
     const int32_t e = execute_packed_multi(plan, in, o, q, d, n_cus, out, report, reserved);
@@ -2503,10 +2638,15 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     mi355q_result_free(res);
     rg.r = nullptr;
     mi355q_exec_options o2 = o;
-    // small replicas did not hold the groups: the largest replica next, then eight windows of it, then another family
-    o2.flags |= !(o.flags & MI355Q_OPT_LDS_BASELINE_LARGE)     ? MI355Q_OPT_LDS_BASELINE_LARGE
-                : !(o.flags & MI355Q_OPT_LDS_BASELINE_WINDOWS) ? MI355Q_OPT_LDS_BASELINE_WINDOWS
-                                                               : MI355Q_OPT_NO_LDS_BASELINE;
+    // small replicas did not hold the groups: the largest replica next, then eight windows of it, then another family.
+    // Windows read the columns once per window: over a large input the partitioned family (one pass + one exchange) is
+    // the cheaper next step — BH007 at 1 B rows: 29.6 ms in eight windows (profiles/r04_refbench_1b_call13.jsonl)
+    int64_t rows_in = 0;
+    for (int f = 0; f < in->n_frags; ++f) rows_in += in->num_rows[f];
+    const bool windows_next = !(o.flags & MI355Q_OPT_LDS_BASELINE_WINDOWS) && rows_in < kIdxPartMinRows;
+    o2.flags |= !(o.flags & MI355Q_OPT_LDS_BASELINE_LARGE) ? MI355Q_OPT_LDS_BASELINE_LARGE
+                : windows_next                             ? MI355Q_OPT_LDS_BASELINE_WINDOWS
+                                                           : MI355Q_OPT_NO_LDS_BASELINE;
     return execute_impl(plan, in, &o2, out, report, nullptr, nullptr);
   }
   if (code) return code;

@@ -111,6 +111,10 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
                             int32_t* d_err, int n_cus, hipStream_t s);
 // copies slots src[i] of every live row of `sub` (layout ps) to slots dst[i] of the same group's row in `fin`
 // (layout pf, same group columns): see k_zip_targets
+// a baseline step over integer keys with ranges, run as a perfect hash over the product of the ranges: entries re-keyed into the baseline table
+hipError_t launch_perfect_twin_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int n_keys, const int32_t* translate,
+                                    const int32_t* key_type, const int64_t* key_min, const int64_t* key_card,
+                                    const int64_t* null_key, const int64_t* sub, int64_t* fin, int32_t* d_err, hipStream_t s);
 // GROUP BY CAST(int column AS DOUBLE | FLOAT): entries of the integer-keyed perfect table re-keyed and merged into the baseline table
 hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, int translate,
                                 int64_t key_min, int64_t null_key, const int64_t* sub, int64_t* fin, int32_t* d_err,

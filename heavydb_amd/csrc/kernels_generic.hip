@@ -871,6 +871,59 @@ __global__ __launch_bounds__(kBlock) void k_cast_key_emit(DevPlan pf, DevPlan ps
   }
 }
 
+// ---- a baseline step whose integer key columns all have ranges ran as a PERFECT hash over the product of the ranges
+// (api.cpp execute_perfect_twin): every live entry's keys are rebuilt from its index — entry = sum_i (key_i - min_i) *
+// prod_{j<i} card_j, a translated NULL key back to the column's NULL — and the entry is merged into the baseline table
+// of the stated plan with the reduce rule.
+struct TwinArgs {
+  int32_t n_keys, idx_key_s;
+  int32_t translate[MI355Q_MAX_GROUP_COLS], key_type[MI355Q_MAX_GROUP_COLS];
+  int64_t key_min[MI355Q_MAX_GROUP_COLS], key_card[MI355Q_MAX_GROUP_COLS], null_key[MI355Q_MAX_GROUP_COLS];
+};
+__global__ __launch_bounds__(kBlock) void k_perfect_twin_emit(DevPlan pf, DevPlan ps, TwinArgs ta,
+                                                               const int64_t* __restrict__ sub, int64_t* __restrict__ fin,
+                                                               int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < ps.entry_count; e += stride) {
+    const int64_t* row_s = sub + e * ps.row_quad;
+    if (is_empty_row(ps, row_s, ta.idx_key_s)) continue;
+    const int64_t* slots_s = row_s + ps.key_quad;
+    int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};
+    int64_t rem = e;
+    for (int g = 0; g < ta.n_keys; ++g) {
+      const int64_t tk = ta.key_min[g] + rem % ta.key_card[g];
+      rem /= ta.key_card[g];
+      keys[g] = ta.translate[g] && tk == ta.null_key[g] ? int_null_of(ta.key_type[g]) : tk;
+    }
+    int64_t* slots_f;
+    if (ta.n_keys == 1) {
+      slots_f = baseline_find_or_insert(fin, (uint32_t)pf.entry_count, pf.row_quad, pf.key_width, keys[0]);
+    } else {
+      bool bad = false;
+      slots_f = baseline_find_or_insert_multi(fin, (uint32_t)pf.entry_count, pf.row_quad, pf.key_width, ta.n_keys, keys, &bad);
+      if (bad) {
+        atomicCAS(d_err, 0, MI355Q_ERR_INVALID_PLAN);
+        continue;
+      }
+    }
+    if (!slots_f) {
+      atomicCAS(d_err, 0, -1);  // out of group slots: the caller grows the table and retries
+      continue;
+    }
+    for (int i = 0; i < pf.n_targets; ++i) {
+      const DevTarget& tf = pf.targets[i];
+      const DevTarget& ts = ps.targets[i];
+      if (tf.slot < 0 || ts.slot < 0 || tf.agg == MI355Q_PROJECT_KEY) continue;  // (baseline: projections read the key columns)
+      int64_t win[2];
+      win[0] = slots_s[ts.slot];
+      win[1] = tf.agg == MI355Q_AVG ? slots_s[ts.slot + 1] : 0;
+      DevTarget lt = tf;
+      lt.slot = 0;
+      reduce_target<true>(lt, pf.init_vals + tf.slot, slots_f + tf.slot, win);
+    }
+  }
+}
+
 struct ZipMap {
   int32_t n;                          // slot copies
   int32_t src[MI355Q_MAX_SLOTS], dst[MI355Q_MAX_SLOTS];  // slot index in the run's row -> slot index in the final row
@@ -1282,6 +1335,24 @@ bool project_simple_shapes(const DevExprSet& xs) {
 
 // `simple`: every expression is of the one-operation shape AND the caller found every source chunk 16-byte aligned —
 // one k_project_simple launch per expression; an overflow raises d_err[2] and the caller comes back with simple = false
+hipError_t launch_perfect_twin_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int n_keys, const int32_t* translate,
+                                    const int32_t* key_type, const int64_t* key_min, const int64_t* key_card,
+                                    const int64_t* null_key, const int64_t* sub, int64_t* fin, int32_t* d_err, hipStream_t s) {
+  if (ps.entry_count <= 0) return hipSuccess;
+  TwinArgs ta{};
+  ta.n_keys = n_keys;
+  ta.idx_key_s = idx_key_s;
+  for (int g = 0; g < n_keys; ++g) {
+    ta.translate[g] = translate[g];
+    ta.key_type[g] = key_type[g];
+    ta.key_min[g] = key_min[g];
+    ta.key_card[g] = key_card[g];
+    ta.null_key[g] = null_key[g];
+  }
+  hipLaunchKernelGGL(k_perfect_twin_emit, dim3(grid_for(ps.entry_count)), dim3(kBlock), 0, s, pf, ps, ta, sub, fin, d_err);
+  return hipGetLastError();
+}
+
 hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, int translate,
                                 int64_t key_min, int64_t null_key, const int64_t* sub, int64_t* fin, int32_t* d_err,
                                 hipStream_t s) {

@@ -39,6 +39,7 @@ bool valid_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_FLOAT; }
 bool int_type(int t) { return t >= MI355Q_INT8 && t <= MI355Q_INT64; }
 
 constexpr int64_t kBaselineGroupbyThreshold = 1000000;  // g_baseline_groupby_threshold, Execute.cpp:113
+thread_local int64_t t_twin_max_entries = 0;            // > 0 inside a PerfectTwinScope
 
 // two's-complement add: a caller-supplied range may end at INT64_MAX
 int64_t wrap_add(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
@@ -433,7 +434,8 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
       card *= c;
       if (card > (__int128)INT64_MAX) perfect = false;
     }
-    if (perfect && (card == 0 || card > (__int128)kBaselineGroupbyThreshold)) perfect = false;
+    const int64_t threshold = t_twin_max_entries > 0 ? t_twin_max_entries : kBaselineGroupbyThreshold;
+    if (perfect && (card == 0 || card > (__int128)threshold)) perfect = false;
     if (perfect) {
       q->desc_type = MI355Q_GROUP_BY_PERFECT_HASH;
       q->entry_count = (int64_t)card;
@@ -564,6 +566,9 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
 
 // getBufferSizeBytes (QueryMemoryDescriptor.cpp:1084-1111); columnar: 8 bytes per group column and
 // entry + getTotalBytesOfColumnarBuffers (every slot column align_to_int64(width * entry_count))
+PerfectTwinScope::PerfectTwinScope(int64_t max_entries) : saved(t_twin_max_entries) { t_twin_max_entries = max_entries; }
+PerfectTwinScope::~PerfectTwinScope() { t_twin_max_entries = saved; }
+
 int64_t qmd_buffer_bytes(const mi355q_qmd& q) {
   if (!q.output_columnar) return q.entry_count * (int64_t)q.row_size;
   return qmd_slot_col_offset(q, q.slot_count);

@@ -20,6 +20,14 @@ struct ResolvedTarget {
 int col_type_code(const mi355q_col_desc& c);  // < 0 = invalid
 int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out);
 int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q);
+// While one lives (per thread), qmd_init lays multi-column integer keys out as a perfect hash up to `max_entries`
+// entries instead of g_baseline_groupby_threshold: the library's own intermediate table of a baseline step (api.cpp
+// execute_perfect_twin); never the layout a caller sees.
+struct PerfectTwinScope {
+  explicit PerfectTwinScope(int64_t max_entries);
+  ~PerfectTwinScope();
+  int64_t saved;
+};
 int64_t qmd_buffer_bytes(const mi355q_qmd& q);
 int64_t qmd_group_col_offset(const mi355q_qmd& q, int g);  // columnar descriptors; -1 otherwise
 int64_t qmd_slot_col_offset(const mi355q_qmd& q, int s);

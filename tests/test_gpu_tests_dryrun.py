@@ -76,7 +76,7 @@ def _install(monkeypatch, oracle):
     monkeypatch.setattr(torch, "empty", lambda *a, **k: real_empty(*a, **{x: y for x, y in k.items() if x != "device"}))
 
     def execute(self, ra, fr, stream=None, out_buffer=None, force_generic=False, kernel_variant=0,
-                scratch_bytes=0, allow_retry=True):
+                scratch_bytes=0, allow_retry=True, **knobs):   # (knobs: flags, tuning — no meaning for the emulation)
         plan = ra.to_plan()
         inp, keep = fr.to_c(plan.n_cols)
         q = capi.QMD()

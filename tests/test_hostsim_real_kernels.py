@@ -310,3 +310,49 @@ def test_cast_key_route_with_null_keys_and_float_collisions(sim, oracle):
         case = cases_mod.Case("cast_key_nulls", ra, [[key[:15_001], val[:15_001]], [key[15_001:], val[15_001:]]])
         rs = flow._check(oracle, case, kernel_variant=2)
         assert rs is not None and rs.report.n_launches >= 2, rs.report.n_launches
+
+
+# ---- baseline steps over several ranged INT keys: a perfect-hash twin (index-partitioned family) + k_perfect_twin_emit --------
+@pytest.mark.parametrize("name", ["PHM006", "MSPHM005", "MSPHM007"])
+def test_perfect_twin_route_on_the_benchmark_shapes(sim, oracle, name):
+    """PerfectHashMultiCol / MultiStep shapes whose key combinations exceed g_baseline_groupby_threshold (baseline layout in
+    the reference, GroupByAndAggregate.cpp:232-365): the step runs on a library-owned perfect-hash table over the product of
+    the key ranges and its live entries are re-keyed into the baseline table of the stated plan.  kernel_variant 2 = the
+    large-input members on a small input."""
+    case = flow._refbench_case(oracle, name, 150_003, 120_000)
+    rs = flow._check(oracle, case, kernel_variant=2)
+    assert rs is not None
+    assert rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.n_launches >= 2, (rs.report.kernel_name, rs.report.n_launches)
+
+
+def test_perfect_twin_route_is_named_by_explain(sim):
+    for name in ("PHM006", "MSPHM005", "MSPHM007"):
+        r = _explain(name, 1_000_000_000)
+        assert "k_perfect_twin_emit" in r and r.endswith("k_idx_scatter + k_idx_aggregate"), (name, r)
+
+
+def test_perfect_twin_route_with_null_keys(sim, oracle):
+    """NULL keys in both key columns (translated to max + 1 in the twin, back to the column's NULL in the baseline key),
+    nullable values, a table too small for the groups (out of slots, as the plain route reports it)"""
+    from heavydb_amd.executor import Executor, ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(8)
+    n = 60_000
+    k0 = rng.integers(-700, 700, n).astype(np.int32)
+    k1 = rng.integers(0, 900, n).astype(np.int32)
+    k0[rng.random(n) < 0.03] = np.iinfo(np.int32).min
+    k1[rng.random(n) < 0.03] = np.iinfo(np.int32).min
+    val = rng.integers(-1000, 1000, n).astype(np.int32)
+    val[rng.random(n) < 0.1] = np.iinfo(np.int32).min
+    descs = [InputColDescriptor(capi.INT32, True, ExpressionRange(True, -700, 699, True)),
+             InputColDescriptor(capi.INT32, True, ExpressionRange(True, 0, 899, True)),
+             InputColDescriptor(capi.INT32, True, ExpressionRange(True, -1000, 999, True))]
+    targets = [TargetExpr(capi.PROJECT_KEY, 0), TargetExpr(capi.PROJECT_KEY, 1), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 2),
+               TargetExpr(capi.MIN, 2), TargetExpr(capi.MAX, 2), TargetExpr(capi.AVG, 2), TargetExpr(capi.COUNT, 2)]
+    ra = RelAlgExecutionUnit(descs, targets, [], [0, 1], max_groups_buffer_entry_guess=131072, num_tuples=n)   # 1401 x 901 > 1 M
+    case = cases_mod.Case("twin_nulls", ra, [[k0[:20_001], k1[:20_001], val[:20_001]], [k0[20_001:], k1[20_001:], val[20_001:]]])
+    rs = flow._check(oracle, case, kernel_variant=2)
+    assert rs is not None and rs.report.kernel_name.decode() == "k_idx_scatter", rs.report.kernel_name
+    ra.max_groups_buffer_entry_guess = 16384       # ~58 K groups do not fit
+    with pytest.raises(Exception) as ei:
+        Executor(0).executeWorkUnit(ra, flow._fetch_result(case), allow_retry=False, kernel_variant=2)
+    assert "-" in str(ei.value) or "slots" in str(ei.value).lower(), str(ei.value)
