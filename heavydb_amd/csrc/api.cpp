@@ -1810,6 +1810,228 @@ int32_t execute_cast_key(const mi355q_plan* plan, const mi355q_inputs* in, const
   return MI355Q_OK;
 }
 
+// Aggregates whose argument is `plain INT column + / - literal` (the reference benchmark's MultiStep shapes:
+// MAX(x10 + 1), SUM(x10 + 1) next to MAX(x10)).  The reference compiles the addition into the row function
+// (ArithmeticIR.cpp:77-150); materialising it as a projected column costs a pass over the input and a value column of
+// the exchange.  Where the column's range says the addition cannot overflow, the step runs on a derived plan that
+// aggregates the COLUMN — MIN / MAX / SUM / AVG / COUNT of (x + L) are MIN(x) + L, MAX(x) + L, SUM(x) + L·COUNT(x),
+// (SUM(x) + L·COUNT(x)) / COUNT(x), COUNT(x), with NULL rows skipped on both sides and wrapping 64-bit sums — and the
+// literal is added while the derived table is copied into the stated layout (k_zip_targets).  The derived plan holds
+// every distinct aggregate once, plus COUNT(x) where a sum needs it.  kNotTaken when the shape does not call for it.
+int32_t execute_shifted_args(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
+                             mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
+  if (plan->n_group_cols < 1 || plan->join_outer_col >= 0 || plan->output_columnar_hint != 0 || o.kernel_variant == 1 ||
+      o.force_generic)
+    return kNotTaken;
+  const int nc = plan->n_cols, nx = plan->n_exprs;
+  // which expressions are `column +- literal` that cannot overflow
+  int src_col[MI355Q_MAX_EXPRS];
+  int64_t shift[MI355Q_MAX_EXPRS];
+  bool any = false;
+  for (int k = 0; k < nx; ++k) {
+    src_col[k] = -1;
+    const mi355q_expr& ex = plan->exprs[k];
+    if (ex.n_nodes != 3 || ex.nodes[0].op != MI355Q_EX_COL || ex.nodes[1].op != MI355Q_EX_LIT ||
+        (ex.nodes[2].op != MI355Q_EX_ADD && ex.nodes[2].op != MI355Q_EX_SUB))
+      continue;
+    const int c = ex.nodes[0].arg;
+    if (c < 0 || c >= nc) continue;
+    const mi355q_col_desc& cd = plan->cols[c];
+    const mi355q_range& r = plan->col_ranges[c];
+    if ((cd.type != MI355Q_INT32 && cd.type != MI355Q_INT64) || cd.encoding != MI355Q_ENC_NONE ||
+        (cd.logical_type != 0 && cd.logical_type != cd.type) || ex.nodes[1].type != cd.type || ex.nodes[2].type != cd.type ||
+        !r.valid || r.min > r.max)
+      continue;
+    const __int128 L = ex.nodes[2].op == MI355Q_EX_ADD ? (__int128)ex.nodes[1].ilit : -(__int128)ex.nodes[1].ilit;
+    const __int128 tmax = cd.type == MI355Q_INT32 ? (__int128)INT32_MAX : (__int128)INT64_MAX;
+    // (the type's minimum is its NULL; the literal itself must be a value of the type)
+    if ((__int128)r.max + L > tmax || (__int128)r.min + L <= -tmax - 1 || L > tmax || L < -tmax) continue;
+    src_col[k] = c;
+    shift[k] = (int64_t)L;
+    any = true;
+  }
+  if (!any) return kNotTaken;
+  // an expression that is also a key, a filter column or a condition stays projected
+  for (int g = 0; g < plan->n_group_cols; ++g)
+    if (plan->group_cols[g] >= nc && plan->group_cols[g] < nc + nx) src_col[plan->group_cols[g] - nc] = -1;
+  for (int i = 0; i < plan->n_quals; ++i)
+    if (plan->quals[i].col >= nc && plan->quals[i].col < nc + nx) src_col[plan->quals[i].col - nc] = -1;
+  for (int t = 0; t < plan->n_targets; ++t) {
+    const mi355q_target& tg = plan->targets[t];
+    if ((tg.agg == MI355Q_COUNT_IF || tg.agg == MI355Q_SUM_IF) && tg.cond.col >= nc && tg.cond.col < nc + nx)
+      src_col[tg.cond.col - nc] = -1;
+    if (tg.agg != MI355Q_PROJECT_KEY && tg.table == 0 && tg.col >= nc && tg.col < nc + nx &&
+        (tg.agg == MI355Q_COUNT_IF || tg.agg == MI355Q_SUM_IF))
+      src_col[tg.col - nc] = -1;
+  }
+  any = false;
+  for (int k = 0; k < nx; ++k) any = any || src_col[k] >= 0;
+  if (!any) return kNotTaken;
+  int64_t total_rows = 0;
+  for (int f = 0; f < in->n_frags; ++f) total_rows += in->num_rows[f];
+  // (kernel_variant 2 = "the large-input members": how the tests reach this route with small tables)
+  if (o.kernel_variant != 2 && total_rows < ((int64_t)4 << 20)) return kNotTaken;
+
+  // the derived plan: the shifted expressions leave (the others move down), every distinct aggregate once
+  mi355q_plan p2 = *plan;
+  int new_col[MI355Q_MAX_EXPRS];  // column index of a kept expression in the derived plan
+  p2.n_exprs = 0;
+  for (int k = 0; k < nx; ++k) {
+    if (src_col[k] >= 0) {
+      new_col[k] = -1;
+    } else {
+      new_col[k] = nc + p2.n_exprs;
+      p2.exprs[p2.n_exprs++] = plan->exprs[k];
+    }
+  }
+  auto moved = [&](int col) { return col >= nc && col < nc + nx ? new_col[col - nc] : col; };
+  for (int g = 0; g < p2.n_group_cols; ++g) p2.group_cols[g] = moved(plan->group_cols[g]);
+  for (int i = 0; i < p2.n_quals; ++i) p2.quals[i].col = moved(plan->quals[i].col);
+  p2.n_targets = 0;
+  int t2_of[MI355Q_MAX_TARGETS], cnt_t2[MI355Q_MAX_TARGETS];  // final target -> derived target; -> the derived COUNT(x)
+  int64_t lit_of[MI355Q_MAX_TARGETS];
+  auto same = [](const mi355q_target& a, const mi355q_target& b) {
+    return a.agg == b.agg && a.col == b.col && a.table == b.table && a.cond.col == b.cond.col && a.cond.op == b.cond.op &&
+           a.cond.ival == b.cond.ival && a.cond.fval == b.cond.fval;
+  };
+  auto add_target = [&](const mi355q_target& tg) {
+    for (int i = 0; i < p2.n_targets; ++i)
+      if (same(p2.targets[i], tg)) return i;
+    if (p2.n_targets >= MI355Q_MAX_TARGETS) return -1;
+    p2.targets[p2.n_targets] = tg;
+    return p2.n_targets++;
+  };
+  for (int t = 0; t < plan->n_targets; ++t) {
+    mi355q_target tg = plan->targets[t];
+    lit_of[t] = 0;
+    cnt_t2[t] = -1;
+    if (tg.agg != MI355Q_PROJECT_KEY && tg.table == 0 && tg.col >= nc && tg.col < nc + nx) {
+      const int k = tg.col - nc;
+      if (src_col[k] >= 0) {
+        tg.col = src_col[k];
+        lit_of[t] = shift[k];
+      } else {
+        tg.col = new_col[k];
+      }
+    }
+    if (tg.agg == MI355Q_COUNT_IF || tg.agg == MI355Q_SUM_IF) tg.cond.col = moved(tg.cond.col);
+    t2_of[t] = tg.agg == MI355Q_PROJECT_KEY ? (p2.n_targets < MI355Q_MAX_TARGETS ? (p2.targets[p2.n_targets] = tg, p2.n_targets++) : -1)
+                                            : add_target(tg);
+    if (t2_of[t] < 0) return kNotTaken;
+  }
+  for (int t = 0; t < plan->n_targets; ++t) {  // the counts the shifted MIN / MAX / SUM targets need
+    const mi355q_target& tg = plan->targets[t];
+    if (!lit_of[t] || tg.agg == MI355Q_COUNT || tg.agg == MI355Q_AVG) continue;  // (AVG carries its own count)
+    mi355q_target cnt{};
+    cnt.agg = MI355Q_COUNT;
+    cnt.col = p2.targets[t2_of[t]].col;
+    cnt.table = 0;
+    cnt_t2[t] = add_target(cnt);
+    if (cnt_t2[t] < 0) return kNotTaken;
+  }
+  mi355q_qmd q, q2;
+  if (qmd_init(*plan, &q) != MI355Q_OK || qmd_init(p2, &q2) != MI355Q_OK) return kNotTaken;
+  if (q.slot_width != 8 || q2.slot_width != 8 || q.output_columnar || q2.output_columnar || q.desc_type != q2.desc_type ||
+      q.entry_count != q2.entry_count || q.desc_type == MI355Q_NON_GROUPED_AGGREGATE ||
+      (q.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && q.key_width != q2.key_width))
+    return kNotTaken;
+  int32_t src[MI355Q_MAX_SLOTS], dst[MI355Q_MAX_SLOTS], kind[MI355Q_MAX_SLOTS], cnt_src[MI355Q_MAX_SLOTS];
+  int64_t lit[MI355Q_MAX_SLOTS];
+  int n = 0;
+  for (int t = 0; t < plan->n_targets; ++t) {
+    const int sf = q.target_slot[t], ss = q2.target_slot[t2_of[t]];
+    if ((sf < 0) != (ss < 0)) return kNotTaken;  // (a projection read from the key columns on both sides)
+    if (sf < 0) continue;
+    const int agg = plan->targets[t].agg;
+    for (int j = 0; j < (agg == MI355Q_AVG ? 2 : 1); ++j) {
+      if (q.init_vals[sf + j] != q2.init_vals[ss + j] || n >= MI355Q_MAX_SLOTS) return kNotTaken;
+      src[n] = ss + j;
+      dst[n] = sf + j;
+      kind[n] = 0;
+      cnt_src[n] = 0;
+      lit[n] = 0;
+      if (lit_of[t] && j == 0 && agg != MI355Q_COUNT) {
+        kind[n] = (agg == MI355Q_SUM || agg == MI355Q_AVG) ? 2 : 1;
+        cnt_src[n] = agg == MI355Q_AVG ? ss + 1 : q2.target_slot[cnt_t2[t]];
+        if (cnt_src[n] < 0) return kNotTaken;
+        lit[n] = lit_of[t];
+      }
+      ++n;
+    }
+  }
+  mi355q_exec_options o2 = o;
+  o2.out_buffer = nullptr;
+  if (reserved) {
+    route_note("aggregates of column + literal from the column's aggregates + k_zip_targets");
+    return execute_impl(&p2, in, &o2, out, report, nullptr, reserved);
+  }
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+  o2.stream = s;
+  mi355q_result* r2 = nullptr;
+  mi355q_exec_report rep2{};
+  if (int32_t e2 = mi355q_execute(&p2, in, &o2, &r2, &rep2)) {
+    if (e2 == MI355Q_ERR_UNSUPPORTED || e2 == MI355Q_ERR_OUT_OF_GPU_MEM) return kNotTaken;
+    return e2;  // (out of slots included: the derived table has the stated table's entry count)
+  }
+  struct R2Guard {
+    mi355q_result* r;
+    ~R2Guard() { if (r) mi355q_result_free(r); }
+  } r2g{r2};
+  if (r2->qmd.desc_type != q.desc_type || r2->qmd.entry_count != q.entry_count || r2->qmd.slot_width != 8 ||
+      r2->qmd.output_columnar)
+    return kNotTaken;
+  for (int t = 0; t < plan->n_targets; ++t)
+    if (r2->qmd.target_slot[t2_of[t]] != q2.target_slot[t2_of[t]]) return kNotTaken;
+  mi355q_result* res = nullptr;
+  if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;
+  struct ResGuard {
+    mi355q_result* r;
+    ~ResGuard() { if (r) mi355q_result_free(r); }
+  } rg{res};
+  HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+  DevWord err;
+  HIP_TRY(hipMalloc(&err.p, 64));
+  HIP_TRY(hipMemsetAsync(err.p, 0, 64, s));
+  HIP_TRY(launch_zip_targets(res->dplan, r2->dplan, r2->qmd.idx_target_as_key, r2->buf, res->buf, src, dst, n, (int32_t*)err.p, s,
+                             kind, cnt_src, lit));
+  if (ev1) HIP_TRY(hipEventRecord(ev1, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_err) return h_err;
+  if (report) {
+    *report = rep2;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->n_launches = rep2.n_launches + 1;
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  rg.r = nullptr;
+  *out = res;
+  return MI355Q_OK;
+}
+
 // Plans with projected expressions (mi355q_expr): scan / filter / PROJECT.  The expressions of a pass of
 // fragments are evaluated into dense temporary columns (k_project), the step runs on the lowered plan — where
 // those columns are ordinary inputs, so every kernel family applies — and the passes' results are folded with
@@ -2104,8 +2326,13 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   }
   if (plan->n_exprs != 0) {
     if (!pend) {
-      const int32_t e = execute_cast_key(plan, in, o, out, report, reserved);
+      const size_t mark = t_route ? t_route->size() : 0;
+      int32_t e = execute_shifted_args(plan, in, o, out, report, reserved);
       if (e != kNotTaken) return e;
+      if (t_route) t_route->resize(mark);
+      e = execute_cast_key(plan, in, o, out, report, reserved);
+      if (e != kNotTaken) return e;
+      if (t_route) t_route->resize(mark);
     }
     if (reserved) {  // the step proper runs on the lowered plan: reserve for that
       route_note("k_project");

@@ -927,6 +927,11 @@ __global__ __launch_bounds__(kBlock) void k_perfect_twin_emit(DevPlan pf, DevPla
 struct ZipMap {
   int32_t n;                          // slot copies
   int32_t src[MI355Q_MAX_SLOTS], dst[MI355Q_MAX_SLOTS];  // slot index in the run's row -> slot index in the final row
+  // aggregates of `column + literal` computed as aggregates of the column (api.cpp execute_shifted_args): where the
+  // group has non-NULL rows (their count sits in the run's slot cnt_src) the copy adds the literal (kind 1: MIN / MAX)
+  // or literal x count (kind 2: SUM, the sum half of AVG); kind 0 = plain copy
+  int32_t kind[MI355Q_MAX_SLOTS], cnt_src[MI355Q_MAX_SLOTS];
+  int64_t lit[MI355Q_MAX_SLOTS];
 };
 __global__ __launch_bounds__(kBlock) void k_zip_targets(DevPlan pf, DevPlan ps, int idx_key_s, const int64_t* __restrict__ sub,
                                                          int64_t* __restrict__ fin, ZipMap zm, int32_t* __restrict__ d_err) {
@@ -976,7 +981,14 @@ __global__ __launch_bounds__(kBlock) void k_zip_targets(DevPlan pf, DevPlan ps, 
         continue;
       }
     }
-    for (int j = 0; j < zm.n; ++j) MQ_STORE64(slots_f + zm.dst[j], slots_s[zm.src[j]]);
+    for (int j = 0; j < zm.n; ++j) {
+      int64_t v = slots_s[zm.src[j]];
+      if (zm.kind[j]) {
+        const int64_t c = slots_s[zm.cnt_src[j]];
+        if (c > 0) v = (int64_t)((uint64_t)v + (uint64_t)zm.lit[j] * (zm.kind[j] == 2 ? (uint64_t)c : 1ull));
+      }
+      MQ_STORE64(slots_f + zm.dst[j], v);
+    }
   }
 }
 
@@ -1271,12 +1283,16 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 }
 
 hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_s, const int64_t* sub, int64_t* fin,
-                              const int32_t* src, const int32_t* dst, int n, int32_t* d_err, hipStream_t s) {
+                              const int32_t* src, const int32_t* dst, int n, int32_t* d_err, hipStream_t s,
+                              const int32_t* kind, const int32_t* cnt_src, const int64_t* lit) {
   ZipMap zm{};
   zm.n = n;
   for (int i = 0; i < n; ++i) {
     zm.src[i] = src[i];
     zm.dst[i] = dst[i];
+    zm.kind[i] = kind ? kind[i] : 0;
+    zm.cnt_src[i] = kind ? cnt_src[i] : 0;
+    zm.lit[i] = kind ? lit[i] : 0;
   }
   if (ps.entry_count <= 0) return hipSuccess;
   hipLaunchKernelGGL(k_zip_targets, dim3(grid_for(ps.entry_count)), dim3(kBlock), 0, s, pf, ps, idx_key_s, sub, fin, zm, d_err);

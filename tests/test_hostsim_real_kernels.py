@@ -124,8 +124,8 @@ def test_no_reference_benchmark_query_takes_the_row_kernel(sim, name, n_rows):
 def test_explain_names_the_stages_of_a_derived_route(sim):
     r = _explain("BH005", 1_000_000_000)      # GROUP BY cast(x100k AS DOUBLE): grouped by x100k itself (100 K-entry perfect hash), then re-keyed
     assert "k_cast_key_emit" in r and r.endswith("k_idx_scatter + k_idx_aggregate"), r
-    r = _explain("MSPHS011", 1_000_000_000)   # MAX(x10 + 1): a projected argument
-    assert r.startswith("k_project"), r
+    r = _explain("MSPHS011", 1_000_000_000)   # MAX(x10 + 1): MAX(x10) of a derived plan, the literal added while it is copied
+    assert r.startswith("aggregates of column + literal") and r.endswith("k_idx_scatter + k_idx_aggregate"), r
     r = _explain("PHS004", 1_000_000_000)     # 10 K-entry perfect hash, five aggregates: windows of the LDS group-by
     assert r == "k_groupby_lds", r
     r = _explain("NGA03", 1_000_000_000)
@@ -286,8 +286,8 @@ def test_cast_key_route_on_the_benchmark_shapes(sim, oracle, name):
 def test_cast_key_route_is_named_by_explain(sim):
     r = _explain("BH003", 1_000_000_000)
     assert "k_cast_key_emit" in r and "k_project" not in r, r
-    r = _explain("MSBS004", 1_000_000_000)    # the other expression (x10 + 1) is still projected
-    assert "k_cast_key_emit" in r and "k_project" in r, r
+    r = _explain("MSBS004", 1_000_000_000)    # the other expression (x10 + 1): from the column's aggregates, no projection either
+    assert "k_cast_key_emit" in r and "column + literal" in r and "k_project" not in r, r
 
 
 def test_cast_key_route_with_null_keys_and_float_collisions(sim, oracle):
@@ -356,3 +356,54 @@ def test_perfect_twin_route_with_null_keys(sim, oracle):
     with pytest.raises(Exception) as ei:
         Executor(0).executeWorkUnit(ra, flow._fetch_result(case), allow_retry=False, kernel_variant=2)
     assert "-" in str(ei.value) or "slots" in str(ei.value).lower(), str(ei.value)
+
+
+# ---- aggregates of `column + literal` from the column's aggregates (execute_shifted_args) -----------------------------------
+@pytest.mark.parametrize("name", ["MSPHS001", "MSPHS003", "MSPHS005", "MSPHS010", "MSPHS012", "MSPHM001", "MSPHM003", "MSPHM005",
+                                  "MSBS001", "MSBS003"])
+def test_shifted_argument_route_on_the_benchmark_shapes(sim, oracle, name):
+    """MultiStep shapes: MAX(x10 + 1) / SUM(x10 + 1) next to MAX(x10).  The derived plan aggregates x10 once, adds COUNT(x10)
+    for the sum, and the literal is added while the derived table is copied into the stated layout — no projected column.
+    kernel_variant 2 = the large-input members on a small input."""
+    case = flow._refbench_case(oracle, name, 150_003, 120_000)
+    rs = flow._check(oracle, case, kernel_variant=2)
+    assert rs is not None and rs.report.n_launches >= 2, rs.report.n_launches
+
+
+def test_shifted_argument_route_is_named_by_explain(sim):
+    for name in ("MSPHS001", "MSPHS004", "MSPHS011", "MSPHM002", "MSPHM005", "MSBS002"):
+        r = _explain(name, 1_000_000_000)
+        assert "column + literal" in r and "k_project" not in r, (name, r)
+
+
+def test_shifted_arguments_with_nulls_and_a_range_that_could_overflow(sim, oracle):
+    from heavydb_amd.executor import Expr, ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(21)
+    n = 50_000
+    key = rng.integers(0, 70_000, n).astype(np.int32)
+    v32 = rng.integers(-500, 500, n).astype(np.int32)
+    v32[rng.random(n) < 0.2] = np.iinfo(np.int32).min
+    v64 = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    v64[rng.random(n) < 0.2] = np.iinfo(np.int64).min
+    descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 69_999)),
+             InputColDescriptor(capi.INT32, True, ExpressionRange(True, -500, 499, True)),
+             InputColDescriptor(capi.INT64, True, ExpressionRange(True, -10**12, 10**12, True))]
+    e0 = Expr.col(1).add(Expr.lit(capi.INT32, 7), capi.INT32).with_range(ExpressionRange(True, -493, 506, True))
+    e1 = Expr.col(2).sub(Expr.lit(capi.INT64, 1000), capi.INT64).with_range(ExpressionRange(True, -10**12 - 1000, 10**12 - 1000, True))
+    for targets in ([TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 3), TargetExpr(capi.MIN, 3), TargetExpr(capi.MAX, 1),
+                     TargetExpr(capi.AVG, 4), TargetExpr(capi.COUNT, 3)],
+                    [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.MAX, 4), TargetExpr(capi.SUM, 4),
+                     TargetExpr(capi.AVG, 3), TargetExpr(capi.MIN, 2)]):
+        ra = RelAlgExecutionUnit(descs, targets, [], [0], exprs=[e0, e1], num_tuples=n)
+        case = cases_mod.Case("shifted_nulls", ra, [[key[:17_003], v32[:17_003], v64[:17_003]], [key[17_003:], v32[17_003:], v64[17_003:]]])
+        rs = flow._check(oracle, case, kernel_variant=2)
+        assert rs is not None and rs.report.n_launches >= 2, rs.report.n_launches
+    # INT32 values up to 2^31 - 3: + 7 may overflow, the expression stays projected (and raises the reference's error 7)
+    big = v32.copy()
+    big[5] = 2**31 - 3
+    descs2 = [descs[0], InputColDescriptor(capi.INT32, True, ExpressionRange(True, -500, 2**31 - 3, True)), descs[2]]
+    ra = RelAlgExecutionUnit(descs2, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 3)], [], [0],
+                             exprs=[Expr.col(1).add(Expr.lit(capi.INT32, 7), capi.INT32).with_range(ExpressionRange(True, -493, 2**31 - 1, True)), e1],
+                             num_tuples=n)
+    case = cases_mod.Case("shifted_overflow", ra, [[key, big, v64]], expect_error=7)
+    flow._check(oracle, case, kernel_variant=2)     # the oracle's code (7) and the product's must agree
