@@ -2865,15 +2865,13 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     mi355q_result_free(res);
     rg.r = nullptr;
     mi355q_exec_options o2 = o;
-    // small replicas did not hold the groups: the largest replica next, then eight windows of it, then another family.
-    // Windows read the columns once per window: over a large input the partitioned family (one pass + one exchange) is
-    // the cheaper next step — BH007 at 1 B rows: 29.6 ms in eight windows (profiles/r04_refbench_1b_call13.jsonl)
-    int64_t rows_in = 0;
-    for (int f = 0; f < in->n_frags; ++f) rows_in += in->num_rows[f];
-    const bool windows_next = !(o.flags & MI355Q_OPT_LDS_BASELINE_WINDOWS) && rows_in < kIdxPartMinRows;
-    o2.flags |= !(o.flags & MI355Q_OPT_LDS_BASELINE_LARGE) ? MI355Q_OPT_LDS_BASELINE_LARGE
-                : windows_next                             ? MI355Q_OPT_LDS_BASELINE_WINDOWS
-                                                           : MI355Q_OPT_NO_LDS_BASELINE;
+    // small replicas did not hold the groups: the largest replica next, then eight windows of it, then another family
+    // (skipping the windows over large inputs was measured and is worse: with <= 65536 entries the families behind them
+    // are the direct global-atomic members — BH007 at 1 B rows: 29.6 ms in eight windows, 638 ms without,
+    // profiles/r04_refbench_1b_call14.jsonl)
+    o2.flags |= !(o.flags & MI355Q_OPT_LDS_BASELINE_LARGE)     ? MI355Q_OPT_LDS_BASELINE_LARGE
+                : !(o.flags & MI355Q_OPT_LDS_BASELINE_WINDOWS) ? MI355Q_OPT_LDS_BASELINE_WINDOWS
+                                                               : MI355Q_OPT_NO_LDS_BASELINE;
     return execute_impl(plan, in, &o2, out, report, nullptr, nullptr);
   }
   if (code) return code;
