@@ -2014,7 +2014,7 @@ int32_t execute_shifted_args(const mi355q_plan* plan, const mi355q_inputs* in, c
   HIP_TRY(hipMalloc(&err.p, 64));
   HIP_TRY(hipMemsetAsync(err.p, 0, 64, s));
   HIP_TRY(launch_zip_targets(res->dplan, r2->dplan, r2->qmd.idx_target_as_key, r2->buf, res->buf, src, dst, n, (int32_t*)err.p, s,
-                             kind, cnt_src, lit));
+                             kind, cnt_src, lit, /*into_empty_table=*/true));
   if (ev1) HIP_TRY(hipEventRecord(ev1, s));
   int32_t h_err = 0;
   HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(h_err), hipMemcpyDeviceToHost, s));

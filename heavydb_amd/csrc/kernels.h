@@ -122,7 +122,8 @@ hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_ke
 // (kind / cnt_src / lit: per copy, the `aggregate of column + literal` fix-up of ZipMap; null = plain copies)
 hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_s, const int64_t* sub, int64_t* fin,
                               const int32_t* src, const int32_t* dst, int n, int32_t* d_err, hipStream_t s,
-                              const int32_t* kind = nullptr, const int32_t* cnt_src = nullptr, const int64_t* lit = nullptr);
+                              const int32_t* kind = nullptr, const int32_t* cnt_src = nullptr, const int64_t* lit = nullptr,
+                              bool into_empty_table = false);
 // projected expressions: d_cols is the pass's extended fragment table [frag][xs.n_cols + xs.n]; the last xs.n
 // pointers of every fragment are the output columns (dense, of each expression's result type).  p = the
 // device plan of the LOWERED plan (quals, join): it decides whether a row's overflow counts.

@@ -932,6 +932,10 @@ struct ZipMap {
   // or literal x count (kind 2: SUM, the sum half of AVG); kind 0 = plain copy
   int32_t kind[MI355Q_MAX_SLOTS], cnt_src[MI355Q_MAX_SLOTS];
   int64_t lit[MI355Q_MAX_SLOTS];
+  // baseline -> baseline with the same keys, entry count and key width into an EMPTY table: an entry keeps its position
+  // (any probe-consistent placement is a valid table, and the run's is one) — a sequential copy instead of one
+  // find-or-insert per group
+  int32_t positional;
 };
 __global__ __launch_bounds__(kBlock) void k_zip_targets(DevPlan pf, DevPlan ps, int idx_key_s, const int64_t* __restrict__ sub,
                                                          int64_t* __restrict__ fin, ZipMap zm, int32_t* __restrict__ d_err) {
@@ -963,6 +967,10 @@ __global__ __launch_bounds__(kBlock) void k_zip_targets(DevPlan pf, DevPlan ps, 
       } else {
         slots_f = row_f;
       }
+    } else if (zm.positional) {
+      int64_t* row_f = fin + e * pf.row_quad;
+      for (int k = 0; k < pf.key_quad; ++k) MQ_STORE64(row_f + k, row_s[k]);
+      slots_f = row_f + pf.key_quad;
     } else {
       int64_t keys[MI355Q_MAX_GROUP_COLS];
       for (int g = 0; g < pf.n_group; ++g) keys[g] = row_key_component(row_s, ps.key_width, g);
@@ -1284,9 +1292,12 @@ hipError_t launch_pack_keys(const PackSpec& ps, const int8_t* const* d_cols, con
 
 hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_s, const int64_t* sub, int64_t* fin,
                               const int32_t* src, const int32_t* dst, int n, int32_t* d_err, hipStream_t s,
-                              const int32_t* kind, const int32_t* cnt_src, const int64_t* lit) {
+                              const int32_t* kind, const int32_t* cnt_src, const int64_t* lit, bool into_empty_table) {
   ZipMap zm{};
   zm.n = n;
+  zm.positional = into_empty_table && pf.desc_type == MI355Q_GROUP_BY_BASELINE_HASH && ps.desc_type == pf.desc_type &&
+                  pf.entry_count == ps.entry_count && pf.key_width == ps.key_width && pf.n_group == ps.n_group &&
+                  pf.key_quad == ps.key_quad;
   for (int i = 0; i < n; ++i) {
     zm.src[i] = src[i];
     zm.dst[i] = dst[i];
