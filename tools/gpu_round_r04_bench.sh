@@ -22,4 +22,10 @@ python tools/make_traffic_json.py $out/pmc_FETCH_SIZE_stats.txt $out/pmc_WRITE_S
 timeout 400 python bench.py > $out/bench_default_with_traffic.json 2> $out/bench_default_with_traffic.err; echo "bench (traffic) exit $?"
 timeout 600 python tools/refbench.py --rows 1e9 --steps 3 --budget-ms 1500 --out $out/refbench_1b.jsonl > $out/refbench_1b.log 2>&1; echo "refbench 1B exit $?"
 timeout 300 python tools/refbench.py --rows 128e6 --steps 3 --budget-ms 1500 --out $out/refbench_128m.jsonl > $out/refbench_128m.log 2>&1; echo "refbench 128M exit $?"
+# HBM bytes the index-partitioned family moves (<= 20 B/row): PHS005 (8-byte records), MSPHS008 (16-byte records)
+for grp in FETCH_SIZE WRITE_SIZE; do
+  timeout 200 rocprofv3 --kernel-trace --pmc $grp -d $out/pmc_idx_$grp -o pmc -- python tools/refbench.py --rows 1e9 --steps 1 --only PHS005,MSPHS008 --out $out/refbench_idx_pmc_$grp.jsonl > $out/pmc_idx_$grp.log 2>&1
+  python tools/rocpd_stats.py $out/pmc_idx_$grp/pmc_results.db > $out/pmc_idx_${grp}_stats.txt 2>&1; rm -rf $out/pmc_idx_$grp
+  grep -E "k_idx_" $out/pmc_idx_${grp}_stats.txt | cut -c1-170
+done
 head -3 $out/cfg3f_kernel_stats.csv
