@@ -1831,7 +1831,7 @@ int32_t execute_shifted_args(const mi355q_plan* plan, const mi355q_inputs* in, c
   for (int k = 0; k < nx; ++k) {
     src_col[k] = -1;
     const mi355q_expr& ex = plan->exprs[k];
-    if (ex.n_nodes != 3 || ex.nodes[0].op != MI355Q_EX_COL || ex.nodes[1].op != MI355Q_EX_LIT ||
+    if (ex.n_nodes != 3 || ex.nodes[0].op != MI355Q_EX_COL || ex.nodes[1].op != MI355Q_EX_LIT || ex.nodes[1].reserved != 0 ||
         (ex.nodes[2].op != MI355Q_EX_ADD && ex.nodes[2].op != MI355Q_EX_SUB))
       continue;
     const int c = ex.nodes[0].arg;

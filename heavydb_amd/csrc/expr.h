@@ -14,6 +14,11 @@
 //                RuntimeFunctions.cpp:46-53
 //   / %          ArithmeticIR.cpp:431-560 codegenDiv (zero check skipped behind a NULL operand), :731-760 codegenMod (zero
 //                check first); div_/mod_<type>_nullable[_lhs|_rhs], RuntimeFunctions.cpp:46-71
+//   comparisons  CompareIR.cpp:230-330 codegenCmp: icmp / fcmp, or <op>_<type>_nullable[_lhs|_rhs] (RuntimeFunctions.cpp:73-107):
+//                BOOLEAN 1 / 0, the INT8 NULL when a nullable operand is NULL
+//   CASE         CaseIR.cpp:67-140 codegenCase: the THEN value where the condition is TRUE (toBool: NULL is not), else the ELSE
+//                value; each branch is its own basic block, so a check that fires in the branch NOT taken does not exist —
+//                every value on the stack carries the error its computation met, and CASE keeps the taken branch's only
 //   error        ErrorCode::OVERFLOW_OR_UNDERFLOW = 7, DIV_BY_ZERO = 1 (QueryEngine/enums.h:30-51)
 #pragma once
 
@@ -30,10 +35,12 @@ MQ_HD int64_t ex_int_min(int t) { return plain_int_null(t); }  // the type's min
 MQ_HD int64_t ex_flt_pattern(float f) { return (int64_t)(uint32_t)flt_bits(f); }
 MQ_HD float ex_flt_of(int64_t v) { return bits_flt((int32_t)(uint32_t)v); }
 
-// *err receives MI355Q_ERR_OVERFLOW_OR_UNDERFLOW / MI355Q_ERR_DIV_BY_ZERO when a check fires (the value returned is then
-// unspecified); the FIRST check that fires along the program is the one reported
+// *err receives MI355Q_ERR_OVERFLOW_OR_UNDERFLOW / MI355Q_ERR_DIV_BY_ZERO when a check fires on the way to the RESULT (the
+// value returned is then unspecified): the first one in evaluation order — operands left to right, then the operation; a
+// CASE's condition, then the branch it takes.  es[] = the error each stack value carries.
 MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos, int32_t* err) {
   int64_t st[4] = {0, 0, 0, 0};
+  int32_t es[4] = {0, 0, 0, 0};
   int sp = 0;
   for (int i = 0; i < e.n_nodes; ++i) {
     const DevExprNode& n = e.nodes[i];
@@ -43,11 +50,14 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
         if (n.type == MI355Q_DOUBLE) st[sp++] = *(const int64_t*)(c + pos * 8);
         else if (n.type == MI355Q_FLOAT) st[sp++] = (int64_t)*(const uint32_t*)(c + pos * 4);
         else st[sp++] = decode_int(c, (int)n.ilit, pos);
+        es[sp - 1] = 0;
         break;
       }
       case MI355Q_EX_LIT:
-        st[sp++] = n.type == MI355Q_DOUBLE ? dbl_bits(n.flit)
+        st[sp++] = n.arg ? n.ilit  // (the NULL literal: its pattern was laid down by the lowering)
+                   : n.type == MI355Q_DOUBLE ? dbl_bits(n.flit)
                    : n.type == MI355Q_FLOAT ? ex_flt_pattern((float)n.flit) : n.ilit;
+        es[sp - 1] = 0;
         break;
       case MI355Q_EX_CAST: {
         const int from = n.arg, to = n.type;
@@ -60,7 +70,7 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
             if (is_null) {
               r = plain_int_null(to);
             } else if (plain_width(to) < plain_width(from) && (v > ex_int_max(to) || v <= ex_int_min(to))) {
-              { if (!*err) *err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW; }
+              if (!es[sp - 1]) es[sp - 1] = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
             }
           } else if (to == MI355Q_DOUBLE) {
             r = is_null ? kNullDoubleBits : dbl_bits((double)v);
@@ -85,6 +95,8 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
       case MI355Q_EX_MOD: {
         const int64_t b = st[--sp];
         const int64_t a = st[sp - 1];
+        int32_t& ev = es[sp - 1];
+        if (!ev) ev = es[sp];  // (lhs first, then rhs, then this operation)
         const int t = n.type;
         const bool ln = (n.flags & EXF_LHS_NULLABLE) != 0, rn = (n.flags & EXF_RHS_NULLABLE) != 0;
         int64_t r;
@@ -93,7 +105,7 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
           // DIV: a NULL pattern in EITHER operand skips the zero check as soon as one of them may be NULL; MOD tests first
           const bool skip = n.op == MI355Q_EX_DIV && (ln || rn) && (a == nul || b == nul);
           if (!skip && b == 0) {
-            { if (!*err) *err = MI355Q_ERR_DIV_BY_ZERO; }
+            if (!ev) ev = MI355Q_ERR_DIV_BY_ZERO;
             r = nul;
           } else if ((ln && a == nul) || (rn && b == nul)) {
             r = nul;
@@ -108,20 +120,68 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
         } else if (t == MI355Q_DOUBLE) {
           const double x = bits_dbl(a), y = bits_dbl(b);
           const bool skip = (ln || rn) && (x == kNullDouble || y == kNullDouble);
-          if (!skip && !(y < 0.0 || y > 0.0)) { if (!*err) *err = MI355Q_ERR_DIV_BY_ZERO; }
+          if (!skip && !(y < 0.0 || y > 0.0) && !ev) ev = MI355Q_ERR_DIV_BY_ZERO;
           r = ((ln && x == kNullDouble) || (rn && y == kNullDouble)) ? kNullDoubleBits : dbl_bits(x / y);
         } else {
           const float x = ex_flt_of(a), y = ex_flt_of(b);
           const bool skip = (ln || rn) && (x == kNullFloat || y == kNullFloat);
-          if (!skip && !(y < 0.0f || y > 0.0f)) { if (!*err) *err = MI355Q_ERR_DIV_BY_ZERO; }
+          if (!skip && !(y < 0.0f || y > 0.0f) && !ev) ev = MI355Q_ERR_DIV_BY_ZERO;
           r = ((ln && x == kNullFloat) || (rn && y == kNullFloat)) ? (int64_t)(uint32_t)kNullFloatBits : ex_flt_pattern(x / y);
         }
         st[sp - 1] = r;
         break;
       }
+      case MI355Q_EX_EQ:
+      case MI355Q_EX_NE:
+      case MI355Q_EX_LT:
+      case MI355Q_EX_LE:
+      case MI355Q_EX_GT:
+      case MI355Q_EX_GE: {
+        const int64_t b = st[--sp];
+        const int64_t a = st[sp - 1];
+        if (!es[sp - 1]) es[sp - 1] = es[sp];
+        const int t = n.arg;  // the operands' type
+        const bool ln = (n.flags & EXF_LHS_NULLABLE) != 0, rn = (n.flags & EXF_RHS_NULLABLE) != 0;
+        // lt / eq / gt as the C operators of the runtime functions give them (a NaN operand: all three false, so that
+        // <, <=, >, >=, = are false and <> is true)
+        bool is_null, lt, eq, gt;
+        if (ex_is_int(t)) {
+          const int64_t nul = plain_int_null(t);
+          is_null = (ln && a == nul) || (rn && b == nul);
+          lt = a < b;
+          eq = a == b;
+          gt = a > b;
+        } else if (t == MI355Q_DOUBLE) {
+          const double x = bits_dbl(a), y = bits_dbl(b);
+          is_null = (ln && x == kNullDouble) || (rn && y == kNullDouble);
+          lt = x < y;
+          eq = x == y;
+          gt = x > y;
+        } else {
+          const float x = ex_flt_of(a), y = ex_flt_of(b);
+          is_null = (ln && x == kNullFloat) || (rn && y == kNullFloat);
+          lt = x < y;
+          eq = x == y;
+          gt = x > y;
+        }
+        const bool v = n.op == MI355Q_EX_EQ ? eq : n.op == MI355Q_EX_NE ? !eq : n.op == MI355Q_EX_LT ? lt
+                       : n.op == MI355Q_EX_LE ? (lt || eq) : n.op == MI355Q_EX_GT ? gt : (gt || eq);
+        st[sp - 1] = is_null ? plain_int_null(MI355Q_INT8) : (v ? 1 : 0);
+        break;
+      }
+      case MI355Q_EX_CASE: {  // stack: ELSE, THEN, cond
+        const int64_t c = st[sp - 1];
+        const int32_t ce = es[sp - 1];
+        sp -= 2;
+        const bool take = c == 1;  // TRUE; 0 and NULL are not
+        st[sp - 1] = take ? st[sp] : st[sp - 1];
+        es[sp - 1] = ce ? ce : take ? es[sp] : es[sp - 1];
+        break;
+      }
       default: {  // MI355Q_EX_ADD / _SUB / _MUL
         const int64_t b = st[--sp];
         const int64_t a = st[sp - 1];
+        if (!es[sp - 1]) es[sp - 1] = es[sp];
         const int t = n.type;
         int64_t r;
         if (ex_is_int(t)) {
@@ -139,7 +199,7 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
               ovf = r > ex_int_max(t) || r < ex_int_min(t);
               r = t == MI355Q_INT8 ? (int64_t)(int8_t)r : t == MI355Q_INT16 ? (int64_t)(int16_t)r : (int64_t)(int32_t)r;
             }
-            if (ovf) { if (!*err) *err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW; }
+            if (ovf && !es[sp - 1]) es[sp - 1] = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
           }
         } else if (t == MI355Q_DOUBLE) {
           const double x = bits_dbl(a), y = bits_dbl(b);
@@ -158,6 +218,7 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
       }
     }
   }
+  if (es[0] && !*err) *err = es[0];
   return st[0];
 }
 

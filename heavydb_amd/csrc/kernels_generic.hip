@@ -1330,7 +1330,7 @@ bool simple_proj_shape(const DevExpr& e, SimpleProj* sp, int* src_type, int* kin
   }
   const DevExprNode& l = e.nodes[1];
   const DevExprNode& o = e.nodes[2];
-  if (l.op != MI355Q_EX_LIT || l.type != c.type || o.type != c.type) return false;
+  if (l.op != MI355Q_EX_LIT || l.arg != 0 /* the NULL literal */ || l.type != c.type || o.type != c.type) return false;
   if (o.op == MI355Q_EX_ADD) *kind = SP_ADD;
   else if (o.op == MI355Q_EX_SUB) *kind = SP_SUB;
   else if (o.op == MI355Q_EX_MUL) *kind = SP_MUL;

@@ -147,7 +147,20 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
           break;
         }
         case MI355Q_EX_LIT: {
-          if (!valid_type(n.type) || sp >= 4) return MI355Q_ERR_INVALID_PLAN;
+          if (!valid_type(n.type) || sp >= 4 || (n.reserved != 0 && n.reserved != 1)) return MI355Q_ERR_INVALID_PLAN;
+          if (n.reserved == 1) {  // the NULL literal of the type
+            o.type = n.type;
+            o.flags = EXF_NULLABLE;
+            o.ilit = n.type == MI355Q_DOUBLE ? kNullDoubleBits
+                     : n.type == MI355Q_FLOAT ? (int64_t)(uint32_t)kNullFloatBits : plain_int_null(n.type);
+            o.flit = 0.0;
+            o.arg = 1;  // (the evaluator pushes ilit as it is)
+            st_type[sp] = n.type;
+            st_null[sp] = true;
+            ++sp;
+            break;
+          }
+          o.arg = 0;
           if (int_type(n.type) &&
               (n.ilit > (n.type == MI355Q_INT8 ? INT8_MAX : n.type == MI355Q_INT16 ? INT16_MAX
                          : n.type == MI355Q_INT32 ? (int64_t)INT32_MAX : INT64_MAX) ||
@@ -181,6 +194,34 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
           const bool nul = st_null[sp - 2] || st_null[sp - 1];
           if (nul) o.flags |= EXF_NULLABLE;
           --sp;
+          st_null[sp - 1] = nul;
+          break;
+        }
+        case MI355Q_EX_EQ:
+        case MI355Q_EX_NE:
+        case MI355Q_EX_LT:
+        case MI355Q_EX_LE:
+        case MI355Q_EX_GT:
+        case MI355Q_EX_GE: {
+          if (n.type != MI355Q_INT8 || sp < 2 || st_type[sp - 1] != st_type[sp - 2]) return MI355Q_ERR_INVALID_PLAN;
+          o.type = MI355Q_INT8;
+          o.arg = st_type[sp - 1];  // the operands' type
+          o.flags = (st_null[sp - 2] ? EXF_LHS_NULLABLE : 0) | (st_null[sp - 1] ? EXF_RHS_NULLABLE : 0);
+          const bool nul = st_null[sp - 2] || st_null[sp - 1];
+          if (nul) o.flags |= EXF_NULLABLE;
+          --sp;
+          st_type[sp - 1] = MI355Q_INT8;
+          st_null[sp - 1] = nul;
+          break;
+        }
+        case MI355Q_EX_CASE: {  // stack: ELSE, THEN, cond
+          if (!valid_type(n.type) || sp < 3 || st_type[sp - 1] != MI355Q_INT8 || st_type[sp - 2] != n.type ||
+              st_type[sp - 3] != n.type)
+            return MI355Q_ERR_INVALID_PLAN;
+          o.type = n.type;
+          const bool nul = st_null[sp - 2] || st_null[sp - 3];
+          o.flags = nul ? EXF_NULLABLE : 0;
+          sp -= 2;
           st_null[sp - 1] = nul;
           break;
         }

@@ -86,6 +86,7 @@ class ExprNode:
     arg: int = 0
     ilit: int = 0
     flit: float = 0.0
+    null_lit: int = 0     # EX_LIT: 1 = the NULL of `type`
 
 
 @dataclass
@@ -105,8 +106,22 @@ class Expr:
         fp = type in (DOUBLE, capi.FLOAT)
         return Expr([ExprNode(capi.EX_LIT, type, 0, 0 if fp else int(v), float(v) if fp else 0.0)])
 
+    @staticmethod
+    def null(type: int) -> "Expr":
+        """the NULL constant of a type (the ELSE of a CASE without one)"""
+        return Expr([ExprNode(capi.EX_LIT, type, null_lit=1)])
+
     def cast(self, type: int) -> "Expr":
         return Expr(self.nodes + [ExprNode(capi.EX_CAST, type)])
+
+    def cmp(self, op: int, other: "Expr") -> "Expr":
+        """self <op> other (capi.EX_EQ .. EX_GE; Analyzer::BinOper with a comparison): a BOOLEAN, stored as INT8 1 / 0 / NULL"""
+        return Expr(self.nodes + other.nodes + [ExprNode(op, capi.INT8)])
+
+    @staticmethod
+    def case(cond: "Expr", then: "Expr", otherwise: "Expr", type: int) -> "Expr":
+        """CASE WHEN cond THEN then ELSE otherwise END (Analyzer::CaseExpr): stack order ELSE, THEN, condition"""
+        return Expr(otherwise.nodes + then.nodes + cond.nodes + [ExprNode(capi.EX_CASE, type)])
 
     def _bin(self, op: int, other: "Expr", type: int) -> "Expr":
         return Expr(self.nodes + other.nodes + [ExprNode(op, type)])
@@ -139,9 +154,14 @@ class Expr:
                                         INT64 if d.encoding == capi.ENC_DATE_IN_DAYS else d.type)
                 st.append((lt, bool(d.nullable)))
             elif n.op == capi.EX_LIT:
-                st.append((n.type, False))
+                st.append((n.type, bool(n.null_lit)))
             elif n.op == capi.EX_CAST:
                 st[-1] = (n.type, st[-1][1])
+            elif n.op == capi.EX_CASE:
+                st.pop()
+                t = st.pop()
+                e = st.pop()
+                st.append((n.type, t[1] or e[1]))
             else:
                 b = st.pop()
                 a = st.pop()
@@ -155,7 +175,7 @@ class Expr:
             raise ValueError("expression too long")
         e.n_nodes = len(self.nodes)
         for i, n in enumerate(self.nodes):
-            e.nodes[i] = capi.ExprNode(n.op, n.type, n.arg, 0, int(n.ilit), float(n.flit))
+            e.nodes[i] = capi.ExprNode(n.op, n.type, n.arg, int(n.null_lit), int(n.ilit), float(n.flit))
         e.range = self.range.to_c()
         return e
 

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 4
+#define MI355Q_ABI_VERSION 5
 
 #define MI355Q_MAX_COLS 16
 #define MI355Q_MAX_QUALS 4
@@ -52,7 +52,7 @@ extern "C" {
 #define MI355Q_MAX_SLOTS 16
 #define MI355Q_MAX_GROUP_COLS 4
 #define MI355Q_MAX_EXPRS 4
-#define MI355Q_MAX_EXPR_NODES 8
+#define MI355Q_MAX_EXPR_NODES 12
 
 /* ---- error codes: numeric values of heavyai::ErrorCode (enums.h:30-51) ---- */
 #define MI355Q_OK 0
@@ -229,7 +229,8 @@ typedef struct mi355q_join_table mi355q_join_table; /* opaque */
 typedef enum mi355q_expr_op {
   MI355Q_EX_COL = 1,   /* push outer column `arg` (decoded): type = the column's logical type,
                           nullable = the column's */
-  MI355Q_EX_LIT = 2,   /* push a literal of `type`: ilit (integers) / flit (DOUBLE, FLOAT); never NULL */
+  MI355Q_EX_LIT = 2,   /* push a literal of `type`: ilit (integers) / flit (DOUBLE, FLOAT); `reserved` = 1: the NULL of
+                          `type` instead (a nullable value) */
   MI355Q_EX_CAST = 3,  /* cast the top of the stack to `type`.  integer -> wider integer: NULL to NULL
                           (cast_<from>_to_<to>_nullable, RuntimeFunctions.cpp:262-300); -> narrower
                           integer: error 7 when v > max(to) or v <= min(to)
@@ -247,15 +248,33 @@ typedef enum mi355q_expr_op {
                           div_<type>_nullable[_lhs|_rhs] (RuntimeFunctions.cpp:46-71); otherwise a divisor equal to
                           zero (floating point: not "ordered and != 0", so NaN too) ends the step with
                           MI355Q_ERR_DIV_BY_ZERO (ErrorCode 1) for a row that counts, like an overflow */
-  MI355Q_EX_MOD = 8    /* lhs % rhs, integers only (codegenMod, :731-760): the divisor is tested against zero FIRST, whatever
+  MI355Q_EX_MOD = 8,   /* lhs % rhs, integers only (codegenMod, :731-760): the divisor is tested against zero FIRST, whatever
                           the operands' NULLs (error 1); then mod_<type>_nullable[_lhs|_rhs] */
+  /* COMPARISONS of two values (column vs column, column vs expression ...): pop rhs, pop lhs — both of ONE type, integer or
+   * floating point, as the analyzer has normalised them — push a BOOLEAN, stored as MI355Q_INT8: 1 / 0, or NULL (the INT8
+   * sentinel) when a NULLABLE operand is NULL (codegenCmp, CompareIR.cpp:230-330: plain icmp / fcmp for NOT NULL operands, else
+   * <op>_<type>_nullable[_lhs|_rhs], RuntimeFunctions.cpp:73-107).  The node's `type` must be MI355Q_INT8.  A filter on a
+   * comparison is a qual `expression column = 1` (TRUE; NULL is not TRUE, toBool LogicalIR.cpp:344-352) — or `IS NULL`. */
+  MI355Q_EX_EQ = 9,
+  MI355Q_EX_NE = 10,
+  MI355Q_EX_LT = 11,
+  MI355Q_EX_LE = 12,
+  MI355Q_EX_GT = 13,
+  MI355Q_EX_GE = 14,
+  /* CASE WHEN cond THEN a ELSE b END (CodeGenerator::codegenCase, CaseIR.cpp:67-140): pop cond (a BOOLEAN as above), pop the
+   * THEN value, pop the ELSE value — pushed in the order ELSE, THEN, cond, so that a chain of WHENs nests in the ELSE position
+   * without growing the stack — push THEN if cond is TRUE, else ELSE (a NULL condition is not TRUE).  Both values have the
+   * node's `type`; the result is nullable if either is.  The branches are LAZY, as the reference's basic blocks are: an
+   * overflow or a division by zero in the branch that is not taken does not end the step (`CASE WHEN b <> 0 THEN a / b ELSE 0
+   * END` never raises error 1).  A CASE without ELSE has the NULL literal there (MI355Q_EX_LIT with `reserved` = 1). */
+  MI355Q_EX_CASE = 15
 } mi355q_expr_op;
 
 typedef struct mi355q_expr_node {
   int32_t op;   /* mi355q_expr_op */
   int32_t type; /* mi355q_type of the node's result (ignored for MI355Q_EX_COL) */
   int32_t arg;  /* MI355Q_EX_COL: outer column index (a physical column, < n_cols) */
-  int32_t reserved;
+  int32_t reserved; /* MI355Q_EX_LIT: 1 = the NULL literal; else 0 */
   int64_t ilit;
   double flit;
 } mi355q_expr_node;

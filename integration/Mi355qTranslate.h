@@ -13,6 +13,7 @@
 #pragma once
 
 #include <functional>
+#include <vector>
 #include <stdexcept>
 #include <string>
 
@@ -113,20 +114,20 @@ inline int64_t int_literal(const SQLTypeInfo& ti, const Datum& d) {
 // `outer_col` resolves a ColumnVar of the outer table to its position among the input columns.
 inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
                       const std::function<int(const Analyzer::ColumnVar*)>& outer_col) {
-  auto push = [&](int32_t op, int32_t type, int32_t arg, int64_t ilit, double flit) {
+  auto push = [&](int32_t op, int32_t type, int32_t arg, int64_t ilit, double flit, int32_t null_lit = 0) {
     if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) unsupported("expression too long");
-    x.nodes[x.n_nodes++] = mi355q_expr_node{op, type, arg, 0, ilit, flit};
+    x.nodes[x.n_nodes++] = mi355q_expr_node{op, type, arg, null_lit, ilit, flit};
   };
   if (auto cv = dynamic_cast<const Analyzer::ColumnVar*>(e)) {
     if (cv->get_rte_idx() != 0) unsupported("expression over an inner column");
     check_supported_type(cv->get_type_info());
     push(MI355Q_EX_COL, 0, outer_col(cv), 0, 0.0);
   } else if (auto c = dynamic_cast<const Analyzer::Constant*>(e)) {
-    if (c->get_is_null()) unsupported("NULL literal");
     const auto& ti = c->get_type_info();
     const Datum d = c->get_constval();
     const int32_t t = logical_type(ti);
-    if (t == MI355Q_DOUBLE) push(MI355Q_EX_LIT, t, 0, 0, d.doubleval);
+    if (c->get_is_null()) push(MI355Q_EX_LIT, t, 0, 0, 0.0, 1);  // the NULL constant (a CASE without ELSE)
+    else if (t == MI355Q_DOUBLE) push(MI355Q_EX_LIT, t, 0, 0, d.doubleval);
     else if (t == MI355Q_FLOAT) push(MI355Q_EX_LIT, t, 0, 0, d.floatval);
     else push(MI355Q_EX_LIT, t, 0, int_literal(ti, d), 0.0);
   } else if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
@@ -137,10 +138,34 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
     const int32_t op = b->get_optype() == kPLUS ? MI355Q_EX_ADD : b->get_optype() == kMINUS ? MI355Q_EX_SUB
                        : b->get_optype() == kMULTIPLY ? MI355Q_EX_MUL : b->get_optype() == kDIVIDE ? MI355Q_EX_DIV
                        : b->get_optype() == kMODULO ? MI355Q_EX_MOD : 0;
-    if (!op) unsupported("binary operator");
+    // a comparison of two VALUES (column vs column, column vs expression; CompareIR.cpp:230-330): a BOOLEAN, INT8 1 / 0 / NULL
+    const int32_t cmp = b->get_optype() == kEQ ? MI355Q_EX_EQ : b->get_optype() == kNE ? MI355Q_EX_NE
+                        : b->get_optype() == kLT ? MI355Q_EX_LT : b->get_optype() == kLE ? MI355Q_EX_LE
+                        : b->get_optype() == kGT ? MI355Q_EX_GT : b->get_optype() == kGE ? MI355Q_EX_GE : 0;
+    if (!op && !cmp) unsupported("binary operator");
+    if (cmp && logical_type(b->get_left_operand()->get_type_info()) != logical_type(b->get_right_operand()->get_type_info()))
+      unsupported("comparison of two types");  // (the analyzer casts both sides to one type: CompareIR.cpp asserts it)
     emit_expr(b->get_left_operand(), x, outer_col);
     emit_expr(b->get_right_operand(), x, outer_col);
-    push(op, logical_type(b->get_type_info()), 0, 0, 0.0);
+    push(op ? op : cmp, op ? logical_type(b->get_type_info()) : MI355Q_INT8, 0, 0, 0.0);
+  } else if (auto ce = dynamic_cast<const Analyzer::CaseExpr*>(e)) {
+    // CASE WHEN c0 THEN t0 WHEN c1 THEN t1 ... ELSE e END (CaseIR.cpp:67-140) = CASE(c0, t0, CASE(c1, t1, ... e)): the plan's
+    // operand order is ELSE, THEN, condition, so the later WHENs are emitted first and the stack stays at <= 4 values
+    const int32_t t = logical_type(ce->get_type_info());
+    std::vector<std::pair<const Analyzer::Expr*, const Analyzer::Expr*>> whens;
+    for (const auto& pr : ce->get_expr_pair_list()) whens.emplace_back(pr.first.get(), pr.second.get());
+    if (whens.empty() || !ce->get_else_expr()) unsupported("CASE shape");
+    std::function<void(size_t)> emit_from = [&](size_t i) {
+      if (i == whens.size()) {
+        emit_expr(ce->get_else_expr(), x, outer_col);
+        return;
+      }
+      emit_from(i + 1);
+      emit_expr(whens[i].second, x, outer_col);
+      emit_expr(whens[i].first, x, outer_col);
+      push(MI355Q_EX_CASE, t, 0, 0, 0.0);
+    };
+    emit_from(0);
   } else {
     unsupported("expression kind");
   }
@@ -168,10 +193,18 @@ inline mi355q_qual translate_qual(const Analyzer::Expr* e, const std::function<i
   }
   auto b = dynamic_cast<const Analyzer::BinOper*>(e);
   auto lit = b ? dynamic_cast<const Analyzer::Constant*>(b->get_right_operand()) : nullptr;
-  if (!b || !lit || lit->get_is_null()) unsupported("qual shape");
+  if (!b) unsupported("qual shape");
   switch (b->get_optype()) {  // SQLOps values are the ABI's (mi355q_op)
     case kEQ: case kNE: case kLT: case kGT: case kLE: case kGE: q.op = (int32_t)b->get_optype(); break;
     default: unsupported("comparison operator");
+  }
+  if (!lit || lit->get_is_null()) {
+    // <value> <cmp> <value> (column vs column ...): the comparison itself is a projected BOOLEAN expression and the qual is
+    // `that column = 1` — TRUE; a NULL comparison is not (toBool, LogicalIR.cpp:344-352)
+    q.col = value_col(e);
+    q.op = MI355Q_EQ;
+    q.ival = 1;
+    return q;
   }
   q.col = value_col(b->get_left_operand());
   const auto& ti = lit->get_type_info();

@@ -149,6 +149,21 @@ class BinOper : public Expr {
   SQLOps op_;
   std::shared_ptr<Expr> left_, right_;
 };
+class CaseExpr : public Expr {  // Analyzer.h:1447
+ public:
+  CaseExpr(const SQLTypeInfo& ti, bool /*has_agg*/,
+           const std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>>& w,
+           std::shared_ptr<Analyzer::Expr> e)
+      : Expr(ti), expr_pair_list(w), else_expr(std::move(e)) {}
+  const std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>>& get_expr_pair_list() const {
+    return expr_pair_list;
+  }
+  const Expr* get_else_expr() const { return else_expr.get(); }
+
+ private:
+  std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>> expr_pair_list;
+  std::shared_ptr<Analyzer::Expr> else_expr;
+};
 class AggExpr : public Expr {
  public:
   AggExpr(const SQLTypeInfo& ti, SQLAgg a, std::shared_ptr<Expr> arg, bool distinct = false,

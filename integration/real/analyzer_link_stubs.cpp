@@ -29,7 +29,7 @@ std::string ColumnVar::toString() const REF_STUB
 bool ColumnVar::operator==(const Expr&) const REF_STUB
 
 Constant::~Constant() {}
-void Constant::set_null_value() REF_STUB
+void Constant::set_null_value() {}  // (called by the constructor of a NULL constant; the binding never reads its value)
 std::shared_ptr<Expr> Constant::deep_copy() const REF_STUB
 std::shared_ptr<Expr> Constant::add_cast(const SQLTypeInfo&) REF_STUB
 bool Constant::operator==(const Expr&) const REF_STUB
@@ -50,6 +50,20 @@ void BinOper::group_predicates(std::list<const Expr*>&, std::list<const Expr*>&,
 bool BinOper::operator==(const Expr&) const REF_STUB
 std::string BinOper::toString() const REF_STUB
 void BinOper::find_expr(std::function<bool(const Expr*)>, std::list<const Expr*>&) const REF_STUB
+
+std::shared_ptr<Expr> CaseExpr::deep_copy() const REF_STUB
+void CaseExpr::check_group_by(const std::list<std::shared_ptr<Expr>>&) const REF_STUB
+void CaseExpr::group_predicates(std::list<const Expr*>&, std::list<const Expr*>&, std::list<const Expr*>&) const REF_STUB
+void CaseExpr::collect_rte_idx(std::set<int>&) const REF_STUB
+void CaseExpr::collect_column_var(std::set<const ColumnVar*, bool (*)(const ColumnVar*, const ColumnVar*)>&, bool) const REF_STUB
+std::shared_ptr<Expr> CaseExpr::rewrite_with_targetlist(const std::vector<std::shared_ptr<TargetEntry>>&) const REF_STUB
+std::shared_ptr<Expr> CaseExpr::rewrite_with_child_targetlist(const std::vector<std::shared_ptr<TargetEntry>>&) const REF_STUB
+std::shared_ptr<Expr> CaseExpr::rewrite_agg_to_var(const std::vector<std::shared_ptr<TargetEntry>>&) const REF_STUB
+bool CaseExpr::operator==(const Expr&) const REF_STUB
+std::string CaseExpr::toString() const REF_STUB
+void CaseExpr::find_expr(std::function<bool(const Expr*)>, std::list<const Expr*>&) const REF_STUB
+std::shared_ptr<Expr> CaseExpr::add_cast(const SQLTypeInfo&) REF_STUB
+void CaseExpr::get_domain(DomainSet&) const REF_STUB
 
 std::shared_ptr<Expr> AggExpr::deep_copy() const REF_STUB
 void AggExpr::group_predicates(std::list<const Expr*>&, std::list<const Expr*>&, std::list<const Expr*>&) const REF_STUB

@@ -143,8 +143,32 @@ int main() {
     auto and_in_or = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, true), false, kOR, kONE, both, lt);
     nq = ng = 0;
     REQ(refuses([&] { translate_conjunct(and_in_or.get(), value_col, qs, &nq, &ng); }));
-    auto ge_cols = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kGE, kONE, x, y);
-    REQ(refuses([&] { translate_qual(ge_cols.get(), value_col); }));  // column-vs-column compare: not in the plan ABI
+    // column-vs-column compare: the comparison is a projected BOOLEAN expression, the qual `that column = 1`
+    auto ge_cols = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kGE, kONE, xb, y);
+    q = translate_qual(ge_cols.get(), value_col);
+    REQ(q.op == MI355Q_EQ && q.ival == 1 && q.col == 100);      // (this check's value_col: 100 = "an expression column")
+    mi355q_expr ec{};
+    emit_expr(ge_cols.get(), ec, outer_col);
+    REQ(ec.n_nodes == 4 && ec.nodes[1].op == MI355Q_EX_CAST && ec.nodes[3].op == MI355Q_EX_GE && ec.nodes[3].type == MI355Q_INT8);
+    auto mixed = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kGE, kONE, x, y);   // INT vs BIGINT without the analyzer's cast
+    mi355q_expr em{};
+    REQ(refuses([&] { emit_expr(mixed.get(), em, outer_col); }));
+    // CASE WHEN y <> 3 THEN y WHEN x_as_bigint >= y THEN y ELSE NULL END
+    {
+      using Analyzer::CaseExpr;
+      auto ne3 = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, true), false, kNE, kONE, y, l3);
+      Datum nul;
+      nul.bigintval = 0;
+      auto null_big = std::make_shared<Constant>(t_big, true, nul);
+      std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>> whens{{ne3, y}, {ge_cols, y}};
+      CaseExpr ce(t_big, false, whens, null_big);
+      mi355q_expr ex{};
+      emit_expr(&ce, ex, outer_col);
+      // ELSE NULL | THEN y | cond (x::bigint >= y) | CASE | THEN y | cond y <> 3 | CASE
+      REQ(ex.n_nodes == 12 && ex.nodes[0].op == MI355Q_EX_LIT && ex.nodes[0].reserved == 1 && ex.nodes[0].type == MI355Q_INT64);
+      REQ(ex.nodes[ex.n_nodes - 1].op == MI355Q_EX_CASE && ex.nodes[ex.n_nodes - 1].type == MI355Q_INT64);
+      REQ(ex.nodes[6].op == MI355Q_EX_CASE && ex.nodes[5].op == MI355Q_EX_GE && ex.nodes[ex.n_nodes - 2].op == MI355Q_EX_NE);
+    }
     // ---- aggregates: SUM(y), COUNT(*), SUM(dim.w), COUNT_IF(x < 1), SUM_IF(y, x < 1), COUNT(DISTINCT x)
     AggExpr sum_y(t_big, kSUM, y, false, nullptr);
     mi355q_target tg = translate_agg(&sum_y, value_col, inner_col);

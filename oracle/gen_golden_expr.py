@@ -16,6 +16,9 @@ on the CPU and through the projection kernel on the device) to it.
            (ArithmeticIR.cpp:187-429).  Integer operand pairs are chosen so that the exact result fits the
            type: the overflow check itself is an LLVM intrinsic (s{add,sub,mul}.with.overflow,
            ArithmeticIR.cpp:840-909), not a runtime function, and is tested against exact integer arithmetic.
+  "cmp"    {eq,ne,lt,le,gt,ge}_<type>_nullable[_lhs|_rhs](lhs, rhs, null, null_bool)  RuntimeFunctions.cpp:73-107,132-149
+           for int8_t .. int64_t, float, double (NaN operands included) — what codegenCmp emits for two values with a
+           nullable operand (CompareIR.cpp:230-330); `out` is the int8 result: 1 / 0 / -128
 Values travel as 64-bit patterns: integers sign-extended, double bits, float bits in the low word.
 """
 from __future__ import annotations
@@ -76,7 +79,7 @@ def main():
     ref = C.CDLL(orc.REF_LIB)
     rng = np.random.default_rng(2027)
     out = {"source": "QueryEngine/RuntimeFunctions.cpp of the reference, compiled unmodified (oracle/ref_shim.cpp)",
-           "cast": [], "arith": []}
+           "cast": [], "arith": [], "cmp": []}
     # ---- casts
     pairs = [(a, b) for a in INTS for b in INTS if a != b]
     pairs += [(a, b) for a in INTS for b in (capi.FLOAT, capi.DOUBLE)]
@@ -128,11 +131,25 @@ def main():
                         r = fn(a, b, null_of(t))
                         out["arith"].append({"op": op, "type": t, "suffix": suffix, "a": bits(t, a), "b": bits(t, b),
                                              "out": bits(t, r)})
+    # ---- comparisons of two values
+    cmps = {"eq": capi.EX_EQ, "ne": capi.EX_NE, "lt": capi.EX_LT, "le": capi.EX_LE, "gt": capi.EX_GT, "ge": capi.EX_GE}
+    for t in INTS + [capi.FLOAT, capi.DOUBLE]:
+        vals = int_samples(t, rng) if t in INTS else fp_samples(t, rng) + [float("nan"), float("inf"), -float("inf")]
+        pick = vals[::3] + [null_of(t)]
+        for name, op in cmps.items():
+            for suffix in ("_nullable", "_nullable_lhs", "_nullable_rhs"):
+                fn = getattr(ref, f"{name}_{TNAME[t]}{suffix}")
+                fn.restype = C.c_int8
+                fn.argtypes = [CT[t], CT[t], C.c_int64 if t in INTS else CT[t], C.c_int8]
+                for a in pick:
+                    for b in pick:
+                        r = fn(a, b, null_of(t), -128)
+                        out["cmp"].append({"op": op, "type": t, "suffix": suffix, "a": bits(t, a), "b": bits(t, b), "out": int(r)})
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
                         "ref_expr_vectors.json")
     with open(path, "w") as fjs:
         json.dump(out, fjs, separators=(",", ":"))
-    print(f"wrote {path}: {len(out['cast'])} cast + {len(out['arith'])} arithmetic vectors")
+    print(f"wrote {path}: {len(out['cast'])} cast + {len(out['arith'])} arithmetic + {len(out['cmp'])} comparison vectors")
 
 
 if __name__ == "__main__":

@@ -1278,13 +1278,59 @@ inline int32_t arith_value(int op, int t, const OrcVal& a, const OrcVal& b, OrcV
   return 0;
 }
 
-// one expression on one row; `p` is the plan as the caller stated it (physical columns only)
-inline int32_t eval_expression(const mi355q_plan& p, const mi355q_expr& x, const int8_t* const* cols, int64_t pos,
-                               OrcVal* out) {
-  OrcVal st[MI355Q_MAX_EXPR_NODES];
-  int sp = 0;
-  for (int i = 0; i < x.n_nodes; ++i) {
-    const mi355q_expr_node& n = x.nodes[i];
+// codegenCmp for one pair of values of one type (CompareIR.cpp:230-330): icmp / fcmp when neither operand can be NULL, else
+// <op>_<type>_nullable[_lhs|_rhs] (RuntimeFunctions.cpp:73-107) with the BOOLEAN NULL (the int8 sentinel) as null_bool_val
+inline OrcVal cmp_value(int op, const OrcVal& a, const OrcVal& b) {
+  OrcVal r{MI355Q_INT8, a.nullable || b.nullable, 0, 0.0, 0.0f};
+  if (val_is_null(a) || val_is_null(b)) {
+    r.i = int_null_of(MI355Q_INT8);
+    return r;
+  }
+  auto pick = [&](auto x, auto y) -> bool {
+    switch (op) {
+      case MI355Q_EX_EQ: return x == y;
+      case MI355Q_EX_NE: return x != y;
+      case MI355Q_EX_LT: return x < y;
+      case MI355Q_EX_LE: return x <= y;
+      case MI355Q_EX_GT: return x > y;
+      default: return x >= y;
+    }
+  };
+  r.i = is_int_type(a.type) ? pick(a.i, b.i) : a.type == MI355Q_DOUBLE ? pick(a.d, b.d) : pick(a.f, b.f);
+  return r;
+}
+
+// one expression on one row; `p` is the plan as the caller stated it (physical columns only).  The postfix program is
+// evaluated from its ROOT the way the generated code runs: the operands of an operation left to right, a CASE's condition
+// and then ONLY the branch it selects (codegenCase, CaseIR.cpp:67-140: each branch is a basic block of its own, so a check
+// in the other branch is never executed).  Operand order of MI355Q_EX_CASE on the stack: ELSE, THEN, condition.
+struct ExprWalk {
+  const mi355q_plan& p;
+  const mi355q_expr& x;
+  const int8_t* const* cols;
+  int64_t pos;
+  // the node where the subtree that ENDS at node `end` starts
+  int start_of(int end) const {
+    int need = 1, i = end;
+    for (;; --i) {
+      const int op = x.nodes[i].op;
+      const int arity = op == MI355Q_EX_COL || op == MI355Q_EX_LIT ? 0 : op == MI355Q_EX_CAST ? 1 : op == MI355Q_EX_CASE ? 3 : 2;
+      need += arity - 1;
+      if (need == 0) return i;
+    }
+  }
+  // get_notnull() == false of the subtree's type
+  bool may_be_null(int end) const {
+    const mi355q_expr_node& n = x.nodes[end];
+    if (n.op == MI355Q_EX_COL) return p.cols[n.arg].nullable != 0;
+    if (n.op == MI355Q_EX_LIT) return n.reserved == 1;
+    if (n.op == MI355Q_EX_CAST) return may_be_null(end - 1);
+    const int last = end - 1, mid = start_of(last) - 1;
+    if (n.op == MI355Q_EX_CASE) return may_be_null(mid) || may_be_null(start_of(mid) - 1);
+    return may_be_null(last) || may_be_null(mid);
+  }
+  int32_t eval(int end, OrcVal* out) const {
+    const mi355q_expr_node& n = x.nodes[end];
     switch (n.op) {
       case MI355Q_EX_COL: {
         const mi355q_col_desc& cd = p.cols[n.arg];
@@ -1292,28 +1338,55 @@ inline int32_t eval_expression(const mi355q_plan& p, const mi355q_expr& x, const
         if (type_is_f32(cd.type)) v.f = decode_flt(cols[n.arg], pos);
         else if (type_is_fp(cd.type)) v.d = decode_dbl(cols[n.arg], pos);
         else v.i = decode_col(cd, cols[n.arg], pos);
-        st[sp++] = v;
-        break;
+        *out = v;
+        return 0;
       }
       case MI355Q_EX_LIT: {
+        if (n.reserved == 1) {  // the NULL constant (a CASE without ELSE)
+          *out = null_of(n.type);
+          return 0;
+        }
         OrcVal v{n.type, false, 0, 0.0, 0.0f};
         if (n.type == MI355Q_DOUBLE) v.d = n.flit;
         else if (n.type == MI355Q_FLOAT) v.f = (float)n.flit;
         else v.i = n.ilit;
-        st[sp++] = v;
-        break;
+        *out = v;
+        return 0;
       }
-      case MI355Q_EX_CAST:
-        if (int32_t e = cast_value(st[sp - 1], n.type, &st[sp - 1])) return e;
-        break;
+      case MI355Q_EX_CAST: {
+        OrcVal v;
+        if (int32_t e = eval(end - 1, &v)) return e;
+        return cast_value(v, n.type, out);
+      }
+      case MI355Q_EX_CASE: {
+        const int cond_end = end - 1, then_end = start_of(cond_end) - 1, else_end = start_of(then_end) - 1;
+        OrcVal c;
+        if (int32_t e = eval(cond_end, &c)) return e;
+        const bool take = !val_is_null(c) && c.i != 0;  // toBool
+        OrcVal v;
+        if (int32_t e = eval(take ? then_end : else_end, &v)) return e;
+        v.nullable = may_be_null(then_end) || may_be_null(else_end);  // the CASE's type: nullable as soon as one branch is
+        v.type = n.type;
+        *out = v;
+        return 0;
+      }
       default: {
-        const OrcVal b = st[--sp];
-        if (int32_t e = arith_value(n.op, n.type, st[sp - 1], b, &st[sp - 1])) return e;
+        const int rhs_end = end - 1, lhs_end = start_of(rhs_end) - 1;
+        OrcVal a, b;
+        if (int32_t e = eval(lhs_end, &a)) return e;
+        if (int32_t e = eval(rhs_end, &b)) return e;
+        if (n.op >= MI355Q_EX_EQ && n.op <= MI355Q_EX_GE) {
+          *out = cmp_value(n.op, a, b);
+          return 0;
+        }
+        return arith_value(n.op, n.type, a, b, out);
       }
     }
   }
-  *out = st[0];
-  return 0;
+};
+inline int32_t eval_expression(const mi355q_plan& p, const mi355q_expr& x, const int8_t* const* cols, int64_t pos,
+                               OrcVal* out) {
+  return ExprWalk{p, x, cols, pos}.eval(x.n_nodes - 1, out);
 }
 
 // The plan with every expression described as the column n_cols + k (type / nullability from the rules
@@ -1337,7 +1410,7 @@ inline int lower_plan(const mi355q_plan& p, mi355q_plan* out) {
         ++sp;
       } else if (n.op == MI355Q_EX_LIT) {
         ty[sp] = n.type;
-        nu[sp] = false;
+        nu[sp] = n.reserved == 1;  // the NULL constant
         ++sp;
       } else if (n.op == MI355Q_EX_CAST) {
         if (sp < 1) return MI355Q_ERR_INVALID_PLAN;
@@ -1348,6 +1421,15 @@ inline int lower_plan(const mi355q_plan& p, mi355q_plan* out) {
         if (n.op == MI355Q_EX_MOD && !is_int_type(n.type)) return MI355Q_ERR_INVALID_PLAN;
         nu[sp - 2] = nu[sp - 2] || nu[sp - 1];
         --sp;
+      } else if (n.op >= MI355Q_EX_EQ && n.op <= MI355Q_EX_GE) {
+        if (sp < 2 || ty[sp - 1] != ty[sp - 2] || n.type != MI355Q_INT8) return MI355Q_ERR_INVALID_PLAN;
+        nu[sp - 2] = nu[sp - 2] || nu[sp - 1];
+        ty[sp - 2] = MI355Q_INT8;
+        --sp;
+      } else if (n.op == MI355Q_EX_CASE) {  // ELSE, THEN, condition
+        if (sp < 3 || ty[sp - 1] != MI355Q_INT8 || ty[sp - 2] != n.type || ty[sp - 3] != n.type) return MI355Q_ERR_INVALID_PLAN;
+        nu[sp - 3] = nu[sp - 3] || nu[sp - 2];
+        sp -= 2;
       } else {
         return MI355Q_ERR_UNSUPPORTED;
       }

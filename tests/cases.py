@@ -72,10 +72,10 @@ def expr_values(e: Expr, descs, cols):
                 null = (a == NULLS[d.type]) if d.nullable else np.zeros(len(a), bool)
                 st.append((a.astype(object), null, d.type))
         elif nd.op == capi.EX_LIT:
-            n = len(st[0][0]) if st else 1
+            n = len(np.asarray(cols[0])) if len(cols) else (len(st[0][0]) if st else 1)
             v = nd.flit if nd.type in (DOUBLE, capi.FLOAT) else nd.ilit
             arr = np.full(n, v, dtype=np.float64 if nd.type == DOUBLE else np.float32 if nd.type == capi.FLOAT else object)
-            st.append((arr, np.zeros(n, bool), nd.type))
+            st.append((arr, np.full(n, bool(nd.null_lit)), nd.type))
         elif nd.op == capi.EX_CAST:
             v, null, t = st.pop()
             if nd.type in (DOUBLE, capi.FLOAT):
@@ -85,6 +85,15 @@ def expr_values(e: Expr, descs, cols):
             else:
                 r = v
             st.append((r, null, nd.type))
+        elif nd.op == capi.EX_CASE:   # stack: ELSE, THEN, condition
+            (c, cn, _), (t, tn, _), (e, en, _) = st.pop(), st.pop(), st.pop()
+            take = (~cn) & np.array([bool(x) for x in c])
+            st.append((np.where(take, t, e), np.where(take, tn, en), nd.type))
+        elif capi.EX_EQ <= nd.op <= capi.EX_GE:
+            (b, bn, _), (a, an, _) = st.pop(), st.pop()
+            f = {capi.EX_EQ: lambda x, y: x == y, capi.EX_NE: lambda x, y: x != y, capi.EX_LT: lambda x, y: x < y,
+                 capi.EX_LE: lambda x, y: x <= y, capi.EX_GT: lambda x, y: x > y, capi.EX_GE: lambda x, y: x >= y}[nd.op]
+            st.append((np.array([int(f(x, y)) for x, y in zip(a, b)], dtype=object), an | bn, capi.INT8))
         else:
             (b, bn, _), (a, an, _) = st.pop(), st.pop()
             if nd.op in (capi.EX_DIV, capi.EX_MOD):
@@ -701,6 +710,31 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("expr_double_division_by_a_positive_column",
                       xra([C(3).div(C(9).add(Expr.lit(DOUBLE, 1e9), DOUBLE), DOUBLE)],
                           [TargetExpr(SUM, NC), TargetExpr(COUNT, NC)]), frags))
+    # comparisons of two values and CASE (CompareIR.cpp:230-330, CaseIR.cpp:67-140): a column-vs-column filter is a qual on the
+    # BOOLEAN expression; the guard of a division keeps error 1 away; CASE as a group key and as an argument
+    cases.append(Case("expr_filter_column_less_than_column",          # WHERE c7 < c2 (NULL c7: not TRUE)
+                      xra([C(7).cast(INT64).cmp(capi.EX_LT, C(2))], [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 7)],
+                          [Qual(NC, EQ, 1)], group=[1]), frags))
+    cases.append(Case("expr_filter_not_equal_columns_nongrouped",     # WHERE c6 <> c5 (INT16 vs INT8 through casts)
+                      xra([C(6).cast(INT32).cmp(capi.EX_NE, C(5).cast(INT32))], [TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(COUNT, 6)],
+                          [Qual(NC, EQ, 1), Qual(1, LT, 60)]), frags))
+    cases.append(Case("expr_case_guards_a_division",                  # SUM(CASE WHEN c5 <> 0 THEN c2 / c5 ELSE 0 END): never error 1
+                      xra([Expr.case(C(5).cast(INT64).cmp(capi.EX_NE, Expr.lit(INT64, 0)), C(2).div(C(5).cast(INT64), INT64),
+                                     Expr.lit(INT64, 0), INT64)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(SUM, NC), TargetExpr(MIN, NC), TargetExpr(COUNT, NC)], group=[1]), frags))
+    cases.append(Case("expr_case_as_group_key_and_null_else",         # GROUP BY CASE WHEN c10 < 20 THEN 0 ELSE 1 END; MAX(CASE WHEN c7 > 0 THEN c7 END)
+                      xra([Expr.case(C(10).cmp(capi.EX_LT, Expr.lit(INT32, 20)), Expr.lit(INT32, 0), Expr.lit(INT32, 1), INT32),
+                           Expr.case(C(7).cmp(capi.EX_GT, Expr.lit(INT32, 0)), C(7), Expr.null(INT32), INT32)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(MAX, NC + 1), TargetExpr(COUNT, NC + 1),
+                           TargetExpr(SUM, NC + 1)], group=[NC]), frags))
+    cases.append(Case("expr_case_two_whens_double",                   # CASE WHEN c9 < -100 THEN -1.0 WHEN c9 < 100 THEN c3 ELSE c9 END
+                      xra([Expr.case(C(9).cmp(capi.EX_LT, Expr.lit(DOUBLE, -100.0)), Expr.lit(DOUBLE, -1.0),
+                                     Expr.case(C(9).cmp(capi.EX_LT, Expr.lit(DOUBLE, 100.0)), C(3), C(9), DOUBLE), DOUBLE)],
+                          [TargetExpr(SUM, NC), TargetExpr(COUNT, NC), TargetExpr(MIN, NC)], [Qual(1, GE, 10)]), frags))
+    cases.append(Case("expr_unguarded_division_in_the_taken_branch_is_error_1",
+                      xra([Expr.case(C(5).cast(INT64).cmp(capi.EX_LT, Expr.lit(INT64, 50)), C(2).div(C(5).cast(INT64), INT64),
+                                     Expr.lit(INT64, 0), INT64)],
+                          [TargetExpr(SUM, NC), TargetExpr(COUNT)]), frags, expect_error=capi.ERR_DIV_BY_ZERO))
     jx = [Expr.col(1).add(Expr.lit(INT64, 2**63 - 10**6), INT64)]   # overflows for positive values of column 1
     jxr = [e.with_range(expr_range(e, fdescs, ffrags)) for e in jx]
     cases.append(Case("expr_join_overflow_only_in_filtered_rows",  # rows with col1 > 0 are dropped by the qual

@@ -227,3 +227,100 @@ def test_invalid_programs_are_refused(oracle):
                              inner_col_descs=[InputColDescriptor(capi.INT64, False)], join_outer_col=2)
     q = capi.QMD()
     assert el.emu_qmd_init(C.byref(ra.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN
+
+
+# ---- comparisons of two values and CASE (round 4) ---------------------------------------------------------------------------
+def test_comparisons_match_the_reference_runtime_functions(oracle):
+    """{eq,ne,lt,le,gt,ge}_<type>_nullable[_lhs|_rhs] of RuntimeFunctions.cpp:73-149, 7 128 vectors incl. NaN / inf operands
+    and NULL patterns under every nullability of the operands: 1 / 0 / the BOOLEAN NULL, bit for bit"""
+    vs = _vectors()["cmp"]
+    assert len(vs) > 7000
+    for v in vs:
+        t, sfx = v["type"], v["suffix"]
+        descs = [InputColDescriptor(t, sfx in ("_nullable", "_nullable_lhs")),
+                 InputColDescriptor(t, sfx in ("_nullable", "_nullable_rhs"))]
+        e = Expr.col(0).cmp(v["op"], Expr.col(1))
+        ob, eb, oc, ec = _eval_both(oracle, _plan(descs, e), [_col_of(t, v["a"]), _col_of(t, v["b"])])
+        assert oc == 0 and ec == 0, v
+        assert ob == v["out"], ("oracle", v, ob)
+        assert eb == v["out"], ("product", v, eb)
+
+
+def test_comparison_vectors_still_match_the_reference_live(oracle):
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built here")
+    ref = C.CDLL(oracle.REF_LIB)
+    ref.le_double_nullable_rhs.restype = C.c_int8
+    ref.le_double_nullable_rhs.argtypes = [C.c_double, C.c_double, C.c_double, C.c_int8]
+    n = 0
+    for v in _vectors()["cmp"]:
+        if v["type"] == capi.DOUBLE and v["op"] == capi.EX_LE and v["suffix"] == "_nullable_rhs":
+            a, b = (struct.unpack("<d", struct.pack("<q", v[k]))[0] for k in ("a", "b"))
+            assert ref.le_double_nullable_rhs(a, b, float(np.finfo(np.float64).tiny), -128) == v["out"]
+            n += 1
+    assert n > 20
+
+
+def _case_eval(oracle, descs, e, cols):
+    ob, eb, oc, ec = _eval_both(oracle, _plan(descs, e), cols)
+    assert oc == ec, (oc, ec)
+    if oc == 0:
+        assert ob == eb, (ob, eb)
+    return ob, oc
+
+
+def test_case_rules(oracle):
+    """codegenCase (CaseIR.cpp:67-140): THEN where the condition is TRUE, a NULL condition is not; the branches are lazy —
+    a check in the branch that is not taken does not fire; an error in the condition or in the TAKEN branch does."""
+    I64, NUL = capi.INT64, -2**63
+    d2 = [InputColDescriptor(I64, True), InputColDescriptor(I64, True)]
+    a, b = Expr.col(0), Expr.col(1)
+    # CASE WHEN b <> 0 THEN a / b ELSE -1 END: the guard of every safe division
+    guard = Expr.case(b.cmp(capi.EX_NE, Expr.lit(I64, 0)), a.div(b, I64), Expr.lit(I64, -1), I64)
+    col = lambda v: np.array([v], dtype=np.int64)
+    assert _case_eval(oracle, d2, guard, [col(84), col(2)]) == (42, 0)
+    assert _case_eval(oracle, d2, guard, [col(84), col(0)]) == (-1, 0)          # no DIV_BY_ZERO: the THEN branch does not run
+    assert _case_eval(oracle, d2, guard, [col(84), col(NUL)]) == (-1, 0)        # NULL <> 0 is NULL: not TRUE
+    assert _case_eval(oracle, d2, guard, [col(NUL), col(2)]) == (NUL, 0)        # NULL / 2
+    # the same division unguarded raises error 1
+    assert _case_eval(oracle, d2, a.div(b, I64), [col(84), col(0)])[1] == capi.ERR_DIV_BY_ZERO
+    # an error in the TAKEN branch counts; in the condition too
+    over = Expr.case(a.cmp(capi.EX_GT, b), a.mul(a, I64), b, I64)
+    assert _case_eval(oracle, d2, over, [col(2**62), col(5)])[1] == 7
+    assert _case_eval(oracle, d2, over, [col(3), col(2**62)]) == (2**62, 0)
+    cond_err = Expr.case(a.div(b, I64).cmp(capi.EX_EQ, Expr.lit(I64, 1)), a, b, I64)
+    assert _case_eval(oracle, d2, cond_err, [col(3), col(0)])[1] == capi.ERR_DIV_BY_ZERO
+    # no ELSE: the NULL constant; a chain of WHENs nests in the ELSE position
+    no_else = Expr.case(a.cmp(capi.EX_LT, b), a, Expr.null(I64), I64)
+    assert _case_eval(oracle, d2, no_else, [col(1), col(2)]) == (1, 0)
+    assert _case_eval(oracle, d2, no_else, [col(2), col(1)]) == (NUL, 0)
+    d1 = [InputColDescriptor(capi.INT32, True)]
+    x = Expr.col(0)
+    chain = Expr.case(x.cmp(capi.EX_LT, Expr.lit(capi.INT32, 10)), Expr.lit(capi.INT32, 1),
+                      Expr.case(x.cmp(capi.EX_LT, Expr.lit(capi.INT32, 100)), Expr.lit(capi.INT32, 2), Expr.lit(capi.INT32, 3), capi.INT32),
+                      capi.INT32)
+    c32 = lambda v: np.array([v], dtype=np.int32)
+    assert [_case_eval(oracle, d1, chain, [c32(v)])[0] for v in (5, 50, 500, -2**31)] == [1, 2, 3, 3]
+    # floating point: DOUBLE branches, FLOAT comparison
+    dd = [InputColDescriptor(capi.DOUBLE, True), InputColDescriptor(capi.DOUBLE, False)]
+    fmax = Expr.case(Expr.col(0).cmp(capi.EX_GE, Expr.col(1)), Expr.col(0), Expr.col(1), capi.DOUBLE)
+    pat = lambda v: struct.unpack("<q", struct.pack("<d", v))[0]
+    f64 = lambda v: np.array([v], dtype=np.float64)
+    assert _case_eval(oracle, dd, fmax, [f64(2.5), f64(1.5)]) == (pat(2.5), 0)
+    assert _case_eval(oracle, dd, fmax, [f64(float(np.finfo(np.float64).tiny)), f64(1.5)]) == (pat(1.5), 0)   # NULL >= x: not TRUE
+    assert _case_eval(oracle, dd, fmax, [f64(float("nan")), f64(1.5)]) == (pat(1.5), 0)
+
+
+def test_invalid_comparison_and_case_programs_are_refused(oracle):
+    d = [InputColDescriptor(capi.INT32, True), InputColDescriptor(capi.INT64, True)]
+    el = emu_lib()
+    el.emu_eval_expr.restype = C.c_int32
+    bad = [Expr.col(0).cmp(capi.EX_LT, Expr.col(1)),                                      # operands of two types
+           Expr([*Expr.col(0).nodes, *Expr.col(0).nodes, capi and __import__("heavydb_amd.executor", fromlist=["ExprNode"]).ExprNode(capi.EX_LT, capi.INT32)]),  # result type must be INT8
+           Expr.case(Expr.col(0), Expr.col(1), Expr.col(1), capi.INT64),                  # condition is not a BOOLEAN
+           Expr.case(Expr.col(0).cmp(capi.EX_LT, Expr.col(0)), Expr.col(0), Expr.col(1), capi.INT64)]   # branches of two types
+    for e in bad:
+        plan = _plan(d, e)
+        ptrs = (C.c_void_p * 2)(0, 0)
+        eb, et = C.c_int64(), C.c_int32()
+        assert el.emu_eval_expr(C.byref(plan), 0, ptrs, 0, C.byref(eb), C.byref(et)) == capi.ERR_INVALID_PLAN

@@ -1165,6 +1165,8 @@ def test_hip_expressions_match_reference_functions(torch_cuda):
         fams.setdefault(("cast", v["from"], v["to"], ""), []).append(v)
     for v in vec["arith"]:
         fams.setdefault(("arith", v["type"], v["op"], v["suffix"]), []).append(v)
+    for v in vec["cmp"]:   # {eq,ne,lt,le,gt,ge}_<type>_nullable[_lhs|_rhs]: the BOOLEAN as INT8 1 / 0 / NULL
+        fams.setdefault(("cmp", v["type"], v["op"], v["suffix"]), []).append(v)
     checked = 0
     for (kind, a, b, sfx), vs in fams.items():
         n = len(vs)
@@ -1177,7 +1179,7 @@ def test_hip_expressions_match_reference_functions(torch_cuda):
             cols = [np.concatenate([_col_of(a, v["a"]) for v in vs]), np.concatenate([_col_of(a, v["b"]) for v in vs])]
             descs = [InputColDescriptor(a, sfx in ("_nullable", "_nullable_lhs")),
                      InputColDescriptor(a, sfx in ("_nullable", "_nullable_rhs"))]
-            e, rt = Expr.col(1)._bin(b, Expr.col(2), a), a
+            e, rt = (Expr.col(1).cmp(b, Expr.col(2)), capi.INT8) if kind == "cmp" else (Expr.col(1)._bin(b, Expr.col(2), a), a)
         descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, n - 1))] + descs
         ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.MIN, len(descs))], [], [0],
                                  exprs=[e.with_range(ExpressionRange())])
@@ -1198,7 +1200,7 @@ def test_hip_expressions_match_reference_functions(torch_cuda):
             else:
                 assert got == want, (kind, a, b, sfx, v, got)
             checked += 1
-    assert checked == len(vec["cast"]) + len(vec["arith"])
+    assert checked == len(vec["cast"]) + len(vec["arith"]) + len(vec["cmp"])
 
 
 @pytest.mark.parametrize("targets", ["key_count_count_key", "count_only"])

@@ -57,7 +57,14 @@ def _expr_sql(e, descs):
             st.append((f"c{n.arg}", descs[n.arg].type in (capi.DOUBLE, capi.FLOAT)))
         elif n.op == capi.EX_LIT:
             fp = n.type in (capi.DOUBLE, capi.FLOAT)
-            st.append((repr(float(n.flit)) if fp else str(int(n.ilit)), fp))
+            st.append(("NULL" if n.null_lit else repr(float(n.flit)) if fp else str(int(n.ilit)), fp))
+        elif n.op == capi.EX_CASE:   # stack: ELSE, THEN, condition
+            (c, _), (t, fp), (e, _) = st.pop(), st.pop(), st.pop()
+            st.append((f"(CASE WHEN {c} THEN {t} ELSE {e} END)", fp))
+        elif capi.EX_EQ <= n.op <= capi.EX_GE:
+            (b, _), (a, _) = st.pop(), st.pop()
+            sym = {capi.EX_EQ: "=", capi.EX_NE: "<>", capi.EX_LT: "<", capi.EX_LE: "<=", capi.EX_GT: ">", capi.EX_GE: ">="}[n.op]
+            st.append((f"({a} {sym} {b})", False))
         elif n.op == capi.EX_CAST:
             x, fp = st.pop()
             to_fp = n.type in (capi.DOUBLE, capi.FLOAT)
