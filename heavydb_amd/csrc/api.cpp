@@ -147,6 +147,8 @@ struct DeviceCtx {
   int64_t wide_bytes = 0;
   void* proj = nullptr;     // dense temporary columns of projected expressions (one pass of fragments)
   int64_t proj_bytes = 0;
+  void* gather = nullptr;   // dense temporary columns of a grouped join's inner side (execute_join_gather; may nest inside proj's step)
+  int64_t gather_bytes = 0;
   void* scratch = nullptr;
   int64_t scratch_bytes = 0;
   void* meta = nullptr;
@@ -331,6 +333,9 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   if (ctx.proj) (void)hipFree(ctx.proj);
   ctx.proj = nullptr;
   ctx.proj_bytes = 0;
+  if (ctx.gather) (void)hipFree(ctx.gather);
+  ctx.gather = nullptr;
+  ctx.gather_bytes = 0;
   if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
   ctx.stream = nullptr;
   for (hipEvent_t e : ctx.events) (void)hipEventDestroy(e);
@@ -1550,6 +1555,203 @@ int32_t execute_multi_value(const mi355q_plan* plan, const mi355q_inputs* in, co
   return MI355Q_OK;
 }
 
+// Grouped steps over fact JOIN dim (SURVEY f2 + GROUP BY: `SELECT f.g, SUM(d.w), COUNT(*) FROM f JOIN d ON f.k = d.k GROUP BY
+// f.g`) with a ONE-TO-ONE join table over a large outer input.  In the row kernel every row probes the table AND updates its
+// group with device atomics; here the probe is its own pass (k_join_gather): per outer row, the inner columns the aggregates
+// read become dense temporary OUTER columns — the column's NULL where the row has no match — plus, for INNER joins, a 0 / 1
+// "matched" column the derived step filters on.  The derived plan has no join, the same targets over those columns and the
+// SAME layout (asserted: the descriptor of the derived plan must equal the stated one bit for bit), so its result is the
+// step's result and every grouped family applies (LDS members, the partitioned families).  One-to-many tables change the
+// row multiplicity and stay in the row kernel.  kNotTaken when the shape does not call for it.
+int32_t execute_join_gather(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o, const mi355q_qmd& q,
+                            const DevPlan& d, int n_cus, mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
+  if (plan->join_outer_col < 0 || plan->n_group_cols < 1 || plan->n_exprs != 0 || o.kernel_variant == 1 || o.force_generic ||
+      (d.join_hash_type != 0 && d.join_hash_type != 1) || q.desc_type == MI355Q_NON_GROUPED_AGGREGATE)
+    return kNotTaken;
+  const int nc = plan->n_cols, nf = in->n_frags;
+  const bool inner_join = plan->join_kind != MI355Q_JOIN_LEFT;
+  int64_t total_rows = 0, max_frag_rows = 0;
+  for (int f = 0; f < nf; ++f) {
+    if (in->num_rows[f] < 0) return kNotTaken;
+    total_rows += in->num_rows[f];
+    max_frag_rows = std::max(max_frag_rows, in->num_rows[f]);
+  }
+  // (kernel_variant 2 = "the large-input members": how the tests reach this route with small tables)
+  if (nf < 1 || (o.kernel_variant != 2 && total_rows < kIdxPartMinRows)) return kNotTaken;
+  // the inner columns the targets read, in order of first use
+  int32_t used[MI355Q_MAX_COLS], dst[MI355Q_MAX_COLS], width[MI355Q_MAX_COLS];
+  int64_t null_pat[MI355Q_MAX_COLS];
+  int n_used = 0;
+  mi355q_plan p2 = *plan;
+  for (int t = 0; t < plan->n_targets; ++t) {
+    const mi355q_target& tg = plan->targets[t];
+    if (tg.agg == MI355Q_PROJECT_KEY || tg.table == 0 || tg.col < 0) continue;
+    if (tg.col >= plan->n_inner_cols) return kNotTaken;
+    int j = 0;
+    while (j < n_used && used[j] != tg.col) ++j;
+    if (j == n_used) {
+      const mi355q_col_desc& cd = plan->inner_cols[tg.col];
+      if (cd.encoding != MI355Q_ENC_NONE || (cd.logical_type != 0 && cd.logical_type != cd.type)) return kNotTaken;
+      if (nc + n_used + 1 + (inner_join ? 1 : 0) > MI355Q_MAX_COLS) return kNotTaken;
+      used[n_used] = tg.col;
+      dst[n_used] = nc + n_used;
+      width[n_used] = plain_width(cd.type);
+      null_pat[n_used] = cd.type == MI355Q_DOUBLE ? kNullDoubleBits
+                         : cd.type == MI355Q_FLOAT ? (int64_t)(uint32_t)kNullFloatBits : plain_int_null(cd.type);
+      p2.cols[nc + n_used] = cd;
+      // (nullable under an outer join, resolve_targets' rule; the RANGE stays the column's own, as the layout decisions read it)
+      if (!inner_join) p2.cols[nc + n_used].nullable = 1;
+      p2.col_ranges[nc + n_used] = plan->inner_col_ranges[tg.col];
+      ++n_used;
+    }
+    p2.targets[t].table = 0;
+    p2.targets[t].col = nc + j;
+  }
+  int flag_col = -1;
+  if (inner_join) {
+    if (plan->n_quals >= MI355Q_MAX_QUALS) return kNotTaken;
+    flag_col = nc + n_used;
+    p2.cols[flag_col] = mi355q_col_desc{MI355Q_INT8, 0, MI355Q_ENC_NONE, 0};
+    p2.col_ranges[flag_col] = mi355q_range{1, 0, 0, 1, 0.0, 0.0, 0};
+    mi355q_qual& mq = p2.quals[p2.n_quals++];
+    mq = mi355q_qual{};
+    mq.col = flag_col;
+    mq.op = MI355Q_EQ;
+    mq.ival = 1;
+  }
+  const int nc2 = nc + n_used + (inner_join ? 1 : 0);
+  p2.n_cols = nc2;
+  p2.join_outer_col = -1;
+  p2.join_table = nullptr;
+  p2.n_join_cols = 0;
+  p2.join_kind = MI355Q_JOIN_INNER;
+  p2.n_inner_cols = 0;
+  mi355q_qmd q2;
+  if (qmd_init(p2, &q2) != MI355Q_OK || std::memcmp(&q, &q2, sizeof(q)) != 0) return kNotTaken;  // the same layout, or not this way
+  int64_t row_bytes = inner_join ? 1 : 0;
+  for (int j = 0; j < n_used; ++j) row_bytes += width[j];
+  mi355q_exec_options o2 = o;
+  if (reserved) {
+    route_note("k_join_gather (inner columns + matched flag as outer columns)");
+    // the derived step's shape: the same fragments with nc2 columns (the pointers are not looked at in reserve mode)
+    std::vector<const void*> fake((size_t)nf * nc2, nullptr);
+    mi355q_inputs in2 = *in;
+    in2.col_buffers = fake.data();
+    in2.inner_col_buffers = nullptr;
+    return execute_impl(&p2, &in2, &o2, out, report, nullptr, reserved);
+  }
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const int64_t budget = std::min<int64_t>((int64_t)16 << 30, ((int64_t)free_b + ctx.gather_bytes) / 3);
+  const int64_t pad = 16 * (int64_t)(nc2 - nc);  // every (fragment, column) chunk starts on a 16-byte boundary
+  int64_t pass_rows = std::max<int64_t>(budget / std::max<int64_t>(row_bytes, 1), max_frag_rows);
+  if (o.pass_rows > 0) pass_rows = std::max<int64_t>(o.pass_rows, max_frag_rows);  // tests: several passes
+  if (pass_rows > total_rows) pass_rows = total_rows;
+  const int64_t tab_bytes = ((int64_t)sizeof(void*) * nf * nc2 + 255) & ~255ll;
+  const int64_t rows_bytes = ((int64_t)sizeof(int64_t) * nf + 255) & ~255ll;
+  const int64_t col_region = ((pass_rows * row_bytes + pad * nf) + 255) & ~255ll;
+  const int64_t need = col_region + tab_bytes + rows_bytes + 256;
+  if (ctx.gather_bytes < need) {
+    if (ctx.gather) (void)hipFree(ctx.gather);
+    ctx.gather = nullptr;
+    ctx.gather_bytes = 0;
+    if (hipMalloc(&ctx.gather, (size_t)need) != hipSuccess) {
+      (void)hipGetLastError();
+      return kNotTaken;  // (the row kernel needs no temporary columns)
+    }
+    ctx.gather_bytes = need;
+  }
+  char* base = (char*)ctx.gather;
+  const int8_t** d_tab = (const int8_t**)(base + col_region);
+  int64_t* d_rows = (int64_t*)(base + col_region + tab_bytes);
+  HIP_TRY(hipMemcpyAsync(d_rows, in->num_rows, sizeof(int64_t) * (size_t)nf, hipMemcpyHostToDevice, s));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+  std::vector<const void*> cols2((size_t)nf * nc2);
+  mi355q_result* res = nullptr;
+  struct ResGuard {
+    mi355q_result*& r;
+    ~ResGuard() { if (r) mi355q_result_free(r); }
+  } rg{res};
+  mi355q_exec_report acc{};
+  int pass = 0, f = 0;
+  while (f < nf) {
+    int f1 = f;
+    int64_t rows = 0, off = 0;
+    while (f1 < nf && (f1 == f || rows + in->num_rows[f1] <= pass_rows)) {
+      for (int c = 0; c < nc; ++c) cols2[(size_t)(f1 - f) * nc2 + c] = in->col_buffers[(size_t)f1 * nc + c];
+      for (int k = nc; k < nc2; ++k) {
+        cols2[(size_t)(f1 - f) * nc2 + k] = base + off;
+        const int w = k == flag_col ? 1 : width[k - nc];
+        off += (in->num_rows[f1] * w + 15) & ~15ll;
+      }
+      rows += in->num_rows[f1];
+      ++f1;
+    }
+    if (off > col_region) return MI355Q_ERR_OUT_OF_GPU_MEM;  // (cannot happen: the region is sized for it)
+    const int pnf = f1 - f;
+    HIP_TRY(hipMemcpyAsync(d_tab, cols2.data(), sizeof(void*) * (size_t)pnf * nc2, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_join_gather(d, n_used, used, dst, width, null_pat, flag_col, nc2, d_tab, d_rows + f, pnf, max_frag_rows, n_cus, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (cols2 is re-used by the next pass; the step below synchronises anyway)
+    mi355q_inputs in2 = *in;
+    in2.n_frags = pnf;
+    in2.col_buffers = cols2.data();
+    in2.num_rows = in->num_rows + f;
+    in2.inner_col_buffers = nullptr;
+    o2 = o;
+    o2.stream = s;
+    o2.out_buffer = pass == 0 ? o.out_buffer : nullptr;
+    mi355q_result* r2 = nullptr;
+    mi355q_exec_report rep2{};
+    if (int32_t e2 = mi355q_execute(&p2, &in2, &o2, &r2, &rep2)) return e2;
+    if (pass == 0) {
+      res = r2;
+      std::snprintf(acc.kernel_name, sizeof(acc.kernel_name), "%s", rep2.kernel_name);
+      acc.variant = rep2.variant;
+    } else {
+      const int32_t er = mi355q_result_reduce(res, r2, s);
+      mi355q_result_free(r2);
+      if (er) return er;
+    }
+    acc.kernel_ms += rep2.kernel_ms;
+    acc.n_launches += rep2.n_launches + 1;
+    acc.spilled_rows += rep2.spilled_rows;
+    f = f1;
+    ++pass;
+  }
+  if (ev1) HIP_TRY(hipEventRecord(ev1, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (report) {
+    *report = acc;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  *out = res;
+  res = nullptr;
+  return MI355Q_OK;
+}
+
 // Baseline steps over 2 - 3 plain INT key columns that all have ranges — the reference's PerfectHashMultiCol / MultiStep
 // shapes beyond g_baseline_groupby_threshold (PHM006, MSPHM005, MSPHM007: ~11 M combinations, Execute.cpp:113,
 // GroupByAndAggregate.cpp:232-365) — over a large input: the product of the ranges still indexes a table the
@@ -2456,6 +2658,13 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     // large-input members" takes it whatever the input size: tests)
     if (!lds_direct && !pend && d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && (tr >= kIdxPartMinRows || o.kernel_variant == 2))
       lds_direct = idx_direct = idx_part_eligible(d, fvh, n_cus);
+  }
+  if (!o.force_generic && in->n_frags > 0 && !pend && plan->join_outer_col >= 0) {
+    const size_t mark = t_route ? t_route->size() : 0;
+    const int32_t e = execute_join_gather(plan, in, o, q, d, n_cus, out, report, reserved);
+    if (e != kNotTaken) return e;
+    if (t_route) t_route->resize(mark);
+    *out = nullptr;
   }
   if (!o.force_generic && in->n_frags > 0 && !lds_direct && !pend) {
     const size_t mark = t_route ? t_route->size() : 0;

@@ -738,6 +738,50 @@ __global__ __launch_bounds__(kBlock) void k_project(DevExprSet xs, DevPlan p, ui
   }
 }
 
+// ---- a grouped step over fact JOIN dim (one-to-one table) as a step WITHOUT a join (api.cpp execute_join_gather): one pass
+// probes the join table per outer row and lays down, as dense temporary outer columns, the inner columns the aggregates
+// read (the column's NULL where the row has no match: LEFT joins) and a 0 / 1 "matched" column (INNER joins filter on it) —
+// the reference's join loop body reads exactly these values through the matched row id (IRCodegen.cpp buildJoinLoops,
+// ColumnIR.cpp codegenOuterJoinNullPlaceholder).
+struct JoinGather {
+  int32_t n_inner, flag_col, nc2, pad_;
+  int32_t inner_col[MI355Q_MAX_COLS], dst_col[MI355Q_MAX_COLS], width[MI355Q_MAX_COLS];
+  int64_t null_pat[MI355Q_MAX_COLS];
+};
+__global__ __launch_bounds__(kBlock) void k_join_gather(DevPlan p, JoinGather jg, const int8_t* const* __restrict__ cols,
+                                                         const int64_t* __restrict__ num_rows, int n_frags) {
+  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kBlock;
+  for (int f = 0; f < n_frags; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * jg.nc2;
+    const int64_t n = num_rows[f];
+    for (int64_t pos = gtid; pos < n; pos += gsize) {
+      int64_t jk[MI355Q_MAX_GROUP_COLS];
+      bool null_key = false;
+      for (int i = 0; i < p.join_n_keys; ++i) {
+        jk[i] = decode_int(fc[p.join_cols[i]], p.join_types[i], pos);
+        null_key = null_key || (p.join_nullables[i] && jk[i] == int_null_of(p.join_types[i]));
+      }
+      int64_t inner_pos = -1;
+      if (!null_key) {  // a NULL key matches nothing (hash_join_idx_nullable)
+        const JoinMatch jm = join_lookup(p, jk);
+        if (jm.count > 0) inner_pos = jm.single;
+      }
+      if (jg.flag_col >= 0) *const_cast<int8_t*>(fc[jg.flag_col] + pos) = inner_pos >= 0 ? 1 : 0;
+      for (int j = 0; j < jg.n_inner; ++j) {
+        const int8_t* src = p.inner_cols[jg.inner_col[j]];
+        int8_t* dst = const_cast<int8_t*>(fc[jg.dst_col[j]]);
+        switch (jg.width[j]) {
+          case 1: *(int8_t*)(dst + pos) = inner_pos >= 0 ? *(const int8_t*)(src + inner_pos) : (int8_t)jg.null_pat[j]; break;
+          case 2: *(int16_t*)(dst + pos * 2) = inner_pos >= 0 ? *(const int16_t*)(src + inner_pos * 2) : (int16_t)jg.null_pat[j]; break;
+          case 4: *(int32_t*)(dst + pos * 4) = inner_pos >= 0 ? *(const int32_t*)(src + inner_pos * 4) : (int32_t)jg.null_pat[j]; break;
+          default: *(int64_t*)(dst + pos * 8) = inner_pos >= 0 ? *(const int64_t*)(src + inner_pos * 8) : jg.null_pat[j];
+        }
+      }
+    }
+  }
+}
+
 // ---- projected expressions of ONE operation over ONE plain column, four rows per lane -------------------------
 // k_project interprets a node list per row, one 4- or 8-byte load and store per lane, and its by-value expression
 // set is indexed with run-time values (so it lives in scratch): 1.4 TB/s on `CAST(x AS DOUBLE)` — 8.7 ms of the
@@ -1407,6 +1451,24 @@ hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_
   }
   hipLaunchKernelGGL(k_project, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, xs, p, qual_expr_mask,
                      d_cols, d_num_rows, n_frags, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_join_gather(const DevPlan& p, int n_inner, const int32_t* inner_col, const int32_t* dst_col, const int32_t* width,
+                              const int64_t* null_pat, int flag_col, int nc2, const int8_t* const* d_cols, const int64_t* d_num_rows,
+                              int n_frags, int64_t max_frag_rows, int n_cus, hipStream_t s) {
+  if (n_frags <= 0) return hipSuccess;
+  JoinGather jg{};
+  jg.n_inner = n_inner;
+  jg.flag_col = flag_col;
+  jg.nc2 = nc2;
+  for (int j = 0; j < n_inner; ++j) {
+    jg.inner_col[j] = inner_col[j];
+    jg.dst_col[j] = dst_col[j];
+    jg.width[j] = width[j];
+    jg.null_pat[j] = null_pat[j];
+  }
+  hipLaunchKernelGGL(k_join_gather, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, p, jg, d_cols, d_num_rows, n_frags);
   return hipGetLastError();
 }
 

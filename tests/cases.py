@@ -515,6 +515,19 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
         cases.append(Case(f"join_{tag}_groupby", jra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 1, 1),
                                                       TargetExpr(AVG, 2, 1)], group=[3], quals=[Qual(1, GT, 0)]),
                           ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, pb))
+    # grouped joins on one-to-one tables (the gather route over large inputs): LEFT with unmatched rows (inner side NULL),
+    # a nullable int32 key, MIN / MAX / COUNT over the inner columns, two group columns, several quals
+    for pb, tag in [(False, "perfect"), (True, "keyed")]:
+        cases.append(Case(f"join_left_{tag}_1to1_groupby", jra([TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(COUNT, 1, 1),
+                                                               TargetExpr(SUM, 1, 1), TargetExpr(MIN, 2, 1), TargetExpr(MAX, 1, 1),
+                                                               TargetExpr(SUM, 1)], group=[3]),
+                          ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, pb))
+        cases[-1].ra.join_kind = capi.JOIN_LEFT
+        cases.append(Case(f"join_{tag}_groupby_two_keys_nullable_join_key",
+                          jra([TargetExpr(PROJECT_KEY, 0), TargetExpr(PROJECT_KEY, 1), TargetExpr(COUNT), TargetExpr(AVG, 1, 1),
+                               TargetExpr(MAX, 2, 1), TargetExpr(MIN, 1)], outer_col=2, group=[3, 2],
+                              quals=[Qual(1, GT, -900000), Qual(0, GE, 0), Qual(3, LT, 25)]),
+                          ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, pb))
     cases.append(Case("join_no_match_at_all", jra([TargetExpr(SUM, 1), TargetExpr(COUNT)], quals=[Qual(0, LT, -10)]),
                       ffrags, [dim_dense, dim_w, dim_f], dim_dense, INT64, dense_rng, False))
     sparse = (rng.permutation(5 * m)[:m].astype(np.int64)) * 1000003

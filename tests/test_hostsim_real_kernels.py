@@ -407,3 +407,52 @@ def test_shifted_arguments_with_nulls_and_a_range_that_could_overflow(sim, oracl
                              num_tuples=n)
     case = cases_mod.Case("shifted_overflow", ra, [[key, big, v64]], expect_error=7)
     flow._check(oracle, case, kernel_variant=2)     # the oracle's code (7) and the product's must agree
+
+
+# ---- grouped joins on one-to-one tables: k_join_gather + the step without a join (execute_join_gather) -------------------------
+def test_grouped_join_gather_route_in_several_passes(sim, oracle):
+    """SELECT f.g, COUNT(*), SUM(d.w), MIN(d.x), AVG(d.x) FROM f [LEFT] JOIN d ON f.k = d.k GROUP BY f.g: the probe is its own pass
+    (inner columns + a matched flag as dense outer columns), the derived step has no join and the stated layout.  Nullable inner
+    column with NULLs, keys that miss, NULL join keys, pass_rows that cuts the input into three passes (folded with the reduce rule)."""
+    from heavydb_amd.executor import Executor, ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(77)
+    m, n = 5_000, 90_000
+    dim_k = rng.permutation(m).astype(np.int64)
+    dim_w = rng.integers(-1000, 1000, m).astype(np.int64)
+    dim_x = rng.integers(-50, 50, m).astype(np.int32)
+    dim_x[rng.random(m) < 0.2] = np.iinfo(np.int32).min
+    fk = rng.integers(-200, m + 200, n).astype(np.int64)
+    fk[rng.random(n) < 0.03] = np.iinfo(np.int64).min
+    fg = rng.integers(0, 40, n).astype(np.int32)
+    fv = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    fdescs = [InputColDescriptor(capi.INT64, True, ExpressionRange(True, -200, m + 199, True)),
+              InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 39)),
+              InputColDescriptor(capi.INT64, False, ExpressionRange(True, -10**6, 10**6))]
+    idescs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 0, m - 1)),
+              InputColDescriptor(capi.INT64, False, ExpressionRange(True, -1000, 999)),
+              InputColDescriptor(capi.INT32, True, ExpressionRange(True, -50, 49, True))]
+    cuts = [0, 30_001, 60_002, n]
+    frags = [[fk[a:b], fg[a:b], fv[a:b]] for a, b in zip(cuts[:-1], cuts[1:])]
+    for kind in (capi.JOIN_INNER, capi.JOIN_LEFT):
+        for pb in (False, True):
+            ra = RelAlgExecutionUnit(fdescs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1, 1),
+                                              TargetExpr(capi.MIN, 2, 1), TargetExpr(capi.AVG, 2, 1), TargetExpr(capi.SUM, 2),
+                                              TargetExpr(capi.COUNT, 2, 1)], [], [1],
+                                     inner_col_descs=idescs, join_outer_col=0, join_kind=kind)
+            case = cases_mod.Case("grouped_join_gather", ra, frags, [dim_k, dim_w, dim_x], dim_k, capi.INT64,
+                                  ExpressionRange(True, 0, m - 1), pb)
+            rs = flow._check(oracle, case, kernel_variant=2, pass_rows=31_000)
+            assert rs is not None and rs.report.n_launches >= 6, rs.report.n_launches     # three passes: gather + step each
+
+
+def test_grouped_join_gather_route_is_named_by_explain(sim, oracle):
+    from heavydb_amd.executor import Executor
+    for name, taken in (("join_left_perfect_1to1_groupby", True), ("join_keyed_groupby", True), ("join_1n_perfect_groupby_int32_key", False)):
+        case = next(c for c in CASES if c.name == name)
+        hj, keep = flow._build_join(case)
+        case.ra.join_table = hj
+        try:
+            r = Executor(0).explain(case.ra, [250_000_000] * 4)
+        finally:
+            case.ra.join_table = None
+        assert r.startswith("k_join_gather") == taken, (name, r)

@@ -200,3 +200,58 @@ def test_keyed_probe_in_several_passes(torch_cuda, oracle, monkeypatch):
     L2-resident slice per partition gets), forced on a small table."""
     test_payload_probe_matches_oracle(torch_cuda, oracle, True, True, "all_targets", True, keyed_passes=3)
     test_payload_probe_matches_oracle(torch_cuda, oracle, False, False, "hot_key", True, keyed_passes=3)
+
+
+@pytest.mark.parametrize("sparse", [False, True], ids=["perfect", "keyed"])
+@pytest.mark.parametrize("left", [False, True], ids=["inner", "left"])
+def test_grouped_join_through_the_gather_route_at_16m_rows(torch_cuda, oracle, left, sparse):
+    """SELECT f.g, COUNT(*), SUM(d.w), MAX(d.x), AVG(d.x), SUM(f.v) FROM f [LEFT] JOIN d ON f.k = d.k GROUP BY f.g over 16 M outer rows:
+    the planner's own choice (api.cpp execute_join_gather: k_join_gather + the step without a join) against the oracle's join loop
+    and against the row kernel (kernel_variant 1).  Keys that miss, NULL join keys, a nullable inner column."""
+    from heavydb_amd.executor import (Executor, ExpressionRange, FetchResult, HashJoin, InputColDescriptor,
+                                      RelAlgExecutionUnit, TargetExpr)
+    torch = torch_cuda
+    rng = np.random.default_rng(5 + 2 * int(left) + int(sparse))
+    m, n = 1_000_000, 16_000_000
+    mul = 1000003 if sparse else 1
+    dim_k = rng.permutation(m).astype(np.int64) * mul
+    dim_w = rng.integers(-1000, 1000, m).astype(np.int64)
+    dim_x = rng.integers(-5000, 5000, m).astype(np.int32)
+    dim_x[rng.random(m) < 0.1] = np.iinfo(np.int32).min
+    fk = rng.integers(-m // 10, m + m // 10, n).astype(np.int64) * mul
+    fk[rng.random(n) < 0.01] = np.iinfo(np.int64).min
+    fg = rng.integers(0, 100, n).astype(np.int32)
+    fv = rng.integers(-10**6, 10**6, n).astype(np.int64)
+    kmin, kmax = int(dim_k.min()), int(dim_k.max())
+    fdescs = [InputColDescriptor(capi.INT64, True, ExpressionRange(True, -(m // 10) * mul, (m + m // 10) * mul, True)),
+              InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 99)),
+              InputColDescriptor(capi.INT64, False, ExpressionRange(True, -10**6, 10**6))]
+    idescs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, kmin, kmax)),
+              InputColDescriptor(capi.INT64, False, ExpressionRange(True, -1000, 999)),
+              InputColDescriptor(capi.INT32, True, ExpressionRange(True, -5000, 4999, True))]
+    dk, dw, dx = (torch.from_numpy(a).cuda() for a in (dim_k, dim_w, dim_x))
+    hj = HashJoin.getInstance(int(dk.data_ptr()), m, capi.INT64, ExpressionRange(True, kmin, kmax))
+    assert hj.info()["hash_type"] == (1 if sparse else 0)
+    ra = RelAlgExecutionUnit(fdescs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1, 1),
+                                      TargetExpr(capi.MAX, 2, 1), TargetExpr(capi.AVG, 2, 1), TargetExpr(capi.SUM, 2)], [], [1],
+                             inner_col_descs=idescs, join_outer_col=0, join_table=hj,
+                             join_kind=capi.JOIN_LEFT if left else capi.JOIN_INNER)
+    cut = n // 2 + 12
+    dev = [torch.from_numpy(a).cuda() for a in (fk, fg, fv)]
+    fr = FetchResult([[int(t.data_ptr()) + o * t.element_size() for t in dev] for o in (0, cut)], [cut, n - cut],
+                     [int(dk.data_ptr()), int(dw.data_ptr()), int(dx.data_ptr())], m, keepalive=dev + [dk, dw, dx])
+    ex = Executor(0)
+    assert ex.explain(ra, [cut, n - cut]).startswith("k_join_gather")
+    rs = ex.executeWorkUnit(ra, fr, allow_retry=False)
+    row = ex.executeWorkUnit(ra, fr, allow_retry=False, kernel_variant=1)
+    assert row.report.kernel_name.decode() == "k_generic"
+    print(f"grouped join 16 M rows ({'keyed' if sparse else 'perfect'}, {'LEFT' if left else 'INNER'}): gather route "
+          f"{rs.report.total_ms:.2f} ms ({rs.report.kernel_name.decode()}), row kernel {row.report.total_ms:.2f} ms")
+    oj = oracle.OracleJoin(dim_k, capi.INT64, kmin, kmax)
+    ra.join_table = None
+    q, want, code = oracle.execute(ra.to_plan(), [[fk[:cut], fg[:cut], fv[:cut]], [fk[cut:], fg[cut:], fv[cut:]]],
+                                   [dim_k, dim_w, dim_x], oj, n_threads=16)
+    ra.join_table = hj
+    assert code == 0
+    compare_buffers(q, want, rs.getStorage())
+    compare_buffers(q, want, row.getStorage())
