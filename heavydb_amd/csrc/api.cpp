@@ -1578,6 +1578,11 @@ int32_t execute_join_gather(const mi355q_plan* plan, const mi355q_inputs* in, co
   }
   // (kernel_variant 2 = "the large-input members": how the tests reach this route with small tables)
   if (nf < 1 || (o.kernel_variant != 2 && total_rows < kIdxPartMinRows)) return kNotTaken;
+  // a perfect-hash table of <= 64 KB is aggregated by the row kernel in a per-workgroup LDS copy (launch_generic): probe and
+  // update in one pass, nothing gained by splitting them — measured at 1 B rows, 100 groups: 49 ms there, 57 ms here; 10 000
+  // groups (global atomics there): 470 ms / 163 ms there, 69 ms here (profiles/r04_grouped_join_1b_call16.jsonl)
+  if (o.kernel_variant != 2 && q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && q.entry_count * (int64_t)q.row_size <= 64 * 1024)
+    return kNotTaken;
   // the inner columns the targets read, in order of first use
   int32_t used[MI355Q_MAX_COLS], dst[MI355Q_MAX_COLS], width[MI355Q_MAX_COLS];
   int64_t null_pat[MI355Q_MAX_COLS];
@@ -1611,7 +1616,7 @@ int32_t execute_join_gather(const mi355q_plan* plan, const mi355q_inputs* in, co
   if (inner_join) {
     if (plan->n_quals >= MI355Q_MAX_QUALS) return kNotTaken;
     flag_col = nc + n_used;
-    p2.cols[flag_col] = mi355q_col_desc{MI355Q_INT8, 0, MI355Q_ENC_NONE, 0};
+    p2.cols[flag_col] = mi355q_col_desc{MI355Q_INT32, 0, MI355Q_ENC_NONE, 0};  // (INT32: the fast families' range filters read INT32 / INT64)
     p2.col_ranges[flag_col] = mi355q_range{1, 0, 0, 1, 0.0, 0.0, 0};
     mi355q_qual& mq = p2.quals[p2.n_quals++];
     mq = mi355q_qual{};
@@ -1628,7 +1633,7 @@ int32_t execute_join_gather(const mi355q_plan* plan, const mi355q_inputs* in, co
   p2.n_inner_cols = 0;
   mi355q_qmd q2;
   if (qmd_init(p2, &q2) != MI355Q_OK || std::memcmp(&q, &q2, sizeof(q)) != 0) return kNotTaken;  // the same layout, or not this way
-  int64_t row_bytes = inner_join ? 1 : 0;
+  int64_t row_bytes = inner_join ? 4 : 0;
   for (int j = 0; j < n_used; ++j) row_bytes += width[j];
   mi355q_exec_options o2 = o;
   if (reserved) {
@@ -1702,7 +1707,7 @@ int32_t execute_join_gather(const mi355q_plan* plan, const mi355q_inputs* in, co
       for (int c = 0; c < nc; ++c) cols2[(size_t)(f1 - f) * nc2 + c] = in->col_buffers[(size_t)f1 * nc + c];
       for (int k = nc; k < nc2; ++k) {
         cols2[(size_t)(f1 - f) * nc2 + k] = base + off;
-        const int w = k == flag_col ? 1 : width[k - nc];
+        const int w = k == flag_col ? 4 : width[k - nc];
         off += (in->num_rows[f1] * w + 15) & ~15ll;
       }
       rows += in->num_rows[f1];

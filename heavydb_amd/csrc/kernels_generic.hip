@@ -740,7 +740,7 @@ __global__ __launch_bounds__(kBlock) void k_project(DevExprSet xs, DevPlan p, ui
 
 // ---- a grouped step over fact JOIN dim (one-to-one table) as a step WITHOUT a join (api.cpp execute_join_gather): one pass
 // probes the join table per outer row and lays down, as dense temporary outer columns, the inner columns the aggregates
-// read (the column's NULL where the row has no match: LEFT joins) and a 0 / 1 "matched" column (INNER joins filter on it) —
+// read (the column's NULL where the row has no match: LEFT joins) and a 0 / 1 INT32 "matched" column (INNER joins filter on it) —
 // the reference's join loop body reads exactly these values through the matched row id (IRCodegen.cpp buildJoinLoops,
 // ColumnIR.cpp codegenOuterJoinNullPlaceholder).
 struct JoinGather {
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_join_gather(DevPlan p, JoinGather jg
         const JoinMatch jm = join_lookup(p, jk);
         if (jm.count > 0) inner_pos = jm.single;
       }
-      if (jg.flag_col >= 0) *const_cast<int8_t*>(fc[jg.flag_col] + pos) = inner_pos >= 0 ? 1 : 0;
+      if (jg.flag_col >= 0) *(int32_t*)const_cast<int8_t*>(fc[jg.flag_col] + pos * 4) = inner_pos >= 0 ? 1 : 0;
       for (int j = 0; j < jg.n_inner; ++j) {
         const int8_t* src = p.inner_cols[jg.inner_col[j]];
         int8_t* dst = const_cast<int8_t*>(fc[jg.dst_col[j]]);

@@ -220,11 +220,11 @@ def test_grouped_join_through_the_gather_route_at_16m_rows(torch_cuda, oracle, l
     dim_x[rng.random(m) < 0.1] = np.iinfo(np.int32).min
     fk = rng.integers(-m // 10, m + m // 10, n).astype(np.int64) * mul
     fk[rng.random(n) < 0.01] = np.iinfo(np.int64).min
-    fg = rng.integers(0, 100, n).astype(np.int32)
+    fg = rng.integers(0, 20_000, n).astype(np.int32)      # (a table beyond the row kernel's 64 KB LDS copy: the route's own territory)
     fv = rng.integers(-10**6, 10**6, n).astype(np.int64)
     kmin, kmax = int(dim_k.min()), int(dim_k.max())
     fdescs = [InputColDescriptor(capi.INT64, True, ExpressionRange(True, -(m // 10) * mul, (m + m // 10) * mul, True)),
-              InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 99)),
+              InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 19_999)),
               InputColDescriptor(capi.INT64, False, ExpressionRange(True, -10**6, 10**6))]
     idescs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, kmin, kmax)),
               InputColDescriptor(capi.INT64, False, ExpressionRange(True, -1000, 999)),
