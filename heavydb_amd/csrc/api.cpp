@@ -1580,7 +1580,7 @@ int32_t execute_join_gather(const mi355q_plan* plan, const mi355q_inputs* in, co
   if (nf < 1 || (o.kernel_variant != 2 && total_rows < kIdxPartMinRows)) return kNotTaken;
   // a perfect-hash table of <= 64 KB is aggregated by the row kernel in a per-workgroup LDS copy (launch_generic): probe and
   // update in one pass, nothing gained by splitting them — measured at 1 B rows, 100 groups: 49 ms there, 57 ms here; 10 000
-  // groups (global atomics there): 470 ms / 163 ms there, 69 ms here (profiles/r04_grouped_join_1b_call16.jsonl)
+  // groups (global atomics there): 470 / 163 ms there (LEFT / INNER), 69 / 64 ms here (profiles/r04_grouped_join_1b_call16/17.jsonl)
   if (o.kernel_variant != 2 && q.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && q.entry_count * (int64_t)q.row_size <= 64 * 1024)
     return kNotTaken;
   // the inner columns the targets read, in order of first use
