@@ -324,3 +324,109 @@ def test_invalid_comparison_and_case_programs_are_refused(oracle):
         ptrs = (C.c_void_p * 2)(0, 0)
         eb, et = C.c_int64(), C.c_int32()
         assert el.emu_eval_expr(C.byref(plan), 0, ptrs, 0, C.byref(eb), C.byref(et)) == capi.ERR_INVALID_PLAN
+
+
+def _random_expr(rng, descs, want_type, depth):
+    """a random well-typed expression of `want_type` over the columns (every micro-op; depth-limited so that the postfix
+    program stays within 12 nodes and a 4-deep stack), or None when none was found"""
+    ints = [capi.INT8, capi.INT16, capi.INT32, capi.INT64]
+    cols_of = [i for i, d in enumerate(descs) if d.type == want_type]
+    choice = int(rng.integers(0, 10))
+    if depth <= 0 or choice <= 1:
+        if cols_of and rng.integers(0, 4):
+            return Expr.col(int(rng.choice(cols_of)))
+        if want_type in (capi.DOUBLE, capi.FLOAT):
+            return Expr.lit(want_type, float(rng.choice([0.0, 1.5, -2.25, 100.0, 1e6])))
+        hi = {capi.INT8: 100, capi.INT16: 30000, capi.INT32: 2**31 - 1, capi.INT64: 2**62}[want_type]
+        if rng.integers(0, 12) == 0:
+            return Expr.null(want_type)
+        return Expr.lit(want_type, int(rng.choice([0, 1, -1, 2, 7, -13, hi, -hi])))
+    if choice <= 3:      # cast from another type
+        # (floating point -> integer is fptosi: undefined outside the target's range in the reference too — only to BIGINT here,
+        # and the tables hold no value beyond 1e9)
+        srcs = [t for t in ints + ([capi.DOUBLE, capi.FLOAT] if want_type not in ints or want_type == capi.INT64 else []) if t != want_type]
+        src = int(rng.choice(srcs))
+        e = _random_expr(rng, descs, src, depth - 1)
+        return e.cast(want_type) if e else None
+    if choice <= 6:      # arithmetic
+        op = int(rng.choice([capi.EX_ADD, capi.EX_SUB, capi.EX_MUL, capi.EX_DIV] + ([capi.EX_MOD] if want_type in ints else [])))
+        a, b = _random_expr(rng, descs, want_type, depth - 1), _random_expr(rng, descs, want_type, depth - 2)
+        return a._bin(op, b, want_type) if a and b else None
+    # CASE WHEN x <op> y THEN .. ELSE .. END
+    ct = int(rng.choice(ints + [capi.DOUBLE, capi.FLOAT]))
+    x, y = _random_expr(rng, descs, ct, depth - 2), _random_expr(rng, descs, ct, 0)
+    t, e = _random_expr(rng, descs, want_type, depth - 2), _random_expr(rng, descs, want_type, depth - 2)
+    if not (x and y and t and e):
+        return None
+    cmp_op = int(rng.choice([capi.EX_EQ, capi.EX_NE, capi.EX_LT, capi.EX_LE, capi.EX_GT, capi.EX_GE]))
+    return Expr.case(x.cmp(cmp_op, y), t, e, want_type)
+
+
+def _stack_depth(e):
+    sp = mx = 0
+    for n in e.nodes:
+        if n.op in (capi.EX_COL, capi.EX_LIT):
+            sp += 1
+        elif n.op == capi.EX_CASE:
+            sp -= 2
+        elif n.op != capi.EX_CAST:
+            sp -= 1
+        mx = max(mx, sp)
+    return mx
+
+
+def test_random_expression_programs_agree(oracle):
+    """Random well-typed programs over every micro-op (casts, + - * / %, comparisons, nested CASE, the NULL literal) on rows
+    with NULLs, zeros and extreme values: the oracle (recursive, lazy, from the root) and the product's evaluator (flat stack
+    machine with a per-value error) must agree on the value AND on the error code, row by row."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("MI355Q_FUZZ_SEED", "20260923")))
+    iters = int(os.environ.get("MI355Q_FUZZ_ITERS", "400"))
+    types = [capi.INT8, capi.INT16, capi.INT32, capi.INT64, capi.DOUBLE, capi.FLOAT]
+    n_rows = 64
+    ol, el = oracle.lib(), emu_lib()
+    ol.orc_eval_expr.restype = C.c_int32
+    ol.orc_eval_expr.argtypes = [C.POINTER(capi.Plan), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64),
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    el.emu_eval_expr.restype = C.c_int32
+    el.emu_eval_expr.argtypes = [C.POINTER(capi.Plan), C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    done = errs = cases = 0
+    for it in range(iters):
+        descs, cols = [], []
+        for t in types:
+            for nullable in (True, False):
+                if t in (capi.DOUBLE, capi.FLOAT):
+                    v = rng.choice([0.0, -0.0, 1.0, -1.5, 3.25, 1e9, -1e-3, 2.5], n_rows).astype(NP[t])
+                    if nullable:
+                        v[rng.random(n_rows) < 0.25] = NP[t](np.finfo(NP[t]).tiny)
+                else:
+                    lo, hi = INT_NULL[t], INT_MAX[t]
+                    v = rng.choice([0, 1, -1, 2, 5, -7, hi, hi - 1, lo + 1], n_rows).astype(NP[t])
+                    if nullable:
+                        v[rng.random(n_rows) < 0.25] = lo
+                descs.append(InputColDescriptor(t, nullable))
+                cols.append(np.ascontiguousarray(v))
+        e = _random_expr(rng, descs, int(rng.choice(types)), int(rng.integers(1, 4)))
+        if e is None or len(e.nodes) > capi.MAX_EXPR_NODES or _stack_depth(e) > 4:
+            continue
+        plan = _plan(descs, e)
+        ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])
+        rt = e.result(descs)[0]
+        cases += 1
+        for pos in range(n_rows):
+            ob, ot, on, eb, et = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32()
+            oc = ol.orc_eval_expr(C.byref(plan), 0, ptrs, pos, C.byref(ob), C.byref(ot), C.byref(on))
+            ec = el.emu_eval_expr(C.byref(plan), 0, ptrs, pos, C.byref(eb), C.byref(et))
+            assert oc == ec, (it, pos, oc, ec, [(n.op, n.type, n.arg) for n in e.nodes])
+            if oc:
+                errs += 1
+                continue
+            assert ot.value == et.value == rt, (it, ot.value, et.value, rt)
+            same = _same_pattern(rt, ob.value, eb.value)
+            if not same and rt in (capi.DOUBLE, capi.FLOAT):   # NaN payloads may differ
+                f = (lambda p: struct.unpack("<d", struct.pack("<q", p))[0]) if rt == capi.DOUBLE else \
+                    (lambda p: struct.unpack("<f", struct.pack("<I", p & 0xffffffff))[0])
+                same = np.isnan(f(ob.value)) and np.isnan(f(eb.value))
+            assert same, (it, pos, hex(ob.value), hex(eb.value), [(n.op, n.type, n.arg, n.ilit, n.flit) for n in e.nodes])
+            done += 1
+    assert cases > iters // 3 and done > 5000 and errs > 50, (cases, done, errs)
