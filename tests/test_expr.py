@@ -326,7 +326,7 @@ def test_invalid_comparison_and_case_programs_are_refused(oracle):
         assert el.emu_eval_expr(C.byref(plan), 0, ptrs, 0, C.byref(eb), C.byref(et)) == capi.ERR_INVALID_PLAN
 
 
-def _random_expr(rng, descs, want_type, depth):
+def _random_expr(rng, descs, want_type, depth, big=True):
     """a random well-typed expression of `want_type` over the columns (every micro-op; depth-limited so that the postfix
     program stays within 12 nodes and a 4-deep stack), or None when none was found"""
     ints = [capi.INT8, capi.INT16, capi.INT32, capi.INT64]
@@ -337,7 +337,10 @@ def _random_expr(rng, descs, want_type, depth):
             return Expr.col(int(rng.choice(cols_of)))
         if want_type in (capi.DOUBLE, capi.FLOAT):
             return Expr.lit(want_type, float(rng.choice([0.0, 1.5, -2.25, 100.0, 1e6])))
-        hi = {capi.INT8: 100, capi.INT16: 30000, capi.INT32: 2**31 - 1, capi.INT64: 2**62}[want_type]
+        # (big=False: literals whose SUMs over a few thousand rows stay far from 2^63 — a partial sum that wraps onto the
+        # NULL sentinel is dropped by the reduce rule of partial tables, in the reference too, and where the partials end
+        # differs between the oracle's threads and the device's workgroups)
+        hi = {capi.INT8: 100, capi.INT16: 30000, capi.INT32: 2**31 - 1 if big else 10**6, capi.INT64: 2**62 if big else 10**9}[want_type]
         if rng.integers(0, 12) == 0:
             return Expr.null(want_type)
         return Expr.lit(want_type, int(rng.choice([0, 1, -1, 2, 7, -13, hi, -hi])))
@@ -346,16 +349,16 @@ def _random_expr(rng, descs, want_type, depth):
         # and the tables hold no value beyond 1e9)
         srcs = [t for t in ints + ([capi.DOUBLE, capi.FLOAT] if want_type not in ints or want_type == capi.INT64 else []) if t != want_type]
         src = int(rng.choice(srcs))
-        e = _random_expr(rng, descs, src, depth - 1)
+        e = _random_expr(rng, descs, src, depth - 1, big)
         return e.cast(want_type) if e else None
     if choice <= 6:      # arithmetic
         op = int(rng.choice([capi.EX_ADD, capi.EX_SUB, capi.EX_MUL, capi.EX_DIV] + ([capi.EX_MOD] if want_type in ints else [])))
-        a, b = _random_expr(rng, descs, want_type, depth - 1), _random_expr(rng, descs, want_type, depth - 2)
+        a, b = _random_expr(rng, descs, want_type, depth - 1, big), _random_expr(rng, descs, want_type, depth - 2, big)
         return a._bin(op, b, want_type) if a and b else None
     # CASE WHEN x <op> y THEN .. ELSE .. END
     ct = int(rng.choice(ints + [capi.DOUBLE, capi.FLOAT]))
-    x, y = _random_expr(rng, descs, ct, depth - 2), _random_expr(rng, descs, ct, 0)
-    t, e = _random_expr(rng, descs, want_type, depth - 2), _random_expr(rng, descs, want_type, depth - 2)
+    x, y = _random_expr(rng, descs, ct, depth - 2, big), _random_expr(rng, descs, ct, 0, big)
+    t, e = _random_expr(rng, descs, want_type, depth - 2, big), _random_expr(rng, descs, want_type, depth - 2, big)
     if not (x and y and t and e):
         return None
     cmp_op = int(rng.choice([capi.EX_EQ, capi.EX_NE, capi.EX_LT, capi.EX_LE, capi.EX_GT, capi.EX_GE]))

@@ -463,3 +463,75 @@ def test_grouped_join_gather_route_is_named_by_explain(sim, oracle):
         ra.join_table = hj
         r = Executor(0).explain(ra, [250_000_000] * 4)
         assert r.startswith("k_join_gather") == taken, (name, groups, r)
+
+
+# ---- whole steps over random expressions (comparisons, CASE, / %, casts) through the real kernels ------------------------------
+def test_random_expression_steps_through_the_real_kernels(sim, oracle):
+    """Random grouped / non-grouped steps whose aggregate arguments, filter and (sometimes) group key are random well-typed
+    expression programs (tests/test_expr._random_expr: every micro-op, nested CASE, NULL literals), planned (variant 0) or
+    through the large-input routes (variant 2: shifted arguments, cast keys, the projection passes): table or error code must
+    equal the oracle's walk over the stated plan."""
+    import os
+    from heavydb_amd.executor import Executor, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.test_expr import _random_expr, _stack_depth
+    from tests.cases import expr_range
+    rng = np.random.default_rng(int(os.environ.get("MI355Q_FUZZ_SEED", "4711")))
+    iters = int(os.environ.get("MI355Q_FUZZ_ITERS", "60"))
+    NPT = {capi.INT32: np.int32, capi.INT64: np.int64, capi.DOUBLE: np.float64}
+    ran = errors = 0
+    for it in range(iters):
+        n = int(rng.integers(40, 4000))
+        descs, cols = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 49))], [rng.integers(0, 50, n).astype(np.int32)]
+        for t in (capi.INT32, capi.INT32, capi.INT64, capi.INT64, capi.DOUBLE):
+            nullable = bool(rng.integers(0, 2))
+            if t == capi.DOUBLE:
+                v = rng.uniform(-50, 50, n)
+                v[rng.random(n) < 0.1] = 0.0
+                if nullable:
+                    v[rng.random(n) < 0.15] = np.finfo(np.float64).tiny
+                r = ExpressionRange(True, 0, 0, nullable, -50.0, 50.0)
+            else:
+                lo, hi = (-1000, 1000) if rng.integers(0, 2) else (0, 5)
+                v = rng.integers(lo, hi + 1, n).astype(NPT[t])
+                if nullable:
+                    v[rng.random(n) < 0.15] = np.iinfo(NPT[t]).min
+                r = ExpressionRange(True, lo, hi, nullable)
+            descs.append(InputColDescriptor(t, nullable, r))
+            cols.append(np.ascontiguousarray(v.astype(NPT[t])))
+        exprs = []
+        for _ in range(int(rng.integers(1, 4))):
+            e = _random_expr(rng, descs, int(rng.choice([capi.INT32, capi.INT64, capi.DOUBLE])), int(rng.integers(1, 4)), big=False)
+            if e is not None and len(e.nodes) <= capi.MAX_EXPR_NODES and _stack_depth(e) <= 4 and any(nd.op == capi.EX_COL for nd in e.nodes):
+                exprs.append(e)
+        if not exprs:
+            continue
+        nc = len(descs)
+        try:
+            exprs = [e.with_range(expr_range(e, descs, [cols])) for e in exprs]
+        except Exception:
+            continue      # (the numpy range helper does not model every program: inf / nan corners)
+        grouped = bool(rng.integers(0, 4))
+        targets = [TargetExpr(capi.PROJECT_KEY)] if grouped else []
+        targets.append(TargetExpr(capi.COUNT))
+        for k in range(len(exprs)):
+            targets.append(TargetExpr(int(rng.choice([capi.SUM, capi.MIN, capi.MAX, capi.AVG, capi.COUNT])), nc + k))
+        targets = targets[:6]
+        quals = [Qual(2, capi.GE, -900)] if rng.integers(0, 3) == 0 else []
+        ra = RelAlgExecutionUnit(descs, targets, quals, [0] if grouped else [], exprs=exprs, num_tuples=n)
+        cut = (n // 2) & ~3
+        case = cases_mod.Case("fuzz_expr_step", ra, [[c[:cut] for c in cols], [c[cut:] for c in cols]])
+        try:
+            q, want, code = oracle.execute(ra.to_plan(), case.frags, n_threads=1)
+        except capi.Mi355qError:
+            continue
+        if code:
+            case.expect_error = code
+            errors += 1
+        try:
+            flow._check(oracle, case, kernel_variant=int(rng.choice([0, 2])))
+        except AssertionError:
+            print("iteration", it, "exprs", [[(nd.op, nd.type, nd.arg, nd.ilit, nd.flit, nd.null_lit) for nd in e.nodes] for e in exprs],
+                  "targets", [(t.agg, t.col) for t in targets], "grouped", grouped)
+            raise
+        ran += 1
+    assert ran > iters // 2, (ran, errors)
