@@ -535,3 +535,47 @@ def test_random_expression_steps_through_the_real_kernels(sim, oracle):
             raise
         ran += 1
     assert ran > iters // 2, (ran, errors)
+
+
+def test_random_perfect_twin_steps(sim, oracle):
+    """Random baseline steps over 2 - 3 ranged INT32 keys whose combinations exceed the perfect-hash threshold (1.0 - 2.2 M),
+    random nullability / NULLs in keys and values, 1 - 3 INT32 value columns, random aggregates: the twin route (variant 2)
+    against the oracle's walk over the stated (baseline) plan."""
+    import os
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(int(os.environ.get("MI355Q_FUZZ_SEED", "99")))
+    taken = 0
+    for it in range(int(os.environ.get("MI355Q_FUZZ_ITERS", "8"))):
+        n = int(rng.integers(2_000, 40_000))
+        nk = int(rng.integers(2, 4))
+        cards = [int(rng.integers(900, 1500)), int(rng.integers(900, 1500))] if nk == 2 else \
+                [int(rng.integers(90, 130)), int(rng.integers(90, 130)), int(rng.integers(100, 130))]
+        descs, cols = [], []
+        for c in cards:
+            lo = int(rng.integers(-500, 500))
+            nullable = bool(rng.integers(0, 2))
+            has_nulls = nullable and bool(rng.integers(0, 2))
+            v = rng.integers(lo, lo + c, n).astype(np.int32)
+            if has_nulls:
+                v[rng.random(n) < 0.05] = np.iinfo(np.int32).min
+            descs.append(InputColDescriptor(capi.INT32, nullable, ExpressionRange(True, lo, lo + c - 1, has_nulls)))
+            cols.append(v)
+        nv = int(rng.integers(1, 4))
+        for _ in range(nv):
+            nullable = bool(rng.integers(0, 2))
+            v = rng.integers(-1000, 1000, n).astype(np.int32)
+            if nullable:
+                v[rng.random(n) < 0.1] = np.iinfo(np.int32).min
+            descs.append(InputColDescriptor(capi.INT32, nullable, ExpressionRange(True, -1000, 999, nullable)))
+            cols.append(v)
+        targets = [TargetExpr(capi.PROJECT_KEY, g) for g in range(nk) if rng.integers(0, 4)] + [TargetExpr(capi.COUNT)]
+        for j in range(nv):
+            targets.append(TargetExpr(int(rng.choice([capi.SUM, capi.MIN, capi.MAX, capi.AVG, capi.COUNT])), nk + j))
+        targets = targets[:capi.MAX_TARGETS] if hasattr(capi, "MAX_TARGETS") else targets[:8]
+        ra = RelAlgExecutionUnit(descs, targets, [], list(range(nk)), max_groups_buffer_entry_guess=131072, num_tuples=n)
+        cut = (n // 3) & ~3
+        case = cases_mod.Case("fuzz_twin", ra, [[c[:cut] for c in cols], [c[cut:] for c in cols]])
+        rs = flow._check(oracle, case, kernel_variant=2)
+        assert rs is not None
+        taken += rs.report.kernel_name.decode() == "k_idx_scatter"
+    assert taken >= 1, taken
