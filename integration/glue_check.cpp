@@ -326,6 +326,62 @@ int main() {
     compare_tables(q, want.data(), (const int64_t*)const_cast<ResultSetStorage*>(rs->getStorage())->getUnderlyingBuffer(), {false, false, false, false});
   }
 
+  // ---------------------------------------------------------------- query 2b: a column-vs-column filter and a CASE argument
+  //   SELECT x, COUNT(*), MAX(CASE WHEN i32 > x THEN x ELSE 0 END) FROM t WHERE i32 <> x GROUP BY x
+  {
+    std::printf("query 2b: SELECT x, COUNT(*), MAX(CASE WHEN i32 > x THEN x ELSE 0 END) FROM t WHERE i32 <> x GROUP BY x\n");
+    RelAlgExecutionUnit ra;
+    ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(2, kTable, kDb, 0));
+    ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(3, kTable, kDb, 0));
+    auto i32 = colvar(t, kTable, 2);
+    auto x = colvar(t, kTable, 3);
+    auto ne = std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kBOOLEAN, false), kNE, i32, x);
+    auto gt = std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kBOOLEAN, false), kGT, i32, x);
+    std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>> whens{{gt, x}};
+    auto cs = std::make_shared<Analyzer::CaseExpr>(SQLTypeInfo(kINT, false), false, whens, int_lit(kINT, 0));
+    ra.groupby_exprs.push_back(x);
+    ra.quals.push_back(ne);
+    Analyzer::AggExpr cnt(SQLTypeInfo(kBIGINT, true), kCOUNT, nullptr), mx(SQLTypeInfo(kINT, false), kMAX, cs);
+    ra.target_exprs = {x.get(), &cnt, &mx};
+    mi355q_plan hp{};
+    hp.abi_version = MI355Q_ABI_VERSION;
+    hp.n_cols = 2;
+    hp.cols[0] = {MI355Q_INT32, 0, 0, 0};
+    hp.col_ranges[0] = {1, 0, 0, INT32_MAX, 0, 0, 0};
+    hp.cols[1] = {MI355Q_INT32, 1, 0, 0};
+    hp.col_ranges[1] = {1, 0, 1, 40, 0, 0, 0};
+    hp.n_exprs = 2;
+    hp.exprs[0].n_nodes = 3;   // i32 <> x: a BOOLEAN (INT8 1 / 0 / NULL)
+    hp.exprs[0].nodes[0] = {MI355Q_EX_COL, 0, 0, 0, 0, 0.0};
+    hp.exprs[0].nodes[1] = {MI355Q_EX_COL, 0, 1, 0, 0, 0.0};
+    hp.exprs[0].nodes[2] = {MI355Q_EX_NE, MI355Q_INT8, 0, 0, 0, 0.0};
+    hp.exprs[1].n_nodes = 6;   // ELSE 0 | THEN x | i32 > x | CASE
+    hp.exprs[1].nodes[0] = {MI355Q_EX_LIT, MI355Q_INT32, 0, 0, 0, 0.0};
+    hp.exprs[1].nodes[1] = {MI355Q_EX_COL, 0, 1, 0, 0, 0.0};
+    hp.exprs[1].nodes[2] = {MI355Q_EX_COL, 0, 0, 0, 0, 0.0};
+    hp.exprs[1].nodes[3] = {MI355Q_EX_COL, 0, 1, 0, 0, 0.0};
+    hp.exprs[1].nodes[4] = {MI355Q_EX_GT, MI355Q_INT8, 0, 0, 0, 0.0};
+    hp.exprs[1].nodes[5] = {MI355Q_EX_CASE, MI355Q_INT32, 0, 0, 0, 0.0};
+    hp.n_group_cols = 1;
+    hp.group_cols[0] = 1;
+    hp.n_quals = 1;
+    hp.quals[0] = {2, MI355Q_EQ, 1, 0.0};   // the comparison column is TRUE
+    hp.n_targets = 3;
+    hp.targets[0] = {MI355Q_PROJECT_KEY, 0, 0, 0, {}};
+    hp.targets[1] = {MI355Q_COUNT, -1, 0, 0, {}};
+    hp.targets[2] = {MI355Q_MAX, 3, 0, 0, {}};
+    hp.join_outer_col = -1;
+    hp.max_groups_buffer_entry_guess = 16384;
+    hp.num_tuples = N;
+    compare_plans(hp, mi355q_glue::to_plan(ra, query_infos, &executor, nullptr, 16384, false));
+    std::vector<int64_t> frag_rows;
+    const FetchResult fr = fetch(t, {2, 3}, &frag_rows);
+    mi355q_qmd q;
+    const std::vector<int64_t> want = oracle_table(hp, t, {2, 3}, frag_rows, nullptr, {}, 0, &q);
+    const ResultSetPtr rs = mi355q_glue::run_query_mi355q(ra, fr, query_infos, qmd_of(q), &executor, 0, 16384, nullptr, {}, 0);
+    compare_tables(q, want.data(), (const int64_t*)const_cast<ResultSetStorage*>(rs->getStorage())->getUnderlyingBuffer(), {false, false, false});
+  }
+
   // ---------------------------------------------------------------- query 3: hash-join probe + SUM
   //   SELECT SUM(t.i32w), SUM(d.w), COUNT(*) FROM t JOIN d ON t.fk = d.k
   {
