@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--verify-rows", type=float, default=0, help="also check every query against the oracle on a table "
                     "of this many rows (test infrastructure; 0 = skip)")
     ap.add_argument("--out", default="")
+    ap.add_argument("--unprepared", action="store_true", help="time Executor.executeWorkUnit (plan structs rebuilt by the Python mirror every "
+                    "step, as the tables of rounds 3 and 4 up to r04_refbench_1b_final did) instead of one mi355q_execute on prepared structs")
     ap.add_argument("--budget-ms", type=float, default=1500.0, help="a query whose step on the first fragment "
                     "extrapolates beyond this at the full size is not run at the full size (the extrapolation is "
                     "reported instead): a shape that still takes the row kernel with a handful of groups serialises "
@@ -166,6 +168,7 @@ def main():
     import torch
     from heavydb_amd import capi
     from heavydb_amd.executor import Executor, FetchResult, generate_column
+    from heavydb_amd.multi_gpu import HipShard
     capi.load_library()
     n_rows = int(args.rows)
     names, descs, gens = schema()
@@ -217,14 +220,30 @@ def main():
                 continue
             rs = ex.executeWorkUnit(ra, fr)      # warm-up (workspace, retry ladder of the entry guess)
             torch.cuda.synchronize()
+            # the plan / input structs of the C-ABI are built once, as bench.py does (the reference compiles a step once too):
+            # a step = one mi355q_execute on them + the result storage it writes
+            prep = None
+            if not args.unprepared:
+                try:
+                    prep = HipShard.prepare(ex, ra, fr)
+                    HipShard.execute_prepared(torch, prep)
+                except capi.Mi355qError:
+                    prep = None              # (a table the retry ladder has to grow: the plain entry point)
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                rs = ex.executeWorkUnit(ra, fr)
+                if prep is not None:
+                    sh = HipShard.execute_prepared(torch, prep)
+                    rs = sh.result_set()
+                    rs.report = sh.report
+                else:
+                    rs = ex.executeWorkUnit(ra, fr)
                 if spec.get("sort"):
                     outbuf = torch.empty(100 * rs.getQueryMemDesc().row_size // 8, dtype=torch.int64, device="cuda:0")
                     rs.sort(len(spec["targets"]) - 1, 100, int(outbuf.data_ptr()), desc=False)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) * 1e3 / args.steps
+            line["prepared"] = prep is not None
             line.update(kernel=rs.report.kernel_name.decode(), variant=int(rs.report.variant), ms=round(ms, 3),
                         rows_per_s=n_rows / ms * 1e3, groups=int(rs.rowCount()),
                         whole_step_frac=round(n_rows * bpr / (ms * 1e-3) / 8e12, 4))
