@@ -545,7 +545,7 @@ def test_random_perfect_twin_steps(sim, oracle):
     from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
     rng = np.random.default_rng(int(os.environ.get("MI355Q_FUZZ_SEED", "99")))
     taken = 0
-    for it in range(int(os.environ.get("MI355Q_FUZZ_ITERS", "8"))):
+    for it in range(int(os.environ.get("MI355Q_FUZZ_ITERS", "3"))):
         n = int(rng.integers(2_000, 40_000))
         nk = int(rng.integers(2, 4))
         cards = [int(rng.integers(900, 1500)), int(rng.integers(900, 1500))] if nk == 2 else \
