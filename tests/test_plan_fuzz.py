@@ -328,7 +328,7 @@ def test_reduce_agrees_on_random_plans(oracle):
     rng = np.random.default_rng(31)
     emu = emu_lib()
     ran = 0
-    for i in range(120):
+    for i in range(70):   # (tools/soak_fuzz.py runs thousands with fresh seeds; the suite keeps a sample — large perfect-hash tables are allocated, copied and reduced three times per plan)
         n_rows = int(rng.integers(2, 300))
         descs, cols = _fuzz_table(rng, n_rows)
         int_cols = [j for j, d in enumerate(descs) if d.type not in (capi.DOUBLE, capi.FLOAT)]
@@ -370,7 +370,7 @@ def test_reduce_agrees_on_random_plans(oracle):
         assert emu.emu_reduce(C.byref(q), mine.ctypes.data, bb.ctypes.data, q.entry_count) == 0
         compare_buffers(q, red, mine, 1e-12)
         ran += 1
-    assert ran > 70, ran
+    assert ran > 40, ran
 
 
 def test_boundary_values_agree(oracle):
