@@ -13,6 +13,7 @@
 //            GroupByRuntime.cpp:208-223, GroupByAndAggregate.cpp:1546-1598), partitions by e / S1 (a partition is a
 //            contiguous slice of the table) and writes narrow records through the producer / flusher pipeline of
 //            k_part_scatter (12 producer waves, 4 flusher waves, 128-byte staging lines, no workgroup barrier):
+//              RS = 2   4-byte records {e : u32}                           NO value column (COUNT(*) / key projections only)
 //              RS = 1   8-byte records {e : u32, v : i32}                 one value column
 //              RS = 0  16-byte records {e, v0, v1, v2}                    two or three value columns, ONE exchange
 //   phase 2  k_idx_aggregate<NV, MM, RS>: one workgroup per (partition, sub-range); the LDS table is indexed by e - lo (no
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
                                                             const int64_t* __restrict__ num_rows, int n_frags, int n_cols,
                                                             IdxGeom g, IdxCols c, v4i32* __restrict__ scratch,
                                                             uint32_t* __restrict__ cnt, IdxSpill sl) {
-  static_assert(RS == 0 || NV == 1, "8-byte records carry one value");
+  static_assert((RS == 0 && NV >= 2) || (RS == 1 && NV == 1) || (RS == 2 && NV == 0), "record size follows the value columns");
+  constexpr int NVA = NV > 0 ? NV : 1;  // (array sizes: no zero-length arrays)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v4i32* stage = (v4i32*)smem_raw;                                          // [P][L] units
   uint32_t* cursor = (uint32_t*)(smem_raw + (size_t)kIdxStageUnits * 16);   // [P] record positions handed out
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
     // ---------------------------------------------------------------------------------------------- producers
     constexpr int64_t kSuperQuads = (int64_t)kIdxProdWaves * 64;  // quads per workgroup step
     uint32_t kmin[NK], kcard[NK], kmul[NK], knull[NK];
-    bool ktr[NK], vnull[NV];
+    bool ktr[NK], vnull[NVA];
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
       kmin[k] = c.key_min[k];
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
     };
     auto quad_of = [&]() -> int64_t { return (gt - base) * kSuperQuads + wave * 64 + lane; };
     struct Tile {
-      v4i32 k[NK], v[NV];
+      v4i32 k[NK], v[NVA];
       int valid;
     };
     auto load_tile = [&](Tile& tl) {
@@ -221,7 +223,9 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
     auto try_stage = [&](const v4i32& rec, uint32_t p, uint32_t s) -> bool {
       if (idx_peek(&flushed[p]) != (s >> lgLr)) return false;
       asm volatile("" ::: "memory");  // compiler order only: the LDS itself runs a wave in order
-      if (RS) {
+      if (RS == 2) {
+        ((uint32_t*)stage)[((size_t)p << lgLr) + (s & Lrm1)] = (uint32_t)rec.x;
+      } else if (RS == 1) {
         ((unsigned long long*)stage)[((size_t)p << lgLr) + (s & Lrm1)] =
             ((unsigned long long)(uint32_t)rec.y << 32) | (unsigned long long)(uint32_t)rec.x;
       } else {
@@ -272,7 +276,7 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
             bad = true;  // a key outside its declared range (reported as out of slots, like the row kernel)
           } else {
             rec.x = (int32_t)e;
-            rec.y = idx_get(cur.v[0], i);
+            if (NV > 0) rec.y = idx_get(cur.v[0], i);
             if (NV > 1) rec.z = idx_get(cur.v[NV > 1 ? 1 : 0], i);
             if (NV > 2) rec.w = idx_get(cur.v[NV > 2 ? 2 : 0], i);
             p = idx_part_of(g, e);
@@ -363,7 +367,7 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
     const int p = seg >> lgSpl;
     const uint32_t sidx = (uint32_t)seg & ((1u << lgSpl) - 1);
     const uint32_t w = idx_peek(&written[p]);
-    const uint32_t rem_units = ((w - (my_fl[k] << lgLr)) + (uint32_t)RS) >> RS;  // < L (+ the half-filled last unit)
+    const uint32_t rem_units = ((w - (my_fl[k] << lgLr)) + ((1u << RS) - 1u)) >> RS;  // < L (+ the partly filled last unit)
     const bool need = sidx * kIdxSegUnits < rem_units && (my_fl[k] << lgL) + sidx * kIdxSegUnits < g.cap;
     idx_flush_segments(need, ((uint32_t)p * g.B + b) * g.cap + (my_fl[k] << lgL) + sidx * kIdxSegUnits, stage, seg - lane,
                        scratch);
@@ -455,6 +459,7 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_aggregate(IdxGeom g, IdxCols 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const uint32_t E = g.S2;
   // sum[NV][E] i64 | rows[E] u32 | cnt[NV][E] u32 | min[NV][E] i32 | max[NV][E] i32 | lcnt[B] u32
+  constexpr int NVA = NV > 0 ? NV : 1;
   unsigned long long* l_sum = (unsigned long long*)smem_raw;
   uint32_t* l_rows = (uint32_t*)(l_sum + (size_t)NV * E);
   uint32_t* l_cnt = l_rows + E;
@@ -463,9 +468,10 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_aggregate(IdxGeom g, IdxCols 
   uint32_t* lcnt = (uint32_t*)(l_max + (MM ? (size_t)NV * E : 0));
   const int t = threadIdx.x, G = gridDim.x;
   const int R = (int)g.R;
-  bool vnull[NV];
+  bool vnull[NVA];
 #pragma unroll
   for (int v = 0; v < NV; ++v) vnull[v] = c.val_nullable[v] != 0;
+  (void)vnull;
   for (int it = 0;; ++it) {
     const int u = blockIdx.x + G * it;
     const int pp = u / R, r = u % R;
@@ -508,9 +514,14 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_aggregate(IdxGeom g, IdxCols 
           }
         }
       };
-      // a unit of the run = 16 bytes = one (RS = 0) or two (RS = 1) records; `n` counts records
+      // a unit of the run = 16 bytes = one (RS = 0), two (RS = 1) or four (RS = 2) records; `n` counts records
       auto unit = [&](const v4i32& q, uint32_t rec0, uint32_t n) {
-        if (RS) {
+        if (RS == 2) {
+          if (rec0 < n) one((uint32_t)q.x, 0, 0, 0);
+          if (rec0 + 1 < n) one((uint32_t)q.y, 0, 0, 0);
+          if (rec0 + 2 < n) one((uint32_t)q.z, 0, 0, 0);
+          if (rec0 + 3 < n) one((uint32_t)q.w, 0, 0, 0);
+        } else if (RS) {
           if (rec0 < n) one((uint32_t)q.x, q.y, 0, 0);
           if (rec0 + 1 < n) one((uint32_t)q.z, q.w, 0, 0);
         } else if (rec0 < n) {
@@ -523,7 +534,7 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_aggregate(IdxGeom g, IdxCols 
         const uint32_t n = lcnt[b];
         if (!n) continue;
         const v4i32* run = scratch + ((size_t)pp * g.B + b) * g.cap;
-        const uint32_t n_units = (n + (uint32_t)RS) >> RS;
+        const uint32_t n_units = (n + ((1u << RS) - 1u)) >> RS;
         const uint32_t last = n_units - 1;
         auto at = [&](uint32_t i) -> uint32_t { return i < last ? i : last; };  // clamped: always loadable
         v4i32 c0 = __builtin_nontemporal_load(run + at(lane)), c1 = __builtin_nontemporal_load(run + at(lane + 64)),
@@ -601,14 +612,8 @@ bool make_idx_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scra
   if (tune_knobs().flags & MI355Q_OPT_NO_IDX_PART) return false;
   if (!lds_describe(p, fv, ((int64_t)1 << 31) - 1, 0, &a, need)) return false;
   if (a.baseline || a.n_flt != 0 || a.n_keys < 1) return false;
-  if (a.n_vals == 0) {
-    // only COUNT(*) / key projections (Sort/S001-003: SELECT key, COUNT(*) ... GROUP BY key): the 8-byte record's value
-    // half carries the first key column again and no target reads it
-    a.n_vals = 1;
-    a.v[0].col = a.key_col[0];
-    a.v[0].type = MI355Q_INT32;
-    a.v[0].nullable = 0;
-  }
+  // (a.n_vals == 0: only COUNT(*) / key projections — Sort/S001-003: SELECT key, COUNT(*) ... GROUP BY key — 4-byte records
+  // that carry the entry index alone, an LDS table of row counts)
   if (p.entry_count <= 65536 || fv.n_frags < 1 || n_cus < 1) return false;
   if (fv.max_frag_rows > 0xfff00000ll) return false;
   for (int v = 0; v < a.n_vals; ++v) {
@@ -635,7 +640,7 @@ bool make_idx_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scra
   IdxGeom& g = h.g;
   g.nk = a.n_keys;
   g.nv = a.n_vals;
-  g.rs = a.n_vals == 1 ? 1 : 0;
+  g.rs = a.n_vals == 0 ? 2 : a.n_vals == 1 ? 1 : 0;
   g.d = (uint32_t)p.entry_count;
   // LDS entries of one unit
   const size_t entry_bytes = 4 + (size_t)g.nv * (12 + (g.mm ? 8 : 0));
@@ -714,7 +719,7 @@ hipError_t idx_launch_aggregate(const IdxPlanHost& h, const DevPlan& p, const v4
 template <int NK, int NV>
 hipError_t idx_run(const IdxPlanHost& h, const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, void* scratch,
                    int n_cus, hipStream_t s, LaunchStats* st) {
-  constexpr int RS = NV == 1 ? 1 : 0;
+  constexpr int RS = NV == 0 ? 2 : NV == 1 ? 1 : 0;
   v4i32* recs = (v4i32*)scratch;
   uint32_t* cnt = (uint32_t*)((char*)scratch + h.rec_bytes);
   char* spill_base = (char*)scratch + h.rec_bytes + h.cnt_bytes;
@@ -775,6 +780,9 @@ hipError_t launch_idx_partitioned(const DevPlan& p, const FragView& fv, int64_t*
   st->n_launches = 0;
 #define MQ_IDX_RUN(NK, NV) return idx_run<NK, NV>(h, p, fv, out, d_err, scratch, n_cus, s, st)
   switch (h.g.nk * 10 + h.g.nv) {
+    case 10: MQ_IDX_RUN(1, 0);
+    case 20: MQ_IDX_RUN(2, 0);
+    case 30: MQ_IDX_RUN(3, 0);
     case 11: MQ_IDX_RUN(1, 1);
     case 12: MQ_IDX_RUN(1, 2);
     case 13: MQ_IDX_RUN(1, 3);

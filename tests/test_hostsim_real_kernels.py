@@ -211,7 +211,7 @@ def test_partitioned_family_with_phase_1_next_to_phase_2(sim, oracle, shape, ove
 
 # ---- perfect-hash tables too large for LDS: the index-partitioned family (kernels_idx.hip) -------------------------------
 IDX_SHAPES = ["PHS005", "PHS006", "PHM004", "PHM005", "MSPHS003", "MSPHS006", "MSPHS007", "MSPHS008", "MSPHS010", "MSPHM003",
-              "MSPHM006"]
+              "MSPHM006", "S001", "S002"]      # (S00x: COUNT(*) only — 4-byte records that carry the entry index alone)
 
 
 @pytest.mark.parametrize("name", IDX_SHAPES)
@@ -252,6 +252,33 @@ def test_idx_partitioned_family_in_several_chunks_and_with_spills(sim, oracle):
         assert rs.report.kernel_name.decode() == "k_idx_scatter", rs.report.kernel_name
         assert rs.report.n_launches >= 2, rs.report.n_launches
         assert rs.report.spilled_rows > 0
+
+
+def test_idx_partitioned_family_count_only_records(sim, oracle):
+    """COUNT(*) / key projections only: 4-byte records that carry the entry index alone (four per 16-byte unit: fragments whose
+    record counts leave every remainder), one to three key columns with NULL keys, a hot entry that spills, several chunks —
+    with 8-byte slots (bigint_count) and with the 4-byte-slot layout the reference gives this shape"""
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(78)
+    n = 260_003
+    k0 = rng.integers(1, 90_001, n).astype(np.int32)
+    k0[rng.random(n) < 0.35] = 4242
+    k0[rng.random(n) < 0.01] = np.iinfo(np.int32).min
+    k1 = rng.integers(0, 3, n).astype(np.int32)
+    k2 = rng.integers(-1, 1, n).astype(np.int32)
+    descs = [InputColDescriptor(capi.INT32, True, ExpressionRange(True, 1, 90_000, True)),
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2)),
+             InputColDescriptor(capi.INT32, True, ExpressionRange(True, -1, 0, False))]
+    cuts = [0, 50_001, 100_003, 180_006, n]
+    frags = [[k0[a:b], k1[a:b], k2[a:b]] for a, b in zip(cuts[:-1], cuts[1:])]
+    for group, big in (([0], True), ([0], False), ([0, 1], True), ([1, 0, 2], True)):
+        targets = [TargetExpr(capi.PROJECT_KEY, g) for g in range(len(group))] + [TargetExpr(capi.COUNT)]
+        ra = RelAlgExecutionUnit(descs, targets, [], group, max_groups_buffer_entry_guess=600_000, bigint_count=big, num_tuples=n)
+        case = cases_mod.Case("idx_count_only", ra, frags)
+        rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=6 << 20)
+        assert rs.report.kernel_name.decode() == "k_idx_scatter", (group, big, rs.report.kernel_name)
+        assert rs.report.n_launches >= 2, rs.report.n_launches
+        assert len(group) > 1 or rs.report.spilled_rows > 0, rs.report.spilled_rows      # (one key: the hot entry's runs overflow)
 
 
 def test_idx_partitioned_family_reports_a_key_outside_its_range(sim, oracle):
