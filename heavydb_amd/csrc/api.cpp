@@ -3083,12 +3083,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     // (skipping the windows over large inputs was measured and is worse: with <= 65536 entries the families behind them
     // are the direct global-atomic members — BH007 at 1 B rows: 29.6 ms in eight windows, 638 ms without,
     // profiles/r04_refbench_1b_call14.jsonl)
-    // (four windows first where the entry count allows; eight are then the rung after)
-    const bool eight_left = (o.flags & MI355Q_OPT_LDS_BASELINE_WINDOWS) && !(o.flags & MI355Q_OPT_LDS_BASELINE_WINDOWS8) &&
-                            lds_baseline_windows_of_third_attempt(q.entry_count) < 8;
     o2.flags |= !(o.flags & MI355Q_OPT_LDS_BASELINE_LARGE)     ? MI355Q_OPT_LDS_BASELINE_LARGE
                 : !(o.flags & MI355Q_OPT_LDS_BASELINE_WINDOWS) ? MI355Q_OPT_LDS_BASELINE_WINDOWS
-                : eight_left                                   ? MI355Q_OPT_LDS_BASELINE_WINDOWS8
                                                                : MI355Q_OPT_NO_LDS_BASELINE;
     return execute_impl(plan, in, &o2, out, report, nullptr, nullptr);
   }

@@ -119,8 +119,6 @@ hipError_t launch_perfect_twin_emit(const DevPlan& pf, const DevPlan& ps, int id
 hipError_t launch_join_gather(const DevPlan& p, int n_inner, const int32_t* inner_col, const int32_t* dst_col, const int32_t* width,
                               const int64_t* null_pat, int flag_col, int nc2, const int8_t* const* d_cols, const int64_t* d_num_rows,
                               int n_frags, int64_t max_frag_rows, int n_cus, hipStream_t s);
-// windows the LDS group-by's third attempt on a baseline table takes (4 where the entry count says the groups fit, else 8)
-uint32_t lds_baseline_windows_of_third_attempt(int64_t entry_count);
 // GROUP BY CAST(int column AS DOUBLE | FLOAT): entries of the integer-keyed perfect table re-keyed and merged into the baseline table
 hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, int translate,
                                 int64_t key_min, int64_t null_key, const int64_t* sub, int64_t* fin, int32_t* d_err,

@@ -1046,6 +1046,4 @@ hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out
   return hipGetLastError();
 }
 
-uint32_t lds_baseline_windows_of_third_attempt(int64_t entry_count) { return lds_third_attempt_windows(entry_count); }
-
 }  // namespace mq

@@ -14,12 +14,7 @@ constexpr int kLdsVals = 3;              // value columns
 constexpr int kLdsKeys = 3;              // key columns (perfect hash)
 constexpr uint32_t kLdsHashSmall = 256;  // slots of one baseline replica, first attempt (many replicas)
 constexpr uint32_t kLdsHashMax = 4096;   // ... at most, second attempt
-constexpr uint32_t kLdsMaxWindows = 8;
-// windows of the third attempt on a baseline table: four when the entry count is an estimate (> the reference's default guess
-// of 16 384) whose groups (entries / 2) fill four windows of kLdsHashMax slots to at most 0.7, else eight
-inline uint32_t lds_third_attempt_windows(int64_t entry_count) {
-  return entry_count > 16384 && entry_count / 2 <= (int64_t)(4 * 4096 * 0.7) ? 4u : 8u;
-}   // windows of a table that does not fit one LDS (the columns are read once per window)
+constexpr uint32_t kLdsMaxWindows = 8;   // windows of a table that does not fit one LDS (the columns are read once per window)
 
 struct LdsVal {
   int32_t col, type, nullable;           // type: MI355Q_INT32 / _INT64 / _DOUBLE (plain)
@@ -97,14 +92,9 @@ inline bool lds_describe(const DevPlan& p, const FragView& fv, int64_t max_entri
     // — the caller's NDV guess x 2 — and skip the first: the reference's default guess is 16 384 whatever the data holds
     // (g_default_max_groups_buffer_entry_guess, Execute.cpp:111), so BH001's ten groups got three windows and ran 2.4 x
     // slower, 5.5 -> 13.5 ms per 1 B rows, profiles/r04_refbench_sel_call5.jsonl; reverted.)
-    // The windows attempt DOES look at the entry count, in one direction only: an estimate (not the default guess) that
-    // says the groups fill four windows to at most 0.7 gets four — the columns are read four times instead of eight — and
-    // eight remain the next rung (BH007, 10 K groups of a BIGINT stride key: 29.6 ms in eight windows at 1 B rows).
     const uint32_t fl = knob_flags;
-    a.entries = (fl & (MI355Q_OPT_LDS_BASELINE_LARGE | MI355Q_OPT_LDS_BASELINE_WINDOWS | MI355Q_OPT_LDS_BASELINE_WINDOWS8)) ? kLdsHashMax
-                                                                                                                      : kLdsHashSmall;
-    if (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS8) a.windows = kLdsMaxWindows;
-    else if (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) a.windows = lds_third_attempt_windows(p.entry_count);
+    a.entries = (fl & (MI355Q_OPT_LDS_BASELINE_LARGE | MI355Q_OPT_LDS_BASELINE_WINDOWS)) ? kLdsHashMax : kLdsHashSmall;
+    if (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) a.windows = kLdsMaxWindows;
   } else {
     return false;
   }

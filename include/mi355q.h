@@ -475,8 +475,6 @@ typedef struct mi355q_exec_options {
                                             uses 256-slot replicas, many of them, for tables with a handful of groups) */
 #define MI355Q_OPT_LDS_BASELINE_WINDOWS 32u /* ... third attempt: the groups spread over 8 windows (classes of a key hash),
                                             one workgroup per window and row stripe, the largest replica each */
-#define MI355Q_OPT_LDS_BASELINE_WINDOWS8 256u /* ... the eight-window attempt proper: the third attempt takes FOUR windows where the
-                                                 table's entry count (2 x the caller's NDV estimate) says the groups fit them */
 #define MI355Q_OPT_LDS_GENERIC_MEMBER 64u /* few-groups LDS GROUP BY: the run-time-role member even where a typed member
                                             (roles compiled in) applies (tests compare the two) */
 #define MI355Q_OPT_NO_IDX_PART 128u       /* large perfect-hash tables: not the index-partitioned family (the library sets this

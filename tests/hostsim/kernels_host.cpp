@@ -176,16 +176,12 @@ bool lds_groupby_eligible(const DevPlan& p, const FragView&, int) {
   }
   return plain_aggs(p, 3);
 }
-uint32_t lds_baseline_windows_of_third_attempt(int64_t entry_count) {   // (the rule of lds_args.h lds_third_attempt_windows)
-  return entry_count > 16384 && entry_count / 2 <= (int64_t)(4 * 4096 * 0.7) ? 4u : 8u;
-}
 hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int, hipStream_t,
                               LaunchStats* st) {
   finish(p, fv, out, d_err, st, "k_groupby_lds", 4, F_LDS_GROUPBY);
   if (p.desc_type == MI355Q_GROUP_BY_BASELINE_HASH) {
     const uint32_t fl = tune_knobs().flags;
-    const int64_t cap = (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS8) ? 8 * (int64_t)g_cfg.lds_large_groups
-                        : (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) ? (int64_t)lds_baseline_windows_of_third_attempt(p.entry_count) * g_cfg.lds_large_groups
+    const int64_t cap = (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) ? 8 * (int64_t)g_cfg.lds_large_groups
                         : (fl & MI355Q_OPT_LDS_BASELINE_LARGE) ? g_cfg.lds_large_groups : g_cfg.lds_small_groups;
     if (live_entries(p, out) > cap) {
       // a replica ran out of room: what the table holds now is not a result

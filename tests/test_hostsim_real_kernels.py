@@ -101,17 +101,6 @@ def test_windowed_baseline_gives_up_beyond_eight_windows(sim, oracle):
     flow._check(oracle, case)
 
 
-def test_windowed_baseline_takes_four_windows_where_the_estimate_allows(sim, oracle):
-    """the third attempt on a baseline table: four windows when the entry count (2 x an NDV estimate, beyond the default guess)
-    says the groups fit them — BH007's shape, 10 K groups in a 20 K-entry table — and eight as the rung after when the estimate
-    was too low (13 K groups announced as 10 K)"""
-    for groups, guess in ((10_000, 20_000), (13_000, 20_500), (10_000, 16_384)):
-        case = flow._baseline_case(oracle, groups, n_rows=60_000)
-        case.ra.max_groups_buffer_entry_guess = guess
-        rs = flow._check(oracle, case)
-        assert rs.report.kernel_name.decode() == "k_groupby_lds", (groups, guess, rs.report.kernel_name)
-
-
 # ---- mi355q_explain: the route of every reference benchmark query at the benchmark's own sizes, without a GPU
 def _explain(name, n_rows):
     from heavydb_amd.executor import Executor
