@@ -92,6 +92,9 @@ inline bool lds_describe(const DevPlan& p, const FragView& fv, int64_t max_entri
     // — the caller's NDV guess x 2 — and skip the first: the reference's default guess is 16 384 whatever the data holds
     // (g_default_max_groups_buffer_entry_guess, Execute.cpp:111), so BH001's ten groups got three windows and ran 2.4 x
     // slower, 5.5 -> 13.5 ms per 1 B rows, profiles/r04_refbench_sel_call5.jsonl; reverted.)
+    // (Also measured: FOUR windows as the third attempt where an NDV estimate says the groups fill them to 0.61 — BH007,
+    // 10 K groups: 32.2 ms against 29.6 ms in eight, profiles/r04_refbench_bh007_four_windows_call20.jsonl: the four-window
+    // tables overflow their probe limit and the eight-window rung runs after all; reverted.)
     const uint32_t fl = knob_flags;
     a.entries = (fl & (MI355Q_OPT_LDS_BASELINE_LARGE | MI355Q_OPT_LDS_BASELINE_WINDOWS)) ? kLdsHashMax : kLdsHashSmall;
     if (fl & MI355Q_OPT_LDS_BASELINE_WINDOWS) a.windows = kLdsMaxWindows;
