@@ -149,6 +149,8 @@ struct DeviceCtx {
   int64_t proj_bytes = 0;
   void* gather = nullptr;   // dense temporary columns of a grouped join's inner side (execute_join_gather; may nest inside proj's step)
   int64_t gather_bytes = 0;
+  void* lattice = nullptr;  // dense INT32 key columns of a lattice-keyed step (execute_affine_twin; may nest inside both)
+  int64_t lattice_bytes = 0;
   void* scratch = nullptr;
   int64_t scratch_bytes = 0;
   void* meta = nullptr;
@@ -336,6 +338,9 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   if (ctx.gather) (void)hipFree(ctx.gather);
   ctx.gather = nullptr;
   ctx.gather_bytes = 0;
+  if (ctx.lattice) (void)hipFree(ctx.lattice);
+  ctx.lattice = nullptr;
+  ctx.lattice_bytes = 0;
   if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
   ctx.stream = nullptr;
   for (hipEvent_t e : ctx.events) (void)hipEventDestroy(e);
@@ -1885,6 +1890,298 @@ int32_t execute_perfect_twin(const mi355q_plan* plan, const mi355q_inputs* in, c
   return MI355Q_OK;
 }
 
+// Baseline steps whose key columns lie on a LATTICE — key = min + stride x i — with few lattice points: the reference
+// benchmark's BIGINT columns x10k_s10k / x100k_s10k / x1m_s10k (multiples of 10 000: BaselineHash/BH007-010,
+// MultiStep/MSBS006-007).  Their RANGE is far too wide for a perfect hash (GroupByAndAggregate.cpp:232-365 sees max - min),
+// so the reference — and the plain route here — hash 8-byte keys.  The stride is found on the first fragment (k_key_gcd), every
+// row's key is then rewritten as its lattice index i in a dense INT32 column and CHECKED (k_affine_keys: a key off the
+// lattice or outside the range gives the route up, nothing is assumed about the data), the step runs grouped by those
+// columns on a library-owned perfect-hash twin (typed LDS members / the index-partitioned family: ONE exchange of 8- or
+// 16-byte records instead of 16-byte records per value column), and k_affine_twin_emit re-keys the twin's entries into the
+// baseline table of the stated plan.  mi355q_explain cannot see the data and names the plain route for these shapes.
+int32_t execute_affine_twin(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o, const mi355q_qmd& q,
+                            int n_cus, mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
+  if (reserved || q.desc_type != MI355Q_GROUP_BY_BASELINE_HASH || plan->n_group_cols < 1 || plan->n_group_cols > 3 ||
+      plan->join_outer_col >= 0 || plan->n_exprs != 0 || q.slot_width != 8 || q.output_columnar ||
+      plan->output_columnar_hint != 0 || o.kernel_variant == 1 || o.force_generic)
+    return kNotTaken;
+  const int nc = plan->n_cols, nf = in->n_frags, ng = plan->n_group_cols;
+  int64_t total_rows = 0, max_frag_rows = 0;
+  int first = -1;
+  for (int f = 0; f < nf; ++f) {
+    if (in->num_rows[f] < 0) return kNotTaken;
+    total_rows += in->num_rows[f];
+    max_frag_rows = std::max(max_frag_rows, in->num_rows[f]);
+    if (first < 0 && in->num_rows[f] > 0) first = f;
+  }
+  // (kernel_variant 2 = "the large-input members": how the tests reach this route with small tables)
+  if (first < 0 || (o.kernel_variant != 2 && total_rows < kIdxPartMinRows)) return kNotTaken;
+  bool proj[MI355Q_MAX_GROUP_COLS];
+  int n_proj = 0;
+  for (int g = 0; g < ng; ++g) {
+    const int c = plan->group_cols[g];
+    if (c < 0 || c >= nc) return kNotTaken;
+    const mi355q_col_desc& cd = plan->cols[c];
+    const mi355q_range& r = plan->col_ranges[c];
+    if ((cd.type != MI355Q_INT32 && cd.type != MI355Q_INT64) || cd.encoding != MI355Q_ENC_NONE ||
+        (cd.logical_type != 0 && cd.logical_type != cd.type) || !r.valid || r.bucket != 0 || r.min > r.max ||
+        (r.has_nulls && !cd.nullable))
+      return kNotTaken;
+    // BIGINT keys, and INT keys over a range too wide for the twin on their own, are looked at for a stride
+    proj[g] = cd.type == MI355Q_INT64 || (__int128)r.max - (__int128)r.min >= ((__int128)1 << 20);
+    n_proj += proj[g] ? 1 : 0;
+  }
+  if (n_proj == 0 || nc + n_proj > MI355Q_MAX_COLS) return kNotTaken;
+  // only where the twin's step is the typed LDS members' or the index-partitioned family's work (no qual, plain INT value
+  // columns: checked here before anything is launched, and on the derived plan below): every other baseline step — the
+  // headline's filtered AVG(double) among them — keeps its own family and pays nothing for this route
+  if (plan->n_quals != 0) return kNotTaken;
+  for (int t = 0; t < plan->n_targets; ++t) {
+    const mi355q_target& tg = plan->targets[t];
+    if (tg.agg == MI355Q_PROJECT_KEY || tg.col < 0) continue;
+    if (tg.table != 0 || tg.col >= nc || tg.agg == MI355Q_COUNT_IF || tg.agg == MI355Q_SUM_IF) return kNotTaken;
+    const mi355q_col_desc& vd = plan->cols[tg.col];
+    if (vd.type != MI355Q_INT32 || vd.encoding != MI355Q_ENC_NONE || (vd.logical_type != 0 && vd.logical_type != vd.type)) return kNotTaken;
+  }
+
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  // ---- the stride of every looked-at key column, from the first non-empty fragment
+  // (a sample: the first 4 M rows — the stride it gives is verified on every row below, a coarser lattice only gives the route up)
+  constexpr int kGcdBlocks = 256;  // partial strides per column handed to the host
+  constexpr int64_t kGcdScratch = 64 * 256;
+  DevWord gw;
+  HIP_TRY(hipMalloc(&gw.p, sizeof(unsigned long long) * (kGcdScratch + kGcdBlocks * MI355Q_MAX_GROUP_COLS) + 64));
+  unsigned long long* g_scr = (unsigned long long*)gw.p;
+  unsigned long long* g_out = g_scr + kGcdScratch;
+  std::vector<unsigned long long> h_g((size_t)kGcdBlocks * MI355Q_MAX_GROUP_COLS);
+  for (int gcol = 0, k = 0; gcol < ng; ++gcol) {
+    if (!proj[gcol]) continue;
+    const int c = plan->group_cols[gcol];
+    HIP_TRY(launch_key_gcd(in->col_buffers[(size_t)first * nc + c], plain_width(plan->cols[c].type),
+                           std::min<int64_t>(in->num_rows[first], (int64_t)4 << 20), plan->col_ranges[c].min, plan->cols[c].nullable, g_scr,
+                           g_out + (size_t)k * kGcdBlocks, s));
+    ++k;
+  }
+  HIP_TRY(hipMemcpyAsync(h_g.data(), g_out, sizeof(unsigned long long) * kGcdBlocks * n_proj, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  // ---- the derived plan
+  mi355q_plan p2 = *plan;
+  int32_t src_col[MI355Q_MAX_GROUP_COLS], dst_col[MI355Q_MAX_GROUP_COLS], width[MI355Q_MAX_GROUP_COLS], nullable[MI355Q_MAX_GROUP_COLS];
+  int64_t kmin[MI355Q_MAX_GROUP_COLS], stride[MI355Q_MAX_GROUP_COLS], card[MI355Q_MAX_GROUP_COLS];
+  int64_t base_of[MI355Q_MAX_GROUP_COLS], stride_of[MI355Q_MAX_GROUP_COLS];
+  int32_t translate[MI355Q_MAX_GROUP_COLS], key_type[MI355Q_MAX_GROUP_COLS];
+  __int128 entries = 1;
+  for (int gcol = 0, k = 0; gcol < ng; ++gcol) {
+    const int c = plan->group_cols[gcol];
+    const mi355q_col_desc& cd = plan->cols[c];
+    const mi355q_range& r = plan->col_ranges[c];
+    translate[gcol] = cd.nullable && (ng == 1 || r.has_nulls);  // (build_dev_plan's rule for the twin's keys)
+    key_type[gcol] = col_type_code(cd);
+    base_of[gcol] = r.min;
+    stride_of[gcol] = 1;
+    __int128 points = (__int128)r.max - (__int128)r.min + 1;
+    if (proj[gcol]) {
+      unsigned long long gg = 0;
+      for (int b = 0; b < kGcdBlocks; ++b) {
+        unsigned long long x = h_g[(size_t)k * kGcdBlocks + b], y = gg;
+        while (y) {
+          const unsigned long long t = x % y;
+          x = y;
+          y = t;
+        }
+        gg = x;
+      }
+      if (gg == 0) gg = 1;  // (every key of the fragment is the minimum, or NULL)
+      if (gg > (unsigned long long)INT64_MAX) return kNotTaken;
+      points = ((__int128)r.max - (__int128)r.min) / (__int128)gg + 1;
+      if (points >= ((__int128)1 << 30)) return kNotTaken;
+      stride_of[gcol] = (int64_t)gg;
+      src_col[k] = c;
+      dst_col[k] = nc + k;
+      width[k] = plain_width(cd.type);
+      nullable[k] = cd.nullable;
+      kmin[k] = r.min;
+      stride[k] = (int64_t)gg;
+      card[k] = (int64_t)points;
+      p2.cols[nc + k] = mi355q_col_desc{MI355Q_INT32, cd.nullable, MI355Q_ENC_NONE, 0};
+      p2.col_ranges[nc + k] = mi355q_range{1, r.has_nulls, 0, (int64_t)points - 1, 0.0, 0.0, 0};
+      p2.group_cols[gcol] = nc + k;
+      ++k;
+    } else if (points >= ((__int128)1 << 30) || r.min <= -((int64_t)1 << 30) || r.min >= ((int64_t)1 << 30)) {
+      return kNotTaken;
+    }
+    entries *= points + (r.has_nulls ? 1 : 0);
+    if (entries > (__int128)kTwinMaxEntries) return kNotTaken;
+  }
+  const int nc2 = nc + n_proj;
+  p2.n_cols = nc2;
+  PerfectTwinScope twin(kTwinMaxEntries);
+  mi355q_qmd q2;
+  if (qmd_init(p2, &q2) != MI355Q_OK) return kNotTaken;
+  if (q2.desc_type != MI355Q_GROUP_BY_PERFECT_HASH || q2.slot_width != 8 || q2.output_columnar ||
+      q2.entry_count * (int64_t)q2.row_size > ((int64_t)4 << 30))
+    return kNotTaken;
+  for (int t = 0; t < plan->n_targets; ++t) {
+    const int sf = q.target_slot[t], ss = q2.target_slot[t];
+    if (plan->targets[t].agg == MI355Q_PROJECT_KEY) {
+      if (sf >= 0) return kNotTaken;  // (baseline: projections are read from the key columns)
+      continue;
+    }
+    if (sf < 0 || ss < 0) return kNotTaken;
+    for (int j = 0; j < (plan->targets[t].agg == MI355Q_AVG ? 2 : 1); ++j)
+      if (q.init_vals[sf + j] != q2.init_vals[ss + j]) return kNotTaken;
+  }
+  {  // the twin's step must be one of the two families this route is for
+    DevPlan d2;
+    if (build_dev_plan(p2, q2, &d2) != MI355Q_OK) return kNotTaken;
+    std::vector<const void*> shape((size_t)nf * nc2);
+    for (int f = 0; f < nf; ++f) {
+      for (int c = 0; c < nc; ++c) shape[(size_t)f * nc2 + c] = in->col_buffers[(size_t)f * nc + c];
+      for (int k = 0; k < n_proj; ++k) shape[(size_t)f * nc2 + nc + k] = (const void*)(uintptr_t)256;  // (16-byte aligned, like the real chunks)
+    }
+    FragView fvh{nullptr, nullptr, shape.data(), in->num_rows, nf, nc2, total_rows, max_frag_rows};
+    if (!lds_groupby_eligible(d2, fvh, n_cus) && !idx_part_eligible(d2, fvh, n_cus)) return kNotTaken;
+  }
+  // ---- passes: lattice indices of a pass of fragments, the twin step on them
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const int64_t budget = std::min<int64_t>((int64_t)16 << 30, ((int64_t)free_b + ctx.lattice_bytes) / 3);
+  const int64_t row_bytes = 4 * (int64_t)n_proj, pad = 16 * (int64_t)n_proj;
+  int64_t pass_rows = std::max<int64_t>(budget / row_bytes, max_frag_rows);
+  if (o.pass_rows > 0) pass_rows = std::max<int64_t>(o.pass_rows, max_frag_rows);  // tests: several passes
+  if (pass_rows > total_rows) pass_rows = total_rows;
+  const int64_t tab_bytes = ((int64_t)sizeof(void*) * nf * nc2 + 255) & ~255ll;
+  const int64_t rows_bytes = ((int64_t)sizeof(int64_t) * nf + 255) & ~255ll;
+  const int64_t col_region = ((pass_rows * row_bytes + pad * nf) + 255) & ~255ll;
+  const int64_t need = col_region + tab_bytes + rows_bytes + 256;
+  if (ctx.lattice_bytes < need) {
+    if (ctx.lattice) (void)hipFree(ctx.lattice);
+    ctx.lattice = nullptr;
+    ctx.lattice_bytes = 0;
+    if (hipMalloc(&ctx.lattice, (size_t)need) != hipSuccess) {
+      (void)hipGetLastError();
+      return kNotTaken;
+    }
+    ctx.lattice_bytes = need;
+  }
+  char* base = (char*)ctx.lattice;
+  const int8_t** d_tab = (const int8_t**)(base + col_region);
+  int64_t* d_rows = (int64_t*)(base + col_region + tab_bytes);
+  int32_t* d_flag = (int32_t*)(base + col_region + tab_bytes + rows_bytes);
+  HIP_TRY(hipMemsetAsync(d_flag, 0, 64, s));
+  HIP_TRY(hipMemcpyAsync(d_rows, in->num_rows, sizeof(int64_t) * (size_t)nf, hipMemcpyHostToDevice, s));
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+  std::vector<const void*> cols2((size_t)nf * nc2);
+  mi355q_result* tw = nullptr;  // the twin table (all passes folded)
+  struct TwGuard {
+    mi355q_result*& r;
+    ~TwGuard() { if (r) mi355q_result_free(r); }
+  } twg{tw};
+  mi355q_exec_report acc{};
+  int pass = 0, f = 0;
+  while (f < nf) {
+    int f1 = f;
+    int64_t rows = 0, off = 0;
+    while (f1 < nf && (f1 == f || rows + in->num_rows[f1] <= pass_rows)) {
+      for (int c = 0; c < nc; ++c) cols2[(size_t)(f1 - f) * nc2 + c] = in->col_buffers[(size_t)f1 * nc + c];
+      for (int k = 0; k < n_proj; ++k) {
+        cols2[(size_t)(f1 - f) * nc2 + nc + k] = base + off;
+        off += (in->num_rows[f1] * 4 + 15) & ~15ll;
+      }
+      rows += in->num_rows[f1];
+      ++f1;
+    }
+    if (off > col_region) return MI355Q_ERR_OUT_OF_GPU_MEM;  // (cannot happen: the region is sized for it)
+    const int pnf = f1 - f;
+    HIP_TRY(hipMemcpyAsync(d_tab, cols2.data(), sizeof(void*) * (size_t)pnf * nc2, hipMemcpyHostToDevice, s));
+    HIP_TRY(launch_affine_keys(n_proj, src_col, dst_col, width, nullable, kmin, stride, card, nc2, d_tab, d_rows + f, pnf, max_frag_rows,
+                               d_flag, n_cus, s));
+    int32_t h_flag = 0;
+    HIP_TRY(hipMemcpyAsync(&h_flag, d_flag, sizeof(h_flag), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (h_flag) return kNotTaken;  // a key off the lattice of the first fragment: the plain route
+    mi355q_inputs in2 = *in;
+    in2.n_frags = pnf;
+    in2.col_buffers = cols2.data();
+    in2.num_rows = in->num_rows + f;
+    mi355q_exec_options o2 = o;
+    o2.stream = s;
+    o2.out_buffer = nullptr;
+    mi355q_result* r2 = nullptr;
+    mi355q_exec_report rep2{};
+    if (int32_t e2 = mi355q_execute(&p2, &in2, &o2, &r2, &rep2)) {
+      if (e2 == MI355Q_ERR_UNSUPPORTED || e2 == MI355Q_ERR_OUT_OF_GPU_MEM || e2 < 0 || e2 == MI355Q_ERR_OUT_OF_SLOTS) return kNotTaken;
+      return e2;
+    }
+    if (r2->qmd.desc_type != MI355Q_GROUP_BY_PERFECT_HASH || r2->qmd.slot_width != 8 || r2->qmd.output_columnar ||
+        r2->qmd.entry_count != q2.entry_count) {
+      mi355q_result_free(r2);
+      return kNotTaken;
+    }
+    if (pass == 0) {
+      tw = r2;
+      std::snprintf(acc.kernel_name, sizeof(acc.kernel_name), "%s", rep2.kernel_name);
+      acc.variant = rep2.variant;
+    } else {
+      const int32_t er = mi355q_result_reduce(tw, r2, s);
+      mi355q_result_free(r2);
+      if (er) return er;
+    }
+    acc.kernel_ms += rep2.kernel_ms;
+    acc.n_launches += rep2.n_launches + 1;
+    acc.spilled_rows += rep2.spilled_rows;
+    f = f1;
+    ++pass;
+  }
+  mi355q_result* res = nullptr;
+  if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;
+  struct ResGuard {
+    mi355q_result* r;
+    ~ResGuard() { if (r) mi355q_result_free(r); }
+  } rg{res};
+  HIP_TRY(launch_init_buffer(res->buf, q.entry_count, make_row_init(q), s));
+  DevWord err;
+  HIP_TRY(hipMalloc(&err.p, 64));
+  HIP_TRY(hipMemsetAsync(err.p, 0, 64, s));
+  HIP_TRY(launch_affine_twin_emit(res->dplan, tw->dplan, tw->qmd.idx_target_as_key, ng, translate, key_type, q2.group_min, q2.group_card,
+                                  q2.group_null_key, base_of, stride_of, tw->buf, res->buf, (int32_t*)err.p, s));
+  if (ev1) HIP_TRY(hipEventRecord(ev1, s));
+  int32_t h_err = 0;
+  HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(h_err), hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  if (h_err) return h_err;
+  if (report) {
+    *report = acc;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->n_launches = acc.n_launches + 1;
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  rg.r = nullptr;
+  *out = res;
+  return MI355Q_OK;
+}
+
 // GROUP BY CAST(<plain integer column> AS DOUBLE | FLOAT) — the reference benchmark's BaselineHash and MultiStep
 // BaselineHash shapes (Benchmarks/synthetic_benchmark/queries/BaselineHash/BH001-006.sql, MultiStep/MSBS001-005.sql).  A
 // floating-point key always takes the baseline layout (GroupByAndAggregate.cpp:232-365: getExprRangeInfo is FloatingPoint),
@@ -2676,6 +2973,12 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     const int32_t e = execute_perfect_twin(plan, in, o, q, n_cus, out, report, reserved);
     if (e != kNotTaken) return e;
     if (t_route) t_route->resize(mark);
+    *out = nullptr;
+  }
+  if (!o.force_generic && in->n_frags > 0 && !pend && !reserved) {
+    // (before the LDS attempt on a small baseline table too: BH007's 10 K lattice points are a typed LDS member's work)
+    const int32_t e = execute_affine_twin(plan, in, o, q, n_cus, out, report, reserved);
+    if (e != kNotTaken) return e;
     *out = nullptr;
   }
   if (!o.force_generic && in->n_frags > 0 && !lds_direct) {

@@ -119,6 +119,18 @@ hipError_t launch_perfect_twin_emit(const DevPlan& pf, const DevPlan& ps, int id
 hipError_t launch_join_gather(const DevPlan& p, int n_inner, const int32_t* inner_col, const int32_t* dst_col, const int32_t* width,
                               const int64_t* null_pat, int flag_col, int nc2, const int8_t* const* d_cols, const int64_t* d_num_rows,
                               int n_frags, int64_t max_frag_rows, int n_cus, hipStream_t s);
+// baseline keys on a lattice (key = min + stride x i): the stride of a column's first fragment, i as dense INT32 columns (verified row
+// by row: *d_flag raised for a key off the lattice), the twin's entries re-keyed into the baseline table
+// (scratch: 64 * 256 words; out256: 256 partial strides the host folds)
+hipError_t launch_key_gcd(const void* col, int width, int64_t n, int64_t kmin, int nullable, unsigned long long* scratch,
+                          unsigned long long* out256, hipStream_t s);
+hipError_t launch_affine_keys(int n, const int32_t* src_col, const int32_t* dst_col, const int32_t* width, const int32_t* nullable,
+                              const int64_t* kmin, const int64_t* stride, const int64_t* card, int nc2, const int8_t* const* d_cols,
+                              const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_flag, int n_cus, hipStream_t s);
+hipError_t launch_affine_twin_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int n_keys, const int32_t* translate,
+                                   const int32_t* key_type, const int64_t* twin_min, const int64_t* twin_card, const int64_t* twin_null,
+                                   const int64_t* base, const int64_t* stride, const int64_t* sub, int64_t* fin, int32_t* d_err,
+                                   hipStream_t s);
 // GROUP BY CAST(int column AS DOUBLE | FLOAT): entries of the integer-keyed perfect table re-keyed and merged into the baseline table
 hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int cast_to_float, int translate,
                                 int64_t key_min, int64_t null_key, const int64_t* sub, int64_t* fin, int32_t* d_err,

@@ -968,6 +968,130 @@ __global__ __launch_bounds__(kBlock) void k_perfect_twin_emit(DevPlan pf, DevPla
   }
 }
 
+// ---- baseline steps whose integer keys lie on a LATTICE (key = min + stride x i: the reference benchmark's BIGINT columns
+// x10k_s10k ... hold multiples of 10 000, no range the planner could index) — api.cpp execute_affine_twin.  k_key_gcd finds
+// the stride of a key column on the first fragment; k_affine_keys writes i as a dense INT32 column and VERIFIES every row of
+// every fragment (a key off the lattice or outside the range raises the flag: the route is given up, nothing is guessed);
+// the step runs grouped by those INT32 columns on a perfect-hash twin; k_affine_twin_emit re-keys its entries.
+MQ_D uint64_t gcd_u64(uint64_t a, uint64_t b) {
+  while (b) {
+    const uint64_t t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+// (two stages without barriers or shuffles: one partial per lane, then 256 lanes fold 256 partials each; the host folds the rest)
+__global__ __launch_bounds__(kBlock) void k_key_gcd(const int8_t* __restrict__ col, int width, int64_t n, int64_t kmin, int nullable,
+                                                     unsigned long long* __restrict__ per_lane) {
+  uint64_t g = 0;
+  const int64_t null_v = width == 4 ? (int64_t)INT32_MIN : INT64_MIN;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+    const int64_t v = width == 4 ? (int64_t)((const int32_t*)col)[i] : ((const int64_t*)col)[i];
+    if (nullable && v == null_v) continue;
+    const uint64_t d = (uint64_t)v - (uint64_t)kmin;
+    if (d == 0) continue;
+    g = g == 0 ? d : (d % g == 0 ? g : gcd_u64(g, d));
+  }
+  per_lane[(size_t)blockIdx.x * kBlock + threadIdx.x] = g;
+}
+__global__ __launch_bounds__(kBlock) void k_key_gcd_fold(const unsigned long long* __restrict__ per_lane, int n_per_lane,
+                                                          unsigned long long* __restrict__ out) {
+  uint64_t g = 0;
+  for (int i = threadIdx.x; i < n_per_lane; i += kBlock) {
+    const uint64_t o = per_lane[i];
+    g = g == 0 ? o : (o == 0 ? g : gcd_u64(g, o));
+  }
+  out[threadIdx.x] = g;
+}
+
+struct AffineKeys {
+  int32_t n, nc2, pad_[2];
+  int32_t src_col[MI355Q_MAX_GROUP_COLS], dst_col[MI355Q_MAX_GROUP_COLS], width[MI355Q_MAX_GROUP_COLS], nullable[MI355Q_MAX_GROUP_COLS];
+  int64_t kmin[MI355Q_MAX_GROUP_COLS], stride[MI355Q_MAX_GROUP_COLS], card[MI355Q_MAX_GROUP_COLS];  // card: lattice points
+};
+__global__ __launch_bounds__(kBlock) void k_affine_keys(AffineKeys ak, const int8_t* const* __restrict__ cols,
+                                                         const int64_t* __restrict__ num_rows, int n_frags, int32_t* __restrict__ d_flag) {
+  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kBlock;
+  bool off_lattice = false;
+  for (int f = 0; f < n_frags; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * ak.nc2;
+    const int64_t n = num_rows[f];
+    for (int64_t pos = gtid; pos < n; pos += gsize) {
+      for (int k = 0; k < ak.n; ++k) {
+        const int8_t* src = fc[ak.src_col[k]];
+        const int64_t v = ak.width[k] == 4 ? (int64_t)((const int32_t*)src)[pos] : ((const int64_t*)src)[pos];
+        const int64_t null_v = ak.width[k] == 4 ? (int64_t)INT32_MIN : INT64_MIN;
+        int32_t out;
+        if (ak.nullable[k] && v == null_v) {
+          out = INT32_MIN;
+        } else {
+          const uint64_t d = (uint64_t)v - (uint64_t)ak.kmin[k];
+          const uint64_t q = d / (uint64_t)ak.stride[k];
+          if (v < ak.kmin[k] || q * (uint64_t)ak.stride[k] != d || q >= (uint64_t)ak.card[k]) off_lattice = true;
+          out = (int32_t)(uint32_t)q;
+        }
+        ((int32_t*)const_cast<int8_t*>(fc[ak.dst_col[k]]))[pos] = out;
+      }
+    }
+  }
+  if (off_lattice) atomicExch(d_flag, 1);  // (rare: the route is given up)
+}
+
+struct AffineTwinArgs {
+  int32_t n_keys, idx_key_s;
+  int32_t translate[MI355Q_MAX_GROUP_COLS], key_type[MI355Q_MAX_GROUP_COLS];
+  // twin side: the key column's minimum, its cardinality (NULL slot included) and the translated NULL key; stated side: the
+  // key of twin value t is base + (t - twin_min) x stride
+  int64_t twin_min[MI355Q_MAX_GROUP_COLS], twin_card[MI355Q_MAX_GROUP_COLS], twin_null[MI355Q_MAX_GROUP_COLS];
+  int64_t base[MI355Q_MAX_GROUP_COLS], stride[MI355Q_MAX_GROUP_COLS];
+};
+__global__ __launch_bounds__(kBlock) void k_affine_twin_emit(DevPlan pf, DevPlan ps, AffineTwinArgs ta,
+                                                              const int64_t* __restrict__ sub, int64_t* __restrict__ fin,
+                                                              int32_t* __restrict__ d_err) {
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < ps.entry_count; e += stride) {
+    const int64_t* row_s = sub + e * ps.row_quad;
+    if (is_empty_row(ps, row_s, ta.idx_key_s)) continue;
+    const int64_t* slots_s = row_s + ps.key_quad;
+    int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};
+    int64_t rem = e;
+    for (int g = 0; g < ta.n_keys; ++g) {
+      const int64_t tk = ta.twin_min[g] + rem % ta.twin_card[g];
+      rem /= ta.twin_card[g];
+      keys[g] = ta.translate[g] && tk == ta.twin_null[g] ? int_null_of(ta.key_type[g])
+                                                          : ta.base[g] + (tk - ta.twin_min[g]) * ta.stride[g];
+    }
+    int64_t* slots_f;
+    if (ta.n_keys == 1) {
+      slots_f = baseline_find_or_insert(fin, (uint32_t)pf.entry_count, pf.row_quad, pf.key_width, keys[0]);
+    } else {
+      bool bad = false;
+      slots_f = baseline_find_or_insert_multi(fin, (uint32_t)pf.entry_count, pf.row_quad, pf.key_width, ta.n_keys, keys, &bad);
+      if (bad) {
+        atomicCAS(d_err, 0, MI355Q_ERR_INVALID_PLAN);
+        continue;
+      }
+    }
+    if (!slots_f) {
+      atomicCAS(d_err, 0, -1);  // out of group slots: the caller grows the table and retries
+      continue;
+    }
+    for (int i = 0; i < pf.n_targets; ++i) {
+      const DevTarget& tf = pf.targets[i];
+      const DevTarget& ts = ps.targets[i];
+      if (tf.slot < 0 || ts.slot < 0 || tf.agg == MI355Q_PROJECT_KEY) continue;  // (baseline: projections read the key columns)
+      int64_t win[2];
+      win[0] = slots_s[ts.slot];
+      win[1] = tf.agg == MI355Q_AVG ? slots_s[ts.slot + 1] : 0;
+      DevTarget lt = tf;
+      lt.slot = 0;
+      reduce_target<true>(lt, pf.init_vals + tf.slot, slots_f + tf.slot, win);
+    }
+  }
+}
+
 struct ZipMap {
   int32_t n;                          // slot copies
   int32_t src[MI355Q_MAX_SLOTS], dst[MI355Q_MAX_SLOTS];  // slot index in the run's row -> slot index in the final row
@@ -1421,6 +1545,55 @@ hipError_t launch_perfect_twin_emit(const DevPlan& pf, const DevPlan& ps, int id
     ta.null_key[g] = null_key[g];
   }
   hipLaunchKernelGGL(k_perfect_twin_emit, dim3(grid_for(ps.entry_count)), dim3(kBlock), 0, s, pf, ps, ta, sub, fin, d_err);
+  return hipGetLastError();
+}
+
+hipError_t launch_key_gcd(const void* col, int width, int64_t n, int64_t kmin, int nullable, unsigned long long* scratch,
+                          unsigned long long* out256, hipStream_t s) {
+  constexpr int kBlocks = 64;  // scratch: kBlocks * kBlock partials
+  hipLaunchKernelGGL(k_key_gcd, dim3(kBlocks), dim3(kBlock), 0, s, (const int8_t*)col, width, n, kmin, nullable, scratch);
+  hipLaunchKernelGGL(k_key_gcd_fold, dim3(1), dim3(kBlock), 0, s, scratch, kBlocks * kBlock, out256);
+  return hipGetLastError();
+}
+
+hipError_t launch_affine_keys(int n, const int32_t* src_col, const int32_t* dst_col, const int32_t* width, const int32_t* nullable,
+                              const int64_t* kmin, const int64_t* stride, const int64_t* card, int nc2, const int8_t* const* d_cols,
+                              const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_flag, int n_cus, hipStream_t s) {
+  if (n_frags <= 0 || n <= 0) return hipSuccess;
+  AffineKeys ak{};
+  ak.n = n;
+  ak.nc2 = nc2;
+  for (int k = 0; k < n; ++k) {
+    ak.src_col[k] = src_col[k];
+    ak.dst_col[k] = dst_col[k];
+    ak.width[k] = width[k];
+    ak.nullable[k] = nullable[k];
+    ak.kmin[k] = kmin[k];
+    ak.stride[k] = stride[k];
+    ak.card[k] = card[k];
+  }
+  hipLaunchKernelGGL(k_affine_keys, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, ak, d_cols, d_num_rows, n_frags, d_flag);
+  return hipGetLastError();
+}
+
+hipError_t launch_affine_twin_emit(const DevPlan& pf, const DevPlan& ps, int idx_key_s, int n_keys, const int32_t* translate,
+                                   const int32_t* key_type, const int64_t* twin_min, const int64_t* twin_card, const int64_t* twin_null,
+                                   const int64_t* base, const int64_t* stride, const int64_t* sub, int64_t* fin, int32_t* d_err,
+                                   hipStream_t s) {
+  if (ps.entry_count <= 0) return hipSuccess;
+  AffineTwinArgs ta{};
+  ta.n_keys = n_keys;
+  ta.idx_key_s = idx_key_s;
+  for (int g = 0; g < n_keys; ++g) {
+    ta.translate[g] = translate[g];
+    ta.key_type[g] = key_type[g];
+    ta.twin_min[g] = twin_min[g];
+    ta.twin_card[g] = twin_card[g];
+    ta.twin_null[g] = twin_null[g];
+    ta.base[g] = base[g];
+    ta.stride[g] = stride[g];
+  }
+  hipLaunchKernelGGL(k_affine_twin_emit, dim3(grid_for(ps.entry_count)), dim3(kBlock), 0, s, pf, ps, ta, sub, fin, d_err);
   return hipGetLastError();
 }
 

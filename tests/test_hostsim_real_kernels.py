@@ -606,3 +606,53 @@ def test_random_perfect_twin_steps(sim, oracle):
         assert rs is not None
         taken += rs.report.kernel_name.decode() == "k_idx_scatter"
     assert taken >= 1, taken
+
+
+# ---- baseline keys on a lattice (key = min + stride x i): stride from the first fragment, verified lattice indices, a perfect twin ----
+LATTICE_SHAPES = ["BH008", "BH009", "BH010", "MSBS006", "MSBS007"]
+
+
+@pytest.mark.parametrize("name", LATTICE_SHAPES)
+def test_lattice_key_route_on_the_benchmark_shapes(sim, oracle, name):
+    """BaselineHash / MultiStep shapes over the BIGINT stride columns (multiples of 10 000): grouped by the lattice index on a
+    perfect-hash twin (k_idx_scatter: one exchange), re-keyed into the stated baseline table.  kernel_variant 2 = the
+    large-input members on a small input."""
+    case = flow._refbench_case(oracle, name, 150_003, 120_000)
+    rs = flow._check(oracle, case, kernel_variant=2)
+    assert rs is not None and rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.n_launches >= 3, \
+        (rs.report.kernel_name, rs.report.n_launches)
+
+
+def test_lattice_key_route_nulls_offsets_passes_and_a_key_off_the_lattice(sim, oracle):
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(31)
+    n = 90_000
+    k0 = (7 + 10_000 * rng.integers(0, 70_000, n)).astype(np.int64)             # BIGINT, stride 10 000, offset 7
+    k0[rng.random(n) < 0.02] = np.iinfo(np.int64).min
+    k1 = (-3_000_000 + 250_000 * rng.integers(0, 9, n)).astype(np.int32)         # INT over a wide range, stride 250 000
+    v0 = rng.integers(-1000, 1000, n).astype(np.int32)
+    v0[rng.random(n) < 0.1] = np.iinfo(np.int32).min
+    v1 = rng.integers(0, 10, n).astype(np.int32)
+    descs = [InputColDescriptor(capi.INT64, True, ExpressionRange(True, 7, 7 + 10_000 * 69_999, True)),
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, -3_000_000, -1_000_000)),
+             InputColDescriptor(capi.INT32, True, ExpressionRange(True, -1000, 999, True)),
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 9))]
+    cuts = [0, 30_001, 60_002, n]
+    frags = [[k0[a:b], k1[a:b], v0[a:b], v1[a:b]] for a, b in zip(cuts[:-1], cuts[1:])]
+    for group, targets in (([0], [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 2), TargetExpr(capi.MIN, 2)]),
+                           ([0, 1], [TargetExpr(capi.PROJECT_KEY, 0), TargetExpr(capi.PROJECT_KEY, 1), TargetExpr(capi.COUNT),
+                                     TargetExpr(capi.AVG, 2), TargetExpr(capi.MAX, 3), TargetExpr(capi.COUNT, 2)]),
+                           ([1, 0], [TargetExpr(capi.PROJECT_KEY, 1), TargetExpr(capi.COUNT)])):
+        ra = RelAlgExecutionUnit(descs, targets, [], group, max_groups_buffer_entry_guess=262_144, num_tuples=n)
+        case = cases_mod.Case("lattice", ra, frags)
+        rs = flow._check(oracle, case, kernel_variant=2, pass_rows=31_000)
+        assert rs is not None and rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.n_launches >= 7, \
+            (group, rs.report.kernel_name, rs.report.n_launches)      # three passes (lattice indices + twin step each) + the emit
+    # one key off the lattice, in the LAST fragment: the route is given up after its check, the plain route answers
+    bad = k0.copy()
+    bad[n - 5] = 7 + 10_000 * 123 + 1
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 2)], [], [0],
+                             max_groups_buffer_entry_guess=262_144, num_tuples=n)
+    case = cases_mod.Case("off_lattice", ra, [[bad[a:b], k1[a:b], v0[a:b], v1[a:b]] for a, b in zip(cuts[:-1], cuts[1:])])
+    rs = flow._check(oracle, case, kernel_variant=2)
+    assert rs is not None and rs.report.kernel_name.decode() != "k_idx_scatter", rs.report.kernel_name
