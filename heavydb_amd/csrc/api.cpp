@@ -2021,6 +2021,20 @@ int32_t execute_affine_twin(const mi355q_plan* plan, const mi355q_inputs* in, co
     entries *= points + (r.has_nulls ? 1 : 0);
     if (entries > (__int128)kTwinMaxEntries) return kNotTaken;
   }
+  // one key, one value column, >= 512 K lattice points: the 16-byte partitioned family does this shape as well as the twin's
+  // two extra passes allow (BH009 at 1 B rows: 8.6 ms there, 9.9 ms here; 100 K points, BH008: 12.5 -> 8.2 ms;
+  // profiles/r04_refbench_lattice_keys_call21.jsonl)
+  {
+    int vcols[MI355Q_MAX_TARGETS], n_v = 0;
+    for (int t = 0; t < plan->n_targets; ++t) {
+      const mi355q_target& tg = plan->targets[t];
+      if (tg.agg == MI355Q_PROJECT_KEY || tg.col < 0) continue;
+      bool seen = false;
+      for (int k = 0; k < n_v; ++k) seen = seen || vcols[k] == tg.col;
+      if (!seen) vcols[n_v++] = tg.col;
+    }
+    if (ng == 1 && n_v <= 1 && entries >= ((__int128)1 << 19) && o.kernel_variant != 2) return kNotTaken;
+  }
   const int nc2 = nc + n_proj;
   p2.n_cols = nc2;
   PerfectTwinScope twin(kTwinMaxEntries);
