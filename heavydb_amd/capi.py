@@ -18,7 +18,7 @@ MAX_SLOTS = 16
 MAX_GROUP_COLS = 4
 MAX_EXPRS = 4
 MAX_EXPR_NODES = 12
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # mi355q_type
 INT8, INT16, INT32, INT64, DOUBLE, FLOAT = 1, 2, 3, 4, 5, 6
@@ -47,6 +47,7 @@ GEN_I32_UNIFORM31, GEN_I32_MOD, GEN_I64_MOD, GEN_I64_MOD_MUL, GEN_F64_UNIT = 1, 
 # mi355q_expr_op (projected expressions)
 EX_COL, EX_LIT, EX_CAST, EX_ADD, EX_SUB, EX_MUL, EX_DIV, EX_MOD = 1, 2, 3, 4, 5, 6, 7, 8
 EX_EQ, EX_NE, EX_LT, EX_LE, EX_GT, EX_GE, EX_CASE = 9, 10, 11, 12, 13, 14, 15
+EX_NOT, EX_AND, EX_OR, EX_IS_NULL, EX_UMINUS = 16, 17, 18, 19, 20
 
 OK = 0
 ERR_DIV_BY_ZERO = 1

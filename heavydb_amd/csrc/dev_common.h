@@ -292,11 +292,11 @@ struct DevPlan {
 // ------------------------------------------------------------------ projected expressions
 // mi355q_expr lowered by plan.cpp (lower_exprs): every node knows the type and nullability of what it
 // pops, so the evaluator (expr.h) is a flat loop without type inference.
-enum : int32_t { EXF_NULLABLE = 1, EXF_LHS_NULLABLE = 2, EXF_RHS_NULLABLE = 4 };
+enum : int32_t { EXF_NULLABLE = 1, EXF_LHS_NULLABLE = 2, EXF_RHS_NULLABLE = 4, EXF_SHORT_CIRCUIT = 8 };
 struct DevExprNode {
   int32_t op, type;  // mi355q_expr_op; plain mi355q_type of the result
-  int32_t arg;       // EX_COL: column index; EX_CAST: the operand's type
-  int32_t flags;     // EXF_*: result / lhs (or cast operand) / rhs nullable
+  int32_t arg;       // EX_COL: column index; EX_CAST / comparisons / EX_IS_NULL: the operand's type
+  int32_t flags;     // EXF_*: result / lhs (or the operand of a unary op) / rhs nullable; EX_AND / EX_OR: the short-circuit form
   int64_t ilit;      // EX_LIT (integers); EX_COL: the column's type code
   double flit;       // EX_LIT (DOUBLE / FLOAT)
 };

@@ -19,6 +19,13 @@
 //   CASE         CaseIR.cpp:67-140 codegenCase: the THEN value where the condition is TRUE (toBool: NULL is not), else the ELSE
 //                value; each branch is its own basic block, so a check that fires in the branch NOT taken does not exist —
 //                every value on the stack carries the error its computation met, and CASE keeps the taken branch's only
+//   NOT AND OR   LogicalIR.cpp:299-379 codegenLogical: toBool operands (NOT NULL) or logical_not / logical_and / logical_or
+//                (RuntimeFunctions.cpp:331-358); :197-297 codegenLogicalShortCircuit where an operand holds an unsafe division:
+//                the first operand decides where it can and the second one's basic block is then never entered
+//   IS NULL      LogicalIR.cpp:381-432 codegenIsNull: constant false for a NOT NULL operand (which is not evaluated), else the
+//                comparison with the type's inline NULL (FCMP_OEQ for doubles / floats)
+//   unary minus  ArithmeticIR.cpp:787-838 codegenUMinus: error 7 for the type's minimum as a value, NULL stays NULL
+//                (uminus_<type>_nullable, RuntimeFunctions.cpp:247-258)
 //   error        ErrorCode::OVERFLOW_OR_UNDERFLOW = 7, DIV_BY_ZERO = 1 (QueryEngine/enums.h:30-51)
 #pragma once
 
@@ -176,6 +183,67 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
         const bool take = c == 1;  // TRUE; 0 and NULL are not
         st[sp - 1] = take ? st[sp] : st[sp - 1];
         es[sp - 1] = ce ? ce : take ? es[sp] : es[sp - 1];
+        break;
+      }
+      case MI355Q_EX_NOT: {
+        const int64_t v = st[sp - 1];
+        if ((n.flags & EXF_LHS_NULLABLE) && v == plain_int_null(MI355Q_INT8)) break;  // logical_not: NULL stays NULL
+        st[sp - 1] = (n.flags & EXF_LHS_NULLABLE) ? (v ? 0 : 1) : (v > 0 ? 0 : 1);       // (toBool on the NOT NULL side)
+        break;
+      }
+      case MI355Q_EX_AND:
+      case MI355Q_EX_OR: {
+        const int64_t b = st[--sp];
+        const int64_t a = st[sp - 1];
+        const int64_t nul = plain_int_null(MI355Q_INT8);
+        const bool is_or = n.op == MI355Q_EX_OR, nullable = (n.flags & EXF_NULLABLE) != 0;
+        int64_t r;
+        if (n.flags & EXF_SHORT_CIRCUIT) {
+          // the first operand alone where it decides — the second one's checks then do not exist
+          if (nullable && a == nul) r = nul;
+          else if (a == (is_or ? 1 : 0)) r = a;
+          else {
+            if (!es[sp - 1]) es[sp - 1] = es[sp];
+            r = b;
+          }
+        } else {
+          if (!es[sp - 1]) es[sp - 1] = es[sp];
+          if (!nullable) r = is_or ? (a > 0 || b > 0) : (a > 0 && b > 0);
+          else if (a == nul) r = is_or ? (b == 0 ? nul : b) : (b == 0 ? b : nul);  // logical_or / logical_and
+          else if (b == nul) r = is_or ? (a == 0 ? nul : a) : (a == 0 ? a : nul);
+          else r = is_or ? (a || b) : (a && b);
+        }
+        st[sp - 1] = r;
+        break;
+      }
+      case MI355Q_EX_IS_NULL: {
+        const int64_t v = st[sp - 1];
+        const int t = n.arg;  // the operand's type
+        if (!(n.flags & EXF_LHS_NULLABLE)) {  // a NOT NULL operand is never evaluated: constant false, no check of it exists
+          st[sp - 1] = 0;
+          es[sp - 1] = 0;
+        } else {
+          st[sp - 1] = ex_is_int(t) ? v == plain_int_null(t) : t == MI355Q_DOUBLE ? bits_dbl(v) == kNullDouble : ex_flt_of(v) == kNullFloat;
+        }
+        break;
+      }
+      case MI355Q_EX_UMINUS: {
+        const int64_t v = st[sp - 1];
+        const int t = n.type;
+        const bool nullable = (n.flags & EXF_LHS_NULLABLE) != 0;
+        if (ex_is_int(t)) {
+          if (v == plain_int_null(t)) {  // the type's minimum: NULL stays NULL, a value cannot be negated
+            if (!nullable && !es[sp - 1]) es[sp - 1] = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+          } else {
+            st[sp - 1] = -v;
+          }
+        } else if (t == MI355Q_DOUBLE) {
+          const double x = bits_dbl(v);
+          if (!(nullable && x == kNullDouble)) st[sp - 1] = dbl_bits(-x);
+        } else {
+          const float x = ex_flt_of(v);
+          if (!(nullable && x == kNullFloat)) st[sp - 1] = ex_flt_pattern(-x);
+        }
         break;
       }
       default: {  // MI355Q_EX_ADD / _SUB / _MUL

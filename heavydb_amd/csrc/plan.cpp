@@ -225,6 +225,41 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
           st_null[sp - 1] = nul;
           break;
         }
+        case MI355Q_EX_NOT: {
+          if (n.type != MI355Q_INT8 || sp < 1 || st_type[sp - 1] != MI355Q_INT8) return MI355Q_ERR_INVALID_PLAN;
+          o.type = MI355Q_INT8;
+          o.flags = st_null[sp - 1] ? (EXF_NULLABLE | EXF_LHS_NULLABLE) : 0;
+          break;
+        }
+        case MI355Q_EX_AND:
+        case MI355Q_EX_OR: {
+          if (n.type != MI355Q_INT8 || sp < 2 || st_type[sp - 1] != MI355Q_INT8 || st_type[sp - 2] != MI355Q_INT8 ||
+              (n.reserved != 0 && n.reserved != 1))
+            return MI355Q_ERR_INVALID_PLAN;
+          o.type = MI355Q_INT8;
+          o.flags = (st_null[sp - 2] ? EXF_LHS_NULLABLE : 0) | (st_null[sp - 1] ? EXF_RHS_NULLABLE : 0) |
+                    (n.reserved == 1 ? EXF_SHORT_CIRCUIT : 0);
+          const bool nul = st_null[sp - 2] || st_null[sp - 1];
+          if (nul) o.flags |= EXF_NULLABLE;
+          --sp;
+          st_null[sp - 1] = nul;
+          break;
+        }
+        case MI355Q_EX_IS_NULL: {
+          if (n.type != MI355Q_INT8 || sp < 1) return MI355Q_ERR_INVALID_PLAN;
+          o.type = MI355Q_INT8;
+          o.arg = st_type[sp - 1];  // the operand's type
+          o.flags = st_null[sp - 1] ? EXF_LHS_NULLABLE : 0;
+          st_type[sp - 1] = MI355Q_INT8;
+          st_null[sp - 1] = false;
+          break;
+        }
+        case MI355Q_EX_UMINUS: {
+          if (!valid_type(n.type) || sp < 1 || st_type[sp - 1] != n.type) return MI355Q_ERR_INVALID_PLAN;
+          o.type = n.type;
+          o.flags = st_null[sp - 1] ? (EXF_NULLABLE | EXF_LHS_NULLABLE) : 0;
+          break;
+        }
         default:
           return MI355Q_ERR_UNSUPPORTED;
       }

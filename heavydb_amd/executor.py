@@ -86,7 +86,7 @@ class ExprNode:
     arg: int = 0
     ilit: int = 0
     flit: float = 0.0
-    null_lit: int = 0     # EX_LIT: 1 = the NULL of `type`
+    null_lit: int = 0     # the node's `reserved`: EX_LIT: 1 = the NULL of `type`; EX_AND / EX_OR: 1 = the short-circuit form
 
 
 @dataclass
@@ -123,6 +123,23 @@ class Expr:
         """CASE WHEN cond THEN then ELSE otherwise END (Analyzer::CaseExpr): stack order ELSE, THEN, condition"""
         return Expr(otherwise.nodes + then.nodes + cond.nodes + [ExprNode(capi.EX_CASE, type)])
 
+    def logical_not(self) -> "Expr":
+        """NOT self (Analyzer::UOper kNOT over a BOOLEAN)"""
+        return Expr(self.nodes + [ExprNode(capi.EX_NOT, capi.INT8)])
+
+    def logical(self, op: int, other: "Expr", short_circuit: bool = False) -> "Expr":
+        """self AND / OR other (capi.EX_AND / EX_OR over BOOLEANs).  short_circuit: the form the reference emits when an operand
+        holds an unsafe division — `self` is evaluated first and `other` only where `self` does not decide"""
+        return Expr(self.nodes + other.nodes + [ExprNode(op, capi.INT8, null_lit=1 if short_circuit else 0)])
+
+    def is_null(self) -> "Expr":
+        """self IS NULL as a NOT NULL BOOLEAN (Analyzer::UOper kISNULL)"""
+        return Expr(self.nodes + [ExprNode(capi.EX_IS_NULL, capi.INT8)])
+
+    def neg(self, type: int) -> "Expr":
+        """-self (Analyzer::UOper kUMINUS); `type` = the operand's type"""
+        return Expr(self.nodes + [ExprNode(capi.EX_UMINUS, type)])
+
     def _bin(self, op: int, other: "Expr", type: int) -> "Expr":
         return Expr(self.nodes + other.nodes + [ExprNode(op, type)])
 
@@ -157,6 +174,10 @@ class Expr:
                 st.append((n.type, bool(n.null_lit)))
             elif n.op == capi.EX_CAST:
                 st[-1] = (n.type, st[-1][1])
+            elif n.op in (capi.EX_NOT, capi.EX_UMINUS):
+                st[-1] = (n.type, st[-1][1])
+            elif n.op == capi.EX_IS_NULL:
+                st[-1] = (capi.INT8, False)
             elif n.op == capi.EX_CASE:
                 st.pop()
                 t = st.pop()

@@ -44,7 +44,7 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 5
+#define MI355Q_ABI_VERSION 6
 
 #define MI355Q_MAX_COLS 16
 #define MI355Q_MAX_QUALS 4
@@ -267,14 +267,38 @@ typedef enum mi355q_expr_op {
    * node's `type`; the result is nullable if either is.  The branches are LAZY, as the reference's basic blocks are: an
    * overflow or a division by zero in the branch that is not taken does not end the step (`CASE WHEN b <> 0 THEN a / b ELSE 0
    * END` never raises error 1).  A CASE without ELSE has the NULL literal there (MI355Q_EX_LIT with `reserved` = 1). */
-  MI355Q_EX_CASE = 15
+  MI355Q_EX_CASE = 15,
+  /* LOGIC over BOOLEAN values (MI355Q_INT8: 1 / 0 / the INT8 NULL); the node's `type` must be MI355Q_INT8.
+   * NOT (CodeGenerator::codegenLogical(UOper), LogicalIR.cpp:363-379): pop a BOOLEAN; a NOT NULL operand gives !(v > 0)
+   * (toBool :344-352), a nullable one logical_not (RuntimeFunctions.cpp:331-334): NULL stays NULL. */
+  MI355Q_EX_NOT = 16,
+  /* AND / OR (codegenLogical(BinOper), LogicalIR.cpp:299-342): pop rhs, pop lhs.  `reserved` = 0, the plain form: BOTH operands
+   * are evaluated (a check that fires in either ends the step); NOT NULL operands give toBool(lhs) op toBool(rhs), otherwise the
+   * three-valued logical_and / logical_or (RuntimeFunctions.cpp:336-358: NULL AND FALSE = FALSE, NULL OR TRUE = TRUE, else
+   * NULL where an operand is NULL).  `reserved` = 1, the SHORT-CIRCUIT form the reference emits when an operand contains a
+   * division whose divisor is not a non-zero constant (codegenLogicalShortCircuit :197-297 after contains_unsafe_division
+   * :26-53; it swaps the operands so that the unsafe one is evaluated SECOND — the caller pushes them in that order): the
+   * first operand alone decides where it can — NULL gives NULL (so here NULL AND FALSE = NULL, as in the reference's phi),
+   * FALSE AND .. = FALSE, TRUE OR .. = TRUE — and the second is then NOT evaluated: its checks cannot fire
+   * (`b <> 0 AND a / b > 1` never raises error 1); otherwise the result is the second operand's value (NULL if it is). */
+  MI355Q_EX_AND = 17,
+  MI355Q_EX_OR = 18,
+  /* x IS NULL as a value (codegenIsNull, LogicalIR.cpp:381-432): pop a value of any type, push a NOT NULL BOOLEAN — 1 where a
+   * NULLABLE operand equals its type's inline NULL (doubles / floats: ordered-equal to NULL_DOUBLE / NULL_FLOAT, the NULL
+   * literal included), else 0.  An operand whose type is NOT NULL is not evaluated at all in the reference (constant
+   * false): a check inside it cannot fire.  `x IS NOT NULL` is NOT(IS NULL(x)) (RelAlgTranslator.cpp:640-643). */
+  MI355Q_EX_IS_NULL = 19,
+  /* -x (codegenUMinus, ArithmeticIR.cpp:787-838): the node's `type` = the operand's.  Integers: a nullable operand equal to
+   * the type's NULL stays NULL (uminus_<type>_nullable, RuntimeFunctions.cpp:247-258); otherwise the type's minimum — which
+   * only a NOT NULL operand can hold as a value — ends the step with error 7.  DOUBLE / FLOAT: fneg, NULL stays NULL. */
+  MI355Q_EX_UMINUS = 20
 } mi355q_expr_op;
 
 typedef struct mi355q_expr_node {
   int32_t op;   /* mi355q_expr_op */
   int32_t type; /* mi355q_type of the node's result (ignored for MI355Q_EX_COL) */
   int32_t arg;  /* MI355Q_EX_COL: outer column index (a physical column, < n_cols) */
-  int32_t reserved; /* MI355Q_EX_LIT: 1 = the NULL literal; else 0 */
+  int32_t reserved; /* MI355Q_EX_LIT: 1 = the NULL literal; MI355Q_EX_AND / _OR: 1 = the short-circuit form; else 0 */
   int64_t ilit;
   double flit;
 } mi355q_expr_node;

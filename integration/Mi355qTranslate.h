@@ -110,6 +110,29 @@ inline int64_t int_literal(const SQLTypeInfo& ti, const Datum& d) {
   }
 }
 
+// contains_unsafe_division (LogicalIR.cpp:26-53) over the expression kinds this binding takes: a kDIVIDE whose divisor is
+// not a constant, or is the NULL / a zero constant.  (The reference walks with Expr::find_expr; kMODULO is not looked at.)
+inline bool contains_unsafe_division(const Analyzer::Expr* e) {
+  if (auto b = dynamic_cast<const Analyzer::BinOper*>(e)) {
+    if (b->get_optype() == kDIVIDE) {
+      auto c = dynamic_cast<const Analyzer::Constant*>(b->get_right_operand());
+      if (!c || c->get_is_null()) return true;
+      const auto& ti = c->get_type_info();
+      const Datum d = c->get_constval();
+      if (ti.get_type() == kDOUBLE ? d.doubleval == 0.0 : ti.get_type() == kFLOAT ? d.floatval == 0.0f : int_literal(ti, d) == 0)
+        return true;
+    }
+    return contains_unsafe_division(b->get_left_operand()) || contains_unsafe_division(b->get_right_operand());
+  }
+  if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) return contains_unsafe_division(u->get_operand());
+  if (auto ce = dynamic_cast<const Analyzer::CaseExpr*>(e)) {
+    for (const auto& pr : ce->get_expr_pair_list())
+      if (contains_unsafe_division(pr.first.get()) || contains_unsafe_division(pr.second.get())) return true;
+    return ce->get_else_expr() && contains_unsafe_division(ce->get_else_expr());
+  }
+  return false;
+}
+
 // postfix program of a value expression over OUTER columns (CodeGenerator::codegenCast / codegenArith shapes).
 // `outer_col` resolves a ColumnVar of the outer table to its position among the input columns.
 inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
@@ -131,9 +154,17 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
     else if (t == MI355Q_FLOAT) push(MI355Q_EX_LIT, t, 0, 0, d.floatval);
     else push(MI355Q_EX_LIT, t, 0, int_literal(ti, d), 0.0);
   } else if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
-    if (u->get_optype() != kCAST) unsupported("unary operator");
     emit_expr(u->get_operand(), x, outer_col);
-    push(MI355Q_EX_CAST, logical_type(u->get_type_info()), 0, 0, 0.0);
+    switch (u->get_optype()) {
+      case kCAST: push(MI355Q_EX_CAST, logical_type(u->get_type_info()), 0, 0, 0.0); break;
+      case kNOT:  // codegenLogical(UOper), LogicalIR.cpp:363-379
+        if (!u->get_operand()->get_type_info().is_boolean()) unsupported("NOT over a value that is not a BOOLEAN");
+        push(MI355Q_EX_NOT, MI355Q_INT8, 0, 0, 0.0);
+        break;
+      case kISNULL: push(MI355Q_EX_IS_NULL, MI355Q_INT8, 0, 0, 0.0); break;  // codegenIsNull, :381-432
+      case kUMINUS: push(MI355Q_EX_UMINUS, logical_type(u->get_type_info()), 0, 0, 0.0); break;  // ArithmeticIR.cpp:787-838
+      default: unsupported("unary operator");
+    }
   } else if (auto b = dynamic_cast<const Analyzer::BinOper*>(e)) {
     const int32_t op = b->get_optype() == kPLUS ? MI355Q_EX_ADD : b->get_optype() == kMINUS ? MI355Q_EX_SUB
                        : b->get_optype() == kMULTIPLY ? MI355Q_EX_MUL : b->get_optype() == kDIVIDE ? MI355Q_EX_DIV
@@ -142,6 +173,25 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
     const int32_t cmp = b->get_optype() == kEQ ? MI355Q_EX_EQ : b->get_optype() == kNE ? MI355Q_EX_NE
                         : b->get_optype() == kLT ? MI355Q_EX_LT : b->get_optype() == kLE ? MI355Q_EX_LE
                         : b->get_optype() == kGT ? MI355Q_EX_GT : b->get_optype() == kGE ? MI355Q_EX_GE : 0;
+    if (b->get_optype() == kAND || b->get_optype() == kOR) {
+      // codegenLogical (LogicalIR.cpp:299-342).  Where an operand holds an unsafe division the reference emits the
+      // short-circuit form, the unsafe operand evaluated second (codegenLogicalShortCircuit :197-297: rhs unsafe -> as
+      // written; else lhs unsafe -> swapped).  Its other motive — LIKELY() / UNLIKELY() annotations on a heavy operand
+      // (get_likelihood :79-117) — needs Analyzer::LikelihoodExpr, which this binding does not take.
+      const Analyzer::Expr* first = b->get_left_operand();
+      const Analyzer::Expr* second = b->get_right_operand();
+      if (!first->get_type_info().is_boolean() || !second->get_type_info().is_boolean()) unsupported("AND / OR over values that are not BOOLEANs");
+      int32_t sc = 0;
+      if (contains_unsafe_division(second)) sc = 1;
+      else if (contains_unsafe_division(first)) {
+        sc = 1;
+        std::swap(first, second);
+      }
+      emit_expr(first, x, outer_col);
+      emit_expr(second, x, outer_col);
+      push(b->get_optype() == kAND ? MI355Q_EX_AND : MI355Q_EX_OR, MI355Q_INT8, 0, 0, 0.0, sc);
+      return;
+    }
     if (!op && !cmp) unsupported("binary operator");
     if (cmp && logical_type(b->get_left_operand()->get_type_info()) != logical_type(b->get_right_operand()->get_type_info()))
       unsupported("comparison of two types");  // (the analyzer casts both sides to one type: CompareIR.cpp asserts it)
@@ -216,25 +266,42 @@ inline mi355q_qual translate_qual(const Analyzer::Expr* e, const std::function<i
   return q;
 }
 
-// One conjunct of simple_quals / quals -> one or more plan quals: a comparison, or a DISJUNCTION of comparisons (`a OR b OR
-// ...`, Analyzer::BinOper kOR nested any way round) whose members share a fresh group number; NOT over a comparison is
-// folded into the operator (NOT(x < 5) = x >= 5: NULL stays "not TRUE" either way, LogicalIR.cpp:299-352).
-inline void translate_conjunct(const Analyzer::Expr* e, const std::function<int(const Analyzer::Expr*)>& value_col,
-                               mi355q_qual* quals, int32_t* n_quals, int32_t* n_groups, int32_t group = 0) {
+// ---- conjuncts of simple_quals / quals
+// translate_qual's shapes
+inline bool qual_shaped(const Analyzer::Expr* e) {
+  if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
+    if (u->get_optype() == kISNULL) return true;
+    auto in = u->get_optype() == kNOT ? dynamic_cast<const Analyzer::UOper*>(u->get_operand()) : nullptr;
+    return in && in->get_optype() == kISNULL;
+  }
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  if (!b) return false;
+  switch (b->get_optype()) {
+    case kEQ: case kNE: case kLT: case kGT: case kLE: case kGE: return true;
+    default: return false;
+  }
+}
+// members of a disjunction of qual shapes (`a OR b OR ...`, Analyzer::BinOper kOR nested any way round; NOT over a comparison
+// counts as the comparison); -1 = not such a disjunction
+inline int disjunction_members(const Analyzer::Expr* e) {
   auto b = dynamic_cast<const Analyzer::BinOper*>(e);
   if (b && b->get_optype() == kOR) {
-    if (!group) {
-      if (*n_groups >= MI355Q_MAX_OR_GROUPS) unsupported("too many disjunctions");
-      group = ++*n_groups;
-    }
-    translate_conjunct(b->get_left_operand(), value_col, quals, n_quals, n_groups, group);
-    translate_conjunct(b->get_right_operand(), value_col, quals, n_quals, n_groups, group);
-    return;
+    const int l = disjunction_members(b->get_left_operand()), r = disjunction_members(b->get_right_operand());
+    return l < 0 || r < 0 ? -1 : l + r;
   }
-  if (b && b->get_optype() == kAND) {
-    if (group) unsupported("AND inside OR");
-    translate_conjunct(b->get_left_operand(), value_col, quals, n_quals, n_groups, 0);
-    translate_conjunct(b->get_right_operand(), value_col, quals, n_quals, n_groups, 0);
+  auto u = dynamic_cast<const Analyzer::UOper*>(e);
+  if (u && u->get_optype() == kNOT)
+    if (auto inner = dynamic_cast<const Analyzer::BinOper*>(u->get_operand())) return qual_shaped(inner) ? 1 : -1;
+  return qual_shaped(e) ? 1 : -1;
+}
+// the members of a disjunction (group > 0), or one comparison (group 0); NOT over a comparison is folded into the operator
+// (NOT(x < 5) = x >= 5: NULL stays "not TRUE" either way, LogicalIR.cpp:299-352)
+inline void emit_disjunction(const Analyzer::Expr* e, const std::function<int(const Analyzer::Expr*)>& value_col,
+                             mi355q_qual* quals, int32_t* n_quals, int32_t group) {
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  if (b && b->get_optype() == kOR) {
+    emit_disjunction(b->get_left_operand(), value_col, quals, n_quals, group);
+    emit_disjunction(b->get_right_operand(), value_col, quals, n_quals, group);
     return;
   }
   mi355q_qual q{};
@@ -255,6 +322,37 @@ inline void translate_conjunct(const Analyzer::Expr* e, const std::function<int(
   }
   if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
   q.op = MI355Q_QUAL_IN_OR_GROUP(q.op, group);
+  quals[(*n_quals)++] = q;
+}
+
+// One conjunct -> plan quals: a top-level AND splits; a comparison is one qual; a disjunction of comparisons is a group of
+// quals while the plan has room (MI355Q_MAX_QUALS, MI355Q_MAX_OR_GROUPS).  Every other BOOLEAN conjunct — AND inside OR, NOT
+// over a disjunction, one disjunction too many — is ONE projected expression (the NOT / AND / OR / IS NULL micro-ops over its
+// comparisons) and the qual `that column = 1`: TRUE; a NULL is not (toBool, LogicalIR.cpp:344-352).  What the plan cannot
+// state either way (a program beyond MI355Q_MAX_EXPR_NODES, an expression kind outside the micro-ops) is refused by emit_expr.
+inline void translate_conjunct(const Analyzer::Expr* e, const std::function<int(const Analyzer::Expr*)>& value_col,
+                               mi355q_qual* quals, int32_t* n_quals, int32_t* n_groups) {
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  if (b && b->get_optype() == kAND) {
+    translate_conjunct(b->get_left_operand(), value_col, quals, n_quals, n_groups);
+    translate_conjunct(b->get_right_operand(), value_col, quals, n_quals, n_groups);
+    return;
+  }
+  const int m = disjunction_members(e);
+  if (m == 1) {
+    emit_disjunction(e, value_col, quals, n_quals, 0);
+    return;
+  }
+  if (m > 1 && *n_quals + m <= MI355Q_MAX_QUALS && *n_groups < MI355Q_MAX_OR_GROUPS) {
+    emit_disjunction(e, value_col, quals, n_quals, ++*n_groups);
+    return;
+  }
+  if (!e->get_type_info().is_boolean()) unsupported("qual shape");
+  if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
+  mi355q_qual q{};
+  q.col = value_col(e);
+  q.op = MI355Q_EQ;
+  q.ival = 1;
   quals[(*n_quals)++] = q;
 }
 

@@ -59,6 +59,7 @@ class SQLTypeInfo {
   bool is_geometry() const { return type_ == kPOINT; }
   int get_dimension() const { return dimension_; }
   bool is_high_precision_timestamp() const { return type_ == kTIMESTAMP && dimension_ > 0; }
+  bool is_boolean() const { return type_ == kBOOLEAN; }
   bool is_integer() const { return type_ == kTINYINT || type_ == kSMALLINT || type_ == kINT || type_ == kBIGINT; }
   // bytes of the SQL type
   int get_logical_size() const {

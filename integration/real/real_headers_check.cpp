@@ -140,9 +140,52 @@ int main() {
     REQ(MI355Q_QUAL_OP(qs[1].op) == MI355Q_IS_NULL && MI355Q_QUAL_OR_GROUP(qs[1].op) == 1 && qs[1].col == 1);
     REQ(MI355Q_QUAL_OP(qs[2].op) == MI355Q_LT && MI355Q_QUAL_OR_GROUP(qs[2].op) == 1);   // NOT(x >= 1) folded
     REQ(qs[3].op == MI355Q_GE);
+    // AND inside OR has no qual shape: the whole conjunct is ONE projected BOOLEAN expression, the qual `that column = 1`
     auto and_in_or = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, true), false, kOR, kONE, both, lt);
     nq = ng = 0;
-    REQ(refuses([&] { translate_conjunct(and_in_or.get(), value_col, qs, &nq, &ng); }));
+    translate_conjunct(and_in_or.get(), value_col, qs, &nq, &ng);
+    REQ(nq == 1 && ng == 0 && qs[0].op == MI355Q_EQ && qs[0].ival == 1 && qs[0].col == 100);
+    {
+      // (x < 1 AND y IS NULL) OR NOT(x >= 1) as a program: COL LIT LT | COL IS_NULL | AND | COL LIT GE NOT | OR
+      auto conj = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kAND, kONE, lt, isnull);
+      auto disj = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kOR, kONE, conj, not_ge);
+      mi355q_expr eb{};
+      emit_expr(disj.get(), eb, outer_col);
+      REQ(eb.n_nodes == 11 && eb.nodes[2].op == MI355Q_EX_LT && eb.nodes[4].op == MI355Q_EX_IS_NULL && eb.nodes[4].type == MI355Q_INT8 &&
+          eb.nodes[5].op == MI355Q_EX_AND && eb.nodes[5].reserved == 0 && eb.nodes[8].op == MI355Q_EX_GE &&
+          eb.nodes[9].op == MI355Q_EX_NOT && eb.nodes[10].op == MI355Q_EX_OR && eb.nodes[10].type == MI355Q_INT8);
+      nq = ng = 0;
+      translate_conjunct(disj.get(), value_col, qs, &nq, &ng);
+      REQ(nq == 1 && ng == 0 && qs[0].op == MI355Q_EQ && qs[0].ival == 1 && qs[0].col == 100);
+      // y <> 0 AND x / y > 1 over BIGINTs: the division's divisor is a column -> the short-circuit form, the unsafe operand
+      // second; written the other way round the operands are swapped (codegenLogicalShortCircuit, LogicalIR.cpp:197-297)
+      Datum zero;
+      zero.bigintval = 0;
+      auto l0 = std::make_shared<Constant>(t_big, false, zero);
+      auto ne0 = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kNE, kONE, y, l0);
+      auto quot = std::make_shared<BinOper>(t_big, false, kDIVIDE, kONE, xb, y);
+      auto gt1 = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kGT, kONE, quot, l3);
+      REQ(contains_unsafe_division(gt1.get()) && !contains_unsafe_division(ne0.get()));
+      auto by_l3 = std::make_shared<BinOper>(t_big, false, kDIVIDE, kONE, y, l3);   // a non-zero constant divisor is safe
+      auto by_l0 = std::make_shared<BinOper>(t_big, false, kDIVIDE, kONE, y, l0);   // a zero constant is not
+      REQ(!contains_unsafe_division(by_l3.get()) && contains_unsafe_division(by_l0.get()));
+      for (int swapped = 0; swapped < 2; ++swapped) {
+        auto guarded = swapped ? std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kAND, kONE, gt1, ne0)
+                               : std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kAND, kONE, ne0, gt1);
+        mi355q_expr eg{};
+        emit_expr(guarded.get(), eg, outer_col);
+        REQ(eg.n_nodes == 10 && eg.nodes[2].op == MI355Q_EX_NE && eg.nodes[6].op == MI355Q_EX_DIV && eg.nodes[8].op == MI355Q_EX_GT &&
+            eg.nodes[9].op == MI355Q_EX_AND && eg.nodes[9].reserved == 1);
+      }
+      // -y, y IS NULL as values
+      auto neg = std::make_shared<UOper>(t_big, false, kUMINUS, y);
+      mi355q_expr en{};
+      emit_expr(neg.get(), en, outer_col);
+      REQ(en.n_nodes == 2 && en.nodes[1].op == MI355Q_EX_UMINUS && en.nodes[1].type == MI355Q_INT64);
+      auto not_y = std::make_shared<UOper>(SQLTypeInfo(kBOOLEAN, false), false, kNOT, y);   // NOT over a BIGINT
+      mi355q_expr ex{};
+      REQ(refuses([&] { emit_expr(not_y.get(), ex, outer_col); }));
+    }
     // column-vs-column compare: the comparison is a projected BOOLEAN expression, the qual `that column = 1`
     auto ge_cols = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kGE, kONE, xb, y);
     q = translate_qual(ge_cols.get(), value_col);

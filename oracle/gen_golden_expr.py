@@ -19,6 +19,11 @@ on the CPU and through the projection kernel on the device) to it.
   "cmp"    {eq,ne,lt,le,gt,ge}_<type>_nullable[_lhs|_rhs](lhs, rhs, null, null_bool)  RuntimeFunctions.cpp:73-107,132-149
            for int8_t .. int64_t, float, double (NaN operands included) — what codegenCmp emits for two values with a
            nullable operand (CompareIR.cpp:230-330); `out` is the int8 result: 1 / 0 / -128
+  "logic"  logical_not(operand, null_bool) / logical_and(lhs, rhs, null_bool) / logical_or(..)   RuntimeFunctions.cpp:331-358
+           over {1, 0, -128}: what codegenLogical emits for a nullable BOOLEAN operand (LogicalIR.cpp:299-379)
+  "uminus" uminus_<type>_nullable(operand, null)                                RuntimeFunctions.cpp:247-258
+           for int8_t .. int64_t, float, double — what codegenUMinus emits for a nullable operand (ArithmeticIR.cpp:787-838);
+           the type's minimum IS the NULL (a NOT NULL operand holding it is an overflow error before any function)
 Values travel as 64-bit patterns: integers sign-extended, double bits, float bits in the low word.
 """
 from __future__ import annotations
@@ -145,11 +150,34 @@ def main():
                     for b in pick:
                         r = fn(a, b, null_of(t), -128)
                         out["cmp"].append({"op": op, "type": t, "suffix": suffix, "a": bits(t, a), "b": bits(t, b), "out": int(r)})
+    # ---- NOT / AND / OR over nullable BOOLEANs
+    out["logic"] = []
+    ref.logical_not.restype = C.c_int8
+    ref.logical_not.argtypes = [C.c_int8, C.c_int8]
+    for a in (1, 0, -128):
+        out["logic"].append({"op": capi.EX_NOT, "a": a, "b": 0, "out": int(ref.logical_not(a, -128))})
+    for name, op in (("logical_and", capi.EX_AND), ("logical_or", capi.EX_OR)):
+        fn = getattr(ref, name)
+        fn.restype = C.c_int8
+        fn.argtypes = [C.c_int8, C.c_int8, C.c_int8]
+        for a in (1, 0, -128):
+            for b in (1, 0, -128):
+                out["logic"].append({"op": op, "a": a, "b": b, "out": int(fn(a, b, -128))})
+    # ---- unary minus
+    out["uminus"] = []
+    for t in INTS + [capi.FLOAT, capi.DOUBLE]:
+        fn = getattr(ref, f"uminus_{TNAME[t]}_nullable")
+        fn.restype = CT[t]
+        fn.argtypes = [CT[t], CT[t]]
+        vals = int_samples(t, rng) if t in INTS else fp_samples(t, rng) + [float("inf"), -float("inf")]
+        for v in vals:
+            out["uminus"].append({"type": t, "in": bits(t, v), "out": bits(t, fn(v, null_of(t)))})
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
                         "ref_expr_vectors.json")
     with open(path, "w") as fjs:
         json.dump(out, fjs, separators=(",", ":"))
-    print(f"wrote {path}: {len(out['cast'])} cast + {len(out['arith'])} arithmetic + {len(out['cmp'])} comparison vectors")
+    print(f"wrote {path}: {len(out['cast'])} cast + {len(out['arith'])} arithmetic + {len(out['cmp'])} comparison + "
+          f"{len(out['logic'])} logic + {len(out['uminus'])} unary-minus vectors")
 
 
 if __name__ == "__main__":

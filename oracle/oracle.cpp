@@ -1314,7 +1314,9 @@ struct ExprWalk {
     int need = 1, i = end;
     for (;; --i) {
       const int op = x.nodes[i].op;
-      const int arity = op == MI355Q_EX_COL || op == MI355Q_EX_LIT ? 0 : op == MI355Q_EX_CAST ? 1 : op == MI355Q_EX_CASE ? 3 : 2;
+      const int arity = op == MI355Q_EX_COL || op == MI355Q_EX_LIT ? 0
+                        : op == MI355Q_EX_CAST || op == MI355Q_EX_NOT || op == MI355Q_EX_IS_NULL || op == MI355Q_EX_UMINUS ? 1
+                        : op == MI355Q_EX_CASE ? 3 : 2;
       need += arity - 1;
       if (need == 0) return i;
     }
@@ -1324,7 +1326,8 @@ struct ExprWalk {
     const mi355q_expr_node& n = x.nodes[end];
     if (n.op == MI355Q_EX_COL) return p.cols[n.arg].nullable != 0;
     if (n.op == MI355Q_EX_LIT) return n.reserved == 1;
-    if (n.op == MI355Q_EX_CAST) return may_be_null(end - 1);
+    if (n.op == MI355Q_EX_CAST || n.op == MI355Q_EX_NOT || n.op == MI355Q_EX_UMINUS) return may_be_null(end - 1);
+    if (n.op == MI355Q_EX_IS_NULL) return false;  // (a NOT NULL BOOLEAN)
     const int last = end - 1, mid = start_of(last) - 1;
     if (n.op == MI355Q_EX_CASE) return may_be_null(mid) || may_be_null(start_of(mid) - 1);
     return may_be_null(last) || may_be_null(mid);
@@ -1357,6 +1360,81 @@ struct ExprWalk {
         OrcVal v;
         if (int32_t e = eval(end - 1, &v)) return e;
         return cast_value(v, n.type, out);
+      }
+      case MI355Q_EX_NOT: {  // codegenLogical(UOper), LogicalIR.cpp:363-379
+        OrcVal v;
+        if (int32_t e = eval(end - 1, &v)) return e;
+        OrcVal r{MI355Q_INT8, v.nullable, 0, 0.0, 0.0f};
+        if (v.nullable) r.i = v.i == int_null_of(MI355Q_INT8) ? v.i : (v.i ? 0 : 1);  // logical_not, RuntimeFunctions.cpp:331-334
+        else r.i = v.i > 0 ? 0 : 1;                                                  // CreateNot(toBool)
+        *out = r;
+        return 0;
+      }
+      case MI355Q_EX_AND:
+      case MI355Q_EX_OR: {
+        const int rhs_end = end - 1, lhs_end = start_of(rhs_end) - 1;
+        const bool is_or = n.op == MI355Q_EX_OR;
+        const bool nullable = may_be_null(lhs_end) || may_be_null(rhs_end);  // the BinOper's type
+        const int64_t nul = int_null_of(MI355Q_INT8);
+        OrcVal a, b;
+        OrcVal r{MI355Q_INT8, nullable, 0, 0.0, 0.0f};
+        if (int32_t e = eval(lhs_end, &a)) return e;
+        if (n.reserved == 1) {
+          // codegenLogicalShortCircuit (LogicalIR.cpp:197-297): nullcheck of the first operand, then `first != (op == kOR)`
+          // branches to the block that evaluates the second operand; the phi takes NULL / the constant / the second value
+          if (nullable && a.i == nul) {
+            r.i = nul;
+          } else if (a.i == (is_or ? 1 : 0)) {
+            r.i = a.i;
+          } else {
+            if (int32_t e = eval(rhs_end, &b)) return e;
+            r.i = b.i;  // (NULL where it is the NULL pattern: the nullcheck_fail block feeds the same value)
+          }
+          *out = r;
+          return 0;
+        }
+        if (int32_t e = eval(rhs_end, &b)) return e;
+        if (!nullable) {
+          r.i = is_or ? (a.i > 0 || b.i > 0) : (a.i > 0 && b.i > 0);  // toBool(lhs) op toBool(rhs), :312-320
+        } else if (is_or) {  // logical_or, RuntimeFunctions.cpp:348-358
+          if (a.i == nul) r.i = b.i == 0 ? nul : b.i;
+          else if (b.i == nul) r.i = a.i == 0 ? nul : a.i;
+          else r.i = (a.i || b.i) ? 1 : 0;
+        } else {  // logical_and, :336-346
+          if (a.i == nul) r.i = b.i == 0 ? b.i : nul;
+          else if (b.i == nul) r.i = a.i == 0 ? a.i : nul;
+          else r.i = (a.i && b.i) ? 1 : 0;
+        }
+        *out = r;
+        return 0;
+      }
+      case MI355Q_EX_IS_NULL: {  // codegenIsNull, LogicalIR.cpp:381-432
+        OrcVal r{MI355Q_INT8, false, 0, 0.0, 0.0f};
+        if (may_be_null(end - 1)) {  // (a NOT NULL operand is not evaluated: constant false)
+          OrcVal v;
+          if (int32_t e = eval(end - 1, &v)) return e;
+          r.i = val_is_null(v) ? 1 : 0;
+        }
+        *out = r;
+        return 0;
+      }
+      case MI355Q_EX_UMINUS: {  // codegenUMinus, ArithmeticIR.cpp:787-838
+        OrcVal v;
+        if (int32_t e = eval(end - 1, &v)) return e;
+        if (val_is_null(v)) {  // uminus_<type>_nullable: NULL stays NULL (and the check is skipped)
+          *out = v;
+          return 0;
+        }
+        if (is_int_type(v.type)) {
+          if (v.i == int_null_of(v.type)) return MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;  // operand == the type's minimum
+          v.i = -v.i;
+        } else if (v.type == MI355Q_DOUBLE) {
+          v.d = -v.d;
+        } else {
+          v.f = -v.f;
+        }
+        *out = v;
+        return 0;
       }
       case MI355Q_EX_CASE: {
         const int cond_end = end - 1, then_end = start_of(cond_end) - 1, else_end = start_of(then_end) - 1;
@@ -1430,6 +1508,20 @@ inline int lower_plan(const mi355q_plan& p, mi355q_plan* out) {
         if (sp < 3 || ty[sp - 1] != MI355Q_INT8 || ty[sp - 2] != n.type || ty[sp - 3] != n.type) return MI355Q_ERR_INVALID_PLAN;
         nu[sp - 3] = nu[sp - 3] || nu[sp - 2];
         sp -= 2;
+      } else if (n.op == MI355Q_EX_NOT) {
+        if (sp < 1 || ty[sp - 1] != MI355Q_INT8 || n.type != MI355Q_INT8) return MI355Q_ERR_INVALID_PLAN;
+      } else if (n.op == MI355Q_EX_AND || n.op == MI355Q_EX_OR) {
+        if (sp < 2 || ty[sp - 1] != MI355Q_INT8 || ty[sp - 2] != MI355Q_INT8 || n.type != MI355Q_INT8 ||
+            (n.reserved != 0 && n.reserved != 1))
+          return MI355Q_ERR_INVALID_PLAN;
+        nu[sp - 2] = nu[sp - 2] || nu[sp - 1];
+        --sp;
+      } else if (n.op == MI355Q_EX_IS_NULL) {
+        if (sp < 1 || n.type != MI355Q_INT8) return MI355Q_ERR_INVALID_PLAN;
+        ty[sp - 1] = MI355Q_INT8;
+        nu[sp - 1] = false;
+      } else if (n.op == MI355Q_EX_UMINUS) {
+        if (sp < 1 || ty[sp - 1] != n.type) return MI355Q_ERR_INVALID_PLAN;
       } else {
         return MI355Q_ERR_UNSUPPORTED;
       }

@@ -85,6 +85,24 @@ def expr_values(e: Expr, descs, cols):
             else:
                 r = v
             st.append((r, null, nd.type))
+        elif nd.op == capi.EX_NOT:
+            v, null, _ = st.pop()
+            st.append((np.array([0 if x else 1 for x in v], dtype=object), null, capi.INT8))
+        elif nd.op in (capi.EX_AND, capi.EX_OR):   # three-valued (a filter / CASE only asks "is it TRUE", where both forms agree)
+            (b, bn, _), (a, an, _) = st.pop(), st.pop()
+            at, bt = np.array([bool(x) for x in a]) & ~an, np.array([bool(x) for x in b]) & ~bn
+            af, bf = ~np.array([bool(x) for x in a]) & ~an, ~np.array([bool(x) for x in b]) & ~bn
+            if nd.op == capi.EX_AND:
+                val, known = at & bt, (at & bt) | af | bf
+            else:
+                val, known = at | bt, at | bt | (af & bf)
+            st.append((np.array([int(x) for x in val], dtype=object), ~known, capi.INT8))
+        elif nd.op == capi.EX_IS_NULL:
+            v, null, _ = st.pop()
+            st.append((np.array([int(x) for x in null], dtype=object), np.zeros(len(null), bool), capi.INT8))
+        elif nd.op == capi.EX_UMINUS:
+            v, null, t = st.pop()
+            st.append((-v, null, t))
         elif nd.op == capi.EX_CASE:   # stack: ELSE, THEN, condition
             (c, cn, _), (t, tn, _), (e, en, _) = st.pop(), st.pop(), st.pop()
             take = (~cn) & np.array([bool(x) for x in c])
@@ -748,6 +766,38 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
                       xra([Expr.case(C(5).cast(INT64).cmp(capi.EX_LT, Expr.lit(INT64, 50)), C(2).div(C(5).cast(INT64), INT64),
                                      Expr.lit(INT64, 0), INT64)],
                           [TargetExpr(SUM, NC), TargetExpr(COUNT)]), frags, expect_error=capi.ERR_DIV_BY_ZERO))
+    # NOT / AND / OR / IS NULL / unary minus as values (LogicalIR.cpp:197-432, ArithmeticIR.cpp:787-838): a filter that has no
+    # qual shape is one BOOLEAN expression `= 1`; the short-circuit form guards a division; IS NULL feeds a CASE; -x in aggregates
+    lt60 = C(1).cmp(capi.EX_LT, Expr.lit(INT64, 60))
+    c7pos = C(7).cmp(capi.EX_GT, Expr.lit(INT32, 0))
+    cases.append(Case("expr_filter_and_inside_or",                    # WHERE (c1 < 60 AND c7 > 0) OR c6 IS NULL
+                      xra([lt60.logical(capi.EX_AND, c7pos).logical(capi.EX_OR, C(6).is_null())],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(COUNT, 7)],
+                          [Qual(NC, EQ, 1)], group=[1]), frags))
+    cases.append(Case("expr_filter_not_over_a_disjunction",           # WHERE NOT (c1 < 60 OR c7 > 0): a NULL c7 with c1 >= 60 is not TRUE
+                      xra([lt60.logical(capi.EX_OR, c7pos).logical_not()],
+                          [TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(COUNT, 7), TargetExpr(MIN, 1)], [Qual(NC, EQ, 1)]), frags))
+    cases.append(Case("expr_short_circuit_and_guards_a_division",     # WHERE c5 <> 0 AND c2 / c5 > 100: never error 1
+                      xra([C(5).cast(INT64).cmp(capi.EX_NE, Expr.lit(INT64, 0)).logical(
+                              capi.EX_AND, C(2).div(C(5).cast(INT64), INT64).cmp(capi.EX_GT, Expr.lit(INT64, 100)), True)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 2)], [Qual(NC, EQ, 1)], group=[1]), frags))
+    cases.append(Case("expr_plain_and_evaluates_the_division_is_error_1",
+                      xra([C(5).cast(INT64).cmp(capi.EX_NE, Expr.lit(INT64, 0)).logical(
+                              capi.EX_AND, C(2).div(C(5).cast(INT64), INT64).cmp(capi.EX_GT, Expr.lit(INT64, 100)))],
+                          [TargetExpr(COUNT)], [Qual(NC, EQ, 1)]), frags, expect_error=capi.ERR_DIV_BY_ZERO))
+    cases.append(Case("expr_is_null_in_case_and_uminus_arguments",    # SUM(CASE WHEN c8 IS NULL THEN 1 ELSE 0 END), SUM(-c2), MIN(-c7), MAX(-c9)
+                      xra([Expr.case(C(8).is_null(), Expr.lit(INT32, 1), Expr.lit(INT32, 0), INT32), C(2).neg(INT64), C(7).neg(INT32),
+                           C(9).neg(DOUBLE)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(SUM, NC), TargetExpr(SUM, NC + 1), TargetExpr(MIN, NC + 2),
+                           TargetExpr(COUNT, NC + 2), TargetExpr(MAX, NC + 3)], group=[10]), frags))
+    cases.append(Case("expr_group_by_a_boolean",                      # GROUP BY (c7 > 0 OR c6 IS NOT NULL): keys 1 / 0 / NULL
+                      xra([c7pos.logical(capi.EX_OR, C(6).is_null().logical_not())],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 3)], group=[NC], guess=64), frags))
+    um = np.array([5, -2**31, 7], dtype=np.int32)
+    um_src = ([InputColDescriptor(INT32, False, col_range([um], INT32, False))], [[um]])
+    cases.append(Case("expr_uminus_of_the_type_minimum_is_error_7",   # -c0 where a NOT NULL INT column holds INT32_MIN
+                      xra([C(0).neg(INT32)], [TargetExpr(SUM, 1)], src=um_src), um_src[1],
+                      expect_error=capi.ERR_OVERFLOW_OR_UNDERFLOW))
     jx = [Expr.col(1).add(Expr.lit(INT64, 2**63 - 10**6), INT64)]   # overflows for positive values of column 1
     jxr = [e.with_range(expr_range(e, fdescs, ffrags)) for e in jx]
     cases.append(Case("expr_join_overflow_only_in_filtered_rows",  # rows with col1 > 0 are dropped by the qual

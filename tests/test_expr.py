@@ -311,6 +311,117 @@ def test_case_rules(oracle):
     assert _case_eval(oracle, dd, fmax, [f64(float("nan")), f64(1.5)]) == (pat(1.5), 0)
 
 
+def test_logic_and_unary_minus_match_the_reference_runtime_functions(oracle):
+    """logical_not / logical_and / logical_or over nullable BOOLEANs and uminus_<type>_nullable (RuntimeFunctions.cpp:247-258,
+    :331-358): both evaluators, bit for bit.  BOOLEAN operands are nullable INT8 columns holding 1 / 0 / -128."""
+    vec = _vectors()
+    b8 = [InputColDescriptor(capi.INT8, True), InputColDescriptor(capi.INT8, True)]
+    for v in vec["logic"]:
+        e = Expr.col(0).logical_not() if v["op"] == capi.EX_NOT else Expr.col(0).logical(v["op"], Expr.col(1))
+        ob, eb, oc, ec = _eval_both(oracle, _plan(b8, e), [_col_of(capi.INT8, v["a"]), _col_of(capi.INT8, v["b"])])
+        assert (oc, ec, ob, eb) == (0, 0, v["out"], v["out"]), (v, ob, eb)
+    assert len(vec["logic"]) == 21
+    n = 0
+    for v in vec["uminus"]:
+        t = v["type"]
+        ob, eb, oc, ec = _eval_both(oracle, _plan([InputColDescriptor(t, True)], Expr.col(0).neg(t)), [_col_of(t, v["in"])])
+        assert oc == 0 and ec == 0, v
+        assert _same_pattern(t, ob, v["out"]) and _same_pattern(t, eb, v["out"]), (v, hex(ob), hex(eb))
+        n += 1
+    assert n > 80
+
+
+def test_logic_rules(oracle):
+    """What the generated IR adds around those functions (LogicalIR.cpp:197-432, ArithmeticIR.cpp:787-838; no runtime function
+    to run): NOT NULL operands go through toBool; the short-circuit form lets the first operand decide (NULL included) and then
+    never enters the second one's block; IS NULL of a NOT NULL operand is constant false without evaluating it; -x of the type's
+    minimum as a VALUE is error 7."""
+    i8 = lambda v: np.array([v], dtype=np.int8)
+    i32 = lambda v: np.array([v], dtype=np.int32)
+    NUL = -128
+    # toBool(lhs) op toBool(rhs) / CreateNot(toBool) on NOT NULL operands
+    nn = [InputColDescriptor(capi.INT8, False), InputColDescriptor(capi.INT8, False)]
+    for a in (0, 1):
+        assert _eval_both(oracle, _plan(nn, Expr.col(0).logical_not()), [i8(a), i8(0)]) == (1 - a, 1 - a, 0, 0)
+        for b in (0, 1):
+            for op, want in ((capi.EX_AND, a & b), (capi.EX_OR, a | b)):
+                for sc in (False, True):
+                    assert _eval_both(oracle, _plan(nn, Expr.col(0).logical(op, Expr.col(1), sc)), [i8(a), i8(b)]) == (want, want, 0, 0)
+    # one nullable operand makes the BinOper nullable: three-valued in the plain form ...
+    mix = [InputColDescriptor(capi.INT8, True), InputColDescriptor(capi.INT8, False)]
+    assert _eval_both(oracle, _plan(mix, Expr.col(0).logical(capi.EX_AND, Expr.col(1))), [i8(NUL), i8(0)])[:2] == (0, 0)
+    assert _eval_both(oracle, _plan(mix, Expr.col(0).logical(capi.EX_OR, Expr.col(1))), [i8(NUL), i8(1)])[:2] == (1, 1)
+    # ... and first-operand-decides in the short-circuit form: NULL AND FALSE = NULL there (the phi's nullcheck_fail input)
+    assert _eval_both(oracle, _plan(mix, Expr.col(0).logical(capi.EX_AND, Expr.col(1), True)), [i8(NUL), i8(0)])[:2] == (NUL, NUL)
+    assert _eval_both(oracle, _plan(mix, Expr.col(0).logical(capi.EX_OR, Expr.col(1), True)), [i8(NUL), i8(1)])[:2] == (NUL, NUL)
+    rmix = [InputColDescriptor(capi.INT8, False), InputColDescriptor(capi.INT8, True)]
+    assert _eval_both(oracle, _plan(rmix, Expr.col(0).logical(capi.EX_AND, Expr.col(1), True)), [i8(1), i8(NUL)])[:2] == (NUL, NUL)
+    assert _eval_both(oracle, _plan(rmix, Expr.col(0).logical(capi.EX_AND, Expr.col(1), True)), [i8(0), i8(NUL)])[:2] == (0, 0)
+    assert _eval_both(oracle, _plan(rmix, Expr.col(0).logical(capi.EX_OR, Expr.col(1), True)), [i8(1), i8(NUL)])[:2] == (1, 1)
+    # b <> 0 AND a / b > 1: the division's zero check exists only where the first operand lets the second run
+    d = [InputColDescriptor(capi.INT32, False), InputColDescriptor(capi.INT32, False)]
+    safe = Expr.col(1).cmp(capi.EX_NE, Expr.lit(capi.INT32, 0))
+    unsafe = Expr.col(0).div(Expr.col(1), capi.INT32).cmp(capi.EX_GT, Expr.lit(capi.INT32, 1))
+    guarded = safe.logical(capi.EX_AND, unsafe, True)
+    assert _eval_both(oracle, _plan(d, guarded), [i32(10), i32(0)]) == (0, 0, 0, 0)
+    assert _eval_both(oracle, _plan(d, guarded), [i32(10), i32(3)]) == (1, 1, 0, 0)
+    assert _eval_both(oracle, _plan(d, guarded), [i32(10), i32(20)]) == (0, 0, 0, 0)
+    plain = safe.logical(capi.EX_AND, unsafe)                 # (the plain form evaluates both: error 1)
+    assert _eval_both(oracle, _plan(d, plain), [i32(10), i32(0)])[2:] == (capi.ERR_DIV_BY_ZERO, capi.ERR_DIV_BY_ZERO)
+    either = Expr.col(1).cmp(capi.EX_EQ, Expr.lit(capi.INT32, 0)).logical(capi.EX_OR, unsafe, True)
+    assert _eval_both(oracle, _plan(d, either), [i32(10), i32(0)]) == (1, 1, 0, 0)
+    assert _eval_both(oracle, _plan(d, either), [i32(10), i32(3)]) == (1, 1, 0, 0)
+    # an error in the FIRST operand ends the step in both forms
+    first_bad = unsafe.logical(capi.EX_OR, safe, True)
+    assert _eval_both(oracle, _plan(d, first_bad), [i32(10), i32(0)])[2:] == (capi.ERR_DIV_BY_ZERO, capi.ERR_DIV_BY_ZERO)
+    # IS NULL: the comparison with the inline NULL for a nullable operand (the NULL literal included) ...
+    for t, null_v, some in ((capi.INT32, -2**31, 5), (capi.INT64, -2**63, -9), (capi.INT8, -128, 0)):
+        dn = [InputColDescriptor(t, True)]
+        assert _eval_both(oracle, _plan(dn, Expr.col(0).is_null()), [_col_of(t, null_v)]) == (1, 1, 0, 0)
+        assert _eval_both(oracle, _plan(dn, Expr.col(0).is_null()), [_col_of(t, some)]) == (0, 0, 0, 0)
+        assert _eval_both(oracle, _plan(dn, Expr.col(0).is_null().logical_not()), [_col_of(t, null_v)]) == (0, 0, 0, 0)   # IS NOT NULL
+        # ... constant false for a NOT NULL one, whatever pattern it holds
+        assert _eval_both(oracle, _plan([InputColDescriptor(t, False)], Expr.col(0).is_null()), [_col_of(t, null_v)]) == (0, 0, 0, 0)
+    tiny = struct.unpack("<q", struct.pack("<d", float(np.finfo(np.float64).tiny)))[0]
+    assert _eval_both(oracle, _plan([InputColDescriptor(capi.DOUBLE, True)], Expr.col(0).is_null()), [_col_of(capi.DOUBLE, tiny)]) == (1, 1, 0, 0)
+    assert _eval_both(oracle, _plan([InputColDescriptor(capi.DOUBLE, True)], Expr.col(0).is_null()),
+                      [np.array([float("nan")])]) == (0, 0, 0, 0)
+    assert _eval_both(oracle, _plan([InputColDescriptor(capi.INT32, False)], Expr.null(capi.INT32).is_null()), [i32(0)]) == (1, 1, 0, 0)
+    # (a NOT NULL operand is not evaluated: its overflow cannot fire; a nullable one is, and it does)
+    big = [InputColDescriptor(capi.INT32, False), InputColDescriptor(capi.INT32, True)]
+    assert _eval_both(oracle, _plan(big, Expr.col(0).add(Expr.col(0), capi.INT32).is_null()), [i32(2**31 - 1), i32(1)]) == (0, 0, 0, 0)
+    assert _eval_both(oracle, _plan(big, Expr.col(0).add(Expr.col(1), capi.INT32).is_null()), [i32(2**31 - 1), i32(1)])[2:] == (7, 7)
+    assert _eval_both(oracle, _plan(big, Expr.col(0).add(Expr.col(1), capi.INT32).is_null()), [i32(2**31 - 1), i32(-2**31)]) == (1, 1, 0, 0)
+    # unary minus: the type's minimum is NULL for a nullable operand and an overflow for a NOT NULL one
+    for t in INTS:
+        lo = INT_NULL[t]
+        assert _eval_both(oracle, _plan([InputColDescriptor(t, True)], Expr.col(0).neg(t)), [_col_of(t, lo)]) == (lo, lo, 0, 0)
+        assert _eval_both(oracle, _plan([InputColDescriptor(t, False)], Expr.col(0).neg(t)), [_col_of(t, lo)])[2:] == (7, 7)
+        assert _eval_both(oracle, _plan([InputColDescriptor(t, False)], Expr.col(0).neg(t)), [_col_of(t, lo + 1)]) == (-lo - 1, -lo - 1, 0, 0)
+        assert _eval_both(oracle, _plan([InputColDescriptor(t, False)], Expr.col(0).neg(t)), [_col_of(t, INT_MAX[t])]) == (lo + 1, lo + 1, 0, 0)
+    nd = _eval_both(oracle, _plan([InputColDescriptor(capi.DOUBLE, False)], Expr.col(0).neg(capi.DOUBLE)), [_col_of(capi.DOUBLE, tiny)])
+    assert nd[0] == nd[1] == struct.unpack("<q", struct.pack("<d", -float(np.finfo(np.float64).tiny)))[0] and nd[2:] == (0, 0)
+
+
+def test_invalid_logic_programs_are_refused(oracle):
+    from heavydb_amd.executor import ExprNode
+    d = [InputColDescriptor(capi.INT32, True), InputColDescriptor(capi.INT8, True)]
+    el = emu_lib()
+    el.emu_eval_expr.restype = C.c_int32
+    bad = [Expr.col(0).logical_not(),                                               # operand is not a BOOLEAN
+           Expr.col(1).logical(capi.EX_AND, Expr.col(0)),                          # one operand is not
+           Expr(Expr.col(1).nodes + [ExprNode(capi.EX_NOT, capi.INT32)]),          # result type must be INT8
+           Expr(Expr.col(1).nodes + Expr.col(1).nodes + [ExprNode(capi.EX_OR, capi.INT8, null_lit=2)]),   # reserved: 0 / 1
+           Expr(Expr.col(0).nodes + [ExprNode(capi.EX_IS_NULL, capi.INT32)]),      # result type must be INT8
+           Expr.col(0).neg(capi.INT64),                                            # the node's type is the operand's
+           Expr([ExprNode(capi.EX_NOT, capi.INT8)])]                               # empty stack
+    for e in bad:
+        plan = _plan(d, e)
+        ptrs = (C.c_void_p * 2)(0, 0)
+        eb, et = C.c_int64(), C.c_int32()
+        assert el.emu_eval_expr(C.byref(plan), 0, ptrs, 0, C.byref(eb), C.byref(et)) == capi.ERR_INVALID_PLAN, [n.op for n in e.nodes]
+
+
 def test_invalid_comparison_and_case_programs_are_refused(oracle):
     d = [InputColDescriptor(capi.INT32, True), InputColDescriptor(capi.INT64, True)]
     el = emu_lib()
@@ -324,6 +435,28 @@ def test_invalid_comparison_and_case_programs_are_refused(oracle):
         ptrs = (C.c_void_p * 2)(0, 0)
         eb, et = C.c_int64(), C.c_int32()
         assert el.emu_eval_expr(C.byref(plan), 0, ptrs, 0, C.byref(eb), C.byref(et)) == capi.ERR_INVALID_PLAN
+
+
+def _random_bool(rng, descs, depth, big=True):
+    """a random BOOLEAN: a comparison, IS NULL, NOT, AND / OR in both forms"""
+    ints = [capi.INT8, capi.INT16, capi.INT32, capi.INT64]
+    choice = int(rng.integers(0, 10)) if depth > 0 else 0
+    if choice <= 4:
+        ct = int(rng.choice(ints + [capi.DOUBLE, capi.FLOAT]))
+        x, y = _random_expr(rng, descs, ct, depth - 1, big), _random_expr(rng, descs, ct, 0, big)
+        if not (x and y):
+            return None
+        return x.cmp(int(rng.choice([capi.EX_EQ, capi.EX_NE, capi.EX_LT, capi.EX_LE, capi.EX_GT, capi.EX_GE])), y)
+    if choice == 5:
+        x = _random_expr(rng, descs, int(rng.choice(ints + [capi.DOUBLE, capi.FLOAT])), depth - 1, big)
+        return x.is_null() if x else None
+    if choice == 6:
+        x = _random_bool(rng, descs, depth - 1, big)
+        return x.logical_not() if x else None
+    a, b = _random_bool(rng, descs, depth - 1, big), _random_bool(rng, descs, depth - 2, big)
+    if not (a and b):
+        return None
+    return a.logical(int(rng.choice([capi.EX_AND, capi.EX_OR])), b, bool(rng.integers(0, 2)))
 
 
 def _random_expr(rng, descs, want_type, depth, big=True):
@@ -351,18 +484,21 @@ def _random_expr(rng, descs, want_type, depth, big=True):
         src = int(rng.choice(srcs))
         e = _random_expr(rng, descs, src, depth - 1, big)
         return e.cast(want_type) if e else None
+    if choice == 4 and rng.integers(0, 2):      # unary minus
+        e = _random_expr(rng, descs, want_type, depth - 1, big)
+        return e.neg(want_type) if e else None
     if choice <= 6:      # arithmetic
         op = int(rng.choice([capi.EX_ADD, capi.EX_SUB, capi.EX_MUL, capi.EX_DIV] + ([capi.EX_MOD] if want_type in ints else [])))
         a, b = _random_expr(rng, descs, want_type, depth - 1, big), _random_expr(rng, descs, want_type, depth - 2, big)
         return a._bin(op, b, want_type) if a and b else None
-    # CASE WHEN x <op> y THEN .. ELSE .. END
-    ct = int(rng.choice(ints + [capi.DOUBLE, capi.FLOAT]))
-    x, y = _random_expr(rng, descs, ct, depth - 2, big), _random_expr(rng, descs, ct, 0, big)
+    if want_type == capi.INT8 and choice == 7:   # a BOOLEAN as the value itself
+        return _random_bool(rng, descs, depth - 1, big)
+    # CASE WHEN <boolean> THEN .. ELSE .. END
+    c = _random_bool(rng, descs, depth - 1 if rng.integers(0, 3) == 0 else 1, big)
     t, e = _random_expr(rng, descs, want_type, depth - 2, big), _random_expr(rng, descs, want_type, depth - 2, big)
-    if not (x and y and t and e):
+    if not (c and t and e):
         return None
-    cmp_op = int(rng.choice([capi.EX_EQ, capi.EX_NE, capi.EX_LT, capi.EX_LE, capi.EX_GT, capi.EX_GE]))
-    return Expr.case(x.cmp(cmp_op, y), t, e, want_type)
+    return Expr.case(c, t, e, want_type)
 
 
 def _stack_depth(e):
@@ -372,7 +508,7 @@ def _stack_depth(e):
             sp += 1
         elif n.op == capi.EX_CASE:
             sp -= 2
-        elif n.op != capi.EX_CAST:
+        elif n.op not in (capi.EX_CAST, capi.EX_NOT, capi.EX_IS_NULL, capi.EX_UMINUS):
             sp -= 1
         mx = max(mx, sp)
     return mx
@@ -409,7 +545,10 @@ def test_random_expression_programs_agree(oracle):
                         v[rng.random(n_rows) < 0.25] = lo
                 descs.append(InputColDescriptor(t, nullable))
                 cols.append(np.ascontiguousarray(v))
-        e = _random_expr(rng, descs, int(rng.choice(types)), int(rng.integers(1, 4)))
+        if rng.integers(0, 3) == 0:   # a BOOLEAN as the program itself: NOT / AND / OR (both forms) / IS NULL over comparisons
+            e = _random_bool(rng, descs, int(rng.integers(1, 4)))
+        else:
+            e = _random_expr(rng, descs, int(rng.choice(types)), int(rng.integers(1, 4)))
         if e is None or len(e.nodes) > capi.MAX_EXPR_NODES or _stack_depth(e) > 4:
             continue
         plan = _plan(descs, e)

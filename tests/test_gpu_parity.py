@@ -1167,11 +1167,23 @@ def test_hip_expressions_match_reference_functions(torch_cuda):
         fams.setdefault(("arith", v["type"], v["op"], v["suffix"]), []).append(v)
     for v in vec["cmp"]:   # {eq,ne,lt,le,gt,ge}_<type>_nullable[_lhs|_rhs]: the BOOLEAN as INT8 1 / 0 / NULL
         fams.setdefault(("cmp", v["type"], v["op"], v["suffix"]), []).append(v)
+    for v in vec["logic"]:   # logical_not / logical_and / logical_or over nullable BOOLEANs (INT8 1 / 0 / NULL)
+        fams.setdefault(("logic", capi.INT8, v["op"], "_nullable"), []).append(v)
+    for v in vec["uminus"]:  # uminus_<type>_nullable
+        fams.setdefault(("uminus", v["type"], 0, ""), []).append(v)
     checked = 0
     for (kind, a, b, sfx), vs in fams.items():
         n = len(vs)
         ids = np.arange(n, dtype=np.int32)
-        if kind == "cast":
+        if kind == "uminus":
+            cols = [np.concatenate([_col_of(a, v["in"]) for v in vs])]
+            descs = [InputColDescriptor(a, True)]
+            e, rt = Expr.col(1).neg(a), a
+        elif kind == "logic":
+            cols = [np.concatenate([_col_of(a, v["a"]) for v in vs]), np.concatenate([_col_of(a, v["b"]) for v in vs])]
+            descs = [InputColDescriptor(a, True), InputColDescriptor(a, True)]
+            e, rt = (Expr.col(1).logical_not() if b == capi.EX_NOT else Expr.col(1).logical(b, Expr.col(2))), capi.INT8
+        elif kind == "cast":
             cols = [np.concatenate([_col_of(a, v["in"]) for v in vs])]
             descs = [InputColDescriptor(a, True)]
             e, rt = Expr.col(1).cast(b), b
@@ -1200,7 +1212,7 @@ def test_hip_expressions_match_reference_functions(torch_cuda):
             else:
                 assert got == want, (kind, a, b, sfx, v, got)
             checked += 1
-    assert checked == len(vec["cast"]) + len(vec["arith"]) + len(vec["cmp"])
+    assert checked == len(vec["cast"]) + len(vec["arith"]) + len(vec["cmp"]) + len(vec["logic"]) + len(vec["uminus"])
 
 
 @pytest.mark.parametrize("targets", ["key_count_count_key", "count_only"])

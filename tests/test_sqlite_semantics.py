@@ -65,6 +65,18 @@ def _expr_sql(e, descs):
             (b, _), (a, _) = st.pop(), st.pop()
             sym = {capi.EX_EQ: "=", capi.EX_NE: "<>", capi.EX_LT: "<", capi.EX_LE: "<=", capi.EX_GT: ">", capi.EX_GE: ">="}[n.op]
             st.append((f"({a} {sym} {b})", False))
+        elif n.op == capi.EX_NOT:
+            x, _ = st.pop()
+            st.append((f"(NOT {x})", False))
+        elif n.op in (capi.EX_AND, capi.EX_OR):
+            (b, _), (a, _) = st.pop(), st.pop()
+            st.append((f"({a} {'AND' if n.op == capi.EX_AND else 'OR'} {b})", False))
+        elif n.op == capi.EX_IS_NULL:
+            x, _ = st.pop()
+            st.append((f"({x} IS NULL)", False))
+        elif n.op == capi.EX_UMINUS:
+            x, fp = st.pop()
+            st.append((f"(-{x})", fp))
         elif n.op == capi.EX_CAST:
             x, fp = st.pop()
             to_fp = n.type in (capi.DOUBLE, capi.FLOAT)
