@@ -2567,9 +2567,7 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
   if (int32_t e = attach_join(lp, in, &d)) return e;
   const int nf = in->n_frags, nc = plan->n_cols, nx = plan->n_exprs, nc2 = nc + nx;
   if (nf == 0) return mi355q_execute(&lp, in, &o, out, report);
-  uint32_t qual_expr_mask = 0;
-  for (int i = 0; i < plan->n_quals; ++i)
-    if (plan->quals[i].col >= nc) qual_expr_mask |= 1u << (plan->quals[i].col - nc);
+  const uint32_t qual_expr_mask = expr_qual_mask(*plan);
   int64_t total_rows = 0, max_frag_rows = 0;
   for (int f = 0; f < nf; ++f) {
     if (in->num_rows[f] < 0) return MI355Q_ERR_INVALID_PLAN;

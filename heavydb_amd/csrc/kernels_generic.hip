@@ -1480,10 +1480,11 @@ hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_
 
 namespace {
 // CAST(plain INT / BIGINT column AS DOUBLE | FLOAT), or that column + - * a literal of its own type
-bool simple_proj_shape(const DevExpr& e, SimpleProj* sp, int* src_type, int* kind) {
+bool simple_proj_shape(const DevExpr& e, int n_phys, SimpleProj* sp, int* src_type, int* kind) {
   if (e.n_nodes < 2 || e.n_nodes > 3) return false;
   const DevExprNode& c = e.nodes[0];
   if (c.op != MI355Q_EX_COL || (c.ilit != MI355Q_INT32 && c.ilit != MI355Q_INT64) || c.type != (int32_t)c.ilit) return false;
+  if (c.arg >= n_phys) return false;  // (the value of an earlier expression: only k_project evaluates a row's expressions in order)
   *src_type = c.type;
   sp->src_col = c.arg;
   sp->nullable = (c.flags & EXF_NULLABLE) ? 1 : 0;
@@ -1523,7 +1524,7 @@ bool project_simple_shapes(const DevExprSet& xs) {
   for (int k = 0; k < xs.n; ++k) {
     SimpleProj sp{};
     int st = 0, kind = 0;
-    if (!simple_proj_shape(xs.e[k], &sp, &st, &kind)) return false;
+    if (!simple_proj_shape(xs.e[k], xs.n_cols, &sp, &st, &kind)) return false;
   }
   return xs.n > 0;
 }
@@ -1615,7 +1616,7 @@ hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_
     for (int k = 0; k < xs.n; ++k) {
       SimpleProj sp{};
       int st = 0, kind = 0;
-      if (!simple_proj_shape(xs.e[k], &sp, &st, &kind)) return hipErrorInvalidValue;
+      if (!simple_proj_shape(xs.e[k], xs.n_cols, &sp, &st, &kind)) return hipErrorInvalidValue;
       sp.dst_col = xs.n_cols + k;
       if (st == MI355Q_INT32) launch_simple_kind<int32_t>(kind, grid, s, sp, d_cols, d_num_rows, n_frags, xs.n_cols + xs.n, d_err);
       else launch_simple_kind<int64_t>(kind, grid, s, sp, d_cols, d_num_rows, n_frags, xs.n_cols + xs.n, d_err);

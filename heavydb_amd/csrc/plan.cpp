@@ -134,15 +134,18 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
       o.flit = n.flit;
       switch (n.op) {
         case MI355Q_EX_COL: {
-          if (n.arg < 0 || n.arg >= p.n_cols || sp >= 4) return MI355Q_ERR_INVALID_PLAN;
-          const int code = col_type_code(p.cols[n.arg]);
+          // a physical column, or the value of an EARLIER expression of the plan (column n_cols + j, j < k): the projection
+          // evaluates the expressions of a row in order, so expression j's dense temporary column already holds it
+          if (n.arg < 0 || n.arg >= p.n_cols + k || sp >= 4) return MI355Q_ERR_INVALID_PLAN;
+          const mi355q_col_desc cd = n.arg < p.n_cols ? p.cols[n.arg] : lowered->cols[n.arg];
+          const int code = col_type_code(cd);
           if (code < 0) return MI355Q_ERR_INVALID_PLAN;
           o.arg = n.arg;
           o.type = tc_logical(code);
           o.ilit = code;
-          o.flags = p.cols[n.arg].nullable ? EXF_NULLABLE : 0;
+          o.flags = cd.nullable ? EXF_NULLABLE : 0;
           st_type[sp] = o.type;
-          st_null[sp] = p.cols[n.arg].nullable != 0;
+          st_null[sp] = cd.nullable != 0;
           ++sp;
           break;
         }
@@ -274,6 +277,23 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
   lowered->n_cols = p.n_cols + p.n_exprs;
   lowered->n_exprs = 0;
   return MI355Q_OK;
+}
+
+// Which expressions are evaluated for EVERY row: the ones a qual reads, and — transitively — the earlier expressions those
+// read (the reference evaluates a filter before anything else of the row, Executor::compileBody).  The checks of the other
+// expressions count only for rows that pass the quals and, under an INNER join, find a match.
+uint32_t expr_qual_mask(const mi355q_plan& p) {
+  uint32_t mask = 0;
+  for (int i = 0; i < p.n_quals && i < MI355Q_MAX_QUALS; ++i)
+    if (p.quals[i].col >= p.n_cols && p.quals[i].col < p.n_cols + MI355Q_MAX_EXPRS) mask |= 1u << (p.quals[i].col - p.n_cols);
+  for (int k = (p.n_exprs < MI355Q_MAX_EXPRS ? p.n_exprs : MI355Q_MAX_EXPRS) - 1; k >= 0; --k) {
+    if (!((mask >> k) & 1u)) continue;
+    const mi355q_expr& x = p.exprs[k];
+    for (int i = 0; i < x.n_nodes && i < MI355Q_MAX_EXPR_NODES; ++i)
+      if (x.nodes[i].op == MI355Q_EX_COL && x.nodes[i].arg >= p.n_cols && x.nodes[i].arg < p.n_cols + k)
+        mask |= 1u << (x.nodes[i].arg - p.n_cols);
+  }
+  return mask;
 }
 
 int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out) {

@@ -40,6 +40,7 @@ void layout_from_qmd(const mi355q_qmd& q, DevPlan* d);
 // (kernels_generic.hip k_project) has written the expression's values into a dense temporary column.
 // `dev` (optional) receives the lowered programs.
 int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev);
+uint32_t expr_qual_mask(const mi355q_plan& p);  // expressions evaluated for every row (read by a qual, directly or through another)
 // one initialised row (key quads then slot init values); quad holds row_size / 8 entries
 void row_init_image(const mi355q_qmd& q, int64_t* quad);
 

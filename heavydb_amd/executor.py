@@ -161,11 +161,15 @@ class Expr:
     def with_range(self, r: ExpressionRange) -> "Expr":
         return Expr(self.nodes, r)
 
-    def result(self, descs: Sequence[InputColDescriptor]) -> Tuple[int, bool]:
-        """(type, nullable) of the value: the typing rules of plan.cpp lower_exprs."""
+    def result(self, descs: Sequence[InputColDescriptor], prior: Sequence["Expr"] = ()) -> Tuple[int, bool]:
+        """(type, nullable) of the value: the typing rules of plan.cpp lower_exprs.  `prior`: the plan's earlier expressions
+        (a column index >= len(descs) reads the value of one of them)."""
         st: List[Tuple[int, bool]] = []
         for n in self.nodes:
-            if n.op == capi.EX_COL:
+            if n.op == capi.EX_COL and n.arg >= len(descs):
+                j = n.arg - len(descs)
+                st.append(prior[j].result(descs, prior[:j]))
+            elif n.op == capi.EX_COL:
                 d = descs[n.arg]
                 lt = d.logical_type or (INT32 if d.encoding == capi.ENC_DICT else
                                         INT64 if d.encoding == capi.ENC_DATE_IN_DAYS else d.type)
@@ -223,7 +227,7 @@ class RelAlgExecutionUnit:
     def col_type(self, c: int) -> int:
         """storage type of outer column c; for a virtual column the expression's result type"""
         n = len(self.input_col_descs)
-        return self.input_col_descs[c].type if c < n else self.exprs[c - n].result(self.input_col_descs)[0]
+        return self.input_col_descs[c].type if c < n else self.exprs[c - n].result(self.input_col_descs, self.exprs[:c - n])[0]
 
     def to_plan(self) -> capi.Plan:
         p = capi.Plan()

@@ -228,7 +228,13 @@ typedef struct mi355q_join_table mi355q_join_table; /* opaque */
  * does; an expression inside a qual is evaluated for every row. */
 typedef enum mi355q_expr_op {
   MI355Q_EX_COL = 1,   /* push outer column `arg` (decoded): type = the column's logical type,
-                          nullable = the column's */
+                          nullable = the column's.  `arg` < n_cols: a physical column; n_cols + j with j < k inside
+                          expression k: the VALUE of the plan's earlier expression j (a program longer than
+                          MI355Q_MAX_EXPR_NODES is stated as several).  Like a column, that value exists for the row
+                          whatever the position of the node: expression j is evaluated whenever k is, before it, and a
+                          check that fires in j counts like one in k — so a subtree moves into an earlier expression
+                          only from a place where it is evaluated unconditionally (not from a CASE branch or from the
+                          second operand of a short-circuit AND / OR) */
   MI355Q_EX_LIT = 2,   /* push a literal of `type`: ilit (integers) / flit (DOUBLE, FLOAT); `reserved` = 1: the NULL of
                           `type` instead (a nullable value) */
   MI355Q_EX_CAST = 3,  /* cast the top of the stack to `type`.  integer -> wider integer: NULL to NULL
@@ -297,7 +303,7 @@ typedef enum mi355q_expr_op {
 typedef struct mi355q_expr_node {
   int32_t op;   /* mi355q_expr_op */
   int32_t type; /* mi355q_type of the node's result (ignored for MI355Q_EX_COL) */
-  int32_t arg;  /* MI355Q_EX_COL: outer column index (a physical column, < n_cols) */
+  int32_t arg;  /* MI355Q_EX_COL: outer column index: a physical column (< n_cols) or an earlier expression (n_cols + j) */
   int32_t reserved; /* MI355Q_EX_LIT: 1 = the NULL literal; MI355Q_EX_AND / _OR: 1 = the short-circuit form; else 0 */
   int64_t ilit;
   double flit;

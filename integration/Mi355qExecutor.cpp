@@ -66,12 +66,30 @@ struct Translator {
     }
     for (size_t k = 0; k < expr_of.size(); ++k)
       if (expr_of[k] == e) return p.n_cols + (int)k;
+    mi355q_expr x{};
+    try {
+      emit(e, x);
+    } catch (const ExprTooLong&) {
+      // (the operands first: an expression reads EARLIER ones)
+      if (!split_plain_logic(e, x, [this](const Analyzer::ColumnVar* cv) { return find(outer_cols, cv->getColumnKey()); },
+                             [this](const Analyzer::Expr* v) { return value_col(v); }))
+        throw;
+    }
+    if (p.n_exprs >= MI355Q_MAX_EXPRS) unsupported("too many projected expressions");
+    x.range = to_range(getExpressionRange(e, query_infos, executor));
+    p.exprs[p.n_exprs] = x;
+    expr_of.push_back(e);
+    return p.n_cols + p.n_exprs++;
+  }
+
+  // a BOOLEAN expression column that no single Analyzer node stands for (translate_where's guarded conjunction)
+  int new_bool_col(const ExprFiller& fill) {
     if (p.n_exprs >= MI355Q_MAX_EXPRS) unsupported("too many projected expressions");
     mi355q_expr& x = p.exprs[p.n_exprs];
     x = mi355q_expr{};
-    emit(e, x);
-    x.range = to_range(getExpressionRange(e, query_infos, executor));
-    expr_of.push_back(e);
+    fill(x, [this](const Analyzer::ColumnVar* cv) { return find(outer_cols, cv->getColumnKey()); });
+    x.range = mi355q_range{1, 1, 0, 1, 0.0, 0.0, 0};
+    expr_of.push_back(nullptr);
     return p.n_cols + p.n_exprs++;
   }
 
@@ -118,9 +136,11 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
   }
   // simple_quals and quals: a conjunction
   int32_t n_or_groups = 0;
+  std::vector<const Analyzer::Expr*> where;
   for (const auto* lst : {&ra.simple_quals, &ra.quals})
-    for (const auto& q : *lst)
-      translate_conjunct(q.get(), [&t](const Analyzer::Expr* v) { return t.value_col(v); }, p.quals, &p.n_quals, &n_or_groups);
+    for (const auto& q : *lst) where.push_back(q.get());
+  translate_where(where, [&t](const Analyzer::Expr* v) { return t.value_col(v); },
+                  [&t](const ExprFiller& fill) { return t.new_bool_col(fill); }, p.quals, &p.n_quals, &n_or_groups);
   // target_exprs (get_target_info, Shared/TargetInfo.h:48-56): aggregates, or projections of a group key
   for (const auto* te : ra.target_exprs) {
     if (p.n_targets >= MI355Q_MAX_TARGETS) unsupported("too many targets");

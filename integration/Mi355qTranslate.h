@@ -28,6 +28,10 @@
 namespace mi355q_glue {
 
 [[noreturn]] inline void unsupported(const char* what) { throw std::runtime_error(std::string("mi355q: ") + what); }
+// a program beyond MI355Q_MAX_EXPR_NODES: the executor half may state it as several expressions (split_plain_logic)
+struct ExprTooLong : std::runtime_error {
+  ExprTooLong() : std::runtime_error("mi355q: expression too long") {}
+};
 
 // Types the plan ABI cannot state are refused here instead of being read as integers of their byte width: DECIMAL /
 // NUMERIC (scale: casts, multiplication and AVG would need scale_decimal_up / _down), none-encoded strings, arrays,
@@ -138,7 +142,7 @@ inline bool contains_unsafe_division(const Analyzer::Expr* e) {
 inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
                       const std::function<int(const Analyzer::ColumnVar*)>& outer_col) {
   auto push = [&](int32_t op, int32_t type, int32_t arg, int64_t ilit, double flit, int32_t null_lit = 0) {
-    if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) unsupported("expression too long");
+    if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
     x.nodes[x.n_nodes++] = mi355q_expr_node{op, type, arg, null_lit, ilit, flit};
   };
   if (auto cv = dynamic_cast<const Analyzer::ColumnVar*>(e)) {
@@ -266,6 +270,52 @@ inline mi355q_qual translate_qual(const Analyzer::Expr* e, const std::function<i
   return q;
 }
 
+// A BOOLEAN program that does not fit MI355Q_MAX_EXPR_NODES (the reference's own `x > 6 AND x < 8 OR (z > 100 AND z < 103)`
+// has 15 nodes): the operands of a PLAIN AND / OR at its root are evaluated whatever the row holds (codegenLogical
+// :299-342 emits both), so each can be an expression of its own and the root reads their values (MI355Q_EX_COL n_cols + j).
+// Not where the short-circuit form applies: there the second operand must stay unevaluated.  `operand_col` = value_col of the
+// executor half (allocates — or finds — the expression of an Analyzer node, splitting it further the same way).
+inline void flatten_plain_logic(const Analyzer::Expr* e, SQLOps op, std::vector<const Analyzer::Expr*>& out) {
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  if (b && b->get_optype() == op) {
+    flatten_plain_logic(b->get_left_operand(), op, out);
+    flatten_plain_logic(b->get_right_operand(), op, out);
+    return;
+  }
+  out.push_back(e);
+}
+inline bool split_plain_logic(const Analyzer::Expr* e, mi355q_expr& x, const std::function<int(const Analyzer::ColumnVar*)>& outer_col,
+                              const std::function<int(const Analyzer::Expr*)>& operand_col) {
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  if (!b || (b->get_optype() != kAND && b->get_optype() != kOR) || contains_unsafe_division(e)) return false;
+  // `a OR b OR c` nested any way round: the operands of the whole chain (three-valued AND / OR are associative)
+  std::vector<const Analyzer::Expr*> ops;
+  flatten_plain_logic(e, b->get_optype(), ops);
+  const int32_t op = b->get_optype() == kAND ? MI355Q_EX_AND : MI355Q_EX_OR;
+  x = mi355q_expr{};
+  for (size_t i = 0; i < ops.size(); ++i) {
+    if (!ops[i]->get_type_info().is_boolean()) return false;
+    // inline while the rest still fits as (value of an expression, op) pairs; else the operand becomes an expression of its own
+    const int reserve = (i ? 1 : 0) + 2 * (int)(ops.size() - 1 - i);
+    mi355q_expr tmp = x;
+    bool inlined = false;
+    try {
+      emit_expr(ops[i], tmp, outer_col);
+      inlined = tmp.n_nodes + reserve <= MI355Q_MAX_EXPR_NODES;
+    } catch (const ExprTooLong&) {
+    }
+    if (inlined) {
+      x = tmp;
+    } else {
+      const int c = operand_col(ops[i]);
+      if (x.n_nodes + 1 + reserve > MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+      x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_COL, 0, c, 0, 0, 0.0};
+    }
+    if (i) x.nodes[x.n_nodes++] = mi355q_expr_node{op, MI355Q_INT8, 0, 0, 0, 0.0};
+  }
+  return true;
+}
+
 // ---- conjuncts of simple_quals / quals
 // translate_qual's shapes
 inline bool qual_shaped(const Analyzer::Expr* e) {
@@ -351,6 +401,59 @@ inline void translate_conjunct(const Analyzer::Expr* e, const std::function<int(
   if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
   mi355q_qual q{};
   q.col = value_col(e);
+  q.op = MI355Q_EQ;
+  q.ival = 1;
+  quals[(*n_quals)++] = q;
+}
+
+// ---- the WHERE clause as a whole: simple_quals and quals, a conjunction
+// The reference does not evaluate every conjunct for every row: prioritizeQuals (LogicalIR.cpp:158-195) sets the quals that
+// hold an unsafe division aside (should_defer_eval :55-77) and the row function evaluates them INSIDE the branch the primary
+// quals open — `WHERE x > 7 AND y / (x - 7) < 44` (Tests/ExecuteTest.cpp:2021) never divides by zero.  The plan evaluates the
+// expression of a qual for every row, so such a WHERE becomes ONE projected BOOLEAN expression: the safe conjuncts ANDed in the
+// plain form, then each deferred conjunct through a short-circuit AND (the second operand's checks exist only where the first
+// is TRUE), and the qual `that column = 1`.  A WHERE without unsafe divisions is translated conjunct by conjunct.
+using OuterCol = std::function<int(const Analyzer::ColumnVar*)>;
+using ExprFiller = std::function<void(mi355q_expr&, const OuterCol&)>;
+inline void flatten_conjuncts(const Analyzer::Expr* e, std::vector<const Analyzer::Expr*>& out) {
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  if (b && b->get_optype() == kAND) {
+    flatten_conjuncts(b->get_left_operand(), out);
+    flatten_conjuncts(b->get_right_operand(), out);
+    return;
+  }
+  out.push_back(e);
+}
+inline void translate_where(const std::vector<const Analyzer::Expr*>& where, const std::function<int(const Analyzer::Expr*)>& value_col,
+                            const std::function<int(const ExprFiller&)>& new_bool_col, mi355q_qual* quals, int32_t* n_quals,
+                            int32_t* n_groups) {
+  std::vector<const Analyzer::Expr*> all, primary, deferred;
+  for (const Analyzer::Expr* e : where) flatten_conjuncts(e, all);
+  for (const Analyzer::Expr* e : all) (contains_unsafe_division(e) ? deferred : primary).push_back(e);
+  if (deferred.empty()) {
+    for (const Analyzer::Expr* e : primary) translate_conjunct(e, value_col, quals, n_quals, n_groups);
+    return;
+  }
+  const int col = new_bool_col([&](mi355q_expr& x, const OuterCol& outer_col) {
+    auto push_and = [&](int32_t short_circuit) {
+      if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+      x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_AND, MI355Q_INT8, 0, short_circuit, 0, 0.0};
+    };
+    int n = 0;
+    for (const Analyzer::Expr* e : primary) {
+      if (!e->get_type_info().is_boolean()) unsupported("qual shape");
+      emit_expr(e, x, outer_col);
+      if (n++) push_and(0);
+    }
+    for (const Analyzer::Expr* e : deferred) {
+      if (!e->get_type_info().is_boolean()) unsupported("qual shape");
+      emit_expr(e, x, outer_col);
+      if (n++) push_and(1);
+    }
+  });
+  if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
+  mi355q_qual q{};
+  q.col = col;
   q.op = MI355Q_EQ;
   q.ival = 1;
   quals[(*n_quals)++] = q;

@@ -177,6 +177,26 @@ int main() {
         REQ(eg.n_nodes == 10 && eg.nodes[2].op == MI355Q_EX_NE && eg.nodes[6].op == MI355Q_EX_DIV && eg.nodes[8].op == MI355Q_EX_GT &&
             eg.nodes[9].op == MI355Q_EX_AND && eg.nodes[9].reserved == 1);
       }
+      // WHERE x < 1 AND x / y > 3 ... (ExecuteTest.cpp:2021's shape): the conjunct with the unsafe division is a DEFERRED qual in
+      // the reference (prioritizeQuals), here the second operand of a short-circuit AND inside one BOOLEAN column
+      {
+        int filled = 0;
+        mi355q_expr ew{};
+        auto new_bool_col = [&](const ExprFiller& fill) {
+          fill(ew, outer_col);
+          ++filled;
+          return 200;
+        };
+        nq = ng = 0;
+        translate_where({gt1.get(), lt.get()}, value_col, new_bool_col, qs, &nq, &ng);   // (written unsafe-first: still deferred)
+        REQ(filled == 1 && nq == 1 && ng == 0 && qs[0].col == 200 && qs[0].op == MI355Q_EQ && qs[0].ival == 1);
+        REQ(ew.n_nodes == 10 && ew.nodes[2].op == MI355Q_EX_LT && ew.nodes[6].op == MI355Q_EX_DIV && ew.nodes[8].op == MI355Q_EX_GT &&
+            ew.nodes[9].op == MI355Q_EX_AND && ew.nodes[9].reserved == 1);
+        filled = 0;
+        nq = ng = 0;
+        translate_where({or1.get(), ge.get()}, value_col, new_bool_col, qs, &nq, &ng);   // no unsafe division: conjunct by conjunct
+        REQ(filled == 0 && nq == 3 && ng == 1 && qs[2].op == MI355Q_GE);
+      }
       // -y, y IS NULL as values
       auto neg = std::make_shared<UOper>(t_big, false, kUMINUS, y);
       mi355q_expr en{};

@@ -1309,6 +1309,10 @@ struct ExprWalk {
   const mi355q_expr& x;
   const int8_t* const* cols;
   int64_t pos;
+  // the LOWERED plan (lower_plan): describes column n_cols + j, the value of an earlier expression of the plan — which the
+  // row function has already evaluated for this row and which `cols` holds like a plain column; nullptr: physical columns only
+  const mi355q_plan* low = nullptr;
+  const mi355q_col_desc& desc_of(int c) const { return c < p.n_cols || !low ? p.cols[c] : low->cols[c]; }
   // the node where the subtree that ENDS at node `end` starts
   int start_of(int end) const {
     int need = 1, i = end;
@@ -1324,7 +1328,7 @@ struct ExprWalk {
   // get_notnull() == false of the subtree's type
   bool may_be_null(int end) const {
     const mi355q_expr_node& n = x.nodes[end];
-    if (n.op == MI355Q_EX_COL) return p.cols[n.arg].nullable != 0;
+    if (n.op == MI355Q_EX_COL) return desc_of(n.arg).nullable != 0;
     if (n.op == MI355Q_EX_LIT) return n.reserved == 1;
     if (n.op == MI355Q_EX_CAST || n.op == MI355Q_EX_NOT || n.op == MI355Q_EX_UMINUS) return may_be_null(end - 1);
     if (n.op == MI355Q_EX_IS_NULL) return false;  // (a NOT NULL BOOLEAN)
@@ -1336,7 +1340,8 @@ struct ExprWalk {
     const mi355q_expr_node& n = x.nodes[end];
     switch (n.op) {
       case MI355Q_EX_COL: {
-        const mi355q_col_desc& cd = p.cols[n.arg];
+        if (n.arg >= p.n_cols && !low) return MI355Q_ERR_INVALID_PLAN;
+        const mi355q_col_desc& cd = desc_of(n.arg);
         OrcVal v{logical_type_of(cd), cd.nullable != 0, 0, 0.0, 0.0f};
         if (type_is_f32(cd.type)) v.f = decode_flt(cols[n.arg], pos);
         else if (type_is_fp(cd.type)) v.d = decode_dbl(cols[n.arg], pos);
@@ -1463,8 +1468,8 @@ struct ExprWalk {
   }
 };
 inline int32_t eval_expression(const mi355q_plan& p, const mi355q_expr& x, const int8_t* const* cols, int64_t pos,
-                               OrcVal* out) {
-  return ExprWalk{p, x, cols, pos}.eval(x.n_nodes - 1, out);
+                               OrcVal* out, const mi355q_plan* lowered = nullptr) {
+  return ExprWalk{p, x, cols, pos, lowered}.eval(x.n_nodes - 1, out);
 }
 
 // The plan with every expression described as the column n_cols + k (type / nullability from the rules
@@ -1482,9 +1487,11 @@ inline int lower_plan(const mi355q_plan& p, mi355q_plan* out) {
     for (int i = 0; i < x.n_nodes; ++i) {
       const mi355q_expr_node& n = x.nodes[i];
       if (n.op == MI355Q_EX_COL) {
-        if (n.arg < 0 || n.arg >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
-        ty[sp] = logical_type_of(p.cols[n.arg]);
-        nu[sp] = p.cols[n.arg].nullable != 0;
+        // a physical column, or the value of an earlier expression (column n_cols + j, j < k: described just above)
+        if (n.arg < 0 || n.arg >= p.n_cols + k) return MI355Q_ERR_INVALID_PLAN;
+        const mi355q_col_desc& cd = n.arg < p.n_cols ? p.cols[n.arg] : out->cols[n.arg];
+        ty[sp] = logical_type_of(cd);
+        nu[sp] = cd.nullable != 0;
         ++sp;
       } else if (n.op == MI355Q_EX_LIT) {
         ty[sp] = n.type;
@@ -1762,10 +1769,16 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
     cols = cx;
     for (int i = 0; i < p.n_quals; ++i)
       if (p.quals[i].col >= np) qual_exprs |= 1u << (p.quals[i].col - np);
+    // ... and the earlier expressions those read (a filter is evaluated before anything else of the row)
+    for (int k = nx - 1; k >= 0; --k)
+      if (qual_exprs & (1u << k))
+        for (int i = 0; i < sp.exprs[k].n_nodes; ++i)
+          if (sp.exprs[k].nodes[i].op == MI355Q_EX_COL && sp.exprs[k].nodes[i].arg >= np)
+            qual_exprs |= 1u << (sp.exprs[k].nodes[i].arg - np);
   }
   auto eval_into_cell = [&](int k, int64_t pos) -> int32_t {
     OrcVal v;
-    if (int32_t e = eval_expression(sp, sp.exprs[k], cx, pos, &v)) return e;
+    if (int32_t e = eval_expression(sp, sp.exprs[k], cx, pos, &v, &p)) return e;
     const int w = type_width(v.type);
     if (v.type == MI355Q_DOUBLE) vcell[k] = dbl_bits(v.d);
     else if (v.type == MI355Q_FLOAT) vcell[k] = (int64_t)(uint32_t)flt_bits(v.f);

@@ -56,13 +56,16 @@ def col_range(arrs: List[np.ndarray], t: int, nullable: bool) -> ExpressionRange
     return ExpressionRange(True, int(a.min()), int(a.max()), has_nulls)
 
 
-def expr_values(e: Expr, descs, cols):
+def expr_values(e: Expr, descs, cols, prior=()):
     """The expression over whole columns with numpy (test infrastructure: ranges of the virtual columns, the
     way getExpressionRange would bound them, and SQLite's input): returns (values, null mask, type).  Integer
     arithmetic is done in Python ints so that an overflow of the node's type is visible (-> None entries)."""
     st = []
     for nd in e.nodes:
-        if nd.op == capi.EX_COL:
+        if nd.op == capi.EX_COL and nd.arg >= len(descs):   # the value of an earlier expression of the plan
+            j = nd.arg - len(descs)
+            st.append(expr_values(prior[j], descs, cols, prior[:j]))
+        elif nd.op == capi.EX_COL:
             d = descs[nd.arg]
             a = np.asarray(cols[nd.arg])
             if d.type in (DOUBLE, capi.FLOAT):
@@ -131,11 +134,11 @@ def expr_values(e: Expr, descs, cols):
     return st[0]
 
 
-def expr_range(e: Expr, descs, frags) -> ExpressionRange:
+def expr_range(e: Expr, descs, frags, prior=()) -> ExpressionRange:
     cols = [np.concatenate([f[c] for f in frags]) for c in range(len(descs))] if frags else []
     if not frags or len(cols[0]) == 0:
         return ExpressionRange(True, 0, -1)
-    v, null, t = expr_values(e, descs, cols)
+    v, null, t = expr_values(e, descs, cols, prior)
     ok = v[~null]
     if len(ok) == 0:
         return ExpressionRange(True, 0, -1, bool(null.any()))
@@ -673,7 +676,7 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     # cast(x1k as float)) — and casts / + - * in aggregate arguments and quals, incl. the overflow error
     def xra(exprs, targets, quals=(), group=(), guess=16384, src=(descs, frags)):
         d, fr = src
-        xs = [e.with_range(expr_range(e, d, fr)) for e in exprs]
+        xs = [e.with_range(expr_range(e, d, fr, exprs[:i])) for i, e in enumerate(exprs)]
         return RelAlgExecutionUnit(list(d), list(targets), list(quals), list(group), max_groups_buffer_entry_guess=guess,
                                    exprs=xs)
     NC = len(descs)
@@ -793,6 +796,25 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("expr_group_by_a_boolean",                      # GROUP BY (c7 > 0 OR c6 IS NOT NULL): keys 1 / 0 / NULL
                       xra([c7pos.logical(capi.EX_OR, C(6).is_null().logical_not())],
                           [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(AVG, 3)], group=[NC], guess=64), frags))
+    # a program longer than 12 nodes as several expressions: the reference's own
+    # `WHERE x > 6 AND x < 8 OR (z > 100 AND z < 103) [OR (t > ..)]` (Tests/ExecuteTest.cpp:1906-1913) has 15 / 23 nodes
+    band = lambda c, t, lo, hi: C(c).cmp(capi.EX_GT, Expr.lit(t, lo)).logical(capi.EX_AND, C(c).cmp(capi.EX_LT, Expr.lit(t, hi)))
+    cases.append(Case("expr_three_bands_composed_of_earlier_expressions",
+                      xra([band(1, INT64, 10, 20), band(6, INT16, 100, 900), band(7, INT32, -5000, 5000),
+                           Expr.col(NC).logical(capi.EX_OR, Expr.col(NC + 1)).logical(capi.EX_OR, Expr.col(NC + 2))],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(COUNT), TargetExpr(SUM, 2), TargetExpr(COUNT, 6)],
+                          [Qual(NC + 3, EQ, 1)], group=[1]), frags))
+    cases.append(Case("expr_value_of_an_earlier_expression_in_arithmetic",   # SUM((c2 + c8) * 2 - (c2 + c8) / 3), MAX(c2 + c8)
+                      xra([C(2).add(C(8), INT64),
+                           Expr.col(NC).mul(Expr.lit(INT64, 2), INT64).sub(Expr.col(NC).div(Expr.lit(INT64, 3), INT64), INT64)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(SUM, NC + 1), TargetExpr(MAX, NC), TargetExpr(COUNT, NC + 1)],
+                          group=[10]), frags))
+    cases.append(Case("expr_error_in_an_earlier_expression_read_by_a_qual",   # (c5 / (c5 - c5)) read by the filter's expression: error 1 on every row
+                      xra([C(5).div(C(5).sub(C(5), INT8), INT8), Expr.col(NC).cmp(capi.EX_GT, Expr.lit(INT8, 0))],
+                          [TargetExpr(COUNT)], [Qual(NC + 1, EQ, 1), Qual(1, LT, 0)]), frags, expect_error=capi.ERR_DIV_BY_ZERO))
+    cases.append(Case("expr_error_in_an_earlier_expression_of_filtered_rows_only",   # the same division behind a target: no row passes, no error
+                      xra([C(5).div(C(5).sub(C(5), INT8), INT8), Expr.col(NC).cast(INT64).add(C(2), INT64)],
+                          [TargetExpr(COUNT), TargetExpr(SUM, NC + 1)], [Qual(1, LT, 0)]), frags))
     um = np.array([5, -2**31, 7], dtype=np.int32)
     um_src = ([InputColDescriptor(INT32, False, col_range([um], INT32, False))], [[um]])
     cases.append(Case("expr_uminus_of_the_type_minimum_is_error_7",   # -c0 where a NOT NULL INT column holds INT32_MIN

@@ -99,9 +99,7 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     if (int32_t e = build_dev_plan(lp, ql, &dl)) return e;
     emu_attach_join(&lp, in, join_hash_type, join_buf, join_min, join_max, join_entries, join_n_keys, join_width, &dl);
     const int nc = plan->n_cols, nx = plan->n_exprs, nc2 = nc + nx;
-    uint32_t qual_expr_mask = 0;
-    for (int i = 0; i < plan->n_quals; ++i)
-      if (plan->quals[i].col >= nc) qual_expr_mask |= 1u << (plan->quals[i].col - nc);
+    const uint32_t qual_expr_mask = expr_qual_mask(*plan);
     std::vector<std::vector<int64_t>> store((size_t)in->n_frags * nx);
     std::vector<const void*> cols2((size_t)in->n_frags * nc2);
     for (int f = 0; f < in->n_frags; ++f) {

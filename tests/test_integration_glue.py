@@ -143,3 +143,96 @@ int main() {
                             "-I" + os.path.join(ROOT, "include"), src, "-o", exe], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
         assert subprocess.run([exe], capture_output=True, text=True).returncode == 0
+
+
+def test_mock_reference_where_clauses_through_to_plan():
+    """The executor half (to_plan, on the mock) on WHERE clauses of the reference's own Select.FilterAndSimpleAggregation
+    (Tests/ExecuteTest.cpp:1906-1913, :2021) that have no qual shape: AND inside OR becomes BOOLEAN expressions — split over
+    several where the program passes 12 nodes, the root reading the values of the earlier ones — and a conjunct with an unsafe
+    division is the second operand of a short-circuit AND behind the other conjuncts (the reference defers such quals)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp")
+        with open(src, "w") as f:
+            f.write('''#include "Mi355qExecutor.h"
+#include <cstdio>
+using namespace mi355q_glue;
+using Analyzer::BinOper;
+static int bad = 0;
+#define REQ(c) do { if (!(c)) { std::printf("line %d: %s\\n", __LINE__, #c); ++bad; } } while (0)
+int main() {
+  const int kDb = 1, kTable = 7;
+  Executor executor;
+  const SQLTypeInfo ti[4] = {SQLTypeInfo(kINT, true), SQLTypeInfo(kINT, false), SQLTypeInfo(kSMALLINT, false), SQLTypeInfo(kBIGINT, false)};
+  for (int c = 0; c < 4; ++c) {
+    executor.column_types[{kTable, c}] = ti[c];
+    executor.column_ranges[{kTable, c}] = ExpressionRange::makeIntRange(-100, 2000, 0, c != 0);
+  }
+  const std::vector<InputTableInfo> query_infos = {{shared::TableKey{kDb, kTable}, 20}};
+  auto col = [&](int c) { return std::make_shared<Analyzer::ColumnVar>(ti[c], shared::ColumnKey{kDb, kTable, c}, 0); };
+  auto lit = [&](int c, int64_t v) {
+    Datum dv;
+    if (c == 2) dv.smallintval = (int16_t)v; else if (c == 3) dv.bigintval = v; else dv.intval = (int32_t)v;
+    return std::make_shared<Analyzer::Constant>(SQLTypeInfo(ti[c].get_type(), true), false, dv);
+  };
+  const SQLTypeInfo tb(kBOOLEAN, false);
+  auto cmp = [&](SQLOps op, int c, int64_t v) { return std::make_shared<BinOper>(tb, op, col(c), lit(c, v)); };
+  auto band = [&](int c, int64_t lo, int64_t hi) { return std::make_shared<BinOper>(tb, kAND, cmp(kGT, c, lo), cmp(kLT, c, hi)); };
+  Analyzer::AggExpr cnt(SQLTypeInfo(kBIGINT, true), kCOUNT, nullptr);
+  auto unit = [&]() {
+    RelAlgExecutionUnit ra;
+    for (int c = 0; c < 4; ++c) ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(c, kTable, kDb, 0));
+    ra.groupby_exprs.push_back(nullptr);
+    ra.target_exprs = {&cnt};
+    return ra;
+  };
+  {  // WHERE x > 6 AND x < 8 OR (z > 100 AND z < 103): 15 nodes -> the z band is expression 0, the root reads its value
+    RelAlgExecutionUnit ra = unit();
+    ra.quals.push_back(std::make_shared<BinOper>(tb, kOR, band(0, 6, 8), band(2, 100, 103)));
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 1 && p.quals[0].col == 4 + 1 && p.quals[0].op == MI355Q_EQ && p.quals[0].ival == 1 && p.n_exprs == 2);
+    REQ(p.exprs[0].n_nodes == 7 && p.exprs[0].nodes[0].arg == 2 && p.exprs[0].nodes[6].op == MI355Q_EX_AND);
+    REQ(p.exprs[1].n_nodes == 9 && p.exprs[1].nodes[0].arg == 0 && p.exprs[1].nodes[6].op == MI355Q_EX_AND &&
+        p.exprs[1].nodes[7].op == MI355Q_EX_COL && p.exprs[1].nodes[7].arg == 4 + 0 && p.exprs[1].nodes[8].op == MI355Q_EX_OR &&
+        p.exprs[1].nodes[8].reserved == 0);
+  }
+  {  // ... OR (t > 1000 AND t < 1002): 23 nodes -> two earlier expressions
+    RelAlgExecutionUnit ra = unit();
+    auto two = std::make_shared<BinOper>(tb, kOR, band(0, 6, 8), band(2, 100, 102));
+    ra.quals.push_back(std::make_shared<BinOper>(tb, kOR, two, band(3, 1000, 1002)));
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 1 && p.quals[0].col == 4 + 2 && p.n_exprs == 3);
+    REQ(p.exprs[2].n_nodes == 11 && p.exprs[2].nodes[7].arg == 4 && p.exprs[2].nodes[8].op == MI355Q_EX_OR &&
+        p.exprs[2].nodes[9].arg == 5 && p.exprs[2].nodes[10].op == MI355Q_EX_OR);
+    REQ(p.exprs[0].nodes[0].arg == 2 && p.exprs[1].nodes[0].arg == 3);
+  }
+  {  // WHERE x > 7 AND y / (x - 7) < 44 (simple_quals: x > 7; quals: the division): one short-circuit AND, 11 nodes
+    RelAlgExecutionUnit ra = unit();
+    ra.simple_quals.push_back(cmp(kGT, 0, 7));
+    auto diff = std::make_shared<BinOper>(ti[1], kMINUS, col(0), lit(0, 7));
+    auto quot = std::make_shared<BinOper>(ti[1], kDIVIDE, col(1), diff);
+    ra.quals.push_back(std::make_shared<BinOper>(tb, kLT, quot, lit(1, 44)));
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 1 && p.quals[0].col == 4 && p.quals[0].op == MI355Q_EQ && p.quals[0].ival == 1 && p.n_exprs == 1);
+    REQ(p.exprs[0].n_nodes == 11 && p.exprs[0].nodes[2].op == MI355Q_EX_GT && p.exprs[0].nodes[7].op == MI355Q_EX_DIV &&
+        p.exprs[0].nodes[9].op == MI355Q_EX_LT && p.exprs[0].nodes[10].op == MI355Q_EX_AND && p.exprs[0].nodes[10].reserved == 1);
+  }
+  {  // WHERE x > 6 AND x < 8 AND z > 100 AND z < 102 (:1905): four plain quals, no expression
+    RelAlgExecutionUnit ra = unit();
+    ra.simple_quals = {cmp(kGT, 0, 6), cmp(kLT, 0, 8), cmp(kGT, 2, 100), cmp(kLT, 2, 102)};
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 4 && p.n_exprs == 0 && p.quals[3].col == 2 && p.quals[3].op == MI355Q_LT && p.quals[3].ival == 102);
+  }
+  std::printf(bad ? "bad\\n" : "ok\\n");
+  return bad ? 1 : 0;
+}
+''')
+        exe = os.path.join(d, "t")
+        integ = os.path.join(ROOT, "integration")
+        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-DMI355Q_GLUE_MOCK_HEADERS", "-I" + integ, "-I" + os.path.join(ROOT, "include"),
+                            src, os.path.join(integ, "Mi355qExecutor.cpp"), os.path.join(integ, "mock", "heavydb_mock.cpp"),
+                            "-L" + os.path.join(ROOT, "heavydb_amd", "lib"), "-lmi355q", "-Wl,-rpath," + os.path.join(ROOT, "heavydb_amd", "lib"),
+                            "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        run = subprocess.run([exe], capture_output=True, text=True)
+        assert run.returncode == 0, run.stdout + run.stderr

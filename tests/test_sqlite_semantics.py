@@ -46,14 +46,17 @@ def _lit(col_type, q):
     return repr(float(q.literal)) if col_type in (capi.DOUBLE, capi.FLOAT) else str(int(q.literal))
 
 
-def _expr_sql(e, descs):
+def _expr_sql(e, descs, prior=()):
     """A projected expression (postfix micro-ops) as SQLite text over the base table's columns: integer
     arithmetic is 64-bit in SQLite (the cases keep clear of overflow), CAST(.. AS REAL) for the casts to
     DOUBLE / FLOAT (the FLOAT cases use values single precision holds exactly), ROUND() — half away from
     zero, like DEF_ROUND_NULLABLE — for floating point -> integer."""
     st = []
     for n in e.nodes:
-        if n.op == capi.EX_COL:
+        if n.op == capi.EX_COL and n.arg >= len(descs):   # the value of an earlier expression of the plan: its text
+            j = n.arg - len(descs)
+            st.append((_expr_sql(prior[j], descs, prior[:j]), prior[j].result(descs, prior[:j])[0] in (capi.DOUBLE, capi.FLOAT)))
+        elif n.op == capi.EX_COL:
             st.append((f"c{n.arg}", descs[n.arg].type in (capi.DOUBLE, capi.FLOAT)))
         elif n.op == capi.EX_LIT:
             fp = n.type in (capi.DOUBLE, capi.FLOAT)
@@ -157,7 +160,7 @@ def _load(case):
         db.executemany(f"INSERT INTO {base} VALUES (" + ",".join("?" * n_cols) + ")", list(zip(*vals)))
     if ra.exprs:
         db.execute("CREATE VIEW f AS SELECT " + ", ".join(f"c{i}" for i in range(n_cols)) + ", " +
-                   ", ".join(f"{_expr_sql(e, ra.input_col_descs)} AS c{n_cols + k}" for k, e in enumerate(ra.exprs)) +
+                   ", ".join(f"{_expr_sql(e, ra.input_col_descs, ra.exprs[:k])} AS c{n_cols + k}" for k, e in enumerate(ra.exprs)) +
                    " FROM fb")
     if case.join_keys is not None:
         keys = case.join_keys if isinstance(case.join_keys, (list, tuple)) else [case.join_keys]
