@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from heavydb_amd import capi
-from heavydb_amd.executor import ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+from heavydb_amd.executor import Expr, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
 from tests.cases import Case, col_range
 from tests.helpers import F32_ATOL, F32_RTOL
 
@@ -334,6 +334,181 @@ def test_reference_queries(oracle, qi, bigint_count):
                     assert math.isclose(a, b, rel_tol=rt, abs_tol=at), (name, sql, t, w, g)
                 else:
                     assert a == b, (name, sql, t, w, g)
+
+
+# ---- the queries of Select.FilterAndSimpleAggregation that carry EXPRESSIONS (Tests/ExecuteTest.cpp:1901-2035): arithmetic over
+# several columns in aggregates and filters, narrowing casts, unary minus, AND inside OR, a division guarded by another
+# conjunct, IS NULL of an expression.  The plan is written the way the analyzer types the tree (the narrower operand is cast
+# to the common type, a literal takes the column's type) and the binding translates it (integration/Mi355qTranslate.h): a
+# filter without a qual shape is a BOOLEAN expression `= 1`, programs beyond 12 nodes are split over expressions.
+class EX:
+    """an expression over column NAMES; built against the query's own column order (and the index of its first expression)"""
+    def __init__(self, names, build):
+        self.names, self.build = names, build
+
+
+def xc(name):
+    return EX([name], lambda ix, nc: Expr.col(ix[name]))
+
+
+def xl(t, v):
+    return EX([], lambda ix, nc: Expr.lit(t, v))
+
+
+def xref(k):   # the value of the plan's earlier expression k
+    return EX([], lambda ix, nc: Expr.col(nc + k))
+
+
+def _x2(method):
+    return lambda a, b, t: EX(a.names + b.names, lambda ix, nc: getattr(a.build(ix, nc), method)(b.build(ix, nc), t))
+
+
+xadd, xsub, xmul, xdiv = _x2("add"), _x2("sub"), _x2("mul"), _x2("div")
+
+
+def xcast(a, t):
+    return EX(a.names, lambda ix, nc: a.build(ix, nc).cast(t))
+
+
+def xneg(a, t):
+    return EX(a.names, lambda ix, nc: a.build(ix, nc).neg(t))
+
+
+def xcmp(a, op, b):
+    code = {"<": capi.EX_LT, ">": capi.EX_GT, "=": capi.EX_EQ, "<>": capi.EX_NE, "<=": capi.EX_LE, ">=": capi.EX_GE}[op]
+    return EX(a.names + b.names, lambda ix, nc: a.build(ix, nc).cmp(code, b.build(ix, nc)))
+
+
+def xlogic(a, op, b, short_circuit=False):
+    code = {"AND": capi.EX_AND, "OR": capi.EX_OR}[op]
+    return EX(a.names + b.names, lambda ix, nc: a.build(ix, nc).logical(code, b.build(ix, nc), short_circuit))
+
+
+def xband(name, t, lo, hi):   # name > lo AND name < hi
+    return xlogic(xcmp(xc(name), ">", xl(t, lo)), "AND", xcmp(xc(name), "<", xl(t, hi)))
+
+
+def _unit_x(descs, frags, targets, quals, group, exprs, **kw):
+    """like _unit; a target's / qual's / group's column may be ("x", k): expression k of `exprs`"""
+    from tests.cases import expr_range
+    is_x = lambda c: isinstance(c, tuple) and c[0] == "x"
+    used = []
+    for n in [g for g in group if not is_x(g)] + [t[2] for t in targets if t[0] == "agg" and t[2] and not is_x(t[2])] + \
+            [c for c, _, _ in quals if not is_x(c)] + [n for e in exprs for n in e.names]:
+        if n not in used:
+            used.append(n)
+    idx = {n: i for i, n in enumerate(used)}
+    src = [NAMES.index(n) for n in used]
+    nc = len(used)
+    d2 = [descs[i] for i in src]
+    f2 = [[f[i] for i in src] for f in frags]
+    col = lambda c: nc + c[1] if is_x(c) else idx[c]
+    built = []
+    for e in exprs:
+        b = e.build(idx, nc)
+        built.append(b.with_range(expr_range(b, d2, f2, built[:])))
+    tx = [TargetExpr(capi.PROJECT_KEY, t[1]) if t[0] == "key" else TargetExpr(t[1], -1 if t[2] is None else col(t[2])) for t in targets]
+    ra = RelAlgExecutionUnit(d2, tx, [Qual(col(c), op, lit) for c, op, lit in quals], [col(g) for g in group], exprs=built, **kw)
+    return ra, f2
+
+
+X0, X1, X2, X3 = ("x", 0), ("x", 1), ("x", 2), ("x", 3)
+_xy = xadd(xc("x"), xc("y"), I32)                                  # x + y
+_xyz = xadd(_xy, xcast(xc("z"), I32), I32)                         # x + y + z
+_xyzt = xadd(xcast(_xyz, I64), xc("t"), I64)                       # x + y + z + t
+_xmy = xsub(xc("x"), xc("y"), I32)                                 # x - y
+_xy15 = xadd(xmul(xc("x"), xc("y"), I32), xl(I32, 15), I32)        # x * y + 15
+T8 = lambda n: xcast(xc(n), I8)
+# (SQL text of the reference, targets, quals, group, expressions)
+EXPR_QUERIES = [
+    ("SELECT SUM(x + y) FROM test;", [agg("SUM", X0)], [], [], [_xy]),
+    ("SELECT SUM(x + y + z) FROM test;", [agg("SUM", X0)], [], [], [_xyz]),
+    ("SELECT SUM(x + y + z + t) FROM test;", [agg("SUM", X0)], [], [], [_xyzt]),
+    ("SELECT COUNT(*) FROM test WHERE x > 6 AND x < 8 OR (z > 100 AND z < 103);", [agg("COUNT")], [q(X1, "=", 1)], [],
+     [xband("z", I16, 100, 103), xlogic(xband("x", I32, 6, 8), "OR", xref(0))]),
+    ("SELECT COUNT(*) FROM test WHERE x > 6 AND x < 8 OR (z > 100 AND z < 102) OR (t > 1000 AND t < 1002);", [agg("COUNT")],
+     [q(X2, "=", 1)], [],
+     [xband("z", I16, 100, 102), xband("t", I64, 1000, 1002), xlogic(xlogic(xband("x", I32, 6, 8), "OR", xref(0)), "OR", xref(1))]),
+    ("SELECT COUNT(*) FROM test WHERE x + y = 49;", [agg("COUNT")], [q(X0, "=", 49)], [], [_xy]),
+    ("SELECT COUNT(*) FROM test WHERE x + y + z = 150;", [agg("COUNT")], [q(X0, "=", 150)], [], [_xyz]),
+    ("SELECT COUNT(*) FROM test WHERE x + y + z + t = 1151;", [agg("COUNT")], [q(X0, "=", 1151)], [], [_xyzt]),
+    ("SELECT COUNT(*) FROM test WHERE CAST(x as TINYINT) + CAST(y as TINYINT) < CAST(z as TINYINT);", [agg("COUNT")],
+     [q(X0, "=", 1)], [], [xcmp(xadd(T8("x"), T8("y"), I8), "<", T8("z"))]),
+    ("SELECT COUNT(*) FROM test WHERE CAST(y as TINYINT) / CAST(x as TINYINT) = 6", [agg("COUNT")], [q(X0, "=", 6)], [],
+     [xdiv(T8("y"), T8("x"), I8)]),
+    ("SELECT SUM(x + y) FROM test WHERE x + y = 49;", [agg("SUM", X0)], [q(X0, "=", 49)], [], [_xy]),
+    ("SELECT SUM(x + y + z) FROM test WHERE x + y = 49;", [agg("SUM", X1)], [q(X0, "=", 49)], [], [_xy, _xyz]),
+    ("SELECT SUM(x + y + z + t) FROM test WHERE x + y = 49;", [agg("SUM", X1)], [q(X0, "=", 49)], [], [_xy, _xyzt]),
+    ("SELECT COUNT(*) FROM test WHERE x - y = -35;", [agg("COUNT")], [q(X0, "=", -35)], [], [_xmy]),
+    ("SELECT COUNT(*) FROM test WHERE x - y + z = 66;", [agg("COUNT")], [q(X0, "=", 66)], [], [xadd(_xmy, xcast(xc("z"), I32), I32)]),
+    ("SELECT COUNT(*) FROM test WHERE x - y + z + t = 1067;", [agg("COUNT")], [q(X0, "=", 1067)], [],
+     [xadd(xcast(xadd(_xmy, xcast(xc("z"), I32), I32), I64), xc("t"), I64)]),
+    ("SELECT COUNT(*) FROM test WHERE y - x = 35;", [agg("COUNT")], [q(X0, "=", 35)], [], [xsub(xc("y"), xc("x"), I32)]),
+    ("SELECT SUM(2 * x) FROM test WHERE x = 7;", [agg("SUM", X0)], [q("x", "=", 7)], [], [xmul(xl(I32, 2), xc("x"), I32)]),
+    ("SELECT SUM(2 * x + z) FROM test WHERE x = 7;", [agg("SUM", X0)], [q("x", "=", 7)], [],
+     [xadd(xmul(xl(I32, 2), xc("x"), I32), xcast(xc("z"), I32), I32)]),
+    ("SELECT SUM(x + y) FROM test WHERE x - y = -35;", [agg("SUM", X0)], [q(X1, "=", -35)], [], [_xy, _xmy]),
+    ("SELECT SUM(x + y - z) FROM test WHERE y - x = 35;", [agg("SUM", X0)], [q(X1, "=", 35)], [],
+     [xsub(_xy, xcast(xc("z"), I32), I32), xsub(xc("y"), xc("x"), I32)]),
+    ("SELECT SUM(x * y + 15) FROM test WHERE x + y + 1 = 50;", [agg("SUM", X0)], [q(X1, "=", 50)], [], [_xy15, xadd(_xy, xl(I32, 1), I32)]),
+    ("SELECT SUM(x * y + 15) FROM test WHERE x + y + z + 1 = 151;", [agg("SUM", X0)], [q(X1, "=", 151)], [],
+     [_xy15, xadd(_xyz, xl(I32, 1), I32)]),
+    ("SELECT SUM(x * y + 15) FROM test WHERE x + y + z + t + 1 = 1152;", [agg("SUM", X0)], [q(X1, "=", 1152)], [],
+     [_xy15, xadd(_xyzt, xl(I64, 1), I64)]),
+    ("SELECT MIN(x * y + 15) FROM test WHERE x + y + 1 = 50;", [agg("MIN", X0)], [q(X1, "=", 50)], [], [_xy15, xadd(_xy, xl(I32, 1), I32)]),
+    ("SELECT MAX(x * y + 15) FROM test WHERE x + y + z + 1 = 151;", [agg("MAX", X0)], [q(X1, "=", 151)], [],
+     [_xy15, xadd(_xyz, xl(I32, 1), I32)]),
+    ("SELECT AVG(x + y) FROM test;", [agg("AVG", X0)], [], [], [_xy]),
+    ("SELECT AVG(x + y + z) FROM test;", [agg("AVG", X0)], [], [], [_xyz]),
+    ("SELECT AVG(x + y + z + t) FROM test;", [agg("AVG", X0)], [], [], [_xyzt]),
+    ("SELECT AVG(u * f) FROM test;", [agg("AVG", X0)], [], [], [xmul(xcast(xc("u"), F32), xc("f"), F32)]),
+    ("SELECT AVG(u * d) FROM test;", [agg("AVG", X0)], [], [], [xmul(xcast(xc("u"), F64), xc("d"), F64)]),
+    ("SELECT SUM(-y) FROM test;", [agg("SUM", X0)], [], [], [xneg(xc("y"), I32)]),
+    ("SELECT SUM(-z) FROM test;", [agg("SUM", X0)], [], [], [xneg(xc("z"), I16)]),
+    ("SELECT SUM(-t) FROM test;", [agg("SUM", X0)], [], [], [xneg(xc("t"), I64)]),
+    ("SELECT SUM(-f) FROM test;", [agg("SUM", X0)], [], [], [xneg(xc("f"), F32)]),
+    ("SELECT SUM(-d) FROM test;", [agg("SUM", X0)], [], [], [xneg(xc("d"), F64)]),
+    ("SELECT COUNT(*) FROM test WHERE x < y AND 1=1;", [agg("COUNT")], [q(X0, "=", 1)], [], [xcmp(xc("x"), "<", xc("y"))]),   # (folded)
+    ("SELECT COUNT(*) FROM test WHERE x < y OR 1<1;", [agg("COUNT")], [q(X0, "=", 1)], [], [xcmp(xc("x"), "<", xc("y"))]),
+    ("SELECT COUNT(*) FROM test WHERE (x > 7 AND y / (x - 7) < 44);", [agg("COUNT")], [q(X0, "=", 1)], [],   # the deferred qual
+     [xlogic(xcmp(xc("x"), ">", xl(I32, 7)), "AND",
+             xcmp(xdiv(xc("y"), xsub(xc("x"), xl(I32, 7), I32), I32), "<", xl(I32, 44)), short_circuit=True)]),
+    ("SELECT COUNT(*) FROM test WHERE fx + 1 IS NULL;", [agg("COUNT")], [q(X0, "IS NULL", 0)], [], [xadd(xc("fx"), xl(I32, 1), I32)]),
+    ("SELECT x, SUM(-y), COUNT(*) FROM test WHERE NOT (z > 100 AND t = 1002) GROUP BY x;",                    # (not the reference's text)
+     [key(), agg("SUM", X0), agg("COUNT")], [q(X1, "=", 1)], ["x"],
+     [xneg(xc("y"), I32), EX(["z", "t"], lambda ix, nc: xlogic(xcmp(xc("z"), ">", xl(I16, 100)), "AND",
+                                                                xcmp(xc("t"), "=", xl(I64, 1002))).build(ix, nc).logical_not())]),
+]
+
+
+def _check_rows(sql, want, rows, fp, qm, name, rel):
+    assert len(rows) == len(want), (name, sql, want, rows)
+    for w, g in zip(want, rows):
+        for t, (a, b) in enumerate(zip(w, g)):
+            if a is None or b is None:
+                assert a is None and b is None, (name, sql, t, w, g)
+            elif fp[t]:
+                rt, at = (F32_RTOL, F32_ATOL) if qm.target_arg_is_f32[t] else (rel, 0.0)
+                assert math.isclose(a, b, rel_tol=rt, abs_tol=at), (name, sql, t, w, g)
+            else:
+                assert a == b, (name, sql, t, w, g)
+
+
+@pytest.mark.parametrize("qi", range(len(EXPR_QUERIES)), ids=[s[0][7:70].replace(" ", "_") for s in EXPR_QUERIES])
+def test_reference_expression_queries(oracle, qi):
+    from tests.test_rowlogic_emu import _emu_execute
+    sql, targets, quals, group, exprs = EXPR_QUERIES[qi]
+    descs, frags, db = _table()
+    ra, frags = _unit_x(descs, frags, targets, quals, group, exprs, num_tuples=sum(REPEAT))
+    plan = ra.to_plan()
+    qm, buf, code = oracle.execute(plan, frags, n_threads=3)
+    assert code == 0, sql
+    fp = [bool(qm.target_is_fp[t]) for t in range(qm.n_targets)]
+    want = sorted((tuple(float(v) if f and v is not None else v for v, f in zip(r, fp)) for r in db.execute(sql).fetchall()), key=_key)
+    eq, ebuf, ecode = _emu_execute(Case("ref", ra, frags), plan, None)
+    assert ecode == 0, sql
+    _check_rows(sql, want, sorted(_rows(oracle.fetch_rows(qm, buf), qm), key=_key), fp, qm, "oracle", 1e-12)
+    _check_rows(sql, want, sorted(_rows(oracle.fetch_rows(eq, ebuf), eq), key=_key), fp, qm, "product row logic", 1e-12)
 
 
 # ---- joins against the reference's `test_inner` (ExecuteTest.cpp:29719-29738: two rows)

@@ -39,6 +39,26 @@ def test_reference_queries_on_gpu(torch_cuda, oracle, qi):
                 assert a == b, (sql, t, w, g)
 
 
+def test_reference_expression_queries_on_gpu(torch_cuda, oracle):
+    """Select.FilterAndSimpleAggregation's queries with expressions (tests/test_execute_style.py EXPR_QUERIES: arithmetic over
+    several columns, narrowing casts, unary minus, AND inside OR split over expressions, the deferred qual behind a short-circuit
+    AND, IS NULL of an expression) through k_project and the kernel families, against SQLite running the reference's text."""
+    from heavydb_amd.executor import Executor
+    from tests.test_execute_style import EXPR_QUERIES, _check_rows, _unit_x
+    assert len(EXPR_QUERIES) == 41
+    ex = Executor(0)
+    for sql, targets, quals, group, exprs in EXPR_QUERIES:
+        descs, frags, db = _table()
+        ra, frags = _unit_x(descs, frags, targets, quals, group, exprs, num_tuples=sum(REPEAT))
+        case = Case("ref", ra, frags)
+        frag_t, inner_t = _upload(torch_cuda, case)
+        rs = ex.executeWorkUnit(ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+        qm = rs.getQueryMemDesc()
+        fp = [bool(qm.target_is_fp[t]) for t in range(qm.n_targets)]
+        want = sorted((tuple(float(v) if f and v is not None else v for v, f in zip(r, fp)) for r in db.execute(sql).fetchall()), key=_key)
+        _check_rows(sql, want, sorted(_rows(rs.fetch(), qm), key=_key), fp, qm, "hip", 1e-9)
+
+
 @pytest.mark.parametrize("ji", range(11))
 def test_reference_join_queries_on_gpu(torch_cuda, oracle, ji):
     from heavydb_amd.executor import Executor
