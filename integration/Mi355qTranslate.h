@@ -114,6 +114,21 @@ inline int64_t int_literal(const SQLTypeInfo& ti, const Datum& d) {
   }
 }
 
+// x IN (c0, c1, ...) (Analyzer::InValues; CodeGenerator::codegen(InValues*), InValuesIR.cpp:23-72: the logical_or chain of
+// `x = ci` comparisons, or a bitmap of the values with the same truth table): taken with non-NULL constants of the
+// argument's own type, as the analyzer leaves them
+inline std::vector<const Analyzer::Constant*> in_list_constants(const Analyzer::InValues* in) {
+  std::vector<const Analyzer::Constant*> out;
+  const int32_t t = logical_type(in->get_arg()->get_type_info());
+  for (const auto& v : in->get_value_list()) {
+    auto c = dynamic_cast<const Analyzer::Constant*>(v.get());
+    if (!c || c->get_is_null() || logical_type(c->get_type_info()) != t) unsupported("IN list member");
+    out.push_back(c);
+  }
+  if (out.empty()) unsupported("empty IN list");
+  return out;
+}
+
 // contains_unsafe_division (LogicalIR.cpp:26-53) over the expression kinds this binding takes: a kDIVIDE whose divisor is
 // not a constant, or is the NULL / a zero constant.  (The reference walks with Expr::find_expr; kMODULO is not looked at.)
 inline bool contains_unsafe_division(const Analyzer::Expr* e) {
@@ -129,6 +144,7 @@ inline bool contains_unsafe_division(const Analyzer::Expr* e) {
     return contains_unsafe_division(b->get_left_operand()) || contains_unsafe_division(b->get_right_operand());
   }
   if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) return contains_unsafe_division(u->get_operand());
+  if (auto in = dynamic_cast<const Analyzer::InValues*>(e)) return contains_unsafe_division(in->get_arg());
   if (auto ce = dynamic_cast<const Analyzer::CaseExpr*>(e)) {
     for (const auto& pr : ce->get_expr_pair_list())
       if (contains_unsafe_division(pr.first.get()) || contains_unsafe_division(pr.second.get())) return true;
@@ -202,6 +218,19 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
     emit_expr(b->get_left_operand(), x, outer_col);
     emit_expr(b->get_right_operand(), x, outer_col);
     push(op ? op : cmp, op ? logical_type(b->get_type_info()) : MI355Q_INT8, 0, 0, 0.0);
+  } else if (auto in = dynamic_cast<const Analyzer::InValues*>(e)) {
+    // (x = c0) OR (x = c1) OR ...: the plain form — every comparison is evaluated, as in the reference's loop
+    const auto vals = in_list_constants(in);
+    const int32_t t = logical_type(in->get_arg()->get_type_info());
+    for (size_t i = 0; i < vals.size(); ++i) {
+      emit_expr(in->get_arg(), x, outer_col);
+      const Datum d = vals[i]->get_constval();
+      if (t == MI355Q_DOUBLE) push(MI355Q_EX_LIT, t, 0, 0, d.doubleval);
+      else if (t == MI355Q_FLOAT) push(MI355Q_EX_LIT, t, 0, 0, d.floatval);
+      else push(MI355Q_EX_LIT, t, 0, int_literal(vals[i]->get_type_info(), d), 0.0);
+      push(MI355Q_EX_EQ, MI355Q_INT8, 0, 0, 0.0);
+      if (i) push(MI355Q_EX_OR, MI355Q_INT8, 0, 0, 0.0);
+    }
   } else if (auto ce = dynamic_cast<const Analyzer::CaseExpr*>(e)) {
     // CASE WHEN c0 THEN t0 WHEN c1 THEN t1 ... ELSE e END (CaseIR.cpp:67-140) = CASE(c0, t0, CASE(c1, t1, ... e)): the plan's
     // operand order is ELSE, THEN, condition, so the later WHENs are emitted first and the stack stays at <= 4 values
@@ -342,6 +371,7 @@ inline int disjunction_members(const Analyzer::Expr* e) {
   auto u = dynamic_cast<const Analyzer::UOper*>(e);
   if (u && u->get_optype() == kNOT)
     if (auto inner = dynamic_cast<const Analyzer::BinOper*>(u->get_operand())) return qual_shaped(inner) ? 1 : -1;
+  if (auto in = dynamic_cast<const Analyzer::InValues*>(e)) return (int)in_list_constants(in).size();  // x = c0 OR x = c1 ...
   return qual_shaped(e) ? 1 : -1;
 }
 // the members of a disjunction (group > 0), or one comparison (group 0); NOT over a comparison is folded into the operator
@@ -352,6 +382,22 @@ inline void emit_disjunction(const Analyzer::Expr* e, const std::function<int(co
   if (b && b->get_optype() == kOR) {
     emit_disjunction(b->get_left_operand(), value_col, quals, n_quals, group);
     emit_disjunction(b->get_right_operand(), value_col, quals, n_quals, group);
+    return;
+  }
+  if (auto in = dynamic_cast<const Analyzer::InValues*>(e)) {
+    const int col = value_col(in->get_arg());
+    for (const Analyzer::Constant* c : in_list_constants(in)) {
+      mi355q_qual qi{};
+      qi.col = col;
+      const auto& ti = c->get_type_info();
+      const Datum d = c->get_constval();
+      if (ti.get_type() == kDOUBLE) qi.fval = d.doubleval;
+      else if (ti.get_type() == kFLOAT) qi.fval = d.floatval;
+      else qi.ival = int_literal(ti, d);
+      if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
+      qi.op = MI355Q_QUAL_IN_OR_GROUP(MI355Q_EQ, group);
+      quals[(*n_quals)++] = qi;
+    }
     return;
   }
   mi355q_qual q{};
@@ -431,8 +477,22 @@ inline void translate_where(const std::vector<const Analyzer::Expr*>& where, con
   for (const Analyzer::Expr* e : where) flatten_conjuncts(e, all);
   for (const Analyzer::Expr* e : all) (contains_unsafe_division(e) ? deferred : primary).push_back(e);
   if (deferred.empty()) {
-    for (const Analyzer::Expr* e : primary) translate_conjunct(e, value_col, quals, n_quals, n_groups);
-    return;
+    // more conjuncts than the plan has quals (`x > 6 AND x < 8 AND z > 100 AND z < 102 AND t > 1000 AND t < 1002`,
+    // ExecuteTest.cpp:1907): the first ones as quals, the rest ANDed into one BOOLEAN expression `= 1`
+    auto needs = [](const Analyzer::Expr* e) {
+      const int m = disjunction_members(e);
+      return m < 1 ? 1 : m;
+    };
+    int total = *n_quals;
+    for (const Analyzer::Expr* e : primary) total += needs(e);
+    size_t i = 0;
+    if (total > MI355Q_MAX_QUALS)
+      for (int used = *n_quals; i < primary.size() && used + needs(primary[i]) <= MI355Q_MAX_QUALS - 1; ++i) used += needs(primary[i]);
+    else
+      i = primary.size();
+    for (size_t k = 0; k < i; ++k) translate_conjunct(primary[k], value_col, quals, n_quals, n_groups);
+    if (i == primary.size()) return;
+    primary.erase(primary.begin(), primary.begin() + (long)i);
   }
   const int col = new_bool_col([&](mi355q_expr& x, const OuterCol& outer_col) {
     auto push_and = [&](int32_t short_circuit) {

@@ -165,6 +165,17 @@ class CaseExpr : public Expr {  // Analyzer.h:1447
   std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>> expr_pair_list;
   std::shared_ptr<Analyzer::Expr> else_expr;
 };
+class InValues : public Expr {  // Analyzer.h:641
+ public:
+  InValues(std::shared_ptr<Analyzer::Expr> a, const std::list<std::shared_ptr<Analyzer::Expr>>& l)
+      : Expr(SQLTypeInfo(kBOOLEAN, a->get_type_info().get_notnull())), arg(std::move(a)), value_list(l) {}
+  const Expr* get_arg() const { return arg.get(); }
+  const std::list<std::shared_ptr<Analyzer::Expr>>& get_value_list() const { return value_list; }
+
+ private:
+  std::shared_ptr<Analyzer::Expr> arg;
+  std::list<std::shared_ptr<Analyzer::Expr>> value_list;
+};
 class AggExpr : public Expr {
  public:
   AggExpr(const SQLTypeInfo& ti, SQLAgg a, std::shared_ptr<Expr> arg, bool distinct = false,

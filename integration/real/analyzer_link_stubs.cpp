@@ -65,6 +65,18 @@ void CaseExpr::find_expr(std::function<bool(const Expr*)>, std::list<const Expr*
 std::shared_ptr<Expr> CaseExpr::add_cast(const SQLTypeInfo&) REF_STUB
 void CaseExpr::get_domain(DomainSet&) const REF_STUB
 
+// (the constructor is out of line in Analyzer.cpp:1707-1709, where the type's nullability also looks at the list)
+InValues::InValues(std::shared_ptr<Analyzer::Expr> a, const std::list<std::shared_ptr<Analyzer::Expr>>& l)
+    : Expr(kBOOLEAN, a->get_type_info().get_notnull()), arg(a), value_list(l) {}
+std::shared_ptr<Expr> InValues::deep_copy() const REF_STUB
+void InValues::group_predicates(std::list<const Expr*>&, std::list<const Expr*>&, std::list<const Expr*>&) const REF_STUB
+std::shared_ptr<Expr> InValues::rewrite_with_targetlist(const std::vector<std::shared_ptr<TargetEntry>>&) const REF_STUB
+std::shared_ptr<Expr> InValues::rewrite_with_child_targetlist(const std::vector<std::shared_ptr<TargetEntry>>&) const REF_STUB
+std::shared_ptr<Expr> InValues::rewrite_agg_to_var(const std::vector<std::shared_ptr<TargetEntry>>&) const REF_STUB
+bool InValues::operator==(const Expr&) const REF_STUB
+std::string InValues::toString() const REF_STUB
+void InValues::find_expr(std::function<bool(const Expr*)>, std::list<const Expr*>&) const REF_STUB
+
 std::shared_ptr<Expr> AggExpr::deep_copy() const REF_STUB
 void AggExpr::group_predicates(std::list<const Expr*>&, std::list<const Expr*>&, std::list<const Expr*>&) const REF_STUB
 std::shared_ptr<Expr> AggExpr::rewrite_with_targetlist(const std::vector<std::shared_ptr<TargetEntry>>&) const REF_STUB

@@ -197,6 +197,25 @@ int main() {
         translate_where({or1.get(), ge.get()}, value_col, new_bool_col, qs, &nq, &ng);   // no unsafe division: conjunct by conjunct
         REQ(filled == 0 && nq == 3 && ng == 1 && qs[2].op == MI355Q_GE);
       }
+      // y IN (3, 0): two quals of one OR group; as a value, (y = 3) OR (y = 0); a list member of another type is refused
+      {
+        using Analyzer::InValues;
+        InValues in_y(y, {l3, l0});
+        nq = ng = 0;
+        translate_conjunct(&in_y, value_col, qs, &nq, &ng);
+        REQ(nq == 2 && ng == 1 && MI355Q_QUAL_OP(qs[0].op) == MI355Q_EQ && MI355Q_QUAL_OR_GROUP(qs[0].op) == 1 && qs[0].col == 1 &&
+            qs[0].ival == 3 && qs[1].ival == 0 && MI355Q_QUAL_OR_GROUP(qs[1].op) == 1);
+        mi355q_expr ei{};
+        emit_expr(&in_y, ei, outer_col);
+        REQ(ei.n_nodes == 7 && ei.nodes[2].op == MI355Q_EX_EQ && ei.nodes[5].op == MI355Q_EX_EQ && ei.nodes[6].op == MI355Q_EX_OR &&
+            ei.nodes[6].reserved == 0 && ei.nodes[4].ilit == 0);
+        InValues in_one(y, {l3});
+        nq = ng = 0;
+        translate_conjunct(&in_one, value_col, qs, &nq, &ng);
+        REQ(nq == 1 && ng == 0 && qs[0].op == MI355Q_EQ && qs[0].ival == 3);
+        InValues in_mixed(y, {lit});   // an INT constant against a BIGINT argument: the analyzer would have cast it
+        REQ(refuses([&] { translate_conjunct(&in_mixed, value_col, qs, &nq, &ng); }));
+      }
       // -y, y IS NULL as values
       auto neg = std::make_shared<UOper>(t_big, false, kUMINUS, y);
       mi355q_expr en{};

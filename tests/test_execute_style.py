@@ -474,6 +474,19 @@ EXPR_QUERIES = [
      [xlogic(xcmp(xc("x"), ">", xl(I32, 7)), "AND",
              xcmp(xdiv(xc("y"), xsub(xc("x"), xl(I32, 7), I32), I32), "<", xl(I32, 44)), short_circuit=True)]),
     ("SELECT COUNT(*) FROM test WHERE fx + 1 IS NULL;", [agg("COUNT")], [q(X0, "IS NULL", 0)], [], [xadd(xc("fx"), xl(I32, 1), I32)]),
+    # six conjuncts for four quals (:1907): three quals, the rest ANDed in one BOOLEAN expression
+    ("SELECT COUNT(*) FROM test WHERE x > 6 AND x < 8 AND z > 100 AND z < 102 AND t > 1000 AND t < 1002;", [agg("COUNT")],
+     [q("x", ">", 6), q("x", "<", 8), q("z", ">", 100), q(X0, "=", 1)], [],
+     [xlogic(xlogic(xcmp(xc("z"), "<", xl(I16, 102)), "AND", xcmp(xc("t"), ">", xl(I64, 1000))), "AND", xcmp(xc("t"), "<", xl(I64, 1002)))]),
+    # Select.In (:7361-7367): an IN list is an OR group of equalities ...
+    ("SELECT COUNT(*) FROM test WHERE x IN (7, 8);", [agg("COUNT")], [("x", capi.EQ | (1 << 8), 7), ("x", capi.EQ | (1 << 8), 8)], [], []),
+    ("SELECT COUNT(*) FROM test WHERE x IN (9, 10);", [agg("COUNT")], [("x", capi.EQ | (1 << 8), 9), ("x", capi.EQ | (1 << 8), 10)], [], []),
+    ("SELECT COUNT(*) FROM test WHERE z IN (101, 102);", [agg("COUNT")], [("z", capi.EQ | (1 << 8), 101), ("z", capi.EQ | (1 << 8), 102)], [], []),
+    ("SELECT COUNT(*) FROM test WHERE z IN (201, 202);", [agg("COUNT")], [("z", capi.EQ | (1 << 8), 201), ("z", capi.EQ | (1 << 8), 202)], [], []),
+    # ... or, as a value, the OR of the comparisons
+    ("SELECT COUNT(*) FROM test WHERE z IN (101, 102) OR (x = 8 AND t IS NULL);", [agg("COUNT")], [q(X1, "=", 1)], [],   # (not the reference's text)
+     [EX(["x", "t"], lambda ix, nc: xcmp(xc("x"), "=", xl(I32, 8)).build(ix, nc).logical(capi.EX_AND, Expr.col(ix["t"]).is_null())),
+      xlogic(xlogic(xcmp(xc("z"), "=", xl(I16, 101)), "OR", xcmp(xc("z"), "=", xl(I16, 102))), "OR", xref(0))]),
     ("SELECT x, SUM(-y), COUNT(*) FROM test WHERE NOT (z > 100 AND t = 1002) GROUP BY x;",                    # (not the reference's text)
      [key(), agg("SUM", X0), agg("COUNT")], [q(X1, "=", 1)], ["x"],
      [xneg(xc("y"), I32), EX(["z", "t"], lambda ix, nc: xlogic(xcmp(xc("z"), ">", xl(I16, 100)), "AND",

@@ -223,6 +223,23 @@ int main() {
     const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
     REQ(p.n_quals == 4 && p.n_exprs == 0 && p.quals[3].col == 2 && p.quals[3].op == MI355Q_LT && p.quals[3].ival == 102);
   }
+  {  // ... AND t > 1000 AND t < 1002 (:1907): six conjuncts for four quals -> three quals and one expression of three comparisons
+    RelAlgExecutionUnit ra = unit();
+    ra.simple_quals = {cmp(kGT, 0, 6), cmp(kLT, 0, 8), cmp(kGT, 2, 100), cmp(kLT, 2, 102), cmp(kGT, 3, 1000), cmp(kLT, 3, 1002)};
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 4 && p.n_exprs == 1 && p.quals[2].col == 2 && p.quals[2].op == MI355Q_GT && p.quals[3].col == 4 &&
+        p.quals[3].op == MI355Q_EQ && p.quals[3].ival == 1);
+    REQ(p.exprs[0].n_nodes == 11 && p.exprs[0].nodes[0].arg == 2 && p.exprs[0].nodes[2].op == MI355Q_EX_LT &&
+        p.exprs[0].nodes[6].op == MI355Q_EX_AND && p.exprs[0].nodes[6].reserved == 0 && p.exprs[0].nodes[10].op == MI355Q_EX_AND);
+  }
+  {  // WHERE x IN (7, 8) AND z > 100: an OR group of two equalities and a plain qual
+    RelAlgExecutionUnit ra = unit();
+    ra.quals.push_back(std::make_shared<Analyzer::InValues>(col(0), std::list<std::shared_ptr<Analyzer::Expr>>{lit(0, 7), lit(0, 8)}));
+    ra.simple_quals.push_back(cmp(kGT, 2, 100));
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 3 && p.n_exprs == 0 && p.quals[0].col == 2 && MI355Q_QUAL_OR_GROUP(p.quals[1].op) == 1 &&
+        MI355Q_QUAL_OP(p.quals[1].op) == MI355Q_EQ && p.quals[1].ival == 7 && p.quals[2].ival == 8 && p.quals[2].col == 0);
+  }
   std::printf(bad ? "bad\\n" : "ok\\n");
   return bad ? 1 : 0;
 }
