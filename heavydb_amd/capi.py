@@ -18,6 +18,7 @@ MAX_SLOTS = 16
 MAX_GROUP_COLS = 4
 MAX_EXPRS = 4
 MAX_EXPR_NODES = 12
+MAX_EXPR_STACK = 8
 ABI_VERSION = 6
 
 # mi355q_type

@@ -46,8 +46,8 @@ MQ_HD float ex_flt_of(int64_t v) { return bits_flt((int32_t)(uint32_t)v); }
 // value returned is then unspecified): the first one in evaluation order — operands left to right, then the operation; a
 // CASE's condition, then the branch it takes.  es[] = the error each stack value carries.
 MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos, int32_t* err) {
-  int64_t st[4] = {0, 0, 0, 0};
-  int32_t es[4] = {0, 0, 0, 0};
+  int64_t st[MI355Q_MAX_EXPR_STACK] = {};
+  int32_t es[MI355Q_MAX_EXPR_STACK] = {};
   int sp = 0;
   for (int i = 0; i < e.n_nodes; ++i) {
     const DevExprNode& n = e.nodes[i];

@@ -123,8 +123,8 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
     if (x.n_nodes < 1 || x.n_nodes > MI355Q_MAX_EXPR_NODES) return MI355Q_ERR_INVALID_PLAN;
     DevExpr& d = ds.e[k];
     d.n_nodes = x.n_nodes;
-    int st_type[4];
-    bool st_null[4];
+    int st_type[MI355Q_MAX_EXPR_STACK];
+    bool st_null[MI355Q_MAX_EXPR_STACK];
     int sp = 0;
     for (int i = 0; i < x.n_nodes; ++i) {
       const mi355q_expr_node& n = x.nodes[i];
@@ -136,7 +136,7 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
         case MI355Q_EX_COL: {
           // a physical column, or the value of an EARLIER expression of the plan (column n_cols + j, j < k): the projection
           // evaluates the expressions of a row in order, so expression j's dense temporary column already holds it
-          if (n.arg < 0 || n.arg >= p.n_cols + k || sp >= 4) return MI355Q_ERR_INVALID_PLAN;
+          if (n.arg < 0 || n.arg >= p.n_cols + k || sp >= MI355Q_MAX_EXPR_STACK) return MI355Q_ERR_INVALID_PLAN;
           const mi355q_col_desc cd = n.arg < p.n_cols ? p.cols[n.arg] : lowered->cols[n.arg];
           const int code = col_type_code(cd);
           if (code < 0) return MI355Q_ERR_INVALID_PLAN;
@@ -150,7 +150,7 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
           break;
         }
         case MI355Q_EX_LIT: {
-          if (!valid_type(n.type) || sp >= 4 || (n.reserved != 0 && n.reserved != 1)) return MI355Q_ERR_INVALID_PLAN;
+          if (!valid_type(n.type) || sp >= MI355Q_MAX_EXPR_STACK || (n.reserved != 0 && n.reserved != 1)) return MI355Q_ERR_INVALID_PLAN;
           if (n.reserved == 1) {  // the NULL literal of the type
             o.type = n.type;
             o.flags = EXF_NULLABLE;

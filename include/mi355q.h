@@ -53,6 +53,7 @@ extern "C" {
 #define MI355Q_MAX_GROUP_COLS 4
 #define MI355Q_MAX_EXPRS 4
 #define MI355Q_MAX_EXPR_NODES 12
+#define MI355Q_MAX_EXPR_STACK 8 /* values on the evaluation stack of a postfix program (CASE WHEN a >= 6 AND a <= 7 ... needs 5) */
 
 /* ---- error codes: numeric values of heavyai::ErrorCode (enums.h:30-51) ---- */
 #define MI355Q_OK 0
@@ -310,7 +311,7 @@ typedef struct mi355q_expr_node {
 } mi355q_expr_node;
 
 typedef struct mi355q_expr {
-  int32_t n_nodes; /* 1..MI355Q_MAX_EXPR_NODES, postfix; the stack never exceeds 4 values and ends at 1 */
+  int32_t n_nodes; /* 1..MI355Q_MAX_EXPR_NODES, postfix; the stack never exceeds MI355Q_MAX_EXPR_STACK values and ends at 1 */
   int32_t reserved;
   mi355q_expr_node nodes[MI355Q_MAX_EXPR_NODES];
   mi355q_range range; /* getExpressionRange of the whole expression (ExpressionRange.cpp: casts keep the

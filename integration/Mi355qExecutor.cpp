@@ -71,9 +71,22 @@ struct Translator {
       emit(e, x);
     } catch (const ExprTooLong&) {
       // (the operands first: an expression reads EARLIER ones)
-      if (!split_plain_logic(e, x, [this](const Analyzer::ColumnVar* cv) { return find(outer_cols, cv->getColumnKey()); },
-                             [this](const Analyzer::Expr* v) { return value_col(v); }))
-        throw;
+      const OuterCol oc = [this](const Analyzer::ColumnVar* cv) { return find(outer_cols, cv->getColumnKey()); };
+      if (!split_plain_logic(e, x, oc, [this](const Analyzer::Expr* v) { return value_col(v); })) {
+        // ... or a CASE whose conditions cannot raise: those are evaluated ahead, in expressions of their own
+        std::vector<const Analyzer::Expr*> conds;
+        hoistable_conditions(e, conds);
+        if (conds.empty()) throw;
+        std::vector<std::pair<const Analyzer::Expr*, int>> at;
+        for (const Analyzer::Expr* c : conds) at.emplace_back(c, value_col(c));
+        const std::function<int(const Analyzer::Expr*)> hoisted = [&at](const Analyzer::Expr* n) {
+          for (const auto& pr : at)
+            if (pr.first == n) return pr.second;
+          return -1;
+        };
+        x = mi355q_expr{};
+        emit_expr(e, x, oc, &hoisted);
+      }
     }
     if (p.n_exprs >= MI355Q_MAX_EXPRS) unsupported("too many projected expressions");
     x.range = to_range(getExpressionRange(e, query_infos, executor));

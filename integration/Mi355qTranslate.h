@@ -156,11 +156,19 @@ inline bool contains_unsafe_division(const Analyzer::Expr* e) {
 // postfix program of a value expression over OUTER columns (CodeGenerator::codegenCast / codegenArith shapes).
 // `outer_col` resolves a ColumnVar of the outer table to its position among the input columns.
 inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
-                      const std::function<int(const Analyzer::ColumnVar*)>& outer_col) {
+                      const std::function<int(const Analyzer::ColumnVar*)>& outer_col,
+                      const std::function<int(const Analyzer::Expr*)>* hoisted = nullptr) {
   auto push = [&](int32_t op, int32_t type, int32_t arg, int64_t ilit, double flit, int32_t null_lit = 0) {
     if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
     x.nodes[x.n_nodes++] = mi355q_expr_node{op, type, arg, null_lit, ilit, flit};
   };
+  if (hoisted) {  // a subtree the caller has stated as an earlier expression: its value
+    const int at = (*hoisted)(e);
+    if (at >= 0) {
+      push(MI355Q_EX_COL, 0, at, 0, 0.0);
+      return;
+    }
+  }
   if (auto cv = dynamic_cast<const Analyzer::ColumnVar*>(e)) {
     if (cv->get_rte_idx() != 0) unsupported("expression over an inner column");
     check_supported_type(cv->get_type_info());
@@ -174,7 +182,7 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
     else if (t == MI355Q_FLOAT) push(MI355Q_EX_LIT, t, 0, 0, d.floatval);
     else push(MI355Q_EX_LIT, t, 0, int_literal(ti, d), 0.0);
   } else if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
-    emit_expr(u->get_operand(), x, outer_col);
+    emit_expr(u->get_operand(), x, outer_col, hoisted);
     switch (u->get_optype()) {
       case kCAST: push(MI355Q_EX_CAST, logical_type(u->get_type_info()), 0, 0, 0.0); break;
       case kNOT:  // codegenLogical(UOper), LogicalIR.cpp:363-379
@@ -207,23 +215,23 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
         sc = 1;
         std::swap(first, second);
       }
-      emit_expr(first, x, outer_col);
-      emit_expr(second, x, outer_col);
+      emit_expr(first, x, outer_col, hoisted);
+      emit_expr(second, x, outer_col, hoisted);
       push(b->get_optype() == kAND ? MI355Q_EX_AND : MI355Q_EX_OR, MI355Q_INT8, 0, 0, 0.0, sc);
       return;
     }
     if (!op && !cmp) unsupported("binary operator");
     if (cmp && logical_type(b->get_left_operand()->get_type_info()) != logical_type(b->get_right_operand()->get_type_info()))
       unsupported("comparison of two types");  // (the analyzer casts both sides to one type: CompareIR.cpp asserts it)
-    emit_expr(b->get_left_operand(), x, outer_col);
-    emit_expr(b->get_right_operand(), x, outer_col);
+    emit_expr(b->get_left_operand(), x, outer_col, hoisted);
+    emit_expr(b->get_right_operand(), x, outer_col, hoisted);
     push(op ? op : cmp, op ? logical_type(b->get_type_info()) : MI355Q_INT8, 0, 0, 0.0);
   } else if (auto in = dynamic_cast<const Analyzer::InValues*>(e)) {
     // (x = c0) OR (x = c1) OR ...: the plain form — every comparison is evaluated, as in the reference's loop
     const auto vals = in_list_constants(in);
     const int32_t t = logical_type(in->get_arg()->get_type_info());
     for (size_t i = 0; i < vals.size(); ++i) {
-      emit_expr(in->get_arg(), x, outer_col);
+      emit_expr(in->get_arg(), x, outer_col, hoisted);
       const Datum d = vals[i]->get_constval();
       if (t == MI355Q_DOUBLE) push(MI355Q_EX_LIT, t, 0, 0, d.doubleval);
       else if (t == MI355Q_FLOAT) push(MI355Q_EX_LIT, t, 0, 0, d.floatval);
@@ -240,12 +248,12 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
     if (whens.empty() || !ce->get_else_expr()) unsupported("CASE shape");
     std::function<void(size_t)> emit_from = [&](size_t i) {
       if (i == whens.size()) {
-        emit_expr(ce->get_else_expr(), x, outer_col);
+        emit_expr(ce->get_else_expr(), x, outer_col, hoisted);
         return;
       }
       emit_from(i + 1);
-      emit_expr(whens[i].second, x, outer_col);
-      emit_expr(whens[i].first, x, outer_col);
+      emit_expr(whens[i].second, x, outer_col, hoisted);
+      emit_expr(whens[i].first, x, outer_col, hoisted);
       push(MI355Q_EX_CASE, t, 0, 0, 0.0);
     };
     emit_from(0);
@@ -297,6 +305,62 @@ inline mi355q_qual translate_qual(const Analyzer::Expr* e, const std::function<i
   else if (ti.get_type() == kFLOAT) q.fval = d.floatval;
   else q.ival = int_literal(ti, d);
   return q;
+}
+
+// Can evaluating `e` end the step (overflow, division by zero)?  Comparisons, logic, IS NULL, IN lists and CASEs over
+// columns, literals, widening casts and floating-point + - * cannot: such a subtree may be evaluated for every row, whatever
+// branch it stands in, without anything to observe — so it can move into an earlier expression from ANYWHERE.
+inline bool cannot_raise(const Analyzer::Expr* e) {
+  if (dynamic_cast<const Analyzer::ColumnVar*>(e) || dynamic_cast<const Analyzer::Constant*>(e)) return true;
+  if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
+    const auto& from = u->get_operand()->get_type_info();
+    const auto& to = u->get_type_info();
+    switch (u->get_optype()) {
+      case kNOT: case kISNULL: return cannot_raise(u->get_operand());
+      case kUMINUS: return to.is_fp() && cannot_raise(u->get_operand());
+      case kCAST:  // integer -> a wider integer or floating point, FLOAT -> DOUBLE
+        if (from.is_fp() ? !(to.is_fp() && to.get_logical_size() >= from.get_logical_size())
+                         : !(to.is_fp() || to.get_logical_size() >= from.get_logical_size()))
+          return false;
+        return cannot_raise(u->get_operand());
+      default: return false;
+    }
+  }
+  if (auto b = dynamic_cast<const Analyzer::BinOper*>(e)) {
+    switch (b->get_optype()) {
+      case kEQ: case kNE: case kLT: case kGT: case kLE: case kGE: case kAND: case kOR: break;
+      case kPLUS: case kMINUS: case kMULTIPLY:
+        if (!b->get_type_info().is_fp()) return false;
+        break;
+      default: return false;
+    }
+    return cannot_raise(b->get_left_operand()) && cannot_raise(b->get_right_operand());
+  }
+  if (auto in = dynamic_cast<const Analyzer::InValues*>(e)) return cannot_raise(in->get_arg());
+  if (auto ce = dynamic_cast<const Analyzer::CaseExpr*>(e)) {
+    for (const auto& pr : ce->get_expr_pair_list())
+      if (!cannot_raise(pr.first.get()) || !cannot_raise(pr.second.get())) return false;
+    return !ce->get_else_expr() || cannot_raise(ce->get_else_expr());
+  }
+  return false;
+}
+// the WHEN conditions of the CASEs under `e` that cannot raise (and are more than a column): what a CASE too long for one
+// program states as earlier expressions (`CASE WHEN x BETWEEN 6 AND 7 THEN 1 WHEN x BETWEEN 8 AND 9 THEN 2 ELSE 3 END`,
+// Tests/ExecuteTest.cpp:5358, has 19 nodes)
+inline void hoistable_conditions(const Analyzer::Expr* e, std::vector<const Analyzer::Expr*>& out) {
+  if (auto ce = dynamic_cast<const Analyzer::CaseExpr*>(e)) {
+    for (const auto& pr : ce->get_expr_pair_list()) {
+      if (cannot_raise(pr.first.get()) && !dynamic_cast<const Analyzer::ColumnVar*>(pr.first.get())) out.push_back(pr.first.get());
+      else hoistable_conditions(pr.first.get(), out);
+      hoistable_conditions(pr.second.get(), out);
+    }
+    if (ce->get_else_expr()) hoistable_conditions(ce->get_else_expr(), out);
+  } else if (auto b = dynamic_cast<const Analyzer::BinOper*>(e)) {
+    hoistable_conditions(b->get_left_operand(), out);
+    hoistable_conditions(b->get_right_operand(), out);
+  } else if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
+    hoistable_conditions(u->get_operand(), out);
+  }
 }
 
 // A BOOLEAN program that does not fit MI355Q_MAX_EXPR_NODES (the reference's own `x > 6 AND x < 8 OR (z > 100 AND z < 103)`

@@ -1532,7 +1532,7 @@ inline int lower_plan(const mi355q_plan& p, mi355q_plan* out) {
       } else {
         return MI355Q_ERR_UNSUPPORTED;
       }
-      if (sp > 4) return MI355Q_ERR_INVALID_PLAN;
+      if (sp > MI355Q_MAX_EXPR_STACK) return MI355Q_ERR_INVALID_PLAN;
     }
     if (sp != 1) return MI355Q_ERR_INVALID_PLAN;
     out->cols[p.n_cols + k] = mi355q_col_desc{ty[0], nu[0] ? 1 : 0, MI355Q_ENC_NONE, 0};

@@ -388,6 +388,19 @@ def xband(name, t, lo, hi):   # name > lo AND name < hi
     return xlogic(xcmp(xc(name), ">", xl(t, lo)), "AND", xcmp(xc(name), "<", xl(t, hi)))
 
 
+def xbetween(name, t, lo, hi):   # name BETWEEN lo AND hi
+    return xlogic(xcmp(xc(name), ">=", xl(t, lo)), "AND", xcmp(xc(name), "<=", xl(t, hi)))
+
+
+def xcase(cond, then, otherwise, t):
+    return EX(cond.names + then.names + otherwise.names,
+              lambda ix, nc: Expr.case(cond.build(ix, nc), then.build(ix, nc), otherwise.build(ix, nc), t))
+
+
+def xnull(t):
+    return EX([], lambda ix, nc: Expr.null(t))
+
+
 def _unit_x(descs, frags, targets, quals, group, exprs, **kw):
     """like _unit; a target's / qual's / group's column may be ("x", k): expression k of `exprs`"""
     from tests.cases import expr_range
@@ -487,6 +500,29 @@ EXPR_QUERIES = [
     ("SELECT COUNT(*) FROM test WHERE z IN (101, 102) OR (x = 8 AND t IS NULL);", [agg("COUNT")], [q(X1, "=", 1)], [],   # (not the reference's text)
      [EX(["x", "t"], lambda ix, nc: xcmp(xc("x"), "=", xl(I32, 8)).build(ix, nc).logical(capi.EX_AND, Expr.col(ix["t"]).is_null())),
       xlogic(xlogic(xcmp(xc("z"), "=", xl(I16, 101)), "OR", xcmp(xc("z"), "=", xl(I16, 102))), "OR", xref(0))]),
+    # Select.Case (:5358-5380).  The SUM's CASE has 19 nodes: its conditions cannot raise, so they are earlier expressions
+    ("SELECT SUM(CASE WHEN x BETWEEN 6 AND 7 THEN 1 WHEN x BETWEEN 8 AND 9 THEN 2 ELSE 3 END) FROM test;", [agg("SUM", X2)], [], [],
+     [xbetween("x", I32, 6, 7), xbetween("x", I32, 8, 9), xcase(xref(0), xl(I32, 1), xcase(xref(1), xl(I32, 2), xl(I32, 3), I32), I32)]),
+    ("SELECT SUM(CASE WHEN x BETWEEN 6 AND 7 THEN 1 END) FROM test;", [agg("SUM", X0)], [], [],
+     [xcase(xbetween("x", I32, 6, 7), xl(I32, 1), xnull(I32), I32)]),
+    ("SELECT SUM(CASE WHEN x BETWEEN 6 AND 7 THEN 1 WHEN x BETWEEN 8 AND 9 THEN 2 ELSE 3 END) FROM test "
+     "WHERE CASE WHEN y BETWEEN 42 AND 43 THEN 5 ELSE 4 END > 4;", [agg("SUM", X3)], [q(X0, ">", 4)], [],
+     [xcase(xbetween("y", I32, 42, 43), xl(I32, 5), xl(I32, 4), I32), xbetween("x", I32, 6, 7), xbetween("x", I32, 8, 9),
+      xcase(xref(1), xl(I32, 1), xcase(xref(2), xl(I32, 2), xl(I32, 3), I32), I32)]),
+    ("SELECT SUM(CASE WHEN x BETWEEN 6 AND 7 THEN 1 WHEN x BETWEEN 8 AND 9 THEN 2 ELSE 3 END) FROM test "     # ASSERT_EQ(NULL, ..) there
+     "WHERE CASE WHEN y BETWEEN 44 AND 45 THEN 5 ELSE 4 END > 4;", [agg("SUM", X3)], [q(X0, ">", 4)], [],
+     [xcase(xbetween("y", I32, 44, 45), xl(I32, 5), xl(I32, 4), I32), xbetween("x", I32, 6, 7), xbetween("x", I32, 8, 9),
+      xcase(xref(1), xl(I32, 1), xcase(xref(2), xl(I32, 2), xl(I32, 3), I32), I32)]),
+    ("SELECT CASE WHEN x + y > 50 THEN 77 ELSE 88 END AS foo, COUNT(*) FROM test GROUP BY foo ORDER BY foo;", [key(), agg("COUNT")], [],
+     [X0], [xcase(xcmp(_xy, ">", xl(I32, 50)), xl(I32, 77), xl(I32, 88), I32)]),
+    ("SELECT SUM(CASE WHEN x BETWEEN 6 AND 7 THEN 1.1 WHEN x BETWEEN 8 AND 9 THEN 2.2 ELSE 3.3 END) FROM test "   # ASSERT_EQ(NULL, ..) there
+     "WHERE CASE WHEN y BETWEEN 44 AND 45 THEN 5.1 ELSE 3.9 END > 4;", [agg("SUM", X3)], [q(X0, ">", 4.0)], [],
+     [xcase(xbetween("y", I32, 44, 45), xl(F64, 5.1), xl(F64, 3.9), F64), xbetween("x", I32, 6, 7), xbetween("x", I32, 8, 9),
+      xcase(xref(1), xl(F64, 1.1), xcase(xref(2), xl(F64, 2.2), xl(F64, 3.3), F64), F64)]),
+    ("SELECT SUM(CASE WHEN x BETWEEN 6 AND 7 THEN 1.1 WHEN x BETWEEN 8 AND 9 THEN 2.2 ELSE 3.3 END) FROM test "   # (the same with rows)
+     "WHERE CASE WHEN y BETWEEN 42 AND 43 THEN 5.1 ELSE 3.9 END > 4;", [agg("SUM", X3)], [q(X0, ">", 4.0)], [],
+     [xcase(xbetween("y", I32, 42, 43), xl(F64, 5.1), xl(F64, 3.9), F64), xbetween("x", I32, 6, 7), xbetween("x", I32, 8, 9),
+      xcase(xref(1), xl(F64, 1.1), xcase(xref(2), xl(F64, 2.2), xl(F64, 3.3), F64), F64)]),
     ("SELECT x, SUM(-y), COUNT(*) FROM test WHERE NOT (z > 100 AND t = 1002) GROUP BY x;",                    # (not the reference's text)
      [key(), agg("SUM", X0), agg("COUNT")], [q(X1, "=", 1)], ["x"],
      [xneg(xc("y"), I32), EX(["z", "t"], lambda ix, nc: xlogic(xcmp(xc("z"), ">", xl(I16, 100)), "AND",

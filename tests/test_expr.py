@@ -461,7 +461,7 @@ def _random_bool(rng, descs, depth, big=True):
 
 def _random_expr(rng, descs, want_type, depth, big=True):
     """a random well-typed expression of `want_type` over the columns (every micro-op; depth-limited so that the postfix
-    program stays within 12 nodes and a 4-deep stack), or None when none was found"""
+    program stays within 12 nodes and the 8-deep stack), or None when none was found"""
     ints = [capi.INT8, capi.INT16, capi.INT32, capi.INT64]
     cols_of = [i for i, d in enumerate(descs) if d.type == want_type]
     choice = int(rng.integers(0, 10))
@@ -549,7 +549,7 @@ def test_random_expression_programs_agree(oracle):
             e = _random_bool(rng, descs, int(rng.integers(1, 4)))
         else:
             e = _random_expr(rng, descs, int(rng.choice(types)), int(rng.integers(1, 4)))
-        if e is None or len(e.nodes) > capi.MAX_EXPR_NODES or _stack_depth(e) > 4:
+        if e is None or len(e.nodes) > capi.MAX_EXPR_NODES or _stack_depth(e) > capi.MAX_EXPR_STACK:
             continue
         plan = _plan(descs, e)
         ptrs = (C.c_void_p * len(cols))(*[c.ctypes.data for c in cols])

@@ -528,7 +528,7 @@ def test_random_expression_steps_through_the_real_kernels(sim, oracle):
         exprs = []
         for _ in range(int(rng.integers(1, 4))):
             e = _random_expr(rng, descs, int(rng.choice([capi.INT32, capi.INT64, capi.DOUBLE])), int(rng.integers(1, 4)), big=False)
-            if e is not None and len(e.nodes) <= capi.MAX_EXPR_NODES and _stack_depth(e) <= 4 and any(nd.op == capi.EX_COL for nd in e.nodes):
+            if e is not None and len(e.nodes) <= capi.MAX_EXPR_NODES and _stack_depth(e) <= capi.MAX_EXPR_STACK and any(nd.op == capi.EX_COL for nd in e.nodes):
                 exprs.append(e)
         if not exprs:
             continue

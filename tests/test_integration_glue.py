@@ -240,6 +240,37 @@ int main() {
     REQ(p.n_quals == 3 && p.n_exprs == 0 && p.quals[0].col == 2 && MI355Q_QUAL_OR_GROUP(p.quals[1].op) == 1 &&
         MI355Q_QUAL_OP(p.quals[1].op) == MI355Q_EQ && p.quals[1].ival == 7 && p.quals[2].ival == 8 && p.quals[2].col == 0);
   }
+  {  // SELECT SUM(CASE WHEN x BETWEEN 6 AND 7 THEN 1 WHEN x BETWEEN 8 AND 9 THEN 2 ELSE 3 END) ... WHERE CASE WHEN y BETWEEN 42 AND 43
+     // THEN 5 ELSE 4 END > 4 (Select.Case, ExecuteTest.cpp:5358-5365): the SUM's CASE has 19 nodes -> its two conditions (they cannot
+     // raise) are expressions 0 and 1 and the CASE reads their values; the WHERE's CASE fits one program
+    using Analyzer::CaseExpr;
+    auto ge_le = [&](int c, int64_t lo, int64_t hi) { return std::make_shared<BinOper>(tb, kAND, cmp(kGE, c, lo), cmp(kLE, c, hi)); };
+    std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>> whens = {{ge_le(0, 6, 7), lit(0, 1)}, {ge_le(0, 8, 9), lit(0, 2)}};
+    auto sum_arg = std::make_shared<CaseExpr>(ti[0], false, whens, lit(0, 3));
+    Analyzer::AggExpr sum(SQLTypeInfo(kBIGINT, false), kSUM, sum_arg);
+    std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>> w2 = {{ge_le(1, 42, 43), lit(1, 5)}};
+    auto where_case = std::make_shared<CaseExpr>(ti[1], false, w2, lit(1, 4));
+    RelAlgExecutionUnit ra = unit();
+    ra.target_exprs = {&sum};
+    ra.quals.push_back(std::make_shared<BinOper>(tb, kGT, where_case, lit(1, 4)));
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_exprs == 4 && p.n_quals == 1 && p.quals[0].col == 4 + 0 && p.quals[0].op == MI355Q_GT && p.quals[0].ival == 4);
+    REQ(p.exprs[0].n_nodes == 10 && p.exprs[0].nodes[9].op == MI355Q_EX_CASE && p.exprs[0].nodes[2].arg == 1);   // the WHERE's CASE came first
+    REQ(p.exprs[1].n_nodes == 7 && p.exprs[1].nodes[2].op == MI355Q_EX_GE && p.exprs[1].nodes[1].ilit == 6 && p.exprs[2].nodes[1].ilit == 8);
+    REQ(p.exprs[3].n_nodes == 7 && p.exprs[3].nodes[0].ilit == 3 && p.exprs[3].nodes[2].op == MI355Q_EX_COL && p.exprs[3].nodes[2].arg == 4 + 2 &&
+        p.exprs[3].nodes[3].op == MI355Q_EX_CASE && p.exprs[3].nodes[5].arg == 4 + 1 && p.exprs[3].nodes[6].op == MI355Q_EX_CASE);
+    REQ(p.targets[0].agg == MI355Q_SUM && p.targets[0].col == 4 + 3);
+    // a condition that CAN raise stays where it is (lazy): in CASE WHEN y / x > 1 THEN 1 WHEN x BETWEEN 8 AND 9 THEN 2 ELSE 3 END (17 nodes)
+    auto quot = std::make_shared<BinOper>(ti[1], kDIVIDE, col(1), col(0));
+    auto risky = std::make_shared<BinOper>(tb, kGT, quot, lit(1, 1));
+    std::list<std::pair<std::shared_ptr<Analyzer::Expr>, std::shared_ptr<Analyzer::Expr>>> w3 = {{risky, lit(0, 1)}, {ge_le(0, 8, 9), lit(0, 2)}};
+    auto risky_case = std::make_shared<CaseExpr>(ti[0], false, w3, lit(0, 3));
+    Analyzer::AggExpr sum2(SQLTypeInfo(kBIGINT, false), kSUM, risky_case);
+    RelAlgExecutionUnit rb = unit();
+    rb.target_exprs = {&sum2};
+    const mi355q_plan pb = to_plan(rb, query_infos, &executor, nullptr, 16384, false);   // the safe second condition is hoisted, the risky one is not
+    REQ(pb.n_exprs == 2 && pb.exprs[0].nodes[1].ilit == 8 && pb.exprs[1].n_nodes == 11 && pb.exprs[1].nodes[2].arg == 4 + 0 && pb.exprs[1].nodes[7].op == MI355Q_EX_DIV);
+  }
   std::printf(bad ? "bad\\n" : "ok\\n");
   return bad ? 1 : 0;
 }
