@@ -2203,10 +2203,19 @@ int32_t execute_affine_twin(const mi355q_plan* plan, const mi355q_inputs* in, co
 // itself (perfect hash: the LDS / partitioned families, no key expression to project), and its entries are then re-keyed
 // with the cast value and merged into the baseline table of the stated plan (kernels_generic.hip k_cast_key_emit).
 // kNotTaken when the shape does not call for it.
+// Does an expression of the plan read the value of another one (MI355Q_EX_COL with arg >= n_cols)?  The derived-plan routes
+// below take expressions out of the plan and renumber the rest: they leave such plans to the projection.
+bool exprs_read_exprs(const mi355q_plan& p) {
+  for (int k = 0; k < p.n_exprs && k < MI355Q_MAX_EXPRS; ++k)
+    for (int i = 0; i < p.exprs[k].n_nodes && i < MI355Q_MAX_EXPR_NODES; ++i)
+      if (p.exprs[k].nodes[i].op == MI355Q_EX_COL && p.exprs[k].nodes[i].arg >= p.n_cols) return true;
+  return false;
+}
+
 int32_t execute_cast_key(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
                          mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
   if (plan->n_group_cols != 1 || plan->join_outer_col >= 0 || plan->output_columnar_hint != 0 || o.kernel_variant == 1 ||
-      o.force_generic)
+      o.force_generic || exprs_read_exprs(*plan))
     return kNotTaken;
   const int nc = plan->n_cols, gc = plan->group_cols[0];
   if (gc < nc || gc >= nc + plan->n_exprs) return kNotTaken;
@@ -2339,7 +2348,7 @@ int32_t execute_cast_key(const mi355q_plan* plan, const mi355q_inputs* in, const
 int32_t execute_shifted_args(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
                              mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
   if (plan->n_group_cols < 1 || plan->join_outer_col >= 0 || plan->output_columnar_hint != 0 || o.kernel_variant == 1 ||
-      o.force_generic)
+      o.force_generic || exprs_read_exprs(*plan))
     return kNotTaken;
   const int nc = plan->n_cols, nx = plan->n_exprs;
   // which expressions are `column +- literal` that cannot overflow

@@ -815,6 +815,12 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("expr_error_in_an_earlier_expression_of_filtered_rows_only",   # the same division behind a target: no row passes, no error
                       xra([C(5).div(C(5).sub(C(5), INT8), INT8), Expr.col(NC).cast(INT64).add(C(2), INT64)],
                           [TargetExpr(COUNT), TargetExpr(SUM, NC + 1)], [Qual(1, LT, 0)]), frags))
+    # the derived-plan routes (cast key, column +- literal) take expressions OUT of the plan and renumber the rest: not where
+    # an expression reads another one's value
+    cases.append(Case("expr_cast_key_and_shifted_argument_read_by_a_later_expression",
+                      xra([C(10).cast(DOUBLE), C(7).add(Expr.lit(INT32, 1), INT32), Expr.col(NC + 1).cast(INT64).mul(Expr.lit(INT64, 2), INT64)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(SUM, NC + 2), TargetExpr(MAX, NC + 1), TargetExpr(COUNT, NC + 2)],
+                          group=[NC], guess=256), frags))
     um = np.array([5, -2**31, 7], dtype=np.int32)
     um_src = ([InputColDescriptor(INT32, False, col_range([um], INT32, False))], [[um]])
     cases.append(Case("expr_uminus_of_the_type_minimum_is_error_7",   # -c0 where a NOT NULL INT column holds INT32_MIN
