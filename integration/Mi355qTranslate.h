@@ -262,10 +262,32 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
   }
 }
 
+// the plan's own qual shapes: <value> <cmp> .., <value> IS NULL, NOT(<value> IS NULL)
+inline bool qual_shaped(const Analyzer::Expr* e) {
+  if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
+    if (u->get_optype() == kISNULL) return true;
+    auto in = u->get_optype() == kNOT ? dynamic_cast<const Analyzer::UOper*>(u->get_operand()) : nullptr;
+    return in && in->get_optype() == kISNULL;
+  }
+  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
+  if (!b) return false;
+  switch (b->get_optype()) {
+    case kEQ: case kNE: case kLT: case kGT: case kLE: case kGE: return true;
+    default: return false;
+  }
+}
 // simple_quals / quals entry, or the condition of COUNT_IF / SUM_IF: <value> <cmp> <literal>, <value> IS NULL,
 // NOT(<value> IS NULL).  `value_col` gives the outer column (or virtual expression column) of a value expression.
 inline mi355q_qual translate_qual(const Analyzer::Expr* e, const std::function<int(const Analyzer::Expr*)>& value_col) {
   mi355q_qual q{};
+  if (!qual_shaped(e) && e->get_type_info().is_boolean()) {
+    // any other BOOLEAN (COUNT_IF(x > 5 AND y IS NULL), SUM_IF(v, k IN (1, 2)), a BOOLEAN column): the condition is a projected
+    // expression and the qual `that column = 1` — TRUE; NULL is not (toBool, LogicalIR.cpp:344-352)
+    q.col = value_col(e);
+    q.op = MI355Q_EQ;
+    q.ival = 1;
+    return q;
+  }
   if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
     if (u->get_optype() == kISNULL) {
       q.col = value_col(u->get_operand());
@@ -410,20 +432,6 @@ inline bool split_plain_logic(const Analyzer::Expr* e, mi355q_expr& x, const std
 }
 
 // ---- conjuncts of simple_quals / quals
-// translate_qual's shapes
-inline bool qual_shaped(const Analyzer::Expr* e) {
-  if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
-    if (u->get_optype() == kISNULL) return true;
-    auto in = u->get_optype() == kNOT ? dynamic_cast<const Analyzer::UOper*>(u->get_operand()) : nullptr;
-    return in && in->get_optype() == kISNULL;
-  }
-  auto b = dynamic_cast<const Analyzer::BinOper*>(e);
-  if (!b) return false;
-  switch (b->get_optype()) {
-    case kEQ: case kNE: case kLT: case kGT: case kLE: case kGE: return true;
-    default: return false;
-  }
-}
 // members of a disjunction of qual shapes (`a OR b OR ...`, Analyzer::BinOper kOR nested any way round; NOT over a comparison
 // counts as the comparison); -1 = not such a disjunction
 inline int disjunction_members(const Analyzer::Expr* e) {

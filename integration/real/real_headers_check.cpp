@@ -264,6 +264,12 @@ int main() {
     AggExpr count_if(SQLTypeInfo(kINT, true), kCOUNT_IF, lt, false, nullptr);
     tg = translate_agg(&count_if, value_col, inner_col);
     REQ(tg.agg == MI355Q_COUNT_IF && tg.col == -1 && tg.cond.op == MI355Q_LT && tg.cond.col == 0 && tg.cond.ival == 1);
+    {  // COUNT_IF(x < 1 AND y IS NULL): a condition without a qual shape is a projected BOOLEAN column `= 1`
+      auto conj2 = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kAND, kONE, lt, isnull);
+      AggExpr count_if2(SQLTypeInfo(kINT, true), kCOUNT_IF, conj2, false, nullptr);
+      tg = translate_agg(&count_if2, value_col, inner_col);
+      REQ(tg.agg == MI355Q_COUNT_IF && tg.col == -1 && tg.cond.col == 100 && tg.cond.op == MI355Q_EQ && tg.cond.ival == 1);
+    }
     AggExpr sum_if(t_big, kSUM_IF, y, false, lt);
     tg = translate_agg(&sum_if, value_col, inner_col);
     REQ(tg.agg == MI355Q_SUM_IF && tg.col == 1 && tg.cond.op == MI355Q_LT && tg.cond.col == 0);
