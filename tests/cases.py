@@ -815,6 +815,11 @@ def build_cases(seed: int = 1234, scale: int = 1) -> List[Case]:
     cases.append(Case("expr_error_in_an_earlier_expression_of_filtered_rows_only",   # the same division behind a target: no row passes, no error
                       xra([C(5).div(C(5).sub(C(5), INT8), INT8), Expr.col(NC).cast(INT64).add(C(2), INT64)],
                           [TargetExpr(COUNT), TargetExpr(SUM, NC + 1)], [Qual(1, LT, 0)]), frags))
+    # COUNT_IF / SUM_IF over a condition that has no qual shape: the condition is a BOOLEAN expression, `that column = 1`
+    cases.append(Case("expr_conditional_aggregates_over_boolean_expressions",   # COUNT_IF(c1 < 60 AND c7 > 0), SUM_IF(c2, c6 IS NULL OR c7 > 0)
+                      xra([lt60.logical(capi.EX_AND, c7pos), C(6).is_null().logical(capi.EX_OR, c7pos)],
+                          [TargetExpr(PROJECT_KEY), TargetExpr(COUNT_IF, cond=Qual(NC, EQ, 1)), TargetExpr(SUM_IF, 2, cond=Qual(NC + 1, EQ, 1)),
+                           TargetExpr(COUNT)], group=[10]), frags))
     # the derived-plan routes (cast key, column +- literal) take expressions OUT of the plan and renumber the rest: not where
     # an expression reads another one's value
     cases.append(Case("expr_cast_key_and_shifted_argument_read_by_a_later_expression",

@@ -86,3 +86,79 @@ def test_malformed_plans_are_rejected_not_crashed():
         tot_bad += bad
     # the mutations must land on both sides of the validation
     assert tot_ok > 500 and tot_bad > 500, (tot_ok, tot_bad)
+
+
+CHILD_EXPR = textwrap.dedent("""
+    import ctypes as C, sys
+    import numpy as np
+    sys.path.insert(0, %r)
+    from heavydb_amd import capi
+    from heavydb_amd.executor import Expr, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.test_expr import _random_bool, _random_expr, _stack_depth
+    lib = capi.load_library()
+    rng = np.random.default_rng(int(sys.argv[1]))
+    types = [capi.INT8, capi.INT16, capi.INT32, capi.INT64, capi.DOUBLE, capi.FLOAT]
+    descs = [InputColDescriptor(t, n, ExpressionRange(True, -100, 100, n, -100.0, 100.0)) for t in types for n in (True, False)]
+    HOSTILE32 = [-1, -2, 0, 3, 4, 5, 8, 12, 13, 15, 16, 17, 21, 22, 31, 32, 64, 255, 1 << 20, -(1 << 31), (1 << 31) - 1]
+    def h32():
+        return int(HOSTILE32[rng.integers(0, len(HOSTILE32))])
+    ok = bad = 0
+    for it in range(int(sys.argv[2])):
+        xs = []
+        for k in range(int(rng.integers(1, capi.MAX_EXPRS + 1))):
+            for attempt in range(20):
+                e = _random_bool(rng, descs, int(rng.integers(1, 4))) if rng.integers(0, 3) == 0 else \\
+                    _random_expr(rng, descs, int(rng.choice(types)), int(rng.integers(1, 4)))
+                if e is not None and len(e.nodes) <= capi.MAX_EXPR_NODES and _stack_depth(e) <= capi.MAX_EXPR_STACK:
+                    break
+            else:
+                e = Expr.col(0)
+            if xs and rng.integers(0, 3) == 0:
+                # the value of an EARLIER expression (a node's hostile `arg` below also names this one or a later one: refused)
+                j = int(rng.integers(0, len(xs)))
+                e = Expr.col(len(descs) + j).is_null()
+            xs.append(e.with_range(ExpressionRange(True, -1000, 1000, True, -1000.0, 1000.0)))
+        nc = len(descs)
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT), TargetExpr(capi.MIN, nc + int(rng.integers(0, len(xs))))],
+                                 [Qual(nc + int(rng.integers(0, len(xs))), capi.IS_NOT_NULL, 0)], [], exprs=xs)
+        p = ra.to_plan()
+        valid = lib.mi355q_qmd_init(C.byref(p), C.byref(capi.QMD())) == 0
+        n0 = p.n_exprs
+        for _ in range(int(rng.integers(0, 3))):
+            k = int(rng.integers(0, n0))
+            x = p.exprs[k]
+            i = int(rng.integers(0, capi.MAX_EXPR_NODES))
+            m = int(rng.integers(0, 7))
+            if m == 0: x.nodes[i].op = h32()
+            elif m == 1: x.nodes[i].type = h32()
+            elif m == 2: x.nodes[i].arg = h32()
+            elif m == 3: x.nodes[i].reserved = h32()
+            elif m == 4: x.n_nodes = h32()
+            elif m == 5: p.n_exprs = h32()
+            else: p.quals[0].col = h32()
+        q = capi.QMD()
+        rc = lib.mi355q_qmd_init(C.byref(p), C.byref(q))
+        if rc == 0:
+            ok += 1
+            assert 0 < q.row_size <= 8 * (capi.MAX_GROUP_COLS + capi.MAX_SLOTS) and q.n_targets == 2
+        else:
+            bad += 1
+            assert rc in (capi.ERR_INVALID_PLAN, capi.ERR_UNSUPPORTED), rc
+    print(ok, bad)
+""") % ROOT
+
+
+def test_malformed_expression_programs_are_rejected_not_crashed():
+    """The same for the projected-expression programs: random well-typed programs over every micro-op (values of earlier
+    expressions included), then 0-2 hostile mutations of a node's op / type / arg / reserved, of a program's length, of the
+    expression count or of the qual's column, through mi355q_qmd_init (which lowers the programs) in a child process."""
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    tot_ok = tot_bad = 0
+    for seed in (11, 12):
+        r = subprocess.run([sys.executable, "-c", CHILD_EXPR, str(seed), "3000"], cwd=ROOT, env=env,
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (seed, r.returncode, r.stdout[-500:], r.stderr[-2000:])
+        ok, bad = (int(x) for x in r.stdout.split())
+        tot_ok += ok
+        tot_bad += bad
+    assert tot_ok > 1000 and tot_bad > 1000, (tot_ok, tot_bad)
