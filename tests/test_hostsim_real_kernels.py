@@ -136,6 +136,24 @@ def test_explain_names_the_stages_of_a_derived_route(sim):
     assert "k_zip_targets" in r and "k_part_scatter" in r, r
 
 
+def test_derived_routes_leave_plans_whose_expressions_read_expressions(sim):
+    """GROUP BY CAST(k AS DOUBLE) takes the cast-key route (the key expression leaves the plan, the rest is renumbered) — unless
+    another expression reads an expression's value: then the step is projected as stated."""
+    from heavydb_amd.executor import Executor, Expr, ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 99_999)), InputColDescriptor(capi.INT32, True, ExpressionRange(True, -5, 5, True))]
+    key = Expr.col(0).cast(capi.DOUBLE).with_range(ExpressionRange(True, 0, 0, False, 0.0, 99_999.0))
+    shifted = Expr.col(1).add(Expr.lit(capi.INT32, 1), capi.INT32).with_range(ExpressionRange(True, -4, 6, True))
+    reads = Expr.col(2 + 1).cast(capi.INT64).with_range(ExpressionRange(True, -4, 6, True))
+    rows = [32_000_000] * 8
+    plain = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.MAX, 3)], [], [2], exprs=[key, shifted])
+    r = Executor(0).explain(plain, rows)
+    assert "k_cast_key_emit" in r and "aggregates of column + literal" in r, r
+    composed = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.MAX, 4)], [], [2],
+                                   exprs=[key, shifted, reads])
+    r = Executor(0).explain(composed, rows)
+    assert "k_cast_key_emit" not in r and "column + literal" not in r and "k_project" in r, r
+
+
 @pytest.mark.parametrize("groups,n_rows", [(20, 5000), (200, 5000), (300, 2000), (1000, 20000), (3000, 20000), (20000, 60000)])
 def test_baseline_lds_chain_with_the_real_kernel(sim, oracle, groups, n_rows):
     """small replicas -> the largest replica -> eight windows -> another family, each lost attempt abandoned without a fold or a
