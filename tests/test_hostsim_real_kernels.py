@@ -517,8 +517,8 @@ def test_random_expression_steps_through_the_real_kernels(sim, oracle):
     through the large-input routes (variant 2: shifted arguments, cast keys, the projection passes): table or error code must
     equal the oracle's walk over the stated plan."""
     import os
-    from heavydb_amd.executor import Executor, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
-    from tests.test_expr import _random_expr, _stack_depth
+    from heavydb_amd.executor import Executor, Expr, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.test_expr import _random_bool, _random_expr, _stack_depth
     from tests.cases import expr_range
     rng = np.random.default_rng(int(os.environ.get("MI355Q_FUZZ_SEED", "4711")))
     iters = int(os.environ.get("MI355Q_FUZZ_ITERS", "60"))
@@ -551,17 +551,33 @@ def test_random_expression_steps_through_the_real_kernels(sim, oracle):
         if not exprs:
             continue
         nc = len(descs)
+        # ... an expression that reads the value of an earlier one, and a BOOLEAN program used as the filter
+        if len(exprs) < capi.MAX_EXPRS and rng.integers(0, 3) == 0:
+            j = int(rng.integers(0, len(exprs)))
+            tj = exprs[j].result(descs, exprs[:j])[0]
+            ref = Expr.col(nc + j)
+            exprs.append(ref.is_null().logical_not().cast(capi.INT32) if rng.integers(0, 2) else
+                         ref.add(Expr.lit(tj, 1), tj) if tj == capi.DOUBLE else ref.cast(capi.DOUBLE).mul(Expr.lit(capi.DOUBLE, 0.5), capi.DOUBLE))
+        filt = None
+        if len(exprs) < capi.MAX_EXPRS and rng.integers(0, 3) == 0:
+            b = _random_bool(rng, descs, int(rng.integers(1, 3)), big=False)
+            if b is not None and len(b.nodes) <= capi.MAX_EXPR_NODES and _stack_depth(b) <= capi.MAX_EXPR_STACK:
+                filt = len(exprs)
+                exprs.append(b)
         try:
-            exprs = [e.with_range(expr_range(e, descs, [cols])) for e in exprs]
+            exprs = [e.with_range(expr_range(e, descs, [cols], exprs[:i])) for i, e in enumerate(exprs)]
         except Exception:
             continue      # (the numpy range helper does not model every program: inf / nan corners)
         grouped = bool(rng.integers(0, 4))
         targets = [TargetExpr(capi.PROJECT_KEY)] if grouped else []
         targets.append(TargetExpr(capi.COUNT))
         for k in range(len(exprs)):
-            targets.append(TargetExpr(int(rng.choice([capi.SUM, capi.MIN, capi.MAX, capi.AVG, capi.COUNT])), nc + k))
+            if k != filt:
+                targets.append(TargetExpr(int(rng.choice([capi.SUM, capi.MIN, capi.MAX, capi.AVG, capi.COUNT])), nc + k))
         targets = targets[:6]
         quals = [Qual(2, capi.GE, -900)] if rng.integers(0, 3) == 0 else []
+        if filt is not None:
+            quals.append(Qual(nc + filt, capi.EQ, 1))
         ra = RelAlgExecutionUnit(descs, targets, quals, [0] if grouped else [], exprs=exprs, num_tuples=n)
         cut = (n // 2) & ~3
         case = cases_mod.Case("fuzz_expr_step", ra, [[c[:cut] for c in cols], [c[cut:] for c in cols]])
