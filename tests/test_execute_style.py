@@ -530,6 +530,38 @@ EXPR_QUERIES = [
 ]
 
 
+# Select.DivByZero (:7402-7432): EXPECT_THROW for a division by `x - x` in a group key, in MOD, in a filter — and the reference's
+# own literal for the short-circuit OR: `WHERE x = x OR y / (x - x) = y` counts every row (2 * g_num_rows), because the operand
+# with the unsafe division is evaluated second and only where the first does not decide (codegenLogicalShortCircuit).
+_x_minus_x = xsub(xc("x"), xc("x"), I32)
+_y_div0 = xdiv(xc("y"), _x_minus_x, I32)
+DIVZERO_QUERIES = [
+    ("SELECT COUNT(*) FROM test GROUP BY y / (x - x);", [agg("COUNT")], [], [X0], [_y_div0], capi.ERR_DIV_BY_ZERO),
+    ("SELECT COUNT(*) FROM test GROUP BY z, y / (x - x);", [agg("COUNT")], [], ["z", X0], [_y_div0], capi.ERR_DIV_BY_ZERO),
+    ("SELECT COUNT(*) FROM test GROUP BY MOD(y , (x - x));", [agg("COUNT")], [], [X0],
+     [EX(["y", "x"], lambda ix, nc: Expr.col(ix["y"]).mod(_x_minus_x.build(ix, nc), I32))], capi.ERR_DIV_BY_ZERO),
+    ("SELECT COUNT(*) FROM test WHERE y / (x - x) = 0;", [agg("COUNT")], [q(X0, "=", 0)], [], [_y_div0], capi.ERR_DIV_BY_ZERO),
+    ("SELECT COUNT(*) FROM test WHERE x = x OR  y / (x - x) = y;", [agg("COUNT")], [q(X0, "=", 1)], [],
+     [xlogic(xcmp(xc("x"), "=", xc("x")), "OR", xcmp(_y_div0, "=", xc("y")), short_circuit=True)], 2 * 10),
+]
+
+
+@pytest.mark.parametrize("qi", range(len(DIVZERO_QUERIES)), ids=[s[0][7:60].replace(" ", "_") for s in DIVZERO_QUERIES])
+def test_reference_div_by_zero_queries(oracle, qi):
+    from tests.test_rowlogic_emu import _emu_execute
+    sql, targets, quals, group, exprs, expect = DIVZERO_QUERIES[qi]
+    descs, frags, db = _table()
+    ra, frags = _unit_x(descs, frags, targets, quals, group, exprs, num_tuples=sum(REPEAT))
+    plan = ra.to_plan()
+    qm, buf, code = oracle.execute(plan, frags, n_threads=3)
+    eq, ebuf, ecode = _emu_execute(Case("ref", ra, frags), plan, None)
+    if expect == capi.ERR_DIV_BY_ZERO:
+        assert code == ecode == capi.ERR_DIV_BY_ZERO, (sql, code, ecode)
+    else:
+        assert code == 0 and ecode == 0, (sql, code, ecode)
+        assert _rows(oracle.fetch_rows(qm, buf), qm) == [(expect,)] and _rows(oracle.fetch_rows(eq, ebuf), eq) == [(expect,)], sql
+
+
 def _check_rows(sql, want, rows, fp, qm, name, rel):
     assert len(rows) == len(want), (name, sql, want, rows)
     for w, g in zip(want, rows):

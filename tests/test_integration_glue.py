@@ -240,6 +240,17 @@ int main() {
     REQ(p.n_quals == 3 && p.n_exprs == 0 && p.quals[0].col == 2 && MI355Q_QUAL_OR_GROUP(p.quals[1].op) == 1 &&
         MI355Q_QUAL_OP(p.quals[1].op) == MI355Q_EQ && p.quals[1].ival == 7 && p.quals[2].ival == 8 && p.quals[2].col == 0);
   }
+  {  // WHERE x = x OR y / (x - x) = y (Select.DivByZero, :7428-7430: ASSERT_EQ(2 * g_num_rows)): the short-circuit OR, unsafe operand second
+    RelAlgExecutionUnit ra = unit();
+    auto xx = std::make_shared<BinOper>(tb, kEQ, col(0), col(0));
+    auto zero = std::make_shared<BinOper>(ti[1], kMINUS, col(0), col(0));
+    auto q0 = std::make_shared<BinOper>(ti[1], kDIVIDE, col(1), zero);
+    ra.quals.push_back(std::make_shared<BinOper>(tb, kOR, xx, std::make_shared<BinOper>(tb, kEQ, q0, col(1))));
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 1 && p.n_exprs == 1 && p.quals[0].col == 4 && p.quals[0].ival == 1);
+    REQ(p.exprs[0].n_nodes == 11 && p.exprs[0].nodes[2].op == MI355Q_EX_EQ && p.exprs[0].nodes[7].op == MI355Q_EX_DIV &&
+        p.exprs[0].nodes[10].op == MI355Q_EX_OR && p.exprs[0].nodes[10].reserved == 1);
+  }
   {  // SELECT SUM(CASE WHEN x BETWEEN 6 AND 7 THEN 1 WHEN x BETWEEN 8 AND 9 THEN 2 ELSE 3 END) ... WHERE CASE WHEN y BETWEEN 42 AND 43
      // THEN 5 ELSE 4 END > 4 (Select.Case, ExecuteTest.cpp:5358-5365): the SUM's CASE has 19 nodes -> its two conditions (they cannot
      // raise) are expressions 0 and 1 and the CASE reads their values; the WHERE's CASE fits one program

@@ -59,6 +59,27 @@ def test_reference_expression_queries_on_gpu(torch_cuda, oracle):
         _check_rows(sql, want, sorted(_rows(rs.fetch(), qm), key=_key), fp, qm, "hip", 1e-9)
 
 
+def test_reference_div_by_zero_queries_on_gpu(torch_cuda, oracle):
+    """Select.DivByZero (tests/test_execute_style.py DIVZERO_QUERIES): error 1 where the reference EXPECT_THROWs, and its own
+    literal — every row — for `WHERE x = x OR y / (x - x) = y` (the short-circuit OR)."""
+    from heavydb_amd import capi
+    from heavydb_amd.executor import Executor
+    from tests.test_execute_style import DIVZERO_QUERIES, _unit_x
+    ex = Executor(0)
+    for sql, targets, quals, group, exprs, expect in DIVZERO_QUERIES:
+        descs, frags, db = _table()
+        ra, frags = _unit_x(descs, frags, targets, quals, group, exprs, num_tuples=sum(REPEAT))
+        case = Case("ref", ra, frags)
+        frag_t, inner_t = _upload(torch_cuda, case)
+        if expect == capi.ERR_DIV_BY_ZERO:
+            with pytest.raises(capi.Mi355qError) as err:
+                ex.executeWorkUnit(ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+            assert err.value.code == capi.ERR_DIV_BY_ZERO, (sql, err.value.code)
+        else:
+            rs = ex.executeWorkUnit(ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+            assert _rows(rs.fetch(), rs.getQueryMemDesc()) == [(expect,)], sql
+
+
 @pytest.mark.parametrize("ji", range(11))
 def test_reference_join_queries_on_gpu(torch_cuda, oracle, ji):
     from heavydb_amd.executor import Executor
