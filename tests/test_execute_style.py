@@ -546,6 +546,48 @@ DIVZERO_QUERIES = [
 ]
 
 
+# Select.OverflowAndUnderFlow (:7495-7531): the filters the reference runs with c(..) — no overflow, the count must equal SQLite's —
+# and the ones it EXPECT_THROWs: error 7.  Integer literals are INT unless they need BIGINT (RelAlgTranslator::translateLiteral),
+# so `z + 32666` is INT arithmetic on CAST(z AS INT) and does not overflow while `x + 2147483640` does for x = 8 (and not for 7).
+# `-ufq - ..` is the reference's own case of unary minus over a NOT NULL column that holds the type's minimum.
+_zi = xcast(xc("z"), I32)
+OVERFLOW_QUERIES = [
+    ("SELECT COUNT(*) FROM test WHERE z + 32600 > 0;", [xadd(_zi, xl(I32, 32600), I32)], ">", 0, None),
+    ("SELECT COUNT(*) FROM test WHERE z + 32666 > 0;", [xadd(_zi, xl(I32, 32666), I32)], ">", 0, None),
+    ("SELECT COUNT(*) FROM test WHERE -32670 - z < 0;", [xsub(xl(I32, -32670), _zi, I32)], "<", 0, None),
+    ("SELECT COUNT(*) FROM test WHERE (z + 16333) * 2 > 0;", [xmul(xadd(_zi, xl(I32, 16333), I32), xl(I32, 2), I32)], ">", 0, None),
+    ("SELECT COUNT(*) FROM test WHERE x + 2147483640 > 0;", [xadd(xc("x"), xl(I32, 2147483640), I32)], ">", 0, 7),
+    ("SELECT COUNT(*) FROM test WHERE -x - 2147483642 < 0;", [xsub(xneg(xc("x"), I32), xl(I32, 2147483642), I32)], "<", 0, 7),
+    ("SELECT COUNT(*) FROM test WHERE t + 9223372036854774000 > 0;", [xadd(xc("t"), xl(I64, 9223372036854774000), I64)], ">", 0, None),
+    ("SELECT COUNT(*) FROM test WHERE t + 9223372036854775000 > 0;", [xadd(xc("t"), xl(I64, 9223372036854775000), I64)], ">", 0, 7),
+    ("SELECT COUNT(*) FROM test WHERE -t - 9223372036854775000 < 0;", [xsub(xneg(xc("t"), I64), xl(I64, 9223372036854775000), I64)], "<", 0, 7),
+    ("SELECT COUNT(*) FROM test WHERE ofd + x - 2 > 0;", [xsub(xadd(xc("ofd"), xc("x"), I32), xl(I32, 2), I32)], ">", 0, 7),
+    ("SELECT COUNT(*) FROM test WHERE ufd * 3 - ofd * 1024 < -2;",
+     [xsub(xmul(xc("ufd"), xl(I32, 3), I32), xmul(xc("ofd"), xl(I32, 1024), I32), I32)], "<", -2, 7),
+    ("SELECT COUNT(*) FROM test WHERE ofd * 2 > 0;", [xmul(xc("ofd"), xl(I32, 2), I32)], ">", 0, 7),
+    ("SELECT COUNT(*) FROM test WHERE ofq + 1 > 0;", [xadd(xc("ofq"), xl(I64, 1), I64)], ">", 0, 7),
+    ("SELECT COUNT(*) FROM test WHERE -ufq - 9223372036854775000 > 0;", [xsub(xneg(xc("ufq"), I64), xl(I64, 9223372036854775000), I64)], ">", 0, 7),
+    ("SELECT COUNT(*) FROM test WHERE -92233720368547758 - ofq <= 0;", [xsub(xl(I64, -92233720368547758), xc("ofq"), I64)], "<=", 0, 7),
+]
+
+
+@pytest.mark.parametrize("qi", range(len(OVERFLOW_QUERIES)), ids=[s[0][30:75].replace(" ", "_") for s in OVERFLOW_QUERIES])
+def test_reference_overflow_queries(oracle, qi):
+    from tests.test_rowlogic_emu import _emu_execute
+    sql, exprs, op, lit, expect = OVERFLOW_QUERIES[qi]
+    descs, frags, db = _table()
+    ra, frags = _unit_x(descs, frags, [agg("COUNT")], [q(X0, op, lit)], [], exprs, num_tuples=sum(REPEAT))
+    plan = ra.to_plan()
+    qm, buf, code = oracle.execute(plan, frags, n_threads=3)
+    eq, ebuf, ecode = _emu_execute(Case("ref", ra, frags), plan, None)
+    if expect:
+        assert code == ecode == expect, (sql, code, ecode)
+    else:
+        want = [tuple(r) for r in db.execute(sql).fetchall()]
+        assert code == 0 and ecode == 0, (sql, code, ecode)
+        assert _rows(oracle.fetch_rows(qm, buf), qm) == want and _rows(oracle.fetch_rows(eq, ebuf), eq) == want, (sql, want)
+
+
 @pytest.mark.parametrize("qi", range(len(DIVZERO_QUERIES)), ids=[s[0][7:60].replace(" ", "_") for s in DIVZERO_QUERIES])
 def test_reference_div_by_zero_queries(oracle, qi):
     from tests.test_rowlogic_emu import _emu_execute

@@ -80,6 +80,27 @@ def test_reference_div_by_zero_queries_on_gpu(torch_cuda, oracle):
             assert _rows(rs.fetch(), rs.getQueryMemDesc()) == [(expect,)], sql
 
 
+def test_reference_overflow_queries_on_gpu(torch_cuda, oracle):
+    """Select.OverflowAndUnderFlow's filters (tests/test_execute_style.py OVERFLOW_QUERIES): SQLite's count where the reference
+    runs c(..), error 7 where it EXPECT_THROWs (unary minus of a NOT NULL INT64_MIN among them)."""
+    from heavydb_amd import capi
+    from heavydb_amd.executor import Executor
+    from tests.test_execute_style import OVERFLOW_QUERIES, _unit_x, agg, q
+    ex = Executor(0)
+    for sql, exprs, op, lit, expect in OVERFLOW_QUERIES:
+        descs, frags, db = _table()
+        ra, frags = _unit_x(descs, frags, [agg("COUNT")], [q(("x", 0), op, lit)], [], exprs, num_tuples=sum(REPEAT))
+        case = Case("ref", ra, frags)
+        frag_t, inner_t = _upload(torch_cuda, case)
+        if expect:
+            with pytest.raises(capi.Mi355qError) as err:
+                ex.executeWorkUnit(ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+            assert err.value.code == expect, (sql, err.value.code)
+        else:
+            rs = ex.executeWorkUnit(ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+            assert _rows(rs.fetch(), rs.getQueryMemDesc()) == [tuple(r) for r in db.execute(sql).fetchall()], sql
+
+
 @pytest.mark.parametrize("ji", range(11))
 def test_reference_join_queries_on_gpu(torch_cuda, oracle, ji):
     from heavydb_amd.executor import Executor
