@@ -35,6 +35,7 @@ COLS = {
     "u": (I32, True, [None, None, None]), "ofd": (I32, True, [2147483647, None, 1]),
     "ufd": (I32, False, [-2147483648, -2147483647, -1]), "ofq": (I64, True, [None, 2**63 - 1, 1]),
     "ufq": (I64, False, [-1, -2**63, -2**63]), "smallint_nulls": (I16, True, [32767, None, 1]),
+    "b": (I8, True, [1, 0, None]), "bn": (I8, False, [1, 0, 1]),      # BOOLEAN: 't', 'f', null / 't', 'f', 't' (NOT NULL)
 }
 NAMES = list(COLS)
 REPEAT = [10, 5, 5]   # g_num_rows = 10
@@ -544,6 +545,44 @@ DIVZERO_QUERIES = [
     ("SELECT COUNT(*) FROM test WHERE x = x OR  y / (x - x) = y;", [agg("COUNT")], [q(X0, "=", 1)], [],
      [xlogic(xcmp(xc("x"), "=", xc("x")), "OR", xcmp(_y_div0, "=", xc("y")), short_circuit=True)], 2 * 10),
 ]
+
+
+# Select.BooleanColumn (:7669-7695): every expectation but the last is the reference's own ASSERT_EQ literal (g_num_rows = 10).
+# A bare BOOLEAN column as a filter is the qual `column = 1`; NOT over it is an expression.
+def xnot(a):
+    return EX(a.names, lambda ix, nc: a.build(ix, nc).logical_not())
+
+
+BOOLEAN_QUERIES = [
+    ("SELECT COUNT(*) FROM test WHERE bn;", [agg("COUNT")], [q("bn", "=", 1)], [], [], [(15,)]),
+    ("SELECT COUNT(*) FROM test WHERE b;", [agg("COUNT")], [q("b", "=", 1)], [], [], [(10,)]),
+    ("SELECT COUNT(*) FROM test WHERE NOT bn;", [agg("COUNT")], [q(X0, "=", 1)], [], [xnot(xc("bn"))], [(5,)]),
+    ("SELECT COUNT(*) FROM test WHERE x < 8 AND bn;", [agg("COUNT")], [q("x", "<", 8), q("bn", "=", 1)], [], [], [(15,)]),
+    ("SELECT COUNT(*) FROM test WHERE x < 8 AND NOT bn;", [agg("COUNT")], [q("x", "<", 8), q(X0, "=", 1)], [], [xnot(xc("bn"))], [(0,)]),
+    ("SELECT COUNT(*) FROM test WHERE x > 7 OR false;", [agg("COUNT")], [q("x", ">", 7)], [], [], [(5,)]),                  # (folded)
+    ("SELECT MAX(x) FROM test WHERE b = CAST('t' AS boolean);", [agg("MAX", "x")], [q("b", "=", 1)], [], [], [(7,)]),
+    (" SELECT SUM(2 *(CASE when x = 7 then 1 else 0 END)) FROM test;", [agg("SUM", X0)], [], [],
+     [xmul(xl(I32, 2), xcase(xcmp(xc("x"), "=", xl(I32, 7)), xl(I32, 1), xl(I32, 0), I32), I32)], [(30,)]),
+    ("SELECT COUNT(*) AS n FROM test GROUP BY x = 7, b ORDER BY n;", [agg("COUNT")], [], [X0, "b"], [xcmp(xc("x"), "=", xl(I32, 7))], None),
+    ("SELECT COUNT(*) FROM test WHERE NOT b;", [agg("COUNT")], [q(X0, "=", 1)], [], [xnot(xc("b"))], [(5,)]),             # (not the reference's: NOT NULL is not TRUE)
+    ("SELECT COUNT(*) FROM test WHERE b IS NULL OR NOT bn;", [agg("COUNT")], [q(X0, "=", 1)], [],                          # (not the reference's)
+     [EX(["b", "bn"], lambda ix, nc: Expr.col(ix["b"]).is_null().logical(capi.EX_OR, Expr.col(ix["bn"]).logical_not()))], [(10,)]),
+]
+
+
+@pytest.mark.parametrize("qi", range(len(BOOLEAN_QUERIES)), ids=[s[0].strip()[7:60].replace(" ", "_") for s in BOOLEAN_QUERIES])
+def test_reference_boolean_column_queries(oracle, qi):
+    from tests.test_rowlogic_emu import _emu_execute
+    sql, targets, quals, group, exprs, expect = BOOLEAN_QUERIES[qi]
+    descs, frags, db = _table()
+    ra, frags = _unit_x(descs, frags, targets, quals, group, exprs, num_tuples=sum(REPEAT))
+    plan = ra.to_plan()
+    qm, buf, code = oracle.execute(plan, frags, n_threads=3)
+    eq, ebuf, ecode = _emu_execute(Case("ref", ra, frags), plan, None)
+    assert code == 0 and ecode == 0, (sql, code, ecode)
+    want = sorted(expect if expect is not None else [tuple(r) for r in db.execute(sql).fetchall()])
+    assert sorted(_rows(oracle.fetch_rows(qm, buf), qm)) == want, ("oracle", sql, want)
+    assert sorted(_rows(oracle.fetch_rows(eq, ebuf), eq)) == want, ("product row logic", sql, want)
 
 
 # Select.OverflowAndUnderFlow (:7495-7531): the filters the reference runs with c(..) — no overflow, the count must equal SQLite's —

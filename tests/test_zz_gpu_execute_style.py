@@ -80,6 +80,21 @@ def test_reference_div_by_zero_queries_on_gpu(torch_cuda, oracle):
             assert _rows(rs.fetch(), rs.getQueryMemDesc()) == [(expect,)], sql
 
 
+def test_reference_boolean_column_queries_on_gpu(torch_cuda, oracle):
+    """Select.BooleanColumn (tests/test_execute_style.py BOOLEAN_QUERIES): the reference's own ASSERT_EQ literals."""
+    from heavydb_amd.executor import Executor
+    from tests.test_execute_style import BOOLEAN_QUERIES, _unit_x
+    ex = Executor(0)
+    for sql, targets, quals, group, exprs, expect in BOOLEAN_QUERIES:
+        descs, frags, db = _table()
+        ra, frags = _unit_x(descs, frags, targets, quals, group, exprs, num_tuples=sum(REPEAT))
+        case = Case("ref", ra, frags)
+        frag_t, inner_t = _upload(torch_cuda, case)
+        rs = ex.executeWorkUnit(ra, _fetch_result(case, frag_t, inner_t), allow_retry=False)
+        want = sorted(expect if expect is not None else [tuple(r) for r in db.execute(sql).fetchall()])
+        assert sorted(_rows(rs.fetch(), rs.getQueryMemDesc())) == want, (sql, want)
+
+
 def test_reference_overflow_queries_on_gpu(torch_cuda, oracle):
     """Select.OverflowAndUnderFlow's filters (tests/test_execute_style.py OVERFLOW_QUERIES): SQLite's count where the reference
     runs c(..), error 7 where it EXPECT_THROWs (unary minus of a NOT NULL INT64_MIN among them)."""
