@@ -524,6 +524,16 @@ EXPR_QUERIES = [
      "WHERE CASE WHEN y BETWEEN 42 AND 43 THEN 5.1 ELSE 3.9 END > 4;", [agg("SUM", X3)], [q(X0, ">", 4.0)], [],
      [xcase(xbetween("y", I32, 42, 43), xl(F64, 5.1), xl(F64, 3.9), F64), xbetween("x", I32, 6, 7), xbetween("x", I32, 8, 9),
       xcase(xref(1), xl(F64, 1.1), xcase(xref(2), xl(F64, 2.2), xl(F64, 3.3), F64), F64)]),
+    # Select.FilterAndGroupBy / GroupByFloat shapes (:2445, :2818-2820, :5319): expressions as group keys, in the filter and the argument at once
+    ("SELECT MIN(x + y) FROM test WHERE x + y > 47 AND x + y < 53 GROUP BY x, y;", [agg("MIN", X0)], [q(X0, ">", 47), q(X0, "<", 53)],
+     ["x", "y"], [_xy]),
+    ("SELECT MIN(x + y) FROM test WHERE x + y > 47 AND x + y < 53 GROUP BY x + 1, x + y;", [agg("MIN", X0)], [q(X0, ">", 47), q(X0, "<", 53)],
+     [X1, X0], [_xy, xadd(xc("x"), xl(I32, 1), I32)]),
+    ("SELECT MIN(x + y) AS n FROM test WHERE x + y > 47 AND x + y < 53 GROUP BY f + 1, f + d ORDER BY n;", [agg("MIN", X0)],
+     [q(X0, ">", 47), q(X0, "<", 53)], [X1, X2], [_xy, xadd(xc("f"), xl(F32, 1.0), F32), xadd(xcast(xc("f"), F64), xc("d"), F64)]),
+    ("SELECT f + d AS s FROM test GROUP BY s ORDER BY s DESC;", [key()], [], [X0], [xadd(xcast(xc("f"), F64), xc("d"), F64)]),
+    ("SELECT t + x, AVG(x) AS avg_x FROM test WHERE z <= 50 and t < 2000 GROUP BY t + x ORDER BY avg_x DESC", [key(), agg("AVG", "x")],
+     [q("z", "<=", 50), q("t", "<", 2000)], [X0], [xadd(xc("t"), xcast(xc("x"), I64), I64)]),
     ("SELECT x, SUM(-y), COUNT(*) FROM test WHERE NOT (z > 100 AND t = 1002) GROUP BY x;",                    # (not the reference's text)
      [key(), agg("SUM", X0), agg("COUNT")], [q(X1, "=", 1)], ["x"],
      [xneg(xc("y"), I32), EX(["z", "t"], lambda ix, nc: xlogic(xcmp(xc("z"), ">", xl(I16, 100)), "AND",
