@@ -574,6 +574,10 @@ BOOLEAN_QUERIES = [
     (" SELECT SUM(2 *(CASE when x = 7 then 1 else 0 END)) FROM test;", [agg("SUM", X0)], [], [],
      [xmul(xl(I32, 2), xcase(xcmp(xc("x"), "=", xl(I32, 7)), xl(I32, 1), xl(I32, 0), I32), I32)], [(30,)]),
     ("SELECT COUNT(*) AS n FROM test GROUP BY x = 7, b ORDER BY n;", [agg("COUNT")], [], [X0, "b"], [xcmp(xc("x"), "=", xl(I32, 7))], None),
+    # Select.CastRoundNullable (:7862-7880): EXPECT_EQ(10, ..) and EXPECT_EQ(11, first key); 8 * 1.6 = 12.8 rounds to 13 (DEF_ROUND_NULLABLE)
+    ("SELECT COUNT(*) FROM test WHERE CAST(fn AS INT) IS NULL;", [agg("COUNT")], [q(X0, "IS NULL", 0)], [], [xcast(xc("fn"), I32)], [(10,)]),
+    ("SELECT CAST(CAST(x AS FLOAT) * 1.6 AS INT) AS key0 FROM test GROUP BY key0 ORDER BY key0;", [key()], [], [X0],
+     [xcast(xmul(xcast(xc("x"), F32), xl(F32, 1.6), F32), I32)], [(11,), (13,)]),
     ("SELECT COUNT(*) FROM test WHERE NOT b;", [agg("COUNT")], [q(X0, "=", 1)], [], [xnot(xc("b"))], [(5,)]),             # (not the reference's: NOT NULL is not TRUE)
     ("SELECT COUNT(*) FROM test WHERE b IS NULL OR NOT bn;", [agg("COUNT")], [q(X0, "=", 1)], [],                          # (not the reference's)
      [EX(["b", "bn"], lambda ix, nc: Expr.col(ix["b"]).is_null().logical(capi.EX_OR, Expr.col(ix["bn"]).logical_not()))], [(10,)]),

@@ -403,6 +403,25 @@ def test_logic_rules(oracle):
     assert nd[0] == nd[1] == struct.unpack("<q", struct.pack("<d", -float(np.finfo(np.float64).tiny)))[0] and nd[2:] == (0, 0)
 
 
+def test_null_with_and_or_literals_of_the_reference(oracle):
+    """Select.NullWithAndOr (Tests/ExecuteTest.cpp:1793-1868): `CAST(NULL AS BOOLEAN) AND val`, `val AND NULL`, `NULL OR val`,
+    `val OR NULL` over table_bool_test's three rows (val = true, false, NULL) — the twelve ASSERT_EQ literals, BOOLEAN_NULL_SENTINEL
+    = the INT8 NULL.  Both evaluators."""
+    NUL = -128
+    d = [InputColDescriptor(capi.INT8, True)]
+    val = {1: 1, 2: 0, 3: NUL}     # id -> val
+    null_b = Expr.null(capi.INT8)
+    want = {("NULL AND val", 1): NUL, ("NULL AND val", 2): 0, ("NULL AND val", 3): NUL,
+            ("val AND NULL", 1): NUL, ("val AND NULL", 2): 0, ("val AND NULL", 3): NUL,
+            ("NULL OR val", 1): 1, ("NULL OR val", 2): NUL, ("NULL OR val", 3): NUL,
+            ("val OR NULL", 1): 1, ("val OR NULL", 2): NUL, ("val OR NULL", 3): NUL}
+    progs = {"NULL AND val": null_b.logical(capi.EX_AND, Expr.col(0)), "val AND NULL": Expr.col(0).logical(capi.EX_AND, null_b),
+             "NULL OR val": null_b.logical(capi.EX_OR, Expr.col(0)), "val OR NULL": Expr.col(0).logical(capi.EX_OR, null_b)}
+    for (name, row), w in want.items():
+        ob, eb, oc, ec = _eval_both(oracle, _plan(d, progs[name]), [np.array([val[row]], dtype=np.int8)])
+        assert (oc, ec, ob, eb) == (0, 0, w, w), (name, row, ob, eb, w)
+
+
 def test_invalid_logic_programs_are_refused(oracle):
     from heavydb_amd.executor import ExprNode
     d = [InputColDescriptor(capi.INT32, True), InputColDescriptor(capi.INT8, True)]
