@@ -534,6 +534,26 @@ EXPR_QUERIES = [
     ("SELECT f + d AS s FROM test GROUP BY s ORDER BY s DESC;", [key()], [], [X0], [xadd(xcast(xc("f"), F64), xc("d"), F64)]),
     ("SELECT t + x, AVG(x) AS avg_x FROM test WHERE z <= 50 and t < 2000 GROUP BY t + x ORDER BY avg_x DESC", [key(), agg("AVG", "x")],
      [q("z", "<=", 50), q("t", "<", 2000)], [X0], [xadd(xc("t"), xcast(xc("x"), I64), I64)]),
+    # Select.FloatAndDoubleTests (:2388-2420): FLOAT and DOUBLE arithmetic in arguments and filters (x * f is FLOAT arithmetic on
+    # CAST(x AS FLOAT); f + d is DOUBLE arithmetic on CAST(f AS DOUBLE))
+    ("SELECT SUM(f + d) FROM test;", [agg("SUM", X0)], [], [], [_fd := xadd(xcast(xc("f"), F64), xc("d"), F64)]),
+    ("SELECT AVG(x * f) FROM test;", [agg("AVG", X0)], [], [], [xmul(xcast(xc("x"), F32), xc("f"), F32)]),
+    ("SELECT AVG(z - 200) FROM test;", [agg("AVG", X0)], [], [], [xsub(xcast(xc("z"), I32), xl(I32, 200), I32)]),
+    ("SELECT SUM(CAST(x AS FLOAT)) FROM test;", [agg("SUM", X0)], [], [], [xcast(xc("x"), F32)]),
+    ("SELECT SUM(CAST(x AS FLOAT)) FROM test GROUP BY z;", [agg("SUM", X0)], [], ["z"], [xcast(xc("x"), F32)]),
+    ("SELECT AVG(CAST(x AS FLOAT)) FROM test;", [agg("AVG", X0)], [], [], [xcast(xc("x"), F32)]),
+    ("SELECT AVG(CAST(x AS FLOAT)) FROM test GROUP BY y;", [agg("AVG", X0)], [], ["y"], [xcast(xc("x"), F32)]),
+    ("SELECT COUNT(*) FROM test WHERE f > 1.0 AND f < 1.2 OR (d > 2.0 AND d < 3.0);", [agg("COUNT")], [q(X1, "=", 1)], [],
+     [xband("d", F64, 2.0, 3.0), xlogic(xband("f", F32, 1.0, 1.2), "OR", xref(0))]),
+    ("SELECT SUM(x + y) FROM test WHERE d + f > 3.0 AND d + f < 4.0;", [agg("SUM", X0)], [q(X1, ">", 3.0), q(X1, "<", 4.0)], [],
+     [_xy, xadd(xc("d"), xcast(xc("f"), F64), F64)]),
+    ("SELECT SUM(f + d) FROM test WHERE x - y = -35;", [agg("SUM", X0)], [q(X1, "=", -35)], [], [_fd, _xmy]),
+    ("SELECT SUM(f + d) FROM test WHERE x + y + 1 = 50;", [agg("SUM", X0)], [q(X1, "=", 50)], [], [_fd, xadd(_xy, xl(I32, 1), I32)]),
+    ("SELECT SUM(f * d + 15) FROM test WHERE x + y + 1 = 50;", [agg("SUM", X0)], [q(X1, "=", 50)], [],
+     [xadd(xmul(xcast(xc("f"), F64), xc("d"), F64), xl(F64, 15.0), F64), xadd(_xy, xl(I32, 1), I32)]),
+    ("SELECT MIN(x), AVG(x * y), MAX(y + 7), AVG(x * f + 15), COUNT(*) FROM test WHERE x + y > 47 AND x + y < 51;",
+     [agg("MIN", "x"), agg("AVG", X0), agg("MAX", X1), agg("AVG", X2), agg("COUNT")], [q(X3, ">", 47), q(X3, "<", 51)], [],
+     [xmul(xc("x"), xc("y"), I32), xadd(xc("y"), xl(I32, 7), I32), xadd(xmul(xcast(xc("x"), F32), xc("f"), F32), xl(F32, 15.0), F32), _xy]),
     ("SELECT x, SUM(-y), COUNT(*) FROM test WHERE NOT (z > 100 AND t = 1002) GROUP BY x;",                    # (not the reference's text)
      [key(), agg("SUM", X0), agg("COUNT")], [q(X1, "=", 1)], ["x"],
      [xneg(xc("y"), I32), EX(["z", "t"], lambda ix, nc: xlogic(xcmp(xc("z"), ">", xl(I16, 100)), "AND",
