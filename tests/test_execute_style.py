@@ -598,6 +598,8 @@ BOOLEAN_QUERIES = [
     ("SELECT COUNT(*) FROM test WHERE CAST(fn AS INT) IS NULL;", [agg("COUNT")], [q(X0, "IS NULL", 0)], [], [xcast(xc("fn"), I32)], [(10,)]),
     ("SELECT CAST(CAST(x AS FLOAT) * 1.6 AS INT) AS key0 FROM test GROUP BY key0 ORDER BY key0;", [key()], [], [X0],
      [xcast(xmul(xcast(xc("x"), F32), xl(F32, 1.6), F32), I32)], [(11,), (13,)]),
+    # Select.OstensibleTautologyPredicate (:27648-27668): COUNT(*) WHERE ofd = ofd == COUNT(*) - COUNT_IF(ofd IS NULL)
+    ("SELECT COUNT(*) FROM test WHERE ofd = ofd;", [agg("COUNT")], [q(X0, "=", 1)], [], [xcmp(xc("ofd"), "=", xc("ofd"))], [(15,)]),
     ("SELECT COUNT(*) FROM test WHERE NOT b;", [agg("COUNT")], [q(X0, "=", 1)], [], [xnot(xc("b"))], [(5,)]),             # (not the reference's: NOT NULL is not TRUE)
     ("SELECT COUNT(*) FROM test WHERE b IS NULL OR NOT bn;", [agg("COUNT")], [q(X0, "=", 1)], [],                          # (not the reference's)
      [EX(["b", "bn"], lambda ix, nc: Expr.col(ix["b"]).is_null().logical(capi.EX_OR, Expr.col(ix["bn"]).logical_not()))], [(10,)]),
