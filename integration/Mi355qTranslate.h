@@ -442,12 +442,16 @@ inline int disjunction_members(const Analyzer::Expr* e) {
   }
   auto u = dynamic_cast<const Analyzer::UOper*>(e);
   if (u && u->get_optype() == kNOT)
-    if (auto inner = dynamic_cast<const Analyzer::BinOper*>(u->get_operand())) return qual_shaped(inner) ? 1 : -1;
+    if (auto inner = dynamic_cast<const Analyzer::BinOper*>(u->get_operand())) {
+      // (folding NOT into the operator is exact for integers — NULL stays "not TRUE" — but not for DOUBLE / FLOAT operands:
+      // NOT(x < 5) is TRUE for a NaN, x >= 5 is not; those keep the NOT, as a BOOLEAN expression)
+      return qual_shaped(inner) && !inner->get_left_operand()->get_type_info().is_fp() ? 1 : -1;
+    }
   if (auto in = dynamic_cast<const Analyzer::InValues*>(e)) return (int)in_list_constants(in).size();  // x = c0 OR x = c1 ...
   return qual_shaped(e) ? 1 : -1;
 }
-// the members of a disjunction (group > 0), or one comparison (group 0); NOT over a comparison is folded into the operator
-// (NOT(x < 5) = x >= 5: NULL stays "not TRUE" either way, LogicalIR.cpp:299-352)
+// the members of a disjunction (group > 0), or one comparison (group 0); NOT over a comparison of integers is folded into the
+// operator (NOT(x < 5) = x >= 5: NULL stays "not TRUE" either way, LogicalIR.cpp:299-352)
 inline void emit_disjunction(const Analyzer::Expr* e, const std::function<int(const Analyzer::Expr*)>& value_col,
                              mi355q_qual* quals, int32_t* n_quals, int32_t group) {
   auto b = dynamic_cast<const Analyzer::BinOper*>(e);

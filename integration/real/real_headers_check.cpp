@@ -216,6 +216,22 @@ int main() {
         InValues in_mixed(y, {lit});   // an INT constant against a BIGINT argument: the analyzer would have cast it
         REQ(refuses([&] { translate_conjunct(&in_mixed, value_col, qs, &nq, &ng); }));
       }
+      // NOT(d < 1.5) over a DOUBLE column is not folded into d >= 1.5 (a NaN passes the first and fails the second): it stays
+      // a BOOLEAN expression `= 1`
+      {
+        auto dcol = std::make_shared<ColumnVar>(t_dbl, ky, 0);
+        Datum dv;
+        dv.doubleval = 1.5;
+        auto dl = std::make_shared<Constant>(t_dbl, false, dv);
+        auto dlt = std::make_shared<BinOper>(SQLTypeInfo(kBOOLEAN, false), false, kLT, kONE, dcol, dl);
+        auto not_dlt = std::make_shared<UOper>(SQLTypeInfo(kBOOLEAN, false), false, kNOT, dlt);
+        nq = ng = 0;
+        translate_conjunct(not_dlt.get(), value_col, qs, &nq, &ng);
+        REQ(nq == 1 && qs[0].col == 100 && qs[0].op == MI355Q_EQ && qs[0].ival == 1);
+        mi355q_expr ed{};
+        emit_expr(not_dlt.get(), ed, outer_col);
+        REQ(ed.n_nodes == 4 && ed.nodes[2].op == MI355Q_EX_LT && ed.nodes[3].op == MI355Q_EX_NOT);
+      }
       // -y, y IS NULL as values
       auto neg = std::make_shared<UOper>(t_big, false, kUMINUS, y);
       mi355q_expr en{};

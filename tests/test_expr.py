@@ -374,6 +374,12 @@ def test_logic_rules(oracle):
     # an error in the FIRST operand ends the step in both forms
     first_bad = unsafe.logical(capi.EX_OR, safe, True)
     assert _eval_both(oracle, _plan(d, first_bad), [i32(10), i32(0)])[2:] == (capi.ERR_DIV_BY_ZERO, capi.ERR_DIV_BY_ZERO)
+    # NOT over a floating-point comparison is not the opposite comparison: a NaN makes `d < 1.5` FALSE and its negation TRUE
+    # (fcmp olt + CreateNot), while `d >= 1.5` is FALSE too — which is why the binding keeps such a NOT as an expression
+    dd = [InputColDescriptor(capi.DOUBLE, False)]
+    nan = [np.array([float("nan")])]
+    assert _eval_both(oracle, _plan(dd, Expr.col(0).cmp(capi.EX_LT, Expr.lit(capi.DOUBLE, 1.5)).logical_not()), nan) == (1, 1, 0, 0)
+    assert _eval_both(oracle, _plan(dd, Expr.col(0).cmp(capi.EX_GE, Expr.lit(capi.DOUBLE, 1.5))), nan) == (0, 0, 0, 0)
     # IS NULL: the comparison with the inline NULL for a nullable operand (the NULL literal included) ...
     for t, null_v, some in ((capi.INT32, -2**31, 5), (capi.INT64, -2**63, -9), (capi.INT8, -128, 0)):
         dn = [InputColDescriptor(t, True)]
