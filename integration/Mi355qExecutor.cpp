@@ -72,7 +72,8 @@ struct Translator {
     } catch (const ExprTooLong&) {
       // (the operands first: an expression reads EARLIER ones)
       const OuterCol oc = [this](const Analyzer::ColumnVar* cv) { return find(outer_cols, cv->getColumnKey()); };
-      if (!split_plain_logic(e, x, oc, [this](const Analyzer::Expr* v) { return value_col(v); })) {
+      if (!split_plain_logic(e, x, oc, [this](const Analyzer::Expr* v) { return value_col(v); }) &&
+          !split_in_list(e, x, oc, [this](const ExprFiller& fill) { return new_bool_col(fill); })) {
         // ... or a CASE whose conditions cannot raise: those are evaluated ahead, in expressions of their own
         std::vector<const Analyzer::Expr*> conds;
         hoistable_conditions(e, conds);

@@ -431,6 +431,44 @@ inline bool split_plain_logic(const Analyzer::Expr* e, mi355q_expr& x, const std
   return true;
 }
 
+// x IN (c0 .. c8) — or NOT IN — beyond one program (`y IN (43, 44, 45, 46, 47, 48, 49)`, Tests/ExecuteTest.cpp:2518: 27 nodes):
+// runs of the list are BOOLEAN expressions of their own and the root ORs their values (the logical_or chain of the reference's
+// loop is associative); `new_bool_col` of the executor half allocates an expression from a filler.
+inline bool split_in_list(const Analyzer::Expr* e, mi355q_expr& x, const std::function<int(const Analyzer::ColumnVar*)>& outer_col,
+                          const std::function<int(const std::function<void(mi355q_expr&, const std::function<int(const Analyzer::ColumnVar*)>&)>&)>& new_bool_col) {
+  auto u = dynamic_cast<const Analyzer::UOper*>(e);
+  const bool negated = u && u->get_optype() == kNOT;
+  auto in = dynamic_cast<const Analyzer::InValues*>(negated ? u->get_operand() : e);
+  if (!in) return false;
+  const auto vals = in_list_constants(in);
+  mi355q_expr probe{};
+  emit_expr(in->get_arg(), probe, outer_col);
+  const int per_value = probe.n_nodes + 2;                                      // the argument, the literal, EQ
+  const size_t per_run = (size_t)((MI355Q_MAX_EXPR_NODES + 1) / (per_value + 1));  // k comparisons and k - 1 ORs
+  if (per_run < 1) return false;
+  std::vector<int> runs;
+  for (size_t lo = 0; lo < vals.size(); lo += per_run) {
+    const size_t hi = std::min(vals.size(), lo + per_run);
+    runs.push_back(new_bool_col([&](mi355q_expr& c, const std::function<int(const Analyzer::ColumnVar*)>& oc) {
+      for (size_t k = lo; k < hi; ++k) {
+        emit_expr(in->get_arg(), c, oc);
+        emit_expr(vals[k], c, oc);
+        if (c.n_nodes + 1 + (k > lo ? 1 : 0) > MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+        c.nodes[c.n_nodes++] = mi355q_expr_node{MI355Q_EX_EQ, MI355Q_INT8, 0, 0, 0, 0.0};
+        if (k > lo) c.nodes[c.n_nodes++] = mi355q_expr_node{MI355Q_EX_OR, MI355Q_INT8, 0, 0, 0, 0.0};
+      }
+    }));
+  }
+  x = mi355q_expr{};
+  if ((int)runs.size() * 2 - 1 + (negated ? 1 : 0) > MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+  for (size_t j = 0; j < runs.size(); ++j) {
+    x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_COL, 0, runs[j], 0, 0, 0.0};
+    if (j) x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_OR, MI355Q_INT8, 0, 0, 0, 0.0};
+  }
+  if (negated) x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_NOT, MI355Q_INT8, 0, 0, 0, 0.0};
+  return true;
+}
+
 // ---- conjuncts of simple_quals / quals
 // members of a disjunction of qual shapes (`a OR b OR ...`, Analyzer::BinOper kOR nested any way round; NOT over a comparison
 // counts as the comparison); -1 = not such a disjunction

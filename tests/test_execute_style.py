@@ -402,6 +402,17 @@ def xnull(t):
     return EX([], lambda ix, nc: Expr.null(t))
 
 
+def xin(name, t, values):   # name IN (values): the OR of the comparisons
+    e = xcmp(xc(name), "=", xl(t, values[0]))
+    for v in values[1:]:
+        e = xlogic(e, "OR", xcmp(xc(name), "=", xl(t, v)))
+    return e
+
+
+def xnot(a):
+    return EX(a.names, lambda ix, nc: a.build(ix, nc).logical_not())
+
+
 def _unit_x(descs, frags, targets, quals, group, exprs, **kw):
     """like _unit; a target's / qual's / group's column may be ("x", k): expression k of `exprs`"""
     from tests.cases import expr_range
@@ -554,6 +565,13 @@ EXPR_QUERIES = [
     ("SELECT MIN(x), AVG(x * y), MAX(y + 7), AVG(x * f + 15), COUNT(*) FROM test WHERE x + y > 47 AND x + y < 51;",
      [agg("MIN", "x"), agg("AVG", X0), agg("MAX", X1), agg("AVG", X2), agg("COUNT")], [q(X3, ">", 47), q(X3, "<", 51)], [],
      [xmul(xc("x"), xc("y"), I32), xadd(xc("y"), xl(I32, 7), I32), xadd(xmul(xcast(xc("x"), F32), xc("f"), F32), xl(F32, 15.0), F32), _xy]),
+    # Select.InValues (:2512-2523): lists beyond one program are runs of three comparisons each, ORed by the root
+    ("SELECT x FROM test WHERE x IN (8, 9, 10, 11, 12, 13, 14) GROUP BY x ORDER BY x;", [key()], [q(X3, "=", 1)], ["x"],
+     [xin("x", I32, [8, 9, 10]), xin("x", I32, [11, 12, 13]), xin("x", I32, [14]), xlogic(xlogic(xref(0), "OR", xref(1)), "OR", xref(2))]),
+    ("SELECT y FROM test WHERE y IN (43, 44, 45, 46, 47, 48, 49) GROUP BY y ORDER BY y;", [key()], [q(X3, "=", 1)], ["y"],
+     [xin("y", I32, [43, 44, 45]), xin("y", I32, [46, 47, 48]), xin("y", I32, [49]), xlogic(xlogic(xref(0), "OR", xref(1)), "OR", xref(2))]),
+    ("SELECT t FROM test WHERE t NOT IN (1001, 1003, 1005, 1007, 1009, -10) GROUP BY t ORDER BY t;", [key()], [q(X2, "=", 1)], ["t"],
+     [xin("t", I64, [1001, 1003, 1005]), xin("t", I64, [1007, 1009, -10]), xnot(xlogic(xref(0), "OR", xref(1)))]),
     ("SELECT x, SUM(-y), COUNT(*) FROM test WHERE NOT (z > 100 AND t = 1002) GROUP BY x;",                    # (not the reference's text)
      [key(), agg("SUM", X0), agg("COUNT")], [q(X1, "=", 1)], ["x"],
      [xneg(xc("y"), I32), EX(["z", "t"], lambda ix, nc: xlogic(xcmp(xc("z"), ">", xl(I16, 100)), "AND",
@@ -579,10 +597,6 @@ DIVZERO_QUERIES = [
 
 # Select.BooleanColumn (:7669-7695): every expectation but the last is the reference's own ASSERT_EQ literal (g_num_rows = 10).
 # A bare BOOLEAN column as a filter is the qual `column = 1`; NOT over it is an expression.
-def xnot(a):
-    return EX(a.names, lambda ix, nc: a.build(ix, nc).logical_not())
-
-
 BOOLEAN_QUERIES = [
     ("SELECT COUNT(*) FROM test WHERE bn;", [agg("COUNT")], [q("bn", "=", 1)], [], [], [(15,)]),
     ("SELECT COUNT(*) FROM test WHERE b;", [agg("COUNT")], [q("b", "=", 1)], [], [], [(10,)]),

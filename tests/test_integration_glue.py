@@ -240,6 +240,20 @@ int main() {
     REQ(p.n_quals == 3 && p.n_exprs == 0 && p.quals[0].col == 2 && MI355Q_QUAL_OR_GROUP(p.quals[1].op) == 1 &&
         MI355Q_QUAL_OP(p.quals[1].op) == MI355Q_EQ && p.quals[1].ival == 7 && p.quals[2].ival == 8 && p.quals[2].col == 0);
   }
+  {  // WHERE t NOT IN (1001, 1003, 1005, 1007, 1009, -10) (Select.InValues, :2521): 6 x 3 + 5 + 1 nodes -> two runs of three comparisons
+     // are expressions 0 and 1, the root is NOT(value 0 OR value 1)
+    RelAlgExecutionUnit ra = unit();
+    std::list<std::shared_ptr<Analyzer::Expr>> vals;
+    for (int64_t v : {1001, 1003, 1005, 1007, 1009, -10}) vals.push_back(lit(3, v));
+    auto in = std::make_shared<Analyzer::InValues>(col(3), vals);
+    ra.quals.push_back(std::make_shared<Analyzer::UOper>(tb, kNOT, in));
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 1 && p.n_exprs == 3 && p.quals[0].col == 4 + 2 && p.quals[0].op == MI355Q_EQ && p.quals[0].ival == 1);
+    REQ(p.exprs[0].n_nodes == 11 && p.exprs[0].nodes[1].ilit == 1001 && p.exprs[0].nodes[9].op == MI355Q_EX_EQ && p.exprs[0].nodes[10].op == MI355Q_EX_OR);
+    REQ(p.exprs[1].n_nodes == 11 && p.exprs[1].nodes[1].ilit == 1007 && p.exprs[1].nodes[8].ilit == -10);
+    REQ(p.exprs[2].n_nodes == 4 && p.exprs[2].nodes[0].arg == 4 && p.exprs[2].nodes[1].arg == 5 && p.exprs[2].nodes[2].op == MI355Q_EX_OR &&
+        p.exprs[2].nodes[3].op == MI355Q_EX_NOT);
+  }
   {  // WHERE x = x OR y / (x - x) = y (Select.DivByZero, :7428-7430: ASSERT_EQ(2 * g_num_rows)): the short-circuit OR, unsafe operand second
     RelAlgExecutionUnit ra = unit();
     auto xx = std::make_shared<BinOper>(tb, kEQ, col(0), col(0));
