@@ -171,8 +171,13 @@ typedef struct mi355q_col_desc {
  * (MI355Q_QUAL_IN_OR_GROUP(op, g), g = 1..3) are OR-ed together, the groups and the plain quals are AND-ed — `x < 5 AND
  * (y = 1 OR y = 2 OR z IS NULL)`.  With the reference's three-valued logic (logical_and / logical_or over nullable booleans,
  * LogicalIR.cpp:299-340) a row passes the filter when the whole condition is TRUE — `toBool`, :344-352: NULL counts as
- * false — i.e. when every plain qual is TRUE and every group has a member that is TRUE; NOT over a comparison is folded
- * into the operator by the binding (NULL stays "not TRUE" either way).  Plans with a disjunction run in the row kernel.
+ * false — i.e. when every plain qual is TRUE and every group has a member that is TRUE; NOT over a comparison of integers is
+ * folded into the operator by the binding (NULL stays "not TRUE" either way; over DOUBLE / FLOAT operands a NaN would tell the
+ * two apart).  Plans with a disjunction run in the row kernel.  Every other BOOLEAN conjunct — AND inside OR, NOT over a
+ * disjunction, a BOOLEAN column, a long IN list — is a projected BOOLEAN expression (mi355q_expr: the NOT / AND / OR / IS NULL
+ * micro-ops over comparisons) and the qual `that column = 1`, which keeps the step in the fast families; a conjunct that
+ * holds an unsafe division — a DEFERRED qual in the reference, evaluated only for rows the other quals let through
+ * (prioritizeQuals, LogicalIR.cpp:158-195) — is the second operand of a short-circuit AND inside such an expression.
  * A member of a group is never a `constrained_not_null` witness (OutputBufferInitialization.cpp:301-324 looks at top-level
  * conjuncts only). */
 #define MI355Q_QUAL_OP(op) ((op) & 0xff)
