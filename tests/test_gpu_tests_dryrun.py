@@ -153,6 +153,10 @@ def test_dryrun_execute_style(monkeypatch, oracle):
         m.test_reference_queries_on_gpu(torch, oracle, qi)
     for ji in range(len(JOIN_QUERIES)):
         m.test_reference_join_queries_on_gpu(torch, oracle, ji)
+    m.test_reference_expression_queries_on_gpu(torch, oracle)
+    m.test_reference_div_by_zero_queries_on_gpu(torch, oracle)
+    m.test_reference_boolean_column_queries_on_gpu(torch, oracle)
+    m.test_reference_overflow_queries_on_gpu(torch, oracle)
 
 
 def test_dryrun_sqlite_scale(monkeypatch, oracle):
