@@ -614,6 +614,10 @@ BOOLEAN_QUERIES = [
      [xcast(xmul(xcast(xc("x"), F32), xl(F32, 1.6), F32), I32)], [(11,), (13,)]),
     # Select.OstensibleTautologyPredicate (:27648-27668): COUNT(*) WHERE ofd = ofd == COUNT(*) - COUNT_IF(ofd IS NULL)
     ("SELECT COUNT(*) FROM test WHERE ofd = ofd;", [agg("COUNT")], [q(X0, "=", 1)], [], [xcmp(xc("ofd"), "=", xc("ofd"))], [(15,)]),
+    # (the same identity over encoded columns — date in days, fixed(16) INT, dictionary ids — decoded by the expression's column node)
+    ("SELECT COUNT(*) FROM test WHERE o1 = o1;", [agg("COUNT")], [q(X0, "=", 1)], [], [xcmp(xc("o1"), "=", xc("o1"))], [(15,)]),
+    ("SELECT COUNT(*) FROM test WHERE fx = fx AND str = str;", [agg("COUNT")], [q(X0, "=", 1), q(X1, "=", 1)], [],
+     [xcmp(xc("fx"), "=", xc("fx")), xcmp(xc("str"), "=", xc("str"))], [(15,)]),
     ("SELECT COUNT(*) FROM test WHERE NOT b;", [agg("COUNT")], [q(X0, "=", 1)], [], [xnot(xc("b"))], [(5,)]),             # (not the reference's: NOT NULL is not TRUE)
     ("SELECT COUNT(*) FROM test WHERE b IS NULL OR NOT bn;", [agg("COUNT")], [q(X0, "=", 1)], [],                          # (not the reference's)
      [EX(["b", "bn"], lambda ix, nc: Expr.col(ix["b"]).is_null().logical(capi.EX_OR, Expr.col(ix["bn"]).logical_not()))], [(10,)]),
