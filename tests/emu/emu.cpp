@@ -51,6 +51,10 @@ extern "C" int32_t emu_eval_expr(const mi355q_plan* plan, int32_t k, const void*
   DevExprSet xs;
   if (int32_t e = lower_exprs(*plan, &lp, &xs)) return e;
   if (k < 0 || k >= xs.n) return MI355Q_ERR_INVALID_PLAN;
+  // (one program on the caller's PHYSICAL columns: a program that reads the value of an earlier expression needs the
+  // projection's extended column table — emu_execute — as orc_eval_expr says too)
+  for (int i = 0; i < xs.e[k].n_nodes; ++i)
+    if (xs.e[k].nodes[i].op == MI355Q_EX_COL && xs.e[k].nodes[i].arg >= plan->n_cols) return MI355Q_ERR_INVALID_PLAN;
   int32_t err = 0;
   *out_bits = eval_expr(xs.e[k], (const int8_t* const*)cols, pos, &err);
   *out_type = xs.e[k].type;
