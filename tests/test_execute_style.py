@@ -572,6 +572,10 @@ EXPR_QUERIES = [
      [xin("y", I32, [43, 44, 45]), xin("y", I32, [46, 47, 48]), xin("y", I32, [49]), xlogic(xlogic(xref(0), "OR", xref(1)), "OR", xref(2))]),
     ("SELECT t FROM test WHERE t NOT IN (1001, 1003, 1005, 1007, 1009, -10) GROUP BY t ORDER BY t;", [key()], [q(X2, "=", 1)], ["t"],
      [xin("t", I64, [1001, 1003, 1005]), xin("t", I64, [1007, 1009, -10]), xnot(xlogic(xref(0), "OR", xref(1)))]),
+    # Select.FilterAndMultipleAggregation (:2578)
+    ("SELECT MIN(x), AVG(x * y), MAX(y + 7), COUNT(*) FROM test WHERE x + y > 47 AND x + y < 51;",
+     [agg("MIN", "x"), agg("AVG", X0), agg("MAX", X1), agg("COUNT")], [q(X2, ">", 47), q(X2, "<", 51)], [],
+     [xmul(xc("x"), xc("y"), I32), xadd(xc("y"), xl(I32, 7), I32), _xy]),
     ("SELECT x, SUM(-y), COUNT(*) FROM test WHERE NOT (z > 100 AND t = 1002) GROUP BY x;",                    # (not the reference's text)
      [key(), agg("SUM", X0), agg("COUNT")], [q(X1, "=", 1)], ["x"],
      [xneg(xc("y"), I32), EX(["z", "t"], lambda ix, nc: xlogic(xcmp(xc("z"), ">", xl(I16, 100)), "AND",

@@ -45,7 +45,7 @@ def test_reference_expression_queries_on_gpu(torch_cuda, oracle):
     AND, IS NULL of an expression) through k_project and the kernel families, against SQLite running the reference's text."""
     from heavydb_amd.executor import Executor
     from tests.test_execute_style import EXPR_QUERIES, _check_rows, _unit_x
-    assert len(EXPR_QUERIES) == 75
+    assert len(EXPR_QUERIES) == 76
     ex = Executor(0)
     for sql, targets, quals, group, exprs in EXPR_QUERIES:
         descs, frags, db = _table()
