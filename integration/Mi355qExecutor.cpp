@@ -90,6 +90,7 @@ struct Translator {
       }
     }
     if (p.n_exprs >= MI355Q_MAX_EXPRS) unsupported("too many projected expressions");
+    check_expr_stack(x);
     x.range = to_range(getExpressionRange(e, query_infos, executor));
     p.exprs[p.n_exprs] = x;
     expr_of.push_back(e);
@@ -102,6 +103,7 @@ struct Translator {
     mi355q_expr& x = p.exprs[p.n_exprs];
     x = mi355q_expr{};
     fill(x, [this](const Analyzer::ColumnVar* cv) { return find(outer_cols, cv->getColumnKey()); });
+    check_expr_stack(x);
     x.range = mi355q_range{1, 1, 0, 1, 0.0, 0.0, 0};
     expr_of.push_back(nullptr);
     return p.n_cols + p.n_exprs++;

@@ -469,6 +469,25 @@ inline bool split_in_list(const Analyzer::Expr* e, mi355q_expr& x, const std::fu
   return true;
 }
 
+// the deepest the evaluation stack of a program gets (the library refuses more than MI355Q_MAX_EXPR_STACK values with
+// MI355Q_ERR_INVALID_PLAN; the binding says "unsupported" first, so that the caller keeps the native path)
+inline int expr_stack_depth(const mi355q_expr& x) {
+  int sp = 0, deepest = 0;
+  for (int i = 0; i < x.n_nodes; ++i) {
+    switch (x.nodes[i].op) {
+      case MI355Q_EX_COL: case MI355Q_EX_LIT: ++sp; break;
+      case MI355Q_EX_CAST: case MI355Q_EX_NOT: case MI355Q_EX_IS_NULL: case MI355Q_EX_UMINUS: break;
+      case MI355Q_EX_CASE: sp -= 2; break;
+      default: --sp;
+    }
+    if (sp > deepest) deepest = sp;
+  }
+  return deepest;
+}
+inline void check_expr_stack(const mi355q_expr& x) {
+  if (expr_stack_depth(x) > MI355Q_MAX_EXPR_STACK) unsupported("expression too deep");
+}
+
 // ---- conjuncts of simple_quals / quals
 // members of a disjunction of qual shapes (`a OR b OR ...`, Analyzer::BinOper kOR nested any way round; NOT over a comparison
 // counts as the comparison); -1 = not such a disjunction

@@ -296,6 +296,30 @@ int main() {
     const mi355q_plan pb = to_plan(rb, query_infos, &executor, nullptr, 16384, false);   // the safe second condition is hoisted, the risky one is not
     REQ(pb.n_exprs == 2 && pb.exprs[0].nodes[1].ilit == 8 && pb.exprs[1].n_nodes == 11 && pb.exprs[1].nodes[2].arg == 4 + 0 && pb.exprs[1].nodes[7].op == MI355Q_EX_DIV);
   }
+  {  // x + (x + (x + ... )) nested to the right nine deep: 9 values on the stack -> refused by the binding (the library would say INVALID_PLAN)
+    std::shared_ptr<Analyzer::Expr> e = col(1);
+    for (int i = 0; i < 5; ++i) e = std::make_shared<BinOper>(ti[1], kPLUS, col(1), e);   // 6 values: fine
+    Analyzer::AggExpr s6(SQLTypeInfo(kBIGINT, false), kSUM, e);
+    RelAlgExecutionUnit ra = unit();
+    ra.target_exprs = {&s6};
+    const mi355q_plan p6 = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p6.n_exprs == 1 && p6.exprs[0].n_nodes == 11 && expr_stack_depth(p6.exprs[0]) == 6);
+    std::shared_ptr<Analyzer::Expr> deep = col(1);
+    for (int i = 0; i < 5; ++i) deep = std::make_shared<BinOper>(ti[1], kPLUS, col(1), std::make_shared<Analyzer::UOper>(ti[1], kUMINUS, deep));
+    // (11 + 5 nodes: too long before it is too deep) -> refused either way
+    Analyzer::AggExpr s9(SQLTypeInfo(kBIGINT, false), kSUM, deep);
+    RelAlgExecutionUnit rb = unit();
+    rb.target_exprs = {&s9};
+    bool refused = false;
+    try { to_plan(rb, query_infos, &executor, nullptr, 16384, false); } catch (const std::runtime_error&) { refused = true; }
+    REQ(refused);
+    mi355q_expr nine{};
+    for (int i = 0; i < 9; ++i) nine.nodes[nine.n_nodes++] = mi355q_expr_node{MI355Q_EX_COL, 0, 1, 0, 0, 0.0};
+    REQ(expr_stack_depth(nine) == 9);
+    bool deep_refused = false;
+    try { check_expr_stack(nine); } catch (const std::runtime_error&) { deep_refused = true; }
+    REQ(deep_refused);
+  }
   std::printf(bad ? "bad\\n" : "ok\\n");
   return bad ? 1 : 0;
 }
