@@ -12,14 +12,14 @@ import os
 import sys
 
 MAX_COLS = 16
-MAX_QUALS = 4
+MAX_QUALS = 8
 MAX_TARGETS = 8
 MAX_SLOTS = 16
 MAX_GROUP_COLS = 4
-MAX_EXPRS = 4
-MAX_EXPR_NODES = 12
+MAX_EXPRS = 8
+MAX_EXPR_NODES = 24
 MAX_EXPR_STACK = 8
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 # mi355q_type
 INT8, INT16, INT32, INT64, DOUBLE, FLOAT = 1, 2, 3, 4, 5, 6
@@ -36,11 +36,13 @@ class OrderEntry(C.Structure):
                 ("reserved", C.c_int32)]
 # mi355q_agg (SQLAgg values)
 AVG, MIN, MAX, SUM, COUNT, PROJECT_KEY = 0, 1, 2, 3, 4, 100
+PROJECT = 101  # a Projection step's non-aggregate target (the value of a column / expression)
 COUNT_IF, SUM_IF = 10, 11
 # mi355q_join_kind
 JOIN_INNER, JOIN_LEFT = 0, 1
 # mi355q_desc_type
 GROUP_BY_PERFECT_HASH, GROUP_BY_BASELINE_HASH, NON_GROUPED_AGGREGATE = 0, 1, 4
+PROJECTION = 2
 OUTPUT_ROWWISE, OUTPUT_COLUMNAR, OUTPUT_ROWWISE_COLUMNAR_DECISIONS = 0, 1, 2  # mi355q_columnar_hint
 # generator kinds
 GEN_I32_UNIFORM31, GEN_I32_MOD, GEN_I64_MOD, GEN_I64_MOD_MUL, GEN_F64_UNIT = 1, 2, 3, 4, 5
@@ -122,6 +124,7 @@ class Plan(C.Structure):
         ("n_exprs", C.c_int32),
         ("reserved3", C.c_int32),
         ("exprs", Expr * MAX_EXPRS),
+        ("scan_limit", C.c_int64),
     ]
 
 
@@ -157,6 +160,7 @@ class QMD(C.Structure):
         ("target_arg_is_f32", C.c_int32 * MAX_TARGETS),
         ("target_null", C.c_int64 * MAX_TARGETS),
         ("init_vals", C.c_int64 * MAX_SLOTS),
+        ("slot_bytes", C.c_int32 * MAX_SLOTS),
     ]
 
     def as_dict(self):
@@ -274,6 +278,7 @@ SYMBOLS = [
     ("mi355q_result_copy_to_host", C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64]),
     ("mi355q_result_reduce", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355q_result_row_count", C.c_int64, [C.c_void_p]),
+    ("mi355q_result_total_matched", C.c_int64, [C.c_void_p]),
     ("mi355q_result_fetch_rows", C.c_int32,
      [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
     ("mi355q_result_to_columns", C.c_int32, [C.c_void_p, _P(C.c_void_p), C.c_int32, _P(C.c_int64), C.c_void_p]),

@@ -21,60 +21,12 @@
 #include <new>
 #include <vector>
 
-#include "kernels.h"
-#include "plan.h"
+#include "api_internal.h"
 
 using namespace mq;
 
-struct mi355q_join_table {
-  int device_id = 0;
-  int hash_type = 0;  // 0 perfect 1:1, 1 keyed 1:1, 2 perfect 1:N, 3 keyed 1:N (mi355q.h)
-  int key_type = MI355Q_INT64;
-  int n_keys = 1, width = 8;  // key components / component width of keyed tables
-  int64_t entry_count = 0;
-  int64_t min_key = 0, max_key = 0;
-  void* buf = nullptr;
-  int64_t bytes = 0;
-  void* bitmap = nullptr;  // perfect tables: presence bitmap (1 bit per slot), for probes that
-                           // only need to know WHETHER a key matches (no inner column read)
-  float build_ms = 0.f;
-  // perfect tables: per-key aggregated payload for the payload probe (kernels_part.hip), built on
-  // first use for one inner column and kept with the table (the inner table does not change under
-  // a join table): rows per key, sum of the inner column over them, non-NULL values among them
-  std::mutex pay_mu;
-  uint32_t* pay_cnt = nullptr;
-  int64_t* pay_wsum = nullptr;
-  uint32_t* pay_wnn = nullptr;
-  void* pay16 = nullptr;         // the same as 16-byte entries (L2 mode of the probe)
-  int64_t* pay8 = nullptr;       // one-to-one tables, L2 mode: the inner value per key slot, INT64_MIN = absent
-  int64_t* pay_kkeys = nullptr;  // keyed tables: the key of every slot (pay16 / pay8 are then per slot)
-  const void* pay16_col = nullptr;
-  bool pay16_built = false, pay_col_built = false;
-  int pay16_has_nulls = 0;
-  const void* pay_col = nullptr;
-  int pay_has_nulls = 0;
-  float pay_build_ms = 0.f;
-  int64_t pay_version = 0, pay16_version = 0;  // mi355q_inputs.inner_version the payloads were built for
-  // a payload the probe plan then refused (built, dropped): not built again for the same column and step shape
-  bool pay_refused = false;
-  const void* pay_refused_col = nullptr;
-  int64_t pay_refused_rows = 0;
-};
-
-struct mi355q_result {
-  mi355q_qmd qmd{};
-  DevPlan dplan{};  // layout + targets for reduce / iteration kernels
-  int device_id = 0;
-  int64_t* buf = nullptr;
-  int64_t bytes = 0;
-  bool owns_buf = false;
-};
-
-namespace {
-
-// mi355q_explain: the route of a step, written down while execute_impl plans it in RESERVE mode (nothing is launched,
-// nothing is allocated: t_plan_only).  Every derived route (projection, row-wise / 8-byte twins, packed keys, one run
-// per value column) notes itself and plans its derived step the same way.
+namespace mq {
+namespace api {
 thread_local std::string* t_route = nullptr;
 thread_local bool t_plan_only = false;
 void route_note(const char* what) {
@@ -83,43 +35,7 @@ void route_note(const char* what) {
   *t_route += what;
 }
 
-#define HIP_TRY(expr)                                     \
-  do {                                                    \
-    hipError_t _e = (expr);                               \
-    if (_e != hipSuccess) {                               \
-      last_hip_error = _e;                                \
-      return _e == hipErrorOutOfMemory ? MI355Q_ERR_OUT_OF_GPU_MEM : MI355Q_ERR_HIP; \
-    }                                                     \
-  } while (0)
-
 thread_local hipError_t last_hip_error = hipSuccess;
-
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = false;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    ok = hipSetDevice(dev) == hipSuccess;
-    // hipGetLastError() is per thread and sticky: another runtime user in this process (torch)
-    // may have left an unrelated error behind, which the launch checks would then report
-    (void)hipGetLastError();
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-
-// MI355Q_OPT_TRACE: host-side wall-clock marks of one execute call on stderr
-struct Trace {
-  bool on;
-  std::chrono::steady_clock::time_point t0;
-  explicit Trace(bool enabled) : on(enabled), t0(std::chrono::steady_clock::now()) {}
-  void mark(const char* what) {
-    if (!on) return;
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    std::fprintf(stderr, "[mi355q] %8.3f ms  %s\n", ms, what);
-  }
-};
 
 int cu_count_of(int dev) {
   static std::mutex mu;
@@ -135,47 +51,31 @@ int cu_count_of(int dev) {
   return cache[dev];
 }
 
-// Per-device workspace kept between calls: the partition scratch (tens of GB for the headline
-// workload — hipMalloc/hipFree of that size costs up to a second per call), the fragment
-// pointer tables and the timing events.  Calls on one device are serialised by `mu`, like
-// the reference's per-device gpu_exec_mutex_ (ExecutionKernel.cpp:216-220).
-struct DeviceCtx {
-  std::recursive_mutex mu;  // the packed multi-column path re-enters mi355q_execute
-  void* aux = nullptr;      // packed key column + temporary tables of that path
-  int64_t aux_bytes = 0;
-  void* wide = nullptr;     // 8-byte-slot table of a step whose result layout has 4-byte slots
-  int64_t wide_bytes = 0;
-  void* proj = nullptr;     // dense temporary columns of projected expressions (one pass of fragments)
-  int64_t proj_bytes = 0;
-  void* gather = nullptr;   // dense temporary columns of a grouped join's inner side (execute_join_gather; may nest inside proj's step)
-  int64_t gather_bytes = 0;
-  void* lattice = nullptr;  // dense INT32 key columns of a lattice-keyed step (execute_affine_twin; may nest inside both)
-  int64_t lattice_bytes = 0;
-  void* scratch = nullptr;
-  int64_t scratch_bytes = 0;
-  void* meta = nullptr;
-  size_t meta_bytes = 0;
-  // pinned host mirror of `meta` (column table, row counts, zeroed error words go to the device as ONE copy that does not
-  // stage through a driver buffer) + 64 bytes the error words and the spill counter come back into
-  char* h_meta = nullptr;
-  std::vector<hipEvent_t> events;
-  hipStream_t stream = nullptr;  // library-owned launch stream (when the caller passes none)
-  struct mi355q_pending* inflight = nullptr;  // a step enqueued by mi355q_execute_async and not yet waited for
-};
 DeviceCtx& ctx_of(int dev) {
   static DeviceCtx ctxs[64];
   return ctxs[dev < 0 ? 0 : dev % 64];
 }
 
-void drain_inflight(DeviceCtx& ctx);  // finishes the step mi355q_execute_async left in flight (defined with finish_step)
+}  // namespace api
+}  // namespace mq
+using namespace mq::api;
 
-// Small pinned-free device scratch for the error word / counters, one per call.
-struct DevWord {
-  void* p = nullptr;
-  ~DevWord() {
-    if (p) (void)hipFree(p);
+namespace {
+
+// MI355Q_OPT_TRACE: host-side wall-clock marks of one execute call on stderr
+struct Trace {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  explicit Trace(bool enabled) : on(enabled), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(stderr, "[mi355q] %8.3f ms  %s\n", ms, what);
   }
 };
+
+
+void drain_inflight(DeviceCtx& ctx);  // finishes the step mi355q_execute_async left in flight (defined with finish_step)
 
 RowInit make_row_init(const mi355q_qmd& q) {
   RowInit r{};
@@ -224,7 +124,9 @@ int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
   return MI355Q_OK;
 }
 
-int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
+}  // namespace
+
+int64_t mq::api::algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
   // every distinct outer column the plan touches is read once per row
   bool used[MI355Q_MAX_COLS] = {false};
   for (int k = 0; k < p.n_exprs && k < MI355Q_MAX_EXPRS; ++k)  // an expression reads its operand columns
@@ -251,7 +153,6 @@ int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
   return per_row * rows;
 }
 
-}  // namespace
 
 extern "C" {
 
@@ -341,6 +242,9 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   if (ctx.lattice) (void)hipFree(ctx.lattice);
   ctx.lattice = nullptr;
   ctx.lattice_bytes = 0;
+  if (ctx.projws) (void)hipFree(ctx.projws);
+  ctx.projws = nullptr;
+  ctx.projws_bytes = 0;
   if (ctx.stream) (void)hipStreamDestroy(ctx.stream);
   ctx.stream = nullptr;
   for (hipEvent_t e : ctx.events) (void)hipEventDestroy(e);
@@ -374,8 +278,6 @@ static ColLayout col_layout_of(const mi355q_qmd& q) {
   L.row_quad = q.row_size / 8;
   return L;
 }
-static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
-                                  mi355q_result** out);
 namespace {
 struct RowTwin {
   mi355q_result* tw = nullptr;
@@ -425,8 +327,8 @@ int32_t mi355q_result_wrap(const mi355q_qmd* qmd, int32_t device_id, void* devic
   return result_create_impl(qmd, device_id, device_buffer, out);
 }
 
-static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer,
-                                  mi355q_result** out) {
+}  // extern "C"
+int32_t mq::api::result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void* device_buffer, mi355q_result** out) {
   if (!qmd || !out || qmd->row_size <= 0 || qmd->entry_count <= 0) return MI355Q_ERR_INVALID_PLAN;
   DeviceGuard g(device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
@@ -462,6 +364,8 @@ static int32_t result_create_impl(const mi355q_qmd* qmd, int32_t device_id, void
   *out = r;
   return MI355Q_OK;
 }
+
+extern "C" {
 
 void mi355q_result_free(mi355q_result* r) {
   if (!r) return;
@@ -535,9 +439,14 @@ int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_r
   return run_reduce(this_rs, that_rs->buf, b.entry_count, stream);
 }
 
+int64_t mi355q_result_total_matched(const mi355q_result* r) {
+  return r && r->qmd.desc_type == MI355Q_PROJECTION ? r->total_matched : -1;
+}
+
 int64_t mi355q_result_row_count(const mi355q_result* r) {
   if (!r) return -1;
   if (r->qmd.desc_type == MI355Q_NON_GROUPED_AGGREGATE) return 1;
+  if (r->qmd.desc_type == MI355Q_PROJECTION) return projection_row_count(r);
   if (r->qmd.output_columnar) {
     RowTwin t;
     if (make_row_twin(r, nullptr, &t)) return -1;
@@ -847,6 +756,7 @@ int32_t mi355q_result_sort(const mi355q_result* r, const mi355q_order_entry* ord
 int32_t mi355q_result_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival,
                                  double* dval, int8_t* is_null, int64_t* n_rows) {
   if (!r || !ival || !dval || !is_null || !n_rows) return MI355Q_ERR_INVALID_PLAN;
+  if (r->qmd.desc_type == MI355Q_PROJECTION) return projection_fetch_rows(r, max_rows, ival, dval, is_null, n_rows);
   if (r->qmd.output_columnar) {
     RowTwin t;
     if (int32_t e = make_row_twin(r, nullptr, &t)) return e;
@@ -2608,7 +2518,8 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
   const int64_t rows_bytes = ((int64_t)sizeof(int64_t) * nf + 255) & ~255ll;
   // (worst case: every fragment of a pass pads every expression chunk once)
   const int64_t col_region = ((pass_rows * row_bytes + pad * nf) + 255) & ~255ll;
-  const int64_t need = col_region + tab_bytes + rows_bytes + 256;
+  const int64_t xs_bytes = ((int64_t)sizeof(DevExprSet) + 255) & ~255ll;  // the lowered programs, read by k_project from device memory
+  const int64_t need = col_region + tab_bytes + rows_bytes + 256 + xs_bytes;
   if (ctx.proj_bytes < need) {
     if (ctx.proj) (void)hipFree(ctx.proj);
     ctx.proj = nullptr;
@@ -2625,6 +2536,7 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
   const int8_t** d_tab = (const int8_t**)(base + col_region);
   int64_t* d_rows = (int64_t*)(base + col_region + tab_bytes);
   int32_t* d_err = (int32_t*)(base + col_region + tab_bytes + rows_bytes);
+  DevExprSet* d_xs = (DevExprSet*)(base + col_region + tab_bytes + rows_bytes + 256);
   HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
   HIP_TRY(hipMemcpyAsync(d_rows, in->num_rows, sizeof(int64_t) * (size_t)nf, hipMemcpyHostToDevice, s));
 
@@ -2669,13 +2581,13 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
     // only raises word 2 and the interpreter (which knows whether the offending row counts) runs after all
     bool simple = project_simple_shapes(xs) && !o.force_generic;
     for (size_t i = 0; simple && i < (size_t)pnf * nc2; ++i) simple = ((uintptr_t)cols2[i] & 15) == 0;
-    HIP_TRY(launch_project(xs, d, qual_expr_mask, d_tab, d_rows + f, pnf, max_frag_rows, d_err, n_cus, s, simple));
+    HIP_TRY(launch_project(xs, d_xs, d, qual_expr_mask, d_tab, d_rows + f, pnf, max_frag_rows, d_err, n_cus, s, simple));
     int32_t h_err3[3] = {0, 0, 0};
     HIP_TRY(hipMemcpyAsync(h_err3, d_err, sizeof(h_err3), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));  // (cols2 is re-used by the next pass; the step below synchronises anyway)
     if (simple && h_err3[2]) {
       HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
-      HIP_TRY(launch_project(xs, d, qual_expr_mask, d_tab, d_rows + f, pnf, max_frag_rows, d_err, n_cus, s, false));
+      HIP_TRY(launch_project(xs, d_xs, d, qual_expr_mask, d_tab, d_rows + f, pnf, max_frag_rows, d_err, n_cus, s, false));
       HIP_TRY(hipMemcpyAsync(h_err3, d_err, sizeof(h_err3), hipMemcpyDeviceToHost, s));
       HIP_TRY(hipStreamSynchronize(s));
     }
@@ -2850,6 +2762,11 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     set_tune_knobs(k);
   }
   if (plan->n_exprs != 0) {
+    {  // a Projection evaluates its expressions in the compaction kernel's registers: no k_project pass
+      bool proj = plan->n_targets > 0;
+      for (int i = 0; i < plan->n_targets && i < MI355Q_MAX_TARGETS; ++i) proj = proj && plan->targets[i].agg == MI355Q_PROJECT;
+      if (proj) return execute_projection(plan, in, o, out, report, reserved);
+    }
     if (!pend) {
       const size_t mark = t_route ? t_route->size() : 0;
       int32_t e = execute_shifted_args(plan, in, o, out, report, reserved);
@@ -2871,6 +2788,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   Trace tr((o.flags & MI355Q_OPT_TRACE) != 0);
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;
+  if (q.desc_type == MI355Q_PROJECTION) return execute_projection(plan, in, o, out, report, reserved);
   DevPlan d;
   if (int32_t e = build_dev_plan(*plan, q, &d)) return e;
   if (int32_t e = attach_join(*plan, in, &d)) return e;

@@ -1,0 +1,276 @@
+// api_projection.cpp — the host side of the PROJECTION family (kernels_proj.hip): plan -> descriptor -> one
+// compaction launch -> result handle, and the accessors that iterate a Projection buffer.
+//
+// Reference shape (heavyai/heavydb): Executor::executePlanWithGroupBy with a Projection descriptor
+// (Execute.cpp:4179-4366) — the kernel gets total_matched / max_matched (KernelParam::TOTAL_MATCHED / MAX_MATCHED,
+// enums.h:62-77; QueryExecutionContext.cpp:660-735), the buffer is compacted to the matched count afterwards
+// (compactProjectionBuffersCpu / Gpu, QueryMemoryInitializer.cpp) — and ResultSet iteration over
+// QueryDescriptionType::Projection storage (ResultSetIteration.cpp: getNextRowImpl skips entries whose key is
+// EMPTY_KEY_64).  The seam's own example of this layout is run_query_external (ExternalExecutor.cpp:408-515).
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "api_internal.h"
+
+using namespace mq;
+using namespace mq::api;
+
+namespace mq {
+namespace api {
+
+namespace {
+
+// device workspace of the family: [ lowered expressions | counters, tile table, descriptors ]
+constexpr int64_t kExprArea = (sizeof(DevExprSet) + 255) & ~(int64_t)255;
+
+int32_t proj_spec_of(const mi355q_plan& lp, int n_phys, const mi355q_qmd& q, ProjSpec* ps) {
+  std::memset(ps, 0, sizeof(*ps));
+  ps->n_targets = q.n_targets;
+  ps->columnar = q.output_columnar;
+  ps->row_quad = 1 + q.n_targets;
+  ps->n_phys_cols = n_phys;
+  ps->n_cols_table = n_phys;
+  ps->entry_count = q.entry_count;
+  for (int i = 0; i < q.n_targets; ++i) {
+    const mi355q_target& t = lp.targets[i];
+    if (t.col < 0 || t.col >= lp.n_cols) return MI355Q_ERR_INVALID_PLAN;
+    ProjTarget& pt = ps->t[i];
+    pt.col = t.col;
+    pt.code = col_type_code(lp.cols[t.col]);
+    if (pt.code < 0) return MI355Q_ERR_INVALID_PLAN;
+    const int st = tc_storage(pt.code);
+    pt.kind = st == MI355Q_DOUBLE ? PROJ_F64 : st == MI355Q_FLOAT ? (q.output_columnar ? PROJ_F32 : PROJ_F32_TO_F64) : PROJ_INT;
+    pt.width = q.slot_bytes[i];
+    pt.col_off = q.output_columnar ? qmd_slot_col_offset(q, i) : 0;
+  }
+  return MI355Q_OK;
+}
+
+}  // namespace
+
+int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o, mi355q_result** out,
+                           mi355q_exec_report* report, int64_t* reserved) {
+  mi355q_plan lp;
+  DevExprSet xs;
+  std::memset(&xs, 0, sizeof(xs));
+  const int n_phys = plan->n_cols;
+  if (plan->n_exprs != 0) {
+    if (int32_t e = lower_exprs(*plan, &lp, &xs)) return e;
+  } else {
+    lp = *plan;
+  }
+  mi355q_qmd q;
+  if (int32_t e = qmd_init(lp, &q)) return e;
+  if (q.desc_type != MI355Q_PROJECTION) return MI355Q_ERR_INVALID_PLAN;
+  DevPlan d;
+  if (int32_t e = build_dev_plan(lp, q, &d)) return e;
+  for (int k = 0; k < d.n_quals; ++k)  // (a member of a disjunction is a plain column comparison: the binding never states one over an expression)
+    if (d.quals[k].or_group != 0 && d.quals[k].col >= n_phys) return MI355Q_ERR_UNSUPPORTED;
+  ProjSpec ps;
+  if (int32_t e = proj_spec_of(lp, n_phys, q, &ps)) return e;
+  const uint32_t qmask = plan->n_exprs ? expr_qual_mask(*plan) : 0u;
+
+  const int nf = in->n_frags, nc = n_phys;
+  int64_t total_rows = 0, max_frag_rows = 0;
+  for (int f = 0; f < nf; ++f) {
+    if (in->num_rows[f] < 0) return MI355Q_ERR_INVALID_PLAN;
+    total_rows += in->num_rows[f];
+    max_frag_rows = std::max(max_frag_rows, in->num_rows[f]);
+  }
+  const int64_t ws_need = kExprArea + projection_scratch_bytes(nf, in->num_rows);
+  if (reserved) {  // mi355q_reserve_workspace / mi355q_explain: nothing is launched
+    route_note(plan->n_exprs ? "k_proj_compact (expressions in registers)" : "k_proj_compact");
+    *reserved = ws_need;
+    if (t_plan_only) return MI355Q_OK;
+  }
+
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  const int n_cus = o.tune_cus > 0 ? std::min(o.tune_cus, cu_count_of(in->device_id)) : cu_count_of(in->device_id);
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  if (ctx.projws_bytes < ws_need) {
+    if (ctx.projws) (void)hipFree(ctx.projws);
+    ctx.projws = nullptr;
+    ctx.projws_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx.projws, (size_t)ws_need));
+    ctx.projws_bytes = ws_need;
+  }
+  if (reserved) return MI355Q_OK;
+
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  // column table | row counts | error word, one upload out of pinned memory
+  const size_t ptr_bytes = sizeof(void*) * (size_t)std::max(1, nf * nc);
+  const size_t rows_bytes = sizeof(int64_t) * (size_t)std::max(1, nf);
+  const size_t meta_bytes = ptr_bytes + rows_bytes + 64;
+  if (ctx.meta_bytes < meta_bytes) {
+    if (ctx.meta) (void)hipFree(ctx.meta);
+    ctx.meta = nullptr;
+    ctx.meta_bytes = 0;
+    if (ctx.h_meta) (void)hipHostFree(ctx.h_meta);
+    ctx.h_meta = nullptr;
+    HIP_TRY(hipMalloc(&ctx.meta, meta_bytes * 2));
+    HIP_TRY(hipHostMalloc((void**)&ctx.h_meta, meta_bytes * 2 + 64, hipHostMallocDefault));
+    ctx.meta_bytes = meta_bytes * 2;
+  }
+  char* mp = (char*)ctx.meta;
+  const int8_t* const* d_cols = (const int8_t* const*)mp;
+  const int64_t* d_rows = (const int64_t*)(mp + ptr_bytes);
+  int32_t* d_err = (int32_t*)(mp + ptr_bytes + rows_bytes);
+  {
+    char* hm = ctx.h_meta;
+    if (nf > 0) {
+      std::memcpy(hm, in->col_buffers, sizeof(void*) * (size_t)(nf * nc));
+      std::memcpy(hm + ptr_bytes, in->num_rows, sizeof(int64_t) * (size_t)nf);
+    }
+    std::memset(hm + ptr_bytes + rows_bytes, 0, 64);
+    const size_t lo = nf > 0 ? 0 : ptr_bytes + rows_bytes;
+    HIP_TRY(hipMemcpyAsync(mp + lo, hm + lo, ptr_bytes + rows_bytes + 64 - lo, hipMemcpyHostToDevice, s));
+  }
+  const DevExprSet* d_xs = nullptr;
+  if (plan->n_exprs != 0) {
+    HIP_TRY(hipMemcpyAsync(ctx.projws, &xs, sizeof(xs), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));  // (xs lives on this frame)
+    d_xs = (const DevExprSet*)ctx.projws;
+  }
+
+  mi355q_result* res = nullptr;
+  if (int32_t e = result_create_impl(&q, in->device_id, o.out_buffer, &res)) return e;
+  struct ResGuard {
+    mi355q_result* r;
+    ~ResGuard() { mi355q_result_free(r); }
+  } rg{res};
+
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  LaunchStats st;
+  if (report) {
+    while ((int)ctx.events.size() < 4) {
+      hipEvent_t e;
+      HIP_TRY(hipEventCreate(&e));
+      ctx.events.push_back(e);
+    }
+    ev_start = ctx.events[0];
+    ev_stop = ctx.events[1];
+    st.k_start = ctx.events[2];
+    st.k_stop = ctx.events[3];
+  }
+  FragView fv{d_cols, d_rows, in->col_buffers, in->num_rows, nf, nc, total_rows, max_frag_rows};
+  if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
+  unsigned long long* d_total = nullptr;
+  HIP_TRY(launch_projection(d, ps, d_xs, qmask, fv, (char*)ctx.projws + kExprArea, res->buf, d_err, &d_total, n_cus, s, &st));
+  if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
+  // the error word and the match count come back together
+  int64_t* h_ret = (int64_t*)(ctx.h_meta + ctx.meta_bytes);
+  HIP_TRY(hipMemcpyAsync(h_ret, d_err, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipMemcpyAsync(h_ret + 1, d_total, 8, hipMemcpyDeviceToHost, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  const int32_t code = (int32_t)h_ret[0];
+  const int64_t total = h_ret[1];
+  if (report) {
+    std::memset(report, 0, sizeof(*report));
+    std::snprintf(report->kernel_name, sizeof(report->kernel_name), "%s", st.kernel_name);
+    float ms = 0.f;
+    if (nf > 0 && total_rows > 0 && hipEventElapsedTime(&ms, st.k_start, st.k_stop) == hipSuccess) report->kernel_ms = ms;
+    if (hipEventElapsedTime(&ms, ev_start, ev_stop) == hipSuccess) report->total_ms = ms;
+    report->n_launches = st.n_launches;
+    report->variant = st.variant;
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+    report->spilled_rows = 0;
+  }
+  if (code) return code;
+  if (total > q.entry_count && plan->scan_limit == 0) {
+    // the row that found the buffer full: the reference's row function answers -pos; here the count the caller needs
+    return total > (int64_t)INT32_MAX ? INT32_MIN : -(int32_t)total;
+  }
+  res->total_matched = total;
+  rg.r = nullptr;
+  *out = res;
+  return MI355Q_OK;
+}
+
+int64_t projection_row_count(const mi355q_result* r) {
+  const mi355q_qmd& q = r->qmd;
+  if (r->total_matched >= 0) return std::min(r->total_matched, q.entry_count);
+  // a wrapped buffer: the entries whose key is not EMPTY_KEY_64 (ResultSet::isEmptyEntry)
+  DeviceGuard g(r->device_id);
+  DevWord cnt;
+  if (hipMalloc(&cnt.p, 8) != hipSuccess) return -1;
+  if (launch_projection_count_live(r->buf, q.output_columnar ? 1 : q.row_size / 8, q.entry_count, (unsigned long long*)cnt.p,
+                                   nullptr) != hipSuccess)
+    return -1;
+  unsigned long long h = 0;
+  if (hipMemcpy(&h, cnt.p, 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return (int64_t)h;
+}
+
+// ResultSet::getNextRow over Projection storage: the non-empty entries in entry order, one value per target —
+// integers as stored (sign-extended; NULL = the type's inline sentinel), DOUBLE / FLOAT targets as doubles
+int32_t projection_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival, double* dval, int8_t* is_null,
+                              int64_t* n_rows) {
+  const mi355q_qmd& q = r->qmd;
+  const int64_t live = projection_row_count(r);
+  if (live < 0) return MI355Q_ERR_HIP;
+  const int64_t n = std::min(live, max_rows);
+  *n_rows = n;
+  if (n == 0) return MI355Q_OK;
+  DeviceGuard g(r->device_id);
+  const int nt = q.n_targets;
+  std::vector<char> host;
+  auto value_out = [&](int64_t row, int t, int64_t v) {
+    const size_t o = (size_t)row * nt + t;
+    ival[o] = 0;
+    dval[o] = 0.0;
+    const bool nullable = q.target_null[t] != kEmptyKey64;  // (a NOT NULL target is never NULL, whatever its bits)
+    if (q.target_arg_is_f32[t]) {
+      dval[o] = (double)bits_flt((int32_t)v);
+      is_null[o] = nullable && (int32_t)v == (int32_t)q.target_null[t];
+    } else if (q.target_is_fp[t]) {
+      dval[o] = bits_dbl(v);
+      is_null[o] = nullable && v == q.target_null[t];
+    } else {
+      ival[o] = v;
+      is_null[o] = nullable && v == q.target_null[t];
+    }
+  };
+  try {
+    if (!q.output_columnar) {
+      const int rq = q.row_size / 8;
+      host.resize((size_t)n * rq * 8);
+      HIP_TRY(hipMemcpy(host.data(), r->buf, host.size(), hipMemcpyDeviceToHost));
+      const int64_t* rows = (const int64_t*)host.data();
+      for (int64_t e = 0; e < n; ++e)
+        for (int t = 0; t < nt; ++t) value_out(e, t, rows[e * rq + 1 + q.target_slot[t]]);
+    } else {
+      for (int t = 0; t < nt; ++t) {
+        const int w = q.slot_bytes[q.target_slot[t]];
+        host.resize((size_t)n * w);
+        HIP_TRY(hipMemcpy(host.data(), (const char*)r->buf + qmd_slot_col_offset(q, q.target_slot[t]), host.size(),
+                          hipMemcpyDeviceToHost));
+        for (int64_t e = 0; e < n; ++e) {
+          int64_t v;
+          switch (w) {
+            case 1: v = ((const int8_t*)host.data())[e]; break;
+            case 2: v = ((const int16_t*)host.data())[e]; break;
+            case 4: v = ((const int32_t*)host.data())[e]; break;
+            default: v = ((const int64_t*)host.data())[e];
+          }
+          value_out(e, t, v);
+        }
+      }
+    }
+  } catch (const std::bad_alloc&) {
+    return MI355Q_ERR_OUT_OF_CPU_MEM;
+  }
+  return MI355Q_OK;
+}
+
+}  // namespace api
+}  // namespace mq

@@ -187,32 +187,34 @@ constexpr int64_t kSecsPerDay = 86400;
 //                     NULL = 255 / 65535 -> NULL_INT
 //   ENC_DATE_IN_DAYS  fixed_width_small_date_decode (DecodersImpl.h:130-139): days -> seconds,
 //                     storage NULL -> NULL_BIGINT
-MQ_HD int64_t decode_int(const int8_t* col, int code, int64_t pos) {
-  if (code < 16) return load_int(col, code, pos);
+// ... the same decoders applied to a value ALREADY LOADED from the chunk (`v` = the storage integer, sign-extended): the
+// vector loads of the streaming kernels fetch four rows at once and decode afterwards
+MQ_HD int64_t decode_loaded(int code, int64_t v) {
+  if (code < 16) return v;
   const int st = tc_storage(code);
   switch (tc_enc(code)) {
-    case MI355Q_ENC_FIXED: {
-      const int64_t v = load_int(col, st, pos);
+    case MI355Q_ENC_FIXED:
       return (tc_nullable(code) && v == plain_int_null(st)) ? plain_int_null(tc_logical(code)) : v;
-    }
     case MI355Q_ENC_DICT: {
       if (st == MI355Q_INT8) {
-        const int64_t v = *(const uint8_t*)(col + pos);
-        return (tc_nullable(code) && v == 255) ? (int64_t)INT32_MIN : v;
+        const int64_t u = v & 0xff;
+        return (tc_nullable(code) && u == 255) ? (int64_t)INT32_MIN : u;
       }
       if (st == MI355Q_INT16) {
-        const int64_t v = *(const uint16_t*)(col + pos * 2);
-        return (tc_nullable(code) && v == 65535) ? (int64_t)INT32_MIN : v;
+        const int64_t u = v & 0xffff;
+        return (tc_nullable(code) && u == 65535) ? (int64_t)INT32_MIN : u;
       }
-      return load_int(col, st, pos);
+      return v;
     }
-    case MI355Q_ENC_DATE_IN_DAYS: {
-      const int64_t v = load_int(col, st, pos);
+    case MI355Q_ENC_DATE_IN_DAYS:
       return v == plain_int_null(st) ? INT64_MIN : v * kSecsPerDay;
-    }
     default:
-      return load_int(col, st, pos);
+      return v;
   }
+}
+MQ_HD int64_t decode_int(const int8_t* col, int code, int64_t pos) {
+  if (code < 16) return load_int(col, code, pos);
+  return decode_loaded(code, load_int(col, tc_storage(code), pos));
 }
 // fixed_width_double_decode (DecodersImpl.h:121-128)
 MQ_HD double decode_dbl(const int8_t* col, int64_t pos) { return *(const double*)(col + pos * 8); }

@@ -45,7 +45,11 @@ MQ_HD float ex_flt_of(int64_t v) { return bits_flt((int32_t)(uint32_t)v); }
 // *err receives MI355Q_ERR_OVERFLOW_OR_UNDERFLOW / MI355Q_ERR_DIV_BY_ZERO when a check fires on the way to the RESULT (the
 // value returned is then unspecified): the first one in evaluation order — operands left to right, then the operation; a
 // CASE's condition, then the branch it takes.  es[] = the error each stack value carries.
-MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos, int32_t* err) {
+// xv (optional): the values of the plan's EARLIER expressions for this row, computed by the caller in order — a kernel that
+// evaluates expressions in registers instead of reading the dense temporary columns a projection pass left (n_phys = the
+// number of physical columns: a column node `arg` >= n_phys reads xv[arg - n_phys]).
+MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos, int32_t* err, const int64_t* xv = nullptr,
+                        int n_phys = 0) {
   int64_t st[MI355Q_MAX_EXPR_STACK] = {};
   int32_t es[MI355Q_MAX_EXPR_STACK] = {};
   int sp = 0;
@@ -53,6 +57,11 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
     const DevExprNode& n = e.nodes[i];
     switch (n.op) {
       case MI355Q_EX_COL: {
+        if (xv && n.arg >= n_phys) {  // the value of an earlier expression, already in the caller's registers
+          st[sp++] = xv[n.arg - n_phys];
+          es[sp - 1] = 0;
+          break;
+        }
         const int8_t* c = cols[n.arg];
         if (n.type == MI355Q_DOUBLE) st[sp++] = *(const int64_t*)(c + pos * 8);
         else if (n.type == MI355Q_FLOAT) st[sp++] = (int64_t)*(const uint32_t*)(c + pos * 4);

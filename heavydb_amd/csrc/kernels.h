@@ -143,9 +143,11 @@ hipError_t launch_zip_targets(const DevPlan& pf, const DevPlan& ps, int idx_key_
 // projected expressions: d_cols is the pass's extended fragment table [frag][xs.n_cols + xs.n]; the last xs.n
 // pointers of every fragment are the output columns (dense, of each expression's result type).  p = the
 // device plan of the LOWERED plan (quals, join): it decides whether a row's overflow counts.
-hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_expr_mask, const int8_t* const* d_cols,
-                          const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_err, int n_cus,
-                          hipStream_t s, bool simple = false);
+// d_xs_area: sizeof(DevExprSet) bytes of device memory the lowered programs are uploaded to (they are too large for the
+// kernel-argument segment); the caller keeps `xs` alive until it has synchronised the stream
+hipError_t launch_project(const DevExprSet& xs, DevExprSet* d_xs_area, const DevPlan& p, uint32_t qual_expr_mask,
+                          const int8_t* const* d_cols, const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_err,
+                          int n_cus, hipStream_t s, bool simple = false);
 // every expression is CAST(plain INT / BIGINT column AS DOUBLE | FLOAT) or column + - * literal (k_project_simple)
 bool project_simple_shapes(const DevExprSet& xs);
 // tmp: table of the packed single-key step (rows = packed key + slot_count slots); out: the
@@ -303,6 +305,34 @@ int64_t join_probe_scratch_bytes(const DevPlan& p, const FragView& fv, const Joi
 hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPayloadView& pay, int64_t* out,
                              int32_t* d_err, void* scratch, int64_t scratch_bytes, int64_t cap_bytes, int n_cus,
                              hipStream_t s, LaunchStats* st);
+
+// ---- PROJECTION family (kernels_proj.hip): order-preserving stream compaction of the rows that pass the quals
+enum ProjKind : int32_t { PROJ_INT = 0, PROJ_F64 = 1, PROJ_F32 = 2, PROJ_F32_TO_F64 = 3 };
+struct ProjTarget {
+  int32_t col;     // source: a physical column (< n_phys_cols) or expression col - n_phys_cols
+  int32_t code;    // type code of the physical column; the result type of an expression
+  int32_t kind;    // ProjKind: how the value is stored
+  int32_t width;   // bytes of the target's slot in the buffer (8 row-wise; the logical width in a columnar buffer)
+  int64_t col_off; // columnar: byte offset of the slot column in the buffer
+};
+struct ProjSpec {
+  int32_t n_targets, columnar;
+  int32_t row_quad;       // row-wise: 1 + n_targets
+  int32_t n_phys_cols;    // physical columns; indices from here on name the plan's expressions
+  int32_t n_cols_table;   // pointers per fragment in the column table
+  int32_t pad_;
+  int64_t entry_count;
+  ProjTarget t[MI355Q_MAX_TARGETS];
+};
+int64_t projection_tile_rows();
+int64_t projection_scratch_bytes(int n_frags, const int64_t* h_num_rows);
+// p: quals of the (lowered) plan; d_xs: the lowered expressions in DEVICE memory (or null); *d_total: device word that
+// holds the number of matching rows once the stream has drained
+hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExprSet* d_xs, uint32_t qual_expr_mask,
+                             const FragView& fv, void* scratch, void* out, int32_t* d_err, unsigned long long** d_total,
+                             int n_cus, hipStream_t s, LaunchStats* st);
+hipError_t launch_projection_count_live(const int64_t* keys, int64_t stride_quads, int64_t entries, unsigned long long* d_count,
+                                        hipStream_t s);
 
 bool join_sum_eligible(const DevPlan& p, const FragView& fv);
 hipError_t launch_join_sum(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus,

@@ -695,10 +695,11 @@ __global__ __launch_bounds__(kBlock) void k_unpack_perfect(PackSpec ps, DevPlan 
 // the outputs.  The reference's row function evaluates target and group-by expressions only for rows that
 // passed the quals (and found a match under an INNER join), so an overflow only counts there; an expression
 // used by a qual is evaluated for every row (Executor::compileBody: filters first, then the body).
-__global__ __launch_bounds__(kBlock) void k_project(DevExprSet xs, DevPlan p, uint32_t qual_expr_mask,
+__global__ __launch_bounds__(kBlock) void k_project(const DevExprSet* __restrict__ xsp, DevPlan p, uint32_t qual_expr_mask,
                                                      const int8_t* const* __restrict__ cols,
                                                      const int64_t* __restrict__ num_rows, int n_frags,
                                                      int32_t* __restrict__ d_err) {
+  const DevExprSet& xs = *xsp;  // (device memory: 8 programs of 24 nodes do not fit the 4 KB of kernel arguments)
   const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t gsize = (int64_t)gridDim.x * kBlock;
   const int nc = xs.n_cols + xs.n;
@@ -1607,9 +1608,9 @@ hipError_t launch_cast_key_emit(const DevPlan& pf, const DevPlan& ps, int idx_ke
   return hipGetLastError();
 }
 
-hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_expr_mask, const int8_t* const* d_cols,
-                          const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_err, int n_cus,
-                          hipStream_t s, bool simple) {
+hipError_t launch_project(const DevExprSet& xs, DevExprSet* d_xs_area, const DevPlan& p, uint32_t qual_expr_mask,
+                          const int8_t* const* d_cols, const int64_t* d_num_rows, int n_frags, int64_t max_frag_rows, int32_t* d_err,
+                          int n_cus, hipStream_t s, bool simple) {
   if (n_frags <= 0 || xs.n <= 0) return hipSuccess;
   if (simple) {
     const dim3 grid(grid_for((max_frag_rows + 7) / 8, n_cus * 8));
@@ -1623,8 +1624,11 @@ hipError_t launch_project(const DevExprSet& xs, const DevPlan& p, uint32_t qual_
     }
     return hipGetLastError();
   }
-  hipLaunchKernelGGL(k_project, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, xs, p, qual_expr_mask,
-                     d_cols, d_num_rows, n_frags, d_err);
+  // (the caller keeps `xs` alive and synchronises the stream after the launch)
+  hipError_t e = hipMemcpyAsync(d_xs_area, &xs, sizeof(xs), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_project, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, (const DevExprSet*)d_xs_area, p,
+                     qual_expr_mask, d_cols, d_num_rows, n_frags, d_err);
   return hipGetLastError();
 }
 

@@ -1,0 +1,522 @@
+// kernels_proj.hip — the PROJECTION family: `SELECT cols / expressions FROM t WHERE quals [LIMIT n]`, one output entry
+// per row that passes the filter (QueryDescriptionType::Projection).
+//
+// What the reference does per matching row (heavyai/heavydb): old = total_matched++ — an atomic on the GPU, a plain
+// counter in the CPU kernel of one fragment (GroupByAndAggregate.cpp:1080-1101) — then get_scan_output_slot /
+// get_columnar_scan_output_offset (GroupByRuntime.cpp:242-269) writes the row's offset in its fragment into entry
+// `old` and the targets are stored behind it with agg_id (TargetExprBuilder.cpp:330-560); a row that finds the buffer
+// full makes the row function answer -pos (GroupByAndAggregate.cpp:1151-1156), and with a scan limit the loop stops
+// at max_matched (QueryTemplateGenerator.cpp:751-780).
+//
+// On gfx950 this is a stream compaction that keeps the CPU executor's order (fragment, then row) — a result
+// identical to the reference's CPU path, not merely the same set:
+//   * a workgroup takes TILES of 16 384 rows off one ticket counter (one returning atomic per 16 K rows);
+//   * pass A streams the filter columns of the tile with 16-byte loads (4 rows per lane and load), evaluates the
+//     quals and keeps the tile's match bits in one 64-bit register per lane;
+//   * the tile's match count is published in a 64-bit {state, value} descriptor and the tile's first output entry
+//     is the sum of its predecessors' counts, read back by one wave ("decoupled look-back": a tile adds the
+//     aggregates of the tiles before it until it meets one whose inclusive prefix is known) — relaxed agent-scope
+//     8-byte atomics on both sides, the hand-off form that needs no fence (MI355X_MICROARCH.md, "8-B agent atomics
+//     both sides");
+//   * pass B walks the tile in sub-tiles of 1 024 / 2 048 rows: ranks from a block scan of the match bits, the
+//     projected columns are loaded ONLY where a quad has a matching row, the entries are assembled in LDS in their
+//     final layout (row-wise rows, or one run per column) and leave as contiguous, fully coalesced stores.
+// Expressions (projected or in a qual) are evaluated in registers by the micro-op evaluator (expr.h): no
+// temporary column, no second pass — the reference compiles them into the row function the same way
+// (Executor::compileBody, NativeCodegen.cpp:3455: filters first, then the body).
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "expr.h"
+#include "fast_common.h"
+#include "kernels.h"
+#include "rowfunc.h"
+
+namespace mq {
+
+namespace {
+
+using fast::v2i64;
+using fast::v4i32;
+
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / 64;
+constexpr int kIters = 16;                          // quads per lane and tile
+constexpr int kIterRows = kBlock * 4;               // rows one iteration of the block covers
+constexpr int64_t kTileRows = (int64_t)kIterRows * kIters;  // 16 384
+
+constexpr uint64_t kStateShift = 62;
+constexpr uint64_t kStateAggregate = 1ull << kStateShift;  // value = the tile's own count
+constexpr uint64_t kStateInclusive = 2ull << kStateShift;  // value = count of the tile and everything before it
+constexpr uint64_t kValueMask = (1ull << kStateShift) - 1;
+
+struct ProjArgs {
+  ProjSpec ps;
+  const DevExprSet* xs;          // device memory; null when the plan has no expressions
+  uint32_t qual_expr_mask;       // expressions a qual reads (evaluated for every row)
+  int32_t n_frags;
+  const int8_t* const* cols;     // [frag][ps.n_cols_table]
+  const int64_t* num_rows;       // [frag]
+  const int64_t* tile_start;     // [frag + 1] first tile of each fragment
+  int64_t n_tiles;
+  unsigned long long* desc;      // [n_tiles], zeroed
+  unsigned long long* counters;  // [0] ticket, [1] total_matched
+  int8_t* out;
+  int32_t* d_err;
+  int32_t sub_iters;             // iterations per sub-tile (1 or 2): what the LDS image holds
+  int32_t vec_mask;              // bit c: column c of every fragment is 16-byte aligned (vector loads allowed)
+  int32_t row_quals;             // the quals hold a disjunction (or_group): evaluated by quals_pass, row by row
+};
+
+// ---- four rows of one column ------------------------------------------------------------------
+struct RawQuad {
+  v2i64 a, b;
+};
+// storage width w; `quad` = index of the 4-row group in the chunk
+MQ_D void load_raw_quad(const int8_t* base, int w, int64_t quad, RawQuad& r) {
+  if (w == 8) {
+    r.a = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + quad * 2);
+    r.b = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + quad * 2 + 1);
+  } else if (w == 4) {
+    r.a = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + quad);
+  } else if (w == 2) {
+    r.a.x = __builtin_nontemporal_load((const MQ_GLOBAL long long*)base + quad);
+  } else {
+    r.a.x = (long long)(unsigned)__builtin_nontemporal_load((const MQ_GLOBAL int*)base + quad);
+  }
+}
+// element i as the sign-extended storage integer (FLOAT: its 32 bits, DOUBLE: its 64 bits)
+MQ_D int64_t raw_elem(const RawQuad& r, int w, int i) {
+  if (w == 8) return i == 0 ? r.a.x : i == 1 ? r.a.y : i == 2 ? r.b.x : r.b.y;
+  if (w == 4) {
+    const uint64_t q = (uint64_t)(i < 2 ? r.a.x : r.a.y);
+    return (int64_t)(int32_t)(uint32_t)(q >> ((i & 1) * 32));
+  }
+  if (w == 2) return (int64_t)(int16_t)(uint16_t)((uint64_t)r.a.x >> (i * 16));
+  return (int64_t)(int8_t)(uint8_t)((uint64_t)r.a.x >> (i * 8));
+}
+// the value col_value_bits would return for that element
+MQ_D int64_t value_of_raw(int code, int64_t raw) {
+  const int st = tc_storage(code);
+  if (st == MI355Q_FLOAT) return (int64_t)(uint32_t)raw;
+  if (st == MI355Q_DOUBLE) return raw;
+  return decode_loaded(code, raw);
+}
+
+// all expressions of `mask`, in order, into xv (an expression may read the earlier ones)
+MQ_D void eval_exprs(const DevExprSet& xs, uint32_t mask, const int8_t* const* fc, int64_t pos, int64_t* xv, int32_t* err) {
+  for (int k = 0; k < xs.n; ++k)
+    if ((mask >> k) & 1u) xv[k] = eval_expr(xs.e[k], fc, pos, err, xv, xs.n_cols);
+}
+
+MQ_D unsigned long long wave_excl_scan_u32x2(unsigned long long v, unsigned long long* total) {
+  // inclusive scan over the wave of two packed 32-bit counters
+  const int lane = threadIdx.x & 63;
+  unsigned long long inc = v;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned long long o = __shfl(inc, lane - d < 0 ? lane : lane - d, 64);
+    if (lane >= d) inc += o;
+  }
+  *total = __shfl(inc, 63, 64);
+  return inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_proj_compact(DevPlan p, ProjArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char s_img[];
+  __shared__ unsigned long long s_wave[kWaves];
+  __shared__ long long s_bcast[2];
+
+  const ProjSpec& ps = a.ps;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_phys = ps.n_phys_cols;
+  int32_t err = 0;
+
+  for (;;) {
+    // ---- the next tile, in ticket order (a tile's predecessors have all been taken by running workgroups)
+    if (tid == 0) s_bcast[0] = (long long)atomicAdd(&a.counters[0], 1ull);
+    __syncthreads();
+    const int64_t tile = s_bcast[0];
+    __syncthreads();
+    if (tile >= a.n_tiles) break;
+    int f = 0;
+    {
+      int lo = 0, hi = a.n_frags;  // tile_start[lo] <= tile < tile_start[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.tile_start[mid] <= tile) lo = mid;
+        else hi = mid;
+      }
+      f = lo;
+    }
+    const int8_t* const* fc = a.cols + (size_t)f * ps.n_cols_table;
+    const int64_t n = a.num_rows[f];
+    const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;  // first row of the tile in its fragment
+
+    // ---- pass A: the filter over the tile, 4 rows per lane and iteration; bit (4 u + i) of m = row i of iteration u
+    uint64_t m = 0;
+    for (int u0 = 0; u0 < kIters; u0 += 4) {
+      uint32_t bits[4] = {0xfu, 0xfu, 0xfu, 0xfu};
+      int64_t r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[j] = row0 + (int64_t)(u0 + j) * kIterRows + tid * 4;
+        const int64_t left = n - r[j];
+        bits[j] = left >= 4 ? 0xfu : left <= 0 ? 0u : ((1u << left) - 1u);
+      }
+      if (a.row_quals) {  // a disjunction among the quals: the row function's whole filter, row by row
+        for (int j = 0; j < 4; ++j) {
+          uint32_t pass = 0;
+          for (int i = 0; i < 4; ++i)
+            if ((bits[j] >> i) & 1u) pass |= (uint32_t)quals_pass(p, fc, r[j] + i) << i;
+          bits[j] = pass;
+        }
+      }
+      for (int k = 0; k < (a.row_quals ? 0 : p.n_quals); ++k) {
+        const DevQual& q = p.quals[k];
+        if (q.col >= n_phys) continue;  // a qual on an expression: below
+        const int8_t* base = fc[q.col];
+        const int w = type_width(q.type);
+        const bool vec = (a.vec_mask >> q.col) & 1;
+        RawQuad raw[4];
+        bool full[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          full[j] = vec && r[j] + 4 <= n;
+          if (full[j]) load_raw_quad(base, w, r[j] >> 2, raw[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          uint32_t pass = 0;
+          if (full[j]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pass |= (uint32_t)qual_on_value(q, value_of_raw(q.type, raw_elem(raw[j], w, i))) << i;
+          } else {
+            for (int i = 0; i < 4; ++i)
+              if ((bits[j] >> i) & 1u) pass |= (uint32_t)eval_qual(q, base, r[j] + i) << i;
+          }
+          // (disjunctions among the quals never reach this family: the plan routes them through an expression)
+          bits[j] &= pass;
+        }
+      }
+      if (a.qual_expr_mask) {  // quals on expressions: evaluated for every row of the tile, in registers
+        for (int j = 0; j < 4; ++j) {
+          for (int i = 0; i < 4; ++i) {
+            if (r[j] + i >= n) continue;
+            int64_t xv[MI355Q_MAX_EXPRS];
+            eval_exprs(*a.xs, a.qual_expr_mask, fc, r[j] + i, xv, &err);
+            bool ok = true;
+            for (int k = 0; k < p.n_quals; ++k) {
+              const DevQual& q = p.quals[k];
+              if (q.col >= n_phys) ok = ok && qual_on_value(q, xv[q.col - n_phys]);
+            }
+            if (!ok) bits[j] &= ~(1u << i);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m |= (uint64_t)bits[j] << (4 * (u0 + j));
+    }
+
+    // ---- the tile's count, its descriptor, and the entries before it
+    {
+      unsigned long long c = (unsigned long long)__popcll(m);
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+      if (lane == 0) s_wave[wave] = c;
+    }
+    __syncthreads();
+    unsigned long long tile_count = 0;
+    for (int w = 0; w < kWaves; ++w) tile_count += s_wave[w];
+    __syncthreads();
+    if (wave == 0) {
+      if (lane == 0)
+        __hip_atomic_store(&a.desc[tile], (tile == 0 ? kStateInclusive : kStateAggregate) | tile_count, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long excl = 0;
+      int64_t idx = tile - 1;  // nearest predecessor this round looks at
+      while (idx >= 0) {
+        const int64_t mine = idx - lane;
+        const bool valid = mine >= 0;
+        unsigned long long d = kStateInclusive;  // (before tile 0: an inclusive prefix of 0)
+        if (valid) d = __hip_atomic_load(&a.desc[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (__any(valid && (d >> kStateShift) == 0)) {  // a predecessor still in pass A: look again
+          __builtin_amdgcn_s_sleep(8);
+          if (valid && (d >> kStateShift) == 0) d = __hip_atomic_load(&a.desc[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const unsigned long long incl_lanes = __ballot((d >> kStateShift) == 2);
+        const int stop = incl_lanes ? __builtin_ctzll(incl_lanes) : 63;  // nearest tile whose inclusive prefix is known
+        unsigned long long v = lane <= stop ? (d & kValueMask) : 0ull;
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        excl += __shfl(v, 0, 64);
+        if (incl_lanes) break;
+        idx -= 64;
+      }
+      if (lane == 0) {
+        if (tile > 0)
+          __hip_atomic_store(&a.desc[tile], kStateInclusive | (excl + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tile == a.n_tiles - 1) a.counters[1] = excl + tile_count;
+        s_bcast[1] = (long long)excl;
+      }
+    }
+    __syncthreads();
+    const int64_t tile_base = s_bcast[1];
+    if (tile_count == 0 || tile_base >= ps.entry_count) continue;  // nothing to write (an empty tile, or past a scan limit)
+
+    // ---- pass B: sub-tile by sub-tile, assemble the entries in LDS and stream them out
+    int64_t done = 0;  // entries of this tile already out
+    const int sub = a.sub_iters;
+    for (int u0 = 0; u0 < kIters; u0 += sub) {
+      const uint32_t mA = (uint32_t)(m >> (4 * u0)) & 0xfu;
+      const uint32_t mB = sub == 2 ? (uint32_t)(m >> (4 * (u0 + 1))) & 0xfu : 0u;
+      const unsigned long long packed = (unsigned long long)__popc(mA) | ((unsigned long long)__popc(mB) << 32);
+      unsigned long long wtot;
+      const unsigned long long wex = wave_excl_scan_u32x2(packed, &wtot);
+      if (lane == 0) s_wave[wave] = wtot;
+      __syncthreads();
+      unsigned long long before = 0, all = 0;
+      for (int w = 0; w < kWaves; ++w) {
+        if (w < wave) before += s_wave[w];
+        all += s_wave[w];
+      }
+      const uint32_t totA = (uint32_t)all, totB = (uint32_t)(all >> 32);
+      const uint32_t exA = (uint32_t)(wex + before), exB = (uint32_t)((wex + before) >> 32);
+      const int64_t sub_total = (int64_t)totA + totB;
+      const int64_t gbase = tile_base + done;  // output entry of the sub-tile's first matching row
+      int64_t n_write = ps.entry_count - gbase;
+      n_write = n_write < 0 ? 0 : n_write > sub_total ? sub_total : n_write;
+      if (sub_total == 0 || n_write == 0) {
+        __syncthreads();
+        done += sub_total;
+        if (gbase >= ps.entry_count) break;
+        continue;
+      }
+      // columnar image: one run per column, each 8-byte aligned; row-wise image: whole rows
+      int32_t img_off[MI355Q_MAX_TARGETS + 1];
+      if (ps.columnar) {
+        int32_t o = 0;
+        img_off[0] = 0;
+        o = (int32_t)sub_total * 8;
+        for (int t = 0; t < ps.n_targets; ++t) {
+          img_off[t + 1] = o;
+          o += ((int32_t)sub_total * ps.t[t].width + 7) & ~7;
+        }
+      }
+      for (int half = 0; half < sub; ++half) {
+        const uint32_t mm = half ? mB : mA;
+        if (!mm) continue;
+        const int64_t r = row0 + (int64_t)(u0 + half) * kIterRows + tid * 4;
+        const uint32_t first = half ? totA + exB : exA;  // rank of the quad's first matching row in the sub-tile
+        // the entry's key: the row's offset in its fragment
+        {
+          uint32_t k = first;
+          for (int i = 0; i < 4; ++i) {
+            if (!((mm >> i) & 1u)) continue;
+            if (ps.columnar) ((int64_t*)s_img)[k] = r + i;
+            else ((int64_t*)s_img)[(size_t)k * ps.row_quad] = r + i;
+            ++k;
+          }
+        }
+        int64_t xv[4][MI355Q_MAX_EXPRS];
+        if (a.xs) {
+          for (int i = 0; i < 4; ++i)
+            if ((mm >> i) & 1u) eval_exprs(*a.xs, (1u << a.xs->n) - 1u, fc, r + i, xv[i], &err);
+        }
+        for (int t = 0; t < ps.n_targets; ++t) {
+          const ProjTarget& pt = ps.t[t];
+          int64_t vals[4];
+          if (pt.col >= n_phys) {
+            for (int i = 0; i < 4; ++i) vals[i] = xv[i][pt.col - n_phys];
+          } else {
+            const int8_t* base = fc[pt.col];
+            const int w = type_width(pt.code);
+            if (((a.vec_mask >> pt.col) & 1) && r + 4 <= n) {
+              RawQuad raw;
+              load_raw_quad(base, w, r >> 2, raw);
+#pragma unroll
+              for (int i = 0; i < 4; ++i) vals[i] = value_of_raw(pt.code, raw_elem(raw, w, i));
+            } else {
+              for (int i = 0; i < 4; ++i) vals[i] = ((mm >> i) & 1u) ? col_value_bits(base, pt.code, r + i) : 0;
+            }
+          }
+          uint32_t k = first;
+          for (int i = 0; i < 4; ++i) {
+            if (!((mm >> i) & 1u)) continue;
+            int64_t v = vals[i];
+            if (pt.kind == PROJ_F32_TO_F64) v = dbl_bits((double)bits_flt((int32_t)(uint32_t)v));
+            if (!ps.columnar) {
+              ((int64_t*)s_img)[(size_t)k * ps.row_quad + 1 + t] = v;
+            } else {
+              char* dst = s_img + img_off[t + 1];
+              switch (pt.width) {
+                case 1: ((int8_t*)dst)[k] = (int8_t)v; break;
+                case 2: ((int16_t*)dst)[k] = (int16_t)v; break;
+                case 4: ((int32_t*)dst)[k] = (int32_t)(uint32_t)v; break;
+                default: ((int64_t*)dst)[k] = v;
+              }
+            }
+            ++k;
+          }
+        }
+      }
+      __syncthreads();
+      // ---- the image leaves as contiguous stores
+      if (!ps.columnar) {
+        const int64_t nq = n_write * ps.row_quad;
+        int64_t* dst = (int64_t*)a.out + gbase * ps.row_quad;
+        const int64_t* src = (const int64_t*)s_img;
+        for (int64_t i = tid; i < nq; i += kBlock) dst[i] = src[i];
+      } else {
+        {
+          int64_t* dst = (int64_t*)a.out + gbase;
+          const int64_t* src = (const int64_t*)s_img;
+          for (int64_t i = tid; i < n_write; i += kBlock) dst[i] = src[i];
+        }
+        for (int t = 0; t < ps.n_targets; ++t) {
+          const ProjTarget& pt = ps.t[t];
+          const char* src = s_img + img_off[t + 1];
+          int8_t* dst = a.out + pt.col_off + gbase * pt.width;
+          switch (pt.width) {
+            case 1:
+              for (int64_t i = tid; i < n_write; i += kBlock) dst[i] = ((const int8_t*)src)[i];
+              break;
+            case 2:
+              for (int64_t i = tid; i < n_write; i += kBlock) ((int16_t*)dst)[i] = ((const int16_t*)src)[i];
+              break;
+            case 4:
+              for (int64_t i = tid; i < n_write; i += kBlock) ((int32_t*)dst)[i] = ((const int32_t*)src)[i];
+              break;
+            default:
+              for (int64_t i = tid; i < n_write; i += kBlock) ((int64_t*)dst)[i] = ((const int64_t*)src)[i];
+          }
+        }
+      }
+      __syncthreads();
+      done += sub_total;
+    }
+  }
+  if (err) atomicCAS(a.d_err, 0, err);
+}
+
+// entries [min(total_matched, entry_count), entry_count) of the buffer: the EMPTY_KEY_64 key — and, row-wise, the zero
+// slots — of an initialised buffer (QueryMemoryInitializer::initRowGroups :617-698; initColumnarGroups :713-738 leaves
+// the slot columns of a columnar projection alone)
+__global__ __launch_bounds__(kBlock) void k_proj_init_tail(ProjSpec ps, const unsigned long long* counters, int64_t* out) {
+  const int64_t live = (int64_t)counters[1] < ps.entry_count ? (int64_t)counters[1] : ps.entry_count;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  if (ps.columnar) {
+    for (int64_t e = live + (int64_t)blockIdx.x * kBlock + threadIdx.x; e < ps.entry_count; e += stride) out[e] = kEmptyKey64;
+    return;
+  }
+  const int64_t q0 = live * ps.row_quad, q1 = ps.entry_count * ps.row_quad;
+  for (int64_t i = q0 + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < q1; i += stride)
+    out[i] = (i % ps.row_quad) == 0 ? kEmptyKey64 : 0;
+}
+
+// ResultSet::rowCount of a projection buffer whose total is not known to the host (a wrapped buffer): the entries
+// whose key is not EMPTY_KEY_64
+__global__ __launch_bounds__(kBlock) void k_proj_count_live(const int64_t* keys, int64_t stride_quads, int64_t entries,
+                                                            unsigned long long* count) {
+  unsigned long long c = 0;
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < entries; e += stride) c += keys[e * stride_quads] != kEmptyKey64;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+}  // namespace
+
+int64_t projection_tile_rows() { return kTileRows; }
+
+int64_t projection_scratch_bytes(int n_frags, const int64_t* h_num_rows) {
+  int64_t tiles = 0;
+  for (int f = 0; f < n_frags; ++f) tiles += (h_num_rows[f] + kTileRows - 1) / kTileRows;
+  // counters (64 B) | tile_start [n_frags + 1] | descriptors [tiles]
+  return 64 + (((int64_t)(n_frags + 1) * 8 + 63) & ~(int64_t)63) + tiles * 8 + 64;
+}
+
+hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExprSet* d_xs, uint32_t qual_expr_mask,
+                             const FragView& fv, void* scratch, void* out, int32_t* d_err, unsigned long long** d_total,
+                             int n_cus, hipStream_t s, LaunchStats* st) {
+  char* sp = (char*)scratch;
+  unsigned long long* counters = (unsigned long long*)sp;
+  int64_t* tile_start = (int64_t*)(sp + 64);
+  const int64_t ts_bytes = ((int64_t)(fv.n_frags + 1) * 8 + 63) & ~(int64_t)63;
+  unsigned long long* desc = (unsigned long long*)(sp + 64 + ts_bytes);
+  std::vector<int64_t> h_ts((size_t)fv.n_frags + 1);
+  int64_t tiles = 0;
+  for (int f = 0; f < fv.n_frags; ++f) {
+    h_ts[f] = tiles;
+    tiles += (fv.h_num_rows[f] + kTileRows - 1) / kTileRows;
+  }
+  h_ts[fv.n_frags] = tiles;
+  *d_total = counters + 1;
+  hipError_t e = hipMemsetAsync(sp, 0, (size_t)(64 + ts_bytes + tiles * 8), s);
+  if (e != hipSuccess) return e;
+  // (a pageable source: the copy is staged by the runtime before the call returns)
+  e = hipMemcpyAsync(tile_start, h_ts.data(), h_ts.size() * 8, hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(s);  // h_ts goes out of scope
+  if (e != hipSuccess) return e;
+
+  ProjArgs a{};
+  a.ps = ps;
+  a.xs = d_xs;
+  a.qual_expr_mask = qual_expr_mask;
+  a.n_frags = fv.n_frags;
+  a.cols = fv.d_cols;
+  a.num_rows = fv.d_num_rows;
+  a.tile_start = tile_start;
+  a.n_tiles = tiles;
+  a.desc = desc;
+  a.counters = counters;
+  a.out = (int8_t*)out;
+  a.d_err = d_err;
+  int row_bytes = 8;
+  for (int t = 0; t < ps.n_targets; ++t) row_bytes += ps.columnar ? ps.t[t].width : 8;
+  a.sub_iters = row_bytes <= 36 ? 2 : 1;
+  a.row_quals = 0;
+  for (int k = 0; k < p.n_quals; ++k) a.row_quals |= p.quals[k].or_group != 0;
+  a.vec_mask = 0;
+  for (int c = 0; c < ps.n_phys_cols && c < 31; ++c)
+    if (fast::all_aligned16(fv, c)) a.vec_mask |= 1 << c;
+  // the LDS image of one sub-tile: every row of it may match; columnar runs are padded to 8 bytes each
+  const size_t lds = (size_t)a.sub_iters * kIterRows * row_bytes + (ps.columnar ? 8 * (size_t)(ps.n_targets + 1) : 0);
+  if (st) {
+    st->kernel_name = "k_proj_compact";
+    st->n_launches = 1;
+    st->variant = a.sub_iters;
+  }
+  if (tiles > 0) {
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    int64_t grid = (int64_t)n_cus * per_cu;
+    if (tune_knobs().blocks_per_cu > 0) grid = (int64_t)n_cus * tune_knobs().blocks_per_cu;
+    if (grid > tiles) grid = tiles;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)k_proj_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+      attr_set = true;
+    }
+    if (st && st->k_start) (void)hipEventRecord(st->k_start, s);
+    hipLaunchKernelGGL(k_proj_compact, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
+    if (st && st->k_stop) (void)hipEventRecord(st->k_stop, s);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  const int64_t tail_quads = ps.columnar ? ps.entry_count : ps.entry_count * ps.row_quad;
+  int64_t g2 = (tail_quads + kBlock * 8 - 1) / (kBlock * 8);
+  g2 = g2 < 1 ? 1 : g2 > (int64_t)n_cus * 8 ? (int64_t)n_cus * 8 : g2;
+  hipLaunchKernelGGL(k_proj_init_tail, dim3((unsigned)g2), dim3(kBlock), 0, s, ps, counters, (int64_t*)out);
+  return hipGetLastError();
+}
+
+hipError_t launch_projection_count_live(const int64_t* keys, int64_t stride_quads, int64_t entries, unsigned long long* d_count,
+                                        hipStream_t s) {
+  hipError_t e = hipMemsetAsync(d_count, 0, 8, s);
+  if (e != hipSuccess) return e;
+  int64_t g = (entries + kBlock * 8 - 1) / (kBlock * 8);
+  g = g < 1 ? 1 : g > 2048 ? 2048 : g;
+  hipLaunchKernelGGL(k_proj_count_live, dim3((unsigned)g), dim3(kBlock), 0, s, keys, stride_quads, entries, d_count);
+  return hipGetLastError();
+}
+
+}  // namespace mq

@@ -322,6 +322,10 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
         // `x IS [NOT] NULL` is itself never NULL (a NOT NULL BOOLEAN, Analyzer UOper kISNULL)
         r.cond_nullable = p.cols[t.cond.col].nullable != 0 && t.cond.op != MI355Q_IS_NULL && t.cond.op != MI355Q_IS_NOT_NULL;
         break;
+      case MI355Q_PROJECT:  // a Projection step's target: the value of an outer column / expression, no aggregate
+        if (grouped || t.col < 0) return MI355Q_ERR_INVALID_PLAN;
+        if (t.table != 0) return MI355Q_ERR_UNSUPPORTED;  // (projections through a join: not in this family yet)
+        break;
       case MI355Q_PROJECT_KEY:
         if (!grouped) return MI355Q_ERR_INVALID_PLAN;
         r.key_idx = t.col < 0 ? 0 : t.col;
@@ -344,7 +348,7 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
       r.arg_f32 = type_is_f32(cd.type);
       r.range = r.table ? &p.inner_col_ranges[r.col] : &p.col_ranges[r.col];
     }
-    const bool is_agg = t.agg != MI355Q_PROJECT_KEY;
+    const bool is_agg = t.agg != MI355Q_PROJECT_KEY && t.agg != MI355Q_PROJECT;
     // constrained_not_null (OutputBufferInitialization.cpp:301-324): `arg IS NOT NULL` among the quals
     r.constrained = false;
     if (is_agg && r.col >= 0 && r.table == 0) {
@@ -423,6 +427,52 @@ void keyless_decision(const mi355q_plan& p, const ResolvedTarget* ts, bool* keyl
 
 }  // namespace
 
+// QueryDescriptionType::Projection (QueryMemoryDescriptor::init, Descriptors/QueryMemoryDescriptor.cpp:394-410): one
+// "group column" — the 8-byte row offset get_scan_output_slot writes (GroupByRuntime.cpp:242-255; groupby_exprs of a
+// projection is one nullptr, get_col_byte_widths gives it sizeof(int64_t)) — and one slot per target from
+// ColSlotContext(target_exprs, {}) (ColSlotContext.cpp:35-100: the target type's width), whose padded sizes the
+// constructor then sets to 8 (setAllUnsetSlotsPaddedSize, :507) — or, for a columnar projection, to the logical widths
+// (isLogicalSizedColumnsAllowed :1129-1135).  entry_count = scan_limit, else max_groups_buffer_entry_count.
+int32_t qmd_init_projection(const mi355q_plan& p, const ResolvedTarget* ts, mi355q_qmd* q) {
+  if (p.n_group_cols != 0 || p.join_outer_col >= 0) return p.join_outer_col >= 0 ? MI355Q_ERR_UNSUPPORTED : MI355Q_ERR_INVALID_PLAN;
+  if (p.scan_limit < 0) return MI355Q_ERR_INVALID_PLAN;
+  if (p.output_columnar_hint == MI355Q_OUTPUT_ROWWISE_COLUMNAR_DECISIONS) return MI355Q_ERR_INVALID_PLAN;
+  q->desc_type = MI355Q_PROJECTION;
+  q->n_targets = p.n_targets;
+  q->group_col_count = 1;
+  q->idx_target_as_key = -1;
+  q->key_width = 8;
+  q->key_bytes = 8;
+  q->entry_count = p.scan_limit > 0 ? p.scan_limit : (p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess : 16384);
+  // pos / output_buffer_entry_count are uint32 in get_scan_output_slot, total_matched an int32
+  if (q->entry_count > (int64_t)INT32_MAX) return MI355Q_ERR_UNSUPPORTED;
+  q->output_columnar = p.output_columnar_hint == MI355Q_OUTPUT_COLUMNAR;
+  q->slot_count = p.n_targets;
+  q->slot_width = 8;
+  for (int i = 0; i < p.n_targets; ++i) {
+    const ResolvedTarget& t = ts[i];
+    const int logical = tc_logical(t.arg_type);
+    q->target_agg[i] = MI355Q_PROJECT;
+    q->target_slot[i] = i;
+    q->target_key_idx[i] = 0;
+    q->target_skip_null[i] = 0;
+    q->target_is_fp[i] = t.arg_fp || t.arg_f32;
+    // row-wise: a FLOAT value is widened to double for its 8-byte slot (castToTypeIn(target_lv, 64) + agg_id_double,
+    // TargetExprBuilder.cpp:485-560; run_query_external fills the slot the same way, ExternalExecutor.cpp:470-479);
+    // columnar: the 4-byte float itself
+    q->target_arg_is_fp[i] = t.arg_fp || (t.arg_f32 && !q->output_columnar);
+    q->target_arg_is_f32[i] = t.arg_f32 && q->output_columnar;
+    q->slot_bytes[i] = q->output_columnar ? plain_width(logical) : 8;
+    q->init_vals[i] = 0;  // init_agg_val_vec: a non-aggregate target starts at 0 (OutputBufferInitialization.cpp:40-47)
+    if (!t.arg_nullable) q->target_null[i] = kEmptyKey64;  // (ResultSet::isNull tests the type first: never NULL)
+    else if (t.arg_fp) q->target_null[i] = kNullDoubleBits;
+    else if (t.arg_f32) q->target_null[i] = q->output_columnar ? (int64_t)kNullFloatBits : dbl_bits((double)bits_flt(kNullFloatBits));
+    else q->target_null[i] = int_null_of(t.arg_type);
+  }
+  q->row_size = 8 + 8 * q->slot_count;
+  return MI355Q_OK;
+}
+
 int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   std::memset(q, 0, sizeof(*q));
   if (p.abi_version != MI355Q_ABI_VERSION) return MI355Q_ERR_INVALID_PLAN;
@@ -453,6 +503,14 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   const bool grouped = p.n_group_cols >= 1;
   ResolvedTarget ts[MI355Q_MAX_TARGETS];
   if (int32_t e = resolve_targets(p, grouped, ts)) return e;
+
+  int n_project = 0;
+  for (int i = 0; i < p.n_targets; ++i) n_project += p.targets[i].agg == MI355Q_PROJECT;
+  if (n_project) {
+    if (n_project != p.n_targets) return MI355Q_ERR_INVALID_PLAN;  // (a target list is all aggregates or none)
+    return qmd_init_projection(p, ts, q);
+  }
+  if (p.scan_limit != 0) return MI355Q_ERR_INVALID_PLAN;  // (scan_limit exists for projections only: RelAlgExecutionUnit.h:178)
 
   q->n_targets = p.n_targets;
   q->group_col_count = p.n_group_cols;
@@ -639,6 +697,7 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
     compact = false;
   }
   q->slot_width = compact ? 4 : 8;
+  for (int j = 0; j < q->slot_count; ++j) q->slot_bytes[j] = q->slot_width;
   q->row_size = q->key_bytes + ((q->slot_width * q->slot_count + 7) & ~7);
   if (q->row_size <= 0) return MI355Q_ERR_INVALID_PLAN;
   q->output_columnar = p.output_columnar_hint == MI355Q_OUTPUT_COLUMNAR;
@@ -679,6 +738,11 @@ int64_t qmd_group_col_offset(const mi355q_qmd& q, int g) {
 int64_t qmd_slot_col_offset(const mi355q_qmd& q, int s) {
   if (!q.output_columnar || s < 0 || s > q.slot_count) return -1;
   const int64_t keys = q.keyless ? 0 : (int64_t)q.group_col_count * 8 * q.entry_count;
+  if (q.desc_type == MI355Q_PROJECTION) {  // logical-sized slot columns (getColOffInBytes, QueryMemoryDescriptor.cpp:906-929)
+    int64_t off = keys;
+    for (int j = 0; j < s; ++j) off += ((int64_t)q.slot_bytes[j] * q.entry_count + 7) & ~(int64_t)7;
+    return off;
+  }
   const int64_t col = ((int64_t)q.slot_width * q.entry_count + 7) & ~(int64_t)7;
   return keys + (int64_t)s * col;
 }

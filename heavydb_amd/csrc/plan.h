@@ -20,6 +20,7 @@ struct ResolvedTarget {
 int col_type_code(const mi355q_col_desc& c);  // < 0 = invalid
 int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out);
 int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q);
+int32_t qmd_init_projection(const mi355q_plan& p, const ResolvedTarget* ts, mi355q_qmd* q);  // the Projection descriptor
 // While one lives (per thread), qmd_init lays multi-column integer keys out as a perfect hash up to `max_entries`
 // entries instead of g_baseline_groupby_threshold: the library's own intermediate table of a baseline step (api.cpp
 // execute_perfect_twin); never the layout a caller sees.

@@ -213,19 +213,29 @@ MQ_FN void a_minmax_f32(int64_t* s, float v, int32_t skip_bits) {
 }
 
 // ---------------------------------------------------------------- filter
-MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
+// The value of a column element as one 64-bit pattern: integers decoded and sign-extended, DOUBLE its bits, FLOAT its
+// bits in the low word — what the projected-expression evaluator (expr.h) and qual_on_value work on.
+MQ_FN int64_t col_value_bits(const int8_t* col, int code, int64_t pos) {
+  const int st = tc_storage(code);
+  if (st == MI355Q_FLOAT) return (int64_t)*(const uint32_t*)(col + pos * 4);
+  if (st == MI355Q_DOUBLE) return *(const int64_t*)(col + pos * 8);
+  return decode_int(col, code, pos);
+}
+// `col <op> literal` on a value already fetched (col_value_bits)
+MQ_FN bool qual_on_value(const DevQual& q, int64_t bits) {
+  const int st = tc_storage(q.type);
   if (q.op == MI355Q_IS_NULL || q.op == MI355Q_IS_NOT_NULL) {
     // codegenIsNull (LogicalIR.cpp:381-432): false on a NOT NULL type, else value == inline NULL
     bool is_null = false;
     if (q.nullable) {
-      if (q.type == MI355Q_FLOAT) is_null = decode_flt(col, pos) == kNullFloat;
-      else if (q.type == MI355Q_DOUBLE) is_null = decode_dbl(col, pos) == kNullDouble;
-      else is_null = decode_int(col, q.type, pos) == int_null_of(q.type);
+      if (st == MI355Q_FLOAT) is_null = bits_flt((int32_t)(uint32_t)bits) == kNullFloat;
+      else if (st == MI355Q_DOUBLE) is_null = bits_dbl(bits) == kNullDouble;
+      else is_null = bits == int_null_of(q.type);
     }
     return q.op == MI355Q_IS_NULL ? is_null : !is_null;
   }
-  if (q.type == MI355Q_FLOAT) {  // the literal is folded to the column's type: compared in float
-    const float v = decode_flt(col, pos);
+  if (st == MI355Q_FLOAT) {  // the literal is folded to the column's type: compared in float
+    const float v = bits_flt((int32_t)(uint32_t)bits);
     const float lit = (float)q.fval;
     if (q.nullable && v == kNullFloat) return false;
     switch (q.op) {
@@ -237,8 +247,8 @@ MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
       default: return v >= lit;
     }
   }
-  if (q.type == MI355Q_DOUBLE) {
-    const double v = decode_dbl(col, pos);
+  if (st == MI355Q_DOUBLE) {
+    const double v = bits_dbl(bits);
     if (q.nullable && v == kNullDouble) return false;
     switch (q.op) {
       case MI355Q_EQ: return v == q.fval;
@@ -249,7 +259,7 @@ MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
       default: return v >= q.fval;
     }
   }
-  const int64_t v = decode_int(col, q.type, pos);
+  const int64_t v = bits;
   if (q.nullable && v == int_null_of(q.type)) return false;
   switch (q.op) {
     case MI355Q_EQ: return v == q.ival;
@@ -259,6 +269,9 @@ MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
     case MI355Q_LE: return v <= q.ival;
     default: return v >= q.ival;
   }
+}
+MQ_FN bool eval_qual(const DevQual& q, const int8_t* col, int64_t pos) {
+  return qual_on_value(q, col_value_bits(col, q.type, pos));
 }
 
 // ---------------------------------------------------------------- join probe

@@ -223,6 +223,9 @@ class RelAlgExecutionUnit:
                           # get 4-byte slots while this is <= UINT32_MAX (pick_target_compact_width)
     # projected expressions: expression k is the virtual outer column len(input_col_descs) + k
     exprs: List[Expr] = field(default_factory=list)
+    # Projection steps (every target capi.PROJECT, no groupby_exprs): LIMIT + OFFSET of a projection without ORDER BY
+    # (RelAlgExecutionUnit::scan_limit); 0 = none, the buffer then has max_groups_buffer_entry_guess entries
+    scan_limit: int = 0
 
     def col_type(self, c: int) -> int:
         """storage type of outer column c; for a virtual column the expression's result type"""
@@ -282,6 +285,7 @@ class RelAlgExecutionUnit:
         p.n_exprs = len(self.exprs)
         for i, e in enumerate(self.exprs):
             p.exprs[i] = e.to_c()
+        p.scan_limit = int(self.scan_limit)
         return p
 
 
@@ -461,7 +465,8 @@ class ResultSet:
             keys.append(raw[o:o + 8 * n].view(np.int64))
         for s in range(q.slot_count):
             o = self._lib.mi355q_qmd_slot_col_offset(C.byref(q), s)
-            slots.append(raw[o:o + q.slot_width * n].view(np.int32 if q.slot_width == 4 else np.int64))
+            w = q.slot_bytes[s] or q.slot_width
+            slots.append(raw[o:o + w * n].view({1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[w]))
         return keys, slots
 
     # -- iteration
@@ -490,6 +495,11 @@ class ResultSet:
 
     def rowCount(self) -> int:
         return self._lib.mi355q_result_row_count(self.handle)
+
+    def totalMatched(self) -> int:
+        """Projection results: rows that passed the quals (the kernel's total_matched); > entryCount() when a
+        scan_limit cut the output.  -1 for any other result."""
+        return self._lib.mi355q_result_total_matched(self.handle)
 
     def fetch(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """All rows in entry order: (ival[n,t], dval[n,t], is_null[n,t])."""

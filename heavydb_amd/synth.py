@@ -157,3 +157,36 @@ CONFIGS = {"cfg1": cfg1, "cfg2": cfg2, "cfg3": lambda *a, **k: cfg3(*a, filtered
            "cfg3f": lambda *a, **k: cfg3(*a, filtered=True, **k), "cfg4": cfg4}
 DEFAULT_ROWS = {"cfg1": 100_000_000, "cfg2": 1_000_000_000, "cfg3": 10_000_000_000,
                 "cfg3f": 10_000_000_000, "cfg4": 10_000_000_000}
+
+
+# ---- projection: SELECT v0, ..., v{n_out-1} FROM t WHERE i32 < k   (row-emitting filter / project)
+def projection(torch, total_rows=1_000_000_000, n_out=3, selectivity=0.5, rank=0, world=1, device_id=0, columnar=False,
+               scan_limit=0, entry_guess=None, cols_cache=None):
+    """One INT32 filter column uniform in [0, 2^31) and n_out value columns (INT64 / DOUBLE alternating).  The output
+    buffer is sized like the reference sizes it after its COUNT(*) pre-flight (RelAlgExecutor::getFilteredCountAll):
+    the expected number of matches plus a small margin, unless entry_guess is given.  cols_cache: a dict that keeps the
+    generated table between calls with the same (rows, n columns) — the generated values do not depend on n_out."""
+    from .capi import PROJECT
+    specs = [ColSpec(INT32, GEN_I32_UNIFORM31, range=ExpressionRange(True, 0, 2**31 - 1))]
+    for i in range(n_out):
+        specs.append(ColSpec(INT64, GEN_I64_MOD, a=1_000_000_007, b=-500_000_000, range=ExpressionRange(True, -500_000_000, 500_000_006))
+                     if i % 2 == 0 else
+                     ColSpec(DOUBLE, GEN_F64_UNIT, a_f=1000.0, range=ExpressionRange(True, 0, 0, False, 0.0, 1000.0)))
+    frags = my_fragments(total_rows, rank, world)
+    key = (total_rows, rank, world, device_id)
+    if cols_cache is not None and key in cols_cache and len(cols_cache[key][0]) >= len(specs):
+        cols, bufs, rows = cols_cache[key]
+        cols, bufs = cols[:len(specs)], [b[:len(specs)] for b in bufs]
+    else:
+        cols, bufs, rows = generate_table(torch, specs, frags, device_id)
+        if cols_cache is not None:
+            cols_cache.clear()
+            cols_cache[key] = (cols, bufs, rows)
+    k = int(selectivity * 2**31)
+    n_local = sum(rows)
+    guess = entry_guess if entry_guess is not None else min(int(n_local * selectivity * 1.01) + 4096, 2**31 - 1)
+    ra = RelAlgExecutionUnit(_descs(specs), [TargetExpr(PROJECT, 1 + i) for i in range(n_out)], [Qual(0, LT, k)],
+                             max_groups_buffer_entry_guess=max(guess, 1), scan_limit=scan_limit,
+                             output_columnar_hint=capi.OUTPUT_COLUMNAR if columnar else 0)
+    return ra, FetchResult(bufs, rows, device_id=device_id, keepalive=cols), dict(
+        bytes_per_row=4 + 8 * n_out, out_bytes_per_row=8 + 8 * n_out, gens=gen_tuples(specs), k=k, cols=cols)

@@ -44,15 +44,15 @@
 extern "C" {
 #endif
 
-#define MI355Q_ABI_VERSION 6
+#define MI355Q_ABI_VERSION 7
 
 #define MI355Q_MAX_COLS 16
-#define MI355Q_MAX_QUALS 4
+#define MI355Q_MAX_QUALS 8
 #define MI355Q_MAX_TARGETS 8
 #define MI355Q_MAX_SLOTS 16
 #define MI355Q_MAX_GROUP_COLS 4
-#define MI355Q_MAX_EXPRS 4
-#define MI355Q_MAX_EXPR_NODES 12
+#define MI355Q_MAX_EXPRS 8
+#define MI355Q_MAX_EXPR_NODES 24
 #define MI355Q_MAX_EXPR_STACK 8 /* values on the evaluation stack of a postfix program (CASE WHEN a >= 6 AND a <= 7 ... needs 5) */
 
 /* ---- error codes: numeric values of heavyai::ErrorCode (enums.h:30-51) ---- */
@@ -142,7 +142,12 @@ typedef enum mi355q_agg {
                            (agg_sum_if*, RuntimeFunctions.cpp:1157-1161,1341-1346,1450-1456;
                            codegenConditionalAggregateCondValSelector: TRUE means == 1, a NULL
                            condition is not TRUE) */
-  MI355Q_PROJECT_KEY = 100
+  MI355Q_PROJECT_KEY = 100,
+  /* a non-aggregate target of a PROJECTION step (no GROUP BY, no aggregate: `SELECT a, b + 1 FROM t WHERE ...`): the value
+   * of outer column / expression `col` of every row that passes the quals, written with agg_id
+   * (TargetExprCodegen::codegenAggregate, TargetExprBuilder.cpp:330-560; is_agg == false).  A step is a Projection when
+   * n_group_cols == 0 and EVERY target is MI355Q_PROJECT. */
+  MI355Q_PROJECT = 101
 } mi355q_agg;
 
 /* join kinds: INNER drops outer rows without a match; LEFT keeps them once with every inner
@@ -154,6 +159,16 @@ typedef enum mi355q_join_kind { MI355Q_JOIN_INNER = 0, MI355Q_JOIN_LEFT = 1 } mi
 typedef enum mi355q_desc_type {
   MI355Q_GROUP_BY_PERFECT_HASH = 0,
   MI355Q_GROUP_BY_BASELINE_HASH = 1,
+  /* QueryDescriptionType::Projection: one output entry per row that passes the quals.  Entry e holds
+   * [ row's offset in its fragment (int64, the "key": get_scan_output_slot / get_columnar_scan_output_offset,
+   * GroupByRuntime.cpp:242-269) | one slot per target ]; entries [row count, entry_count) keep the EMPTY_KEY_64 key of
+   * an initialised buffer.  entry_count = scan_limit, or max_groups_buffer_entry_guess when the plan has none
+   * (QueryMemoryDescriptor.cpp:394-410).  Row-wise: 8-byte slots (integers sign-extended, FLOAT widened to double);
+   * columnar (output_columnar_hint): slot columns of the targets' LOGICAL widths (isLogicalSizedColumnsAllowed, :1129),
+   * each align_to_int64(width * entry_count) bytes.  The entries come out in (fragment, row) order — the order the
+   * reference's CPU executor produces with one kernel per fragment (its GPU kernel's order is that of an atomic
+   * counter). */
+  MI355Q_PROJECTION = 2,
   MI355Q_NON_GROUPED_AGGREGATE = 4
 } mi355q_desc_type;
 
@@ -383,6 +398,15 @@ typedef struct mi355q_plan {
   int32_t n_exprs;
   int32_t reserved3;
   mi355q_expr exprs[MI355Q_MAX_EXPRS];
+  /* Projection steps: RelAlgExecutionUnit::scan_limit (RelAlgExecutionUnit.h:178) — LIMIT + OFFSET of a projection
+   * without ORDER BY; 0 = none.  With a limit the output buffer has exactly that many entries and the step ends
+   * normally when more rows match (the first scan_limit of them, in (fragment, row) order, are kept; the reference stops
+   * its loop at max_matched, QueryTemplateGenerator.cpp:751-780).  Without one, a row that finds the buffer full ends
+   * the step with a NEGATIVE code — get_scan_output_slot returns NULL and the row function answers -pos
+   * (GroupByAndAggregate.cpp:1151-1156) — here -(number of matching rows), clamped to INT32_MIN: the caller re-runs with
+   * max_groups_buffer_entry_guess = that count (the reference sizes the buffer by a COUNT(*) pre-flight,
+   * RelAlgExecutor::getFilteredCountAll, or doubles the guess). */
+  int64_t scan_limit;
 } mi355q_plan;
 
 /* plan.output_columnar_hint */
@@ -454,6 +478,9 @@ typedef struct mi355q_qmd {
                                                    (ResultSet::isNull tests the type first) */
   int64_t init_vals[MI355Q_MAX_SLOTS];          /* init_agg_val_vec
                                                    (OutputBufferInitialization.cpp:24) */
+  int32_t slot_bytes[MI355Q_MAX_SLOTS];         /* getPaddedSlotWidthBytes(slot): slot_width for every slot, except in a
+                                                   COLUMNAR PROJECTION, whose slot columns have the targets' logical
+                                                   widths (1 / 2 / 4 / 8) */
 } mi355q_qmd;
 
 /* FetchResult mirror (ColumnFetcher.h:46-49): borrowed device pointers. */
@@ -614,6 +641,9 @@ int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_r
                              void* stream);
 /* number of non-empty entries (ResultSet::rowCount, ResultSet.h:327) */
 int64_t mi355q_result_row_count(const mi355q_result* r);
+/* Projection results: the rows that passed the quals (the kernel's total_matched word, KernelParam::TOTAL_MATCHED,
+ * enums.h:62-77); > entry_count when a scan_limit cut the output.  -1 for any other result. */
+int64_t mi355q_result_total_matched(const mi355q_result* r);
 /* Materialise rows the way ResultSet::getNextRow does, in entry order: for every
  * non-empty entry one row of n_targets values.  Integer-typed targets land in ival,
  * double-typed in dval (AVG = sum/count, NULL if count == 0); is_null flags SQL NULL.

@@ -407,6 +407,10 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
     d.agg = t.agg;
     d.col = t.col;
     d.table = t.table;
+    if (t.agg == MI355Q_PROJECT) {  // a Projection's target (TargetInfo.is_agg == false, no GROUP BY)
+      if (is_group_by || t.col < 0) return MI355Q_ERR_INVALID_PLAN;
+      if (t.table != 0) return MI355Q_ERR_UNSUPPORTED;
+    }
     if (t.agg == MI355Q_PROJECT_KEY) {
       if (!is_group_by) return MI355Q_ERR_INVALID_PLAN;
       d.key_idx = t.col < 0 ? 0 : t.col;
@@ -439,14 +443,14 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
     // constrained_not_null (OutputBufferInitialization.cpp:301-324): a qual `arg IS NOT NULL` (or
     // NOT(arg IS NULL), the same thing here) on the aggregate's own argument expression
     d.constrained = false;
-    if (d.col >= 0 && d.table == 0 && t.agg != MI355Q_PROJECT_KEY) {
+    if (d.col >= 0 && d.table == 0 && t.agg != MI355Q_PROJECT_KEY && t.agg != MI355Q_PROJECT) {
       for (int k = 0; k < p.n_quals; ++k)
         if (p.quals[k].op == MI355Q_IS_NOT_NULL && p.quals[k].col == d.col) d.constrained = true;
     }
     // TargetInfo.cpp:64-81: skip_null_val = !arg.notnull ; TargetExprBuilder.cpp:684-690:
     // non-grouped aggregates with an argument force skip_null_val = true; otherwise a constrained
     // argument turns it off.
-    d.skip_null = (d.col >= 0 && t.agg != MI355Q_PROJECT_KEY) &&
+    d.skip_null = (d.col >= 0 && t.agg != MI355Q_PROJECT_KEY && t.agg != MI355Q_PROJECT) &&
                   ((d.arg_nullable && !d.constrained) || !is_group_by);
     // COUNT_IF: skip_null_val follows the nullability of the condition (its argument)
     // (`x IS [NOT] NULL` is itself a NOT NULL BOOLEAN)
@@ -539,6 +543,48 @@ int64_t bucketed_cardinality(const mi355q_range& r) {
   return c + 1 + (r.has_nulls ? 1 : 0);
 }
 
+// QueryMemoryDescriptor::init, case QueryDescriptionType::Projection (Descriptors/QueryMemoryDescriptor.cpp:394-410)
+// + the constructor (:452-546).  A projection's groupby_exprs is one nullptr: get_col_byte_widths gives that "group
+// column" — the row offset — 8 bytes (group_col_widths = {8}); entry_count = scan_limit, else
+// max_groups_buffer_entry_count; col_slot_context = ColSlotContext(target_exprs, {}) (ColSlotContext.cpp:35-100): one
+// slot per target of the target type's LOGICAL width, padded size unset — the constructor pads every unset slot to 8
+// (setAllUnsetSlotsPaddedSize(8), :507) unless the buffer is a columnar projection, whose slots keep their logical
+// widths (isLogicalSizedColumnsAllowed :1129-1135 -> setAllSlotsPaddedSizeToLogicalSize :540-546).
+int qmd_init_projection(const mi355q_plan& p, const std::vector<TargetDesc>& ts, mi355q_qmd& q) {
+  if (p.n_group_cols != 0) return MI355Q_ERR_INVALID_PLAN;
+  if (p.join_outer_col >= 0) return MI355Q_ERR_UNSUPPORTED;
+  if (p.scan_limit < 0 || p.output_columnar_hint < 0 || p.output_columnar_hint > 1) return MI355Q_ERR_INVALID_PLAN;
+  q.desc_type = MI355Q_PROJECTION;
+  q.n_targets = p.n_targets;
+  q.group_col_count = 1;
+  q.idx_target_as_key = -1;
+  q.key_width = 8;
+  q.key_bytes = 8;
+  q.entry_count = p.scan_limit ? p.scan_limit : (p.max_groups_buffer_entry_guess > 0 ? p.max_groups_buffer_entry_guess : 16384);
+  if (q.entry_count > INT32_MAX) return MI355Q_ERR_UNSUPPORTED;  // (uint32 pos / int32 total_matched of the runtime)
+  q.output_columnar = p.output_columnar_hint == MI355Q_OUTPUT_COLUMNAR;
+  q.slot_count = p.n_targets;
+  q.slot_width = 8;
+  for (int i = 0; i < p.n_targets; ++i) {
+    const TargetDesc& t = ts[i];
+    q.target_agg[i] = MI355Q_PROJECT;
+    q.target_slot[i] = i;
+    q.target_is_fp[i] = t.arg_fp || t.arg_f32;
+    // row-wise: the value is cast to the slot's 64 bits before agg_id / agg_id_double (castToTypeIn(target_lv,
+    // chosen_bytes << 3), TargetExprBuilder.cpp:485-505): a FLOAT becomes a double; columnar: agg_id_float on 4 bytes
+    q.target_arg_is_fp[i] = t.arg_fp || (t.arg_f32 && !q.output_columnar);
+    q.target_arg_is_f32[i] = t.arg_f32 && q.output_columnar;
+    q.slot_bytes[i] = q.output_columnar ? type_width(t.arg_type) : 8;
+    q.init_vals[i] = 0;  // init_agg_val_vec: `if (!agg_info.is_agg ...) push_back(0)` (OutputBufferInitialization.cpp:40-47)
+    if (!t.arg_nullable) q.target_null[i] = kEmptyKey64;
+    else if (t.arg_fp) q.target_null[i] = dbl_bits(kNullDouble);
+    else if (t.arg_f32) q.target_null[i] = q.output_columnar ? (int64_t)flt_bits(kNullFloat) : dbl_bits((double)kNullFloat);
+    else q.target_null[i] = int_null_of(t.arg_type);
+  }
+  q.row_size = 8 + 8 * q.slot_count;  // getRowSize: align8(key bytes) + padded slots
+  return 0;
+}
+
 int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   memset(&q, 0, sizeof(q));
   if (p.n_targets < 1 || p.n_targets > MI355Q_MAX_TARGETS) return MI355Q_ERR_INVALID_PLAN;
@@ -546,6 +592,13 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
   const bool is_group_by = p.n_group_cols > 0;
   std::vector<TargetDesc> ts;
   if (int e = build_targets(p, is_group_by, ts)) return e;
+  {
+    int n_project = 0;
+    for (int i = 0; i < p.n_targets; ++i) n_project += p.targets[i].agg == MI355Q_PROJECT;
+    if (n_project && n_project != p.n_targets) return MI355Q_ERR_INVALID_PLAN;
+    if (n_project) return qmd_init_projection(p, ts, q);
+    if (p.scan_limit != 0) return MI355Q_ERR_INVALID_PLAN;
+  }
 
   q.n_targets = p.n_targets;
   q.group_col_count = p.n_group_cols;
@@ -720,6 +773,7 @@ int qmd_init(const mi355q_plan& p, mi355q_qmd& q) {
     compact = false;
   }
   q.slot_width = compact ? 4 : 8;
+  for (int j = 0; j < q.slot_count; ++j) q.slot_bytes[j] = q.slot_width;
   // getRowSize (QueryMemoryDescriptor.cpp:848-860); slots packed back to back
   // (ColSlotContext::getAlignedPaddedSizeForRange, ColSlotContext.cpp:152-166)
   q.key_bytes = 0;
@@ -762,14 +816,14 @@ int64_t col_group_off(const mi355q_qmd& q, int group_idx) {
 int64_t col_slot_off(const mi355q_qmd& q, int col_idx) {
   int64_t offset = 0;
   if (!q.keyless) offset += col_group_off(q, q.group_col_count);  // getPrependedGroupBufferSizeInBytes
-  for (int index = 0; index < col_idx; ++index) offset += align_to_int64((int64_t)q.slot_width * q.entry_count);
+  for (int index = 0; index < col_idx; ++index) offset += align_to_int64((int64_t)q.slot_bytes[index] * q.entry_count);
   return offset;
 }
 // getBufferSizeBytes (:1084-1111): 8 * group columns * entries + getTotalBytesOfColumnarBuffers
 int64_t buffer_bytes(const mi355q_qmd& q) {
   if (!q.output_columnar) return q.entry_count * (int64_t)q.row_size;
   int64_t total = q.keyless ? 0 : (int64_t)sizeof(int64_t) * q.group_col_count * q.entry_count;
-  for (int s = 0; s < q.slot_count; ++s) total += align_to_int64((int64_t)q.slot_width * q.entry_count);
+  for (int s = 0; s < q.slot_count; ++s) total += align_to_int64((int64_t)q.slot_bytes[s] * q.entry_count);
   return total;
 }
 // one entry of a columnar buffer <-> the row image the row-wise code works on (key quads, slots)
@@ -874,6 +928,11 @@ void init_buffer(const mi355q_qmd& q, int64_t* buf) {
         for (int64_t e = 0; e < q.entry_count; ++e) c[e] = kEmptyKey64;
         buffer_ptr += 8 * q.entry_count;
       }
+    }
+    // (:738) a Projection's slot columns are NOT initialised; zero here so that the bytes are defined
+    if (q.desc_type == MI355Q_PROJECTION) {
+      memset(buffer_ptr, 0, (size_t)(buffer_bytes(q) - 8 * q.entry_count));
+      return;
     }
     for (int i = 0; i < q.slot_count; ++i) {
       if (q.slot_width == 4) {
@@ -1552,7 +1611,27 @@ struct ExecCtx {
   const OrcJoin* join;
   const int8_t* const* inner_cols;
   int64_t inner_rows;
+  int32_t* total_matched = nullptr;  // Projection: the kernel's total_matched word (KernelParam::TOTAL_MATCHED)
 };
+
+// get_scan_output_slot / get_columnar_scan_output_offset (GroupByRuntime.cpp:242-269), as written there
+inline int64_t* get_scan_output_slot(int64_t* output_buffer, const uint32_t output_buffer_entry_count, const uint32_t pos,
+                                     const int64_t offset_in_fragment, const uint32_t row_size_quad) {
+  uint64_t off = static_cast<uint64_t>(pos) * static_cast<uint64_t>(row_size_quad);
+  if (pos < output_buffer_entry_count) {
+    output_buffer[off] = offset_in_fragment;
+    return output_buffer + off + 1;
+  }
+  return NULL;
+}
+inline int32_t get_columnar_scan_output_offset(int64_t* output_buffer, const uint32_t output_buffer_entry_count,
+                                               const uint32_t pos, const int64_t offset_in_fragment) {
+  if (pos < output_buffer_entry_count) {
+    output_buffer[pos] = offset_in_fragment;
+    return pos;
+  }
+  return -1;
+}
 
 // DEF_CMP_NULLABLE (RuntimeFunctions.cpp:73-83) + toBool (>0): NULL operand -> false
 inline bool eval_qual(const mi355q_plan& p, const mi355q_qual& q_in, const int8_t* const* cols,
@@ -1827,6 +1906,57 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
     for (int k = 0; k < nx; ++k)  // group-by and target expressions: rows that reach the body
       if (!(qual_exprs & (1u << k)))
         if (int32_t e = eval_into_cell(k, pos)) return e;
+    if (q.desc_type == MI355Q_PROJECTION) {
+      // GroupByAndAggregate::codegen (GroupByAndAggregate.cpp:1080-1101): crt_matched = 1, old_total_matched =
+      // total_matched++ (the CPU form of the atomic add); codegenOutputSlot (:1255-1275): the entry `old_total_matched`
+      // of a buffer of max_matched entries, its key = the row's offset in the fragment
+      const int32_t old_total_matched = (*c.total_matched)++;
+      const uint32_t max_matched = (uint32_t)q.entry_count;  // Execute.cpp:4278-4280: the scan limit, else the entry count
+      int64_t* out_slots = nullptr;
+      int32_t out_off = -1;
+      if (q.output_columnar) {
+        out_off = get_columnar_scan_output_offset(buf, max_matched, (uint32_t)old_total_matched, pos);
+      } else {
+        out_slots = get_scan_output_slot(buf, max_matched, (uint32_t)old_total_matched, pos, (uint32_t)rq);
+      }
+      if (q.output_columnar ? out_off < 0 : !out_slots) {
+        // "return -pos" (GroupByAndAggregate.cpp:1151-1156).  With a scan limit the template's loop has stopped before
+        // (QueryTemplateGenerator.cpp:751-780: the loop goes on while old_total_matched + crt_matched < max_matched).
+        if (p.scan_limit) return 0;
+        if (pos == 0) continue;  // (-0: the row function's answer for row 0 is "no error"; the row is lost)
+        return -(int32_t)pos;
+      }
+      for (int ti = 0; ti < p.n_targets; ++ti) {
+        const TargetDesc& t = c.ts[ti];
+        const auto& cd = *t.cd;
+        const int8_t* col = cols[t.col];
+        if (!q.output_columnar) {
+          // agg_id / agg_id_double on the 8-byte slot (RuntimeFunctions.cpp:1171-1173,1466-1470) of the value cast to the
+          // slot's width: integers sign-extended, a float widened to double
+          int64_t v;
+          if (t.arg_f32) v = dbl_bits((double)decode_flt(col, pos));
+          else if (t.arg_fp) v = dbl_bits(decode_dbl(col, pos));
+          else v = decode_col(cd, col, pos);
+          out_slots[t.slot] = v;
+        } else {
+          // columnar projection: the slot's column at its logical width (agg_id_int8 / 16 / 32, agg_id, agg_id_float,
+          // agg_id_double; RuntimeFunctions.cpp:1213-1220,1171,1462-1470)
+          int8_t* base = reinterpret_cast<int8_t*>(buf) + col_slot_off(q, t.slot);
+          switch (q.slot_bytes[t.slot]) {
+            case 1: reinterpret_cast<int8_t*>(base)[out_off] = (int8_t)decode_col(cd, col, pos); break;
+            case 2: reinterpret_cast<int16_t*>(base)[out_off] = (int16_t)decode_col(cd, col, pos); break;
+            case 4:
+              if (t.arg_f32) reinterpret_cast<float*>(base)[out_off] = decode_flt(col, pos);
+              else reinterpret_cast<int32_t*>(base)[out_off] = (int32_t)decode_col(cd, col, pos);
+              break;
+            default:
+              reinterpret_cast<int64_t*>(base)[out_off] = t.arg_fp ? dbl_bits(decode_dbl(col, pos)) : decode_col(cd, col, pos);
+          }
+        }
+      }
+      if (p.scan_limit && (uint32_t)(old_total_matched + 1) >= max_matched) return 0;  // limit reached: the loop ends
+      continue;
+    }
     int64_t* slots;
     int64_t keys[MI355Q_MAX_GROUP_COLS] = {0, 0, 0, 0};  // group_by_expr_cache_: values as decoded
     // columnar output: the entry ("bin") comes from the *_columnar runtime functions and the
@@ -2425,6 +2555,10 @@ ORC_EXPORT const void* orc_join_buffer(const void* jp) {
 // output buffer (Execute.cpp:3121-3153, one ExecutionKernel per fragment on CPU), then the
 // buffers are reduced into the first one in order (Execute.cpp:1772-1792).  Input
 // pointers are HOST pointers.  out_buf must hold qmd.entry_count * qmd.row_size bytes.
+static thread_local int32_t t_last_total_matched = 0;
+// total_matched of the calling thread's last Projection run
+ORC_EXPORT int64_t orc_last_total_matched() { return t_last_total_matched; }
+
 ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                                const void* join, int32_t n_threads, int64_t* out_buf,
                                mi355q_qmd* out_qmd) {
@@ -2440,6 +2574,20 @@ ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   c.inner_rows = in->inner_num_rows;
   if (plan->join_outer_col >= 0 && !c.join) return MI355Q_ERR_INVALID_PLAN;
   if (out_qmd) *out_qmd = c.qmd;
+  if (c.qmd.desc_type == MI355Q_PROJECTION) {
+    // multifrag_query (RuntimeFunctions.cpp:2434-2471): the fragments one after the other through the same row function,
+    // ONE output buffer and ONE total_matched word — the shape of the reference's multi-fragment (GPU) kernel, run here
+    // in row order like its CPU kernel (pos_start 0, pos_step 1)
+    t_last_total_matched = 0;
+    c.total_matched = &t_last_total_matched;
+    init_buffer(c.qmd, out_buf);
+    for (int f = 0; f < in->n_frags; ++f) {
+      if (plan->scan_limit && t_last_total_matched >= c.qmd.entry_count) break;  // (the loop condition of every later fragment fails at once)
+      const int8_t* const* cols = reinterpret_cast<const int8_t* const*>(in->col_buffers + (size_t)f * plan->n_cols);
+      if (const int32_t e = run_fragment(c, cols, in->num_rows[f], out_buf)) return e;
+    }
+    return 0;
+  }
   const size_t quads = (size_t)(buffer_bytes(c.qmd) / 8);
   n_threads = std::max(1, std::min(n_threads, std::max(1, in->n_frags)));
 
@@ -2505,6 +2653,49 @@ ORC_EXPORT int64_t orc_row_count(const mi355q_qmd* q, const int64_t* buf) {
 ORC_EXPORT int32_t orc_fetch_rows(const mi355q_qmd* q, const int64_t* buf, int64_t max_rows,
                                   int64_t* ival, double* dval, int8_t* is_null,
                                   int64_t* n_rows) {
+  if (q->desc_type == MI355Q_PROJECTION) {
+    // getTargetValueFromBufferRowwise / Colwise over Projection storage: the slot at its padded width, integers
+    // sign-extended (read_int_from_buff), a 4-byte fp slot a float, an 8-byte fp slot a double — also for a FLOAT
+    // target (ResultSetIteration.cpp makeTargetValue: `chosen_type.is_fp()` reads by slot width); isNull by the
+    // target type's inline NULL unless the type is NOT NULL
+    const int rq = q->row_size / 8;
+    int64_t n = 0;
+    for (int64_t e = 0; e < q->entry_count && n < max_rows; ++e) {
+      if (is_empty_entry(*q, buf, e)) continue;
+      for (int t = 0; t < q->n_targets; ++t) {
+        const size_t o = (size_t)n * q->n_targets + t;
+        const int s = q->target_slot[t];
+        int64_t v;
+        if (!q->output_columnar) {
+          v = buf[e * rq + 1 + s];
+        } else {
+          const int8_t* base = reinterpret_cast<const int8_t*>(buf) + col_slot_off(*q, s);
+          switch (q->slot_bytes[s]) {
+            case 1: v = reinterpret_cast<const int8_t*>(base)[e]; break;
+            case 2: v = reinterpret_cast<const int16_t*>(base)[e]; break;
+            case 4: v = reinterpret_cast<const int32_t*>(base)[e]; break;
+            default: v = reinterpret_cast<const int64_t*>(base)[e];
+          }
+        }
+        ival[o] = 0;
+        dval[o] = 0;
+        const bool nullable = q->target_null[t] != kEmptyKey64;
+        if (q->target_arg_is_f32[t]) {
+          dval[o] = (double)bits_flt((int32_t)v);
+          is_null[o] = nullable && (int32_t)v == (int32_t)q->target_null[t];
+        } else if (q->target_is_fp[t]) {
+          dval[o] = bits_dbl(v);
+          is_null[o] = nullable && v == q->target_null[t];
+        } else {
+          ival[o] = v;
+          is_null[o] = nullable && v == q->target_null[t];
+        }
+      }
+      ++n;
+    }
+    *n_rows = n;
+    return 0;
+  }
   if (q->output_columnar) {  // getTargetValueFromBufferColwise reads the same values through column offsets
     const mi355q_qmd qr = rowwise_of(*q);
     const std::vector<int64_t> rows = col_to_rows(*q, buf);

@@ -102,6 +102,8 @@ def lib() -> C.CDLL:
         l.orc_fetch_rows.restype = C.c_int32
         l.orc_fetch_rows.argtypes = [P(capi.QMD), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                      C.c_void_p, P(C.c_int64)]
+        l.orc_last_total_matched.restype = C.c_int64
+        l.orc_last_total_matched.argtypes = []
         l.orc_splitmix64.restype = C.c_uint64
         l.orc_splitmix64.argtypes = [C.c_uint64]
         l.orc_generate_column.restype = C.c_int32
@@ -287,6 +289,11 @@ def execute(plan: capi.Plan, frag_cols: Sequence[Sequence[np.ndarray]],
     code = lib().orc_execute(C.byref(plan), C.byref(inp), join.handle if join else None,
                              n_threads, buf.ctypes.data, C.byref(out_q))
     return out_q, buf, code
+
+
+def last_total_matched() -> int:
+    """total_matched of this thread's last Projection run through execute()"""
+    return lib().orc_last_total_matched()
 
 
 def buffer_bytes(q: capi.QMD) -> int:

@@ -364,8 +364,9 @@ def hostsim_lib(real_fast: bool = False) -> str:
     real_srcs = ["kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_idx.hip", "fast_common.h", "lds_args.h"] if real_fast else []
     deps = [os.path.join(src_dir, f) for f in ("hip_host.cpp", "kernels_host.cpp", "shim/hip/hip_runtime.h",
                                                "shim/hip/hip_runtime_api.h")] + \
-        [os.path.join(csrc, f) for f in ["api.cpp", "plan.cpp", "kernels_generic.hip", "kernels.h", "rowfunc.h",
-                                         "dev_common.h", "plan.h", "expr.h"] + real_srcs] + \
+        [os.path.join(csrc, f) for f in ["api.cpp", "api_projection.cpp", "api_internal.h", "plan.cpp", "kernels_generic.hip",
+                                         "kernels_proj.hip", "kernels.h", "rowfunc.h", "dev_common.h", "plan.h", "expr.h",
+                                         "fast_common.h"] + real_srcs] + \
         [os.path.join(ROOT, "include", "mi355q.h"), os.path.abspath(__file__)]   # (the build recipe patches the sources)
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(out_dir, exist_ok=True)
@@ -380,23 +381,36 @@ def hostsim_lib(real_fast: bool = False) -> str:
             f.write(kg.replace(decl, "int64_t* const s_tab = (int64_t*)hipsim::dynamic_shared();"))
         # kernels whose body holds a barrier, a wave shuffle / ballot or LDS run as fibers; the rest as plain loops
         names, plain = [], []
-        for m in re.finditer(r"__global__[^{;]*?void\s+(k_\w+)\s*\(", kg):
-            depth, i = 0, kg.index("{", m.end())
-            start = i
-            while True:
-                depth += {"{": 1, "}": -1}.get(kg[i], 0)
-                i += 1
-                if depth == 0:
-                    break
-            (names if re.search(r"__syncthreads|__shfl|__ballot|__shared__", kg[start:i]) else plain).append(m.group(1))
+        with open(os.path.join(csrc, "kernels_proj.hip")) as f:
+            kp_src = f.read()
+        for text in (kg, kp_src):
+            for m in re.finditer(r"__global__[^{;]*?void\s+(k_\w+)\s*\(", text):
+                depth, i = 0, text.index("{", m.end())
+                start = i
+                while True:
+                    depth += {"{": 1, "}": -1}.get(text[i], 0)
+                    i += 1
+                    if depth == 0:
+                        break
+                (names if re.search(r"__syncthreads|__shfl|__ballot|__shared__|__any", text[start:i]) else plain).append(m.group(1))
         with open(os.path.join(out_dir, "barrier_kernels.inc"), "w") as f:
             f.write("".join(f'    "{n}",\n' for n in names))
         with open(os.path.join(out_dir, "plain_kernels.inc"), "w") as f:
             f.write("".join(f'    "{n}",\n' for n in plain))
         flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-w", "-I" + os.path.join(src_dir, "shim"), "-I" + csrc,
                  "-I" + os.path.join(ROOT, "include"), "-I" + out_dir]
-        srcs = [os.path.join(csrc, "api.cpp"), os.path.join(csrc, "plan.cpp"), kg_cpp,
-                os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
+        # the Projection family (kernels_proj.hip) is the real device source in BOTH simulations: its workgroups take tiles
+        # off a ticket counter, so a tile's predecessors are always finished when blocks run one after the other
+        with open(os.path.join(csrc, "kernels_proj.hip")) as f:
+            kp = f.read()
+        kp, n_sub = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char (\w+)\[\];",
+                            r"char* const \1 = (char*)hipsim::dynamic_shared();", kp)
+        assert n_sub == 1 and "extern __shared__" not in kp
+        kp_cpp = os.path.join(out_dir, "kernels_proj_host.cpp")
+        with open(kp_cpp, "w") as f:
+            f.write(kp)
+        srcs = [os.path.join(csrc, "api.cpp"), os.path.join(csrc, "api_projection.cpp"), os.path.join(csrc, "plan.cpp"), kg_cpp,
+                kp_cpp, os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
         if real_fast:
             flags.append("-DHOSTSIM_REAL_FAST")
             for name in ("kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_idx.hip"):

@@ -1,0 +1,163 @@
+"""Projection (row-emitting filter / project) cases shared by the CPU tests (host simulation of the library) and the
+`-m gpu` tests: `SELECT c0, c1, ... FROM t WHERE quals [LIMIT n]` as a RelAlgExecutionUnit whose targets are all
+capi.PROJECT.  Shapes follow the reference's own projection tests (Tests/ExecuteTest.cpp `SELECT x, y FROM test WHERE
+...`, Select.FilterAndSimpleAggregation's filters without the aggregate; Tests/ResultSetTest.cpp Iterate.* over
+Projection storage) and its runtime (get_scan_output_slot / get_columnar_scan_output_offset, GroupByRuntime.cpp:242-269)."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+from heavydb_amd import capi
+from heavydb_amd.executor import Expr, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+
+NP = {capi.INT8: np.int8, capi.INT16: np.int16, capi.INT32: np.int32, capi.INT64: np.int64, capi.DOUBLE: np.float64,
+      capi.FLOAT: np.float32}
+INT_NULL = {capi.INT8: -2**7, capi.INT16: -2**15, capi.INT32: -2**31, capi.INT64: -2**63}
+
+
+@dataclass
+class ProjCase:
+    name: str
+    ra: RelAlgExecutionUnit
+    frags: List[List[np.ndarray]]
+    expect_error: Optional[int] = None   # > 0: that code; < 0: any negative code (buffer full)
+    min_rows: int = 0                    # the case is meant to produce at least this many rows
+
+
+def _col(rng, t, n, lo=-1000, hi=1000, null_every=0):
+    if t == capi.DOUBLE:
+        a = rng.uniform(lo, hi, n).astype(np.float64)
+        if null_every:
+            a[::null_every] = np.finfo(np.float64).tiny  # NULL_DOUBLE = DBL_MIN
+        return a
+    if t == capi.FLOAT:
+        a = rng.uniform(lo, hi, n).astype(np.float32)
+        if null_every:
+            a[::null_every] = np.finfo(np.float32).tiny  # NULL_FLOAT = FLT_MIN
+        return a
+    info = np.iinfo(NP[t])
+    a = rng.integers(max(lo, info.min + 1), min(hi, info.max) + 1, n).astype(NP[t])
+    if null_every:
+        a[::null_every] = INT_NULL[t]
+    return a
+
+
+def _split(cols, sizes):
+    out, o = [], 0
+    for s in sizes:
+        out.append([c[o:o + s] for c in cols])
+        o += s
+    return out
+
+
+def build_cases(scale: int = 1) -> List[ProjCase]:
+    """scale multiplies the row counts (1: a few 10 K rows — several 16 K-row tiles per fragment, ragged ends)."""
+    rng = np.random.default_rng(20250923)
+    cases: List[ProjCase] = []
+    D = InputColDescriptor
+    R = ExpressionRange
+
+    def add(name, descs, cols, targets, quals, sizes, **kw):
+        err = kw.pop("expect_error", None)
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT, c) for c in targets], quals, **kw)
+        cases.append(ProjCase(name, ra, _split(cols, sizes), err))
+
+    n = 40_000 * scale
+    # 1. one int32 filter, three int64 / double columns out; two fragments with ragged sizes
+    f = _col(rng, capi.INT32, n, 0, 999)
+    a = _col(rng, capi.INT64, n, -10**12, 10**12)
+    b = _col(rng, capi.DOUBLE, n)
+    c = _col(rng, capi.INT64, n, 0, 10**6)
+    descs = [D(capi.INT32), D(capi.INT64), D(capi.DOUBLE), D(capi.INT64)]
+    for sel, k in (("1pct", 10), ("50pct", 500), ("99pct", 990)):
+        add(f"i32_filter_{sel}_3cols", descs, [f, a, b, c], [1, 2, 3], [Qual(0, capi.LT, k)], [n // 2 + 3, n - n // 2 - 3],
+            max_groups_buffer_entry_guess=n)
+    add("i32_filter_50pct_1col", descs, [f, a, b, c], [1], [Qual(0, capi.LT, 500)], [n], max_groups_buffer_entry_guess=n)
+    add("i32_filter_columnar_3cols", descs, [f, a, b, c], [1, 2, 3], [Qual(0, capi.LT, 500)], [17_001, n - 17_001],
+        max_groups_buffer_entry_guess=n, output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    # 2. no filter at all: every row, in order; the filter column itself projected
+    add("no_filter_2cols", descs, [f, a, b, c], [0, 3], [], [n], max_groups_buffer_entry_guess=n)
+    # 3. nothing matches / empty input / empty fragment in the middle
+    add("nothing_matches", descs, [f, a, b, c], [1, 2], [Qual(0, capi.LT, -5)], [n], max_groups_buffer_entry_guess=64)
+    add("empty_input", descs, [f[:0], a[:0], b[:0], c[:0]], [1], [Qual(0, capi.LT, 500)], [0], max_groups_buffer_entry_guess=64)
+    add("empty_middle_fragment", descs, [f, a, b, c], [1, 3], [Qual(0, capi.GE, 900)], [1000, 0, n - 1000],
+        max_groups_buffer_entry_guess=n)
+    # 4. every type, nullable, as filter and as output; row-wise and columnar (logical-sized slot columns)
+    m = 21_000 * scale
+    tcols = [_col(rng, capi.INT8, m, -100, 100, 7), _col(rng, capi.INT16, m, -3000, 3000, 11), _col(rng, capi.INT32, m, -10**6, 10**6, 13),
+             _col(rng, capi.INT64, m, -10**15, 10**15, 17), _col(rng, capi.DOUBLE, m, -1e6, 1e6, 19), _col(rng, capi.FLOAT, m, -1e3, 1e3, 23)]
+    tdescs = [D(capi.INT8, True), D(capi.INT16, True), D(capi.INT32, True), D(capi.INT64, True), D(capi.DOUBLE, True), D(capi.FLOAT, True)]
+    for hint, tag in ((0, "rowwise"), (capi.OUTPUT_COLUMNAR, "columnar")):
+        add(f"all_types_nullable_{tag}", tdescs, tcols, [0, 1, 2, 3, 4, 5], [Qual(1, capi.GT, -1500), Qual(4, capi.LT, 5e5)],
+            [m // 3, m - m // 3], max_groups_buffer_entry_guess=m, output_columnar_hint=hint)
+        add(f"is_null_filter_{tag}", tdescs, tcols, [2, 5, 0], [Qual(2, capi.IS_NULL)], [m], max_groups_buffer_entry_guess=m,
+            output_columnar_hint=hint)
+        add(f"float_filter_{tag}", tdescs, tcols, [5, 3], [Qual(5, capi.GE, 0.0), Qual(3, capi.IS_NOT_NULL)], [m - 5, 5],
+            max_groups_buffer_entry_guess=m, output_columnar_hint=hint)
+    # NOT NULL columns that hold the sentinel pattern: never NULL (ResultSet::isNull tests the type first)
+    s32 = _col(rng, capi.INT32, 4096, -5, 5)
+    s32[::5] = INT_NULL[capi.INT32]
+    add("not_null_holding_sentinel", [D(capi.INT32)], [s32], [0], [], [4096], max_groups_buffer_entry_guess=4096)
+    # 5. encoded inputs: kENCODING_FIXED (int64 stored as int16), dictionary ids (uint8), DATE in days (int32 -> seconds)
+    e16 = _col(rng, capi.INT16, m, -30000, 30000, 9)
+    d8 = rng.integers(0, 255, m).astype(np.uint8).view(np.int8)
+    d8.view(np.uint8)[::13] = 255
+    days = _col(rng, capi.INT32, m, -20000, 20000, 29)
+    add("encoded_columns", [D(capi.INT16, True, R(), capi.ENC_FIXED, capi.INT64), D(capi.INT8, True, R(), capi.ENC_DICT),
+                            D(capi.INT32, True, R(), capi.ENC_DATE_IN_DAYS)],
+        [e16, d8, days], [0, 1, 2], [Qual(0, capi.GT, -10000)], [m], max_groups_buffer_entry_guess=m)
+    add("encoded_columns_columnar", [D(capi.INT16, True, R(), capi.ENC_FIXED, capi.INT64), D(capi.INT8, True, R(), capi.ENC_DICT),
+                                     D(capi.INT32, True, R(), capi.ENC_DATE_IN_DAYS)],
+        [e16, d8, days], [2, 1, 0], [Qual(1, capi.LT, 100)], [m // 2, m - m // 2], max_groups_buffer_entry_guess=m,
+        output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    # 6. LIMIT: the first scan_limit matches in (fragment, row) order, the step ends normally; the limit is never reached
+    add("scan_limit_cuts", descs, [f, a, b, c], [1, 3], [Qual(0, capi.LT, 500)], [n // 2, n - n // 2], scan_limit=1000)
+    add("scan_limit_cuts_columnar", descs, [f, a, b, c], [1, 3], [Qual(0, capi.LT, 500)], [n // 2, n - n // 2], scan_limit=777,
+        output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    add("scan_limit_not_reached", descs, [f, a, b, c], [2], [Qual(0, capi.LT, 3)], [n], scan_limit=n)
+    add("scan_limit_inside_first_tile", descs, [f, a, b, c], [0], [Qual(0, capi.GE, 0)], [n], scan_limit=5)
+    # 7. the buffer is too small and there is no limit: a negative code (the caller resizes and retries)
+    add("buffer_full_no_limit", descs, [f, a, b, c], [1], [Qual(0, capi.LT, 500)], [n], max_groups_buffer_entry_guess=100, expect_error=-1)
+    # 8. a disjunction among the quals (OR group)
+    add("or_group", descs, [f, a, b, c], [0, 3], [Qual(0, capi.LT, 100, 1), Qual(0, capi.GT, 900, 1), Qual(3, capi.GE, 1000)], [n],
+        max_groups_buffer_entry_guess=n)
+    # 9. many fragments, some smaller than a tile, unaligned chunk starts (the scalar path of the loads)
+    sizes = [1, 3, 16384, 16385, 5, 70, 1000] + [n - 33848]
+    add("many_small_fragments", descs, [f, a, b, c], [1, 2, 3], [Qual(0, capi.LT, 700)], sizes, max_groups_buffer_entry_guess=n)
+    # 10. eight output columns (the widest row: sub-tiles of 1 024 rows)
+    w8 = [_col(rng, capi.INT64, m, -10**9, 10**9) for _ in range(8)] + [_col(rng, capi.INT32, m, 0, 99)]
+    add("eight_columns", [D(capi.INT64)] * 8 + [D(capi.INT32)], w8, list(range(8)), [Qual(8, capi.LT, 60)], [m],
+        max_groups_buffer_entry_guess=m)
+
+    # 11. projected expressions and expressions in quals, evaluated in the compaction kernel's registers
+    def add_x(name, descs_, cols_, exprs, targets, quals, sizes_, **kw):
+        err = kw.pop("expect_error", None)
+        ra = RelAlgExecutionUnit(descs_, [TargetExpr(capi.PROJECT, t) for t in targets], quals, exprs=exprs, **kw)
+        cases.append(ProjCase(name, ra, _split(cols_, sizes_), err))
+    x = _col(rng, capi.INT32, m, -1000, 1000, 31)
+    y = _col(rng, capi.INT32, m, -50, 50)
+    z = _col(rng, capi.DOUBLE, m, -10, 10, 37)
+    xd = [D(capi.INT32, True), D(capi.INT32), D(capi.DOUBLE, True)]
+    I32, F64 = capi.INT32, capi.DOUBLE
+    C_, L = Expr.col, Expr.lit
+    add_x("expr_targets", xd, [x, y, z], [C_(0).add(C_(1), I32), C_(2).mul(L(F64, 2.5), F64), C_(0).cast(F64)], [3, 4, 5, 1],
+          [Qual(1, capi.GT, 0)], [m // 2, m - m // 2], max_groups_buffer_entry_guess=m)
+    add_x("expr_targets_columnar", xd, [x, y, z], [C_(0).add(C_(1), I32), C_(0).cast(capi.INT64).mul(L(capi.INT64, 1000), capi.INT64)], [3, 4, 0],
+          [Qual(1, capi.GT, 0)], [m], max_groups_buffer_entry_guess=m, output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    # WHERE x + y > 100 (a BOOLEAN expression = 1) AND y < 40; the CASE of a guarded division as output
+    cond = C_(0).add(C_(1), I32).cmp(capi.EX_GT, L(I32, 100))
+    guarded = Expr.case(C_(1).cmp(capi.EX_NE, L(I32, 0)), C_(0).div(C_(1), I32), L(I32, 0), I32)
+    add_x("expr_in_qual_and_case", xd, [x, y, z], [cond, guarded], [0, 1, 4], [Qual(3, capi.EQ, 1), Qual(1, capi.LT, 40)], [m],
+          max_groups_buffer_entry_guess=m)
+    # an expression that reads an earlier one; the root is filtered on
+    band = C_(0).cmp(capi.EX_GT, L(I32, -200)).logical(capi.EX_AND, C_(0).cmp(capi.EX_LT, L(I32, 200)))
+    add_x("expr_reads_expr", xd, [x, y, z], [band, C_(3).logical(capi.EX_OR, C_(1).cmp(capi.EX_EQ, L(I32, 7)))], [0, 1], [Qual(4, capi.EQ, 1)],
+          [m], max_groups_buffer_entry_guess=m)
+    # a division by zero in a row that passes: error 1; in a row the filter drops: none
+    add_x("div_by_zero_counts", xd, [x, y, z], [C_(0).div(C_(1), I32)], [3], [Qual(1, capi.GE, 0)], [m], max_groups_buffer_entry_guess=m,
+          expect_error=capi.ERR_DIV_BY_ZERO)
+    add_x("div_by_zero_filtered_out", xd, [x, y, z], [C_(0).div(C_(1), I32)], [3], [Qual(1, capi.GT, 0)], [m], max_groups_buffer_entry_guess=m)
+    return cases

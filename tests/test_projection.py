@@ -1,0 +1,131 @@
+"""The PROJECTION family on the CPU: the real kernels_proj.hip (and api_projection.cpp / plan.cpp) compiled for the host
+(tests/hostsim) against the oracle's restatement of the reference's projection runtime.  The same cases run on the device
+in tests/test_zz_gpu_projection.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from heavydb_amd import capi
+from tests import proj_cases
+from tests.helpers import compare_buffers, compare_rows, hostsim_lib, qmd_equal
+
+CASES = proj_cases.build_cases()
+
+
+@pytest.fixture(scope="module")
+def sim():
+    lib = capi.load_library(hostsim_lib())
+    saved = capi._lib
+    capi._lib = lib
+    yield lib
+    capi._lib = saved
+
+
+def aligned(a, offset=0):
+    a = np.ascontiguousarray(a)
+    raw = np.empty(a.nbytes + 128, np.uint8)
+    off = (-raw.ctypes.data) % 64 + offset
+    out = raw[off:off + a.nbytes].view(a.dtype)
+    out[...] = a
+    return out
+
+
+def check_projection(oracle, case, make_fetch_result, **opts):
+    """oracle vs product for one case; make_fetch_result(case) -> FetchResult over the case's fragments"""
+    from heavydb_amd.executor import Executor
+    plan = case.ra.to_plan()
+    q, want, code = oracle.execute(plan, case.frags)
+    ex = Executor(0)
+    fr = make_fetch_result(case)
+    if case.expect_error is not None:
+        with pytest.raises(capi.Mi355qError) as ei:
+            ex.executeWorkUnit(case.ra, fr, allow_retry=False, **opts)
+        if case.expect_error > 0:
+            assert code == case.expect_error and ei.value.code == case.expect_error, (code, ei.value.code)
+        else:
+            assert code < 0 and ei.value.code < 0, (code, ei.value.code)
+            # the product's negative code carries the count the caller needs for the retry
+            matched = sum(int(np.count_nonzero(_passes(case, f))) for f in range(len(case.frags)))
+            assert ei.value.code == -matched
+        return None
+    assert code == 0
+    rs = ex.executeWorkUnit(case.ra, fr, allow_retry=False, **opts)
+    qg = rs.getQueryMemDesc()
+    qmd_equal(q, qg)
+    assert q.desc_type == capi.PROJECTION
+    n_live = oracle.row_count(q, want)
+    assert rs.rowCount() == n_live
+    if case.ra.scan_limit == 0:
+        assert rs.totalMatched() == oracle.last_total_matched() == n_live
+    else:
+        assert rs.totalMatched() >= n_live
+    got = rs.getStorage()
+    if not q.output_columnar:
+        # the whole buffer, entry by entry: same rows in the same (fragment, row) order, the tail EMPTY / zero
+        compare_buffers(q, want, got, 0.0)
+    else:
+        raw_w, raw_g = want.view(np.int8), got.view(np.int8)
+        n = q.entry_count
+        assert (raw_w[:8 * n].view(np.int64) == raw_g[:8 * n].view(np.int64)).all()   # the key column, EMPTY tail included
+        for s in range(q.slot_count):
+            o = oracle.col_slot_off(q, s)
+            assert o == capi.load_library().mi355q_qmd_slot_col_offset(C.byref(qg), s)
+            w = q.slot_bytes[s]
+            assert (raw_w[o:o + w * n_live] == raw_g[o:o + w * n_live]).all(), s   # (the slot columns' tails are uninitialised)
+    compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 0.0)
+    return rs
+
+
+def _passes(case, f):
+    """numpy restatement of the case's plain quals (used only to count matches of the buffer-full case)"""
+    cols = case.frags[f]
+    ok = np.ones(len(cols[0]), bool)
+    for ql in case.ra.simple_quals:
+        v = cols[ql.col]
+        ok &= {capi.LT: v < ql.literal, capi.GT: v > ql.literal, capi.LE: v <= ql.literal, capi.GE: v >= ql.literal,
+               capi.EQ: v == ql.literal, capi.NE: v != ql.literal}[ql.op]
+    return ok
+
+
+def host_fetch_result(case, offset=0):
+    from heavydb_amd.executor import FetchResult
+    frags = [[aligned(a, offset) for a in cols] for cols in case.frags]
+    return FetchResult([[a.ctypes.data for a in cols] for cols in frags], [len(cols[0]) for cols in frags], [], 0, 0, [frags])
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_projection_case_on_the_host_simulation(sim, oracle, case):
+    check_projection(oracle, case, host_fetch_result)
+
+
+@pytest.mark.parametrize("name", ["i32_filter_50pct_3cols", "all_types_nullable_columnar", "encoded_columns"])
+def test_projection_unaligned_chunks_take_the_scalar_loads(sim, oracle, name):
+    case = next(c for c in CASES if c.name == name)
+    check_projection(oracle, case, lambda c: host_fetch_result(c, offset=8))
+
+
+def test_projection_descriptor_matches_the_reference_rules(oracle):
+    """QueryMemoryDescriptor::init, case Projection (QueryMemoryDescriptor.cpp:394-410) + constructor (:507,:540-546)"""
+    from heavydb_amd.executor import InputColDescriptor as D, RelAlgExecutionUnit, TargetExpr
+    descs = [D(capi.INT8, True), D(capi.INT32), D(capi.DOUBLE, True), D(capi.FLOAT, True)]
+    targets = [TargetExpr(capi.PROJECT, c) for c in range(4)]
+    lib = capi.load_library()
+    for hint in (0, capi.OUTPUT_COLUMNAR):
+        for limit, guess, want_entries in ((0, 0, 16384), (0, 5000, 5000), (300, 5000, 300)):
+            ra = RelAlgExecutionUnit(descs, targets, max_groups_buffer_entry_guess=guess, scan_limit=limit, output_columnar_hint=hint)
+            q = capi.QMD()
+            assert lib.mi355q_qmd_init(C.byref(ra.to_plan()), C.byref(q)) == 0
+            qmd_equal(oracle.qmd_init(ra.to_plan()), q)
+            assert (q.desc_type, q.entry_count, q.group_col_count, q.key_bytes, q.slot_count) == (capi.PROJECTION, want_entries, 1, 8, 4)
+            assert list(q.slot_bytes[:4]) == ([1, 4, 8, 4] if hint else [8, 8, 8, 8])
+            want_bytes = want_entries * 40 if not hint else sum((w * want_entries + 7) // 8 * 8 for w in (8, 1, 4, 8, 4))
+            assert lib.mi355q_qmd_buffer_bytes(C.byref(q)) == want_bytes == oracle.buffer_bytes(q)
+    # a target list is all aggregates or none; scan_limit belongs to projections; no GROUP BY
+    bad = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT, 0), TargetExpr(capi.COUNT)])
+    q = capi.QMD()
+    assert lib.mi355q_qmd_init(C.byref(bad.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN
+    bad = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT)], scan_limit=5)
+    assert lib.mi355q_qmd_init(C.byref(bad.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN
+    bad = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT, 0)], groupby_exprs=[1])
+    assert lib.mi355q_qmd_init(C.byref(bad.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN

@@ -9,5 +9,13 @@ case $step in
   before)   # the "before" of the expression-fusion work: the five BOOLEAN-filter shapes through the k_project interpreter pass
     timeout 500 python tools/bool_filter_bench.py --rows 1e9 --steps 3 > $out/bool_filter_1b.jsonl 2> $out/bool_filter.err; echo "bool_filter exit $?"
     cat $out/bool_filter_1b.jsonl; tail -5 $out/bool_filter.err ;;
+  proj1)    # first contact of the Projection family: the case matrix on the device, then the 1 B-row bench lines
+    timeout 900 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -x -q -p no:cacheprovider -k "case_on_the_device or larger_random" > $out/pytest.log 2>&1
+    echo "pytest exit $?"; tail -5 $out/pytest.log
+    timeout 600 python tools/proj_bench.py --rows 1e9 --steps 3 > $out/proj_bench_1b.jsonl 2> $out/proj_bench.err; echo "bench exit $?"
+    cat $out/proj_bench_1b.jsonl; tail -3 $out/proj_bench.err ;;
+  proj1b)   # the 1 B-row property + oracle tests of the Projection family
+    timeout 1500 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -x -q -p no:cacheprovider -k "1b_rows" > $out/pytest.log 2>&1
+    echo "pytest exit $?"; tail -8 $out/pytest.log ;;
   *) echo "unknown step $step"; exit 2 ;;
 esac
