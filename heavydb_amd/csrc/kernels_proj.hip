@@ -26,6 +26,7 @@
 // (Executor::compileBody, NativeCodegen.cpp:3455: filters first, then the body).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "expr.h"
@@ -67,6 +68,13 @@ struct ProjArgs {
   int32_t sub_iters;             // iterations per sub-tile (1 or 2): what the LDS image holds
   int32_t vec_mask;              // bit c: column c of every fragment is 16-byte aligned (vector loads allowed)
   int32_t row_quals;             // the quals hold a disjunction (or_group): evaluated by quals_pass, row by row
+  // quals over plain INT32 / INT64 columns, normalised at plan time to lo <= v <= hi (+ negation, + NULL exclusion):
+  // qmode 1 = INT32 (compared in 32 bits: lo / hi clamped to the type), 2 = INT64, 0 = the general comparison
+  int32_t qmode[MI355Q_MAX_QUALS];
+  fast::RangeFilter qf[MI355Q_MAX_QUALS];
+  int32_t out16;                 // row-wise buffer on a 16-byte boundary (paired stores for odd target counts)
+  int32_t fast_quals;            // every qual compares an aligned physical column with a literal, no disjunction
+  int32_t fast_targets;          // every target is an aligned physical column
 };
 
 // ---- four rows of one column ------------------------------------------------------------------
@@ -122,7 +130,399 @@ MQ_D unsigned long long wave_excl_scan_u32x2(unsigned long long v, unsigned long
   return inc - v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_proj_compact(DevPlan p, ProjArgs a) {
+
+// the whole filter of one row — every kind of qual (any column type and encoding, disjunctions, quals on expressions).  ONE
+// call site per kernel (the general path of pass A), so that the row function is instantiated once
+template <bool HX>
+MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const int8_t* const* fc, int64_t pos, int32_t* err) {
+  const int n_phys = a.ps.n_phys_cols;
+  int64_t xv[HX ? MI355Q_MAX_EXPRS : 1];
+  if (HX && a.qual_expr_mask) eval_exprs(*a.xs, a.qual_expr_mask, fc, pos, xv, err);
+  uint32_t seen = 0, any = 0;
+#pragma unroll 1
+  for (int k = 0; k < p.n_quals; ++k) {
+    const DevQual& q = p.quals[k];
+    const bool t = (HX && q.col >= n_phys) ? qual_on_value(q, xv[HX ? q.col - n_phys : 0]) : eval_qual(q, fc[q.col < n_phys ? q.col : 0], pos);
+    if (q.or_group == 0) {
+      if (!t) return false;
+    } else {
+      seen |= 1u << q.or_group;
+      if (t) any |= 1u << q.or_group;
+    }
+  }
+  return seen == any;
+}
+
+// ---- pass A: the filter over one tile.  Bit (4 u + i) of the result = row i of the lane's quad in iteration u.
+// Four iterations at a time.  Where all four lie inside the fragment and the plan's quals are comparisons of aligned
+// physical columns with literals (a.fast_quals), every qual is one vector load per quad and lane — INT32 / INT64 range
+// forms compare in registers, the other types go through qual_on_value; everything else (a fragment's ragged end,
+// unaligned chunks, disjunctions, quals on expressions) takes row_passes, row by row.
+template <bool HX>
+MQ_D uint64_t tile_filter(const DevPlan& p, const ProjArgs& a, const int8_t* const* fc, int64_t n, int64_t row0, int32_t* err) {
+  const int tid = threadIdx.x;
+  uint64_t m = 0;
+#pragma unroll 1
+  for (int u0 = 0; u0 < kIters; u0 += 4) {
+    uint32_t bits[4];
+    int64_t r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[j] = row0 + (int64_t)(u0 + j) * kIterRows + tid * 4;
+      const int64_t left = n - r[j];
+      bits[j] = left >= 4 ? 0xfu : left <= 0 ? 0u : ((1u << left) - 1u);
+    }
+    const bool inside = row0 + (int64_t)(u0 + 4) * kIterRows <= n;  // (uniform)
+    if (inside && a.fast_quals) {
+#pragma unroll 1
+      for (int k = 0; k < p.n_quals; ++k) {
+        const DevQual& q = p.quals[k];
+        const int8_t* base = fc[q.col];
+        const int mode = a.qmode[k];
+        if (mode == 1) {  // plain INT32 column, range form, compared in 32 bits
+          const fast::RangeFilter& f = a.qf[k];
+          const int32_t lo = (int32_t)f.lo, hi = (int32_t)f.hi, nul = (int32_t)f.null_val;
+          v4i32 x[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) x[j] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + (r[j] >> 2));
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            uint32_t pass = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int32_t v = x[j][i];
+              bool in = v >= lo && v <= hi;
+              if (f.negate) in = !in;
+              if (f.nullable && v == nul) in = false;
+              pass |= (uint32_t)in << i;
+            }
+            bits[j] &= pass;
+          }
+        } else if (mode == 2) {  // plain INT64 column, range form
+          const fast::RangeFilter& f = a.qf[k];
+          v2i64 xa[4], xb[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            xa[j] = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r[j] >> 2) * 2);
+            xb[j] = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r[j] >> 2) * 2 + 1);
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            uint32_t pass = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int64_t v = i == 0 ? xa[j].x : i == 1 ? xa[j].y : i == 2 ? xb[j].x : xb[j].y;
+              pass |= (uint32_t)fast::filter_pass<int64_t>(f, v) << i;
+            }
+            bits[j] &= pass;
+          }
+        } else {  // any other column type / encoding: one quad at a time through the general comparison
+          const int w = type_width(q.type);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            RawQuad raw;
+            load_raw_quad(base, w, r[j] >> 2, raw);
+            uint32_t pass = 0;
+#pragma unroll 1
+            for (int i = 0; i < 4; ++i) pass |= (uint32_t)qual_on_value(q, value_of_raw(q.type, raw_elem(raw, w, i))) << i;
+            bits[j] &= pass;
+          }
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int ji = 0; ji < 16; ++ji) {
+        const int j = ji >> 2, i = ji & 3;
+        const uint32_t bj = j == 0 ? bits[0] : j == 1 ? bits[1] : j == 2 ? bits[2] : bits[3];
+        if (!((bj >> i) & 1u)) continue;
+        const int64_t rj = j == 0 ? r[0] : j == 1 ? r[1] : j == 2 ? r[2] : r[3];
+        if (!row_passes<HX>(p, a, fc, rj + i, err)) {
+          const uint32_t clr = ~(1u << i);
+          if (j == 0) bits[0] &= clr;
+          if (j == 1) bits[1] &= clr;
+          if (j == 2) bits[2] &= clr;
+          if (j == 3) bits[3] &= clr;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m |= (uint64_t)bits[j] << (4 * (u0 + j));
+  }
+  return m;
+}
+
+// the tile's predecessors: publishes the tile's count, returns the number of matches before the tile (wave 0 only)
+MQ_D unsigned long long tile_lookback(unsigned long long* desc, unsigned long long* counters, int64_t n_tiles, int64_t tile,
+                                      unsigned long long tile_count) {
+  const int lane = threadIdx.x & 63;
+  if (lane == 0)
+    __hip_atomic_store(&desc[tile], (tile == 0 ? kStateInclusive : kStateAggregate) | tile_count, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  unsigned long long excl = 0;
+  int64_t idx = tile - 1;  // nearest predecessor this round looks at
+  while (idx >= 0) {
+    const int64_t mine = idx - lane;
+    const bool valid = mine >= 0;
+    unsigned long long d = kStateInclusive;  // (before tile 0: an inclusive prefix of 0)
+    if (valid) d = __hip_atomic_load(&desc[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__any(valid && (d >> kStateShift) == 0)) {  // a predecessor still in pass A: look again
+      __builtin_amdgcn_s_sleep(8);
+      if (valid && (d >> kStateShift) == 0) d = __hip_atomic_load(&desc[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long incl_lanes = __ballot((d >> kStateShift) == 2);
+    const int stop = incl_lanes ? __builtin_ctzll(incl_lanes) : 63;  // nearest tile whose inclusive prefix is known
+    unsigned long long v = lane <= stop ? (d & kValueMask) : 0ull;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    excl += __shfl(v, 0, 64);
+    if (incl_lanes) break;
+    idx -= 64;
+  }
+  if (lane == 0) {
+    if (tile > 0)
+      __hip_atomic_store(&desc[tile], kStateInclusive | (excl + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile == n_tiles - 1) counters[1] = excl + tile_count;
+  }
+  return excl;
+}
+
+// ---- the FAST row-wise member: quals are range forms over plain INT32 / INT64 columns, targets are plain INT64 /
+// DOUBLE / INT32 / FLOAT columns, every chunk 16-byte aligned (anything else: the general member below).  No LDS image:
+// the rank of every matching row of the tile is known after ONE exchange — per iteration a lane's rank inside its wave
+// is a sum of mbcnt over the four bit planes of the wave's match masks (ballots), the (iteration, wave) totals are
+// scanned by one wave — and every lane then stores its rows whole: 8 (1 + NT) contiguous bytes per row, adjacent ranks
+// adjacent in memory, so the stores of a tile fill whole lines in the L2.  The projected columns of one iteration are
+// loaded together (NT x 16 / 32 bytes in flight per lane), only for quads with a match.
+struct FastArgs {
+  int32_t n_quals, n_targets, n_frags, n_cols_table;
+  int32_t qcol[MI355Q_MAX_QUALS], qmode[MI355Q_MAX_QUALS];  // mode 1: INT32 in 32 bits, 2: INT64
+  fast::RangeFilter qf[MI355Q_MAX_QUALS];
+  int32_t tcol[MI355Q_MAX_TARGETS], tkind[MI355Q_MAX_TARGETS];  // kind 0: 8 raw bytes, 1: INT32 sign-extended, 2: FLOAT -> double
+  int64_t entry_count;
+  const int8_t* const* cols;
+  const int64_t* num_rows;
+  const int64_t* tile_start;
+  int64_t n_tiles;
+  unsigned long long* desc;
+  unsigned long long* counters;
+  int64_t* out;
+  int32_t out16, pad_;
+};
+
+template <typename T>
+MQ_D bool range_pass(const fast::RangeFilter& f, T v);
+template <>
+MQ_D bool range_pass<int32_t>(const fast::RangeFilter& f, int32_t v) {
+  bool in = v >= (int32_t)f.lo && v <= (int32_t)f.hi;
+  if (f.negate) in = !in;
+  if (f.nullable && v == (int32_t)f.null_val) in = false;
+  return in;
+}
+template <>
+MQ_D bool range_pass<int64_t>(const fast::RangeFilter& f, int64_t v) { return fast::filter_pass<int64_t>(f, v); }
+
+// one qual over four iterations of the tile: bits[j] &= pass mask of the lane's quad of iteration u0 + j
+template <typename T>
+MQ_D void fast_qual(const fast::RangeFilter& f, const int8_t* base, const int64_t (&r)[4], bool inside, int64_t n, uint32_t (&bits)[4]) {
+  if (inside) {
+    fast::Quad<T> x[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fast::load_quad<T>(base, r[j] >> 2, x[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t pass = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pass |= (uint32_t)range_pass<T>(f, x[j].v[i]) << i;
+      bits[j] &= pass;
+    }
+  } else {  // the fragment's ragged end: row by row, only inside the fragment
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint32_t pass = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((bits[j] >> i) & 1u) pass |= (uint32_t)range_pass<T>(f, fast::load_one<T>(base, r[j] + i)) << i;
+      bits[j] = pass;
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(kBlock) void k_proj_rows(FastArgs a, int) {
+  extern __shared__ __attribute__((aligned(16))) char s_stage[];  // per wave: 256 rows of the output, assembled before they leave
+  __shared__ uint32_t s_cnt[kIters * kWaves];   // matches of (iteration, wave); then their exclusive prefix in that order
+  __shared__ long long s_bcast[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int rq = 1 + NT;
+  int64_t* const stage = (int64_t*)s_stage + (size_t)wave * 256 * rq;
+
+  for (;;) {
+    if (tid == 0) s_bcast[0] = (long long)atomicAdd(&a.counters[0], 1ull);
+    __syncthreads();
+    const int64_t tile = s_bcast[0];
+    if (tile >= a.n_tiles) break;
+    int f = 0;
+    {
+      int lo = 0, hi = a.n_frags;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.tile_start[mid] <= tile) lo = mid;
+        else hi = mid;
+      }
+      f = lo;
+    }
+    const int8_t* const* fc = a.cols + (size_t)f * a.n_cols_table;
+    const int64_t n = a.num_rows[f];
+    const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;
+
+    // ---- pass A
+    uint64_t m = 0;
+#pragma unroll 1
+    for (int u0 = 0; u0 < kIters; u0 += 4) {
+      uint32_t bits[4];
+      int64_t r[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        r[j] = row0 + (int64_t)(u0 + j) * kIterRows + tid * 4;
+        const int64_t left = n - r[j];
+        bits[j] = left >= 4 ? 0xfu : left <= 0 ? 0u : ((1u << left) - 1u);
+      }
+      const bool inside = row0 + (int64_t)(u0 + 4) * kIterRows <= n;  // (uniform)
+#pragma unroll 1
+      for (int k = 0; k < a.n_quals; ++k) {
+        if (a.qmode[k] == 1) fast_qual<int32_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
+        else fast_qual<int64_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m |= (uint64_t)bits[j] << (4 * (u0 + j));
+    }
+
+    // ---- matches of every (iteration, wave): lane u of the wave keeps iteration u's
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < kIters; ++u) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) c += (uint32_t)__popcll(__ballot((m >> (4 * u + b)) & 1ull));
+      if (lane == u) mine = c;
+    }
+    if (lane < kIters) s_cnt[lane * kWaves + wave] = mine;
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan of the 64 counts in (iteration, wave) order; the tile's total; its predecessors
+      const uint32_t v = s_cnt[lane];
+      uint32_t inc = v;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl(inc, lane - d < 0 ? lane : lane - d, 64);
+        if (lane >= d) inc += o;
+      }
+      const unsigned long long tile_count = (unsigned long long)__shfl(inc, 63, 64);
+      s_cnt[lane] = inc - v;
+      const unsigned long long excl = tile_lookback(a.desc, a.counters, a.n_tiles, tile, tile_count);
+      if (lane == 0) s_bcast[1] = (long long)excl;
+    }
+    __syncthreads();
+    const int64_t tile_base = s_bcast[1];
+    if (tile_base >= a.entry_count) continue;  // past a scan limit (or a full buffer): nothing of this tile is kept
+
+    // ---- pass B
+#pragma unroll 1
+    for (int u = 0; u < kIters; ++u) {
+      const uint32_t mm = (uint32_t)(m >> (4 * u)) & 0xfu;
+      // rank of the lane's first matching row of this iteration (ballots: every lane of the wave takes part)
+      uint32_t before = 0, wave_cnt = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned long long bal = __ballot((mm >> b) & 1u);
+        before += __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+        wave_cnt += (uint32_t)__popcll(bal);
+      }
+      if (wave_cnt == 0) continue;  // (uniform)
+      const int64_t first = tile_base + s_cnt[u * kWaves + wave] + before;
+      const int64_t r = row0 + (int64_t)u * kIterRows + tid * 4;
+      const bool inside = row0 + (int64_t)(u + 1) * kIterRows <= n;  // (uniform)
+      if (mm) {
+      int64_t vals[NT][4];
+      if (inside) {  // every projected column of the quad first: independent 16-byte loads (a 4-byte column's quad waits,
+                     // packed, in the first two value registers)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int8_t* base = fc[a.tcol[t]];
+          if (a.tkind[t] == 0) {
+            const v2i64 x = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2) * 2);
+            const v2i64 y = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2) * 2 + 1);
+            vals[t][0] = x.x; vals[t][1] = x.y; vals[t][2] = y.x; vals[t][3] = y.y;
+          } else {
+            const v2i64 x = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2));
+            vals[t][0] = x.x; vals[t][1] = x.y;
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (a.tkind[t] == 0) continue;
+          const int32_t x0 = (int32_t)(uint32_t)(uint64_t)vals[t][0], x1 = (int32_t)(uint32_t)((uint64_t)vals[t][0] >> 32);
+          const int32_t x2 = (int32_t)(uint32_t)(uint64_t)vals[t][1], x3 = (int32_t)(uint32_t)((uint64_t)vals[t][1] >> 32);
+          if (a.tkind[t] == 1) {
+            vals[t][0] = x0; vals[t][1] = x1; vals[t][2] = x2; vals[t][3] = x3;
+          } else {
+            vals[t][0] = dbl_bits((double)bits_flt(x0)); vals[t][1] = dbl_bits((double)bits_flt(x1));
+            vals[t][2] = dbl_bits((double)bits_flt(x2)); vals[t][3] = dbl_bits((double)bits_flt(x3));
+          }
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int8_t* base = fc[a.tcol[t]];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int64_t v = 0;
+            if ((mm >> i) & 1u) {
+              if (a.tkind[t] == 0) v = fast::load_one<int64_t>(base, r + i);
+              else {
+                const int32_t x = fast::load_one<int32_t>(base, r + i);
+                v = a.tkind[t] == 1 ? (int64_t)x : dbl_bits((double)bits_flt(x));
+              }
+            }
+            vals[t][i] = v;
+          }
+        }
+      }
+      // the wave's rows of this iteration, in rank order, into its LDS stage ...
+      {
+        uint32_t k = before;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (!((mm >> i) & 1u)) continue;
+          int64_t* row = stage + (size_t)k * rq;
+          row[0] = r + i;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) row[1 + t] = vals[t][i];
+          ++k;
+        }
+      }
+      }
+      (void)first;
+      // ... and out of it as one contiguous run: the wave's ranks are adjacent, so are its bytes (64 lanes x 8 / 16 bytes
+      // per store instead of one 8- / 16-byte piece per line)
+      __builtin_amdgcn_wave_barrier();
+      {
+        const int64_t wfirst = tile_base + s_cnt[u * kWaves + wave];  // rank of the wave's first row of this iteration
+        int64_t n_rows = (int64_t)wave_cnt;
+        if (wfirst + n_rows > a.entry_count) n_rows = a.entry_count > wfirst ? a.entry_count - wfirst : 0;
+        const int64_t nq = n_rows * rq;
+        int64_t* dst = a.out + wfirst * rq;
+        if ((((uintptr_t)dst) & 15) == 0) {
+          const int64_t n2 = nq >> 1;
+          for (int64_t q = lane; q < n2; q += 64) ((v2i64*)dst)[q] = ((const v2i64*)stage)[q];
+          if ((nq & 1) && lane == 0) dst[nq - 1] = stage[nq - 1];
+        } else {
+          for (int64_t q = lane; q < nq; q += 64) dst[q] = stage[q];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs a) {
   extern __shared__ __attribute__((aligned(16))) char s_img[];
   __shared__ unsigned long long s_wave[kWaves];
   __shared__ long long s_bcast[2];
@@ -153,70 +553,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact(DevPlan p, ProjArgs a) 
     const int64_t n = a.num_rows[f];
     const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;  // first row of the tile in its fragment
 
-    // ---- pass A: the filter over the tile, 4 rows per lane and iteration; bit (4 u + i) of m = row i of iteration u
-    uint64_t m = 0;
-    for (int u0 = 0; u0 < kIters; u0 += 4) {
-      uint32_t bits[4] = {0xfu, 0xfu, 0xfu, 0xfu};
-      int64_t r[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        r[j] = row0 + (int64_t)(u0 + j) * kIterRows + tid * 4;
-        const int64_t left = n - r[j];
-        bits[j] = left >= 4 ? 0xfu : left <= 0 ? 0u : ((1u << left) - 1u);
-      }
-      if (a.row_quals) {  // a disjunction among the quals: the row function's whole filter, row by row
-        for (int j = 0; j < 4; ++j) {
-          uint32_t pass = 0;
-          for (int i = 0; i < 4; ++i)
-            if ((bits[j] >> i) & 1u) pass |= (uint32_t)quals_pass(p, fc, r[j] + i) << i;
-          bits[j] = pass;
-        }
-      }
-      for (int k = 0; k < (a.row_quals ? 0 : p.n_quals); ++k) {
-        const DevQual& q = p.quals[k];
-        if (q.col >= n_phys) continue;  // a qual on an expression: below
-        const int8_t* base = fc[q.col];
-        const int w = type_width(q.type);
-        const bool vec = (a.vec_mask >> q.col) & 1;
-        RawQuad raw[4];
-        bool full[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          full[j] = vec && r[j] + 4 <= n;
-          if (full[j]) load_raw_quad(base, w, r[j] >> 2, raw[j]);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          uint32_t pass = 0;
-          if (full[j]) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pass |= (uint32_t)qual_on_value(q, value_of_raw(q.type, raw_elem(raw[j], w, i))) << i;
-          } else {
-            for (int i = 0; i < 4; ++i)
-              if ((bits[j] >> i) & 1u) pass |= (uint32_t)eval_qual(q, base, r[j] + i) << i;
-          }
-          // (disjunctions among the quals never reach this family: the plan routes them through an expression)
-          bits[j] &= pass;
-        }
-      }
-      if (a.qual_expr_mask) {  // quals on expressions: evaluated for every row of the tile, in registers
-        for (int j = 0; j < 4; ++j) {
-          for (int i = 0; i < 4; ++i) {
-            if (r[j] + i >= n) continue;
-            int64_t xv[MI355Q_MAX_EXPRS];
-            eval_exprs(*a.xs, a.qual_expr_mask, fc, r[j] + i, xv, &err);
-            bool ok = true;
-            for (int k = 0; k < p.n_quals; ++k) {
-              const DevQual& q = p.quals[k];
-              if (q.col >= n_phys) ok = ok && qual_on_value(q, xv[q.col - n_phys]);
-            }
-            if (!ok) bits[j] &= ~(1u << i);
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m |= (uint64_t)bits[j] << (4 * (u0 + j));
-    }
+    const uint64_t m = tile_filter<true>(p, a, fc, n, row0, &err);
 
     // ---- the tile's count, its descriptor, and the entries before it
     {
@@ -229,34 +566,8 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact(DevPlan p, ProjArgs a) 
     for (int w = 0; w < kWaves; ++w) tile_count += s_wave[w];
     __syncthreads();
     if (wave == 0) {
-      if (lane == 0)
-        __hip_atomic_store(&a.desc[tile], (tile == 0 ? kStateInclusive : kStateAggregate) | tile_count, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      unsigned long long excl = 0;
-      int64_t idx = tile - 1;  // nearest predecessor this round looks at
-      while (idx >= 0) {
-        const int64_t mine = idx - lane;
-        const bool valid = mine >= 0;
-        unsigned long long d = kStateInclusive;  // (before tile 0: an inclusive prefix of 0)
-        if (valid) d = __hip_atomic_load(&a.desc[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__any(valid && (d >> kStateShift) == 0)) {  // a predecessor still in pass A: look again
-          __builtin_amdgcn_s_sleep(8);
-          if (valid && (d >> kStateShift) == 0) d = __hip_atomic_load(&a.desc[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const unsigned long long incl_lanes = __ballot((d >> kStateShift) == 2);
-        const int stop = incl_lanes ? __builtin_ctzll(incl_lanes) : 63;  // nearest tile whose inclusive prefix is known
-        unsigned long long v = lane <= stop ? (d & kValueMask) : 0ull;
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        excl += __shfl(v, 0, 64);
-        if (incl_lanes) break;
-        idx -= 64;
-      }
-      if (lane == 0) {
-        if (tile > 0)
-          __hip_atomic_store(&a.desc[tile], kStateInclusive | (excl + tile_count), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tile == a.n_tiles - 1) a.counters[1] = excl + tile_count;
-        s_bcast[1] = (long long)excl;
-      }
+      const unsigned long long excl = tile_lookback(a.desc, a.counters, a.n_tiles, tile, tile_count);
+      if (lane == 0) s_bcast[1] = (long long)excl;
     }
     __syncthreads();
     const int64_t tile_base = s_bcast[1];
@@ -479,25 +790,99 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
   a.vec_mask = 0;
   for (int c = 0; c < ps.n_phys_cols && c < 31; ++c)
     if (fast::all_aligned16(fv, c)) a.vec_mask |= 1 << c;
-  // the LDS image of one sub-tile: every row of it may match; columnar runs are padded to 8 bytes each
-  const size_t lds = (size_t)a.sub_iters * kIterRows * row_bytes + (ps.columnar ? 8 * (size_t)(ps.n_targets + 1) : 0);
+  for (int k = 0; k < p.n_quals && k < MI355Q_MAX_QUALS; ++k) {
+    a.qmode[k] = 0;
+    const DevQual& dq = p.quals[k];
+    if (dq.col < ps.n_phys_cols && (dq.type == MI355Q_INT32 || dq.type == MI355Q_INT64) && fast::make_range_filter(dq, &a.qf[k])) {
+      a.qmode[k] = dq.type == MI355Q_INT32 ? 1 : 2;
+      if (dq.type == MI355Q_INT32) {  // compared in 32 bits: an empty range stays empty, everything else is inside the type
+        if (a.qf[k].lo > a.qf[k].hi) {
+          a.qf[k].lo = 1;
+          a.qf[k].hi = 0;
+        } else {
+          a.qf[k].lo = std::max<int64_t>(a.qf[k].lo, INT32_MIN);
+          a.qf[k].hi = std::min<int64_t>(a.qf[k].hi, INT32_MAX);
+        }
+      }
+    }
+  }
+  a.out16 = (((uintptr_t)out) & 15) == 0;
+  a.fast_quals = !a.row_quals && qual_expr_mask == 0;
+  for (int k = 0; k < p.n_quals; ++k)
+    a.fast_quals = a.fast_quals && p.quals[k].col < ps.n_phys_cols && p.quals[k].col < 31 && ((a.vec_mask >> p.quals[k].col) & 1);
+  a.fast_targets = 1;
+  for (int t = 0; t < ps.n_targets; ++t)
+    a.fast_targets = a.fast_targets && ps.t[t].col < ps.n_phys_cols && ps.t[t].col < 31 && ((a.vec_mask >> ps.t[t].col) & 1);
+  // the fast row-wise member: range quals over plain INT32 / INT64 columns, plain 4- / 8-byte targets, aligned chunks
+  bool fast_ok = !ps.columnar && !d_xs && !a.row_quals && ps.n_targets >= 1 && ps.n_targets <= 8 && tune_knobs().pass_rows != -1;
+  FastArgs fa{};
+  for (int k = 0; k < p.n_quals && fast_ok; ++k) {
+    const int c = p.quals[k].col;
+    fast_ok = a.qmode[k] != 0 && c < ps.n_phys_cols && c < 31 && ((a.vec_mask >> c) & 1);
+    fa.qcol[k] = c;
+    fa.qmode[k] = a.qmode[k];
+    fa.qf[k] = a.qf[k];
+  }
+  for (int t = 0; t < ps.n_targets && fast_ok; ++t) {
+    const ProjTarget& pt = ps.t[t];
+    fast_ok = pt.col < ps.n_phys_cols && pt.col < 31 && ((a.vec_mask >> pt.col) & 1) &&
+              (pt.code == MI355Q_INT64 || pt.code == MI355Q_DOUBLE || pt.code == MI355Q_INT32 || pt.code == MI355Q_FLOAT);
+    fa.tcol[t] = pt.col;
+    fa.tkind[t] = (pt.code == MI355Q_INT64 || pt.code == MI355Q_DOUBLE) ? 0 : pt.code == MI355Q_INT32 ? 1 : 2;
+  }
+  // the LDS image of one sub-tile (general member): every row of it may match; columnar runs are padded to 8 bytes each
+  const size_t lds = fast_ok ? 0 : (size_t)a.sub_iters * kIterRows * row_bytes + (ps.columnar ? 8 * (size_t)(ps.n_targets + 1) : 0);
   if (st) {
     st->kernel_name = "k_proj_compact";
     st->n_launches = 1;
-    st->variant = a.sub_iters;
+    st->variant = fast_ok ? 0 : a.sub_iters;
   }
   if (tiles > 0) {
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    // fast member: 256 staged rows per wave
+    const size_t fast_lds = (size_t)kWaves * 256 * (1 + ps.n_targets) * 8;
+    const int per_cu = fast_ok ? std::min<int>(4, (int)((158 * 1024) / (fast_lds + 512))) : lds <= 80 * 1024 ? 2 : 1;
     int64_t grid = (int64_t)n_cus * per_cu;
     if (tune_knobs().blocks_per_cu > 0) grid = (int64_t)n_cus * tune_knobs().blocks_per_cu;
     if (grid > tiles) grid = tiles;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)k_proj_compact, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
-      attr_set = true;
-    }
     if (st && st->k_start) (void)hipEventRecord(st->k_start, s);
-    hipLaunchKernelGGL(k_proj_compact, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
+    if (!fast_ok) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_proj_compact_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k_proj_compact_lds, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
+    } else {
+      fa.n_quals = p.n_quals;
+      fa.n_targets = ps.n_targets;
+      fa.n_frags = fv.n_frags;
+      fa.n_cols_table = ps.n_cols_table;
+      fa.entry_count = ps.entry_count;
+      fa.cols = fv.d_cols;
+      fa.num_rows = fv.d_num_rows;
+      fa.tile_start = tile_start;
+      fa.n_tiles = tiles;
+      fa.desc = desc;
+      fa.counters = counters;
+      fa.out = (int64_t*)out;
+      fa.out16 = a.out16;
+      static bool fast_attr_set = false;
+      if (!fast_attr_set) {  // (NT = 8: 72 KB of staging per workgroup)
+        (void)hipFuncSetAttribute((const void*)k_proj_rows<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute((const void*)k_proj_rows<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        fast_attr_set = true;
+      }
+      switch (ps.n_targets) {
+        case 1: hipLaunchKernelGGL((k_proj_rows<1>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+        case 2: hipLaunchKernelGGL((k_proj_rows<2>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+        case 3: hipLaunchKernelGGL((k_proj_rows<3>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+        case 4: hipLaunchKernelGGL((k_proj_rows<4>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+        case 5: hipLaunchKernelGGL((k_proj_rows<5>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+        case 6: hipLaunchKernelGGL((k_proj_rows<6>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+        case 7: hipLaunchKernelGGL((k_proj_rows<7>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+        default: hipLaunchKernelGGL((k_proj_rows<8>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+      }
+    }
     if (st && st->k_stop) (void)hipEventRecord(st->k_stop, s);
     e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -405,7 +405,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
             kp = f.read()
         kp, n_sub = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) char (\w+)\[\];",
                             r"char* const \1 = (char*)hipsim::dynamic_shared();", kp)
-        assert n_sub == 1 and "extern __shared__" not in kp
+        assert n_sub == 2 and "extern __shared__" not in kp
         kp_cpp = os.path.join(out_dir, "kernels_proj_host.cpp")
         with open(kp_cpp, "w") as f:
             f.write(kp)

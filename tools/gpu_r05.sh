@@ -17,5 +17,11 @@ case $step in
   proj1b)   # the 1 B-row property + oracle tests of the Projection family
     timeout 1500 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -x -q -p no:cacheprovider -k "1b_rows" > $out/pytest.log 2>&1
     echo "pytest exit $?"; tail -8 $out/pytest.log ;;
+  projpmc)  # HBM traffic of the Projection kernel (separate passes per counter, as the guide prescribes): $3 = proj_bench args
+    for ctr in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
+      tag=$(echo $ctr | tr ' ' '_')
+      rocprofv3 --kernel-trace --pmc $ctr -d $out/pmc_$tag -o pmc -- python tools/proj_bench.py --rows 1e9 --steps 0 ${3:---sel 0.99 --cols 3} > $out/pmc_$tag.log 2>&1
+      python tools/rocpd_stats.py $out/pmc_$tag/pmc_results.db | sed -n '/PMC/,$p' | grep -E "k_proj" | tee -a $out/pmc_summary.txt
+    done ;;
   *) echo "unknown step $step"; exit 2 ;;
 esac
