@@ -306,6 +306,8 @@ struct FastArgs {
   unsigned long long* counters;
   int64_t* out;
   int32_t out16, pad_;
+  int32_t tw[MI355Q_MAX_TARGETS];        // columnar: bytes of the target's slot (8 or 4)
+  int64_t tcol_off[MI355Q_MAX_TARGETS];  // columnar: byte offset of the slot column
 };
 
 template <typename T>
@@ -346,14 +348,24 @@ MQ_D void fast_qual(const fast::RangeFilter& f, const int8_t* base, const int64_
   }
 }
 
-template <int NT>
-__global__ __launch_bounds__(kBlock) void k_proj_rows(FastArgs a, int) {
-  extern __shared__ __attribute__((aligned(16))) char s_stage[];  // per wave: 256 rows of the output, assembled before they leave
+// NT targets; COL: a columnar buffer (one run per column) instead of whole rows.  A wave stages the quads of LH lanes at a
+// time (ranks are lane-major: a run of lanes is a run of entries): all 64 while 256 staged entries fit the LDS budget of
+// four workgroups per CU, else 32.
+template <int NT, bool COL>
+__global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
+  extern __shared__ __attribute__((aligned(16))) char s_stage[];  // per wave: the entries of one step, assembled before they leave
   __shared__ uint32_t s_cnt[kIters * kWaves];   // matches of (iteration, wave); then their exclusive prefix in that order
   __shared__ long long s_bcast[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int rq = 1 + NT;
-  int64_t* const stage = (int64_t*)s_stage + (size_t)wave * 256 * rq;
+  constexpr int LH = NT > 3 ? 32 : 64;
+  constexpr int kStageRows = LH * 4;
+  char* const stage = s_stage + (size_t)wave * kStageRows * rq * 8;
+  // columnar: the stage holds the key run, then one run per target of its slot width
+  int32_t run_off[NT + 1];
+  run_off[0] = kStageRows * 8;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) run_off[t + 1] = run_off[t] + kStageRows * (COL ? a.tw[t] : 8);
 
   for (;;) {
     if (tid == 0) s_bcast[0] = (long long)atomicAdd(&a.counters[0], 1ull);
@@ -427,97 +439,123 @@ __global__ __launch_bounds__(kBlock) void k_proj_rows(FastArgs a, int) {
 #pragma unroll 1
     for (int u = 0; u < kIters; ++u) {
       const uint32_t mm = (uint32_t)(m >> (4 * u)) & 0xfu;
-      // rank of the lane's first matching row of this iteration (ballots: every lane of the wave takes part)
-      uint32_t before = 0, wave_cnt = 0;
+      // per bit plane (row i of every lane's quad): matches in lower lanes, matches in the wave (ballots: every lane takes part)
+      unsigned long long bal[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const unsigned long long bal = __ballot((mm >> b) & 1u);
-        before += __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-        wave_cnt += (uint32_t)__popcll(bal);
-      }
-      if (wave_cnt == 0) continue;  // (uniform)
-      const int64_t first = tile_base + s_cnt[u * kWaves + wave] + before;
+      for (int b = 0; b < 4; ++b) bal[b] = __ballot((mm >> b) & 1u);
+      if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0) continue;  // (uniform)
       const int64_t r = row0 + (int64_t)u * kIterRows + tid * 4;
       const bool inside = row0 + (int64_t)(u + 1) * kIterRows <= n;  // (uniform)
-      if (mm) {
       int64_t vals[NT][4];
-      if (inside) {  // every projected column of the quad first: independent 16-byte loads (a 4-byte column's quad waits,
-                     // packed, in the first two value registers)
+      if (mm) {
+        if (inside) {  // every projected column of the quad first: independent 16-byte loads (a 4-byte column's quad waits,
+                       // packed, in the first two value registers)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int8_t* base = fc[a.tcol[t]];
-          if (a.tkind[t] == 0) {
-            const v2i64 x = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2) * 2);
-            const v2i64 y = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2) * 2 + 1);
-            vals[t][0] = x.x; vals[t][1] = x.y; vals[t][2] = y.x; vals[t][3] = y.y;
-          } else {
-            const v2i64 x = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2));
-            vals[t][0] = x.x; vals[t][1] = x.y;
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (a.tkind[t] == 0) continue;
-          const int32_t x0 = (int32_t)(uint32_t)(uint64_t)vals[t][0], x1 = (int32_t)(uint32_t)((uint64_t)vals[t][0] >> 32);
-          const int32_t x2 = (int32_t)(uint32_t)(uint64_t)vals[t][1], x3 = (int32_t)(uint32_t)((uint64_t)vals[t][1] >> 32);
-          if (a.tkind[t] == 1) {
-            vals[t][0] = x0; vals[t][1] = x1; vals[t][2] = x2; vals[t][3] = x3;
-          } else {
-            vals[t][0] = dbl_bits((double)bits_flt(x0)); vals[t][1] = dbl_bits((double)bits_flt(x1));
-            vals[t][2] = dbl_bits((double)bits_flt(x2)); vals[t][3] = dbl_bits((double)bits_flt(x3));
-          }
-        }
-      } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int8_t* base = fc[a.tcol[t]];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            int64_t v = 0;
-            if ((mm >> i) & 1u) {
-              if (a.tkind[t] == 0) v = fast::load_one<int64_t>(base, r + i);
-              else {
-                const int32_t x = fast::load_one<int32_t>(base, r + i);
-                v = a.tkind[t] == 1 ? (int64_t)x : dbl_bits((double)bits_flt(x));
-              }
+          for (int t = 0; t < NT; ++t) {
+            const int8_t* base = fc[a.tcol[t]];
+            if (a.tkind[t] == 0) {
+              const v2i64 x = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2) * 2);
+              const v2i64 y = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2) * 2 + 1);
+              vals[t][0] = x.x; vals[t][1] = x.y; vals[t][2] = y.x; vals[t][3] = y.y;
+            } else {
+              const v2i64 x = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2));
+              vals[t][0] = x.x; vals[t][1] = x.y;
             }
-            vals[t][i] = v;
+          }
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            if (a.tkind[t] == 0) continue;
+            const int32_t x0 = (int32_t)(uint32_t)(uint64_t)vals[t][0], x1 = (int32_t)(uint32_t)((uint64_t)vals[t][0] >> 32);
+            const int32_t x2 = (int32_t)(uint32_t)(uint64_t)vals[t][1], x3 = (int32_t)(uint32_t)((uint64_t)vals[t][1] >> 32);
+            if (a.tkind[t] != 2) {  // INT32 sign-extended (or, in a columnar buffer, the 4 bytes as they are)
+              vals[t][0] = x0; vals[t][1] = x1; vals[t][2] = x2; vals[t][3] = x3;
+            } else {
+              vals[t][0] = dbl_bits((double)bits_flt(x0)); vals[t][1] = dbl_bits((double)bits_flt(x1));
+              vals[t][2] = dbl_bits((double)bits_flt(x2)); vals[t][3] = dbl_bits((double)bits_flt(x3));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int8_t* base = fc[a.tcol[t]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              int64_t v = 0;
+              if ((mm >> i) & 1u) {
+                if (a.tkind[t] == 0) v = fast::load_one<int64_t>(base, r + i);
+                else {
+                  const int32_t x = fast::load_one<int32_t>(base, r + i);
+                  v = a.tkind[t] != 2 ? (int64_t)x : dbl_bits((double)bits_flt(x));
+                }
+              }
+              vals[t][i] = v;
+            }
           }
         }
       }
-      // the wave's rows of this iteration, in rank order, into its LDS stage ...
-      {
-        uint32_t k = before;
+      uint32_t step_off = 0;  // matches of the wave in the earlier steps of this iteration
+#pragma unroll
+      for (int h = 0; h < 64 / LH; ++h) {
+        const unsigned long long hmask = LH == 64 ? ~0ull : (h == 0 ? 0xffffffffull : 0xffffffff00000000ull);
+        uint32_t step_cnt = 0, k = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const unsigned long long hb = bal[b] & hmask;
+          step_cnt += (uint32_t)__popcll(hb);
+          k += __builtin_amdgcn_mbcnt_hi((uint32_t)(hb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hb, 0u));
+        }
+        if (step_cnt == 0) continue;  // (uniform)
+        const bool in_step = LH == 64 || (lane >> 5) == h;
+        // the wave's entries of this step, in rank order, into its stage ...
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (!((mm >> i) & 1u)) continue;
-          int64_t* row = stage + (size_t)k * rq;
-          row[0] = r + i;
+          if (!in_step || !((mm >> i) & 1u)) continue;
+          if (!COL) {
+            int64_t* row = (int64_t*)stage + (size_t)k * rq;
+            row[0] = r + i;
 #pragma unroll
-          for (int t = 0; t < NT; ++t) row[1 + t] = vals[t][i];
+            for (int t = 0; t < NT; ++t) row[1 + t] = vals[t][i];
+          } else {
+            ((int64_t*)stage)[k] = r + i;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+              if (a.tw[t] == 8) ((int64_t*)(stage + run_off[t]))[k] = vals[t][i];
+              else ((int32_t*)(stage + run_off[t]))[k] = (int32_t)vals[t][i];
+            }
+          }
           ++k;
         }
-      }
-      }
-      (void)first;
-      // ... and out of it as one contiguous run: the wave's ranks are adjacent, so are its bytes (64 lanes x 8 / 16 bytes
-      // per store instead of one 8- / 16-byte piece per line)
-      __builtin_amdgcn_wave_barrier();
-      {
-        const int64_t wfirst = tile_base + s_cnt[u * kWaves + wave];  // rank of the wave's first row of this iteration
-        int64_t n_rows = (int64_t)wave_cnt;
+        // ... and out of it as contiguous runs: the wave's ranks are adjacent, so are its bytes (64 lanes x 8 / 16 bytes
+        // per store instead of one small piece per line)
+        __builtin_amdgcn_wave_barrier();
+        const int64_t wfirst = tile_base + s_cnt[u * kWaves + wave] + step_off;  // rank of the wave's first entry of this step
+        int64_t n_rows = (int64_t)step_cnt;
         if (wfirst + n_rows > a.entry_count) n_rows = a.entry_count > wfirst ? a.entry_count - wfirst : 0;
-        const int64_t nq = n_rows * rq;
-        int64_t* dst = a.out + wfirst * rq;
-        if ((((uintptr_t)dst) & 15) == 0) {
-          const int64_t n2 = nq >> 1;
-          for (int64_t q = lane; q < n2; q += 64) ((v2i64*)dst)[q] = ((const v2i64*)stage)[q];
-          if ((nq & 1) && lane == 0) dst[nq - 1] = stage[nq - 1];
+        if (!COL) {
+          const int64_t nq = n_rows * rq;
+          int64_t* dst = a.out + wfirst * rq;
+          if ((((uintptr_t)dst) & 15) == 0) {
+            const int64_t n2 = nq >> 1;
+            for (int64_t q = lane; q < n2; q += 64) ((v2i64*)dst)[q] = ((const v2i64*)stage)[q];
+            if ((nq & 1) && lane == 0) dst[nq - 1] = ((const int64_t*)stage)[nq - 1];
+          } else {
+            for (int64_t q = lane; q < nq; q += 64) dst[q] = ((const int64_t*)stage)[q];
+          }
         } else {
-          for (int64_t q = lane; q < nq; q += 64) dst[q] = stage[q];
+          for (int64_t q = lane; q < n_rows; q += 64) a.out[wfirst + q] = ((const int64_t*)stage)[q];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            char* col = (char*)a.out + a.tcol_off[t];
+            if (a.tw[t] == 8) {
+              for (int64_t q = lane; q < n_rows; q += 64) ((int64_t*)col)[wfirst + q] = ((const int64_t*)(stage + run_off[t]))[q];
+            } else {
+              for (int64_t q = lane; q < n_rows; q += 64) ((int32_t*)col)[wfirst + q] = ((const int32_t*)(stage + run_off[t]))[q];
+            }
+          }
         }
+        __builtin_amdgcn_wave_barrier();
+        step_off += step_cnt;
       }
-      __builtin_amdgcn_wave_barrier();
     }
   }
 }
@@ -814,7 +852,7 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
   for (int t = 0; t < ps.n_targets; ++t)
     a.fast_targets = a.fast_targets && ps.t[t].col < ps.n_phys_cols && ps.t[t].col < 31 && ((a.vec_mask >> ps.t[t].col) & 1);
   // the fast row-wise member: range quals over plain INT32 / INT64 columns, plain 4- / 8-byte targets, aligned chunks
-  bool fast_ok = !ps.columnar && !d_xs && !a.row_quals && ps.n_targets >= 1 && ps.n_targets <= 8 && tune_knobs().pass_rows != -1;
+  bool fast_ok = !d_xs && !a.row_quals && ps.n_targets >= 1 && ps.n_targets <= 8 && tune_knobs().pass_rows != -1;
   FastArgs fa{};
   for (int k = 0; k < p.n_quals && fast_ok; ++k) {
     const int c = p.quals[k].col;
@@ -828,7 +866,10 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
     fast_ok = pt.col < ps.n_phys_cols && pt.col < 31 && ((a.vec_mask >> pt.col) & 1) &&
               (pt.code == MI355Q_INT64 || pt.code == MI355Q_DOUBLE || pt.code == MI355Q_INT32 || pt.code == MI355Q_FLOAT);
     fa.tcol[t] = pt.col;
-    fa.tkind[t] = (pt.code == MI355Q_INT64 || pt.code == MI355Q_DOUBLE) ? 0 : pt.code == MI355Q_INT32 ? 1 : 2;
+    // (a columnar buffer keeps a FLOAT as its 4 bytes: the same move as an INT32)
+    fa.tkind[t] = (pt.code == MI355Q_INT64 || pt.code == MI355Q_DOUBLE) ? 0 : (pt.code == MI355Q_INT32 || ps.columnar) ? 1 : 2;
+    fa.tw[t] = ps.columnar ? pt.width : 8;
+    fa.tcol_off[t] = pt.col_off;
   }
   // the LDS image of one sub-tile (general member): every row of it may match; columnar runs are padded to 8 bytes each
   const size_t lds = fast_ok ? 0 : (size_t)a.sub_iters * kIterRows * row_bytes + (ps.columnar ? 8 * (size_t)(ps.n_targets + 1) : 0);
@@ -839,7 +880,7 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
   }
   if (tiles > 0) {
     // fast member: 256 staged rows per wave
-    const size_t fast_lds = (size_t)kWaves * 256 * (1 + ps.n_targets) * 8;
+    const size_t fast_lds = (size_t)kWaves * (ps.n_targets > 3 ? 32 : 64) * 4 * (1 + ps.n_targets) * 8;
     const int per_cu = fast_ok ? std::min<int>(4, (int)((158 * 1024) / (fast_lds + 512))) : lds <= 80 * 1024 ? 2 : 1;
     int64_t grid = (int64_t)n_cus * per_cu;
     if (tune_knobs().blocks_per_cu > 0) grid = (int64_t)n_cus * tune_knobs().blocks_per_cu;
@@ -866,22 +907,23 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
       fa.counters = counters;
       fa.out = (int64_t*)out;
       fa.out16 = a.out16;
-      static bool fast_attr_set = false;
-      if (!fast_attr_set) {  // (NT = 8: 72 KB of staging per workgroup)
-        (void)hipFuncSetAttribute((const void*)k_proj_rows<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        (void)hipFuncSetAttribute((const void*)k_proj_rows<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-        fast_attr_set = true;
-      }
+#define MQ_PROJ_FAST(N)                                                                                                   \
+  case N:                                                                                                                  \
+    if (ps.columnar) hipLaunchKernelGGL((k_proj_fast<N, true>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0);   \
+    else hipLaunchKernelGGL((k_proj_fast<N, false>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0);              \
+    break
       switch (ps.n_targets) {
-        case 1: hipLaunchKernelGGL((k_proj_rows<1>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
-        case 2: hipLaunchKernelGGL((k_proj_rows<2>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
-        case 3: hipLaunchKernelGGL((k_proj_rows<3>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
-        case 4: hipLaunchKernelGGL((k_proj_rows<4>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
-        case 5: hipLaunchKernelGGL((k_proj_rows<5>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
-        case 6: hipLaunchKernelGGL((k_proj_rows<6>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
-        case 7: hipLaunchKernelGGL((k_proj_rows<7>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
-        default: hipLaunchKernelGGL((k_proj_rows<8>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0); break;
+        MQ_PROJ_FAST(1);
+        MQ_PROJ_FAST(2);
+        MQ_PROJ_FAST(3);
+        MQ_PROJ_FAST(4);
+        MQ_PROJ_FAST(5);
+        MQ_PROJ_FAST(6);
+        MQ_PROJ_FAST(7);
+        default:
+          MQ_PROJ_FAST(8);
       }
+#undef MQ_PROJ_FAST
     }
     if (st && st->k_stop) (void)hipEventRecord(st->k_stop, s);
     e = hipGetLastError();
