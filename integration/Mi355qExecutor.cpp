@@ -157,6 +157,14 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
     for (const auto& q : *lst) where.push_back(q.get());
   translate_where(where, [&t](const Analyzer::Expr* v) { return t.value_col(v); },
                   [&t](const ExprFiller& fill) { return t.new_bool_col(fill); }, p.quals, &p.n_quals, &n_or_groups);
+  // A Projection (QueryDescriptionType::Projection): groupby_exprs is {nullptr} and no target is an aggregate — every target
+  // is then a row-wise value (a column or an expression, TargetInfo.is_agg == false) and the step emits one entry per
+  // row that passes the quals, scan_limit of them at most (GroupByAndAggregate::initQueryMemoryDescriptor :870-905 picks the
+  // description type the same way: `group_col_widths.empty() ... is_agg` -> NonGroupedAggregate, else Projection).
+  bool projection = group_exprs.empty() && !ra.target_exprs.empty();
+  for (const auto* te : ra.target_exprs) projection = projection && !dynamic_cast<const Analyzer::AggExpr*>(te);
+  if (projection && !ra.join_quals.empty()) unsupported("projection through a join");
+  p.scan_limit = projection ? (int64_t)ra.scan_limit : 0;
   // target_exprs (get_target_info, Shared/TargetInfo.h:48-56): aggregates, or projections of a group key
   for (const auto* te : ra.target_exprs) {
     if (p.n_targets >= MI355Q_MAX_TARGETS) unsupported("too many targets");
@@ -165,6 +173,9 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
     if (auto agg = dynamic_cast<const Analyzer::AggExpr*>(te)) {
       tg = translate_agg(agg, [&t](const Analyzer::Expr* v) { return t.value_col(v); },
                          [&t](const Analyzer::ColumnVar* cv) { return t.find(t.inner_cols, cv->getColumnKey()); });
+    } else if (projection) {
+      tg.agg = MI355Q_PROJECT;
+      tg.col = t.value_col(te);
     } else {
       tg.agg = MI355Q_PROJECT_KEY;
       int idx = -1;
@@ -262,7 +273,7 @@ ResultSetPtr run_query_mi355q(const RelAlgExecutionUnit& ra, const FetchResult& 
   check(mi355q_qmd_init(&plan, &qmd));
   CHECK_EQ(qmd.entry_count, (int64_t)query_mem_desc.getEntryCount());
   CHECK_EQ(qmd.row_size, (int32_t)query_mem_desc.getRowSize());
-  CHECK_EQ(qmd.slot_width, (int32_t)query_mem_desc.getCompactByteWidth());
+  if (qmd.desc_type != MI355Q_PROJECTION) CHECK_EQ(qmd.slot_width, (int32_t)query_mem_desc.getCompactByteWidth());
   CHECK_EQ(qmd.keyless != 0, query_mem_desc.hasKeylessHash());
   CHECK_EQ(qmd.output_columnar != 0, query_mem_desc.didOutputColumnar());
   CHECK_EQ(mi355q_qmd_buffer_bytes(&qmd), (int64_t)query_mem_desc.getBufferSizeBytes(ExecutorDeviceType::GPU));

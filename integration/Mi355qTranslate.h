@@ -25,10 +25,24 @@
 #include "Shared/sqltypes.h"
 #endif
 
+// The plan ABI's caps as this binding sees them.  A test build may LOWER them (-DMI355Q_GLUE_MAX_EXPR_NODES=12
+// -DMI355Q_GLUE_MAX_QUALS=4: the caps of ABI 6) so that the splitting machinery below — programs stated as several
+// expressions, conjuncts folded into a BOOLEAN expression — stays exercised by the reference's own WHERE clauses.
+#ifndef MI355Q_GLUE_MAX_EXPR_NODES
+#define MI355Q_GLUE_MAX_EXPR_NODES MI355Q_MAX_EXPR_NODES
+#endif
+#ifndef MI355Q_GLUE_MAX_QUALS
+#define MI355Q_GLUE_MAX_QUALS MI355Q_MAX_QUALS
+#endif
+static_assert(MI355Q_GLUE_MAX_EXPR_NODES <= MI355Q_MAX_EXPR_NODES && MI355Q_GLUE_MAX_QUALS <= MI355Q_MAX_QUALS, "the binding cannot exceed the ABI");
+
 namespace mi355q_glue {
+constexpr int kGlueMaxExprNodes = MI355Q_GLUE_MAX_EXPR_NODES;
+constexpr int kGlueMaxQuals = MI355Q_GLUE_MAX_QUALS;
+
 
 [[noreturn]] inline void unsupported(const char* what) { throw std::runtime_error(std::string("mi355q: ") + what); }
-// a program beyond MI355Q_MAX_EXPR_NODES: the executor half may state it as several expressions (split_plain_logic)
+// a program beyond kGlueMaxExprNodes: the executor half may state it as several expressions (split_plain_logic)
 struct ExprTooLong : std::runtime_error {
   ExprTooLong() : std::runtime_error("mi355q: expression too long") {}
 };
@@ -159,7 +173,7 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
                       const std::function<int(const Analyzer::ColumnVar*)>& outer_col,
                       const std::function<int(const Analyzer::Expr*)>* hoisted = nullptr) {
   auto push = [&](int32_t op, int32_t type, int32_t arg, int64_t ilit, double flit, int32_t null_lit = 0) {
-    if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+    if (x.n_nodes >= kGlueMaxExprNodes) throw ExprTooLong();
     x.nodes[x.n_nodes++] = mi355q_expr_node{op, type, arg, null_lit, ilit, flit};
   };
   if (hoisted) {  // a subtree the caller has stated as an earlier expression: its value
@@ -385,7 +399,7 @@ inline void hoistable_conditions(const Analyzer::Expr* e, std::vector<const Anal
   }
 }
 
-// A BOOLEAN program that does not fit MI355Q_MAX_EXPR_NODES (the reference's own `x > 6 AND x < 8 OR (z > 100 AND z < 103)`
+// A BOOLEAN program that does not fit kGlueMaxExprNodes (the reference's own `x > 6 AND x < 8 OR (z > 100 AND z < 103)`
 // has 15 nodes): the operands of a PLAIN AND / OR at its root are evaluated whatever the row holds (codegenLogical
 // :299-342 emits both), so each can be an expression of its own and the root reads their values (MI355Q_EX_COL n_cols + j).
 // Not where the short-circuit form applies: there the second operand must stay unevaluated.  `operand_col` = value_col of the
@@ -416,14 +430,14 @@ inline bool split_plain_logic(const Analyzer::Expr* e, mi355q_expr& x, const std
     bool inlined = false;
     try {
       emit_expr(ops[i], tmp, outer_col);
-      inlined = tmp.n_nodes + reserve <= MI355Q_MAX_EXPR_NODES;
+      inlined = tmp.n_nodes + reserve <= kGlueMaxExprNodes;
     } catch (const ExprTooLong&) {
     }
     if (inlined) {
       x = tmp;
     } else {
       const int c = operand_col(ops[i]);
-      if (x.n_nodes + 1 + reserve > MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+      if (x.n_nodes + 1 + reserve > kGlueMaxExprNodes) throw ExprTooLong();
       x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_COL, 0, c, 0, 0, 0.0};
     }
     if (i) x.nodes[x.n_nodes++] = mi355q_expr_node{op, MI355Q_INT8, 0, 0, 0, 0.0};
@@ -444,7 +458,7 @@ inline bool split_in_list(const Analyzer::Expr* e, mi355q_expr& x, const std::fu
   mi355q_expr probe{};
   emit_expr(in->get_arg(), probe, outer_col);
   const int per_value = probe.n_nodes + 2;                                      // the argument, the literal, EQ
-  const size_t per_run = (size_t)((MI355Q_MAX_EXPR_NODES + 1) / (per_value + 1));  // k comparisons and k - 1 ORs
+  const size_t per_run = (size_t)((kGlueMaxExprNodes + 1) / (per_value + 1));  // k comparisons and k - 1 ORs
   if (per_run < 1) return false;
   std::vector<int> runs;
   for (size_t lo = 0; lo < vals.size(); lo += per_run) {
@@ -453,14 +467,14 @@ inline bool split_in_list(const Analyzer::Expr* e, mi355q_expr& x, const std::fu
       for (size_t k = lo; k < hi; ++k) {
         emit_expr(in->get_arg(), c, oc);
         emit_expr(vals[k], c, oc);
-        if (c.n_nodes + 1 + (k > lo ? 1 : 0) > MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+        if (c.n_nodes + 1 + (k > lo ? 1 : 0) > kGlueMaxExprNodes) throw ExprTooLong();
         c.nodes[c.n_nodes++] = mi355q_expr_node{MI355Q_EX_EQ, MI355Q_INT8, 0, 0, 0, 0.0};
         if (k > lo) c.nodes[c.n_nodes++] = mi355q_expr_node{MI355Q_EX_OR, MI355Q_INT8, 0, 0, 0, 0.0};
       }
     }));
   }
   x = mi355q_expr{};
-  if ((int)runs.size() * 2 - 1 + (negated ? 1 : 0) > MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+  if ((int)runs.size() * 2 - 1 + (negated ? 1 : 0) > kGlueMaxExprNodes) throw ExprTooLong();
   for (size_t j = 0; j < runs.size(); ++j) {
     x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_COL, 0, runs[j], 0, 0, 0.0};
     if (j) x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_OR, MI355Q_INT8, 0, 0, 0, 0.0};
@@ -527,7 +541,7 @@ inline void emit_disjunction(const Analyzer::Expr* e, const std::function<int(co
       if (ti.get_type() == kDOUBLE) qi.fval = d.doubleval;
       else if (ti.get_type() == kFLOAT) qi.fval = d.floatval;
       else qi.ival = int_literal(ti, d);
-      if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
+      if (*n_quals >= kGlueMaxQuals) unsupported("too many quals");
       qi.op = MI355Q_QUAL_IN_OR_GROUP(MI355Q_EQ, group);
       quals[(*n_quals)++] = qi;
     }
@@ -549,16 +563,16 @@ inline void emit_disjunction(const Analyzer::Expr* e, const std::function<int(co
   } else {
     q = translate_qual(e, value_col);
   }
-  if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
+  if (*n_quals >= kGlueMaxQuals) unsupported("too many quals");
   q.op = MI355Q_QUAL_IN_OR_GROUP(q.op, group);
   quals[(*n_quals)++] = q;
 }
 
 // One conjunct -> plan quals: a top-level AND splits; a comparison is one qual; a disjunction of comparisons is a group of
-// quals while the plan has room (MI355Q_MAX_QUALS, MI355Q_MAX_OR_GROUPS).  Every other BOOLEAN conjunct — AND inside OR, NOT
+// quals while the plan has room (kGlueMaxQuals, MI355Q_MAX_OR_GROUPS).  Every other BOOLEAN conjunct — AND inside OR, NOT
 // over a disjunction, one disjunction too many — is ONE projected expression (the NOT / AND / OR / IS NULL micro-ops over its
 // comparisons) and the qual `that column = 1`: TRUE; a NULL is not (toBool, LogicalIR.cpp:344-352).  What the plan cannot
-// state either way (a program beyond MI355Q_MAX_EXPR_NODES, an expression kind outside the micro-ops) is refused by emit_expr.
+// state either way (a program beyond kGlueMaxExprNodes, an expression kind outside the micro-ops) is refused by emit_expr.
 inline void translate_conjunct(const Analyzer::Expr* e, const std::function<int(const Analyzer::Expr*)>& value_col,
                                mi355q_qual* quals, int32_t* n_quals, int32_t* n_groups) {
   auto b = dynamic_cast<const Analyzer::BinOper*>(e);
@@ -572,12 +586,12 @@ inline void translate_conjunct(const Analyzer::Expr* e, const std::function<int(
     emit_disjunction(e, value_col, quals, n_quals, 0);
     return;
   }
-  if (m > 1 && *n_quals + m <= MI355Q_MAX_QUALS && *n_groups < MI355Q_MAX_OR_GROUPS) {
+  if (m > 1 && *n_quals + m <= kGlueMaxQuals && *n_groups < MI355Q_MAX_OR_GROUPS) {
     emit_disjunction(e, value_col, quals, n_quals, ++*n_groups);
     return;
   }
   if (!e->get_type_info().is_boolean()) unsupported("qual shape");
-  if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
+  if (*n_quals >= kGlueMaxQuals) unsupported("too many quals");
   mi355q_qual q{};
   q.col = value_col(e);
   q.op = MI355Q_EQ;
@@ -619,8 +633,8 @@ inline void translate_where(const std::vector<const Analyzer::Expr*>& where, con
     int total = *n_quals;
     for (const Analyzer::Expr* e : primary) total += needs(e);
     size_t i = 0;
-    if (total > MI355Q_MAX_QUALS)
-      for (int used = *n_quals; i < primary.size() && used + needs(primary[i]) <= MI355Q_MAX_QUALS - 1; ++i) used += needs(primary[i]);
+    if (total > kGlueMaxQuals)
+      for (int used = *n_quals; i < primary.size() && used + needs(primary[i]) <= kGlueMaxQuals - 1; ++i) used += needs(primary[i]);
     else
       i = primary.size();
     for (size_t k = 0; k < i; ++k) translate_conjunct(primary[k], value_col, quals, n_quals, n_groups);
@@ -629,7 +643,7 @@ inline void translate_where(const std::vector<const Analyzer::Expr*>& where, con
   }
   const int col = new_bool_col([&](mi355q_expr& x, const OuterCol& outer_col) {
     auto push_and = [&](int32_t short_circuit) {
-      if (x.n_nodes >= MI355Q_MAX_EXPR_NODES) throw ExprTooLong();
+      if (x.n_nodes >= kGlueMaxExprNodes) throw ExprTooLong();
       x.nodes[x.n_nodes++] = mi355q_expr_node{MI355Q_EX_AND, MI355Q_INT8, 0, short_circuit, 0, 0.0};
     };
     int n = 0;
@@ -644,7 +658,7 @@ inline void translate_where(const std::vector<const Analyzer::Expr*>& where, con
       if (n++) push_and(1);
     }
   });
-  if (*n_quals >= MI355Q_MAX_QUALS) unsupported("too many quals");
+  if (*n_quals >= kGlueMaxQuals) unsupported("too many quals");
   mi355q_qual q{};
   q.col = col;
   q.op = MI355Q_EQ;

@@ -81,6 +81,12 @@ std::shared_ptr<Analyzer::Constant> int_lit(SQLTypes t, int64_t v) {
   return std::make_shared<Analyzer::Constant>(SQLTypeInfo(t, true), false, d);
 }
 
+std::shared_ptr<Analyzer::Constant> dbl_lit(double v) {
+  Datum d{};
+  d.doubleval = v;
+  return std::make_shared<Analyzer::Constant>(SQLTypeInfo(kDOUBLE, true), false, d);
+}
+
 // two fragments per column (16-byte aligned split), as fetchChunks would hand them over
 FetchResult fetch(const Table& t, const std::vector<int>& cols, std::vector<int64_t>* frag_rows) {
   const int64_t cut = (t.n_rows / 3) / 4 * 4;
@@ -199,7 +205,8 @@ void compare_plans(const mi355q_plan& a, const mi355q_plan& b) {
                a.exprs[k].range.fp_min == b.exprs[k].range.fp_min && a.exprs[k].range.fp_max == b.exprs[k].range.fp_max, "plan: expression range");
   }
   expect(a.join_outer_col == b.join_outer_col && a.join_kind == b.join_kind && a.n_join_cols == b.n_join_cols, "plan: join");
-  expect(a.max_groups_buffer_entry_guess == b.max_groups_buffer_entry_guess && a.num_tuples == b.num_tuples, "plan: options");
+  expect(a.max_groups_buffer_entry_guess == b.max_groups_buffer_entry_guess && a.num_tuples == b.num_tuples && a.scan_limit == b.scan_limit,
+         "plan: options");
 }
 
 }  // namespace
@@ -488,6 +495,63 @@ int main() {
     }
     expect(thrown, "out of slots must surface as QueryExecutionError (negative code or 3)");
   }
+  // ---------------------------------------------------------------- query 5: a Projection (row-emitting filter / project)
+  //   SELECT key, f64 * 2.0, x FROM t WHERE i32 < 2^27 [LIMIT 1000]  — groupby_exprs {nullptr}, no aggregate among the targets
+  for (const size_t limit : {(size_t)0, (size_t)1000}) {
+    std::printf("query 5: SELECT key, f64 * 2.0, x FROM t WHERE i32 < 134217728%s\n", limit ? " LIMIT 1000" : "");
+    RelAlgExecutionUnit ra;
+    for (int c : {0, 1, 2, 3}) ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(c, kTable, kDb, 0));
+    auto key = colvar(t, kTable, 0), f64 = colvar(t, kTable, 1), i32 = colvar(t, kTable, 2), x = colvar(t, kTable, 3);
+    ra.simple_quals.push_back(std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kBOOLEAN, true), kLT, i32, int_lit(kINT, 1 << 27)));
+    ra.groupby_exprs.push_back(nullptr);
+    auto twice = std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kDOUBLE, true), kMULTIPLY, f64, dbl_lit(2.0));
+    ra.target_exprs = {key.get(), twice.get(), x.get()};
+    ra.scan_limit = limit;
+    const size_t guess = (size_t)(N / 8);  // (what the COUNT(*) pre-flight would say, with room: 1/16 of the rows match)
+    mi355q_plan hp{};
+    hp.abi_version = MI355Q_ABI_VERSION;
+    hp.n_cols = 4;
+    hp.cols[0] = {MI355Q_INT64, 0, 0, 0};
+    hp.cols[1] = {MI355Q_DOUBLE, 0, 0, 0};
+    hp.cols[2] = {MI355Q_INT32, 0, 0, 0};
+    hp.cols[3] = {MI355Q_INT32, 1, 0, 0};
+    hp.col_ranges[0] = {1, 0, 7, key_max, 0, 0, 0};
+    hp.col_ranges[1] = {1, 0, 0, 0, 0.0, 1000.0, 0};
+    hp.col_ranges[2] = {1, 0, 0, INT32_MAX, 0, 0, 0};
+    hp.col_ranges[3] = {1, 0, 1, 40, 0, 0, 0};
+    hp.n_quals = 1;
+    hp.quals[0] = {2, MI355Q_LT, 1 << 27, 0.0};
+    hp.n_exprs = 1;
+    hp.exprs[0].n_nodes = 3;
+    hp.exprs[0].nodes[0] = {MI355Q_EX_COL, 0, 1, 0, 0, 0.0};
+    hp.exprs[0].nodes[1] = {MI355Q_EX_LIT, MI355Q_DOUBLE, 0, 0, 0, 2.0};
+    hp.exprs[0].nodes[2] = {MI355Q_EX_MUL, MI355Q_DOUBLE, 0, 0, 0, 0.0};
+    hp.exprs[0].range = {1, 0, 0, 0, 0.0, 2000.0, 0};
+    hp.n_targets = 3;
+    hp.targets[0] = {MI355Q_PROJECT, 0, 0, 0, {}};
+    hp.targets[1] = {MI355Q_PROJECT, 4, 0, 0, {}};
+    hp.targets[2] = {MI355Q_PROJECT, 3, 0, 0, {}};
+    hp.join_outer_col = -1;
+    hp.max_groups_buffer_entry_guess = (int64_t)guess;
+    hp.num_tuples = N;
+    hp.scan_limit = (int64_t)limit;
+    compare_plans(hp, mi355q_glue::to_plan(ra, query_infos, &executor, nullptr, guess, false));
+    std::vector<int64_t> frag_rows;
+    const FetchResult fr = fetch(t, {0, 1, 2, 3}, &frag_rows);
+    mi355q_qmd q;
+    const std::vector<int64_t> want = oracle_table(hp, t, {0, 1, 2, 3}, frag_rows, nullptr, {}, 0, &q);
+    const std::string route = mi355q_glue::explain_query_mi355q(ra, query_infos, &executor, 0, guess, nullptr, 0, false);
+    std::printf("  %s\n", route.c_str());
+    expect(route.find("k_proj_compact") != std::string::npos, "a projection plans the compaction family");
+    const ResultSetPtr rs = mi355q_glue::run_query_mi355q(ra, fr, query_infos, qmd_of(q), &executor, 0, guess, nullptr, {}, 0);
+    expect(q.desc_type == MI355Q_PROJECTION && q.entry_count == (int64_t)(limit ? limit : guess) && q.row_size == 32, "layout");
+    // the whole ResultSetStorage image, entry by entry: same rows in the same (fragment, row) order, EMPTY_KEY_64 tail
+    const int64_t* got = (const int64_t*)const_cast<ResultSetStorage*>(rs->getStorage())->getUnderlyingBuffer();
+    bool same = true;
+    for (size_t i = 0; i < want.size() && same; ++i) same = want[i] == got[i];
+    expect(same, "projection buffer differs from the oracle's");
+  }
+
   std::printf(g_failures ? "glue_check: %d FAILURE(S)\n" : "glue_check: all queries agree with the oracle\n", g_failures);
   return g_failures ? 1 : 0;
 }

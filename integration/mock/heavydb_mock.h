@@ -230,6 +230,7 @@ struct RelAlgExecutionUnit {
   JoinQualsPerNestingLevel join_quals;
   std::list<std::shared_ptr<Analyzer::Expr>> groupby_exprs;  // {nullptr}: non-grouped
   std::vector<Analyzer::Expr*> target_exprs;
+  size_t scan_limit{0};  // (RelAlgExecutionUnit.h:178) LIMIT + OFFSET of a projection without ORDER BY
 };
 
 struct FetchResultFragmentInfo {

@@ -147,7 +147,8 @@ int main() {
 
 def test_mock_reference_where_clauses_through_to_plan():
     """The executor half (to_plan, on the mock) on WHERE clauses of the reference's own Select.FilterAndSimpleAggregation
-    (Tests/ExecuteTest.cpp:1906-1913, :2021) that have no qual shape: AND inside OR becomes BOOLEAN expressions — split over
+    (Tests/ExecuteTest.cpp:1906-1913, :2021) that have no qual shape — compiled with the binding's caps LOWERED to ABI 6's (12 nodes,
+    4 quals) so that the splitting machinery keeps running on them: AND inside OR becomes BOOLEAN expressions — split over
     several where the program passes 12 nodes, the root reading the values of the earlier ones — and a conjunct with an unsafe
     division is the second operand of a short-circuit AND behind the other conjuncts (the reference defers such quals)."""
     import tempfile
@@ -319,6 +320,88 @@ int main() {
     bool deep_refused = false;
     try { check_expr_stack(nine); } catch (const std::runtime_error&) { deep_refused = true; }
     REQ(deep_refused);
+  }
+  std::printf(bad ? "bad\\n" : "ok\\n");
+  return bad ? 1 : 0;
+}
+''')
+        exe = os.path.join(d, "t")
+        integ = os.path.join(ROOT, "integration")
+        r = subprocess.run(["g++", "-std=c++17", "-Wall", "-DMI355Q_GLUE_MOCK_HEADERS", "-DMI355Q_GLUE_MAX_EXPR_NODES=12", "-DMI355Q_GLUE_MAX_QUALS=4", "-I" + integ, "-I" + os.path.join(ROOT, "include"),
+                            src, os.path.join(integ, "Mi355qExecutor.cpp"), os.path.join(integ, "mock", "heavydb_mock.cpp"),
+                            "-L" + os.path.join(ROOT, "heavydb_amd", "lib"), "-lmi355q", "-Wl,-rpath," + os.path.join(ROOT, "heavydb_amd", "lib"),
+                            "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        run = subprocess.run([exe], capture_output=True, text=True)
+        assert run.returncode == 0, run.stdout + run.stderr
+
+
+def test_abi7_caps_state_the_reference_where_clauses_whole():
+    """With ABI 7's caps (8 quals, 8 expressions x 24 nodes) the WHERE clauses the binding had to split under ABI 6 are stated
+    whole: `x > 6 AND x < 8 OR (z > 100 AND z < 103)` (ExecuteTest.cpp:1911) is ONE 15-node expression, the six conjuncts of :1907 are
+    six plain quals (no expression, every fast family stays eligible), and a projection (no GROUP BY, no aggregate) maps to
+    MI355Q_PROJECT targets with the unit's scan_limit."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.cpp")
+        with open(src, "w") as f:
+            f.write('''#include "Mi355qExecutor.h"
+#include <cstdio>
+using namespace mi355q_glue;
+using Analyzer::BinOper;
+static int bad = 0;
+#define REQ(c) do { if (!(c)) { std::printf("line %d: %s\\n", __LINE__, #c); ++bad; } } while (0)
+int main() {
+  const int kDb = 1, kTable = 7;
+  Executor executor;
+  const SQLTypeInfo ti[4] = {SQLTypeInfo(kINT, true), SQLTypeInfo(kINT, false), SQLTypeInfo(kSMALLINT, false), SQLTypeInfo(kBIGINT, false)};
+  for (int c = 0; c < 4; ++c) {
+    executor.column_types[{kTable, c}] = ti[c];
+    executor.column_ranges[{kTable, c}] = ExpressionRange::makeIntRange(-100, 2000, 0, c != 0);
+  }
+  const std::vector<InputTableInfo> query_infos = {{shared::TableKey{kDb, kTable}, 20}};
+  auto col = [&](int c) { return std::make_shared<Analyzer::ColumnVar>(ti[c], shared::ColumnKey{kDb, kTable, c}, 0); };
+  auto lit = [&](int c, int64_t v) {
+    Datum dv;
+    if (c == 2) dv.smallintval = (int16_t)v; else if (c == 3) dv.bigintval = v; else dv.intval = (int32_t)v;
+    return std::make_shared<Analyzer::Constant>(SQLTypeInfo(ti[c].get_type(), true), false, dv);
+  };
+  const SQLTypeInfo tb(kBOOLEAN, false);
+  auto cmp = [&](SQLOps op, int c, int64_t v) { return std::make_shared<BinOper>(tb, op, col(c), lit(c, v)); };
+  auto band = [&](int c, int64_t lo, int64_t hi) { return std::make_shared<BinOper>(tb, kAND, cmp(kGT, c, lo), cmp(kLT, c, hi)); };
+  Analyzer::AggExpr cnt(SQLTypeInfo(kBIGINT, true), kCOUNT, nullptr);
+  auto unit = [&]() {
+    RelAlgExecutionUnit ra;
+    for (int c = 0; c < 4; ++c) ra.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(c, kTable, kDb, 0));
+    ra.groupby_exprs.push_back(nullptr);
+    ra.target_exprs = {&cnt};
+    return ra;
+  };
+  {
+    RelAlgExecutionUnit ra = unit();
+    ra.quals.push_back(std::make_shared<BinOper>(tb, kOR, band(0, 6, 8), band(2, 100, 103)));
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 1 && p.quals[0].col == 4 && p.quals[0].op == MI355Q_EQ && p.quals[0].ival == 1 && p.n_exprs == 1);
+    REQ(p.exprs[0].n_nodes == 15 && p.exprs[0].nodes[14].op == MI355Q_EX_OR);
+  }
+  {
+    RelAlgExecutionUnit ra = unit();
+    ra.simple_quals = {cmp(kGT, 0, 6), cmp(kLT, 0, 8), cmp(kGT, 2, 100), cmp(kLT, 2, 102), cmp(kGT, 3, 1000), cmp(kLT, 3, 1002)};
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_quals == 6 && p.n_exprs == 0 && p.quals[5].col == 3 && p.quals[5].op == MI355Q_LT && p.quals[5].ival == 1002);
+  }
+  {  // SELECT x, y + 1 FROM t WHERE z > 100 LIMIT 10
+    RelAlgExecutionUnit ra = unit();
+    auto x = col(0);
+    auto y1 = std::make_shared<BinOper>(ti[1], kPLUS, col(1), lit(1, 1));
+    ra.target_exprs = {x.get(), y1.get()};
+    ra.simple_quals = {cmp(kGT, 2, 100)};
+    ra.scan_limit = 10;
+    const mi355q_plan p = to_plan(ra, query_infos, &executor, nullptr, 16384, false);
+    REQ(p.n_targets == 2 && p.targets[0].agg == MI355Q_PROJECT && p.targets[0].col == 0 && p.targets[1].agg == MI355Q_PROJECT &&
+        p.targets[1].col == 4 && p.n_exprs == 1 && p.exprs[0].n_nodes == 3 && p.scan_limit == 10 && p.n_group_cols == 0);
+    mi355q_qmd q;
+    REQ(mi355q_qmd_init(&p, &q) == 0 && q.desc_type == MI355Q_PROJECTION && q.entry_count == 10 && q.row_size == 24);
   }
   std::printf(bad ? "bad\\n" : "ok\\n");
   return bad ? 1 : 0;
