@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "api_internal.h"
+#include "boolfilter.h"
 
 using namespace mq;
 
@@ -242,6 +243,8 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   if (ctx.lattice) (void)hipFree(ctx.lattice);
   ctx.lattice = nullptr;
   ctx.lattice_bytes = 0;
+  if (ctx.bf_table) (void)hipFree(ctx.bf_table);
+  ctx.bf_table = nullptr;
   if (ctx.projws) (void)hipFree(ctx.projws);
   ctx.projws = nullptr;
   ctx.projws_bytes = 0;
@@ -2761,6 +2764,43 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     k.overlap_cus = o.tune_overlap_cus;
     set_tune_knobs(k);
   }
+  if (plan->n_exprs != 0 && !pend && !step_bool_filter() && !o.force_generic) {
+    // A filter of comparisons with literals under AND / OR / NOT is compiled into atoms + a truth table and evaluated by
+    // the consuming kernel on the values it holds in registers (boolfilter.h): no temporary column, no second pass.
+    BoolFilterHost bfh;
+    mi355q_plan rest;
+    if (compile_bool_filter(*plan, &bfh, &rest)) {
+      const size_t mark = t_route ? t_route->size() : 0;
+      int32_t e = kNotTaken;
+      {
+        DeviceGuard gb(in->device_id);
+        DeviceCtx& cb = ctx_of(in->device_id);
+        std::lock_guard<std::recursive_mutex> lb(cb.mu);
+        bool have = true;
+        if (!t_plan_only) {
+          if (!cb.bf_table) have = gb.ok && hipMalloc(&cb.bf_table, sizeof(BoolFilter)) == hipSuccess;
+          // (a synchronous copy out of this frame: atoms + truth table, 1.2 KB)
+          have = have && hipMemcpy(cb.bf_table, &bfh.bf, sizeof(BoolFilter), hipMemcpyHostToDevice) == hipSuccess;
+        }
+        if (have) {
+          struct BfScope {
+            BfScope(const BoolFilter* b, const BoolFilter* d) { set_step_bool_filter(b, d); }
+            ~BfScope() { set_step_bool_filter(nullptr, nullptr); }
+          } scope(&bfh.bf, (const BoolFilter*)cb.bf_table);
+          route_note("filter compiled (atoms + truth table)");
+          e = execute_impl(&rest, in, &o, out, report, nullptr, reserved);
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+      if (e != kNotTaken) {
+        if (e == MI355Q_OK && report && !reserved) report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+        return e;
+      }
+      if (t_route) t_route->resize(mark);
+      *out = nullptr;
+    }
+  }
   if (plan->n_exprs != 0) {
     {  // a Projection evaluates its expressions in the compaction kernel's registers: no k_project pass
       bool proj = plan->n_targets > 0;
@@ -2792,6 +2832,10 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   DevPlan d;
   if (int32_t e = build_dev_plan(*plan, q, &d)) return e;
   if (int32_t e = attach_join(*plan, in, &d)) return e;
+  // a compiled filter travels beside the plan (its quals are gone): only the families that take one may run the step —
+  // no derived plans, no row kernel; kNotTaken sends the caller back to the projection pass
+  d.bf_active = step_bool_filter() != nullptr;
+  const bool bf_step = d.bf_active != 0;
 
   DeviceGuard g(in->device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
@@ -2900,7 +2944,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     if (!lds_direct && !pend && d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && (tr >= kIdxPartMinRows || o.kernel_variant == 2))
       lds_direct = idx_direct = idx_part_eligible(d, fvh, n_cus);
   }
-  if (!o.force_generic && in->n_frags > 0 && !pend && plan->join_outer_col >= 0) {
+  if (bf_step && (!lds_direct || idx_direct || in->n_frags <= 0)) return kNotTaken;
+  if (!o.force_generic && in->n_frags > 0 && !pend && plan->join_outer_col >= 0 && !bf_step) {
     const size_t mark = t_route ? t_route->size() : 0;
     const int32_t e = execute_join_gather(plan, in, o, q, d, n_cus, out, report, reserved);
     if (e != kNotTaken) return e;
@@ -3015,7 +3060,9 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   // ---- plan-time kernel selection (a fixed family; no JIT)
   StepKind kind = K_GENERIC;
   JoinPayloadView pay{};
-  if (!o.force_generic && nf > 0) {
+  if (bf_step) {
+    if (!o.force_generic && nf > 0 && o.kernel_variant == 0 && lds_groupby_eligible(d, fv, n_cus)) kind = K_LDS_GROUPBY;
+  } else if (!o.force_generic && nf > 0) {
     if (scan_count_eligible(d, fv)) kind = K_SCAN_COUNT;
     else if (o.kernel_variant != 1 && scan_agg_eligible(d, fv)) kind = K_SCAN_AGG;
     else if (perfect_lds_eligible(d, fv)) kind = K_PERFECT_LDS;
@@ -3146,6 +3193,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     }
   }
 
+  if (bf_step && kind != K_LDS_GROUPBY) return kNotTaken;
   tr.mark("setup done");
   int64_t scratch_bytes = 0;
   int64_t scratch_cap = o.scratch_bytes;

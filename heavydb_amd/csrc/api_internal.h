@@ -111,6 +111,7 @@ struct DeviceCtx {
   int64_t gather_bytes = 0;
   void* lattice = nullptr;  // dense INT32 key columns of a lattice-keyed step (execute_affine_twin; may nest inside both)
   int64_t lattice_bytes = 0;
+  void* bf_table = nullptr; // a compiled filter in device memory (boolfilter.h BoolFilter: atoms + truth table)
   void* projws = nullptr;   // Projection family: lowered expressions, ticket / total counters, tile table, tile descriptors
   int64_t projws_bytes = 0;
   void* scratch = nullptr;

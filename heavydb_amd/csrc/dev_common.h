@@ -288,6 +288,9 @@ struct DevPlan {
   // the key column and writes the (translated) key into a slot that still holds the init value before the
   // aggregate runs — per kernel and in row order that is MIN(key, values); applied here as one more MIN
   int32_t col0_key_quirk;
+  // the step's filter is NOT in quals[] (n_quals = 0) but a BoolFilter compiled at plan time (boolfilter.h), handed to the
+  // kernel beside the plan: only families that take one may run the step
+  int32_t bf_active;
   const int8_t* inner_cols[MI355Q_MAX_COLS];
 };
 

@@ -43,6 +43,12 @@ struct TuneKnobs {
 };
 const TuneKnobs& tune_knobs();
 void set_tune_knobs(const TuneKnobs& k);
+// the compiled filter of the step being planned / launched on this thread (boolfilter.h; table already in device memory),
+// or null: the step's filter is its plan's quals
+struct BoolFilter;
+const BoolFilter* step_bool_filter();      // the host copy (columns, atom counts: what eligibility looks at)
+const BoolFilter* step_bool_filter_dev();  // the same filter in device memory (what a kernel is handed)
+void set_step_bool_filter(const BoolFilter* bf, const BoolFilter* dev);
 
 // ---- generic family (kernels_generic.hip)
 hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,

@@ -1210,6 +1210,14 @@ inline int grid_for(int64_t work_items, int max_blocks = 2048) {
 static thread_local TuneKnobs g_knobs;
 const TuneKnobs& tune_knobs() { return g_knobs; }
 void set_tune_knobs(const TuneKnobs& k) { g_knobs = k; }
+static thread_local const BoolFilter* t_step_bf = nullptr;
+static thread_local const BoolFilter* t_step_bf_dev = nullptr;
+const BoolFilter* step_bool_filter() { return t_step_bf; }
+const BoolFilter* step_bool_filter_dev() { return t_step_bf_dev; }
+void set_step_bool_filter(const BoolFilter* bf, const BoolFilter* dev) {
+  t_step_bf = bf;
+  t_step_bf_dev = dev;
+}
 
 hipError_t launch_init_buffer(int64_t* buf, int64_t entry_count, const RowInit& init,
                               hipStream_t s) {

@@ -177,7 +177,9 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
                                                             LdsArgs a, DevPlan p, int64_t* __restrict__ out,
                                                             int32_t* __restrict__ d_err) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ BoolFilter s_bf;  // the compiled filter: atoms + truth table (a.bf_on)
   const int t = threadIdx.x;
+  if (a.bf_on) bf_load(a.bf, &s_bf, t, kLdsBlock);  // (visible after the barrier behind the replicas' initialisation)
   const uint32_t K = 1u << a.copies_lg;
   const uint32_t ne = a.entries;
   // windows: this workgroup's window, its row stripe and the number of stripes (T = 1: the whole table, every workgroup a stripe)
@@ -301,11 +303,18 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           bool pass = true;
+          if (NF > 0 && a.bf_on) {  // atoms on the filter columns' values + one bit of the truth table
+            int64_t fval[NF > 0 ? NF : 1];
 #pragma unroll
-          for (int k = 0; k < NF; ++k) {
-            if (k >= a.n_flt) break;
-            pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], rawq_i32(fr[k][u], i))
-                                                          : filter_pass<int64_t>(a.flt[k], rawq_i64(fr[k][u], i)));
+            for (int k = 0; k < NF; ++k) fval[k] = k < a.n_flt ? rawq_int(fr[k][u], a.flt_type[k], i) : 0;
+            pass = bf_row_passes<(NF > 0 ? NF : 1)>(s_bf, fval);
+          } else {
+#pragma unroll
+            for (int k = 0; k < NF; ++k) {
+              if (k >= a.n_flt) break;
+              pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], rawq_i32(fr[k][u], i))
+                                                            : filter_pass<int64_t>(a.flt[k], rawq_i64(fr[k][u], i)));
+            }
           }
           if (!pass) continue;
           int64_t kv[NK], vv[NV];
@@ -328,11 +337,19 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
     const int64_t tail = (nq << 2) + gtid;
     if (tail < n) {
       bool pass = true;
+      if (NF > 0 && a.bf_on) {
+        int64_t fval[NF > 0 ? NF : 1];
 #pragma unroll
-      for (int k = 0; k < NF; ++k) {
-        if (k >= a.n_flt) break;
-        pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], load_one<int32_t>(fb[k], tail))
-                                                      : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fb[k], tail)));
+        for (int k = 0; k < NF; ++k)
+          fval[k] = k >= a.n_flt ? 0 : a.flt_type[k] == MI355Q_INT32 ? (int64_t)load_one<int32_t>(fb[k], tail) : load_one<int64_t>(fb[k], tail);
+        pass = bf_row_passes<(NF > 0 ? NF : 1)>(s_bf, fval);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          if (k >= a.n_flt) break;
+          pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], load_one<int32_t>(fb[k], tail))
+                                                        : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fb[k], tail)));
+        }
       }
       if (pass) {
         int64_t kv[NK], vv[NV];

@@ -4,6 +4,7 @@
 
 #include <cstring>
 
+#include "boolfilter.h"
 #include "fast_common.h"
 
 namespace mq {
@@ -39,6 +40,9 @@ struct LdsArgs {
   int32_t typed, mm;
   uint32_t xcd_aware;                    // windows: stripe-mates on one XCD (lds_window_map); set by the launcher
   uint32_t t_off_keys, t_off_sum, t_off_rows, t_off_cnt, t_off_min, t_off_max;
+  // a filter compiled at plan time (boolfilter.h) instead of range quals: flt[k].col / flt_type[k] name its columns
+  int32_t bf_on, pad_bf_;
+  const BoolFilter* bf;                  // DEVICE memory
 };
 
 
@@ -58,6 +62,19 @@ inline bool lds_describe(const DevPlan& p, const FragView& fv, int64_t max_entri
     if (!all_aligned16(fv, p.quals[i].col)) return false;
   }
   a.n_flt = p.n_quals;
+  if (p.bf_active) {  // the compiled filter's columns take the filter slots
+    const BoolFilter* bf = step_bool_filter();
+    if (!bf || p.n_quals != 0 || bf->n_cols > 4) return false;
+    for (int k = 0; k < bf->n_cols; ++k) {
+      if (!all_aligned16(fv, bf->col[k])) return false;
+      a.flt[k] = no_filter();
+      a.flt[k].col = bf->col[k];
+      a.flt_type[k] = bf->col_type[k];
+    }
+    a.n_flt = bf->n_cols;
+    a.bf_on = 1;
+    a.bf = step_bool_filter_dev();
+  }
   // keys
   if (p.desc_type == MI355Q_GROUP_BY_PERFECT_HASH) {
     if (p.n_group < 1 || p.n_group > kLdsKeys || p.entry_count < 1 || p.entry_count > max_entries) return false;

@@ -2625,6 +2625,15 @@ ORC_EXPORT int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in,
   return 0;
 }
 
+// the projection runtime on a caller's buffer (golden vectors): the quad index of the slots / the offset, -1 when full
+ORC_EXPORT int64_t orc_get_scan_output_slot(int64_t* buf, uint32_t entry_count, uint32_t pos, int64_t offset_in_fragment,
+                                            uint32_t row_size_quad) {
+  int64_t* p = get_scan_output_slot(buf, entry_count, pos, offset_in_fragment, row_size_quad);
+  return p ? p - buf : -1;
+}
+ORC_EXPORT int32_t orc_get_columnar_scan_output_offset(int64_t* buf, uint32_t entry_count, uint32_t pos, int64_t offset_in_fragment) {
+  return get_columnar_scan_output_offset(buf, entry_count, pos, offset_in_fragment);
+}
 // get_group_value_columnar_slot on a columnar buffer's key columns: the bin, or -1 when full
 ORC_EXPORT int32_t orc_get_group_value_columnar_slot(int64_t* buf, uint32_t entry_count, const int64_t* key,
                                                      uint32_t key_count) {

@@ -364,7 +364,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
     real_srcs = ["kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_idx.hip", "fast_common.h", "lds_args.h"] if real_fast else []
     deps = [os.path.join(src_dir, f) for f in ("hip_host.cpp", "kernels_host.cpp", "shim/hip/hip_runtime.h",
                                                "shim/hip/hip_runtime_api.h")] + \
-        [os.path.join(csrc, f) for f in ["api.cpp", "api_projection.cpp", "api_internal.h", "plan.cpp", "kernels_generic.hip",
+        [os.path.join(csrc, f) for f in ["api.cpp", "api_projection.cpp", "api_internal.h", "boolfilter.cpp", "boolfilter.h", "plan.cpp", "kernels_generic.hip",
                                          "kernels_proj.hip", "kernels.h", "rowfunc.h", "dev_common.h", "plan.h", "expr.h",
                                          "fast_common.h"] + real_srcs] + \
         [os.path.join(ROOT, "include", "mi355q.h"), os.path.abspath(__file__)]   # (the build recipe patches the sources)
@@ -397,7 +397,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
             f.write("".join(f'    "{n}",\n' for n in names))
         with open(os.path.join(out_dir, "plain_kernels.inc"), "w") as f:
             f.write("".join(f'    "{n}",\n' for n in plain))
-        flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-w", "-I" + os.path.join(src_dir, "shim"), "-I" + csrc,
+        flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-w", "-DHOSTSIM_DEVICE_CODE", "-I" + os.path.join(src_dir, "shim"), "-I" + csrc,
                  "-I" + os.path.join(ROOT, "include"), "-I" + out_dir]
         # the Projection family (kernels_proj.hip) is the real device source in BOTH simulations: its workgroups take tiles
         # off a ticket counter, so a tile's predecessors are always finished when blocks run one after the other
@@ -409,7 +409,8 @@ def hostsim_lib(real_fast: bool = False) -> str:
         kp_cpp = os.path.join(out_dir, "kernels_proj_host.cpp")
         with open(kp_cpp, "w") as f:
             f.write(kp)
-        srcs = [os.path.join(csrc, "api.cpp"), os.path.join(csrc, "api_projection.cpp"), os.path.join(csrc, "plan.cpp"), kg_cpp,
+        srcs = [os.path.join(csrc, "api.cpp"), os.path.join(csrc, "api_projection.cpp"), os.path.join(csrc, "boolfilter.cpp"),
+                os.path.join(csrc, "plan.cpp"), kg_cpp,
                 kp_cpp, os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
         if real_fast:
             flags.append("-DHOSTSIM_REAL_FAST")

@@ -160,6 +160,7 @@ hipError_t launch_perfect_lds(const DevPlan& p, const FragView& fv, int64_t* out
   return hipSuccess;
 }
 bool lds_groupby_eligible(const DevPlan& p, const FragView&, int) {
+  if (p.bf_active) return false;  // (the stand-in runs the row function on the plan's quals: it takes no compiled filter)
   if (!on(F_LDS_GROUPBY) || p.join_col >= 0 || p.col0_key_quirk || p.slot_width != 8 || p.n_quals > MI355Q_MAX_QUALS) return false;
   for (int i = 0; i < p.n_quals; ++i)
     if (p.quals[i].type != MI355Q_INT32 && p.quals[i].type != MI355Q_INT64) return false;

@@ -105,7 +105,7 @@ CHILD_EXPR = textwrap.dedent("""
     ok = bad = 0
     for it in range(int(sys.argv[2])):
         xs = []
-        for k in range(int(rng.integers(1, capi.MAX_EXPRS + 1))):
+        for k in range(int(rng.integers(1, min(capi.MAX_EXPRS, capi.MAX_COLS - len(descs)) + 1))):
             for attempt in range(20):
                 e = _random_bool(rng, descs, int(rng.integers(1, 4))) if rng.integers(0, 3) == 0 else \\
                     _random_expr(rng, descs, int(rng.choice(types)), int(rng.integers(1, 4)))

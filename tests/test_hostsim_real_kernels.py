@@ -690,3 +690,77 @@ def test_lattice_key_route_nulls_offsets_passes_and_a_key_off_the_lattice(sim, o
     case = cases_mod.Case("off_lattice", ra, [[bad[a:b], k1[a:b], v0[a:b], v1[a:b]] for a, b in zip(cuts[:-1], cuts[1:])])
     rs = flow._check(oracle, case, kernel_variant=2)
     assert rs is not None and rs.report.kernel_name.decode() != "k_idx_scatter", rs.report.kernel_name
+
+
+# ---- filters compiled at plan time (boolfilter.h): atoms + truth table evaluated by the consuming kernel
+def _bool_filter_cases(oracle, n_rows=30_000, null_every=7):
+    """the shapes of tools/bool_filter_bench.py (+ a few of the reference's own WHERE clauses) over a small table:
+    g (1 000 groups), v, a, b uniform in [0, 1 M), c nullable"""
+    from heavydb_amd.executor import Expr, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.cases import Case
+    rng = np.random.default_rng(77)
+    g = rng.integers(0, 1000, n_rows).astype(np.int32)
+    v = rng.integers(0, 1_000_000, n_rows).astype(np.int32)
+    a = rng.integers(0, 1_000_000, n_rows).astype(np.int32)
+    b = rng.integers(0, 1_000_000, n_rows).astype(np.int64)   # (an INT64 filter column beside the INT32 ones)
+    c = rng.integers(0, 1_000_000, n_rows).astype(np.int32)
+    c[::null_every] = -2**31
+    I32, I64 = capi.INT32, capi.INT64
+    descs = [InputColDescriptor(I32, False, ExpressionRange(True, 0, 999)), InputColDescriptor(I32, False, ExpressionRange(True, 0, 999_999)),
+             InputColDescriptor(I32, False, ExpressionRange(True, 0, 999_999)), InputColDescriptor(I64, False, ExpressionRange(True, 0, 999_999)),
+             InputColDescriptor(I32, True, ExpressionRange(True, 0, 999_999, True))]
+    C_, L = Expr.col, Expr.lit
+    a_lt = C_(2).cmp(capi.EX_LT, L(I32, 500_000))
+    b_gt = C_(3).cmp(capi.EX_GT, L(I64, 250_000))
+    c_lt = C_(4).cmp(capi.EX_LT, L(I32, 100_000))
+    band = lambda col, t, lo, hi: C_(col).cmp(capi.EX_GT, L(t, lo)).logical(capi.EX_AND, C_(col).cmp(capi.EX_LT, L(t, hi)))
+    nc = 5
+    shapes = [
+        ("and_in_or", [a_lt.logical(capi.EX_AND, b_gt).logical(capi.EX_OR, C_(4).is_null())], [Qual(nc, capi.EQ, 1)]),
+        ("not_or", [a_lt.logical(capi.EX_OR, b_gt).logical_not()], [Qual(nc, capi.EQ, 1)]),
+        ("composed", [band(2, I32, 100_000, 200_000), band(3, I64, 300_000, 400_000),
+                      band(4, I32, 500_000, 600_000).logical(capi.EX_OR, C_(nc)).logical(capi.EX_OR, C_(nc + 1))], [Qual(nc + 2, capi.EQ, 1)]),
+        # NULL-aware: NOT over a comparison of the nullable column (NULL stays NULL: not TRUE), mirrored literal, a plain qual beside it
+        ("not_null_cmp_and_plain_qual", [c_lt.logical_not().logical(capi.EX_OR, L(I32, 900_000).cmp(capi.EX_LT, C_(2)))],
+         [Qual(nc, capi.EQ, 1), Qual(1, capi.GE, 1000)]),
+        # the short-circuit forms differ from the plain ones on NULL: NULL AND FALSE = NULL (not TRUE either way), NULL OR TRUE
+        ("short_circuit_or", [c_lt.logical(capi.EX_OR, a_lt, True)], [Qual(nc, capi.EQ, 1)]),
+        ("is_not_null_and_in_list", [C_(2).cmp(capi.EX_EQ, L(I32, int(a[5]))).logical(capi.EX_OR, C_(2).cmp(capi.EX_EQ, L(I32, int(a[9]))))
+                                     .logical(capi.EX_OR, C_(4).is_null().logical_not().logical(capi.EX_AND, c_lt))], [Qual(nc, capi.EQ, 1)]),
+    ]
+    out = []
+    for name, exprs, quals in shapes:
+        xs = [e.with_range(ExpressionRange(True, 0, 1, True)) for e in exprs]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1)], quals, [0], exprs=xs,
+                                 num_tuples=n_rows)
+        half = n_rows // 2 // 4 * 4
+        out.append(Case(name, ra, [[x[:half] for x in (g, v, a, b, c)], [x[half:] for x in (g, v, a, b, c)]]))
+    return out
+
+
+@pytest.mark.parametrize("idx", range(6), ids=["and_in_or", "not_or", "composed", "not_null_cmp_and_plain_qual", "short_circuit_or",
+                                                "is_not_null_and_in_list"])
+def test_compiled_bool_filters_in_the_lds_groupby(sim, oracle, idx):
+    """BOOLEAN filters of comparisons with literals no longer take the interpreter pass: the route is the LDS group-by alone,
+    the result the oracle's (which evaluates the expression programs node by node)"""
+    from heavydb_amd.executor import Executor
+    case = _bool_filter_cases(oracle)[idx]
+    rs = flow._check(oracle, case)
+    assert rs is not None and rs.report.kernel_name.decode() == "k_groupby_lds", rs.report.kernel_name
+    route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
+    assert "filter compiled" in route and "k_project" not in route and "k_groupby_lds" in route, route
+
+
+def test_filters_with_arithmetic_still_take_the_projection_pass(sim, oracle):
+    """`b <> 0 AND a / b > 3` (the guarded division) can raise: not a truth table"""
+    from heavydb_amd.executor import Executor, Expr, Qual
+    base = _bool_filter_cases(oracle)[0]
+    I32 = capi.INT32
+    C_, L = Expr.col, Expr.lit
+    e = C_(2).cmp(capi.EX_NE, L(I32, 0)).logical(capi.EX_AND, C_(1).div(C_(2), I32).cmp(capi.EX_GT, L(I32, 3)), True)
+    base.ra.exprs = [e.with_range(base.ra.exprs[0].range)]
+    base.ra.simple_quals = [Qual(5, capi.EQ, 1)]
+    rs = flow._check(oracle, base)
+    assert rs is not None
+    route = Executor(0).explain(base.ra, [len(f[0]) for f in base.frags])
+    assert "k_project" in route and "filter compiled" not in route, route

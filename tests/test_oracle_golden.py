@@ -497,3 +497,57 @@ def test_multi_column_perfect_hash_matches_reference_function(oracle):
             off = lib.orc_perfect_hash_slot(buf.ctypes.data, call["hashed_index"], key.ctypes.data, kc, rq)
             assert off == call["returned_quad_offset"], call
         assert buf.tolist() == tr["final_buffer"]
+
+
+def test_projection_runtime_matches_reference_vectors(oracle):
+    """get_scan_output_slot / get_columnar_scan_output_offset (GroupByRuntime.cpp:242-269) restated in oracle.cpp, and the
+    projection step built on them (run_fragment's Projection branch), against traces the reference's own functions produced
+    (oracle/gen_golden_projection.py -> tests/golden/ref_projection_vectors.json): the slot / offset every call returns — -1
+    once the buffer is full — and the final buffer image, row-wise (8-byte slots, agg_id / agg_id_double) and columnar
+    (logical-width columns, agg_id_int8 / 16 / 32 / agg_id_float)."""
+    import ctypes as C
+    import json
+    import os
+    from heavydb_amd import capi
+    from heavydb_amd.executor import InputColDescriptor as D, RelAlgExecutionUnit, TargetExpr
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_projection_vectors.json")))
+    lib = oracle.lib()
+    lib.orc_get_scan_output_slot.restype = C.c_int64
+    lib.orc_get_scan_output_slot.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64, C.c_uint32]
+    lib.orc_get_columnar_scan_output_offset.restype = C.c_int32
+    lib.orc_get_columnar_scan_output_offset.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64]
+    EMPTY = 2**63 - 1
+    assert len(g["rowwise"]) >= 4 and len(g["columnar"]) >= 3
+    for tr in g["rowwise"]:
+        ec, rq = tr["entry_count"], tr["row_size_quad"]
+        buf = np.zeros(ec * rq, dtype=np.int64)
+        buf.reshape(ec, rq)[:, 0] = EMPTY
+        for c in tr["calls"]:
+            got = lib.orc_get_scan_output_slot(buf.ctypes.data, ec, c["old_total_matched"], c["offset_in_fragment"], rq)
+            assert got == c["slot_quad"]
+            if got >= 0:
+                for s in range(rq - 1):
+                    buf[got + s] = np.array([c["dval"]], dtype=np.float64).view(np.int64)[0] if s == 1 else c["ivals"][s]
+        assert buf.tolist() == tr["final"]
+    for tr in g["columnar"]:
+        ec = tr["entry_count"]
+        keys = np.full(ec, EMPTY, dtype=np.int64)
+        for c in tr["calls"]:
+            assert lib.orc_get_columnar_scan_output_offset(keys.ctypes.data, ec, c["old_total_matched"], c["offset_in_fragment"]) == c["offset"]
+        assert keys.tolist() == tr["keys"]
+        # the same trace as a projection STEP of the oracle: the input columns hold exactly the traced values, every row passes
+        n = len(tr["calls"])
+        cols = [np.array([c["v8"] for c in tr["calls"]], dtype=np.int8), np.array([c["v16"] for c in tr["calls"]], dtype=np.int16),
+                np.array([c["v32"] for c in tr["calls"]], dtype=np.int32), np.array([c["vf"] for c in tr["calls"]], dtype=np.float32)]
+        ra = RelAlgExecutionUnit([D(capi.INT8), D(capi.INT16), D(capi.INT32), D(capi.FLOAT)], [TargetExpr(capi.PROJECT, i) for i in range(4)],
+                                 scan_limit=ec, output_columnar_hint=capi.OUTPUT_COLUMNAR)
+        q, buf, code = oracle.execute(ra.to_plan(), [cols])
+        assert code == 0 and q.entry_count == ec
+        raw = buf.view(np.int8)
+        live = min(n, ec)
+        # (the step's key is the row's offset in the fragment = its index here, not the traced random offset)
+        assert raw[:8 * ec].view(np.int64).tolist() == list(range(live)) + [EMPTY] * (ec - live)
+        for s, (name, dt) in enumerate((("c8", np.int8), ("c16", np.int16), ("c32", np.int32), ("cf_bits", np.int32))):
+            o = oracle.col_slot_off(q, s)
+            w = np.dtype(dt).itemsize
+            assert raw[o:o + w * live].view(dt).tolist() == tr[name][:live], name

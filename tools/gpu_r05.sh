@@ -9,6 +9,9 @@ case $step in
   before)   # the "before" of the expression-fusion work: the five BOOLEAN-filter shapes through the k_project interpreter pass
     timeout 500 python tools/bool_filter_bench.py --rows 1e9 --steps 3 > $out/bool_filter_1b.jsonl 2> $out/bool_filter.err; echo "bool_filter exit $?"
     cat $out/bool_filter_1b.jsonl; tail -5 $out/bool_filter.err ;;
+  after)    # the five BOOLEAN-filter shapes with the filter compiled into the consuming kernel (+ parity on a sample)
+    timeout 500 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --verify-rows 4e6 > $out/bool_filter_1b.jsonl 2> $out/bool_filter.err; echo "bool_filter exit $?"
+    cat $out/bool_filter_1b.jsonl; tail -5 $out/bool_filter.err ;;
   proj1)    # first contact of the Projection family: the case matrix on the device, then the 1 B-row bench lines
     timeout 900 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -x -q -p no:cacheprovider -k "case_on_the_device or larger_random" > $out/pytest.log 2>&1
     echo "pytest exit $?"; tail -5 $out/pytest.log
