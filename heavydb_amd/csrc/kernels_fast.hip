@@ -333,6 +333,140 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __rest
   for (int i = 0; i < p.n_targets; ++i) reduce_target<true>(p.targets[i], p.init_vals, out, part);
 }
 
+// ---- typed members of the scan-aggregate family: every argument column a plain INT32, no quals, ONE set of aggregate
+// kinds for all columns (the reference benchmark's NonGroupedAgg/NGA01-05.sql: six INT columns, one kind each) — the
+// accumulators a kind does not need do not exist, MIN / MAX compare in 32 bits, the NULL test is one compare, and two
+// quads per column are in flight.  OPS: 1 = rows with a value, 2 = sum, 4 = min, 8 = max.
+template <int NC, int OPS, bool NUL, int UQ>
+__global__ __launch_bounds__(kBlock) void k_scan_agg_i32(const int8_t* const* __restrict__ cols, const int64_t* __restrict__ num_rows,
+                                                          int n_frags, int n_cols, ScanAggArgs a, DevPlan p, int64_t* __restrict__ out) {
+  uint32_t cnt[NC];
+  int64_t sum[NC];
+  int32_t mn[NC], mx[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    cnt[c] = 0;
+    sum[c] = 0;
+    mn[c] = INT32_MAX;
+    mx[c] = INT32_MIN;
+  }
+  unsigned long long rows = 0;
+  auto one = [&](int c, int32_t x) {
+    const bool ok = !NUL || x != INT32_MIN;
+    if (OPS & 1) cnt[c] += ok ? 1u : 0u;
+    if (OPS & 2) sum[c] += ok ? (int64_t)x : 0;
+    if (OPS & 4) mn[c] = (ok && x < mn[c]) ? x : mn[c];
+    if (OPS & 8) mx[c] = (ok && x > mx[c]) ? x : mx[c];   // (a NULL is INT32_MIN: it never raises a maximum anyway)
+  };
+  const int64_t tile_q = (int64_t)kBlock * UQ;
+  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kBlock;
+  for (int f = 0; f < n_frags; ++f) {
+    const int8_t* const* fc = cols + (size_t)f * n_cols;
+    const int64_t n = num_rows[f];
+    const int64_t nq = n >> 2;
+    const int64_t n_tiles = nq / tile_q;
+    const int8_t* cbase[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cbase[c] = c < a.n_used ? fc[a.col[c]] : nullptr;
+    for (int64_t t = (blockIdx.x + (int64_t)f * 7) % gridDim.x; t < n_tiles; t += gridDim.x) {
+      const int64_t q0 = t * tile_q + threadIdx.x;
+      v4i32 x[NC][UQ];
+#pragma unroll
+      for (int u = 0; u < UQ; ++u)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+          if (c < a.n_used) x[c][u] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)cbase[c] + q0 + (int64_t)u * kBlock);
+#pragma unroll
+      for (int u = 0; u < UQ; ++u)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          if (c >= a.n_used) break;
+          one(c, x[c][u].x);
+          one(c, x[c][u].y);
+          one(c, x[c][u].z);
+          one(c, x[c][u].w);
+        }
+      rows += 4 * UQ;
+    }
+    for (int64_t q = n_tiles * tile_q + gtid; q < nq; q += gsize) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (c >= a.n_used) break;
+        const v4i32 v = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)cbase[c] + q);
+        one(c, v.x);
+        one(c, v.y);
+        one(c, v.z);
+        one(c, v.w);
+      }
+      rows += 4;
+    }
+    const int64_t tail = (nq << 2) + gtid;
+    if (tail < n) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        if (c >= a.n_used) break;
+        one(c, load_one<int32_t>(cbase[c], tail));
+      }
+      rows += 1;
+    }
+  }
+  // wave reduce, then one fold per workgroup in LDS (the epilogue of k_scan_agg on the accumulators this member keeps)
+  __shared__ unsigned long long s_rows[kBlock / 64];
+  __shared__ ColAcc s_acc[kBlock / 64][kScanAggCols];
+  rows = wave_sum_u64(rows);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    if (c >= a.n_used) break;
+    ColAcc r{};
+    r.cnt = (OPS & 1) ? wave_sum_u64((unsigned long long)cnt[c]) : rows;   // (without NULLs every row has a value)
+    r.sum_i = (OPS & 2) ? wave_sum_i64(sum[c]) : 0;
+    r.min_i = (OPS & 4) ? wave_min_i64((long long)mn[c]) : INT64_MAX;
+    r.max_i = (OPS & 8) ? wave_max_i64((long long)mx[c]) : INT64_MIN;
+    if (lane == 0) s_acc[wave][c] = r;
+  }
+  if (lane == 0) s_rows[wave] = rows;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  unsigned long long all_rows = 0;
+  for (int w = 0; w < kBlock / 64; ++w) all_rows += s_rows[w];
+  if (!all_rows) return;
+  int64_t part[MI355Q_MAX_SLOTS];
+  for (int j = 0; j < p.slot_count; ++j) part[j] = p.init_vals[j];
+  for (int i = 0; i < p.n_targets; ++i) {
+    const DevTarget& t = p.targets[i];
+    const int cs = a.target_cslot[i];
+    if (cs < 0) {
+      part[t.slot] = (int64_t)all_rows;
+      continue;
+    }
+    ColAcc r = s_acc[0][cs];
+    for (int w = 1; w < kBlock / 64; ++w) {
+      const ColAcc& o = s_acc[w][cs];
+      r.cnt += o.cnt;
+      r.sum_i += o.sum_i;
+      r.min_i = o.min_i < r.min_i ? o.min_i : r.min_i;
+      r.max_i = r.max_i < o.max_i ? o.max_i : r.max_i;
+    }
+    switch (t.agg) {
+      case MI355Q_COUNT: part[t.slot] = (int64_t)r.cnt; break;
+      case MI355Q_AVG:
+        part[t.slot + 1] = (int64_t)r.cnt;
+        [[fallthrough]];
+      case MI355Q_SUM:
+        if (r.cnt) part[t.slot] = r.sum_i;
+        break;
+      case MI355Q_MIN:
+        if (r.cnt) part[t.slot] = r.min_i;
+        break;
+      default:
+        if (r.cnt) part[t.slot] = r.max_i;
+    }
+  }
+  for (int i = 0; i < p.n_targets; ++i) reduce_target<true>(p.targets[i], p.init_vals, out, part);
+}
+
 // =========================================================================== perfect_lds
 template <typename VT>
 MQ_D void slot_apply_lds(int op, int64_t* s, int64_t key, VT val);
@@ -761,12 +895,70 @@ hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, i
   st->kernel_name = "k_scan_agg";
   st->n_launches = 1;
   rec(st->k_start, s);
+  // the typed members: plain INT32 argument columns, no quals, one set of aggregate kinds
+  {
+    bool typed = a.n_flt == 0 && a.n_used >= 1 && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
+    bool nul = false;
+    for (int c = 0; c < a.n_used; ++c) {
+      typed = typed && a.type[c] == MI355Q_INT32;
+      nul = nul || a.nullable[c] != 0;
+    }
+    int ops = 0;
+    for (int i = 0; i < p.n_targets; ++i) {
+      if (a.target_cslot[i] < 0) continue;
+      switch (p.targets[i].agg) {
+        case MI355Q_COUNT: ops |= 1; break;
+        case MI355Q_SUM: ops |= 2; break;
+        case MI355Q_AVG: ops |= 2; break;
+        case MI355Q_MIN: ops |= 4; break;
+        default: ops |= 8;
+      }
+    }
+    // (with NULLs every kind needs to know whether a column had a value at all; without them that is the row count)
+    if (nul) ops |= 1;
+    // the instantiated kind sets: count, sum, min, max (each with the value count where the columns are nullable), or all
+    const int set = ops == 1 ? 1 : (ops & ~1) == 2 ? 2 : (ops & ~1) == 4 ? 4 : (ops & ~1) == 8 ? 8 : 15;
+    if (typed && ops != 0) {
+      st->variant = 5;
+      // workgroups per CU, measured at 1 B rows x six columns (profiles/r05_nga_sweep_blocks_per_cu.jsonl): the members
+      // without a 64-bit sum gain up to four (3.45 ms = 0.87 of 8 TB/s), the ones with one lose beyond two
+      const int grid = stream_grid(n_cus, (set == 2 || set == 15) ? 2 : 4, fv.total_rows);
+#define MQ_SA(NC, OPS, NUL, UQ) \
+  hipLaunchKernelGGL((k_scan_agg_i32<NC, OPS, NUL, UQ>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out)
+#define MQ_SA_OPS(NC, UQ)                                   \
+  do {                                                      \
+    if (nul) {                                              \
+      if (set == 1) MQ_SA(NC, 1, true, UQ);                 \
+      else if (set == 2) MQ_SA(NC, 3, true, UQ);            \
+      else if (set == 4) MQ_SA(NC, 5, true, UQ);            \
+      else if (set == 8) MQ_SA(NC, 9, true, UQ);            \
+      else MQ_SA(NC, 15, true, UQ);                         \
+    } else {                                                \
+      if (set == 1) MQ_SA(NC, 1, false, UQ);                \
+      else if (set == 2) MQ_SA(NC, 2, false, UQ);           \
+      else if (set == 4) MQ_SA(NC, 4, false, UQ);           \
+      else if (set == 8) MQ_SA(NC, 8, false, UQ);           \
+      else MQ_SA(NC, 15, false, UQ);                        \
+    }                                                       \
+  } while (0)
+      if (a.n_used <= 2) MQ_SA_OPS(2, 4);
+      else if (a.n_used <= 4) MQ_SA_OPS(4, 2);
+      else if (a.n_used <= 6) MQ_SA_OPS(6, 2);
+      else MQ_SA_OPS(8, 1);
+#undef MQ_SA_OPS
+#undef MQ_SA
+      rec(st->k_stop, s);
+      return hipGetLastError();
+    }
+  }
   // every lane keeps about eight 16-byte loads in flight: quads per column per step by the number of columns
   const int streams = a.n_used + a.n_flt;
   if (streams <= 2)
     hipLaunchKernelGGL((k_scan_agg<4, 2, 2>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out);
   else if (streams <= 4)
     hipLaunchKernelGGL((k_scan_agg<2, 4, 4>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out);
+  else if (a.n_flt <= 4)
+    hipLaunchKernelGGL((k_scan_agg<1, kScanAggCols, 4>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out);
   else
     hipLaunchKernelGGL((k_scan_agg<1, kScanAggCols, MI355Q_MAX_QUALS>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out);
   rec(st->k_stop, s);

@@ -12,6 +12,15 @@ case $step in
   after)    # the five BOOLEAN-filter shapes with the filter compiled into the consuming kernel (+ parity on a sample)
     timeout 500 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --verify-rows 4e6 > $out/bool_filter_1b.jsonl 2> $out/bool_filter.err; echo "bool_filter exit $?"
     cat $out/bool_filter_1b.jsonl; tail -5 $out/bool_filter.err ;;
+  nga)      # the typed scan-aggregate members: NGA01-05 at 1 B rows (parity on a sample) + the refbench parity tests
+    timeout 400 python tools/refbench.py --rows 1e9 --steps 3 --only NGA --verify-rows 2e6 --out $out/refbench_nga.jsonl > $out/refbench.log 2>&1; echo "refbench exit $?"
+    python - <<PY
+import json
+for l in open("$out/refbench_nga.jsonl"):
+    d=json.loads(l); print(d.get("query"), (d.get("route") or "")[:60], d.get("ms"), d.get("whole_step_frac"), d.get("verified_rows"))
+PY
+    ;;
+  ngasweep) timeout 400 python tools/nga_sweep.py --rows 1e9 > $out/nga_sweep.jsonl 2> $out/err.log; echo "exit $?"; cat $out/nga_sweep.jsonl; tail -3 $out/err.log ;;
   proj1)    # first contact of the Projection family: the case matrix on the device, then the 1 B-row bench lines
     timeout 900 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -x -q -p no:cacheprovider -k "case_on_the_device or larger_random" > $out/pytest.log 2>&1
     echo "pytest exit $?"; tail -5 $out/pytest.log
