@@ -2638,6 +2638,41 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
 
 }  // namespace
 
+namespace {
+// An INNER join on ONE key against a dense OneToOne perfect table (mi355q_join_table::dense) whose inner side no target reads:
+// a row has a match exactly when its key lies in [min, max] (hash_join_idx, GroupByRuntime.cpp:287-297: in range ->
+// the slot, and no slot of a dense table is -1; a NULL key matches nothing, hash_join_idx_nullable :311-318), so the step is
+// the same step WITHOUT the join and with the two range quals on the key column — a plain scan for the non-grouped
+// shapes (BASELINE cfg4, Query A on the dense dimension).  kNotTaken for everything else.
+int32_t execute_dense_join_as_filter(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o,
+                                     mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
+  const mi355q_join_table* jt = plan->join_table;
+  if (plan->join_outer_col < 0 || !jt || !jt->dense || plan->join_kind != MI355Q_JOIN_INNER || plan->n_join_cols > 1 ||
+      plan->n_exprs != 0 || plan->n_quals + 2 > MI355Q_MAX_QUALS || o.force_generic || o.kernel_variant != 0)
+    return kNotTaken;
+  for (int t = 0; t < plan->n_targets && t < MI355Q_MAX_TARGETS; ++t)
+    if (plan->targets[t].table != 0 && plan->targets[t].agg != MI355Q_PROJECT_KEY) return kNotTaken;
+  const int kc = plan->join_outer_col;
+  if (kc >= plan->n_cols || col_type_code(plan->cols[kc]) < 0) return kNotTaken;
+  const int lt = tc_logical(col_type_code(plan->cols[kc]));
+  if (lt < MI355Q_INT8 || lt > MI355Q_INT64) return kNotTaken;
+  mi355q_plan p2 = *plan;
+  p2.join_outer_col = -1;
+  p2.join_table = nullptr;
+  p2.n_join_cols = 0;
+  p2.n_inner_cols = 0;
+  p2.quals[p2.n_quals++] = mi355q_qual{kc, MI355Q_GE, jt->min_key, 0.0};
+  p2.quals[p2.n_quals++] = mi355q_qual{kc, MI355Q_LE, jt->max_key, 0.0};
+  mi355q_qmd qa, qb;   // the layout does not look at the join or at the quals: the derived step's result IS the step's
+  if (qmd_init(*plan, &qa) || qmd_init(p2, &qb) || std::memcmp(&qa, &qb, sizeof(qa)) != 0) return kNotTaken;
+  route_note("join on a dense one-to-one table = range filter on the key");
+  mi355q_inputs in2 = *in;
+  in2.inner_col_buffers = nullptr;
+  in2.inner_num_rows = 0;
+  return execute_impl(&p2, &in2, &o, out, report, nullptr, reserved);
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------- execute
 int32_t mi355q_execute(const mi355q_plan* plan, const mi355q_inputs* in,
                        const mi355q_exec_options* opts, mi355q_result** out,
@@ -2945,6 +2980,13 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
       lds_direct = idx_direct = idx_part_eligible(d, fvh, n_cus);
   }
   if (bf_step && (!lds_direct || idx_direct || in->n_frags <= 0)) return kNotTaken;
+  if (!pend && plan->join_outer_col >= 0 && !bf_step) {
+    const size_t mark = t_route ? t_route->size() : 0;
+    const int32_t e = execute_dense_join_as_filter(plan, in, o, out, report, reserved);
+    if (e != kNotTaken) return e;
+    if (t_route) t_route->resize(mark);
+    *out = nullptr;
+  }
   if (!o.force_generic && in->n_frags > 0 && !pend && plan->join_outer_col >= 0 && !bf_step) {
     const size_t mark = t_route ? t_route->size() : 0;
     const int32_t e = execute_join_gather(plan, in, o, q, d, n_cus, out, report, reserved);
@@ -3523,6 +3565,7 @@ int32_t mi355q_join_build(const mi355q_join_spec* spec, void* stream, mi355q_joi
   HIP_TRY(hipStreamSynchronize(s));
   (void)hipEventElapsedTime(&jt->build_ms, e0, e1);
   if (h_err) return h_err;
+  jt->dense = jt->hash_type == 0 && !spec->key_nullable && spec->num_rows == jt->entry_count;
   jg.j = nullptr;
   *out = jt;
   return MI355Q_OK;

@@ -23,6 +23,9 @@ struct mi355q_join_table {
   void* bitmap = nullptr;  // perfect tables: presence bitmap (1 bit per slot), for probes that
                            // only need to know WHETHER a key matches (no inner column read)
   float build_ms = 0.f;
+  // OneToOne perfect table in which EVERY slot holds a row id: the inner key column is NOT NULL, the build met no duplicate
+  // and rows == max - min + 1.  hash_join_idx (GroupByRuntime.cpp:287-297) then answers >= 0 exactly for min <= key <= max.
+  bool dense = false;
   // perfect tables: per-key aggregated payload for the payload probe (kernels_part.hip), built on
   // first use for one inner column and kept with the table (the inner table does not change under
   // a join table): rows per key, sum of the inner column over them, non-NULL values among them

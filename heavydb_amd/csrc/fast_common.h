@@ -272,6 +272,27 @@ inline bool make_range_filter(const DevQual& q, RangeFilter* f) {
   return true;
 }
 
+// Two range quals on ONE column (x > 6 AND x < 8; the two bounds a dense join leaves on its key) are one range: the
+// families load a filter column once per RangeFilter.  Returns the new count.
+inline int merge_range_filters(RangeFilter* f, int32_t* type, int n) {
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n;) {
+      if (f[i].col == f[j].col && type[i] == type[j] && !f[i].negate && !f[j].negate && f[i].null_val == f[j].null_val) {
+        f[i].lo = f[j].lo > f[i].lo ? f[j].lo : f[i].lo;
+        f[i].hi = f[j].hi < f[i].hi ? f[j].hi : f[i].hi;
+        f[i].nullable = f[i].nullable || f[j].nullable;
+        for (int k = j; k + 1 < n; ++k) {
+          f[k] = f[k + 1];
+          type[k] = type[k + 1];
+        }
+        --n;
+      } else {
+        ++j;
+      }
+    }
+  return n;
+}
+
 inline RangeFilter no_filter() {
   RangeFilter f{};
   f.lo = INT64_MIN;

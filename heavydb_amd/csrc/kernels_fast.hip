@@ -854,7 +854,7 @@ static bool scan_agg_args(const DevPlan& p, const FragView& fv, ScanAggArgs* a) 
     a->flt_type[i] = p.quals[i].type;
     if (!all_aligned16(fv, p.quals[i].col)) return false;
   }
-  a->n_flt = p.n_quals;
+  a->n_flt = merge_range_filters(a->flt, a->flt_type, p.n_quals);
   for (int i = 0; i < p.n_targets; ++i) {
     const DevTarget& t = p.targets[i];
     a->target_cslot[i] = -1;

@@ -61,7 +61,7 @@ inline bool lds_describe(const DevPlan& p, const FragView& fv, int64_t max_entri
     a.flt_type[i] = p.quals[i].type;
     if (!all_aligned16(fv, p.quals[i].col)) return false;
   }
-  a.n_flt = p.n_quals;
+  a.n_flt = merge_range_filters(a.flt, a.flt_type, p.n_quals);
   if (p.bf_active) {  // the compiled filter's columns take the filter slots
     const BoolFilter* bf = step_bool_filter();
     if (!bf || p.n_quals != 0 || bf->n_cols > 4) return false;

@@ -21,6 +21,9 @@ for l in open("$out/refbench_nga.jsonl"):
 PY
     ;;
   ngasweep) timeout 400 python tools/nga_sweep.py --rows 1e9 > $out/nga_sweep.jsonl 2> $out/err.log; echo "exit $?"; cat $out/nga_sweep.jsonl; tail -3 $out/err.log ;;
+  cfg4a)    # BASELINE cfg4, Query A on the dense dimension: the join is a range filter on the key (driver-style line, --verify)
+    timeout 900 python bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline --verify > $out/bench_cfg4a_dense.json 2> $out/err.log; echo "exit $?"
+    cat $out/bench_cfg4a_dense.json; tail -3 $out/err.log ;;
   proj1)    # first contact of the Projection family: the case matrix on the device, then the 1 B-row bench lines
     timeout 900 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -x -q -p no:cacheprovider -k "case_on_the_device or larger_random" > $out/pytest.log 2>&1
     echo "pytest exit $?"; tail -5 $out/pytest.log
