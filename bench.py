@@ -64,7 +64,38 @@ def parse_args():
                          "rank), so the final merge is skipped (SURVEY 8e's second mode)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic.json"),
                     help="per-kernel HBM bytes/launch from a rocprofv3 --pmc pass (optional)")
+    ap.add_argument("--hostsim", action="store_true",
+                    help="TEST ONLY (tests/test_bench_multi_rank.py): every rank runs the host simulation of the library "
+                         "(tests/hostsim) on CPU tensors and gloo carries the collectives — exercises the N-rank control flow "
+                         "of this script without a GPU; its numbers are not measurements")
     return ap.parse_args()
+
+
+def _free_port() -> int:
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _bind_host_simulation(torch):
+    """--hostsim: this process's `device` is the host simulation of the library (the real device sources compiled for the
+    CPU, tests/hostsim); tensors are CPU tensors."""
+    from heavydb_amd import capi
+    from tests.helpers import hostsim_lib
+    capi._lib = capi.load_library(hostsim_lib(real_fast=True))
+    real = {n: getattr(torch, n) for n in ("zeros", "empty", "full", "arange", "tensor")}
+    strip = lambda f: (lambda *a, **k: f(*a, **{x: y for x, y in k.items() if x != "device" or not str(y).startswith("cuda")}))  # noqa: E731
+    for n, f in real.items():
+        setattr(torch, n, strip(f))
+
+    class _Stream:
+        def synchronize(self):
+            pass
+    torch.cuda.current_stream = lambda *a, **k: _Stream()
+    torch.cuda.synchronize = lambda *a, **k: None
+    torch.cuda.set_device = lambda *a, **k: None
+    torch.cuda.empty_cache = lambda *a, **k: None
 
 
 def fit_rows(cfg: str, want_rows: int, world: int, free_bytes: int, bytes_per_row: int) -> int:
@@ -189,18 +220,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        print(f"bench.py: --gpus {args.gpus} needs torch.distributed.run (WORLD_SIZE unset)",
-              file=sys.stderr)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, one process per GPU, the way the
+        # driver does (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)", file=sys.stderr)
         sys.exit(2)
+    if args.hostsim:
+        _bind_host_simulation(torch)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device(f"cuda:{local_rank}"))
+        if args.hostsim:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device(f"cuda:{local_rank}"))
     torch.cuda.set_device(local_rank)
+    if args.hostsim:
+        local_rank = 0  # (one simulated device per process)
     lib = capi.load_library()  # fails loudly if the HIP extension is missing
     import ctypes as C
     name = C.create_string_buffer(256)
@@ -211,13 +255,13 @@ def main():
     cfg = args.config
     want = int(args.rows) if args.rows else synth.DEFAULT_ROWS[cfg]
     bpr = {"cfg1": 4, "cfg2": 12, "cfg3": 16, "cfg3f": 20, "cfg4": 16}[cfg]
-    total_rows = fit_rows(cfg, want, world, free.value, bpr)
+    total_rows = want if args.hostsim else fit_rows(cfg, want, world, free.value, bpr)
     if world > 1:  # all ranks must agree
         t = torch.tensor([total_rows], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         total_rows = int(t.item())
 
-    ceiling = measure_ceiling(torch, local_rank) if rank == 0 else None
+    ceiling = measure_ceiling(torch, local_rank) if rank == 0 and not args.hostsim else None
 
     prepart = bool(args.prepartitioned and cfg in ("cfg3", "cfg3f") and world > 1)
     extra = {"prepartitioned": True} if prepart else {}
@@ -394,10 +438,12 @@ def main():
     }
     if per_rank:
         out["per_rank"] = per_rank
-        out["ranks_reported_by_rccl"] = world if dist is None else dist.get_world_size()
+    out["ranks_reported_by_rccl"] = 1 if dist is None else dist.get_world_size()
+    if args.hostsim:
+        out["data"] = "HOST SIMULATION (tests/hostsim + gloo): control flow only, not a measurement"
     if verify:
         out["verify"] = verify
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.hostsim:
         try:
             out["cpu_baseline"] = cpu_baseline(cfg, info, args.cpu_seconds, int(args.cpu_rows))
         except Exception as e:  # the baseline is a report, never a reason to lose the bench line
