@@ -526,7 +526,7 @@ int main() {
     hp.exprs[0].nodes[0] = {MI355Q_EX_COL, 0, 1, 0, 0, 0.0};
     hp.exprs[0].nodes[1] = {MI355Q_EX_LIT, MI355Q_DOUBLE, 0, 0, 0, 2.0};
     hp.exprs[0].nodes[2] = {MI355Q_EX_MUL, MI355Q_DOUBLE, 0, 0, 0, 0.0};
-    hp.exprs[0].range = {1, 0, 0, 0, 0.0, 2000.0, 0};
+    hp.exprs[0].range = {0, 0, 0, 0, 0.0, 0.0, 0};  // (the mock catalog has no range for a floating-point product; a projection's layout does not look at it)
     hp.n_targets = 3;
     hp.targets[0] = {MI355Q_PROJECT, 0, 0, 0, {}};
     hp.targets[1] = {MI355Q_PROJECT, 4, 0, 0, {}};

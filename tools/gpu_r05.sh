@@ -24,6 +24,10 @@ PY
   cfg4a)    # BASELINE cfg4, Query A on the dense dimension: the join is a range filter on the key (driver-style line, --verify)
     timeout 900 python bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline --verify > $out/bench_cfg4a_dense.json 2> $out/err.log; echo "exit $?"
     cat $out/bench_cfg4a_dense.json; tail -3 $out/err.log ;;
+  suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
+    timeout 2500 python -u -m pytest tests -m gpu -q -p no:cacheprovider ${3:-} > $out/pytest_gpu.log 2>&1
+    echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
   proj1)    # first contact of the Projection family: the case matrix on the device, then the 1 B-row bench lines
     timeout 900 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -x -q -p no:cacheprovider -k "case_on_the_device or larger_random" > $out/pytest.log 2>&1
     echo "pytest exit $?"; tail -5 $out/pytest.log
