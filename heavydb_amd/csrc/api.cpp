@@ -2979,7 +2979,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     if (!lds_direct && !pend && d.desc_type == MI355Q_GROUP_BY_PERFECT_HASH && (tr >= kIdxPartMinRows || o.kernel_variant == 2))
       lds_direct = idx_direct = idx_part_eligible(d, fvh, n_cus);
   }
-  if (bf_step && (!lds_direct || idx_direct || in->n_frags <= 0)) return kNotTaken;
+  if (bf_step && in->n_frags <= 0) return kNotTaken;
+  if (bf_step && q.desc_type != MI355Q_NON_GROUPED_AGGREGATE && (!lds_direct || idx_direct)) return kNotTaken;
   if (!pend && plan->join_outer_col >= 0 && !bf_step) {
     const size_t mark = t_route ? t_route->size() : 0;
     const int32_t e = execute_dense_join_as_filter(plan, in, o, out, report, reserved);
@@ -3103,7 +3104,8 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   StepKind kind = K_GENERIC;
   JoinPayloadView pay{};
   if (bf_step) {
-    if (!o.force_generic && nf > 0 && o.kernel_variant == 0 && lds_groupby_eligible(d, fv, n_cus)) kind = K_LDS_GROUPBY;
+    if (!o.force_generic && nf > 0 && scan_agg_eligible(d, fv)) kind = K_SCAN_AGG;
+    else if (!o.force_generic && nf > 0 && o.kernel_variant == 0 && lds_groupby_eligible(d, fv, n_cus)) kind = K_LDS_GROUPBY;
   } else if (!o.force_generic && nf > 0) {
     if (scan_count_eligible(d, fv)) kind = K_SCAN_COUNT;
     else if (o.kernel_variant != 1 && scan_agg_eligible(d, fv)) kind = K_SCAN_AGG;
@@ -3235,7 +3237,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     }
   }
 
-  if (bf_step && kind != K_LDS_GROUPBY) return kNotTaken;
+  if (bf_step && kind != K_LDS_GROUPBY && kind != K_SCAN_AGG) return kNotTaken;
   tr.mark("setup done");
   int64_t scratch_bytes = 0;
   int64_t scratch_cap = o.scratch_bytes;

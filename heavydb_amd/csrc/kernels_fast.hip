@@ -19,6 +19,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "boolfilter.h"
 #include "fast_common.h"
 
 namespace mq {
@@ -64,6 +65,9 @@ struct ScanAggArgs {
   RangeFilter flt[MI355Q_MAX_QUALS];
   int32_t flt_type[MI355Q_MAX_QUALS];
   int32_t target_cslot[MI355Q_MAX_TARGETS];  // index into col[] of each target's argument, -1 = COUNT(*)
+  // a filter compiled at plan time (boolfilter.h) instead of range quals: flt[k].col / flt_type[k] name its columns
+  int32_t bf_on, pad_bf_;
+  const BoolFilter* bf;  // DEVICE memory
 };
 
 struct ColAcc {
@@ -184,6 +188,11 @@ template <int UQ, int NC, int NF>
 __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __restrict__ cols,
                                                       const int64_t* __restrict__ num_rows, int n_frags, int n_cols,
                                                       ScanAggArgs a, DevPlan p, int64_t* __restrict__ out) {
+  __shared__ BoolFilter s_bf;  // the compiled filter: atoms + truth table (a.bf_on)
+  if (a.bf_on) {
+    bf_load(a.bf, &s_bf, threadIdx.x, kBlock);
+    __syncthreads();
+  }
   ColAcc acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -233,10 +242,22 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __rest
       for (int u = 0; u < UQ; ++u) {
         if (u >= n_quads) break;
         uint32_t pass = 15u;
+        if (a.bf_on) {  // atoms on the filter columns' values + one bit of the truth table per row
+          pass = 0u;
 #pragma unroll
-        for (int k = 0; k < NF; ++k) {
-          if (k >= a.n_flt) break;
-          pass &= scan_agg_filter(a.flt[k], a.flt_type[k], fr[k][u]);
+          for (int i = 0; i < 4; ++i) {
+            int64_t fval[NF];
+#pragma unroll
+            for (int k = 0; k < NF; ++k)
+              fval[k] = k >= a.n_flt ? 0 : a.flt_type[k] == MI355Q_INT32 ? (int64_t)raw_i32(fr[k][u], i) : raw_i64(fr[k][u], i);
+            pass |= (bf_row_passes<NF>(s_bf, fval) ? 1u : 0u) << i;
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < NF; ++k) {
+            if (k >= a.n_flt) break;
+            pass &= scan_agg_filter(a.flt[k], a.flt_type[k], fr[k][u]);
+          }
         }
         rows_passing += __popc(pass);
 #pragma unroll
@@ -252,9 +273,17 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __rest
     const int64_t tail = (nq << 2) + gtid;
     if (tail < n) {
       bool pass = true;
-      for (int k = 0; k < a.n_flt; ++k) {
-        pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], load_one<int32_t>(fc[a.flt[k].col], tail))
-                                                      : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fc[a.flt[k].col], tail)));
+      if (a.bf_on) {
+        int64_t fval[NF];
+#pragma unroll
+        for (int k = 0; k < NF; ++k)
+          fval[k] = k >= a.n_flt ? 0 : a.flt_type[k] == MI355Q_INT32 ? (int64_t)load_one<int32_t>(fbase[k], tail) : load_one<int64_t>(fbase[k], tail);
+        pass = bf_row_passes<NF>(s_bf, fval);
+      } else {
+        for (int k = 0; k < a.n_flt; ++k) {
+          pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], load_one<int32_t>(fc[a.flt[k].col], tail))
+                                                        : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fc[a.flt[k].col], tail)));
+        }
       }
       if (pass) {
         rows_passing += 1;
@@ -855,6 +884,19 @@ static bool scan_agg_args(const DevPlan& p, const FragView& fv, ScanAggArgs* a) 
     if (!all_aligned16(fv, p.quals[i].col)) return false;
   }
   a->n_flt = merge_range_filters(a->flt, a->flt_type, p.n_quals);
+  if (p.bf_active) {  // the compiled filter's columns take the filter slots
+    const BoolFilter* bf = step_bool_filter();
+    if (!bf || p.n_quals != 0 || bf->n_cols > 4) return false;
+    for (int k = 0; k < bf->n_cols; ++k) {
+      if (!all_aligned16(fv, bf->col[k])) return false;
+      a->flt[k] = no_filter();
+      a->flt[k].col = bf->col[k];
+      a->flt_type[k] = bf->col_type[k];
+    }
+    a->n_flt = bf->n_cols;
+    a->bf_on = 1;
+    a->bf = step_bool_filter_dev();
+  }
   for (int i = 0; i < p.n_targets; ++i) {
     const DevTarget& t = p.targets[i];
     a->target_cslot[i] = -1;

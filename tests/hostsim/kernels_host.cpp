@@ -138,6 +138,7 @@ hipError_t launch_scan_count(const DevPlan& p, const FragView& fv, int64_t* out,
   return hipSuccess;
 }
 bool scan_agg_eligible(const DevPlan& p, const FragView&) {
+  if (p.bf_active) return false;  // (the stand-in runs the row function on the plan's quals: it takes no compiled filter)
   if (!on(F_SCAN_AGG) || p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col >= 0 || p.slot_width != 8) return false;
   for (int i = 0; i < p.n_quals; ++i)
     if (p.quals[i].type != MI355Q_INT32 && p.quals[i].type != MI355Q_INT64) return false;

@@ -764,3 +764,18 @@ def test_filters_with_arithmetic_still_take_the_projection_pass(sim, oracle):
     assert rs is not None
     route = Executor(0).explain(base.ra, [len(f[0]) for f in base.frags])
     assert "k_project" in route and "filter compiled" not in route, route
+
+
+@pytest.mark.parametrize("idx", range(6), ids=["and_in_or", "not_or", "composed", "not_null_cmp_and_plain_qual", "short_circuit_or",
+                                                "is_not_null_and_in_list"])
+def test_compiled_bool_filters_in_the_scan_aggregate(sim, oracle, idx):
+    """the same filters over a NON-GROUPED step — SELECT COUNT(*), SUM(v), MIN(c) FROM t WHERE <filter>, the shape of the reference's
+    Select.FilterAndSimpleAggregation — run in k_scan_agg with the compiled filter, no interpreter pass"""
+    from heavydb_amd.executor import Executor, TargetExpr
+    case = _bool_filter_cases(oracle)[idx]
+    case.ra.groupby_exprs = []
+    case.ra.target_exprs = [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 4)]
+    rs = flow._check(oracle, case)
+    assert rs is not None and rs.report.kernel_name.decode() == "k_scan_agg", rs.report.kernel_name
+    route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
+    assert "filter compiled" in route and "k_project" not in route and "k_scan_agg" in route, route
