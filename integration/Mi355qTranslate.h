@@ -198,7 +198,19 @@ inline void emit_expr(const Analyzer::Expr* e, mi355q_expr& x,
   } else if (auto u = dynamic_cast<const Analyzer::UOper*>(e)) {
     emit_expr(u->get_operand(), x, outer_col, hoisted);
     switch (u->get_optype()) {
-      case kCAST: push(MI355Q_EX_CAST, logical_type(u->get_type_info()), 0, 0, 0.0); break;
+      case kCAST: {
+        // DATE, TIME and TIMESTAMP(0) all live in 8-byte integers, but a cast between two of them (or to / from one of
+        // another precision) TRUNCATES or RESCALES in the reference (codegenCastTimestampToDate / ...ToTime /
+        // codegenCastBetweenTimestamps, CastIR.cpp:104-124): there is no micro-op for that, and an INT64 -> INT64
+        // no-op would group CAST(ts AS DATE) by the wrong values.  Refused (the reference's own path runs the step).
+        const SQLTypeInfo& from = u->get_operand()->get_type_info();
+        const SQLTypeInfo& to = u->get_type_info();
+        if ((from.is_time() || to.is_time()) &&
+            (from.get_type() != to.get_type() || from.get_dimension() != to.get_dimension()))
+          unsupported("cast between date / time types (or to / from one)");
+        push(MI355Q_EX_CAST, logical_type(to), 0, 0, 0.0);
+        break;
+      }
       case kNOT:  // codegenLogical(UOper), LogicalIR.cpp:363-379
         if (!u->get_operand()->get_type_info().is_boolean()) unsupported("NOT over a value that is not a BOOLEAN");
         push(MI355Q_EX_NOT, MI355Q_INT8, 0, 0, 0.0);

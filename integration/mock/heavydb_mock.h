@@ -60,6 +60,7 @@ class SQLTypeInfo {
   int get_dimension() const { return dimension_; }
   bool is_high_precision_timestamp() const { return type_ == kTIMESTAMP && dimension_ > 0; }
   bool is_boolean() const { return type_ == kBOOLEAN; }
+  bool is_time() const { return type_ == kTIME || type_ == kTIMESTAMP || type_ == kDATE; }  // (sqltypes.h is_datetime)
   bool is_integer() const { return type_ == kTINYINT || type_ == kSMALLINT || type_ == kINT || type_ == kBIGINT; }
   // bytes of the SQL type
   int get_logical_size() const {

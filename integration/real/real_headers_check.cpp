@@ -87,6 +87,22 @@ int main() {
     REQ(e.n_nodes == 2 && e.nodes[0].op == MI355Q_EX_COL && e.nodes[0].arg == 0 && e.nodes[1].op == MI355Q_EX_CAST &&
         e.nodes[1].type == MI355Q_DOUBLE);
   }
+  {  // CAST(ts AS DATE) / CAST(d AS TIMESTAMP) / TIMESTAMP(0) -> TIMESTAMP(3): truncating / rescaling casts in the reference
+     // (CastIR.cpp:104-124), all INT64 -> INT64 by logical type: refused, not lowered to a no-op
+    const SQLTypeInfo t_ts(kTIMESTAMP, 0, 0, false), t_date(kDATE, false), t_ts3(kTIMESTAMP, 3, 0, false);
+    auto ts = std::make_shared<ColumnVar>(t_ts, kx, 0);
+    int refused = 0;
+    for (const SQLTypeInfo& to : {t_date, t_ts3, t_big}) {
+      auto cast = std::make_shared<UOper>(to, false, kCAST, ts);
+      mi355q_expr e{};
+      try {
+        emit_expr(cast.get(), e, outer_col);
+      } catch (const std::runtime_error&) {
+        ++refused;
+      }
+    }
+    REQ(refused == 3);
+  }
   {
     Datum one;
     one.intval = 1;

@@ -28,6 +28,36 @@ PY
     timeout 2500 python -u -m pytest tests -m gpu -q -p no:cacheprovider ${3:-} > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
+  cfg1cost) timeout 300 python tools/cfg1_cost.py > $out/cfg1_cost.txt 2>&1; echo "exit $?"; tail -40 $out/cfg1_cost.txt ;;
+  final)    # the round's kept lines on ONE build: every BASELINE config (roofline + cpu_baseline + verify), the default line's
+            # rocprofv3 kernel summary and FETCH / WRITE passes (-> profiles/traffic.json), the Projection / filter / NGA shapes,
+            # the Projection kernel's rocprofv3 summary and counters, the reference's 57 benchmark steps at 1 B rows
+    timeout 400 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench default exit $? $(python -c "import json; d=json.load(open('$out/bench_default.json')); print(d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('whole_step_frac'))")"
+    for spec in "cfg1:--config cfg1 --steps 50 --warmup 5" "cfg2:--config cfg2 --steps 20 --warmup 3" "cfg3:--config cfg3" "cfg3f:--config cfg3f" "cfg4:--config cfg4" "cfg4_sum_dim:--config cfg4 --sum-dim" "cfg4_sparse:--config cfg4 --sparse" "cfg4_sparse_sum_dim:--config cfg4 --sparse --sum-dim"; do
+      tag=${spec%%:*}; args=${spec#*:}
+      timeout 600 python bench.py $args --verify > $out/bench_$tag.json 2> $out/bench_$tag.err
+      echo "$tag: exit $? $(python -c "import json; d=json.load(open('$out/bench_$tag.json')); print(d['ms_per_step'], d['roofline'].get('frac'), d['roofline'].get('whole_step_frac'), d['cpu_baseline']['value'] if d.get('cpu_baseline') else None)" 2>&1)"
+    done
+    timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o cfg3f -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_rocprof.json 2> $out/bench_rocprof.err
+    find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/cfg3f_kernel_stats.csv \; ; rm -rf $out/trace
+    for grp in FETCH_SIZE WRITE_SIZE; do
+      timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $out/pmc_$grp -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$grp.log 2>&1
+      python tools/rocpd_stats.py $out/pmc_$grp/pmc_results.db > $out/pmc_${grp}_stats.txt 2>&1; rm -rf $out/pmc_$grp
+    done
+    python tools/make_traffic_json.py $out/pmc_FETCH_SIZE_stats.txt $out/pmc_WRITE_SIZE_stats.txt 1e10 r05 && cp profiles/traffic.json $out/traffic.json
+    timeout 400 python bench.py > $out/bench_default_with_traffic.json 2> $out/bench_default_with_traffic.err; echo "bench (traffic) exit $?"
+    timeout 500 python tools/proj_bench.py --rows 1e9 --steps 5 > $out/proj_bench_1b.jsonl 2> $out/proj_bench.err; echo "proj bench exit $?"
+    timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/trace_proj -o proj -- python tools/proj_bench.py --rows 1e9 --steps 5 --sel 0.5 --cols 3 > $out/proj_rocprof.jsonl 2> $out/proj_rocprof.err
+    find $out/trace_proj -name "*kernel_stats.csv" -exec cp {} $out/proj_sel50_cols3_kernel_stats.csv \; ; rm -rf $out/trace_proj
+    for grp in FETCH_SIZE WRITE_SIZE; do
+      timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $out/pmc_proj_$grp -o pmc -- python tools/proj_bench.py --rows 1e9 --steps 0 --sel 0.5 --cols 3 > $out/pmc_proj_$grp.log 2>&1
+      python tools/rocpd_stats.py $out/pmc_proj_$grp/pmc_results.db | sed -n '/PMC/,$p' | grep -E "k_proj" > $out/pmc_proj_${grp}_stats.txt 2>&1; rm -rf $out/pmc_proj_$grp
+      cat $out/pmc_proj_${grp}_stats.txt | cut -c1-170
+    done
+    timeout 400 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --verify-rows 4e6 > $out/bool_filter_1b.jsonl 2> $out/bool_filter.err; echo "bool filter exit $?"
+    timeout 300 python tools/nga_sweep.py --rows 1e9 --bpc 0 > $out/nga_1b.jsonl 2> $out/nga.err; echo "nga exit $?"
+    timeout 700 python tools/refbench.py --rows 1e9 --steps 3 --budget-ms 1500 --out $out/refbench_1b.jsonl > $out/refbench_1b.log 2>&1; echo "refbench 1B exit $?"
+    head -3 $out/cfg3f_kernel_stats.csv ;;
   proj1)    # first contact of the Projection family: the case matrix on the device, then the 1 B-row bench lines
     timeout 900 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -x -q -p no:cacheprovider -k "case_on_the_device or larger_random" > $out/pytest.log 2>&1
     echo "pytest exit $?"; tail -5 $out/pytest.log
