@@ -664,11 +664,16 @@ inline void translate_where(const std::vector<const Analyzer::Expr*>& where, con
       emit_expr(e, x, outer_col);
       if (n++) push_and(0);
     }
+    // the deferred conjuncts are ALL evaluated once the primary ones pass (compileBody ANDs them inside sc_true): plain
+    // ANDs among themselves, ONE short-circuit AND behind the primary operand — `x > 0 AND a / b > 1 AND c / d > 1` with
+    // a / b > 1 FALSE and d = 0 raises DIV_BY_ZERO here as it does there
+    int m = 0;
     for (const Analyzer::Expr* e : deferred) {
       if (!e->get_type_info().is_boolean()) unsupported("qual shape");
       emit_expr(e, x, outer_col);
-      if (n++) push_and(1);
+      if (m++) push_and(0);
     }
+    if (n && m) push_and(1);
   });
   if (*n_quals >= kGlueMaxQuals) unsupported("too many quals");
   mi355q_qual q{};
