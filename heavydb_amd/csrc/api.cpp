@@ -1321,6 +1321,9 @@ void drain_inflight(DeviceCtx& ctx) {
     // the step was re-run after the call had returned: a consumer enqueued behind the first launches (pads, slices,
     // a collective) worked on the table the abandoned attempt left — tell the caller to redo it
     if (p->code == MI355Q_OK && p->tail->recomputed) p->code = MI355Q_STEP_RECOMPUTED;
+    // the asynchronous call never selects the members that can ask for another plan (execute_impl: `!pend`), and the
+    // result has been handed out, so planning again is not possible here: an internal code must not reach the caller
+    if (p->code == kRetryNoLds || p->code == kRetryNoIdx || p->code == kNotTaken) p->code = MI355Q_ERR_UNSUPPORTED;
     delete p->tail;
     p->tail = nullptr;
   }
@@ -3076,8 +3079,20 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     }
     std::memset(hm + ptr_bytes + rows_bytes, 0, 64);
     const size_t lo = nf > 0 ? 0 : ptr_bytes + rows_bytes;
-    HIP_TRY(hipMemcpyAsync(mp + lo, hm + lo, ptr_bytes + rows_bytes + 64 - lo, hipMemcpyHostToDevice, s));
+    // (reserve / explain launch nothing: no upload to leave in flight)
+    if (!reserved) HIP_TRY(hipMemcpyAsync(mp + lo, hm + lo, ptr_bytes + rows_bytes + 64 - lo, hipMemcpyHostToDevice, s));
   }
+  // The upload reads the SHARED pinned block: a return that does not reach finish_step (an allocation that fails, a HIP
+  // error, kNotTaken) must not leave it in flight — the next call on another stream rewrites h_meta and ctx.meta while
+  // the stale copy could still land.  Disarmed where the step synchronises itself or stays in flight by
+  // design (mi355q_execute_async: the next call drains it first).
+  struct UploadGuard {
+    hipStream_t s;
+    bool armed;
+    ~UploadGuard() {
+      if (armed) (void)hipStreamSynchronize(s);
+    }
+  } upload_guard{s, !reserved};
 
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   LaunchStats st;
@@ -3385,6 +3400,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   tail->trace = tr.on;
   tail->knobs = tune_knobs();
   tail->h_ret = (int32_t*)(ctx.h_meta + ctx.meta_bytes);
+  upload_guard.armed = false;  // (finish_step synchronises the stream; a pending step is drained before the next call)
   if (pend) {  // mi355q_execute_async: the rest runs in mi355q_wait (or before the next call on this device)
     mi355q_pending* p = new (std::nothrow) mi355q_pending();
     if (!p) {

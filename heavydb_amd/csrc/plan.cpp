@@ -499,6 +499,10 @@ int32_t qmd_init(const mi355q_plan& p, mi355q_qmd* q) {
   }
   for (int i = 0; i < p.n_quals; ++i) {
     if (p.quals[i].col < 0 || p.quals[i].col >= p.n_cols) return MI355Q_ERR_INVALID_PLAN;
+    // the OR-group bits are stated once, here: every later reader of quals[].op may rely on MI355Q_QUAL_OP() /
+    // MI355Q_QUAL_OR_GROUP() being in range (build_dev_plan repeats the check for plans that reach it another way)
+    const int32_t op = p.quals[i].op;
+    if (op < 0 || (op >> 16) != 0 || MI355Q_QUAL_OR_GROUP(op) > MI355Q_MAX_OR_GROUPS) return MI355Q_ERR_INVALID_PLAN;
   }
   const bool grouped = p.n_group_cols >= 1;
   ResolvedTarget ts[MI355Q_MAX_TARGETS];
