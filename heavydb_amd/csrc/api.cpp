@@ -2802,7 +2802,10 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     k.overlap_cus = o.tune_overlap_cus;
     set_tune_knobs(k);
   }
-  if (plan->n_exprs != 0 && !pend && !step_bool_filter() && !o.force_generic) {
+  bool proj_step = plan->n_targets > 0;
+  for (int i = 0; i < plan->n_targets && i < MI355Q_MAX_TARGETS; ++i) proj_step = proj_step && plan->targets[i].agg == MI355Q_PROJECT;
+  // (a Projection evaluates its expressions — filters included — in the compaction kernel's registers: below)
+  if (plan->n_exprs != 0 && !pend && !step_bool_filter() && !o.force_generic && !proj_step) {
     // A filter of comparisons with literals under AND / OR / NOT is compiled into atoms + a truth table and evaluated by
     // the consuming kernel on the values it holds in registers (boolfilter.h): no temporary column, no second pass.
     BoolFilterHost bfh;
@@ -2841,9 +2844,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   }
   if (plan->n_exprs != 0) {
     {  // a Projection evaluates its expressions in the compaction kernel's registers: no k_project pass
-      bool proj = plan->n_targets > 0;
-      for (int i = 0; i < plan->n_targets && i < MI355Q_MAX_TARGETS; ++i) proj = proj && plan->targets[i].agg == MI355Q_PROJECT;
-      if (proj) return execute_projection(plan, in, o, out, report, reserved);
+      if (proj_step) return execute_projection(plan, in, o, out, report, reserved);
     }
     if (!pend) {
       const size_t mark = t_route ? t_route->size() : 0;

@@ -201,8 +201,13 @@ void compare_plans(const mi355q_plan& a, const mi355q_plan& b) {
       const auto &x = a.exprs[k].nodes[i], &y = b.exprs[k].nodes[i];
       expect(x.op == y.op && x.arg == y.arg && x.ilit == y.ilit && x.flit == y.flit && (x.op == MI355Q_EX_COL || x.type == y.type), "plan: expression node");
     }
-    expect(a.exprs[k].range.min == b.exprs[k].range.min && a.exprs[k].range.max == b.exprs[k].range.max &&
-               a.exprs[k].range.fp_min == b.exprs[k].range.fp_min && a.exprs[k].range.fp_max == b.exprs[k].range.fp_max, "plan: expression range");
+    const bool range_ok = a.exprs[k].range.min == b.exprs[k].range.min && a.exprs[k].range.max == b.exprs[k].range.max &&
+                          a.exprs[k].range.fp_min == b.exprs[k].range.fp_min && a.exprs[k].range.fp_max == b.exprs[k].range.fp_max;
+    if (!range_ok)
+      std::printf("  expression %d range: by hand [%lld, %lld] [%g, %g], translated [%lld, %lld] [%g, %g]\n", k, (long long)a.exprs[k].range.min,
+                  (long long)a.exprs[k].range.max, a.exprs[k].range.fp_min, a.exprs[k].range.fp_max, (long long)b.exprs[k].range.min,
+                  (long long)b.exprs[k].range.max, b.exprs[k].range.fp_min, b.exprs[k].range.fp_max);
+    expect(range_ok, "plan: expression range");
   }
   expect(a.join_outer_col == b.join_outer_col && a.join_kind == b.join_kind && a.n_join_cols == b.n_join_cols, "plan: join");
   expect(a.max_groups_buffer_entry_guess == b.max_groups_buffer_entry_guess && a.num_tuples == b.num_tuples && a.scan_limit == b.scan_limit,
