@@ -204,6 +204,7 @@ OPT_TRACE, OPT_NO_PAIR_RENDEZVOUS, OPT_PROBE_NO_PACING, OPT_NO_LDS_BASELINE, OPT
 OPT_LDS_BASELINE_WINDOWS = 32
 OPT_LDS_GENERIC_MEMBER = 64
 OPT_NO_IDX_PART = 128
+OPT_NO_COMPILED_FILTER = 256
 
 
 class ExecReport(C.Structure):

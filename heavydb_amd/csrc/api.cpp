@@ -2484,7 +2484,7 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
                           mi355q_result** out, mi355q_exec_report* report) {
   mi355q_plan lp;
   DevExprSet xs;
-  if (int32_t e = lower_exprs(*plan, &lp, &xs)) return e;
+  if (int32_t e = lower_exprs(*plan, &lp, &xs, true)) return e;
   mi355q_qmd q;
   if (int32_t e = qmd_init(*plan, &q)) return e;
   DevPlan d;
@@ -2500,7 +2500,7 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
     max_frag_rows = std::max(max_frag_rows, in->num_rows[f]);
   }
   int64_t row_bytes = 0;
-  for (int k = 0; k < nx; ++k) row_bytes += plain_width(xs.e[k].type);
+  for (int k = 0; k < nx; ++k) row_bytes += plain_width(xs.e[k].store_type);
 
   DeviceGuard g(in->device_id);
   if (!g.ok) return MI355Q_ERR_HIP;
@@ -2575,7 +2575,7 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
       for (int c = 0; c < nc; ++c) cols2[(size_t)(f1 - f) * nc2 + c] = in->col_buffers[(size_t)f1 * nc + c];
       for (int k = 0; k < nx; ++k) {
         cols2[(size_t)(f1 - f) * nc2 + nc + k] = base + off;
-        off += (in->num_rows[f1] * plain_width(xs.e[k].type) + 15) & ~15ll;
+        off += (in->num_rows[f1] * plain_width(xs.e[k].store_type) + 15) & ~15ll;
       }
       rows += in->num_rows[f1];
       ++f1;
@@ -2805,7 +2805,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   bool proj_step = plan->n_targets > 0;
   for (int i = 0; i < plan->n_targets && i < MI355Q_MAX_TARGETS; ++i) proj_step = proj_step && plan->targets[i].agg == MI355Q_PROJECT;
   // (a Projection evaluates its expressions — filters included — in the compaction kernel's registers: below)
-  if (plan->n_exprs != 0 && !pend && !step_bool_filter() && !o.force_generic && !proj_step) {
+  if (plan->n_exprs != 0 && !pend && !step_bool_filter() && !o.force_generic && !proj_step && !(o.flags & MI355Q_OPT_NO_COMPILED_FILTER)) {
     // A filter of comparisons with literals under AND / OR / NOT is compiled into atoms + a truth table and evaluated by
     // the consuming kernel on the values it holds in registers (boolfilter.h): no temporary column, no second pass.
     BoolFilterHost bfh;
@@ -2858,7 +2858,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     if (reserved) {  // the step proper runs on the lowered plan: reserve for that
       route_note("k_project");
       mi355q_plan lp;
-      if (int32_t e = lower_exprs(*plan, &lp, nullptr)) return e;
+      if (int32_t e = lower_exprs(*plan, &lp, nullptr, true)) return e;
       return execute_impl(&lp, in, &o, out, report, nullptr, reserved);
     }
     return execute_projected(plan, in, o, out, report);

@@ -306,11 +306,18 @@ struct DevExprNode {
   double flit;       // EX_LIT (DOUBLE / FLOAT)
 };
 struct DevExpr {
-  int32_t n_nodes, type, nullable, pad_;
+  int32_t n_nodes, type, nullable;
+  int32_t store_type;  // the type of the dense temporary column a projection pass writes: `type`, or INT32 for a BOOLEAN
+                       // that only quals read (the typed families filter on 4- and 8-byte columns; plan.cpp lower_exprs)
   DevExprNode nodes[MI355Q_MAX_EXPR_NODES];
 };
 struct DevExprSet {
   int32_t n, n_cols;  // expressions; physical columns (expression k is written as column n_cols + k)
+  // k_project: the physical columns it loads up front for every row of a tile (expr.h eval_expr_rows `raw`), as the COL
+  // node that reads them describes them (type / type code)
+  int32_t n_pre, pre_col[4], pre_type[4], pre_code[4];
+  int32_t noerr_mask;  // bit k: expression k cannot raise an error (no arithmetic, cast or unary minus in it)
+  int32_t pad_[2];
   DevExpr e[MI355Q_MAX_EXPRS];
 };
 

@@ -695,45 +695,100 @@ __global__ __launch_bounds__(kBlock) void k_unpack_perfect(PackSpec ps, DevPlan 
 // the outputs.  The reference's row function evaluates target and group-by expressions only for rows that
 // passed the quals (and found a match under an INNER join), so an overflow only counts there; an expression
 // used by a qual is evaluated for every row (Executor::compileBody: filters first, then the body).
+constexpr int kProgQuads = MI355Q_MAX_EXPRS * MI355Q_MAX_EXPR_NODES * (int)sizeof(XNode) / 8;  // the programs in LDS, 8-byte words
+constexpr int kProjJ = 4;  // rows of a lane evaluated together: a node is decoded once per 4 x 64 rows (expr.h eval_expr_rows)
 __global__ __launch_bounds__(kBlock) void k_project(const DevExprSet* __restrict__ xsp, DevPlan p, uint32_t qual_expr_mask,
                                                      const int8_t* const* __restrict__ cols,
-                                                     const int64_t* __restrict__ num_rows, int n_frags,
+                                                     const int64_t* __restrict__ num_rows, int n_frags, int stack_below,
                                                      int32_t* __restrict__ d_err) {
+  extern __shared__ __attribute__((aligned(16))) int64_t s_proj_stack[];  // the programs, then stack_below x kProjJ x kBlock values
   const DevExprSet& xs = *xsp;  // (device memory: 8 programs of 24 nodes do not fit the 4 KB of kernel arguments)
-  const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t gsize = (int64_t)gridDim.x * kBlock;
   const int nc = xs.n_cols + xs.n;
+  constexpr int kTile = kProjJ * kBlock;
+  // LDS: the programs as XNodes (handler + literal), then the stack
+  XNode* const s_prog = (XNode*)s_proj_stack;
+  for (int w = threadIdx.x; w < xs.n * MI355Q_MAX_EXPR_NODES; w += kBlock) {
+    const DevExprNode& n = xs.e[w / MI355Q_MAX_EXPR_NODES].nodes[w % MI355Q_MAX_EXPR_NODES];
+    XNode x;
+    x.h = n.flags >> kExHandlerShift;
+    x.pad_ = 0;
+    x.lit = n.ilit;
+    s_prog[w] = x;
+  }
+  __syncthreads();
+  ExLdsStack stk;
+  stk.st = s_proj_stack + kProgQuads;
+  stk.tid = threadIdx.x;
   for (int f = 0; f < n_frags; ++f) {
     const int8_t* const* fc = cols + (size_t)f * nc;
     const int64_t n = num_rows[f];
-    for (int64_t pos = gtid; pos < n; pos += gsize) {
-      uint32_t err_mask = 0;
-      int32_t first_err = 0, first_qual_err = 0;  // the code of the first expression that failed (7 overflow, 1 division by zero)
-      for (int k = 0; k < xs.n; ++k) {
-        int32_t err = 0;
-        const int64_t v = eval_expr(xs.e[k], fc, pos, &err);
-        store_expr_value(const_cast<int8_t*>(fc[xs.n_cols + k]), xs.e[k].type, pos, v);
-        if (err) {
-          err_mask |= 1u << k;
-          if (!first_err) first_err = err;
-          if (!first_qual_err && ((qual_expr_mask >> k) & 1u)) first_qual_err = err;
+#pragma unroll 1
+    for (int64_t base = (int64_t)blockIdx.x * kTile; base < n; base += (int64_t)gridDim.x * kTile) {
+      int64_t pos[kProjJ];
+      bool live[kProjJ];
+#pragma unroll
+      for (int j = 0; j < kProjJ; ++j) {
+        const int64_t r = base + j * kBlock + threadIdx.x;
+        live[j] = r < n;
+        pos[j] = live[j] ? r : n - 1;  // (a lane past the end evaluates the last row again and keeps nothing of it)
+      }
+      // every plain physical column the programs read, all rows of the tile, in one batch of independent loads
+      int64_t raw[kExPre][kProjJ];
+#pragma unroll
+      for (int c = 0; c < kExPre; ++c) {
+        if (c < xs.n_pre) {
+          const int8_t* col = fc[xs.pre_col[c]];
+          if (xs.pre_code[c] == MI355Q_INT32) {
+#pragma unroll
+            for (int j = 0; j < kProjJ; ++j) raw[c][j] = (int64_t)*(const int32_t*)(col + pos[j] * 4);
+          } else {  // INT64 / DOUBLE: the 8 bytes as they are
+#pragma unroll
+            for (int j = 0; j < kProjJ; ++j) raw[c][j] = *(const int64_t*)(col + pos[j] * 8);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < kProjJ; ++j) raw[c][j] = 0;
         }
       }
-      if (err_mask) {  // rare: does the row count?
-        bool counts = (err_mask & qual_expr_mask) != 0;
+      uint32_t err_mask[kProjJ] = {};
+      int32_t first_err[kProjJ] = {}, first_qual_err[kProjJ] = {};  // the code of the first expression that failed (7 / 1)
+      bool any_err = false;
+#pragma unroll 1
+      for (int k = 0; k < xs.n; ++k) {
+        int64_t v[kProjJ];
+        int32_t err[kProjJ];
+        if ((xs.noerr_mask >> k) & 1) eval_expr_rows<kProjJ, kBlock, false>(xs.e[k], s_prog + k * MI355Q_MAX_EXPR_NODES, fc, pos, raw, stk, v, err);
+        else eval_expr_rows<kProjJ, kBlock, true>(xs.e[k], s_prog + k * MI355Q_MAX_EXPR_NODES, fc, pos, raw, stk, v, err);
+        int8_t* dst = const_cast<int8_t*>(fc[xs.n_cols + k]);
+#pragma unroll
+        for (int j = 0; j < kProjJ; ++j) {
+          if (!live[j]) continue;
+          store_expr_value(dst, xs.e[k], pos[j], v[j]);
+          if (err[j]) {
+            any_err = true;
+            err_mask[j] |= 1u << k;
+            if (!first_err[j]) first_err[j] = err[j];
+            if (!first_qual_err[j] && ((qual_expr_mask >> k) & 1u)) first_qual_err[j] = err[j];
+          }
+        }
+      }
+      if (!any_err) continue;
+      for (int j = 0; j < kProjJ; ++j) {  // rare: does the row count?
+        if (!err_mask[j]) continue;
+        bool counts = (err_mask[j] & qual_expr_mask) != 0;
         if (!counts) {
-          counts = quals_pass(p, fc, pos);
+          counts = quals_pass(p, fc, pos[j]);
           if (counts && p.join_col >= 0 && p.join_kind != MI355Q_JOIN_LEFT) {
             int64_t jk[MI355Q_MAX_GROUP_COLS];
             bool null_key = false;
             for (int i = 0; i < p.join_n_keys; ++i) {
-              jk[i] = decode_int(fc[p.join_cols[i]], p.join_types[i], pos);
+              jk[i] = decode_int(fc[p.join_cols[i]], p.join_types[i], pos[j]);
               null_key = null_key || (p.join_nullables[i] && jk[i] == int_null_of(p.join_types[i]));
             }
             counts = !null_key && join_lookup(p, jk).count > 0;
           }
         }
-        if (counts) atomicCAS(d_err, 0, first_qual_err ? first_qual_err : first_err);
+        if (counts) atomicCAS(d_err, 0, first_qual_err[j] ? first_qual_err[j] : first_err[j]);
       }
     }
   }
@@ -1632,11 +1687,68 @@ hipError_t launch_project(const DevExprSet& xs, DevExprSet* d_xs_area, const Dev
     }
     return hipGetLastError();
   }
-  // (the caller keeps `xs` alive and synchronises the stream after the launch)
-  hipError_t e = hipMemcpyAsync(d_xs_area, &xs, sizeof(xs), hipMemcpyHostToDevice, s);
+  // the device copy of the programs: every node labelled with its typed handler (expr.h XH_*), literals as patterns, and
+  // the plain physical columns the programs read (the first kExPre of them) listed for the per-tile batch of loads
+  static thread_local DevExprSet up;  // (the upload's source outlives the call: the caller synchronises the stream)
+  up = xs;
+  up.n_pre = 0;
+  up.noerr_mask = 0;
+  for (int k = 0; k < up.n; ++k) {
+    bool noerr = true;
+    for (int i = 0; i < up.e[k].n_nodes; ++i) {
+      const int op = up.e[k].nodes[i].op;
+      noerr = noerr && (op == MI355Q_EX_COL || op == MI355Q_EX_LIT || (op >= MI355Q_EX_EQ && op <= MI355Q_EX_GE) || op == MI355Q_EX_CASE ||
+                        op == MI355Q_EX_NOT || op == MI355Q_EX_AND || op == MI355Q_EX_OR || op == MI355Q_EX_IS_NULL);
+    }
+    if (noerr) up.noerr_mask |= 1 << k;
+  }
+  for (int k = 0; k < up.n; ++k)
+    for (int i = 0; i < up.e[k].n_nodes; ++i) {
+      DevExprNode& n = up.e[k].nodes[i];
+      int h = XH_GCOL;
+      if (n.op == MI355Q_EX_COL) {
+        const int code = (int)n.ilit;
+        if (n.arg < up.n_cols && (code == MI355Q_INT32 || code == MI355Q_INT64 || code == MI355Q_DOUBLE)) {
+          int slot = -1;
+          for (int c = 0; c < up.n_pre; ++c)
+            if (up.pre_col[c] == n.arg) slot = c;
+          if (slot < 0 && up.n_pre < kExPre) {
+            slot = up.n_pre++;
+            up.pre_col[slot] = n.arg;
+            up.pre_type[slot] = n.type;
+            up.pre_code[slot] = code;
+          }
+          if (slot >= 0) h = XH_COLPRE + slot;
+        }
+        else h = XH_GCOL;
+      } else {
+        h = xh_of(n);
+        if (n.op == MI355Q_EX_LIT) {  // (ex_lit's pattern, laid down once)
+          n.ilit = ex_lit(n);
+          n.arg = 1;
+        }
+      }
+      n.flags = (n.flags & ((1 << kExHandlerShift) - 1)) | (h << kExHandlerShift);
+    }
+  hipError_t e = hipMemcpyAsync(d_xs_area, &up, sizeof(up), hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_project, dim3(grid_for(max_frag_rows, n_cus * 8)), dim3(kBlock), 0, s, (const DevExprSet*)d_xs_area, p,
-                     qual_expr_mask, d_cols, d_num_rows, n_frags, d_err);
+  // LDS: the evaluation stack BELOW its top (the top stays in registers), sized for the deepest of the programs
+  int deepest = 1;
+  for (int k = 0; k < xs.n; ++k) {
+    int sp = 0;
+    for (int i = 0; i < xs.e[k].n_nodes; ++i) {
+      const int op = xs.e[k].nodes[i].op;
+      if (op == MI355Q_EX_COL || op == MI355Q_EX_LIT) ++sp;
+      else if (op == MI355Q_EX_CASE) sp -= 2;
+      else if (op != MI355Q_EX_CAST && op != MI355Q_EX_NOT && op != MI355Q_EX_IS_NULL && op != MI355Q_EX_UMINUS) --sp;
+      if (sp > deepest) deepest = sp;
+    }
+  }
+  const int below = deepest - 1;
+  const size_t lds = (size_t)kProgQuads * 8 + (size_t)below * kProjJ * kBlock * 8;
+  const int64_t tiles = (max_frag_rows + kProjJ * kBlock - 1) / (kProjJ * kBlock);
+  hipLaunchKernelGGL(k_project, dim3(grid_for(tiles * kBlock, n_cus * 8)), dim3(kBlock), lds, s, (const DevExprSet*)d_xs_area, p,
+                     qual_expr_mask, d_cols, d_num_rows, n_frags, below, d_err);
   return hipGetLastError();
 }
 

@@ -109,7 +109,7 @@ int col_type_code(const mi355q_col_desc& c) {
 // Type rules of the micro-op programs (what Analyzer::BinOper::normalize_simple_predicate / the analyzer's
 // common-type casts leave for the code generator): both operands of + - * already have the node's type,
 // casts go between any two numeric types, a column node takes the column's logical type.
-int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev) {
+int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev, bool widen_filter_bools) {
   if (p.n_exprs < 0 || p.n_exprs > MI355Q_MAX_EXPRS || p.n_cols < 0 || p.n_cols + p.n_exprs > MI355Q_MAX_COLS)
     return MI355Q_ERR_INVALID_PLAN;
   if (lowered != &p) *lowered = p;
@@ -269,10 +269,29 @@ int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev)
     }
     if (sp != 1) return MI355Q_ERR_INVALID_PLAN;
     d.type = st_type[0];
+    d.store_type = d.type;
     d.nullable = st_null[0] ? 1 : 0;
     const int c = p.n_cols + k;
     lowered->cols[c] = mi355q_col_desc{d.type, d.nullable, MI355Q_ENC_NONE, 0};
     lowered->col_ranges[c] = x.range;
+  }
+  if (widen_filter_bools) {
+    for (int k = 0; k < p.n_exprs; ++k) {
+      const int c = p.n_cols + k;
+      if (ds.e[k].type != MI355Q_INT8) continue;
+      bool filter_only = false, other = false;
+      for (int i = 0; i < p.n_quals && i < MI355Q_MAX_QUALS; ++i) filter_only = filter_only || p.quals[i].col == c;
+      for (int i = 0; i < p.n_group_cols && i < MI355Q_MAX_GROUP_COLS; ++i) other = other || p.group_cols[i] == c;
+      for (int i = 0; i < p.n_targets && i < MI355Q_MAX_TARGETS; ++i)
+        other = other || (p.targets[i].table == 0 && p.targets[i].col == c) || p.targets[i].cond.col == c;
+      other = other || p.join_outer_col == c;
+      for (int i = 1; i < p.n_join_cols && i < MI355Q_MAX_GROUP_COLS; ++i) other = other || p.join_outer_cols[i] == c;
+      for (int j = k + 1; j < p.n_exprs; ++j)
+        for (int i = 0; i < p.exprs[j].n_nodes; ++i) other = other || (p.exprs[j].nodes[i].op == MI355Q_EX_COL && p.exprs[j].nodes[i].arg == c);
+      if (!filter_only || other) continue;
+      ds.e[k].store_type = MI355Q_INT32;
+      lowered->cols[c].type = MI355Q_INT32;
+    }
   }
   lowered->n_cols = p.n_cols + p.n_exprs;
   lowered->n_exprs = 0;

@@ -40,7 +40,10 @@ void layout_from_qmd(const mi355q_qmd& q, DevPlan* d);
 // n_exprs == 0 — the plan every kernel family and the layout code see after the projection pass
 // (kernels_generic.hip k_project) has written the expression's values into a dense temporary column.
 // `dev` (optional) receives the lowered programs.
-int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev);
+// widen_filter_bools: an INT8 (BOOLEAN) expression that ONLY quals read is described — and stored by the projection pass —
+// as an INT32 column (its NULL becomes the INT32 NULL), so that the typed families, which filter on 4- and 8-byte
+// columns, take the lowered step
+int32_t lower_exprs(const mi355q_plan& p, mi355q_plan* lowered, DevExprSet* dev, bool widen_filter_bools = false);
 uint32_t expr_qual_mask(const mi355q_plan& p);  // expressions evaluated for every row (read by a qual, directly or through another)
 // one initialised row (key quads then slot init values); quad holds row_size / 8 entries
 void row_init_image(const mi355q_qmd& q, int64_t* quad);

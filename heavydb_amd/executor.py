@@ -693,14 +693,14 @@ class Executor:
         return got.value
 
     def explain(self, ra_exe_unit: RelAlgExecutionUnit, frag_rows: Sequence[int], kernel_variant: int = 0,
-                inner_rows: int = 0) -> str:
+                inner_rows: int = 0, flags: int = 0) -> str:
         """mi355q_explain: the route a step of this plan would take over fragments of these sizes (ExecutionOptions::
         just_explain of the reference shows the generated kernel; this shows which members of the fixed family run).
         No column data is needed: only the shape of the input decides."""
         plan = ra_exe_unit.to_plan()
         fr = FetchResult([[0] * plan.n_cols for _ in frag_rows], list(frag_rows), [0] * 8 if inner_rows else [], inner_rows)
         inp, keep = fr.to_c(plan.n_cols)
-        opts = self._opts(None, None, False, kernel_variant, 0)
+        opts = self._opts(None, None, False, kernel_variant, 0, flags=flags)
         buf = C.create_string_buffer(512)
         got = C.c_int64()
         check(self._lib.mi355q_explain(C.byref(plan), C.byref(inp), C.byref(opts), buf, 512, C.byref(got)), "explain")

@@ -542,6 +542,8 @@ typedef struct mi355q_exec_options {
                                             (roles compiled in) applies (tests compare the two) */
 #define MI355Q_OPT_NO_IDX_PART 128u       /* large perfect-hash tables: not the index-partitioned family (the library sets this
                                             itself when it re-runs a step whose spill list overflowed) */
+#define MI355Q_OPT_NO_COMPILED_FILTER 256u /* BOOLEAN filters: the interpreter pass (k_project) even where the filter compiles
+                                            into atoms + a truth table (tests and tools/bool_filter_bench.py compare the two) */
 
 /* per-call timing/selection report (what launchGpuCode logs,
  * QueryExecutionContext.cpp:334,364,579) */

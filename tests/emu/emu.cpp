@@ -96,7 +96,7 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
     // evaluated into dense temporary columns and the step runs on the lowered plan
     mi355q_plan lp;
     DevExprSet xs;
-    if (int32_t e = lower_exprs(*plan, &lp, &xs)) return e;
+    if (int32_t e = lower_exprs(*plan, &lp, &xs, true)) return e;
     mi355q_qmd ql;
     if (int32_t e = qmd_init(*plan, &ql)) return e;
     DevPlan dl;
@@ -120,7 +120,7 @@ extern "C" int32_t emu_execute(const mi355q_plan* plan, const mi355q_inputs* in,
         for (int k = 0; k < nx; ++k) {
           int32_t err = 0;
           const int64_t v = eval_expr(xs.e[k], fc, pos, &err);
-          store_expr_value((int8_t*)fc[nc + k], xs.e[k].type, pos, v);
+          store_expr_value((int8_t*)fc[nc + k], xs.e[k], pos, v);
           if (err) {
             err_mask |= 1u << k;
             if (!first_err) first_err = err;

@@ -374,11 +374,12 @@ def hostsim_lib(real_fast: bool = False) -> str:
         # the one construct the stand-in cannot express: dynamic LDS declared `extern __shared__`
         with open(os.path.join(csrc, "kernels_generic.hip")) as f:
             kg = f.read()
-        decl = "extern __shared__ __attribute__((aligned(16))) int64_t s_tab[];"
-        assert kg.count(decl) == 1
+        kg_host, n_sub = re.subn(r"extern __shared__ __attribute__\(\(aligned\(16\)\)\) int64_t (\w+)\[\];",
+                                 r"int64_t* const \1 = (int64_t*)hipsim::dynamic_shared();", kg)
+        assert n_sub == 2 and "extern __shared__" not in kg_host
         kg_cpp = os.path.join(out_dir, "kernels_generic_host.cpp")
         with open(kg_cpp, "w") as f:
-            f.write(kg.replace(decl, "int64_t* const s_tab = (int64_t*)hipsim::dynamic_shared();"))
+            f.write(kg_host)
         # kernels whose body holds a barrier, a wave shuffle / ballot or LDS run as fibers; the rest as plain loops
         names, plain = [], []
         with open(os.path.join(csrc, "kernels_proj.hip")) as f:

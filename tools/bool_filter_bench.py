@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--verify-rows", type=float, default=0, help="also check every shape against the oracle on a table of this many rows")
+    ap.add_argument("--interpreted", action="store_true", help="MI355Q_OPT_NO_COMPILED_FILTER: every expression through k_project")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -71,15 +72,16 @@ def main():
             [InputColDescriptor(capi.INT32, i == 4, ExpressionRange(True, 0, 999_999, False)) for i in range(1, 5)]
     fr = FetchResult(bufs, rows, keepalive=cols)
     ex = Executor(0)
+    flags = capi.OPT_NO_COMPILED_FILTER if args.interpreted else 0
     for name, exprs, quals, reads in shapes(capi, Expr, Qual):
         xs = [e.with_range(ExpressionRange(True, 0, 1, True)) for e in exprs]
         ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1)], quals, [0],
                                  exprs=xs, num_tuples=n)
         best, rs = None, None
         for _ in range(args.steps):
-            rs = ex.executeWorkUnit(ra, fr, allow_retry=False)
+            rs = ex.executeWorkUnit(ra, fr, allow_retry=False, flags=flags)
             best = rs.report.total_ms if best is None else min(best, rs.report.total_ms)
-        line = {"shape": name, "rows": n, "route": ex.explain(ra, rows), "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3),
+        line = {"shape": name, "rows": n, "interpreted": bool(args.interpreted), "route": ex.explain(ra, rows, flags=flags), "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3),
                 "bytes_per_row": 4 * len(reads), "whole_step_frac": round(4 * len(reads) * n / (best * 1e-3) / 8e12, 4),
                 "groups": rs.rowCount()}
         if args.verify_rows:
@@ -88,7 +90,7 @@ def main():
             m = min(int(args.verify_rows), rows[0])
             host = [t[:m].cpu().numpy() for t in cols]
             small = FetchResult([[int(t.data_ptr()) for t in cols]], [m], keepalive=cols)
-            got = ex.executeWorkUnit(ra, small, allow_retry=False)
+            got = ex.executeWorkUnit(ra, small, allow_retry=False, flags=flags)
             q, want, code = orc.execute(ra.to_plan(), [host], n_threads=8)
             assert code == 0
             compare_buffers(q, want, got.getStorage())

@@ -25,9 +25,17 @@ PY
     timeout 900 python bench.py --config cfg4 --steps 5 --warmup 2 --no-cpu-baseline --verify > $out/bench_cfg4a_dense.json 2> $out/err.log; echo "exit $?"
     cat $out/bench_cfg4a_dense.json; tail -3 $out/err.log ;;
   suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
-    timeout 2500 python -u -m pytest tests -m gpu -q -p no:cacheprovider ${3:-} > $out/pytest_gpu.log 2>&1
+    timeout 2500 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200
     python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
+  interp)   # k_project alone: the five BOOLEAN-filter shapes with MI355Q_OPT_NO_COMPILED_FILTER (every expression through the interpreter pass)
+    timeout 500 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --interpreted --verify-rows 4e6 > $out/bool_filter_1b_interpreted.jsonl 2> $out/err.log; echo "exit $?"
+    cut -c1-330 $out/bool_filter_1b_interpreted.jsonl; tail -5 $out/err.log
+    timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o interp -- python tools/bool_filter_bench.py --rows 1e9 --steps 3 --interpreted > /dev/null 2> $out/rocprof.err
+    find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/interp_kernel_stats.csv \; ; rm -rf $out/trace; cut -c1-200 $out/interp_kernel_stats.csv | head -8 ;;
+  interppmc) # k_project's instruction mix and stall split (SQ counters; one pass, kernel trace only)
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/pmc -o pmc -- python tools/bool_filter_bench.py --rows 1e9 --steps 1 --interpreted > $out/pmc.log 2>&1
+    python tools/rocpd_stats.py $out/pmc/pmc_results.db > $out/pmc_stats.txt 2>&1; rm -rf $out/pmc; grep -E "k_project|k_perfect_lds|k_groupby" $out/pmc_stats.txt | cut -c1-200; tail -3 $out/pmc.log ;;
   cfg1cost) timeout 300 python tools/cfg1_cost.py > $out/cfg1_cost.txt 2>&1; echo "exit $?"; tail -40 $out/cfg1_cost.txt ;;
   final)    # the round's kept lines on ONE build: every BASELINE config (roofline + cpu_baseline + verify), the default line's
             # rocprofv3 kernel summary and FETCH / WRITE passes (-> profiles/traffic.json), the Projection / filter / NGA shapes,
