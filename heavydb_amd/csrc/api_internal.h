@@ -124,6 +124,12 @@ struct DeviceCtx {
   // pinned host mirror of `meta` (column table, row counts, zeroed error words go to the device as ONE copy that does not
   // stage through a driver buffer) + 64 bytes the error words and the spill counter come back into
   char* h_meta = nullptr;
+  // what `meta` holds on the device: the table bytes of the last upload, and whether its error words are still the zeros
+  // that upload laid down (a prepared step over resident columns sends the same table every time: the copy — a DMA command
+  // ahead of the kernel, ~8 us of a 60 us scan — is then skipped)
+  std::vector<char> meta_shadow;
+  bool meta_err_clean = false;
+  int32_t* h_ret_dev = nullptr;  // the device's address of the 64 return bytes behind h_meta (k_words_to_host writes them)
   std::vector<hipEvent_t> events;
   hipStream_t stream = nullptr;  // library-owned launch stream (when the caller passes none)
   struct mi355q_pending* inflight = nullptr;  // a step enqueued by mi355q_execute_async and not yet waited for

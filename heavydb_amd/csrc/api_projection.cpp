@@ -116,6 +116,7 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
     ctx.meta_bytes = 0;
     if (ctx.h_meta) (void)hipHostFree(ctx.h_meta);
     ctx.h_meta = nullptr;
+    ctx.h_ret_dev = nullptr;
     HIP_TRY(hipMalloc(&ctx.meta, meta_bytes * 2));
     HIP_TRY(hipHostMalloc((void**)&ctx.h_meta, meta_bytes * 2 + 64, hipHostMallocDefault));
     ctx.meta_bytes = meta_bytes * 2;
@@ -132,6 +133,8 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
     }
     std::memset(hm + ptr_bytes + rows_bytes, 0, 64);
     const size_t lo = nf > 0 ? 0 : ptr_bytes + rows_bytes;
+    ctx.meta_shadow.clear();  // (execute_impl's record of what `meta` holds)
+    ctx.meta_err_clean = false;
     HIP_TRY(hipMemcpyAsync(mp + lo, hm + lo, ptr_bytes + rows_bytes + 64 - lo, hipMemcpyHostToDevice, s));
   }
   const DevExprSet* d_xs = nullptr;

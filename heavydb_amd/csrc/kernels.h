@@ -41,6 +41,8 @@ struct TuneKnobs {
   uint32_t flags = 0;  // MI355Q_OPT_*
   int overlap_cus = 0;  // partitioned GROUP BY: CUs of phase 1 while phase 2 of the previous chunk runs on the rest
 };
+// n 32-bit words of device memory into host memory the device can address (hipHostGetDevicePointer), one wave
+hipError_t launch_words_to_host(const int32_t* d_src, int32_t* h_dst_dev, int n, hipStream_t s);
 const TuneKnobs& tune_knobs();
 void set_tune_knobs(const TuneKnobs& k);
 // the compiled filter of the step being planned / launched on this thread (boolfilter.h; table already in device memory),

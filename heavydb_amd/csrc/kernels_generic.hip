@@ -18,6 +18,11 @@ namespace {
 
 constexpr int kBlock = 256;
 
+// the step's error words (+ the spill counter's copy) into pinned host memory, behind the step's kernels on their stream
+__global__ __launch_bounds__(64) void k_words_to_host(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+}
+
 __global__ __launch_bounds__(kBlock) void k_init_buffer(int64_t* __restrict__ buf,
                                                          int64_t total_quads, RowInit init) {
   const int64_t stride = (int64_t)gridDim.x * kBlock;
@@ -1261,6 +1266,11 @@ inline int grid_for(int64_t work_items, int max_blocks = 2048) {
 }
 
 }  // namespace
+
+hipError_t launch_words_to_host(const int32_t* d_src, int32_t* h_dst_dev, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_words_to_host, dim3(1), dim3(64), 0, s, d_src, h_dst_dev, n);
+  return hipGetLastError();
+}
 
 static thread_local TuneKnobs g_knobs;
 const TuneKnobs& tune_knobs() { return g_knobs; }

@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -397,7 +398,10 @@ hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) {
   if (bytes) std::memmove(dst, src, bytes);
   return hipSuccess;
 }
+static std::atomic<int> g_h2d_async{0};
+extern "C" int hostsim_h2d_async_copies() { return g_h2d_async.load(); }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind k, hipStream_t) {
+  if (k == hipMemcpyHostToDevice) ++g_h2d_async;
   return hipMemcpy(dst, src, bytes, k);
 }
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t) {
@@ -427,6 +431,10 @@ hipError_t hipEventCreate(hipEvent_t* e) {
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned) {
   *p = std::malloc(bytes ? bytes : 1);
   return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned) {
+  *dev = host;
+  return hipSuccess;
 }
 hipError_t hipHostFree(void* p) {
   std::free(p);

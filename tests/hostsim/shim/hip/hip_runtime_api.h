@@ -57,6 +57,7 @@ hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipDeviceSynchronize(void);
 enum { hipHostMallocDefault = 0 };
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
+hipError_t hipHostGetDevicePointer(void** dev, void* host, unsigned flags);
 hipError_t hipHostFree(void* p);
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);

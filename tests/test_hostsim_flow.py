@@ -315,3 +315,37 @@ def test_arrow_child_moved_out_survives_its_parent(sim, oracle):
     moved_a.release(C.byref(moved_a))
     assert not moved_s.release and not moved_a.release
     del junk
+
+
+def test_the_fragment_table_is_uploaded_once_for_repeated_steps(sim, oracle):
+    """a prepared step over resident columns sends the same column table every time: the second call skips the copy (and its
+    DMA command ahead of the kernel); a changed row count, or error words a step left non-zero, send it again"""
+    from heavydb_amd.executor import Executor, FetchResult
+    sim.hostsim_h2d_async_copies.restype = C.c_int
+    sim.hostsim_configure(ALL_ROUTES, 64, 150, 0)
+    case = _baseline_case(oracle, 20)
+    q, want, code = oracle.execute(case.ra.to_plan(), case.frags, n_threads=2)
+    ex = Executor(0)
+    fr = _fetch_result(case)
+    rs = ex.executeWorkUnit(case.ra, fr, allow_retry=False)
+    compare_buffers(q, want, rs.getStorage(), case.fp_rtol)
+    c0 = sim.hostsim_h2d_async_copies()
+    for _ in range(3):
+        rs = ex.executeWorkUnit(case.ra, fr, allow_retry=False)
+        compare_buffers(q, want, rs.getStorage(), case.fp_rtol)
+    assert sim.hostsim_h2d_async_copies() == c0, "the same table was uploaded again"
+    # fewer rows in the last fragment, the same pointers: a different table
+    n_last = len(case.frags[1][0]) - 7
+    short = [case.frags[0], [a[:n_last] for a in case.frags[1]]]
+    q2, want2, _ = oracle.execute(case.ra.to_plan(), short, n_threads=2)
+    fr2 = FetchResult(fr.col_buffers, [fr.num_rows[0], n_last], keepalive=[fr])
+    rs = ex.executeWorkUnit(case.ra, fr2, allow_retry=False)
+    compare_buffers(q2, want2, rs.getStorage(), case.fp_rtol)
+    assert sim.hostsim_h2d_async_copies() > c0
+    # a step whose LDS replicas overflow leaves a non-zero error word: the next call must lay the zeros down again
+    big = _baseline_case(oracle, 120)
+    qb, wantb, _ = oracle.execute(big.ra.to_plan(), big.frags, n_threads=2)
+    frb = _fetch_result(big)
+    for _ in range(2):
+        rs = ex.executeWorkUnit(big.ra, frb, allow_retry=False)
+        compare_buffers(qb, wantb, rs.getStorage(), big.fp_rtol)
