@@ -511,7 +511,10 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
 // queries have none); anything else — quals, wider values, DOUBLE arguments — stays with the generic member.
 MQ_D int32_t v4_get(const v4i32& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
-template <int KK, int NK, int NV, bool MM, int UQ>
+// FM = 1: the step has a filter — up to kTypedFlt plain INT32 columns under range quals (make_range_filter; two quals on
+// one column are one range), or under a filter compiled at plan time (boolfilter.h: atoms + truth table, a.bf_on)
+constexpr int kTypedFlt = 3;
+template <int KK, int NK, int NV, bool MM, int UQ, int FM>
 __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* const* __restrict__ cols,
                                                                   const int64_t* __restrict__ num_rows, int n_frags, int n_cols,
                                                                   LdsArgs a, DevPlan p, int64_t* __restrict__ out,
@@ -519,8 +522,13 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   static_assert(KK == 0 || NK == 1, "baseline members take one key column");
   constexpr bool kBase = KK != 0;
   constexpr int KW = KK == 1 ? 2 : 1;  // 16-byte loads per key quad
+  constexpr int TF = FM ? kTypedFlt : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ BoolFilter s_bf;  // (FM, a.bf_on: visible after the barrier behind the replicas' initialisation)
   const int t = threadIdx.x;
+  if constexpr (FM != 0) {
+    if (a.bf_on) bf_load(a.bf, &s_bf, t, kLdsBlock);
+  }
   const uint32_t K = 1u << a.copies_lg;
   const uint32_t E = a.entries;
   const uint32_t T = a.windows;
@@ -569,6 +577,46 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
 #pragma unroll
   for (int c = 0; c < NV; ++c) vnull[c] = a.v[c].nullable != 0;
   const uint32_t n_entries = (uint32_t)p.entry_count;
+  // the range filters in the columns' own 32 bits (a bound beyond them is the type's; an empty range is lo > hi)
+  const int nfl = FM ? a.n_flt : 0;
+  int32_t flo[TF], fhi[TF], fnv[TF];
+  bool fneg[TF], fnul[TF];
+#pragma unroll
+  for (int c = 0; c < TF; ++c) {
+    flo[c] = 1;
+    fhi[c] = 0;
+    fnv[c] = INT32_MIN;
+    fneg[c] = fnul[c] = false;
+    if (c < nfl) {
+      const int64_t lo = a.flt[c].lo, hi = a.flt[c].hi;
+      if (lo <= hi && lo <= (int64_t)INT32_MAX && hi >= (int64_t)INT32_MIN) {
+        flo[c] = lo < (int64_t)INT32_MIN ? INT32_MIN : (int32_t)lo;
+        fhi[c] = hi > (int64_t)INT32_MAX ? INT32_MAX : (int32_t)hi;
+      }
+      fneg[c] = a.flt[c].negate != 0;
+      fnul[c] = a.flt[c].nullable != 0;
+      fnv[c] = (int32_t)a.flt[c].null_val;
+    }
+  }
+  auto row_passes = [&](const int32_t (&fv)[TF]) -> bool {
+    if constexpr (FM == 0) return true;
+    if (a.bf_on) {
+      int64_t vals[TF];
+#pragma unroll
+      for (int c = 0; c < TF; ++c) vals[c] = (int64_t)fv[c];
+      return bf_row_passes<TF>(s_bf, vals);
+    }
+    bool pass = true;
+#pragma unroll
+    for (int c = 0; c < TF; ++c) {
+      if (c >= nfl) break;
+      bool in = fv[c] >= flo[c] && fv[c] <= fhi[c];
+      if (fneg[c]) in = !in;
+      if (fnul[c] && fv[c] == fnv[c]) in = false;
+      pass = pass && in;
+    }
+    return pass;
+  };
 
   // entry e takes one row's values
   auto update = [&](uint32_t e, const int32_t (&vv)[NV]) {
@@ -644,6 +692,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   struct Tile {
     v4i32 k[NK][UQ][KW];
     v4i32 v[NV][UQ];
+    v4i32 f[TF][UQ];
   };
   const int64_t tile_q = (int64_t)kLdsBlock * UQ;
   const int64_t gtid = (int64_t)stripe * kLdsBlock + t;
@@ -654,15 +703,22 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
     const int64_t n = num_rows[f];
     const int64_t nq = n >> 2;
     const int64_t n_tiles = nq / tile_q;
-    const int8_t *kb[NK], *vb[NV];
+    const int8_t *kb[NK], *vb[NV], *fb[TF];
 #pragma unroll
     for (int g = 0; g < NK; ++g) kb[g] = fc[a.key_col[g]];
 #pragma unroll
     for (int c = 0; c < NV; ++c) vb[c] = fc[a.v[c].col];
+#pragma unroll
+    for (int c = 0; c < TF; ++c) fb[c] = c < nfl ? fc[a.flt[c].col] : nullptr;
     auto load_tile = [&](Tile& tl, int64_t q0, int64_t stride) {
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
         const int64_t quad = q0 + (int64_t)u * stride;
+        if constexpr (FM != 0) {
+#pragma unroll
+          for (int c = 0; c < TF; ++c)
+            if (c < nfl) tl.f[c][u] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)fb[c] + quad);
+        }
 #pragma unroll
         for (int g = 0; g < NK; ++g) {
 #pragma unroll
@@ -689,6 +745,12 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
             else key[i] = key_of(v4_get(tl.k[0][u][0], i), 0);
             hh[i] = lds_key_mix(key[i]);
             acc[i] = !(T > 1 && lds_mix_window(T, hh[i]) != win);
+            if constexpr (FM != 0) {
+              int32_t fv[TF];
+#pragma unroll
+              for (int c = 0; c < TF; ++c) fv[c] = c < nfl ? v4_get(tl.f[c][u], i) : 0;
+              acc[i] = acc[i] && row_passes(fv);
+            }
           }
 #pragma unroll
           for (int i = 0; i < 4; ++i) k0[i] = acc[i] ? *(volatile int64_t*)&my_keys[hh[i] & (E - 1)] : kEmptyKey64;
@@ -709,6 +771,12 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             int32_t klo[NK], vv[NV];
+            if constexpr (FM != 0) {
+              int32_t fv[TF];
+#pragma unroll
+              for (int c = 0; c < TF; ++c) fv[c] = c < nfl ? v4_get(tl.f[c][u], i) : 0;
+              if (!row_passes(fv)) continue;
+            }
 #pragma unroll
             for (int g = 0; g < NK; ++g) klo[g] = v4_get(tl.k[g][u][0], i);
             const uint32_t e = perfect_entry(klo);
@@ -751,7 +819,10 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
       }
 #pragma unroll
       for (int c = 0; c < NV; ++c) vv[c] = load_one<int32_t>(vb[c], tail);
-      one_row(klo, khi, vv);
+      int32_t fv[TF];
+#pragma unroll
+      for (int c = 0; c < TF; ++c) fv[c] = c < nfl ? load_one<int32_t>(fb[c], tail) : 0;
+      if (row_passes(fv)) one_row(klo, khi, vv);
     }
   }
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
@@ -906,9 +977,10 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out
     }
     return (off + 15u) & ~15u;
   };
-  // typed member (k_groupby_lds_typed): no quals, 1 - 3 plain INT32 value columns; perfect hash over INT32 keys whose
+  // typed member (k_groupby_lds_typed): up to three plain INT32 filter columns, 1 - 3 plain INT32 value columns; perfect hash over INT32 keys whose
   // ranges keep the index arithmetic in 32 bits, or a baseline table over one BIGINT / DOUBLE / FLOAT / INT key
-  a.typed = a.n_flt == 0 && a.n_vals >= 1 && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
+  a.typed = a.n_flt <= kTypedFlt && a.n_vals >= 1 && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
+  for (int k = 0; k < a.n_flt; ++k) a.typed = a.typed && a.flt_type[k] == MI355Q_INT32;
   a.mm = 0;
   for (int c = 0; c < a.n_vals; ++c) {
     a.typed = a.typed && a.v[c].type == MI355Q_INT32;
@@ -992,7 +1064,14 @@ template <int KK, int NK, int NV, bool MM>
 void launch_typed_member(const LdsLaunch& l) {
   // two quads per lane and column while the tile (this one and the next in flight) stays within ~64 registers
   constexpr int UQ = (NK * (KK == 1 ? 2 : 1) + NV) <= 3 ? 2 : 1;
-  auto k = k_groupby_lds_typed<KK, NK, NV, MM, UQ>;
+  if (l.a.n_flt > 0) {  // the filtered member: one quad per lane and column (up to three more columns in the tile)
+    auto k = k_groupby_lds_typed<KK, NK, NV, MM, 1, 1>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds);
+    hipLaunchKernelGGL(k, dim3(l.grid), dim3(kLdsBlock), l.lds, l.s, l.fv.d_cols, l.fv.d_num_rows, l.fv.n_frags, l.fv.n_cols,
+                       l.a, l.p, l.out, l.d_err);
+    return;
+  }
+  auto k = k_groupby_lds_typed<KK, NK, NV, MM, UQ, 0>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds);
   hipLaunchKernelGGL(k, dim3(l.grid), dim3(kLdsBlock), l.lds, l.s, l.fv.d_cols, l.fv.d_num_rows, l.fv.n_frags, l.fv.n_cols,
                      l.a, l.p, l.out, l.d_err);

@@ -779,3 +779,81 @@ def test_compiled_bool_filters_in_the_scan_aggregate(sim, oracle, idx):
     assert rs is not None and rs.report.kernel_name.decode() == "k_scan_agg", rs.report.kernel_name
     route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
     assert "filter compiled" in route and "k_project" not in route and "k_scan_agg" in route, route
+
+
+# ---- the typed member under filters (round 5): up to three plain INT32 filter columns, range quals or a compiled filter
+def _filtered_lds_case(oracle, quals, exprs=(), baseline=False, n=9003, nullable_flt=False, seed=11):
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(seed)
+    I32 = capi.INT32
+    g = rng.integers(0, 50, n).astype(np.int32)
+    v = rng.integers(-1000, 1000, n).astype(np.int32)
+    a = rng.integers(-20, 20, n).astype(np.int32)
+    b = rng.integers(0, 100, n).astype(np.int32)
+    c = rng.integers(0, 100, n).astype(np.int32)
+    if nullable_flt:
+        a[rng.random(n) < 0.1] = -2**31
+        c[rng.random(n) < 0.2] = -2**31
+    if baseline:
+        key = (g.astype(np.int64) * 1000003 + 17)
+        kd = InputColDescriptor(capi.INT64, False, ExpressionRange(False))
+    else:
+        key, kd = g, InputColDescriptor(I32, False, ExpressionRange(True, 0, 49))
+    descs = [kd, InputColDescriptor(I32, False, ExpressionRange(True, -1000, 999)),
+             InputColDescriptor(I32, nullable_flt, ExpressionRange(True, -20, 19, nullable_flt)),
+             InputColDescriptor(I32, False, ExpressionRange(True, 0, 99)),
+             InputColDescriptor(I32, nullable_flt, ExpressionRange(True, 0, 99, nullable_flt))]
+    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 1)],
+                             list(quals), [0], exprs=[e.with_range(ExpressionRange(True, 0, 1, True)) for e in exprs],
+                             max_groups_buffer_entry_guess=256, num_tuples=n)
+    h = n // 2 + 1
+    cols = [key, v, a, b, c]
+    return cases_mod.Case("f", ra, [[x[:h] for x in cols], [x[h:] for x in cols]])
+
+
+def _typed_filter_quals():
+    from heavydb_amd.executor import Qual
+    return {
+        "one_range": [Qual(2, capi.LT, 5)],
+        "two_bounds_one_column": [Qual(3, capi.GT, 10), Qual(3, capi.LE, 80)],
+        "three_columns": [Qual(2, capi.GE, -5), Qual(3, capi.LT, 70), Qual(4, capi.GT, 20)],
+        "not_equal": [Qual(3, capi.NE, 42), Qual(2, capi.LT, 100)],
+        "is_not_null": [Qual(2, capi.IS_NOT_NULL, 0), Qual(4, capi.LT, 50)],
+        "is_null": [Qual(4, capi.IS_NULL, 0)],
+        "bound_beyond_int32": [Qual(3, capi.LT, 1 << 40), Qual(2, capi.GT, -(1 << 40))],
+        "empty_range": [Qual(3, capi.LT, -(1 << 40))],
+        "empty_range_negated": [Qual(3, capi.NE, 1 << 40)],
+    }
+
+
+@pytest.mark.parametrize("member", ["typed", "generic"])
+@pytest.mark.parametrize("baseline", [False, True], ids=["perfect", "baseline"])
+@pytest.mark.parametrize("nullable", [False, True], ids=["notnull", "nullable"])
+@pytest.mark.parametrize("shape", list(_typed_filter_quals()))
+def test_typed_lds_member_under_range_filters(sim, oracle, shape, nullable, baseline, member):
+    if shape in ("is_not_null", "is_null") and not nullable:
+        pytest.skip("the qual is constant on a NOT NULL column")
+    case = _filtered_lds_case(oracle, _typed_filter_quals()[shape], baseline=baseline, nullable_flt=nullable)
+    rs = flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_LDS_GENERIC_MEMBER if member == "generic" else 0)
+    assert rs is not None
+    name = rs.report.kernel_name.decode()
+    assert name in ("k_groupby_lds", "k_perfect_lds"), name   # (one range qual over a perfect-hash table: the older family)
+    if name == "k_groupby_lds":
+        assert rs.report.variant == (4 if member == "generic" else 5), rs.report.variant
+    assert name == "k_groupby_lds" or (shape in ("one_range", "is_null", "empty_range", "empty_range_negated", "two_bounds_one_column") and not baseline), (name, shape)
+
+
+@pytest.mark.parametrize("baseline", [False, True], ids=["perfect", "baseline"])
+@pytest.mark.parametrize("nullable", [False, True], ids=["notnull", "nullable"])
+def test_typed_lds_member_under_a_compiled_filter(sim, oracle, nullable, baseline):
+    """(a < 5 AND b > 30) OR c IS NULL, and NOT (a < 0 OR b > 60): atoms + truth table inside the typed member"""
+    from heavydb_amd.executor import Executor, Expr, Qual
+    I32 = capi.INT32
+    C_, L = Expr.col, lambda x: Expr.lit(I32, x)
+    for e in (C_(2).cmp(capi.EX_LT, L(5)).logical(capi.EX_AND, C_(3).cmp(capi.EX_GT, L(30))).logical(capi.EX_OR, C_(4).is_null()),
+              C_(2).cmp(capi.EX_LT, L(0)).logical(capi.EX_OR, C_(3).cmp(capi.EX_GT, L(60))).logical_not()):
+        case = _filtered_lds_case(oracle, [Qual(5, capi.EQ, 1)], exprs=[e], baseline=baseline, nullable_flt=nullable)
+        rs = flow._check(oracle, case, kernel_variant=0)
+        assert rs is not None and rs.report.kernel_name.decode() == "k_groupby_lds" and rs.report.variant == 5, (rs.report.kernel_name, rs.report.variant)
+        route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
+        assert "filter compiled" in route and "k_project" not in route, route
