@@ -280,6 +280,7 @@ SYMBOLS = [
     ("mi355q_result_reduce", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355q_result_row_count", C.c_int64, [C.c_void_p]),
     ("mi355q_result_total_matched", C.c_int64, [C.c_void_p]),
+    ("mi355q_result_append", C.c_int32, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mi355q_result_fetch_rows", C.c_int32,
      [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _P(C.c_int64)]),
     ("mi355q_result_to_columns", C.c_int32, [C.c_void_p, _P(C.c_void_p), C.c_int32, _P(C.c_int64), C.c_void_p]),

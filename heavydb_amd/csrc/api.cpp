@@ -412,6 +412,8 @@ int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_r
   if (!this_rs || !that_rs) return MI355Q_ERR_INVALID_PLAN;
   const mi355q_qmd& a = this_rs->qmd;
   const mi355q_qmd& b = that_rs->qmd;
+  // projections are not reduced but appended (Executor::resultsUnion, Execute.cpp:1670-1694)
+  if (a.desc_type == MI355Q_PROJECTION && b.desc_type == MI355Q_PROJECTION) return projection_append(this_rs, that_rs, (hipStream_t)stream);
   if (a.desc_type != b.desc_type || a.row_size != b.row_size || a.slot_count != b.slot_count ||
       a.keyless != b.keyless || a.key_width != b.key_width || a.output_columnar != b.output_columnar ||
       this_rs->device_id != that_rs->device_id) {
@@ -440,6 +442,11 @@ int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_r
     return store_row_twin(ta, this_rs, (hipStream_t)stream);
   }
   return run_reduce(this_rs, that_rs->buf, b.entry_count, stream);
+}
+
+int32_t mi355q_result_append(mi355q_result* this_rs, const mi355q_result* that_rs, void* stream) {
+  if (!this_rs || !that_rs) return MI355Q_ERR_INVALID_PLAN;
+  return projection_append(this_rs, that_rs, (hipStream_t)stream);
 }
 
 int64_t mi355q_result_total_matched(const mi355q_result* r) {

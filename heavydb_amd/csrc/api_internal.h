@@ -57,6 +57,7 @@ struct mi355q_result {
   int64_t bytes = 0;
   bool owns_buf = false;
   int64_t total_matched = -1;  // Projection results: rows that passed the quals; -1 = not known to the host (a wrapped buffer)
+  int64_t live_rows = -1;      // Projection results put together by mi355q_result_append: the rows at the front of the buffer
 };
 
 namespace mq {
@@ -154,6 +155,7 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
                            mi355q_exec_report* report, int64_t* reserved);
 // result accessors of a Projection buffer
 int64_t projection_row_count(const mi355q_result* r);
+int32_t projection_append(mi355q_result* this_rs, const mi355q_result* that_rs, hipStream_t s);
 int32_t projection_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival, double* dval, int8_t* is_null, int64_t* n_rows);
 
 }  // namespace api

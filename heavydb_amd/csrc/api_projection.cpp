@@ -199,8 +199,85 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
   return MI355Q_OK;
 }
 
+// ResultSet::append (ResultSet.cpp:307-335; Executor::resultsUnion -> get_merged_result, Execute.cpp:1642-1694): the
+// results of a projection over several devices / kernels are not reduced but laid one behind the other — the entry
+// count becomes the sum, iteration walks the first storage and then the appended ones.  A result here is ONE buffer, so
+// `this` gets a new buffer of both entry counts: its own rows, then that's, then the EMPTY_KEY_64 tail.
+int32_t projection_append(mi355q_result* a, const mi355q_result* b, hipStream_t s) {
+  const mi355q_qmd& qa = a->qmd;
+  const mi355q_qmd& qb = b->qmd;
+  if (qa.desc_type != MI355Q_PROJECTION || qb.desc_type != MI355Q_PROJECTION || qa.output_columnar != qb.output_columnar ||
+      qa.row_size != qb.row_size || qa.slot_count != qb.slot_count || qa.n_targets != qb.n_targets || a->device_id != b->device_id)
+    return MI355Q_ERR_INVALID_PLAN;
+  for (int j = 0; j < qa.slot_count && j < MI355Q_MAX_SLOTS; ++j)
+    if (qa.slot_bytes[j] != qb.slot_bytes[j]) return MI355Q_ERR_INVALID_PLAN;
+  for (int t = 0; t < qa.n_targets && t < MI355Q_MAX_TARGETS; ++t)
+    if (qa.target_slot[t] != qb.target_slot[t] || qa.target_is_fp[t] != qb.target_is_fp[t] ||
+        qa.target_arg_is_f32[t] != qb.target_arg_is_f32[t] || qa.target_null[t] != qb.target_null[t])
+      return MI355Q_ERR_INVALID_PLAN;
+  const int64_t na = projection_row_count(a), nb = projection_row_count(b);
+  if (na < 0 || nb < 0) return MI355Q_ERR_HIP;
+  // (a wrapped buffer may hold its rows anywhere: only results whose rows are known to sit at the front are appended)
+  if ((a->total_matched < 0 && a->live_rows < 0) || (b->total_matched < 0 && b->live_rows < 0)) return MI355Q_ERR_UNSUPPORTED;
+  mi355q_qmd nq = qa;
+  nq.entry_count = qa.entry_count + qb.entry_count;
+  if (nq.entry_count > (int64_t)INT32_MAX) return MI355Q_ERR_UNSUPPORTED;
+  mi355q_result* tmp = nullptr;
+  if (int32_t e = result_create_impl(&nq, a->device_id, nullptr, &tmp)) return e;
+  struct TmpGuard {
+    mi355q_result*& r;
+    ~TmpGuard() { if (r) mi355q_result_free(r); }
+  } tg{tmp};
+  DeviceGuard g(a->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  char* dst = (char*)tmp->buf;
+  const int64_t tail = nq.entry_count - (na + nb);
+  if (!nq.output_columnar) {
+    const int64_t rb = nq.row_size;
+    if (na) HIP_TRY(hipMemcpyAsync(dst, a->buf, (size_t)(na * rb), hipMemcpyDeviceToDevice, s));
+    if (nb) HIP_TRY(hipMemcpyAsync(dst + na * rb, b->buf, (size_t)(nb * rb), hipMemcpyDeviceToDevice, s));
+    if (tail) {
+      RowInit ri{};
+      ri.row_quad = nq.row_size / 8;
+      row_init_image(nq, ri.quad);
+      HIP_TRY(launch_init_buffer((int64_t*)(dst + (na + nb) * rb), tail, ri, s));
+    }
+  } else {
+    // the key column (8 bytes per entry), then every slot column at its logical width
+    if (na) HIP_TRY(hipMemcpyAsync(dst, a->buf, (size_t)(na * 8), hipMemcpyDeviceToDevice, s));
+    if (nb) HIP_TRY(hipMemcpyAsync(dst + na * 8, b->buf, (size_t)(nb * 8), hipMemcpyDeviceToDevice, s));
+    if (tail) {
+      RowInit ri{};
+      ri.row_quad = 1;
+      ri.quad[0] = kEmptyKey64;
+      HIP_TRY(launch_init_buffer((int64_t*)(dst + (na + nb) * 8), tail, ri, s));
+    }
+    for (int j = 0; j < nq.slot_count; ++j) {
+      const int64_t w = nq.slot_bytes[j];
+      char* col = dst + qmd_slot_col_offset(nq, j);
+      if (na) HIP_TRY(hipMemcpyAsync(col, (const char*)a->buf + qmd_slot_col_offset(qa, j), (size_t)(na * w), hipMemcpyDeviceToDevice, s));
+      if (nb) HIP_TRY(hipMemcpyAsync(col + na * w, (const char*)b->buf + qmd_slot_col_offset(qb, j), (size_t)(nb * w), hipMemcpyDeviceToDevice, s));
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(s));
+  if (a->owns_buf && a->buf) (void)hipFree(a->buf);
+  a->buf = tmp->buf;
+  a->bytes = tmp->bytes;
+  a->owns_buf = true;
+  a->qmd = nq;
+  a->dplan = tmp->dplan;
+  tmp->buf = nullptr;  // (moved)
+  tmp->owns_buf = false;
+  a->live_rows = na + nb;
+  // the rows that passed the quals on both sides, where both sides know (a scan_limit may have cut either output)
+  const int64_t ta = a->total_matched >= 0 ? a->total_matched : na, tb = b->total_matched >= 0 ? b->total_matched : nb;
+  a->total_matched = ta + tb;
+  return MI355Q_OK;
+}
+
 int64_t projection_row_count(const mi355q_result* r) {
   const mi355q_qmd& q = r->qmd;
+  if (r->live_rows >= 0) return r->live_rows;
   if (r->total_matched >= 0) return std::min(r->total_matched, q.entry_count);
   // a wrapped buffer: the entries whose key is not EMPTY_KEY_64 (ResultSet::isEmptyEntry)
   DeviceGuard g(r->device_id);

@@ -501,6 +501,11 @@ class ResultSet:
         scan_limit cut the output.  -1 for any other result."""
         return self._lib.mi355q_result_total_matched(self.handle)
 
+    def append(self, that: "ResultSet", stream: int | None = None) -> None:
+        """ResultSet::append (ResultSet.cpp:307-335): a Projection result followed by another one's rows — how the
+        reference puts the devices' / kernels' projections together (Executor::resultsUnion)."""
+        check(self._lib.mi355q_result_append(self.handle, that.handle, C.c_void_p(stream or 0)), "result_append")
+
     def fetch(self) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """All rows in entry order: (ival[n,t], dval[n,t], is_null[n,t])."""
         q = self.getQueryMemDesc()

@@ -245,6 +245,12 @@ def _gather_to_rank0(out: ShardOps, shard: ShardOps, dist, torch, group, rq: int
 def merge(shard: ShardOps, dist, torch, group=None, gather_to_rank0: bool = False,
           prepartitioned: bool = False) -> ShardOps:
     """The final-aggregate merge of one step across the ranks of `group`."""
+    if shard.qmd().desc_type == capi.PROJECTION:
+        # a projection is not reduced: the devices' results are laid one behind the other (Executor::resultsUnion ->
+        # ResultSet::append, Execute.cpp:1642-1694, ResultSet.cpp:307-335).  Here every rank keeps the rows of its own
+        # fragments on its device — the result is the ranks' parts in rank order, total_matched their sum (all_reduce
+        # by the caller where it needs the number); parts on ONE device are put together by mi355q_result_append.
+        return shard
     if shard.qmd().desc_type == capi.GROUP_BY_BASELINE_HASH:
         return merge_keyed(shard, dist, torch, group, gather_to_rank0, prepartitioned)
     return merge_dense(shard, dist, torch, group)

@@ -641,6 +641,12 @@ int32_t mi355q_result_copy_to_host(const mi355q_result* r, void* dst, int64_t ds
  * :783-826).  Both on the same device. */
 int32_t mi355q_result_reduce(mi355q_result* this_rs, const mi355q_result* that_rs,
                              void* stream);
+/* Projection results: this = this's rows followed by that's (ResultSet::append, ResultSet.cpp:307-335, as
+ * Executor::resultsUnion puts the devices' results together, Execute.cpp:1642-1694): the entry count becomes the sum of
+ * both, total_matched too; `this` moves into a buffer the library owns (mi355q_result_device_ptr changes — a caller-
+ * provided out_buffer is left behind, not freed).  mi355q_result_reduce does the same when both sides are projections.
+ * MI355Q_ERR_UNSUPPORTED for a wrapped buffer (its rows need not sit at the front). */
+int32_t mi355q_result_append(mi355q_result* this_rs, const mi355q_result* that_rs, void* stream);
 /* number of non-empty entries (ResultSet::rowCount, ResultSet.h:327) */
 int64_t mi355q_result_row_count(const mi355q_result* r);
 /* Projection results: the rows that passed the quals (the kernel's total_matched word, KernelParam::TOTAL_MATCHED,

@@ -174,6 +174,16 @@ def _table(shape, seed=7):
         descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, 8999 * 1000003 + 7))]
         ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT)], groupby_exprs=[0], max_groups_buffer_entry_guess=18_000)
         cols = [key]
+    elif shape == "projection":  # SELECT a, v FROM t WHERE f < 2^30: rows are emitted, not aggregated — nothing is reduced
+        a = rng.integers(-1000, 1000, n).astype(np.int64)
+        v = (rng.random(n) * 10.0).astype(np.float64)
+        fil = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+        descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, -1000, 999)),
+                 InputColDescriptor(capi.DOUBLE, False, ExpressionRange(True, 0, 0, False, 0.0, 10.0)),
+                 InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 2**31 - 1))]
+        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT, 0), TargetExpr(capi.PROJECT, 1)], [Qual(2, capi.LT, 2**30)],
+                                 max_groups_buffer_entry_guess=n)
+        cols = [a, v, fil]
     elif shape == "perfect_float":  # float slots: merged by the reduce rule, not by all_reduce
         key = rng.integers(0, 300, n).astype(np.int32)
         val = (rng.random(n) * 10.0).astype(np.float32)
@@ -290,6 +300,21 @@ def _worker(rank, world, port, shape, errq, real_library=False):
             shard = NumpyShard(torch, orc, q, buf)
         before = shard.buffer().numpy().copy()
         out = merge(shard, dist, torch, gather_to_rank0=True, prepartitioned=prepart)
+        if q.desc_type == capi.PROJECTION:
+            # every rank keeps the rows of its own fragments (Executor::resultsUnion appends the devices' results): the part
+            # is the oracle's over this rank's fragments, and the parts together are as many rows as the whole step emits
+            assert out is shard and np.array_equal(before, out.buffer().numpy())
+            q_mine, want_mine, code = orc.execute(plan, mine, n_threads=1)
+            assert code == 0
+            mine_rows = orc.fetch_rows(q_mine, want_mine)
+            compare_rows(q_mine, mine_rows, orc.fetch_rows(q, out.buffer().numpy().reshape(-1)), 0.0)
+            total = torch.tensor([len(mine_rows[0])], dtype=torch.int64)
+            dist.all_reduce(total)
+            q_all, want, code = orc.execute(plan, frags, n_threads=2)
+            assert code == 0 and int(total.item()) == orc.row_count(q_all, want) > 0
+            dist.barrier()
+            dist.destroy_process_group()
+            return
         if prepart and rank != 0:
             assert out is shard and np.array_equal(before, out.buffer().numpy())  # nothing moved
         if mismatched:
@@ -348,7 +373,8 @@ def test_slice_exchange_over_gloo(world, shape):
 @pytest.mark.parametrize("shape", ["keyed", "keyed_two_columns", "keyed_compact", "perfect", "perfect_nullable",
                                    "perfect_float", "non_grouped", "perfect_two_columns_unprojected",
                                    "perfect_columnar", "perfect_nullable_columnar", "keyed_columnar",
-                                   "keyed_two_columns_columnar", "perfect_two_columns_unprojected_columnar", "keyed_prepartitioned"])
+                                   "keyed_two_columns_columnar", "perfect_two_columns_unprojected_columnar", "keyed_prepartitioned",
+                                   "projection", "projection_columnar"])
 def test_merge_over_gloo(shape, world, real_library=False):
     import torch.multiprocessing as mp
     from oracle import oracle as orc
@@ -378,7 +404,8 @@ def test_merge_over_gloo(shape, world, real_library=False):
 @pytest.mark.parametrize("world,shape", [(2, "keyed_sliced"), (3, "keyed_sliced_dense"), (2, "keyed"), (2, "keyed_two_columns"),
                                          (3, "keyed_compact"), (2, "perfect"), (3, "perfect_nullable"), (2, "perfect_float"),
                                          (2, "non_grouped"), (2, "keyed_columnar"), (2, "perfect_columnar"),
-                                         (2, "keyed_prepartitioned"), (3, "keyed_sliced_mismatched")])
+                                         (2, "keyed_prepartitioned"), (3, "keyed_sliced_mismatched"), (2, "projection"),
+                                         (3, "projection_columnar")])
 def test_merge_over_gloo_with_the_librarys_own_code(world, shape):
     """The same choreography with the PRODUCT on every rank instead of the numpy twin: each rank's step runs through
     mi355q_execute, its shard is a HipShard (mi355q_shard_pads / _merge_slices with the LDS slice fold / _partition /

@@ -129,3 +129,63 @@ def test_projection_descriptor_matches_the_reference_rules(oracle):
     assert lib.mi355q_qmd_init(C.byref(bad.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN
     bad = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT, 0)], groupby_exprs=[1])
     assert lib.mi355q_qmd_init(C.byref(bad.to_plan()), C.byref(q)) == capi.ERR_INVALID_PLAN
+
+
+@pytest.mark.parametrize("name", ["i32_filter_columnar_3cols", "empty_middle_fragment", "scan_limit_cuts", "scan_limit_cuts_columnar", "many_small_fragments"])
+def test_projection_results_are_appended_not_reduced(sim, oracle, name):
+    """ResultSet::append (ResultSet.cpp:307-335; Executor::resultsUnion, Execute.cpp:1670-1694): one result per fragment,
+    laid one behind the other, holds the rows of the step over all fragments in (fragment, row) order; entry counts and
+    total_matched add up; mi355q_result_reduce on two projections does the same"""
+    from heavydb_amd.executor import Executor, FetchResult
+    case = next((c for c in CASES if c.name == name), None)
+    if case is None:
+        pytest.skip("no such case in this matrix")
+    if case.expect_error is not None or len(case.frags) < 2:
+        pytest.skip("needs two fragments and a step that succeeds")
+    plan = case.ra.to_plan()
+    q, want, code = oracle.execute(plan, case.frags)
+    assert code == 0
+    ex = Executor(0)
+    parts = []
+    keep = []
+    for f in range(len(case.frags)):
+        cols = [aligned(a) for a in case.frags[f]]
+        keep.append(cols)
+        fr = FetchResult([[a.ctypes.data for a in cols]], [len(cols[0])], [], 0, 0, [cols])
+        parts.append(ex.executeWorkUnit(case.ra, fr, allow_retry=False))
+    n_each = [p.rowCount() for p in parts]
+    whole = parts[0]
+    for k, p in enumerate(parts[1:]):
+        if k % 2 == 0:
+            whole.append(p)
+        else:   # (the reduce entry point: the same thing for two projections)
+            check_code = capi.load_library().mi355q_result_reduce(whole.handle, p.handle, None)
+            assert check_code == 0
+    qa = whole.getQueryMemDesc()
+    assert qa.entry_count == q.entry_count * len(parts) and whole.rowCount() == sum(n_each)
+    if case.ra.scan_limit:   # (how far past the limit the count runs is the kernel's business: check_projection)
+        assert whole.totalMatched() >= whole.rowCount()
+    else:
+        assert whole.totalMatched() == sum(oracle_total(oracle, plan, case, f) for f in range(len(case.frags))) == whole.rowCount()
+    # the rows, in order: a scan limit cuts each part on its own, so the union is compared part by part against the oracle
+    iv, dv, nl = whole.fetch()
+    off = 0
+    for f in range(len(case.frags)):
+        qf, wf, cf = oracle.execute(plan, [case.frags[f]])
+        assert cf == 0
+        wi, wd, wn = oracle.fetch_rows(qf, wf)
+        n = len(wi)
+        assert n == n_each[f]
+        assert (iv[off:off + n] == wi).all() and (nl[off:off + n] == wn).all()
+        assert ((dv[off:off + n] == wd) | (np.isnan(dv[off:off + n]) & np.isnan(wd))).all()
+        off += n
+    assert off == len(iv)
+    # the tail of the key column is EMPTY_KEY_64
+    raw = whole.getStorage().view(np.int64)
+    keys = raw[:qa.entry_count] if qa.output_columnar else raw.reshape(qa.entry_count, -1)[:, 0]
+    assert (keys[off:] == 0x7FFFFFFFFFFFFFFF).all() and (keys[:off] != 0x7FFFFFFFFFFFFFFF).all()
+
+
+def oracle_total(oracle, plan, case, f):
+    oracle.execute(plan, [case.frags[f]])
+    return oracle.last_total_matched()
