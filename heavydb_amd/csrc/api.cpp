@@ -85,7 +85,9 @@ RowInit make_row_init(const mi355q_qmd& q) {
   return r;
 }
 
-int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
+}  // namespace
+
+int32_t mq::api::attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
   if (p.join_outer_col < 0) return MI355Q_OK;
   if (!p.join_table) return MI355Q_ERR_INVALID_PLAN;
   const mi355q_join_table* jt = p.join_table;
@@ -124,8 +126,6 @@ int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d) {
   }
   return MI355Q_OK;
 }
-
-}  // namespace
 
 int64_t mq::api::algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in) {
   // every distinct outer column the plan touches is read once per row

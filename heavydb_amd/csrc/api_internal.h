@@ -154,6 +154,7 @@ int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in);
 int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o, mi355q_result** out,
                            mi355q_exec_report* report, int64_t* reserved);
 // result accessors of a Projection buffer
+int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d);  // (api.cpp) the join table and the inner columns
 int64_t projection_row_count(const mi355q_result* r);
 int32_t projection_append(mi355q_result* this_rs, const mi355q_result* that_rs, hipStream_t s);
 int32_t projection_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t* ival, double* dval, int8_t* is_null, int64_t* n_rows);

@@ -36,10 +36,11 @@ int32_t proj_spec_of(const mi355q_plan& lp, int n_phys, const mi355q_qmd& q, Pro
   ps->entry_count = q.entry_count;
   for (int i = 0; i < q.n_targets; ++i) {
     const mi355q_target& t = lp.targets[i];
-    if (t.col < 0 || t.col >= lp.n_cols) return MI355Q_ERR_INVALID_PLAN;
+    const bool inner = t.table != 0;  // a column of the join's inner table, read through the matched row
+    if (t.col < 0 || t.col >= (inner ? lp.n_inner_cols : lp.n_cols)) return MI355Q_ERR_INVALID_PLAN;
     ProjTarget& pt = ps->t[i];
-    pt.col = t.col;
-    pt.code = col_type_code(lp.cols[t.col]);
+    pt.col = inner ? kProjInnerCol + t.col : t.col;
+    pt.code = col_type_code(inner ? lp.inner_cols[t.col] : lp.cols[t.col]);
     if (pt.code < 0) return MI355Q_ERR_INVALID_PLAN;
     const int st = tc_storage(pt.code);
     pt.kind = st == MI355Q_DOUBLE ? PROJ_F64 : st == MI355Q_FLOAT ? (q.output_columnar ? PROJ_F32 : PROJ_F32_TO_F64) : PROJ_INT;
@@ -67,6 +68,10 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
   if (q.desc_type != MI355Q_PROJECTION) return MI355Q_ERR_INVALID_PLAN;
   DevPlan d;
   if (int32_t e = build_dev_plan(lp, q, &d)) return e;
+  if (int32_t e = attach_join(lp, in, &d)) return e;
+  // one entry per joined row: a one-to-one table gives at most one per outer row, which the compaction's match bit states;
+  // the matching SETS of a one-to-many table (HashJoin::codegenMatchingSet) would need a count per row
+  if (d.join_col >= 0 && d.join_hash_type >= 2) return MI355Q_ERR_UNSUPPORTED;
   for (int k = 0; k < d.n_quals; ++k)  // (a member of a disjunction is a plain column comparison: the binding never states one over an expression)
     if (d.quals[k].or_group != 0 && d.quals[k].col >= n_phys) return MI355Q_ERR_UNSUPPORTED;
   ProjSpec ps;
@@ -82,7 +87,7 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
   }
   const int64_t ws_need = kExprArea + projection_scratch_bytes(nf, in->num_rows);
   if (reserved) {  // mi355q_reserve_workspace / mi355q_explain: nothing is launched
-    route_note(plan->n_exprs ? "k_proj_compact (expressions in registers)" : "k_proj_compact");
+    route_note(d.join_col >= 0 ? "k_proj_compact (join probe per row)" : plan->n_exprs ? "k_proj_compact (expressions in registers)" : "k_proj_compact");
     *reserved = ws_need;
     if (t_plan_only) return MI355Q_OK;
   }

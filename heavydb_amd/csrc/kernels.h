@@ -316,6 +316,7 @@ hipError_t launch_join_probe(const DevPlan& p, const FragView& fv, const JoinPay
 
 // ---- PROJECTION family (kernels_proj.hip): order-preserving stream compaction of the rows that pass the quals
 enum ProjKind : int32_t { PROJ_INT = 0, PROJ_F64 = 1, PROJ_F32 = 2, PROJ_F32_TO_F64 = 3 };
+constexpr int32_t kProjInnerCol = 64;  // ProjTarget::col from here on: column (col - 64) of the join's inner table
 struct ProjTarget {
   int32_t col;     // source: a physical column (< n_phys_cols) or expression col - n_phys_cols
   int32_t code;    // type code of the physical column; the result type of an expression

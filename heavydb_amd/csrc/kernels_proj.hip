@@ -131,9 +131,31 @@ MQ_D unsigned long long wave_excl_scan_u32x2(unsigned long long v, unsigned long
 }
 
 
+// the inner row an outer row joins through a ONE-TO-ONE table (process_row's probe, rowfunc.h): >= 0, or -1 = no match
+// (a NULL key matches nothing: hash_join_idx_nullable)
+MQ_D int64_t proj_join_row(const DevPlan& p, const int8_t* const* fc, int64_t pos) {
+  int64_t jk[MI355Q_MAX_GROUP_COLS];
+  bool null_key = false;
+  for (int i = 0; i < p.join_n_keys; ++i) {
+    jk[i] = decode_int(fc[p.join_cols[i]], p.join_types[i], pos);
+    null_key = null_key || (p.join_nullables[i] && jk[i] == int_null_of(p.join_types[i]));
+  }
+  if (null_key) return -1;
+  const JoinMatch jm = join_lookup(p, jk);
+  return jm.count > 0 ? jm.single : -1;
+}
+// the value an unmatched row of a LEFT join shows for an inner column: the type's NULL (codegenOuterJoinNullPlaceholder)
+MQ_D int64_t proj_null_bits(int code) {
+  const int st = tc_storage(code);
+  if (st == MI355Q_DOUBLE) return kNullDoubleBits;
+  if (st == MI355Q_FLOAT) return (int64_t)(uint32_t)kNullFloatBits;
+  return int_null_of(code);
+}
+
 // the whole filter of one row — every kind of qual (any column type and encoding, disjunctions, quals on expressions).  ONE
 // call site per kernel (the general path of pass A), so that the row function is instantiated once
-template <bool HX>
+// HJ: the step joins — an INNER join keeps the rows that find a match
+template <bool HX, bool HJ = false>
 MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const int8_t* const* fc, int64_t pos, int32_t* err) {
   const int n_phys = a.ps.n_phys_cols;
   int64_t xv[HX ? MI355Q_MAX_EXPRS : 1];
@@ -150,7 +172,9 @@ MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const int8_t* const* f
       if (t) any |= 1u << q.or_group;
     }
   }
-  return seen == any;
+  if (seen != any) return false;
+  if (HJ && p.join_kind != MI355Q_JOIN_LEFT) return proj_join_row(p, fc, pos) >= 0;
+  return true;
 }
 
 // ---- pass A: the filter over one tile.  Bit (4 u + i) of the result = row i of the lane's quad in iteration u.
@@ -158,7 +182,7 @@ MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const int8_t* const* f
 // physical columns with literals (a.fast_quals), every qual is one vector load per quad and lane — INT32 / INT64 range
 // forms compare in registers, the other types go through qual_on_value; everything else (a fragment's ragged end,
 // unaligned chunks, disjunctions, quals on expressions) takes row_passes, row by row.
-template <bool HX>
+template <bool HX, bool HJ = false>
 MQ_D uint64_t tile_filter(const DevPlan& p, const ProjArgs& a, const int8_t* const* fc, int64_t n, int64_t row0, int32_t* err) {
   const int tid = threadIdx.x;
   uint64_t m = 0;
@@ -236,7 +260,7 @@ MQ_D uint64_t tile_filter(const DevPlan& p, const ProjArgs& a, const int8_t* con
         const uint32_t bj = j == 0 ? bits[0] : j == 1 ? bits[1] : j == 2 ? bits[2] : bits[3];
         if (!((bj >> i) & 1u)) continue;
         const int64_t rj = j == 0 ? r[0] : j == 1 ? r[1] : j == 2 ? r[2] : r[3];
-        if (!row_passes<HX>(p, a, fc, rj + i, err)) {
+        if (!row_passes<HX, HJ>(p, a, fc, rj + i, err)) {
           const uint32_t clr = ~(1u << i);
           if (j == 0) bits[0] &= clr;
           if (j == 1) bits[1] &= clr;
@@ -560,6 +584,9 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
   }
 }
 
+// HJ: the step joins a one-to-one hash table (fast_quals is off: every row takes row_passes, which probes for an INNER
+// join; pass B probes again for the rows it writes and reads the inner columns through the matched row)
+template <bool HJ>
 __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs a) {
   extern __shared__ __attribute__((aligned(16))) char s_img[];
   __shared__ unsigned long long s_wave[kWaves];
@@ -591,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs
     const int64_t n = a.num_rows[f];
     const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;  // first row of the tile in its fragment
 
-    const uint64_t m = tile_filter<true>(p, a, fc, n, row0, &err);
+    const uint64_t m = tile_filter<true, HJ>(p, a, fc, n, row0, &err);
 
     // ---- the tile's count, its descriptor, and the entries before it
     {
@@ -670,10 +697,19 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs
           for (int i = 0; i < 4; ++i)
             if ((mm >> i) & 1u) eval_exprs(*a.xs, (1u << a.xs->n) - 1u, fc, r + i, xv[i], &err);
         }
+        int64_t inner_pos[4] = {-1, -1, -1, -1};
+        if (HJ) {
+          for (int i = 0; i < 4; ++i)
+            if ((mm >> i) & 1u) inner_pos[i] = proj_join_row(p, fc, r + i);
+        }
         for (int t = 0; t < ps.n_targets; ++t) {
           const ProjTarget& pt = ps.t[t];
           int64_t vals[4];
-          if (pt.col >= n_phys) {
+          if (HJ && pt.col >= kProjInnerCol) {  // an inner column: the matched row's value, or NULL (LEFT join, no match)
+            const int8_t* base = p.inner_cols[pt.col - kProjInnerCol];
+            for (int i = 0; i < 4; ++i)
+              vals[i] = !((mm >> i) & 1u) ? 0 : inner_pos[i] >= 0 ? col_value_bits(base, pt.code, inner_pos[i]) : proj_null_bits(pt.code);
+          } else if (pt.col >= n_phys) {
             for (int i = 0; i < 4; ++i) vals[i] = xv[i][pt.col - n_phys];
           } else {
             const int8_t* base = fc[pt.col];
@@ -845,14 +881,14 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
     }
   }
   a.out16 = (((uintptr_t)out) & 15) == 0;
-  a.fast_quals = !a.row_quals && qual_expr_mask == 0;
+  a.fast_quals = !a.row_quals && qual_expr_mask == 0 && p.join_col < 0;  // (a join: every row takes row_passes, which probes)
   for (int k = 0; k < p.n_quals; ++k)
     a.fast_quals = a.fast_quals && p.quals[k].col < ps.n_phys_cols && p.quals[k].col < 31 && ((a.vec_mask >> p.quals[k].col) & 1);
   a.fast_targets = 1;
   for (int t = 0; t < ps.n_targets; ++t)
     a.fast_targets = a.fast_targets && ps.t[t].col < ps.n_phys_cols && ps.t[t].col < 31 && ((a.vec_mask >> ps.t[t].col) & 1);
   // the fast row-wise member: range quals over plain INT32 / INT64 columns, plain 4- / 8-byte targets, aligned chunks
-  bool fast_ok = !d_xs && !a.row_quals && ps.n_targets >= 1 && ps.n_targets <= 8 && tune_knobs().pass_rows != -1;
+  bool fast_ok = !d_xs && !a.row_quals && p.join_col < 0 && ps.n_targets >= 1 && ps.n_targets <= 8 && tune_knobs().pass_rows != -1;
   FastArgs fa{};
   for (int k = 0; k < p.n_quals && fast_ok; ++k) {
     const int c = p.quals[k].col;
@@ -889,10 +925,12 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
     if (!fast_ok) {
       static bool attr_set = false;
       if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)k_proj_compact_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        (void)hipFuncSetAttribute((const void*)k_proj_compact_lds<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
+        (void)hipFuncSetAttribute((const void*)k_proj_compact_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
       }
-      hipLaunchKernelGGL(k_proj_compact_lds, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
+      if (p.join_col >= 0) hipLaunchKernelGGL(k_proj_compact_lds<true>, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
+      else hipLaunchKernelGGL(k_proj_compact_lds<false>, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
     } else {
       fa.n_quals = p.n_quals;
       fa.n_targets = ps.n_targets;

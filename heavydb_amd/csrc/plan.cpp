@@ -343,7 +343,7 @@ int32_t resolve_targets(const mi355q_plan& p, bool grouped, ResolvedTarget* out)
         break;
       case MI355Q_PROJECT:  // a Projection step's target: the value of an outer column / expression, no aggregate
         if (grouped || t.col < 0) return MI355Q_ERR_INVALID_PLAN;
-        if (t.table != 0) return MI355Q_ERR_UNSUPPORTED;  // (projections through a join: not in this family yet)
+        if (t.table != 0 && p.join_outer_col < 0) return MI355Q_ERR_INVALID_PLAN;  // (an inner column needs the join)
         break;
       case MI355Q_PROJECT_KEY:
         if (!grouped) return MI355Q_ERR_INVALID_PLAN;
@@ -453,7 +453,8 @@ void keyless_decision(const mi355q_plan& p, const ResolvedTarget* ts, bool* keyl
 // constructor then sets to 8 (setAllUnsetSlotsPaddedSize, :507) — or, for a columnar projection, to the logical widths
 // (isLogicalSizedColumnsAllowed :1129-1135).  entry_count = scan_limit, else max_groups_buffer_entry_count.
 int32_t qmd_init_projection(const mi355q_plan& p, const ResolvedTarget* ts, mi355q_qmd* q) {
-  if (p.n_group_cols != 0 || p.join_outer_col >= 0) return p.join_outer_col >= 0 ? MI355Q_ERR_UNSUPPORTED : MI355Q_ERR_INVALID_PLAN;
+  // (a join: every joined row is one entry — the one-to-one tables are executed, api_projection.cpp)
+  if (p.n_group_cols != 0) return MI355Q_ERR_INVALID_PLAN;
   if (p.scan_limit < 0) return MI355Q_ERR_INVALID_PLAN;
   if (p.output_columnar_hint == MI355Q_OUTPUT_ROWWISE_COLUMNAR_DECISIONS) return MI355Q_ERR_INVALID_PLAN;
   q->desc_type = MI355Q_PROJECTION;

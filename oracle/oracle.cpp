@@ -409,7 +409,7 @@ int build_targets(const mi355q_plan& p, bool is_group_by, std::vector<TargetDesc
     d.table = t.table;
     if (t.agg == MI355Q_PROJECT) {  // a Projection's target (TargetInfo.is_agg == false, no GROUP BY)
       if (is_group_by || t.col < 0) return MI355Q_ERR_INVALID_PLAN;
-      if (t.table != 0) return MI355Q_ERR_UNSUPPORTED;
+      if (t.table != 0 && (p.join_outer_col < 0 || t.col >= p.n_inner_cols)) return MI355Q_ERR_INVALID_PLAN;
     }
     if (t.agg == MI355Q_PROJECT_KEY) {
       if (!is_group_by) return MI355Q_ERR_INVALID_PLAN;
@@ -552,7 +552,6 @@ int64_t bucketed_cardinality(const mi355q_range& r) {
 // widths (isLogicalSizedColumnsAllowed :1129-1135 -> setAllSlotsPaddedSizeToLogicalSize :540-546).
 int qmd_init_projection(const mi355q_plan& p, const std::vector<TargetDesc>& ts, mi355q_qmd& q) {
   if (p.n_group_cols != 0) return MI355Q_ERR_INVALID_PLAN;
-  if (p.join_outer_col >= 0) return MI355Q_ERR_UNSUPPORTED;
   if (p.scan_limit < 0 || p.output_columnar_hint < 0 || p.output_columnar_hint > 1) return MI355Q_ERR_INVALID_PLAN;
   q.desc_type = MI355Q_PROJECTION;
   q.n_targets = p.n_targets;
@@ -1907,6 +1906,12 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
       if (!(qual_exprs & (1u << k)))
         if (int32_t e = eval_into_cell(k, pos)) return e;
     if (q.desc_type == MI355Q_PROJECTION) {
+     // the body runs once per joined row (the join loops enclose it, IRCodegen.cpp buildJoinLoops): one output entry each;
+     // an inner column is read through the matched row id, or is the type's NULL where a LEFT join found no match
+     // (codegenOuterJoinNullPlaceholder, ColumnIR.cpp)
+     for (int jm_i = 0; jm_i < jm.count; ++jm_i) {
+      const int64_t inner_pos = p.join_outer_col < 0 ? -1 : jm.ids ? (int64_t)jm.ids[jm_i] : jm.single;
+      const int64_t pos_outer = pos;
       // GroupByAndAggregate::codegen (GroupByAndAggregate.cpp:1080-1101): crt_matched = 1, old_total_matched =
       // total_matched++ (the CPU form of the atomic add); codegenOutputSlot (:1255-1275): the entry `old_total_matched`
       // of a buffer of max_matched entries, its key = the row's offset in the fragment
@@ -1929,7 +1934,26 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
       for (int ti = 0; ti < p.n_targets; ++ti) {
         const TargetDesc& t = c.ts[ti];
         const auto& cd = *t.cd;
-        const int8_t* col = cols[t.col];
+        if (t.table && inner_pos < 0) {  // LEFT join, no match: the NULL of the inner column's type
+          const int64_t nul = int_null_of(t.arg_type);
+          if (!q.output_columnar) {
+            out_slots[t.slot] = t.arg_f32 ? dbl_bits((double)kNullFloat) : t.arg_fp ? dbl_bits(kNullDouble) : nul;
+          } else {
+            int8_t* base = reinterpret_cast<int8_t*>(buf) + col_slot_off(q, t.slot);
+            switch (q.slot_bytes[t.slot]) {
+              case 1: reinterpret_cast<int8_t*>(base)[out_off] = (int8_t)nul; break;
+              case 2: reinterpret_cast<int16_t*>(base)[out_off] = (int16_t)nul; break;
+              case 4:
+                if (t.arg_f32) reinterpret_cast<float*>(base)[out_off] = kNullFloat;
+                else reinterpret_cast<int32_t*>(base)[out_off] = (int32_t)nul;
+                break;
+              default: reinterpret_cast<int64_t*>(base)[out_off] = t.arg_fp ? dbl_bits(kNullDouble) : nul;
+            }
+          }
+          continue;
+        }
+        const int8_t* col = t.table ? c.inner_cols[t.col] : cols[t.col];
+        const int64_t pos = t.table ? inner_pos : pos_outer;
         if (!q.output_columnar) {
           // agg_id / agg_id_double on the 8-byte slot (RuntimeFunctions.cpp:1171-1173,1466-1470) of the value cast to the
           // slot's width: integers sign-extended, a float widened to double
@@ -1955,6 +1979,7 @@ int32_t run_fragment(const ExecCtx& c, const int8_t* const* cols, int64_t num_ro
         }
       }
       if (p.scan_limit && (uint32_t)(old_total_matched + 1) >= max_matched) return 0;  // limit reached: the loop ends
+     }
       continue;
     }
     int64_t* slots;

@@ -25,6 +25,14 @@ class ProjCase:
     frags: List[List[np.ndarray]]
     expect_error: Optional[int] = None   # > 0: that code; < 0: any negative code (buffer full)
     min_rows: int = 0                    # the case is meant to produce at least this many rows
+    # a join (the fields of tests/cases.py Case, read by test_hostsim_flow._build_join / _oracle_join)
+    inner: List[np.ndarray] = field(default_factory=list)
+    join_keys: object = None
+    join_key_type: object = capi.INT64
+    join_range: Optional[ExpressionRange] = None
+    join_prefer_baseline: bool = False
+    join_one_to_many: int = 0
+    join_key_nullable: object = False
 
 
 def _col(rng, t, n, lo=-1000, hi=1000, null_every=0):
@@ -160,4 +168,63 @@ def build_cases(scale: int = 1) -> List[ProjCase]:
     add_x("div_by_zero_counts", xd, [x, y, z], [C_(0).div(C_(1), I32)], [3], [Qual(1, capi.GE, 0)], [m], max_groups_buffer_entry_guess=m,
           expect_error=capi.ERR_DIV_BY_ZERO)
     add_x("div_by_zero_filtered_out", xd, [x, y, z], [C_(0).div(C_(1), I32)], [3], [Qual(1, capi.GT, 0)], [m], max_groups_buffer_entry_guess=m)
+    return cases
+
+
+def build_join_cases() -> List[ProjCase]:
+    """SELECT t.a, d.w, d.f, ... FROM t JOIN d ON t.k = d.k WHERE ...: every joined row is one output entry (Joins_* of
+    Tests/ExecuteTest.cpp without the aggregate; the join loops enclose the row function's body, IRCodegen.cpp buildJoinLoops;
+    an unmatched row of a LEFT join shows the inner columns' NULLs, ColumnIR.cpp codegenOuterJoinNullPlaceholder)."""
+    rng = np.random.default_rng(77)
+    D, R = InputColDescriptor, ExpressionRange
+    cases: List[ProjCase] = []
+    m, n = 700, 30_000
+    dk = rng.permutation(m).astype(np.int64)                      # dense unique keys 0 .. m-1
+    dw = rng.integers(-1000, 1000, m).astype(np.int64)
+    df = rng.random(m)
+    dg = rng.random(m).astype(np.float32)
+    ds = rng.integers(-100, 100, m).astype(np.int16)
+    ds[::9] = INT_NULL[capi.INT16]
+    inner_descs = [D(capi.INT64, False, R(True, 0, m - 1)), D(capi.INT64, False, R(True, -1000, 999)), D(capi.DOUBLE), D(capi.FLOAT),
+                   D(capi.INT16, True, R(True, -100, 99, True))]
+    inner = [dk, dw, df, dg, ds]
+    k = rng.integers(-60, m + 60, n).astype(np.int64)              # some keys miss
+    a = rng.integers(-10**9, 10**9, n).astype(np.int64)
+    f = rng.integers(0, 1000, n).astype(np.int32)
+    k32 = rng.integers(0, m + 40, n).astype(np.int32)
+    k32[::11] = INT_NULL[capi.INT32]                               # a NULL key matches nothing
+    descs = [D(capi.INT64, False, R(True, -60, m + 59)), D(capi.INT64), D(capi.INT32, False, R(True, 0, 999)),
+             D(capi.INT32, True, R(True, 0, m + 39, True))]
+    frags = _split([k, a, f, k32], [n // 2 + 5, n - n // 2 - 5])
+    dense = R(True, 0, m - 1)
+
+    def add(name, targets, quals=(), outer_col=0, kind=capi.JOIN_INNER, keyed=False, **kw):
+        err = kw.pop("expect_error", None)
+        otm = kw.pop("one_to_many", 0)
+        jk = kw.pop("join_keys", dk)
+        inn = kw.pop("inner", inner)
+        ra = RelAlgExecutionUnit(list(descs), [TargetExpr(capi.PROJECT, c, t) for c, t in targets], list(quals),
+                                 inner_col_descs=list(inner_descs), join_outer_col=outer_col, join_kind=kind,
+                                 max_groups_buffer_entry_guess=kw.pop("guess", n), **kw)
+        cases.append(ProjCase(name, ra, frags, err, 0, list(inn), jk, capi.INT64, dense if not otm else R(True, 0, m - 1), keyed, otm,
+                              False))
+
+    both = [(1, 0), (1, 1), (2, 1), (3, 1), (4, 1)]                # t.a, d.w, d.f, d.g (FLOAT), d.s (nullable INT16)
+    for keyed in (False, True):
+        tag = "keyed" if keyed else "perfect"
+        add(f"join_inner_{tag}", both, keyed=keyed)
+        add(f"join_inner_{tag}_filtered", both, [Qual(2, capi.LT, 300)], keyed=keyed)
+        add(f"join_left_{tag}", both, kind=capi.JOIN_LEFT, keyed=keyed)
+        add(f"join_left_{tag}_columnar", both, [Qual(2, capi.GE, 100)], kind=capi.JOIN_LEFT, keyed=keyed,
+            output_columnar_hint=capi.OUTPUT_COLUMNAR)
+        add(f"join_inner_{tag}_nullable_int32_key", [(0, 0), (1, 1), (4, 1)], outer_col=3, keyed=keyed)
+    add("join_outer_columns_only", [(1, 0), (2, 0)], [Qual(2, capi.LT, 500)])            # a semi-join: the match filters
+    add("join_inner_columnar", both, output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    add("join_scan_limit", both, scan_limit=1234)
+    add("join_left_nothing_matches", [(1, 0), (1, 1), (2, 1)], [Qual(0, capi.LT, 0)], kind=capi.JOIN_LEFT)
+    add("join_inner_nothing_matches", [(1, 0), (1, 1)], [Qual(0, capi.LT, 0)])
+    # duplicates on the inner side: a one-to-many table — every match would be an entry; this family answers "unsupported"
+    dup = np.concatenate([dk[:m - 50], dk[:50]])
+    add("join_one_to_many_is_refused", [(1, 0), (1, 1)], one_to_many=1, join_keys=dup, inner=[dup, dw, df, dg, ds],
+        expect_error=capi.ERR_UNSUPPORTED)
     return cases

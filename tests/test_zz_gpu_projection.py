@@ -32,7 +32,21 @@ def torch_cuda():
 def device_fetch_result(torch, case):
     from heavydb_amd.executor import FetchResult
     frags = [[torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in cols] for cols in case.frags]
-    return FetchResult([[int(t.data_ptr()) for t in cols] for cols in frags], [len(cols[0]) for cols in case.frags], [], 0, 0, [frags])
+    inner = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in case.inner]
+    return FetchResult([[int(t.data_ptr()) for t in cols] for cols in frags], [len(cols[0]) for cols in case.frags],
+                       [int(t.data_ptr()) for t in inner], len(case.inner[0]) if case.inner else 0, 0, [frags, inner])
+
+
+JOIN_CASES = proj_cases.build_join_cases()
+
+
+@pytest.mark.parametrize("case", JOIN_CASES, ids=[c.name for c in JOIN_CASES])
+def test_projection_through_a_join_on_the_device(torch_cuda, oracle, case):
+    """SELECT t.a, d.w, ... FROM t JOIN d ON ...: one entry per joined row, inner columns through the matched row id"""
+    from tests.test_gpu_parity import _build_join
+    rs = check_projection(oracle, case, lambda c: device_fetch_result(torch_cuda, c), make_join=lambda c: _build_join(torch_cuda, c))
+    if rs is not None:
+        assert rs.report.kernel_name.decode() == "k_proj_compact"
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
