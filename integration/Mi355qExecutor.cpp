@@ -163,7 +163,8 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
   // description type the same way: `group_col_widths.empty() ... is_agg` -> NonGroupedAggregate, else Projection).
   bool projection = group_exprs.empty() && !ra.target_exprs.empty();
   for (const auto* te : ra.target_exprs) projection = projection && !dynamic_cast<const Analyzer::AggExpr*>(te);
-  if (projection && !ra.join_quals.empty()) unsupported("projection through a join");
+  // (a projection through a join: one entry per joined row; an inner table's column is a target of table 1, read through
+  // the matched row — one-to-one hash tables; the library answers "unsupported" for a one-to-many table)
   p.scan_limit = projection ? (int64_t)ra.scan_limit : 0;
   // target_exprs (get_target_info, Shared/TargetInfo.h:48-56): aggregates, or projections of a group key
   for (const auto* te : ra.target_exprs) {
@@ -175,7 +176,14 @@ mi355q_plan to_plan(const RelAlgExecutionUnit& ra, const std::vector<InputTableI
                          [&t](const Analyzer::ColumnVar* cv) { return t.find(t.inner_cols, cv->getColumnKey()); });
     } else if (projection) {
       tg.agg = MI355Q_PROJECT;
-      tg.col = t.value_col(te);
+      auto cv = dynamic_cast<const Analyzer::ColumnVar*>(te);
+      if (cv && cv->get_rte_idx() != 0) {  // a column of the join's inner table
+        tg.table = 1;
+        tg.col = t.find(t.inner_cols, cv->getColumnKey());
+        if (tg.col < 0) unsupported("a projected inner column that is not among the inputs");
+      } else {
+        tg.col = t.value_col(te);
+      }
     } else {
       tg.agg = MI355Q_PROJECT_KEY;
       int idx = -1;

@@ -474,6 +474,70 @@ int main() {
     expect(q.desc_type == MI355Q_NON_GROUPED_AGGREGATE, "layout");
     compare_tables(q, want.data(), (const int64_t*)const_cast<ResultSetStorage*>(rs->getStorage())->getUnderlyingBuffer(), {false, false, false});
     std::printf("  SUM(t.key) = %lld, SUM(d.w) = %lld, COUNT(*) = %lld\n", (long long)want[0], (long long)want[1], (long long)want[2]);
+    // ------------------------------------------------------------ query 6: a Projection through the same join
+    //   SELECT t.key, d.w FROM t LEFT JOIN d ON t.fk = d.k WHERE t.i32 < 2^27   — one entry per joined row, d.w NULL where unmatched
+    {
+      std::printf("query 6: SELECT t.key, d.w FROM t LEFT JOIN d ON t.fk = d.k WHERE t.i32 < 134217728\n");
+      RelAlgExecutionUnit ra6;
+      ra6.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(4, kTable, kDb, 0));
+      ra6.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(0, kTable, kDb, 0));
+      ra6.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(2, kTable, kDb, 0));
+      ra6.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(0, kDim, kDb, 1));
+      ra6.input_col_descs.push_back(std::make_shared<const InputColDescriptor>(1, kDim, kDb, 1));
+      auto i32 = colvar(t, kTable, 2);
+      JoinCondition jc6;
+      jc6.type = JoinType::LEFT;
+      jc6.quals.push_back(std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kBOOLEAN, true), kEQ, fk, dk));
+      ra6.join_quals.push_back(jc6);
+      ra6.simple_quals.push_back(std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kBOOLEAN, true), kLT, i32, int_lit(kINT, 1 << 27)));
+      ra6.groupby_exprs.push_back(nullptr);
+      ra6.target_exprs = {v.get(), dw.get()};
+      const size_t guess = (size_t)(N / 8);
+      mi355q_plan h6{};
+      h6.abi_version = MI355Q_ABI_VERSION;
+      h6.n_cols = 3;
+      h6.cols[0] = {MI355Q_INT64, 0, 0, 0};
+      h6.cols[1] = {MI355Q_INT64, 0, 0, 0};
+      h6.cols[2] = {MI355Q_INT32, 0, 0, 0};
+      h6.col_ranges[0] = {1, 0, -50, M + 49, 0, 0, 0};
+      h6.col_ranges[1] = {1, 0, 7, key_max, 0, 0, 0};
+      h6.col_ranges[2] = {1, 0, 0, INT32_MAX, 0, 0, 0};
+      h6.n_inner_cols = 2;
+      h6.inner_cols[0] = {MI355Q_INT64, 0, 0, 0};
+      h6.inner_cols[1] = {MI355Q_INT64, 0, 0, 0};
+      h6.inner_col_ranges[0] = {1, 0, 0, M - 1, 0, 0, 0};
+      h6.inner_col_ranges[1] = {1, 0, -1000, 1000, 0, 0, 0};
+      h6.n_quals = 1;
+      h6.quals[0] = {2, MI355Q_LT, 1 << 27, 0.0};
+      h6.n_targets = 2;
+      h6.targets[0] = {MI355Q_PROJECT, 1, 0, 0, {}};
+      h6.targets[1] = {MI355Q_PROJECT, 1, 1, 0, {}};
+      h6.join_outer_col = 0;
+      h6.join_outer_cols[0] = 0;
+      h6.join_kind = MI355Q_JOIN_LEFT;
+      h6.max_groups_buffer_entry_guess = (int64_t)guess;
+      h6.num_tuples = N + M;
+      compare_plans(h6, mi355q_glue::to_plan(ra6, qi2, &executor, jt, guess, false));
+      std::vector<int64_t> fr6_rows;
+      const FetchResult fr6 = fetch(t, {4, 0, 2}, &fr6_rows);
+      mi355q_qmd q6;
+      const std::vector<int64_t> want6 = oracle_table(h6, t, {4, 0, 2}, fr6_rows, oj, {d.cols[0].host.data(), d.cols[1].host.data()}, M, &q6);
+      const ResultSetPtr rs6 = mi355q_glue::run_query_mi355q(ra6, fr6, qi2, qmd_of(q6), &executor, 0, guess, jt,
+                                                             {(const int8_t*)d.cols[0].dev, (const int8_t*)d.cols[1].dev}, M);
+      expect(q6.desc_type == MI355Q_PROJECTION && q6.row_size == 24, "layout");
+      const int64_t* got6 = (const int64_t*)const_cast<ResultSetStorage*>(rs6->getStorage())->getUnderlyingBuffer();
+      bool same6 = true;
+      int64_t nulls = 0, live = 0;
+      for (size_t i = 0; i < want6.size() && same6; ++i) same6 = want6[i] == got6[i];
+      for (int64_t e = 0; e < q6.entry_count; ++e) {
+        if (want6[(size_t)e * 3] == INT64_MAX) break;
+        ++live;
+        nulls += want6[(size_t)e * 3 + 2] == INT64_MIN;
+      }
+      expect(same6, "projection-through-a-join buffer differs from the oracle's");
+      expect(live > 0 && nulls > 0 && nulls < live, "the LEFT join shows both matched rows and NULL inner values");
+      std::printf("  %lld rows, %lld of them without a match (d.w NULL)\n", (long long)live, (long long)nulls);
+    }
     mi355q_join_free(jt);
     orc_join_free(oj);
   }
