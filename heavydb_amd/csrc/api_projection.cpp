@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "api_internal.h"
+#include "expr.h"
 
 using namespace mq;
 using namespace mq::api;
@@ -76,6 +77,10 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
     if (d.quals[k].or_group != 0 && d.quals[k].col >= n_phys) return MI355Q_ERR_UNSUPPORTED;
   ProjSpec ps;
   if (int32_t e = proj_spec_of(lp, n_phys, q, &ps)) return e;
+  if (plan->n_exprs != 0) {  // the device copy: every node with its typed handler (physical columns are loaded where they are read)
+    const int deepest = xh_label_programs(&xs, false);
+    ps.x_info = deepest | (xs.n << 8);
+  }
   const uint32_t qmask = plan->n_exprs ? expr_qual_mask(*plan) : 0u;
 
   const int nf = in->n_frags, nc = n_phys;

@@ -378,7 +378,62 @@ inline int xh_of(const DevExprNode& n) {
   }
 }
 
+// The device copy of a plan's programs: every node labelled with its handler (above the EXF_* bits of `flags`), literals
+// laid down as patterns, the error-free programs marked, and — use_pre — the first kExPre plain physical columns the
+// programs read listed for the caller's per-tile batch of loads (their column nodes become XH_COLPRE + slot).
+// Returns the deepest evaluation stack of the programs.
+inline int xh_label_programs(DevExprSet* up, bool use_pre) {
+  int deepest = 1;
+  up->n_pre = 0;
+  up->noerr_mask = 0;
+  for (int k = 0; k < up->n; ++k) {
+    bool noerr = true;
+    int sp = 0;
+    for (int i = 0; i < up->e[k].n_nodes; ++i) {
+      DevExprNode& n = up->e[k].nodes[i];
+      const int op = n.op;
+      noerr = noerr && (op == MI355Q_EX_COL || op == MI355Q_EX_LIT || (op >= MI355Q_EX_EQ && op <= MI355Q_EX_GE) || op == MI355Q_EX_CASE ||
+                        op == MI355Q_EX_NOT || op == MI355Q_EX_AND || op == MI355Q_EX_OR || op == MI355Q_EX_IS_NULL);
+      if (op == MI355Q_EX_COL || op == MI355Q_EX_LIT) ++sp;
+      else if (op == MI355Q_EX_CASE) sp -= 2;
+      else if (op != MI355Q_EX_CAST && op != MI355Q_EX_NOT && op != MI355Q_EX_IS_NULL && op != MI355Q_EX_UMINUS) --sp;
+      if (sp > deepest) deepest = sp;
+      int h = XH_GCOL;
+      if (op == MI355Q_EX_COL) {
+        const int code = (int)n.ilit;
+        if (use_pre && n.arg < up->n_cols && (code == MI355Q_INT32 || code == MI355Q_INT64 || code == MI355Q_DOUBLE)) {
+          int slot = -1;
+          for (int c = 0; c < up->n_pre; ++c)
+            if (up->pre_col[c] == n.arg) slot = c;
+          if (slot < 0 && up->n_pre < 4) {
+            slot = up->n_pre++;
+            up->pre_col[slot] = n.arg;
+            up->pre_type[slot] = n.type;
+            up->pre_code[slot] = code;
+          }
+          if (slot >= 0) h = XH_COLPRE + slot;
+        }
+      } else {
+        h = xh_of(n);
+        if (op == MI355Q_EX_LIT) {  // (ex_lit's pattern, laid down once)
+          n.ilit = ex_lit(n);
+          n.arg = 1;
+        }
+      }
+      n.flags = (n.flags & ((1 << kExHandlerShift) - 1)) | (h << kExHandlerShift);
+    }
+    if (noerr) up->noerr_mask |= 1 << k;
+  }
+  return deepest;
+}
+
 #if defined(__HIPCC__) || defined(HOSTSIM_DEVICE_CODE)
+// a value every lane of the wave holds alike, moved to a scalar register (the host simulation has no such distinction)
+#if defined(__HIPCC__)
+#define MQ_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define MQ_WAVE_UNIFORM(x) (x)
+#endif
 // the node a handler stands for: exactly the fields the ex_* function of its family reads
 template <int H>
 MQ_D int64_t xh_binary(int64_t a, int64_t b, int32_t& ev) {  // XH_CMP .. XH_LOGIC - 1
@@ -462,9 +517,12 @@ MQ_HD int32_t ex_err_dec(uint32_t x) { return (int32_t)(x + (x >> 1) * 5u); }
 constexpr int kExPre = 4;
 // NT: threads of the workgroup; ERR = false: a program that cannot raise an error (comparisons, AND / OR / NOT, IS NULL,
 // CASE over columns and literals) carries none
+// xv (optional, LDS): the values of the plan's EARLIER expressions for these rows — value of expression k, row j at
+// xv[(k * J + j) * NT + tid] — for a kernel that keeps no temporary columns (a column node `arg` >= n_phys reads them)
 template <int J, int NT, bool ERR>
 MQ_D void eval_expr_rows(const DevExpr& e, const XNode* prog, const int8_t* const* cols, const int64_t (&pos)[J],
-                         const int64_t (&raw)[kExPre][J], const ExLdsStack& s, int64_t (&out)[J], int32_t (&err)[J]) {
+                         const int64_t (&raw)[kExPre][J], const ExLdsStack& s, int64_t (&out)[J], int32_t (&err)[J],
+                         const int64_t* xv = nullptr, int n_phys = 0) {
   int64_t tv[J];
   int32_t te[J];
   uint32_t be[J];  // the errors of the values below the top, two bits each, the nearest in bits 0-1
@@ -480,9 +538,8 @@ MQ_D void eval_expr_rows(const DevExpr& e, const XNode* prog, const int8_t* cons
   XNode nd = prog[0];
 #pragma unroll 1
   for (int i = 0; i < nn; ++i) {
-    const int h = __builtin_amdgcn_readfirstlane(nd.h);
-    const int64_t lit = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(nd.lit >> 32)) << 32) |
-                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)nd.lit));
+    const int h = MQ_WAVE_UNIFORM(nd.h);
+    const int64_t lit = (int64_t)(((uint64_t)(uint32_t)MQ_WAVE_UNIFORM((int)(nd.lit >> 32)) << 32) | (uint32_t)MQ_WAVE_UNIFORM((int)nd.lit));
     if (i + 1 < nn) nd = prog[i + 1];
     if (h <= XH_LIT || h == XH_GCOL) {  // push
       if (sp > 0) {
@@ -509,8 +566,13 @@ MQ_D void eval_expr_rows(const DevExpr& e, const XNode* prog, const int8_t* cons
         for (int j = 0; j < J; ++j) tv[j] = raw[3][j];
       } else {
         const DevExprNode& n = e.nodes[i];
+        if (xv && n.arg >= n_phys) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) tv[j] = ex_col(n, cols, pos[j]);
+          for (int j = 0; j < J; ++j) tv[j] = xv[(size_t)((n.arg - n_phys) * J + j) * NT + s.tid];
+        } else {
+#pragma unroll
+          for (int j = 0; j < J; ++j) tv[j] = ex_col(n, cols, pos[j]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < J; ++j) te[j] = 0;

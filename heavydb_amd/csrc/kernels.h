@@ -329,7 +329,7 @@ struct ProjSpec {
   int32_t row_quad;       // row-wise: 1 + n_targets
   int32_t n_phys_cols;    // physical columns; indices from here on name the plan's expressions
   int32_t n_cols_table;   // pointers per fragment in the column table
-  int32_t pad_;
+  int32_t x_info;         // expressions (uploaded with their handlers, expr.h xh_label_programs): deepest stack | count << 8
   int64_t entry_count;
   ProjTarget t[MI355Q_MAX_TARGETS];
 };

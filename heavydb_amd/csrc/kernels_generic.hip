@@ -1697,63 +1697,13 @@ hipError_t launch_project(const DevExprSet& xs, DevExprSet* d_xs_area, const Dev
     }
     return hipGetLastError();
   }
-  // the device copy of the programs: every node labelled with its typed handler (expr.h XH_*), literals as patterns, and
-  // the plain physical columns the programs read (the first kExPre of them) listed for the per-tile batch of loads
+  // the device copy of the programs: handlers, literal patterns, the columns loaded per tile (expr.h xh_label_programs)
   static thread_local DevExprSet up;  // (the upload's source outlives the call: the caller synchronises the stream)
   up = xs;
-  up.n_pre = 0;
-  up.noerr_mask = 0;
-  for (int k = 0; k < up.n; ++k) {
-    bool noerr = true;
-    for (int i = 0; i < up.e[k].n_nodes; ++i) {
-      const int op = up.e[k].nodes[i].op;
-      noerr = noerr && (op == MI355Q_EX_COL || op == MI355Q_EX_LIT || (op >= MI355Q_EX_EQ && op <= MI355Q_EX_GE) || op == MI355Q_EX_CASE ||
-                        op == MI355Q_EX_NOT || op == MI355Q_EX_AND || op == MI355Q_EX_OR || op == MI355Q_EX_IS_NULL);
-    }
-    if (noerr) up.noerr_mask |= 1 << k;
-  }
-  for (int k = 0; k < up.n; ++k)
-    for (int i = 0; i < up.e[k].n_nodes; ++i) {
-      DevExprNode& n = up.e[k].nodes[i];
-      int h = XH_GCOL;
-      if (n.op == MI355Q_EX_COL) {
-        const int code = (int)n.ilit;
-        if (n.arg < up.n_cols && (code == MI355Q_INT32 || code == MI355Q_INT64 || code == MI355Q_DOUBLE)) {
-          int slot = -1;
-          for (int c = 0; c < up.n_pre; ++c)
-            if (up.pre_col[c] == n.arg) slot = c;
-          if (slot < 0 && up.n_pre < kExPre) {
-            slot = up.n_pre++;
-            up.pre_col[slot] = n.arg;
-            up.pre_type[slot] = n.type;
-            up.pre_code[slot] = code;
-          }
-          if (slot >= 0) h = XH_COLPRE + slot;
-        }
-        else h = XH_GCOL;
-      } else {
-        h = xh_of(n);
-        if (n.op == MI355Q_EX_LIT) {  // (ex_lit's pattern, laid down once)
-          n.ilit = ex_lit(n);
-          n.arg = 1;
-        }
-      }
-      n.flags = (n.flags & ((1 << kExHandlerShift) - 1)) | (h << kExHandlerShift);
-    }
+  const int deepest = xh_label_programs(&up, true);
   hipError_t e = hipMemcpyAsync(d_xs_area, &up, sizeof(up), hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return e;
   // LDS: the evaluation stack BELOW its top (the top stays in registers), sized for the deepest of the programs
-  int deepest = 1;
-  for (int k = 0; k < xs.n; ++k) {
-    int sp = 0;
-    for (int i = 0; i < xs.e[k].n_nodes; ++i) {
-      const int op = xs.e[k].nodes[i].op;
-      if (op == MI355Q_EX_COL || op == MI355Q_EX_LIT) ++sp;
-      else if (op == MI355Q_EX_CASE) sp -= 2;
-      else if (op != MI355Q_EX_CAST && op != MI355Q_EX_NOT && op != MI355Q_EX_IS_NULL && op != MI355Q_EX_UMINUS) --sp;
-      if (sp > deepest) deepest = sp;
-    }
-  }
   const int below = deepest - 1;
   const size_t lds = (size_t)kProgQuads * 8 + (size_t)below * kProjJ * kBlock * 8;
   const int64_t tiles = (max_frag_rows + kProjJ * kBlock - 1) / (kProjJ * kBlock);

@@ -75,6 +75,10 @@ struct ProjArgs {
   int32_t out16;                 // row-wise buffer on a 16-byte boundary (paired stores for odd target counts)
   int32_t fast_quals;            // every qual compares an aligned physical column with a literal, no disjunction
   int32_t fast_targets;          // every target is an aligned physical column
+  // expressions: the typed-handler evaluator's area in the workgroup's dynamic LDS, behind the output image — the
+  // programs as XNodes, x_below stack levels of 4 x kBlock values, then the values of the expressions (n x 4 x kBlock);
+  // x_lds_off < 0: no room (very deep programs beside a wide image) — the row-at-a-time evaluator with its private stack
+  int32_t x_lds_off, x_below;
 };
 
 // ---- four rows of one column ------------------------------------------------------------------
@@ -118,6 +122,34 @@ MQ_D void eval_exprs(const DevExprSet& xs, uint32_t mask, const int8_t* const* f
     if ((mask >> k) & 1u) xv[k] = eval_expr(xs.e[k], fc, pos, err, xv, xs.n_cols);
 }
 
+// ---- the expressions in LDS form (expr.h eval_expr_rows: typed handlers, the stack below its top and the expressions'
+// values in LDS — nothing in scratch memory)
+constexpr int kXJ = 4;  // rows evaluated together: the four rows of a lane's quad
+struct ProjExprLds {
+  const XNode* prog;  // MI355Q_MAX_EXPR_NODES per expression
+  ExLdsStack stk;
+  int64_t* xv;        // value of expression k, row j of the quad: xv[(k * kXJ + j) * kBlock + tid]
+};
+// the expressions of `mask`, in order, for the rows pos[0..3] (out-of-fragment rows clamped by the caller); err[j] = the first
+// error row j met (its value is then unspecified)
+MQ_D void eval_exprs_lds(const DevExprSet& xs, const ProjExprLds& L, uint32_t mask, const int8_t* const* fc, const int64_t (&pos)[kXJ],
+                         int32_t (&err)[kXJ]) {
+  const int64_t raw[kExPre][kXJ] = {};
+#pragma unroll 1
+  for (int k = 0; k < xs.n; ++k) {
+    if (!((mask >> k) & 1u)) continue;
+    int64_t v[kXJ];
+    int32_t e[kXJ];
+    if ((xs.noerr_mask >> k) & 1) eval_expr_rows<kXJ, kBlock, false>(xs.e[k], L.prog + k * MI355Q_MAX_EXPR_NODES, fc, pos, raw, L.stk, v, e, L.xv, xs.n_cols);
+    else eval_expr_rows<kXJ, kBlock, true>(xs.e[k], L.prog + k * MI355Q_MAX_EXPR_NODES, fc, pos, raw, L.stk, v, e, L.xv, xs.n_cols);
+#pragma unroll
+    for (int j = 0; j < kXJ; ++j) {
+      L.xv[(size_t)(k * kXJ + j) * kBlock + L.stk.tid] = v[j];
+      if (e[j] && !err[j]) err[j] = e[j];
+    }
+  }
+}
+
 MQ_D unsigned long long wave_excl_scan_u32x2(unsigned long long v, unsigned long long* total) {
   // inclusive scan over the wave of two packed 32-bit counters
   const int lane = threadIdx.x & 63;
@@ -155,16 +187,29 @@ MQ_D int64_t proj_null_bits(int code) {
 // the whole filter of one row — every kind of qual (any column type and encoding, disjunctions, quals on expressions).  ONE
 // call site per kernel (the general path of pass A), so that the row function is instantiated once
 // HJ: the step joins — an INNER join keeps the rows that find a match
+// L (HX): the LDS form of the evaluator, or L.xv == nullptr
 template <bool HX, bool HJ = false>
-MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const int8_t* const* fc, int64_t pos, int32_t* err) {
+MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const ProjExprLds& L, const int8_t* const* fc, int64_t pos, int32_t* err) {
   const int n_phys = a.ps.n_phys_cols;
   int64_t xv[HX ? MI355Q_MAX_EXPRS : 1];
-  if (HX && a.qual_expr_mask) eval_exprs(*a.xs, a.qual_expr_mask, fc, pos, xv, err);
+  const bool lds_x = HX && L.xv != nullptr;
+  if (HX && a.qual_expr_mask) {
+    if (lds_x) {  // (one row: the quad's other slots repeat it)
+      const int64_t p4[kXJ] = {pos, pos, pos, pos};
+      int32_t e4[kXJ] = {0, 0, 0, 0};
+      eval_exprs_lds(*a.xs, L, a.qual_expr_mask, fc, p4, e4);
+      if (e4[0] && !*err) *err = e4[0];
+    } else {
+      eval_exprs(*a.xs, a.qual_expr_mask, fc, pos, xv, err);
+    }
+  }
   uint32_t seen = 0, any = 0;
 #pragma unroll 1
   for (int k = 0; k < p.n_quals; ++k) {
     const DevQual& q = p.quals[k];
-    const bool t = (HX && q.col >= n_phys) ? qual_on_value(q, xv[HX ? q.col - n_phys : 0]) : eval_qual(q, fc[q.col < n_phys ? q.col : 0], pos);
+    const bool t = (HX && q.col >= n_phys)
+                       ? qual_on_value(q, lds_x ? L.xv[(size_t)((q.col - n_phys) * kXJ) * kBlock + L.stk.tid] : xv[HX ? q.col - n_phys : 0])
+                       : eval_qual(q, fc[q.col < n_phys ? q.col : 0], pos);
     if (q.or_group == 0) {
       if (!t) return false;
     } else {
@@ -183,7 +228,7 @@ MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const int8_t* const* f
 // forms compare in registers, the other types go through qual_on_value; everything else (a fragment's ragged end,
 // unaligned chunks, disjunctions, quals on expressions) takes row_passes, row by row.
 template <bool HX, bool HJ = false>
-MQ_D uint64_t tile_filter(const DevPlan& p, const ProjArgs& a, const int8_t* const* fc, int64_t n, int64_t row0, int32_t* err) {
+MQ_D uint64_t tile_filter(const DevPlan& p, const ProjArgs& a, const ProjExprLds& L, const int8_t* const* fc, int64_t n, int64_t row0, int32_t* err) {
   const int tid = threadIdx.x;
   uint64_t m = 0;
 #pragma unroll 1
@@ -260,7 +305,7 @@ MQ_D uint64_t tile_filter(const DevPlan& p, const ProjArgs& a, const int8_t* con
         const uint32_t bj = j == 0 ? bits[0] : j == 1 ? bits[1] : j == 2 ? bits[2] : bits[3];
         if (!((bj >> i) & 1u)) continue;
         const int64_t rj = j == 0 ? r[0] : j == 1 ? r[1] : j == 2 ? r[2] : r[3];
-        if (!row_passes<HX, HJ>(p, a, fc, rj + i, err)) {
+        if (!row_passes<HX, HJ>(p, a, L, fc, rj + i, err)) {
           const uint32_t clr = ~(1u << i);
           if (j == 0) bits[0] &= clr;
           if (j == 1) bits[1] &= clr;
@@ -596,6 +641,24 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n_phys = ps.n_phys_cols;
   int32_t err = 0;
+  // the expressions' LDS area: programs (copied once), stack, values
+  ProjExprLds L{};
+  L.stk.tid = tid;
+  if (a.xs && a.x_lds_off >= 0) {
+    XNode* const s_prog = (XNode*)(s_img + a.x_lds_off);
+    for (int w = tid; w < a.xs->n * MI355Q_MAX_EXPR_NODES; w += kBlock) {
+      const DevExprNode& nd = a.xs->e[w / MI355Q_MAX_EXPR_NODES].nodes[w % MI355Q_MAX_EXPR_NODES];
+      XNode x;
+      x.h = nd.flags >> kExHandlerShift;
+      x.pad_ = 0;
+      x.lit = nd.ilit;
+      s_prog[w] = x;
+    }
+    L.prog = s_prog;
+    L.stk.st = (int64_t*)(s_prog + MI355Q_MAX_EXPRS * MI355Q_MAX_EXPR_NODES);
+    L.xv = L.stk.st + (size_t)a.x_below * kXJ * kBlock;
+    __syncthreads();
+  }
 
   for (;;) {
     // ---- the next tile, in ticket order (a tile's predecessors have all been taken by running workgroups)
@@ -618,7 +681,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs
     const int64_t n = a.num_rows[f];
     const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;  // first row of the tile in its fragment
 
-    const uint64_t m = tile_filter<true, HJ>(p, a, fc, n, row0, &err);
+    const uint64_t m = tile_filter<true, HJ>(p, a, L, fc, n, row0, &err);
 
     // ---- the tile's count, its descriptor, and the entries before it
     {
@@ -693,7 +756,16 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs
           }
         }
         int64_t xv[4][MI355Q_MAX_EXPRS];
-        if (a.xs) {
+        if (a.xs && L.xv) {  // the quad's four rows together (a row past the fragment's end repeats the last one)
+          int64_t p4[kXJ];
+          int32_t e4[kXJ] = {0, 0, 0, 0};
+#pragma unroll
+          for (int i = 0; i < kXJ; ++i) p4[i] = r + i < n ? r + i : n - 1;
+          eval_exprs_lds(*a.xs, L, (1u << a.xs->n) - 1u, fc, p4, e4);
+#pragma unroll
+          for (int i = 0; i < kXJ; ++i)
+            if (((mm >> i) & 1u) && e4[i] && !err) err = e4[i];  // (only a row that is emitted counts)
+        } else if (a.xs) {
           for (int i = 0; i < 4; ++i)
             if ((mm >> i) & 1u) eval_exprs(*a.xs, (1u << a.xs->n) - 1u, fc, r + i, xv[i], &err);
         }
@@ -710,7 +782,11 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs
             for (int i = 0; i < 4; ++i)
               vals[i] = !((mm >> i) & 1u) ? 0 : inner_pos[i] >= 0 ? col_value_bits(base, pt.code, inner_pos[i]) : proj_null_bits(pt.code);
           } else if (pt.col >= n_phys) {
-            for (int i = 0; i < 4; ++i) vals[i] = xv[i][pt.col - n_phys];
+            if (L.xv) {
+              for (int i = 0; i < 4; ++i) vals[i] = L.xv[(size_t)((pt.col - n_phys) * kXJ + i) * kBlock + tid];
+            } else {
+              for (int i = 0; i < 4; ++i) vals[i] = xv[i][pt.col - n_phys];
+            }
           } else {
             const int8_t* base = fc[pt.col];
             const int w = type_width(pt.code);
@@ -908,7 +984,20 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
     fa.tcol_off[t] = pt.col_off;
   }
   // the LDS image of one sub-tile (general member): every row of it may match; columnar runs are padded to 8 bytes each
-  const size_t lds = fast_ok ? 0 : (size_t)a.sub_iters * kIterRows * row_bytes + (ps.columnar ? 8 * (size_t)(ps.n_targets + 1) : 0);
+  size_t lds = fast_ok ? 0 : (size_t)a.sub_iters * kIterRows * row_bytes + (ps.columnar ? 8 * (size_t)(ps.n_targets + 1) : 0);
+  a.x_lds_off = -1;
+  a.x_below = 0;
+  const int x_deepest = ps.x_info & 0xff, x_n = ps.x_info >> 8;
+  if (d_xs && !fast_ok && x_deepest > 0) {  // + the expressions' area (programs, stack below the top, values)
+    const size_t img = (lds + 15) & ~(size_t)15;
+    const size_t xarea = (size_t)MI355Q_MAX_EXPRS * MI355Q_MAX_EXPR_NODES * sizeof(XNode) +
+                         (size_t)(x_deepest - 1 + x_n) * kXJ * kBlock * 8;
+    if (img + xarea <= 156 * 1024) {
+      a.x_lds_off = (int32_t)img;
+      a.x_below = x_deepest - 1;
+      lds = img + xarea;
+    }
+  }
   if (st) {
     st->kernel_name = "k_proj_compact";
     st->n_launches = 1;

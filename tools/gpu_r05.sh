@@ -36,6 +36,11 @@ PY
   interppmc) # k_project's instruction mix and stall split (SQ counters; one pass, kernel trace only)
     timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/pmc -o pmc -- python tools/bool_filter_bench.py --rows 1e9 --steps 1 --interpreted > $out/pmc.log 2>&1
     python tools/rocpd_stats.py $out/pmc/pmc_results.db > $out/pmc_stats.txt 2>&1; rm -rf $out/pmc; grep -E "k_project|k_perfect_lds|k_groupby" $out/pmc_stats.txt | cut -c1-200; tail -3 $out/pmc.log ;;
+  projvar)  # the Projection family's general member: the plain shapes forced through it, expressions in registers, a join probe per row
+    for v in ${3:-general expr join}; do
+      timeout 400 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant $v >> $out/proj_variants_1b.jsonl 2>> $out/err.log; echo "$v exit $?"
+    done
+    cut -c1-420 $out/proj_variants_1b.jsonl; tail -5 $out/err.log ;;
   cfg1cost) timeout 300 python tools/cfg1_cost.py > $out/cfg1_cost.txt 2>&1; echo "exit $?"; tail -40 $out/cfg1_cost.txt ;;
   final)    # the round's kept lines on ONE build: every BASELINE config (roofline + cpu_baseline + verify), the default line's
             # rocprofv3 kernel summary and FETCH / WRITE passes (-> profiles/traffic.json), the Projection / filter / NGA shapes,

@@ -25,6 +25,10 @@ def main():
     ap.add_argument("--sel", default="0.01,0.5,0.99")
     ap.add_argument("--cols", default="1,3,6")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
+    ap.add_argument("--variant", default="plain", choices=["plain", "general", "expr", "join"],
+                    help="general: the same shapes through the general member (pass_rows = -1); expr: the second target is v1 * 2.0 "
+                         "and a third one v0 + 1 (expressions in registers); join: SELECT v.., d.w FROM t JOIN d ON t.fk = d.k "
+                         "(d: 1 M rows, dense keys; fk = i32 >> 11)")
     args = ap.parse_args()
     import torch
     from heavydb_amd import capi, synth
@@ -38,12 +42,46 @@ def main():
         for n_out in [int(x) for x in args.cols.split(",")]:
             for columnar in ([False, True] if n_out == 3 else [False]):
                 ra, fr, info = synth.projection(torch, n, n_out, sel, columnar=columnar, cols_cache=cache)
+                opts = {}
+                if args.variant == "general":
+                    opts["pass_rows"] = -1
+                elif args.variant == "expr":
+                    from heavydb_amd.executor import Expr, ExpressionRange, TargetExpr
+                    nc = len(ra.input_col_descs)
+                    xs = [Expr.col(1).add(Expr.lit(capi.INT64, 1), capi.INT64).with_range(ExpressionRange(True, -500_000_000, 500_000_007))]
+                    tg = [TargetExpr(capi.PROJECT, nc)]
+                    if n_out >= 2:
+                        xs.append(Expr.col(2).mul(Expr.lit(capi.DOUBLE, 2.0), capi.DOUBLE).with_range(ExpressionRange()))
+                        tg.append(TargetExpr(capi.PROJECT, nc + 1))
+                    tg += [TargetExpr(capi.PROJECT, 1 + i) for i in range(2, n_out)]
+                    ra.exprs, ra.target_exprs = xs, tg
+                elif args.variant == "join":
+                    from heavydb_amd.executor import ExpressionRange, FetchResult, HashJoin, InputColDescriptor, TargetExpr
+                    m = 1 << 20
+                    if "join" not in cache:
+                        dk = torch.randperm(m, device="cuda").to(torch.int64)
+                        dw = torch.randint(-1000, 1000, (m,), device="cuda", dtype=torch.int64)
+                        fks = [(c.view(torch.int32) >> 11).contiguous() for c in [info["cols"][0]]]
+                        cache["join"] = (dk, dw, fks, HashJoin.getInstance(int(dk.data_ptr()), m, capi.INT64, ExpressionRange(True, 0, m - 1)))
+                    dk, dw, fks, hj = cache["join"]
+                    nc = len(ra.input_col_descs)
+                    off, bufs = 0, []
+                    for b, r in zip(fr.col_buffers, fr.num_rows):
+                        bufs.append(list(b) + [int(fks[0].data_ptr()) + off * 4])
+                        off += r
+                    ra.input_col_descs = list(ra.input_col_descs) + [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, m - 1))]
+                    ra.inner_col_descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 0, m - 1)),
+                                          InputColDescriptor(capi.INT64, False, ExpressionRange(True, -1000, 999))]
+                    ra.join_outer_col, ra.join_table = nc, hj
+                    ra.target_exprs = list(ra.target_exprs) + [TargetExpr(capi.PROJECT, 1, 1)]
+                    fr = FetchResult(bufs, fr.num_rows, [int(dk.data_ptr()), int(dw.data_ptr())], m, keepalive=[fr, dk, dw, fks])
+                    info = dict(info, bytes_per_row=info["bytes_per_row"] + 4, out_bytes_per_row=info["out_bytes_per_row"] + 8)
                 q = capi.QMD()
                 assert lib.mi355q_qmd_init(ctypes.byref(ra.to_plan()), ctypes.byref(q)) == 0
                 out = torch.empty(lib.mi355q_qmd_buffer_bytes(ctypes.byref(q)) // 8, dtype=torch.int64, device="cuda")
                 best = kbest = None
                 for _ in range(args.steps + 1):  # (the first step allocates the family's workspace)
-                    rs = ex.executeWorkUnit(ra, fr, allow_retry=False, out_buffer=int(out.data_ptr()), tune_blocks_per_cu=args.blocks_per_cu)
+                    rs = ex.executeWorkUnit(ra, fr, allow_retry=False, out_buffer=int(out.data_ptr()), tune_blocks_per_cu=args.blocks_per_cu, **opts)
                     if best is not None or args.steps == 0:
                         best = rs.report.total_ms if best is None else min(best, rs.report.total_ms)
                         kbest = rs.report.kernel_ms if kbest is None else min(kbest, rs.report.kernel_ms)
@@ -51,7 +89,7 @@ def main():
                         best, kbest = float("inf"), float("inf")
                 matched = rs.totalMatched()
                 bytes_ = info["bytes_per_row"] * n + info["out_bytes_per_row"] * matched
-                print(json.dumps({"shape": f"sel{sel}_cols{n_out}_{'columnar' if columnar else 'rowwise'}", "rows": n, "matched": matched,
+                print(json.dumps({"shape": f"sel{sel}_cols{n_out}_{'columnar' if columnar else 'rowwise'}", "variant": args.variant, "rows": n, "matched": matched,
                                   "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3), "kernel_ms": round(kbest, 3),
                                   "read_bytes_per_row": info["bytes_per_row"], "written_bytes_per_match": info["out_bytes_per_row"],
                                   "algorithmic_gb": round(bytes_ / 1e9, 3), "gbps": round(bytes_ / (best * 1e-3) / 1e9, 1),
