@@ -154,6 +154,19 @@ int64_t algorithmic_bytes(const mi355q_plan& p, const mi355q_inputs& in);
 int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, const mi355q_exec_options& o, mi355q_result** out,
                            mi355q_exec_report* report, int64_t* reserved);
 // result accessors of a Projection buffer
+// ---- shared between api.cpp (the step executor), api_result.cpp (result objects, shards) and api_join.cpp
+RowInit make_row_init(const mi355q_qmd& q);
+ColLayout col_layout_of(const mi355q_qmd& q);
+// the device operations that walk rows run on a row-wise twin of a columnar buffer (same entries, same values)
+struct RowTwin {
+  mi355q_result* tw = nullptr;
+  ~RowTwin() {
+    if (tw) mi355q_result_free(tw);
+  }
+};
+int32_t make_row_twin(const mi355q_result* r, hipStream_t s, RowTwin* out);
+int32_t store_row_twin(const RowTwin& t, mi355q_result* r, hipStream_t s);
+int32_t run_reduce(mi355q_result* dst, const int64_t* rows, int64_t n_rows, void* stream);
 int32_t attach_join(const mi355q_plan& p, const mi355q_inputs* in, DevPlan* d);  // (api.cpp) the join table and the inner columns
 int64_t projection_row_count(const mi355q_result* r);
 int32_t projection_append(mi355q_result* this_rs, const mi355q_result* that_rs, hipStream_t s);

@@ -364,7 +364,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
     real_srcs = ["kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_idx.hip", "fast_common.h", "lds_args.h"] if real_fast else []
     deps = [os.path.join(src_dir, f) for f in ("hip_host.cpp", "kernels_host.cpp", "shim/hip/hip_runtime.h",
                                                "shim/hip/hip_runtime_api.h")] + \
-        [os.path.join(csrc, f) for f in ["api.cpp", "api_projection.cpp", "api_internal.h", "boolfilter.cpp", "boolfilter.h", "plan.cpp", "kernels_generic.hip",
+        [os.path.join(csrc, f) for f in ["api.cpp", "api_projection.cpp", "api_result.cpp", "api_join.cpp", "api_internal.h", "boolfilter.cpp", "boolfilter.h", "plan.cpp", "kernels_generic.hip",
                                          "kernels_proj.hip", "kernels.h", "rowfunc.h", "dev_common.h", "plan.h", "expr.h",
                                          "fast_common.h"] + real_srcs] + \
         [os.path.join(ROOT, "include", "mi355q.h"), os.path.abspath(__file__)]   # (the build recipe patches the sources)
@@ -410,7 +410,8 @@ def hostsim_lib(real_fast: bool = False) -> str:
         kp_cpp = os.path.join(out_dir, "kernels_proj_host.cpp")
         with open(kp_cpp, "w") as f:
             f.write(kp)
-        srcs = [os.path.join(csrc, "api.cpp"), os.path.join(csrc, "api_projection.cpp"), os.path.join(csrc, "boolfilter.cpp"),
+        srcs = [os.path.join(csrc, "api.cpp"), os.path.join(csrc, "api_projection.cpp"), os.path.join(csrc, "api_result.cpp"),
+                os.path.join(csrc, "api_join.cpp"), os.path.join(csrc, "boolfilter.cpp"),
                 os.path.join(csrc, "plan.cpp"), kg_cpp,
                 kp_cpp, os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
         if real_fast:
