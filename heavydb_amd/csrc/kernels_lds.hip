@@ -523,6 +523,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   constexpr bool kBase = KK != 0;
   constexpr int KW = KK == 1 ? 2 : 1;  // 16-byte loads per key quad
   constexpr int TF = FM ? kTypedFlt : 1;
+  constexpr int NVA = NV ? NV : 1;  // (NV = 0: the COUNT(*)-only members — arrays of one unused element)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ BoolFilter s_bf;  // (FM, a.bf_on: visible after the barrier behind the replicas' initialisation)
   const int t = threadIdx.x;
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   bool bad = false, full = false;
   // uniform per-column constants (static indices after unrolling: scalar registers, never a scratch copy of `a`)
   uint32_t kmin[NK], kcard[NK], kmul[NK], knull[NK];
-  bool ktr[NK], vnull[NV];
+  bool ktr[NK], vnull[NVA];
 #pragma unroll
   for (int g = 0; g < NK; ++g) {
     kmin[g] = (uint32_t)(int32_t)a.key_min[g];
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   };
 
   // entry e takes one row's values
-  auto update = [&](uint32_t e, const int32_t (&vv)[NV]) {
+  auto update = [&](uint32_t e, const int32_t (&vv)[NVA]) {
     atomicAdd(my_rows + e, 1u);
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
     return e < E ? e : kNoSlot;
   };
   // one row on its own (quad remainders, tail rows)
-  auto one_row = [&](const int32_t (&klo)[NK], int32_t khi, const int32_t (&vv)[NV]) {
+  auto one_row = [&](const int32_t (&klo)[NK], int32_t khi, const int32_t (&vv)[NVA]) {
     uint32_t e;
     if constexpr (kBase) {
       const int64_t key = key_of(klo[0], khi);
@@ -691,7 +692,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
 
   struct Tile {
     v4i32 k[NK][UQ][KW];
-    v4i32 v[NV][UQ];
+    v4i32 v[NVA][UQ];
     v4i32 f[TF][UQ];
   };
   const int64_t tile_q = (int64_t)kLdsBlock * UQ;
@@ -703,7 +704,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
     const int64_t n = num_rows[f];
     const int64_t nq = n >> 2;
     const int64_t n_tiles = nq / tile_q;
-    const int8_t *kb[NK], *vb[NV], *fb[TF];
+    const int8_t *kb[NK], *vb[NVA], *fb[TF];
 #pragma unroll
     for (int g = 0; g < NK; ++g) kb[g] = fc[a.key_col[g]];
 #pragma unroll
@@ -762,7 +763,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
               e = slow_locate(key[i], hh[i]);
               if (e == kNoSlot) continue;
             }
-            int32_t vv[NV];
+            int32_t vv[NVA];
 #pragma unroll
             for (int c = 0; c < NV; ++c) vv[c] = v4_get(tl.v[c][u], i);
             update(e, vv);
@@ -770,7 +771,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            int32_t klo[NK], vv[NV];
+            int32_t klo[NK], vv[NVA];
             if constexpr (FM != 0) {
               int32_t fv[TF];
 #pragma unroll
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
     }
     const int64_t tail = (nq << 2) + gtid;
     if (tail < n) {
-      int32_t klo[NK], vv[NV];
+      int32_t klo[NK], vv[NVA];
       int32_t khi = 0;
 #pragma unroll
       for (int g = 0; g < NK; ++g) {
@@ -979,7 +980,9 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out
   };
   // typed member (k_groupby_lds_typed): up to three plain INT32 filter columns, 1 - 3 plain INT32 value columns; perfect hash over INT32 keys whose
   // ranges keep the index arithmetic in 32 bits, or a baseline table over one BIGINT / DOUBLE / FLOAT / INT key
-  a.typed = a.n_flt <= kTypedFlt && a.n_vals >= 1 && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
+  // (no value column at all — COUNT(*) alone — is typed only under a filter: the unfiltered count shapes have members of
+  // their own, k_perfect_lds's count program and the index family's count-only member)
+  a.typed = a.n_flt <= kTypedFlt && (a.n_vals >= 1 || a.n_flt >= 1) && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
   for (int k = 0; k < a.n_flt; ++k) a.typed = a.typed && a.flt_type[k] == MI355Q_INT32;
   a.mm = 0;
   for (int c = 0; c < a.n_vals; ++c) {
@@ -1080,6 +1083,7 @@ template <int KK, int NK>
 void launch_typed_nv(const LdsLaunch& l) {
   const bool mm = l.a.mm != 0;
   switch (l.a.n_vals) {
+    case 0: launch_typed_member<KK, NK, 0, false>(l); break;  // COUNT(*) alone: the entries' row counters are the result
     case 1: mm ? launch_typed_member<KK, NK, 1, true>(l) : launch_typed_member<KK, NK, 1, false>(l); break;
     case 2: mm ? launch_typed_member<KK, NK, 2, true>(l) : launch_typed_member<KK, NK, 2, false>(l); break;
     default: mm ? launch_typed_member<KK, NK, 3, true>(l) : launch_typed_member<KK, NK, 3, false>(l);

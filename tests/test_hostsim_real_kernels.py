@@ -782,7 +782,7 @@ def test_compiled_bool_filters_in_the_scan_aggregate(sim, oracle, idx):
 
 
 # ---- the typed member under filters (round 5): up to three plain INT32 filter columns, range quals or a compiled filter
-def _filtered_lds_case(oracle, quals, exprs=(), baseline=False, n=9003, nullable_flt=False, seed=11):
+def _filtered_lds_case(oracle, quals, exprs=(), baseline=False, n=9003, nullable_flt=False, seed=11, count_only=False):
     from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
     rng = np.random.default_rng(seed)
     I32 = capi.INT32
@@ -803,7 +803,8 @@ def _filtered_lds_case(oracle, quals, exprs=(), baseline=False, n=9003, nullable
              InputColDescriptor(I32, nullable_flt, ExpressionRange(True, -20, 19, nullable_flt)),
              InputColDescriptor(I32, False, ExpressionRange(True, 0, 99)),
              InputColDescriptor(I32, nullable_flt, ExpressionRange(True, 0, 99, nullable_flt))]
-    ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 1)],
+    targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT)] + ([] if count_only else [TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 1)])
+    ra = RelAlgExecutionUnit(descs, targets,
                              list(quals), [0], exprs=[e.with_range(ExpressionRange(True, 0, 1, True)) for e in exprs],
                              max_groups_buffer_entry_guess=256, num_tuples=n)
     h = n // 2 + 1
@@ -857,3 +858,18 @@ def test_typed_lds_member_under_a_compiled_filter(sim, oracle, nullable, baselin
         assert rs is not None and rs.report.kernel_name.decode() == "k_groupby_lds" and rs.report.variant == 5, (rs.report.kernel_name, rs.report.variant)
         route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
         assert "filter compiled" in route and "k_project" not in route, route
+
+
+@pytest.mark.parametrize("member", ["typed", "generic"])
+@pytest.mark.parametrize("baseline", [False, True], ids=["perfect", "baseline"])
+@pytest.mark.parametrize("shape", ["two_bounds_one_column", "three_columns", "not_equal", "is_not_null"])
+def test_typed_lds_member_count_only_under_filters(sim, oracle, shape, baseline, member):
+    """SELECT key, COUNT(*) FROM t WHERE ... GROUP BY key: no value column at all (the NV = 0 typed members)"""
+    case = _filtered_lds_case(oracle, _typed_filter_quals()[shape], baseline=baseline, nullable_flt=True, count_only=True)
+    rs = flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_LDS_GENERIC_MEMBER if member == "generic" else 0)
+    assert rs is not None
+    name = rs.report.kernel_name.decode()
+    if name == "k_groupby_lds":
+        assert rs.report.variant == (4 if member == "generic" else 5), rs.report.variant
+    else:
+        assert name == "k_perfect_lds" and not baseline and shape == "two_bounds_one_column", (name, shape)
