@@ -56,6 +56,12 @@ MQ_HD int64_t ex_lit(const DevExprNode& n) {
          : n.type == MI355Q_DOUBLE ? dbl_bits(n.flit)
          : n.type == MI355Q_FLOAT ? ex_flt_pattern((float)n.flit) : n.ilit;
 }
+// The VALUE of an expression, as anything outside it sees it (a target, a qual, a later expression), is a value of its
+// type: where a floating-point operand was cast to a narrower integer it does not fit (undefined in the reference:
+// fptosi), the type's low bits, sign-extended, remain — what the dense temporary column of the projection pass stores
+MQ_HD int64_t ex_wrap_int(int t, int64_t r) {
+  return t == MI355Q_INT8 ? (int64_t)(int8_t)r : t == MI355Q_INT16 ? (int64_t)(int16_t)r : t == MI355Q_INT32 ? (int64_t)(int32_t)r : r;
+}
 MQ_HD int64_t ex_cast(const DevExprNode& n, int64_t v, int32_t& ev) {
   const int from = n.arg, to = n.type;
   const bool nullable = (n.flags & EXF_LHS_NULLABLE) != 0;
@@ -305,7 +311,7 @@ MQ_HD int64_t eval_expr(const DevExpr& e, const int8_t* const* cols, int64_t pos
     }
   }
   if (es[0] && !*err) *err = es[0];
-  return st[0];
+  return ex_wrap_int(e.type, st[0]);
 }
 
 // ---- typed handlers.  The flat loops above decide, per node and per row, what `type`, the nullability flags and the
@@ -673,7 +679,7 @@ MQ_D void eval_expr_rows(const DevExpr& e, const XNode* prog, const int8_t* cons
   }
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    out[j] = tv[j];
+    out[j] = ex_wrap_int(e.type, tv[j]);
     err[j] = ERR ? te[j] : 0;
   }
 }

@@ -356,7 +356,8 @@ def hostsim_lib(real_fast: bool = False) -> str:
         return _hostsim[key]
     src_dir = os.path.join(ROOT, "tests", "hostsim")
     csrc = os.path.join(ROOT, "heavydb_amd", "csrc")
-    out_dir = os.path.join(ROOT, "tests", "_hostsim_real" if real_fast else "_hostsim")
+    san = os.environ.get("MI355Q_HOSTSIM_SANITIZE", "")   # "address": an ASan build of the simulation (run under LD_PRELOAD of the runtime)
+    out_dir = os.path.join(ROOT, "tests", ("_hostsim_real" if real_fast else "_hostsim") + ("_" + san if san else ""))
     out = os.path.join(out_dir, "libmi355q_hostsim_real.so" if real_fast else "libmi355q_hostsim.so")
     cxx = "/opt/rocm/lib/llvm/bin/clang++"
     if not os.path.exists(cxx):
@@ -400,6 +401,8 @@ def hostsim_lib(real_fast: bool = False) -> str:
             f.write("".join(f'    "{n}",\n' for n in plain))
         flags = ["-std=c++17", "-O1", "-g", "-fPIC", "-pthread", "-w", "-DHOSTSIM_DEVICE_CODE", "-I" + os.path.join(src_dir, "shim"), "-I" + csrc,
                  "-I" + os.path.join(ROOT, "include"), "-I" + out_dir]
+        if san:
+            flags += ["-fsanitize=" + san, "-fno-omit-frame-pointer", "-shared-libsan"]
         # the Projection family (kernels_proj.hip) is the real device source in BOTH simulations: its workgroups take tiles
         # off a ticket counter, so a tile's predecessors are always finished when blocks run one after the other
         with open(os.path.join(csrc, "kernels_proj.hip")) as f:
@@ -471,6 +474,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
             obj = os.path.join(out_dir, os.path.basename(src) + ".o")
             subprocess.run([cxx] + flags + ["-c", src, "-o", obj], check=True)
             objs.append(obj)
-        subprocess.run([cxx, "-shared", "-pthread", "-Wl,-Bsymbolic", "-o", out] + objs, check=True)
+        subprocess.run([cxx, "-shared", "-pthread", "-Wl,-Bsymbolic", "-o", out] + objs +
+                       (["-fsanitize=" + san, "-shared-libsan"] if san else []), check=True)
     _hostsim[key] = out
     return out
