@@ -264,7 +264,10 @@ typedef enum mi355q_expr_op {
                           (codegenCastBetweenIntTypesOverflowChecks, CastIR.cpp:497-553; NULL passes);
                           integer -> DOUBLE / FLOAT: sitofp; DOUBLE <-> FLOAT: fpext / fptrunc;
                           DOUBLE / FLOAT -> integer: round half away from zero, then truncate
-                          (DEF_ROUND_NULLABLE, RuntimeFunctions.cpp:283-293) */
+                          (DEF_ROUND_NULLABLE, RuntimeFunctions.cpp:283-293); a value the integer type does not
+                          hold is UNDEFINED in the reference (fptosi) and here: the conversion instruction's answer
+                          (the host's and the device's differ), of which the expression's value keeps the type's
+                          low bits */
   MI355Q_EX_ADD = 4,   /* pop rhs, pop lhs, push lhs + rhs; both operands have the node's `type`
                           (the analyzer has normalised them); NULL if either operand is NULL */
   MI355Q_EX_SUB = 5,
