@@ -187,28 +187,20 @@ MQ_D int64_t proj_null_bits(int code) {
 // the whole filter of one row — every kind of qual (any column type and encoding, disjunctions, quals on expressions).  ONE
 // call site per kernel (the general path of pass A), so that the row function is instantiated once
 // HJ: the step joins — an INNER join keeps the rows that find a match
-// L (HX): the LDS form of the evaluator, or L.xv == nullptr
+// L (HX): the LDS form of the evaluator, or L.xv == nullptr.  xslot >= 0: the quals' expressions have been evaluated for
+// this row's quad (tile_filter): the row's values are slot xslot of L.xv
 template <bool HX, bool HJ = false>
-MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const ProjExprLds& L, const int8_t* const* fc, int64_t pos, int32_t* err) {
+MQ_D bool row_passes(const DevPlan& p, const ProjArgs& a, const ProjExprLds& L, const int8_t* const* fc, int64_t pos, int32_t* err, int xslot) {
   const int n_phys = a.ps.n_phys_cols;
   int64_t xv[HX ? MI355Q_MAX_EXPRS : 1];
-  const bool lds_x = HX && L.xv != nullptr;
-  if (HX && a.qual_expr_mask) {
-    if (lds_x) {  // (one row: the quad's other slots repeat it)
-      const int64_t p4[kXJ] = {pos, pos, pos, pos};
-      int32_t e4[kXJ] = {0, 0, 0, 0};
-      eval_exprs_lds(*a.xs, L, a.qual_expr_mask, fc, p4, e4);
-      if (e4[0] && !*err) *err = e4[0];
-    } else {
-      eval_exprs(*a.xs, a.qual_expr_mask, fc, pos, xv, err);
-    }
-  }
+  const bool lds_x = HX && xslot >= 0;
+  if (HX && a.qual_expr_mask && !lds_x) eval_exprs(*a.xs, a.qual_expr_mask, fc, pos, xv, err);
   uint32_t seen = 0, any = 0;
 #pragma unroll 1
   for (int k = 0; k < p.n_quals; ++k) {
     const DevQual& q = p.quals[k];
     const bool t = (HX && q.col >= n_phys)
-                       ? qual_on_value(q, lds_x ? L.xv[(size_t)((q.col - n_phys) * kXJ) * kBlock + L.stk.tid] : xv[HX ? q.col - n_phys : 0])
+                       ? qual_on_value(q, lds_x ? L.xv[(size_t)((q.col - n_phys) * kXJ + xslot) * kBlock + L.stk.tid] : xv[HX ? q.col - n_phys : 0])
                        : eval_qual(q, fc[q.col < n_phys ? q.col : 0], pos);
     if (q.or_group == 0) {
       if (!t) return false;
@@ -303,9 +295,20 @@ MQ_D uint64_t tile_filter(const DevPlan& p, const ProjArgs& a, const ProjExprLds
       for (int ji = 0; ji < 16; ++ji) {
         const int j = ji >> 2, i = ji & 3;
         const uint32_t bj = j == 0 ? bits[0] : j == 1 ? bits[1] : j == 2 ? bits[2] : bits[3];
-        if (!((bj >> i) & 1u)) continue;
         const int64_t rj = j == 0 ? r[0] : j == 1 ? r[1] : j == 2 ? r[2] : r[3];
-        if (!row_passes<HX, HJ>(p, a, L, fc, rj + i, err)) {
+        const bool quad_x = HX && a.qual_expr_mask && L.xv != nullptr;
+        if (quad_x && i == 0 && bj) {  // the quals' expressions for the quad's four rows together (rows past the end repeat the last)
+          int64_t p4[kXJ];
+          int32_t e4[kXJ] = {0, 0, 0, 0};
+#pragma unroll
+          for (int x = 0; x < kXJ; ++x) p4[x] = rj + x < n ? rj + x : n - 1;
+          eval_exprs_lds(*a.xs, L, a.qual_expr_mask, fc, p4, e4);
+#pragma unroll
+          for (int x = 0; x < kXJ; ++x)
+            if (((bj >> x) & 1u) && e4[x] && !*err) *err = e4[x];
+        }
+        if (!((bj >> i) & 1u)) continue;
+        if (!row_passes<HX, HJ>(p, a, L, fc, rj + i, err, quad_x ? i : -1)) {
           const uint32_t clr = ~(1u << i);
           if (j == 0) bits[0] &= clr;
           if (j == 1) bits[1] &= clr;

@@ -192,6 +192,11 @@ def test_random_expressions_through_the_kernel_evaluator(sim, oracle, chunk):
             ra3 = RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 0)], [Qual(nc, capi.EQ, 1)], exprs=[e])
             r3 = _run(oracle, ra3, frags, keep)
             seen[r3] = seen.get(r3, 0) + 1
+            # (4) ... and as the filter of a Projection (the quals' expressions of a quad are evaluated together in pass A)
+            ra4 = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT, 0), TargetExpr(capi.PROJECT, 4)], [Qual(nc, capi.EQ, 1)], exprs=[e],
+                                      max_groups_buffer_entry_guess=N)
+            r4 = _run(oracle, ra4, frags, keep)
+            seen[r4] = seen.get(r4, 0) + 1
         for r in (r1, r2):
             seen[r] = seen.get(r, 0) + 1
     assert seen.get("ok", 0) > ITERS // 8, seen

@@ -62,6 +62,8 @@ def test_random_expressions_on_the_device(torch_cuda, oracle, chunk):
                 RelAlgExecutionUnit(descs, [TargetExpr(capi.MIN, nc), TargetExpr(capi.MAX, nc), TargetExpr(capi.COUNT, nc)], exprs=[e])]
         if t == F.I8:
             runs.append(RelAlgExecutionUnit(descs, [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 0)], [Qual(nc, capi.EQ, 1)], exprs=[e]))
+            runs.append(RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT, 0), TargetExpr(capi.PROJECT, 4)], [Qual(nc, capi.EQ, 1)], exprs=[e],
+                                            max_groups_buffer_entry_guess=F.N))
         for ra in runs:
             try:
                 r = F._run(oracle, ra, frags, keep)
