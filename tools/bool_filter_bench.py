@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--rows", type=float, default=1e9)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--verify-rows", type=float, default=0, help="also check every shape against the oracle on a table of this many rows")
+    ap.add_argument("--count-only", action="store_true", help="SELECT g, COUNT(*) ...: no value column (the NV = 0 typed members)")
+    ap.add_argument("--generic-member", action="store_true", help="MI355Q_OPT_LDS_GENERIC_MEMBER: the run-time-role member of k_groupby_lds")
     ap.add_argument("--interpreted", action="store_true", help="MI355Q_OPT_NO_COMPILED_FILTER: every expression through k_project")
     args = ap.parse_args()
     import numpy as np
@@ -72,16 +74,19 @@ def main():
             [InputColDescriptor(capi.INT32, i == 4, ExpressionRange(True, 0, 999_999, False)) for i in range(1, 5)]
     fr = FetchResult(bufs, rows, keepalive=cols)
     ex = Executor(0)
-    flags = capi.OPT_NO_COMPILED_FILTER if args.interpreted else 0
+    flags = (capi.OPT_NO_COMPILED_FILTER if args.interpreted else 0) | (capi.OPT_LDS_GENERIC_MEMBER if args.generic_member else 0)
     for name, exprs, quals, reads in shapes(capi, Expr, Qual):
         xs = [e.with_range(ExpressionRange(True, 0, 1, True)) for e in exprs]
-        ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1)], quals, [0],
+        targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT)] + ([] if args.count_only else [TargetExpr(capi.SUM, 1)])
+        ra = RelAlgExecutionUnit(descs, targets, quals, [0],
                                  exprs=xs, num_tuples=n)
         best, rs = None, None
         for _ in range(args.steps):
             rs = ex.executeWorkUnit(ra, fr, allow_retry=False, flags=flags)
             best = rs.report.total_ms if best is None else min(best, rs.report.total_ms)
-        line = {"shape": name, "rows": n, "interpreted": bool(args.interpreted), "route": ex.explain(ra, rows, flags=flags), "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3),
+        if args.count_only:
+            reads = [c for c in reads if c != 1]   # (no target reads the value column)
+        line = {"shape": name, "rows": n, "interpreted": bool(args.interpreted), "count_only": bool(args.count_only), "generic_member": bool(args.generic_member), "route": ex.explain(ra, rows, flags=flags), "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3),
                 "bytes_per_row": 4 * len(reads), "whole_step_frac": round(4 * len(reads) * n / (best * 1e-3) / 8e12, 4),
                 "groups": rs.rowCount()}
         if args.verify_rows:

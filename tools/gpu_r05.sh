@@ -41,6 +41,10 @@ PY
       timeout 400 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant $v >> $out/proj_variants_1b.jsonl 2>> $out/err.log; echo "$v exit $?"
     done
     cut -c1-420 $out/proj_variants_1b.jsonl; tail -5 $out/err.log ;;
+  countonly) # SELECT g, COUNT(*) ... WHERE <filter> GROUP BY g: the NV = 0 typed members next to the run-time-role member
+    timeout 300 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --count-only --verify-rows 4e6 > $out/count_only_typed.jsonl 2> $out/err.log; echo "exit $?"
+    timeout 300 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --count-only --generic-member > $out/count_only_generic.jsonl 2>> $out/err.log; echo "exit $?"
+    cut -c1-260 $out/count_only_typed.jsonl $out/count_only_generic.jsonl; tail -3 $out/err.log ;;
   cfg1cost) timeout 300 python tools/cfg1_cost.py > $out/cfg1_cost.txt 2>&1; echo "exit $?"; tail -40 $out/cfg1_cost.txt ;;
   final)    # the round's kept lines on ONE build: every BASELINE config (roofline + cpu_baseline + verify), the default line's
             # rocprofv3 kernel summary and FETCH / WRITE passes (-> profiles/traffic.json), the Projection / filter / NGA shapes,
