@@ -45,6 +45,9 @@ PY
     timeout 300 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --count-only --verify-rows 4e6 > $out/count_only_typed.jsonl 2> $out/err.log; echo "exit $?"
     timeout 300 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --count-only --generic-member > $out/count_only_generic.jsonl 2>> $out/err.log; echo "exit $?"
     cut -c1-260 $out/count_only_typed.jsonl $out/count_only_generic.jsonl; tail -3 $out/err.log ;;
+  r1bound)  # the headline with R = 1 (fewer groups): the bound of everything a cheaper second read of the records could gain
+    MI355Q_TRACE=0 timeout 500 python tools/headline_r1_bound.py 1e10 > $out/headline_r1_bound.jsonl 2> $out/err.log; echo "exit $?"
+    cut -c1-400 $out/headline_r1_bound.jsonl; tail -4 $out/err.log ;;
   cfg1cost) timeout 300 python tools/cfg1_cost.py > $out/cfg1_cost.txt 2>&1; echo "exit $?"; tail -40 $out/cfg1_cost.txt ;;
   final)    # the round's kept lines on ONE build: every BASELINE config (roofline + cpu_baseline + verify), the default line's
             # rocprofv3 kernel summary and FETCH / WRITE passes (-> profiles/traffic.json), the Projection / filter / NGA shapes,
