@@ -1285,7 +1285,9 @@ int32_t execute_affine_twin(const mi355q_plan* plan, const mi355q_inputs* in, co
   // only where the twin's step is the typed LDS members' or the index-partitioned family's work (no qual, plain INT value
   // columns: checked here before anything is launched, and on the derived plan below): every other baseline step — the
   // headline's filtered AVG(double) among them — keeps its own family and pays nothing for this route
-  if (plan->n_quals != 0) return kNotTaken;
+  // (a compiled filter travelling beside the plan is a qual too: the `rest` plan of execute_bool_filter has n_quals = 0;
+  // ADVICE r05)
+  if (plan->n_quals != 0 || step_bool_filter()) return kNotTaken;
   for (int t = 0; t < plan->n_targets; ++t) {
     const mi355q_target& tg = plan->targets[t];
     if (tg.agg == MI355Q_PROJECT_KEY || tg.col < 0) continue;
@@ -2786,7 +2788,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
         HIP_TRY(launch_scan_count(d, fv, res->buf, n_cus, s, &st));
         break;
       case K_SCAN_AGG:
-        HIP_TRY(launch_scan_agg(d, fv, res->buf, n_cus, s, &st));
+        HIP_TRY(launch_scan_agg(d, fv, res->buf, d_err, n_cus, s, &st));
         break;
       case K_PERFECT_LDS:
         HIP_TRY(launch_perfect_lds(d, fv, res->buf, d_err, n_cus, s, &st));

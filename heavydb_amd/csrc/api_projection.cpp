@@ -201,7 +201,10 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
   if (code) return code;
   if (total > q.entry_count && plan->scan_limit == 0) {
     // the row that found the buffer full: the reference's row function answers -pos; here the count the caller needs
-    return total > (int64_t)INT32_MAX ? INT32_MIN : -(int32_t)total;
+    // (counts within 64 of INT32_MAX are reported as that bound: the codes next to INT32_MIN are the step executor's
+    // internal ones — kNotTaken, kRetryNo* — and must not leave a route by accident)
+    constexpr int64_t kMaxReported = (int64_t)INT32_MAX - 64;
+    return -(int32_t)(total > kMaxReported ? kMaxReported : total);
   }
   res->total_matched = total;
   rg.r = nullptr;
@@ -330,21 +333,38 @@ int32_t projection_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t*
       is_null[o] = nullable && v == q.target_null[t];
     }
   };
+  // a WRAPPED buffer (no match count, no live count: the caller's bytes) need not keep its rows at the front: the entries
+  // whose key is not EMPTY_KEY_64, in entry order (ResultSet::isEmptyEntry).  Otherwise the first n entries.
+  const bool wrapped = r->live_rows < 0 && r->total_matched < 0;
+  const int64_t n_scan = wrapped ? q.entry_count : n;
   try {
+    std::vector<int64_t> pick;  // wrapped: the entry of output row i
     if (!q.output_columnar) {
       const int rq = q.row_size / 8;
-      host.resize((size_t)n * rq * 8);
+      host.resize((size_t)n_scan * rq * 8);
       HIP_TRY(hipMemcpy(host.data(), r->buf, host.size(), hipMemcpyDeviceToHost));
       const int64_t* rows = (const int64_t*)host.data();
-      for (int64_t e = 0; e < n; ++e)
-        for (int t = 0; t < nt; ++t) value_out(e, t, rows[e * rq + 1 + q.target_slot[t]]);
+      int64_t o = 0;
+      for (int64_t e = 0; e < n_scan && o < n; ++e) {
+        if (wrapped && rows[e * rq] == kEmptyKey64) continue;
+        for (int t = 0; t < nt; ++t) value_out(o, t, rows[e * rq + 1 + q.target_slot[t]]);
+        ++o;
+      }
     } else {
+      if (wrapped) {
+        host.resize((size_t)n_scan * 8);
+        HIP_TRY(hipMemcpy(host.data(), r->buf, host.size(), hipMemcpyDeviceToHost));
+        const int64_t* keys = (const int64_t*)host.data();
+        for (int64_t e = 0; e < n_scan && (int64_t)pick.size() < n; ++e)
+          if (keys[e] != kEmptyKey64) pick.push_back(e);
+      }
       for (int t = 0; t < nt; ++t) {
         const int w = q.slot_bytes[q.target_slot[t]];
-        host.resize((size_t)n * w);
+        host.resize((size_t)n_scan * w);
         HIP_TRY(hipMemcpy(host.data(), (const char*)r->buf + qmd_slot_col_offset(q, q.target_slot[t]), host.size(),
                           hipMemcpyDeviceToHost));
-        for (int64_t e = 0; e < n; ++e) {
+        for (int64_t i = 0; i < n; ++i) {
+          const int64_t e = wrapped ? pick[(size_t)i] : i;
           int64_t v;
           switch (w) {
             case 1: v = ((const int8_t*)host.data())[e]; break;
@@ -352,7 +372,7 @@ int32_t projection_fetch_rows(const mi355q_result* r, int64_t max_rows, int64_t*
             case 4: v = ((const int32_t*)host.data())[e]; break;
             default: v = ((const int64_t*)host.data())[e];
           }
-          value_out(e, t, v);
+          value_out(i, t, v);
         }
       }
     }

@@ -12,7 +12,9 @@ namespace mq {
 namespace {
 
 struct Sym {               // one value on the symbolic stack
-  enum Kind { COL, LIT, BOOL } kind;
+  enum Kind { COL, LIT, BOOL, VAL } kind;   // VAL: an arithmetic value (only a program atom can consume it)
+  int first = -1;          // the first node of the subtree that computes it (-1: not a contiguous run of this expression's nodes)
+  bool casted = false;     // COL: under a cast (transparent for a range atom; a program atom restates the cast)
   int col = -1;            // COL: physical column
   int type = 0;            // COL / LIT: the value's integer type (after transparent casts)
   bool nullable = false;   // COL
@@ -26,6 +28,44 @@ struct Compiler {
   std::vector<BoolAtom> atoms;
   std::vector<int> atom_col;   // physical column of each atom
   bool ok = true;
+  // program atoms (regprog.h): placeholder id kProgBase + k; the filter columns their operands read
+  static constexpr int kProgBase = 1000;
+  std::vector<RegProg> progs;
+  std::vector<int> prog_cols;  // physical columns read by programs, in first-use order
+
+  // nodes [first, last] of expression k as a program atom (the BOOLEAN of a comparison / IS NULL over an arithmetic value,
+  // two columns, a DOUBLE column, ...); -1: not a shape regprog.h states, or no room
+  int add_prog_atom(const DevExpr& e, int first, int last) {
+    if (first < 0) return -1;
+    std::vector<int> cols = prog_cols;
+    auto slot_of = [&](int col) -> int {
+      for (size_t i = 0; i < cols.size(); ++i)
+        if (cols[i] == col) return (int)i;
+      cols.push_back(col);
+      return (int)cols.size() - 1;   // (provisional: the final slots are assigned when the filter is laid out)
+    };
+    RegProg rp;
+    if (!rp_compile(e, first, last, xs.n_cols, slot_of, &rp)) return -1;
+    if (rp.type != MI355Q_INT8) return -1;
+    // the steps name PHYSICAL columns until the layout pass (operand slots depend on the range atoms' columns too)
+    for (int i = 0; i < rp.n_steps; ++i)
+      if (rp.step[i].kind == RP_LDX_COL || rp.step[i].kind == RP_LDY_COL) rp.step[i].arg = cols[(size_t)rp.step[i].arg];
+    for (size_t i = 0; i < progs.size(); ++i)
+      if (std::memcmp(&progs[i], &rp, sizeof(RegProg)) == 0) return kProgBase + (int)i;
+    if ((int)progs.size() >= kBfMaxProgs) return -1;
+    prog_cols = cols;
+    progs.push_back(rp);
+    return kProgBase + (int)progs.size() - 1;
+  }
+  bool prog_atom_sym(const DevExpr& e, int first, int last, Sym* r) {
+    const int id = add_prog_atom(e, first, last);
+    if (id < 0) return false;
+    r->kind = Sym::BOOL;
+    r->first = -1;
+    r->prog.clear();
+    r->prog.push_back(placeholder(id, progs[(size_t)(id - kProgBase)].nullable != 0));
+    return true;
+  }
 
   int add_atom(int col, const BoolAtom& a) {
     for (size_t i = 0; i < atoms.size(); ++i)
@@ -76,6 +116,13 @@ struct Compiler {
     return n;
   }
 
+  // does a reduced program hold a program atom that can raise?
+  bool holds_raising_atom(const std::vector<DevExprNode>& prog) const {
+    for (const DevExprNode& n : prog)
+      if (n.op == MI355Q_EX_LIT && n.arg < 0 && -1 - n.arg >= kProgBase && progs[(size_t)(-1 - n.arg - kProgBase)].can_raise) return true;
+    return false;
+  }
+
   bool walk(int k, Sym* result) {
     const DevExpr& e = xs.e[k];
     std::vector<Sym> st;
@@ -84,12 +131,15 @@ struct Compiler {
       switch (n.op) {
         case MI355Q_EX_COL: {
           Sym s;
-          if (n.arg >= xs.n_cols) {  // the value of an earlier expression: expanded in place (a filter of comparisons cannot
-                                     // raise, so where it is evaluated does not matter)
-            if (!walk(n.arg - xs.n_cols, &s) || s.kind != Sym::BOOL) return false;
+          if (n.arg >= xs.n_cols) {  // the value of an earlier expression: expanded in place.  Where a filter of comparisons is
+                                     // evaluated does not matter — but an expression that can RAISE is also evaluated on its
+                                     // own, for every row, ahead of the one that reads it: its errors are not this root's
+            if (!walk(n.arg - xs.n_cols, &s) || s.kind != Sym::BOOL || holds_raising_atom(s.prog)) return false;
+            s.first = -1;
           } else {
-            if (!ex_is_int(n.type)) return false;
+            if (!ex_is_int(n.type) && n.type != MI355Q_DOUBLE) return false;
             s.kind = Sym::COL;
+            s.first = i;
             s.col = n.arg;
             s.type = n.type;
             s.nullable = (n.flags & EXF_NULLABLE) != 0;
@@ -98,26 +148,45 @@ struct Compiler {
           break;
         }
         case MI355Q_EX_LIT: {
-          if (n.arg != 0 || !ex_is_int(n.type)) return false;  // (no NULL literal, no floating point)
+          if (n.arg != 0 || !(ex_is_int(n.type) || n.type == MI355Q_DOUBLE)) return false;  // (no NULL literal, no FLOAT)
           Sym s;
           s.kind = Sym::LIT;
+          s.first = i;
           s.type = n.type;
           s.ival = n.ilit;
           st.push_back(std::move(s));
           break;
         }
         case MI355Q_EX_CAST: {
-          if (st.empty() || !ex_is_int(n.type)) return false;
+          if (st.empty()) return false;
           Sym& t = st.back();
-          if (t.kind == Sym::COL) {
-            if (plain_width(n.type) < plain_width(t.type)) return false;  // narrowing: can raise error 7
+          if (t.kind == Sym::COL && ex_is_int(n.type) && ex_is_int(t.type) && plain_width(n.type) >= plain_width(t.type)) {
+            t.type = n.type;   // widening: transparent for a range atom
+            t.casted = true;
+          } else if (t.kind == Sym::LIT && ex_is_int(n.type) && ex_is_int(t.type) && t.ival <= ex_int_max(n.type) && t.ival > ex_int_min(n.type)) {
             t.type = n.type;
-          } else if (t.kind == Sym::LIT) {
-            if (t.ival > ex_int_max(n.type) || t.ival <= ex_int_min(n.type)) return false;
+            t.casted = true;
+          } else if (t.kind == Sym::COL || t.kind == Sym::LIT || t.kind == Sym::VAL) {
+            t.kind = Sym::VAL;  // narrowing, to / from floating point, over an arithmetic value: a step of a program atom
             t.type = n.type;
           } else {
             return false;
           }
+          break;
+        }
+        case MI355Q_EX_ADD: case MI355Q_EX_SUB: case MI355Q_EX_MUL: case MI355Q_EX_DIV: case MI355Q_EX_MOD: {
+          if (st.size() < 2) return false;
+          Sym b = std::move(st.back());
+          st.pop_back();
+          Sym& a = st.back();
+          if (a.kind == Sym::BOOL || b.kind == Sym::BOOL || a.first < 0 || b.first < 0) return false;
+          a.kind = Sym::VAL;
+          a.type = n.type;
+          break;
+        }
+        case MI355Q_EX_UMINUS: {
+          if (st.empty() || st.back().kind == Sym::BOOL || st.back().first < 0) return false;
+          st.back().kind = Sym::VAL;
           break;
         }
         case MI355Q_EX_EQ: case MI355Q_EX_NE: case MI355Q_EX_LT: case MI355Q_EX_LE: case MI355Q_EX_GT: case MI355Q_EX_GE: {
@@ -126,9 +195,10 @@ struct Compiler {
           st.pop_back();
           Sym a = std::move(st.back());
           st.pop_back();
-          int op;
-          const Sym* c;
-          int64_t lit;
+          if (a.kind == Sym::BOOL || b.kind == Sym::BOOL) return false;
+          int op = 0;
+          const Sym* c = nullptr;
+          int64_t lit = 0;
           if (a.kind == Sym::COL && b.kind == Sym::LIT) {
             c = &a;
             lit = b.ival;
@@ -139,14 +209,15 @@ struct Compiler {
             lit = a.ival;
             op = n.op == MI355Q_EX_EQ ? MI355Q_EQ : n.op == MI355Q_EX_NE ? MI355Q_NE : n.op == MI355Q_EX_LT ? MI355Q_GT
                  : n.op == MI355Q_EX_LE ? MI355Q_GE : n.op == MI355Q_EX_GT ? MI355Q_LT : MI355Q_LE;
-          } else {
+          }
+          Sym r;
+          int atom;
+          if (c && ex_is_int(c->type) && cmp_atom(*c, op, n.arg, lit, &atom)) {
+            r.kind = Sym::BOOL;
+            r.prog.push_back(placeholder(atom, atoms[atom].nullable != 0));
+          } else if (!prog_atom_sym(e, a.first, i, &r)) {  // two columns, an arithmetic operand, a DOUBLE column: a program atom
             return false;
           }
-          int atom;
-          if (!cmp_atom(*c, op, n.arg, lit, &atom)) return false;
-          Sym r;
-          r.kind = Sym::BOOL;
-          r.prog.push_back(placeholder(atom, atoms[atom].nullable != 0));
           st.push_back(std::move(r));
           break;
         }
@@ -156,14 +227,14 @@ struct Compiler {
           st.pop_back();
           Sym r;
           r.kind = Sym::BOOL;
-          if (a.kind == Sym::COL) {
-            int atom;
-            if (!cmp_atom(a, MI355Q_IS_NULL, a.type == MI355Q_INT64 ? MI355Q_INT64 : MI355Q_INT32, 0, &atom)) return false;
+          int atom;
+          if (a.kind == Sym::COL && ex_is_int(a.type) &&
+              cmp_atom(a, MI355Q_IS_NULL, a.type == MI355Q_INT64 ? MI355Q_INT64 : MI355Q_INT32, 0, &atom)) {
             r.prog.push_back(placeholder(atom, false));
           } else if (a.kind == Sym::BOOL) {
             r.prog = std::move(a.prog);
             r.prog.push_back(n);
-          } else {
+          } else if (!prog_atom_sym(e, a.first, i, &r)) {  // `(a + b) IS NULL`, a DOUBLE column
             return false;
           }
           st.push_back(std::move(r));
@@ -186,7 +257,7 @@ struct Compiler {
           break;
         }
         default:
-          return false;  // arithmetic, CASE, unary minus: the projection pass
+          return false;  // CASE: the projection pass
       }
     }
     if (st.size() != 1) return false;
@@ -194,6 +265,37 @@ struct Compiler {
     return true;
   }
 };
+
+// A reduced program (placeholders, NOT, AND / OR in both forms, IS NULL) for one state vector: the BOOLEAN it leaves and
+// — *raiser — 0, or 1 + the PROGRAM atom whose error is the value's.  The loop of expr.h eval_expr over the same ex_*
+// functions; the error a value carries is here the atom's tag instead of its code (ex_logic / ex_is_null only ask
+// whether there is one and keep the first).
+int64_t eval_reduced(const std::vector<DevExprNode>& prog, const int* state_of_placeholder /* by -1 - arg */, int n_range,
+                     int32_t* raiser) {
+  int64_t st[MI355Q_MAX_EXPR_NODES + 1] = {};
+  int32_t es[MI355Q_MAX_EXPR_NODES + 1] = {};
+  int sp = 0;
+  for (const DevExprNode& n : prog) {
+    switch (n.op) {
+      case MI355Q_EX_LIT: {
+        const int id = -1 - n.arg;
+        const int pos = id >= Compiler::kProgBase ? n_range + (id - Compiler::kProgBase) : id;
+        const int s = state_of_placeholder[pos];
+        st[sp] = s == 1 ? 1 : s == 2 ? plain_int_null(MI355Q_INT8) : 0;
+        es[sp] = s == 3 ? 1 + (id - Compiler::kProgBase) : 0;
+        ++sp;
+        break;
+      }
+      case MI355Q_EX_NOT: st[sp - 1] = ex_not(n, st[sp - 1]); break;
+      case MI355Q_EX_IS_NULL: st[sp - 1] = ex_is_null(n, st[sp - 1], es[sp - 1]); break;
+      default:  // MI355Q_EX_AND / _OR
+        --sp;
+        st[sp - 1] = ex_logic(n, st[sp - 1], st[sp], es[sp - 1], es[sp]);
+    }
+  }
+  *raiser = es[0];
+  return st[0];
+}
 
 }  // namespace
 
@@ -214,9 +316,13 @@ bool compile_bool_filter(const mi355q_plan& plan, BoolFilterHost* out, mi355q_pl
   }
   if (plan.join_outer_col >= np) return false;
 
-  Compiler c{plan, xs, {}, {}, true};
+  Compiler c{plan, xs, {}, {}, true, {}, {}};
   std::vector<int> plain_atoms;                    // conjuncts that are atoms themselves: must be TRUE
-  std::vector<std::vector<DevExprNode>> roots;     // conjuncts that are BOOLEAN programs: must evaluate to 1
+  struct Root {
+    int expr;                                      // (-1: a NOT NULL test stated as a program)
+    std::vector<DevExprNode> prog;
+  };
+  std::vector<Root> roots;                         // conjuncts that are BOOLEAN programs: must evaluate to 1
   for (int i = 0; i < plan.n_quals; ++i) {
     const mi355q_qual& q = plan.quals[i];
     if (MI355Q_QUAL_OR_GROUP(q.op) != 0 || q.op < 0 || (q.op >> 16) != 0) return false;
@@ -237,7 +343,7 @@ bool compile_bool_filter(const mi355q_plan& plan, BoolFilterHost* out, mi355q_pl
         nn.op = MI355Q_EX_NOT;
         nn.type = MI355Q_INT8;
         prog.push_back(nn);
-        roots.push_back(std::move(prog));
+        roots.push_back(Root{-1, std::move(prog)});
       } else {
         if (!c.cmp_atom(s, op, code, q.ival, &atom)) return false;
         plain_atoms.push_back(atom);
@@ -249,26 +355,41 @@ bool compile_bool_filter(const mi355q_plan& plan, BoolFilterHost* out, mi355q_pl
       Sym r;
       if (!c.walk(q.col - np, &r) || r.kind != Sym::BOOL) return false;
       if ((int)r.prog.size() > MI355Q_MAX_EXPR_NODES) return false;
-      roots.push_back(std::move(r.prog));
+      roots.push_back(Root{q.col - np, std::move(r.prog)});
     }
   }
-  const int na = (int)c.atoms.size();
-  if (na < 1 || na > kBfMaxAtoms) return false;
-  // ---- atoms grouped by column (the kernels walk their filter columns in a fixed order)
+  // an expression that can raise is evaluated for every row whether a qual names it or not (the row function evaluates the
+  // filter's expressions in order before any qual): every expression must be a root here, each once
+  {
+    bool any_raise = false;
+    for (const RegProg& rp : c.progs) any_raise = any_raise || rp.can_raise;
+    if (any_raise) {
+      uint32_t seen = 0;
+      for (const Root& r : roots)
+        if (r.expr >= 0) {
+          if (seen & (1u << r.expr)) return false;
+          seen |= 1u << r.expr;
+        }
+      if (seen != (1u << plan.n_exprs) - 1u) return false;
+    }
+  }
+  const int na = (int)c.atoms.size(), npg = (int)c.progs.size();
+  if (na + npg < 1 || na + npg > kBfMaxAtoms) return false;
+  // ---- the filter's columns: those of the range atoms (grouped: the kernels walk them in a fixed order), then the ones
+  // only programs read
   BoolFilterHost& o = *out;
   std::memset(&o, 0, sizeof(o));
-  std::vector<int> order;   // new position -> old atom
-  for (int i = 0; i < na; ++i) {
-    int slot = -1;
+  auto col_slot = [&](int col, bool add) -> int {
     for (int k = 0; k < o.bf.n_cols; ++k)
-      if (o.bf.col[k] == c.atom_col[i]) slot = k;
-    if (slot < 0) {
-      if (o.bf.n_cols >= kBfMaxCols) return false;
-      o.bf.col[o.bf.n_cols] = c.atom_col[i];
-      o.bf.col_type[o.bf.n_cols] = col_type_code(plan.cols[c.atom_col[i]]);
-      ++o.bf.n_cols;
-    }
-  }
+      if (o.bf.col[k] == col) return k;
+    if (!add || o.bf.n_cols >= kBfMaxCols) return -1;
+    o.bf.col[o.bf.n_cols] = col;
+    o.bf.col_type[o.bf.n_cols] = col_type_code(plan.cols[col]);
+    return o.bf.n_cols++;
+  };
+  for (int i = 0; i < na; ++i)
+    if (col_slot(c.atom_col[i], true) < 0) return false;
+  std::vector<int> order;   // new position -> old atom
   std::vector<int> new_of_old(na, -1);
   for (int k = 0; k < o.bf.n_cols; ++k)
     for (int i = 0; i < na; ++i)
@@ -279,51 +400,68 @@ bool compile_bool_filter(const mi355q_plan& plan, BoolFilterHost* out, mi355q_pl
         ++o.bf.atoms_of_col[k];
       }
   o.bf.n_atoms = na;
-  // ---- the truth table: the filter's own programs, run by the evaluator of the interpreter pass, once per state vector
+  o.bf.n_progs = npg;
+  for (int k = 0; k < npg; ++k) {
+    RegProg rp = c.progs[(size_t)k];
+    for (int i = 0; i < rp.n_steps; ++i)
+      if (rp.step[i].kind == RP_LDX_COL || rp.step[i].kind == RP_LDY_COL) {
+        const int slot = col_slot(rp.step[i].arg, true);
+        if (slot < 0) return false;
+        rp.step[i].arg = slot;
+      }
+    o.bf.prog[k] = rp;
+    o.bf.any_raise |= rp.can_raise;
+  }
+  // ---- the truth table: the filter's own programs, run by the evaluator's functions, once per state vector
+  int radix[kBfMaxAtoms];
   uint32_t n_states = 1;
-  for (int i = 0; i < na; ++i) n_states *= 3u;
+  for (int i = 0; i < na + npg; ++i) {
+    radix[i] = i >= na && o.bf.prog[i - na].can_raise ? 4 : 3;
+    n_states *= (uint32_t)radix[i];
+    if (n_states > 6561u) return false;
+  }
+  if (o.bf.any_raise && n_states > (uint32_t)kBfErrStates) return false;
   o.table_words = (int)((n_states + 31u) >> 5);
-  std::vector<DevExpr> progs(roots.size());
-  for (size_t r = 0; r < roots.size(); ++r) {
-    std::memset(&progs[r], 0, sizeof(DevExpr));
-    progs[r].n_nodes = (int)roots[r].size();
-    progs[r].type = MI355Q_INT8;
-    for (size_t i = 0; i < roots[r].size(); ++i) progs[r].nodes[i] = roots[r][i];
-    // (depth check: the evaluator's stack)
+  for (const Root& r : roots) {  // (depth check: the evaluator's stack)
     int sp = 0, deepest = 0;
-    for (const DevExprNode& n : roots[r]) {
+    for (const DevExprNode& n : r.prog) {
       if (n.op == MI355Q_EX_LIT) ++sp;
       else if (n.op == MI355Q_EX_AND || n.op == MI355Q_EX_OR) --sp;
       deepest = sp > deepest ? sp : deepest;
     }
     if (deepest > MI355Q_MAX_EXPR_STACK) return false;
   }
-  int state[kBfMaxAtoms];
+  // the order errors surface in: the expressions' own (a plain IS NOT NULL test cannot raise)
+  std::vector<const Root*> by_expr;
+  for (const Root& r : roots) by_expr.push_back(&r);
+  for (size_t i = 1; i < by_expr.size(); ++i)
+    for (size_t j = i; j > 0 && by_expr[j]->expr < by_expr[j - 1]->expr; --j) std::swap(by_expr[j], by_expr[j - 1]);
+  int state[kBfMaxAtoms];       // by position in the state index (range atoms regrouped, then programs)
+  int state_old[kBfMaxAtoms];   // as the placeholders name them: range atom ids, then programs
   for (uint32_t idx = 0; idx < n_states; ++idx) {
     uint32_t x = idx;
     bool possible = true;
-    for (int i = 0; i < na; ++i) {
-      state[i] = (int)(x % 3u);
-      x /= 3u;
-      if (state[i] == 2 && !o.bf.atom[i].nullable) possible = false;
+    for (int i = 0; i < na + npg; ++i) {
+      state[i] = (int)(x % (uint32_t)radix[i]);
+      x /= (uint32_t)radix[i];
+      const bool nullable = i < na ? o.bf.atom[i].nullable != 0 : o.bf.prog[i - na].nullable != 0;
+      if (state[i] == 2 && !nullable) possible = false;
     }
     if (!possible) continue;
+    for (int i = 0; i < na; ++i) state_old[i] = state[new_of_old[i]];
+    for (int i = 0; i < npg; ++i) state_old[na + i] = state[na + i];
     bool pass = true;
-    for (int a : plain_atoms) pass = pass && state[new_of_old[a]] == 1;
-    for (size_t r = 0; r < progs.size() && pass; ++r) {
-      DevExpr e = progs[r];
-      for (int i = 0; i < e.n_nodes; ++i) {
-        DevExprNode& n = e.nodes[i];
-        if (n.op != MI355Q_EX_LIT || n.arg >= 0) continue;
-        const int s = state[new_of_old[-1 - n.arg]];
-        n.arg = s == 2 ? 1 : 0;                            // (1: "the NULL literal, pattern in ilit")
-        n.ilit = s == 2 ? plain_int_null(MI355Q_INT8) : s;
-        n.flit = 0.0;
-      }
-      int32_t err = 0;
-      const int64_t v = eval_expr(e, nullptr, 0, &err);
-      if (err) return false;  // (cannot happen: no node of the reduced program can raise)
-      pass = v == 1;
+    int32_t raiser = 0;
+    for (int a : plain_atoms) pass = pass && state_old[a] == 1;
+    for (const Root* r : by_expr) {
+      int32_t tag = 0;
+      const int64_t v = eval_reduced(r->prog, state_old, na, &tag);
+      if (tag && !raiser) raiser = tag;
+      pass = pass && v == 1;
+    }
+    if (raiser) {
+      o.bf.etable[idx >> 3] |= (uint32_t)raiser << ((idx & 7u) * 4u);
+      continue;  // (the row ends the step: it passes nothing)
     }
     if (pass) o.bf.table[idx >> 5] |= 1u << (idx & 31u);
   }

@@ -13,29 +13,48 @@
 //     program (expr.h eval_expr — the evaluator the interpreter pass uses, so the three-valued and short-circuit rules
 //     are the same code) once per state vector with the atoms replaced by literals.
 // A kernel evaluates the atoms on the column values it already holds in registers and looks one bit up in LDS.
-// Filters with arithmetic, comparisons of two columns, CASE, narrowing casts or floating-point leaves are not
+//
+// Round 6 — PROGRAM atoms.  A leaf that is not `column <op> literal` — `a / b > 3`, `x + y > 100`, `a < b`, `f * 2.0 < g`,
+// `CAST(x AS BIGINT) * 1000 >= k`, `d < 0.5` on a DOUBLE column — is an atom too when its operand subtree never holds more
+// than two live values: it is compiled into a two-register program of typed steps (regprog.h: one instantiation of the
+// expr.h function per operation and type, a wave-uniform switch per step and FOUR rows) that leaves the comparison's
+// BOOLEAN.  Such an atom can RAISE (error 7 / error 1), so it has a fourth state, ERROR; whether the error of an atom in
+// that state is the row's outcome depends on the states of the others (`b <> 0 AND a / b > 3` in the short-circuit form
+// never evaluates the division where b = 0 — the reference's deferred quals, LogicalIR.cpp:158-297), which the plan-time
+// run over all state vectors records next to the truth table: a 4-bit "which atom raises" table, filled by the same
+// ex_logic / ex_not / ex_is_null (expr.h) that propagate errors in the interpreter.
+// Filters with CASE, leaves of more than two live values, INT8 / INT16 / FLOAT arithmetic or encoded columns are not
 // taken (the step then runs through the projection pass, kernels_generic.hip k_project).
 #pragma once
 
+#include <cstddef>
+
 #include "dev_common.h"
 #include "fast_common.h"
+#include "regprog.h"
 
 namespace mq {
 
 constexpr int kBfMaxAtoms = 8;
 constexpr int kBfMaxCols = 4;
 constexpr int kBfTableWords = 206;  // ceil(3^8 / 32)
+constexpr int kBfMaxProgs = 4;      // program atoms (they count towards kBfMaxAtoms)
+constexpr int kBfErrStates = 2048;  // state vectors of a filter whose atoms can raise (a nibble each)
 
 struct BoolAtom {
   int64_t lo, hi, null_val;
   int32_t negate, nullable;  // nullable: the column can hold null_val, and the atom is then NULL (IS NULL atoms: 0)
 };
 struct BoolFilter {
-  int32_t n_cols, n_atoms;
-  int32_t col[kBfMaxCols], col_type[kBfMaxCols];  // physical column; MI355Q_INT32 / MI355Q_INT64
-  int32_t atoms_of_col[kBfMaxCols];               // atoms are stored grouped by column, in column order
+  int32_t n_cols, n_atoms;                         // n_atoms: the RANGE atoms (the program atoms follow them in the state index)
+  int32_t col[kBfMaxCols], col_type[kBfMaxCols];  // physical column; MI355Q_INT32 / MI355Q_INT64 / MI355Q_DOUBLE (program operands only)
+  int32_t atoms_of_col[kBfMaxCols];               // range atoms are stored grouped by column, in column order
   BoolAtom atom[kBfMaxAtoms];
-  uint32_t table[kBfTableWords];                   // 3^n_atoms bits
+  uint32_t table[kBfTableWords];                   // one bit per state vector (mixed radix: 3 per range atom, then 3 or 4 per program)
+  // ---- program atoms (round 6); everything from here on is only copied into LDS when n_progs != 0
+  int32_t n_progs, any_raise;
+  RegProg prog[kBfMaxProgs];                       // operand slot c of a program = filter column c
+  uint32_t etable[kBfErrStates / 8];               // any_raise: per state vector 0, or 1 + the program atom whose error is the row's
 };
 // A kernel receives a POINTER to the filter in device memory and copies it into LDS (a by-value kernel argument indexed
 // with a run-time atom number would be lowered to a scratch copy of the whole argument block).
@@ -68,7 +87,69 @@ MQ_D bool bf_row_passes(const BoolFilter& bf, const int64_t (&vals)[NF]) {
 MQ_D void bf_load(const BoolFilter* src, BoolFilter* s_dst, int tid, int block) {
   const uint32_t* a = (const uint32_t*)src;
   uint32_t* b = (uint32_t*)s_dst;
-  for (uint32_t w = tid; w < sizeof(BoolFilter) / 4; w += block) b[w] = a[w];
+  const uint32_t head = (uint32_t)(offsetof(BoolFilter, n_progs) / 4) + 2u;
+  const uint32_t words = src->n_progs ? (uint32_t)(sizeof(BoolFilter) / 4) : head;
+  for (uint32_t w = tid; w < words; w += block) b[w] = a[w];
+}
+// The filter for the FOUR rows of a quad: vals[j][c] = row j's value of filter column c (integers sign-extended, DOUBLE
+// as its bits); `valid` = the rows that exist (bit j).  Returns the rows that pass (bit j); *err receives the error a
+// VALID row raises (program atoms only), if it holds none yet.
+template <int NF>
+MQ_D uint32_t bf_quad_pass(const BoolFilter& bf, const int64_t (&vals)[4][NF], uint32_t valid, int32_t* err) {
+  uint32_t idx[4] = {0, 0, 0, 0}, mul = 1;
+  int ai = 0;
+#pragma unroll
+  for (int c = 0; c < NF; ++c) {
+    if (c >= bf.n_cols) break;
+    for (int k = 0; k < bf.atoms_of_col[c]; ++k) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) idx[j] += bf_atom_state(bf.atom[ai], vals[j][c]) * mul;
+      mul *= 3u;
+      ++ai;
+    }
+  }
+  uint32_t epack[4] = {0, 0, 0, 0};  // two bits per program atom: the error it raised (ex_err_enc)
+  const int np = bf.n_progs;
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int k = 0; k < np; ++k) {
+    int64_t out[4];
+    int32_t e4[4];
+    rp_eval<4, NF>(bf.prog[k], vals, out, e4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t st = e4[j] ? 3u : out[j] == 1 ? 1u : out[j] == 0 ? 0u : 2u;  // (anything else is the INT8 NULL)
+      idx[j] += st * mul;
+      epack[j] |= ex_err_enc(e4[j]) << (2 * k);
+    }
+    mul *= bf.prog[k].can_raise ? 4u : 3u;
+  }
+  uint32_t pass = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t bit = (bf.table[idx[j] >> 5] >> (idx[j] & 31u)) & 1u;
+    if (epack[j] && ((valid >> j) & 1u)) {  // rare: an atom of this row is in its ERROR state — is it the row's outcome?
+      const uint32_t nib = (bf.etable[idx[j] >> 3] >> ((idx[j] & 7u) * 4u)) & 15u;
+      if (nib) {
+        if (!*err) *err = ex_err_dec((epack[j] >> (2u * (nib - 1u))) & 3u);
+        bit = 0;
+      }
+    }
+    pass |= bit << j;
+  }
+  return pass & valid;
+}
+// one row on its own (fragment tails): through the quad form when the filter has program atoms
+template <int NF>
+MQ_D bool bf_one_row_passes(const BoolFilter& bf, const int64_t (&vals)[NF], int32_t* err) {
+  if (bf.n_progs == 0) return bf_row_passes<NF>(bf, vals);
+  int64_t qv[4][NF];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int c = 0; c < NF; ++c) qv[j][c] = vals[c];
+  return bf_quad_pass<NF>(bf, qv, 1u, err) & 1u;
 }
 #endif
 

@@ -269,6 +269,16 @@ inline bool make_range_filter(const DevQual& q, RangeFilter* f) {
       break;
     default: return false;
   }
+  // bounds inside the column's type (members that compare an INT32 column in 32 bits truncate them): a literal outside
+  // the type — `i32 = 5000000000`, `i32 <= 5000000000` — leaves the empty range or the type's own bound, never a wrapped
+  // one (a negated empty range passes every non-NULL row, as `i32 <> 5000000000` does)
+  if (f->lo > f->hi || f->lo > tmax || f->hi < tmin) {
+    f->lo = 1;
+    f->hi = 0;
+  } else {
+    if (f->lo < tmin) f->lo = tmin;
+    if (f->hi > tmax) f->hi = tmax;
+  }
   return true;
 }
 

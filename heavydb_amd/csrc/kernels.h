@@ -215,7 +215,7 @@ struct FragView {
 
 // non-grouped aggregates over up to 8 plain int32 / int64 / double columns with up to 4 integer range quals
 bool scan_agg_eligible(const DevPlan& p, const FragView& fv);
-hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus, hipStream_t s,
+hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int n_cus, hipStream_t s,
                            LaunchStats* st);
 // GROUP BY with few groups, whole table replicated in every workgroup's LDS (kernels_lds.hip): perfect-hash layouts
 // of 1-3 integer key columns with <= 65536 entries, or a baseline layout over one 8-byte / int32 key with at most a

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
   char* const my_rep = smem + (size_t)((uint32_t)t & (K - 1)) * a.copy_bytes;
   volatile uint32_t* const s_full = (volatile uint32_t*)(smem + ((size_t)a.copy_bytes << a.copies_lg));  // behind the replicas
   bool bad = false, full = false;
+  int32_t bf_err = 0;  // the error a program atom of the compiled filter raised for one of this lane's rows
 
   // one row whose quals passed: kv = the key columns' values (DOUBLE keys as their bit pattern), vv = the value columns'
   auto one_row = [&](const int64_t (&kv)[NK], const int64_t (&vv)[NV]) {
@@ -300,10 +301,22 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
         if (u >= n_quads) break;
+        uint32_t qmask = 15u;
+        const bool prog_atoms = NF > 0 && a.bf_on && s_bf.n_progs != 0;  // (uniform) program atoms: the quad's four rows together
+        if (prog_atoms) {
+          int64_t qv[4][NF > 0 ? NF : 1];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < NF; ++k) qv[i][k] = k < a.n_flt ? rawq_int(fr[k][u], a.flt_type[k] == MI355Q_INT32 ? MI355Q_INT32 : MI355Q_INT64, i) : 0;
+          qmask = bf_quad_pass<(NF > 0 ? NF : 1)>(s_bf, qv, 15u, &bf_err);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           bool pass = true;
-          if (NF > 0 && a.bf_on) {  // atoms on the filter columns' values + one bit of the truth table
+          if (prog_atoms) {
+            pass = (qmask >> i) & 1u;
+          } else if (NF > 0 && a.bf_on) {  // atoms on the filter columns' values + one bit of the truth table
             int64_t fval[NF > 0 ? NF : 1];
 #pragma unroll
             for (int k = 0; k < NF; ++k) fval[k] = k < a.n_flt ? rawq_int(fr[k][u], a.flt_type[k], i) : 0;
@@ -342,7 +355,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
 #pragma unroll
         for (int k = 0; k < NF; ++k)
           fval[k] = k >= a.n_flt ? 0 : a.flt_type[k] == MI355Q_INT32 ? (int64_t)load_one<int32_t>(fb[k], tail) : load_one<int64_t>(fb[k], tail);
-        pass = bf_row_passes<(NF > 0 ? NF : 1)>(s_bf, fval);
+        pass = bf_one_row_passes<(NF > 0 ? NF : 1)>(s_bf, fval, &bf_err);
       } else {
 #pragma unroll
         for (int k = 0; k < NF; ++k) {
@@ -364,6 +377,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
     }
   }
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+  if (bf_err) atomicCAS(d_err, 0, bf_err);  // a program atom of the compiled filter raised (error 7 / error 1)
   // a lost attempt (this workgroup's, or another's) is neither folded nor flushed: the caller takes another member and
   // initialises the table again
   if (t == 0 && a.baseline && *(volatile int32_t*)(d_err + 1)) *s_full = 1u;
@@ -564,6 +578,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   int32_t* const my_min = (int32_t*)(my_rep + a.t_off_min);
   int32_t* const my_max = (int32_t*)(my_rep + a.t_off_max);
   bool bad = false, full = false;
+  int32_t bf_err = 0;  // the error a program atom of the compiled filter raised for one of this lane's rows
   // uniform per-column constants (static indices after unrolling: scalar registers, never a scratch copy of `a`)
   uint32_t kmin[NK], kcard[NK], kmul[NK], knull[NK];
   bool ktr[NK], vnull[NVA];
@@ -605,7 +620,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
       int64_t vals[TF];
 #pragma unroll
       for (int c = 0; c < TF; ++c) vals[c] = (int64_t)fv[c];
-      return bf_row_passes<TF>(s_bf, vals);
+      return bf_one_row_passes<TF>(s_bf, vals, &bf_err);
     }
     bool pass = true;
 #pragma unroll
@@ -733,6 +748,21 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
         if (u >= n_quads) break;
+        // a compiled filter with PROGRAM atoms (`a / b > 3`, `x + y > 100`, `a < b`): the quad's four rows together, one
+        // wave-uniform switch per program step (regprog.h)
+        uint32_t qmask = 15u;
+        bool prog_atoms = false;
+        if constexpr (FM != 0) {
+          prog_atoms = a.bf_on && s_bf.n_progs != 0;
+          if (prog_atoms) {
+            int64_t qv[4][TF];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int c = 0; c < TF; ++c) qv[i][c] = c < nfl ? (int64_t)v4_get(tl.f[c][u], i) : 0;
+            qmask = bf_quad_pass<TF>(s_bf, qv, 15u, &bf_err);
+          }
+        }
         if constexpr (kBase) {
           // the four rows of a quad together: keys and hashes first, then the four first-probe reads of the key array
           // in one go (one LDS round trip instead of four dependent ones — a wave's step is a chain of latencies, and
@@ -750,7 +780,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
               int32_t fv[TF];
 #pragma unroll
               for (int c = 0; c < TF; ++c) fv[c] = c < nfl ? v4_get(tl.f[c][u], i) : 0;
-              acc[i] = acc[i] && row_passes(fv);
+              acc[i] = acc[i] && (prog_atoms ? ((qmask >> i) & 1u) != 0 : row_passes(fv));
             }
           }
 #pragma unroll
@@ -776,7 +806,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
               int32_t fv[TF];
 #pragma unroll
               for (int c = 0; c < TF; ++c) fv[c] = c < nfl ? v4_get(tl.f[c][u], i) : 0;
-              if (!row_passes(fv)) continue;
+              if (!(prog_atoms ? ((qmask >> i) & 1u) != 0 : row_passes(fv))) continue;
             }
 #pragma unroll
             for (int g = 0; g < NK; ++g) klo[g] = v4_get(tl.k[g][u][0], i);
@@ -827,6 +857,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
     }
   }
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+  if (bf_err) atomicCAS(d_err, 0, bf_err);  // a program atom of the compiled filter raised (error 7 / error 1)
   if (t == 0 && kBase && *(volatile int32_t*)(d_err + 1)) *s_full = 1u;
   __syncthreads();
   if (*s_full) return;  // a lost attempt is neither folded nor flushed
@@ -1042,6 +1073,10 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out
     if (stripes < 1) stripes = 1;
     if (fv.total_rows / stripes >= 0xfff00000ll) return false;
   }
+  // the run-time-role member's widest instantiation filters on NF = 4 columns (launch_lds_groupby); a step with more
+  // range filters than that (e.g. x <> 1 AND … AND x <> 5: negated quals do not merge) goes to another family instead of
+  // running with the quals past the fourth dropped
+  if (!a.typed && a.n_flt > kLdsGenericFlt) return false;
   return a.n_flt + a.n_keys + a.n_vals <= 8;
 }
 
@@ -1140,7 +1175,7 @@ hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out
   else if (a.n_flt <= 1 && a.n_keys == 1 && a.n_vals <= 1) MQ_LDS_LAUNCH(1, 1, 1, 2);       // PHS / BH shapes
   else if (a.n_flt <= 1 && a.n_vals <= 1) MQ_LDS_LAUNCH(1, 3, 1, 1);                     // PHM shapes
   else if (a.n_flt <= 1 && a.n_keys == 1) MQ_LDS_LAUNCH(1, 1, 3, 1);                     // MultiStep, one key
-  else MQ_LDS_LAUNCH(4, 3, 3, 1);
+  else MQ_LDS_LAUNCH(kLdsGenericFlt, 3, 3, 1);
 #undef MQ_LDS_LAUNCH
   rec(st->k_stop, s);
   return hipGetLastError();

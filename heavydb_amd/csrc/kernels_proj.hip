@@ -765,12 +765,24 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs
 #pragma unroll
           for (int i = 0; i < kXJ; ++i) p4[i] = r + i < n ? r + i : n - 1;
           eval_exprs_lds(*a.xs, L, (1u << a.xs->n) - 1u, fc, p4, e4);
+          // only a row that is EMITTED counts: one whose rank lies past the scan limit / the buffer's end is never
+          // written, and the reference's loop stops at max_matched before it would evaluate it
+          uint32_t kk = first;
 #pragma unroll
-          for (int i = 0; i < kXJ; ++i)
-            if (((mm >> i) & 1u) && e4[i] && !err) err = e4[i];  // (only a row that is emitted counts)
+          for (int i = 0; i < kXJ; ++i) {
+            if (!((mm >> i) & 1u)) continue;
+            if (e4[i] && !err && (int64_t)kk < n_write) err = e4[i];
+            ++kk;
+          }
         } else if (a.xs) {
-          for (int i = 0; i < 4; ++i)
-            if ((mm >> i) & 1u) eval_exprs(*a.xs, (1u << a.xs->n) - 1u, fc, r + i, xv[i], &err);
+          uint32_t kk = first;
+          for (int i = 0; i < 4; ++i) {
+            if (!((mm >> i) & 1u)) continue;
+            int32_t e1 = 0;
+            eval_exprs(*a.xs, (1u << a.xs->n) - 1u, fc, r + i, xv[i], &e1);
+            if (e1 && !err && (int64_t)kk < n_write) err = e1;
+            ++kk;
+          }
         }
         int64_t inner_pos[4] = {-1, -1, -1, -1};
         if (HJ) {

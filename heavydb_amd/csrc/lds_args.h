@@ -13,6 +13,7 @@ using namespace fast;
 
 constexpr int kLdsVals = 3;              // value columns
 constexpr int kLdsKeys = 3;              // key columns (perfect hash)
+constexpr int kLdsGenericFlt = 4;        // filter columns of the run-time-role member's widest instantiation (NF)
 constexpr uint32_t kLdsHashSmall = 256;  // slots of one baseline replica, first attempt (many replicas)
 constexpr uint32_t kLdsHashMax = 4096;   // ... at most, second attempt
 constexpr uint32_t kLdsMaxWindows = 8;   // windows of a table that does not fit one LDS (the columns are read once per window)

@@ -406,7 +406,7 @@ typedef struct mi355q_plan {
    * normally when more rows match (the first scan_limit of them, in (fragment, row) order, are kept; the reference stops
    * its loop at max_matched, QueryTemplateGenerator.cpp:751-780).  Without one, a row that finds the buffer full ends
    * the step with a NEGATIVE code — get_scan_output_slot returns NULL and the row function answers -pos
-   * (GroupByAndAggregate.cpp:1151-1156) — here -(number of matching rows), clamped to INT32_MIN: the caller re-runs with
+   * (GroupByAndAggregate.cpp:1151-1156) — here -(number of matching rows), clamped to -(INT32_MAX - 64): the caller re-runs with
    * max_groups_buffer_entry_guess = that count (the reference sizes the buffer by a COUNT(*) pre-flight,
    * RelAlgExecutor::getFilteredCountAll, or doubles the guess). */
   int64_t scan_limit;

@@ -132,6 +132,13 @@ def build_cases(scale: int = 1) -> List[ProjCase]:
     # 8. a disjunction among the quals (OR group)
     add("or_group", descs, [f, a, b, c], [0, 3], [Qual(0, capi.LT, 100, 1), Qual(0, capi.GT, 900, 1), Qual(3, capi.GE, 1000)], [n],
         max_groups_buffer_entry_guess=n)
+    # 8b. literals outside the column's type: `i32 = 5000000000` matches nothing, `<>` every row, `<=` every row —
+    # the members that compare an INT32 column in 32 bits must not wrap the bound
+    fw = _col(rng, capi.INT32, n, 700_000_000, 2_000_000_000)
+    for tag, op, lit in (("eq", capi.EQ, 5_000_000_000), ("ne", capi.NE, 5_000_000_000), ("le", capi.LE, 5_000_000_000),
+                         ("ge_neg", capi.GE, -5_000_000_000), ("lt_neg", capi.LT, -5_000_000_000)):
+        add(f"literal_beyond_int32_{tag}", descs, [fw, a, b, c], [0, 1], [Qual(0, op, lit)], [n // 2, n - n // 2],
+            max_groups_buffer_entry_guess=n)
     # 9. many fragments, some smaller than a tile, unaligned chunk starts (the scalar path of the loads)
     sizes = [1, 3, 16384, 16385, 5, 70, 1000] + [n - 33848]
     add("many_small_fragments", descs, [f, a, b, c], [1, 2, 3], [Qual(0, capi.LT, 700)], sizes, max_groups_buffer_entry_guess=n)
@@ -167,6 +174,11 @@ def build_cases(scale: int = 1) -> List[ProjCase]:
     # a division by zero in a row that passes: error 1; in a row the filter drops: none
     add_x("div_by_zero_counts", xd, [x, y, z], [C_(0).div(C_(1), I32)], [3], [Qual(1, capi.GE, 0)], [m], max_groups_buffer_entry_guess=m,
           expect_error=capi.ERR_DIV_BY_ZERO)
+    # ... in a row that passes but lies past the LIMIT: never written, never raised (the reference's loop stops at max_matched)
+    y_late = y.copy()
+    y_late[:m // 2] = np.where(y_late[:m // 2] == 0, 1, y_late[:m // 2])
+    assert (y_late[m // 2:] == 0).any()
+    add_x("div_by_zero_past_the_limit", xd, [x, y_late, z], [C_(0).div(C_(1), I32)], [3], [Qual(1, capi.GE, 0)], [m], scan_limit=100)
     add_x("div_by_zero_filtered_out", xd, [x, y, z], [C_(0).div(C_(1), I32)], [3], [Qual(1, capi.GT, 0)], [m], max_groups_buffer_entry_guess=m)
     return cases
 

@@ -751,19 +751,115 @@ def test_compiled_bool_filters_in_the_lds_groupby(sim, oracle, idx):
     assert "filter compiled" in route and "k_project" not in route and "k_groupby_lds" in route, route
 
 
-def test_filters_with_arithmetic_still_take_the_projection_pass(sim, oracle):
-    """`b <> 0 AND a / b > 3` (the guarded division) can raise: not a truth table"""
-    from heavydb_amd.executor import Executor, Expr, Qual
-    base = _bool_filter_cases(oracle)[0]
-    I32 = capi.INT32
+# ---- round 6: PROGRAM atoms (regprog.h) — leaves with arithmetic, two columns, DOUBLE operands compiled into two-register
+# programs of typed steps; the atom's fourth state (ERROR) and the "which atom raises" table
+def _prog_atom_table(n=30_011, seed=5, zero_b=True, nulls=True):
+    """g (50 groups), v INT32, a INT32 in [-1000, 1000), b INT32 in [-5, 6) (zeros!), c nullable INT32, w INT64, d DOUBLE (nullable)"""
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor
+    rng = np.random.default_rng(seed)
+    g = rng.integers(0, 50, n).astype(np.int32)
+    v = rng.integers(-1000, 1000, n).astype(np.int32)
+    a = rng.integers(-1000, 1000, n).astype(np.int32)
+    b = rng.integers(-5, 6, n).astype(np.int32)
+    if not zero_b:
+        b[b == 0] = 3
+    c = rng.integers(0, 100, n).astype(np.int32)
+    w = rng.integers(-10**12, 10**12, n).astype(np.int64)
+    d = rng.uniform(-10, 10, n)
+    if nulls:
+        c[rng.random(n) < 0.15] = -2**31
+        d[rng.random(n) < 0.1] = np.finfo(np.float64).tiny
+    I32, I64, F64 = capi.INT32, capi.INT64, capi.DOUBLE
+    R = ExpressionRange
+    descs = [InputColDescriptor(I32, False, R(True, 0, 49)), InputColDescriptor(I32, False, R(True, -1000, 999)),
+             InputColDescriptor(I32, False, R(True, -1000, 999)), InputColDescriptor(I32, False, R(True, -5, 5)),
+             InputColDescriptor(I32, nulls, R(True, 0, 99, nulls)), InputColDescriptor(I64, False, R(True, -10**12, 10**12)),
+             InputColDescriptor(F64, nulls, R(True, 0, 0, nulls, -10.0, 10.0))]
+    return descs, [g, v, a, b, c, w, d]
+
+
+def _prog_atom_shapes():
+    from heavydb_amd.executor import Expr
+    I32, I64, F64 = capi.INT32, capi.INT64, capi.DOUBLE
     C_, L = Expr.col, Expr.lit
-    e = C_(2).cmp(capi.EX_NE, L(I32, 0)).logical(capi.EX_AND, C_(1).div(C_(2), I32).cmp(capi.EX_GT, L(I32, 3)), True)
-    base.ra.exprs = [e.with_range(base.ra.exprs[0].range)]
-    base.ra.simple_quals = [Qual(5, capi.EQ, 1)]
-    rs = flow._check(oracle, base)
-    assert rs is not None
-    route = Executor(0).explain(base.ra, [len(f[0]) for f in base.frags])
-    assert "k_project" in route and "filter compiled" not in route, route
+    A, B, Cn, W, D, V = 2, 3, 4, 5, 6, 1
+    sc = True
+    return {
+        # the reference's deferred qual: the division is never evaluated where b = 0 (short-circuit AND)
+        "guarded_div": (C_(B).cmp(capi.EX_NE, L(I32, 0)).logical(capi.EX_AND, C_(A).div(C_(B), I32).cmp(capi.EX_GT, L(I32, 3)), sc), None),
+        # unguarded: rows with b = 0 raise error 1
+        "unguarded_div": (C_(A).div(C_(B), I32).cmp(capi.EX_GT, L(I32, 3)), capi.ERR_DIV_BY_ZERO),
+        # the plain AND evaluates both sides: the guard does not help
+        "plain_and_does_not_guard": (C_(B).cmp(capi.EX_NE, L(I32, 0)).logical(capi.EX_AND, C_(A).div(C_(B), I32).cmp(capi.EX_GT, L(I32, 3))),
+                                     capi.ERR_DIV_BY_ZERO),
+        "sum_of_two_columns": (C_(A).add(C_(V), I32).cmp(capi.EX_GT, L(I32, 100)), None),
+        "column_vs_column": (C_(A).cmp(capi.EX_LT, C_(V)), None),
+        "nullable_column_vs_column": (C_(Cn).cmp(capi.EX_GE, C_(B)).logical(capi.EX_OR, C_(Cn).is_null()), None),
+        "affine": (C_(A).mul(L(I32, 3), I32).sub(L(I32, 7), I32).cmp(capi.EX_LE, L(I32, 500)), None),
+        "overflow_raises": (C_(A).mul(L(I32, 5_000_000), I32).cmp(capi.EX_GT, L(I32, 0)), capi.ERR_OVERFLOW_OR_UNDERFLOW),
+        "widened_product": (C_(A).cast(I64).mul(L(I64, 5_000_000), I64).cmp(capi.EX_GT, C_(W)), None),
+        "modulo": (C_(A).mod(L(I32, 7), I32).cmp(capi.EX_EQ, L(I32, 3)).logical(capi.EX_OR, C_(B).cmp(capi.EX_GT, L(I32, 3))), None),
+        "double_column": (C_(D).cmp(capi.EX_LT, L(F64, 2.5)).logical(capi.EX_AND, C_(A).cmp(capi.EX_GT, L(I32, -500))), None),
+        "double_arithmetic": (C_(D).mul(L(F64, 2.0), F64).cmp(capi.EX_GT, C_(A).cast(F64)), None),
+        "double_division_guarded": (C_(D).cmp(capi.EX_NE, L(F64, 0.0)).logical(capi.EX_AND, L(F64, 1.0).div(C_(D), F64).cmp(capi.EX_LT, L(F64, 0.5)), sc), None),
+        "is_null_of_a_sum": (C_(Cn).add(C_(A), I32).is_null().logical_not(), None),
+        "not_over_program_atom": (C_(A).add(C_(V), I32).cmp(capi.EX_GT, L(I32, 100)).logical_not().logical(capi.EX_OR, C_(Cn).cmp(capi.EX_LT, L(I32, 10))), None),
+        "uminus": (C_(A).neg(I32).cmp(capi.EX_GT, C_(V)), None),
+        "two_program_atoms_short_circuit_or": (C_(B).cmp(capi.EX_EQ, L(I32, 0)).logical(capi.EX_OR, L(I32, 100).div(C_(B), I32).cmp(capi.EX_GT, C_(A)), sc)
+                                               .logical(capi.EX_AND, C_(A).add(C_(V), I32).cmp(capi.EX_LT, L(I32, 900))), None),
+    }
+
+
+def _prog_atom_case(name, grouped=True, typed=True, quals=(), n=30_011):
+    from heavydb_amd.executor import ExpressionRange, Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.cases import Case
+    descs, cols = _prog_atom_table(n)
+    e, err = _prog_atom_shapes()[name]
+    nc = len(descs)
+    targets = ([TargetExpr(capi.PROJECT_KEY)] if grouped else []) + [TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1)] + \
+              ([] if typed else [TargetExpr(capi.MIN, 5)])   # (an INT64 value column: the run-time-role member)
+    ra = RelAlgExecutionUnit(descs, targets, [Qual(nc, capi.EQ, 1)] + list(quals), [0] if grouped else [],
+                             exprs=[e.with_range(ExpressionRange(True, 0, 1, True))], max_groups_buffer_entry_guess=256, num_tuples=n)
+    h = n // 2 // 4 * 4 + 4
+    case = Case(name, ra, [[x[:h] for x in cols], [x[h:] for x in cols]])
+    case.expect_error = err
+    return case
+
+
+@pytest.mark.parametrize("consumer", ["typed_lds", "generic_lds", "scan_agg"])
+@pytest.mark.parametrize("name", list(_prog_atom_shapes()))
+def test_program_atoms_in_compiled_filters(sim, oracle, name, consumer):
+    """filters whose leaves hold arithmetic, two columns or DOUBLE operands run inside the consuming kernel (no k_project
+    pass), values AND error codes as the oracle's node-by-node evaluation gives them"""
+    from heavydb_amd.executor import Executor
+    case = _prog_atom_case(name, grouped=consumer != "scan_agg", typed=consumer == "typed_lds")
+    route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
+    assert "filter compiled" in route and "k_project" not in route, route
+    rs = flow._check(oracle, case, kernel_variant=0)
+    if case.expect_error is None:
+        kn = rs.report.kernel_name.decode()
+        assert kn == ("k_scan_agg" if consumer == "scan_agg" else "k_groupby_lds"), kn
+        uses_double = name.startswith("double")
+        if consumer == "typed_lds" and not uses_double and name != "widened_product":
+            assert rs.report.variant == 5, rs.report.variant
+        # the interpreter pass agrees
+        flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_NO_COMPILED_FILTER)
+
+
+def test_program_atoms_beside_plain_quals_and_range_atoms(sim, oracle):
+    from heavydb_amd.executor import Qual
+    for name in ("guarded_div", "sum_of_two_columns", "double_column"):
+        case = _prog_atom_case(name, quals=[Qual(1, capi.GE, -500), Qual(4, capi.IS_NOT_NULL, 0)])
+        rs = flow._check(oracle, case, kernel_variant=0)
+        assert rs is not None and rs.report.kernel_name.decode() == "k_groupby_lds"
+
+
+def test_an_error_in_a_dropped_row_still_counts_when_the_expression_is_evaluated(sim, oracle):
+    """a plain qual that drops the row does not stop the filter's expressions from being evaluated (the row function evaluates
+    them first): the unguarded division raises although `v >= 2000` passes nothing"""
+    from heavydb_amd.executor import Qual
+    case = _prog_atom_case("unguarded_div", quals=[Qual(1, capi.GE, 2000)])
+    flow._check(oracle, case, kernel_variant=0)
 
 
 @pytest.mark.parametrize("idx", range(6), ids=["and_in_or", "not_or", "composed", "not_null_cmp_and_plain_qual", "short_circuit_or",
@@ -824,6 +920,10 @@ def _typed_filter_quals():
         "bound_beyond_int32": [Qual(3, capi.LT, 1 << 40), Qual(2, capi.GT, -(1 << 40))],
         "empty_range": [Qual(3, capi.LT, -(1 << 40))],
         "empty_range_negated": [Qual(3, capi.NE, 1 << 40)],
+        # more range filters than the run-time-role member's widest instantiation takes (negated quals do not merge)
+        "five_negated_one_column": [Qual(3, capi.NE, k) for k in (1, 2, 3, 4, 5)],
+        "seven_quals_three_columns": [Qual(3, capi.NE, 7), Qual(3, capi.NE, 9), Qual(3, capi.NE, 11), Qual(2, capi.NE, 0), Qual(2, capi.NE, 1),
+                                      Qual(4, capi.NE, 50), Qual(4, capi.NE, 51)],
     }
 
 
@@ -838,6 +938,8 @@ def test_typed_lds_member_under_range_filters(sim, oracle, shape, nullable, base
     rs = flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_LDS_GENERIC_MEMBER if member == "generic" else 0)
     assert rs is not None
     name = rs.report.kernel_name.decode()
+    if shape in ("five_negated_one_column", "seven_quals_three_columns"):   # too many filters for the LDS members: any family, the oracle's result
+        return
     assert name in ("k_groupby_lds", "k_perfect_lds"), name   # (one range qual over a perfect-hash table: the older family)
     if name == "k_groupby_lds":
         assert rs.report.variant == (4 if member == "generic" else 5), rs.report.variant
