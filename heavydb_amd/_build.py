@@ -19,8 +19,8 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libmi355q.so")
 
-SOURCES = ["api.cpp", "api_projection.cpp", "api_result.cpp", "api_join.cpp", "boolfilter.cpp", "plan.cpp", "kernels_generic.hip", "kernels_fast.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_lds.hip", "kernels_idx.hip", "kernels_proj.hip"]  # missing files are skipped
-HEADERS = ["dev_common.h", "rowfunc.h", "plan.h", "kernels.h", "fast_common.h", "expr.h", "lds_args.h", "api_internal.h", "boolfilter.h", os.path.join("..", "..", "include", "mi355q.h")]
+SOURCES = ["api.cpp", "api_projection.cpp", "api_result.cpp", "api_join.cpp", "boolfilter.cpp", "plan.cpp", "kernels_generic.hip", "kernels_fast.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_lds.hip", "kernels_idx.hip", "kernels_proj.hip", "kernels_filter.hip"]  # missing files are skipped
+HEADERS = ["dev_common.h", "rowfunc.h", "plan.h", "kernels.h", "fast_common.h", "expr.h", "lds_args.h", "api_internal.h", "boolfilter.h", "regprog.h", os.path.join("..", "..", "include", "mi355q.h")]
 ARCH = "gfx950"
 
 

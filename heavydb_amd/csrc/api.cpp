@@ -238,6 +238,9 @@ int32_t mi355q_release_workspace(int32_t device_id) {
   ctx.lattice_bytes = 0;
   if (ctx.bf_table) (void)hipFree(ctx.bf_table);
   ctx.bf_table = nullptr;
+  if (ctx.maskws) (void)hipFree(ctx.maskws);
+  ctx.maskws = nullptr;
+  ctx.maskws_bytes = 0;
   if (ctx.projws) (void)hipFree(ctx.projws);
   ctx.projws = nullptr;
   ctx.projws_bytes = 0;
@@ -2075,6 +2078,181 @@ int32_t execute_projected(const mi355q_plan* plan, const mi355q_inputs* in, cons
   return MI355Q_OK;
 }
 
+
+// A filter compiled at plan time whose atoms include PROGRAMS (boolfilter.h, regprog.h: `b <> 0 AND a / b > 3`, `x + y > 100`,
+// `a < b`, DOUBLE leaves): the pre-pass k_filter_mask streams the filter's columns once and leaves one byte per row, the step
+// proper is `rest` (the stated plan without quals and expressions) with ONE more column — the mask, INT8 NOT NULL in [0, 1] —
+// and the qual `mask = 1`, which every typed family loads as one 4-byte word per quad.  Errors (7 / 1) surface from the
+// pre-pass: every row evaluates the filter's expressions, as the row function does ahead of its quals.
+// kNotTaken: unaligned filter columns, no room for one more column (the caller falls through to the interpreter pass).
+int32_t execute_masked(const mi355q_plan* plan, const mi355q_plan& rest, const BoolFilterHost& bfh, const mi355q_inputs* in,
+                       const mi355q_exec_options& o, mi355q_result** out, mi355q_exec_report* report, int64_t* reserved) {
+  const int nc = rest.n_cols, nc2 = nc + 1, nf = in->n_frags;
+  if (nc2 > MI355Q_MAX_COLS || rest.n_quals != 0 || rest.n_exprs != 0) return kNotTaken;
+  mi355q_plan mp = rest;
+  mp.n_cols = nc2;
+  std::memset(&mp.cols[nc], 0, sizeof(mp.cols[nc]));
+  mp.cols[nc].type = MI355Q_INT8;
+  std::memset(&mp.col_ranges[nc], 0, sizeof(mp.col_ranges[nc]));
+  mp.col_ranges[nc].valid = 1;
+  mp.col_ranges[nc].min = 0;
+  mp.col_ranges[nc].max = 1;
+  mp.n_quals = 1;
+  std::memset(&mp.quals[0], 0, sizeof(mp.quals[0]));
+  mp.quals[0].col = nc;
+  mp.quals[0].op = MI355Q_EQ;
+  mp.quals[0].ival = 1;
+  int64_t total_rows = 0, max_frag_rows = 0;
+  for (int f = 0; f < nf; ++f) {
+    if (in->num_rows[f] < 0) return MI355Q_ERR_INVALID_PLAN;
+    total_rows += in->num_rows[f];
+    max_frag_rows = std::max(max_frag_rows, in->num_rows[f]);
+  }
+  if (reserved) {  // mi355q_reserve_workspace / mi355q_explain: nothing is launched
+    route_note("k_filter_mask (program atoms + truth table -> 1 B/row)");
+    return execute_impl(&mp, in, &o, out, report, nullptr, reserved);
+  }
+  if (nf == 0) return mi355q_execute(&mp, in, &o, out, report);
+  {
+    FragView hv{nullptr, nullptr, in->col_buffers, in->num_rows, nf, nc, total_rows, max_frag_rows};
+    if (!filter_mask_eligible(bfh.bf, hv)) return kNotTaken;
+  }
+  DeviceGuard g(in->device_id);
+  if (!g.ok) return MI355Q_ERR_HIP;
+  const int n_cus = o.tune_cus > 0 ? std::min(o.tune_cus, cu_count_of(in->device_id)) : cu_count_of(in->device_id);
+  DeviceCtx& ctx = ctx_of(in->device_id);
+  std::lock_guard<std::recursive_mutex> ctx_lock(ctx.mu);
+  hipStream_t s = (hipStream_t)o.stream;
+  if (!s) {
+    if (!ctx.stream) HIP_TRY(hipStreamCreateWithFlags(&ctx.stream, hipStreamNonBlocking));
+    s = ctx.stream;
+  }
+  // one pass of fragments = as many as the mask region holds (1 B/row: 16 GB of it cover 16 G rows)
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const int64_t budget = std::min<int64_t>((int64_t)16 << 30, ((int64_t)free_b + ctx.maskws_bytes) / 3);
+  int64_t pass_rows = std::max<int64_t>(budget, max_frag_rows);
+  if (o.pass_rows > 0) pass_rows = std::max<int64_t>(o.pass_rows, max_frag_rows);  // tests: several passes
+  if (pass_rows > total_rows) pass_rows = total_rows;
+  const int64_t tab_bytes = ((int64_t)sizeof(void*) * nf * nc + 255) & ~255ll;    // the pre-pass's view: the stated columns
+  const int64_t mtab_bytes = ((int64_t)sizeof(void*) * nf + 255) & ~255ll;        // per fragment: its mask chunk
+  const int64_t rows_bytes = ((int64_t)sizeof(int64_t) * nf + 255) & ~255ll;
+  const int64_t col_region = (pass_rows + 32 * (int64_t)nf + 255) & ~255ll;
+  const int64_t need = col_region + tab_bytes + mtab_bytes + rows_bytes + 256;
+  if (ctx.maskws_bytes < need) {
+    if (ctx.maskws) (void)hipFree(ctx.maskws);
+    ctx.maskws = nullptr;
+    ctx.maskws_bytes = 0;
+    hipError_t he = hipMalloc(&ctx.maskws, (size_t)need);
+    if (he != hipSuccess) {
+      last_hip_error = he;
+      (void)hipGetLastError();
+      return MI355Q_ERR_OUT_OF_GPU_MEM;
+    }
+    ctx.maskws_bytes = need;
+  }
+  if (!ctx.bf_table) HIP_TRY(hipMalloc(&ctx.bf_table, sizeof(BoolFilter)));
+  HIP_TRY(hipMemcpy(ctx.bf_table, &bfh.bf, sizeof(BoolFilter), hipMemcpyHostToDevice));  // (synchronous: out of the caller's frame)
+  char* base = (char*)ctx.maskws;
+  const int8_t** d_tab = (const int8_t**)(base + col_region);
+  int8_t** d_mtab = (int8_t**)(base + col_region + tab_bytes);
+  int64_t* d_rows = (int64_t*)(base + col_region + tab_bytes + mtab_bytes);
+  int32_t* d_err = (int32_t*)(base + col_region + tab_bytes + mtab_bytes + rows_bytes);
+  HIP_TRY(hipMemsetAsync(d_err, 0, 64, s));
+  HIP_TRY(hipMemcpyAsync(d_rows, in->num_rows, sizeof(int64_t) * (size_t)nf, hipMemcpyHostToDevice, s));
+
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (report) {
+    HIP_TRY(hipEventCreate(&ev0));
+    HIP_TRY(hipEventCreate(&ev1));
+    HIP_TRY(hipEventRecord(ev0, s));
+  }
+  struct EvGuard {
+    hipEvent_t a, b;
+    ~EvGuard() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } evg{ev0, ev1};
+  std::vector<const void*> cols2((size_t)nf * nc2);
+  std::vector<void*> masks((size_t)nf);
+  mi355q_result* res = nullptr;
+  struct ResGuard {
+    mi355q_result*& r;
+    ~ResGuard() { if (r) mi355q_result_free(r); }
+  } rg{res};
+  mi355q_exec_report acc{};
+  int pass = 0, f = 0;
+  while (f < nf) {
+    int f1 = f;
+    int64_t rows = 0, off = 0;
+    while (f1 < nf && (f1 == f || rows + in->num_rows[f1] <= pass_rows)) {
+      for (int c = 0; c < nc; ++c) cols2[(size_t)(f1 - f) * nc2 + c] = in->col_buffers[(size_t)f1 * nc + c];
+      cols2[(size_t)(f1 - f) * nc2 + nc] = base + off;
+      masks[(size_t)(f1 - f)] = base + off;
+      off += filter_mask_chunk_bytes(in->num_rows[f1]);
+      rows += in->num_rows[f1];
+      ++f1;
+    }
+    if (off > col_region) return MI355Q_ERR_OUT_OF_GPU_MEM;  // (cannot happen: the region is sized for it)
+    const int pnf = f1 - f;
+    HIP_TRY(hipMemcpyAsync(d_tab, in->col_buffers + (size_t)f * nc, sizeof(void*) * (size_t)pnf * nc, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d_mtab, masks.data(), sizeof(void*) * (size_t)pnf, hipMemcpyHostToDevice, s));
+    int64_t prows = 0, pmax = 0;
+    for (int i = f; i < f1; ++i) {
+      prows += in->num_rows[i];
+      pmax = std::max(pmax, in->num_rows[i]);
+    }
+    FragView fv{d_tab, d_rows + f, in->col_buffers + (size_t)f * nc, in->num_rows + f, pnf, nc, prows, pmax};
+    HIP_TRY(launch_filter_mask(bfh.bf, (const BoolFilter*)ctx.bf_table, fv, d_mtab, d_err, n_cus, s));
+    int32_t h_err = 0;
+    if (bfh.bf.any_raise) {  // (a filter that cannot raise leaves nothing to look at: the step proper is enqueued right behind)
+      HIP_TRY(hipMemcpyAsync(&h_err, d_err, sizeof(h_err), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      if (h_err) return h_err;
+    } else {
+      HIP_TRY(hipStreamSynchronize(s));  // (masks / cols2 are re-used by the next pass; the step below synchronises anyway)
+    }
+    mi355q_inputs in2 = *in;
+    in2.n_frags = pnf;
+    in2.col_buffers = cols2.data();
+    in2.num_rows = in->num_rows + f;
+    mi355q_exec_options o2 = o;
+    o2.stream = s;
+    o2.out_buffer = pass == 0 ? o.out_buffer : nullptr;
+    mi355q_result* r2 = nullptr;
+    mi355q_exec_report rep2{};
+    if (int32_t e2 = mi355q_execute(&mp, &in2, &o2, &r2, &rep2)) return e2;
+    if (pass == 0) {
+      res = r2;
+      std::snprintf(acc.kernel_name, sizeof(acc.kernel_name), "%s", rep2.kernel_name);
+      acc.variant = rep2.variant;
+    } else {
+      const int32_t er = mi355q_result_reduce(res, r2, s);
+      mi355q_result_free(r2);
+      if (er) return er;
+    }
+    acc.kernel_ms += rep2.kernel_ms;
+    acc.n_launches += rep2.n_launches + 1;
+    acc.spilled_rows += rep2.spilled_rows;
+    f = f1;
+    ++pass;
+  }
+  if (ev1) {
+    HIP_TRY(hipEventRecord(ev1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  if (report) {
+    *report = acc;
+    (void)hipEventElapsedTime(&report->total_ms, ev0, ev1);
+    report->rows_scanned = total_rows;
+    report->algorithmic_bytes = algorithmic_bytes(*plan, *in);
+  }
+  *out = res;
+  res = nullptr;
+  return MI355Q_OK;
+}
+
 }  // namespace
 
 namespace {
@@ -2249,7 +2427,10 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     if (compile_bool_filter(*plan, &bfh, &rest)) {
       const size_t mark = t_route ? t_route->size() : 0;
       int32_t e = kNotTaken;
-      {
+      if (bfh.bf.n_progs != 0) {  // program atoms: the row-mask pre-pass, then the step with `mask = 1`
+        route_note("filter compiled (atoms + programs + truth table)");
+        e = execute_masked(plan, rest, bfh, in, o, out, report, reserved);
+      } else {
         DeviceGuard gb(in->device_id);
         DeviceCtx& cb = ctx_of(in->device_id);
         std::lock_guard<std::recursive_mutex> lb(cb.mu);
@@ -2788,7 +2969,7 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
         HIP_TRY(launch_scan_count(d, fv, res->buf, n_cus, s, &st));
         break;
       case K_SCAN_AGG:
-        HIP_TRY(launch_scan_agg(d, fv, res->buf, d_err, n_cus, s, &st));
+        HIP_TRY(launch_scan_agg(d, fv, res->buf, n_cus, s, &st));
         break;
       case K_PERFECT_LDS:
         HIP_TRY(launch_perfect_lds(d, fv, res->buf, d_err, n_cus, s, &st));

@@ -116,6 +116,8 @@ struct DeviceCtx {
   void* lattice = nullptr;  // dense INT32 key columns of a lattice-keyed step (execute_affine_twin; may nest inside both)
   int64_t lattice_bytes = 0;
   void* bf_table = nullptr; // a compiled filter in device memory (boolfilter.h BoolFilter: atoms + truth table)
+  void* maskws = nullptr;   // the row mask of a compiled filter with program atoms (execute_masked: one pass of fragments)
+  int64_t maskws_bytes = 0;
   void* projws = nullptr;   // Projection family: lowered expressions, ticket / total counters, tile table, tile descriptors
   int64_t projws_bytes = 0;
   void* scratch = nullptr;

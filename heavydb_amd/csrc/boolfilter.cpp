@@ -1,6 +1,7 @@
 // boolfilter.cpp — plan-time compilation of a step's filter into atoms + a truth table (boolfilter.h).  Host C++.
 #include "boolfilter.h"
 
+#include <array>
 #include <cstring>
 #include <vector>
 
@@ -31,30 +32,32 @@ struct Compiler {
   // program atoms (regprog.h): placeholder id kProgBase + k; the filter columns their operands read
   static constexpr int kProgBase = 1000;
   std::vector<RegProg> progs;
-  std::vector<int> prog_cols;  // physical columns read by programs, in first-use order
+  std::vector<std::array<int, 2>> prog_ops;  // the physical columns behind each program's operand slots (-1: unused)
 
   // nodes [first, last] of expression k as a program atom (the BOOLEAN of a comparison / IS NULL over an arithmetic value,
   // two columns, a DOUBLE column, ...); -1: not a shape regprog.h states, or no room
   int add_prog_atom(const DevExpr& e, int first, int last) {
     if (first < 0) return -1;
-    std::vector<int> cols = prog_cols;
+    int ops[2] = {-1, -1};  // the physical columns behind operand slots 0 / 1
     auto slot_of = [&](int col) -> int {
-      for (size_t i = 0; i < cols.size(); ++i)
-        if (cols[i] == col) return (int)i;
-      cols.push_back(col);
-      return (int)cols.size() - 1;   // (provisional: the final slots are assigned when the filter is laid out)
+      for (int i = 0; i < 2; ++i) {
+        if (ops[i] == col) return i;
+        if (ops[i] < 0) {
+          ops[i] = col;
+          return i;
+        }
+      }
+      return -1;  // a third column: more than two live operands
     };
     RegProg rp;
     if (!rp_compile(e, first, last, xs.n_cols, slot_of, &rp)) return -1;
     if (rp.type != MI355Q_INT8) return -1;
-    // the steps name PHYSICAL columns until the layout pass (operand slots depend on the range atoms' columns too)
-    for (int i = 0; i < rp.n_steps; ++i)
-      if (rp.step[i].kind == RP_LDX_COL || rp.step[i].kind == RP_LDY_COL) rp.step[i].arg = cols[(size_t)rp.step[i].arg];
+    rp.n_ops = ops[1] >= 0 ? 2 : ops[0] >= 0 ? 1 : 0;
     for (size_t i = 0; i < progs.size(); ++i)
-      if (std::memcmp(&progs[i], &rp, sizeof(RegProg)) == 0) return kProgBase + (int)i;
+      if (std::memcmp(&progs[i], &rp, sizeof(RegProg)) == 0 && prog_ops[i][0] == ops[0] && prog_ops[i][1] == ops[1]) return kProgBase + (int)i;
     if ((int)progs.size() >= kBfMaxProgs) return -1;
-    prog_cols = cols;
     progs.push_back(rp);
+    prog_ops.push_back({ops[0], ops[1]});
     return kProgBase + (int)progs.size() - 1;
   }
   bool prog_atom_sym(const DevExpr& e, int first, int last, Sym* r) {
@@ -402,15 +405,14 @@ bool compile_bool_filter(const mi355q_plan& plan, BoolFilterHost* out, mi355q_pl
   o.bf.n_atoms = na;
   o.bf.n_progs = npg;
   for (int k = 0; k < npg; ++k) {
-    RegProg rp = c.progs[(size_t)k];
-    for (int i = 0; i < rp.n_steps; ++i)
-      if (rp.step[i].kind == RP_LDX_COL || rp.step[i].kind == RP_LDY_COL) {
-        const int slot = col_slot(rp.step[i].arg, true);
-        if (slot < 0) return false;
-        rp.step[i].arg = slot;
-      }
-    o.bf.prog[k] = rp;
-    o.bf.any_raise |= rp.can_raise;
+    for (int i = 0; i < 2; ++i) {
+      const int col = c.prog_ops[(size_t)k][i];
+      const int slot = col < 0 ? 0 : col_slot(col, true);
+      if (slot < 0) return false;
+      o.bf.prog_op[k][i] = slot;
+    }
+    o.bf.prog[k] = c.progs[(size_t)k];
+    o.bf.any_raise |= c.progs[(size_t)k].can_raise;
   }
   // ---- the truth table: the filter's own programs, run by the evaluator's functions, once per state vector
   int radix[kBfMaxAtoms];

@@ -53,7 +53,8 @@ struct BoolFilter {
   uint32_t table[kBfTableWords];                   // one bit per state vector (mixed radix: 3 per range atom, then 3 or 4 per program)
   // ---- program atoms (round 6); everything from here on is only copied into LDS when n_progs != 0
   int32_t n_progs, any_raise;
-  RegProg prog[kBfMaxProgs];                       // operand slot c of a program = filter column c
+  int32_t prog_op[kBfMaxProgs][2];                 // the filter column behind operand slot 0 / 1 of each program
+  RegProg prog[kBfMaxProgs];
   uint32_t etable[kBfErrStates / 8];               // any_raise: per state vector 0, or 1 + the program atom whose error is the row's
 };
 // A kernel receives a POINTER to the filter in device memory and copies it into LDS (a by-value kernel argument indexed
@@ -94,6 +95,10 @@ MQ_D void bf_load(const BoolFilter* src, BoolFilter* s_dst, int tid, int block) 
 // The filter for the FOUR rows of a quad: vals[j][c] = row j's value of filter column c (integers sign-extended, DOUBLE
 // as its bits); `valid` = the rows that exist (bit j).  Returns the rows that pass (bit j); *err receives the error a
 // VALID row raises (program atoms only), if it holds none yet.
+// The programs' typed steps are INLINED here (four rows of every member, 64-bit divisions among them): this is for a kernel
+// that holds nothing but the filter's columns — the row-mask pre-pass (kernels_filter.hip).  Measured in round 6: inlined
+// into the typed few-groups member it took the member from 52 to 128 registers + scratch (2.66 -> 9.8 ms per 1 B rows on
+// the PLAIN shape); behind a non-inlined call the values live across the call site did the same (13.2 ms).
 template <int NF>
 MQ_D uint32_t bf_quad_pass(const BoolFilter& bf, const int64_t (&vals)[4][NF], uint32_t valid, int32_t* err) {
   uint32_t idx[4] = {0, 0, 0, 0}, mul = 1;
@@ -114,12 +119,31 @@ MQ_D uint32_t bf_quad_pass(const BoolFilter& bf, const int64_t (&vals)[4][NF], u
 #pragma unroll 1
 #endif
   for (int k = 0; k < np; ++k) {
-    int64_t out[4];
-    int32_t e4[4];
-    rp_eval<4, NF>(bf.prog[k], vals, out, e4);
+    // the program's (at most two) operand columns, picked with wave-uniform selects (a run-time index into a register
+    // array would be laid out in scratch)
+    const int ca = bf.prog_op[k][0], cb = bf.prog_op[k][1];
+    int64_t av[4], bv[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t st = e4[j] ? 3u : out[j] == 1 ? 1u : out[j] == 0 ? 0u : 2u;  // (anything else is the INT8 NULL)
+      av[j] = vals[j][0];
+      bv[j] = vals[j][0];
+#pragma unroll
+      for (int c = 1; c < NF; ++c) {
+        if (ca == c) av[j] = vals[j][c];
+        if (cb == c) bv[j] = vals[j][c];
+      }
+    }
+    int64_t ops[4][2], outv[4];
+    int32_t e4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ops[j][0] = av[j];
+      ops[j][1] = bv[j];
+    }
+    rp_eval<4, 2>(bf.prog[k], ops, outv, e4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t st = e4[j] ? 3u : outv[j] == 1 ? 1u : outv[j] == 0 ? 0u : 2u;  // (anything else is the INT8 NULL)
       idx[j] += st * mul;
       epack[j] |= ex_err_enc(e4[j]) << (2 * k);
     }

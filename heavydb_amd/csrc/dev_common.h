@@ -13,9 +13,11 @@
 #include <hip/hip_runtime.h>
 #define MQ_HD __host__ __device__ __forceinline__
 #define MQ_D __device__ __forceinline__
+#define MQ_D_NOINLINE static __device__ __attribute__((noinline))
 #else
 #define MQ_HD inline
 #define MQ_D inline
+#define MQ_D_NOINLINE static __attribute__((noinline))
 #endif
 
 namespace mq {

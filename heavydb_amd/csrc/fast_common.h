@@ -239,15 +239,17 @@ inline bool all_aligned16(const FragView& fv, int col) {
 }
 
 // Turn `col <op> literal` on an integer column into an inclusive range (+ negate for <>).
-inline bool make_range_filter(const DevQual& q, RangeFilter* f) {
+// allow_int8: the caller's kernel also filters on a plain 1-byte column (TINYINT / BOOLEAN — and the row mask a compiled
+// filter's pre-pass leaves, kernels_filter.hip): four rows are one 4-byte load
+inline bool make_range_filter(const DevQual& q, RangeFilter* f, bool allow_int8 = false) {
   if (q.or_group != 0) return false;  // a member of a disjunction is not a conjunct (those plans take the row kernel)
-  if (q.type != MI355Q_INT32 && q.type != MI355Q_INT64) return false;
+  if (q.type != MI355Q_INT32 && q.type != MI355Q_INT64 && !(allow_int8 && q.type == MI355Q_INT8)) return false;
   f->col = q.col;
   f->negate = 0;
   f->nullable = q.nullable;
   f->null_val = int_null_of(q.type);
-  const int64_t tmin = q.type == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN;
-  const int64_t tmax = q.type == MI355Q_INT32 ? (int64_t)INT32_MAX : INT64_MAX;
+  const int64_t tmin = q.type == MI355Q_INT8 ? (int64_t)INT8_MIN : q.type == MI355Q_INT32 ? (int64_t)INT32_MIN : INT64_MIN;
+  const int64_t tmax = q.type == MI355Q_INT8 ? (int64_t)INT8_MAX : q.type == MI355Q_INT32 ? (int64_t)INT32_MAX : INT64_MAX;
   const int64_t x = q.ival;
   switch (q.op) {
     case MI355Q_EQ: f->lo = x; f->hi = x; break;

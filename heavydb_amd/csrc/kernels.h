@@ -215,7 +215,7 @@ struct FragView {
 
 // non-grouped aggregates over up to 8 plain int32 / int64 / double columns with up to 4 integer range quals
 bool scan_agg_eligible(const DevPlan& p, const FragView& fv);
-hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int n_cus, hipStream_t s,
+hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus, hipStream_t s,
                            LaunchStats* st);
 // GROUP BY with few groups, whole table replicated in every workgroup's LDS (kernels_lds.hip): perfect-hash layouts
 // of 1-3 integer key columns with <= 65536 entries, or a baseline layout over one 8-byte / int32 key with at most a
@@ -342,6 +342,12 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
                              int n_cus, hipStream_t s, LaunchStats* st);
 hipError_t launch_projection_count_live(const int64_t* keys, int64_t stride_quads, int64_t entries, unsigned long long* d_count,
                                         hipStream_t s);
+
+// the row mask of a compiled filter with program atoms (kernels_filter.hip): one byte per row, 1 = the row passes
+int64_t filter_mask_chunk_bytes(int64_t n_rows);  // bytes of one fragment's mask chunk (16-byte multiple)
+bool filter_mask_eligible(const BoolFilter& bf, const FragView& fv);
+hipError_t launch_filter_mask(const BoolFilter& bf, const BoolFilter* d_bf, const FragView& fv, int8_t* const* d_mask, int32_t* d_err,
+                              int n_cus, hipStream_t s);
 
 bool join_sum_eligible(const DevPlan& p, const FragView& fv);
 hipError_t launch_join_sum(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus,

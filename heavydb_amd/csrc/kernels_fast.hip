@@ -68,7 +68,6 @@ struct ScanAggArgs {
   // a filter compiled at plan time (boolfilter.h) instead of range quals: flt[k].col / flt_type[k] name its columns
   int32_t bf_on, pad_bf_;
   const BoolFilter* bf;  // DEVICE memory
-  int32_t* d_err;        // the step's error word (a program atom of the compiled filter can raise error 7 / error 1)
 };
 
 struct ColAcc {
@@ -126,7 +125,9 @@ MQ_D uint32_t scan_agg_filter(const RangeFilter& f, int type, const RawQuad& r) 
   uint32_t m = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const bool p = type == MI355Q_INT32 ? filter_pass<int32_t>(f, raw_i32(r, i)) : filter_pass<int64_t>(f, raw_i64(r, i));
+    const bool p = type == MI355Q_INT32 ? filter_pass<int32_t>(f, raw_i32(r, i))
+                   : type == MI355Q_INT8 ? filter_pass<int32_t>(f, (int32_t)(int8_t)((uint32_t)r.lo.x >> (8 * i)))  // (four 1-byte rows in lo.x)
+                                         : filter_pass<int64_t>(f, raw_i64(r, i));
     m |= (p ? 1u : 0u) << i;
   }
   return m;
@@ -206,7 +207,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __rest
     acc[c].max_f = -1.7976931348623157e308;
   }
   unsigned long long rows_passing = 0;
-  int32_t bf_err = 0;
   const int64_t tile_q = (int64_t)kBlock * UQ;
   const int64_t gtid = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int64_t gsize = (int64_t)gridDim.x * kBlock;
@@ -232,7 +232,8 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __rest
 #pragma unroll
         for (int k = 0; k < NF; ++k) {
           if (k >= a.n_flt) break;
-          load_raw(fbase[k], quad, a.flt_type[k] != MI355Q_INT32, fr[k][u]);
+          if (a.flt_type[k] == MI355Q_INT8) fr[k][u].lo.x = (int)__builtin_nontemporal_load((const MQ_GLOBAL uint32_t*)fbase[k] + quad);
+          else load_raw(fbase[k], quad, a.flt_type[k] != MI355Q_INT32, fr[k][u]);
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -244,15 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __rest
       for (int u = 0; u < UQ; ++u) {
         if (u >= n_quads) break;
         uint32_t pass = 15u;
-        if (a.bf_on && s_bf.n_progs != 0) {  // program atoms (regprog.h): the quad's four rows together
-          int64_t qv[4][NF];
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int k = 0; k < NF; ++k)
-              qv[i][k] = k >= a.n_flt ? 0 : a.flt_type[k] == MI355Q_INT32 ? (int64_t)raw_i32(fr[k][u], i) : raw_i64(fr[k][u], i);
-          pass = bf_quad_pass<NF>(s_bf, qv, 15u, &bf_err);
-        } else if (a.bf_on) {  // atoms on the filter columns' values + one bit of the truth table per row
+        if (a.bf_on) {  // atoms on the filter columns' values + one bit of the truth table per row
           pass = 0u;
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
@@ -288,11 +281,12 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __rest
 #pragma unroll
         for (int k = 0; k < NF; ++k)
           fval[k] = k >= a.n_flt ? 0 : a.flt_type[k] == MI355Q_INT32 ? (int64_t)load_one<int32_t>(fbase[k], tail) : load_one<int64_t>(fbase[k], tail);
-        pass = bf_one_row_passes<NF>(s_bf, fval, &bf_err);
+        pass = bf_row_passes<NF>(s_bf, fval);
       } else {
         for (int k = 0; k < a.n_flt; ++k) {
           pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], load_one<int32_t>(fc[a.flt[k].col], tail))
-                                                        : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fc[a.flt[k].col], tail)));
+                          : a.flt_type[k] == MI355Q_INT8 ? filter_pass<int32_t>(a.flt[k], (int32_t)load_one<int8_t>(fc[a.flt[k].col], tail))
+                                                         : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fc[a.flt[k].col], tail)));
         }
       }
       if (pass) {
@@ -311,7 +305,6 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg(const int8_t* const* __rest
   // wave reduce, then one fold per workgroup in LDS
   __shared__ unsigned long long s_rows[kBlock / 64];
   __shared__ ColAcc s_acc[kBlock / 64][kScanAggCols];
-  if (bf_err && a.d_err) atomicCAS(a.d_err, 0, bf_err);  // a program atom of the compiled filter raised
   rows_passing = wave_sum_u64(rows_passing);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
@@ -890,7 +883,7 @@ static bool scan_agg_args(const DevPlan& p, const FragView& fv, ScanAggArgs* a) 
   if (p.desc_type != MI355Q_NON_GROUPED_AGGREGATE || p.join_col >= 0 || p.n_quals > MI355Q_MAX_QUALS) return false;
   std::memset(a, 0, sizeof(*a));
   for (int i = 0; i < p.n_quals; ++i) {
-    if (!make_range_filter(p.quals[i], &a->flt[i])) return false;
+    if (!make_range_filter(p.quals[i], &a->flt[i], true)) return false;  // (1-byte filter columns too)
     a->flt_type[i] = p.quals[i].type;
     if (!all_aligned16(fv, p.quals[i].col)) return false;
   }
@@ -941,10 +934,9 @@ bool scan_agg_eligible(const DevPlan& p, const FragView& fv) {
   return scan_agg_args(p, fv, &a);
 }
 
-hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int n_cus, hipStream_t s, LaunchStats* st) {
+hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int n_cus, hipStream_t s, LaunchStats* st) {
   ScanAggArgs a;
   if (!scan_agg_args(p, fv, &a)) return hipErrorInvalidValue;
-  a.d_err = d_err;
   const int grid = stream_grid(n_cus, 2, fv.total_rows);
   st->kernel_name = "k_scan_agg";
   st->n_launches = 1;

@@ -1,0 +1,176 @@
+// kernels_filter.hip — the ROW MASK of a filter compiled at plan time whose atoms include programs (round 6).
+//
+// The reference compiles a WHERE clause into the row function (Executor::compileBody, NativeCodegen.cpp:3455; arithmetic
+// leaves: codegenArith / codegenDiv, ArithmeticIR.cpp:39-560; the short-circuit forms behind prioritizeQuals,
+// LogicalIR.cpp:158-297).  Here a filter of comparisons with literals is evaluated INSIDE the consuming kernel (atoms +
+// truth table, boolfilter.h).  A filter with PROGRAM atoms — `b <> 0 AND a / b > 3`, `x + y > 100`, `a < b`, DOUBLE
+// leaves: two-register programs of typed steps, regprog.h — is evaluated by this pre-pass instead: it streams the
+// filter's columns ONCE (16-byte loads, two quads per lane in flight), runs atoms, programs and the truth table on the four
+// rows of a quad together and leaves ONE BYTE per row (1 = the row passes).  The step proper then runs without the
+// filter's columns and with the qual `mask = 1` on that 1-byte column — which every typed family loads as one 4-byte word
+// per quad.  Bytes: the filter's columns are read once either way; the mask adds 1 B/row written + 1 B/row read (the
+// interpreter pass of rounds 3-5 wrote and re-read a 4-byte column per expression and ran ~450 wave instructions per 64
+// rows).  An error a row raises (error 7 / error 1) ends the step exactly as the row function's would: every row evaluates
+// the filter's expressions, whatever the plain quals say of it.
+#include "boolfilter.h"
+#include "fast_common.h"
+#include "kernels.h"
+
+namespace mq {
+
+using namespace fast;
+
+namespace {
+
+constexpr int kFmBlock = 256;
+
+struct FilterMaskArgs {
+  int32_t n_flt, n_frags, n_cols_table, pad_;
+  int32_t col[kBfMaxCols], width[kBfMaxCols];  // the filter's columns: index in the column table, bytes per value (4 / 8)
+  const BoolFilter* bf;                         // DEVICE memory
+  const int8_t* const* cols;
+  const int64_t* num_rows;
+  int8_t* const* mask;                          // per fragment: ceil(n / 4) * 4 bytes, 16-byte aligned
+  int32_t* d_err;
+};
+
+template <int NF>
+MQ_D void fm_load_quad(const FilterMaskArgs& a, const int8_t* const* fc, int64_t quad, v4i32 (&lo)[NF], v4i32 (&hi)[NF]) {
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+    if (k >= a.n_flt) break;
+    const int8_t* base = fc[a.col[k]];
+    if (a.width[k] == 8) {
+      lo[k] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2);
+      hi[k] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2 + 1);
+    } else {
+      lo[k] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad);
+    }
+  }
+}
+MQ_D int32_t fm_v4(const v4i32& v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+template <int NF>
+MQ_D void fm_values(const FilterMaskArgs& a, const v4i32 (&lo)[NF], const v4i32 (&hi)[NF], int64_t (&vals)[4][NF]) {
+#pragma unroll
+  for (int k = 0; k < NF; ++k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (k >= a.n_flt) {
+        vals[i][k] = 0;
+      } else if (a.width[k] == 8) {
+        const v4i32& h = i < 2 ? lo[k] : hi[k];
+        const int j = (i & 1) * 2;
+        vals[i][k] = (int64_t)(((uint64_t)(uint32_t)fm_v4(h, j + 1) << 32) | (uint64_t)(uint32_t)fm_v4(h, j));
+      } else {
+        vals[i][k] = (int64_t)fm_v4(lo[k], i);
+      }
+    }
+  }
+}
+
+// NF: filter columns this member holds registers for
+template <int NF>
+__global__ __launch_bounds__(kFmBlock) void k_filter_mask(FilterMaskArgs a) {
+  __shared__ BoolFilter s_bf;
+  bf_load(a.bf, &s_bf, threadIdx.x, kFmBlock);
+  __syncthreads();
+  int32_t err = 0;
+  const int64_t gtid = (int64_t)blockIdx.x * kFmBlock + threadIdx.x;
+  const int64_t gsize = (int64_t)gridDim.x * kFmBlock;
+  for (int f = 0; f < a.n_frags; ++f) {
+    const int8_t* const* fc = a.cols + (size_t)f * a.n_cols_table;
+    const int64_t n = a.num_rows[f];
+    const int64_t nq = n >> 2;
+    uint32_t* const out = (uint32_t*)a.mask[f];
+    // ONE copy of the evaluator in the kernel (the programs' typed members are inlined four rows wide: ~5 K instructions).
+    // Every lane walks the fragment's quads with the loads of its NEXT quad in flight while this one's programs run; the
+    // fragment's last, partial quad takes the same path with its rows loaded one by one (a row past the end repeats the
+    // last one and is not valid).
+    const int64_t nq_all = (n + 3) >> 2;
+    auto load_vals = [&](int64_t quad, v4i32 (&lo)[NF], v4i32 (&hi)[NF]) {
+      if (quad < nq) {
+        fm_load_quad<NF>(a, fc, quad, lo, hi);
+      } else if (quad < nq_all) {  // (one lane per fragment)
+        const int left = (int)(n & 3);
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+          if (k >= a.n_flt) break;
+          int64_t v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int64_t pos = (nq << 2) + (i < left ? i : left - 1);
+            v[i] = a.width[k] == 8 ? load_one<int64_t>(fc[a.col[k]], pos) : (int64_t)load_one<int32_t>(fc[a.col[k]], pos);
+          }
+          if (a.width[k] == 8) {
+            lo[k].x = (int)(uint32_t)v[0]; lo[k].y = (int)(uint32_t)((uint64_t)v[0] >> 32); lo[k].z = (int)(uint32_t)v[1]; lo[k].w = (int)(uint32_t)((uint64_t)v[1] >> 32);
+            hi[k].x = (int)(uint32_t)v[2]; hi[k].y = (int)(uint32_t)((uint64_t)v[2] >> 32); hi[k].z = (int)(uint32_t)v[3]; hi[k].w = (int)(uint32_t)((uint64_t)v[3] >> 32);
+          } else {
+            lo[k].x = (int)v[0]; lo[k].y = (int)v[1]; lo[k].z = (int)v[2]; lo[k].w = (int)v[3];
+          }
+        }
+      }
+    };
+    v4i32 lo_c[NF], hi_c[NF], lo_n[NF], hi_n[NF];
+    int64_t q = gtid;
+    load_vals(q, lo_c, hi_c);
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+    for (; q < nq_all; q += gsize) {
+      load_vals(q + gsize, lo_n, hi_n);
+      int64_t vals[4][NF];
+      fm_values<NF>(a, lo_c, hi_c, vals);
+      const uint32_t valid = q < nq ? 15u : (1u << (int)(n & 3)) - 1u;
+      const uint32_t m = bf_quad_pass<NF>(s_bf, vals, valid, &err);
+      // one byte per row: 1 = the row passes
+      const uint32_t w = (m & 1u) | ((m & 2u) << 7) | ((m & 4u) << 14) | ((m & 8u) << 21);
+      __builtin_nontemporal_store(w, (MQ_GLOBAL uint32_t*)out + q);
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        lo_c[k] = lo_n[k];
+        hi_c[k] = hi_n[k];
+      }
+    }
+  }
+  if (err) atomicCAS(a.d_err, 0, err);
+}
+
+}  // namespace
+
+int64_t filter_mask_chunk_bytes(int64_t n_rows) { return ((((n_rows + 3) >> 2) << 2) + 15) & ~(int64_t)15; }
+
+bool filter_mask_eligible(const BoolFilter& bf, const FragView& fv) {
+  if (bf.n_cols < 1 || bf.n_cols > kBfMaxCols) return false;
+  for (int k = 0; k < bf.n_cols; ++k) {
+    const int t = bf.col_type[k];
+    if (t != MI355Q_INT32 && t != MI355Q_INT64 && t != MI355Q_DOUBLE) return false;
+    if (!all_aligned16(fv, bf.col[k])) return false;
+  }
+  return true;
+}
+
+hipError_t launch_filter_mask(const BoolFilter& bf, const BoolFilter* d_bf, const FragView& fv, int8_t* const* d_mask, int32_t* d_err,
+                              int n_cus, hipStream_t s) {
+  FilterMaskArgs a{};
+  a.n_flt = bf.n_cols;
+  a.n_frags = fv.n_frags;
+  a.n_cols_table = fv.n_cols;
+  for (int k = 0; k < bf.n_cols; ++k) {
+    a.col[k] = bf.col[k];
+    a.width[k] = bf.col_type[k] == MI355Q_INT32 ? 4 : 8;
+  }
+  a.bf = d_bf;
+  a.cols = fv.d_cols;
+  a.num_rows = fv.d_num_rows;
+  a.mask = d_mask;
+  a.d_err = d_err;
+  int64_t want = (fv.max_frag_rows / 4 + kFmBlock - 1) / kFmBlock;
+  int64_t grid = (int64_t)n_cus * 8;
+  if (grid > want) grid = want;
+  if (grid < 1) grid = 1;
+  if (bf.n_cols <= 2) hipLaunchKernelGGL(k_filter_mask<2>, dim3((unsigned)grid), dim3(kFmBlock), 0, s, a);
+  else hipLaunchKernelGGL(k_filter_mask<kBfMaxCols>, dim3((unsigned)grid), dim3(kFmBlock), 0, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace mq

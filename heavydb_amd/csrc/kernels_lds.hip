@@ -46,6 +46,17 @@ constexpr size_t kLdsBudget = 152 * 1024;
 struct RawQ {
   v4i32 lo, hi;
 };
+// w: bytes per value — 8, 4, or 1 (a TINYINT / BOOLEAN / row-mask filter column: the quad's four bytes in lo.x)
+MQ_D void load_rawq_w(const int8_t* base, int64_t quad, int w, RawQ& r) {
+  if (w == 1) {
+    r.lo.x = (int)__builtin_nontemporal_load((const MQ_GLOBAL uint32_t*)base + quad);
+  } else if (w == 8) {
+    r.lo = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2);
+    r.hi = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2 + 1);
+  } else {
+    r.lo = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad);
+  }
+}
 MQ_D void load_rawq(const int8_t* base, int64_t quad, bool w8, RawQ& r) {
   if (w8) {
     r.lo = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base + quad * 2);
@@ -60,7 +71,11 @@ MQ_D int64_t rawq_i64(const RawQ& r, int i) {
   return (int64_t)(((uint64_t)(uint32_t)(j ? h.w : h.y) << 32) | (uint64_t)(uint32_t)(j ? h.z : h.x));
 }
 MQ_D int32_t rawq_i32(const RawQ& r, int i) { return i == 0 ? r.lo.x : i == 1 ? r.lo.y : i == 2 ? r.lo.z : r.lo.w; }
-MQ_D int64_t rawq_int(const RawQ& r, int type, int i) { return type == MI355Q_INT32 ? (int64_t)rawq_i32(r, i) : rawq_i64(r, i); }
+MQ_D int32_t rawq_i8(const RawQ& r, int i) { return (int32_t)(int8_t)((uint32_t)r.lo.x >> (8 * i)); }
+MQ_D int64_t rawq_int(const RawQ& r, int type, int i) {
+  return type == MI355Q_INT32 ? (int64_t)rawq_i32(r, i) : type == MI355Q_INT8 ? (int64_t)rawq_i8(r, i) : rawq_i64(r, i);
+}
+MQ_D int flt_width(int type) { return type == MI355Q_INT32 ? 4 : type == MI355Q_INT8 ? 1 : 8; }
 
 MQ_D void lds_min_f64(int64_t* s, double v) {
   int64_t old = *(volatile int64_t*)s;
@@ -212,7 +227,6 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
   char* const my_rep = smem + (size_t)((uint32_t)t & (K - 1)) * a.copy_bytes;
   volatile uint32_t* const s_full = (volatile uint32_t*)(smem + ((size_t)a.copy_bytes << a.copies_lg));  // behind the replicas
   bool bad = false, full = false;
-  int32_t bf_err = 0;  // the error a program atom of the compiled filter raised for one of this lane's rows
 
   // one row whose quals passed: kv = the key columns' values (DOUBLE keys as their bit pattern), vv = the value columns'
   auto one_row = [&](const int64_t (&kv)[NK], const int64_t (&vv)[NV]) {
@@ -290,7 +304,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
         const int64_t quad = q0 + (int64_t)u * stride;
 #pragma unroll
         for (int k = 0; k < NF; ++k)
-          if (k < a.n_flt) load_rawq(fb[k], quad, a.flt_type[k] != MI355Q_INT32, fr[k][u]);
+          if (k < a.n_flt) load_rawq_w(fb[k], quad, flt_width(a.flt_type[k]), fr[k][u]);
 #pragma unroll
         for (int g = 0; g < NK; ++g)
           if (g < a.n_keys) load_rawq(kb[g], quad, a.key_type[g] != MI355Q_INT32 && a.key_type[g] != MI355Q_FLOAT, kr[g][u]);
@@ -301,22 +315,10 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
         if (u >= n_quads) break;
-        uint32_t qmask = 15u;
-        const bool prog_atoms = NF > 0 && a.bf_on && s_bf.n_progs != 0;  // (uniform) program atoms: the quad's four rows together
-        if (prog_atoms) {
-          int64_t qv[4][NF > 0 ? NF : 1];
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int k = 0; k < NF; ++k) qv[i][k] = k < a.n_flt ? rawq_int(fr[k][u], a.flt_type[k] == MI355Q_INT32 ? MI355Q_INT32 : MI355Q_INT64, i) : 0;
-          qmask = bf_quad_pass<(NF > 0 ? NF : 1)>(s_bf, qv, 15u, &bf_err);
-        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           bool pass = true;
-          if (prog_atoms) {
-            pass = (qmask >> i) & 1u;
-          } else if (NF > 0 && a.bf_on) {  // atoms on the filter columns' values + one bit of the truth table
+          if (NF > 0 && a.bf_on) {  // atoms on the filter columns' values + one bit of the truth table
             int64_t fval[NF > 0 ? NF : 1];
 #pragma unroll
             for (int k = 0; k < NF; ++k) fval[k] = k < a.n_flt ? rawq_int(fr[k][u], a.flt_type[k], i) : 0;
@@ -326,7 +328,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
             for (int k = 0; k < NF; ++k) {
               if (k >= a.n_flt) break;
               pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], rawq_i32(fr[k][u], i))
-                                                            : filter_pass<int64_t>(a.flt[k], rawq_i64(fr[k][u], i)));
+                              : a.flt_type[k] == MI355Q_INT8 ? filter_pass<int32_t>(a.flt[k], rawq_i8(fr[k][u], i))
+                                                             : filter_pass<int64_t>(a.flt[k], rawq_i64(fr[k][u], i)));
             }
           }
           if (!pass) continue;
@@ -355,13 +358,14 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
 #pragma unroll
         for (int k = 0; k < NF; ++k)
           fval[k] = k >= a.n_flt ? 0 : a.flt_type[k] == MI355Q_INT32 ? (int64_t)load_one<int32_t>(fb[k], tail) : load_one<int64_t>(fb[k], tail);
-        pass = bf_one_row_passes<(NF > 0 ? NF : 1)>(s_bf, fval, &bf_err);
+        pass = bf_row_passes<(NF > 0 ? NF : 1)>(s_bf, fval);
       } else {
 #pragma unroll
         for (int k = 0; k < NF; ++k) {
           if (k >= a.n_flt) break;
           pass = pass && (a.flt_type[k] == MI355Q_INT32 ? filter_pass<int32_t>(a.flt[k], load_one<int32_t>(fb[k], tail))
-                                                        : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fb[k], tail)));
+                          : a.flt_type[k] == MI355Q_INT8 ? filter_pass<int32_t>(a.flt[k], (int32_t)load_one<int8_t>(fb[k], tail))
+                                                         : filter_pass<int64_t>(a.flt[k], load_one<int64_t>(fb[k], tail)));
         }
       }
       if (pass) {
@@ -377,7 +381,6 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds(const int8_t* const* 
     }
   }
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
-  if (bf_err) atomicCAS(d_err, 0, bf_err);  // a program atom of the compiled filter raised (error 7 / error 1)
   // a lost attempt (this workgroup's, or another's) is neither folded nor flushed: the caller takes another member and
   // initialises the table again
   if (t == 0 && a.baseline && *(volatile int32_t*)(d_err + 1)) *s_full = 1u;
@@ -578,7 +581,6 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   int32_t* const my_min = (int32_t*)(my_rep + a.t_off_min);
   int32_t* const my_max = (int32_t*)(my_rep + a.t_off_max);
   bool bad = false, full = false;
-  int32_t bf_err = 0;  // the error a program atom of the compiled filter raised for one of this lane's rows
   // uniform per-column constants (static indices after unrolling: scalar registers, never a scratch copy of `a`)
   uint32_t kmin[NK], kcard[NK], kmul[NK], knull[NK];
   bool ktr[NK], vnull[NVA];
@@ -596,9 +598,10 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   // the range filters in the columns' own 32 bits (a bound beyond them is the type's; an empty range is lo > hi)
   const int nfl = FM ? a.n_flt : 0;
   int32_t flo[TF], fhi[TF], fnv[TF];
-  bool fneg[TF], fnul[TF];
+  bool fneg[TF], fnul[TF], f8[TF];  // f8: a 1-byte filter column (TINYINT / BOOLEAN / a compiled filter's row mask)
 #pragma unroll
   for (int c = 0; c < TF; ++c) {
+    f8[c] = c < nfl && a.flt_type[c] == MI355Q_INT8;
     flo[c] = 1;
     fhi[c] = 0;
     fnv[c] = INT32_MIN;
@@ -620,7 +623,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
       int64_t vals[TF];
 #pragma unroll
       for (int c = 0; c < TF; ++c) vals[c] = (int64_t)fv[c];
-      return bf_one_row_passes<TF>(s_bf, vals, &bf_err);
+      return bf_row_passes<TF>(s_bf, vals);
     }
     bool pass = true;
 #pragma unroll
@@ -733,7 +736,10 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
         if constexpr (FM != 0) {
 #pragma unroll
           for (int c = 0; c < TF; ++c)
-            if (c < nfl) tl.f[c][u] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)fb[c] + quad);
+            if (c < nfl) {
+              if (f8[c]) tl.f[c][u].x = (int)__builtin_nontemporal_load((const MQ_GLOBAL uint32_t*)fb[c] + quad);  // four 1-byte rows
+              else tl.f[c][u] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)fb[c] + quad);
+            }
         }
 #pragma unroll
         for (int g = 0; g < NK; ++g) {
@@ -748,21 +754,6 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
 #pragma unroll
       for (int u = 0; u < UQ; ++u) {
         if (u >= n_quads) break;
-        // a compiled filter with PROGRAM atoms (`a / b > 3`, `x + y > 100`, `a < b`): the quad's four rows together, one
-        // wave-uniform switch per program step (regprog.h)
-        uint32_t qmask = 15u;
-        bool prog_atoms = false;
-        if constexpr (FM != 0) {
-          prog_atoms = a.bf_on && s_bf.n_progs != 0;
-          if (prog_atoms) {
-            int64_t qv[4][TF];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int c = 0; c < TF; ++c) qv[i][c] = c < nfl ? (int64_t)v4_get(tl.f[c][u], i) : 0;
-            qmask = bf_quad_pass<TF>(s_bf, qv, 15u, &bf_err);
-          }
-        }
         if constexpr (kBase) {
           // the four rows of a quad together: keys and hashes first, then the four first-probe reads of the key array
           // in one go (one LDS round trip instead of four dependent ones — a wave's step is a chain of latencies, and
@@ -779,8 +770,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
             if constexpr (FM != 0) {
               int32_t fv[TF];
 #pragma unroll
-              for (int c = 0; c < TF; ++c) fv[c] = c < nfl ? v4_get(tl.f[c][u], i) : 0;
-              acc[i] = acc[i] && (prog_atoms ? ((qmask >> i) & 1u) != 0 : row_passes(fv));
+              for (int c = 0; c < TF; ++c) fv[c] = c >= nfl ? 0 : f8[c] ? (int32_t)(int8_t)((uint32_t)tl.f[c][u].x >> (8 * i)) : v4_get(tl.f[c][u], i);
+              acc[i] = acc[i] && row_passes(fv);
             }
           }
 #pragma unroll
@@ -805,8 +796,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
             if constexpr (FM != 0) {
               int32_t fv[TF];
 #pragma unroll
-              for (int c = 0; c < TF; ++c) fv[c] = c < nfl ? v4_get(tl.f[c][u], i) : 0;
-              if (!(prog_atoms ? ((qmask >> i) & 1u) != 0 : row_passes(fv))) continue;
+              for (int c = 0; c < TF; ++c) fv[c] = c >= nfl ? 0 : f8[c] ? (int32_t)(int8_t)((uint32_t)tl.f[c][u].x >> (8 * i)) : v4_get(tl.f[c][u], i);
+              if (!row_passes(fv)) continue;
             }
 #pragma unroll
             for (int g = 0; g < NK; ++g) klo[g] = v4_get(tl.k[g][u][0], i);
@@ -852,12 +843,11 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
       for (int c = 0; c < NV; ++c) vv[c] = load_one<int32_t>(vb[c], tail);
       int32_t fv[TF];
 #pragma unroll
-      for (int c = 0; c < TF; ++c) fv[c] = c < nfl ? load_one<int32_t>(fb[c], tail) : 0;
+      for (int c = 0; c < TF; ++c) fv[c] = c >= nfl ? 0 : f8[c] ? (int32_t)load_one<int8_t>(fb[c], tail) : load_one<int32_t>(fb[c], tail);
       if (row_passes(fv)) one_row(klo, khi, vv);
     }
   }
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
-  if (bf_err) atomicCAS(d_err, 0, bf_err);  // a program atom of the compiled filter raised (error 7 / error 1)
   if (t == 0 && kBase && *(volatile int32_t*)(d_err + 1)) *s_full = 1u;
   __syncthreads();
   if (*s_full) return;  // a lost attempt is neither folded nor flushed
@@ -979,7 +969,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
 bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out) {
   LdsArgs& a = *out;
   bool need[kLdsVals][4] = {};
-  if (!lds_describe(p, fv, 65536, tune_knobs().flags, &a, need)) return false;
+  if (!lds_describe(p, fv, 65536, tune_knobs().flags, &a, need, true)) return false;
   // one replica: 8-byte arrays first, then the 4-byte counters
   auto lay_out = [&](uint32_t entries) -> uint32_t {
     uint32_t off = 0;
@@ -1014,7 +1004,7 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out
   // (no value column at all — COUNT(*) alone — is typed only under a filter: the unfiltered count shapes have members of
   // their own, k_perfect_lds's count program and the index family's count-only member)
   a.typed = a.n_flt <= kTypedFlt && (a.n_vals >= 1 || a.n_flt >= 1) && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
-  for (int k = 0; k < a.n_flt; ++k) a.typed = a.typed && a.flt_type[k] == MI355Q_INT32;
+  for (int k = 0; k < a.n_flt; ++k) a.typed = a.typed && (a.flt_type[k] == MI355Q_INT32 || (a.flt_type[k] == MI355Q_INT8 && !a.bf_on));
   a.mm = 0;
   for (int c = 0; c < a.n_vals; ++c) {
     a.typed = a.typed && a.v[c].type == MI355Q_INT32;

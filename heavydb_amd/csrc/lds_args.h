@@ -50,15 +50,16 @@ struct LdsArgs {
 // What a few-groups / index-partitioned GROUP BY needs of a plan: quals, key columns (perfect hash: 1 - 3 plain integer columns
 // with their ranges; baseline: one 8-byte-wide key), value columns and the accumulators the targets need of each
 // (need[c] = {non-NULL count, sum, min, max}).  Perfect-hash tables of more than `max_entries` entries are refused.
+// allow_int8_flt: the caller's kernels load 1-byte filter columns (kernels_lds.hip)
 inline bool lds_describe(const DevPlan& p, const FragView& fv, int64_t max_entries, uint32_t knob_flags, LdsArgs* out,
-                         bool (&need)[kLdsVals][4]) {
+                         bool (&need)[kLdsVals][4], bool allow_int8_flt = false) {
   LdsArgs& a = *out;
   std::memset(&a, 0, sizeof(a));
   a.windows = 1;
   if (p.desc_type == MI355Q_NON_GROUPED_AGGREGATE || p.join_col >= 0 || p.col0_key_quirk || p.slot_width != 8) return false;
   if (p.n_quals > MI355Q_MAX_QUALS) return false;
   for (int i = 0; i < p.n_quals; ++i) {
-    if (!make_range_filter(p.quals[i], &a.flt[i])) return false;
+    if (!make_range_filter(p.quals[i], &a.flt[i], allow_int8_flt)) return false;
     a.flt_type[i] = p.quals[i].type;
     if (!all_aligned16(fv, p.quals[i].col)) return false;
   }

@@ -14,8 +14,9 @@
 //     nullability flags stay wave-uniform run-time values) — picked by a wave-uniform switch ONCE per step and J rows of a
 //     lane: no stack in LDS or scratch, no node decode per row, the semantics (NULL rules, error 7 / error 1, the
 //     evaluation order of the checks) stated once, in expr.h.
-// Consumers: the atoms of a filter compiled at plan time (boolfilter.h: an atom is then the BOOLEAN such a program leaves),
-// the typed expression targets of the Projection family (kernels_proj.hip k_proj_fast).
+// Consumers: the atoms of a filter compiled at plan time (boolfilter.h: an atom is then the BOOLEAN such a program leaves;
+// evaluated by the row-mask pre-pass, kernels_filter.hip), the typed expression targets of the Projection family
+// (kernels_proj.hip k_proj_fast).
 // Programs that do not fit (CASE, more than two live values, INT8 / INT16 / FLOAT arithmetic, encoded columns, values of
 // earlier expressions) keep the interpreter (expr.h eval_expr_rows).
 #pragma once
@@ -50,6 +51,7 @@ struct RegProg {
   int32_t type;       // plain type of the value x holds at the end
   int32_t nullable;
   int32_t can_raise;  // some step can raise error 7 / 1 (arithmetic, narrowing or floating-point casts, unary minus)
+  int32_t has_divmod, n_ops;  // a division / modulo step; operand slots the program reads (1 or 2: slots 0 and 1)
   RpStep step[kRpMaxSteps];
 };
 
@@ -126,6 +128,7 @@ inline bool rp_compile(const DevExpr& e, int first, int last, int n_phys_cols, S
         if (depth != 2 || !rp_type_ok(n.type) || (n.op == MI355Q_EX_MOD && n.type == MI355Q_DOUBLE)) return false;
         s.kind = RP_BIN;
         if (ex_is_int(n.type) || n.op == MI355Q_EX_DIV) p.can_raise = 1;
+        if (n.op == MI355Q_EX_DIV || n.op == MI355Q_EX_MOD) p.has_divmod = 1;
         depth = 1;
         types[0] = n.type;
         nulls[0] = (n.flags & EXF_NULLABLE) != 0;
@@ -177,8 +180,15 @@ MQ_HD int64_t rp_cast(int flags, int64_t v, int32_t& ev) {
 }
 
 // one step's operation on J rows; `s` is wave-uniform (an LDS or scalar copy of the step)
+// (the rows of one step run one AFTER the other: left to itself the scheduler interleaves the J copies of a member — four
+// 64-bit divisions at once — and the kernel around it pays with its registers: k_filter_mask 172 VGPRs, two waves per SIMD)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RP_ROW_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define RP_ROW_FENCE ((void)0)
+#endif
 #define RP_ROWS(expr)                        \
-  _Pragma("unroll") for (int j = 0; j < J; ++j) { expr; }
+  _Pragma("unroll") for (int j = 0; j < J; ++j) { expr; RP_ROW_FENCE; }
 template <int J>
 MQ_HD void rp_apply_unary(const RpStep& s, int64_t (&v)[J], int32_t (&ev)[J]) {
   const int fl = s.flags;
@@ -236,7 +246,9 @@ MQ_HD void rp_apply_unary(const RpStep& s, int64_t (&v)[J], int32_t (&ev)[J]) {
     }
   }
 }
-template <int J>
+// DIVMOD = false: a consumer whose programs never divide (the division members are the large ones: four rows of a 64-bit
+// division inlined into a streaming kernel cost it its registers)
+template <int J, bool DIVMOD>
 MQ_HD void rp_apply_binary(const RpStep& s, int64_t (&x)[J], const int64_t (&y)[J], int32_t (&ex)[J], const int32_t (&ey)[J]) {
   const int fl = s.flags;
   RP_ROWS(if (!ex[j]) ex[j] = ey[j])  // (lhs first, then rhs, then this operation)
@@ -251,16 +263,23 @@ MQ_HD void rp_apply_binary(const RpStep& s, int64_t (&x)[J], const int64_t (&y)[
     RP_BIN_T(MI355Q_EX_ADD)
     RP_BIN_T(MI355Q_EX_SUB)
     RP_BIN_T(MI355Q_EX_MUL)
-    RP_BIN_T(MI355Q_EX_DIV)
     RP_BIN_T(MI355Q_EX_EQ)
     RP_BIN_T(MI355Q_EX_NE)
     RP_BIN_T(MI355Q_EX_LT)
     RP_BIN_T(MI355Q_EX_LE)
     RP_BIN_T(MI355Q_EX_GT)
     RP_BIN_T(MI355Q_EX_GE)
-    default:  // MI355Q_EX_MOD: integers only
-      if (t == MI355Q_INT32) { RP_ROWS(x[j] = (rp_binary<MI355Q_EX_MOD, MI355Q_INT32>(fl, x[j], y[j], ex[j]))) }
-      else { RP_ROWS(x[j] = (rp_binary<MI355Q_EX_MOD, MI355Q_INT64>(fl, x[j], y[j], ex[j]))) }
+    default:
+      if constexpr (DIVMOD) {
+        if (s.op == MI355Q_EX_DIV) {
+          if (t == MI355Q_INT32) { RP_ROWS(x[j] = (rp_binary<MI355Q_EX_DIV, MI355Q_INT32>(fl, x[j], y[j], ex[j]))) }
+          else if (t == MI355Q_INT64) { RP_ROWS(x[j] = (rp_binary<MI355Q_EX_DIV, MI355Q_INT64>(fl, x[j], y[j], ex[j]))) }
+          else { RP_ROWS(x[j] = (rp_binary<MI355Q_EX_DIV, MI355Q_DOUBLE>(fl, x[j], y[j], ex[j]))) }
+        } else {  // MI355Q_EX_MOD: integers only
+          if (t == MI355Q_INT32) { RP_ROWS(x[j] = (rp_binary<MI355Q_EX_MOD, MI355Q_INT32>(fl, x[j], y[j], ex[j]))) }
+          else { RP_ROWS(x[j] = (rp_binary<MI355Q_EX_MOD, MI355Q_INT64>(fl, x[j], y[j], ex[j]))) }
+        }
+      }
   }
 #undef RP_BIN_T
 }
@@ -268,7 +287,7 @@ MQ_HD void rp_apply_binary(const RpStep& s, int64_t (&x)[J], const int64_t (&y)[
 // The program for J rows of a lane.  vals[j][c] = operand slot c of row j; out[j] = the value (ex_wrap_int'ed to the
 // program's type), err[j] = 0 or the first error row j met in evaluation order (its value is then unspecified).
 // `p` should live in LDS (or constant memory): every field read is wave-uniform.
-template <int J, int NC>
+template <int J, int NC, bool DIVMOD = true>
 MQ_HD void rp_eval(const RegProg& p, const int64_t (&vals)[J][NC], int64_t (&out)[J], int32_t (&err)[J]) {
   int64_t x[J], y[J];
   int32_t ex[J], ey[J];
@@ -301,13 +320,32 @@ MQ_HD void rp_eval(const RegProg& p, const int64_t (&vals)[J][NC], int64_t (&out
       }
       case RP_LDX_LIT: RP_ROWS(x[j] = s.lit; ex[j] = 0) break;
       case RP_LDY_LIT: RP_ROWS(y[j] = s.lit; ey[j] = 0) break;
-      case RP_UNX: rp_apply_unary<J>(s, x, ex); break;
-      case RP_UNY: rp_apply_unary<J>(s, y, ey); break;
-      default: rp_apply_binary<J>(s, x, y, ex, ey);
+      case RP_UNX:
+      case RP_UNY: {  // ONE copy of the unary members: a step on y swaps the registers around it
+        const bool on_y = s.kind == RP_UNY;
+        if (on_y) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const int64_t tv = x[j]; x[j] = y[j]; y[j] = tv;
+            const int32_t te = ex[j]; ex[j] = ey[j]; ey[j] = te;
+          }
+        }
+        rp_apply_unary<J>(s, x, ex);
+        if (on_y) {
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const int64_t tv = x[j]; x[j] = y[j]; y[j] = tv;
+            const int32_t te = ex[j]; ex[j] = ey[j]; ey[j] = te;
+          }
+        }
+        break;
+      }
+      default: rp_apply_binary<J, DIVMOD>(s, x, y, ex, ey);
     }
   }
   RP_ROWS(out[j] = ex_wrap_int(p.type, x[j]); err[j] = ex[j])
 }
 #undef RP_ROWS
+#undef RP_ROW_FENCE
 
 }  // namespace mq

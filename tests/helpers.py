@@ -366,7 +366,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
     deps = [os.path.join(src_dir, f) for f in ("hip_host.cpp", "kernels_host.cpp", "shim/hip/hip_runtime.h",
                                                "shim/hip/hip_runtime_api.h")] + \
         [os.path.join(csrc, f) for f in ["api.cpp", "api_projection.cpp", "api_result.cpp", "api_join.cpp", "api_internal.h", "boolfilter.cpp", "boolfilter.h", "plan.cpp", "kernels_generic.hip",
-                                         "kernels_proj.hip", "kernels.h", "rowfunc.h", "dev_common.h", "plan.h", "expr.h",
+                                         "kernels_proj.hip", "kernels_filter.hip", "regprog.h", "kernels.h", "rowfunc.h", "dev_common.h", "plan.h", "expr.h",
                                          "fast_common.h"] + real_srcs] + \
         [os.path.join(ROOT, "include", "mi355q.h"), os.path.abspath(__file__)]   # (the build recipe patches the sources)
     if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
@@ -385,7 +385,9 @@ def hostsim_lib(real_fast: bool = False) -> str:
         names, plain = [], []
         with open(os.path.join(csrc, "kernels_proj.hip")) as f:
             kp_src = f.read()
-        for text in (kg, kp_src):
+        with open(os.path.join(csrc, "kernels_filter.hip")) as f:
+            kf_src = f.read()   # (the row-mask pre-pass of compiled filters: the real device source in both simulations, no dynamic LDS)
+        for text in (kg, kp_src, kf_src):
             for m in re.finditer(r"__global__[^{;]*?void\s+(k_\w+)\s*\(", text):
                 depth, i = 0, text.index("{", m.end())
                 start = i
@@ -413,10 +415,13 @@ def hostsim_lib(real_fast: bool = False) -> str:
         kp_cpp = os.path.join(out_dir, "kernels_proj_host.cpp")
         with open(kp_cpp, "w") as f:
             f.write(kp)
+        kf_cpp = os.path.join(out_dir, "kernels_filter_host.cpp")
+        with open(kf_cpp, "w") as f:
+            f.write(kf_src)
         srcs = [os.path.join(csrc, "api.cpp"), os.path.join(csrc, "api_projection.cpp"), os.path.join(csrc, "api_result.cpp"),
                 os.path.join(csrc, "api_join.cpp"), os.path.join(csrc, "boolfilter.cpp"),
                 os.path.join(csrc, "plan.cpp"), kg_cpp,
-                kp_cpp, os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
+                kp_cpp, kf_cpp, os.path.join(src_dir, "kernels_host.cpp"), os.path.join(src_dir, "hip_host.cpp")]
         if real_fast:
             flags.append("-DHOSTSIM_REAL_FAST")
             for name in ("kernels_fast.hip", "kernels_lds.hip", "kernels_part.hip", "kernels_sort.hip", "kernels_idx.hip"):

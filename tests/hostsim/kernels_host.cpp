@@ -144,7 +144,7 @@ bool scan_agg_eligible(const DevPlan& p, const FragView&) {
     if (p.quals[i].type != MI355Q_INT32 && p.quals[i].type != MI355Q_INT64) return false;
   return plain_aggs(p, 8);
 }
-hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int32_t*, int, hipStream_t, LaunchStats* st) {
+hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, int, hipStream_t, LaunchStats* st) {
   finish(p, fv, out, nullptr, st, "k_scan_agg", 0, F_SCAN_AGG);
   return hipSuccess;
 }

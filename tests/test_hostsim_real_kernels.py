@@ -829,8 +829,9 @@ def _prog_atom_case(name, grouped=True, typed=True, quals=(), n=30_011):
 @pytest.mark.parametrize("consumer", ["typed_lds", "generic_lds", "scan_agg"])
 @pytest.mark.parametrize("name", list(_prog_atom_shapes()))
 def test_program_atoms_in_compiled_filters(sim, oracle, name, consumer):
-    """filters whose leaves hold arithmetic, two columns or DOUBLE operands run inside the consuming kernel (no k_project
-    pass), values AND error codes as the oracle's node-by-node evaluation gives them"""
+    """filters whose leaves hold arithmetic, two columns or DOUBLE operands are compiled into program atoms: the row-mask pre-pass
+    (k_filter_mask) evaluates them, the consumer filters on one byte per row — no interpreter pass; values AND error codes as
+    the oracle's node-by-node evaluation gives them"""
     from heavydb_amd.executor import Executor
     case = _prog_atom_case(name, grouped=consumer != "scan_agg", typed=consumer == "typed_lds")
     route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
@@ -839,8 +840,8 @@ def test_program_atoms_in_compiled_filters(sim, oracle, name, consumer):
     if case.expect_error is None:
         kn = rs.report.kernel_name.decode()
         assert kn == ("k_scan_agg" if consumer == "scan_agg" else "k_groupby_lds"), kn
-        uses_double = name.startswith("double")
-        if consumer == "typed_lds" and not uses_double and name != "widened_product":
+        assert "k_filter_mask" in route, route   # the row-mask pre-pass; the consumer filters on `mask = 1` (one byte per row)
+        if consumer == "typed_lds":
             assert rs.report.variant == 5, rs.report.variant
         # the interpreter pass agrees
         flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_NO_COMPILED_FILTER)

@@ -60,3 +60,28 @@ def test_typed_members_under_a_compiled_filter_on_the_device(torch_cuda, oracle,
         assert rs.report.kernel_name.decode() == "k_groupby_lds" and rs.report.variant == 5, (rs.report.kernel_name, rs.report.variant)
         # the interpreter pass (MI355Q_OPT_NO_COMPILED_FILTER) agrees
         _run(torch_cuda, oracle, case, capi.OPT_NO_COMPILED_FILTER)
+
+
+# ---- round 6: program atoms (regprog.h) on the device — the shapes of test_program_atoms_in_compiled_filters at 2 M rows
+from tests.test_hostsim_real_kernels import _prog_atom_case, _prog_atom_shapes  # noqa: E402
+
+
+@pytest.mark.parametrize("consumer", ["typed_lds", "generic_lds", "scan_agg"])
+@pytest.mark.parametrize("name", list(_prog_atom_shapes()))
+def test_program_atoms_on_the_device(torch_cuda, oracle, name, consumer):
+    from heavydb_amd.executor import Executor, FetchResult
+    case = _prog_atom_case(name, grouped=consumer != "scan_agg", typed=consumer == "typed_lds", n=2_000_003)
+    route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
+    assert "filter compiled" in route and "k_project" not in route, route
+    if case.expect_error is not None:
+        q, want, code = oracle.execute(case.ra.to_plan(), case.frags, n_threads=8)
+        assert code == case.expect_error
+        frags = [[torch_cuda.from_numpy(np.ascontiguousarray(a)).cuda() for a in cols] for cols in case.frags]
+        fr = FetchResult([[int(t.data_ptr()) for t in cols] for cols in frags], [len(cols[0]) for cols in case.frags], keepalive=[frags])
+        with pytest.raises(capi.Mi355qError) as ei:
+            Executor(0).executeWorkUnit(case.ra, fr, allow_retry=False)
+        assert ei.value.code == case.expect_error, ei.value.code
+        return
+    rs = _run(torch_cuda, oracle, case)
+    assert rs.report.kernel_name.decode() == ("k_scan_agg" if consumer == "scan_agg" else "k_groupby_lds"), rs.report.kernel_name
+    _run(torch_cuda, oracle, case, capi.OPT_NO_COMPILED_FILTER)   # the interpreter pass agrees

@@ -8,6 +8,9 @@
     not_or          NOT (a < K OR b > L)
     guarded_div     b <> 0 AND a / b > 3                     the deferred qual: a short-circuit AND inside the expression
     composed        three bands ORed, as three expressions    a root that reads the values of two earlier expressions
+    sum_gt          a + b > 1 000 000                        round 6: program atoms (regprog.h) — arithmetic over two columns,
+    col_lt_col      a < b                                    a comparison of two columns,
+    affine          a * 3 - 7 <= 1 500 000                   a chain over one column
 
 over --rows rows (device-generated, 32 M-row fragments).  Fraction = the columns a step reads (4 B each) / time / 8 TB/s; the
 expression steps additionally write and re-read 1 B/row.  NOT RUN on the device yet: written in the last (GPU-less) session of
@@ -38,6 +41,10 @@ def shapes(capi, Expr, Qual):
         ("composed", [band(2, 100_000, 200_000), band(3, 300_000, 400_000),
                       band(4, 500_000, 600_000).logical(capi.EX_OR, C(nc)).logical(capi.EX_OR, C(nc + 1))], [Qual(nc + 2, capi.EQ, 1)],
          [0, 1, 2, 3, 4]),
+        # round 6: leaves with arithmetic / two columns (program atoms, regprog.h)
+        ("sum_gt", [C(2).add(C(3), I32).cmp(capi.EX_GT, L(1_000_000))], [Qual(nc, capi.EQ, 1)], [0, 1, 2, 3]),
+        ("col_lt_col", [C(2).cmp(capi.EX_LT, C(3))], [Qual(nc, capi.EQ, 1)], [0, 1, 2, 3]),
+        ("affine", [C(2).mul(L(3), I32).sub(L(7), I32).cmp(capi.EX_LE, L(1_500_000))], [Qual(nc, capi.EQ, 1)], [0, 1, 2]),
     ]
 
 
@@ -48,6 +55,7 @@ def main():
     ap.add_argument("--verify-rows", type=float, default=0, help="also check every shape against the oracle on a table of this many rows")
     ap.add_argument("--count-only", action="store_true", help="SELECT g, COUNT(*) ...: no value column (the NV = 0 typed members)")
     ap.add_argument("--generic-member", action="store_true", help="MI355Q_OPT_LDS_GENERIC_MEMBER: the run-time-role member of k_groupby_lds")
+    ap.add_argument("--only", default="", help="comma-separated shape names")
     ap.add_argument("--interpreted", action="store_true", help="MI355Q_OPT_NO_COMPILED_FILTER: every expression through k_project")
     args = ap.parse_args()
     import numpy as np
@@ -76,6 +84,8 @@ def main():
     ex = Executor(0)
     flags = (capi.OPT_NO_COMPILED_FILTER if args.interpreted else 0) | (capi.OPT_LDS_GENERIC_MEMBER if args.generic_member else 0)
     for name, exprs, quals, reads in shapes(capi, Expr, Qual):
+        if args.only and name not in args.only.split(','):
+            continue
         xs = [e.with_range(ExpressionRange(True, 0, 1, True)) for e in exprs]
         targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT)] + ([] if args.count_only else [TargetExpr(capi.SUM, 1)])
         ra = RelAlgExecutionUnit(descs, targets, quals, [0],

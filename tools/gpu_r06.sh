@@ -1,0 +1,24 @@
+#!/bin/bash
+# round 6: ONE script for every GPU call of the round.  usage: tools/gpu_r06.sh <step> [out-dir] [extra args]
+step=${1:-help}
+out=${2:-gpurun_out/r06_$step}
+mkdir -p $out
+export TMPDIR=/tmp PYTHONUNBUFFERED=1
+python -c "import torch; x=torch.zeros(4).cuda(); print('device ok', x.sum().item())" || { echo "no GPU"; exit 3; }
+case $step in
+  atoms)    # program atoms (regprog.h): the BOOLEAN-filter shapes incl. the arithmetic ones, compiled vs interpreted; device parity tests
+    timeout 600 python -u -m pytest tests/test_zz_gpu_typed_filters.py -m gpu -x -q -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
+    timeout 500 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --verify-rows 4e6 > $out/bool_filter_1b.jsonl 2> $out/bool_filter.err; echo "bool_filter exit $?"
+    cut -c1-300 $out/bool_filter_1b.jsonl; tail -5 $out/bool_filter.err
+    timeout 400 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --interpreted --only guarded_div,sum_gt,col_lt_col,affine > $out/bool_filter_1b_interpreted.jsonl 2>> $out/bool_filter.err; echo "interp exit $?"
+    cut -c1-300 $out/bool_filter_1b_interpreted.jsonl ;;
+  atomsprof) # per-kernel times of the program-atom shapes (rocprofv3 kernel trace)
+    cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
+    timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o atoms -- python tools/bool_filter_bench.py --rows 1e9 --steps 3 --only ${3:-guarded_div,sum_gt,col_lt_col,affine} > $out/bench.jsonl 2> $out/rocprof.err
+    find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/atoms_kernel_stats.csv \; ; rm -rf $out/trace; cut -c1-160 $out/atoms_kernel_stats.csv | head -12; cut -c1-200 $out/bench.jsonl ;;
+  suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
+    timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
+    echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200
+    python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 ;;
+  *) echo "unknown step $step"; exit 2 ;;
+esac
