@@ -2427,10 +2427,9 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
     if (compile_bool_filter(*plan, &bfh, &rest)) {
       const size_t mark = t_route ? t_route->size() : 0;
       int32_t e = kNotTaken;
-      if (bfh.bf.n_progs != 0) {  // program atoms: the row-mask pre-pass, then the step with `mask = 1`
-        route_note("filter compiled (atoms + programs + truth table)");
-        e = execute_masked(plan, rest, bfh, in, o, out, report, reserved);
-      } else {
+      const bool fused_progs = bfh.bf.n_progs == 0 || (bfh.bf.all_lean && bfh.bf.all_i32 && bfh.bf.n_progs <= kLdsFusedProgs &&
+                                                       !(o.flags & MI355Q_OPT_FILTER_PREPASS));
+      if (fused_progs) {
         DeviceGuard gb(in->device_id);
         DeviceCtx& cb = ctx_of(in->device_id);
         std::lock_guard<std::recursive_mutex> lb(cb.mu);
@@ -2450,6 +2449,12 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
         } else {
           (void)hipGetLastError();
         }
+      }
+      if (e == kNotTaken && bfh.bf.n_progs != 0) {  // program atoms no family evaluates itself: the row-mask pre-pass, then `mask = 1`
+        if (t_route) t_route->resize(mark);
+        *out = nullptr;
+        route_note("filter compiled (atoms + programs + truth table)");
+        e = execute_masked(plan, rest, bfh, in, o, out, report, reserved);
       }
       if (e != kNotTaken) {
         if (e == MI355Q_OK && report && !reserved) report->algorithmic_bytes = algorithmic_bytes(*plan, *in);

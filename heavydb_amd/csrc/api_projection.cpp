@@ -77,7 +77,11 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
     if (d.quals[k].or_group != 0 && d.quals[k].col >= n_phys) return MI355Q_ERR_UNSUPPORTED;
   ProjSpec ps;
   if (int32_t e = proj_spec_of(lp, n_phys, q, &ps)) return e;
+  ProjForms forms;
+  forms.ok = 0;
   if (plan->n_exprs != 0) {  // the device copy: every node with its typed handler (physical columns are loaded where they are read)
+    // (before the labelling rewrites the nodes: targets that are `[CAST](column) <op> literal` — the fast member's forms)
+    projection_forms(xs, ps, expr_qual_mask(*plan), &forms);
     const int deepest = xh_label_programs(&xs, false);
     ps.x_info = deepest | (xs.n << 8);
   }
@@ -177,7 +181,7 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
   FragView fv{d_cols, d_rows, in->col_buffers, in->num_rows, nf, nc, total_rows, max_frag_rows};
   if (ev_start) HIP_TRY(hipEventRecord(ev_start, s));
   unsigned long long* d_total = nullptr;
-  HIP_TRY(launch_projection(d, ps, d_xs, qmask, fv, (char*)ctx.projws + kExprArea, res->buf, d_err, &d_total, n_cus, s, &st));
+  HIP_TRY(launch_projection(d, ps, d_xs, qmask, fv, (char*)ctx.projws + kExprArea, res->buf, d_err, &d_total, n_cus, s, &st, &forms));
   if (ev_stop) HIP_TRY(hipEventRecord(ev_stop, s));
   // the error word and the match count come back together
   int64_t* h_ret = (int64_t*)(ctx.h_meta + ctx.meta_bytes);

@@ -414,6 +414,14 @@ bool compile_bool_filter(const mi355q_plan& plan, BoolFilterHost* out, mi355q_pl
     o.bf.prog[k] = c.progs[(size_t)k];
     o.bf.any_raise |= c.progs[(size_t)k].can_raise;
   }
+  o.bf.all_lean = npg > 0;
+  o.bf.all_i32 = 1;
+  for (int k = 0; k < o.bf.n_cols; ++k) o.bf.all_i32 = o.bf.all_i32 && o.bf.col_type[k] == MI355Q_INT32;
+  for (int k = 0; k < npg; ++k) {
+    const int32_t types[2] = {o.bf.col_type[o.bf.prog_op[k][0]], c.prog_ops[(size_t)k][1] >= 0 ? o.bf.col_type[o.bf.prog_op[k][1]] : MI355Q_INT32};
+    pair_atom_of(o.bf.prog[k], types, &o.bf.pair[k]);
+    o.bf.all_lean = o.bf.all_lean && o.bf.pair[k].lean;
+  }
   // ---- the truth table: the filter's own programs, run by the evaluator's functions, once per state vector
   int radix[kBfMaxAtoms];
   uint32_t n_states = 1;

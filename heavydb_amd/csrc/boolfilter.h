@@ -39,12 +39,107 @@ constexpr int kBfMaxAtoms = 8;
 constexpr int kBfMaxCols = 4;
 constexpr int kBfTableWords = 206;  // ceil(3^8 / 32)
 constexpr int kBfMaxProgs = 4;      // program atoms (they count towards kBfMaxAtoms)
+constexpr int kLdsFusedProgs = 2;   // lean program atoms the typed few-groups member (kernels_lds.hip) evaluates itself
 constexpr int kBfErrStates = 2048;  // state vectors of a filter whose atoms can raise (a nibble each)
 
 struct BoolAtom {
   int64_t lo, hi, null_val;
   int32_t negate, nullable;  // nullable: the column can hold null_val, and the atom is then NULL (IS NULL atoms: 0)
 };
+// A program atom in its LEAN form (round 6): the program is `a <cmp> b` over two INT32 columns, or `(a <op> b) <cmp> literal`
+// with a an INT32 column, b an INT32 column or literal and <op> one of + - * / % at INT32 — the shapes of `a / b > 3`,
+// `x + y > 100`, `a < b`.  pair_eval below states the same semantics as the program's steps (ex_arith / ex_divmod / ex_cmp,
+// expr.h) on 32-bit values instead of 64-bit patterns; tests/test_expr.py holds the two against each other on every edge.
+struct PairAtom {
+  int32_t lean;          // 1: this form states the program
+  int32_t op;            // 0: compare the two operands; else MI355Q_EX_ADD .. MI355Q_EX_MOD
+  int32_t ln, rn;        // the operands can be NULL (INT32_MIN)
+  int32_t b_is_lit, b_lit;
+  int32_t lo, hi, negate;  // the comparison as a range of the value (op 0: of sign(a - b))
+  int32_t pad_;
+};
+MQ_HD uint32_t pair_eval(const PairAtom& pa, int32_t a, int32_t bc, int32_t& err) {  // -> 0 FALSE, 1 TRUE, 2 NULL, 3 ERROR
+  const int32_t nul = INT32_MIN;
+  const int32_t b = pa.b_is_lit ? pa.b_lit : bc;
+  const bool ln = pa.ln != 0, rn = pa.rn != 0;
+  const bool is_null = (ln && a == nul) || (rn && b == nul);
+  int32_t v;
+  if (pa.op == 0) {
+    if (is_null) return 2u;
+    v = a < b ? -1 : a > b ? 1 : 0;
+  } else {
+    if (pa.op == MI355Q_EX_DIV || pa.op == MI355Q_EX_MOD) {
+      // DIV: a NULL pattern in EITHER operand skips the zero check as soon as one of them may be NULL; MOD tests first
+      const bool skip = pa.op == MI355Q_EX_DIV && (ln || rn) && (a == nul || b == nul);
+      if (!skip && b == 0) {
+        err = MI355Q_ERR_DIV_BY_ZERO;
+        return 3u;
+      }
+      if (is_null) return 2u;
+      if (b == 0) v = nul;
+      else if (b == -1) v = pa.op == MI355Q_EX_DIV ? (int32_t)(0u - (uint32_t)a) : 0;
+      else v = pa.op == MI355Q_EX_DIV ? a / b : a % b;
+    } else {
+      if (is_null) return 2u;
+      const int64_t r = pa.op == MI355Q_EX_ADD ? (int64_t)a + b : pa.op == MI355Q_EX_SUB ? (int64_t)a - b : (int64_t)a * b;
+      if (r > (int64_t)INT32_MAX || r < (int64_t)INT32_MIN) {
+        err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+        return 3u;
+      }
+      v = (int32_t)r;
+    }
+    if ((ln || rn) && v == nul) return 2u;  // (a value that is the NULL pattern, behind a nullable operand: the comparison's NULL)
+  }
+  bool in = v >= pa.lo && v <= pa.hi;
+  if (pa.negate) in = !in;
+  return in ? 1u : 0u;
+}
+// a compiled program -> its lean form (pa->lean = 0: not one of the shapes); col_type[slot] = the filter columns' types
+inline void pair_atom_of(const RegProg& p, const int32_t (&op_col_type)[2], PairAtom* pa) {
+  *pa = PairAtom{};
+  const RpStep* s = p.step;
+  if (p.n_steps < 3 || s[0].kind != RP_LDX_COL || op_col_type[0] != MI355Q_INT32 || s[0].arg != 0) return;
+  const bool b_col = s[1].kind == RP_LDY_COL, b_lit = s[1].kind == RP_LDY_LIT;
+  if (!b_col && !b_lit) return;
+  if (b_col && (op_col_type[1] != MI355Q_INT32 || s[1].arg != 1)) return;
+  if (b_lit && (s[1].type != MI355Q_INT32 || s[1].lit > INT32_MAX || s[1].lit < INT32_MIN)) return;
+  const RpStep* cmp;
+  int64_t c;
+  if (p.n_steps == 3 && b_col && s[2].kind == RP_BIN && s[2].op >= MI355Q_EX_EQ && s[2].op <= MI355Q_EX_GE && s[2].arg == MI355Q_INT32) {
+    cmp = &s[2];
+    pa->op = 0;
+    pa->ln = (s[2].flags & EXF_LHS_NULLABLE) != 0;
+    pa->rn = (s[2].flags & EXF_RHS_NULLABLE) != 0;
+    c = 0;
+  } else if (p.n_steps == 5 && s[2].kind == RP_BIN && s[2].op >= MI355Q_EX_ADD && s[2].op <= MI355Q_EX_MOD && s[2].type == MI355Q_INT32 &&
+             s[3].kind == RP_LDY_LIT && s[3].type == MI355Q_INT32 && s[4].kind == RP_BIN && s[4].op >= MI355Q_EX_EQ &&
+             s[4].op <= MI355Q_EX_GE && s[4].arg == MI355Q_INT32) {
+    cmp = &s[4];
+    pa->op = s[2].op;
+    pa->ln = (s[2].flags & EXF_LHS_NULLABLE) != 0;
+    pa->rn = (s[2].flags & EXF_RHS_NULLABLE) != 0;
+    // (the comparison's left side is NULL exactly where the arithmetic says so: its flag is the arithmetic's result flag)
+    if (((s[4].flags & EXF_LHS_NULLABLE) != 0) != (pa->ln || pa->rn) || (s[4].flags & EXF_RHS_NULLABLE)) return;
+    c = s[3].lit;
+  } else {
+    return;
+  }
+  pa->b_is_lit = b_lit;
+  pa->b_lit = b_lit ? (int32_t)s[1].lit : 0;
+  // the comparison as a range of the value: what make_range_filter states for `value <op> c` at INT32
+  DevQual dq{};
+  dq.op = cmp->op == MI355Q_EX_EQ ? MI355Q_EQ : cmp->op == MI355Q_EX_NE ? MI355Q_NE : cmp->op == MI355Q_EX_LT ? MI355Q_LT
+          : cmp->op == MI355Q_EX_LE ? MI355Q_LE : cmp->op == MI355Q_EX_GT ? MI355Q_GT : MI355Q_GE;
+  dq.type = MI355Q_INT32;
+  dq.ival = c;
+  fast::RangeFilter f;
+  if (!fast::make_range_filter(dq, &f)) return;
+  pa->lo = (int32_t)f.lo;
+  pa->hi = (int32_t)f.hi;
+  pa->negate = f.negate;
+  pa->lean = 1;
+}
+
 struct BoolFilter {
   int32_t n_cols, n_atoms;                         // n_atoms: the RANGE atoms (the program atoms follow them in the state index)
   int32_t col[kBfMaxCols], col_type[kBfMaxCols];  // physical column; MI355Q_INT32 / MI355Q_INT64 / MI355Q_DOUBLE (program operands only)
@@ -54,6 +149,8 @@ struct BoolFilter {
   // ---- program atoms (round 6); everything from here on is only copied into LDS when n_progs != 0
   int32_t n_progs, any_raise;
   int32_t prog_op[kBfMaxProgs][2];                 // the filter column behind operand slot 0 / 1 of each program
+  int32_t all_lean, all_i32;                       // every program has a lean form (PairAtom); every filter column is INT32
+  PairAtom pair[kBfMaxProgs];
   RegProg prog[kBfMaxProgs];
   uint32_t etable[kBfErrStates / 8];               // any_raise: per state vector 0, or 1 + the program atom whose error is the row's
 };

@@ -333,13 +333,31 @@ struct ProjSpec {
   int64_t entry_count;
   ProjTarget t[MI355Q_MAX_TARGETS];
 };
+// A Projection target that is `[CAST](column) <op> literal` (or a cast alone) over a plain INT32 / INT64 / DOUBLE column,
+// <op> one of + - * : evaluated by the FAST member on the quad it has loaded — one ex_cast / ex_arith (expr.h) per row
+// behind wave-uniform branches — instead of sending the whole step to the general member's interpreter (round 6; the
+// reference compiles target expressions into the row function, NativeCodegen.cpp:3455, ArithmeticIR.cpp:39-431)
+struct ProjForm {
+  int32_t on;                   // 1: this target is a form
+  int32_t src_col, src_code;    // the physical column it reads
+  int32_t cast_to, cast_flags;  // 0: no cast; else ex_cast from the column's type to this one
+  int32_t op, type, flags;      // 0: no operation; else MI355Q_EX_ADD / _SUB / _MUL at `type` (EXF_* of the node)
+  int32_t lit_first, can_raise; // literal <op> value; the form can raise error 7
+  int64_t lit;                  // the literal's pattern (ex_lit)
+};
+struct ProjForms {
+  int32_t ok, pad_;
+  ProjForm f[MI355Q_MAX_TARGETS];
+};
+// the forms of a Projection step's expression targets; ok = 0: some expression is not a form (or a qual reads one)
+void projection_forms(const DevExprSet& xs, const ProjSpec& ps, uint32_t qual_expr_mask, ProjForms* out);
 int64_t projection_tile_rows();
 int64_t projection_scratch_bytes(int n_frags, const int64_t* h_num_rows);
 // p: quals of the (lowered) plan; d_xs: the lowered expressions in DEVICE memory (or null); *d_total: device word that
 // holds the number of matching rows once the stream has drained
 hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExprSet* d_xs, uint32_t qual_expr_mask,
                              const FragView& fv, void* scratch, void* out, int32_t* d_err, unsigned long long** d_total,
-                             int n_cus, hipStream_t s, LaunchStats* st);
+                             int n_cus, hipStream_t s, LaunchStats* st, const ProjForms* forms = nullptr);
 hipError_t launch_projection_count_live(const int64_t* keys, int64_t stride_quads, int64_t entries, unsigned long long* d_count,
                                         hipStream_t s);
 

@@ -890,7 +890,7 @@ static bool scan_agg_args(const DevPlan& p, const FragView& fv, ScanAggArgs* a) 
   a->n_flt = merge_range_filters(a->flt, a->flt_type, p.n_quals);
   if (p.bf_active) {  // the compiled filter's columns take the filter slots
     const BoolFilter* bf = step_bool_filter();
-    if (!bf || p.n_quals != 0 || bf->n_cols > 4) return false;
+    if (!bf || p.n_quals != 0 || bf->n_cols > 4 || bf->n_progs != 0) return false;  // (program atoms: the row-mask pre-pass)
     for (int k = 0; k < bf->n_cols; ++k) {
       if (!all_aligned16(fv, bf->col[k])) return false;
       a->flt[k] = no_filter();

@@ -68,12 +68,96 @@ MQ_D void fm_values(const FilterMaskArgs& a, const v4i32 (&lo)[NF], const v4i32 
   }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FM_UNIFORM(x) __builtin_amdgcn_readfirstlane((int)(x))
+#else
+#define FM_UNIFORM(x) ((int)(x))
+#endif
+// what bf_quad_pass (boolfilter.h) reads of the filter per quad, read ONCE per workgroup into scalar registers: every one
+// of those reads is an LDS round trip the next one waits for, and a quad's evaluation is a chain of them (the first
+// version of this kernel ran 5.3 - 8.0 ms per 1 B rows with 3 waves per SIMD: latency, not bandwidth or arithmetic)
+struct FmMeta {
+  int n_progs;
+  uint32_t atoms_of;   // range atoms of filter column c: byte c
+  uint64_t prog_meta;  // program k: 16 bits — operand columns (4 bits each), can_raise (bit 8)
+};
+template <int NF>
+MQ_D uint32_t fm_quad_pass(const BoolFilter& bf, const FmMeta& mt, const int64_t (&vals)[4][NF], uint32_t valid, int32_t* err) {
+  uint32_t idx[4] = {0, 0, 0, 0}, mul = 1;
+  int ai = 0;
+#pragma unroll
+  for (int c = 0; c < NF; ++c) {
+    const int cnt = (int)((mt.atoms_of >> (8 * c)) & 255u);
+    for (int k = 0; k < cnt; ++k) {
+      const BoolAtom at = bf.atom[ai];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) idx[j] += bf_atom_state(at, vals[j][c]) * mul;
+      mul *= 3u;
+      ++ai;
+    }
+  }
+  uint32_t epack[4] = {0, 0, 0, 0};  // two bits per program atom: the error it raised (ex_err_enc)
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int k = 0; k < mt.n_progs; ++k) {
+    const uint32_t pm = (uint32_t)(mt.prog_meta >> (16 * k)) & 0xffffu;
+    const int ca = (int)(pm & 15u), cb = (int)((pm >> 4) & 15u);
+    int64_t ops[4][2], outv[4];
+    int32_t e4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ops[j][0] = vals[j][0];
+      ops[j][1] = vals[j][0];
+#pragma unroll
+      for (int c = 1; c < NF; ++c) {
+        if (ca == c) ops[j][0] = vals[j][c];
+        if (cb == c) ops[j][1] = vals[j][c];
+      }
+    }
+    rp_eval<4, 2>(bf.prog[k], ops, outv, e4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t st = e4[j] ? 3u : outv[j] == 1 ? 1u : outv[j] == 0 ? 0u : 2u;  // (anything else is the INT8 NULL)
+      idx[j] += st * mul;
+      epack[j] |= ex_err_enc(e4[j]) << (2 * k);
+    }
+    mul *= ((pm >> 8) & 1u) ? 4u : 3u;
+  }
+  uint32_t w4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w4[j] = bf.table[idx[j] >> 5];  // (four independent reads: one round trip)
+  uint32_t pass = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t bit = (w4[j] >> (idx[j] & 31u)) & 1u;
+    if (epack[j] && ((valid >> j) & 1u)) {  // rare: an atom of this row is in its ERROR state — is it the row's outcome?
+      const uint32_t nib = (bf.etable[idx[j] >> 3] >> ((idx[j] & 7u) * 4u)) & 15u;
+      if (nib) {
+        if (!*err) *err = ex_err_dec((epack[j] >> (2u * (nib - 1u))) & 3u);
+        bit = 0;
+      }
+    }
+    pass |= bit << j;
+  }
+  return pass & valid;
+}
+
 // NF: filter columns this member holds registers for
 template <int NF>
 __global__ __launch_bounds__(kFmBlock) void k_filter_mask(FilterMaskArgs a) {
   __shared__ BoolFilter s_bf;
   bf_load(a.bf, &s_bf, threadIdx.x, kFmBlock);
   __syncthreads();
+  FmMeta mt;
+  mt.n_progs = FM_UNIFORM(s_bf.n_progs);
+  mt.atoms_of = 0;
+  mt.prog_meta = 0;
+#pragma unroll
+  for (int c = 0; c < kBfMaxCols; ++c) mt.atoms_of |= (uint32_t)FM_UNIFORM(c < s_bf.n_cols ? s_bf.atoms_of_col[c] : 0) << (8 * c);
+#pragma unroll
+  for (int k = 0; k < kBfMaxProgs; ++k)
+    mt.prog_meta |= (uint64_t)(uint32_t)FM_UNIFORM((s_bf.prog_op[k][0] & 15) | ((s_bf.prog_op[k][1] & 15) << 4) | (s_bf.prog[k].can_raise ? 256 : 0)) << (16 * k);
   int32_t err = 0;
   const int64_t gtid = (int64_t)blockIdx.x * kFmBlock + threadIdx.x;
   const int64_t gsize = (int64_t)gridDim.x * kFmBlock;
@@ -121,7 +205,7 @@ __global__ __launch_bounds__(kFmBlock) void k_filter_mask(FilterMaskArgs a) {
       int64_t vals[4][NF];
       fm_values<NF>(a, lo_c, hi_c, vals);
       const uint32_t valid = q < nq ? 15u : (1u << (int)(n & 3)) - 1u;
-      const uint32_t m = bf_quad_pass<NF>(s_bf, vals, valid, &err);
+      const uint32_t m = fm_quad_pass<NF>(s_bf, mt, vals, valid, &err);
       // one byte per row: 1 = the row passes
       const uint32_t w = (m & 1u) | ((m & 2u) << 7) | ((m & 4u) << 14) | ((m & 8u) << 21);
       __builtin_nontemporal_store(w, (MQ_GLOBAL uint32_t*)out + q);
@@ -130,6 +214,170 @@ __global__ __launch_bounds__(kFmBlock) void k_filter_mask(FilterMaskArgs a) {
         lo_c[k] = lo_n[k];
         hi_c[k] = hi_n[k];
       }
+    }
+  }
+  if (err) atomicCAS(a.d_err, 0, err);
+}
+
+// ---- the LEAN member: every filter column a plain INT32, every program a PairAtom (boolfilter.h): `a <cmp> b`,
+// `(a <op> b) <cmp> literal` at INT32.  Values stay 32 bits wide, a program is ONE typed operation per row behind a few
+// scalar branches (no steps, no register selects per step), the tile loop is uniform (a workgroup walks tiles of kFmBlock
+// quads, the next tile's loads in flight while this one's rows are looked at).
+constexpr int kFmHoisted = 2;  // pair atoms kept in scalar registers for the whole kernel (the rest are read per quad)
+struct FmPairs {
+  PairAtom pa[kFmHoisted];
+};
+template <int NF>
+MQ_D uint32_t fm_quad_pass_i32(const BoolFilter& bf, const FmMeta& mt, const FmPairs& hp, const v4i32 (&col)[NF], uint32_t valid, int32_t* err) {
+  uint32_t idx[4] = {0, 0, 0, 0}, mul = 1;
+  int ai = 0;
+#pragma unroll
+  for (int c = 0; c < NF; ++c) {
+    const int cnt = (int)((mt.atoms_of >> (8 * c)) & 255u);
+    for (int k = 0; k < cnt; ++k) {
+      const BoolAtom at = bf.atom[ai];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) idx[j] += bf_atom_state(at, (int64_t)fm_v4(col[c], j)) * mul;
+      mul *= 3u;
+      ++ai;
+    }
+  }
+  uint32_t epack[4] = {0, 0, 0, 0};
+#if defined(__HIPCC__)
+#pragma unroll 1
+#endif
+  for (int k = 0; k < mt.n_progs; ++k) {
+    const uint32_t pm = (uint32_t)(mt.prog_meta >> (16 * k)) & 0xffffu;
+    const int ca = (int)(pm & 15u), cb = (int)((pm >> 4) & 15u);
+    PairAtom pa;
+    if (k == 0) {
+      pa = hp.pa[0];
+    } else if (k == 1) {
+      pa = hp.pa[1];
+    } else {
+      pa = bf.pair[k];
+      pa.op = FM_UNIFORM(pa.op);
+      pa.ln = FM_UNIFORM(pa.ln);
+      pa.rn = FM_UNIFORM(pa.rn);
+      pa.b_is_lit = FM_UNIFORM(pa.b_is_lit);
+      pa.b_lit = FM_UNIFORM(pa.b_lit);
+      pa.lo = FM_UNIFORM(pa.lo);
+      pa.hi = FM_UNIFORM(pa.hi);
+      pa.negate = FM_UNIFORM(pa.negate);
+    }
+    v4i32 av = col[0], bv = col[0];
+#pragma unroll
+    for (int c = 1; c < NF; ++c) {
+      if (ca == c) av = col[c];
+      if (cb == c) bv = col[c];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int32_t e = 0;
+      const uint32_t st = pair_eval(pa, fm_v4(av, j), fm_v4(bv, j), e);
+      idx[j] += st * mul;
+      epack[j] |= ex_err_enc(e) << (2 * k);
+    }
+    mul *= ((pm >> 8) & 1u) ? 4u : 3u;
+  }
+  uint32_t w4[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w4[j] = bf.table[idx[j] >> 5];  // (four independent reads: one round trip)
+  uint32_t pass = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t bit = (w4[j] >> (idx[j] & 31u)) & 1u;
+    if (epack[j] && ((valid >> j) & 1u)) {  // rare: an atom of this row is in its ERROR state — is it the row's outcome?
+      const uint32_t nib = (bf.etable[idx[j] >> 3] >> ((idx[j] & 7u) * 4u)) & 15u;
+      if (nib) {
+        if (!*err) *err = ex_err_dec((epack[j] >> (2u * (nib - 1u))) & 3u);
+        bit = 0;
+      }
+    }
+    pass |= bit << j;
+  }
+  return pass & valid;
+}
+
+template <int NF>
+__global__ __launch_bounds__(kFmBlock) void k_filter_mask_i32(FilterMaskArgs a) {
+  __shared__ BoolFilter s_bf;
+  bf_load(a.bf, &s_bf, threadIdx.x, kFmBlock);
+  __syncthreads();
+  FmMeta mt;
+  mt.n_progs = FM_UNIFORM(s_bf.n_progs);
+  mt.atoms_of = 0;
+  mt.prog_meta = 0;
+#pragma unroll
+  for (int c = 0; c < kBfMaxCols; ++c) mt.atoms_of |= (uint32_t)FM_UNIFORM(c < s_bf.n_cols ? s_bf.atoms_of_col[c] : 0) << (8 * c);
+#pragma unroll
+  for (int k = 0; k < kBfMaxProgs; ++k)
+    mt.prog_meta |= (uint64_t)(uint32_t)FM_UNIFORM((s_bf.prog_op[k][0] & 15) | ((s_bf.prog_op[k][1] & 15) << 4) | (s_bf.prog[k].can_raise ? 256 : 0)) << (16 * k);
+  FmPairs hp;
+#pragma unroll
+  for (int k = 0; k < kFmHoisted; ++k) {
+    const PairAtom& src = s_bf.pair[k];
+    hp.pa[k] = PairAtom{};
+    hp.pa[k].op = FM_UNIFORM(src.op);
+    hp.pa[k].ln = FM_UNIFORM(src.ln);
+    hp.pa[k].rn = FM_UNIFORM(src.rn);
+    hp.pa[k].b_is_lit = FM_UNIFORM(src.b_is_lit);
+    hp.pa[k].b_lit = FM_UNIFORM(src.b_lit);
+    hp.pa[k].lo = FM_UNIFORM(src.lo);
+    hp.pa[k].hi = FM_UNIFORM(src.hi);
+    hp.pa[k].negate = FM_UNIFORM(src.negate);
+  }
+  int32_t err = 0;
+  const int tid = threadIdx.x;
+  for (int f = 0; f < a.n_frags; ++f) {
+    const int8_t* const* fc = a.cols + (size_t)f * a.n_cols_table;
+    const int64_t n = a.num_rows[f];
+    const int64_t nq = n >> 2;
+    uint32_t* const out = (uint32_t*)a.mask[f];
+    const int8_t* base[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) base[k] = k < a.n_flt ? fc[a.col[k]] : nullptr;
+    const int64_t n_tiles = (nq + kFmBlock - 1) / kFmBlock;
+    auto load_tile = [&](int64_t t, v4i32 (&col)[NF]) {
+      const int64_t q = t * kFmBlock + tid;
+      if (q < nq) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k)
+          if (k < a.n_flt) col[k] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)base[k] + q);
+      }
+    };
+    v4i32 cur[NF], nxt[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) cur[k] = nxt[k] = v4i32{0, 0, 0, 0};
+    int64_t t = (blockIdx.x + (int64_t)f * 7) % gridDim.x;
+    if (t < n_tiles) load_tile(t, nxt);
+    for (; t < n_tiles; t += gridDim.x) {  // (uniform)
+#pragma unroll
+      for (int k = 0; k < NF; ++k) cur[k] = nxt[k];
+      if (t + gridDim.x < n_tiles) load_tile(t + gridDim.x, nxt);
+      const int64_t q = t * kFmBlock + tid;
+      const uint32_t m = fm_quad_pass_i32<NF>(s_bf, mt, hp, cur, q < nq ? 15u : 0u, &err);
+      const uint32_t w = (m & 1u) | ((m & 2u) << 7) | ((m & 4u) << 14) | ((m & 8u) << 21);
+      if (q < nq) __builtin_nontemporal_store(w, (MQ_GLOBAL uint32_t*)out + q);
+    }
+    // the fragment's last, partial quad: its rows one by one (a row past the end repeats the last one and is not valid)
+    if ((n & 3) && blockIdx.x == (unsigned)(f % (int)gridDim.x) && tid == 0) {
+      const int left = (int)(n & 3);
+      v4i32 col[NF];
+#pragma unroll
+      for (int k = 0; k < NF; ++k) {
+        col[k] = v4i32{0, 0, 0, 0};
+        if (k < a.n_flt) {
+          const int64_t p0 = nq << 2;
+          col[k].x = load_one<int32_t>(base[k], p0);
+          col[k].y = load_one<int32_t>(base[k], p0 + (left > 1 ? 1 : 0));
+          col[k].z = load_one<int32_t>(base[k], p0 + (left > 2 ? 2 : left - 1));
+          col[k].w = col[k].z;
+        }
+      }
+      const uint32_t m = fm_quad_pass_i32<NF>(s_bf, mt, hp, col, (1u << left) - 1u, &err);
+      const uint32_t w = (m & 1u) | ((m & 2u) << 7) | ((m & 4u) << 14) | ((m & 8u) << 21);
+      out[nq] = w;
     }
   }
   if (err) atomicCAS(a.d_err, 0, err);
@@ -168,7 +416,10 @@ hipError_t launch_filter_mask(const BoolFilter& bf, const BoolFilter* d_bf, cons
   int64_t grid = (int64_t)n_cus * 8;
   if (grid > want) grid = want;
   if (grid < 1) grid = 1;
-  if (bf.n_cols <= 2) hipLaunchKernelGGL(k_filter_mask<2>, dim3((unsigned)grid), dim3(kFmBlock), 0, s, a);
+  const bool lean = bf.all_lean && bf.all_i32 && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
+  if (lean && bf.n_cols <= 2) hipLaunchKernelGGL(k_filter_mask_i32<2>, dim3((unsigned)grid), dim3(kFmBlock), 0, s, a);
+  else if (lean) hipLaunchKernelGGL(k_filter_mask_i32<kBfMaxCols>, dim3((unsigned)grid), dim3(kFmBlock), 0, s, a);
+  else if (bf.n_cols <= 2) hipLaunchKernelGGL(k_filter_mask<2>, dim3((unsigned)grid), dim3(kFmBlock), 0, s, a);
   else hipLaunchKernelGGL(k_filter_mask<kBfMaxCols>, dim3((unsigned)grid), dim3(kFmBlock), 0, s, a);
   return hipGetLastError();
 }

@@ -617,8 +617,82 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
       fnv[c] = (int32_t)a.flt[c].null_val;
     }
   }
+  int32_t bf_err = 0;  // the error a program atom of the compiled filter raised for one of this lane's rows
+  // a compiled filter's LEAN program atoms (boolfilter.h PairAtom: `a / b > 3`, `x + y > 100`, `a < b` over INT32 columns):
+  // at most kLdsFusedProgs, read once into scalar registers; a row evaluates each with ONE 32-bit operation (pair_eval)
+  int n_fprog = 0;
+  uint32_t f_atoms_of = 0;
+  PairAtom fpa[kLdsFusedProgs];
+  int fca[kLdsFusedProgs], fcb[kLdsFusedProgs];
+  bool fraise[kLdsFusedProgs];
+#pragma unroll
+  for (int k = 0; k < kLdsFusedProgs; ++k) {
+    fpa[k] = PairAtom{};
+    fca[k] = fcb[k] = 0;
+    fraise[k] = false;
+  }
+  if constexpr (FM != 0) {
+    if (a.bf_on) {
+      n_fprog = MQ_WAVE_UNIFORM(s_bf.n_progs);
+      if (n_fprog) {
+#pragma unroll
+        for (int c = 0; c < TF; ++c) f_atoms_of |= (uint32_t)MQ_WAVE_UNIFORM(c < s_bf.n_cols ? s_bf.atoms_of_col[c] : 0) << (8 * c);
+#pragma unroll
+        for (int k = 0; k < kLdsFusedProgs; ++k) {
+          const PairAtom& src = s_bf.pair[k];
+          fpa[k].op = MQ_WAVE_UNIFORM(src.op);
+          fpa[k].ln = MQ_WAVE_UNIFORM(src.ln);
+          fpa[k].rn = MQ_WAVE_UNIFORM(src.rn);
+          fpa[k].b_is_lit = MQ_WAVE_UNIFORM(src.b_is_lit);
+          fpa[k].b_lit = MQ_WAVE_UNIFORM(src.b_lit);
+          fpa[k].lo = MQ_WAVE_UNIFORM(src.lo);
+          fpa[k].hi = MQ_WAVE_UNIFORM(src.hi);
+          fpa[k].negate = MQ_WAVE_UNIFORM(src.negate);
+          fca[k] = MQ_WAVE_UNIFORM(s_bf.prog_op[k][0]);
+          fcb[k] = MQ_WAVE_UNIFORM(s_bf.prog_op[k][1]);
+          fraise[k] = MQ_WAVE_UNIFORM(s_bf.prog[k].can_raise) != 0;
+        }
+      }
+    }
+  }
   auto row_passes = [&](const int32_t (&fv)[TF]) -> bool {
     if constexpr (FM == 0) return true;
+    if (a.bf_on && n_fprog) {
+      uint32_t idx = 0, mul = 1, ep = 0;
+      int ai = 0;
+#pragma unroll
+      for (int c = 0; c < TF; ++c) {
+        const int cnt = (int)((f_atoms_of >> (8 * c)) & 255u);
+        for (int k = 0; k < cnt; ++k) {
+          idx += bf_atom_state(s_bf.atom[ai], (int64_t)fv[c]) * mul;
+          mul *= 3u;
+          ++ai;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kLdsFusedProgs; ++k) {
+        if (k >= n_fprog) break;
+        int32_t av = fv[0], bv = fv[0];
+#pragma unroll
+        for (int c = 1; c < TF; ++c) {
+          if (fca[k] == c) av = fv[c];
+          if (fcb[k] == c) bv = fv[c];
+        }
+        int32_t e = 0;
+        idx += pair_eval(fpa[k], av, bv, e) * mul;
+        ep |= ex_err_enc(e) << (2 * k);
+        mul *= fraise[k] ? 4u : 3u;
+      }
+      bool bit = (s_bf.table[idx >> 5] >> (idx & 31u)) & 1u;
+      if (ep) {  // rare: an atom of this row is in its ERROR state — is it the row's outcome?
+        const uint32_t nib = (s_bf.etable[idx >> 3] >> ((idx & 7u) * 4u)) & 15u;
+        if (nib) {
+          if (!bf_err) bf_err = ex_err_dec((ep >> (2u * (nib - 1u))) & 3u);
+          bit = false;
+        }
+      }
+      return bit;
+    }
     if (a.bf_on) {
       int64_t vals[TF];
 #pragma unroll
@@ -848,6 +922,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
     }
   }
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
+  if (bf_err) atomicCAS(d_err, 0, bf_err);  // a program atom of the compiled filter raised (error 7 / error 1)
   if (t == 0 && kBase && *(volatile int32_t*)(d_err + 1)) *s_full = 1u;
   __syncthreads();
   if (*s_full) return;  // a lost attempt is neither folded nor flushed
@@ -1067,6 +1142,7 @@ bool make_lds_args(const DevPlan& p, const FragView& fv, int n_cus, LdsArgs* out
   // range filters than that (e.g. x <> 1 AND … AND x <> 5: negated quals do not merge) goes to another family instead of
   // running with the quals past the fourth dropped
   if (!a.typed && a.n_flt > kLdsGenericFlt) return false;
+  if (!a.typed && a.bf_on && step_bool_filter() && step_bool_filter()->n_progs != 0) return false;  // (program atoms: the typed member or the pre-pass)
   return a.n_flt + a.n_keys + a.n_vals <= 8;
 }
 

@@ -27,9 +27,11 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstring>
 #include <vector>
 
 #include "expr.h"
+#include "regprog.h"
 #include "fast_common.h"
 #include "kernels.h"
 #include "rowfunc.h"
@@ -380,7 +382,33 @@ struct FastArgs {
   int32_t out16, pad_;
   int32_t tw[MI355Q_MAX_TARGETS];        // columnar: bytes of the target's slot (8 or 4)
   int64_t tcol_off[MI355Q_MAX_TARGETS];  // columnar: byte offset of the slot column
+  // targets that are forms (kernels.h ProjForm): tcol / tkind describe the column the form READS (kind 0 or 1)
+  int32_t any_form, pad2_;
+  int32_t f_on[MI355Q_MAX_TARGETS], f_src_type[MI355Q_MAX_TARGETS], f_cast_to[MI355Q_MAX_TARGETS], f_cast_flags[MI355Q_MAX_TARGETS];
+  int32_t f_op[MI355Q_MAX_TARGETS], f_type[MI355Q_MAX_TARGETS], f_flags[MI355Q_MAX_TARGETS], f_lit_first[MI355Q_MAX_TARGETS];
+  int64_t f_lit[MI355Q_MAX_TARGETS];
+  int32_t* d_err;
 };
+// one row of a form target: the column's value (ex_col: integers sign-extended, DOUBLE as its bits) -> the target's value
+MQ_D int64_t form_eval(int cast_from, int cast_to, int cast_flags, int op, int type, int flags, bool lit_first, int64_t lit, int64_t v,
+                       int32_t& ev) {
+  if (cast_to) {
+    DevExprNode n{};
+    n.op = MI355Q_EX_CAST;
+    n.arg = cast_from;
+    n.type = cast_to;
+    n.flags = cast_flags;
+    v = ex_cast(n, v, ev);
+  }
+  if (op) {
+    DevExprNode n{};
+    n.op = op;
+    n.type = type;
+    n.flags = flags;
+    v = lit_first ? ex_arith(n, lit, v, ev) : ex_arith(n, v, lit, ev);
+  }
+  return ex_wrap_int(op ? type : cast_to, v);
+}
 
 template <typename T>
 MQ_D bool range_pass(const fast::RangeFilter& f, T v);
@@ -433,6 +461,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
   constexpr int LH = NT > 3 ? 32 : 64;
   constexpr int kStageRows = LH * 4;
   char* const stage = s_stage + (size_t)wave * kStageRows * rq * 8;
+  int32_t err = 0;  // the error a form target raised for an emitted row
   // columnar: the stage holds the key run, then one run per target of its slot width
   int32_t run_off[NT + 1];
   run_off[0] = kStageRows * 8;
@@ -565,6 +594,21 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
           }
         }
       }
+      // targets that are forms: [CAST](column) <op> literal on the quad just loaded (wave-uniform branches on the form)
+      int32_t ferr[4] = {0, 0, 0, 0};
+      if (a.any_form && mm) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (!a.f_on[t]) continue;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int32_t e = 0;
+            vals[t][i] = form_eval(a.f_src_type[t], a.f_cast_to[t], a.f_cast_flags[t], a.f_op[t], a.f_type[t], a.f_flags[t],
+                                   a.f_lit_first[t] != 0, a.f_lit[t], vals[t][i], e);
+            if (e && !ferr[i]) ferr[i] = e;
+          }
+        }
+      }
       uint32_t step_off = 0;  // matches of the wave in the earlier steps of this iteration
 #pragma unroll
       for (int h = 0; h < 64 / LH; ++h) {
@@ -578,10 +622,13 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
         }
         if (step_cnt == 0) continue;  // (uniform)
         const bool in_step = LH == 64 || (lane >> 5) == h;
+        const int64_t wfirst = tile_base + s_cnt[u * kWaves + wave] + step_off;  // rank of the wave's first entry of this step
         // the wave's entries of this step, in rank order, into its stage ...
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (!in_step || !((mm >> i) & 1u)) continue;
+          // (the error of a form counts for a row that is EMITTED: one past the scan limit / the buffer's end is not)
+          if (ferr[i] && !err && wfirst + (int64_t)k < a.entry_count) err = ferr[i];
           if (!COL) {
             int64_t* row = (int64_t*)stage + (size_t)k * rq;
             row[0] = r + i;
@@ -600,7 +647,6 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
         // ... and out of it as contiguous runs: the wave's ranks are adjacent, so are its bytes (64 lanes x 8 / 16 bytes
         // per store instead of one small piece per line)
         __builtin_amdgcn_wave_barrier();
-        const int64_t wfirst = tile_base + s_cnt[u * kWaves + wave] + step_off;  // rank of the wave's first entry of this step
         int64_t n_rows = (int64_t)step_cnt;
         if (wfirst + n_rows > a.entry_count) n_rows = a.entry_count > wfirst ? a.entry_count - wfirst : 0;
         if (!COL) {
@@ -630,6 +676,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
       }
     }
   }
+  if (err) atomicCAS(a.d_err, 0, err);
 }
 
 // HJ: the step joins a one-to-one hash table (fast_quals is off: every row takes row_passes, which probes for an INNER
@@ -903,6 +950,63 @@ __global__ __launch_bounds__(kBlock) void k_proj_count_live(const int64_t* keys,
 
 int64_t projection_tile_rows() { return kTileRows; }
 
+void projection_forms(const DevExprSet& xs, const ProjSpec& ps, uint32_t qual_expr_mask, ProjForms* out) {
+  std::memset(out, 0, sizeof(*out));
+  if (qual_expr_mask != 0) return;  // (an expression inside a qual: the general member evaluates the filter's expressions)
+  uint32_t used = 0;
+  for (int t = 0; t < ps.n_targets; ++t) {
+    const ProjTarget& pt = ps.t[t];
+    if (pt.col < ps.n_phys_cols || pt.col >= kProjInnerCol) continue;
+    const int k = pt.col - ps.n_phys_cols;
+    if (k < 0 || k >= xs.n) return;
+    used |= 1u << k;
+    const DevExpr& e = xs.e[k];
+    ProjForm& f = out->f[t];
+    // [COL][CAST]? | [COL][CAST]?[LIT][op] | [LIT][COL][CAST]?[op]
+    int i = 0;
+    const bool lit_first = e.n_nodes >= 1 && e.nodes[0].op == MI355Q_EX_LIT;
+    const DevExprNode* lit = nullptr;
+    if (lit_first) lit = &e.nodes[i++];
+    if (i >= e.n_nodes || e.nodes[i].op != MI355Q_EX_COL) return;
+    const DevExprNode& col = e.nodes[i++];
+    const int code = (int)col.ilit;
+    if (col.arg < 0 || col.arg >= xs.n_cols || !rp_type_ok(code) || col.type != code) return;
+    f.src_col = col.arg;
+    f.src_code = code;
+    int cur = code;
+    if (i < e.n_nodes && e.nodes[i].op == MI355Q_EX_CAST) {
+      const DevExprNode& c = e.nodes[i++];
+      if (!rp_type_ok(c.type) || c.arg != cur) return;
+      f.cast_to = c.type;
+      f.cast_flags = c.flags & (EXF_NULLABLE | EXF_LHS_NULLABLE);
+      if (ex_is_int(c.type) && (!ex_is_int(cur) || plain_width(c.type) < plain_width(cur))) f.can_raise = 1;
+      cur = c.type;
+    }
+    if (i < e.n_nodes) {
+      if (!lit_first) {
+        if (e.nodes[i].op != MI355Q_EX_LIT) return;
+        lit = &e.nodes[i++];
+      }
+      if (i != e.n_nodes - 1) return;
+      const DevExprNode& op = e.nodes[i];
+      if (op.op != MI355Q_EX_ADD && op.op != MI355Q_EX_SUB && op.op != MI355Q_EX_MUL) return;
+      if (!lit || lit->arg != 0 || lit->type != op.type || cur != op.type || !rp_type_ok(op.type)) return;
+      f.op = op.op;
+      f.type = op.type;
+      f.flags = op.flags & (EXF_NULLABLE | EXF_LHS_NULLABLE | EXF_RHS_NULLABLE);
+      f.lit_first = lit_first;
+      f.lit = ex_lit(*lit);
+      if (ex_is_int(op.type)) f.can_raise = 1;
+    } else if (lit_first || !f.cast_to) {
+      return;  // (a literal alone, a bare column: not shapes a binding states as an expression)
+    }
+    if (e.type != (f.op ? f.type : f.cast_to)) return;
+    f.on = 1;
+  }
+  if (used != (xs.n >= 32 ? ~0u : (1u << xs.n) - 1u)) return;  // (an expression no target reads would still be evaluated — and could raise)
+  out->ok = 1;
+}
+
 int64_t projection_scratch_bytes(int n_frags, const int64_t* h_num_rows) {
   int64_t tiles = 0;
   for (int f = 0; f < n_frags; ++f) tiles += (h_num_rows[f] + kTileRows - 1) / kTileRows;
@@ -912,7 +1016,7 @@ int64_t projection_scratch_bytes(int n_frags, const int64_t* h_num_rows) {
 
 hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExprSet* d_xs, uint32_t qual_expr_mask,
                              const FragView& fv, void* scratch, void* out, int32_t* d_err, unsigned long long** d_total,
-                             int n_cus, hipStream_t s, LaunchStats* st) {
+                             int n_cus, hipStream_t s, LaunchStats* st, const ProjForms* forms) {
   char* sp = (char*)scratch;
   unsigned long long* counters = (unsigned long long*)sp;
   int64_t* tile_start = (int64_t*)(sp + 64);
@@ -979,8 +1083,10 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
   for (int t = 0; t < ps.n_targets; ++t)
     a.fast_targets = a.fast_targets && ps.t[t].col < ps.n_phys_cols && ps.t[t].col < 31 && ((a.vec_mask >> ps.t[t].col) & 1);
   // the fast row-wise member: range quals over plain INT32 / INT64 columns, plain 4- / 8-byte targets, aligned chunks
-  bool fast_ok = !d_xs && !a.row_quals && p.join_col < 0 && ps.n_targets >= 1 && ps.n_targets <= 8 && tune_knobs().pass_rows != -1;
+  const bool forms_ok = forms && forms->ok && !(tune_knobs().flags & MI355Q_OPT_LDS_GENERIC_MEMBER);
+  bool fast_ok = (!d_xs || forms_ok) && !a.row_quals && p.join_col < 0 && ps.n_targets >= 1 && ps.n_targets <= 8 && tune_knobs().pass_rows != -1;
   FastArgs fa{};
+  fa.d_err = d_err;
   for (int k = 0; k < p.n_quals && fast_ok; ++k) {
     const int c = p.quals[k].col;
     fast_ok = a.qmode[k] != 0 && c < ps.n_phys_cols && c < 31 && ((a.vec_mask >> c) & 1);
@@ -990,6 +1096,25 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
   }
   for (int t = 0; t < ps.n_targets && fast_ok; ++t) {
     const ProjTarget& pt = ps.t[t];
+    if (pt.col >= ps.n_phys_cols && pt.col < kProjInnerCol) {  // an expression: its form reads ONE plain column
+      const ProjForm& pf = forms->f[t];
+      fast_ok = forms_ok && pf.on && pf.src_col < ps.n_phys_cols && pf.src_col < 31 && ((a.vec_mask >> pf.src_col) & 1);
+      fa.tcol[t] = pf.src_col;
+      fa.tkind[t] = pf.src_code == MI355Q_INT32 ? 1 : 0;
+      fa.tw[t] = ps.columnar ? pt.width : 8;
+      fa.tcol_off[t] = pt.col_off;
+      fa.any_form = 1;
+      fa.f_on[t] = 1;
+      fa.f_src_type[t] = pf.src_code;
+      fa.f_cast_to[t] = pf.cast_to;
+      fa.f_cast_flags[t] = pf.cast_flags;
+      fa.f_op[t] = pf.op;
+      fa.f_type[t] = pf.type;
+      fa.f_flags[t] = pf.flags;
+      fa.f_lit_first[t] = pf.lit_first;
+      fa.f_lit[t] = pf.lit;
+      continue;
+    }
     fast_ok = pt.col < ps.n_phys_cols && pt.col < 31 && ((a.vec_mask >> pt.col) & 1) &&
               (pt.code == MI355Q_INT64 || pt.code == MI355Q_DOUBLE || pt.code == MI355Q_INT32 || pt.code == MI355Q_FLOAT);
     fa.tcol[t] = pt.col;

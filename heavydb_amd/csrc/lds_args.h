@@ -67,6 +67,9 @@ inline bool lds_describe(const DevPlan& p, const FragView& fv, int64_t max_entri
   if (p.bf_active) {  // the compiled filter's columns take the filter slots
     const BoolFilter* bf = step_bool_filter();
     if (!bf || p.n_quals != 0 || bf->n_cols > 4) return false;
+    // program atoms: only in their lean form (PairAtom: INT32 operands, one operation), at most kLdsFusedProgs of them, and
+    // only in the typed member (make_lds_args) — everything else takes the row-mask pre-pass (kernels_filter.hip)
+    if (bf->n_progs != 0 && !(bf->all_lean && bf->all_i32 && bf->n_progs <= kLdsFusedProgs)) return false;
     for (int k = 0; k < bf->n_cols; ++k) {
       if (!all_aligned16(fv, bf->col[k])) return false;
       a.flt[k] = no_filter();

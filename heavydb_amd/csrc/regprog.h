@@ -43,7 +43,7 @@ struct RpStep {
   int32_t type;      // the node's result type
   int32_t arg;       // RP_LD?_COL: operand slot; casts / comparisons / IS NULL: the operand's type (DevExprNode::arg)
   int32_t flags;     // EXF_* of the node
-  int32_t pad_;
+  uint32_t packed;   // kind | op << 4 | type << 9 | arg << 12 | flags << 15: what the device reads (one word, one readfirstlane)
   int64_t lit;       // RP_LD?_LIT
 };
 struct RegProg {
@@ -146,6 +146,10 @@ inline bool rp_compile(const DevExpr& e, int first, int last, int n_phys_cols, S
     if (!push_step(s)) return false;
   }
   if (depth != 1 || p.n_steps < 1) return false;
+  for (int i = 0; i < p.n_steps; ++i) {
+    RpStep& s = p.step[i];
+    s.packed = (uint32_t)s.kind | ((uint32_t)s.op << 4) | ((uint32_t)s.type << 9) | ((uint32_t)s.arg << 12) | ((uint32_t)s.flags << 15);
+  }
   p.type = types[0];
   p.nullable = nulls[0] ? 1 : 0;
   return true;
@@ -292,19 +296,35 @@ MQ_HD void rp_eval(const RegProg& p, const int64_t (&vals)[J][NC], int64_t (&out
   int64_t x[J], y[J];
   int32_t ex[J], ey[J];
   RP_ROWS(x[j] = 0; y[j] = 0; ex[j] = 0; ey[j] = 0)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int ns = __builtin_amdgcn_readfirstlane(p.n_steps);
+#else
   const int ns = p.n_steps;
+#endif
+  // a step is read ONE AHEAD of its use (an LDS round trip per step otherwise parks the wave: the steps of a program are a
+  // dependent chain), as one packed word + the literal
+  uint32_t pk_next = p.step[0].packed;
+  int64_t lit_next = p.step[0].lit;
 #if defined(__HIPCC__)
 #pragma unroll 1
 #endif
   for (int i = 0; i < ns; ++i) {
-    RpStep s = p.step[i];
 #if defined(__HIP_DEVICE_COMPILE__)
-    s.kind = __builtin_amdgcn_readfirstlane(s.kind);
-    s.op = __builtin_amdgcn_readfirstlane(s.op);
-    s.type = __builtin_amdgcn_readfirstlane(s.type);
-    s.arg = __builtin_amdgcn_readfirstlane(s.arg);
-    s.flags = __builtin_amdgcn_readfirstlane(s.flags);
+    const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)pk_next);
+#else
+    const uint32_t pk = pk_next;
 #endif
+    RpStep s;
+    s.lit = lit_next;
+    if (i + 1 < ns) {
+      pk_next = p.step[i + 1].packed;
+      lit_next = p.step[i + 1].lit;
+    }
+    s.kind = (int32_t)(pk & 15u);
+    s.op = (int32_t)((pk >> 4) & 31u);
+    s.type = (int32_t)((pk >> 9) & 7u);
+    s.arg = (int32_t)((pk >> 12) & 7u);
+    s.flags = (int32_t)((pk >> 15) & 15u);
     switch (s.kind) {
       case RP_LDX_COL:
       case RP_LDY_COL: {

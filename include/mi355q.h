@@ -547,6 +547,10 @@ typedef struct mi355q_exec_options {
                                             itself when it re-runs a step whose spill list overflowed) */
 #define MI355Q_OPT_NO_COMPILED_FILTER 256u /* BOOLEAN filters: the interpreter pass (k_project) even where the filter compiles
                                             into atoms + a truth table (tests and tools/bool_filter_bench.py compare the two) */
+#define MI355Q_OPT_FILTER_PREPASS 512u    /* compiled filters with program atoms (arithmetic / two-column leaves): the row-mask
+                                            pre-pass (k_filter_mask) even where the typed few-groups member evaluates the
+                                            atoms itself; with MI355Q_OPT_LDS_GENERIC_MEMBER the pre-pass's general member
+                                            (tests and tools/bool_filter_bench.py compare them) */
 
 /* per-call timing/selection report (what launchGpuCode logs,
  * QueryExecutionContext.cpp:334,364,579) */

@@ -162,6 +162,21 @@ def build_cases(scale: int = 1) -> List[ProjCase]:
           [Qual(1, capi.GT, 0)], [m // 2, m - m // 2], max_groups_buffer_entry_guess=m)
     add_x("expr_targets_columnar", xd, [x, y, z], [C_(0).add(C_(1), I32), C_(0).cast(capi.INT64).mul(L(capi.INT64, 1000), capi.INT64)], [3, 4, 0],
           [Qual(1, capi.GT, 0)], [m], max_groups_buffer_entry_guess=m, output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    # round 6: targets that are FORMS — [CAST](column) <op> literal — evaluated by the fast member on the quad it loads
+    I64 = capi.INT64
+    add_x("expr_form_targets", xd, [x, y, z], [C_(0).add(L(I32, 5), I32), C_(2).mul(L(F64, 2.5), F64), C_(0).cast(I64).mul(L(I64, 1000), I64),
+                                             L(I32, 10).sub(C_(1), I32), C_(1).cast(F64)], [3, 4, 5, 6, 7, 1],
+          [Qual(1, capi.GT, -10)], [m // 2 + 1, m - m // 2 - 1], max_groups_buffer_entry_guess=m)
+    add_x("expr_form_targets_columnar", xd, [x, y, z], [C_(0).add(L(I32, 5), I32), C_(2).sub(L(F64, 0.5), F64), C_(0).cast(I64).mul(L(I64, 1000), I64)],
+          [3, 4, 5, 2], [Qual(1, capi.GT, 0)], [m], max_groups_buffer_entry_guess=m, output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    # ... an overflow in an emitted row raises error 7; in a row the filter drops, or one past the LIMIT, none
+    big = x.astype(np.int32).copy()
+    big[m // 2:] = 2**31 - 3
+    add_x("expr_form_overflow_counts", xd, [big, y, z], [C_(0).add(L(I32, 5), I32)], [3], [Qual(1, capi.GE, -50)], [m], max_groups_buffer_entry_guess=m,
+          expect_error=capi.ERR_OVERFLOW_OR_UNDERFLOW)
+    add_x("expr_form_overflow_past_the_limit", xd, [big, y, z], [C_(0).add(L(I32, 5), I32)], [3, 1], [Qual(1, capi.GE, -50)], [m], scan_limit=50)
+    add_x("expr_form_overflow_filtered_out", xd, [big, np.where(np.arange(m) >= m // 2, -60, y).astype(np.int32), z], [C_(0).add(L(I32, 5), I32)], [3, 1],
+          [Qual(1, capi.GE, -50)], [m], max_groups_buffer_entry_guess=m)
     # WHERE x + y > 100 (a BOOLEAN expression = 1) AND y < 40; the CASE of a guarded division as output
     cond = C_(0).add(C_(1), I32).cmp(capi.EX_GT, L(I32, 100))
     guarded = Expr.case(C_(1).cmp(capi.EX_NE, L(I32, 0)), C_(0).div(C_(1), I32), L(I32, 0), I32)

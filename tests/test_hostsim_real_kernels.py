@@ -836,15 +836,79 @@ def test_program_atoms_in_compiled_filters(sim, oracle, name, consumer):
     case = _prog_atom_case(name, grouped=consumer != "scan_agg", typed=consumer == "typed_lds")
     route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
     assert "filter compiled" in route and "k_project" not in route, route
-    rs = flow._check(oracle, case, kernel_variant=0)
+    rs = flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_LDS_GENERIC_MEMBER if consumer == "generic_lds" else 0)
     if case.expect_error is None:
         kn = rs.report.kernel_name.decode()
         assert kn == ("k_scan_agg" if consumer == "scan_agg" else "k_groupby_lds"), kn
-        assert "k_filter_mask" in route, route   # the row-mask pre-pass; the consumer filters on `mask = 1` (one byte per row)
+        lean = name in ("guarded_div", "sum_of_two_columns", "column_vs_column", "nullable_column_vs_column", "modulo",
+                        "not_over_program_atom")
         if consumer == "typed_lds":
             assert rs.report.variant == 5, rs.report.variant
+            # lean atoms (INT32 operands, one operation) are evaluated by the typed member itself; the rest by the row-mask pre-pass
+            assert ("k_filter_mask" in route) == (not lean), (name, route)
+            # ... and the pre-pass (both of its members) agrees
+            flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_FILTER_PREPASS)
+            flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_FILTER_PREPASS | capi.OPT_LDS_GENERIC_MEMBER)
+        else:
+            assert "k_filter_mask" in route, route   # the consumer filters on `mask = 1` (one byte per row)
         # the interpreter pass agrees
         flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_NO_COMPILED_FILTER)
+
+
+@pytest.mark.parametrize("member", ["fused", "lean", "general"])
+@pytest.mark.parametrize("nullable", [False, True], ids=["notnull", "nullable"])
+@pytest.mark.parametrize("op", ["cmp2", "add", "sub", "mul", "div", "mod", "add_lit", "mul_lit", "div_lit", "mod_lit"])
+def test_pair_atoms_on_edge_values(sim, oracle, op, nullable, member):
+    """the LEAN form of a program atom (boolfilter.h pair_eval: 32-bit values) against the program's own steps (the general
+    member of the pre-pass, MI355Q_OPT_LDS_GENERIC_MEMBER) and the oracle, on every pair of INT32 edge values: first with the
+    rows that raise (the code must be the oracle's), then without them (the groups must be the oracle's)"""
+    from heavydb_amd.executor import Expr, ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.cases import Case
+    I32 = capi.INT32
+    edge = np.array([-2**31, -2**31 + 1, -65536, -7, -2, -1, 0, 1, 2, 3, 7, 46341, 65536, 2**31 - 2, 2**31 - 1], dtype=np.int64)
+    a, b = [x.ravel() for x in np.meshgrid(edge, edge)]
+    C_, L = Expr.col, lambda v: Expr.lit(I32, v)
+    lit = {"add_lit": 5, "mul_lit": 65536, "div_lit": -1, "mod_lit": 7}.get(op)
+    rhs = L(lit) if lit is not None else C_(2)
+    base = op.split("_")[0]
+    val = {"add": C_(1).add(rhs, I32), "sub": C_(1).sub(rhs, I32), "mul": C_(1).mul(rhs, I32), "div": C_(1).div(rhs, I32),
+           "mod": C_(1).mod(rhs, I32)}.get(base)
+    bb = np.full_like(b, lit) if lit is not None else b
+    with np.errstate(all="ignore"):
+        exact = {"add": a + bb, "sub": a - bb, "mul": a * bb}.get(base)
+    nul = -2**31
+    is_null = ((a == nul) | ((bb == nul) & (lit is None))) if nullable else np.zeros(len(a), bool)
+    if base in ("add", "sub", "mul"):
+        raises = ~is_null & ((exact > 2**31 - 1) | (exact < -2**31))
+    elif base == "div":
+        skip = (np.full(len(a), nullable) & ((a == nul) | (bb == nul)))
+        raises = ~skip & (bb == 0)
+    elif base == "mod":
+        raises = bb == 0
+    else:
+        raises = np.zeros(len(a), bool)
+    for cmp_op, k in ((capi.EX_GT, 3), (capi.EX_LE, -1), (capi.EX_NE, 0), (capi.EX_EQ, nul)):
+        e = C_(1).cmp(cmp_op, C_(2)) if op == "cmp2" else val.cmp(cmp_op, L(k))
+        for keep, expect_err in ((np.ones(len(a), bool), None), (~raises, 0)):
+            aa, b2 = a[keep].astype(np.int32), b[keep].astype(np.int32)
+            if len(aa) < 8:
+                continue
+            rep = 40   # (several quads per lane, a ragged end)
+            aa, b2 = np.tile(aa, rep)[:-3], np.tile(b2, rep)[:-3]
+            g = (np.arange(len(aa)) % 13).astype(np.int32)
+            descs = [InputColDescriptor(I32, False, ExpressionRange(True, 0, 12)),
+                     InputColDescriptor(I32, nullable, ExpressionRange(True, -2**31 + 1, 2**31 - 1, nullable)),
+                     InputColDescriptor(I32, nullable, ExpressionRange(True, -2**31 + 1, 2**31 - 1, nullable))]
+            ra = RelAlgExecutionUnit(descs, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT)], [Qual(3, capi.EQ, 1)], [0],
+                                     exprs=[e.with_range(ExpressionRange(True, 0, 1, True))], max_groups_buffer_entry_guess=64, num_tuples=len(aa))
+            h = len(aa) // 2 // 4 * 4
+            case = Case(f"{op}", ra, [[x[:h] for x in (g, aa, b2)], [x[h:] for x in (g, aa, b2)]])
+            q, want, code = oracle.execute(ra.to_plan(), case.frags, n_threads=2)
+            if expect_err == 0:
+                assert code == 0, (op, cmp_op, code)
+            case.expect_error = code if code else None
+            flow._check(oracle, case, kernel_variant=0, flags={"general": capi.OPT_LDS_GENERIC_MEMBER | capi.OPT_FILTER_PREPASS,
+                                                               "lean": capi.OPT_FILTER_PREPASS, "fused": 0}[member])
 
 
 def test_program_atoms_beside_plain_quals_and_range_atoms(sim, oracle):

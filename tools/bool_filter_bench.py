@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--count-only", action="store_true", help="SELECT g, COUNT(*) ...: no value column (the NV = 0 typed members)")
     ap.add_argument("--generic-member", action="store_true", help="MI355Q_OPT_LDS_GENERIC_MEMBER: the run-time-role member of k_groupby_lds")
     ap.add_argument("--only", default="", help="comma-separated shape names")
+    ap.add_argument("--prepass", action="store_true", help="MI355Q_OPT_FILTER_PREPASS: program atoms through the row-mask pre-pass even where the typed member evaluates them itself")
     ap.add_argument("--interpreted", action="store_true", help="MI355Q_OPT_NO_COMPILED_FILTER: every expression through k_project")
     args = ap.parse_args()
     import numpy as np
@@ -82,7 +83,7 @@ def main():
             [InputColDescriptor(capi.INT32, i == 4, ExpressionRange(True, 0, 999_999, False)) for i in range(1, 5)]
     fr = FetchResult(bufs, rows, keepalive=cols)
     ex = Executor(0)
-    flags = (capi.OPT_NO_COMPILED_FILTER if args.interpreted else 0) | (capi.OPT_LDS_GENERIC_MEMBER if args.generic_member else 0)
+    flags = (capi.OPT_NO_COMPILED_FILTER if args.interpreted else 0) | (capi.OPT_FILTER_PREPASS if args.prepass else 0) | (capi.OPT_LDS_GENERIC_MEMBER if args.generic_member else 0)
     for name, exprs, quals, reads in shapes(capi, Expr, Qual):
         if args.only and name not in args.only.split(','):
             continue
@@ -96,7 +97,7 @@ def main():
             best = rs.report.total_ms if best is None else min(best, rs.report.total_ms)
         if args.count_only:
             reads = [c for c in reads if c != 1]   # (no target reads the value column)
-        line = {"shape": name, "rows": n, "interpreted": bool(args.interpreted), "count_only": bool(args.count_only), "generic_member": bool(args.generic_member), "route": ex.explain(ra, rows, flags=flags), "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3),
+        line = {"shape": name, "rows": n, "interpreted": bool(args.interpreted), "prepass": bool(args.prepass), "count_only": bool(args.count_only), "generic_member": bool(args.generic_member), "route": ex.explain(ra, rows, flags=flags), "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3),
                 "bytes_per_row": 4 * len(reads), "whole_step_frac": round(4 * len(reads) * n / (best * 1e-3) / 8e12, 4),
                 "groups": rs.rowCount()}
         if args.verify_rows:

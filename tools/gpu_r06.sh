@@ -11,11 +11,21 @@ case $step in
     timeout 500 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --verify-rows 4e6 > $out/bool_filter_1b.jsonl 2> $out/bool_filter.err; echo "bool_filter exit $?"
     cut -c1-300 $out/bool_filter_1b.jsonl; tail -5 $out/bool_filter.err
     timeout 400 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --interpreted --only guarded_div,sum_gt,col_lt_col,affine > $out/bool_filter_1b_interpreted.jsonl 2>> $out/bool_filter.err; echo "interp exit $?"
-    cut -c1-300 $out/bool_filter_1b_interpreted.jsonl ;;
+    cut -c1-300 $out/bool_filter_1b_interpreted.jsonl
+    timeout 400 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --prepass --verify-rows 4e6 --only guarded_div,sum_gt,col_lt_col,affine > $out/bool_filter_1b_prepass.jsonl 2>> $out/bool_filter.err; echo "prepass exit $?"
+    cut -c1-300 $out/bool_filter_1b_prepass.jsonl ;;
   atomsprof) # per-kernel times of the program-atom shapes (rocprofv3 kernel trace)
     cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
     timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o atoms -- python tools/bool_filter_bench.py --rows 1e9 --steps 3 --only ${3:-guarded_div,sum_gt,col_lt_col,affine} > $out/bench.jsonl 2> $out/rocprof.err
     find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/atoms_kernel_stats.csv \; ; rm -rf $out/trace; cut -c1-160 $out/atoms_kernel_stats.csv | head -12; cut -c1-200 $out/bench.jsonl ;;
+  atomspmc) # k_filter_mask's instruction mix and stall split (SQ counters; one pass, kernel trace only)
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/pmc -o pmc -- python tools/bool_filter_bench.py --rows 1e9 --steps 1 --only ${3:-col_lt_col} > $out/pmc.log 2>&1
+    python tools/rocpd_stats.py $out/pmc/pmc_results.db > $out/pmc_stats.txt 2>&1; rm -rf $out/pmc; grep -E "k_filter_mask|k_groupby" $out/pmc_stats.txt | cut -c1-260; tail -3 $out/pmc.log ;;
+  projexpr) # Projection with expression targets: forms in the fast member next to the plain shape and the general member's interpreter
+    timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant plain > $out/proj_plain.jsonl 2> $out/err.log; echo "plain exit $?"
+    timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant expr > $out/proj_expr.jsonl 2>> $out/err.log; echo "expr exit $?"
+    timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant expr --generic-member > $out/proj_expr_interpreted.jsonl 2>> $out/err.log; echo "expr interp exit $?"
+    cut -c1-260 $out/proj_plain.jsonl $out/proj_expr.jsonl $out/proj_expr_interpreted.jsonl; tail -3 $out/err.log ;;
   suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
     timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200

@@ -29,6 +29,7 @@ def main():
                     help="general: the same shapes through the general member (pass_rows = -1); expr: the second target is v1 * 2.0 "
                          "and a third one v0 + 1 (expressions in registers); join: SELECT v.., d.w FROM t JOIN d ON t.fk = d.k "
                          "(d: 1 M rows, dense keys; fk = i32 >> 11)")
+    ap.add_argument("--generic-member", action="store_true", help="MI355Q_OPT_LDS_GENERIC_MEMBER: expression targets through the general member's interpreter even where they are forms of the fast member")
     args = ap.parse_args()
     import torch
     from heavydb_amd import capi, synth
@@ -42,7 +43,7 @@ def main():
         for n_out in [int(x) for x in args.cols.split(",")]:
             for columnar in ([False, True] if n_out == 3 else [False]):
                 ra, fr, info = synth.projection(torch, n, n_out, sel, columnar=columnar, cols_cache=cache)
-                opts = {}
+                opts = {"flags": capi.OPT_LDS_GENERIC_MEMBER} if args.generic_member else {}
                 if args.variant == "general":
                     opts["pass_rows"] = -1
                 elif args.variant == "expr":
