@@ -49,6 +49,29 @@ def test_projection_through_a_join_on_the_device(torch_cuda, oracle, case):
         assert rs.report.kernel_name.decode() == "k_proj_compact"
 
 
+@pytest.mark.parametrize("case", [c for c in JOIN_CASES if c.expect_error is None and not c.ra.scan_limit],
+                         ids=[c.name for c in JOIN_CASES if c.expect_error is None and not c.ra.scan_limit])
+def test_projection_through_a_join_on_the_device_agrees_with_sqlite(torch_cuda, case):
+    """the DEVICE's rows against SQLite's JOIN / LEFT JOIN over the same tables (the arbiter of the reference's own
+    ExecuteTest): a pin of the joined-row semantics that owes nothing to the oracle's restatement of the join loop"""
+    from heavydb_amd.executor import Executor
+    from tests.test_gpu_parity import _build_join
+    from tests.test_sqlite_semantics import _key, projection_rows_sqlite, rows_agree
+    hj, keep = _build_join(torch_cuda, case)
+    case.ra.join_table = hj
+    try:
+        rs = Executor(0).executeWorkUnit(case.ra, device_fetch_result(torch_cuda, case), allow_retry=False)
+    finally:
+        case.ra.join_table = None
+    q = rs.getQueryMemDesc()
+    iv, dv, nu = rs.fetch()
+    got = sorted((tuple(None if nu[r, t] else float(dv[r, t]) if q.target_is_fp[t] else int(iv[r, t]) for t in range(q.n_targets))
+                  for r in range(iv.shape[0])), key=_key)
+    fp = [bool(q.target_is_fp[t]) for t in range(q.n_targets)]
+    want = sorted((tuple(float(v) if f and v is not None else v for v, f in zip(r, fp)) for r in projection_rows_sqlite(case)), key=_key)
+    rows_agree(case, q, want, got)
+
+
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
 def test_projection_case_on_the_device(torch_cuda, oracle, case):
     rs = check_projection(oracle, case, lambda c: device_fetch_result(torch_cuda, c))
