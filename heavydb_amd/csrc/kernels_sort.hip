@@ -16,8 +16,6 @@
 // Ties at the k-th position are broken arbitrarily, as in the reference.
 #include <hip/hip_runtime.h>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>  // device radix sort of (order key, entry) pairs — the reference uses
-                                // thrust::sort_by_key at the same spot (ResultSetSortImpl.cu)
 
 #include "kernels.h"
 #include "rowfunc.h"
@@ -244,11 +242,43 @@ __global__ __launch_bounds__(kBlock) void k_sort_iota(uint32_t* __restrict__ per
   for (int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x; e < n; e += stride) perm[e] = (uint32_t)e;
 }
 
+// ---- the pairs sort: a hand-written ONE-SWEEP least-significant-digit radix sort of (64-bit order key, 32-bit entry index)
+// pairs (round 6; rounds 3-5 called rocprim::radix_sort_pairs here, the reference calls thrust::sort_by_key at the same
+// spot, ResultSetSortImpl.cu:40-60, InPlaceSortImpl.cu:29-75).  Eight passes of 8-bit digits over two ping-pong buffers:
+//   k_radix_hist   ONE pass over the keys: the 8 x 256 digit histograms (LDS atomics per workgroup, then global)
+//   k_radix_scan   per digit position the exclusive prefix of its histogram = where each digit value's run starts; a
+//                  position at which EVERY key holds the same digit is marked skipped (order keys of counts, small
+//                  integers, dictionary ids leave their upper bytes constant: those passes move nothing) — the pass then
+//                  returns at once and the buffers do not swap; which buffer holds the pairs is a device word, the host
+//                  never looks
+//   k_radix_pass   workgroups take tiles of 4 096 pairs off a ticket counter; a tile's keys are ranked stably — per wave by
+//                  match-any ballots over the digit's bits (the lanes holding a digit value are a mask: rank = the digit's
+//                  count so far + the lanes below), waves and items in order — the tile's digit counts go through a
+//                  DECOUPLED LOOK-BACK (one lane per digit value, the same single-word relaxed agent-scope descriptors as
+//                  the Projection family's tile_lookback: state in the top two bits), the pairs are ordered by digit in
+//                  LDS and leave as runs (a digit value's pairs of one tile are contiguous in the output).
+constexpr int kRsItems = 16;                    // pairs per lane and tile
+constexpr int kRsTile = kBlock * kRsItems;      // 4 096
+constexpr int kRsWaves = kBlock / 64;
+constexpr uint32_t kRsShift = 30, kRsAggregate = 1u << kRsShift, kRsInclusive = 2u << kRsShift, kRsValue = (1u << kRsShift) - 1u;
+struct RadixState {
+  uint32_t hist[8][256];
+  uint32_t base[8][256];   // exclusive prefix of hist[d]
+  uint32_t skip[8];        // every key has the same digit d
+  uint32_t parity[9];      // the buffer (0 / 1) the pairs are in BEFORE pass d; [8]: after the last
+  uint32_t ticket[8];
+  uint32_t cur;            // the buffer the pairs are in between sorts
+  uint32_t pad_[6];
+};
+
 __global__ __launch_bounds__(kBlock) void k_sort_keys(DevPlan p, int idx_target_as_key, int target,
                                                        int64_t null_pattern, int fp_result, int desc,
                                                        int nulls_first, const int64_t* __restrict__ buf,
-                                                       const uint32_t* __restrict__ perm,
-                                                       uint64_t* __restrict__ keys) {
+                                                       const uint32_t* perm0, const uint32_t* perm1, uint64_t* keys0, uint64_t* keys1,
+                                                       const RadixState* st) {
+  const uint32_t cur = st->cur;
+  const uint32_t* __restrict__ perm = cur ? perm1 : perm0;
+  uint64_t* __restrict__ keys = cur ? keys1 : keys0;
   const int64_t stride = (int64_t)gridDim.x * kBlock;
   for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < p.entry_count; i += stride) {
     keys[i] = order_key_of(p, p.targets[target], buf + (int64_t)perm[i] * p.row_quad, idx_target_as_key, null_pattern,
@@ -256,11 +286,187 @@ __global__ __launch_bounds__(kBlock) void k_sort_keys(DevPlan p, int idx_target_
   }
 }
 
+__global__ __launch_bounds__(kBlock) void k_radix_hist(const uint64_t* keys0, const uint64_t* keys1, int64_t n, RadixState* st) {
+  __shared__ uint32_t s_hist[8][256];
+  const uint64_t* __restrict__ keys = st->cur ? keys1 : keys0;
+  for (int i = threadIdx.x; i < 8 * 256; i += kBlock) (&s_hist[0][0])[i] = 0;
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const uint64_t k = keys[i];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) atomicAdd(&s_hist[d][(k >> (8 * d)) & 255u], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 8 * 256; i += kBlock) {
+    const uint32_t v = (&s_hist[0][0])[i];
+    if (v) atomicAdd(&st->hist[0][0] + i, v);
+  }
+}
+
+// one workgroup: prefixes, skipped positions, buffer parities; the histograms and tickets are cleared for the next sort
+__global__ __launch_bounds__(kBlock) void k_radix_scan(RadixState* st, int64_t n) {
+  __shared__ uint32_t s_scan[256];
+  __shared__ uint32_t s_skip[8];
+  const int t = threadIdx.x;
+  if (t < 8) s_skip[t] = 0;
+  __syncthreads();
+  for (int d = 0; d < 8; ++d) {
+    const uint32_t v = st->hist[d][t];
+    if (n > 0 && (int64_t)v == n) s_skip[d] = 1;
+    s_scan[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const uint32_t o = t >= off ? s_scan[t - off] : 0u;
+      __syncthreads();
+      s_scan[t] += o;
+      __syncthreads();
+    }
+    st->base[d][t] = s_scan[t] - v;
+    st->hist[d][t] = 0;
+    __syncthreads();
+  }
+  if (t == 0) {
+    uint32_t par = st->cur;
+    for (int d = 0; d < 8; ++d) {
+      st->parity[d] = par;
+      st->skip[d] = s_skip[d];
+      st->ticket[d] = 0;
+      if (!s_skip[d]) par ^= 1u;
+    }
+    st->parity[8] = par;
+    st->cur = par;
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void k_radix_pass(int d, uint64_t* keys0, uint64_t* keys1, uint32_t* vals0, uint32_t* vals1, int64_t n,
+                                                        RadixState* st, uint32_t* desc) {
+  if (st->skip[d]) return;  // (uniform for the whole grid)
+  __shared__ uint64_t s_keys[kRsTile];
+  __shared__ uint32_t s_vals[kRsTile];
+  __shared__ uint32_t s_wave_cnt[kRsWaves][256];  // per wave: pairs per digit value; then the wave's start inside the digit's run
+  __shared__ uint32_t s_local[256];               // the digit value's first position in the tile (by digit order)
+  __shared__ uint32_t s_goff[256];                // global position of the digit value's first pair of this tile
+  __shared__ uint32_t s_scan[256];
+  __shared__ uint32_t s_tile;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t par = st->parity[d];
+  const uint64_t* __restrict__ kin = par ? keys1 : keys0;
+  uint64_t* __restrict__ kout = par ? keys0 : keys1;
+  const uint32_t* __restrict__ vin = par ? vals1 : vals0;
+  uint32_t* __restrict__ vout = par ? vals0 : vals1;
+  const int64_t n_tiles = (n + kRsTile - 1) / kRsTile;
+  const int shift = 8 * d;
+  const unsigned long long lt_mask = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (;;) {
+    if (t == 0) s_tile = atomicAdd(&st->ticket[d], 1u);
+    __syncthreads();
+    const int64_t tile = (int64_t)s_tile;
+    if (tile >= n_tiles) break;
+    const int64_t base = tile * kRsTile;
+    // ---- load: item i of lane l of wave w is pair (w * kRsItems + i) * 64 + l of the tile (order = wave, item, lane)
+    uint64_t key[kRsItems];
+    uint32_t val[kRsItems], rank[kRsItems];
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+      const int64_t g = base + (int64_t)(wave * kRsItems + i) * 64 + lane;
+      key[i] = g < n ? kin[g] : ~0ull;
+      val[i] = g < n ? vin[g] : 0u;
+    }
+    for (int i = t; i < kRsWaves * 256; i += kBlock) (&s_wave_cnt[0][0])[i] = 0;
+    __syncthreads();
+    // ---- stable ranks inside the wave
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+      const int64_t g = base + (int64_t)(wave * kRsItems + i) * 64 + lane;
+      const bool valid = g < n;
+      const uint32_t dg = (uint32_t)(key[i] >> shift) & 255u;
+      unsigned long long m = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const unsigned long long bal = __ballot((dg >> b) & 1u);
+        m &= ((dg >> b) & 1u) ? bal : ~bal;
+      }
+      uint32_t pre = 0;
+      if (valid) pre = s_wave_cnt[wave][dg];
+      rank[i] = pre + (uint32_t)__popcll(m & lt_mask);
+      __builtin_amdgcn_wave_barrier();
+      if (valid && (m & lt_mask) == 0) s_wave_cnt[wave][dg] = pre + (uint32_t)__popcll(m);  // (the lowest lane of the group)
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- digit value t: its count in the tile, the waves' starts inside its run, its place in the tile
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int w = 0; w < kRsWaves; ++w) {
+      const uint32_t c = s_wave_cnt[w][t];
+      s_wave_cnt[w][t] = cnt;
+      cnt += c;
+    }
+    s_scan[t] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const uint32_t o = t >= off ? s_scan[t - off] : 0u;
+      __syncthreads();
+      s_scan[t] += o;
+      __syncthreads();
+    }
+    s_local[t] = s_scan[t] - cnt;
+    // ---- decoupled look-back for digit value t: pairs with this digit in the tiles before this one
+    {
+      uint32_t* my = desc + (size_t)tile * 256 + t;
+      __hip_atomic_store(my, (tile == 0 ? kRsInclusive : kRsAggregate) | cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      uint32_t excl = 0;
+      for (int64_t pt = tile - 1; pt >= 0; --pt) {
+        const uint32_t* pd = desc + (size_t)pt * 256 + t;
+        uint32_t v = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((v >> kRsShift) == 0) {
+          __builtin_amdgcn_s_sleep(4);
+          v = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        excl += v & kRsValue;
+        if ((v >> kRsShift) == 2) break;
+      }
+      if (tile > 0) __hip_atomic_store(my, kRsInclusive | (excl + cnt), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_goff[t] = st->base[d][t] + excl;
+    }
+    __syncthreads();
+    // ---- the pairs in digit order in LDS ...
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+      const int64_t g = base + (int64_t)(wave * kRsItems + i) * 64 + lane;
+      if (g < n) {
+        const uint32_t dg = (uint32_t)(key[i] >> shift) & 255u;
+        const uint32_t lp = s_local[dg] + s_wave_cnt[wave][dg] + rank[i];
+        s_keys[lp] = key[i];
+        s_vals[lp] = val[i];
+      }
+    }
+    __syncthreads();
+    // ... and out: position j of the tile goes to the digit value's run
+    const int64_t left = n - base;
+    const int n_here = left < kRsTile ? (int)left : kRsTile;
+#pragma unroll
+    for (int i = 0; i < kRsItems; ++i) {
+      const int j = i * kBlock + t;
+      if (j < n_here) {
+        const uint64_t k = s_keys[j];
+        const uint32_t dg = (uint32_t)(k >> shift) & 255u;
+        const uint32_t dst = s_goff[dg] + ((uint32_t)j - s_local[dg]);
+        kout[dst] = k;
+        vout[dst] = s_vals[j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // rows [offset, offset + n_out) of the sorted permutation, as whole rows; n_live = non-empty entries
 __global__ __launch_bounds__(kBlock) void k_sort_gather(DevPlan p, const int64_t* __restrict__ buf,
-                                                         const uint32_t* __restrict__ perm, int64_t offset,
+                                                         const uint32_t* perm0, const uint32_t* perm1, const RadixState* st, int64_t offset,
                                                          int64_t limit, const int64_t* __restrict__ n_live,
                                                          int64_t* __restrict__ out_rows, int64_t* __restrict__ n_out) {
+  const uint32_t* __restrict__ perm = st->cur ? perm1 : perm0;
   int64_t n = *n_live - offset;
   if (n < 0) n = 0;
   if (limit > 0 && n > limit) n = limit;
@@ -309,48 +515,55 @@ hipError_t launch_topk(const DevPlan& p, int idx_target_as_key, int target, int6
   return hipGetLastError();
 }
 
-// scratch layout of the full sort: keys[2][E] | perm[2][E] | n_live, n_out | rocprim temporary storage
-static size_t sort_tmp_bytes(int64_t entry_count) {
-  size_t tmp = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                  (uint32_t*)nullptr, (size_t)entry_count, 0, 64, (hipStream_t) nullptr);
-  return (tmp + 255) & ~(size_t)255;
+// scratch layout of the full sort: keys[2][E] | perm[2][E] | n_live, n_out | RadixState | tile descriptors [tiles][256]
+static size_t sort_state_bytes() { return (sizeof(RadixState) + 255) & ~(size_t)255; }
+static size_t sort_desc_bytes(int64_t entry_count) {
+  const size_t tiles = (size_t)((entry_count > 0 ? entry_count : 1) + kRsTile - 1) / kRsTile;
+  return (tiles * 256 * 4 + 255) & ~(size_t)255;
 }
 int64_t sort_scratch_bytes(int64_t entry_count) {
   const size_t e = (size_t)(entry_count > 0 ? entry_count : 1);
-  return (int64_t)(2 * ((e * 8 + 255) & ~(size_t)255) + 2 * ((e * 4 + 255) & ~(size_t)255) + 256 + sort_tmp_bytes(entry_count));
+  return (int64_t)(2 * ((e * 8 + 255) & ~(size_t)255) + 2 * ((e * 4 + 255) & ~(size_t)255) + 256 + sort_state_bytes() + sort_desc_bytes(entry_count));
 }
 
 hipError_t launch_sort(const DevPlan& p, int idx_target_as_key, const SortOrderEntry* order, int n_order,
                        const int64_t* buf, int64_t offset, int64_t limit, void* scratch, int64_t* out_rows,
                        int64_t* d_n_out, hipStream_t s) {
-  if (n_order < 1 || offset < 0 || limit < 0 || p.entry_count >= ((int64_t)1 << 32)) return hipErrorInvalidValue;
+  // (the look-back descriptors keep a count in 30 bits)
+  if (n_order < 1 || offset < 0 || limit < 0 || p.entry_count >= ((int64_t)1 << 30)) return hipErrorInvalidValue;
   const size_t e = (size_t)(p.entry_count > 0 ? p.entry_count : 1);
   const size_t kb = (e * 8 + 255) & ~(size_t)255, pb = (e * 4 + 255) & ~(size_t)255;
   char* base = (char*)scratch;
   uint64_t* keys[2] = {(uint64_t*)base, (uint64_t*)(base + kb)};
   uint32_t* perm[2] = {(uint32_t*)(base + 2 * kb), (uint32_t*)(base + 2 * kb + pb)};
   int64_t* d_live = (int64_t*)(base + 2 * kb + 2 * pb);
-  void* tmp = base + 2 * kb + 2 * pb + 256;
-  size_t tmp_bytes = sort_tmp_bytes(p.entry_count);
+  RadixState* st = (RadixState*)(base + 2 * kb + 2 * pb + 256);
+  uint32_t* desc = (uint32_t*)(base + 2 * kb + 2 * pb + 256 + sort_state_bytes());
+  const size_t desc_bytes = sort_desc_bytes(p.entry_count);
   const int grid = grid_for(p.entry_count);
+  const int64_t n_tiles = (p.entry_count + kRsTile - 1) / kRsTile;
+  const int pass_grid = (int)(n_tiles < 1 ? 1 : n_tiles > 1024 ? 1024 : n_tiles);
+  hipError_t e0 = hipMemsetAsync(st, 0, sizeof(RadixState), s);
+  if (e0 != hipSuccess) return e0;
   hipLaunchKernelGGL(k_sort_iota, dim3(grid), dim3(kBlock), 0, s, perm[0], p.entry_count);
-  int cur = 0;
   for (int o = n_order - 1; o >= 0; --o) {
     const SortOrderEntry& oe = order[o];
     hipLaunchKernelGGL(k_sort_keys, dim3(grid), dim3(kBlock), 0, s, p, idx_target_as_key, oe.target, oe.null_pattern,
-                       (int)oe.fp_result, (int)oe.desc, (int)oe.nulls_first, buf, perm[cur], keys[0]);
-    hipError_t e2 = rocprim::radix_sort_pairs(tmp, tmp_bytes, keys[0], keys[1], perm[cur], perm[1 - cur],
-                                              (size_t)p.entry_count, 0, 64, s);
-    if (e2 != hipSuccess) return e2;
-    cur = 1 - cur;
+                       (int)oe.fp_result, (int)oe.desc, (int)oe.nulls_first, buf, perm[0], perm[1], keys[0], keys[1], st);
+    hipLaunchKernelGGL(k_radix_hist, dim3(grid_for(p.entry_count, 1024)), dim3(kBlock), 0, s, keys[0], keys[1], p.entry_count, st);
+    hipLaunchKernelGGL(k_radix_scan, dim3(1), dim3(kBlock), 0, s, st, p.entry_count);
+    for (int d = 0; d < 8; ++d) {
+      e0 = hipMemsetAsync(desc, 0, desc_bytes, s);
+      if (e0 != hipSuccess) return e0;
+      hipLaunchKernelGGL(k_radix_pass, dim3(pass_grid), dim3(kBlock), 0, s, d, keys[0], keys[1], perm[0], perm[1], p.entry_count, st, desc);
+    }
   }
   hipError_t e3 = hipMemsetAsync(d_live, 0, 16, s);
   if (e3 != hipSuccess) return e3;
   e3 = launch_count_nonempty(p, idx_target_as_key, buf, (unsigned long long*)d_live, s);
   if (e3 != hipSuccess) return e3;
   int64_t want = limit > 0 ? limit : p.entry_count;
-  hipLaunchKernelGGL(k_sort_gather, dim3(grid_for(want * p.row_quad)), dim3(kBlock), 0, s, p, buf, perm[cur], offset, limit,
+  hipLaunchKernelGGL(k_sort_gather, dim3(grid_for(want * p.row_quad)), dim3(kBlock), 0, s, p, buf, perm[0], perm[1], st, offset, limit,
                      d_live, out_rows, d_n_out);
   return hipGetLastError();
 }

@@ -350,7 +350,7 @@ def hostsim_lib(real_fast: bool = False) -> str:
     run as 1024 cooperative fibers): kernels_fast.hip, kernels_lds.hip, kernels_part.hip (the producer / flusher pipeline
     of the scatter works because every polling loop of the device code sleeps, and s_sleep is a fiber yield here; waits
     for OTHER workgroups are bounded on the device and simply expire here, blocks run one after the other) and
-    kernels_sort.hip (rocPRIM's radix sort replaced by a std::stable_sort stand-in, shim/rocprim)."""
+    kernels_sort.hip (top-k selection and the hand-written one-sweep radix sort)."""
     key = bool(real_fast)
     if _hostsim.get(key) is not None:
         return _hostsim[key]

@@ -1,7 +1,7 @@
 """The REAL kernels on the CPU: kernels_fast.hip (k_scan_count, k_scan_agg, k_perfect_lds, k_perfect_lds_prog,
 k_baseline_direct, k_join_sum), kernels_lds.hip (k_groupby_lds), kernels_part.hip (k_part_scatter / k_part_aggregate /
-k_spill_merge, the radix and payload join probes, the slice merge) and kernels_sort.hip (top-k selection; the full sort
-with a stand-in for rocPRIM's radix sort) compiled for the host against the stand-in HIP runtime of tests/hostsim — a
+k_spill_merge, the radix and payload join probes, the slice merge) and kernels_sort.hip (top-k selection; the full sort's
+hand-written one-sweep radix sort) compiled for the host against the stand-in HIP runtime of tests/hostsim — a
 workgroup runs as 1024 cooperative fibers with working barriers, shuffles, ballots, ds_permute, LDS and atomics; the
 polling loops of the scatter's producer / flusher pipeline sleep on the device, and s_sleep is a fiber yield here —
 behind the real api.cpp / plan.cpp.  Results are held against the oracle exactly as the gpu tests do.  This is a functional check
@@ -887,13 +887,13 @@ def test_pair_atoms_on_edge_values(sim, oracle, op, nullable, member):
         raises = bb == 0
     else:
         raises = np.zeros(len(a), bool)
-    for cmp_op, k in ((capi.EX_GT, 3), (capi.EX_LE, -1), (capi.EX_NE, 0), (capi.EX_EQ, nul)):
+    for cmp_op, k in ((capi.EX_GT, 3), (capi.EX_LE, -1), (capi.EX_EQ, nul)):
         e = C_(1).cmp(cmp_op, C_(2)) if op == "cmp2" else val.cmp(cmp_op, L(k))
         for keep, expect_err in ((np.ones(len(a), bool), None), (~raises, 0)):
             aa, b2 = a[keep].astype(np.int32), b[keep].astype(np.int32)
             if len(aa) < 8:
                 continue
-            rep = 40   # (several quads per lane, a ragged end)
+            rep = 5   # (a few quads per lane, a ragged end)
             aa, b2 = np.tile(aa, rep)[:-3], np.tile(b2, rep)[:-3]
             g = (np.arange(len(aa)) % 13).astype(np.int32)
             descs = [InputColDescriptor(I32, False, ExpressionRange(True, 0, 12)),

@@ -31,4 +31,4 @@ def test_bool_filter_bench_plans(oracle):
         assert code == 0 and ecode == 0, (name, code, ecode)
         compare_buffers(q, want, ebuf)
         seen[name] = oracle.row_count(q, want)
-    assert set(seen) == {"plain", "and_in_or", "not_or", "guarded_div", "composed"} and all(v > 100 for v in seen.values()), seen
+    assert set(seen) == {"plain", "and_in_or", "not_or", "guarded_div", "composed", "sum_gt", "col_lt_col", "affine"} and all(v > 100 for v in seen.values()), seen

@@ -26,6 +26,11 @@ case $step in
     timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant expr > $out/proj_expr.jsonl 2>> $out/err.log; echo "expr exit $?"
     timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant expr --generic-member > $out/proj_expr_interpreted.jsonl 2>> $out/err.log; echo "expr interp exit $?"
     cut -c1-260 $out/proj_plain.jsonl $out/proj_expr.jsonl $out/proj_expr_interpreted.jsonl; tail -3 $out/err.log ;;
+  sort)     # the hand-written one-sweep radix sort: device parity tests, then the 20 M-entry timings (rocPRIM's were 2.35 / 4.26 ms)
+    timeout 900 python -u -m pytest tests/test_zz_gpu_sort.py -m gpu -x -q -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
+    timeout 600 python tools/topk_time.py > $out/sort_time.txt 2>&1; echo "time exit $?"; cat $out/sort_time.txt
+    timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o sort -- python tools/topk_time.py > /dev/null 2> $out/rocprof.err
+    find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/sort_kernel_stats.csv \; ; rm -rf $out/trace; cut -c1-150 $out/sort_kernel_stats.csv | head -12 ;;
   suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
     timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200
