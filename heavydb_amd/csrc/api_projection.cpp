@@ -72,7 +72,9 @@ int32_t execute_projection(const mi355q_plan* plan, const mi355q_inputs* in, con
   if (int32_t e = attach_join(lp, in, &d)) return e;
   // one entry per joined row: a one-to-one table gives at most one per outer row, which the compaction's match bit states;
   // the matching SETS of a one-to-many table (HashJoin::codegenMatchingSet) would need a count per row
-  if (d.join_col >= 0 && d.join_hash_type >= 2) return MI355Q_ERR_UNSUPPORTED;
+  // (round 6: the matching sets of a one-to-many table are entries too — k_proj_join_1n; with expressions the family still
+  // answers "unsupported")
+  if (d.join_col >= 0 && d.join_hash_type >= 2 && plan->n_exprs != 0) return MI355Q_ERR_UNSUPPORTED;
   for (int k = 0; k < d.n_quals; ++k)  // (a member of a disjunction is a plain column comparison: the binding never states one over an expression)
     if (d.quals[k].or_group != 0 && d.quals[k].col >= n_phys) return MI355Q_ERR_UNSUPPORTED;
   ProjSpec ps;

@@ -920,6 +920,137 @@ __global__ __launch_bounds__(kBlock) void k_proj_compact_lds(DevPlan p, ProjArgs
   if (err) atomicCAS(a.d_err, 0, err);
 }
 
+// ---- ONE-TO-MANY joins under a Projection (round 6): every matching inner row of an outer row is an entry — the matching SET
+// of HashJoin::codegenMatchingSet (HashJoin.cpp:209) walked by the join loop around the row function's body (IRCodegen.cpp:635
+// buildJoinLoops, :1233 codegenJoinLoops); the table is [offsets | counts | payload] (perfect) or [keys | offsets | counts |
+// payload] (keyed), HashJoinRuntime.cpp:702 count_matches, :1027 fill_row_ids.  The compaction counts ENTRIES instead of
+// rows: pass A probes every row that passes the quals for its match count (a LEFT join counts an unmatched row once, with
+// the inner columns' NULLs), the (iteration, wave) totals are scanned, the tile's total goes through the same look-back;
+// pass B probes again and every lane writes its rows' entries — a row's matches in payload order, rows in (fragment, row)
+// order, as the reference's CPU executor emits them — straight to the buffer (no LDS image: a row may have any number of
+// matches).  Plain column targets of either side; quals of any kind without expressions.
+MQ_D JoinMatch proj_join_matches(const DevPlan& p, const int8_t* const* fc, int64_t pos) {
+  int64_t jk[MI355Q_MAX_GROUP_COLS];
+  bool null_key = false;
+  for (int i = 0; i < p.join_n_keys; ++i) {
+    jk[i] = decode_int(fc[p.join_cols[i]], p.join_types[i], pos);
+    null_key = null_key || (p.join_nullables[i] && jk[i] == int_null_of(p.join_types[i]));
+  }
+  if (null_key) return JoinMatch{nullptr, -1, 0};
+  return join_lookup(p, jk);
+}
+__global__ __launch_bounds__(kBlock) void k_proj_join_1n(DevPlan p, ProjArgs a) {
+  __shared__ unsigned long long s_cnt[kIters * kWaves];  // entries of (iteration, wave); then their exclusive prefix in that order
+  __shared__ long long s_bcast[2];
+  const ProjSpec& ps = a.ps;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const bool left = p.join_kind == MI355Q_JOIN_LEFT;
+  int32_t err = 0;
+  ProjExprLds L{};
+  for (;;) {
+    if (tid == 0) s_bcast[0] = (long long)atomicAdd(&a.counters[0], 1ull);
+    __syncthreads();
+    const int64_t tile = s_bcast[0];
+    __syncthreads();
+    if (tile >= a.n_tiles) break;
+    int f = 0;
+    {
+      int lo = 0, hi = a.n_frags;
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.tile_start[mid] <= tile) lo = mid;
+        else hi = mid;
+      }
+      f = lo;
+    }
+    const int8_t* const* fc = a.cols + (size_t)f * ps.n_cols_table;
+    const int64_t n = a.num_rows[f];
+    const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;
+    const uint64_t m = tile_filter<false, false>(p, a, L, fc, n, row0, &err);  // the quals alone
+    // ---- pass A: entries per (iteration, wave)
+#pragma unroll 1
+    for (int u = 0; u < kIters; ++u) {
+      const uint32_t mm = (uint32_t)(m >> (4 * u)) & 0xfu;
+      const int64_t r = row0 + (int64_t)u * kIterRows + tid * 4;
+      unsigned long long c = 0;
+      for (int i = 0; i < 4; ++i) {
+        if (!((mm >> i) & 1u)) continue;
+        const int32_t k = proj_join_matches(p, fc, r + i).count;
+        c += (unsigned long long)(k > 0 ? k : left ? 1 : 0);
+      }
+      for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+      if (lane == 0) s_cnt[u * kWaves + wave] = c;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const unsigned long long v = s_cnt[lane];
+      unsigned long long inc = v;
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl(inc, lane - d < 0 ? lane : lane - d, 64);
+        if (lane >= d) inc += o;
+      }
+      const unsigned long long tile_count = __shfl(inc, 63, 64);
+      s_cnt[lane] = inc - v;
+      const unsigned long long excl = tile_lookback(a.desc, a.counters, a.n_tiles, tile, tile_count);
+      if (lane == 0) s_bcast[1] = (long long)excl;
+    }
+    __syncthreads();
+    const int64_t tile_base = s_bcast[1];
+    if (tile_base >= ps.entry_count) continue;  // past a scan limit (or a full buffer)
+    // ---- pass B: probe again, write the entries
+#pragma unroll 1
+    for (int u = 0; u < kIters; ++u) {
+      const uint32_t mm = (uint32_t)(m >> (4 * u)) & 0xfu;
+      const int64_t r = row0 + (int64_t)u * kIterRows + tid * 4;
+      JoinMatch jm[4];
+      unsigned long long c = 0;
+      for (int i = 0; i < 4; ++i) {
+        jm[i] = JoinMatch{nullptr, -1, 0};
+        if (!((mm >> i) & 1u)) continue;
+        jm[i] = proj_join_matches(p, fc, r + i);
+        if (jm[i].count <= 0) {
+          jm[i] = JoinMatch{nullptr, -1, left ? 1 : 0};   // LEFT join: once, with the inner columns' NULLs
+        }
+        c += (unsigned long long)jm[i].count;
+      }
+      unsigned long long inc = c;
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl(inc, lane - d < 0 ? lane : lane - d, 64);
+        if (lane >= d) inc += o;
+      }
+      int64_t e = tile_base + (int64_t)s_cnt[u * kWaves + wave] + (int64_t)(inc - c);
+      for (int i = 0; i < 4; ++i) {
+        for (int32_t j = 0; j < jm[i].count; ++j, ++e) {
+          if (e >= ps.entry_count) break;
+          const int64_t inner_pos = jm[i].ids ? (int64_t)jm[i].ids[j] : jm[i].single;
+          if (ps.columnar) ((int64_t*)a.out)[e] = r + i;
+          else ((int64_t*)a.out)[e * ps.row_quad] = r + i;
+          for (int t = 0; t < ps.n_targets; ++t) {
+            const ProjTarget& pt = ps.t[t];
+            int64_t v;
+            if (pt.col >= kProjInnerCol) v = inner_pos >= 0 ? col_value_bits(p.inner_cols[pt.col - kProjInnerCol], pt.code, inner_pos) : proj_null_bits(pt.code);
+            else v = col_value_bits(fc[pt.col], pt.code, r + i);
+            if (pt.kind == PROJ_F32_TO_F64) v = dbl_bits((double)bits_flt((int32_t)(uint32_t)v));
+            if (!ps.columnar) {
+              ((int64_t*)a.out)[e * ps.row_quad + 1 + t] = v;
+            } else {
+              char* dst = (char*)a.out + pt.col_off;
+              switch (pt.width) {
+                case 1: ((int8_t*)dst)[e] = (int8_t)v; break;
+                case 2: ((int16_t*)dst)[e] = (int16_t)v; break;
+                case 4: ((int32_t*)dst)[e] = (int32_t)(uint32_t)v; break;
+                default: ((int64_t*)dst)[e] = v;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (err) atomicCAS(a.d_err, 0, err);
+}
+
 // entries [min(total_matched, entry_count), entry_count) of the buffer: the EMPTY_KEY_64 key — and, row-wise, the zero
 // slots — of an initialised buffer (QueryMemoryInitializer::initRowGroups :617-698; initColumnarGroups :713-738 leaves
 // the slot columns of a columnar projection alone)
@@ -1158,7 +1289,8 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
         (void)hipFuncSetAttribute((const void*)k_proj_compact_lds<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);
         attr_set = true;
       }
-      if (p.join_col >= 0) hipLaunchKernelGGL(k_proj_compact_lds<true>, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
+      if (p.join_col >= 0 && p.join_hash_type >= 2) hipLaunchKernelGGL(k_proj_join_1n, dim3((unsigned)std::min<int64_t>(tiles, (int64_t)n_cus * 4)), dim3(kBlock), 0, s, p, a);
+      else if (p.join_col >= 0) hipLaunchKernelGGL(k_proj_compact_lds<true>, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
       else hipLaunchKernelGGL(k_proj_compact_lds<false>, dim3((unsigned)grid), dim3(kBlock), lds, s, p, a);
     } else {
       fa.n_quals = p.n_quals;

@@ -29,6 +29,9 @@ int32_t orc_execute(const mi355q_plan* plan, const mi355q_inputs* in, const void
                     int64_t* out_buf, mi355q_qmd* out_qmd);
 void* orc_join_build(const void* key_col, int key_type, int key_nullable, int64_t num_rows, int64_t min_key,
                      int64_t max_key, int prefer_baseline, int64_t max_perfect_entries, int32_t* err);
+void* orc_join_build_n(const void* const* key_cols, const int32_t* key_types, const int32_t* key_nullables, int32_t n_keys, int64_t num_rows,
+                       int64_t min_key, int64_t max_key, int prefer_baseline, int64_t max_perfect_entries, int32_t one_to_many,
+                       int64_t keyed_entries, int32_t* err);
 void orc_join_free(void* j);
 }
 
@@ -537,6 +540,75 @@ int main() {
       expect(same6, "projection-through-a-join buffer differs from the oracle's");
       expect(live > 0 && nulls > 0 && nulls < live, "the LEFT join shows both matched rows and NULL inner values");
       std::printf("  %lld rows, %lld of them without a match (d.w NULL)\n", (long long)live, (long long)nulls);
+      // ---------------------------------------------------------- query 7: the same Projection through a ONE-TO-MANY table
+      //   the dimension's keys folded onto half their range: every key has two rows -> two entries per matching outer row,
+      //   in the payload's order (which depends on the build order: compared per outer row as a set)
+      {
+        std::printf("query 7: SELECT t.key, d2.w FROM t JOIN d2 ON t.fk = d2.k WHERE t.i32 < 134217728   (d2: every key twice)\n");
+        std::vector<int64_t> k2((size_t)M);
+        for (int64_t i = 0; i < M; ++i) k2[(size_t)i] = ((const int64_t*)d.cols[0].host.data())[i] % (M / 2);
+        void* d_k2 = nullptr;
+        HIPCK(hipMalloc(&d_k2, (size_t)M * 8));
+        HIPCK(hipMemcpy(d_k2, k2.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+        mi355q_join_spec js2 = js;
+        js2.key_buffer = d_k2;
+        js2.key_range = {1, 0, 0, M / 2 - 1, 0, 0, 0};
+        js2.one_to_many = 2;
+        mi355q_join_table* jt2 = nullptr;
+        MQCK(mi355q_join_build(&js2, nullptr, &jt2));
+        const void* kc[1] = {k2.data()};
+        const int32_t kt[1] = {MI355Q_INT64}, kn[1] = {0};
+        int32_t oerr2 = 0;
+        void* oj2 = orc_join_build_n(kc, kt, kn, 1, M, 0, M / 2 - 1, 0, 0, 2, 0, &oerr2);
+        expect(oj2 != nullptr && oerr2 == 0, "oracle one-to-many join build");
+        executor.column_ranges[{kDim, 0}] = ExpressionRange::makeIntRange(0, M / 2 - 1, 0, false);
+        RelAlgExecutionUnit ra7 = ra6;
+        ra7.join_quals.clear();
+        JoinCondition jc7;
+        jc7.type = JoinType::INNER;
+        jc7.quals.push_back(std::make_shared<Analyzer::BinOper>(SQLTypeInfo(kBOOLEAN, true), kEQ, fk, dk));
+        ra7.join_quals.push_back(jc7);
+        mi355q_plan h7 = h6;
+        h7.join_kind = MI355Q_JOIN_INNER;
+        h7.inner_col_ranges[0] = {1, 0, 0, M / 2 - 1, 0, 0, 0};
+        const size_t guess7 = (size_t)(N / 2);
+        h7.max_groups_buffer_entry_guess = (int64_t)guess7;
+        compare_plans(h7, mi355q_glue::to_plan(ra7, qi2, &executor, jt2, guess7, false));
+        mi355q_qmd q7;
+        const std::vector<int64_t> want7 = oracle_table(h7, t, {4, 0, 2}, fr6_rows, oj2, {k2.data(), d.cols[1].host.data()}, M, &q7);
+        const ResultSetPtr rs7 = mi355q_glue::run_query_mi355q(ra7, fr6, qi2, qmd_of(q7), &executor, 0, guess7, jt2,
+                                                               {(const int8_t*)d_k2, (const int8_t*)d.cols[1].dev}, M);
+        const int64_t* got7 = (const int64_t*)const_cast<ResultSetStorage*>(rs7->getStorage())->getUnderlyingBuffer();
+        int64_t live7 = 0, pairs = 0;
+        bool same7 = true;
+        for (int64_t e = 0; e < q7.entry_count && same7;) {
+          if (want7[(size_t)e * 3] == INT64_MAX) {
+            same7 = got7[(size_t)e * 3] == INT64_MAX;
+            break;
+          }
+          int64_t e1 = e;
+          while (e1 < q7.entry_count && want7[(size_t)e1 * 3] == want7[(size_t)e * 3] && want7[(size_t)e1 * 3 + 1] == want7[(size_t)e * 3 + 1]) ++e1;
+          std::vector<int64_t> a, b;
+          for (int64_t x = e; x < e1; ++x) {
+            same7 = same7 && got7[(size_t)x * 3] == want7[(size_t)x * 3] && got7[(size_t)x * 3 + 1] == want7[(size_t)x * 3 + 1];
+            a.push_back(want7[(size_t)x * 3 + 2]);
+            b.push_back(got7[(size_t)x * 3 + 2]);
+          }
+          std::sort(a.begin(), a.end());
+          std::sort(b.begin(), b.end());
+          same7 = same7 && a == b;
+          pairs += (e1 - e) >= 2;
+          live7 += e1 - e;
+          e = e1;
+        }
+        expect(same7, "one-to-many projection differs from the oracle's");
+        expect(live7 > 0 && pairs > 0, "every matching outer row shows its two inner rows");
+        std::printf("  %lld entries, %lld outer rows with both of their matches\n", (long long)live7, (long long)pairs);
+        executor.column_ranges[{kDim, 0}] = ExpressionRange::makeIntRange(0, M - 1, 0, false);
+        mi355q_join_free(jt2);
+        orc_join_free(oj2);
+        HIPCK(hipFree(d_k2));
+      }
     }
     mi355q_join_free(jt);
     orc_join_free(oj);

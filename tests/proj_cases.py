@@ -250,8 +250,21 @@ def build_join_cases() -> List[ProjCase]:
     add("join_scan_limit", both, scan_limit=1234)
     add("join_left_nothing_matches", [(1, 0), (1, 1), (2, 1)], [Qual(0, capi.LT, 0)], kind=capi.JOIN_LEFT)
     add("join_inner_nothing_matches", [(1, 0), (1, 1)], [Qual(0, capi.LT, 0)])
-    # duplicates on the inner side: a one-to-many table — every match would be an entry; this family answers "unsupported"
-    dup = np.concatenate([dk[:m - 50], dk[:50]])
-    add("join_one_to_many_is_refused", [(1, 0), (1, 1)], one_to_many=1, join_keys=dup, inner=[dup, dw, df, dg, ds],
-        expect_error=capi.ERR_UNSUPPORTED)
+    # duplicates on the inner side: a one-to-many table — every match is an entry, a row's matches in payload order (round 6:
+    # k_proj_join_1n; HashJoin::codegenMatchingSet + the join loop around the body)
+    dup = np.concatenate([dk[:m - 50], dk[:50], dk[:20], dk[5:8]])        # keys with 1, 2, 3 and 4 matches; 50 keys with none
+    m2 = len(dup)
+    inner2 = [dup, rng.integers(-1000, 1000, m2).astype(np.int64), rng.random(m2), rng.random(m2).astype(np.float32),
+              np.where(np.arange(m2) % 9 == 0, INT_NULL[capi.INT16], rng.integers(-100, 100, m2)).astype(np.int16)]
+    for keyed in (False, True):
+        tag = "keyed" if keyed else "perfect"
+        add(f"join_1n_inner_{tag}", both, one_to_many=1, join_keys=dup, inner=inner2, keyed=keyed, guess=3 * n)
+        add(f"join_1n_left_{tag}_filtered", both, [Qual(2, capi.LT, 700)], kind=capi.JOIN_LEFT, one_to_many=1, join_keys=dup, inner=inner2,
+            keyed=keyed, guess=3 * n)
+    add("join_1n_inner_columnar", both, one_to_many=1, join_keys=dup, inner=inner2, guess=3 * n, output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    add("join_1n_left_nullable_int32_key", [(0, 0), (1, 1), (4, 1)], outer_col=3, kind=capi.JOIN_LEFT, one_to_many=1, join_keys=dup, inner=inner2,
+        guess=3 * n)
+    add("join_1n_scan_limit", both, one_to_many=1, join_keys=dup, inner=inner2, scan_limit=1777)
+    add("join_1n_buffer_full", [(1, 0), (1, 1)], one_to_many=1, join_keys=dup, inner=inner2, guess=500, expect_error=-1)
+    add("join_1n_outer_columns_only", [(1, 0), (2, 0)], [Qual(2, capi.LT, 500)], one_to_many=1, join_keys=dup, inner=inner2, guess=3 * n)
     return cases

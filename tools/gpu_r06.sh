@@ -31,6 +31,12 @@ case $step in
     timeout 600 python tools/topk_time.py > $out/sort_time.txt 2>&1; echo "time exit $?"; cat $out/sort_time.txt
     timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o sort -- python tools/topk_time.py > /dev/null 2> $out/rocprof.err
     find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/sort_kernel_stats.csv \; ; rm -rf $out/trace; cut -c1-150 $out/sort_kernel_stats.csv | head -12 ;;
+  proj1n)   # one-to-many joins under a Projection: device parity (oracle + SQLite), the binding's query 7, the bench lines
+    timeout 900 python -u -m pytest tests/test_zz_gpu_projection.py tests/test_integration_glue.py -m gpu -q -p no:cacheprovider -k "join or glue" > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -4 $out/pytest.log
+    for v in join join1n; do
+      timeout 400 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant $v >> $out/proj_join_variants_1b.jsonl 2>> $out/err.log; echo "$v exit $?"
+    done
+    cut -c1-330 $out/proj_join_variants_1b.jsonl; tail -3 $out/err.log ;;
   suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
     timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200

@@ -25,7 +25,7 @@ def main():
     ap.add_argument("--sel", default="0.01,0.5,0.99")
     ap.add_argument("--cols", default="1,3,6")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--variant", default="plain", choices=["plain", "general", "expr", "join"],
+    ap.add_argument("--variant", default="plain", choices=["plain", "general", "expr", "join", "join1n"],
                     help="general: the same shapes through the general member (pass_rows = -1); expr: the second target is v1 * 2.0 "
                          "and a third one v0 + 1 (expressions in registers); join: SELECT v.., d.w FROM t JOIN d ON t.fk = d.k "
                          "(d: 1 M rows, dense keys; fk = i32 >> 11)")
@@ -56,14 +56,18 @@ def main():
                         tg.append(TargetExpr(capi.PROJECT, nc + 1))
                     tg += [TargetExpr(capi.PROJECT, 1 + i) for i in range(2, n_out)]
                     ra.exprs, ra.target_exprs = xs, tg
-                elif args.variant == "join":
+                elif args.variant in ("join", "join1n"):
                     from heavydb_amd.executor import ExpressionRange, FetchResult, HashJoin, InputColDescriptor, TargetExpr
                     m = 1 << 20
+                    one_n = args.variant == "join1n"   # every key of the dimension twice: two entries per matching outer row
                     if "join" not in cache:
                         dk = torch.randperm(m, device="cuda").to(torch.int64)
+                        if one_n:
+                            dk = dk % (m // 2)
                         dw = torch.randint(-1000, 1000, (m,), device="cuda", dtype=torch.int64)
                         fks = [(c.view(torch.int32) >> 11).contiguous() for c in [info["cols"][0]]]
-                        cache["join"] = (dk, dw, fks, HashJoin.getInstance(int(dk.data_ptr()), m, capi.INT64, ExpressionRange(True, 0, m - 1)))
+                        cache["join"] = (dk, dw, fks, HashJoin.getInstance(int(dk.data_ptr()), m, capi.INT64, ExpressionRange(True, 0, (m // 2 if one_n else m) - 1),
+                                                                           one_to_many=2 if one_n else 0))
                     dk, dw, fks, hj = cache["join"]
                     nc = len(ra.input_col_descs)
                     off, bufs = 0, []
@@ -77,6 +81,8 @@ def main():
                     ra.target_exprs = list(ra.target_exprs) + [TargetExpr(capi.PROJECT, 1, 1)]
                     fr = FetchResult(bufs, fr.num_rows, [int(dk.data_ptr()), int(dw.data_ptr())], m, keepalive=[fr, dk, dw, fks])
                     info = dict(info, bytes_per_row=info["bytes_per_row"] + 4, out_bytes_per_row=info["out_bytes_per_row"] + 8)
+                    if one_n:
+                        ra.max_groups_buffer_entry_guess = 2 * ra.max_groups_buffer_entry_guess
                 q = capi.QMD()
                 assert lib.mi355q_qmd_init(ctypes.byref(ra.to_plan()), ctypes.byref(q)) == 0
                 out = torch.empty(lib.mi355q_qmd_buffer_bytes(ctypes.byref(q)) // 8, dtype=torch.int64, device="cuda")
