@@ -58,6 +58,8 @@ def parse_args():
                     "(probe_keyed_passes; 0 = the library's choice)")
     ap.add_argument("--sparse", action="store_true", help="cfg4: sparse dim keys -> keyed {key, row id} join table (3.2 GB)")
     ap.add_argument("--sum-dim", action="store_true", help="cfg4: Query B, also SUM(dim.w) (reads an inner column)")
+    ap.add_argument("--holes", type=int, default=0, help="cfg4: the dimension without the keys = 5 (mod HOLES): a perfect table with empty slots "
+                                                          "(the general probe; the dense dimension's join is planned away as a range filter)")
     ap.add_argument("--verify", action="store_true", help="size-independent property checks")
     ap.add_argument("--prepartitioned", action="store_true",
                     help="cfg3/cfg3f, N > 1: the table arrives hash-partitioned by key (every key on one "
@@ -120,6 +122,7 @@ def cpu_baseline(cfg: str, info: dict, target_s: float, sample_rows: int = 0) ->
     generator is reported so it can be taken out of the kernel phase."""
     import numpy as np
     from heavydb_amd import capi
+    from heavydb_amd import synth as synth_mod
     from oracle import oracle as orc
     plan = info["ra"].to_plan()
     full = {"cfg1": 100_000_000, "cfg2": 1_000_000_000}.get(cfg, 1_000_000_000)
@@ -141,11 +144,13 @@ def cpu_baseline(cfg: str, info: dict, target_s: float, sample_rows: int = 0) ->
     if cfg == "cfg4":
         m = info["dim_rows"]
         mul = info.get("dim_mul", 1)
-        dim_k = np.arange(m, dtype=np.int64) * mul
+        span = info.get("key_span", m)
+        dim_k = synth_mod.dim_keys_with_holes(np, span, mul, info.get("dim_holes", 0))
+        assert len(dim_k) == m
         g = info["dim_w_gen"]
         dim_w = orc.generate_column(m, g[0], g[1], g[2], g[3], g[4], g[5])
         t0 = time.perf_counter()
-        join = orc.OracleJoin(dim_k, capi.INT64, 0, (m - 1) * mul)
+        join = orc.OracleJoin(dim_k, capi.INT64, 0, (span - 1) * mul)
         build_s = time.perf_counter() - t0
         inner = [dim_k, dim_w]
         plan.join_table = None
@@ -266,7 +271,7 @@ def main():
     prepart = bool(args.prepartitioned and cfg in ("cfg3", "cfg3f") and world > 1)
     extra = {"prepartitioned": True} if prepart else {}
     if cfg == "cfg4":
-        extra = {"sparse": bool(args.sparse), "sum_dim": bool(args.sum_dim)}
+        extra = {"sparse": bool(args.sparse), "sum_dim": bool(args.sum_dim), "holes": int(args.holes)}
     ra, fr, info = synth.CONFIGS[cfg](torch, total_rows, rank, world, local_rank, **extra)
     info["ra"] = ra
     if cfg == "cfg4":

@@ -128,16 +128,30 @@ def cfg3(torch, total_rows=10_000_000_000, rank=0, world=1, device_id=0, filtere
 
 
 # ---- cfg4: fact JOIN dim ON fact.k = dim.k ; SUM(fact.v) [, SUM(dim.w)]
+def dim_keys_with_holes(xp, dim_rows, mul=1, holes=0):
+    """the dimension's keys: 0 .. dim_rows - 1 (x mul); holes = h > 0: without the keys whose index is 5 (mod h) — a perfect
+    table with EMPTY slots (the general hash_join_idx probe: round 5's dense dimension is planned away as a range filter)"""
+    k = xp.arange(dim_rows, dtype=xp.int64)
+    if holes:
+        k = k[k % holes != 5]
+    return k * mul
+
+
 def cfg4(torch, total_rows=10_000_000_000, rank=0, world=1, device_id=0, dim_rows=100_000_000,
-         sparse=False, sum_dim=False):
+         sparse=False, sum_dim=False, holes=0):
     mul = 1_000_003 if sparse else 1
     dev = f"cuda:{device_id}"
-    dim_k = torch.arange(dim_rows, dtype=torch.int64, device=dev) * mul
+    key_span = dim_rows                      # the fact keys and the key range cover [0, key_span) x mul whatever the holes
+    dim_k = torch.arange(dim_rows, dtype=torch.int64, device=dev)
+    if holes:
+        dim_k = dim_k[dim_k % holes != 5].contiguous()
+    dim_k = dim_k * mul
+    dim_rows = int(dim_k.numel())
     dim_w = torch.empty(dim_rows, dtype=torch.int64, device=dev)
     generate_column(int(dim_w.data_ptr()), dim_rows, GEN_I64_MOD, SEED0 + 100, 2001, -1000, 0, 0.0, 0, 0, device_id)
-    krange = ExpressionRange(True, 0, (dim_rows - 1) * mul)
+    krange = ExpressionRange(True, 0, (key_span - 1) * mul)
     hj = HashJoin.getInstance(int(dim_k.data_ptr()), dim_rows, INT64, krange, device_id=device_id)
-    specs = [ColSpec(INT64, GEN_I64_MOD_MUL if sparse else GEN_I64_MOD, a=dim_rows, b=mul if sparse else 0, c=0,
+    specs = [ColSpec(INT64, GEN_I64_MOD_MUL if sparse else GEN_I64_MOD, a=key_span, b=mul if sparse else 0, c=0,
                      range=krange),
              ColSpec(INT64, GEN_I64_MOD, a=2_000_001, b=-1_000_000, range=ExpressionRange(True, -10**6, 10**6))]
     frags = my_fragments(total_rows, rank, world)
@@ -149,7 +163,7 @@ def cfg4(torch, total_rows=10_000_000_000, rank=0, world=1, device_id=0, dim_row
                              join_outer_col=0, join_table=hj)
     fr = FetchResult(bufs, rows, [int(dim_k.data_ptr()), int(dim_w.data_ptr())], dim_rows, device_id,
                      keepalive=cols + [dim_k, dim_w, hj])
-    return ra, fr, dict(bytes_per_row=16, join=hj.info(), gens=gen_tuples(specs), dim_mul=mul,
+    return ra, fr, dict(bytes_per_row=16, join=hj.info(), gens=gen_tuples(specs), dim_mul=mul, dim_holes=holes, key_span=key_span,
                         dim_w_gen=(GEN_I64_MOD, SEED0 + 100, 2001, -1000, 0, 0.0))
 
 

@@ -130,10 +130,11 @@ def test_cfg4_one_billion_rows_vs_oracle(torch_cuda, oracle, sparse, sum_dim):
     assert info["join"]["hash_type"] == (1 if sparse else 0)
     rs = Executor(0).executeWorkUnit(ra, fr)
     mul = info["dim_mul"]
-    dim_k = np.arange(m, dtype=np.int64) * mul
+    dim_k = synth.dim_keys_with_holes(np, span, mul, holes)
+    assert len(dim_k) == m
     g = info["dim_w_gen"]
     dim_w = oracle.generate_column(m, g[0], g[1], g[2], g[3], g[4], g[5])
-    join = oracle.OracleJoin(dim_k, capi.INT64, 0, (m - 1) * mul)
+    join = oracle.OracleJoin(dim_k, capi.INT64, 0, (span - 1) * mul)
     assert join.info()["hash_type"] == info["join"]["hash_type"]
     assert join.info()["entry_count"] == info["join"]["entry_count"]
     plan = ra.to_plan()
@@ -199,13 +200,15 @@ def test_cfg3_unfiltered_full_size_vs_oracle(torch_cuda, oracle):
     _cfg3_full_size(torch_cuda, oracle, False)
 
 
-def _cfg4_full_size(torch, oracle, sparse: bool, sum_dim: bool):
+def _cfg4_full_size(torch, oracle, sparse: bool, sum_dim: bool, holes: int = 0, n: int = 10_000_000_000):
     from heavydb_amd import synth
     from heavydb_amd.executor import Executor
-    n, m = 10_000_000_000, 100_000_000
+    m = 100_000_000
     if _free_gb(torch) < (n * 16 + (60 << 30)) / 2**30:
         pytest.skip("needs ~220 GB of free HBM")
-    ra, fr, info = synth.cfg4(torch, n, dim_rows=m, sparse=sparse, sum_dim=sum_dim)
+    ra, fr, info = synth.cfg4(torch, n, dim_rows=m, sparse=sparse, sum_dim=sum_dim, holes=holes)
+    span = m
+    m = fr.inner_num_rows
     assert info["join"]["hash_type"] == (1 if sparse else 0)
     mul = info["dim_mul"]
     rs = Executor(0).executeWorkUnit(ra, fr)
@@ -217,10 +220,11 @@ def _cfg4_full_size(torch, oracle, sparse: bool, sum_dim: bool):
     ra.join_table = None
     del rs, fr                # 160 GB of fact columns are not needed while the host scans
     _free_gb(torch)
-    dim_k = np.arange(m, dtype=np.int64) * mul
+    dim_k = synth.dim_keys_with_holes(np, span, mul, holes)
+    assert len(dim_k) == m
     g = info["dim_w_gen"]
     dim_w = oracle.generate_column(m, g[0], g[1], g[2], g[3], g[4], g[5])
-    join = oracle.OracleJoin(dim_k, capi.INT64, 0, (m - 1) * mul)
+    join = oracle.OracleJoin(dim_k, capi.INT64, 0, (span - 1) * mul)
     assert join.info()["hash_type"] == info["join"]["hash_type"]
     assert join.info()["entry_count"] == info["join"]["entry_count"]
     t0 = time.time()
@@ -237,6 +241,14 @@ def test_cfg4_full_size_vs_oracle(torch_cuda, oracle, sum_dim):
     """cfg4 at 10 B fact rows x 100 M dim rows (dense keys, perfect int32[] table): SUM(fact.v) [, SUM(dim.w)]
     bit-exact against the oracle's probe of its own table (hash_join_idx, GroupByRuntime.cpp:287-297)."""
     _cfg4_full_size(torch_cuda, oracle, False, sum_dim)
+
+
+@pytest.mark.parametrize("sum_dim", [False, True], ids=["query_a", "query_b"])
+def test_cfg4_dimension_with_holes_vs_oracle(torch_cuda, oracle, sum_dim):
+    """the same probe over a dimension WITH HOLES (every 16th key missing: slots of the perfect table stay -1, 1 / 16 of the
+    fact rows find no match) at 2 B fact rows: the general hash_join_idx probe — the dense dimension's INNER join is planned
+    away as a range filter"""
+    _cfg4_full_size(torch_cuda, oracle, False, sum_dim, holes=16, n=2_000_000_000)
 
 
 @pytest.mark.parametrize("sum_dim", [False, True], ids=["query_a", "query_b"])

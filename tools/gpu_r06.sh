@@ -19,7 +19,7 @@ case $step in
     timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o atoms -- python tools/bool_filter_bench.py --rows 1e9 --steps 3 --only ${3:-guarded_div,sum_gt,col_lt_col,affine} > $out/bench.jsonl 2> $out/rocprof.err
     find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/atoms_kernel_stats.csv \; ; rm -rf $out/trace; cut -c1-160 $out/atoms_kernel_stats.csv | head -12; cut -c1-200 $out/bench.jsonl ;;
   atomspmc) # k_filter_mask's instruction mix and stall split (SQ counters; one pass, kernel trace only)
-    timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/pmc -o pmc -- python tools/bool_filter_bench.py --rows 1e9 --steps 1 --only ${3:-col_lt_col} > $out/pmc.log 2>&1
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/pmc -o pmc -- python tools/bool_filter_bench.py --rows 1e9 --steps 1 --prepass --only ${3:-guarded_div} > $out/pmc.log 2>&1
     python tools/rocpd_stats.py $out/pmc/pmc_results.db > $out/pmc_stats.txt 2>&1; rm -rf $out/pmc; grep -E "k_filter_mask|k_groupby" $out/pmc_stats.txt | cut -c1-260; tail -3 $out/pmc.log ;;
   projexpr) # Projection with expression targets: forms in the fast member next to the plain shape and the general member's interpreter
     timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant plain > $out/proj_plain.jsonl 2> $out/err.log; echo "plain exit $?"
@@ -37,6 +37,36 @@ case $step in
       timeout 400 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant $v >> $out/proj_join_variants_1b.jsonl 2>> $out/err.log; echo "$v exit $?"
     done
     cut -c1-330 $out/proj_join_variants_1b.jsonl; tail -3 $out/err.log ;;
+  cfg4)     # BASELINE cfg4 on a dimension WITH HOLES (the general perfect probe), Query A and B, driver-style lines + the 2 B-row parity tests
+    timeout 900 python -u -m pytest tests/test_zz_gpu_baseline_sizes.py -m gpu -q -p no:cacheprovider -k "holes" > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
+    for spec in "cfg4a_holes:--config cfg4 --holes 16" "cfg4b_holes:--config cfg4 --holes 16 --sum-dim"; do
+      tag=${spec%%:*}; args=${spec#*:}
+      timeout 600 python bench.py $args --steps 5 --warmup 2 --no-cpu-baseline --verify > $out/bench_$tag.json 2> $out/bench_$tag.err
+      echo "$tag: exit $? $(python -c "import json; d=json.load(open('$out/bench_$tag.json')); print(d['ms_per_step'], d['roofline'].get('frac'), d['roofline'].get('whole_step_frac'), d['config'].get('route'))" 2>&1)"
+    done ;;
+  final)    # the round's kept lines on ONE build: every BASELINE config (roofline + cpu_baseline + verify), the default line's
+            # rocprofv3 kernel summary and FETCH / WRITE passes (-> profiles/traffic.json), the Projection / filter / NGA / sort shapes,
+            # the reference's 57 benchmark steps at 1 B rows
+    timeout 400 python bench.py > $out/bench_default.json 2> $out/bench_default.err; echo "bench default exit $? $(python -c "import json; d=json.load(open('$out/bench_default.json')); print(d['ms_per_step'], d['roofline']['frac'], d['roofline'].get('whole_step_frac'))")"
+    for spec in "cfg1:--config cfg1 --steps 50 --warmup 5" "cfg2:--config cfg2 --steps 20 --warmup 3" "cfg3:--config cfg3" "cfg3f:--config cfg3f" "cfg4:--config cfg4" "cfg4_sum_dim:--config cfg4 --sum-dim" "cfg4_holes:--config cfg4 --holes 16" "cfg4_holes_sum_dim:--config cfg4 --holes 16 --sum-dim" "cfg4_sparse:--config cfg4 --sparse" "cfg4_sparse_sum_dim:--config cfg4 --sparse --sum-dim"; do
+      tag=${spec%%:*}; args=${spec#*:}
+      timeout 600 python bench.py $args --verify > $out/bench_$tag.json 2> $out/bench_$tag.err
+      echo "$tag: exit $? $(python -c "import json; d=json.load(open('$out/bench_$tag.json')); print(d['ms_per_step'], d['roofline'].get('frac'), d['roofline'].get('whole_step_frac'), d['cpu_baseline']['value'] if d.get('cpu_baseline') else None)" 2>&1)"
+    done
+    timeout 300 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o cfg3f -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $out/bench_rocprof.json 2> $out/bench_rocprof.err
+    find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/cfg3f_kernel_stats.csv \; ; rm -rf $out/trace
+    for grp in FETCH_SIZE WRITE_SIZE; do
+      timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $out/pmc_$grp -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline > $out/pmc_$grp.log 2>&1
+      python tools/rocpd_stats.py $out/pmc_$grp/pmc_results.db > $out/pmc_${grp}_stats.txt 2>&1; rm -rf $out/pmc_$grp
+    done
+    python tools/make_traffic_json.py $out/pmc_FETCH_SIZE_stats.txt $out/pmc_WRITE_SIZE_stats.txt 1e10 r06 && cp profiles/traffic.json $out/traffic.json
+    timeout 400 python bench.py > $out/bench_default_with_traffic.json 2> $out/bench_default_with_traffic.err; echo "bench (traffic) exit $?"
+    timeout 500 python tools/proj_bench.py --rows 1e9 --steps 5 > $out/proj_bench_1b.jsonl 2> $out/proj_bench.err; echo "proj bench exit $?"
+    timeout 400 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --verify-rows 4e6 > $out/bool_filter_1b.jsonl 2> $out/bool_filter.err; echo "bool filter exit $?"
+    timeout 300 python tools/nga_sweep.py --rows 1e9 --bpc 0 > $out/nga_1b.jsonl 2> $out/nga.err; echo "nga exit $?"
+    timeout 300 python tools/topk_time.py > $out/sort_time.txt 2>&1; echo "sort exit $?"
+    timeout 700 python tools/refbench.py --rows 1e9 --steps 3 --budget-ms 1500 --out $out/refbench_1b.jsonl > $out/refbench_1b.log 2>&1; echo "refbench 1B exit $?"
+    head -3 $out/cfg3f_kernel_stats.csv ;;
   suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
     timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200
