@@ -451,7 +451,8 @@ MQ_D void fast_qual(const fast::RangeFilter& f, const int8_t* base, const int64_
 // NT targets; COL: a columnar buffer (one run per column) instead of whole rows.  A wave stages the quads of LH lanes at a
 // time (ranks are lane-major: a run of lanes is a run of entries): all 64 while 256 staged entries fit the LDS budget of
 // four workgroups per CU, else 32.
-template <int NT, bool COL>
+// XF: some target is a form (kernels.h ProjForm) — members without forms carry none of that code
+template <int NT, bool COL, bool XF = false>
 __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
   extern __shared__ __attribute__((aligned(16))) char s_stage[];  // per wave: the entries of one step, assembled before they leave
   __shared__ uint32_t s_cnt[kIters * kWaves];   // matches of (iteration, wave); then their exclusive prefix in that order
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
       }
       // targets that are forms: [CAST](column) <op> literal on the quad just loaded (wave-uniform branches on the form)
       int32_t ferr[4] = {0, 0, 0, 0};
-      if (a.any_form && mm) {
+      if (XF && mm) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
           if (!a.f_on[t]) continue;
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
         for (int i = 0; i < 4; ++i) {
           if (!in_step || !((mm >> i) & 1u)) continue;
           // (the error of a form counts for a row that is EMITTED: one past the scan limit / the buffer's end is not)
-          if (ferr[i] && !err && wfirst + (int64_t)k < a.entry_count) err = ferr[i];
+          if (XF && ferr[i] && !err && wfirst + (int64_t)k < a.entry_count) err = ferr[i];
           if (!COL) {
             int64_t* row = (int64_t*)stage + (size_t)k * rq;
             row[0] = r + i;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
       }
     }
   }
-  if (err) atomicCAS(a.d_err, 0, err);
+  if (XF && err) atomicCAS(a.d_err, 0, err);
 }
 
 // HJ: the step joins a one-to-one hash table (fast_quals is off: every row takes row_passes, which probes for an INNER
@@ -1229,7 +1230,7 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
     const ProjTarget& pt = ps.t[t];
     if (pt.col >= ps.n_phys_cols && pt.col < kProjInnerCol) {  // an expression: its form reads ONE plain column
       const ProjForm& pf = forms->f[t];
-      fast_ok = forms_ok && pf.on && pf.src_col < ps.n_phys_cols && pf.src_col < 31 && ((a.vec_mask >> pf.src_col) & 1);
+      fast_ok = forms_ok && pf.on && ps.n_targets <= 4 && pf.src_col < ps.n_phys_cols && pf.src_col < 31 && ((a.vec_mask >> pf.src_col) & 1);
       fa.tcol[t] = pf.src_col;
       fa.tkind[t] = pf.src_code == MI355Q_INT32 ? 1 : 0;
       fa.tw[t] = ps.columnar ? pt.width : 8;
@@ -1311,6 +1312,20 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
     if (ps.columnar) hipLaunchKernelGGL((k_proj_fast<N, true>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0);   \
     else hipLaunchKernelGGL((k_proj_fast<N, false>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0);              \
     break
+#define MQ_PROJ_FAST_XF(N)                                                                                                      \
+  case N:                                                                                                                       \
+    if (ps.columnar) hipLaunchKernelGGL((k_proj_fast<N, true, true>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0);  \
+    else hipLaunchKernelGGL((k_proj_fast<N, false, true>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0);             \
+    break
+      if (fa.any_form) {  // (≤ 4 targets: checked above)
+        switch (ps.n_targets) {
+          MQ_PROJ_FAST_XF(1);
+          MQ_PROJ_FAST_XF(2);
+          MQ_PROJ_FAST_XF(3);
+          default:
+            MQ_PROJ_FAST_XF(4);
+        }
+      } else
       switch (ps.n_targets) {
         MQ_PROJ_FAST(1);
         MQ_PROJ_FAST(2);
@@ -1323,6 +1338,7 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
           MQ_PROJ_FAST(8);
       }
 #undef MQ_PROJ_FAST
+#undef MQ_PROJ_FAST_XF
     }
     if (st && st->k_stop) (void)hipEventRecord(st->k_stop, s);
     e = hipGetLastError();

@@ -165,7 +165,13 @@ def build_cases(scale: int = 1) -> List[ProjCase]:
     # round 6: targets that are FORMS — [CAST](column) <op> literal — evaluated by the fast member on the quad it loads
     I64 = capi.INT64
     add_x("expr_form_targets", xd, [x, y, z], [C_(0).add(L(I32, 5), I32), C_(2).mul(L(F64, 2.5), F64), C_(0).cast(I64).mul(L(I64, 1000), I64),
-                                             L(I32, 10).sub(C_(1), I32), C_(1).cast(F64)], [3, 4, 5, 6, 7, 1],
+                                             ], [3, 4, 5, 1],
+          [Qual(1, capi.GT, -10)], [m // 2 + 1, m - m // 2 - 1], max_groups_buffer_entry_guess=m)
+    add_x("expr_form_targets_literal_first_and_cast", xd, [x, y, z], [L(I32, 10).sub(C_(1), I32), C_(1).cast(F64)], [3, 4, 0],
+          [Qual(1, capi.GT, -10)], [m], max_groups_buffer_entry_guess=m)
+    # (forms are instantiated for <= 4 targets: a wider row keeps the general member's interpreter)
+    add_x("expr_targets_six_wide", xd, [x, y, z], [C_(0).add(L(I32, 5), I32), C_(2).mul(L(F64, 2.5), F64), C_(0).cast(I64).mul(L(I64, 1000), I64),
+                                                 L(I32, 10).sub(C_(1), I32), C_(1).cast(F64)], [3, 4, 5, 6, 7, 1],
           [Qual(1, capi.GT, -10)], [m // 2 + 1, m - m // 2 - 1], max_groups_buffer_entry_guess=m)
     add_x("expr_form_targets_columnar", xd, [x, y, z], [C_(0).add(L(I32, 5), I32), C_(2).sub(L(F64, 0.5), F64), C_(0).cast(I64).mul(L(I64, 1000), I64)],
           [3, 4, 5, 2], [Qual(1, capi.GT, 0)], [m], max_groups_buffer_entry_guess=m, output_columnar_hint=capi.OUTPUT_COLUMNAR)
