@@ -57,6 +57,12 @@ MQ_D void load_quad<double>(const int8_t* base, int64_t quad, Quad<double>& q) {
   q.v[0] = bits_dbl(a.x); q.v[1] = bits_dbl(a.y);
   q.v[2] = bits_dbl(b.x); q.v[3] = bits_dbl(b.y);
 }
+// a 1-byte column (TINYINT / BOOLEAN; the row mask of a compiled filter, kernels_filter.hip): four rows = one 4-byte load
+template <>
+MQ_D void load_quad<int8_t>(const int8_t* base, int64_t quad, Quad<int8_t>& q) {
+  const uint32_t x = __builtin_nontemporal_load((const MQ_GLOBAL uint32_t*)base + quad);
+  q.v[0] = (int8_t)x; q.v[1] = (int8_t)(x >> 8); q.v[2] = (int8_t)(x >> 16); q.v[3] = (int8_t)(x >> 24);
+}
 template <>
 MQ_D void load_quad<none_t>(const int8_t*, int64_t, Quad<none_t>&) {}
 
@@ -316,7 +322,7 @@ inline RangeFilter no_filter() {
 // Common shape test for the grouped fast families: at most one integer qual, every value
 // aggregate on ONE NOT NULL column of type int64/double, COUNT(*) and key projections free.
 struct FastShape {
-  int fil_type = 0;   // 0 none / MI355Q_INT32 / MI355Q_INT64
+  int fil_type = 0;   // 0 none / MI355Q_INT32 / MI355Q_INT64 / MI355Q_INT8 (every dispatch on it names all four)
   RangeFilter flt;
   int vcol = -1, vtype = 0;
   SlotProg sp;
@@ -338,7 +344,7 @@ inline bool grouped_fast_shape(const DevPlan& p, const FragView& fv, FastShape* 
   if (p.group_nullable && p.desc_type != MI355Q_GROUP_BY_BASELINE_HASH) return false;
   s->flt = no_filter();
   if (p.n_quals == 1) {
-    if (!make_range_filter(p.quals[0], &s->flt)) return false;
+    if (!make_range_filter(p.quals[0], &s->flt, true)) return false;  // (INT32 / INT64, or a 1-byte column: the filter mask)
     s->fil_type = p.quals[0].type;
     if (!all_aligned16(fv, p.quals[0].col)) return false;
   }

@@ -1130,6 +1130,9 @@ hipError_t launch_perfect_lds(const DevPlan& p, const FragView& fv, int64_t* out
   } else if (fs.fil_type == MI355Q_INT32) {
     e = k32 ? launch_perfect_lds_v<int32_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus)
             : launch_perfect_lds_v<int32_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus);
+  } else if (fs.fil_type == MI355Q_INT8) {
+    e = k32 ? launch_perfect_lds_v<int8_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus)
+            : launch_perfect_lds_v<int8_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus);
   } else {
     e = k32 ? launch_perfect_lds_v<int64_t, int32_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus)
             : launch_perfect_lds_v<int64_t, int64_t>(fs, a, fv, out, d_err, grid, lds, s, n_cus);
@@ -1215,6 +1218,7 @@ hipError_t launch_baseline_fast(const DevPlan& p, const FragView& fv, int64_t* o
   hipError_t e;
   if (fs.fil_type == 0) e = launch_baseline_direct_v<none_t>(fs, a, fv, out, d_err, grid, s);
   else if (fs.fil_type == MI355Q_INT32) e = launch_baseline_direct_v<int32_t>(fs, a, fv, out, d_err, grid, s);
+  else if (fs.fil_type == MI355Q_INT8) e = launch_baseline_direct_v<int8_t>(fs, a, fv, out, d_err, grid, s);
   else e = launch_baseline_direct_v<int64_t>(fs, a, fv, out, d_err, grid, s);
   rec(st->k_stop, s);
   return e;

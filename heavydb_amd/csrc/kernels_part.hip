@@ -2496,6 +2496,8 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
         e2 = launch_scatter_v<none_t>(fs, h.g.B, h.lds1, s, fv, c.f0, c.nf, p.group_col, sa, buf_recs(b), buf_cnt(b), buf_sl(b));
       else if (fs.fil_type == MI355Q_INT32)
         e2 = launch_scatter_v<int32_t>(fs, h.g.B, h.lds1, s, fv, c.f0, c.nf, p.group_col, sa, buf_recs(b), buf_cnt(b), buf_sl(b));
+      else if (fs.fil_type == MI355Q_INT8)
+        e2 = launch_scatter_v<int8_t>(fs, h.g.B, h.lds1, s, fv, c.f0, c.nf, p.group_col, sa, buf_recs(b), buf_cnt(b), buf_sl(b));
       else
         e2 = launch_scatter_v<int64_t>(fs, h.g.B, h.lds1, s, fv, c.f0, c.nf, p.group_col, sa, buf_recs(b), buf_cnt(b), buf_sl(b));
       if (e2 != hipSuccess) return e2;
@@ -2551,6 +2553,8 @@ hipError_t launch_baseline_partitioned(const DevPlan& p, const FragView& fv, int
       e = launch_scatter_v<none_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, sa, recs, cnt, sl);
     else if (fs.fil_type == MI355Q_INT32)
       e = launch_scatter_v<int32_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, sa, recs, cnt, sl);
+    else if (fs.fil_type == MI355Q_INT8)
+      e = launch_scatter_v<int8_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, sa, recs, cnt, sl);
     else
       e = launch_scatter_v<int64_t>(fs, h.g.B, h.lds1, s, fv, f, f1 - f, p.group_col, sa, recs, cnt, sl);
     if (e != hipSuccess) return e;

@@ -839,11 +839,12 @@ def test_program_atoms_in_compiled_filters(sim, oracle, name, consumer):
     rs = flow._check(oracle, case, kernel_variant=0, flags=capi.OPT_LDS_GENERIC_MEMBER if consumer == "generic_lds" else 0)
     if case.expect_error is None:
         kn = rs.report.kernel_name.decode()
-        assert kn == ("k_scan_agg" if consumer == "scan_agg" else "k_groupby_lds"), kn
+        # (behind the row mask the step has ONE 1-byte qual: the planner may give a perfect-hash few-groups step to k_perfect_lds)
+        assert kn == "k_scan_agg" if consumer == "scan_agg" else kn in ("k_groupby_lds", "k_perfect_lds"), kn
         lean = name in ("guarded_div", "sum_of_two_columns", "column_vs_column", "nullable_column_vs_column", "modulo",
                         "not_over_program_atom")
         if consumer == "typed_lds":
-            assert rs.report.variant == 5, rs.report.variant
+            assert rs.report.variant == 5 or kn == "k_perfect_lds", rs.report.variant
             # lean atoms (INT32 operands, one operation) are evaluated by the typed member itself; the rest by the row-mask pre-pass
             assert ("k_filter_mask" in route) == (not lean), (name, route)
             # ... and the pre-pass (both of its members) agrees
@@ -911,12 +912,52 @@ def test_pair_atoms_on_edge_values(sim, oracle, op, nullable, member):
                                                                "lean": capi.OPT_FILTER_PREPASS, "fused": 0}[member])
 
 
+@pytest.mark.parametrize("family,variant", [("k_part_scatter", 2), ("k_baseline_direct", 1), ("k_perfect_lds", 0)])
+@pytest.mark.parametrize("name", ["guarded_div", "affine", "double_arithmetic", "unguarded_div"])
+def test_program_atoms_through_the_mask_in_the_large_table_families(sim, oracle, name, family, variant):
+    """the row mask (1 B/row, `mask = 1`) is a filter column the FastShape families take too (round 6: Quad<int8_t>): a filter
+    with program atoms in front of the partitioned GROUP BY (the headline family), the direct baseline member and the
+    perfect-hash LDS member — no interpreter pass, no 4-byte temporary column"""
+    from heavydb_amd.executor import Executor
+    case = _mask_large_case(name, family)
+    err = case.expect_error
+    rs = flow._check(oracle, case, kernel_variant=variant, flags=capi.OPT_FILTER_PREPASS)
+    if err is None:
+        assert rs.report.kernel_name.decode() == family, rs.report.kernel_name
+        route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags], kernel_variant=variant, flags=capi.OPT_FILTER_PREPASS)
+        assert "k_filter_mask" in route and "k_project" not in route, route
+
+
+def _mask_large_case(name, family, n=40_003, n_groups=3000):
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, Qual, RelAlgExecutionUnit, TargetExpr
+    from tests.cases import Case
+    descs, cols = _prog_atom_table(n, seed=9)
+    e, err = _prog_atom_shapes()[name]
+    rng = np.random.default_rng(1)
+    if family == "k_perfect_lds":   # SELECT g, SUM(w) ... GROUP BY g: one INT64 value column, 50 groups
+        key_desc, key = descs[0], cols[0]
+        targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 5)]
+    else:                           # SELECT k, COUNT(*), AVG(d2) ... GROUP BY k: one 8-byte baseline key, 3 000 groups
+        key = (rng.integers(0, n_groups, len(cols[0])) * 1_000_003 + 7).astype(np.int64)
+        key_desc = InputColDescriptor(capi.INT64, False, ExpressionRange(False))
+        targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.AVG, 5)]
+    descs = [key_desc] + descs[1:]
+    cols = [key] + cols[1:]
+    nc = len(descs)
+    ra = RelAlgExecutionUnit(descs, targets, [Qual(nc, capi.EQ, 1)], [0], exprs=[e.with_range(ExpressionRange(True, 0, 1, True))],
+                             max_groups_buffer_entry_guess=max(8192, 2 * n_groups), num_tuples=len(key))
+    h = len(key) // 2 // 4 * 4
+    case = Case(name, ra, [[x[:h] for x in cols], [x[h:] for x in cols]])
+    case.expect_error = err
+    return case
+
+
 def test_program_atoms_beside_plain_quals_and_range_atoms(sim, oracle):
     from heavydb_amd.executor import Qual
     for name in ("guarded_div", "sum_of_two_columns", "double_column"):
         case = _prog_atom_case(name, quals=[Qual(1, capi.GE, -500), Qual(4, capi.IS_NOT_NULL, 0)])
         rs = flow._check(oracle, case, kernel_variant=0)
-        assert rs is not None and rs.report.kernel_name.decode() == "k_groupby_lds"
+        assert rs is not None and rs.report.kernel_name.decode() in ("k_groupby_lds", "k_perfect_lds")
 
 
 def test_an_error_in_a_dropped_row_still_counts_when_the_expression_is_evaluated(sim, oracle):

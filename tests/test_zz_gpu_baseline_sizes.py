@@ -130,6 +130,7 @@ def test_cfg4_one_billion_rows_vs_oracle(torch_cuda, oracle, sparse, sum_dim):
     assert info["join"]["hash_type"] == (1 if sparse else 0)
     rs = Executor(0).executeWorkUnit(ra, fr)
     mul = info["dim_mul"]
+    span, holes = m, 0
     dim_k = synth.dim_keys_with_holes(np, span, mul, holes)
     assert len(dim_k) == m
     g = info["dim_w_gen"]

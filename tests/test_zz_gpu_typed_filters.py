@@ -83,5 +83,25 @@ def test_program_atoms_on_the_device(torch_cuda, oracle, name, consumer):
         assert ei.value.code == case.expect_error, ei.value.code
         return
     rs = _run(torch_cuda, oracle, case)
-    assert rs.report.kernel_name.decode() == ("k_scan_agg" if consumer == "scan_agg" else "k_groupby_lds"), rs.report.kernel_name
+    kn = rs.report.kernel_name.decode()
+    assert kn == "k_scan_agg" if consumer == "scan_agg" else kn in ("k_groupby_lds", "k_perfect_lds"), kn
     _run(torch_cuda, oracle, case, capi.OPT_NO_COMPILED_FILTER)   # the interpreter pass agrees
+
+
+@pytest.mark.parametrize("family,variant", [("k_part_scatter", 2), ("k_baseline_direct", 1), ("k_perfect_lds", 0)])
+@pytest.mark.parametrize("name", ["guarded_div", "affine", "double_arithmetic"])
+def test_program_atoms_through_the_mask_in_the_large_table_families_on_the_device(torch_cuda, oracle, name, family, variant):
+    """the row mask in front of the partitioned GROUP BY (the headline family, 150 K groups over 3 M rows), the direct baseline
+    member and the perfect-hash LDS member"""
+    from tests.test_hostsim_real_kernels import _mask_large_case
+    from heavydb_amd.executor import Executor, FetchResult
+    case = _mask_large_case(name, family, n=3_000_003, n_groups=150_000)
+    q, want, code = oracle.execute(case.ra.to_plan(), case.frags, n_threads=8)
+    assert code == 0
+    frags = [[torch_cuda.from_numpy(np.ascontiguousarray(a)).cuda() for a in cols] for cols in case.frags]
+    fr = FetchResult([[int(t.data_ptr()) for t in cols] for cols in frags], [len(cols[0]) for cols in case.frags], keepalive=[frags])
+    rs = Executor(0).executeWorkUnit(case.ra, fr, allow_retry=False, kernel_variant=variant, flags=capi.OPT_FILTER_PREPASS)
+    qmd_equal(q, rs.getQueryMemDesc())
+    compare_buffers(q, want, rs.getStorage(), 1e-9)
+    compare_rows(q, oracle.fetch_rows(q, want), rs.fetch(), 1e-9)
+    assert rs.report.kernel_name.decode() == family, rs.report.kernel_name
