@@ -303,7 +303,8 @@ int64_t eval_reduced(const std::vector<DevExprNode>& prog, const int* state_of_p
 }  // namespace
 
 bool compile_bool_filter(const mi355q_plan& plan, BoolFilterHost* out, mi355q_plan* rest) {
-  if (plan.n_exprs <= 0 || plan.n_exprs > MI355Q_MAX_EXPRS || plan.n_quals <= 0 || plan.n_quals > MI355Q_MAX_QUALS) return false;
+  // (n_exprs = 0: a filter of plain quals alone — several of them in front of a family that filters on one column, api.cpp)
+  if (plan.n_exprs < 0 || plan.n_exprs > MI355Q_MAX_EXPRS || plan.n_quals <= 0 || plan.n_quals > MI355Q_MAX_QUALS) return false;
   mi355q_plan lp;
   DevExprSet xs;
   if (lower_exprs(plan, &lp, &xs) != MI355Q_OK) return false;
@@ -414,7 +415,7 @@ bool compile_bool_filter(const mi355q_plan& plan, BoolFilterHost* out, mi355q_pl
     o.bf.prog[k] = c.progs[(size_t)k];
     o.bf.any_raise |= c.progs[(size_t)k].can_raise;
   }
-  o.bf.all_lean = npg > 0;
+  o.bf.all_lean = 1;  // (vacuously so without programs: range atoms alone also take the lean member of the pre-pass)
   o.bf.all_i32 = 1;
   for (int k = 0; k < o.bf.n_cols; ++k) o.bf.all_i32 = o.bf.all_i32 && o.bf.col_type[k] == MI355Q_INT32;
   for (int k = 0; k < npg; ++k) {

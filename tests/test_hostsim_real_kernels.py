@@ -952,6 +952,25 @@ def _mask_large_case(name, family, n=40_003, n_groups=3000):
     return case
 
 
+@pytest.mark.parametrize("quals", ["two_columns", "three_columns_negated", "int64_column", "is_not_null"])
+def test_several_plain_quals_in_front_of_the_partitioned_family_take_the_mask(sim, oracle, quals):
+    """`a < K AND b > L` over a large-cardinality baseline GROUP BY used to fall to the row kernel (the partitioned family filters
+    on ONE column): the quals are compiled into range atoms, the pre-pass leaves the row mask, the step runs on `mask = 1`"""
+    from heavydb_amd.executor import Executor, Qual
+    case = _mask_large_case("guarded_div", "k_part_scatter")
+    case.ra.exprs = []
+    case.expect_error = None
+    case.ra.simple_quals = {"two_columns": [Qual(2, capi.LT, 300), Qual(3, capi.GT, -3)],
+                            "three_columns_negated": [Qual(2, capi.NE, 7), Qual(3, capi.LE, 2), Qual(1, capi.GE, -900)],
+                            "int64_column": [Qual(5, capi.GT, -10**11), Qual(2, capi.LT, 500)],
+                            "is_not_null": [Qual(4, capi.IS_NOT_NULL, 0), Qual(4, capi.LT, 60), Qual(2, capi.GT, -800)]}[quals]
+    rs = flow._check(oracle, case, kernel_variant=2)
+    assert rs.report.kernel_name.decode() == "k_part_scatter", rs.report.kernel_name
+    route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags], kernel_variant=2)
+    assert "quals compiled" in route and "k_filter_mask" in route and "k_generic" not in route, route
+    flow._check(oracle, case, kernel_variant=2, flags=capi.OPT_NO_COMPILED_FILTER)   # (the row kernel agrees)
+
+
 def test_program_atoms_beside_plain_quals_and_range_atoms(sim, oracle):
     from heavydb_amd.executor import Qual
     for name in ("guarded_div", "sum_of_two_columns", "double_column"):

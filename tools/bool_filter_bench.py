@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--count-only", action="store_true", help="SELECT g, COUNT(*) ...: no value column (the NV = 0 typed members)")
     ap.add_argument("--generic-member", action="store_true", help="MI355Q_OPT_LDS_GENERIC_MEMBER: the run-time-role member of k_groupby_lds")
     ap.add_argument("--only", default="", help="comma-separated shape names")
+    ap.add_argument("--big-key", action="store_true", help="g is an INT64 key with 10 M values (baseline hash: the partitioned family, the headline's) instead of 1 000 INT32 groups")
     ap.add_argument("--prepass", action="store_true", help="MI355Q_OPT_FILTER_PREPASS: program atoms through the row-mask pre-pass even where the typed member evaluates them itself")
     ap.add_argument("--interpreted", action="store_true", help="MI355Q_OPT_NO_COMPILED_FILTER: every expression through k_project")
     args = ap.parse_args()
@@ -69,17 +70,21 @@ def main():
     # 0 g: 1 000 groups; 1 v; 2 a, 3 b: uniform [0, 1 M); 4 c: uniform [0, 1 M), stated nullable (no NULLs generated)
     gens = [(capi.GEN_I32_MOD, 21, 1000), (capi.GEN_I32_MOD, 22, 1_000_000), (capi.GEN_I32_MOD, 23, 1_000_000),
             (capi.GEN_I32_MOD, 24, 1_000_000), (capi.GEN_I32_MOD, 25, 1_000_000)]
-    cols = [torch.empty(n, dtype=torch.int32, device="cuda:0") for _ in gens]
+    if args.big_key:
+        gens[0] = (capi.GEN_I64_MOD_MUL, 21, 10_000_000)
+    cols = [torch.empty(n, dtype=torch.int64 if (args.big_key and i == 0) else torch.int32, device="cuda:0") for i, _ in enumerate(gens)]
     bufs, rows, off = [], [], 0
     while off < n:
         k = min(frag, n - off)
         for t, (kind, seed, mod) in zip(cols, gens):
-            generate_column(int(t.data_ptr()) + off * 4, k, kind, seed, mod, 0, 0, 0.0, 0, off, 0)
-        bufs.append([int(t.data_ptr()) + off * 4 for t in cols])
+            generate_column(int(t.data_ptr()) + off * t.element_size(), k, kind, seed, mod, 1_000_003 if kind == capi.GEN_I64_MOD_MUL else 0,
+                            7 if kind == capi.GEN_I64_MOD_MUL else 0, 0.0, 0, off, 0)
+        bufs.append([int(t.data_ptr()) + off * t.element_size() for t in cols])
         rows.append(k)
         off += k
     torch.cuda.synchronize()
-    descs = [InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 999))] + \
+    descs = [InputColDescriptor(capi.INT64, False, ExpressionRange(True, 7, 9_999_999 * 1_000_003 + 7)) if args.big_key else
+             InputColDescriptor(capi.INT32, False, ExpressionRange(True, 0, 999))] + \
             [InputColDescriptor(capi.INT32, i == 4, ExpressionRange(True, 0, 999_999, False)) for i in range(1, 5)]
     fr = FetchResult(bufs, rows, keepalive=cols)
     ex = Executor(0)
@@ -90,7 +95,7 @@ def main():
         xs = [e.with_range(ExpressionRange(True, 0, 1, True)) for e in exprs]
         targets = [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT)] + ([] if args.count_only else [TargetExpr(capi.SUM, 1)])
         ra = RelAlgExecutionUnit(descs, targets, quals, [0],
-                                 exprs=xs, num_tuples=n)
+                                 exprs=xs, num_tuples=n, **({"max_groups_buffer_entry_guess": 20_000_000} if args.big_key else {}))
         best, rs = None, None
         for _ in range(args.steps):
             rs = ex.executeWorkUnit(ra, fr, allow_retry=False, flags=flags)
@@ -98,7 +103,8 @@ def main():
         if args.count_only:
             reads = [c for c in reads if c != 1]   # (no target reads the value column)
         line = {"shape": name, "rows": n, "interpreted": bool(args.interpreted), "prepass": bool(args.prepass), "count_only": bool(args.count_only), "generic_member": bool(args.generic_member), "route": ex.explain(ra, rows, flags=flags), "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3),
-                "bytes_per_row": 4 * len(reads), "whole_step_frac": round(4 * len(reads) * n / (best * 1e-3) / 8e12, 4),
+                "bytes_per_row": 4 * len(reads) + (4 if args.big_key else 0), "big_key": bool(args.big_key),
+                "whole_step_frac": round((4 * len(reads) + (4 if args.big_key else 0)) * n / (best * 1e-3) / 8e12, 4),
                 "groups": rs.rowCount()}
         if args.verify_rows:
             from oracle import oracle as orc

@@ -67,6 +67,11 @@ case $step in
     timeout 300 python tools/topk_time.py > $out/sort_time.txt 2>&1; echo "sort exit $?"
     timeout 700 python tools/refbench.py --rows 1e9 --steps 3 --budget-ms 1500 --out $out/refbench_1b.jsonl > $out/refbench_1b.log 2>&1; echo "refbench 1B exit $?"
     head -3 $out/cfg3f_kernel_stats.csv ;;
+  bigkey)   # compiled filters in front of the partitioned GROUP BY (10 M INT64 keys): the mask route vs the interpreter's INT32 column
+    timeout 900 python -u -m pytest tests/test_zz_gpu_typed_filters.py tests/test_zz_gpu_baseline_sizes.py -m gpu -q -p no:cacheprovider -k "large_table or cfg4_one_billion" > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
+    timeout 600 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --big-key --verify-rows 4e6 --only plain,guarded_div,sum_gt,affine > $out/bool_filter_big_key.jsonl 2> $out/err.log; echo "exit $?"
+    timeout 600 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --big-key --interpreted --only guarded_div,sum_gt,affine > $out/bool_filter_big_key_interpreted.jsonl 2>> $out/err.log; echo "exit $?"
+    cut -c1-330 $out/bool_filter_big_key.jsonl $out/bool_filter_big_key_interpreted.jsonl; tail -3 $out/err.log ;;
   suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
     timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200
