@@ -2464,6 +2464,22 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
       *out = nullptr;
     }
   }
+  if (plan->n_exprs != 0 && proj_step && !pend && !step_bool_filter() && !o.force_generic && !(o.flags & MI355Q_OPT_NO_COMPILED_FILTER)) {
+    // a Projection whose expressions all belong to the FILTER (`SELECT a, b FROM t WHERE x + y > 100`): the filter is compiled,
+    // the row-mask pre-pass evaluates it, the Projection runs on `mask = 1` — in its fast member where the targets allow —
+    // instead of evaluating the quals' expressions row by row in the general member.  With a LIMIT only where the filter
+    // cannot raise: the pre-pass looks at every row, the reference's loop stops at the limit.
+    BoolFilterHost bfh;
+    mi355q_plan rest;
+    if (compile_bool_filter(*plan, &bfh, &rest) && (!bfh.bf.any_raise || plan->scan_limit == 0)) {
+      const size_t mark = t_route ? t_route->size() : 0;
+      route_note("filter compiled (atoms + programs + truth table)");
+      const int32_t e = execute_masked(plan, rest, bfh, in, o, out, report, reserved);
+      if (e != kNotTaken) return e;
+      if (t_route) t_route->resize(mark);
+      *out = nullptr;
+    }
+  }
   if (plan->n_exprs != 0) {
     {  // a Projection evaluates its expressions in the compaction kernel's registers: no k_project pass
       if (proj_step) return execute_projection(plan, in, o, out, report, reserved);

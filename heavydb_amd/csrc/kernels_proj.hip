@@ -368,7 +368,7 @@ MQ_D unsigned long long tile_lookback(unsigned long long* desc, unsigned long lo
 // loaded together (NT x 16 / 32 bytes in flight per lane), only for quads with a match.
 struct FastArgs {
   int32_t n_quals, n_targets, n_frags, n_cols_table;
-  int32_t qcol[MI355Q_MAX_QUALS], qmode[MI355Q_MAX_QUALS];  // mode 1: INT32 in 32 bits, 2: INT64
+  int32_t qcol[MI355Q_MAX_QUALS], qmode[MI355Q_MAX_QUALS];  // mode 1: INT32 in 32 bits, 2: INT64, 3: INT8 (four rows = one 4-byte load)
   fast::RangeFilter qf[MI355Q_MAX_QUALS];
   int32_t tcol[MI355Q_MAX_TARGETS], tkind[MI355Q_MAX_TARGETS];  // kind 0: 8 raw bytes, 1: INT32 sign-extended, 2: FLOAT -> double
   int64_t entry_count;
@@ -421,6 +421,8 @@ MQ_D bool range_pass<int32_t>(const fast::RangeFilter& f, int32_t v) {
 }
 template <>
 MQ_D bool range_pass<int64_t>(const fast::RangeFilter& f, int64_t v) { return fast::filter_pass<int64_t>(f, v); }
+template <>
+MQ_D bool range_pass<int8_t>(const fast::RangeFilter& f, int8_t v) { return fast::filter_pass<int8_t>(f, v); }  // (a 1-byte column: the row mask)
 
 // one qual over four iterations of the tile: bits[j] &= pass mask of the lane's quad of iteration u0 + j
 template <typename T>
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
 #pragma unroll 1
       for (int k = 0; k < a.n_quals; ++k) {
         if (a.qmode[k] == 1) fast_qual<int32_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
+        else if (a.qmode[k] == 3) fast_qual<int8_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
         else fast_qual<int64_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
       }
 #pragma unroll
@@ -1221,10 +1224,12 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
   fa.d_err = d_err;
   for (int k = 0; k < p.n_quals && fast_ok; ++k) {
     const int c = p.quals[k].col;
-    fast_ok = a.qmode[k] != 0 && c < ps.n_phys_cols && c < 31 && ((a.vec_mask >> c) & 1);
-    fa.qcol[k] = c;
     fa.qmode[k] = a.qmode[k];
     fa.qf[k] = a.qf[k];
+    // a plain 1-byte column (TINYINT / BOOLEAN; the row mask of a compiled filter): the fast member's own mode
+    if (a.qmode[k] == 0 && p.quals[k].type == MI355Q_INT8 && c < ps.n_phys_cols && fast::make_range_filter(p.quals[k], &fa.qf[k], true)) fa.qmode[k] = 3;
+    fast_ok = fa.qmode[k] != 0 && c < ps.n_phys_cols && c < 31 && ((a.vec_mask >> c) & 1);
+    fa.qcol[k] = c;
   }
   for (int t = 0; t < ps.n_targets && fast_ok; ++t) {
     const ProjTarget& pt = ps.t[t];

@@ -183,6 +183,17 @@ def build_cases(scale: int = 1) -> List[ProjCase]:
     add_x("expr_form_overflow_past_the_limit", xd, [big, y, z], [C_(0).add(L(I32, 5), I32)], [3, 1], [Qual(1, capi.GE, -50)], [m], scan_limit=50)
     add_x("expr_form_overflow_filtered_out", xd, [big, np.where(np.arange(m) >= m // 2, -60, y).astype(np.int32), z], [C_(0).add(L(I32, 5), I32)], [3, 1],
           [Qual(1, capi.GE, -50)], [m], max_groups_buffer_entry_guess=m)
+    # round 6: expressions that all belong to the FILTER: compiled, evaluated by the row-mask pre-pass, the Projection runs on `mask = 1`
+    add_x("expr_filter_sum", xd, [x, y, z], [C_(0).add(C_(1), I32).cmp(capi.EX_GT, L(I32, 100))], [0, 1, 2], [Qual(3, capi.EQ, 1), Qual(1, capi.LT, 40)],
+          [m // 2 + 3, m - m // 2 - 3], max_groups_buffer_entry_guess=m)
+    add_x("expr_filter_guarded_div_columnar", xd, [x, y, z],
+          [C_(1).cmp(capi.EX_NE, L(I32, 0)).logical(capi.EX_AND, C_(0).div(C_(1), I32).cmp(capi.EX_GT, L(I32, 3)), True)], [0, 2], [Qual(3, capi.EQ, 1)],
+          [m], max_groups_buffer_entry_guess=m, output_columnar_hint=capi.OUTPUT_COLUMNAR)
+    add_x("expr_filter_double_and_limit", xd, [x, y, z], [C_(2).cmp(capi.EX_LT, C_(1).cast(F64))], [0, 2], [Qual(3, capi.EQ, 1)], [m], scan_limit=500)
+    add_x("expr_filter_unguarded_div_raises", xd, [x, y, z], [C_(0).div(C_(1), I32).cmp(capi.EX_GT, L(I32, 3))], [0], [Qual(3, capi.EQ, 1)], [m],
+          max_groups_buffer_entry_guess=m, expect_error=capi.ERR_DIV_BY_ZERO)
+    # (a filter that can raise, under a LIMIT, keeps the general member; its pass A evaluates a whole tile's quals before the
+    # limit is known: an error in a row of the tile that reaches the limit counts even behind the last row kept — DESIGN §3.2)
     # WHERE x + y > 100 (a BOOLEAN expression = 1) AND y < 40; the CASE of a guarded division as output
     cond = C_(0).add(C_(1), I32).cmp(capi.EX_GT, L(I32, 100))
     guarded = Expr.case(C_(1).cmp(capi.EX_NE, L(I32, 0)), C_(0).div(C_(1), I32), L(I32, 0), I32)

@@ -147,6 +147,13 @@ def test_projection_through_a_join_on_the_host_simulation(sim, oracle, case):
 @pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
 def test_projection_case_on_the_host_simulation(sim, oracle, case):
     rs = check_projection(oracle, case, host_fetch_result)
+    if case.name.startswith("expr_filter_"):
+        from heavydb_amd.executor import Executor
+        route = Executor(0).explain(case.ra, [len(f[0]) for f in case.frags])
+        assert "k_filter_mask" in route and "k_proj_compact" in route, route
+        if rs is not None:
+            assert rs.report.variant == 0, rs.report.variant   # the fast member, on the mask
+            check_projection(oracle, case, host_fetch_result, flags=capi.OPT_NO_COMPILED_FILTER)   # the general member agrees
     if case.name.startswith("expr_form_") and rs is not None:
         # targets that are `[CAST](column) <op> literal` stay in the fast member (report.variant 0) ...
         assert rs.report.variant == 0, rs.report.variant

@@ -25,7 +25,9 @@ case $step in
     timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant plain > $out/proj_plain.jsonl 2> $out/err.log; echo "plain exit $?"
     timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant expr > $out/proj_expr.jsonl 2>> $out/err.log; echo "expr exit $?"
     timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant expr --generic-member > $out/proj_expr_interpreted.jsonl 2>> $out/err.log; echo "expr interp exit $?"
-    cut -c1-260 $out/proj_plain.jsonl $out/proj_expr.jsonl $out/proj_expr_interpreted.jsonl; tail -3 $out/err.log ;;
+    timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant exprfilter > $out/proj_exprfilter.jsonl 2>> $out/err.log; echo "exprfilter exit $?"
+    timeout 300 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant exprfilter --interpreted > $out/proj_exprfilter_interpreted.jsonl 2>> $out/err.log; echo "exprfilter interp exit $?"
+    cut -c1-260 $out/proj_plain.jsonl $out/proj_expr.jsonl $out/proj_expr_interpreted.jsonl $out/proj_exprfilter.jsonl $out/proj_exprfilter_interpreted.jsonl; tail -3 $out/err.log ;;
   sort)     # the hand-written one-sweep radix sort: device parity tests, then the 20 M-entry timings (rocPRIM's were 2.35 / 4.26 ms)
     timeout 900 python -u -m pytest tests/test_zz_gpu_sort.py -m gpu -x -q -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
     timeout 600 python tools/topk_time.py > $out/sort_time.txt 2>&1; echo "time exit $?"; cat $out/sort_time.txt

@@ -25,10 +25,11 @@ def main():
     ap.add_argument("--sel", default="0.01,0.5,0.99")
     ap.add_argument("--cols", default="1,3,6")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    ap.add_argument("--variant", default="plain", choices=["plain", "general", "expr", "join", "join1n"],
+    ap.add_argument("--variant", default="plain", choices=["plain", "general", "expr", "exprfilter", "join", "join1n"],
                     help="general: the same shapes through the general member (pass_rows = -1); expr: the second target is v1 * 2.0 "
                          "and a third one v0 + 1 (expressions in registers); join: SELECT v.., d.w FROM t JOIN d ON t.fk = d.k "
                          "(d: 1 M rows, dense keys; fk = i32 >> 11)")
+    ap.add_argument("--interpreted", action="store_true", help="MI355Q_OPT_NO_COMPILED_FILTER: an expression filter through the general member's interpreter instead of the row-mask pre-pass")
     ap.add_argument("--generic-member", action="store_true", help="MI355Q_OPT_LDS_GENERIC_MEMBER: expression targets through the general member's interpreter even where they are forms of the fast member")
     args = ap.parse_args()
     import torch
@@ -43,7 +44,7 @@ def main():
         for n_out in [int(x) for x in args.cols.split(",")]:
             for columnar in ([False, True] if n_out == 3 else [False]):
                 ra, fr, info = synth.projection(torch, n, n_out, sel, columnar=columnar, cols_cache=cache)
-                opts = {"flags": capi.OPT_LDS_GENERIC_MEMBER} if args.generic_member else {}
+                opts = {"flags": (capi.OPT_LDS_GENERIC_MEMBER if args.generic_member else 0) | (capi.OPT_NO_COMPILED_FILTER if args.interpreted else 0)}
                 if args.variant == "general":
                     opts["pass_rows"] = -1
                 elif args.variant == "expr":
@@ -56,6 +57,13 @@ def main():
                         tg.append(TargetExpr(capi.PROJECT, nc + 1))
                     tg += [TargetExpr(capi.PROJECT, 1 + i) for i in range(2, n_out)]
                     ra.exprs, ra.target_exprs = xs, tg
+                elif args.variant == "exprfilter":   # WHERE i32 + 5 < k + 5: the same rows through an expression (a lean program atom)
+                    from heavydb_amd.executor import Expr, ExpressionRange, Qual
+                    nc = len(ra.input_col_descs)
+                    k_lit = int(ra.simple_quals[0].literal)
+                    ra.exprs = [Expr.col(0).cast(capi.INT64).add(Expr.lit(capi.INT64, 5), capi.INT64).cmp(capi.EX_LT, Expr.lit(capi.INT64, k_lit + 5))
+                                .with_range(ExpressionRange(True, 0, 1, False))]
+                    ra.simple_quals = [Qual(nc, capi.EQ, 1)]
                 elif args.variant in ("join", "join1n"):
                     from heavydb_amd.executor import ExpressionRange, FetchResult, HashJoin, InputColDescriptor, TargetExpr
                     m = 1 << 20
