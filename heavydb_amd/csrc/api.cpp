@@ -2779,7 +2779,11 @@ int32_t execute_impl(const mi355q_plan* plan, const mi355q_inputs* in,
   } else if (!o.force_generic && nf > 0) {
     if (scan_count_eligible(d, fv)) kind = K_SCAN_COUNT;
     else if (o.kernel_variant != 1 && scan_agg_eligible(d, fv)) kind = K_SCAN_AGG;
-    else if (perfect_lds_eligible(d, fv)) kind = K_PERFECT_LDS;
+    // (a 1-byte filter column — the row mask of a compiled filter — in front of a few-groups step: the typed LDS member reads it
+    // at 1.98 ms per 1 B rows, k_perfect_lds's 4-byte quad loads at ~3 ms: measured in round 6)
+    else if (!(d.n_quals == 1 && d.quals[0].type == MI355Q_INT8 && o.kernel_variant == 0 && lds_groupby_typed_eligible(d, fv, n_cus)) &&
+             perfect_lds_eligible(d, fv))
+      kind = K_PERFECT_LDS;
     // few groups: the table replicated in every workgroup's LDS (perfect-hash layouts up to 64 K entries that fit;
     // baseline layouts whose entry guess says "small" — if the groups turn out to be too many the step is re-run)
     else if (o.kernel_variant == 0 && lds_groupby_eligible(d, fv, n_cus) &&

@@ -227,6 +227,7 @@ bool idx_part_eligible(const DevPlan& p, const FragView& fv, int n_cus);
 int64_t idx_part_scratch_bytes(const DevPlan& p, const FragView& fv, int n_cus, int64_t cap_bytes);
 hipError_t launch_idx_partitioned(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, void* scratch,
                                   int64_t scratch_bytes, int64_t cap_bytes, int n_cus, hipStream_t s, LaunchStats* st);
+bool lds_groupby_typed_eligible(const DevPlan& p, const FragView& fv, int n_cus);  // ... and a TYPED member (roles compiled in) would run it
 hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int n_cus,
                               hipStream_t s, LaunchStats* st);
 bool scan_count_eligible(const DevPlan& p, const FragView& fv);

@@ -631,7 +631,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
     fca[k] = fcb[k] = 0;
     fraise[k] = false;
   }
-  if constexpr (FM != 0) {
+  if constexpr (FM == 2) {  // (FM = 2: the member of filters with lean program atoms; FM = 1 carries none of this)
     if (a.bf_on) {
       n_fprog = MQ_WAVE_UNIFORM(s_bf.n_progs);
       if (n_fprog) {
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
   }
   auto row_passes = [&](const int32_t (&fv)[TF]) -> bool {
     if constexpr (FM == 0) return true;
-    if (a.bf_on && n_fprog) {
+    if (FM == 2 && a.bf_on && n_fprog) {
       uint32_t idx = 0, mul = 1, ep = 0;
       int ai = 0;
 #pragma unroll
@@ -922,7 +922,7 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
     }
   }
   if (bad) atomicCAS(d_err, 0, MI355Q_ERR_OUT_OF_SLOTS);
-  if (bf_err) atomicCAS(d_err, 0, bf_err);  // a program atom of the compiled filter raised (error 7 / error 1)
+  if (FM == 2 && bf_err) atomicCAS(d_err, 0, bf_err);  // a program atom of the compiled filter raised (error 7 / error 1)
   if (t == 0 && kBase && *(volatile int32_t*)(d_err + 1)) *s_full = 1u;
   __syncthreads();
   if (*s_full) return;  // a lost attempt is neither folded nor flushed
@@ -1152,6 +1152,10 @@ bool lds_groupby_eligible(const DevPlan& p, const FragView& fv, int n_cus) {
   LdsArgs a;
   return make_lds_args(p, fv, n_cus, &a);
 }
+bool lds_groupby_typed_eligible(const DevPlan& p, const FragView& fv, int n_cus) {
+  LdsArgs a;
+  return make_lds_args(p, fv, n_cus, &a) && a.typed;
+}
 
 namespace {
 struct LdsLaunch {
@@ -1168,6 +1172,13 @@ template <int KK, int NK, int NV, bool MM>
 void launch_typed_member(const LdsLaunch& l) {
   // two quads per lane and column while the tile (this one and the next in flight) stays within ~64 registers
   constexpr int UQ = (NK * (KK == 1 ? 2 : 1) + NV) <= 3 ? 2 : 1;
+  if (l.a.n_flt > 0 && l.a.bf_on && step_bool_filter() && step_bool_filter()->n_progs != 0) {  // ... with lean program atoms
+    auto k = k_groupby_lds_typed<KK, NK, NV, MM, 1, 2>;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds);
+    hipLaunchKernelGGL(k, dim3(l.grid), dim3(kLdsBlock), l.lds, l.s, l.fv.d_cols, l.fv.d_num_rows, l.fv.n_frags, l.fv.n_cols,
+                       l.a, l.p, l.out, l.d_err);
+    return;
+  }
   if (l.a.n_flt > 0) {  // the filtered member: one quad per lane and column (up to three more columns in the tile)
     auto k = k_groupby_lds_typed<KK, NK, NV, MM, 1, 1>;
     (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds);

@@ -178,6 +178,7 @@ bool lds_groupby_eligible(const DevPlan& p, const FragView&, int) {
   }
   return plain_aggs(p, 3);
 }
+bool lds_groupby_typed_eligible(const DevPlan&, const FragView&, int) { return false; }  // (the stand-in has no typed members)
 hipError_t launch_lds_groupby(const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, int, hipStream_t,
                               LaunchStats* st) {
   finish(p, fv, out, d_err, st, "k_groupby_lds", 4, F_LDS_GROUPBY);
