@@ -146,7 +146,11 @@ typedef enum mi355q_agg {
   /* a non-aggregate target of a PROJECTION step (no GROUP BY, no aggregate: `SELECT a, b + 1 FROM t WHERE ...`): the value
    * of outer column / expression `col` of every row that passes the quals, written with agg_id
    * (TargetExprCodegen::codegenAggregate, TargetExprBuilder.cpp:330-560; is_agg == false).  A step is a Projection when
-   * n_group_cols == 0 and EVERY target is MI355Q_PROJECT. */
+   * n_group_cols == 0 and EVERY target is MI355Q_PROJECT.  Through a join (`table` = 1 reads the inner side): every JOINED
+   * row is an entry — one per outer row over a one-to-one table, the whole matching set over a one-to-many table
+   * (HashJoin::codegenMatchingSet, HashJoin.cpp:209; the entries of one outer row in the payload run's order, which
+   * depends on the build order as in the reference); a LEFT join keeps an unmatched row once with the inner columns'
+   * NULLs.  MI355Q_ERR_UNSUPPORTED: a one-to-many table together with projected expressions. */
   MI355Q_PROJECT = 101
 } mi355q_agg;
 
