@@ -56,39 +56,55 @@ struct PairAtom {
   int32_t ln, rn;        // the operands can be NULL (INT32_MIN)
   int32_t b_is_lit, b_lit;
   int32_t lo, hi, negate;  // the comparison as a range of the value (op 0: of sign(a - b))
+  int32_t op2, lit2;     // a CHAIN: ((a <op> b) <op2> lit2) <cmp> literal — `a * 3 - 7 <= k`; 0: none
   int32_t pad_;
 };
+// one INT32 operation of a pair atom: -> 0 (the value is in v), 2 NULL, 3 ERROR (err set).  ex_arith / ex_divmod (expr.h) on
+// 32-bit values: NULL operands give NULL before any check except MOD's zero test; DIV skips its zero test behind a NULL
+// pattern as soon as one operand may be NULL
+MQ_HD uint32_t pair_arith(int op, int32_t a, int32_t b, bool ln, bool rn, int32_t& v, int32_t& err) {
+  const int32_t nul = INT32_MIN;
+  const bool is_null = (ln && a == nul) || (rn && b == nul);
+  if (op == MI355Q_EX_DIV || op == MI355Q_EX_MOD) {
+    const bool skip = op == MI355Q_EX_DIV && (ln || rn) && (a == nul || b == nul);
+    if (!skip && b == 0) {
+      err = MI355Q_ERR_DIV_BY_ZERO;
+      return 3u;
+    }
+    if (is_null) return 2u;
+    if (b == 0) v = nul;
+    else if (b == -1) v = op == MI355Q_EX_DIV ? (int32_t)(0u - (uint32_t)a) : 0;
+    else v = op == MI355Q_EX_DIV ? a / b : a % b;
+  } else {
+    if (is_null) return 2u;
+    const int64_t r = op == MI355Q_EX_ADD ? (int64_t)a + b : op == MI355Q_EX_SUB ? (int64_t)a - b : (int64_t)a * b;
+    if (r > (int64_t)INT32_MAX || r < (int64_t)INT32_MIN) {
+      err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
+      return 3u;
+    }
+    v = (int32_t)r;
+  }
+  return 0u;
+}
 MQ_HD uint32_t pair_eval(const PairAtom& pa, int32_t a, int32_t bc, int32_t& err) {  // -> 0 FALSE, 1 TRUE, 2 NULL, 3 ERROR
   const int32_t nul = INT32_MIN;
   const int32_t b = pa.b_is_lit ? pa.b_lit : bc;
   const bool ln = pa.ln != 0, rn = pa.rn != 0;
-  const bool is_null = (ln && a == nul) || (rn && b == nul);
   int32_t v;
   if (pa.op == 0) {
-    if (is_null) return 2u;
+    if ((ln && a == nul) || (rn && b == nul)) return 2u;
     v = a < b ? -1 : a > b ? 1 : 0;
   } else {
-    if (pa.op == MI355Q_EX_DIV || pa.op == MI355Q_EX_MOD) {
-      // DIV: a NULL pattern in EITHER operand skips the zero check as soon as one of them may be NULL; MOD tests first
-      const bool skip = pa.op == MI355Q_EX_DIV && (ln || rn) && (a == nul || b == nul);
-      if (!skip && b == 0) {
-        err = MI355Q_ERR_DIV_BY_ZERO;
-        return 3u;
-      }
-      if (is_null) return 2u;
-      if (b == 0) v = nul;
-      else if (b == -1) v = pa.op == MI355Q_EX_DIV ? (int32_t)(0u - (uint32_t)a) : 0;
-      else v = pa.op == MI355Q_EX_DIV ? a / b : a % b;
-    } else {
-      if (is_null) return 2u;
-      const int64_t r = pa.op == MI355Q_EX_ADD ? (int64_t)a + b : pa.op == MI355Q_EX_SUB ? (int64_t)a - b : (int64_t)a * b;
-      if (r > (int64_t)INT32_MAX || r < (int64_t)INT32_MIN) {
-        err = MI355Q_ERR_OVERFLOW_OR_UNDERFLOW;
-        return 3u;
-      }
-      v = (int32_t)r;
+    const uint32_t st = pair_arith(pa.op, a, b, ln, rn, v, err);
+    if (st) return st;
+    const bool vn = ln || rn;  // (a value that is the NULL pattern, behind a nullable operand: NULL for whatever reads it)
+    if (pa.op2) {
+      int32_t w;
+      const uint32_t st2 = pair_arith(pa.op2, v, pa.lit2, vn, false, w, err);
+      if (st2) return st2;
+      v = w;
     }
-    if ((ln || rn) && v == nul) return 2u;  // (a value that is the NULL pattern, behind a nullable operand: the comparison's NULL)
+    if (vn && v == nul) return 2u;
   }
   bool in = v >= pa.lo && v <= pa.hi;
   if (pa.negate) in = !in;
@@ -121,6 +137,22 @@ inline void pair_atom_of(const RegProg& p, const int32_t (&op_col_type)[2], Pair
     // (the comparison's left side is NULL exactly where the arithmetic says so: its flag is the arithmetic's result flag)
     if (((s[4].flags & EXF_LHS_NULLABLE) != 0) != (pa->ln || pa->rn) || (s[4].flags & EXF_RHS_NULLABLE)) return;
     c = s[3].lit;
+  } else if (p.n_steps == 7 && s[2].kind == RP_BIN && s[2].op >= MI355Q_EX_ADD && s[2].op <= MI355Q_EX_MOD && s[2].type == MI355Q_INT32 &&
+             s[3].kind == RP_LDY_LIT && s[3].type == MI355Q_INT32 && s[3].lit <= INT32_MAX && s[3].lit >= INT32_MIN &&
+             s[4].kind == RP_BIN && s[4].op >= MI355Q_EX_ADD && s[4].op <= MI355Q_EX_MOD && s[4].type == MI355Q_INT32 &&
+             s[5].kind == RP_LDY_LIT && s[5].type == MI355Q_INT32 && s[6].kind == RP_BIN && s[6].op >= MI355Q_EX_EQ &&
+             s[6].op <= MI355Q_EX_GE && s[6].arg == MI355Q_INT32) {
+    // a chain: ((a <op> b) <op2> literal) <cmp> literal
+    cmp = &s[6];
+    pa->op = s[2].op;
+    pa->ln = (s[2].flags & EXF_LHS_NULLABLE) != 0;
+    pa->rn = (s[2].flags & EXF_RHS_NULLABLE) != 0;
+    const bool vn = pa->ln || pa->rn;
+    if (((s[4].flags & EXF_LHS_NULLABLE) != 0) != vn || (s[4].flags & EXF_RHS_NULLABLE)) return;
+    if (((s[6].flags & EXF_LHS_NULLABLE) != 0) != vn || (s[6].flags & EXF_RHS_NULLABLE)) return;
+    pa->op2 = s[4].op;
+    pa->lit2 = (int32_t)s[3].lit;
+    c = s[5].lit;
   } else {
     return;
   }

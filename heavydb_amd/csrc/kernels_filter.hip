@@ -264,6 +264,8 @@ MQ_D uint32_t fm_quad_pass_i32(const BoolFilter& bf, const FmMeta& mt, const FmP
       pa.lo = FM_UNIFORM(pa.lo);
       pa.hi = FM_UNIFORM(pa.hi);
       pa.negate = FM_UNIFORM(pa.negate);
+      pa.op2 = FM_UNIFORM(pa.op2);
+      pa.lit2 = FM_UNIFORM(pa.lit2);
     }
     v4i32 av = col[0], bv = col[0];
 #pragma unroll
@@ -326,6 +328,8 @@ __global__ __launch_bounds__(kFmBlock) void k_filter_mask_i32(FilterMaskArgs a) 
     hp.pa[k].lo = FM_UNIFORM(src.lo);
     hp.pa[k].hi = FM_UNIFORM(src.hi);
     hp.pa[k].negate = FM_UNIFORM(src.negate);
+    hp.pa[k].op2 = FM_UNIFORM(src.op2);
+    hp.pa[k].lit2 = FM_UNIFORM(src.lit2);
   }
   int32_t err = 0;
   const int tid = threadIdx.x;

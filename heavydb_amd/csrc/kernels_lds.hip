@@ -648,6 +648,8 @@ __global__ __launch_bounds__(kLdsBlock) void k_groupby_lds_typed(const int8_t* c
           fpa[k].lo = MQ_WAVE_UNIFORM(src.lo);
           fpa[k].hi = MQ_WAVE_UNIFORM(src.hi);
           fpa[k].negate = MQ_WAVE_UNIFORM(src.negate);
+          fpa[k].op2 = MQ_WAVE_UNIFORM(src.op2);
+          fpa[k].lit2 = MQ_WAVE_UNIFORM(src.lit2);
           fca[k] = MQ_WAVE_UNIFORM(s_bf.prog_op[k][0]);
           fcb[k] = MQ_WAVE_UNIFORM(s_bf.prog_op[k][1]);
           fraise[k] = MQ_WAVE_UNIFORM(s_bf.prog[k].can_raise) != 0;

@@ -842,7 +842,7 @@ def test_program_atoms_in_compiled_filters(sim, oracle, name, consumer):
         # (behind the row mask the step has ONE 1-byte qual: the planner may give a perfect-hash few-groups step to k_perfect_lds)
         assert kn == "k_scan_agg" if consumer == "scan_agg" else kn in ("k_groupby_lds", "k_perfect_lds"), kn
         lean = name in ("guarded_div", "sum_of_two_columns", "column_vs_column", "nullable_column_vs_column", "modulo",
-                        "not_over_program_atom")
+                        "not_over_program_atom", "affine")
         if consumer == "typed_lds":
             assert rs.report.variant == 5 or kn == "k_perfect_lds", rs.report.variant
             # lean atoms (INT32 operands, one operation) are evaluated by the typed member itself; the rest by the row-mask pre-pass
@@ -858,7 +858,8 @@ def test_program_atoms_in_compiled_filters(sim, oracle, name, consumer):
 
 @pytest.mark.parametrize("member", ["fused", "lean", "general"])
 @pytest.mark.parametrize("nullable", [False, True], ids=["notnull", "nullable"])
-@pytest.mark.parametrize("op", ["cmp2", "add", "sub", "mul", "div", "mod", "add_lit", "mul_lit", "div_lit", "mod_lit"])
+@pytest.mark.parametrize("op", ["cmp2", "add", "sub", "mul", "div", "mod", "add_lit", "mul_lit", "div_lit", "mod_lit", "chain_mul_sub", "chain_add_div",
+                                "chain_cols_mod"])
 def test_pair_atoms_on_edge_values(sim, oracle, op, nullable, member):
     """the LEAN form of a program atom (boolfilter.h pair_eval: 32-bit values) against the program's own steps (the general
     member of the pre-pass, MI355Q_OPT_LDS_GENERIC_MEMBER) and the oracle, on every pair of INT32 edge values: first with the
@@ -872,14 +873,28 @@ def test_pair_atoms_on_edge_values(sim, oracle, op, nullable, member):
     lit = {"add_lit": 5, "mul_lit": 65536, "div_lit": -1, "mod_lit": 7}.get(op)
     rhs = L(lit) if lit is not None else C_(2)
     base = op.split("_")[0]
-    val = {"add": C_(1).add(rhs, I32), "sub": C_(1).sub(rhs, I32), "mul": C_(1).mul(rhs, I32), "div": C_(1).div(rhs, I32),
-           "mod": C_(1).mod(rhs, I32)}.get(base)
+    if base == "chain":   # ((a <op> b) <op2> literal) <cmp> literal: which rows raise is the oracle's to say (one code per shape)
+        val = {"chain_mul_sub": C_(1).mul(L(3), I32).sub(L(7), I32), "chain_add_div": C_(1).add(C_(2), I32).div(L(3), I32),
+               "chain_cols_mod": C_(1).sub(C_(2), I32).mod(L(-1), I32)}[op]
+        from heavydb_amd.executor import ExpressionRange as _R, InputColDescriptor as _D, RelAlgExecutionUnit as _U, TargetExpr as _T
+        probe = _U([_D(I32, nullable, _R(True, -2**31 + 1, 2**31 - 1, nullable))] * 2, [_T(capi.PROJECT, 2)],
+                   exprs=[Expr(val.nodes[:]).with_range(_R(True, -2**31, 2**31 - 1, True))], max_groups_buffer_entry_guess=8)
+        probe.exprs[0].nodes = [type(n)(n.op, n.type, n.arg - 1 if n.op == capi.EX_COL else n.arg, n.ilit, n.flit, n.null_lit) for n in val.nodes]
+        raises = np.zeros(len(a), bool)
+        for i in range(len(a)):   # one row at a time through the oracle: does the value expression raise?
+            _, _, code_i = oracle.execute(probe.to_plan(), [[np.array([a[i]], np.int32), np.array([b[i]], np.int32)]])
+            raises[i] = code_i > 0
+    else:
+        val = {"add": C_(1).add(rhs, I32), "sub": C_(1).sub(rhs, I32), "mul": C_(1).mul(rhs, I32), "div": C_(1).div(rhs, I32),
+               "mod": C_(1).mod(rhs, I32)}.get(base)
     bb = np.full_like(b, lit) if lit is not None else b
     with np.errstate(all="ignore"):
         exact = {"add": a + bb, "sub": a - bb, "mul": a * bb}.get(base)
     nul = -2**31
     is_null = ((a == nul) | ((bb == nul) & (lit is None))) if nullable else np.zeros(len(a), bool)
-    if base in ("add", "sub", "mul"):
+    if base == "chain":
+        pass
+    elif base in ("add", "sub", "mul"):
         raises = ~is_null & ((exact > 2**31 - 1) | (exact < -2**31))
     elif base == "div":
         skip = (np.full(len(a), nullable) & ((a == nul) | (bb == nul)))
