@@ -48,6 +48,9 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kIters = 16;                          // quads per lane and tile
 constexpr int kIterRows = kBlock * 4;               // rows one iteration of the block covers
 constexpr int64_t kTileRows = (int64_t)kIterRows * kIters;  // 16 384
+constexpr int kCntBits = 15;                        // a tile's matches (<= 16 384) in the low bits of its count word, its fragment above
+constexpr uint32_t kSparseTile = 1024;              // fast member: tiles with at most this many matches (6 %) emit entry by entry
+constexpr int64_t kSplitMinTiles = 4096;            // the fast member's split route from 67 M rows (below: one fused launch)
 
 constexpr uint64_t kStateShift = 62;
 constexpr uint64_t kStateAggregate = 1ull << kStateShift;  // value = the tile's own count
@@ -379,7 +382,7 @@ struct FastArgs {
   unsigned long long* desc;
   unsigned long long* counters;
   int64_t* out;
-  int32_t out16, pad_;
+  int32_t out16, columnar;
   int32_t tw[MI355Q_MAX_TARGETS];        // columnar: bytes of the target's slot (8 or 4)
   int64_t tcol_off[MI355Q_MAX_TARGETS];  // columnar: byte offset of the slot column
   // targets that are forms (kernels.h ProjForm): tcol / tkind describe the column the form READS (kind 0 or 1)
@@ -388,6 +391,11 @@ struct FastArgs {
   int32_t f_op[MI355Q_MAX_TARGETS], f_type[MI355Q_MAX_TARGETS], f_flags[MI355Q_MAX_TARGETS], f_lit_first[MI355Q_MAX_TARGETS];
   int64_t f_lit[MI355Q_MAX_TARGETS];
   int32_t* d_err;
+  // the SPLIT route (large inputs): pass A ran in k_proj_mask — pre_mask[tile * kBlock + tid] is the lane's 64 match bits,
+  // desc[tile] the number of matches BEFORE the tile (k_proj_scan_tiles); no look-back
+  unsigned long long* pre_mask;
+  uint32_t* pre_cnt;  // [tile] matches of the tile (low 15 bits; <= kSparseTile -> k_proj_sparse emits it, else k_proj_fast) | fragment << 15
+  uint32_t* dense;    // [counters[2]] the tiles with more matches than that, in order: k_proj_fast's tickets walk this list
 };
 // one row of a form target: the column's value (ex_col: integers sign-extended, DOUBLE as its bits) -> the target's value
 MQ_D int64_t form_eval(int cast_from, int cast_to, int cast_flags, int op, int type, int flags, bool lit_first, int64_t lit, int64_t v,
@@ -450,12 +458,286 @@ MQ_D void fast_qual(const fast::RangeFilter& f, const int8_t* base, const int64_
   }
 }
 
+// pass A of the fast member for one tile: bit 4 u + i = row i of the lane's quad in iteration u passes every qual
+MQ_D uint64_t fast_pass_a(const FastArgs& a, const int8_t* const* fc, int64_t n, int64_t row0, int tid) {
+  uint64_t m = 0;
+#pragma unroll 1
+  for (int u0 = 0; u0 < kIters; u0 += 4) {
+    uint32_t bits[4];
+    int64_t r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      r[j] = row0 + (int64_t)(u0 + j) * kIterRows + tid * 4;
+      const int64_t left = n - r[j];
+      bits[j] = left >= 4 ? 0xfu : left <= 0 ? 0u : ((1u << left) - 1u);
+    }
+    const bool inside = row0 + (int64_t)(u0 + 4) * kIterRows <= n;  // (uniform)
+#pragma unroll 1
+    for (int k = 0; k < a.n_quals; ++k) {
+      if (a.qmode[k] == 1) fast_qual<int32_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
+      else if (a.qmode[k] == 3) fast_qual<int8_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
+      else fast_qual<int64_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m |= (uint64_t)bits[j] << (4 * (u0 + j));
+  }
+  return m;
+}
+// the fragment a tile belongs to
+MQ_D int fast_tile_frag(const FastArgs& a, int64_t tile) {
+  int lo = 0, hi = a.n_frags;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.tile_start[mid] <= tile) lo = mid;
+    else hi = mid;
+  }
+  return lo;
+}
+
+// ---- the SPLIT route of the fast member (round 6).  The fused kernel's tile is a chain — ticket, pass A, the look-back,
+// pass B — and at four workgroups per CU the chain, not the memory system, sets the pace when few rows match: 1 B rows with a
+// 4-byte filter column took 2.0 ms at 0.1 % selectivity where the column streams in 0.65 ms.  Here pass A is a kernel of its own
+// with nothing to wait for (k_proj_mask: the lane's 64 match bits = 1 bit per row, and the tile's count), one workgroup scans
+// the counts (k_proj_scan_tiles), and k_proj_fast runs as pass B alone.
+__global__ __launch_bounds__(kBlock) void k_proj_mask(FastArgs a) {
+  __shared__ uint32_t s_w[kWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int64_t tile = blockIdx.x; tile < a.n_tiles; tile += gridDim.x) {
+    const int f = fast_tile_frag(a, tile);
+    const int8_t* const* fc = a.cols + (size_t)f * a.n_cols_table;
+    const int64_t n = a.num_rows[f];
+    const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;
+    const uint64_t m = fast_pass_a(a, fc, n, row0, tid);
+    __builtin_nontemporal_store((unsigned long long)m, a.pre_mask + tile * kBlock + tid);
+    uint32_t c = (uint32_t)__popcll(m);
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+    if (lane == 0) s_w[wave] = c;
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t t = 0;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w) t += s_w[w];
+      a.pre_cnt[tile] = t | ((uint32_t)f << kCntBits);
+    }
+    __syncthreads();
+  }
+}
+// desc[tile] = matches before the tile; counters[1] = matches of all tiles; dense[0 .. counters[2]) = the tiles with more than
+// kSparseTile matches, in order.  ONE workgroup of 1 024 lanes, a run of tiles each.
+__global__ __launch_bounds__(1024) void k_proj_scan_tiles(const uint32_t* cnt, unsigned long long* desc, int64_t n_tiles,
+                                                          unsigned long long* counters, uint32_t* dense) {
+  __shared__ unsigned long long s_sum[1024];
+  __shared__ uint32_t s_dense[1024];
+  constexpr uint32_t kCntMask = (1u << kCntBits) - 1u;
+  const int tid = threadIdx.x;
+  const int64_t per = (((n_tiles + 1023) / 1024) + 3) & ~(int64_t)3;  // (runs start on 16-byte boundaries of the counts)
+  const int64_t lo = (int64_t)tid * per < n_tiles ? (int64_t)tid * per : n_tiles, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  unsigned long long sum = 0;
+  uint32_t nd = 0;
+  {  // (four 16-byte loads in flight per lane: a run is read in a few latencies, not one per tile)
+    int64_t i = lo;
+    for (; i + 16 <= hi; i += 16) {
+      v4i32 c[4];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) c[x] = *(const v4i32*)(cnt + i + 4 * x);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const uint32_t w[4] = {(uint32_t)c[x].x & kCntMask, (uint32_t)c[x].y & kCntMask, (uint32_t)c[x].z & kCntMask, (uint32_t)c[x].w & kCntMask};
+#pragma unroll
+        for (int y = 0; y < 4; ++y) {
+          sum += w[y];
+          nd += w[y] > kSparseTile;
+        }
+      }
+    }
+    for (; i < hi; ++i) {
+      const uint32_t w = cnt[i] & kCntMask;
+      sum += w;
+      nd += w > kSparseTile;
+    }
+  }
+  s_sum[tid] = sum;
+  s_dense[tid] = nd;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const unsigned long long o = tid >= d ? s_sum[tid - d] : 0ull;
+    const uint32_t od = tid >= d ? s_dense[tid - d] : 0u;
+    __syncthreads();
+    s_sum[tid] += o;
+    s_dense[tid] += od;
+    __syncthreads();
+  }
+  unsigned long long run = s_sum[tid] - sum;
+  uint32_t di = s_dense[tid] - nd;
+  {
+    int64_t i = lo;
+    for (; i + 8 <= hi; i += 8) {
+      v4i32 c[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) c[x] = *(const v4i32*)(cnt + i + 4 * x);
+      const uint32_t cc[8] = {(uint32_t)c[0].x, (uint32_t)c[0].y, (uint32_t)c[0].z, (uint32_t)c[0].w,
+                              (uint32_t)c[1].x, (uint32_t)c[1].y, (uint32_t)c[1].z, (uint32_t)c[1].w};
+#pragma unroll
+      for (int x = 0; x < 8; ++x) {
+        const uint32_t w = cc[x] & kCntMask;
+        desc[i + x] = run;
+        run += w;
+        if (w > kSparseTile) dense[di++] = (uint32_t)(i + x);
+      }
+    }
+    for (; i < hi; ++i) {
+      const uint32_t w = cnt[i] & kCntMask;
+      desc[i] = run;
+      run += w;
+      if (w > kSparseTile) dense[di++] = (uint32_t)i;
+    }
+  }
+  if (tid == 1023) {
+    counters[1] = s_sum[1023];
+    counters[2] = s_dense[1023];
+  }
+}
+
+// pass B of the SPARSE tiles of the split route (at most kSparseTile matches): the tile's matches are listed in LDS in rank
+// order (their row inside the tile, 14 bits each), then entry j is the work of lane j — it loads its row's columns one value each
+// and writes the entry: adjacent lanes write adjacent entries, and every load of the tile is in flight at once.  (The quad path
+// of k_proj_fast walks the 16 iterations one after the other, each a load -> stage -> store round trip: at 1 % selectivity nearly
+// every (iteration, wave) holds a match or two and a tile cost sixteen exposed latencies — 0.75 ms per 1 B rows at 0.1 %.)  One
+// member for every shape: the target count, the layout and the forms are run-time values here.
+__global__ __launch_bounds__(kBlock) void k_proj_sparse(FastArgs a) {
+  __shared__ uint16_t s_list[kSparseTile];
+  __shared__ uint32_t s_cnt[kIters * kWaves];
+  constexpr uint32_t kCntMask = (1u << kCntBits) - 1u;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = a.n_targets, rq = 1 + nt;
+  int32_t err = 0;
+  // the NEXT tile's count word, base and match bits are loaded while this tile is emitted (a tile is a chain of a few dependent
+  // loads otherwise)
+  int64_t tile = blockIdx.x;
+  uint32_t w_next = 0;
+  unsigned long long base_next = 0, m_next = 0;
+  if (tile < a.n_tiles) {
+    w_next = a.pre_cnt[tile];
+    base_next = a.desc[tile];
+    m_next = __builtin_nontemporal_load(a.pre_mask + tile * kBlock + tid);
+  }
+  for (; tile < a.n_tiles; tile += gridDim.x) {
+    const uint32_t w = w_next;
+    const int64_t tile_base = (int64_t)base_next;
+    const uint64_t m = m_next;
+    if (tile + gridDim.x < a.n_tiles) {
+      w_next = a.pre_cnt[tile + gridDim.x];
+      base_next = a.desc[tile + gridDim.x];
+      m_next = __builtin_nontemporal_load(a.pre_mask + (tile + gridDim.x) * kBlock + tid);
+    }
+    const uint32_t tile_matches = w & kCntMask;
+    if (tile_matches == 0 || tile_matches > kSparseTile) continue;  // (uniform)
+    if (tile_base >= a.entry_count) continue;
+    const int f = (int)(w >> kCntBits);
+    const int8_t* const* fc = a.cols + (size_t)f * a.n_cols_table;
+    const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;
+    // matches of every (iteration, wave), their exclusive prefix in that order (as k_proj_fast)
+    uint32_t mine = 0;
+#pragma unroll
+    for (int u = 0; u < kIters; ++u) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) c += (uint32_t)__popcll(__ballot((m >> (4 * u + b)) & 1ull));
+      if (lane == u) mine = c;
+    }
+    if (lane < kIters) s_cnt[lane * kWaves + wave] = mine;
+    __syncthreads();
+    if (wave == 0) {
+      const uint32_t v = s_cnt[lane];
+      uint32_t inc = v;
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl(inc, lane - d < 0 ? lane : lane - d, 64);
+        if (lane >= d) inc += o;
+      }
+      s_cnt[lane] = inc - v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < kIters; ++u) {
+      const uint32_t mm = (uint32_t)(m >> (4 * u)) & 0xfu;
+      if (!__any(mm != 0)) continue;  // (uniform)
+      uint32_t k = s_cnt[u * kWaves + wave];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const unsigned long long bal = __ballot((mm >> b) & 1u);
+        k += __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if ((mm >> i) & 1u) s_list[k++] = (uint16_t)(u * kIterRows + tid * 4 + i);
+    }
+    __syncthreads();
+    // entries j and j + kBlock of a lane together (their loads, then their stores), four targets at a time
+    int64_t n_emit = (int64_t)tile_matches;
+    if (tile_base + n_emit > a.entry_count) n_emit = a.entry_count - tile_base;  // the scan limit / the buffer's end
+#pragma unroll 1
+    for (int64_t j0 = tid; j0 < n_emit; j0 += 2 * kBlock) {
+      const bool two = j0 + kBlock < n_emit;
+      const int64_t rank[2] = {tile_base + j0, tile_base + j0 + kBlock};
+      const int64_t rr[2] = {row0 + (int64_t)s_list[j0], row0 + (int64_t)s_list[two ? j0 + kBlock : j0]};
+#pragma unroll
+      for (int y = 0; y < 2; ++y) {
+        if (y == 1 && !two) break;
+        if (!a.columnar) a.out[rank[y] * rq] = rr[y];
+        else a.out[rank[y]] = rr[y];
+      }
+#pragma unroll 1
+      for (int t0 = 0; t0 < nt; t0 += 4) {
+        int64_t v[2][4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int t = t0 + x < nt ? t0 + x : nt - 1;
+          const int8_t* base = fc[a.tcol[t]];
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            if (a.tkind[t] == 0) v[y][x] = __builtin_nontemporal_load((const MQ_GLOBAL long long*)base + rr[y]);
+            else v[y][x] = (int64_t)__builtin_nontemporal_load((const MQ_GLOBAL int*)base + rr[y]);
+          }
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int t = t0 + x;
+          if (t >= nt) break;
+#pragma unroll
+          for (int y = 0; y < 2; ++y) {
+            if (y == 1 && !two) break;
+            int64_t val = v[y][x];
+            if (a.tkind[t] == 2) val = dbl_bits((double)bits_flt((int32_t)val));
+            if (a.any_form && a.f_on[t]) {
+              int32_t e = 0;
+              val = form_eval(a.f_src_type[t], a.f_cast_to[t], a.f_cast_flags[t], a.f_op[t], a.f_type[t], a.f_flags[t], a.f_lit_first[t] != 0,
+                              a.f_lit[t], val, e);
+              if (e && !err) err = e;
+            }
+            if (!a.columnar) a.out[rank[y] * rq + 1 + t] = val;
+            else {
+              char* col = (char*)a.out + a.tcol_off[t];
+              if (a.tw[t] == 8) ((int64_t*)col)[rank[y]] = val;
+              else ((int32_t*)col)[rank[y]] = (int32_t)val;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // (s_list / s_cnt are the next tile's)
+  }
+  if (err) atomicCAS(a.d_err, 0, err);
+}
+
 // NT targets; COL: a columnar buffer (one run per column) instead of whole rows.  A wave stages the quads of LH lanes at a
 // time (ranks are lane-major: a run of lanes is a run of entries): all 64 while 256 staged entries fit the LDS budget of
 // four workgroups per CU, else 32.
 // XF: some target is a form (kernels.h ProjForm) — members without forms carry none of that code
+// (an empty statement the optimiser cannot move: it keeps SimplifyCFG from merging the LAST stores of two branches into one store
+// through a phi of two offsets of `vals` — an address no longer constant, which leaves the whole array in scratch)
+#define MQ_NO_STORE_SINK() asm volatile("")
 template <int NT, bool COL, bool XF = false>
-__global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
+__global__ __launch_bounds__(kBlock, (XF || COL) ? 1 : NT <= 3 ? 4 : 3) void k_proj_fast(FastArgs a, int) {
   extern __shared__ __attribute__((aligned(16))) char s_stage[];  // per wave: the entries of one step, assembled before they leave
   __shared__ uint32_t s_cnt[kIters * kWaves];   // matches of (iteration, wave); then their exclusive prefix in that order
   __shared__ long long s_bcast[2];
@@ -471,47 +753,23 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
 #pragma unroll
   for (int t = 0; t < NT; ++t) run_off[t + 1] = run_off[t] + kStageRows * (COL ? a.tw[t] : 8);
 
+  // (the split route: the tickets walk the list of dense tiles — IN ORDER, as the look-back keeps the fused launch: workgroups
+  // that take tiles by position drift apart and the entries they write no longer fill the buffer front to back; measured 20 – 30 %
+  // slower on wide rows)
+  const int64_t n_tickets = a.pre_mask ? (int64_t)a.counters[2] : a.n_tiles;
   for (;;) {
     if (tid == 0) s_bcast[0] = (long long)atomicAdd(&a.counters[0], 1ull);
     __syncthreads();
-    const int64_t tile = s_bcast[0];
-    if (tile >= a.n_tiles) break;
-    int f = 0;
-    {
-      int lo = 0, hi = a.n_frags;
-      while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (a.tile_start[mid] <= tile) lo = mid;
-        else hi = mid;
-      }
-      f = lo;
-    }
+    const int64_t ticket = s_bcast[0];
+    if (ticket >= n_tickets) break;
+    const int64_t tile = a.pre_mask ? (int64_t)a.dense[ticket] : ticket;
+    const int f = fast_tile_frag(a, tile);
     const int8_t* const* fc = a.cols + (size_t)f * a.n_cols_table;
     const int64_t n = a.num_rows[f];
     const int64_t row0 = (tile - a.tile_start[f]) * kTileRows;
 
-    // ---- pass A
-    uint64_t m = 0;
-#pragma unroll 1
-    for (int u0 = 0; u0 < kIters; u0 += 4) {
-      uint32_t bits[4];
-      int64_t r[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        r[j] = row0 + (int64_t)(u0 + j) * kIterRows + tid * 4;
-        const int64_t left = n - r[j];
-        bits[j] = left >= 4 ? 0xfu : left <= 0 ? 0u : ((1u << left) - 1u);
-      }
-      const bool inside = row0 + (int64_t)(u0 + 4) * kIterRows <= n;  // (uniform)
-#pragma unroll 1
-      for (int k = 0; k < a.n_quals; ++k) {
-        if (a.qmode[k] == 1) fast_qual<int32_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
-        else if (a.qmode[k] == 3) fast_qual<int8_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
-        else fast_qual<int64_t>(a.qf[k], fc[a.qcol[k]], r, inside, n, bits);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) m |= (uint64_t)bits[j] << (4 * (u0 + j));
-    }
+    // ---- pass A (or its result, on the split route)
+    const uint64_t m = a.pre_mask ? (uint64_t)__builtin_nontemporal_load(a.pre_mask + tile * kBlock + tid) : fast_pass_a(a, fc, n, row0, tid);
 
     // ---- matches of every (iteration, wave): lane u of the wave keeps iteration u's
     uint32_t mine = 0;
@@ -533,25 +791,23 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
       }
       const unsigned long long tile_count = (unsigned long long)__shfl(inc, 63, 64);
       s_cnt[lane] = inc - v;
-      const unsigned long long excl = tile_lookback(a.desc, a.counters, a.n_tiles, tile, tile_count);
+      const unsigned long long excl = a.pre_mask ? a.desc[tile] : tile_lookback(a.desc, a.counters, a.n_tiles, tile, tile_count);
       if (lane == 0) s_bcast[1] = (long long)excl;
     }
     __syncthreads();
     const int64_t tile_base = s_bcast[1];
     if (tile_base >= a.entry_count) continue;  // past a scan limit (or a full buffer): nothing of this tile is kept
 
-    // ---- pass B
-#pragma unroll 1
-    for (int u = 0; u < kIters; ++u) {
+    // ---- pass B.  The projected columns of G iterations are loaded TOGETHER (only the quads with a match), then the
+    // iterations are emitted in order: one exposed memory latency per G iterations instead of one per iteration (round 6: at
+    // 1 % selectivity nearly every (iteration, wave) holds a match, so a tile's pass B was 16 dependent load -> store
+    // round trips: 3.0 ms per 1 B rows and one column where the filter column streams in 0.65 ms).  G is what the member's
+    // registers allow at four waves per SIMD.
+    constexpr int G = (XF || COL) ? 1 : NT == 1 ? 2 : 1;
+    auto load_iter = [&](int u, int64_t (&vals)[NT][4]) __attribute__((always_inline)) {
       const uint32_t mm = (uint32_t)(m >> (4 * u)) & 0xfu;
-      // per bit plane (row i of every lane's quad): matches in lower lanes, matches in the wave (ballots: every lane takes part)
-      unsigned long long bal[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bal[b] = __ballot((mm >> b) & 1u);
-      if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0) continue;  // (uniform)
       const int64_t r = row0 + (int64_t)u * kIterRows + tid * 4;
       const bool inside = row0 + (int64_t)(u + 1) * kIterRows <= n;  // (uniform)
-      int64_t vals[NT][4];
       if (mm) {
         if (inside) {  // every projected column of the quad first: independent 16-byte loads (a 4-byte column's quad waits,
                        // packed, in the first two value registers)
@@ -565,18 +821,7 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
             } else {
               const v2i64 x = __builtin_nontemporal_load((const MQ_GLOBAL v2i64*)base + (r >> 2));
               vals[t][0] = x.x; vals[t][1] = x.y;
-            }
-          }
-#pragma unroll
-          for (int t = 0; t < NT; ++t) {
-            if (a.tkind[t] == 0) continue;
-            const int32_t x0 = (int32_t)(uint32_t)(uint64_t)vals[t][0], x1 = (int32_t)(uint32_t)((uint64_t)vals[t][0] >> 32);
-            const int32_t x2 = (int32_t)(uint32_t)(uint64_t)vals[t][1], x3 = (int32_t)(uint32_t)((uint64_t)vals[t][1] >> 32);
-            if (a.tkind[t] != 2) {  // INT32 sign-extended (or, in a columnar buffer, the 4 bytes as they are)
-              vals[t][0] = x0; vals[t][1] = x1; vals[t][2] = x2; vals[t][3] = x3;
-            } else {
-              vals[t][0] = dbl_bits((double)bits_flt(x0)); vals[t][1] = dbl_bits((double)bits_flt(x1));
-              vals[t][2] = dbl_bits((double)bits_flt(x2)); vals[t][3] = dbl_bits((double)bits_flt(x3));
+              MQ_NO_STORE_SINK();
             }
           }
         } else {
@@ -595,6 +840,31 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
               }
               vals[t][i] = v;
             }
+          }
+          MQ_NO_STORE_SINK();
+        }
+      }
+    };
+    auto emit_iter = [&](int u, int64_t (&vals)[NT][4]) __attribute__((always_inline)) {
+      const uint32_t mm = (uint32_t)(m >> (4 * u)) & 0xfu;
+      // per bit plane (row i of every lane's quad): matches in lower lanes, matches in the wave (ballots: every lane takes part)
+      unsigned long long bal[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bal[b] = __ballot((mm >> b) & 1u);
+      if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0) return;  // (uniform)
+      const int64_t r = row0 + (int64_t)u * kIterRows + tid * 4;
+      const bool inside = row0 + (int64_t)(u + 1) * kIterRows <= n;  // (uniform)
+      if (mm && inside) {  // (a 4-byte column's quad waited, packed, in the first two value registers)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (a.tkind[t] == 0) continue;
+          const int32_t x0 = (int32_t)(uint32_t)(uint64_t)vals[t][0], x1 = (int32_t)(uint32_t)((uint64_t)vals[t][0] >> 32);
+          const int32_t x2 = (int32_t)(uint32_t)(uint64_t)vals[t][1], x3 = (int32_t)(uint32_t)((uint64_t)vals[t][1] >> 32);
+          if (a.tkind[t] != 2) {  // INT32 sign-extended (or, in a columnar buffer, the 4 bytes as they are)
+            vals[t][0] = x0; vals[t][1] = x1; vals[t][2] = x2; vals[t][3] = x3;
+          } else {
+            vals[t][0] = dbl_bits((double)bits_flt(x0)); vals[t][1] = dbl_bits((double)bits_flt(x1));
+            vals[t][2] = dbl_bits((double)bits_flt(x2)); vals[t][3] = dbl_bits((double)bits_flt(x3));
           }
         }
       }
@@ -678,6 +948,14 @@ __global__ __launch_bounds__(kBlock) void k_proj_fast(FastArgs a, int) {
         __builtin_amdgcn_wave_barrier();
         step_off += step_cnt;
       }
+    };
+#pragma unroll 1
+    for (int u0 = 0; u0 < kIters; u0 += G) {
+      int64_t vals[G][NT][4];
+#pragma unroll
+      for (int g = 0; g < G; ++g) load_iter(u0 + g, vals[g]);
+#pragma unroll
+      for (int g = 0; g < G; ++g) emit_iter(u0 + g, vals[g]);
     }
   }
   if (XF && err) atomicCAS(a.d_err, 0, err);
@@ -1145,8 +1423,9 @@ void projection_forms(const DevExprSet& xs, const ProjSpec& ps, uint32_t qual_ex
 int64_t projection_scratch_bytes(int n_frags, const int64_t* h_num_rows) {
   int64_t tiles = 0;
   for (int f = 0; f < n_frags; ++f) tiles += (h_num_rows[f] + kTileRows - 1) / kTileRows;
-  // counters (64 B) | tile_start [n_frags + 1] | descriptors [tiles]
-  return 64 + (((int64_t)(n_frags + 1) * 8 + 63) & ~(int64_t)63) + tiles * 8 + 64;
+  // counters (64 B) | tile_start [n_frags + 1] | descriptors [tiles] | the split route's match bits [tiles][kBlock]
+  return 64 + (((int64_t)(n_frags + 1) * 8 + 63) & ~(int64_t)63) + ((tiles * 8 + 63) & ~(int64_t)63) + 64 +
+         (tiles >= kSplitMinTiles || tune_knobs().pass_rows == -3 ? tiles * kBlock * 8 + 2 * ((tiles * 4 + 127) & ~(int64_t)63) : 0);
 }
 
 hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExprSet* d_xs, uint32_t qual_expr_mask,
@@ -1312,6 +1591,24 @@ hipError_t launch_projection(const DevPlan& p, const ProjSpec& ps, const DevExpr
       fa.counters = counters;
       fa.out = (int64_t*)out;
       fa.out16 = a.out16;
+      // the split route: pass A and the tiles' prefix in kernels of their own (pass_rows -2 / -3: tests and tools force one route)
+      const bool split = fv.n_frags < (1 << (32 - kCntBits)) && (tune_knobs().pass_rows == -3 || (tiles >= kSplitMinTiles && tune_knobs().pass_rows != -2));
+      if (split) {
+        fa.pre_mask = (unsigned long long*)(sp + 64 + ts_bytes + ((tiles * 8 + 63) & ~(int64_t)63) + 64);
+        fa.pre_cnt = (uint32_t*)(fa.pre_mask + tiles * kBlock);
+        fa.dense = fa.pre_cnt + ((tiles + 15) & ~(int64_t)15);
+        fa.columnar = ps.columnar;
+        // (tiles by position: a grid beyond what is resident at once would run as a second, mostly idle round)
+        static int occ_mask = 0, occ_sparse = 0;
+        if (!occ_mask) {
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_mask, k_proj_mask, kBlock, 0) != hipSuccess || occ_mask < 1) occ_mask = 4;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ_sparse, k_proj_sparse, kBlock, 0) != hipSuccess || occ_sparse < 1) occ_sparse = 4;
+        }
+        hipLaunchKernelGGL(k_proj_mask, dim3((unsigned)std::min<int64_t>(tiles, (int64_t)n_cus * occ_mask)), dim3(kBlock), 0, s, fa);
+        hipLaunchKernelGGL(k_proj_scan_tiles, dim3(1), dim3(1024), 0, s, fa.pre_cnt, desc, tiles, counters, fa.dense);
+        hipLaunchKernelGGL(k_proj_sparse, dim3((unsigned)std::min<int64_t>(tiles, (int64_t)n_cus * occ_sparse)), dim3(kBlock), 0, s, fa);
+        if (st) st->variant = 16;
+      }
 #define MQ_PROJ_FAST(N)                                                                                                   \
   case N:                                                                                                                  \
     if (ps.columnar) hipLaunchKernelGGL((k_proj_fast<N, true>), dim3((unsigned)grid), dim3(kBlock), fast_lds, s, fa, 0);   \

@@ -162,6 +162,20 @@ def test_projection_case_on_the_host_simulation(sim, oracle, case):
         assert rs2.report.variant != 0
 
 
+_FAST_SPLIT = [c for c in CASES if c.expect_error is None or c.expect_error != capi.ERR_UNSUPPORTED]
+
+
+@pytest.mark.parametrize("case", _FAST_SPLIT, ids=[c.name for c in _FAST_SPLIT])
+def test_projection_split_route_on_the_host_simulation(sim, oracle, case):
+    """round 6: large inputs run the fast member as three kernels (k_proj_mask: the match bits and the tiles' counts;
+    k_proj_scan_tiles; k_proj_fast as pass B alone).  pass_rows = -3 forces that route at any size: every case the fused fast
+    member takes gives the same buffer (same entries, same order, same errors, same LIMIT cut), the others are untouched."""
+    rs = check_projection(oracle, case, host_fetch_result, pass_rows=-3)
+    if rs is not None and case.name != "empty_input":   # (no tile: no launch)
+        rs0 = check_projection(oracle, case, host_fetch_result, pass_rows=-2)   # the fused launch, forced
+        assert (rs.report.variant == 16) == (rs0.report.variant == 0), (rs.report.variant, rs0.report.variant)
+
+
 @pytest.mark.parametrize("name", ["i32_filter_50pct_3cols", "all_types_nullable_columnar", "encoded_columns"])
 def test_projection_unaligned_chunks_take_the_scalar_loads(sim, oracle, name):
     case = next(c for c in CASES if c.name == name)

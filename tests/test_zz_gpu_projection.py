@@ -79,12 +79,20 @@ def test_projection_case_on_the_device(torch_cuda, oracle, case):
         assert rs.report.kernel_name.decode() == "k_proj_compact"
 
 
+@pytest.mark.parametrize("case", CASES, ids=[c.name for c in CASES])
+def test_projection_split_route_on_the_device(torch_cuda, oracle, case):
+    """the fast member's split route (k_proj_mask + k_proj_scan_tiles + pass B; what inputs from 67 M rows take) forced on the
+    small cases: whole buffers against the oracle"""
+    check_projection(oracle, case, lambda c: device_fetch_result(torch_cuda, c), pass_rows=-3)
+
+
 def test_projection_larger_random_tables(torch_cuda, oracle):
     """4 M-row versions of the generic cases: hundreds of tiles per fragment, every workgroup busy, look-back chains"""
     for case in proj_cases.build_cases(scale=100):
         if case.name in ("i32_filter_50pct_3cols", "i32_filter_columnar_3cols", "all_types_nullable_columnar", "scan_limit_cuts",
                          "many_small_fragments", "expr_targets", "expr_in_qual_and_case"):
             check_projection(oracle, case, lambda c: device_fetch_result(torch_cuda, c))
+            check_projection(oracle, case, lambda c: device_fetch_result(torch_cuda, c), pass_rows=-3)   # the split route
 
 
 _TABLE = {}

@@ -39,6 +39,23 @@ case $step in
       timeout 400 python tools/proj_bench.py --rows 1e9 --steps 3 --sel 0.5 --cols 3 --variant $v >> $out/proj_join_variants_1b.jsonl 2>> $out/err.log; echo "$v exit $?"
     done
     cut -c1-330 $out/proj_join_variants_1b.jsonl; tail -3 $out/err.log ;;
+  projlow)  # the Projection family's low end: device parity of the whole projection file, then the plain shapes at 0.1 / 1 / 10 % and the
+            # round's usual three, the fast member as one fused launch and as the split route (k_proj_mask + scan + pass B)
+    timeout 1500 python -u -m pytest tests/test_zz_gpu_projection.py -m gpu -q -p no:cacheprovider > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
+    for route in fused split; do
+      timeout 600 python tools/proj_bench.py --rows 1e9 --steps 5 --sel ${3:-0.001,0.01,0.1,0.5,0.99} --cols 1,3,6 --route $route > $out/proj_low_1b_$route.jsonl 2>> $out/err.log; echo "bench $route exit $?"
+    done
+    python -c "
+import json
+rows = {}
+for route in ('fused', 'split'):
+    for l in open('$out/proj_low_1b_%s.jsonl' % route):
+        d = json.loads(l); rows.setdefault(d['shape'], {})[route] = (d['ms'], d['frac'], d['must_move_frac'], d['route'])
+for k, v in rows.items(): print(k, v)"; tail -3 $out/err.log ;;
+  projprof) # per-kernel times of the fast member's split route (rocprofv3 kernel trace)
+    cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
+    timeout 400 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o proj -- python tools/proj_bench.py --rows 1e9 --steps 3 --sel ${3:-0.001} --cols ${4:-1} --route split > $out/bench.jsonl 2> $out/rocprof.err
+    find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/proj_kernel_stats.csv \; ; rm -rf $out/trace; cut -c1-160 $out/proj_kernel_stats.csv | head -12; cut -c1-200 $out/bench.jsonl ;;
   cfg4)     # BASELINE cfg4 on a dimension WITH HOLES (the general perfect probe), Query A and B, driver-style lines + the 2 B-row parity tests
     timeout 900 python -u -m pytest tests/test_zz_gpu_baseline_sizes.py -m gpu -q -p no:cacheprovider -k "holes" > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
     for spec in "cfg4a_holes:--config cfg4 --holes 16" "cfg4b_holes:--config cfg4 --holes 16 --sum-dim"; do

@@ -29,6 +29,7 @@ def main():
                     help="general: the same shapes through the general member (pass_rows = -1); expr: the second target is v1 * 2.0 "
                          "and a third one v0 + 1 (expressions in registers); join: SELECT v.., d.w FROM t JOIN d ON t.fk = d.k "
                          "(d: 1 M rows, dense keys; fk = i32 >> 11)")
+    ap.add_argument("--route", default="auto", choices=["auto", "fused", "split"], help="the fast member as ONE launch (ticket + look-back; pass_rows -2) or as k_proj_mask + k_proj_scan_tiles + pass B (pass_rows -3); auto: split from 4 096 tiles")
     ap.add_argument("--interpreted", action="store_true", help="MI355Q_OPT_NO_COMPILED_FILTER: an expression filter through the general member's interpreter instead of the row-mask pre-pass")
     ap.add_argument("--generic-member", action="store_true", help="MI355Q_OPT_LDS_GENERIC_MEMBER: expression targets through the general member's interpreter even where they are forms of the fast member")
     args = ap.parse_args()
@@ -45,6 +46,8 @@ def main():
             for columnar in ([False, True] if n_out == 3 else [False]):
                 ra, fr, info = synth.projection(torch, n, n_out, sel, columnar=columnar, cols_cache=cache)
                 opts = {"flags": (capi.OPT_LDS_GENERIC_MEMBER if args.generic_member else 0) | (capi.OPT_NO_COMPILED_FILTER if args.interpreted else 0)}
+                if args.route != "auto":
+                    opts["pass_rows"] = {"fused": -2, "split": -3}[args.route]
                 if args.variant == "general":
                     opts["pass_rows"] = -1
                 elif args.variant == "expr":
@@ -104,11 +107,15 @@ def main():
                         best, kbest = float("inf"), float("inf")
                 matched = rs.totalMatched()
                 bytes_ = info["bytes_per_row"] * n + info["out_bytes_per_row"] * matched
-                print(json.dumps({"shape": f"sel{sel}_cols{n_out}_{'columnar' if columnar else 'rowwise'}", "variant": args.variant, "rows": n, "matched": matched,
+                # what a step must MOVE: the filter column whole, the projected columns' matching rows only, the entries written
+                # (the projected columns are read lazily: at 1 % the algorithmic figure counts bytes no kernel reads)
+                must = 4 * n + (info["bytes_per_row"] - 4) * matched + info["out_bytes_per_row"] * matched
+                print(json.dumps({"shape": f"sel{sel}_cols{n_out}_{'columnar' if columnar else 'rowwise'}", "variant": args.variant, "route": "split" if rs.report.variant == 16 else "fused" if rs.report.variant == 0 else "general", "rows": n, "matched": matched,
                                   "kernel": rs.report.kernel_name.decode(), "ms": round(best, 3), "kernel_ms": round(kbest, 3),
                                   "read_bytes_per_row": info["bytes_per_row"], "written_bytes_per_match": info["out_bytes_per_row"],
                                   "algorithmic_gb": round(bytes_ / 1e9, 3), "gbps": round(bytes_ / (best * 1e-3) / 1e9, 1),
                                   "frac": round(bytes_ / (best * 1e-3) / 8e12, 4), "kernel_frac": round(bytes_ / (kbest * 1e-3) / 8e12, 4),
+                                  "must_move_gb": round(must / 1e9, 3), "must_move_frac": round(must / (best * 1e-3) / 8e12, 4),
                                   "rows_per_s": round(n / (best * 1e-3), 0)}), flush=True)
                 del out
 
