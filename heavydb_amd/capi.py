@@ -206,6 +206,7 @@ OPT_LDS_GENERIC_MEMBER = 64
 OPT_NO_IDX_PART = 128
 OPT_NO_COMPILED_FILTER = 256
 OPT_FILTER_PREPASS = 512
+OPT_NO_IDX_PACK = 1024
 
 
 class ExecReport(C.Structure):

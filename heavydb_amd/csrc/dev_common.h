@@ -257,6 +257,10 @@ struct DevTarget {
   int32_t agg, col, table, arg_type;  // arg_type: type code of the argument column
   int32_t arg_nullable, skip_null, slot, arg_fp;
   int32_t key_idx, arg_f32;  // PROJECT_KEY: which group column; FLOAT argument (slot = float bits)
+  // the argument column's ExpressionRange where it is a valid integer range inside INT32 (arg_rng = 1: [arg_lo, arg_hi],
+  // arg_has_nulls as the range says): what the index-partitioned family packs narrow records from (kernels_idx.hip) — a
+  // HINT, every kernel that uses it must stay exact for a value outside it
+  int32_t arg_rng, arg_lo, arg_hi, arg_has_nulls;
   DevQual cond;           // COUNT_IF / SUM_IF
 };
 struct DevPlan {

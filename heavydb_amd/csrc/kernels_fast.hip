@@ -402,14 +402,21 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg_i32(const int8_t* const* __
     const int8_t* cbase[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) cbase[c] = c < a.n_used ? fc[a.col[c]] : nullptr;
-    for (int64_t t = (blockIdx.x + (int64_t)f * 7) % gridDim.x; t < n_tiles; t += gridDim.x) {
+    // software pipeline: the next tile's loads are issued before this tile's values are looked at (the members with a 64-bit
+    // sum spend ~300 VALU instructions per tile: without it a wave had nothing in flight meanwhile — NGA02 / NGA05 0.56)
+    v4i32 x[NC][UQ], y[NC][UQ];
+    auto load_tile = [&](v4i32 (&d)[NC][UQ], int64_t t) {
       const int64_t q0 = t * tile_q + threadIdx.x;
-      v4i32 x[NC][UQ];
 #pragma unroll
       for (int u = 0; u < UQ; ++u)
 #pragma unroll
         for (int c = 0; c < NC; ++c)
-          if (c < a.n_used) x[c][u] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)cbase[c] + q0 + (int64_t)u * kBlock);
+          if (c < a.n_used) d[c][u] = __builtin_nontemporal_load((const MQ_GLOBAL v4i32*)cbase[c] + q0 + (int64_t)u * kBlock);
+    };
+    int64_t t = (blockIdx.x + (int64_t)f * 7) % gridDim.x;
+    if (t < n_tiles) load_tile(x, t);
+    for (; t < n_tiles; t += gridDim.x) {
+      if (t + gridDim.x < n_tiles) load_tile(y, t + gridDim.x);
 #pragma unroll
       for (int u = 0; u < UQ; ++u)
 #pragma unroll
@@ -421,6 +428,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_agg_i32(const int8_t* const* __
           one(c, x[c][u].w);
         }
       rows += 4 * UQ;
+#pragma unroll
+      for (int u = 0; u < UQ; ++u)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) x[c][u] = y[c][u];
     }
     for (int64_t q = n_tiles * tile_q + gtid; q < nq; q += gsize) {
 #pragma unroll
@@ -966,9 +977,10 @@ hipError_t launch_scan_agg(const DevPlan& p, const FragView& fv, int64_t* out, i
     const int set = ops == 1 ? 1 : (ops & ~1) == 2 ? 2 : (ops & ~1) == 4 ? 4 : (ops & ~1) == 8 ? 8 : 15;
     if (typed && ops != 0) {
       st->variant = 5;
-      // workgroups per CU, measured at 1 B rows x six columns (profiles/r05_nga_sweep_blocks_per_cu.jsonl): the members
-      // without a 64-bit sum gain up to four (3.45 ms = 0.87 of 8 TB/s), the ones with one lose beyond two
-      const int grid = stream_grid(n_cus, (set == 2 || set == 15) ? 2 : 4, fv.total_rows);
+      // workgroups per CU, measured at 1 B rows x six columns with the software pipeline (profiles/
+      // r06_nga_1b_pipelined_sweep.jsonl): the members without a 64-bit sum are best at three (3.51 - 3.58 ms = 0.84 - 0.86 of
+      // 8 TB/s; four: 3.72 - 3.77), the ones with one at two (3.94 ms = 0.76; three: 4.20)
+      const int grid = stream_grid(n_cus, (set == 2 || set == 15) ? 2 : 3, fv.total_rows);
 #define MQ_SA(NC, OPS, NUL, UQ) \
   hipLaunchKernelGGL((k_scan_agg_i32<NC, OPS, NUL, UQ>), dim3(grid), dim3(kBlock), 0, s, fv.d_cols, fv.d_num_rows, fv.n_frags, fv.n_cols, a, p, out)
 #define MQ_SA_OPS(NC, UQ)                                   \

@@ -16,6 +16,13 @@
 //              RS = 2   4-byte records {e : u32}                           NO value column (COUNT(*) / key projections only)
 //              RS = 1   8-byte records {e : u32, v : i32}                 one value column
 //              RS = 0  16-byte records {e, v0, v1, v2}                    two or three value columns, ONE exchange
+//            PACKED records (PK, round 6): where the plan carries the value columns' ExpressionRanges (DevTarget::arg_rng —
+//            the benchmark's y10 / x100 have 10 / 100 values) a record is ONE word: the entry's index INSIDE its partition
+//            (the run names the partition) above the values' codes (value - min, 0 = NULL where the column is nullable):
+//              RS = 3   2-byte records   bits(S1) + value bits <= 16   (PHS005 / 006: 9 .. 12 + 4 bits; Sort/S00x: index only)
+//              RS = 2   4-byte records   ... <= 32                      (PHS007: 14 + 4; MSPHS005: 14 + 7 + 4 instead of 16 bytes)
+//            the range is a HINT: a value outside it leaves as a full record through the spill list, so the result is exact
+//            whatever the data holds.
 //   phase 2  k_idx_aggregate<NV, MM, RS>: one workgroup per (partition, sub-range); the LDS table is indexed by e - lo (no
 //            keys, no probing): rows (u32) and per value column non-NULL count (u32), sum (i64), min / max (i32) — the
 //            typed LDS layout of kernels_lds.hip; every live entry is then merged into the (initialised) output table with
@@ -48,6 +55,7 @@ constexpr uint32_t kIdxSpillBlock = 256;
 constexpr unsigned long long kIdxSpillBusy = ~0ull;
 constexpr uint32_t kIdxSpillMin = 1u << 20;
 constexpr size_t kIdxLdsTable = 150 * 1024;
+constexpr size_t kIdxLdsTablePk = 158 * 1024;  // (packed records: PHS007's 9 766 entries x 16 bytes fit ONE sub-range)
 
 struct IdxGeom {
   int32_t P, lgL, B;      // partitions, log2(units per staged line), scatter workgroups
@@ -58,6 +66,9 @@ struct IdxGeom {
   uint32_t R, S2;         // sub-ranges per partition, entries per sub-range (= LDS entries of a unit)
   int32_t nk, nv, mm, rs;
   uint32_t spill_cap;
+  int32_t pk;             // packed records: (entry - partition's first entry) << vb | value codes
+  uint32_t vb;            // bits of the value codes together
+  int32_t mmode;          // packed records, phase 2: 0 no min / max; 1 min, 2 max, 3 both (codes); 4 a presence mask (<= 32 values)
 };
 
 // what both phases need of the plan (static indices after unrolling: never a scratch copy)
@@ -67,6 +78,9 @@ struct IdxCols {
   int64_t key_min64[kLdsKeys], key_null64[kLdsKeys];
   int32_t val_col[kLdsVals], val_nullable[kLdsVals];
   int32_t target_v[MI355Q_MAX_TARGETS];
+  // packed records: code = value - val_min (+ 1 where the column is nullable: 0 = NULL), val_card values, at bit val_shift
+  int32_t val_min[kLdsVals];
+  uint32_t val_card[kLdsVals], val_shift[kLdsVals], val_mask[kLdsVals];
 };
 
 struct IdxSpill {
@@ -132,12 +146,13 @@ MQ_D void idx_flush_segments(bool need, uint32_t dst_unit, const v4i32* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------- phase 1
-template <int NK, int NV, int RS>
+template <int NK, int NV, int RS, bool PK>
 __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* __restrict__ cols,
                                                             const int64_t* __restrict__ num_rows, int n_frags, int n_cols,
                                                             IdxGeom g, IdxCols c, v4i32* __restrict__ scratch,
                                                             uint32_t* __restrict__ cnt, IdxSpill sl) {
-  static_assert((RS == 0 && NV >= 2) || (RS == 1 && NV == 1) || (RS == 2 && NV == 0), "record size follows the value columns");
+  static_assert(PK ? (RS == 3 || (RS == 2 && NV >= 1)) : ((RS == 0 && NV >= 2) || (RS == 1 && NV == 1) || (RS == 2 && NV == 0)),
+                "record size follows the value columns (or the packed word)");
   constexpr int NVA = NV > 0 ? NV : 1;  // (array sizes: no zero-length arrays)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   v4i32* stage = (v4i32*)smem_raw;                                          // [P][L] units
@@ -223,7 +238,9 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
     auto try_stage = [&](const v4i32& rec, uint32_t p, uint32_t s) -> bool {
       if (idx_peek(&flushed[p]) != (s >> lgLr)) return false;
       asm volatile("" ::: "memory");  // compiler order only: the LDS itself runs a wave in order
-      if (RS == 2) {
+      if (RS == 3) {
+        ((uint16_t*)stage)[((size_t)p << lgLr) + (s & Lrm1)] = (uint16_t)rec.x;
+      } else if (RS == 2) {
         ((uint32_t*)stage)[((size_t)p << lgLr) + (s & Lrm1)] = (uint32_t)rec.x;
       } else if (RS == 1) {
         ((unsigned long long*)stage)[((size_t)p << lgLr) + (s & Lrm1)] =
@@ -280,9 +297,35 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
             if (NV > 1) rec.z = idx_get(cur.v[NV > 1 ? 1 : 0], i);
             if (NV > 2) rec.w = idx_get(cur.v[NV > 2 ? 2 : 0], i);
             p = idx_part_of(g, e);
-            s = atomicAdd(&cursor[p], 1u);
-            if (s >= cap_recs) idx_spill(sl, sp_blk, rec);
-            else park = !try_stage(rec, p, s);
+            if (PK) {
+              // the packed word; a value outside its declared range (the range is a hint) leaves as a full record
+              const v4i32 full = rec;
+              uint32_t w = (e - p * g.S1) << g.vb;
+              bool fits = true;
+#pragma unroll
+              for (int v = 0; v < NV; ++v) {
+                const int32_t val = idx_get(full, v + 1);
+                uint32_t code = 0;
+                if (!(vnull[v] && val == INT32_MIN)) {
+                  const uint32_t dv = (uint32_t)val - (uint32_t)c.val_min[v];
+                  fits = fits && dv < c.val_card[v];
+                  code = dv + (vnull[v] ? 1u : 0u);
+                }
+                w |= code << c.val_shift[v];
+              }
+              rec = v4i32{(int32_t)w, 0, 0, 0};
+              if (!fits) {
+                idx_spill(sl, sp_blk, full);
+              } else {
+                s = atomicAdd(&cursor[p], 1u);
+                if (s >= cap_recs) idx_spill(sl, sp_blk, full);
+                else park = !try_stage(rec, p, s);
+              }
+            } else {
+              s = atomicAdd(&cursor[p], 1u);
+              if (s >= cap_recs) idx_spill(sl, sp_blk, rec);
+              else park = !try_stage(rec, p, s);
+            }
           }
         }
         // line not open yet: park the record in pending slot i; if an older record still waits there, the WHOLE wave
@@ -573,6 +616,154 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_aggregate(IdxGeom g, IdxCols 
   }
 }
 
+// ------------------------------------------------------------------------------------- phase 2, packed records
+// The packed word names small codes, so a unit's LDS entry shrinks and a record costs fewer LDS atomics (the plain member:
+// rows + per value column cnt, sum (64-bit), min, max = 5 for PHS005; this one: 2):
+//   cs[NV][E]   u64  {non-NULL values : sum of their codes} in ONE 64-bit add (the plan bounds records x max code < 2^32)
+//   first[E]    u32  NV = 0: the entry's rows; else the rows whose FIRST value is NULL (rows = cs[0].cnt + first: a NULL is
+//                    the rare case, the common record does not touch it)
+//   MMODE 4:    mask[NV][E] u32, bit = code seen (every column <= 32 values: min and max from one atomicOr)
+//   MMODE 1-3:  min[NV][E] (bit 0) / max[NV][E] (bit 1) of the codes, u32
+// Emission converts back: sum = cnt x min_value + sum of codes, min / max = min_value + code.
+template <int NV, int MMODE>
+__global__ __launch_bounds__(kIdxBlock) void k_idx_aggregate_pk(IdxGeom g, IdxCols c, DevPlan p, const v4i32* __restrict__ scratch,
+                                                                 const uint32_t* __restrict__ cnt, int64_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const uint32_t E = g.S2;
+  constexpr int NVA = NV > 0 ? NV : 1;
+  constexpr int NM = MMODE == 4 ? 1 : (MMODE & 1) + ((MMODE >> 1) & 1);  // 4-byte arrays per value column
+  unsigned long long* l_cs = (unsigned long long*)smem_raw;
+  uint32_t* l_first = (uint32_t*)(l_cs + (size_t)NV * E);
+  uint32_t* l_m0 = l_first + E;                                              // mask, or min (or max alone)
+  uint32_t* l_m1 = l_m0 + (MMODE == 3 ? (size_t)NV * E : 0);                 // max beside min
+  uint32_t* lcnt = l_m0 + (size_t)NM * NV * E;
+  const int t = threadIdx.x, G = gridDim.x;
+  const int R = (int)g.R;
+  const uint32_t vb = g.vb;
+  const bool half = g.rs == 3;
+  bool vnull[NVA];
+  uint32_t vsh[NVA], vmk[NVA];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) {
+    vnull[v] = c.val_nullable[v] != 0;
+    vsh[v] = c.val_shift[v];
+    vmk[v] = c.val_mask[v];
+  }
+  (void)vnull; (void)vsh; (void)vmk;
+  for (int it = 0;; ++it) {
+    const int u = blockIdx.x + G * it;
+    const int pp = u / R, r = u % R;
+    if (pp >= g.P) break;
+    const uint64_t p_lo = (uint64_t)pp * g.S1;
+    const uint64_t p_hi = p_lo + g.S1 < g.d ? p_lo + g.S1 : g.d;
+    uint64_t a = p_lo + (uint64_t)r * g.S2, z = a + g.S2;
+    if (z > p_hi) z = p_hi;
+    if (a > z) a = z;
+    const uint32_t lo = (uint32_t)a, n_slots = (uint32_t)(z - a);
+    const uint32_t sub_lo = (uint32_t)(a - p_lo);
+    if (it > 0) __syncthreads();  // the previous unit's emission is done before the arrays are cleared
+    for (int i = t; i < g.B; i += kIdxBlock) lcnt[i] = cnt[(size_t)pp * g.B + i];
+    for (uint32_t e = t; e < n_slots; e += kIdxBlock) {
+      l_first[e] = 0;
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        l_cs[v * E + e] = 0;
+        if (MMODE == 4) l_m0[v * E + e] = 0;
+        if (MMODE == 1 || MMODE == 3) l_m0[v * E + e] = 0xffffffffu;
+        if (MMODE == 2) l_m0[v * E + e] = 0;
+        if (MMODE == 3) l_m1[v * E + e] = 0;
+      }
+    }
+    __syncthreads();
+    if (n_slots) {
+      auto one = [&](uint32_t w) {
+        const uint32_t e = (w >> vb) - sub_lo;
+        if (e >= n_slots) return;  // the partition's other sub-range
+        if (NV == 0) atomicAdd(l_first + e, 1u);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          uint32_t code = (w >> vsh[v]) & vmk[v];
+          if (vnull[v]) {
+            if (code == 0) {
+              if (v == 0) atomicAdd(l_first + e, 1u);
+              continue;
+            }
+            code -= 1;
+          }
+          atomicAdd(l_cs + v * E + e, ((unsigned long long)1 << 32) | (unsigned long long)code);
+          if (MMODE == 4) atomicOr(l_m0 + v * E + e, 1u << code);
+          if (MMODE == 1 || MMODE == 3) atomicMin(l_m0 + v * E + e, code);
+          if (MMODE == 2) atomicMax(l_m0 + v * E + e, code);
+          if (MMODE == 3) atomicMax(l_m1 + v * E + e, code);
+        }
+      };
+      // a unit of the run = 16 bytes = four words or eight half-words; `n` counts records
+      auto unit = [&](const v4i32& q, uint32_t rec0, uint32_t n) {
+        const uint32_t ww[4] = {(uint32_t)q.x, (uint32_t)q.y, (uint32_t)q.z, (uint32_t)q.w};
+        if (half) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (rec0 + 2 * j < n) one(ww[j] & 0xffffu);
+            if (rec0 + 2 * j + 1 < n) one(ww[j] >> 16);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (rec0 + j < n) one(ww[j]);
+        }
+      };
+      const int rs = half ? 3 : 2;
+      const int wave = t >> 6, lane = t & 63;
+      for (int b = wave; b < g.B; b += kIdxBlock / 64) {
+        const uint32_t n = lcnt[b];
+        if (!n) continue;
+        const v4i32* run = scratch + ((size_t)pp * g.B + b) * g.cap;
+        const uint32_t n_units = (n + ((1u << rs) - 1u)) >> rs;
+        const uint32_t last = n_units - 1;
+        auto at = [&](uint32_t i) -> uint32_t { return i < last ? i : last; };  // clamped: always loadable
+        v4i32 c0 = __builtin_nontemporal_load(run + at(lane)), c1 = __builtin_nontemporal_load(run + at(lane + 64));
+        for (uint32_t base = 0; base < n_units; base += 128) {
+          const uint32_t i = base + lane, nx = i + 128;
+          const v4i32 n0 = __builtin_nontemporal_load(run + at(nx)), n1 = __builtin_nontemporal_load(run + at(nx + 64));
+          unit(c0, i < n_units ? (i << rs) : n, n);
+          unit(c1, i + 64 < n_units ? ((i + 64) << rs) : n, n);
+          c0 = n0; c1 = n1;
+        }
+      }
+    }
+    __syncthreads();
+    for (uint32_t e = t; e < n_slots; e += kIdxBlock) {
+      uint32_t cn[kLdsVals] = {0, 0, 0};
+      int64_t sm[kLdsVals] = {0, 0, 0};
+      int32_t mn[kLdsVals] = {0, 0, 0}, mx[kLdsVals] = {0, 0, 0};
+      uint32_t rows = l_first[e];
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        const unsigned long long cs = l_cs[v * E + e];
+        cn[v] = (uint32_t)(cs >> 32);
+        sm[v] = (int64_t)cn[v] * (int64_t)c.val_min[v] + (int64_t)(uint32_t)cs;
+        if (v == 0) rows += cn[0];
+        if (cn[v]) {
+          if (MMODE == 4) {
+            const uint32_t m = l_m0[v * E + e];
+            mn[v] = c.val_min[v] + (int32_t)__builtin_ctz(m);
+            mx[v] = c.val_min[v] + 31 - (int32_t)__builtin_clz(m);
+          }
+          if (MMODE == 1 || MMODE == 3) mn[v] = c.val_min[v] + (int32_t)l_m0[v * E + e];
+          if (MMODE == 2) mx[v] = c.val_min[v] + (int32_t)l_m0[v * E + e];
+          if (MMODE == 3) mx[v] = c.val_min[v] + (int32_t)l_m1[v * E + e];
+        }
+      }
+      if (!rows) continue;
+      switch (g.nk) {
+        case 1: idx_emit<1>(c, p, out, lo + e, rows, cn, sm, mn, mx); break;
+        case 2: idx_emit<2>(c, p, out, lo + e, rows, cn, sm, mn, mx); break;
+        default: idx_emit<3>(c, p, out, lo + e, rows, cn, sm, mn, mx);
+      }
+    }
+  }
+}
+
 // records that met a full run: applied one by one, each as the partial of a single row
 template <int NK>
 __global__ __launch_bounds__(256) void k_idx_spill(IdxGeom g, IdxCols c, DevPlan p, IdxSpill sl, int64_t* __restrict__ out) {
@@ -604,7 +795,7 @@ struct IdxPlanHost {
   size_t lds1, lds2;
 };
 
-bool make_idx_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scratch_cap, IdxPlanHost* out) {
+bool make_idx_plan_impl(const DevPlan& p, const FragView& fv, int n_cus, int64_t scratch_cap, bool allow_pk, IdxPlanHost* out) {
   IdxPlanHost& h = *out;
   std::memset(&h, 0, sizeof(h));
   LdsArgs a;
@@ -642,22 +833,76 @@ bool make_idx_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scra
   g.nv = a.n_vals;
   g.rs = a.n_vals == 0 ? 2 : a.n_vals == 1 ? 1 : 0;
   g.d = (uint32_t)p.entry_count;
-  // LDS entries of one unit
-  const size_t entry_bytes = 4 + (size_t)g.nv * (12 + (g.mm ? 8 : 0));
-  const uint32_t e_max = (uint32_t)((kIdxLdsTable - (size_t)n_cus * 4) / entry_bytes) & ~3u;
-  if (e_max < 64) return false;
-  const uint64_t units = ((uint64_t)g.d + e_max - 1) / e_max;
-  uint32_t P = 16;  // a line's segments (<= 64) must fit one flusher wave pass
-  while (P < 1024 && P < units) P <<= 1;
-  while (P < 1024 && P < (uint32_t)n_cus && (uint64_t)P * 64 <= g.d) P <<= 1;  // enough units to occupy the device
-  g.P = (int32_t)P;
-  g.S1 = (uint32_t)(((uint64_t)g.d + P - 1) / P);
-  if (g.S1 < 2) return false;
-  g.s1_rcp = (uint32_t)(((uint64_t)1 << 32) / g.S1);
-  g.R = (g.S1 + e_max - 1) / e_max;
-  if (g.R < 1) g.R = 1;
+  // packed records: every value column's range known (DevTarget::arg_rng) and narrow
+  uint32_t vb = 0, max_code = 0;
+  bool known = allow_pk && !(tune_knobs().flags & MI355Q_OPT_NO_IDX_PACK);
+  bool mask_ok = true;  // every column <= 32 values: min / max from a presence mask
+  int need_min = 0, need_max = 0;
+  for (int v = 0; v < g.nv; ++v) {
+    need_min |= need[v][2] ? 1 : 0;
+    need_max |= need[v][3] ? 1 : 0;
+  }
+  for (int v = 0; v < g.nv && known; ++v) {
+    const DevTarget* tg = nullptr;
+    for (int i = 0; i < p.n_targets && !tg; ++i)
+      if (a.target_v[i] == v) tg = &p.targets[i];
+    if (!tg || !tg->arg_rng || tg->arg_lo > tg->arg_hi) {
+      known = false;
+      break;
+    }
+    const uint64_t card = (uint64_t)((int64_t)tg->arg_hi - (int64_t)tg->arg_lo + 1);
+    const uint64_t codes = card + (h.c.val_nullable[v] ? 1 : 0);
+    uint32_t bits = 0;
+    while (bits < 33 && ((uint64_t)1 << bits) < codes) ++bits;
+    if (bits > 20) {
+      known = false;
+      break;
+    }
+    h.c.val_min[v] = tg->arg_lo;
+    h.c.val_card[v] = (uint32_t)card;
+    h.c.val_shift[v] = vb;
+    h.c.val_mask[v] = (uint32_t)(((uint64_t)1 << bits) - 1);
+    vb += bits;
+    if (card > 32) mask_ok = false;
+    if ((uint32_t)card - 1 > max_code) max_code = (uint32_t)card - 1;
+  }
+  // LDS entries of one unit.  Plain records: rows u32 + per value column cnt u32, sum i64 (+ min, max i32).  Packed records
+  // (k_idx_aggregate_pk): first u32 + per value column {cnt : sum of codes} u64 (+ a presence mask u32, or min / max codes u32)
+  const int mmode = !g.mm ? 0 : mask_ok ? 4 : (need_min ? 1 : 0) | (need_max ? 2 : 0);
+  const size_t entry_pk = 4 + (size_t)g.nv * (8 + (mmode == 4 ? 4 : mmode == 3 ? 8 : mmode ? 4 : 0));
+  const size_t entry_plain = 4 + (size_t)g.nv * (12 + (g.mm ? 8 : 0));
+  size_t entry_bytes = 0;
+  uint32_t P = 0;
+  for (int attempt = known ? 0 : 1; attempt < 2; ++attempt) {
+    const bool pk = attempt == 0;
+    entry_bytes = pk ? entry_pk : entry_plain;
+    const uint32_t e_max = (uint32_t)(((pk ? kIdxLdsTablePk : kIdxLdsTable) - (size_t)n_cus * 4) / entry_bytes) & ~3u;
+    if (e_max < 64) return false;
+    const uint64_t units = ((uint64_t)g.d + e_max - 1) / e_max;
+    P = 16;  // a line's segments (<= 64) must fit one flusher wave pass
+    while (P < 1024 && P < units) P <<= 1;
+    while (P < 1024 && P < (uint32_t)n_cus && (uint64_t)P * 64 <= g.d) P <<= 1;  // enough units to occupy the device
+    g.P = (int32_t)P;
+    g.S1 = (uint32_t)(((uint64_t)g.d + P - 1) / P);
+    if (g.S1 < 2) return false;
+    g.s1_rcp = (uint32_t)(((uint64_t)1 << 32) / g.S1);
+    g.R = (g.S1 + e_max - 1) / e_max;
+    if (g.R < 1) g.R = 1;
+    g.S2 = ((g.S1 + g.R - 1) / g.R + 3) & ~3u;  // (every array of the LDS table stays 16-byte aligned)
+    g.pk = 0;
+    g.rs = a.n_vals == 0 ? 2 : a.n_vals == 1 ? 1 : 0;
+    if (!pk) break;
+    uint32_t eb = 0;
+    while (eb < 32 && ((uint64_t)1 << eb) < (uint64_t)g.S1) ++eb;
+    if (g.R <= (uint32_t)kIdxMaxSub && (eb + vb <= 16 || (g.nv >= 1 && eb + vb <= 32))) {
+      g.pk = 1;
+      g.rs = eb + vb <= 16 ? 3 : 2;
+      g.vb = vb;
+      g.mmode = mmode;
+      break;
+    }
+  }
   if (g.R > (uint32_t)kIdxMaxSub) return false;
-  g.S2 = ((g.S1 + g.R - 1) / g.R + 3) & ~3u;  // (every array of the LDS table stays 16-byte aligned)
   g.L = kIdxStageUnits / P;
   g.lgL = 0;
   while ((1u << g.lgL) < g.L) ++g.lgL;
@@ -667,11 +912,13 @@ bool make_idx_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scra
   if (chunk_rows > 0xfff00000ll) chunk_rows = 0xfff00000ll;  // 32-bit run positions / LDS counters per chunk
   if (scratch_cap <= 0) scratch_cap = kDefaultScratchCap;
   for (;;) {
-    const double per_run = (double)chunk_rows / ((double)P * g.B) / recs_per_unit;  // units
-    uint64_t cap = (uint64_t)(per_run * 1.2 + 6.0 * __builtin_sqrt(per_run + 1.0)) + g.L;
+    const double per_run = (double)chunk_rows / ((double)P * g.B);  // records
+    uint64_t cap = (uint64_t)((per_run * 1.2 + 6.0 * __builtin_sqrt(per_run + 1.0)) / recs_per_unit) + g.L;  // units
     cap = (cap + g.L - 1) / g.L * g.L;  // whole lines
     const bool too_many = (uint64_t)P * g.B * cap >= ((uint64_t)1 << 31);  // 32-bit unit indices in phase 1
     if (!too_many) {
+      // packed records: a unit's {cnt : sum of codes} word must hold every record of a partition (B runs of cap units)
+      if (g.pk && (uint64_t)g.B * cap * recs_per_unit * (uint64_t)(max_code ? max_code : 1) >= ((uint64_t)1 << 32)) return false;
       g.cap = (uint32_t)cap;
       h.rec_bytes = (int64_t)P * g.B * (int64_t)cap * 16;
       h.cnt_bytes = ((int64_t)P * g.B * 4 + 255) & ~255ll;
@@ -697,10 +944,15 @@ bool make_idx_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scra
   return h.lds1 <= 160 * 1024 && h.lds2 <= 160 * 1024;
 }
 
-template <int NK, int NV, int RS>
+bool make_idx_plan(const DevPlan& p, const FragView& fv, int n_cus, int64_t scratch_cap, IdxPlanHost* out) {
+  // (the packed word first; its only own refusal is the bound of the sums of codes)
+  return make_idx_plan_impl(p, fv, n_cus, scratch_cap, true, out) || make_idx_plan_impl(p, fv, n_cus, scratch_cap, false, out);
+}
+
+template <int NK, int NV, int RS, bool PK>
 hipError_t idx_launch_scatter(const IdxPlanHost& h, const FragView& fv, int f0, int nf, v4i32* recs, uint32_t* cnt,
                               const IdxSpill& sl, hipStream_t s) {
-  auto k = k_idx_scatter<NK, NV, RS>;
+  auto k = k_idx_scatter<NK, NV, RS, PK>;
   (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds1);
   hipLaunchKernelGGL(k, dim3(h.g.B), dim3(kIdxBlock), h.lds1, s, fv.d_cols + (size_t)f0 * fv.n_cols, fv.d_num_rows + f0, nf,
                      fv.n_cols, h.g, h.c, recs, cnt, sl);
@@ -716,10 +968,31 @@ hipError_t idx_launch_aggregate(const IdxPlanHost& h, const DevPlan& p, const v4
   return hipGetLastError();
 }
 
-template <int NK, int NV>
+template <int NV, int MMODE>
+hipError_t idx_launch_aggregate_pk(const IdxPlanHost& h, const DevPlan& p, const v4i32* recs, const uint32_t* cnt, int64_t* out,
+                                   int n_cus, hipStream_t s) {
+  auto k = k_idx_aggregate_pk<NV, MMODE>;
+  (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.lds2);
+  const int units = h.g.P * (int)h.g.R;
+  hipLaunchKernelGGL(k, dim3(units < n_cus ? units : n_cus), dim3(kIdxBlock), h.lds2, s, h.g, h.c, p, recs, cnt, out);
+  return hipGetLastError();
+}
+template <int NV>
+hipError_t idx_aggregate_pk(const IdxPlanHost& h, const DevPlan& p, const v4i32* recs, const uint32_t* cnt, int64_t* out, int n_cus,
+                            hipStream_t s) {
+  if (NV == 0) return idx_launch_aggregate_pk<NV, 0>(h, p, recs, cnt, out, n_cus, s);
+  switch (h.g.mmode) {
+    case 0: return idx_launch_aggregate_pk<NV, 0>(h, p, recs, cnt, out, n_cus, s);
+    case 1: return idx_launch_aggregate_pk<NV, (NV > 0 ? 1 : 0)>(h, p, recs, cnt, out, n_cus, s);
+    case 2: return idx_launch_aggregate_pk<NV, (NV > 0 ? 2 : 0)>(h, p, recs, cnt, out, n_cus, s);
+    case 3: return idx_launch_aggregate_pk<NV, (NV > 0 ? 3 : 0)>(h, p, recs, cnt, out, n_cus, s);
+    default: return idx_launch_aggregate_pk<NV, (NV > 0 ? 4 : 0)>(h, p, recs, cnt, out, n_cus, s);
+  }
+}
+
+template <int NK, int NV, int RS, bool PK>
 hipError_t idx_run(const IdxPlanHost& h, const DevPlan& p, const FragView& fv, int64_t* out, int32_t* d_err, void* scratch,
                    int n_cus, hipStream_t s, LaunchStats* st) {
-  constexpr int RS = NV == 0 ? 2 : NV == 1 ? 1 : 0;
   v4i32* recs = (v4i32*)scratch;
   uint32_t* cnt = (uint32_t*)((char*)scratch + h.rec_bytes);
   char* spill_base = (char*)scratch + h.rec_bytes + h.cnt_bytes;
@@ -737,15 +1010,19 @@ hipError_t idx_run(const IdxPlanHost& h, const DevPlan& p, const FragView& fv, i
     hipError_t e = hipMemsetAsync(spill_base, 0, 256, s);
     if (e != hipSuccess) return e;
     if (ev_pool && ev_i + 1 < st->n_ev) (void)hipEventRecord(ev_pool[ev_i], s);
-    e = idx_launch_scatter<NK, NV, RS>(h, fv, f, f1 - f, recs, cnt, sl, s);
+    e = idx_launch_scatter<NK, NV, RS, PK>(h, fv, f, f1 - f, recs, cnt, sl, s);
     if (e != hipSuccess) return e;
     if (ev_pool && ev_i + 1 < st->n_ev) {
       (void)hipEventRecord(ev_pool[ev_i + 1], s);
       ev_i += 2;
     }
     st->n_launches += 1;
-    e = h.g.mm ? idx_launch_aggregate<NK, NV, true, RS>(h, p, recs, cnt, out, n_cus, s)
-               : idx_launch_aggregate<NK, NV, false, RS>(h, p, recs, cnt, out, n_cus, s);
+    if constexpr (PK) {
+      e = idx_aggregate_pk<NV>(h, p, recs, cnt, out, n_cus, s);
+    } else {
+      e = (NV > 0 && h.g.mm) ? idx_launch_aggregate<NK, NV, (NV > 0), RS>(h, p, recs, cnt, out, n_cus, s)
+                             : idx_launch_aggregate<NK, NV, false, RS>(h, p, recs, cnt, out, n_cus, s);
+    }
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_idx_spill<NK>, dim3(256), dim3(256), 0, s, h.g, h.c, p, sl, out);
     e = hipGetLastError();
@@ -776,9 +1053,15 @@ hipError_t launch_idx_partitioned(const DevPlan& p, const FragView& fv, int64_t*
   if (!make_idx_plan(p, fv, n_cus, cap_bytes, &h)) return hipErrorInvalidValue;
   if (h.scratch_bytes + 64 > scratch_bytes) return hipErrorInvalidValue;
   st->kernel_name = "k_idx_scatter";
-  st->variant = 6;
+  st->variant = h.g.pk ? (h.g.rs == 3 ? 8 : 7) : 6;  // 6: plain records; 7 / 8: the packed 4- / 2-byte word
   st->n_launches = 0;
-#define MQ_IDX_RUN(NK, NV) return idx_run<NK, NV>(h, p, fv, out, d_err, scratch, n_cus, s, st)
+  // the plain record of NV value columns, or the packed word (2 or 4 bytes)
+#define MQ_IDX_RUN(NK, NV)                                                                                     \
+  do {                                                                                                         \
+    if (h.g.pk && h.g.rs == 3) return idx_run<NK, NV, 3, true>(h, p, fv, out, d_err, scratch, n_cus, s, st);    \
+    if (h.g.pk && NV > 0) return idx_run<NK, NV, (NV > 0 ? 2 : 3), true>(h, p, fv, out, d_err, scratch, n_cus, s, st); \
+    return idx_run<NK, NV, (NV == 0 ? 2 : NV == 1 ? 1 : 0), false>(h, p, fv, out, d_err, scratch, n_cus, s, st);       \
+  } while (0)
   switch (h.g.nk * 10 + h.g.nv) {
     case 10: MQ_IDX_RUN(1, 0);
     case 20: MQ_IDX_RUN(2, 0);

@@ -869,6 +869,17 @@ int32_t build_dev_plan(const mi355q_plan& p, const mi355q_qmd& q, DevPlan* d) {
     o.arg_nullable = ts[i].arg_nullable;
     o.arg_fp = ts[i].arg_fp;  // COUNT(double col) still decodes a double
     o.arg_f32 = ts[i].arg_f32;
+    o.arg_rng = 0;
+    o.arg_lo = o.arg_hi = 0;
+    o.arg_has_nulls = 1;
+    if (const mi355q_range* rg = ts[i].range) {
+      if (rg->valid && !o.arg_fp && rg->bucket == 0 && rg->min <= rg->max && rg->min >= INT32_MIN + 1 && rg->max <= INT32_MAX) {
+        o.arg_rng = 1;
+        o.arg_lo = (int32_t)rg->min;
+        o.arg_hi = (int32_t)rg->max;
+        o.arg_has_nulls = rg->has_nulls != 0;
+      }
+    }
     if (ts[i].agg == MI355Q_COUNT_IF || ts[i].agg == MI355Q_SUM_IF) {
       const mi355q_qual& c = p.targets[i].cond;
       if (MI355Q_QUAL_OR_GROUP(c.op) != 0 || c.op < 0 || (c.op >> 16) != 0) return MI355Q_ERR_INVALID_PLAN;

@@ -555,6 +555,9 @@ typedef struct mi355q_exec_options {
                                             pre-pass (k_filter_mask) even where the typed few-groups member evaluates the
                                             atoms itself; with MI355Q_OPT_LDS_GENERIC_MEMBER the pre-pass's general member
                                             (tests and tools/bool_filter_bench.py compare them) */
+#define MI355Q_OPT_NO_IDX_PACK 1024u      /* index-partitioned family: the plain 4 / 8 / 16-byte records even where the value
+                                            columns' ranges allow the packed 2- or 4-byte word (tests and tools/refbench.py
+                                            compare the two) */
 
 /* per-call timing/selection report (what launchGpuCode logs,
  * QueryExecutionContext.cpp:334,364,579) */

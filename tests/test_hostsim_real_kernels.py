@@ -241,7 +241,60 @@ def test_idx_partitioned_family_on_the_benchmark_shapes(sim, oracle, name):
     case = flow._refbench_case(oracle, name, 150_003, 120_000)
     rs = flow._check(oracle, case, kernel_variant=2)
     assert rs is not None
+    # (the benchmark's value columns carry their ranges: the packed 2- or 4-byte word, round 6)
+    assert rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.variant in (7, 8), (rs.report.kernel_name, rs.report.variant)
+    rs = flow._check(oracle, case, kernel_variant=2, flags=capi.OPT_NO_IDX_PACK)
     assert rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.variant == 6, (rs.report.kernel_name, rs.report.variant)
+
+
+def test_idx_partitioned_family_packed_records_with_values_outside_their_declared_range(sim, oracle):
+    """the packed word is built from the value columns' ExpressionRanges, and those are a HINT: values beyond them (and NULLs
+    in a column whose range says it has none, INT32_MIN in a NOT NULL column) leave as full records through the spill list —
+    the table is the oracle's whatever the data holds.  Both packed widths, one to three value columns."""
+    from heavydb_amd.executor import ExpressionRange, InputColDescriptor, RelAlgExecutionUnit, TargetExpr
+    rng = np.random.default_rng(79)
+    n = 200_003
+    i32 = np.iinfo(np.int32)
+    for card, want_variant in ((70_000, 8), (3_000_000, 7)):
+        key = rng.integers(1, card + 1, n).astype(np.int32)
+        v0 = rng.integers(1, 11, n).astype(np.int32)            # declared [1, 10], nullable, "no NULLs"
+        v0[rng.random(n) < 0.01] = i32.min                      # ... NULLs all the same (code 0)
+        v0[rng.random(n) < 0.002] = 11                          # just outside
+        v0[rng.random(n) < 0.002] = -7
+        v0[rng.random(n) < 0.001] = i32.max
+        v1 = rng.integers(-3, 4, n).astype(np.int32)            # declared [-3, 3], NOT NULL
+        v1[rng.random(n) < 0.002] = i32.min                     # the NOT NULL column's INT32_MIN is a value
+        v1[rng.random(n) < 0.002] = 1 << 20
+        v2 = rng.integers(0, 100, n).astype(np.int32)           # declared [0, 99], nullable, has NULLs
+        v2[rng.random(n) < 0.05] = i32.min
+        descs = [InputColDescriptor(capi.INT32, True, ExpressionRange(True, 1, card, False)),
+                 InputColDescriptor(capi.INT32, True, ExpressionRange(True, 1, 10, False)),
+                 InputColDescriptor(capi.INT32, False, ExpressionRange(True, -3, 3, False)),
+                 InputColDescriptor(capi.INT32, True, ExpressionRange(True, 0, 99, True))]
+        cuts = [0, 50_001, 100_003, n]
+        frags = [[key[a:b], v0[a:b], v1[a:b], v2[a:b]] for a, b in zip(cuts[:-1], cuts[1:])]
+        for targets in ([TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT, 1), TargetExpr(capi.SUM, 1), TargetExpr(capi.MAX, 1),
+                         TargetExpr(capi.MIN, 1), TargetExpr(capi.AVG, 1)],
+                        [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.COUNT), TargetExpr(capi.SUM, 1), TargetExpr(capi.MIN, 2),
+                         TargetExpr(capi.MAX, 2)],
+                        [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.AVG, 3), TargetExpr(capi.SUM, 2), TargetExpr(capi.MAX, 1),
+                         TargetExpr(capi.COUNT, 3)],
+                        # (a column of 100 values: no presence mask — the minimum alone, both, neither)
+                        [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.MIN, 3), TargetExpr(capi.SUM, 1)],
+                        [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.MIN, 3), TargetExpr(capi.MAX, 3), TargetExpr(capi.COUNT, 2)],
+                        [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 3), TargetExpr(capi.AVG, 1)]):
+            ra = RelAlgExecutionUnit(descs, targets, [], [0], max_groups_buffer_entry_guess=2 * card)
+            case = cases_mod.Case("idx_packed_hint", ra, frags)
+            rs = flow._check(oracle, case, kernel_variant=2)
+            assert rs.report.kernel_name.decode() == "k_idx_scatter", rs.report.kernel_name
+            assert rs.report.variant in (7, 8) and rs.report.variant <= max(want_variant, 7), (card, rs.report.variant)
+            assert rs.report.spilled_rows > 0
+        # a value column without a range: the plain records
+        descs2 = list(descs)
+        descs2[1] = InputColDescriptor(capi.INT32, True, ExpressionRange(False, 0, 0, False))
+        ra = RelAlgExecutionUnit(descs2, [TargetExpr(capi.PROJECT_KEY), TargetExpr(capi.SUM, 1)], [], [0], max_groups_buffer_entry_guess=2 * card)
+        rs = flow._check(oracle, cases_mod.Case("idx_no_range", ra, frags), kernel_variant=2)
+        assert rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.variant == 6, (rs.report.kernel_name, rs.report.variant)
 
 
 def test_idx_partitioned_family_in_several_chunks_and_with_spills(sim, oracle):
@@ -266,9 +319,16 @@ def test_idx_partitioned_family_in_several_chunks_and_with_spills(sim, oracle):
         cuts = [0] + [(n * k // 5) & ~3 for k in range(1, 5)] + [n]
         frags = [[key[a:b], val[a:b], v2[a:b]] for a, b in zip(cuts[:-1], cuts[1:])]
         case = cases_mod.Case("idx_skew", ra, frags)
-        rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=18 << 20)
+        rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=18 << 20, flags=capi.OPT_NO_IDX_PACK)
         assert rs.report.kernel_name.decode() == "k_idx_scatter", rs.report.kernel_name
         assert rs.report.n_launches >= 2, rs.report.n_launches
+        assert rs.report.spilled_rows > 0
+        # the packed word (2-byte records hold eight per unit: the runs are short, one chunk) with a hotter entry
+        key2 = key.copy()
+        key2[rng.random(n) < 0.9] = 4242
+        frags2 = [[key2[a:b], val[a:b], v2[a:b]] for a, b in zip(cuts[:-1], cuts[1:])]
+        rs = flow._check(oracle, cases_mod.Case("idx_skew_packed", ra, frags2), kernel_variant=2, scratch_bytes=18 << 20)
+        assert rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.variant in (7, 8), (rs.report.kernel_name, rs.report.variant)
         assert rs.report.spilled_rows > 0
 
 
@@ -293,10 +353,14 @@ def test_idx_partitioned_family_count_only_records(sim, oracle):
         targets = [TargetExpr(capi.PROJECT_KEY, g) for g in range(len(group))] + [TargetExpr(capi.COUNT)]
         ra = RelAlgExecutionUnit(descs, targets, [], group, max_groups_buffer_entry_guess=600_000, bigint_count=big, num_tuples=n)
         case = cases_mod.Case("idx_count_only", ra, frags)
-        rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=6 << 20)
-        assert rs.report.kernel_name.decode() == "k_idx_scatter", (group, big, rs.report.kernel_name)
+        rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=6 << 20, flags=capi.OPT_NO_IDX_PACK)
+        assert rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.variant == 6, (group, big, rs.report.kernel_name)
         assert rs.report.n_launches >= 2, rs.report.n_launches
         assert len(group) > 1 or rs.report.spilled_rows > 0, rs.report.spilled_rows      # (one key: the hot entry's runs overflow)
+        # the 2-byte word (the entry's index inside its partition alone) where a partition has <= 65 536 entries
+        rs = flow._check(oracle, case, kernel_variant=2, scratch_bytes=6 << 20)
+        assert rs.report.kernel_name.decode() == "k_idx_scatter" and rs.report.variant in (6, 8), (group, big, rs.report.variant)
+        assert len(group) > 1 or rs.report.variant == 8
 
 
 def test_idx_partitioned_family_reports_a_key_outside_its_range(sim, oracle):

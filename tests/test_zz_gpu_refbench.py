@@ -96,7 +96,19 @@ def test_refbench_idx_partitioned_family(torch_cuda, oracle, name):
     against the oracle; kernel_variant 2 takes the family on a 2 M-row input (odd count: quad remainders and tails)"""
     rep = {}
     kernel = _run(torch_cuda, oracle, name, 2_000_003, 150_000, 2, report=rep)
+    # (round 6: the benchmark's value columns carry their ranges — the packed 2- / 4-byte word, variants 8 / 7)
+    assert kernel == "k_idx_scatter" and rep["variant"] in (7, 8), (kernel, rep)
+    kernel = _run(torch_cuda, oracle, name, 2_000_003, 150_000, 2, flags=capi.OPT_NO_IDX_PACK, report=rep)
     assert kernel == "k_idx_scatter" and rep["variant"] == 6, (kernel, rep)
+
+
+@pytest.mark.parametrize("name", ["S001", "S003", "PHS007", "MSPHS005", "MSPHS012", "PHM006", "MSPHM005"])
+def test_refbench_idx_partitioned_family_packed_at_benchmark_cardinalities(torch_cuda, oracle, name):
+    """the packed word at the benchmark's own cardinalities (10 M entries: 14 index bits + the value codes in 4 bytes; the
+    Sort shapes: the index alone in 2 bytes), 16 M rows against the oracle"""
+    rep = {}
+    kernel = _run(torch_cuda, oracle, name, 16_000_003, 0, 0, report=rep)
+    assert kernel == "k_idx_scatter" and rep["variant"] in (7, 8), (name, kernel, rep)
 
 
 def test_refbench_idx_partitioned_family_planned_at_16m_rows(torch_cuda, oracle):

@@ -91,6 +91,21 @@ for k, v in rows.items(): print(k, v)"; tail -3 $out/err.log ;;
     timeout 600 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --big-key --verify-rows 4e6 --only plain,guarded_div,sum_gt,affine > $out/bool_filter_big_key.jsonl 2> $out/err.log; echo "exit $?"
     timeout 600 python tools/bool_filter_bench.py --rows 1e9 --steps 3 --big-key --interpreted --only guarded_div,sum_gt,affine > $out/bool_filter_big_key_interpreted.jsonl 2>> $out/err.log; echo "exit $?"
     cut -c1-330 $out/bool_filter_big_key.jsonl $out/bool_filter_big_key_interpreted.jsonl; tail -3 $out/err.log ;;
+  idxprof)  # index-partitioned family: per-kernel times of the benchmark's lowest steps (rocprofv3 kernel trace), then the refbench lines
+    cd /tmp; export TMPDIR=/tmp; cd - > /dev/null
+    timeout 500 rocprofv3 --kernel-trace --stats -f csv -d $out/trace -o idx -- python tools/refbench.py --rows 1e9 --steps 3 --only ${3:-S001,S003,PHS005,PHS007,MSPHS005,MSPHS012,PHM006} --out $out/refbench_idx.jsonl > $out/refbench.log 2> $out/rocprof.err
+    find $out/trace -name "*kernel_stats.csv" -exec cp {} $out/idx_kernel_stats.csv \; ; rm -rf $out/trace; cut -c1-170 $out/idx_kernel_stats.csv | head -24; cut -c1-250 $out/refbench_idx.jsonl; tail -3 $out/rocprof.err ;;
+  idxpmc)   # k_idx_scatter's instruction mix and stall split (SQ counters; kernel trace only)
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $out/pmc -o pmc -- python tools/refbench.py --rows 1e9 --steps 1 --only ${3:-S001,PHS005} > $out/pmc.log 2>&1
+    python tools/rocpd_stats.py $out/pmc/pmc_results.db > $out/pmc_stats.txt 2>&1; rm -rf $out/pmc; grep -E "k_idx" $out/pmc_stats.txt | cut -c1-260; tail -3 $out/pmc.log
+    timeout 300 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD -d $out/pmc2 -o pmc -- python tools/refbench.py --rows 1e9 --steps 1 --only ${3:-S001,PHS005} > $out/pmc2.log 2>&1
+    python tools/rocpd_stats.py $out/pmc2/pmc_results.db > $out/pmc2_stats.txt 2>&1; rm -rf $out/pmc2; grep -E "k_idx" $out/pmc2_stats.txt | cut -c1-260; tail -3 $out/pmc2.log ;;
+  idxtest)  # index-partitioned family: device parity (plain + packed records), then the per-kernel profile of the lowest steps
+    timeout 1500 python -u -m pytest tests/test_zz_gpu_refbench.py -m gpu -x -q -p no:cacheprovider -k "idx_partitioned" > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
+    bash tools/gpu_r06.sh idxprof $out ${3:-S001,S003,PHS005,PHS006,PHS007,MSPHS005,MSPHS012,PHM006,MSBS005,MSPHM005} ;;
+  nga)      # typed scan-aggregate members (software-pipelined): device parity of the NGA shapes, then the blocks-per-CU sweep
+    timeout 900 python -u -m pytest tests/test_zz_gpu_refbench.py tests/test_zz_gpu_typed_filters.py -m gpu -x -q -p no:cacheprovider -k "NGA or nga or scan_agg" > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
+    timeout 400 python tools/nga_sweep.py --rows 1e9 --bpc ${3:-0,2,3,4} > $out/nga_1b.jsonl 2> $out/nga.err; echo "nga exit $?"; cat $out/nga_1b.jsonl; tail -3 $out/nga.err ;;
   suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
     timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200

@@ -164,6 +164,8 @@ def main():
                     "extrapolates beyond this at the full size is not run at the full size (the extrapolation is "
                     "reported instead): a shape that still takes the row kernel with a handful of groups serialises "
                     "the device on a few cache lines for minutes")
+    ap.add_argument("--flags", type=int, default=0, help="MI355Q_OPT_* bits for every step (1024 = MI355Q_OPT_NO_IDX_PACK: the "
+                    "index-partitioned family's plain records instead of the packed word)")
     args = ap.parse_args()
     import torch
     from heavydb_amd import capi
@@ -205,10 +207,10 @@ def main():
         try:
             # probe on the first fragment: kernel choice and a rate
             fr1 = FetchResult(bufs[:1], rows[:1], keepalive=cols)
-            ex.executeWorkUnit(ra, fr1)
+            ex.executeWorkUnit(ra, fr1, flags=args.flags)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            rs1 = ex.executeWorkUnit(ra, fr1)
+            rs1 = ex.executeWorkUnit(ra, fr1, flags=args.flags)
             torch.cuda.synchronize()
             probe_ms = (time.perf_counter() - t0) * 1e3
             est = probe_ms * n_rows / rows[0]
@@ -218,14 +220,14 @@ def main():
                 print(json.dumps(line), flush=True)
                 out_lines.append(line)
                 continue
-            rs = ex.executeWorkUnit(ra, fr)      # warm-up (workspace, retry ladder of the entry guess)
+            rs = ex.executeWorkUnit(ra, fr, flags=args.flags)      # warm-up (workspace, retry ladder of the entry guess)
             torch.cuda.synchronize()
             # the plan / input structs of the C-ABI are built once, as bench.py does (the reference compiles a step once too):
             # a step = one mi355q_execute on them + the result storage it writes
             prep = None
             if not args.unprepared:
                 try:
-                    prep = HipShard.prepare(ex, ra, fr)
+                    prep = HipShard.prepare(ex, ra, fr, flags=args.flags)
                     HipShard.execute_prepared(torch, prep)
                 except capi.Mi355qError:
                     prep = None              # (a table the retry ladder has to grow: the plain entry point)
@@ -237,7 +239,7 @@ def main():
                     rs = sh.result_set()
                     rs.report = sh.report
                 else:
-                    rs = ex.executeWorkUnit(ra, fr)
+                    rs = ex.executeWorkUnit(ra, fr, flags=args.flags)
                 if spec.get("sort"):
                     outbuf = torch.empty(100 * rs.getQueryMemDesc().row_size // 8, dtype=torch.int64, device="cuda:0")
                     rs.sort(len(spec["targets"]) - 1, 100, int(outbuf.data_ptr()), desc=False)
