@@ -431,7 +431,10 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
 // One group's partial — rows, and per value column non-NULL count / sum / min / max — merged into row `e` of the output
 // table, target by target, with the reduce rule (reduce_target: what ResultSetStorage::reduce does with two buffers), as the
 // flush of k_groupby_lds_typed does.  The table is initialised before the step, so a later chunk merges again.
-template <int NK>
+// A: atomic merges (the spill records: several lanes may hold records of one entry); phase 2 emits every entry from exactly one
+// lane of one workgroup per launch, so it merges with plain read-modify-writes (10 M entries x 7 slots of global atomics cost
+// PHS007 ~2 ms per launch).
+template <int NK, bool A>
 MQ_D void idx_emit(const IdxCols& c, const DevPlan& p, int64_t* __restrict__ out, uint32_t e, uint32_t rows,
                    const uint32_t (&cn)[kLdsVals], const int64_t (&sm)[kLdsVals], const int32_t (&mn)[kLdsVals],
                    const int32_t (&mx)[kLdsVals]) {
@@ -491,7 +494,7 @@ MQ_D void idx_emit(const IdxCols& c, const DevPlan& p, int64_t* __restrict__ out
     int64_t win2[2] = {v0, v1};
     DevTarget lt = tg;
     lt.slot = 0;
-    reduce_target<true>(lt, p.init_vals + tg.slot, slots + tg.slot, win2);
+    reduce_target<A>(lt, p.init_vals + tg.slot, slots + tg.slot, win2);
   }
 }
 
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_aggregate(IdxGeom g, IdxCols 
           mx[v] = l_max[v * E + e];
         }
       }
-      idx_emit<NK>(c, p, out, lo + e, rows, cn, sm, mn, mx);
+      idx_emit<NK, false>(c, p, out, lo + e, rows, cn, sm, mn, mx);
     }
   }
 }
@@ -756,9 +759,9 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_aggregate_pk(IdxGeom g, IdxCo
       }
       if (!rows) continue;
       switch (g.nk) {
-        case 1: idx_emit<1>(c, p, out, lo + e, rows, cn, sm, mn, mx); break;
-        case 2: idx_emit<2>(c, p, out, lo + e, rows, cn, sm, mn, mx); break;
-        default: idx_emit<3>(c, p, out, lo + e, rows, cn, sm, mn, mx);
+        case 1: idx_emit<1, false>(c, p, out, lo + e, rows, cn, sm, mn, mx); break;
+        case 2: idx_emit<2, false>(c, p, out, lo + e, rows, cn, sm, mn, mx); break;
+        default: idx_emit<3, false>(c, p, out, lo + e, rows, cn, sm, mn, mx);
       }
     }
   }
@@ -782,7 +785,7 @@ __global__ __launch_bounds__(256) void k_idx_spill(IdxGeom g, IdxCols c, DevPlan
       sm[v] = vv[v];
       mn[v] = mx[v] = vv[v];
     }
-    idx_emit<NK>(c, p, out, (uint32_t)r.x, 1u, cn, sm, mn, mx);
+    idx_emit<NK, true>(c, p, out, (uint32_t)r.x, 1u, cn, sm, mn, mx);
   }
 }
 
