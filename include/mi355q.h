@@ -567,7 +567,8 @@ typedef struct mi355q_exec_report {
                            measured on the launch stream; avg = kernel_ms / n_launches */
   float total_ms;       /* HIP-event time of the whole call on the launch stream */
   int32_t n_launches;   /* launches of the dominant kernel */
-  int32_t variant;
+  int32_t variant;      /* member of the family that ran (informational; e.g. k_groupby_lds: 4 run-time roles, 5 typed;
+                           k_idx_scatter: 6 plain records, 7 / 8 the packed 4- / 2-byte word) */
   int64_t rows_scanned;
   int64_t algorithmic_bytes; /* column bytes the plan must read */
   int64_t spilled_rows;      /* rows that took the direct-atomic spill path */

@@ -85,6 +85,11 @@ for k, v in rows.items(): print(k, v)"; tail -3 $out/err.log ;;
     timeout 300 python tools/nga_sweep.py --rows 1e9 --bpc 0 > $out/nga_1b.jsonl 2> $out/nga.err; echo "nga exit $?"
     timeout 300 python tools/topk_time.py > $out/sort_time.txt 2>&1; echo "sort exit $?"
     timeout 700 python tools/refbench.py --rows 1e9 --steps 3 --budget-ms 1500 --out $out/refbench_1b.jsonl > $out/refbench_1b.log 2>&1; echo "refbench 1B exit $?"
+    timeout 500 python tools/refbench.py --rows 1e9 --steps 3 --flags 1024 --only S00,PHS005,PHS006,PHS007,PHM004,PHM005,PHM006,MSPHS,MSPHM,MSBS003,MSBS004,MSBS005,BH005,BH006 --out $out/refbench_1b_idx_plain_records.jsonl > $out/refbench_1b_plain.log 2>&1; echo "refbench (plain idx records) exit $?"
+    python -c "
+import json, statistics
+rows=[json.loads(l) for l in open('$out/refbench_1b.jsonl')]
+print('refbench:', len(rows), 'steps', round(sum(r.get('ms', 0) for r in rows), 1), 'ms; skipped', [r['query'] for r in rows if 'ms' not in r], 'median', statistics.median(r['whole_step_frac'] for r in rows))"
     head -3 $out/cfg3f_kernel_stats.csv ;;
   bigkey)   # compiled filters in front of the partitioned GROUP BY (10 M INT64 keys): the mask route vs the interpreter's INT32 column
     timeout 900 python -u -m pytest tests/test_zz_gpu_typed_filters.py tests/test_zz_gpu_baseline_sizes.py -m gpu -q -p no:cacheprovider -k "large_table or cfg4_one_billion" > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log

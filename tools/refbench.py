@@ -209,10 +209,16 @@ def main():
             fr1 = FetchResult(bufs[:1], rows[:1], keepalive=cols)
             ex.executeWorkUnit(ra, fr1, flags=args.flags)
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            rs1 = ex.executeWorkUnit(ra, fr1, flags=args.flags)
-            torch.cuda.synchronize()
-            probe_ms = (time.perf_counter() - t0) * 1e3
+            probe_ms = None
+            for _ in range(2):   # (the faster of two: one call of a derived-plan route now and then stalls ~0.2 s in the driver's
+                t0 = time.perf_counter()   # allocator — 1.4 GB of twin / result tables per call — and would fake a skip)
+                rs1 = ex.executeWorkUnit(ra, fr1, flags=args.flags)
+                torch.cuda.synchronize()
+                ms1 = (time.perf_counter() - t0) * 1e3
+                dev_ms = float(rs1.report.total_ms)     # HIP-event time of the call on its stream: no allocator stall in it
+                if dev_ms > 0:
+                    ms1 = min(ms1, dev_ms)
+                probe_ms = ms1 if probe_ms is None else min(probe_ms, ms1)
             est = probe_ms * n_rows / rows[0]
             if est > args.budget_ms:
                 line.update(kernel=rs1.report.kernel_name.decode(), skipped=True, probe_rows=rows[0], probe_ms=round(probe_ms, 3),
