@@ -98,6 +98,19 @@ MQ_D uint32_t idx_part_of(const IdxGeom& g, uint32_t e) {
   return q + (e - q * g.S1 >= g.S1 ? 1u : 0u);
 }
 
+// packed records (the plan admits them for tables of <= 2^24 entries and partitions of > 256): partition AND the index
+// inside it from full-rate 24-bit multiplies (v_mul_hi_u32_u24 / v_mul_u32_u24) instead of two quarter-rate 32-bit ones
+MQ_D void idx_part_split24(const IdxGeom& g, uint32_t e, uint32_t& p, uint32_t& el) {
+  uint32_t q = (uint32_t)(((uint64_t)(e & 0xffffffu) * (uint64_t)(g.s1_rcp & 0xffffffu)) >> 32);
+  uint32_t rem = e - (q & 0xffffffu) * (g.S1 & 0xffffffu);  // (q < 2^16, S1 < 2^24)
+  if (rem >= g.S1) {
+    q += 1u;
+    rem -= g.S1;
+  }
+  p = q;
+  el = rem;
+}
+
 // spill positions are handed out from workgroup-private blocks (one global atomic per 256 entries)
 MQ_D uint32_t idx_spill_slot(const IdxSpill& sl, unsigned long long* blk) {
   for (;;) {
@@ -287,7 +300,7 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
             if (ktr[k] && kv == INT32_MIN) ku = knull[k];
             const uint32_t dd = ku - kmin[k];
             in_range = in_range && dd < kcard[k];
-            e += dd * kmul[k];
+            e += k == 0 ? dd : dd * kmul[k];  // (the first component's multiplier is 1: mul_lo is a quarter-rate instruction)
           }
           if (!in_range || e >= g.d) {
             bad = true;  // a key outside its declared range (reported as out of slots, like the row kernel)
@@ -296,11 +309,13 @@ __global__ __launch_bounds__(kIdxBlock) void k_idx_scatter(const int8_t* const* 
             if (NV > 0) rec.y = idx_get(cur.v[0], i);
             if (NV > 1) rec.z = idx_get(cur.v[NV > 1 ? 1 : 0], i);
             if (NV > 2) rec.w = idx_get(cur.v[NV > 2 ? 2 : 0], i);
-            p = idx_part_of(g, e);
+            uint32_t el = 0;
+            if (PK) idx_part_split24(g, e, p, el);
+            else p = idx_part_of(g, e);
             if (PK) {
               // the packed word; a value outside its declared range (the range is a hint) leaves as a full record
               const v4i32 full = rec;
-              uint32_t w = (e - p * g.S1) << g.vb;
+              uint32_t w = el << g.vb;
               bool fits = true;
 #pragma unroll
               for (int v = 0; v < NV; ++v) {
@@ -897,7 +912,9 @@ bool make_idx_plan_impl(const DevPlan& p, const FragView& fv, int n_cus, int64_t
     if (!pk) break;
     uint32_t eb = 0;
     while (eb < 32 && ((uint64_t)1 << eb) < (uint64_t)g.S1) ++eb;
-    if (g.R <= (uint32_t)kIdxMaxSub && (eb + vb <= 16 || (g.nv >= 1 && eb + vb <= 32))) {
+    // (<= 2^24 entries, partitions of > 256 entries: idx_part_split24's operands fit 24 bits)
+    const bool fits24 = g.d <= (1u << 24) && g.S1 > 256u && g.s1_rcp < (1u << 24);
+    if (fits24 && g.R <= (uint32_t)kIdxMaxSub && (eb + vb <= 16 || (g.nv >= 1 && eb + vb <= 32))) {
       g.pk = 1;
       g.rs = eb + vb <= 16 ? 3 : 2;
       g.vb = vb;
