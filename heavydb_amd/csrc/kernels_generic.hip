@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(kBlock) void k_zip_targets(DevPlan pf, DevPlan ps, 
               rem -= d * pf.group_mul[g];
               tk = d * (pf.group_bucket[g] ? pf.group_bucket[g] : 1) + pf.group_min[g];
             }
-            MQ_STORE64(row_f + g, tk);
+            row_f[g] = tk;  // (entry e's row is this lane's alone: plain stores, no agent-scope write-through)
           }
         }
         slots_f = row_f + pf.n_group;
@@ -1203,7 +1203,7 @@ __global__ __launch_bounds__(kBlock) void k_zip_targets(DevPlan pf, DevPlan ps, 
       }
     } else if (zm.positional) {
       int64_t* row_f = fin + e * pf.row_quad;
-      for (int k = 0; k < pf.key_quad; ++k) MQ_STORE64(row_f + k, row_s[k]);
+      for (int k = 0; k < pf.key_quad; ++k) row_f[k] = row_s[k];
       slots_f = row_f + pf.key_quad;
     } else {
       int64_t keys[MI355Q_MAX_GROUP_COLS];
@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(kBlock) void k_zip_targets(DevPlan pf, DevPlan ps, 
         const int64_t c = slots_s[zm.cnt_src[j]];
         if (c > 0) v = (int64_t)((uint64_t)v + (uint64_t)zm.lit[j] * (zm.kind[j] == 2 ? (uint64_t)c : 1ull));
       }
-      MQ_STORE64(slots_f + zm.dst[j], v);
+      slots_f[zm.dst[j]] = v;  // (the row belongs to this lane — its own entry, or the slot it just claimed)
     }
   }
 }
