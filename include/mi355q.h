@@ -352,7 +352,10 @@ typedef struct mi355q_plan {
   int32_t abi_version; /* MI355Q_ABI_VERSION */
   int32_t n_cols;      /* outer-table input columns (input_col_descs) */
   mi355q_col_desc cols[MI355Q_MAX_COLS];
-  mi355q_range col_ranges[MI355Q_MAX_COLS];
+  mi355q_range col_ranges[MI355Q_MAX_COLS]; /* of EVERY input column, not only the group keys: the keyless decisions read the
+                                               aggregate arguments' ranges (get_keyless_info), and the index-partitioned family
+                                               packs narrow records from them — as a HINT: a value outside its declared range
+                                               costs time (a spill-list record), never correctness */
   int32_t n_inner_cols; /* inner (dim) table columns reachable via the join */
   mi355q_col_desc inner_cols[MI355Q_MAX_COLS];
   mi355q_range inner_col_ranges[MI355Q_MAX_COLS];
