@@ -111,6 +111,15 @@ print('refbench:', len(rows), 'steps', round(sum(r.get('ms', 0) for r in rows), 
   nga)      # typed scan-aggregate members (software-pipelined): device parity of the NGA shapes, then the blocks-per-CU sweep
     timeout 900 python -u -m pytest tests/test_zz_gpu_refbench.py tests/test_zz_gpu_typed_filters.py -m gpu -x -q -p no:cacheprovider -k "NGA or nga or scan_agg" > $out/pytest.log 2>&1; echo "pytest exit $?"; tail -3 $out/pytest.log
     timeout 400 python tools/nga_sweep.py --rows 1e9 --bpc ${3:-0,2,3,4} > $out/nga_1b.jsonl 2> $out/nga.err; echo "nga exit $?"; cat $out/nga_1b.jsonl; tail -3 $out/nga.err ;;
+  idxtraffic) # index-partitioned family: HBM traffic by PMC (separate FETCH_SIZE / WRITE_SIZE passes), packed and plain records
+    for mode in packed plain; do
+      fl=0; [ $mode = plain ] && fl=1024
+      for grp in FETCH_SIZE WRITE_SIZE; do
+        timeout 300 rocprofv3 --kernel-trace --pmc $grp -d $out/pmc_${mode}_$grp -o pmc -- python tools/refbench.py --rows 1e9 --steps 1 --flags $fl --only ${3:-S001,PHS005,PHS007,MSPHS005} > $out/pmc_${mode}_$grp.log 2>&1
+        python tools/rocpd_stats.py $out/pmc_${mode}_$grp/pmc_results.db > $out/pmc_${mode}_${grp}_stats.txt 2>&1; rm -rf $out/pmc_${mode}_$grp
+        echo "== $mode $grp"; grep -E "k_idx_(scatter|aggregate)" $out/pmc_${mode}_${grp}_stats.txt | grep "$grp" | cut -c1-200
+      done
+    done ;;
   suite)    # the whole -m gpu suite (no -x: every failure listed), then smoke()
     timeout 2700 python -u -m pytest tests -m gpu -q -p no:cacheprovider "${@:3}" > $out/pytest_gpu.log 2>&1
     echo "pytest exit $?"; grep -n "FAILED\|Fatal\|fault" $out/pytest_gpu.log | head -20; tail -2 $out/pytest_gpu.log | cut -c1-200
